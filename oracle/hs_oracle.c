@@ -1,0 +1,496 @@
+/* hs_oracle.c -- event-level CPU restatement of the reference hot path.
+ * TEST INFRASTRUCTURE ONLY (see hs_oracle.h).  Plain C11, no dependencies.
+ *
+ * Each handler cites the reference code it restates (paths relative to
+ * /root/reference/happysimulator).  Nothing here is shared with the product.
+ */
+#include "hs_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "hs_rng_ref.h"
+
+/* ---------------------------------------------------------------- events */
+typedef struct {
+    int64_t time;   /* Event.time (ns)                      core/event.py:149 */
+    uint64_t idx;   /* Event._sort_index                    core/event.py:165 */
+    int32_t kind;   /* HSO_EV_*                                               */
+    int32_t node;   /* target node                                            */
+    int32_t req;    /* request slot (payload / context), -1 if none           */
+    int32_t aux;    /* per-kind scratch (service slot ...)                    */
+} hso_event;
+
+/* request = the payload Event's identity + its context dict
+ * (context["created_at"], load/source.py:76-79; forwarded unchanged by
+ * Entity.forward, core/entity.py:100-105). */
+typedef struct {
+    int64_t created_ns;
+    uint64_t idx;       /* sort index of the payload Event object (kept on retarget, queue_driver.py:86-90) */
+    double service_s;   /* service_time_s captured by the generator frame (server/server.py:246-247) */
+    int32_t hops;
+    int32_t next_free;
+} hso_request;
+
+typedef struct {
+    int32_t *buf; int64_t head, len, cap;  /* FIFOQueue deque, components/queue_policy.py:75-114 */
+} hso_fifo;
+
+typedef struct {
+    /* Source */
+    int64_t arr_time_ns;      /* ArrivalTimeProvider.current_time */
+    uint64_t arr_draws;
+    int64_t generated;        /* Source._generated_count, load/source.py:159 */
+    /* Server / QueuedResource */
+    hso_fifo fifo;
+    int64_t accepted, dropped;            /* Queue.stats_*, components/queue.py:127-139 */
+    int32_t active;                       /* FixedConcurrency._active, server/concurrency.py:67-141 */
+    int64_t completed, rejected;          /* Server._requests_*, server/server.py:112-114 */
+    double total_service_s;               /* Server._total_service_time */
+    uint64_t svc_draws;
+    /* Sink */
+    int64_t received;
+    int64_t *sink_t, *sink_created; int64_t sink_cap;
+} hso_node;
+
+struct hso_sim {
+    hso_graph g;   /* deep-copied arrays */
+    hso_params p;
+    hso_node *nodes;
+    hso_event *heap; int64_t heap_len, heap_cap, heap_peak;
+    hso_request *reqs; int32_t req_len, req_cap, req_free;
+    uint64_t counter;          /* active sort counter */
+    int64_t current_ns;
+    int64_t processed, by_kind[HSO_EV_KINDS];
+    hsr_mt19937 mt_py, mt_np;
+    /* trace */
+    int64_t *tr_t; int32_t *tr_kind; int32_t *tr_node; int64_t *tr_idx; int64_t tr_len;
+};
+
+/* ------------------------------------------------------------------ heap
+ * heapq with Event.__lt__ = (time, _sort_index), core/event.py:337-344,
+ * core/event_heap.py:54-108.  push/pop follow CPython heapq's sift procedures
+ * step for step (see heap_pop). */
+static int ev_lt(const hso_event *a, const hso_event *b) {
+    if (a->time != b->time) return a->time < b->time;
+    return a->idx < b->idx;
+}
+static void heap_push(hso_sim *s, hso_event e) {
+    if (s->heap_len == s->heap_cap) {
+        s->heap_cap = s->heap_cap ? s->heap_cap * 2 : 1024;
+        s->heap = (hso_event *)realloc(s->heap, (size_t)s->heap_cap * sizeof(hso_event));
+    }
+    int64_t i = s->heap_len++;
+    while (i > 0) {
+        int64_t par = (i - 1) >> 1;
+        if (!ev_lt(&e, &s->heap[par])) break;
+        s->heap[i] = s->heap[par];
+        i = par;
+    }
+    s->heap[i] = e;
+    if (s->heap_len > s->heap_peak) s->heap_peak = s->heap_len;
+}
+static hso_event heap_pop(hso_sim *s) {
+    /* heapq.heappop: move the last leaf to the root, sift the hole DOWN to a leaf
+     * always following the smaller child (right child on a tie: `not left < right`),
+     * then sift the item back UP (_siftup then _siftdown in CPython's heapq).  The
+     * exact procedure is mirrored so that equal (time, idx) keys -- possible between
+     * init-time and run-time sort counters, SURVEY.md A1 -- pop in heapq's order. */
+    hso_event top = s->heap[0];
+    hso_event last = s->heap[--s->heap_len];
+    int64_t n = s->heap_len;
+    if (n == 0) return top;
+    int64_t pos = 0, child = 1;
+    while (child < n) {
+        int64_t right = child + 1;
+        if (right < n && !ev_lt(&s->heap[child], &s->heap[right])) child = right;
+        s->heap[pos] = s->heap[child];
+        pos = child;
+        child = 2 * pos + 1;
+    }
+    while (pos > 0) {
+        int64_t par = (pos - 1) >> 1;
+        if (!ev_lt(&last, &s->heap[par])) break;
+        s->heap[pos] = s->heap[par];
+        pos = par;
+    }
+    s->heap[pos] = last;
+    return top;
+}
+
+/* ----------------------------------------------------------------- utils */
+static uint64_t next_index(hso_sim *s) { return s->counter++; } /* _next_sort_index, core/event.py:62-67 */
+
+static int32_t req_alloc(hso_sim *s) {
+    int32_t r;
+    if (s->req_free >= 0) { r = s->req_free; s->req_free = s->reqs[r].next_free; return r; }
+    if (s->req_len == s->req_cap) {
+        s->req_cap = s->req_cap ? s->req_cap * 2 : 1024;
+        s->reqs = (hso_request *)realloc(s->reqs, (size_t)s->req_cap * sizeof(hso_request));
+    }
+    return s->req_len++;
+}
+static void req_release(hso_sim *s, int32_t r) { s->reqs[r].next_free = s->req_free; s->req_free = r; }
+
+static void fifo_push(hso_fifo *f, int32_t v) {
+    if (f->len == f->cap) {
+        int64_t ncap = f->cap ? f->cap * 2 : 16;
+        int32_t *nb = (int32_t *)malloc((size_t)ncap * sizeof(int32_t));
+        for (int64_t i = 0; i < f->len; ++i) nb[i] = f->buf[(f->head + i) % f->cap];
+        free(f->buf);
+        f->buf = nb; f->head = 0; f->cap = ncap;
+    }
+    f->buf[(f->head + f->len) % f->cap] = v;
+    f->len++;
+}
+static int32_t fifo_pop(hso_fifo *f) {
+    int32_t v = f->buf[f->head];
+    f->head = (f->head + 1) % f->cap;
+    f->len--;
+    return v;
+}
+
+static double draw_uniform(hso_sim *s, int32_t node, int stream_kind, uint64_t *draws) {
+    if (s->p.rng_mode == HSO_RNG_MT19937) {
+        /* arrivals: np.random.random() (global); service: random.random() (global) -- SURVEY A5 */
+        (*draws)++;
+        return stream_kind == HS_STREAM_ARRIVAL ? hsr_mt_res53(&s->mt_np) : hsr_mt_res53(&s->mt_py);
+    }
+    uint64_t sid = (s->g.stream_base[node] << 3) | (uint64_t)stream_kind;
+    return hsr_uniform(s->p.seed, sid, (*draws)++);
+}
+
+static double exp1(hso_sim *s, double u) {
+    /* stock streams use libm log (math.log); the Philox-plugged streams use hs_log */
+    if (s->p.rng_mode == HSO_RNG_MT19937) return -log(1.0 - u);
+    return hsr_exp1(u);
+}
+
+/* ArrivalTimeProvider.next_arrival_time, constant-rate fast path
+ * (load/arrival_time_provider.py:57-82): t' = from_seconds(to_seconds(t) + E/rate). */
+static int64_t next_arrival(hso_sim *s, int32_t n) {
+    hso_node *nd = &s->nodes[n];
+    double target_area;
+    if (s->g.arr_kind[n] == HSO_ARR_POISSON)
+        target_area = exp1(s, draw_uniform(s, n, HS_STREAM_ARRIVAL, &nd->arr_draws)); /* poisson_arrival.py:31 */
+    else
+        target_area = 1.0;                                                             /* constant_arrival.py:23 */
+    double t_start = hsr_seconds_from_ns(nd->arr_time_ns);
+    double t_next = t_start + target_area / s->g.rate[n];
+    nd->arr_time_ns = hsr_ns_from_seconds(t_next);
+    return nd->arr_time_ns;
+}
+
+/* LatencyDistribution.get_latency(...).to_seconds() as used at server/server.py:246-247:
+ * Duration.from_seconds(sample) (first truncation) then float(ns)/1e9. */
+static double sample_latency_s(hso_sim *s, int32_t n, int stream_kind, uint64_t *draws) {
+    double sample;
+    if (s->g.lat_kind[n] == HSO_LAT_EXP) {
+        double lambda = 1.0 / s->g.lat_mean[n];                      /* exponential.py:36 */
+        sample = exp1(s, draw_uniform(s, n, stream_kind, draws)) / lambda; /* random.expovariate */
+    } else {
+        sample = s->g.lat_mean[n];                                   /* constant.py:33-35 */
+    }
+    return hsr_seconds_from_ns(hsr_ns_from_seconds(sample));
+}
+
+static void trace(hso_sim *s, const hso_event *e) {
+    if (s->tr_len < s->p.trace_cap) {
+        int64_t i = s->tr_len++;
+        s->tr_t[i] = e->time; s->tr_kind[i] = e->kind; s->tr_node[i] = e->node; s->tr_idx[i] = (int64_t)e->idx;
+    }
+}
+
+/* a Request-carrying Event aimed at `node`: which handler it lands in */
+static int32_t arrival_kind_for(const hso_sim *s, int32_t node) {
+    switch (s->g.kind[node]) {
+        case HSO_SERVER: return HSO_EV_ENQUEUE;
+        case HSO_SINK: return HSO_EV_SINK;
+        default: return -1;
+    }
+}
+
+/* -------------------------------------------------------------- handlers */
+
+/* Source.handle_event, load/source.py:142-180 + SimpleEventProvider.get_events :67-86 */
+static void on_source(hso_sim *s, const hso_event *e) {
+    int32_t n = e->node;
+    hso_node *nd = &s->nodes[n];
+    int64_t stop = s->g.stop_after_ns[n];
+    int has_payload = !(stop >= 0 && e->time > stop);               /* :68 */
+    hso_event payload;
+    if (has_payload) {
+        int32_t r = req_alloc(s);
+        s->reqs[r].created_ns = e->time;                            /* context["created_at"] = time */
+        s->reqs[r].hops = 0;
+        s->reqs[r].service_s = 0.0;
+        payload.time = e->time;
+        payload.idx = next_index(s);                                /* payload constructed first (:158) */
+        s->reqs[r].idx = payload.idx;
+        payload.node = s->g.target[n];
+        payload.kind = arrival_kind_for(s, payload.node);
+        payload.req = r; payload.aux = 0;
+    }
+    nd->generated++;                                                /* :159 */
+    hso_event tick;
+    tick.time = next_arrival(s, n);                                 /* :170 */
+    tick.idx = next_index(s);                                       /* SourceEvent constructed second (:171) */
+    tick.kind = HSO_EV_SOURCE; tick.node = n; tick.req = -1; tick.aux = 0;
+    if (has_payload) heap_push(s, payload);                         /* return [*payload_events, next_tick] (:174) */
+    heap_push(s, tick);
+}
+
+/* QueuedResource.handle_event -> Queue._handle_enqueue, queued_resource.py:139-143, queue.py:122-147 */
+static void on_enqueue(hso_sim *s, const hso_event *e) {
+    int32_t n = e->node;
+    hso_node *nd = &s->nodes[n];
+    int was_empty = nd->fifo.len == 0;                              /* queue.py:124 */
+    int64_t cap = s->g.queue_cap[n];
+    if (cap >= 0 && nd->fifo.len >= cap) {                          /* FIFOQueue.push, queue_policy.py:94-98 */
+        nd->dropped++;                                              /* queue.py:128 */
+        req_release(s, e->req);
+        return;
+    }
+    fifo_push(&nd->fifo, e->req);
+    nd->accepted++;                                                 /* queue.py:138 */
+    if (was_empty) {                                                /* queue.py:144-146 */
+        hso_event nf = {e->time, next_index(s), HSO_EV_NOTIFY, n, -1, 0};
+        heap_push(s, nf);
+    }
+}
+
+/* QueueDriver._handle_notify, queue_driver.py:92-99 */
+static void on_notify(hso_sim *s, const hso_event *e) {
+    int32_t n = e->node;
+    if (!(s->nodes[n].active < s->g.concurrency[n])) return;        /* has_capacity, concurrency.py:122-131 */
+    hso_event pl = {e->time, next_index(s), HSO_EV_POLL, n, -1, 0};
+    heap_push(s, pl);
+}
+
+/* Queue._handle_poll, queue.py:149-166 */
+static void on_poll(hso_sim *s, const hso_event *e) {
+    int32_t n = e->node;
+    hso_node *nd = &s->nodes[n];
+    if (nd->fifo.len == 0) return;                                  /* :151-154 */
+    int32_t r = fifo_pop(&nd->fifo);
+    hso_event dv = {e->time, next_index(s), HSO_EV_DELIVER, n, r, 0};
+    heap_push(s, dv);
+}
+
+/* QueueDriver._handle_delivery/_handle_work_payload, queue_driver.py:66-90:
+ * the SAME payload object is re-timed, re-targeted and re-pushed with its
+ * original sort index; the schedule_poll completion hook is attached. */
+static void on_deliver(hso_sim *s, const hso_event *e) {
+    hso_event wk = {e->time, s->reqs[e->req].idx, HSO_EV_WORK, e->node, e->req, 0};
+    heap_push(s, wk);
+}
+
+/* Server.handle_queued_event up to the yield, server/server.py:202-250, via
+ * Event._start_process (core/event.py:313-325) and the first
+ * ProcessContinuation.invoke (core/event.py:465-508). */
+static void on_work(hso_sim *s, const hso_event *e) {
+    int32_t n = e->node;
+    hso_node *nd = &s->nodes[n];
+    (void)next_index(s);              /* the continuation built by _start_process: invoked at once, never pushed */
+    if (!(nd->active < s->g.concurrency[n])) {                      /* acquire failed, server.py:223-234 */
+        nd->rejected++;
+        req_release(s, e->req);
+        /* generator returns immediately -> StopIteration; hook schedule_poll sees no capacity -> nothing */
+        return;
+    }
+    nd->active++;
+    double service_s = sample_latency_s(s, n, HS_STREAM_SERVICE, &nd->svc_draws); /* :246-247 */
+    s->reqs[e->req].service_s = service_s;
+    /* `yield service_time_s` -> resume_time = self.time + delay (event.py:499) = ns + int(delay*1e9) (temporal.py:222) */
+    hso_event ct = {e->time + hsr_ns_from_seconds(service_s), next_index(s), HSO_EV_CONTINUATION, n, e->req, 0};
+    heap_push(s, ct);
+}
+
+/* generator resumes after the yield, server/server.py:252-273; StopIteration
+ * path of ProcessContinuation.invoke (core/event.py:522-533) then the
+ * schedule_poll completion hook (queue_driver.py:79-84). */
+static void on_continuation(hso_sim *s, const hso_event *e) {
+    int32_t n = e->node;
+    hso_node *nd = &s->nodes[n];
+    nd->active = nd->active > 0 ? nd->active - 1 : 0;               /* release, concurrency.py:112-119 */
+    nd->completed++;
+    nd->total_service_s += s->reqs[e->req].service_s;               /* :256-257 */
+    int32_t dn = s->g.target[n];
+    if (dn >= 0) {                                                  /* forward(event, downstream), :271-272 */
+        hso_event fw = {e->time, next_index(s), arrival_kind_for(s, dn), dn, e->req, 0};
+        heap_push(s, fw);
+    } else {
+        req_release(s, e->req);
+    }
+    if (nd->active < s->g.concurrency[n]) {                         /* schedule_poll hook */
+        hso_event pl = {e->time, next_index(s), HSO_EV_POLL, n, -1, 0};
+        heap_push(s, pl);
+    }
+}
+
+/* Sink.handle_event, components/common.py:36-44 */
+static void on_sink(hso_sim *s, const hso_event *e) {
+    hso_node *nd = &s->nodes[e->node];
+    if (nd->received == nd->sink_cap) {
+        nd->sink_cap = nd->sink_cap ? nd->sink_cap * 2 : 256;
+        nd->sink_t = (int64_t *)realloc(nd->sink_t, (size_t)nd->sink_cap * sizeof(int64_t));
+        nd->sink_created = (int64_t *)realloc(nd->sink_created, (size_t)nd->sink_cap * sizeof(int64_t));
+    }
+    nd->sink_t[nd->received] = e->time;
+    nd->sink_created[nd->received] = s->reqs[e->req].created_ns;
+    nd->received++;
+    req_release(s, e->req);
+}
+
+/* ------------------------------------------------------------------- API */
+#define DUP(field, type)                                                         \
+    do {                                                                         \
+        type *c_ = (type *)malloc((size_t)n * sizeof(type));                     \
+        if (g->field) memcpy(c_, g->field, (size_t)n * sizeof(type));            \
+        else memset(c_, 0, (size_t)n * sizeof(type));                            \
+        s->g.field = c_;                                                         \
+    } while (0)
+
+hso_sim *hso_create(const hso_graph *g, const hso_params *p) {
+    hso_sim *s = (hso_sim *)calloc(1, sizeof(hso_sim));
+    int32_t n = g->n_nodes;
+    s->g.n_nodes = n;
+    DUP(kind, int32_t); DUP(target, int32_t); DUP(stream_base, uint64_t);
+    DUP(arr_kind, int32_t); DUP(rate, double); DUP(stop_after_ns, int64_t);
+    DUP(concurrency, int32_t); DUP(lat_kind, int32_t); DUP(lat_mean, double); DUP(lat_min, double);
+    DUP(queue_cap, int64_t); DUP(alt_target, int32_t); DUP(ttl, int32_t);
+    s->p = *p;
+    s->nodes = (hso_node *)calloc((size_t)n, sizeof(hso_node));
+    s->req_free = -1;
+    s->current_ns = p->start_ns;
+    if (p->trace_cap > 0) {
+        s->tr_t = (int64_t *)malloc((size_t)p->trace_cap * 8);
+        s->tr_kind = (int32_t *)malloc((size_t)p->trace_cap * 4);
+        s->tr_node = (int32_t *)malloc((size_t)p->trace_cap * 4);
+        s->tr_idx = (int64_t *)malloc((size_t)p->trace_cap * 8);
+    }
+    if (p->rng_mode == HSO_RNG_MT19937) {
+        uint32_t key = p->mt_seed_py;
+        hsr_mt_init_by_array(&s->mt_py, &key, 1);   /* random.seed(int) */
+        hsr_mt_init_genrand(&s->mt_np, p->mt_seed_np); /* np.random.seed(int) */
+    }
+    /* Simulation.__init__ bootstrap, core/simulation.py:145-154 + Source.start, load/source.py:120-140:
+     * sources in list order; their first SourceEvents take indices 0..S-1 from the GLOBAL counter. */
+    s->counter = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        if (s->g.kind[i] != HSO_SOURCE) continue;
+        s->nodes[i].arr_time_ns = p->start_ns;                      /* provider.current_time = start_time */
+        hso_event tick;
+        tick.time = next_arrival(s, i);
+        tick.idx = next_index(s);
+        tick.kind = HSO_EV_SOURCE; tick.node = i; tick.req = -1; tick.aux = 0;
+        heap_push(s, tick);
+    }
+    /* run(): _active_sim_context switches Event construction to the per-heap
+     * counter, which starts again at 0 (core/event_heap.py:48, core/sim_future.py:64-73). */
+    s->counter = 0;
+    return s;
+}
+
+/* Simulation._execute_until, core/simulation.py:449-505 (no cancellation on this path) */
+int hso_run_until(hso_sim *s, int64_t end_ns) {
+    while (s->heap_len > 0 && s->current_ns <= end_ns) {            /* :472 tests the PREVIOUS event's time */
+        hso_event e = heap_pop(s);
+        if (e.time < s->current_ns) continue;                       /* time travel drop, :480-489 */
+        s->current_ns = e.time;
+        s->processed++;
+        s->by_kind[e.kind]++;
+        trace(s, &e);
+        switch (e.kind) {
+            case HSO_EV_SOURCE: on_source(s, &e); break;
+            case HSO_EV_ENQUEUE: on_enqueue(s, &e); break;
+            case HSO_EV_NOTIFY: on_notify(s, &e); break;
+            case HSO_EV_POLL: on_poll(s, &e); break;
+            case HSO_EV_DELIVER: on_deliver(s, &e); break;
+            case HSO_EV_WORK: on_work(s, &e); break;
+            case HSO_EV_CONTINUATION: on_continuation(s, &e); break;
+            case HSO_EV_SINK: on_sink(s, &e); break;
+            default: return -1;
+        }
+    }
+    return 0;
+}
+
+void hso_get_summary(const hso_sim *s, hso_summary *out) {
+    out->events_processed = s->processed;
+    memcpy(out->events_by_kind, s->by_kind, sizeof(s->by_kind));
+    out->final_time_ns = s->current_ns;
+    out->heap_peak = s->heap_peak;
+    out->sort_index_next = (int64_t)s->counter;
+}
+
+void hso_get_node_stats(const hso_sim *s, int64_t *generated, int64_t *accepted, int64_t *dropped,
+                        int64_t *completed, int64_t *rejected, double *total_service_s,
+                        int64_t *received, int64_t *depth, int64_t *active) {
+    for (int32_t i = 0; i < s->g.n_nodes; ++i) {
+        const hso_node *nd = &s->nodes[i];
+        if (generated) generated[i] = nd->generated;
+        if (accepted) accepted[i] = nd->accepted;
+        if (dropped) dropped[i] = nd->dropped;
+        if (completed) completed[i] = nd->completed;
+        if (rejected) rejected[i] = nd->rejected;
+        if (total_service_s) total_service_s[i] = nd->total_service_s;
+        if (received) received[i] = nd->received;
+        if (depth) depth[i] = nd->fifo.len;
+        if (active) active[i] = nd->active;
+    }
+}
+
+int64_t hso_sink_count(const hso_sim *s, int32_t node) { return s->nodes[node].received; }
+
+int64_t hso_read_sink(const hso_sim *s, int32_t node, int64_t *t_ns, int64_t *created_ns, int64_t cap) {
+    const hso_node *nd = &s->nodes[node];
+    int64_t n = nd->received < cap ? nd->received : cap;
+    if (n > 0) {
+        memcpy(t_ns, nd->sink_t, (size_t)n * 8);
+        memcpy(created_ns, nd->sink_created, (size_t)n * 8);
+    }
+    return n;
+}
+
+int64_t hso_read_trace(const hso_sim *s, int64_t *t_ns, int32_t *kind, int32_t *node, int64_t *sort_index,
+                       int64_t cap) {
+    int64_t n = s->tr_len < cap ? s->tr_len : cap;
+    if (n > 0) {
+        memcpy(t_ns, s->tr_t, (size_t)n * 8);
+        memcpy(kind, s->tr_kind, (size_t)n * 4);
+        memcpy(node, s->tr_node, (size_t)n * 4);
+        memcpy(sort_index, s->tr_idx, (size_t)n * 8);
+    }
+    return n;
+}
+
+void hso_destroy(hso_sim *s) {
+    if (!s) return;
+    for (int32_t i = 0; i < s->g.n_nodes; ++i) {
+        free(s->nodes[i].fifo.buf); free(s->nodes[i].sink_t); free(s->nodes[i].sink_created);
+    }
+    free((void *)s->g.kind); free((void *)s->g.target); free((void *)s->g.stream_base);
+    free((void *)s->g.arr_kind); free((void *)s->g.rate); free((void *)s->g.stop_after_ns);
+    free((void *)s->g.concurrency); free((void *)s->g.lat_kind); free((void *)s->g.lat_mean);
+    free((void *)s->g.lat_min); free((void *)s->g.queue_cap); free((void *)s->g.alt_target); free((void *)s->g.ttl);
+    free(s->nodes); free(s->heap); free(s->reqs);
+    free(s->tr_t); free(s->tr_kind); free(s->tr_node); free(s->tr_idx);
+    free(s);
+}
+
+/* ------------------------------------------------------ scalar exports */
+double hso_uniform(uint64_t seed, uint64_t sid, uint64_t k) { return hsr_uniform(seed, sid, k); }
+double hso_log(double x) { return hs_log_ref(x); }
+void hso_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { hsr_philox4x32_10(ctr, key, out); }
+double hso_mt_py_random(uint32_t seed, int64_t n_skip) {
+    hsr_mt19937 g; uint32_t key = seed; hsr_mt_init_by_array(&g, &key, 1);
+    double v = 0; for (int64_t i = 0; i <= n_skip; ++i) v = hsr_mt_res53(&g);
+    return v;
+}
+double hso_mt_np_random(uint32_t seed, int64_t n_skip) {
+    hsr_mt19937 g; hsr_mt_init_genrand(&g, seed);
+    double v = 0; for (int64_t i = 0; i <= n_skip; ++i) v = hsr_mt_res53(&g);
+    return v;
+}

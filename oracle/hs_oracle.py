@@ -1,0 +1,253 @@
+"""ctypes binding of the CPU oracle (oracle/libhs_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of bench.py -- never by the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libhs_oracle.so")
+
+SOURCE, SERVER, SINK, LINK, ROUTER = 0, 1, 2, 3, 4
+ARR_POISSON, ARR_CONSTANT = 0, 1
+LAT_EXP, LAT_CONST = 0, 1
+RNG_PHILOX, RNG_MT19937 = 0, 1
+EV_KINDS = 10
+EV_NAMES = ["source", "enqueue", "notify", "poll", "deliver", "work", "continuation", "sink", "link", "route"]
+STREAM_ARRIVAL, STREAM_SERVICE, STREAM_LINK, STREAM_ROUTE = 0, 1, 2, 3
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (seconds)."""
+    srcs = [os.path.join(_HERE, f) for f in ("hs_oracle.c", "hs_oracle.h", "hs_rng_ref.h")]
+    if (
+        force
+        or not os.path.exists(_LIB_PATH)
+        or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs if os.path.exists(s))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libhs_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class _Graph(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int32),
+        ("kind", C.POINTER(C.c_int32)),
+        ("target", C.POINTER(C.c_int32)),
+        ("stream_base", C.POINTER(C.c_uint64)),
+        ("arr_kind", C.POINTER(C.c_int32)),
+        ("rate", C.POINTER(C.c_double)),
+        ("stop_after_ns", C.POINTER(C.c_int64)),
+        ("concurrency", C.POINTER(C.c_int32)),
+        ("lat_kind", C.POINTER(C.c_int32)),
+        ("lat_mean", C.POINTER(C.c_double)),
+        ("lat_min", C.POINTER(C.c_double)),
+        ("queue_cap", C.POINTER(C.c_int64)),
+        ("alt_target", C.POINTER(C.c_int32)),
+        ("ttl", C.POINTER(C.c_int32)),
+    ]
+
+
+class _Params(C.Structure):
+    _fields_ = [
+        ("start_ns", C.c_int64),
+        ("end_ns", C.c_int64),
+        ("seed", C.c_uint64),
+        ("rng_mode", C.c_int32),
+        ("mt_seed_py", C.c_uint32),
+        ("mt_seed_np", C.c_uint32),
+        ("trace_cap", C.c_int64),
+    ]
+
+
+class _Summary(C.Structure):
+    _fields_ = [
+        ("events_processed", C.c_int64),
+        ("events_by_kind", C.c_int64 * EV_KINDS),
+        ("final_time_ns", C.c_int64),
+        ("heap_peak", C.c_int64),
+        ("sort_index_next", C.c_int64),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.hso_create.restype = C.c_void_p
+        L.hso_create.argtypes = [C.POINTER(_Graph), C.POINTER(_Params)]
+        L.hso_run_until.restype = C.c_int
+        L.hso_run_until.argtypes = [C.c_void_p, C.c_int64]
+        L.hso_get_summary.argtypes = [C.c_void_p, C.POINTER(_Summary)]
+        L.hso_get_node_stats.argtypes = [C.c_void_p] + [C.c_void_p] * 9
+        L.hso_sink_count.restype = C.c_int64
+        L.hso_sink_count.argtypes = [C.c_void_p, C.c_int32]
+        L.hso_read_sink.restype = C.c_int64
+        L.hso_read_sink.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]
+        L.hso_read_trace.restype = C.c_int64
+        L.hso_read_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.hso_destroy.argtypes = [C.c_void_p]
+        L.hso_uniform.restype = C.c_double
+        L.hso_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        L.hso_log.restype = C.c_double
+        L.hso_log.argtypes = [C.c_double]
+        L.hso_philox.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hso_mt_py_random.restype = C.c_double
+        L.hso_mt_py_random.argtypes = [C.c_uint32, C.c_int64]
+        L.hso_mt_np_random.restype = C.c_double
+        L.hso_mt_np_random.argtypes = [C.c_uint32, C.c_int64]
+        _lib = L
+    return _lib
+
+
+@dataclass
+class Graph:
+    """Node-array description of a lowered entity graph (oracle side)."""
+
+    kind: list = field(default_factory=list)
+    target: list = field(default_factory=list)
+    stream_base: list = field(default_factory=list)
+    arr_kind: list = field(default_factory=list)
+    rate: list = field(default_factory=list)
+    stop_after_ns: list = field(default_factory=list)
+    concurrency: list = field(default_factory=list)
+    lat_kind: list = field(default_factory=list)
+    lat_mean: list = field(default_factory=list)
+    lat_min: list = field(default_factory=list)
+    queue_cap: list = field(default_factory=list)
+    alt_target: list = field(default_factory=list)
+    ttl: list = field(default_factory=list)
+
+    def _add(self, **kw) -> int:
+        defaults = dict(
+            kind=0, target=-1, stream_base=len(self.kind), arr_kind=0, rate=0.0, stop_after_ns=-1,
+            concurrency=1, lat_kind=LAT_CONST, lat_mean=0.0, lat_min=0.0, queue_cap=-1, alt_target=-1, ttl=0,
+        )
+        defaults.update(kw)
+        for k, v in defaults.items():
+            getattr(self, k).append(v)
+        return len(self.kind) - 1
+
+    def source(self, arr_kind, rate, target=-1, stop_after_ns=-1, stream_base=None) -> int:
+        kw = dict(kind=SOURCE, arr_kind=arr_kind, rate=float(rate), target=target, stop_after_ns=stop_after_ns)
+        if stream_base is not None:
+            kw["stream_base"] = stream_base
+        return self._add(**kw)
+
+    def server(self, lat_kind, lat_mean, concurrency=1, queue_cap=-1, target=-1, stream_base=None) -> int:
+        kw = dict(kind=SERVER, lat_kind=lat_kind, lat_mean=float(lat_mean), concurrency=concurrency,
+                  queue_cap=queue_cap, target=target)
+        if stream_base is not None:
+            kw["stream_base"] = stream_base
+        return self._add(**kw)
+
+    def sink(self) -> int:
+        return self._add(kind=SINK)
+
+    def __len__(self) -> int:
+        return len(self.kind)
+
+
+def mm1_chains(n: int, rate=8.0, mean=0.1, arr_kind=ARR_POISSON, lat_kind=LAT_EXP, concurrency=1,
+               queue_cap=-1, stop_after_ns=-1, stream_base0: int = 0) -> Graph:
+    """n independent Source -> Server -> Sink chains; chain i uses stream base stream_base0 + i
+    for BOTH its source (arrival stream) and its server (service stream).
+
+    Node order: all sources (list order = chain order), then per chain server, sink."""
+    g = Graph()
+    srcs = [g.source(arr_kind, rate, stream_base=stream_base0 + i, stop_after_ns=stop_after_ns) for i in range(n)]
+    for i in range(n):
+        sv = g.server(lat_kind, mean, concurrency=concurrency, queue_cap=queue_cap, stream_base=stream_base0 + i)
+        sk = g.sink()
+        g.target[srcs[i]] = sv
+        g.target[sv] = sk
+    return g
+
+
+class Result:
+    pass
+
+
+def run(g: Graph, end_ns: int, start_ns: int = 0, seed: int = 42, rng_mode: int = RNG_PHILOX,
+        mt_seed_py: int = 42, mt_seed_np: int = 42, trace_cap: int = 0, windows: list | None = None) -> Result:
+    """Run the oracle once; returns a Result with summary, per-node stats, sink records, trace."""
+    L = lib()
+    n = len(g)
+    arrs = {
+        "kind": np.asarray(g.kind, np.int32), "target": np.asarray(g.target, np.int32),
+        "stream_base": np.asarray(g.stream_base, np.uint64), "arr_kind": np.asarray(g.arr_kind, np.int32),
+        "rate": np.asarray(g.rate, np.float64), "stop_after_ns": np.asarray(g.stop_after_ns, np.int64),
+        "concurrency": np.asarray(g.concurrency, np.int32), "lat_kind": np.asarray(g.lat_kind, np.int32),
+        "lat_mean": np.asarray(g.lat_mean, np.float64), "lat_min": np.asarray(g.lat_min, np.float64),
+        "queue_cap": np.asarray(g.queue_cap, np.int64), "alt_target": np.asarray(g.alt_target, np.int32),
+        "ttl": np.asarray(g.ttl, np.int32),
+    }
+    G = _Graph()
+    G.n_nodes = n
+    for name, a in arrs.items():
+        ftype = dict(_Graph._fields_)[name]
+        setattr(G, name, a.ctypes.data_as(ftype))
+    P = _Params(start_ns, end_ns, seed, rng_mode, mt_seed_py, mt_seed_np, trace_cap)
+    h = L.hso_create(C.byref(G), C.byref(P))
+    try:
+        for w_end in (windows or []):
+            L.hso_run_until(h, int(w_end))
+        rc = L.hso_run_until(h, int(end_ns))
+        if rc != 0:
+            raise RuntimeError("oracle: unsupported event kind")
+        S = _Summary()
+        L.hso_get_summary(h, C.byref(S))
+        r = Result()
+        r.events_processed = S.events_processed
+        r.events_by_kind = np.array(list(S.events_by_kind), np.int64)
+        r.final_time_ns = S.final_time_ns
+        r.heap_peak = S.heap_peak
+        names = ["generated", "accepted", "dropped", "completed", "rejected", "total_service_s",
+                 "received", "depth", "active"]
+        bufs = {nm: np.zeros(n, np.float64 if nm == "total_service_s" else np.int64) for nm in names}
+        L.hso_get_node_stats(h, *[bufs[nm].ctypes.data for nm in names])
+        for nm in names:
+            setattr(r, nm, bufs[nm])
+        r.sinks = {}
+        for i in range(n):
+            if g.kind[i] == SINK:
+                c = L.hso_sink_count(h, i)
+                t = np.zeros(c, np.int64)
+                cr = np.zeros(c, np.int64)
+                L.hso_read_sink(h, i, t.ctypes.data, cr.ctypes.data, c)
+                r.sinks[i] = (t, cr)
+        if trace_cap:
+            t = np.zeros(trace_cap, np.int64); k = np.zeros(trace_cap, np.int32)
+            nd = np.zeros(trace_cap, np.int32); ix = np.zeros(trace_cap, np.int64)
+            m = L.hso_read_trace(h, t.ctypes.data, k.ctypes.data, nd.ctypes.data, ix.ctypes.data, trace_cap)
+            r.trace = (t[:m], k[:m], nd[:m], ix[:m])
+        return r
+    finally:
+        L.hso_destroy(h)
+
+
+def uniform(seed: int, sid: int, k: int) -> float:
+    return lib().hso_uniform(seed, sid, k)
+
+
+def log(x: float) -> float:
+    return lib().hso_log(x)
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().hso_philox(c, k, o)
+    return list(o)

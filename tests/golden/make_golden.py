@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures by running the LIVE upstream reference.
+
+Run by hand in the build container (needs /root/reference):
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Two families:
+  * Oracle-A: the stock reference, `random.seed(s); np.random.seed(s)` (MT19937
+    global streams) -- the README quick-start and the constant-rate cases.
+  * Oracle-B: the same reference engine with per-entity counter-based streams
+    plugged in through its own extension points (Seam 3): a
+    `LatencyDistribution` subclass and an `ArrivalTimeProvider` subclass that
+    draw from tests/golden/hs_streams_py.py.  The reference's event loop, queue
+    protocol, server generator, truncation rules and sort-index ledger all run
+    unmodified.
+
+Every case records: the spec (so tests can rebuild the same graph for the C
+oracle and the HIP engine), summary scalars, per-chain statistics, every Sink
+record (completion ns + latency_s), and -- for small cases -- the full
+processed-event trace (time ns, kind, node, sort index) captured by wrapping
+the simulation's `EventHeap.pop`.
+
+The GPU box has no /root/reference; tests only read the .npz files.
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import refshim  # noqa: E402
+
+refshim.install()
+
+import hs_streams_py as hs  # noqa: E402
+from happysimulator import (  # noqa: E402
+    ConstantLatency, ExponentialLatency, Instant, Server, Simulation, Sink, Source,
+)
+from happysimulator.components.queued_resource import _QueuedResourceWorkerAdapter  # noqa: E402
+from happysimulator.core.event import ProcessContinuation  # noqa: E402
+from happysimulator.core.temporal import Duration  # noqa: E402
+from happysimulator.distributions.latency_distribution import LatencyDistribution  # noqa: E402
+from happysimulator.load.arrival_time_provider import ArrivalTimeProvider  # noqa: E402
+from happysimulator.load.profile import ConstantRateProfile  # noqa: E402
+from happysimulator.load.providers.constant_arrival import ConstantArrivalTimeProvider  # noqa: E402
+from happysimulator.load.source import SimpleEventProvider  # noqa: E402
+
+EV = {"source": 0, "enqueue": 1, "notify": 2, "poll": 3, "deliver": 4, "work": 5, "continuation": 6, "sink": 7}
+
+
+# ---- Seam-3 plug-ins (ours; they only choose the random numbers) ------------------------
+class PhiloxExponentialLatency(LatencyDistribution):
+    """Same arithmetic as distributions/exponential.py:29-45 with u from a Philox stream and
+    hs_log in place of math.log:  sample = -log(1-u) / lambda,  lambda = 1/mean."""
+
+    def __init__(self, mean_latency, stream: hs.Stream):
+        super().__init__(mean_latency)
+        self._lambda = 1 / self._mean_latency
+        self._stream = stream
+
+    def get_latency(self, current_time):
+        sample = hs.exp1(self._stream.next_uniform()) / self._lambda
+        return Duration.from_seconds(sample)
+
+
+class PhiloxPoissonArrival(ArrivalTimeProvider):
+    """load/providers/poisson_arrival.py:29-31 with u from a Philox stream and hs_log."""
+
+    def __init__(self, profile, start_time, stream: hs.Stream):
+        super().__init__(profile, start_time)
+        self._stream = stream
+
+    def _get_target_integral_value(self) -> float:
+        return hs.exp1(self._stream.next_uniform())
+
+
+def _per_chain(v, n):
+    return list(v) if isinstance(v, (list, tuple)) else [v] * n
+
+
+def build_chains(spec, chain_ids, seed):
+    """Build reference entities for the given chains; returns (sources, entities, handles)."""
+    n = spec["n_chains"]
+    rate = _per_chain(spec["rate"], n)
+    mean = _per_chain(spec["mean"], n)
+    conc = _per_chain(spec.get("concurrency", 1), n)
+    qcap = _per_chain(spec.get("queue_cap"), n)
+    arr = _per_chain(spec["arr"], n)
+    svc = _per_chain(spec["svc"], n)
+    stop = spec.get("stop_after_s")
+    sources, entities, handles = [], [], []
+    for local, i in enumerate(chain_ids):
+        base = i if spec["mode"] == "single" else 0
+        sink = Sink(f"sink{i}") if spec.get("downstream", True) else None
+        if svc[i] == "exp":
+            if spec["rng"] == "philox":
+                st = PhiloxExponentialLatency(mean[i], hs.Stream(seed, base, hs.STREAM_SERVICE))
+            else:
+                st = ExponentialLatency(mean[i])
+        else:
+            st = ConstantLatency(mean[i])
+        server = Server(f"srv{i}", concurrency=conc[i], service_time=st, queue_capacity=qcap[i], downstream=sink)
+        if spec["rng"] == "philox":
+            stop_instant = None if stop is None else Instant.from_seconds(stop)
+            if arr[i] == "poisson":
+                prov = PhiloxPoissonArrival(ConstantRateProfile(rate=rate[i]), Instant.Epoch,
+                                            hs.Stream(seed, base, hs.STREAM_ARRIVAL))
+            else:
+                prov = ConstantArrivalTimeProvider(ConstantRateProfile(rate=rate[i]), start_time=Instant.Epoch)
+            source = Source(f"src{i}", SimpleEventProvider(server, "Request", stop_instant), prov)
+        else:
+            factory = Source.poisson if arr[i] == "poisson" else Source.constant
+            source = factory(rate=rate[i], target=server, name=f"src{i}", stop_after=stop)
+        sources.append(source)
+        entities.append(server)
+        if sink is not None:
+            entities.append(sink)
+        handles.append((source, server, sink))
+    return sources, entities, handles
+
+
+def classify(ev, node_of):
+    et = ev.event_type
+    tgt = ev.target
+    if et == "source_event":
+        return EV["source"], node_of[id(tgt)]
+    if et == "QUEUE_NOTIFY":
+        return EV["notify"], node_of[id(tgt)]
+    if et == "QUEUE_POLL":
+        return EV["poll"], node_of[id(tgt)]
+    if et == "QUEUE_DELIVER":
+        return EV["deliver"], node_of[id(tgt)]
+    if isinstance(tgt, _QueuedResourceWorkerAdapter):
+        return (EV["continuation"] if isinstance(ev, ProcessContinuation) else EV["work"]), node_of[id(tgt)]
+    if isinstance(tgt, Server):
+        return EV["enqueue"], node_of[id(tgt)]
+    if isinstance(tgt, Sink):
+        return EV["sink"], node_of[id(tgt)]
+    raise RuntimeError(f"unclassified event {ev!r}")
+
+
+def run_sim(spec, chain_ids, seed, want_trace):
+    if spec["rng"] == "mt":
+        random.seed(seed)
+        np.random.seed(seed)
+    sources, entities, handles = build_chains(spec, chain_ids, seed)
+    sim = Simulation(start_time=Instant.from_seconds(spec.get("start_s", 0)) if spec.get("start_s") else None,
+                     end_time=Instant.from_seconds(spec["end_s"]), sources=sources, entities=entities)
+    # chain-local node numbering: chain c -> (source=c, server=c, sink=c); kinds disambiguate
+    node_of = {}
+    for local, (src, srv, snk) in enumerate(handles):
+        c = chain_ids[local]
+        node_of[id(src)] = c
+        node_of[id(srv)] = c
+        node_of[id(srv._queue)] = c
+        node_of[id(srv._driver)] = c
+        node_of[id(srv._worker)] = c
+        if snk is not None:
+            node_of[id(snk)] = c
+    trace = []
+    if want_trace:
+        heap = sim._event_heap
+        orig_pop = heap.pop
+
+        def pop():
+            e = orig_pop()
+            k, nd = classify(e, node_of)
+            trace.append((e.time.nanoseconds, k, nd, e._sort_index))
+            return e
+
+        heap.pop = pop
+    summary = sim.run()
+    return sim, summary, handles, trace
+
+
+def run_case(spec):
+    n = spec["n_chains"]
+    want_trace = spec.get("trace", False)
+    out = {}
+    stats = {k: np.zeros(n, np.int64) for k in
+             ("generated", "accepted", "dropped", "completed", "rejected", "received", "depth", "active")}
+    total_service = np.zeros(n, np.float64)
+    sink_t, sink_lat, sink_off = [], [], [0]
+    traces = []
+    totals, finals, durations = [], [], []
+    if spec["mode"] == "single":
+        groups = [(list(range(n)), spec["seed"])]
+    else:  # replicas: one Simulation per chain, seed = base_seed + i (parallel/runner.py:115-142)
+        groups = [([i], spec["seed"] + i) for i in range(n)]
+    for chain_ids, seed in groups:
+        sim, summary, handles, trace = run_sim(spec, chain_ids, seed, want_trace)
+        totals.append(summary.total_events_processed)
+        finals.append(sim._current_time.nanoseconds)
+        durations.append(summary.duration_s)
+        traces.extend(trace)
+        for local, (src, srv, snk) in enumerate(handles):
+            i = chain_ids[local]
+            stats["generated"][i] = src.generated_count
+            stats["accepted"][i] = srv.stats_accepted
+            stats["dropped"][i] = srv.stats_dropped
+            stats["completed"][i] = srv._requests_completed
+            stats["rejected"][i] = srv._requests_rejected
+            stats["depth"][i] = srv.depth
+            stats["active"][i] = srv.active_requests
+            total_service[i] = srv._total_service_time
+            if snk is not None:
+                stats["received"][i] = snk.events_received
+    # sink records in chain order (groups are in chain order too)
+        for local, (src, srv, snk) in enumerate(handles):
+            if snk is not None:
+                sink_t.extend(t.nanoseconds for t in snk.completion_times)
+                sink_lat.extend(snk.latencies_s)
+            sink_off.append(len(sink_t))
+    meta = dict(spec=spec, total_events=totals, final_ns=finals, duration_s=durations)
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    for k, v in stats.items():
+        out[k] = v
+    out["total_service_s"] = total_service
+    out["sink_t_ns"] = np.asarray(sink_t, np.int64)
+    out["sink_latency_s"] = np.asarray(sink_lat, np.float64)
+    out["sink_off"] = np.asarray(sink_off, np.int64)
+    if want_trace:
+        tr = np.asarray(traces, np.int64).reshape(-1, 4)
+        out["trace"] = tr
+    return out, meta
+
+
+CASES = [
+    # --- Oracle-A: stock MT19937 streams -------------------------------------------------
+    dict(name="quickstart_mt42", n_chains=1, arr="poisson", rate=8.0, svc="exp", mean=0.1, end_s=60.0,
+         rng="mt", seed=42, mode="single", trace=True),
+    dict(name="quickstart_mt7_c2", n_chains=1, arr="poisson", rate=14.0, svc="exp", mean=0.1, concurrency=2,
+         end_s=40.0, rng="mt", seed=7, mode="single", trace=True),
+    dict(name="const_r8", n_chains=1, arr="constant", rate=8.0, svc="const", mean=0.1, end_s=60.0,
+         rng="mt", seed=1, mode="single", trace=True),
+    dict(name="const_r10", n_chains=1, arr="constant", rate=10.0, svc="const", mean=0.1, end_s=60.0,
+         rng="mt", seed=1, mode="single", trace=True),
+    dict(name="const_r12_overload", n_chains=1, arr="constant", rate=12.0, svc="const", mean=0.1, end_s=60.0,
+         rng="mt", seed=1, mode="single", trace=True),
+    dict(name="const_r25_cap3", n_chains=1, arr="constant", rate=25.0, svc="const", mean=0.1, queue_cap=3,
+         end_s=20.0, rng="mt", seed=1, mode="single", trace=True),
+    dict(name="const_r20_c2_cap2", n_chains=1, arr="constant", rate=20.0, svc="const", mean=0.25, concurrency=2,
+         queue_cap=2, end_s=20.0, rng="mt", seed=1, mode="single", trace=True),
+    dict(name="const_4chains_ties", n_chains=4, arr="constant", rate=[10.0, 10.0, 5.0, 20.0], svc="const",
+         mean=[0.1, 0.05, 0.2, 0.05], end_s=10.0, rng="mt", seed=1, mode="single", trace=True),
+    # --- Oracle-B: Philox-plugged reference ---------------------------------------------
+    dict(name="philox_1chain_s42", n_chains=1, arr="poisson", rate=8.0, svc="exp", mean=0.1, end_s=60.0,
+         rng="philox", seed=42, mode="single", trace=True),
+    dict(name="philox_16chains_single", n_chains=16, arr="poisson", rate=8.0, svc="exp", mean=0.1, end_s=30.0,
+         rng="philox", seed=42, mode="single", trace=True),
+    dict(name="philox_16chains_replicas", n_chains=16, arr="poisson", rate=8.0, svc="exp", mean=0.1, end_s=30.0,
+         rng="philox", seed=42, mode="replicas", trace=False),
+    dict(name="philox_c3_rho08", n_chains=4, arr="poisson", rate=24.0, svc="exp", mean=0.1, concurrency=3,
+         end_s=30.0, rng="philox", seed=7, mode="single", trace=True),
+    dict(name="philox_overload_cap4", n_chains=4, arr="poisson", rate=15.0, svc="exp", mean=0.1, queue_cap=4,
+         end_s=30.0, rng="philox", seed=11, mode="single", trace=True),
+    dict(name="philox_c2_cap1_overload", n_chains=3, arr="poisson", rate=30.0, svc="exp", mean=0.1, concurrency=2,
+         queue_cap=1, end_s=20.0, rng="philox", seed=5, mode="single", trace=True),
+    dict(name="philox_stop_after", n_chains=2, arr="poisson", rate=8.0, svc="exp", mean=0.1, stop_after_s=10.0,
+         end_s=20.0, rng="philox", seed=3, mode="single", trace=True),
+    dict(name="philox_mixed_8", n_chains=8, arr=["poisson", "constant"] * 4, rate=[8.0, 10.0, 3.0, 20.0, 12.0, 5.0, 9.5, 40.0],
+         svc=["exp", "exp", "const", "const", "exp", "exp", "exp", "const"],
+         mean=[0.1, 0.08, 0.2, 0.04, 0.05, 0.25, 0.1, 0.02], concurrency=[1, 1, 1, 1, 2, 2, 1, 1],
+         end_s=20.0, rng="philox", seed=99, mode="single", trace=True),
+    dict(name="philox_no_downstream", n_chains=2, arr="poisson", rate=8.0, svc="exp", mean=0.1, downstream=False,
+         end_s=15.0, rng="philox", seed=8, mode="single", trace=True),
+    dict(name="philox_256chains_single", n_chains=256, arr="poisson", rate=8.0, svc="exp", mean=0.1, end_s=10.0,
+         rng="philox", seed=2026, mode="single", trace=False),
+    dict(name="philox_64chains_replicas", n_chains=64, arr="poisson", rate=8.0, svc="exp", mean=0.1, end_s=20.0,
+         rng="philox", seed=1000, mode="replicas", trace=False),
+]
+
+
+def main(argv):
+    only = set(argv[1:])
+    for spec in CASES:
+        if only and spec["name"] not in only:
+            continue
+        out, meta = run_case(dict(spec))
+        path = os.path.join(HERE, spec["name"] + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{spec['name']}: events={sum(meta['total_events'])} final={meta['final_ns'][-1]} "
+              f"sink_records={len(out['sink_t_ns'])} -> {os.path.getsize(path)} B")
+
+
+if __name__ == "__main__":
+    main(sys.argv)

@@ -1,0 +1,98 @@
+"""Shared test helpers: golden loading and spec -> oracle graph lowering."""
+from __future__ import annotations
+
+import glob
+import json
+import os
+
+import numpy as np
+
+from oracle import hs_oracle as O
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+class Golden:
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.meta = json.loads(bytes(z["meta"]).decode())
+        self.spec = self.meta["spec"]
+        self.arrays = {k: z[k] for k in z.files if k != "meta"}
+
+    def __getattr__(self, k):
+        try:
+            return self.arrays[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def sink_records(self, chain):
+        a, b = self.sink_off[chain], self.sink_off[chain + 1]
+        return self.sink_t_ns[a:b], self.sink_latency_s[a:b]
+
+
+def per_chain(v, n):
+    return list(v) if isinstance(v, (list, tuple)) else [v] * n
+
+
+def ns_from_seconds(x: float) -> int:
+    """Instant.from_seconds (core/temporal.py:188-207)."""
+    if isinstance(x, int):
+        return x * 1_000_000_000
+    return int(x * 1_000_000_000)
+
+
+def spec_chain_params(spec):
+    n = spec["n_chains"]
+    return dict(
+        n=n,
+        arr=[O.ARR_POISSON if a == "poisson" else O.ARR_CONSTANT for a in per_chain(spec["arr"], n)],
+        rate=[float(r) for r in per_chain(spec["rate"], n)],
+        svc=[O.LAT_EXP if s == "exp" else O.LAT_CONST for s in per_chain(spec["svc"], n)],
+        mean=[float(m) for m in per_chain(spec["mean"], n)],
+        conc=per_chain(spec.get("concurrency", 1), n),
+        qcap=[-1 if q is None else int(q) for q in per_chain(spec.get("queue_cap"), n)],
+        stop_ns=-1 if spec.get("stop_after_s") is None else ns_from_seconds(spec["stop_after_s"]),
+        downstream=spec.get("downstream", True),
+        end_ns=ns_from_seconds(spec["end_s"]),
+    )
+
+
+def oracle_graph_for(spec, chain_ids, stream_bases):
+    """Oracle node graph for the given chains: sources first (list order), then server[, sink] per chain.
+    Returns (graph, chain -> (src, srv, snk) node ids)."""
+    p = spec_chain_params(spec)
+    g = O.Graph()
+    nodes = {}
+    srcs = []
+    for c, base in zip(chain_ids, stream_bases):
+        srcs.append(g.source(p["arr"][c], p["rate"][c], stop_after_ns=p["stop_ns"], stream_base=base))
+    for k, (c, base) in enumerate(zip(chain_ids, stream_bases)):
+        sv = g.server(p["svc"][c], p["mean"][c], concurrency=p["conc"][c], queue_cap=p["qcap"][c], stream_base=base)
+        sk = g.sink() if p["downstream"] else -1
+        g.target[srcs[k]] = sv
+        g.target[sv] = sk
+        nodes[c] = (srcs[k], sv, sk)
+    return g, nodes
+
+
+def run_oracle_for_spec(spec, trace_cap=0):
+    """Run the C oracle the way the golden was produced (single heap, or one heap per replica).
+    Returns a list of (chain_ids, nodes, result)."""
+    n = spec["n_chains"]
+    p = spec_chain_params(spec)
+    rng = O.RNG_MT19937 if spec["rng"] == "mt" else O.RNG_PHILOX
+    runs = []
+    if spec["mode"] == "single":
+        groups = [(list(range(n)), spec["seed"], list(range(n)))]
+    else:
+        groups = [([i], spec["seed"] + i, [0]) for i in range(n)]
+    for chain_ids, seed, bases in groups:
+        g, nodes = oracle_graph_for(spec, chain_ids, bases)
+        r = O.run(g, p["end_ns"], seed=seed, rng_mode=rng, mt_seed_py=seed & 0xFFFFFFFF,
+                  mt_seed_np=seed & 0xFFFFFFFF, trace_cap=trace_cap)
+        runs.append((chain_ids, nodes, r))
+    return runs

@@ -1,0 +1,64 @@
+"""CPU: the C oracle (oracle/hs_oracle.c) against the live-reference goldens.
+
+This is what PINS the oracle: every fixture under tests/golden/ was produced by the
+upstream reference itself (tests/golden/make_golden.py).  Compared bit-exactly:
+total events, per-kind histogram, final time, every per-chain statistic, every
+Sink record (ns + latency_s), and -- where recorded -- the full processed-event
+trace including the reference's `_sort_index` of each event.
+"""
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import hs_oracle as O
+
+
+@pytest.mark.parametrize("name", H.golden_names())
+def test_oracle_matches_reference_golden(name):
+    gold = H.Golden(name)
+    spec = gold.spec
+    want_trace = "trace" in gold.arrays
+    runs = H.run_oracle_for_spec(spec, trace_cap=(len(gold.trace) + 16) if want_trace else 0)
+    assert [r.events_processed for _, _, r in runs] == gold.meta["total_events"]
+    assert [r.final_time_ns for _, _, r in runs] == gold.meta["final_ns"]
+    for (chain_ids, nodes, r), dur in zip(runs, gold.meta["duration_s"]):
+        # duration_s = (t_last - t_start).to_seconds()  (core/simulation.py:546)
+        assert float(r.final_time_ns) / 1e9 == dur
+        for c in chain_ids:
+            src, srv, snk = nodes[c]
+            assert r.generated[src] == gold.generated[c]
+            assert r.accepted[srv] == gold.accepted[c]
+            assert r.dropped[srv] == gold.dropped[c]
+            assert r.completed[srv] == gold.completed[c]
+            assert r.rejected[srv] == gold.rejected[c]
+            assert r.depth[srv] == gold.depth[c]
+            assert r.active[srv] == gold.active[c]
+            assert r.total_service_s[srv] == gold.total_service_s[c]  # same fp64 sum order
+            if snk >= 0:
+                t, created = r.sinks[snk]
+                gt, glat = gold.sink_records(c)
+                assert r.received[snk] == gold.received[c]
+                np.testing.assert_array_equal(t, gt)
+                # Sink latency rule: (t - created_at).to_seconds() (components/common.py:39-40)
+                np.testing.assert_array_equal((t - created).astype(np.float64) / 1e9, glat)
+    if want_trace:
+        assert spec["mode"] == "single"
+        (chain_ids, nodes, r), = runs
+        node_chain = {}
+        for c, trio in nodes.items():
+            for nd in trio:
+                if nd >= 0:
+                    node_chain[nd] = c
+        t, k, nd, ix = r.trace
+        got = np.stack([t, k.astype(np.int64), np.array([node_chain[x] for x in nd], np.int64), ix], axis=1)
+        np.testing.assert_array_equal(got, gold.trace)
+
+
+def test_known_reference_numbers():
+    """Numbers quoted in SURVEY.md 8(c) (captured from the reference during the survey)."""
+    g = H.Golden("quickstart_mt42")
+    assert g.meta["total_events"] == [3621] and g.generated[0] == 483 and g.received[0] == 482
+    assert list(g.sink_t_ns[:3]) == [160664539, 437456572, 631679305]
+    assert H.Golden("const_r8").meta["total_events"] == [4318]
+    assert H.Golden("const_r10").meta["total_events"] == [4805]
+    assert H.Golden("const_r12_overload").meta["total_events"] == [4445]
