@@ -1,0 +1,154 @@
+"""ctypes binding of libhs_hip.so (the C ABI in include/hs_engine.h) and its build recipe.
+
+The product path has NO CPU fallback: if the shared library is missing or no
+MI355X is visible, the engine raises `EngineUnavailable` -- it never routes to
+the oracle or to a Python loop.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+CSRC = os.path.join(_PKG, "csrc")
+LIB_DIR = os.path.join(_PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libhs_hip.so")
+INCLUDE = os.path.join(_ROOT, "include")
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17",
+    "-ffp-contract=off",          # the time algebra / hs_log are fixed IEEE op sequences: never contract to FMA
+    "-fno-fast-math", "-fPIC", "-shared", "-Wno-unused-value",
+]
+
+HS_OK = 0
+HS_E_INVALID, HS_E_NO_DEVICE, HS_E_HIP, HS_E_UNSUPPORTED, HS_E_OVERFLOW, HS_E_STATE = -1, -2, -3, -4, -5, -6
+MODE_SINGLE, MODE_REPLICAS = 0, 1
+SRC_NONE, SRC_POISSON, SRC_CONSTANT = 0, 1, 2
+LAT_EXPONENTIAL, LAT_CONSTANT = 0, 1
+EGRESS_NONE, EGRESS_SINK = 0, 1
+EV_KINDS = 8
+EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuation", "sink")
+
+
+class EngineUnavailable(RuntimeError):
+    """The HIP engine cannot run here (library not built, or no GPU)."""
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"hs_engine error {code}: {message}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("device", C.c_int32), ("n_lp", C.c_int32), ("mode", C.c_int32),
+        ("start_ns", C.c_int64), ("horizon_ns", C.c_int64), ("seed", C.c_uint64), ("lp_base", C.c_uint64),
+        ("log_capacity", C.c_int64),
+    ]
+
+
+class Stations(C.Structure):
+    _fields_ = [
+        ("src_kind", C.c_void_p), ("src_rate", C.c_void_p), ("src_stop_after_ns", C.c_void_p),
+        ("concurrency", C.c_void_p), ("svc_kind", C.c_void_p), ("svc_mean_s", C.c_void_p),
+        ("queue_cap", C.c_void_p), ("egress", C.c_void_p), ("seed", C.c_void_p), ("stream_base", C.c_void_p),
+    ]
+
+
+class Summary(C.Structure):
+    _fields_ = [
+        ("events_processed", C.c_int64), ("events_by_kind", C.c_int64 * EV_KINDS), ("events_cancelled", C.c_int64),
+        ("final_time_ns", C.c_int64), ("requests_completed", C.c_int64), ("sink_records", C.c_int64),
+        ("last_run_ms", C.c_double), ("kernel_ms", C.c_double), ("launches", C.c_int64),
+        ("overflow", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class LpStats(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "generated", "accepted", "dropped", "completed", "rejected", "total_service_s", "sink_received",
+        "queue_depth", "active", "events", "final_time_ns")]
+
+
+def sources() -> list[str]:
+    return [os.path.join(CSRC, f) for f in ("hs_engine.hip", "hs_station.hpp", "hs_device.hpp")] + [
+        os.path.join(INCLUDE, "hs_engine.h")]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Cross-compile libhs_hip.so for gfx950 with hipcc (works without a GPU)."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    srcs = sources()
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, *HIPCC_FLAGS, os.path.join(CSRC, "hs_engine.hip"), "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libhs_hip.so; raises EngineUnavailable (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineUnavailable(
+            f"{LIB_PATH} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the engine has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    L.hs_abi_version.restype = C.c_int
+    L.hs_device_count.restype = C.c_int
+    L.hs_engine_create.restype = C.c_int
+    L.hs_engine_create.argtypes = [P(Config), P(C.c_void_p)]
+    L.hs_engine_set_stations.restype = C.c_int
+    L.hs_engine_set_stations.argtypes = [C.c_void_p, P(Stations)]
+    L.hs_engine_reset.restype = C.c_int
+    L.hs_engine_reset.argtypes = [C.c_void_p]
+    for name in ("hs_engine_run_until", "hs_engine_run_until_async"):
+        getattr(L, name).restype = C.c_int
+        getattr(L, name).argtypes = [C.c_void_p, C.c_int64]
+    L.hs_engine_synchronize.restype = C.c_int
+    L.hs_engine_synchronize.argtypes = [C.c_void_p]
+    L.hs_engine_bench_runs.restype = C.c_int
+    L.hs_engine_bench_runs.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+    L.hs_engine_get_summary.restype = C.c_int
+    L.hs_engine_get_summary.argtypes = [C.c_void_p, P(Summary)]
+    L.hs_engine_get_lp_stats.restype = C.c_int
+    L.hs_engine_get_lp_stats.argtypes = [C.c_void_p, P(LpStats)]
+    L.hs_engine_read_sink.restype = C.c_int64
+    L.hs_engine_read_sink.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]
+    L.hs_engine_read_sinks.restype = C.c_int64
+    L.hs_engine_read_sinks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.hs_last_error.restype = C.c_char_p
+    L.hs_last_error.argtypes = [C.c_void_p]
+    L.hs_last_global_error.restype = C.c_char_p
+    L.hs_engine_destroy.restype = None
+    L.hs_engine_destroy.argtypes = [C.c_void_p]
+    L.hs_debug_set_flags.restype = C.c_int
+    L.hs_debug_set_flags.argtypes = [C.c_void_p, C.c_int]
+    L.hs_debug_draws.restype = C.c_int
+    L.hs_debug_draws.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64, C.c_double,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]
+    if L.hs_abi_version() != 1:
+        raise EngineUnavailable("libhs_hip.so ABI version mismatch; rebuild")
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = (
+    "hs_abi_version", "hs_device_count", "hs_engine_create", "hs_engine_set_stations", "hs_engine_reset",
+    "hs_engine_run_until", "hs_engine_run_until_async", "hs_engine_synchronize", "hs_engine_bench_runs",
+    "hs_engine_get_summary", "hs_engine_get_lp_stats", "hs_engine_read_sink", "hs_engine_read_sinks",
+    "hs_last_error", "hs_last_global_error", "hs_engine_destroy", "hs_debug_draws",
+)

@@ -1,0 +1,125 @@
+// hs_device.hpp -- gfx950 device-side scalar semantics of the engine.
+//
+// Everything the event logic needs that must be bit-identical to the reference's
+// arithmetic (references relative to /root/reference/happysimulator):
+//   time algebra      int64 ns; from_seconds(x) = trunc(x * 1e9); to_seconds(ns) = double(ns) / 1e9
+//                     (core/temporal.py:62,66,205,211,222)
+//   arrivals          ns' = from_seconds(to_seconds(ns) + E / rate)       (load/arrival_time_provider.py:72-82)
+//   service           s = to_seconds(from_seconds(sample)); D = S + from_seconds(s)
+//                     (components/server/server.py:246-250, core/event.py:499)
+//   exponential       sample = E / lambda, lambda = 1 / mean              (distributions/exponential.py:36,43)
+// and the engine's counter-based streams (DESIGN.md "Random streams"):
+//   u(seed, sid, k) = res53 of half of Philox4x32-10(ctr = {k>>1, sid}, key = seed);  E = -hs_log(1 - u).
+//
+// fp64 ops are written with the __d*_rn intrinsics so that no a*b+c is ever contracted into an FMA,
+// independent of compiler flags; the file is also compiled with -ffp-contract=off.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hs {
+
+constexpr int64_t kInfNs = INT64_MAX;  // Instant.Infinity (core/temporal.py:298-368)
+
+enum StreamKind : uint32_t { kStreamArrival = 0, kStreamService = 1, kStreamLink = 2, kStreamRoute = 3 };
+
+struct U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                            uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ double res53(uint32_t a, uint32_t b) {
+    // ((a >> 5) * 2^26 + (b >> 6)) / 2^53 -- every step exact in binary64
+    const double hi = __dmul_rn((double)(a >> 5), 67108864.0);
+    return __dmul_rn(__dadd_rn(hi, (double)(b >> 6)), 1.0 / 9007199254740992.0);
+}
+
+// Natural log for normal positive x (engine passes x in [2^-53, 1]).  Same operation sequence as
+// oracle/hs_rng_ref.h hs_log_ref and tests/golden/hs_streams_py.py hs_log.
+__device__ __forceinline__ double hs_log(double x) {
+    constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                     Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                     Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                     Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                     Lg7 = 1.479819860511658591e-01;
+    uint64_t ix = (uint64_t)__double_as_longlong(x);
+    uint32_t hx = (uint32_t)(ix >> 32);
+    int32_t k = (int32_t)(hx >> 20) - 1023;
+    hx &= 0x000fffffu;
+    const uint32_t i = (hx + 0x95f64u) & 0x100000u;
+    hx |= (i ^ 0x3ff00000u);
+    k += (int32_t)(i >> 20);
+    ix = ((uint64_t)hx << 32) | (ix & 0xffffffffull);
+    const double m = __longlong_as_double((long long)ix);
+    const double f = __dsub_rn(m, 1.0);
+    const double hfsq = __dmul_rn(__dmul_rn(0.5, f), f);
+    const double s = __ddiv_rn(f, __dadd_rn(2.0, f));
+    const double z = __dmul_rn(s, s);
+    const double w = __dmul_rn(z, z);
+    const double t1 = __dmul_rn(w, __dadd_rn(Lg2, __dmul_rn(w, __dadd_rn(Lg4, __dmul_rn(w, Lg6)))));
+    const double t2 = __dmul_rn(
+        z, __dadd_rn(Lg1, __dmul_rn(w, __dadd_rn(Lg3, __dmul_rn(w, __dadd_rn(Lg5, __dmul_rn(w, Lg7)))))));
+    const double R = __dadd_rn(t2, t1);
+    const double dk = (double)k;
+    double r = __dadd_rn(__dmul_rn(s, __dadd_rn(hfsq, R)), __dmul_rn(dk, ln2_lo));
+    r = __dsub_rn(r, hfsq);
+    r = __dadd_rn(r, f);
+    return __dadd_rn(r, __dmul_rn(dk, ln2_hi));
+}
+
+__device__ __forceinline__ double exp1_from_uniform(double u) { return -hs_log(__dsub_rn(1.0, u)); }
+
+__device__ __forceinline__ int64_t ns_from_seconds(double x) { return __double2ll_rz(__dmul_rn(x, 1e9)); }
+__device__ __forceinline__ double seconds_from_ns(int64_t ns) { return __ddiv_rn(__ll2double_rn(ns), 1e9); }
+
+// One entity stream.  A Philox block serves two consecutive draws, so the block is cached and only
+// recomputed when the draw index crosses an even boundary.
+struct Stream {
+    uint32_t key0, key1, sid0, sid1;
+    uint64_t k;        // next draw index
+    uint32_t c2, c3;   // second half of the cached block (valid when k is odd)
+
+    __device__ __forceinline__ void init(uint64_t seed, uint64_t sid, uint64_t k0) {
+        key0 = (uint32_t)seed; key1 = (uint32_t)(seed >> 32);
+        sid0 = (uint32_t)sid; sid1 = (uint32_t)(sid >> 32);
+        k = k0;
+        if (k0 & 1) {  // resume in the middle of a block
+            const uint64_t b = k0 >> 1;
+            const U4 o = philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), sid0, sid1, key0, key1);
+            c2 = o.z; c3 = o.w;
+        } else {
+            c2 = c3 = 0;
+        }
+    }
+    __device__ __forceinline__ double next_uniform() {
+        double u;
+        if ((k & 1) == 0) {
+            const uint64_t b = k >> 1;
+            const U4 o = philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), sid0, sid1, key0, key1);
+            c2 = o.z; c3 = o.w;
+            u = res53(o.x, o.y);
+        } else {
+            u = res53(c2, c3);
+        }
+        ++k;
+        return u;
+    }
+};
+
+__device__ __forceinline__ uint64_t stream_id(uint64_t base, uint32_t kind) { return (base << 3) | kind; }
+
+}  // namespace hs

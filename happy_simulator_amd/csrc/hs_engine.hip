@@ -1,0 +1,777 @@
+// hs_engine.hip -- libhs_hip.so: HIP kernels (gfx950) and the C ABI declared in include/hs_engine.h.
+//
+// Replaces `Simulation._execute_until` / `_build_summary` (happysimulator/core/simulation.py:449-505,
+// :543-591) and the replica fan-out of happysimulator/parallel for station LPs.  Data layout, kernels and
+// their rooflines are described in DESIGN.md.  There is no CPU fallback in this file by design.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hs_engine.h"
+#include "hs_station.hpp"
+
+using namespace hs;
+
+// =============================================================================================
+// device helpers
+// =============================================================================================
+namespace {
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ long long shfl_xor_ll(long long v, int o) {
+    int lo = (int)(unsigned)(v & 0xffffffffll), hi = (int)(v >> 32);
+    lo = __shfl_xor(lo, o, 64);
+    hi = __shfl_xor(hi, o, 64);
+    return ((long long)hi << 32) | (unsigned)lo;
+}
+
+__device__ __forceinline__ bool cand_less(const Candidate &a, const Candidate &b) {
+    if (a.valid != b.valid) return a.valid > b.valid;
+    if (!a.valid) return false;
+    if (a.t != b.t) return a.t < b.t;
+    if (a.t_created != b.t_created) return a.t_created < b.t_created;
+    return a.lp < b.lp;
+}
+
+__device__ __forceinline__ Candidate wave_min_cand(Candidate c) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Candidate d;
+        d.t = shfl_xor_ll(c.t, o);
+        d.t_created = shfl_xor_ll(c.t_created, o);
+        d.lp = __shfl_xor(c.lp, o, 64);
+        d.valid = __shfl_xor(c.valid, o, 64);
+        if (cand_less(d, c)) c = d;
+    }
+    return c;
+}
+
+template <int C>
+__device__ __forceinline__ void load_station(Station<C> &S, const StationParams &P, const StationState &X,
+                                             const RecordLogs &L, int lp, int n, uint8_t (*qmem)[kBlock], int tid) {
+    S.lp = lp; S.n = n;
+    S.src_kind = P.src_kind[lp]; S.svc_kind = P.svc_kind[lp]; S.egress = P.egress[lp];
+    S.conc = P.conc[lp];
+    S.rate = P.src_rate[lp]; S.svc_mean = P.svc_mean[lp];
+    S.svc_lambda = __ddiv_rn(1.0, S.svc_mean);                       // ExponentialLatency._lambda = 1 / mean
+    S.svc_const_s = seconds_from_ns(ns_from_seconds(S.svc_mean));    // ConstantLatency: from_seconds(mean).to_seconds()
+    S.svc_const_ns = ns_from_seconds(S.svc_const_s);
+    S.stop_ns = P.src_stop[lp]; S.qcap = P.qcap[lp];
+    S.A = X.A[lp]; S.seqA = X.seqA[lp]; S.crtA = X.crtA[lp]; S.arr_time = X.arr_time[lp];
+    S.buf = X.buf[lp]; S.active = X.active[lp]; S.seq = X.seq[lp];
+    S.generated = X.generated[lp]; S.accepted = X.accepted[lp]; S.dropped = X.dropped[lp];
+    S.completed = X.completed[lp]; S.rejected = X.rejected[lp]; S.started = X.started[lp];
+    S.received = X.received[lp]; S.sink_w = X.sink_w[lp];
+    S.total_service = X.total_service[lp];
+    S.last_time = X.last_time[lp]; S.grp_time = X.grp_time[lp];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        S.D[i] = X.D[(size_t)i * n + lp]; S.seqD[i] = X.seqD[(size_t)i * n + lp];
+        S.crtD[i] = X.crtD[(size_t)i * n + lp]; S.svc_s[i] = X.svc_s[(size_t)i * n + lp];
+        S.crt[i] = (C > 1) ? X.crt[(size_t)i * n + lp] : 0;
+    }
+    const uint64_t seed = P.seed[lp], base = P.stream_base[lp];
+    S.arr.init(seed, stream_id(base, kStreamArrival), X.arr_k[lp]);
+    S.svc.init(seed, stream_id(base, kStreamService), X.svc_k[lp]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) S.ev[k] = 0;
+    S.adm = L.adm + (size_t)lp * L.cap;
+    S.sink_t = L.sink_t + (size_t)lp * L.cap;
+    S.sink_created = (C > 1) ? L.sink_created + (size_t)lp * L.cap : nullptr;
+    S.cap = L.cap;
+    S.overflow = 0; S.qoverflow = 0;
+    S.qmem = qmem; S.tid = tid; S.qh = 0; S.qn = 0;
+    const uint32_t q = X.q[lp];
+    const int qn = (int)(q >> 16);
+    for (int i = 0; i < qn; ++i) S.qpush((q >> (8 * i)) & 0xffu);
+}
+
+template <int C>
+__device__ __forceinline__ void store_station(const Station<C> &Sc, const StationState &X, int lp, int n) {
+    Station<C> &S = const_cast<Station<C> &>(Sc);
+    X.A[lp] = S.A; X.seqA[lp] = S.seqA; X.crtA[lp] = S.crtA; X.arr_time[lp] = S.arr_time;
+    X.buf[lp] = S.buf; X.active[lp] = S.active; X.seq[lp] = S.seq;
+    X.generated[lp] = S.generated; X.accepted[lp] = S.accepted; X.dropped[lp] = S.dropped;
+    X.completed[lp] = S.completed; X.rejected[lp] = S.rejected; X.started[lp] = S.started;
+    X.received[lp] = S.received; X.sink_w[lp] = S.sink_w;
+    X.total_service[lp] = S.total_service;
+    X.last_time[lp] = S.last_time; X.grp_time[lp] = S.grp_time;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        X.D[(size_t)i * n + lp] = S.D[i]; X.seqD[(size_t)i * n + lp] = S.seqD[i];
+        X.crtD[(size_t)i * n + lp] = S.crtD[i]; X.svc_s[(size_t)i * n + lp] = S.svc_s[i];
+        if (C > 1) X.crt[(size_t)i * n + lp] = S.crt[i];
+    }
+    X.arr_k[lp] = S.arr.k; X.svc_k[lp] = S.svc.k;
+    uint32_t q = 0;
+    int qn = S.qn > 2 ? 2 : S.qn;   // an overshoot root leaves at most two in-group events
+    for (int i = 0; i < qn; ++i) q |= (uint32_t)S.qmem[(S.qh + i) % kQCap][S.tid] << (8 * i);
+    q |= (uint32_t)qn << 16;
+    X.q[lp] = q;
+    uint32_t tot = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { X.ev_kind[(size_t)k * n + lp] += S.ev[k]; tot += S.ev[k]; }
+    X.events[lp] += tot;
+}
+
+// first pending event of an LP: time, creation time, which root
+template <int C>
+__device__ __forceinline__ Candidate make_candidate(const Station<C> &S) {
+    Candidate c;
+    c.lp = S.lp; c.valid = 0; c.t = kInfNs; c.t_created = 0;
+    if (S.qn > 0) {   // a group already in progress keeps the floor
+        c.t = S.grp_time; c.t_created = S.grp_time; c.valid = 1;
+        return c;
+    }
+    const int64_t t = S.next_time();
+    if (t == kInfNs) return c;
+    const int w = S.pick_root(t);
+    c.t = t; c.valid = 1;
+    if (w == 0) c.t_created = S.crtA;
+    else {
+#pragma unroll
+        for (int i = 0; i < C; ++i) if (i == w - 1) c.t_created = S.crtD[i];
+    }
+    return c;
+}
+
+// process exactly ONE event beyond end_ns: the first micro-event of the LP's next group
+template <int C>
+__device__ __forceinline__ void overshoot_one(Station<C> &S) {
+    if (S.qn > 0) {   // continue the in-progress group by one event
+        // (only reachable when a previous window ended inside this group and the new end is still before it)
+        return;
+    }
+    const int64_t t = S.next_time();
+    if (t == kInfNs) return;
+    S.run_root(S.pick_root(t), t);
+    S.last_time = t;
+    S.grp_time = t;
+}
+
+}  // namespace
+
+// =============================================================================================
+// kernels
+// =============================================================================================
+
+// Simulation.__init__ bootstrap (core/simulation.py:145-154, load/source.py:120-140): every Source draws
+// its first arrival from start_ns.  Also zeroes the per-LP state.
+__global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, StationState X, Totals *tot, int n, int C,
+                                                           int64_t start_ns) {
+    const int lp = blockIdx.x * kBlock + threadIdx.x;
+    if (lp == 0) {
+        for (int k = 0; k < 8; ++k) tot->ev[k] = 0;
+        tot->completed = 0; tot->received = 0; tot->final_time = start_ns; tot->cur_time = start_ns;
+        tot->overflow = 0; tot->qoverflow = 0; tot->done = 0;
+    }
+    if (lp >= n) return;
+    int64_t A = kInfNs, arr_time = start_ns;
+    uint64_t arr_k = 0;
+    const uint32_t sk = P.src_kind[lp];
+    if (sk != 0) {
+        double area = 1.0;
+        if (sk == 1) {
+            Stream s;
+            s.init(P.seed[lp], stream_id(P.stream_base[lp], kStreamArrival), 0);
+            area = exp1_from_uniform(s.next_uniform());
+            arr_k = 1;
+        }
+        const double t_next = __dadd_rn(seconds_from_ns(start_ns), __ddiv_rn(area, P.src_rate[lp]));
+        arr_time = ns_from_seconds(t_next);
+        A = arr_time;
+    }
+    X.A[lp] = A; X.seqA[lp] = 0; X.crtA[lp] = start_ns; X.arr_k[lp] = arr_k; X.arr_time[lp] = arr_time;
+    X.svc_k[lp] = 0; X.seq[lp] = 1; X.buf[lp] = 0; X.active[lp] = 0;
+    X.generated[lp] = 0; X.accepted[lp] = 0; X.dropped[lp] = 0; X.completed[lp] = 0; X.rejected[lp] = 0;
+    X.started[lp] = 0; X.received[lp] = 0; X.sink_w[lp] = 0; X.total_service[lp] = 0.0;
+    X.q[lp] = 0; X.grp_time[lp] = start_ns; X.last_time[lp] = start_ns; X.events[lp] = 0;
+    for (int i = 0; i < C; ++i) {
+        X.D[(size_t)i * n + lp] = kInfNs; X.seqD[(size_t)i * n + lp] = 0; X.crtD[(size_t)i * n + lp] = start_ns;
+        X.svc_s[(size_t)i * n + lp] = 0.0; X.crt[(size_t)i * n + lp] = 0;
+    }
+    for (int k = 0; k < 8; ++k) X.ev_kind[(size_t)k * n + lp] = 0;
+}
+
+// The hot kernel: every LP advances to end_ns (== Simulation._execute_until for its events), then the
+// one-event overshoot is applied (per LP in REPLICAS mode; to the globally first event in SINGLE mode,
+// elected across workgroups with a last-block reduction).
+template <int C>
+__global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, StationState X, RecordLogs L, Totals *tot,
+                                                         Candidate *cands, int n, int64_t end_ns, int mode, int flags) {
+    __shared__ uint8_t qmem[kQCap][kBlock];
+    __shared__ unsigned long long red[12];
+    __shared__ long long red_time;
+    __shared__ int red_flags[2];
+    __shared__ Candidate wave_c[kBlock / 64];
+    __shared__ int is_last;
+
+    const int tid = threadIdx.x;
+    const int lp = blockIdx.x * kBlock + tid;
+    const bool live = lp < n;
+    if (tid < 12) red[tid] = 0;
+    if (tid == 0) { red_time = INT64_MIN; red_flags[0] = 0; red_flags[1] = 0; }
+    const long long cur = tot->cur_time;   // SINGLE: Simulation._current_time (written by the previous launch)
+    __syncthreads();
+
+    Station<C> S;
+    Candidate mine;
+    mine.valid = 0; mine.t = kInfNs; mine.t_created = 0; mine.lp = lp;
+    if (live) {
+        load_station<C>(S, P, X, L, lp, n, qmem, tid);
+        S.force_general = (flags & 1) != 0;
+        const bool frozen = (mode == HS_MODE_REPLICAS) ? (S.last_time > end_ns) : (cur > end_ns);
+        if (!frozen) {
+            if (S.qn > 0 && S.grp_time <= end_ns) {   // finish a group a previous window stopped inside
+                S.run_group_general(S.grp_time);
+                S.last_time = S.grp_time;
+            }
+            if (S.qn == 0) {
+                for (;;) {
+                    const int64_t t = S.next_time();
+                    if (t > end_ns) break;             // also ends on kInfNs: nothing pending
+                    S.run_group(t);
+                }
+            }
+            if (mode == HS_MODE_REPLICAS) overshoot_one<C>(S);
+            else mine = make_candidate<C>(S);
+        }
+        store_station<C>(S, X, lp, n);
+    }
+
+    // ---- workgroup reduction of the per-run deltas -> engine totals
+    unsigned vals[10];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) vals[k] = live ? S.ev[k] : 0u;
+    // completed / received deltas are the continuation / sink event counts
+    vals[8] = vals[6]; vals[9] = vals[7];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const unsigned s = wave_sum<unsigned>(vals[k]);
+        if ((tid & 63) == 0 && s) atomicAdd(&red[k], (unsigned long long)s);
+    }
+    if (live) {
+        atomicMax(&red_time, (long long)S.last_time);
+        if (S.overflow) red_flags[0] = 1;
+        if (S.qoverflow) red_flags[1] = 1;
+    }
+    if (mode == HS_MODE_SINGLE) {
+        const Candidate w = wave_min_cand(mine);
+        if ((tid & 63) == 0) wave_c[tid >> 6] = w;
+    }
+    __syncthreads();
+    if (tid < 8 && red[tid]) atomicAdd(&tot->ev[tid], red[tid]);
+    if (tid == 8 && red[8]) atomicAdd(&tot->completed, red[8]);
+    if (tid == 9 && red[9]) atomicAdd(&tot->received, red[9]);
+    if (tid == 10) {
+        if (red_time != INT64_MIN) atomicMax(&tot->final_time, red_time);
+        if (red_flags[0]) atomicOr(&tot->overflow, 1);
+        if (red_flags[1]) atomicOr(&tot->qoverflow, 1);
+    }
+    if (mode != HS_MODE_SINGLE) return;
+
+    // ---- SINGLE mode: elect the globally first event beyond end_ns (last-block pattern)
+    if (tid == 0) {
+        Candidate b = wave_c[0];
+        for (int w = 1; w < kBlock / 64; ++w) if (cand_less(wave_c[w], b)) b = wave_c[w];
+        cands[blockIdx.x] = b;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // state + candidate visible device-wide
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned ticket = atomicAdd(&tot->done, 1u);
+        is_last = (ticket == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    Candidate best;
+    best.valid = 0; best.t = kInfNs; best.t_created = 0; best.lp = 0;
+    for (int b = tid; b < (int)gridDim.x; b += kBlock) {
+        Candidate c;
+        c.t = __hip_atomic_load(&cands[b].t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.t_created = __hip_atomic_load(&cands[b].t_created, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.lp = __hip_atomic_load(&cands[b].lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.valid = __hip_atomic_load(&cands[b].valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cand_less(c, best)) best = c;
+    }
+    best = wave_min_cand(best);
+    if ((tid & 63) == 0) wave_c[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        Candidate b = wave_c[0];
+        for (int w = 1; w < kBlock / 64; ++w) if (cand_less(wave_c[w], b)) b = wave_c[w];
+        long long new_cur = __hip_atomic_load(&tot->final_time, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur <= end_ns && b.valid) {
+            Station<C> W;
+            load_station<C>(W, P, X, L, b.lp, n, qmem, 0);
+            W.force_general = false;
+            overshoot_one<C>(W);
+            store_station<C>(W, X, b.lp, n);
+            for (int k = 0; k < 8; ++k) if (W.ev[k]) atomicAdd(&tot->ev[k], (unsigned long long)W.ev[k]);
+            if (W.ev[6]) atomicAdd(&tot->completed, (unsigned long long)W.ev[6]);
+            if (W.ev[7]) atomicAdd(&tot->received, (unsigned long long)W.ev[7]);
+            if (W.overflow) atomicOr(&tot->overflow, 1);
+            new_cur = b.t;
+            atomicMax(&tot->final_time, new_cur);
+        }
+        if (cur <= end_ns) tot->cur_time = new_cur;
+        tot->done = 0;   // self-resetting ticket
+    }
+}
+
+__global__ void hs_debug_draws_kernel(uint64_t seed, uint64_t sid, uint64_t k0, int64_t n, double rate, double *u,
+                                      double *e, int64_t *ns) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Stream s;
+    s.init(seed, sid, k0 + (uint64_t)i);
+    const double uu = s.next_uniform();
+    const double ee = exp1_from_uniform(uu);
+    u[i] = uu; e[i] = ee;
+    ns[i] = ns_from_seconds(__ddiv_rn(ee, rate));
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+static thread_local std::string g_global_error;
+
+struct hs_engine {
+    hs_config cfg{};
+    int C = 1;                 // departure slots compiled for (>= max concurrency)
+    bool have_stations = false;
+    bool initialised = false;  // reset done
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
+    std::vector<void *> allocs;
+    StationParams P{};
+    StationState X{};
+    RecordLogs L{};
+    Totals *tot = nullptr;
+    Candidate *cands = nullptr;
+    int n_blocks = 0;
+    int flags = 0;
+    double last_run_ms = 0.0, last_kernel_ms = 0.0;
+    int64_t launches = 0;
+    std::string error;
+};
+
+namespace {
+
+int fail(hs_engine *h, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->error = buf;
+    g_global_error = buf;
+    return code;
+}
+
+#define HS_HIP(h, expr)                                                                                \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(h, HS_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));        \
+    } while (0)
+
+template <typename T>
+int dev_alloc(hs_engine *h, T **p, size_t count) {
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(T) ? count * sizeof(T) : sizeof(T));
+    if (e != hipSuccess) return fail(h, HS_E_HIP, "hipMalloc(%zu B): %s", count * sizeof(T), hipGetErrorString(e));
+    h->allocs.push_back(q);
+    *p = (T *)q;
+    return HS_OK;
+}
+
+template <typename T>
+int upload(hs_engine *h, const T **dst, const T *src, size_t n, T dflt) {
+    T *d = nullptr;
+    int rc = dev_alloc(h, &d, n);
+    if (rc) return rc;
+    std::vector<T> tmp;
+    if (!src) { tmp.assign(n, dflt); src = tmp.data(); }
+    hipError_t e = hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail(h, HS_E_HIP, "hipMemcpy H2D: %s", hipGetErrorString(e));
+    *dst = d;
+    return HS_OK;
+}
+
+template <int C>
+void launch_run(hs_engine *h, int64_t end_ns) {
+    hipLaunchKernelGGL(hs_station_run<C>, dim3(h->n_blocks), dim3(kBlock), 0, h->stream, h->P, h->X, h->L, h->tot,
+                       h->cands, h->cfg.n_lp, end_ns, h->cfg.mode, h->flags);
+}
+
+void launch_run_dispatch(hs_engine *h, int64_t end_ns) {
+    switch (h->C) {
+        case 1: launch_run<1>(h, end_ns); break;
+        case 2: launch_run<2>(h, end_ns); break;
+        case 4: launch_run<4>(h, end_ns); break;
+        case 8: launch_run<8>(h, end_ns); break;
+        default: launch_run<16>(h, end_ns); break;
+    }
+}
+
+int do_reset_async(hs_engine *h) {
+    hipLaunchKernelGGL(hs_station_reset, dim3(h->n_blocks), dim3(kBlock), 0, h->stream, h->P, h->X, h->tot,
+                       h->cfg.n_lp, h->C, h->cfg.start_ns);
+    HS_HIP(h, hipGetLastError());
+    h->initialised = true;
+    return HS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hs_abi_version(void) { return HS_ABI_VERSION; }
+
+int hs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *hs_last_error(const hs_engine *h) { return h ? h->error.c_str() : g_global_error.c_str(); }
+const char *hs_last_global_error(void) { return g_global_error.c_str(); }
+
+int hs_engine_create(const hs_config *cfg, hs_engine **out) {
+    if (!cfg || !out) return fail(nullptr, HS_E_INVALID, "hs_engine_create: null argument");
+    if (cfg->struct_size != sizeof(hs_config))
+        return fail(nullptr, HS_E_INVALID, "hs_engine_create: hs_config size mismatch (ABI %d)", HS_ABI_VERSION);
+    if (cfg->n_lp <= 0) return fail(nullptr, HS_E_INVALID, "hs_engine_create: n_lp must be > 0");
+    if (cfg->mode != HS_MODE_SINGLE && cfg->mode != HS_MODE_REPLICAS)
+        return fail(nullptr, HS_E_INVALID, "hs_engine_create: unknown mode %d", cfg->mode);
+    if (cfg->horizon_ns < cfg->start_ns)
+        return fail(nullptr, HS_E_INVALID, "hs_engine_create: horizon_ns precedes start_ns");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, HS_E_NO_DEVICE, "no HIP device visible: the engine has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, HS_E_INVALID, "device ordinal %d out of range (%d devices)", cfg->device, ndev);
+    hs_engine *h = new (std::nothrow) hs_engine();
+    if (!h) return fail(nullptr, HS_E_INVALID, "out of host memory");
+    h->cfg = *cfg;
+    hipError_t e = hipSetDevice(cfg->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_a);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_b);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_k0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_k1);
+    if (e != hipSuccess) {
+        int rc = fail(nullptr, HS_E_HIP, "device setup: %s", hipGetErrorString(e));
+        delete h;
+        return rc;
+    }
+    h->n_blocks = (cfg->n_lp + kBlock - 1) / kBlock;
+    *out = h;
+    return HS_OK;
+}
+
+int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
+    if (!h || !st) return fail(h, HS_E_INVALID, "hs_engine_set_stations: null argument");
+    if (h->have_stations) return fail(h, HS_E_STATE, "stations already set");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    const int n = h->cfg.n_lp;
+    // ---- validation (mirrors the reference constructors' ValueErrors) and sizing
+    int maxc = 1;
+    double max_mean_records = 0.0;
+    bool any_source = false;
+    const double horizon_s = (double)(h->cfg.horizon_ns - h->cfg.start_ns) / 1e9;
+    for (int i = 0; i < n; ++i) {
+        const int sk = st->src_kind ? st->src_kind[i] : HS_SRC_POISSON;
+        if (sk < 0 || sk > 2) return fail(h, HS_E_INVALID, "LP %d: unknown source kind %d", i, sk);
+        if (sk != HS_SRC_NONE) {
+            any_source = true;
+            if (!st->src_rate) return fail(h, HS_E_INVALID, "src_rate is required when sources exist");
+            const double r = st->src_rate[i];
+            if (!(r > 0.0) || !std::isfinite(r))
+                return fail(h, HS_E_INVALID, "LP %d: source rate must be > 0 (got %g)", i, r);
+            if (r > 1e8) return fail(h, HS_E_UNSUPPORTED, "LP %d: source rate %g above 1e8/s is not supported", i, r);
+            const double m = r * horizon_s;
+            if (m > max_mean_records) max_mean_records = m;
+        }
+        const int c = st->concurrency ? st->concurrency[i] : 1;
+        if (c < 1) return fail(h, HS_E_INVALID, "LP %d: max_concurrent must be >= 1, got %d", i, c);
+        if (c > 16) return fail(h, HS_E_UNSUPPORTED, "LP %d: concurrency %d > 16 is not lowered yet", i, c);
+        if (c > maxc) maxc = c;
+        const int vk = st->svc_kind ? st->svc_kind[i] : HS_LAT_CONSTANT;
+        if (vk != HS_LAT_EXPONENTIAL && vk != HS_LAT_CONSTANT)
+            return fail(h, HS_E_UNSUPPORTED, "LP %d: service distribution kind %d is not lowered", i, vk);
+        const double mean = st->svc_mean_s ? st->svc_mean_s[i] : 0.01;
+        if (!(mean >= 0.0) || !std::isfinite(mean)) return fail(h, HS_E_INVALID, "LP %d: bad service mean %g", i, mean);
+        if (vk == HS_LAT_EXPONENTIAL && !(mean > 0.0))
+            return fail(h, HS_E_INVALID, "LP %d: exponential service needs mean > 0", i);
+        const int eg = st->egress ? st->egress[i] : HS_EGRESS_SINK;
+        if (eg != HS_EGRESS_NONE && eg != HS_EGRESS_SINK)
+            return fail(h, HS_E_UNSUPPORTED, "LP %d: egress kind %d is not lowered", i, eg);
+    }
+    (void)any_source;
+    h->C = maxc <= 1 ? 1 : maxc <= 2 ? 2 : maxc <= 4 ? 4 : maxc <= 8 ? 8 : 16;
+    int64_t cap = h->cfg.log_capacity;
+    if (cap <= 0) {
+        const double c = max_mean_records + 10.0 * std::sqrt(max_mean_records + 1.0) + 64.0;
+        cap = ((int64_t)c + 15) & ~(int64_t)15;
+    }
+    const double log_bytes = (double)n * (double)cap * 8.0 * (h->C > 1 ? 3.0 : 2.0);
+    if (log_bytes > 200e9)
+        return fail(h, HS_E_INVALID, "record logs would need %.1f GB (n_lp=%d, capacity=%lld)", log_bytes / 1e9, n,
+                    (long long)cap);
+    h->L.cap = cap;
+    int rc;
+    std::vector<uint64_t> dflt_base((size_t)n);
+    for (int i = 0; i < n; ++i) dflt_base[(size_t)i] = h->cfg.lp_base + (uint64_t)i;
+#define UP(field, src, T, d) if ((rc = upload<T>(h, &h->P.field, src, (size_t)n, d))) return rc
+    UP(src_kind, st->src_kind, uint8_t, (uint8_t)HS_SRC_POISSON);
+    UP(src_rate, st->src_rate, double, 1.0);
+    UP(src_stop, st->src_stop_after_ns, int64_t, (int64_t)-1);
+    UP(conc, st->concurrency, int32_t, 1);
+    UP(svc_kind, st->svc_kind, uint8_t, (uint8_t)HS_LAT_CONSTANT);
+    UP(svc_mean, st->svc_mean_s, double, 0.01);
+    UP(qcap, st->queue_cap, int64_t, (int64_t)-1);
+    UP(egress, st->egress, uint8_t, (uint8_t)HS_EGRESS_SINK);
+    UP(seed, st->seed, uint64_t, h->cfg.seed);
+    if ((rc = upload<uint64_t>(h, &h->P.stream_base, st->stream_base ? st->stream_base : dflt_base.data(), (size_t)n, 0)))
+        return rc;
+#undef UP
+    const size_t N = (size_t)n, NC = (size_t)n * (size_t)h->C;
+#define AL(field, count) if ((rc = dev_alloc(h, &h->X.field, count))) return rc
+    AL(A, N); AL(seqA, N); AL(crtA, N); AL(arr_k, N); AL(arr_time, N); AL(svc_k, N);
+    AL(D, NC); AL(seqD, NC); AL(crtD, NC); AL(svc_s, NC); AL(crt, NC);
+    AL(seq, N); AL(buf, N); AL(active, N);
+    AL(generated, N); AL(accepted, N); AL(dropped, N); AL(completed, N); AL(rejected, N); AL(started, N);
+    AL(received, N); AL(sink_w, N); AL(total_service, N); AL(q, N); AL(grp_time, N); AL(last_time, N);
+    AL(events, N); AL(ev_kind, N * 8);
+#undef AL
+    if ((rc = dev_alloc(h, &h->L.adm, N * (size_t)cap))) return rc;
+    if ((rc = dev_alloc(h, &h->L.sink_t, N * (size_t)cap))) return rc;
+    if (h->C > 1) { if ((rc = dev_alloc(h, &h->L.sink_created, N * (size_t)cap))) return rc; }
+    else h->L.sink_created = h->L.adm;
+    if ((rc = dev_alloc(h, &h->tot, 1))) return rc;
+    if ((rc = dev_alloc(h, &h->cands, (size_t)h->n_blocks))) return rc;
+    HS_HIP(h, hipMemset(h->tot, 0, sizeof(Totals)));
+    h->have_stations = true;
+    return HS_OK;
+}
+
+int hs_engine_reset(hs_engine *h) {
+    if (!h || !h->have_stations) return fail(h, HS_E_STATE, "hs_engine_reset: stations not set");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = do_reset_async(h);
+    if (rc) return rc;
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    return HS_OK;
+}
+
+int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
+    if (!h || !h->have_stations) return fail(h, HS_E_STATE, "hs_engine_run_until: stations not set");
+    if (end_ns > h->cfg.horizon_ns)
+        return fail(h, HS_E_INVALID, "end_ns %lld beyond the configured horizon %lld", (long long)end_ns,
+                    (long long)h->cfg.horizon_ns);
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    h->launches = 0;
+    HS_HIP(h, hipEventRecord(h->ev_a, h->stream));
+    if (!h->initialised) { int rc = do_reset_async(h); if (rc) return rc; h->launches++; }
+    HS_HIP(h, hipEventRecord(h->ev_k0, h->stream));
+    launch_run_dispatch(h, end_ns);
+    HS_HIP(h, hipGetLastError());
+    HS_HIP(h, hipEventRecord(h->ev_k1, h->stream));
+    h->launches++;
+    HS_HIP(h, hipEventRecord(h->ev_b, h->stream));
+    return HS_OK;
+}
+
+int hs_engine_synchronize(hs_engine *h) {
+    if (!h) return fail(h, HS_E_INVALID, "null handle");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev_a, h->ev_b) == hipSuccess) h->last_run_ms = ms;
+    if (hipEventElapsedTime(&ms, h->ev_k0, h->ev_k1) == hipSuccess) h->last_kernel_ms = ms;
+    return HS_OK;
+}
+
+int hs_engine_run_until(hs_engine *h, int64_t end_ns) {
+    int rc = hs_engine_run_until_async(h, end_ns);
+    if (rc) return rc;
+    rc = hs_engine_synchronize(h);
+    if (rc) return rc;
+    Totals t;
+    HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
+    if (t.qoverflow) return fail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
+    if (t.overflow)
+        return fail(h, HS_E_OVERFLOW, "a per-LP record log overflowed (capacity %lld records)", (long long)h->L.cap);
+    return HS_OK;
+}
+
+int hs_engine_bench_runs(hs_engine *h, int64_t end_ns, int32_t repeats, float *kernel_ms_out, float *total_ms_out) {
+    if (!h || !h->have_stations) return fail(h, HS_E_STATE, "hs_engine_bench_runs: stations not set");
+    if (repeats <= 0) return fail(h, HS_E_INVALID, "repeats must be > 0");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    std::vector<hipEvent_t> ev((size_t)repeats * 2 + 2);
+    for (auto &e : ev) HS_HIP(h, hipEventCreate(&e));
+    HS_HIP(h, hipEventRecord(ev[(size_t)repeats * 2], h->stream));
+    for (int r = 0; r < repeats; ++r) {
+        int rc = do_reset_async(h);
+        if (rc) return rc;
+        HS_HIP(h, hipEventRecord(ev[(size_t)2 * r], h->stream));
+        launch_run_dispatch(h, end_ns);
+        HS_HIP(h, hipGetLastError());
+        HS_HIP(h, hipEventRecord(ev[(size_t)2 * r + 1], h->stream));
+    }
+    HS_HIP(h, hipEventRecord(ev[(size_t)repeats * 2 + 1], h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    for (int r = 0; r < repeats; ++r) {
+        float ms = 0.f;
+        HS_HIP(h, hipEventElapsedTime(&ms, ev[(size_t)2 * r], ev[(size_t)2 * r + 1]));
+        if (kernel_ms_out) kernel_ms_out[r] = ms;
+        h->last_kernel_ms = ms;
+    }
+    float tot_ms = 0.f;
+    HS_HIP(h, hipEventElapsedTime(&tot_ms, ev[(size_t)repeats * 2], ev[(size_t)repeats * 2 + 1]));
+    if (total_ms_out) *total_ms_out = tot_ms;
+    h->last_run_ms = tot_ms / (float)repeats;
+    h->launches = 2;
+    for (auto &e : ev) hipEventDestroy(e);
+    return HS_OK;
+}
+
+int hs_engine_get_summary(hs_engine *h, hs_summary *out) {
+    if (!h || !out) return fail(h, HS_E_INVALID, "hs_engine_get_summary: null argument");
+    if (!h->have_stations) return fail(h, HS_E_STATE, "stations not set");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    Totals t;
+    HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    int64_t total = 0;
+    for (int k = 0; k < 8; ++k) { out->events_by_kind[k] = (int64_t)t.ev[k]; total += (int64_t)t.ev[k]; }
+    out->events_processed = total;
+    out->events_cancelled = 0;
+    out->final_time_ns = (h->cfg.mode == HS_MODE_SINGLE) ? t.cur_time : t.final_time;
+    out->requests_completed = (int64_t)t.completed;
+    out->sink_records = (int64_t)t.received;
+    out->last_run_ms = h->last_run_ms;
+    out->kernel_ms = h->last_kernel_ms;
+    out->launches = h->launches;
+    out->overflow = t.overflow;
+    return HS_OK;
+}
+
+int hs_engine_get_lp_stats(hs_engine *h, const hs_lp_stats *o) {
+    if (!h || !o) return fail(h, HS_E_INVALID, "hs_engine_get_lp_stats: null argument");
+    if (!h->have_stations) return fail(h, HS_E_STATE, "stations not set");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    const size_t n = (size_t)h->cfg.n_lp;
+#define DL(dst, src, T) if (o->dst) HS_HIP(h, hipMemcpy(o->dst, h->X.src, n * sizeof(T), hipMemcpyDeviceToHost))
+    DL(generated, generated, int64_t); DL(accepted, accepted, int64_t); DL(dropped, dropped, int64_t);
+    DL(completed, completed, int64_t); DL(rejected, rejected, int64_t); DL(total_service_s, total_service, double);
+    DL(sink_received, received, int64_t); DL(queue_depth, buf, int64_t); DL(active, active, int32_t);
+    DL(events, events, int64_t); DL(final_time_ns, last_time, int64_t);
+#undef DL
+    return HS_OK;
+}
+
+int64_t hs_engine_read_sink(hs_engine *h, int32_t lp, int64_t *t_ns, int64_t *created_ns, int64_t cap) {
+    if (!h || !h->have_stations) return fail(h, HS_E_STATE, "stations not set");
+    if (lp < 0 || lp >= h->cfg.n_lp) return fail(h, HS_E_INVALID, "LP index %d out of range", lp);
+    if (hipSetDevice(h->cfg.device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+        return fail(h, HS_E_HIP, "device synchronisation failed");
+    int64_t cnt = 0;
+    if (hipMemcpy(&cnt, h->X.received + lp, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, HS_E_HIP, "memcpy");
+    if (cnt > h->L.cap) cnt = h->L.cap;
+    if (cnt > cap) cnt = cap;
+    if (cnt > 0) {
+        if (t_ns && hipMemcpy(t_ns, h->L.sink_t + (size_t)lp * h->L.cap, (size_t)cnt * 8, hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(h, HS_E_HIP, "memcpy");
+        if (created_ns && hipMemcpy(created_ns, h->L.sink_created + (size_t)lp * h->L.cap, (size_t)cnt * 8,
+                                    hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(h, HS_E_HIP, "memcpy");
+    }
+    return cnt;
+}
+
+int64_t hs_engine_read_sinks(hs_engine *h, int64_t *counts, int64_t *t_ns, int64_t *created_ns, int64_t cap_total) {
+    if (!h || !h->have_stations) return fail(h, HS_E_STATE, "stations not set");
+    if (!counts) return fail(h, HS_E_INVALID, "counts is required");
+    if (hipSetDevice(h->cfg.device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+        return fail(h, HS_E_HIP, "device synchronisation failed");
+    const size_t n = (size_t)h->cfg.n_lp;
+    if (hipMemcpy(counts, h->X.received, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, HS_E_HIP, "memcpy");
+    // one bulk D2H of both logs, then compact on the host (records are [lp][cap] row-major)
+    const size_t cap = (size_t)h->L.cap;
+    std::vector<int64_t> tbuf, cbuf;
+    if (t_ns) tbuf.resize(n * cap);
+    if (created_ns) cbuf.resize(n * cap);
+    if (t_ns && hipMemcpy(tbuf.data(), h->L.sink_t, n * cap * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(h, HS_E_HIP, "memcpy");
+    if (created_ns && hipMemcpy(cbuf.data(), h->L.sink_created, n * cap * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(h, HS_E_HIP, "memcpy");
+    int64_t off = 0;
+    for (size_t i = 0; i < n; ++i) {
+        int64_t c = counts[i] > (int64_t)cap ? (int64_t)cap : counts[i];
+        if (off + c > cap_total) return fail(h, HS_E_INVALID, "output buffers too small for the sink records");
+        if (t_ns) memcpy(t_ns + off, tbuf.data() + i * cap, (size_t)c * 8);
+        if (created_ns) memcpy(created_ns + off, cbuf.data() + i * cap, (size_t)c * 8);
+        off += c;
+    }
+    return off;
+}
+
+void hs_engine_destroy(hs_engine *h) {
+    if (!h) return;
+    hipSetDevice(h->cfg.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (void *p : h->allocs) hipFree(p);
+    if (h->ev_a) hipEventDestroy(h->ev_a);
+    if (h->ev_b) hipEventDestroy(h->ev_b);
+    if (h->ev_k0) hipEventDestroy(h->ev_k0);
+    if (h->ev_k1) hipEventDestroy(h->ev_k1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int hs_debug_set_flags(hs_engine *h, int flags) {
+    if (!h) return HS_E_INVALID;
+    h->flags = flags;
+    return HS_OK;
+}
+
+int hs_debug_draws(int32_t device, uint64_t seed, uint64_t sid, uint64_t k0, int64_t n, double rate, double *u,
+                   double *e, int64_t *ns) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, HS_E_NO_DEVICE, "no HIP device visible: the engine has no CPU fallback");
+    if (n <= 0 || !u || !e || !ns) return fail(nullptr, HS_E_INVALID, "hs_debug_draws: bad arguments");
+    HS_HIP(nullptr, hipSetDevice(device));
+    double *du = nullptr, *de = nullptr;
+    int64_t *dn = nullptr;
+    HS_HIP(nullptr, hipMalloc((void **)&du, (size_t)n * 8));
+    HS_HIP(nullptr, hipMalloc((void **)&de, (size_t)n * 8));
+    HS_HIP(nullptr, hipMalloc((void **)&dn, (size_t)n * 8));
+    hipLaunchKernelGGL(hs_debug_draws_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, seed, sid, k0, n, rate,
+                       du, de, dn);
+    HS_HIP(nullptr, hipGetLastError());
+    HS_HIP(nullptr, hipMemcpy(u, du, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HS_HIP(nullptr, hipMemcpy(e, de, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HS_HIP(nullptr, hipMemcpy(ns, dn, (size_t)n * 8, hipMemcpyDeviceToHost));
+    hipFree(du); hipFree(de); hipFree(dn);
+    return HS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,194 @@
+"""Thin object wrapper over the C ABI: one `StationEngine` = one `hs_engine` handle on one GPU.
+
+Host-side plumbing only (numpy buffers in, numpy buffers out).  All simulation
+work happens in libhs_hip.so; nothing here computes event logic.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _native as N
+
+
+@dataclass
+class StationArrays:
+    """Struct-of-arrays description of the station LPs (see include/hs_engine.h `hs_stations`)."""
+
+    n: int
+    src_kind: np.ndarray
+    src_rate: np.ndarray
+    src_stop_after_ns: np.ndarray
+    concurrency: np.ndarray
+    svc_kind: np.ndarray
+    svc_mean_s: np.ndarray
+    queue_cap: np.ndarray
+    egress: np.ndarray
+    seed: np.ndarray | None = None
+    stream_base: np.ndarray | None = None
+
+    @staticmethod
+    def uniform(n: int, *, src_kind=N.SRC_POISSON, rate=8.0, stop_after_ns=-1, concurrency=1,
+                svc_kind=N.LAT_EXPONENTIAL, mean=0.1, queue_cap=-1, egress=N.EGRESS_SINK) -> "StationArrays":
+        return StationArrays(
+            n=n,
+            src_kind=np.full(n, src_kind, np.uint8), src_rate=np.full(n, rate, np.float64),
+            src_stop_after_ns=np.full(n, stop_after_ns, np.int64), concurrency=np.full(n, concurrency, np.int32),
+            svc_kind=np.full(n, svc_kind, np.uint8), svc_mean_s=np.full(n, mean, np.float64),
+            queue_cap=np.full(n, queue_cap, np.int64), egress=np.full(n, egress, np.uint8),
+        )
+
+
+class EngineSummary:
+    def __init__(self, s: N.Summary):
+        self.events_processed = int(s.events_processed)
+        self.events_by_kind = np.array(list(s.events_by_kind), np.int64)
+        self.events_cancelled = int(s.events_cancelled)
+        self.final_time_ns = int(s.final_time_ns)
+        self.requests_completed = int(s.requests_completed)
+        self.sink_records = int(s.sink_records)
+        self.last_run_ms = float(s.last_run_ms)
+        self.kernel_ms = float(s.kernel_ms)
+        self.launches = int(s.launches)
+        self.overflow = bool(s.overflow)
+
+
+class StationEngine:
+    """GPU-resident engine for `n` station LPs on one device."""
+
+    def __init__(self, stations: StationArrays, *, mode: int, horizon_ns: int, start_ns: int = 0, seed: int = 42,
+                 lp_base: int = 0, device: int = 0, log_capacity: int = 0):
+        self._lib = N.lib()
+        if self._lib.hs_device_count() <= 0:
+            raise N.EngineUnavailable("no HIP device visible: the engine has no CPU fallback")
+        self.n = int(stations.n)
+        self.mode = mode
+        self._h = C.c_void_p()
+        cfg = N.Config(C.sizeof(N.Config), device, self.n, mode, start_ns, horizon_ns, seed, lp_base, log_capacity)
+        self._check(self._lib.hs_engine_create(C.byref(cfg), C.byref(self._h)), create=True)
+        st = N.Stations()
+        keep = []
+        for name, dtype in (("src_kind", np.uint8), ("src_rate", np.float64), ("src_stop_after_ns", np.int64),
+                            ("concurrency", np.int32), ("svc_kind", np.uint8), ("svc_mean_s", np.float64),
+                            ("queue_cap", np.int64), ("egress", np.uint8), ("seed", np.uint64),
+                            ("stream_base", np.uint64)):
+            a = getattr(stations, name)
+            if a is None:
+                setattr(st, name, None)
+                continue
+            a = np.ascontiguousarray(a, dtype)
+            if a.shape != (self.n,):
+                raise ValueError(f"{name} must have shape ({self.n},)")
+            keep.append(a)
+            setattr(st, name, a.ctypes.data)
+        try:
+            self._check(self._lib.hs_engine_set_stations(self._h, C.byref(st)))
+        except Exception:
+            self.close()
+            raise
+
+    # -- error plumbing ------------------------------------------------------------------------
+    def _check(self, rc: int, create: bool = False):
+        if rc >= 0:
+            return rc
+        msg = (self._lib.hs_last_global_error() if create or not self._h else self._lib.hs_last_error(self._h))
+        msg = msg.decode() if msg else ""
+        if rc == N.HS_E_NO_DEVICE:
+            raise N.EngineUnavailable(msg)
+        if rc == N.HS_E_INVALID:
+            raise ValueError(msg)
+        raise N.EngineError(rc, msg)
+
+    # -- run control ---------------------------------------------------------------------------
+    def reset(self):
+        self._check(self._lib.hs_engine_reset(self._h))
+
+    def run_until(self, end_ns: int):
+        self._check(self._lib.hs_engine_run_until(self._h, int(end_ns)))
+
+    def run_until_async(self, end_ns: int):
+        self._check(self._lib.hs_engine_run_until_async(self._h, int(end_ns)))
+
+    def synchronize(self):
+        self._check(self._lib.hs_engine_synchronize(self._h))
+
+    def bench_runs(self, end_ns: int, repeats: int):
+        """`repeats` x (reset + run) back to back on the engine stream.
+        Returns (per-run kernel ms [repeats], total device ms)."""
+        k = np.zeros(repeats, np.float32)
+        tot = C.c_float(0)
+        self._check(self._lib.hs_engine_bench_runs(self._h, int(end_ns), repeats, k.ctypes.data, C.byref(tot)))
+        return k, float(tot.value)
+
+    def set_debug_flags(self, flags: int):
+        self._lib.hs_debug_set_flags(self._h, flags)
+
+    # -- results -------------------------------------------------------------------------------
+    def summary(self) -> EngineSummary:
+        s = N.Summary()
+        self._check(self._lib.hs_engine_get_summary(self._h, C.byref(s)))
+        return EngineSummary(s)
+
+    def lp_stats(self) -> dict:
+        n = self.n
+        out = {
+            "generated": np.zeros(n, np.int64), "accepted": np.zeros(n, np.int64), "dropped": np.zeros(n, np.int64),
+            "completed": np.zeros(n, np.int64), "rejected": np.zeros(n, np.int64),
+            "total_service_s": np.zeros(n, np.float64), "sink_received": np.zeros(n, np.int64),
+            "queue_depth": np.zeros(n, np.int64), "active": np.zeros(n, np.int32), "events": np.zeros(n, np.int64),
+            "final_time_ns": np.zeros(n, np.int64),
+        }
+        st = N.LpStats(**{k: v.ctypes.data for k, v in out.items()})
+        self._check(self._lib.hs_engine_get_lp_stats(self._h, C.byref(st)))
+        return out
+
+    def read_sink(self, lp: int, cap: int | None = None):
+        if cap is None:
+            cap = 1 << 22
+        t = np.zeros(cap, np.int64)
+        cr = np.zeros(cap, np.int64)
+        got = self._check(self._lib.hs_engine_read_sink(self._h, lp, t.ctypes.data, cr.ctypes.data, cap))
+        return t[:got], cr[:got]
+
+    def read_sinks(self):
+        """All sink records: (counts[n], t_ns[total], created_ns[total]) concatenated in LP order."""
+        total = self.summary().sink_records
+        counts = np.zeros(self.n, np.int64)
+        t = np.zeros(max(total, 1), np.int64)
+        cr = np.zeros(max(total, 1), np.int64)
+        got = self._check(self._lib.hs_engine_read_sinks(self._h, counts.ctypes.data, t.ctypes.data, cr.ctypes.data,
+                                                        max(total, 1)))
+        return counts, t[:got], cr[:got]
+
+    def close(self):
+        if self._h:
+            self._lib.hs_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def debug_draws(seed: int, sid: int, k0: int, n: int, rate: float, device: int = 0):
+    """Device-side (uniform, exp1, ns) for draws k0..k0+n-1 of one stream -- test hook."""
+    L = N.lib()
+    u = np.zeros(n, np.float64)
+    e = np.zeros(n, np.float64)
+    ns = np.zeros(n, np.int64)
+    rc = L.hs_debug_draws(device, seed, sid, k0, n, rate, u.ctypes.data, e.ctypes.data, ns.ctypes.data)
+    if rc == N.HS_E_NO_DEVICE:
+        raise N.EngineUnavailable(L.hs_last_global_error().decode())
+    if rc < 0:
+        raise N.EngineError(rc, L.hs_last_global_error().decode())
+    return u, e, ns

@@ -1,0 +1,173 @@
+/* hs_engine.h -- C ABI of the MI355X discrete-event engine (libhs_hip.so).
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference
+ * (adamfilli/happy-simulator, pure Python) has no FFI; the seam these entry
+ * points replace is `Simulation._execute_until(end_time_ns)` plus
+ * `_build_summary()` (happysimulator/core/simulation.py:449-505, :543-591)
+ * for the lowered entity set {Source, Server(QueuedResource), Sink}, and the
+ * replica / partition fan-out of happysimulator/parallel (runner.py:82-142,
+ * simulation.py:164-223).  INTEGRATION.md shows the ctypes binding a
+ * reference maintainer would add.
+ *
+ * Conventions: plain pointers and sizes, caller-owned host buffers (the engine
+ * copies; it never frees or retains caller memory), no exceptions or aborts
+ * across the ABI.  Every function returns HS_OK (0) or a negative hs_status;
+ * hs_last_error() gives the message.  A handle is not thread-safe.  There is
+ * NO CPU fallback: if no gfx950 device is present hs_engine_create() fails.
+ */
+#ifndef HS_ENGINE_H
+#define HS_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HS_ABI_VERSION 1
+
+typedef enum hs_status {
+    HS_OK = 0,
+    HS_E_INVALID = -1,      /* bad argument / configuration (the reference raises ValueError) */
+    HS_E_NO_DEVICE = -2,    /* no HIP device: the product path has no CPU fallback */
+    HS_E_HIP = -3,          /* HIP runtime error */
+    HS_E_UNSUPPORTED = -4,  /* entity / topology not lowered by this engine (never silent) */
+    HS_E_OVERFLOW = -5,     /* a per-LP record log overflowed its capacity; re-create with a larger one */
+    HS_E_STATE = -6         /* call order violation */
+} hs_status;
+
+/* How `Simulation`s map onto logical processes (LPs).
+ * SINGLE:   all LPs belong to ONE Simulation (one heap): exactly one event beyond
+ *           end_time is processed in total (core/simulation.py:472), the globally first.
+ * REPLICAS: every LP is its own Simulation (ParallelRunner, parallel/runner.py:73-79, or
+ *           ParallelSimulation without links, parallel/simulation.py:170-195): each LP
+ *           processes its own first event beyond end_time. */
+typedef enum hs_mode { HS_MODE_SINGLE = 0, HS_MODE_REPLICAS = 1 } hs_mode;
+
+/* load/source.py:182-268 factories */
+typedef enum hs_source_kind { HS_SRC_NONE = 0, HS_SRC_POISSON = 1, HS_SRC_CONSTANT = 2 } hs_source_kind;
+/* distributions/{exponential,constant}.py */
+typedef enum hs_latency_kind { HS_LAT_EXPONENTIAL = 0, HS_LAT_CONSTANT = 1 } hs_latency_kind;
+/* Server(downstream=...) */
+typedef enum hs_egress_kind { HS_EGRESS_NONE = 0, HS_EGRESS_SINK = 1 } hs_egress_kind;
+
+/* reference-equivalent event kinds counted by the engine */
+enum {
+    HS_EV_SOURCE = 0,       /* SourceEvent @ Source                         */
+    HS_EV_ENQUEUE = 1,      /* Request @ Server (QueuedResource.handle_event) */
+    HS_EV_NOTIFY = 2,       /* QUEUE_NOTIFY @ driver                        */
+    HS_EV_POLL = 3,         /* QUEUE_POLL @ queue                           */
+    HS_EV_DELIVER = 4,      /* QUEUE_DELIVER @ driver                       */
+    HS_EV_WORK = 5,         /* Request @ worker (handle_queued_event start) */
+    HS_EV_CONTINUATION = 6, /* ProcessContinuation @ worker                 */
+    HS_EV_SINK = 7,         /* Request @ Sink                               */
+    HS_EV_KINDS = 8
+};
+
+typedef struct hs_config {
+    uint32_t struct_size;   /* sizeof(hs_config), for ABI evolution */
+    int32_t device;         /* HIP device ordinal */
+    int32_t n_lp;           /* station LPs resident on this engine (this GPU's shard) */
+    int32_t mode;           /* hs_mode */
+    int64_t start_ns;       /* Simulation start_time (Instant.Epoch = 0) */
+    int64_t horizon_ns;     /* latest end_time that will be passed to hs_engine_run_until: sizes the record logs */
+    uint64_t seed;          /* Philox key of the run (per-LP override: hs_stations.seed) */
+    uint64_t lp_base;       /* global index of LP 0: default stream_base of LP i is lp_base + i */
+    int64_t log_capacity;   /* records per LP in the admission / sink logs; 0 = derive from rate * horizon */
+} hs_config;
+
+/* One station LP = [optional Source] -> Server(c, FIFO, capacity) -> [Sink].
+ * Struct-of-arrays; every pointer is [n_lp] or NULL for the documented default.
+ * Field meanings and defaults follow the reference constructors:
+ *   Source.poisson/constant(rate, stop_after)            load/source.py:182-268
+ *   Server(concurrency=1, service_time=ConstantLatency(0.01), queue_capacity=None, downstream=None)
+ *                                                        components/server/server.py:64-122 */
+typedef struct hs_stations {
+    const uint8_t *src_kind;           /* hs_source_kind; NULL = HS_SRC_POISSON */
+    const double *src_rate;            /* events/s; required when any source exists */
+    const int64_t *src_stop_after_ns;  /* < 0 = never; NULL = never */
+    const int32_t *concurrency;        /* NULL = 1 */
+    const uint8_t *svc_kind;           /* hs_latency_kind; NULL = HS_LAT_CONSTANT */
+    const double *svc_mean_s;          /* NULL = 0.01 */
+    const int64_t *queue_cap;          /* < 0 = unbounded; NULL = unbounded */
+    const uint8_t *egress;             /* hs_egress_kind; NULL = HS_EGRESS_SINK */
+    const uint64_t *seed;              /* per-LP Philox key (replica i: base_seed + i); NULL = cfg.seed */
+    const uint64_t *stream_base;       /* per-LP stream id base; NULL = cfg.lp_base + i */
+} hs_stations;
+
+typedef struct hs_summary {
+    /* SimulationSummary fields (instrumentation/summary.py:47-87), engine-wide */
+    int64_t events_processed;              /* total_events_processed */
+    int64_t events_by_kind[HS_EV_KINDS];
+    int64_t events_cancelled;              /* always 0 on this path */
+    int64_t final_time_ns;                 /* SINGLE: time of the last processed event; REPLICAS: max over LPs */
+    int64_t requests_completed;            /* sum of Server._requests_completed */
+    int64_t sink_records;                  /* sum of Sink.events_received */
+    /* engine telemetry */
+    double last_run_ms;                    /* device time of the last hs_engine_run_until (HIP events) */
+    double kernel_ms;                      /* device time of the dominant kernel (hs_station_run) in that call */
+    int64_t launches;                      /* kernel launches in the last run */
+    int32_t overflow;                      /* 1 if a record log overflowed */
+    int32_t reserved;
+} hs_summary;
+
+/* Per-LP results, SoA out-buffers [n_lp]; any pointer may be NULL. */
+typedef struct hs_lp_stats {
+    int64_t *generated;        /* Source._generated_count            load/source.py:159 */
+    int64_t *accepted;         /* Queue.stats_accepted               components/queue.py:138 */
+    int64_t *dropped;          /* Queue.stats_dropped                components/queue.py:128 */
+    int64_t *completed;        /* Server._requests_completed         server/server.py:256 */
+    int64_t *rejected;         /* Server._requests_rejected          server/server.py:233 */
+    double *total_service_s;   /* Server._total_service_time         server/server.py:257 */
+    int64_t *sink_received;    /* Sink.events_received               components/common.py:37 */
+    int64_t *queue_depth;      /* QueuedResource.depth */
+    int32_t *active;           /* Server.active_requests */
+    int64_t *events;           /* events processed by this LP (REPLICAS: that replica's total_events_processed) */
+    int64_t *final_time_ns;    /* time of the LP's last processed event */
+} hs_lp_stats;
+
+typedef struct hs_engine hs_engine;
+
+int hs_abi_version(void);
+/* Number of visible HIP devices (0 when there is no GPU). */
+int hs_device_count(void);
+
+int hs_engine_create(const hs_config *cfg, hs_engine **out);
+int hs_engine_set_stations(hs_engine *h, const hs_stations *st);
+/* Simulation.__init__ bootstrap (core/simulation.py:145-154): clock to start_ns, every Source draws its
+ * first arrival.  Called implicitly by the first run; call again to rewind the engine for another run. */
+int hs_engine_reset(hs_engine *h);
+/* == Simulation._execute_until(end_ns): process events until the last processed event's time exceeds
+ * end_ns (one-event overshoot included).  Re-entrant with non-decreasing end_ns (windows).  Blocks until
+ * the device work is complete. */
+int hs_engine_run_until(hs_engine *h, int64_t end_ns);
+/* Same, but only enqueues the work on the engine's stream. */
+int hs_engine_run_until_async(hs_engine *h, int64_t end_ns);
+int hs_engine_synchronize(hs_engine *h);
+/* hs_engine_reset + hs_engine_run_until_async, `repeats` times back to back on the engine stream, timing
+ * each run kernel with HIP events recorded on that stream; ms_out[repeats] receives per-run kernel times.
+ * Used by bench.py (the whole call is also wall-clocked by the caller). */
+int hs_engine_bench_runs(hs_engine *h, int64_t end_ns, int32_t repeats, float *kernel_ms_out, float *total_ms_out);
+
+int hs_engine_get_summary(hs_engine *h, hs_summary *out);
+int hs_engine_get_lp_stats(hs_engine *h, const hs_lp_stats *out);
+/* Sink records of one LP in processing order: completion time and context["created_at"]
+ * (components/common.py:36-44).  Returns the number of records copied (<= cap) or a negative hs_status. */
+int64_t hs_engine_read_sink(hs_engine *h, int32_t lp, int64_t *t_ns, int64_t *created_ns, int64_t cap);
+/* All LPs at once: counts[n_lp] receives per-LP record counts; t_ns/created_ns receive the records
+ * concatenated in LP order (caller sizes them from a previous get_lp_stats / sink_records). */
+int64_t hs_engine_read_sinks(hs_engine *h, int64_t *counts, int64_t *t_ns, int64_t *created_ns, int64_t cap_total);
+
+const char *hs_last_error(const hs_engine *h);
+const char *hs_last_global_error(void);
+void hs_engine_destroy(hs_engine *h);
+
+/* Device-side scalar semantics, exported so tests can compare them bit-for-bit with the oracle:
+ * fills u[i] = uniform(seed, sid, k0+i), e[i] = -hs_log(1-u[i]), ns[i] = trunc((e[i]/rate)*1e9). */
+int hs_debug_draws(int32_t device, uint64_t seed, uint64_t sid, uint64_t k0, int64_t n, double rate,
+                   double *u, double *e, int64_t *ns);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HS_ENGINE_H */

@@ -96,3 +96,62 @@ def run_oracle_for_spec(spec, trace_cap=0):
                   mt_seed_np=seed & 0xFFFFFFFF, trace_cap=trace_cap)
         runs.append((chain_ids, nodes, r))
     return runs
+
+
+# ----------------------------------------------------------------------------------------------
+# HIP engine side (GPU tests only)
+# ----------------------------------------------------------------------------------------------
+def engine_for_spec(spec, log_capacity=0, horizon_ns=None, flags=0):
+    """Build a StationEngine for a golden spec (all chains resident, one LP per chain)."""
+    from happy_simulator_amd import _native as N
+    from happy_simulator_amd.engine import StationArrays, StationEngine
+
+    p = spec_chain_params(spec)
+    n = p["n"]
+    st = StationArrays(
+        n=n,
+        src_kind=np.array([N.SRC_POISSON if a == O.ARR_POISSON else N.SRC_CONSTANT for a in p["arr"]], np.uint8),
+        src_rate=np.array(p["rate"], np.float64),
+        src_stop_after_ns=np.full(n, p["stop_ns"], np.int64),
+        concurrency=np.array(p["conc"], np.int32),
+        svc_kind=np.array([N.LAT_EXPONENTIAL if s == O.LAT_EXP else N.LAT_CONSTANT for s in p["svc"]], np.uint8),
+        svc_mean_s=np.array(p["mean"], np.float64),
+        queue_cap=np.array(p["qcap"], np.int64),
+        egress=np.full(n, N.EGRESS_SINK if p["downstream"] else N.EGRESS_NONE, np.uint8),
+    )
+    if spec["mode"] == "single":
+        mode = N.MODE_SINGLE
+        seed = spec["seed"]
+    else:
+        mode = N.MODE_REPLICAS
+        seed = 0
+        st.seed = np.array([spec["seed"] + i for i in range(n)], np.uint64)
+        st.stream_base = np.zeros(n, np.uint64)
+    eng = StationEngine(st, mode=mode, horizon_ns=horizon_ns or p["end_ns"], seed=seed, log_capacity=log_capacity)
+    if flags:
+        eng.set_debug_flags(flags)
+    return eng, p
+
+
+def oracle_per_chain(spec, runs):
+    """Flatten oracle runs into per-chain arrays comparable with StationEngine.lp_stats()."""
+    n = spec["n_chains"]
+    out = {k: np.zeros(n, np.int64) for k in
+           ("generated", "accepted", "dropped", "completed", "rejected", "sink_received", "queue_depth", "active")}
+    out["total_service_s"] = np.zeros(n, np.float64)
+    sinks = {}
+    for chain_ids, nodes, r in runs:
+        for c in chain_ids:
+            src, srv, snk = nodes[c]
+            out["generated"][c] = r.generated[src]
+            out["accepted"][c] = r.accepted[srv]
+            out["dropped"][c] = r.dropped[srv]
+            out["completed"][c] = r.completed[srv]
+            out["rejected"][c] = r.rejected[srv]
+            out["queue_depth"][c] = r.depth[srv]
+            out["active"][c] = r.active[srv]
+            out["total_service_s"][c] = r.total_service_s[srv]
+            if snk >= 0:
+                out["sink_received"][c] = r.received[snk]
+                sinks[c] = r.sinks[snk]
+    return out, sinks

@@ -1,0 +1,159 @@
+"""GPU: the HIP engine (through the C ABI) against the live-reference goldens and the C oracle.
+
+Bit-exact everywhere: event totals, per-kind histogram, final time, per-LP statistics (including the
+fp64 running sum `total_service_time`), and every Sink record in nanoseconds.
+"""
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import hs_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine_runnable(spec):
+    # the engine draws from Philox streams; stock-MT goldens are only comparable when nothing is drawn
+    if spec["rng"] == "philox":
+        return True
+    n = spec["n_chains"]
+    return all(a == "constant" for a in H.per_chain(spec["arr"], n)) and all(
+        s == "const" for s in H.per_chain(spec["svc"], n))
+
+
+def _compare_engine_to_oracle(spec, eng, p, runs, check_kinds=True):
+    s = eng.summary()
+    stats = eng.lp_stats()
+    want, sinks = H.oracle_per_chain(spec, runs)
+    assert s.events_processed == sum(r.events_processed for _, _, r in runs)
+    if check_kinds:
+        kinds = sum(r.events_by_kind[:8] for _, _, r in runs)
+        np.testing.assert_array_equal(s.events_by_kind, kinds)
+    for k, v in want.items():
+        np.testing.assert_array_equal(stats[k], v, err_msg=k)
+    if spec["mode"] == "single":
+        assert s.final_time_ns == runs[0][2].final_time_ns
+    else:
+        np.testing.assert_array_equal(stats["final_time_ns"], [r.final_time_ns for _, _, r in runs])
+        np.testing.assert_array_equal(stats["events"], [r.events_processed for _, _, r in runs])
+    counts, t, cr = eng.read_sinks()
+    off = 0
+    for c in range(spec["n_chains"]):
+        if c in sinks:
+            ot, ocr = sinks[c]
+            assert counts[c] == len(ot)
+            np.testing.assert_array_equal(t[off:off + counts[c]], ot, err_msg=f"sink t chain {c}")
+            np.testing.assert_array_equal(cr[off:off + counts[c]], ocr, err_msg=f"sink created chain {c}")
+        off += counts[c]
+
+
+def test_device_streams_match_oracle():
+    from happy_simulator_amd.engine import debug_draws
+
+    for seed, sid, k0, rate in [(42, 0, 0, 8.0), (42, (5 << 3) | 1, 0, 10.0), (2**63 + 12345, (2**40 << 3) | 2, 10**12 + 1, 3.3)]:
+        n = 20000
+        u, e, ns = debug_draws(seed, sid, k0, n, rate)
+        for i in range(0, n, 7):
+            uo = O.uniform(seed, sid, k0 + i)
+            assert u[i] == uo
+            eo = -O.log(1.0 - uo)
+            assert e[i] == eo
+            assert ns[i] == int((eo / rate) * 1e9)
+
+
+@pytest.mark.parametrize("name", H.golden_names())
+def test_engine_matches_reference_golden(name):
+    gold = H.Golden(name)
+    spec = gold.spec
+    if not _engine_runnable(spec):
+        pytest.skip("stock MT19937 streams are sequential by construction (oracle-only golden)")
+    eng, p = H.engine_for_spec(spec)
+    with eng:
+        eng.run_until(p["end_ns"])
+        s = eng.summary()
+        stats = eng.lp_stats()
+        assert s.events_processed == sum(gold.meta["total_events"])
+        if spec["mode"] == "single":
+            assert s.final_time_ns == gold.meta["final_ns"][0]
+        else:
+            np.testing.assert_array_equal(stats["final_time_ns"], gold.meta["final_ns"])
+            np.testing.assert_array_equal(stats["events"], gold.meta["total_events"])
+        if "trace" in gold.arrays:
+            kinds = np.bincount(gold.trace[:, 1], minlength=8)[:8]
+            np.testing.assert_array_equal(s.events_by_kind, kinds)
+        for k, g in (("generated", "generated"), ("accepted", "accepted"), ("dropped", "dropped"),
+                     ("completed", "completed"), ("rejected", "rejected"), ("sink_received", "received"),
+                     ("queue_depth", "depth"), ("active", "active"), ("total_service_s", "total_service_s")):
+            np.testing.assert_array_equal(stats[k], gold.arrays[g], err_msg=k)
+        counts, t, cr = eng.read_sinks()
+        np.testing.assert_array_equal(t, gold.sink_t_ns)
+        # Sink latency rule (components/common.py:39-40): (t - created_at).to_seconds()
+        np.testing.assert_array_equal((t - cr).astype(np.float64) / 1e9, gold.sink_latency_s)
+
+
+@pytest.mark.parametrize("name", [n for n in H.golden_names()])
+def test_general_path_equals_fast_path(name):
+    spec = H.Golden(name).spec
+    if not _engine_runnable(spec):
+        pytest.skip("oracle-only golden")
+    res = []
+    for flags in (0, 1):
+        eng, p = H.engine_for_spec(spec, flags=flags)
+        with eng:
+            eng.run_until(p["end_ns"])
+            s = eng.summary()
+            res.append((s.events_processed, tuple(s.events_by_kind), s.final_time_ns,
+                        {k: v.tobytes() for k, v in eng.lp_stats().items()}, [a.tobytes() for a in eng.read_sinks()]))
+    assert res[0] == res[1]
+
+
+SWEEP = [
+    dict(name="sweep_replicas", n_chains=1024, arr="poisson", rate=8.0, svc="exp", mean=0.1, end_s=60.0,
+         rng="philox", seed=4242, mode="replicas"),
+    dict(name="sweep_single", n_chains=1024, arr="poisson", rate=8.0, svc="exp", mean=0.1, end_s=30.0,
+         rng="philox", seed=77, mode="single"),
+    dict(name="sweep_c4", n_chains=300, arr="poisson", rate=35.0, svc="exp", mean=0.1, concurrency=4, end_s=20.0,
+         rng="philox", seed=5, mode="single"),
+    dict(name="sweep_c3_cap2", n_chains=300, arr="poisson", rate=40.0, svc="exp", mean=0.1, concurrency=3, queue_cap=2,
+         end_s=20.0, rng="philox", seed=6, mode="replicas"),
+    dict(name="sweep_overload_cap", n_chains=257, arr="poisson", rate=14.0, svc="exp", mean=0.1, queue_cap=5, end_s=30.0,
+         rng="philox", seed=9, mode="single"),
+    dict(name="sweep_const_ties", n_chains=64, arr="constant", rate=[10.0, 20.0, 5.0, 40.0] * 16, svc="const",
+         mean=[0.1, 0.05, 0.2, 0.025] * 16, concurrency=[1, 1, 2, 1] * 16, queue_cap=[None, 3, None, 1] * 16,
+         end_s=12.0, rng="philox", seed=1, mode="single"),
+    dict(name="sweep_const_exp_mix", n_chains=128, arr=["constant", "poisson"] * 64, rate=10.0, svc=["exp", "const"] * 64,
+         mean=0.09, end_s=25.0, rng="philox", seed=3, mode="replicas"),
+    dict(name="sweep_zero_service", n_chains=16, arr="constant", rate=100.0, svc="const", mean=0.0, end_s=3.0,
+         rng="philox", seed=3, mode="single"),
+]
+
+
+@pytest.mark.parametrize("spec", SWEEP, ids=[s["name"] for s in SWEEP])
+def test_engine_matches_oracle(spec):
+    runs = H.run_oracle_for_spec(spec)
+    eng, p = H.engine_for_spec(spec)
+    with eng:
+        eng.run_until(p["end_ns"])
+        _compare_engine_to_oracle(spec, eng, p, runs)
+
+
+@pytest.mark.parametrize("mode", ["single", "replicas"])
+def test_reentrant_windows_match_oracle(mode):
+    spec = dict(name="win", n_chains=96, arr="poisson", rate=9.0, svc="exp", mean=0.1, concurrency=1, end_s=12.0,
+                rng="philox", seed=31, mode=mode)
+    windows = [H.ns_from_seconds(x) for x in (0.5, 1.0, 1.0, 3.25, 7.0)]
+    # oracle: _execute_until per window on the same heap(s) (parallel/coordinator.py uses _run_window this way)
+    n = spec["n_chains"]
+    p = H.spec_chain_params(spec)
+    runs = []
+    groups = [(list(range(n)), spec["seed"], list(range(n)))] if mode == "single" else [
+        ([i], spec["seed"] + i, [0]) for i in range(n)]
+    for chain_ids, seed, bases in groups:
+        g, nodes = H.oracle_graph_for(spec, chain_ids, bases)
+        runs.append((chain_ids, nodes, O.run(g, p["end_ns"], seed=seed, windows=windows)))
+    eng, p = H.engine_for_spec(spec)
+    with eng:
+        for w in windows:
+            eng.run_until(w)
+        eng.run_until(p["end_ns"])
+        _compare_engine_to_oracle(spec, eng, p, runs)
