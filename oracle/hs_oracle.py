@@ -199,16 +199,21 @@ def run(g: Graph, end_ns: int, start_ns: int = 0, seed: int = 42, rng_mode: int 
         ftype = dict(_Graph._fields_)[name]
         setattr(G, name, a.ctypes.data_as(ftype))
     P = _Params(start_ns, end_ns, seed, rng_mode, mt_seed_py, mt_seed_np, trace_cap)
+    import time as _time
+
     h = L.hso_create(C.byref(G), C.byref(P))
     try:
+        t0 = _time.perf_counter()
         for w_end in (windows or []):
             L.hso_run_until(h, int(w_end))
         rc = L.hso_run_until(h, int(end_ns))
+        run_seconds = _time.perf_counter() - t0
         if rc != 0:
             raise RuntimeError("oracle: unsupported event kind")
         S = _Summary()
         L.hso_get_summary(h, C.byref(S))
         r = Result()
+        r.run_seconds = run_seconds  # wall time of the event loop only (graph build excluded)
         r.events_processed = S.events_processed
         r.events_by_kind = np.array(list(S.events_by_kind), np.int64)
         r.final_time_ns = S.final_time_ns

@@ -1,0 +1,111 @@
+"""GPU: BASELINE-size runs (65 536 station LPs, 60 s) checked through size-independent properties and
+through exact oracle parity on a sample of LPs (LPs are independent, so an LP's results do not depend on
+how many other LPs share the heap -- SURVEY.md A4)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import hs_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+N_LP = 65536
+END_NS = 60_000_000_000
+
+
+def _engine(mode, seed=42, per_lp_seed=False):
+    from happy_simulator_amd import _native as N
+    from happy_simulator_amd.engine import StationArrays, StationEngine
+
+    st = StationArrays.uniform(N_LP, rate=8.0, mean=0.1)
+    return StationEngine(st, mode=N.MODE_SINGLE if mode == "single" else N.MODE_REPLICAS, horizon_ns=END_NS, seed=seed)
+
+
+def _digest(eng):
+    h = hashlib.sha256()
+    s = eng.summary()
+    h.update(np.array([s.events_processed, s.final_time_ns, s.requests_completed, s.sink_records]).tobytes())
+    h.update(s.events_by_kind.tobytes())
+    for k, v in sorted(eng.lp_stats().items()):
+        h.update(v.tobytes())
+    for a in eng.read_sinks():
+        h.update(a.tobytes())
+    return h.hexdigest()
+
+
+@pytest.fixture(scope="module")
+def single_run():
+    eng = _engine("single")
+    eng.run_until(END_NS)
+    yield eng
+    eng.close()
+
+
+def test_event_accounting_identities(single_run):
+    eng = single_run
+    s = eng.summary()
+    st = eng.lp_stats()
+    k = s.events_by_kind
+    assert s.events_processed == k.sum() == st["events"].sum()
+    assert k[0] == st["generated"].sum()                       # SourceEvent == ticks
+    assert k[1] == st["accepted"].sum() + st["dropped"].sum()  # every payload is an enqueue attempt
+    assert k[4] == k[5]                                        # each QUEUE_DELIVER re-emits its payload
+    assert k[6] == st["completed"].sum() == s.requests_completed
+    assert st["rejected"].sum() == 0
+    # conservation: accepted = completed + waiting + in service
+    np.testing.assert_array_equal(st["accepted"], st["completed"] + st["queue_depth"] + st["active"])
+    # the overshoot event (one for the whole Simulation) may complete a request whose Sink event is never processed
+    assert 0 <= k[6] - k[7] <= 1 and k[7] == st["sink_received"].sum() == s.sink_records
+    # polls = completions + notifies that found a free server; a delivery needs a poll
+    assert k[3] >= k[6] and k[3] <= k[6] + k[2] and k[4] <= k[3]
+    # about 7.5 reference events per request at rho = 0.8
+    assert 7.3 < s.events_processed / s.requests_completed < 7.7
+    assert s.final_time_ns > END_NS and s.final_time_ns - END_NS < 1_000_000   # the overshoot is the globally first event
+
+
+def test_sink_records_are_ordered_and_causal(single_run):
+    counts, t, cr = single_run.read_sinks()
+    off = np.concatenate([[0], np.cumsum(counts)])
+    assert (t >= cr).all() and (cr > 0).all() and (t <= END_NS).all()
+    d = np.diff(t)
+    dc = np.diff(cr)
+    boundary = np.zeros(len(t) - 1, bool)
+    boundary[off[1:-1][off[1:-1] < len(t)] - 1] = True
+    assert (d[~boundary] >= 0).all()    # completion order within an LP
+    assert (dc[~boundary] >= 0).all()   # FIFO: created_at is non-decreasing too
+
+
+def test_runs_are_deterministic(single_run):
+    a = _digest(single_run)
+    single_run.reset()
+    single_run.run_until(END_NS)
+    assert _digest(single_run) == a
+    eng2 = _engine("single")
+    with eng2:
+        eng2.run_until(END_NS)
+        assert _digest(eng2) == a
+
+
+def test_replicas_vs_single_overshoot_relation_and_sampled_oracle_parity(single_run):
+    s1 = single_run.summary()
+    rep = _engine("replicas")
+    with rep:
+        rep.run_until(END_NS)
+        s2 = rep.summary()
+        st = rep.lp_stats()
+        # N Simulations process N overshoot events, one Simulation processes 1
+        assert s2.events_processed - s1.events_processed == N_LP - 1
+        rng = np.random.default_rng(5)
+        sample = sorted(set([0, 1, 255, 256, 4095, N_LP - 1] + list(rng.integers(0, N_LP, 42))))
+        for lp in sample:
+            g = O.mm1_chains(1, rate=8.0, mean=0.1, stream_base0=int(lp))
+            r = O.run(g, END_NS, seed=42)
+            assert st["events"][lp] == r.events_processed
+            assert st["final_time_ns"][lp] == r.final_time_ns
+            assert st["generated"][lp] == r.generated[0]
+            assert st["completed"][lp] == r.completed[1]
+            assert st["total_service_s"][lp] == r.total_service_s[1]
+            t, cr = rep.read_sink(int(lp))
+            np.testing.assert_array_equal(t, r.sinks[2][0])
+            np.testing.assert_array_equal(cr, r.sinks[2][1])
