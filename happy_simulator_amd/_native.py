@@ -27,7 +27,7 @@ HS_OK = 0
 HS_E_INVALID, HS_E_NO_DEVICE, HS_E_HIP, HS_E_UNSUPPORTED, HS_E_OVERFLOW, HS_E_STATE = -1, -2, -3, -4, -5, -6
 MODE_SINGLE, MODE_REPLICAS = 0, 1
 SRC_NONE, SRC_POISSON, SRC_CONSTANT = 0, 1, 2
-LAT_EXPONENTIAL, LAT_CONSTANT = 0, 1
+LAT_EXPONENTIAL, LAT_CONSTANT, LAT_NO_SERVER = 0, 1, 2
 EGRESS_NONE, EGRESS_SINK = 0, 1
 EV_KINDS = 8
 EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuation", "sink")
@@ -101,6 +101,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.getmtime(src) > os.path.getmtime(LIB_PATH) for src in sources() if os.path.exists(src))
+    if stale and os.path.exists(hipcc):
+        build()     # never run a library older than its sources
     if not os.path.exists(LIB_PATH):
         raise EngineUnavailable(
             f"{LIB_PATH} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -510,8 +510,10 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if (c > 16) return fail(h, HS_E_UNSUPPORTED, "LP %d: concurrency %d > 16 is not lowered yet", i, c);
         if (c > maxc) maxc = c;
         const int vk = st->svc_kind ? st->svc_kind[i] : HS_LAT_CONSTANT;
-        if (vk != HS_LAT_EXPONENTIAL && vk != HS_LAT_CONSTANT)
+        if (vk != HS_LAT_EXPONENTIAL && vk != HS_LAT_CONSTANT && vk != HS_LAT_NO_SERVER)
             return fail(h, HS_E_UNSUPPORTED, "LP %d: service distribution kind %d is not lowered", i, vk);
+        if (vk == HS_LAT_NO_SERVER && sk == HS_SRC_NONE)
+            return fail(h, HS_E_INVALID, "LP %d: neither a Source nor a Server", i);
         const double mean = st->svc_mean_s ? st->svc_mean_s[i] : 0.01;
         if (!(mean >= 0.0) || !std::isfinite(mean)) return fail(h, HS_E_INVALID, "LP %d: bad service mean %g", i, mean);
         if (vk == HS_LAT_EXPONENTIAL && !(mean > 0.0))

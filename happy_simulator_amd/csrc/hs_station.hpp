@@ -243,6 +243,12 @@ struct Station {
     }
     // Sink.handle_event (components/common.py:36-44); the record itself was staged by do_cont.
     __device__ __forceinline__ void do_sink() { ev[7]++; received++; }
+    // A Source wired straight to a Sink/Counter (no Server in this LP): the payload IS the Sink's event.
+    __device__ __forceinline__ void stage_direct_sink(int64_t t) {
+        if (sink_w < cap) { sink_t[sink_w] = t; if (C > 1) sink_created[sink_w] = t; else adm[sink_w] = t; }
+        else overflow = 1;
+        sink_w++;
+    }
 
     // ---- chains with at most one event in flight (fast path pieces) ---------------------------
     // returns true if the general FIFO must take over (a same-time continuation was created)
@@ -261,7 +267,10 @@ struct Station {
     // ---- roots: the first micro-event of a pending tick / departure; created events go to the FIFO
     __device__ __forceinline__ void root_tick(int64_t t) {
         const uint32_t r = do_tick(t);
-        if (r & 1u) qpush(Q_ENQ);
+        if (r & 1u) {
+            if (svc_kind == 2) { if (egress == 1) { stage_direct_sink(t); qpush(Q_SINK); } }
+            else qpush(Q_ENQ);
+        }
         if (r & 2u) qpush(Q_TICK);
     }
     __device__ __forceinline__ void root_cont(int slot, int64_t t) {
@@ -330,7 +339,11 @@ struct Station {
             bool general = false;
             if (A == t) {
                 const uint32_t r = do_tick(t);
-                if (r & 2u) { if (r & 1u) qpush(Q_ENQ); qpush(Q_TICK); general = true; }
+                if (svc_kind == 2) {             // Source -> Sink directly
+                    if ((r & 1u) && egress == 1) { stage_direct_sink(t); do_sink(); }
+                    if (r & 2u) { qpush(Q_TICK); general = true; }
+                }
+                else if (r & 2u) { if (r & 1u) qpush(Q_ENQ); qpush(Q_TICK); general = true; }
                 else if (r & 1u) general = chain_from_enqueue(t);
             } else {
                 int slot = 0;

@@ -1,0 +1,359 @@
+"""Host-side mirror of the reference's entity constructors for the hot path.
+
+These classes carry PARAMETERS into the engine and RESULTS back out; they contain no event logic (that
+lives in csrc/).  Names, argument meaning, defaults and error behaviour follow the reference:
+
+  Source.poisson / Source.constant / Source(name, event_provider, arrival_time_provider)
+                                                   happysimulator/load/source.py:93-268
+  SimpleEventProvider(target, event_type, stop_after)            load/source.py:31-86
+  ExponentialLatency / ConstantLatency             distributions/exponential.py:15-45, constant.py:15-35
+  Server(name, concurrency, service_time, queue_policy, queue_capacity, downstream)
+                                                   components/server/server.py:43-273
+  Sink / Counter                                   components/common.py:18-95
+  LatencyTracker                                   instrumentation/collectors.py:18-60
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from .core.temporal import Duration, Instant
+
+
+class Entity:
+    """Base of every simulation actor (core/entity.py:31-127): a name and topology links."""
+
+    def __init__(self, name: str):
+        self.name = name
+
+    def downstream_entities(self) -> list["Entity"]:
+        return []
+
+    def has_capacity(self) -> bool:
+        return True
+
+
+# ---- distributions -------------------------------------------------------------------------------
+class LatencyDistribution:
+    def __init__(self, mean_latency):
+        if isinstance(mean_latency, Duration):
+            self._mean_latency = mean_latency.to_seconds()
+        else:
+            self._mean_latency = float(mean_latency)
+
+    @property
+    def mean(self) -> float:
+        return self._mean_latency
+
+
+class ExponentialLatency(LatencyDistribution):
+    """Exponentially distributed latency; on the engine: sample = -hs_log(1-u) / (1/mean)."""
+
+    def __init__(self, mean_latency):
+        super().__init__(mean_latency)
+        self._lambda = 1 / self._mean_latency
+
+
+class ConstantLatency(LatencyDistribution):
+    pass
+
+
+# ---- queue policy --------------------------------------------------------------------------------
+class FIFOQueue:
+    """components/queue_policy.py:75-114 -- the only policy lowered to the engine."""
+
+    def __init__(self, capacity: float = float("inf")):
+        self._capacity = capacity
+
+    @property
+    def capacity(self) -> float:
+        return self._capacity
+
+
+# ---- load ----------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class ConstantRateProfile:
+    rate: float
+
+
+class SimpleEventProvider:
+    def __init__(self, target: Entity, event_type: str = "Request", stop_after: Instant | None = None,
+                 context_fn=None):
+        if context_fn is not None:
+            raise NotImplementedError("context_fn is arbitrary Python and is not lowered to the engine")
+        self._target = target
+        self._event_type = event_type
+        self._stop_after = stop_after
+        self._generated = 0
+
+
+class _ArrivalProvider:
+    kind = "constant"
+
+    def __init__(self, profile: ConstantRateProfile, start_time: Instant = None):
+        if not isinstance(profile, ConstantRateProfile):
+            raise NotImplementedError("only ConstantRateProfile arrivals are lowered (time-varying profiles: SURVEY N3)")
+        self.profile = profile
+
+
+class ConstantArrivalTimeProvider(_ArrivalProvider):
+    kind = "constant"
+
+
+class PoissonArrivalTimeProvider(_ArrivalProvider):
+    kind = "poisson"
+
+
+class Source(Entity):
+    def __init__(self, name: str, event_provider: SimpleEventProvider, arrival_time_provider: _ArrivalProvider):
+        super().__init__(name)
+        self._event_provider = event_provider
+        self._time_provider = arrival_time_provider
+        self._generated_count = 0
+
+    @classmethod
+    def _make(cls, provider_cls, rate, target, event_type, name, stop_after, event_provider):
+        if event_provider is None:
+            if target is None:
+                raise ValueError("Either 'target' or 'event_provider' must be provided")
+            event_provider = SimpleEventProvider(target, event_type, cls._resolve_stop_after(stop_after))
+        return cls(name=name, event_provider=event_provider,
+                   arrival_time_provider=provider_cls(ConstantRateProfile(rate=rate), start_time=Instant.Epoch))
+
+    @classmethod
+    def constant(cls, rate: float, target: Entity | None = None, event_type: str = "Request", *,
+                 name: str = "Source", stop_after=None, event_provider=None) -> "Source":
+        return cls._make(ConstantArrivalTimeProvider, rate, target, event_type, name, stop_after, event_provider)
+
+    @classmethod
+    def poisson(cls, rate: float, target: Entity | None = None, event_type: str = "Request", *,
+                name: str = "Source", stop_after=None, event_provider=None) -> "Source":
+        return cls._make(PoissonArrivalTimeProvider, rate, target, event_type, name, stop_after, event_provider)
+
+    @staticmethod
+    def _resolve_stop_after(stop_after):
+        if stop_after is None:
+            return None
+        if isinstance(stop_after, Instant):
+            return stop_after
+        return Instant.from_seconds(stop_after)
+
+    @property
+    def generated_count(self) -> int:
+        return self._generated_count
+
+    @property
+    def rate(self) -> float:
+        return self._time_provider.profile.rate
+
+    def downstream_entities(self) -> list[Entity]:
+        t = getattr(self._event_provider, "_target", None)
+        return [t] if isinstance(t, Entity) else []
+
+    def __repr__(self):
+        return f"<Source {self.name}>"
+
+
+# ---- server --------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class ServerStats:
+    requests_completed: int = 0
+    requests_rejected: int = 0
+    total_service_time: float = 0.0
+
+
+class _QueueView:
+    """What users read off `server.queue`: acceptance / drop counters and depth."""
+
+    def __init__(self):
+        self.stats_accepted = 0
+        self.stats_dropped = 0
+        self.depth = 0
+
+
+class Server(Entity):
+    def __init__(self, name: str, concurrency: int = 1, service_time: LatencyDistribution | None = None,
+                 queue_policy: FIFOQueue | None = None, queue_capacity: int | None = None,
+                 downstream: Entity | None = None):
+        super().__init__(name)
+        if not isinstance(concurrency, int):
+            raise NotImplementedError("only FixedConcurrency (an int) is lowered to the engine")
+        if concurrency < 1:
+            raise ValueError(f"max_concurrent must be >= 1, got {concurrency}")   # server/concurrency.py:87-88
+        if queue_policy is None:
+            queue_policy = FIFOQueue(capacity=queue_capacity if queue_capacity is not None else float("inf"))
+        elif not isinstance(queue_policy, FIFOQueue):
+            raise NotImplementedError("only FIFOQueue is lowered to the engine")
+        self._policy = queue_policy
+        self._concurrency = concurrency
+        self._service_time = service_time or ConstantLatency(0.01)
+        self._downstream = downstream
+        self._queue = _QueueView()
+        self._requests_completed = 0
+        self._requests_rejected = 0
+        self._total_service_time = 0.0
+        self._active = 0
+
+    def downstream_entities(self) -> list[Entity]:
+        return [self._downstream] if self._downstream is not None else []
+
+    @property
+    def downstream(self):
+        return self._downstream
+
+    @downstream.setter
+    def downstream(self, target):
+        self._downstream = target
+
+    @property
+    def concurrency(self) -> int:
+        return self._concurrency
+
+    @property
+    def service_time(self) -> LatencyDistribution:
+        return self._service_time
+
+    @property
+    def queue(self) -> _QueueView:
+        return self._queue
+
+    @property
+    def depth(self) -> int:
+        return self._queue.depth
+
+    @property
+    def stats_accepted(self) -> int:
+        return self._queue.stats_accepted
+
+    @property
+    def stats_dropped(self) -> int:
+        return self._queue.stats_dropped
+
+    @property
+    def active_requests(self) -> int:
+        return self._active
+
+    @property
+    def utilization(self) -> float:
+        return self._active / self._concurrency if self._concurrency else 0.0
+
+    @property
+    def average_service_time(self) -> float:
+        return self._total_service_time / self._requests_completed if self._requests_completed else 0.0
+
+    @property
+    def stats(self) -> ServerStats:
+        return ServerStats(self._requests_completed, self._requests_rejected, self._total_service_time)
+
+    def has_capacity(self, weight: int = 1) -> bool:
+        return self._active < self._concurrency
+
+
+# ---- sinks ---------------------------------------------------------------------------------------
+def _percentile_sorted(sorted_values, p: float) -> float:
+    """instrumentation/data.py:197-210."""
+    n = len(sorted_values)
+    if n == 0:
+        return 0.0
+    if p <= 0:
+        return float(sorted_values[0])
+    if p >= 1:
+        return float(sorted_values[-1])
+    pos = p * (n - 1)
+    lo = int(pos)
+    hi = min(lo + 1, n - 1)
+    frac = pos - lo
+    return float(sorted_values[lo] * (1.0 - frac) + sorted_values[hi] * frac)
+
+
+class _RecordSink(Entity):
+    """Shared result holder: the engine hands back (completion ns, created_at ns) arrays; the Python lists the
+    reference exposes are materialised lazily (31 M-element lists are the user's choice, not ours)."""
+
+    def __init__(self, name: str):
+        super().__init__(name)
+        self._t_ns = np.zeros(0, np.int64)
+        self._created_ns = np.zeros(0, np.int64)
+
+    def _set_records(self, t_ns: np.ndarray, created_ns: np.ndarray):
+        self._t_ns = t_ns
+        self._created_ns = created_ns
+
+    @property
+    def completion_ns(self) -> np.ndarray:
+        return self._t_ns
+
+    @property
+    def latencies_array(self) -> np.ndarray:
+        # (event.time - created_at).to_seconds() = float(ns) / 1e9   (components/common.py:39-40)
+        return (self._t_ns - self._created_ns).astype(np.float64) / 1_000_000_000
+
+
+class Sink(_RecordSink):
+    def __init__(self, name: str = "Sink"):
+        super().__init__(name)
+
+    @property
+    def events_received(self) -> int:
+        return int(len(self._t_ns))
+
+    @property
+    def completion_times(self) -> list[Instant]:
+        return [Instant(int(t)) for t in self._t_ns]
+
+    @property
+    def latencies_s(self) -> list[float]:
+        return self.latencies_array.tolist()
+
+    def average_latency(self) -> float:
+        lat = self.latencies_s
+        return sum(lat) / len(lat) if lat else 0.0
+
+    def latency_time_series_seconds(self):
+        return [t.to_seconds() for t in self.completion_times], list(self.latencies_s)
+
+    def latency_stats(self) -> dict:
+        lat = self.latencies_s
+        n = len(lat)
+        if n == 0:
+            return {"count": 0, "avg": 0.0, "min": 0.0, "max": 0.0, "p50": 0.0, "p99": 0.0}
+        s = sorted(lat)
+        return {"count": n, "avg": sum(s) / n, "min": s[0], "max": s[-1],
+                "p50": _percentile_sorted(s, 0.50), "p99": _percentile_sorted(s, 0.99)}
+
+
+class Counter(_RecordSink):
+    def __init__(self, name: str = "Counter"):
+        super().__init__(name)
+        self._event_type = "Request"
+
+    @property
+    def total(self) -> int:
+        return int(len(self._t_ns))
+
+    @property
+    def by_type(self) -> dict:
+        return {self._event_type: self.total} if self.total else {}
+
+
+class LatencyTracker(_RecordSink):
+    def __init__(self, name: str = "LatencyTracker"):
+        super().__init__(name)
+
+    @property
+    def count(self) -> int:
+        return int(len(self._t_ns))
+
+    def mean_latency(self) -> float:
+        lat = self.latencies_array
+        return float(sum(lat.tolist()) / len(lat)) if len(lat) else 0.0
+
+    def _pct(self, p):
+        return _percentile_sorted(sorted(self.latencies_array.tolist()), p)
+
+    def p50(self) -> float:
+        return self._pct(0.50)
+
+    def p99(self) -> float:
+        return self._pct(0.99)

@@ -1,0 +1,103 @@
+"""`Simulation` -- host-side mirror of happysimulator/core/simulation.py:66-288 whose `run()` executes on the
+MI355X engine instead of the Python heap loop.  Same constructor, same `SimulationSummary`."""
+from __future__ import annotations
+
+import time as _time
+
+from . import _native as N
+from .core.temporal import Instant
+from .engine import StationEngine
+from .entities import Counter, Entity, LatencyTracker, Server, Sink
+from .lowering import LoweredGraph, UnsupportedTopology, lower, write_back
+from .summary import EntitySummary, QueueStats, SimulationSummary
+
+_DEFAULT_SEED = 42
+
+
+def seed(value: int) -> None:
+    """Default Philox key for Simulations created afterwards (the reference's idiom is `random.seed(42)`)."""
+    global _DEFAULT_SEED
+    _DEFAULT_SEED = int(value)
+
+
+class Simulation:
+    def __init__(self, start_time: Instant | None = None, end_time: Instant | None = None, sources=None,
+                 entities=None, probes=None, trace_recorder=None, fault_schedule=None, duration: float | None = None,
+                 *, seed: int | None = None, device: int = 0):
+        if duration is not None and end_time is not None:
+            raise ValueError("Cannot specify both 'duration' and 'end_time'")        # core/simulation.py:79-80
+        self._start_time = start_time if start_time is not None else Instant.Epoch
+        if duration is not None:
+            self._end_time = self._start_time + duration
+        elif end_time is not None:
+            self._end_time = end_time
+        else:
+            self._end_time = Instant.Infinity
+        self._sources = list(sources or [])
+        self._entities = list(entities or [])
+        if probes:
+            raise UnsupportedTopology("probes are daemon Sources polling Python attributes; not lowered (SURVEY N4)")
+        if trace_recorder is not None:
+            raise UnsupportedTopology("trace recorders force the reference's slow loop; profile with rocprofv3 instead")
+        if fault_schedule is not None:
+            raise UnsupportedTopology("fault schedules are not lowered")
+        self._seed = _DEFAULT_SEED if seed is None else int(seed)
+        self._device = device
+        self._summary: SimulationSummary | None = None
+        self._graph: LoweredGraph | None = None
+        self._events_processed = 0
+        self._events_cancelled = 0
+        self._current_time = self._start_time
+        self._engine_summary = None
+
+    @property
+    def summary(self) -> SimulationSummary | None:
+        return self._summary
+
+    def lowered(self) -> LoweredGraph:
+        if self._graph is None:
+            self._graph = lower(self._sources, self._entities)
+        return self._graph
+
+    def run(self) -> SimulationSummary:
+        if self._end_time == Instant.Infinity:
+            raise UnsupportedTopology("auto-terminating runs (end_time = Infinity) are not lowered; pass end_time/duration")
+        wall0 = _time.monotonic()
+        g = self.lowered()
+        end_ns = self._end_time.nanoseconds
+        with StationEngine(g.arrays(), mode=N.MODE_SINGLE, horizon_ns=end_ns, start_ns=self._start_time.nanoseconds,
+                           seed=self._seed, device=self._device) as eng:
+            eng.run_until(end_ns)
+            es = eng.summary()
+            stats = eng.lp_stats()
+            counts, t_ns, created_ns = eng.read_sinks()
+        write_back(g, stats, counts, t_ns, created_ns)
+        self._engine_summary = es
+        self._events_processed = es.events_processed
+        self._current_time = Instant(es.final_time_ns)
+        self._summary = self._build_summary(_time.monotonic() - wall0)
+        return self._summary
+
+    # core/simulation.py:543-591
+    def _build_summary(self, wall_elapsed: float) -> SimulationSummary:
+        duration_s = (self._current_time - self._start_time).to_seconds()
+        eps = self._events_processed / duration_s if duration_s > 0 else 0.0
+        entities: dict[str, EntitySummary] = {}
+        for comp in self._entities:
+            if not isinstance(comp, Entity):
+                continue
+            queue_stats = None
+            if isinstance(comp, Server):
+                queue_stats = QueueStats(peak_depth=0, total_accepted=comp.stats_accepted,
+                                         total_dropped=comp.stats_dropped)
+            handled = 0
+            for attr in ("count", "events_received", "stats_processed"):
+                val = getattr(comp, attr, None)
+                if isinstance(val, int):
+                    handled = val
+                    break
+            entities[comp.name] = EntitySummary(name=comp.name, entity_type=type(comp).__name__,
+                                                events_handled=handled, queue_stats=queue_stats)
+        return SimulationSummary(duration_s=duration_s, total_events_processed=self._events_processed,
+                                 events_cancelled=self._events_cancelled, events_per_second=eps,
+                                 wall_clock_seconds=wall_elapsed, entities=entities)

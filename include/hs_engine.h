@@ -47,7 +47,11 @@ typedef enum hs_mode { HS_MODE_SINGLE = 0, HS_MODE_REPLICAS = 1 } hs_mode;
 /* load/source.py:182-268 factories */
 typedef enum hs_source_kind { HS_SRC_NONE = 0, HS_SRC_POISSON = 1, HS_SRC_CONSTANT = 2 } hs_source_kind;
 /* distributions/{exponential,constant}.py */
-typedef enum hs_latency_kind { HS_LAT_EXPONENTIAL = 0, HS_LAT_CONSTANT = 1 } hs_latency_kind;
+typedef enum hs_latency_kind {
+    HS_LAT_EXPONENTIAL = 0,
+    HS_LAT_CONSTANT = 1,
+    HS_LAT_NO_SERVER = 2   /* svc_kind only: the LP has no Server, its Source feeds the Sink/Counter directly */
+} hs_latency_kind;
 /* Server(downstream=...) */
 typedef enum hs_egress_kind { HS_EGRESS_NONE = 0, HS_EGRESS_SINK = 1 } hs_egress_kind;
 

@@ -1,0 +1,116 @@
+"""GPU: the reference-shaped Python API end to end (Simulation / Source / Server / Sink / ParallelRunner),
+checked against the live-reference goldens.  These read like the reference's own integration tests
+(tests/integration/core_simulation/test_simulation_basic_counter.py, tests/unit/test_ergonomic_api.py)."""
+import numpy as np
+import pytest
+
+import happy_simulator_amd as hs
+import helpers as H
+from happy_simulator_amd import Instant
+
+pytestmark = pytest.mark.gpu
+
+
+def test_quick_start_matches_philox_plugged_reference():
+    gold = H.Golden("philox_1chain_s42")
+    sink = hs.Sink()
+    server = hs.Server("srv", service_time=hs.ExponentialLatency(0.1), downstream=sink)
+    source = hs.Source.poisson(rate=8, target=server)
+    sim = hs.Simulation(end_time=Instant.from_seconds(60), sources=[source], entities=[server, sink], seed=42)
+    summary = sim.run()
+    assert summary.total_events_processed == gold.meta["total_events"][0] == 3630
+    assert summary.duration_s == gold.meta["duration_s"][0]
+    assert summary.events_per_second == summary.total_events_processed / summary.duration_s
+    assert source.generated_count == gold.generated[0]
+    assert server.stats_accepted == gold.accepted[0] and server.stats_dropped == 0
+    assert server.stats.requests_completed == gold.completed[0]
+    assert server.stats.total_service_time == gold.total_service_s[0]
+    assert sink.events_received == gold.received[0]
+    assert sink.latencies_s == gold.sink_latency_s.tolist()
+    assert [t.nanoseconds for t in sink.completion_times] == gold.sink_t_ns.tolist()
+    es = summary.entities
+    assert es["srv"].entity_type == "Server" and es["srv"].events_handled == 0      # attr sniffing, simulation.py:579-583
+    assert es["srv"].queue_stats.total_accepted == gold.accepted[0] and es["srv"].queue_stats.peak_depth == 0
+    assert es["Sink"].events_handled == sink.events_received
+    st = sink.latency_stats()
+    assert st["count"] == sink.events_received and st["min"] <= st["p50"] <= st["p99"] <= st["max"]
+    assert "Events processed: 3630" in str(summary)
+
+
+def test_basic_counter_overshoot_known_answer():
+    """Reference: tests/integration/core_simulation/test_simulation_basic_counter.py:7-34."""
+    counter = hs.Counter()
+    source = hs.Source.constant(rate=1, target=counter)
+    sim = hs.Simulation(start_time=Instant.Epoch, end_time=Instant.from_seconds(60), sources=[source],
+                        entities=[counter])
+    summary = sim.run()
+    assert source.generated_count == 61     # the overshoot tick is processed ...
+    assert counter.total == 60              # ... but its payload is not
+    assert summary.duration_s == 61.0
+
+
+@pytest.mark.parametrize("rate,name", [(8, "const_r8"), (10, "const_r10"), (12, "const_r12_overload")])
+def test_constant_rate_goldens_through_the_api(rate, name):
+    gold = H.Golden(name)
+    sink = hs.Sink()
+    server = hs.Server("srv", service_time=hs.ConstantLatency(0.1), downstream=sink)
+    source = hs.Source.constant(rate=rate, target=server)
+    summary = hs.Simulation(duration=60, sources=[source], entities=[server, sink]).run()
+    assert summary.total_events_processed == gold.meta["total_events"][0]
+    assert summary.duration_s == gold.meta["duration_s"][0]
+    assert source.generated_count == gold.generated[0]
+    assert sink.events_received == gold.received[0]
+    assert server.stats_accepted == gold.accepted[0] and server.depth == gold.depth[0]
+    assert server.stats.total_service_time == gold.total_service_s[0]
+    assert sink.latencies_s == gold.sink_latency_s.tolist()
+
+
+def test_sixteen_chains_in_one_simulation():
+    gold = H.Golden("philox_16chains_single")
+    chains = []
+    for i in range(16):
+        sink = hs.Sink(f"sink{i}")
+        srv = hs.Server(f"srv{i}", service_time=hs.ExponentialLatency(0.1), downstream=sink)
+        chains.append((hs.Source.poisson(rate=8, target=srv, name=f"src{i}"), srv, sink))
+    summary = hs.Simulation(duration=30.0, sources=[c[0] for c in chains],
+                            entities=[e for c in chains for e in c[1:]], seed=42).run()
+    assert summary.total_events_processed == gold.meta["total_events"][0]
+    assert summary.duration_s == gold.meta["duration_s"][0]
+    for i, (src, srv, sink) in enumerate(chains):
+        assert src.generated_count == gold.generated[i]
+        assert srv.stats.requests_completed == gold.completed[i]
+        t, lat = gold.sink_records(i)
+        assert sink.latencies_s == lat.tolist()
+        np.testing.assert_array_equal(sink.completion_ns, t)
+
+
+def _build_mm1():
+    sink = hs.Sink()
+    server = hs.Server("srv", service_time=hs.ExponentialLatency(0.1), downstream=sink)
+    source = hs.Source.poisson(rate=8, target=server)
+    sim = hs.Simulation(end_time=Instant.from_seconds(20), sources=[source], entities=[server, sink])
+    sim.sink = sink
+    return sim
+
+
+def test_parallel_runner_replicas_match_reference():
+    gold = H.Golden("philox_64chains_replicas")
+    results = hs.ParallelRunner(max_workers=8).run_replicas(_build_mm1, n_replicas=64, base_seed=1000)
+    assert [r.name for r in results] == [f"replica_{i}" for i in range(64)]
+    assert [r.summary.total_events_processed for r in results] == gold.meta["total_events"]
+    assert [r.summary.duration_s for r in results] == gold.meta["duration_s"]
+
+
+def test_parallel_simulation_without_links_equals_separate_runs():
+    parts, solo = [], []
+    for i in range(5):
+        def build(i=i):
+            sink = hs.Sink(f"k{i}")
+            srv = hs.Server(f"s{i}", service_time=hs.ExponentialLatency(0.05 + 0.01 * i), downstream=sink)
+            return hs.Source.poisson(rate=10, target=srv, name=f"src{i}"), srv, sink
+        src, srv, sink = build()
+        parts.append(hs.SimulationPartition(name=f"p{i}", entities=[srv, sink], sources=[src]))
+    ps = hs.ParallelSimulation(parts, duration=10.0, seed=7).run()
+    assert set(ps.partitions) == {f"p{i}" for i in range(5)}
+    assert ps.total_events_processed == sum(s.total_events_processed for s in ps.partitions.values())
+    assert ps.total_events_processed > 5 * 500
