@@ -336,7 +336,10 @@ struct Station {
 #pragma unroll
         for (int i = 0; i < C; ++i) n_at += (D[i] == t) ? 1 : 0;
         if (n_at == 1 && !force_general) {
-            bool general = false;
+            // Fast path: one event in flight at a time.  Both kinds of root converge on ONE poll/deliver/work
+            // site so that a wavefront whose lanes mix ticks and departures executes the (expensive) service
+            // draw once per iteration, not once per branch.
+            bool general = false, want_poll = false;
             if (A == t) {
                 const uint32_t r = do_tick(t);
                 if (svc_kind == 2) {             // Source -> Sink directly
@@ -344,15 +347,16 @@ struct Station {
                     if (r & 2u) { qpush(Q_TICK); general = true; }
                 }
                 else if (r & 2u) { if (r & 1u) qpush(Q_ENQ); qpush(Q_TICK); general = true; }
-                else if (r & 1u) general = chain_from_enqueue(t);
+                else if (r & 1u) want_poll = do_enqueue(t) && do_notify();
             } else {
                 int slot = 0;
 #pragma unroll
                 for (int i = 0; i < C; ++i) if (D[i] == t) slot = i;
                 const uint32_t r = do_cont(slot, t);
                 if (r & 1u) do_sink();
-                if (r & 2u) general = chain_from_poll(t);
+                want_poll = (r & 2u) != 0;
             }
+            if (want_poll) general = chain_from_poll(t);
             if (general) drain(t);
         } else {
             run_group_general(t);
