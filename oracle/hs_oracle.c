@@ -49,6 +49,11 @@ typedef struct {
     int64_t completed, rejected;          /* Server._requests_*, server/server.py:112-114 */
     double total_service_s;               /* Server._total_service_time */
     uint64_t svc_draws;
+    /* NetworkLink / RandomRouter */
+    int64_t packets_sent;                 /* NetworkLink.packets_sent, components/network/link.py:162 */
+    uint64_t link_draws;
+    int64_t routed;                       /* RandomRouter.stats_routed, components/random_router.py:36 */
+    uint64_t route_draws;
     /* Sink */
     int64_t received;
     int64_t *sink_t, *sink_created; int64_t sink_cap;
@@ -207,6 +212,8 @@ static int32_t arrival_kind_for(const hso_sim *s, int32_t node) {
     switch (s->g.kind[node]) {
         case HSO_SERVER: return HSO_EV_ENQUEUE;
         case HSO_SINK: return HSO_EV_SINK;
+        case HSO_LINK: return HSO_EV_LINK;
+        case HSO_ROUTER: return HSO_EV_ROUTE;
         default: return -1;
     }
 }
@@ -252,6 +259,7 @@ static void on_enqueue(hso_sim *s, const hso_event *e) {
         req_release(s, e->req);
         return;
     }
+    s->reqs[e->req].idx = e->idx;   /* the queued payload IS this Event object (a forwarded request is a new Event) */
     fifo_push(&nd->fifo, e->req);
     nd->accepted++;                                                 /* queue.py:138 */
     if (was_empty) {                                                /* queue.py:144-146 */
@@ -343,6 +351,51 @@ static void on_sink(hso_sim *s, const hso_event *e) {
     req_release(s, e->req);
 }
 
+/* RandomRouter.handle_event, components/random_router.py:32-45.  The stock router calls
+ * random.randint (global MT19937); the Philox-plugged router of tests/golden/make_golden.py picks
+ * idx = int(u * len(targets)) from the node's ROUTE stream -- same handler otherwise. */
+static void on_route(hso_sim *s, const hso_event *e) {
+    int32_t n = e->node;
+    hso_node *nd = &s->nodes[n];
+    nd->routed++;
+    int32_t cnt = s->g.rt_cnt[n];
+    double u = draw_uniform(s, n, HS_STREAM_ROUTE, &nd->route_draws);
+    int32_t idx = (int32_t)(u * (double)cnt);
+    int32_t tgt = s->g.rt_targets[s->g.rt_off[n] + idx];
+    hso_event ev = {e->time, next_index(s), arrival_kind_for(s, tgt), tgt, e->req, 0};
+    heap_push(s, ev);
+}
+
+/* NetworkLink.handle_event up to its yield, components/network/link.py:114-154 (no loss, no bandwidth):
+ * delay = latency.get_latency(now).to_seconds() [+ jitter.get_latency(now).to_seconds()], max(0, .)
+ * (_calculate_delay :190-216).  Modelled link: latency = ConstantLatency(lat_min),
+ * jitter = ExponentialLatency(lat_mean) when lat_kind == EXP, no jitter otherwise. */
+static void on_link(hso_sim *s, const hso_event *e) {
+    int32_t n = e->node;
+    hso_node *nd = &s->nodes[n];
+    (void)next_index(s);                                            /* continuation built by _start_process */
+    double delay = hsr_seconds_from_ns(hsr_ns_from_seconds(s->g.lat_min[n]));      /* ConstantLatency */
+    if (s->g.lat_kind[n] == HSO_LAT_EXP) {
+        double lambda = 1.0 / s->g.lat_mean[n];
+        double sample = exp1(s, draw_uniform(s, n, HS_STREAM_LINK, &nd->link_draws)) / lambda;
+        delay = delay + hsr_seconds_from_ns(hsr_ns_from_seconds(sample));           /* jitter */
+    }
+    if (!(delay > 0.0)) delay = 0.0;                                /* max(0.0, delay) */
+    hso_event ct = {e->time + hsr_ns_from_seconds(delay), next_index(s), HSO_EV_LINK_CONT, n, e->req, 0};
+    heap_push(s, ct);
+}
+
+/* transit over: link.py:156-189 -- a NEW Event for the egress with a copy of the context */
+static void on_link_cont(hso_sim *s, const hso_event *e) {
+    int32_t n = e->node;
+    hso_node *nd = &s->nodes[n];
+    nd->packets_sent++;
+    int32_t eg = s->g.target[n];
+    if (eg < 0) { req_release(s, e->req); return; }
+    hso_event fw = {e->time, next_index(s), arrival_kind_for(s, eg), eg, e->req, 0};
+    heap_push(s, fw);
+}
+
 /* ------------------------------------------------------------------- API */
 #define DUP(field, type)                                                         \
     do {                                                                         \
@@ -359,7 +412,13 @@ hso_sim *hso_create(const hso_graph *g, const hso_params *p) {
     DUP(kind, int32_t); DUP(target, int32_t); DUP(stream_base, uint64_t);
     DUP(arr_kind, int32_t); DUP(rate, double); DUP(stop_after_ns, int64_t);
     DUP(concurrency, int32_t); DUP(lat_kind, int32_t); DUP(lat_mean, double); DUP(lat_min, double);
-    DUP(queue_cap, int64_t); DUP(alt_target, int32_t); DUP(ttl, int32_t);
+    DUP(queue_cap, int64_t); DUP(rt_off, int32_t); DUP(rt_cnt, int32_t);
+    {
+        int32_t m = g->n_rt > 0 ? g->n_rt : 1;
+        int32_t *c_ = (int32_t *)calloc((size_t)m, sizeof(int32_t));
+        if (g->rt_targets && g->n_rt > 0) memcpy(c_, g->rt_targets, (size_t)g->n_rt * sizeof(int32_t));
+        s->g.rt_targets = c_; s->g.n_rt = g->n_rt;
+    }
     s->p = *p;
     s->nodes = (hso_node *)calloc((size_t)n, sizeof(hso_node));
     s->req_free = -1;
@@ -411,6 +470,9 @@ int hso_run_until(hso_sim *s, int64_t end_ns) {
             case HSO_EV_WORK: on_work(s, &e); break;
             case HSO_EV_CONTINUATION: on_continuation(s, &e); break;
             case HSO_EV_SINK: on_sink(s, &e); break;
+            case HSO_EV_LINK: on_link(s, &e); break;
+            case HSO_EV_LINK_CONT: on_link_cont(s, &e); break;
+            case HSO_EV_ROUTE: on_route(s, &e); break;
             default: return -1;
         }
     }
@@ -439,6 +501,13 @@ void hso_get_node_stats(const hso_sim *s, int64_t *generated, int64_t *accepted,
         if (received) received[i] = nd->received;
         if (depth) depth[i] = nd->fifo.len;
         if (active) active[i] = nd->active;
+    }
+}
+
+void hso_get_net_stats(const hso_sim *s, int64_t *packets_sent, int64_t *routed) {
+    for (int32_t i = 0; i < s->g.n_nodes; ++i) {
+        if (packets_sent) packets_sent[i] = s->nodes[i].packets_sent;
+        if (routed) routed[i] = s->nodes[i].routed;
     }
 }
 
@@ -474,7 +543,7 @@ void hso_destroy(hso_sim *s) {
     free((void *)s->g.kind); free((void *)s->g.target); free((void *)s->g.stream_base);
     free((void *)s->g.arr_kind); free((void *)s->g.rate); free((void *)s->g.stop_after_ns);
     free((void *)s->g.concurrency); free((void *)s->g.lat_kind); free((void *)s->g.lat_mean);
-    free((void *)s->g.lat_min); free((void *)s->g.queue_cap); free((void *)s->g.alt_target); free((void *)s->g.ttl);
+    free((void *)s->g.lat_min); free((void *)s->g.queue_cap); free((void *)s->g.rt_off); free((void *)s->g.rt_cnt); free((void *)s->g.rt_targets);
     free(s->nodes); free(s->heap); free(s->reqs);
     free(s->tr_t); free(s->tr_kind); free(s->tr_node); free(s->tr_idx);
     free(s);

@@ -19,8 +19,9 @@ SOURCE, SERVER, SINK, LINK, ROUTER = 0, 1, 2, 3, 4
 ARR_POISSON, ARR_CONSTANT = 0, 1
 LAT_EXP, LAT_CONST = 0, 1
 RNG_PHILOX, RNG_MT19937 = 0, 1
-EV_KINDS = 10
-EV_NAMES = ["source", "enqueue", "notify", "poll", "deliver", "work", "continuation", "sink", "link", "route"]
+EV_KINDS = 11
+EV_NAMES = ["source", "enqueue", "notify", "poll", "deliver", "work", "continuation", "sink", "link", "link_cont",
+            "route"]
 STREAM_ARRIVAL, STREAM_SERVICE, STREAM_LINK, STREAM_ROUTE = 0, 1, 2, 3
 
 
@@ -50,8 +51,10 @@ class _Graph(C.Structure):
         ("lat_mean", C.POINTER(C.c_double)),
         ("lat_min", C.POINTER(C.c_double)),
         ("queue_cap", C.POINTER(C.c_int64)),
-        ("alt_target", C.POINTER(C.c_int32)),
-        ("ttl", C.POINTER(C.c_int32)),
+        ("rt_off", C.POINTER(C.c_int32)),
+        ("rt_cnt", C.POINTER(C.c_int32)),
+        ("rt_targets", C.POINTER(C.c_int32)),
+        ("n_rt", C.c_int32),
     ]
 
 
@@ -91,6 +94,7 @@ def lib():
         L.hso_run_until.argtypes = [C.c_void_p, C.c_int64]
         L.hso_get_summary.argtypes = [C.c_void_p, C.POINTER(_Summary)]
         L.hso_get_node_stats.argtypes = [C.c_void_p] + [C.c_void_p] * 9
+        L.hso_get_net_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.hso_sink_count.restype = C.c_int64
         L.hso_sink_count.argtypes = [C.c_void_p, C.c_int32]
         L.hso_read_sink.restype = C.c_int64
@@ -126,13 +130,14 @@ class Graph:
     lat_mean: list = field(default_factory=list)
     lat_min: list = field(default_factory=list)
     queue_cap: list = field(default_factory=list)
-    alt_target: list = field(default_factory=list)
-    ttl: list = field(default_factory=list)
+    rt_off: list = field(default_factory=list)
+    rt_cnt: list = field(default_factory=list)
+    rt_targets: list = field(default_factory=list)   # flat target list of all routers (not per node)
 
     def _add(self, **kw) -> int:
         defaults = dict(
             kind=0, target=-1, stream_base=len(self.kind), arr_kind=0, rate=0.0, stop_after_ns=-1,
-            concurrency=1, lat_kind=LAT_CONST, lat_mean=0.0, lat_min=0.0, queue_cap=-1, alt_target=-1, ttl=0,
+            concurrency=1, lat_kind=LAT_CONST, lat_mean=0.0, lat_min=0.0, queue_cap=-1, rt_off=0, rt_cnt=0,
         )
         defaults.update(kw)
         for k, v in defaults.items():
@@ -154,6 +159,23 @@ class Graph:
 
     def sink(self) -> int:
         return self._add(kind=SINK)
+
+    def link(self, lat_min, jitter_mean=None, target=-1, stream_base=None) -> int:
+        """NetworkLink(latency=ConstantLatency(lat_min), jitter=ExponentialLatency(jitter_mean) | None, egress=target)."""
+        kw = dict(kind=LINK, lat_min=float(lat_min), target=target,
+                  lat_kind=LAT_CONST if jitter_mean is None else LAT_EXP,
+                  lat_mean=0.0 if jitter_mean is None else float(jitter_mean))
+        if stream_base is not None:
+            kw["stream_base"] = stream_base
+        return self._add(**kw)
+
+    def router(self, targets, stream_base=None) -> int:
+        """RandomRouter(targets=[...]) with the Philox-plugged uniform choice."""
+        kw = dict(kind=ROUTER, rt_off=len(self.rt_targets), rt_cnt=len(targets))
+        if stream_base is not None:
+            kw["stream_base"] = stream_base
+        self.rt_targets.extend(int(t) for t in targets)
+        return self._add(**kw)
 
     def __len__(self) -> int:
         return len(self.kind)
@@ -190,11 +212,13 @@ def run(g: Graph, end_ns: int, start_ns: int = 0, seed: int = 42, rng_mode: int 
         "rate": np.asarray(g.rate, np.float64), "stop_after_ns": np.asarray(g.stop_after_ns, np.int64),
         "concurrency": np.asarray(g.concurrency, np.int32), "lat_kind": np.asarray(g.lat_kind, np.int32),
         "lat_mean": np.asarray(g.lat_mean, np.float64), "lat_min": np.asarray(g.lat_min, np.float64),
-        "queue_cap": np.asarray(g.queue_cap, np.int64), "alt_target": np.asarray(g.alt_target, np.int32),
-        "ttl": np.asarray(g.ttl, np.int32),
+        "queue_cap": np.asarray(g.queue_cap, np.int64), "rt_off": np.asarray(g.rt_off, np.int32),
+        "rt_cnt": np.asarray(g.rt_cnt, np.int32),
+        "rt_targets": np.asarray(g.rt_targets if g.rt_targets else [0], np.int32),
     }
     G = _Graph()
     G.n_nodes = n
+    G.n_rt = len(g.rt_targets)
     for name, a in arrs.items():
         ftype = dict(_Graph._fields_)[name]
         setattr(G, name, a.ctypes.data_as(ftype))
@@ -224,6 +248,9 @@ def run(g: Graph, end_ns: int, start_ns: int = 0, seed: int = 42, rng_mode: int 
         L.hso_get_node_stats(h, *[bufs[nm].ctypes.data for nm in names])
         for nm in names:
             setattr(r, nm, bufs[nm])
+        r.packets_sent = np.zeros(n, np.int64)
+        r.routed = np.zeros(n, np.int64)
+        L.hso_get_net_stats(h, r.packets_sent.ctypes.data, r.routed.ctypes.data)
         r.sinks = {}
         for i in range(n):
             if g.kind[i] == SINK:

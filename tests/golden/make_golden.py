@@ -52,7 +52,12 @@ from happysimulator.load.profile import ConstantRateProfile  # noqa: E402
 from happysimulator.load.providers.constant_arrival import ConstantArrivalTimeProvider  # noqa: E402
 from happysimulator.load.source import SimpleEventProvider  # noqa: E402
 
-EV = {"source": 0, "enqueue": 1, "notify": 2, "poll": 3, "deliver": 4, "work": 5, "continuation": 6, "sink": 7}
+from happysimulator.components.network.link import NetworkLink  # noqa: E402
+from happysimulator.components.random_router import RandomRouter  # noqa: E402
+from happysimulator.core.event import Event  # noqa: E402
+
+EV = {"source": 0, "enqueue": 1, "notify": 2, "poll": 3, "deliver": 4, "work": 5, "continuation": 6, "sink": 7,
+      "link": 8, "link_cont": 9, "route": 10}
 
 
 # ---- Seam-3 plug-ins (ours; they only choose the random numbers) ------------------------
@@ -79,6 +84,22 @@ class PhiloxPoissonArrival(ArrivalTimeProvider):
 
     def _get_target_integral_value(self) -> float:
         return hs.exp1(self._stream.next_uniform())
+
+
+class PhiloxRandomRouter(RandomRouter):
+    """components/random_router.py:32-45 with the target index drawn from a Philox stream
+    (idx = int(u * len(targets))) instead of the global `random.randint`; the handler body is otherwise the
+    reference's: count, build a new Event for the chosen target with the same context."""
+
+    def __init__(self, name, *, targets, stream: hs.Stream):
+        super().__init__(name, targets=targets)
+        self._stream = stream
+
+    def handle_event(self, event):
+        self.stats_routed += 1
+        idx = int(self._stream.next_uniform() * len(self.targets))
+        self.target_counts[self.targets[idx].name] += 1
+        return [Event(time=self.now, event_type=event.event_type, target=self.targets[idx], context=event.context)]
 
 
 def _per_chain(v, n):
@@ -143,6 +164,10 @@ def classify(ev, node_of):
         return EV["enqueue"], node_of[id(tgt)]
     if isinstance(tgt, Sink):
         return EV["sink"], node_of[id(tgt)]
+    if isinstance(tgt, RandomRouter):
+        return EV["route"], node_of[id(tgt)]
+    if isinstance(tgt, NetworkLink):
+        return (EV["link_cont"] if isinstance(ev, ProcessContinuation) else EV["link"]), node_of[id(tgt)]
     raise RuntimeError(f"unclassified event {ev!r}")
 
 
@@ -232,6 +257,94 @@ def run_case(spec):
     return out, meta
 
 
+def run_ring_case(spec):
+    """N stations on a ring, reference components only:
+    Source.poisson(ext_rate) -> Server_i(Exp mean) -> RandomRouter_i([Sink_i, Link_i]);
+    Link_i = NetworkLink(latency=ConstantLatency(lat_min), jitter=Exp(jitter_mean), egress=Server_{i+1})."""
+    n, seed = spec["n"], spec["seed"]
+    sinks = [Sink(f"sink{i}") for i in range(n)]
+    servers = [Server(f"srv{i}", concurrency=spec.get("concurrency", 1),
+                      service_time=PhiloxExponentialLatency(spec["mean"], hs.Stream(seed, i, hs.STREAM_SERVICE)),
+                      queue_capacity=spec.get("queue_cap")) for i in range(n)]
+    links, routers, sources = [], [], []
+    for i in range(n):
+        jit = None
+        if spec.get("jitter_mean") is not None:
+            jit = PhiloxExponentialLatency(spec["jitter_mean"], hs.Stream(seed, i, hs.STREAM_LINK))
+        links.append(NetworkLink(f"link{i}", latency=ConstantLatency(spec["lat_min"]), jitter=jit,
+                                 egress=servers[(i + 1) % n]))
+        routers.append(PhiloxRandomRouter(f"router{i}", targets=[sinks[i], links[i]],
+                                          stream=hs.Stream(seed, i, hs.STREAM_ROUTE)))
+        servers[i].downstream = routers[i]
+        rate = spec["ext_rate"][i] if isinstance(spec["ext_rate"], list) else spec["ext_rate"]
+        if rate > 0:
+            prov = PhiloxPoissonArrival(ConstantRateProfile(rate=rate), Instant.Epoch,
+                                        hs.Stream(seed, i, hs.STREAM_ARRIVAL))
+            sources.append(Source(f"src{i}", SimpleEventProvider(servers[i], "Request", None), prov))
+        else:
+            sources.append(None)
+    sim = Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=[s for s in sources if s is not None],
+                     entities=servers + routers + links + sinks)
+    node_of = {}
+    for i in range(n):
+        for obj in (sources[i], servers[i], servers[i]._queue, servers[i]._driver, servers[i]._worker, routers[i],
+                    links[i], sinks[i]):
+            if obj is not None:
+                node_of[id(obj)] = i
+    trace = []
+    if spec.get("trace"):
+        heap = sim._event_heap
+        orig_pop = heap.pop
+
+        def pop():
+            e = orig_pop()
+            k, nd = classify(e, node_of)
+            trace.append((e.time.nanoseconds, k, nd, e._sort_index))
+            return e
+
+        heap.pop = pop
+    summary = sim.run()
+    out = {}
+    meta = dict(spec=spec, total_events=[summary.total_events_processed], final_ns=[sim._current_time.nanoseconds],
+                duration_s=[summary.duration_s])
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    out["generated"] = np.array([s.generated_count if s is not None else 0 for s in sources], np.int64)
+    out["accepted"] = np.array([s.stats_accepted for s in servers], np.int64)
+    out["dropped"] = np.array([s.stats_dropped for s in servers], np.int64)
+    out["completed"] = np.array([s._requests_completed for s in servers], np.int64)
+    out["rejected"] = np.array([s._requests_rejected for s in servers], np.int64)
+    out["depth"] = np.array([s.depth for s in servers], np.int64)
+    out["active"] = np.array([s.active_requests for s in servers], np.int64)
+    out["total_service_s"] = np.array([s._total_service_time for s in servers], np.float64)
+    out["received"] = np.array([k.events_received for k in sinks], np.int64)
+    out["routed"] = np.array([r.stats_routed for r in routers], np.int64)
+    out["packets_sent"] = np.array([l.packets_sent for l in links], np.int64)
+    sink_t, sink_lat, off = [], [], [0]
+    for k in sinks:
+        sink_t.extend(t.nanoseconds for t in k.completion_times)
+        sink_lat.extend(k.latencies_s)
+        off.append(len(sink_t))
+    out["sink_t_ns"] = np.asarray(sink_t, np.int64)
+    out["sink_latency_s"] = np.asarray(sink_lat, np.float64)
+    out["sink_off"] = np.asarray(off, np.int64)
+    if spec.get("trace"):
+        out["trace"] = np.asarray(trace, np.int64).reshape(-1, 4)
+    return out, meta
+
+
+RING_CASES = [
+    dict(name="ring_8_s42", topology="ring", n=8, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, end_s=20.0,
+         seed=42, trace=True),
+    dict(name="ring_3_short_hops", topology="ring", n=3, ext_rate=4.0, mean=0.1, lat_min=0.0005, jitter_mean=0.002,
+         end_s=15.0, seed=7, trace=True),
+    dict(name="ring_5_const_link", topology="ring", n=5, ext_rate=[4.0, 0.0, 6.0, 2.0, 4.0], mean=0.08, lat_min=0.003,
+         jitter_mean=None, end_s=15.0, seed=11, trace=True),
+    dict(name="ring_6_c2_cap3", topology="ring", n=6, ext_rate=9.0, mean=0.1, concurrency=2, queue_cap=3, lat_min=0.001,
+         jitter_mean=0.005, end_s=10.0, seed=3, trace=True),
+    dict(name="ring_64_s2026", topology="ring", n=64, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, end_s=8.0,
+         seed=2026, trace=False),
+]
+
 CASES = [
     # --- Oracle-A: stock MT19937 streams -------------------------------------------------
     dict(name="quickstart_mt42", n_chains=1, arr="poisson", rate=8.0, svc="exp", mean=0.1, end_s=60.0,
@@ -280,6 +393,14 @@ CASES = [
 
 def main(argv):
     only = set(argv[1:])
+    for spec in RING_CASES:
+        if only and spec["name"] not in only:
+            continue
+        out, meta = run_ring_case(dict(spec))
+        path = os.path.join(HERE, spec["name"] + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{spec['name']}: events={sum(meta['total_events'])} final={meta['final_ns'][-1]} "
+              f"sink_records={len(out['sink_t_ns'])} -> {os.path.getsize(path)} B")
     for spec in CASES:
         if only and spec["name"] not in only:
             continue

@@ -12,8 +12,9 @@ from oracle import hs_oracle as O
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+def golden_names(topology="chains"):
+    names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return [n for n in names if (n.startswith("ring_")) == (topology == "ring")]
 
 
 class Golden:
@@ -96,6 +97,37 @@ def run_oracle_for_spec(spec, trace_cap=0):
                   mt_seed_np=seed & 0xFFFFFFFF, trace_cap=trace_cap)
         runs.append((chain_ids, nodes, r))
     return runs
+
+
+def ring_params(spec):
+    n = spec["n"]
+    return dict(
+        n=n, ext_rate=[float(r) for r in per_chain(spec["ext_rate"], n)], mean=float(spec["mean"]),
+        conc=int(spec.get("concurrency", 1)), qcap=-1 if spec.get("queue_cap") is None else int(spec["queue_cap"]),
+        lat_min=float(spec["lat_min"]), jitter_mean=spec.get("jitter_mean"), end_ns=ns_from_seconds(spec["end_s"]),
+        p_targets=2)
+
+
+def oracle_ring_graph(spec):
+    """Oracle nodes for a ring golden: sources (list order) first, then per station server, router, sink, link.
+    Station i's entities all use stream base i.  Returns (graph, {i: dict(src, srv, rtr, snk, lnk)})."""
+    p = ring_params(spec)
+    n = p["n"]
+    g = O.Graph()
+    nodes = {i: {} for i in range(n)}
+    for i in range(n):
+        nodes[i]["src"] = g.source(O.ARR_POISSON, p["ext_rate"][i], stream_base=i) if p["ext_rate"][i] > 0 else -1
+    for i in range(n):
+        nodes[i]["srv"] = g.server(O.LAT_EXP, p["mean"], concurrency=p["conc"], queue_cap=p["qcap"], stream_base=i)
+        nodes[i]["snk"] = g.sink()
+        nodes[i]["lnk"] = g.link(p["lat_min"], p["jitter_mean"], stream_base=i)
+        nodes[i]["rtr"] = g.router([nodes[i]["snk"], nodes[i]["lnk"]], stream_base=i)
+    for i in range(n):
+        if nodes[i]["src"] >= 0:
+            g.target[nodes[i]["src"]] = nodes[i]["srv"]
+        g.target[nodes[i]["srv"]] = nodes[i]["rtr"]
+        g.target[nodes[i]["lnk"]] = nodes[(i + 1) % n]["srv"]
+    return g, nodes
 
 
 # ----------------------------------------------------------------------------------------------

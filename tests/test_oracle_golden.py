@@ -62,3 +62,36 @@ def test_known_reference_numbers():
     assert H.Golden("const_r8").meta["total_events"] == [4318]
     assert H.Golden("const_r10").meta["total_events"] == [4805]
     assert H.Golden("const_r12_overload").meta["total_events"] == [4445]
+
+
+@pytest.mark.parametrize("name", H.golden_names("ring"))
+def test_oracle_matches_reference_ring_golden(name):
+    """Ring of stations built from reference components only (Server -> RandomRouter -> [Sink | NetworkLink ->
+    next Server]); the live reference ran with Philox-plugged streams (make_golden.py run_ring_case)."""
+    gold = H.Golden(name)
+    spec = gold.spec
+    want_trace = "trace" in gold.arrays
+    g, nodes = H.oracle_ring_graph(spec)
+    r = O.run(g, H.ns_from_seconds(spec["end_s"]), seed=spec["seed"],
+              trace_cap=(len(gold.trace) + 16) if want_trace else 0)
+    assert [r.events_processed] == gold.meta["total_events"]
+    assert [r.final_time_ns] == gold.meta["final_ns"]
+    for i in range(spec["n"]):
+        nd = nodes[i]
+        if nd["src"] >= 0:
+            assert r.generated[nd["src"]] == gold.generated[i]
+        for k, arr in (("accepted", r.accepted), ("dropped", r.dropped), ("completed", r.completed),
+                       ("rejected", r.rejected), ("depth", r.depth), ("active", r.active),
+                       ("total_service_s", r.total_service_s)):
+            assert arr[nd["srv"]] == gold.arrays[k][i], (k, i)
+        assert r.routed[nd["rtr"]] == gold.routed[i]
+        assert r.packets_sent[nd["lnk"]] == gold.packets_sent[i]
+        t, created = r.sinks[nd["snk"]]
+        gt, glat = gold.sink_records(i)
+        np.testing.assert_array_equal(t, gt)
+        np.testing.assert_array_equal((t - created).astype(np.float64) / 1e9, glat)
+    if want_trace:
+        node_station = {v: i for i, d in nodes.items() for v in d.values() if v >= 0}
+        t, k, nd, ix = r.trace
+        got = np.stack([t, k.astype(np.int64), np.array([node_station[x] for x in nd], np.int64), ix], axis=1)
+        np.testing.assert_array_equal(got, gold.trace)
