@@ -28,9 +28,11 @@ HS_E_INVALID, HS_E_NO_DEVICE, HS_E_HIP, HS_E_UNSUPPORTED, HS_E_OVERFLOW, HS_E_ST
 MODE_SINGLE, MODE_REPLICAS = 0, 1
 SRC_NONE, SRC_POISSON, SRC_CONSTANT = 0, 1, 2
 LAT_EXPONENTIAL, LAT_CONSTANT, LAT_NO_SERVER = 0, 1, 2
-EGRESS_NONE, EGRESS_SINK = 0, 1
-EV_KINDS = 8
-EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuation", "sink")
+EGRESS_NONE, EGRESS_SINK, EGRESS_LINK, EGRESS_ROUTER = 0, 1, 2, 3
+EV_KINDS = 11
+EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuation", "sink", "link", "link_cont",
+            "route")
+ABI_VERSION = 2
 
 
 class EngineUnavailable(RuntimeError):
@@ -63,9 +65,23 @@ class Summary(C.Structure):
     _fields_ = [
         ("events_processed", C.c_int64), ("events_by_kind", C.c_int64 * EV_KINDS), ("events_cancelled", C.c_int64),
         ("final_time_ns", C.c_int64), ("requests_completed", C.c_int64), ("sink_records", C.c_int64),
-        ("last_run_ms", C.c_double), ("kernel_ms", C.c_double), ("launches", C.c_int64),
+        ("last_run_ms", C.c_double), ("kernel_ms", C.c_double), ("launches", C.c_int64), ("window_ns", C.c_int64),
         ("overflow", C.c_int32), ("reserved", C.c_int32),
     ]
+
+
+class Network(C.Structure):
+    _fields_ = [
+        ("egress_kind", C.c_void_p), ("router_target0", C.c_void_p), ("router_target1", C.c_void_p),
+        ("link_of", C.c_void_p), ("router_stream_base", C.c_void_p), ("n_links", C.c_int32),
+        ("link_dst", C.c_void_p), ("link_lat_min_s", C.c_void_p), ("link_jitter_kind", C.c_void_p),
+        ("link_jitter_mean_s", C.c_void_p), ("link_stream_base", C.c_void_p), ("link_src", C.c_void_p),
+        ("bag_capacity", C.c_int32),
+    ]
+
+
+class NetStats(C.Structure):
+    _fields_ = [("routed", C.c_void_p), ("link_entered", C.c_void_p), ("link_packets_sent", C.c_void_p)]
 
 
 class LpStats(C.Structure):
@@ -118,6 +134,10 @@ def lib():
     L.hs_engine_create.argtypes = [P(Config), P(C.c_void_p)]
     L.hs_engine_set_stations.restype = C.c_int
     L.hs_engine_set_stations.argtypes = [C.c_void_p, P(Stations)]
+    L.hs_engine_set_network.restype = C.c_int
+    L.hs_engine_set_network.argtypes = [C.c_void_p, P(Network)]
+    L.hs_engine_get_net_stats.restype = C.c_int
+    L.hs_engine_get_net_stats.argtypes = [C.c_void_p, P(NetStats)]
     L.hs_engine_reset.restype = C.c_int
     L.hs_engine_reset.argtypes = [C.c_void_p]
     for name in ("hs_engine_run_until", "hs_engine_run_until_async"):
@@ -145,14 +165,15 @@ def lib():
     L.hs_debug_draws.restype = C.c_int
     L.hs_debug_draws.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64, C.c_double,
                                  C.c_void_p, C.c_void_p, C.c_void_p]
-    if L.hs_abi_version() != 1:
+    if L.hs_abi_version() != ABI_VERSION:
         raise EngineUnavailable("libhs_hip.so ABI version mismatch; rebuild")
     _lib = L
     return L
 
 
 EXPORTED_SYMBOLS = (
-    "hs_abi_version", "hs_device_count", "hs_engine_create", "hs_engine_set_stations", "hs_engine_reset",
+    "hs_abi_version", "hs_device_count", "hs_engine_create", "hs_engine_set_stations", "hs_engine_set_network",
+    "hs_engine_get_net_stats", "hs_engine_reset",
     "hs_engine_run_until", "hs_engine_run_until_async", "hs_engine_synchronize", "hs_engine_bench_runs",
     "hs_engine_get_summary", "hs_engine_get_lp_stats", "hs_engine_read_sink", "hs_engine_read_sinks",
     "hs_last_error", "hs_last_global_error", "hs_engine_destroy", "hs_debug_draws",

@@ -14,7 +14,7 @@
 #include <vector>
 
 #include "../../include/hs_engine.h"
-#include "hs_station.hpp"
+#include "hs_netstation.hpp"
 
 using namespace hs;
 
@@ -170,10 +170,14 @@ __device__ __forceinline__ void overshoot_one(Station<C> &S) {
 // Simulation.__init__ bootstrap (core/simulation.py:145-154, load/source.py:120-140): every Source draws
 // its first arrival from start_ns.  Also zeroes the per-LP state.
 __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, StationState X, Totals *tot, int n, int C,
-                                                           int64_t start_ns) {
+                                                           int64_t start_ns, NetState NX, int n_links) {
     const int lp = blockIdx.x * kBlock + threadIdx.x;
+    if (NX.next_time != nullptr) {   // network engine: clear routing / link / bag state
+        for (int l = lp; l < n_links; l += gridDim.x * kBlock) { NX.link_k[l] = 0; NX.link_in[l] = 0; NX.link_packets[l] = 0; }
+        if (lp < n) { NX.route_k[lp] = 0; NX.routed[lp] = 0; NX.bag_cnt[lp] = 0; NX.in_cnt[lp] = 0; NX.in_cnt[n + lp] = 0; }
+    }
     if (lp == 0) {
-        for (int k = 0; k < 8; ++k) tot->ev[k] = 0;
+        for (int k = 0; k < 11; ++k) tot->ev[k] = 0;
         tot->completed = 0; tot->received = 0; tot->final_time = start_ns; tot->cur_time = start_ns;
         tot->overflow = 0; tot->qoverflow = 0; tot->done = 0;
     }
@@ -193,6 +197,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
         arr_time = ns_from_seconds(t_next);
         A = arr_time;
     }
+    if (NX.next_time != nullptr) NX.next_time[lp] = A;
     X.A[lp] = A; X.seqA[lp] = 0; X.crtA[lp] = start_ns; X.arr_k[lp] = arr_k; X.arr_time[lp] = arr_time;
     X.svc_k[lp] = 0; X.seq[lp] = 1; X.buf[lp] = 0; X.active[lp] = 0;
     X.generated[lp] = 0; X.accepted[lp] = 0; X.dropped[lp] = 0; X.completed[lp] = 0; X.rejected[lp] = 0;
@@ -202,7 +207,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
         X.D[(size_t)i * n + lp] = kInfNs; X.seqD[(size_t)i * n + lp] = 0; X.crtD[(size_t)i * n + lp] = start_ns;
         X.svc_s[(size_t)i * n + lp] = 0.0; X.crt[(size_t)i * n + lp] = 0;
     }
-    for (int k = 0; k < 8; ++k) X.ev_kind[(size_t)k * n + lp] = 0;
+    for (int k = 0; k < 11; ++k) X.ev_kind[(size_t)k * n + lp] = 0;
 }
 
 // The hot kernel: every LP advances to end_ns (== Simulation._execute_until for its events), then the
@@ -331,6 +336,240 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// network engine (hs_netstation.hpp): one launch per conservative time window
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+template <int C>
+__device__ __forceinline__ void load_net(NetStation<C> &S, const StationParams &P, const NetParams &NP,
+                                         const StationState &X, const NetState &NX, const RecordLogs &L, int lp, int n,
+                                         uint8_t (*qmem)[kBlock], int64_t (*enqpay)[kBlock], int tid, int send_idx) {
+    S.lp = lp; S.n = n;
+    S.src_kind = P.src_kind[lp]; S.svc_kind = P.svc_kind[lp]; S.egress = NP.egress[lp];
+    S.conc = P.conc[lp]; S.rt0 = NP.rt0[lp]; S.rt1 = NP.rt1[lp]; S.link_of = NP.link_of[lp];
+    S.rate = P.src_rate[lp];
+    const double mean = P.svc_mean[lp];
+    S.svc_lambda = __ddiv_rn(1.0, mean);
+    S.svc_const_s = seconds_from_ns(ns_from_seconds(mean));
+    S.svc_const_ns = ns_from_seconds(S.svc_const_s);
+    S.stop_ns = P.src_stop[lp]; S.qcap = P.qcap[lp];
+    S.seed = P.seed[lp]; S.route_base = NP.route_base[lp];
+    S.A = X.A[lp]; S.seqA = X.seqA[lp]; S.crtA = X.crtA[lp]; S.arr_time = X.arr_time[lp];
+    S.buf = X.buf[lp]; S.active = X.active[lp]; S.seq = X.seq[lp];
+    S.generated = X.generated[lp]; S.accepted = X.accepted[lp]; S.dropped = X.dropped[lp];
+    S.completed = X.completed[lp]; S.rejected = X.rejected[lp]; S.started = X.started[lp];
+    S.received = X.received[lp]; S.routed = NX.routed[lp];
+    S.total_service = X.total_service[lp];
+    S.last_time = X.last_time[lp];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        S.D[i] = X.D[(size_t)i * n + lp]; S.seqD[i] = X.seqD[(size_t)i * n + lp];
+        S.crtD[i] = X.crtD[(size_t)i * n + lp]; S.svc_s[i] = X.svc_s[(size_t)i * n + lp];
+        S.crt[i] = X.crt[(size_t)i * n + lp];
+    }
+    const uint64_t base = P.stream_base[lp];
+    S.arr.init(S.seed, stream_id(base, kStreamArrival), X.arr_k[lp]);
+    S.svc.init(S.seed, stream_id(base, kStreamService), X.svc_k[lp]);
+    S.rte.init(S.seed, stream_id(S.route_base, kStreamRoute), NX.route_k[lp]);
+#pragma unroll
+    for (int k = 0; k < 11; ++k) S.ev[k] = 0;
+    S.adm = L.adm + (size_t)lp * L.cap;
+    S.sink_t = L.sink_t + (size_t)lp * L.cap;
+    S.sink_created = L.sink_created + (size_t)lp * L.cap;
+    S.cap = L.cap;
+    S.overflow = 0; S.qoverflow = 0; S.bagoverflow = 0;
+    S.np = &NP; S.ns = &NX; S.send_idx = send_idx;
+    S.bag_n = NX.bag_cnt[lp];
+    S.qmem = qmem; S.enqpay = enqpay; S.tid = tid; S.qh = 0; S.qn = 0; S.ph = 0; S.pn = 0;
+}
+
+template <int C>
+__device__ __forceinline__ void store_net(NetStation<C> &S, const StationState &X, const NetState &NX, int lp, int n) {
+    X.A[lp] = S.A; X.seqA[lp] = S.seqA; X.crtA[lp] = S.crtA; X.arr_time[lp] = S.arr_time;
+    X.buf[lp] = S.buf; X.active[lp] = S.active; X.seq[lp] = S.seq;
+    X.generated[lp] = S.generated; X.accepted[lp] = S.accepted; X.dropped[lp] = S.dropped;
+    X.completed[lp] = S.completed; X.rejected[lp] = S.rejected; X.started[lp] = S.started;
+    X.received[lp] = S.received; X.sink_w[lp] = S.received; NX.routed[lp] = S.routed;
+    X.total_service[lp] = S.total_service;
+    X.last_time[lp] = S.last_time;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        X.D[(size_t)i * n + lp] = S.D[i]; X.seqD[(size_t)i * n + lp] = S.seqD[i];
+        X.crtD[(size_t)i * n + lp] = S.crtD[i]; X.svc_s[(size_t)i * n + lp] = S.svc_s[i];
+        X.crt[(size_t)i * n + lp] = S.crt[i];
+    }
+    X.arr_k[lp] = S.arr.k; X.svc_k[lp] = S.svc.k; NX.route_k[lp] = S.rte.k;
+    NX.bag_cnt[lp] = S.bag_n;
+    NX.next_time[lp] = S.next_time();
+    uint32_t tot = 0;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) { if (S.ev[k]) X.ev_kind[(size_t)k * n + lp] += S.ev[k]; tot += S.ev[k]; }
+    X.events[lp] += tot;
+}
+
+}  // namespace
+
+// One conservative window: every LP merges the messages sent to it during the previous window, then
+// processes all of its timestamp groups with time <= wend.  flags bit 0: force the general path;
+// bit 1: FINAL launch (after the last window): elect and process the single overshoot event.
+template <int C>
+__global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetParams NP, StationState X, NetState NX,
+                                                        RecordLogs L, Totals *tot, Candidate *cands, int n,
+                                                        int64_t wend, int win, int flags) {
+    __shared__ uint8_t qmem[kQCap][kBlock];
+    __shared__ int64_t enqpay[kEnqPay][kBlock];
+    __shared__ unsigned long long red[14];
+    __shared__ long long red_time;
+    __shared__ int red_flags[3];
+    __shared__ Candidate wave_c[kBlock / 64];
+    __shared__ int is_last;
+
+    const int tid = threadIdx.x;
+    const int lp = blockIdx.x * kBlock + tid;
+    const bool live = lp < n;
+    const bool final_launch = (flags & 2) != 0;
+    const int merge_idx = (win + 1) & 1, send_idx = win & 1;
+    if (tid < 14) red[tid] = 0;
+    if (tid == 0) { red_time = INT64_MIN; red_flags[0] = red_flags[1] = red_flags[2] = 0; }
+
+    int64_t nt = kInfNs;
+    int merge_overflow = 0;
+    if (live) {
+        nt = NX.next_time[lp];
+        const size_t cs = (size_t)merge_idx * n + lp;
+        const int c = NX.in_cnt[cs];
+        if (c > 0) {   // EXCHANGE: take delivery of the messages sent during the previous window
+            int bn = NX.bag_cnt[lp];
+            const int cc = c < NX.bag_cap ? c : NX.bag_cap;
+            if (c > NX.bag_cap) merge_overflow = 1;
+            for (int i = 0; i < cc; ++i) {
+                if (bn >= NX.bag_cap) { merge_overflow = 1; break; }
+                const size_t src = cs * NX.bag_cap + i, dst = (size_t)lp * NX.bag_cap + bn;
+                const int64_t t = NX.in_t[src];
+                NX.bag_t[dst] = t; NX.bag_ts[dst] = NX.in_ts[src]; NX.bag_cr[dst] = NX.in_cr[src];
+                NX.bag_link[dst] = NX.in_link[src];
+                nt = t < nt ? t : nt;
+                ++bn;
+            }
+            NX.bag_cnt[lp] = bn;
+            NX.in_cnt[cs] = 0;
+            NX.next_time[lp] = nt;
+        }
+    }
+    const bool act = live && (nt <= wend || final_launch);
+    if (!__syncthreads_or((int)act | merge_overflow)) return;   // nothing happens in this workgroup's window
+
+    NetStation<C> S;
+    Candidate mine;
+    mine.valid = 0; mine.t = kInfNs; mine.t_created = 0; mine.lp = lp;
+    if (act) {
+        load_net<C>(S, P, NP, X, NX, L, lp, n, qmem, enqpay, tid, send_idx);
+        for (;;) {
+            const int64_t t = S.next_time();
+            if (t > wend) break;
+            S.run_group(t, (flags & 1) != 0);
+        }
+        if (final_launch) {
+            const int64_t t = S.next_time();
+            if (t != kInfNs) {
+                const int w = S.pick_root(t);
+                mine.t = t; mine.valid = 1;
+                if (w == 1) mine.t_created = S.crtA;
+                else if (w >= 64) mine.t_created = NX.bag_ts[(size_t)lp * NX.bag_cap + (w - 64)];
+                else {
+#pragma unroll
+                    for (int i = 0; i < C; ++i) if (i == w - 2) mine.t_created = S.crtD[i];
+                }
+            }
+        }
+        store_net<C>(S, X, NX, lp, n);
+    }
+
+    unsigned vals[13];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) vals[k] = act ? S.ev[k] : 0u;
+    vals[11] = vals[6]; vals[12] = vals[7];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        const unsigned s = wave_sum<unsigned>(vals[k]);
+        if ((tid & 63) == 0 && s) atomicAdd(&red[k], (unsigned long long)s);
+    }
+    if (act) {
+        atomicMax(&red_time, (long long)S.last_time);
+        if (S.overflow) red_flags[0] = 1;
+        if (S.qoverflow) red_flags[1] = 1;
+        if (S.bagoverflow) red_flags[2] = 1;
+    }
+    if (merge_overflow) red_flags[2] = 1;
+    if (final_launch) {
+        const Candidate w = wave_min_cand(mine);
+        if ((tid & 63) == 0) wave_c[tid >> 6] = w;
+    }
+    __syncthreads();
+    if (tid < 11 && red[tid]) atomicAdd(&tot->ev[tid], red[tid]);
+    if (tid == 11 && red[11]) atomicAdd(&tot->completed, red[11]);
+    if (tid == 12 && red[12]) atomicAdd(&tot->received, red[12]);
+    if (tid == 13) {
+        if (red_time != INT64_MIN) atomicMax(&tot->final_time, red_time);
+        if (red_flags[0]) atomicOr(&tot->overflow, 1);
+        if (red_flags[1]) atomicOr(&tot->qoverflow, 1);
+        if (red_flags[2]) atomicOr(&tot->overflow, 2);
+    }
+    if (!final_launch) return;
+
+    if (tid == 0) {
+        Candidate b = wave_c[0];
+        for (int w = 1; w < kBlock / 64; ++w) if (cand_less(wave_c[w], b)) b = wave_c[w];
+        cands[blockIdx.x] = b;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned ticket = atomicAdd(&tot->done, 1u);
+        is_last = (ticket == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    Candidate best;
+    best.valid = 0; best.t = kInfNs; best.t_created = 0; best.lp = 0;
+    for (int b = tid; b < (int)gridDim.x; b += kBlock) {
+        Candidate c;
+        c.t = __hip_atomic_load(&cands[b].t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.t_created = __hip_atomic_load(&cands[b].t_created, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.lp = __hip_atomic_load(&cands[b].lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.valid = __hip_atomic_load(&cands[b].valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cand_less(c, best)) best = c;
+    }
+    best = wave_min_cand(best);
+    if ((tid & 63) == 0) wave_c[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        Candidate b = wave_c[0];
+        for (int w = 1; w < kBlock / 64; ++w) if (cand_less(wave_c[w], b)) b = wave_c[w];
+        long long new_cur = __hip_atomic_load(&tot->final_time, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b.valid) {
+            // the one event beyond end_time (core/simulation.py:472): first micro-event of the winner's next group
+            NetStation<C> W;
+            load_net<C>(W, P, NP, X, NX, L, b.lp, n, qmem, enqpay, 0, send_idx);
+            const int64_t t = W.next_time();
+            const int w = W.pick_root(t);
+            if (w == 1) (void)W.do_tick(t);
+            else if (w >= 64) (void)W.do_msg(w - 64, t);
+            else (void)W.do_cont_core(w - 2, t);
+            W.last_time = t;
+            store_net<C>(W, X, NX, b.lp, n);
+            for (int k = 0; k < 11; ++k) if (W.ev[k]) atomicAdd(&tot->ev[k], (unsigned long long)W.ev[k]);
+            if (W.ev[6]) atomicAdd(&tot->completed, (unsigned long long)W.ev[6]);
+            new_cur = b.t;
+            atomicMax(&tot->final_time, new_cur);
+        }
+        tot->cur_time = new_cur;
+        tot->done = 0;
+    }
+}
+
 __global__ void hs_debug_draws_kernel(uint64_t seed, uint64_t sid, uint64_t k0, int64_t n, double rate, double *u,
                                       double *e, int64_t *ns) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -361,6 +600,11 @@ struct hs_engine {
     RecordLogs L{};
     Totals *tot = nullptr;
     Candidate *cands = nullptr;
+    bool is_net = false;
+    NetParams NP{};
+    NetState NX{};
+    int64_t window_ns = 0;
+    bool net_ran = false;
     int n_blocks = 0;
     int flags = 0;
     double last_run_ms = 0.0, last_kernel_ms = 0.0;
@@ -426,11 +670,45 @@ void launch_run_dispatch(hs_engine *h, int64_t end_ns) {
     }
 }
 
+template <int C>
+void launch_net(hs_engine *h, int64_t wend, int win, int flags) {
+    hipLaunchKernelGGL(hs_net_window<C>, dim3(h->n_blocks), dim3(kBlock), 0, h->stream, h->P, h->NP, h->X, h->NX, h->L,
+                       h->tot, h->cands, h->cfg.n_lp, wend, win, flags);
+}
+void launch_net_dispatch(hs_engine *h, int64_t wend, int win, int flags) {
+    switch (h->C) {
+        case 1: launch_net<1>(h, wend, win, flags); break;
+        case 2: launch_net<2>(h, wend, win, flags); break;
+        default: launch_net<4>(h, wend, win, flags); break;
+    }
+}
+
+// EXECUTE / EXCHANGE / ADVANCE (parallel/coordinator.py:87-124) as a stream of window launches
+int run_net_async(hs_engine *h, int64_t end_ns) {
+    const int64_t W = h->window_ns;
+    int64_t t0 = h->cfg.start_ns;
+    int win = 0;
+    for (;;) {
+        int64_t wend = t0 + W - 1;
+        if (wend >= end_ns || wend < t0) wend = end_ns;
+        launch_net_dispatch(h, wend, win, h->flags & 1);
+        ++win;
+        if (wend >= end_ns) break;
+        t0 = wend + 1;
+    }
+    launch_net_dispatch(h, end_ns, win, (h->flags & 1) | 2);   // FINAL: merge the last window's messages, overshoot
+    HS_HIP(h, hipGetLastError());
+    h->launches += win + 1;
+    h->net_ran = true;
+    return HS_OK;
+}
+
 int do_reset_async(hs_engine *h) {
     hipLaunchKernelGGL(hs_station_reset, dim3(h->n_blocks), dim3(kBlock), 0, h->stream, h->P, h->X, h->tot,
-                       h->cfg.n_lp, h->C, h->cfg.start_ns);
+                       h->cfg.n_lp, h->C, h->cfg.start_ns, h->NX, h->is_net ? h->NP.n_links : 0);
     HS_HIP(h, hipGetLastError());
     h->initialised = true;
+    h->net_ran = false;
     return HS_OK;
 }
 
@@ -557,16 +835,135 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     AL(seq, N); AL(buf, N); AL(active, N);
     AL(generated, N); AL(accepted, N); AL(dropped, N); AL(completed, N); AL(rejected, N); AL(started, N);
     AL(received, N); AL(sink_w, N); AL(total_service, N); AL(q, N); AL(grp_time, N); AL(last_time, N);
-    AL(events, N); AL(ev_kind, N * 8);
+    AL(events, N); AL(ev_kind, N * 11);
 #undef AL
     if ((rc = dev_alloc(h, &h->L.adm, N * (size_t)cap))) return rc;
     if ((rc = dev_alloc(h, &h->L.sink_t, N * (size_t)cap))) return rc;
-    if (h->C > 1) { if ((rc = dev_alloc(h, &h->L.sink_created, N * (size_t)cap))) return rc; }
-    else h->L.sink_created = h->L.adm;
+    if (h->C > 1) {
+        // explicit created_at column: completions leave in a different order than admissions
+        if ((rc = dev_alloc(h, &h->L.sink_created_own, N * (size_t)cap))) return rc;
+    }
+    h->L.sink_created = (h->C > 1) ? h->L.sink_created_own : h->L.adm;
     if ((rc = dev_alloc(h, &h->tot, 1))) return rc;
     if ((rc = dev_alloc(h, &h->cands, (size_t)h->n_blocks))) return rc;
     HS_HIP(h, hipMemset(h->tot, 0, sizeof(Totals)));
     h->have_stations = true;
+    return HS_OK;
+}
+
+int hs_engine_set_network(hs_engine *h, const hs_network *net) {
+    if (!h || !net) return fail(h, HS_E_INVALID, "hs_engine_set_network: null argument");
+    if (!h->have_stations) return fail(h, HS_E_STATE, "set stations before the network");
+    if (h->is_net) return fail(h, HS_E_STATE, "network already set");
+    if (h->initialised) return fail(h, HS_E_STATE, "set the network before the first run");
+    if (h->cfg.mode != HS_MODE_SINGLE) return fail(h, HS_E_INVALID, "a network of stations is one Simulation: HS_MODE_SINGLE");
+    if (h->C > 4) return fail(h, HS_E_UNSUPPORTED, "networked stations support concurrency <= 4 for now");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    const int n = h->cfg.n_lp, nl = net->n_links;
+    if (nl < 0) return fail(h, HS_E_INVALID, "n_links < 0");
+    if (!net->egress_kind) return fail(h, HS_E_INVALID, "egress_kind is required");
+    if (nl > 0 && (!net->link_dst || !net->link_lat_min_s || !net->link_src))
+        return fail(h, HS_E_INVALID, "link_dst, link_src and link_lat_min_s are required");
+    // lookahead W = min over links of int(to_seconds(from_seconds(lat_min)) * 1e9) -- the same truncations the
+    // device applies (core/temporal.py:62,66)
+    int64_t W = INT64_MAX;
+    for (int l = 0; l < nl; ++l) {
+        const double lm = net->link_lat_min_s[l];
+        if (!(lm > 0.0) || !std::isfinite(lm))
+            return fail(h, HS_E_INVALID, "link %d: min latency must be > 0 (conservative windows need lookahead), got %g", l, lm);
+        const double lc = (double)(int64_t)(lm * 1e9) / 1e9;
+        const int64_t w = (int64_t)(lc * 1e9);
+        if (w <= 0) return fail(h, HS_E_INVALID, "link %d: min latency %g s truncates to 0 ns", l, lm);
+        if (w < W) W = w;
+        if (net->link_dst[l] < 0 || net->link_dst[l] >= n || net->link_src[l] < 0 || net->link_src[l] >= n)
+            return fail(h, HS_E_INVALID, "link %d: endpoint out of range", l);
+        const int jk = net->link_jitter_kind ? net->link_jitter_kind[l] : HS_LAT_CONSTANT;
+        if (jk == HS_LAT_EXPONENTIAL && !(net->link_jitter_mean_s && net->link_jitter_mean_s[l] > 0.0))
+            return fail(h, HS_E_INVALID, "link %d: exponential jitter needs mean > 0", l);
+        if (jk != HS_LAT_EXPONENTIAL && jk != HS_LAT_CONSTANT)
+            return fail(h, HS_E_UNSUPPORTED, "link %d: jitter kind %d is not lowered", l, jk);
+    }
+    std::vector<int32_t> rt0((size_t)n, -1), rt1((size_t)n, -1), lof((size_t)n, -1);
+    std::vector<uint8_t> link_used((size_t)(nl > 0 ? nl : 1), 0);
+    auto use_link = [&](int lp, int l) -> int {
+        if (l < 0 || l >= nl) return fail(h, HS_E_INVALID, "LP %d: link index %d out of range", lp, l);
+        if (net->link_src[l] != lp) return fail(h, HS_E_INVALID, "LP %d uses link %d whose source is LP %d", lp, l, net->link_src[l]);
+        if (link_used[(size_t)l]) return fail(h, HS_E_INVALID, "link %d is referenced twice", l);
+        link_used[(size_t)l] = 1;
+        return HS_OK;
+    };
+    for (int i = 0; i < n; ++i) {
+        const int ek = net->egress_kind[i];
+        int rc2;
+        if (ek == HS_EGRESS_ROUTER) {
+            if (!net->router_target0 || !net->router_target1) return fail(h, HS_E_INVALID, "router targets are required");
+            rt0[(size_t)i] = net->router_target0[i]; rt1[(size_t)i] = net->router_target1[i];
+            if (rt0[(size_t)i] >= 0 && (rc2 = use_link(i, rt0[(size_t)i]))) return rc2;
+            if (rt1[(size_t)i] >= 0 && (rc2 = use_link(i, rt1[(size_t)i]))) return rc2;
+            if (rt0[(size_t)i] < -1 || rt1[(size_t)i] < -1) return fail(h, HS_E_INVALID, "LP %d: bad router target", i);
+        } else if (ek == HS_EGRESS_LINK) {
+            if (!net->link_of) return fail(h, HS_E_INVALID, "link_of is required");
+            lof[(size_t)i] = net->link_of[i];
+            if ((rc2 = use_link(i, lof[(size_t)i]))) return rc2;
+        } else if (ek != HS_EGRESS_NONE && ek != HS_EGRESS_SINK) {
+            return fail(h, HS_E_UNSUPPORTED, "LP %d: egress kind %d is not lowered", i, ek);
+        }
+    }
+    if (nl == 0) W = h->cfg.horizon_ns - h->cfg.start_ns + 1;   // no links: one window
+    h->window_ns = W;
+    int rc;
+    std::vector<uint64_t> rbase((size_t)n), lbase((size_t)(nl > 0 ? nl : 1));
+    std::vector<uint64_t> sbase((size_t)n);
+    HS_HIP(h, hipMemcpy(sbase.data(), h->P.stream_base, (size_t)n * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) rbase[(size_t)i] = net->router_stream_base ? net->router_stream_base[i] : sbase[(size_t)i];
+    for (int l = 0; l < nl; ++l)
+        lbase[(size_t)l] = net->link_stream_base ? net->link_stream_base[l] : sbase[(size_t)net->link_src[l]];
+    const size_t NL = (size_t)(nl > 0 ? nl : 1);
+    std::vector<uint8_t> jk(NL, (uint8_t)HS_LAT_CONSTANT);
+    std::vector<double> jm(NL, 0.0), lmin(NL, 1.0);
+    std::vector<int32_t> ldst(NL, 0);
+    for (int l = 0; l < nl; ++l) {
+        jk[(size_t)l] = net->link_jitter_kind ? net->link_jitter_kind[l] : (uint8_t)HS_LAT_CONSTANT;
+        jm[(size_t)l] = net->link_jitter_mean_s ? net->link_jitter_mean_s[l] : 0.0;
+        lmin[(size_t)l] = net->link_lat_min_s[l];
+        ldst[(size_t)l] = net->link_dst[l];
+    }
+    if ((rc = upload<uint8_t>(h, &h->NP.egress, net->egress_kind, (size_t)n, 0))) return rc;
+    if ((rc = upload<int32_t>(h, &h->NP.rt0, rt0.data(), (size_t)n, -1))) return rc;
+    if ((rc = upload<int32_t>(h, &h->NP.rt1, rt1.data(), (size_t)n, -1))) return rc;
+    if ((rc = upload<int32_t>(h, &h->NP.link_of, lof.data(), (size_t)n, -1))) return rc;
+    if ((rc = upload<uint64_t>(h, &h->NP.route_base, rbase.data(), (size_t)n, 0))) return rc;
+    h->NP.n_links = nl;
+    if ((rc = upload<int32_t>(h, &h->NP.link_dst, ldst.data(), NL, 0))) return rc;
+    if ((rc = upload<double>(h, &h->NP.link_lat_min, lmin.data(), NL, 0.0))) return rc;
+    if ((rc = upload<uint8_t>(h, &h->NP.link_jit_kind, jk.data(), NL, 1))) return rc;
+    if ((rc = upload<double>(h, &h->NP.link_jit_mean, jm.data(), NL, 0.0))) return rc;
+    if ((rc = upload<uint64_t>(h, &h->NP.link_base, lbase.data(), NL, 0))) return rc;
+    const int bag = net->bag_capacity > 0 ? net->bag_capacity : 16;
+    h->NX.bag_cap = bag;
+    const size_t N = (size_t)n, NB = (size_t)n * (size_t)bag;
+#define ALN(field, count) if ((rc = dev_alloc(h, &h->NX.field, count))) return rc
+    ALN(route_k, N); ALN(routed, N); ALN(link_k, NL); ALN(link_in, NL); ALN(link_packets, NL); ALN(next_time, N);
+    ALN(bag_cnt, N); ALN(bag_t, NB); ALN(bag_ts, NB); ALN(bag_cr, NB); ALN(bag_link, NB);
+    ALN(in_cnt, 2 * N); ALN(in_t, 2 * NB); ALN(in_ts, 2 * NB); ALN(in_cr, 2 * NB); ALN(in_link, 2 * NB);
+#undef ALN
+    if (!h->L.sink_created_own) {   // not every completion reaches the Sink any more: explicit created_at column
+        if ((rc = dev_alloc(h, &h->L.sink_created_own, N * (size_t)h->L.cap))) return rc;
+    }
+    h->L.sink_created = h->L.sink_created_own;
+    h->is_net = true;
+    return HS_OK;
+}
+
+int hs_engine_get_net_stats(hs_engine *h, const hs_net_stats *o) {
+    if (!h || !o) return fail(h, HS_E_INVALID, "hs_engine_get_net_stats: null argument");
+    if (!h->is_net) return fail(h, HS_E_STATE, "no network set");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    const size_t n = (size_t)h->cfg.n_lp, nl = (size_t)h->NP.n_links;
+    if (o->routed) HS_HIP(h, hipMemcpy(o->routed, h->NX.routed, n * 8, hipMemcpyDeviceToHost));
+    if (o->link_entered && nl) HS_HIP(h, hipMemcpy(o->link_entered, h->NX.link_in, nl * 8, hipMemcpyDeviceToHost));
+    if (o->link_packets_sent && nl) HS_HIP(h, hipMemcpy(o->link_packets_sent, h->NX.link_packets, nl * 8, hipMemcpyDeviceToHost));
     return HS_OK;
 }
 
@@ -589,10 +986,16 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
     HS_HIP(h, hipEventRecord(h->ev_a, h->stream));
     if (!h->initialised) { int rc = do_reset_async(h); if (rc) return rc; h->launches++; }
     HS_HIP(h, hipEventRecord(h->ev_k0, h->stream));
-    launch_run_dispatch(h, end_ns);
-    HS_HIP(h, hipGetLastError());
+    if (h->is_net) {
+        if (h->net_ran) return fail(h, HS_E_STATE, "network engine: one hs_engine_run_until per hs_engine_reset");
+        int rc = run_net_async(h, end_ns);
+        if (rc) return rc;
+    } else {
+        launch_run_dispatch(h, end_ns);
+        HS_HIP(h, hipGetLastError());
+        h->launches++;
+    }
     HS_HIP(h, hipEventRecord(h->ev_k1, h->stream));
-    h->launches++;
     HS_HIP(h, hipEventRecord(h->ev_b, h->stream));
     return HS_OK;
 }
@@ -615,6 +1018,9 @@ int hs_engine_run_until(hs_engine *h, int64_t end_ns) {
     Totals t;
     HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
     if (t.qoverflow) return fail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
+    if (t.overflow & 2)
+        return fail(h, HS_E_OVERFLOW, "a station's in-flight message bag overflowed (capacity %d); raise bag_capacity",
+                    (int)h->NX.bag_cap);
     if (t.overflow)
         return fail(h, HS_E_OVERFLOW, "a per-LP record log overflowed (capacity %lld records)", (long long)h->L.cap);
     return HS_OK;
@@ -631,7 +1037,8 @@ int hs_engine_bench_runs(hs_engine *h, int64_t end_ns, int32_t repeats, float *k
         int rc = do_reset_async(h);
         if (rc) return rc;
         HS_HIP(h, hipEventRecord(ev[(size_t)2 * r], h->stream));
-        launch_run_dispatch(h, end_ns);
+        if (h->is_net) { h->launches = 0; int rc2 = run_net_async(h, end_ns); if (rc2) return rc2; }
+        else launch_run_dispatch(h, end_ns);
         HS_HIP(h, hipGetLastError());
         HS_HIP(h, hipEventRecord(ev[(size_t)2 * r + 1], h->stream));
     }
@@ -647,7 +1054,7 @@ int hs_engine_bench_runs(hs_engine *h, int64_t end_ns, int32_t repeats, float *k
     HS_HIP(h, hipEventElapsedTime(&tot_ms, ev[(size_t)repeats * 2], ev[(size_t)repeats * 2 + 1]));
     if (total_ms_out) *total_ms_out = tot_ms;
     h->last_run_ms = tot_ms / (float)repeats;
-    h->launches = 2;
+    if (!h->is_net) h->launches = 2;
     for (auto &e : ev) hipEventDestroy(e);
     return HS_OK;
 }
@@ -661,7 +1068,7 @@ int hs_engine_get_summary(hs_engine *h, hs_summary *out) {
     HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
     memset(out, 0, sizeof *out);
     int64_t total = 0;
-    for (int k = 0; k < 8; ++k) { out->events_by_kind[k] = (int64_t)t.ev[k]; total += (int64_t)t.ev[k]; }
+    for (int k = 0; k < HS_EV_KINDS; ++k) { out->events_by_kind[k] = (int64_t)t.ev[k]; total += (int64_t)t.ev[k]; }
     out->events_processed = total;
     out->events_cancelled = 0;
     out->final_time_ns = (h->cfg.mode == HS_MODE_SINGLE) ? t.cur_time : t.final_time;
@@ -670,6 +1077,7 @@ int hs_engine_get_summary(hs_engine *h, hs_summary *out) {
     out->last_run_ms = h->last_run_ms;
     out->kernel_ms = h->last_kernel_ms;
     out->launches = h->launches;
+    out->window_ns = h->window_ns;
     out->overflow = t.overflow;
     return HS_OK;
 }

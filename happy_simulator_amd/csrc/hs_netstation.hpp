@@ -1,0 +1,377 @@
+// hs_netstation.hpp -- station LPs that exchange requests over links: conservative time windows.
+//
+// Extends the station LP of hs_station.hpp to networks built from the reference's components:
+//
+//   [Source] -> Server_i -> { nothing | Sink_i | NetworkLink -> Server_j | RandomRouter([Sink_i | NetworkLink ...]) }
+//
+// (components/random_router.py:32-45, components/network/link.py:114-189).  This is the engine-side
+// replacement of the reference's partitioned execution (`parallel/coordinator.py:75-172`: EXECUTE all
+// partitions to T+W, EXCHANGE outboxes, ADVANCE), with one LP per lane instead of one partition per thread:
+//
+//   * A request travelling over a link is a MESSAGE {arrival ns, send ns, created_at ns, link}.  Its transit
+//     time is >= the link's constant latency, so with W = min over links of that latency every message sent
+//     inside a window [T, T+W) arrives at or after T+W: all LPs can process a whole window independently
+//     (`PartitionLink.min_latency > 0` plays the same role in the reference, parallel/link.py:41-45).
+//   * Messages are appended to the DESTINATION LP's incoming bag with one device-scope atomic slot
+//     reservation; bags are double-buffered by window parity, and the owner merges the previous window's
+//     bag at the start of the next launch (kernel boundary = the exchange barrier).
+//   * The link's continuation event (transit over) and the Request it creates at the egress Server both
+//     happen at the arrival timestamp; both are processed -- and counted -- by the destination LP.
+//
+// Same-timestamp order follows creation order as in hs_station.hpp; a message's creation stamp is its send
+// time.  Local events precede a message created in the same nanosecond (cross-LP creation order inside one
+// nanosecond is the one piece of the reference's global sort index that is not reconstructed).
+#pragma once
+
+#include "hs_station.hpp"
+
+namespace hs {
+
+enum : uint32_t { EG_NONE = 0, EG_SINK = 1, EG_LINK = 2, EG_ROUTER = 3 };
+
+struct NetParams {
+    const uint8_t *egress;        // [n_lp] EG_*
+    const int32_t *rt0, *rt1;     // [n_lp] router targets in RandomRouter(targets=[...]) order: -1 = the LP's Sink, else link
+    const int32_t *link_of;       // [n_lp] EG_LINK: the link
+    const uint64_t *route_base;   // [n_lp] stream base of the router entity
+    int32_t n_links;
+    const int32_t *link_dst;      // [n_links] destination LP
+    const double *link_lat_min;   // [n_links] ConstantLatency(latency) seconds
+    const uint8_t *link_jit_kind; // [n_links] 0 = ExponentialLatency jitter, 1 = no jitter
+    const double *link_jit_mean;  // [n_links]
+    const uint64_t *link_base;    // [n_links] stream base of the link entity
+};
+
+struct NetState {
+    uint64_t *route_k;            // [n_lp] route draws consumed
+    int64_t *routed;              // [n_lp] RandomRouter.stats_routed
+    uint64_t *link_k;             // [n_links] jitter draws consumed (touched only by the link's source LP)
+    int64_t *link_in;             // [n_links] requests that entered the link (Request@Link events)
+    int64_t *link_packets;        // [n_links] NetworkLink.packets_sent (touched only by the destination LP)
+    int64_t *next_time;           // [n_lp] earliest pending local event or bagged message
+    // current bag (owner only)
+    int32_t *bag_cnt;             // [n_lp]
+    int64_t *bag_t, *bag_ts, *bag_cr;   // [n_lp][bag_cap]
+    int32_t *bag_link;            // [n_lp][bag_cap]
+    // incoming bags, double-buffered by window parity: [2][n_lp] / [2][n_lp][bag_cap]
+    int32_t *in_cnt;
+    int64_t *in_t, *in_ts, *in_cr;
+    int32_t *in_link;
+    int32_t bag_cap;
+};
+
+constexpr int kEnqPay = 8;   // ENQ payload FIFO depth (general path only)
+
+template <int C>
+struct NetStation {
+    // parameters
+    int lp, n;
+    uint32_t src_kind, svc_kind, egress;
+    int32_t conc, rt0, rt1, link_of;
+    double rate, svc_lambda, svc_const_s;
+    int64_t stop_ns, qcap, svc_const_ns;
+    uint64_t seed, route_base;
+    // state
+    int64_t A, crtA, arr_time, buf, generated, accepted, dropped, completed, rejected, started, received, routed;
+    uint32_t seqA, seq;
+    int32_t active;
+    int64_t D[C], crtD[C], crt[C];
+    uint32_t seqD[C];
+    double svc_s[C];
+    double total_service;
+    int64_t last_time;
+    Stream arr, svc, rte;
+    uint32_t ev[11];
+    // logs
+    int64_t *adm, *sink_t, *sink_created;
+    int64_t cap;
+    int overflow, qoverflow, bagoverflow;
+    // network
+    const NetParams *np;
+    const NetState *ns;
+    int send_idx;
+    int32_t bag_n;
+    // in-group FIFO + ENQ payloads (LDS columns)
+    uint8_t (*qmem)[kBlock];
+    int64_t (*enqpay)[kBlock];
+    int tid, qh, qn, ph, pn;
+
+    __device__ __forceinline__ void qpush(uint32_t code) {
+        if (qn >= kQCap) { qoverflow = 1; return; }
+        qmem[(qh + qn) % kQCap][tid] = (uint8_t)code;
+        ++qn;
+    }
+    __device__ __forceinline__ uint32_t qpop() {
+        const uint32_t c = qmem[qh][tid];
+        qh = (qh + 1) % kQCap;
+        --qn;
+        return c;
+    }
+    __device__ __forceinline__ void push_enq(int64_t created) {
+        if (pn >= kEnqPay) { qoverflow = 1; return; }
+        enqpay[(ph + pn) % kEnqPay][tid] = created;
+        ++pn;
+        qpush(Q_ENQ);
+    }
+    __device__ __forceinline__ int64_t pop_enq_payload() {
+        const int64_t v = enqpay[ph][tid];
+        ph = (ph + 1) % kEnqPay;
+        --pn;
+        return v;
+    }
+
+    // ---- bag (pending inbound messages of this LP; global memory, owner-only)
+    __device__ __forceinline__ size_t bidx(int i) const { return (size_t)lp * ns->bag_cap + i; }
+    __device__ __forceinline__ int64_t bag_min() const {
+        int64_t m = kInfNs;
+        for (int i = 0; i < bag_n; ++i) { const int64_t t = ns->bag_t[bidx(i)]; m = t < m ? t : m; }
+        return m;
+    }
+    __device__ __forceinline__ void bag_remove(int i) {
+        const int last = bag_n - 1;
+        if (i != last) {
+            ns->bag_t[bidx(i)] = ns->bag_t[bidx(last)]; ns->bag_ts[bidx(i)] = ns->bag_ts[bidx(last)];
+            ns->bag_cr[bidx(i)] = ns->bag_cr[bidx(last)]; ns->bag_link[bidx(i)] = ns->bag_link[bidx(last)];
+        }
+        bag_n = last;
+    }
+
+    __device__ __forceinline__ int64_t next_arrival() {
+        double area;
+        if (src_kind == 1) area = exp1_from_uniform(arr.next_uniform());
+        else area = 1.0;
+        const double t_next = __dadd_rn(seconds_from_ns(arr_time), __ddiv_rn(area, rate));
+        arr_time = ns_from_seconds(t_next);
+        return arr_time;
+    }
+    __device__ __forceinline__ void sample_service(double &s, int64_t &dur_ns) {
+        if (svc_kind == 0) {
+            const double sample = __ddiv_rn(exp1_from_uniform(svc.next_uniform()), svc_lambda);
+            s = seconds_from_ns(ns_from_seconds(sample));
+            dur_ns = ns_from_seconds(s);
+        } else { s = svc_const_s; dur_ns = svc_const_ns; }
+    }
+
+    // ---- handlers (see hs_station.hpp for the reference citations of the shared ones)
+    __device__ __forceinline__ uint32_t do_tick(int64_t t) {
+        ev[0]++; generated++;
+        const bool payload = !(stop_ns >= 0 && t > stop_ns);
+        const int64_t a2 = next_arrival();
+        uint32_t r = payload ? 1u : 0u;
+        if (a2 == t) { r |= 2u; A = kInfNs; }
+        else if (a2 < t) { A = kInfNs; }
+        else { A = a2; seqA = seq++; crtA = t; }
+        return r;
+    }
+    __device__ __forceinline__ bool do_enqueue(int64_t t, int64_t created) {
+        (void)t;
+        ev[1]++;
+        if (qcap >= 0 && buf >= qcap) { dropped++; return false; }
+        const bool was_empty = (buf == 0);
+        if (accepted < cap) adm[accepted] = created; else overflow = 1;
+        accepted++; buf++;
+        return was_empty;
+    }
+    __device__ __forceinline__ bool do_notify() { ev[2]++; return active < conc; }
+    __device__ __forceinline__ bool do_poll() {
+        ev[3]++;
+        if (buf == 0) return false;
+        buf--;
+        return true;
+    }
+    // `known_created`: created_at of the head request when the caller still has it in a register (the request
+    // that was enqueued by this very chain into an empty buffer); otherwise it is read back from the log.
+    __device__ __forceinline__ uint32_t do_deliver_work(int64_t t, bool have_created, int64_t known_created) {
+        ev[4]++; ev[5]++;
+        const int64_t k = started++;
+        if (active >= conc) { rejected++; return 0; }
+        active++;
+        double s; int64_t dur;
+        sample_service(s, dur);
+        const int64_t created = have_created ? known_created : ((k < cap) ? adm[k] : 0);
+        int j = 0;
+#pragma unroll
+        for (int i = C - 1; i >= 0; --i) if (D[i] == kInfNs) j = i;
+        const int64_t d = t + dur;
+        uint32_t same = 0;
+#pragma unroll
+        for (int i = 0; i < C; ++i) if (i == j) {
+            svc_s[i] = s; crt[i] = created;
+            if (d == t) { D[i] = kInfNs - 1; same = (uint32_t)i + 1; }
+            else { D[i] = d; seqD[i] = seq++; crtD[i] = t; }
+        }
+        return same;
+    }
+
+    // NetworkLink.handle_event up to its yield (components/network/link.py:114-154, _calculate_delay :190-216)
+    // executed for a request that enters link `l` at time t; the continuation becomes a message to the egress LP.
+    __device__ __forceinline__ void send_link(int32_t l, int64_t t, int64_t created) {
+        ev[8]++;
+        ns->link_in[l]++;
+        double delay = seconds_from_ns(ns_from_seconds(np->link_lat_min[l]));          // ConstantLatency
+        if (np->link_jit_kind[l] == 0) {
+            Stream js;
+            js.init(seed, stream_id(np->link_base[l], kStreamLink), ns->link_k[l]);
+            ns->link_k[l]++;
+            const double lam = __ddiv_rn(1.0, np->link_jit_mean[l]);
+            const double sample = __ddiv_rn(exp1_from_uniform(js.next_uniform()), lam);
+            delay = __dadd_rn(delay, seconds_from_ns(ns_from_seconds(sample)));        // + jitter
+        }
+        if (!(delay > 0.0)) delay = 0.0;                                               // max(0.0, delay)
+        const int64_t t_arr = t + ns_from_seconds(delay);
+        const int32_t dst = np->link_dst[l];
+        const size_t cslot = (size_t)send_idx * n + dst;
+        const int pos = atomicAdd(&ns->in_cnt[cslot], 1);
+        if (pos < ns->bag_cap) {
+            const size_t b = cslot * ns->bag_cap + pos;
+            ns->in_t[b] = t_arr; ns->in_ts[b] = t; ns->in_cr[b] = created; ns->in_link[b] = l;
+        } else bagoverflow = 1;
+    }
+
+    // generator resumes (server/server.py:252-273): statistics only
+    __device__ __forceinline__ int64_t do_cont_core(int slot, int64_t t) {
+        (void)t;
+        ev[6]++;
+        double s = 0.0; int64_t cr = 0;
+#pragma unroll
+        for (int i = 0; i < C; ++i) if (i == slot) { s = svc_s[i]; cr = crt[i]; D[i] = kInfNs; }
+        active = active > 0 ? active - 1 : 0;
+        completed++;
+        total_service = __dadd_rn(total_service, s);
+        return cr;
+    }
+    // the forwarded request's way out of the LP: Sink / RandomRouter / NetworkLink (all at time t)
+    __device__ __forceinline__ void do_egress(int64_t t, int64_t created) {
+        int32_t target = -2;             // -2 nothing, -1 sink, >= 0 link
+        if (egress == EG_SINK) target = -1;
+        else if (egress == EG_LINK) target = link_of;
+        else if (egress == EG_ROUTER) {  // RandomRouter.handle_event (components/random_router.py:32-45)
+            ev[10]++; routed++;
+            const double u = rte.next_uniform();
+            const int idx = (int)__dmul_rn(u, 2.0);
+            target = idx == 0 ? rt0 : rt1;
+        }
+        if (target == -1) {              // Sink.handle_event (components/common.py:36-44)
+            ev[7]++;
+            if (received < cap) { sink_t[received] = t; sink_created[received] = created; } else overflow = 1;
+            received++;
+        } else if (target >= 0) send_link(target, t, created);
+    }
+    // full continuation: statistics, egress chain, schedule_poll hook.  Returns true if QUEUE_POLL is created.
+    __device__ __forceinline__ bool do_cont(int slot, int64_t t) {
+        const int64_t cr = do_cont_core(slot, t);
+        do_egress(t, cr);
+        return active < conc;
+    }
+    // NetworkLink continuation at the egress side (link.py:156-189): transit over, a new Request for the Server
+    __device__ __forceinline__ int64_t do_msg(int i, int64_t t) {
+        (void)t;
+        ev[9]++;
+        const int64_t created = ns->bag_cr[bidx(i)];
+        ns->link_packets[ns->bag_link[bidx(i)]]++;
+        bag_remove(i);
+        return created;
+    }
+
+    __device__ __forceinline__ bool chain_from_poll(int64_t t, bool have_created, int64_t created) {
+        if (!do_poll()) return false;
+        const uint32_t same = do_deliver_work(t, have_created, created);
+        if (same) { qpush(Q_CONT | ((same - 1) << 3)); return true; }
+        return false;
+    }
+
+    // ---- general path ----------------------------------------------------------------------
+    __device__ __forceinline__ void root_tick(int64_t t) {
+        const uint32_t r = do_tick(t);
+        if (r & 1u) push_enq(t);
+        if (r & 2u) qpush(Q_TICK);
+    }
+    __device__ __forceinline__ void root_cont(int slot, int64_t t) { if (do_cont(slot, t)) qpush(Q_POLL); }
+    __device__ __forceinline__ void root_msg(int i, int64_t t) { push_enq(do_msg(i, t)); }
+
+    // pending root at time t with the earliest creation: 0 none, 1 tick, 2+slot departure, 64+i message
+    __device__ __forceinline__ int pick_root(int64_t t) const {
+        int best = 0; int64_t bc = 0; uint32_t bs = 0; bool bmsg = false; int64_t bl = 0;
+        if (A == t) { best = 1; bc = crtA; bs = seqA; }
+#pragma unroll
+        for (int i = 0; i < C; ++i)
+            if (D[i] == t && (best == 0 || (int32_t)(seqD[i] - bs) < 0)) { best = 2 + i; bc = crtD[i]; bs = seqD[i]; }
+        for (int i = 0; i < bag_n; ++i) {
+            if (ns->bag_t[bidx(i)] != t) continue;
+            const int64_t ts = ns->bag_ts[bidx(i)];
+            const int64_t ln = ns->bag_link[bidx(i)];
+            bool better;
+            if (best == 0) better = true;
+            else if (!bmsg) better = ts < bc;                       // local event first on equal creation time
+            else better = (ts < bc) || (ts == bc && ln < bl);
+            if (better) { best = 64 + i; bc = ts; bmsg = true; bl = ln; }
+        }
+        return best;
+    }
+    __device__ __forceinline__ void run_root(int w, int64_t t) {
+        if (w == 1) root_tick(t);
+        else if (w >= 64) root_msg(w - 64, t);
+        else root_cont(w - 2, t);
+    }
+    __device__ __forceinline__ void drain(int64_t t) {
+        while (qn > 0) {
+            const uint32_t code = qpop();
+            switch (code & 7u) {
+                case Q_ENQ: if (do_enqueue(t, pop_enq_payload())) qpush(Q_NOTIFY); break;
+                case Q_NOTIFY: if (do_notify()) qpush(Q_POLL); break;
+                case Q_POLL: if (do_poll()) qpush(Q_DELIVER); break;
+                case Q_DELIVER: { const uint32_t sm = do_deliver_work(t, false, 0); if (sm) qpush(Q_CONT | ((sm - 1) << 3)); } break;
+                case Q_TICK: root_tick(t); break;
+                case Q_CONT: root_cont((int)(code >> 3), t); break;
+                default: break;
+            }
+        }
+    }
+    __device__ __forceinline__ void run_group_general(int64_t t) {
+        for (;;) { const int w = pick_root(t); if (w == 0) break; run_root(w, t); }
+        drain(t);
+    }
+
+    __device__ __forceinline__ int64_t next_local() const {
+        int64_t t = A;
+#pragma unroll
+        for (int i = 0; i < C; ++i) t = D[i] < t ? D[i] : t;
+        return t;
+    }
+    __device__ __forceinline__ int64_t next_time() const { const int64_t a = next_local(), b = bag_min(); return a < b ? a : b; }
+
+    __device__ __forceinline__ void run_group(int64_t t, bool force_general) {
+        int n_at = (A == t) ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < C; ++i) n_at += (D[i] == t) ? 1 : 0;
+        int mi = -1;
+        for (int i = 0; i < bag_n; ++i) if (ns->bag_t[bidx(i)] == t) { ++n_at; mi = i; }
+        if (n_at == 1 && !force_general) {
+            bool general = false, want_poll = false, have_created = false;
+            int64_t created = 0;
+            if (A == t) {
+                const uint32_t r = do_tick(t);
+                if (r & 2u) { if (r & 1u) push_enq(t); qpush(Q_TICK); general = true; }
+                else if (r & 1u) { want_poll = do_enqueue(t, t) && do_notify(); have_created = true; created = t; }
+            } else if (mi >= 0) {
+                created = do_msg(mi, t);
+                want_poll = do_enqueue(t, created) && do_notify();
+                have_created = true;
+            } else {
+                int slot = 0;
+#pragma unroll
+                for (int i = 0; i < C; ++i) if (D[i] == t) slot = i;
+                want_poll = do_cont(slot, t);
+            }
+            // `have_created` is only valid when the buffer was empty before this chain's enqueue, which is exactly
+            // when do_enqueue returned true (was_empty) -- the only way want_poll is set on the arrival branches.
+            if (want_poll) general = chain_from_poll(t, have_created, created);
+            if (general) drain(t);
+        } else {
+            run_group_general(t);
+        }
+        last_time = t;
+    }
+};
+
+}  // namespace hs

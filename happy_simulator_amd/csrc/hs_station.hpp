@@ -66,18 +66,19 @@ struct StationState {           // read-write; [n_lp] each unless noted
     int64_t *grp_time;          // timestamp of that pending group
     int64_t *last_time;         // time of the LP's last processed event
     int64_t *events;            // events processed by this LP
-    int64_t *ev_kind;           // [HS_EV_KINDS][n_lp]
+    int64_t *ev_kind;           // [HS_EV_KINDS = 11][n_lp]
 };
 
 struct RecordLogs {
     int64_t *adm;               // [n_lp][cap] created_at of the k-th accepted request (FIFO backing store)
     int64_t *sink_t;            // [n_lp][cap] completion time of the m-th sink record
     int64_t *sink_created;      // [n_lp][cap] created_at of the m-th sink record (C > 1; C == 1 aliases adm)
+    int64_t *sink_created_own;  // the separately allocated column (null when the alias is the only option)
     int64_t cap;
 };
 
 struct Totals {                 // engine-wide accumulators (device memory)
-    unsigned long long ev[8];
+    unsigned long long ev[11];
     unsigned long long completed;
     unsigned long long received;
     long long final_time;       // max over LPs of last processed time (REPLICAS) / global current time (SINGLE)

@@ -41,6 +41,28 @@ class StationArrays:
         )
 
 
+@dataclass
+class NetworkArrays:
+    """Links / routers between stations (see include/hs_engine.h `hs_network`)."""
+
+    egress_kind: np.ndarray            # [n] N.EGRESS_*
+    router_target0: np.ndarray         # [n] -1 = the station's Sink, >= 0 = link index
+    router_target1: np.ndarray
+    link_of: np.ndarray                # [n] link index for EGRESS_LINK
+    link_src: np.ndarray               # [n_links]
+    link_dst: np.ndarray
+    link_lat_min_s: np.ndarray
+    link_jitter_kind: np.ndarray       # N.LAT_EXPONENTIAL (jitter) | N.LAT_CONSTANT (none)
+    link_jitter_mean_s: np.ndarray
+    router_stream_base: np.ndarray | None = None
+    link_stream_base: np.ndarray | None = None
+    bag_capacity: int = 0
+
+    @property
+    def n_links(self) -> int:
+        return int(len(self.link_dst))
+
+
 class EngineSummary:
     def __init__(self, s: N.Summary):
         self.events_processed = int(s.events_processed)
@@ -52,6 +74,7 @@ class EngineSummary:
         self.last_run_ms = float(s.last_run_ms)
         self.kernel_ms = float(s.kernel_ms)
         self.launches = int(s.launches)
+        self.window_ns = int(s.window_ns)
         self.overflow = bool(s.overflow)
 
 
@@ -59,7 +82,7 @@ class StationEngine:
     """GPU-resident engine for `n` station LPs on one device."""
 
     def __init__(self, stations: StationArrays, *, mode: int, horizon_ns: int, start_ns: int = 0, seed: int = 42,
-                 lp_base: int = 0, device: int = 0, log_capacity: int = 0):
+                 lp_base: int = 0, device: int = 0, log_capacity: int = 0, network: "NetworkArrays | None" = None):
         self._lib = N.lib()
         if self._lib.hs_device_count() <= 0:
             raise N.EngineUnavailable("no HIP device visible: the engine has no CPU fallback")
@@ -83,11 +106,54 @@ class StationEngine:
                 raise ValueError(f"{name} must have shape ({self.n},)")
             keep.append(a)
             setattr(st, name, a.ctypes.data)
+        self.n_links = 0
         try:
             self._check(self._lib.hs_engine_set_stations(self._h, C.byref(st)))
+            if network is not None:
+                self._set_network(network)
         except Exception:
             self.close()
             raise
+
+    def _set_network(self, net: "NetworkArrays"):
+        nw = N.Network()
+        keep = []
+
+        def put(name, arr, dtype, length):
+            if arr is None:
+                setattr(nw, name, None)
+                return
+            a = np.ascontiguousarray(arr, dtype)
+            if a.shape != (length,):
+                raise ValueError(f"{name} must have shape ({length},)")
+            keep.append(a)
+            setattr(nw, name, a.ctypes.data if length else None)
+
+        nl = net.n_links
+        put("egress_kind", net.egress_kind, np.uint8, self.n)
+        put("router_target0", net.router_target0, np.int32, self.n)
+        put("router_target1", net.router_target1, np.int32, self.n)
+        put("link_of", net.link_of, np.int32, self.n)
+        put("router_stream_base", net.router_stream_base, np.uint64, self.n)
+        nw.n_links = nl
+        put("link_dst", net.link_dst, np.int32, nl)
+        put("link_src", net.link_src, np.int32, nl)
+        put("link_lat_min_s", net.link_lat_min_s, np.float64, nl)
+        put("link_jitter_kind", net.link_jitter_kind, np.uint8, nl)
+        put("link_jitter_mean_s", net.link_jitter_mean_s, np.float64, nl)
+        put("link_stream_base", net.link_stream_base, np.uint64, nl)
+        nw.bag_capacity = int(net.bag_capacity)
+        self._check(self._lib.hs_engine_set_network(self._h, C.byref(nw)))
+        self.n_links = nl
+
+    def net_stats(self) -> dict:
+        out = {"routed": np.zeros(self.n, np.int64), "link_entered": np.zeros(max(self.n_links, 1), np.int64),
+               "link_packets_sent": np.zeros(max(self.n_links, 1), np.int64)}
+        st = N.NetStats(**{k: v.ctypes.data for k, v in out.items()})
+        self._check(self._lib.hs_engine_get_net_stats(self._h, C.byref(st)))
+        out["link_entered"] = out["link_entered"][:self.n_links]
+        out["link_packets_sent"] = out["link_packets_sent"][:self.n_links]
+        return out
 
     # -- error plumbing ------------------------------------------------------------------------
     def _check(self, rc: int, create: bool = False):

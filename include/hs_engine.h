@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HS_ABI_VERSION 1
+#define HS_ABI_VERSION 2
 
 typedef enum hs_status {
     HS_OK = 0,
@@ -52,8 +52,15 @@ typedef enum hs_latency_kind {
     HS_LAT_CONSTANT = 1,
     HS_LAT_NO_SERVER = 2   /* svc_kind only: the LP has no Server, its Source feeds the Sink/Counter directly */
 } hs_latency_kind;
-/* Server(downstream=...) */
-typedef enum hs_egress_kind { HS_EGRESS_NONE = 0, HS_EGRESS_SINK = 1 } hs_egress_kind;
+/* Server(downstream=...): nothing, a Sink-like collector, a NetworkLink to another station's Server
+ * (components/network/link.py:114), or a RandomRouter over {the station's Sink, NetworkLinks}
+ * (components/random_router.py:9).  LINK and ROUTER need hs_engine_set_network. */
+typedef enum hs_egress_kind {
+    HS_EGRESS_NONE = 0,
+    HS_EGRESS_SINK = 1,
+    HS_EGRESS_LINK = 2,
+    HS_EGRESS_ROUTER = 3
+} hs_egress_kind;
 
 /* reference-equivalent event kinds counted by the engine */
 enum {
@@ -65,7 +72,10 @@ enum {
     HS_EV_WORK = 5,         /* Request @ worker (handle_queued_event start) */
     HS_EV_CONTINUATION = 6, /* ProcessContinuation @ worker                 */
     HS_EV_SINK = 7,         /* Request @ Sink                               */
-    HS_EV_KINDS = 8
+    HS_EV_LINK = 8,         /* Request @ NetworkLink (transit starts)       */
+    HS_EV_LINK_CONT = 9,    /* ProcessContinuation @ NetworkLink (transit over) */
+    HS_EV_ROUTE = 10,       /* Request @ RandomRouter                       */
+    HS_EV_KINDS = 11
 };
 
 typedef struct hs_config {
@@ -99,6 +109,32 @@ typedef struct hs_stations {
     const uint64_t *stream_base;       /* per-LP stream id base; NULL = cfg.lp_base + i */
 } hs_stations;
 
+/* Links between stations (the engine-side form of the reference's partition links, parallel/link.py:18-79,
+ * and of `NetworkLink(latency=ConstantLatency(lat_min), jitter=ExponentialLatency(jitter_mean) | None,
+ * egress=<Server of station dst>)`).  The smallest constant latency over all links is the lookahead W of the
+ * conservative time windows; it must be > 0 (the reference enforces min_latency > 0 the same way). */
+typedef struct hs_network {
+    const uint8_t *egress_kind;      /* [n_lp] hs_egress_kind; replaces hs_stations.egress */
+    const int32_t *router_target0;   /* [n_lp] RandomRouter targets in constructor order: -1 = the station's Sink, */
+    const int32_t *router_target1;   /* [n_lp]   >= 0 = link index; used when egress_kind == HS_EGRESS_ROUTER */
+    const int32_t *link_of;          /* [n_lp] link index when egress_kind == HS_EGRESS_LINK */
+    const uint64_t *router_stream_base; /* [n_lp] NULL = the station's stream base */
+    int32_t n_links;
+    const int32_t *link_dst;         /* [n_links] destination station (its Server) */
+    const double *link_lat_min_s;    /* [n_links] ConstantLatency seconds, > 0 */
+    const uint8_t *link_jitter_kind; /* [n_links] HS_LAT_EXPONENTIAL = exponential jitter, HS_LAT_CONSTANT = none */
+    const double *link_jitter_mean_s;/* [n_links] */
+    const uint64_t *link_stream_base;/* [n_links] NULL = stream base of the source station */
+    const int32_t *link_src;         /* [n_links] source station (for the default stream base and validation) */
+    int32_t bag_capacity;            /* in-flight messages per destination station; 0 = 16 */
+} hs_network;
+
+typedef struct hs_net_stats {
+    int64_t *routed;                 /* [n_lp]    RandomRouter.stats_routed            components/random_router.py:36 */
+    int64_t *link_entered;           /* [n_links] requests that entered the link (Request@Link events) */
+    int64_t *link_packets_sent;      /* [n_links] NetworkLink.packets_sent             components/network/link.py:162 */
+} hs_net_stats;
+
 typedef struct hs_summary {
     /* SimulationSummary fields (instrumentation/summary.py:47-87), engine-wide */
     int64_t events_processed;              /* total_events_processed */
@@ -109,8 +145,9 @@ typedef struct hs_summary {
     int64_t sink_records;                  /* sum of Sink.events_received */
     /* engine telemetry */
     double last_run_ms;                    /* device time of the last hs_engine_run_until (HIP events) */
-    double kernel_ms;                      /* device time of the dominant kernel (hs_station_run) in that call */
-    int64_t launches;                      /* kernel launches in the last run */
+    double kernel_ms;                      /* device time of the dominant kernel(s) in that call */
+    int64_t launches;                      /* kernel launches in the last run (network engine: windows + 1) */
+    int64_t window_ns;                     /* network engine: lookahead W; 0 otherwise */
     int32_t overflow;                      /* 1 if a record log overflowed */
     int32_t reserved;
 } hs_summary;
@@ -138,6 +175,11 @@ int hs_device_count(void);
 
 int hs_engine_create(const hs_config *cfg, hs_engine **out);
 int hs_engine_set_stations(hs_engine *h, const hs_stations *st);
+/* Optional, after hs_engine_set_stations and before the first run: connect stations with links / routers.
+ * Requires HS_MODE_SINGLE.  The engine then advances in conservative windows of W = min link latency; one
+ * hs_engine_run_until per hs_engine_reset (windows are internal, the call is not re-entrant). */
+int hs_engine_set_network(hs_engine *h, const hs_network *net);
+int hs_engine_get_net_stats(hs_engine *h, const hs_net_stats *out);
 /* Simulation.__init__ bootstrap (core/simulation.py:145-154): clock to start_ns, every Source draws its
  * first arrival.  Called implicitly by the first run; call again to rewind the engine for another run. */
 int hs_engine_reset(hs_engine *h);

@@ -187,3 +187,45 @@ def oracle_per_chain(spec, runs):
                 out["sink_received"][c] = r.received[snk]
                 sinks[c] = r.sinks[snk]
     return out, sinks
+
+
+def ring_engine_for_spec(spec, flags=0, bag_capacity=0, log_capacity=0):
+    """StationEngine for a ring spec: station i = Source_i -> Server_i -> RandomRouter_i([Sink_i, Link_i -> Server_{i+1}])."""
+    from happy_simulator_amd import _native as N
+    from happy_simulator_amd.engine import NetworkArrays, StationArrays, StationEngine
+
+    p = ring_params(spec)
+    n = p["n"]
+    rates = np.array(p["ext_rate"], np.float64)
+    st = StationArrays(
+        n=n,
+        src_kind=np.where(rates > 0, N.SRC_POISSON, N.SRC_NONE).astype(np.uint8),
+        src_rate=np.where(rates > 0, rates, 1.0),
+        src_stop_after_ns=np.full(n, -1, np.int64),
+        concurrency=np.full(n, p["conc"], np.int32),
+        svc_kind=np.full(n, N.LAT_EXPONENTIAL, np.uint8),
+        svc_mean_s=np.full(n, p["mean"], np.float64),
+        queue_cap=np.full(n, p["qcap"], np.int64),
+        egress=np.full(n, N.EGRESS_SINK, np.uint8),
+    )
+    jit = p["jitter_mean"]
+    net = NetworkArrays(
+        egress_kind=np.full(n, N.EGRESS_ROUTER, np.uint8),
+        router_target0=np.full(n, -1, np.int32),             # targets=[sink_i, link_i]
+        router_target1=np.arange(n, dtype=np.int32),
+        link_of=np.full(n, -1, np.int32),
+        link_src=np.arange(n, dtype=np.int32),
+        link_dst=((np.arange(n) + 1) % n).astype(np.int32),
+        link_lat_min_s=np.full(n, p["lat_min"], np.float64),
+        link_jitter_kind=np.full(n, N.LAT_CONSTANT if jit is None else N.LAT_EXPONENTIAL, np.uint8),
+        link_jitter_mean_s=np.full(n, 0.0 if jit is None else jit, np.float64),
+        bag_capacity=bag_capacity,
+    )
+    # external rate 4/s + forwarded 4/s per station: size the logs for the total admission rate
+    horizon_s = p["end_ns"] / 1e9
+    lam = 2.0 * float(rates.max()) + 1.0
+    cap = log_capacity or int(lam * horizon_s + 10 * (lam * horizon_s) ** 0.5 + 64)
+    eng = StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=p["end_ns"], seed=spec["seed"], log_capacity=cap, network=net)
+    if flags:
+        eng.set_debug_flags(flags)
+    return eng, p

@@ -27,9 +27,9 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_abi_version_and_struct_sizes(lib):
-    assert lib.hs_abi_version() == 1
+    assert lib.hs_abi_version() == N.ABI_VERSION == 2
     assert C.sizeof(N.Config) == 56
-    assert C.sizeof(N.Summary) == 8 * (1 + 8 + 1 + 1 + 1 + 1) + 8 + 8 + 8 + 8
+    assert C.sizeof(N.Summary) == 8 * (1 + 11 + 1 + 1 + 1 + 1) + 8 + 8 + 8 + 8 + 8
 
 
 def test_no_gpu_means_loud_failure(lib):

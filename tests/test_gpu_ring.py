@@ -1,0 +1,115 @@
+"""GPU: networks of stations (Server -> RandomRouter -> [Sink | NetworkLink -> next Server]) on the windowed
+engine, against the live-reference ring goldens and the C oracle.  Bit-exact: totals, per-kind histogram, final
+time, every per-station statistic, router / link counters, every Sink record."""
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import hs_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_against_oracle(spec, eng, r, nodes):
+    s = eng.summary()
+    st = eng.lp_stats()
+    ns = eng.net_stats()
+    assert s.events_processed == r.events_processed
+    np.testing.assert_array_equal(s.events_by_kind, r.events_by_kind)
+    assert s.final_time_ns == r.final_time_ns
+    n = spec["n"]
+    srv = [nodes[i]["srv"] for i in range(n)]
+    src = [nodes[i]["src"] for i in range(n)]
+    np.testing.assert_array_equal(st["generated"], [r.generated[x] if x >= 0 else 0 for x in src])
+    for k, arr in (("accepted", r.accepted), ("dropped", r.dropped), ("completed", r.completed),
+                   ("rejected", r.rejected), ("queue_depth", r.depth), ("active", r.active),
+                   ("total_service_s", r.total_service_s)):
+        np.testing.assert_array_equal(st[k], arr[srv], err_msg=k)
+    np.testing.assert_array_equal(ns["routed"], r.routed[[nodes[i]["rtr"] for i in range(n)]])
+    np.testing.assert_array_equal(ns["link_packets_sent"], r.packets_sent[[nodes[i]["lnk"] for i in range(n)]])
+    counts, t, cr = eng.read_sinks()
+    off = 0
+    for i in range(n):
+        ot, ocr = r.sinks[nodes[i]["snk"]]
+        assert counts[i] == len(ot), i
+        np.testing.assert_array_equal(t[off:off + counts[i]], ot, err_msg=f"sink t {i}")
+        np.testing.assert_array_equal(cr[off:off + counts[i]], ocr, err_msg=f"sink created {i}")
+        off += counts[i]
+
+
+@pytest.mark.parametrize("name", H.golden_names("ring"))
+def test_ring_engine_matches_reference_golden(name):
+    gold = H.Golden(name)
+    spec = gold.spec
+    eng, p = H.ring_engine_for_spec(spec)
+    with eng:
+        eng.run_until(p["end_ns"])
+        s = eng.summary()
+        st = eng.lp_stats()
+        ns = eng.net_stats()
+        assert s.events_processed == gold.meta["total_events"][0]
+        assert s.final_time_ns == gold.meta["final_ns"][0]
+        assert s.window_ns > 0 and s.launches > 1
+        if "trace" in gold.arrays:
+            np.testing.assert_array_equal(s.events_by_kind, np.bincount(gold.trace[:, 1], minlength=11)[:11])
+        for k, g in (("generated", "generated"), ("accepted", "accepted"), ("dropped", "dropped"),
+                     ("completed", "completed"), ("rejected", "rejected"), ("sink_received", "received"),
+                     ("queue_depth", "depth"), ("active", "active"), ("total_service_s", "total_service_s")):
+            np.testing.assert_array_equal(st[k], gold.arrays[g], err_msg=k)
+        np.testing.assert_array_equal(ns["routed"], gold.routed)
+        np.testing.assert_array_equal(ns["link_packets_sent"], gold.packets_sent)
+        counts, t, cr = eng.read_sinks()
+        np.testing.assert_array_equal(t, gold.sink_t_ns)
+        np.testing.assert_array_equal((t - cr).astype(np.float64) / 1e9, gold.sink_latency_s)
+
+
+RING_SWEEP = [
+    dict(name="ring_1024", topology="ring", n=1024, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, end_s=10.0, seed=11),
+    dict(name="ring_300_c2_cap", topology="ring", n=300, ext_rate=9.0, mean=0.1, concurrency=2, queue_cap=4, lat_min=0.002,
+         jitter_mean=0.004, end_s=6.0, seed=12),
+    dict(name="ring_257_fixed_latency", topology="ring", n=257, ext_rate=4.0, mean=0.1, lat_min=0.0025, jitter_mean=None,
+         end_s=8.0, seed=13),
+    dict(name="ring_2_dense", topology="ring", n=2, ext_rate=4.5, mean=0.1, lat_min=0.0001, jitter_mean=0.0005, end_s=4.0,
+         seed=14),
+]
+
+
+@pytest.mark.parametrize("spec", RING_SWEEP, ids=[s["name"] for s in RING_SWEEP])
+def test_ring_engine_matches_oracle(spec):
+    g, nodes = H.oracle_ring_graph(spec)
+    r = O.run(g, H.ns_from_seconds(spec["end_s"]), seed=spec["seed"])
+    eng, p = H.ring_engine_for_spec(spec)
+    with eng:
+        eng.run_until(p["end_ns"])
+        _check_against_oracle(spec, eng, r, nodes)
+
+
+def test_ring_general_path_equals_fast_path():
+    spec = RING_SWEEP[1]
+    res = []
+    for flags in (0, 1):
+        eng, p = H.ring_engine_for_spec(spec, flags=flags)
+        with eng:
+            eng.run_until(p["end_ns"])
+            s = eng.summary()
+            res.append((s.events_processed, tuple(s.events_by_kind), s.final_time_ns,
+                        {k: v.tobytes() for k, v in eng.lp_stats().items()},
+                        {k: v.tobytes() for k, v in eng.net_stats().items()}, [a.tobytes() for a in eng.read_sinks()]))
+    assert res[0] == res[1]
+
+
+def test_ring_rejects_zero_lookahead_and_second_run():
+    from happy_simulator_amd import _native as N
+
+    spec = dict(RING_SWEEP[3], lat_min=0.0)
+    with pytest.raises(ValueError, match="min latency must be > 0"):
+        H.ring_engine_for_spec(spec)
+    eng, p = H.ring_engine_for_spec(RING_SWEEP[3])
+    with eng:
+        eng.run_until(p["end_ns"])
+        with pytest.raises(N.EngineError, match="one hs_engine_run_until per hs_engine_reset"):
+            eng.run_until(p["end_ns"])
+        a = eng.summary().events_processed
+        eng.reset()
+        eng.run_until(p["end_ns"])
+        assert eng.summary().events_processed == a
