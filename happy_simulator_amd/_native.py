@@ -91,7 +91,7 @@ class LpStats(C.Structure):
 
 
 def sources() -> list[str]:
-    return [os.path.join(CSRC, f) for f in ("hs_engine.hip", "hs_station.hpp", "hs_device.hpp")] + [
+    return [os.path.join(CSRC, f) for f in ("hs_engine.hip", "hs_station.hpp", "hs_netstation.hpp", "hs_device.hpp")] + [
         os.path.join(INCLUDE, "hs_engine.h")]
 
 
