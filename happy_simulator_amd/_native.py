@@ -165,6 +165,8 @@ def lib():
     L.hs_debug_draws.restype = C.c_int
     L.hs_debug_draws.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64, C.c_double,
                                  C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hs_debug_const_div.restype = C.c_int
+    L.hs_debug_const_div.argtypes = [C.c_int32, C.c_double, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     if L.hs_abi_version() != ABI_VERSION:
         raise EngineUnavailable("libhs_hip.so ABI version mismatch; rebuild")
     _lib = L
@@ -176,5 +178,6 @@ EXPORTED_SYMBOLS = (
     "hs_engine_get_net_stats", "hs_engine_reset",
     "hs_engine_run_until", "hs_engine_run_until_async", "hs_engine_synchronize", "hs_engine_bench_runs",
     "hs_engine_get_summary", "hs_engine_get_lp_stats", "hs_engine_read_sink", "hs_engine_read_sinks",
-    "hs_last_error", "hs_last_global_error", "hs_engine_destroy", "hs_debug_draws",
+    "hs_last_error", "hs_last_global_error", "hs_engine_destroy", "hs_debug_draws", "hs_debug_set_flags",
+    "hs_debug_const_div",
 )

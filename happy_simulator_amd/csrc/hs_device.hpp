@@ -30,8 +30,10 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
                                             uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one widening 32x32->64 multiply per product (v_mad_u64_u32) instead of a mul_hi + mul_lo pair
+        const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         c0 = hi1 ^ c1 ^ k0;
         c1 = lo1;
         c2 = hi0 ^ c3 ^ k1;
@@ -84,7 +86,48 @@ __device__ __forceinline__ double hs_log(double x) {
 __device__ __forceinline__ double exp1_from_uniform(double u) { return -hs_log(__dsub_rn(1.0, u)); }
 
 __device__ __forceinline__ int64_t ns_from_seconds(double x) { return __double2ll_rz(__dmul_rn(x, 1e9)); }
-__device__ __forceinline__ double seconds_from_ns(int64_t ns) { return __ddiv_rn(__ll2double_rn(ns), 1e9); }
+// double(ns) / 1e9, correctly rounded: the constant-divisor sequence of ConstDiv below with b = 1e9 and
+// y = RN(1 / 1e9) = 1e-9 (bit-identical to the IEEE quotient; five multiply/FMA instead of a division)
+__device__ __forceinline__ double seconds_from_ns(int64_t ns) {
+    const double a = __ll2double_rn(ns);
+    const double q0 = __dmul_rn(a, 1e-9);
+    const double r0 = __fma_rn(-1e9, q0, a);
+    const double q1 = __fma_rn(r0, 1e-9, q0);
+    const double r1 = __fma_rn(-1e9, q1, a);
+    return __fma_rn(r1, 1e-9, q1);
+}
+// the plain IEEE division, kept for the device-vs-division test hook
+__device__ __forceinline__ double seconds_from_ns_ieee(int64_t ns) { return __ddiv_rn(__ll2double_rn(ns), 1e9); }
+
+// a / b for a divisor that is constant per LP (1e9, a source's rate, a server's lambda): y = RN(1 / b) is
+// computed once with a true division, then every quotient costs one multiply and four FMAs instead of the
+// ~13-instruction v_div_scale / v_rcp / v_div_fmas / v_div_fixup sequence.  The result is the correctly
+// rounded quotient, bit-identical to a / b (Markstein 1990: with y = RN(1/b) and q faithful, the residual
+// r = a - b q is exact in one FMA and RN(q + r y) = RN(a / b); the first correction makes q faithful, the
+// second makes it exact).  The theorem excludes divisors whose significand is all ones and needs the
+// intermediates to stay normal; `fast` is false for such divisors and the hardware division is used.
+// tests/test_gpu_parity.py::test_constant_divisor_quotients_are_ieee compares 10^7 quotients per divisor.
+struct ConstDiv {
+    double b, y;
+    bool fast;
+    __device__ __forceinline__ void init(double divisor) {
+        b = divisor;
+        y = __ddiv_rn(1.0, divisor);
+        const uint64_t bits = (uint64_t)__double_as_longlong(divisor);
+        const uint32_t ex = (uint32_t)(bits >> 52) & 0x7ffu;
+        const bool all_ones = (bits & 0x000fffffffffffffull) == 0x000fffffffffffffull;
+        fast = !all_ones && ex > 1023u - 200u && ex < 1023u + 200u && (bits >> 63) == 0;
+    }
+    // a must be finite and either 0 or of magnitude in [2^-300, 2^300] (every caller: event times, -log(1-u))
+    __device__ __forceinline__ double div(double a) const {
+        if (!fast) return __ddiv_rn(a, b);
+        const double q0 = __dmul_rn(a, y);
+        const double r0 = __fma_rn(-b, q0, a);
+        const double q1 = __fma_rn(r0, y, q0);
+        const double r1 = __fma_rn(-b, q1, a);
+        return __fma_rn(r1, y, q1);
+    }
+};
 
 // One entity stream.  A Philox block serves two consecutive draws, so the block is cached and only
 // recomputed when the draw index crosses an even boundary.

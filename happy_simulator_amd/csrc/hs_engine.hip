@@ -60,7 +60,8 @@ __device__ __forceinline__ Candidate wave_min_cand(Candidate c) {
 
 template <int C>
 __device__ __forceinline__ void load_station(Station<C> &S, const StationParams &P, const StationState &X,
-                                             const RecordLogs &L, int lp, int n, uint8_t (*qmem)[kBlock], int tid) {
+                                             const RecordLogs &L, int lp, int n, uint8_t (*qmem)[kBlock],
+                                             double (*ring_a)[kBlock], double (*ring_s)[kBlock], int tid) {
     S.lp = lp; S.n = n;
     S.src_kind = P.src_kind[lp]; S.svc_kind = P.svc_kind[lp]; S.egress = P.egress[lp];
     S.conc = P.conc[lp];
@@ -82,9 +83,8 @@ __device__ __forceinline__ void load_station(Station<C> &S, const StationParams 
         S.crtD[i] = X.crtD[(size_t)i * n + lp]; S.svc_s[i] = X.svc_s[(size_t)i * n + lp];
         S.crt[i] = (C > 1) ? X.crt[(size_t)i * n + lp] : 0;
     }
-    const uint64_t seed = P.seed[lp], base = P.stream_base[lp];
-    S.arr.init(seed, stream_id(base, kStreamArrival), X.arr_k[lp]);
-    S.svc.init(seed, stream_id(base, kStreamService), X.svc_k[lp]);
+    S.tid = tid;
+    S.init_streams(P.seed[lp], P.stream_base[lp], X.arr_k[lp], X.svc_k[lp], ring_a, ring_s);
 #pragma unroll
     for (int k = 0; k < 8; ++k) S.ev[k] = 0;
     S.adm = L.adm + (size_t)lp * L.cap;
@@ -114,7 +114,7 @@ __device__ __forceinline__ void store_station(const Station<C> &Sc, const Statio
         X.crtD[(size_t)i * n + lp] = S.crtD[i]; X.svc_s[(size_t)i * n + lp] = S.svc_s[i];
         if (C > 1) X.crt[(size_t)i * n + lp] = S.crt[i];
     }
-    X.arr_k[lp] = S.arr.k; X.svc_k[lp] = S.svc.k;
+    X.arr_k[lp] = S.arr_k; X.svc_k[lp] = S.svc_k;   // draws CONSUMED; pre-drawn values still in the rings are dropped
     uint32_t q = 0;
     int qn = S.qn > 2 ? 2 : S.qn;   // an overshoot root leaves at most two in-group events
     for (int i = 0; i < qn; ++i) q |= (uint32_t)S.qmem[(S.qh + i) % kQCap][S.tid] << (8 * i);
@@ -217,6 +217,8 @@ template <int C>
 __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, StationState X, RecordLogs L, Totals *tot,
                                                          Candidate *cands, int n, int64_t end_ns, int mode, int flags) {
     __shared__ uint8_t qmem[kQCap][kBlock];
+    __shared__ double ring_a[kRing][kBlock];    // pre-drawn arrival increments, one column per LP
+    __shared__ double ring_s[kRing][kBlock];    // pre-drawn service times
     __shared__ unsigned long long red[12];
     __shared__ long long red_time;
     __shared__ int red_flags[2];
@@ -235,19 +237,53 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
     Candidate mine;
     mine.valid = 0; mine.t = kInfNs; mine.t_created = 0; mine.lp = lp;
     if (live) {
-        load_station<C>(S, P, X, L, lp, n, qmem, tid);
+        load_station<C>(S, P, X, L, lp, n, qmem, ring_a, ring_s, tid);
         S.force_general = (flags & 1) != 0;
         const bool frozen = (mode == HS_MODE_REPLICAS) ? (S.last_time > end_ns) : (cur > end_ns);
         if (!frozen) {
+            bool pre_group = false;
             if (S.qn > 0 && S.grp_time <= end_ns) {   // finish a group a previous window stopped inside
                 S.run_group_general(S.grp_time);
                 S.last_time = S.grp_time;
+                pre_group = true;
             }
             if (S.qn == 0) {
-                for (;;) {
-                    const int64_t t = S.next_time();
-                    if (t > end_ns) break;             // also ends on kInfNs: nothing pending
-                    S.run_group(t);
+                if constexpr (C == 1) {
+                    // (1) request-order loop (hs_station.hpp): one whole request per iteration.  Uniform loops: the
+                    // wavefront iterates until its slowest lane is done, finished lanes are predicated off.
+                    bool event_order = true;
+                    if (!pre_group) {
+                        const bool elig = S.req_eligible();
+                        typename Station<C>::ReqCursor rc;
+                        rc.bail = false; rc.done = true;
+                        if (elig) S.req_begin(rc, end_ns);   // (touches the LP's statistics: eligible lanes only)
+                        for (;;) {
+                            const bool act = elig && !rc.bail && !rc.done;
+                            if (!__any(act)) break;
+                            S.top_up(act);             // wave-level refill of the pre-drawn stream values
+                            S.req_step(rc, act);
+                        }
+                        if (elig && !rc.bail) { S.req_finish(rc); event_order = false; }
+                        else if (elig) {               // same-timestamp hazard: start over in event order
+                            load_station<C>(S, P, X, L, lp, n, qmem, ring_a, ring_s, tid);
+                            S.force_general = (flags & 1) != 0;
+                        }
+                    }
+                    // (2) event-order loop for whatever (1) does not cover
+                    for (;;) {
+                        const int64_t t = S.next_time();
+                        const bool act = event_order && t <= end_ns;   // t == kInfNs: nothing pending
+                        if (!__any(act)) break;
+                        S.top_up(act);
+                        S.step_c1(t, act);
+                    }
+                } else {
+                    for (;;) {
+                        S.top_up();
+                        const int64_t t = S.next_time();
+                        if (t > end_ns) break;         // also ends on kInfNs: nothing pending
+                        S.run_group(t);
+                    }
                 }
             }
             if (mode == HS_MODE_REPLICAS) overshoot_one<C>(S);
@@ -320,7 +356,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
         long long new_cur = __hip_atomic_load(&tot->final_time, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur <= end_ns && b.valid) {
             Station<C> W;
-            load_station<C>(W, P, X, L, b.lp, n, qmem, 0);
+            load_station<C>(W, P, X, L, b.lp, n, qmem, ring_a, ring_s, 0);
             W.force_general = false;
             overshoot_one<C>(W);
             store_station<C>(W, X, b.lp, n);
@@ -580,6 +616,18 @@ __global__ void hs_debug_draws_kernel(uint64_t seed, uint64_t sid, uint64_t k0, 
     const double ee = exp1_from_uniform(uu);
     u[i] = uu; e[i] = ee;
     ns[i] = ns_from_seconds(__ddiv_rn(ee, rate));
+}
+
+// test hook: constant-divisor quotients (ConstDiv, seconds_from_ns) next to the IEEE division
+__global__ void hs_debug_const_div_kernel(double b, int64_t n, const double *a, double *q_fast, double *q_ieee,
+                                          double *q_ns) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ConstDiv d;
+    d.init(b);
+    q_fast[i] = d.div(a[i]);
+    q_ieee[i] = __ddiv_rn(a[i], b);
+    q_ns[i] = seconds_from_ns((int64_t)a[i]);
 }
 
 // =============================================================================================
@@ -1181,6 +1229,26 @@ int hs_debug_draws(int32_t device, uint64_t seed, uint64_t sid, uint64_t k0, int
     HS_HIP(nullptr, hipMemcpy(e, de, (size_t)n * 8, hipMemcpyDeviceToHost));
     HS_HIP(nullptr, hipMemcpy(ns, dn, (size_t)n * 8, hipMemcpyDeviceToHost));
     hipFree(du); hipFree(de); hipFree(dn);
+    return HS_OK;
+}
+
+int hs_debug_const_div(int32_t device, double b, int64_t n, const double *a, double *q_fast, double *q_ieee,
+                       double *q_ns) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, HS_E_NO_DEVICE, "no HIP device visible: the engine has no CPU fallback");
+    if (n <= 0 || !a || !q_fast || !q_ieee || !q_ns) return fail(nullptr, HS_E_INVALID, "hs_debug_const_div: bad arguments");
+    HS_HIP(nullptr, hipSetDevice(device));
+    double *d[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (auto &p : d) HS_HIP(nullptr, hipMalloc((void **)&p, (size_t)n * 8));
+    HS_HIP(nullptr, hipMemcpy(d[0], a, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(hs_debug_const_div_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, b, n, d[0], d[1],
+                       d[2], d[3]);
+    HS_HIP(nullptr, hipGetLastError());
+    HS_HIP(nullptr, hipMemcpy(q_fast, d[1], (size_t)n * 8, hipMemcpyDeviceToHost));
+    HS_HIP(nullptr, hipMemcpy(q_ieee, d[2], (size_t)n * 8, hipMemcpyDeviceToHost));
+    HS_HIP(nullptr, hipMemcpy(q_ns, d[3], (size_t)n * 8, hipMemcpyDeviceToHost));
+    for (auto &p : d) hipFree(p);
     return HS_OK;
 }
 

@@ -31,6 +31,36 @@ enum : uint32_t { Q_ENQ = 1, Q_NOTIFY = 2, Q_POLL = 3, Q_DELIVER = 4, Q_TICK = 5
 
 constexpr int kBlock = 256;     // LPs per workgroup (4 wavefronts)
 constexpr int kQCap = 48;       // in-group FIFO capacity per LP (LDS)
+constexpr int kRing = 24;       // pre-drawn values buffered per stream per LP (LDS)
+constexpr int kRefill = 8;      // values generated per wave-level refill (4 Philox blocks)
+
+// Per-lane ring of pre-drawn stream values, column `tid` of an LDS array [kRing][kBlock].  The serial
+// per-LP recursion consumes one value at a time; the expensive part of a draw (Philox block, hs_log,
+// the division by the rate / lambda) is produced kRefill values at a time by ALL lanes of the wavefront
+// in straight-line code (refill_*), instead of once per loop iteration inside divergent branches.
+struct DrawRing {
+    double (*mem)[kBlock];
+    int tid, head, n;
+    __device__ __forceinline__ void reset(double (*m)[kBlock], int t) { mem = m; tid = t; head = 0; n = 0; }
+    __device__ __forceinline__ void push(double v) {
+        int i = head + n;
+        i = i >= kRing ? i - kRing : i;
+        mem[i][tid] = v;
+        ++n;
+    }
+    __device__ __forceinline__ double peek() const { return mem[head][tid]; }   // garbage when n == 0 (never used then)
+    __device__ __forceinline__ void advance_if(bool p) {
+        const int nh = (head + 1 == kRing) ? 0 : head + 1;
+        head = p ? nh : head;
+        n -= p ? 1 : 0;
+    }
+    __device__ __forceinline__ double pop() {
+        const double v = mem[head][tid];
+        head = (head + 1 == kRing) ? 0 : head + 1;
+        --n;
+        return v;
+    }
+};
 
 struct StationParams {          // read-only, [n_lp] each
     const uint8_t *src_kind;
@@ -117,7 +147,12 @@ struct Station {
     int64_t crt[C];
     double total_service;
     int64_t last_time, grp_time;
-    Stream arr, svc;
+    // entity streams (DESIGN.md "Random streams"): draws consumed so far + the pre-drawn values
+    uint32_t key0, key1, asid0, asid1, ssid0, ssid1;
+    uint64_t arr_k, svc_k;
+    DrawRing ra, rs;            // ra: E / rate per arrival draw;  rs: service_time_s per service draw
+    ConstDiv div_rate, div_lambda;
+    double inc_const;           // constant source: 1.0 / rate
     // per-run deltas
     uint32_t ev[8];
     // logs
@@ -143,12 +178,80 @@ struct Station {
         return c;
     }
 
+    __device__ __forceinline__ void init_streams(uint64_t seed, uint64_t base, uint64_t ak, uint64_t sk,
+                                                 double (*ring_a)[kBlock], double (*ring_s)[kBlock]) {
+        key0 = (uint32_t)seed; key1 = (uint32_t)(seed >> 32);
+        const uint64_t sa = stream_id(base, kStreamArrival), ss = stream_id(base, kStreamService);
+        asid0 = (uint32_t)sa; asid1 = (uint32_t)(sa >> 32);
+        ssid0 = (uint32_t)ss; ssid1 = (uint32_t)(ss >> 32);
+        arr_k = ak; svc_k = sk;
+        ra.reset(ring_a, tid); rs.reset(ring_s, tid);
+        div_rate.init(rate);
+        div_lambda.init(svc_lambda);
+        inc_const = __ddiv_rn(1.0, rate);
+    }
+    // value of arrival draw k: E / rate with E = -log(1 - u)          (providers/poisson_arrival.py:31,
+    //                                                                   load/arrival_time_provider.py:76)
+    __device__ __forceinline__ double arr_value(double u) const { return div_rate.div(exp1_from_uniform(u)); }
+    // value of service draw k: get_latency(...).to_seconds() of random.expovariate(lambda)
+    //                                         (distributions/exponential.py:43, server/server.py:246-247)
+    __device__ __forceinline__ double svc_value(double u) const {
+        const double sample = div_lambda.div(exp1_from_uniform(u));
+        return seconds_from_ns(ns_from_seconds(sample));      // Duration.from_seconds(sample).to_seconds()
+    }
+    // Append `blocks` Philox blocks (two draws each) to the ring; a ring that ends on an odd draw index
+    // takes only the second half of its first block.  Needs room for 2 * blocks values.
+    template <int BLOCKS>
+    __device__ __forceinline__ void refill_arr() {
+        const uint64_t kg = arr_k + (uint64_t)ra.n;
+        const uint64_t b0 = kg >> 1;
+        const bool odd = (kg & 1) != 0;
+#pragma unroll
+        for (int i = 0; i < BLOCKS; ++i) {
+            const uint64_t b = b0 + (uint64_t)i;
+            const U4 o = philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), asid0, asid1, key0, key1);
+            const double v0 = arr_value(res53(o.x, o.y)), v1 = arr_value(res53(o.z, o.w));
+            if (!(i == 0 && odd)) ra.push(v0);
+            ra.push(v1);
+        }
+    }
+    template <int BLOCKS>
+    __device__ __forceinline__ void refill_svc() {
+        const uint64_t kg = svc_k + (uint64_t)rs.n;
+        const uint64_t b0 = kg >> 1;
+        const bool odd = (kg & 1) != 0;
+#pragma unroll
+        for (int i = 0; i < BLOCKS; ++i) {
+            const uint64_t b = b0 + (uint64_t)i;
+            const U4 o = philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), ssid0, ssid1, key0, key1);
+            const double v0 = svc_value(res53(o.x, o.y)), v1 = svc_value(res53(o.z, o.w));
+            if (!(i == 0 && odd)) rs.push(v0);
+            rs.push(v1);
+        }
+    }
+    __device__ __forceinline__ bool wants_arr() const { return src_kind == 1 && A != kInfNs && ra.n == 0; }
+    __device__ __forceinline__ bool wants_svc() const { return svc_kind == 0 && rs.n == 0; }
+    // Wave-level top-up, called at a point where the whole wavefront is converged on the main loop: if any lane
+    // has run dry, every lane with room generates kRefill more values (lanes consume at similar rates, so the
+    // refills stay in step: ~93 % of the generated lanes-worth of values are used).
+    __device__ __forceinline__ void top_up(bool act = true) {
+        if (__any(act && wants_arr())) {
+            if (src_kind == 1 && A != kInfNs && ra.n <= kRing - kRefill) refill_arr<kRefill / 2>();
+        }
+        if (__any(act && wants_svc())) {
+            if (svc_kind == 0 && rs.n <= kRing - kRefill) refill_svc<kRefill / 2>();
+        }
+    }
+
     // ---- ArrivalTimeProvider.next_arrival_time, constant-rate fast path (load/arrival_time_provider.py:72-82)
     __device__ __forceinline__ int64_t next_arrival() {
-        double area;
-        if (src_kind == 1) area = exp1_from_uniform(arr.next_uniform());  // Poisson: -log(1-u) (providers/poisson_arrival.py:31)
-        else area = 1.0;                                                  // constant   (providers/constant_arrival.py:23)
-        const double t_next = __dadd_rn(seconds_from_ns(arr_time), __ddiv_rn(area, rate));
+        double inc;
+        if (src_kind == 1) {                       // Poisson: -log(1-u) / rate
+            if (ra.n == 0) refill_arr<1>();        // ran dry inside a group (rare): one block, in place
+            inc = ra.pop();
+            ++arr_k;
+        } else inc = inc_const;                    // constant: 1.0 / rate   (providers/constant_arrival.py:23)
+        const double t_next = __dadd_rn(seconds_from_ns(arr_time), inc);
         arr_time = ns_from_seconds(t_next);
         return arr_time;
     }
@@ -156,8 +259,9 @@ struct Station {
     // ---- service sample: get_latency(...).to_seconds() then `yield s` (server/server.py:246-250)
     __device__ __forceinline__ void sample_service(double &s, int64_t &dur_ns) {
         if (svc_kind == 0) {
-            const double sample = __ddiv_rn(exp1_from_uniform(svc.next_uniform()), svc_lambda);  // expovariate(lambda)
-            s = seconds_from_ns(ns_from_seconds(sample));   // Duration.from_seconds(sample).to_seconds()
+            if (rs.n == 0) refill_svc<1>();
+            s = rs.pop();
+            ++svc_k;
             dur_ns = ns_from_seconds(s);                    // Instant + float: ns + int(s * 1e9)
         } else {
             s = svc_const_s;
@@ -363,6 +467,209 @@ struct Station {
             run_group_general(t);
         }
         last_time = t;
+    }
+
+    // ---- C == 1: one timestamp group per lane per call, as straight-line predicated code -----------------
+    // Same semantics as run_group()'s fast path (exactly one pending event at `t`, at most one event in flight),
+    // but without per-lane branches: a wavefront whose lanes mix ticks and departures runs ONE instruction
+    // stream with selects instead of every branch body under a different exec mask.  Everything that would
+    // leave that regime is detected BEFORE any state is committed (`slow`) and handed to run_group():
+    // A == D ties, stop_after reached, a next tick that truncates onto / before `t`, a zero-length service,
+    // a Source wired straight to a Sink.  `act` = this lane still has a group with t <= end_ns.
+    // top_up() has run: every lane that may consume a stream value has at least one in its ring.
+    __device__ __forceinline__ void step_c1(int64_t t, bool act) {
+        static_assert(C == 1, "step_c1 is the single-slot specialisation");
+        const bool tick = (A == t);
+        const bool dep = !tick;
+        // speculative next arrival (load/arrival_time_provider.py:72-82) and service sample (server.py:246-250)
+        const double inc = (src_kind == 1) ? ra.peek() : inc_const;
+        const int64_t a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc));
+        const double s_new = (svc_kind == 0) ? rs.peek() : svc_const_s;
+        const int64_t dur = (svc_kind == 0) ? ns_from_seconds(s_new) : svc_const_ns;
+        // which reference events happen in this group
+        const bool enq_drop = qcap >= 0 && buf >= qcap;                 // FIFOQueue.push refuses (queue_policy.py:94-98)
+        const bool acc = tick && !enq_drop;
+        const bool notify = acc && buf == 0;                            // queue.py:124,144-146
+        const int32_t active_dep = active > 0 ? active - 1 : 0;
+        const bool poll = (notify && active < conc) || (dep && active_dep < conc);   // queue_driver.py:94-99 / :79-84
+        const int64_t buf_enq = buf + (acc ? 1 : 0);
+        const bool deliver = poll && buf_enq > 0;                       // queue.py:149-166
+        const bool slow = act && (force_general || svc_kind == 2 || (tick && D[0] == t) ||
+                                  (tick && ((stop_ns >= 0 && t > stop_ns) || a2 <= t)) || (deliver && dur == 0));
+        const bool fast = act && !slow;
+        const bool tick_f = fast && tick, dep_f = fast && dep, acc_f = fast && acc;
+        const bool poll_f = fast && poll, del_f = fast && deliver;
+        // Source.handle_event
+        ev[0] += tick_f; generated += tick_f;
+        arr_time = tick_f ? a2 : arr_time;
+        A = tick_f ? a2 : A;
+        seqA = tick_f ? seq : seqA;
+        crtA = tick_f ? t : crtA;
+        seq += tick_f ? 1u : 0u;
+        const bool pop_a = tick_f && src_kind == 1;
+        ra.advance_if(pop_a);
+        arr_k += pop_a ? 1u : 0u;
+        // Queue._handle_enqueue / QueueDriver._handle_notify
+        ev[1] += tick_f;
+        dropped += (tick_f && enq_drop) ? 1 : 0;
+        if (acc_f) { if (accepted < cap) adm[accepted] = t; else overflow = 1; }
+        accepted += acc_f;
+        ev[2] += (fast && notify) ? 1u : 0u;
+        // generator resumes: statistics, Sink record, schedule_poll hook
+        ev[6] += dep_f;
+        completed += dep_f;
+        total_service = dep_f ? __dadd_rn(total_service, svc_s[0]) : total_service;
+        active = dep_f ? active_dep : active;
+        const bool sink_f = dep_f && egress == 1;
+        if (sink_f) { if (sink_w < cap) sink_t[sink_w] = t; else overflow = 1; }
+        sink_w += sink_f; ev[7] += sink_f; received += sink_f;
+        // QUEUE_POLL, then QUEUE_DELIVER + the retargeted payload at the worker
+        ev[3] += poll_f;
+        buf = fast ? (buf_enq - (deliver ? 1 : 0)) : buf;
+        ev[4] += del_f; ev[5] += del_f;
+        started += del_f;
+        active += del_f ? 1 : 0;
+        svc_s[0] = del_f ? s_new : svc_s[0];
+        D[0] = del_f ? (t + dur) : (dep_f ? kInfNs : D[0]);
+        seqD[0] = del_f ? seq : seqD[0];
+        crtD[0] = del_f ? t : crtD[0];
+        seq += del_f ? 1u : 0u;
+        const bool pop_s = del_f && svc_kind == 0;
+        rs.advance_if(pop_s);
+        svc_k += pop_s ? 1u : 0u;
+        last_time = fast ? t : last_time;
+        if (slow) run_group(t);
+    }
+
+    // ---- C == 1, unbounded FIFO: the LP in REQUEST order instead of event order ---------------------------
+    // With one worker and a FIFO buffer, request k starts at S_k = max(a_k, D_{k-1}) and departs at
+    // D_k = S_k + service_k, and the service draws are consumed in arrival order.  Every reference event of
+    // request k happens at a_k (SourceEvent, Request@Server, QUEUE_NOTIFY iff the buffer was empty = request k-1
+    // had started: S_{k-1} < a_k, QUEUE_POLL iff the worker was idle: D_{k-1} < a_k), at S_k (QUEUE_DELIVER,
+    // Request@worker) or at D_k (ProcessContinuation, Request@Sink, the completion QUEUE_POLL), and is processed
+    // by `_execute_until(T)` iff that time is <= T.  One iteration therefore handles one whole request -- one
+    // arrival value, one service value, no tick/departure divergence between lanes -- and counts the same events
+    // the event-order loop counts.  Anything whose outcome depends on the order of two events at the SAME
+    // nanosecond (a_k == S_{k-1}, a_k == D_{k-1}, a next tick that truncates onto / before a_k, a zero-length
+    // service) makes the lane `bail`: its state is reloaded and re-run by the event-order loop (step_c1), which
+    // reproduces the reference's creation-order tie-breaking.  Equal timestamps that cannot change any outcome
+    // (a_k == D_j, j < k-1: request k-1 is still waiting either way) are left alone.
+    struct ReqCursor {
+        int64_t T;                  // end of the window
+        int64_t Sprev, Dprev;       // start / departure of the previous request in FIFO order (kInfNs: not started)
+        int64_t nb;                 // requests that arrived in an earlier launch and are still waiting
+        int64_t pendD, pendS;       // the request in service when the window ends
+        double pend_s;
+        int64_t lt;                 // time of the latest processed event
+        uint32_t n_tick, n_notify, n_poll, n_start, n_dep;
+        bool pend, blocked, bail, done;
+    };
+    __device__ __forceinline__ bool req_eligible() const {
+        return C == 1 && !force_general && qn == 0 && conc == 1 && qcap < 0 && stop_ns < 0 && svc_kind != 2 &&
+               (egress == 0 || egress == 1) && !(buf > 0 && active == 0) && active <= 1;
+    }
+    __device__ __forceinline__ void req_count_departure(ReqCursor &c, bool p, int64_t d, double s) {
+        total_service = p ? __dadd_rn(total_service, s) : total_service;
+        if (p && egress == 1) {
+            const int64_t w = sink_w + (int64_t)c.n_dep;
+            if (w < cap) sink_t[w] = d; else overflow = 1;
+        }
+        c.n_dep += p ? 1u : 0u;
+        c.lt = (p && d > c.lt) ? d : c.lt;
+    }
+    __device__ __forceinline__ void req_begin(ReqCursor &c, int64_t T) {
+        c.T = T; c.nb = buf; c.lt = last_time;
+        c.n_tick = c.n_notify = c.n_poll = c.n_start = c.n_dep = 0;
+        c.blocked = c.bail = c.done = false;
+        const bool busy = active > 0;
+        c.Sprev = busy ? crtD[0] : INT64_MIN;
+        c.Dprev = busy ? D[0] : INT64_MIN;
+        const bool dep0 = busy && D[0] <= T;      // the request already in service departs inside the window
+        req_count_departure(c, dep0, D[0], svc_s[0]);
+        c.pend = busy && !dep0;
+        c.pendD = D[0]; c.pendS = crtD[0]; c.pend_s = svc_s[0];
+    }
+    __device__ __forceinline__ void req_step(ReqCursor &c, bool act) {
+        const int64_t T = c.T;
+        const bool bk = c.nb > 0 && !c.blocked;          // next in FIFO order: a request that is already waiting
+        const bool arr = !bk && A <= T;                  // ... or the next arrival
+        const bool fin = !bk && !arr;
+        // arrival part at a_k = A
+        const double inc = (src_kind == 1) ? ra.peek() : inc_const;
+        const int64_t a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc));
+        const bool tie_a = arr && (A == c.Sprev || A == c.Dprev || a2 <= A);
+        const bool notify = arr && c.Sprev < A;
+        const bool idle = arr && c.Dprev < A;
+        // start part at S_k
+        const int64_t Sk = bk ? c.Dprev : (A > c.Dprev ? A : c.Dprev);
+        const bool st = (bk || arr) && Sk <= T;
+        const double s_new = (svc_kind == 0) ? rs.peek() : svc_const_s;
+        const int64_t dur = (svc_kind == 0) ? ns_from_seconds(s_new) : svc_const_ns;
+        const int64_t Dk = Sk + dur;
+        const bool dp = st && Dk <= T;                   // departure part at D_k
+        const bool bail = act && (tie_a || (st && dur == 0));
+        const bool go = act && !bail && !fin;
+        c.bail = c.bail || bail;
+        c.done = c.done || (act && fin);
+        const bool arr_g = go && arr, st_g = go && st, dp_g = go && dp;
+        // Source.handle_event + Queue._handle_enqueue (+ notify / poll when the buffer is empty / the worker idle)
+        if (arr_g) {
+            const int64_t w = accepted + (int64_t)c.n_tick;
+            if (w < cap) adm[w] = A; else overflow = 1;
+        }
+        c.n_tick += arr_g ? 1u : 0u;
+        c.n_notify += (go && notify) ? 1u : 0u;
+        c.n_poll += (go && idle) ? 1u : 0u;
+        c.lt = (arr_g && A > c.lt) ? A : c.lt;
+        crtA = arr_g ? A : crtA;
+        arr_time = arr_g ? a2 : arr_time;
+        const bool pop_a = arr_g && src_kind == 1;
+        ra.advance_if(pop_a);
+        arr_k += pop_a ? 1u : 0u;
+        // QUEUE_DELIVER + Request@worker: the service sample is drawn at the start of service
+        c.n_start += st_g ? 1u : 0u;
+        c.lt = (st_g && Sk > c.lt) ? Sk : c.lt;
+        const bool pop_s = st_g && svc_kind == 0;
+        rs.advance_if(pop_s);
+        svc_k += pop_s ? 1u : 0u;
+        // ProcessContinuation + Request@Sink + completion poll
+        req_count_departure(c, dp_g, Dk, s_new);
+        // cursor
+        c.pend = st_g ? !dp : c.pend;
+        c.pendD = st_g ? Dk : c.pendD;
+        c.pendS = st_g ? Sk : c.pendS;
+        c.pend_s = st_g ? s_new : c.pend_s;
+        // the request just looked at becomes "the previous request" -- also a waiting one that cannot start any
+        // more (the worker stays busy beyond T): from then on nobody starts and every arrival finds a non-empty buffer
+        const bool looked = go && (arr || bk);
+        c.Sprev = looked ? (st ? Sk : kInfNs) : c.Sprev;
+        c.Dprev = looked ? (st ? Dk : kInfNs) : c.Dprev;
+        c.blocked = c.blocked || (go && bk && !st);
+        c.nb -= (go && bk && st) ? 1 : 0;
+        A = arr_g ? a2 : A;                              // last: `A` is read above
+    }
+    // fold the window's deltas into the LP state exactly as the event-order loop would have left it
+    __device__ __forceinline__ void req_finish(const ReqCursor &c) {
+        ev[0] += c.n_tick; ev[1] += c.n_tick; ev[2] += c.n_notify; ev[3] += c.n_poll + c.n_dep;
+        ev[4] += c.n_start; ev[5] += c.n_start; ev[6] += c.n_dep;
+        generated += c.n_tick; accepted += c.n_tick; started += c.n_start; completed += c.n_dep;
+        if (egress == 1) { ev[7] += c.n_dep; received += c.n_dep; sink_w += c.n_dep; }
+        buf += (int64_t)c.n_tick - (int64_t)c.n_start;   // waiting: every arrival is admitted, every start takes one
+        active = c.pend ? 1 : 0;
+        D[0] = c.pend ? c.pendD : kInfNs;
+        crtD[0] = c.pend ? c.pendS : crtD[0];
+        svc_s[0] = c.pend ? c.pend_s : svc_s[0];
+        // creation stamps: only their order matters (pick_root).  The pending departure was created at pendS, the
+        // pending tick at crtA; a tick that also started the service created the next tick first.
+        // (No two of this window's events shared a timestamp -- the lane would have bailed -- so times decide; stamps
+        // that were not re-created in this window keep their order.)
+        if ((c.n_tick | c.n_start) != 0u) {
+            const bool d_first = c.pend && c.pendS < crtA;
+            seqA = seq + (d_first ? 1u : 0u);
+            seqD[0] = seq + (d_first ? 0u : 1u);
+            seq += 2u;
+        }
+        last_time = c.lt;
     }
 };
 

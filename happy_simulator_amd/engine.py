@@ -258,3 +258,16 @@ def debug_draws(seed: int, sid: int, k0: int, n: int, rate: float, device: int =
     if rc < 0:
         raise N.EngineError(rc, L.hs_last_global_error().decode())
     return u, e, ns
+
+
+def debug_const_div(a: np.ndarray, b: float, device: int = 0):
+    """Device-side a / b by the constant-divisor sequence, by IEEE division, and seconds_from_ns(int(a)) -- test hook."""
+    L = N.lib()
+    a = np.ascontiguousarray(a, np.float64)
+    qf, qi, qn = (np.zeros(len(a), np.float64) for _ in range(3))
+    rc = L.hs_debug_const_div(device, float(b), len(a), a.ctypes.data, qf.ctypes.data, qi.ctypes.data, qn.ctypes.data)
+    if rc == N.HS_E_NO_DEVICE:
+        raise N.EngineUnavailable(L.hs_last_global_error().decode())
+    if rc < 0:
+        raise N.EngineError(rc, L.hs_last_global_error().decode())
+    return qf, qi, qn

@@ -217,6 +217,12 @@ int hs_debug_set_flags(hs_engine *h, int flags);
 int hs_debug_draws(int32_t device, uint64_t seed, uint64_t sid, uint64_t k0, int64_t n, double rate,
                    double *u, double *e, int64_t *ns);
 
+/* Debug: the engine divides by per-LP constants (1e9, rate, lambda) with a multiply + FMA sequence that must be
+ * bit-identical to the IEEE quotient.  q_fast[i] = that sequence for a[i] / b, q_ieee[i] = the hardware
+ * division, q_ns[i] = seconds_from_ns((int64)a[i]) (compare with a[i] / 1e9). */
+int hs_debug_const_div(int32_t device, double b, int64_t n, const double *a, double *q_fast, double *q_ieee,
+                       double *q_ns);
+
 #ifdef __cplusplus
 }
 #endif

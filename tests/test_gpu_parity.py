@@ -62,6 +62,27 @@ def test_device_streams_match_oracle():
             assert ns[i] == int((eo / rate) * 1e9)
 
 
+def test_constant_divisor_quotients_are_ieee():
+    """The engine divides by per-LP constants with multiply + FMA (hs_device.hpp ConstDiv / seconds_from_ns); every
+    quotient must be bit-identical to the IEEE division the reference's arithmetic performs."""
+    from happy_simulator_amd.engine import debug_const_div
+
+    rng = np.random.default_rng(7)
+    n = 4_000_000
+    ns = rng.integers(0, 2**40, n).astype(np.float64)
+    qf, qi, qn = debug_const_div(ns, 1e9)
+    np.testing.assert_array_equal(qf, ns / 1e9)
+    np.testing.assert_array_equal(qi, ns / 1e9)
+    np.testing.assert_array_equal(qn, ns / 1e9)
+    e = -np.log1p(-rng.random(n))                      # the range of E = -log(1 - u)
+    tiny = np.ldexp(rng.random(n) + 0.5, rng.integers(-60, 8, n))
+    for b in (8.0, 10.0, 1.0 / 0.1, 3.3, 0.1, 7.0, 1.0 / 0.013, 12345.678, float(np.nextafter(2.0, 0.0))):
+        for a in (e, tiny):
+            qf, qi, _ = debug_const_div(a, b)
+            np.testing.assert_array_equal(qf, a / b, err_msg=f"b={b!r}")
+            np.testing.assert_array_equal(qi, a / b)
+
+
 @pytest.mark.parametrize("name", H.golden_names())
 def test_engine_matches_reference_golden(name):
     gold = H.Golden(name)
