@@ -32,7 +32,7 @@ EGRESS_NONE, EGRESS_SINK, EGRESS_LINK, EGRESS_ROUTER = 0, 1, 2, 3
 EV_KINDS = 11
 EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuation", "sink", "link", "link_cont",
             "route")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class EngineUnavailable(RuntimeError):
@@ -76,7 +76,16 @@ class Network(C.Structure):
         ("link_of", C.c_void_p), ("router_stream_base", C.c_void_p), ("n_links", C.c_int32),
         ("link_dst", C.c_void_p), ("link_lat_min_s", C.c_void_p), ("link_jitter_kind", C.c_void_p),
         ("link_jitter_mean_s", C.c_void_p), ("link_stream_base", C.c_void_p), ("link_src", C.c_void_p),
-        ("bag_capacity", C.c_int32),
+        ("bag_capacity", C.c_int32), ("n_global_lp", C.c_int32), ("link_gid", C.c_void_p),
+        ("n_global_links", C.c_int64),
+    ]
+
+
+class Shard(C.Structure):
+    _fields_ = [
+        ("rank", C.c_int32), ("world", C.c_int32), ("shard_lo", C.c_void_p), ("outbox_dev", C.c_void_p),
+        ("inbox_dev", C.c_void_p), ("msg_capacity", C.c_int32), ("reserved", C.c_int32), ("window_ns", C.c_int64),
+        ("gvt_dev", C.c_void_p), ("cand_dev", C.c_void_p),
     ]
 
 
@@ -138,6 +147,19 @@ def lib():
     L.hs_engine_set_network.argtypes = [C.c_void_p, P(Network)]
     L.hs_engine_get_net_stats.restype = C.c_int
     L.hs_engine_get_net_stats.argtypes = [C.c_void_p, P(NetStats)]
+    L.hs_engine_set_stream.restype = C.c_int
+    L.hs_engine_set_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.hs_engine_shard_attach.restype = C.c_int
+    L.hs_engine_shard_attach.argtypes = [C.c_void_p, P(Shard)]
+    L.hs_engine_shard_begin.restype = C.c_int
+    L.hs_engine_shard_begin.argtypes = [C.c_void_p, C.c_int64]
+    for name in ("hs_engine_shard_window", "hs_engine_shard_inject", "hs_engine_shard_final"):
+        getattr(L, name).restype = C.c_int
+        getattr(L, name).argtypes = [C.c_void_p, C.c_int64]
+    L.hs_engine_shard_progress.restype = C.c_int
+    L.hs_engine_shard_progress.argtypes = [C.c_void_p, C.c_int64, P(C.c_int64)]
+    L.hs_engine_shard_overshoot.restype = C.c_int
+    L.hs_engine_shard_overshoot.argtypes = [C.c_void_p, C.c_int32]
     L.hs_engine_reset.restype = C.c_int
     L.hs_engine_reset.argtypes = [C.c_void_p]
     for name in ("hs_engine_run_until", "hs_engine_run_until_async"):
@@ -175,7 +197,9 @@ def lib():
 
 EXPORTED_SYMBOLS = (
     "hs_abi_version", "hs_device_count", "hs_engine_create", "hs_engine_set_stations", "hs_engine_set_network",
-    "hs_engine_get_net_stats", "hs_engine_reset",
+    "hs_engine_get_net_stats", "hs_engine_set_stream", "hs_engine_shard_attach", "hs_engine_shard_begin",
+    "hs_engine_shard_window", "hs_engine_shard_inject", "hs_engine_shard_progress", "hs_engine_shard_final",
+    "hs_engine_shard_overshoot", "hs_engine_reset",
     "hs_engine_run_until", "hs_engine_run_until_async", "hs_engine_synchronize", "hs_engine_bench_runs",
     "hs_engine_get_summary", "hs_engine_get_lp_stats", "hs_engine_read_sink", "hs_engine_read_sinks",
     "hs_last_error", "hs_last_global_error", "hs_engine_destroy", "hs_debug_draws", "hs_debug_set_flags",

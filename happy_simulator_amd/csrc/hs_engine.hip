@@ -381,8 +381,10 @@ namespace {
 template <int C>
 __device__ __forceinline__ void load_net(NetStation<C> &S, const StationParams &P, const NetParams &NP,
                                          const StationState &X, const NetState &NX, const RecordLogs &L, int lp, int n,
-                                         uint8_t (*qmem)[kBlock], int64_t (*enqpay)[kBlock], int tid, int send_idx) {
+                                         uint8_t (*qmem)[kBlock], int64_t (*enqpay)[kBlock], int tid, int send_idx,
+                                         const ShardCtl &SC) {
     S.lp = lp; S.n = n;
+    S.sc = &SC; S.sent_min = kInfNs;
     S.src_kind = P.src_kind[lp]; S.svc_kind = P.svc_kind[lp]; S.egress = NP.egress[lp];
     S.conc = P.conc[lp]; S.rt0 = NP.rt0[lp]; S.rt1 = NP.rt1[lp]; S.link_of = NP.link_of[lp];
     S.rate = P.src_rate[lp];
@@ -453,7 +455,7 @@ __device__ __forceinline__ void store_net(NetStation<C> &S, const StationState &
 template <int C>
 __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetParams NP, StationState X, NetState NX,
                                                         RecordLogs L, Totals *tot, Candidate *cands, int n,
-                                                        int64_t wend, int win, int flags) {
+                                                        int64_t wend, int win, int flags, ShardCtl SC) {
     __shared__ uint8_t qmem[kQCap][kBlock];
     __shared__ int64_t enqpay[kEnqPay][kBlock];
     __shared__ unsigned long long red[14];
@@ -467,8 +469,19 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
     const bool live = lp < n;
     const bool final_launch = (flags & 2) != 0;
     const int merge_idx = (win + 1) & 1, send_idx = win & 1;
+    __shared__ long long red_gvt;
     if (tid < 14) red[tid] = 0;
-    if (tid == 0) { red_time = INT64_MIN; red_flags[0] = red_flags[1] = red_flags[2] = 0; }
+    if (tid == 0) { red_time = INT64_MIN; red_flags[0] = red_flags[1] = red_flags[2] = 0; red_gvt = kInfNs; }
+    if (SC.wend_slots != nullptr) {
+        // sharded network: every workgroup derives the same window end from the global virtual time
+        const int64_t prev = SC.wend_slots[(win + 1) & 1];
+        const int64_t gvt = *SC.gvt_in;
+        const int64_t base = gvt > prev + 1 ? gvt : prev + 1;
+        wend = (base > SC.end_ns - (SC.W - 1)) ? SC.end_ns : base + (SC.W - 1);
+        if (final_launch) wend = SC.end_ns;
+        if (blockIdx.x == 0 && tid == 0) SC.wend_slots[win & 1] = wend;
+    }
+    __syncthreads();
 
     int64_t nt = kInfNs;
     int merge_overflow = 0;
@@ -495,18 +508,27 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
         }
     }
     const bool act = live && (nt <= wend || final_launch);
-    if (!__syncthreads_or((int)act | merge_overflow)) return;   // nothing happens in this workgroup's window
+    if (!__syncthreads_or((int)act | merge_overflow)) {         // nothing happens in this workgroup's window
+        if (SC.wend_slots != nullptr) {                         // ... but its pending work still bounds the GVT
+            if (live) atomicMin(&red_gvt, (long long)nt);
+            __syncthreads();
+            if (tid == 0 && red_gvt != kInfNs) atomicMin((long long *)SC.gvt_out, red_gvt);
+        }
+        return;
+    }
 
     NetStation<C> S;
     Candidate mine;
     mine.valid = 0; mine.t = kInfNs; mine.t_created = 0; mine.lp = lp;
     if (act) {
-        load_net<C>(S, P, NP, X, NX, L, lp, n, qmem, enqpay, tid, send_idx);
+        load_net<C>(S, P, NP, X, NX, L, lp, n, qmem, enqpay, tid, send_idx, SC);
         for (;;) {
             const int64_t t = S.next_time();
             if (t > wend) break;
             S.run_group(t, (flags & 1) != 0);
         }
+        nt = S.next_time();
+        nt = S.sent_min < nt ? S.sent_min : nt;
         if (final_launch) {
             const int64_t t = S.next_time();
             if (t != kInfNs) {
@@ -539,11 +561,13 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
         if (S.bagoverflow) red_flags[2] = 1;
     }
     if (merge_overflow) red_flags[2] = 1;
+    if (SC.wend_slots != nullptr && live) atomicMin(&red_gvt, (long long)nt);
     if (final_launch) {
         const Candidate w = wave_min_cand(mine);
         if ((tid & 63) == 0) wave_c[tid >> 6] = w;
     }
     __syncthreads();
+    if (SC.wend_slots != nullptr && tid == 14 && red_gvt != kInfNs) atomicMin((long long *)SC.gvt_out, red_gvt);
     if (tid < 11 && red[tid]) atomicAdd(&tot->ev[tid], red[tid]);
     if (tid == 11 && red[11]) atomicAdd(&tot->completed, red[11]);
     if (tid == 12 && red[12]) atomicAdd(&tot->received, red[12]);
@@ -585,10 +609,19 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
         Candidate b = wave_c[0];
         for (int w = 1; w < kBlock / 64; ++w) if (cand_less(wave_c[w], b)) b = wave_c[w];
         long long new_cur = __hip_atomic_load(&tot->final_time, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (flags & 4) {
+            // sharded network: the election continues across the ranks on the host (hs_engine_shard_overshoot runs
+            // the winner); publish this rank's candidate
+            SC.cand_out[0] = b.valid; SC.cand_out[1] = b.t; SC.cand_out[2] = b.t_created;
+            SC.cand_out[3] = SC.lp_base + b.lp;
+            tot->cur_time = new_cur;
+            tot->done = 0;
+            return;
+        }
         if (b.valid) {
             // the one event beyond end_time (core/simulation.py:472): first micro-event of the winner's next group
             NetStation<C> W;
-            load_net<C>(W, P, NP, X, NX, L, b.lp, n, qmem, enqpay, 0, send_idx);
+            load_net<C>(W, P, NP, X, NX, L, b.lp, n, qmem, enqpay, 0, send_idx, SC);
             const int64_t t = W.next_time();
             const int w = W.pick_root(t);
             if (w == 1) (void)W.do_tick(t);
@@ -604,6 +637,56 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
         tot->cur_time = new_cur;
         tot->done = 0;
     }
+}
+
+// Sharded network, after the host exchanged the outbox rows: append the messages other ranks sent to this rank's
+// stations to the incoming bags of parity `send_idx` (the window that just ran), so that the next launch merges
+// them together with the locally sent ones.  Also clears this rank's outbox counters and re-arms the GVT slot
+// the NEXT window will accumulate into.
+__global__ void hs_shard_inject(NetState NX, const int64_t *inbox, int64_t *outbox, int world, int msg_cap, int row,
+                                int n, int64_t lp_base, int send_idx, const int32_t *gid2local, int64_t n_gid,
+                                int64_t *gvt_next, Totals *tot) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0) *gvt_next = kInfNs;
+    if (idx < world) outbox[(size_t)idx * row] = 0;
+    if (idx >= (int64_t)world * msg_cap) return;
+    const int r = (int)(idx / msg_cap), i = (int)(idx % msg_cap);
+    const int64_t *rowp = inbox + (size_t)r * row;
+    const int64_t cnt = rowp[0];
+    if (cnt > msg_cap && i == 0) atomicOr(&tot->overflow, 2);
+    if (i >= cnt) return;
+    const int64_t *m = rowp + 1 + 4 * (size_t)i;
+    const int64_t dst = (m[3] >> 32) - lp_base, gid = m[3] & 0xffffffffll;
+    if (dst < 0 || dst >= n || gid >= n_gid || gid2local[gid] < 0) { atomicOr(&tot->overflow, 4); return; }
+    const size_t cslot = (size_t)send_idx * n + (size_t)dst;
+    const int pos = atomicAdd(&NX.in_cnt[cslot], 1);
+    if (pos < NX.bag_cap) {
+        const size_t b = cslot * NX.bag_cap + pos;
+        NX.in_t[b] = m[0]; NX.in_ts[b] = m[1]; NX.in_cr[b] = m[2]; NX.in_link[b] = gid2local[gid];
+    } else atomicOr(&tot->overflow, 2);
+}
+
+// Sharded network: this rank owns the globally first event beyond end_ns -- process it (core/simulation.py:472).
+template <int C>
+__global__ void hs_shard_overshoot(StationParams P, NetParams NP, StationState X, NetState NX, RecordLogs L,
+                                   Totals *tot, int n, int lp, int win, ShardCtl SC) {
+    __shared__ uint8_t qmem[kQCap][kBlock];
+    __shared__ int64_t enqpay[kEnqPay][kBlock];
+    if (threadIdx.x != 0) return;
+    NetStation<C> W;
+    load_net<C>(W, P, NP, X, NX, L, lp, n, qmem, enqpay, 0, win & 1, SC);
+    const int64_t t = W.next_time();
+    if (t == kInfNs) return;
+    const int w = W.pick_root(t);
+    if (w == 1) (void)W.do_tick(t);
+    else if (w >= 64) (void)W.do_msg(w - 64, t);
+    else (void)W.do_cont_core(w - 2, t);
+    W.last_time = t;
+    store_net<C>(W, X, NX, lp, n);
+    for (int k = 0; k < 11; ++k) if (W.ev[k]) atomicAdd(&tot->ev[k], (unsigned long long)W.ev[k]);
+    if (W.ev[6]) atomicAdd(&tot->completed, (unsigned long long)W.ev[6]);
+    atomicMax(&tot->final_time, (long long)t);
+    tot->cur_time = t;
 }
 
 __global__ void hs_debug_draws_kernel(uint64_t seed, uint64_t sid, uint64_t k0, int64_t n, double rate, double *u,
@@ -651,6 +734,17 @@ struct hs_engine {
     bool is_net = false;
     NetParams NP{};
     NetState NX{};
+    ShardCtl SC{};             // wend_slots == nullptr: the engine holds the whole network
+    bool net_global = false;   // link endpoints are network-wide station indices (set_network with n_global_lp > 0)
+    int32_t n_global_lp = 0;
+    int32_t *gid2local = nullptr;
+    int64_t n_gid = 0;
+    const int64_t *inbox = nullptr;
+    int64_t *shard_gvt = nullptr;
+    int64_t final_win = 0;
+    bool external_stream = false;
+    hipStream_t own_stream = nullptr;
+    std::vector<int32_t> h_link_dst;
     int64_t window_ns = 0;
     bool net_ran = false;
     int n_blocks = 0;
@@ -721,7 +815,7 @@ void launch_run_dispatch(hs_engine *h, int64_t end_ns) {
 template <int C>
 void launch_net(hs_engine *h, int64_t wend, int win, int flags) {
     hipLaunchKernelGGL(hs_net_window<C>, dim3(h->n_blocks), dim3(kBlock), 0, h->stream, h->P, h->NP, h->X, h->NX, h->L,
-                       h->tot, h->cands, h->cfg.n_lp, wend, win, flags);
+                       h->tot, h->cands, h->cfg.n_lp, wend, win, flags, h->SC);
 }
 void launch_net_dispatch(hs_engine *h, int64_t wend, int win, int flags) {
     switch (h->C) {
@@ -804,6 +898,7 @@ int hs_engine_create(const hs_config *cfg, hs_engine **out) {
         return rc;
     }
     h->n_blocks = (cfg->n_lp + kBlock - 1) / kBlock;
+    h->own_stream = h->stream;
     *out = h;
     return HS_OK;
 }
@@ -909,6 +1004,14 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     HS_HIP(h, hipSetDevice(h->cfg.device));
     const int n = h->cfg.n_lp, nl = net->n_links;
     if (nl < 0) return fail(h, HS_E_INVALID, "n_links < 0");
+    // A shard of a larger network: link endpoints are network-wide station indices, this engine owns
+    // [lp_base, lp_base + n_lp).  Otherwise the engine holds the whole network and endpoints are its own indices.
+    const bool global = net->n_global_lp > 0;
+    const int64_t lo = global ? (int64_t)h->cfg.lp_base : 0;
+    const int64_t n_all = global ? net->n_global_lp : n;
+    if (global && (lo + n > n_all)) return fail(h, HS_E_INVALID, "shard [%lld, %lld) exceeds the %lld stations of the network",
+                                                (long long)lo, (long long)(lo + n), (long long)n_all);
+    if (global && !net->link_gid) return fail(h, HS_E_INVALID, "a shard needs link_gid (network-wide link ids)");
     if (!net->egress_kind) return fail(h, HS_E_INVALID, "egress_kind is required");
     if (nl > 0 && (!net->link_dst || !net->link_lat_min_s || !net->link_src))
         return fail(h, HS_E_INVALID, "link_dst, link_src and link_lat_min_s are required");
@@ -923,8 +1026,11 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
         const int64_t w = (int64_t)(lc * 1e9);
         if (w <= 0) return fail(h, HS_E_INVALID, "link %d: min latency %g s truncates to 0 ns", l, lm);
         if (w < W) W = w;
-        if (net->link_dst[l] < 0 || net->link_dst[l] >= n || net->link_src[l] < 0 || net->link_src[l] >= n)
+        if (net->link_dst[l] < 0 || net->link_dst[l] >= n_all || net->link_src[l] < 0 || net->link_src[l] >= n_all)
             return fail(h, HS_E_INVALID, "link %d: endpoint out of range", l);
+        const bool src_here = net->link_src[l] >= lo && net->link_src[l] < lo + n;
+        const bool dst_here = net->link_dst[l] >= lo && net->link_dst[l] < lo + n;
+        if (!src_here && !dst_here) return fail(h, HS_E_INVALID, "link %d touches no station of this shard", l);
         const int jk = net->link_jitter_kind ? net->link_jitter_kind[l] : HS_LAT_CONSTANT;
         if (jk == HS_LAT_EXPONENTIAL && !(net->link_jitter_mean_s && net->link_jitter_mean_s[l] > 0.0))
             return fail(h, HS_E_INVALID, "link %d: exponential jitter needs mean > 0", l);
@@ -935,7 +1041,7 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     std::vector<uint8_t> link_used((size_t)(nl > 0 ? nl : 1), 0);
     auto use_link = [&](int lp, int l) -> int {
         if (l < 0 || l >= nl) return fail(h, HS_E_INVALID, "LP %d: link index %d out of range", lp, l);
-        if (net->link_src[l] != lp) return fail(h, HS_E_INVALID, "LP %d uses link %d whose source is LP %d", lp, l, net->link_src[l]);
+        if (net->link_src[l] != lo + lp) return fail(h, HS_E_INVALID, "LP %d uses link %d whose source is station %d", lp, l, net->link_src[l]);
         if (link_used[(size_t)l]) return fail(h, HS_E_INVALID, "link %d is referenced twice", l);
         link_used[(size_t)l] = 1;
         return HS_OK;
@@ -964,8 +1070,11 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     std::vector<uint64_t> sbase((size_t)n);
     HS_HIP(h, hipMemcpy(sbase.data(), h->P.stream_base, (size_t)n * 8, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; ++i) rbase[(size_t)i] = net->router_stream_base ? net->router_stream_base[i] : sbase[(size_t)i];
-    for (int l = 0; l < nl; ++l)
-        lbase[(size_t)l] = net->link_stream_base ? net->link_stream_base[l] : sbase[(size_t)net->link_src[l]];
+    for (int l = 0; l < nl; ++l) {
+        const int64_t sl = net->link_src[l] - lo;   // incoming links of a shard (remote source) are never drawn from here
+        lbase[(size_t)l] = net->link_stream_base ? net->link_stream_base[l]
+                                                 : (sl >= 0 && sl < n ? sbase[(size_t)sl] : 0);
+    }
     const size_t NL = (size_t)(nl > 0 ? nl : 1);
     std::vector<uint8_t> jk(NL, (uint8_t)HS_LAT_CONSTANT);
     std::vector<double> jm(NL, 0.0), lmin(NL, 1.0);
@@ -987,6 +1096,31 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     if ((rc = upload<uint8_t>(h, &h->NP.link_jit_kind, jk.data(), NL, 1))) return rc;
     if ((rc = upload<double>(h, &h->NP.link_jit_mean, jm.data(), NL, 0.0))) return rc;
     if ((rc = upload<uint64_t>(h, &h->NP.link_base, lbase.data(), NL, 0))) return rc;
+    h->NP.link_gid = nullptr;
+    if (net->link_gid && nl > 0) {
+        std::vector<int32_t> gid((size_t)nl);
+        int64_t gmax = -1;
+        for (int l = 0; l < nl; ++l) {
+            if (net->link_gid[l] < 0 || net->link_gid[l] > 0x7fffffffll) return fail(h, HS_E_INVALID, "link %d: bad link_gid", l);
+            gid[(size_t)l] = (int32_t)net->link_gid[l];
+            if (net->link_gid[l] > gmax) gmax = net->link_gid[l];
+        }
+        h->n_gid = net->n_global_links > gmax + 1 ? net->n_global_links : gmax + 1;
+        std::vector<int32_t> g2l((size_t)h->n_gid, -1);
+        for (int l = 0; l < nl; ++l) {
+            if (g2l[(size_t)gid[(size_t)l]] >= 0) return fail(h, HS_E_INVALID, "link_gid %d appears twice", gid[(size_t)l]);
+            g2l[(size_t)gid[(size_t)l]] = l;
+        }
+        if ((rc = upload<int32_t>(h, &h->NP.link_gid, gid.data(), (size_t)nl, 0))) return rc;
+        const int32_t *g2l_dev = nullptr;
+        if ((rc = upload<int32_t>(h, &g2l_dev, g2l.data(), (size_t)h->n_gid, -1))) return rc;
+        h->gid2local = const_cast<int32_t *>(g2l_dev);
+    }
+    h->net_global = global;
+    h->n_global_lp = (int32_t)n_all;
+    h->SC = ShardCtl{};
+    h->SC.lp_base = lo;
+    h->h_link_dst.assign(ldst.begin(), ldst.end());
     const int bag = net->bag_capacity > 0 ? net->bag_capacity : 16;
     h->NX.bag_cap = bag;
     const size_t N = (size_t)n, NB = (size_t)n * (size_t)bag;
@@ -1000,6 +1134,143 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     }
     h->L.sink_created = h->L.sink_created_own;
     h->is_net = true;
+    return HS_OK;
+}
+
+int hs_engine_set_stream(hs_engine *h, void *hip_stream, int external) {
+    if (!h) return fail(h, HS_E_INVALID, "null handle");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    // external != 0: run on the caller's stream; a NULL handle then means the device's default (null) stream,
+    // which is what torch.cuda.current_stream().cuda_stream is unless the caller switched streams
+    h->stream = external ? (hipStream_t)hip_stream : h->own_stream;
+    h->external_stream = external != 0;
+    return HS_OK;
+}
+
+int hs_engine_shard_attach(hs_engine *h, const hs_shard *sh) {
+    if (!h || !sh) return fail(h, HS_E_INVALID, "hs_engine_shard_attach: null argument");
+    if (!h->is_net || !h->net_global) return fail(h, HS_E_STATE, "set a network with n_global_lp > 0 before attaching the shard");
+    if (h->initialised) return fail(h, HS_E_STATE, "attach the shard before the first run");
+    if (sh->world < 1 || sh->rank < 0 || sh->rank >= sh->world || !sh->shard_lo)
+        return fail(h, HS_E_INVALID, "bad rank / world / shard_lo");
+    if (sh->shard_lo[sh->rank] != (int64_t)h->cfg.lp_base || sh->shard_lo[sh->rank + 1] != (int64_t)h->cfg.lp_base + h->cfg.n_lp)
+        return fail(h, HS_E_INVALID, "shard_lo[rank] does not match this engine's [lp_base, lp_base + n_lp)");
+    if (sh->shard_lo[0] != 0 || sh->shard_lo[sh->world] != h->n_global_lp)
+        return fail(h, HS_E_INVALID, "shard_lo must cover [0, n_global_lp)");
+    if (!sh->outbox_dev || !sh->inbox_dev || !sh->gvt_dev || !sh->cand_dev || sh->msg_capacity < 1)
+        return fail(h, HS_E_INVALID, "exchange buffers are required");
+    if (sh->window_ns < 1 || sh->window_ns > h->window_ns)
+        return fail(h, HS_E_INVALID, "window_ns must be the minimum lookahead over ALL shards (got %lld, this shard's links allow %lld)",
+                    (long long)sh->window_ns, (long long)h->window_ns);
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    const int nl = h->NP.n_links;
+    std::vector<int32_t> lrank((size_t)(nl > 0 ? nl : 1), sh->rank);
+    for (int l = 0; l < nl; ++l) {
+        const int64_t d = h->h_link_dst[(size_t)l];
+        int r = 0;
+        while (r + 1 < sh->world && d >= sh->shard_lo[r + 1]) ++r;
+        lrank[(size_t)l] = r;
+    }
+    int rc;
+    if ((rc = upload<int32_t>(h, &h->SC.link_rank, lrank.data(), lrank.size(), 0))) return rc;
+    if ((rc = dev_alloc(h, &h->SC.wend_slots, 2))) return rc;
+    h->SC.gvt_in = sh->gvt_dev; h->SC.gvt_out = sh->gvt_dev;     // re-pointed per launch (parity)
+    h->SC.outbox = sh->outbox_dev; h->SC.cand_out = sh->cand_dev;
+    h->SC.msg_cap = sh->msg_capacity; h->SC.row = 1 + 4 * sh->msg_capacity;
+    h->SC.rank = sh->rank; h->SC.world = sh->world;
+    h->SC.W = sh->window_ns;
+    h->SC.lp_base = (int64_t)h->cfg.lp_base;
+    h->inbox = sh->inbox_dev;
+    h->window_ns = sh->window_ns;
+    h->shard_gvt = sh->gvt_dev;
+    return HS_OK;
+}
+
+// Sharded run, driven by the host one window at a time (all calls only enqueue work on the engine's stream):
+//   begin;  for k = 0, 1, ...: window(k); <all-to-all outbox -> inbox>; inject(k); <all-reduce(min) gvt[k & 1]>;
+//   every so often progress() (synchronises) until the returned window end reaches end_ns;
+//   final(k); <all-gather cand>; overshoot(lp) on the winner.
+int hs_engine_shard_begin(hs_engine *h, int64_t end_ns) {
+    if (!h || !h->SC.wend_slots) return fail(h, HS_E_STATE, "hs_engine_shard_begin: no shard attached");
+    if (end_ns > h->cfg.horizon_ns) return fail(h, HS_E_INVALID, "end_ns beyond the configured horizon");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = do_reset_async(h);
+    if (rc) return rc;
+    h->SC.end_ns = end_ns;
+    const int64_t init_slots[2] = {h->cfg.start_ns - 1, h->cfg.start_ns - 1};
+    const int64_t init_gvt[2] = {kInfNs, h->cfg.start_ns};       // window 0 reads gvt[1], accumulates into gvt[0]
+    HS_HIP(h, hipMemcpyAsync(h->SC.wend_slots, init_slots, sizeof init_slots, hipMemcpyHostToDevice, h->stream));
+    HS_HIP(h, hipMemcpyAsync(h->shard_gvt, init_gvt, sizeof init_gvt, hipMemcpyHostToDevice, h->stream));
+    HS_HIP(h, hipMemsetAsync(h->SC.outbox, 0, (size_t)h->SC.world * h->SC.row * 8, h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));                   // the host arrays above are stack memory
+    h->launches = 1;
+    h->net_ran = true;
+    return HS_OK;
+}
+
+int hs_engine_shard_window(hs_engine *h, int64_t k) {
+    if (!h || !h->SC.wend_slots) return fail(h, HS_E_STATE, "hs_engine_shard_window: no shard attached");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    h->SC.gvt_in = h->shard_gvt + ((k + 1) & 1);
+    h->SC.gvt_out = h->shard_gvt + (k & 1);
+    launch_net_dispatch(h, 0, (int)(k & 0x3fffffff), h->flags & 1);
+    HS_HIP(h, hipGetLastError());
+    h->launches++;
+    return HS_OK;
+}
+
+int hs_engine_shard_inject(hs_engine *h, int64_t k) {
+    if (!h || !h->SC.wend_slots) return fail(h, HS_E_STATE, "hs_engine_shard_inject: no shard attached");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    const int64_t items = (int64_t)h->SC.world * h->SC.msg_cap;
+    const unsigned blocks = (unsigned)((items + 255) / 256);
+    hipLaunchKernelGGL(hs_shard_inject, dim3(blocks ? blocks : 1), dim3(256), 0, h->stream, h->NX, h->inbox, h->SC.outbox,
+                       h->SC.world, h->SC.msg_cap, h->SC.row, h->cfg.n_lp, h->SC.lp_base, (int)(k & 1), h->gid2local,
+                       h->n_gid, h->shard_gvt + ((k + 1) & 1), h->tot);
+    HS_HIP(h, hipGetLastError());
+    h->launches++;
+    return HS_OK;
+}
+
+int hs_engine_shard_progress(hs_engine *h, int64_t k_last, int64_t *wend_out) {
+    if (!h || !h->SC.wend_slots || !wend_out) return fail(h, HS_E_STATE, "hs_engine_shard_progress: no shard attached");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    HS_HIP(h, hipMemcpyAsync(wend_out, h->SC.wend_slots + (k_last & 1), 8, hipMemcpyDeviceToHost, h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    Totals t;
+    HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
+    if (t.qoverflow) return fail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
+    if (t.overflow & 4) return fail(h, HS_E_INVALID, "a message arrived for a station or link this shard does not own");
+    if (t.overflow & 2) return fail(h, HS_E_OVERFLOW, "a message bag or an exchange row overflowed; raise bag_capacity / msg_capacity");
+    if (t.overflow) return fail(h, HS_E_OVERFLOW, "a per-LP record log overflowed (capacity %lld records)", (long long)h->L.cap);
+    return HS_OK;
+}
+
+int hs_engine_shard_final(hs_engine *h, int64_t k) {
+    if (!h || !h->SC.wend_slots) return fail(h, HS_E_STATE, "hs_engine_shard_final: no shard attached");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    h->SC.gvt_in = h->shard_gvt + ((k + 1) & 1);
+    h->SC.gvt_out = h->shard_gvt + (k & 1);
+    launch_net_dispatch(h, h->SC.end_ns, (int)(k & 0x3fffffff), (h->flags & 1) | 2 | 4);
+    HS_HIP(h, hipGetLastError());
+    h->launches++;
+    h->final_win = k;
+    return HS_OK;
+}
+
+int hs_engine_shard_overshoot(hs_engine *h, int32_t lp) {
+    if (!h || !h->SC.wend_slots) return fail(h, HS_E_STATE, "hs_engine_shard_overshoot: no shard attached");
+    if (lp < 0 || lp >= h->cfg.n_lp) return fail(h, HS_E_INVALID, "LP index %d out of range", lp);
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    const int win = (int)(h->final_win & 0x3fffffff);
+    switch (h->C) {
+        case 1: hipLaunchKernelGGL(hs_shard_overshoot<1>, dim3(1), dim3(64), 0, h->stream, h->P, h->NP, h->X, h->NX, h->L, h->tot, h->cfg.n_lp, lp, win, h->SC); break;
+        case 2: hipLaunchKernelGGL(hs_shard_overshoot<2>, dim3(1), dim3(64), 0, h->stream, h->P, h->NP, h->X, h->NX, h->L, h->tot, h->cfg.n_lp, lp, win, h->SC); break;
+        default: hipLaunchKernelGGL(hs_shard_overshoot<4>, dim3(1), dim3(64), 0, h->stream, h->P, h->NP, h->X, h->NX, h->L, h->tot, h->cfg.n_lp, lp, win, h->SC); break;
+    }
+    HS_HIP(h, hipGetLastError());
+    h->launches++;
     return HS_OK;
 }
 
@@ -1035,6 +1306,7 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
     if (!h->initialised) { int rc = do_reset_async(h); if (rc) return rc; h->launches++; }
     HS_HIP(h, hipEventRecord(h->ev_k0, h->stream));
     if (h->is_net) {
+        if (h->net_global) return fail(h, HS_E_STATE, "a shard of a partitioned network is driven with hs_engine_shard_*");
         if (h->net_ran) return fail(h, HS_E_STATE, "network engine: one hs_engine_run_until per hs_engine_reset");
         int rc = run_net_async(h, end_ns);
         if (rc) return rc;
@@ -1200,7 +1472,7 @@ void hs_engine_destroy(hs_engine *h) {
     if (h->ev_b) hipEventDestroy(h->ev_b);
     if (h->ev_k0) hipEventDestroy(h->ev_k0);
     if (h->ev_k1) hipEventDestroy(h->ev_k1);
-    if (h->stream) hipStreamDestroy(h->stream);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
 }
 

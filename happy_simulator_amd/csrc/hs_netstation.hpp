@@ -40,6 +40,23 @@ struct NetParams {
     const uint8_t *link_jit_kind; // [n_links] 0 = ExponentialLatency jitter, 1 = no jitter
     const double *link_jit_mean;  // [n_links]
     const uint64_t *link_base;    // [n_links] stream base of the link entity
+    const int32_t *link_gid;      // [n_links] network-wide link id (tie-break key); null = the index itself
+};
+
+// A network partitioned over several engines (one per GPU): links whose destination station lives on another
+// engine put their messages into an OUTBOX row per destination rank instead of the destination's bag; the host
+// exchanges the rows between the ranks after every window (torch.distributed all-to-all over RCCL) and the
+// receiver injects them into its bags (hs_shard_inject).  Window ends follow the global virtual time:
+// wend = min(end, max(prev_wend + 1, GVT) + W - 1), GVT = all-reduce(min) over the ranks' earliest pending work.
+struct ShardCtl {
+    int64_t *wend_slots;          // [2] window end of launch k at [k & 1]; null = unsharded (host passes wend)
+    const int64_t *gvt_in;        // GVT after the previous window (all-reduced)
+    int64_t *gvt_out;             // this rank's earliest pending work after this window (atomicMin)
+    int64_t end_ns, W, lp_base;
+    int64_t *outbox;              // [world][row] : row = {count, 4 x int64 per message ...}
+    int64_t *cand_out;            // [4] {valid, t, t_created, global lp} of the rank's first event beyond end_ns
+    const int32_t *link_rank;     // [n_links] rank that owns the link's destination station
+    int32_t msg_cap, row, rank, world;
 };
 
 struct NetState {
@@ -89,6 +106,8 @@ struct NetStation {
     // network
     const NetParams *np;
     const NetState *ns;
+    const ShardCtl *sc;
+    int64_t sent_min;             // earliest arrival among the messages this LP sent in this window
     int send_idx;
     int32_t bag_n;
     // in-group FIFO + ENQ payloads (LDS columns)
@@ -219,14 +238,28 @@ struct NetStation {
         }
         if (!(delay > 0.0)) delay = 0.0;                                               // max(0.0, delay)
         const int64_t t_arr = t + ns_from_seconds(delay);
-        const int32_t dst = np->link_dst[l];
-        const size_t cslot = (size_t)send_idx * n + dst;
+        sent_min = t_arr < sent_min ? t_arr : sent_min;
+        const int32_t dst = np->link_dst[l];                 // network-wide station index
+        if (sc->wend_slots != nullptr && sc->link_rank[l] != sc->rank) {
+            // destination lives on another engine: append to that rank's outbox row
+            int64_t *row = sc->outbox + (size_t)sc->link_rank[l] * sc->row;
+            const unsigned long long pos = atomicAdd((unsigned long long *)row, 1ull);
+            if (pos < (unsigned long long)sc->msg_cap) {
+                int64_t *m = row + 1 + 4 * pos;
+                const int64_t gid = np->link_gid ? np->link_gid[l] : l;
+                m[0] = t_arr; m[1] = t; m[2] = created; m[3] = ((int64_t)dst << 32) | gid;
+            } else bagoverflow = 1;
+            return;
+        }
+        const int32_t dl = dst - (int32_t)sc->lp_base;       // local index on this engine
+        const size_t cslot = (size_t)send_idx * n + dl;
         const int pos = atomicAdd(&ns->in_cnt[cslot], 1);
         if (pos < ns->bag_cap) {
             const size_t b = cslot * ns->bag_cap + pos;
             ns->in_t[b] = t_arr; ns->in_ts[b] = t; ns->in_cr[b] = created; ns->in_link[b] = l;
         } else bagoverflow = 1;
     }
+    __device__ __forceinline__ int64_t gid_of(int64_t l) const { return np->link_gid ? np->link_gid[l] : l; }
 
     // generator resumes (server/server.py:252-273): statistics only
     __device__ __forceinline__ int64_t do_cont_core(int slot, int64_t t) {
@@ -299,7 +332,7 @@ struct NetStation {
         for (int i = 0; i < bag_n; ++i) {
             if (ns->bag_t[bidx(i)] != t) continue;
             const int64_t ts = ns->bag_ts[bidx(i)];
-            const int64_t ln = ns->bag_link[bidx(i)];
+            const int64_t ln = gid_of(ns->bag_link[bidx(i)]);
             bool better;
             if (best == 0) better = true;
             else if (!bmsg) better = ts < bc;                       // local event first on equal creation time

@@ -57,6 +57,10 @@ class NetworkArrays:
     router_stream_base: np.ndarray | None = None
     link_stream_base: np.ndarray | None = None
     bag_capacity: int = 0
+    # one shard of a partitioned network (happy_simulator_amd/sharded.py): network-wide endpoints and link ids
+    n_global_lp: int = 0
+    link_gid: np.ndarray | None = None
+    n_global_links: int = 0
 
     @property
     def n_links(self) -> int:
@@ -143,6 +147,9 @@ class StationEngine:
         put("link_jitter_mean_s", net.link_jitter_mean_s, np.float64, nl)
         put("link_stream_base", net.link_stream_base, np.uint64, nl)
         nw.bag_capacity = int(net.bag_capacity)
+        nw.n_global_lp = int(net.n_global_lp)
+        put("link_gid", net.link_gid, np.int64, nl)
+        nw.n_global_links = int(net.n_global_links)
         self._check(self._lib.hs_engine_set_network(self._h, C.byref(nw)))
         self.n_links = nl
 
@@ -168,6 +175,13 @@ class StationEngine:
         raise N.EngineError(rc, msg)
 
     # -- run control ---------------------------------------------------------------------------
+    def set_stream(self, hip_stream: int | None):
+        """Enqueue on the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream); None = own stream."""
+        if hip_stream is None:
+            self._check(self._lib.hs_engine_set_stream(self._h, None, 0))
+        else:
+            self._check(self._lib.hs_engine_set_stream(self._h, C.c_void_p(int(hip_stream)), 1))
+
     def reset(self):
         self._check(self._lib.hs_engine_reset(self._h))
 

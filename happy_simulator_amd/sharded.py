@@ -1,0 +1,332 @@
+"""A station network partitioned over several engines -- one shard per GPU, one process per GPU.
+
+This is the MI355X form of the reference's coordinated parallel run
+(`ParallelSimulation._run_coordinated` -> `WindowedCoordinator.run`, happysimulator/parallel/simulation.py:197-223,
+parallel/coordinator.py:75-172): EXECUTE every partition to the window end, EXCHANGE the cross-partition events,
+ADVANCE.  Differences by design:
+
+* a partition is a contiguous block of station LPs resident in one GPU's HBM (`shard_bounds`), not a thread;
+* the exchange is one all-to-all of fixed-size outbox rows (RCCL over xGMI) instead of Python lists drained on
+  the main thread, and the receiver injects the messages on the device (`hs_engine_shard_inject`);
+* window ends follow the global virtual time: `wend = min(end, max(prev + 1, GVT) + W - 1)` with
+  `GVT = all_reduce(min)` of every rank's earliest pending work and `W` = the smallest link latency (the
+  reference's `min(link.min_latency)`, parallel/simulation.py:82-87) -- idle stretches are skipped in one step;
+* nothing runs past the end of a window, so the reference's windowed "time travel" drops
+  cannot happen: the result is bit-identical to the single-heap run, for any number of shards.
+
+The per-window protocol only ENQUEUES device work (engine launches and collectives share torch's current
+stream); the host synchronises once every `sync_every` windows to learn how far the GVT has advanced.
+
+`LocalComm` runs several shards inside one process on one GPU (virtual shards) with tensor copies in place of
+RCCL -- same protocol, same kernels -- so the sharding logic is testable on a single-GPU box.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _native as N
+from .engine import EngineSummary, NetworkArrays, StationArrays, StationEngine
+
+INF_NS = np.iinfo(np.int64).max
+
+
+def shard_bounds(n_stations: int, world: int) -> np.ndarray:
+    """Contiguous block partition: rank r owns stations [lo[r], lo[r+1])."""
+    base, rem = divmod(n_stations, world)
+    sizes = [base + (1 if r < rem else 0) for r in range(world)]
+    return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# communicators: how rows / scalars travel between shards
+# ------------------------------------------------------------------------------------------------------------
+class LocalComm:
+    """All `world` shards live in this process (virtual shards on one device): copies instead of collectives."""
+
+    def __init__(self, world: int):
+        self.world = world
+        self.local_ranks = list(range(world))
+
+    def exchange(self, outboxes, inboxes):
+        import torch
+
+        stacked = torch.stack(outboxes)                  # [src, dst, row]
+        for j, inbox in enumerate(inboxes):
+            inbox.copy_(stacked[:, j, :])                # row i of shard j's inbox = what shard i sent to j
+
+    def allreduce_min(self, scalars):
+        import torch
+
+        m = torch.stack([s.reshape(()) for s in scalars]).min()
+        for s in scalars:
+            s.fill_(m)
+
+    def allgather_rows(self, rows):
+        import torch
+
+        return torch.stack(rows).cpu().numpy()
+
+    def reduce_host(self, dicts):
+        return _combine(dicts)
+
+
+class DistComm:
+    """One shard per process: torch.distributed (backend "nccl" is RCCL on ROCm; "gloo" on CPU tensors for tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        self._dist = dist
+        self._group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.local_ranks = [self.rank]
+
+    def exchange(self, outboxes, inboxes):
+        self._dist.all_to_all_single(inboxes[0], outboxes[0], group=self._group)
+
+    def allreduce_min(self, scalars):
+        self._dist.all_reduce(scalars[0], op=self._dist.ReduceOp.MIN, group=self._group)
+
+    def allgather_rows(self, rows):
+        import torch
+
+        out = [torch.empty_like(rows[0]) for _ in range(self.world)]
+        self._dist.all_gather(out, rows[0], group=self._group)
+        return torch.stack(out).cpu().numpy()
+
+    def reduce_host(self, dicts):
+        import torch
+
+        local = _combine(dicts)
+        dev = "cuda" if self._dist.get_backend(self._group) == "nccl" else "cpu"
+        out = {}
+        for k in sorted(local):
+            v = local[k]
+            if isinstance(v, np.ndarray):
+                t = torch.as_tensor(v, dtype=torch.int64, device=dev).clone()
+            else:
+                t = torch.tensor([int(v)], dtype=torch.int64, device=dev)
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX if k.startswith("max_") else self._dist.ReduceOp.SUM,
+                                  group=self._group)
+            out[k] = t.cpu().numpy() if isinstance(v, np.ndarray) else int(t.item())
+        return out
+
+
+def _combine(dicts):
+    out = {}
+    for d in dicts:
+        for k, v in d.items():
+            if k not in out:
+                out[k] = v.copy() if isinstance(v, np.ndarray) else v
+            elif k.startswith("max_"):
+                out[k] = max(out[k], v)
+            else:
+                out[k] = out[k] + v
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# splitting a network description into shards
+# ------------------------------------------------------------------------------------------------------------
+def shard_arrays(stations: StationArrays, net: NetworkArrays, lo: int, hi: int):
+    """The slice [lo, hi) of a network as (StationArrays, NetworkArrays) for one engine: local stations, every link
+    that starts or ends in the slice (network-wide endpoints + ids), router / link references re-indexed."""
+    n = stations.n
+    sl = slice(lo, hi)
+    base = stations.stream_base if stations.stream_base is not None else np.arange(n, dtype=np.uint64)
+    st = StationArrays(
+        n=hi - lo, src_kind=stations.src_kind[sl], src_rate=stations.src_rate[sl],
+        src_stop_after_ns=stations.src_stop_after_ns[sl], concurrency=stations.concurrency[sl],
+        svc_kind=stations.svc_kind[sl], svc_mean_s=stations.svc_mean_s[sl], queue_cap=stations.queue_cap[sl],
+        egress=stations.egress[sl], seed=None if stations.seed is None else stations.seed[sl],
+        stream_base=np.asarray(base, np.uint64)[sl])
+    src, dst = np.asarray(net.link_src), np.asarray(net.link_dst)
+    touch = ((src >= lo) & (src < hi)) | ((dst >= lo) & (dst < hi))
+    gids = np.nonzero(touch)[0].astype(np.int64)
+    local_of = np.full(net.n_links, -1, np.int64)
+    local_of[gids] = np.arange(len(gids))
+
+    def remap(a):
+        a = np.asarray(a, np.int64)[sl]
+        return np.where(a >= 0, local_of[np.clip(a, 0, max(net.n_links - 1, 0))], a).astype(np.int32)
+
+    lbase = net.link_stream_base if net.link_stream_base is not None else np.asarray(base, np.uint64)[src]
+    rbase = net.router_stream_base if net.router_stream_base is not None else np.asarray(base, np.uint64)
+    sub = NetworkArrays(
+        egress_kind=net.egress_kind[sl], router_target0=remap(net.router_target0),
+        router_target1=remap(net.router_target1), link_of=remap(net.link_of),
+        link_src=src[gids].astype(np.int32), link_dst=dst[gids].astype(np.int32),
+        link_lat_min_s=np.asarray(net.link_lat_min_s)[gids], link_jitter_kind=np.asarray(net.link_jitter_kind)[gids],
+        link_jitter_mean_s=np.asarray(net.link_jitter_mean_s)[gids],
+        router_stream_base=np.asarray(rbase, np.uint64)[sl], link_stream_base=np.asarray(lbase, np.uint64)[gids],
+        bag_capacity=net.bag_capacity, n_global_lp=n, link_gid=gids, n_global_links=net.n_links)
+    return st, sub
+
+
+# ------------------------------------------------------------------------------------------------------------
+# one shard on the GPU
+# ------------------------------------------------------------------------------------------------------------
+class GpuShard:
+    """One engine + its exchange tensors (torch owns the device memory so torch.distributed can move it)."""
+
+    def __init__(self, stations: StationArrays, net: NetworkArrays, rank: int, bounds: np.ndarray, *, horizon_ns: int,
+                 start_ns: int = 0, seed: int = 42, device: int = 0, msg_capacity: int = 256, log_capacity: int = 0):
+        import torch
+
+        self.rank, self.world = rank, len(bounds) - 1
+        self.lo, self.hi = int(bounds[rank]), int(bounds[rank + 1])
+        self.bounds = np.ascontiguousarray(bounds, np.int64)
+        self.gids = np.asarray(net.link_gid, np.int64)
+        self.msg_capacity = msg_capacity
+        dev = torch.device("cuda", device)
+        row = 1 + 4 * msg_capacity
+        self.outbox = torch.zeros((self.world, row), dtype=torch.int64, device=dev)
+        self.inbox = torch.zeros((self.world, row), dtype=torch.int64, device=dev)
+        self.gvt = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.cand = torch.zeros(4, dtype=torch.int64, device=dev)
+        self.engine = StationEngine(stations, mode=N.MODE_SINGLE, horizon_ns=horizon_ns, start_ns=start_ns, seed=seed,
+                                    lp_base=self.lo, device=device, log_capacity=log_capacity, network=net)
+        self.engine.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        self.local_window_ns = self.engine.summary().window_ns
+        self._attached = False
+
+    def attach(self, window_ns: int):
+        sh = N.Shard(self.rank, self.world, self.bounds.ctypes.data, self.outbox.data_ptr(), self.inbox.data_ptr(),
+                     self.msg_capacity, 0, int(window_ns), self.gvt.data_ptr(), self.cand.data_ptr())
+        e = self.engine
+        e._check(e._lib.hs_engine_shard_attach(e._h, C.byref(sh)))
+        self._attached = True
+
+    # -- the per-window protocol (enqueue only) ------------------------------------------------------------
+    def begin(self, end_ns):
+        e = self.engine
+        e._check(e._lib.hs_engine_shard_begin(e._h, int(end_ns)))
+
+    def window(self, k):
+        e = self.engine
+        e._check(e._lib.hs_engine_shard_window(e._h, k))
+
+    def inject(self, k):
+        e = self.engine
+        e._check(e._lib.hs_engine_shard_inject(e._h, k))
+
+    def gvt_slot(self, k):
+        return self.gvt[(k & 1):(k & 1) + 1]
+
+    def progress(self, k_last) -> int:
+        e = self.engine
+        w = C.c_int64(0)
+        e._check(e._lib.hs_engine_shard_progress(e._h, k_last, C.byref(w)))
+        return int(w.value)
+
+    def final(self, k):
+        e = self.engine
+        e._check(e._lib.hs_engine_shard_final(e._h, k))
+
+    def overshoot(self, lp_local):
+        e = self.engine
+        e._check(e._lib.hs_engine_shard_overshoot(e._h, int(lp_local)))
+
+    def totals(self) -> dict:
+        s = self.engine.summary()
+        return {"events": s.events_processed, "by_kind": s.events_by_kind.copy(), "completed": s.requests_completed,
+                "sink_records": s.sink_records, "max_final_ns": s.final_time_ns, "launches": s.launches}
+
+    def close(self):
+        self.engine.close()
+
+
+@dataclass
+class ShardedSummary:
+    events_processed: int
+    events_by_kind: np.ndarray
+    requests_completed: int
+    sink_records: int
+    final_time_ns: int
+    windows: int
+    window_ns: int
+    world: int
+
+
+class ShardedNetwork:
+    """Drives the shards this process owns through the window protocol.  `shards` are the local shard objects
+    (GpuShard, or any object with the same methods), `comm` moves rows and scalars between all shards."""
+
+    def __init__(self, shards: list, comm, *, window_ns: int, sync_every: int = 64):
+        self.shards = shards
+        self.comm = comm
+        self.window_ns = int(window_ns)
+        self.sync_every = max(1, int(sync_every))
+        self.windows = 0
+
+    @classmethod
+    def on_gpu(cls, stations: StationArrays, net: NetworkArrays, comm, *, horizon_ns: int, start_ns: int = 0,
+               seed: int = 42, device: int = 0, msg_capacity: int = 256, log_capacity: int = 0, sync_every: int = 64):
+        """Partition `stations` / `net` (network-wide descriptions, identical on every rank) over comm.world shards
+        and build the shards this process owns on `device`."""
+        import torch
+
+        bounds = shard_bounds(stations.n, comm.world)
+        shards = []
+        for r in comm.local_ranks:
+            st, sub = shard_arrays(stations, net, int(bounds[r]), int(bounds[r + 1]))
+            shards.append(GpuShard(st, sub, r, bounds, horizon_ns=horizon_ns, start_ns=start_ns, seed=seed,
+                                   device=device, msg_capacity=msg_capacity, log_capacity=log_capacity))
+        # the lookahead is a property of the whole network: min over all shards' links
+        dev = shards[0].gvt.device
+        w = [torch.tensor([s.local_window_ns], dtype=torch.int64, device=dev) for s in shards]
+        comm.allreduce_min(w)
+        window_ns = int(w[0].item())
+        for s in shards:
+            s.attach(window_ns)
+        return cls(shards, comm, window_ns=window_ns, sync_every=sync_every)
+
+    def run_until(self, end_ns: int) -> ShardedSummary:
+        sh, comm = self.shards, self.comm
+        for s in sh:
+            s.begin(end_ns)
+        k = 0
+        while True:
+            for _ in range(self.sync_every):
+                for s in sh:
+                    s.window(k)                                        # EXECUTE
+                comm.exchange([s.outbox for s in sh], [s.inbox for s in sh])   # EXCHANGE
+                for s in sh:
+                    s.inject(k)
+                comm.allreduce_min([s.gvt_slot(k) for s in sh])        # GVT
+                k += 1
+            wends = [s.progress(k - 1) for s in sh]                    # the only host synchronisation
+            if min(wends) >= end_ns:
+                break
+        self.windows = k
+        for s in sh:
+            s.final(k)
+        cands = comm.allgather_rows([s.cand for s in sh])              # [world, 4]: valid, t, t_created, station
+        valid = cands[cands[:, 0] != 0]
+        winner_t = None
+        if len(valid):
+            order = np.lexsort((valid[:, 3], valid[:, 2], valid[:, 1]))  # by (t, t_created, station)
+            _, t, _, station = (int(x) for x in valid[order[0]])
+            winner_t = t
+            for s in sh:
+                if s.lo <= station < s.hi:
+                    s.overshoot(station - s.lo)                        # the one event beyond end_time
+        tot = comm.reduce_host([s.totals() for s in sh])
+        final = winner_t if winner_t is not None else int(tot["max_final_ns"])
+        return ShardedSummary(events_processed=int(tot["events"]), events_by_kind=np.asarray(tot["by_kind"]),
+                              requests_completed=int(tot["completed"]), sink_records=int(tot["sink_records"]),
+                              final_time_ns=final, windows=k, window_ns=self.window_ns, world=comm.world)
+
+    def close(self):
+        for s in self.shards:
+            s.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

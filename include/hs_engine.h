@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HS_ABI_VERSION 2
+#define HS_ABI_VERSION 3
 
 typedef enum hs_status {
     HS_OK = 0,
@@ -127,7 +127,32 @@ typedef struct hs_network {
     const uint64_t *link_stream_base;/* [n_links] NULL = stream base of the source station */
     const int32_t *link_src;         /* [n_links] source station (for the default stream base and validation) */
     int32_t bag_capacity;            /* in-flight messages per destination station; 0 = 16 */
+    /* --- one shard of a network partitioned over several engines (one per GPU); 0 / NULL = the whole network ---
+     * The engine owns stations [cfg.lp_base, cfg.lp_base + cfg.n_lp) of n_global_lp; link_src / link_dst are then
+     * NETWORK-WIDE station indices, the link table holds every link that starts or ends in the shard, and
+     * link_gid gives each link its network-wide id.  This is the engine-side form of the reference's
+     * SimulationPartition / PartitionLink split (parallel/partition.py:21-38, parallel/link.py:18-79). */
+    int32_t n_global_lp;
+    const int64_t *link_gid;         /* [n_links] */
+    int64_t n_global_links;
 } hs_network;
+
+/* Exchange buffers of a shard: device memory owned by the caller (torch tensors on the host side, so that
+ * torch.distributed / RCCL can move them).  A row is {count, then 4 x int64 per message}: arrival ns, send ns,
+ * created_at ns, (destination station << 32 | link gid).  Replaces the reference's per-partition Python outbox lists
+ * (parallel/simulation.py:107,142-151) and `_exchange_events` (parallel/coordinator.py:182-227). */
+typedef struct hs_shard {
+    int32_t rank, world;
+    const int64_t *shard_lo;         /* host, [world + 1]: rank r owns stations [shard_lo[r], shard_lo[r+1]) */
+    int64_t *outbox_dev;             /* device int64 [world][1 + 4 * msg_capacity]: row r = messages for rank r */
+    int64_t *inbox_dev;              /* device, same shape: row r = messages from rank r (after the all-to-all) */
+    int32_t msg_capacity;
+    int32_t reserved;
+    int64_t window_ns;               /* lookahead W = min over ALL shards of hs_summary.window_ns (caller all-reduces) */
+    int64_t *gvt_dev;                /* device int64[2]: window k accumulates this rank's earliest pending work into
+                                        [k & 1]; the caller all-reduces (min) it before window k + 1 reads it */
+    int64_t *cand_dev;               /* device int64[4]: {valid, t, t_created, station} first event beyond end_ns */
+} hs_shard;
 
 typedef struct hs_net_stats {
     int64_t *routed;                 /* [n_lp]    RandomRouter.stats_routed            components/random_router.py:36 */
@@ -180,6 +205,27 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st);
  * hs_engine_run_until per hs_engine_reset (windows are internal, the call is not re-entrant). */
 int hs_engine_set_network(hs_engine *h, const hs_network *net);
 int hs_engine_get_net_stats(hs_engine *h, const hs_net_stats *out);
+/* external != 0: run on the caller's HIP stream (e.g. torch's current stream, so that collectives and engine
+ * launches are ordered by the stream; a NULL handle is the device's default stream).  external == 0: back to the
+ * engine's own stream. */
+int hs_engine_set_stream(hs_engine *h, void *hip_stream, int external);
+/* Sharded network = WindowedCoordinator.run (parallel/coordinator.py:75-172) with one partition per GPU and
+ * GVT-driven windows.  After create / set_stations / set_network(n_global_lp > 0) / shard_attach, per run:
+ *   shard_begin(end);
+ *   for k = 0, 1, 2, ...:  shard_window(k)            EXECUTE: window end = min(end, max(prev+1, GVT) + W - 1)
+ *                          all-to-all outbox -> inbox   EXCHANGE (caller: RCCL)
+ *                          shard_inject(k)
+ *                          all-reduce(min) gvt_dev[k&1] GVT     (caller: RCCL)
+ *      until shard_progress(k) reports a window end == end;
+ *   shard_final(k+1); all-gather cand_dev; shard_overshoot(station - lp_base) on the rank that owns the minimum.
+ * All calls except shard_progress only enqueue work on the engine's stream. */
+int hs_engine_shard_attach(hs_engine *h, const hs_shard *sh);
+int hs_engine_shard_begin(hs_engine *h, int64_t end_ns);
+int hs_engine_shard_window(hs_engine *h, int64_t k);
+int hs_engine_shard_inject(hs_engine *h, int64_t k);
+int hs_engine_shard_progress(hs_engine *h, int64_t k_last, int64_t *window_end_out);
+int hs_engine_shard_final(hs_engine *h, int64_t k);
+int hs_engine_shard_overshoot(hs_engine *h, int32_t lp);
 /* Simulation.__init__ bootstrap (core/simulation.py:145-154): clock to start_ns, every Source draws its
  * first arrival.  Called implicitly by the first run; call again to rewind the engine for another run. */
 int hs_engine_reset(hs_engine *h);

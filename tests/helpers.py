@@ -189,10 +189,10 @@ def oracle_per_chain(spec, runs):
     return out, sinks
 
 
-def ring_engine_for_spec(spec, flags=0, bag_capacity=0, log_capacity=0):
-    """StationEngine for a ring spec: station i = Source_i -> Server_i -> RandomRouter_i([Sink_i, Link_i -> Server_{i+1}])."""
+def ring_arrays(spec, bag_capacity=0, log_capacity=0):
+    """(StationArrays, NetworkArrays, log capacity, params) of a ring spec -- network-wide description."""
     from happy_simulator_amd import _native as N
-    from happy_simulator_amd.engine import NetworkArrays, StationArrays, StationEngine
+    from happy_simulator_amd.engine import NetworkArrays, StationArrays
 
     p = ring_params(spec)
     n = p["n"]
@@ -225,6 +225,15 @@ def ring_engine_for_spec(spec, flags=0, bag_capacity=0, log_capacity=0):
     horizon_s = p["end_ns"] / 1e9
     lam = 2.0 * float(rates.max()) + 1.0
     cap = log_capacity or int(lam * horizon_s + 10 * (lam * horizon_s) ** 0.5 + 64)
+    return st, net, cap, p
+
+
+def ring_engine_for_spec(spec, flags=0, bag_capacity=0, log_capacity=0):
+    """StationEngine for a ring spec: station i = Source_i -> Server_i -> RandomRouter_i([Sink_i, Link_i -> Server_{i+1}])."""
+    from happy_simulator_amd import _native as N
+    from happy_simulator_amd.engine import StationEngine
+
+    st, net, cap, p = ring_arrays(spec, bag_capacity, log_capacity)
     eng = StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=p["end_ns"], seed=spec["seed"], log_capacity=cap, network=net)
     if flags:
         eng.set_debug_flags(flags)

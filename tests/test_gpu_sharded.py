@@ -1,0 +1,108 @@
+"""GPU: a station network partitioned over several engines (virtual shards on one device, LocalComm) must give
+exactly the single-engine result -- which is itself pinned against the live-reference ring goldens and the oracle
+(tests/test_gpu_ring.py).  Same protocol and kernels as the one-process-per-GPU RCCL path (DistComm)."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _single(spec):
+    eng, p = H.ring_engine_for_spec(spec)
+    with eng:
+        eng.run_until(p["end_ns"])
+        s = eng.summary()
+        return dict(events=s.events_processed, by_kind=s.events_by_kind, final=s.final_time_ns, stats=eng.lp_stats(),
+                    net=eng.net_stats(), sinks=eng.read_sinks(), completed=s.requests_completed,
+                    sink_records=s.sink_records)
+
+
+def _sharded(spec, world, sync_every=16, msg_capacity=64):
+    from happy_simulator_amd.sharded import LocalComm, ShardedNetwork
+
+    st, net, cap, p = H.ring_arrays(spec)
+    sn = ShardedNetwork.on_gpu(st, net, LocalComm(world), horizon_ns=p["end_ns"], seed=spec["seed"], log_capacity=cap,
+                               sync_every=sync_every, msg_capacity=msg_capacity)
+    with sn:
+        summ = sn.run_until(p["end_ns"])
+        stats = {}
+        for s in sn.shards:
+            for k, v in s.engine.lp_stats().items():
+                stats.setdefault(k, []).append(v)
+        stats = {k: np.concatenate(v) for k, v in stats.items()}
+        nl = net.n_links
+        netst = {"routed": np.concatenate([s.engine.net_stats()["routed"] for s in sn.shards]),
+                 "link_entered": np.zeros(nl, np.int64), "link_packets_sent": np.zeros(nl, np.int64)}
+        for s in sn.shards:
+            ns = s.engine.net_stats()
+            netst["link_entered"][s.gids] += ns["link_entered"]
+            netst["link_packets_sent"][s.gids] += ns["link_packets_sent"]
+        parts = [s.engine.read_sinks() for s in sn.shards]
+        sinks = tuple(np.concatenate([p_[i] for p_ in parts]) for i in range(3))
+        return summ, stats, netst, sinks
+
+
+SPECS = [
+    dict(name="ring_64", topology="ring", n=64, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, end_s=6.0, seed=21),
+    dict(name="ring_7_dense", topology="ring", n=7, ext_rate=4.5, mean=0.1, lat_min=0.0002, jitter_mean=0.0008, end_s=3.0, seed=22),
+    dict(name="ring_300_c2_cap", topology="ring", n=300, ext_rate=9.0, mean=0.1, concurrency=2, queue_cap=4, lat_min=0.002,
+         jitter_mean=0.004, end_s=4.0, seed=23),
+    dict(name="ring_33_fixed_latency", topology="ring", n=33, ext_rate=4.0, mean=0.1, lat_min=0.0025, jitter_mean=None,
+         end_s=5.0, seed=24),
+]
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("spec", SPECS, ids=[s["name"] for s in SPECS])
+def test_sharded_equals_single_engine(spec, world):
+    one = _single(spec)
+    summ, stats, netst, sinks = _sharded(spec, world)
+    assert summ.events_processed == one["events"]
+    np.testing.assert_array_equal(summ.events_by_kind, one["by_kind"])
+    assert summ.final_time_ns == one["final"]
+    assert summ.requests_completed == one["completed"] and summ.sink_records == one["sink_records"]
+    for k in ("generated", "accepted", "dropped", "completed", "rejected", "total_service_s", "sink_received",
+              "queue_depth", "active", "events", "final_time_ns"):
+        np.testing.assert_array_equal(stats[k], one["stats"][k], err_msg=k)
+    for k in ("routed", "link_entered", "link_packets_sent"):
+        np.testing.assert_array_equal(netst[k], one["net"][k], err_msg=k)
+    for a, b in zip(sinks, one["sinks"]):
+        np.testing.assert_array_equal(a, b)
+    assert summ.world == world and summ.windows >= 1
+
+
+@pytest.mark.parametrize("name", H.golden_names("ring"))
+def test_sharded_matches_reference_golden(name):
+    gold = H.Golden(name)
+    spec = gold.spec
+    world = 2 if spec["n"] < 6 else 3
+    summ, stats, netst, sinks = _sharded(spec, world, sync_every=8)
+    assert summ.events_processed == gold.meta["total_events"][0]
+    assert summ.final_time_ns == gold.meta["final_ns"][0]
+    for k, g in (("generated", "generated"), ("accepted", "accepted"), ("dropped", "dropped"), ("completed", "completed"),
+                 ("sink_received", "received"), ("queue_depth", "depth"), ("total_service_s", "total_service_s")):
+        np.testing.assert_array_equal(stats[k], gold.arrays[g], err_msg=k)
+    np.testing.assert_array_equal(netst["routed"], gold.routed)
+    np.testing.assert_array_equal(netst["link_packets_sent"], gold.packets_sent)
+    np.testing.assert_array_equal(sinks[1], gold.sink_t_ns)
+
+
+def test_gvt_windows_skip_idle_time():
+    """Sparse traffic: GVT-driven window ends jump over idle stretches, so far fewer windows than end / W run."""
+    spec = dict(name="sparse", topology="ring", n=16, ext_rate=0.05, mean=0.1, lat_min=0.001, jitter_mean=0.01, end_s=40.0,
+                seed=31)
+    one = _single(spec)
+    summ, *_ = _sharded(spec, 2, sync_every=4)
+    assert summ.events_processed == one["events"] and summ.final_time_ns == one["final"]
+    assert summ.windows < 0.2 * (40.0 / 0.001)
+
+
+def test_exchange_row_overflow_is_reported():
+    from happy_simulator_amd import _native as N
+
+    spec = dict(name="tiny_rows", topology="ring", n=2, ext_rate=400.0, mean=0.001, lat_min=0.05, jitter_mean=None,
+                end_s=2.0, seed=5)
+    with pytest.raises(N.EngineError, match="overflow"):
+        _sharded(spec, 2, msg_capacity=2)
