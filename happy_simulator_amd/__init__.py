@@ -14,11 +14,11 @@ with a host-side mirror of the reference's `Simulation / Source / Server / Sink 
 from ._native import EngineError, EngineUnavailable  # noqa: F401
 from .core.temporal import Duration, Instant  # noqa: F401
 from .entities import (ConstantArrivalTimeProvider, ConstantLatency, ConstantRateProfile, Counter, Entity,  # noqa: F401
-                       ExponentialLatency, FIFOQueue, LatencyTracker, PoissonArrivalTimeProvider, Server,
-                       ServerStats, SimpleEventProvider, Sink, Source)
+                       ExponentialLatency, FIFOQueue, LatencyTracker, NetworkLink, NetworkLinkStats,
+                       PoissonArrivalTimeProvider, RandomRouter, Server, ServerStats, SimpleEventProvider, Sink, Source)
 from .lowering import UnsupportedTopology  # noqa: F401
-from .parallel import (ParallelResult, ParallelRunner, ParallelSimulation, PartitionLink, RunConfig,  # noqa: F401
-                       SimulationPartition, reduce_summaries, shard_range)
+from .parallel import (ParallelResult, ParallelRunner, ParallelSimulation, ParallelSimulationSummary,  # noqa: F401
+                       PartitionLink, RunConfig, SimulationPartition, reduce_summaries, shard_range)
 from .simulation import Simulation, seed  # noqa: F401
 from .summary import EntitySummary, QueueStats, SimulationSummary  # noqa: F401
 

@@ -11,6 +11,9 @@ lives in csrc/).  Names, argument meaning, defaults and error behaviour follow t
                                                    components/server/server.py:43-273
   Sink / Counter                                   components/common.py:18-95
   LatencyTracker                                   instrumentation/collectors.py:18-60
+  NetworkLink(name, latency, bandwidth_bps, packet_loss_rate, jitter, egress)
+                                                   components/network/link.py:36-234
+  RandomRouter(name, targets=[...])                components/random_router.py:9-45
 """
 from __future__ import annotations
 
@@ -357,3 +360,57 @@ class LatencyTracker(_RecordSink):
 
     def p99(self) -> float:
         return self._pct(0.99)
+
+
+# ---- networks of stations ------------------------------------------------------------------------
+@dataclass(frozen=True)
+class NetworkLinkStats:
+    bytes_transmitted: int = 0
+    packets_sent: int = 0
+    packets_dropped: int = 0
+
+
+class NetworkLink(Entity):
+    """Point-to-point link (components/network/link.py:36-234).  Lowered: a constant base latency > 0 (it is the
+    lookahead of the conservative windows) plus optional exponential jitter, towards a Server.  Bandwidth and
+    packet loss are not lowered (payload sizes / the global `random` stream are host-Python state)."""
+
+    def __init__(self, name: str, latency: LatencyDistribution, bandwidth_bps: float | None = None,
+                 packet_loss_rate: float = 0.0, jitter: LatencyDistribution | None = None, egress: Entity | None = None):
+        super().__init__(name)
+        if packet_loss_rate < 0.0 or packet_loss_rate > 1.0:
+            raise ValueError(f"packet_loss_rate must be in [0, 1], got {packet_loss_rate}")   # link.py:71-72
+        self.latency = latency
+        self.bandwidth_bps = bandwidth_bps
+        self.packet_loss_rate = packet_loss_rate
+        self.jitter = jitter
+        self.egress = egress
+        self.bytes_transmitted = 0
+        self.packets_sent = 0
+        self.packets_dropped = 0
+        self._entered = 0
+
+    def downstream_entities(self) -> list[Entity]:
+        return [self.egress] if self.egress is not None else []
+
+    @property
+    def link_stats(self) -> NetworkLinkStats:
+        return NetworkLinkStats(self.bytes_transmitted, self.packets_sent, self.packets_dropped)
+
+    @property
+    def current_utilization(self) -> float:
+        return 0.0          # bandwidth is infinite on the lowered path (link.py:93-95)
+
+
+class RandomRouter(Entity):
+    """Uniform random fan-out (components/random_router.py:9-45); the engine draws the target from the router's own
+    Philox stream: index = int(u * len(targets))."""
+
+    def __init__(self, name: str, *, targets: list[Entity]):
+        super().__init__(name)
+        self.targets = targets
+        self.stats_routed = 0
+        self.target_counts: dict[str, int] = {}
+
+    def downstream_entities(self) -> list[Entity]:
+        return list(self.targets)

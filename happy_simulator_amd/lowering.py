@@ -1,8 +1,14 @@
-"""Graph lowering: the user's Source / Server / Sink objects -> station LPs (struct-of-arrays).
+"""Graph lowering: the user's Source / Server / Sink / NetworkLink / RandomRouter objects -> station LPs
+(struct-of-arrays) and, when stations are connected, the link table of the windowed network engine.
 
 Walks `sources` and `entities` the way the reference's topology discovery does
 (happysimulator/visual/topology.py:81-146: follow `downstream_entities()`), and refuses -- explicitly,
 never silently -- anything the engine does not run.
+
+A station LP = [Source] -> Server -> egress, where the egress is one of
+    nothing | a Sink-like collector | NetworkLink -> another station's Server
+            | RandomRouter([Sink-like | NetworkLink, Sink-like | NetworkLink])
+Every entity of station i draws from Philox streams with stream base i (DESIGN.md "Random streams").
 """
 from __future__ import annotations
 
@@ -11,9 +17,11 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _native as N
-from .engine import StationArrays
-from .entities import (ConstantLatency, Counter, Entity, ExponentialLatency, LatencyTracker, Server, Sink, Source,
-                       _RecordSink)
+from .engine import NetworkArrays, StationArrays
+from .entities import (ConstantLatency, Counter, Entity, ExponentialLatency, LatencyTracker, NetworkLink,
+                       RandomRouter, Server, Sink, Source, _RecordSink)
+
+_SINKS = (Sink, Counter, LatencyTracker)
 
 
 class UnsupportedTopology(NotImplementedError):
@@ -25,11 +33,19 @@ class Station:
     source: Source | None = None
     server: Server | None = None
     sink: _RecordSink | None = None
+    router: RandomRouter | None = None
+    links: list = field(default_factory=list)        # NetworkLink objects leaving this station (router order)
+    link_ids: list = field(default_factory=list)     # their indices in LoweredGraph.links
 
 
 @dataclass
 class LoweredGraph:
     stations: list[Station] = field(default_factory=list)
+    links: list = field(default_factory=list)        # (NetworkLink, source station, destination station)
+
+    @property
+    def is_network(self) -> bool:
+        return bool(self.links) or any(st.router is not None for st in self.stations)
 
     def arrays(self) -> StationArrays:
         n = len(self.stations)
@@ -58,19 +74,63 @@ class LoweredGraph:
             a.egress[i] = N.EGRESS_SINK if st.sink is not None else N.EGRESS_NONE
         return a
 
+    def network_arrays(self, bag_capacity: int = 0) -> NetworkArrays:
+        n, nl = len(self.stations), len(self.links)
+        eg = np.zeros(n, np.uint8)
+        rt0 = np.full(n, -1, np.int32)
+        rt1 = np.full(n, -1, np.int32)
+        lof = np.full(n, -1, np.int32)
+        for i, st in enumerate(self.stations):
+            if st.router is not None:
+                eg[i] = N.EGRESS_ROUTER
+                ids = iter(st.link_ids)
+                tg = [(-1 if isinstance(t, _SINKS) else next(ids)) for t in st.router.targets]
+                rt0[i], rt1[i] = tg
+            elif st.links:
+                eg[i] = N.EGRESS_LINK
+                lof[i] = st.link_ids[0]
+            else:
+                eg[i] = N.EGRESS_SINK if st.sink is not None else N.EGRESS_NONE
+        jk = np.full(nl, N.LAT_CONSTANT, np.uint8)
+        jm = np.zeros(nl, np.float64)
+        for l, (lk, _, _) in enumerate(self.links):
+            if lk.jitter is not None:
+                jk[l] = N.LAT_EXPONENTIAL
+                jm[l] = lk.jitter.mean
+        return NetworkArrays(
+            egress_kind=eg, router_target0=rt0, router_target1=rt1, link_of=lof,
+            link_src=np.array([s for _, s, _ in self.links], np.int32).reshape(nl),
+            link_dst=np.array([d for _, _, d in self.links], np.int32).reshape(nl),
+            link_lat_min_s=np.array([lk.latency.mean for lk, _, _ in self.links], np.float64).reshape(nl),
+            link_jitter_kind=jk, link_jitter_mean_s=jm, bag_capacity=bag_capacity)
+
+    def log_capacity(self, horizon_s: float) -> int:
+        """Records per station: a station's admissions are bounded by its own source plus everything its upstream
+        links can deliver; a generous bound is the total source rate reachable through links into it.  For the
+        lowered shapes (fan-in of a few links) sum the rates of the station and its direct upstream stations twice."""
+        n = len(self.stations)
+        rate = np.array([st.source.rate if st.source is not None else 0.0 for st in self.stations], np.float64)
+        inflow = rate.copy()
+        for _ in range(4):                                 # a few hops of upstream contribution
+            nxt = rate.copy()
+            for _, s, d in self.links:
+                nxt[d] += inflow[s]
+            inflow = nxt
+        lam = float(inflow.max()) if n else 0.0
+        mean = lam * horizon_s
+        return int(mean + 10.0 * (mean + 1.0) ** 0.5 + 64)
+
 
 def lower(sources: list, entities: list) -> LoweredGraph:
     sources = list(sources or [])
     entities = list(entities or [])
     g = LoweredGraph()
-    used_servers: dict[int, int] = {}
+    station_of_server: dict[int, int] = {}
     used_sinks: dict[int, int] = {}
+    used_links: dict[int, int] = {}
+    used_routers: dict[int, int] = {}
 
     def check_sink(obj, owner):
-        if not isinstance(obj, (Sink, Counter, LatencyTracker)):
-            raise UnsupportedTopology(
-                f"{owner} forwards to {type(obj).__name__} '{getattr(obj, 'name', obj)}': only Sink / Counter / "
-                "LatencyTracker terminate a station on the engine")
         if id(obj) in used_sinks:
             raise UnsupportedTopology(
                 f"sink '{obj.name}' has several upstreams; merged sinks need cross-LP ordering (not lowered yet)")
@@ -83,41 +143,85 @@ def lower(sources: list, entities: list) -> LoweredGraph:
         if sv.concurrency > 16:
             raise UnsupportedTopology(f"server '{sv.name}': concurrency {sv.concurrency} > 16 is not lowered yet")
 
+    def check_link(lk: NetworkLink, owner: str):
+        if id(lk) in used_links:
+            raise UnsupportedTopology(f"link '{lk.name}' is used by several senders (not lowered)")
+        if not isinstance(lk.latency, ConstantLatency) or not (lk.latency.mean > 0):
+            raise UnsupportedTopology(
+                f"link '{lk.name}': the base latency must be a ConstantLatency > 0 -- it is the lookahead of the "
+                "conservative time windows (the reference enforces min_latency > 0 the same way, parallel/link.py:41-45)")
+        if lk.jitter is not None and not isinstance(lk.jitter, ExponentialLatency):
+            raise UnsupportedTopology(f"link '{lk.name}': jitter {type(lk.jitter).__name__} is not lowered")
+        if lk.bandwidth_bps is not None or lk.packet_loss_rate != 0.0:
+            raise UnsupportedTopology(f"link '{lk.name}': bandwidth limits / packet loss are not lowered")
+        if not isinstance(lk.egress, Server):
+            raise UnsupportedTopology(f"link '{lk.name}' must deliver to a Server (got {type(lk.egress).__name__})")
+        used_links[id(lk)] = len(g.stations)
+
+    def attach_egress(st: Station, obj, owner: str):
+        if obj is None:
+            return
+        if isinstance(obj, _SINKS):
+            check_sink(obj, owner)
+            st.sink = obj
+        elif isinstance(obj, NetworkLink):
+            check_link(obj, owner)
+            st.links.append(obj)
+        elif isinstance(obj, RandomRouter):
+            if id(obj) in used_routers:
+                raise UnsupportedTopology(f"router '{obj.name}' has several upstreams (not lowered)")
+            used_routers[id(obj)] = len(g.stations)
+            if len(obj.targets) != 2:
+                raise UnsupportedTopology(f"router '{obj.name}': exactly two targets are lowered, got {len(obj.targets)}")
+            st.router = obj
+            for t in obj.targets:
+                if isinstance(t, _SINKS):
+                    if st.sink is not None:
+                        raise UnsupportedTopology(f"router '{obj.name}': at most one Sink target")
+                    check_sink(t, f"router '{obj.name}'")
+                    st.sink = t
+                elif isinstance(t, NetworkLink):
+                    check_link(t, f"router '{obj.name}'")
+                    st.links.append(t)
+                else:
+                    raise UnsupportedTopology(
+                        f"router '{obj.name}' targets {type(t).__name__}: only Sink-like collectors and NetworkLinks")
+        else:
+            raise UnsupportedTopology(
+                f"{owner} forwards to {type(obj).__name__} '{getattr(obj, 'name', obj)}': only Sink / Counter / "
+                "LatencyTracker / NetworkLink / RandomRouter leave a station on the engine")
+
+    def add_server_station(sv: Server, src: Source | None):
+        check_server(sv)
+        station_of_server[id(sv)] = len(g.stations)
+        st = Station(source=src, server=sv)
+        attach_egress(st, sv.downstream, f"server '{sv.name}'")
+        g.stations.append(st)
+
     for src in sources:
         if not isinstance(src, Source):
             raise UnsupportedTopology(f"source {type(src).__name__} is not a lowered Source")
         if not (src.rate > 0):
             raise UnsupportedTopology(f"source '{src.name}': rate must be > 0")
         tgt = src._event_provider._target
-        st = Station(source=src)
         if isinstance(tgt, Server):
-            if id(tgt) in used_servers:
+            if id(tgt) in station_of_server:
                 raise UnsupportedTopology(f"server '{tgt.name}' is fed by several sources (not lowered yet)")
-            used_servers[id(tgt)] = len(g.stations)
-            check_server(tgt)
-            st.server = tgt
-            if tgt.downstream is not None:
-                check_sink(tgt.downstream, f"server '{tgt.name}'")
-                st.sink = tgt.downstream
-        elif isinstance(tgt, (Sink, Counter, LatencyTracker)):
+            add_server_station(tgt, src)
+        elif isinstance(tgt, _SINKS):
+            st = Station(source=src)
             check_sink(tgt, f"source '{src.name}'")
             st.sink = tgt
+            g.stations.append(st)
         else:
             raise UnsupportedTopology(
                 f"source '{src.name}' targets {type(tgt).__name__}: only Server / Sink / Counter / LatencyTracker")
-        g.stations.append(st)
 
     for ent in entities:
         if isinstance(ent, Server):
-            if id(ent) not in used_servers:       # a server nobody feeds: it exists, it never sees an event
-                check_server(ent)
-                used_servers[id(ent)] = len(g.stations)
-                st = Station(server=ent)
-                if ent.downstream is not None:
-                    check_sink(ent.downstream, f"server '{ent.name}'")
-                    st.sink = ent.downstream
-                g.stations.append(st)
-        elif isinstance(ent, (Sink, Counter, LatencyTracker, Source)):
+            if id(ent) not in station_of_server:      # no Source of its own: fed by links, or never sees an event
+                add_server_station(ent, None)
+        elif isinstance(ent, (Sink, Counter, LatencyTracker, Source, NetworkLink, RandomRouter)):
             continue
         elif isinstance(ent, Entity):
             raise UnsupportedTopology(f"entity {type(ent).__name__} '{ent.name}' is not lowered to the engine")
@@ -125,13 +229,45 @@ def lower(sources: list, entities: list) -> LoweredGraph:
             raise UnsupportedTopology(f"object {ent!r} is not an Entity")
     if not g.stations:
         raise UnsupportedTopology("nothing to simulate: no sources and no servers")
+
+    # Station order defines the entity stream numbering (station i's entities draw from stream base i): Servers in the
+    # order the user listed them in `entities` (construction order of the topology), then whatever is only reachable
+    # from a Source, in source order.
+    pos = {id(e): k for k, e in enumerate(entities)}
+    src_pos = {id(s): k for k, s in enumerate(sources)}
+
+    def order_key(st: Station):
+        if st.server is not None and id(st.server) in pos:
+            return (0, pos[id(st.server)])
+        if st.server is None and st.sink is not None and id(st.sink) in pos:
+            return (0, pos[id(st.sink)])          # Source -> Sink station: its collector's place
+        return (1, src_pos.get(id(st.source), 0))
+
+    g.stations.sort(key=order_key)
+    station_of_server = {id(st.server): i for i, st in enumerate(g.stations) if st.server is not None}
+
+    # resolve link destinations (every Server is a station by now) in station order, router-target order
+    for i, st in enumerate(g.stations):
+        for lk in st.links:
+            dst = station_of_server.get(id(lk.egress))
+            if dst is None:
+                raise UnsupportedTopology(
+                    f"link '{lk.name}' delivers to server '{lk.egress.name}', which is not part of this Simulation")
+            st.link_ids.append(len(g.links))
+            g.links.append((lk, i, dst))
     return g
 
 
-def write_back(g: LoweredGraph, stats: dict, counts: np.ndarray, t_ns: np.ndarray, created_ns: np.ndarray) -> None:
-    """Put the engine's per-LP results onto the user's objects, under the attribute names the reference uses."""
+def write_back(g: LoweredGraph, stats: dict, counts: np.ndarray, t_ns: np.ndarray, created_ns: np.ndarray,
+               net_stats: dict | None = None, lo: int = 0, hi: int | None = None) -> None:
+    """Put the engine's per-LP results onto the user's objects, under the attribute names the reference uses.
+    `stats` / `counts` are indexed by station; `lo:hi` restricts the write-back to one shard's stations (the sink
+    records `t_ns` / `created_ns` are then that shard's records only)."""
     off = 0
+    hi = len(g.stations) if hi is None else hi
     for i, st in enumerate(g.stations):
+        if not (lo <= i < hi):
+            continue
         if st.source is not None:
             st.source._generated_count = int(stats["generated"][i])
             ep = st.source._event_provider
@@ -150,3 +286,17 @@ def write_back(g: LoweredGraph, stats: dict, counts: np.ndarray, t_ns: np.ndarra
         if st.sink is not None:
             st.sink._set_records(t_ns[off:off + c].copy(), created_ns[off:off + c].copy())
         off += c
+        if net_stats is not None:
+            for lk, l in zip(st.links, st.link_ids):
+                lk.packets_sent = int(net_stats["link_packets_sent"][l])
+                lk._entered = int(net_stats["link_entered"][l])
+            if st.router is not None:
+                st.router.stats_routed = int(net_stats["routed"][i])
+                tc = {}
+                ids = iter(st.link_ids)
+                for t in st.router.targets:
+                    if isinstance(t, _SINKS):
+                        tc[t.name] = tc.get(t.name, 0) + c
+                    else:
+                        tc[t.name] = tc.get(t.name, 0) + int(net_stats["link_entered"][next(ids)])
+                st.router.target_counts = {k: v for k, v in tc.items() if v}

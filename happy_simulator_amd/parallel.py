@@ -4,7 +4,8 @@
   replica and seeds `random` with `base_seed + i`.  Here all replicas are lowered into ONE engine launch --
   one LP per lane, `HS_MODE_REPLICAS`, per-LP Philox key `base_seed + i` -- so 4 096 replicas cost one kernel.
 * `ParallelSimulation` without links (parallel/simulation.py:170-195): every partition is an independent
-  Simulation; same batching.  Linked partitions (windows + GVT) are the next scope row.
+  Simulation; same batching.  With links (parallel/simulation.py:197-223): one shard of the windowed network
+  engine per partition (happy_simulator_amd/sharded.py) -- a GPU per partition under torch.distributed.
 * Across GPUs (one process per GPU, torch.distributed): `shard_range` block-partitions replicas / LPs over
   ranks and `reduce_summaries` combines the per-rank totals (SUM of events, MAX of final time).  There is no
   data-path collective because the units are independent.
@@ -152,16 +153,38 @@ class PartitionLink:
 
 @dataclass
 class ParallelSimulationSummary:
+    """happysimulator/parallel/summary.py:12-86."""
+
     duration_s: float
     total_events_processed: int
     partitions: dict
     wall_clock_seconds: float
+    events_per_second: float = 0.0
+    entities: dict = field(default_factory=dict)
     total_windows: int = 0
     total_cross_partition_events: int = 0
+    window_size_s: float = 0.0
+
+    def to_dict(self) -> dict:
+        return {"duration_s": self.duration_s, "total_events_processed": self.total_events_processed,
+                "events_per_second": self.events_per_second, "wall_clock_seconds": self.wall_clock_seconds,
+                "partitions": {k: v.to_dict() for k, v in self.partitions.items()},
+                "total_windows": self.total_windows,
+                "total_cross_partition_events": self.total_cross_partition_events,
+                "window_size_s": self.window_size_s}
 
 
 class ParallelSimulation:
-    """Independent partitions only (no links): each partition runs as its own Simulation, all in one launch."""
+    """`ParallelSimulation(partitions, links=..., seed=...)` (happysimulator/parallel/simulation.py:31-284).
+
+    * no links: every partition is an independent Simulation; all of them run as ONE engine launch.
+    * links: the partitions form one network whose stations are connected by `NetworkLink`s.  Each partition becomes
+      one shard of the windowed network engine (happy_simulator_amd/sharded.py): a GPU per partition when
+      torch.distributed is initialised with world_size == len(partitions) (RCCL exchange + GVT all-reduce), otherwise
+      virtual shards on one GPU.  The lookahead is the smallest `NetworkLink` base latency, which must be at least the
+      `PartitionLink.min_latency` declared for the partition pair it crosses.  Unlike the reference's coordinator --
+      which overshoots each window by one event and then drops late cross-partition events as "time travel"
+       -- the result is exactly the single-heap `Simulation.run()` of the same entities."""
 
     def __init__(self, partitions: list[SimulationPartition], *, start_time: Instant | None = None,
                  end_time: Instant | None = None, duration: float | None = None, max_workers: int | None = None,
@@ -169,26 +192,166 @@ class ParallelSimulation:
                  device: int = 0):
         if duration is not None and end_time is not None:
             raise ValueError("Cannot specify both 'duration' and 'end_time'")
-        if links:
-            raise UnsupportedTopology("linked partitions (windowed coordination) are the next scope row")
-        names = [p.name for p in partitions]
-        if len(set(names)) != len(names):
-            raise ValueError("partition names must be unique")
+        self._links = list(links or [])
+        self._validate(partitions, self._links, window_size)
         self._partitions = partitions
-        self._sims = [Simulation(start_time=start_time, end_time=end_time, duration=duration, sources=p.sources,
-                                 entities=p.entities, seed=seed) for p in partitions]
         self._seed = seed
         self._device = device
+        self._start = start_time if start_time is not None else Instant.Epoch
+        if duration is not None:
+            self._end = self._start + duration
+        elif end_time is not None:
+            self._end = end_time
+        else:
+            self._end = Instant.Infinity
+        if not self._links:
+            self._sims = [Simulation(start_time=start_time, end_time=end_time, duration=duration, sources=p.sources,
+                                     entities=p.entities, seed=seed) for p in partitions]
+        else:
+            self._lower_linked()
+
+    # parallel/validation.py:19-110
+    @staticmethod
+    def _validate(partitions, links, window_size):
+        names = [p.name for p in partitions]
+        seen = set()
+        for nm in names:
+            if nm in seen:
+                raise ValueError(f"Duplicate partition name: '{nm}'")
+            seen.add(nm)
+        owner: dict[int, str] = {}
+        for p in partitions:
+            for e in p.entities:
+                if id(e) in owner:
+                    raise ValueError(f"Entity '{getattr(e, 'name', e)}' is in partitions '{owner[id(e)]}' and '{p.name}'")
+                owner[id(e)] = p.name
+        for p in partitions:
+            for src in p.sources:
+                tgt = getattr(getattr(src, "_event_provider", None), "_target", None)
+                if tgt is not None and owner.get(id(tgt), p.name) != p.name:
+                    raise ValueError(f"Source '{src.name}' in partition '{p.name}' targets entity '{tgt.name}' in "
+                                     f"partition '{owner[id(tgt)]}'")
+        for lk in links:
+            if lk.source_partition not in seen:
+                raise ValueError(f"PartitionLink references unknown source partition '{lk.source_partition}'")
+            if lk.dest_partition not in seen:
+                raise ValueError(f"PartitionLink references unknown dest partition '{lk.dest_partition}'")
+            if lk.latency is not None or lk.packet_loss != 0.0:
+                raise UnsupportedTopology("PartitionLink latency overrides / packet loss are not lowered")
+        if window_size is not None and links:
+            m = min(lk.min_latency for lk in links)
+            if window_size > m:
+                raise ValueError(f"window_size ({window_size}s) must be <= min(link.min_latency) ({m}s)")
+
+    def _lower_linked(self):
+        from .lowering import lower
+
+        if self._end == Instant.Infinity:
+            raise UnsupportedTopology("auto-terminating runs are not lowered; pass end_time/duration")
+        parts = self._partitions
+        owner = {id(e): k for k, p in enumerate(parts) for e in list(p.entities) + list(p.sources)}
+        g = lower([s for p in parts for s in p.sources], [e for p in parts for e in p.entities])
+        part_of = []
+        for st in g.stations:
+            ref = st.server if st.server is not None else (st.sink if st.sink is not None else st.source)
+            if id(ref) not in owner:
+                raise UnsupportedTopology(f"'{ref.name}' is not listed in any partition's entities")
+            part_of.append(owner[id(ref)])
+        if any(a > b for a, b in zip(part_of, part_of[1:])):
+            raise UnsupportedTopology("list every Server in its partition's `entities` so that partitions are contiguous")
+        sizes = np.bincount(np.asarray(part_of, np.int64), minlength=len(parts))
+        if (sizes == 0).any():
+            raise UnsupportedTopology("a partition without a Server / Source station cannot be a shard")
+        declared = {(lk.source_partition, lk.dest_partition): lk.min_latency for lk in self._links}
+        self._cross_links = []
+        for l, (lk, s, d) in enumerate(g.links):
+            ps, pd = part_of[s], part_of[d]
+            if ps == pd:
+                continue
+            key = (parts[ps].name, parts[pd].name)
+            if key not in declared:                                    # parallel/validation.py:188-200
+                raise ValueError(f"Entity in partition '{key[0]}' references entity '{lk.egress.name}' in partition "
+                                 f"'{key[1]}' but no PartitionLink exists from '{key[0]}' to '{key[1]}'")
+            if lk.latency.mean < declared[key]:                        # parallel/coordinator.py:213-219 (RuntimeError there)
+                raise ValueError(f"link '{lk.name}' can deliver after {lk.latency.mean}s, less than the PartitionLink "
+                                 f"min_latency {declared[key]}s")
+            self._cross_links.append(l)
+        self._graph = g
+        self._bounds = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
 
     def run(self) -> ParallelSimulationSummary:
+        if self._links:
+            return self._run_linked()
         wall0 = _time.monotonic()
         # every partition is its own Simulation (own heap, own overshoot); all share the run's Philox key and
         # number their entities globally (partition i = stream base i), so identical partitions still draw
         # independent streams
         n = len(self._sims)
         summaries = _run_independent(self._sims, [self._seed] * n, self._device, stream_bases=list(range(n)))
+        dur = max(s.duration_s for s in summaries)
+        tot = sum(s.total_events_processed for s in summaries)
         return ParallelSimulationSummary(
-            duration_s=max(s.duration_s for s in summaries),
-            total_events_processed=sum(s.total_events_processed for s in summaries),
+            duration_s=dur, total_events_processed=tot, events_per_second=tot / dur if dur > 0 else 0.0,
             partitions={p.name: s for p, s in zip(self._partitions, summaries)},
             wall_clock_seconds=_time.monotonic() - wall0)
+
+    def _run_linked(self) -> ParallelSimulationSummary:
+        import torch.distributed as dist
+
+        from .sharded import DistComm, LocalComm, ShardedNetwork
+        from .summary import SimulationSummary as _SS
+
+        wall0 = _time.monotonic()
+        g, parts = self._graph, self._partitions
+        world = len(parts)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() == world and world > 1:
+            comm = DistComm()                     # one partition per process / GPU
+        else:
+            comm = LocalComm(world)               # virtual shards on this GPU
+        end_ns, start_ns = self._end.nanoseconds, self._start.nanoseconds
+        st, net = g.arrays(), g.network_arrays()
+        cap = g.log_capacity((end_ns - start_ns) / 1e9)
+        with ShardedNetwork.on_gpu(st, net, comm, horizon_ns=end_ns, start_ns=start_ns, seed=self._seed,
+                                   device=self._device, log_capacity=cap, bounds=self._bounds) as sn:
+            summ = sn.run_until(end_ns)
+            part_summaries = {}
+            cross_local = 0
+            for s in sn.shards:
+                stats = s.engine.lp_stats()
+                counts, t_ns, created_ns = s.engine.read_sinks()
+                ns = s.engine.net_stats()
+                full = {k: np.zeros(st.n, v.dtype) for k, v in stats.items()}
+                for k, v in stats.items():
+                    full[k][s.lo:s.hi] = v
+                fc = np.zeros(st.n, np.int64)
+                fc[s.lo:s.hi] = counts
+                fnet = {"routed": np.zeros(st.n, np.int64), "link_entered": np.zeros(net.n_links, np.int64),
+                        "link_packets_sent": np.zeros(net.n_links, np.int64)}
+                fnet["routed"][s.lo:s.hi] = ns["routed"]
+                fnet["link_entered"][s.gids] = ns["link_entered"]
+                fnet["link_packets_sent"][s.gids] = ns["link_packets_sent"]
+                # packets_sent is counted where the link ENDS: only write links back from the shard that owns the
+                # destination (with virtual shards every object is visited by both ends' shards; the owner wins)
+                write_back(g, full, fc, t_ns, created_ns, None, lo=s.lo, hi=s.hi)
+                for l, (lk, src, dst) in enumerate(g.links):
+                    if s.lo <= dst < s.hi:
+                        lk.packets_sent = int(fnet["link_packets_sent"][l])
+                    if s.lo <= src < s.hi:
+                        lk._entered = int(fnet["link_entered"][l])
+                for i in range(s.lo, s.hi):
+                    if g.stations[i].router is not None:
+                        g.stations[i].router.stats_routed = int(fnet["routed"][i])
+                cross_local += int(sum(fnet["link_entered"][l] for l in self._cross_links
+                                       if s.lo <= g.links[l][1] < s.hi))
+                tot = s.totals()
+                dur = (tot["max_final_ns"] - start_ns) / 1e9
+                part_summaries[parts[s.rank].name] = _SS(
+                    duration_s=dur, total_events_processed=tot["events"],
+                    events_per_second=tot["events"] / dur if dur > 0 else 0.0)
+            cross = comm.reduce_host([{"cross": cross_local}])["cross"]
+        dur = (summ.final_time_ns - start_ns) / 1e9
+        return ParallelSimulationSummary(
+            duration_s=dur, total_events_processed=summ.events_processed,
+            events_per_second=summ.events_processed / dur if dur > 0 else 0.0,
+            partitions=part_summaries, wall_clock_seconds=_time.monotonic() - wall0, total_windows=summ.windows,
+            total_cross_partition_events=int(cross), window_size_s=summ.window_ns / 1e9)

@@ -265,12 +265,16 @@ class ShardedNetwork:
 
     @classmethod
     def on_gpu(cls, stations: StationArrays, net: NetworkArrays, comm, *, horizon_ns: int, start_ns: int = 0,
-               seed: int = 42, device: int = 0, msg_capacity: int = 256, log_capacity: int = 0, sync_every: int = 64):
+               seed: int = 42, device: int = 0, msg_capacity: int = 256, log_capacity: int = 0, sync_every: int = 64,
+               bounds: np.ndarray | None = None):
         """Partition `stations` / `net` (network-wide descriptions, identical on every rank) over comm.world shards
-        and build the shards this process owns on `device`."""
+        and build the shards this process owns on `device`.  `bounds` (world + 1 station offsets) overrides the
+        balanced block partition, e.g. with the user's own SimulationPartition sizes."""
         import torch
 
-        bounds = shard_bounds(stations.n, comm.world)
+        bounds = shard_bounds(stations.n, comm.world) if bounds is None else np.asarray(bounds, np.int64)
+        if len(bounds) != comm.world + 1 or bounds[0] != 0 or bounds[-1] != stations.n or (np.diff(bounds) <= 0).any():
+            raise ValueError("bounds must be world + 1 increasing station offsets covering every station")
         shards = []
         for r in comm.local_ranks:
             st, sub = shard_arrays(stations, net, int(bounds[r]), int(bounds[r + 1]))

@@ -65,13 +65,17 @@ class Simulation:
         wall0 = _time.monotonic()
         g = self.lowered()
         end_ns = self._end_time.nanoseconds
+        net = g.network_arrays() if g.is_network else None
+        horizon_s = (end_ns - self._start_time.nanoseconds) / 1e9
         with StationEngine(g.arrays(), mode=N.MODE_SINGLE, horizon_ns=end_ns, start_ns=self._start_time.nanoseconds,
-                           seed=self._seed, device=self._device) as eng:
+                           seed=self._seed, device=self._device, network=net,
+                           log_capacity=g.log_capacity(horizon_s) if net is not None else 0) as eng:
             eng.run_until(end_ns)
             es = eng.summary()
             stats = eng.lp_stats()
             counts, t_ns, created_ns = eng.read_sinks()
-        write_back(g, stats, counts, t_ns, created_ns)
+            net_stats = eng.net_stats() if net is not None else None
+        write_back(g, stats, counts, t_ns, created_ns, net_stats)
         self._engine_summary = es
         self._events_processed = es.events_processed
         self._current_time = Instant(es.final_time_ns)

@@ -114,3 +114,98 @@ def test_parallel_simulation_without_links_equals_separate_runs():
     assert set(ps.partitions) == {f"p{i}" for i in range(5)}
     assert ps.total_events_processed == sum(s.total_events_processed for s in ps.partitions.values())
     assert ps.total_events_processed > 5 * 500
+
+
+# ---- networks of stations through the API (Server -> RandomRouter -> [Sink | NetworkLink -> next Server]) --------
+def _build_ring(spec):
+    """The reference-side construction of tests/golden/make_golden.py::run_ring_case, with this package's classes."""
+    n = spec["n"]
+    sinks = [hs.Sink(f"sink{i}") for i in range(n)]
+    servers = [hs.Server(f"srv{i}", concurrency=spec.get("concurrency", 1),
+                         service_time=hs.ExponentialLatency(spec["mean"]), queue_capacity=spec.get("queue_cap"))
+               for i in range(n)]
+    links, routers, sources = [], [], []
+    for i in range(n):
+        jit = None if spec.get("jitter_mean") is None else hs.ExponentialLatency(spec["jitter_mean"])
+        links.append(hs.NetworkLink(f"link{i}", latency=hs.ConstantLatency(spec["lat_min"]), jitter=jit,
+                                    egress=servers[(i + 1) % n]))
+        routers.append(hs.RandomRouter(f"router{i}", targets=[sinks[i], links[i]]))
+        servers[i].downstream = routers[i]
+        rate = spec["ext_rate"][i] if isinstance(spec["ext_rate"], list) else spec["ext_rate"]
+        if rate > 0:
+            sources.append(hs.Source.poisson(rate=rate, target=servers[i], name=f"src{i}"))
+    return sources, servers, routers, links, sinks
+
+
+def _check_ring_objects(gold, servers, routers, links, sinks):
+    assert [s.stats_accepted for s in servers] == gold.accepted.tolist()
+    assert [s.stats_dropped for s in servers] == gold.dropped.tolist()
+    assert [s.stats.requests_completed for s in servers] == gold.completed.tolist()
+    assert [s.stats.total_service_time for s in servers] == gold.total_service_s.tolist()
+    assert [s.depth for s in servers] == gold.depth.tolist()
+    assert [r.stats_routed for r in routers] == gold.routed.tolist()
+    assert [l.packets_sent for l in links] == gold.packets_sent.tolist()
+    assert [k.events_received for k in sinks] == gold.received.tolist()
+    lat = [x for k in sinks for x in k.latencies_s]
+    assert lat == gold.sink_latency_s.tolist()
+
+
+@pytest.mark.parametrize("name", ["ring_8_s42", "ring_5_const_link", "ring_6_c2_cap3"])
+def test_ring_network_through_the_api_matches_reference_golden(name):
+    gold = H.Golden(name)
+    spec = gold.spec
+    sources, servers, routers, links, sinks = _build_ring(spec)
+    sim = hs.Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=sources,
+                        entities=servers + routers + links + sinks, seed=spec["seed"])
+    summary = sim.run()
+    assert summary.total_events_processed == gold.meta["total_events"][0]
+    assert summary.duration_s == gold.meta["duration_s"][0]
+    _check_ring_objects(gold, servers, routers, links, sinks)
+    r0 = routers[0]
+    assert sum(r0.target_counts.values()) in (r0.stats_routed, r0.stats_routed - 1)   # -1: the overshoot event
+
+
+def test_linked_partitions_equal_the_single_heap_run():
+    """ParallelSimulation with links (parallel/simulation.py:197-223): one shard per partition, exact result."""
+    gold = H.Golden("ring_8_s42")
+    spec = gold.spec
+    sources, servers, routers, links, sinks = _build_ring(spec)
+    src_of = {id(s._event_provider._target): s for s in sources}
+    parts = []
+    for k, idx in enumerate(([0, 1, 2], [3, 4], [5, 6, 7])):
+        ents = [servers[i] for i in idx] + [routers[i] for i in idx] + [links[i] for i in idx] + [sinks[i] for i in idx]
+        parts.append(hs.SimulationPartition(name=f"p{k}", entities=ents,
+                                            sources=[src_of[id(servers[i])] for i in idx if id(servers[i]) in src_of]))
+    plinks = [hs.PartitionLink("p0", "p1", min_latency=0.001), hs.PartitionLink("p1", "p2", min_latency=0.0005),
+              hs.PartitionLink("p2", "p0", min_latency=0.001)]
+    ps = hs.ParallelSimulation(parts, end_time=Instant.from_seconds(spec["end_s"]), links=plinks, seed=spec["seed"])
+    summary = ps.run()
+    assert summary.total_events_processed == gold.meta["total_events"][0]
+    assert summary.duration_s == gold.meta["duration_s"][0]
+    assert summary.total_windows > 0 and summary.window_size_s == 0.001
+    assert summary.total_cross_partition_events == sum(links[i]._entered for i in (2, 4, 7))
+    assert set(summary.partitions) == {"p0", "p1", "p2"}
+    assert sum(p.total_events_processed for p in summary.partitions.values()) == summary.total_events_processed
+    _check_ring_objects(gold, servers, routers, links, sinks)
+
+
+def test_linked_partitions_validation():
+    spec = dict(n=4, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.01)
+    sources, servers, routers, links, sinks = _build_ring(spec)
+    mk = lambda idx, nm: hs.SimulationPartition(                                                   # noqa: E731
+        name=nm, entities=[servers[i] for i in idx] + [routers[i] for i in idx] + [links[i] for i in idx] +
+        [sinks[i] for i in idx], sources=[sources[i] for i in idx])
+    a, b = mk([0, 1], "a"), mk([2, 3], "b")
+    with pytest.raises(ValueError, match="no PartitionLink exists from 'b' to 'a'"):
+        hs.ParallelSimulation([a, b], duration=1.0, links=[hs.PartitionLink("a", "b", min_latency=0.001)])
+    with pytest.raises(ValueError, match="less than the PartitionLink min_latency"):
+        hs.ParallelSimulation([a, b], duration=1.0, links=[hs.PartitionLink("a", "b", min_latency=0.001),
+                                                            hs.PartitionLink("b", "a", min_latency=0.5)])
+    with pytest.raises(ValueError, match="min_latency must be > 0"):
+        hs.PartitionLink("a", "b", min_latency=0.0)
+    with pytest.raises(ValueError, match="unknown dest partition"):
+        hs.ParallelSimulation([a, b], duration=1.0, links=[hs.PartitionLink("a", "zz", min_latency=0.001)])
+    with pytest.raises(hs.UnsupportedTopology, match="lookahead"):
+        hs.Simulation(duration=1.0, sources=[], entities=[
+            hs.Server("x", downstream=hs.NetworkLink("l", latency=hs.ExponentialLatency(0.01), egress=hs.Server("y")))
+        ]).run()
