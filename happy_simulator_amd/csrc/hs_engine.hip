@@ -87,10 +87,10 @@ __device__ __forceinline__ void load_station(Station<C> &S, const StationParams 
     S.init_streams(P.seed[lp], P.stream_base[lp], X.arr_k[lp], X.svc_k[lp], ring_a, ring_s);
 #pragma unroll
     for (int k = 0; k < 8; ++k) S.ev[k] = 0;
-    S.adm = L.adm + (size_t)lp * L.cap;
-    S.sink_t = L.sink_t + (size_t)lp * L.cap;
-    S.sink_created = (C > 1) ? L.sink_created + (size_t)lp * L.cap : nullptr;
-    S.cap = L.cap;
+    S.adm = L.adm + lp;
+    S.sink_t = L.sink_t + lp;
+    S.sink_created = (C > 1) ? L.sink_created + lp : nullptr;
+    S.cap = L.cap; S.ls = n;
     S.overflow = 0; S.qoverflow = 0;
     S.qmem = qmem; S.tid = tid; S.qh = 0; S.qn = 0;
     const uint32_t q = X.q[lp];
@@ -413,10 +413,10 @@ __device__ __forceinline__ void load_net(NetStation<C> &S, const StationParams &
     S.rte.init(S.seed, stream_id(S.route_base, kStreamRoute), NX.route_k[lp]);
 #pragma unroll
     for (int k = 0; k < 11; ++k) S.ev[k] = 0;
-    S.adm = L.adm + (size_t)lp * L.cap;
-    S.sink_t = L.sink_t + (size_t)lp * L.cap;
-    S.sink_created = L.sink_created + (size_t)lp * L.cap;
-    S.cap = L.cap;
+    S.adm = L.adm + lp;
+    S.sink_t = L.sink_t + lp;
+    S.sink_created = L.sink_created + lp;
+    S.cap = L.cap; S.ls = n;
     S.overflow = 0; S.qoverflow = 0; S.bagoverflow = 0;
     S.np = &NP; S.ns = &NX; S.send_idx = send_idx;
     S.bag_n = NX.bag_cnt[lp];
@@ -687,6 +687,37 @@ __global__ void hs_shard_overshoot(StationParams P, NetParams NP, StationState X
     if (W.ev[6]) atomicAdd(&tot->completed, (unsigned long long)W.ev[6]);
     atomicMax(&tot->final_time, (long long)t);
     tot->cur_time = t;
+}
+
+// Read-back of the record logs.  The logs are [cap][n_lp] (record k of LP lp at k * n + lp) so that the run kernels'
+// appends coalesce; the C ABI hands records out per LP, concatenated in LP order.  64 x 64 tiles through LDS: coalesced
+// reads along lp, coalesced writes along k.
+__global__ void __launch_bounds__(256) hs_gather_logs(const int64_t *__restrict__ log, const int64_t *__restrict__ cnt,
+                                                      const int64_t *__restrict__ off, int64_t *__restrict__ out, int n,
+                                                      int64_t cap) {
+    __shared__ int64_t tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int lp0 = blockIdx.x * 64;
+    const int64_t k0 = (int64_t)blockIdx.y * 64;
+    for (int kk = ty; kk < 64; kk += 4) {
+        const int64_t k = k0 + kk;
+        const int lp = lp0 + tx;
+        tile[kk][tx] = (k < cap && lp < n) ? log[(size_t)k * n + lp] : 0;
+    }
+    __syncthreads();
+    for (int l = ty; l < 64; l += 4) {
+        const int lp = lp0 + l;
+        if (lp >= n) continue;
+        int64_t c = cnt[lp];
+        c = c > cap ? cap : c;
+        const int64_t k = k0 + tx;
+        if (k < c) out[off[lp] + k] = tile[tx][l];
+    }
+}
+// one LP's records (hs_engine_read_sink)
+__global__ void hs_gather_one(const int64_t *__restrict__ log, int64_t *__restrict__ out, int n, int lp, int64_t cnt) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < cnt) out[k] = log[(size_t)k * n + lp];
 }
 
 __global__ void hs_debug_draws_kernel(uint64_t seed, uint64_t sid, uint64_t k0, int64_t n, double rate, double *u,
@@ -1427,11 +1458,21 @@ int64_t hs_engine_read_sink(hs_engine *h, int32_t lp, int64_t *t_ns, int64_t *cr
     if (cnt > h->L.cap) cnt = h->L.cap;
     if (cnt > cap) cnt = cap;
     if (cnt > 0) {
-        if (t_ns && hipMemcpy(t_ns, h->L.sink_t + (size_t)lp * h->L.cap, (size_t)cnt * 8, hipMemcpyDeviceToHost) != hipSuccess)
-            return fail(h, HS_E_HIP, "memcpy");
-        if (created_ns && hipMemcpy(created_ns, h->L.sink_created + (size_t)lp * h->L.cap, (size_t)cnt * 8,
-                                    hipMemcpyDeviceToHost) != hipSuccess)
-            return fail(h, HS_E_HIP, "memcpy");
+        int64_t *tmp = nullptr;
+        if (hipMalloc(&tmp, (size_t)cnt * 8) != hipSuccess) return fail(h, HS_E_HIP, "hipMalloc of the read-back staging buffer failed");
+        const int64_t *cols[2] = {h->L.sink_t, h->L.sink_created};
+        int64_t *dsts[2] = {t_ns, created_ns};
+        for (int c = 0; c < 2; ++c) {
+            if (!dsts[c]) continue;
+            hipLaunchKernelGGL(hs_gather_one, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, cols[c], tmp,
+                               h->cfg.n_lp, lp, cnt);
+            if (hipStreamSynchronize(h->stream) != hipSuccess ||
+                hipMemcpy(dsts[c], tmp, (size_t)cnt * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+                hipFree(tmp);
+                return fail(h, HS_E_HIP, "sink read-back failed");
+            }
+        }
+        hipFree(tmp);
     }
     return cnt;
 }
@@ -1443,24 +1484,38 @@ int64_t hs_engine_read_sinks(hs_engine *h, int64_t *counts, int64_t *t_ns, int64
         return fail(h, HS_E_HIP, "device synchronisation failed");
     const size_t n = (size_t)h->cfg.n_lp;
     if (hipMemcpy(counts, h->X.received, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, HS_E_HIP, "memcpy");
-    // one bulk D2H of both logs, then compact on the host (records are [lp][cap] row-major)
-    const size_t cap = (size_t)h->L.cap;
-    std::vector<int64_t> tbuf, cbuf;
-    if (t_ns) tbuf.resize(n * cap);
-    if (created_ns) cbuf.resize(n * cap);
-    if (t_ns && hipMemcpy(tbuf.data(), h->L.sink_t, n * cap * 8, hipMemcpyDeviceToHost) != hipSuccess)
-        return fail(h, HS_E_HIP, "memcpy");
-    if (created_ns && hipMemcpy(cbuf.data(), h->L.sink_created, n * cap * 8, hipMemcpyDeviceToHost) != hipSuccess)
-        return fail(h, HS_E_HIP, "memcpy");
-    int64_t off = 0;
+    // exclusive offsets of each LP's run in the concatenated output; the transposition [cap][n_lp] -> per-LP runs
+    // happens on the device (hs_gather_logs), then one bulk D2H per column
+    const int64_t cap = h->L.cap;
+    std::vector<int64_t> off(n);
+    int64_t total = 0, maxc = 0;
     for (size_t i = 0; i < n; ++i) {
-        int64_t c = counts[i] > (int64_t)cap ? (int64_t)cap : counts[i];
-        if (off + c > cap_total) return fail(h, HS_E_INVALID, "output buffers too small for the sink records");
-        if (t_ns) memcpy(t_ns + off, tbuf.data() + i * cap, (size_t)c * 8);
-        if (created_ns) memcpy(created_ns + off, cbuf.data() + i * cap, (size_t)c * 8);
-        off += c;
+        const int64_t c = counts[i] > cap ? cap : counts[i];
+        off[i] = total;
+        total += c;
+        maxc = c > maxc ? c : maxc;
     }
-    return off;
+    if (total > cap_total) return fail(h, HS_E_INVALID, "output buffers too small for the sink records");
+    if (total == 0 || (!t_ns && !created_ns)) return total;
+    int64_t *d_off = nullptr, *d_out = nullptr;
+    if (hipMalloc(&d_off, n * 8) != hipSuccess || hipMalloc(&d_out, (size_t)total * 8) != hipSuccess) {
+        if (d_off) hipFree(d_off);
+        return fail(h, HS_E_HIP, "hipMalloc of the read-back staging buffers failed");
+    }
+    bool ok = hipMemcpy(d_off, off.data(), n * 8, hipMemcpyHostToDevice) == hipSuccess;
+    const int64_t *cols[2] = {h->L.sink_t, h->L.sink_created};
+    int64_t *dsts[2] = {t_ns, created_ns};
+    for (int c = 0; c < 2 && ok; ++c) {
+        if (!dsts[c]) continue;
+        const dim3 grid((unsigned)((n + 63) / 64), (unsigned)((maxc + 63) / 64));
+        hipLaunchKernelGGL(hs_gather_logs, grid, dim3(256), 0, h->stream, cols[c], h->X.received, d_off, d_out, (int)n, cap);
+        ok = hipStreamSynchronize(h->stream) == hipSuccess &&
+             hipMemcpy(dsts[c], d_out, (size_t)total * 8, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    hipFree(d_off);
+    hipFree(d_out);
+    if (!ok) return fail(h, HS_E_HIP, "sink read-back failed");
+    return total;
 }
 
 void hs_engine_destroy(hs_engine *h) {

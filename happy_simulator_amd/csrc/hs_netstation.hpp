@@ -100,8 +100,8 @@ struct NetStation {
     Stream arr, svc, rte;
     uint32_t ev[11];
     // logs
-    int64_t *adm, *sink_t, *sink_created;
-    int64_t cap;
+    int64_t *adm, *sink_t, *sink_created;   // record k at [k * ls] (hs_station.hpp)
+    int64_t cap, ls;
     int overflow, qoverflow, bagoverflow;
     // network
     const NetParams *np;
@@ -187,7 +187,7 @@ struct NetStation {
         ev[1]++;
         if (qcap >= 0 && buf >= qcap) { dropped++; return false; }
         const bool was_empty = (buf == 0);
-        if (accepted < cap) adm[accepted] = created; else overflow = 1;
+        if (accepted < cap) adm[accepted * ls] = created; else overflow = 1;
         accepted++; buf++;
         return was_empty;
     }
@@ -207,7 +207,7 @@ struct NetStation {
         active++;
         double s; int64_t dur;
         sample_service(s, dur);
-        const int64_t created = have_created ? known_created : ((k < cap) ? adm[k] : 0);
+        const int64_t created = have_created ? known_created : ((k < cap) ? adm[k * ls] : 0);
         int j = 0;
 #pragma unroll
         for (int i = C - 1; i >= 0; --i) if (D[i] == kInfNs) j = i;
@@ -286,7 +286,7 @@ struct NetStation {
         }
         if (target == -1) {              // Sink.handle_event (components/common.py:36-44)
             ev[7]++;
-            if (received < cap) { sink_t[received] = t; sink_created[received] = created; } else overflow = 1;
+            if (received < cap) { sink_t[received * ls] = t; sink_created[received * ls] = created; } else overflow = 1;
             received++;
         } else if (target >= 0) send_link(target, t, created);
     }

@@ -100,9 +100,9 @@ struct StationState {           // read-write; [n_lp] each unless noted
 };
 
 struct RecordLogs {
-    int64_t *adm;               // [n_lp][cap] created_at of the k-th accepted request (FIFO backing store)
-    int64_t *sink_t;            // [n_lp][cap] completion time of the m-th sink record
-    int64_t *sink_created;      // [n_lp][cap] created_at of the m-th sink record (C > 1; C == 1 aliases adm)
+    int64_t *adm;               // [cap][n_lp] created_at of the k-th accepted request (FIFO backing store)
+    int64_t *sink_t;            // [cap][n_lp] completion time of the m-th sink record
+    int64_t *sink_created;      // [cap][n_lp] created_at of the m-th sink record (C > 1; C == 1 aliases adm)
     int64_t *sink_created_own;  // the separately allocated column (null when the alias is the only option)
     int64_t cap;
 };
@@ -156,8 +156,10 @@ struct Station {
     // per-run deltas
     uint32_t ev[8];
     // logs
+    // logs: record k of this LP is at [k * ls] (ls = n_lp: the logs are [cap][n_lp], so the 64 lanes of a
+    // wavefront appending their k-th records write 512 contiguous bytes)
     int64_t *adm, *sink_t, *sink_created;
-    int64_t cap;
+    int64_t cap, ls;
     int overflow;
     // in-group FIFO (LDS), column `tid`
     uint8_t (*qmem)[kBlock];
@@ -287,7 +289,7 @@ struct Station {
         ev[1]++;
         if (qcap >= 0 && buf >= qcap) { dropped++; return false; }        // FIFOQueue.push refuses (queue_policy.py:94-98)
         const bool was_empty = (buf == 0);
-        if (accepted < cap) adm[accepted] = t; else overflow = 1;        // context["created_at"] = tick time
+        if (accepted < cap) adm[accepted * ls] = t; else overflow = 1;   // context["created_at"] = tick time
         accepted++;
         buf++;
         return was_empty;
@@ -320,7 +322,7 @@ struct Station {
 #pragma unroll
         for (int i = 0; i < C; ++i) if (i == j) {
             svc_s[i] = s;
-            if (C > 1) crt[i] = (k < cap) ? adm[k] : 0;
+            if (C > 1) crt[i] = (k < cap) ? adm[k * ls] : 0;
             if (d == t) { D[i] = kInfNs - 1; same = (uint32_t)i + 1; }   // in-group continuation: parked, not pending
             else { D[i] = d; seqD[i] = seq++; crtD[i] = t; }
         }
@@ -338,7 +340,7 @@ struct Station {
         total_service = __dadd_rn(total_service, s);
         uint32_t r = 0;
         if (egress == 1) {
-            if (sink_w < cap) { sink_t[sink_w] = t; if (C > 1) sink_created[sink_w] = cr; }
+            if (sink_w < cap) { sink_t[sink_w * ls] = t; if (C > 1) sink_created[sink_w * ls] = cr; }
             else overflow = 1;
             sink_w++;
             r |= 1u;
@@ -350,7 +352,7 @@ struct Station {
     __device__ __forceinline__ void do_sink() { ev[7]++; received++; }
     // A Source wired straight to a Sink/Counter (no Server in this LP): the payload IS the Sink's event.
     __device__ __forceinline__ void stage_direct_sink(int64_t t) {
-        if (sink_w < cap) { sink_t[sink_w] = t; if (C > 1) sink_created[sink_w] = t; else adm[sink_w] = t; }
+        if (sink_w < cap) { sink_t[sink_w * ls] = t; if (C > 1) sink_created[sink_w * ls] = t; else adm[sink_w * ls] = t; }
         else overflow = 1;
         sink_w++;
     }
@@ -512,7 +514,7 @@ struct Station {
         // Queue._handle_enqueue / QueueDriver._handle_notify
         ev[1] += tick_f;
         dropped += (tick_f && enq_drop) ? 1 : 0;
-        if (acc_f) { if (accepted < cap) adm[accepted] = t; else overflow = 1; }
+        if (acc_f) { if (accepted < cap) adm[accepted * ls] = t; else overflow = 1; }
         accepted += acc_f;
         ev[2] += (fast && notify) ? 1u : 0u;
         // generator resumes: statistics, Sink record, schedule_poll hook
@@ -521,7 +523,7 @@ struct Station {
         total_service = dep_f ? __dadd_rn(total_service, svc_s[0]) : total_service;
         active = dep_f ? active_dep : active;
         const bool sink_f = dep_f && egress == 1;
-        if (sink_f) { if (sink_w < cap) sink_t[sink_w] = t; else overflow = 1; }
+        if (sink_f) { if (sink_w < cap) sink_t[sink_w * ls] = t; else overflow = 1; }
         sink_w += sink_f; ev[7] += sink_f; received += sink_f;
         // QUEUE_POLL, then QUEUE_DELIVER + the retargeted payload at the worker
         ev[3] += poll_f;
@@ -572,7 +574,7 @@ struct Station {
         total_service = p ? __dadd_rn(total_service, s) : total_service;
         if (p && egress == 1) {
             const int64_t w = sink_w + (int64_t)c.n_dep;
-            if (w < cap) sink_t[w] = d; else overflow = 1;
+            if (w < cap) sink_t[w * ls] = d; else overflow = 1;
         }
         c.n_dep += p ? 1u : 0u;
         c.lt = (p && d > c.lt) ? d : c.lt;
@@ -615,7 +617,7 @@ struct Station {
         // Source.handle_event + Queue._handle_enqueue (+ notify / poll when the buffer is empty / the worker idle)
         if (arr_g) {
             const int64_t w = accepted + (int64_t)c.n_tick;
-            if (w < cap) adm[w] = A; else overflow = 1;
+            if (w < cap) adm[w * ls] = A; else overflow = 1;
         }
         c.n_tick += arr_g ? 1u : 0u;
         c.n_notify += (go && notify) ? 1u : 0u;
