@@ -7,6 +7,7 @@
 #include "hs_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -31,7 +32,12 @@ typedef struct {
     double service_s;   /* service_time_s captured by the generator frame (server/server.py:246-247) */
     int32_t hops;
     int32_t next_free;
+    int64_t client_id;  /* context["metadata"]["client_id"] (as an int; the key string is its decimal form), -1 = none */
+    int32_t lb_hook;    /* LB node whose `on_complete` hook rides on this Event (load_balancer.py:413-431), -1 = none */
 } hso_request;
+
+/* ConsistentHash ring point (strategies.py:336-433): md5 digest as a big-endian 128-bit integer + backend node */
+typedef struct { uint64_t hi, lo; int32_t backend; int32_t seq; } hso_ring_pt;
 
 typedef struct {
     int32_t *buf; int64_t head, len, cap;  /* FIFOQueue deque, components/queue_policy.py:75-114 */
@@ -54,6 +60,11 @@ typedef struct {
     uint64_t link_draws;
     int64_t routed;                       /* RandomRouter.stats_routed, components/random_router.py:36 */
     uint64_t route_draws;
+    /* LoadBalancer */
+    int64_t lb_received, lb_forwarded, lb_failed, lb_no_backend, lb_in_flight, lb_next_id;
+    int64_t *lb_total_requests;           /* [rt_cnt] BackendInfo.total_requests */
+    hso_ring_pt *ring; int64_t ring_len;
+    uint64_t key_draws;
     /* Sink */
     int64_t received;
     int64_t *sink_t, *sink_created; int64_t sink_cap;
@@ -214,6 +225,7 @@ static int32_t arrival_kind_for(const hso_sim *s, int32_t node) {
         case HSO_SINK: return HSO_EV_SINK;
         case HSO_LINK: return HSO_EV_LINK;
         case HSO_ROUTER: return HSO_EV_ROUTE;
+        case HSO_LB: return HSO_EV_LB;
         default: return -1;
     }
 }
@@ -232,6 +244,12 @@ static void on_source(hso_sim *s, const hso_event *e) {
         s->reqs[r].created_ns = e->time;                            /* context["created_at"] = time */
         s->reqs[r].hops = 0;
         s->reqs[r].service_s = 0.0;
+        s->reqs[r].client_id = -1;
+        s->reqs[r].lb_hook = -1;
+        if (s->g.n_clients && s->g.n_clients[n] > 0) {              /* chash_example.py:83: one id per Request */
+            double u = draw_uniform(s, n, HS_STREAM_KEY, &nd->key_draws);
+            s->reqs[r].client_id = (int64_t)(u * (double)s->g.n_clients[n]);
+        }
         payload.time = e->time;
         payload.idx = next_index(s);                                /* payload constructed first (:158) */
         s->reqs[r].idx = payload.idx;
@@ -254,17 +272,25 @@ static void on_enqueue(hso_sim *s, const hso_event *e) {
     hso_node *nd = &s->nodes[n];
     int was_empty = nd->fifo.len == 0;                              /* queue.py:124 */
     int64_t cap = s->g.queue_cap[n];
+    int32_t hook = s->reqs[e->req].lb_hook;                         /* Event.on_complete of this Event */
+    s->reqs[e->req].lb_hook = -1;                                   /* hooks are one-shot (core/event.py:290-311) */
     if (cap >= 0 && nd->fifo.len >= cap) {                          /* FIFOQueue.push, queue_policy.py:94-98 */
         nd->dropped++;                                              /* queue.py:128 */
         req_release(s, e->req);
-        return;
+    } else {
+        s->reqs[e->req].idx = e->idx;   /* the queued payload IS this Event object (a forwarded request is a new Event) */
+        fifo_push(&nd->fifo, e->req);
+        nd->accepted++;                                             /* queue.py:138 */
+        if (was_empty) {                                            /* queue.py:144-146 */
+            hso_event nf = {e->time, next_index(s), HSO_EV_NOTIFY, n, -1, 0};
+            heap_push(s, nf);
+        }
     }
-    s->reqs[e->req].idx = e->idx;   /* the queued payload IS this Event object (a forwarded request is a new Event) */
-    fifo_push(&nd->fifo, e->req);
-    nd->accepted++;                                                 /* queue.py:138 */
-    if (was_empty) {                                                /* queue.py:144-146 */
-        hso_event nf = {e->time, next_index(s), HSO_EV_NOTIFY, n, -1, 0};
-        heap_push(s, nf);
+    /* Event.invoke (core/event.py:277-283): the handler returned a plain list, so the completion hooks run NOW --
+     * after the handler's own events were constructed -- and their events are appended: the LB's `_lb_response`. */
+    if (hook >= 0) {
+        hso_event rs = {e->time, next_index(s), HSO_EV_LB_RESP, hook, -1, 0};
+        heap_push(s, rs);
     }
 }
 
@@ -348,7 +374,13 @@ static void on_sink(hso_sim *s, const hso_event *e) {
     nd->sink_t[nd->received] = e->time;
     nd->sink_created[nd->received] = s->reqs[e->req].created_ns;
     nd->received++;
+    int32_t hook = s->reqs[e->req].lb_hook;                         /* a Sink used directly as an LB backend */
+    s->reqs[e->req].lb_hook = -1;
     req_release(s, e->req);
+    if (hook >= 0) {
+        hso_event rs = {e->time, next_index(s), HSO_EV_LB_RESP, hook, -1, 0};
+        heap_push(s, rs);
+    }
 }
 
 /* RandomRouter.handle_event, components/random_router.py:32-45.  The stock router calls
@@ -396,6 +428,139 @@ static void on_link_cont(hso_sim *s, const hso_event *e) {
     heap_push(s, fw);
 }
 
+/* ------------------------------------------------------------------- md5 (RFC 1321)
+ * ConsistentHash._hash = int(hashlib.md5(key.encode()).hexdigest(), 16), strategies.py:377-379. */
+void hso_md5(const char *msg, int64_t len, uint8_t out[16]) {
+    static const uint32_t K[64] = {
+        0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501,
+        0x698098d8, 0x8b44f7af, 0xffff5bb1, 0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821,
+        0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8,
+        0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a,
+        0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70,
+        0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665,
+        0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1,
+        0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+    static const int R[64] = {7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9, 14, 20, 5, 9, 14, 20,
+                              5, 9, 14, 20, 5, 9, 14, 20, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23,
+                              6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
+    uint32_t h0 = 0x67452301, h1 = 0xefcdab89, h2 = 0x98badcfe, h3 = 0x10325476;
+    int64_t padded = ((len + 8) / 64 + 1) * 64;
+    uint8_t *buf = (uint8_t *)calloc((size_t)padded, 1);
+    memcpy(buf, msg, (size_t)len);
+    buf[len] = 0x80;
+    uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; ++i) buf[padded - 8 + i] = (uint8_t)(bits >> (8 * i));
+    for (int64_t off = 0; off < padded; off += 64) {
+        uint32_t M[16];
+        for (int i = 0; i < 16; ++i)
+            M[i] = (uint32_t)buf[off + 4 * i] | ((uint32_t)buf[off + 4 * i + 1] << 8) |
+                   ((uint32_t)buf[off + 4 * i + 2] << 16) | ((uint32_t)buf[off + 4 * i + 3] << 24);
+        uint32_t a = h0, b = h1, c = h2, d = h3;
+        for (int i = 0; i < 64; ++i) {
+            uint32_t f; int g;
+            if (i < 16) { f = (b & c) | (~b & d); g = i; }
+            else if (i < 32) { f = (d & b) | (~d & c); g = (5 * i + 1) & 15; }
+            else if (i < 48) { f = b ^ c ^ d; g = (3 * i + 5) & 15; }
+            else { f = c ^ (b | ~d); g = (7 * i) & 15; }
+            uint32_t x = a + f + K[i] + M[g];
+            a = d; d = c; c = b;
+            b = b + ((x << R[i]) | (x >> (32 - R[i])));
+        }
+        h0 += a; h1 += b; h2 += c; h3 += d;
+    }
+    free(buf);
+    uint32_t hs[4] = {h0, h1, h2, h3};
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out[4 * i + j] = (uint8_t)(hs[i] >> (8 * j));
+}
+static void md5_u128(const char *msg, int64_t len, uint64_t *hi, uint64_t *lo) {
+    uint8_t d[16];
+    hso_md5(msg, len, d);
+    uint64_t h = 0, l = 0;
+    for (int i = 0; i < 8; ++i) { h = (h << 8) | d[i]; l = (l << 8) | d[8 + i]; }   /* int(hexdigest, 16): big-endian */
+    *hi = h; *lo = l;
+}
+static int ring_cmp(const void *pa, const void *pb) {
+    const hso_ring_pt *a = (const hso_ring_pt *)pa, *b = (const hso_ring_pt *)pb;
+    if (a->hi != b->hi) return a->hi < b->hi ? -1 : 1;
+    if (a->lo != b->lo) return a->lo < b->lo ? -1 : 1;
+    return a->seq < b->seq ? -1 : (a->seq > b->seq);        /* list.sort is stable: insertion order on equal hashes */
+}
+/* ConsistentHash.add_backend for every backend in LoadBalancer.__init__ order (strategies.py:381-391) */
+static void lb_build_ring(hso_sim *s, int32_t n) {
+    hso_node *nd = &s->nodes[n];
+    int32_t cnt = s->g.rt_cnt[n], v = s->g.vnodes[n];
+    nd->ring_len = (int64_t)cnt * v;
+    nd->ring = (hso_ring_pt *)malloc((size_t)(nd->ring_len > 0 ? nd->ring_len : 1) * sizeof(hso_ring_pt));
+    nd->lb_total_requests = (int64_t *)calloc((size_t)(cnt > 0 ? cnt : 1), sizeof(int64_t));
+    char key[512];
+    int64_t k = 0;
+    for (int32_t b = 0; b < cnt; ++b) {
+        int32_t be = s->g.rt_targets[s->g.rt_off[n] + b];
+        int32_t nl = s->g.name_off[be + 1] - s->g.name_off[be];
+        for (int32_t i = 0; i < v; ++i) {
+            memcpy(key, s->g.names + s->g.name_off[be], (size_t)nl);
+            int m = snprintf(key + nl, sizeof(key) - (size_t)nl, ":%d", i);     /* f"{backend.name}:{i}" */
+            md5_u128(key, nl + m, &nd->ring[k].hi, &nd->ring[k].lo);
+            nd->ring[k].backend = be; nd->ring[k].seq = (int32_t)k;
+            ++k;
+        }
+    }
+    qsort(nd->ring, (size_t)nd->ring_len, sizeof(hso_ring_pt), ring_cmp);
+}
+/* ConsistentHash.select (strategies.py:412-433): first ring point with hash >= md5(key), else the first point */
+static int32_t lb_select_key(const hso_sim *s, int32_t n, const char *key, int64_t len) {
+    const hso_node *nd = &s->nodes[n];
+    uint64_t hi, lo;
+    md5_u128(key, len, &hi, &lo);
+    int64_t a = 0, b = nd->ring_len;                                /* lower bound == the reference's linear scan */
+    while (a < b) {
+        int64_t m = (a + b) >> 1;
+        const hso_ring_pt *p = &nd->ring[m];
+        int ge = (p->hi > hi) || (p->hi == hi && p->lo >= lo);
+        if (ge) b = m; else a = m + 1;
+    }
+    if (a == nd->ring_len) a = 0;
+    return nd->ring[a].backend;
+}
+int32_t hso_lb_select(const hso_sim *s, int32_t node, const char *key) { return lb_select_key(s, node, key, (int64_t)strlen(key)); }
+
+/* LoadBalancer._forward_request, load_balancer.py:347-433 (all backends healthy, ConsistentHash strategy) */
+static void on_lb(hso_sim *s, const hso_event *e) {
+    int32_t n = e->node;
+    hso_node *nd = &s->nodes[n];
+    nd->lb_received++;                                              /* :349 */
+    if (s->g.rt_cnt[n] == 0) {                                      /* no healthy backends, :352-366 */
+        nd->lb_no_backend++; nd->lb_failed++;
+        req_release(s, e->req);
+        return;
+    }
+    char key[32];
+    int len = snprintf(key, sizeof key, "%lld", (long long)s->reqs[e->req].client_id);   /* str(metadata["client_id"]) */
+    int32_t be = lb_select_key(s, n, key, len);
+    nd->lb_next_id++;                                               /* :375-376 */
+    nd->lb_in_flight++;                                             /* :378-382 */
+    for (int32_t b = 0; b < s->g.rt_cnt[n]; ++b)
+        if (s->g.rt_targets[s->g.rt_off[n] + b] == be) { nd->lb_total_requests[b]++; break; }   /* :385-386 */
+    nd->lb_forwarded++;                                             /* :388 */
+    /* a NEW Event for the backend, same context (created_at survives), + the response hook (:398-431) */
+    s->reqs[e->req].lb_hook = n;
+    hso_event fw = {e->time, next_index(s), arrival_kind_for(s, be), be, e->req, 0};
+    heap_push(s, fw);
+}
+/* LoadBalancer._handle_response, load_balancer.py:435-473: bookkeeping only */
+static void on_lb_resp(hso_sim *s, const hso_event *e) {
+    hso_node *nd = &s->nodes[e->node];
+    if (nd->lb_in_flight > 0) nd->lb_in_flight--;
+}
+
+void hso_get_lb_stats(const hso_sim *s, int32_t node, int64_t out[5], int64_t *total_requests, int32_t *ring_backend) {
+    const hso_node *nd = &s->nodes[node];
+    out[0] = nd->lb_received; out[1] = nd->lb_forwarded; out[2] = nd->lb_failed; out[3] = nd->lb_no_backend;
+    out[4] = nd->lb_in_flight;
+    if (total_requests) memcpy(total_requests, nd->lb_total_requests, (size_t)s->g.rt_cnt[node] * 8);
+    if (ring_backend) for (int64_t i = 0; i < nd->ring_len; ++i) ring_backend[i] = nd->ring[i].backend;
+}
+
 /* ------------------------------------------------------------------- API */
 #define DUP(field, type)                                                         \
     do {                                                                         \
@@ -413,6 +578,16 @@ hso_sim *hso_create(const hso_graph *g, const hso_params *p) {
     DUP(arr_kind, int32_t); DUP(rate, double); DUP(stop_after_ns, int64_t);
     DUP(concurrency, int32_t); DUP(lat_kind, int32_t); DUP(lat_mean, double); DUP(lat_min, double);
     DUP(queue_cap, int64_t); DUP(rt_off, int32_t); DUP(rt_cnt, int32_t);
+    DUP(n_clients, int64_t); DUP(vnodes, int32_t);
+    {
+        int32_t *no = (int32_t *)calloc((size_t)n + 1, sizeof(int32_t));
+        if (g->name_off) memcpy(no, g->name_off, ((size_t)n + 1) * sizeof(int32_t));
+        s->g.name_off = no;
+        int32_t nb = no[n] > 0 ? no[n] : 1;
+        char *nm = (char *)calloc((size_t)nb, 1);
+        if (g->names && no[n] > 0) memcpy(nm, g->names, (size_t)no[n]);
+        s->g.names = nm;
+    }
     {
         int32_t m = g->n_rt > 0 ? g->n_rt : 1;
         int32_t *c_ = (int32_t *)calloc((size_t)m, sizeof(int32_t));
@@ -436,6 +611,7 @@ hso_sim *hso_create(const hso_graph *g, const hso_params *p) {
     }
     /* Simulation.__init__ bootstrap, core/simulation.py:145-154 + Source.start, load/source.py:120-140:
      * sources in list order; their first SourceEvents take indices 0..S-1 from the GLOBAL counter. */
+    for (int32_t i = 0; i < n; ++i) if (s->g.kind[i] == HSO_LB) lb_build_ring(s, i);
     s->counter = 0;
     for (int32_t i = 0; i < n; ++i) {
         if (s->g.kind[i] != HSO_SOURCE) continue;
@@ -473,6 +649,8 @@ int hso_run_until(hso_sim *s, int64_t end_ns) {
             case HSO_EV_LINK: on_link(s, &e); break;
             case HSO_EV_LINK_CONT: on_link_cont(s, &e); break;
             case HSO_EV_ROUTE: on_route(s, &e); break;
+            case HSO_EV_LB: on_lb(s, &e); break;
+            case HSO_EV_LB_RESP: on_lb_resp(s, &e); break;
             default: return -1;
         }
     }
@@ -539,10 +717,12 @@ void hso_destroy(hso_sim *s) {
     if (!s) return;
     for (int32_t i = 0; i < s->g.n_nodes; ++i) {
         free(s->nodes[i].fifo.buf); free(s->nodes[i].sink_t); free(s->nodes[i].sink_created);
+        free(s->nodes[i].ring); free(s->nodes[i].lb_total_requests);
     }
     free((void *)s->g.kind); free((void *)s->g.target); free((void *)s->g.stream_base);
     free((void *)s->g.arr_kind); free((void *)s->g.rate); free((void *)s->g.stop_after_ns);
     free((void *)s->g.concurrency); free((void *)s->g.lat_kind); free((void *)s->g.lat_mean);
+    free((void *)s->g.n_clients); free((void *)s->g.vnodes); free((void *)s->g.names); free((void *)s->g.name_off);
     free((void *)s->g.lat_min); free((void *)s->g.queue_cap); free((void *)s->g.rt_off); free((void *)s->g.rt_cnt); free((void *)s->g.rt_targets);
     free(s->nodes); free(s->heap); free(s->reqs);
     free(s->tr_t); free(s->tr_kind); free(s->tr_node); free(s->tr_idx);

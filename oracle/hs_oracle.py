@@ -15,14 +15,14 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libhs_oracle.so")
 
-SOURCE, SERVER, SINK, LINK, ROUTER = 0, 1, 2, 3, 4
+SOURCE, SERVER, SINK, LINK, ROUTER, LB = 0, 1, 2, 3, 4, 5
 ARR_POISSON, ARR_CONSTANT = 0, 1
 LAT_EXP, LAT_CONST = 0, 1
 RNG_PHILOX, RNG_MT19937 = 0, 1
-EV_KINDS = 11
+EV_KINDS = 13
 EV_NAMES = ["source", "enqueue", "notify", "poll", "deliver", "work", "continuation", "sink", "link", "link_cont",
-            "route"]
-STREAM_ARRIVAL, STREAM_SERVICE, STREAM_LINK, STREAM_ROUTE = 0, 1, 2, 3
+            "route", "lb", "lb_resp"]
+STREAM_ARRIVAL, STREAM_SERVICE, STREAM_LINK, STREAM_ROUTE, STREAM_KEY = 0, 1, 2, 3, 4
 
 
 def build(force: bool = False) -> str:
@@ -55,6 +55,10 @@ class _Graph(C.Structure):
         ("rt_cnt", C.POINTER(C.c_int32)),
         ("rt_targets", C.POINTER(C.c_int32)),
         ("n_rt", C.c_int32),
+        ("n_clients", C.POINTER(C.c_int64)),
+        ("vnodes", C.POINTER(C.c_int32)),
+        ("names", C.c_char_p),
+        ("name_off", C.POINTER(C.c_int32)),
     ]
 
 
@@ -95,6 +99,10 @@ def lib():
         L.hso_get_summary.argtypes = [C.c_void_p, C.POINTER(_Summary)]
         L.hso_get_node_stats.argtypes = [C.c_void_p] + [C.c_void_p] * 9
         L.hso_get_net_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hso_get_lb_stats.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hso_lb_select.restype = C.c_int32
+        L.hso_lb_select.argtypes = [C.c_void_p, C.c_int32, C.c_char_p]
+        L.hso_md5.argtypes = [C.c_char_p, C.c_int64, C.c_void_p]
         L.hso_sink_count.restype = C.c_int64
         L.hso_sink_count.argtypes = [C.c_void_p, C.c_int32]
         L.hso_read_sink.restype = C.c_int64
@@ -132,27 +140,32 @@ class Graph:
     queue_cap: list = field(default_factory=list)
     rt_off: list = field(default_factory=list)
     rt_cnt: list = field(default_factory=list)
-    rt_targets: list = field(default_factory=list)   # flat target list of all routers (not per node)
+    rt_targets: list = field(default_factory=list)   # flat target list of all routers / load balancers (not per node)
+    n_clients: list = field(default_factory=list)
+    vnodes: list = field(default_factory=list)
+    names: list = field(default_factory=list)        # entity names (only an LB's backends need theirs)
 
     def _add(self, **kw) -> int:
         defaults = dict(
             kind=0, target=-1, stream_base=len(self.kind), arr_kind=0, rate=0.0, stop_after_ns=-1,
             concurrency=1, lat_kind=LAT_CONST, lat_mean=0.0, lat_min=0.0, queue_cap=-1, rt_off=0, rt_cnt=0,
+            n_clients=0, vnodes=0, names="",
         )
         defaults.update(kw)
         for k, v in defaults.items():
             getattr(self, k).append(v)
         return len(self.kind) - 1
 
-    def source(self, arr_kind, rate, target=-1, stop_after_ns=-1, stream_base=None) -> int:
-        kw = dict(kind=SOURCE, arr_kind=arr_kind, rate=float(rate), target=target, stop_after_ns=stop_after_ns)
+    def source(self, arr_kind, rate, target=-1, stop_after_ns=-1, stream_base=None, n_clients=0) -> int:
+        kw = dict(kind=SOURCE, arr_kind=arr_kind, rate=float(rate), target=target, stop_after_ns=stop_after_ns,
+                  n_clients=int(n_clients))
         if stream_base is not None:
             kw["stream_base"] = stream_base
         return self._add(**kw)
 
-    def server(self, lat_kind, lat_mean, concurrency=1, queue_cap=-1, target=-1, stream_base=None) -> int:
+    def server(self, lat_kind, lat_mean, concurrency=1, queue_cap=-1, target=-1, stream_base=None, name="") -> int:
         kw = dict(kind=SERVER, lat_kind=lat_kind, lat_mean=float(lat_mean), concurrency=concurrency,
-                  queue_cap=queue_cap, target=target)
+                  queue_cap=queue_cap, target=target, names=name)
         if stream_base is not None:
             kw["stream_base"] = stream_base
         return self._add(**kw)
@@ -175,6 +188,14 @@ class Graph:
         if stream_base is not None:
             kw["stream_base"] = stream_base
         self.rt_targets.extend(int(t) for t in targets)
+        return self._add(**kw)
+
+    def load_balancer(self, backends, vnodes, stream_base=None) -> int:
+        """LoadBalancer(backends=[...], strategy=ConsistentHash(virtual_nodes=vnodes)); backends need names."""
+        kw = dict(kind=LB, rt_off=len(self.rt_targets), rt_cnt=len(backends), vnodes=int(vnodes))
+        if stream_base is not None:
+            kw["stream_base"] = stream_base
+        self.rt_targets.extend(int(t) for t in backends)
         return self._add(**kw)
 
     def __len__(self) -> int:
@@ -202,7 +223,8 @@ class Result:
 
 
 def run(g: Graph, end_ns: int, start_ns: int = 0, seed: int = 42, rng_mode: int = RNG_PHILOX,
-        mt_seed_py: int = 42, mt_seed_np: int = 42, trace_cap: int = 0, windows: list | None = None) -> Result:
+        mt_seed_py: int = 42, mt_seed_np: int = 42, trace_cap: int = 0, windows: list | None = None,
+        lb_probe: int = 0) -> Result:
     """Run the oracle once; returns a Result with summary, per-node stats, sink records, trace."""
     L = lib()
     n = len(g)
@@ -215,13 +237,20 @@ def run(g: Graph, end_ns: int, start_ns: int = 0, seed: int = 42, rng_mode: int 
         "queue_cap": np.asarray(g.queue_cap, np.int64), "rt_off": np.asarray(g.rt_off, np.int32),
         "rt_cnt": np.asarray(g.rt_cnt, np.int32),
         "rt_targets": np.asarray(g.rt_targets if g.rt_targets else [0], np.int32),
+        "n_clients": np.asarray(g.n_clients, np.int64), "vnodes": np.asarray(g.vnodes, np.int32),
     }
+    enc = [nm.encode() for nm in g.names]
+    names_blob = b"".join(enc) + b"\0"
+    name_off = np.zeros(n + 1, np.int32)
+    name_off[1:] = np.cumsum([len(b) for b in enc])
     G = _Graph()
     G.n_nodes = n
     G.n_rt = len(g.rt_targets)
     for name, a in arrs.items():
         ftype = dict(_Graph._fields_)[name]
         setattr(G, name, a.ctypes.data_as(ftype))
+    G.names = names_blob
+    G.name_off = name_off.ctypes.data_as(C.POINTER(C.c_int32))
     P = _Params(start_ns, end_ns, seed, rng_mode, mt_seed_py, mt_seed_np, trace_cap)
     import time as _time
 
@@ -251,6 +280,15 @@ def run(g: Graph, end_ns: int, start_ns: int = 0, seed: int = 42, rng_mode: int 
         r.packets_sent = np.zeros(n, np.int64)
         r.routed = np.zeros(n, np.int64)
         L.hso_get_net_stats(h, r.packets_sent.ctypes.data, r.routed.ctypes.data)
+        r.lbs = {}
+        for i in range(n):
+            if g.kind[i] == LB:
+                st = np.zeros(5, np.int64)
+                tot = np.zeros(max(g.rt_cnt[i], 1), np.int64)
+                ring = np.zeros(max(g.rt_cnt[i] * g.vnodes[i], 1), np.int32)
+                L.hso_get_lb_stats(h, i, st.ctypes.data, tot.ctypes.data, ring.ctypes.data)
+                r.lbs[i] = dict(stats=st, total_requests=tot[:g.rt_cnt[i]], ring_backend=ring[:g.rt_cnt[i] * g.vnodes[i]],
+                                select=[L.hso_lb_select(h, i, str(c).encode()) for c in range(lb_probe)])
         r.sinks = {}
         for i in range(n):
             if g.kind[i] == SINK:
@@ -267,6 +305,38 @@ def run(g: Graph, end_ns: int, start_ns: int = 0, seed: int = 42, rng_mode: int 
         return r
     finally:
         L.hso_destroy(h)
+
+
+def lb_topology(n_sources, n_backends, rate, mean, vnodes, n_clients, concurrency=1, queue_cap=-1,
+                stop_after_ns=-1, shared_sink=True) -> Graph:
+    """S sources (Poisson, client ids from their KEY stream) -> LoadBalancer(ConsistentHash(vnodes)) -> B Server backends
+    -> one shared Sink or one per backend (tests/golden/make_golden.py run_lb_case).  Node order: sources 0..S-1,
+    LB = S, backends S+1..S+B, sinks after; stream bases: source i -> i, backend j -> S + j; names "srv<j>"."""
+    def per(v, m):
+        return list(v) if isinstance(v, (list, tuple)) else [v] * m
+    S, B = n_sources, n_backends
+    g = Graph()
+    rate, mean, conc, qcap = per(rate, S), per(mean, B), per(concurrency, B), per(queue_cap, B)
+    for i in range(S):
+        g.source(ARR_POISSON, rate[i], target=S, stop_after_ns=stop_after_ns, stream_base=i, n_clients=n_clients)
+    lb = g._add(kind=LB)          # placeholder, filled in below once the backend nodes exist
+    assert lb == S
+    bes = [g.server(LAT_EXP, mean[j], concurrency=conc[j], queue_cap=-1 if qcap[j] is None else qcap[j],
+                    stream_base=S + j, name=f"srv{j}") for j in range(B)]
+    sinks = [g.sink() for _ in range(1 if shared_sink else B)]
+    for j, b in enumerate(bes):
+        g.target[b] = sinks[0] if shared_sink else sinks[j]
+    g.rt_off[lb] = len(g.rt_targets)
+    g.rt_cnt[lb] = B
+    g.vnodes[lb] = int(vnodes)
+    g.rt_targets.extend(bes)
+    return g
+
+
+def md5(data: bytes) -> bytes:
+    out = (C.c_uint8 * 16)()
+    lib().hso_md5(data, len(data), out)
+    return bytes(out)
 
 
 def uniform(seed: int, sid: int, k: int) -> float:

@@ -56,8 +56,12 @@ from happysimulator.components.network.link import NetworkLink  # noqa: E402
 from happysimulator.components.random_router import RandomRouter  # noqa: E402
 from happysimulator.core.event import Event  # noqa: E402
 
+from happysimulator.components.load_balancer.load_balancer import LoadBalancer  # noqa: E402
+from happysimulator.components.load_balancer.strategies import ConsistentHash  # noqa: E402
+from happysimulator.load.event_provider import EventProvider  # noqa: E402
+
 EV = {"source": 0, "enqueue": 1, "notify": 2, "poll": 3, "deliver": 4, "work": 5, "continuation": 6, "sink": 7,
-      "link": 8, "link_cont": 9, "route": 10}
+      "link": 8, "link_cont": 9, "route": 10, "lb": 11, "lb_resp": 12}
 
 
 # ---- Seam-3 plug-ins (ours; they only choose the random numbers) ------------------------
@@ -100,6 +104,25 @@ class PhiloxRandomRouter(RandomRouter):
         idx = int(self._stream.next_uniform() * len(self.targets))
         self.target_counts[self.targets[idx].name] += 1
         return [Event(time=self.now, event_type=event.event_type, target=self.targets[idx], context=event.context)]
+
+
+class PhiloxClientProvider(EventProvider):
+    """The request factory of examples/visual/chash_example.py:69-88 (`ClientRequestProvider`): one Request per
+    tick whose metadata carries a random client_id for the ConsistentHash strategy -- with the id drawn from the
+    source's KEY stream (client_id = int(u * n_clients)) instead of a private `random.Random`."""
+
+    def __init__(self, target, n_clients: int, stream: hs.Stream, stop_after=None):
+        self._target = target
+        self._n_clients = n_clients
+        self._stream = stream
+        self._stop_after = stop_after
+
+    def get_events(self, time):
+        if self._stop_after is not None and time > self._stop_after:
+            return []
+        client_id = int(self._stream.next_uniform() * self._n_clients)
+        return [Event(time=time, event_type="Request", target=self._target,
+                      context={"metadata": {"client_id": str(client_id)}})]
 
 
 def _per_chain(v, n):
@@ -166,6 +189,8 @@ def classify(ev, node_of):
         return EV["sink"], node_of[id(tgt)]
     if isinstance(tgt, RandomRouter):
         return EV["route"], node_of[id(tgt)]
+    if isinstance(tgt, LoadBalancer):
+        return (EV["lb_resp"] if et == "_lb_response" else EV["lb"]), node_of[id(tgt)]
     if isinstance(tgt, NetworkLink):
         return (EV["link_cont"] if isinstance(ev, ProcessContinuation) else EV["link"]), node_of[id(tgt)]
     raise RuntimeError(f"unclassified event {ev!r}")
@@ -332,6 +357,107 @@ def run_ring_case(spec):
     return out, meta
 
 
+def run_lb_case(spec):
+    """BASELINE configs[4] in miniature, reference components only (examples/visual/chash_example.py wiring):
+    S x Source(Poisson rate_i, PhiloxClientProvider) -> LoadBalancer(ConsistentHash(vnodes)) -> B x Server(c, Exp mean,
+    queue_cap) -> Sink (one shared Sink, or one per backend).  Node numbering of the trace = the oracle graph's:
+    sources 0..S-1, LB = S, backends S+1..S+B, sinks after that."""
+    S, B, seed = spec["n_sources"], spec["n_backends"], spec["seed"]
+    shared = spec.get("shared_sink", True)
+    sinks = [Sink("sink")] if shared else [Sink(f"sink{j}") for j in range(B)]
+    conc = _per_chain(spec.get("concurrency", 1), B)
+    qcap = _per_chain(spec.get("queue_cap"), B)
+    mean = _per_chain(spec["mean"], B)
+    servers = [Server(f"srv{j}", concurrency=conc[j],
+                      service_time=PhiloxExponentialLatency(mean[j], hs.Stream(seed, S + j, hs.STREAM_SERVICE)),
+                      queue_capacity=qcap[j], downstream=sinks[0] if shared else sinks[j]) for j in range(B)]
+    lb = LoadBalancer("lb", backends=servers, strategy=ConsistentHash(virtual_nodes=spec["vnodes"]))
+    rate = _per_chain(spec["rate"], S)
+    stop = spec.get("stop_after_s")
+    stop_instant = None if stop is None else Instant.from_seconds(stop)
+    sources = []
+    for i in range(S):
+        prov = PhiloxPoissonArrival(ConstantRateProfile(rate=rate[i]), Instant.Epoch, hs.Stream(seed, i, hs.STREAM_ARRIVAL))
+        ep = PhiloxClientProvider(lb, spec["n_clients"], hs.Stream(seed, i, hs.STREAM_KEY), stop_instant)
+        sources.append(Source(f"src{i}", ep, prov))
+    sim = Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=sources, entities=[lb, *servers, *sinks])
+    node_of = {id(lb): S}
+    for i, src in enumerate(sources):
+        node_of[id(src)] = i
+    for j, srv in enumerate(servers):
+        for obj in (srv, srv._queue, srv._driver, srv._worker):
+            node_of[id(obj)] = S + 1 + j
+    for j, k in enumerate(sinks):
+        node_of[id(k)] = S + 1 + B + j
+    trace = []
+    if spec.get("trace"):
+        heap = sim._event_heap
+        orig_pop = heap.pop
+
+        def pop():
+            e = orig_pop()
+            k, nd = classify(e, node_of)
+            trace.append((e.time.nanoseconds, k, nd, e._sort_index))
+            return e
+
+        heap.pop = pop
+    summary = sim.run()
+    out = {}
+    meta = dict(spec=spec, total_events=[summary.total_events_processed], final_ns=[sim._current_time.nanoseconds],
+                duration_s=[summary.duration_s])
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    out["generated"] = np.array([s.generated_count for s in sources], np.int64)
+    out["accepted"] = np.array([s.stats_accepted for s in servers], np.int64)
+    out["dropped"] = np.array([s.stats_dropped for s in servers], np.int64)
+    out["completed"] = np.array([s._requests_completed for s in servers], np.int64)
+    out["rejected"] = np.array([s._requests_rejected for s in servers], np.int64)
+    out["depth"] = np.array([s.depth for s in servers], np.int64)
+    out["active"] = np.array([s.active_requests for s in servers], np.int64)
+    out["total_service_s"] = np.array([s._total_service_time for s in servers], np.float64)
+    out["received"] = np.array([k.events_received for k in sinks], np.int64)
+    st = lb.stats
+    out["lb_stats"] = np.array([st.requests_received, st.requests_forwarded, st.requests_failed,
+                                st.no_backend_available, len(lb._in_flight)], np.int64)
+    out["backend_total_requests"] = np.array([lb.get_backend_info(s).total_requests for s in servers], np.int64)
+    # the ring itself (hash is a 128-bit int: split) and the client -> backend map the strategy implements
+    ring = lb.strategy._ring
+    out["ring_hash_hi"] = np.array([h >> 64 for h, _ in ring], np.uint64)
+    out["ring_hash_lo"] = np.array([h & ((1 << 64) - 1) for h, _ in ring], np.uint64)
+    out["ring_backend"] = np.array([int(nm[3:]) for _, nm in ring], np.int32)
+    probe = []
+    for cid in range(min(spec["n_clients"], 4096)):
+        ev = Event(time=Instant.Epoch, event_type="Request", target=lb, context={"metadata": {"client_id": str(cid)}})
+        probe.append(int(lb.strategy.select(servers, ev).name[3:]))
+    out["client_backend"] = np.array(probe, np.int32)
+    sink_t, sink_lat, off = [], [], [0]
+    for k in sinks:
+        sink_t.extend(t.nanoseconds for t in k.completion_times)
+        sink_lat.extend(k.latencies_s)
+        off.append(len(sink_t))
+    out["sink_t_ns"] = np.asarray(sink_t, np.int64)
+    out["sink_latency_s"] = np.asarray(sink_lat, np.float64)
+    out["sink_off"] = np.asarray(off, np.int64)
+    if spec.get("trace"):
+        out["trace"] = np.asarray(trace, np.int64).reshape(-1, 4)
+    return out, meta
+
+
+LB_CASES = [
+    # the chash_example wiring: 1 source, 3 backends with concurrency 3, 150 vnodes, 200 clients
+    dict(name="lb_chash_example", topology="lb", n_sources=1, n_backends=3, rate=30.0, mean=0.1, concurrency=3,
+         vnodes=150, n_clients=200, end_s=20.0, seed=42, trace=True),
+    dict(name="lb_4src_8be", topology="lb", n_sources=4, n_backends=8, rate=[12.0, 9.0, 15.0, 6.0], mean=0.1,
+         vnodes=150, n_clients=5000, end_s=20.0, seed=7, trace=True),
+    dict(name="lb_cap2_overload", topology="lb", n_sources=3, n_backends=4, rate=20.0, mean=0.1, concurrency=1,
+         queue_cap=2, vnodes=20, n_clients=1000, end_s=15.0, seed=11, trace=True),
+    dict(name="lb_per_backend_sinks", topology="lb", n_sources=6, n_backends=16, rate=16.0, mean=0.1,
+         concurrency=[1, 2] * 8, vnodes=100, n_clients=100000, end_s=15.0, seed=3, shared_sink=False, trace=True),
+    dict(name="lb_stop_after", topology="lb", n_sources=2, n_backends=4, rate=20.0, mean=0.1, vnodes=50,
+         n_clients=777, stop_after_s=6.0, end_s=12.0, seed=5, trace=True),
+    dict(name="lb_64src_256be", topology="lb", n_sources=64, n_backends=256, rate=24.0, mean=0.1, vnodes=150,
+         n_clients=65536, end_s=8.0, seed=2026, trace=False),
+]
+
 RING_CASES = [
     dict(name="ring_8_s42", topology="ring", n=8, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, end_s=20.0,
          seed=42, trace=True),
@@ -393,6 +519,14 @@ CASES = [
 
 def main(argv):
     only = set(argv[1:])
+    for spec in LB_CASES:
+        if only and spec["name"] not in only:
+            continue
+        out, meta = run_lb_case(dict(spec))
+        path = os.path.join(HERE, spec["name"] + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{spec['name']}: events={sum(meta['total_events'])} final={meta['final_ns'][-1]} "
+              f"sink_records={len(out['sink_t_ns'])} lb={out['lb_stats'].tolist()} -> {os.path.getsize(path)} B")
     for spec in RING_CASES:
         if only and spec["name"] not in only:
             continue

@@ -14,7 +14,11 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def golden_names(topology="chains"):
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if (n.startswith("ring_")) == (topology == "ring")]
+
+    def topo(n):
+        return "ring" if n.startswith("ring_") else "lb" if n.startswith("lb_") else "chains"
+
+    return [n for n in names if topo(n) == topology]
 
 
 class Golden:
@@ -128,6 +132,26 @@ def oracle_ring_graph(spec):
         g.target[nodes[i]["srv"]] = nodes[i]["rtr"]
         g.target[nodes[i]["lnk"]] = nodes[(i + 1) % n]["srv"]
     return g, nodes
+
+
+def lb_params(spec):
+    S, B = spec["n_sources"], spec["n_backends"]
+    return dict(
+        S=S, B=B, rate=[float(r) for r in per_chain(spec["rate"], S)], mean=[float(m) for m in per_chain(spec["mean"], B)],
+        conc=[int(c) for c in per_chain(spec.get("concurrency", 1), B)],
+        qcap=[-1 if q is None else int(q) for q in per_chain(spec.get("queue_cap"), B)],
+        vnodes=int(spec["vnodes"]), n_clients=int(spec["n_clients"]),
+        stop_ns=-1 if spec.get("stop_after_s") is None else ns_from_seconds(spec["stop_after_s"]),
+        shared_sink=bool(spec.get("shared_sink", True)), end_ns=ns_from_seconds(spec["end_s"]))
+
+
+def oracle_lb_graph(spec):
+    """Oracle nodes of a load-balancer golden (make_golden.py run_lb_case): sources 0..S-1, LB = S, backends S+1..S+B,
+    then the Sink(s).  Returns (graph, params)."""
+    p = lb_params(spec)
+    g = O.lb_topology(p["S"], p["B"], p["rate"], p["mean"], p["vnodes"], p["n_clients"], p["conc"], p["qcap"],
+                      p["stop_ns"], p["shared_sink"])
+    return g, p
 
 
 # ----------------------------------------------------------------------------------------------

@@ -95,3 +95,53 @@ def test_oracle_matches_reference_ring_golden(name):
         t, k, nd, ix = r.trace
         got = np.stack([t, k.astype(np.int64), np.array([node_station[x] for x in nd], np.int64), ix], axis=1)
         np.testing.assert_array_equal(got, gold.trace)
+
+
+@pytest.mark.parametrize("name", H.golden_names("lb"))
+def test_oracle_matches_reference_lb_golden(name):
+    """BASELINE configs[4] in miniature: Sources -> LoadBalancer(ConsistentHash) -> Server backends -> Sink(s), reference
+    components only, client ids / arrivals / services from Philox-plugged streams (make_golden.py run_lb_case).  Pins the
+    oracle's md5 ring, its key -> backend selection, the LB's two extra events per request (Request@LB, `_lb_response`
+    fired by the completion hook when the backend's enqueue handler returns) and the whole trace with sort indices."""
+    gold = H.Golden(name)
+    spec = gold.spec
+    want_trace = "trace" in gold.arrays
+    g, p = H.oracle_lb_graph(spec)
+    S, B = p["S"], p["B"]
+    r = O.run(g, p["end_ns"], seed=spec["seed"], trace_cap=(len(gold.trace) + 16) if want_trace else 0,
+              lb_probe=len(gold.client_backend))
+    assert [r.events_processed] == gold.meta["total_events"]
+    assert [r.final_time_ns] == gold.meta["final_ns"]
+    lb = r.lbs[S]
+    np.testing.assert_array_equal(lb["stats"], gold.lb_stats)
+    np.testing.assert_array_equal(lb["total_requests"], gold.backend_total_requests)
+    np.testing.assert_array_equal(lb["ring_backend"] - (S + 1), gold.ring_backend)       # the sorted md5 ring
+    np.testing.assert_array_equal(np.array(lb["select"]) - (S + 1), gold.client_backend)  # ConsistentHash.select
+    np.testing.assert_array_equal(r.generated[:S], gold.generated)
+    be = slice(S + 1, S + 1 + B)
+    for k in ("accepted", "dropped", "completed", "rejected", "depth", "active", "total_service_s"):
+        np.testing.assert_array_equal(getattr(r, k)[be], gold.arrays[k], err_msg=k)
+    sinks = sorted(r.sinks)
+    np.testing.assert_array_equal([r.received[i] for i in sinks], gold.received)
+    t = np.concatenate([r.sinks[i][0] for i in sinks])
+    cr = np.concatenate([r.sinks[i][1] for i in sinks])
+    np.testing.assert_array_equal(t, gold.sink_t_ns)
+    np.testing.assert_array_equal((t - cr).astype(np.float64) / 1e9, gold.sink_latency_s)
+    if want_trace:
+        tt, k, nd, ix = r.trace
+        got = np.stack([tt, k.astype(np.int64), nd.astype(np.int64), ix], axis=1)
+        np.testing.assert_array_equal(got, gold.trace)
+
+
+def test_oracle_md5_known_answers():
+    """RFC 1321 appendix A.5 test suite + lengths around the 56/64-byte padding boundary."""
+    import hashlib
+
+    rfc = {b"": "d41d8cd98f00b204e9800998ecf8427e", b"a": "0cc175b9c0f1b6a831c399e269772661",
+           b"abc": "900150983cd24fb0d6963f7d28e17f72", b"message digest": "f96b697d7cb7938d525a2f31aaf161d0",
+           b"abcdefghijklmnopqrstuvwxyz": "c3fcd3d76192e4007dfb496cca67e13b"}
+    for msg, hexd in rfc.items():
+        assert O.md5(msg).hex() == hexd
+    for n in (55, 56, 57, 63, 64, 65, 119, 120, 200):
+        msg = bytes((i * 7 + 3) & 0xFF for i in range(n))
+        assert O.md5(msg) == hashlib.md5(msg).digest()
