@@ -49,9 +49,16 @@ def parse():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--cpu-sample-s", type=float, default=20.0,
                     help="simulated seconds of the same 65 536-LP workload timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--workload", choices=("grid", "ring"), default="grid",
+    ap.add_argument("--workload", choices=("grid", "ring", "lb"), default="grid",
                     help="grid = the headline metric (independent M/M/1 chains, weak scaling); ring = BASELINE configs[2]/[3]: "
-                         "ONE 65 536-station ring network, sharded over the GPUs (strong scaling, RCCL exchange + GVT)")
+                         "ONE 65 536-station ring network, sharded over the GPUs (strong scaling, RCCL exchange + GVT); "
+                         "lb = BASELINE configs[4]: 32 768 Sources -> LoadBalancer(ConsistentHash(150)) -> 32 768 Servers -> "
+                         "one Sink (one topology per GPU, replicas only)")
+    ap.add_argument("--lb-backends", type=int, default=32768)
+    ap.add_argument("--lb-sources", type=int, default=32768)
+    ap.add_argument("--lb-rate", type=float, default=6.0, help="lb: Poisson rate per source (mean backend load = rate * S / B)")
+    ap.add_argument("--lb-clients", type=int, default=1 << 20)
+    ap.add_argument("--lb-vnodes", type=int, default=150)
     ap.add_argument("--lat-min", type=float, default=0.001, help="ring: constant link latency = lookahead (s)")
     ap.add_argument("--jitter", type=float, default=0.01, help="ring: mean of the exponential link jitter (s)")
     ap.add_argument("--sync-every", type=int, default=256, help="ring, N > 1: windows between host synchronisations")
@@ -160,6 +167,83 @@ def ring_main(args, rank, local_rank, world, distributed, dist):
         print(json.dumps(out))
 
 
+def lb_main(args, rank, local_rank, world, distributed, dist):
+    """BASELINE configs[4].  One step = one complete run of the load-balancer topology: every Source's ticks, the
+    (backend, time) sort, every backend's queue protocol, the shared Sink's merge, the overshoot election."""
+    import numpy as np
+    import torch
+
+    from happy_simulator_amd import _native as N
+    from happy_simulator_amd.lb_engine import LbBackendArrays, LbSourceArrays, LoadBalancerEngine
+
+    S, B = args.lb_sources, args.lb_backends
+    end_ns = int(args.end_s * 1_000_000_000)
+    src = LbSourceArrays(n=S, src_rate=np.full(S, args.lb_rate), n_clients=np.full(S, args.lb_clients, np.int64),
+                         src_kind=np.full(S, N.SRC_POISSON, np.uint8))
+    be = LbBackendArrays(n=B, names=[f"srv{j}" for j in range(B)], concurrency=np.full(B, 1, np.int32),
+                         svc_kind=np.full(B, N.LAT_EXPONENTIAL, np.uint8), svc_mean_s=np.full(B, args.mean))
+    t_build = time.perf_counter()
+    eng = LoadBalancerEngine(src, be, virtual_nodes=args.lb_vnodes, horizon_ns=end_ns, shared_sink=True,
+                             seed=args.seed + rank, device=local_rank)
+    t_build = time.perf_counter() - t_build
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        eng.bench_runs(end_ns, args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run_ms, sort_ms = eng.bench_runs(end_ns, args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    s = eng.summary()
+    st = eng.stats()
+    t_elapsed = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t_events = torch.tensor([float(s.events_processed)], dtype=torch.float64, device="cuda")
+    if distributed:
+        dist.all_reduce(t_elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t_events, op=dist.ReduceOp.SUM)
+    elapsed = float(t_elapsed.item())
+    if rank == 0:
+        step_s = elapsed / args.steps
+        n_req = int(st["lb"][0])
+        n_done = int(s.sink_records)
+        tb, bb = int(end_ns).bit_length(), int(B - 1).bit_length()
+        p1, p2 = -(-(tb + bb) // 8), -(-tb // 8)
+        sort_bytes = 40 * (p1 * n_req + p2 * n_done)          # per pass and element: 8 B histogram read + 16 B in + 16 B out
+        sort_s = float(np.mean(sort_ms)) * 1e-3
+        out = {
+            "metric": "committed events/sec (whole node), consistent-hash load balancer, 32 768 servers",
+            "value": float(t_events.item()) / step_s, "unit": "events/s", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
+            "config": {
+                "workload": f"{S} x Source.poisson({args.lb_rate:g}) with uniform client ids in [0, {args.lb_clients}) -> "
+                            f"LoadBalancer(ConsistentHash(virtual_nodes={args.lb_vnodes})) -> {B} x Server(Exp {args.mean:g}) -> one "
+                            f"Sink, {args.end_s:g} s simulated, seed {args.seed} (BASELINE configs[4])",
+                "events_per_step_per_gpu": s.events_processed, "requests_per_step_per_gpu": n_req,
+                "sink_records_per_step_per_gpu": n_done, "device_ms_per_step": float(np.mean(run_ms)),
+                "sort_ms_per_step": float(np.mean(sort_ms)), "launches_per_step": s.launches,
+                "host_ring_build_s": t_build, "max_backend_requests": int(st["total_requests"].max()),
+                "parallelism": f"replicas x{args.gpus} (one topology per GPU, no data-path collective)",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "radix_hist + radix_scatter (all passes of both sorts)",
+                "achieved": sort_bytes / sort_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": sort_bytes / sort_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_step": sort_bytes, "passes": [p1, p2],
+                "note": "40 B per element and 8-bit pass: 8 B histogram read, 16 B (key, value) in, 16 B out; "
+                        f"{p1} passes over the {n_req} Requests by (backend, arrival ns), {p2} passes over the {n_done} "
+                        "completions by completion ns; time = HIP events around the two sorts on the engine stream",
+            },
+        }
+        print(json.dumps(out))
+    eng.close()
+
+
 def cpu_baseline(args):
     """The C oracle (event-level restatement of the reference loop) on ONE host core, same workload,
     bounded horizon.  Reported beside the GPU number; never the thing measured as `value`."""
@@ -201,6 +285,12 @@ def main():
     from happy_simulator_amd import _native as N
     from happy_simulator_amd.engine import StationArrays, StationEngine
 
+    if args.workload == "lb":
+        lb_main(args, rank, local_rank, world, distributed, dist if distributed else None)
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.workload == "ring":
         ring_main(args, rank, local_rank, world, distributed, dist if distributed else None)
         if distributed:

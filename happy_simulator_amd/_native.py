@@ -29,10 +29,10 @@ MODE_SINGLE, MODE_REPLICAS = 0, 1
 SRC_NONE, SRC_POISSON, SRC_CONSTANT = 0, 1, 2
 LAT_EXPONENTIAL, LAT_CONSTANT, LAT_NO_SERVER = 0, 1, 2
 EGRESS_NONE, EGRESS_SINK, EGRESS_LINK, EGRESS_ROUTER = 0, 1, 2, 3
-EV_KINDS = 11
+EV_KINDS = 13
 EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuation", "sink", "link", "link_cont",
-            "route")
-ABI_VERSION = 3
+            "route", "lb", "lb_resp")
+ABI_VERSION = 4
 
 
 class EngineUnavailable(RuntimeError):
@@ -99,8 +99,31 @@ class LpStats(C.Structure):
         "queue_depth", "active", "events", "final_time_ns")]
 
 
+class LbConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("device", C.c_int32), ("n_sources", C.c_int32), ("n_backends", C.c_int32),
+        ("start_ns", C.c_int64), ("horizon_ns", C.c_int64), ("seed", C.c_uint64), ("virtual_nodes", C.c_int32),
+        ("shared_sink", C.c_int32), ("tick_capacity", C.c_int64),
+    ]
+
+
+class LbSources(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("src_kind", "src_rate", "src_stop_after_ns", "n_clients", "stream_base")]
+
+
+class LbBackends(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("concurrency", "svc_kind", "svc_mean_s", "queue_cap", "egress", "stream_base",
+                                          "names", "name_off")]
+
+
+class LbStats(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("generated", "lb", "total_requests", "accepted", "dropped", "completed",
+                                          "rejected", "total_service_s", "queue_depth", "active", "sink_received")]
+
+
 def sources() -> list[str]:
-    return [os.path.join(CSRC, f) for f in ("hs_engine.hip", "hs_station.hpp", "hs_netstation.hpp", "hs_device.hpp")] + [
+    return [os.path.join(CSRC, f) for f in ("hs_engine.hip", "hs_lb.hip", "hs_station.hpp", "hs_netstation.hpp",
+                                            "hs_device.hpp", "hs_radix.hpp")] + [
         os.path.join(INCLUDE, "hs_engine.h")]
 
 
@@ -111,7 +134,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *HIPCC_FLAGS, os.path.join(CSRC, "hs_engine.hip"), "-o", LIB_PATH]
+    cmd = [hipcc, *HIPCC_FLAGS, os.path.join(CSRC, "hs_engine.hip"), os.path.join(CSRC, "hs_lb.hip"), "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -189,6 +212,33 @@ def lib():
                                  C.c_void_p, C.c_void_p, C.c_void_p]
     L.hs_debug_const_div.restype = C.c_int
     L.hs_debug_const_div.argtypes = [C.c_int32, C.c_double, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hs_lb_create.restype = C.c_int
+    L.hs_lb_create.argtypes = [P(LbConfig), P(LbSources), P(LbBackends), P(C.c_void_p)]
+    L.hs_lb_run.restype = C.c_int
+    L.hs_lb_run.argtypes = [C.c_void_p, C.c_int64]
+    L.hs_lb_bench_runs.restype = C.c_int
+    L.hs_lb_bench_runs.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+    L.hs_lb_get_summary.restype = C.c_int
+    L.hs_lb_get_summary.argtypes = [C.c_void_p, P(Summary)]
+    L.hs_lb_get_stats.restype = C.c_int
+    L.hs_lb_get_stats.argtypes = [C.c_void_p, P(LbStats)]
+    L.hs_lb_read_sink.restype = C.c_int64
+    L.hs_lb_read_sink.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]
+    L.hs_lb_ring.restype = C.c_int
+    L.hs_lb_ring.argtypes = [C.c_void_p, C.c_void_p]
+    L.hs_lb_select.restype = C.c_int32
+    L.hs_lb_select.argtypes = [C.c_void_p, C.c_char_p]
+    L.hs_lb_last_error.restype = C.c_char_p
+    L.hs_lb_last_error.argtypes = [C.c_void_p]
+    L.hs_lb_destroy.restype = None
+    L.hs_lb_destroy.argtypes = [C.c_void_p]
+    L.hs_md5.restype = None
+    L.hs_md5.argtypes = [C.c_char_p, C.c_int64, C.c_void_p]
+    L.hs_debug_lb_flags.restype = C.c_int
+    L.hs_debug_lb_flags.argtypes = [C.c_void_p, C.c_int]
+    L.hs_debug_radix_sort.restype = C.c_int
+    L.hs_debug_radix_sort.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]
     if L.hs_abi_version() != ABI_VERSION:
         raise EngineUnavailable("libhs_hip.so ABI version mismatch; rebuild")
     _lib = L
@@ -204,4 +254,7 @@ EXPORTED_SYMBOLS = (
     "hs_engine_get_summary", "hs_engine_get_lp_stats", "hs_engine_read_sink", "hs_engine_read_sinks",
     "hs_last_error", "hs_last_global_error", "hs_engine_destroy", "hs_debug_draws", "hs_debug_set_flags",
     "hs_debug_const_div",
+    "hs_lb_create", "hs_lb_run", "hs_lb_bench_runs", "hs_lb_get_summary", "hs_lb_get_stats", "hs_lb_read_sink",
+    "hs_lb_ring", "hs_lb_select", "hs_lb_last_error", "hs_lb_destroy", "hs_md5", "hs_debug_radix_sort",
+    "hs_debug_lb_flags",
 )

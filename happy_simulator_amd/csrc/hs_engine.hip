@@ -1419,7 +1419,8 @@ int hs_engine_get_summary(hs_engine *h, hs_summary *out) {
     HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
     memset(out, 0, sizeof *out);
     int64_t total = 0;
-    for (int k = 0; k < HS_EV_KINDS; ++k) { out->events_by_kind[k] = (int64_t)t.ev[k]; total += (int64_t)t.ev[k]; }
+    for (int k = 0; k < HS_EV_KINDS; ++k) out->events_by_kind[k] = 0;
+    for (int k = 0; k < 11; ++k) { out->events_by_kind[k] = (int64_t)t.ev[k]; total += (int64_t)t.ev[k]; }   // station / network kinds
     out->events_processed = total;
     out->events_cancelled = 0;
     out->final_time_ns = (h->cfg.mode == HS_MODE_SINGLE) ? t.cur_time : t.final_time;

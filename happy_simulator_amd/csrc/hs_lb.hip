@@ -1,0 +1,1105 @@
+// hs_lb.hip -- load-balancer topologies on the GPU (the hs_lb_* part of include/hs_engine.h).
+//
+//     S x Source -> LoadBalancer(ConsistentHash) -> B x Server -> Sink(s)
+//
+// Replaces, for this entity set, `Simulation._execute_until` (happysimulator/core/simulation.py:449-505) together
+// with LoadBalancer._forward_request / _handle_response (components/load_balancer/load_balancer.py:347-473) and
+// ConsistentHash (components/load_balancer/strategies.py:336-433).  Every hop from a Source's tick to the backend's
+// queue takes zero simulated time and the graph is feed-forward, so one run is a pipeline of passes, each with one
+// logical process per lane (see the ABI comment in include/hs_engine.h):
+//
+//   hs_lbk_sources     S lanes   ticks -> (backend << TB | arrival ns, creation stamp) in [tick][source] logs
+//   radix sort         HBM       by (backend, arrival ns)                      (hs_radix.hpp)
+//   hs_lb_segments     n lanes   per-backend segment offsets in the sorted list
+//   hs_lbk_backends<C> B lanes   Queue / Driver / Worker protocol over each backend's arrival list
+//   radix sort         HBM       shared Sink: completions by completion ns
+//   hs_lb_sink_finish  n lanes   ties of the merged Sink order + gather of created_at
+//   hs_lb_finalize     1 block   election of the one event beyond end_ns (core/simulation.py:472) + totals
+//
+// Event accounting (reference-equivalent, SURVEY.md 3.2 + (f) N1): a tick at t <= end processes SourceEvent@Source,
+// Request@LoadBalancer, Request@Server and `_lb_response`@LoadBalancer (the forwarded Event's completion hook fires as
+// soon as the backend's non-generator enqueue handler returns: core/event.py:277-283) -- all at t -- then the
+// backend's QUEUE_NOTIFY / QUEUE_POLL / QUEUE_DELIVER / Request@worker / ProcessContinuation / Request@Sink events as
+// in hs_station.hpp.  Same-timestamp order inside a backend follows creation order exactly as there; an arrival's
+// Request@Server is TWO generations below its SourceEvent (SourceEvent -> Request@LB -> Request@Server), which is
+// modelled by the Q_PRE pseudo-events of the in-group FIFO.  There is no CPU fallback in this file.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hs_engine.h"
+#include "hs_device.hpp"
+#include "hs_radix.hpp"
+
+using namespace hs;
+
+namespace {
+
+constexpr int kLbBlock = 256;
+constexpr int kLbQCap = 48;                  // in-group FIFO depth per backend (LDS)
+constexpr uint32_t kStreamKey = 4;           // stream kind of a Source's client-id draws
+constexpr uint64_t kCrtMask = (1ull << 56) - 1;
+
+enum : uint32_t { LQ_NOTIFY = 2, LQ_POLL = 3, LQ_DELIVER = 4, LQ_PRE = 5, LQ_CONT = 6 };
+
+struct LbTotals {
+    unsigned long long ev[HS_EV_KINDS];
+    unsigned long long completed, received;
+    long long last_time;          // latest processed event time <= end
+    long long final_time;         // Simulation._current_time after the run (the overshoot event's time)
+    int qoverflow, bad_client;
+};
+
+struct LbCand { long long t, t_created; int idx, valid; double svc_s; };
+
+struct LbSrc {                    // [S] each
+    const uint8_t *kind; const double *rate; const int64_t *stop; const int64_t *n_clients; const uint64_t *base;
+    int64_t *count;               // Requests emitted (ticks with a payload at t <= end)
+    int64_t *generated;           // Source._generated_count
+    LbCand *cand;                 // the pending SourceEvent beyond end
+};
+
+struct LbBe {                     // [B] each
+    const int32_t *conc; const uint8_t *svc_kind; const double *svc_mean; const int64_t *qcap; const uint8_t *egress;
+    const uint64_t *base;
+    int64_t *accepted, *dropped, *completed, *rejected, *received, *depth;
+    int32_t *active;
+    double *total_service;
+    LbCand *cand;                 // the earliest pending departure beyond end
+};
+
+__device__ __forceinline__ bool cand_before(const LbCand &a, const LbCand &b) {
+    if (a.valid != b.valid) return a.valid > b.valid;
+    if (!a.valid) return false;
+    if (a.t != b.t) return a.t < b.t;
+    if (a.t_created != b.t_created) return a.t_created < b.t_created;
+    return a.idx < b.idx;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1. Sources.  Source.handle_event (load/source.py:142-180) with a client-id request factory
+//    (examples/visual/chash_example.py:69-88) and ConsistentHash.select as a table lookup.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint64_t seed, int64_t start_ns, int64_t end_ns,
+                                                          const int32_t *__restrict__ client_be, int64_t n_table,
+                                                          uint64_t *__restrict__ keys, uint64_t *__restrict__ vals,
+                                                          int64_t cap, int tb, LbTotals *tot) {
+    const int s = blockIdx.x * kLbBlock + threadIdx.x;
+    const bool live = s < S;
+    uint32_t n_tick = 0, n_req = 0;
+    int bad = 0, over = 0;
+    int64_t last = INT64_MIN;
+    if (live) {
+        const uint32_t kind = P.kind[s];
+        const double rate = P.rate[s];
+        const int64_t stop = P.stop[s];
+        const double nclients = (double)P.n_clients[s];
+        Stream arr, key;
+        arr.init(seed, stream_id(P.base[s], kStreamArrival), 0);
+        key.init(seed, stream_id(P.base[s], kStreamKey), 0);
+        int64_t arr_time = start_ns;
+        // ArrivalTimeProvider.next_arrival_time, constant-rate fast path (load/arrival_time_provider.py:72-82)
+        auto next_arrival = [&]() {
+            const double area = (kind == HS_SRC_POISSON) ? exp1_from_uniform(arr.next_uniform()) : 1.0;
+            arr_time = ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), __ddiv_rn(area, rate)));
+            return arr_time;
+        };
+        int64_t A = next_arrival();          // Source.start at Simulation.__init__ (load/source.py:120-140)
+        int64_t root_crt = start_ns;         // creation time of the SourceEvent that heads the current same-ns chain
+        uint32_t depth = 0;
+        while (A <= end_ns) {
+            const int64_t t = A;
+            ++n_tick;
+            last = t;
+            if (!(stop >= 0 && t > stop)) {  // the provider returns one Request
+                const int64_t cid = __double2ll_rz(__dmul_rn(key.next_uniform(), nclients));
+                int32_t be = 0;
+                if (cid >= 0 && cid < n_table) be = client_be[cid]; else bad = 1;
+                if ((int64_t)n_req < cap) {
+                    keys[(size_t)n_req * S + s] = ((uint64_t)be << tb) | (uint64_t)t;
+                    vals[(size_t)n_req * S + s] = ((uint64_t)(depth > 30 ? 30 : depth) << 56) | ((uint64_t)root_crt & kCrtMask);
+                } else over = 1;
+                ++n_req;
+            }
+            const int64_t a2 = next_arrival();
+            if (a2 == t) { ++depth; A = a2; }                    // next tick on the same nanosecond: a descendant
+            else if (a2 < t) A = kInfNs;                          // popped later as "time travel" and dropped (simulation.py:480-489)
+            else { A = a2; root_crt = t; depth = 0; }
+        }
+        P.count[s] = (int64_t)(n_req < (uint32_t)cap ? n_req : (uint32_t)cap);
+        P.generated[s] = n_tick;
+        LbCand c;
+        c.t = A; c.t_created = root_crt; c.idx = s; c.valid = (A != kInfNs) ? 1 : 0; c.svc_s = 0.0;
+        P.cand[s] = c;
+    }
+    const uint32_t st = wave_sum<uint32_t>(n_tick), sr = wave_sum<uint32_t>(n_req);
+    if ((threadIdx.x & 63) == 0) {
+        if (st) atomicAdd(&tot->ev[HS_EV_SOURCE], (unsigned long long)st);
+        if (sr) { atomicAdd(&tot->ev[HS_EV_LB], (unsigned long long)sr); atomicAdd(&tot->ev[HS_EV_LB_RESP], (unsigned long long)sr); }
+    }
+    if (live && last != INT64_MIN) atomicMax(&tot->last_time, (long long)last);
+    if (bad) atomicOr(&tot->bad_client, 1);
+    if (over) atomicOr(&tot->bad_client, 2);
+}
+
+// validity of slot i = (tick k, source s) of the [cap][S] arrival logs
+struct TickValid {
+    const int64_t *count; int S;
+    __device__ __forceinline__ bool operator()(int64_t i) const {
+        const int64_t k = i / S;
+        return k < count[i - k * S];
+    }
+};
+struct NoVal { __device__ __forceinline__ uint64_t operator()(int64_t) const { return 0ull; } };
+struct SlotVal { __device__ __forceinline__ uint64_t operator()(int64_t i) const { return (uint64_t)i; } };
+
+// ---------------------------------------------------------------------------------------------
+// 2b. Segment offsets: backend b's arrivals are sorted[off[b] .. off[b+1])
+// ---------------------------------------------------------------------------------------------
+__global__ void hs_lb_segments(const uint64_t *__restrict__ skey, const int64_t *n_ptr, int tb, int B,
+                               int64_t *__restrict__ off) {
+    const int64_t n = *n_ptr;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    const int64_t b_prev = i == 0 ? -1 : (int64_t)(skey[i - 1] >> tb);
+    const int64_t b_here = i == n ? (int64_t)B : (int64_t)(skey[i] >> tb);
+    for (int64_t b = b_prev + 1; b <= b_here; ++b) off[b] = i;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3. Backends: QueuedResource + Queue + QueueDriver + worker in front of every Server
+//    (components/queued_resource.py:52-143, queue.py:75-170, queue_driver.py:27-99, server/server.py:202-273)
+// ---------------------------------------------------------------------------------------------
+template <int C>
+struct LbBackend {
+    int32_t conc;
+    uint32_t svc_kind, egress;
+    double svc_lambda, svc_const_s;
+    int64_t svc_const_ns, qcap;
+    // arrivals
+    const uint64_t *akey; uint64_t *aval;
+    int64_t ai, aend;
+    uint64_t tmask;
+    int64_t At, Acrt; uint32_t Adepth;
+    // state
+    int64_t buf, accepted, dropped, completed, rejected, started, received;
+    int32_t active;
+    uint32_t seq;
+    int64_t D[C], crtD[C], crt[C];
+    uint32_t seqD[C];
+    double svc_s[C];
+    double total_service;
+    int64_t last_time;
+    Stream svc;
+    uint32_t ev[8];
+    int64_t *adm, *sink_t, *sink_created, *sink_S;   // this backend's segment of the dense logs
+    int qoverflow;
+    uint8_t (*qmem)[kLbBlock];
+    int tid, qh, qn;
+
+    __device__ __forceinline__ void qpush(uint32_t code) {
+        if (qn >= kLbQCap) { qoverflow = 1; return; }
+        qmem[(qh + qn) % kLbQCap][tid] = (uint8_t)code;
+        ++qn;
+    }
+    __device__ __forceinline__ uint32_t qpop() {
+        const uint32_t c = qmem[qh][tid];
+        qh = (qh + 1) % kLbQCap;
+        --qn;
+        return c;
+    }
+    __device__ __forceinline__ void load_arrival() {
+        if (ai < aend) {
+            const uint64_t v = aval[ai];
+            At = (int64_t)(akey[ai] & tmask); Acrt = (int64_t)(v & kCrtMask); Adepth = (uint32_t)(v >> 56);
+        } else { At = kInfNs; Acrt = 0; Adepth = 0; }
+    }
+    __device__ __forceinline__ int64_t peek_time(int64_t j) const { return j < aend ? (int64_t)(akey[j] & tmask) : kInfNs; }
+
+    __device__ __forceinline__ void sample_service(double &s, int64_t &dur_ns) {
+        if (svc_kind == HS_LAT_EXPONENTIAL) {   // random.expovariate(lambda) -> Duration.from_seconds -> to_seconds (server.py:246-247)
+            const double sample = __ddiv_rn(exp1_from_uniform(svc.next_uniform()), svc_lambda);
+            s = seconds_from_ns(ns_from_seconds(sample));
+            dur_ns = ns_from_seconds(s);        // `yield s`: resume at now + int(s * 1e9) (core/event.py:499)
+        } else { s = svc_const_s; dur_ns = svc_const_ns; }
+    }
+    // Queue._handle_enqueue (components/queue.py:122-147).  True: QUEUE_NOTIFY created.
+    __device__ __forceinline__ bool do_enqueue(int64_t t) {
+        ev[HS_EV_ENQUEUE]++;
+        if (qcap >= 0 && buf >= qcap) { dropped++; return false; }       // FIFOQueue.push refuses (queue_policy.py:94-98)
+        const bool was_empty = (buf == 0);
+        adm[accepted] = t;                                               // context["created_at"] = the tick's time
+        accepted++; buf++;
+        return was_empty;
+    }
+    __device__ __forceinline__ bool do_notify() { ev[HS_EV_NOTIFY]++; return active < conc; }       // queue_driver.py:92-99
+    __device__ __forceinline__ bool do_poll() {                                                       // queue.py:149-166
+        ev[HS_EV_POLL]++;
+        if (buf == 0) return false;
+        buf--;
+        return true;
+    }
+    // QUEUE_DELIVER + the retargeted payload at the worker (queue_driver.py:66-90, server/server.py:202-250).
+    // Returns slot + 1 when the service takes zero nanoseconds (continuation inside this group), else 0.
+    __device__ __forceinline__ uint32_t do_deliver_work(int64_t t) {
+        ev[HS_EV_DELIVER]++; ev[HS_EV_WORK]++;
+        const int64_t k = started++;
+        if (active >= conc) { rejected++; return 0; }                    // acquire() failed (server.py:223-234)
+        active++;
+        double s; int64_t dur;
+        sample_service(s, dur);
+        const int64_t created = adm[k];
+        int j = 0;
+#pragma unroll
+        for (int i = C - 1; i >= 0; --i) if (D[i] == kInfNs) j = i;
+        const int64_t d = t + dur;
+        uint32_t same = 0;
+#pragma unroll
+        for (int i = 0; i < C; ++i) if (i == j) {
+            svc_s[i] = s; crt[i] = created; crtD[i] = t;
+            if (d == t) { D[i] = kInfNs - 1; same = (uint32_t)i + 1; }
+            else { D[i] = d; seqD[i] = seq++; }
+        }
+        return same;
+    }
+    // generator resumes (server/server.py:252-273): statistics, forward to the Sink (components/common.py:36-44),
+    // schedule_poll hook (queue_driver.py:79-84).  True: QUEUE_POLL created.
+    __device__ __forceinline__ bool do_cont(int slot, int64_t t) {
+        ev[HS_EV_CONTINUATION]++;
+        double s = 0.0; int64_t cr = 0, st = 0;
+#pragma unroll
+        for (int i = 0; i < C; ++i) if (i == slot) { s = svc_s[i]; cr = crt[i]; st = crtD[i]; D[i] = kInfNs; }
+        active = active > 0 ? active - 1 : 0;
+        completed++;
+        total_service = __dadd_rn(total_service, s);
+        if (egress == HS_EGRESS_SINK) {
+            ev[HS_EV_SINK]++;
+            sink_t[received] = t; sink_created[received] = cr; sink_S[received] = st;
+            received++;
+        }
+        return active < conc;
+    }
+    __device__ __forceinline__ bool chain_from_poll(int64_t t) {
+        if (!do_poll()) return false;
+        const uint32_t same = do_deliver_work(t);
+        if (same) { qpush(LQ_CONT | ((same - 1) << 3)); return true; }
+        return false;
+    }
+    __device__ __forceinline__ void drain(int64_t t) {
+        while (qn > 0) {
+            const uint32_t code = qpop();
+            switch (code & 7u) {
+                case LQ_PRE:                      // SourceEvent -> Request@LoadBalancer -> Request@Server, one hop per generation
+                    if ((code >> 3) > 0) qpush(LQ_PRE | (((code >> 3) - 1) << 3));
+                    else if (do_enqueue(t)) qpush(LQ_NOTIFY);
+                    break;
+                case LQ_NOTIFY: if (do_notify()) qpush(LQ_POLL); break;
+                case LQ_POLL: if (do_poll()) qpush(LQ_DELIVER); break;
+                case LQ_DELIVER: { const uint32_t sm = do_deliver_work(t); if (sm) qpush(LQ_CONT | ((sm - 1) << 3)); } break;
+                case LQ_CONT: if (do_cont((int)(code >> 3), t)) qpush(LQ_POLL); break;
+                default: break;
+            }
+        }
+    }
+    // Among the arrivals at time t (a run of the sorted list starting at ai) bring the one whose SourceEvent was
+    // created first to the head (stable: list order on equal stamps).  Runs longer than one are rare.
+    __device__ __forceinline__ void order_arrival_run(int64_t t) {
+        int64_t m = ai; uint64_t best = aval[ai] & kCrtMask;
+        for (int64_t j = ai + 1; peek_time(j) == t; ++j) {
+            const uint64_t c = aval[j] & kCrtMask;
+            if (c < best) { best = c; m = j; }
+        }
+        if (m != ai) {
+            const uint64_t v = aval[m];
+            for (int64_t j = m; j > ai; --j) aval[j] = aval[j - 1];
+            aval[ai] = v;
+            load_arrival();
+        }
+    }
+    __device__ __forceinline__ void run_group_general(int64_t t) {
+        for (;;) {
+            // pending departure at t with the earliest creation
+            int bd = -1; uint32_t bs = 0;
+#pragma unroll
+            for (int i = 0; i < C; ++i)
+                if (D[i] == t && (bd < 0 || (int32_t)(seqD[i] - bs) < 0)) { bd = i; bs = seqD[i]; }
+            const bool arr = (At == t);
+            if (arr) order_arrival_run(t);
+            if (bd < 0 && !arr) break;
+            bool take_arr = arr;
+            if (arr && bd >= 0) {
+                int64_t cd = 0;
+#pragma unroll
+                for (int i = 0; i < C; ++i) if (i == bd) cd = crtD[i];
+                take_arr = Acrt < cd;             // the backend's own event first on equal creation times
+            }
+            if (take_arr) {
+                qpush(LQ_PRE | ((1u + Adepth) << 3));
+                ++ai;
+                load_arrival();
+            } else if (do_cont(bd, t)) qpush(LQ_POLL);
+        }
+        drain(t);
+    }
+    __device__ __forceinline__ int64_t next_time() const {
+        int64_t t = At;
+#pragma unroll
+        for (int i = 0; i < C; ++i) t = D[i] < t ? D[i] : t;
+        return t;
+    }
+    __device__ __forceinline__ void run_group(int64_t t, bool force_general) {
+        int n_at = 0;
+#pragma unroll
+        for (int i = 0; i < C; ++i) n_at += (D[i] == t) ? 1 : 0;
+        const bool arr = (At == t);
+        if (arr) n_at += (peek_time(ai + 1) == t) ? 2 : 1;
+        if (n_at == 1 && !force_general) {
+            bool want_poll, general = false;
+            if (arr) {
+                ++ai;
+                load_arrival();
+                want_poll = do_enqueue(t) && do_notify();
+            } else {
+                int slot = 0;
+#pragma unroll
+                for (int i = 0; i < C; ++i) if (D[i] == t) slot = i;
+                want_poll = do_cont(slot, t);
+            }
+            if (want_poll) general = chain_from_poll(t);
+            if (general) drain(t);
+        } else run_group_general(t);
+        last_time = t;
+    }
+};
+
+template <int C>
+__global__ void __launch_bounds__(kLbBlock) hs_lbk_backends(LbBe P, int B, int S, uint64_t seed, int64_t start_ns,
+                                                           int64_t end_ns, const uint64_t *__restrict__ skey,
+                                                           uint64_t *__restrict__ sval, const int64_t *__restrict__ off,
+                                                           int tb, int64_t *__restrict__ adm, int64_t *__restrict__ sink_t,
+                                                           int64_t *__restrict__ sink_created, int64_t *__restrict__ sink_S,
+                                                           LbTotals *tot, int flags) {
+    __shared__ uint8_t qmem[kLbQCap][kLbBlock];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x * kLbBlock + tid;
+    const bool live = b < B;
+    LbBackend<C> X;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) X.ev[k] = 0;
+    X.qoverflow = 0; X.last_time = INT64_MIN; X.completed = 0; X.received = 0;
+    if (live) {
+        X.conc = P.conc[b]; X.svc_kind = P.svc_kind[b]; X.egress = P.egress[b]; X.qcap = P.qcap[b];
+        const double mean = P.svc_mean[b];
+        X.svc_lambda = __ddiv_rn(1.0, mean);                             // ExponentialLatency._lambda = 1 / mean
+        X.svc_const_s = seconds_from_ns(ns_from_seconds(mean));          // ConstantLatency
+        X.svc_const_ns = ns_from_seconds(X.svc_const_s);
+        X.akey = skey; X.aval = sval; X.ai = off[b]; X.aend = off[b + 1];
+        X.tmask = tb >= 64 ? ~0ull : ((1ull << tb) - 1);
+        X.buf = 0; X.accepted = 0; X.dropped = 0; X.rejected = 0; X.started = 0; X.active = 0; X.seq = 0;
+        X.total_service = 0.0;
+#pragma unroll
+        for (int i = 0; i < C; ++i) { X.D[i] = kInfNs; X.crtD[i] = start_ns; X.crt[i] = 0; X.seqD[i] = 0; X.svc_s[i] = 0.0; }
+        X.svc.init(seed, stream_id(P.base[b], kStreamService), 0);
+        const int64_t o = off[b];
+        X.adm = adm + o; X.sink_t = sink_t + o; X.sink_created = sink_created + o; X.sink_S = sink_S + o;
+        X.qmem = qmem; X.tid = tid; X.qh = 0; X.qn = 0;
+        X.load_arrival();
+        const bool force_general = (flags & 1) != 0;
+        for (;;) {
+            const int64_t t = X.next_time();
+            if (t > end_ns) break;                                       // also kInfNs: nothing pending
+            X.run_group(t, force_general);
+        }
+        P.accepted[b] = X.accepted; P.dropped[b] = X.dropped; P.completed[b] = X.completed; P.rejected[b] = X.rejected;
+        P.received[b] = X.received; P.depth[b] = X.buf; P.active[b] = X.active; P.total_service[b] = X.total_service;
+        // the earliest pending departure is this backend's candidate for the one event beyond end_ns
+        LbCand c;
+        c.t = kInfNs; c.t_created = 0; c.idx = S + b; c.valid = 0; c.svc_s = 0.0;
+        uint32_t bs = 0;
+#pragma unroll
+        for (int i = 0; i < C; ++i)
+            if (X.D[i] != kInfNs && (!c.valid || X.D[i] < c.t || (X.D[i] == c.t && (int32_t)(X.seqD[i] - bs) < 0))) {
+                c.t = X.D[i]; c.t_created = X.crtD[i]; c.svc_s = X.svc_s[i]; c.valid = 1; bs = X.seqD[i];
+            }
+        P.cand[b] = c;
+    }
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        const uint32_t s = wave_sum<uint32_t>(live ? X.ev[k] : 0u);
+        if ((tid & 63) == 0 && s) atomicAdd(&tot->ev[k], (unsigned long long)s);
+    }
+    const uint32_t sc = wave_sum<uint32_t>(live ? X.ev[HS_EV_CONTINUATION] : 0u), sr = wave_sum<uint32_t>(live ? X.ev[HS_EV_SINK] : 0u);
+    if ((tid & 63) == 0) {
+        if (sc) atomicAdd(&tot->completed, (unsigned long long)sc);
+        if (sr) atomicAdd(&tot->received, (unsigned long long)sr);
+    }
+    if (live && X.last_time != INT64_MIN) atomicMax(&tot->last_time, (long long)X.last_time);
+    if (live && X.qoverflow) atomicOr(&tot->qoverflow, 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 4. Shared Sink: slot i of the dense completion log is valid iff it lies in the used part of its backend's segment
+// ---------------------------------------------------------------------------------------------
+struct SinkValid {
+    const uint64_t *skey; const int64_t *off; const int64_t *received; int tb;
+    __device__ __forceinline__ bool operator()(int64_t i) const {
+        const int64_t b = (int64_t)(skey[i] >> tb);
+        return i - off[b] < received[b];
+    }
+};
+
+// Completions with equal timestamps: the Sink processes them in the creation order of their ProcessContinuations,
+// i.e. by service start (then backend; a backend's own completions are already in its order).  The radix sort is
+// stable in slot order = (backend, completion order), so only runs of equal keys need a look.
+__global__ void hs_lb_sink_finish(const uint64_t *__restrict__ mkey, const uint64_t *__restrict__ mslot, const int64_t *n_ptr,
+                                  const int64_t *__restrict__ sink_created, const int64_t *__restrict__ sink_S,
+                                  int64_t *__restrict__ out_t, int64_t *__restrict__ out_created) {
+    const int64_t n = *n_ptr;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = mkey[i];
+    const bool same_prev = i > 0 && mkey[i - 1] == k;
+    const bool same_next = i + 1 < n && mkey[i + 1] == k;
+    if (!same_prev && !same_next) {
+        out_t[i] = (int64_t)k;
+        out_created[i] = sink_created[mslot[i]];
+        return;
+    }
+    if (same_prev) return;                       // the head of the run writes the whole run
+    int64_t len = 1;
+    while (i + len < n && mkey[i + len] == k) ++len;
+    for (int64_t a = 0; a < len; ++a) {          // selection by (service start, slot): rank of element a within the run
+        const uint64_t sa = mslot[i + a];
+        const int64_t Sa = sink_S[sa];
+        int64_t r = 0;
+        for (int64_t c = 0; c < len; ++c) {
+            const uint64_t sc = mslot[i + c];
+            const int64_t Sc = sink_S[sc];
+            if (Sc < Sa || (Sc == Sa && sc < sa)) ++r;
+        }
+        out_t[i + r] = (int64_t)k;
+        out_created[i + r] = sink_created[sa];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 5. The one event beyond end_ns (core/simulation.py:472: the loop tests the PREVIOUS event's time) + totals
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kLbBlock) hs_lb_finalize(LbSrc PS, LbBe PB, int S, int B, int64_t start_ns, LbTotals *tot) {
+    __shared__ LbCand wc[kLbBlock / 64];
+    const int tid = threadIdx.x;
+    LbCand best;
+    best.valid = 0; best.t = kInfNs; best.t_created = 0; best.idx = 0; best.svc_s = 0.0;
+    for (int i = tid; i < S + B; i += kLbBlock) {
+        const LbCand c = i < S ? PS.cand[i] : PB.cand[i - S];
+        if (cand_before(c, best)) best = c;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        LbCand d;
+        d.t = __shfl_xor(best.t, o, 64); d.t_created = __shfl_xor(best.t_created, o, 64);
+        d.idx = __shfl_xor(best.idx, o, 64); d.valid = __shfl_xor(best.valid, o, 64); d.svc_s = __shfl_xor(best.svc_s, o, 64);
+        if (cand_before(d, best)) best = d;
+    }
+    if ((tid & 63) == 0) wc[tid >> 6] = best;
+    __syncthreads();
+    if (tid != 0) return;
+    for (int w = 1; w < kLbBlock / 64; ++w) if (cand_before(wc[w], best)) best = wc[w];
+    long long fin = tot->last_time == INT64_MIN ? start_ns : tot->last_time;
+    if (best.valid) {
+        if (best.idx < S) {                       // SourceEvent: the tick is counted, its Request is not processed
+            PS.generated[best.idx] += 1;
+            tot->ev[HS_EV_SOURCE] += 1;
+        } else {                                  // ProcessContinuation: the Server's statistics move, the Sink's do not
+            const int b = best.idx - S;
+            PB.completed[b] += 1;
+            PB.active[b] = PB.active[b] > 0 ? PB.active[b] - 1 : 0;
+            PB.total_service[b] = __dadd_rn(PB.total_service[b], best.svc_s);
+            tot->ev[HS_EV_CONTINUATION] += 1;
+            tot->completed += 1;
+        }
+        fin = best.t;
+    }
+    tot->final_time = fin;
+}
+
+__global__ void hs_lb_clear(LbTotals *tot) {
+    for (int k = 0; k < HS_EV_KINDS; ++k) tot->ev[k] = 0;
+    tot->completed = 0; tot->received = 0; tot->last_time = INT64_MIN; tot->final_time = 0;
+    tot->qoverflow = 0; tot->bad_client = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host: md5 (RFC 1321) -- ConsistentHash._hash = int(hashlib.md5(key.encode()).hexdigest(), 16)
+// ---------------------------------------------------------------------------------------------
+struct Md5 {
+    uint32_t a = 0x67452301u, b = 0xefcdab89u, c = 0x98badcfeu, d = 0x10325476u;
+    static uint32_t rotl(uint32_t x, int s) { return (x << s) | (x >> (32 - s)); }
+    void block(const uint8_t *p) {
+        static const uint32_t T[64] = {
+            0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501,
+            0x698098d8, 0x8b44f7af, 0xffff5bb1, 0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821,
+            0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8,
+            0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a,
+            0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70,
+            0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665,
+            0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1,
+            0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+        static const int Sh[4][4] = {{7, 12, 17, 22}, {5, 9, 14, 20}, {4, 11, 16, 23}, {6, 10, 15, 21}};
+        uint32_t w[16];
+        for (int i = 0; i < 16; ++i) memcpy(&w[i], p + 4 * i, 4);        // little-endian host (x86-64)
+        uint32_t A = a, Bv = b, Cv = c, Dv = d;
+        for (int i = 0; i < 64; ++i) {
+            const int rnd = i >> 4;
+            uint32_t f; int g;
+            switch (rnd) {
+                case 0: f = Dv ^ (Bv & (Cv ^ Dv)); g = i; break;
+                case 1: f = Cv ^ (Dv & (Bv ^ Cv)); g = (5 * i + 1) & 15; break;
+                case 2: f = Bv ^ Cv ^ Dv; g = (3 * i + 5) & 15; break;
+                default: f = Cv ^ (Bv | ~Dv); g = (7 * i) & 15; break;
+            }
+            const uint32_t tmp = Dv;
+            Dv = Cv; Cv = Bv;
+            Bv = Bv + rotl(A + f + T[i] + w[g], Sh[rnd][i & 3]);
+            A = tmp;
+        }
+        a += A; b += Bv; c += Cv; d += Dv;
+    }
+    void digest(const char *msg, size_t len, uint8_t out[16]) {
+        size_t off = 0;
+        for (; off + 64 <= len; off += 64) block((const uint8_t *)msg + off);
+        uint8_t tail[128] = {0};
+        const size_t rem = len - off;
+        memcpy(tail, msg + off, rem);
+        tail[rem] = 0x80;
+        const size_t tl = rem + 9 <= 64 ? 64 : 128;
+        const uint64_t bits = (uint64_t)len * 8;
+        memcpy(tail + tl - 8, &bits, 8);
+        block(tail);
+        if (tl == 128) block(tail + 64);
+        memcpy(out, &a, 4); memcpy(out + 4, &b, 4); memcpy(out + 8, &c, 4); memcpy(out + 12, &d, 4);
+    }
+};
+
+struct RingPoint { uint64_t hi, lo; int32_t backend, seq; };
+
+void md5_u128(const char *msg, size_t len, uint64_t &hi, uint64_t &lo) {
+    uint8_t dg[16];
+    Md5 m;
+    m.digest(msg, len, dg);
+    hi = lo = 0;
+    for (int i = 0; i < 8; ++i) { hi = (hi << 8) | dg[i]; lo = (lo << 8) | dg[8 + i]; }   // hexdigest read as one big integer
+}
+
+thread_local std::string g_lb_error;
+
+}  // namespace
+
+struct hs_lb {
+    hs_lb_config cfg{};
+    int C = 1, tb = 1, bb = 1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evs0 = nullptr, evs1 = nullptr, evs2 = nullptr, evs3 = nullptr;
+    std::vector<void *> allocs;
+    std::vector<RingPoint> ring;
+    LbSrc PS{};
+    LbBe PB{};
+    LbTotals *tot = nullptr;
+    int32_t *client_be = nullptr;
+    int64_t n_table = 0, cap = 0, n_slots = 0;
+    uint64_t *keys0 = nullptr, *vals0 = nullptr;      // [cap][S] arrival logs
+    uint64_t *kA = nullptr, *vA = nullptr, *kB = nullptr, *vB = nullptr;   // dense ping-pong buffers [n_slots]
+    uint64_t *skey = nullptr, *sval = nullptr;        // where the sorted arrivals ended up
+    uint64_t *mkey = nullptr, *mslot = nullptr;       // where the merged Sink order ended up
+    int64_t *off = nullptr, *adm = nullptr, *sink_t = nullptr, *sink_created = nullptr, *sink_S = nullptr;
+    int64_t *out_t = nullptr, *out_created = nullptr;
+    int64_t *n_slots_dev = nullptr, *n_arr = nullptr, *n_done = nullptr;
+    uint32_t *hist = nullptr, *row_total = nullptr, *digit_base = nullptr;
+    int n_tiles = 0;
+    bool ran = false;
+    int flags = 0;
+    double last_run_ms = 0.0, last_sort_ms = 0.0;
+    int64_t launches = 0;
+    std::string error;
+};
+
+namespace {
+
+int lfail(hs_lb *h, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->error = buf;
+    g_lb_error = buf;
+    return code;
+}
+
+#define LB_HIP(h, expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return lfail(h, HS_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));        \
+    } while (0)
+
+template <typename T>
+int lalloc(hs_lb *h, T **p, size_t count) {
+    void *q = nullptr;
+    const size_t bytes = count * sizeof(T) ? count * sizeof(T) : sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return lfail(h, HS_E_HIP, "hipMalloc(%zu B): %s", bytes, hipGetErrorString(e));
+    h->allocs.push_back(q);
+    *p = (T *)q;
+    return HS_OK;
+}
+template <typename T>
+int lupload(hs_lb *h, const T **dst, const T *src, size_t n, T dflt) {
+    T *d = nullptr;
+    int rc = lalloc(h, &d, n);
+    if (rc) return rc;
+    std::vector<T> tmp;
+    if (!src) { tmp.assign(n, dflt); src = tmp.data(); }
+    if (hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return lfail(h, HS_E_HIP, "hipMemcpy H2D failed");
+    *dst = d;
+    return HS_OK;
+}
+
+int bit_length(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b < 1 ? 1 : b; }
+
+int32_t ring_select(const std::vector<RingPoint> &ring, const char *key, size_t len) {
+    uint64_t hi, lo;
+    md5_u128(key, len, hi, lo);
+    size_t a = 0, b = ring.size();                    // first point with hash >= md5(key): the reference's linear scan
+    while (a < b) {
+        const size_t m = (a + b) >> 1;
+        const bool ge = ring[m].hi > hi || (ring[m].hi == hi && ring[m].lo >= lo);
+        if (ge) b = m; else a = m + 1;
+    }
+    if (a == ring.size()) a = 0;                      // wrap around to the first node
+    return ring[a].backend;
+}
+
+// One stable LSD sort over key bits [0, bits): pass 0 reads (k_in, v_in) through `valid` / `mk`, later passes
+// ping-pong between (kA, vA) and (kB, vB).  n_in_dev = slots of pass 0, n_out_dev receives the valid count.
+template <typename Valid, typename MakeVal>
+void radix_sort_async(hs_lb *h, const uint64_t *k_in, const uint64_t *v_in, const int64_t *n_in_dev, int64_t *n_out_dev,
+                      int bits, Valid valid, MakeVal mk, uint64_t **k_res, uint64_t **v_res,
+                      const uint64_t *keep_through_pass0 = nullptr) {
+    const int passes = (bits + kRadixBits - 1) / kRadixBits;
+    const dim3 grid((unsigned)h->n_tiles), blk(kRadixThreads);
+    // `valid` may read a buffer that is itself one of the ping-pong buffers (the previous sort's result): pass 0, the
+    // only pass that evaluates `valid`, must then write the OTHER buffer
+    const bool startB = keep_through_pass0 == h->kA;
+    uint64_t *ko = startB ? h->kB : h->kA, *vo = startB ? h->vB : h->vA;
+    const uint64_t *ki = k_in, *vi = v_in;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * kRadixBits;
+        const int64_t *n_dev = p == 0 ? n_in_dev : n_out_dev;
+        if (p == 0) {
+            hipLaunchKernelGGL((radix_hist<Valid>), grid, blk, 0, h->stream, ki, n_dev, shift, h->hist, h->n_tiles, valid);
+        } else {
+            hipLaunchKernelGGL((radix_hist<RadixAll>), grid, blk, 0, h->stream, ki, n_dev, shift, h->hist, h->n_tiles, RadixAll{});
+        }
+        hipLaunchKernelGGL(radix_scan_rows, dim3(kRadixBins), blk, 0, h->stream, h->hist, h->n_tiles, h->row_total);
+        hipLaunchKernelGGL(radix_scan_digits, dim3(1), blk, 0, h->stream, h->row_total, h->digit_base,
+                           p == 0 ? n_out_dev : (int64_t *)nullptr);
+        if (p == 0) {
+            hipLaunchKernelGGL((radix_scatter<Valid, MakeVal>), grid, blk, 0, h->stream, ki, vi, ko, vo, n_dev, shift, h->hist,
+                               h->digit_base, h->n_tiles, valid, mk);
+        } else {
+            hipLaunchKernelGGL((radix_scatter<RadixAll, NoVal>), grid, blk, 0, h->stream, ki, vi, ko, vo, n_dev, shift, h->hist,
+                               h->digit_base, h->n_tiles, RadixAll{}, NoVal{});
+        }
+        h->launches += 4;
+        ki = ko; vi = vo;
+        if (ko == h->kA) { ko = h->kB; vo = h->vB; } else { ko = h->kA; vo = h->vA; }
+    }
+    *k_res = const_cast<uint64_t *>(ki);
+    *v_res = const_cast<uint64_t *>(vi);
+}
+
+template <int C>
+void launch_backends(hs_lb *h, int64_t end_ns) {
+    const int B = h->cfg.n_backends;
+    hipLaunchKernelGGL(hs_lbk_backends<C>, dim3((B + kLbBlock - 1) / kLbBlock), dim3(kLbBlock), 0, h->stream, h->PB, B,
+                       h->cfg.n_sources, h->cfg.seed, h->cfg.start_ns, end_ns, h->skey, h->sval, h->off, h->tb, h->adm,
+                       h->sink_t, h->sink_created, h->sink_S, h->tot, h->flags);
+}
+
+int run_async(hs_lb *h, int64_t end_ns) {
+    const int S = h->cfg.n_sources, B = h->cfg.n_backends;
+    h->launches = 0;
+    hipLaunchKernelGGL(hs_lb_clear, dim3(1), dim3(1), 0, h->stream, h->tot);
+    hipLaunchKernelGGL(hs_lbk_sources, dim3((S + kLbBlock - 1) / kLbBlock), dim3(kLbBlock), 0, h->stream, h->PS, S, h->cfg.seed,
+                       h->cfg.start_ns, end_ns, h->client_be, h->n_table, h->keys0, h->vals0, h->cap, h->tb, h->tot);
+    hipEventRecord(h->evs0, h->stream);
+    radix_sort_async(h, h->keys0, h->vals0, h->n_slots_dev, h->n_arr, h->tb + h->bb, TickValid{h->PS.count, S}, NoVal{},
+                     &h->skey, &h->sval);
+    hipEventRecord(h->evs1, h->stream);
+    hipLaunchKernelGGL(hs_lb_segments, dim3((unsigned)((h->n_slots + 1 + 255) / 256)), dim3(256), 0, h->stream, h->skey,
+                       h->n_arr, h->tb, B, h->off);
+    switch (h->C) {
+        case 1: launch_backends<1>(h, end_ns); break;
+        case 2: launch_backends<2>(h, end_ns); break;
+        case 4: launch_backends<4>(h, end_ns); break;
+        case 8: launch_backends<8>(h, end_ns); break;
+        default: launch_backends<16>(h, end_ns); break;
+    }
+    hipEventRecord(h->evs2, h->stream);
+    if (h->cfg.shared_sink) {
+        // completions by completion ns; the validity functor reads the sorted arrival keys (which slot belongs to which
+        // backend), so pass 0 must not overwrite them
+        radix_sort_async(h, (const uint64_t *)h->sink_t, (const uint64_t *)nullptr, h->n_arr, h->n_done, h->tb,
+                         SinkValid{h->skey, h->off, h->PB.received, h->tb}, SlotVal{}, &h->mkey, &h->mslot, h->skey);
+        hipLaunchKernelGGL(hs_lb_sink_finish, dim3((unsigned)((h->n_slots + 255) / 256)), dim3(256), 0, h->stream, h->mkey,
+                           h->mslot, h->n_done, h->sink_created, h->sink_S, h->out_t, h->out_created);
+    }
+    hipEventRecord(h->evs3, h->stream);
+    hipLaunchKernelGGL(hs_lb_finalize, dim3(1), dim3(kLbBlock), 0, h->stream, h->PS, h->PB, S, B, h->cfg.start_ns, h->tot);
+    h->launches += 6;
+    LB_HIP(h, hipGetLastError());
+    h->ran = true;
+    return HS_OK;
+}
+
+int check_flags(hs_lb *h) {
+    LbTotals t;
+    LB_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
+    if (t.qoverflow) return lfail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
+    if (t.bad_client & 1) return lfail(h, HS_E_INVALID, "a client id fell outside the client table");
+    if (t.bad_client & 2) return lfail(h, HS_E_OVERFLOW, "a source's tick log overflowed (capacity %lld ticks); raise tick_capacity", (long long)h->cap);
+    return HS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *hs_lb_last_error(const hs_lb *h) { return h ? h->error.c_str() : g_lb_error.c_str(); }
+
+void hs_md5(const char *msg, int64_t len, uint8_t out[16]) {
+    Md5 m;
+    m.digest(msg, (size_t)len, out);
+}
+
+int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_backends *be, hs_lb **out) {
+    if (!cfg || !src || !be || !out) return lfail(nullptr, HS_E_INVALID, "hs_lb_create: null argument");
+    if (cfg->struct_size != sizeof(hs_lb_config)) return lfail(nullptr, HS_E_INVALID, "hs_lb_create: hs_lb_config size mismatch (ABI %d)", HS_ABI_VERSION);
+    const int S = cfg->n_sources, B = cfg->n_backends;
+    if (S <= 0) return lfail(nullptr, HS_E_INVALID, "hs_lb_create: n_sources must be > 0");
+    if (B <= 0) return lfail(nullptr, HS_E_INVALID, "hs_lb_create: n_backends must be > 0 (the reference rejects every request otherwise)");
+    if (cfg->virtual_nodes < 1) return lfail(nullptr, HS_E_INVALID, "virtual_nodes must be >= 1, got %d", cfg->virtual_nodes);
+    if (cfg->horizon_ns < cfg->start_ns || cfg->start_ns < 0) return lfail(nullptr, HS_E_INVALID, "hs_lb_create: bad start / horizon");
+    if (!src->src_rate || !src->n_clients) return lfail(nullptr, HS_E_INVALID, "src_rate and n_clients are required");
+    if (!be->names || !be->name_off) return lfail(nullptr, HS_E_INVALID, "backend names are required (the ring hashes them)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return lfail(nullptr, HS_E_NO_DEVICE, "no HIP device visible: the engine has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return lfail(nullptr, HS_E_INVALID, "device ordinal %d out of range (%d devices)", cfg->device, ndev);
+    // ---- validation + sizing
+    const double horizon_s = (double)(cfg->horizon_ns - cfg->start_ns) / 1e9;
+    double max_ticks = 0.0;
+    int64_t kmax = 0;
+    for (int i = 0; i < S; ++i) {
+        const int sk = src->src_kind ? src->src_kind[i] : HS_SRC_POISSON;
+        if (sk != HS_SRC_POISSON && sk != HS_SRC_CONSTANT) return lfail(nullptr, HS_E_INVALID, "source %d: unknown source kind %d", i, sk);
+        const double r = src->src_rate[i];
+        if (!(r > 0.0) || !std::isfinite(r)) return lfail(nullptr, HS_E_INVALID, "source %d: rate must be > 0 (got %g)", i, r);
+        if (r > 1e8) return lfail(nullptr, HS_E_UNSUPPORTED, "source %d: rate %g above 1e8/s is not supported", i, r);
+        max_ticks = std::max(max_ticks, r * horizon_s);
+        if (src->n_clients[i] < 1) return lfail(nullptr, HS_E_INVALID, "source %d: n_clients must be >= 1", i);
+        kmax = std::max(kmax, src->n_clients[i]);
+    }
+    if (kmax > (1ll << 26)) return lfail(nullptr, HS_E_UNSUPPORTED, "n_clients above 2^26 is not supported (client -> backend table)");
+    int maxc = 1;
+    for (int j = 0; j < B; ++j) {
+        const int c = be->concurrency ? be->concurrency[j] : 1;
+        if (c < 1) return lfail(nullptr, HS_E_INVALID, "backend %d: max_concurrent must be >= 1, got %d", j, c);
+        if (c > 16) return lfail(nullptr, HS_E_UNSUPPORTED, "backend %d: concurrency %d > 16 is not lowered yet", j, c);
+        maxc = std::max(maxc, c);
+        const int vk = be->svc_kind ? be->svc_kind[j] : HS_LAT_CONSTANT;
+        if (vk != HS_LAT_EXPONENTIAL && vk != HS_LAT_CONSTANT) return lfail(nullptr, HS_E_UNSUPPORTED, "backend %d: service distribution kind %d is not lowered", j, vk);
+        const double mean = be->svc_mean_s ? be->svc_mean_s[j] : 0.01;
+        if (!(mean >= 0.0) || !std::isfinite(mean) || (vk == HS_LAT_EXPONENTIAL && !(mean > 0.0)))
+            return lfail(nullptr, HS_E_INVALID, "backend %d: bad service mean %g", j, mean);
+        const int eg = be->egress ? be->egress[j] : HS_EGRESS_SINK;
+        if (eg != HS_EGRESS_NONE && eg != HS_EGRESS_SINK) return lfail(nullptr, HS_E_UNSUPPORTED, "backend %d: egress kind %d is not lowered", j, eg);
+        if (be->name_off[j + 1] < be->name_off[j] || be->name_off[j + 1] - be->name_off[j] > 200)
+            return lfail(nullptr, HS_E_INVALID, "backend %d: bad name", j);
+    }
+    hs_lb *h = new (std::nothrow) hs_lb();
+    if (!h) return lfail(nullptr, HS_E_INVALID, "out of host memory");
+    h->cfg = *cfg;
+    h->C = maxc <= 1 ? 1 : maxc <= 2 ? 2 : maxc <= 4 ? 4 : maxc <= 8 ? 8 : 16;
+    h->tb = bit_length((uint64_t)cfg->horizon_ns);
+    h->bb = bit_length((uint64_t)(B - 1));
+    if (h->tb + h->bb > 64 || h->tb > 56) { delete h; return lfail(nullptr, HS_E_UNSUPPORTED, "horizon x backends do not fit the 64-bit sort key"); }
+    int64_t cap = cfg->tick_capacity;
+    if (cap <= 0) cap = ((int64_t)(max_ticks + 10.0 * std::sqrt(max_ticks + 1.0) + 64.0) + 15) & ~(int64_t)15;
+    h->cap = cap;
+    h->n_slots = cap * (int64_t)S;
+    if ((double)h->n_slots * 88.0 > 200e9) { delete h; return lfail(nullptr, HS_E_INVALID, "buffers would need %.1f GB", (double)h->n_slots * 88.0 / 1e9); }
+    h->n_tiles = (int)((h->n_slots + kRadixTile - 1) / kRadixTile);
+    // ---- the ring: ConsistentHash.add_backend for every backend in order (strategies.py:381-391)
+    const int V = cfg->virtual_nodes;
+    h->ring.resize((size_t)B * V);
+    {
+        char key[256];
+        size_t k = 0;
+        for (int j = 0; j < B; ++j) {
+            const int nl = be->name_off[j + 1] - be->name_off[j];
+            memcpy(key, be->names + be->name_off[j], (size_t)nl);
+            for (int i = 0; i < V; ++i, ++k) {
+                const int m = snprintf(key + nl, sizeof(key) - (size_t)nl, ":%d", i);          // f"{backend.name}:{i}"
+                md5_u128(key, (size_t)(nl + m), h->ring[k].hi, h->ring[k].lo);
+                h->ring[k].backend = j; h->ring[k].seq = (int32_t)k;
+            }
+        }
+        std::sort(h->ring.begin(), h->ring.end(), [](const RingPoint &x, const RingPoint &y) {
+            if (x.hi != y.hi) return x.hi < y.hi;
+            if (x.lo != y.lo) return x.lo < y.lo;
+            return x.seq < y.seq;                     // list.sort is stable
+        });
+    }
+    // ---- client id -> backend (ConsistentHash.select for key str(id)); a pure function of the id
+    std::vector<int32_t> table((size_t)kmax);
+    {
+        char key[32];
+        for (int64_t c = 0; c < kmax; ++c) {
+            const int m = snprintf(key, sizeof key, "%lld", (long long)c);
+            table[(size_t)c] = ring_select(h->ring, key, (size_t)m);
+        }
+    }
+    h->n_table = kmax;
+    hipError_t e = hipSetDevice(cfg->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    hipEvent_t *evs[6] = {&h->ev0, &h->ev1, &h->evs0, &h->evs1, &h->evs2, &h->evs3};
+    for (auto pe : evs) if (e == hipSuccess) e = hipEventCreate(pe);
+    if (e != hipSuccess) { int rc = lfail(nullptr, HS_E_HIP, "device setup: %s", hipGetErrorString(e)); hs_lb_destroy(h); return rc; }
+    int rc = HS_OK;
+    std::vector<uint64_t> sbase((size_t)S), bbase((size_t)B);
+    for (int i = 0; i < S; ++i) sbase[(size_t)i] = (uint64_t)i;
+    for (int j = 0; j < B; ++j) bbase[(size_t)j] = (uint64_t)S + (uint64_t)j;
+#define TRY(x) do { if ((rc = (x))) { g_lb_error = h->error; hs_lb_destroy(h); return rc; } } while (0)
+    TRY(lupload<uint8_t>(h, &h->PS.kind, src->src_kind, (size_t)S, (uint8_t)HS_SRC_POISSON));
+    TRY(lupload<double>(h, &h->PS.rate, src->src_rate, (size_t)S, 1.0));
+    TRY(lupload<int64_t>(h, &h->PS.stop, src->src_stop_after_ns, (size_t)S, (int64_t)-1));
+    TRY(lupload<int64_t>(h, &h->PS.n_clients, src->n_clients, (size_t)S, (int64_t)1));
+    TRY(lupload<uint64_t>(h, &h->PS.base, src->stream_base ? src->stream_base : sbase.data(), (size_t)S, 0));
+    TRY(lalloc(h, &h->PS.count, (size_t)S)); TRY(lalloc(h, &h->PS.generated, (size_t)S)); TRY(lalloc(h, &h->PS.cand, (size_t)S));
+    TRY(lupload<int32_t>(h, &h->PB.conc, be->concurrency, (size_t)B, 1));
+    TRY(lupload<uint8_t>(h, &h->PB.svc_kind, be->svc_kind, (size_t)B, (uint8_t)HS_LAT_CONSTANT));
+    TRY(lupload<double>(h, &h->PB.svc_mean, be->svc_mean_s, (size_t)B, 0.01));
+    TRY(lupload<int64_t>(h, &h->PB.qcap, be->queue_cap, (size_t)B, (int64_t)-1));
+    TRY(lupload<uint8_t>(h, &h->PB.egress, be->egress, (size_t)B, (uint8_t)HS_EGRESS_SINK));
+    TRY(lupload<uint64_t>(h, &h->PB.base, be->stream_base ? be->stream_base : bbase.data(), (size_t)B, 0));
+    TRY(lalloc(h, &h->PB.accepted, (size_t)B)); TRY(lalloc(h, &h->PB.dropped, (size_t)B)); TRY(lalloc(h, &h->PB.completed, (size_t)B));
+    TRY(lalloc(h, &h->PB.rejected, (size_t)B)); TRY(lalloc(h, &h->PB.received, (size_t)B)); TRY(lalloc(h, &h->PB.depth, (size_t)B));
+    TRY(lalloc(h, &h->PB.active, (size_t)B)); TRY(lalloc(h, &h->PB.total_service, (size_t)B)); TRY(lalloc(h, &h->PB.cand, (size_t)B));
+    {
+        const int32_t *dt = nullptr;
+        TRY(lupload<int32_t>(h, &dt, table.data(), (size_t)kmax, 0));
+        h->client_be = const_cast<int32_t *>(dt);
+    }
+    const size_t NS = (size_t)h->n_slots;
+    TRY(lalloc(h, &h->keys0, NS)); TRY(lalloc(h, &h->vals0, NS));
+    TRY(lalloc(h, &h->kA, NS)); TRY(lalloc(h, &h->vA, NS)); TRY(lalloc(h, &h->kB, NS)); TRY(lalloc(h, &h->vB, NS));
+    TRY(lalloc(h, &h->off, (size_t)B + 1));
+    TRY(lalloc(h, &h->adm, NS)); TRY(lalloc(h, &h->sink_t, NS)); TRY(lalloc(h, &h->sink_created, NS)); TRY(lalloc(h, &h->sink_S, NS));
+    if (cfg->shared_sink) { TRY(lalloc(h, &h->out_t, NS)); TRY(lalloc(h, &h->out_created, NS)); }
+    TRY(lalloc(h, &h->n_slots_dev, 1)); TRY(lalloc(h, &h->n_arr, 1)); TRY(lalloc(h, &h->n_done, 1));
+    TRY(lalloc(h, &h->hist, (size_t)kRadixBins * (size_t)h->n_tiles)); TRY(lalloc(h, &h->row_total, (size_t)kRadixBins));
+    TRY(lalloc(h, &h->digit_base, (size_t)kRadixBins));
+    TRY(lalloc(h, &h->tot, 1));
+#undef TRY
+    if (hipMemcpy(h->n_slots_dev, &h->n_slots, 8, hipMemcpyHostToDevice) != hipSuccess) {
+        rc = lfail(nullptr, HS_E_HIP, "hipMemcpy failed"); hs_lb_destroy(h); return rc;
+    }
+    *out = h;
+    return HS_OK;
+}
+
+int hs_lb_run(hs_lb *h, int64_t end_ns) {
+    if (!h) return lfail(h, HS_E_INVALID, "hs_lb_run: null handle");
+    if (end_ns < h->cfg.start_ns || end_ns > h->cfg.horizon_ns) return lfail(h, HS_E_INVALID, "end_ns outside [start_ns, horizon_ns]");
+    LB_HIP(h, hipSetDevice(h->cfg.device));
+    LB_HIP(h, hipEventRecord(h->ev0, h->stream));
+    int rc = run_async(h, end_ns);
+    if (rc) return rc;
+    LB_HIP(h, hipEventRecord(h->ev1, h->stream));
+    LB_HIP(h, hipStreamSynchronize(h->stream));
+    float ms = 0, s1 = 0, s2 = 0;
+    hipEventElapsedTime(&ms, h->ev0, h->ev1);
+    hipEventElapsedTime(&s1, h->evs0, h->evs1);
+    hipEventElapsedTime(&s2, h->evs2, h->evs3);
+    h->last_run_ms = ms; h->last_sort_ms = s1 + s2;
+    return check_flags(h);
+}
+
+int hs_lb_bench_runs(hs_lb *h, int64_t end_ns, int32_t repeats, float *run_ms_out, float *sort_ms_out) {
+    if (!h || repeats <= 0) return lfail(h, HS_E_INVALID, "hs_lb_bench_runs: bad argument");
+    for (int r = 0; r < repeats; ++r) {
+        int rc = hs_lb_run(h, end_ns);
+        if (rc) return rc;
+        if (run_ms_out) run_ms_out[r] = (float)h->last_run_ms;
+        if (sort_ms_out) sort_ms_out[r] = (float)h->last_sort_ms;
+    }
+    return HS_OK;
+}
+
+int hs_lb_get_summary(hs_lb *h, hs_summary *out) {
+    if (!h || !out) return lfail(h, HS_E_INVALID, "hs_lb_get_summary: null argument");
+    if (!h->ran) return lfail(h, HS_E_STATE, "hs_lb_run has not been called");
+    LB_HIP(h, hipSetDevice(h->cfg.device));
+    LB_HIP(h, hipStreamSynchronize(h->stream));
+    LbTotals t;
+    LB_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    int64_t total = 0;
+    for (int k = 0; k < HS_EV_KINDS; ++k) { out->events_by_kind[k] = (int64_t)t.ev[k]; total += (int64_t)t.ev[k]; }
+    out->events_processed = total;
+    out->final_time_ns = t.final_time;
+    out->requests_completed = (int64_t)t.completed;
+    out->sink_records = (int64_t)t.received;
+    out->last_run_ms = h->last_run_ms;
+    out->kernel_ms = h->last_sort_ms;
+    out->launches = h->launches;
+    return HS_OK;
+}
+
+int hs_lb_get_stats(hs_lb *h, const hs_lb_stats *o) {
+    if (!h || !o) return lfail(h, HS_E_INVALID, "hs_lb_get_stats: null argument");
+    if (!h->ran) return lfail(h, HS_E_STATE, "hs_lb_run has not been called");
+    LB_HIP(h, hipSetDevice(h->cfg.device));
+    LB_HIP(h, hipStreamSynchronize(h->stream));
+    const size_t S = (size_t)h->cfg.n_sources, B = (size_t)h->cfg.n_backends;
+    if (o->generated) LB_HIP(h, hipMemcpy(o->generated, h->PS.generated, S * 8, hipMemcpyDeviceToHost));
+#define DL(dst, srcp, T) if (o->dst) LB_HIP(h, hipMemcpy(o->dst, h->PB.srcp, B * sizeof(T), hipMemcpyDeviceToHost))
+    DL(accepted, accepted, int64_t); DL(dropped, dropped, int64_t); DL(completed, completed, int64_t);
+    DL(rejected, rejected, int64_t); DL(total_service_s, total_service, double); DL(queue_depth, depth, int64_t);
+    DL(active, active, int32_t); DL(sink_received, received, int64_t);
+#undef DL
+    if (o->total_requests || o->lb) {
+        std::vector<int64_t> off(B + 1);
+        LB_HIP(h, hipMemcpy(off.data(), h->off, (B + 1) * 8, hipMemcpyDeviceToHost));
+        if (o->total_requests) for (size_t j = 0; j < B; ++j) o->total_requests[j] = off[j + 1] - off[j];
+        if (o->lb) { o->lb[0] = off[B]; o->lb[1] = off[B]; o->lb[2] = 0; o->lb[3] = 0; o->lb[4] = 0; }
+    }
+    return HS_OK;
+}
+
+int64_t hs_lb_read_sink(hs_lb *h, int32_t sink, int64_t *t_ns, int64_t *created_ns, int64_t cap) {
+    if (!h || !h->ran) return lfail(h, HS_E_STATE, "hs_lb_run has not been called");
+    if (hipSetDevice(h->cfg.device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+        return lfail(h, HS_E_HIP, "device synchronisation failed");
+    const int B = h->cfg.n_backends;
+    int64_t cnt = 0;
+    const int64_t *src_t, *src_c;
+    if (h->cfg.shared_sink) {
+        if (sink != 0) return lfail(h, HS_E_INVALID, "shared sink: the only sink index is 0");
+        if (hipMemcpy(&cnt, h->n_done, 8, hipMemcpyDeviceToHost) != hipSuccess) return lfail(h, HS_E_HIP, "memcpy");
+        src_t = h->out_t; src_c = h->out_created;
+    } else {
+        if (sink < 0 || sink >= B) return lfail(h, HS_E_INVALID, "sink index %d out of range", sink);
+        int64_t o = 0;
+        if (hipMemcpy(&cnt, h->PB.received + sink, 8, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(&o, h->off + sink, 8, hipMemcpyDeviceToHost) != hipSuccess) return lfail(h, HS_E_HIP, "memcpy");
+        src_t = h->sink_t + o; src_c = h->sink_created + o;
+    }
+    if (cnt > cap) cnt = cap;
+    if (cnt > 0) {
+        if (t_ns && hipMemcpy(t_ns, src_t, (size_t)cnt * 8, hipMemcpyDeviceToHost) != hipSuccess) return lfail(h, HS_E_HIP, "memcpy");
+        if (created_ns && hipMemcpy(created_ns, src_c, (size_t)cnt * 8, hipMemcpyDeviceToHost) != hipSuccess) return lfail(h, HS_E_HIP, "memcpy");
+    }
+    return cnt;
+}
+
+int hs_lb_ring(hs_lb *h, int32_t *ring_backend) {
+    if (!h || !ring_backend) return lfail(h, HS_E_INVALID, "hs_lb_ring: null argument");
+    for (size_t i = 0; i < h->ring.size(); ++i) ring_backend[i] = h->ring[i].backend;
+    return HS_OK;
+}
+
+int32_t hs_lb_select(hs_lb *h, const char *key) {
+    if (!h || !key) return lfail(h, HS_E_INVALID, "hs_lb_select: null argument");
+    return ring_select(h->ring, key, strlen(key));
+}
+
+void hs_lb_destroy(hs_lb *h) {
+    if (!h) return;
+    hipSetDevice(h->cfg.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (void *p : h->allocs) hipFree(p);
+    hipEvent_t evs[6] = {h->ev0, h->ev1, h->evs0, h->evs1, h->evs2, h->evs3};
+    for (auto e : evs) if (e) hipEventDestroy(e);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int hs_debug_lb_flags(hs_lb *h, int flags) {
+    if (!h) return HS_E_INVALID;
+    h->flags = flags;
+    return HS_OK;
+}
+
+int hs_debug_radix_sort(int32_t device, int64_t n, int32_t key_bits, const uint64_t *keys_in, const uint64_t *vals_in,
+                        uint64_t *keys_out, uint64_t *vals_out, float *device_ms) {
+    if (n <= 0 || key_bits < 1 || key_bits > 64 || !keys_in || !vals_in || !keys_out || !vals_out)
+        return lfail(nullptr, HS_E_INVALID, "hs_debug_radix_sort: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return lfail(nullptr, HS_E_NO_DEVICE, "no HIP device visible");
+    hs_lb h;
+    h.cfg.device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking) != hipSuccess)
+        return lfail(nullptr, HS_E_HIP, "device setup failed");
+    hipEventCreate(&h.ev0); hipEventCreate(&h.ev1);
+    h.n_slots = n;
+    h.n_tiles = (int)((n + kRadixTile - 1) / kRadixTile);
+    uint64_t *k0 = nullptr, *v0 = nullptr;
+    int rc = HS_OK;
+    const size_t N = (size_t)n;
+    if ((rc = lalloc(&h, &k0, N)) || (rc = lalloc(&h, &v0, N)) || (rc = lalloc(&h, &h.kA, N)) || (rc = lalloc(&h, &h.vA, N)) ||
+        (rc = lalloc(&h, &h.kB, N)) || (rc = lalloc(&h, &h.vB, N)) || (rc = lalloc(&h, &h.n_slots_dev, 1)) ||
+        (rc = lalloc(&h, &h.n_arr, 1)) || (rc = lalloc(&h, &h.hist, (size_t)kRadixBins * (size_t)h.n_tiles)) ||
+        (rc = lalloc(&h, &h.row_total, (size_t)kRadixBins)) || (rc = lalloc(&h, &h.digit_base, (size_t)kRadixBins))) {
+        g_lb_error = h.error;
+    } else {
+        hipMemcpy(k0, keys_in, N * 8, hipMemcpyHostToDevice);
+        hipMemcpy(v0, vals_in, N * 8, hipMemcpyHostToDevice);
+        hipMemcpy(h.n_slots_dev, &n, 8, hipMemcpyHostToDevice);
+        uint64_t *kr = nullptr, *vr = nullptr;
+        hipEventRecord(h.ev0, h.stream);
+        radix_sort_async(&h, k0, v0, h.n_slots_dev, h.n_arr, key_bits, RadixAll{}, NoVal{}, &kr, &vr);
+        hipEventRecord(h.ev1, h.stream);
+        if (hipStreamSynchronize(h.stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = lfail(nullptr, HS_E_HIP, "radix sort failed");
+        else {
+            hipMemcpy(keys_out, kr, N * 8, hipMemcpyDeviceToHost);
+            hipMemcpy(vals_out, vr, N * 8, hipMemcpyDeviceToHost);
+            float ms = 0;
+            hipEventElapsedTime(&ms, h.ev0, h.ev1);
+            if (device_ms) *device_ms = ms;
+        }
+    }
+    for (void *p : h.allocs) hipFree(p);
+    h.allocs.clear();
+    hipEventDestroy(h.ev0); hipEventDestroy(h.ev1);
+    hipStreamDestroy(h.stream);
+    h.stream = nullptr; h.ev0 = h.ev1 = nullptr;
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,182 @@
+// hs_radix.hpp -- stable LSD radix sort of (uint64 key, uint64 value) pairs for gfx950, 8-bit digits.
+//
+// Used by the load-balancer engine (hs_lb.hip) for the two places where the reference's global event heap
+// (core/event_heap.py:54-108) really orders events of DIFFERENT entities against each other:
+//   * requests fanned out by the LoadBalancer must reach each backend in (time, creation) order
+//     -> sort by (backend, arrival ns);
+//   * one Sink shared by all backends records completions in global processing order
+//     -> sort by completion ns.
+//
+// Everything is sized for the worst case at engine creation and driven by a DEVICE-side element count, so a whole
+// run is enqueued without a single host synchronisation.  Per pass (HBM-bound; 40 B per element):
+//   radix_hist     8 B read   per-tile digit histogram -> hist[digit][tile]
+//   radix_scan_*   --         exclusive scan of hist in (digit, tile) order
+//   radix_scatter  16 B read + 16 B write; ranks are computed with wavefront ballots (64 lanes), no sorting in LDS
+// A tile is 256 threads x kItems rows of 64 consecutive elements per wavefront, so ranks are stable by construction:
+// element order = (wave, row, lane).  Elements can be masked out of the FIRST pass (ragged inputs) by a validity
+// functor; from then on the data is dense.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hs {
+
+constexpr int kRadixBits = 8;
+constexpr int kRadixBins = 1 << kRadixBits;
+constexpr int kRadixThreads = 256;
+constexpr int kRadixWaves = kRadixThreads / 64;
+constexpr int kRadixItems = 16;                                   // rows of 64 elements per wavefront per tile
+constexpr int kRadixTile = kRadixThreads * kRadixItems;           // 4096 elements
+
+// validity of input slot i in the first pass
+struct RadixAll {
+    __device__ __forceinline__ bool operator()(int64_t) const { return true; }
+};
+
+__device__ __forceinline__ uint64_t lanemask_lt() {
+    const unsigned lane = __lane_id();
+    return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+
+// lanes of the wavefront (among `valid` ones) whose 8-bit digit equals this lane's
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
+    uint64_t m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < kRadixBits; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t v = __ballot(bit);
+        m &= bit ? v : ~v;
+    }
+    return m;
+}
+
+// hist[digit * n_tiles + tile] = number of valid elements of the tile with that digit
+template <typename Valid>
+__global__ void __launch_bounds__(kRadixThreads) radix_hist(const uint64_t *__restrict__ keys, const int64_t *n_ptr,
+                                                            int shift, uint32_t *__restrict__ hist, int n_tiles,
+                                                            Valid valid) {
+    __shared__ uint32_t h[kRadixBins];
+    const int tid = threadIdx.x;
+    h[tid] = 0;
+    __syncthreads();
+    const int64_t n = *n_ptr;
+    const int64_t base = (int64_t)blockIdx.x * kRadixTile;
+    if (base < n) {
+#pragma unroll 4
+        for (int r = 0; r < kRadixItems; ++r) {
+            const int64_t i = base + (int64_t)r * kRadixThreads + tid;
+            if (i < n && valid(i)) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (kRadixBins - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    hist[(size_t)tid * n_tiles + blockIdx.x] = h[tid];
+}
+
+// exclusive scan of every digit row (one block per digit), row totals out
+__global__ void __launch_bounds__(kRadixThreads) radix_scan_rows(uint32_t *__restrict__ hist, int n_tiles,
+                                                                 uint32_t *__restrict__ row_total) {
+    __shared__ uint32_t wsum[kRadixWaves];
+    __shared__ uint32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    uint32_t *row = hist + (size_t)blockIdx.x * n_tiles;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n_tiles; c0 += kRadixThreads) {
+        const int i = c0 + tid;
+        const uint32_t v = i < n_tiles ? row[i] : 0u;
+        uint32_t s = v;                                            // inclusive scan inside the wavefront
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(s, o, 64);
+            if (lane >= o) s += t;
+        }
+        if (lane == 63) wsum[w] = s;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int k = 0; k < w; ++k) wbase += wsum[k];
+        const uint32_t c = carry;
+        if (i < n_tiles) row[i] = c + wbase + s - v;
+        __syncthreads();
+        if (tid == kRadixThreads - 1) carry = c + wbase + s;
+        __syncthreads();
+    }
+    if (tid == 0) row_total[blockIdx.x] = carry;
+}
+
+// exclusive scan of the 256 row totals -> digit bases; also the element count of the pass (all digits)
+__global__ void __launch_bounds__(kRadixThreads) radix_scan_digits(const uint32_t *__restrict__ row_total,
+                                                                   uint32_t *__restrict__ digit_base, int64_t *n_out) {
+    __shared__ uint32_t wsum[kRadixWaves];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t v = row_total[tid];
+    uint32_t s = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(s, o, 64);
+        if (lane >= o) s += t;
+    }
+    if (lane == 63) wsum[w] = s;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int k = 0; k < w; ++k) wbase += wsum[k];
+    digit_base[tid] = wbase + s - v;
+    if (tid == kRadixThreads - 1 && n_out) *n_out = (int64_t)(wbase + s);
+}
+
+// Stable scatter of one pass.  MakeVal builds the value of input slot i when the pass starts from keys only
+// (vals_in == nullptr): e.g. the slot index itself.
+template <typename Valid, typename MakeVal>
+__global__ void __launch_bounds__(kRadixThreads) radix_scatter(const uint64_t *__restrict__ keys_in,
+                                                               const uint64_t *__restrict__ vals_in,
+                                                               uint64_t *__restrict__ keys_out,
+                                                               uint64_t *__restrict__ vals_out, const int64_t *n_ptr,
+                                                               int shift, const uint32_t *__restrict__ hist,
+                                                               const uint32_t *__restrict__ digit_base, int n_tiles,
+                                                               Valid valid, MakeVal make_val) {
+    __shared__ uint32_t cnt[kRadixWaves][kRadixBins];
+    __shared__ uint32_t off[kRadixWaves][kRadixBins];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t n = *n_ptr;
+    const int64_t base = (int64_t)blockIdx.x * kRadixTile;
+    if (base >= n) return;
+#pragma unroll
+    for (int k = 0; k < kRadixWaves; ++k) cnt[k][tid] = 0;
+    __syncthreads();
+    uint64_t key[kRadixItems], val[kRadixItems];
+    uint32_t rank[kRadixItems];                                    // low 24 bits rank in the wave's chunk, high 8 digit
+    const uint64_t lt = lanemask_lt();
+    const int64_t wbase = base + (int64_t)w * (kRadixItems * 64);
+#pragma unroll
+    for (int r = 0; r < kRadixItems; ++r) {
+        const int64_t i = wbase + r * 64 + lane;
+        const bool ok = i < n && valid(i);
+        key[r] = ok ? keys_in[i] : 0ull;
+        val[r] = ok ? (vals_in ? vals_in[i] : make_val(i)) : 0ull;
+        const uint32_t d = (uint32_t)(key[r] >> shift) & (kRadixBins - 1);
+        const uint64_t m = match_digit(d, ok);
+        const uint32_t before = cnt[w][d];                         // elements of earlier rows with this digit
+        const uint32_t pos = (uint32_t)__popcll(m & lt);
+        rank[r] = ok ? ((d << 24) | (before + pos)) : 0xffffffffu;
+        __builtin_amdgcn_wave_barrier();
+        if (ok && pos == 0) cnt[w][d] = before + (uint32_t)__popcll(m);   // one leader per digit value
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {   // thread `tid` owns digit `tid`: global base of the tile's run + the waves' sub-runs
+        uint32_t run = hist[(size_t)tid * n_tiles + blockIdx.x] + digit_base[tid];
+#pragma unroll
+        for (int k = 0; k < kRadixWaves; ++k) { off[k][tid] = run; run += cnt[k][tid]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kRadixItems; ++r) {
+        if (rank[r] == 0xffffffffu) continue;
+        const uint32_t d = rank[r] >> 24;
+        const size_t p = (size_t)off[w][d] + (rank[r] & 0xffffffu);
+        keys_out[p] = key[r];
+        vals_out[p] = val[r];
+    }
+}
+
+}  // namespace hs

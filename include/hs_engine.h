@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HS_ABI_VERSION 3
+#define HS_ABI_VERSION 4
 
 typedef enum hs_status {
     HS_OK = 0,
@@ -75,7 +75,9 @@ enum {
     HS_EV_LINK = 8,         /* Request @ NetworkLink (transit starts)       */
     HS_EV_LINK_CONT = 9,    /* ProcessContinuation @ NetworkLink (transit over) */
     HS_EV_ROUTE = 10,       /* Request @ RandomRouter                       */
-    HS_EV_KINDS = 11
+    HS_EV_LB = 11,          /* Request @ LoadBalancer (forwarded to the selected backend)        */
+    HS_EV_LB_RESP = 12,     /* _lb_response @ LoadBalancer (completion hook of the forwarded Request) */
+    HS_EV_KINDS = 13
 };
 
 typedef struct hs_config {
@@ -249,6 +251,98 @@ int64_t hs_engine_read_sink(hs_engine *h, int32_t lp, int64_t *t_ns, int64_t *cr
 /* All LPs at once: counts[n_lp] receives per-LP record counts; t_ns/created_ns receive the records
  * concatenated in LP order (caller sizes them from a previous get_lp_stats / sink_records). */
 int64_t hs_engine_read_sinks(hs_engine *h, int64_t *counts, int64_t *t_ns, int64_t *created_ns, int64_t cap_total);
+
+/* =====================================================================================================
+ * Load-balancer topologies (BASELINE configs[4]; reference: components/load_balancer/load_balancer.py:347-433,
+ * strategies.py:336-433, wiring of examples/visual/chash_example.py:118-140):
+ *
+ *     S x Source  ->  LoadBalancer(strategy=ConsistentHash(virtual_nodes))  ->  B x Server  ->  Sink(s)
+ *
+ * All hops between a Source's tick and the backend's queue take zero simulated time, so there is no lookahead for
+ * conservative windows; but the graph is feed-forward, so one `_execute_until(end)` is a PIPELINE of device passes:
+ *   1. every Source LP (one lane each) generates its ticks up to end_ns, draws the client id of each Request
+ *      (metadata["client_id"] = str(int(u * n_clients)), u from the source's KEY stream -- the Philox-plugged form of
+ *      chash_example.py:69-88) and looks up the backend ConsistentHash.select picks for it;
+ *   2. the Requests are radix-sorted by (backend, arrival ns) -- this is the part of the reference's global heap
+ *      order (core/event_heap.py:54-108) that matters to a backend;
+ *   3. every backend LP (one lane each) runs the Queue/Driver/Worker protocol over its arrival list;
+ *   4. completions of a Sink shared by all backends are radix-sorted by completion ns (the Sink's processing order);
+ *   5. the first event beyond end_ns is elected among all LPs (one-event overshoot, core/simulation.py:472).
+ * The md5 ring is built on the host once, at creation (ConsistentHash.add_backend runs in LoadBalancer.__init__).
+ * One run per hs_lb_run call (the call is not re-entrant: it restarts from start_ns). */
+typedef struct hs_lb_config {
+    uint32_t struct_size;
+    int32_t device;
+    int32_t n_sources;
+    int32_t n_backends;
+    int64_t start_ns;
+    int64_t horizon_ns;        /* latest end_ns that will be passed to hs_lb_run: sizes every buffer */
+    uint64_t seed;             /* Philox key of the run */
+    int32_t virtual_nodes;     /* ConsistentHash(virtual_nodes=...), >= 1 */
+    int32_t shared_sink;       /* 1: every backend's downstream is ONE Sink; 0: one Sink per backend (or none, see egress) */
+    int64_t tick_capacity;     /* ticks per source in the arrival log; 0 = derive from rate * horizon */
+} hs_lb_config;
+
+typedef struct hs_lb_sources {     /* [n_sources] each; NULL = documented default */
+    const uint8_t *src_kind;           /* hs_source_kind (POISSON / CONSTANT); NULL = POISSON */
+    const double *src_rate;            /* required */
+    const int64_t *src_stop_after_ns;  /* < 0 = never; the provider returns no Request when time > stop_after */
+    const int64_t *n_clients;          /* client ids are drawn uniformly from [0, n_clients); required, >= 1 */
+    const uint64_t *stream_base;       /* NULL = i */
+} hs_lb_sources;
+
+typedef struct hs_lb_backends {    /* [n_backends] each */
+    const int32_t *concurrency;        /* NULL = 1 */
+    const uint8_t *svc_kind;           /* hs_latency_kind; NULL = HS_LAT_CONSTANT */
+    const double *svc_mean_s;          /* NULL = 0.01 */
+    const int64_t *queue_cap;          /* < 0 = unbounded */
+    const uint8_t *egress;             /* HS_EGRESS_NONE / HS_EGRESS_SINK; NULL = SINK */
+    const uint64_t *stream_base;       /* NULL = n_sources + j */
+    const char *names;                 /* concatenated backend names (the ring hashes "<name>:<i>"); required */
+    const int32_t *name_off;           /* [n_backends + 1] offsets into names */
+} hs_lb_backends;
+
+typedef struct hs_lb_stats {       /* any pointer may be NULL */
+    int64_t *generated;        /* [n_sources]  Source._generated_count */
+    int64_t *lb;               /* [5] LoadBalancer.stats: requests_received, requests_forwarded, requests_failed,
+                                      no_backend_available, len(_in_flight) */
+    int64_t *total_requests;   /* [n_backends] BackendInfo.total_requests (load_balancer.py:385-386) */
+    int64_t *accepted, *dropped, *completed, *rejected;   /* [n_backends] as hs_lp_stats */
+    double *total_service_s;   /* [n_backends] */
+    int64_t *queue_depth;      /* [n_backends] */
+    int32_t *active;           /* [n_backends] */
+    int64_t *sink_received;    /* [n_backends] Request@Sink events caused by this backend's completions */
+} hs_lb_stats;
+
+typedef struct hs_lb hs_lb;
+
+int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_backends *be, hs_lb **out);
+/* Simulation.__init__ + run() to end_ns.  Blocks until the device work is complete. */
+int hs_lb_run(hs_lb *h, int64_t end_ns);
+/* `repeats` complete runs back to back on the engine's stream; per-run device time of the whole pipeline and of the
+ * sort passes alone (HIP events on that stream). */
+int hs_lb_bench_runs(hs_lb *h, int64_t end_ns, int32_t repeats, float *run_ms_out, float *sort_ms_out);
+int hs_lb_get_summary(hs_lb *h, hs_summary *out);
+int hs_lb_get_stats(hs_lb *h, const hs_lb_stats *out);
+/* Sink records in the Sink's processing order.  shared_sink: sink must be 0 (all completions, global order);
+ * otherwise sink = backend index.  Returns the number of records copied or a negative hs_status. */
+int64_t hs_lb_read_sink(hs_lb *h, int32_t sink, int64_t *t_ns, int64_t *created_ns, int64_t cap);
+/* The sorted ring's backend index per point, [n_backends * virtual_nodes] (strategies.py:381-391). */
+int hs_lb_ring(hs_lb *h, int32_t *ring_backend);
+/* ConsistentHash.select for a key string (strategies.py:412-433): backend index. */
+int32_t hs_lb_select(hs_lb *h, const char *key);
+const char *hs_lb_last_error(const hs_lb *h);
+void hs_lb_destroy(hs_lb *h);
+/* md5 digest of a byte string (the ring's hash function), exported so tests can check it against RFC 1321. */
+void hs_md5(const char *msg, int64_t len, uint8_t out[16]);
+
+/* Debug: bit 0 routes every timestamp group of every backend through the general in-group FIFO path. */
+int hs_debug_lb_flags(hs_lb *h, int flags);
+
+/* Debug / tests: stable LSD radix sort of n (key, value) pairs on `device` over key bits [0, key_bits) --
+ * the sort the load-balancer engine uses (csrc/hs_radix.hpp).  Host arrays in, host arrays out. */
+int hs_debug_radix_sort(int32_t device, int64_t n, int32_t key_bits, const uint64_t *keys_in, const uint64_t *vals_in,
+                        uint64_t *keys_out, uint64_t *vals_out, float *device_ms);
 
 const char *hs_last_error(const hs_engine *h);
 const char *hs_last_global_error(void);
