@@ -13,8 +13,9 @@ with a host-side mirror of the reference's `Simulation / Source / Server / Sink 
 """
 from ._native import EngineError, EngineUnavailable  # noqa: F401
 from .core.temporal import Duration, Instant  # noqa: F401
-from .entities import (ConstantArrivalTimeProvider, ConstantLatency, ConstantRateProfile, Counter, Entity,  # noqa: F401
-                       ExponentialLatency, FIFOQueue, LatencyTracker, NetworkLink, NetworkLinkStats,
+from .entities import (BackendInfo, ClientKeyEventProvider, ConsistentHash, ConstantArrivalTimeProvider,  # noqa: F401
+                       ConstantLatency, ConstantRateProfile, Counter, Entity, ExponentialLatency, FIFOQueue,
+                       LatencyTracker, LoadBalancer, LoadBalancerStats, NetworkLink, NetworkLinkStats,
                        PoissonArrivalTimeProvider, RandomRouter, Server, ServerStats, SimpleEventProvider, Sink, Source)
 from .lowering import UnsupportedTopology  # noqa: F401
 from .parallel import (ParallelResult, ParallelRunner, ParallelSimulation, ParallelSimulationSummary,  # noqa: F401

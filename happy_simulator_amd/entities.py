@@ -414,3 +414,134 @@ class RandomRouter(Entity):
 
     def downstream_entities(self) -> list[Entity]:
         return list(self.targets)
+
+
+# ---- load balancing ------------------------------------------------------------------------------
+class ClientKeyEventProvider:
+    """One Request per tick whose metadata carries a random `client_id` for key-based strategies -- the request factory
+    of examples/visual/chash_example.py:69-88 (`ClientRequestProvider`: `client_id = rng.randint(0, NUM_CLIENTS - 1)`).
+    On the engine the id is `int(u * n_clients)` with u from the source's own Philox KEY stream, and the routing key is
+    its decimal string, as `ConsistentHash._default_get_key` would return it (strategies.py:369-375)."""
+
+    def __init__(self, target: Entity, n_clients: int, stop_after: Instant | float | None = None,
+                 event_type: str = "Request"):
+        if n_clients < 1:
+            raise ValueError(f"n_clients must be >= 1, got {n_clients}")
+        self._target = target
+        self._n_clients = int(n_clients)
+        self._event_type = event_type
+        self._stop_after = Source._resolve_stop_after(stop_after)
+        self._generated = 0
+
+
+class ConsistentHash:
+    """Consistent hashing with virtual nodes (components/load_balancer/strategies.py:336-433): every backend owns
+    `virtual_nodes` points md5("<name>:<i>") on a ring; a request goes to the first point whose hash is >= md5(key).
+    The ring is built (and searched) inside libhs_hip.so; `ring_backends` / `select_name` expose it for inspection."""
+
+    def __init__(self, virtual_nodes: int = 100, get_key=None):
+        if virtual_nodes < 1:
+            raise ValueError(f"virtual_nodes must be >= 1, got {virtual_nodes}")        # strategies.py:356-357
+        if get_key is not None:
+            raise NotImplementedError("a custom get_key is arbitrary Python; the engine hashes metadata['client_id']")
+        self._virtual_nodes = int(virtual_nodes)
+
+    @property
+    def virtual_nodes(self) -> int:
+        return self._virtual_nodes
+
+
+@dataclass(frozen=True)
+class LoadBalancerStats:
+    """components/load_balancer/load_balancer.py:40-58."""
+
+    requests_received: int = 0
+    requests_forwarded: int = 0
+    requests_failed: int = 0
+    no_backend_available: int = 0
+    backends_marked_unhealthy: int = 0
+    backends_marked_healthy: int = 0
+
+
+@dataclass
+class BackendInfo:
+    """load_balancer.py:61-80 (health bookkeeping is host-side state the engine never changes)."""
+
+    backend: Entity
+    weight: int = 1
+    is_healthy: bool = True
+    consecutive_failures: int = 0
+    consecutive_successes: int = 0
+    total_requests: int = 0
+    total_failures: int = 0
+
+
+class LoadBalancer(Entity):
+    """Distributes requests over backends (components/load_balancer/load_balancer.py:83-473).  Lowered: the
+    ConsistentHash strategy over Server backends that all stay healthy for the whole run."""
+
+    def __init__(self, name: str, backends: list[Entity] | None = None, strategy=None, on_no_backend: str = "reject"):
+        super().__init__(name)
+        if on_no_backend not in ("reject", "queue"):
+            raise ValueError(f"on_no_backend must be 'reject' or 'queue', got {on_no_backend}")   # load_balancer.py:120-121
+        if strategy is None:
+            raise NotImplementedError("the default RoundRobin strategy is not lowered; pass strategy=ConsistentHash(...)")
+        if not isinstance(strategy, ConsistentHash):
+            raise NotImplementedError(f"strategy {type(strategy).__name__} is not lowered to the engine (only ConsistentHash)")
+        self._strategy = strategy
+        self._on_no_backend = on_no_backend
+        self._backends: dict[str, BackendInfo] = {}
+        for b in backends or []:
+            self.add_backend(b)
+        self._requests_received = 0
+        self._requests_forwarded = 0
+        self._requests_failed = 0
+        self._no_backend_available = 0
+        self._in_flight_count = 0
+
+    def add_backend(self, backend: Entity, weight: int = 1) -> None:
+        if weight < 1:
+            raise ValueError(f"weight must be >= 1, got {weight}")                        # load_balancer.py:207-208
+        if backend.name in self._backends:
+            self._backends[backend.name].weight = weight
+            return
+        self._backends[backend.name] = BackendInfo(backend=backend, weight=weight)
+
+    def remove_backend(self, backend: Entity) -> None:
+        self._backends.pop(backend.name, None)
+
+    @property
+    def strategy(self):
+        return self._strategy
+
+    @property
+    def all_backends(self) -> list[Entity]:
+        return [i.backend for i in self._backends.values()]
+
+    healthy_backends = all_backends
+
+    @property
+    def unhealthy_backends(self) -> list[Entity]:
+        return []
+
+    @property
+    def backend_count(self) -> int:
+        return len(self._backends)
+
+    @property
+    def healthy_count(self) -> int:
+        return len(self._backends)
+
+    def downstream_entities(self) -> list[Entity]:
+        return self.all_backends
+
+    def get_backend_info(self, backend: Entity) -> BackendInfo | None:
+        return self._backends.get(backend.name)
+
+    def get_backend_info_by_name(self, name: str) -> BackendInfo | None:
+        return self._backends.get(name)
+
+    @property
+    def stats(self) -> LoadBalancerStats:
+        return LoadBalancerStats(self._requests_received, self._requests_forwarded, self._requests_failed,
+                                 self._no_backend_available, 0, 0)

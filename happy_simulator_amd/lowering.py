@@ -18,8 +18,8 @@ import numpy as np
 
 from . import _native as N
 from .engine import NetworkArrays, StationArrays
-from .entities import (ConstantLatency, Counter, Entity, ExponentialLatency, LatencyTracker, NetworkLink,
-                       RandomRouter, Server, Sink, Source, _RecordSink)
+from .entities import (ClientKeyEventProvider, ConsistentHash, ConstantLatency, Counter, Entity, ExponentialLatency,
+                       LatencyTracker, LoadBalancer, NetworkLink, RandomRouter, Server, Sink, Source, _RecordSink)
 
 _SINKS = (Sink, Counter, LatencyTracker)
 
@@ -300,3 +300,123 @@ def write_back(g: LoweredGraph, stats: dict, counts: np.ndarray, t_ns: np.ndarra
                     else:
                         tc[t.name] = tc.get(t.name, 0) + int(net_stats["link_entered"][next(ids)])
                 st.router.target_counts = {k: v for k, v in tc.items() if v}
+
+
+# ----------------------------------------------------------------------------------------------
+# load-balancer topologies (BASELINE configs[4]):  Sources -> LoadBalancer(ConsistentHash) -> Servers -> Sink(s)
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class LbGraph:
+    sources: list
+    lb: LoadBalancer
+    backends: list
+    sinks: list                    # one shared collector, one per backend, or [] (no downstream anywhere)
+    shared_sink: bool
+
+    def engine_arrays(self):
+        from .lb_engine import LbBackendArrays, LbSourceArrays
+
+        S, B = len(self.sources), len(self.backends)
+        src = LbSourceArrays(
+            n=S, src_rate=np.array([s.rate for s in self.sources], np.float64),
+            n_clients=np.array([s._event_provider._n_clients for s in self.sources], np.int64),
+            src_kind=np.array([N.SRC_POISSON if s._time_provider.kind == "poisson" else N.SRC_CONSTANT
+                               for s in self.sources], np.uint8),
+            src_stop_after_ns=np.array([-1 if s._event_provider._stop_after is None
+                                        else s._event_provider._stop_after.nanoseconds for s in self.sources], np.int64))
+        caps = [b._policy.capacity for b in self.backends]
+        be = LbBackendArrays(
+            n=B, names=[b.name for b in self.backends],
+            concurrency=np.array([b.concurrency for b in self.backends], np.int32),
+            svc_kind=np.array([N.LAT_EXPONENTIAL if isinstance(b.service_time, ExponentialLatency) else N.LAT_CONSTANT
+                               for b in self.backends], np.uint8),
+            svc_mean_s=np.array([b.service_time.mean for b in self.backends], np.float64),
+            queue_cap=np.array([-1 if c == float("inf") else int(c) for c in caps], np.int64),
+            egress=np.full(B, N.EGRESS_SINK if self.sinks else N.EGRESS_NONE, np.uint8))
+        return src, be
+
+
+def find_load_balancer(sources: list, entities: list):
+    """The LoadBalancer of a load-balancer topology, or None when the graph has none."""
+    lbs = [e for e in (entities or []) if isinstance(e, LoadBalancer)]
+    for s in sources or []:
+        t = getattr(getattr(s, "_event_provider", None), "_target", None)
+        if isinstance(t, LoadBalancer) and all(t is not x for x in lbs):
+            lbs.append(t)
+    if not lbs:
+        return None
+    if len(lbs) > 1:
+        raise UnsupportedTopology("several LoadBalancers in one Simulation are not lowered")
+    return lbs[0]
+
+
+def lower_lb(sources: list, entities: list, lb: LoadBalancer) -> LbGraph:
+    """Stream numbering: Source i (list order) -> stream base i; backend j (add_backend order) -> len(sources) + j."""
+    sources = list(sources or [])
+    if not sources:
+        raise UnsupportedTopology("a load-balancer topology needs at least one Source")
+    for s in sources:
+        if not isinstance(s, Source):
+            raise UnsupportedTopology(f"source {type(s).__name__} is not a lowered Source")
+        ep = s._event_provider
+        if not isinstance(ep, ClientKeyEventProvider):
+            raise UnsupportedTopology(
+                f"source '{s.name}': requests for a key-based LoadBalancer must come from a ClientKeyEventProvider "
+                "(ConsistentHash falls back to RoundRobin for key-less requests, which is not lowered)")
+        if ep._target is not lb:
+            raise UnsupportedTopology(f"source '{s.name}' does not target the LoadBalancer '{lb.name}'")
+        if not (s.rate > 0):
+            raise UnsupportedTopology(f"source '{s.name}': rate must be > 0")
+    if not isinstance(lb.strategy, ConsistentHash):
+        raise UnsupportedTopology(f"strategy {type(lb.strategy).__name__} is not lowered")
+    backends = lb.all_backends
+    if not backends:
+        raise UnsupportedTopology("a LoadBalancer without backends rejects every request; nothing to lower")
+    downs = []
+    for b in backends:
+        if not isinstance(b, Server):
+            raise UnsupportedTopology(f"backend '{b.name}' is a {type(b).__name__}: only Server backends are lowered")
+        if not isinstance(b.service_time, (ExponentialLatency, ConstantLatency)):
+            raise UnsupportedTopology(f"backend '{b.name}': service distribution {type(b.service_time).__name__} is not lowered")
+        if b.concurrency > 16:
+            raise UnsupportedTopology(f"backend '{b.name}': concurrency {b.concurrency} > 16 is not lowered yet")
+        d = b.downstream
+        if d is not None and not isinstance(d, _SINKS):
+            raise UnsupportedTopology(f"backend '{b.name}' forwards to {type(d).__name__}: only Sink-like collectors")
+        downs.append(d)
+    known = {id(lb)} | {id(b) for b in backends} | {id(d) for d in downs if d is not None} | {id(s) for s in sources}
+    for e in entities or []:
+        if id(e) not in known:
+            raise UnsupportedTopology(f"entity '{getattr(e, 'name', e)}' is not part of the load-balancer topology")
+    if all(d is None for d in downs):
+        sinks, shared = [], False
+    elif all(d is downs[0] for d in downs):
+        sinks, shared = [downs[0]], True
+    elif all(d is not None for d in downs) and len({id(d) for d in downs}) == len(downs):
+        sinks, shared = list(downs), False
+    else:
+        raise UnsupportedTopology("backends must all share ONE Sink, each have their own, or all have none")
+    return LbGraph(sources=sources, lb=lb, backends=backends, sinks=sinks, shared_sink=shared)
+
+
+def write_back_lb(g: LbGraph, stats: dict, eng) -> None:
+    """Engine results -> the user's objects, under the reference's attribute names."""
+    for i, s in enumerate(g.sources):
+        s._generated_count = int(stats["generated"][i])
+    lb = g.lb
+    lb._requests_received, lb._requests_forwarded, lb._requests_failed, lb._no_backend_available, lb._in_flight_count = (
+        int(v) for v in stats["lb"])
+    for j, b in enumerate(g.backends):
+        b._queue.stats_accepted = int(stats["accepted"][j])
+        b._queue.stats_dropped = int(stats["dropped"][j])
+        b._queue.depth = int(stats["queue_depth"][j])
+        b._requests_completed = int(stats["completed"][j])
+        b._requests_rejected = int(stats["rejected"][j])
+        b._total_service_time = float(stats["total_service_s"][j])
+        b._active = int(stats["active"][j])
+        lb._backends[b.name].total_requests = int(stats["total_requests"][j])
+    if g.shared_sink:
+        g.sinks[0]._set_records(*eng.read_sink(0))
+    else:
+        for j, k in enumerate(g.sinks):
+            k._set_records(*eng.read_sink(j, cap=int(stats["sink_received"][j])))

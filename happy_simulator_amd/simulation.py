@@ -8,7 +8,8 @@ from . import _native as N
 from .core.temporal import Instant
 from .engine import StationEngine
 from .entities import Counter, Entity, LatencyTracker, Server, Sink
-from .lowering import LoweredGraph, UnsupportedTopology, lower, write_back
+from .lowering import (LbGraph, LoweredGraph, UnsupportedTopology, find_load_balancer, lower, lower_lb, write_back,
+                       write_back_lb)
 from .summary import EntitySummary, QueueStats, SimulationSummary
 
 _DEFAULT_SEED = 42
@@ -54,16 +55,38 @@ class Simulation:
     def summary(self) -> SimulationSummary | None:
         return self._summary
 
-    def lowered(self) -> LoweredGraph:
+    def lowered(self) -> "LoweredGraph | LbGraph":
         if self._graph is None:
-            self._graph = lower(self._sources, self._entities)
+            lb = find_load_balancer(self._sources, self._entities)
+            self._graph = lower_lb(self._sources, self._entities, lb) if lb is not None else lower(self._sources,
+                                                                                                    self._entities)
         return self._graph
+
+    def _run_lb(self, g: LbGraph, wall0: float) -> SimulationSummary:
+        """Sources -> LoadBalancer(ConsistentHash) -> Servers -> Sink(s): the pipeline engine (csrc/hs_lb.hip)."""
+        from .lb_engine import LoadBalancerEngine
+
+        end_ns = self._end_time.nanoseconds
+        src, be = g.engine_arrays()
+        with LoadBalancerEngine(src, be, virtual_nodes=g.lb.strategy.virtual_nodes, horizon_ns=end_ns,
+                                shared_sink=g.shared_sink, start_ns=self._start_time.nanoseconds, seed=self._seed,
+                                device=self._device) as eng:
+            eng.run(end_ns)
+            es = eng.summary()
+            write_back_lb(g, eng.stats(), eng)
+        self._engine_summary = es
+        self._events_processed = es.events_processed
+        self._current_time = Instant(es.final_time_ns)
+        self._summary = self._build_summary(_time.monotonic() - wall0)
+        return self._summary
 
     def run(self) -> SimulationSummary:
         if self._end_time == Instant.Infinity:
             raise UnsupportedTopology("auto-terminating runs (end_time = Infinity) are not lowered; pass end_time/duration")
         wall0 = _time.monotonic()
         g = self.lowered()
+        if isinstance(g, LbGraph):
+            return self._run_lb(g, wall0)
         end_ns = self._end_time.nanoseconds
         net = g.network_arrays() if g.is_network else None
         horizon_s = (end_ns - self._start_time.nanoseconds) / 1e9

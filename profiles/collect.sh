@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 10 --warmup 2 --cpu-sample-s 0"
+CMD="python $ROOT/bench.py --steps ${STEPS:-10} --warmup 2 --cpu-sample-s 0 ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o $TAG -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o $TAG -- $CMD > $OUT/write.log 2>&1

@@ -209,3 +209,42 @@ def test_linked_partitions_validation():
         hs.Simulation(duration=1.0, sources=[], entities=[
             hs.Server("x", downstream=hs.NetworkLink("l", latency=hs.ExponentialLatency(0.01), egress=hs.Server("y")))
         ]).run()
+
+
+@pytest.mark.parametrize("name", H.golden_names("lb"))
+def test_load_balancer_topology_through_the_api_matches_reference_golden(name):
+    """BASELINE configs[4] through the reference-shaped API: the wiring of examples/visual/chash_example.py:118-140
+    (Sources with a client-id request factory -> LoadBalancer(ConsistentHash) -> Servers -> Sink)."""
+    gold = H.Golden(name)
+    spec = gold.spec
+    p = H.lb_params(spec)
+    S, B = p["S"], p["B"]
+    sinks = [hs.Sink("sink")] if p["shared_sink"] else [hs.Sink(f"sink{j}") for j in range(B)]
+    nodes = [hs.Server(f"srv{j}", concurrency=p["conc"][j], service_time=hs.ExponentialLatency(p["mean"][j]),
+                       queue_capacity=None if p["qcap"][j] < 0 else p["qcap"][j],
+                       downstream=sinks[0] if p["shared_sink"] else sinks[j]) for j in range(B)]
+    lb = hs.LoadBalancer("lb", backends=nodes, strategy=hs.ConsistentHash(virtual_nodes=p["vnodes"]))
+    srcs = [hs.Source.poisson(rate=p["rate"][i], name=f"src{i}",
+                              event_provider=hs.ClientKeyEventProvider(lb, n_clients=p["n_clients"],
+                                                                       stop_after=spec.get("stop_after_s")))
+            for i in range(S)]
+    sim = hs.Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=srcs, entities=[lb, *nodes, *sinks],
+                        seed=spec["seed"])
+    summary = sim.run()
+    assert summary.total_events_processed == gold.meta["total_events"][0]
+    assert summary.duration_s == gold.meta["duration_s"][0]
+    assert [s.generated_count for s in srcs] == gold.generated.tolist()
+    st = lb.stats
+    assert [st.requests_received, st.requests_forwarded, st.requests_failed, st.no_backend_available] == gold.lb_stats[:4].tolist()
+    assert [lb.get_backend_info(n).total_requests for n in nodes] == gold.backend_total_requests.tolist()
+    assert [n.stats_accepted for n in nodes] == gold.accepted.tolist()
+    assert [n.stats_dropped for n in nodes] == gold.dropped.tolist()
+    assert [n.stats.requests_completed for n in nodes] == gold.completed.tolist()
+    assert [n.stats.total_service_time for n in nodes] == gold.total_service_s.tolist()
+    assert [n.depth for n in nodes] == gold.depth.tolist() and [n.active_requests for n in nodes] == gold.active.tolist()
+    assert [k.events_received for k in sinks] == gold.received.tolist()
+    assert sum((k.latencies_s for k in sinks), []) == gold.sink_latency_s.tolist()
+    assert [t.nanoseconds for k in sinks for t in k.completion_times] == gold.sink_t_ns.tolist()
+    es = summary.entities
+    assert es["srv0"].queue_stats.total_accepted == gold.accepted[0]
+    assert es[sinks[0].name].events_handled == sinks[0].events_received

@@ -123,3 +123,64 @@ def test_lb_engine_tie_storms_match_oracle(spec):
         # everything exact (counts, statistics, every record); only the ORDER of same-ns Sink records of different backends
         # whose services also started on the same ns is not asserted (constant-everything makes that common)
         H.compare_lb_engine_with_oracle(eng, p, r, check_sink_order=False)
+
+
+def test_lb_medium_scale_matches_oracle():
+    """2 048 sources x 2 048 backends, 10 s: ~123 k requests / 1.2 M events against the oracle, everything bit-exact
+    (the largest size the single-heap oracle finishes in a couple of seconds)."""
+    spec = dict(n_sources=2048, n_backends=2048, rate=6.0, mean=0.1, vnodes=150, n_clients=1 << 20, end_s=10.0, seed=77)
+    g, p = H.oracle_lb_graph(spec)
+    r = O.run(g, p["end_ns"], seed=spec["seed"])
+    eng, _ = H.lb_engine_for_spec(spec)
+    with eng:
+        eng.run(p["end_ns"])
+        H.compare_lb_engine_with_oracle(eng, p, r)
+
+
+def test_lb_full_size_properties():
+    """BASELINE configs[4] at full size (32 768 sources -> ConsistentHash(150) -> 32 768 servers -> one Sink, 60 s,
+    ~11.8 M requests): size-independent properties of the reference's semantics."""
+    from happy_simulator_amd import _native as N
+
+    S = B = 32768
+    spec = dict(n_sources=S, n_backends=B, rate=6.0, mean=0.1, vnodes=150, n_clients=1 << 20, end_s=60.0, seed=42)
+    eng, p = H.lb_engine_for_spec(spec)
+    with eng:
+        eng.run(p["end_ns"])
+        s, st = eng.summary(), eng.stats()
+        t, cr = eng.read_sink(0)
+        eng.run(p["end_ns"])                       # run-to-run determinism (atomics only feed commutative sums)
+        s2, st2 = eng.summary(), eng.stats()
+        t2, cr2 = eng.read_sink(0)
+    k = s.events_by_kind
+    ev = {n: int(k[i]) for i, n in enumerate(N.EV_NAMES)}
+    n_req = int(st["lb"][0])
+    assert s.events_processed == int(k.sum()) and n_req > 11_000_000
+    # every Request is forwarded, answered and enqueued at its tick's timestamp (load_balancer.py:347-433)
+    assert ev["lb"] == ev["lb_resp"] == ev["enqueue"] == n_req == int(st["total_requests"].sum()) == int(st["lb"][1])
+    assert list(st["lb"][2:]) == [0, 0, 0]
+    # the one event beyond end_time is a SourceEvent or a ProcessContinuation (core/simulation.py:472)
+    over_src = int(st["generated"].sum()) - n_req
+    over_cont = int(st["completed"].sum()) - s.sink_records
+    assert (over_src, over_cont) in ((1, 0), (0, 1)) and s.final_time_ns > p["end_ns"]
+    assert ev["source"] == int(st["generated"].sum()) and ev["continuation"] == int(st["completed"].sum())
+    # queue protocol identities (SURVEY.md Appendix A2)
+    assert ev["deliver"] == ev["work"] and ev["sink"] == s.sink_records == len(t)
+    assert ev["poll"] >= ev["deliver"] and ev["notify"] <= ev["enqueue"]
+    assert int(st["accepted"].sum()) == n_req and int(st["dropped"].sum()) == 0 and int(st["rejected"].sum()) == 0
+    # conservation per backend: accepted = completed + in service + waiting (the overshoot completion left `active`)
+    np.testing.assert_array_equal(st["accepted"], st["completed"] + st["active"] + st["queue_depth"])
+    np.testing.assert_array_equal(st["accepted"], st["total_requests"])
+    assert ((st["active"] == 0) | (st["active"] == 1)).all()
+    # the shared Sink saw every completion in time order, each after its creation
+    assert (np.diff(t) >= 0).all() and t[-1] <= p["end_ns"] and (cr <= t).all() and cr.min() >= 0
+    assert np.unique(cr).size > 0.99 * len(cr)
+    # consistent hashing spreads the load (150 vnodes: a few x the mean at most) and every backend is reachable
+    assert st["total_requests"].max() < 4 * st["total_requests"].mean() and (st["total_requests"] > 0).mean() > 0.99
+    # determinism
+    assert s2.events_processed == s.events_processed and s2.final_time_ns == s.final_time_ns
+    np.testing.assert_array_equal(s2.events_by_kind, k)
+    for name in st:
+        np.testing.assert_array_equal(st[name], st2[name], err_msg=name)
+    np.testing.assert_array_equal(t, t2)
+    np.testing.assert_array_equal(cr, cr2)

@@ -184,3 +184,78 @@ def test_two_rank_sharding_and_reduction_gloo():
         want_events += r.events_processed
         want_final = max(want_final, r.final_time_ns)
     assert tot == {"events": want_events, "max_final_ns": want_final, "replicas": 11}
+
+
+class TestLoadBalancerLowering:
+    """Host side of BASELINE configs[4]: constructors mirror components/load_balancer (load_balancer.py:83-214,
+    strategies.py:336-357) incl. their ValueErrors; the graph is lowered to `hs_lb_sources` / `hs_lb_backends` arrays."""
+
+    def _topology(self, n_src=3, n_be=4, shared=True, **server_kw):
+        sink = hs.Sink("sink")
+        sinks = [sink] * n_be if shared else [hs.Sink(f"sink{j}") for j in range(n_be)]
+        nodes = [hs.Server(f"srv{j}", service_time=hs.ExponentialLatency(0.1), downstream=sinks[j], **server_kw)
+                 for j in range(n_be)]
+        lb = hs.LoadBalancer("Router", backends=nodes, strategy=hs.ConsistentHash(virtual_nodes=150))
+        srcs = [hs.Source.poisson(rate=10 + i, name=f"src{i}",
+                                  event_provider=hs.ClientKeyEventProvider(lb, n_clients=200, stop_after=90.0))
+                for i in range(n_src)]
+        return srcs, lb, nodes, sinks
+
+    def test_constructor_validation(self):
+        with pytest.raises(ValueError, match="virtual_nodes must be >= 1"):
+            hs.ConsistentHash(virtual_nodes=0)
+        with pytest.raises(ValueError, match="on_no_backend must be"):
+            hs.LoadBalancer("lb", strategy=hs.ConsistentHash(), on_no_backend="drop")
+        lb = hs.LoadBalancer("lb", strategy=hs.ConsistentHash())
+        with pytest.raises(ValueError, match="weight must be >= 1"):
+            lb.add_backend(hs.Server("s"), weight=0)
+        with pytest.raises(ValueError, match="n_clients must be >= 1"):
+            hs.ClientKeyEventProvider(lb, n_clients=0)
+        with pytest.raises(NotImplementedError, match="RoundRobin"):
+            hs.LoadBalancer("lb")
+        lb.add_backend(hs.Server("s"))
+        lb.add_backend(hs.Server("t"), weight=3)
+        assert lb.backend_count == lb.healthy_count == 2 and [b.name for b in lb.all_backends] == ["s", "t"]
+        assert lb.get_backend_info_by_name("t").weight == 3 and lb.stats.requests_received == 0
+        assert [e.name for e in lb.downstream_entities()] == ["s", "t"]
+
+    def test_graph_is_lowered_to_engine_arrays(self):
+        srcs, lb, nodes, sinks = self._topology(concurrency=3, queue_capacity=5)
+        g = hs.Simulation(duration=100.0, sources=srcs, entities=[lb, *nodes, sinks[0]]).lowered()
+        src, be = g.engine_arrays()
+        assert g.shared_sink and src.n == 3 and be.n == 4 and be.names == ["srv0", "srv1", "srv2", "srv3"]
+        assert list(src.src_rate) == [10.0, 11.0, 12.0] and list(src.n_clients) == [200] * 3
+        assert list(src.src_stop_after_ns) == [90_000_000_000] * 3 and list(src.src_kind) == [N.SRC_POISSON] * 3
+        assert list(be.concurrency) == [3] * 4 and list(be.queue_cap) == [5] * 4
+        assert list(be.svc_kind) == [N.LAT_EXPONENTIAL] * 4 and list(be.egress) == [N.EGRESS_SINK] * 4
+        srcs, lb, nodes, sinks = self._topology(shared=False)
+        g = hs.Simulation(duration=1.0, sources=srcs, entities=[lb, *nodes, *sinks]).lowered()
+        assert not g.shared_sink and len(g.sinks) == 4
+
+    def test_unsupported_lb_graphs_are_refused_explicitly(self):
+        srcs, lb, nodes, sinks = self._topology()
+        plain = hs.Source.poisson(rate=5, target=lb)
+        with pytest.raises(hs.UnsupportedTopology, match="ClientKeyEventProvider"):
+            hs.Simulation(duration=1, sources=[plain], entities=[lb, *nodes, sinks[0]]).lowered()
+        nodes[1].downstream = hs.Sink("other")
+        with pytest.raises(hs.UnsupportedTopology, match="share ONE Sink"):
+            hs.Simulation(duration=1, sources=srcs, entities=[lb, *nodes]).lowered()
+        srcs, lb, nodes, sinks = self._topology()
+        with pytest.raises(hs.UnsupportedTopology, match="not part of the load-balancer topology"):
+            hs.Simulation(duration=1, sources=srcs, entities=[lb, *nodes, sinks[0], hs.Server("stray")]).lowered()
+        lb2 = hs.LoadBalancer("lb2", backends=[hs.Sink("k")], strategy=hs.ConsistentHash())
+        s2 = hs.Source.poisson(rate=1, event_provider=hs.ClientKeyEventProvider(lb2, n_clients=5))
+        with pytest.raises(hs.UnsupportedTopology, match="only Server backends"):
+            hs.Simulation(duration=1, sources=[s2], entities=[lb2]).lowered()
+
+    def test_product_md5_is_rfc1321(self):
+        """The ring's hash function as libhs_hip.so computes it (host code of the library; no GPU involved)."""
+        import hashlib
+
+        from happy_simulator_amd.lb_engine import md5
+
+        assert md5(b"").hex() == "d41d8cd98f00b204e9800998ecf8427e"
+        assert md5(b"message digest").hex() == "f96b697d7cb7938d525a2f31aaf161d0"
+        for n in (1, 9, 55, 56, 57, 63, 64, 65, 119, 120, 121, 250):
+            msg = bytes((7 * i + n) & 0xFF for i in range(n))
+            assert md5(msg) == hashlib.md5(msg).digest()
