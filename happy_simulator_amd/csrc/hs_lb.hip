@@ -55,6 +55,7 @@ struct LbTotals {
     long long last_time;          // latest processed event time <= end
     long long final_time;         // Simulation._current_time after the run (the overshoot event's time)
     int qoverflow, bad_client;
+    long long max_count;          // most Requests emitted by one source (rows of the arrival log in use)
 };
 
 struct LbCand { long long t, t_created; int idx, valid; double svc_s; };
@@ -90,6 +91,27 @@ __device__ __forceinline__ T wave_sum(T v) {
     return v;
 }
 
+__device__ __forceinline__ LbCand cand_shfl_xor(const LbCand &c, int o) {
+    LbCand d;
+    d.t = __shfl_xor(c.t, o, 64); d.t_created = __shfl_xor(c.t_created, o, 64);
+    d.idx = __shfl_xor(c.idx, o, 64); d.valid = __shfl_xor(c.valid, o, 64); d.svc_s = __shfl_xor(c.svc_s, o, 64);
+    return d;
+}
+// earliest candidate of the workgroup -> out[blockIdx.x]   (every thread of the block must call this)
+__device__ __forceinline__ void block_min_cand(LbCand c, LbCand *wc, LbCand *out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const LbCand d = cand_shfl_xor(c, o);
+        if (cand_before(d, c)) c = d;
+    }
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kLbBlock / 64; ++w) if (cand_before(wc[w], c)) c = wc[w];
+        out[blockIdx.x] = c;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 1. Sources.  Source.handle_event (load/source.py:142-180) with a client-id request factory
 //    (examples/visual/chash_example.py:69-88) and ConsistentHash.select as a table lookup.
@@ -98,11 +120,14 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
                                                           const int32_t *__restrict__ client_be, int64_t n_table,
                                                           uint64_t *__restrict__ keys, uint64_t *__restrict__ vals,
                                                           int64_t cap, int tb, LbTotals *tot) {
+    __shared__ LbCand wc[kLbBlock / 64];
     const int s = blockIdx.x * kLbBlock + threadIdx.x;
     const bool live = s < S;
     uint32_t n_tick = 0, n_req = 0;
     int bad = 0, over = 0;
     int64_t last = INT64_MIN;
+    LbCand c;
+    c.t = kInfNs; c.t_created = 0; c.idx = s; c.valid = 0; c.svc_s = 0.0;
     if (live) {
         const uint32_t kind = P.kind[s];
         const double rate = P.rate[s];
@@ -142,10 +167,10 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
         }
         P.count[s] = (int64_t)(n_req < (uint32_t)cap ? n_req : (uint32_t)cap);
         P.generated[s] = n_tick;
-        LbCand c;
-        c.t = A; c.t_created = root_crt; c.idx = s; c.valid = (A != kInfNs) ? 1 : 0; c.svc_s = 0.0;
-        P.cand[s] = c;
+        c.t = A; c.t_created = root_crt; c.valid = (A != kInfNs) ? 1 : 0;
     }
+    block_min_cand(c, wc, P.cand);
+    if (live && n_req) atomicMax(&tot->max_count, (long long)(n_req < (uint32_t)cap ? n_req : (uint32_t)cap));
     const uint32_t st = wave_sum<uint32_t>(n_tick), sr = wave_sum<uint32_t>(n_req);
     if ((threadIdx.x & 63) == 0) {
         if (st) atomicAdd(&tot->ev[HS_EV_SOURCE], (unsigned long long)st);
@@ -158,11 +183,23 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
 
 // validity of slot i = (tick k, source s) of the [cap][S] arrival logs
 struct TickValid {
-    const int64_t *count; int S;
+    const int64_t *count; int S; bool fits32;
     __device__ __forceinline__ bool operator()(int64_t i) const {
+        if (fits32) {                              // 32-bit division: a fraction of the 64-bit sequence
+            const uint32_t k = (uint32_t)i / (uint32_t)S;
+            return (int64_t)k < count[(uint32_t)i - k * (uint32_t)S];
+        }
         const int64_t k = i / S;
         return k < count[i - k * S];
     }
+};
+// the arrival log is [tick][source]: only the first max_count rows hold anything
+__global__ void hs_lb_rows(const LbTotals *tot, int S, int64_t *n_slots) { *n_slots = (int64_t)tot->max_count * S; }
+
+// value carried through the Sink merge: created_at and the slot in one word when they fit (no gather afterwards)
+struct PackCreatedSlot {
+    const int64_t *created; int slot_bits;
+    __device__ __forceinline__ uint64_t operator()(int64_t i) const { return ((uint64_t)created[i] << slot_bits) | (uint64_t)i; }
 };
 struct NoVal { __device__ __forceinline__ uint64_t operator()(int64_t) const { return 0ull; } };
 struct SlotVal { __device__ __forceinline__ uint64_t operator()(int64_t i) const { return (uint64_t)i; } };
@@ -170,14 +207,39 @@ struct SlotVal { __device__ __forceinline__ uint64_t operator()(int64_t i) const
 // ---------------------------------------------------------------------------------------------
 // 2b. Segment offsets: backend b's arrivals are sorted[off[b] .. off[b+1])
 // ---------------------------------------------------------------------------------------------
-__global__ void hs_lb_segments(const uint64_t *__restrict__ skey, const int64_t *n_ptr, int tb, int B,
-                               int64_t *__restrict__ off) {
+// The sort ran on key bits [g, ...) only (one or two 8-bit passes saved): elements whose keys agree above bit g are still
+// in input order.  Such runs are short and rare (two Requests for one backend within 2^g ns); the thread at the head of a
+// run puts it in full-key order, stably.  g <= tb, so a run never spans two backends.
+__global__ void hs_lb_segments(uint64_t *__restrict__ skey, uint64_t *__restrict__ sval, const int64_t *n_ptr, int tb,
+                               int g, int B, int64_t *__restrict__ off) {
     const int64_t n = *n_ptr;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
-    const int64_t b_prev = i == 0 ? -1 : (int64_t)(skey[i - 1] >> tb);
-    const int64_t b_here = i == n ? (int64_t)B : (int64_t)(skey[i] >> tb);
+    const uint64_t k_prev = i == 0 ? 0ull : skey[i - 1];
+    const uint64_t k_here = i == n ? 0ull : skey[i];
+    const int64_t b_prev = i == 0 ? -1 : (int64_t)(k_prev >> tb);
+    const int64_t b_here = i == n ? (int64_t)B : (int64_t)(k_here >> tb);
     for (int64_t b = b_prev + 1; b <= b_here; ++b) off[b] = i;
+    if (g == 0 || i == n) return;
+    const uint64_t hi = k_here >> g;
+    if (i > 0 && (k_prev >> g) == hi) return;              // not the head of its run
+    int64_t len = 1;
+    bool sorted = true;
+    uint64_t last = k_here;
+    while (i + len < n) {
+        const uint64_t k = skey[i + len];
+        if ((k >> g) != hi) break;
+        sorted = sorted && k >= last;
+        last = k;
+        ++len;
+    }
+    if (len == 1 || sorted) return;
+    for (int64_t a = 1; a < len; ++a) {                    // stable insertion sort by the full key
+        const uint64_t k = skey[i + a], v = sval[i + a];
+        int64_t j = a;
+        while (j > 0 && skey[i + j - 1] > k) { skey[i + j] = skey[i + j - 1]; sval[i + j] = sval[i + j - 1]; --j; }
+        skey[i + j] = k; sval[i + j] = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -361,6 +423,84 @@ struct LbBackend {
         for (int i = 0; i < C; ++i) t = D[i] < t ? D[i] : t;
         return t;
     }
+
+    // ---- one worker, unbounded FIFO: the backend in REQUEST order instead of event order ------------------------
+    // Request k of the arrival list starts at S_k = max(a_k, D_{k-1}) and departs at D_k = S_k + service_k; service
+    // draws are consumed in start order = arrival order.  Its reference events happen at a_k (Request@Server,
+    // QUEUE_NOTIFY iff the buffer is empty, QUEUE_POLL iff the worker is idle then), at S_k (QUEUE_DELIVER,
+    // Request@worker) and at D_k (ProcessContinuation, Request@Sink, the completion QUEUE_POLL), and count iff that
+    // time is <= T.  Same-nanosecond coincidences have ONE outcome each here, whatever the order of the roots, because
+    // an arrival's Request@Server is two generations below its SourceEvent while a completion's QUEUE_POLL is one
+    // below its ProcessContinuation (the POLL always runs first):
+    //   a_k == D_{k-1}, nobody waiting:  the completion's POLL finds the buffer empty, then the enqueue notifies an
+    //                                    idle worker -> NOTIFY, POLL, start at a_k;
+    //   a_k == S_{k-1} == D_{k-2}:       request k-1 left the buffer through the completion's POLL before the enqueue
+    //                                    -> NOTIFY, but the worker is busy again when it runs -> no POLL;
+    //   a_k == a_{k-1} == S_{k-1}:       both enqueues precede the first NOTIFY's POLL -> the buffer is not empty.
+    // A zero-nanosecond service (probability ~1e-8 per request) chains further events into the same timestamp: the
+    // lane bails out and is re-run from its initial state by the event-order loop.
+    __device__ __forceinline__ bool run_request_order(int64_t T) {
+        const int64_t n = aend - ai;
+        const uint64_t *kp = akey + ai;
+        int64_t Sprev = INT64_MIN, Dprev = INT64_MIN, aprev = INT64_MIN, lt = INT64_MIN;
+        uint32_t n_notify = 0, n_poll = 0, n_start = 0, n_dep = 0;
+        bool pend = false;
+        int64_t pendD = kInfNs, pendS = 0;
+        double pend_s = 0.0, tsvc = 0.0;
+        constexpr int kAhead = 8;
+        uint64_t cur[kAhead], nxt[kAhead];
+#pragma unroll
+        for (int j = 0; j < kAhead; ++j) cur[j] = j < n ? kp[j] : 0ull;
+        bool blocked = false;
+        for (int64_t base = 0; base < n && !blocked; base += kAhead) {
+#pragma unroll
+            for (int j = 0; j < kAhead; ++j) nxt[j] = (base + kAhead + j) < n ? kp[base + kAhead + j] : 0ull;   // in flight while cur is processed
+#pragma unroll
+            for (int j = 0; j < kAhead; ++j) {
+                if (base + j >= n || blocked) continue;
+                const int64_t a = (int64_t)(cur[j] & tmask);
+                const bool notify = Sprev < a || (Sprev == a && aprev < a);
+                const bool idle = notify && Dprev <= a;
+                const int64_t S = Dprev > a ? Dprev : a;
+                n_notify += notify ? 1u : 0u;
+                lt = a > lt ? a : lt;
+                if (S > T) { blocked = true; continue; }              // this request and every later one never start
+                double sv; int64_t dur;
+                sample_service(sv, dur);
+                if (dur == 0) return false;
+                const int64_t Dk = S + dur;
+                n_poll += idle ? 1u : 0u;
+                ++n_start;
+                lt = S > lt ? S : lt;
+                if (Dk <= T) {
+                    lt = Dk > lt ? Dk : lt;
+                    tsvc = __dadd_rn(tsvc, sv);
+                    if (egress == HS_EGRESS_SINK) { sink_t[n_dep] = Dk; sink_created[n_dep] = a; sink_S[n_dep] = S; }
+                    ++n_dep;
+                    pend = false;
+                } else { pend = true; pendD = Dk; pendS = S; pend_s = sv; }
+                Sprev = S; Dprev = Dk; aprev = a;
+            }
+#pragma unroll
+            for (int j = 0; j < kAhead; ++j) cur[j] = nxt[j];
+        }
+        if (n > 0) {                                                  // arrivals behind a blocked head were not iterated
+            const int64_t a_last = (int64_t)(kp[n - 1] & tmask);
+            lt = a_last > lt ? a_last : lt;
+        }
+        // fold into the LP state exactly as the event-order loop would have left it
+        ev[HS_EV_ENQUEUE] = (uint32_t)n; ev[HS_EV_NOTIFY] = n_notify; ev[HS_EV_POLL] = n_poll + n_dep;
+        ev[HS_EV_DELIVER] = n_start; ev[HS_EV_WORK] = n_start; ev[HS_EV_CONTINUATION] = n_dep;
+        ev[HS_EV_SINK] = egress == HS_EGRESS_SINK ? n_dep : 0u;
+        accepted = n; started = n_start; completed = n_dep; received = egress == HS_EGRESS_SINK ? n_dep : 0;
+        buf = n - (int64_t)n_start;
+        active = pend ? 1 : 0;
+        D[0] = pend ? pendD : kInfNs; crtD[0] = pendS; svc_s[0] = pend_s; seqD[0] = 0;
+        total_service = tsvc;
+        last_time = n > 0 ? lt : INT64_MIN;
+        ai = aend; At = kInfNs;
+        return true;
+    }
     __device__ __forceinline__ void run_group(int64_t t, bool force_general) {
         int n_at = 0;
 #pragma unroll
@@ -394,9 +534,12 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_backends(LbBe P, int B, int S
                                                            int64_t *__restrict__ sink_created, int64_t *__restrict__ sink_S,
                                                            LbTotals *tot, int flags) {
     __shared__ uint8_t qmem[kLbQCap][kLbBlock];
+    __shared__ LbCand wc[kLbBlock / 64];
     const int tid = threadIdx.x;
     const int b = blockIdx.x * kLbBlock + tid;
     const bool live = b < B;
+    LbCand c;
+    c.t = kInfNs; c.t_created = 0; c.idx = S + b; c.valid = 0; c.svc_s = 0.0;
     LbBackend<C> X;
 #pragma unroll
     for (int k = 0; k < 8; ++k) X.ev[k] = 0;
@@ -417,26 +560,37 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_backends(LbBe P, int B, int S
         const int64_t o = off[b];
         X.adm = adm + o; X.sink_t = sink_t + o; X.sink_created = sink_created + o; X.sink_S = sink_S + o;
         X.qmem = qmem; X.tid = tid; X.qh = 0; X.qn = 0;
-        X.load_arrival();
         const bool force_general = (flags & 1) != 0;
-        for (;;) {
-            const int64_t t = X.next_time();
-            if (t > end_ns) break;                                       // also kInfNs: nothing pending
-            X.run_group(t, force_general);
+        bool event_order = true;
+        if constexpr (C == 1) {
+            if (!force_general && (flags & 2) == 0 && X.qcap < 0 && X.conc == 1) {
+                event_order = !X.run_request_order(end_ns);
+                if (event_order) {                                       // zero-length service: start over in event order
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) X.ev[k] = 0;
+                    X.svc.init(seed, stream_id(P.base[b], kStreamService), 0);
+                }
+            }
+        }
+        if (event_order) {
+            X.load_arrival();
+            for (;;) {
+                const int64_t t = X.next_time();
+                if (t > end_ns) break;                                   // also kInfNs: nothing pending
+                X.run_group(t, force_general);
+            }
         }
         P.accepted[b] = X.accepted; P.dropped[b] = X.dropped; P.completed[b] = X.completed; P.rejected[b] = X.rejected;
         P.received[b] = X.received; P.depth[b] = X.buf; P.active[b] = X.active; P.total_service[b] = X.total_service;
         // the earliest pending departure is this backend's candidate for the one event beyond end_ns
-        LbCand c;
-        c.t = kInfNs; c.t_created = 0; c.idx = S + b; c.valid = 0; c.svc_s = 0.0;
         uint32_t bs = 0;
 #pragma unroll
         for (int i = 0; i < C; ++i)
             if (X.D[i] != kInfNs && (!c.valid || X.D[i] < c.t || (X.D[i] == c.t && (int32_t)(X.seqD[i] - bs) < 0))) {
                 c.t = X.D[i]; c.t_created = X.crtD[i]; c.svc_s = X.svc_s[i]; c.valid = 1; bs = X.seqD[i];
             }
-        P.cand[b] = c;
     }
+    block_min_cand(c, wc, P.cand);
 #pragma unroll
     for (int k = 1; k < 8; ++k) {
         const uint32_t s = wave_sum<uint32_t>(live ? X.ev[k] : 0u);
@@ -465,34 +619,45 @@ struct SinkValid {
 // Completions with equal timestamps: the Sink processes them in the creation order of their ProcessContinuations,
 // i.e. by service start (then backend; a backend's own completions are already in its order).  The radix sort is
 // stable in slot order = (backend, completion order), so only runs of equal keys need a look.
-__global__ void hs_lb_sink_finish(const uint64_t *__restrict__ mkey, const uint64_t *__restrict__ mslot, const int64_t *n_ptr,
+// slot_bits > 0: the merged value is (created_at << slot_bits) | slot; slot_bits == 0: the value is the slot and created_at
+// is gathered from the completion log.  The merge sorted on key bits [g, tb) only: a run of completions within the same
+// 2^g ns is still in slot order and is ordered here by (completion ns, service start, slot).
+__global__ void hs_lb_sink_finish(const uint64_t *__restrict__ mkey, const uint64_t *__restrict__ mval, const int64_t *n_ptr,
                                   const int64_t *__restrict__ sink_created, const int64_t *__restrict__ sink_S,
-                                  int64_t *__restrict__ out_t, int64_t *__restrict__ out_created) {
+                                  int64_t *__restrict__ out_t, int64_t *__restrict__ out_created, int slot_bits, int g) {
     const int64_t n = *n_ptr;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const uint64_t smask = slot_bits ? ((1ull << slot_bits) - 1) : ~0ull;
     const uint64_t k = mkey[i];
-    const bool same_prev = i > 0 && mkey[i - 1] == k;
-    const bool same_next = i + 1 < n && mkey[i + 1] == k;
+    const uint64_t hi = k >> g;
+    const bool same_prev = i > 0 && (mkey[i - 1] >> g) == hi;
+    const bool same_next = i + 1 < n && (mkey[i + 1] >> g) == hi;
     if (!same_prev && !same_next) {
+        const uint64_t v = mval[i];
         out_t[i] = (int64_t)k;
-        out_created[i] = sink_created[mslot[i]];
+        out_created[i] = slot_bits ? (int64_t)(v >> slot_bits) : sink_created[v];
         return;
     }
     if (same_prev) return;                       // the head of the run writes the whole run
     int64_t len = 1;
-    while (i + len < n && mkey[i + len] == k) ++len;
-    for (int64_t a = 0; a < len; ++a) {          // selection by (service start, slot): rank of element a within the run
-        const uint64_t sa = mslot[i + a];
-        const int64_t Sa = sink_S[sa];
+    while (i + len < n && (mkey[i + len] >> g) == hi) ++len;
+    for (int64_t a = 0; a < len; ++a) {          // rank of element a within the run by (t, service start, slot)
+        const uint64_t ka = mkey[i + a], va = mval[i + a], sa = va & smask;
+        int64_t Sa = 0;
+        bool haveS = false;
         int64_t r = 0;
         for (int64_t c = 0; c < len; ++c) {
-            const uint64_t sc = mslot[i + c];
+            if (c == a) continue;
+            const uint64_t kc = mkey[i + c];
+            if (kc != ka) { r += kc < ka ? 1 : 0; continue; }
+            if (!haveS) { Sa = sink_S[sa]; haveS = true; }
+            const uint64_t sc = mval[i + c] & smask;
             const int64_t Sc = sink_S[sc];
             if (Sc < Sa || (Sc == Sa && sc < sa)) ++r;
         }
-        out_t[i + r] = (int64_t)k;
-        out_created[i + r] = sink_created[sa];
+        out_t[i + r] = (int64_t)ka;
+        out_created[i + r] = slot_bits ? (int64_t)(va >> slot_bits) : sink_created[sa];
     }
 }
 
@@ -504,15 +669,14 @@ __global__ void __launch_bounds__(kLbBlock) hs_lb_finalize(LbSrc PS, LbBe PB, in
     const int tid = threadIdx.x;
     LbCand best;
     best.valid = 0; best.t = kInfNs; best.t_created = 0; best.idx = 0; best.svc_s = 0.0;
-    for (int i = tid; i < S + B; i += kLbBlock) {
-        const LbCand c = i < S ? PS.cand[i] : PB.cand[i - S];
+    const int nbs = (S + kLbBlock - 1) / kLbBlock, nbb = (B + kLbBlock - 1) / kLbBlock;   // one candidate per workgroup
+    for (int i = tid; i < nbs + nbb; i += kLbBlock) {
+        const LbCand c = i < nbs ? PS.cand[i] : PB.cand[i - nbs];
         if (cand_before(c, best)) best = c;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        LbCand d;
-        d.t = __shfl_xor(best.t, o, 64); d.t_created = __shfl_xor(best.t_created, o, 64);
-        d.idx = __shfl_xor(best.idx, o, 64); d.valid = __shfl_xor(best.valid, o, 64); d.svc_s = __shfl_xor(best.svc_s, o, 64);
+        const LbCand d = cand_shfl_xor(best, o);
         if (cand_before(d, best)) best = d;
     }
     if ((tid & 63) == 0) wc[tid >> 6] = best;
@@ -540,7 +704,7 @@ __global__ void __launch_bounds__(kLbBlock) hs_lb_finalize(LbSrc PS, LbBe PB, in
 __global__ void hs_lb_clear(LbTotals *tot) {
     for (int k = 0; k < HS_EV_KINDS; ++k) tot->ev[k] = 0;
     tot->completed = 0; tot->received = 0; tot->last_time = INT64_MIN; tot->final_time = 0;
-    tot->qoverflow = 0; tot->bad_client = 0;
+    tot->qoverflow = 0; tot->bad_client = 0; tot->max_count = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -611,7 +775,8 @@ thread_local std::string g_lb_error;
 
 struct hs_lb {
     hs_lb_config cfg{};
-    int C = 1, tb = 1, bb = 1;
+    int C = 1, tb = 1, bb = 1, slot_bits = 0;
+    int g_arr = 0, g_sink = 0;     // low key bits the two sorts skip (fixed up afterwards inside short runs)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evs0 = nullptr, evs1 = nullptr, evs2 = nullptr, evs3 = nullptr;
     std::vector<void *> allocs;
@@ -698,8 +863,8 @@ int32_t ring_select(const std::vector<RingPoint> &ring, const char *key, size_t 
 template <typename Valid, typename MakeVal>
 void radix_sort_async(hs_lb *h, const uint64_t *k_in, const uint64_t *v_in, const int64_t *n_in_dev, int64_t *n_out_dev,
                       int bits, Valid valid, MakeVal mk, uint64_t **k_res, uint64_t **v_res,
-                      const uint64_t *keep_through_pass0 = nullptr) {
-    const int passes = (bits + kRadixBits - 1) / kRadixBits;
+                      const uint64_t *keep_through_pass0 = nullptr, int shift0 = 0) {
+    const int passes = (bits - shift0 + kRadixBits - 1) / kRadixBits;
     const dim3 grid((unsigned)h->n_tiles), blk(kRadixThreads);
     // `valid` may read a buffer that is itself one of the ping-pong buffers (the previous sort's result): pass 0, the
     // only pass that evaluates `valid`, must then write the OTHER buffer
@@ -707,7 +872,7 @@ void radix_sort_async(hs_lb *h, const uint64_t *k_in, const uint64_t *v_in, cons
     uint64_t *ko = startB ? h->kB : h->kA, *vo = startB ? h->vB : h->vA;
     const uint64_t *ki = k_in, *vi = v_in;
     for (int p = 0; p < passes; ++p) {
-        const int shift = p * kRadixBits;
+        const int shift = shift0 + p * kRadixBits;
         const int64_t *n_dev = p == 0 ? n_in_dev : n_out_dev;
         if (p == 0) {
             hipLaunchKernelGGL((radix_hist<Valid>), grid, blk, 0, h->stream, ki, n_dev, shift, h->hist, h->n_tiles, valid);
@@ -746,12 +911,13 @@ int run_async(hs_lb *h, int64_t end_ns) {
     hipLaunchKernelGGL(hs_lb_clear, dim3(1), dim3(1), 0, h->stream, h->tot);
     hipLaunchKernelGGL(hs_lbk_sources, dim3((S + kLbBlock - 1) / kLbBlock), dim3(kLbBlock), 0, h->stream, h->PS, S, h->cfg.seed,
                        h->cfg.start_ns, end_ns, h->client_be, h->n_table, h->keys0, h->vals0, h->cap, h->tb, h->tot);
+    hipLaunchKernelGGL(hs_lb_rows, dim3(1), dim3(1), 0, h->stream, h->tot, S, h->n_slots_dev);
     hipEventRecord(h->evs0, h->stream);
-    radix_sort_async(h, h->keys0, h->vals0, h->n_slots_dev, h->n_arr, h->tb + h->bb, TickValid{h->PS.count, S}, NoVal{},
-                     &h->skey, &h->sval);
+    radix_sort_async(h, h->keys0, h->vals0, h->n_slots_dev, h->n_arr, h->tb + h->bb,
+                     TickValid{h->PS.count, S, h->n_slots < (1ll << 31)}, NoVal{}, &h->skey, &h->sval, nullptr, h->g_arr);
     hipEventRecord(h->evs1, h->stream);
     hipLaunchKernelGGL(hs_lb_segments, dim3((unsigned)((h->n_slots + 1 + 255) / 256)), dim3(256), 0, h->stream, h->skey,
-                       h->n_arr, h->tb, B, h->off);
+                       h->sval, h->n_arr, h->tb, h->g_arr, B, h->off);
     switch (h->C) {
         case 1: launch_backends<1>(h, end_ns); break;
         case 2: launch_backends<2>(h, end_ns); break;
@@ -763,10 +929,15 @@ int run_async(hs_lb *h, int64_t end_ns) {
     if (h->cfg.shared_sink) {
         // completions by completion ns; the validity functor reads the sorted arrival keys (which slot belongs to which
         // backend), so pass 0 must not overwrite them
-        radix_sort_async(h, (const uint64_t *)h->sink_t, (const uint64_t *)nullptr, h->n_arr, h->n_done, h->tb,
-                         SinkValid{h->skey, h->off, h->PB.received, h->tb}, SlotVal{}, &h->mkey, &h->mslot, h->skey);
+        if (h->slot_bits)
+            radix_sort_async(h, (const uint64_t *)h->sink_t, (const uint64_t *)nullptr, h->n_arr, h->n_done, h->tb,
+                             SinkValid{h->skey, h->off, h->PB.received, h->tb}, PackCreatedSlot{h->sink_created, h->slot_bits},
+                             &h->mkey, &h->mslot, h->skey, h->g_sink);
+        else
+            radix_sort_async(h, (const uint64_t *)h->sink_t, (const uint64_t *)nullptr, h->n_arr, h->n_done, h->tb,
+                             SinkValid{h->skey, h->off, h->PB.received, h->tb}, SlotVal{}, &h->mkey, &h->mslot, h->skey, h->g_sink);
         hipLaunchKernelGGL(hs_lb_sink_finish, dim3((unsigned)((h->n_slots + 255) / 256)), dim3(256), 0, h->stream, h->mkey,
-                           h->mslot, h->n_done, h->sink_created, h->sink_S, h->out_t, h->out_created);
+                           h->mslot, h->n_done, h->sink_created, h->sink_S, h->out_t, h->out_created, h->slot_bits, h->g_sink);
     }
     hipEventRecord(h->evs3, h->stream);
     hipLaunchKernelGGL(hs_lb_finalize, dim3(1), dim3(kLbBlock), 0, h->stream, h->PS, h->PB, S, B, h->cfg.start_ns, h->tot);
@@ -854,6 +1025,18 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     h->n_slots = cap * (int64_t)S;
     if ((double)h->n_slots * 88.0 > 200e9) { delete h; return lfail(nullptr, HS_E_INVALID, "buffers would need %.1f GB", (double)h->n_slots * 88.0 / 1e9); }
     h->n_tiles = (int)((h->n_slots + kRadixTile - 1) / kRadixTile);
+    {   // sort on whole 8-bit digits only: the ragged low bits are left to the run fix-ups; the arrival sort may drop one
+        // more digit while its buckets stay within ~4 us (two Requests for one backend that close are rare)
+        const int r = (h->tb + h->bb) % kRadixBits;
+        h->g_arr = (r + kRadixBits <= 12 && r + kRadixBits <= h->tb) ? r + kRadixBits : (r <= h->tb ? r : 0);
+        h->g_sink = h->tb % kRadixBits;
+        if (h->tb <= kRadixBits) { h->g_sink = 0; }
+        if (h->tb + h->bb - h->g_arr < kRadixBits) h->g_arr = 0;
+    }
+    {
+        const int sb = bit_length((uint64_t)(h->n_slots > 1 ? h->n_slots - 1 : 1));
+        h->slot_bits = (h->tb + sb <= 64) ? sb : 0;                     // created_at (tb bits) and the slot share one word
+    }
     // ---- the ring: ConsistentHash.add_backend for every backend in order (strategies.py:381-391)
     const int V = cfg->virtual_nodes;
     h->ring.resize((size_t)B * V);

@@ -11,7 +11,8 @@
 // run is enqueued without a single host synchronisation.  Per pass (HBM-bound; 40 B per element):
 //   radix_hist     8 B read   per-tile digit histogram -> hist[digit][tile]
 //   radix_scan_*   --         exclusive scan of hist in (digit, tile) order
-//   radix_scatter  16 B read + 16 B write; ranks are computed with wavefront ballots (64 lanes), no sorting in LDS
+//   radix_scatter  16 B read + 16 B write; ranks from wavefront ballots (64 lanes), tile reordered through LDS so the
+//                  stores are contiguous runs
 // A tile is 256 threads x kItems rows of 64 consecutive elements per wavefront, so ranks are stable by construction:
 // element order = (wave, row, lane).  Elements can be masked out of the FIRST pass (ragged inputs) by a validity
 // functor; from then on the data is dense.
@@ -125,7 +126,9 @@ __global__ void __launch_bounds__(kRadixThreads) radix_scan_digits(const uint32_
 }
 
 // Stable scatter of one pass.  MakeVal builds the value of input slot i when the pass starts from keys only
-// (vals_in == nullptr): e.g. the slot index itself.
+// (vals_in == nullptr): e.g. the slot index itself.  The tile is first put in digit order in LDS (32 KB, keys then values), then written
+// out by consecutive threads, so that a wavefront store covers a handful of contiguous runs (one per digit value
+// present) instead of 64 unrelated cache lines.
 template <typename Valid, typename MakeVal>
 __global__ void __launch_bounds__(kRadixThreads) radix_scatter(const uint64_t *__restrict__ keys_in,
                                                                const uint64_t *__restrict__ vals_in,
@@ -134,8 +137,11 @@ __global__ void __launch_bounds__(kRadixThreads) radix_scatter(const uint64_t *_
                                                                int shift, const uint32_t *__restrict__ hist,
                                                                const uint32_t *__restrict__ digit_base, int n_tiles,
                                                                Valid valid, MakeVal make_val) {
-    __shared__ uint32_t cnt[kRadixWaves][kRadixBins];
-    __shared__ uint32_t off[kRadixWaves][kRadixBins];
+    __shared__ uint64_t sbuf[kRadixTile];                 // the tile in digit order: keys first, then values (32 KB)
+    __shared__ uint32_t cnt[kRadixWaves][kRadixBins];     // per wave: elements with the digit; then: local start of its sub-run
+    __shared__ uint32_t dstart[kRadixBins];               // start of the digit's run inside the sorted tile
+    __shared__ uint32_t gbase[kRadixBins];                // global position of the digit's run of this tile
+    __shared__ uint32_t wsum[kRadixWaves];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t n = *n_ptr;
     const int64_t base = (int64_t)blockIdx.x * kRadixTile;
@@ -163,19 +169,62 @@ __global__ void __launch_bounds__(kRadixThreads) radix_scatter(const uint64_t *_
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    {   // thread `tid` owns digit `tid`: global base of the tile's run + the waves' sub-runs
-        uint32_t run = hist[(size_t)tid * n_tiles + blockIdx.x] + digit_base[tid];
+    uint32_t total;
+    {   // thread `tid` owns digit `tid`: the tile's count, its start in the sorted tile (block-wide exclusive scan), the
+        // waves' sub-runs, and the run's global position
+        uint32_t c[kRadixWaves];
+        total = 0;
 #pragma unroll
-        for (int k = 0; k < kRadixWaves; ++k) { off[k][tid] = run; run += cnt[k][tid]; }
+        for (int k = 0; k < kRadixWaves; ++k) { c[k] = cnt[k][tid]; total += c[k]; }
+        uint32_t sc = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(sc, o, 64);
+            if (lane >= o) sc += t;
+        }
+        if (lane == 63) wsum[w] = sc;
+        __syncthreads();
+        uint32_t wb = 0;
+        for (int k = 0; k < w; ++k) wb += wsum[k];
+        const uint32_t start = wb + sc - total;
+        dstart[tid] = start;
+        gbase[tid] = hist[(size_t)tid * n_tiles + blockIdx.x] + digit_base[tid];
+        uint32_t run = start;
+#pragma unroll
+        for (int k = 0; k < kRadixWaves; ++k) { cnt[k][tid] = run; run += c[k]; }
+    }
+    __syncthreads();
+    uint32_t n_tile = 0;
+#pragma unroll
+    for (int k = 0; k < kRadixWaves; ++k) n_tile += wsum[k];       // valid elements of the tile
+    uint32_t lpos[kRadixItems];
+#pragma unroll
+    for (int r = 0; r < kRadixItems; ++r) {
+        lpos[r] = rank[r] == 0xffffffffu ? 0xffffffffu : cnt[w][rank[r] >> 24] + (rank[r] & 0xffffffu);
+        if (lpos[r] != 0xffffffffu) sbuf[lpos[r]] = key[r];
+    }
+    __syncthreads();
+    size_t g[kRadixItems];                                         // global position of sorted element tid + r * 256
+#pragma unroll
+    for (int r = 0; r < kRadixItems; ++r) {
+        const uint32_t p = (uint32_t)tid + (uint32_t)r * kRadixThreads;
+        g[r] = 0;
+        if (p < n_tile) {
+            const uint64_t k = sbuf[p];
+            const uint32_t d = (uint32_t)(k >> shift) & (kRadixBins - 1);
+            g[r] = (size_t)gbase[d] + (p - dstart[d]);
+            keys_out[g[r]] = k;
+        }
     }
     __syncthreads();
 #pragma unroll
+    for (int r = 0; r < kRadixItems; ++r)
+        if (lpos[r] != 0xffffffffu) sbuf[lpos[r]] = val[r];
+    __syncthreads();
+#pragma unroll
     for (int r = 0; r < kRadixItems; ++r) {
-        if (rank[r] == 0xffffffffu) continue;
-        const uint32_t d = rank[r] >> 24;
-        const size_t p = (size_t)off[w][d] + (rank[r] & 0xffffffu);
-        keys_out[p] = key[r];
-        vals_out[p] = val[r];
+        const uint32_t p = (uint32_t)tid + (uint32_t)r * kRadixThreads;
+        if (p < n_tile) vals_out[g[r]] = sbuf[p];
     }
 }
 

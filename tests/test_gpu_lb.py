@@ -84,7 +84,7 @@ SWEEP = [
 
 
 @pytest.mark.parametrize("spec", SWEEP, ids=[s["name"] for s in SWEEP])
-@pytest.mark.parametrize("flags", [0, 1], ids=["fast", "general"])
+@pytest.mark.parametrize("flags", [0, 1, 2], ids=["request_order", "general_fifo", "event_order"])
 def test_lb_engine_matches_oracle(spec, flags):
     g, p = H.oracle_lb_graph(spec)
     r = O.run(g, p["end_ns"], seed=spec["seed"])
