@@ -133,41 +133,67 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
         const double rate = P.rate[s];
         const int64_t stop = P.stop[s];
         const double nclients = (double)P.n_clients[s];
-        Stream arr, key;
-        arr.init(seed, stream_id(P.base[s], kStreamArrival), 0);
-        key.init(seed, stream_id(P.base[s], kStreamKey), 0);
-        int64_t arr_time = start_ns;
-        // ArrivalTimeProvider.next_arrival_time, constant-rate fast path (load/arrival_time_provider.py:72-82)
-        auto next_arrival = [&]() {
-            const double area = (kind == HS_SRC_POISSON) ? exp1_from_uniform(arr.next_uniform()) : 1.0;
-            arr_time = ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), __ddiv_rn(area, rate)));
-            return arr_time;
-        };
-        int64_t A = next_arrival();          // Source.start at Simulation.__init__ (load/source.py:120-140)
+        const uint64_t sa = stream_id(P.base[s], kStreamArrival), sk = stream_id(P.base[s], kStreamKey);
+        const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+        const double inc_const = __ddiv_rn(1.0, rate);       // constant source: target area 1.0 (providers/constant_arrival.py:23)
+        // Tick d happens at A_d = from_seconds(to_seconds(A_{d-1}) + E_d / rate)  (load/arrival_time_provider.py:72-82;
+        // A_{-1} = start: Source.start at Simulation.__init__, load/source.py:120-140) and, while the provider still
+        // returns Requests, draws client id number d.  Both streams are therefore indexed by the tick number: the
+        // expensive part (Philox, hs_log, the division, the client -> backend lookup) is produced eight ticks at a time
+        // in straight-line code -- independent chains the SIMD can overlap -- and only the ns recursion is serial.
+        constexpr int kChunk = 8;
+        int64_t arr_time = start_ns, t_prev = start_ns;
         int64_t root_crt = start_ns;         // creation time of the SourceEvent that heads the current same-ns chain
         uint32_t depth = 0;
-        while (A <= end_ns) {
-            const int64_t t = A;
-            ++n_tick;
-            last = t;
-            if (!(stop >= 0 && t > stop)) {  // the provider returns one Request
-                const int64_t cid = __double2ll_rz(__dmul_rn(key.next_uniform(), nclients));
-                int32_t be = 0;
-                if (cid >= 0 && cid < n_table) be = client_be[cid]; else bad = 1;
-                if ((int64_t)n_req < cap) {
-                    keys[(size_t)n_req * S + s] = ((uint64_t)be << tb) | (uint64_t)t;
-                    vals[(size_t)n_req * S + s] = ((uint64_t)(depth > 30 ? 30 : depth) << 56) | ((uint64_t)root_crt & kCrtMask);
-                } else over = 1;
-                ++n_req;
+        int64_t A = kInfNs;
+        bool done = false, dead = false;
+        for (uint64_t d0 = 0; !done; d0 += kChunk) {
+            double inc[kChunk];
+            int32_t be[kChunk];
+#pragma unroll
+            for (int j = 0; j < kChunk; j += 2) {
+                const uint64_t blk = (d0 + j) >> 1;
+                if (kind == HS_SRC_POISSON) {
+                    const U4 o = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)sa, (uint32_t)(sa >> 32), k0, k1);
+                    inc[j] = __ddiv_rn(exp1_from_uniform(res53(o.x, o.y)), rate);
+                    inc[j + 1] = __ddiv_rn(exp1_from_uniform(res53(o.z, o.w)), rate);
+                } else { inc[j] = inc_const; inc[j + 1] = inc_const; }
+                const U4 q = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)sk, (uint32_t)(sk >> 32), k0, k1);
+                const int64_t c0 = __double2ll_rz(__dmul_rn(res53(q.x, q.y), nclients));
+                const int64_t c1 = __double2ll_rz(__dmul_rn(res53(q.z, q.w), nclients));
+                const bool ok0 = c0 >= 0 && c0 < n_table, ok1 = c1 >= 0 && c1 < n_table;
+                be[j] = ok0 ? client_be[c0] : -1;
+                be[j + 1] = ok1 ? client_be[c1] : -1;
             }
-            const int64_t a2 = next_arrival();
-            if (a2 == t) { ++depth; A = a2; }                    // next tick on the same nanosecond: a descendant
-            else if (a2 < t) A = kInfNs;                          // popped later as "time travel" and dropped (simulation.py:480-489)
-            else { A = a2; root_crt = t; depth = 0; }
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j) {
+                if (done) continue;
+                const uint64_t d = d0 + j;
+                const int64_t a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc[j]));
+                arr_time = a2;
+                if (d > 0) {
+                    if (a2 == t_prev) ++depth;                            // next tick on the same nanosecond: a descendant
+                    else if (a2 < t_prev) { done = true; dead = true; continue; }   // popped later as "time travel" and dropped (simulation.py:480-489)
+                    else { root_crt = t_prev; depth = 0; }
+                }
+                if (a2 > end_ns) { A = a2; done = true; continue; }       // the pending SourceEvent beyond end
+                const int64_t t = a2;
+                t_prev = t;
+                ++n_tick;
+                last = t;
+                if (!(stop >= 0 && t > stop)) {                           // the provider returns one Request
+                    if (be[j] < 0) bad = 1;
+                    if ((int64_t)n_req < cap) {
+                        keys[(size_t)n_req * S + s] = ((uint64_t)(be[j] < 0 ? 0 : be[j]) << tb) | (uint64_t)t;
+                        vals[(size_t)n_req * S + s] = ((uint64_t)(depth > 30 ? 30 : depth) << 56) | ((uint64_t)root_crt & kCrtMask);
+                    } else over = 1;
+                    ++n_req;
+                }
+            }
         }
         P.count[s] = (int64_t)(n_req < (uint32_t)cap ? n_req : (uint32_t)cap);
         P.generated[s] = n_tick;
-        c.t = A; c.t_created = root_crt; c.valid = (A != kInfNs) ? 1 : 0;
+        c.t = A; c.t_created = root_crt; c.valid = (!dead && A != kInfNs) ? 1 : 0;
     }
     block_min_cand(c, wc, P.cand);
     if (live && n_req) atomicMax(&tot->max_count, (long long)(n_req < (uint32_t)cap ? n_req : (uint32_t)cap));
@@ -243,6 +269,34 @@ __global__ void hs_lb_segments(uint64_t *__restrict__ skey, uint64_t *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// 2c. Service samples of single-worker FIFO backends, one lane per Request.  Such a backend starts its requests in
+//     arrival order, so the request in slot off[b] + k consumes service draw k of backend b whatever happens before
+//     it: the draw (Philox block, hs_log, two divisions-worth of fp64) is a pure function of (seed, b, k) and is taken
+//     off the backend lane's serial recursion.  get_latency(...).to_seconds() of random.expovariate(1 / mean)
+//     (distributions/exponential.py:36,43, components/server/server.py:246-247).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) hs_lb_service_draws(const uint64_t *__restrict__ skey, const int64_t *n_ptr,
+                                                           const int64_t *__restrict__ off, int tb, LbBe P, uint64_t seed,
+                                                           double *__restrict__ sv_out) {
+    const int64_t n = *n_ptr;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t b = (int64_t)(skey[i] >> tb);
+    const double mean = P.svc_mean[b];
+    double sv;
+    if (P.svc_kind[b] == HS_LAT_EXPONENTIAL) {
+        const uint64_t k = (uint64_t)(i - off[b]);
+        const uint64_t sid = stream_id(P.base[b], kStreamService), blk = k >> 1;
+        const U4 o = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)sid, (uint32_t)(sid >> 32), (uint32_t)seed,
+                                   (uint32_t)(seed >> 32));
+        const double u = (k & 1) ? res53(o.z, o.w) : res53(o.x, o.y);
+        const double lambda = __ddiv_rn(1.0, mean);
+        sv = seconds_from_ns(ns_from_seconds(__ddiv_rn(exp1_from_uniform(u), lambda)));
+    } else sv = seconds_from_ns(ns_from_seconds(mean));
+    sv_out[i] = sv;
+}
+
+// ---------------------------------------------------------------------------------------------
 // 3. Backends: QueuedResource + Queue + QueueDriver + worker in front of every Server
 //    (components/queued_resource.py:52-143, queue.py:75-170, queue_driver.py:27-99, server/server.py:202-273)
 // ---------------------------------------------------------------------------------------------
@@ -254,6 +308,7 @@ struct LbBackend {
     int64_t svc_const_ns, qcap;
     // arrivals
     const uint64_t *akey; uint64_t *aval;
+    const double *asv;            // pre-drawn service time of the request in each slot (request-order loop)
     int64_t ai, aend;
     uint64_t tmask;
     int64_t At, Acrt; uint32_t Adepth;
@@ -448,13 +503,19 @@ struct LbBackend {
         int64_t pendD = kInfNs, pendS = 0;
         double pend_s = 0.0, tsvc = 0.0;
         constexpr int kAhead = 8;
+        const double *sp = asv + ai;
         uint64_t cur[kAhead], nxt[kAhead];
+        double scur[kAhead], snxt[kAhead];
 #pragma unroll
-        for (int j = 0; j < kAhead; ++j) cur[j] = j < n ? kp[j] : 0ull;
+        for (int j = 0; j < kAhead; ++j) { cur[j] = j < n ? kp[j] : 0ull; scur[j] = j < n ? sp[j] : 0.0; }
         bool blocked = false;
         for (int64_t base = 0; base < n && !blocked; base += kAhead) {
 #pragma unroll
-            for (int j = 0; j < kAhead; ++j) nxt[j] = (base + kAhead + j) < n ? kp[base + kAhead + j] : 0ull;   // in flight while cur is processed
+            for (int j = 0; j < kAhead; ++j) {                          // in flight while cur is processed
+                const bool in = (base + kAhead + j) < n;
+                nxt[j] = in ? kp[base + kAhead + j] : 0ull;
+                snxt[j] = in ? sp[base + kAhead + j] : 0.0;
+            }
 #pragma unroll
             for (int j = 0; j < kAhead; ++j) {
                 if (base + j >= n || blocked) continue;
@@ -465,8 +526,8 @@ struct LbBackend {
                 n_notify += notify ? 1u : 0u;
                 lt = a > lt ? a : lt;
                 if (S > T) { blocked = true; continue; }              // this request and every later one never start
-                double sv; int64_t dur;
-                sample_service(sv, dur);
+                const double sv = scur[j];                            // hs_lb_service_draws
+                const int64_t dur = ns_from_seconds(sv);              // `yield s`: resume at now + int(s * 1e9) (core/event.py:499)
                 if (dur == 0) return false;
                 const int64_t Dk = S + dur;
                 n_poll += idle ? 1u : 0u;
@@ -482,7 +543,7 @@ struct LbBackend {
                 Sprev = S; Dprev = Dk; aprev = a;
             }
 #pragma unroll
-            for (int j = 0; j < kAhead; ++j) cur[j] = nxt[j];
+            for (int j = 0; j < kAhead; ++j) { cur[j] = nxt[j]; scur[j] = snxt[j]; }
         }
         if (n > 0) {                                                  // arrivals behind a blocked head were not iterated
             const int64_t a_last = (int64_t)(kp[n - 1] & tmask);
@@ -532,7 +593,7 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_backends(LbBe P, int B, int S
                                                            uint64_t *__restrict__ sval, const int64_t *__restrict__ off,
                                                            int tb, int64_t *__restrict__ adm, int64_t *__restrict__ sink_t,
                                                            int64_t *__restrict__ sink_created, int64_t *__restrict__ sink_S,
-                                                           LbTotals *tot, int flags) {
+                                                           const double *__restrict__ svdraw, LbTotals *tot, int flags) {
     __shared__ uint8_t qmem[kLbQCap][kLbBlock];
     __shared__ LbCand wc[kLbBlock / 64];
     const int tid = threadIdx.x;
@@ -550,7 +611,7 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_backends(LbBe P, int B, int S
         X.svc_lambda = __ddiv_rn(1.0, mean);                             // ExponentialLatency._lambda = 1 / mean
         X.svc_const_s = seconds_from_ns(ns_from_seconds(mean));          // ConstantLatency
         X.svc_const_ns = ns_from_seconds(X.svc_const_s);
-        X.akey = skey; X.aval = sval; X.ai = off[b]; X.aend = off[b + 1];
+        X.akey = skey; X.aval = sval; X.asv = svdraw; X.ai = off[b]; X.aend = off[b + 1];
         X.tmask = tb >= 64 ? ~0ull : ((1ull << tb) - 1);
         X.buf = 0; X.accepted = 0; X.dropped = 0; X.rejected = 0; X.started = 0; X.active = 0; X.seq = 0;
         X.total_service = 0.0;
@@ -792,6 +853,8 @@ struct hs_lb {
     uint64_t *mkey = nullptr, *mslot = nullptr;       // where the merged Sink order ended up
     int64_t *off = nullptr, *adm = nullptr, *sink_t = nullptr, *sink_created = nullptr, *sink_S = nullptr;
     int64_t *out_t = nullptr, *out_created = nullptr;
+    double *svdraw = nullptr;                         // [n_slots] service sample per Request slot (single-worker FIFO backends)
+    bool any_simple = false;
     int64_t *n_slots_dev = nullptr, *n_arr = nullptr, *n_done = nullptr;
     uint32_t *hist = nullptr, *row_total = nullptr, *digit_base = nullptr;
     int n_tiles = 0;
@@ -902,7 +965,7 @@ void launch_backends(hs_lb *h, int64_t end_ns) {
     const int B = h->cfg.n_backends;
     hipLaunchKernelGGL(hs_lbk_backends<C>, dim3((B + kLbBlock - 1) / kLbBlock), dim3(kLbBlock), 0, h->stream, h->PB, B,
                        h->cfg.n_sources, h->cfg.seed, h->cfg.start_ns, end_ns, h->skey, h->sval, h->off, h->tb, h->adm,
-                       h->sink_t, h->sink_created, h->sink_S, h->tot, h->flags);
+                       h->sink_t, h->sink_created, h->sink_S, h->svdraw, h->tot, h->flags);
 }
 
 int run_async(hs_lb *h, int64_t end_ns) {
@@ -918,6 +981,9 @@ int run_async(hs_lb *h, int64_t end_ns) {
     hipEventRecord(h->evs1, h->stream);
     hipLaunchKernelGGL(hs_lb_segments, dim3((unsigned)((h->n_slots + 1 + 255) / 256)), dim3(256), 0, h->stream, h->skey,
                        h->sval, h->n_arr, h->tb, h->g_arr, B, h->off);
+    if (h->C == 1 && h->any_simple && (h->flags & 3) == 0)
+        hipLaunchKernelGGL(hs_lb_service_draws, dim3((unsigned)((h->n_slots + 255) / 256)), dim3(256), 0, h->stream, h->skey,
+                           h->n_arr, h->off, h->tb, h->PB, h->cfg.seed, h->svdraw);
     switch (h->C) {
         case 1: launch_backends<1>(h, end_ns); break;
         case 2: launch_backends<2>(h, end_ns); break;
@@ -1104,6 +1170,9 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     TRY(lalloc(h, &h->off, (size_t)B + 1));
     TRY(lalloc(h, &h->adm, NS)); TRY(lalloc(h, &h->sink_t, NS)); TRY(lalloc(h, &h->sink_created, NS)); TRY(lalloc(h, &h->sink_S, NS));
     if (cfg->shared_sink) { TRY(lalloc(h, &h->out_t, NS)); TRY(lalloc(h, &h->out_created, NS)); }
+    for (int j = 0; j < B; ++j)
+        if ((be->concurrency ? be->concurrency[j] : 1) == 1 && (be->queue_cap ? be->queue_cap[j] : -1) < 0) h->any_simple = true;
+    TRY(lalloc(h, &h->svdraw, (h->C == 1 && h->any_simple) ? NS : (size_t)1));
     TRY(lalloc(h, &h->n_slots_dev, 1)); TRY(lalloc(h, &h->n_arr, 1)); TRY(lalloc(h, &h->n_done, 1));
     TRY(lalloc(h, &h->hist, (size_t)kRadixBins * (size_t)h->n_tiles)); TRY(lalloc(h, &h->row_total, (size_t)kRadixBins));
     TRY(lalloc(h, &h->digit_base, (size_t)kRadixBins));
