@@ -173,7 +173,10 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
                                                            int64_t start_ns, NetState NX, int n_links) {
     const int lp = blockIdx.x * kBlock + threadIdx.x;
     if (NX.next_time != nullptr) {   // network engine: clear routing / link / bag state
-        for (int l = lp; l < n_links; l += gridDim.x * kBlock) { NX.link_k[l] = 0; NX.link_in[l] = 0; NX.link_packets[l] = 0; }
+        for (int l = lp; l < n_links; l += gridDim.x * kBlock) {
+            NX.link_k[l] = 0; NX.link_in[l] = 0; NX.link_packets[l] = 0;
+            if (NX.aq_tail != nullptr) { NX.aq_tail[l] = 0; NX.aq_head[l] = 0; NX.aq_ea[l] = start_ns; }
+        }
         if (lp < n) { NX.route_k[lp] = 0; NX.routed[lp] = 0; NX.bag_cnt[lp] = 0; NX.in_cnt[lp] = 0; NX.in_cnt[n + lp] = 0; }
     }
     if (lp == 0) {
@@ -384,7 +387,7 @@ __device__ __forceinline__ void load_net(NetStation<C> &S, const StationParams &
                                          uint8_t (*qmem)[kBlock], int64_t (*enqpay)[kBlock], int tid, int send_idx,
                                          const ShardCtl &SC) {
     S.lp = lp; S.n = n;
-    S.sc = &SC; S.sent_min = kInfNs;
+    S.sc = &SC; S.sent_min = kInfNs; S.sent_async = false;
     S.src_kind = P.src_kind[lp]; S.svc_kind = P.svc_kind[lp]; S.egress = NP.egress[lp];
     S.conc = P.conc[lp]; S.rt0 = NP.rt0[lp]; S.rt1 = NP.rt1[lp]; S.link_of = NP.link_of[lp];
     S.rate = P.src_rate[lp];
@@ -485,7 +488,30 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
 
     int64_t nt = kInfNs;
     int merge_overflow = 0;
-    if (live) {
+    if (live && (flags & 8)) {
+        // after hs_net_async: whatever is still in this LP's link queues arrives beyond end_ns (it only matters to the
+        // election of the one event beyond end_ns); nothing is appended any more, plain bookkeeping
+        nt = NX.next_time[lp];
+        int bn = NX.bag_cnt[lp];
+        for (int q = NP.in_off[lp]; q < NP.in_off[lp + 1]; ++q) {
+            const int l = NP.in_links[q];
+            const unsigned long long tail = ag_load(&NX.aq_tail[l]);
+            unsigned long long head = NX.aq_head[l];
+            for (; head < tail; ++head) {
+                if (bn >= NX.bag_cap) { merge_overflow = 1; break; }
+                const size_t slot = (size_t)l * NX.aq_cap + (size_t)(head % (unsigned long long)NX.aq_cap);
+                const size_t dst = (size_t)lp * NX.bag_cap + bn;
+                const int64_t t = ag_load(&NX.aq_t[slot]);
+                NX.bag_t[dst] = t; NX.bag_ts[dst] = ag_load(&NX.aq_ts[slot]); NX.bag_cr[dst] = ag_load(&NX.aq_cr[slot]);
+                NX.bag_link[dst] = l;
+                nt = t < nt ? t : nt;
+                ++bn;
+            }
+            NX.aq_head[l] = head;
+        }
+        NX.bag_cnt[lp] = bn;
+        NX.next_time[lp] = nt;
+    } else if (live) {
         nt = NX.next_time[lp];
         const size_t cs = (size_t)merge_idx * n + lp;
         const int c = NX.in_cnt[cs];
@@ -639,6 +665,130 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Asynchronous conservative engine: the whole run of a station network in ONE launch, every LP resident.
+//
+// The windowed engine above advances all LPs in lock-step windows of W = min link latency (one launch per window:
+// 60 002 launches for 60 s of a ring with 1 ms links).  But an LP only has to wait for the LPs that can SEND to it, and
+// with counter-based streams a sender knows a lot about its future: its next completion is `min D` when all workers
+// are busy, and otherwise no earlier than (its next arrival, or the earliest thing its own senders may still deliver)
+// + the duration of the next service to start -- which is service draw number `svc.k`, already determined.  Every LP
+// publishes, per outgoing link, a lower bound `aq_ea` on the arrival time of any message it has not appended yet
+// (next completion bound + the link's transit floor) and processes its own events strictly below the minimum of its
+// incoming links' bounds (Chandy-Misra-Bryant null messages, carried by one 8-byte word per link).  Bounds grow by
+// at least the transit floor per hop, so the ring cannot deadlock; results are those of the windowed engine and of the
+// reference's single heap (same per-LP code, same message order), independent of timing.
+//
+// All LPs must be co-resident (they spin on each other): the host launches this kernel cooperatively and falls back to
+// the windowed engine when the grid does not fit.  Every spin is bounded (kAsyncMaxIter): a wave that gives up raises
+// overflow bit 8 and the host reports an error instead of hanging the device.
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned kAsyncMaxIter = 1u << 21;
+
+template <int C>
+__global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParams NP, StationState X, NetState NX,
+                                                       RecordLogs L, Totals *tot, int n, int64_t end_ns, int flags,
+                                                       ShardCtl SC) {
+    __shared__ uint8_t qmem[kQCap][kBlock];
+    __shared__ int64_t enqpay[kEnqPay][kBlock];
+    __shared__ unsigned long long red[14];
+    __shared__ long long red_time;
+    __shared__ int red_flags[4];
+    const int tid = threadIdx.x;
+    const int lp = blockIdx.x * kBlock + tid;
+    const bool live = lp < n;
+    if (tid < 14) red[tid] = 0;
+    if (tid == 0) { red_time = INT64_MIN; red_flags[0] = red_flags[1] = red_flags[2] = red_flags[3] = 0; }
+    __syncthreads();
+
+    NetStation<C> S;
+    bool done = !live;
+    int gave_up = 0;
+    if (live) {
+        load_net<C>(S, P, NP, X, NX, L, lp, n, qmem, enqpay, tid, 0, SC);
+        // this LP's outgoing links (router targets in constructor order, or the single link) and what it last published
+        int32_t out_l[2] = {-1, -1};
+        if (S.egress == EG_LINK) out_l[0] = S.link_of;
+        else if (S.egress == EG_ROUTER) { out_l[0] = S.rt0; out_l[1] = S.rt1; }
+        int64_t out_pub[2] = {INT64_MIN, INT64_MIN};
+        uint64_t dur_k = ~0ull;
+        int dur_free = -1;
+        int64_t dur_next = 0;
+        const bool force_general = (flags & 1) != 0;
+        for (unsigned iter = 0;; ++iter) {
+            if (!done) {
+                const int64_t H = S.async_receive();                  // messages below H are all in the bag now
+                const int64_t limit = (H - 1) < end_ns ? (H - 1) : end_ns;
+                for (;;) {
+                    const int64_t t = S.next_time();
+                    if (t > limit) break;
+                    if (!(S.async_can_send(out_l[0]) && S.async_can_send(out_l[1]))) break;   // a consumer is behind: wait
+                    S.run_group(t, force_general);
+                }
+                const int64_t t2 = S.next_time();
+                const int64_t base = t2 < H ? t2 : H;                 // nothing happens here before `base`
+                // lower bound of this LP's next completion (= its next chance to send)
+                int64_t dmin = kInfNs;
+#pragma unroll
+                for (int i = 0; i < C; ++i) dmin = S.D[i] < dmin ? S.D[i] : dmin;
+                int64_t lb = dmin;
+                if (S.active < S.conc) {
+                    const int free = S.conc - S.active;
+                    if (S.svc.k != dur_k || free != dur_free) { dur_next = S.peek_service_ns(free); dur_k = S.svc.k; dur_free = free; }
+                    const int64_t started = (base == kInfNs) ? kInfNs : base + dur_next;
+                    lb = started < lb ? started : lb;
+                }
+                bool drained = !S.sent_async;
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    const int32_t l = out_l[o];
+                    if (l < 0) continue;
+                    const int64_t v = (lb == kInfNs) ? kInfNs : lb + NP.link_lat_ns[l];
+                    if (v > out_pub[o]) {
+                        if (!drained) { drain_stores(); drained = true; }   // the appended messages first, then the bound
+                        ag_store(&NX.aq_ea[l], v);
+                        out_pub[o] = v;
+                    }
+                }
+                S.sent_async = false;
+                done = base > end_ns;                                 // nothing at or before end_ns can happen any more
+            }
+            if (__all(done)) break;
+            if (iter >= kAsyncMaxIter) { gave_up = 1; break; }
+        }
+        store_net<C>(S, X, NX, lp, n);
+    }
+
+    // ---- workgroup reduction of the run's deltas -> engine totals (as in hs_net_window)
+    unsigned vals[13];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) vals[k] = live ? S.ev[k] : 0u;
+    vals[11] = vals[6]; vals[12] = vals[7];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        const unsigned sm = wave_sum<unsigned>(vals[k]);
+        if ((tid & 63) == 0 && sm) atomicAdd(&red[k], (unsigned long long)sm);
+    }
+    if (live) {
+        atomicMax(&red_time, (long long)S.last_time);
+        if (S.overflow) red_flags[0] = 1;
+        if (S.qoverflow) red_flags[1] = 1;
+        if (S.bagoverflow) red_flags[2] = 1;
+        if (gave_up) red_flags[3] = 1;
+    }
+    __syncthreads();
+    if (tid < 11 && red[tid]) atomicAdd(&tot->ev[tid], red[tid]);
+    if (tid == 11 && red[11]) atomicAdd(&tot->completed, red[11]);
+    if (tid == 12 && red[12]) atomicAdd(&tot->received, red[12]);
+    if (tid == 13) {
+        if (red_time != INT64_MIN) atomicMax(&tot->final_time, red_time);
+        if (red_flags[0]) atomicOr(&tot->overflow, 1);
+        if (red_flags[1]) atomicOr(&tot->qoverflow, 1);
+        if (red_flags[2]) atomicOr(&tot->overflow, 2);
+        if (red_flags[3]) atomicOr(&tot->overflow, 8);
+    }
+}
+
 // Sharded network, after the host exchanged the outbox rows: append the messages other ranks sent to this rank's
 // stations to the incoming bags of parity `send_idx` (the window that just ran), so that the next launch merges
 // them together with the locally sent ones.  Also clears this rank's outbox counters and re-arms the GVT slot
@@ -778,6 +928,8 @@ struct hs_engine {
     std::vector<int32_t> h_link_dst;
     int64_t window_ns = 0;
     bool net_ran = false;
+    bool async_ok = false;     // the network can run on hs_net_async (whole network on this engine, queues allocated)
+    int async_fit = -1;        // -1 unknown, 0 the grid is not co-resident (windowed engine), 1 it is
     int n_blocks = 0;
     int flags = 0;
     double last_run_ms = 0.0, last_kernel_ms = 0.0;
@@ -856,8 +1008,50 @@ void launch_net_dispatch(hs_engine *h, int64_t wend, int win, int flags) {
     }
 }
 
+template <int C>
+hipError_t launch_async(hs_engine *h, int64_t end_ns, NetState NX) {
+    int n = h->cfg.n_lp, flags = h->flags & 1;
+    void *args[] = {&h->P, &h->NP, &h->X, &NX, &h->L, &h->tot, &n, &end_ns, &flags, &h->SC};
+    return hipLaunchCooperativeKernel((const void *)hs_net_async<C>, dim3(h->n_blocks), dim3(kBlock), args, 0, h->stream);
+}
+template <int C>
+int async_blocks_per_cu() {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hs_net_async<C>, kBlock, 0) != hipSuccess) return 0;
+    return nb;
+}
+
+// The whole run in one launch of hs_net_async + the final launch of hs_net_window (election of the one event beyond
+// end_ns).  Returns 1 if it ran, 0 if the network has to use the windowed engine, < 0 on error.
+int try_run_net_whole(hs_engine *h, int64_t end_ns) {
+    if (!h->async_ok || (h->flags & 16)) return 0;
+    if (h->async_fit < 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->cfg.device) != hipSuccess) return 0;
+        const int per_cu = h->C == 1 ? async_blocks_per_cu<1>() : h->C == 2 ? async_blocks_per_cu<2>() : async_blocks_per_cu<4>();
+        h->async_fit = (prop.cooperativeLaunch && (long long)per_cu * prop.multiProcessorCount >= h->n_blocks) ? 1 : 0;
+    }
+    if (!h->async_fit) return 0;
+    NetState NX = h->NX;
+    NX.aq_on = 1;
+    hipError_t e = h->C == 1 ? launch_async<1>(h, end_ns, NX) : h->C == 2 ? launch_async<2>(h, end_ns, NX) : launch_async<4>(h, end_ns, NX);
+    if (e != hipSuccess) { (void)hipGetLastError(); h->async_fit = 0; return 0; }   // not co-resident after all: windows
+    const NetState keep = h->NX;
+    h->NX = NX;
+    launch_net_dispatch(h, end_ns, 1, (h->flags & 1) | 2 | 8);       // FINAL: leftover queue entries, overshoot
+    h->NX = keep;
+    HS_HIP(h, hipGetLastError());
+    h->launches += 2;
+    h->net_ran = true;
+    return 1;
+}
+
 // EXECUTE / EXCHANGE / ADVANCE (parallel/coordinator.py:87-124) as a stream of window launches
 int run_net_async(hs_engine *h, int64_t end_ns) {
+    {
+        const int whole = try_run_net_whole(h, end_ns);
+        if (whole != 0) return whole < 0 ? whole : HS_OK;
+    }
     const int64_t W = h->window_ns;
     int64_t t0 = h->cfg.start_ns;
     int win = 0;
@@ -1127,6 +1321,23 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     if ((rc = upload<uint8_t>(h, &h->NP.link_jit_kind, jk.data(), NL, 1))) return rc;
     if ((rc = upload<double>(h, &h->NP.link_jit_mean, jm.data(), NL, 0.0))) return rc;
     if ((rc = upload<uint64_t>(h, &h->NP.link_base, lbase.data(), NL, 0))) return rc;
+    {   // incoming links per LP (CSR) and the transit floor of every link, for the asynchronous engine
+        std::vector<int32_t> in_off((size_t)n + 1, 0), in_links(NL, 0);
+        std::vector<int64_t> lat_ns(NL, 1);
+        if (!global) {
+            for (int l = 0; l < nl; ++l) in_off[(size_t)net->link_dst[l] + 1]++;
+            for (int i = 0; i < n; ++i) in_off[(size_t)i + 1] += in_off[(size_t)i];
+            std::vector<int32_t> cur(in_off.begin(), in_off.end() - 1);
+            for (int l = 0; l < nl; ++l) in_links[(size_t)cur[(size_t)net->link_dst[l]]++] = l;
+        }
+        for (int l = 0; l < nl; ++l) {
+            const double lc = (double)(int64_t)(net->link_lat_min_s[l] * 1e9) / 1e9;   // ConstantLatency.get_latency().to_seconds()
+            lat_ns[(size_t)l] = (int64_t)(lc * 1e9);
+        }
+        if ((rc = upload<int32_t>(h, &h->NP.in_off, in_off.data(), (size_t)n + 1, 0))) return rc;
+        if ((rc = upload<int32_t>(h, &h->NP.in_links, in_links.data(), NL, 0))) return rc;
+        if ((rc = upload<int64_t>(h, &h->NP.link_lat_ns, lat_ns.data(), NL, 1))) return rc;
+    }
     h->NP.link_gid = nullptr;
     if (net->link_gid && nl > 0) {
         std::vector<int32_t> gid((size_t)nl);
@@ -1159,6 +1370,13 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     ALN(route_k, N); ALN(routed, N); ALN(link_k, NL); ALN(link_in, NL); ALN(link_packets, NL); ALN(next_time, N);
     ALN(bag_cnt, N); ALN(bag_t, NB); ALN(bag_ts, NB); ALN(bag_cr, NB); ALN(bag_link, NB);
     ALN(in_cnt, 2 * N); ALN(in_t, 2 * NB); ALN(in_ts, 2 * NB); ALN(in_cr, 2 * NB); ALN(in_link, 2 * NB);
+    h->NX.aq_cap = bag;
+    h->NX.aq_on = 0;
+    if (!global && nl > 0) {
+        const size_t NQ = NL * (size_t)bag;
+        ALN(aq_t, NQ); ALN(aq_ts, NQ); ALN(aq_cr, NQ); ALN(aq_tail, NL); ALN(aq_head, NL); ALN(aq_ea, NL);
+        h->async_ok = true;
+    }
 #undef ALN
     if (!h->L.sink_created_own) {   // not every completion reaches the Sink any more: explicit created_at column
         if ((rc = dev_alloc(h, &h->L.sink_created_own, N * (size_t)h->L.cap))) return rc;
@@ -1369,6 +1587,9 @@ int hs_engine_run_until(hs_engine *h, int64_t end_ns) {
     Totals t;
     HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
     if (t.qoverflow) return fail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
+    if (t.overflow & 8)
+        return fail(h, HS_E_HIP, "the asynchronous network engine gave up waiting for a neighbour (bounded spin); "
+                                 "set debug flag 16 to use the windowed engine");
     if (t.overflow & 2)
         return fail(h, HS_E_OVERFLOW, "a station's in-flight message bag overflowed (capacity %d); raise bag_capacity",
                     (int)h->NX.bag_cap);
@@ -1407,6 +1628,12 @@ int hs_engine_bench_runs(hs_engine *h, int64_t end_ns, int32_t repeats, float *k
     h->last_run_ms = tot_ms / (float)repeats;
     if (!h->is_net) h->launches = 2;
     for (auto &e : ev) hipEventDestroy(e);
+    Totals t;                                                       // a timed run that overflowed is not a result
+    HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
+    if (t.qoverflow) return fail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
+    if (t.overflow & 8) return fail(h, HS_E_HIP, "the asynchronous network engine gave up waiting for a neighbour (bounded spin)");
+    if (t.overflow & 2) return fail(h, HS_E_OVERFLOW, "a station's in-flight message bag overflowed (capacity %d); raise bag_capacity", (int)h->NX.bag_cap);
+    if (t.overflow) return fail(h, HS_E_OVERFLOW, "a per-LP record log overflowed (capacity %lld records)", (long long)h->L.cap);
     return HS_OK;
 }
 

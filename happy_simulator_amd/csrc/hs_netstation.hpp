@@ -41,6 +41,10 @@ struct NetParams {
     const double *link_jit_mean;  // [n_links]
     const uint64_t *link_base;    // [n_links] stream base of the link entity
     const int32_t *link_gid;      // [n_links] network-wide link id (tie-break key); null = the index itself
+    // asynchronous engine (hs_net_async): incoming links of every LP (CSR) and each link's transit floor in ns
+    const int32_t *in_off;        // [n_lp + 1]
+    const int32_t *in_links;      // [n_links] link ids grouped by destination LP
+    const int64_t *link_lat_ns;   // [n_links] from_seconds(to_seconds(from_seconds(lat_min))): no transit is shorter
 };
 
 // A network partitioned over several engines (one per GPU): links whose destination station lives on another
@@ -75,7 +79,32 @@ struct NetState {
     int64_t *in_t, *in_ts, *in_cr;
     int32_t *in_link;
     int32_t bag_cap;
+    // asynchronous engine: one single-producer / single-consumer message queue per link.  Every word below is written
+    // with write-through (sc1) agent-scope stores and read with agent-scope loads -- the data is its own flag
+    // (cdna_hip_programming.md section 6, Guideline 16, recipe R2); the producer drains its stores (vmcnt(0)) between
+    // the payload, `aq_tail` and `aq_ea`, so a consumer that sees a value of `aq_ea` also sees every message below it.
+    int64_t *aq_t, *aq_ts, *aq_cr;   // [n_links][aq_cap] arrival ns, send ns, created_at ns
+    unsigned long long *aq_tail;     // [n_links] messages appended so far (producer)
+    unsigned long long *aq_head;     // [n_links] messages taken so far (consumer; the producer reads it for flow control)
+    int64_t *aq_ea;                  // [n_links] every message NOT yet appended arrives at or after this time
+    int32_t aq_cap;
+    int32_t aq_on;                   // 1 inside hs_net_async / its final launch: send_link uses the queues
 };
+
+// agent-scope accesses of the words LPs of different workgroups exchange (write-through store / cache-bypassing load)
+__device__ __forceinline__ void ag_store(int64_t *p, int64_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ag_store(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int64_t ag_load(const int64_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ag_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 constexpr int kEnqPay = 8;   // ENQ payload FIFO depth (general path only)
 
@@ -108,6 +137,7 @@ struct NetStation {
     const NetState *ns;
     const ShardCtl *sc;
     int64_t sent_min;             // earliest arrival among the messages this LP sent in this window
+    bool sent_async;              // asynchronous engine: a message was appended since the last publication of aq_ea
     int send_idx;
     int32_t bag_n;
     // in-group FIFO + ENQ payloads (LDS columns)
@@ -240,6 +270,18 @@ struct NetStation {
         const int64_t t_arr = t + ns_from_seconds(delay);
         sent_min = t_arr < sent_min ? t_arr : sent_min;
         const int32_t dst = np->link_dst[l];                 // network-wide station index
+        if (ns->aq_on) {
+            // asynchronous engine: append to the link's queue (this LP is its only producer); link_in[l] is the
+            // sequence number of this message
+            const unsigned long long seq = (unsigned long long)ns->link_in[l];
+            if (seq - ag_load(&ns->aq_head[l]) > (unsigned long long)ns->aq_cap) { bagoverflow = 1; return; }
+            const size_t slot = (size_t)l * ns->aq_cap + (size_t)((seq - 1) % (unsigned long long)ns->aq_cap);
+            ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t); ag_store(&ns->aq_cr[slot], created);
+            drain_stores();
+            ag_store(&ns->aq_tail[l], seq);
+            sent_async = true;
+            return;
+        }
         if (sc->wend_slots != nullptr && sc->link_rank[l] != sc->rank) {
             // destination lives on another engine: append to that rank's outbox row
             int64_t *row = sc->outbox + (size_t)sc->link_rank[l] * sc->row;
@@ -311,6 +353,58 @@ struct NetStation {
         const uint32_t same = do_deliver_work(t, have_created, created);
         if (same) { qpush(Q_CONT | ((same - 1) << 3)); return true; }
         return false;
+    }
+
+    // ---- asynchronous engine -----------------------------------------------------------------
+    // take delivery of everything the incoming links hold; returns min over those links of aq_ea (kInfNs: no in-links)
+    __device__ __forceinline__ int64_t async_receive() {
+        int64_t H = kInfNs;
+        const int a = np->in_off[lp], b = np->in_off[lp + 1];
+        for (int q = a; q < b; ++q) {
+            const int l = np->in_links[q];
+            const int64_t ea = ag_load(&ns->aq_ea[l]);                 // read BEFORE the tail: see the ordering note above
+            H = ea < H ? ea : H;
+            const unsigned long long tail = ag_load(&ns->aq_tail[l]);
+            unsigned long long head = ns->aq_head[l];                  // ours
+            if (head == tail) continue;
+            for (; head < tail && bag_n < ns->bag_cap; ++head) {
+                const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head % (unsigned long long)ns->aq_cap);
+                const size_t d = bidx(bag_n);
+                ns->bag_t[d] = ag_load(&ns->aq_t[slot]); ns->bag_ts[d] = ag_load(&ns->aq_ts[slot]);
+                ns->bag_cr[d] = ag_load(&ns->aq_cr[slot]); ns->bag_link[d] = l;
+                ++bag_n;
+            }
+            ag_store(&ns->aq_head[l], head);
+            if (head < tail) {
+                // the bag is full: what stays in the queue was sent no earlier than its first entry (send times do not
+                // decrease along a queue), so it arrives no earlier than that + the link's transit floor
+                const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head % (unsigned long long)ns->aq_cap);
+                const int64_t lb = ag_load(&ns->aq_ts[slot]) + np->link_lat_ns[l];
+                H = lb < H ? lb : H;
+            }
+        }
+        return H;
+    }
+    // back-pressure: an LP processes events only while each of its outgoing queues can take what one timestamp group
+    // may send (one message per completion, at most C completions per group)
+    __device__ __forceinline__ bool async_can_send(int32_t l) const {
+        if (l < 0) return true;
+        const unsigned long long inflight = (unsigned long long)ns->link_in[l] - ag_load(&ns->aq_head[l]);
+        return inflight + (unsigned long long)C <= (unsigned long long)ns->aq_cap;
+    }
+    // Shortest duration among the next `free` services to start: service draws svc.k .. svc.k + free - 1, not consumed
+    // (pure functions of the draw index).  With `free` idle workers that many requests can be in service before any
+    // completion, so the first completion of a not-yet-started request is no earlier than its start + this.
+    __device__ __forceinline__ int64_t peek_service_ns(int free) const {
+        if (svc_kind != 0) return svc_const_ns;
+        Stream c = svc;
+        int64_t m = kInfNs;
+        for (int i = 0; i < free; ++i) {
+            const double sample = __ddiv_rn(exp1_from_uniform(c.next_uniform()), svc_lambda);
+            const int64_t d = ns_from_seconds(seconds_from_ns(ns_from_seconds(sample)));
+            m = d < m ? d : m;
+        }
+        return m;
     }
 
     // ---- general path ----------------------------------------------------------------------

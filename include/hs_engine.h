@@ -352,7 +352,8 @@ void hs_engine_destroy(hs_engine *h);
 /* Device-side scalar semantics, exported so tests can compare them bit-for-bit with the oracle:
  * fills u[i] = uniform(seed, sid, k0+i), e[i] = -hs_log(1-u[i]), ns[i] = trunc((e[i]/rate)*1e9). */
 /* Debug: bit 0 routes every timestamp group through the general in-group FIFO path (tests compare it with
- * the fast path). */
+ * the fast path); bit 4 (16) runs a station network on the windowed engine (one launch per window) even when the
+ * asynchronous whole-run engine is available. */
 int hs_debug_set_flags(hs_engine *h, int flags);
 
 int hs_debug_draws(int32_t device, uint64_t seed, uint64_t sid, uint64_t k0, int64_t n, double rate,

@@ -1,6 +1,7 @@
-"""GPU: networks of stations (Server -> RandomRouter -> [Sink | NetworkLink -> next Server]) on the windowed
-engine, against the live-reference ring goldens and the C oracle.  Bit-exact: totals, per-kind histogram, final
-time, every per-station statistic, router / link counters, every Sink record."""
+"""GPU: networks of stations (Server -> RandomRouter -> [Sink | NetworkLink -> next Server]) on BOTH network engines --
+the asynchronous one (hs_net_async: the whole run in one cooperative launch, per-link lower bounds instead of global
+windows) and the windowed one (debug flag 16) -- against the live-reference ring goldens and the C oracle.  Bit-exact:
+totals, per-kind histogram, final time, every per-station statistic, router / link counters, every Sink record."""
 import numpy as np
 import pytest
 
@@ -37,11 +38,15 @@ def _check_against_oracle(spec, eng, r, nodes):
         off += counts[i]
 
 
+ENGINES = pytest.mark.parametrize("engine_flags", [0, 16], ids=["async", "windowed"])
+
+
+@ENGINES
 @pytest.mark.parametrize("name", H.golden_names("ring"))
-def test_ring_engine_matches_reference_golden(name):
+def test_ring_engine_matches_reference_golden(name, engine_flags):
     gold = H.Golden(name)
     spec = gold.spec
-    eng, p = H.ring_engine_for_spec(spec)
+    eng, p = H.ring_engine_for_spec(spec, flags=engine_flags)
     with eng:
         eng.run_until(p["end_ns"])
         s = eng.summary()
@@ -51,7 +56,7 @@ def test_ring_engine_matches_reference_golden(name):
         assert s.final_time_ns == gold.meta["final_ns"][0]
         assert s.window_ns > 0 and s.launches > 1
         if "trace" in gold.arrays:
-            np.testing.assert_array_equal(s.events_by_kind, np.bincount(gold.trace[:, 1], minlength=11)[:11])
+            np.testing.assert_array_equal(s.events_by_kind, np.bincount(gold.trace[:, 1], minlength=len(s.events_by_kind)))
         for k, g in (("generated", "generated"), ("accepted", "accepted"), ("dropped", "dropped"),
                      ("completed", "completed"), ("rejected", "rejected"), ("sink_received", "received"),
                      ("queue_depth", "depth"), ("active", "active"), ("total_service_s", "total_service_s")):
@@ -74,20 +79,21 @@ RING_SWEEP = [
 ]
 
 
+@ENGINES
 @pytest.mark.parametrize("spec", RING_SWEEP, ids=[s["name"] for s in RING_SWEEP])
-def test_ring_engine_matches_oracle(spec):
+def test_ring_engine_matches_oracle(spec, engine_flags):
     g, nodes = H.oracle_ring_graph(spec)
     r = O.run(g, H.ns_from_seconds(spec["end_s"]), seed=spec["seed"])
-    eng, p = H.ring_engine_for_spec(spec)
+    eng, p = H.ring_engine_for_spec(spec, flags=engine_flags)
     with eng:
         eng.run_until(p["end_ns"])
         _check_against_oracle(spec, eng, r, nodes)
 
 
-def test_ring_general_path_equals_fast_path():
+def test_ring_general_path_equals_fast_path_and_async_equals_windowed():
     spec = RING_SWEEP[1]
     res = []
-    for flags in (0, 1):
+    for flags in (0, 1, 16, 17):
         eng, p = H.ring_engine_for_spec(spec, flags=flags)
         with eng:
             eng.run_until(p["end_ns"])
@@ -95,7 +101,7 @@ def test_ring_general_path_equals_fast_path():
             res.append((s.events_processed, tuple(s.events_by_kind), s.final_time_ns,
                         {k: v.tobytes() for k, v in eng.lp_stats().items()},
                         {k: v.tobytes() for k, v in eng.net_stats().items()}, [a.tobytes() for a in eng.read_sinks()]))
-    assert res[0] == res[1]
+    assert res[0] == res[1] == res[2] == res[3]
 
 
 def test_ring_rejects_zero_lookahead_and_second_run():
