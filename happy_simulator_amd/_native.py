@@ -207,6 +207,8 @@ def lib():
     L.hs_engine_destroy.argtypes = [C.c_void_p]
     L.hs_debug_set_flags.restype = C.c_int
     L.hs_debug_set_flags.argtypes = [C.c_void_p, C.c_int]
+    L.hs_debug_async_counters.restype = C.c_int
+    L.hs_debug_async_counters.argtypes = [C.c_void_p, C.c_void_p]
     L.hs_debug_draws.restype = C.c_int
     L.hs_debug_draws.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64, C.c_double,
                                  C.c_void_p, C.c_void_p, C.c_void_p]
@@ -253,7 +255,7 @@ EXPORTED_SYMBOLS = (
     "hs_engine_run_until", "hs_engine_run_until_async", "hs_engine_synchronize", "hs_engine_bench_runs",
     "hs_engine_get_summary", "hs_engine_get_lp_stats", "hs_engine_read_sink", "hs_engine_read_sinks",
     "hs_last_error", "hs_last_global_error", "hs_engine_destroy", "hs_debug_draws", "hs_debug_set_flags",
-    "hs_debug_const_div",
+    "hs_debug_const_div", "hs_debug_async_counters",
     "hs_lb_create", "hs_lb_run", "hs_lb_bench_runs", "hs_lb_get_summary", "hs_lb_get_stats", "hs_lb_read_sink",
     "hs_lb_ring", "hs_lb_select", "hs_lb_last_error", "hs_lb_destroy", "hs_md5", "hs_debug_radix_sort",
     "hs_debug_lb_flags",

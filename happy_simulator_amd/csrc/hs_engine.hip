@@ -183,6 +183,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
         for (int k = 0; k < 11; ++k) tot->ev[k] = 0;
         tot->completed = 0; tot->received = 0; tot->final_time = start_ns; tot->cur_time = start_ns;
         tot->overflow = 0; tot->qoverflow = 0; tot->done = 0;
+        tot->dbg[0] = tot->dbg[1] = tot->dbg[2] = tot->dbg[3] = 0;
     }
     if (lp >= n) return;
     int64_t A = kInfNs, arr_time = start_ns;
@@ -688,15 +689,19 @@ constexpr unsigned kAsyncMaxIter = 1u << 21;
 template <int C>
 __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParams NP, StationState X, NetState NX,
                                                        RecordLogs L, Totals *tot, int n, int64_t end_ns, int flags,
-                                                       ShardCtl SC) {
+                                                       ShardCtl SC, int lanes) {
     __shared__ uint8_t qmem[kQCap][kBlock];
     __shared__ int64_t enqpay[kEnqPay][kBlock];
     __shared__ unsigned long long red[14];
     __shared__ long long red_time;
     __shared__ int red_flags[4];
     const int tid = threadIdx.x;
-    const int lp = blockIdx.x * kBlock + tid;
-    const bool live = lp < n;
+    // `lanes` LPs per wavefront (64 by default; 32 / 16 for experiments, debug flag 32).  Measured on the 65 536-station
+    // ring: 16 LPs per wavefront (4 wavefronts per SIMD, 128 VGPRs with spills) is 2.4x SLOWER than 64 -- progress is bound
+    // by how fast bounds travel from LP to LP, and neighbours inside one wavefront exchange them once per iteration
+    const int lane = tid & 63;
+    const int lp = (blockIdx.x * (kBlock / 64) + (tid >> 6)) * lanes + lane;
+    const bool live = lane < lanes && lp < n;
     if (tid < 14) red[tid] = 0;
     if (tid == 0) { red_time = INT64_MIN; red_flags[0] = red_flags[1] = red_flags[2] = red_flags[3] = 0; }
     __syncthreads();
@@ -715,7 +720,9 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         int dur_free = -1;
         int64_t dur_next = 0;
         const bool force_general = (flags & 1) != 0;
+        unsigned n_groups = 0, n_iter = 0;
         for (unsigned iter = 0;; ++iter) {
+            n_iter = iter + 1;
             if (!done) {
                 const int64_t H = S.async_receive();                  // messages below H are all in the bag now
                 const int64_t limit = (H - 1) < end_ns ? (H - 1) : end_ns;
@@ -724,6 +731,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                     if (t > limit) break;
                     if (!(S.async_can_send(out_l[0]) && S.async_can_send(out_l[1]))) break;   // a consumer is behind: wait
                     S.run_group(t, force_general);
+                    ++n_groups;
                 }
                 const int64_t t2 = S.next_time();
                 const int64_t base = t2 < H ? t2 : H;                 // nothing happens here before `base`
@@ -757,6 +765,11 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             if (iter >= kAsyncMaxIter) { gave_up = 1; break; }
         }
         store_net<C>(S, X, NX, lp, n);
+        atomicAdd(&tot->dbg[2], (unsigned long long)n_groups);
+        if ((tid & 63) == 0) {
+            atomicAdd(&tot->dbg[0], (unsigned long long)n_iter); atomicMax(&tot->dbg[1], (unsigned long long)n_iter);
+            atomicAdd(&tot->dbg[3], 1ull);
+        }
     }
 
     // ---- workgroup reduction of the run's deltas -> engine totals (as in hs_net_window)
@@ -930,6 +943,7 @@ struct hs_engine {
     bool net_ran = false;
     bool async_ok = false;     // the network can run on hs_net_async (whole network on this engine, queues allocated)
     int async_fit = -1;        // -1 unknown, 0 the grid is not co-resident (windowed engine), 1 it is
+    int async_lanes = 64;      // LPs per wavefront in hs_net_async
     int n_blocks = 0;
     int flags = 0;
     double last_run_ms = 0.0, last_kernel_ms = 0.0;
@@ -1010,9 +1024,11 @@ void launch_net_dispatch(hs_engine *h, int64_t wend, int win, int flags) {
 
 template <int C>
 hipError_t launch_async(hs_engine *h, int64_t end_ns, NetState NX) {
-    int n = h->cfg.n_lp, flags = h->flags & 1;
-    void *args[] = {&h->P, &h->NP, &h->X, &NX, &h->L, &h->tot, &n, &end_ns, &flags, &h->SC};
-    return hipLaunchCooperativeKernel((const void *)hs_net_async<C>, dim3(h->n_blocks), dim3(kBlock), args, 0, h->stream);
+    int n = h->cfg.n_lp, flags = h->flags & 1, lanes = h->async_lanes;
+    const int per_block = (kBlock / 64) * lanes;
+    void *args[] = {&h->P, &h->NP, &h->X, &NX, &h->L, &h->tot, &n, &end_ns, &flags, &h->SC, &lanes};
+    return hipLaunchCooperativeKernel((const void *)hs_net_async<C>, dim3((unsigned)((n + per_block - 1) / per_block)),
+                                      dim3(kBlock), args, 0, h->stream);
 }
 template <int C>
 int async_blocks_per_cu() {
@@ -1029,7 +1045,12 @@ int try_run_net_whole(hs_engine *h, int64_t end_ns) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, h->cfg.device) != hipSuccess) return 0;
         const int per_cu = h->C == 1 ? async_blocks_per_cu<1>() : h->C == 2 ? async_blocks_per_cu<2>() : async_blocks_per_cu<4>();
-        h->async_fit = (prop.cooperativeLaunch && (long long)per_cu * prop.multiProcessorCount >= h->n_blocks) ? 1 : 0;
+        const long long resident = prop.cooperativeLaunch ? (long long)per_cu * prop.multiProcessorCount : 0;   // workgroups
+        h->async_fit = 0;
+        for (int lanes = (h->flags & 32) ? 16 : 64; lanes <= 64; lanes *= 2) {
+            const int per_block = (kBlock / 64) * lanes;
+            if (((long long)h->cfg.n_lp + per_block - 1) / per_block <= resident) { h->async_lanes = lanes; h->async_fit = 1; break; }
+        }
     }
     if (!h->async_fit) return 0;
     NetState NX = h->NX;
@@ -1757,6 +1778,15 @@ void hs_engine_destroy(hs_engine *h) {
     if (h->ev_k1) hipEventDestroy(h->ev_k1);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
+}
+
+int hs_debug_async_counters(hs_engine *h, unsigned long long out[4]) {
+    if (!h || !out) return HS_E_INVALID;
+    Totals t;
+    if (hipSetDevice(h->cfg.device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess ||
+        hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost) != hipSuccess) return HS_E_HIP;
+    for (int i = 0; i < 4; ++i) out[i] = t.dbg[i];
+    return HS_OK;
 }
 
 int hs_debug_set_flags(hs_engine *h, int flags) {

@@ -117,6 +117,7 @@ struct Totals {                 // engine-wide accumulators (device memory)
     int qoverflow;
     unsigned int done;          // last-block ticket
     int pad;
+    unsigned long long dbg[4];  // asynchronous engine telemetry: sum of wave iterations, max, groups run, waves
 };
 
 struct Candidate {              // an LP's first event beyond end_ns (SINGLE-mode overshoot election)

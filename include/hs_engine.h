@@ -355,6 +355,9 @@ void hs_engine_destroy(hs_engine *h);
  * the fast path); bit 4 (16) runs a station network on the windowed engine (one launch per window) even when the
  * asynchronous whole-run engine is available. */
 int hs_debug_set_flags(hs_engine *h, int flags);
+/* Debug: telemetry of the last asynchronous network run: {sum over wavefronts of loop iterations, max over wavefronts,
+ * timestamp groups run (sum over LPs), wavefronts}. */
+int hs_debug_async_counters(hs_engine *h, unsigned long long out[4]);
 
 int hs_debug_draws(int32_t device, uint64_t seed, uint64_t sid, uint64_t k0, int64_t n, double rate,
                    double *u, double *e, int64_t *ns);

@@ -25,3 +25,9 @@ with eng:
     s = eng.summary()
     print(json.dumps(dict(bench_ms=[float(x) for x in k], events=s.events_processed, ev_per_s=float(s.events_processed / (k.mean() * 1e-3)),
                           us_per_window=float(k.mean()) * 1e3 / s.launches)))
+    import ctypes as C
+    from happy_simulator_amd import _native as N
+    out = (C.c_ulonglong * 4)()
+    if N.lib().hs_debug_async_counters(eng._h, out) == 0 and out[3]:
+        print(json.dumps(dict(async_wave_iterations_avg=out[0] / out[3], async_wave_iterations_max=out[1],
+                              groups_per_lp=out[2] / a.n, waves=out[3])))
