@@ -27,9 +27,12 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_abi_version_and_struct_sizes(lib):
-    assert lib.hs_abi_version() == N.ABI_VERSION == 3
+    assert lib.hs_abi_version() == N.ABI_VERSION == 4
     assert C.sizeof(N.Config) == 56
-    assert C.sizeof(N.Summary) == 8 * (1 + 11 + 1 + 1 + 1 + 1) + 8 + 8 + 8 + 8 + 8
+    assert N.EV_KINDS == 13 and len(N.EV_NAMES) == 13
+    assert C.sizeof(N.Summary) == 8 * (1 + 13 + 1 + 1 + 1 + 1) + 8 + 8 + 8 + 8 + 8
+    assert C.sizeof(N.LbConfig) == 56 and C.sizeof(N.LbSources) == 40 and C.sizeof(N.LbBackends) == 64
+    assert C.sizeof(N.LbStats) == 88
 
 
 def test_no_gpu_means_loud_failure(lib):
@@ -44,6 +47,21 @@ def test_no_gpu_means_loud_failure(lib):
 
     with pytest.raises(N.EngineUnavailable):
         StationEngine(StationArrays.uniform(4), mode=N.MODE_SINGLE, horizon_ns=10**9)
+    # the load-balancer engine: same rule
+    import numpy as np
+
+    from happy_simulator_amd.lb_engine import LbBackendArrays, LbSourceArrays, LoadBalancerEngine
+
+    lcfg = N.LbConfig(C.sizeof(N.LbConfig), 0, 1, 1, 0, 10**9, 42, 10, 1, 0)
+    rate, ncl, off = np.array([1.0]), np.array([4], np.int64), np.array([0, 1], np.int32)
+    src = N.LbSources(None, rate.ctypes.data, None, ncl.ctypes.data, None)
+    names = C.create_string_buffer(b"s")
+    be = N.LbBackends(None, None, None, None, None, None, C.cast(names, C.c_void_p).value, off.ctypes.data)
+    assert lib.hs_lb_create(C.byref(lcfg), C.byref(src), C.byref(be), C.byref(h)) == N.HS_E_NO_DEVICE
+    assert b"no CPU fallback" in lib.hs_lb_last_error(None)
+    with pytest.raises(N.EngineUnavailable):
+        LoadBalancerEngine(LbSourceArrays(n=1, src_rate=rate, n_clients=ncl), LbBackendArrays(n=1, names=["s"]),
+                           virtual_nodes=10, horizon_ns=10**9)
 
 
 def test_bad_config_is_rejected_before_touching_a_device(lib):
