@@ -183,8 +183,124 @@ static double exp1(hso_sim *s, double u) {
     return hsr_exp1(u);
 }
 
-/* ArrivalTimeProvider.next_arrival_time, constant-rate fast path
- * (load/arrival_time_provider.py:57-82): t' = from_seconds(to_seconds(t) + E/rate). */
+/* ---- time-varying profiles: the general path of ArrivalTimeProvider.next_arrival_time ------------------------------
+ * (load/arrival_time_provider.py:84-144) with numerics/integration.py:11-90 and numerics/root_finding.py:27-152. */
+typedef struct { int32_t kind; double p[4]; } hso_profile;
+
+/* rate_fn(t) = profile.get_rate(Instant.from_seconds(t))   (arrival_time_provider.py:85-86, load/profile.py:52-113) */
+static double prof_rate(const hso_profile *pf, double t_seconds) {
+    double t = hsr_seconds_from_ns(hsr_ns_from_seconds(t_seconds));
+    if (pf->kind == HSO_PROF_LINEAR_RAMP) {
+        double duration = pf->p[0], start = pf->p[1], end = pf->p[2];
+        if (t <= 0) return start;
+        if (t >= duration) return end;
+        double fraction = t / duration;
+        return start + fraction * (end - start);
+    }
+    if (pf->kind == HSO_PROF_SPIKE) {
+        double baseline = pf->p[0], spike = pf->p[1], warmup = pf->p[2], dur = pf->p[3];
+        if (t < warmup) return baseline;
+        if (t < warmup + dur) return spike;
+        return baseline;
+    }
+    return pf->p[0];
+}
+static double simpson3(double fa, double fm, double fb, double h) { return h / 3.0 * (fa + 4.0 * fm + fb); }
+static double simpson_adaptive(const hso_profile *pf, double a, double b, double fa, double fb, double s_whole, int depth,
+                               double tol) {
+    double m = (a + b) / 2.0;
+    double h = (b - a) / 2.0;
+    double fm = prof_rate(pf, m);
+    double lm = (a + m) / 2.0;
+    double rm = (m + b) / 2.0;
+    double flm = prof_rate(pf, lm);
+    double frm = prof_rate(pf, rm);
+    double s_left = simpson3(fa, flm, fm, h / 2.0);
+    double s_right = simpson3(fm, frm, fb, h / 2.0);
+    double s_combined = s_left + s_right;
+    double error_estimate = (s_combined - s_whole) / 15.0;
+    if (depth >= 50 || fabs(error_estimate) < tol) return s_combined + error_estimate;   /* Richardson extrapolation */
+    double left = simpson_adaptive(pf, a, m, fa, fm, s_left, depth + 1, tol / 2.0);
+    double right = simpson_adaptive(pf, m, b, fm, fb, s_right, depth + 1, tol / 2.0);
+    return left + right;
+}
+static double integrate_simpson(const hso_profile *pf, double a, double b, double tol) {
+    if (a == b) return 0.0;
+    if (a > b) return -integrate_simpson(pf, b, a, tol);
+    double fa = prof_rate(pf, a), fb = prof_rate(pf, b);
+    double m = (a + b) / 2.0;
+    double fm = prof_rate(pf, m);
+    double h = (b - a) / 2.0;
+    double s_whole = simpson3(fa, fm, fb, h);
+    return simpson_adaptive(pf, a, b, fa, fb, s_whole, 0, tol);
+}
+typedef struct { const hso_profile *pf; double t_start, target; } hso_objective;
+static double objective(const hso_objective *o, double t) { return integrate_simpson(o->pf, o->t_start, t, 1e-10) - o->target; }
+static double dmin2(double a, double b) { return b < a ? b : a; }   /* Python min(a, b) */
+static double dmax2(double a, double b) { return b > a ? b : a; }   /* Python max(a, b) */
+
+/* brentq(f, a, b): numerics/root_finding.py:27-152.  Returns 1 when converged. */
+static int brentq(const hso_objective *o, double a, double b, double *root) {
+    const double xtol = 1e-12, rtol = 4 * 2.220446049250313e-16;
+    double fa = objective(o, a), fb = objective(o, b);
+    if (fa * fb > 0) return 0;                                       /* ValueError in the reference */
+    if (fabs(fa) < fabs(fb)) { double t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
+    double c = a, fc = fa, d = b - a, e = d;
+    for (int iteration = 0; iteration < 100; ++iteration) {
+        double tol = 2.0 * rtol * fabs(b) + xtol;
+        double m = (c - b) / 2.0;
+        if (fabs(m) <= tol || fb == 0) { *root = b; return 1; }
+        if (fabs(e) >= tol && fabs(fa) > fabs(fb)) {
+            double sr = fb / fa, p, q;
+            if (a == c) { p = 2.0 * m * sr; q = 1.0 - sr; }
+            else {
+                q = fa / fc;
+                double r = fb / fc;
+                p = sr * (2.0 * m * q * (q - r) - (b - a) * (r - 1.0));
+                q = (q - 1.0) * (r - 1.0) * (sr - 1.0);
+            }
+            if (p > 0) q = -q; else p = -p;
+            if (2.0 * p < dmin2(3.0 * m * q - fabs(tol * q), fabs(e * q))) { e = d; d = p / q; }
+            else { d = m; e = m; }
+        } else { d = m; e = m; }
+        a = b; fa = fb;
+        if (fabs(d) > tol) b = b + d;
+        else if (m > 0) b = b + tol;
+        else b = b - tol;
+        fb = objective(o, b);
+        if (fb * fc > 0) { c = a; fc = fa; d = b - a; e = d; }
+        else if (fabs(fc) < fabs(fb)) { a = b; b = c; c = a; fa = fb; fb = fc; fc = fa; }
+    }
+    *root = b;
+    return 0;
+}
+int64_t hso_profile_next_arrival(int32_t prof_kind, const double p[4], int64_t t_start_ns, double target_area) {
+    hso_profile pf;
+    pf.kind = prof_kind;
+    memcpy(pf.p, p, sizeof pf.p);
+    double t_start_sec = hsr_seconds_from_ns(t_start_ns);
+    hso_objective o = {&pf, t_start_sec, target_area};
+    double current_rate = prof_rate(&pf, t_start_sec), t_high;
+    if (current_rate > 0) {
+        double estimated_delay = (target_area / current_rate) * 2.0;          /* optimistic linear prediction */
+        estimated_delay = dmax2(1e-9, dmin2(estimated_delay, 3600.0));
+        t_high = t_start_sec + estimated_delay;
+    } else t_high = t_start_sec + 0.1;
+    double t_low = t_start_sec;
+    int found = 0;
+    for (int i = 0; i < 50; ++i) {                                             /* bracket search, geometric expansion */
+        if (objective(&o, t_high) > 0) { found = 1; break; }
+        double step = dmax2(1e-6, t_high - t_low);
+        t_high += step * 2.0;
+    }
+    if (!found) return -1;                                                     /* RuntimeError in the reference */
+    double root;
+    if (!brentq(&o, t_low, t_high, &root)) return -1;
+    return hsr_ns_from_seconds(root);                                          /* Instant.from_seconds(result.root) */
+}
+
+/* ArrivalTimeProvider.next_arrival_time (load/arrival_time_provider.py:57-144): constant-rate fast path
+ * t' = from_seconds(to_seconds(t) + E/rate), otherwise the general path above. */
 static int64_t next_arrival(hso_sim *s, int32_t n) {
     hso_node *nd = &s->nodes[n];
     double target_area;
@@ -192,6 +308,11 @@ static int64_t next_arrival(hso_sim *s, int32_t n) {
         target_area = exp1(s, draw_uniform(s, n, HS_STREAM_ARRIVAL, &nd->arr_draws)); /* poisson_arrival.py:31 */
     else
         target_area = 1.0;                                                             /* constant_arrival.py:23 */
+    if (s->g.prof_kind && s->g.prof_kind[n] != HSO_PROF_CONSTANT) {
+        int64_t t = hso_profile_next_arrival(s->g.prof_kind[n], s->g.prof_p + 4 * (size_t)n, nd->arr_time_ns, target_area);
+        nd->arr_time_ns = t < 0 ? INT64_MAX : t;                    /* the reference raises: the run would abort */
+        return nd->arr_time_ns;
+    }
     double t_start = hsr_seconds_from_ns(nd->arr_time_ns);
     double t_next = t_start + target_area / s->g.rate[n];
     nd->arr_time_ns = hsr_ns_from_seconds(t_next);
@@ -578,7 +699,12 @@ hso_sim *hso_create(const hso_graph *g, const hso_params *p) {
     DUP(arr_kind, int32_t); DUP(rate, double); DUP(stop_after_ns, int64_t);
     DUP(concurrency, int32_t); DUP(lat_kind, int32_t); DUP(lat_mean, double); DUP(lat_min, double);
     DUP(queue_cap, int64_t); DUP(rt_off, int32_t); DUP(rt_cnt, int32_t);
-    DUP(n_clients, int64_t); DUP(vnodes, int32_t);
+    DUP(n_clients, int64_t); DUP(vnodes, int32_t); DUP(prof_kind, int32_t);
+    {
+        double *pp = (double *)calloc((size_t)n * 4 + 1, sizeof(double));
+        if (g->prof_p) memcpy(pp, g->prof_p, (size_t)n * 4 * sizeof(double));
+        s->g.prof_p = pp;
+    }
     {
         int32_t *no = (int32_t *)calloc((size_t)n + 1, sizeof(int32_t));
         if (g->name_off) memcpy(no, g->name_off, ((size_t)n + 1) * sizeof(int32_t));
@@ -722,6 +848,7 @@ void hso_destroy(hso_sim *s) {
     free((void *)s->g.kind); free((void *)s->g.target); free((void *)s->g.stream_base);
     free((void *)s->g.arr_kind); free((void *)s->g.rate); free((void *)s->g.stop_after_ns);
     free((void *)s->g.concurrency); free((void *)s->g.lat_kind); free((void *)s->g.lat_mean);
+    free((void *)s->g.prof_kind); free((void *)s->g.prof_p);
     free((void *)s->g.n_clients); free((void *)s->g.vnodes); free((void *)s->g.names); free((void *)s->g.name_off);
     free((void *)s->g.lat_min); free((void *)s->g.queue_cap); free((void *)s->g.rt_off); free((void *)s->g.rt_cnt); free((void *)s->g.rt_targets);
     free(s->nodes); free(s->heap); free(s->reqs);

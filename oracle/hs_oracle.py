@@ -19,6 +19,7 @@ SOURCE, SERVER, SINK, LINK, ROUTER, LB = 0, 1, 2, 3, 4, 5
 ARR_POISSON, ARR_CONSTANT = 0, 1
 LAT_EXP, LAT_CONST = 0, 1
 RNG_PHILOX, RNG_MT19937 = 0, 1
+PROF_CONSTANT, PROF_LINEAR_RAMP, PROF_SPIKE = 0, 1, 2
 EV_KINDS = 13
 EV_NAMES = ["source", "enqueue", "notify", "poll", "deliver", "work", "continuation", "sink", "link", "link_cont",
             "route", "lb", "lb_resp"]
@@ -59,6 +60,8 @@ class _Graph(C.Structure):
         ("vnodes", C.POINTER(C.c_int32)),
         ("names", C.c_char_p),
         ("name_off", C.POINTER(C.c_int32)),
+        ("prof_kind", C.POINTER(C.c_int32)),
+        ("prof_p", C.POINTER(C.c_double)),
     ]
 
 
@@ -103,6 +106,8 @@ def lib():
         L.hso_lb_select.restype = C.c_int32
         L.hso_lb_select.argtypes = [C.c_void_p, C.c_int32, C.c_char_p]
         L.hso_md5.argtypes = [C.c_char_p, C.c_int64, C.c_void_p]
+        L.hso_profile_next_arrival.restype = C.c_int64
+        L.hso_profile_next_arrival.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_double]
         L.hso_sink_count.restype = C.c_int64
         L.hso_sink_count.argtypes = [C.c_void_p, C.c_int32]
         L.hso_read_sink.restype = C.c_int64
@@ -144,21 +149,28 @@ class Graph:
     n_clients: list = field(default_factory=list)
     vnodes: list = field(default_factory=list)
     names: list = field(default_factory=list)        # entity names (only an LB's backends need theirs)
+    prof_kind: list = field(default_factory=list)
+    prof_p: list = field(default_factory=list)       # 4 parameters per node
 
     def _add(self, **kw) -> int:
         defaults = dict(
             kind=0, target=-1, stream_base=len(self.kind), arr_kind=0, rate=0.0, stop_after_ns=-1,
             concurrency=1, lat_kind=LAT_CONST, lat_mean=0.0, lat_min=0.0, queue_cap=-1, rt_off=0, rt_cnt=0,
-            n_clients=0, vnodes=0, names="",
+            n_clients=0, vnodes=0, names="", prof_kind=PROF_CONSTANT, prof_p=(0.0, 0.0, 0.0, 0.0),
         )
         defaults.update(kw)
         for k, v in defaults.items():
             getattr(self, k).append(v)
         return len(self.kind) - 1
 
-    def source(self, arr_kind, rate, target=-1, stop_after_ns=-1, stream_base=None, n_clients=0) -> int:
+    def source(self, arr_kind, rate, target=-1, stop_after_ns=-1, stream_base=None, n_clients=0, profile=None) -> int:
+        """profile: None (ConstantRateProfile(rate)) | ("ramp", duration_s, start_rate, end_rate) |
+        ("spike", baseline_rate, spike_rate, warmup_s, spike_duration_s)."""
         kw = dict(kind=SOURCE, arr_kind=arr_kind, rate=float(rate), target=target, stop_after_ns=stop_after_ns,
                   n_clients=int(n_clients))
+        if profile is not None:
+            kw["prof_kind"] = PROF_LINEAR_RAMP if profile[0] == "ramp" else PROF_SPIKE
+            kw["prof_p"] = tuple(float(x) for x in profile[1:]) + (0.0,) * (5 - len(profile))
         if stream_base is not None:
             kw["stream_base"] = stream_base
         return self._add(**kw)
@@ -238,6 +250,8 @@ def run(g: Graph, end_ns: int, start_ns: int = 0, seed: int = 42, rng_mode: int 
         "rt_cnt": np.asarray(g.rt_cnt, np.int32),
         "rt_targets": np.asarray(g.rt_targets if g.rt_targets else [0], np.int32),
         "n_clients": np.asarray(g.n_clients, np.int64), "vnodes": np.asarray(g.vnodes, np.int32),
+        "prof_kind": np.asarray(g.prof_kind, np.int32),
+        "prof_p": np.asarray(g.prof_p, np.float64).reshape(-1),
     }
     enc = [nm.encode() for nm in g.names]
     names_blob = b"".join(enc) + b"\0"
@@ -331,6 +345,13 @@ def lb_topology(n_sources, n_backends, rate, mean, vnodes, n_clients, concurrenc
     g.vnodes[lb] = int(vnodes)
     g.rt_targets.extend(bes)
     return g
+
+
+def profile_next_arrival(profile, t_start_ns: int, target_area: float) -> int:
+    """ArrivalTimeProvider.next_arrival_time (general path) for ("ramp", ...) / ("spike", ...) profiles; -1 = raises."""
+    kind = PROF_LINEAR_RAMP if profile[0] == "ramp" else PROF_SPIKE
+    p = (C.c_double * 4)(*(tuple(float(x) for x in profile[1:]) + (0.0,) * (5 - len(profile))))
+    return int(lib().hso_profile_next_arrival(kind, p, int(t_start_ns), float(target_area)))
 
 
 def md5(data: bytes) -> bytes:

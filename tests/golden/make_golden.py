@@ -48,7 +48,7 @@ from happysimulator.core.event import ProcessContinuation  # noqa: E402
 from happysimulator.core.temporal import Duration  # noqa: E402
 from happysimulator.distributions.latency_distribution import LatencyDistribution  # noqa: E402
 from happysimulator.load.arrival_time_provider import ArrivalTimeProvider  # noqa: E402
-from happysimulator.load.profile import ConstantRateProfile  # noqa: E402
+from happysimulator.load.profile import ConstantRateProfile, LinearRampProfile, SpikeProfile  # noqa: E402
 from happysimulator.load.providers.constant_arrival import ConstantArrivalTimeProvider  # noqa: E402
 from happysimulator.load.source import SimpleEventProvider  # noqa: E402
 
@@ -139,6 +139,16 @@ def build_chains(spec, chain_ids, seed):
     arr = _per_chain(spec["arr"], n)
     svc = _per_chain(spec["svc"], n)
     stop = spec.get("stop_after_s")
+    profiles = spec.get("profile") or [None] * n          # per chain: None | ["ramp", d, s, e] | ["spike", b, s, w, d]
+
+    def make_profile(i):
+        pr = profiles[i]
+        if pr is None:
+            return ConstantRateProfile(rate=rate[i])
+        if pr[0] == "ramp":
+            return LinearRampProfile(duration_s=pr[1], start_rate=pr[2], end_rate=pr[3])
+        return SpikeProfile(baseline_rate=pr[1], spike_rate=pr[2], warmup_s=pr[3], spike_duration_s=pr[4])
+
     sources, entities, handles = [], [], []
     for local, i in enumerate(chain_ids):
         base = i if spec["mode"] == "single" else 0
@@ -154,10 +164,9 @@ def build_chains(spec, chain_ids, seed):
         if spec["rng"] == "philox":
             stop_instant = None if stop is None else Instant.from_seconds(stop)
             if arr[i] == "poisson":
-                prov = PhiloxPoissonArrival(ConstantRateProfile(rate=rate[i]), Instant.Epoch,
-                                            hs.Stream(seed, base, hs.STREAM_ARRIVAL))
+                prov = PhiloxPoissonArrival(make_profile(i), Instant.Epoch, hs.Stream(seed, base, hs.STREAM_ARRIVAL))
             else:
-                prov = ConstantArrivalTimeProvider(ConstantRateProfile(rate=rate[i]), start_time=Instant.Epoch)
+                prov = ConstantArrivalTimeProvider(make_profile(i), start_time=Instant.Epoch)
             source = Source(f"src{i}", SimpleEventProvider(server, "Request", stop_instant), prov)
         else:
             factory = Source.poisson if arr[i] == "poisson" else Source.constant
@@ -510,6 +519,17 @@ CASES = [
          end_s=20.0, rng="philox", seed=99, mode="single", trace=True),
     dict(name="philox_no_downstream", n_chains=2, arr="poisson", rate=8.0, svc="exp", mean=0.1, downstream=False,
          end_s=15.0, rng="philox", seed=8, mode="single", trace=True),
+    # --- time-varying profiles: the general path of ArrivalTimeProvider.next_arrival_time ------
+    dict(name="profile_ramp_poisson", n_chains=3, arr="poisson", rate=1.0, svc="exp", mean=[0.05, 0.03, 0.08],
+         concurrency=[1, 2, 1], profile=[["ramp", 15.0, 5.0, 30.0], ["ramp", 10.0, 40.0, 4.0], ["ramp", 8.0, 0.0, 20.0]],
+         end_s=25.0, rng="philox", seed=21, mode="single", trace=True),
+    dict(name="profile_spike_const", n_chains=2, arr="constant", rate=1.0, svc="exp", mean=[0.02, 0.05],
+         queue_cap=[None, 5], profile=[["spike", 10.0, 150.0, 3.0, 2.0], ["spike", 4.0, 60.0, 1.5, 4.0]],
+         end_s=10.0, rng="philox", seed=22, mode="single", trace=True),
+    dict(name="profile_mixed_4", n_chains=4, arr=["poisson", "constant", "poisson", "constant"], rate=[8.0, 1.0, 1.0, 1.0],
+         svc=["exp", "const", "exp", "exp"], mean=[0.1, 0.04, 0.03, 0.06],
+         profile=[None, ["ramp", 12.0, 20.0, 2.0], ["spike", 6.0, 90.0, 4.0, 3.0], ["ramp", 20.0, 2.0, 25.0]],
+         end_s=16.0, rng="philox", seed=23, mode="single", trace=True),
     dict(name="philox_256chains_single", n_chains=256, arr="poisson", rate=8.0, svc="exp", mean=0.1, end_s=10.0,
          rng="philox", seed=2026, mode="single", trace=False),
     dict(name="philox_64chains_replicas", n_chains=64, arr="poisson", rate=8.0, svc="exp", mean=0.1, end_s=20.0,

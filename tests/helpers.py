@@ -63,6 +63,7 @@ def spec_chain_params(spec):
         stop_ns=-1 if spec.get("stop_after_s") is None else ns_from_seconds(spec["stop_after_s"]),
         downstream=spec.get("downstream", True),
         end_ns=ns_from_seconds(spec["end_s"]),
+        profile=[None if pr is None else tuple(pr) for pr in (spec.get("profile") or [None] * n)],
     )
 
 
@@ -74,7 +75,8 @@ def oracle_graph_for(spec, chain_ids, stream_bases):
     nodes = {}
     srcs = []
     for c, base in zip(chain_ids, stream_bases):
-        srcs.append(g.source(p["arr"][c], p["rate"][c], stop_after_ns=p["stop_ns"], stream_base=base))
+        srcs.append(g.source(p["arr"][c], p["rate"][c], stop_after_ns=p["stop_ns"], stream_base=base,
+                             profile=p["profile"][c]))
     for k, (c, base) in enumerate(zip(chain_ids, stream_bases)):
         sv = g.server(p["svc"][c], p["mean"][c], concurrency=p["conc"][c], queue_cap=p["qcap"][c], stream_base=base)
         sk = g.sink() if p["downstream"] else -1

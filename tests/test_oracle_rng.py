@@ -86,3 +86,45 @@ def test_counter_overshoot_known_answer():
     r = O.run(g, 60_000_000_000)
     assert r.generated[s] == 61
     assert r.received[k] == 60
+
+
+class TestProfileArrivalKnownAnswers:
+    """The reference's own golden vectors for time-varying profiles, restated
+    (tests/regression/test_arrival_time_regression.py:46-103,126-165: ConstantArrivalTimeProvider over LinearRampProfile /
+    SpikeProfile, tolerance 1e-8 upstream).  The oracle's general path (adaptive Simpson + bracket + Brent,
+    load/arrival_time_provider.py:84-144) is additionally bit-exact against the LIVE reference through the
+    tests/golden/profile_*.npz fixtures."""
+
+    LINEAR_RAMP_10_100_FIRST_10 = [0.095864499, 0.184655976, 0.267741515, 0.346097448, 0.420449859, 0.49135612,
+                                   0.55925515, 0.624499924, 0.687379335, 0.748133387]
+    LINEAR_RAMP_100_10_FIRST_10 = [0.010004504, 0.020018032, 0.030040609, 0.040072259, 0.050113007, 0.060162878,
+                                   0.070221897, 0.080290089, 0.090367479, 0.100454092]
+    SPIKE_PROFILE_FIRST_30 = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.799999999, 0.899999998, 0.999999998, 1.099999998,
+                              1.199999998, 1.299999998, 1.399999998, 1.499999998, 1.599999998, 1.699999998, 1.799999998,
+                              1.899999998, 1.999999997, 2.009999997, 2.019999996, 2.029999996, 2.039999995, 2.049999994,
+                              2.059999994, 2.069999993, 2.079999993, 2.089999992, 2.099999991]
+
+    @staticmethod
+    def _arrivals(profile, n):
+        t, out = 0, []
+        for _ in range(n):
+            t = O.profile_next_arrival(profile, t, 1.0)      # ConstantArrivalTimeProvider: target area 1.0
+            assert t >= 0
+            out.append(t / 1e9)
+        return out
+
+    def test_linear_ramp_up(self):
+        got = self._arrivals(("ramp", 10.0, 10.0, 100.0), 10)
+        assert max(abs(a - b) for a, b in zip(got, self.LINEAR_RAMP_10_100_FIRST_10)) < 1e-8
+
+    def test_linear_ramp_down(self):
+        got = self._arrivals(("ramp", 10.0, 100.0, 10.0), 10)
+        assert max(abs(a - b) for a, b in zip(got, self.LINEAR_RAMP_100_10_FIRST_10)) < 1e-8
+
+    def test_spike(self):
+        got = self._arrivals(("spike", 10.0, 100.0, 2.0, 1.0), 30)
+        assert max(abs(a - b) for a, b in zip(got, self.SPIKE_PROFILE_FIRST_30)) < 1e-8
+
+    def test_zero_rate_forever_is_an_error(self):
+        """`RuntimeError: Could not find event ...` upstream (arrival_time_provider.py:124-132)."""
+        assert O.profile_next_arrival(("ramp", 1.0, 0.0, 0.0), 0, 1.0) == -1
