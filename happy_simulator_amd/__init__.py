@@ -15,8 +15,9 @@ from ._native import EngineError, EngineUnavailable  # noqa: F401
 from .core.temporal import Duration, Instant  # noqa: F401
 from .entities import (BackendInfo, ClientKeyEventProvider, ConsistentHash, ConstantArrivalTimeProvider,  # noqa: F401
                        ConstantLatency, ConstantRateProfile, Counter, Entity, ExponentialLatency, FIFOQueue,
-                       LatencyTracker, LoadBalancer, LoadBalancerStats, NetworkLink, NetworkLinkStats,
-                       PoissonArrivalTimeProvider, RandomRouter, Server, ServerStats, SimpleEventProvider, Sink, Source)
+                       LatencyTracker, LinearRampProfile, LoadBalancer, LoadBalancerStats, NetworkLink, NetworkLinkStats,
+                       PoissonArrivalTimeProvider, RandomRouter, Server, ServerStats, SimpleEventProvider, Sink, Source,
+                       SpikeProfile)
 from .lowering import UnsupportedTopology  # noqa: F401
 from .parallel import (ParallelResult, ParallelRunner, ParallelSimulation, ParallelSimulationSummary,  # noqa: F401
                        PartitionLink, RunConfig, SimulationPartition, reduce_summaries, shard_range)

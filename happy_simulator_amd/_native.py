@@ -27,6 +27,7 @@ HS_OK = 0
 HS_E_INVALID, HS_E_NO_DEVICE, HS_E_HIP, HS_E_UNSUPPORTED, HS_E_OVERFLOW, HS_E_STATE = -1, -2, -3, -4, -5, -6
 MODE_SINGLE, MODE_REPLICAS = 0, 1
 SRC_NONE, SRC_POISSON, SRC_CONSTANT = 0, 1, 2
+PROF_CONSTANT, PROF_LINEAR_RAMP, PROF_SPIKE = 0, 1, 2
 LAT_EXPONENTIAL, LAT_CONSTANT, LAT_NO_SERVER = 0, 1, 2
 EGRESS_NONE, EGRESS_SINK, EGRESS_LINK, EGRESS_ROUTER = 0, 1, 2, 3
 EV_KINDS = 13
@@ -58,6 +59,7 @@ class Stations(C.Structure):
         ("src_kind", C.c_void_p), ("src_rate", C.c_void_p), ("src_stop_after_ns", C.c_void_p),
         ("concurrency", C.c_void_p), ("svc_kind", C.c_void_p), ("svc_mean_s", C.c_void_p),
         ("queue_cap", C.c_void_p), ("egress", C.c_void_p), ("seed", C.c_void_p), ("stream_base", C.c_void_p),
+        ("src_profile_kind", C.c_void_p), ("src_profile_params", C.c_void_p),
     ]
 
 
@@ -123,7 +125,7 @@ class LbStats(C.Structure):
 
 def sources() -> list[str]:
     return [os.path.join(CSRC, f) for f in ("hs_engine.hip", "hs_lb.hip", "hs_station.hpp", "hs_netstation.hpp",
-                                            "hs_device.hpp", "hs_radix.hpp")] + [
+                                            "hs_device.hpp", "hs_radix.hpp", "hs_profile.hpp")] + [
         os.path.join(INCLUDE, "hs_engine.h")]
 
 

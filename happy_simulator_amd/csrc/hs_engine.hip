@@ -58,8 +58,8 @@ __device__ __forceinline__ Candidate wave_min_cand(Candidate c) {
     return c;
 }
 
-template <int C>
-__device__ __forceinline__ void load_station(Station<C> &S, const StationParams &P, const StationState &X,
+template <int C, bool PF>
+__device__ __forceinline__ void load_station(Station<C, PF> &S, const StationParams &P, const StationState &X,
                                              const RecordLogs &L, int lp, int n, uint8_t (*qmem)[kBlock],
                                              double (*ring_a)[kBlock], double (*ring_s)[kBlock], int tid) {
     S.lp = lp; S.n = n;
@@ -70,6 +70,12 @@ __device__ __forceinline__ void load_station(Station<C> &S, const StationParams 
     S.svc_const_s = seconds_from_ns(ns_from_seconds(S.svc_mean));    // ConstantLatency: from_seconds(mean).to_seconds()
     S.svc_const_ns = ns_from_seconds(S.svc_const_s);
     S.stop_ns = P.src_stop[lp]; S.qcap = P.qcap[lp];
+    S.prof.kind = kProfConstant;
+    if constexpr (PF) {
+        S.prof.kind = P.prof_kind[lp];
+        S.prof.p0 = P.prof_p[lp]; S.prof.p1 = P.prof_p[(size_t)n + lp]; S.prof.p2 = P.prof_p[(size_t)2 * n + lp];
+        S.prof.p3 = P.prof_p[(size_t)3 * n + lp];
+    }
     S.A = X.A[lp]; S.seqA = X.seqA[lp]; S.crtA = X.crtA[lp]; S.arr_time = X.arr_time[lp];
     S.buf = X.buf[lp]; S.active = X.active[lp]; S.seq = X.seq[lp];
     S.generated = X.generated[lp]; S.accepted = X.accepted[lp]; S.dropped = X.dropped[lp];
@@ -98,9 +104,9 @@ __device__ __forceinline__ void load_station(Station<C> &S, const StationParams 
     for (int i = 0; i < qn; ++i) S.qpush((q >> (8 * i)) & 0xffu);
 }
 
-template <int C>
-__device__ __forceinline__ void store_station(const Station<C> &Sc, const StationState &X, int lp, int n) {
-    Station<C> &S = const_cast<Station<C> &>(Sc);
+template <int C, bool PF>
+__device__ __forceinline__ void store_station(const Station<C, PF> &Sc, const StationState &X, int lp, int n) {
+    Station<C, PF> &S = const_cast<Station<C, PF> &>(Sc);
     X.A[lp] = S.A; X.seqA[lp] = S.seqA; X.crtA[lp] = S.crtA; X.arr_time[lp] = S.arr_time;
     X.buf[lp] = S.buf; X.active[lp] = S.active; X.seq[lp] = S.seq;
     X.generated[lp] = S.generated; X.accepted[lp] = S.accepted; X.dropped[lp] = S.dropped;
@@ -127,8 +133,8 @@ __device__ __forceinline__ void store_station(const Station<C> &Sc, const Statio
 }
 
 // first pending event of an LP: time, creation time, which root
-template <int C>
-__device__ __forceinline__ Candidate make_candidate(const Station<C> &S) {
+template <int C, bool PF>
+__device__ __forceinline__ Candidate make_candidate(const Station<C, PF> &S) {
     Candidate c;
     c.lp = S.lp; c.valid = 0; c.t = kInfNs; c.t_created = 0;
     if (S.qn > 0) {   // a group already in progress keeps the floor
@@ -148,8 +154,8 @@ __device__ __forceinline__ Candidate make_candidate(const Station<C> &S) {
 }
 
 // process exactly ONE event beyond end_ns: the first micro-event of the LP's next group
-template <int C>
-__device__ __forceinline__ void overshoot_one(Station<C> &S) {
+template <int C, bool PF>
+__device__ __forceinline__ void overshoot_one(Station<C, PF> &S) {
     if (S.qn > 0) {   // continue the in-progress group by one event
         // (only reachable when a previous window ended inside this group and the new end is still before it)
         return;
@@ -166,6 +172,14 @@ __device__ __forceinline__ void overshoot_one(Station<C> &S) {
 // =============================================================================================
 // kernels
 // =============================================================================================
+
+__device__ __noinline__ int64_t first_profile_arrival(const StationParams &P, int lp, int n, int64_t start_ns, double area) {
+    Profile pf;
+    pf.kind = P.prof_kind[lp];
+    pf.p0 = P.prof_p[lp]; pf.p1 = P.prof_p[(size_t)n + lp]; pf.p2 = P.prof_p[(size_t)2 * n + lp];
+    pf.p3 = P.prof_p[(size_t)3 * n + lp];
+    return prof_next_arrival(pf, start_ns, area);
+}
 
 // Simulation.__init__ bootstrap (core/simulation.py:145-154, load/source.py:120-140): every Source draws
 // its first arrival from start_ns.  Also zeroes the per-LP state.
@@ -197,8 +211,12 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
             area = exp1_from_uniform(s.next_uniform());
             arr_k = 1;
         }
-        const double t_next = __dadd_rn(seconds_from_ns(start_ns), __ddiv_rn(area, P.src_rate[lp]));
-        arr_time = ns_from_seconds(t_next);
+        if (P.prof_kind[lp] != kProfConstant) {   // time-varying rate: the general path (hs_profile.hpp)
+            arr_time = first_profile_arrival(P, lp, n, start_ns, area);
+        } else {
+            const double t_next = __dadd_rn(seconds_from_ns(start_ns), __ddiv_rn(area, P.src_rate[lp]));
+            arr_time = ns_from_seconds(t_next);
+        }
         A = arr_time;
     }
     if (NX.next_time != nullptr) NX.next_time[lp] = A;
@@ -217,7 +235,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
 // The hot kernel: every LP advances to end_ns (== Simulation._execute_until for its events), then the
 // one-event overshoot is applied (per LP in REPLICAS mode; to the globally first event in SINGLE mode,
 // elected across workgroups with a last-block reduction).
-template <int C>
+template <int C, bool PF>
 __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, StationState X, RecordLogs L, Totals *tot,
                                                          Candidate *cands, int n, int64_t end_ns, int mode, int flags) {
     __shared__ uint8_t qmem[kQCap][kBlock];
@@ -237,11 +255,11 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
     const long long cur = tot->cur_time;   // SINGLE: Simulation._current_time (written by the previous launch)
     __syncthreads();
 
-    Station<C> S;
+    Station<C, PF> S;
     Candidate mine;
     mine.valid = 0; mine.t = kInfNs; mine.t_created = 0; mine.lp = lp;
     if (live) {
-        load_station<C>(S, P, X, L, lp, n, qmem, ring_a, ring_s, tid);
+        load_station<C, PF>(S, P, X, L, lp, n, qmem, ring_a, ring_s, tid);
         S.force_general = (flags & 1) != 0;
         const bool frozen = (mode == HS_MODE_REPLICAS) ? (S.last_time > end_ns) : (cur > end_ns);
         if (!frozen) {
@@ -258,7 +276,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
                     bool event_order = true;
                     if (!pre_group) {
                         const bool elig = S.req_eligible();
-                        typename Station<C>::ReqCursor rc;
+                        typename Station<C, PF>::ReqCursor rc;
                         rc.bail = false; rc.done = true;
                         if (elig) S.req_begin(rc, end_ns);   // (touches the LP's statistics: eligible lanes only)
                         for (;;) {
@@ -269,7 +287,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
                         }
                         if (elig && !rc.bail) { S.req_finish(rc); event_order = false; }
                         else if (elig) {               // same-timestamp hazard: start over in event order
-                            load_station<C>(S, P, X, L, lp, n, qmem, ring_a, ring_s, tid);
+                            load_station<C, PF>(S, P, X, L, lp, n, qmem, ring_a, ring_s, tid);
                             S.force_general = (flags & 1) != 0;
                         }
                     }
@@ -290,10 +308,10 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
                     }
                 }
             }
-            if (mode == HS_MODE_REPLICAS) overshoot_one<C>(S);
-            else mine = make_candidate<C>(S);
+            if (mode == HS_MODE_REPLICAS) overshoot_one<C, PF>(S);
+            else mine = make_candidate<C, PF>(S);
         }
-        store_station<C>(S, X, lp, n);
+        store_station<C, PF>(S, X, lp, n);
     }
 
     // ---- workgroup reduction of the per-run deltas -> engine totals
@@ -359,11 +377,11 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
         for (int w = 1; w < kBlock / 64; ++w) if (cand_less(wave_c[w], b)) b = wave_c[w];
         long long new_cur = __hip_atomic_load(&tot->final_time, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur <= end_ns && b.valid) {
-            Station<C> W;
-            load_station<C>(W, P, X, L, b.lp, n, qmem, ring_a, ring_s, 0);
+            Station<C, PF> W;
+            load_station<C, PF>(W, P, X, L, b.lp, n, qmem, ring_a, ring_s, 0);
             W.force_general = false;
-            overshoot_one<C>(W);
-            store_station<C>(W, X, b.lp, n);
+            overshoot_one<C, PF>(W);
+            store_station<C, PF>(W, X, b.lp, n);
             for (int k = 0; k < 8; ++k) if (W.ev[k]) atomicAdd(&tot->ev[k], (unsigned long long)W.ev[k]);
             if (W.ev[6]) atomicAdd(&tot->completed, (unsigned long long)W.ev[6]);
             if (W.ev[7]) atomicAdd(&tot->received, (unsigned long long)W.ev[7]);
@@ -926,6 +944,7 @@ struct hs_engine {
     Totals *tot = nullptr;
     Candidate *cands = nullptr;
     bool is_net = false;
+    bool any_profile = false;  // some source has a time-varying rate profile
     NetParams NP{};
     NetState NX{};
     ShardCtl SC{};             // wend_slots == nullptr: the engine holds the whole network
@@ -995,8 +1014,12 @@ int upload(hs_engine *h, const T **dst, const T *src, size_t n, T dflt) {
 
 template <int C>
 void launch_run(hs_engine *h, int64_t end_ns) {
-    hipLaunchKernelGGL(hs_station_run<C>, dim3(h->n_blocks), dim3(kBlock), 0, h->stream, h->P, h->X, h->L, h->tot,
-                       h->cands, h->cfg.n_lp, end_ns, h->cfg.mode, h->flags);
+    if (h->any_profile)
+        hipLaunchKernelGGL((hs_station_run<C, true>), dim3(h->n_blocks), dim3(kBlock), 0, h->stream, h->P, h->X, h->L, h->tot,
+                           h->cands, h->cfg.n_lp, end_ns, h->cfg.mode, h->flags);
+    else
+        hipLaunchKernelGGL((hs_station_run<C, false>), dim3(h->n_blocks), dim3(kBlock), 0, h->stream, h->P, h->X, h->L, h->tot,
+                           h->cands, h->cfg.n_lp, end_ns, h->cfg.mode, h->flags);
 }
 
 void launch_run_dispatch(hs_engine *h, int64_t end_ns) {
@@ -1190,6 +1213,23 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
             return fail(h, HS_E_UNSUPPORTED, "LP %d: egress kind %d is not lowered", i, eg);
     }
     (void)any_source;
+    // time-varying profiles (load/profile.py:52-113); src_rate of such a source is its PEAK rate (it sizes the logs)
+    std::vector<uint8_t> pk((size_t)n, (uint8_t)0);
+    std::vector<double> pp((size_t)n * 4, 0.0);
+    for (int i = 0; i < n && st->src_profile_kind; ++i) {
+        const int k = st->src_profile_kind[i];
+        if (k == 0) continue;
+        if (k != 1 && k != 2) return fail(h, HS_E_UNSUPPORTED, "LP %d: profile kind %d is not lowered", i, k);
+        if (!st->src_profile_params) return fail(h, HS_E_INVALID, "src_profile_params is required with src_profile_kind");
+        const double *q = st->src_profile_params + 4 * (size_t)i;
+        for (int j = 0; j < 4; ++j) {
+            if (!std::isfinite(q[j]) || q[j] < 0.0) return fail(h, HS_E_INVALID, "LP %d: bad profile parameter %g", i, q[j]);
+            pp[(size_t)j * n + i] = q[j];
+        }
+        if (k == 1 && !(q[0] > 0.0)) return fail(h, HS_E_INVALID, "LP %d: LinearRampProfile needs duration_s > 0", i);
+        pk[(size_t)i] = (uint8_t)k;
+        h->any_profile = true;
+    }
     h->C = maxc <= 1 ? 1 : maxc <= 2 ? 2 : maxc <= 4 ? 4 : maxc <= 8 ? 8 : 16;
     int64_t cap = h->cfg.log_capacity;
     if (cap <= 0) {
@@ -1217,6 +1257,8 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     if ((rc = upload<uint64_t>(h, &h->P.stream_base, st->stream_base ? st->stream_base : dflt_base.data(), (size_t)n, 0)))
         return rc;
 #undef UP
+    if ((rc = upload<uint8_t>(h, &h->P.prof_kind, pk.data(), (size_t)n, 0))) return rc;
+    if ((rc = upload<double>(h, &h->P.prof_p, pp.data(), (size_t)n * 4, 0.0))) return rc;
     const size_t N = (size_t)n, NC = (size_t)n * (size_t)h->C;
 #define AL(field, count) if ((rc = dev_alloc(h, &h->X.field, count))) return rc
     AL(A, N); AL(seqA, N); AL(crtA, N); AL(arr_k, N); AL(arr_time, N); AL(svc_k, N);
@@ -1247,6 +1289,7 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     if (h->initialised) return fail(h, HS_E_STATE, "set the network before the first run");
     if (h->cfg.mode != HS_MODE_SINGLE) return fail(h, HS_E_INVALID, "a network of stations is one Simulation: HS_MODE_SINGLE");
     if (h->C > 4) return fail(h, HS_E_UNSUPPORTED, "networked stations support concurrency <= 4 for now");
+    if (h->any_profile) return fail(h, HS_E_UNSUPPORTED, "time-varying rate profiles are not lowered for networked stations yet");
     HS_HIP(h, hipSetDevice(h->cfg.device));
     const int n = h->cfg.n_lp, nl = net->n_links;
     if (nl < 0) return fail(h, HS_E_INVALID, "n_links < 0");

@@ -23,6 +23,7 @@
 #pragma once
 
 #include "hs_device.hpp"
+#include "hs_profile.hpp"
 
 namespace hs {
 
@@ -73,6 +74,8 @@ struct StationParams {          // read-only, [n_lp] each
     const uint8_t *egress;
     const uint64_t *seed;
     const uint64_t *stream_base;
+    const uint8_t *prof_kind;       // time-varying arrival rate (hs_profile.hpp): 0 constant, 1 linear ramp, 2 spike
+    const double *prof_p;           // [4][n_lp]
 };
 
 struct StationState {           // read-write; [n_lp] each unless noted
@@ -128,7 +131,9 @@ struct Candidate {              // an LP's first event beyond end_ns (SINGLE-mod
 };
 
 // ---------------------------------------------------------------------------------------------
-template <int C>
+// PF: the LP may have a time-varying arrival profile (hs_profile.hpp).  A separate instantiation, because the numerical
+// inversion needs a 4 KB per-lane stack and would otherwise tax the constant-rate kernel's registers.
+template <int C, bool PF = false>
 struct Station {
     // parameters
     int lp, n;
@@ -154,6 +159,7 @@ struct Station {
     DrawRing ra, rs;            // ra: E / rate per arrival draw;  rs: service_time_s per service draw
     ConstDiv div_rate, div_lambda;
     double inc_const;           // constant source: 1.0 / rate
+    Profile prof;               // kind != 0: the ring holds target AREAS (E, not E / rate) and next_arrival() inverts the profile
     // per-run deltas
     uint32_t ev[8];
     // logs
@@ -189,7 +195,7 @@ struct Station {
         ssid0 = (uint32_t)ss; ssid1 = (uint32_t)(ss >> 32);
         arr_k = ak; svc_k = sk;
         ra.reset(ring_a, tid); rs.reset(ring_s, tid);
-        div_rate.init(rate);
+        div_rate.init((PF && prof.kind != kProfConstant) ? 1.0 : rate);
         div_lambda.init(svc_lambda);
         inc_const = __ddiv_rn(1.0, rate);
     }
@@ -254,6 +260,12 @@ struct Station {
             inc = ra.pop();
             ++arr_k;
         } else inc = inc_const;                    // constant: 1.0 / rate   (providers/constant_arrival.py:23)
+        if constexpr (PF) {
+            if (prof.kind != kProfConstant) {      // general path (load/arrival_time_provider.py:84-144)
+                arr_time = prof_next_arrival(prof, arr_time, src_kind == 1 ? inc : 1.0);
+                return arr_time;
+            }
+        }
         const double t_next = __dadd_rn(seconds_from_ns(arr_time), inc);
         arr_time = ns_from_seconds(t_next);
         return arr_time;
@@ -497,7 +509,7 @@ struct Station {
         const bool poll = (notify && active < conc) || (dep && active_dep < conc);   // queue_driver.py:94-99 / :79-84
         const int64_t buf_enq = buf + (acc ? 1 : 0);
         const bool deliver = poll && buf_enq > 0;                       // queue.py:149-166
-        const bool slow = act && (force_general || svc_kind == 2 || (tick && D[0] == t) ||
+        const bool slow = act && (force_general || svc_kind == 2 || (PF && prof.kind != kProfConstant) || (tick && D[0] == t) ||
                                   (tick && ((stop_ns >= 0 && t > stop_ns) || a2 <= t)) || (deliver && dur == 0));
         const bool fast = act && !slow;
         const bool tick_f = fast && tick, dep_f = fast && dep, acc_f = fast && acc;
@@ -569,6 +581,7 @@ struct Station {
     };
     __device__ __forceinline__ bool req_eligible() const {
         return C == 1 && !force_general && qn == 0 && conc == 1 && qcap < 0 && stop_ns < 0 && svc_kind != 2 &&
+               !(PF && prof.kind != kProfConstant) &&
                (egress == 0 || egress == 1) && !(buf > 0 && active == 0) && active <= 1;
     }
     __device__ __forceinline__ void req_count_departure(ReqCursor &c, bool p, int64_t d, double s) {

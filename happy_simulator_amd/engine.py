@@ -28,6 +28,8 @@ class StationArrays:
     egress: np.ndarray
     seed: np.ndarray | None = None
     stream_base: np.ndarray | None = None
+    src_profile_kind: np.ndarray | None = None      # N.PROF_*; None = constant rate everywhere
+    src_profile_params: np.ndarray | None = None    # [n, 4]
 
     @staticmethod
     def uniform(n: int, *, src_kind=N.SRC_POISSON, rate=8.0, stop_after_ns=-1, concurrency=1,
@@ -100,14 +102,15 @@ class StationEngine:
         for name, dtype in (("src_kind", np.uint8), ("src_rate", np.float64), ("src_stop_after_ns", np.int64),
                             ("concurrency", np.int32), ("svc_kind", np.uint8), ("svc_mean_s", np.float64),
                             ("queue_cap", np.int64), ("egress", np.uint8), ("seed", np.uint64),
-                            ("stream_base", np.uint64)):
+                            ("stream_base", np.uint64), ("src_profile_kind", np.uint8),
+                            ("src_profile_params", np.float64)):
             a = getattr(stations, name)
             if a is None:
                 setattr(st, name, None)
                 continue
             a = np.ascontiguousarray(a, dtype)
-            if a.shape != (self.n,):
-                raise ValueError(f"{name} must have shape ({self.n},)")
+            if a.shape != ((self.n, 4) if name == "src_profile_params" else (self.n,)):
+                raise ValueError(f"{name} has the wrong shape for {self.n} stations")
             keep.append(a)
             setattr(st, name, a.ctypes.data)
         self.n_links = 0

@@ -79,6 +79,58 @@ class FIFOQueue:
 class ConstantRateProfile:
     rate: float
 
+    def get_rate(self, time: Instant) -> float:
+        return self.rate
+
+    @property
+    def peak_rate(self) -> float:
+        return self.rate
+
+
+@dataclass(frozen=True)
+class LinearRampProfile:
+    """Rate ramping linearly from start_rate to end_rate over duration_s, constant afterwards (load/profile.py:52-75)."""
+
+    duration_s: float
+    start_rate: float
+    end_rate: float
+
+    def get_rate(self, time: Instant) -> float:
+        t = time.to_seconds()
+        if t <= 0:
+            return self.start_rate
+        if t >= self.duration_s:
+            return self.end_rate
+        fraction = t / self.duration_s
+        return self.start_rate + fraction * (self.end_rate - self.start_rate)
+
+    @property
+    def peak_rate(self) -> float:
+        return max(self.start_rate, self.end_rate)
+
+
+@dataclass(frozen=True)
+class SpikeProfile:
+    """baseline_rate, then spike_rate during [warmup_s, warmup_s + spike_duration_s), then baseline_rate again
+    (load/profile.py:78-113)."""
+
+    baseline_rate: float = 10.0
+    spike_rate: float = 150.0
+    warmup_s: float = 10.0
+    spike_duration_s: float = 15.0
+
+    def get_rate(self, time: Instant) -> float:
+        t = time.to_seconds()
+        if t < self.warmup_s:
+            return self.baseline_rate
+        if t < self.warmup_s + self.spike_duration_s:
+            return self.spike_rate
+        return self.baseline_rate
+
+    @property
+    def peak_rate(self) -> float:
+        return max(self.baseline_rate, self.spike_rate)
+
 
 class SimpleEventProvider:
     def __init__(self, target: Entity, event_type: str = "Request", stop_after: Instant | None = None,
@@ -94,9 +146,11 @@ class SimpleEventProvider:
 class _ArrivalProvider:
     kind = "constant"
 
-    def __init__(self, profile: ConstantRateProfile, start_time: Instant = None):
-        if not isinstance(profile, ConstantRateProfile):
-            raise NotImplementedError("only ConstantRateProfile arrivals are lowered (time-varying profiles: SURVEY N3)")
+    def __init__(self, profile, start_time: Instant = None):
+        if not isinstance(profile, (ConstantRateProfile, LinearRampProfile, SpikeProfile)):
+            raise NotImplementedError(
+                f"profile {type(profile).__name__} is arbitrary Python; the engine lowers ConstantRateProfile, "
+                "LinearRampProfile and SpikeProfile (load/profile.py)")
         self.profile = profile
 
 
@@ -134,6 +188,17 @@ class Source(Entity):
                 name: str = "Source", stop_after=None, event_provider=None) -> "Source":
         return cls._make(PoissonArrivalTimeProvider, rate, target, event_type, name, stop_after, event_provider)
 
+    @classmethod
+    def with_profile(cls, profile, target: Entity | None = None, event_type: str = "Request", *, poisson: bool = True,
+                     name: str = "Source", stop_after=None, event_provider=None) -> "Source":
+        """A Source whose arrival rate follows `profile` (load/source.py:271-320)."""
+        if event_provider is None:
+            if target is None:
+                raise ValueError("Either 'target' or 'event_provider' must be provided")
+            event_provider = SimpleEventProvider(target, event_type, cls._resolve_stop_after(stop_after))
+        provider_cls = PoissonArrivalTimeProvider if poisson else ConstantArrivalTimeProvider
+        return cls(name=name, event_provider=event_provider, arrival_time_provider=provider_cls(profile, start_time=Instant.Epoch))
+
     @staticmethod
     def _resolve_stop_after(stop_after):
         if stop_after is None:
@@ -148,7 +213,8 @@ class Source(Entity):
 
     @property
     def rate(self) -> float:
-        return self._time_provider.profile.rate
+        """The profile's rate; for a time-varying profile its peak (what sizes the engine's record logs)."""
+        return self._time_provider.profile.peak_rate
 
     def downstream_entities(self) -> list[Entity]:
         t = getattr(self._event_provider, "_target", None)

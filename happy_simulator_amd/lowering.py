@@ -18,8 +18,9 @@ import numpy as np
 
 from . import _native as N
 from .engine import NetworkArrays, StationArrays
-from .entities import (ClientKeyEventProvider, ConsistentHash, ConstantLatency, Counter, Entity, ExponentialLatency,
-                       LatencyTracker, LoadBalancer, NetworkLink, RandomRouter, Server, Sink, Source, _RecordSink)
+from .entities import (ClientKeyEventProvider, ConsistentHash, ConstantLatency, ConstantRateProfile, Counter, Entity,
+                       ExponentialLatency, LatencyTracker, LinearRampProfile, LoadBalancer, NetworkLink, RandomRouter, Server,
+                       Sink, Source, SpikeProfile, _RecordSink)
 
 _SINKS = (Sink, Counter, LatencyTracker)
 
@@ -54,7 +55,18 @@ class LoweredGraph:
             if st.source is not None:
                 prov = st.source._time_provider
                 a.src_kind[i] = N.SRC_POISSON if prov.kind == "poisson" else N.SRC_CONSTANT
-                a.src_rate[i] = float(prov.profile.rate)
+                a.src_rate[i] = float(prov.profile.peak_rate)
+                pr = prov.profile
+                if not isinstance(pr, ConstantRateProfile):
+                    if a.src_profile_kind is None:
+                        a.src_profile_kind = np.zeros(n, np.uint8)
+                        a.src_profile_params = np.zeros((n, 4), np.float64)
+                    if isinstance(pr, LinearRampProfile):
+                        a.src_profile_kind[i] = N.PROF_LINEAR_RAMP
+                        a.src_profile_params[i, :3] = (pr.duration_s, pr.start_rate, pr.end_rate)
+                    else:
+                        a.src_profile_kind[i] = N.PROF_SPIKE
+                        a.src_profile_params[i] = (pr.baseline_rate, pr.spike_rate, pr.warmup_s, pr.spike_duration_s)
                 stop = st.source._event_provider._stop_after
                 a.src_stop_after_ns[i] = -1 if stop is None else stop.nanoseconds
             else:

@@ -109,7 +109,15 @@ typedef struct hs_stations {
     const uint8_t *egress;             /* hs_egress_kind; NULL = HS_EGRESS_SINK */
     const uint64_t *seed;              /* per-LP Philox key (replica i: base_seed + i); NULL = cfg.seed */
     const uint64_t *stream_base;       /* per-LP stream id base; NULL = cfg.lp_base + i */
+    /* Time-varying arrival rate (Source.with_profile, load/source.py:271-320; load/profile.py:52-113): the next arrival
+     * is found by the reference's own numerical procedure -- adaptive Simpson + bracket search + Brent
+     * (load/arrival_time_provider.py:84-144) -- restated on the device (csrc/hs_profile.hpp).  src_rate of such a source
+     * is its PEAK rate (used to size the record logs).  NULL = every source has a ConstantRateProfile(src_rate). */
+    const uint8_t *src_profile_kind;   /* hs_profile_kind */
+    const double *src_profile_params;  /* [n_lp][4]: LINEAR_RAMP {duration_s, start_rate, end_rate, -};
+                                          SPIKE {baseline_rate, spike_rate, warmup_s, spike_duration_s} */
 } hs_stations;
+typedef enum hs_profile_kind { HS_PROF_CONSTANT = 0, HS_PROF_LINEAR_RAMP = 1, HS_PROF_SPIKE = 2 } hs_profile_kind;
 
 /* Links between stations (the engine-side form of the reference's partition links, parallel/link.py:18-79,
  * and of `NetworkLink(latency=ConstantLatency(lat_min), jitter=ExponentialLatency(jitter_mean) | None,

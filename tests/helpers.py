@@ -177,6 +177,15 @@ def engine_for_spec(spec, log_capacity=0, horizon_ns=None, flags=0):
         queue_cap=np.array(p["qcap"], np.int64),
         egress=np.full(n, N.EGRESS_SINK if p["downstream"] else N.EGRESS_NONE, np.uint8),
     )
+    if any(pr is not None for pr in p["profile"]):
+        st.src_profile_kind = np.zeros(n, np.uint8)
+        st.src_profile_params = np.zeros((n, 4), np.float64)
+        for i, pr in enumerate(p["profile"]):
+            if pr is None:
+                continue
+            st.src_profile_kind[i] = N.PROF_LINEAR_RAMP if pr[0] == "ramp" else N.PROF_SPIKE
+            st.src_profile_params[i, :len(pr) - 1] = pr[1:]
+            st.src_rate[i] = max(pr[2], pr[3]) if pr[0] == "ramp" else max(pr[1], pr[2])     # peak: sizes the logs
     if spec["mode"] == "single":
         mode = N.MODE_SINGLE
         seed = spec["seed"]

@@ -248,3 +248,41 @@ def test_load_balancer_topology_through_the_api_matches_reference_golden(name):
     es = summary.entities
     assert es["srv0"].queue_stats.total_accepted == gold.accepted[0]
     assert es[sinks[0].name].events_handled == sinks[0].events_received
+
+
+def test_time_varying_profiles_through_the_api_match_reference_golden():
+    """`Source.with_profile(LinearRampProfile | SpikeProfile, poisson=...)` (load/source.py:271-320): arrival times come
+    from the reference's adaptive-Simpson + Brent inversion, restated on the device (csrc/hs_profile.hpp)."""
+    gold = H.Golden("profile_mixed_4")
+    spec = gold.spec
+    p = H.spec_chain_params(spec)
+
+    def profile(i):
+        pr = p["profile"][i]
+        if pr is None:
+            return None
+        return hs.LinearRampProfile(*pr[1:]) if pr[0] == "ramp" else hs.SpikeProfile(*pr[1:])
+
+    chains = []
+    for i in range(p["n"]):
+        sink = hs.Sink(f"sink{i}")
+        svc = hs.ExponentialLatency(p["mean"][i]) if spec["svc"][i] == "exp" else hs.ConstantLatency(p["mean"][i])
+        srv = hs.Server(f"srv{i}", service_time=svc, downstream=sink)
+        pr = profile(i)
+        if pr is None:
+            src = hs.Source.poisson(rate=p["rate"][i], target=srv, name=f"src{i}")
+        else:
+            src = hs.Source.with_profile(pr, target=srv, poisson=spec["arr"][i] == "poisson", name=f"src{i}")
+        chains.append((src, srv, sink))
+    sim = hs.Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=[c[0] for c in chains],
+                        entities=[e for c in chains for e in c[1:]], seed=spec["seed"])
+    summary = sim.run()
+    assert summary.total_events_processed == gold.meta["total_events"][0]
+    assert summary.duration_s == gold.meta["duration_s"][0]
+    assert [c[0].generated_count for c in chains] == gold.generated.tolist()
+    assert [c[1].stats.requests_completed for c in chains] == gold.completed.tolist()
+    assert [c[1].stats.total_service_time for c in chains] == gold.total_service_s.tolist()
+    for i, c in enumerate(chains):
+        gt, glat = gold.sink_records(i)
+        assert [t.nanoseconds for t in c[2].completion_times] == gt.tolist()
+        assert c[2].latencies_s == glat.tolist()

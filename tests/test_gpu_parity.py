@@ -180,3 +180,40 @@ def test_reentrant_windows_match_oracle(mode):
             eng.run_until(w)
         eng.run_until(p["end_ns"])
         _compare_engine_to_oracle(spec, eng, p, runs)
+
+
+def test_profile_sweep_matches_oracle():
+    """192 chains with random LinearRamp / Spike profiles (Poisson and deterministic arrivals, zero start rates, kinks and
+    discontinuities inside the horizon) against the oracle: every count, statistic and Sink record."""
+    rng = np.random.default_rng(5)
+    n = 192
+    prof, arr = [], []
+    for i in range(n):
+        if i % 3 == 0:
+            prof.append(["ramp", float(rng.uniform(2, 12)), float(rng.choice([0.0, 3.0, 25.0])), float(rng.uniform(4, 40))])
+        elif i % 3 == 1:
+            prof.append(["spike", float(rng.uniform(2, 12)), float(rng.uniform(40, 120)), float(rng.uniform(1, 6)),
+                         float(rng.uniform(0.5, 4))])
+        else:
+            prof.append(None)
+        arr.append("poisson" if i % 2 else "constant")
+    spec = dict(name="profile_sweep", n_chains=n, arr=arr, rate=8.0, svc="exp", mean=0.04, concurrency=[1, 2] * (n // 2),
+                profile=prof, end_s=10.0, rng="philox", seed=77, mode="single")
+    runs = H.run_oracle_for_spec(spec)
+    want, sinks = H.oracle_per_chain(spec, runs)
+    eng, p = H.engine_for_spec(spec)
+    with eng:
+        eng.run_until(p["end_ns"])
+        s = eng.summary()
+        st = eng.lp_stats()
+        counts, t, cr = eng.read_sinks()
+    assert s.events_processed == sum(r.events_processed for _, _, r in runs)
+    assert s.final_time_ns == runs[0][2].final_time_ns
+    for k in want:
+        np.testing.assert_array_equal(st[k], want[k], err_msg=k)
+    off = 0
+    for c in range(n):
+        ot, ocr = sinks[c]
+        np.testing.assert_array_equal(t[off:off + counts[c]], ot)
+        np.testing.assert_array_equal(cr[off:off + counts[c]], ocr)
+        off += counts[c]

@@ -259,3 +259,29 @@ class TestLoadBalancerLowering:
         for n in (1, 9, 55, 56, 57, 63, 64, 65, 119, 120, 121, 250):
             msg = bytes((7 * i + n) & 0xFF for i in range(n))
             assert md5(msg) == hashlib.md5(msg).digest()
+
+
+def test_profiles_are_lowered_and_unknown_profiles_refused():
+    """Source.with_profile (load/source.py:271-320) with the reference's parametric profiles (load/profile.py:38-113)."""
+    ramp = hs.LinearRampProfile(duration_s=10.0, start_rate=5.0, end_rate=30.0)
+    spike = hs.SpikeProfile(baseline_rate=10.0, spike_rate=150.0, warmup_s=3.0, spike_duration_s=2.0)
+    assert ramp.get_rate(Instant.from_seconds(5.0)) == 17.5 and ramp.get_rate(Instant.from_seconds(11.0)) == 30.0
+    assert spike.get_rate(Instant.from_seconds(2.9)) == 10.0 and spike.get_rate(Instant.from_seconds(3.0)) == 150.0
+    s1 = hs.Source.with_profile(ramp, target=hs.Server("a", downstream=hs.Sink("ka")), name="s1")
+    s2 = hs.Source.with_profile(spike, target=hs.Server("b", downstream=hs.Sink("kb")), poisson=False, name="s2")
+    s3 = hs.Source.poisson(rate=4, target=hs.Server("c", downstream=hs.Sink("kc")), name="s3")
+    a = hs.Simulation(duration=20, sources=[s1, s2, s3]).lowered().arrays()
+    assert list(a.src_profile_kind) == [N.PROF_LINEAR_RAMP, N.PROF_SPIKE, N.PROF_CONSTANT]
+    assert a.src_profile_params[0].tolist() == [10.0, 5.0, 30.0, 0.0]
+    assert a.src_profile_params[1].tolist() == [10.0, 150.0, 3.0, 2.0]
+    assert list(a.src_kind) == [N.SRC_POISSON, N.SRC_CONSTANT, N.SRC_POISSON]
+    assert list(a.src_rate) == [30.0, 150.0, 4.0]              # peak rates size the record logs
+    with pytest.raises(ValueError, match="target"):
+        hs.Source.with_profile(ramp)
+
+    class Custom:
+        def get_rate(self, t):
+            return 1.0
+
+    with pytest.raises(NotImplementedError, match="arbitrary Python"):
+        hs.Source.with_profile(Custom(), target=hs.Sink())
