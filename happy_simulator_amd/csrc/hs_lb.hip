@@ -268,6 +268,23 @@ __global__ void hs_lb_segments(uint64_t *__restrict__ skey, uint64_t *__restrict
     }
 }
 
+// keys-only variant of the run fix-up above (latency statistics)
+__global__ void hs_lb_fix_runs(uint64_t *__restrict__ keys, const int64_t *n_ptr, int g) {
+    const int64_t n = *n_ptr;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t hi = keys[i] >> g;
+    if (i > 0 && (keys[i - 1] >> g) == hi) return;
+    int64_t len = 1;
+    while (i + len < n && (keys[i + len] >> g) == hi) ++len;
+    for (int64_t a = 1; a < len; ++a) {
+        const uint64_t k = keys[i + a];
+        int64_t j = a;
+        while (j > 0 && keys[i + j - 1] > k) { keys[i + j] = keys[i + j - 1]; --j; }
+        keys[i + j] = k;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 2c. Service samples of single-worker FIFO backends, one lane per Request.  Such a backend starts its requests in
 //     arrival order, so the request in slot off[b] + k consumes service draw k of backend b whatever happens before
@@ -762,6 +779,48 @@ __global__ void __launch_bounds__(kLbBlock) hs_lb_finalize(LbSrc PS, LbBe PB, in
     tot->final_time = fin;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sink.latency_stats() of the shared Sink on the device (components/common.py:59-76, instrumentation/data.py:197-210):
+// latencies (completion ns - created_at ns; latency_s = float(ns) / 1e9 is monotone in ns) are radix-sorted as integers,
+// then count / avg / min / max / p50 / p99 follow the reference's formulas: avg = sum(sorted) / n with the sum taken
+// left to right in binary64 (CPython < 3.12 `sum`), percentile p = s[lo] * (1 - frac) + s[hi] * frac at pos = p * (n - 1).
+// ---------------------------------------------------------------------------------------------
+__global__ void hs_lb_latency_keys(const int64_t *__restrict__ t, const int64_t *__restrict__ created, const int64_t *n_ptr,
+                                   uint64_t *__restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < *n_ptr) keys[i] = (uint64_t)(t[i] - created[i]);
+}
+__device__ __forceinline__ double percentile_sorted_ns(const uint64_t *s, int64_t n, double p) {
+    const double pos = __dmul_rn(p, (double)(n - 1));
+    const int64_t lo = (int64_t)pos;
+    const int64_t hi = lo + 1 < n - 1 ? lo + 1 : n - 1;
+    const double frac = __dsub_rn(pos, (double)lo);
+    const double a = seconds_from_ns_ieee((int64_t)s[lo]), b = seconds_from_ns_ieee((int64_t)s[hi]);
+    return __dadd_rn(__dmul_rn(a, __dsub_rn(1.0, frac)), __dmul_rn(b, frac));
+}
+__global__ void __launch_bounds__(64) hs_lb_latency_stats_kernel(const uint64_t *__restrict__ sorted, const int64_t *n_ptr,
+                                                                 double *__restrict__ out) {
+    const int64_t n = *n_ptr;
+    const int lane = threadIdx.x;
+    if (n <= 0) { if (lane < 6) out[lane] = 0.0; return; }
+    // sequential left-to-right sum: the wavefront converts 64 values at a time, then they are added in index order
+    double sum = 0.0;
+    for (int64_t base = 0; base < n; base += 64) {
+        const int64_t i = base + lane;
+        const double v = i < n ? seconds_from_ns_ieee((int64_t)sorted[i]) : 0.0;
+        const int m = (n - base) < 64 ? (int)(n - base) : 64;
+        for (int j = 0; j < m; ++j) sum = __dadd_rn(sum, __shfl(v, j, 64));
+    }
+    if (lane == 0) {
+        out[0] = (double)n;
+        out[1] = __ddiv_rn(sum, (double)n);
+        out[2] = seconds_from_ns_ieee((int64_t)sorted[0]);
+        out[3] = seconds_from_ns_ieee((int64_t)sorted[n - 1]);
+        out[4] = percentile_sorted_ns(sorted, n, 0.50);
+        out[5] = percentile_sorted_ns(sorted, n, 0.99);
+    }
+}
+
 __global__ void hs_lb_clear(LbTotals *tot) {
     for (int k = 0; k < HS_EV_KINDS; ++k) tot->ev[k] = 0;
     tot->completed = 0; tot->received = 0; tot->last_time = INT64_MIN; tot->final_time = 0;
@@ -855,7 +914,7 @@ struct hs_lb {
     int64_t *out_t = nullptr, *out_created = nullptr;
     double *svdraw = nullptr;                         // [n_slots] service sample per Request slot (single-worker FIFO backends)
     bool any_simple = false;
-    int64_t *n_slots_dev = nullptr, *n_arr = nullptr, *n_done = nullptr;
+    int64_t *n_slots_dev = nullptr, *n_arr = nullptr, *n_done = nullptr, *n_tmp = nullptr;
     uint32_t *hist = nullptr, *row_total = nullptr, *digit_base = nullptr;
     int n_tiles = 0;
     bool ran = false;
@@ -1173,7 +1232,7 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     for (int j = 0; j < B; ++j)
         if ((be->concurrency ? be->concurrency[j] : 1) == 1 && (be->queue_cap ? be->queue_cap[j] : -1) < 0) h->any_simple = true;
     TRY(lalloc(h, &h->svdraw, (h->C == 1 && h->any_simple) ? NS : (size_t)1));
-    TRY(lalloc(h, &h->n_slots_dev, 1)); TRY(lalloc(h, &h->n_arr, 1)); TRY(lalloc(h, &h->n_done, 1));
+    TRY(lalloc(h, &h->n_slots_dev, 1)); TRY(lalloc(h, &h->n_arr, 1)); TRY(lalloc(h, &h->n_done, 1)); TRY(lalloc(h, &h->n_tmp, 1));
     TRY(lalloc(h, &h->hist, (size_t)kRadixBins * (size_t)h->n_tiles)); TRY(lalloc(h, &h->row_total, (size_t)kRadixBins));
     TRY(lalloc(h, &h->digit_base, (size_t)kRadixBins));
     TRY(lalloc(h, &h->tot, 1));
@@ -1278,6 +1337,33 @@ int64_t hs_lb_read_sink(hs_lb *h, int32_t sink, int64_t *t_ns, int64_t *created_
         if (created_ns && hipMemcpy(created_ns, src_c, (size_t)cnt * 8, hipMemcpyDeviceToHost) != hipSuccess) return lfail(h, HS_E_HIP, "memcpy");
     }
     return cnt;
+}
+
+int hs_lb_latency_stats(hs_lb *h, double out[6]) {
+    if (!h || !out) return lfail(h, HS_E_INVALID, "hs_lb_latency_stats: null argument");
+    if (!h->ran) return lfail(h, HS_E_STATE, "hs_lb_run has not been called");
+    if (!h->cfg.shared_sink) return lfail(h, HS_E_INVALID, "hs_lb_latency_stats is for the shared Sink; per-backend Sinks are small: read them");
+    LB_HIP(h, hipSetDevice(h->cfg.device));
+    // the sort buffers are free between runs: keys0 <- latencies, sorted in the ping-pong buffers
+    hipLaunchKernelGGL(hs_lb_latency_keys, dim3((unsigned)((h->n_slots + 255) / 256)), dim3(256), 0, h->stream, h->out_t,
+                       h->out_created, h->n_done, h->keys0);
+    uint64_t *kr = nullptr, *vr = nullptr;
+    const int g = h->tb % kRadixBits;
+    radix_sort_async(h, h->keys0, (const uint64_t *)nullptr, h->n_done, h->n_tmp, h->tb, RadixAll{}, NoVal{}, &kr, &vr, nullptr,
+                     h->tb > kRadixBits ? g : 0);
+    (void)vr;
+    double *d_out = nullptr;
+    LB_HIP(h, hipMalloc(&d_out, 6 * sizeof(double)));
+    if (h->tb > kRadixBits && g) {
+        // the ragged low bits were skipped: finish short runs in place (keys only) with the segment kernel's fix-up
+        hipLaunchKernelGGL(hs_lb_fix_runs, dim3((unsigned)((h->n_slots + 255) / 256)), dim3(256), 0, h->stream, kr, h->n_done, g);
+    }
+    hipLaunchKernelGGL(hs_lb_latency_stats_kernel, dim3(1), dim3(64), 0, h->stream, kr, h->n_done, d_out);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, 6 * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(d_out);
+    if (e != hipSuccess) return lfail(h, HS_E_HIP, "latency statistics failed: %s", hipGetErrorString(e));
+    return HS_OK;
 }
 
 int hs_lb_ring(hs_lb *h, int32_t *ring_backend) {

@@ -383,6 +383,9 @@ class Sink(_RecordSink):
         return [t.to_seconds() for t in self.completion_times], list(self.latencies_s)
 
     def latency_stats(self) -> dict:
+        dev = getattr(self, "_device_latency_stats", None)
+        if dev is not None:                      # a load balancer's shared Sink: computed by the engine (hs_lb_latency_stats)
+            return dict(dev)
         lat = self.latencies_s
         n = len(lat)
         if n == 0:

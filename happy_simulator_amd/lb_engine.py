@@ -158,6 +158,12 @@ class LoadBalancerEngine:
         n = self._check(self._lib.hs_lb_read_sink(self._h, sink, t.ctypes.data, cr.ctypes.data, cap))
         return t[:n], cr[:n]
 
+    def latency_stats(self) -> dict:
+        """`Sink.latency_stats()` of the shared Sink, computed on the device."""
+        out = (C.c_double * 6)()
+        self._check(self._lib.hs_lb_latency_stats(self._h, out))
+        return {"count": int(out[0]), "avg": out[1], "min": out[2], "max": out[3], "p50": out[4], "p99": out[5]}
+
     def ring(self) -> np.ndarray:
         out = np.zeros(self.B * self.virtual_nodes, np.int32)
         self._check(self._lib.hs_lb_ring(self._h, out.ctypes.data))

@@ -429,6 +429,7 @@ def write_back_lb(g: LbGraph, stats: dict, eng) -> None:
         lb._backends[b.name].total_requests = int(stats["total_requests"][j])
     if g.shared_sink:
         g.sinks[0]._set_records(*eng.read_sink(0))
+        g.sinks[0]._device_latency_stats = eng.latency_stats()      # Sink.latency_stats(): sorted on the device
     else:
         for j, k in enumerate(g.sinks):
             k._set_records(*eng.read_sink(j, cap=int(stats["sink_received"][j])))

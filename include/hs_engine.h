@@ -335,6 +335,10 @@ int hs_lb_get_stats(hs_lb *h, const hs_lb_stats *out);
 /* Sink records in the Sink's processing order.  shared_sink: sink must be 0 (all completions, global order);
  * otherwise sink = backend index.  Returns the number of records copied or a negative hs_status. */
 int64_t hs_lb_read_sink(hs_lb *h, int32_t sink, int64_t *t_ns, int64_t *created_ns, int64_t cap);
+/* Sink.latency_stats() of the shared Sink, computed on the device (components/common.py:59-76 with
+ * instrumentation/data.py:197-210): out = {count, avg, min, max, p50, p99} in seconds.  avg = sum(sorted latencies) / n with
+ * the sum taken left to right in binary64 (what CPython's `sum` does before 3.12). */
+int hs_lb_latency_stats(hs_lb *h, double out[6]);
 /* The sorted ring's backend index per point, [n_backends * virtual_nodes] (strategies.py:381-391). */
 int hs_lb_ring(hs_lb *h, int32_t *ring_backend);
 /* ConsistentHash.select for a key string (strategies.py:412-433): backend index. */

@@ -184,3 +184,48 @@ def test_lb_full_size_properties():
         np.testing.assert_array_equal(st[name], st2[name], err_msg=name)
     np.testing.assert_array_equal(t, t2)
     np.testing.assert_array_equal(cr, cr2)
+
+
+def _python_latency_stats(lat):
+    """components/common.py:59-76 + instrumentation/data.py:197-210, verbatim semantics on a Python list."""
+    n = len(lat)
+    if n == 0:
+        return {"count": 0, "avg": 0.0, "min": 0.0, "max": 0.0, "p50": 0.0, "p99": 0.0}
+    s = sorted(lat)
+
+    def pct(p):
+        pos = p * (n - 1)
+        lo = int(pos)
+        hi = min(lo + 1, n - 1)
+        frac = pos - lo
+        return float(s[lo] * (1.0 - frac) + s[hi] * frac)
+
+    total = 0.0
+    for v in s:              # left-to-right binary64 sum (CPython < 3.12 `sum`)
+        total += v
+    return {"count": n, "avg": total / n, "min": s[0], "max": s[-1], "p50": pct(0.50), "p99": pct(0.99)}
+
+
+@pytest.mark.parametrize("name", [n for n in H.golden_names("lb") if H.Golden(n).spec.get("shared_sink", True)])
+def test_device_latency_stats_match_reference_formulas(name):
+    """Sink.latency_stats() of the shared Sink from the device (radix sort of the latencies, sequential sum, interpolated
+    percentiles) == the reference's formulas applied to the live reference's own latency list."""
+    gold = H.Golden(name)
+    eng, p = H.lb_engine_for_spec(gold.spec)
+    with eng:
+        eng.run(p["end_ns"])
+        got = eng.latency_stats()
+        eng.run(p["end_ns"])                 # the statistics pass must leave the engine re-runnable
+        assert eng.summary().events_processed == gold.meta["total_events"][0]
+    assert got == _python_latency_stats(gold.sink_latency_s.tolist())
+
+
+def test_device_latency_stats_at_scale():
+    spec = dict(n_sources=4096, n_backends=4096, rate=6.0, mean=0.1, vnodes=150, n_clients=1 << 20, end_s=20.0, seed=3)
+    eng, p = H.lb_engine_for_spec(spec)
+    with eng:
+        eng.run(p["end_ns"])
+        got = eng.latency_stats()
+        t, cr = eng.read_sink(0)
+    want = _python_latency_stats(((t - cr).astype(np.float64) / 1e9).tolist())
+    assert len(t) > 400_000 and got == want
