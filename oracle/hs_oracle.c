@@ -203,7 +203,7 @@ static double prof_rate(const hso_profile *pf, double t_seconds) {
         if (t < warmup + dur) return spike;
         return baseline;
     }
-    return pf->p[0];
+    return pf->p[0];                                                 /* _ProbeProfile.get_rate: self.rate */
 }
 static double simpson3(double fa, double fm, double fb, double h) { return h / 3.0 * (fa + 4.0 * fm + fb); }
 static double simpson_adaptive(const hso_profile *pf, double a, double b, double fa, double fb, double s_whole, int depth,
@@ -385,6 +385,45 @@ static void on_source(hso_sim *s, const hso_event *e) {
     tick.kind = HSO_EV_SOURCE; tick.node = n; tick.req = -1; tick.aux = 0;
     if (has_payload) heap_push(s, payload);                         /* return [*payload_events, next_tick] (:174) */
     heap_push(s, tick);
+}
+
+/* Probe tick: Source.handle_event with _ProbeEventProvider (instrumentation/probe.py:69-78): one daemon `probe_event`
+ * aimed at a CallbackEntity, then the next tick. */
+static void on_probe_tick(hso_sim *s, const hso_event *e) {
+    int32_t n = e->node;
+    hso_node *nd = &s->nodes[n];
+    hso_event pe = {e->time, next_index(s), HSO_EV_PROBE, n, -1, 0};
+    nd->generated++;
+    hso_event tick;
+    tick.time = next_arrival(s, n);
+    tick.idx = next_index(s);
+    tick.kind = HSO_EV_PROBE_TICK; tick.node = n; tick.req = -1; tick.aux = 0;
+    heap_push(s, pe);
+    heap_push(s, tick);
+}
+/* measure_callback (instrumentation/probe.py:51-66): data.add_stat(getattr(target, metric), event.time) */
+static void on_probe_event(hso_sim *s, const hso_event *e) {
+    hso_node *nd = &s->nodes[e->node];
+    const hso_node *tg = &s->nodes[s->g.target[e->node]];
+    int64_t v = 0;
+    switch (s->g.probe_metric[e->node]) {
+        case HSO_M_DEPTH: v = tg->fifo.len; break;                   /* QueuedResource.depth */
+        case HSO_M_ACTIVE: v = tg->active; break;                    /* Server.active_requests */
+        case HSO_M_ACCEPTED: v = tg->accepted; break;
+        case HSO_M_DROPPED: v = tg->dropped; break;
+        case HSO_M_COMPLETED: v = tg->completed; break;
+        case HSO_M_RECEIVED: v = tg->received; break;                /* Sink.events_received */
+        case HSO_M_GENERATED: v = tg->generated; break;              /* Source.generated_count */
+        default: break;
+    }
+    if (nd->received == nd->sink_cap) {
+        nd->sink_cap = nd->sink_cap ? nd->sink_cap * 2 : 256;
+        nd->sink_t = (int64_t *)realloc(nd->sink_t, (size_t)nd->sink_cap * sizeof(int64_t));
+        nd->sink_created = (int64_t *)realloc(nd->sink_created, (size_t)nd->sink_cap * sizeof(int64_t));
+    }
+    nd->sink_t[nd->received] = e->time;
+    nd->sink_created[nd->received] = v;
+    nd->received++;
 }
 
 /* QueuedResource.handle_event -> Queue._handle_enqueue, queued_resource.py:139-143, queue.py:122-147 */
@@ -699,7 +738,7 @@ hso_sim *hso_create(const hso_graph *g, const hso_params *p) {
     DUP(arr_kind, int32_t); DUP(rate, double); DUP(stop_after_ns, int64_t);
     DUP(concurrency, int32_t); DUP(lat_kind, int32_t); DUP(lat_mean, double); DUP(lat_min, double);
     DUP(queue_cap, int64_t); DUP(rt_off, int32_t); DUP(rt_cnt, int32_t);
-    DUP(n_clients, int64_t); DUP(vnodes, int32_t); DUP(prof_kind, int32_t);
+    DUP(n_clients, int64_t); DUP(vnodes, int32_t); DUP(prof_kind, int32_t); DUP(probe_metric, int32_t);
     {
         double *pp = (double *)calloc((size_t)n * 4 + 1, sizeof(double));
         if (g->prof_p) memcpy(pp, g->prof_p, (size_t)n * 4 * sizeof(double));
@@ -748,6 +787,17 @@ hso_sim *hso_create(const hso_graph *g, const hso_params *p) {
         tick.kind = HSO_EV_SOURCE; tick.node = i; tick.req = -1; tick.aux = 0;
         heap_push(s, tick);
     }
+    /* then the probes, in list order (core/simulation.py:156-160) */
+    for (int32_t i = 0; i < n; ++i) {
+        if (s->g.kind[i] != HSO_PROBE) continue;
+        s->nodes[i].arr_time_ns = p->start_ns;
+        hso_event tick;
+        tick.time = next_arrival(s, i);
+        if (tick.time == INT64_MAX) continue;                       /* "Rate is zero indefinitely. Source will not start." */
+        tick.idx = next_index(s);
+        tick.kind = HSO_EV_PROBE_TICK; tick.node = i; tick.req = -1; tick.aux = 0;
+        heap_push(s, tick);
+    }
     /* run(): _active_sim_context switches Event construction to the per-heap
      * counter, which starts again at 0 (core/event_heap.py:48, core/sim_future.py:64-73). */
     s->counter = 0;
@@ -777,6 +827,8 @@ int hso_run_until(hso_sim *s, int64_t end_ns) {
             case HSO_EV_ROUTE: on_route(s, &e); break;
             case HSO_EV_LB: on_lb(s, &e); break;
             case HSO_EV_LB_RESP: on_lb_resp(s, &e); break;
+            case HSO_EV_PROBE_TICK: on_probe_tick(s, &e); break;
+            case HSO_EV_PROBE: on_probe_event(s, &e); break;
             default: return -1;
         }
     }
@@ -848,7 +900,7 @@ void hso_destroy(hso_sim *s) {
     free((void *)s->g.kind); free((void *)s->g.target); free((void *)s->g.stream_base);
     free((void *)s->g.arr_kind); free((void *)s->g.rate); free((void *)s->g.stop_after_ns);
     free((void *)s->g.concurrency); free((void *)s->g.lat_kind); free((void *)s->g.lat_mean);
-    free((void *)s->g.prof_kind); free((void *)s->g.prof_p);
+    free((void *)s->g.prof_kind); free((void *)s->g.prof_p); free((void *)s->g.probe_metric);
     free((void *)s->g.n_clients); free((void *)s->g.vnodes); free((void *)s->g.names); free((void *)s->g.name_off);
     free((void *)s->g.lat_min); free((void *)s->g.queue_cap); free((void *)s->g.rt_off); free((void *)s->g.rt_cnt); free((void *)s->g.rt_targets);
     free(s->nodes); free(s->heap); free(s->reqs);

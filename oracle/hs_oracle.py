@@ -15,14 +15,15 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libhs_oracle.so")
 
-SOURCE, SERVER, SINK, LINK, ROUTER, LB = 0, 1, 2, 3, 4, 5
+SOURCE, SERVER, SINK, LINK, ROUTER, LB, PROBE = 0, 1, 2, 3, 4, 5, 6
+M_DEPTH, M_ACTIVE, M_ACCEPTED, M_DROPPED, M_COMPLETED, M_RECEIVED, M_GENERATED = range(7)
 ARR_POISSON, ARR_CONSTANT = 0, 1
 LAT_EXP, LAT_CONST = 0, 1
 RNG_PHILOX, RNG_MT19937 = 0, 1
-PROF_CONSTANT, PROF_LINEAR_RAMP, PROF_SPIKE = 0, 1, 2
-EV_KINDS = 13
+PROF_CONSTANT, PROF_LINEAR_RAMP, PROF_SPIKE, PROF_GENERAL_CONSTANT = 0, 1, 2, 3
+EV_KINDS = 15
 EV_NAMES = ["source", "enqueue", "notify", "poll", "deliver", "work", "continuation", "sink", "link", "link_cont",
-            "route", "lb", "lb_resp"]
+            "route", "lb", "lb_resp", "probe_tick", "probe"]
 STREAM_ARRIVAL, STREAM_SERVICE, STREAM_LINK, STREAM_ROUTE, STREAM_KEY = 0, 1, 2, 3, 4
 
 
@@ -62,6 +63,7 @@ class _Graph(C.Structure):
         ("name_off", C.POINTER(C.c_int32)),
         ("prof_kind", C.POINTER(C.c_int32)),
         ("prof_p", C.POINTER(C.c_double)),
+        ("probe_metric", C.POINTER(C.c_int32)),
     ]
 
 
@@ -151,12 +153,13 @@ class Graph:
     names: list = field(default_factory=list)        # entity names (only an LB's backends need theirs)
     prof_kind: list = field(default_factory=list)
     prof_p: list = field(default_factory=list)       # 4 parameters per node
+    probe_metric: list = field(default_factory=list)
 
     def _add(self, **kw) -> int:
         defaults = dict(
             kind=0, target=-1, stream_base=len(self.kind), arr_kind=0, rate=0.0, stop_after_ns=-1,
             concurrency=1, lat_kind=LAT_CONST, lat_mean=0.0, lat_min=0.0, queue_cap=-1, rt_off=0, rt_cnt=0,
-            n_clients=0, vnodes=0, names="", prof_kind=PROF_CONSTANT, prof_p=(0.0, 0.0, 0.0, 0.0),
+            n_clients=0, vnodes=0, names="", prof_kind=PROF_CONSTANT, prof_p=(0.0, 0.0, 0.0, 0.0), probe_metric=0,
         )
         defaults.update(kw)
         for k, v in defaults.items():
@@ -184,6 +187,11 @@ class Graph:
 
     def sink(self) -> int:
         return self._add(kind=SINK)
+
+    def probe(self, target: int, metric: int, interval: float) -> int:
+        """Probe(target, metric, data, interval): add it AFTER every source (probes start after sources)."""
+        return self._add(kind=PROBE, target=target, arr_kind=ARR_CONSTANT, probe_metric=metric,
+                         prof_kind=PROF_GENERAL_CONSTANT, prof_p=(1.0 / interval, 0.0, 0.0, 0.0))
 
     def link(self, lat_min, jitter_mean=None, target=-1, stream_base=None) -> int:
         """NetworkLink(latency=ConstantLatency(lat_min), jitter=ExponentialLatency(jitter_mean) | None, egress=target)."""
@@ -252,6 +260,7 @@ def run(g: Graph, end_ns: int, start_ns: int = 0, seed: int = 42, rng_mode: int 
         "n_clients": np.asarray(g.n_clients, np.int64), "vnodes": np.asarray(g.vnodes, np.int32),
         "prof_kind": np.asarray(g.prof_kind, np.int32),
         "prof_p": np.asarray(g.prof_p, np.float64).reshape(-1),
+        "probe_metric": np.asarray(g.probe_metric, np.int32),
     }
     enc = [nm.encode() for nm in g.names]
     names_blob = b"".join(enc) + b"\0"
@@ -305,7 +314,7 @@ def run(g: Graph, end_ns: int, start_ns: int = 0, seed: int = 42, rng_mode: int 
                                 select=[L.hso_lb_select(h, i, str(c).encode()) for c in range(lb_probe)])
         r.sinks = {}
         for i in range(n):
-            if g.kind[i] == SINK:
+            if g.kind[i] in (SINK, PROBE):        # a probe's samples come back as (sample ns, value)
                 c = L.hso_sink_count(h, i)
                 t = np.zeros(c, np.int64)
                 cr = np.zeros(c, np.int64)

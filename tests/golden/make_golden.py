@@ -60,8 +60,15 @@ from happysimulator.components.load_balancer.load_balancer import LoadBalancer  
 from happysimulator.components.load_balancer.strategies import ConsistentHash  # noqa: E402
 from happysimulator.load.event_provider import EventProvider  # noqa: E402
 
+from happysimulator.instrumentation.probe import Probe  # noqa: E402
+
 EV = {"source": 0, "enqueue": 1, "notify": 2, "poll": 3, "deliver": 4, "work": 5, "continuation": 6, "sink": 7,
-      "link": 8, "link_cont": 9, "route": 10, "lb": 11, "lb_resp": 12}
+      "link": 8, "link_cont": 9, "route": 10, "lb": 11, "lb_resp": 12, "probe_tick": 13, "probe": 14}
+# metric name -> (which entity of the chain carries it, the reference attribute read by getattr)
+PROBE_METRICS = {"depth": ("server", "depth"), "active_requests": ("server", "active_requests"),
+                 "stats_accepted": ("server", "stats_accepted"), "stats_dropped": ("server", "stats_dropped"),
+                 "requests_completed": ("server", "_requests_completed"), "events_received": ("sink", "events_received"),
+                 "generated_count": ("source", "generated_count")}
 
 
 # ---- Seam-3 plug-ins (ours; they only choose the random numbers) ------------------------
@@ -183,7 +190,9 @@ def classify(ev, node_of):
     et = ev.event_type
     tgt = ev.target
     if et == "source_event":
-        return EV["source"], node_of[id(tgt)]
+        return (EV["probe_tick"] if isinstance(tgt, Probe) else EV["source"]), node_of[id(tgt)]
+    if et == "probe_event":
+        return EV["probe"], node_of.get(id(tgt), -1)
     if et == "QUEUE_NOTIFY":
         return EV["notify"], node_of[id(tgt)]
     if et == "QUEUE_POLL":
@@ -210,8 +219,27 @@ def run_sim(spec, chain_ids, seed, want_trace):
         random.seed(seed)
         np.random.seed(seed)
     sources, entities, handles = build_chains(spec, chain_ids, seed)
+    probes, probe_data = [], {}
+    for local, c in enumerate(chain_ids):
+        pr = (spec.get("probes") or [None] * spec["n_chains"])[c]
+        if pr is None:
+            continue
+        who, attr = PROBE_METRICS[pr[0]]
+        target = {"source": handles[local][0], "server": handles[local][1], "sink": handles[local][2]}[who]
+        probe, data = Probe.on(target, attr, interval=pr[1])
+        data._ns = []                  # Data keeps seconds; keep the exact nanoseconds beside it
+
+        def add_stat(value, time, _orig=data.add_stat, _d=data):
+            _d._ns.append((time.nanoseconds, value))
+            _orig(value, time)
+
+        data.add_stat = add_stat
+        probes.append((c, probe))
+        probe_data[c] = data
     sim = Simulation(start_time=Instant.from_seconds(spec.get("start_s", 0)) if spec.get("start_s") else None,
-                     end_time=Instant.from_seconds(spec["end_s"]), sources=sources, entities=entities)
+                     end_time=Instant.from_seconds(spec["end_s"]), sources=sources, entities=entities,
+                     probes=[p for _, p in probes])
+    sim._probe_data = probe_data
     # chain-local node numbering: chain c -> (source=c, server=c, sink=c); kinds disambiguate
     node_of = {}
     for local, (src, srv, snk) in enumerate(handles):
@@ -223,14 +251,24 @@ def run_sim(spec, chain_ids, seed, want_trace):
         node_of[id(srv._worker)] = c
         if snk is not None:
             node_of[id(snk)] = c
+    for c, probe in probes:
+        node_of[id(probe)] = c
     trace = []
     if want_trace:
         heap = sim._event_heap
         orig_pop = heap.pop
 
+        cb_chain = {}                      # CallbackEntity of a probe_event -> chain (resolved through its closure)
+        for c, probe in probes:
+            cb_chain[id(probe._event_provider.data_sink)] = c
+
         def pop():
             e = orig_pop()
             k, nd = classify(e, node_of)
+            if k == EV["probe"]:
+                fn = e.target._fn if hasattr(e.target, "_fn") else e.target.fn
+                cells = {id(cell.cell_contents) for cell in (fn.__closure__ or ())}
+                nd = next(c for key, c in cb_chain.items() if key in cells)
             trace.append((e.time.nanoseconds, k, nd, e._sort_index))
             return e
 
@@ -253,8 +291,10 @@ def run_case(spec):
         groups = [(list(range(n)), spec["seed"])]
     else:  # replicas: one Simulation per chain, seed = base_seed + i (parallel/runner.py:115-142)
         groups = [([i], spec["seed"] + i) for i in range(n)]
+    probe_all = {}
     for chain_ids, seed in groups:
         sim, summary, handles, trace = run_sim(spec, chain_ids, seed, want_trace)
+        probe_all.update(sim._probe_data)
         totals.append(summary.total_events_processed)
         finals.append(sim._current_time.nanoseconds)
         durations.append(summary.duration_s)
@@ -279,6 +319,17 @@ def run_case(spec):
             sink_off.append(len(sink_t))
     meta = dict(spec=spec, total_events=totals, final_ns=finals, duration_s=durations)
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    if spec.get("probes"):
+        pt, pv, poff = [], [], [0]
+        for i in range(n):
+            d = probe_all.get(i)
+            if d is not None:
+                pt.extend(t for t, _ in d._ns)
+                pv.extend(int(v) for _, v in d._ns)
+            poff.append(len(pt))
+        out["probe_t_ns"] = np.asarray(pt, np.int64)
+        out["probe_v"] = np.asarray(pv, np.int64)
+        out["probe_off"] = np.asarray(poff, np.int64)
     for k, v in stats.items():
         out[k] = v
     out["total_service_s"] = total_service
@@ -530,6 +581,14 @@ CASES = [
          svc=["exp", "const", "exp", "exp"], mean=[0.1, 0.04, 0.03, 0.06],
          profile=[None, ["ramp", 12.0, 20.0, 2.0], ["spike", 6.0, 90.0, 4.0, 3.0], ["ramp", 20.0, 2.0, 25.0]],
          end_s=16.0, rng="philox", seed=23, mode="single", trace=True),
+    # --- probes: Probe.on(target, metric, interval) = a daemon Source sampling an attribute --------
+    dict(name="probe_depth_4chains", n_chains=4, arr="poisson", rate=[12.0, 9.0, 30.0, 8.0], svc="exp", mean=[0.1, 0.1, 0.05, 0.1],
+         concurrency=[1, 1, 2, 1], queue_cap=[None, None, 6, None],
+         probes=[["depth", 0.5], ["active_requests", 0.25], ["stats_dropped", 1.0], ["events_received", 0.3]],
+         end_s=20.0, rng="philox", seed=31, mode="single", trace=True),
+    dict(name="probe_const_ties", n_chains=3, arr="constant", rate=[10.0, 20.0, 4.0], svc="const", mean=[0.1, 0.07, 0.2],
+         probes=[["depth", 0.1], ["generated_count", 0.05], ["requests_completed", 0.25]],
+         end_s=6.0, rng="philox", seed=32, mode="single", trace=True),
     dict(name="philox_256chains_single", n_chains=256, arr="poisson", rate=8.0, svc="exp", mean=0.1, end_s=10.0,
          rng="philox", seed=2026, mode="single", trace=False),
     dict(name="philox_64chains_replicas", n_chains=64, arr="poisson", rate=8.0, svc="exp", mean=0.1, end_s=20.0,

@@ -64,7 +64,14 @@ def spec_chain_params(spec):
         downstream=spec.get("downstream", True),
         end_ns=ns_from_seconds(spec["end_s"]),
         profile=[None if pr is None else tuple(pr) for pr in (spec.get("profile") or [None] * n)],
+        probes=[None if pr is None else (pr[0], float(pr[1])) for pr in (spec.get("probes") or [None] * n)],
     )
+
+
+# Probe metric name -> (entity of the chain that carries it, oracle metric id, engine metric id); make_golden.PROBE_METRICS
+PROBE_METRICS = {"depth": ("server", 0), "active_requests": ("server", 1), "stats_accepted": ("server", 2),
+                 "stats_dropped": ("server", 3), "requests_completed": ("server", 4), "events_received": ("sink", 5),
+                 "generated_count": ("source", 6)}
 
 
 def oracle_graph_for(spec, chain_ids, stream_bases):
@@ -83,6 +90,13 @@ def oracle_graph_for(spec, chain_ids, stream_bases):
         g.target[srcs[k]] = sv
         g.target[sv] = sk
         nodes[c] = (srcs[k], sv, sk)
+    g.probe_nodes = {}
+    for c in chain_ids:                                   # probes start after every source, in list order
+        pr = p["probes"][c]
+        if pr is not None:
+            who, mid = PROBE_METRICS[pr[0]]
+            tgt = nodes[c][{"source": 0, "server": 1, "sink": 2}[who]]
+            g.probe_nodes[c] = g.probe(tgt, mid, pr[1])
     return g, nodes
 
 
@@ -101,6 +115,7 @@ def run_oracle_for_spec(spec, trace_cap=0):
         g, nodes = oracle_graph_for(spec, chain_ids, bases)
         r = O.run(g, p["end_ns"], seed=seed, rng_mode=rng, mt_seed_py=seed & 0xFFFFFFFF,
                   mt_seed_np=seed & 0xFFFFFFFF, trace_cap=trace_cap)
+        r.probe_nodes = g.probe_nodes
         runs.append((chain_ids, nodes, r))
     return runs
 

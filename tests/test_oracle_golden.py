@@ -41,6 +41,16 @@ def test_oracle_matches_reference_golden(name):
                 np.testing.assert_array_equal(t, gt)
                 # Sink latency rule: (t - created_at).to_seconds() (components/common.py:39-40)
                 np.testing.assert_array_equal((t - created).astype(np.float64) / 1e9, glat)
+    if "probe_t_ns" in gold.arrays:          # Probe samples: (time ns, getattr(target, metric)) in sampling order
+        for chain_ids, nodes, r in runs:
+            for c in chain_ids:
+                a, b = gold.probe_off[c], gold.probe_off[c + 1]
+                if c in r.probe_nodes:
+                    t, v = r.sinks[r.probe_nodes[c]]
+                    np.testing.assert_array_equal(t, gold.probe_t_ns[a:b])
+                    np.testing.assert_array_equal(v, gold.probe_v[a:b])
+                else:
+                    assert a == b
     if want_trace:
         assert spec["mode"] == "single"
         (chain_ids, nodes, r), = runs
@@ -49,6 +59,8 @@ def test_oracle_matches_reference_golden(name):
             for nd in trio:
                 if nd >= 0:
                     node_chain[nd] = c
+        for c, nd in r.probe_nodes.items():
+            node_chain[nd] = c
         t, k, nd, ix = r.trace
         got = np.stack([t, k.astype(np.int64), np.array([node_chain[x] for x in nd], np.int64), ix], axis=1)
         np.testing.assert_array_equal(got, gold.trace)
