@@ -13,7 +13,7 @@ with a host-side mirror of the reference's `Simulation / Source / Server / Sink 
 """
 from ._native import EngineError, EngineUnavailable  # noqa: F401
 from .core.temporal import Duration, Instant  # noqa: F401
-from .entities import (BackendInfo, ClientKeyEventProvider, ConsistentHash, ConstantArrivalTimeProvider,  # noqa: F401
+from .entities import (BackendInfo, ClientKeyEventProvider, ConsistentHash, ConstantArrivalTimeProvider, Data, Probe,  # noqa: F401
                        ConstantLatency, ConstantRateProfile, Counter, Entity, ExponentialLatency, FIFOQueue,
                        LatencyTracker, LinearRampProfile, LoadBalancer, LoadBalancerStats, NetworkLink, NetworkLinkStats,
                        PoissonArrivalTimeProvider, RandomRouter, Server, ServerStats, SimpleEventProvider, Sink, Source,

@@ -30,9 +30,12 @@ SRC_NONE, SRC_POISSON, SRC_CONSTANT = 0, 1, 2
 PROF_CONSTANT, PROF_LINEAR_RAMP, PROF_SPIKE = 0, 1, 2
 LAT_EXPONENTIAL, LAT_CONSTANT, LAT_NO_SERVER = 0, 1, 2
 EGRESS_NONE, EGRESS_SINK, EGRESS_LINK, EGRESS_ROUTER = 0, 1, 2, 3
-EV_KINDS = 13
+EV_KINDS = 15
 EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuation", "sink", "link", "link_cont",
-            "route", "lb", "lb_resp")
+            "route", "lb", "lb_resp", "probe_tick", "probe")
+PROBE_METRICS = {"depth": 0, "active_requests": 1, "stats_accepted": 2, "stats_dropped": 3, "requests_completed": 4,
+                 "_requests_completed": 4, "events_received": 5, "generated_count": 6}
+PROBE_NONE = 255
 ABI_VERSION = 4
 
 
@@ -60,6 +63,7 @@ class Stations(C.Structure):
         ("concurrency", C.c_void_p), ("svc_kind", C.c_void_p), ("svc_mean_s", C.c_void_p),
         ("queue_cap", C.c_void_p), ("egress", C.c_void_p), ("seed", C.c_void_p), ("stream_base", C.c_void_p),
         ("src_profile_kind", C.c_void_p), ("src_profile_params", C.c_void_p),
+        ("probe_metric", C.c_void_p), ("probe_interval_s", C.c_void_p),
     ]
 
 
@@ -200,6 +204,8 @@ def lib():
     L.hs_engine_get_lp_stats.argtypes = [C.c_void_p, P(LpStats)]
     L.hs_engine_read_sink.restype = C.c_int64
     L.hs_engine_read_sink.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]
+    L.hs_engine_read_probe.restype = C.c_int64
+    L.hs_engine_read_probe.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]
     L.hs_engine_read_sinks.restype = C.c_int64
     L.hs_engine_read_sinks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.hs_last_error.restype = C.c_char_p
@@ -257,7 +263,7 @@ EXPORTED_SYMBOLS = (
     "hs_engine_shard_window", "hs_engine_shard_inject", "hs_engine_shard_progress", "hs_engine_shard_final",
     "hs_engine_shard_overshoot", "hs_engine_reset",
     "hs_engine_run_until", "hs_engine_run_until_async", "hs_engine_synchronize", "hs_engine_bench_runs",
-    "hs_engine_get_summary", "hs_engine_get_lp_stats", "hs_engine_read_sink", "hs_engine_read_sinks",
+    "hs_engine_get_summary", "hs_engine_get_lp_stats", "hs_engine_read_sink", "hs_engine_read_sinks", "hs_engine_read_probe",
     "hs_last_error", "hs_last_global_error", "hs_engine_destroy", "hs_debug_draws", "hs_debug_set_flags",
     "hs_debug_const_div", "hs_debug_async_counters",
     "hs_lb_create", "hs_lb_run", "hs_lb_bench_runs", "hs_lb_get_summary", "hs_lb_get_stats", "hs_lb_read_sink",

@@ -71,10 +71,14 @@ __device__ __forceinline__ void load_station(Station<C, PF> &S, const StationPar
     S.svc_const_ns = ns_from_seconds(S.svc_const_s);
     S.stop_ns = P.src_stop[lp]; S.qcap = P.qcap[lp];
     S.prof.kind = kProfConstant;
+    S.p_metric = kProbeNone; S.PA = kInfNs; S.evp[0] = S.evp[1] = 0;
     if constexpr (PF) {
         S.prof.kind = P.prof_kind[lp];
         S.prof.p0 = P.prof_p[lp]; S.prof.p1 = P.prof_p[(size_t)n + lp]; S.prof.p2 = P.prof_p[(size_t)2 * n + lp];
         S.prof.p3 = P.prof_p[(size_t)3 * n + lp];
+        S.p_metric = P.probe_metric[lp]; S.p_rate = P.probe_rate[lp];
+        S.PA = X.PA[lp]; S.seqP = X.seqP[lp]; S.crtP = X.crtP[lp]; S.p_arr = X.p_arr[lp]; S.p_n = X.p_n[lp];
+        S.probe_t = L.probe_t + lp; S.probe_v = L.probe_v + lp; S.pcap = L.pcap;
     }
     S.A = X.A[lp]; S.seqA = X.seqA[lp]; S.crtA = X.crtA[lp]; S.arr_time = X.arr_time[lp];
     S.buf = X.buf[lp]; S.active = X.active[lp]; S.seq = X.seq[lp];
@@ -129,6 +133,11 @@ __device__ __forceinline__ void store_station(const Station<C, PF> &Sc, const St
     uint32_t tot = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { X.ev_kind[(size_t)k * n + lp] += S.ev[k]; tot += S.ev[k]; }
+    if constexpr (PF) {
+        X.PA[lp] = S.PA; X.seqP[lp] = S.seqP; X.crtP[lp] = S.crtP; X.p_arr[lp] = S.p_arr; X.p_n[lp] = S.p_n;
+        X.ev_probe[lp] += S.evp[0]; X.ev_probe[(size_t)n + lp] += S.evp[1];
+        tot += S.evp[0] + S.evp[1];
+    }
     X.events[lp] += tot;
 }
 
@@ -146,6 +155,7 @@ __device__ __forceinline__ Candidate make_candidate(const Station<C, PF> &S) {
     const int w = S.pick_root(t);
     c.t = t; c.valid = 1;
     if (w == 0) c.t_created = S.crtA;
+    else if (w == kRootProbe) c.t_created = S.crtP;
     else {
 #pragma unroll
         for (int i = 0; i < C; ++i) if (i == w - 1) c.t_created = S.crtD[i];
@@ -173,6 +183,11 @@ __device__ __forceinline__ void overshoot_one(Station<C, PF> &S) {
 // kernels
 // =============================================================================================
 
+__device__ __noinline__ int64_t first_probe_tick(double rate, int64_t start_ns) {
+    Profile pp;
+    pp.kind = kProfGeneralConstant; pp.p0 = rate; pp.p1 = pp.p2 = pp.p3 = 0.0;
+    return prof_next_arrival(pp, start_ns, 1.0);
+}
 __device__ __noinline__ int64_t first_profile_arrival(const StationParams &P, int lp, int n, int64_t start_ns, double area) {
     Profile pf;
     pf.kind = P.prof_kind[lp];
@@ -194,7 +209,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
         if (lp < n) { NX.route_k[lp] = 0; NX.routed[lp] = 0; NX.bag_cnt[lp] = 0; NX.in_cnt[lp] = 0; NX.in_cnt[n + lp] = 0; }
     }
     if (lp == 0) {
-        for (int k = 0; k < 11; ++k) tot->ev[k] = 0;
+        for (int k = 0; k < 15; ++k) tot->ev[k] = 0;
         tot->completed = 0; tot->received = 0; tot->final_time = start_ns; tot->cur_time = start_ns;
         tot->overflow = 0; tot->qoverflow = 0; tot->done = 0;
         tot->dbg[0] = tot->dbg[1] = tot->dbg[2] = tot->dbg[3] = 0;
@@ -230,6 +245,16 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
         X.svc_s[(size_t)i * n + lp] = 0.0; X.crt[(size_t)i * n + lp] = 0;
     }
     for (int k = 0; k < 11; ++k) X.ev_kind[(size_t)k * n + lp] = 0;
+    if (X.PA != nullptr) {   // probes start after the sources (core/simulation.py:156-160): first tick from start_ns
+        int64_t PA = kInfNs, p_arr = start_ns;
+        if (P.probe_metric[lp] != kProbeNone) {
+            p_arr = first_probe_tick(P.probe_rate[lp], start_ns);
+            PA = p_arr;
+        }
+        X.PA[lp] = PA; X.seqP[lp] = 1; X.crtP[lp] = start_ns; X.p_arr[lp] = p_arr; X.p_n[lp] = 0;
+        X.ev_probe[lp] = 0; X.ev_probe[(size_t)n + lp] = 0;
+        X.seq[lp] = 2;
+    }
 }
 
 // The hot kernel: every LP advances to end_ns (== Simulation._execute_until for its events), then the
@@ -343,6 +368,10 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
         if (red_flags[0]) atomicOr(&tot->overflow, 1);
         if (red_flags[1]) atomicOr(&tot->qoverflow, 1);
     }
+    if constexpr (PF) {      // probe events straight to the totals (rare LPs)
+        if (live && S.evp[0]) atomicAdd(&tot->ev[13], (unsigned long long)S.evp[0]);
+        if (live && S.evp[1]) atomicAdd(&tot->ev[14], (unsigned long long)S.evp[1]);
+    }
     if (mode != HS_MODE_SINGLE) return;
 
     // ---- SINGLE mode: elect the globally first event beyond end_ns (last-block pattern)
@@ -385,6 +414,10 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
             for (int k = 0; k < 8; ++k) if (W.ev[k]) atomicAdd(&tot->ev[k], (unsigned long long)W.ev[k]);
             if (W.ev[6]) atomicAdd(&tot->completed, (unsigned long long)W.ev[6]);
             if (W.ev[7]) atomicAdd(&tot->received, (unsigned long long)W.ev[7]);
+            if constexpr (PF) {
+                if (W.evp[0]) atomicAdd(&tot->ev[13], (unsigned long long)W.evp[0]);
+                if (W.evp[1]) atomicAdd(&tot->ev[14], (unsigned long long)W.evp[1]);
+            }
             if (W.overflow) atomicOr(&tot->overflow, 1);
             new_cur = b.t;
             atomicMax(&tot->final_time, new_cur);
@@ -944,7 +977,8 @@ struct hs_engine {
     Totals *tot = nullptr;
     Candidate *cands = nullptr;
     bool is_net = false;
-    bool any_profile = false;  // some source has a time-varying rate profile
+    bool any_profile = false;  // some source has a time-varying rate profile (or a probe: same kernel instantiation)
+    bool any_probe = false;
     NetParams NP{};
     NetState NX{};
     ShardCtl SC{};             // wend_slots == nullptr: the engine holds the whole network
@@ -1230,6 +1264,23 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         pk[(size_t)i] = (uint8_t)k;
         h->any_profile = true;
     }
+    // Probes (instrumentation/probe.py:81-164): at most one per LP; rate = 1.0 / interval as the reference computes it
+    std::vector<uint8_t> pm((size_t)n, (uint8_t)255);
+    std::vector<double> prate((size_t)n, 1.0);
+    double min_interval = 0.0;
+    for (int i = 0; i < n && st->probe_metric; ++i) {
+        const int m = st->probe_metric[i];
+        if (m == 255) continue;
+        if (m < 0 || m > 6) return fail(h, HS_E_UNSUPPORTED, "LP %d: probe metric %d is not lowered", i, m);
+        if (!st->probe_interval_s) return fail(h, HS_E_INVALID, "probe_interval_s is required with probe_metric");
+        const double iv = st->probe_interval_s[i];
+        if (!(iv > 0.0) || !std::isfinite(iv)) return fail(h, HS_E_INVALID, "Probe interval must be positive.");   // probe.py:29-30
+        pm[(size_t)i] = (uint8_t)m;
+        prate[(size_t)i] = 1.0 / iv;
+        if (min_interval == 0.0 || iv < min_interval) min_interval = iv;
+        h->any_probe = true;
+    }
+    if (h->any_probe) h->any_profile = true;                        // probes run on the general-path instantiation
     h->C = maxc <= 1 ? 1 : maxc <= 2 ? 2 : maxc <= 4 ? 4 : maxc <= 8 ? 8 : 16;
     int64_t cap = h->cfg.log_capacity;
     if (cap <= 0) {
@@ -1259,6 +1310,8 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
 #undef UP
     if ((rc = upload<uint8_t>(h, &h->P.prof_kind, pk.data(), (size_t)n, 0))) return rc;
     if ((rc = upload<double>(h, &h->P.prof_p, pp.data(), (size_t)n * 4, 0.0))) return rc;
+    if ((rc = upload<uint8_t>(h, &h->P.probe_metric, pm.data(), (size_t)n, 255))) return rc;
+    if ((rc = upload<double>(h, &h->P.probe_rate, prate.data(), (size_t)n, 1.0))) return rc;
     const size_t N = (size_t)n, NC = (size_t)n * (size_t)h->C;
 #define AL(field, count) if ((rc = dev_alloc(h, &h->X.field, count))) return rc
     AL(A, N); AL(seqA, N); AL(crtA, N); AL(arr_k, N); AL(arr_time, N); AL(svc_k, N);
@@ -1267,6 +1320,15 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     AL(generated, N); AL(accepted, N); AL(dropped, N); AL(completed, N); AL(rejected, N); AL(started, N);
     AL(received, N); AL(sink_w, N); AL(total_service, N); AL(q, N); AL(grp_time, N); AL(last_time, N);
     AL(events, N); AL(ev_kind, N * 11);
+    if (h->any_profile) {      // the general-path instantiation of the run kernel loads / stores the probe state of every LP
+        AL(PA, N); AL(seqP, N); AL(crtP, N); AL(p_arr, N); AL(p_n, N); AL(ev_probe, N * 2);
+    }
+    if (h->any_probe) {
+        h->L.pcap = (int64_t)(horizon_s / min_interval) + 8;
+        if ((double)h->L.pcap * (double)n * 16.0 > 50e9) return fail(h, HS_E_INVALID, "probe logs would need %.1f GB", (double)h->L.pcap * n * 16.0 / 1e9);
+        if ((rc = dev_alloc(h, &h->L.probe_t, N * (size_t)h->L.pcap))) return rc;
+        if ((rc = dev_alloc(h, &h->L.probe_v, N * (size_t)h->L.pcap))) return rc;
+    }
 #undef AL
     if ((rc = dev_alloc(h, &h->L.adm, N * (size_t)cap))) return rc;
     if ((rc = dev_alloc(h, &h->L.sink_t, N * (size_t)cap))) return rc;
@@ -1289,7 +1351,7 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     if (h->initialised) return fail(h, HS_E_STATE, "set the network before the first run");
     if (h->cfg.mode != HS_MODE_SINGLE) return fail(h, HS_E_INVALID, "a network of stations is one Simulation: HS_MODE_SINGLE");
     if (h->C > 4) return fail(h, HS_E_UNSUPPORTED, "networked stations support concurrency <= 4 for now");
-    if (h->any_profile) return fail(h, HS_E_UNSUPPORTED, "time-varying rate profiles are not lowered for networked stations yet");
+    if (h->any_profile) return fail(h, HS_E_UNSUPPORTED, "time-varying rate profiles and probes are not lowered for networked stations yet");
     HS_HIP(h, hipSetDevice(h->cfg.device));
     const int n = h->cfg.n_lp, nl = net->n_links;
     if (nl < 0) return fail(h, HS_E_INVALID, "n_links < 0");
@@ -1710,8 +1772,7 @@ int hs_engine_get_summary(hs_engine *h, hs_summary *out) {
     HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
     memset(out, 0, sizeof *out);
     int64_t total = 0;
-    for (int k = 0; k < HS_EV_KINDS; ++k) out->events_by_kind[k] = 0;
-    for (int k = 0; k < 11; ++k) { out->events_by_kind[k] = (int64_t)t.ev[k]; total += (int64_t)t.ev[k]; }   // station / network kinds
+    for (int k = 0; k < HS_EV_KINDS; ++k) { out->events_by_kind[k] = (int64_t)t.ev[k]; total += (int64_t)t.ev[k]; }
     out->events_processed = total;
     out->events_cancelled = 0;
     out->final_time_ns = (h->cfg.mode == HS_MODE_SINGLE) ? t.cur_time : t.final_time;
@@ -1808,6 +1869,36 @@ int64_t hs_engine_read_sinks(hs_engine *h, int64_t *counts, int64_t *t_ns, int64
     hipFree(d_out);
     if (!ok) return fail(h, HS_E_HIP, "sink read-back failed");
     return total;
+}
+
+int64_t hs_engine_read_probe(hs_engine *h, int32_t lp, int64_t *t_ns, int64_t *values, int64_t cap) {
+    if (!h || !h->have_stations) return fail(h, HS_E_STATE, "stations not set");
+    if (lp < 0 || lp >= h->cfg.n_lp) return fail(h, HS_E_INVALID, "LP index %d out of range", lp);
+    if (!h->any_probe) return 0;
+    if (hipSetDevice(h->cfg.device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+        return fail(h, HS_E_HIP, "device synchronisation failed");
+    int64_t cnt = 0;
+    if (hipMemcpy(&cnt, h->X.p_n + lp, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, HS_E_HIP, "memcpy");
+    if (cnt > h->L.pcap) cnt = h->L.pcap;
+    if (cnt > cap) cnt = cap;
+    if (cnt > 0) {
+        int64_t *tmp = nullptr;
+        if (hipMalloc(&tmp, (size_t)cnt * 8) != hipSuccess) return fail(h, HS_E_HIP, "hipMalloc of the read-back staging buffer failed");
+        const int64_t *cols[2] = {h->L.probe_t, h->L.probe_v};
+        int64_t *dsts[2] = {t_ns, values};
+        for (int c = 0; c < 2; ++c) {
+            if (!dsts[c]) continue;
+            hipLaunchKernelGGL(hs_gather_one, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, cols[c], tmp,
+                               h->cfg.n_lp, lp, cnt);
+            if (hipStreamSynchronize(h->stream) != hipSuccess ||
+                hipMemcpy(dsts[c], tmp, (size_t)cnt * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+                hipFree(tmp);
+                return fail(h, HS_E_HIP, "probe read-back failed");
+            }
+        }
+        hipFree(tmp);
+    }
+    return cnt;
 }
 
 void hs_engine_destroy(hs_engine *h) {

@@ -13,7 +13,8 @@
 
 namespace hs {
 
-enum : uint32_t { kProfConstant = 0, kProfLinearRamp = 1, kProfSpike = 2 };
+enum : uint32_t { kProfConstant = 0, kProfLinearRamp = 1, kProfSpike = 2,
+                  kProfGeneralConstant = 3 /* constant rate p0 through the general path (instrumentation/probe.py:24-35) */ };
 
 struct Profile {
     uint32_t kind;
@@ -29,6 +30,7 @@ __device__ __forceinline__ double prof_rate(const Profile &pf, double t_seconds)
         const double fraction = t / pf.p0;
         return pf.p1 + fraction * (pf.p2 - pf.p1);
     }
+    if (pf.kind == kProfGeneralConstant) return pf.p0;
     if (t < pf.p2) return pf.p0;                       // SpikeProfile
     if (t < pf.p2 + pf.p3) return pf.p1;
     return pf.p0;

@@ -28,7 +28,8 @@
 namespace hs {
 
 // in-group event codes (low 3 bits) | slot << 3
-enum : uint32_t { Q_ENQ = 1, Q_NOTIFY = 2, Q_POLL = 3, Q_DELIVER = 4, Q_TICK = 5, Q_CONT = 6, Q_SINK = 7 };
+enum : uint32_t { Q_PSAMPLE = 0, Q_ENQ = 1, Q_NOTIFY = 2, Q_POLL = 3, Q_DELIVER = 4, Q_TICK = 5, Q_CONT = 6, Q_SINK = 7 };
+constexpr int kRootProbe = 99;  // pick_root: the pending probe tick
 
 constexpr int kBlock = 256;     // LPs per workgroup (4 wavefronts)
 constexpr int kQCap = 48;       // in-group FIFO capacity per LP (LDS)
@@ -76,7 +77,13 @@ struct StationParams {          // read-only, [n_lp] each
     const uint64_t *stream_base;
     const uint8_t *prof_kind;       // time-varying arrival rate (hs_profile.hpp): 0 constant, 1 linear ramp, 2 spike
     const double *prof_p;           // [4][n_lp]
+    const uint8_t *probe_metric;    // Probe attached to this LP: kProbe* metric, 255 = none
+    const double *probe_rate;       // 1.0 / interval  (_ProbeProfile.rate, instrumentation/probe.py:27-35)
 };
+
+// what a Probe samples with getattr(target, metric) (instrumentation/probe.py:51-66)
+enum : uint32_t { kProbeDepth = 0, kProbeActive = 1, kProbeAccepted = 2, kProbeDropped = 3, kProbeCompleted = 4,
+                  kProbeReceived = 5, kProbeGenerated = 6, kProbeNone = 255 };
 
 struct StationState {           // read-write; [n_lp] each unless noted
     int64_t *A;                 // pending tick time (kInfNs: none)
@@ -99,7 +106,12 @@ struct StationState {           // read-write; [n_lp] each unless noted
     int64_t *grp_time;          // timestamp of that pending group
     int64_t *last_time;         // time of the LP's last processed event
     int64_t *events;            // events processed by this LP
-    int64_t *ev_kind;           // [HS_EV_KINDS = 11][n_lp]
+    int64_t *ev_kind;           // [11][n_lp] station / network kinds
+    // Probe (PF instantiation only)
+    int64_t *PA;                // pending probe tick (kInfNs: none)
+    uint32_t *seqP;
+    int64_t *crtP, *p_arr, *p_n;   // creation time of the pending tick, the probe provider's current_time, samples taken
+    int64_t *ev_probe;          // [2][n_lp] SourceEvent@Probe, probe_event
 };
 
 struct RecordLogs {
@@ -108,10 +120,12 @@ struct RecordLogs {
     int64_t *sink_created;      // [cap][n_lp] created_at of the m-th sink record (C > 1; C == 1 aliases adm)
     int64_t *sink_created_own;  // the separately allocated column (null when the alias is the only option)
     int64_t cap;
+    int64_t *probe_t, *probe_v; // [pcap][n_lp] sample time / sampled value
+    int64_t pcap;
 };
 
 struct Totals {                 // engine-wide accumulators (device memory)
-    unsigned long long ev[11];
+    unsigned long long ev[15];  // HS_EV_KINDS; the station / network engines fill 0..10 and 13..14 (probes)
     unsigned long long completed;
     unsigned long long received;
     long long final_time;       // max over LPs of last processed time (REPLICAS) / global current time (SINGLE)
@@ -160,6 +174,12 @@ struct Station {
     ConstDiv div_rate, div_lambda;
     double inc_const;           // constant source: 1.0 / rate
     Profile prof;               // kind != 0: the ring holds target AREAS (E, not E / rate) and next_arrival() inverts the profile
+    // Probe (PF): a daemon Source of its own (instrumentation/probe.py:81-164) whose ticks sample this LP
+    uint32_t p_metric, seqP;
+    double p_rate;
+    int64_t PA, crtP, p_arr, p_n, pcap;
+    int64_t *probe_t, *probe_v;
+    uint32_t evp[2];
     // per-run deltas
     uint32_t ev[8];
     // logs
@@ -370,6 +390,35 @@ struct Station {
         sink_w++;
     }
 
+    // ---- Probe: Source.handle_event with _ProbeEventProvider, then the measurement callback ------------------
+    __device__ __forceinline__ bool has_probe() const { return PF && p_metric != kProbeNone; }
+    __device__ __forceinline__ void root_probe(int64_t t) {
+        evp[0]++;
+        Profile pp;
+        pp.kind = kProfGeneralConstant; pp.p0 = p_rate; pp.p1 = pp.p2 = pp.p3 = 0.0;
+        qpush(Q_PSAMPLE);                                                 // the daemon probe_event, created first
+        const int64_t a2 = prof_next_arrival(pp, p_arr, 1.0);             // ConstantArrivalTimeProvider over _ProbeProfile
+        p_arr = a2;
+        if (a2 <= t) PA = kInfNs;
+        else { PA = a2; seqP = seq++; crtP = t; }
+    }
+    __device__ __forceinline__ void do_probe_sample(int64_t t) {
+        evp[1]++;
+        int64_t v = 0;
+        switch (p_metric) {
+            case kProbeDepth: v = buf; break;
+            case kProbeActive: v = active; break;
+            case kProbeAccepted: v = accepted; break;
+            case kProbeDropped: v = dropped; break;
+            case kProbeCompleted: v = completed; break;
+            case kProbeReceived: v = received; break;
+            case kProbeGenerated: v = generated; break;
+            default: break;
+        }
+        if (p_n < pcap) { probe_t[p_n * ls] = t; probe_v[p_n * ls] = v; } else overflow = 1;
+        p_n++;
+    }
+
     // ---- chains with at most one event in flight (fast path pieces) ---------------------------
     // returns true if the general FIFO must take over (a same-time continuation was created)
     __device__ __forceinline__ bool chain_from_poll(int64_t t) {
@@ -407,10 +456,15 @@ struct Station {
 #pragma unroll
         for (int i = 0; i < C; ++i)
             if (D[i] == t && (best < 0 || (int32_t)(seqD[i] - bs) < 0)) { best = 1 + i; bs = seqD[i]; }
+        if constexpr (PF) {
+            if (has_probe() && PA == t && (best < 0 || (int32_t)(seqP - bs) < 0)) { best = kRootProbe; bs = seqP; }
+        }
         return best;
     }
     __device__ __forceinline__ void run_root(int which, int64_t t) {
-        if (which == 0) root_tick(t); else root_cont(which - 1, t);
+        if (which == 0) root_tick(t);
+        else if (PF && which == kRootProbe) root_probe(t);
+        else root_cont(which - 1, t);
     }
 
     // general in-group FIFO drain
@@ -429,6 +483,7 @@ struct Station {
                 case Q_TICK: root_tick(t); break;
                 case Q_CONT: root_cont((int)(code >> 3), t); break;
                 case Q_SINK: do_sink(); break;
+                case Q_PSAMPLE: if constexpr (PF) do_probe_sample(t); break;
                 default: break;
             }
         }
@@ -448,6 +503,7 @@ struct Station {
         int64_t t = A;
 #pragma unroll
         for (int i = 0; i < C; ++i) t = D[i] < t ? D[i] : t;
+        if constexpr (PF) { if (has_probe() && PA < t) t = PA; }
         return t;
     }
 
@@ -455,6 +511,7 @@ struct Station {
         int n_at = (A == t) ? 1 : 0;
 #pragma unroll
         for (int i = 0; i < C; ++i) n_at += (D[i] == t) ? 1 : 0;
+        if constexpr (PF) { if (has_probe() && PA == t) n_at += 2; }      // a probe tick: always the general path
         if (n_at == 1 && !force_general) {
             // Fast path: one event in flight at a time.  Both kinds of root converge on ONE poll/deliver/work
             // site so that a wavefront whose lanes mix ticks and departures executes the (expensive) service
@@ -509,7 +566,8 @@ struct Station {
         const bool poll = (notify && active < conc) || (dep && active_dep < conc);   // queue_driver.py:94-99 / :79-84
         const int64_t buf_enq = buf + (acc ? 1 : 0);
         const bool deliver = poll && buf_enq > 0;                       // queue.py:149-166
-        const bool slow = act && (force_general || svc_kind == 2 || (PF && prof.kind != kProfConstant) || (tick && D[0] == t) ||
+        const bool slow = act && (force_general || svc_kind == 2 || (PF && (prof.kind != kProfConstant || has_probe())) ||
+                                  (tick && D[0] == t) ||
                                   (tick && ((stop_ns >= 0 && t > stop_ns) || a2 <= t)) || (deliver && dur == 0));
         const bool fast = act && !slow;
         const bool tick_f = fast && tick, dep_f = fast && dep, acc_f = fast && acc;
@@ -581,7 +639,7 @@ struct Station {
     };
     __device__ __forceinline__ bool req_eligible() const {
         return C == 1 && !force_general && qn == 0 && conc == 1 && qcap < 0 && stop_ns < 0 && svc_kind != 2 &&
-               !(PF && prof.kind != kProfConstant) &&
+               !(PF && (prof.kind != kProfConstant || has_probe())) &&
                (egress == 0 || egress == 1) && !(buf > 0 && active == 0) && active <= 1;
     }
     __device__ __forceinline__ void req_count_departure(ReqCursor &c, bool p, int64_t d, double s) {

@@ -30,6 +30,8 @@ class StationArrays:
     stream_base: np.ndarray | None = None
     src_profile_kind: np.ndarray | None = None      # N.PROF_*; None = constant rate everywhere
     src_profile_params: np.ndarray | None = None    # [n, 4]
+    probe_metric: np.ndarray | None = None          # N.PROBE_METRICS ids, N.PROBE_NONE = no probe on the LP
+    probe_interval_s: np.ndarray | None = None
 
     @staticmethod
     def uniform(n: int, *, src_kind=N.SRC_POISSON, rate=8.0, stop_after_ns=-1, concurrency=1,
@@ -103,7 +105,8 @@ class StationEngine:
                             ("concurrency", np.int32), ("svc_kind", np.uint8), ("svc_mean_s", np.float64),
                             ("queue_cap", np.int64), ("egress", np.uint8), ("seed", np.uint64),
                             ("stream_base", np.uint64), ("src_profile_kind", np.uint8),
-                            ("src_profile_params", np.float64)):
+                            ("src_profile_params", np.float64), ("probe_metric", np.uint8),
+                            ("probe_interval_s", np.float64)):
             a = getattr(stations, name)
             if a is None:
                 setattr(st, name, None)
@@ -234,6 +237,13 @@ class StationEngine:
         cr = np.zeros(cap, np.int64)
         got = self._check(self._lib.hs_engine_read_sink(self._h, lp, t.ctypes.data, cr.ctypes.data, cap))
         return t[:got], cr[:got]
+
+    def read_probe(self, lp: int, cap: int = 1 << 22):
+        """(sample ns, value) of the LP's Probe in sampling order."""
+        t = np.zeros(cap, np.int64)
+        v = np.zeros(cap, np.int64)
+        got = self._check(self._lib.hs_engine_read_probe(self._h, lp, t.ctypes.data, v.ctypes.data, cap))
+        return t[:got].copy(), v[:got].copy()
 
     def read_sinks(self):
         """All sink records: (counts[n], t_ns[total], created_ns[total]) concatenated in LP order."""

@@ -614,3 +614,83 @@ class LoadBalancer(Entity):
     def stats(self) -> LoadBalancerStats:
         return LoadBalancerStats(self._requests_received, self._requests_forwarded, self._requests_failed,
                                  self._no_backend_available, 0, 0)
+
+
+# ---- probes --------------------------------------------------------------------------------------
+class Data:
+    """Time-series container of a Probe (instrumentation/data.py:20-110): `values` = [(time_s, value), ...]."""
+
+    def __init__(self) -> None:
+        self._t_ns = np.zeros(0, np.int64)
+        self._v = np.zeros(0, np.int64)
+        self._scale = None           # utilisation: value / concurrency
+
+    def _set(self, t_ns: np.ndarray, v: np.ndarray, scale=None) -> None:
+        self._t_ns, self._v, self._scale = t_ns, v, scale
+
+    def _val(self, v):
+        return int(v) if self._scale is None else int(v) / self._scale
+
+    @property
+    def values(self) -> list:
+        return [(float(t) / 1_000_000_000, self._val(v)) for t, v in zip(self._t_ns.tolist(), self._v.tolist())]
+
+    def times(self) -> list:
+        return [float(t) / 1_000_000_000 for t in self._t_ns.tolist()]
+
+    def raw_values(self) -> list:
+        return [self._val(v) for v in self._v.tolist()]
+
+    def count(self) -> int:
+        return int(len(self._v))
+
+    def mean(self) -> float:
+        vals = self.raw_values()
+        return sum(vals) / len(vals) if vals else 0.0
+
+    def min(self) -> float:
+        vals = self.raw_values()
+        return min(vals) if vals else 0.0
+
+    def max(self) -> float:
+        vals = self.raw_values()
+        return max(vals) if vals else 0.0
+
+    def __len__(self) -> int:
+        return self.count()
+
+
+class Probe(Entity):
+    """Periodic metric sampler (instrumentation/probe.py:81-164): a daemon Source that reads `getattr(target, metric)`
+    every `interval` seconds into a Data container.  Lowered metrics: Server.depth / active_requests / utilization /
+    stats_accepted / stats_dropped / requests completed, Sink.events_received, Source.generated_count."""
+
+    _LOWERED = {"depth", "active_requests", "utilization", "stats_accepted", "stats_dropped", "requests_completed",
+                "_requests_completed", "events_received", "generated_count", "_generated_count"}
+
+    def __init__(self, target: Entity, metric: str, data: Data, interval: float = 1.0, start_time: Instant | None = None):
+        if interval <= 0:
+            raise ValueError("Probe interval must be positive.")                  # probe.py:29-30
+        if start_time is not None and start_time != Instant.Epoch:
+            raise NotImplementedError("a probe start_time other than the Simulation's is not lowered")
+        if metric not in self._LOWERED:
+            raise NotImplementedError(f"probe metric '{metric}' is an arbitrary attribute; lowered: {sorted(self._LOWERED)}")
+        super().__init__(f"Probe_{target.name}_{metric}")
+        self.target = target
+        self.metric = metric
+        self.data_sink = data
+        self.interval = float(interval)
+
+    @classmethod
+    def on(cls, target: Entity, metric: str, interval: float = 1.0):
+        data = Data()
+        return cls(target=target, metric=metric, data=data, interval=interval), data
+
+    @classmethod
+    def on_many(cls, target: Entity, metrics: list, interval: float = 1.0):
+        probes, data = [], {}
+        for m in metrics:
+            p, d = cls.on(target, m, interval=interval)
+            probes.append(p)
+            data[m] = d
+        return probes, data

@@ -31,6 +31,7 @@ class UnsupportedTopology(NotImplementedError):
 
 @dataclass
 class Station:
+    probe: object | None = None                      # the Probe sampling one of this station's entities
     source: Source | None = None
     server: Server | None = None
     sink: _RecordSink | None = None
@@ -84,6 +85,14 @@ class LoweredGraph:
                 a.svc_kind[i] = N.LAT_NO_SERVER
                 a.svc_mean_s[i] = 0.0
             a.egress[i] = N.EGRESS_SINK if st.sink is not None else N.EGRESS_NONE
+            if st.probe is not None:
+                if a.probe_metric is None:
+                    a.probe_metric = np.full(n, N.PROBE_NONE, np.uint8)
+                    a.probe_interval_s = np.ones(n, np.float64)
+                m = st.probe.metric
+                a.probe_metric[i] = N.PROBE_METRICS["active_requests" if m == "utilization" else
+                                                    "generated_count" if m == "_generated_count" else m]
+                a.probe_interval_s[i] = st.probe.interval
         return a
 
     def network_arrays(self, bag_capacity: int = 0) -> NetworkArrays:
@@ -131,6 +140,40 @@ class LoweredGraph:
         lam = float(inflow.max()) if n else 0.0
         mean = lam * horizon_s
         return int(mean + 10.0 * (mean + 1.0) ** 0.5 + 64)
+
+
+def attach_probes(g: LoweredGraph, probes: list) -> None:
+    """Probe(target, metric, interval) -> the station that owns `target` (one probe per station)."""
+    from .entities import Probe
+
+    owner = {}
+    for i, st in enumerate(g.stations):
+        for obj in (st.source, st.server, st.sink):
+            if obj is not None:
+                owner[id(obj)] = i
+    for pr in probes or []:
+        if not isinstance(pr, Probe):
+            raise UnsupportedTopology(f"probe {type(pr).__name__} is not a lowered Probe")
+        i = owner.get(id(pr.target))
+        if i is None:
+            raise UnsupportedTopology(f"probe '{pr.name}': its target is not an entity of this Simulation")
+        st = g.stations[i]
+        if st.probe is not None:
+            raise UnsupportedTopology(f"station of '{pr.target.name}' already has a probe; one Probe per station is lowered")
+        kinds = {"generated_count": Source, "_generated_count": Source, "events_received": _SINKS}
+        want = kinds.get(pr.metric, Server)
+        if not isinstance(pr.target, want):
+            raise UnsupportedTopology(f"probe '{pr.name}': metric '{pr.metric}' is not an attribute of {type(pr.target).__name__}")
+        if g.is_network:
+            raise UnsupportedTopology("probes are not lowered for networked stations yet")
+        st.probe = pr
+
+
+def write_back_probes(g: LoweredGraph, eng) -> None:
+    for i, st in enumerate(g.stations):
+        if st.probe is not None:
+            t, v = eng.read_probe(i)
+            st.probe.data_sink._set(t, v, st.server.concurrency if st.probe.metric == "utilization" else None)
 
 
 def lower(sources: list, entities: list) -> LoweredGraph:

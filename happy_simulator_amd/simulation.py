@@ -8,8 +8,8 @@ from . import _native as N
 from .core.temporal import Instant
 from .engine import StationEngine
 from .entities import Counter, Entity, LatencyTracker, Server, Sink
-from .lowering import (LbGraph, LoweredGraph, UnsupportedTopology, find_load_balancer, lower, lower_lb, write_back,
-                       write_back_lb)
+from .lowering import (LbGraph, LoweredGraph, UnsupportedTopology, attach_probes, find_load_balancer, lower, lower_lb,
+                       write_back, write_back_lb, write_back_probes)
 from .summary import EntitySummary, QueueStats, SimulationSummary
 
 _DEFAULT_SEED = 42
@@ -36,8 +36,7 @@ class Simulation:
             self._end_time = Instant.Infinity
         self._sources = list(sources or [])
         self._entities = list(entities or [])
-        if probes:
-            raise UnsupportedTopology("probes are daemon Sources polling Python attributes; not lowered (SURVEY N4)")
+        self._probes = list(probes or [])
         if trace_recorder is not None:
             raise UnsupportedTopology("trace recorders force the reference's slow loop; profile with rocprofv3 instead")
         if fault_schedule is not None:
@@ -60,6 +59,10 @@ class Simulation:
             lb = find_load_balancer(self._sources, self._entities)
             self._graph = lower_lb(self._sources, self._entities, lb) if lb is not None else lower(self._sources,
                                                                                                     self._entities)
+            if self._probes:
+                if lb is not None:
+                    raise UnsupportedTopology("probes are not lowered for load-balancer topologies yet")
+                attach_probes(self._graph, self._probes)
         return self._graph
 
     def _run_lb(self, g: LbGraph, wall0: float) -> SimulationSummary:
@@ -98,6 +101,8 @@ class Simulation:
             stats = eng.lp_stats()
             counts, t_ns, created_ns = eng.read_sinks()
             net_stats = eng.net_stats() if net is not None else None
+            if self._probes:
+                write_back_probes(g, eng)
         write_back(g, stats, counts, t_ns, created_ns, net_stats)
         self._engine_summary = es
         self._events_processed = es.events_processed

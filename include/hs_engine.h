@@ -77,7 +77,9 @@ enum {
     HS_EV_ROUTE = 10,       /* Request @ RandomRouter                       */
     HS_EV_LB = 11,          /* Request @ LoadBalancer (forwarded to the selected backend)        */
     HS_EV_LB_RESP = 12,     /* _lb_response @ LoadBalancer (completion hook of the forwarded Request) */
-    HS_EV_KINDS = 13
+    HS_EV_PROBE_TICK = 13,  /* SourceEvent @ Probe (instrumentation/probe.py:81-164)                         */
+    HS_EV_PROBE = 14,       /* probe_event (daemon) @ the measurement callback                                */
+    HS_EV_KINDS = 15
 };
 
 typedef struct hs_config {
@@ -116,7 +118,23 @@ typedef struct hs_stations {
     const uint8_t *src_profile_kind;   /* hs_profile_kind */
     const double *src_profile_params;  /* [n_lp][4]: LINEAR_RAMP {duration_s, start_rate, end_rate, -};
                                           SPIKE {baseline_rate, spike_rate, warmup_s, spike_duration_s} */
+    /* Probe(target, metric, interval) attached to the LP's Source / Server / Sink (instrumentation/probe.py:81-164):
+     * a daemon Source of its own that samples getattr(target, metric) every `interval` seconds (tick times follow
+     * ConstantArrivalTimeProvider over _ProbeProfile: the general numerical path, like the reference).  Each tick is two
+     * reference events (SourceEvent@Probe, probe_event).  One probe per LP.  NULL = no probes. */
+    const uint8_t *probe_metric;       /* hs_probe_metric; 255 = none */
+    const double *probe_interval_s;    /* > 0 */
 } hs_stations;
+typedef enum hs_probe_metric {
+    HS_PROBE_DEPTH = 0,        /* QueuedResource.depth */
+    HS_PROBE_ACTIVE = 1,       /* Server.active_requests */
+    HS_PROBE_ACCEPTED = 2,     /* stats_accepted */
+    HS_PROBE_DROPPED = 3,      /* stats_dropped */
+    HS_PROBE_COMPLETED = 4,    /* Server._requests_completed */
+    HS_PROBE_RECEIVED = 5,     /* Sink.events_received */
+    HS_PROBE_GENERATED = 6,    /* Source.generated_count */
+    HS_PROBE_NONE = 255
+} hs_probe_metric;
 typedef enum hs_profile_kind { HS_PROF_CONSTANT = 0, HS_PROF_LINEAR_RAMP = 1, HS_PROF_SPIKE = 2 } hs_profile_kind;
 
 /* Links between stations (the engine-side form of the reference's partition links, parallel/link.py:18-79,
@@ -356,6 +374,10 @@ int hs_debug_lb_flags(hs_lb *h, int flags);
  * the sort the load-balancer engine uses (csrc/hs_radix.hpp).  Host arrays in, host arrays out. */
 int hs_debug_radix_sort(int32_t device, int64_t n, int32_t key_bits, const uint64_t *keys_in, const uint64_t *vals_in,
                         uint64_t *keys_out, uint64_t *vals_out, float *device_ms);
+
+/* Samples of the LP's Probe in sampling order: (sample time ns, value) -- what the reference appends to the probe's
+ * Data container (instrumentation/probe.py:63).  Returns the number copied or a negative hs_status. */
+int64_t hs_engine_read_probe(hs_engine *h, int32_t lp, int64_t *t_ns, int64_t *values, int64_t cap);
 
 const char *hs_last_error(const hs_engine *h);
 const char *hs_last_global_error(void);

@@ -201,6 +201,13 @@ def engine_for_spec(spec, log_capacity=0, horizon_ns=None, flags=0):
             st.src_profile_kind[i] = N.PROF_LINEAR_RAMP if pr[0] == "ramp" else N.PROF_SPIKE
             st.src_profile_params[i, :len(pr) - 1] = pr[1:]
             st.src_rate[i] = max(pr[2], pr[3]) if pr[0] == "ramp" else max(pr[1], pr[2])     # peak: sizes the logs
+    if any(pr is not None for pr in p["probes"]):
+        st.probe_metric = np.full(n, N.PROBE_NONE, np.uint8)
+        st.probe_interval_s = np.ones(n, np.float64)
+        for i, pr in enumerate(p["probes"]):
+            if pr is not None:
+                st.probe_metric[i] = PROBE_METRICS[pr[0]][1]
+                st.probe_interval_s[i] = pr[1]
     if spec["mode"] == "single":
         mode = N.MODE_SINGLE
         seed = spec["seed"]

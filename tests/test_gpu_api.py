@@ -286,3 +286,34 @@ def test_time_varying_profiles_through_the_api_match_reference_golden():
         gt, glat = gold.sink_records(i)
         assert [t.nanoseconds for t in c[2].completion_times] == gt.tolist()
         assert c[2].latencies_s == glat.tolist()
+
+
+def test_probes_through_the_api_match_reference_golden():
+    """`Simulation(probes=[Probe.on(server, "depth", 0.5), ...])`: sample times and values equal what the live reference's
+    probes appended to their Data containers (tests/golden/probe_depth_4chains.npz)."""
+    gold = H.Golden("probe_depth_4chains")
+    spec = gold.spec
+    p = H.spec_chain_params(spec)
+    chains, probes, datas = [], [], []
+    for i in range(p["n"]):
+        sink = hs.Sink(f"sink{i}")
+        srv = hs.Server(f"srv{i}", concurrency=p["conc"][i], service_time=hs.ExponentialLatency(p["mean"][i]),
+                        queue_capacity=None if p["qcap"][i] < 0 else p["qcap"][i], downstream=sink)
+        src = hs.Source.poisson(rate=p["rate"][i], target=srv, name=f"src{i}")
+        metric, interval = p["probes"][i]
+        target = {"server": srv, "sink": sink, "source": src}[H.PROBE_METRICS[metric][0]]
+        pr, d = hs.Probe.on(target, metric, interval=interval)
+        chains.append((src, srv, sink))
+        probes.append(pr)
+        datas.append(d)
+    sim = hs.Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=[c[0] for c in chains],
+                        entities=[e for c in chains for e in c[1:]], probes=probes, seed=spec["seed"])
+    summary = sim.run()
+    assert summary.total_events_processed == gold.meta["total_events"][0]
+    assert summary.duration_s == gold.meta["duration_s"][0]
+    for i, d in enumerate(datas):
+        a, b = gold.probe_off[i], gold.probe_off[i + 1]
+        assert d.raw_values() == gold.probe_v[a:b].tolist()
+        assert d.times() == (gold.probe_t_ns[a:b].astype(np.float64) / 1e9).tolist()        # Data stores time.to_seconds()
+        assert d.count() == b - a and d.max() == max(gold.probe_v[a:b].tolist())
+    assert [c[2].events_received for c in chains] == gold.received.tolist()

@@ -27,9 +27,9 @@ def _compare_engine_to_oracle(spec, eng, p, runs, check_kinds=True):
     want, sinks = H.oracle_per_chain(spec, runs)
     assert s.events_processed == sum(r.events_processed for _, _, r in runs)
     if check_kinds:
-        kinds = sum(r.events_by_kind[:8] for _, _, r in runs)
-        np.testing.assert_array_equal(s.events_by_kind[:8], kinds)
-        assert not s.events_by_kind[8:].any()          # no link / router events without a network
+        kinds = sum(r.events_by_kind for _, _, r in runs)
+        np.testing.assert_array_equal(s.events_by_kind, kinds)
+        assert not s.events_by_kind[8:13].any()        # no link / router / load-balancer events without those entities
     for k, v in want.items():
         np.testing.assert_array_equal(stats[k], v, err_msg=k)
     if spec["mode"] == "single":
@@ -101,9 +101,13 @@ def test_engine_matches_reference_golden(name):
             np.testing.assert_array_equal(stats["final_time_ns"], gold.meta["final_ns"])
             np.testing.assert_array_equal(stats["events"], gold.meta["total_events"])
         if "trace" in gold.arrays:
-            kinds = np.bincount(gold.trace[:, 1], minlength=8)[:8]
-            np.testing.assert_array_equal(s.events_by_kind[:8], kinds)
-            assert not s.events_by_kind[8:].any()
+            np.testing.assert_array_equal(s.events_by_kind, np.bincount(gold.trace[:, 1], minlength=len(s.events_by_kind)))
+        if "probe_t_ns" in gold.arrays:          # Probe samples: what the reference appended to each probe's Data
+            for c in range(spec["n_chains"]):
+                a, b = gold.probe_off[c], gold.probe_off[c + 1]
+                pt, pv = eng.read_probe(c)
+                np.testing.assert_array_equal(pt, gold.probe_t_ns[a:b], err_msg=f"probe times chain {c}")
+                np.testing.assert_array_equal(pv, gold.probe_v[a:b], err_msg=f"probe values chain {c}")
         for k, g in (("generated", "generated"), ("accepted", "accepted"), ("dropped", "dropped"),
                      ("completed", "completed"), ("rejected", "rejected"), ("sink_received", "received"),
                      ("queue_depth", "depth"), ("active", "active"), ("total_service_s", "total_service_s")):

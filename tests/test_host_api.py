@@ -124,8 +124,8 @@ class TestLowering:
         tandem = hs.Server("t1", downstream=hs.Server("t2"))
         with pytest.raises(hs.UnsupportedTopology, match="forwards to Server"):
             hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=tandem)]).lowered()
-        with pytest.raises(hs.UnsupportedTopology, match="probes"):
-            hs.Simulation(duration=1, probes=[object()])
+        with pytest.raises(hs.UnsupportedTopology, match="not a lowered Probe"):
+            hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=hs.Sink())], probes=[object()]).lowered()
 
 
 def test_shard_range_partitions_exactly():
@@ -285,3 +285,30 @@ def test_profiles_are_lowered_and_unknown_profiles_refused():
 
     with pytest.raises(NotImplementedError, match="arbitrary Python"):
         hs.Source.with_profile(Custom(), target=hs.Sink())
+
+
+def test_probes_are_lowered_onto_their_station():
+    """Probe.on(target, metric, interval) (instrumentation/probe.py:81-164) -> hs_stations.probe_metric / probe_interval_s."""
+    sink = hs.Sink("k")
+    srv = hs.Server("s", concurrency=2, service_time=hs.ExponentialLatency(0.1), downstream=sink)
+    src = hs.Source.poisson(rate=8, target=srv, name="src")
+    other = hs.Server("t", downstream=hs.Sink("k2"))
+    src2 = hs.Source.poisson(rate=3, target=other, name="src2")
+    p1, d1 = hs.Probe.on(srv, "depth", interval=0.5)
+    p2, d2 = hs.Probe.on(other.downstream, "events_received", interval=2.0)
+    sim = hs.Simulation(duration=10, sources=[src, src2], entities=[srv, sink, other, other.downstream], probes=[p1, p2])
+    a = sim.lowered().arrays()
+    assert list(a.probe_metric) == [N.PROBE_METRICS["depth"], N.PROBE_METRICS["events_received"]]
+    assert list(a.probe_interval_s) == [0.5, 2.0] and p1.name == "Probe_s_depth" and len(d1) == 0
+    with pytest.raises(ValueError, match="interval must be positive"):
+        hs.Probe.on(srv, "depth", interval=0.0)
+    with pytest.raises(NotImplementedError, match="arbitrary attribute"):
+        hs.Probe.on(srv, "some_custom_attr")
+    p3, _ = hs.Probe.on(srv, "active_requests")
+    with pytest.raises(hs.UnsupportedTopology, match="one Probe per station"):
+        hs.Simulation(duration=1, sources=[src], entities=[srv, sink], probes=[p1, p3]).lowered()
+    p4, _ = hs.Probe.on(sink, "depth")
+    with pytest.raises(hs.UnsupportedTopology, match="not an attribute of Sink"):
+        hs.Simulation(duration=1, sources=[src], entities=[srv, sink], probes=[p4]).lowered()
+    probes, data = hs.Probe.on_many(srv, ["depth", "utilization"], interval=1.0)
+    assert [p.metric for p in probes] == ["depth", "utilization"] and set(data) == {"depth", "utilization"}
