@@ -216,9 +216,14 @@ def lb_main(args, rank, local_rank, world, distributed, dist):
         n_req = int(st["lb"][0])
         n_done = int(s.sink_records)
         tb, bb = int(end_ns).bit_length(), int(B - 1).bit_length()
-        r = (tb + bb) % 8                                      # low key bits the sorts skip (csrc/hs_lb.hip hs_lb_create)
-        g_arr = r + 8 if (r + 8 <= 12 and r + 8 <= tb) else (r if r <= tb else 0)
-        g_sink = tb % 8 if tb > 8 else 0
+        # low key bits the sorts skip (csrc/hs_lb.hip hs_lb_create): whole digits while a bucket holds <= 1 element on average
+        total_rate = args.lb_rate * S
+        g_arr, g = 0, (tb + bb) % 8
+        while g <= tb and tb + bb - g >= 8 and (total_rate / B * 2.0 ** g * 1e-9 <= 1.0 or g == (tb + bb) % 8):
+            g_arr, g = g, g + 8
+        g_sink, g = 0, tb % 8
+        while tb - g >= 8 and (total_rate * 2.0 ** g * 1e-9 <= 1.0 or g == tb % 8):
+            g_sink, g = g, g + 8
         p1, p2 = -(-(tb + bb - g_arr) // 8), -(-(tb - g_sink) // 8)
         sort_bytes = 40 * (p1 * n_req + p2 * n_done)          # per pass and element: 8 B histogram read + 16 B in + 16 B out
         sort_s = float(np.mean(sort_ms)) * 1e-3

@@ -233,10 +233,12 @@ struct SlotVal { __device__ __forceinline__ uint64_t operator()(int64_t i) const
 // ---------------------------------------------------------------------------------------------
 // 2b. Segment offsets: backend b's arrivals are sorted[off[b] .. off[b+1])
 // ---------------------------------------------------------------------------------------------
-// The sort ran on key bits [g, ...) only (one or two 8-bit passes saved): elements whose keys agree above bit g are still
-// in input order.  Such runs are short and rare (two Requests for one backend within 2^g ns); the thread at the head of a
-// run puts it in full-key order, stably.  g <= tb, so a run never spans two backends.
-__global__ void hs_lb_segments(uint64_t *__restrict__ skey, uint64_t *__restrict__ sval, const int64_t *n_ptr, int tb,
+// The sort ran on key bits [g, ...) only (whole 8-bit passes saved): elements whose keys agree above bit g are still in
+// input order.  Such runs are short (the host picks g so that a bucket holds <= 1 element on average); every element
+// finds its place inside its run by counting the run's smaller (key, position) pairs -- stable -- and the list is
+// written out in full-key order to the other ping-pong buffer.  g <= tb, so a run never spans two backends.
+__global__ void hs_lb_segments(const uint64_t *__restrict__ skey, const uint64_t *__restrict__ sval,
+                               uint64_t *__restrict__ fkey, uint64_t *__restrict__ fval, const int64_t *n_ptr, int tb,
                                int g, int B, int64_t *__restrict__ off) {
     const int64_t n = *n_ptr;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -246,26 +248,26 @@ __global__ void hs_lb_segments(uint64_t *__restrict__ skey, uint64_t *__restrict
     const int64_t b_prev = i == 0 ? -1 : (int64_t)(k_prev >> tb);
     const int64_t b_here = i == n ? (int64_t)B : (int64_t)(k_here >> tb);
     for (int64_t b = b_prev + 1; b <= b_here; ++b) off[b] = i;
-    if (g == 0 || i == n) return;
-    const uint64_t hi = k_here >> g;
-    if (i > 0 && (k_prev >> g) == hi) return;              // not the head of its run
-    int64_t len = 1;
-    bool sorted = true;
-    uint64_t last = k_here;
-    while (i + len < n) {
-        const uint64_t k = skey[i + len];
-        if ((k >> g) != hi) break;
-        sorted = sorted && k >= last;
-        last = k;
-        ++len;
+    if (i == n) return;
+    int64_t pos = i;
+    if (g > 0) {
+        const uint64_t hi = k_here >> g;
+        int64_t lo = i, rank = 0;
+        while (lo > 0) {                                     // elements of the run before this one
+            const uint64_t k = skey[lo - 1];
+            if ((k >> g) != hi) break;
+            rank += (k <= k_here) ? 1 : 0;                   // equal keys keep their input order
+            --lo;
+        }
+        for (int64_t j = i + 1; j < n; ++j) {                // ... and after it
+            const uint64_t k = skey[j];
+            if ((k >> g) != hi) break;
+            rank += (k < k_here) ? 1 : 0;
+        }
+        pos = lo + rank;
     }
-    if (len == 1 || sorted) return;
-    for (int64_t a = 1; a < len; ++a) {                    // stable insertion sort by the full key
-        const uint64_t k = skey[i + a], v = sval[i + a];
-        int64_t j = a;
-        while (j > 0 && skey[i + j - 1] > k) { skey[i + j] = skey[i + j - 1]; sval[i + j] = sval[i + j - 1]; --j; }
-        skey[i + j] = k; sval[i + j] = v;
-    }
+    fkey[pos] = k_here;
+    fval[pos] = sval[i];
 }
 
 // keys-only variant of the run fix-up above (latency statistics)
@@ -699,7 +701,8 @@ struct SinkValid {
 // stable in slot order = (backend, completion order), so only runs of equal keys need a look.
 // slot_bits > 0: the merged value is (created_at << slot_bits) | slot; slot_bits == 0: the value is the slot and created_at
 // is gathered from the completion log.  The merge sorted on key bits [g, tb) only: a run of completions within the same
-// 2^g ns is still in slot order and is ordered here by (completion ns, service start, slot).
+// 2^g ns is still in slot order; every element finds its place in its run by counting the run's elements that precede it
+// in (completion ns, service start, slot) order.
 __global__ void hs_lb_sink_finish(const uint64_t *__restrict__ mkey, const uint64_t *__restrict__ mval, const int64_t *n_ptr,
                                   const int64_t *__restrict__ sink_created, const int64_t *__restrict__ sink_S,
                                   int64_t *__restrict__ out_t, int64_t *__restrict__ out_created, int slot_bits, int g) {
@@ -707,36 +710,24 @@ __global__ void hs_lb_sink_finish(const uint64_t *__restrict__ mkey, const uint6
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t smask = slot_bits ? ((1ull << slot_bits) - 1) : ~0ull;
-    const uint64_t k = mkey[i];
+    const uint64_t k = mkey[i], v = mval[i], slot = v & smask;
     const uint64_t hi = k >> g;
-    const bool same_prev = i > 0 && (mkey[i - 1] >> g) == hi;
-    const bool same_next = i + 1 < n && (mkey[i + 1] >> g) == hi;
-    if (!same_prev && !same_next) {
-        const uint64_t v = mval[i];
-        out_t[i] = (int64_t)k;
-        out_created[i] = slot_bits ? (int64_t)(v >> slot_bits) : sink_created[v];
-        return;
-    }
-    if (same_prev) return;                       // the head of the run writes the whole run
-    int64_t len = 1;
-    while (i + len < n && (mkey[i + len] >> g) == hi) ++len;
-    for (int64_t a = 0; a < len; ++a) {          // rank of element a within the run by (t, service start, slot)
-        const uint64_t ka = mkey[i + a], va = mval[i + a], sa = va & smask;
-        int64_t Sa = 0;
-        bool haveS = false;
-        int64_t r = 0;
-        for (int64_t c = 0; c < len; ++c) {
-            if (c == a) continue;
-            const uint64_t kc = mkey[i + c];
-            if (kc != ka) { r += kc < ka ? 1 : 0; continue; }
-            if (!haveS) { Sa = sink_S[sa]; haveS = true; }
-            const uint64_t sc = mval[i + c] & smask;
-            const int64_t Sc = sink_S[sc];
-            if (Sc < Sa || (Sc == Sa && sc < sa)) ++r;
-        }
-        out_t[i + r] = (int64_t)ka;
-        out_created[i + r] = slot_bits ? (int64_t)(va >> slot_bits) : sink_created[sa];
-    }
+    int64_t lo = i, rank = 0, S_me = 0;
+    bool haveS = false;
+    // before(c): element c precedes this one: smaller time, or equal time and (earlier service start, then lower slot)
+    auto before = [&](int64_t c) {
+        const uint64_t kc = mkey[c];
+        if (kc != k) return kc < k;
+        if (!haveS) { S_me = sink_S[slot]; haveS = true; }
+        const uint64_t sc = mval[c] & smask;
+        const int64_t Sc = sink_S[sc];
+        return Sc < S_me || (Sc == S_me && sc < slot);
+    };
+    while (lo > 0 && (mkey[lo - 1] >> g) == hi) { rank += before(lo - 1) ? 1 : 0; --lo; }
+    for (int64_t j = i + 1; j < n && (mkey[j] >> g) == hi; ++j) rank += before(j) ? 1 : 0;
+    const int64_t pos = lo + rank;
+    out_t[pos] = (int64_t)k;
+    out_created[pos] = slot_bits ? (int64_t)(v >> slot_bits) : sink_created[slot];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1038,8 +1029,12 @@ int run_async(hs_lb *h, int64_t end_ns) {
     radix_sort_async(h, h->keys0, h->vals0, h->n_slots_dev, h->n_arr, h->tb + h->bb,
                      TickValid{h->PS.count, S, h->n_slots < (1ll << 31)}, NoVal{}, &h->skey, &h->sval, nullptr, h->g_arr);
     hipEventRecord(h->evs1, h->stream);
-    hipLaunchKernelGGL(hs_lb_segments, dim3((unsigned)((h->n_slots + 1 + 255) / 256)), dim3(256), 0, h->stream, h->skey,
-                       h->sval, h->n_arr, h->tb, h->g_arr, B, h->off);
+    {   // segment offsets + full-key order inside the runs the sort left, written to the other ping-pong buffer
+        uint64_t *fk = h->skey == h->kA ? h->kB : h->kA, *fv = h->skey == h->kA ? h->vB : h->vA;
+        hipLaunchKernelGGL(hs_lb_segments, dim3((unsigned)((h->n_slots + 1 + 255) / 256)), dim3(256), 0, h->stream, h->skey,
+                           h->sval, fk, fv, h->n_arr, h->tb, h->g_arr, B, h->off);
+        h->skey = fk; h->sval = fv;
+    }
     if (h->C == 1 && h->any_simple && (h->flags & 3) == 0)
         hipLaunchKernelGGL(hs_lb_service_draws, dim3((unsigned)((h->n_slots + 255) / 256)), dim3(256), 0, h->stream, h->skey,
                            h->n_arr, h->off, h->tb, h->PB, h->cfg.seed, h->svdraw);
@@ -1108,7 +1103,7 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     if (cfg->device < 0 || cfg->device >= ndev) return lfail(nullptr, HS_E_INVALID, "device ordinal %d out of range (%d devices)", cfg->device, ndev);
     // ---- validation + sizing
     const double horizon_s = (double)(cfg->horizon_ns - cfg->start_ns) / 1e9;
-    double max_ticks = 0.0;
+    double max_ticks = 0.0, total_rate = 0.0;
     int64_t kmax = 0;
     for (int i = 0; i < S; ++i) {
         const int sk = src->src_kind ? src->src_kind[i] : HS_SRC_POISSON;
@@ -1117,6 +1112,7 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
         if (!(r > 0.0) || !std::isfinite(r)) return lfail(nullptr, HS_E_INVALID, "source %d: rate must be > 0 (got %g)", i, r);
         if (r > 1e8) return lfail(nullptr, HS_E_UNSUPPORTED, "source %d: rate %g above 1e8/s is not supported", i, r);
         max_ticks = std::max(max_ticks, r * horizon_s);
+        total_rate += r;
         if (src->n_clients[i] < 1) return lfail(nullptr, HS_E_INVALID, "source %d: n_clients must be >= 1", i);
         kmax = std::max(kmax, src->n_clients[i]);
     }
@@ -1150,13 +1146,20 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     h->n_slots = cap * (int64_t)S;
     if ((double)h->n_slots * 88.0 > 200e9) { delete h; return lfail(nullptr, HS_E_INVALID, "buffers would need %.1f GB", (double)h->n_slots * 88.0 / 1e9); }
     h->n_tiles = (int)((h->n_slots + kRadixTile - 1) / kRadixTile);
-    {   // sort on whole 8-bit digits only: the ragged low bits are left to the run fix-ups; the arrival sort may drop one
-        // more digit while its buckets stay within ~4 us (two Requests for one backend that close are rare)
-        const int r = (h->tb + h->bb) % kRadixBits;
-        h->g_arr = (r + kRadixBits <= 12 && r + kRadixBits <= h->tb) ? r + kRadixBits : (r <= h->tb ? r : 0);
-        h->g_sink = h->tb % kRadixBits;
-        if (h->tb <= kRadixBits) { h->g_sink = 0; }
-        if (h->tb + h->bb - h->g_arr < kRadixBits) h->g_arr = 0;
+    {   // The sorts skip low key bits: elements whose keys agree on the sorted bits stay in input order and are put in
+        // full-key order inside those runs afterwards (hs_lb_segments / hs_lb_sink_finish).  Skip whole 8-bit digits while
+        // the EXPECTED number of elements per bucket stays <= 1 (runs of two or three, rare longer ones): a bucket of the
+        // arrival sort is (one backend, 2^g ns) and sees total_rate / B requests per second on average, a bucket of the
+        // Sink merge is 2^g ns of all completions.
+        const double per_backend = total_rate / (double)B;
+        const int r_arr = (h->tb + h->bb) % kRadixBits;
+        h->g_arr = 0;
+        for (int g = r_arr; g <= h->tb && h->tb + h->bb - g >= kRadixBits; g += kRadixBits)
+            if (per_backend * std::ldexp(1.0, g) * 1e-9 <= 1.0 || g == r_arr) h->g_arr = g; else break;
+        h->g_sink = 0;
+        const int r_snk = h->tb % kRadixBits;
+        for (int g = r_snk; h->tb - g >= kRadixBits; g += kRadixBits)
+            if (total_rate * std::ldexp(1.0, g) * 1e-9 <= 1.0 || g == r_snk) h->g_sink = g; else break;
     }
     {
         const int sb = bit_length((uint64_t)(h->n_slots > 1 ? h->n_slots - 1 : 1));
