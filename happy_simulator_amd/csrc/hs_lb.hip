@@ -56,6 +56,20 @@ struct LbTotals {
     long long final_time;         // Simulation._current_time after the run (the overshoot event's time)
     int qoverflow, bad_client;
     long long max_count;          // most Requests emitted by one source (rows of the arrival log in use)
+    long long max_be;             // most Requests routed to one backend (rows of the wave-coalesced layout in use)
+    int use_t;                    // this run uses the [row][backend] layout for the backend streams (max_be <= rows)
+    int pad;
+};
+
+// The per-backend streams (arrival times in, service samples in, completion records out) in the layout the backend
+// lanes want: [k][backend], so that the 64 lanes of a wavefront reading / appending their k-th elements touch 512
+// contiguous bytes -- with dense per-backend segments every lane walks its own cache lines and the kernel is bound by the
+// texture addresser.  The rows are sized at creation for 3x the mean load; a run whose busiest backend needs more falls
+// back to the dense segments (device-side flag, same kernels, stride 1).
+struct LbLayout {
+    int64_t rows;
+    uint64_t *tkey;               // [rows][B] sorted arrival keys of backend b, request k
+    double *tsv;                  // [rows][B] service sample of that request (single-worker FIFO backends)
 };
 
 struct LbCand { long long t, t_created; int idx, valid; double svc_s; };
@@ -270,6 +284,53 @@ __global__ void hs_lb_segments(const uint64_t *__restrict__ skey, const uint64_t
     fval[pos] = sval[i];
 }
 
+__global__ void hs_lb_maxcount(const int64_t *__restrict__ off, int B, LbTotals *tot) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    long long c = b < B ? (long long)(off[b + 1] - off[b]) : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const long long d = __shfl_xor(c, o, 64); c = d > c ? d : c; }
+    if ((threadIdx.x & 63) == 0 && c) atomicMax(&tot->max_be, c);
+}
+// decide the layout of this run; n_merge = slots the Sink merge has to look at
+__global__ void hs_lb_layout(LbTotals *tot, LbLayout LY, int B, const int64_t *n_arr, int64_t *n_merge, int force_dense) {
+    const int t = (!force_dense && LY.rows > 0 && tot->max_be <= LY.rows) ? 1 : 0;
+    tot->use_t = t;
+    *n_merge = t ? (int64_t)tot->max_be * B : *n_arr;
+}
+// dense sorted segments -> [k][backend]: one workgroup per 64 backends, 64 x 64 tiles through LDS (coalesced both ways)
+__global__ void __launch_bounds__(256) hs_lb_transpose(const uint64_t *__restrict__ skey, const int64_t *__restrict__ off, int B,
+                                                       LbLayout LY, const LbTotals *tot) {
+    if (!tot->use_t) return;
+    __shared__ uint64_t tile[64][65];
+    __shared__ int64_t seg_off[65];
+    __shared__ int64_t max_len;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int b0 = blockIdx.x * 64;
+    if (threadIdx.x < 65) seg_off[threadIdx.x] = off[(b0 + (int)threadIdx.x) < B ? b0 + (int)threadIdx.x : B];
+    if (threadIdx.x == 0) max_len = 0;
+    __syncthreads();
+    if (threadIdx.x < 64) atomicMax((long long *)&max_len, (long long)(seg_off[threadIdx.x + 1] - seg_off[threadIdx.x]));
+    __syncthreads();
+    const int64_t ml = max_len;
+    for (int64_t k0 = 0; k0 < ml; k0 += 64) {
+        for (int r = ty; r < 64; r += 4) {                       // row r = backend b0 + r: 64 consecutive elements
+            const int64_t len = seg_off[r + 1] - seg_off[r];
+            tile[r][tx] = (k0 + tx < len) ? skey[seg_off[r] + k0 + tx] : 0ull;
+        }
+        __syncthreads();
+        for (int kk = ty; kk < 64; kk += 4) {                    // row kk of the output: 64 consecutive backends
+            const int64_t k = k0 + kk;
+            const int64_t len = seg_off[tx + 1] - seg_off[tx];
+            if (k < len && b0 + tx < B) LY.tkey[(size_t)k * B + b0 + tx] = tile[tx][kk];
+        }
+        __syncthreads();
+    }
+}
+__global__ void hs_lb_gather_strided(const int64_t *__restrict__ src, int64_t stride, int64_t cnt, int64_t *__restrict__ out) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < cnt) out[k] = src[(size_t)k * stride];
+}
+
 // keys-only variant of the run fix-up above (latency statistics)
 __global__ void hs_lb_fix_runs(uint64_t *__restrict__ keys, const int64_t *n_ptr, int g) {
     const int64_t n = *n_ptr;
@@ -296,15 +357,28 @@ __global__ void hs_lb_fix_runs(uint64_t *__restrict__ keys, const int64_t *n_ptr
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) hs_lb_service_draws(const uint64_t *__restrict__ skey, const int64_t *n_ptr,
                                                            const int64_t *__restrict__ off, int tb, LbBe P, uint64_t seed,
-                                                           double *__restrict__ sv_out) {
-    const int64_t n = *n_ptr;
+                                                           double *__restrict__ sv_out, LbLayout LY, int B,
+                                                           const LbTotals *tot) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t b = (int64_t)(skey[i] >> tb);
+    int64_t b;
+    uint64_t k;
+    double *dst;
+    if (tot->use_t) {                                        // slot i of the [k][backend] layout
+        if (i >= (int64_t)tot->max_be * B) return;
+        const int64_t kk = i < (1ll << 32) ? (int64_t)((uint32_t)i / (uint32_t)B) : i / B;
+        b = i - kk * B;
+        if (kk >= off[b + 1] - off[b]) return;
+        k = (uint64_t)kk;
+        dst = LY.tsv + i;
+    } else {
+        if (i >= *n_ptr) return;
+        b = (int64_t)(skey[i] >> tb);
+        k = (uint64_t)(i - off[b]);
+        dst = sv_out + i;
+    }
     const double mean = P.svc_mean[b];
     double sv;
     if (P.svc_kind[b] == HS_LAT_EXPONENTIAL) {
-        const uint64_t k = (uint64_t)(i - off[b]);
         const uint64_t sid = stream_id(P.base[b], kStreamService), blk = k >> 1;
         const U4 o = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)sid, (uint32_t)(sid >> 32), (uint32_t)seed,
                                    (uint32_t)(seed >> 32));
@@ -312,7 +386,7 @@ __global__ void __launch_bounds__(256) hs_lb_service_draws(const uint64_t *__res
         const double lambda = __ddiv_rn(1.0, mean);
         sv = seconds_from_ns(ns_from_seconds(__ddiv_rn(exp1_from_uniform(u), lambda)));
     } else sv = seconds_from_ns(ns_from_seconds(mean));
-    sv_out[i] = sv;
+    *dst = sv;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -328,6 +402,9 @@ struct LbBackend {
     // arrivals
     const uint64_t *akey; uint64_t *aval;
     const double *asv;            // pre-drawn service time of the request in each slot (request-order loop)
+    const uint64_t *rkey;         // request-order loop: element k of this backend at rkey[k * rs] / asv[k * rs]
+    int64_t rs;                   // 1 (dense segment) or B ([k][backend] layout)
+    int64_t ss;                   // stride of the completion logs (sink_t / sink_created / sink_S), same two cases
     int64_t ai, aend;
     uint64_t tmask;
     int64_t At, Acrt; uint32_t Adepth;
@@ -424,7 +501,7 @@ struct LbBackend {
         total_service = __dadd_rn(total_service, s);
         if (egress == HS_EGRESS_SINK) {
             ev[HS_EV_SINK]++;
-            sink_t[received] = t; sink_created[received] = cr; sink_S[received] = st;
+            sink_t[received * ss] = t; sink_created[received * ss] = cr; sink_S[received * ss] = st;
             received++;
         }
         return active < conc;
@@ -515,25 +592,25 @@ struct LbBackend {
     // lane bails out and is re-run from its initial state by the event-order loop.
     __device__ __forceinline__ bool run_request_order(int64_t T) {
         const int64_t n = aend - ai;
-        const uint64_t *kp = akey + ai;
+        const uint64_t *kp = rkey;
         int64_t Sprev = INT64_MIN, Dprev = INT64_MIN, aprev = INT64_MIN, lt = INT64_MIN;
         uint32_t n_notify = 0, n_poll = 0, n_start = 0, n_dep = 0;
         bool pend = false;
         int64_t pendD = kInfNs, pendS = 0;
         double pend_s = 0.0, tsvc = 0.0;
         constexpr int kAhead = 8;
-        const double *sp = asv + ai;
+        const double *sp = asv;
         uint64_t cur[kAhead], nxt[kAhead];
         double scur[kAhead], snxt[kAhead];
 #pragma unroll
-        for (int j = 0; j < kAhead; ++j) { cur[j] = j < n ? kp[j] : 0ull; scur[j] = j < n ? sp[j] : 0.0; }
+        for (int j = 0; j < kAhead; ++j) { cur[j] = j < n ? kp[j * rs] : 0ull; scur[j] = j < n ? sp[j * rs] : 0.0; }
         bool blocked = false;
         for (int64_t base = 0; base < n && !blocked; base += kAhead) {
 #pragma unroll
             for (int j = 0; j < kAhead; ++j) {                          // in flight while cur is processed
                 const bool in = (base + kAhead + j) < n;
-                nxt[j] = in ? kp[base + kAhead + j] : 0ull;
-                snxt[j] = in ? sp[base + kAhead + j] : 0.0;
+                nxt[j] = in ? kp[(base + kAhead + j) * rs] : 0ull;
+                snxt[j] = in ? sp[(base + kAhead + j) * rs] : 0.0;
             }
 #pragma unroll
             for (int j = 0; j < kAhead; ++j) {
@@ -555,7 +632,7 @@ struct LbBackend {
                 if (Dk <= T) {
                     lt = Dk > lt ? Dk : lt;
                     tsvc = __dadd_rn(tsvc, sv);
-                    if (egress == HS_EGRESS_SINK) { sink_t[n_dep] = Dk; sink_created[n_dep] = a; sink_S[n_dep] = S; }
+                    if (egress == HS_EGRESS_SINK) { sink_t[n_dep * ss] = Dk; sink_created[n_dep * ss] = a; sink_S[n_dep * ss] = S; }
                     ++n_dep;
                     pend = false;
                 } else { pend = true; pendD = Dk; pendS = S; pend_s = sv; }
@@ -565,7 +642,7 @@ struct LbBackend {
             for (int j = 0; j < kAhead; ++j) { cur[j] = nxt[j]; scur[j] = snxt[j]; }
         }
         if (n > 0) {                                                  // arrivals behind a blocked head were not iterated
-            const int64_t a_last = (int64_t)(kp[n - 1] & tmask);
+            const int64_t a_last = (int64_t)(kp[(n - 1) * rs] & tmask);
             lt = a_last > lt ? a_last : lt;
         }
         // fold into the LP state exactly as the event-order loop would have left it
@@ -612,7 +689,8 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_backends(LbBe P, int B, int S
                                                            uint64_t *__restrict__ sval, const int64_t *__restrict__ off,
                                                            int tb, int64_t *__restrict__ adm, int64_t *__restrict__ sink_t,
                                                            int64_t *__restrict__ sink_created, int64_t *__restrict__ sink_S,
-                                                           const double *__restrict__ svdraw, LbTotals *tot, int flags) {
+                                                           const double *__restrict__ svdraw, LbTotals *tot, int flags,
+                                                           LbLayout LY) {
     __shared__ uint8_t qmem[kLbQCap][kLbBlock];
     __shared__ LbCand wc[kLbBlock / 64];
     const int tid = threadIdx.x;
@@ -638,7 +716,11 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_backends(LbBe P, int B, int S
         for (int i = 0; i < C; ++i) { X.D[i] = kInfNs; X.crtD[i] = start_ns; X.crt[i] = 0; X.seqD[i] = 0; X.svc_s[i] = 0.0; }
         X.svc.init(seed, stream_id(P.base[b], kStreamService), 0);
         const int64_t o = off[b];
-        X.adm = adm + o; X.sink_t = sink_t + o; X.sink_created = sink_created + o; X.sink_S = sink_S + o;
+        const bool T = tot->use_t != 0;
+        X.rkey = T ? LY.tkey + b : skey + o; X.asv = T ? LY.tsv + b : svdraw + o; X.rs = T ? B : 1;
+        X.ss = T ? B : 1;
+        const int64_t so = T ? b : o;
+        X.adm = adm + o; X.sink_t = sink_t + so; X.sink_created = sink_created + so; X.sink_S = sink_S + so;
         X.qmem = qmem; X.tid = tid; X.qh = 0; X.qn = 0;
         const bool force_general = (flags & 1) != 0;
         bool event_order = true;
@@ -689,8 +771,13 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_backends(LbBe P, int B, int S
 // 4. Shared Sink: slot i of the dense completion log is valid iff it lies in the used part of its backend's segment
 // ---------------------------------------------------------------------------------------------
 struct SinkValid {
-    const uint64_t *skey; const int64_t *off; const int64_t *received; int tb;
+    const uint64_t *skey; const int64_t *off; const int64_t *received; int tb; const LbTotals *tot; int B;
     __device__ __forceinline__ bool operator()(int64_t i) const {
+        if (tot->use_t) {                                    // slot i = (completion m, backend b) of the [m][backend] logs
+            if (i < (1ll << 32)) { const uint32_t m = (uint32_t)i / (uint32_t)B; return (int64_t)m < received[(uint32_t)i - m * (uint32_t)B]; }
+            const int64_t m = i / B;
+            return m < received[i - m * B];
+        }
         const int64_t b = (int64_t)(skey[i] >> tb);
         return i - off[b] < received[b];
     }
@@ -815,7 +902,7 @@ __global__ void __launch_bounds__(64) hs_lb_latency_stats_kernel(const uint64_t 
 __global__ void hs_lb_clear(LbTotals *tot) {
     for (int k = 0; k < HS_EV_KINDS; ++k) tot->ev[k] = 0;
     tot->completed = 0; tot->received = 0; tot->last_time = INT64_MIN; tot->final_time = 0;
-    tot->qoverflow = 0; tot->bad_client = 0; tot->max_count = 0;
+    tot->qoverflow = 0; tot->bad_client = 0; tot->max_count = 0; tot->max_be = 0; tot->use_t = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -903,6 +990,9 @@ struct hs_lb {
     uint64_t *mkey = nullptr, *mslot = nullptr;       // where the merged Sink order ended up
     int64_t *off = nullptr, *adm = nullptr, *sink_t = nullptr, *sink_created = nullptr, *sink_S = nullptr;
     int64_t *out_t = nullptr, *out_created = nullptr;
+    LbLayout LY{};                                    // [k][backend] copies of the backend streams (rows == 0: not allocated)
+    int64_t n_layout = 0;                             // max(n_slots, rows * B): slots of the completion logs / draw grid
+    int64_t *n_merge = nullptr;                       // device: slots the Sink merge scans
     double *svdraw = nullptr;                         // [n_slots] service sample per Request slot (single-worker FIFO backends)
     bool any_simple = false;
     int64_t *n_slots_dev = nullptr, *n_arr = nullptr, *n_done = nullptr, *n_tmp = nullptr;
@@ -976,9 +1066,12 @@ int32_t ring_select(const std::vector<RingPoint> &ring, const char *key, size_t 
 template <typename Valid, typename MakeVal>
 void radix_sort_async(hs_lb *h, const uint64_t *k_in, const uint64_t *v_in, const int64_t *n_in_dev, int64_t *n_out_dev,
                       int bits, Valid valid, MakeVal mk, uint64_t **k_res, uint64_t **v_res,
-                      const uint64_t *keep_through_pass0 = nullptr, int shift0 = 0) {
+                      const uint64_t *keep_through_pass0 = nullptr, int shift0 = 0, int64_t slots_pass0 = 0) {
     const int passes = (bits - shift0 + kRadixBits - 1) / kRadixBits;
-    const dim3 grid((unsigned)h->n_tiles), blk(kRadixThreads);
+    // pass 0 may scan a sparse input (slots_pass0 of them); every later pass sees at most n_slots dense elements
+    const int tiles0 = slots_pass0 > 0 ? (int)((slots_pass0 + kRadixTile - 1) / kRadixTile) : h->n_tiles;
+    const int tiles_rest = (int)((h->n_slots + kRadixTile - 1) / kRadixTile);
+    const dim3 blk(kRadixThreads);
     // `valid` may read a buffer that is itself one of the ping-pong buffers (the previous sort's result): pass 0, the
     // only pass that evaluates `valid`, must then write the OTHER buffer
     const bool startB = keep_through_pass0 == h->kA;
@@ -987,20 +1080,22 @@ void radix_sort_async(hs_lb *h, const uint64_t *k_in, const uint64_t *v_in, cons
     for (int p = 0; p < passes; ++p) {
         const int shift = shift0 + p * kRadixBits;
         const int64_t *n_dev = p == 0 ? n_in_dev : n_out_dev;
+        const int nt = p == 0 ? tiles0 : (tiles_rest < h->n_tiles ? tiles_rest : h->n_tiles);
+        const dim3 grid((unsigned)nt);
         if (p == 0) {
-            hipLaunchKernelGGL((radix_hist<Valid>), grid, blk, 0, h->stream, ki, n_dev, shift, h->hist, h->n_tiles, valid);
+            hipLaunchKernelGGL((radix_hist<Valid>), grid, blk, 0, h->stream, ki, n_dev, shift, h->hist, nt, valid);
         } else {
-            hipLaunchKernelGGL((radix_hist<RadixAll>), grid, blk, 0, h->stream, ki, n_dev, shift, h->hist, h->n_tiles, RadixAll{});
+            hipLaunchKernelGGL((radix_hist<RadixAll>), grid, blk, 0, h->stream, ki, n_dev, shift, h->hist, nt, RadixAll{});
         }
-        hipLaunchKernelGGL(radix_scan_rows, dim3(kRadixBins), blk, 0, h->stream, h->hist, h->n_tiles, h->row_total);
+        hipLaunchKernelGGL(radix_scan_rows, dim3(kRadixBins), blk, 0, h->stream, h->hist, nt, h->row_total);
         hipLaunchKernelGGL(radix_scan_digits, dim3(1), blk, 0, h->stream, h->row_total, h->digit_base,
                            p == 0 ? n_out_dev : (int64_t *)nullptr);
         if (p == 0) {
             hipLaunchKernelGGL((radix_scatter<Valid, MakeVal>), grid, blk, 0, h->stream, ki, vi, ko, vo, n_dev, shift, h->hist,
-                               h->digit_base, h->n_tiles, valid, mk);
+                               h->digit_base, nt, valid, mk);
         } else {
             hipLaunchKernelGGL((radix_scatter<RadixAll, NoVal>), grid, blk, 0, h->stream, ki, vi, ko, vo, n_dev, shift, h->hist,
-                               h->digit_base, h->n_tiles, RadixAll{}, NoVal{});
+                               h->digit_base, nt, RadixAll{}, NoVal{});
         }
         h->launches += 4;
         ki = ko; vi = vo;
@@ -1015,7 +1110,7 @@ void launch_backends(hs_lb *h, int64_t end_ns) {
     const int B = h->cfg.n_backends;
     hipLaunchKernelGGL(hs_lbk_backends<C>, dim3((B + kLbBlock - 1) / kLbBlock), dim3(kLbBlock), 0, h->stream, h->PB, B,
                        h->cfg.n_sources, h->cfg.seed, h->cfg.start_ns, end_ns, h->skey, h->sval, h->off, h->tb, h->adm,
-                       h->sink_t, h->sink_created, h->sink_S, h->svdraw, h->tot, h->flags);
+                       h->sink_t, h->sink_created, h->sink_S, h->svdraw, h->tot, h->flags, h->LY);
 }
 
 int run_async(hs_lb *h, int64_t end_ns) {
@@ -1027,7 +1122,8 @@ int run_async(hs_lb *h, int64_t end_ns) {
     hipLaunchKernelGGL(hs_lb_rows, dim3(1), dim3(1), 0, h->stream, h->tot, S, h->n_slots_dev);
     hipEventRecord(h->evs0, h->stream);
     radix_sort_async(h, h->keys0, h->vals0, h->n_slots_dev, h->n_arr, h->tb + h->bb,
-                     TickValid{h->PS.count, S, h->n_slots < (1ll << 31)}, NoVal{}, &h->skey, &h->sval, nullptr, h->g_arr);
+                     TickValid{h->PS.count, S, h->n_slots < (1ll << 31)}, NoVal{}, &h->skey, &h->sval, nullptr, h->g_arr,
+                     h->n_slots);
     hipEventRecord(h->evs1, h->stream);
     {   // segment offsets + full-key order inside the runs the sort left, written to the other ping-pong buffer
         uint64_t *fk = h->skey == h->kA ? h->kB : h->kA, *fv = h->skey == h->kA ? h->vB : h->vA;
@@ -1035,9 +1131,16 @@ int run_async(hs_lb *h, int64_t end_ns) {
                            h->sval, fk, fv, h->n_arr, h->tb, h->g_arr, B, h->off);
         h->skey = fk; h->sval = fv;
     }
+    // layout of the backend streams for this run: [k][backend] when the busiest backend fits the allocated rows
+    hipLaunchKernelGGL(hs_lb_maxcount, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->off, B, h->tot);
+    hipLaunchKernelGGL(hs_lb_layout, dim3(1), dim3(1), 0, h->stream, h->tot, h->LY, B, h->n_arr, h->n_merge,
+                       (h->flags & 4) ? 1 : 0);
+    if (h->LY.rows > 0 && (h->flags & 4) == 0)
+        hipLaunchKernelGGL(hs_lb_transpose, dim3((B + 63) / 64), dim3(256), 0, h->stream, h->skey, h->off, B, h->LY, h->tot);
     if (h->C == 1 && h->any_simple && (h->flags & 3) == 0)
-        hipLaunchKernelGGL(hs_lb_service_draws, dim3((unsigned)((h->n_slots + 255) / 256)), dim3(256), 0, h->stream, h->skey,
-                           h->n_arr, h->off, h->tb, h->PB, h->cfg.seed, h->svdraw);
+        hipLaunchKernelGGL(hs_lb_service_draws, dim3((unsigned)((h->n_layout + 255) / 256)), dim3(256), 0, h->stream, h->skey,
+                           h->n_arr, h->off, h->tb, h->PB, h->cfg.seed, h->svdraw, h->LY, B, h->tot);
+    h->launches += 4;
     switch (h->C) {
         case 1: launch_backends<1>(h, end_ns); break;
         case 2: launch_backends<2>(h, end_ns); break;
@@ -1050,12 +1153,13 @@ int run_async(hs_lb *h, int64_t end_ns) {
         // completions by completion ns; the validity functor reads the sorted arrival keys (which slot belongs to which
         // backend), so pass 0 must not overwrite them
         if (h->slot_bits)
-            radix_sort_async(h, (const uint64_t *)h->sink_t, (const uint64_t *)nullptr, h->n_arr, h->n_done, h->tb,
-                             SinkValid{h->skey, h->off, h->PB.received, h->tb}, PackCreatedSlot{h->sink_created, h->slot_bits},
-                             &h->mkey, &h->mslot, h->skey, h->g_sink);
+            radix_sort_async(h, (const uint64_t *)h->sink_t, (const uint64_t *)nullptr, h->n_merge, h->n_done, h->tb,
+                             SinkValid{h->skey, h->off, h->PB.received, h->tb, h->tot, B},
+                             PackCreatedSlot{h->sink_created, h->slot_bits}, &h->mkey, &h->mslot, h->skey, h->g_sink, h->n_layout);
         else
-            radix_sort_async(h, (const uint64_t *)h->sink_t, (const uint64_t *)nullptr, h->n_arr, h->n_done, h->tb,
-                             SinkValid{h->skey, h->off, h->PB.received, h->tb}, SlotVal{}, &h->mkey, &h->mslot, h->skey, h->g_sink);
+            radix_sort_async(h, (const uint64_t *)h->sink_t, (const uint64_t *)nullptr, h->n_merge, h->n_done, h->tb,
+                             SinkValid{h->skey, h->off, h->PB.received, h->tb, h->tot, B}, SlotVal{}, &h->mkey, &h->mslot,
+                             h->skey, h->g_sink, h->n_layout);
         hipLaunchKernelGGL(hs_lb_sink_finish, dim3((unsigned)((h->n_slots + 255) / 256)), dim3(256), 0, h->stream, h->mkey,
                            h->mslot, h->n_done, h->sink_created, h->sink_S, h->out_t, h->out_created, h->slot_bits, h->g_sink);
     }
@@ -1145,7 +1249,15 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     h->cap = cap;
     h->n_slots = cap * (int64_t)S;
     if ((double)h->n_slots * 88.0 > 200e9) { delete h; return lfail(nullptr, HS_E_INVALID, "buffers would need %.1f GB", (double)h->n_slots * 88.0 / 1e9); }
-    h->n_tiles = (int)((h->n_slots + kRadixTile - 1) / kRadixTile);
+    {   // rows of the [k][backend] layout: three times the mean load of a backend (consistent hashing with >= 100 virtual
+        // nodes keeps the busiest backend below ~2x); capped so that the five transposed arrays stay within ~4x n_slots
+        const double mean_be = total_rate * horizon_s / (double)B;
+        int64_t rows = (int64_t)(3.0 * mean_be) + 64;
+        if ((double)rows * (double)B > 4.0 * (double)h->n_slots) rows = 0;
+        h->LY.rows = rows;
+        h->n_layout = std::max<int64_t>(h->n_slots, rows * (int64_t)B);
+    }
+    h->n_tiles = (int)((h->n_layout + kRadixTile - 1) / kRadixTile);
     {   // The sorts skip low key bits: elements whose keys agree on the sorted bits stay in input order and are put in
         // full-key order inside those runs afterwards (hs_lb_segments / hs_lb_sink_finish).  Skip whole 8-bit digits while
         // the EXPECTED number of elements per bucket stays <= 1 (runs of two or three, rare longer ones): a bucket of the
@@ -1162,7 +1274,7 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
             if (total_rate * std::ldexp(1.0, g) * 1e-9 <= 1.0 || g == r_snk) h->g_sink = g; else break;
     }
     {
-        const int sb = bit_length((uint64_t)(h->n_slots > 1 ? h->n_slots - 1 : 1));
+        const int sb = bit_length((uint64_t)(h->n_layout > 1 ? h->n_layout - 1 : 1));
         h->slot_bits = (h->tb + sb <= 64) ? sb : 0;                     // created_at (tb bits) and the slot share one word
     }
     // ---- the ring: ConsistentHash.add_backend for every backend in order (strategies.py:381-391)
@@ -1230,7 +1342,13 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     TRY(lalloc(h, &h->keys0, NS)); TRY(lalloc(h, &h->vals0, NS));
     TRY(lalloc(h, &h->kA, NS)); TRY(lalloc(h, &h->vA, NS)); TRY(lalloc(h, &h->kB, NS)); TRY(lalloc(h, &h->vB, NS));
     TRY(lalloc(h, &h->off, (size_t)B + 1));
-    TRY(lalloc(h, &h->adm, NS)); TRY(lalloc(h, &h->sink_t, NS)); TRY(lalloc(h, &h->sink_created, NS)); TRY(lalloc(h, &h->sink_S, NS));
+    const size_t NL = (size_t)h->n_layout;
+    TRY(lalloc(h, &h->adm, NS)); TRY(lalloc(h, &h->sink_t, NL)); TRY(lalloc(h, &h->sink_created, NL)); TRY(lalloc(h, &h->sink_S, NL));
+    if (h->LY.rows > 0) {
+        TRY(lalloc(h, &h->LY.tkey, (size_t)h->LY.rows * (size_t)B));
+        TRY(lalloc(h, &h->LY.tsv, (size_t)h->LY.rows * (size_t)B));
+    }
+    TRY(lalloc(h, &h->n_merge, 1));
     if (cfg->shared_sink) { TRY(lalloc(h, &h->out_t, NS)); TRY(lalloc(h, &h->out_created, NS)); }
     for (int j = 0; j < B; ++j)
         if ((be->concurrency ? be->concurrency[j] : 1) == 1 && (be->queue_cap ? be->queue_cap[j] : -1) < 0) h->any_simple = true;
@@ -1330,8 +1448,30 @@ int64_t hs_lb_read_sink(hs_lb *h, int32_t sink, int64_t *t_ns, int64_t *created_
     } else {
         if (sink < 0 || sink >= B) return lfail(h, HS_E_INVALID, "sink index %d out of range", sink);
         int64_t o = 0;
+        LbTotals tt;
         if (hipMemcpy(&cnt, h->PB.received + sink, 8, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(&o, h->off + sink, 8, hipMemcpyDeviceToHost) != hipSuccess) return lfail(h, HS_E_HIP, "memcpy");
+            hipMemcpy(&o, h->off + sink, 8, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(&tt, h->tot, sizeof tt, hipMemcpyDeviceToHost) != hipSuccess) return lfail(h, HS_E_HIP, "memcpy");
+        if (tt.use_t) {                      // [m][backend] logs: gather the backend's column
+            if (cnt > cap) cnt = cap;
+            if (cnt <= 0) return 0;
+            int64_t *tmp = nullptr;
+            if (hipMalloc(&tmp, (size_t)cnt * 8) != hipSuccess) return lfail(h, HS_E_HIP, "hipMalloc of the read-back staging buffer failed");
+            const int64_t *cols[2] = {h->sink_t + sink, h->sink_created + sink};
+            int64_t *dsts[2] = {t_ns, created_ns};
+            for (int c = 0; c < 2; ++c) {
+                if (!dsts[c]) continue;
+                hipLaunchKernelGGL(hs_lb_gather_strided, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, cols[c],
+                                   (int64_t)B, cnt, tmp);
+                if (hipStreamSynchronize(h->stream) != hipSuccess ||
+                    hipMemcpy(dsts[c], tmp, (size_t)cnt * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+                    hipFree(tmp);
+                    return lfail(h, HS_E_HIP, "sink read-back failed");
+                }
+            }
+            hipFree(tmp);
+            return cnt;
+        }
         src_t = h->sink_t + o; src_c = h->sink_created + o;
     }
     if (cnt > cap) cnt = cap;

@@ -367,7 +367,8 @@ void hs_lb_destroy(hs_lb *h);
 void hs_md5(const char *msg, int64_t len, uint8_t out[16]);
 
 /* Debug: bit 0 routes every timestamp group of every backend through the general in-group FIFO path; bit 1 disables the
- * request-order loop of single-worker unbounded backends (event-order loop with its single-event fast path instead). */
+ * request-order loop of single-worker unbounded backends (event-order loop with its single-event fast path instead);
+ * bit 2 keeps the backend streams in dense per-backend segments instead of the wave-coalesced [k][backend] layout. */
 int hs_debug_lb_flags(hs_lb *h, int flags);
 
 /* Debug / tests: stable LSD radix sort of n (key, value) pairs on `device` over key bits [0, key_bits) --
