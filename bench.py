@@ -168,6 +168,8 @@ def ring_main(args, rank, local_rank, world, distributed, dist):
                 **info,
             },
         }
+        if args.gpus == 1 and args.cpu_sample_s > 0:
+            out["cpu_baseline"] = cpu_baseline_ring(args)
         print(json.dumps(out))
 
 
@@ -252,6 +254,8 @@ def lb_main(args, rank, local_rank, world, distributed, dist):
                         "completions by completion ns; time = HIP events around the two sorts on the engine stream",
             },
         }
+        if args.gpus == 1 and args.cpu_sample_s > 0:
+            out["cpu_baseline"] = cpu_baseline_lb(args)
         print(json.dumps(out))
     eng.close()
 
@@ -271,6 +275,51 @@ def cpu_baseline(args):
         "sample": f"{args.n_lp} chains, one heap, {args.cpu_sample_s:g} s simulated, {r.events_processed} events in "
                   f"{r.run_seconds:.2f} s (oracle/hs_oracle.c, gcc -O2, 1 thread; steady-state events/s is "
                   f"horizon-independent)",
+        "host_cores_available": os.cpu_count(),
+    }
+
+
+def cpu_baseline_lb(args):
+    """The C oracle on ONE host core on the same load-balancer topology (all sources, the md5 ring, all backends, the
+    shared Sink in one heap), bounded horizon."""
+    from oracle import hs_oracle as O
+
+    t0 = time.perf_counter()
+    g = O.lb_topology(args.lb_sources, args.lb_backends, args.lb_rate, args.mean, args.lb_vnodes, args.lb_clients)
+    horizon = min(args.cpu_sample_s, args.end_s) / 8.0        # ~9.5 events per request: keep the sample to ~10-20 s of CPU
+    r = O.run(g, int(horizon * 1e9), seed=args.seed)
+    return {
+        "value": r.events_processed / r.run_seconds, "unit": "events/s", "cores": 1, "kind": "port",
+        "sample": f"the same topology, one heap, {horizon:g} s simulated, {r.events_processed} events in {r.run_seconds:.2f} s "
+                  f"(+ {time.perf_counter() - t0 - r.run_seconds:.1f} s to build the ring and the graph; oracle/hs_oracle.c, "
+                  "gcc -O2, 1 thread)",
+        "host_cores_available": os.cpu_count(),
+    }
+
+
+def cpu_baseline_ring(args):
+    """The C oracle on ONE host core on the same ring network, bounded horizon."""
+    from oracle import hs_oracle as O
+
+    n = args.n_lp
+    g = O.Graph()
+    src = [g.source(O.ARR_POISSON, args.rate / 2.0, stream_base=i) for i in range(n)]
+    srv, snk, lnk, rtr = [], [], [], []
+    for i in range(n):
+        srv.append(g.server(O.LAT_EXP, args.mean, stream_base=i))
+        snk.append(g.sink())
+        lnk.append(g.link(args.lat_min, args.jitter, stream_base=i))
+        rtr.append(g.router([snk[i], lnk[i]], stream_base=i))
+    for i in range(n):
+        g.target[src[i]] = srv[i]
+        g.target[srv[i]] = rtr[i]
+        g.target[lnk[i]] = srv[(i + 1) % n]
+    horizon = min(args.cpu_sample_s, args.end_s) / 2.0
+    r = O.run(g, int(horizon * 1e9), seed=args.seed)
+    return {
+        "value": r.events_processed / r.run_seconds, "unit": "events/s", "cores": 1, "kind": "port",
+        "sample": f"the same {n}-station ring, one heap, {horizon:g} s simulated, {r.events_processed} events in "
+                  f"{r.run_seconds:.2f} s (oracle/hs_oracle.c, gcc -O2, 1 thread)",
         "host_cores_available": os.cpu_count(),
     }
 

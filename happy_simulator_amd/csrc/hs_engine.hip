@@ -772,10 +772,68 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         int64_t dur_next = 0;
         const bool force_general = (flags & 1) != 0;
         unsigned n_groups = 0, n_iter = 0;
+        // In-wavefront chains.  When this LP's only incoming link comes from the LP in the previous lane, its bound need
+        // not wait for that neighbour's next publication: a sender's bound is a (min, +) map of its own input bound,
+        //     ea_j(H) = min(a_j, H + b_j),   a_j = min(min D, [idle worker] next own event + dur) + transit floor,
+        //                                     b_j = [idle worker] dur + transit floor, else infinity,
+        // and such maps compose associatively -- a 6-step prefix scan over the lanes gives every lane the bound it would
+        // reach after up to 63 publish / poll round trips, from the senders' CURRENT states (valid: a bound computed from a
+        // state covers everything that state can still send).  Chains are cut where the previous lane is not the sender.
+        int32_t next_l = -1;                                  // my link to the LP in the next lane, if any
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+            if (out_l[o] >= 0 && NP.link_dst[out_l[o]] == lp + 1) next_l = out_l[o];
+        const int in_deg = NP.in_off[lp + 1] - NP.in_off[lp];
+        const int32_t my_in = in_deg == 1 ? NP.in_links[NP.in_off[lp]] : -1;
+        const int32_t prev_next = __shfl_up(next_l, 1, 64);
+        const bool chain = (flags & 64) == 0 && lane > 0 && my_in >= 0 && prev_next == my_in;
+        const int64_t next_lat = next_l >= 0 ? NP.link_lat_ns[next_l] : 0;
+        auto sat = [](int64_t a, int64_t b) { return (a == kInfNs || b == kInfNs) ? kInfNs : a + b; };
+        auto peek_dur = [&]() {
+            const int free = S.conc - S.active;
+            if (S.svc.k != dur_k || free != dur_free) { dur_next = S.peek_service_ns(free); dur_k = S.svc.k; dur_free = free; }
+            return dur_next;
+        };
         for (unsigned iter = 0;; ++iter) {
             n_iter = iter + 1;
+            int64_t H = kInfNs;
+            if (!done) H = S.async_receive();                         // messages below H are all in the bag now
+            // (min, +) map of this LP as the sender on next_l, from its state before this iteration's processing
+            int64_t mA = kInfNs, mB = kInfNs;
+            if (!done && next_l >= 0) {
+                int64_t dmin = kInfNs;
+#pragma unroll
+                for (int i = 0; i < C; ++i) dmin = S.D[i] < dmin ? S.D[i] : dmin;
+                int64_t a = dmin;
+                if (S.active < S.conc) {
+                    const int64_t dur = peek_dur();
+                    const int64_t own = sat(S.next_time(), dur);
+                    a = own < a ? own : a;
+                    mB = dur + next_lat;
+                }
+                mA = sat(a, next_lat);
+            }
+            if (!chain) {                                             // head of a chain: its input bound is known
+                if (!done && S.undrained < H) H = S.undrained;
+                const int64_t v = sat(H, mB);
+                mA = v < mA ? v : mA;
+                mB = kInfNs;
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {                        // prefix composition m_i o m_{i-1} o ... (Kogge-Stone)
+                const int64_t pA = __shfl_up(mA, o, 64), pB = __shfl_up(mB, o, 64);
+                if (lane >= o) {
+                    const int64_t v = sat(pA, mB);
+                    mA = v < mA ? v : mA;
+                    mB = sat(pB, mB);
+                }
+            }
+            {
+                const int64_t hp = __shfl_up(mA, 1, 64);              // the previous lane's bound towards me
+                if (chain && hp > H) H = hp;
+                if (!done && S.undrained < H) H = S.undrained;        // ... never beyond what is still sitting in a queue
+            }
             if (!done) {
-                const int64_t H = S.async_receive();                  // messages below H are all in the bag now
                 const int64_t limit = (H - 1) < end_ns ? (H - 1) : end_ns;
                 for (;;) {
                     const int64_t t = S.next_time();
@@ -792,24 +850,26 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                 for (int i = 0; i < C; ++i) dmin = S.D[i] < dmin ? S.D[i] : dmin;
                 int64_t lb = dmin;
                 if (S.active < S.conc) {
-                    const int free = S.conc - S.active;
-                    if (S.svc.k != dur_k || free != dur_free) { dur_next = S.peek_service_ns(free); dur_k = S.svc.k; dur_free = free; }
-                    const int64_t started = (base == kInfNs) ? kInfNs : base + dur_next;
+                    const int64_t started = sat(base, peek_dur());
                     lb = started < lb ? started : lb;
                 }
-                bool drained = !S.sent_async;
+                if (S.sent_async) {
+                    // payloads complete -> tails -> complete: only then may a bound that no longer covers those messages
+                    // be seen, through memory (aq_ea below) or through the in-wavefront scan of the next iteration
+                    drain_stores();
+#pragma unroll
+                    for (int o = 0; o < 2; ++o)
+                        if (out_l[o] >= 0) ag_store(&NX.aq_tail[out_l[o]], (unsigned long long)NX.link_in[out_l[o]]);
+                    drain_stores();
+                    S.sent_async = false;
+                }
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {
                     const int32_t l = out_l[o];
                     if (l < 0) continue;
                     const int64_t v = (lb == kInfNs) ? kInfNs : lb + NP.link_lat_ns[l];
-                    if (v > out_pub[o]) {
-                        if (!drained) { drain_stores(); drained = true; }   // the appended messages first, then the bound
-                        ag_store(&NX.aq_ea[l], v);
-                        out_pub[o] = v;
-                    }
+                    if (v > out_pub[o]) { ag_store(&NX.aq_ea[l], v); out_pub[o] = v; }
                 }
-                S.sent_async = false;
                 done = base > end_ns;                                 // nothing at or before end_ns can happen any more
             }
             if (__all(done)) break;

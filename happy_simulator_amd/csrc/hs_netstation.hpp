@@ -138,6 +138,7 @@ struct NetStation {
     const ShardCtl *sc;
     int64_t sent_min;             // earliest arrival among the messages this LP sent in this window
     bool sent_async;              // asynchronous engine: a message was appended since the last publication of aq_ea
+    int64_t undrained;            // asynchronous engine: earliest possible arrival among messages left in a queue (bag full)
     int send_idx;
     int32_t bag_n;
     // in-group FIFO + ENQ payloads (LDS columns)
@@ -277,9 +278,7 @@ struct NetStation {
             if (seq - ag_load(&ns->aq_head[l]) > (unsigned long long)ns->aq_cap) { bagoverflow = 1; return; }
             const size_t slot = (size_t)l * ns->aq_cap + (size_t)((seq - 1) % (unsigned long long)ns->aq_cap);
             ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t); ag_store(&ns->aq_cr[slot], created);
-            drain_stores();
-            ag_store(&ns->aq_tail[l], seq);
-            sent_async = true;
+            sent_async = true;          // the caller publishes aq_tail (= link_in) after draining these stores
             return;
         }
         if (sc->wend_slots != nullptr && sc->link_rank[l] != sc->rank) {
@@ -359,6 +358,7 @@ struct NetStation {
     // take delivery of everything the incoming links hold; returns min over those links of aq_ea (kInfNs: no in-links)
     __device__ __forceinline__ int64_t async_receive() {
         int64_t H = kInfNs;
+        undrained = kInfNs;
         const int a = np->in_off[lp], b = np->in_off[lp + 1];
         for (int q = a; q < b; ++q) {
             const int l = np->in_links[q];
@@ -380,10 +380,10 @@ struct NetStation {
                 // decrease along a queue), so it arrives no earlier than that + the link's transit floor
                 const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head % (unsigned long long)ns->aq_cap);
                 const int64_t lb = ag_load(&ns->aq_ts[slot]) + np->link_lat_ns[l];
-                H = lb < H ? lb : H;
+                undrained = lb < undrained ? lb : undrained;
             }
         }
-        return H;
+        return H;                         // the caller caps it with `undrained`
     }
     // back-pressure: an LP processes events only while each of its outgoing queues can take what one timestamp group
     // may send (one message per completion, at most C completions per group)
