@@ -767,6 +767,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         if (S.egress == EG_LINK) out_l[0] = S.link_of;
         else if (S.egress == EG_ROUTER) { out_l[0] = S.rt0; out_l[1] = S.rt1; }
         int64_t out_pub[2] = {INT64_MIN, INT64_MIN};
+        unsigned long long head_seen[2] = {0ull, 0ull};
         uint64_t dur_k = ~0ull;
         int dur_free = -1;
         int64_t dur_next = 0;
@@ -838,7 +839,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                 for (;;) {
                     const int64_t t = S.next_time();
                     if (t > limit) break;
-                    if (!(S.async_can_send(out_l[0]) && S.async_can_send(out_l[1]))) break;   // a consumer is behind: wait
+                    if (!(S.async_can_send(out_l[0], head_seen[0]) && S.async_can_send(out_l[1], head_seen[1]))) break;   // a consumer is behind: wait
                     S.run_group(t, force_general);
                     ++n_groups;
                 }

@@ -387,10 +387,14 @@ struct NetStation {
     }
     // back-pressure: an LP processes events only while each of its outgoing queues can take what one timestamp group
     // may send (one message per completion, at most C completions per group)
-    __device__ __forceinline__ bool async_can_send(int32_t l) const {
+    // `head_seen` caches the consumer's published position: it only moves forward, so a stale value errs on the safe
+    // side and the (cache-bypassing) reload is needed only when the queue looks full
+    __device__ __forceinline__ bool async_can_send(int32_t l, unsigned long long &head_seen) const {
         if (l < 0) return true;
-        const unsigned long long inflight = (unsigned long long)ns->link_in[l] - ag_load(&ns->aq_head[l]);
-        return inflight + (unsigned long long)C <= (unsigned long long)ns->aq_cap;
+        const unsigned long long sent = (unsigned long long)ns->link_in[l];
+        if (sent - head_seen + (unsigned long long)C <= (unsigned long long)ns->aq_cap) return true;
+        head_seen = ag_load(&ns->aq_head[l]);
+        return sent - head_seen + (unsigned long long)C <= (unsigned long long)ns->aq_cap;
     }
     // Shortest duration among the next `free` services to start: service draws svc.k .. svc.k + free - 1, not consumed
     // (pure functions of the draw index).  With `free` idle workers that many requests can be in service before any
