@@ -173,6 +173,14 @@ def ring_main(args, rank, local_rank, world, distributed, dist):
         print(json.dumps(out))
 
 
+def lb_traffic():
+    """HBM bytes of the sort kernels per step from the committed PMC passes (profiles/r01_lb_pmc_traffic.json), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r01_lb_pmc_traffic.json"))).get("hbm_bytes_per_step")
+    except Exception:
+        return None
+
+
 def lb_main(args, rank, local_rank, world, distributed, dist):
     """BASELINE configs[4].  One step = one complete run of the load-balancer topology: every Source's ticks, the
     (backend, time) sort, every backend's queue protocol, the shared Sink's merge, the overshoot election."""
@@ -247,7 +255,7 @@ def lb_main(args, rank, local_rank, world, distributed, dist):
             "roofline": {
                 "bound": "hbm", "kernel": "radix_hist + radix_scatter (all passes of both sorts)",
                 "achieved": sort_bytes / sort_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": sort_bytes / sort_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "frac": sort_bytes / sort_s / 1e9 / HBM_PEAK_GBS, "traffic": lb_traffic(),
                 "algorithmic_bytes_per_step": sort_bytes, "passes": [p1, p2],
                 "note": "40 B per element and 8-bit pass: 8 B histogram read, 16 B (key, value) in, 16 B out; "
                         f"{p1} passes over the {n_req} Requests by (backend, arrival ns), {p2} passes over the {n_done} "
