@@ -475,6 +475,7 @@ __device__ __forceinline__ void load_net(NetStation<C> &S, const StationParams &
     S.overflow = 0; S.qoverflow = 0; S.bagoverflow = 0;
     S.np = &NP; S.ns = &NX; S.send_idx = send_idx;
     S.bag_n = NX.bag_cnt[lp];
+    S.bmin = S.bag_scan_min();
     S.qmem = qmem; S.enqpay = enqpay; S.tid = tid; S.qh = 0; S.qn = 0; S.ph = 0; S.pn = 0;
 }
 

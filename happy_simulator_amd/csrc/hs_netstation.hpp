@@ -141,6 +141,7 @@ struct NetStation {
     int64_t undrained;            // asynchronous engine: earliest possible arrival among messages left in a queue (bag full)
     int send_idx;
     int32_t bag_n;
+    int64_t bmin;                 // min over the bag's arrival times (kInfNs: empty)
     // in-group FIFO + ENQ payloads (LDS columns)
     uint8_t (*qmem)[kBlock];
     int64_t (*enqpay)[kBlock];
@@ -172,11 +173,14 @@ struct NetStation {
 
     // ---- bag (pending inbound messages of this LP; global memory, owner-only)
     __device__ __forceinline__ size_t bidx(int i) const { return (size_t)lp * ns->bag_cap + i; }
-    __device__ __forceinline__ int64_t bag_min() const {
+    // earliest arrival in the bag, kept in a register (`bmin`): next_time() runs several times per step and a scan of the
+    // bag is a chain of global loads; the scan is only redone when a message leaves the bag
+    __device__ __forceinline__ int64_t bag_scan_min() const {
         int64_t m = kInfNs;
         for (int i = 0; i < bag_n; ++i) { const int64_t t = ns->bag_t[bidx(i)]; m = t < m ? t : m; }
         return m;
     }
+    __device__ __forceinline__ int64_t bag_min() const { return bmin; }
     __device__ __forceinline__ void bag_remove(int i) {
         const int last = bag_n - 1;
         if (i != last) {
@@ -184,6 +188,7 @@ struct NetStation {
             ns->bag_cr[bidx(i)] = ns->bag_cr[bidx(last)]; ns->bag_link[bidx(i)] = ns->bag_link[bidx(last)];
         }
         bag_n = last;
+        bmin = bag_scan_min();
     }
 
     __device__ __forceinline__ int64_t next_arrival() {
@@ -370,7 +375,9 @@ struct NetStation {
             for (; head < tail && bag_n < ns->bag_cap; ++head) {
                 const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head % (unsigned long long)ns->aq_cap);
                 const size_t d = bidx(bag_n);
-                ns->bag_t[d] = ag_load(&ns->aq_t[slot]); ns->bag_ts[d] = ag_load(&ns->aq_ts[slot]);
+                const int64_t ta = ag_load(&ns->aq_t[slot]);
+                bmin = ta < bmin ? ta : bmin;
+                ns->bag_t[d] = ta; ns->bag_ts[d] = ag_load(&ns->aq_ts[slot]);
                 ns->bag_cr[d] = ag_load(&ns->aq_cr[slot]); ns->bag_link[d] = l;
                 ++bag_n;
             }
