@@ -773,7 +773,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         int dur_free = -1;
         int64_t dur_next = 0;
         const bool force_general = (flags & 1) != 0;
-        unsigned n_groups = 0, n_iter = 0;
+        unsigned n_groups = 0, n_iter = 0, groups_before = 0;
         // In-wavefront chains.  When this LP's only incoming link comes from the LP in the previous lane, its bound need
         // not wait for that neighbour's next publication: a sender's bound is a (min, +) map of its own input bound,
         //     ea_j(H) = min(a_j, H + b_j),   a_j = min(min D, [idle worker] next own event + dur) + transit floor,
@@ -876,6 +876,8 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             }
             if (__all(done)) break;
             if (iter >= kAsyncMaxIter) { gave_up = 1; break; }
+            if ((flags & 128) && !__any(n_groups != groups_before)) __builtin_amdgcn_s_sleep(64);   // experiment: back off when idle
+            groups_before = n_groups;
         }
         store_net<C>(S, X, NX, lp, n);
         atomicAdd(&tot->dbg[2], (unsigned long long)n_groups);
@@ -1143,7 +1145,7 @@ void launch_net_dispatch(hs_engine *h, int64_t wend, int win, int flags) {
 
 template <int C>
 hipError_t launch_async(hs_engine *h, int64_t end_ns, NetState NX) {
-    int n = h->cfg.n_lp, flags = h->flags & 1, lanes = h->async_lanes;
+    int n = h->cfg.n_lp, flags = h->flags & (1 | 64 | 128), lanes = h->async_lanes;
     const int per_block = (kBlock / 64) * lanes;
     void *args[] = {&h->P, &h->NP, &h->X, &NX, &h->L, &h->tot, &n, &end_ns, &flags, &h->SC, &lanes};
     return hipLaunchCooperativeKernel((const void *)hs_net_async<C>, dim3((unsigned)((n + per_block - 1) / per_block)),

@@ -279,8 +279,8 @@ struct NetStation {
         if (ns->aq_on) {
             // asynchronous engine: append to the link's queue (this LP is its only producer); link_in[l] is the
             // sequence number of this message
+            // (room for this group's messages was checked before the group started: async_can_send)
             const unsigned long long seq = (unsigned long long)ns->link_in[l];
-            if (seq - ag_load(&ns->aq_head[l]) > (unsigned long long)ns->aq_cap) { bagoverflow = 1; return; }
             const size_t slot = (size_t)l * ns->aq_cap + (size_t)((seq - 1) % (unsigned long long)ns->aq_cap);
             ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t); ag_store(&ns->aq_cr[slot], created);
             sent_async = true;          // the caller publishes aq_tail (= link_in) after draining these stores
@@ -434,7 +434,7 @@ struct NetStation {
 #pragma unroll
         for (int i = 0; i < C; ++i)
             if (D[i] == t && (best == 0 || (int32_t)(seqD[i] - bs) < 0)) { best = 2 + i; bc = crtD[i]; bs = seqD[i]; }
-        for (int i = 0; i < bag_n; ++i) {
+        for (int i = 0; bmin == t && i < bag_n; ++i) {
             if (ns->bag_t[bidx(i)] != t) continue;
             const int64_t ts = ns->bag_ts[bidx(i)];
             const int64_t ln = gid_of(ns->bag_link[bidx(i)]);
@@ -483,7 +483,8 @@ struct NetStation {
 #pragma unroll
         for (int i = 0; i < C; ++i) n_at += (D[i] == t) ? 1 : 0;
         int mi = -1;
-        for (int i = 0; i < bag_n; ++i) if (ns->bag_t[bidx(i)] == t) { ++n_at; mi = i; }
+        if (bmin == t)                    // (the bag's earliest arrival is in a register: no scan for local-only groups)
+            for (int i = 0; i < bag_n; ++i) if (ns->bag_t[bidx(i)] == t) { ++n_at; mi = i; }
         if (n_at == 1 && !force_general) {
             bool general = false, want_poll = false, have_created = false;
             int64_t created = 0;

@@ -388,7 +388,8 @@ void hs_engine_destroy(hs_engine *h);
  * fills u[i] = uniform(seed, sid, k0+i), e[i] = -hs_log(1-u[i]), ns[i] = trunc((e[i]/rate)*1e9). */
 /* Debug: bit 0 routes every timestamp group through the general in-group FIFO path (tests compare it with
  * the fast path); bit 4 (16) runs a station network on the windowed engine (one launch per window) even when the
- * asynchronous whole-run engine is available. */
+ * asynchronous whole-run engine is available; bit 6 (64) disables the asynchronous engine's in-wavefront scan of the
+ * per-link bounds; bit 7 (128) makes its idle wavefronts back off (s_sleep) between polls. */
 int hs_debug_set_flags(hs_engine *h, int flags);
 /* Debug: telemetry of the last asynchronous network run: {sum over wavefronts of loop iterations, max over wavefronts,
  * timestamp groups run (sum over LPs), wavefronts}. */

@@ -12,10 +12,11 @@ ap.add_argument("--end-s", type=float, default=60.0)
 ap.add_argument("--lat-min", type=float, default=0.001)
 ap.add_argument("--jitter", type=float, default=0.01)
 ap.add_argument("--repeats", type=int, default=2)
+ap.add_argument("--flags", type=int, default=0)
 a = ap.parse_args()
 spec = dict(name="ring_full", topology="ring", n=a.n, ext_rate=4.0, mean=0.1, lat_min=a.lat_min, jitter_mean=a.jitter,
             end_s=a.end_s, seed=42)
-eng, p = H.ring_engine_for_spec(spec)
+eng, p = H.ring_engine_for_spec(spec, flags=a.flags)
 with eng:
     t0 = time.perf_counter(); eng.run_until(p["end_ns"]); t1 = time.perf_counter()
     s = eng.summary()
