@@ -109,3 +109,28 @@ def test_replicas_vs_single_overshoot_relation_and_sampled_oracle_parity(single_
             t, cr = rep.read_sink(int(lp))
             np.testing.assert_array_equal(t, r.sinks[2][0])
             np.testing.assert_array_equal(cr, r.sinks[2][1])
+
+
+def test_baseline_config1_4096_replicas_seed_matched():
+    """BASELINE configs[1] verbatim: 4 096 independent M/M/1 replicas (Poisson 8/s, Exp mean 0.1 s), 60 s, replica i seeded
+    base_seed + i as ParallelRunner.run_replicas does (parallel/runner.py:115-142) -- every replica's event count, final
+    time, statistics and Sink records against 4 096 separate runs of the oracle."""
+    import helpers as H
+
+    spec = dict(name="config1", n_chains=4096, arr="poisson", rate=8.0, svc="exp", mean=0.1, end_s=60.0, rng="philox",
+                seed=20260923, mode="replicas")
+    runs = H.run_oracle_for_spec(spec)
+    want, sinks = H.oracle_per_chain(spec, runs)
+    eng, p = H.engine_for_spec(spec)
+    with eng:
+        eng.run_until(p["end_ns"])
+        s = eng.summary()
+        st = eng.lp_stats()
+        counts, t, cr = eng.read_sinks()
+    assert s.events_processed == sum(r.events_processed for _, _, r in runs) > 14_000_000
+    np.testing.assert_array_equal(st["events"], [r.events_processed for _, _, r in runs])
+    np.testing.assert_array_equal(st["final_time_ns"], [r.final_time_ns for _, _, r in runs])
+    for k in want:
+        np.testing.assert_array_equal(st[k], want[k], err_msg=k)
+    np.testing.assert_array_equal(t, np.concatenate([sinks[c][0] for c in range(4096)]))
+    np.testing.assert_array_equal(cr, np.concatenate([sinks[c][1] for c in range(4096)]))
