@@ -221,3 +221,50 @@ def test_profile_sweep_matches_oracle():
         np.testing.assert_array_equal(t[off:off + counts[c]], ot)
         np.testing.assert_array_equal(cr[off:off + counts[c]], ocr)
         off += counts[c]
+
+
+def test_nonzero_start_time_matches_oracle():
+    """`Simulation(start_time=Instant.from_seconds(5), ...)`: sources draw their first arrival from start_time
+    (load/source.py:120-140); chains, a ring (both network engines) and a load-balancer topology against the oracle."""
+    from happy_simulator_amd import _native as N
+    from happy_simulator_amd.engine import StationArrays, StationEngine
+    from happy_simulator_amd.lb_engine import LbBackendArrays, LbSourceArrays, LoadBalancerEngine
+
+    start, end = 5_000_000_000, 13_000_000_000
+    # chains
+    n = 96
+    g = O.mm1_chains(n, rate=8.0, mean=0.1)
+    r = O.run(g, end, start_ns=start, seed=9)
+    with StationEngine(StationArrays.uniform(n, rate=8.0, mean=0.1), mode=N.MODE_SINGLE, horizon_ns=end, start_ns=start,
+                       seed=9) as eng:
+        eng.run_until(end)
+        s = eng.summary()
+        assert (s.events_processed, s.final_time_ns) == (r.events_processed, r.final_time_ns)
+        np.testing.assert_array_equal(s.events_by_kind, r.events_by_kind)
+        counts, t, cr = eng.read_sinks()
+        np.testing.assert_array_equal(t, np.concatenate([r.sinks[i][0] for i in sorted(r.sinks)]))
+        assert t.min() > start
+    # ring, both engines
+    spec = dict(name="ring_start", topology="ring", n=48, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, end_s=13.0,
+                seed=10)
+    gr, nodes = H.oracle_ring_graph(spec)
+    rr = O.run(gr, end, start_ns=start, seed=10)
+    st, net, cap, _ = H.ring_arrays(spec)
+    for flags in (0, 16):
+        with StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=end, start_ns=start, seed=10, log_capacity=cap, network=net) as eng:
+            if flags:
+                eng.set_debug_flags(flags)
+            eng.run_until(end)
+            s = eng.summary()
+            assert (s.events_processed, s.final_time_ns) == (rr.events_processed, rr.final_time_ns), flags
+            np.testing.assert_array_equal(s.events_by_kind, rr.events_by_kind)
+    # load balancer
+    lspec = dict(n_sources=24, n_backends=40, rate=20.0, mean=0.1, vnodes=100, n_clients=5000, end_s=13.0, seed=11)
+    gl, p = H.oracle_lb_graph(lspec)
+    rl = O.run(gl, end, start_ns=start, seed=11)
+    src = LbSourceArrays(n=24, src_rate=np.full(24, 20.0), n_clients=np.full(24, 5000, np.int64))
+    be = LbBackendArrays(n=40, names=[f"srv{j}" for j in range(40)], svc_kind=np.full(40, N.LAT_EXPONENTIAL, np.uint8),
+                         svc_mean_s=np.full(40, 0.1))
+    with LoadBalancerEngine(src, be, virtual_nodes=100, horizon_ns=end, start_ns=start, seed=11) as eng:
+        eng.run(end)
+        H.compare_lb_engine_with_oracle(eng, p, rl)
