@@ -36,7 +36,7 @@ EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuat
 PROBE_METRICS = {"depth": 0, "active_requests": 1, "stats_accepted": 2, "stats_dropped": 3, "requests_completed": 4,
                  "_requests_completed": 4, "events_received": 5, "generated_count": 6}
 PROBE_NONE = 255
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class EngineUnavailable(RuntimeError):
@@ -83,7 +83,7 @@ class Network(C.Structure):
         ("link_dst", C.c_void_p), ("link_lat_min_s", C.c_void_p), ("link_jitter_kind", C.c_void_p),
         ("link_jitter_mean_s", C.c_void_p), ("link_stream_base", C.c_void_p), ("link_src", C.c_void_p),
         ("bag_capacity", C.c_int32), ("n_global_lp", C.c_int32), ("link_gid", C.c_void_p),
-        ("n_global_links", C.c_int64),
+        ("n_global_links", C.c_int64), ("link_loss_rate", C.c_void_p),
     ]
 
 
@@ -96,7 +96,8 @@ class Shard(C.Structure):
 
 
 class NetStats(C.Structure):
-    _fields_ = [("routed", C.c_void_p), ("link_entered", C.c_void_p), ("link_packets_sent", C.c_void_p)]
+    _fields_ = [("routed", C.c_void_p), ("link_entered", C.c_void_p), ("link_packets_sent", C.c_void_p),
+                ("link_packets_dropped", C.c_void_p)]
 
 
 class LpStats(C.Structure):

@@ -22,7 +22,7 @@ namespace hs {
 
 constexpr int64_t kInfNs = INT64_MAX;  // Instant.Infinity (core/temporal.py:298-368)
 
-enum StreamKind : uint32_t { kStreamArrival = 0, kStreamService = 1, kStreamLink = 2, kStreamRoute = 3 };
+enum StreamKind : uint32_t { kStreamArrival = 0, kStreamService = 1, kStreamLink = 2, kStreamRoute = 3, kStreamKey = 4, kStreamLoss = 5 };
 
 struct U4 { uint32_t x, y, z, w; };
 

@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
     const int lp = blockIdx.x * kBlock + threadIdx.x;
     if (NX.next_time != nullptr) {   // network engine: clear routing / link / bag state
         for (int l = lp; l < n_links; l += gridDim.x * kBlock) {
-            NX.link_k[l] = 0; NX.link_in[l] = 0; NX.link_packets[l] = 0;
+            NX.link_k[l] = 0; NX.link_in[l] = 0; NX.link_sent[l] = 0; NX.link_packets[l] = 0;
             if (NX.aq_tail != nullptr) { NX.aq_tail[l] = 0; NX.aq_head[l] = 0; NX.aq_ea[l] = start_ns; }
         }
         if (lp < n) { NX.route_k[lp] = 0; NX.routed[lp] = 0; NX.bag_cnt[lp] = 0; NX.in_cnt[lp] = 0; NX.in_cnt[n + lp] = 0; }
@@ -861,7 +861,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                     drain_stores();
 #pragma unroll
                     for (int o = 0; o < 2; ++o)
-                        if (out_l[o] >= 0) ag_store(&NX.aq_tail[out_l[o]], (unsigned long long)NX.link_in[out_l[o]]);
+                        if (out_l[o] >= 0) ag_store(&NX.aq_tail[out_l[o]], (unsigned long long)NX.link_sent[out_l[o]]);
                     drain_stores();
                     S.sent_async = false;
                 }
@@ -1492,13 +1492,19 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     }
     const size_t NL = (size_t)(nl > 0 ? nl : 1);
     std::vector<uint8_t> jk(NL, (uint8_t)HS_LAT_CONSTANT);
-    std::vector<double> jm(NL, 0.0), lmin(NL, 1.0);
+    std::vector<double> jm(NL, 0.0), lmin(NL, 1.0), lloss(NL, 0.0);
     std::vector<int32_t> ldst(NL, 0);
     for (int l = 0; l < nl; ++l) {
         jk[(size_t)l] = net->link_jitter_kind ? net->link_jitter_kind[l] : (uint8_t)HS_LAT_CONSTANT;
         jm[(size_t)l] = net->link_jitter_mean_s ? net->link_jitter_mean_s[l] : 0.0;
         lmin[(size_t)l] = net->link_lat_min_s[l];
         ldst[(size_t)l] = net->link_dst[l];
+        if (net->link_loss_rate) {
+            const double pl = net->link_loss_rate[l];
+            if (!(pl >= 0.0 && pl <= 1.0))                       // components/network/link.py:71-72
+                return fail(h, HS_E_INVALID, "link %d: packet_loss_rate must be in [0, 1], got %g", l, pl);
+            lloss[(size_t)l] = pl;
+        }
     }
     if ((rc = upload<uint8_t>(h, &h->NP.egress, net->egress_kind, (size_t)n, 0))) return rc;
     if ((rc = upload<int32_t>(h, &h->NP.rt0, rt0.data(), (size_t)n, -1))) return rc;
@@ -1511,6 +1517,7 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     if ((rc = upload<uint8_t>(h, &h->NP.link_jit_kind, jk.data(), NL, 1))) return rc;
     if ((rc = upload<double>(h, &h->NP.link_jit_mean, jm.data(), NL, 0.0))) return rc;
     if ((rc = upload<uint64_t>(h, &h->NP.link_base, lbase.data(), NL, 0))) return rc;
+    if ((rc = upload<double>(h, &h->NP.link_loss, lloss.data(), NL, 0.0))) return rc;
     {   // incoming links per LP (CSR) and the transit floor of every link, for the asynchronous engine
         std::vector<int32_t> in_off((size_t)n + 1, 0), in_links(NL, 0);
         std::vector<int64_t> lat_ns(NL, 1);
@@ -1557,7 +1564,7 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     h->NX.bag_cap = bag;
     const size_t N = (size_t)n, NB = (size_t)n * (size_t)bag;
 #define ALN(field, count) if ((rc = dev_alloc(h, &h->NX.field, count))) return rc
-    ALN(route_k, N); ALN(routed, N); ALN(link_k, NL); ALN(link_in, NL); ALN(link_packets, NL); ALN(next_time, N);
+    ALN(route_k, N); ALN(routed, N); ALN(link_k, NL); ALN(link_in, NL); ALN(link_sent, NL); ALN(link_packets, NL); ALN(next_time, N);
     ALN(bag_cnt, N); ALN(bag_t, NB); ALN(bag_ts, NB); ALN(bag_cr, NB); ALN(bag_link, NB);
     ALN(in_cnt, 2 * N); ALN(in_t, 2 * NB); ALN(in_ts, 2 * NB); ALN(in_cr, 2 * NB); ALN(in_link, 2 * NB);
     h->NX.aq_cap = bag;
@@ -1722,6 +1729,12 @@ int hs_engine_get_net_stats(hs_engine *h, const hs_net_stats *o) {
     if (o->routed) HS_HIP(h, hipMemcpy(o->routed, h->NX.routed, n * 8, hipMemcpyDeviceToHost));
     if (o->link_entered && nl) HS_HIP(h, hipMemcpy(o->link_entered, h->NX.link_in, nl * 8, hipMemcpyDeviceToHost));
     if (o->link_packets_sent && nl) HS_HIP(h, hipMemcpy(o->link_packets_sent, h->NX.link_packets, nl * 8, hipMemcpyDeviceToHost));
+    if (o->link_packets_dropped && nl) {                     // entered - not lost
+        std::vector<int64_t> in(nl), sent(nl);
+        HS_HIP(h, hipMemcpy(in.data(), h->NX.link_in, nl * 8, hipMemcpyDeviceToHost));
+        HS_HIP(h, hipMemcpy(sent.data(), h->NX.link_sent, nl * 8, hipMemcpyDeviceToHost));
+        for (size_t l = 0; l < nl; ++l) o->link_packets_dropped[l] = in[l] - sent[l];
+    }
     return HS_OK;
 }
 

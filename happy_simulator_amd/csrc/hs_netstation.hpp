@@ -40,6 +40,7 @@ struct NetParams {
     const uint8_t *link_jit_kind; // [n_links] 0 = ExponentialLatency jitter, 1 = no jitter
     const double *link_jit_mean;  // [n_links]
     const uint64_t *link_base;    // [n_links] stream base of the link entity
+    const double *link_loss;      // [n_links] NetworkLink.packet_loss_rate (0 = lossless)
     const int32_t *link_gid;      // [n_links] network-wide link id (tie-break key); null = the index itself
     // asynchronous engine (hs_net_async): incoming links of every LP (CSR) and each link's transit floor in ns
     const int32_t *in_off;        // [n_lp + 1]
@@ -68,6 +69,8 @@ struct NetState {
     int64_t *routed;              // [n_lp] RandomRouter.stats_routed
     uint64_t *link_k;             // [n_links] jitter draws consumed (touched only by the link's source LP)
     int64_t *link_in;             // [n_links] requests that entered the link (Request@Link events)
+    int64_t *link_sent;           // [n_links] of those, the ones not lost (link_in - link_sent = packets_dropped); also the
+                                  //           sequence number of the link's asynchronous queue
     int64_t *link_packets;        // [n_links] NetworkLink.packets_sent (touched only by the destination LP)
     int64_t *next_time;           // [n_lp] earliest pending local event or bagged message
     // current bag (owner only)
@@ -262,7 +265,16 @@ struct NetStation {
     // executed for a request that enters link `l` at time t; the continuation becomes a message to the egress LP.
     __device__ __forceinline__ void send_link(int32_t l, int64_t t, int64_t created) {
         ev[8]++;
-        ns->link_in[l]++;
+        const int64_t entered = ns->link_in[l]++;
+        const double loss = np->link_loss[l];
+        if (loss > 0.0) {
+            // packet loss is decided before anything else (link.py:131-138: `random.random() < packet_loss_rate`, here u
+            // of the link's LOSS stream, one draw per packet that enters); the generator ends without yielding
+            Stream ls;
+            ls.init(seed, stream_id(np->link_base[l], kStreamLoss), (uint64_t)entered);
+            if (ls.next_uniform() < loss) return;
+        }
+        ns->link_sent[l]++;
         double delay = seconds_from_ns(ns_from_seconds(np->link_lat_min[l]));          // ConstantLatency
         if (np->link_jit_kind[l] == 0) {
             Stream js;
@@ -277,13 +289,13 @@ struct NetStation {
         sent_min = t_arr < sent_min ? t_arr : sent_min;
         const int32_t dst = np->link_dst[l];                 // network-wide station index
         if (ns->aq_on) {
-            // asynchronous engine: append to the link's queue (this LP is its only producer); link_in[l] is the
+            // asynchronous engine: append to the link's queue (this LP is its only producer); link_sent[l] is the
             // sequence number of this message
             // (room for this group's messages was checked before the group started: async_can_send)
-            const unsigned long long seq = (unsigned long long)ns->link_in[l];
+            const unsigned long long seq = (unsigned long long)ns->link_sent[l];
             const size_t slot = (size_t)l * ns->aq_cap + (size_t)((seq - 1) % (unsigned long long)ns->aq_cap);
             ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t); ag_store(&ns->aq_cr[slot], created);
-            sent_async = true;          // the caller publishes aq_tail (= link_in) after draining these stores
+            sent_async = true;          // the caller publishes aq_tail (= link_sent) after draining these stores
             return;
         }
         if (sc->wend_slots != nullptr && sc->link_rank[l] != sc->rank) {
@@ -398,7 +410,7 @@ struct NetStation {
     // side and the (cache-bypassing) reload is needed only when the queue looks full
     __device__ __forceinline__ bool async_can_send(int32_t l, unsigned long long &head_seen) const {
         if (l < 0) return true;
-        const unsigned long long sent = (unsigned long long)ns->link_in[l];
+        const unsigned long long sent = (unsigned long long)ns->link_sent[l];
         if (sent - head_seen + (unsigned long long)C <= (unsigned long long)ns->aq_cap) return true;
         head_seen = ag_load(&ns->aq_head[l]);
         return sent - head_seen + (unsigned long long)C <= (unsigned long long)ns->aq_cap;

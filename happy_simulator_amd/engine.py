@@ -60,6 +60,7 @@ class NetworkArrays:
     link_jitter_mean_s: np.ndarray
     router_stream_base: np.ndarray | None = None
     link_stream_base: np.ndarray | None = None
+    link_loss_rate: np.ndarray | None = None   # [n_links] NetworkLink.packet_loss_rate; None = lossless
     bag_capacity: int = 0
     # one shard of a partitioned network (happy_simulator_amd/sharded.py): network-wide endpoints and link ids
     n_global_lp: int = 0
@@ -152,6 +153,7 @@ class StationEngine:
         put("link_jitter_kind", net.link_jitter_kind, np.uint8, nl)
         put("link_jitter_mean_s", net.link_jitter_mean_s, np.float64, nl)
         put("link_stream_base", net.link_stream_base, np.uint64, nl)
+        put("link_loss_rate", net.link_loss_rate, np.float64, nl)
         nw.bag_capacity = int(net.bag_capacity)
         nw.n_global_lp = int(net.n_global_lp)
         put("link_gid", net.link_gid, np.int64, nl)
@@ -161,11 +163,12 @@ class StationEngine:
 
     def net_stats(self) -> dict:
         out = {"routed": np.zeros(self.n, np.int64), "link_entered": np.zeros(max(self.n_links, 1), np.int64),
-               "link_packets_sent": np.zeros(max(self.n_links, 1), np.int64)}
+               "link_packets_sent": np.zeros(max(self.n_links, 1), np.int64),
+               "link_packets_dropped": np.zeros(max(self.n_links, 1), np.int64)}
         st = N.NetStats(**{k: v.ctypes.data for k, v in out.items()})
         self._check(self._lib.hs_engine_get_net_stats(self._h, C.byref(st)))
-        out["link_entered"] = out["link_entered"][:self.n_links]
-        out["link_packets_sent"] = out["link_packets_sent"][:self.n_links]
+        for k in ("link_entered", "link_packets_sent", "link_packets_dropped"):
+            out[k] = out[k][:self.n_links]
         return out
 
     # -- error plumbing ------------------------------------------------------------------------

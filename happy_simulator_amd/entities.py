@@ -441,8 +441,10 @@ class NetworkLinkStats:
 
 class NetworkLink(Entity):
     """Point-to-point link (components/network/link.py:36-234).  Lowered: a constant base latency > 0 (it is the
-    lookahead of the conservative windows) plus optional exponential jitter, towards a Server.  Bandwidth and
-    packet loss are not lowered (payload sizes / the global `random` stream are host-Python state)."""
+    lookahead of the conservative windows) plus optional exponential jitter, towards a Server.  `packet_loss_rate` is
+    lowered with the link's own Philox LOSS stream in place of the process-wide `random.random()` (link.py:131).
+    `bandwidth_bps` is accepted: requests of the lowered event providers carry no payload_size, so their transmission
+    time is 0 s and `bytes_transmitted` stays 0, as in the reference (link.py:209-234)."""
 
     def __init__(self, name: str, latency: LatencyDistribution, bandwidth_bps: float | None = None,
                  packet_loss_rate: float = 0.0, jitter: LatencyDistribution | None = None, egress: Entity | None = None):

@@ -123,7 +123,10 @@ class LoweredGraph:
             link_src=np.array([s for _, s, _ in self.links], np.int32).reshape(nl),
             link_dst=np.array([d for _, _, d in self.links], np.int32).reshape(nl),
             link_lat_min_s=np.array([lk.latency.mean for lk, _, _ in self.links], np.float64).reshape(nl),
-            link_jitter_kind=jk, link_jitter_mean_s=jm, bag_capacity=bag_capacity)
+            link_jitter_kind=jk, link_jitter_mean_s=jm,
+            link_loss_rate=(np.array([lk.packet_loss_rate for lk, _, _ in self.links], np.float64).reshape(nl)
+                            if any(lk.packet_loss_rate for lk, _, _ in self.links) else None),
+            bag_capacity=bag_capacity)
 
     def log_capacity(self, horizon_s: float) -> int:
         """Records per station: a station's admissions are bounded by its own source plus everything its upstream
@@ -207,8 +210,9 @@ def lower(sources: list, entities: list) -> LoweredGraph:
                 "conservative time windows (the reference enforces min_latency > 0 the same way, parallel/link.py:41-45)")
         if lk.jitter is not None and not isinstance(lk.jitter, ExponentialLatency):
             raise UnsupportedTopology(f"link '{lk.name}': jitter {type(lk.jitter).__name__} is not lowered")
-        if lk.bandwidth_bps is not None or lk.packet_loss_rate != 0.0:
-            raise UnsupportedTopology(f"link '{lk.name}': bandwidth limits / packet loss are not lowered")
+        # packet_loss_rate is lowered (the link's own LOSS stream).  bandwidth_bps is accepted as it is: requests built by
+        # the lowered event providers carry no payload_size, so the transmission time (link.py:209-214) is 0 s and
+        # bytes_transmitted stays 0, which is what the reference computes for them as well.
         if not isinstance(lk.egress, Server):
             raise UnsupportedTopology(f"link '{lk.name}' must deliver to a Server (got {type(lk.egress).__name__})")
         used_links[id(lk)] = len(g.stations)
@@ -344,6 +348,7 @@ def write_back(g: LoweredGraph, stats: dict, counts: np.ndarray, t_ns: np.ndarra
         if net_stats is not None:
             for lk, l in zip(st.links, st.link_ids):
                 lk.packets_sent = int(net_stats["link_packets_sent"][l])
+                lk.packets_dropped = int(net_stats["link_packets_dropped"][l])
                 lk._entered = int(net_stats["link_entered"][l])
             if st.router is not None:
                 st.router.stats_routed = int(net_stats["routed"][i])

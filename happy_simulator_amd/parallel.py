@@ -326,22 +326,24 @@ class ParallelSimulation:
                 fc = np.zeros(st.n, np.int64)
                 fc[s.lo:s.hi] = counts
                 fnet = {"routed": np.zeros(st.n, np.int64), "link_entered": np.zeros(net.n_links, np.int64),
-                        "link_packets_sent": np.zeros(net.n_links, np.int64)}
+                        "link_packets_sent": np.zeros(net.n_links, np.int64),
+                        "link_packets_dropped": np.zeros(net.n_links, np.int64)}
                 fnet["routed"][s.lo:s.hi] = ns["routed"]
-                fnet["link_entered"][s.gids] = ns["link_entered"]
-                fnet["link_packets_sent"][s.gids] = ns["link_packets_sent"]
+                for k in ("link_entered", "link_packets_sent", "link_packets_dropped"):
+                    fnet[k][s.gids] = ns[k]
                 # packets_sent is counted where the link ENDS: only write links back from the shard that owns the
                 # destination (with virtual shards every object is visited by both ends' shards; the owner wins)
                 write_back(g, full, fc, t_ns, created_ns, None, lo=s.lo, hi=s.hi)
                 for l, (lk, src, dst) in enumerate(g.links):
                     if s.lo <= dst < s.hi:
                         lk.packets_sent = int(fnet["link_packets_sent"][l])
-                    if s.lo <= src < s.hi:
+                    if s.lo <= src < s.hi:                       # losses are decided where the link STARTS
                         lk._entered = int(fnet["link_entered"][l])
+                        lk.packets_dropped = int(fnet["link_packets_dropped"][l])
                 for i in range(s.lo, s.hi):
                     if g.stations[i].router is not None:
                         g.stations[i].router.stats_routed = int(fnet["routed"][i])
-                cross_local += int(sum(fnet["link_entered"][l] for l in self._cross_links
+                cross_local += int(sum(fnet["link_entered"][l] - fnet["link_packets_dropped"][l] for l in self._cross_links
                                        if s.lo <= g.links[l][1] < s.hi))
                 tot = s.totals()
                 dur = (tot["max_final_ns"] - start_ns) / 1e9

@@ -163,6 +163,7 @@ def shard_arrays(stations: StationArrays, net: NetworkArrays, lo: int, hi: int):
         link_lat_min_s=np.asarray(net.link_lat_min_s)[gids], link_jitter_kind=np.asarray(net.link_jitter_kind)[gids],
         link_jitter_mean_s=np.asarray(net.link_jitter_mean_s)[gids],
         router_stream_base=np.asarray(rbase, np.uint64)[sl], link_stream_base=np.asarray(lbase, np.uint64)[gids],
+        link_loss_rate=None if net.link_loss_rate is None else np.asarray(net.link_loss_rate, np.float64)[gids],
         bag_capacity=net.bag_capacity, n_global_lp=n, link_gid=gids, n_global_links=net.n_links)
     return st, sub
 

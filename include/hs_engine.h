@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HS_ABI_VERSION 4
+#define HS_ABI_VERSION 5
 
 typedef enum hs_status {
     HS_OK = 0,
@@ -163,6 +163,12 @@ typedef struct hs_network {
     int32_t n_global_lp;
     const int64_t *link_gid;         /* [n_links] */
     int64_t n_global_links;
+    /* NetworkLink(packet_loss_rate) (components/network/link.py:131-138): every request entering the link is lost
+     * with this probability (u of the link's LOSS stream < rate, where the reference asks the process-wide
+     * `random.random()`); in [0, 1].  NULL = lossless.  NetworkLink(bandwidth_bps) needs no field: the lowered event
+     * providers put no payload_size into the metadata, so the transmission time (link.py:209-214) is 0 for any
+     * bandwidth and bytes_transmitted stays 0, exactly as in the reference. */
+    const double *link_loss_rate;    /* [n_links] */
 } hs_network;
 
 /* Exchange buffers of a shard: device memory owned by the caller (torch tensors on the host side, so that
@@ -186,6 +192,7 @@ typedef struct hs_net_stats {
     int64_t *routed;                 /* [n_lp]    RandomRouter.stats_routed            components/random_router.py:36 */
     int64_t *link_entered;           /* [n_links] requests that entered the link (Request@Link events) */
     int64_t *link_packets_sent;      /* [n_links] NetworkLink.packets_sent             components/network/link.py:162 */
+    int64_t *link_packets_dropped;   /* [n_links] NetworkLink.packets_dropped          components/network/link.py:132 */
 } hs_net_stats;
 
 typedef struct hs_summary {

@@ -58,6 +58,7 @@ typedef struct {
     /* NetworkLink / RandomRouter */
     int64_t packets_sent;                 /* NetworkLink.packets_sent, components/network/link.py:162 */
     uint64_t link_draws;
+    uint64_t loss_draws;                  /* packets that entered a lossy link */
     int64_t routed;                       /* RandomRouter.stats_routed, components/random_router.py:36 */
     uint64_t route_draws;
     /* LoadBalancer */
@@ -558,7 +559,10 @@ static void on_route(hso_sim *s, const hso_event *e) {
     heap_push(s, ev);
 }
 
-/* NetworkLink.handle_event up to its yield, components/network/link.py:114-154 (no loss, no bandwidth):
+/* NetworkLink.handle_event up to its yield, components/network/link.py:114-154.  Packet loss (:131-138) is decided
+ * first -- the generator returns before its first yield, so the event costs the continuation's sort index and nothing
+ * else; `dropped` of the link node = packets_dropped.  Bandwidth: the lowered providers put no payload_size in the
+ * metadata, so the transmission time (:209-214) is 0 * 8 / bandwidth = 0.0 whatever the bandwidth.
  * delay = latency.get_latency(now).to_seconds() [+ jitter.get_latency(now).to_seconds()], max(0, .)
  * (_calculate_delay :190-216).  Modelled link: latency = ConstantLatency(lat_min),
  * jitter = ExponentialLatency(lat_mean) when lat_kind == EXP, no jitter otherwise. */
@@ -566,6 +570,11 @@ static void on_link(hso_sim *s, const hso_event *e) {
     int32_t n = e->node;
     hso_node *nd = &s->nodes[n];
     (void)next_index(s);                                            /* continuation built by _start_process */
+    if (s->g.loss[n] > 0.0 && draw_uniform(s, n, HS_STREAM_LOSS, &nd->loss_draws) < s->g.loss[n]) {
+        nd->dropped++;                                              /* packets_dropped, link.py:132 */
+        req_release(s, e->req);
+        return;
+    }
     double delay = hsr_seconds_from_ns(hsr_ns_from_seconds(s->g.lat_min[n]));      /* ConstantLatency */
     if (s->g.lat_kind[n] == HSO_LAT_EXP) {
         double lambda = 1.0 / s->g.lat_mean[n];
@@ -738,7 +747,7 @@ hso_sim *hso_create(const hso_graph *g, const hso_params *p) {
     DUP(arr_kind, int32_t); DUP(rate, double); DUP(stop_after_ns, int64_t);
     DUP(concurrency, int32_t); DUP(lat_kind, int32_t); DUP(lat_mean, double); DUP(lat_min, double);
     DUP(queue_cap, int64_t); DUP(rt_off, int32_t); DUP(rt_cnt, int32_t);
-    DUP(n_clients, int64_t); DUP(vnodes, int32_t); DUP(prof_kind, int32_t); DUP(probe_metric, int32_t);
+    DUP(n_clients, int64_t); DUP(vnodes, int32_t); DUP(prof_kind, int32_t); DUP(probe_metric, int32_t); DUP(loss, double);
     {
         double *pp = (double *)calloc((size_t)n * 4 + 1, sizeof(double));
         if (g->prof_p) memcpy(pp, g->prof_p, (size_t)n * 4 * sizeof(double));
@@ -900,7 +909,7 @@ void hso_destroy(hso_sim *s) {
     free((void *)s->g.kind); free((void *)s->g.target); free((void *)s->g.stream_base);
     free((void *)s->g.arr_kind); free((void *)s->g.rate); free((void *)s->g.stop_after_ns);
     free((void *)s->g.concurrency); free((void *)s->g.lat_kind); free((void *)s->g.lat_mean);
-    free((void *)s->g.prof_kind); free((void *)s->g.prof_p); free((void *)s->g.probe_metric);
+    free((void *)s->g.prof_kind); free((void *)s->g.prof_p); free((void *)s->g.probe_metric); free((void *)s->g.loss);
     free((void *)s->g.n_clients); free((void *)s->g.vnodes); free((void *)s->g.names); free((void *)s->g.name_off);
     free((void *)s->g.lat_min); free((void *)s->g.queue_cap); free((void *)s->g.rt_off); free((void *)s->g.rt_cnt); free((void *)s->g.rt_targets);
     free(s->nodes); free(s->heap); free(s->reqs);

@@ -64,6 +64,7 @@ class _Graph(C.Structure):
         ("prof_kind", C.POINTER(C.c_int32)),
         ("prof_p", C.POINTER(C.c_double)),
         ("probe_metric", C.POINTER(C.c_int32)),
+        ("loss", C.POINTER(C.c_double)),
     ]
 
 
@@ -154,12 +155,13 @@ class Graph:
     prof_kind: list = field(default_factory=list)
     prof_p: list = field(default_factory=list)       # 4 parameters per node
     probe_metric: list = field(default_factory=list)
+    loss: list = field(default_factory=list)
 
     def _add(self, **kw) -> int:
         defaults = dict(
             kind=0, target=-1, stream_base=len(self.kind), arr_kind=0, rate=0.0, stop_after_ns=-1,
             concurrency=1, lat_kind=LAT_CONST, lat_mean=0.0, lat_min=0.0, queue_cap=-1, rt_off=0, rt_cnt=0,
-            n_clients=0, vnodes=0, names="", prof_kind=PROF_CONSTANT, prof_p=(0.0, 0.0, 0.0, 0.0), probe_metric=0,
+            n_clients=0, vnodes=0, names="", prof_kind=PROF_CONSTANT, prof_p=(0.0, 0.0, 0.0, 0.0), probe_metric=0, loss=0.0,
         )
         defaults.update(kw)
         for k, v in defaults.items():
@@ -193,9 +195,10 @@ class Graph:
         return self._add(kind=PROBE, target=target, arr_kind=ARR_CONSTANT, probe_metric=metric,
                          prof_kind=PROF_GENERAL_CONSTANT, prof_p=(1.0 / interval, 0.0, 0.0, 0.0))
 
-    def link(self, lat_min, jitter_mean=None, target=-1, stream_base=None) -> int:
-        """NetworkLink(latency=ConstantLatency(lat_min), jitter=ExponentialLatency(jitter_mean) | None, egress=target)."""
-        kw = dict(kind=LINK, lat_min=float(lat_min), target=target,
+    def link(self, lat_min, jitter_mean=None, target=-1, stream_base=None, loss=0.0) -> int:
+        """NetworkLink(latency=ConstantLatency(lat_min), jitter=ExponentialLatency(jitter_mean) | None, egress=target,
+        packet_loss_rate=loss)."""
+        kw = dict(kind=LINK, lat_min=float(lat_min), target=target, loss=float(loss),
                   lat_kind=LAT_CONST if jitter_mean is None else LAT_EXP,
                   lat_mean=0.0 if jitter_mean is None else float(jitter_mean))
         if stream_base is not None:
@@ -261,6 +264,7 @@ def run(g: Graph, end_ns: int, start_ns: int = 0, seed: int = 42, rng_mode: int 
         "prof_kind": np.asarray(g.prof_kind, np.int32),
         "prof_p": np.asarray(g.prof_p, np.float64).reshape(-1),
         "probe_metric": np.asarray(g.probe_metric, np.int32),
+        "loss": np.asarray(g.loss, np.float64),
     }
     enc = [nm.encode() for nm in g.names]
     names_blob = b"".join(enc) + b"\0"

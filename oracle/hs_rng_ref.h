@@ -35,7 +35,7 @@
 #include <stdint.h>
 #include <string.h>
 
-enum { HS_STREAM_ARRIVAL = 0, HS_STREAM_SERVICE = 1, HS_STREAM_LINK = 2, HS_STREAM_ROUTE = 3, HS_STREAM_KEY = 4 };
+enum { HS_STREAM_ARRIVAL = 0, HS_STREAM_SERVICE = 1, HS_STREAM_LINK = 2, HS_STREAM_ROUTE = 3, HS_STREAM_KEY = 4, HS_STREAM_LOSS = 5 };
 
 static inline void hsr_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];

@@ -15,7 +15,7 @@ from __future__ import annotations
 import struct
 
 M32 = 0xFFFFFFFF
-STREAM_ARRIVAL, STREAM_SERVICE, STREAM_LINK, STREAM_ROUTE, STREAM_KEY = 0, 1, 2, 3, 4
+STREAM_ARRIVAL, STREAM_SERVICE, STREAM_LINK, STREAM_ROUTE, STREAM_KEY, STREAM_LOSS = 0, 1, 2, 3, 4, 5
 
 
 def philox4x32_10(ctr, key):

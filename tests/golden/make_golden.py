@@ -113,6 +113,17 @@ class PhiloxRandomRouter(RandomRouter):
         return [Event(time=self.now, event_type=event.event_type, target=self.targets[idx], context=event.context)]
 
 
+class _PerLinkRandom:
+    """Stands in for the `random` module inside components/network/link.py so that the reference's own loss test
+    (`random.random() < self.packet_loss_rate`, link.py:131) reads the calling link's Philox LOSS stream instead of the
+    process-wide MT19937; the handler body that runs is the reference's, untouched."""
+
+    @staticmethod
+    def random():
+        link = sys._getframe(1).f_locals["self"]
+        return link._loss_stream.next_uniform()
+
+
 class PhiloxClientProvider(EventProvider):
     """The request factory of examples/visual/chash_example.py:69-88 (`ClientRequestProvider`): one Request per
     tick whose metadata carries a random client_id for the ConsistentHash strategy -- with the id drawn from the
@@ -347,6 +358,9 @@ def run_ring_case(spec):
     Source.poisson(ext_rate) -> Server_i(Exp mean) -> RandomRouter_i([Sink_i, Link_i]);
     Link_i = NetworkLink(latency=ConstantLatency(lat_min), jitter=Exp(jitter_mean), egress=Server_{i+1})."""
     n, seed = spec["n"], spec["seed"]
+    import happysimulator.components.network.link as link_mod
+
+    link_mod.random = _PerLinkRandom       # the loss test of every link reads that link's own Philox stream
     sinks = [Sink(f"sink{i}") for i in range(n)]
     servers = [Server(f"srv{i}", concurrency=spec.get("concurrency", 1),
                       service_time=PhiloxExponentialLatency(spec["mean"], hs.Stream(seed, i, hs.STREAM_SERVICE)),
@@ -356,8 +370,12 @@ def run_ring_case(spec):
         jit = None
         if spec.get("jitter_mean") is not None:
             jit = PhiloxExponentialLatency(spec["jitter_mean"], hs.Stream(seed, i, hs.STREAM_LINK))
+        loss = spec.get("loss", 0.0)
         links.append(NetworkLink(f"link{i}", latency=ConstantLatency(spec["lat_min"]), jitter=jit,
+                                 bandwidth_bps=spec.get("bandwidth_bps"),
+                                 packet_loss_rate=loss[i] if isinstance(loss, list) else loss,
                                  egress=servers[(i + 1) % n]))
+        links[i]._loss_stream = hs.Stream(seed, i, hs.STREAM_LOSS)
         routers.append(PhiloxRandomRouter(f"router{i}", targets=[sinks[i], links[i]],
                                           stream=hs.Stream(seed, i, hs.STREAM_ROUTE)))
         servers[i].downstream = routers[i]
@@ -404,6 +422,8 @@ def run_ring_case(spec):
     out["received"] = np.array([k.events_received for k in sinks], np.int64)
     out["routed"] = np.array([r.stats_routed for r in routers], np.int64)
     out["packets_sent"] = np.array([l.packets_sent for l in links], np.int64)
+    out["packets_dropped"] = np.array([l.packets_dropped for l in links], np.int64)
+    out["bytes_transmitted"] = np.array([l.bytes_transmitted for l in links], np.int64)
     sink_t, sink_lat, off = [], [], [0]
     for k in sinks:
         sink_t.extend(t.nanoseconds for t in k.completion_times)
@@ -519,6 +539,14 @@ LB_CASES = [
 ]
 
 RING_CASES = [
+    # NetworkLink(packet_loss_rate): lost packets vanish at the link (link.py:131-138)
+    dict(name="ring_8_loss", topology="ring", n=8, ext_rate=6.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, loss=0.2,
+         end_s=20.0, seed=42, trace=True),
+    # per-link loss rates incl. 0 and 1, fixed latency, c = 2, and a bandwidth limit (no payload_size in the metadata of
+    # SimpleEventProvider's requests => transmission time 0, bytes_transmitted 0: link.py:209-234)
+    dict(name="ring_5_loss_mixed", topology="ring", n=5, ext_rate=[6.0, 3.0, 7.0, 2.0, 5.0], mean=0.08, concurrency=2,
+         lat_min=0.002, jitter_mean=None, loss=[0.0, 0.5, 1.0, 0.1, 0.03], bandwidth_bps=1e6, end_s=15.0, seed=13,
+         trace=True),
     dict(name="ring_8_s42", topology="ring", n=8, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, end_s=20.0,
          seed=42, trace=True),
     dict(name="ring_3_short_hops", topology="ring", n=3, ext_rate=4.0, mean=0.1, lat_min=0.0005, jitter_mean=0.002,

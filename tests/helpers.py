@@ -126,7 +126,7 @@ def ring_params(spec):
         n=n, ext_rate=[float(r) for r in per_chain(spec["ext_rate"], n)], mean=float(spec["mean"]),
         conc=int(spec.get("concurrency", 1)), qcap=-1 if spec.get("queue_cap") is None else int(spec["queue_cap"]),
         lat_min=float(spec["lat_min"]), jitter_mean=spec.get("jitter_mean"), end_ns=ns_from_seconds(spec["end_s"]),
-        p_targets=2)
+        loss=[float(x) for x in per_chain(spec.get("loss", 0.0), n)], p_targets=2)
 
 
 def oracle_ring_graph(spec):
@@ -141,7 +141,7 @@ def oracle_ring_graph(spec):
     for i in range(n):
         nodes[i]["srv"] = g.server(O.LAT_EXP, p["mean"], concurrency=p["conc"], queue_cap=p["qcap"], stream_base=i)
         nodes[i]["snk"] = g.sink()
-        nodes[i]["lnk"] = g.link(p["lat_min"], p["jitter_mean"], stream_base=i)
+        nodes[i]["lnk"] = g.link(p["lat_min"], p["jitter_mean"], stream_base=i, loss=p["loss"][i])
         nodes[i]["rtr"] = g.router([nodes[i]["snk"], nodes[i]["lnk"]], stream_base=i)
     for i in range(n):
         if nodes[i]["src"] >= 0:
@@ -276,6 +276,7 @@ def ring_arrays(spec, bag_capacity=0, log_capacity=0):
         link_lat_min_s=np.full(n, p["lat_min"], np.float64),
         link_jitter_kind=np.full(n, N.LAT_CONSTANT if jit is None else N.LAT_EXPONENTIAL, np.uint8),
         link_jitter_mean_s=np.full(n, 0.0 if jit is None else jit, np.float64),
+        link_loss_rate=np.array(p["loss"], np.float64) if any(p["loss"]) else None,
         bag_capacity=bag_capacity,
     )
     # external rate 4/s + forwarded 4/s per station: size the logs for the total admission rate

@@ -127,7 +127,10 @@ def _build_ring(spec):
     links, routers, sources = [], [], []
     for i in range(n):
         jit = None if spec.get("jitter_mean") is None else hs.ExponentialLatency(spec["jitter_mean"])
+        loss = spec.get("loss", 0.0)
         links.append(hs.NetworkLink(f"link{i}", latency=hs.ConstantLatency(spec["lat_min"]), jitter=jit,
+                                    bandwidth_bps=spec.get("bandwidth_bps"),
+                                    packet_loss_rate=loss[i] if isinstance(loss, list) else loss,
                                     egress=servers[(i + 1) % n]))
         routers.append(hs.RandomRouter(f"router{i}", targets=[sinks[i], links[i]]))
         servers[i].downstream = routers[i]
@@ -145,12 +148,16 @@ def _check_ring_objects(gold, servers, routers, links, sinks):
     assert [s.depth for s in servers] == gold.depth.tolist()
     assert [r.stats_routed for r in routers] == gold.routed.tolist()
     assert [l.packets_sent for l in links] == gold.packets_sent.tolist()
+    if "packets_dropped" in gold.arrays:
+        assert [l.packets_dropped for l in links] == gold.packets_dropped.tolist()
+        assert [l.bytes_transmitted for l in links] == gold.bytes_transmitted.tolist()
+        assert [l.link_stats.packets_dropped for l in links] == gold.packets_dropped.tolist()
     assert [k.events_received for k in sinks] == gold.received.tolist()
     lat = [x for k in sinks for x in k.latencies_s]
     assert lat == gold.sink_latency_s.tolist()
 
 
-@pytest.mark.parametrize("name", ["ring_8_s42", "ring_5_const_link", "ring_6_c2_cap3"])
+@pytest.mark.parametrize("name", ["ring_8_s42", "ring_5_const_link", "ring_6_c2_cap3", "ring_8_loss", "ring_5_loss_mixed"])
 def test_ring_network_through_the_api_matches_reference_golden(name):
     gold = H.Golden(name)
     spec = gold.spec

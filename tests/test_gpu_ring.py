@@ -28,6 +28,7 @@ def _check_against_oracle(spec, eng, r, nodes):
         np.testing.assert_array_equal(st[k], arr[srv], err_msg=k)
     np.testing.assert_array_equal(ns["routed"], r.routed[[nodes[i]["rtr"] for i in range(n)]])
     np.testing.assert_array_equal(ns["link_packets_sent"], r.packets_sent[[nodes[i]["lnk"] for i in range(n)]])
+    np.testing.assert_array_equal(ns["link_packets_dropped"], r.dropped[[nodes[i]["lnk"] for i in range(n)]])
     counts, t, cr = eng.read_sinks()
     off = 0
     for i in range(n):
@@ -63,6 +64,9 @@ def test_ring_engine_matches_reference_golden(name, engine_flags):
             np.testing.assert_array_equal(st[k], gold.arrays[g], err_msg=k)
         np.testing.assert_array_equal(ns["routed"], gold.routed)
         np.testing.assert_array_equal(ns["link_packets_sent"], gold.packets_sent)
+        if "packets_dropped" in gold.arrays:                       # NetworkLink(packet_loss_rate) goldens
+            np.testing.assert_array_equal(ns["link_packets_dropped"], gold.packets_dropped)
+            assert ns["link_packets_dropped"].sum() > 0
         counts, t, cr = eng.read_sinks()
         np.testing.assert_array_equal(t, gold.sink_t_ns)
         np.testing.assert_array_equal((t - cr).astype(np.float64) / 1e9, gold.sink_latency_s)
@@ -76,6 +80,11 @@ RING_SWEEP = [
          end_s=8.0, seed=13),
     dict(name="ring_2_dense", topology="ring", n=2, ext_rate=4.5, mean=0.1, lat_min=0.0001, jitter_mean=0.0005, end_s=4.0,
          seed=14),
+    # NetworkLink(packet_loss_rate): uniform and per-link rates (incl. a dead link)
+    dict(name="ring_700_loss", topology="ring", n=700, ext_rate=6.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, loss=0.25,
+         end_s=8.0, seed=15),
+    dict(name="ring_9_c2_loss_mixed", topology="ring", n=9, ext_rate=9.0, mean=0.1, concurrency=2, queue_cap=5,
+         lat_min=0.0005, jitter_mean=None, loss=[0.0, 1.0, 0.5, 0.01, 0.99, 0.0, 0.3, 0.7, 0.1], end_s=12.0, seed=16),
 ]
 
 

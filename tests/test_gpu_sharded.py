@@ -34,11 +34,13 @@ def _sharded(spec, world, sync_every=16, msg_capacity=64):
         stats = {k: np.concatenate(v) for k, v in stats.items()}
         nl = net.n_links
         netst = {"routed": np.concatenate([s.engine.net_stats()["routed"] for s in sn.shards]),
-                 "link_entered": np.zeros(nl, np.int64), "link_packets_sent": np.zeros(nl, np.int64)}
+                 "link_entered": np.zeros(nl, np.int64), "link_packets_sent": np.zeros(nl, np.int64),
+                 "link_packets_dropped": np.zeros(nl, np.int64)}
         for s in sn.shards:
             ns = s.engine.net_stats()
             netst["link_entered"][s.gids] += ns["link_entered"]
             netst["link_packets_sent"][s.gids] += ns["link_packets_sent"]
+            netst["link_packets_dropped"][s.gids] += ns["link_packets_dropped"]
         parts = [s.engine.read_sinks() for s in sn.shards]
         sinks = tuple(np.concatenate([p_[i] for p_ in parts]) for i in range(3))
         return summ, stats, netst, sinks
@@ -66,7 +68,7 @@ def test_sharded_equals_single_engine(spec, world):
     for k in ("generated", "accepted", "dropped", "completed", "rejected", "total_service_s", "sink_received",
               "queue_depth", "active", "events", "final_time_ns"):
         np.testing.assert_array_equal(stats[k], one["stats"][k], err_msg=k)
-    for k in ("routed", "link_entered", "link_packets_sent"):
+    for k in ("routed", "link_entered", "link_packets_sent", "link_packets_dropped"):
         np.testing.assert_array_equal(netst[k], one["net"][k], err_msg=k)
     for a, b in zip(sinks, one["sinks"]):
         np.testing.assert_array_equal(a, b)
@@ -86,6 +88,8 @@ def test_sharded_matches_reference_golden(name):
         np.testing.assert_array_equal(stats[k], gold.arrays[g], err_msg=k)
     np.testing.assert_array_equal(netst["routed"], gold.routed)
     np.testing.assert_array_equal(netst["link_packets_sent"], gold.packets_sent)
+    if "packets_dropped" in gold.arrays:
+        np.testing.assert_array_equal(netst["link_packets_dropped"], gold.packets_dropped)
     np.testing.assert_array_equal(sinks[1], gold.sink_t_ns)
 
 

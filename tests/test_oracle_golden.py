@@ -98,6 +98,9 @@ def test_oracle_matches_reference_ring_golden(name):
             assert arr[nd["srv"]] == gold.arrays[k][i], (k, i)
         assert r.routed[nd["rtr"]] == gold.routed[i]
         assert r.packets_sent[nd["lnk"]] == gold.packets_sent[i]
+        if "packets_dropped" in gold.arrays:
+            assert r.dropped[nd["lnk"]] == gold.packets_dropped[i]
+            assert gold.bytes_transmitted[i] == 0          # no payload_size in the metadata: bandwidth has no effect
         t, created = r.sinks[nd["snk"]]
         gt, glat = gold.sink_records(i)
         np.testing.assert_array_equal(t, gt)
