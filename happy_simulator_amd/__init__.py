@@ -12,6 +12,7 @@ with a host-side mirror of the reference's `Simulation / Source / Server / Sink 
     summary = Simulation(end_time=Instant.from_seconds(60), sources=[source], entities=[server, sink]).run()
 """
 from ._native import EngineError, EngineUnavailable  # noqa: F401
+from .core.event import Event  # noqa: F401
 from .core.temporal import Duration, Instant  # noqa: F401
 from .entities import (BackendInfo, ClientKeyEventProvider, ConsistentHash, ConstantArrivalTimeProvider, Data, Probe,  # noqa: F401
                        ConstantLatency, ConstantRateProfile, Counter, Entity, ExponentialLatency, FIFOQueue,

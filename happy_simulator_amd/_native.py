@@ -64,6 +64,7 @@ class Stations(C.Structure):
         ("queue_cap", C.c_void_p), ("egress", C.c_void_p), ("seed", C.c_void_p), ("stream_base", C.c_void_p),
         ("src_profile_kind", C.c_void_p), ("src_profile_params", C.c_void_p),
         ("probe_metric", C.c_void_p), ("probe_interval_s", C.c_void_p),
+        ("sched_off", C.c_void_p), ("sched_time_ns", C.c_void_p),
     ]
 
 

@@ -72,7 +72,12 @@ __device__ __forceinline__ void load_station(Station<C, PF> &S, const StationPar
     S.stop_ns = P.src_stop[lp]; S.qcap = P.qcap[lp];
     S.prof.kind = kProfConstant;
     S.p_metric = kProbeNone; S.PA = kInfNs; S.evp[0] = S.evp[1] = 0;
+    S.SA = kInfNs; S.sc_i = S.sc_end = 0; S.sc_t = P.sched_t;
     if constexpr (PF) {
+        if (P.sched_off != nullptr) {
+            S.sc_i = X.sched_i[lp]; S.sc_end = P.sched_off[lp + 1];
+            S.SA = S.sc_i < S.sc_end ? P.sched_t[S.sc_i] : kInfNs;
+        }
         S.prof.kind = P.prof_kind[lp];
         S.prof.p0 = P.prof_p[lp]; S.prof.p1 = P.prof_p[(size_t)n + lp]; S.prof.p2 = P.prof_p[(size_t)2 * n + lp];
         S.prof.p3 = P.prof_p[(size_t)3 * n + lp];
@@ -137,6 +142,7 @@ __device__ __forceinline__ void store_station(const Station<C, PF> &Sc, const St
         X.PA[lp] = S.PA; X.seqP[lp] = S.seqP; X.crtP[lp] = S.crtP; X.p_arr[lp] = S.p_arr; X.p_n[lp] = S.p_n;
         X.ev_probe[lp] += S.evp[0]; X.ev_probe[(size_t)n + lp] += S.evp[1];
         tot += S.evp[0] + S.evp[1];
+        if (S.sc_t != nullptr) X.sched_i[lp] = S.sc_i;
     }
     X.events[lp] += tot;
 }
@@ -156,6 +162,7 @@ __device__ __forceinline__ Candidate make_candidate(const Station<C, PF> &S) {
     c.t = t; c.valid = 1;
     if (w == 0) c.t_created = S.crtA;
     else if (w == kRootProbe) c.t_created = S.crtP;
+    else if (w == kRootSched) c.t_created = INT64_MIN;   // constructed before run()
     else {
 #pragma unroll
         for (int i = 0; i < C; ++i) if (i == w - 1) c.t_created = S.crtD[i];
@@ -254,6 +261,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
         X.PA[lp] = PA; X.seqP[lp] = 1; X.crtP[lp] = start_ns; X.p_arr[lp] = p_arr; X.p_n[lp] = 0;
         X.ev_probe[lp] = 0; X.ev_probe[(size_t)n + lp] = 0;
         X.seq[lp] = 2;
+        if (P.sched_off != nullptr) X.sched_i[lp] = P.sched_off[lp];
     }
 }
 
@@ -1345,10 +1353,31 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         h->any_probe = true;
     }
     if (h->any_probe) h->any_profile = true;                        // probes run on the general-path instantiation
+    // Requests injected with Simulation.schedule(): validated here, run by the general-path instantiation too
+    int64_t n_sched = 0, max_sched = 0;
+    if (st->sched_off) {
+        if (st->sched_off[0] != 0) return fail(h, HS_E_INVALID, "sched_off[0] must be 0");
+        for (int i = 0; i < n; ++i) {
+            const int64_t a = st->sched_off[i], b = st->sched_off[i + 1];
+            if (b < a) return fail(h, HS_E_INVALID, "sched_off must not decrease (LP %d)", i);
+            if (b > a && !st->sched_time_ns) return fail(h, HS_E_INVALID, "sched_time_ns is required with sched_off");
+            if (b > a && (st->svc_kind ? st->svc_kind[i] : HS_LAT_CONSTANT) == HS_LAT_NO_SERVER)
+                return fail(h, HS_E_UNSUPPORTED, "LP %d: scheduled Requests need a Server to receive them", i);
+            for (int64_t k = a; k < b; ++k) {
+                if (st->sched_time_ns[k] < h->cfg.start_ns)
+                    return fail(h, HS_E_INVALID, "LP %d: scheduled time %lld ns lies before start_ns", i, (long long)st->sched_time_ns[k]);
+                if (k > a && st->sched_time_ns[k] < st->sched_time_ns[k - 1])
+                    return fail(h, HS_E_INVALID, "LP %d: scheduled times must be ascending", i);
+            }
+            if (b - a > max_sched) max_sched = b - a;
+        }
+        n_sched = st->sched_off[n];
+        if (n_sched > 0) h->any_profile = true;
+    }
     h->C = maxc <= 1 ? 1 : maxc <= 2 ? 2 : maxc <= 4 ? 4 : maxc <= 8 ? 8 : 16;
     int64_t cap = h->cfg.log_capacity;
     if (cap <= 0) {
-        const double c = max_mean_records + 10.0 * std::sqrt(max_mean_records + 1.0) + 64.0;
+        const double c = max_mean_records + 10.0 * std::sqrt(max_mean_records + 1.0) + 64.0 + (double)max_sched;
         cap = ((int64_t)c + 15) & ~(int64_t)15;
     }
     const double log_bytes = (double)n * (double)cap * 8.0 * (h->C > 1 ? 3.0 : 2.0);
@@ -1376,6 +1405,11 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     if ((rc = upload<double>(h, &h->P.prof_p, pp.data(), (size_t)n * 4, 0.0))) return rc;
     if ((rc = upload<uint8_t>(h, &h->P.probe_metric, pm.data(), (size_t)n, 255))) return rc;
     if ((rc = upload<double>(h, &h->P.probe_rate, prate.data(), (size_t)n, 1.0))) return rc;
+    h->P.sched_off = nullptr; h->P.sched_t = nullptr;
+    if (n_sched > 0) {
+        if ((rc = upload<int64_t>(h, &h->P.sched_off, st->sched_off, (size_t)n + 1, 0))) return rc;
+        if ((rc = upload<int64_t>(h, &h->P.sched_t, st->sched_time_ns, (size_t)n_sched, 0))) return rc;
+    }
     const size_t N = (size_t)n, NC = (size_t)n * (size_t)h->C;
 #define AL(field, count) if ((rc = dev_alloc(h, &h->X.field, count))) return rc
     AL(A, N); AL(seqA, N); AL(crtA, N); AL(arr_k, N); AL(arr_time, N); AL(svc_k, N);
@@ -1385,7 +1419,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     AL(received, N); AL(sink_w, N); AL(total_service, N); AL(q, N); AL(grp_time, N); AL(last_time, N);
     AL(events, N); AL(ev_kind, N * 11);
     if (h->any_profile) {      // the general-path instantiation of the run kernel loads / stores the probe state of every LP
-        AL(PA, N); AL(seqP, N); AL(crtP, N); AL(p_arr, N); AL(p_n, N); AL(ev_probe, N * 2);
+        AL(PA, N); AL(seqP, N); AL(crtP, N); AL(p_arr, N); AL(p_n, N); AL(ev_probe, N * 2); AL(sched_i, N);
     }
     if (h->any_probe) {
         h->L.pcap = (int64_t)(horizon_s / min_interval) + 8;
@@ -1415,7 +1449,7 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     if (h->initialised) return fail(h, HS_E_STATE, "set the network before the first run");
     if (h->cfg.mode != HS_MODE_SINGLE) return fail(h, HS_E_INVALID, "a network of stations is one Simulation: HS_MODE_SINGLE");
     if (h->C > 4) return fail(h, HS_E_UNSUPPORTED, "networked stations support concurrency <= 4 for now");
-    if (h->any_profile) return fail(h, HS_E_UNSUPPORTED, "time-varying rate profiles and probes are not lowered for networked stations yet");
+    if (h->any_profile) return fail(h, HS_E_UNSUPPORTED, "time-varying rate profiles, probes and scheduled Requests are not lowered for networked stations yet");
     HS_HIP(h, hipSetDevice(h->cfg.device));
     const int n = h->cfg.n_lp, nl = net->n_links;
     if (nl < 0) return fail(h, HS_E_INVALID, "n_links < 0");

@@ -30,6 +30,7 @@ namespace hs {
 // in-group event codes (low 3 bits) | slot << 3
 enum : uint32_t { Q_PSAMPLE = 0, Q_ENQ = 1, Q_NOTIFY = 2, Q_POLL = 3, Q_DELIVER = 4, Q_TICK = 5, Q_CONT = 6, Q_SINK = 7 };
 constexpr int kRootProbe = 99;  // pick_root: the pending probe tick
+constexpr int kRootSched = 98;  // pick_root: the next Request injected with Simulation.schedule()
 
 constexpr int kBlock = 256;     // LPs per workgroup (4 wavefronts)
 constexpr int kQCap = 48;       // in-group FIFO capacity per LP (LDS)
@@ -79,6 +80,10 @@ struct StationParams {          // read-only, [n_lp] each
     const double *prof_p;           // [4][n_lp]
     const uint8_t *probe_metric;    // Probe attached to this LP: kProbe* metric, 255 = none
     const double *probe_rate;       // 1.0 / interval  (_ProbeProfile.rate, instrumentation/probe.py:27-35)
+    // Simulation.schedule() (core/simulation.py:195-206): Requests injected before run(), per LP sorted by time (stable in
+    // call order): LP lp owns sched_t[sched_off[lp] .. sched_off[lp + 1]).  null = none.
+    const int64_t *sched_off;       // [n_lp + 1]
+    const int64_t *sched_t;
 };
 
 // what a Probe samples with getattr(target, metric) (instrumentation/probe.py:51-66)
@@ -112,6 +117,7 @@ struct StationState {           // read-write; [n_lp] each unless noted
     uint32_t *seqP;
     int64_t *crtP, *p_arr, *p_n;   // creation time of the pending tick, the probe provider's current_time, samples taken
     int64_t *ev_probe;          // [2][n_lp] SourceEvent@Probe, probe_event
+    int64_t *sched_i;           // [n_lp] index into sched_t of the LP's next scheduled Request (PF instantiation only)
 };
 
 struct RecordLogs {
@@ -180,6 +186,10 @@ struct Station {
     int64_t PA, crtP, p_arr, p_n, pcap;
     int64_t *probe_t, *probe_v;
     uint32_t evp[2];
+    // Simulation.schedule() (PF): the next injected Request; it was constructed before run(), so it precedes every
+    // run-time event of the same nanosecond
+    int64_t SA, sc_i, sc_end;
+    const int64_t *sc_t;
     // per-run deltas
     uint32_t ev[8];
     // logs
@@ -419,6 +429,14 @@ struct Station {
         p_n++;
     }
 
+    // ---- Simulation.schedule(): the injected Event IS the Request@Server (QueuedResource.handle_event -> enqueue)
+    __device__ __forceinline__ bool has_sched() const { return PF && SA != kInfNs; }
+    __device__ __forceinline__ void root_sched(int64_t t) {
+        ++sc_i;
+        SA = sc_i < sc_end ? sc_t[sc_i] : kInfNs;
+        if (do_enqueue(t)) qpush(Q_NOTIFY);
+    }
+
     // ---- chains with at most one event in flight (fast path pieces) ---------------------------
     // returns true if the general FIFO must take over (a same-time continuation was created)
     __device__ __forceinline__ bool chain_from_poll(int64_t t) {
@@ -452,6 +470,7 @@ struct Station {
     __device__ __forceinline__ int pick_root(int64_t t) const {
         int best = -1;
         uint32_t bs = 0xffffffffu;
+        if constexpr (PF) { if (SA == t) return kRootSched; }
         if (A == t) { best = 0; bs = seqA; }
 #pragma unroll
         for (int i = 0; i < C; ++i)
@@ -464,6 +483,7 @@ struct Station {
     __device__ __forceinline__ void run_root(int which, int64_t t) {
         if (which == 0) root_tick(t);
         else if (PF && which == kRootProbe) root_probe(t);
+        else if (PF && which == kRootSched) root_sched(t);
         else root_cont(which - 1, t);
     }
 
@@ -503,7 +523,7 @@ struct Station {
         int64_t t = A;
 #pragma unroll
         for (int i = 0; i < C; ++i) t = D[i] < t ? D[i] : t;
-        if constexpr (PF) { if (has_probe() && PA < t) t = PA; }
+        if constexpr (PF) { if (has_probe() && PA < t) t = PA; if (SA < t) t = SA; }
         return t;
     }
 
@@ -512,6 +532,7 @@ struct Station {
 #pragma unroll
         for (int i = 0; i < C; ++i) n_at += (D[i] == t) ? 1 : 0;
         if constexpr (PF) { if (has_probe() && PA == t) n_at += 2; }      // a probe tick: always the general path
+        if constexpr (PF) { if (SA == t) n_at += 2; }                     // so is a scheduled Request
         if (n_at == 1 && !force_general) {
             // Fast path: one event in flight at a time.  Both kinds of root converge on ONE poll/deliver/work
             // site so that a wavefront whose lanes mix ticks and departures executes the (expensive) service
@@ -566,7 +587,8 @@ struct Station {
         const bool poll = (notify && active < conc) || (dep && active_dep < conc);   // queue_driver.py:94-99 / :79-84
         const int64_t buf_enq = buf + (acc ? 1 : 0);
         const bool deliver = poll && buf_enq > 0;                       // queue.py:149-166
-        const bool slow = act && (force_general || svc_kind == 2 || (PF && (prof.kind != kProfConstant || has_probe())) ||
+        const bool slow = act && (force_general || svc_kind == 2 ||
+                                  (PF && (prof.kind != kProfConstant || has_probe() || has_sched())) ||
                                   (tick && D[0] == t) ||
                                   (tick && ((stop_ns >= 0 && t > stop_ns) || a2 <= t)) || (deliver && dur == 0));
         const bool fast = act && !slow;
@@ -639,7 +661,7 @@ struct Station {
     };
     __device__ __forceinline__ bool req_eligible() const {
         return C == 1 && !force_general && qn == 0 && conc == 1 && qcap < 0 && stop_ns < 0 && svc_kind != 2 &&
-               !(PF && (prof.kind != kProfConstant || has_probe())) &&
+               !(PF && (prof.kind != kProfConstant || has_probe() || has_sched())) &&
                (egress == 0 || egress == 1) && !(buf > 0 && active == 0) && active <= 1;
     }
     __device__ __forceinline__ void req_count_departure(ReqCursor &c, bool p, int64_t d, double s) {

@@ -32,6 +32,9 @@ class StationArrays:
     src_profile_params: np.ndarray | None = None    # [n, 4]
     probe_metric: np.ndarray | None = None          # N.PROBE_METRICS ids, N.PROBE_NONE = no probe on the LP
     probe_interval_s: np.ndarray | None = None
+    # Simulation.schedule(): Requests injected before run(); station i gets sched_time_ns[sched_off[i]:sched_off[i + 1]]
+    sched_off: np.ndarray | None = None             # [n + 1] int64
+    sched_time_ns: np.ndarray | None = None         # ascending per station, ties in the caller's order
 
     @staticmethod
     def uniform(n: int, *, src_kind=N.SRC_POISSON, rate=8.0, stop_after_ns=-1, concurrency=1,
@@ -117,6 +120,15 @@ class StationEngine:
                 raise ValueError(f"{name} has the wrong shape for {self.n} stations")
             keep.append(a)
             setattr(st, name, a.ctypes.data)
+        if stations.sched_off is not None:
+            off = np.ascontiguousarray(stations.sched_off, np.int64)
+            if off.shape != (self.n + 1,):
+                raise ValueError(f"sched_off must have shape ({self.n + 1},)")
+            tt = np.ascontiguousarray(stations.sched_time_ns if stations.sched_time_ns is not None else [], np.int64)
+            if tt.shape != (int(off[-1]),):
+                raise ValueError("sched_time_ns must hold sched_off[-1] times")
+            keep += [off, tt]
+            st.sched_off, st.sched_time_ns = off.ctypes.data, (tt.ctypes.data if len(tt) else None)
         self.n_links = 0
         try:
             self._check(self._lib.hs_engine_set_stations(self._h, C.byref(st)))

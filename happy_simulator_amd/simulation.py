@@ -4,7 +4,12 @@ from __future__ import annotations
 
 import time as _time
 
+import warnings
+
+import numpy as np
+
 from . import _native as N
+from .core.event import Event
 from .core.temporal import Instant
 from .engine import StationEngine
 from .entities import Counter, Entity, LatencyTracker, Server, Sink
@@ -49,6 +54,51 @@ class Simulation:
         self._events_cancelled = 0
         self._current_time = self._start_time
         self._engine_summary = None
+        self._scheduled: list[Event] = []
+
+    def schedule(self, events) -> None:
+        """Inject Events from outside the event loop, before run() (core/simulation.py:195-206).  Lowered: Requests for a
+        Server of this Simulation; they enter the Server's queue at their time like a Source's payload would, with
+        context["created_at"] = their own time.  An Event built before run() precedes run-time events of the same ns."""
+        if self._summary is not None:
+            raise UnsupportedTopology("schedule() after run(): the engine run is over (build a new Simulation)")
+        for ev in (events if isinstance(events, list) else [events]):
+            if not isinstance(ev, Event):
+                raise TypeError(f"schedule() takes Event objects, got {type(ev).__name__}")
+            self._scheduled.append(ev)
+
+    def _schedule_arrays(self, g: LoweredGraph, arrays) -> list[int]:
+        """Scheduled Events -> per-station ascending time lists (stable in call order).  Returns the times of the
+        cancelled ones."""
+        if not self._scheduled:
+            return []
+        if g.is_network:
+            raise UnsupportedTopology("schedule() is not lowered for networked stations yet")
+        station_of = {id(st.server): i for i, st in enumerate(g.stations) if st.server is not None}
+        per: list[list[int]] = [[] for _ in g.stations]
+        cancelled: list[int] = []
+        start_ns = self._start_time.nanoseconds
+        for ev in self._scheduled:
+            if ev.cancelled:                       # lazy deletion: skipped when popped, counted (simulation.py:475-477)
+                cancelled.append(ev.time.nanoseconds)
+                continue
+            i = station_of.get(id(ev.target))
+            if i is None:
+                raise UnsupportedTopology(
+                    f"scheduled event {ev!r}: only Requests for a Server of this Simulation are lowered")
+            if ev.on_complete:
+                raise UnsupportedTopology(f"scheduled event {ev!r}: completion hooks are host Python (not lowered)")
+            if ev.context.get("created_at") != ev.time:
+                raise UnsupportedTopology(f"scheduled event {ev!r}: a custom created_at is not lowered")
+            if ev.time.nanoseconds < start_ns:     # "time travel": the loop skips it without counting (simulation.py:480-489)
+                warnings.warn(f"Time travel detected: {ev!r} lies before the simulation start; skipping event", stacklevel=3)
+                continue
+            per[i].append(ev.time.nanoseconds)
+        off = np.zeros(len(g.stations) + 1, np.int64)
+        off[1:] = np.cumsum([len(p) for p in per])
+        arrays.sched_off = off
+        arrays.sched_time_ns = np.array([t for p in per for t in sorted(p)], np.int64)   # sorted() is stable
+        return cancelled
 
     @property
     def summary(self) -> SimulationSummary | None:
@@ -89,11 +139,15 @@ class Simulation:
         wall0 = _time.monotonic()
         g = self.lowered()
         if isinstance(g, LbGraph):
+            if self._scheduled:
+                raise UnsupportedTopology("schedule() is not lowered for load-balancer topologies yet")
             return self._run_lb(g, wall0)
         end_ns = self._end_time.nanoseconds
         net = g.network_arrays() if g.is_network else None
         horizon_s = (end_ns - self._start_time.nanoseconds) / 1e9
-        with StationEngine(g.arrays(), mode=N.MODE_SINGLE, horizon_ns=end_ns, start_ns=self._start_time.nanoseconds,
+        arrays = g.arrays()
+        cancelled_ns = self._schedule_arrays(g, arrays)
+        with StationEngine(arrays, mode=N.MODE_SINGLE, horizon_ns=end_ns, start_ns=self._start_time.nanoseconds,
                            seed=self._seed, device=self._device, network=net,
                            log_capacity=g.log_capacity(horizon_s) if net is not None else 0) as eng:
             eng.run_until(end_ns)
@@ -104,6 +158,10 @@ class Simulation:
             if self._probes:
                 write_back_probes(g, eng)
         write_back(g, stats, counts, t_ns, created_ns, net_stats)
+        # a cancelled event is counted when the loop pops it: everything up to the last processed event, or the whole
+        # heap when the run ended with nothing left beyond end_time (core/simulation.py:472-477)
+        drained = es.final_time_ns <= end_ns
+        self._events_cancelled = sum(1 for t in cancelled_ns if drained or t <= es.final_time_ns)
         self._engine_summary = es
         self._events_processed = es.events_processed
         self._current_time = Instant(es.final_time_ns)

@@ -124,6 +124,12 @@ typedef struct hs_stations {
      * reference events (SourceEvent@Probe, probe_event).  One probe per LP.  NULL = no probes. */
     const uint8_t *probe_metric;       /* hs_probe_metric; 255 = none */
     const double *probe_interval_s;    /* > 0 */
+    /* Simulation.schedule(Event(time, "Request", target=<the LP's Server>)) before run() (core/simulation.py:195-206):
+     * LP i receives the Requests sched_time_ns[sched_off[i] .. sched_off[i + 1]), ascending per LP and, among equal
+     * times, in the order the caller built the Events; context["created_at"] = the Event's own time (core/event.py:176).
+     * An Event built before run() precedes every run-time event of the same nanosecond on its LP.  NULL = none. */
+    const int64_t *sched_off;          /* [n_lp + 1] */
+    const int64_t *sched_time_ns;      /* [sched_off[n_lp]], each >= start_ns */
 } hs_stations;
 typedef enum hs_probe_metric {
     HS_PROBE_DEPTH = 0,        /* QueuedResource.depth */

@@ -78,6 +78,8 @@ struct hso_sim {
     hso_event *heap; int64_t heap_len, heap_cap, heap_peak;
     hso_request *reqs; int32_t req_len, req_cap, req_free;
     uint64_t counter;          /* active sort counter */
+    uint64_t global_counter;   /* the process-wide counter after Simulation.__init__ (core/event.py:53): Events a caller
+                                  builds for Simulation.schedule() before run() take their index from it */
     int64_t current_ns;
     int64_t processed, by_kind[HSO_EV_KINDS];
     hsr_mt19937 mt_py, mt_np;
@@ -809,8 +811,28 @@ hso_sim *hso_create(const hso_graph *g, const hso_params *p) {
     }
     /* run(): _active_sim_context switches Event construction to the per-heap
      * counter, which starts again at 0 (core/event_heap.py:48, core/sim_future.py:64-73). */
+    s->global_counter = s->counter;
     s->counter = 0;
     return s;
+}
+
+/* Simulation.schedule(Event(time, "Request", target=<node>)) before run() (core/simulation.py:195-206): the Event was
+ * constructed outside the run, so its sort index comes from the process-wide counter, which Simulation.__init__ reset
+ * and the bootstrap SourceEvents advanced (core/event.py:53-67,165); context["created_at"] = its own time (:176).
+ * Calls must come in the order the caller constructed the Events.  Returns 0, or -1 for a node that takes no Request. */
+int hso_schedule(hso_sim *s, int32_t node, int64_t time_ns) {
+    int32_t k = arrival_kind_for(s, node);
+    if (k < 0 || k == HSO_EV_LB) return -1;
+    int32_t r = req_alloc(s);
+    s->reqs[r].created_ns = time_ns;
+    s->reqs[r].hops = 0;
+    s->reqs[r].service_s = 0.0;
+    s->reqs[r].client_id = -1;
+    s->reqs[r].lb_hook = -1;
+    hso_event ev = {time_ns, s->global_counter++, k, node, r, 0};
+    s->reqs[r].idx = ev.idx;
+    heap_push(s, ev);
+    return 0;
 }
 
 /* Simulation._execute_until, core/simulation.py:449-505 (no cancellation on this path) */

@@ -100,6 +100,8 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         L.hso_create.restype = C.c_void_p
         L.hso_create.argtypes = [C.POINTER(_Graph), C.POINTER(_Params)]
+        L.hso_schedule.restype = C.c_int
+        L.hso_schedule.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
         L.hso_run_until.restype = C.c_int
         L.hso_run_until.argtypes = [C.c_void_p, C.c_int64]
         L.hso_get_summary.argtypes = [C.c_void_p, C.POINTER(_Summary)]
@@ -245,10 +247,9 @@ class Result:
     pass
 
 
-def run(g: Graph, end_ns: int, start_ns: int = 0, seed: int = 42, rng_mode: int = RNG_PHILOX,
-        mt_seed_py: int = 42, mt_seed_np: int = 42, trace_cap: int = 0, windows: list | None = None,
-        lb_probe: int = 0) -> Result:
-    """Run the oracle once; returns a Result with summary, per-node stats, sink records, trace."""
+def _create(g: Graph, end_ns: int, start_ns: int, seed: int, rng_mode: int, mt_seed_py: int, mt_seed_np: int,
+            trace_cap: int):
+    """hso_create for a Graph; returns the handle (the C side copies every array)."""
     L = lib()
     n = len(g)
     arrs = {
@@ -279,10 +280,23 @@ def run(g: Graph, end_ns: int, start_ns: int = 0, seed: int = 42, rng_mode: int 
     G.names = names_blob
     G.name_off = name_off.ctypes.data_as(C.POINTER(C.c_int32))
     P = _Params(start_ns, end_ns, seed, rng_mode, mt_seed_py, mt_seed_np, trace_cap)
+    return L.hso_create(C.byref(G), C.byref(P))
+
+
+def run(g: Graph, end_ns: int, start_ns: int = 0, seed: int = 42, rng_mode: int = RNG_PHILOX,
+        mt_seed_py: int = 42, mt_seed_np: int = 42, trace_cap: int = 0, windows: list | None = None,
+        lb_probe: int = 0, schedule: list | None = None) -> Result:
+    """Run the oracle once; returns a Result with summary, per-node stats, sink records, trace.
+    schedule: [(node, time_ns), ...] = Simulation.schedule(Event(time, "Request", target=node)) calls before run()."""
+    L = lib()
+    n = len(g)
     import time as _time
 
-    h = L.hso_create(C.byref(G), C.byref(P))
+    h = _create(g, end_ns, start_ns, seed, rng_mode, mt_seed_py, mt_seed_np, trace_cap)
     try:
+        for node, t_ns in (schedule or []):
+            if L.hso_schedule(h, int(node), int(t_ns)) != 0:
+                raise ValueError(f"oracle: node {node} takes no scheduled Request")
         t0 = _time.perf_counter()
         for w_end in (windows or []):
             L.hso_run_until(h, int(w_end))
@@ -332,6 +346,45 @@ def run(g: Graph, end_ns: int, start_ns: int = 0, seed: int = 42, rng_mode: int 
         return r
     finally:
         L.hso_destroy(h)
+
+
+def run_blocks_parallel(graphs: list, end_ns: int, seed: int = 42) -> dict:
+    """Independent graphs (blocks of chains: what the reference's ParallelRunner does with processes,
+    parallel/runner.py:43-142), each in its own oracle instance on its own host thread -- ctypes drops the GIL for the
+    call, so the event loops really run side by side.  Instances are created first; the clock covers the event loops
+    only (first start to last finish).  Returns dict(events, wall_seconds, threads)."""
+    import threading
+    import time as _time
+
+    L = lib()
+    hs = [_create(g, end_ns, 0, seed, RNG_PHILOX, 42, 42, 0) for g in graphs]
+    gate = threading.Barrier(len(hs) + 1)
+    rcs = [0] * len(hs)
+
+    def work(i):
+        gate.wait()
+        rcs[i] = L.hso_run_until(hs[i], int(end_ns))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(hs))]
+    for t in ts:
+        t.start()
+    gate.wait()
+    t0 = _time.perf_counter()
+    for t in ts:
+        t.join()
+    wall = _time.perf_counter() - t0
+    events = 0
+    try:
+        if any(rcs):
+            raise RuntimeError("oracle: unsupported event kind")
+        for h in hs:
+            S = _Summary()
+            L.hso_get_summary(h, C.byref(S))
+            events += S.events_processed
+    finally:
+        for h in hs:
+            L.hso_destroy(h)
+    return dict(events=int(events), wall_seconds=wall, threads=len(hs))
 
 
 def lb_topology(n_sources, n_backends, rate, mean, vnodes, n_clients, concurrency=1, queue_cap=-1,

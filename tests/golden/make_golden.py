@@ -179,7 +179,9 @@ def build_chains(spec, chain_ids, seed):
         else:
             st = ConstantLatency(mean[i])
         server = Server(f"srv{i}", concurrency=conc[i], service_time=st, queue_capacity=qcap[i], downstream=sink)
-        if spec["rng"] == "philox":
+        if rate[i] == 0 and profiles[i] is None:
+            source = None                 # a station fed by Simulation.schedule() only
+        elif spec["rng"] == "philox":
             stop_instant = None if stop is None else Instant.from_seconds(stop)
             if arr[i] == "poisson":
                 prov = PhiloxPoissonArrival(make_profile(i), Instant.Epoch, hs.Stream(seed, base, hs.STREAM_ARRIVAL))
@@ -189,7 +191,8 @@ def build_chains(spec, chain_ids, seed):
         else:
             factory = Source.poisson if arr[i] == "poisson" else Source.constant
             source = factory(rate=rate[i], target=server, name=f"src{i}", stop_after=stop)
-        sources.append(source)
+        if source is not None:
+            sources.append(source)
         entities.append(server)
         if sink is not None:
             entities.append(sink)
@@ -255,7 +258,8 @@ def run_sim(spec, chain_ids, seed, want_trace):
     node_of = {}
     for local, (src, srv, snk) in enumerate(handles):
         c = chain_ids[local]
-        node_of[id(src)] = c
+        if src is not None:
+            node_of[id(src)] = c
         node_of[id(srv)] = c
         node_of[id(srv._queue)] = c
         node_of[id(srv._driver)] = c
@@ -284,6 +288,11 @@ def run_sim(spec, chain_ids, seed, want_trace):
             return e
 
         heap.pop = pop
+    # Simulation.schedule(): one-off Requests built by the caller AFTER the Simulation (core/simulation.py:195-206)
+    for c, t_s in spec.get("schedule") or []:
+        if c in chain_ids:
+            sim.schedule(Event(time=Instant.from_seconds(t_s), event_type="Request",
+                               target=handles[chain_ids.index(c)][1]))
     summary = sim.run()
     return sim, summary, handles, trace
 
@@ -312,7 +321,7 @@ def run_case(spec):
         traces.extend(trace)
         for local, (src, srv, snk) in enumerate(handles):
             i = chain_ids[local]
-            stats["generated"][i] = src.generated_count
+            stats["generated"][i] = src.generated_count if src is not None else 0
             stats["accepted"][i] = srv.stats_accepted
             stats["dropped"][i] = srv.stats_dropped
             stats["completed"][i] = srv._requests_completed
@@ -609,6 +618,17 @@ CASES = [
          svc=["exp", "const", "exp", "exp"], mean=[0.1, 0.04, 0.03, 0.06],
          profile=[None, ["ramp", 12.0, 20.0, 2.0], ["spike", 6.0, 90.0, 4.0, 3.0], ["ramp", 20.0, 2.0, 25.0]],
          end_s=16.0, rng="philox", seed=23, mode="single", trace=True),
+    # --- Simulation.schedule(): one-off Requests injected before run() --------------------------
+    dict(name="schedule_only", n_chains=3, arr="poisson", rate=0.0, svc=["const", "exp", "exp"], mean=[0.5, 0.2, 0.05],
+         concurrency=[1, 2, 1], queue_cap=[None, None, 2],
+         schedule=[[0, 1.0], [0, 1.2], [0, 1.2], [1, 0.3], [2, 0.5], [1, 0.31], [1, 0.32], [2, 0.5], [2, 0.5], [2, 0.5],
+                   [2, 0.5], [0, 7.25], [1, 4.0], [0, 30.0]],
+         end_s=10.0, rng="philox", seed=41, mode="single", trace=True),
+    dict(name="schedule_with_sources", n_chains=4, arr=["poisson", "constant", "poisson", "poisson"],
+         rate=[8.0, 5.0, 0.0, 12.0], svc="exp", mean=[0.1, 0.15, 0.3, 0.06], concurrency=[1, 1, 1, 2],
+         schedule=[[0, 2.000000001], [1, 3.3000001], [2, 1.0], [2, 1.1], [3, 0.7500003], [0, 2.000000001], [3, 9.1],
+                   [1, 0.05], [2, 6.123456789], [0, 11.9999], [3, 12.5]],
+         end_s=12.0, rng="philox", seed=42, mode="single", trace=True),
     # --- probes: Probe.on(target, metric, interval) = a daemon Source sampling an attribute --------
     dict(name="probe_depth_4chains", n_chains=4, arr="poisson", rate=[12.0, 9.0, 30.0, 8.0], svc="exp", mean=[0.1, 0.1, 0.05, 0.1],
          concurrency=[1, 1, 2, 1], queue_cap=[None, None, 6, None],

@@ -65,6 +65,10 @@ def spec_chain_params(spec):
         end_ns=ns_from_seconds(spec["end_s"]),
         profile=[None if pr is None else tuple(pr) for pr in (spec.get("profile") or [None] * n)],
         probes=[None if pr is None else (pr[0], float(pr[1])) for pr in (spec.get("probes") or [None] * n)],
+        # Simulation.schedule(): (chain, time ns) in the caller's construction order; a chain with rate 0 has no Source
+        schedule=[(int(c), ns_from_seconds(float(t))) for c, t in (spec.get("schedule") or [])],
+        no_source=[float(r) == 0.0 and pr is None
+                   for r, pr in zip(per_chain(spec["rate"], n), spec.get("profile") or [None] * n)],
     )
 
 
@@ -82,12 +86,14 @@ def oracle_graph_for(spec, chain_ids, stream_bases):
     nodes = {}
     srcs = []
     for c, base in zip(chain_ids, stream_bases):
-        srcs.append(g.source(p["arr"][c], p["rate"][c], stop_after_ns=p["stop_ns"], stream_base=base,
+        srcs.append(-1 if p["no_source"][c] else
+                    g.source(p["arr"][c], p["rate"][c], stop_after_ns=p["stop_ns"], stream_base=base,
                              profile=p["profile"][c]))
     for k, (c, base) in enumerate(zip(chain_ids, stream_bases)):
         sv = g.server(p["svc"][c], p["mean"][c], concurrency=p["conc"][c], queue_cap=p["qcap"][c], stream_base=base)
         sk = g.sink() if p["downstream"] else -1
-        g.target[srcs[k]] = sv
+        if srcs[k] >= 0:
+            g.target[srcs[k]] = sv
         g.target[sv] = sk
         nodes[c] = (srcs[k], sv, sk)
     g.probe_nodes = {}
@@ -114,7 +120,8 @@ def run_oracle_for_spec(spec, trace_cap=0):
     for chain_ids, seed, bases in groups:
         g, nodes = oracle_graph_for(spec, chain_ids, bases)
         r = O.run(g, p["end_ns"], seed=seed, rng_mode=rng, mt_seed_py=seed & 0xFFFFFFFF,
-                  mt_seed_np=seed & 0xFFFFFFFF, trace_cap=trace_cap)
+                  mt_seed_np=seed & 0xFFFFFFFF, trace_cap=trace_cap,
+                  schedule=[(nodes[c][1], t) for c, t in p["schedule"] if c in nodes])
         r.probe_nodes = g.probe_nodes
         runs.append((chain_ids, nodes, r))
     return runs
@@ -183,8 +190,9 @@ def engine_for_spec(spec, log_capacity=0, horizon_ns=None, flags=0):
     n = p["n"]
     st = StationArrays(
         n=n,
-        src_kind=np.array([N.SRC_POISSON if a == O.ARR_POISSON else N.SRC_CONSTANT for a in p["arr"]], np.uint8),
-        src_rate=np.array(p["rate"], np.float64),
+        src_kind=np.array([N.SRC_NONE if ns else N.SRC_POISSON if a == O.ARR_POISSON else N.SRC_CONSTANT
+                           for a, ns in zip(p["arr"], p["no_source"])], np.uint8),
+        src_rate=np.array([1.0 if ns else r for r, ns in zip(p["rate"], p["no_source"])], np.float64),
         src_stop_after_ns=np.full(n, p["stop_ns"], np.int64),
         concurrency=np.array(p["conc"], np.int32),
         svc_kind=np.array([N.LAT_EXPONENTIAL if s == O.LAT_EXP else N.LAT_CONSTANT for s in p["svc"]], np.uint8),
@@ -208,6 +216,13 @@ def engine_for_spec(spec, log_capacity=0, horizon_ns=None, flags=0):
             if pr is not None:
                 st.probe_metric[i] = PROBE_METRICS[pr[0]][1]
                 st.probe_interval_s[i] = pr[1]
+    if p["schedule"]:              # Simulation.schedule(): per station ascending, ties in call order (stable sort)
+        per = [[] for _ in range(n)]
+        for c, t in p["schedule"]:
+            per[c].append(t)
+        st.sched_off = np.zeros(n + 1, np.int64)
+        st.sched_off[1:] = np.cumsum([len(x) for x in per])
+        st.sched_time_ns = np.array([t for x in per for t in sorted(x)], np.int64)
     if spec["mode"] == "single":
         mode = N.MODE_SINGLE
         seed = spec["seed"]
@@ -232,7 +247,7 @@ def oracle_per_chain(spec, runs):
     for chain_ids, nodes, r in runs:
         for c in chain_ids:
             src, srv, snk = nodes[c]
-            out["generated"][c] = r.generated[src]
+            out["generated"][c] = r.generated[src] if src >= 0 else 0
             out["accepted"][c] = r.accepted[srv]
             out["dropped"][c] = r.dropped[srv]
             out["completed"][c] = r.completed[srv]

@@ -324,3 +324,70 @@ def test_probes_through_the_api_match_reference_golden():
         assert d.times() == (gold.probe_t_ns[a:b].astype(np.float64) / 1e9).tolist()        # Data stores time.to_seconds()
         assert d.count() == b - a and d.max() == max(gold.probe_v[a:b].tolist())
     assert [c[2].events_received for c in chains] == gold.received.tolist()
+
+
+def test_schedule_through_the_api_matches_reference_golden():
+    """Simulation.schedule(Event(...)) before run() (core/simulation.py:195-206): stations fed only by scheduled Requests,
+    and scheduled Requests on top of Sources -- against what the live reference produced for the same calls."""
+    for name in ("schedule_only", "schedule_with_sources"):
+        gold = H.Golden(name)
+        spec = gold.spec
+        p = H.spec_chain_params(spec)
+        n = p["n"]
+        sinks = [hs.Sink(f"sink{i}") for i in range(n)]
+        servers = [hs.Server(f"srv{i}", concurrency=p["conc"][i],
+                             service_time=(hs.ExponentialLatency if H.per_chain(spec["svc"], n)[i] == "exp"
+                                           else hs.ConstantLatency)(p["mean"][i]),
+                             queue_capacity=None if p["qcap"][i] < 0 else p["qcap"][i], downstream=sinks[i])
+                   for i in range(n)]
+        sources = []
+        for i in range(n):
+            if p["no_source"][i]:
+                continue
+            make = hs.Source.poisson if H.per_chain(spec["arr"], n)[i] == "poisson" else hs.Source.constant
+            sources.append(make(rate=p["rate"][i], target=servers[i], name=f"src{i}"))
+        # entity order = the golden's construction order: server, sink per chain (stream base i <-> chain i)
+        sim = hs.Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=sources,
+                            entities=[e for pair in zip(servers, sinks) for e in pair], seed=spec["seed"])
+        events = [hs.Event(time=Instant.from_seconds(t), event_type="Request", target=servers[c])
+                  for c, t in spec["schedule"]]
+        sim.schedule(events[:3])
+        for ev in events[3:]:
+            sim.schedule(ev)
+        summary = sim.run()
+        assert summary.total_events_processed == gold.meta["total_events"][0]
+        assert summary.duration_s == gold.meta["duration_s"][0]
+        assert summary.events_cancelled == 0
+        assert [s.stats_accepted for s in servers] == gold.accepted.tolist()
+        assert [s.stats_dropped for s in servers] == gold.dropped.tolist()
+        assert [s.stats.requests_completed for s in servers] == gold.completed.tolist()
+        assert [s.stats.total_service_time for s in servers] == gold.total_service_s.tolist()
+        assert [k.events_received for k in sinks] == gold.received.tolist()
+        assert [x for k in sinks for x in k.latencies_s] == gold.sink_latency_s.tolist()
+        with pytest.raises(hs.UnsupportedTopology, match="after run"):
+            sim.schedule(events[0])
+
+
+def test_schedule_cancelled_events_and_refusals():
+    """Event.cancel() before run(): the event is skipped when popped and counted (tests/test_event_cancellation.py:86-108
+    pins 3 processed / 2 cancelled for the same pattern on a counting entity)."""
+    sink = hs.Sink("sink")
+    server = hs.Server("srv", service_time=hs.ConstantLatency(0.1), downstream=sink)
+    sim = hs.Simulation(end_time=Instant.from_seconds(10.0), sources=[], entities=[server, sink])
+    evs = [hs.Event(time=Instant.from_seconds(float(t)), event_type="Request", target=server) for t in range(1, 6)]
+    sim.schedule(evs)
+    evs[1].cancel()
+    evs[3].cancel()
+    summary = sim.run()
+    assert summary.events_cancelled == 2
+    assert sink.events_received == 3 and server.stats_accepted == 3
+    assert [t.nanoseconds for t in sink.completion_times] == [1_100_000_000, 3_100_000_000, 5_100_000_000]
+    # each request: Request@Server, Notify, Poll, Deliver, Request@worker, continuation, Request@Sink, completion Poll
+    assert summary.total_events_processed == 3 * 8
+    other = hs.Server("elsewhere", service_time=hs.ConstantLatency(0.1))
+    sim2 = hs.Simulation(end_time=Instant.from_seconds(1.0), sources=[], entities=[server])
+    sim2.schedule(hs.Event(time=Instant.from_seconds(0.5), event_type="Request", target=other))
+    with pytest.raises(hs.UnsupportedTopology, match="only Requests for a Server of this Simulation"):
+        sim2.run()
+    with pytest.raises(ValueError, match="must have a 'target'"):
+        hs.Event(time=Instant.from_seconds(0.5), event_type="Request")

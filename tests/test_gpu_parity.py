@@ -186,6 +186,37 @@ def test_reentrant_windows_match_oracle(mode):
         _compare_engine_to_oracle(spec, eng, p, runs)
 
 
+@pytest.mark.parametrize("mode", ["single", "replicas"])
+def test_scheduled_requests_match_oracle(mode):
+    """Simulation.schedule(): 160 stations (Poisson / constant / no source, c = 1..3, bounded queues), 3 000 Requests
+    injected before run() at random nanoseconds plus bursts at one timestamp and some beyond the horizon; whole run and
+    re-entrant windows against the oracle: every count, statistic and Sink record."""
+    rng = np.random.default_rng(17)
+    n = 160
+    rate = [0.0 if i % 4 == 0 else float(rng.uniform(3, 12)) for i in range(n)]
+    sched = [[int(rng.integers(0, n)), float(rng.integers(1, 14_000_000_000)) / 1e9 + 1e-9] for _ in range(3000)]
+    sched += [[5, 3.000000007]] * 6 + [[8, 2.500000001]] * 9 + [[12, 15.5], [12, 14.25], [16, 15.0]]
+    spec = dict(name="sched", n_chains=n, arr=["poisson", "constant"] * (n // 2), rate=rate, svc="exp", mean=0.07,
+                concurrency=[1, 2, 1, 3] * (n // 4), queue_cap=[None, None, 4, None, 2] * (n // 5), schedule=sched,
+                end_s=13.0, rng="philox", seed=19, mode=mode)
+    runs = H.run_oracle_for_spec(spec)
+    eng, p = H.engine_for_spec(spec)
+    with eng:
+        eng.run_until(p["end_ns"])
+        _compare_engine_to_oracle(spec, eng, p, runs)
+    if mode == "single":
+        windows = [H.ns_from_seconds(x) for x in (0.5, 2.5, 3.0, 3.000000007, 9.0)]
+        g, nodes = H.oracle_graph_for(spec, list(range(n)), list(range(n)))
+        r = O.run(g, p["end_ns"], seed=spec["seed"], windows=windows,
+                  schedule=[(nodes[c][1], t) for c, t in p["schedule"]])
+        eng, p = H.engine_for_spec(spec)
+        with eng:
+            for w in windows:
+                eng.run_until(w)
+            eng.run_until(p["end_ns"])
+            _compare_engine_to_oracle(spec, eng, p, [(list(range(n)), nodes, r)])
+
+
 def test_profile_sweep_matches_oracle():
     """192 chains with random LinearRamp / Spike profiles (Poisson and deterministic arrivals, zero start rates, kinks and
     discontinuities inside the horizon) against the oracle: every count, statistic and Sink record."""

@@ -312,3 +312,43 @@ def test_probes_are_lowered_onto_their_station():
         hs.Simulation(duration=1, sources=[src], entities=[srv, sink], probes=[p4]).lowered()
     probes, data = hs.Probe.on_many(srv, ["depth", "utilization"], interval=1.0)
     assert [p.metric for p in probes] == ["depth", "utilization"] and set(data) == {"depth", "utilization"}
+
+
+def test_schedule_is_lowered_to_per_station_time_lists():
+    """Simulation.schedule() (core/simulation.py:195-206) -> hs_stations.sched_off / sched_time_ns: per station, ascending,
+    ties in call order; cancelled events are kept out and counted; events before start_time are dropped with the
+    reference's "time travel" warning."""
+    import warnings
+
+    k0, k1 = hs.Sink("k0"), hs.Sink("k1")
+    s0 = hs.Server("s0", service_time=hs.ConstantLatency(0.1), downstream=k0)
+    s1 = hs.Server("s1", service_time=hs.ExponentialLatency(0.1), downstream=k1)
+    src = hs.Source.poisson(rate=5, target=s1, name="src")
+    sim = hs.Simulation(start_time=hs.Instant.from_seconds(1.0), end_time=hs.Instant.from_seconds(9.0), sources=[src],
+                        entities=[s0, k0, s1, k1])
+
+    def ev(t, target):
+        return hs.Event(time=hs.Instant.from_seconds(t), event_type="Request", target=target)
+
+    evs = [ev(3.0, s0), ev(2.0, s1), ev(2.5, s0), ev(2.5, s0), ev(0.5, s0), ev(8.0, s1), ev(4.0, s0)]
+    sim.schedule(evs[:4])
+    sim.schedule(evs[4])
+    sim.schedule(evs[5:])
+    evs[6].cancel()
+    assert evs[6].cancelled and not evs[0].cancelled and evs[0].context["created_at"] == evs[0].time
+    g = sim.lowered()
+    a = g.arrays()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        cancelled = sim._schedule_arrays(g, a)
+    assert any("Time travel" in str(x.message) for x in w)
+    assert cancelled == [4_000_000_000]
+    assert a.sched_off.tolist() == [0, 3, 5]
+    assert a.sched_time_ns.tolist() == [2_500_000_000, 2_500_000_000, 3_000_000_000, 2_000_000_000, 8_000_000_000]
+    with pytest.raises(TypeError, match="Event objects"):
+        sim.schedule("Request")
+    hooked = hs.Event(time=hs.Instant.from_seconds(2.0), event_type="Request", target=s0, on_complete=[lambda t: None])
+    sim2 = hs.Simulation(duration=5, sources=[], entities=[s0, k0])
+    sim2.schedule(hooked)
+    with pytest.raises(hs.UnsupportedTopology, match="completion hooks"):
+        sim2._schedule_arrays(sim2.lowered(), sim2.lowered().arrays())

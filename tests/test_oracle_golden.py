@@ -26,7 +26,7 @@ def test_oracle_matches_reference_golden(name):
         assert float(r.final_time_ns) / 1e9 == dur
         for c in chain_ids:
             src, srv, snk = nodes[c]
-            assert r.generated[src] == gold.generated[c]
+            assert (r.generated[src] if src >= 0 else 0) == gold.generated[c]
             assert r.accepted[srv] == gold.accepted[c]
             assert r.dropped[srv] == gold.dropped[c]
             assert r.completed[srv] == gold.completed[c]
