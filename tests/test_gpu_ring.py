@@ -128,3 +128,57 @@ def test_ring_rejects_zero_lookahead_and_second_run():
         eng.reset()
         eng.run_until(p["end_ns"])
         assert eng.summary().events_processed == a
+
+
+def test_ring_full_size_properties_and_engine_agreement():
+    """BASELINE configs[2] at full size: one 65 536-station ring for 60 s (external Poisson 4/s per station, Exp 0.1 s
+    service, RandomRouter([Sink, NetworkLink(1 ms + Exp 10 ms) -> next Server])) = 2.7e8 reference events.  The oracle
+    needs minutes for this, so the checks are the size-independent ones: per-station conservation through routers and
+    links, the event-accounting identities, ordering / causality of every Sink record -- and bit-for-bit agreement of the
+    two network engines, whose synchronisation algorithms share nothing (asynchronous per-link lower bounds in one
+    cooperative launch vs 60 002 conservative windows)."""
+    spec = dict(name="ring_full", topology="ring", n=65536, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.01,
+                end_s=60.0, seed=42)
+    n = spec["n"]
+    res = {}
+    for flags in (0, 16):
+        eng, p = H.ring_engine_for_spec(spec, flags=flags)
+        with eng:
+            eng.run_until(p["end_ns"])
+            s = eng.summary()
+            res[flags] = (s.events_processed, s.events_by_kind.copy(), s.final_time_ns, eng.lp_stats(), eng.net_stats(),
+                          eng.read_sinks(), s.launches)
+    ev, kinds, final, st, ns, (counts, t, cr), launches = res[0]
+    assert launches < 10 and res[16][6] > 60000             # one cooperative launch (+ the election) vs one per window
+    # the two engines agree on everything
+    assert ev == res[16][0] and final == res[16][2]
+    np.testing.assert_array_equal(kinds, res[16][1])
+    for k in st:
+        np.testing.assert_array_equal(st[k], res[16][3][k], err_msg=k)
+    for k in ns:
+        np.testing.assert_array_equal(ns[k], res[16][4][k], err_msg=k)
+    for a, b in zip((counts, t, cr), res[16][5]):
+        np.testing.assert_array_equal(a, b)
+    # conservation.  Every event with time <= end is processed plus exactly ONE beyond it, and that one is the first of
+    # its timestamp group: a SourceEvent, a worker continuation or a link continuation -- whose zero-delay child is then
+    # the only created-but-unprocessed event of the run.
+    prev = np.roll(np.arange(n), 1)                          # link i ends at station i + 1
+    s1 = st["generated"] + ns["link_packets_sent"][prev] - (st["accepted"] + st["dropped"])   # Request@Server pending
+    s2 = st["completed"] - ns["routed"]                                                      # Request@Router pending
+    s3 = ns["routed"] - st["sink_received"] - ns["link_entered"]                             # never the overshoot
+    assert s1.min() >= 0 and s2.min() >= 0 and not s3.any() and s1.sum() + s2.sum() <= 1
+    assert st["dropped"].sum() == 0 and ns["link_packets_dropped"].sum() == 0                # unbounded queues, no loss
+    in_flight = ns["link_entered"] - ns["link_packets_sent"]
+    assert in_flight.min() >= 0 and in_flight.max() <= 8     # a handful of 1-11 ms transits are open at t = 60 s
+    # the reference's event kinds line up with the per-entity counters (SURVEY appendix A2)
+    assert kinds[0] == st["generated"].sum() and kinds[10] == ns["routed"].sum() and kinds[8] == ns["link_entered"].sum()
+    assert kinds[1] == (st["accepted"] + st["dropped"]).sum() and kinds[9] == ns["link_packets_sent"].sum()
+    assert kinds[7] == st["sink_received"].sum() == counts.sum() and kinds[6] == st["completed"].sum()
+    assert ev == kinds.sum() and 2.5e8 < ev < 2.9e8
+    # Sink records: per station in processing order, completion after creation, nothing beyond the last event
+    off = np.concatenate([[0], np.cumsum(counts)])
+    d = np.diff(t)
+    d[off[1:-1] - 1] = 0                                     # station boundaries
+    assert d.min() >= 0 and (t - cr).min() >= 0 and t.max() <= final
+    load = st["completed"] / 60.0
+    assert 7.6 < load.mean() < 8.1                           # 4/s external + 4/s forwarded per station, rho = 0.8

@@ -110,3 +110,28 @@ def test_exchange_row_overflow_is_reported():
                 end_s=2.0, seed=5)
     with pytest.raises(N.EngineError, match="overflow"):
         _sharded(spec, 2, msg_capacity=2)
+
+
+def test_full_station_count_sharded_equals_single_engine():
+    """BASELINE configs[3] at full size: the 65 536-station ring cut into 4 contiguous segments (virtual shards, the same
+    kernels and exchange protocol as one process per GPU over RCCL) for the full 60 simulated seconds = 60 002 GVT-driven
+    windows, 2.7e8 events; every total, statistic, link counter and Sink record equals the single-engine run."""
+    import time
+
+    spec = dict(name="ring_full_sharded", topology="ring", n=65536, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.01,
+                end_s=60.0, seed=42)
+    one = _single(spec)
+    t0 = time.perf_counter()
+    summ, stats, netst, sinks = _sharded(spec, 4, sync_every=64)
+    wall = time.perf_counter() - t0
+    assert summ.events_processed == one["events"] and summ.final_time_ns == one["final"]
+    np.testing.assert_array_equal(summ.events_by_kind, one["by_kind"])
+    for k in ("generated", "accepted", "completed", "total_service_s", "sink_received", "queue_depth", "active", "events"):
+        np.testing.assert_array_equal(stats[k], one["stats"][k], err_msg=k)
+    for k in ("routed", "link_entered", "link_packets_sent"):
+        np.testing.assert_array_equal(netst[k], one["net"][k], err_msg=k)
+    for a, b in zip(sinks, one["sinks"]):
+        np.testing.assert_array_equal(a, b)
+    assert summ.world == 4 and 59000 < summ.windows < 60100
+    assert 2.5e8 < summ.events_processed < 2.9e8
+    assert wall < 240.0
