@@ -166,7 +166,7 @@ def lib():
         raise EngineUnavailable(
             f"{LIB_PATH} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(the engine has no CPU fallback)")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(os.environ.get("HS_HIP_LIB") or LIB_PATH)   # HS_HIP_LIB: an instrumented build (tools/cycles.py)
     P = C.POINTER
     L.hs_abi_version.restype = C.c_int
     L.hs_device_count.restype = C.c_int

@@ -312,12 +312,31 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
                         typename Station<C, PF>::ReqCursor rc;
                         rc.bail = false; rc.done = true;
                         if (elig) S.req_begin(rc, end_ns);   // (touches the LP's statistics: eligible lanes only)
+#ifdef HS_CYCLES   // tools/cycles.py: where the request-order loop spends its time (never defined in the shipped library)
+                        unsigned long long cyc_top = 0, cyc_step = 0, n_it = 0;
+#endif
                         for (;;) {
                             const bool act = elig && !rc.bail && !rc.done;
                             if (!__any(act)) break;
+#ifdef HS_CYCLES
+                            const unsigned long long c0 = __builtin_readcyclecounter();
+#endif
                             S.top_up(act);             // wave-level refill of the pre-drawn stream values
+#ifdef HS_CYCLES
+                            const unsigned long long c1 = __builtin_readcyclecounter();
+#endif
                             S.req_step(rc, act);
+#ifdef HS_CYCLES
+                            const unsigned long long c2 = __builtin_readcyclecounter();
+                            cyc_top += c1 - c0; cyc_step += c2 - c1; ++n_it;
+#endif
                         }
+#ifdef HS_CYCLES
+                        if ((tid & 63) == 0) {
+                            atomicAdd(&tot->dbg[0], cyc_top); atomicAdd(&tot->dbg[1], cyc_step);
+                            atomicAdd(&tot->dbg[2], n_it); atomicAdd(&tot->dbg[3], 1ull);
+                        }
+#endif
                         if (elig && !rc.bail) { S.req_finish(rc); event_order = false; }
                         else if (elig) {               // same-timestamp hazard: start over in event order
                             load_station<C, PF>(S, P, X, L, lp, n, qmem, ring_a, ring_s, tid);
