@@ -1583,4 +1583,27 @@ int hs_debug_radix_sort(int32_t device, int64_t n, int32_t key_bits, const uint6
     return rc;
 }
 
+// One Sink fed by several stations (the canonical `servers = [Server(..., downstream=sink) ...]` wiring): each station
+// logs its own completions in processing order; the shared Sink's lists are their merge by completion time.  Stable, so
+// records of one station keep their order and equal timestamps of different stations come in station order (the
+// reference orders those by event creation: DESIGN.md "known deviations" (i)).  In place.
+int hs_merge_sink_records(int32_t device, int64_t n, int64_t *t_ns, int64_t *created_ns) {
+    if (n < 0 || (n > 0 && (!t_ns || !created_ns))) return lfail(nullptr, HS_E_INVALID, "hs_merge_sink_records: bad argument");
+    if (n < 2) return HS_OK;
+    int64_t tmax = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (t_ns[i] < 0) return lfail(nullptr, HS_E_INVALID, "hs_merge_sink_records: negative timestamp");
+        if (t_ns[i] > tmax) tmax = t_ns[i];
+    }
+    int bits = 1;
+    while (bits < 63 && (tmax >> bits) != 0) ++bits;
+    std::vector<uint64_t> ko((size_t)n), vo((size_t)n);
+    const int rc = hs_debug_radix_sort(device, n, bits, (const uint64_t *)t_ns, (const uint64_t *)created_ns, ko.data(),
+                                       vo.data(), nullptr);
+    if (rc != HS_OK) return rc;
+    memcpy(t_ns, ko.data(), (size_t)n * 8);
+    memcpy(created_ns, vo.data(), (size_t)n * 8);
+    return HS_OK;
+}
+
 }  // extern "C"

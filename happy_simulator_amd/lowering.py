@@ -150,9 +150,12 @@ def attach_probes(g: LoweredGraph, probes: list) -> None:
     from .entities import Probe
 
     owner = {}
+    shared = set()
     for i, st in enumerate(g.stations):
         for obj in (st.source, st.server, st.sink):
             if obj is not None:
+                if id(obj) in owner:
+                    shared.add(id(obj))
                 owner[id(obj)] = i
     for pr in probes or []:
         if not isinstance(pr, Probe):
@@ -160,6 +163,8 @@ def attach_probes(g: LoweredGraph, probes: list) -> None:
         i = owner.get(id(pr.target))
         if i is None:
             raise UnsupportedTopology(f"probe '{pr.name}': its target is not an entity of this Simulation")
+        if id(pr.target) in shared:
+            raise UnsupportedTopology(f"probe '{pr.name}': a Sink shared by several stations is not sampled on the engine yet")
         st = g.stations[i]
         if st.probe is not None:
             raise UnsupportedTopology(f"station of '{pr.target.name}' already has a probe; one Probe per station is lowered")
@@ -189,10 +194,9 @@ def lower(sources: list, entities: list) -> LoweredGraph:
     used_routers: dict[int, int] = {}
 
     def check_sink(obj, owner):
-        if id(obj) in used_sinks:
-            raise UnsupportedTopology(
-                f"sink '{obj.name}' has several upstreams; merged sinks need cross-LP ordering (not lowered yet)")
-        used_sinks[id(obj)] = len(g.stations)
+        # one collector may hang behind several stations (`[Server(..., downstream=sink) for ...]`): every station logs its
+        # own completions and write_back() merges them by completion time on the device (hs_merge_sink_records)
+        used_sinks.setdefault(id(obj), len(g.stations))
 
     def check_server(sv: Server):
         if not isinstance(sv.service_time, (ExponentialLatency, ConstantLatency)):
@@ -318,12 +322,13 @@ def lower(sources: list, entities: list) -> LoweredGraph:
 
 
 def write_back(g: LoweredGraph, stats: dict, counts: np.ndarray, t_ns: np.ndarray, created_ns: np.ndarray,
-               net_stats: dict | None = None, lo: int = 0, hi: int | None = None) -> None:
+               net_stats: dict | None = None, lo: int = 0, hi: int | None = None, device: int = 0) -> None:
     """Put the engine's per-LP results onto the user's objects, under the attribute names the reference uses.
     `stats` / `counts` are indexed by station; `lo:hi` restricts the write-back to one shard's stations (the sink
     records `t_ns` / `created_ns` are then that shard's records only)."""
     off = 0
     hi = len(g.stations) if hi is None else hi
+    per_sink: dict[int, tuple] = {}
     for i, st in enumerate(g.stations):
         if not (lo <= i < hi):
             continue
@@ -343,7 +348,7 @@ def write_back(g: LoweredGraph, stats: dict, counts: np.ndarray, t_ns: np.ndarra
             sv._active = int(stats["active"][i])
         c = int(counts[i])
         if st.sink is not None:
-            st.sink._set_records(t_ns[off:off + c].copy(), created_ns[off:off + c].copy())
+            per_sink.setdefault(id(st.sink), (st.sink, []))[1].append((t_ns[off:off + c], created_ns[off:off + c]))
         off += c
         if net_stats is not None:
             for lk, l in zip(st.links, st.link_ids):
@@ -360,6 +365,15 @@ def write_back(g: LoweredGraph, stats: dict, counts: np.ndarray, t_ns: np.ndarra
                     else:
                         tc[t.name] = tc.get(t.name, 0) + int(net_stats["link_entered"][next(ids)])
                 st.router.target_counts = {k: v for k, v in tc.items() if v}
+    for sink, parts in per_sink.values():
+        t = np.concatenate([p[0] for p in parts]) if len(parts) > 1 else parts[0][0].copy()
+        cr = np.concatenate([p[1] for p in parts]) if len(parts) > 1 else parts[0][1].copy()
+        if len(parts) > 1:          # a Sink shared by several stations: its lists are in global processing order
+            t, cr = np.ascontiguousarray(t, np.int64), np.ascontiguousarray(cr, np.int64)
+            rc = N.lib().hs_merge_sink_records(device, len(t), t.ctypes.data, cr.ctypes.data)
+            if rc != N.HS_OK:
+                raise N.EngineError(rc, (N.lib().hs_lb_last_error(None) or b"").decode())
+        sink._set_records(t, cr)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -157,7 +157,7 @@ class Simulation:
             net_stats = eng.net_stats() if net is not None else None
             if self._probes:
                 write_back_probes(g, eng)
-        write_back(g, stats, counts, t_ns, created_ns, net_stats)
+        write_back(g, stats, counts, t_ns, created_ns, net_stats, device=self._device)
         # a cancelled event is counted when the loop pops it: everything up to the last processed event, or the whole
         # heap when the run ended with nothing left beyond end_time (core/simulation.py:472-477)
         drained = es.final_time_ns <= end_ns

@@ -388,6 +388,10 @@ int hs_debug_lb_flags(hs_lb *h, int flags);
  * the sort the load-balancer engine uses (csrc/hs_radix.hpp).  Host arrays in, host arrays out. */
 int hs_debug_radix_sort(int32_t device, int64_t n, int32_t key_bits, const uint64_t *keys_in, const uint64_t *vals_in,
                         uint64_t *keys_out, uint64_t *vals_out, float *device_ms);
+/* Merge of per-station Sink logs into ONE Sink shared by several stations (components/common.py:36-44 appends in global
+ * processing order): stable device sort of n (completion ns, created_at ns) records by completion time, in place on host
+ * arrays.  Feed it the stations' records concatenated in station order. */
+int hs_merge_sink_records(int32_t device, int64_t n, int64_t *t_ns, int64_t *created_ns);
 
 /* Samples of the LP's Probe in sampling order: (sample time ns, value) -- what the reference appends to the probe's
  * Data container (instrumentation/probe.py:63).  Returns the number copied or a negative hs_status. */

@@ -170,7 +170,13 @@ def build_chains(spec, chain_ids, seed):
     sources, entities, handles = [], [], []
     for local, i in enumerate(chain_ids):
         base = i if spec["mode"] == "single" else 0
-        sink = Sink(f"sink{i}") if spec.get("downstream", True) else None
+        if spec.get("shared_sink"):      # one collector behind every server: its lists are in global processing order
+            shared = getattr(build_chains, "_shared", None)
+            if local == 0 or shared is None:
+                shared = build_chains._shared = Sink("sink")
+            sink = shared
+        else:
+            sink = Sink(f"sink{i}") if spec.get("downstream", True) else None
         if svc[i] == "exp":
             if spec["rng"] == "philox":
                 st = PhiloxExponentialLatency(mean[i], hs.Stream(seed, base, hs.STREAM_SERVICE))
@@ -194,7 +200,7 @@ def build_chains(spec, chain_ids, seed):
         if source is not None:
             sources.append(source)
         entities.append(server)
-        if sink is not None:
+        if sink is not None and not any(e is sink for e in entities):
             entities.append(sink)
         handles.append((source, server, sink))
     return sources, entities, handles
@@ -329,11 +335,11 @@ def run_case(spec):
             stats["depth"][i] = srv.depth
             stats["active"][i] = srv.active_requests
             total_service[i] = srv._total_service_time
-            if snk is not None:
+            if snk is not None and not (spec.get("shared_sink") and local > 0):
                 stats["received"][i] = snk.events_received
     # sink records in chain order (groups are in chain order too)
         for local, (src, srv, snk) in enumerate(handles):
-            if snk is not None:
+            if snk is not None and not (spec.get("shared_sink") and local > 0):   # a shared Sink: all records under chain 0
                 sink_t.extend(t.nanoseconds for t in snk.completion_times)
                 sink_lat.extend(snk.latencies_s)
             sink_off.append(len(sink_t))
@@ -618,6 +624,10 @@ CASES = [
          svc=["exp", "const", "exp", "exp"], mean=[0.1, 0.04, 0.03, 0.06],
          profile=[None, ["ramp", 12.0, 20.0, 2.0], ["spike", 6.0, 90.0, 4.0, 3.0], ["ramp", 20.0, 2.0, 25.0]],
          end_s=16.0, rng="philox", seed=23, mode="single", trace=True),
+    # --- one Sink behind several servers: completion_times / latencies_s in global processing order -------------
+    dict(name="philox_shared_sink_6", n_chains=6, arr="poisson", rate=[8.0, 5.0, 12.0, 3.0, 9.0, 20.0], svc="exp",
+         mean=[0.1, 0.15, 0.05, 0.2, 0.08, 0.04], concurrency=[1, 1, 2, 1, 1, 3], shared_sink=True,
+         end_s=20.0, rng="philox", seed=51, mode="single", trace=True),
     # --- Simulation.schedule(): one-off Requests injected before run() --------------------------
     dict(name="schedule_only", n_chains=3, arr="poisson", rate=0.0, svc=["const", "exp", "exp"], mean=[0.5, 0.2, 0.05],
          concurrency=[1, 2, 1], queue_cap=[None, None, 2],

@@ -91,11 +91,16 @@ def oracle_graph_for(spec, chain_ids, stream_bases):
                              profile=p["profile"][c]))
     for k, (c, base) in enumerate(zip(chain_ids, stream_bases)):
         sv = g.server(p["svc"][c], p["mean"][c], concurrency=p["conc"][c], queue_cap=p["qcap"][c], stream_base=base)
-        sk = g.sink() if p["downstream"] else -1
+        if spec.get("shared_sink"):        # one Sink node behind every server; its records are reported under the first chain
+            if k == 0:
+                shared_sk = g.sink()
+            sk = shared_sk
+        else:
+            sk = g.sink() if p["downstream"] else -1
         if srcs[k] >= 0:
             g.target[srcs[k]] = sv
         g.target[sv] = sk
-        nodes[c] = (srcs[k], sv, sk)
+        nodes[c] = (srcs[k], sv, sk if not (spec.get("shared_sink") and k > 0) else -1)
     g.probe_nodes = {}
     for c in chain_ids:                                   # probes start after every source, in list order
         pr = p["probes"][c]

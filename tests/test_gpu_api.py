@@ -391,3 +391,27 @@ def test_schedule_cancelled_events_and_refusals():
         sim2.run()
     with pytest.raises(ValueError, match="must have a 'target'"):
         hs.Event(time=Instant.from_seconds(0.5), event_type="Request")
+
+
+def test_one_sink_behind_several_servers_matches_reference_golden():
+    """`servers = [Server(..., downstream=sink) ...]`: the shared Sink's completion_times / latencies_s are in global
+    processing order (components/common.py:36-44) -- here the device merge of the per-station logs."""
+    gold = H.Golden("philox_shared_sink_6")
+    spec = gold.spec
+    p = H.spec_chain_params(spec)
+    n = p["n"]
+    sink = hs.Sink("sink")
+    servers = [hs.Server(f"srv{i}", concurrency=p["conc"][i], service_time=hs.ExponentialLatency(p["mean"][i]),
+                         downstream=sink) for i in range(n)]
+    sources = [hs.Source.poisson(rate=p["rate"][i], target=servers[i], name=f"src{i}") for i in range(n)]
+    sim = hs.Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=sources, entities=servers + [sink],
+                        seed=spec["seed"])
+    summary = sim.run()
+    assert summary.total_events_processed == gold.meta["total_events"][0]
+    assert sink.events_received == gold.received[0] == len(gold.sink_t_ns)
+    assert [t.nanoseconds for t in sink.completion_times] == gold.sink_t_ns.tolist()
+    assert sink.latencies_s == gold.sink_latency_s.tolist()
+    assert [s.stats.requests_completed for s in servers] == gold.completed.tolist()
+    st = sink.latency_stats()
+    assert st["count"] == len(gold.sink_t_ns) and st["max"] == gold.sink_latency_s.max()
+    assert summary.entities["sink"].events_handled == gold.received[0]

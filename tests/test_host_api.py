@@ -114,9 +114,14 @@ class TestLowering:
         sink = hs.Sink()
         s1 = hs.Server("a", downstream=sink)
         s2 = hs.Server("b", downstream=sink)
-        with pytest.raises(hs.UnsupportedTopology, match="several upstreams"):
-            hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=s1), hs.Source.poisson(1, target=s2)],
+        # one collector behind several servers IS lowered: per-station logs, merged by time on the device at write-back
+        g = hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=s1), hs.Source.poisson(1, target=s2)],
                           entities=[s1, s2, sink]).lowered()
+        assert [st.sink for st in g.stations] == [sink, sink]
+        pr, _ = hs.Probe.on(sink, "events_received")
+        with pytest.raises(hs.UnsupportedTopology, match="shared by several stations"):
+            hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=s1), hs.Source.poisson(1, target=s2)],
+                          entities=[s1, s2, sink], probes=[pr]).lowered()
         with pytest.raises(hs.UnsupportedTopology, match="only Server / Sink"):
             hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=Custom("x"))]).lowered()
         with pytest.raises(hs.UnsupportedTopology, match="not lowered"):
