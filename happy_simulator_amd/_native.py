@@ -160,7 +160,7 @@ def lib():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     stale = (not os.path.exists(LIB_PATH)) or any(
         os.path.getmtime(src) > os.path.getmtime(LIB_PATH) for src in sources() if os.path.exists(src))
-    if stale and os.path.exists(hipcc):
+    if stale and os.path.exists(hipcc) and not os.environ.get("HS_HIP_LIB"):
         build()     # never run a library older than its sources
     if not os.path.exists(LIB_PATH):
         raise EngineUnavailable(

@@ -460,8 +460,8 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
 // ---------------------------------------------------------------------------------------------
 namespace {
 
-template <int C>
-__device__ __forceinline__ void load_net(NetStation<C> &S, const StationParams &P, const NetParams &NP,
+template <int C, bool FAST = false>
+__device__ __forceinline__ void load_net(NetStation<C, FAST> &S, const StationParams &P, const NetParams &NP,
                                          const StationState &X, const NetState &NX, const RecordLogs &L, int lp, int n,
                                          uint8_t (*qmem)[kBlock], int64_t (*enqpay)[kBlock], int tid, int send_idx,
                                          const ShardCtl &SC) {
@@ -501,13 +501,44 @@ __device__ __forceinline__ void load_net(NetStation<C> &S, const StationParams &
     S.cap = L.cap; S.ls = n;
     S.overflow = 0; S.qoverflow = 0; S.bagoverflow = 0;
     S.np = &NP; S.ns = &NX; S.send_idx = send_idx;
+    S.tid = tid;
+    S.ha = S.na = S.hs_ = S.nsv = S.hj = S.nj = S.rn = 0; S.rbits = 0; S.fl_link = -1; S.fi_link = -1; S.fi_packets = 0;
     S.bag_n = NX.bag_cnt[lp];
+    if constexpr (FAST) {
+        // (S.fl was set by the caller.)  The bag moves into LDS for the lifetime of the kernel ...
+        if (S.bag_n > kLBag) { S.bagoverflow = 1; S.bag_n = kLBag; }
+        for (int i = 0; i < S.bag_n; ++i) {
+            const size_t b = (size_t)lp * NX.bag_cap + i;
+            S.bg_set(i, NX.bag_t[b], NX.bag_ts[b], NX.bag_cr[b], NX.bag_link[b]);
+        }
+        // ... and the LP's outgoing link into registers when there is exactly one
+        int32_t l = -1;
+        if (S.egress == EG_LINK) l = S.link_of;
+        else if (S.egress == EG_ROUTER) l = (S.rt0 >= 0 && S.rt1 < 0) ? S.rt0 : (S.rt1 >= 0 && S.rt0 < 0) ? S.rt1 : -1;
+        if (l >= 0) {
+            S.fl_link = l; S.fl_dst = NP.link_dst[l]; S.fl_jit = NP.link_jit_kind[l];
+            S.fl_delay0 = seconds_from_ns(ns_from_seconds(NP.link_lat_min[l]));
+            S.fl_lam = __ddiv_rn(1.0, NP.link_jit_mean[l]);
+            S.fl_loss = NP.link_loss[l];
+            S.fl_in = NX.link_in[l]; S.fl_sent = NX.link_sent[l];
+            S.jit.init(S.seed, stream_id(NP.link_base[l], kStreamLink), NX.link_k[l]);
+        }
+        if (NP.in_off[lp + 1] - NP.in_off[lp] == 1) {          // ... and the counter of its only incoming link
+            S.fi_link = NP.in_links[NP.in_off[lp]];
+            S.fi_packets = NX.link_packets[S.fi_link];
+        }
+        // the created_at cache starts cold: requests admitted before this launch are read from the log
+        for (int i = 0; i < kNRing; ++i) {
+            const int64_t k = S.accepted - 1 - i;
+            if (k >= 0 && k < S.cap) S.fl.crc[k & (kNRing - 1)][tid] = S.adm[k * S.ls];
+        }
+    }
     S.bmin = S.bag_scan_min();
-    S.qmem = qmem; S.enqpay = enqpay; S.tid = tid; S.qh = 0; S.qn = 0; S.ph = 0; S.pn = 0;
+    S.qmem = qmem; S.enqpay = enqpay; S.qh = 0; S.qn = 0; S.ph = 0; S.pn = 0;
 }
 
-template <int C>
-__device__ __forceinline__ void store_net(NetStation<C> &S, const StationState &X, const NetState &NX, int lp, int n) {
+template <int C, bool FAST = false>
+__device__ __forceinline__ void store_net(NetStation<C, FAST> &S, const StationState &X, const NetState &NX, int lp, int n) {
     X.A[lp] = S.A; X.seqA[lp] = S.seqA; X.crtA[lp] = S.crtA; X.arr_time[lp] = S.arr_time;
     X.buf[lp] = S.buf; X.active[lp] = S.active; X.seq[lp] = S.seq;
     X.generated[lp] = S.generated; X.accepted[lp] = S.accepted; X.dropped[lp] = S.dropped;
@@ -521,7 +552,19 @@ __device__ __forceinline__ void store_net(NetStation<C> &S, const StationState &
         X.crtD[(size_t)i * n + lp] = S.crtD[i]; X.svc_s[(size_t)i * n + lp] = S.svc_s[i];
         X.crt[(size_t)i * n + lp] = S.crt[i];
     }
-    X.arr_k[lp] = S.arr.k; X.svc_k[lp] = S.svc.k; NX.route_k[lp] = S.rte.k;
+    // draws CONSUMED (pre-drawn values still in the FAST rings are dropped: pure functions of the index)
+    X.arr_k[lp] = S.arr_consumed(); X.svc_k[lp] = S.svc_consumed(); NX.route_k[lp] = S.rte_consumed();
+    if constexpr (FAST) {
+        for (int i = 0; i < S.bag_n; ++i) {
+            const size_t b = (size_t)lp * NX.bag_cap + i;
+            NX.bag_t[b] = S.bg_t(i); NX.bag_ts[b] = S.bg_ts(i); NX.bag_cr[b] = S.bg_cr(i); NX.bag_link[b] = S.bg_link(i);
+        }
+        if (S.fl_link >= 0) {
+            NX.link_in[S.fl_link] = S.fl_in; NX.link_sent[S.fl_link] = S.fl_sent;
+            NX.link_k[S.fl_link] = S.jit.k - (uint64_t)S.nj;
+        }
+        if (S.fi_link >= 0) NX.link_packets[S.fi_link] = S.fi_packets;
+    }
     NX.bag_cnt[lp] = S.bag_n;
     NX.next_time[lp] = S.next_time();
     uint32_t tot = 0;
@@ -764,6 +807,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
 // overflow bit 8 and the host reports an error instead of hanging the device.
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned kAsyncMaxIter = 1u << 21;
+constexpr int kAsyncGroupCap = 2;   // event groups per LP per iteration of hs_net_async (debug flags bits 8..15 override)
 
 template <int C>
 __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParams NP, StationState X, NetState NX,
@@ -771,6 +815,10 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                                                        ShardCtl SC, int lanes) {
     __shared__ uint8_t qmem[kQCap][kBlock];
     __shared__ int64_t enqpay[kEnqPay][kBlock];
+    __shared__ double ring_a[kNRing][kBlock], ring_s[kNRing][kBlock], ring_j[kNRing][kBlock];   // pre-drawn E values
+    __shared__ int64_t lbag_t[kLBag][kBlock], lbag_ts[kLBag][kBlock], lbag_cr[kLBag][kBlock];   // the bags, in LDS
+    __shared__ int32_t lbag_link[kLBag][kBlock];
+    __shared__ int64_t crc[kNRing][kBlock];                                                     // created_at of the FIFO's tail
     __shared__ unsigned long long red[14];
     __shared__ long long red_time;
     __shared__ int red_flags[4];
@@ -785,11 +833,12 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
     if (tid == 0) { red_time = INT64_MIN; red_flags[0] = red_flags[1] = red_flags[2] = red_flags[3] = 0; }
     __syncthreads();
 
-    NetStation<C> S;
+    NetStation<C, true> S;
+    S.fl = NetFastLds{ring_a, ring_s, ring_j, lbag_t, lbag_ts, lbag_cr, lbag_link, crc};
     bool done = !live;
     int gave_up = 0;
     if (live) {
-        load_net<C>(S, P, NP, X, NX, L, lp, n, qmem, enqpay, tid, 0, SC);
+        load_net<C, true>(S, P, NP, X, NX, L, lp, n, qmem, enqpay, tid, 0, SC);
         // this LP's outgoing links (router targets in constructor order, or the single link) and what it last published
         int32_t out_l[2] = {-1, -1};
         if (S.egress == EG_LINK) out_l[0] = S.link_of;
@@ -800,6 +849,10 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         int dur_free = -1;
         int64_t dur_next = 0;
         const bool force_general = (flags & 1) != 0;
+        // Groups per LP per iteration.  The loop below is divergent: a lane with a long stretch of ready groups would keep
+        // the other 63 idle, and their bounds only move at iteration boundaries -- so every lane takes a few groups, then
+        // the wavefront exchanges bounds again and (measured) many more lanes are ready in the next trip.
+        const int group_cap = ((flags >> 8) & 0xff) ? ((flags >> 8) & 0xff) : kAsyncGroupCap;
         unsigned n_groups = 0, n_iter = 0, groups_before = 0;
         // In-wavefront chains.  When this LP's only incoming link comes from the LP in the previous lane, its bound need
         // not wait for that neighbour's next publication: a sender's bound is a (min, +) map of its own input bound,
@@ -820,13 +873,27 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         auto sat = [](int64_t a, int64_t b) { return (a == kInfNs || b == kInfNs) ? kInfNs : a + b; };
         auto peek_dur = [&]() {
             const int free = S.conc - S.active;
-            if (S.svc.k != dur_k || free != dur_free) { dur_next = S.peek_service_ns(free); dur_k = S.svc.k; dur_free = free; }
+            const uint64_t sk = S.svc_consumed();
+            if (sk != dur_k || free != dur_free) { dur_next = S.peek_service_ns(free); dur_k = sk; dur_free = free; }
             return dur_next;
         };
+#ifdef HS_CYCLES   // tools/cycles.py --ring: cycles in receive / bound scan / group processing / publication
+        unsigned long long cyc[4] = {0, 0, 0, 0};
+#endif
+#ifdef HS_TRIPS
+        unsigned long long trips = 0;
+#endif
         for (unsigned iter = 0;; ++iter) {
             n_iter = iter + 1;
+            S.top_up(!done);                                          // whole wavefront: refill the pre-drawn values
             int64_t H = kInfNs;
+#ifdef HS_CYCLES
+            const unsigned long long q0 = __builtin_readcyclecounter();
+#endif
             if (!done) H = S.async_receive();                         // messages below H are all in the bag now
+#ifdef HS_CYCLES
+            const unsigned long long q1 = __builtin_readcyclecounter();
+#endif
             // (min, +) map of this LP as the sender on next_l, from its state before this iteration's processing
             int64_t mA = kInfNs, mB = kInfNs;
             if (!done && next_l >= 0) {
@@ -862,15 +929,25 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                 if (chain && hp > H) H = hp;
                 if (!done && S.undrained < H) H = S.undrained;        // ... never beyond what is still sitting in a queue
             }
+#ifdef HS_CYCLES
+            const unsigned long long q2 = __builtin_readcyclecounter();
+            unsigned long long q3 = q2;
+#endif
             if (!done) {
                 const int64_t limit = (H - 1) < end_ns ? (H - 1) : end_ns;
-                for (;;) {
+                for (int g = 0; g < group_cap; ++g) {
                     const int64_t t = S.next_time();
                     if (t > limit) break;
                     if (!(S.async_can_send(out_l[0], head_seen[0]) && S.async_can_send(out_l[1], head_seen[1]))) break;   // a consumer is behind: wait
                     S.run_group(t, force_general);
                     ++n_groups;
+#ifdef HS_TRIPS       // experiment: wave-level trips of this loop (counted by the first active lane) instead of publish cycles
+                    if ((__ffsll((unsigned long long)__ballot(1)) - 1) == lane) ++trips;
+#endif
                 }
+#ifdef HS_CYCLES
+                q3 = __builtin_readcyclecounter();
+#endif
                 const int64_t t2 = S.next_time();
                 const int64_t base = t2 < H ? t2 : H;                 // nothing happens here before `base`
                 // lower bound of this LP's next completion (= its next chance to send)
@@ -888,7 +965,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                     drain_stores();
 #pragma unroll
                     for (int o = 0; o < 2; ++o)
-                        if (out_l[o] >= 0) ag_store(&NX.aq_tail[out_l[o]], (unsigned long long)NX.link_sent[out_l[o]]);
+                        if (out_l[o] >= 0) ag_store(&NX.aq_tail[out_l[o]], (unsigned long long)S.link_sent_of(out_l[o]));
                     drain_stores();
                     S.sent_async = false;
                 }
@@ -901,17 +978,35 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                 }
                 done = base > end_ns;                                 // nothing at or before end_ns can happen any more
             }
+#ifdef HS_CYCLES
+            {
+                const unsigned long long q4 = __builtin_readcyclecounter();
+                cyc[0] += q1 - q0; cyc[1] += q2 - q1; cyc[2] += q3 - q2;
+#ifndef HS_TRIPS
+                cyc[3] += q4 - q3;
+#else
+                (void)q4;
+#endif
+            }
+#endif
             if (__all(done)) break;
             if (iter >= kAsyncMaxIter) { gave_up = 1; break; }
             if ((flags & 128) && !__any(n_groups != groups_before)) __builtin_amdgcn_s_sleep(64);   // experiment: back off when idle
             groups_before = n_groups;
         }
-        store_net<C>(S, X, NX, lp, n);
+        store_net<C, true>(S, X, NX, lp, n);
+#ifdef HS_CYCLES
+        if ((tid & 63) == 0) for (int k = 0; k < 4; ++k) atomicAdd(&tot->dbg[k], cyc[k]);
+#ifdef HS_TRIPS
+        atomicAdd(&tot->dbg[3], trips);      // (on top of lane 0's publish cycles: read it as trips when HS_TRIPS is on)
+#endif
+#else
         atomicAdd(&tot->dbg[2], (unsigned long long)n_groups);
         if ((tid & 63) == 0) {
             atomicAdd(&tot->dbg[0], (unsigned long long)n_iter); atomicMax(&tot->dbg[1], (unsigned long long)n_iter);
             atomicAdd(&tot->dbg[3], 1ull);
         }
+#endif
     }
 
     // ---- workgroup reduction of the run's deltas -> engine totals (as in hs_net_window)
@@ -1172,7 +1267,7 @@ void launch_net_dispatch(hs_engine *h, int64_t wend, int win, int flags) {
 
 template <int C>
 hipError_t launch_async(hs_engine *h, int64_t end_ns, NetState NX) {
-    int n = h->cfg.n_lp, flags = h->flags & (1 | 64 | 128), lanes = h->async_lanes;
+    int n = h->cfg.n_lp, flags = h->flags & (1 | 64 | 128 | 0xff00), lanes = h->async_lanes;
     const int per_block = (kBlock / 64) * lanes;
     void *args[] = {&h->P, &h->NP, &h->X, &NX, &h->L, &h->tot, &n, &end_ns, &flags, &h->SC, &lanes};
     return hipLaunchCooperativeKernel((const void *)hs_net_async<C>, dim3((unsigned)((n + per_block - 1) / per_block)),

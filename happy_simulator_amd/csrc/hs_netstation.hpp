@@ -111,7 +111,30 @@ __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0
 
 constexpr int kEnqPay = 8;   // ENQ payload FIFO depth (general path only)
 
-template <int C>
+// ---- FAST instantiation (hs_net_async only) ------------------------------------------------------------------------
+// The asynchronous engine runs a wavefront's event groups in a divergent loop with only a few lanes active per trip
+// (measured on the 65 536-station ring: ~3 of 64), so whatever a group costs is paid almost per LANE.  Three things kept
+// that cost high and are removed here without touching the results:
+//   * random draws (Philox + hs_log) ran inline in the divergent branches -> the E = -log(1-u) values of the arrival,
+//     service and link-jitter streams and the router's choices are pre-drawn by the WHOLE wavefront into small per-lane
+//     rings (LDS / a register of bits) at a converged point (top_up), exactly as hs_station.hpp does;
+//   * the bag of pending messages lived in global memory (a chain of ~1 us loads per message) -> LDS columns;
+//   * the state of the LP's outgoing link (counters, parameters) lived in global memory -> registers.
+// Draws are pure functions of (stream, index) and are consumed in the same order, so nothing observable changes.
+constexpr int kLBag = 8;     // LDS bag entries per LP (a full bag leaves messages in their queue: async_receive)
+constexpr int kNRing = 8;    // pre-drawn values per stream per LP
+struct NetFastLds {
+    double (*ring_a)[kBlock];
+    double (*ring_s)[kBlock];
+    double (*ring_j)[kBlock];
+    int64_t (*bag_t)[kBlock];
+    int64_t (*bag_ts)[kBlock];
+    int64_t (*bag_cr)[kBlock];
+    int32_t (*bag_link)[kBlock];
+    int64_t (*crc)[kBlock];       // created_at of the last kNRing admitted requests (slot = admission index mod kNRing)
+};
+
+template <int C, bool FAST = false>
 struct NetStation {
     // parameters
     int lp, n;
@@ -145,6 +168,18 @@ struct NetStation {
     int send_idx;
     int32_t bag_n;
     int64_t bmin;                 // min over the bag's arrival times (kInfNs: empty)
+    // FAST: pre-drawn values (ring head / count per stream), router choices as bits, the one outgoing link in registers
+    NetFastLds fl;
+    int ha, na, hs_, nsv, hj, nj, rn;
+    uint32_t rbits;
+    int32_t fl_link;              // the LP's only outgoing link (-1: none or two -> the global-memory path)
+    int32_t fl_dst;
+    uint32_t fl_jit;              // 0 = exponential jitter
+    double fl_delay0, fl_lam, fl_loss;
+    int64_t fl_in, fl_sent;
+    Stream jit;
+    int32_t fi_link;              // the LP's only incoming link (-1: none or several): its packets_sent counter in a register
+    int64_t fi_packets;
     // in-group FIFO + ENQ payloads (LDS columns)
     uint8_t (*qmem)[kBlock];
     int64_t (*enqpay)[kBlock];
@@ -176,27 +211,89 @@ struct NetStation {
 
     // ---- bag (pending inbound messages of this LP; global memory, owner-only)
     __device__ __forceinline__ size_t bidx(int i) const { return (size_t)lp * ns->bag_cap + i; }
+    __device__ __forceinline__ int bag_capacity() const {
+        if constexpr (FAST) return kLBag < ns->bag_cap ? kLBag : ns->bag_cap;
+        else return ns->bag_cap;
+    }
+    __device__ __forceinline__ int64_t bg_t(int i) const { if constexpr (FAST) return fl.bag_t[i][tid]; else return ns->bag_t[bidx(i)]; }
+    __device__ __forceinline__ int64_t bg_ts(int i) const { if constexpr (FAST) return fl.bag_ts[i][tid]; else return ns->bag_ts[bidx(i)]; }
+    __device__ __forceinline__ int64_t bg_cr(int i) const { if constexpr (FAST) return fl.bag_cr[i][tid]; else return ns->bag_cr[bidx(i)]; }
+    __device__ __forceinline__ int32_t bg_link(int i) const { if constexpr (FAST) return fl.bag_link[i][tid]; else return ns->bag_link[bidx(i)]; }
+    __device__ __forceinline__ void bg_set(int i, int64_t t, int64_t ts, int64_t cr, int32_t l) {
+        if constexpr (FAST) { fl.bag_t[i][tid] = t; fl.bag_ts[i][tid] = ts; fl.bag_cr[i][tid] = cr; fl.bag_link[i][tid] = l; }
+        else { const size_t d = bidx(i); ns->bag_t[d] = t; ns->bag_ts[d] = ts; ns->bag_cr[d] = cr; ns->bag_link[d] = l; }
+    }
     // earliest arrival in the bag, kept in a register (`bmin`): next_time() runs several times per step and a scan of the
     // bag is a chain of global loads; the scan is only redone when a message leaves the bag
     __device__ __forceinline__ int64_t bag_scan_min() const {
         int64_t m = kInfNs;
-        for (int i = 0; i < bag_n; ++i) { const int64_t t = ns->bag_t[bidx(i)]; m = t < m ? t : m; }
+        for (int i = 0; i < bag_n; ++i) { const int64_t t = bg_t(i); m = t < m ? t : m; }
         return m;
     }
     __device__ __forceinline__ int64_t bag_min() const { return bmin; }
     __device__ __forceinline__ void bag_remove(int i) {
         const int last = bag_n - 1;
-        if (i != last) {
-            ns->bag_t[bidx(i)] = ns->bag_t[bidx(last)]; ns->bag_ts[bidx(i)] = ns->bag_ts[bidx(last)];
-            ns->bag_cr[bidx(i)] = ns->bag_cr[bidx(last)]; ns->bag_link[bidx(i)] = ns->bag_link[bidx(last)];
-        }
+        if (i != last) bg_set(i, bg_t(last), bg_ts(last), bg_cr(last), bg_link(last));
         bag_n = last;
         bmin = bag_scan_min();
     }
 
+    // ---- pre-drawn values (FAST).  Stream::k counts GENERATED draws; consumed = k - ring count (store_net)
+    __device__ __forceinline__ void refill_a(int m) {
+        for (int i = 0; i < m; ++i) { fl.ring_a[(ha + na) & (kNRing - 1)][tid] = exp1_from_uniform(arr.next_uniform()); ++na; }
+    }
+    __device__ __forceinline__ void refill_s(int m) {
+        for (int i = 0; i < m; ++i) { fl.ring_s[(hs_ + nsv) & (kNRing - 1)][tid] = exp1_from_uniform(svc.next_uniform()); ++nsv; }
+    }
+    __device__ __forceinline__ void refill_j(int m) {
+        for (int i = 0; i < m; ++i) { fl.ring_j[(hj + nj) & (kNRing - 1)][tid] = exp1_from_uniform(jit.next_uniform()); ++nj; }
+    }
+    __device__ __forceinline__ void refill_r(int m) {
+        for (int i = 0; i < m; ++i) { rbits |= (uint32_t)((int)__dmul_rn(rte.next_uniform(), 2.0) & 1) << rn; ++rn; }
+    }
+    __device__ __forceinline__ double arr_E() {
+        if constexpr (FAST) {
+            if (na == 0) refill_a(2);
+            const double v = fl.ring_a[ha][tid];
+            ha = (ha + 1) & (kNRing - 1); --na;
+            return v;
+        } else return exp1_from_uniform(arr.next_uniform());
+    }
+    __device__ __forceinline__ double svc_E() {
+        if constexpr (FAST) {
+            if (nsv == 0) refill_s(2);
+            const double v = fl.ring_s[hs_][tid];
+            hs_ = (hs_ + 1) & (kNRing - 1); --nsv;
+            return v;
+        } else return exp1_from_uniform(svc.next_uniform());
+    }
+    __device__ __forceinline__ int route_idx() {
+        if constexpr (FAST) {
+            if (rn == 0) refill_r(2);
+            const int idx = (int)(rbits & 1u);
+            rbits >>= 1; --rn;
+            return idx;
+        } else return (int)__dmul_rn(rte.next_uniform(), 2.0);
+    }
+    __device__ __forceinline__ uint64_t arr_consumed() const { return FAST ? arr.k - (uint64_t)na : arr.k; }
+    __device__ __forceinline__ uint64_t svc_consumed() const { return FAST ? svc.k - (uint64_t)nsv : svc.k; }
+    __device__ __forceinline__ uint64_t rte_consumed() const { return FAST ? rte.k - (uint64_t)rn : rte.k; }
+    // Wave-level top-up at a converged point: when some lane has run dry, every lane with room draws 4 more values
+    // (2 Philox blocks) -- 64 lanes at the price the divergent loop would pay for one
+    __device__ __forceinline__ void top_up(bool act) {
+        if constexpr (FAST) {
+            const bool wa = src_kind == 1 && A != kInfNs, ws = svc_kind == 0, wj = fl_link >= 0 && fl_jit == 0;
+            const bool wr = egress == EG_ROUTER;
+            if (__any(act && wa && na == 0)) { if (act && wa && na <= kNRing - 4) refill_a(4); }
+            if (__any(act && ws && nsv == 0)) { if (act && ws && nsv <= kNRing - 4) refill_s(4); }
+            if (__any(act && wj && nj == 0)) { if (act && wj && nj <= kNRing - 4) refill_j(4); }
+            if (__any(act && wr && rn == 0)) { if (act && wr && rn <= 24) refill_r(8); }
+        }
+    }
+
     __device__ __forceinline__ int64_t next_arrival() {
         double area;
-        if (src_kind == 1) area = exp1_from_uniform(arr.next_uniform());
+        if (src_kind == 1) area = arr_E();
         else area = 1.0;
         const double t_next = __dadd_rn(seconds_from_ns(arr_time), __ddiv_rn(area, rate));
         arr_time = ns_from_seconds(t_next);
@@ -204,7 +301,7 @@ struct NetStation {
     }
     __device__ __forceinline__ void sample_service(double &s, int64_t &dur_ns) {
         if (svc_kind == 0) {
-            const double sample = __ddiv_rn(exp1_from_uniform(svc.next_uniform()), svc_lambda);
+            const double sample = __ddiv_rn(svc_E(), svc_lambda);
             s = seconds_from_ns(ns_from_seconds(sample));
             dur_ns = ns_from_seconds(s);
         } else { s = svc_const_s; dur_ns = svc_const_ns; }
@@ -227,6 +324,7 @@ struct NetStation {
         if (qcap >= 0 && buf >= qcap) { dropped++; return false; }
         const bool was_empty = (buf == 0);
         if (accepted < cap) adm[accepted * ls] = created; else overflow = 1;
+        if constexpr (FAST) fl.crc[accepted & (kNRing - 1)][tid] = created;   // the FIFO's head is usually still in here
         accepted++; buf++;
         return was_empty;
     }
@@ -246,7 +344,10 @@ struct NetStation {
         active++;
         double s; int64_t dur;
         sample_service(s, dur);
-        const int64_t created = have_created ? known_created : ((k < cap) ? adm[k * ls] : 0);
+        int64_t created;
+        if (have_created) created = known_created;
+        else if (FAST && accepted - k <= kNRing) created = fl.crc[k & (kNRing - 1)][tid];   // no global round trip
+        else created = (k < cap) ? adm[k * ls] : 0;
         int j = 0;
 #pragma unroll
         for (int i = C - 1; i >= 0; --i) if (D[i] == kInfNs) j = i;
@@ -263,7 +364,38 @@ struct NetStation {
 
     // NetworkLink.handle_event up to its yield (components/network/link.py:114-154, _calculate_delay :190-216)
     // executed for a request that enters link `l` at time t; the continuation becomes a message to the egress LP.
+    __device__ __forceinline__ int64_t link_sent_of(int32_t l) const {
+        if constexpr (FAST) { if (l == fl_link) return fl_sent; }
+        return ns->link_sent[l];
+    }
+    // the LP's only outgoing link with its state in registers and the jitter E pre-drawn (FAST; queue path only)
+    __device__ __forceinline__ void send_link_fast(int64_t t, int64_t created) {
+        ev[8]++;
+        const int64_t entered = fl_in++;
+        if (fl_loss > 0.0) {
+            Stream ls;
+            ls.init(seed, stream_id(np->link_base[fl_link], kStreamLoss), (uint64_t)entered);
+            if (ls.next_uniform() < fl_loss) return;
+        }
+        ++fl_sent;
+        double delay = fl_delay0;
+        if (fl_jit == 0) {
+            if (nj == 0) refill_j(2);
+            const double e = fl.ring_j[hj][tid];
+            hj = (hj + 1) & (kNRing - 1); --nj;
+            const double sample = __ddiv_rn(e, fl_lam);
+            delay = __dadd_rn(delay, seconds_from_ns(ns_from_seconds(sample)));
+        }
+        if (!(delay > 0.0)) delay = 0.0;
+        const int64_t t_arr = t + ns_from_seconds(delay);
+        sent_min = t_arr < sent_min ? t_arr : sent_min;
+        const unsigned long long sq = (unsigned long long)fl_sent;
+        const size_t slot = (size_t)fl_link * ns->aq_cap + (size_t)((sq - 1) % (unsigned long long)ns->aq_cap);
+        ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t); ag_store(&ns->aq_cr[slot], created);
+        sent_async = true;
+    }
     __device__ __forceinline__ void send_link(int32_t l, int64_t t, int64_t created) {
+        if constexpr (FAST) { if (l == fl_link) { send_link_fast(t, created); return; } }
         ev[8]++;
         const int64_t entered = ns->link_in[l]++;
         const double loss = np->link_loss[l];
@@ -338,8 +470,7 @@ struct NetStation {
         else if (egress == EG_LINK) target = link_of;
         else if (egress == EG_ROUTER) {  // RandomRouter.handle_event (components/random_router.py:32-45)
             ev[10]++; routed++;
-            const double u = rte.next_uniform();
-            const int idx = (int)__dmul_rn(u, 2.0);
+            const int idx = route_idx();
             target = idx == 0 ? rt0 : rt1;
         }
         if (target == -1) {              // Sink.handle_event (components/common.py:36-44)
@@ -358,8 +489,9 @@ struct NetStation {
     __device__ __forceinline__ int64_t do_msg(int i, int64_t t) {
         (void)t;
         ev[9]++;
-        const int64_t created = ns->bag_cr[bidx(i)];
-        ns->link_packets[ns->bag_link[bidx(i)]]++;
+        const int64_t created = bg_cr(i);
+        if (FAST && bg_link(i) == fi_link) fi_packets++;
+        else ns->link_packets[bg_link(i)]++;
         bag_remove(i);
         return created;
     }
@@ -384,13 +516,12 @@ struct NetStation {
             const unsigned long long tail = ag_load(&ns->aq_tail[l]);
             unsigned long long head = ns->aq_head[l];                  // ours
             if (head == tail) continue;
-            for (; head < tail && bag_n < ns->bag_cap; ++head) {
+            const int bcap = bag_capacity();
+            for (; head < tail && bag_n < bcap; ++head) {
                 const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head % (unsigned long long)ns->aq_cap);
-                const size_t d = bidx(bag_n);
                 const int64_t ta = ag_load(&ns->aq_t[slot]);
                 bmin = ta < bmin ? ta : bmin;
-                ns->bag_t[d] = ta; ns->bag_ts[d] = ag_load(&ns->aq_ts[slot]);
-                ns->bag_cr[d] = ag_load(&ns->aq_cr[slot]); ns->bag_link[d] = l;
+                bg_set(bag_n, ta, ag_load(&ns->aq_ts[slot]), ag_load(&ns->aq_cr[slot]), l);
                 ++bag_n;
             }
             ag_store(&ns->aq_head[l], head);
@@ -410,7 +541,7 @@ struct NetStation {
     // side and the (cache-bypassing) reload is needed only when the queue looks full
     __device__ __forceinline__ bool async_can_send(int32_t l, unsigned long long &head_seen) const {
         if (l < 0) return true;
-        const unsigned long long sent = (unsigned long long)ns->link_sent[l];
+        const unsigned long long sent = (unsigned long long)link_sent_of(l);
         if (sent - head_seen + (unsigned long long)C <= (unsigned long long)ns->aq_cap) return true;
         head_seen = ag_load(&ns->aq_head[l]);
         return sent - head_seen + (unsigned long long)C <= (unsigned long long)ns->aq_cap;
@@ -420,10 +551,13 @@ struct NetStation {
     // completion, so the first completion of a not-yet-started request is no earlier than its start + this.
     __device__ __forceinline__ int64_t peek_service_ns(int free) const {
         if (svc_kind != 0) return svc_const_ns;
-        Stream c = svc;
+        Stream c = svc;                   // FAST: positioned behind the pre-drawn values, which come first
         int64_t m = kInfNs;
         for (int i = 0; i < free; ++i) {
-            const double sample = __ddiv_rn(exp1_from_uniform(c.next_uniform()), svc_lambda);
+            double e;
+            if (FAST && i < nsv) e = fl.ring_s[(hs_ + i) & (kNRing - 1)][tid];
+            else e = exp1_from_uniform(c.next_uniform());
+            const double sample = __ddiv_rn(e, svc_lambda);
             const int64_t d = ns_from_seconds(seconds_from_ns(ns_from_seconds(sample)));
             m = d < m ? d : m;
         }
@@ -447,9 +581,9 @@ struct NetStation {
         for (int i = 0; i < C; ++i)
             if (D[i] == t && (best == 0 || (int32_t)(seqD[i] - bs) < 0)) { best = 2 + i; bc = crtD[i]; bs = seqD[i]; }
         for (int i = 0; bmin == t && i < bag_n; ++i) {
-            if (ns->bag_t[bidx(i)] != t) continue;
-            const int64_t ts = ns->bag_ts[bidx(i)];
-            const int64_t ln = gid_of(ns->bag_link[bidx(i)]);
+            if (bg_t(i) != t) continue;
+            const int64_t ts = bg_ts(i);
+            const int64_t ln = gid_of(bg_link(i));
             bool better;
             if (best == 0) better = true;
             else if (!bmsg) better = ts < bc;                       // local event first on equal creation time
@@ -496,7 +630,7 @@ struct NetStation {
         for (int i = 0; i < C; ++i) n_at += (D[i] == t) ? 1 : 0;
         int mi = -1;
         if (bmin == t)                    // (the bag's earliest arrival is in a register: no scan for local-only groups)
-            for (int i = 0; i < bag_n; ++i) if (ns->bag_t[bidx(i)] == t) { ++n_at; mi = i; }
+            for (int i = 0; i < bag_n; ++i) if (bg_t(i) == t) { ++n_at; mi = i; }
         if (n_at == 1 && !force_general) {
             bool general = false, want_poll = false, have_created = false;
             int64_t created = 0;

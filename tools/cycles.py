@@ -18,6 +18,7 @@ ap.add_argument("--build", action="store_true")
 ap.add_argument("--n-lp", type=int, default=65536)
 ap.add_argument("--end-s", type=float, default=60.0)
 ap.add_argument("--define", action="append", default=[])
+ap.add_argument("--ring", action="store_true", help="the asynchronous network engine on the 65 536-station ring")
 a = ap.parse_args()
 from happy_simulator_amd import _native as N
 if a.build:
@@ -26,6 +27,22 @@ if a.build:
            os.path.join(N.CSRC, "hs_engine.hip"), os.path.join(N.CSRC, "hs_lb.hip"), "-o", OUT]
     subprocess.check_call(cmd)
     print("built", OUT)
+    sys.exit(0)
+if a.ring:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    spec = dict(name="ring_full", topology="ring", n=a.n_lp, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.01,
+                end_s=a.end_s, seed=42)
+    eng, p = H.ring_engine_for_spec(spec)
+    with eng:
+        eng.run_until(p["end_ns"])
+        s = eng.summary()
+        out = (C.c_ulonglong * 4)()
+        N.lib().hs_debug_async_counters(eng._h, out)
+        waves = (a.n_lp + 63) // 64
+        print(json.dumps(dict(events=s.events_processed, kernel_ms=float(s.kernel_ms), waves=waves,
+                              cycles_per_wave=dict(receive=out[0] / waves, bound_scan=out[1] / waves,
+                                                   groups=out[2] / waves, publish=out[3] / waves))))
     sys.exit(0)
 from happy_simulator_amd.engine import StationArrays, StationEngine
 end_ns = int(a.end_s * 1e9)
