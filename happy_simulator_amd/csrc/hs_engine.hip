@@ -885,7 +885,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
 #endif
         for (unsigned iter = 0;; ++iter) {
             n_iter = iter + 1;
-            S.top_up(!done);                                          // whole wavefront: refill the pre-drawn values
+            S.top_up(!done, group_cap < 4 ? group_cap : 4);           // whole wavefront: refill the pre-drawn values
             int64_t H = kInfNs;
 #ifdef HS_CYCLES
             const unsigned long long q0 = __builtin_readcyclecounter();
@@ -939,7 +939,8 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                     const int64_t t = S.next_time();
                     if (t > limit) break;
                     if (!(S.async_can_send(out_l[0], head_seen[0]) && S.async_can_send(out_l[1], head_seen[1]))) break;   // a consumer is behind: wait
-                    S.run_group(t, force_general);
+                    if constexpr (C == 1) S.step1(t, force_general);
+                    else S.run_group(t, force_general);
                     ++n_groups;
 #ifdef HS_TRIPS       // experiment: wave-level trips of this loop (counted by the first active lane) instead of publish cycles
                     if ((__ffsll((unsigned long long)__ballot(1)) - 1) == lane) ++trips;

@@ -280,14 +280,15 @@ struct NetStation {
     __device__ __forceinline__ uint64_t rte_consumed() const { return FAST ? rte.k - (uint64_t)rn : rte.k; }
     // Wave-level top-up at a converged point: when some lane has run dry, every lane with room draws 4 more values
     // (2 Philox blocks) -- 64 lanes at the price the divergent loop would pay for one
-    __device__ __forceinline__ void top_up(bool act) {
+    // (`need` = what one iteration may consume per stream: the groups-per-iteration cap)
+    __device__ __forceinline__ void top_up(bool act, int need) {
         if constexpr (FAST) {
             const bool wa = src_kind == 1 && A != kInfNs, ws = svc_kind == 0, wj = fl_link >= 0 && fl_jit == 0;
             const bool wr = egress == EG_ROUTER;
-            if (__any(act && wa && na == 0)) { if (act && wa && na <= kNRing - 4) refill_a(4); }
-            if (__any(act && ws && nsv == 0)) { if (act && ws && nsv <= kNRing - 4) refill_s(4); }
-            if (__any(act && wj && nj == 0)) { if (act && wj && nj <= kNRing - 4) refill_j(4); }
-            if (__any(act && wr && rn == 0)) { if (act && wr && rn <= 24) refill_r(8); }
+            if (__any(act && wa && na < need)) { if (act && wa && na <= kNRing - 4) refill_a(4); }
+            if (__any(act && ws && nsv < need)) { if (act && ws && nsv <= kNRing - 4) refill_s(4); }
+            if (__any(act && wj && nj < need)) { if (act && wj && nj <= kNRing - 4) refill_j(4); }
+            if (__any(act && wr && rn < need)) { if (act && wr && rn <= 24) refill_r(8); }
         }
     }
 
@@ -623,6 +624,115 @@ struct NetStation {
         return t;
     }
     __device__ __forceinline__ int64_t next_time() const { const int64_t a = next_local(), b = bag_min(); return a < b ? a : b; }
+
+    // ---- C == 1, FAST: one timestamp group as straight-line predicated code ----------------------------------------
+    // The asynchronous engine's group loop is divergent by nature (every lane is at a different event); run_group()'s three
+    // root kinds (tick / message / departure) then execute one after the other, each for a handful of lanes.  Here the
+    // common case -- exactly one pending root at `t`, nothing that creates a same-timestamp successor -- is ONE instruction
+    // stream with selects, the same idea as Station::step_c1: the reference events of the group are decided first from
+    // speculative peeks at the pre-drawn values, anything unusual is detected before a single word of state changes and is
+    // handed to run_group() (ties, a next tick on / before `t`, a zero-length service, an empty ring, a lossy or second
+    // link).  Event counts, statistics, creation stamps and draw consumption are exactly run_group()'s.
+    __device__ __forceinline__ void step1(int64_t t, bool force_general) {
+        static_assert(C == 1, "step1 is the single-worker specialisation");
+        const bool tick = (A == t), dep = (D[0] == t);
+        int cnt = (tick ? 1 : 0) + (dep ? 1 : 0), mi = 0;
+        if (bmin == t)
+            for (int i = 0; i < bag_n; ++i) if (bg_t(i) == t) { ++cnt; mi = i; }
+        const bool msg = !tick && !dep;                               // (cnt == 1 is checked below)
+        // speculative draws: peeks, nothing consumed yet
+        const bool poisson = src_kind == 1, svc_exp = svc_kind == 0;
+        const double area = poisson ? fl.ring_a[ha][tid] : 1.0;
+        const int64_t a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), __ddiv_rn(area, rate)));
+        const double svc_e = fl.ring_s[hs_][tid];
+        const double s_new = svc_exp ? seconds_from_ns(ns_from_seconds(__ddiv_rn(svc_e, svc_lambda))) : svc_const_s;
+        const int64_t dur = svc_exp ? ns_from_seconds(s_new) : svc_const_ns;
+        const bool router = egress == EG_ROUTER;
+        const int ridx = (int)(rbits & 1u);
+        const int32_t target = egress == EG_SINK ? -1 : egress == EG_LINK ? link_of : router ? (ridx == 0 ? rt0 : rt1) : -2;
+        const bool to_sink = dep && target == -1, to_link = dep && target >= 0;
+        // which reference events happen
+        const bool payload = tick && !(stop_ns >= 0 && t > stop_ns);
+        const bool arrv = payload || msg;
+        const bool acc = arrv && !(qcap >= 0 && buf >= qcap);
+        const bool notify = acc && buf == 0;
+        const bool poll = (notify && active < conc) || dep;
+        const int64_t buf1 = buf + (acc ? 1 : 0);
+        const bool deliver = poll && buf1 > 0;
+        const bool slow = force_general || cnt != 1 || (tick && (a2 <= t || (poisson && na == 0))) ||
+                          (deliver && (dur == 0 || (svc_exp && nsv == 0))) || (dep && router && rn == 0) ||
+                          (to_link && (target != fl_link || fl_loss > 0.0 || (fl_jit == 0 && nj == 0)));
+        if (slow) { run_group(t, force_general); return; }
+        // ---- Source.handle_event
+        ev[0] += tick; generated += tick;
+        arr_time = tick ? a2 : arr_time;
+        A = tick ? a2 : A;
+        seqA = tick ? seq : seqA;
+        crtA = tick ? t : crtA;
+        seq += tick ? 1u : 0u;
+        if (tick && poisson) { ha = (ha + 1) & (kNRing - 1); --na; }
+        // ---- NetworkLink continuation at the egress side: the message leaves the bag
+        int64_t created_in = t;
+        if (msg) {
+            ev[9]++;
+            created_in = bg_cr(mi);
+            if (bg_link(mi) == fi_link) fi_packets++; else ns->link_packets[bg_link(mi)]++;
+            bag_remove(mi);
+        }
+        // ---- Queue._handle_enqueue / QueueDriver._handle_notify
+        ev[1] += arrv;
+        dropped += (arrv && !acc) ? 1 : 0;
+        if (acc) {
+            if (accepted < cap) adm[accepted * ls] = created_in; else overflow = 1;
+            fl.crc[accepted & (kNRing - 1)][tid] = created_in;
+        }
+        accepted += acc;
+        ev[2] += notify;
+        // ---- worker continuation: statistics, then the forwarded request's way out
+        int64_t created_out = 0;
+        if (dep) {
+            ev[6]++; completed++;
+            total_service = __dadd_rn(total_service, svc_s[0]);
+            created_out = crt[0];
+            active = active > 0 ? active - 1 : 0;
+            D[0] = kInfNs;
+            if (router) { ev[10]++; routed++; rbits >>= 1; --rn; }
+        }
+        if (to_sink) {
+            ev[7]++;
+            if (received < cap) { sink_t[received * ls] = t; sink_created[received * ls] = created_out; } else overflow = 1;
+            received++;
+        }
+        if (to_link) {                                                // send_link_fast without the loss branch
+            ev[8]++; fl_in++; fl_sent++;
+            double delay = fl_delay0;
+            if (fl_jit == 0) {
+                const double e = fl.ring_j[hj][tid];
+                hj = (hj + 1) & (kNRing - 1); --nj;
+                delay = __dadd_rn(delay, seconds_from_ns(ns_from_seconds(__ddiv_rn(e, fl_lam))));
+            }
+            if (!(delay > 0.0)) delay = 0.0;
+            const int64_t t_arr = t + ns_from_seconds(delay);
+            sent_min = t_arr < sent_min ? t_arr : sent_min;
+            const size_t slot = (size_t)fl_link * ns->aq_cap + (size_t)(((unsigned long long)fl_sent - 1) % (unsigned long long)ns->aq_cap);
+            ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t); ag_store(&ns->aq_cr[slot], created_out);
+            sent_async = true;
+        }
+        // ---- QUEUE_POLL, then QUEUE_DELIVER + the retargeted payload at the worker
+        ev[3] += poll;
+        buf = buf1 - (deliver ? 1 : 0);
+        if (deliver) {
+            ev[4]++; ev[5]++;
+            const int64_t k = started++;
+            active++;
+            int64_t created = created_in;                             // arrival side: the request that found the buffer empty
+            if (dep) created = (accepted - k <= kNRing) ? fl.crc[k & (kNRing - 1)][tid] : ((k < cap) ? adm[k * ls] : 0);
+            svc_s[0] = s_new; crt[0] = created;
+            D[0] = t + dur; seqD[0] = seq++; crtD[0] = t;
+            if (svc_exp) { hs_ = (hs_ + 1) & (kNRing - 1); --nsv; }
+        }
+        last_time = t;
+    }
 
     __device__ __forceinline__ void run_group(int64_t t, bool force_general) {
         int n_at = (A == t) ? 1 : 0;
