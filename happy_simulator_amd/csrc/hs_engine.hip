@@ -502,6 +502,7 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST> &S, const StationPa
     S.overflow = 0; S.qoverflow = 0; S.bagoverflow = 0;
     S.np = &NP; S.ns = &NX; S.send_idx = send_idx;
     S.tid = tid;
+    S.inc_const = __ddiv_rn(1.0, S.rate);
     S.ha = S.na = S.hs_ = S.nsv = S.hj = S.nj = S.rn = 0; S.rbits = 0; S.fl_link = -1; S.fi_link = -1; S.fi_packets = 0;
     S.bag_n = NX.bag_cnt[lp];
     if constexpr (FAST) {
@@ -622,7 +623,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
             unsigned long long head = NX.aq_head[l];
             for (; head < tail; ++head) {
                 if (bn >= NX.bag_cap) { merge_overflow = 1; break; }
-                const size_t slot = (size_t)l * NX.aq_cap + (size_t)(head % (unsigned long long)NX.aq_cap);
+                const size_t slot = (size_t)l * NX.aq_cap + (size_t)(head & (unsigned long long)(NX.aq_cap - 1));
                 const size_t dst = (size_t)lp * NX.bag_cap + bn;
                 const int64_t t = ag_load(&NX.aq_t[slot]);
                 NX.bag_t[dst] = t; NX.bag_ts[dst] = ag_load(&NX.aq_ts[slot]); NX.bag_cr[dst] = ag_load(&NX.aq_cr[slot]);
@@ -997,7 +998,13 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         }
         store_net<C, true>(S, X, NX, lp, n);
 #ifdef HS_CYCLES
+#ifdef HS_STEP
+        // every lane's own view: head / commit cycles summed over lanes (divide by groups), slow groups
+        atomicAdd(&tot->dbg[0], S.cy_head); atomicAdd(&tot->dbg[1], S.cy_commit); atomicAdd(&tot->dbg[3], S.n_slow);
+        if ((tid & 63) == 0) atomicAdd(&tot->dbg[2], cyc[2]);
+#else
         if ((tid & 63) == 0) for (int k = 0; k < 4; ++k) atomicAdd(&tot->dbg[k], cyc[k]);
+#endif
 #ifdef HS_TRIPS
         atomicAdd(&tot->dbg[3], trips);      // (on top of lane 0's publish cycles: read it as trips when HS_TRIPS is on)
 #endif
@@ -1716,10 +1723,12 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     ALN(route_k, N); ALN(routed, N); ALN(link_k, NL); ALN(link_in, NL); ALN(link_sent, NL); ALN(link_packets, NL); ALN(next_time, N);
     ALN(bag_cnt, N); ALN(bag_t, NB); ALN(bag_ts, NB); ALN(bag_cr, NB); ALN(bag_link, NB);
     ALN(in_cnt, 2 * N); ALN(in_t, 2 * NB); ALN(in_ts, 2 * NB); ALN(in_cr, 2 * NB); ALN(in_link, 2 * NB);
-    h->NX.aq_cap = bag;
+    int aqc = 1;
+    while (aqc < bag) aqc <<= 1;      // a power of two: queue slots are addressed with a mask, not a 64-bit modulo
+    h->NX.aq_cap = aqc;
     h->NX.aq_on = 0;
     if (!global && nl > 0) {
-        const size_t NQ = NL * (size_t)bag;
+        const size_t NQ = NL * (size_t)aqc;
         ALN(aq_t, NQ); ALN(aq_ts, NQ); ALN(aq_cr, NQ); ALN(aq_tail, NL); ALN(aq_head, NL); ALN(aq_ea, NL);
         h->async_ok = true;
     }

@@ -90,7 +90,7 @@ struct NetState {
     unsigned long long *aq_tail;     // [n_links] messages appended so far (producer)
     unsigned long long *aq_head;     // [n_links] messages taken so far (consumer; the producer reads it for flow control)
     int64_t *aq_ea;                  // [n_links] every message NOT yet appended arrives at or after this time
-    int32_t aq_cap;
+    int32_t aq_cap;               // entries per link queue, a power of two (slot = sequence number & (aq_cap - 1))
     int32_t aq_on;                   // 1 inside hs_net_async / its final launch: send_link uses the queues
 };
 
@@ -175,11 +175,14 @@ struct NetStation {
     int32_t fl_link;              // the LP's only outgoing link (-1: none or two -> the global-memory path)
     int32_t fl_dst;
     uint32_t fl_jit;              // 0 = exponential jitter
-    double fl_delay0, fl_lam, fl_loss;
+    double fl_delay0, fl_lam, fl_loss, inc_const;
     int64_t fl_in, fl_sent;
     Stream jit;
     int32_t fi_link;              // the LP's only incoming link (-1: none or several): its packets_sent counter in a register
     int64_t fi_packets;
+#ifdef HS_STEP                    // tools/cycles.py: cycles in step1's decision part / commit part, slow-path groups
+    unsigned long long cy_head = 0, cy_commit = 0, n_slow = 0;
+#endif
     // in-group FIFO + ENQ payloads (LDS columns)
     uint8_t (*qmem)[kBlock];
     int64_t (*enqpay)[kBlock];
@@ -238,34 +241,45 @@ struct NetStation {
         bmin = bag_scan_min();
     }
 
-    // ---- pre-drawn values (FAST).  Stream::k counts GENERATED draws; consumed = k - ring count (store_net)
+    // ---- pre-drawn values (FAST).  Stream::k counts GENERATED draws; consumed = k - ring count (store_net).
+    // The rings hold the values as the handlers use them: the arrival increment E / rate, the service time
+    // to_seconds(from_seconds(E / lambda)), the jitter to_seconds(from_seconds(E / lambda_link)) -- the divisions and ns
+    // truncations run here, for 64 lanes at once, not in the divergent group loop.
+    __device__ __forceinline__ double svc_value(double e) const { return seconds_from_ns(ns_from_seconds(__ddiv_rn(e, svc_lambda))); }
     __device__ __forceinline__ void refill_a(int m) {
-        for (int i = 0; i < m; ++i) { fl.ring_a[(ha + na) & (kNRing - 1)][tid] = exp1_from_uniform(arr.next_uniform()); ++na; }
+        for (int i = 0; i < m; ++i) {
+            fl.ring_a[(ha + na) & (kNRing - 1)][tid] = __ddiv_rn(exp1_from_uniform(arr.next_uniform()), rate); ++na;
+        }
     }
     __device__ __forceinline__ void refill_s(int m) {
-        for (int i = 0; i < m; ++i) { fl.ring_s[(hs_ + nsv) & (kNRing - 1)][tid] = exp1_from_uniform(svc.next_uniform()); ++nsv; }
+        for (int i = 0; i < m; ++i) {
+            fl.ring_s[(hs_ + nsv) & (kNRing - 1)][tid] = svc_value(exp1_from_uniform(svc.next_uniform())); ++nsv;
+        }
     }
     __device__ __forceinline__ void refill_j(int m) {
-        for (int i = 0; i < m; ++i) { fl.ring_j[(hj + nj) & (kNRing - 1)][tid] = exp1_from_uniform(jit.next_uniform()); ++nj; }
+        for (int i = 0; i < m; ++i) {
+            const double sample = __ddiv_rn(exp1_from_uniform(jit.next_uniform()), fl_lam);
+            fl.ring_j[(hj + nj) & (kNRing - 1)][tid] = seconds_from_ns(ns_from_seconds(sample)); ++nj;
+        }
     }
     __device__ __forceinline__ void refill_r(int m) {
         for (int i = 0; i < m; ++i) { rbits |= (uint32_t)((int)__dmul_rn(rte.next_uniform(), 2.0) & 1) << rn; ++rn; }
     }
-    __device__ __forceinline__ double arr_E() {
+    __device__ __forceinline__ double arr_inc() {                     // E / rate of the next Poisson arrival
         if constexpr (FAST) {
             if (na == 0) refill_a(2);
             const double v = fl.ring_a[ha][tid];
             ha = (ha + 1) & (kNRing - 1); --na;
             return v;
-        } else return exp1_from_uniform(arr.next_uniform());
+        } else return __ddiv_rn(exp1_from_uniform(arr.next_uniform()), rate);
     }
-    __device__ __forceinline__ double svc_E() {
+    __device__ __forceinline__ double svc_s_next() {                  // service time of the next start, seconds
         if constexpr (FAST) {
             if (nsv == 0) refill_s(2);
             const double v = fl.ring_s[hs_][tid];
             hs_ = (hs_ + 1) & (kNRing - 1); --nsv;
             return v;
-        } else return exp1_from_uniform(svc.next_uniform());
+        } else return svc_value(exp1_from_uniform(svc.next_uniform()));
     }
     __device__ __forceinline__ int route_idx() {
         if constexpr (FAST) {
@@ -293,17 +307,14 @@ struct NetStation {
     }
 
     __device__ __forceinline__ int64_t next_arrival() {
-        double area;
-        if (src_kind == 1) area = arr_E();
-        else area = 1.0;
-        const double t_next = __dadd_rn(seconds_from_ns(arr_time), __ddiv_rn(area, rate));
+        const double inc = src_kind == 1 ? arr_inc() : __ddiv_rn(1.0, rate);
+        const double t_next = __dadd_rn(seconds_from_ns(arr_time), inc);
         arr_time = ns_from_seconds(t_next);
         return arr_time;
     }
     __device__ __forceinline__ void sample_service(double &s, int64_t &dur_ns) {
         if (svc_kind == 0) {
-            const double sample = __ddiv_rn(svc_E(), svc_lambda);
-            s = seconds_from_ns(ns_from_seconds(sample));
+            s = svc_s_next();
             dur_ns = ns_from_seconds(s);
         } else { s = svc_const_s; dur_ns = svc_const_ns; }
     }
@@ -382,16 +393,14 @@ struct NetStation {
         double delay = fl_delay0;
         if (fl_jit == 0) {
             if (nj == 0) refill_j(2);
-            const double e = fl.ring_j[hj][tid];
+            delay = __dadd_rn(delay, fl.ring_j[hj][tid]);
             hj = (hj + 1) & (kNRing - 1); --nj;
-            const double sample = __ddiv_rn(e, fl_lam);
-            delay = __dadd_rn(delay, seconds_from_ns(ns_from_seconds(sample)));
         }
         if (!(delay > 0.0)) delay = 0.0;
         const int64_t t_arr = t + ns_from_seconds(delay);
         sent_min = t_arr < sent_min ? t_arr : sent_min;
         const unsigned long long sq = (unsigned long long)fl_sent;
-        const size_t slot = (size_t)fl_link * ns->aq_cap + (size_t)((sq - 1) % (unsigned long long)ns->aq_cap);
+        const size_t slot = (size_t)fl_link * ns->aq_cap + (size_t)((sq - 1) & (unsigned long long)(ns->aq_cap - 1));
         ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t); ag_store(&ns->aq_cr[slot], created);
         sent_async = true;
     }
@@ -426,7 +435,7 @@ struct NetStation {
             // sequence number of this message
             // (room for this group's messages was checked before the group started: async_can_send)
             const unsigned long long seq = (unsigned long long)ns->link_sent[l];
-            const size_t slot = (size_t)l * ns->aq_cap + (size_t)((seq - 1) % (unsigned long long)ns->aq_cap);
+            const size_t slot = (size_t)l * ns->aq_cap + (size_t)((seq - 1) & (unsigned long long)(ns->aq_cap - 1));
             ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t); ag_store(&ns->aq_cr[slot], created);
             sent_async = true;          // the caller publishes aq_tail (= link_sent) after draining these stores
             return;
@@ -519,7 +528,7 @@ struct NetStation {
             if (head == tail) continue;
             const int bcap = bag_capacity();
             for (; head < tail && bag_n < bcap; ++head) {
-                const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head % (unsigned long long)ns->aq_cap);
+                const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
                 const int64_t ta = ag_load(&ns->aq_t[slot]);
                 bmin = ta < bmin ? ta : bmin;
                 bg_set(bag_n, ta, ag_load(&ns->aq_ts[slot]), ag_load(&ns->aq_cr[slot]), l);
@@ -529,7 +538,7 @@ struct NetStation {
             if (head < tail) {
                 // the bag is full: what stays in the queue was sent no earlier than its first entry (send times do not
                 // decrease along a queue), so it arrives no earlier than that + the link's transit floor
-                const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head % (unsigned long long)ns->aq_cap);
+                const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
                 const int64_t lb = ag_load(&ns->aq_ts[slot]) + np->link_lat_ns[l];
                 undrained = lb < undrained ? lb : undrained;
             }
@@ -555,11 +564,10 @@ struct NetStation {
         Stream c = svc;                   // FAST: positioned behind the pre-drawn values, which come first
         int64_t m = kInfNs;
         for (int i = 0; i < free; ++i) {
-            double e;
-            if (FAST && i < nsv) e = fl.ring_s[(hs_ + i) & (kNRing - 1)][tid];
-            else e = exp1_from_uniform(c.next_uniform());
-            const double sample = __ddiv_rn(e, svc_lambda);
-            const int64_t d = ns_from_seconds(seconds_from_ns(ns_from_seconds(sample)));
+            double sv;
+            if (FAST && i < nsv) sv = fl.ring_s[(hs_ + i) & (kNRing - 1)][tid];
+            else sv = svc_value(exp1_from_uniform(c.next_uniform()));
+            const int64_t d = ns_from_seconds(sv);
             m = d < m ? d : m;
         }
         return m;
@@ -635,6 +643,9 @@ struct NetStation {
     // link).  Event counts, statistics, creation stamps and draw consumption are exactly run_group()'s.
     __device__ __forceinline__ void step1(int64_t t, bool force_general) {
         static_assert(C == 1, "step1 is the single-worker specialisation");
+#ifdef HS_STEP
+        const unsigned long long z0 = __builtin_readcyclecounter();
+#endif
         const bool tick = (A == t), dep = (D[0] == t);
         int cnt = (tick ? 1 : 0) + (dep ? 1 : 0), mi = 0;
         if (bmin == t)
@@ -642,10 +653,9 @@ struct NetStation {
         const bool msg = !tick && !dep;                               // (cnt == 1 is checked below)
         // speculative draws: peeks, nothing consumed yet
         const bool poisson = src_kind == 1, svc_exp = svc_kind == 0;
-        const double area = poisson ? fl.ring_a[ha][tid] : 1.0;
-        const int64_t a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), __ddiv_rn(area, rate)));
-        const double svc_e = fl.ring_s[hs_][tid];
-        const double s_new = svc_exp ? seconds_from_ns(ns_from_seconds(__ddiv_rn(svc_e, svc_lambda))) : svc_const_s;
+        const double inc = poisson ? fl.ring_a[ha][tid] : inc_const;
+        const int64_t a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc));
+        const double s_new = svc_exp ? fl.ring_s[hs_][tid] : svc_const_s;
         const int64_t dur = svc_exp ? ns_from_seconds(s_new) : svc_const_ns;
         const bool router = egress == EG_ROUTER;
         const int ridx = (int)(rbits & 1u);
@@ -662,6 +672,11 @@ struct NetStation {
         const bool slow = force_general || cnt != 1 || (tick && (a2 <= t || (poisson && na == 0))) ||
                           (deliver && (dur == 0 || (svc_exp && nsv == 0))) || (dep && router && rn == 0) ||
                           (to_link && (target != fl_link || fl_loss > 0.0 || (fl_jit == 0 && nj == 0)));
+#ifdef HS_STEP
+        const unsigned long long z1 = __builtin_readcyclecounter();
+        cy_head += z1 - z0;
+        if (slow) ++n_slow;
+#endif
         if (slow) { run_group(t, force_general); return; }
         // ---- Source.handle_event
         ev[0] += tick; generated += tick;
@@ -683,7 +698,9 @@ struct NetStation {
         ev[1] += arrv;
         dropped += (arrv && !acc) ? 1 : 0;
         if (acc) {
+#ifndef HS_EXP_NOLOG
             if (accepted < cap) adm[accepted * ls] = created_in; else overflow = 1;
+#endif
             fl.crc[accepted & (kNRing - 1)][tid] = created_in;
         }
         accepted += acc;
@@ -700,21 +717,22 @@ struct NetStation {
         }
         if (to_sink) {
             ev[7]++;
+#ifndef HS_EXP_NOLOG
             if (received < cap) { sink_t[received * ls] = t; sink_created[received * ls] = created_out; } else overflow = 1;
+#endif
             received++;
         }
         if (to_link) {                                                // send_link_fast without the loss branch
             ev[8]++; fl_in++; fl_sent++;
             double delay = fl_delay0;
             if (fl_jit == 0) {
-                const double e = fl.ring_j[hj][tid];
+                delay = __dadd_rn(delay, fl.ring_j[hj][tid]);
                 hj = (hj + 1) & (kNRing - 1); --nj;
-                delay = __dadd_rn(delay, seconds_from_ns(ns_from_seconds(__ddiv_rn(e, fl_lam))));
             }
             if (!(delay > 0.0)) delay = 0.0;
             const int64_t t_arr = t + ns_from_seconds(delay);
             sent_min = t_arr < sent_min ? t_arr : sent_min;
-            const size_t slot = (size_t)fl_link * ns->aq_cap + (size_t)(((unsigned long long)fl_sent - 1) % (unsigned long long)ns->aq_cap);
+            const size_t slot = (size_t)fl_link * ns->aq_cap + (size_t)(((unsigned long long)fl_sent - 1) & (unsigned long long)(ns->aq_cap - 1));
             ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t); ag_store(&ns->aq_cr[slot], created_out);
             sent_async = true;
         }
@@ -732,6 +750,9 @@ struct NetStation {
             if (svc_exp) { hs_ = (hs_ + 1) & (kNRing - 1); --nsv; }
         }
         last_time = t;
+#ifdef HS_STEP
+        cy_commit += __builtin_readcyclecounter() - z1;
+#endif
     }
 
     __device__ __forceinline__ void run_group(int64_t t, bool force_general) {
