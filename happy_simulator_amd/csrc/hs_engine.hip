@@ -804,10 +804,10 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
 // reference's single heap (same per-LP code, same message order), independent of timing.
 //
 // All LPs must be co-resident (they spin on each other): the host launches this kernel cooperatively and falls back to
-// the windowed engine when the grid does not fit.  Every spin is bounded (kAsyncMaxIter): a wave that gives up raises
+// the windowed engine when the grid does not fit.  Every spin is bounded (kAsyncMaxIter idle iterations): a wave that gives up raises
 // overflow bit 8 and the host reports an error instead of hanging the device.
 // ---------------------------------------------------------------------------------------------
-constexpr unsigned kAsyncMaxIter = 1u << 21;
+constexpr unsigned kAsyncMaxIter = 1u << 23;   // consecutive iterations in which a wavefront processed nothing (~25 s)
 constexpr int kAsyncGroupCap = 2;   // event groups per LP per iteration of hs_net_async (debug flags bits 8..15 override)
 
 template <int C>
@@ -854,7 +854,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         // the other 63 idle, and their bounds only move at iteration boundaries -- so every lane takes a few groups, then
         // the wavefront exchanges bounds again and (measured) many more lanes are ready in the next trip.
         const int group_cap = ((flags >> 8) & 0xff) ? ((flags >> 8) & 0xff) : kAsyncGroupCap;
-        unsigned n_groups = 0, n_iter = 0, groups_before = 0;
+        unsigned n_groups = 0, n_iter = 0, groups_before = 0, idle_iters = 0;
         // In-wavefront chains.  When this LP's only incoming link comes from the LP in the previous lane, its bound need
         // not wait for that neighbour's next publication: a sender's bound is a (min, +) map of its own input bound,
         //     ea_j(H) = min(a_j, H + b_j),   a_j = min(min D, [idle worker] next own event + dur) + transit floor,
@@ -992,8 +992,12 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             }
 #endif
             if (__all(done)) break;
-            if (iter >= kAsyncMaxIter) { gave_up = 1; break; }
-            if ((flags & 128) && !__any(n_groups != groups_before)) __builtin_amdgcn_s_sleep(64);   // experiment: back off when idle
+            // the spin bound counts iterations in which the whole wavefront processed nothing (with at most kAsyncGroupCap
+            // groups per LP per iteration, the number of WORKING iterations grows with the run and is not a sign of a hang)
+            const bool wave_idle = !__any(n_groups != groups_before);
+            idle_iters = wave_idle ? idle_iters + 1 : 0;
+            if (idle_iters >= kAsyncMaxIter) { gave_up = 1; break; }
+            if ((flags & 128) && wave_idle) __builtin_amdgcn_s_sleep(64);   // experiment: back off when idle
             groups_before = n_groups;
         }
         store_net<C, true>(S, X, NX, lp, n);

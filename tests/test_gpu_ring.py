@@ -80,6 +80,10 @@ RING_SWEEP = [
          end_s=8.0, seed=13),
     dict(name="ring_2_dense", topology="ring", n=2, ext_rate=4.5, mean=0.1, lat_min=0.0001, jitter_mean=0.0005, end_s=4.0,
          seed=14),
+    # two stations, a quarter of a million event groups each: far more loop iterations than a wavefront of the full-size
+    # ring ever needs (the asynchronous engine takes at most two groups per LP per iteration)
+    dict(name="ring_2_long", topology="ring", n=2, ext_rate=450.0, mean=0.001, lat_min=0.0001, jitter_mean=0.0002, end_s=100.0,
+         seed=17),
     # NetworkLink(packet_loss_rate): uniform and per-link rates (incl. a dead link)
     dict(name="ring_700_loss", topology="ring", n=700, ext_rate=6.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, loss=0.25,
          end_s=8.0, seed=15),
