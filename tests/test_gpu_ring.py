@@ -186,3 +186,59 @@ def test_ring_full_size_properties_and_engine_agreement():
     assert d.min() >= 0 and (t - cr).min() >= 0 and t.max() <= final
     load = st["completed"] / 60.0
     assert 7.6 < load.mean() < 8.1                           # 4/s external + 4/s forwarded per station, rho = 0.8
+
+
+@ENGINES
+def test_two_links_per_station_mesh_matches_oracle(engine_flags):
+    """Every station's RandomRouter chooses between TWO NetworkLinks (to the next and the next-but-one station) and no
+    Sink; lossy links keep the load finite.  Two outgoing and two incoming links per station: none of the asynchronous
+    engine's single-link shortcuts (link state in registers, in-wavefront chains) applies, the general code must agree
+    with the oracle too."""
+    from happy_simulator_amd import _native as N
+    from happy_simulator_amd.engine import NetworkArrays, StationArrays, StationEngine
+
+    n, end_s, seed = 37, 9.0, 23
+    rates = np.array([3.0 if i % 3 else 0.0 for i in range(n)])
+    loss = np.array([0.45 + 0.01 * (l % 7) for l in range(2 * n)])
+    g = O.Graph()
+    src = [g.source(O.ARR_POISSON, rates[i], stream_base=i) if rates[i] > 0 else -1 for i in range(n)]
+    srv = [g.server(O.LAT_EXP, 0.05, concurrency=1, stream_base=i) for i in range(n)]
+    lnk = [g.link(0.002, 0.004 if l % 2 else None, stream_base=1000 + l, loss=loss[l]) for l in range(2 * n)]
+    rtr = [g.router([lnk[2 * i], lnk[2 * i + 1]], stream_base=i) for i in range(n)]
+    for i in range(n):
+        if src[i] >= 0:
+            g.target[src[i]] = srv[i]
+        g.target[srv[i]] = rtr[i]
+        g.target[lnk[2 * i]] = srv[(i + 1) % n]
+        g.target[lnk[2 * i + 1]] = srv[(i + 2) % n]
+    r = O.run(g, H.ns_from_seconds(end_s), seed=seed)
+    st = StationArrays(
+        n=n, src_kind=np.where(rates > 0, N.SRC_POISSON, N.SRC_NONE).astype(np.uint8), src_rate=np.where(rates > 0, rates, 1.0),
+        src_stop_after_ns=np.full(n, -1, np.int64), concurrency=np.ones(n, np.int32),
+        svc_kind=np.full(n, N.LAT_EXPONENTIAL, np.uint8), svc_mean_s=np.full(n, 0.05), queue_cap=np.full(n, -1, np.int64),
+        egress=np.full(n, N.EGRESS_NONE, np.uint8))
+    net = NetworkArrays(
+        egress_kind=np.full(n, N.EGRESS_ROUTER, np.uint8), router_target0=np.arange(0, 2 * n, 2, dtype=np.int32),
+        router_target1=np.arange(1, 2 * n, 2, dtype=np.int32), link_of=np.full(n, -1, np.int32),
+        link_src=np.repeat(np.arange(n), 2).astype(np.int32),
+        link_dst=np.array([(i + 1 + (l % 2)) % n for i in range(n) for l in range(2)], np.int32),
+        link_lat_min_s=np.full(2 * n, 0.002),
+        link_jitter_kind=np.array([N.LAT_EXPONENTIAL if l % 2 else N.LAT_CONSTANT for l in range(2 * n)], np.uint8),
+        link_jitter_mean_s=np.array([0.004 if l % 2 else 0.0 for l in range(2 * n)]),
+        link_stream_base=np.arange(1000, 1000 + 2 * n, dtype=np.uint64), link_loss_rate=loss)
+    with StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=H.ns_from_seconds(end_s), seed=seed, log_capacity=2048,
+                       network=net) as eng:
+        if engine_flags:
+            eng.set_debug_flags(engine_flags)
+        eng.run_until(H.ns_from_seconds(end_s))
+        s = eng.summary()
+        stt, ns = eng.lp_stats(), eng.net_stats()
+        assert s.events_processed == r.events_processed and s.final_time_ns == r.final_time_ns
+        np.testing.assert_array_equal(s.events_by_kind, r.events_by_kind)
+        for k, arr in (("accepted", r.accepted), ("completed", r.completed), ("queue_depth", r.depth), ("active", r.active),
+                       ("total_service_s", r.total_service_s)):
+            np.testing.assert_array_equal(stt[k], arr[srv], err_msg=k)
+        np.testing.assert_array_equal(ns["routed"], r.routed[rtr])
+        np.testing.assert_array_equal(ns["link_packets_sent"], r.packets_sent[lnk])
+        np.testing.assert_array_equal(ns["link_packets_dropped"], r.dropped[lnk])
+        assert ns["link_packets_dropped"].sum() > 100 and s.events_by_kind[7] == 0
