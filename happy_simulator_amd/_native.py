@@ -191,6 +191,13 @@ def lib():
     L.hs_engine_shard_progress.argtypes = [C.c_void_p, C.c_int64, P(C.c_int64)]
     L.hs_engine_shard_overshoot.restype = C.c_int
     L.hs_engine_shard_overshoot.argtypes = [C.c_void_p, C.c_int32]
+    L.hs_engine_shard_async_setup.restype = C.c_int
+    L.hs_engine_shard_async_setup.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+    for name in ("hs_engine_shard_round", "hs_engine_shard_inject_async"):
+        getattr(L, name).restype = C.c_int
+        getattr(L, name).argtypes = [C.c_void_p]
+    L.hs_engine_shard_async_done.restype = C.c_int
+    L.hs_engine_shard_async_done.argtypes = [C.c_void_p, P(C.c_int32)]
     L.hs_engine_reset.restype = C.c_int
     L.hs_engine_reset.argtypes = [C.c_void_p]
     for name in ("hs_engine_run_until", "hs_engine_run_until_async"):
@@ -265,7 +272,8 @@ EXPORTED_SYMBOLS = (
     "hs_abi_version", "hs_device_count", "hs_engine_create", "hs_engine_set_stations", "hs_engine_set_network",
     "hs_engine_get_net_stats", "hs_engine_set_stream", "hs_engine_shard_attach", "hs_engine_shard_begin",
     "hs_engine_shard_window", "hs_engine_shard_inject", "hs_engine_shard_progress", "hs_engine_shard_final",
-    "hs_engine_shard_overshoot", "hs_engine_reset",
+    "hs_engine_shard_overshoot", "hs_engine_shard_async_setup", "hs_engine_shard_round",
+    "hs_engine_shard_inject_async", "hs_engine_shard_async_done", "hs_engine_reset",
     "hs_engine_run_until", "hs_engine_run_until_async", "hs_engine_synchronize", "hs_engine_bench_runs",
     "hs_engine_get_summary", "hs_engine_get_lp_stats", "hs_engine_read_sink", "hs_engine_read_sinks", "hs_engine_read_probe",
     "hs_last_error", "hs_last_global_error", "hs_engine_destroy", "hs_debug_draws", "hs_debug_set_flags",

@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
         for (int k = 0; k < 15; ++k) tot->ev[k] = 0;
         tot->completed = 0; tot->received = 0; tot->final_time = start_ns; tot->cur_time = start_ns;
         tot->overflow = 0; tot->qoverflow = 0; tot->done = 0;
-        tot->dbg[0] = tot->dbg[1] = tot->dbg[2] = tot->dbg[3] = 0;
+        tot->dbg[0] = tot->dbg[1] = tot->dbg[2] = tot->dbg[3] = 0; tot->not_done = 0;
     }
     if (lp >= n) return;
     int64_t A = kInfNs, arr_time = start_ns;
@@ -504,11 +504,11 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST> &S, const StationPa
     S.tid = tid;
     S.inc_const = __ddiv_rn(1.0, S.rate);
     S.ha = S.na = S.hs_ = S.nsv = S.hj = S.nj = S.rn = 0; S.rbits = 0; S.fl_link = -1; S.fi_link = -1; S.fi_packets = 0;
+    S.fl_remote = false;
     S.bag_n = NX.bag_cnt[lp];
     if constexpr (FAST) {
         // (S.fl was set by the caller.)  The bag moves into LDS for the lifetime of the kernel ...
-        if (S.bag_n > kLBag) { S.bagoverflow = 1; S.bag_n = kLBag; }
-        for (int i = 0; i < S.bag_n; ++i) {
+        for (int i = 0; i < S.bag_n && i < kLBag; ++i) {      // (entries beyond kLBag stay where they are)
             const size_t b = (size_t)lp * NX.bag_cap + i;
             S.bg_set(i, NX.bag_t[b], NX.bag_ts[b], NX.bag_cr[b], NX.bag_link[b]);
         }
@@ -518,6 +518,7 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST> &S, const StationPa
         else if (S.egress == EG_ROUTER) l = (S.rt0 >= 0 && S.rt1 < 0) ? S.rt0 : (S.rt1 >= 0 && S.rt0 < 0) ? S.rt1 : -1;
         if (l >= 0) {
             S.fl_link = l; S.fl_dst = NP.link_dst[l]; S.fl_jit = NP.link_jit_kind[l];
+            S.fl_remote = SC.wend_slots != nullptr && SC.link_rank[l] != SC.rank;
             S.fl_delay0 = seconds_from_ns(ns_from_seconds(NP.link_lat_min[l]));
             S.fl_lam = __ddiv_rn(1.0, NP.link_jit_mean[l]);
             S.fl_loss = NP.link_loss[l];
@@ -556,7 +557,7 @@ __device__ __forceinline__ void store_net(NetStation<C, FAST> &S, const StationS
     // draws CONSUMED (pre-drawn values still in the FAST rings are dropped: pure functions of the index)
     X.arr_k[lp] = S.arr_consumed(); X.svc_k[lp] = S.svc_consumed(); NX.route_k[lp] = S.rte_consumed();
     if constexpr (FAST) {
-        for (int i = 0; i < S.bag_n; ++i) {
+        for (int i = 0; i < S.bag_n && i < kLBag; ++i) {
             const size_t b = (size_t)lp * NX.bag_cap + i;
             NX.bag_t[b] = S.bg_t(i); NX.bag_ts[b] = S.bg_ts(i); NX.bag_cr[b] = S.bg_cr(i); NX.bag_link[b] = S.bg_link(i);
         }
@@ -808,12 +809,13 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
 // overflow bit 8 and the host reports an error instead of hanging the device.
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned kAsyncMaxIter = 1u << 23;   // consecutive iterations in which a wavefront processed nothing (~25 s)
+constexpr unsigned kAsyncBlockedMax = 1u << 17;   // ... while a lane waits for buffer space: a buffer deadlock (~1 s)
 constexpr int kAsyncGroupCap = 2;   // event groups per LP per iteration of hs_net_async (debug flags bits 8..15 override)
 
 template <int C>
 __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParams NP, StationState X, NetState NX,
                                                        RecordLogs L, Totals *tot, int n, int64_t end_ns, int flags,
-                                                       ShardCtl SC, int lanes) {
+                                                       ShardCtl SC, int lanes, int max_iters) {
     __shared__ uint8_t qmem[kQCap][kBlock];
     __shared__ int64_t enqpay[kEnqPay][kBlock];
     __shared__ double ring_a[kNRing][kBlock], ring_s[kNRing][kBlock], ring_j[kNRing][kBlock];   // pre-drawn E values
@@ -855,6 +857,8 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         // the wavefront exchanges bounds again and (measured) many more lanes are ready in the next trip.
         const int group_cap = ((flags >> 8) & 0xff) ? ((flags >> 8) & 0xff) : kAsyncGroupCap;
         unsigned n_groups = 0, n_iter = 0, groups_before = 0, idle_iters = 0;
+        bool aborted = false, blocked = false;
+        unsigned blocked_iters = 0;
         // In-wavefront chains.  When this LP's only incoming link comes from the LP in the previous lane, its bound need
         // not wait for that neighbour's next publication: a sender's bound is a (min, +) map of its own input bound,
         //     ea_j(H) = min(a_j, H + b_j),   a_j = min(min D, [idle worker] next own event + dur) + transit floor,
@@ -863,9 +867,13 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         // reach after up to 63 publish / poll round trips, from the senders' CURRENT states (valid: a bound computed from a
         // state covers everything that state can still send).  Chains are cut where the previous lane is not the sender.
         int32_t next_l = -1;                                  // my link to the LP in the next lane, if any
+        bool out_remote[2] = {false, false};                  // a shard: links that leave it go to an outbox row, no queue
 #pragma unroll
-        for (int o = 0; o < 2; ++o)
-            if (out_l[o] >= 0 && NP.link_dst[out_l[o]] == lp + 1) next_l = out_l[o];
+        for (int o = 0; o < 2; ++o) {
+            if (out_l[o] < 0) continue;
+            out_remote[o] = SC.wend_slots != nullptr && SC.link_rank[out_l[o]] != SC.rank;
+            if (!out_remote[o] && NP.link_dst[out_l[o]] == (int32_t)SC.lp_base + lp + 1) next_l = out_l[o];
+        }
         const int in_deg = NP.in_off[lp + 1] - NP.in_off[lp];
         const int32_t my_in = in_deg == 1 ? NP.in_links[NP.in_off[lp]] : -1;
         const int32_t prev_next = __shfl_up(next_l, 1, 64);
@@ -934,12 +942,15 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             const unsigned long long q2 = __builtin_readcyclecounter();
             unsigned long long q3 = q2;
 #endif
+            blocked = false;
             if (!done) {
                 const int64_t limit = (H - 1) < end_ns ? (H - 1) : end_ns;
+                blocked = S.undrained != kInfNs;                      // the bag is full and a queue still holds messages
                 for (int g = 0; g < group_cap; ++g) {
                     const int64_t t = S.next_time();
                     if (t > limit) break;
-                    if (!(S.async_can_send(out_l[0], head_seen[0]) && S.async_can_send(out_l[1], head_seen[1]))) break;   // a consumer is behind: wait
+                    if (!((out_remote[0] || S.async_can_send(out_l[0], head_seen[0])) &&
+                          (out_remote[1] || S.async_can_send(out_l[1], head_seen[1])))) { blocked = true; break; }   // a consumer is behind: wait
                     if constexpr (C == 1) S.step1(t, force_general);
                     else S.run_group(t, force_general);
                     ++n_groups;
@@ -992,15 +1003,25 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             }
 #endif
             if (__all(done)) break;
+            if (max_iters > 0 && (int)(iter + 1) >= max_iters) break; // a shard's exchange round is over
+            // a fatal condition anywhere ends the launch everywhere: nobody spins on a dead neighbour
+            if (__any(aborted) || ((iter & 31u) == 31u && __hip_atomic_load(&tot->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) break;
             // the spin bound counts iterations in which the whole wavefront processed nothing (with at most kAsyncGroupCap
             // groups per LP per iteration, the number of WORKING iterations grows with the run and is not a sign of a hang)
             const bool wave_idle = !__any(n_groups != groups_before);
             idle_iters = wave_idle ? idle_iters + 1 : 0;
-            if (idle_iters >= kAsyncMaxIter) { gave_up = 1; break; }
+            if (idle_iters >= kAsyncMaxIter) { gave_up = 1; atomicOr(&tot->overflow, 8); break; }
+            // Bounded buffers + time-ordered processing can deadlock on a cycle: every LP waits for room in its outgoing
+            // queue while its own bag is full of messages it may not process yet.  A wavefront that makes no progress for
+            // a long time while one of its lanes waits for buffer space reports that (raise bag_capacity) instead of spinning.
+            if (wave_idle && __any(!done && blocked)) {
+                if (++blocked_iters >= kAsyncBlockedMax) { atomicOr(&tot->overflow, 2); aborted = true; }
+            } else blocked_iters = 0;
             if ((flags & 128) && wave_idle) __builtin_amdgcn_s_sleep(64);   // experiment: back off when idle
             groups_before = n_groups;
         }
         store_net<C, true>(S, X, NX, lp, n);
+        if (max_iters > 0 && !done) atomicAdd(&tot->not_done, 1ull);
 #ifdef HS_CYCLES
 #ifdef HS_STEP
         // every lane's own view: head / commit cycles summed over lanes (divide by groups), slow groups
@@ -1076,6 +1097,49 @@ __global__ void hs_shard_inject(NetState NX, const int64_t *inbox, int64_t *outb
         const size_t b = cslot * NX.bag_cap + pos;
         NX.in_t[b] = m[0]; NX.in_ts[b] = m[1]; NX.in_cr[b] = m[2]; NX.in_link[b] = gid2local[gid];
     } else atomicOr(&tot->overflow, 2);
+}
+
+// ---- asynchronous shard rounds ------------------------------------------------------------------------------------
+// Each shard runs hs_net_async for a bounded number of iterations (a ROUND); between rounds the host moves the outbox
+// rows (all-to-all) and the lower bounds of the cross-shard links (all-reduce MAX).  A cross link behaves like any other
+// link of the asynchronous engine -- messages in its queue, a bound in aq_ea -- only that queue and bound are refilled
+// between launches instead of by a concurrently running producer.  Exchange rounds therefore follow the boundary LPs'
+// lookahead (tens of ms of simulated time), not the 1 ms link floor of the windowed protocol.
+// What this rank publishes after a round: the bounds of the cross links that START here, and whether it still has work.
+__global__ void hs_shard_bounds_out(const int64_t *aq_ea, const int32_t *cross_local, const uint8_t *cross_role, int n_cross,
+                                    int64_t *bounds, const Totals *tot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_cross) bounds[i] = (cross_role[i] & 1) ? aq_ea[cross_local[i]] : INT64_MIN;
+    if (i == n_cross) bounds[n_cross] = tot->not_done ? 1 : 0;
+}
+// After the exchange: the received messages go to the queues of their links (row r holds what rank r sent here, in send
+// order; a link has one producer, so one thread per row keeps every queue in order), the all-reduced bounds become the
+// aq_ea of the cross links that END here.  One workgroup; the engine's kernel is not running.
+__global__ void hs_shard_inject_async(NetState NX, const int64_t *inbox, int64_t *outbox, int world, int msg_cap, int row,
+                                      int n, int64_t lp_base, const int32_t *gid2local, int64_t n_gid,
+                                      const int32_t *cross_local, const uint8_t *cross_role, int n_cross,
+                                      const int64_t *bounds, Totals *tot) {
+    const int tid = threadIdx.x;
+    for (int r = tid; r < world; r += blockDim.x) {
+        const int64_t *rowp = inbox + (size_t)r * row;
+        int64_t cnt = rowp[0];
+        if (cnt > msg_cap) { atomicOr(&tot->overflow, 2); cnt = msg_cap; }
+        for (int64_t i = 0; i < cnt; ++i) {
+            const int64_t *m = rowp + 1 + 4 * (size_t)i;
+            const int64_t dst = (m[3] >> 32) - lp_base, gid = m[3] & 0xffffffffll;
+            if (dst < 0 || dst >= n || gid >= n_gid || gid2local[gid] < 0) { atomicOr(&tot->overflow, 4); continue; }
+            const int l = gid2local[gid];
+            const unsigned long long tail = NX.aq_tail[l], head = NX.aq_head[l];
+            if (tail - head >= (unsigned long long)NX.aq_cap) { atomicOr(&tot->overflow, 2); continue; }
+            const size_t slot = (size_t)l * NX.aq_cap + (size_t)(tail & (unsigned long long)(NX.aq_cap - 1));
+            NX.aq_t[slot] = m[0]; NX.aq_ts[slot] = m[1]; NX.aq_cr[slot] = m[2];
+            NX.aq_tail[l] = tail + 1;
+        }
+        outbox[(size_t)r * row] = 0;
+    }
+    for (int i = tid; i < n_cross; i += blockDim.x)
+        if (cross_role[i] & 2) NX.aq_ea[cross_local[i]] = bounds[i];
+    if (tid == 0) tot->not_done = 0;
 }
 
 // Sharded network: this rank owns the globally first event beyond end_ns -- process it (core/simulation.py:472).
@@ -1189,10 +1253,18 @@ struct hs_engine {
     int64_t final_win = 0;
     bool external_stream = false;
     hipStream_t own_stream = nullptr;
-    std::vector<int32_t> h_link_dst;
+    std::vector<int32_t> h_link_dst, h_link_src, h_gid2local;
     int64_t window_ns = 0;
     bool net_ran = false;
     bool async_ok = false;     // the network can run on hs_net_async (whole network on this engine, queues allocated)
+    int round_iters = 0;       // > 0: hs_net_async runs one exchange round of a shard (that many iterations), not a whole run
+    // asynchronous shard rounds (hs_engine_shard_async_*): the network's cross-shard links
+    int n_cross = 0;
+    const int32_t *cross_local = nullptr;   // [n_cross] local link index (-1: this shard does not touch the link)
+    const uint8_t *cross_role = nullptr;    // [n_cross] bit 0: the source station is here, bit 1: the destination is
+    int64_t *cross_bounds = nullptr;        // device int64[n_cross + 1], owned by the caller (all-reduced with MAX)
+    bool shard_async = false;
+    int round_iters_cfg = 0;
     int async_fit = -1;        // -1 unknown, 0 the grid is not co-resident (windowed engine), 1 it is
     int async_lanes = 64;      // LPs per wavefront in hs_net_async
     int n_blocks = 0;
@@ -1281,7 +1353,8 @@ template <int C>
 hipError_t launch_async(hs_engine *h, int64_t end_ns, NetState NX) {
     int n = h->cfg.n_lp, flags = h->flags & (1 | 64 | 128 | 0xff00), lanes = h->async_lanes;
     const int per_block = (kBlock / 64) * lanes;
-    void *args[] = {&h->P, &h->NP, &h->X, &NX, &h->L, &h->tot, &n, &end_ns, &flags, &h->SC, &lanes};
+    int max_iters = h->round_iters;
+    void *args[] = {&h->P, &h->NP, &h->X, &NX, &h->L, &h->tot, &n, &end_ns, &flags, &h->SC, &lanes, &max_iters};
     return hipLaunchCooperativeKernel((const void *)hs_net_async<C>, dim3((unsigned)((n + per_block - 1) / per_block)),
                                       dim3(kBlock), args, 0, h->stream);
 }
@@ -1294,8 +1367,8 @@ int async_blocks_per_cu() {
 
 // The whole run in one launch of hs_net_async + the final launch of hs_net_window (election of the one event beyond
 // end_ns).  Returns 1 if it ran, 0 if the network has to use the windowed engine, < 0 on error.
-int try_run_net_whole(hs_engine *h, int64_t end_ns) {
-    if (!h->async_ok || (h->flags & 16)) return 0;
+int try_run_net_whole(hs_engine *h, int64_t end_ns);
+int ensure_async_fit(hs_engine *h) {
     if (h->async_fit < 0) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, h->cfg.device) != hipSuccess) return 0;
@@ -1307,7 +1380,11 @@ int try_run_net_whole(hs_engine *h, int64_t end_ns) {
             if (((long long)h->cfg.n_lp + per_block - 1) / per_block <= resident) { h->async_lanes = lanes; h->async_fit = 1; break; }
         }
     }
-    if (!h->async_fit) return 0;
+    return h->async_fit;
+}
+int try_run_net_whole(hs_engine *h, int64_t end_ns) {
+    if (!h->async_ok || (h->flags & 16)) return 0;
+    if (!ensure_async_fit(h)) return 0;
     NetState NX = h->NX;
     NX.aq_on = 1;
     hipError_t e = h->C == 1 ? launch_async<1>(h, end_ns, NX) : h->C == 2 ? launch_async<2>(h, end_ns, NX) : launch_async<4>(h, end_ns, NX);
@@ -1681,11 +1758,12 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     {   // incoming links per LP (CSR) and the transit floor of every link, for the asynchronous engine
         std::vector<int32_t> in_off((size_t)n + 1, 0), in_links(NL, 0);
         std::vector<int64_t> lat_ns(NL, 1);
-        if (!global) {
-            for (int l = 0; l < nl; ++l) in_off[(size_t)net->link_dst[l] + 1]++;
+        {   // (a shard: only the links that END here, indexed by the local station)
+            auto here = [&](int l) { return net->link_dst[l] >= lo && net->link_dst[l] < lo + n; };
+            for (int l = 0; l < nl; ++l) if (here(l)) in_off[(size_t)(net->link_dst[l] - lo) + 1]++;
             for (int i = 0; i < n; ++i) in_off[(size_t)i + 1] += in_off[(size_t)i];
             std::vector<int32_t> cur(in_off.begin(), in_off.end() - 1);
-            for (int l = 0; l < nl; ++l) in_links[(size_t)cur[(size_t)net->link_dst[l]]++] = l;
+            for (int l = 0; l < nl; ++l) if (here(l)) in_links[(size_t)cur[(size_t)(net->link_dst[l] - lo)]++] = l;
         }
         for (int l = 0; l < nl; ++l) {
             const double lc = (double)(int64_t)(net->link_lat_min_s[l] * 1e9) / 1e9;   // ConstantLatency.get_latency().to_seconds()
@@ -1713,6 +1791,7 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
         if ((rc = upload<int32_t>(h, &h->NP.link_gid, gid.data(), (size_t)nl, 0))) return rc;
         const int32_t *g2l_dev = nullptr;
         if ((rc = upload<int32_t>(h, &g2l_dev, g2l.data(), (size_t)h->n_gid, -1))) return rc;
+        h->h_gid2local = g2l;
         h->gid2local = const_cast<int32_t *>(g2l_dev);
     }
     h->net_global = global;
@@ -1720,6 +1799,7 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     h->SC = ShardCtl{};
     h->SC.lp_base = lo;
     h->h_link_dst.assign(ldst.begin(), ldst.end());
+    h->h_link_src.assign(net->link_src, net->link_src + nl);
     const int bag = net->bag_capacity > 0 ? net->bag_capacity : 16;
     h->NX.bag_cap = bag;
     const size_t N = (size_t)n, NB = (size_t)n * (size_t)bag;
@@ -1729,12 +1809,13 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     ALN(in_cnt, 2 * N); ALN(in_t, 2 * NB); ALN(in_ts, 2 * NB); ALN(in_cr, 2 * NB); ALN(in_link, 2 * NB);
     int aqc = 1;
     while (aqc < bag) aqc <<= 1;      // a power of two: queue slots are addressed with a mask, not a 64-bit modulo
+    if (global && aqc < 64) aqc = 64; // a shard's incoming cross links are filled a whole exchange round at a time
     h->NX.aq_cap = aqc;
     h->NX.aq_on = 0;
-    if (!global && nl > 0) {
+    if (nl > 0) {
         const size_t NQ = NL * (size_t)aqc;
         ALN(aq_t, NQ); ALN(aq_ts, NQ); ALN(aq_cr, NQ); ALN(aq_tail, NL); ALN(aq_head, NL); ALN(aq_ea, NL);
-        h->async_ok = true;
+        h->async_ok = !global;        // the whole network in one cooperative launch; shards: hs_engine_shard_round
     }
 #undef ALN
     if (!h->L.sink_created_own) {   // not every completion reaches the Sink any more: explicit created_at column
@@ -1855,12 +1936,104 @@ int hs_engine_shard_progress(hs_engine *h, int64_t k_last, int64_t *wend_out) {
     return HS_OK;
 }
 
+// Asynchronous rounds instead of windows (same attach / begin / final / overshoot):
+//   begin;  loop: round; <all-to-all outbox -> inbox>; <all-reduce(MAX) bounds>; inject_async;
+//   every so often async_done() (synchronises) until no rank has work left;  final(0); <all-gather cand>; overshoot.
+int hs_engine_shard_async_setup(hs_engine *h, int32_t n_cross, const int64_t *cross_gid, int64_t *bounds_dev,
+                                int32_t max_iters) {
+    if (!h || !h->SC.wend_slots) return fail(h, HS_E_STATE, "hs_engine_shard_async_setup: no shard attached");
+    if (n_cross < 0 || (n_cross > 0 && !cross_gid) || !bounds_dev || max_iters < 1)
+        return fail(h, HS_E_INVALID, "hs_engine_shard_async_setup: bad argument");
+    if (!h->NX.aq_tail) return fail(h, HS_E_STATE, "the network has no links");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    if (!ensure_async_fit(h)) return fail(h, HS_E_UNSUPPORTED, "the shard's stations are not co-resident on this device (asynchronous rounds need a cooperative launch)");
+    const int64_t lo = (int64_t)h->cfg.lp_base, hi = lo + h->cfg.n_lp;
+    std::vector<int32_t> loc((size_t)(n_cross > 0 ? n_cross : 1), -1);
+    std::vector<uint8_t> role((size_t)(n_cross > 0 ? n_cross : 1), 0);
+    int out_here = 0;
+    for (int i = 0; i < n_cross; ++i) {
+        const int64_t g = cross_gid[i];
+        if (g < 0 || g >= h->n_gid) return fail(h, HS_E_INVALID, "cross link id %lld out of range", (long long)g);
+        const int l = h->h_gid2local[(size_t)g];
+        if (l < 0) continue;
+        loc[(size_t)i] = l;
+        const bool s_here = h->h_link_src[(size_t)l] >= lo && h->h_link_src[(size_t)l] < hi;
+        const bool d_here = h->h_link_dst[(size_t)l] >= lo && h->h_link_dst[(size_t)l] < hi;
+        if (s_here && d_here) return fail(h, HS_E_INVALID, "link %lld does not cross a shard boundary", (long long)g);
+        role[(size_t)i] = (uint8_t)((s_here ? 1 : 0) | (d_here ? 2 : 0));
+        out_here += s_here ? 1 : 0;
+    }
+    // a round may append group_cap x iterations x C messages per outgoing cross link: to one outbox row on this side, to
+    // one link queue on the other.  The iterations per round are clamped to what those hold.
+    const long long per_iter = (long long)kAsyncGroupCap * h->C;
+    long long fit = (h->NX.aq_cap / 2) / per_iter;
+    if (out_here > 0) { const long long f2 = h->SC.msg_cap / (per_iter * out_here); if (f2 < fit) fit = f2; }
+    if (fit < 1)
+        return fail(h, HS_E_INVALID, "msg_capacity %d is too small for %d outgoing cross links x %lld messages per iteration; "
+                    "raise msg_capacity", h->SC.msg_cap, out_here, per_iter);
+    if (max_iters > fit) max_iters = (int32_t)fit;
+    int rc;
+    if ((rc = upload<int32_t>(h, &h->cross_local, loc.data(), loc.size(), -1))) return rc;
+    if ((rc = upload<uint8_t>(h, &h->cross_role, role.data(), role.size(), 0))) return rc;
+    h->n_cross = n_cross;
+    h->cross_bounds = bounds_dev;
+    h->round_iters_cfg = max_iters;
+    h->shard_async = true;
+    return HS_OK;
+}
+
+int hs_engine_shard_round(hs_engine *h) {
+    if (!h || !h->shard_async) return fail(h, HS_E_STATE, "hs_engine_shard_round: call hs_engine_shard_async_setup first");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    NetState NX = h->NX;
+    NX.aq_on = 1;
+    h->round_iters = h->round_iters_cfg;
+    const int64_t end_ns = h->SC.end_ns;
+    hipError_t e = h->C == 1 ? launch_async<1>(h, end_ns, NX) : h->C == 2 ? launch_async<2>(h, end_ns, NX) : launch_async<4>(h, end_ns, NX);
+    h->round_iters = 0;
+    if (e != hipSuccess) return fail(h, HS_E_HIP, "cooperative launch failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(hs_shard_bounds_out, dim3((unsigned)((h->n_cross + 1 + 255) / 256)), dim3(256), 0, h->stream, h->NX.aq_ea,
+                       h->cross_local, h->cross_role, h->n_cross, h->cross_bounds, h->tot);
+    HS_HIP(h, hipGetLastError());
+    h->launches += 2;
+    return HS_OK;
+}
+
+int hs_engine_shard_inject_async(hs_engine *h) {
+    if (!h || !h->shard_async) return fail(h, HS_E_STATE, "hs_engine_shard_inject_async: call hs_engine_shard_async_setup first");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(hs_shard_inject_async, dim3(1), dim3(256), 0, h->stream, h->NX, h->inbox, h->SC.outbox, h->SC.world,
+                       h->SC.msg_cap, h->SC.row, h->cfg.n_lp, h->SC.lp_base, h->gid2local, h->n_gid, h->cross_local,
+                       h->cross_role, h->n_cross, h->cross_bounds, h->tot);
+    HS_HIP(h, hipGetLastError());
+    h->launches++;
+    return HS_OK;
+}
+
+// synchronises; *any_not_done = the all-reduced "some rank still has work" flag of the last exchanged round
+int hs_engine_shard_async_done(hs_engine *h, int32_t *any_not_done) {
+    if (!h || !h->shard_async || !any_not_done) return fail(h, HS_E_STATE, "hs_engine_shard_async_done: not set up");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    int64_t v = 0;
+    HS_HIP(h, hipMemcpyAsync(&v, h->cross_bounds + h->n_cross, 8, hipMemcpyDeviceToHost, h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    *any_not_done = v != 0;
+    Totals t;
+    HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
+    if (t.qoverflow) return fail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
+    if (t.overflow & 4) return fail(h, HS_E_INVALID, "a message arrived for a station or link this shard does not own");
+    if (t.overflow & 8) return fail(h, HS_E_HIP, "the asynchronous engine gave up waiting for a neighbour (bounded spin exhausted)");
+    if (t.overflow & 2) return fail(h, HS_E_OVERFLOW, "a message bag, a link queue or an exchange row overflowed; raise bag_capacity / msg_capacity");
+    if (t.overflow) return fail(h, HS_E_OVERFLOW, "a per-LP record log overflowed (capacity %lld records)", (long long)h->L.cap);
+    return HS_OK;
+}
+
 int hs_engine_shard_final(hs_engine *h, int64_t k) {
     if (!h || !h->SC.wend_slots) return fail(h, HS_E_STATE, "hs_engine_shard_final: no shard attached");
     HS_HIP(h, hipSetDevice(h->cfg.device));
     h->SC.gvt_in = h->shard_gvt + ((k + 1) & 1);
     h->SC.gvt_out = h->shard_gvt + (k & 1);
-    launch_net_dispatch(h, h->SC.end_ns, (int)(k & 0x3fffffff), (h->flags & 1) | 2 | 4);
+    launch_net_dispatch(h, h->SC.end_ns, (int)(k & 0x3fffffff), (h->flags & 1) | 2 | 4 | (h->shard_async ? 8 : 0));
     HS_HIP(h, hipGetLastError());
     h->launches++;
     h->final_win = k;

@@ -174,6 +174,7 @@ struct NetStation {
     uint32_t rbits;
     int32_t fl_link;              // the LP's only outgoing link (-1: none or two -> the global-memory path)
     int32_t fl_dst;
+    bool fl_remote;               // ... whose destination lives on another shard: messages go to that rank's outbox row
     uint32_t fl_jit;              // 0 = exponential jitter
     double fl_delay0, fl_lam, fl_loss, inc_const;
     int64_t fl_in, fl_sent;
@@ -214,16 +215,14 @@ struct NetStation {
 
     // ---- bag (pending inbound messages of this LP; global memory, owner-only)
     __device__ __forceinline__ size_t bidx(int i) const { return (size_t)lp * ns->bag_cap + i; }
-    __device__ __forceinline__ int bag_capacity() const {
-        if constexpr (FAST) return kLBag < ns->bag_cap ? kLBag : ns->bag_cap;
-        else return ns->bag_cap;
-    }
-    __device__ __forceinline__ int64_t bg_t(int i) const { if constexpr (FAST) return fl.bag_t[i][tid]; else return ns->bag_t[bidx(i)]; }
-    __device__ __forceinline__ int64_t bg_ts(int i) const { if constexpr (FAST) return fl.bag_ts[i][tid]; else return ns->bag_ts[bidx(i)]; }
-    __device__ __forceinline__ int64_t bg_cr(int i) const { if constexpr (FAST) return fl.bag_cr[i][tid]; else return ns->bag_cr[bidx(i)]; }
-    __device__ __forceinline__ int32_t bg_link(int i) const { if constexpr (FAST) return fl.bag_link[i][tid]; else return ns->bag_link[bidx(i)]; }
+    // FAST: entries 0 .. kLBag-1 live in LDS, the (rarely used) rest of the bag at the same index in global memory
+    __device__ __forceinline__ int bag_capacity() const { return ns->bag_cap; }
+    __device__ __forceinline__ int64_t bg_t(int i) const { if (FAST && i < kLBag) return fl.bag_t[i][tid]; return ns->bag_t[bidx(i)]; }
+    __device__ __forceinline__ int64_t bg_ts(int i) const { if (FAST && i < kLBag) return fl.bag_ts[i][tid]; return ns->bag_ts[bidx(i)]; }
+    __device__ __forceinline__ int64_t bg_cr(int i) const { if (FAST && i < kLBag) return fl.bag_cr[i][tid]; return ns->bag_cr[bidx(i)]; }
+    __device__ __forceinline__ int32_t bg_link(int i) const { if (FAST && i < kLBag) return fl.bag_link[i][tid]; return ns->bag_link[bidx(i)]; }
     __device__ __forceinline__ void bg_set(int i, int64_t t, int64_t ts, int64_t cr, int32_t l) {
-        if constexpr (FAST) { fl.bag_t[i][tid] = t; fl.bag_ts[i][tid] = ts; fl.bag_cr[i][tid] = cr; fl.bag_link[i][tid] = l; }
+        if (FAST && i < kLBag) { fl.bag_t[i][tid] = t; fl.bag_ts[i][tid] = ts; fl.bag_cr[i][tid] = cr; fl.bag_link[i][tid] = l; }
         else { const size_t d = bidx(i); ns->bag_t[d] = t; ns->bag_ts[d] = ts; ns->bag_cr[d] = cr; ns->bag_link[d] = l; }
     }
     // earliest arrival in the bag, kept in a register (`bmin`): next_time() runs several times per step and a scan of the
@@ -376,6 +375,19 @@ struct NetStation {
 
     // NetworkLink.handle_event up to its yield (components/network/link.py:114-154, _calculate_delay :190-216)
     // executed for a request that enters link `l` at time t; the continuation becomes a message to the egress LP.
+    __device__ __forceinline__ bool link_is_remote(int32_t l) const {
+        return sc->wend_slots != nullptr && sc->link_rank[l] != sc->rank;
+    }
+    // a message for a station of another shard: append to that rank's outbox row (the host exchanges the rows)
+    __device__ __forceinline__ void outbox_append(int32_t l, int32_t dst, int64_t t_arr, int64_t t, int64_t created) {
+        int64_t *row = sc->outbox + (size_t)sc->link_rank[l] * sc->row;
+        const unsigned long long pos = atomicAdd((unsigned long long *)row, 1ull);
+        if (pos < (unsigned long long)sc->msg_cap) {
+            int64_t *m = row + 1 + 4 * pos;
+            const int64_t gid = np->link_gid ? np->link_gid[l] : l;
+            m[0] = t_arr; m[1] = t; m[2] = created; m[3] = ((int64_t)dst << 32) | gid;
+        } else bagoverflow = 1;
+    }
     __device__ __forceinline__ int64_t link_sent_of(int32_t l) const {
         if constexpr (FAST) { if (l == fl_link) return fl_sent; }
         return ns->link_sent[l];
@@ -399,6 +411,7 @@ struct NetStation {
         if (!(delay > 0.0)) delay = 0.0;
         const int64_t t_arr = t + ns_from_seconds(delay);
         sent_min = t_arr < sent_min ? t_arr : sent_min;
+        if (fl_remote) { outbox_append(fl_link, fl_dst, t_arr, t, created); return; }
         const unsigned long long sq = (unsigned long long)fl_sent;
         const size_t slot = (size_t)fl_link * ns->aq_cap + (size_t)((sq - 1) & (unsigned long long)(ns->aq_cap - 1));
         ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t); ag_store(&ns->aq_cr[slot], created);
@@ -430,6 +443,10 @@ struct NetStation {
         const int64_t t_arr = t + ns_from_seconds(delay);
         sent_min = t_arr < sent_min ? t_arr : sent_min;
         const int32_t dst = np->link_dst[l];                 // network-wide station index
+        if (link_is_remote(l)) {                             // destination lives on another engine
+            outbox_append(l, dst, t_arr, t, created);
+            return;
+        }
         if (ns->aq_on) {
             // asynchronous engine: append to the link's queue (this LP is its only producer); link_sent[l] is the
             // sequence number of this message
@@ -438,17 +455,6 @@ struct NetStation {
             const size_t slot = (size_t)l * ns->aq_cap + (size_t)((seq - 1) & (unsigned long long)(ns->aq_cap - 1));
             ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t); ag_store(&ns->aq_cr[slot], created);
             sent_async = true;          // the caller publishes aq_tail (= link_sent) after draining these stores
-            return;
-        }
-        if (sc->wend_slots != nullptr && sc->link_rank[l] != sc->rank) {
-            // destination lives on another engine: append to that rank's outbox row
-            int64_t *row = sc->outbox + (size_t)sc->link_rank[l] * sc->row;
-            const unsigned long long pos = atomicAdd((unsigned long long *)row, 1ull);
-            if (pos < (unsigned long long)sc->msg_cap) {
-                int64_t *m = row + 1 + 4 * pos;
-                const int64_t gid = np->link_gid ? np->link_gid[l] : l;
-                m[0] = t_arr; m[1] = t; m[2] = created; m[3] = ((int64_t)dst << 32) | gid;
-            } else bagoverflow = 1;
             return;
         }
         const int32_t dl = dst - (int32_t)sc->lp_base;       // local index on this engine
@@ -732,9 +738,12 @@ struct NetStation {
             if (!(delay > 0.0)) delay = 0.0;
             const int64_t t_arr = t + ns_from_seconds(delay);
             sent_min = t_arr < sent_min ? t_arr : sent_min;
-            const size_t slot = (size_t)fl_link * ns->aq_cap + (size_t)(((unsigned long long)fl_sent - 1) & (unsigned long long)(ns->aq_cap - 1));
-            ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t); ag_store(&ns->aq_cr[slot], created_out);
-            sent_async = true;
+            if (fl_remote) outbox_append(fl_link, fl_dst, t_arr, t, created_out);
+            else {
+                const size_t slot = (size_t)fl_link * ns->aq_cap + (size_t)(((unsigned long long)fl_sent - 1) & (unsigned long long)(ns->aq_cap - 1));
+                ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t); ag_store(&ns->aq_cr[slot], created_out);
+                sent_async = true;
+            }
         }
         // ---- QUEUE_POLL, then QUEUE_DELIVER + the retargeted payload at the worker
         ev[3] += poll;

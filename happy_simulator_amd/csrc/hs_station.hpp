@@ -141,6 +141,7 @@ struct Totals {                 // engine-wide accumulators (device memory)
     unsigned int done;          // last-block ticket
     int pad;
     unsigned long long dbg[4];  // asynchronous engine telemetry: sum of wave iterations, max, groups run, waves
+    unsigned long long not_done; // shard rounds of hs_net_async: LPs that still have work at or before end_ns
 };
 
 struct Candidate {              // an LP's first event beyond end_ns (SINGLE-mode overshoot election)

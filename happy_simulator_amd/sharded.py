@@ -64,6 +64,13 @@ class LocalComm:
         for s in scalars:
             s.fill_(m)
 
+    def allreduce_max(self, vectors):
+        import torch
+
+        m = torch.stack(vectors).max(dim=0).values
+        for v in vectors:
+            v.copy_(m)
+
     def allgather_rows(self, rows):
         import torch
 
@@ -90,6 +97,9 @@ class DistComm:
 
     def allreduce_min(self, scalars):
         self._dist.all_reduce(scalars[0], op=self._dist.ReduceOp.MIN, group=self._group)
+
+    def allreduce_max(self, vectors):
+        self._dist.all_reduce(vectors[0], op=self._dist.ReduceOp.MAX, group=self._group)
 
     def allgather_rows(self, rows):
         import torch
@@ -228,6 +238,30 @@ class GpuShard:
         e = self.engine
         e._check(e._lib.hs_engine_shard_final(e._h, k))
 
+    # -- asynchronous exchange rounds (enqueue only, except round_done) ----------------------------------------
+    def async_setup(self, cross_gid: np.ndarray, max_iters: int):
+        import torch
+
+        self.cross_gid = np.ascontiguousarray(cross_gid, np.int64)
+        self.bounds = torch.zeros(len(self.cross_gid) + 1, dtype=torch.int64, device=self.outbox.device)
+        e = self.engine
+        e._check(e._lib.hs_engine_shard_async_setup(e._h, len(self.cross_gid), self.cross_gid.ctypes.data,
+                                                    self.bounds.data_ptr(), int(max_iters)))
+
+    def round(self):
+        e = self.engine
+        e._check(e._lib.hs_engine_shard_round(e._h))
+
+    def inject_async(self):
+        e = self.engine
+        e._check(e._lib.hs_engine_shard_inject_async(e._h))
+
+    def round_done(self) -> bool:
+        e = self.engine
+        flag = C.c_int32(0)
+        e._check(e._lib.hs_engine_shard_async_done(e._h, C.byref(flag)))
+        return flag.value == 0
+
     def overshoot(self, lp_local):
         e = self.engine
         e._check(e._lib.hs_engine_shard_overshoot(e._h, int(lp_local)))
@@ -257,17 +291,18 @@ class ShardedNetwork:
     """Drives the shards this process owns through the window protocol.  `shards` are the local shard objects
     (GpuShard, or any object with the same methods), `comm` moves rows and scalars between all shards."""
 
-    def __init__(self, shards: list, comm, *, window_ns: int, sync_every: int = 64):
+    def __init__(self, shards: list, comm, *, window_ns: int, sync_every: int = 64, rounds: bool = False):
         self.shards = shards
         self.comm = comm
         self.window_ns = int(window_ns)
         self.sync_every = max(1, int(sync_every))
         self.windows = 0
+        self.rounds = bool(rounds)       # asynchronous exchange rounds instead of windows (GpuShard.async_setup done)
 
     @classmethod
     def on_gpu(cls, stations: StationArrays, net: NetworkArrays, comm, *, horizon_ns: int, start_ns: int = 0,
                seed: int = 42, device: int = 0, msg_capacity: int = 256, log_capacity: int = 0, sync_every: int = 64,
-               bounds: np.ndarray | None = None):
+               bounds: np.ndarray | None = None, rounds: bool = True, round_iters: int = 16):
         """Partition `stations` / `net` (network-wide descriptions, identical on every rank) over comm.world shards
         and build the shards this process owns on `device`.  `bounds` (world + 1 station offsets) overrides the
         balanced block partition, e.g. with the user's own SimulationPartition sizes."""
@@ -288,28 +323,58 @@ class ShardedNetwork:
         window_ns = int(w[0].item())
         for s in shards:
             s.attach(window_ns)
-        return cls(shards, comm, window_ns=window_ns, sync_every=sync_every)
+        if rounds:
+            # the network's cross-shard links (the same list on every rank): their bounds travel between the rounds
+            src, dst = np.asarray(net.link_src, np.int64), np.asarray(net.link_dst, np.int64)
+            rank_of = lambda x: np.searchsorted(bounds, x, side="right") - 1          # noqa: E731
+            cross = np.nonzero(rank_of(src) != rank_of(dst))[0].astype(np.int64)
+            for s in shards:
+                s.async_setup(cross, round_iters)
+        return cls(shards, comm, window_ns=window_ns, sync_every=sync_every, rounds=rounds)
+
+    def _run_rounds(self, end_ns: int) -> int:
+        """Asynchronous rounds: every shard runs the asynchronous engine for a few iterations, then messages (all-to-all)
+        and the cross links' lower bounds (all-reduce MAX) are exchanged.  Returns the number of rounds."""
+        sh, comm = self.shards, self.comm
+        r = 0
+        while True:
+            for _ in range(self.sync_every):
+                for s in sh:
+                    s.round()                                          # EXECUTE (one cooperative launch per shard)
+                comm.exchange([s.outbox for s in sh], [s.inbox for s in sh])   # EXCHANGE messages ...
+                comm.allreduce_max([s.bounds for s in sh])             # ... and bounds (+ the "still working" flag)
+                for s in sh:
+                    s.inject_async()
+                r += 1
+            if all([s.round_done() for s in sh]):                      # the only host synchronisation
+                break
+        return r
 
     def run_until(self, end_ns: int) -> ShardedSummary:
         sh, comm = self.shards, self.comm
         for s in sh:
             s.begin(end_ns)
         k = 0
-        while True:
-            for _ in range(self.sync_every):
-                for s in sh:
-                    s.window(k)                                        # EXECUTE
-                comm.exchange([s.outbox for s in sh], [s.inbox for s in sh])   # EXCHANGE
-                for s in sh:
-                    s.inject(k)
-                comm.allreduce_min([s.gvt_slot(k) for s in sh])        # GVT
-                k += 1
-            wends = [s.progress(k - 1) for s in sh]                    # the only host synchronisation
-            if min(wends) >= end_ns:
-                break
+        if self.rounds:
+            k = self._run_rounds(end_ns)
+            for s in sh:
+                s.final(0)
+        else:
+            while True:
+                for _ in range(self.sync_every):
+                    for s in sh:
+                        s.window(k)                                    # EXECUTE
+                    comm.exchange([s.outbox for s in sh], [s.inbox for s in sh])   # EXCHANGE
+                    for s in sh:
+                        s.inject(k)
+                    comm.allreduce_min([s.gvt_slot(k) for s in sh])    # GVT
+                    k += 1
+                wends = [s.progress(k - 1) for s in sh]                # the only host synchronisation
+                if min(wends) >= end_ns:
+                    break
+            for s in sh:
+                s.final(k)
         self.windows = k
-        for s in sh:
-            s.final(k)
         cands = comm.allgather_rows([s.cand for s in sh])              # [world, 4]: valid, t, t_created, station
         valid = cands[cands[:, 0] != 0]
         winner_t = None

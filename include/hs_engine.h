@@ -267,6 +267,17 @@ int hs_engine_shard_inject(hs_engine *h, int64_t k);
 int hs_engine_shard_progress(hs_engine *h, int64_t k_last, int64_t *window_end_out);
 int hs_engine_shard_final(hs_engine *h, int64_t k);
 int hs_engine_shard_overshoot(hs_engine *h, int32_t lp);
+/* Asynchronous exchange ROUNDS instead of windows (same attach / begin / final / overshoot): every shard runs the
+ * asynchronous engine (per-link lower bounds, hs_net_async) for `max_iters` iterations, then the caller moves the outbox
+ * rows (all-to-all) and all-reduces (MAX) `bounds_dev` -- device int64[n_cross + 1]: the lower bound of every cross-shard
+ * link (network-wide ids in cross_gid, the same list on every rank) and, last, an "I still have work" flag -- and calls
+ * inject_async.  Rounds follow the boundary stations' lookahead (tens of ms of simulated time) instead of the smallest
+ * link latency.  async_done synchronises and reports the all-reduced flag of the last round.
+ *   begin; do { round; <all-to-all>; <all-reduce MAX bounds_dev>; inject_async; } while (any_not_done); final(0); ... */
+int hs_engine_shard_async_setup(hs_engine *h, int32_t n_cross, const int64_t *cross_gid, int64_t *bounds_dev, int32_t max_iters);
+int hs_engine_shard_round(hs_engine *h);
+int hs_engine_shard_inject_async(hs_engine *h);
+int hs_engine_shard_async_done(hs_engine *h, int32_t *any_not_done);
 /* Simulation.__init__ bootstrap (core/simulation.py:145-154): clock to start_ns, every Source draws its
  * first arrival.  Called implicitly by the first run; call again to rewind the engine for another run. */
 int hs_engine_reset(hs_engine *h);

@@ -242,3 +242,30 @@ def test_two_links_per_station_mesh_matches_oracle(engine_flags):
         np.testing.assert_array_equal(ns["link_packets_sent"], r.packets_sent[lnk])
         np.testing.assert_array_equal(ns["link_packets_dropped"], r.dropped[lnk])
         assert ns["link_packets_dropped"].sum() > 100 and s.events_by_kind[7] == 0
+
+
+def test_buffer_deadlock_is_reported_not_spun_on():
+    """20 messages in flight per link (400/s x 50 ms) against 16-entry queues and bags: on a cycle every station ends up
+    waiting for room in its outgoing queue while its own bag is full of messages it may not process yet.  The asynchronous
+    engine reports that within about a second (raise bag_capacity); with room for the traffic it agrees with the windowed
+    engine."""
+    import time
+
+    from happy_simulator_amd import _native as N
+
+    spec = dict(name="deep_links", topology="ring", n=2, ext_rate=400.0, mean=0.001, lat_min=0.05, jitter_mean=None, end_s=2.0,
+                seed=5)
+    eng, p = H.ring_engine_for_spec(spec)
+    with eng:
+        t0 = time.perf_counter()
+        with pytest.raises(N.EngineError, match="bag_capacity"):
+            eng.run_until(p["end_ns"])
+        assert time.perf_counter() - t0 < 10.0
+    res = []
+    for flags in (0, 16):
+        eng, p = H.ring_engine_for_spec(spec, flags=flags, bag_capacity=128)
+        with eng:
+            eng.run_until(p["end_ns"])
+            s = eng.summary()
+            res.append((s.events_processed, s.final_time_ns, tuple(s.events_by_kind), [a.tobytes() for a in eng.read_sinks()]))
+    assert res[0] == res[1] and res[0][0] > 10000

@@ -19,12 +19,12 @@ def _single(spec):
                     sink_records=s.sink_records)
 
 
-def _sharded(spec, world, sync_every=16, msg_capacity=64):
+def _sharded(spec, world, sync_every=16, msg_capacity=64, rounds=True, bag_capacity=0):
     from happy_simulator_amd.sharded import LocalComm, ShardedNetwork
 
-    st, net, cap, p = H.ring_arrays(spec)
+    st, net, cap, p = H.ring_arrays(spec, bag_capacity=bag_capacity)
     sn = ShardedNetwork.on_gpu(st, net, LocalComm(world), horizon_ns=p["end_ns"], seed=spec["seed"], log_capacity=cap,
-                               sync_every=sync_every, msg_capacity=msg_capacity)
+                               sync_every=sync_every, msg_capacity=msg_capacity, rounds=rounds)
     with sn:
         summ = sn.run_until(p["end_ns"])
         stats = {}
@@ -56,11 +56,15 @@ SPECS = [
 ]
 
 
+PROTOCOLS = pytest.mark.parametrize("rounds", [True, False], ids=["async_rounds", "windows"])
+
+
+@PROTOCOLS
 @pytest.mark.parametrize("world", [2, 3, 4])
 @pytest.mark.parametrize("spec", SPECS, ids=[s["name"] for s in SPECS])
-def test_sharded_equals_single_engine(spec, world):
+def test_sharded_equals_single_engine(spec, world, rounds):
     one = _single(spec)
-    summ, stats, netst, sinks = _sharded(spec, world)
+    summ, stats, netst, sinks = _sharded(spec, world, rounds=rounds)
     assert summ.events_processed == one["events"]
     np.testing.assert_array_equal(summ.events_by_kind, one["by_kind"])
     assert summ.final_time_ns == one["final"]
@@ -75,12 +79,13 @@ def test_sharded_equals_single_engine(spec, world):
     assert summ.world == world and summ.windows >= 1
 
 
+@PROTOCOLS
 @pytest.mark.parametrize("name", H.golden_names("ring"))
-def test_sharded_matches_reference_golden(name):
+def test_sharded_matches_reference_golden(name, rounds):
     gold = H.Golden(name)
     spec = gold.spec
     world = 2 if spec["n"] < 6 else 3
-    summ, stats, netst, sinks = _sharded(spec, world, sync_every=8)
+    summ, stats, netst, sinks = _sharded(spec, world, sync_every=8, rounds=rounds)
     assert summ.events_processed == gold.meta["total_events"][0]
     assert summ.final_time_ns == gold.meta["final_ns"][0]
     for k, g in (("generated", "generated"), ("accepted", "accepted"), ("dropped", "dropped"), ("completed", "completed"),
@@ -98,9 +103,12 @@ def test_gvt_windows_skip_idle_time():
     spec = dict(name="sparse", topology="ring", n=16, ext_rate=0.05, mean=0.1, lat_min=0.001, jitter_mean=0.01, end_s=40.0,
                 seed=31)
     one = _single(spec)
-    summ, *_ = _sharded(spec, 2, sync_every=4)
+    summ, *_ = _sharded(spec, 2, sync_every=4, rounds=False)
     assert summ.events_processed == one["events"] and summ.final_time_ns == one["final"]
     assert summ.windows < 0.2 * (40.0 / 0.001)
+    rsum, *_ = _sharded(spec, 2, sync_every=4, rounds=True)              # asynchronous rounds: fewer exchanges still
+    assert rsum.events_processed == one["events"] and rsum.final_time_ns == one["final"]
+    assert rsum.windows < summ.windows
 
 
 def test_exchange_row_overflow_is_reported():
@@ -109,10 +117,17 @@ def test_exchange_row_overflow_is_reported():
     spec = dict(name="tiny_rows", topology="ring", n=2, ext_rate=400.0, mean=0.001, lat_min=0.05, jitter_mean=None,
                 end_s=2.0, seed=5)
     with pytest.raises(N.EngineError, match="overflow"):
-        _sharded(spec, 2, msg_capacity=2)
+        _sharded(spec, 2, msg_capacity=2, rounds=False)
+    # asynchronous rounds size their length to the rows: two messages per iteration fit, so rounds of one iteration ...
+    ref, *_ = _sharded(spec, 2, msg_capacity=256, rounds=False, bag_capacity=128)   # (20 messages in flight per link)
+    summ, *_ = _sharded(spec, 2, msg_capacity=2, rounds=True, bag_capacity=128)
+    assert summ.events_processed == ref.events_processed and summ.final_time_ns == ref.final_time_ns
+    with pytest.raises(ValueError, match="msg_capacity 1 is too small"):       # ... but not even one iteration fits here
+        _sharded(spec, 2, msg_capacity=1, rounds=True)
 
 
-def test_full_station_count_sharded_equals_single_engine():
+@PROTOCOLS
+def test_full_station_count_sharded_equals_single_engine(rounds):
     """BASELINE configs[3] at full size: the 65 536-station ring cut into 4 contiguous segments (virtual shards, the same
     kernels and exchange protocol as one process per GPU over RCCL) for the full 60 simulated seconds = 60 002 GVT-driven
     windows, 2.7e8 events; every total, statistic, link counter and Sink record equals the single-engine run."""
@@ -122,8 +137,9 @@ def test_full_station_count_sharded_equals_single_engine():
                 end_s=60.0, seed=42)
     one = _single(spec)
     t0 = time.perf_counter()
-    summ, stats, netst, sinks = _sharded(spec, 4, sync_every=64)
+    summ, stats, netst, sinks = _sharded(spec, 4, sync_every=64 if not rounds else 8, rounds=rounds)
     wall = time.perf_counter() - t0
+    print(f"4 shards, {'asynchronous rounds' if rounds else 'windows'}: {summ.windows} exchanges, {wall:.2f} s wall")
     assert summ.events_processed == one["events"] and summ.final_time_ns == one["final"]
     np.testing.assert_array_equal(summ.events_by_kind, one["by_kind"])
     for k in ("generated", "accepted", "completed", "total_service_s", "sink_received", "queue_depth", "active", "events"):
@@ -132,6 +148,6 @@ def test_full_station_count_sharded_equals_single_engine():
         np.testing.assert_array_equal(netst[k], one["net"][k], err_msg=k)
     for a, b in zip(sinks, one["sinks"]):
         np.testing.assert_array_equal(a, b)
-    assert summ.world == 4 and 59000 < summ.windows < 60100
+    assert summ.world == 4 and (59000 < summ.windows < 60100 if not rounds else summ.windows < 2000)
     assert 2.5e8 < summ.events_processed < 2.9e8
     assert wall < 240.0
