@@ -61,7 +61,10 @@ def parse():
     ap.add_argument("--lb-vnodes", type=int, default=150)
     ap.add_argument("--lat-min", type=float, default=0.001, help="ring: constant link latency = lookahead (s)")
     ap.add_argument("--jitter", type=float, default=0.01, help="ring: mean of the exponential link jitter (s)")
-    ap.add_argument("--sync-every", type=int, default=256, help="ring, N > 1: windows between host synchronisations")
+    ap.add_argument("--sync-every", type=int, default=0,
+                    help="ring, N > 1: exchanges between host synchronisations (0 = 8 rounds / 256 windows)")
+    ap.add_argument("--ring-windows", action="store_true",
+                    help="ring, N > 1: the windowed protocol (one exchange per 1 ms window) instead of asynchronous rounds")
     return ap.parse_args()
 
 
@@ -120,8 +123,10 @@ def ring_main(args, rank, local_rank, world, distributed, dist):
         info["device_ms_per_step"] = float(np.mean(kernel_ms))
         eng.close()
     else:
+        rounds = not args.ring_windows
         sn = ShardedNetwork.on_gpu(st, net, DistComm(), horizon_ns=end_ns, seed=args.seed, device=local_rank,
-                                   log_capacity=cap, sync_every=args.sync_every)
+                                   log_capacity=cap, sync_every=args.sync_every or (8 if rounds else 256), rounds=rounds)
+        info["exchange_protocol"] = "asynchronous rounds" if rounds else "windows"
         for _ in range(args.warmup):
             sn.run_until(end_ns)
         barrier()
@@ -152,13 +157,17 @@ def ring_main(args, rank, local_rank, world, distributed, dist):
                             f"{args.end_s:g} s simulated, seed {args.seed} (BASELINE configs[2]/[3])",
                 "n_stations": args.n_lp, "events_per_step": events, "requests_per_step": requests,
                 "launches_per_step": windows, "lookahead_ns": window_ns,
-                "parallelism": f"{args.gpus} contiguous ring segment(s); per window: all-to-all of boundary messages + "
-                               "all-reduce(min) GVT over RCCL" if args.gpus > 1 else
+                "parallelism": (f"{args.gpus} contiguous ring segments, each on the asynchronous engine; per exchange round "
+                                f"({windows} per run): all-to-all of boundary messages + all-reduce(max) of the cross links' "
+                                "lower bounds over RCCL" if not args.ring_windows else
+                                f"{args.gpus} contiguous ring segments; per 1 ms window ({windows} per run): all-to-all of boundary "
+                                "messages + all-reduce(min) GVT over RCCL") if args.gpus > 1 else
                                ("1 engine, asynchronous: the whole run in one cooperative launch (hs_net_async) + the election launch"
                                 if windows <= 4 else "1 engine, one launch per window"),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "hs_net_async<1>" if (args.gpus == 1 and windows <= 4) else "hs_net_window<1>",
+                "bound": "hbm", "kernel": "hs_net_async<1>" if ((args.gpus == 1 and windows <= 4) or
+                                                                 (args.gpus > 1 and not args.ring_windows)) else "hs_net_window<1>",
                 "achieved": algo_bytes / step_s / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": algo_bytes / step_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes_per_launch": algo_bytes,

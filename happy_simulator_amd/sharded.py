@@ -19,6 +19,15 @@ stream); the host synchronises once every `sync_every` windows to learn how far 
 
 `LocalComm` runs several shards inside one process on one GPU (virtual shards) with tensor copies in place of
 RCCL -- same protocol, same kernels -- so the sharding logic is testable on a single-GPU box.
+
+**Asynchronous rounds (the default, `rounds=True`).**  The window protocol pays one exchange per smallest link
+latency (60 000 exchanges for 60 s of a ring with 1 ms links).  With rounds, every shard runs the ASYNCHRONOUS engine
+(`hs_net_async`: per-link lower bounds, no windows inside the shard) for a few iterations, then the ranks exchange the
+boundary messages (the same all-to-all) and all-reduce (MAX) one vector: the lower bound of every cross-shard link plus a
+"still working" flag.  A cross link then looks to its destination like any other link of the asynchronous engine -- a
+queue refilled and a bound raised between launches -- and exchange rounds follow the boundary stations' lookahead (their
+next possible completion + the link floor: tens of ms) instead of the link floor alone: 88 exchanges instead of 59 968
+for the 65 536-station ring on 4 shards, the same bits.  `rounds=False` keeps the window protocol.
 """
 from __future__ import annotations
 
@@ -243,10 +252,10 @@ class GpuShard:
         import torch
 
         self.cross_gid = np.ascontiguousarray(cross_gid, np.int64)
-        self.bounds = torch.zeros(len(self.cross_gid) + 1, dtype=torch.int64, device=self.outbox.device)
+        self.xbounds = torch.zeros(len(self.cross_gid) + 1, dtype=torch.int64, device=self.outbox.device)
         e = self.engine
         e._check(e._lib.hs_engine_shard_async_setup(e._h, len(self.cross_gid), self.cross_gid.ctypes.data,
-                                                    self.bounds.data_ptr(), int(max_iters)))
+                                                    self.xbounds.data_ptr(), int(max_iters)))
 
     def round(self):
         e = self.engine
@@ -342,7 +351,7 @@ class ShardedNetwork:
                 for s in sh:
                     s.round()                                          # EXECUTE (one cooperative launch per shard)
                 comm.exchange([s.outbox for s in sh], [s.inbox for s in sh])   # EXCHANGE messages ...
-                comm.allreduce_max([s.bounds for s in sh])             # ... and bounds (+ the "still working" flag)
+                comm.allreduce_max([s.xbounds for s in sh])             # ... and bounds (+ the "still working" flag)
                 for s in sh:
                     s.inject_async()
                 r += 1

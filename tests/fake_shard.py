@@ -86,6 +86,53 @@ class FakeShard:
         self.outbox[:, 0] = 0
         self.gvt[(k + 1) & 1] = INF
 
+    # ---- asynchronous exchange rounds (GpuShard.async_setup / round / inject_async / round_done) -----------------
+    def async_setup(self, cross_gid, max_events):
+        """cross_gid: the links (link i = station i -> i + 1) that cross a shard boundary, the same list on every rank."""
+        self.cross = [int(g) for g in cross_gid]
+        self.xbounds = torch.zeros(len(self.cross) + 1, dtype=torch.int64)
+        self.in_bound = {g: 0 for g in self.cross if self._rank_of((g + 1) % self.n) == self.rank}
+        self.max_events = max_events
+
+    def round(self):
+        # every message a neighbour has not sent yet arrives at or after its link's bound: process strictly below the minimum
+        H = min(self.in_bound.values()) if self.in_bound else INF
+        done = 0
+        while self.heap and self.heap[0][0] < H and self.heap[0][0] <= self.end and done < self.max_events:
+            t, i = heapq.heappop(self.heap)
+            self._process(t, i)
+            done += 1
+            j, ta = (i + 1) % self.n, t + hop_ns(i, self.W)
+            r = self._rank_of(j)
+            if r == self.rank:
+                heapq.heappush(self.heap, (ta, j))
+            else:
+                c = int(self.outbox[r, 0])
+                assert c < self.cap
+                self.outbox[r, 1 + 4 * c:5 + 4 * c] = torch.tensor([ta, t, 0, (j << 32) | i])
+                self.outbox[r, 0] = c + 1
+        nxt = min(self.heap[0][0] if self.heap else INF, H)          # nothing happens here before `nxt`
+        for k, g in enumerate(self.cross):
+            mine = self._rank_of(g) == self.rank
+            self.xbounds[k] = (INF if nxt == INF else nxt + hop_ns(g, self.W)) if mine else -INF - 1
+        self.xbounds[len(self.cross)] = 1 if nxt <= self.end else 0
+        self.launches += 1
+
+    def inject_async(self):
+        for r in range(self.world):
+            for c in range(int(self.inbox[r, 0])):
+                ta, _, _, w3 = (int(x) for x in self.inbox[r, 1 + 4 * c:5 + 4 * c])
+                j = w3 >> 32
+                assert self.lo <= j < self.hi
+                heapq.heappush(self.heap, (ta, j))
+        self.outbox[:, 0] = 0
+        for k, g in enumerate(self.cross):
+            if g in self.in_bound:
+                self.in_bound[g] = int(self.xbounds[k])
+
+    def round_done(self):
+        return int(self.xbounds[len(self.cross)]) == 0
+
     def gvt_slot(self, k):
         return self.gvt[(k & 1):(k & 1) + 1]
 

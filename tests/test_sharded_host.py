@@ -65,7 +65,29 @@ def test_virtual_shards_match_single_heap(world, sync_every):
     assert s.windows % sync_every == 0 and s.world == world
 
 
-def _rank_main(rank, world, port, q):
+def _cross_links(bounds):
+    rank_of = lambda x: int(np.searchsorted(bounds, x, side="right") - 1)        # noqa: E731
+    return [i for i in range(N_ST) if rank_of(i) != rank_of((i + 1) % N_ST)]
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
+@pytest.mark.parametrize("per_round", [1, 4, 1000])
+def test_virtual_shards_with_asynchronous_rounds_match_single_heap(world, per_round):
+    """The round protocol of ShardedNetwork (execute below the cross links' bounds; all-to-all messages; all-reduce MAX
+    bounds + the "still working" flag; inject) -- the host loop the GPU shards run, on the token ring."""
+    ev, last, counts = F.reference_run(N_ST, W, END)
+    b = shard_bounds(N_ST, world)
+    shards = [F.FakeShard(N_ST, r, b, W) for r in range(world)]
+    for sh in shards:
+        sh.async_setup(_cross_links(b), per_round)
+    sn = ShardedNetwork(shards, LocalComm(world), window_ns=W, sync_every=3, rounds=True)
+    s = sn.run_until(END)
+    assert s.events_processed == ev and s.final_time_ns == last
+    np.testing.assert_array_equal(np.concatenate([sh.counts for sh in shards]), counts)
+    assert s.windows % 3 == 0 and s.world == world
+
+
+def _rank_main(rank, world, port, q, rounds=False):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -74,21 +96,24 @@ def _rank_main(rank, world, port, q):
     comm = DistComm()
     b = shard_bounds(N_ST, world)
     shard = F.FakeShard(N_ST, rank, b, W)
-    sn = ShardedNetwork([shard], comm, window_ns=W, sync_every=5)
+    if rounds:
+        shard.async_setup(_cross_links(b), 6)
+    sn = ShardedNetwork([shard], comm, window_ns=W, sync_every=5, rounds=rounds)
     s = sn.run_until(END)
     q.put((rank, s.events_processed, s.final_time_ns, s.windows, shard.counts.tolist(), shard.events))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_process_gloo_run_matches_single_heap():
+@pytest.mark.parametrize("rounds", [False, True], ids=["windows", "async_rounds"])
+def test_two_process_gloo_run_matches_single_heap(rounds):
     import torch.multiprocessing as mp
 
     ev, last, counts = F.reference_run(N_ST, W, END)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + ((os.getpid() * 7) % 2000)
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + ((os.getpid() * 7 + (991 if rounds else 0)) % 2000)
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q, rounds)) for r in range(2)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=180) for _ in range(2))
