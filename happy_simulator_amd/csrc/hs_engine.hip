@@ -508,7 +508,8 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST> &S, const StationPa
     S.bag_n = NX.bag_cnt[lp];
     if constexpr (FAST) {
         // (S.fl was set by the caller.)  The bag moves into LDS for the lifetime of the kernel ...
-        for (int i = 0; i < S.bag_n && i < kLBag; ++i) {      // (entries beyond kLBag stay where they are)
+        if (S.bag_n > kLBag) { S.bagoverflow = 1; S.bag_n = kLBag; }   // (a fresh run starts with empty bags)
+        for (int i = 0; i < S.bag_n; ++i) {
             const size_t b = (size_t)lp * NX.bag_cap + i;
             S.bg_set(i, NX.bag_t[b], NX.bag_ts[b], NX.bag_cr[b], NX.bag_link[b]);
         }
@@ -557,7 +558,7 @@ __device__ __forceinline__ void store_net(NetStation<C, FAST> &S, const StationS
     // draws CONSUMED (pre-drawn values still in the FAST rings are dropped: pure functions of the index)
     X.arr_k[lp] = S.arr_consumed(); X.svc_k[lp] = S.svc_consumed(); NX.route_k[lp] = S.rte_consumed();
     if constexpr (FAST) {
-        for (int i = 0; i < S.bag_n && i < kLBag; ++i) {
+        for (int i = 0; i < S.bag_n; ++i) {
             const size_t b = (size_t)lp * NX.bag_cap + i;
             NX.bag_t[b] = S.bg_t(i); NX.bag_ts[b] = S.bg_ts(i); NX.bag_cr[b] = S.bg_cr(i); NX.bag_link[b] = S.bg_link(i);
         }

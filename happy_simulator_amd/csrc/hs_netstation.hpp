@@ -215,14 +215,18 @@ struct NetStation {
 
     // ---- bag (pending inbound messages of this LP; global memory, owner-only)
     __device__ __forceinline__ size_t bidx(int i) const { return (size_t)lp * ns->bag_cap + i; }
-    // FAST: entries 0 .. kLBag-1 live in LDS, the (rarely used) rest of the bag at the same index in global memory
-    __device__ __forceinline__ int bag_capacity() const { return ns->bag_cap; }
-    __device__ __forceinline__ int64_t bg_t(int i) const { if (FAST && i < kLBag) return fl.bag_t[i][tid]; return ns->bag_t[bidx(i)]; }
-    __device__ __forceinline__ int64_t bg_ts(int i) const { if (FAST && i < kLBag) return fl.bag_ts[i][tid]; return ns->bag_ts[bidx(i)]; }
-    __device__ __forceinline__ int64_t bg_cr(int i) const { if (FAST && i < kLBag) return fl.bag_cr[i][tid]; return ns->bag_cr[bidx(i)]; }
-    __device__ __forceinline__ int32_t bg_link(int i) const { if (FAST && i < kLBag) return fl.bag_link[i][tid]; return ns->bag_link[bidx(i)]; }
+    // FAST: the bag lives in LDS (kLBag entries); when it is full, further messages wait in their link's queue, whose
+    // capacity follows bag_capacity (async_receive / `undrained`)
+    __device__ __forceinline__ int bag_capacity() const {
+        if constexpr (FAST) return kLBag < ns->bag_cap ? kLBag : ns->bag_cap;
+        else return ns->bag_cap;
+    }
+    __device__ __forceinline__ int64_t bg_t(int i) const { if constexpr (FAST) return fl.bag_t[i][tid]; else return ns->bag_t[bidx(i)]; }
+    __device__ __forceinline__ int64_t bg_ts(int i) const { if constexpr (FAST) return fl.bag_ts[i][tid]; else return ns->bag_ts[bidx(i)]; }
+    __device__ __forceinline__ int64_t bg_cr(int i) const { if constexpr (FAST) return fl.bag_cr[i][tid]; else return ns->bag_cr[bidx(i)]; }
+    __device__ __forceinline__ int32_t bg_link(int i) const { if constexpr (FAST) return fl.bag_link[i][tid]; else return ns->bag_link[bidx(i)]; }
     __device__ __forceinline__ void bg_set(int i, int64_t t, int64_t ts, int64_t cr, int32_t l) {
-        if (FAST && i < kLBag) { fl.bag_t[i][tid] = t; fl.bag_ts[i][tid] = ts; fl.bag_cr[i][tid] = cr; fl.bag_link[i][tid] = l; }
+        if constexpr (FAST) { fl.bag_t[i][tid] = t; fl.bag_ts[i][tid] = ts; fl.bag_cr[i][tid] = cr; fl.bag_link[i][tid] = l; }
         else { const size_t d = bidx(i); ns->bag_t[d] = t; ns->bag_ts[d] = ts; ns->bag_cr[d] = cr; ns->bag_link[d] = l; }
     }
     // earliest arrival in the bag, kept in a register (`bmin`): next_time() runs several times per step and a scan of the
