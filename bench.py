@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--lat-min", type=float, default=0.001, help="ring: constant link latency = lookahead (s)")
     ap.add_argument("--jitter", type=float, default=0.01, help="ring: mean of the exponential link jitter (s)")
     ap.add_argument("--sync-every", type=int, default=0,
-                    help="ring, N > 1: exchanges between host synchronisations (0 = 8 rounds / 256 windows)")
+                    help="ring, N > 1: exchanges between host synchronisations (0 = 4 rounds / 256 windows)")
     ap.add_argument("--ring-windows", action="store_true",
                     help="ring, N > 1: the windowed protocol (one exchange per 1 ms window) instead of asynchronous rounds")
     return ap.parse_args()
@@ -125,7 +125,7 @@ def ring_main(args, rank, local_rank, world, distributed, dist):
     else:
         rounds = not args.ring_windows
         sn = ShardedNetwork.on_gpu(st, net, DistComm(), horizon_ns=end_ns, seed=args.seed, device=local_rank,
-                                   log_capacity=cap, sync_every=args.sync_every or (8 if rounds else 256), rounds=rounds)
+                                   log_capacity=cap, sync_every=args.sync_every or (4 if rounds else 256), rounds=rounds)
         info["exchange_protocol"] = "asynchronous rounds" if rounds else "windows"
         for _ in range(args.warmup):
             sn.run_until(end_ns)

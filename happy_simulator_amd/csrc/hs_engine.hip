@@ -1810,7 +1810,7 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     ALN(in_cnt, 2 * N); ALN(in_t, 2 * NB); ALN(in_ts, 2 * NB); ALN(in_cr, 2 * NB); ALN(in_link, 2 * NB);
     int aqc = 1;
     while (aqc < bag) aqc <<= 1;      // a power of two: queue slots are addressed with a mask, not a 64-bit modulo
-    if (global && aqc < 64) aqc = 64; // a shard's incoming cross links are filled a whole exchange round at a time
+    if (global && aqc < 256) aqc = 256; // a shard's incoming cross links are filled a whole exchange round at a time
     h->NX.aq_cap = aqc;
     h->NX.aq_on = 0;
     if (nl > 0) {
