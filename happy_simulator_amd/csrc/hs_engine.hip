@@ -890,9 +890,6 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
 #ifdef HS_CYCLES   // tools/cycles.py --ring: cycles in receive / bound scan / group processing / publication
         unsigned long long cyc[4] = {0, 0, 0, 0};
 #endif
-#ifdef HS_TRIPS
-        unsigned long long trips = 0;
-#endif
         for (unsigned iter = 0;; ++iter) {
             n_iter = iter + 1;
             S.top_up(!done, group_cap < 4 ? group_cap : 4);           // whole wavefront: refill the pre-drawn values
@@ -955,9 +952,6 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                     if constexpr (C == 1) S.step1(t, force_general);
                     else S.run_group(t, force_general);
                     ++n_groups;
-#ifdef HS_TRIPS       // experiment: wave-level trips of this loop (counted by the first active lane) instead of publish cycles
-                    if ((__ffsll((unsigned long long)__ballot(1)) - 1) == lane) ++trips;
-#endif
                 }
 #ifdef HS_CYCLES
                 q3 = __builtin_readcyclecounter();
@@ -996,11 +990,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             {
                 const unsigned long long q4 = __builtin_readcyclecounter();
                 cyc[0] += q1 - q0; cyc[1] += q2 - q1; cyc[2] += q3 - q2;
-#ifndef HS_TRIPS
                 cyc[3] += q4 - q3;
-#else
-                (void)q4;
-#endif
             }
 #endif
             if (__all(done)) break;
@@ -1024,16 +1014,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         store_net<C, true>(S, X, NX, lp, n);
         if (max_iters > 0 && !done) atomicAdd(&tot->not_done, 1ull);
 #ifdef HS_CYCLES
-#ifdef HS_STEP
-        // every lane's own view: head / commit cycles summed over lanes (divide by groups), slow groups
-        atomicAdd(&tot->dbg[0], S.cy_head); atomicAdd(&tot->dbg[1], S.cy_commit); atomicAdd(&tot->dbg[3], S.n_slow);
-        if ((tid & 63) == 0) atomicAdd(&tot->dbg[2], cyc[2]);
-#else
         if ((tid & 63) == 0) for (int k = 0; k < 4; ++k) atomicAdd(&tot->dbg[k], cyc[k]);
-#endif
-#ifdef HS_TRIPS
-        atomicAdd(&tot->dbg[3], trips);      // (on top of lane 0's publish cycles: read it as trips when HS_TRIPS is on)
-#endif
 #else
         atomicAdd(&tot->dbg[2], (unsigned long long)n_groups);
         if ((tid & 63) == 0) {

@@ -181,9 +181,6 @@ struct NetStation {
     Stream jit;
     int32_t fi_link;              // the LP's only incoming link (-1: none or several): its packets_sent counter in a register
     int64_t fi_packets;
-#ifdef HS_STEP                    // tools/cycles.py: cycles in step1's decision part / commit part, slow-path groups
-    unsigned long long cy_head = 0, cy_commit = 0, n_slow = 0;
-#endif
     // in-group FIFO + ENQ payloads (LDS columns)
     uint8_t (*qmem)[kBlock];
     int64_t (*enqpay)[kBlock];
@@ -653,9 +650,6 @@ struct NetStation {
     // link).  Event counts, statistics, creation stamps and draw consumption are exactly run_group()'s.
     __device__ __forceinline__ void step1(int64_t t, bool force_general) {
         static_assert(C == 1, "step1 is the single-worker specialisation");
-#ifdef HS_STEP
-        const unsigned long long z0 = __builtin_readcyclecounter();
-#endif
         const bool tick = (A == t), dep = (D[0] == t);
         int cnt = (tick ? 1 : 0) + (dep ? 1 : 0), mi = 0;
         if (bmin == t)
@@ -682,11 +676,6 @@ struct NetStation {
         const bool slow = force_general || cnt != 1 || (tick && (a2 <= t || (poisson && na == 0))) ||
                           (deliver && (dur == 0 || (svc_exp && nsv == 0))) || (dep && router && rn == 0) ||
                           (to_link && (target != fl_link || fl_loss > 0.0 || (fl_jit == 0 && nj == 0)));
-#ifdef HS_STEP
-        const unsigned long long z1 = __builtin_readcyclecounter();
-        cy_head += z1 - z0;
-        if (slow) ++n_slow;
-#endif
         if (slow) { run_group(t, force_general); return; }
         // ---- Source.handle_event
         ev[0] += tick; generated += tick;
@@ -708,9 +697,7 @@ struct NetStation {
         ev[1] += arrv;
         dropped += (arrv && !acc) ? 1 : 0;
         if (acc) {
-#ifndef HS_EXP_NOLOG
             if (accepted < cap) adm[accepted * ls] = created_in; else overflow = 1;
-#endif
             fl.crc[accepted & (kNRing - 1)][tid] = created_in;
         }
         accepted += acc;
@@ -727,9 +714,7 @@ struct NetStation {
         }
         if (to_sink) {
             ev[7]++;
-#ifndef HS_EXP_NOLOG
             if (received < cap) { sink_t[received * ls] = t; sink_created[received * ls] = created_out; } else overflow = 1;
-#endif
             received++;
         }
         if (to_link) {                                                // send_link_fast without the loss branch
@@ -763,9 +748,6 @@ struct NetStation {
             if (svc_exp) { hs_ = (hs_ + 1) & (kNRing - 1); --nsv; }
         }
         last_time = t;
-#ifdef HS_STEP
-        cy_commit += __builtin_readcyclecounter() - z1;
-#endif
     }
 
     __device__ __forceinline__ void run_group(int64_t t, bool force_general) {

@@ -403,6 +403,26 @@ class ShardedNetwork:
                               requests_completed=int(tot["completed"]), sink_records=int(tot["sink_records"]),
                               final_time_ns=final, windows=k, window_ns=self.window_ns, world=comm.world)
 
+    def collect(self, n_stations: int, n_links: int):
+        """Whole-network results from this process's shards, as one engine would report them: (lp_stats dict, sink counts,
+        sink t, sink created_at, net_stats dict).  Per-link counters are summed over the two ends' shards (each end keeps
+        the counters it owns, the other end reports 0)."""
+        stats, counts, ts, crs = {}, np.zeros(n_stations, np.int64), [], []
+        net = {"routed": np.zeros(n_stations, np.int64), "link_entered": np.zeros(n_links, np.int64),
+               "link_packets_sent": np.zeros(n_links, np.int64), "link_packets_dropped": np.zeros(n_links, np.int64)}
+        for s in sorted(self.shards, key=lambda x: x.lo):
+            for k, v in s.engine.lp_stats().items():
+                stats.setdefault(k, np.zeros(n_stations, v.dtype))[s.lo:s.hi] = v
+            c, t, cr = s.engine.read_sinks()
+            counts[s.lo:s.hi] = c
+            ts.append(t)
+            crs.append(cr)
+            ns = s.engine.net_stats()
+            net["routed"][s.lo:s.hi] = ns["routed"]
+            for k in ("link_entered", "link_packets_sent", "link_packets_dropped"):
+                net[k][s.gids] += ns[k]
+        return stats, counts, np.concatenate(ts), np.concatenate(crs), net
+
     def close(self):
         for s in self.shards:
             s.close()

@@ -147,6 +147,8 @@ class Simulation:
         horizon_s = (end_ns - self._start_time.nanoseconds) / 1e9
         arrays = g.arrays()
         cancelled_ns = self._schedule_arrays(g, arrays)
+        if net is not None and arrays.n > self._resident_stations():
+            return self._run_time_shared(g, arrays, net, end_ns, horizon_s, wall0)
         with StationEngine(arrays, mode=N.MODE_SINGLE, horizon_ns=end_ns, start_ns=self._start_time.nanoseconds,
                            seed=self._seed, device=self._device, network=net,
                            log_capacity=g.log_capacity(horizon_s) if net is not None else 0) as eng:
@@ -162,6 +164,31 @@ class Simulation:
         # heap when the run ended with nothing left beyond end_time (core/simulation.py:472-477)
         drained = es.final_time_ns <= end_ns
         self._events_cancelled = sum(1 for t in cancelled_ns if drained or t <= es.final_time_ns)
+        self._engine_summary = es
+        self._events_processed = es.events_processed
+        self._current_time = Instant(es.final_time_ns)
+        self._summary = self._build_summary(_time.monotonic() - wall0)
+        return self._summary
+
+    def _resident_stations(self) -> int:
+        """Stations one cooperative launch of the asynchronous network engine holds: one 256-lane workgroup per CU (its
+        LDS rings and bags fill the CU)."""
+        import torch
+
+        return torch.cuda.get_device_properties(self._device).multi_processor_count * 256
+
+    def _run_time_shared(self, g, arrays, net, end_ns: int, horizon_s: float, wall0: float) -> SimulationSummary:
+        """A network with more stations than one cooperative launch holds: contiguous segments take turns on the device
+        under the asynchronous-rounds protocol of the multi-GPU path (happy_simulator_amd/sharded.py) -- the same bits as
+        one engine, a few dozen rounds instead of tens of thousands of windows."""
+        from .sharded import LocalComm, ShardedNetwork
+
+        world = -(-arrays.n // self._resident_stations())
+        with ShardedNetwork.on_gpu(arrays, net, LocalComm(world), horizon_ns=end_ns, start_ns=self._start_time.nanoseconds,
+                                   seed=self._seed, device=self._device, log_capacity=g.log_capacity(horizon_s)) as sn:
+            es = sn.run_until(end_ns)
+            stats, counts, t_ns, created_ns, net_stats = sn.collect(arrays.n, net.n_links)
+        write_back(g, stats, counts, t_ns, created_ns, net_stats, device=self._device)
         self._engine_summary = es
         self._events_processed = es.events_processed
         self._current_time = Instant(es.final_time_ns)

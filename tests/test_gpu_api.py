@@ -415,3 +415,29 @@ def test_one_sink_behind_several_servers_matches_reference_golden():
     st = sink.latency_stats()
     assert st["count"] == len(gold.sink_t_ns) and st["max"] == gold.sink_latency_s.max()
     assert summary.entities["sink"].events_handled == gold.received[0]
+
+
+def test_network_larger_than_one_cooperative_launch_is_time_shared(monkeypatch):
+    """More stations than one cooperative launch of the asynchronous engine holds (65 536 on an MI355X): Simulation.run()
+    lets contiguous segments take turns on the device under the asynchronous-rounds protocol.  Forced here with a small
+    capacity: every object of a 1 500-station ring ends up exactly as after the single-launch run."""
+    spec = dict(n=1500, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, loss=0.1)
+
+    def run(limit):
+        if limit:
+            monkeypatch.setattr(hs.Simulation, "_resident_stations", lambda self: limit)
+        sources, servers, routers, links, sinks = _build_ring(spec)
+        sim = hs.Simulation(end_time=Instant.from_seconds(6.0), sources=sources, entities=servers + routers + links + sinks,
+                            seed=77)
+        summary = sim.run()
+        monkeypatch.undo()
+        return (summary.total_events_processed, summary.duration_s,
+                [s.stats_accepted for s in servers], [s.stats.requests_completed for s in servers],
+                [s.stats.total_service_time for s in servers], [r.stats_routed for r in routers],
+                [l.packets_sent for l in links], [l.packets_dropped for l in links],
+                [k.events_received for k in sinks], [x for k in sinks for x in k.latencies_s])
+
+    whole = run(0)
+    shared = run(400)                    # 4 segments of <= 400 stations
+    assert whole == shared
+    assert whole[0] > 100_000 and sum(whole[7]) > 0
