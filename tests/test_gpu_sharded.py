@@ -151,3 +151,47 @@ def test_full_station_count_sharded_equals_single_engine(rounds):
     assert summ.world == 4 and (59000 < summ.windows < 60100 if not rounds else summ.windows < 200)
     assert 2.5e8 < summ.events_processed < 2.9e8
     assert wall < 240.0
+
+
+@PROTOCOLS
+@pytest.mark.parametrize("world", [2, 5])
+def test_sharded_mesh_with_two_links_per_station(world, rounds):
+    """An irregular network: every station's RandomRouter chooses between links to the next and to the station seven
+    further on (lossy, different jitters), c = 2 with bounded queues on every third station -- most links cross a shard
+    boundary somewhere, several per pair of shards.  Both shard protocols against the single windowed engine."""
+    from happy_simulator_amd import _native as N
+    from happy_simulator_amd.engine import NetworkArrays, StationArrays, StationEngine
+    from happy_simulator_amd.sharded import LocalComm, ShardedNetwork
+
+    n, end_ns, seed = 61, 7_000_000_000, 29
+    rates = np.array([2.0 + (i % 4) if i % 5 else 0.0 for i in range(n)])
+    st = StationArrays(
+        n=n, src_kind=np.where(rates > 0, N.SRC_POISSON, N.SRC_NONE).astype(np.uint8), src_rate=np.where(rates > 0, rates, 1.0),
+        src_stop_after_ns=np.full(n, -1, np.int64), concurrency=np.array([2 if i % 3 == 0 else 1 for i in range(n)], np.int32),
+        svc_kind=np.full(n, N.LAT_EXPONENTIAL, np.uint8), svc_mean_s=np.full(n, 0.04),
+        queue_cap=np.array([3 if i % 3 == 0 else -1 for i in range(n)], np.int64), egress=np.full(n, N.EGRESS_NONE, np.uint8))
+    net = NetworkArrays(
+        egress_kind=np.full(n, N.EGRESS_ROUTER, np.uint8), router_target0=np.arange(0, 2 * n, 2, dtype=np.int32),
+        router_target1=np.arange(1, 2 * n, 2, dtype=np.int32), link_of=np.full(n, -1, np.int32),
+        link_src=np.repeat(np.arange(n), 2).astype(np.int32),
+        link_dst=np.array([(i + (1 if l == 0 else 7)) % n for i in range(n) for l in range(2)], np.int32),
+        link_lat_min_s=np.array([0.001 + 0.0005 * (l % 3) for l in range(2 * n)]),
+        link_jitter_kind=np.array([N.LAT_EXPONENTIAL if l % 2 else N.LAT_CONSTANT for l in range(2 * n)], np.uint8),
+        link_jitter_mean_s=np.array([0.003 if l % 2 else 0.0 for l in range(2 * n)]),
+        link_stream_base=np.arange(500, 500 + 2 * n, dtype=np.uint64),
+        link_loss_rate=np.array([0.4 + 0.02 * (l % 6) for l in range(2 * n)]))
+    with StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=end_ns, seed=seed, log_capacity=1024, network=net) as eng:
+        eng.set_debug_flags(16)                                   # the windowed engine, one device
+        eng.run_until(end_ns)
+        s = eng.summary()
+        one = (s.events_processed, s.final_time_ns, tuple(s.events_by_kind), {k: v.tobytes() for k, v in eng.lp_stats().items()},
+               {k: v.tobytes() for k, v in eng.net_stats().items()})
+    sn = ShardedNetwork.on_gpu(st, net, LocalComm(world), horizon_ns=end_ns, seed=seed, log_capacity=1024, msg_capacity=2048,
+                               rounds=rounds)
+    with sn:
+        summ = sn.run_until(end_ns)
+        stats, counts, t, cr, netst = sn.collect(n, 2 * n)
+    assert (summ.events_processed, summ.final_time_ns, tuple(summ.events_by_kind)) == one[:3]
+    assert {k: v.tobytes() for k, v in stats.items()} == one[3]
+    assert {k: v.tobytes() for k, v in netst.items()} == one[4]
+    assert summ.events_processed > 5000
