@@ -504,7 +504,7 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST> &S, const StationPa
     S.tid = tid;
     S.inc_const = __ddiv_rn(1.0, S.rate);
     S.ha = S.na = S.hs_ = S.nsv = S.hj = S.nj = S.rn = 0; S.rbits = 0; S.fl_link = -1; S.fi_link = -1; S.fi_packets = 0;
-    S.fl_remote = false;
+    S.fl_remote = false; S.fi_head = 0;
     S.bag_n = NX.bag_cnt[lp];
     if constexpr (FAST) {
         // (S.fl was set by the caller.)  The bag moves into LDS for the lifetime of the kernel ...
@@ -529,6 +529,7 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST> &S, const StationPa
         if (NP.in_off[lp + 1] - NP.in_off[lp] == 1) {          // ... and the counter of its only incoming link
             S.fi_link = NP.in_links[NP.in_off[lp]];
             S.fi_packets = NX.link_packets[S.fi_link];
+            S.fi_head = NX.aq_head[S.fi_link];
         }
         // the created_at cache starts cold: requests admitted before this launch are read from the log
         for (int i = 0; i < kNRing; ++i) {

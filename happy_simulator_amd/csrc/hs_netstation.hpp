@@ -181,6 +181,7 @@ struct NetStation {
     Stream jit;
     int32_t fi_link;              // the LP's only incoming link (-1: none or several): its packets_sent counter in a register
     int64_t fi_packets;
+    unsigned long long fi_head;   // ... and this LP's position in that link's queue (the only writer of aq_head[fi_link])
     // in-group FIFO + ENQ payloads (LDS columns)
     uint8_t (*qmem)[kBlock];
     int64_t (*enqpay)[kBlock];
@@ -522,7 +523,36 @@ struct NetStation {
 
     // ---- asynchronous engine -----------------------------------------------------------------
     // take delivery of everything the incoming links hold; returns min over those links of aq_ea (kInfNs: no in-links)
+    // one incoming link (FAST): its id and this LP's queue position are in registers, so the only global round trip is
+    // the (bound, tail) pair.  (Loading that pair ahead of time, before this wavefront's publication drains, is NOT safe:
+    // the in-wavefront scan hands a lane its neighbour's bound from the neighbour's CURRENT state, and the messages that
+    // state has already sent are only guaranteed to be behind a tail read after the neighbour's drains.)
+    __device__ __forceinline__ int64_t async_receive_one() {
+        const int l = fi_link;
+        const int64_t ea = ag_load(&ns->aq_ea[l]);                     // bound BEFORE tail, as in async_receive
+        const unsigned long long tail = ag_load(&ns->aq_tail[l]);
+        undrained = kInfNs;
+        unsigned long long head = fi_head;
+        if (head != tail) {
+            const int bcap = bag_capacity();
+            for (; head < tail && bag_n < bcap; ++head) {
+                const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
+                const int64_t ta = ag_load(&ns->aq_t[slot]);
+                bmin = ta < bmin ? ta : bmin;
+                bg_set(bag_n, ta, ag_load(&ns->aq_ts[slot]), ag_load(&ns->aq_cr[slot]), l);
+                ++bag_n;
+            }
+            fi_head = head;
+            ag_store(&ns->aq_head[l], head);
+            if (head < tail) {
+                const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
+                undrained = ag_load(&ns->aq_ts[slot]) + np->link_lat_ns[l];
+            }
+        }
+        return ea;
+    }
     __device__ __forceinline__ int64_t async_receive() {
+        if constexpr (FAST) { if (fi_link >= 0) return async_receive_one(); }
         int64_t H = kInfNs;
         undrained = kInfNs;
         const int a = np->in_off[lp], b = np->in_off[lp + 1];
