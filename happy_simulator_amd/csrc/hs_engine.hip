@@ -258,6 +258,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
             p_arr = first_probe_tick(P.probe_rate[lp], start_ns);
             PA = p_arr;
         }
+        if (NX.next_time != nullptr && PA < A) NX.next_time[lp] = PA;   // network engine: the LP's first pending event
         X.PA[lp] = PA; X.seqP[lp] = 1; X.crtP[lp] = start_ns; X.p_arr[lp] = p_arr; X.p_n[lp] = 0;
         X.ev_probe[lp] = 0; X.ev_probe[(size_t)n + lp] = 0;
         X.seq[lp] = 2;
@@ -503,6 +504,15 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST> &S, const StationPa
     S.np = &NP; S.ns = &NX; S.send_idx = send_idx;
     S.tid = tid;
     S.inc_const = __ddiv_rn(1.0, S.rate);
+    S.p_metric = kProbeNone; S.PA = kInfNs; S.evp[0] = S.evp[1] = 0; S.p_n = 0; S.pcap = 0; S.seqP = 0; S.crtP = 0; S.p_arr = 0;
+    S.p_rate = 1.0; S.probe_t = nullptr; S.probe_v = nullptr;
+    if constexpr (!FAST) {
+        if (X.PA != nullptr) {      // probes on a network: windowed engine only
+            S.p_metric = P.probe_metric[lp]; S.p_rate = P.probe_rate[lp];
+            S.PA = X.PA[lp]; S.seqP = X.seqP[lp]; S.crtP = X.crtP[lp]; S.p_arr = X.p_arr[lp]; S.p_n = X.p_n[lp];
+            S.probe_t = L.probe_t + lp; S.probe_v = L.probe_v + lp; S.pcap = L.pcap;
+        }
+    }
     S.ha = S.na = S.hs_ = S.nsv = S.hj = S.nj = S.rn = 0; S.rbits = 0; S.fl_link = -1; S.fi_link = -1; S.fi_packets = 0;
     S.fl_remote = false; S.fi_head = 0;
     S.bag_n = NX.bag_cnt[lp];
@@ -572,6 +582,13 @@ __device__ __forceinline__ void store_net(NetStation<C, FAST> &S, const StationS
     NX.bag_cnt[lp] = S.bag_n;
     NX.next_time[lp] = S.next_time();
     uint32_t tot = 0;
+    if constexpr (!FAST) {
+        if (X.PA != nullptr) {
+            X.PA[lp] = S.PA; X.seqP[lp] = S.seqP; X.crtP[lp] = S.crtP; X.p_arr[lp] = S.p_arr; X.p_n[lp] = S.p_n;
+            X.ev_probe[lp] += S.evp[0]; X.ev_probe[(size_t)n + lp] += S.evp[1];
+            tot += S.evp[0] + S.evp[1];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 11; ++k) { if (S.ev[k]) X.ev_kind[(size_t)k * n + lp] += S.ev[k]; tot += S.ev[k]; }
     X.events[lp] += tot;
@@ -689,6 +706,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
                 mine.t = t; mine.valid = 1;
                 if (w == 1) mine.t_created = S.crtA;
                 else if (w >= 64) mine.t_created = NX.bag_ts[(size_t)lp * NX.bag_cap + (w - 64)];
+                else if (w == 63) mine.t_created = S.crtP;
                 else {
 #pragma unroll
                     for (int i = 0; i < C; ++i) if (i == w - 2) mine.t_created = S.crtD[i];
@@ -714,6 +732,8 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
         if (S.bagoverflow) red_flags[2] = 1;
     }
     if (merge_overflow) red_flags[2] = 1;
+    if (act && S.evp[0]) atomicAdd(&tot->ev[13], (unsigned long long)S.evp[0]);    // probe events straight to the totals (rare LPs)
+    if (act && S.evp[1]) atomicAdd(&tot->ev[14], (unsigned long long)S.evp[1]);
     if (SC.wend_slots != nullptr && live) atomicMin(&red_gvt, (long long)nt);
     if (final_launch) {
         const Candidate w = wave_min_cand(mine);
@@ -779,10 +799,12 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
             const int w = W.pick_root(t);
             if (w == 1) (void)W.do_tick(t);
             else if (w >= 64) (void)W.do_msg(w - 64, t);
+            else if (w == 63) W.root_probe(t);                 // the SourceEvent of the Probe; its probe_event stays unprocessed
             else (void)W.do_cont_core(w - 2, t);
             W.last_time = t;
             store_net<C>(W, X, NX, b.lp, n);
             for (int k = 0; k < 11; ++k) if (W.ev[k]) atomicAdd(&tot->ev[k], (unsigned long long)W.ev[k]);
+            if (W.evp[0]) atomicAdd(&tot->ev[13], (unsigned long long)W.evp[0]);
             if (W.ev[6]) atomicAdd(&tot->completed, (unsigned long long)W.ev[6]);
             new_cur = b.t;
             atomicMax(&tot->final_time, new_cur);
@@ -1222,6 +1244,7 @@ struct hs_engine {
     Totals *tot = nullptr;
     Candidate *cands = nullptr;
     bool is_net = false;
+    bool any_timevarying = false, any_sched = false;   // (subsets of any_profile: what a network does not lower)
     bool any_profile = false;  // some source has a time-varying rate profile (or a probe: same kernel instantiation)
     bool any_probe = false;
     NetParams NP{};
@@ -1521,6 +1544,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if (k == 1 && !(q[0] > 0.0)) return fail(h, HS_E_INVALID, "LP %d: LinearRampProfile needs duration_s > 0", i);
         pk[(size_t)i] = (uint8_t)k;
         h->any_profile = true;
+        h->any_timevarying = true;
     }
     // Probes (instrumentation/probe.py:81-164): at most one per LP; rate = 1.0 / interval as the reference computes it
     std::vector<uint8_t> pm((size_t)n, (uint8_t)255);
@@ -1558,7 +1582,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
             if (b - a > max_sched) max_sched = b - a;
         }
         n_sched = st->sched_off[n];
-        if (n_sched > 0) h->any_profile = true;
+        if (n_sched > 0) { h->any_profile = true; h->any_sched = true; }
     }
     h->C = maxc <= 1 ? 1 : maxc <= 2 ? 2 : maxc <= 4 ? 4 : maxc <= 8 ? 8 : 16;
     int64_t cap = h->cfg.log_capacity;
@@ -1635,7 +1659,10 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     if (h->initialised) return fail(h, HS_E_STATE, "set the network before the first run");
     if (h->cfg.mode != HS_MODE_SINGLE) return fail(h, HS_E_INVALID, "a network of stations is one Simulation: HS_MODE_SINGLE");
     if (h->C > 4) return fail(h, HS_E_UNSUPPORTED, "networked stations support concurrency <= 4 for now");
-    if (h->any_profile) return fail(h, HS_E_UNSUPPORTED, "time-varying rate profiles, probes and scheduled Requests are not lowered for networked stations yet");
+    if (h->any_timevarying || h->any_sched)
+        return fail(h, HS_E_UNSUPPORTED, "time-varying rate profiles and scheduled Requests are not lowered for networked stations yet");
+    if (h->any_probe && net->n_global_lp > 0)
+        return fail(h, HS_E_UNSUPPORTED, "probes are not lowered for a sharded network yet");
     HS_HIP(h, hipSetDevice(h->cfg.device));
     const int n = h->cfg.n_lp, nl = net->n_links;
     if (nl < 0) return fail(h, HS_E_INVALID, "n_links < 0");
@@ -1798,7 +1825,8 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     if (nl > 0) {
         const size_t NQ = NL * (size_t)aqc;
         ALN(aq_t, NQ); ALN(aq_ts, NQ); ALN(aq_cr, NQ); ALN(aq_tail, NL); ALN(aq_head, NL); ALN(aq_ea, NL);
-        h->async_ok = !global;        // the whole network in one cooperative launch; shards: hs_engine_shard_round
+        h->async_ok = !global && !h->any_probe;   // the whole network in one cooperative launch (shards: hs_engine_shard_round);
+                                                  // probes sample inside the windowed engine's groups
     }
 #undef ALN
     if (!h->L.sink_created_own) {   // not every completion reaches the Sink any more: explicit created_at column

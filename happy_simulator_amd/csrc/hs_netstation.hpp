@@ -111,6 +111,16 @@ __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0
 
 constexpr int kEnqPay = 8;   // ENQ payload FIFO depth (general path only)
 
+// Next tick of a Probe: the general numerical path of ArrivalTimeProvider (adaptive Simpson + Brent, hs_profile.hpp) over
+// _ProbeProfile(interval).  Deliberately NOT inlined: its explicit recursion stack (4 KB of scratch per lane) inside the
+// register-starved network kernels made hs_net_window<2> misbehave; as a callee it has its own frame and is only entered
+// by the rare lane that owns a probe.
+__device__ __noinline__ inline int64_t probe_next_tick(double rate, int64_t from_ns) {
+    Profile pp;
+    pp.kind = kProfGeneralConstant; pp.p0 = rate; pp.p1 = pp.p2 = pp.p3 = 0.0;
+    return prof_next_arrival(pp, from_ns, 1.0);
+}
+
 // ---- FAST instantiation (hs_net_async only) ------------------------------------------------------------------------
 // The asynchronous engine runs a wavefront's event groups in a divergent loop with only a few lanes active per trip
 // (measured on the 65 536-station ring: ~3 of 64), so whatever a group costs is paid almost per LANE.  Three things kept
@@ -154,6 +164,13 @@ struct NetStation {
     int64_t last_time;
     Stream arr, svc, rte;
     uint32_t ev[11];
+    // Probe attached to this station (instrumentation/probe.py:81-164), as in hs_station.hpp: a daemon Source of its own
+    // whose ticks sample one attribute.  Networks with probes run on the windowed engine (never the FAST instantiation).
+    uint32_t p_metric, seqP;
+    double p_rate;
+    int64_t PA, crtP, p_arr, p_n, pcap;
+    int64_t *probe_t, *probe_v;
+    uint32_t evp[2];
     // logs
     int64_t *adm, *sink_t, *sink_created;   // record k at [k * ls] (hs_station.hpp)
     int64_t cap, ls;
@@ -318,6 +335,33 @@ struct NetStation {
             s = svc_s_next();
             dur_ns = ns_from_seconds(s);
         } else { s = svc_const_s; dur_ns = svc_const_ns; }
+    }
+
+    // ---- Probe: Source.handle_event with _ProbeEventProvider, then the measurement callback (hs_station.hpp)
+    __device__ __forceinline__ bool has_probe() const { return !FAST && p_metric != kProbeNone; }
+    __device__ __forceinline__ void root_probe(int64_t t) {
+        evp[0]++;
+        qpush(Q_PSAMPLE);                                                 // the daemon probe_event, created first
+        const int64_t a2 = probe_next_tick(p_rate, p_arr);                // ConstantArrivalTimeProvider over _ProbeProfile
+        p_arr = a2;
+        if (a2 <= t) PA = kInfNs;
+        else { PA = a2; seqP = seq++; crtP = t; }
+    }
+    __device__ __forceinline__ void do_probe_sample(int64_t t) {
+        evp[1]++;
+        int64_t v = 0;
+        switch (p_metric) {
+            case kProbeDepth: v = buf; break;
+            case kProbeActive: v = active; break;
+            case kProbeAccepted: v = accepted; break;
+            case kProbeDropped: v = dropped; break;
+            case kProbeCompleted: v = completed; break;
+            case kProbeReceived: v = received; break;
+            case kProbeGenerated: v = generated; break;
+            default: break;
+        }
+        if (p_n < pcap) { probe_t[p_n * ls] = t; probe_v[p_n * ls] = v; } else overflow = 1;
+        p_n++;
     }
 
     // ---- handlers (see hs_station.hpp for the reference citations of the shared ones)
@@ -626,6 +670,7 @@ struct NetStation {
 #pragma unroll
         for (int i = 0; i < C; ++i)
             if (D[i] == t && (best == 0 || (int32_t)(seqD[i] - bs) < 0)) { best = 2 + i; bc = crtD[i]; bs = seqD[i]; }
+        if (has_probe() && PA == t && (best == 0 || (int32_t)(seqP - bs) < 0)) { best = 63; bc = crtP; bs = seqP; }
         for (int i = 0; bmin == t && i < bag_n; ++i) {
             if (bg_t(i) != t) continue;
             const int64_t ts = bg_ts(i);
@@ -641,6 +686,7 @@ struct NetStation {
     __device__ __forceinline__ void run_root(int w, int64_t t) {
         if (w == 1) root_tick(t);
         else if (w >= 64) root_msg(w - 64, t);
+        else if (!FAST && w == 63) { if constexpr (!FAST) root_probe(t); }
         else root_cont(w - 2, t);
     }
     __device__ __forceinline__ void drain(int64_t t) {
@@ -653,6 +699,7 @@ struct NetStation {
                 case Q_DELIVER: { const uint32_t sm = do_deliver_work(t, false, 0); if (sm) qpush(Q_CONT | ((sm - 1) << 3)); } break;
                 case Q_TICK: root_tick(t); break;
                 case Q_CONT: root_cont((int)(code >> 3), t); break;
+                case Q_PSAMPLE: if constexpr (!FAST) do_probe_sample(t); break;
                 default: break;
             }
         }
@@ -666,6 +713,7 @@ struct NetStation {
         int64_t t = A;
 #pragma unroll
         for (int i = 0; i < C; ++i) t = D[i] < t ? D[i] : t;
+        if (has_probe() && PA < t) t = PA;
         return t;
     }
     __device__ __forceinline__ int64_t next_time() const { const int64_t a = next_local(), b = bag_min(); return a < b ? a : b; }
@@ -787,6 +835,7 @@ struct NetStation {
         int mi = -1;
         if (bmin == t)                    // (the bag's earliest arrival is in a register: no scan for local-only groups)
             for (int i = 0; i < bag_n; ++i) if (bg_t(i) == t) { ++n_at; mi = i; }
+        if (has_probe() && PA == t) n_at += 2;                           // a probe tick: always the general path
         if (n_at == 1 && !force_general) {
             bool general = false, want_poll = false, have_created = false;
             int64_t created = 0;

@@ -172,8 +172,6 @@ def attach_probes(g: LoweredGraph, probes: list) -> None:
         want = kinds.get(pr.metric, Server)
         if not isinstance(pr.target, want):
             raise UnsupportedTopology(f"probe '{pr.name}': metric '{pr.metric}' is not an attribute of {type(pr.target).__name__}")
-        if g.is_network:
-            raise UnsupportedTopology("probes are not lowered for networked stations yet")
         st.probe = pr
 
 

@@ -162,7 +162,12 @@ def shard_arrays(stations: StationArrays, net: NetworkArrays, lo: int, hi: int):
         src_stop_after_ns=stations.src_stop_after_ns[sl], concurrency=stations.concurrency[sl],
         svc_kind=stations.svc_kind[sl], svc_mean_s=stations.svc_mean_s[sl], queue_cap=stations.queue_cap[sl],
         egress=stations.egress[sl], seed=None if stations.seed is None else stations.seed[sl],
-        stream_base=np.asarray(base, np.uint64)[sl])
+        stream_base=np.asarray(base, np.uint64)[sl],
+        # (not lowered on shards yet: passed on so that the engine refuses them instead of losing them silently)
+        src_profile_kind=None if stations.src_profile_kind is None else stations.src_profile_kind[sl],
+        src_profile_params=None if stations.src_profile_params is None else stations.src_profile_params[sl],
+        probe_metric=None if stations.probe_metric is None else stations.probe_metric[sl],
+        probe_interval_s=None if stations.probe_interval_s is None else stations.probe_interval_s[sl])
     src, dst = np.asarray(net.link_src), np.asarray(net.link_dst)
     touch = ((src >= lo) & (src < hi)) | ((dst >= lo) & (dst < hi))
     gids = np.nonzero(touch)[0].astype(np.int64)

@@ -147,7 +147,7 @@ class Simulation:
         horizon_s = (end_ns - self._start_time.nanoseconds) / 1e9
         arrays = g.arrays()
         cancelled_ns = self._schedule_arrays(g, arrays)
-        if net is not None and arrays.n > self._resident_stations():
+        if net is not None and arrays.n > self._resident_stations() and not self._probes:
             return self._run_time_shared(g, arrays, net, end_ns, horizon_s, wall0)
         with StationEngine(arrays, mode=N.MODE_SINGLE, horizon_ns=end_ns, start_ns=self._start_time.nanoseconds,
                            seed=self._seed, device=self._device, network=net,

@@ -401,22 +401,45 @@ def run_ring_case(spec):
             sources.append(Source(f"src{i}", SimpleEventProvider(servers[i], "Request", None), prov))
         else:
             sources.append(None)
+    probes, probe_data = [], {}
+    for i, pr in enumerate(spec.get("probes") or []):
+        if pr is None:
+            continue
+        who, attr = PROBE_METRICS[pr[0]]
+        target = {"source": sources[i], "server": servers[i], "sink": sinks[i]}[who]
+        probe, data = Probe.on(target, attr, interval=pr[1])
+        data._ns = []
+
+        def add_stat(value, time, _orig=data.add_stat, _d=data):
+            _d._ns.append((time.nanoseconds, value))
+            _orig(value, time)
+
+        data.add_stat = add_stat
+        probes.append((i, probe))
+        probe_data[i] = data
     sim = Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=[s for s in sources if s is not None],
-                     entities=servers + routers + links + sinks)
+                     entities=servers + routers + links + sinks, probes=[p for _, p in probes])
     node_of = {}
     for i in range(n):
         for obj in (sources[i], servers[i], servers[i]._queue, servers[i]._driver, servers[i]._worker, routers[i],
                     links[i], sinks[i]):
             if obj is not None:
                 node_of[id(obj)] = i
+    for i, probe in probes:
+        node_of[id(probe)] = i
     trace = []
     if spec.get("trace"):
         heap = sim._event_heap
         orig_pop = heap.pop
+        cb_station = {id(probe._event_provider.data_sink): i for i, probe in probes}
 
         def pop():
             e = orig_pop()
             k, nd = classify(e, node_of)
+            if k == EV["probe"]:
+                fn = e.target._fn if hasattr(e.target, "_fn") else e.target.fn
+                cells = {id(cell.cell_contents) for cell in (fn.__closure__ or ())}
+                nd = next(c for key, c in cb_station.items() if key in cells)
             trace.append((e.time.nanoseconds, k, nd, e._sort_index))
             return e
 
@@ -437,6 +460,17 @@ def run_ring_case(spec):
     out["received"] = np.array([k.events_received for k in sinks], np.int64)
     out["routed"] = np.array([r.stats_routed for r in routers], np.int64)
     out["packets_sent"] = np.array([l.packets_sent for l in links], np.int64)
+    if probes:
+        pt, pv, poff = [], [], [0]
+        for i in range(n):
+            d = probe_data.get(i)
+            if d is not None:
+                pt.extend(t for t, _ in d._ns)
+                pv.extend(int(v) for _, v in d._ns)
+            poff.append(len(pt))
+        out["probe_t_ns"] = np.asarray(pt, np.int64)
+        out["probe_v"] = np.asarray(pv, np.int64)
+        out["probe_off"] = np.asarray(poff, np.int64)
     out["packets_dropped"] = np.array([l.packets_dropped for l in links], np.int64)
     out["bytes_transmitted"] = np.array([l.bytes_transmitted for l in links], np.int64)
     sink_t, sink_lat, off = [], [], [0]
@@ -554,6 +588,12 @@ LB_CASES = [
 ]
 
 RING_CASES = [
+    # probes on networked stations (depth / active / counters sampled between the messages and the local events)
+    dict(name="ring_6_probes", topology="ring", n=6, ext_rate=[8.0, 5.0, 9.0, 0.0, 6.0, 7.0], mean=0.09, concurrency=1,
+         queue_cap=None, lat_min=0.002, jitter_mean=0.006,
+         probes=[["depth", 0.25], ["active_requests", 0.1], None, ["stats_accepted", 0.5], ["events_received", 0.3],
+                 ["requests_completed", 0.4]],
+         end_s=12.0, seed=61, trace=True),
     # NetworkLink(packet_loss_rate): lost packets vanish at the link (link.py:131-138)
     dict(name="ring_8_loss", topology="ring", n=8, ext_rate=6.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, loss=0.2,
          end_s=20.0, seed=42, trace=True),

@@ -138,7 +138,8 @@ def ring_params(spec):
         n=n, ext_rate=[float(r) for r in per_chain(spec["ext_rate"], n)], mean=float(spec["mean"]),
         conc=int(spec.get("concurrency", 1)), qcap=-1 if spec.get("queue_cap") is None else int(spec["queue_cap"]),
         lat_min=float(spec["lat_min"]), jitter_mean=spec.get("jitter_mean"), end_ns=ns_from_seconds(spec["end_s"]),
-        loss=[float(x) for x in per_chain(spec.get("loss", 0.0), n)], p_targets=2)
+        loss=[float(x) for x in per_chain(spec.get("loss", 0.0), n)], p_targets=2,
+        probes=[None if pr is None else (pr[0], float(pr[1])) for pr in (spec.get("probes") or [None] * n)])
 
 
 def oracle_ring_graph(spec):
@@ -160,6 +161,11 @@ def oracle_ring_graph(spec):
             g.target[nodes[i]["src"]] = nodes[i]["srv"]
         g.target[nodes[i]["srv"]] = nodes[i]["rtr"]
         g.target[nodes[i]["lnk"]] = nodes[(i + 1) % n]["srv"]
+    for i in range(n):                                    # probes start after every source, in list order
+        pr = p["probes"][i]
+        if pr is not None:
+            who, mid = PROBE_METRICS[pr[0]]
+            nodes[i]["prb"] = g.probe(nodes[i][{"source": "src", "server": "srv", "sink": "snk"}[who]], mid, pr[1])
     return g, nodes
 
 
@@ -285,6 +291,13 @@ def ring_arrays(spec, bag_capacity=0, log_capacity=0):
         queue_cap=np.full(n, p["qcap"], np.int64),
         egress=np.full(n, N.EGRESS_SINK, np.uint8),
     )
+    if any(pr is not None for pr in p["probes"]):
+        st.probe_metric = np.full(n, N.PROBE_NONE, np.uint8)
+        st.probe_interval_s = np.ones(n, np.float64)
+        for i, pr in enumerate(p["probes"]):
+            if pr is not None:
+                st.probe_metric[i] = PROBE_METRICS[pr[0]][1]
+                st.probe_interval_s[i] = pr[1]
     jit = p["jitter_mean"]
     net = NetworkArrays(
         egress_kind=np.full(n, N.EGRESS_ROUTER, np.uint8),

@@ -441,3 +441,31 @@ def test_network_larger_than_one_cooperative_launch_is_time_shared(monkeypatch):
     shared = run(400)                    # 4 segments of <= 400 stations
     assert whole == shared
     assert whole[0] > 100_000 and sum(whole[7]) > 0
+
+
+def test_probes_on_networked_stations_match_reference_golden():
+    """Probe.on(server / sink, metric, interval) on the stations of a ring (windowed network engine): the samples the live
+    reference appended to each probe's Data, value for value."""
+    gold = H.Golden("ring_6_probes")
+    spec = gold.spec
+    sources, servers, routers, links, sinks = _build_ring(spec)
+    probes, datas = [], {}
+    for i, pr in enumerate(spec["probes"]):
+        if pr is None:
+            continue
+        who, attr = {"depth": ("server", "depth"), "active_requests": ("server", "active_requests"),
+                     "stats_accepted": ("server", "stats_accepted"), "events_received": ("sink", "events_received"),
+                     "requests_completed": ("server", "requests_completed")}[pr[0]]
+        probe, data = hs.Probe.on({"server": servers[i], "sink": sinks[i]}[who], attr, interval=pr[1])
+        probes.append(probe)
+        datas[i] = data
+    sim = hs.Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=sources,
+                        entities=servers + routers + links + sinks, probes=probes, seed=spec["seed"])
+    summary = sim.run()
+    assert summary.total_events_processed == gold.meta["total_events"][0]
+    _check_ring_objects(gold, servers, routers, links, sinks)
+    for i, data in datas.items():
+        a, b = gold.probe_off[i], gold.probe_off[i + 1]
+        assert data.times() == [x / 1_000_000_000 for x in gold.probe_t_ns[a:b].tolist()]     # Instant.to_seconds()
+        assert [int(v) for v in data.raw_values()] == gold.probe_v[a:b].tolist()
+        assert data.count() == b - a > 0

@@ -66,10 +66,17 @@ def test_ring_engine_matches_reference_golden(name, engine_flags):
         np.testing.assert_array_equal(ns["link_packets_sent"], gold.packets_sent)
         if "packets_dropped" in gold.arrays:                       # NetworkLink(packet_loss_rate) goldens
             np.testing.assert_array_equal(ns["link_packets_dropped"], gold.packets_dropped)
-            assert ns["link_packets_dropped"].sum() > 0
+            assert ns["link_packets_dropped"].sum() > 0 or not spec.get("loss")
         counts, t, cr = eng.read_sinks()
         np.testing.assert_array_equal(t, gold.sink_t_ns)
         np.testing.assert_array_equal((t - cr).astype(np.float64) / 1e9, gold.sink_latency_s)
+        if "probe_t_ns" in gold.arrays:                     # probes on networked stations (windowed engine either way)
+            for i in range(spec["n"]):
+                a, b = gold.probe_off[i], gold.probe_off[i + 1]
+                pt, pv = eng.read_probe(i)
+                np.testing.assert_array_equal(pt, gold.probe_t_ns[a:b], err_msg=f"probe times station {i}")
+                np.testing.assert_array_equal(pv, gold.probe_v[a:b], err_msg=f"probe values station {i}")
+            assert s.events_by_kind[13] > 0 and s.events_by_kind[14] > 0
 
 
 RING_SWEEP = [

@@ -107,6 +107,14 @@ def test_oracle_matches_reference_ring_golden(name):
         gt, glat = gold.sink_records(i)
         np.testing.assert_array_equal(t, gt)
         np.testing.assert_array_equal((t - created).astype(np.float64) / 1e9, glat)
+        if "probe_t_ns" in gold.arrays:                     # probes on networked stations
+            a, b = gold.probe_off[i], gold.probe_off[i + 1]
+            if "prb" in nd:
+                pt, pv = r.sinks[nd["prb"]]
+                np.testing.assert_array_equal(pt, gold.probe_t_ns[a:b])
+                np.testing.assert_array_equal(pv, gold.probe_v[a:b])
+            else:
+                assert a == b
     if want_trace:
         node_station = {v: i for i, d in nodes.items() for v in d.values() if v >= 0}
         t, k, nd, ix = r.trace
