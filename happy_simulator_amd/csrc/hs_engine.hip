@@ -506,7 +506,13 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST> &S, const StationPa
     S.inc_const = __ddiv_rn(1.0, S.rate);
     S.p_metric = kProbeNone; S.PA = kInfNs; S.evp[0] = S.evp[1] = 0; S.p_n = 0; S.pcap = 0; S.seqP = 0; S.crtP = 0; S.p_arr = 0;
     S.p_rate = 1.0; S.probe_t = nullptr; S.probe_v = nullptr;
+    S.prof_kind = kProfConstant; S.prof_p0 = S.prof_p1 = S.prof_p2 = S.prof_p3 = 0.0;
     if constexpr (!FAST) {
+        if (P.prof_kind[lp] != kProfConstant) {
+            S.prof_kind = P.prof_kind[lp];
+            S.prof_p0 = P.prof_p[lp]; S.prof_p1 = P.prof_p[(size_t)n + lp]; S.prof_p2 = P.prof_p[(size_t)2 * n + lp];
+            S.prof_p3 = P.prof_p[(size_t)3 * n + lp];
+        }
         if (X.PA != nullptr) {      // probes on a network: windowed engine only
             S.p_metric = P.probe_metric[lp]; S.p_rate = P.probe_rate[lp];
             S.PA = X.PA[lp]; S.seqP = X.seqP[lp]; S.crtP = X.crtP[lp]; S.p_arr = X.p_arr[lp]; S.p_n = X.p_n[lp];
@@ -1659,10 +1665,10 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     if (h->initialised) return fail(h, HS_E_STATE, "set the network before the first run");
     if (h->cfg.mode != HS_MODE_SINGLE) return fail(h, HS_E_INVALID, "a network of stations is one Simulation: HS_MODE_SINGLE");
     if (h->C > 4) return fail(h, HS_E_UNSUPPORTED, "networked stations support concurrency <= 4 for now");
-    if (h->any_timevarying || h->any_sched)
-        return fail(h, HS_E_UNSUPPORTED, "time-varying rate profiles and scheduled Requests are not lowered for networked stations yet");
-    if (h->any_probe && net->n_global_lp > 0)
-        return fail(h, HS_E_UNSUPPORTED, "probes are not lowered for a sharded network yet");
+    if (h->any_sched)
+        return fail(h, HS_E_UNSUPPORTED, "scheduled Requests are not lowered for networked stations yet");
+    if ((h->any_probe || h->any_timevarying) && net->n_global_lp > 0)
+        return fail(h, HS_E_UNSUPPORTED, "probes and time-varying rate profiles are not lowered for a sharded network yet");
     HS_HIP(h, hipSetDevice(h->cfg.device));
     const int n = h->cfg.n_lp, nl = net->n_links;
     if (nl < 0) return fail(h, HS_E_INVALID, "n_links < 0");
@@ -1825,8 +1831,9 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     if (nl > 0) {
         const size_t NQ = NL * (size_t)aqc;
         ALN(aq_t, NQ); ALN(aq_ts, NQ); ALN(aq_cr, NQ); ALN(aq_tail, NL); ALN(aq_head, NL); ALN(aq_ea, NL);
-        h->async_ok = !global && !h->any_probe;   // the whole network in one cooperative launch (shards: hs_engine_shard_round);
-                                                  // probes sample inside the windowed engine's groups
+        // the whole network in one cooperative launch (shards: hs_engine_shard_round); probes and time-varying profiles
+        // run inside the windowed engine's groups
+        h->async_ok = !global && !h->any_probe && !h->any_timevarying;
     }
 #undef ALN
     if (!h->L.sink_created_own) {   // not every completion reaches the Sink any more: explicit created_at column

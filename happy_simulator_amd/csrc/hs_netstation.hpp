@@ -120,6 +120,13 @@ __device__ __noinline__ inline int64_t probe_next_tick(double rate, int64_t from
     pp.kind = kProfGeneralConstant; pp.p0 = rate; pp.p1 = pp.p2 = pp.p3 = 0.0;
     return prof_next_arrival(pp, from_ns, 1.0);
 }
+// Next arrival of a Source with a time-varying rate profile (load/arrival_time_provider.py:84-144), same reasons.
+__device__ __noinline__ inline int64_t profile_next_tick(uint32_t kind, double p0, double p1, double p2, double p3,
+                                                         int64_t from_ns, double area) {
+    Profile pf;
+    pf.kind = kind; pf.p0 = p0; pf.p1 = p1; pf.p2 = p2; pf.p3 = p3;
+    return prof_next_arrival(pf, from_ns, area);
+}
 
 // ---- FAST instantiation (hs_net_async only) ------------------------------------------------------------------------
 // The asynchronous engine runs a wavefront's event groups in a divergent loop with only a few lanes active per trip
@@ -171,6 +178,9 @@ struct NetStation {
     int64_t PA, crtP, p_arr, p_n, pcap;
     int64_t *probe_t, *probe_v;
     uint32_t evp[2];
+    // time-varying arrival rate of this station's Source (load/profile.py); 0 = constant.  Windowed engine only, like probes.
+    uint32_t prof_kind;
+    double prof_p0, prof_p1, prof_p2, prof_p3;
     // logs
     int64_t *adm, *sink_t, *sink_created;   // record k at [k * ls] (hs_station.hpp)
     int64_t cap, ls;
@@ -325,6 +335,13 @@ struct NetStation {
     }
 
     __device__ __forceinline__ int64_t next_arrival() {
+        if constexpr (!FAST) {
+            if (prof_kind != kProfConstant) {      // general path: invert the profile for the target area E (Poisson) or 1.0
+                const double area = src_kind == 1 ? exp1_from_uniform(arr.next_uniform()) : 1.0;
+                arr_time = profile_next_tick(prof_kind, prof_p0, prof_p1, prof_p2, prof_p3, arr_time, area);
+                return arr_time;
+            }
+        }
         const double inc = src_kind == 1 ? arr_inc() : __ddiv_rn(1.0, rate);
         const double t_next = __dadd_rn(seconds_from_ns(arr_time), inc);
         arr_time = ns_from_seconds(t_next);

@@ -395,9 +395,15 @@ def run_ring_case(spec):
                                           stream=hs.Stream(seed, i, hs.STREAM_ROUTE)))
         servers[i].downstream = routers[i]
         rate = spec["ext_rate"][i] if isinstance(spec["ext_rate"], list) else spec["ext_rate"]
+        pr = (spec.get("profile") or [None] * n)[i]
         if rate > 0:
-            prov = PhiloxPoissonArrival(ConstantRateProfile(rate=rate), Instant.Epoch,
-                                        hs.Stream(seed, i, hs.STREAM_ARRIVAL))
+            if pr is None:
+                profile = ConstantRateProfile(rate=rate)
+            elif pr[0] == "ramp":
+                profile = LinearRampProfile(duration_s=pr[1], start_rate=pr[2], end_rate=pr[3])
+            else:
+                profile = SpikeProfile(baseline_rate=pr[1], spike_rate=pr[2], warmup_s=pr[3], spike_duration_s=pr[4])
+            prov = PhiloxPoissonArrival(profile, Instant.Epoch, hs.Stream(seed, i, hs.STREAM_ARRIVAL))
             sources.append(Source(f"src{i}", SimpleEventProvider(servers[i], "Request", None), prov))
         else:
             sources.append(None)
@@ -588,6 +594,11 @@ LB_CASES = [
 ]
 
 RING_CASES = [
+    # time-varying arrival profiles on networked stations (ramp up, ramp down to a trickle, a spike) + one probe
+    dict(name="ring_5_profiles", topology="ring", n=5, ext_rate=[6.0, 30.0, 4.0, 5.0, 40.0], mean=0.06, lat_min=0.002,
+         jitter_mean=0.005,
+         profile=[["ramp", 8.0, 1.0, 14.0], ["ramp", 6.0, 30.0, 2.0], None, ["spike", 3.0, 40.0, 4.0, 2.0], None],
+         probes=[None, None, ["depth", 0.5], None, None], end_s=12.0, seed=71, trace=True),
     # probes on networked stations (depth / active / counters sampled between the messages and the local events)
     dict(name="ring_6_probes", topology="ring", n=6, ext_rate=[8.0, 5.0, 9.0, 0.0, 6.0, 7.0], mean=0.09, concurrency=1,
          queue_cap=None, lat_min=0.002, jitter_mean=0.006,

@@ -139,7 +139,8 @@ def ring_params(spec):
         conc=int(spec.get("concurrency", 1)), qcap=-1 if spec.get("queue_cap") is None else int(spec["queue_cap"]),
         lat_min=float(spec["lat_min"]), jitter_mean=spec.get("jitter_mean"), end_ns=ns_from_seconds(spec["end_s"]),
         loss=[float(x) for x in per_chain(spec.get("loss", 0.0), n)], p_targets=2,
-        probes=[None if pr is None else (pr[0], float(pr[1])) for pr in (spec.get("probes") or [None] * n)])
+        probes=[None if pr is None else (pr[0], float(pr[1])) for pr in (spec.get("probes") or [None] * n)],
+        profile=[None if pr is None else tuple(pr) for pr in (spec.get("profile") or [None] * n)])
 
 
 def oracle_ring_graph(spec):
@@ -150,7 +151,8 @@ def oracle_ring_graph(spec):
     g = O.Graph()
     nodes = {i: {} for i in range(n)}
     for i in range(n):
-        nodes[i]["src"] = g.source(O.ARR_POISSON, p["ext_rate"][i], stream_base=i) if p["ext_rate"][i] > 0 else -1
+        nodes[i]["src"] = (g.source(O.ARR_POISSON, p["ext_rate"][i], stream_base=i, profile=p["profile"][i])
+                           if p["ext_rate"][i] > 0 else -1)
     for i in range(n):
         nodes[i]["srv"] = g.server(O.LAT_EXP, p["mean"], concurrency=p["conc"], queue_cap=p["qcap"], stream_base=i)
         nodes[i]["snk"] = g.sink()
@@ -298,6 +300,14 @@ def ring_arrays(spec, bag_capacity=0, log_capacity=0):
             if pr is not None:
                 st.probe_metric[i] = PROBE_METRICS[pr[0]][1]
                 st.probe_interval_s[i] = pr[1]
+    if any(pr is not None for pr in p["profile"]):
+        st.src_profile_kind = np.zeros(n, np.uint8)
+        st.src_profile_params = np.zeros((n, 4), np.float64)
+        for i, pr in enumerate(p["profile"]):
+            if pr is not None:
+                st.src_profile_kind[i] = N.PROF_LINEAR_RAMP if pr[0] == "ramp" else N.PROF_SPIKE
+                st.src_profile_params[i, :len(pr) - 1] = pr[1:]
+                st.src_rate[i] = max(pr[2], pr[3]) if pr[0] == "ramp" else max(pr[1], pr[2])   # peak: sizes the logs
     jit = p["jitter_mean"]
     net = NetworkArrays(
         egress_kind=np.full(n, N.EGRESS_ROUTER, np.uint8),

@@ -135,7 +135,12 @@ def _build_ring(spec):
         routers.append(hs.RandomRouter(f"router{i}", targets=[sinks[i], links[i]]))
         servers[i].downstream = routers[i]
         rate = spec["ext_rate"][i] if isinstance(spec["ext_rate"], list) else spec["ext_rate"]
-        if rate > 0:
+        pr = (spec.get("profile") or [None] * n)[i]
+        if rate > 0 and pr is not None:
+            profile = (hs.LinearRampProfile(duration_s=pr[1], start_rate=pr[2], end_rate=pr[3]) if pr[0] == "ramp" else
+                       hs.SpikeProfile(baseline_rate=pr[1], spike_rate=pr[2], warmup_s=pr[3], spike_duration_s=pr[4]))
+            sources.append(hs.Source.with_profile(profile, target=servers[i], poisson=True, name=f"src{i}"))
+        elif rate > 0:
             sources.append(hs.Source.poisson(rate=rate, target=servers[i], name=f"src{i}"))
     return sources, servers, routers, links, sinks
 
@@ -443,10 +448,11 @@ def test_network_larger_than_one_cooperative_launch_is_time_shared(monkeypatch):
     assert whole[0] > 100_000 and sum(whole[7]) > 0
 
 
-def test_probes_on_networked_stations_match_reference_golden():
-    """Probe.on(server / sink, metric, interval) on the stations of a ring (windowed network engine): the samples the live
-    reference appended to each probe's Data, value for value."""
-    gold = H.Golden("ring_6_probes")
+@pytest.mark.parametrize("name", ["ring_6_probes", "ring_5_profiles"])
+def test_probes_and_profiles_on_networked_stations_match_reference_golden(name):
+    """Probe.on(server / sink, metric, interval) and Source.with_profile(LinearRamp / Spike) on the stations of a ring
+    (windowed network engine): every object as the live reference left it, probe samples value for value."""
+    gold = H.Golden(name)
     spec = gold.spec
     sources, servers, routers, links, sinks = _build_ring(spec)
     probes, datas = [], {}
