@@ -262,7 +262,13 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
         X.PA[lp] = PA; X.seqP[lp] = 1; X.crtP[lp] = start_ns; X.p_arr[lp] = p_arr; X.p_n[lp] = 0;
         X.ev_probe[lp] = 0; X.ev_probe[(size_t)n + lp] = 0;
         X.seq[lp] = 2;
-        if (P.sched_off != nullptr) X.sched_i[lp] = P.sched_off[lp];
+        if (P.sched_off != nullptr) {
+            X.sched_i[lp] = P.sched_off[lp];
+            if (NX.next_time != nullptr && P.sched_off[lp] < P.sched_off[lp + 1]) {   // network engine: first pending event
+                const int64_t s0 = P.sched_t[P.sched_off[lp]];
+                if (s0 < NX.next_time[lp]) NX.next_time[lp] = s0;
+            }
+        }
     }
 }
 
@@ -507,7 +513,12 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST> &S, const StationPa
     S.p_metric = kProbeNone; S.PA = kInfNs; S.evp[0] = S.evp[1] = 0; S.p_n = 0; S.pcap = 0; S.seqP = 0; S.crtP = 0; S.p_arr = 0;
     S.p_rate = 1.0; S.probe_t = nullptr; S.probe_v = nullptr;
     S.prof_kind = kProfConstant; S.prof_p0 = S.prof_p1 = S.prof_p2 = S.prof_p3 = 0.0;
+    S.SA = kInfNs; S.sc_i = S.sc_end = 0; S.sc_t = P.sched_t;
     if constexpr (!FAST) {
+        if (P.sched_off != nullptr) {
+            S.sc_i = X.sched_i[lp]; S.sc_end = P.sched_off[lp + 1];
+            S.SA = S.sc_i < S.sc_end ? P.sched_t[S.sc_i] : kInfNs;
+        }
         if (P.prof_kind[lp] != kProfConstant) {
             S.prof_kind = P.prof_kind[lp];
             S.prof_p0 = P.prof_p[lp]; S.prof_p1 = P.prof_p[(size_t)n + lp]; S.prof_p2 = P.prof_p[(size_t)2 * n + lp];
@@ -593,6 +604,7 @@ __device__ __forceinline__ void store_net(NetStation<C, FAST> &S, const StationS
             X.PA[lp] = S.PA; X.seqP[lp] = S.seqP; X.crtP[lp] = S.crtP; X.p_arr[lp] = S.p_arr; X.p_n[lp] = S.p_n;
             X.ev_probe[lp] += S.evp[0]; X.ev_probe[(size_t)n + lp] += S.evp[1];
             tot += S.evp[0] + S.evp[1];
+            if (S.sc_t != nullptr && X.sched_i != nullptr) X.sched_i[lp] = S.sc_i;
         }
     }
 #pragma unroll
@@ -713,6 +725,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
                 if (w == 1) mine.t_created = S.crtA;
                 else if (w >= 64) mine.t_created = NX.bag_ts[(size_t)lp * NX.bag_cap + (w - 64)];
                 else if (w == 63) mine.t_created = S.crtP;
+                else if (w == 62) mine.t_created = INT64_MIN;     // constructed before run()
                 else {
 #pragma unroll
                     for (int i = 0; i < C; ++i) if (i == w - 2) mine.t_created = S.crtD[i];
@@ -806,6 +819,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
             if (w == 1) (void)W.do_tick(t);
             else if (w >= 64) (void)W.do_msg(w - 64, t);
             else if (w == 63) W.root_probe(t);                 // the SourceEvent of the Probe; its probe_event stays unprocessed
+            else if (w == 62) W.root_sched(t);                 // the injected Request@Server; its QUEUE_NOTIFY stays unprocessed
             else (void)W.do_cont_core(w - 2, t);
             W.last_time = t;
             store_net<C>(W, X, NX, b.lp, n);
@@ -1665,10 +1679,8 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     if (h->initialised) return fail(h, HS_E_STATE, "set the network before the first run");
     if (h->cfg.mode != HS_MODE_SINGLE) return fail(h, HS_E_INVALID, "a network of stations is one Simulation: HS_MODE_SINGLE");
     if (h->C > 4) return fail(h, HS_E_UNSUPPORTED, "networked stations support concurrency <= 4 for now");
-    if (h->any_sched)
-        return fail(h, HS_E_UNSUPPORTED, "scheduled Requests are not lowered for networked stations yet");
-    if ((h->any_probe || h->any_timevarying) && net->n_global_lp > 0)
-        return fail(h, HS_E_UNSUPPORTED, "probes and time-varying rate profiles are not lowered for a sharded network yet");
+    if ((h->any_probe || h->any_timevarying || h->any_sched) && net->n_global_lp > 0)
+        return fail(h, HS_E_UNSUPPORTED, "probes, time-varying rate profiles and scheduled Requests are not lowered for a sharded network yet");
     HS_HIP(h, hipSetDevice(h->cfg.device));
     const int n = h->cfg.n_lp, nl = net->n_links;
     if (nl < 0) return fail(h, HS_E_INVALID, "n_links < 0");
@@ -1833,7 +1845,7 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
         ALN(aq_t, NQ); ALN(aq_ts, NQ); ALN(aq_cr, NQ); ALN(aq_tail, NL); ALN(aq_head, NL); ALN(aq_ea, NL);
         // the whole network in one cooperative launch (shards: hs_engine_shard_round); probes and time-varying profiles
         // run inside the windowed engine's groups
-        h->async_ok = !global && !h->any_probe && !h->any_timevarying;
+        h->async_ok = !global && !h->any_probe && !h->any_timevarying && !h->any_sched;
     }
 #undef ALN
     if (!h->L.sink_created_own) {   // not every completion reaches the Sink any more: explicit created_at column

@@ -181,6 +181,9 @@ struct NetStation {
     // time-varying arrival rate of this station's Source (load/profile.py); 0 = constant.  Windowed engine only, like probes.
     uint32_t prof_kind;
     double prof_p0, prof_p1, prof_p2, prof_p3;
+    // Simulation.schedule(): Requests injected before run() (hs_station.hpp); they precede every run-time event of their ns
+    int64_t SA, sc_i, sc_end;
+    const int64_t *sc_t;
     // logs
     int64_t *adm, *sink_t, *sink_created;   // record k at [k * ls] (hs_station.hpp)
     int64_t cap, ls;
@@ -379,6 +382,14 @@ struct NetStation {
         }
         if (p_n < pcap) { probe_t[p_n * ls] = t; probe_v[p_n * ls] = v; } else overflow = 1;
         p_n++;
+    }
+
+    // ---- Simulation.schedule(): the injected Event IS the Request@Server
+    __device__ __forceinline__ bool has_sched() const { return !FAST && SA != kInfNs; }
+    __device__ __forceinline__ void root_sched(int64_t t) {
+        ++sc_i;
+        SA = sc_i < sc_end ? sc_t[sc_i] : kInfNs;
+        if (do_enqueue(t, t)) qpush(Q_NOTIFY);
     }
 
     // ---- handlers (see hs_station.hpp for the reference citations of the shared ones)
@@ -683,6 +694,7 @@ struct NetStation {
     // pending root at time t with the earliest creation: 0 none, 1 tick, 2+slot departure, 64+i message
     __device__ __forceinline__ int pick_root(int64_t t) const {
         int best = 0; int64_t bc = 0; uint32_t bs = 0; bool bmsg = false; int64_t bl = 0;
+        if (has_sched() && SA == t) return 62;
         if (A == t) { best = 1; bc = crtA; bs = seqA; }
 #pragma unroll
         for (int i = 0; i < C; ++i)
@@ -704,6 +716,7 @@ struct NetStation {
         if (w == 1) root_tick(t);
         else if (w >= 64) root_msg(w - 64, t);
         else if (!FAST && w == 63) { if constexpr (!FAST) root_probe(t); }
+        else if (!FAST && w == 62) { if constexpr (!FAST) root_sched(t); }
         else root_cont(w - 2, t);
     }
     __device__ __forceinline__ void drain(int64_t t) {
@@ -731,6 +744,7 @@ struct NetStation {
 #pragma unroll
         for (int i = 0; i < C; ++i) t = D[i] < t ? D[i] : t;
         if (has_probe() && PA < t) t = PA;
+        if (has_sched() && SA < t) t = SA;
         return t;
     }
     __device__ __forceinline__ int64_t next_time() const { const int64_t a = next_local(), b = bag_min(); return a < b ? a : b; }
@@ -853,6 +867,7 @@ struct NetStation {
         if (bmin == t)                    // (the bag's earliest arrival is in a register: no scan for local-only groups)
             for (int i = 0; i < bag_n; ++i) if (bg_t(i) == t) { ++n_at; mi = i; }
         if (has_probe() && PA == t) n_at += 2;                           // a probe tick: always the general path
+        if (has_sched() && SA == t) n_at += 2;                           // so is a scheduled Request
         if (n_at == 1 && !force_general) {
             bool general = false, want_poll = false, have_created = false;
             int64_t created = 0;

@@ -167,7 +167,10 @@ def shard_arrays(stations: StationArrays, net: NetworkArrays, lo: int, hi: int):
         src_profile_kind=None if stations.src_profile_kind is None else stations.src_profile_kind[sl],
         src_profile_params=None if stations.src_profile_params is None else stations.src_profile_params[sl],
         probe_metric=None if stations.probe_metric is None else stations.probe_metric[sl],
-        probe_interval_s=None if stations.probe_interval_s is None else stations.probe_interval_s[sl])
+        probe_interval_s=None if stations.probe_interval_s is None else stations.probe_interval_s[sl],
+        sched_off=None if stations.sched_off is None else (np.asarray(stations.sched_off)[lo:hi + 1] - int(stations.sched_off[lo])),
+        sched_time_ns=None if stations.sched_off is None else np.asarray(stations.sched_time_ns)[
+            int(stations.sched_off[lo]):int(stations.sched_off[hi])])
     src, dst = np.asarray(net.link_src), np.asarray(net.link_dst)
     touch = ((src >= lo) & (src < hi)) | ((dst >= lo) & (dst < hi))
     gids = np.nonzero(touch)[0].astype(np.int64)

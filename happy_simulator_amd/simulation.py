@@ -72,8 +72,6 @@ class Simulation:
         cancelled ones."""
         if not self._scheduled:
             return []
-        if g.is_network:
-            raise UnsupportedTopology("schedule() is not lowered for networked stations yet")
         station_of = {id(st.server): i for i, st in enumerate(g.stations) if st.server is not None}
         per: list[list[int]] = [[] for _ in g.stations]
         cancelled: list[int] = []
@@ -147,7 +145,8 @@ class Simulation:
         horizon_s = (end_ns - self._start_time.nanoseconds) / 1e9
         arrays = g.arrays()
         cancelled_ns = self._schedule_arrays(g, arrays)
-        if net is not None and arrays.n > self._resident_stations() and not self._probes:
+        if (net is not None and arrays.n > self._resident_stations() and not self._probes and not self._scheduled
+                and arrays.src_profile_kind is None):
             return self._run_time_shared(g, arrays, net, end_ns, horizon_s, wall0)
         with StationEngine(arrays, mode=N.MODE_SINGLE, horizon_ns=end_ns, start_ns=self._start_time.nanoseconds,
                            seed=self._seed, device=self._device, network=net,

@@ -450,6 +450,8 @@ def run_ring_case(spec):
             return e
 
         heap.pop = pop
+    for i, t_s in spec.get("schedule") or []:          # Simulation.schedule(): Requests for station i's Server, before run()
+        sim.schedule(Event(time=Instant.from_seconds(t_s), event_type="Request", target=servers[i]))
     summary = sim.run()
     out = {}
     meta = dict(spec=spec, total_events=[summary.total_events_processed], final_ns=[sim._current_time.nanoseconds],
@@ -594,6 +596,11 @@ LB_CASES = [
 ]
 
 RING_CASES = [
+    # Simulation.schedule() on networked stations: bursts at one timestamp, a station without a Source, one beyond the end
+    dict(name="ring_4_schedule", topology="ring", n=4, ext_rate=[5.0, 0.0, 7.0, 4.0], mean=0.08, lat_min=0.002,
+         jitter_mean=0.004,
+         schedule=[[1, 0.5], [1, 0.5], [0, 2.000000003], [1, 0.5], [3, 7.25], [2, 1.0000001], [1, 3.3], [0, 9.5], [2, 10.4]],
+         end_s=10.0, seed=81, trace=True),
     # time-varying arrival profiles on networked stations (ramp up, ramp down to a trickle, a spike) + one probe
     dict(name="ring_5_profiles", topology="ring", n=5, ext_rate=[6.0, 30.0, 4.0, 5.0, 40.0], mean=0.06, lat_min=0.002,
          jitter_mean=0.005,

@@ -140,7 +140,8 @@ def ring_params(spec):
         lat_min=float(spec["lat_min"]), jitter_mean=spec.get("jitter_mean"), end_ns=ns_from_seconds(spec["end_s"]),
         loss=[float(x) for x in per_chain(spec.get("loss", 0.0), n)], p_targets=2,
         probes=[None if pr is None else (pr[0], float(pr[1])) for pr in (spec.get("probes") or [None] * n)],
-        profile=[None if pr is None else tuple(pr) for pr in (spec.get("profile") or [None] * n)])
+        profile=[None if pr is None else tuple(pr) for pr in (spec.get("profile") or [None] * n)],
+        schedule=[(int(c), ns_from_seconds(float(t))) for c, t in (spec.get("schedule") or [])])
 
 
 def oracle_ring_graph(spec):
@@ -308,6 +309,13 @@ def ring_arrays(spec, bag_capacity=0, log_capacity=0):
                 st.src_profile_kind[i] = N.PROF_LINEAR_RAMP if pr[0] == "ramp" else N.PROF_SPIKE
                 st.src_profile_params[i, :len(pr) - 1] = pr[1:]
                 st.src_rate[i] = max(pr[2], pr[3]) if pr[0] == "ramp" else max(pr[1], pr[2])   # peak: sizes the logs
+    if p["schedule"]:
+        per = [[] for _ in range(n)]
+        for c, t in p["schedule"]:
+            per[c].append(t)
+        st.sched_off = np.zeros(n + 1, np.int64)
+        st.sched_off[1:] = np.cumsum([len(x) for x in per])
+        st.sched_time_ns = np.array([t for x in per for t in sorted(x)], np.int64)
     jit = p["jitter_mean"]
     net = NetworkArrays(
         egress_kind=np.full(n, N.EGRESS_ROUTER, np.uint8),

@@ -448,15 +448,16 @@ def test_network_larger_than_one_cooperative_launch_is_time_shared(monkeypatch):
     assert whole[0] > 100_000 and sum(whole[7]) > 0
 
 
-@pytest.mark.parametrize("name", ["ring_6_probes", "ring_5_profiles"])
+@pytest.mark.parametrize("name", ["ring_6_probes", "ring_5_profiles", "ring_4_schedule"])
 def test_probes_and_profiles_on_networked_stations_match_reference_golden(name):
-    """Probe.on(server / sink, metric, interval) and Source.with_profile(LinearRamp / Spike) on the stations of a ring
-    (windowed network engine): every object as the live reference left it, probe samples value for value."""
+    """Probe.on(server / sink, metric, interval), Source.with_profile(LinearRamp / Spike) and Simulation.schedule() on the
+    stations of a ring (windowed network engine): every object as the live reference left it, probe samples value for
+    value."""
     gold = H.Golden(name)
     spec = gold.spec
     sources, servers, routers, links, sinks = _build_ring(spec)
     probes, datas = [], {}
-    for i, pr in enumerate(spec["probes"]):
+    for i, pr in enumerate(spec.get("probes") or []):
         if pr is None:
             continue
         who, attr = {"depth": ("server", "depth"), "active_requests": ("server", "active_requests"),
@@ -467,8 +468,11 @@ def test_probes_and_profiles_on_networked_stations_match_reference_golden(name):
         datas[i] = data
     sim = hs.Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=sources,
                         entities=servers + routers + links + sinks, probes=probes, seed=spec["seed"])
+    for i, t_s in spec.get("schedule") or []:
+        sim.schedule(hs.Event(time=Instant.from_seconds(t_s), event_type="Request", target=servers[i]))
     summary = sim.run()
     assert summary.total_events_processed == gold.meta["total_events"][0]
+    assert summary.duration_s == gold.meta["duration_s"][0]
     _check_ring_objects(gold, servers, routers, links, sinks)
     for i, data in datas.items():
         a, b = gold.probe_off[i], gold.probe_off[i + 1]

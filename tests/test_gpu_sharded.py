@@ -87,7 +87,7 @@ def test_sharded_matches_reference_golden(name, rounds):
     gold = H.Golden(name)
     spec = gold.spec
     world = 2 if spec["n"] < 6 else 3
-    if spec.get("probes") or spec.get("profile"):   # both run inside one engine's windowed groups: refused on shards, explicitly
+    if spec.get("probes") or spec.get("profile") or spec.get("schedule"):   # windowed single engine only: refused on shards
         with pytest.raises(N.EngineError, match="not lowered for a sharded network"):
             _sharded(spec, world, sync_every=8, rounds=rounds)
         return

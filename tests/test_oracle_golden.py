@@ -87,7 +87,8 @@ def test_oracle_matches_reference_ring_golden(name):
     want_trace = "trace" in gold.arrays
     g, nodes = H.oracle_ring_graph(spec)
     r = O.run(g, H.ns_from_seconds(spec["end_s"]), seed=spec["seed"],
-              trace_cap=(len(gold.trace) + 16) if want_trace else 0)
+              trace_cap=(len(gold.trace) + 16) if want_trace else 0,
+              schedule=[(nodes[c]["srv"], t) for c, t in H.ring_params(spec)["schedule"]])
     assert [r.events_processed] == gold.meta["total_events"]
     assert [r.final_time_ns] == gold.meta["final_ns"]
     for i in range(spec["n"]):
