@@ -479,3 +479,37 @@ def test_probes_and_profiles_on_networked_stations_match_reference_golden(name):
         assert data.times() == [x / 1_000_000_000 for x in gold.probe_t_ns[a:b].tolist()]     # Instant.to_seconds()
         assert [int(v) for v in data.raw_values()] == gold.probe_v[a:b].tolist()
         assert data.count() == b - a > 0
+
+
+def test_ring_with_one_shared_sink_matches_oracle():
+    """Every router of a ring forwards to the SAME Sink: its completion_times / latencies are the merge of the stations'
+    logs in global processing order (device merge at write-back), as the oracle's single Sink node records them."""
+    from oracle import hs_oracle as O
+
+    n, end_s, seed = 7, 9.0, 91
+    sink = hs.Sink("sink")
+    servers = [hs.Server(f"srv{i}", service_time=hs.ExponentialLatency(0.07)) for i in range(n)]
+    links = [hs.NetworkLink(f"link{i}", latency=hs.ConstantLatency(0.0015), jitter=hs.ExponentialLatency(0.004),
+                            egress=servers[(i + 1) % n]) for i in range(n)]
+    routers = [hs.RandomRouter(f"router{i}", targets=[sink, links[i]]) for i in range(n)]
+    for i in range(n):
+        servers[i].downstream = routers[i]
+    sources = [hs.Source.poisson(rate=3.0 + i, target=servers[i], name=f"src{i}") for i in range(n)]
+    summary = hs.Simulation(end_time=Instant.from_seconds(end_s), sources=sources,
+                            entities=servers + routers + links + [sink], seed=seed).run()
+    g = O.Graph()
+    src = [g.source(O.ARR_POISSON, 3.0 + i, stream_base=i) for i in range(n)]
+    srv = [g.server(O.LAT_EXP, 0.07, stream_base=i) for i in range(n)]
+    snk = g.sink()
+    lnk = [g.link(0.0015, 0.004, stream_base=i) for i in range(n)]
+    rtr = [g.router([snk, lnk[i]], stream_base=i) for i in range(n)]
+    for i in range(n):
+        g.target[src[i]] = srv[i]
+        g.target[srv[i]] = rtr[i]
+        g.target[lnk[i]] = srv[(i + 1) % n]
+    r = O.run(g, H.ns_from_seconds(end_s), seed=seed)
+    assert summary.total_events_processed == r.events_processed
+    t, created = r.sinks[snk]
+    assert sink.events_received == len(t) > 300
+    assert [x.nanoseconds for x in sink.completion_times] == t.tolist()
+    assert sink.latencies_s == ((t - created).astype(np.float64) / 1e9).tolist()
