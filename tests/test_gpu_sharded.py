@@ -60,7 +60,7 @@ PROTOCOLS = pytest.mark.parametrize("rounds", [True, False], ids=["async_rounds"
 
 
 @PROTOCOLS
-@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("world", [1, 2, 3, 4])
 @pytest.mark.parametrize("spec", SPECS, ids=[s["name"] for s in SPECS])
 def test_sharded_equals_single_engine(spec, world, rounds):
     one = _single(spec)
