@@ -467,8 +467,8 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
 // ---------------------------------------------------------------------------------------------
 namespace {
 
-template <int C, bool FAST = false>
-__device__ __forceinline__ void load_net(NetStation<C, FAST> &S, const StationParams &P, const NetParams &NP,
+template <int C, bool FAST = false, bool PF = !FAST>
+__device__ __forceinline__ void load_net(NetStation<C, FAST, PF> &S, const StationParams &P, const NetParams &NP,
                                          const StationState &X, const NetState &NX, const RecordLogs &L, int lp, int n,
                                          uint8_t (*qmem)[kBlock], int64_t (*enqpay)[kBlock], int tid, int send_idx,
                                          const ShardCtl &SC) {
@@ -514,7 +514,7 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST> &S, const StationPa
     S.p_rate = 1.0; S.probe_t = nullptr; S.probe_v = nullptr;
     S.prof_kind = kProfConstant; S.prof_p0 = S.prof_p1 = S.prof_p2 = S.prof_p3 = 0.0;
     S.SA = kInfNs; S.sc_i = S.sc_end = 0; S.sc_t = P.sched_t;
-    if constexpr (!FAST) {
+    if constexpr (PF) {
         if (P.sched_off != nullptr) {
             S.sc_i = X.sched_i[lp]; S.sc_end = P.sched_off[lp + 1];
             S.SA = S.sc_i < S.sc_end ? P.sched_t[S.sc_i] : kInfNs;
@@ -568,8 +568,8 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST> &S, const StationPa
     S.qmem = qmem; S.enqpay = enqpay; S.qh = 0; S.qn = 0; S.ph = 0; S.pn = 0;
 }
 
-template <int C, bool FAST = false>
-__device__ __forceinline__ void store_net(NetStation<C, FAST> &S, const StationState &X, const NetState &NX, int lp, int n) {
+template <int C, bool FAST = false, bool PF = !FAST>
+__device__ __forceinline__ void store_net(NetStation<C, FAST, PF> &S, const StationState &X, const NetState &NX, int lp, int n) {
     X.A[lp] = S.A; X.seqA[lp] = S.seqA; X.crtA[lp] = S.crtA; X.arr_time[lp] = S.arr_time;
     X.buf[lp] = S.buf; X.active[lp] = S.active; X.seq[lp] = S.seq;
     X.generated[lp] = S.generated; X.accepted[lp] = S.accepted; X.dropped[lp] = S.dropped;
@@ -599,7 +599,7 @@ __device__ __forceinline__ void store_net(NetStation<C, FAST> &S, const StationS
     NX.bag_cnt[lp] = S.bag_n;
     NX.next_time[lp] = S.next_time();
     uint32_t tot = 0;
-    if constexpr (!FAST) {
+    if constexpr (PF) {
         if (X.PA != nullptr) {
             X.PA[lp] = S.PA; X.seqP[lp] = S.seqP; X.crtP[lp] = S.crtP; X.p_arr[lp] = S.p_arr; X.p_n[lp] = S.p_n;
             X.ev_probe[lp] += S.evp[0]; X.ev_probe[(size_t)n + lp] += S.evp[1];
@@ -856,7 +856,7 @@ constexpr unsigned kAsyncMaxIter = 1u << 23;   // consecutive iterations in whic
 constexpr unsigned kAsyncBlockedMax = 1u << 17;   // ... while a lane waits for buffer space: a buffer deadlock (~1 s)
 constexpr int kAsyncGroupCap = 2;   // event groups per LP per iteration of hs_net_async (debug flags bits 8..15 override)
 
-template <int C>
+template <int C, bool PF>
 __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParams NP, StationState X, NetState NX,
                                                        RecordLogs L, Totals *tot, int n, int64_t end_ns, int flags,
                                                        ShardCtl SC, int lanes, int max_iters) {
@@ -880,12 +880,12 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
     if (tid == 0) { red_time = INT64_MIN; red_flags[0] = red_flags[1] = red_flags[2] = red_flags[3] = 0; }
     __syncthreads();
 
-    NetStation<C, true> S;
+    NetStation<C, true, PF> S;
     S.fl = NetFastLds{ring_a, ring_s, ring_j, lbag_t, lbag_ts, lbag_cr, lbag_link, crc};
     bool done = !live;
     int gave_up = 0;
     if (live) {
-        load_net<C, true>(S, P, NP, X, NX, L, lp, n, qmem, enqpay, tid, 0, SC);
+        load_net<C, true, PF>(S, P, NP, X, NX, L, lp, n, qmem, enqpay, tid, 0, SC);
         // this LP's outgoing links (router targets in constructor order, or the single link) and what it last published
         int32_t out_l[2] = {-1, -1};
         if (S.egress == EG_LINK) out_l[0] = S.link_of;
@@ -1054,8 +1054,12 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             if ((flags & 128) && wave_idle) __builtin_amdgcn_s_sleep(64);   // experiment: back off when idle
             groups_before = n_groups;
         }
-        store_net<C, true>(S, X, NX, lp, n);
+        store_net<C, true, PF>(S, X, NX, lp, n);
         if (max_iters > 0 && !done) atomicAdd(&tot->not_done, 1ull);
+        if constexpr (PF) {      // probe events straight to the totals (rare LPs)
+            if (S.evp[0]) atomicAdd(&tot->ev[13], (unsigned long long)S.evp[0]);
+            if (S.evp[1]) atomicAdd(&tot->ev[14], (unsigned long long)S.evp[1]);
+        }
 #ifdef HS_CYCLES
         if ((tid & 63) == 0) for (int k = 0; k < 4; ++k) atomicAdd(&tot->dbg[k], cyc[k]);
 #else
@@ -1290,6 +1294,7 @@ struct hs_engine {
     const uint8_t *cross_role = nullptr;    // [n_cross] bit 0: the source station is here, bit 1: the destination is
     int64_t *cross_bounds = nullptr;        // device int64[n_cross + 1], owned by the caller (all-reduced with MAX)
     bool shard_async = false;
+    bool net_pf = false;       // the network has probes / profiles / scheduled Requests: the PF instantiation of hs_net_async
     int round_iters_cfg = 0;
     int async_fit = -1;        // -1 unknown, 0 the grid is not co-resident (windowed engine), 1 it is
     int async_lanes = 64;      // LPs per wavefront in hs_net_async
@@ -1381,13 +1386,13 @@ hipError_t launch_async(hs_engine *h, int64_t end_ns, NetState NX) {
     const int per_block = (kBlock / 64) * lanes;
     int max_iters = h->round_iters;
     void *args[] = {&h->P, &h->NP, &h->X, &NX, &h->L, &h->tot, &n, &end_ns, &flags, &h->SC, &lanes, &max_iters};
-    return hipLaunchCooperativeKernel((const void *)hs_net_async<C>, dim3((unsigned)((n + per_block - 1) / per_block)),
-                                      dim3(kBlock), args, 0, h->stream);
+    const void *fn = h->net_pf ? (const void *)hs_net_async<C, true> : (const void *)hs_net_async<C, false>;
+    return hipLaunchCooperativeKernel(fn, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(kBlock), args, 0, h->stream);
 }
-template <int C>
+template <int C, bool PF>
 int async_blocks_per_cu() {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hs_net_async<C>, kBlock, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hs_net_async<C, PF>, kBlock, 0) != hipSuccess) return 0;
     return nb;
 }
 
@@ -1398,7 +1403,8 @@ int ensure_async_fit(hs_engine *h) {
     if (h->async_fit < 0) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, h->cfg.device) != hipSuccess) return 0;
-        const int per_cu = h->C == 1 ? async_blocks_per_cu<1>() : h->C == 2 ? async_blocks_per_cu<2>() : async_blocks_per_cu<4>();
+        const int per_cu = h->net_pf ? (h->C == 1 ? async_blocks_per_cu<1, true>() : h->C == 2 ? async_blocks_per_cu<2, true>() : async_blocks_per_cu<4, true>())
+                                     : (h->C == 1 ? async_blocks_per_cu<1, false>() : h->C == 2 ? async_blocks_per_cu<2, false>() : async_blocks_per_cu<4, false>());
         const long long resident = prop.cooperativeLaunch ? (long long)per_cu * prop.multiProcessorCount : 0;   // workgroups
         h->async_fit = 0;
         for (int lanes = (h->flags & 32) ? 16 : 64; lanes <= 64; lanes *= 2) {
@@ -1843,9 +1849,10 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     if (nl > 0) {
         const size_t NQ = NL * (size_t)aqc;
         ALN(aq_t, NQ); ALN(aq_ts, NQ); ALN(aq_cr, NQ); ALN(aq_tail, NL); ALN(aq_head, NL); ALN(aq_ea, NL);
-        // the whole network in one cooperative launch (shards: hs_engine_shard_round); probes and time-varying profiles
-        // run inside the windowed engine's groups
-        h->async_ok = !global && !h->any_probe && !h->any_timevarying && !h->any_sched;
+        // the whole network in one cooperative launch (shards: hs_engine_shard_round); with probes, time-varying profiles
+        // or scheduled Requests the PF instantiation of the kernel
+        h->async_ok = !global;
+        h->net_pf = h->any_probe || h->any_timevarying || h->any_sched;
     }
 #undef ALN
     if (!h->L.sink_created_own) {   // not every completion reaches the Sink any more: explicit created_at column

@@ -151,7 +151,10 @@ struct NetFastLds {
     int64_t (*crc)[kBlock];       // created_at of the last kNRing admitted requests (slot = admission index mod kNRing)
 };
 
-template <int C, bool FAST = false>
+// PF: the station may carry a Probe, a time-varying arrival profile or Requests injected with Simulation.schedule() -- the
+// rare roots.  The windowed engine always has them; the asynchronous engine has a second instantiation for networks
+// that use any of them, so that the common one keeps its registers.
+template <int C, bool FAST = false, bool PF = !FAST>
 struct NetStation {
     // parameters
     int lp, n;
@@ -172,7 +175,7 @@ struct NetStation {
     Stream arr, svc, rte;
     uint32_t ev[11];
     // Probe attached to this station (instrumentation/probe.py:81-164), as in hs_station.hpp: a daemon Source of its own
-    // whose ticks sample one attribute.  Networks with probes run on the windowed engine (never the FAST instantiation).
+    // whose ticks sample one attribute (PF instantiations).
     uint32_t p_metric, seqP;
     double p_rate;
     int64_t PA, crtP, p_arr, p_n, pcap;
@@ -279,7 +282,8 @@ struct NetStation {
     __device__ __forceinline__ double svc_value(double e) const { return seconds_from_ns(ns_from_seconds(__ddiv_rn(e, svc_lambda))); }
     __device__ __forceinline__ void refill_a(int m) {
         for (int i = 0; i < m; ++i) {
-            fl.ring_a[(ha + na) & (kNRing - 1)][tid] = __ddiv_rn(exp1_from_uniform(arr.next_uniform()), rate); ++na;
+            const double e = exp1_from_uniform(arr.next_uniform());
+            fl.ring_a[(ha + na) & (kNRing - 1)][tid] = (PF && prof_kind != kProfConstant) ? e : __ddiv_rn(e, rate); ++na;
         }
     }
     __device__ __forceinline__ void refill_s(int m) {
@@ -302,7 +306,10 @@ struct NetStation {
             const double v = fl.ring_a[ha][tid];
             ha = (ha + 1) & (kNRing - 1); --na;
             return v;
-        } else return __ddiv_rn(exp1_from_uniform(arr.next_uniform()), rate);
+        } else {
+            const double e = exp1_from_uniform(arr.next_uniform());
+            return (PF && prof_kind != kProfConstant) ? e : __ddiv_rn(e, rate);
+        }
     }
     __device__ __forceinline__ double svc_s_next() {                  // service time of the next start, seconds
         if constexpr (FAST) {
@@ -338,9 +345,9 @@ struct NetStation {
     }
 
     __device__ __forceinline__ int64_t next_arrival() {
-        if constexpr (!FAST) {
+        if constexpr (PF) {
             if (prof_kind != kProfConstant) {      // general path: invert the profile for the target area E (Poisson) or 1.0
-                const double area = src_kind == 1 ? exp1_from_uniform(arr.next_uniform()) : 1.0;
+                const double area = src_kind == 1 ? arr_inc() : 1.0;   // (for such a Source the ring / stream value IS E)
                 arr_time = profile_next_tick(prof_kind, prof_p0, prof_p1, prof_p2, prof_p3, arr_time, area);
                 return arr_time;
             }
@@ -358,7 +365,7 @@ struct NetStation {
     }
 
     // ---- Probe: Source.handle_event with _ProbeEventProvider, then the measurement callback (hs_station.hpp)
-    __device__ __forceinline__ bool has_probe() const { return !FAST && p_metric != kProbeNone; }
+    __device__ __forceinline__ bool has_probe() const { return PF && p_metric != kProbeNone; }
     __device__ __forceinline__ void root_probe(int64_t t) {
         evp[0]++;
         qpush(Q_PSAMPLE);                                                 // the daemon probe_event, created first
@@ -385,7 +392,7 @@ struct NetStation {
     }
 
     // ---- Simulation.schedule(): the injected Event IS the Request@Server
-    __device__ __forceinline__ bool has_sched() const { return !FAST && SA != kInfNs; }
+    __device__ __forceinline__ bool has_sched() const { return PF && SA != kInfNs; }
     __device__ __forceinline__ void root_sched(int64_t t) {
         ++sc_i;
         SA = sc_i < sc_end ? sc_t[sc_i] : kInfNs;
@@ -715,8 +722,8 @@ struct NetStation {
     __device__ __forceinline__ void run_root(int w, int64_t t) {
         if (w == 1) root_tick(t);
         else if (w >= 64) root_msg(w - 64, t);
-        else if (!FAST && w == 63) { if constexpr (!FAST) root_probe(t); }
-        else if (!FAST && w == 62) { if constexpr (!FAST) root_sched(t); }
+        else if (PF && w == 63) { if constexpr (PF) root_probe(t); }
+        else if (PF && w == 62) { if constexpr (PF) root_sched(t); }
         else root_cont(w - 2, t);
     }
     __device__ __forceinline__ void drain(int64_t t) {
@@ -729,7 +736,7 @@ struct NetStation {
                 case Q_DELIVER: { const uint32_t sm = do_deliver_work(t, false, 0); if (sm) qpush(Q_CONT | ((sm - 1) << 3)); } break;
                 case Q_TICK: root_tick(t); break;
                 case Q_CONT: root_cont((int)(code >> 3), t); break;
-                case Q_PSAMPLE: if constexpr (!FAST) do_probe_sample(t); break;
+                case Q_PSAMPLE: if constexpr (PF) do_probe_sample(t); break;
                 default: break;
             }
         }
@@ -782,6 +789,11 @@ struct NetStation {
         const bool poll = (notify && active < conc) || dep;
         const int64_t buf1 = buf + (acc ? 1 : 0);
         const bool deliver = poll && buf1 > 0;
+        if constexpr (PF) {
+            if (has_probe() && PA == t) cnt += 2;                     // the rare roots: always the general path
+            if (has_sched() && SA == t) cnt += 2;
+            if (tick && prof_kind != kProfConstant) cnt += 2;         // (its next arrival is a numerical inversion)
+        }
         const bool slow = force_general || cnt != 1 || (tick && (a2 <= t || (poisson && na == 0))) ||
                           (deliver && (dur == 0 || (svc_exp && nsv == 0))) || (dep && router && rn == 0) ||
                           (to_link && (target != fl_link || fl_loss > 0.0 || (fl_jit == 0 && nj == 0)));

@@ -56,6 +56,8 @@ def test_ring_engine_matches_reference_golden(name, engine_flags):
         assert s.events_processed == gold.meta["total_events"][0]
         assert s.final_time_ns == gold.meta["final_ns"][0]
         assert s.window_ns > 0 and s.launches > 1
+        if engine_flags == 0:
+            assert s.launches <= 4          # reset + ONE cooperative launch + the election, also with probes / profiles
         if "trace" in gold.arrays:
             np.testing.assert_array_equal(s.events_by_kind, np.bincount(gold.trace[:, 1], minlength=len(s.events_by_kind)))
         for k, g in (("generated", "generated"), ("accepted", "accepted"), ("dropped", "dropped"),
@@ -70,7 +72,7 @@ def test_ring_engine_matches_reference_golden(name, engine_flags):
         counts, t, cr = eng.read_sinks()
         np.testing.assert_array_equal(t, gold.sink_t_ns)
         np.testing.assert_array_equal((t - cr).astype(np.float64) / 1e9, gold.sink_latency_s)
-        if "probe_t_ns" in gold.arrays:                     # probes on networked stations (windowed engine either way)
+        if "probe_t_ns" in gold.arrays:                     # probes on networked stations (both engines)
             for i in range(spec["n"]):
                 a, b = gold.probe_off[i], gold.probe_off[i + 1]
                 pt, pv = eng.read_probe(i)
