@@ -326,6 +326,8 @@ class ShardedNetwork:
         balanced block partition, e.g. with the user's own SimulationPartition sizes."""
         import torch
 
+        if stations.src_profile_kind is not None or stations.sched_off is not None:
+            rounds = False               # time-varying profiles / scheduled Requests: the window protocol (windowed engine)
         bounds = shard_bounds(stations.n, comm.world) if bounds is None else np.asarray(bounds, np.int64)
         if len(bounds) != comm.world + 1 or bounds[0] != 0 or bounds[-1] != stations.n or (np.diff(bounds) <= 0).any():
             raise ValueError("bounds must be world + 1 increasing station offsets covering every station")
@@ -430,6 +432,13 @@ class ShardedNetwork:
             for k in ("link_entered", "link_packets_sent", "link_packets_dropped"):
                 net[k][s.gids] += ns[k]
         return stats, counts, np.concatenate(ts), np.concatenate(crs), net
+
+    def read_probe(self, station: int):
+        """Samples of the Probe on network-wide station `station` (owned by one of this process's shards)."""
+        for s in self.shards:
+            if s.lo <= station < s.hi:
+                return s.engine.read_probe(station - s.lo)
+        raise IndexError(f"station {station} is not on this process's shards")
 
     def close(self):
         for s in self.shards:

@@ -145,9 +145,8 @@ class Simulation:
         horizon_s = (end_ns - self._start_time.nanoseconds) / 1e9
         arrays = g.arrays()
         cancelled_ns = self._schedule_arrays(g, arrays)
-        if (net is not None and arrays.n > self._resident_stations() and not self._probes and not self._scheduled
-                and arrays.src_profile_kind is None):
-            return self._run_time_shared(g, arrays, net, end_ns, horizon_s, wall0)
+        if net is not None and arrays.n > self._resident_stations():
+            return self._run_time_shared(g, arrays, net, end_ns, horizon_s, wall0, cancelled_ns)
         with StationEngine(arrays, mode=N.MODE_SINGLE, horizon_ns=end_ns, start_ns=self._start_time.nanoseconds,
                            seed=self._seed, device=self._device, network=net,
                            log_capacity=g.log_capacity(horizon_s) if net is not None else 0) as eng:
@@ -176,7 +175,7 @@ class Simulation:
 
         return torch.cuda.get_device_properties(self._device).multi_processor_count * 256
 
-    def _run_time_shared(self, g, arrays, net, end_ns: int, horizon_s: float, wall0: float) -> SimulationSummary:
+    def _run_time_shared(self, g, arrays, net, end_ns: int, horizon_s: float, wall0: float, cancelled_ns=()) -> SimulationSummary:
         """A network with more stations than one cooperative launch holds: contiguous segments take turns on the device
         under the asynchronous-rounds protocol of the multi-GPU path (happy_simulator_amd/sharded.py) -- the same bits as
         one engine, a few dozen rounds instead of tens of thousands of windows."""
@@ -187,7 +186,11 @@ class Simulation:
                                    seed=self._seed, device=self._device, log_capacity=g.log_capacity(horizon_s)) as sn:
             es = sn.run_until(end_ns)
             stats, counts, t_ns, created_ns, net_stats = sn.collect(arrays.n, net.n_links)
+            if self._probes:
+                write_back_probes(g, sn)
         write_back(g, stats, counts, t_ns, created_ns, net_stats, device=self._device)
+        drained = es.final_time_ns <= end_ns
+        self._events_cancelled = sum(1 for t in cancelled_ns if drained or t <= es.final_time_ns)
         self._engine_summary = es
         self._events_processed = es.events_processed
         self._current_time = Instant(es.final_time_ns)

@@ -43,6 +43,8 @@ def _sharded(spec, world, sync_every=16, msg_capacity=64, rounds=True, bag_capac
             netst["link_packets_dropped"][s.gids] += ns["link_packets_dropped"]
         parts = [s.engine.read_sinks() for s in sn.shards]
         sinks = tuple(np.concatenate([p_[i] for p_ in parts]) for i in range(3))
+        if spec.get("probes"):
+            summ.probes = {i: sn.read_probe(i) for i, pr in enumerate(spec["probes"]) if pr is not None}
         return summ, stats, netst, sinks
 
 
@@ -82,16 +84,15 @@ def test_sharded_equals_single_engine(spec, world, rounds):
 @PROTOCOLS
 @pytest.mark.parametrize("name", H.golden_names("ring"))
 def test_sharded_matches_reference_golden(name, rounds):
-    from happy_simulator_amd import _native as N
-
     gold = H.Golden(name)
     spec = gold.spec
     world = 2 if spec["n"] < 6 else 3
-    if spec.get("probes") or spec.get("profile") or spec.get("schedule"):   # windowed single engine only: refused on shards
-        with pytest.raises(N.EngineError, match="not lowered for a sharded network"):
-            _sharded(spec, world, sync_every=8, rounds=rounds)
-        return
     summ, stats, netst, sinks = _sharded(spec, world, sync_every=8, rounds=rounds)
+    if "probe_t_ns" in gold.arrays:          # probes sample on whichever shard owns their station
+        for i, (pt, pv) in summ.probes.items():
+            a, b = gold.probe_off[i], gold.probe_off[i + 1]
+            np.testing.assert_array_equal(pt, gold.probe_t_ns[a:b])
+            np.testing.assert_array_equal(pv, gold.probe_v[a:b])
     assert summ.events_processed == gold.meta["total_events"][0]
     assert summ.final_time_ns == gold.meta["final_ns"][0]
     for k, g in (("generated", "generated"), ("accepted", "accepted"), ("dropped", "dropped"), ("completed", "completed"),
