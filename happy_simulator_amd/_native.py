@@ -166,6 +166,15 @@ def lib():
         raise EngineUnavailable(
             f"{LIB_PATH} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(the engine has no CPU fallback)")
+    # One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so.7 + HSA runtime; whichever copy is mapped
+    # first serves both.  torch first is the order every GPU test and bench runs in; this library first leaves torch (device
+    # properties, the shard exchange tensors) with "No HIP GPUs are available" -- seen on MI355X with a script that ran a
+    # network through Simulation.run() before anything had imported torch.  So torch, when installed, always goes first.
+    if not os.environ.get("HS_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(os.environ.get("HS_HIP_LIB") or LIB_PATH)   # HS_HIP_LIB: an instrumented build (tools/cycles.py)
     P = C.POINTER
     L.hs_abi_version.restype = C.c_int

@@ -1691,15 +1691,6 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     HS_HIP(h, hipSetDevice(h->cfg.device));
     const int n = h->cfg.n_lp, nl = net->n_links;
     if (nl < 0) return fail(h, HS_E_INVALID, "n_links < 0");
-    // OPEN ISSUE (round 1): time-varying profiles on networked stations match the live-reference golden (5 stations) and an
-    // 8-station ring, but rings of 130 and 1 500 stations with a ramp profile on station 97 did not terminate, on either
-    // network engine, while the oracle runs the same configuration in half a second and probes (the same non-inlined
-    // numerical callee) work at 1 500 stations.  Until that is understood the combination is refused beyond one wavefront
-    // of stations instead of risking a hung device; scheduled Requests on networks were never run at scale either and get
-    // the same limit.
-    if ((h->any_timevarying || h->any_sched) && (net->n_global_lp > 0 ? net->n_global_lp : n) > 64)
-        return fail(h, HS_E_UNSUPPORTED, "time-varying profiles / scheduled Requests on networked stations are validated up to "
-                    "64 stations only (open issue); this network has %d", net->n_global_lp > 0 ? net->n_global_lp : n);
     // A shard of a larger network: link endpoints are network-wide station indices, this engine owns
     // [lp_base, lp_base + n_lp).  Otherwise the engine holds the whole network and endpoints are its own indices.
     const bool global = net->n_global_lp > 0;

@@ -85,3 +85,17 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "hs_oracle" not in text and "oracle/" not in text.replace("oracle/hs_rng_ref.h", "").replace(
                     "oracle/ ", ""), f
+
+
+def test_library_is_loaded_after_torch():
+    """One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7, and a process that maps this library's
+    copy first leaves torch without a device (seen on MI355X).  _native.lib() therefore imports torch before dlopen --
+    checked in a fresh interpreter, where nothing else has imported it."""
+    import subprocess
+    import sys
+
+    code = ("import sys; from happy_simulator_amd import _native as N; assert 'torch' not in sys.modules; N.lib(); "
+            "assert 'torch' in sys.modules; print('ok')")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr

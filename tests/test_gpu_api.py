@@ -516,13 +516,36 @@ def test_ring_with_one_shared_sink_matches_oracle():
     assert sink.latencies_s == ((t - created).astype(np.float64) / 1e9).tolist()
 
 
-def test_profiles_and_schedule_on_large_networks_are_refused_for_now():
-    """Open issue of round 1: profiles / scheduled Requests on networked stations are pinned by goldens on small rings, but a
-    130-station ring with a ramp profile on station 97 did not terminate -- refused beyond 64 stations instead of risking a
-    hang."""
-    spec = dict(n=300, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.01,
-                profile=[["ramp", 3.0, 1.0, 9.0] if i == 7 else None for i in range(300)])
+def test_profiles_and_schedule_on_a_large_network_through_the_api_match_oracle():
+    """Source.with_profile and Simulation.schedule() on a 300-station ring (several wavefronts, two workgroups) through the
+    API, every Server / router / link / Sink counter against the oracle.  (Round 1 refused this beyond 64 stations after a
+    130-station ring with LinearRampProfile(3 s, 1 -> 9) on station 97 seemed to hang; the cause was that one arrival: the
+    reference's own adaptive-Simpson inversion needs ~10^8 rate evaluations for it -- DESIGN.md section 1.2.)"""
+    from oracle import hs_oracle as O
+
+    n = 300
+    prof = [None] * n
+    prof[7], prof[97], prof[250], prof[131] = ["ramp", 3.0, 1.0, 9.0], ["ramp", 5.0, 3.0, 20.0], ["ramp", 4.0, 12.0, 2.0], \
+        ["spike", 3.0, 30.0, 1.0, 1.5]
+    spec = dict(name="ring_300_api", topology="ring", n=n, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, profile=prof,
+                schedule=[[200, 0.5], [200, 0.5], [64, 1.25], [299, 3.000000001]], end_s=4.0, seed=63)
     sources, servers, routers, links, sinks = _build_ring(spec)
-    sim = hs.Simulation(end_time=Instant.from_seconds(1.0), sources=sources, entities=servers + routers + links + sinks)
-    with pytest.raises(hs.EngineError, match="validated up to 64 stations"):
-        sim.run()
+    sim = hs.Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=sources,
+                        entities=servers + routers + links + sinks, seed=spec["seed"])
+    for i, t_s in spec["schedule"]:
+        sim.schedule(hs.Event(time=Instant.from_seconds(t_s), event_type="Request", target=servers[i]))
+    summary = sim.run()
+    g, nodes = H.oracle_ring_graph(spec)
+    p = H.ring_params(spec)
+    r = O.run(g, p["end_ns"], seed=spec["seed"], schedule=[(nodes[c]["srv"], t) for c, t in p["schedule"]])
+    assert summary.total_events_processed == r.events_processed > 30 * n
+    srv, rtr, lnk, snk = ([nodes[i][k] for i in range(n)] for k in ("srv", "rtr", "lnk", "snk"))
+    assert [s.stats_accepted for s in servers] == r.accepted[srv].tolist()
+    assert [s.stats.requests_completed for s in servers] == r.completed[srv].tolist()
+    assert [s.stats.total_service_time for s in servers] == r.total_service_s[srv].tolist()
+    assert [s.depth for s in servers] == r.depth[srv].tolist()
+    assert [x.stats_routed for x in routers] == r.routed[rtr].tolist()
+    assert [x.packets_sent for x in links] == r.packets_sent[lnk].tolist()
+    for i in range(n):
+        t, created = r.sinks[snk[i]]
+        assert [x.nanoseconds for x in sinks[i].completion_times] == t.tolist()

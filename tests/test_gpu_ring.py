@@ -197,6 +197,35 @@ def test_ring_full_size_properties_and_engine_agreement():
     assert 7.6 < load.mean() < 8.1                           # 4/s external + 4/s forwarded per station, rho = 0.8
 
 
+def _big_ring_with_profiles_and_schedule(n, seed):
+    """Ramps / spikes / scheduled Requests sprinkled over every wavefront of an n-station ring."""
+    prof = [None] * n
+    for i in range(5, n, 31):
+        prof[i] = ["ramp", 2.0 + (i % 5), 3.0 + (i % 4), 6.0 + (i % 17)] if i % 2 else ["ramp", 3.0 + (i % 3), 12.0, 2.0 + (i % 3)]
+    for i in range(64, n, 97):
+        prof[i] = ["spike", 3.0 + (i % 2), 30.0, 1.0 + (i % 3), 1.5]
+    prof[97 % n] = ["ramp", 5.0, 3.0, 20.0]
+    sched = [[i, 0.25 + 0.37 * k + 1e-9 * (i % 7)] for i in range(3, n, 61) for k in range(4)] + [[n - 1, 2.5], [n - 1, 2.5]]
+    return dict(name=f"ring_{n}_profiles_schedule", topology="ring", n=n, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.006,
+                profile=prof, schedule=sched, end_s=5.0, seed=seed)
+
+
+@ENGINES
+@pytest.mark.parametrize("n", [130, 1500])
+def test_profiles_and_schedule_on_large_rings_match_oracle(n, engine_flags):
+    """Source.with_profile and Simulation.schedule() on networks beyond one wavefront / one workgroup, both engines, against
+    the oracle (the goldens pin the same features on 4- and 5-station rings against the live reference)."""
+    spec = _big_ring_with_profiles_and_schedule(n, seed=90 + n)
+    g, nodes = H.oracle_ring_graph(spec)
+    p = H.ring_params(spec)
+    r = O.run(g, p["end_ns"], seed=spec["seed"], schedule=[(nodes[c]["srv"], t) for c, t in p["schedule"]])
+    eng, p = H.ring_engine_for_spec(spec, flags=engine_flags)
+    with eng:
+        eng.run_until(p["end_ns"])
+        _check_against_oracle(spec, eng, r, nodes)
+        assert r.events_processed > 30 * n
+
+
 @ENGINES
 def test_two_links_per_station_mesh_matches_oracle(engine_flags):
     """Every station's RandomRouter chooses between TWO NetworkLinks (to the next and the next-but-one station) and no
