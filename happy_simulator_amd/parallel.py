@@ -22,7 +22,7 @@ from . import _native as N
 from .core.temporal import Instant
 from .engine import StationArrays, StationEngine
 from .lowering import UnsupportedTopology, write_back
-from .simulation import Simulation
+from .simulation import Simulation, entity_summaries
 from .summary import SimulationSummary
 
 
@@ -153,25 +153,76 @@ class PartitionLink:
 
 @dataclass
 class ParallelSimulationSummary:
-    """happysimulator/parallel/summary.py:12-86."""
+    """happysimulator/parallel/summary.py:12-86 -- same fields, `to_dict()` keys and `__str__` layout.
+
+    How the timing fields read on this engine (the formulas are the reference's, parallel/simulation.py:256-263):
+    `partition_wall_times[name]` is the wall clock the partition spent executing on the device.  Independent partitions
+    all advance inside ONE launch, so each one's time is that launch's (a partition run alone takes as long: the launch is
+    bound by its slowest lane, not by the number of lanes); linked partitions that are virtual shards of one GPU take turns
+    on it and split the execution time; with one process per GPU each process reports its own partition.  `speedup` is
+    their sum over the whole run's wall clock (lowering, engine set-up and write-back included), `parallelism_efficiency`
+    that per partition; `barrier_overhead_seconds` is the host time inside the exchange / GVT / inject calls of a linked
+    run (coordinator.py:105-109), `coordination_efficiency` = 1 - overhead / wall clock."""
 
     duration_s: float
     total_events_processed: int
-    partitions: dict
-    wall_clock_seconds: float
     events_per_second: float = 0.0
+    wall_clock_seconds: float = 0.0
+    partitions: dict = field(default_factory=dict)
     entities: dict = field(default_factory=dict)
+    partition_wall_times: dict = field(default_factory=dict)
+    speedup: float = 1.0
+    parallelism_efficiency: float = 1.0
     total_windows: int = 0
     total_cross_partition_events: int = 0
     window_size_s: float = 0.0
+    barrier_overhead_seconds: float = 0.0
+    coordination_efficiency: float = 1.0
 
     def to_dict(self) -> dict:
         return {"duration_s": self.duration_s, "total_events_processed": self.total_events_processed,
                 "events_per_second": self.events_per_second, "wall_clock_seconds": self.wall_clock_seconds,
                 "partitions": {k: v.to_dict() for k, v in self.partitions.items()},
+                "entities": {k: v.to_dict() for k, v in self.entities.items()},
+                "partition_wall_times": dict(self.partition_wall_times),
+                "speedup": self.speedup, "parallelism_efficiency": self.parallelism_efficiency,
                 "total_windows": self.total_windows,
                 "total_cross_partition_events": self.total_cross_partition_events,
-                "window_size_s": self.window_size_s}
+                "window_size_s": self.window_size_s,
+                "barrier_overhead_seconds": self.barrier_overhead_seconds,
+                "coordination_efficiency": self.coordination_efficiency}
+
+    def __str__(self) -> str:
+        lines = ["Parallel Simulation Summary",
+                 f"  Duration: {self.duration_s:.2f}s (sim) / {self.wall_clock_seconds:.3f}s (wall)",
+                 f"  Events processed: {self.total_events_processed}",
+                 f"  Events/sec (sim): {self.events_per_second:.1f}",
+                 f"  Partitions: {len(self.partitions)}",
+                 f"  Speedup: {self.speedup:.2f}x",
+                 f"  Efficiency: {self.parallelism_efficiency:.1%}"]
+        if self.total_windows > 0:
+            lines += [f"  Windows: {self.total_windows} (size={self.window_size_s:.4f}s)",
+                      f"  Cross-partition events: {self.total_cross_partition_events}",
+                      f"  Barrier overhead: {self.barrier_overhead_seconds:.3f}s",
+                      f"  Coordination efficiency: {self.coordination_efficiency:.1%}"]
+        return "\n".join(lines)
+
+
+def _parallel_summary(part_summaries: dict, part_wall: dict, wall: float, *, duration_s: float, total_events: int,
+                      n_partitions: int, windows: int = 0, cross: int = 0, window_s: float = 0.0,
+                      barrier_s: float = 0.0) -> ParallelSimulationSummary:
+    """ParallelSimulation._build_summary (parallel/simulation.py:225-284)."""
+    entities = {}
+    for ps in part_summaries.values():
+        entities.update(ps.entities)
+    speedup = sum(part_wall.values()) / wall if wall > 0 else 1.0
+    return ParallelSimulationSummary(
+        duration_s=duration_s, total_events_processed=total_events,
+        events_per_second=total_events / duration_s if duration_s > 0 else 0.0, wall_clock_seconds=wall,
+        partitions=part_summaries, entities=entities, partition_wall_times=part_wall, speedup=speedup,
+        parallelism_efficiency=speedup / n_partitions if n_partitions > 0 else 1.0, total_windows=windows,
+        total_cross_partition_events=cross, window_size_s=window_s, barrier_overhead_seconds=barrier_s,
+        coordination_efficiency=1.0 - barrier_s / wall if wall > 0 else 1.0)
 
 
 class ParallelSimulation:
@@ -290,10 +341,10 @@ class ParallelSimulation:
         summaries = _run_independent(self._sims, [self._seed] * n, self._device, stream_bases=list(range(n)))
         dur = max(s.duration_s for s in summaries)
         tot = sum(s.total_events_processed for s in summaries)
-        return ParallelSimulationSummary(
-            duration_s=dur, total_events_processed=tot, events_per_second=tot / dur if dur > 0 else 0.0,
-            partitions={p.name: s for p, s in zip(self._partitions, summaries)},
-            wall_clock_seconds=_time.monotonic() - wall0)
+        launch = sum(s.wall_clock_seconds for s in summaries)      # _run_independent books launch / n on every partition
+        return _parallel_summary({p.name: s for p, s in zip(self._partitions, summaries)},
+                                 {p.name: launch for p in self._partitions}, _time.monotonic() - wall0,
+                                 duration_s=dur, total_events=tot, n_partitions=n)
 
     def _run_linked(self) -> ParallelSimulationSummary:
         import torch.distributed as dist
@@ -350,10 +401,13 @@ class ParallelSimulation:
                 part_summaries[parts[s.rank].name] = _SS(
                     duration_s=dur, total_events_processed=tot["events"],
                     events_per_second=tot["events"] / dur if dur > 0 else 0.0)
+            for s in sn.shards:              # every shard has written back: the objects hold the results now
+                part_summaries[parts[s.rank].name].entities = entity_summaries(parts[s.rank].entities)
             cross = comm.reduce_host([{"cross": cross_local}])["cross"]
         dur = (summ.final_time_ns - start_ns) / 1e9
-        return ParallelSimulationSummary(
-            duration_s=dur, total_events_processed=summ.events_processed,
-            events_per_second=summ.events_processed / dur if dur > 0 else 0.0,
-            partitions=part_summaries, wall_clock_seconds=_time.monotonic() - wall0, total_windows=summ.windows,
-            total_cross_partition_events=int(cross), window_size_s=summ.window_ns / 1e9)
+        # this process's shards take turns on its GPU: they split the time run_until spent outside the exchanges
+        busy = max(summ.run_seconds - summ.exchange_seconds, 0.0) / max(len(part_summaries), 1)
+        return _parallel_summary(part_summaries, {name: busy for name in part_summaries}, _time.monotonic() - wall0,
+                                 duration_s=dur, total_events=summ.events_processed, n_partitions=world,
+                                 windows=summ.windows, cross=int(cross), window_s=summ.window_ns / 1e9,
+                                 barrier_s=summ.exchange_seconds)

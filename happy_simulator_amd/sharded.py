@@ -32,6 +32,7 @@ next possible completion + the link floor: tens of ms) instead of the link floor
 from __future__ import annotations
 
 import ctypes as C
+import time as _time
 from dataclasses import dataclass
 
 import numpy as np
@@ -302,6 +303,8 @@ class ShardedSummary:
     windows: int
     window_ns: int
     world: int
+    run_seconds: float = 0.0        # host wall clock of run_until
+    exchange_seconds: float = 0.0   # ... of which in EXCHANGE / GVT / inject calls (coordinator.py:105-109's barrier time)
 
 
 class ShardedNetwork:
@@ -363,10 +366,12 @@ class ShardedNetwork:
             for _ in range(self.sync_every):
                 for s in sh:
                     s.round()                                          # EXECUTE (one cooperative launch per shard)
+                t0 = _time.perf_counter()
                 comm.exchange([s.outbox for s in sh], [s.inbox for s in sh])   # EXCHANGE messages ...
                 comm.allreduce_max([s.xbounds for s in sh])             # ... and bounds (+ the "still working" flag)
                 for s in sh:
                     s.inject_async()
+                self._exchange_s += _time.perf_counter() - t0
                 r += 1
             if all([s.round_done() for s in sh]):                      # the only host synchronisation
                 break
@@ -374,6 +379,8 @@ class ShardedNetwork:
 
     def run_until(self, end_ns: int) -> ShardedSummary:
         sh, comm = self.shards, self.comm
+        wall0 = _time.perf_counter()
+        self._exchange_s = 0.0
         for s in sh:
             s.begin(end_ns)
         k = 0
@@ -386,10 +393,12 @@ class ShardedNetwork:
                 for _ in range(self.sync_every):
                     for s in sh:
                         s.window(k)                                    # EXECUTE
+                    t0 = _time.perf_counter()
                     comm.exchange([s.outbox for s in sh], [s.inbox for s in sh])   # EXCHANGE
                     for s in sh:
                         s.inject(k)
                     comm.allreduce_min([s.gvt_slot(k) for s in sh])    # GVT
+                    self._exchange_s += _time.perf_counter() - t0
                     k += 1
                 wends = [s.progress(k - 1) for s in sh]                # the only host synchronisation
                 if min(wends) >= end_ns:
@@ -411,7 +420,8 @@ class ShardedNetwork:
         final = winner_t if winner_t is not None else int(tot["max_final_ns"])
         return ShardedSummary(events_processed=int(tot["events"]), events_by_kind=np.asarray(tot["by_kind"]),
                               requests_completed=int(tot["completed"]), sink_records=int(tot["sink_records"]),
-                              final_time_ns=final, windows=k, window_ns=self.window_ns, world=comm.world)
+                              final_time_ns=final, windows=k, window_ns=self.window_ns, world=comm.world,
+                              run_seconds=_time.perf_counter() - wall0, exchange_seconds=self._exchange_s)
 
     def collect(self, n_stations: int, n_links: int):
         """Whole-network results from this process's shards, as one engine would report them: (lp_stats dict, sink counts,

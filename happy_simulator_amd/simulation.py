@@ -201,22 +201,28 @@ class Simulation:
     def _build_summary(self, wall_elapsed: float) -> SimulationSummary:
         duration_s = (self._current_time - self._start_time).to_seconds()
         eps = self._events_processed / duration_s if duration_s > 0 else 0.0
-        entities: dict[str, EntitySummary] = {}
-        for comp in self._entities:
-            if not isinstance(comp, Entity):
-                continue
-            queue_stats = None
-            if isinstance(comp, Server):
-                queue_stats = QueueStats(peak_depth=0, total_accepted=comp.stats_accepted,
-                                         total_dropped=comp.stats_dropped)
-            handled = 0
-            for attr in ("count", "events_received", "stats_processed"):
-                val = getattr(comp, attr, None)
-                if isinstance(val, int):
-                    handled = val
-                    break
-            entities[comp.name] = EntitySummary(name=comp.name, entity_type=type(comp).__name__,
-                                                events_handled=handled, queue_stats=queue_stats)
         return SimulationSummary(duration_s=duration_s, total_events_processed=self._events_processed,
                                  events_cancelled=self._events_cancelled, events_per_second=eps,
-                                 wall_clock_seconds=wall_elapsed, entities=entities)
+                                 wall_clock_seconds=wall_elapsed, entities=entity_summaries(self._entities))
+
+
+def entity_summaries(entities) -> dict[str, EntitySummary]:
+    """Simulation._build_entity_summaries (core/simulation.py:560-591): `events_handled` is the first int among the
+    attributes count / events_received / stats_processed; QueuedResources report accepted / dropped (peak depth is never
+    tracked by the reference, :572)."""
+    out: dict[str, EntitySummary] = {}
+    for comp in entities:
+        if not isinstance(comp, Entity):
+            continue
+        queue_stats = None
+        if isinstance(comp, Server):
+            queue_stats = QueueStats(peak_depth=0, total_accepted=comp.stats_accepted, total_dropped=comp.stats_dropped)
+        handled = 0
+        for attr in ("count", "events_received", "stats_processed"):
+            val = getattr(comp, attr, None)
+            if isinstance(val, int):
+                handled = val
+                break
+        out[comp.name] = EntitySummary(name=comp.name, entity_type=type(comp).__name__, events_handled=handled,
+                                       queue_stats=queue_stats)
+    return out

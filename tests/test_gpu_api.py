@@ -114,6 +114,12 @@ def test_parallel_simulation_without_links_equals_separate_runs():
     assert set(ps.partitions) == {f"p{i}" for i in range(5)}
     assert ps.total_events_processed == sum(s.total_events_processed for s in ps.partitions.values())
     assert ps.total_events_processed > 5 * 500
+    # parallel/summary.py: one launch advanced all five, so each partition's wall time is that launch's
+    assert set(ps.partition_wall_times) == set(ps.partitions) and len(set(ps.partition_wall_times.values())) == 1
+    assert 0.0 < ps.speedup <= 5.0 and ps.parallelism_efficiency == ps.speedup / 5
+    assert ps.total_windows == 0 and ps.coordination_efficiency == 1.0 and "Windows" not in str(ps)
+    assert ps.entities["s3"].queue_stats.total_accepted == parts[3].entities[0].stats_accepted > 0
+    assert ps.entities["k3"].events_handled == parts[3].entities[1].events_received > 0
 
 
 # ---- networks of stations through the API (Server -> RandomRouter -> [Sink | NetworkLink -> next Server]) --------
@@ -199,6 +205,15 @@ def test_linked_partitions_equal_the_single_heap_run():
     assert set(summary.partitions) == {"p0", "p1", "p2"}
     assert sum(p.total_events_processed for p in summary.partitions.values()) == summary.total_events_processed
     _check_ring_objects(gold, servers, routers, links, sinks)
+    # the rest of parallel/summary.py: timing split and merged entity summaries
+    assert 0.0 < summary.barrier_overhead_seconds < summary.wall_clock_seconds
+    assert summary.coordination_efficiency == 1.0 - summary.barrier_overhead_seconds / summary.wall_clock_seconds
+    assert set(summary.partition_wall_times) == {"p0", "p1", "p2"} and summary.speedup > 0.0
+    assert summary.parallelism_efficiency == summary.speedup / 3
+    assert [summary.entities[f"srv{i}"].queue_stats.total_accepted for i in range(8)] == gold.accepted.tolist()
+    assert [summary.entities[f"sink{i}"].events_handled for i in range(8)] == gold.received.tolist()
+    assert set(summary.partitions["p1"].entities) == {"srv3", "srv4", "router3", "router4", "link3", "link4", "sink3", "sink4"}
+    assert "Coordination efficiency" in str(summary)
 
 
 def test_linked_partitions_validation():

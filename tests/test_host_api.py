@@ -357,3 +357,55 @@ def test_schedule_is_lowered_to_per_station_time_lists():
     sim2.schedule(hooked)
     with pytest.raises(hs.UnsupportedTopology, match="completion hooks"):
         sim2._schedule_arrays(sim2.lowered(), sim2.lowered().arrays())
+
+
+def test_parallel_summary_formulas_and_layout():
+    """ParallelSimulation._build_summary (parallel/simulation.py:225-284): speedup = sum of partition wall times / wall
+    clock, efficiency = speedup / partitions, coordination efficiency = 1 - barrier / wall; entities are the merge of the
+    partitions' entity summaries."""
+    from happy_simulator_amd.parallel import _parallel_summary
+    from happy_simulator_amd.summary import EntitySummary, QueueStats, SimulationSummary
+
+    ea = EntitySummary("srv_a", "Server", 0, QueueStats(0, 5, 1))
+    eb = EntitySummary("sink_b", "Sink", 9)
+    parts = {"a": SimulationSummary(2.0, 10, entities={"srv_a": ea}), "b": SimulationSummary(3.0, 20, entities={"sink_b": eb})}
+    s = _parallel_summary(parts, {"a": 0.5, "b": 0.25}, 2.0, duration_s=3.0, total_events=30, n_partitions=2, windows=4,
+                          cross=7, window_s=0.001, barrier_s=0.5)
+    assert (s.speedup, s.parallelism_efficiency, s.coordination_efficiency) == (0.375, 0.1875, 0.75)
+    assert s.events_per_second == 10.0 and list(s.entities) == ["srv_a", "sink_b"]
+    d = s.to_dict()
+    assert list(d) == ["duration_s", "total_events_processed", "events_per_second", "wall_clock_seconds", "partitions",
+                       "entities", "partition_wall_times", "speedup", "parallelism_efficiency", "total_windows",
+                       "total_cross_partition_events", "window_size_s", "barrier_overhead_seconds", "coordination_efficiency"]
+    assert d["entities"]["srv_a"]["queue"] == {"peak_depth": 0, "total_accepted": 5, "total_dropped": 1}
+    assert "Barrier overhead: 0.500s" in str(s) and "Speedup: 0.38x" in str(s)
+    quiet = _parallel_summary(parts, {"a": 1.0, "b": 1.0}, 1.0, duration_s=3.0, total_events=30, n_partitions=2)
+    assert "Windows" not in str(quiet) and quiet.speedup == 2.0 and quiet.parallelism_efficiency == 1.0
+
+
+@pytest.mark.live_reference
+def test_parallel_summary_mirror_equals_the_live_reference_class():
+    """Same constructor keywords, `to_dict()` and `__str__` as happysimulator/parallel/summary.py, field for field."""
+    import os
+    import sys
+
+    if not os.path.isdir("/root/reference/happysimulator"):
+        pytest.skip("needs /root/reference (build container only)")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import refshim
+
+    refshim.install()
+    from happysimulator.instrumentation.summary import SimulationSummary as RefSS
+    from happysimulator.parallel.summary import ParallelSimulationSummary as Ref
+
+    from happy_simulator_amd.parallel import ParallelSimulationSummary as Mine
+    from happy_simulator_amd.summary import SimulationSummary as MySS
+
+    kw = dict(duration_s=12.5, total_events_processed=1234, events_per_second=98.72, wall_clock_seconds=0.25,
+              partition_wall_times={"p0": 0.1, "p1": 0.12}, speedup=0.88, parallelism_efficiency=0.44, total_windows=125,
+              total_cross_partition_events=77, window_size_s=0.1, barrier_overhead_seconds=0.01, coordination_efficiency=0.96)
+    ref = Ref(partitions={"p0": RefSS(12.5, 600, 0, 48.0, 0.1), "p1": RefSS(12.4, 634, 0, 51.1, 0.12)}, **kw)
+    mine = Mine(partitions={"p0": MySS(12.5, 600, 0, 48.0, 0.1), "p1": MySS(12.4, 634, 0, 51.1, 0.12)}, **kw)
+    assert mine.to_dict() == ref.to_dict()
+    assert str(mine) == str(ref)
+    assert str(Mine(duration_s=1.0, total_events_processed=3)) == str(Ref(1.0, 3, 0.0, 0.0))       # defaults, no windows

@@ -63,6 +63,7 @@ def test_virtual_shards_match_single_heap(world, sync_every):
     assert s.events_processed == ev and s.final_time_ns == last
     np.testing.assert_array_equal(np.concatenate([sh.counts for sh in shards]), counts)
     assert s.windows % sync_every == 0 and s.world == world
+    assert s.run_seconds >= s.exchange_seconds > 0.0     # host time in the exchange / GVT calls = the reference's barrier time
 
 
 def _cross_links(bounds):
