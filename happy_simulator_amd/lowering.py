@@ -20,7 +20,7 @@ from . import _native as N
 from .engine import NetworkArrays, StationArrays
 from .entities import (ClientKeyEventProvider, ConsistentHash, ConstantLatency, ConstantRateProfile, Counter, Entity,
                        ExponentialLatency, LatencyTracker, LinearRampProfile, LoadBalancer, NetworkLink, RandomRouter, Server,
-                       Sink, Source, SpikeProfile, _RecordSink)
+                       Sink, Source, _RecordSink)
 
 _SINKS = (Sink, Counter, LatencyTracker)
 

@@ -38,7 +38,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _native as N
-from .engine import EngineSummary, NetworkArrays, StationArrays, StationEngine
+from .engine import NetworkArrays, StationArrays, StationEngine
 
 INF_NS = np.iinfo(np.int64).max
 

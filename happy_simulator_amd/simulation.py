@@ -12,7 +12,7 @@ from . import _native as N
 from .core.event import Event
 from .core.temporal import Instant
 from .engine import StationEngine
-from .entities import Counter, Entity, LatencyTracker, Server, Sink
+from .entities import Entity, Server
 from .lowering import (LbGraph, LoweredGraph, UnsupportedTopology, attach_probes, find_load_balancer, lower, lower_lb,
                        write_back, write_back_lb, write_back_probes)
 from .summary import EntitySummary, QueueStats, SimulationSummary
