@@ -92,6 +92,14 @@ class Simulation:
                 warnings.warn(f"Time travel detected: {ev!r} lies before the simulation start; skipping event", stacklevel=3)
                 continue
             per[i].append(ev.time.nanoseconds)
+        if any(p.count(start_ns) > 1 for p in per):
+            # DESIGN.md section 5, deviation (iii): the reference numbers injected Events from the process-wide counter and
+            # run-time events from 0 again, so at the very start of a run the Notify / Poll of the first Request overtake
+            # a second Request injected for the same Server and instant; the engine takes injected Requests first.
+            warnings.warn("several Requests are scheduled for one Server at exactly the start time: the reference lets the "
+                          "first one's queue events overtake the others (sort-index restart at run()); this engine enqueues "
+                          "them back to back, so event totals (and, with a bounded queue, drops) of that instant can differ",
+                          stacklevel=3)
         off = np.zeros(len(g.stations) + 1, np.int64)
         off[1:] = np.cumsum([len(p) for p in per])
         arrays.sched_off = off

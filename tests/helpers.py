@@ -28,6 +28,15 @@ class Golden:
         self.spec = self.meta["spec"]
         self.arrays = {k: z[k] for k in z.files if k != "meta"}
 
+    @classmethod
+    def from_results(cls, out, meta):
+        """Wrap what make_golden.run_case / run_ring_case returned (a run of the live reference in this process)."""
+        g = cls.__new__(cls)
+        g.meta = json.loads(json.dumps(meta))          # the same round trip a fixture goes through
+        g.spec = g.meta["spec"]
+        g.arrays = {k: np.asarray(v) for k, v in out.items() if k != "meta"}
+        return g
+
     def __getattr__(self, k):
         try:
             return self.arrays[k]

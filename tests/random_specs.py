@@ -1,0 +1,89 @@
+"""Seeded random configurations (chains, rings, load-balancer topologies) with every lowered feature mixed in: bounded and
+unbounded queues, concurrency, stop_after, no downstream, replicas, probes, time-varying profiles, scheduled Requests, shared
+Sinks, lossy links.  tests/test_oracle_live_reference.py runs the LIVE reference on them against the oracle (build container);
+tests/test_gpu_random.py runs the engines against the oracle (MI355X)."""
+import numpy as np
+
+
+def profile(rng):
+    """A LinearRamp or Spike profile whose brackets stay narrow (start rates >= 4: see DESIGN.md section 1.2 for what a ramp
+    from ~0 costs in the reference's own integrator)."""
+    if rng.random() < 0.5:
+        return ["ramp", float(np.round(rng.uniform(2.0, 10.0), 2)), float(rng.choice([4.0, 8.0, 25.0])),
+                float(np.round(rng.uniform(2.0, 30.0), 2))]
+    return ["spike", float(np.round(rng.uniform(3.0, 10.0), 2)), float(np.round(rng.uniform(20.0, 80.0), 1)),
+            float(np.round(rng.uniform(0.5, 3.0), 2)), float(np.round(rng.uniform(0.5, 2.0), 2))]
+
+
+def schedule(rng, n, end_s):
+    ev = [[int(rng.integers(0, n)), float(np.round(rng.uniform(0.0, end_s * 1.05), int(rng.choice([1, 3, 9]))))]
+          for _ in range(int(rng.integers(1, 9)))]
+    return ev + ev[:int(rng.integers(0, 3))]                        # duplicates: same target, same instant
+
+
+def station_spec(k):
+    rng = np.random.default_rng(1000 + k)
+    n = int(rng.integers(1, 7))
+    conc = [int(rng.choice([1, 1, 2, 3])) for _ in range(n)]
+    mean = [float(rng.choice([0.02, 0.05, 0.1, 0.25])) for _ in range(n)]
+    rho = rng.uniform(0.3, 1.6, n)                                   # under- and overloaded chains
+    spec = dict(
+        name=f"live_station_{k}", n_chains=n, arr=[str(rng.choice(["poisson", "constant"])) for _ in range(n)],
+        rate=[float(np.round(r * c / m, 3)) for r, c, m in zip(rho, conc, mean)],
+        svc=[str(rng.choice(["exp", "exp", "const"])) for _ in range(n)], mean=mean, concurrency=conc,
+        queue_cap=[None if rng.random() < 0.5 else int(rng.integers(0, 5)) for _ in range(n)],
+        stop_after_s=None if rng.random() < 0.7 else float(np.round(rng.uniform(1.0, 5.0), 3)),
+        downstream=bool(rng.random() < 0.85), end_s=float(np.round(rng.uniform(2.0, 8.0), 3)), rng="philox",
+        seed=int(rng.integers(1, 10_000)), mode=str(rng.choice(["single", "single", "replicas"])), trace=True)
+    if spec["mode"] == "single":                                     # the features below are per Simulation
+        if rng.random() < 0.3:
+            metrics = ["depth", "active_requests", "stats_accepted", "stats_dropped", "requests_completed", "generated_count"]
+            if spec["downstream"]:
+                metrics.append("events_received")
+            spec["probes"] = [None if rng.random() < 0.4 else [str(rng.choice(metrics)), float(rng.choice([0.1, 0.25, 0.3, 0.5]))]
+                              for _ in range(n)]
+        if rng.random() < 0.3 and spec["stop_after_s"] is None:
+            spec["profile"] = [None if rng.random() < 0.5 else profile(rng) for _ in range(n)]
+        if rng.random() < 0.3:
+            spec["schedule"] = schedule(rng, n, spec["end_s"])
+        if rng.random() < 0.15 and spec["downstream"] and n > 1 and "probes" not in spec:
+            spec["shared_sink"] = True
+    return spec
+
+
+def ring_spec(k):
+    rng = np.random.default_rng(2000 + k)
+    n = int(rng.integers(2, 8))
+    spec = dict(
+        name=f"live_ring_{k}", topology="ring", n=n, ext_rate=[float(rng.choice([0.0, 3.0, 5.0, 9.0])) for _ in range(n)],
+        mean=float(rng.choice([0.05, 0.1])), concurrency=int(rng.choice([1, 1, 2])),
+        queue_cap=None if rng.random() < 0.6 else int(rng.integers(1, 5)),
+        lat_min=float(rng.choice([0.0005, 0.002, 0.01])), jitter_mean=None if rng.random() < 0.3 else float(rng.choice([0.002, 0.01])),
+        end_s=float(np.round(rng.uniform(2.0, 6.0), 3)), seed=int(rng.integers(1, 10_000)), trace=True)
+    if sum(spec["ext_rate"]) == 0.0:
+        spec["ext_rate"][0] = 4.0
+    if rng.random() < 0.4:
+        spec["loss"] = [float(rng.choice([0.0, 0.1, 0.5, 1.0])) for _ in range(n)]
+    if rng.random() < 0.3:
+        spec["probes"] = [None if rng.random() < 0.4 else
+                          [str(rng.choice(["depth", "active_requests", "stats_accepted", "requests_completed", "events_received"])),
+                           float(rng.choice([0.1, 0.25, 0.3, 0.5]))] for _ in range(n)]
+    if rng.random() < 0.3:
+        spec["profile"] = [None if (rng.random() < 0.5 or spec["ext_rate"][i] == 0.0) else profile(rng) for i in range(n)]
+    if rng.random() < 0.3:
+        spec["schedule"] = schedule(rng, n, spec["end_s"])
+    return spec
+
+
+def lb_spec(k):
+    rng = np.random.default_rng(3000 + k)
+    S, B = int(rng.integers(1, 7)), int(rng.integers(1, 13))
+    conc = [int(rng.choice([1, 1, 2, 3])) for _ in range(B)]
+    return dict(
+        name=f"live_lb_{k}", topology="lb", n_sources=S, n_backends=B,
+        rate=[float(np.round(rng.uniform(2.0, 14.0 * B / S), 2)) for _ in range(S)], mean=float(rng.choice([0.05, 0.1, 0.2])),
+        concurrency=conc, queue_cap=None if rng.random() < 0.5 else int(rng.integers(0, 4)),
+        vnodes=int(rng.choice([1, 7, 50, 150])), n_clients=int(rng.choice([1, 13, 1000, 100000])),
+        stop_after_s=None if rng.random() < 0.7 else float(np.round(rng.uniform(1.0, 4.0), 3)),
+        shared_sink=bool(rng.random() < 0.6), end_s=float(np.round(rng.uniform(2.0, 6.0), 3)),
+        seed=int(rng.integers(1, 10_000)), trace=True)

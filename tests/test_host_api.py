@@ -409,3 +409,27 @@ def test_parallel_summary_mirror_equals_the_live_reference_class():
     assert mine.to_dict() == ref.to_dict()
     assert str(mine) == str(ref)
     assert str(Mine(duration_s=1.0, total_events_processed=3)) == str(Ref(1.0, 3, 0.0, 0.0))       # defaults, no windows
+
+
+def test_two_requests_scheduled_at_the_start_instant_warn_about_the_tie_break():
+    """the one practical instance of the injected-event tie-break deviation is announced."""
+    import warnings
+
+    from happy_simulator_amd.engine import StationArrays
+
+    sink = hs.Sink()
+    srv = hs.Server("srv", service_time=hs.ConstantLatency(0.1), downstream=sink)
+    sim = hs.Simulation(end_time=Instant.from_seconds(1.0), sources=[], entities=[srv, sink])
+    for t in (0.0, 0.5, 0.5, 0.0):
+        sim.schedule(hs.Event(time=Instant.from_seconds(t), event_type="Request", target=srv))
+    g = sim.lowered()
+    with pytest.warns(UserWarning, match="exactly the start time"):
+        sim._schedule_arrays(g, g.arrays())
+    sim2 = hs.Simulation(end_time=Instant.from_seconds(1.0), sources=[], entities=[srv, sink])
+    for t in (0.0, 0.5, 0.5):                           # duplicates later in the run are ordered exactly: no warning
+        sim2.schedule(hs.Event(time=Instant.from_seconds(t), event_type="Request", target=srv))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        arrays = g.arrays()
+        sim2._schedule_arrays(sim2.lowered(), arrays)
+    assert arrays.sched_time_ns.tolist() == [0, 500_000_000, 500_000_000] and isinstance(arrays, StationArrays)

@@ -15,7 +15,12 @@ from oracle import hs_oracle as O
 
 @pytest.mark.parametrize("name", H.golden_names())
 def test_oracle_matches_reference_golden(name):
-    gold = H.Golden(name)
+    check_oracle_against_station_golden(H.Golden(name))
+
+
+def check_oracle_against_station_golden(gold):
+    """Oracle == the reference's results for a chains spec (also used with freshly generated results by
+    tests/test_oracle_live_reference.py)."""
     spec = gold.spec
     want_trace = "trace" in gold.arrays
     runs = H.run_oracle_for_spec(spec, trace_cap=(len(gold.trace) + 16) if want_trace else 0)
@@ -82,7 +87,10 @@ def test_known_reference_numbers():
 def test_oracle_matches_reference_ring_golden(name):
     """Ring of stations built from reference components only (Server -> RandomRouter -> [Sink | NetworkLink ->
     next Server]); the live reference ran with Philox-plugged streams (make_golden.py run_ring_case)."""
-    gold = H.Golden(name)
+    check_oracle_against_ring_golden(H.Golden(name))
+
+
+def check_oracle_against_ring_golden(gold):
     spec = gold.spec
     want_trace = "trace" in gold.arrays
     g, nodes = H.oracle_ring_graph(spec)
@@ -129,7 +137,10 @@ def test_oracle_matches_reference_lb_golden(name):
     components only, client ids / arrivals / services from Philox-plugged streams (make_golden.py run_lb_case).  Pins the
     oracle's md5 ring, its key -> backend selection, the LB's two extra events per request (Request@LB, `_lb_response`
     fired by the completion hook when the backend's enqueue handler returns) and the whole trace with sort indices."""
-    gold = H.Golden(name)
+    check_oracle_against_lb_golden(H.Golden(name))
+
+
+def check_oracle_against_lb_golden(gold):
     spec = gold.spec
     want_trace = "trace" in gold.arrays
     g, p = H.oracle_lb_graph(spec)

@@ -1,0 +1,52 @@
+"""CPU, build container only (needs /root/reference): the oracle against the LIVE reference on randomly drawn
+configurations -- beyond the 43 committed fixtures, which were produced by exactly the same code path
+(tests/golden/make_golden.py: the reference's own event loop, queue protocol, Server generator and sort-index ledger with
+per-entity Philox streams plugged in through its extension points).  Every count, statistic, Sink record and, for the
+small cases, the full processed-event trace incl. `_sort_index`.  Skipped where the reference is absent (the GPU box)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H
+from test_oracle_golden import (check_oracle_against_lb_golden, check_oracle_against_ring_golden,
+                                check_oracle_against_station_golden)
+
+pytestmark = pytest.mark.live_reference
+
+if not os.path.isdir("/root/reference/happysimulator"):
+    pytest.skip("needs /root/reference (build container only)", allow_module_level=True)
+
+sys.path.insert(0, H.GOLDEN_DIR)
+import make_golden as MG  # noqa: E402  (imports the reference through refshim)
+from random_specs import lb_spec as _lb_spec, ring_spec as _ring_spec, station_spec as _station_spec  # noqa: E402
+
+
+@pytest.mark.parametrize("k", range(40))
+def test_oracle_equals_live_reference_on_random_station_specs(k):
+    spec = _station_spec(k)
+    if spec["mode"] == "replicas":
+        spec["trace"] = False                      # traces are recorded for one Simulation
+    out, meta = MG.run_case(spec)
+    gold = H.Golden.from_results(out, meta)
+    assert sum(gold.meta["total_events"]) > 0
+    check_oracle_against_station_golden(gold)
+
+
+@pytest.mark.parametrize("k", range(30))
+def test_oracle_equals_live_reference_on_random_ring_specs(k):
+    spec = _ring_spec(k)
+    out, meta = MG.run_ring_case(spec)
+    gold = H.Golden.from_results(out, meta)
+    assert gold.meta["total_events"][0] > 100
+    check_oracle_against_ring_golden(gold)
+
+
+@pytest.mark.parametrize("k", range(20))
+def test_oracle_equals_live_reference_on_random_load_balancer_specs(k):
+    spec = _lb_spec(k)
+    out, meta = MG.run_lb_case(spec)
+    gold = H.Golden.from_results(out, meta)
+    assert gold.meta["total_events"][0] > 50
+    check_oracle_against_lb_golden(gold)
