@@ -1,15 +1,30 @@
-"""Mirror of happysimulator/instrumentation/summary.py:14-87 (the output contract of `Simulation.run()`)."""
+"""What `Simulation.run()` hands back: the output contract of happysimulator/instrumentation/summary.py:14-87, kept field
+for field (names, `to_dict()` keys, the text `print(summary)` shows) because callers and notebooks read it.
+
+The engine fills these from device counters (`hs_engine_get_summary`, per-LP statistics); nothing here computes anything
+beyond formatting.  The text layout is described once, as rows of (label, how to render), instead of being spelled out in
+every `__str__`; tests/test_host_api.py compares the rendered text and the dictionaries with the live reference classes."""
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Any
+from typing import Any, Callable, Iterable
+
+
+def render(title: str, rows: Iterable[tuple[str, str]]) -> str:
+    """`title` followed by one two-space indented `label: value` line per row."""
+    return "\n".join([title] + [f"  {label}: {value}" for label, value in rows])
 
 
 @dataclass
 class QueueStats:
+    """Queue counters of a QueuedResource; `peak_depth` is always 0 in the reference too (core/simulation.py:572)."""
+
     peak_depth: int
     total_accepted: int
     total_dropped: int
+
+    def as_text(self) -> str:
+        return f"peak={self.peak_depth}, accepted={self.total_accepted}, dropped={self.total_dropped}"
 
 
 @dataclass
@@ -20,12 +35,23 @@ class EntitySummary:
     queue_stats: QueueStats | None = None
 
     def to_dict(self) -> dict[str, Any]:
-        result: dict[str, Any] = {"name": self.name, "type": self.entity_type, "events_handled": self.events_handled}
-        if self.queue_stats is not None:
-            result["queue"] = {"peak_depth": self.queue_stats.peak_depth,
-                               "total_accepted": self.queue_stats.total_accepted,
-                               "total_dropped": self.queue_stats.total_dropped}
-        return result
+        d: dict[str, Any] = dict(name=self.name, type=self.entity_type, events_handled=self.events_handled)
+        q = self.queue_stats
+        if q is not None:
+            d["queue"] = dict(peak_depth=q.peak_depth, total_accepted=q.total_accepted, total_dropped=q.total_dropped)
+        return d
+
+    def as_text(self) -> str:
+        text = f"{self.name} ({self.entity_type}): {self.events_handled} events"
+        return text if self.queue_stats is None else f"{text} | queue: {self.queue_stats.as_text()}"
+
+
+# (dictionary key, text label, renderer) of the scalar fields, in the reference's order
+_SCALARS: tuple[tuple[str, str, Callable[[Any], str]], ...] = (
+    ("total_events_processed", "Events processed", str),
+    ("events_cancelled", "Events cancelled", str),
+    ("events_per_second", "Events/sec (sim)", lambda v: f"{v:.1f}"),
+)
 
 
 @dataclass
@@ -33,30 +59,21 @@ class SimulationSummary:
     duration_s: float
     total_events_processed: int
     events_cancelled: int = 0
-    events_per_second: float = 0.0      # events per SIMULATED second (core/simulation.py:547)
+    events_per_second: float = 0.0      # per SIMULATED second (core/simulation.py:547), not wall clock
     wall_clock_seconds: float = 0.0
     entities: dict[str, EntitySummary] = field(default_factory=dict)
 
-    def __str__(self) -> str:
-        lines = [
-            "Simulation Summary",
-            f"  Duration: {self.duration_s:.2f}s (sim) / {self.wall_clock_seconds:.3f}s (wall)",
-            f"  Events processed: {self.total_events_processed}",
-            f"  Events cancelled: {self.events_cancelled}",
-            f"  Events/sec (sim): {self.events_per_second:.1f}",
-        ]
-        if self.entities:
-            lines.append("  Entities:")
-            for name, es in self.entities.items():
-                line = f"    {name} ({es.entity_type}): {es.events_handled} events"
-                if es.queue_stats is not None:
-                    qs = es.queue_stats
-                    line += f" | queue: peak={qs.peak_depth}, accepted={qs.total_accepted}, dropped={qs.total_dropped}"
-                lines.append(line)
-        return "\n".join(lines)
-
     def to_dict(self) -> dict[str, Any]:
-        return {"duration_s": self.duration_s, "total_events_processed": self.total_events_processed,
-                "events_cancelled": self.events_cancelled, "events_per_second": self.events_per_second,
-                "wall_clock_seconds": self.wall_clock_seconds,
-                "entities": {name: es.to_dict() for name, es in self.entities.items()}}
+        d: dict[str, Any] = {"duration_s": self.duration_s}
+        d.update((key, getattr(self, key)) for key, _, _ in _SCALARS)
+        d["wall_clock_seconds"] = self.wall_clock_seconds
+        d["entities"] = {name: e.to_dict() for name, e in self.entities.items()}
+        return d
+
+    def __str__(self) -> str:
+        rows = [("Duration", f"{self.duration_s:.2f}s (sim) / {self.wall_clock_seconds:.3f}s (wall)")]
+        rows += [(label, fmt(getattr(self, key))) for key, label, fmt in _SCALARS]
+        text = render("Simulation Summary", rows)
+        if self.entities:
+            text += "\n  Entities:" + "".join(f"\n    {e.as_text()}" for e in self.entities.values())
+        return text

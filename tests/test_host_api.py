@@ -409,6 +409,18 @@ def test_parallel_summary_mirror_equals_the_live_reference_class():
     assert mine.to_dict() == ref.to_dict()
     assert str(mine) == str(ref)
     assert str(Mine(duration_s=1.0, total_events_processed=3)) == str(Ref(1.0, 3, 0.0, 0.0))       # defaults, no windows
+    # ... and the per-run summary with its entity / queue lines (instrumentation/summary.py:14-87)
+    from happysimulator.instrumentation.summary import EntitySummary as RefES, QueueStats as RefQS
+
+    from happy_simulator_amd.summary import EntitySummary as MyES, QueueStats as MyQS
+
+    def build(SS, ES, QS):
+        return SS(duration_s=60.000000001, total_events_processed=4321, events_cancelled=2, events_per_second=72.016,
+                  wall_clock_seconds=0.0123, entities={"srv": ES("srv", "Server", 0, QS(0, 480, 3)), "Sink": ES("Sink", "Sink", 477)})
+    a, b = build(MySS, MyES, MyQS), build(RefSS, RefES, RefQS)
+    assert a.to_dict() == b.to_dict() and list(a.to_dict()) == list(b.to_dict())
+    assert str(a) == str(b)
+    assert str(MySS(1.5, 10)) == str(RefSS(1.5, 10)) and MySS(1.5, 10).to_dict() == RefSS(1.5, 10).to_dict()
 
 
 def test_two_requests_scheduled_at_the_start_instant_warn_about_the_tie_break():
