@@ -87,3 +87,32 @@ def lb_spec(k):
         stop_after_s=None if rng.random() < 0.7 else float(np.round(rng.uniform(1.0, 4.0), 3)),
         shared_sink=bool(rng.random() < 0.6), end_s=float(np.round(rng.uniform(2.0, 6.0), 3)),
         seed=int(rng.integers(1, 10_000)), trace=True)
+
+
+def tie_spec(k):
+    """Tie storms: lock-step constant-rate sources, constant service times that are multiples of one another, Requests
+    scheduled at the start instant and at the sources' own tick times, c up to 16, zero-capacity queues -- every same-nanosecond
+    order the reference's sort-index ledger decides.  (Reference vs oracle only: across LPs and at the start instant the engines
+    document tie-break deviations)"""
+    rng = np.random.default_rng(50_000 + k)
+    n = int(rng.integers(2, 7))
+    base_rate = float(rng.choice([2.0, 4.0, 5.0, 10.0]))
+    spec = dict(name=f"tie_{k}", n_chains=n, arr=[str(rng.choice(["constant", "constant", "poisson"])) for _ in range(n)],
+                rate=[base_rate * float(rng.choice([1.0, 1.0, 2.0, 0.5])) for _ in range(n)],
+                svc=[str(rng.choice(["const", "const", "exp"])) for _ in range(n)],
+                mean=[float(rng.choice([0.05, 0.1, 0.2, 0.25, 0.5])) for _ in range(n)],
+                concurrency=[int(rng.choice([1, 2, 4, 8, 16])) for _ in range(n)],
+                queue_cap=[None if rng.random() < 0.4 else int(rng.integers(0, 3)) for _ in range(n)],
+                stop_after_s=None if rng.random() < 0.6 else float(rng.choice([1.0, 2.0, 2.5])),
+                downstream=bool(rng.random() < 0.8), end_s=float(rng.choice([2.0, 3.0, 4.5])), rng="philox",
+                seed=int(rng.integers(1, 10_000)), mode="single", trace=True)
+    if rng.random() < 0.5:
+        spec["schedule"] = [[int(rng.integers(0, n)), float(rng.choice([0.0, 0.0, 0.1, 0.2, 0.25, 0.5, 1.0, 2.0]))]
+                            for _ in range(int(rng.integers(1, 8)))]
+    if rng.random() < 0.3:
+        spec["probes"] = [None if rng.random() < 0.4 else
+                          [str(rng.choice(["depth", "active_requests", "stats_accepted", "generated_count"])),
+                           float(rng.choice([0.1, 0.25, 0.5]))] for _ in range(n)]
+    if rng.random() < 0.15 and spec["downstream"] and "probes" not in spec:
+        spec["shared_sink"] = True
+    return spec

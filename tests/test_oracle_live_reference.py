@@ -20,7 +20,7 @@ if not os.path.isdir("/root/reference/happysimulator"):
 
 sys.path.insert(0, H.GOLDEN_DIR)
 import make_golden as MG  # noqa: E402  (imports the reference through refshim)
-from random_specs import lb_spec as _lb_spec, ring_spec as _ring_spec, station_spec as _station_spec  # noqa: E402
+from random_specs import lb_spec as _lb_spec, ring_spec as _ring_spec, station_spec as _station_spec, tie_spec  # noqa: E402
 
 
 @pytest.mark.parametrize("k", range(40))
@@ -50,3 +50,11 @@ def test_oracle_equals_live_reference_on_random_load_balancer_specs(k):
     gold = H.Golden.from_results(out, meta)
     assert gold.meta["total_events"][0] > 50
     check_oracle_against_lb_golden(gold)
+
+
+@pytest.mark.parametrize("k", range(40))
+def test_oracle_equals_live_reference_on_tie_storms(k):
+    """Same-nanosecond orders (lock-step constant sources, Requests injected at the start instant, c up to 16): the oracle's
+    sort-index ledger against the reference's, full traces."""
+    out, meta = MG.run_case(tie_spec(k))
+    check_oracle_against_station_golden(H.Golden.from_results(out, meta))
