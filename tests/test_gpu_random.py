@@ -72,7 +72,7 @@ def test_two_requests_scheduled_at_the_start_instant_deviate_by_one_notify():
     that one finds the queue empty again (a second Notify); the engines enqueue both first (one Notify).  Measured on MI355X:
     220 (reference == oracle) vs 219 events, everything else identical."""
     spec = RS.ring_spec(24)
-    assert sorted(spec["schedule"])[:2] == [[1, 0.0], [1, 0.0]]
+    assert [e for e in spec["schedule"] if e[1] == 0.0] == [[1, 0.0], [1, 0.0]]
     g, nodes = H.oracle_ring_graph(spec)
     p = H.ring_params(spec)
     r = O.run(g, p["end_ns"], seed=spec["seed"], schedule=[(nodes[c]["srv"], t) for c, t in p["schedule"]])
