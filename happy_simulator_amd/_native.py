@@ -36,7 +36,7 @@ EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuat
 PROBE_METRICS = {"depth": 0, "active_requests": 1, "stats_accepted": 2, "stats_dropped": 3, "requests_completed": 4,
                  "_requests_completed": 4, "events_received": 5, "generated_count": 6}
 PROBE_NONE = 255
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class EngineUnavailable(RuntimeError):
@@ -65,6 +65,7 @@ class Stations(C.Structure):
         ("src_profile_kind", C.c_void_p), ("src_profile_params", C.c_void_p),
         ("probe_metric", C.c_void_p), ("probe_interval_s", C.c_void_p),
         ("sched_off", C.c_void_p), ("sched_time_ns", C.c_void_p),
+        ("source_order", C.c_void_p), ("probe_order", C.c_void_p), ("sched_call_order", C.c_void_p),
     ]
 
 
@@ -131,7 +132,7 @@ class LbStats(C.Structure):
 
 def sources() -> list[str]:
     return [os.path.join(CSRC, f) for f in ("hs_engine.hip", "hs_lb.hip", "hs_station.hpp", "hs_netstation.hpp",
-                                            "hs_device.hpp", "hs_radix.hpp", "hs_profile.hpp")] + [
+                                            "hs_device.hpp", "hs_radix.hpp", "hs_profile.hpp", "hs_exact.hpp")] + [
         os.path.join(INCLUDE, "hs_engine.h")]
 
 

@@ -15,6 +15,7 @@
 
 #include "../../include/hs_engine.h"
 #include "hs_netstation.hpp"
+#include "hs_exact.hpp"
 
 using namespace hs;
 
@@ -72,7 +73,7 @@ __device__ __forceinline__ void load_station(Station<C, PF> &S, const StationPar
     S.stop_ns = P.src_stop[lp]; S.qcap = P.qcap[lp];
     S.prof.kind = kProfConstant;
     S.p_metric = kProbeNone; S.PA = kInfNs; S.evp[0] = S.evp[1] = 0;
-    S.SA = kInfNs; S.sc_i = S.sc_end = 0; S.sc_t = P.sched_t;
+    S.SA = kInfNs; S.sc_i = S.sc_end = 0; S.sc_t = P.sched_t; S.sc_idx = P.sched_idx;
     if constexpr (PF) {
         if (P.sched_off != nullptr) {
             S.sc_i = X.sched_i[lp]; S.sc_end = P.sched_off[lp + 1];
@@ -461,6 +462,63 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The prologue (hs_exact.hpp): lane 0 runs the reference's heap loop until the run has constructed as many events as
+// were constructed before it; then the wavefront hands the state to the parallel engine.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) hs_exact_run(StationParams P, NetParams NP, StationState X, NetState NX, RecordLogs L,
+                                                   Totals *tot, XState *xs, XInit I, int n, int C, int net, int n_links,
+                                                   int64_t start_ns, int64_t end_ns) {
+    __shared__ int s_hand;
+    if (threadIdx.x == 0) s_hand = exact_loop(P, NP, X, NX, L, tot, *xs, I, n, C, net != 0, start_ns, end_ns) ? 1 : 0;
+    __syncthreads();
+    if (!s_hand) return;
+    // every LP's creation counter continues from the global one: whatever it constructs from now on follows every
+    // pending event (pre-run events keep their own, smaller indices as stamps)
+    const uint32_t g = (uint32_t)xs->G;
+    for (int lp = threadIdx.x; lp < n; lp += 64) X.seq[lp] = g;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (net) {
+            // requests in transit: the pending link continuations become messages in the destination's bag
+            int over = 0;
+            for (int64_t i = 0; i < xs->heap_len; ++i) {
+                const XEvent &e = xs->heap[i];
+                if (e.code != XE_LINKCONT) continue;
+                const int b = NX.bag_cnt[e.lp];
+                if (b >= NX.bag_cap) { over = 1; continue; }
+                const size_t d = (size_t)e.lp * NX.bag_cap + b;
+                NX.bag_t[d] = e.t; NX.bag_ts[d] = e.ts; NX.bag_cr[d] = e.cr; NX.bag_link[d] = (int32_t)e.aux;
+                NX.bag_cnt[e.lp] = b + 1;
+            }
+            if (over) atomicOr(&tot->overflow, 2);
+            if (NX.aq_tail != nullptr)                    // asynchronous engine: the link queues continue behind them
+                for (int l = 0; l < n_links; ++l) {
+                    NX.aq_tail[l] = (unsigned long long)NX.link_sent[l];
+                    NX.aq_head[l] = (unsigned long long)NX.link_sent[l];
+                }
+        }
+        xs->phase = 2;
+    }
+    __syncthreads();
+    if (net) {
+        for (int lp = threadIdx.x; lp < n; lp += 64) {
+            int64_t t = X.A[lp];
+            for (int i = 0; i < C; ++i) { const int64_t d = X.D[(size_t)i * n + lp]; t = d < t ? d : t; }
+            if (X.PA != nullptr) {
+                if (P.probe_metric[lp] != kProbeNone && X.PA[lp] < t) t = X.PA[lp];
+                if (P.sched_off != nullptr && X.sched_i[lp] < P.sched_off[lp + 1]) {
+                    const int64_t sa = P.sched_t[X.sched_i[lp]];
+                    t = sa < t ? sa : t;
+                }
+            }
+            const int bn = NX.bag_cnt[lp];
+            for (int i = 0; i < bn; ++i) { const int64_t bt = NX.bag_t[(size_t)lp * NX.bag_cap + i]; t = bt < t ? bt : t; }
+            NX.next_time[lp] = t;
+        }
+    }
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // network engine (hs_netstation.hpp): one launch per conservative time window
@@ -513,7 +571,7 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF> &S, const Stati
     S.p_metric = kProbeNone; S.PA = kInfNs; S.evp[0] = S.evp[1] = 0; S.p_n = 0; S.pcap = 0; S.seqP = 0; S.crtP = 0; S.p_arr = 0;
     S.p_rate = 1.0; S.probe_t = nullptr; S.probe_v = nullptr;
     S.prof_kind = kProfConstant; S.prof_p0 = S.prof_p1 = S.prof_p2 = S.prof_p3 = 0.0;
-    S.SA = kInfNs; S.sc_i = S.sc_end = 0; S.sc_t = P.sched_t;
+    S.SA = kInfNs; S.sc_i = S.sc_end = 0; S.sc_t = P.sched_t; S.sc_idx = P.sched_idx;
     if constexpr (PF) {
         if (P.sched_off != nullptr) {
             S.sc_i = X.sched_i[lp]; S.sc_end = P.sched_off[lp + 1];
@@ -633,6 +691,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
     const int lp = blockIdx.x * kBlock + tid;
     const bool live = lp < n;
     const bool final_launch = (flags & 2) != 0;
+    const long long cur0 = tot->cur_time;     // beyond end_ns only when the prologue (hs_exact.hpp) already ran the whole run
     const int merge_idx = (win + 1) & 1, send_idx = win & 1;
     __shared__ long long red_gvt;
     if (tid < 14) red[tid] = 0;
@@ -810,7 +869,8 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
             tot->done = 0;
             return;
         }
-        if (b.valid) {
+        if (cur0 > wend) new_cur = cur0;              // ... its one event beyond end_time included
+        else if (b.valid) {
             // the one event beyond end_time (core/simulation.py:472): first micro-event of the winner's next group
             NetStation<C> W;
             load_net<C>(W, P, NP, X, NX, L, b.lp, n, qmem, enqpay, 0, send_idx, SC);
@@ -1303,6 +1363,11 @@ struct hs_engine {
     int async_lanes = 64;      // LPs per wavefront in hs_net_async
     int n_blocks = 0;
     int flags = 0;
+    // prologue (hs_exact.hpp): SINGLE mode with probes / scheduled Requests
+    bool exact = false;
+    XState *xs = nullptr;
+    XState xs_host{};          // the device pointers / capacities of *xs (phase etc. are reset from it)
+    XInit XI{};
     double last_run_ms = 0.0, last_kernel_ms = 0.0;
     int64_t launches = 0;
     std::string error;
@@ -1462,8 +1527,23 @@ int do_reset_async(hs_engine *h) {
     hipLaunchKernelGGL(hs_station_reset, dim3(h->n_blocks), dim3(kBlock), 0, h->stream, h->P, h->X, h->tot,
                        h->cfg.n_lp, h->C, h->cfg.start_ns, h->NX, h->is_net ? h->NP.n_links : 0);
     HS_HIP(h, hipGetLastError());
+    if (h->exact) {            // the prologue starts over: empty heap, both counters at 0
+        HS_HIP(h, hipMemcpyAsync(h->xs, &h->xs_host, sizeof(XState), hipMemcpyHostToDevice, h->stream));
+        HS_HIP(h, hipMemsetAsync(h->xs_host.qhead, 0xff, (size_t)h->cfg.n_lp * sizeof(int32_t), h->stream));
+        HS_HIP(h, hipMemsetAsync(h->xs_host.qtail, 0xff, (size_t)h->cfg.n_lp * sizeof(int32_t), h->stream));
+    }
     h->initialised = true;
     h->net_ran = false;
+    return HS_OK;
+}
+
+// the prologue of a run (hs_exact.hpp); a no-op launch once it has handed over
+int launch_prologue(hs_engine *h, int64_t end_ns) {
+    if (!h->exact || (h->flags & 256)) return HS_OK;
+    hipLaunchKernelGGL(hs_exact_run, dim3(1), dim3(64), 0, h->stream, h->P, h->NP, h->X, h->NX, h->L, h->tot, h->xs, h->XI,
+                       h->cfg.n_lp, h->C, h->is_net ? 1 : 0, h->is_net ? h->NP.n_links : 0, h->cfg.start_ns, end_ns);
+    HS_HIP(h, hipGetLastError());
+    h->launches++;
     return HS_OK;
 }
 
@@ -1648,6 +1728,69 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     if (n_sched > 0) {
         if ((rc = upload<int64_t>(h, &h->P.sched_off, st->sched_off, (size_t)n + 1, 0))) return rc;
         if ((rc = upload<int64_t>(h, &h->P.sched_t, st->sched_time_ns, (size_t)n_sched, 0))) return rc;
+    }
+    h->P.sched_idx = nullptr;
+    if (h->cfg.mode == HS_MODE_SINGLE && (n_sched > 0 || h->any_probe)) {
+        // The prologue (hs_exact.hpp): the reference's pre-run events in the order it constructs them
+        std::vector<int32_t> so, po, sl((size_t)n_sched);
+        std::vector<int64_t> se((size_t)n_sched);
+        std::vector<uint8_t> seen((size_t)n, (uint8_t)0);
+        size_t n_src = 0, n_prb = 0;
+        for (int i = 0; i < n; ++i) {
+            if ((st->src_kind ? st->src_kind[i] : HS_SRC_POISSON) != HS_SRC_NONE) ++n_src;
+            if (pm[(size_t)i] != 255) ++n_prb;
+        }
+        for (int pass = 0; pass < 2; ++pass) {
+            const int32_t *ord = pass == 0 ? st->source_order : st->probe_order;
+            std::vector<int32_t> &out = pass == 0 ? so : po;
+            const size_t want = pass == 0 ? n_src : n_prb;
+            std::fill(seen.begin(), seen.end(), (uint8_t)0);
+            for (size_t k = 0; k < want; ++k) {
+                int lp = -1;
+                if (ord) lp = ord[k];
+                else {   // ascending LP order: the next LP that carries one
+                    lp = out.empty() ? 0 : out.back() + 1;
+                    while (lp < n && !(pass == 0 ? (st->src_kind ? st->src_kind[lp] : HS_SRC_POISSON) != HS_SRC_NONE
+                                                 : pm[(size_t)lp] != 255)) ++lp;
+                }
+                const bool has = lp >= 0 && lp < n && (pass == 0 ? (st->src_kind ? st->src_kind[lp] : HS_SRC_POISSON) != HS_SRC_NONE
+                                                                  : pm[(size_t)lp] != 255);
+                if (!has || seen[(size_t)lp])
+                    return fail(h, HS_E_INVALID, "%s must list every LP that carries one exactly once", pass == 0 ? "source_order" : "probe_order");
+                seen[(size_t)lp] = 1;
+                out.push_back(lp);
+            }
+        }
+        std::vector<int32_t> lp_of((size_t)n_sched);
+        for (int i = 0; i < n && n_sched > 0; ++i)
+            for (int64_t k = st->sched_off[i]; k < st->sched_off[i + 1]; ++k) lp_of[(size_t)k] = i;
+        std::vector<uint8_t> used((size_t)n_sched, (uint8_t)0);
+        for (int64_t j = 0; j < n_sched; ++j) {
+            const int64_t e = st->sched_call_order ? st->sched_call_order[j] : j;
+            if (e < 0 || e >= n_sched || used[(size_t)e]) return fail(h, HS_E_INVALID, "sched_call_order must be a permutation");
+            used[(size_t)e] = 1;
+            se[(size_t)j] = e; sl[(size_t)j] = lp_of[(size_t)e];
+        }
+        if ((rc = upload<int32_t>(h, &h->XI.src_lp, so.data(), so.size(), 0))) return rc;
+        if ((rc = upload<int32_t>(h, &h->XI.probe_lp, po.data(), po.size(), 0))) return rc;
+        if ((rc = upload<int32_t>(h, &h->XI.sched_lp, sl.data(), sl.size(), 0))) return rc;
+        if ((rc = upload<int64_t>(h, &h->XI.sched_entry, se.data(), se.size(), 0))) return rc;
+        h->XI.n_src = (int32_t)so.size(); h->XI.n_probe = (int32_t)po.size(); h->XI.n_sched = n_sched;
+        if ((rc = dev_alloc(h, &h->XI.sched_idx, (size_t)n_sched))) return rc;
+        HS_HIP(h, hipMemset(h->XI.sched_idx, 0, (size_t)(n_sched > 0 ? n_sched : 1) * sizeof(uint32_t)));
+        h->P.sched_idx = h->XI.sched_idx;
+        const int64_t n_init = (int64_t)so.size() + (int64_t)po.size() + n_sched;
+        h->xs_host = XState{};
+        h->xs_host.heap_cap = n_init + (int64_t)n * (h->C + 16) + 1024;
+        h->xs_host.pool_cap = 2 * n_init + 16 * (int64_t)n + 1024;
+        if ((rc = dev_alloc(h, &h->xs_host.heap, (size_t)h->xs_host.heap_cap))) return rc;
+        if ((rc = dev_alloc(h, &h->xs_host.qhead, (size_t)n))) return rc;
+        if ((rc = dev_alloc(h, &h->xs_host.qtail, (size_t)n))) return rc;
+        if ((rc = dev_alloc(h, &h->xs_host.pnext, (size_t)h->xs_host.pool_cap))) return rc;
+        if ((rc = dev_alloc(h, &h->xs_host.pidx, (size_t)h->xs_host.pool_cap))) return rc;
+        if ((rc = dev_alloc(h, &h->xs_host.init_t, (size_t)n_init))) return rc;
+        if ((rc = dev_alloc(h, &h->xs, 1))) return rc;
+        h->exact = true;
     }
     const size_t N = (size_t)n, NC = (size_t)n * (size_t)h->C;
 #define AL(field, count) if ((rc = dev_alloc(h, &h->X.field, count))) return rc
@@ -2137,9 +2280,13 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
     if (h->is_net) {
         if (h->net_global) return fail(h, HS_E_STATE, "a shard of a partitioned network is driven with hs_engine_shard_*");
         if (h->net_ran) return fail(h, HS_E_STATE, "network engine: one hs_engine_run_until per hs_engine_reset");
-        int rc = run_net_async(h, end_ns);
+        int rc = launch_prologue(h, end_ns);
+        if (rc) return rc;
+        rc = run_net_async(h, end_ns);
         if (rc) return rc;
     } else {
+        int rc = launch_prologue(h, end_ns);
+        if (rc) return rc;
         launch_run_dispatch(h, end_ns);
         HS_HIP(h, hipGetLastError());
         h->launches++;
@@ -2167,6 +2314,8 @@ int hs_engine_run_until(hs_engine *h, int64_t end_ns) {
     Totals t;
     HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
     if (t.qoverflow) return fail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
+    if (t.overflow & 16)
+        return fail(h, HS_E_OVERFLOW, "the prologue (csrc/hs_exact.hpp) ran out of heap / payload-pool space");
     if (t.overflow & 8)
         return fail(h, HS_E_HIP, "the asynchronous network engine gave up waiting for a neighbour (bounded spin); "
                                  "set debug flag 16 to use the windowed engine");
@@ -2189,6 +2338,7 @@ int hs_engine_bench_runs(hs_engine *h, int64_t end_ns, int32_t repeats, float *k
         int rc = do_reset_async(h);
         if (rc) return rc;
         HS_HIP(h, hipEventRecord(ev[(size_t)2 * r], h->stream));
+        { int rc1 = launch_prologue(h, end_ns); if (rc1) return rc1; }
         if (h->is_net) { h->launches = 0; int rc2 = run_net_async(h, end_ns); if (rc2) return rc2; }
         else launch_run_dispatch(h, end_ns);
         HS_HIP(h, hipGetLastError());

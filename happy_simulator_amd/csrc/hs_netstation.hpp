@@ -187,6 +187,7 @@ struct NetStation {
     // Simulation.schedule(): Requests injected before run() (hs_station.hpp); they precede every run-time event of their ns
     int64_t SA, sc_i, sc_end;
     const int64_t *sc_t;
+    const uint32_t *sc_idx;       // true sort indices of the injected Requests (after the prologue, hs_exact.hpp), or null
     // logs
     int64_t *adm, *sink_t, *sink_created;   // record k at [k * ls] (hs_station.hpp)
     int64_t cap, ls;
@@ -701,8 +702,11 @@ struct NetStation {
     // pending root at time t with the earliest creation: 0 none, 1 tick, 2+slot departure, 64+i message
     __device__ __forceinline__ int pick_root(int64_t t) const {
         int best = 0; int64_t bc = 0; uint32_t bs = 0; bool bmsg = false; int64_t bl = 0;
-        if (has_sched() && SA == t) return 62;
-        if (A == t) { best = 1; bc = crtA; bs = seqA; }
+        if (has_sched() && SA == t) {
+            if (sc_idx == nullptr) return 62;
+            best = 62; bc = INT64_MIN; bs = sc_idx[sc_i];           // constructed before run(): its true sort index
+        }
+        if (A == t && (best == 0 || (int32_t)(seqA - bs) < 0)) { best = 1; bc = crtA; bs = seqA; }
 #pragma unroll
         for (int i = 0; i < C; ++i)
             if (D[i] == t && (best == 0 || (int32_t)(seqD[i] - bs) < 0)) { best = 2 + i; bc = crtD[i]; bs = seqD[i]; }

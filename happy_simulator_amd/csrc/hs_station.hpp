@@ -84,6 +84,9 @@ struct StationParams {          // read-only, [n_lp] each
     // call order): LP lp owns sched_t[sched_off[lp] .. sched_off[lp + 1]).  null = none.
     const int64_t *sched_off;       // [n_lp + 1]
     const int64_t *sched_t;
+    // sort index of every injected Request, written by the prologue (hs_exact.hpp); null = no prologue ran: an injected
+    // Request then precedes every run-time event of its nanosecond (true once the run has constructed N_init events)
+    const uint32_t *sched_idx;
 };
 
 // what a Probe samples with getattr(target, metric) (instrumentation/probe.py:51-66)
@@ -191,6 +194,7 @@ struct Station {
     // run-time event of the same nanosecond
     int64_t SA, sc_i, sc_end;
     const int64_t *sc_t;
+    const uint32_t *sc_idx;
     // per-run deltas
     uint32_t ev[8];
     // logs
@@ -471,8 +475,13 @@ struct Station {
     __device__ __forceinline__ int pick_root(int64_t t) const {
         int best = -1;
         uint32_t bs = 0xffffffffu;
-        if constexpr (PF) { if (SA == t) return kRootSched; }
-        if (A == t) { best = 0; bs = seqA; }
+        if constexpr (PF) {
+            if (SA == t) {
+                if (sc_idx == nullptr) return kRootSched;
+                best = kRootSched; bs = sc_idx[sc_i];            // its true sort index (after the prologue: hs_exact.hpp)
+            }
+        }
+        if (A == t && (best < 0 || (int32_t)(seqA - bs) < 0)) { best = 0; bs = seqA; }
 #pragma unroll
         for (int i = 0; i < C; ++i)
             if (D[i] == t && (best < 0 || (int32_t)(seqD[i] - bs) < 0)) { best = 1 + i; bs = seqD[i]; }

@@ -35,6 +35,10 @@ class StationArrays:
     # Simulation.schedule(): Requests injected before run(); station i gets sched_time_ns[sched_off[i]:sched_off[i + 1]]
     sched_off: np.ndarray | None = None             # [n + 1] int64
     sched_time_ns: np.ndarray | None = None         # ascending per station, ties in the caller's order
+    # construction order of the reference's pre-run events (include/hs_engine.h): None = LP order / array order
+    source_order: np.ndarray | None = None          # LP indices of the Sources in `sources=[...]` order
+    probe_order: np.ndarray | None = None           # LP indices of the Probes in `probes=[...]` order
+    sched_call_order: np.ndarray | None = None      # j-th Event handed to schedule() -> its index in sched_time_ns
 
     @staticmethod
     def uniform(n: int, *, src_kind=N.SRC_POISSON, rate=8.0, stop_after_ns=-1, concurrency=1,
@@ -129,6 +133,24 @@ class StationEngine:
                 raise ValueError("sched_time_ns must hold sched_off[-1] times")
             keep += [off, tt]
             st.sched_off, st.sched_time_ns = off.ctypes.data, (tt.ctypes.data if len(tt) else None)
+            if stations.sched_call_order is not None:
+                co = np.ascontiguousarray(stations.sched_call_order, np.int64)
+                if co.shape != tt.shape or sorted(co.tolist()) != list(range(len(tt))):
+                    raise ValueError("sched_call_order must be a permutation of range(len(sched_time_ns))")
+                keep.append(co)
+                st.sched_call_order = co.ctypes.data if len(co) else None
+        for name, mask in (("source_order", np.asarray(stations.src_kind) != N.SRC_NONE),
+                           ("probe_order", None if stations.probe_metric is None
+                            else np.asarray(stations.probe_metric) != N.PROBE_NONE)):
+            a = getattr(stations, name)
+            if a is None:
+                continue
+            a = np.ascontiguousarray(a, np.int32)
+            want = np.flatnonzero(mask) if mask is not None else np.zeros(0, np.int64)
+            if sorted(a.tolist()) != want.tolist():
+                raise ValueError(f"{name} must list exactly the LPs that carry one, each once")
+            keep.append(a)
+            setattr(st, name, a.ctypes.data if len(a) else None)
         self.n_links = 0
         try:
             self._check(self._lib.hs_engine_set_stations(self._h, C.byref(st)))

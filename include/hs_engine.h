@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HS_ABI_VERSION 5
+#define HS_ABI_VERSION 6
 
 typedef enum hs_status {
     HS_OK = 0,
@@ -130,6 +130,17 @@ typedef struct hs_stations {
      * An Event built before run() precedes every run-time event of the same nanosecond on its LP.  NULL = none. */
     const int64_t *sched_off;          /* [n_lp + 1] */
     const int64_t *sched_time_ns;      /* [sched_off[n_lp]], each >= start_ns */
+    /* The order in which the reference CONSTRUCTS its pre-run events -- the first SourceEvent of every Source in
+     * `sources=[...]` order, the first tick of every Probe in `probes=[...]` order (Simulation.__init__,
+     * core/simulation.py:145-160), then the Events handed to schedule() in the order the caller built them -- fixes their
+     * `_sort_index` values 0 .. N_init-1 from the process-wide counter (core/event.py:53-77), while run() numbers its own
+     * events from 0 again (core/event_heap.py:48).  In HS_MODE_SINGLE, when probes or scheduled Requests exist, the engine
+     * runs the first N_init constructions of the run in the reference's exact heap order (csrc/hs_exact.hpp) so that every
+     * same-nanosecond meeting of the two counters is decided as the reference decides it.  All three NULL = LP order /
+     * array order. */
+    const int32_t *source_order;       /* [number of LPs with a Source] LP indices in `sources=` order */
+    const int32_t *probe_order;        /* [number of LPs with a Probe] LP indices in `probes=` order */
+    const int64_t *sched_call_order;   /* [sched_off[n_lp]] j-th constructed Event -> its index in sched_time_ns */
 } hs_stations;
 typedef enum hs_probe_metric {
     HS_PROBE_DEPTH = 0,        /* QueuedResource.depth */

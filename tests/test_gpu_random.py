@@ -13,14 +13,16 @@ from test_gpu_ring import _check_against_oracle
 pytestmark = pytest.mark.gpu
 
 STATION_CASES = list(range(40))
-# ring case 24 schedules two Requests for one Server at t = start: documented tie-break deviation (iii) of DESIGN.md section 5
-# (the engines count one Notify fewer than reference == oracle; every statistic and Sink record still agrees) -- it has
-# its own test below
-RING_CASES = [k for k in range(30) if k != 24]
+RING_CASES = list(range(30))          # incl. case 24: two Requests injected for one Server at the start instant
+# Tie storms (random_specs.tie_spec): lock-step constant sources, Requests injected at the start instant and on the sources'
+# own tick times, probes on the same nanoseconds, c <= 16 -- every order the reference's TWO sort counters decide, reproduced
+# by the prologue (csrc/hs_exact.hpp).  Case 85 is left out: its one event beyond end_time is a tie between two LPs whose
+# candidates were also CREATED in the same nanosecond (documented cross-LP deviation (i)).
+TIE_CASES = [k for k in range(100) if k != 85]
 
 
-def check_station_case(k):
-    spec = RS.station_spec(k)
+def check_station_case(k, spec=None):
+    spec = spec or RS.station_spec(k)
     spec["trace"] = False
     shared = bool(spec.pop("shared_sink", False))        # shared Sinks are merged by the API layer: tests/test_gpu_api.py
     runs = H.run_oracle_for_spec(spec)
@@ -66,23 +68,22 @@ def test_network_engines_match_oracle_on_random_specs(k, engine_flags):
     check_ring_case(k, engine_flags)
 
 
-def test_two_requests_scheduled_at_the_start_instant_deviate_by_one_notify():
-    """Deviation (iii), pinned so that it cannot change silently: the reference restarts the sort index at run(), so the
-    first injected Request's Notify / Poll overtake a second Request injected for the same Server at the start instant and
-    that one finds the queue empty again (a second Notify); the engines enqueue both first (one Notify).  Measured on MI355X:
-    220 (reference == oracle) vs 219 events, everything else identical."""
+@pytest.mark.parametrize("k", TIE_CASES)
+def test_tie_storms_match_oracle(k):
+    check_station_case(k, RS.tie_spec(k))
+
+
+def test_prologue_off_reproduces_the_old_deviation():
+    """The control experiment: with the prologue disabled (debug flag 256) ring case 24 -- two Requests injected for one Server
+    at the start instant -- counts one QUEUE_NOTIFY fewer than reference == oracle; with it (the default) the case is exact
+    (test_network_engines_match_oracle_on_random_specs[24-*])."""
     spec = RS.ring_spec(24)
     assert [e for e in spec["schedule"] if e[1] == 0.0] == [[1, 0.0], [1, 0.0]]
     g, nodes = H.oracle_ring_graph(spec)
     p = H.ring_params(spec)
     r = O.run(g, p["end_ns"], seed=spec["seed"], schedule=[(nodes[c]["srv"], t) for c, t in p["schedule"]])
-    for flags in (0, 16):
-        eng, p = H.ring_engine_for_spec(spec, flags=flags)
-        with eng:
-            eng.run_until(p["end_ns"])
-            s, st = eng.summary(), eng.lp_stats()
-            diff = np.asarray(r.events_by_kind) - np.asarray(s.events_by_kind)
-            assert diff.tolist() == [0, 0, 1] + [0] * (len(diff) - 3) and r.events_processed - s.events_processed == 1
-            assert s.final_time_ns == r.final_time_ns
-            srv = [nodes[i]["srv"] for i in range(spec["n"])]
-            np.testing.assert_array_equal(st["accepted"], r.accepted[srv])
+    eng, p = H.ring_engine_for_spec(spec, flags=16 | 256)
+    with eng:
+        eng.run_until(p["end_ns"])
+        s = eng.summary()
+        assert r.events_processed - s.events_processed == 1
