@@ -65,7 +65,7 @@ class Stations(C.Structure):
         ("src_profile_kind", C.c_void_p), ("src_profile_params", C.c_void_p),
         ("probe_metric", C.c_void_p), ("probe_interval_s", C.c_void_p),
         ("sched_off", C.c_void_p), ("sched_time_ns", C.c_void_p),
-        ("source_order", C.c_void_p), ("probe_order", C.c_void_p), ("sched_call_order", C.c_void_p),
+        ("source_order", C.c_void_p), ("probe_order", C.c_void_p), ("sched_rank", C.c_void_p),
     ]
 
 

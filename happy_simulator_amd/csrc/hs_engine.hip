@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <new>
 #include <string>
 #include <vector>
@@ -43,7 +44,7 @@ __device__ __forceinline__ bool cand_less(const Candidate &a, const Candidate &b
     if (!a.valid) return false;
     if (a.t != b.t) return a.t < b.t;
     if (a.t_created != b.t_created) return a.t_created < b.t_created;
-    return a.lp < b.lp;
+    return a.rank < b.rank;
 }
 
 __device__ __forceinline__ Candidate wave_min_cand(Candidate c) {
@@ -53,6 +54,7 @@ __device__ __forceinline__ Candidate wave_min_cand(Candidate c) {
         d.t = shfl_xor_ll(c.t, o);
         d.t_created = shfl_xor_ll(c.t_created, o);
         d.lp = __shfl_xor(c.lp, o, 64);
+        d.rank = __shfl_xor(c.rank, o, 64);
         d.valid = __shfl_xor(c.valid, o, 64);
         if (cand_less(d, c)) c = d;
     }
@@ -152,7 +154,7 @@ __device__ __forceinline__ void store_station(const Station<C, PF> &Sc, const St
 template <int C, bool PF>
 __device__ __forceinline__ Candidate make_candidate(const Station<C, PF> &S) {
     Candidate c;
-    c.lp = S.lp; c.valid = 0; c.t = kInfNs; c.t_created = 0;
+    c.lp = S.lp; c.rank = S.lp; c.valid = 0; c.t = kInfNs; c.t_created = 0;
     if (S.qn > 0) {   // a group already in progress keeps the floor
         c.t = S.grp_time; c.t_created = S.grp_time; c.valid = 1;
         return c;
@@ -298,7 +300,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
 
     Station<C, PF> S;
     Candidate mine;
-    mine.valid = 0; mine.t = kInfNs; mine.t_created = 0; mine.lp = lp;
+    mine.valid = 0; mine.t = kInfNs; mine.t_created = 0; mine.lp = lp; mine.rank = lp;
     if (live) {
         load_station<C, PF>(S, P, X, L, lp, n, qmem, ring_a, ring_s, tid);
         S.force_general = (flags & 1) != 0;
@@ -369,7 +371,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
                 }
             }
             if (mode == HS_MODE_REPLICAS) overshoot_one<C, PF>(S);
-            else mine = make_candidate<C, PF>(S);
+            else { mine = make_candidate<C, PF>(S); mine.rank = P.tie_rank != nullptr ? P.tie_rank[lp] : lp; }
         }
         store_station<C, PF>(S, X, lp, n);
     }
@@ -424,12 +426,13 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
     if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     Candidate best;
-    best.valid = 0; best.t = kInfNs; best.t_created = 0; best.lp = 0;
+    best.valid = 0; best.t = kInfNs; best.t_created = 0; best.lp = 0; best.rank = 0;
     for (int b = tid; b < (int)gridDim.x; b += kBlock) {
         Candidate c;
         c.t = __hip_atomic_load(&cands[b].t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         c.t_created = __hip_atomic_load(&cands[b].t_created, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         c.lp = __hip_atomic_load(&cands[b].lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.rank = __hip_atomic_load(&cands[b].rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         c.valid = __hip_atomic_load(&cands[b].valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cand_less(c, best)) best = c;
     }
@@ -766,7 +769,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
 
     NetStation<C> S;
     Candidate mine;
-    mine.valid = 0; mine.t = kInfNs; mine.t_created = 0; mine.lp = lp;
+    mine.valid = 0; mine.t = kInfNs; mine.t_created = 0; mine.lp = lp; mine.rank = lp;
     if (act) {
         load_net<C>(S, P, NP, X, NX, L, lp, n, qmem, enqpay, tid, send_idx, SC);
         for (;;) {
@@ -844,12 +847,13 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
     if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     Candidate best;
-    best.valid = 0; best.t = kInfNs; best.t_created = 0; best.lp = 0;
+    best.valid = 0; best.t = kInfNs; best.t_created = 0; best.lp = 0; best.rank = 0;
     for (int b = tid; b < (int)gridDim.x; b += kBlock) {
         Candidate c;
         c.t = __hip_atomic_load(&cands[b].t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         c.t_created = __hip_atomic_load(&cands[b].t_created, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         c.lp = __hip_atomic_load(&cands[b].lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.rank = __hip_atomic_load(&cands[b].rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         c.valid = __hip_atomic_load(&cands[b].valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cand_less(c, best)) best = c;
     }
@@ -1729,6 +1733,20 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if ((rc = upload<int64_t>(h, &h->P.sched_off, st->sched_off, (size_t)n + 1, 0))) return rc;
         if ((rc = upload<int64_t>(h, &h->P.sched_t, st->sched_time_ns, (size_t)n_sched, 0))) return rc;
     }
+    h->P.tie_rank = nullptr;
+    if (st->source_order) {
+        std::vector<int32_t> tr((size_t)n, -1);
+        int32_t k = 0;
+        for (int i = 0; i < n; ++i)
+            if ((st->src_kind ? st->src_kind[i] : HS_SRC_POISSON) != HS_SRC_NONE) {
+                const int32_t lp = st->source_order[k];
+                if (lp < 0 || lp >= n || tr[(size_t)lp] >= 0 || (st->src_kind ? st->src_kind[lp] : HS_SRC_POISSON) == HS_SRC_NONE)
+                    return fail(h, HS_E_INVALID, "source_order must list every LP that carries a Source exactly once");
+                tr[(size_t)lp] = k++;
+            }
+        for (int i = 0; i < n; ++i) if (tr[(size_t)i] < 0) tr[(size_t)i] = k++;
+        if ((rc = upload<int32_t>(h, &h->P.tie_rank, tr.data(), (size_t)n, 0))) return rc;
+    }
     h->P.sched_idx = nullptr;
     if (h->cfg.mode == HS_MODE_SINGLE && (n_sched > 0 || h->any_probe)) {
         // The prologue (hs_exact.hpp): the reference's pre-run events in the order it constructs them
@@ -1764,13 +1782,21 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         std::vector<int32_t> lp_of((size_t)n_sched);
         for (int i = 0; i < n && n_sched > 0; ++i)
             for (int64_t k = st->sched_off[i]; k < st->sched_off[i + 1]; ++k) lp_of[(size_t)k] = i;
-        std::vector<uint8_t> used((size_t)n_sched, (uint8_t)0);
-        for (int64_t j = 0; j < n_sched; ++j) {
-            const int64_t e = st->sched_call_order ? st->sched_call_order[j] : j;
-            if (e < 0 || e >= n_sched || used[(size_t)e]) return fail(h, HS_E_INVALID, "sched_call_order must be a permutation");
-            used[(size_t)e] = 1;
-            se[(size_t)j] = e; sl[(size_t)j] = lp_of[(size_t)e];
+        std::vector<int64_t> sr((size_t)n_sched);
+        for (int64_t j = 0; j < n_sched; ++j) se[(size_t)j] = j;
+        if (st->sched_rank) {
+            std::sort(se.begin(), se.end(), [&](int64_t a, int64_t b) { return st->sched_rank[a] < st->sched_rank[b]; });
+            for (int64_t j = 0; j < n_sched; ++j) {
+                const int64_t r = st->sched_rank[se[(size_t)j]];
+                if (r < 0 || (j > 0 && r == st->sched_rank[se[(size_t)j - 1]]))
+                    return fail(h, HS_E_INVALID, "sched_rank must hold distinct positions >= 0");
+            }
         }
+        for (int64_t j = 0; j < n_sched; ++j) {
+            sl[(size_t)j] = lp_of[(size_t)se[(size_t)j]];
+            sr[(size_t)j] = st->sched_rank ? st->sched_rank[se[(size_t)j]] : j;
+        }
+        if ((rc = upload<int64_t>(h, &h->XI.sched_rank, sr.data(), sr.size(), 0))) return rc;
         if ((rc = upload<int32_t>(h, &h->XI.src_lp, so.data(), so.size(), 0))) return rc;
         if ((rc = upload<int32_t>(h, &h->XI.probe_lp, po.data(), po.size(), 0))) return rc;
         if ((rc = upload<int32_t>(h, &h->XI.sched_lp, sl.data(), sl.size(), 0))) return rc;
@@ -1779,7 +1805,10 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if ((rc = dev_alloc(h, &h->XI.sched_idx, (size_t)n_sched))) return rc;
         HS_HIP(h, hipMemset(h->XI.sched_idx, 0, (size_t)(n_sched > 0 ? n_sched : 1) * sizeof(uint32_t)));
         h->P.sched_idx = h->XI.sched_idx;
-        const int64_t n_init = (int64_t)so.size() + (int64_t)po.size() + n_sched;
+        int64_t rank_span = 0;                                  // positions 0 .. rank_span-1 (cancelled Events leave gaps)
+        for (int64_t j = 0; j < n_sched; ++j) if (sr[(size_t)j] + 1 > rank_span) rank_span = sr[(size_t)j] + 1;
+        if (rank_span > n_sched + (1 << 20)) return fail(h, HS_E_INVALID, "sched_rank positions are implausibly sparse");
+        const int64_t n_init = (int64_t)so.size() + (int64_t)po.size() + rank_span;
         h->xs_host = XState{};
         h->xs_host.heap_cap = n_init + (int64_t)n * (h->C + 16) + 1024;
         h->xs_host.pool_cap = 2 * n_init + 16 * (int64_t)n + 1024;

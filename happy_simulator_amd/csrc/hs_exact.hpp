@@ -76,6 +76,7 @@ struct XInit {        // pre-run events in the order the reference constructs th
     const int32_t *probe_lp;     // [n_probe] LPs of the Probes in `probes=[...]` order
     const int32_t *sched_lp;     // [n_sched] LP of the j-th Event handed to schedule(), in construction order
     const int64_t *sched_entry;  // [n_sched] its position in StationParams::sched_t
+    const int64_t *sched_rank;   // [n_sched] its position among all Events the caller constructed (cancelled ones leave gaps)
     int32_t n_src, n_probe;
     int64_t n_sched;
     uint32_t *sched_idx;         // [n_sched] OUT, indexed like sched_t: the Event's sort index
@@ -164,9 +165,11 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
             S.init_t[g] = a;
             xpush(S, xev(a, g++, XE_PTICK, lp, 0, 0, kXInitFlag));
         }
+        const unsigned long long g0 = g;
         for (int64_t j = 0; j < I.n_sched; ++j) {
             const int64_t e = I.sched_entry[j];
             const int64_t t = P.sched_t[e];
+            g = g0 + (unsigned long long)I.sched_rank[j];
             I.sched_idx[e] = (uint32_t)g;
             S.init_t[g] = t;
             xpush(S, xev(t, g++, XE_SCHED, I.sched_lp[j], t, 0, kXInitFlag));   // context["created_at"] = its own time (event.py:176)

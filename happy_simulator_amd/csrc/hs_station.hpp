@@ -87,6 +87,9 @@ struct StationParams {          // read-only, [n_lp] each
     // sort index of every injected Request, written by the prologue (hs_exact.hpp); null = no prologue ran: an injected
     // Request then precedes every run-time event of its nanosecond (true once the run has constructed N_init events)
     const uint32_t *sched_idx;
+    // cross-LP ties the creation times do not decide go to the Source the reference constructed first: the LP's position in
+    // `sources=[...]` (sourceless LPs after them); null = LP order
+    const int32_t *tie_rank;
 };
 
 // what a Probe samples with getattr(target, metric) (instrumentation/probe.py:51-66)
@@ -152,6 +155,8 @@ struct Candidate {              // an LP's first event beyond end_ns (SINGLE-mod
     long long t_created;        // when it was created (proxy for the global sort index)
     int lp;
     int valid;
+    int rank;                   // last key: the LP's position in the reference's construction order (`sources=[...]`), else lp
+    int pad;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -38,7 +38,7 @@ class StationArrays:
     # construction order of the reference's pre-run events (include/hs_engine.h): None = LP order / array order
     source_order: np.ndarray | None = None          # LP indices of the Sources in `sources=[...]` order
     probe_order: np.ndarray | None = None           # LP indices of the Probes in `probes=[...]` order
-    sched_call_order: np.ndarray | None = None      # j-th Event handed to schedule() -> its index in sched_time_ns
+    sched_rank: np.ndarray | None = None            # like sched_time_ns: the Event's position among all constructed Events
 
     @staticmethod
     def uniform(n: int, *, src_kind=N.SRC_POISSON, rate=8.0, stop_after_ns=-1, concurrency=1,
@@ -133,12 +133,12 @@ class StationEngine:
                 raise ValueError("sched_time_ns must hold sched_off[-1] times")
             keep += [off, tt]
             st.sched_off, st.sched_time_ns = off.ctypes.data, (tt.ctypes.data if len(tt) else None)
-            if stations.sched_call_order is not None:
-                co = np.ascontiguousarray(stations.sched_call_order, np.int64)
-                if co.shape != tt.shape or sorted(co.tolist()) != list(range(len(tt))):
-                    raise ValueError("sched_call_order must be a permutation of range(len(sched_time_ns))")
+            if stations.sched_rank is not None:
+                co = np.ascontiguousarray(stations.sched_rank, np.int64)
+                if co.shape != tt.shape or len(set(co.tolist())) != len(co) or (len(co) and co.min() < 0):
+                    raise ValueError("sched_rank must hold one distinct position >= 0 per scheduled time")
                 keep.append(co)
-                st.sched_call_order = co.ctypes.data if len(co) else None
+                st.sched_rank = co.ctypes.data if len(co) else None
         for name, mask in (("source_order", np.asarray(stations.src_kind) != N.SRC_NONE),
                            ("probe_order", None if stations.probe_metric is None
                             else np.asarray(stations.probe_metric) != N.PROBE_NONE)):

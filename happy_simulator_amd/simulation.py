@@ -73,10 +73,10 @@ class Simulation:
         if not self._scheduled:
             return []
         station_of = {id(st.server): i for i, st in enumerate(g.stations) if st.server is not None}
-        per: list[list[int]] = [[] for _ in g.stations]
+        per: list[list[tuple[int, int]]] = [[] for _ in g.stations]
         cancelled: list[int] = []
         start_ns = self._start_time.nanoseconds
-        for ev in self._scheduled:
+        for rank, ev in enumerate(self._scheduled):     # rank: the Event's position among everything the caller constructed
             if ev.cancelled:                       # lazy deletion: skipped when popped, counted (simulation.py:475-477)
                 cancelled.append(ev.time.nanoseconds)
                 continue
@@ -91,19 +91,15 @@ class Simulation:
             if ev.time.nanoseconds < start_ns:     # "time travel": the loop skips it without counting (simulation.py:480-489)
                 warnings.warn(f"Time travel detected: {ev!r} lies before the simulation start; skipping event", stacklevel=3)
                 continue
-            per[i].append(ev.time.nanoseconds)
-        if any(p.count(start_ns) > 1 for p in per):
-            # DESIGN.md section 5, deviation (iii): the reference numbers injected Events from the process-wide counter and
-            # run-time events from 0 again, so at the very start of a run the Notify / Poll of the first Request overtake
-            # a second Request injected for the same Server and instant; the engine takes injected Requests first.
-            warnings.warn("several Requests are scheduled for one Server at exactly the start time: the reference lets the "
-                          "first one's queue events overtake the others (sort-index restart at run()); this engine enqueues "
-                          "them back to back, so event totals (and, with a bounded queue, drops) of that instant can differ",
-                          stacklevel=3)
+            per[i].append((ev.time.nanoseconds, rank))
+        # Same-nanosecond order against run-time events is the reference's: the engine replays the first constructions of
+        # the run in exact heap order (csrc/hs_exact.hpp) from the construction ranks handed over here.
         off = np.zeros(len(g.stations) + 1, np.int64)
         off[1:] = np.cumsum([len(p) for p in per])
+        flat = [tr for p in per for tr in sorted(p)]                         # ascending time, ties in construction order
         arrays.sched_off = off
-        arrays.sched_time_ns = np.array([t for p in per for t in sorted(p)], np.int64)   # sorted() is stable
+        arrays.sched_time_ns = np.array([t for t, _ in flat], np.int64)
+        arrays.sched_rank = np.array([r for _, r in flat], np.int64)
         return cancelled
 
     @property
@@ -152,6 +148,11 @@ class Simulation:
         net = g.network_arrays() if g.is_network else None
         horizon_s = (end_ns - self._start_time.nanoseconds) / 1e9
         arrays = g.arrays()
+        # the order in which Simulation.__init__ constructs the first SourceEvents / probe ticks (core/simulation.py:145-160)
+        st_of = {id(o): i for i, st in enumerate(g.stations) for o in (st.source, st.probe) if o is not None}
+        arrays.source_order = np.array([st_of[id(s)] for s in self._sources], np.int32)
+        if self._probes:
+            arrays.probe_order = np.array([st_of[id(p)] for p in self._probes], np.int32)
         cancelled_ns = self._schedule_arrays(g, arrays)
         if net is not None and arrays.n > self._resident_stations():
             return self._run_time_shared(g, arrays, net, end_ns, horizon_s, wall0, cancelled_ns)

@@ -140,7 +140,10 @@ typedef struct hs_stations {
      * array order. */
     const int32_t *source_order;       /* [number of LPs with a Source] LP indices in `sources=` order */
     const int32_t *probe_order;        /* [number of LPs with a Probe] LP indices in `probes=` order */
-    const int64_t *sched_call_order;   /* [sched_off[n_lp]] j-th constructed Event -> its index in sched_time_ns */
+    const int64_t *sched_rank;         /* [sched_off[n_lp]], indexed like sched_time_ns: the Event's position among ALL the
+                                          Events the caller constructed for schedule(), distinct and >= 0 (an Event that was
+                                          cancelled before run() keeps its position -- it consumed a sort index -- but is not
+                                          passed to the engine); NULL = array order */
 } hs_stations;
 typedef enum hs_probe_metric {
     HS_PROBE_DEPTH = 0,        /* QueuedResource.depth */

@@ -203,7 +203,7 @@ def oracle_lb_graph(spec):
 
 def sched_arrays(n, schedule):
     """Simulation.schedule() calls [(station, t_ns), ...] in construction order -> (sched_off, sched_time_ns per station
-    ascending with ties in call order, sched_call_order: j-th call -> its index in sched_time_ns)."""
+    ascending with ties in call order, sched_rank: for every entry of sched_time_ns its position among the calls)."""
     per = [[] for _ in range(n)]
     for j, (c, t) in enumerate(schedule):
         per[c].append((t, j))
@@ -211,10 +211,8 @@ def sched_arrays(n, schedule):
     off[1:] = np.cumsum([len(x) for x in per])
     flat = [tj for x in per for tj in sorted(x)]          # (t, j): ascending time, ties in call order
     times = np.array([t for t, _ in flat], np.int64)
-    call_order = np.zeros(len(flat), np.int64)
-    for pos, (_, j) in enumerate(flat):
-        call_order[j] = pos
-    return off, times, call_order
+    rank = np.array([j for _, j in flat], np.int64)
+    return off, times, rank
 
 
 # ----------------------------------------------------------------------------------------------
@@ -256,7 +254,7 @@ def engine_for_spec(spec, log_capacity=0, horizon_ns=None, flags=0):
                 st.probe_metric[i] = PROBE_METRICS[pr[0]][1]
                 st.probe_interval_s[i] = pr[1]
     if p["schedule"]:              # Simulation.schedule(): per station ascending, ties in call order (stable sort)
-        st.sched_off, st.sched_time_ns, st.sched_call_order = sched_arrays(n, p["schedule"])
+        st.sched_off, st.sched_time_ns, st.sched_rank = sched_arrays(n, p["schedule"])
     if spec["mode"] == "single":
         mode = N.MODE_SINGLE
         seed = spec["seed"]
@@ -330,7 +328,7 @@ def ring_arrays(spec, bag_capacity=0, log_capacity=0):
                 st.src_profile_params[i, :len(pr) - 1] = pr[1:]
                 st.src_rate[i] = max(pr[2], pr[3]) if pr[0] == "ramp" else max(pr[1], pr[2])   # peak: sizes the logs
     if p["schedule"]:
-        st.sched_off, st.sched_time_ns, st.sched_call_order = sched_arrays(n, p["schedule"])
+        st.sched_off, st.sched_time_ns, st.sched_rank = sched_arrays(n, p["schedule"])
     jit = p["jitter_mean"]
     net = NetworkArrays(
         egress_kind=np.full(n, N.EGRESS_ROUTER, np.uint8),

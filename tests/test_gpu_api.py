@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import happy_simulator_amd as hs
+from oracle import hs_oracle as O
 import helpers as H
 from happy_simulator_amd import Instant
 
@@ -564,3 +565,58 @@ def test_profiles_and_schedule_on_a_large_network_through_the_api_match_oracle()
     for i in range(n):
         t, created = r.sinks[snk[i]]
         assert [x.nanoseconds for x in sinks[i].completion_times] == t.tolist()
+
+
+@pytest.mark.parametrize("k", [5, 7, 8, 10, 26, 62, 3, 17])
+def test_tie_storms_through_the_api_with_sources_listed_in_another_order(k):
+    """The reference numbers its pre-run events in the order `sources=[...]`, `probes=[...]` and the schedule() calls construct
+    them; the API hands that order to the engine (hs_stations.source_order / probe_order / sched_rank) and the prologue
+    (csrc/hs_exact.hpp) replays the two sort counters.  Tie storms (several Requests injected for one Server at the start
+    instant, lock-step constant sources, probes on the same nanoseconds) with the Sources listed BACKWARDS, against the oracle
+    built in that same construction order."""
+    import random_specs as RS
+
+    spec = RS.tie_spec(k)
+    spec.pop("shared_sink", None)
+    p = H.spec_chain_params(spec)
+    n = p["n"]
+    perm = list(range(n))[::-1]
+    g, nodes = H.oracle_graph_for(spec, perm, perm)                  # sources, then probes, constructed in `perm` order
+    r = O.run(g, p["end_ns"], seed=spec["seed"], schedule=[(nodes[c][1], t) for c, t in p["schedule"]])
+    sinks = [hs.Sink(f"sink{i}") if p["downstream"] else None for i in range(n)]
+    servers = [hs.Server(f"srv{i}", concurrency=p["conc"][i],
+                         service_time=(hs.ExponentialLatency if H.per_chain(spec["svc"], n)[i] == "exp"
+                                       else hs.ConstantLatency)(p["mean"][i]),
+                         queue_capacity=None if p["qcap"][i] < 0 else p["qcap"][i], downstream=sinks[i]) for i in range(n)]
+    stop = None if p["stop_ns"] < 0 else spec["stop_after_s"]
+    srcs = {}
+    for i in range(n):
+        make = hs.Source.poisson if H.per_chain(spec["arr"], n)[i] == "poisson" else hs.Source.constant
+        srcs[i] = make(rate=p["rate"][i], target=servers[i], name=f"src{i}", stop_after=stop)
+    probes, datas = [], {}
+    for c in perm:
+        if p["probes"][c] is not None:
+            metric, interval = p["probes"][c]
+            target = {"server": servers[c], "sink": sinks[c], "source": srcs[c]}[H.PROBE_METRICS[metric][0]]
+            pr, datas[c] = hs.Probe.on(target, metric, interval=interval)
+            probes.append(pr)
+    entities = [e for pair in zip(servers, sinks) for e in pair if e is not None]      # station i = chain i = stream base i
+    sim = hs.Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=[srcs[c] for c in perm], entities=entities,
+                        probes=probes, seed=spec["seed"])
+    for c, t in spec.get("schedule") or []:
+        sim.schedule(hs.Event(time=Instant.from_seconds(float(t)), event_type="Request", target=servers[c]))
+    summary = sim.run()
+    assert summary.total_events_processed == r.events_processed
+    assert int(round(summary.duration_s * 1e9)) == r.final_time_ns
+    srv = [nodes[c][1] for c in range(n)]
+    assert [s.stats_accepted for s in servers] == r.accepted[srv].tolist()
+    assert [s.stats_dropped for s in servers] == r.dropped[srv].tolist()
+    assert [s.stats.requests_completed for s in servers] == r.completed[srv].tolist()
+    assert [s.stats.total_service_time for s in servers] == r.total_service_s[srv].tolist()
+    assert [srcs[c].generated_count for c in range(n)] == [int(r.generated[nodes[c][0]]) for c in range(n)]
+    for c in range(n):
+        if sinks[c] is not None:
+            assert [t.nanoseconds for t in sinks[c].completion_times] == r.sinks[nodes[c][2]][0].tolist()
+        if c in datas:
+            t, v = r.sinks[g.probe_nodes[c]]
+            assert datas[c].raw_values() == v.tolist()

@@ -423,8 +423,10 @@ def test_parallel_summary_mirror_equals_the_live_reference_class():
     assert str(MySS(1.5, 10)) == str(RefSS(1.5, 10)) and MySS(1.5, 10).to_dict() == RefSS(1.5, 10).to_dict()
 
 
-def test_two_requests_scheduled_at_the_start_instant_warn_about_the_tie_break():
-    """the one practical instance of the injected-event tie-break deviation is announced."""
+def test_scheduled_requests_carry_their_construction_rank():
+    """Simulation.schedule(): several Requests for one Server at exactly the start time used to be announced as a tie-break
+    deviation; the engine now replays the reference's two sort counters (csrc/hs_exact.hpp) from the construction ranks --
+    no warning, and a cancelled Event keeps its rank (it consumed a sort index) without being handed to the engine."""
     import warnings
 
     from happy_simulator_amd.engine import StationArrays
@@ -432,16 +434,15 @@ def test_two_requests_scheduled_at_the_start_instant_warn_about_the_tie_break():
     sink = hs.Sink()
     srv = hs.Server("srv", service_time=hs.ConstantLatency(0.1), downstream=sink)
     sim = hs.Simulation(end_time=Instant.from_seconds(1.0), sources=[], entities=[srv, sink])
-    for t in (0.0, 0.5, 0.5, 0.0):
-        sim.schedule(hs.Event(time=Instant.from_seconds(t), event_type="Request", target=srv))
+    evs = [hs.Event(time=Instant.from_seconds(t), event_type="Request", target=srv) for t in (0.0, 0.5, 0.5, 0.0, 0.25)]
+    for ev in evs:
+        sim.schedule(ev)
+    evs[2].cancel()
     g = sim.lowered()
-    with pytest.warns(UserWarning, match="exactly the start time"):
-        sim._schedule_arrays(g, g.arrays())
-    sim2 = hs.Simulation(end_time=Instant.from_seconds(1.0), sources=[], entities=[srv, sink])
-    for t in (0.0, 0.5, 0.5):                           # duplicates later in the run are ordered exactly: no warning
-        sim2.schedule(hs.Event(time=Instant.from_seconds(t), event_type="Request", target=srv))
+    arrays = g.arrays()
     with warnings.catch_warnings():
         warnings.simplefilter("error")
-        arrays = g.arrays()
-        sim2._schedule_arrays(sim2.lowered(), arrays)
-    assert arrays.sched_time_ns.tolist() == [0, 500_000_000, 500_000_000] and isinstance(arrays, StationArrays)
+        cancelled = sim._schedule_arrays(g, arrays)
+    assert isinstance(arrays, StationArrays) and cancelled == [500_000_000]
+    assert arrays.sched_time_ns.tolist() == [0, 0, 250_000_000, 500_000_000]
+    assert arrays.sched_rank.tolist() == [0, 3, 4, 1]
