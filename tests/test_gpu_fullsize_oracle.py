@@ -1,0 +1,75 @@
+"""GPU: exact oracle parity at the BASELINE station counts -- every LP, every statistic, every Sink record.
+
+The oracle runs ONE heap for the whole configuration, as the reference would (the grid: 65 536 chains x 60 s = 2.4e8 events
+in about half a minute on one host core; the ring and the load balancer over a shorter horizon so that the whole file
+stays under a minute of CPU).  Bar: array equality."""
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import hs_oracle as O
+from test_gpu_ring import _check_against_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_grid_65536_chains_60s_every_lp_equals_the_single_heap_oracle():
+    """The headline workload itself (bench.py --workload grid): 65 536 Source.poisson(8) -> Server(Exp 0.1) -> Sink chains in
+    one Simulation, 60 s, seed 42."""
+    n, end_ns = 65536, 60_000_000_000
+    spec = dict(name="grid_full", n_chains=n, arr="poisson", rate=8.0, svc="exp", mean=0.1, end_s=60.0, rng="philox",
+                seed=42, mode="single")
+    g = O.mm1_chains(n, rate=8.0, mean=0.1)
+    r = O.run(g, end_ns, seed=42)
+    eng, p = H.engine_for_spec(spec)
+    with eng:
+        eng.run_until(end_ns)
+        s, st = eng.summary(), eng.lp_stats()
+        counts, t, cr = eng.read_sinks()
+    assert s.events_processed == r.events_processed == 237_150_263
+    np.testing.assert_array_equal(s.events_by_kind, r.events_by_kind)
+    assert s.final_time_ns == r.final_time_ns
+    src, srv, snk = np.arange(n), n + 2 * np.arange(n), n + 2 * np.arange(n) + 1      # mm1_chains node order
+    np.testing.assert_array_equal(st["generated"], r.generated[src])
+    for k, arr in (("accepted", r.accepted), ("dropped", r.dropped), ("completed", r.completed), ("rejected", r.rejected),
+                   ("queue_depth", r.depth), ("active", r.active), ("total_service_s", r.total_service_s)):
+        np.testing.assert_array_equal(st[k], arr[srv], err_msg=k)
+    np.testing.assert_array_equal(st["sink_received"], r.received[snk])
+    np.testing.assert_array_equal(counts, r.received[snk])
+    np.testing.assert_array_equal(t, np.concatenate([r.sinks[int(i)][0] for i in snk]))
+    np.testing.assert_array_equal(cr, np.concatenate([r.sinks[int(i)][1] for i in snk]))
+
+
+RING_SPEC = dict(name="ring_full_10s", topology="ring", n=65536, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.01,
+                 end_s=10.0, seed=42)
+
+
+@pytest.fixture(scope="module")
+def ring_oracle():
+    g, nodes = H.oracle_ring_graph(RING_SPEC)
+    return O.run(g, H.ring_params(RING_SPEC)["end_ns"], seed=RING_SPEC["seed"]), nodes
+
+
+@pytest.mark.parametrize("engine_flags", [0, 16], ids=["async", "windowed"])
+def test_ring_65536_stations_10s_equals_the_oracle(engine_flags, ring_oracle):
+    """BASELINE configs[2] at its station count, 10 s (4.2e7 events): totals, per-station statistics, router / link counters
+    and every Sink record of both network engines against the oracle's single heap."""
+    r, nodes = ring_oracle
+    eng, p = H.ring_engine_for_spec(RING_SPEC, flags=engine_flags)
+    with eng:
+        eng.run_until(p["end_ns"])
+        assert eng.summary().events_processed > 40_000_000
+        _check_against_oracle(RING_SPEC, eng, r, nodes)
+
+
+def test_lb_32768_backends_3s_equals_the_oracle():
+    """BASELINE configs[4] at its size (32 768 sources -> LoadBalancer(ConsistentHash(150)) -> 32 768 servers -> one Sink),
+    3 s: the md5 ring, every routing decision, every backend's statistics and the shared Sink's record order."""
+    spec = dict(n_sources=32768, n_backends=32768, rate=6.0, mean=0.1, vnodes=150, n_clients=1 << 20, end_s=3.0, seed=42)
+    g, p = H.oracle_lb_graph(spec)
+    r = O.run(g, p["end_ns"], seed=spec["seed"])
+    eng, p = H.lb_engine_for_spec(spec)
+    with eng:
+        eng.run(p["end_ns"])
+        assert eng.summary().events_processed > 5_000_000
+        H.compare_lb_engine_with_oracle(eng, p, r)
