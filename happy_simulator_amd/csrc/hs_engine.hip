@@ -278,9 +278,20 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
 // The hot kernel: every LP advances to end_ns (== Simulation._execute_until for its events), then the
 // one-event overshoot is applied (per LP in REPLICAS mode; to the globally first event in SINGLE mode,
 // elected across workgroups with a last-block reduction).
-template <int C, bool PF>
-__global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, StationState X, RecordLogs L, Totals *tot,
+//
+// PC (producer / consumer, the <1, false> instantiation): the per-request work has two halves of about equal cost -- the
+// stream values (Philox4x32-10, hs_log, the constant-divisor quotients, the ns truncations: independent from request to
+// request) and the serial request step (the ns recursion, the Lindley recursion, event counting, the log appends).  With one
+// LP per lane a 65 536-LP grid is ONE wavefront per SIMD, so inside one wavefront the two halves only alternate and the
+// SIMD idles on every dependent-instruction latency (measured: VALU busy 47 % of the wave's cycles).  PC launches 512
+// threads per 256 LPs: wavefronts 0-3 run the request step for LP `tid`, wavefronts 4-7 -- one on each SIMD, next to its
+// consumer -- produce the same LP's stream values into the same LDS rings, and the SIMD interleaves the two instruction
+// streams.  The rings become single-producer / single-consumer queues with 16-bit produced / consumed counters in LDS
+// (release / acquire at workgroup scope); values are pure functions of (stream, index), so who computes them is invisible.
+template <int C, bool PF, bool PC = false>
+__global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(StationParams P, StationState X, RecordLogs L, Totals *tot,
                                                          Candidate *cands, int n, int64_t end_ns, int mode, int flags) {
+    static_assert(!PC || (C == 1 && !PF), "producer / consumer waves serve the request-order loop of <1, false>");
     __shared__ uint8_t qmem[kQCap][kBlock];
     __shared__ double ring_a[kRing][kBlock];    // pre-drawn arrival increments, one column per LP
     __shared__ double ring_s[kRing][kBlock];    // pre-drawn service times
@@ -289,87 +300,192 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
     __shared__ int red_flags[2];
     __shared__ Candidate wave_c[kBlock / 64];
     __shared__ int is_last;
+    __shared__ uint32_t pc_prod[PC ? kBlock : 1];   // values produced so far: arrival count | service count << 16 (mod 2^16)
+    __shared__ uint32_t pc_cons[PC ? kBlock : 1];   // values consumed so far, same packing
+    __shared__ int pc_done[kBlock / 64];            // consumer wavefront w has left the request-order loop
 
-    const int tid = threadIdx.x;
+    const int tid = PC ? (int)(threadIdx.x & (kBlock - 1)) : (int)threadIdx.x;
+    const bool producer = PC && threadIdx.x >= kBlock;
     const int lp = blockIdx.x * kBlock + tid;
-    const bool live = lp < n;
-    if (tid < 12) red[tid] = 0;
-    if (tid == 0) { red_time = INT64_MIN; red_flags[0] = 0; red_flags[1] = 0; }
+    const bool live = lp < n && !producer;
+    if (threadIdx.x < 12) red[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { red_time = INT64_MIN; red_flags[0] = 0; red_flags[1] = 0; }
+    if constexpr (PC) {
+        if (!producer) { pc_prod[tid] = 0; pc_cons[tid] = 0; if ((tid & 63) == 0) pc_done[tid >> 6] = 0; }
+    }
     const long long cur = tot->cur_time;   // SINGLE: Simulation._current_time (written by the previous launch)
     __syncthreads();
 
     Station<C, PF> S;
     Candidate mine;
     mine.valid = 0; mine.t = kInfNs; mine.t_created = 0; mine.lp = lp; mine.rank = lp;
+    if constexpr (PC) {
+        if (producer) {
+            // ---- producer wavefront: stream values for LP `tid`, as long as its consumer is in the request-order loop
+            const int w = tid >> 6;
+            bool wants_a = false, wants_s = false;
+            uint64_t gen_a = 0, gen_s = 0;          // absolute index of the next value to generate
+            uint32_t prod_a = 0, prod_s = 0;        // values written to the rings so far
+            int slot_a = 0, slot_s = 0;
+            if (lp < n) {
+                S.tid = tid;
+                S.rate = P.src_rate[lp];
+                S.svc_lambda = __ddiv_rn(1.0, P.svc_mean[lp]);
+                S.prof.kind = kProfConstant;
+                S.init_streams(P.seed[lp], P.stream_base[lp], X.arr_k[lp], X.svc_k[lp], ring_a, ring_s);
+                wants_a = P.src_kind[lp] == 1 && X.A[lp] != kInfNs;
+                wants_s = P.svc_kind[lp] == 0;
+                gen_a = S.arr_k; gen_s = S.svc_k;
+            }
+            for (;;) {
+                if (__hip_atomic_load(&pc_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                const uint32_t c = __hip_atomic_load(&pc_cons[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t out_a = (prod_a - (c & 0xffffu)) & 0xffffu, out_s = (prod_s - (c >> 16)) & 0xffffu;
+                const bool do_a = wants_a && out_a + (uint32_t)kRefill <= (uint32_t)kRing;
+                const bool do_s = wants_s && out_s + (uint32_t)kRefill <= (uint32_t)kRing;
+                if (!__any(do_a || do_s)) { __builtin_amdgcn_s_sleep(2); continue; }
+                if (__any(do_a)) {
+                    if (do_a) {
+                        const uint64_t b0 = gen_a >> 1;
+                        const bool odd = (gen_a & 1) != 0;
+#pragma unroll
+                        for (int i = 0; i < kRefill / 2; ++i) {
+                            const uint64_t b = b0 + (uint64_t)i;
+                            const U4 o = philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), S.asid0, S.asid1, S.key0, S.key1);
+                            const double v0 = S.arr_value(res53(o.x, o.y)), v1 = S.arr_value(res53(o.z, o.w));
+                            if (!(i == 0 && odd)) { ring_a[slot_a][tid] = v0; slot_a = slot_a + 1 == kRing ? 0 : slot_a + 1; ++prod_a; ++gen_a; }
+                            ring_a[slot_a][tid] = v1; slot_a = slot_a + 1 == kRing ? 0 : slot_a + 1; ++prod_a; ++gen_a;
+                        }
+                    }
+                }
+                if (__any(do_s)) {
+                    if (do_s) {
+                        const uint64_t b0 = gen_s >> 1;
+                        const bool odd = (gen_s & 1) != 0;
+#pragma unroll
+                        for (int i = 0; i < kRefill / 2; ++i) {
+                            const uint64_t b = b0 + (uint64_t)i;
+                            const U4 o = philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), S.ssid0, S.ssid1, S.key0, S.key1);
+                            const double v0 = S.svc_value(res53(o.x, o.y)), v1 = S.svc_value(res53(o.z, o.w));
+                            if (!(i == 0 && odd)) { ring_s[slot_s][tid] = v0; slot_s = slot_s + 1 == kRing ? 0 : slot_s + 1; ++prod_s; ++gen_s; }
+                            ring_s[slot_s][tid] = v1; slot_s = slot_s + 1 == kRing ? 0 : slot_s + 1; ++prod_s; ++gen_s;
+                        }
+                    }
+                }
+                // the values first, then the counters (release: the ring stores are complete before the count moves)
+                __hip_atomic_store(&pc_prod[tid], (prod_a & 0xffffu) | (prod_s << 16), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
     if (live) {
         load_station<C, PF>(S, P, X, L, lp, n, qmem, ring_a, ring_s, tid);
         S.force_general = (flags & 1) != 0;
-        const bool frozen = (mode == HS_MODE_REPLICAS) ? (S.last_time > end_ns) : (cur > end_ns);
-        if (!frozen) {
-            bool pre_group = false;
-            if (S.qn > 0 && S.grp_time <= end_ns) {   // finish a group a previous window stopped inside
-                S.run_group_general(S.grp_time);
-                S.last_time = S.grp_time;
-                pre_group = true;
-            }
-            if (S.qn == 0) {
-                if constexpr (C == 1) {
-                    // (1) request-order loop (hs_station.hpp): one whole request per iteration.  Uniform loops: the
-                    // wavefront iterates until its slowest lane is done, finished lanes are predicated off.
-                    bool event_order = true;
-                    if (!pre_group) {
-                        const bool elig = S.req_eligible();
-                        typename Station<C, PF>::ReqCursor rc;
-                        rc.bail = false; rc.done = true;
-                        if (elig) S.req_begin(rc, end_ns);   // (touches the LP's statistics: eligible lanes only)
+    }
+    const bool frozen = (mode == HS_MODE_REPLICAS) ? (live && S.last_time > end_ns) : (cur > end_ns);
+    bool pre_group = false;
+    bool event_order = true;
+    if (live && !frozen && S.qn > 0 && S.grp_time <= end_ns) {   // finish a group a previous window stopped inside
+        S.run_group_general(S.grp_time);
+        S.last_time = S.grp_time;
+        pre_group = true;
+    }
+    if constexpr (C == 1) {
+        bool bail_reload = false;
+        if (!producer) {
+            // (1) request-order loop (hs_station.hpp): one whole request per iteration.  Uniform loops: the
+            // wavefront iterates until its slowest lane is done, finished lanes are predicated off.
+            const bool elig = live && !frozen && !pre_group && S.qn == 0 && S.req_eligible();
+            typename Station<C, PF>::ReqCursor rc;
+            rc.bail = false; rc.done = true;
+            if (elig) S.req_begin(rc, end_ns);   // (touches the LP's statistics: eligible lanes only)
 #ifdef HS_CYCLES   // tools/cycles.py: where the request-order loop spends its time (never defined in the shipped library)
-                        unsigned long long cyc_top = 0, cyc_step = 0, n_it = 0;
+            unsigned long long cyc_top = 0, cyc_step = 0, n_it = 0;
 #endif
-                        for (;;) {
-                            const bool act = elig && !rc.bail && !rc.done;
-                            if (!__any(act)) break;
+            uint32_t seen = 0;                   // PC: produced counters as last read (arrival | service << 16)
+            const uint64_t ak0 = S.arr_k, sk0 = S.svc_k;
+            for (;;) {
+                const bool act = elig && !rc.bail && !rc.done;
+                if (!__any(act)) break;
 #ifdef HS_CYCLES
-                            const unsigned long long c0 = __builtin_readcyclecounter();
+                const unsigned long long c0 = __builtin_readcyclecounter();
 #endif
-                            S.top_up(act);             // wave-level refill of the pre-drawn stream values
-#ifdef HS_CYCLES
-                            const unsigned long long c1 = __builtin_readcyclecounter();
-#endif
-                            S.req_step(rc, act);
-#ifdef HS_CYCLES
-                            const unsigned long long c2 = __builtin_readcyclecounter();
-                            cyc_top += c1 - c0; cyc_step += c2 - c1; ++n_it;
-#endif
-                        }
-#ifdef HS_CYCLES
-                        if ((tid & 63) == 0) {
-                            atomicAdd(&tot->dbg[0], cyc_top); atomicAdd(&tot->dbg[1], cyc_step);
-                            atomicAdd(&tot->dbg[2], n_it); atomicAdd(&tot->dbg[3], 1ull);
-                        }
-#endif
-                        if (elig && !rc.bail) { S.req_finish(rc); event_order = false; }
-                        else if (elig) {               // same-timestamp hazard: start over in event order
-                            load_station<C, PF>(S, P, X, L, lp, n, qmem, ring_a, ring_s, tid);
-                            S.force_general = (flags & 1) != 0;
+                if constexpr (PC) {
+                    // every lane that may consume needs one value of each stream; the producer runs ahead, so this rarely waits
+                    const bool need_a = act && S.src_kind == 1 && S.A != kInfNs, need_s = act && S.svc_kind == 0;
+                    const uint32_t ca = (uint32_t)(S.arr_k - ak0) & 0xffffu, cs = (uint32_t)(S.svc_k - sk0) & 0xffffu;
+                    unsigned spins = 0;
+                    while (__any((need_a && (seen & 0xffffu) == ca) || (need_s && (seen >> 16) == cs))) {
+                        seen = __hip_atomic_load(&pc_prod[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (__any((need_a && (seen & 0xffffu) == ca) || (need_s && (seen >> 16) == cs))) __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1u << 22)) {      // bounded (~0.1 s): report instead of hanging the device
+                            if (elig) { S.qoverflow = 1; rc.done = true; }
+                            break;
                         }
                     }
-                    // (2) event-order loop for whatever (1) does not cover
-                    for (;;) {
-                        const int64_t t = S.next_time();
-                        const bool act = event_order && t <= end_ns;   // t == kInfNs: nothing pending
-                        if (!__any(act)) break;
-                        S.top_up(act);
-                        S.step_c1(t, act);
-                    }
+                    if (spins > (1u << 22)) continue;
                 } else {
-                    for (;;) {
-                        S.top_up();
-                        const int64_t t = S.next_time();
-                        if (t > end_ns) break;         // also ends on kInfNs: nothing pending
-                        S.run_group(t);
-                    }
+                    S.top_up(act);             // wave-level refill of the pre-drawn stream values
                 }
+#ifdef HS_CYCLES
+                const unsigned long long c1 = __builtin_readcyclecounter();
+#endif
+                S.req_step(rc, act);
+                if constexpr (PC) {
+                    __hip_atomic_store(&pc_cons[tid], ((uint32_t)(S.arr_k - ak0) & 0xffffu) | ((uint32_t)(S.svc_k - sk0) << 16),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    seen = __hip_atomic_load(&pc_prod[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+#ifdef HS_CYCLES
+                const unsigned long long c2 = __builtin_readcyclecounter();
+                cyc_top += c1 - c0; cyc_step += c2 - c1; ++n_it;
+#endif
             }
+#ifdef HS_CYCLES
+            if ((tid & 63) == 0) {
+                atomicAdd(&tot->dbg[0], cyc_top); atomicAdd(&tot->dbg[1], cyc_step);
+                atomicAdd(&tot->dbg[2], n_it); atomicAdd(&tot->dbg[3], 1ull);
+            }
+#endif
+            if constexpr (PC) {
+                if ((tid & 63) == 0) __hip_atomic_store(&pc_done[tid >> 6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (elig && !rc.bail) { S.req_finish(rc); event_order = false; }
+            bail_reload = elig && rc.bail;     // same-timestamp hazard: start over in event order
+        }
+        if constexpr (PC) __syncthreads();     // the producers have left their loop: the rings belong to the consumers again
+        if (!producer) {
+            if constexpr (PC) {
+                // lanes that go on in event order refill their own rings from the consumed counts (the producer's leftovers
+                // are values of later indices; dropping them changes nothing)
+                S.ra.head = 0; S.ra.n = 0; S.rs.head = 0; S.rs.n = 0;
+            }
+            if (bail_reload) {
+                load_station<C, PF>(S, P, X, L, lp, n, qmem, ring_a, ring_s, tid);
+                S.force_general = (flags & 1) != 0;
+            }
+        }
+        // (2) event-order loop for whatever (1) does not cover
+        if (!producer) {
+            for (;;) {
+                const int64_t t = live && !frozen && S.qn == 0 ? S.next_time() : kInfNs;
+                const bool act = live && !frozen && S.qn == 0 && event_order && t <= end_ns;   // t == kInfNs: nothing pending
+                if (!__any(act)) break;
+                S.top_up(act);
+                S.step_c1(t, act);
+            }
+        }
+    } else {
+        if (live && !frozen && S.qn == 0) {
+            for (;;) {
+                S.top_up();
+                const int64_t t = S.next_time();
+                if (t > end_ns) break;         // also ends on kInfNs: nothing pending
+                S.run_group(t);
+            }
+        }
+    }
+    if (live) {
+        if (!frozen) {
             if (mode == HS_MODE_REPLICAS) overshoot_one<C, PF>(S);
             else { mine = make_candidate<C, PF>(S); mine.rank = P.tie_rank != nullptr ? P.tie_rank[lp] : lp; }
         }
@@ -382,25 +498,27 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
     for (int k = 0; k < 8; ++k) vals[k] = live ? S.ev[k] : 0u;
     // completed / received deltas are the continuation / sink event counts
     vals[8] = vals[6]; vals[9] = vals[7];
+    if (!producer) {
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
-        const unsigned s = wave_sum<unsigned>(vals[k]);
-        if ((tid & 63) == 0 && s) atomicAdd(&red[k], (unsigned long long)s);
+        for (int k = 0; k < 10; ++k) {
+            const unsigned s = wave_sum<unsigned>(vals[k]);
+            if ((tid & 63) == 0 && s) atomicAdd(&red[k], (unsigned long long)s);
+        }
     }
     if (live) {
         atomicMax(&red_time, (long long)S.last_time);
         if (S.overflow) red_flags[0] = 1;
         if (S.qoverflow) red_flags[1] = 1;
     }
-    if (mode == HS_MODE_SINGLE) {
+    if (mode == HS_MODE_SINGLE && !producer) {
         const Candidate w = wave_min_cand(mine);
         if ((tid & 63) == 0) wave_c[tid >> 6] = w;
     }
     __syncthreads();
-    if (tid < 8 && red[tid]) atomicAdd(&tot->ev[tid], red[tid]);
-    if (tid == 8 && red[8]) atomicAdd(&tot->completed, red[8]);
-    if (tid == 9 && red[9]) atomicAdd(&tot->received, red[9]);
-    if (tid == 10) {
+    if (threadIdx.x < 8 && red[threadIdx.x]) atomicAdd(&tot->ev[threadIdx.x], red[threadIdx.x]);
+    if (threadIdx.x == 8 && red[8]) atomicAdd(&tot->completed, red[8]);
+    if (threadIdx.x == 9 && red[9]) atomicAdd(&tot->received, red[9]);
+    if (threadIdx.x == 10) {
         if (red_time != INT64_MIN) atomicMax(&tot->final_time, red_time);
         if (red_flags[0]) atomicOr(&tot->overflow, 1);
         if (red_flags[1]) atomicOr(&tot->qoverflow, 1);
@@ -412,7 +530,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
     if (mode != HS_MODE_SINGLE) return;
 
     // ---- SINGLE mode: elect the globally first event beyond end_ns (last-block pattern)
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         Candidate b = wave_c[0];
         for (int w = 1; w < kBlock / 64; ++w) if (cand_less(wave_c[w], b)) b = wave_c[w];
         cands[blockIdx.x] = b;
@@ -423,23 +541,25 @@ __global__ void __launch_bounds__(kBlock) hs_station_run(StationParams P, Statio
     }
     __syncthreads();
     if (!is_last) return;
-    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     Candidate best;
     best.valid = 0; best.t = kInfNs; best.t_created = 0; best.lp = 0; best.rank = 0;
-    for (int b = tid; b < (int)gridDim.x; b += kBlock) {
-        Candidate c;
-        c.t = __hip_atomic_load(&cands[b].t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c.t_created = __hip_atomic_load(&cands[b].t_created, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c.lp = __hip_atomic_load(&cands[b].lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c.rank = __hip_atomic_load(&cands[b].rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c.valid = __hip_atomic_load(&cands[b].valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cand_less(c, best)) best = c;
+    if (!producer) {
+        for (int b = tid; b < (int)gridDim.x; b += kBlock) {
+            Candidate c;
+            c.t = __hip_atomic_load(&cands[b].t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c.t_created = __hip_atomic_load(&cands[b].t_created, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c.lp = __hip_atomic_load(&cands[b].lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c.rank = __hip_atomic_load(&cands[b].rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c.valid = __hip_atomic_load(&cands[b].valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cand_less(c, best)) best = c;
+        }
+        best = wave_min_cand(best);
+        if ((tid & 63) == 0) wave_c[tid >> 6] = best;
     }
-    best = wave_min_cand(best);
-    if ((tid & 63) == 0) wave_c[tid >> 6] = best;
     __syncthreads();
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         Candidate b = wave_c[0];
         for (int w = 1; w < kBlock / 64; ++w) if (cand_less(wave_c[w], b)) b = wave_c[w];
         long long new_cur = __hip_atomic_load(&tot->final_time, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1421,6 +1541,13 @@ int upload(hs_engine *h, const T **dst, const T *src, size_t n, T dflt) {
 
 template <int C>
 void launch_run(hs_engine *h, int64_t end_ns) {
+    if constexpr (C == 1) {
+        if (!h->any_profile && !(h->flags & 512)) {     // producer / consumer wavefronts (debug flag 512: the one-role kernel)
+            hipLaunchKernelGGL((hs_station_run<1, false, true>), dim3(h->n_blocks), dim3(2 * kBlock), 0, h->stream, h->P, h->X,
+                               h->L, h->tot, h->cands, h->cfg.n_lp, end_ns, h->cfg.mode, h->flags);
+            return;
+        }
+    }
     if (h->any_profile)
         hipLaunchKernelGGL((hs_station_run<C, true>), dim3(h->n_blocks), dim3(kBlock), 0, h->stream, h->P, h->X, h->L, h->tot,
                            h->cands, h->cfg.n_lp, end_ns, h->cfg.mode, h->flags);
