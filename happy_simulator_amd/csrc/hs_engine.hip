@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
                 const uint32_t out_a = (prod_a - (c & 0xffffu)) & 0xffffu, out_s = (prod_s - (c >> 16)) & 0xffffu;
                 const bool do_a = wants_a && out_a + (uint32_t)kRefill <= (uint32_t)kRing;
                 const bool do_s = wants_s && out_s + (uint32_t)kRefill <= (uint32_t)kRing;
-                if (!__any(do_a || do_s)) { __builtin_amdgcn_s_sleep(2); continue; }
+                if (!__any(do_a || do_s)) { __builtin_amdgcn_s_sleep(HS_PC_SLEEP_P); continue; }
                 if (__any(do_a)) {
                     if (do_a) {
                         const uint64_t b0 = gen_a >> 1;
@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
                     unsigned spins = 0;
                     while (__any((need_a && (seen & 0xffffu) == ca) || (need_s && (seen >> 16) == cs))) {
                         seen = __hip_atomic_load(&pc_prod[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (__any((need_a && (seen & 0xffffu) == ca) || (need_s && (seen >> 16) == cs))) __builtin_amdgcn_s_sleep(1);
+                        if (__any((need_a && (seen & 0xffffu) == ca) || (need_s && (seen >> 16) == cs))) __builtin_amdgcn_s_sleep(HS_PC_SLEEP_C);
                         if (++spins > (1u << 22)) {      // bounded (~0.1 s): report instead of hanging the device
                             if (elig) { S.qoverflow = 1; rc.done = true; }
                             break;
@@ -1119,6 +1119,9 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
 #endif
         for (unsigned iter = 0;; ++iter) {
             n_iter = iter + 1;
+#ifdef HS_JITTER   // scratch build: pseudo-random per-wavefront delays (results must not depend on timing)
+            if ((((iter + 1u) * 2654435761u + (blockIdx.x * 4u + (tid >> 6)) * 40503u) >> 7 & (HS_JITTER)) == 0) __builtin_amdgcn_s_sleep(127);
+#endif
             S.top_up(!done, group_cap < 4 ? group_cap : 4);           // whole wavefront: refill the pre-drawn values
             int64_t H = kInfNs;
 #ifdef HS_CYCLES
@@ -1176,9 +1179,23 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                     if (t > limit) break;
                     if (!((out_remote[0] || S.async_can_send(out_l[0], head_seen[0])) &&
                           (out_remote[1] || S.async_can_send(out_l[1], head_seen[1])))) { blocked = true; break; }   // a consumer is behind: wait
+#ifdef HS_RINGSTAT
+                    S.stat_gl = 0; S.stat_slow = 0;
+#endif
                     if constexpr (C == 1) S.step1(t, force_general);
                     else S.run_group(t, force_general);
                     ++n_groups;
+#ifdef HS_RINGSTAT
+                    {   // one trip of the wavefront: how many lanes ran it, did any take the general path / a global read
+                        const unsigned long long m = __ballot(1);
+                        const bool leader = (unsigned)lane == (unsigned)__builtin_ctzll(m);
+                        const int any_gl = __any(S.stat_gl), any_slow = __any(S.stat_slow);
+                        if (leader) {
+                            atomicAdd(&tot->dbg[0], 1ull); atomicAdd(&tot->dbg[1], (unsigned long long)any_gl);
+                            atomicAdd(&tot->dbg[2], (unsigned long long)any_slow); atomicAdd(&tot->dbg[3], (unsigned long long)__builtin_popcountll(m));
+                        }
+                    }
+#endif
                 }
 #ifdef HS_CYCLES
                 q3 = __builtin_readcyclecounter();
@@ -1246,6 +1263,8 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         }
 #ifdef HS_CYCLES
         if ((tid & 63) == 0) for (int k = 0; k < 4; ++k) atomicAdd(&tot->dbg[k], cyc[k]);
+#elif defined(HS_RINGSTAT)
+        (void)n_iter;
 #else
         atomicAdd(&tot->dbg[2], (unsigned long long)n_groups);
         if ((tid & 63) == 0) {

@@ -104,6 +104,16 @@ __device__ __forceinline__ void ag_store(unsigned long long *p, unsigned long lo
 __device__ __forceinline__ int64_t ag_load(const int64_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// the bound word of a link: everything the producer made visible before it published this value must be seen by the
+// loads that FOLLOW this one (the tail, the payload) -- an acquire, not just program order: two relaxed loads of different
+// addresses may be serviced in either order
+__device__ __forceinline__ int64_t ag_load_acquire(const int64_t *p) {
+#ifdef HS_NO_ACQ
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 __device__ __forceinline__ unsigned long long ag_load(const unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -220,6 +230,9 @@ struct NetStation {
     uint8_t (*qmem)[kBlock];
     int64_t (*enqpay)[kBlock];
     int tid, qh, qn, ph, pn;
+#ifdef HS_RINGSTAT   // scratch statistics build (never defined in the shipped library)
+    int stat_gl, stat_slow;
+#endif
 
     __device__ __forceinline__ void qpush(uint32_t code) {
         if (qn >= kQCap) { qoverflow = 1; return; }
@@ -609,7 +622,7 @@ struct NetStation {
     // state has already sent are only guaranteed to be behind a tail read after the neighbour's drains.)
     __device__ __forceinline__ int64_t async_receive_one() {
         const int l = fi_link;
-        const int64_t ea = ag_load(&ns->aq_ea[l]);                     // bound BEFORE tail, as in async_receive
+        const int64_t ea = ag_load_acquire(&ns->aq_ea[l]);                     // bound BEFORE tail, as in async_receive
         const unsigned long long tail = ag_load(&ns->aq_tail[l]);
         undrained = kInfNs;
         unsigned long long head = fi_head;
@@ -638,7 +651,7 @@ struct NetStation {
         const int a = np->in_off[lp], b = np->in_off[lp + 1];
         for (int q = a; q < b; ++q) {
             const int l = np->in_links[q];
-            const int64_t ea = ag_load(&ns->aq_ea[l]);                 // read BEFORE the tail: see the ordering note above
+            const int64_t ea = ag_load_acquire(&ns->aq_ea[l]);                 // read BEFORE the tail: see the ordering note above
             H = ea < H ? ea : H;
             const unsigned long long tail = ag_load(&ns->aq_tail[l]);
             unsigned long long head = ns->aq_head[l];                  // ours
@@ -801,6 +814,10 @@ struct NetStation {
         const bool slow = force_general || cnt != 1 || (tick && (a2 <= t || (poisson && na == 0))) ||
                           (deliver && (dur == 0 || (svc_exp && nsv == 0))) || (dep && router && rn == 0) ||
                           (to_link && (target != fl_link || fl_loss > 0.0 || (fl_jit == 0 && nj == 0)));
+#ifdef HS_RINGSTAT
+        if (slow) stat_slow = 1;
+        if (deliver && dep && !(accepted - started <= kNRing)) stat_gl = 1;
+#endif
         if (slow) { run_group(t, force_general); return; }
         // ---- Source.handle_event
         ev[0] += tick; generated += tick;

@@ -34,8 +34,20 @@ constexpr int kRootSched = 98;  // pick_root: the next Request injected with Sim
 
 constexpr int kBlock = 256;     // LPs per workgroup (4 wavefronts)
 constexpr int kQCap = 48;       // in-group FIFO capacity per LP (LDS)
-constexpr int kRing = 24;       // pre-drawn values buffered per stream per LP (LDS)
-constexpr int kRefill = 8;      // values generated per wave-level refill (4 Philox blocks)
+#ifndef HS_KRING                // (tuning builds override these; the shipped values are the measured optimum)
+#define HS_KRING 24
+#endif
+#ifndef HS_KREFILL
+#define HS_KREFILL 8
+#endif
+#ifndef HS_PC_SLEEP_P
+#define HS_PC_SLEEP_P 2
+#endif
+#ifndef HS_PC_SLEEP_C
+#define HS_PC_SLEEP_C 1
+#endif
+constexpr int kRing = HS_KRING;       // pre-drawn values buffered per stream per LP (LDS)
+constexpr int kRefill = HS_KREFILL;   // values generated per wave-level refill (4 Philox blocks)
 
 // Per-lane ring of pre-drawn stream values, column `tid` of an LDS array [kRing][kBlock].  The serial
 // per-LP recursion consumes one value at a time; the expensive part of a draw (Philox block, hs_log,
