@@ -216,7 +216,10 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
             NX.link_k[l] = 0; NX.link_in[l] = 0; NX.link_sent[l] = 0; NX.link_packets[l] = 0;
             if (NX.aq_tail != nullptr) { NX.aq_tail[l] = 0; NX.aq_head[l] = 0; NX.aq_ea[l] = start_ns; }
         }
-        if (lp < n) { NX.route_k[lp] = 0; NX.routed[lp] = 0; NX.bag_cnt[lp] = 0; NX.in_cnt[lp] = 0; NX.in_cnt[n + lp] = 0; }
+        if (lp < n) {
+            NX.route_k[lp] = 0; NX.routed[lp] = 0; NX.bag_cnt[lp] = 0; NX.in_cnt[lp] = 0; NX.in_cnt[n + lp] = 0;
+            if (NX.early_upto != nullptr) { NX.early_upto[lp] = 0; NX.d_pre[lp] = start_ns; }
+        }
     }
     if (lp == 0) {
         for (int k = 0; k < 15; ++k) tot->ev[k] = 0;
@@ -712,7 +715,8 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF> &S, const Stati
         }
     }
     S.ha = S.na = S.hs_ = S.nsv = S.hj = S.nj = S.rn = 0; S.rbits = 0; S.fl_link = -1; S.fi_link = -1; S.fi_packets = 0;
-    S.fl_remote = false; S.fi_head = 0;
+    S.fl_remote = false; S.fi_head = 0; S.pf_s0 = S.pf_s1 = -1; S.pf_v0 = S.pf_v1 = 0;
+    S.presend = false; S.early_upto = S.completed; S.D_pre = S.last_time; S.fl_q = 0; S.end_ns = kInfNs;
     S.bag_n = NX.bag_cnt[lp];
     if constexpr (FAST) {
         // (S.fl was set by the caller.)  The bag moves into LDS for the lifetime of the kernel ...
@@ -732,17 +736,23 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF> &S, const Stati
             S.fl_lam = __ddiv_rn(1.0, NP.link_jit_mean[l]);
             S.fl_loss = NP.link_loss[l];
             S.fl_in = NX.link_in[l]; S.fl_sent = NX.link_sent[l];
+            S.fl_q = (NX.aq_tail != nullptr && !S.fl_remote) ? (int64_t)NX.aq_tail[l] : S.fl_sent;
             S.jit.init(S.seed, stream_id(NP.link_base[l], kStreamLink), NX.link_k[l]);
+        }
+        if (C == 1 && l >= 0 && S.conc == 1 && S.fl_loss == 0.0 && NX.early_upto != nullptr) {
+            S.presend = true;                                   // departures are pre-sent (hs_netstation.hpp `early_upto`)
+            const int64_t eu = NX.early_upto[lp];
+            if (eu > S.completed) { S.early_upto = eu; S.D_pre = NX.d_pre[lp]; }
         }
         if (NP.in_off[lp + 1] - NP.in_off[lp] == 1) {          // ... and the counter of its only incoming link
             S.fi_link = NP.in_links[NP.in_off[lp]];
             S.fi_packets = NX.link_packets[S.fi_link];
             S.fi_head = NX.aq_head[S.fi_link];
         }
-        // the created_at cache starts cold: requests admitted before this launch are read from the log
+        // the created_at window: the next kNRing requests to start, as far as they are admitted (read from the log)
         for (int i = 0; i < kNRing; ++i) {
-            const int64_t k = S.accepted - 1 - i;
-            if (k >= 0 && k < S.cap) S.fl.crc[k & (kNRing - 1)][tid] = S.adm[k * S.ls];
+            const int64_t k = S.started + i;
+            if (k < S.accepted && k < S.cap) S.fl.crc[k & (kNRing - 1)][tid] = S.adm[k * S.ls];
         }
     }
     S.bmin = S.bag_scan_min();
@@ -776,6 +786,7 @@ __device__ __forceinline__ void store_net(NetStation<C, FAST, PF> &S, const Stat
             NX.link_k[S.fl_link] = S.jit.k - (uint64_t)S.nj;
         }
         if (S.fi_link >= 0) NX.link_packets[S.fi_link] = S.fi_packets;
+        if (S.presend) { NX.early_upto[lp] = S.early_upto; NX.d_pre[lp] = S.D_pre; }
     }
     NX.bag_cnt[lp] = S.bag_n;
     NX.next_time[lp] = S.next_time();
@@ -1038,7 +1049,13 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned kAsyncMaxIter = 1u << 23;   // consecutive iterations in which a wavefront processed nothing (~25 s)
 constexpr unsigned kAsyncBlockedMax = 1u << 17;   // ... while a lane waits for buffer space: a buffer deadlock (~1 s)
-constexpr int kAsyncGroupCap = 2;   // event groups per LP per iteration of hs_net_async (debug flags bits 8..15 override)
+#ifndef HS_GROUP_CAP
+#define HS_GROUP_CAP 4
+#endif
+#ifndef HS_LOOK
+#define HS_LOOK 4
+#endif
+constexpr int kAsyncGroupCap = HS_GROUP_CAP;   // event groups per LP per iteration of hs_net_async (debug flags bits 8..15 override)
 
 template <int C, bool PF>
 __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParams NP, StationState X, NetState NX,
@@ -1070,15 +1087,16 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
     int gave_up = 0;
     if (live) {
         load_net<C, true, PF>(S, P, NP, X, NX, L, lp, n, qmem, enqpay, tid, 0, SC);
+        S.end_ns = end_ns;
+#ifdef HS_CYC2
+        S.cy2[0] = S.cy2[1] = S.cy2[2] = S.cy2[3] = 0;
+#endif
         // this LP's outgoing links (router targets in constructor order, or the single link) and what it last published
         int32_t out_l[2] = {-1, -1};
         if (S.egress == EG_LINK) out_l[0] = S.link_of;
         else if (S.egress == EG_ROUTER) { out_l[0] = S.rt0; out_l[1] = S.rt1; }
         int64_t out_pub[2] = {INT64_MIN, INT64_MIN};
         unsigned long long head_seen[2] = {0ull, 0ull};
-        uint64_t dur_k = ~0ull;
-        int dur_free = -1;
-        int64_t dur_next = 0;
         const bool force_general = (flags & 1) != 0;
         // Groups per LP per iteration.  The loop below is divergent: a lane with a long stretch of ready groups would keep
         // the other 63 idle, and their bounds only move at iteration boundaries -- so every lane takes a few groups, then
@@ -1108,12 +1126,6 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         const bool chain = (flags & 64) == 0 && lane > 0 && my_in >= 0 && prev_next == my_in;
         const int64_t next_lat = next_l >= 0 ? NP.link_lat_ns[next_l] : 0;
         auto sat = [](int64_t a, int64_t b) { return (a == kInfNs || b == kInfNs) ? kInfNs : a + b; };
-        auto peek_dur = [&]() {
-            const int free = S.conc - S.active;
-            const uint64_t sk = S.svc_consumed();
-            if (sk != dur_k || free != dur_free) { dur_next = S.peek_service_ns(free); dur_k = sk; dur_free = free; }
-            return dur_next;
-        };
 #ifdef HS_CYCLES   // tools/cycles.py --ring: cycles in receive / bound scan / group processing / publication
         unsigned long long cyc[4] = {0, 0, 0, 0};
 #endif
@@ -1122,6 +1134,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
 #ifdef HS_JITTER   // scratch build: pseudo-random per-wavefront delays (results must not depend on timing)
             if ((((iter + 1u) * 2654435761u + (blockIdx.x * 4u + (tid >> 6)) * 40503u) >> 7 & (HS_JITTER)) == 0) __builtin_amdgcn_s_sleep(127);
 #endif
+            S.pf_commit();                                            // created_at prefetches of the previous iteration -> LDS
             S.top_up(!done, group_cap < 4 ? group_cap : 4);           // whole wavefront: refill the pre-drawn values
             int64_t H = kInfNs;
 #ifdef HS_CYCLES
@@ -1131,33 +1144,31 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
 #ifdef HS_CYCLES
             const unsigned long long q1 = __builtin_readcyclecounter();
 #endif
-            // (min, +) map of this LP as the sender on next_l, from its state before this iteration's processing
-            int64_t mA = kInfNs, mB = kInfNs;
-            if (!done && next_l >= 0) {
-                int64_t dmin = kInfNs;
-#pragma unroll
-                for (int i = 0; i < C; ++i) dmin = S.D[i] < dmin ? S.D[i] : dmin;
-                int64_t a = dmin;
-                if (S.active < S.conc) {
-                    const int64_t dur = peek_dur();
-                    const int64_t own = sat(S.next_time(), dur);
-                    a = own < a ? own : a;
-                    mB = dur + next_lat;
-                }
-                mA = sat(a, next_lat);
-            }
+            // The map of this LP as the sender on next_l, from its state before this iteration's processing:
+            //     ea(H) = min(mA, max(H + mB, mD))
+            // mA: what it can still send whatever its input bound is; H + mB: an admission that only a message from upstream
+            // can cause (arrives >= H); mD: ... which, behind a backlog whose departures are already fixed, cannot leave before
+            // that backlog has (pre-sending stations, hs_netstation.hpp `early_upto`).  The family is closed under composition:
+            //     (A2,B2,D2) o (A1,B1,D1) = (min(A2, max(A1 + B2, D2)), B1 + B2, max(D1 + B2, D2)).
+            int64_t mA = kInfNs, mB = kInfNs, mD = INT64_MIN;
+            if (!done && next_l >= 0) S.bound_map(next_l, next_lat, mA, mB, mD);
+            auto satd = [](int64_t d, int64_t b) { return d == INT64_MIN ? INT64_MIN : (b == kInfNs ? kInfNs : d + b); };
             if (!chain) {                                             // head of a chain: its input bound is known
                 if (!done && S.undrained < H) H = S.undrained;
-                const int64_t v = sat(H, mB);
+                int64_t v = sat(H, mB);
+                v = v > mD ? v : mD;
                 mA = v < mA ? v : mA;
-                mB = kInfNs;
+                mB = kInfNs; mD = INT64_MIN;
             }
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {                        // prefix composition m_i o m_{i-1} o ... (Kogge-Stone)
-                const int64_t pA = __shfl_up(mA, o, 64), pB = __shfl_up(mB, o, 64);
+                const int64_t pA = __shfl_up(mA, o, 64), pB = __shfl_up(mB, o, 64), pD = __shfl_up(mD, o, 64);
                 if (lane >= o) {
-                    const int64_t v = sat(pA, mB);
+                    int64_t v = sat(pA, mB);
+                    v = v > mD ? v : mD;
                     mA = v < mA ? v : mA;
+                    const int64_t d2 = satd(pD, mB);
+                    mD = d2 > mD ? d2 : mD;
                     mB = sat(pB, mB);
                 }
             }
@@ -1202,15 +1213,6 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
 #endif
                 const int64_t t2 = S.next_time();
                 const int64_t base = t2 < H ? t2 : H;                 // nothing happens here before `base`
-                // lower bound of this LP's next completion (= its next chance to send)
-                int64_t dmin = kInfNs;
-#pragma unroll
-                for (int i = 0; i < C; ++i) dmin = S.D[i] < dmin ? S.D[i] : dmin;
-                int64_t lb = dmin;
-                if (S.active < S.conc) {
-                    const int64_t started = sat(base, peek_dur());
-                    lb = started < lb ? started : lb;
-                }
                 if (S.sent_async) {
                     // payloads complete -> tails -> complete: only then may a bound that no longer covers those messages
                     // be seen, through memory (aq_ea below) or through the in-wavefront scan of the next iteration
@@ -1225,7 +1227,12 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                 for (int o = 0; o < 2; ++o) {
                     const int32_t l = out_l[o];
                     if (l < 0) continue;
-                    const int64_t v = (lb == kInfNs) ? kInfNs : lb + NP.link_lat_ns[l];
+                    // the bound of everything this LP has NOT appended to link l yet: its map evaluated at `base`
+                    int64_t bA, bB, bD;
+                    S.bound_map(l, NP.link_lat_ns[l], bA, bB, bD);
+                    int64_t v = sat(base, bB);
+                    v = v > bD ? v : bD;
+                    v = v < bA ? v : bA;
                     if (v > out_pub[o]) { ag_store(&NX.aq_ea[l], v); out_pub[o] = v; }
                 }
                 done = base > end_ns;                                 // nothing at or before end_ns can happen any more
@@ -1261,7 +1268,9 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             if (S.evp[0]) atomicAdd(&tot->ev[13], (unsigned long long)S.evp[0]);
             if (S.evp[1]) atomicAdd(&tot->ev[14], (unsigned long long)S.evp[1]);
         }
-#ifdef HS_CYCLES
+#ifdef HS_CYC2
+        if ((tid & 63) == 0) for (int k = 0; k < 4; ++k) atomicAdd(&tot->dbg[k], S.cy2[k]);
+#elif defined(HS_CYCLES)
         if ((tid & 63) == 0) for (int k = 0; k < 4; ++k) atomicAdd(&tot->dbg[k], cyc[k]);
 #elif defined(HS_RINGSTAT)
         (void)n_iter;
@@ -2162,12 +2171,17 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     ALN(in_cnt, 2 * N); ALN(in_t, 2 * NB); ALN(in_ts, 2 * NB); ALN(in_cr, 2 * NB); ALN(in_link, 2 * NB);
     int aqc = 1;
     while (aqc < bag) aqc <<= 1;      // a power of two: queue slots are addressed with a mask, not a 64-bit modulo
+#ifndef HS_AQ_MIN
+#define HS_AQ_MIN 64
+#endif
+    if (aqc < HS_AQ_MIN) aqc = HS_AQ_MIN;   // pre-sent messages (hs_netstation.hpp `early_upto`) sit in the queue for a whole backlog
     if (global && aqc < 256) aqc = 256; // a shard's incoming cross links are filled a whole exchange round at a time
     h->NX.aq_cap = aqc;
     h->NX.aq_on = 0;
     if (nl > 0) {
         const size_t NQ = NL * (size_t)aqc;
         ALN(aq_t, NQ); ALN(aq_ts, NQ); ALN(aq_cr, NQ); ALN(aq_tail, NL); ALN(aq_head, NL); ALN(aq_ea, NL);
+        ALN(early_upto, (size_t)n); ALN(d_pre, (size_t)n);
         // the whole network in one cooperative launch (shards: hs_engine_shard_round); with probes, time-varying profiles
         // or scheduled Requests the PF instantiation of the kernel
         // (time-varying profiles and scheduled Requests stay on the windowed engine; the asynchronous PF instantiation is
@@ -2323,9 +2337,10 @@ int hs_engine_shard_async_setup(hs_engine *h, int32_t n_cross, const int64_t *cr
         role[(size_t)i] = (uint8_t)((s_here ? 1 : 0) | (d_here ? 2 : 0));
         out_here += s_here ? 1 : 0;
     }
-    // a round may append group_cap x iterations x C messages per outgoing cross link: to one outbox row on this side, to
+    // a round may append 2 x group_cap x iterations x C messages per outgoing cross link: to one outbox row on this side, to
     // one link queue on the other.  The iterations per round are clamped to what those hold.
-    const long long per_iter = (long long)kAsyncGroupCap * h->C;
+    // (a group of a pre-sending station may append two: a departure that was not pre-sent + the next request's pre-send)
+    const long long per_iter = 2ll * kAsyncGroupCap * h->C;
     long long fit = (h->NX.aq_cap / 2) / per_iter;
     if (out_here > 0) { const long long f2 = h->SC.msg_cap / (per_iter * out_here); if (f2 < fit) fit = f2; }
     if (fit < 1)

@@ -90,6 +90,9 @@ struct NetState {
     unsigned long long *aq_tail;     // [n_links] messages appended so far (producer)
     unsigned long long *aq_head;     // [n_links] messages taken so far (consumer; the producer reads it for flow control)
     int64_t *aq_ea;                  // [n_links] every message NOT yet appended arrives at or after this time
+    // pre-sent departures (hs_net_async, one-worker stations): see NetStation::early_upto
+    int64_t *early_upto;             // [n_lp]
+    int64_t *d_pre;                  // [n_lp]
     int32_t aq_cap;               // entries per link queue, a power of two (slot = sequence number & (aq_cap - 1))
     int32_t aq_on;                   // 1 inside hs_net_async / its final launch: send_link uses the queues
 };
@@ -149,6 +152,10 @@ __device__ __noinline__ inline int64_t profile_next_tick(uint32_t kind, double p
 //   * the state of the LP's outgoing link (counters, parameters) lived in global memory -> registers.
 // Draws are pure functions of (stream, index) and are consumed in the same order, so nothing observable changes.
 constexpr int kLBag = 8;     // LDS bag entries per LP (a full bag leaves messages in their queue: async_receive)
+#ifndef HS_LOOK
+#define HS_LOOK 4
+#endif
+constexpr int kLookMax = HS_LOOK;   // completions / services a sender's bound looks ahead over (pre-drawn route / service draws)
 constexpr int kNRing = 8;    // pre-drawn values per stream per LP
 struct NetFastLds {
     double (*ring_a)[kBlock];
@@ -158,7 +165,7 @@ struct NetFastLds {
     int64_t (*bag_ts)[kBlock];
     int64_t (*bag_cr)[kBlock];
     int32_t (*bag_link)[kBlock];
-    int64_t (*crc)[kBlock];       // created_at of the last kNRing admitted requests (slot = admission index mod kNRing)
+    int64_t (*crc)[kBlock];       // created_at of the NEXT kNRing requests to start: ordinals [started, started + kNRing), slot = ordinal mod kNRing
 };
 
 // PF: the station may carry a Probe, a time-varying arrival profile or Requests injected with Simulation.schedule() -- the
@@ -222,7 +229,29 @@ struct NetStation {
     uint32_t fl_jit;              // 0 = exponential jitter
     double fl_delay0, fl_lam, fl_loss, inc_const;
     int64_t fl_in, fl_sent;
+    // PRE-SENDING (C == 1, FAST, the one outgoing link in registers, lossless).  With one worker and a FIFO buffer the whole
+    // future of a request is fixed the moment it is admitted: it starts at S = max(arrival, departure of the request before
+    // it) and leaves at D = S + its service time -- service draw number `ordinal`, route draw number `ordinal`, the link's next
+    // jitter draw: all pure functions of indices that are known now.  So the message it will become is appended to the link's
+    // queue AT ADMISSION (or at the start of service when the pre-drawn rings do not reach that far), with the same
+    // {arrival, send time D, created_at} it would carry if it were sent when the completion is processed -- the completion then
+    // only counts the reference's events.  The receiver sees the same messages in the same order, just earlier in wall-clock
+    // time, and the sender's bound on the link starts from the departure of the LAST admitted request instead of its clock:
+    // the lookahead grows by the station's whole backlog.
+    //   early_upto  requests with ordinal < early_upto have had their way out decided and (if it is the link) their message
+    //               appended; completed <= early_upto <= accepted
+    //   D_pre       departure time of request early_upto - 1 (any time <= now once that request has completed)
+    //   fl_q        messages appended to the link's queue so far (the queue's sequence number; fl_sent is the statistic)
+    int64_t early_upto, D_pre, fl_q, end_ns;
+    bool presend;
     Stream jit;
+    // FAST: the created_at window.  Slot j & 7 of `crc` holds request j for j in [started, started + kNRing); when a start frees
+    // a slot and the request that now enters the window was admitted long ago (a queue deeper than the window), its
+    // created_at comes back from the admission log in HBM -- as a PREFETCH: the load is issued at the start, the value is
+    // committed to LDS at the top of the next iteration (pf_commit), and it is first needed kNRing starts later.  (It used to be
+    // a synchronous read at delivery time: 64 % of the wavefront's group trips stalled on one, measured on the full ring.)
+    int64_t pf_v0, pf_v1;
+    int pf_s0, pf_s1;             // slots the prefetched values belong to (-1: none pending)
     int32_t fi_link;              // the LP's only incoming link (-1: none or several): its packets_sent counter in a register
     int64_t fi_packets;
     unsigned long long fi_head;   // ... and this LP's position in that link's queue (the only writer of aq_head[fi_link])
@@ -232,6 +261,12 @@ struct NetStation {
     int tid, qh, qn, ph, pn;
 #ifdef HS_RINGSTAT   // scratch statistics build (never defined in the shipped library)
     int stat_gl, stat_slow;
+#endif
+#ifdef HS_CYC2       // scratch build: cycles inside step1 (classification / arrival side / departure side / start of service)
+    unsigned long long cy2[4];
+#define HS_CY2(k) { const unsigned long long now_ = __builtin_readcyclecounter(); cy2[k] += now_ - cy_t; cy_t = now_; }
+#else
+#define HS_CY2(k)
 #endif
 
     __device__ __forceinline__ void qpush(uint32_t code) {
@@ -430,7 +465,7 @@ struct NetStation {
         if (qcap >= 0 && buf >= qcap) { dropped++; return false; }
         const bool was_empty = (buf == 0);
         if (accepted < cap) adm[accepted * ls] = created; else overflow = 1;
-        if constexpr (FAST) fl.crc[accepted & (kNRing - 1)][tid] = created;   // the FIFO's head is usually still in here
+        if constexpr (FAST) { if (accepted - started < kNRing) fl.crc[accepted & (kNRing - 1)][tid] = created; }   // inside the window
         accepted++; buf++;
         return was_empty;
     }
@@ -441,19 +476,39 @@ struct NetStation {
         buf--;
         return true;
     }
+    // FAST created_at window (see pf_v0): commit pending prefetches; after request k started, request k + kNRing enters
+    __device__ __forceinline__ void pf_commit() {
+        if constexpr (FAST) {
+            if (pf_s0 >= 0) { fl.crc[pf_s0][tid] = pf_v0; pf_s0 = -1; }
+            if (pf_s1 >= 0) { fl.crc[pf_s1][tid] = pf_v1; pf_s1 = -1; }
+        }
+    }
+    __device__ __forceinline__ void window_advance(int64_t k) {
+        if constexpr (FAST) {
+            const int64_t j = k + kNRing;
+            if (j < accepted) {                       // admitted while the window was full: its created_at is in the log
+                const int64_t v = (j < cap) ? adm[j * ls] : 0;
+                const int slot = (int)(j & (kNRing - 1));
+                if (pf_s0 < 0) { pf_v0 = v; pf_s0 = slot; }
+                else if (pf_s1 < 0) { pf_v1 = v; pf_s1 = slot; }
+                else fl.crc[slot][tid] = v;           // (more than two starts per iteration: synchronous)
+            }
+        }
+    }
     // `known_created`: created_at of the head request when the caller still has it in a register (the request
     // that was enqueued by this very chain into an empty buffer); otherwise it is read back from the log.
     __device__ __forceinline__ uint32_t do_deliver_work(int64_t t, bool have_created, int64_t known_created) {
         ev[4]++; ev[5]++;
         const int64_t k = started++;
-        if (active >= conc) { rejected++; return 0; }
+        if (active >= conc) { rejected++; if constexpr (FAST) { pf_commit(); window_advance(k); } return 0; }
         active++;
         double s; int64_t dur;
         sample_service(s, dur);
         int64_t created;
         if (have_created) created = known_created;
-        else if (FAST && accepted - k <= kNRing) created = fl.crc[k & (kNRing - 1)][tid];   // no global round trip
+        else if constexpr (FAST) { pf_commit(); created = fl.crc[k & (kNRing - 1)][tid]; }   // no global round trip
         else created = (k < cap) ? adm[k * ls] : 0;
+        if constexpr (FAST) window_advance(k);
         int j = 0;
 #pragma unroll
         for (int i = C - 1; i >= 0; --i) if (D[i] == kInfNs) j = i;
@@ -483,13 +538,41 @@ struct NetStation {
             m[0] = t_arr; m[1] = t; m[2] = created; m[3] = ((int64_t)dst << 32) | gid;
         } else bagoverflow = 1;
     }
-    __device__ __forceinline__ int64_t link_sent_of(int32_t l) const {
-        if constexpr (FAST) { if (l == fl_link) return fl_sent; }
+    __device__ __forceinline__ int64_t link_sent_of(int32_t l) const {   // the link queue's sequence number
+        if constexpr (FAST) { if (l == fl_link) return fl_q; }
         return ns->link_sent[l];
+    }
+    // append {arrival, send time, created_at} to the LP's one outgoing link (queue or, on a shard, the outbox row)
+    __device__ __forceinline__ void fl_append(int64_t t_arr, int64_t t_send, int64_t created) {
+        sent_min = t_arr < sent_min ? t_arr : sent_min;
+        ++fl_q;
+        if (fl_remote) { outbox_append(fl_link, fl_dst, t_arr, t_send, created); return; }
+        const size_t slot = (size_t)fl_link * ns->aq_cap + (size_t)(((unsigned long long)fl_q - 1) & (unsigned long long)(ns->aq_cap - 1));
+        ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t_send); ag_store(&ns->aq_cr[slot], created);
+        sent_async = true;
+    }
+    // Decide the way out of request `ordinal` (departure D, created_at `created`) ahead of time; `bit_off` = its distance, in
+    // completions, from the next one.  False when the pre-drawn route / jitter values do not reach that far.
+    __device__ __forceinline__ bool pre_send(int64_t ordinal, int bit_off, int64_t D, int64_t created) {
+        const bool router = egress == EG_ROUTER;
+        if (router && bit_off >= rn) return false;
+        const int32_t target = egress == EG_SINK ? -1 : egress == EG_LINK ? link_of
+                             : router ? (((rbits >> bit_off) & 1u) == 0 ? rt0 : rt1) : -2;
+        if (target >= 0 && D <= end_ns) {
+            if (fl_jit == 0 && nj == 0) return false;
+            double delay = fl_delay0;
+            if (fl_jit == 0) { delay = __dadd_rn(delay, fl.ring_j[hj][tid]); hj = (hj + 1) & (kNRing - 1); --nj; }
+            if (!(delay > 0.0)) delay = 0.0;
+            fl_append(D + ns_from_seconds(delay), D, created);
+        }
+        early_upto = ordinal + 1;
+        D_pre = D;
+        return true;
     }
     // the LP's only outgoing link with its state in registers and the jitter E pre-drawn (FAST; queue path only)
     __device__ __forceinline__ void send_link_fast(int64_t t, int64_t created) {
         ev[8]++;
+        if (presend && completed - 1 < early_upto) { fl_in++; fl_sent++; return; }   // its message was appended ahead of time
         const int64_t entered = fl_in++;
         if (fl_loss > 0.0) {
             Stream ls;
@@ -504,13 +587,7 @@ struct NetStation {
             hj = (hj + 1) & (kNRing - 1); --nj;
         }
         if (!(delay > 0.0)) delay = 0.0;
-        const int64_t t_arr = t + ns_from_seconds(delay);
-        sent_min = t_arr < sent_min ? t_arr : sent_min;
-        if (fl_remote) { outbox_append(fl_link, fl_dst, t_arr, t, created); return; }
-        const unsigned long long sq = (unsigned long long)fl_sent;
-        const size_t slot = (size_t)fl_link * ns->aq_cap + (size_t)((sq - 1) & (unsigned long long)(ns->aq_cap - 1));
-        ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t); ag_store(&ns->aq_cr[slot], created);
-        sent_async = true;
+        fl_append(t + ns_from_seconds(delay), t, created);
     }
     __device__ __forceinline__ void send_link(int32_t l, int64_t t, int64_t created) {
         if constexpr (FAST) { if (l == fl_link) { send_link_fast(t, created); return; } }
@@ -576,6 +653,11 @@ struct NetStation {
     }
     // the forwarded request's way out of the LP: Sink / RandomRouter / NetworkLink (all at time t)
     __device__ __forceinline__ void do_egress(int64_t t, int64_t created) {
+        const bool pre = FAST && C == 1 && presend && completed - 1 < early_upto;   // way out decided ahead of time
+        do_egress_inner(t, created);
+        if (FAST && C == 1 && !pre) { if (early_upto < completed) { early_upto = completed; D_pre = t; } }
+    }
+    __device__ __forceinline__ void do_egress_inner(int64_t t, int64_t created) {
         int32_t target = -2;             // -2 nothing, -1 sink, >= 0 link
         if (egress == EG_SINK) target = -1;
         else if (egress == EG_LINK) target = link_of;
@@ -676,15 +758,15 @@ struct NetStation {
         return H;                         // the caller caps it with `undrained`
     }
     // back-pressure: an LP processes events only while each of its outgoing queues can take what one timestamp group
-    // may send (one message per completion, at most C completions per group)
+    // may send (one message per completion, at most C completions per group; a pre-sending station up to two per group)
     // `head_seen` caches the consumer's published position: it only moves forward, so a stale value errs on the safe
     // side and the (cache-bypassing) reload is needed only when the queue looks full
     __device__ __forceinline__ bool async_can_send(int32_t l, unsigned long long &head_seen) const {
         if (l < 0) return true;
         const unsigned long long sent = (unsigned long long)link_sent_of(l);
-        if (sent - head_seen + (unsigned long long)C <= (unsigned long long)ns->aq_cap) return true;
+        if (sent - head_seen + 2ull * C <= (unsigned long long)ns->aq_cap) return true;
         head_seen = ag_load(&ns->aq_head[l]);
-        return sent - head_seen + (unsigned long long)C <= (unsigned long long)ns->aq_cap;
+        return sent - head_seen + 2ull * C <= (unsigned long long)ns->aq_cap;
     }
     // Shortest duration among the next `free` services to start: service draws svc.k .. svc.k + free - 1, not consumed
     // (pure functions of the draw index).  With `free` idle workers that many requests can be in service before any
@@ -701,6 +783,99 @@ struct NetStation {
             m = d < m ? d : m;
         }
         return m;
+    }
+
+    // ---- look-ahead over the pre-drawn decisions (C == 1, FAST) ----------------------------------------------------
+    // A sender's bound on link l is the earliest time it can still SEND on l.  Completions leave in start order (one worker),
+    // the router's choice for the k-th completion from now is route draw number routed + k -- already drawn (`rbits`) -- and the
+    // service times of the next requests to start are pre-drawn too (`ring_s`).  So the bound need not stop at the next
+    // completion: it is the lower bound of the first completion whose route draw says `l`,
+    //     busy:  D + s_1 + ... + s_q          idle:  (next possible start) + s_1 + ... + s_(q+1)
+    // (q = completions before it that go elsewhere; s_i = service time of the i-th next request to start: the next service
+    // cannot start before the previous one ends, whatever arrives).  Truncating the sums is conservative.
+    __device__ __forceinline__ int skip_to_link(int32_t l) const {
+        if (egress != EG_ROUTER) return 0;                            // EG_LINK: every completion enters the link
+        int q = 0;
+        uint32_t b = rbits;
+        while (q < rn && ((b & 1u) == 0 ? rt0 : rt1) != l) { ++q; b >>= 1; }
+        return q;                                                     // == rn: none of the known decisions goes to l
+    }
+    __device__ __forceinline__ int64_t sum_services(int m) const {   // of the next m requests to start, m <= services_known()
+        if (svc_kind != 0) return (int64_t)m * svc_const_ns;
+        int64_t sum = 0;
+        for (int i = 0; i < m; ++i) sum += ns_from_seconds(fl.ring_s[(hs_ + i) & (kNRing - 1)][tid]);
+        return sum;
+    }
+    __device__ __forceinline__ int services_known() const { return svc_kind != 0 ? kNRing : nsv; }
+
+    // The map  ea(H) = min(mA, max(H + mB, mD))  of this LP as the sender on link l (transit floor `lat`), from its CURRENT
+    // state: a lower bound on the arrival of every message it has not appended to l yet, given that nothing reaches it from
+    // upstream before H.  (min D / next own event / the next free workers' service times: every quantity is already determined.)
+    __device__ __forceinline__ void bound_map(int32_t l, int64_t lat, int64_t &mA, int64_t &mB, int64_t &mD) const {
+        auto sat = [](int64_t a, int64_t b) { return (a == kInfNs || b == kInfNs) ? kInfNs : a + b; };
+        mA = kInfNs; mB = kInfNs; mD = INT64_MIN;
+        if constexpr (C == 1 && FAST) {
+            const int known = services_known();
+            if (presend && l == fl_link) {
+                // Requests with ordinal < early_upto are pre-sent; the first message still to come belongs to request u =
+                // early_upto or a later one -- whichever is the first whose (pre-drawn) route decision is l:
+                //   u in service          leaves at D[0]; the requests behind it start when it leaves;
+                //   u waiting             starts exactly when request u - 1 (pre-sent, departure D_pre) leaves;
+                //   u not admitted yet    is admitted at a >= min(next own arrival, H), starts at >= max(a, D_pre);
+                // each later candidate adds the service time of the request in front of it.  Truncated sums are conservative.
+                const int64_t u = early_upto;
+                const int boff = (int)(u - completed);               // its distance from the next completion
+                int q = 0;                                           // requests from u on that go elsewhere first
+                if (egress == EG_ROUTER) {
+                    uint32_t b = boff < 32 ? rbits >> boff : 0u;
+                    const int have = rn - boff;
+                    while (q < have && q < kLookMax && ((b & 1u) == 0 ? rt0 : rt1) != l) { ++q; b >>= 1; }
+                }
+                if (u < started) {                                   // in service
+                    const int e = q < known ? q : known;
+                    mA = sat(sat(D[0], sum_services(e)), lat);
+                    return;
+                }
+                const int off = (int)(u - started);
+                int64_t sd = 0;
+                if (svc_kind != 0) sd = (int64_t)(q + 1) * svc_const_ns;
+                else for (int i = 0; i <= q && off + i < known; ++i) sd += ns_from_seconds(fl.ring_s[(hs_ + off + i) & (kNRing - 1)][tid]);
+                if (u < accepted) { mA = sat(sat(D_pre, sd), lat); return; }
+                int64_t arr_next = A < bmin ? A : bmin;              // the next admission the LP already knows about
+                if (has_sched() && SA < arr_next) arr_next = SA;
+                const int64_t own = arr_next > D_pre ? arr_next : D_pre;
+                mA = sat(sat(own, sd), lat);
+                mB = sd + lat;
+                mD = sat(sat(D_pre, sd), lat);
+                return;
+            }
+            if (kLookMax > 1) {
+                // one worker: look ahead to the first completion that is routed to l (see skip_to_link)
+                int m = skip_to_link(l) + 1;
+                m = m < kLookMax ? m : kLookMax;
+                if (active >= conc) {
+                    const int e = (m - 1) < known ? (m - 1) : known;
+                    mA = sat(sat(D[0], sum_services(e)), lat);
+                } else {
+                    const int e = m < known ? m : known;
+                    const int64_t sd = sum_services(e);
+                    mA = sat(sat(next_time(), sd), lat);
+                    mB = sd + lat;
+                }
+                return;
+            }
+        }
+        int64_t dmin = kInfNs;
+#pragma unroll
+        for (int i = 0; i < C; ++i) dmin = D[i] < dmin ? D[i] : dmin;
+        int64_t a = dmin;
+        if (active < conc) {
+            const int64_t dur = peek_service_ns(conc - active);
+            const int64_t own = sat(next_time(), dur);
+            a = own < a ? own : a;
+            mB = dur + lat;
+        }
+        mA = sat(a, lat);
     }
 
     // ---- general path ----------------------------------------------------------------------
@@ -783,6 +958,9 @@ struct NetStation {
     // link).  Event counts, statistics, creation stamps and draw consumption are exactly run_group()'s.
     __device__ __forceinline__ void step1(int64_t t, bool force_general) {
         static_assert(C == 1, "step1 is the single-worker specialisation");
+#ifdef HS_CYC2
+        unsigned long long cy_t = __builtin_readcyclecounter();
+#endif
         const bool tick = (A == t), dep = (D[0] == t);
         int cnt = (tick ? 1 : 0) + (dep ? 1 : 0), mi = 0;
         if (bmin == t)
@@ -811,14 +989,16 @@ struct NetStation {
             if (has_sched() && SA == t) cnt += 2;
             if (tick && prof_kind != kProfConstant) cnt += 2;         // (its next arrival is a numerical inversion)
         }
+        const bool pre_done = presend && dep && completed < early_upto;   // the departing request's message went out ahead of time
         const bool slow = force_general || cnt != 1 || (tick && (a2 <= t || (poisson && na == 0))) ||
                           (deliver && (dur == 0 || (svc_exp && nsv == 0))) || (dep && router && rn == 0) ||
-                          (to_link && (target != fl_link || fl_loss > 0.0 || (fl_jit == 0 && nj == 0)));
+                          (to_link && (target != fl_link || fl_loss > 0.0 || (!pre_done && fl_jit == 0 && nj == 0)));
 #ifdef HS_RINGSTAT
         if (slow) stat_slow = 1;
-        if (deliver && dep && !(accepted - started <= kNRing)) stat_gl = 1;
+        if (deliver && dep && started + kNRing < accepted) stat_gl = 1;   // a prefetch is issued
 #endif
         if (slow) { run_group(t, force_general); return; }
+        HS_CY2(0)
         // ---- Source.handle_event
         ev[0] += tick; generated += tick;
         arr_time = tick ? a2 : arr_time;
@@ -840,10 +1020,21 @@ struct NetStation {
         dropped += (arrv && !acc) ? 1 : 0;
         if (acc) {
             if (accepted < cap) adm[accepted * ls] = created_in; else overflow = 1;
-            fl.crc[accepted & (kNRing - 1)][tid] = created_in;
+            if (accepted - started < kNRing) fl.crc[accepted & (kNRing - 1)][tid] = created_in;
+        }
+        if (acc && presend && early_upto == accepted) {
+            // pre-send at admission: the request's start and departure are already determined (see `early_upto`)
+            const int off = (int)(accepted - started);                 // requests that start before it
+            if (!svc_exp || off < nsv) {
+                const double s_k = svc_exp ? fl.ring_s[(hs_ + off) & (kNRing - 1)][tid] : svc_const_s;
+                const int64_t dur_k = svc_exp ? ns_from_seconds(s_k) : svc_const_ns;
+                const int64_t s_at = t > D_pre ? t : D_pre;
+                if (dur_k > 0) (void)pre_send(accepted, (int)(accepted - completed), s_at + dur_k, created_in);
+            }
         }
         accepted += acc;
         ev[2] += notify;
+        HS_CY2(1)
         // ---- worker continuation: statistics, then the forwarded request's way out
         int64_t created_out = 0;
         if (dep) {
@@ -861,21 +1052,18 @@ struct NetStation {
         }
         if (to_link) {                                                // send_link_fast without the loss branch
             ev[8]++; fl_in++; fl_sent++;
-            double delay = fl_delay0;
-            if (fl_jit == 0) {
-                delay = __dadd_rn(delay, fl.ring_j[hj][tid]);
-                hj = (hj + 1) & (kNRing - 1); --nj;
-            }
-            if (!(delay > 0.0)) delay = 0.0;
-            const int64_t t_arr = t + ns_from_seconds(delay);
-            sent_min = t_arr < sent_min ? t_arr : sent_min;
-            if (fl_remote) outbox_append(fl_link, fl_dst, t_arr, t, created_out);
-            else {
-                const size_t slot = (size_t)fl_link * ns->aq_cap + (size_t)(((unsigned long long)fl_sent - 1) & (unsigned long long)(ns->aq_cap - 1));
-                ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t); ag_store(&ns->aq_cr[slot], created_out);
-                sent_async = true;
+            if (!pre_done) {
+                double delay = fl_delay0;
+                if (fl_jit == 0) {
+                    delay = __dadd_rn(delay, fl.ring_j[hj][tid]);
+                    hj = (hj + 1) & (kNRing - 1); --nj;
+                }
+                if (!(delay > 0.0)) delay = 0.0;
+                fl_append(t + ns_from_seconds(delay), t, created_out);
             }
         }
+        if (dep && early_upto < completed) { early_upto = completed; D_pre = t; }   // (left the ordinary way)
+        HS_CY2(2)
         // ---- QUEUE_POLL, then QUEUE_DELIVER + the retargeted payload at the worker
         ev[3] += poll;
         buf = buf1 - (deliver ? 1 : 0);
@@ -884,12 +1072,15 @@ struct NetStation {
             const int64_t k = started++;
             active++;
             int64_t created = created_in;                             // arrival side: the request that found the buffer empty
-            if (dep) created = (accepted - k <= kNRing) ? fl.crc[k & (kNRing - 1)][tid] : ((k < cap) ? adm[k * ls] : 0);
+            if (dep) created = fl.crc[k & (kNRing - 1)][tid];        // the window always holds the next request to start
+            window_advance(k);
+            if (presend && k >= early_upto) (void)pre_send(k, (int)(k - completed), t + dur, created);   // pre-send at the start
             svc_s[0] = s_new; crt[0] = created;
             D[0] = t + dur; seqD[0] = seq++; crtD[0] = t;
             if (svc_exp) { hs_ = (hs_ + 1) & (kNRing - 1); --nsv; }
         }
         last_time = t;
+        HS_CY2(3)
     }
 
     __device__ __forceinline__ void run_group(int64_t t, bool force_general) {

@@ -143,12 +143,13 @@ def test_exchange_row_overflow_is_reported():
                 end_s=2.0, seed=5)
     with pytest.raises(N.EngineError, match="overflow"):
         _sharded(spec, 2, msg_capacity=2, rounds=False)
-    # asynchronous rounds size their length to the rows: two messages per iteration fit, so rounds of one iteration ...
+    # asynchronous rounds size their length to the rows: an iteration may append 2 x 4 groups x 1 worker = 8 messages to a
+    # cross link (pre-sending stations: a departure + the next request's pre-send per group), so rounds of one iteration ...
     ref, *_ = _sharded(spec, 2, msg_capacity=256, rounds=False, bag_capacity=128)   # (20 messages in flight per link)
-    summ, *_ = _sharded(spec, 2, msg_capacity=2, rounds=True, bag_capacity=128)
+    summ, *_ = _sharded(spec, 2, msg_capacity=8, rounds=True, bag_capacity=128)
     assert summ.events_processed == ref.events_processed and summ.final_time_ns == ref.final_time_ns
-    with pytest.raises(ValueError, match="msg_capacity 1 is too small"):       # ... but not even one iteration fits here
-        _sharded(spec, 2, msg_capacity=1, rounds=True)
+    with pytest.raises(ValueError, match="msg_capacity 4 is too small"):       # ... but not even one iteration fits here
+        _sharded(spec, 2, msg_capacity=4, rounds=True)
 
 
 @PROTOCOLS
