@@ -37,6 +37,82 @@ SURVEY_BYTES_PER_EVENT = 128        # traffic of an engine that 
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def csrc_sha16():
+    """Fingerprint of the kernel sources: a committed profile is quoted only while it describes the code that runs."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "happy_simulator_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_roofline(workload):
+    """The newest committed profile of this workload (profiles/derive_roofline.py): HBM bytes per launch from the PMC passes,
+    the VALU issue fraction from the SQ pass.  `current` is False when the kernel sources changed after it was taken --
+    the line then carries traffic = null instead of a stale number."""
+    import glob
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_roofline_{workload}.json")))
+    if not paths:
+        return None
+    try:
+        d = json.load(open(paths[-1]))
+    except Exception:
+        return None
+    d["file"] = os.path.relpath(paths[-1], ROOT)
+    d["current"] = d.get("csrc_sha16") == csrc_sha16()
+    return d
+
+
+def reference_python():
+    """The reference's own Python path as timed in the build container (tools/measure_reference_python.py); the GPU box has
+    no /root/reference, so the figure travels as a committed file and is labelled with the hardware it was measured on."""
+    import glob
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_reference_python.json")))
+    if not paths:
+        return None
+    try:
+        d = json.load(open(paths[-1]))
+    except Exception:
+        return None
+    d["file"] = os.path.relpath(paths[-1], ROOT)
+    return d
+
+
+def api_run(args, device):
+    """Wall time of the user-visible call: build the 3 x n_lp reference-API objects, `hs.Simulation(...).run()` (lowering, the
+    engine run, the read-back of every statistic and Sink record into the Python objects)."""
+    import happy_simulator_amd as hs
+
+    n = args.n_lp
+    t0 = time.perf_counter()
+    sinks = [hs.Sink(f"sink{i}") for i in range(n)]
+    servers = [hs.Server(f"srv{i}", service_time=hs.ExponentialLatency(args.mean), downstream=sinks[i]) for i in range(n)]
+    sources = [hs.Source.poisson(rate=args.rate, target=servers[i], name=f"src{i}") for i in range(n)]
+    sim = hs.Simulation(end_time=hs.Instant.from_seconds(args.end_s), sources=sources,
+                        entities=[e for pair in zip(servers, sinks) for e in pair], seed=args.seed, device=device)
+    t1 = time.perf_counter()
+    summary = sim.run()
+    t2 = time.perf_counter()
+    return {"api_construct_s": t1 - t0, "api_run_s": t2 - t1, "api_events": summary.total_events_processed}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU (torch.distributed.run, 127.0.0.1)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    raise SystemExit(subprocess.call(cmd))
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,6 +130,10 @@ def parse():
                          "ONE 65 536-station ring network, sharded over the GPUs (strong scaling, RCCL exchange + GVT); "
                          "lb = BASELINE configs[4]: 32 768 Sources -> LoadBalancer(ConsistentHash(150)) -> 32 768 Servers -> "
                          "one Sink (one topology per GPU, replicas only)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="grid: weak = every GPU its own n_lp chains (the default); strong = n_lp chains in total, split over the GPUs")
+    ap.add_argument("--api-run", type=int, default=1,
+                    help="grid, 1 GPU: also time the user-visible hs.Simulation(...).run() at this size (config.api_run_s)")
     ap.add_argument("--lb-backends", type=int, default=32768)
     ap.add_argument("--lb-sources", type=int, default=32768)
     ap.add_argument("--lb-rate", type=float, default=6.0, help="lb: Poisson rate per source (mean backend load = rate * S / B)")
@@ -359,6 +439,8 @@ def main():
     import numpy as np
     import torch
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -389,9 +471,14 @@ def main():
             dist.destroy_process_group()
         return
     end_ns = int(args.end_s * 1_000_000_000)
-    st = StationArrays.uniform(args.n_lp, rate=args.rate, mean=args.mean)
-    eng = StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=end_ns, seed=args.seed,
-                        lp_base=rank * args.n_lp, device=local_rank)
+    n_total = args.n_lp
+    if args.scaling == "strong":          # the metric's 65 536 servers in total: rank r owns the contiguous block [lo, hi)
+        lo, hi = rank * n_total // world, (rank + 1) * n_total // world
+    else:                                 # every rank its own n_lp chains with disjoint stream ids
+        lo, hi = rank * n_total, (rank + 1) * n_total
+    n_mine = hi - lo
+    st = StationArrays.uniform(n_mine, rate=args.rate, mean=args.mean)
+    eng = StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=end_ns, seed=args.seed, lp_base=lo, device=local_rank)
 
     def barrier():
         if distributed:
@@ -419,16 +506,12 @@ def main():
 
     if rank == 0:
         k_avg_ms = float(np.mean(kernel_ms))
-        algo_bytes = requests_per_step * BYTES_PER_REQUEST + args.n_lp * STATE_BYTES_PER_LP
+        algo_bytes = requests_per_step * BYTES_PER_REQUEST + n_mine * STATE_BYTES_PER_LP
         achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9
         survey_model = events_per_step * SURVEY_BYTES_PER_EVENT / (k_avg_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        prof = measured_roofline("grid")
+        full = n_mine == 65536 and args.end_s == 60.0      # the configuration the profile was taken on
+        traffic = prof["hbm_bytes_per_launch"] if (prof and prof.get("current") and full and "hbm_bytes_per_launch" in prof) else None
         out = {
             "metric": "committed events/sec (whole node), 65 536-server M/M/1 grid",
             "value": total_events_per_step * args.steps / elapsed,
@@ -438,15 +521,18 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "int64+f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.n_lp} independent Source.poisson({args.rate:g}) -> Server(Exp {args.mean:g}) -> Sink "
-                            f"chains per GPU in one Simulation, {args.end_s:g} s simulated, Philox seed {args.seed} "
+                "workload": (f"{args.n_lp} independent Source.poisson({args.rate:g}) -> Server(Exp {args.mean:g}) -> Sink "
+                             f"chains per GPU in one Simulation" if args.scaling == "weak" else
+                             f"{args.n_lp} independent Source.poisson({args.rate:g}) -> Server(Exp {args.mean:g}) -> Sink chains "
+                             f"in total, a contiguous block of {n_mine} per GPU") +
+                            f", {args.end_s:g} s simulated, Philox seed {args.seed} "
                             f"(BASELINE configs[1] scaled to the metric's 65 536-server grid, SURVEY 8(d) 2b)",
-                "n_lp_per_gpu": args.n_lp,
+                "n_lp_per_gpu": n_mine,
                 "events_per_step_per_gpu": events_per_step,
                 "requests_per_step_per_gpu": requests_per_step,
                 "requests_per_s": requests_per_step * args.gpus * args.steps / elapsed,
@@ -454,13 +540,19 @@ def main():
                 "parallelism": f"lp-shard x{args.gpus} (no data-path collective)",
             },
             "roofline": {
-                "bound": "hbm",
-                "kernel": "hs_station_run<1>",
+                # the binding resource is VALU issue (the serial per-LP recursion), not HBM: `achieved` / `frac` are the HBM
+                # figures the contract asks for, `valu` is the measured issue fraction of the same kernel
+                "bound": "valu",
+                "kernel": "hs_station_run<1, false, true> (producer / consumer wavefronts)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "valu": None if not prof or "valu_busy_frac" not in prof else {
+                    "busy_frac": prof["valu_busy_frac"], "waves_per_simd": prof.get("waves_per_simd"),
+                    "kernel_us_under_rocprof": prof.get("kernel_us_rocprof"), "profile": prof["file"],
+                    "profile_commit": prof.get("commit"), "profile_is_of_this_code": bool(prof.get("current"))},
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "algorithmic_bytes_per_event": algo_bytes / events_per_step,
                 "survey_8d_model_GBps": survey_model,
@@ -470,12 +562,18 @@ def main():
                 "note": "algorithmic bytes = 16 B x requests (adm + sink_t appends) + 576 B x LPs (state in/out); "
                         "SURVEY 8(d)'s 128 B/event prices an engine that materialises every reference event and "
                         "would exceed the HBM peak here (survey_8d_model_GBps) because this kernel keeps event "
-                        "records in registers; the kernel is bound by the serial per-LP recursion, not by HBM "
-                        "(DESIGN.md section 6)",
+                        "records in registers; the kernel is bound by VALU issue of the serial per-LP recursion, not by HBM "
+                        "(DESIGN.md section 6); traffic / valu come from the committed rocprofv3 passes named in `valu.profile` "
+                        "and are null when the kernel sources changed since",
             },
         }
         if args.cpu_sample_s > 0 and args.gpus == 1:
             out["cpu_baseline"] = cpu_baseline(args)
+            ref = reference_python()
+            if ref is not None:
+                out["cpu_baseline"]["reference_python"] = ref
+        if args.api_run and args.gpus == 1:
+            out["config"].update(api_run(args, local_rank))
         print(json.dumps(out))
     eng.close()
     if distributed:

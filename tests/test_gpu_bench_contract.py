@@ -36,8 +36,23 @@ def test_bench_prints_one_contract_line(args):
     assert d["unit"] == "events/s" and d["value"] > 1e6 and d["ms_per_step"] > 0
     assert d["data"] == "synthetic" and d["vs_baseline"] is None and "workload" in d["config"]
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["bound"] in ("hbm", "mfma", "valu") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    if r["bound"] == "valu":                 # the grid: the HBM figures of the contract + the measured VALU issue fraction
+        assert "valu" in r and (r["valu"] is None or 0.0 < r["valu"]["busy_frac"] <= 1.0)
+        assert "api_run_s" in d["config"] and d["config"]["api_events"] == d["config"]["events_per_step_per_gpu"]
+        ref = c_ref = d["cpu_baseline"].get("reference_python")
+        assert ref is None or (ref["single_process_65536_chains"]["value"] > 1e3 and "cpu" in c_ref)
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 1e4 and c["unit"] == "events/s" and c["sample"]
     assert d["value"] > c["value"]
+
+
+def test_bench_strong_scaling_and_self_launch_flags():
+    """`--scaling strong` keeps the metric's total station count (here on one GPU: the same numbers as weak), and a plain
+    `python bench.py --gpus N` without a launcher starts its own ranks (checked with N = 1: no torch.distributed.run child)."""
+    weak = _run("--steps", "2", "--warmup", "1", "--n-lp", "2048", "--end-s", "5", "--cpu-sample-s", "0", "--api-run", "0")
+    strong = _run("--steps", "2", "--warmup", "1", "--n-lp", "2048", "--end-s", "5", "--cpu-sample-s", "0", "--api-run", "0",
+                  "--scaling", "strong")
+    assert strong["scaling"] == "strong" and weak["scaling"] == "weak"
+    assert strong["config"]["events_per_step_per_gpu"] == weak["config"]["events_per_step_per_gpu"]
