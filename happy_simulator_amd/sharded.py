@@ -373,9 +373,32 @@ class ShardedNetwork:
                     s.inject_async()
                 self._exchange_s += _time.perf_counter() - t0
                 r += 1
-            if all([s.round_done() for s in sh]):                      # the only host synchronisation
+            done = self._all_ranks([lambda s=s: s.round_done() for s in sh])   # the only host synchronisation
+            if all(done):
                 break
         return r
+
+    def _all_ranks(self, calls):
+        """Run the shards' host-synchronising calls and make an engine error COLLECTIVE: an error flag is all-reduced (MAX)
+        after them, so that a rank whose shard overflowed does not leave the others waiting in the next collective -- every
+        rank raises together (the failing one its own EngineError, the others a note that a peer failed)."""
+        import torch
+
+        out, exc = [], None
+        for c in calls:
+            try:
+                out.append(c())
+            except N.EngineError as e:
+                exc = exc or e
+                out.append(False)
+        dev = self.shards[0].gvt.device
+        flags = [torch.tensor([1 if exc is not None else 0], dtype=torch.int64, device=dev) for _ in self.shards]
+        self.comm.allreduce_max(flags)
+        if exc is not None:
+            raise exc
+        if int(flags[0].item()) != 0:
+            raise N.EngineError(N.HS_E_STATE, "another rank's shard reported an engine error (see that rank's message)")
+        return out
 
     def run_until(self, end_ns: int) -> ShardedSummary:
         sh, comm = self.shards, self.comm
@@ -400,7 +423,7 @@ class ShardedNetwork:
                     comm.allreduce_min([s.gvt_slot(k) for s in sh])    # GVT
                     self._exchange_s += _time.perf_counter() - t0
                     k += 1
-                wends = [s.progress(k - 1) for s in sh]                # the only host synchronisation
+                wends = self._all_ranks([lambda s=s: s.progress(k - 1) for s in sh])   # the only host synchronisation
                 if min(wends) >= end_ns:
                     break
             for s in sh:
