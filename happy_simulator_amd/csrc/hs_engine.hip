@@ -596,6 +596,27 @@ __global__ void __launch_bounds__(64) hs_exact_run(StationParams P, NetParams NP
                                                    Totals *tot, XState *xs, XInit I, int n, int C, int net, int n_links,
                                                    int64_t start_ns, int64_t end_ns) {
     __shared__ int s_hand;
+    if (I.per_lp) {
+        // HS_MODE_REPLICAS: every LP is its own Simulation -- one lane per LP, each with its own slice of the buffers
+        const int lp = blockIdx.x * 64 + threadIdx.x;
+        if (lp >= n) return;
+        XState &S = xs[1 + lp];
+        if (S.phase == 0 && S.heap == nullptr) {
+            const XState &B = xs[0];                       // slice the shared buffers
+            S.heap = B.heap + (size_t)lp * I.heap_cap_lp; S.heap_cap = I.heap_cap_lp; S.heap_len = 0;
+            S.qhead = B.qhead; S.qtail = B.qtail;
+            S.pnext = B.pnext + (size_t)lp * I.pool_cap_lp; S.pidx = B.pidx + (size_t)lp * I.pool_cap_lp;
+            S.pool_n = 0; S.pool_cap = I.pool_cap_lp;
+            S.init_t = B.init_t + (size_t)lp * I.init_cap_lp;
+            S.err = 0; S.processed = 0;
+        }
+        // (the pool's list cells are addressed relative to the LP's slice: qhead / qtail hold slice-local indices)
+        if (exact_loop(P, NP, X, NX, L, tot, S, I, n, C, false, start_ns, end_ns, lp)) {
+            X.seq[lp] = (uint32_t)S.G;
+            S.phase = 2;
+        }
+        return;
+    }
     if (threadIdx.x == 0) s_hand = exact_loop(P, NP, X, NX, L, tot, *xs, I, n, C, net != 0, start_ns, end_ns) ? 1 : 0;
     __syncthreads();
     if (!s_hand) return;
@@ -1687,6 +1708,7 @@ int do_reset_async(hs_engine *h) {
                        h->cfg.n_lp, h->C, h->cfg.start_ns, h->NX, h->is_net ? h->NP.n_links : 0);
     HS_HIP(h, hipGetLastError());
     if (h->exact) {            // the prologue starts over: empty heap, both counters at 0
+        if (h->XI.per_lp) HS_HIP(h, hipMemsetAsync(h->xs, 0, ((size_t)h->cfg.n_lp + 1) * sizeof(XState), h->stream));
         HS_HIP(h, hipMemcpyAsync(h->xs, &h->xs_host, sizeof(XState), hipMemcpyHostToDevice, h->stream));
         HS_HIP(h, hipMemsetAsync(h->xs_host.qhead, 0xff, (size_t)h->cfg.n_lp * sizeof(int32_t), h->stream));
         HS_HIP(h, hipMemsetAsync(h->xs_host.qtail, 0xff, (size_t)h->cfg.n_lp * sizeof(int32_t), h->stream));
@@ -1699,7 +1721,7 @@ int do_reset_async(hs_engine *h) {
 // the prologue of a run (hs_exact.hpp); a no-op launch once it has handed over
 int launch_prologue(hs_engine *h, int64_t end_ns) {
     if (!h->exact || (h->flags & 256)) return HS_OK;
-    hipLaunchKernelGGL(hs_exact_run, dim3(1), dim3(64), 0, h->stream, h->P, h->NP, h->X, h->NX, h->L, h->tot, h->xs, h->XI,
+    hipLaunchKernelGGL(hs_exact_run, dim3(h->XI.per_lp ? (unsigned)((h->cfg.n_lp + 63) / 64) : 1u), dim3(64), 0, h->stream, h->P, h->NP, h->X, h->NX, h->L, h->tot, h->xs, h->XI,
                        h->cfg.n_lp, h->C, h->is_net ? 1 : 0, h->is_net ? h->NP.n_links : 0, h->cfg.start_ns, end_ns);
     HS_HIP(h, hipGetLastError());
     h->launches++;
@@ -1903,6 +1925,47 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if ((rc = upload<int32_t>(h, &h->P.tie_rank, tr.data(), (size_t)n, 0))) return rc;
     }
     h->P.sched_idx = nullptr;
+    if (h->cfg.mode == HS_MODE_REPLICAS && (n_sched > 0 || h->any_probe)) {
+        // One prologue per LP (every LP is its own Simulation): its Events sorted by construction rank inside the LP
+        std::vector<int64_t> se((size_t)n_sched), sr((size_t)n_sched);
+        int64_t span = 0;
+        for (int i = 0; i < n && n_sched > 0; ++i) {
+            const int64_t a = st->sched_off[i], b = st->sched_off[i + 1];
+            for (int64_t k = a; k < b; ++k) se[(size_t)k] = k;
+            if (st->sched_rank) {
+                std::sort(se.begin() + a, se.begin() + b, [&](int64_t x, int64_t y) { return st->sched_rank[x] < st->sched_rank[y]; });
+                for (int64_t k = a; k < b; ++k) {
+                    const int64_t r = st->sched_rank[se[(size_t)k]];
+                    if (r < 0 || (k > a && r == st->sched_rank[se[(size_t)k - 1]]))
+                        return fail(h, HS_E_INVALID, "LP %d: sched_rank must hold distinct positions >= 0", i);
+                }
+            }
+            for (int64_t k = a; k < b; ++k) {
+                sr[(size_t)k] = st->sched_rank ? st->sched_rank[se[(size_t)k]] : k - a;
+                if (sr[(size_t)k] + 1 > span) span = sr[(size_t)k] + 1;
+            }
+        }
+        if (span > max_sched + (1 << 16)) return fail(h, HS_E_INVALID, "sched_rank positions are implausibly sparse");
+        if ((rc = upload<int64_t>(h, &h->XI.sched_rank, sr.data(), sr.size(), 0))) return rc;
+        if ((rc = upload<int64_t>(h, &h->XI.sched_entry, se.data(), se.size(), 0))) return rc;
+        h->XI.n_src = 0; h->XI.n_probe = 0; h->XI.n_sched = n_sched; h->XI.per_lp = 1;
+        if ((rc = dev_alloc(h, &h->XI.sched_idx, (size_t)n_sched))) return rc;
+        HS_HIP(h, hipMemset(h->XI.sched_idx, 0, (size_t)(n_sched > 0 ? n_sched : 1) * sizeof(uint32_t)));
+        h->P.sched_idx = h->XI.sched_idx;
+        const int64_t n_init_lp = 2 + span;
+        h->XI.init_cap_lp = n_init_lp;
+        h->XI.heap_cap_lp = n_init_lp + h->C + 32;
+        h->XI.pool_cap_lp = 2 * n_init_lp + 64;
+        h->xs_host = XState{};
+        if ((rc = dev_alloc(h, &h->xs_host.heap, (size_t)n * (size_t)h->XI.heap_cap_lp))) return rc;
+        if ((rc = dev_alloc(h, &h->xs_host.qhead, (size_t)n))) return rc;
+        if ((rc = dev_alloc(h, &h->xs_host.qtail, (size_t)n))) return rc;
+        if ((rc = dev_alloc(h, &h->xs_host.pnext, (size_t)n * (size_t)h->XI.pool_cap_lp))) return rc;
+        if ((rc = dev_alloc(h, &h->xs_host.pidx, (size_t)n * (size_t)h->XI.pool_cap_lp))) return rc;
+        if ((rc = dev_alloc(h, &h->xs_host.init_t, (size_t)n * (size_t)n_init_lp))) return rc;
+        if ((rc = dev_alloc(h, &h->xs, (size_t)n + 1))) return rc;
+        h->exact = true;
+    }
     if (h->cfg.mode == HS_MODE_SINGLE && (n_sched > 0 || h->any_probe)) {
         // The prologue (hs_exact.hpp): the reference's pre-run events in the order it constructs them
         std::vector<int32_t> so, po, sl((size_t)n_sched);

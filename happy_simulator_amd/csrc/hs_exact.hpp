@@ -80,6 +80,10 @@ struct XInit {        // pre-run events in the order the reference constructs th
     int32_t n_src, n_probe;
     int64_t n_sched;
     uint32_t *sched_idx;         // [n_sched] OUT, indexed like sched_t: the Event's sort index
+    // HS_MODE_REPLICAS: one prologue per LP; sched_entry / sched_rank are sorted by (LP, rank) so that LP i's Events are the
+    // positions [sched_off[i], sched_off[i + 1]); the buffers of XState[0] are cut into per-LP slices of these sizes
+    int32_t per_lp;
+    int64_t heap_cap_lp, pool_cap_lp, init_cap_lp;
 };
 
 namespace xdetail {
@@ -141,10 +145,35 @@ __device__ inline double xuniform(uint64_t seed, uint64_t sid, uint64_t k) {
 }  // namespace xdetail
 
 // The sequential loop.  Called by lane 0 of hs_exact_run; returns true when the parallel engine takes over.
+// `only` >= 0 (HS_MODE_REPLICAS): LP `only` is a Simulation of its own -- its own heap, its own two counters, its own clock
+// (X.last_time) -- and S / I.sched_* are that LP's slices.
 __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, const StationState &X, const NetState &NX,
                                   const RecordLogs &L, Totals *tot, XState &S, const XInit &I, int n, int C, bool net,
-                                  int64_t start_ns, int64_t end_ns) {
+                                  int64_t start_ns, int64_t end_ns, int only = -1) {
     using namespace xdetail;
+    if (S.phase == 0 && only >= 0) {
+        unsigned long long g = 0;
+        const int lp = only;
+        if (P.src_kind[lp] != 0 && X.A[lp] != kInfNs) {
+            X.seqA[lp] = 0; S.init_t[g] = X.A[lp];
+            xpush(S, xev(X.A[lp], g++, XE_TICK, lp, 0, 0, kXInitFlag));
+        }
+        if (P.probe_metric[lp] != kProbeNone && X.PA[lp] != kInfNs) {
+            X.seqP[lp] = (uint32_t)g; S.init_t[g] = X.PA[lp];
+            xpush(S, xev(X.PA[lp], g++, XE_PTICK, lp, 0, 0, kXInitFlag));
+        }
+        const unsigned long long g0 = g;
+        if (P.sched_off != nullptr)
+            for (int64_t j = P.sched_off[lp]; j < P.sched_off[lp + 1]; ++j) {   // (sorted by construction rank inside the LP)
+                const int64_t e = I.sched_entry[j];
+                const int64_t t = P.sched_t[e];
+                g = g0 + (unsigned long long)I.sched_rank[j];
+                I.sched_idx[e] = (uint32_t)g;
+                S.init_t[g] = t;
+                xpush(S, xev(t, g++, XE_SCHED, lp, t, 0, kXInitFlag));
+            }
+        S.n_init = g; S.G = 0; S.tc = INT64_MAX; S.phase = 1;
+    }
     if (S.phase == 0) {
         // Simulation.__init__: sources in list order, then probes (core/simulation.py:145-160); then the Events the caller
         // built for schedule(), in construction order -- all numbered by the process-wide counter
@@ -185,7 +214,7 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
     for (int k = 0; k < 15; ++k) evk[k] = 0;
     unsigned long long n_completed = 0, n_received = 0;
     int overflow = 0;
-    int64_t cur = tot->cur_time;
+    int64_t cur = only >= 0 ? X.last_time[only] : tot->cur_time;
     bool handover = false;
     const size_t N = (size_t)n;
 
@@ -400,8 +429,8 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
     if (n_received) atomicAdd(&tot->received, n_received);
     if (overflow) atomicOr(&tot->overflow, overflow);
     if (S.err) atomicOr(&tot->overflow, 16);
-    tot->cur_time = cur;
-    if (cur > tot->final_time) tot->final_time = cur;
+    if (only >= 0) atomicMax(&tot->final_time, (long long)cur);
+    else { tot->cur_time = cur; if (cur > tot->final_time) tot->final_time = cur; }
     (void)start_ns;
     return handover;
 }

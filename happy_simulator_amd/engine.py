@@ -135,8 +135,8 @@ class StationEngine:
             st.sched_off, st.sched_time_ns = off.ctypes.data, (tt.ctypes.data if len(tt) else None)
             if stations.sched_rank is not None:
                 co = np.ascontiguousarray(stations.sched_rank, np.int64)
-                if co.shape != tt.shape or len(set(co.tolist())) != len(co) or (len(co) and co.min() < 0):
-                    raise ValueError("sched_rank must hold one distinct position >= 0 per scheduled time")
+                if co.shape != tt.shape or (len(co) and co.min() < 0):
+                    raise ValueError("sched_rank must hold one position >= 0 per scheduled time")
                 keep.append(co)
                 st.sched_rank = co.ctypes.data if len(co) else None
         for name, mask in (("source_order", np.asarray(stations.src_kind) != N.SRC_NONE),

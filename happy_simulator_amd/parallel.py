@@ -21,7 +21,7 @@ import numpy as np
 from . import _native as N
 from .core.temporal import Instant
 from .engine import StationArrays, StationEngine
-from .lowering import UnsupportedTopology, write_back
+from .lowering import UnsupportedTopology, write_back, write_back_probes
 from .simulation import Simulation, entity_summaries
 from .summary import SimulationSummary
 
@@ -68,9 +68,56 @@ def reduce_summaries(local: dict, group=None) -> dict:
 
 
 def _concat(arrs: list[StationArrays]) -> StationArrays:
+    """One StationArrays for several Simulations' stations.  EVERY field LoweredGraph.arrays() / Simulation._schedule_arrays
+    can produce is carried -- time-varying profiles, probes, scheduled Requests -- with the field's default where a
+    Simulation does not use it (dropping them would silently run a ramp source at its peak rate, lose probe samples, ignore
+    schedule() calls)."""
     keys = ("src_kind", "src_rate", "src_stop_after_ns", "concurrency", "svc_kind", "svc_mean_s", "queue_cap", "egress")
     n = sum(a.n for a in arrs)
-    return StationArrays(n=n, **{k: np.concatenate([getattr(a, k) for a in arrs]) for k in keys})
+    out = StationArrays(n=n, **{k: np.concatenate([getattr(a, k) for a in arrs]) for k in keys})
+    if any(a.src_profile_kind is not None for a in arrs):
+        out.src_profile_kind = np.concatenate([a.src_profile_kind if a.src_profile_kind is not None
+                                               else np.zeros(a.n, np.uint8) for a in arrs])
+        out.src_profile_params = np.concatenate([a.src_profile_params if a.src_profile_params is not None
+                                                 else np.zeros((a.n, 4), np.float64) for a in arrs])
+    if any(a.probe_metric is not None for a in arrs):
+        out.probe_metric = np.concatenate([a.probe_metric if a.probe_metric is not None
+                                           else np.full(a.n, N.PROBE_NONE, np.uint8) for a in arrs])
+        out.probe_interval_s = np.concatenate([a.probe_interval_s if a.probe_interval_s is not None
+                                               else np.ones(a.n, np.float64) for a in arrs])
+    if any(a.sched_off is not None for a in arrs):
+        offs, times, ranks, base = [np.zeros(1, np.int64)], [], [], 0
+        for a in arrs:
+            o = np.asarray(a.sched_off, np.int64) if a.sched_off is not None else np.zeros(a.n + 1, np.int64)
+            t = np.asarray(a.sched_time_ns, np.int64) if a.sched_off is not None else np.zeros(0, np.int64)
+            r = (np.asarray(a.sched_rank, np.int64) if getattr(a, "sched_rank", None) is not None
+                 else np.arange(len(t), dtype=np.int64))
+            offs.append(o[1:] + base)
+            times.append(t)
+            ranks.append(r)                               # every Simulation numbers its own Events (one prologue per LP)
+            base += len(t)
+        out.sched_off = np.concatenate(offs)
+        out.sched_time_ns = np.concatenate(times)
+        out.sched_rank = np.concatenate(ranks)
+    return out
+
+
+def write_back_probes_sharded(g, sn) -> None:
+    """Probe samples of the stations this process's shards own."""
+    for i, stn in enumerate(g.stations):
+        if stn.probe is not None and any(s.lo <= i < s.hi for s in sn.shards):
+            t, v = sn.read_probe(i)
+            stn.probe.data_sink._set(t, v, stn.server.concurrency if stn.probe.metric == "utilization" else None)
+
+
+class _LpOffset:
+    """read_probe() of one Simulation's stations inside a batched engine."""
+
+    def __init__(self, eng, off):
+        self._eng, self._off = eng, off
+
+    def read_probe(self, i):
+        return self._eng.read_probe(self._off + i)
 
 
 def _run_independent(sims: list[Simulation], seeds: list[int], device: int = 0,
@@ -89,7 +136,12 @@ def _run_independent(sims: list[Simulation], seeds: list[int], device: int = 0,
     if Instant.Infinity.nanoseconds in ends:
         raise UnsupportedTopology("auto-terminating runs are not lowered; pass end_time/duration")
     end_ns, start_ns = ends.pop(), starts.pop()
-    st = _concat([g.arrays() for g in graphs])
+    per_sim, cancelled = [], []
+    for s, g in zip(sims, graphs):
+        a = g.arrays()
+        cancelled.append(s._schedule_arrays(g, a))         # Simulation.schedule() calls of this replica
+        per_sim.append(a)
+    st = _concat(per_sim)
     st.seed = np.asarray(seeds, np.uint64)
     st.stream_base = (np.zeros(st.n, np.uint64) if stream_bases is None else np.asarray(stream_bases, np.uint64))
     wall0 = _time.monotonic()
@@ -97,6 +149,9 @@ def _run_independent(sims: list[Simulation], seeds: list[int], device: int = 0,
         eng.run_until(end_ns)
         stats = eng.lp_stats()
         counts, t_ns, created_ns = eng.read_sinks()
+        for i, (s, g) in enumerate(zip(sims, graphs)):
+            if s._probes:
+                write_back_probes(g, _LpOffset(eng, i))
     wall = _time.monotonic() - wall0
     out = []
     off = 0
@@ -107,6 +162,8 @@ def _run_independent(sims: list[Simulation], seeds: list[int], device: int = 0,
         off += c
         s._events_processed = int(stats["events"][i])
         s._current_time = Instant(int(stats["final_time_ns"][i]))
+        final_ns = int(stats["final_time_ns"][i])            # a cancelled Event is counted when the loop pops it
+        s._events_cancelled = sum(1 for t in cancelled[i] if final_ns <= end_ns or t <= final_ns)
         s._summary = s._build_summary(wall / len(sims))
         out.append(s._summary)
     return out
@@ -257,7 +314,7 @@ class ParallelSimulation:
             self._end = Instant.Infinity
         if not self._links:
             self._sims = [Simulation(start_time=start_time, end_time=end_time, duration=duration, sources=p.sources,
-                                     entities=p.entities, seed=seed) for p in partitions]
+                                     entities=p.entities, probes=p.probes, seed=seed) for p in partitions]
         else:
             self._lower_linked()
 
@@ -327,6 +384,17 @@ class ParallelSimulation:
                 raise ValueError(f"link '{lk.name}' can deliver after {lk.latency.mean}s, less than the PartitionLink "
                                  f"min_latency {declared[key]}s")
             self._cross_links.append(l)
+        if any(p.probes for p in parts):
+            from .lowering import attach_probes
+
+            attach_probes(g, [pr for p in parts for pr in p.probes])
+        # a collector behind stations of SEVERAL partitions (the reference allows it when it is not registered in any
+        # partition): its records are merged from all of them after the run -- which needs them in one process
+        seen: dict[int, int] = {}
+        self._sink_spans = False
+        for i, st in enumerate(g.stations):
+            if st.sink is not None and seen.setdefault(id(st.sink), part_of[i]) != part_of[i]:
+                self._sink_spans = True
         self._graph = g
         self._bounds = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
 
@@ -357,6 +425,9 @@ class ParallelSimulation:
         world = len(parts)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() == world and world > 1:
             comm = DistComm()                     # one partition per process / GPU
+            if self._sink_spans:
+                raise UnsupportedTopology("a Sink / Counter fed from several partitions cannot be merged across processes yet: "
+                                          "give every partition its own collector (or run the partitions on one GPU)")
         else:
             comm = LocalComm(world)               # virtual shards on this GPU
         end_ns, start_ns = self._end.nanoseconds, self._start.nanoseconds
@@ -367,28 +438,22 @@ class ParallelSimulation:
             summ = sn.run_until(end_ns)
             part_summaries = {}
             cross_local = 0
+            # ONE write-back over all of this process's shards: a collector fed by stations of several shards gets its
+            # records merged in completion order (hs_merge_sink_records) instead of being overwritten shard by shard
+            full, fc, t_all, cr_all, fnet = sn.collect(st.n, net.n_links)
+            local = sorted(sn.shards, key=lambda x: x.lo)
+            if len(local) == world:
+                write_back(g, full, fc, t_all, cr_all, None, device=self._device)
+            else:                                  # one shard per process: its own stations only
+                write_back(g, full, fc, t_all, cr_all, None, lo=local[0].lo, hi=local[0].hi, device=self._device)
+            if any(p.probes for p in parts):
+                write_back_probes_sharded(g, sn)
             for s in sn.shards:
-                stats = s.engine.lp_stats()
-                counts, t_ns, created_ns = s.engine.read_sinks()
-                ns = s.engine.net_stats()
-                full = {k: np.zeros(st.n, v.dtype) for k, v in stats.items()}
-                for k, v in stats.items():
-                    full[k][s.lo:s.hi] = v
-                fc = np.zeros(st.n, np.int64)
-                fc[s.lo:s.hi] = counts
-                fnet = {"routed": np.zeros(st.n, np.int64), "link_entered": np.zeros(net.n_links, np.int64),
-                        "link_packets_sent": np.zeros(net.n_links, np.int64),
-                        "link_packets_dropped": np.zeros(net.n_links, np.int64)}
-                fnet["routed"][s.lo:s.hi] = ns["routed"]
-                for k in ("link_entered", "link_packets_sent", "link_packets_dropped"):
-                    fnet[k][s.gids] = ns[k]
-                # packets_sent is counted where the link ENDS: only write links back from the shard that owns the
-                # destination (with virtual shards every object is visited by both ends' shards; the owner wins)
-                write_back(g, full, fc, t_ns, created_ns, None, lo=s.lo, hi=s.hi)
+                # packets_sent is counted where the link ENDS, losses where it STARTS: each end's shard owns its counters
                 for l, (lk, src, dst) in enumerate(g.links):
                     if s.lo <= dst < s.hi:
                         lk.packets_sent = int(fnet["link_packets_sent"][l])
-                    if s.lo <= src < s.hi:                       # losses are decided where the link STARTS
+                    if s.lo <= src < s.hi:
                         lk._entered = int(fnet["link_entered"][l])
                         lk.packets_dropped = int(fnet["link_packets_dropped"][l])
                 for i in range(s.lo, s.hi):

@@ -201,7 +201,7 @@ def oracle_lb_graph(spec):
     return g, p
 
 
-def sched_arrays(n, schedule):
+def sched_arrays(n, schedule, per_station=False):
     """Simulation.schedule() calls [(station, t_ns), ...] in construction order -> (sched_off, sched_time_ns per station
     ascending with ties in call order, sched_rank: for every entry of sched_time_ns its position among the calls)."""
     per = [[] for _ in range(n)]
@@ -212,6 +212,12 @@ def sched_arrays(n, schedule):
     flat = [tj for x in per for tj in sorted(x)]          # (t, j): ascending time, ties in call order
     times = np.array([t for t, _ in flat], np.int64)
     rank = np.array([j for _, j in flat], np.int64)
+    if per_station:                 # every station is a Simulation of its own: positions among ITS OWN schedule() calls
+        pos = {}
+        for c, x in enumerate(per):
+            for r, (_, j) in enumerate(sorted(x, key=lambda tj: tj[1])):
+                pos[j] = r
+        rank = np.array([pos[j] for _, j in flat], np.int64)
     return off, times, rank
 
 
@@ -254,7 +260,7 @@ def engine_for_spec(spec, log_capacity=0, horizon_ns=None, flags=0):
                 st.probe_metric[i] = PROBE_METRICS[pr[0]][1]
                 st.probe_interval_s[i] = pr[1]
     if p["schedule"]:              # Simulation.schedule(): per station ascending, ties in call order (stable sort)
-        st.sched_off, st.sched_time_ns, st.sched_rank = sched_arrays(n, p["schedule"])
+        st.sched_off, st.sched_time_ns, st.sched_rank = sched_arrays(n, p["schedule"], per_station=spec["mode"] != "single")
     if spec["mode"] == "single":
         mode = N.MODE_SINGLE
         seed = spec["seed"]

@@ -620,3 +620,78 @@ def test_tie_storms_through_the_api_with_sources_listed_in_another_order(k):
         if c in datas:
             t, v = r.sinks[g.probe_nodes[c]]
             assert datas[c].raw_values() == v.tolist()
+
+
+def test_batched_replicas_carry_profiles_probes_and_scheduled_requests():
+    """ParallelRunner batches its replicas into one launch; every optional per-station field must survive the batching:
+    a replica with a LinearRampProfile source, a Probe and schedule()d Requests equals the same Simulation run on its own
+    (round-1 advisor finding: `_concat` dropped them -- the ramp ran at its peak rate, probes came back empty)."""
+    datas = {}
+
+    def build(k=None):
+        sink = hs.Sink("sink")
+        srv = hs.Server("srv", service_time=hs.ExponentialLatency(0.05), queue_capacity=6, downstream=sink)
+        src = hs.Source.with_profile(hs.LinearRampProfile(duration_s=4.0, start_rate=4.0, end_rate=20.0), target=srv,
+                                     poisson=True, name="src")
+        pr, d = hs.Probe.on(srv, "depth", interval=0.25)
+        sim = hs.Simulation(end_time=Instant.from_seconds(6.0), sources=[src], entities=[srv, sink], probes=[pr])
+        evs = [hs.Event(time=Instant.from_seconds(t), event_type="Request", target=srv) for t in (0.0, 0.0, 1.5, 3.0)]
+        sim.schedule(evs)
+        evs[2].cancel()
+        sim._parts = (src, srv, sink, d)
+        return sim
+
+    sims = []
+
+    def build_and_keep():
+        sims.append(build())
+        return sims[-1]
+
+    res = hs.ParallelRunner().run_sweep([hs.RunConfig(name=f"r{i}", build_fn=build_and_keep, seed=900 + i) for i in range(5)])
+    for i, (r, s) in enumerate(zip(res, sims)):
+        alone = build()
+        alone._seed = 900 + i
+        want = alone.run()
+        assert r.summary.total_events_processed == want.total_events_processed > 300
+        assert r.summary.duration_s == want.duration_s and r.summary.events_cancelled == want.events_cancelled == 1
+        for a, b in zip(s._parts[:3], alone._parts[:3]):
+            assert type(a) is type(b)
+        assert s._parts[0].generated_count == alone._parts[0].generated_count
+        assert s._parts[1].stats_accepted == alone._parts[1].stats_accepted
+        assert s._parts[1].stats_dropped == alone._parts[1].stats_dropped
+        assert s._parts[2].latencies_s == alone._parts[2].latencies_s
+        assert s._parts[3].raw_values() == alone._parts[3].raw_values() and s._parts[3].count() == 24
+    assert len({r.summary.total_events_processed for r in res}) > 1          # different seeds, different runs
+
+
+def test_linked_partitions_with_one_sink_fed_from_every_partition():
+    """A collector behind Servers of SEVERAL partitions (advisor finding: each shard's write-back used to overwrite it, only
+    the last shard's records survived): the linked run merges all shards' records in completion order and equals the
+    single-heap Simulation of the same objects."""
+    def build():
+        n = 6
+        sink = hs.Sink("sink")
+        servers = [hs.Server(f"srv{i}", service_time=hs.ExponentialLatency(0.06)) for i in range(n)]
+        links = [hs.NetworkLink(f"link{i}", latency=hs.ConstantLatency(0.002), jitter=hs.ExponentialLatency(0.005),
+                                egress=servers[(i + 1) % n]) for i in range(n)]
+        routers = [hs.RandomRouter(f"router{i}", targets=[sink, links[i]]) for i in range(n)]
+        for i in range(n):
+            servers[i].downstream = routers[i]
+        sources = [hs.Source.poisson(rate=4.0 + i, target=servers[i], name=f"src{i}") for i in range(n)]
+        return sink, servers, links, routers, sources
+
+    sink1, servers, links, routers, sources = build()
+    want = hs.Simulation(end_time=Instant.from_seconds(8.0), sources=sources, entities=servers + routers + links + [sink1],
+                         seed=77).run()
+    sink, servers, links, routers, sources = build()
+    parts = []
+    for k, idx in enumerate(([0, 1], [2, 3, 4], [5])):
+        parts.append(hs.SimulationPartition(name=f"p{k}", sources=[sources[i] for i in idx],
+                                            entities=[servers[i] for i in idx] + [routers[i] for i in idx] + [links[i] for i in idx]))
+    plinks = [hs.PartitionLink("p0", "p1", min_latency=0.002), hs.PartitionLink("p1", "p2", min_latency=0.002),
+              hs.PartitionLink("p2", "p0", min_latency=0.002)]
+    got = hs.ParallelSimulation(parts, end_time=Instant.from_seconds(8.0), links=plinks, seed=77).run()
+    assert got.total_events_processed == want.total_events_processed and got.duration_s == want.duration_s
+    assert sink.events_received == sink1.events_received > 200
+    assert [t.nanoseconds for t in sink.completion_times] == [t.nanoseconds for t in sink1.completion_times]
+    assert sink.latencies_s == sink1.latencies_s
