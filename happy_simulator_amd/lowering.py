@@ -128,21 +128,31 @@ class LoweredGraph:
                             if any(lk.packet_loss_rate for lk, _, _ in self.links) else None),
             bag_capacity=bag_capacity)
 
-    def log_capacity(self, horizon_s: float) -> int:
-        """Records per station: a station's admissions are bounded by its own source plus everything its upstream
-        links can deliver; a generous bound is the total source rate reachable through links into it.  For the
-        lowered shapes (fan-in of a few links) sum the rates of the station and its direct upstream stations twice."""
+    def log_capacity(self, horizon_s: float, extra: int = 0) -> int:
+        """Records per station.  A station admits what its own Source generates plus what its upstream links deliver, and a
+        sender cannot forward more than it serves: solve  inflow[d] = rate[d] + sum over links s -> d of
+        share * min(inflow[s], concurrency[s] / mean_service[s])  to its fixed point (share = 1 behind a plain link, 1 / number
+        of targets behind a RandomRouter) -- also on deep tandems and cycles, where a fixed number of hops undercounts
+        (round-1 advisor finding: a 10-station tandem overflowed its logs).  `extra`: injected Requests per station."""
         n = len(self.stations)
         rate = np.array([st.source.rate if st.source is not None else 0.0 for st in self.stations], np.float64)
+        mu = np.array([(st.server.concurrency / st.server.service_time.mean) if (st.server is not None and
+                       st.server.service_time.mean > 0) else np.inf for st in self.stations], np.float64)
+        share = np.array([1.0 / max(len(self.stations[s].router.targets), 1) if self.stations[s].router is not None else 1.0
+                          for _, s, _ in self.links], np.float64)
         inflow = rate.copy()
-        for _ in range(4):                                 # a few hops of upstream contribution
+        for _ in range(4 * n + 16):
+            out = np.minimum(inflow, mu)
             nxt = rate.copy()
-            for _, s, d in self.links:
-                nxt[d] += inflow[s]
+            for k, (_, s, d) in enumerate(self.links):
+                nxt[d] += share[k] * out[s]
+            if np.allclose(nxt, inflow, rtol=1e-9, atol=1e-12):
+                inflow = nxt
+                break
             inflow = nxt
         lam = float(inflow.max()) if n else 0.0
         mean = lam * horizon_s
-        return int(mean + 10.0 * (mean + 1.0) ** 0.5 + 64)
+        return int(mean + 10.0 * (mean + 1.0) ** 0.5 + 64) + int(extra)
 
 
 def attach_probes(g: LoweredGraph, probes: list) -> None:

@@ -297,7 +297,8 @@ class ParallelSimulation:
     def __init__(self, partitions: list[SimulationPartition], *, start_time: Instant | None = None,
                  end_time: Instant | None = None, duration: float | None = None, max_workers: int | None = None,
                  links: list[PartitionLink] | None = None, window_size: float | None = None, seed: int = 42,
-                 device: int = 0):
+                 device: int = 0, log_capacity: int | None = None, bag_capacity: int | None = None,
+                 msg_capacity: int | None = None):
         if duration is not None and end_time is not None:
             raise ValueError("Cannot specify both 'duration' and 'end_time'")
         self._links = list(links or [])
@@ -305,6 +306,7 @@ class ParallelSimulation:
         self._partitions = partitions
         self._seed = seed
         self._device = device
+        self._log_capacity, self._bag_capacity, self._msg_capacity = log_capacity, bag_capacity, msg_capacity
         self._start = start_time if start_time is not None else Instant.Epoch
         if duration is not None:
             self._end = self._start + duration
@@ -431,10 +433,11 @@ class ParallelSimulation:
         else:
             comm = LocalComm(world)               # virtual shards on this GPU
         end_ns, start_ns = self._end.nanoseconds, self._start.nanoseconds
-        st, net = g.arrays(), g.network_arrays()
-        cap = g.log_capacity((end_ns - start_ns) / 1e9)
+        st, net = g.arrays(), g.network_arrays(self._bag_capacity or 0)
+        cap = self._log_capacity or g.log_capacity((end_ns - start_ns) / 1e9)
         with ShardedNetwork.on_gpu(st, net, comm, horizon_ns=end_ns, start_ns=start_ns, seed=self._seed,
-                                   device=self._device, log_capacity=cap, bounds=self._bounds) as sn:
+                                   device=self._device, log_capacity=cap, bounds=self._bounds,
+                                   **({"msg_capacity": self._msg_capacity} if self._msg_capacity else {})) as sn:
             summ = sn.run_until(end_ns)
             part_summaries = {}
             cross_local = 0

@@ -29,7 +29,8 @@ def seed(value: int) -> None:
 class Simulation:
     def __init__(self, start_time: Instant | None = None, end_time: Instant | None = None, sources=None,
                  entities=None, probes=None, trace_recorder=None, fault_schedule=None, duration: float | None = None,
-                 *, seed: int | None = None, device: int = 0):
+                 *, seed: int | None = None, device: int = 0, log_capacity: int | None = None,
+                 bag_capacity: int | None = None, msg_capacity: int | None = None):
         if duration is not None and end_time is not None:
             raise ValueError("Cannot specify both 'duration' and 'end_time'")        # core/simulation.py:79-80
         self._start_time = start_time if start_time is not None else Instant.Epoch
@@ -48,6 +49,9 @@ class Simulation:
             raise UnsupportedTopology("fault schedules are not lowered")
         self._seed = _DEFAULT_SEED if seed is None else int(seed)
         self._device = device
+        # engine capacities (records per station log / in-flight messages per station / messages per exchange row); None =
+        # derived from the rates.  An HS_E_OVERFLOW names the one to raise.
+        self._log_capacity, self._bag_capacity, self._msg_capacity = log_capacity, bag_capacity, msg_capacity
         self._summary: SimulationSummary | None = None
         self._graph: LoweredGraph | None = None
         self._events_processed = 0
@@ -145,7 +149,7 @@ class Simulation:
                 raise UnsupportedTopology("schedule() is not lowered for load-balancer topologies yet")
             return self._run_lb(g, wall0)
         end_ns = self._end_time.nanoseconds
-        net = g.network_arrays() if g.is_network else None
+        net = g.network_arrays(self._bag_capacity or 0) if g.is_network else None
         horizon_s = (end_ns - self._start_time.nanoseconds) / 1e9
         arrays = g.arrays()
         # the order in which Simulation.__init__ constructs the first SourceEvents / probe ticks (core/simulation.py:145-160)
@@ -158,7 +162,7 @@ class Simulation:
             return self._run_time_shared(g, arrays, net, end_ns, horizon_s, wall0, cancelled_ns)
         with StationEngine(arrays, mode=N.MODE_SINGLE, horizon_ns=end_ns, start_ns=self._start_time.nanoseconds,
                            seed=self._seed, device=self._device, network=net,
-                           log_capacity=g.log_capacity(horizon_s) if net is not None else 0) as eng:
+                           log_capacity=self._log_cap(g, horizon_s, arrays, net is not None)) as eng:
             eng.run_until(end_ns)
             es = eng.summary()
             stats = eng.lp_stats()
@@ -177,6 +181,14 @@ class Simulation:
         self._summary = self._build_summary(_time.monotonic() - wall0)
         return self._summary
 
+    def _log_cap(self, g, horizon_s: float, arrays, is_net: bool) -> int:
+        if self._log_capacity:
+            return int(self._log_capacity)
+        if not is_net:
+            return 0                           # the engine derives it from the rates (and the scheduled Requests)
+        extra = int(np.diff(arrays.sched_off).max()) if arrays.sched_off is not None and len(arrays.sched_off) > 1 else 0
+        return g.log_capacity(horizon_s, extra)
+
     def _resident_stations(self) -> int:
         """Stations one cooperative launch of the asynchronous network engine holds: one 256-lane workgroup per CU (its
         LDS rings and bags fill the CU)."""
@@ -192,7 +204,8 @@ class Simulation:
 
         world = -(-arrays.n // self._resident_stations())
         with ShardedNetwork.on_gpu(arrays, net, LocalComm(world), horizon_ns=end_ns, start_ns=self._start_time.nanoseconds,
-                                   seed=self._seed, device=self._device, log_capacity=g.log_capacity(horizon_s)) as sn:
+                                   seed=self._seed, device=self._device, log_capacity=self._log_cap(g, horizon_s, arrays, True),
+                                   **({"msg_capacity": self._msg_capacity} if self._msg_capacity else {})) as sn:
             es = sn.run_until(end_ns)
             stats, counts, t_ns, created_ns, net_stats = sn.collect(arrays.n, net.n_links)
             if self._probes:

@@ -446,3 +446,26 @@ def test_scheduled_requests_carry_their_construction_rank():
     assert isinstance(arrays, StationArrays) and cancelled == [500_000_000]
     assert arrays.sched_time_ns.tolist() == [0, 0, 250_000_000, 500_000_000]
     assert arrays.sched_rank.tolist() == [0, 3, 4, 1]
+
+
+def test_log_capacity_follows_deep_tandems_and_cycles():
+    """Round-1 advisor finding: the per-station record capacity looked only 4 hops upstream, so the last station of a 10-station
+    tandem (every station with its own 100/s Source, everything forwarded) overflowed.  The inflow is now solved to its fixed
+    point, capped by what each sender can serve."""
+    n = 10
+    servers = [hs.Server(f"s{i}", service_time=hs.ExponentialLatency(0.0005)) for i in range(n)]
+    for i in range(n - 1):
+        servers[i].downstream = hs.NetworkLink(f"l{i}", latency=hs.ConstantLatency(0.001), egress=servers[i + 1])
+    sources = [hs.Source.poisson(rate=100, target=servers[i], name=f"src{i}") for i in range(n)]
+    g = hs.Simulation(duration=10, sources=sources, entities=servers).lowered()
+    assert g.log_capacity(10.0) > 10 * 100 * n                 # the last station admits ~ n x 100 x 10 s records
+    # a ring where every router forwards half: inflow = 4 / (1 - 1/2) = 8 per station
+    sinks = [hs.Sink(f"k{i}") for i in range(4)]
+    ring = [hs.Server(f"r{i}", service_time=hs.ExponentialLatency(0.05)) for i in range(4)]
+    for i in range(4):
+        ring[i].downstream = hs.RandomRouter(f"rt{i}", targets=[sinks[i], hs.NetworkLink(f"rl{i}", latency=hs.ConstantLatency(0.001),
+                                                                                          egress=ring[(i + 1) % 4])])
+    g2 = hs.Simulation(duration=10, sources=[hs.Source.poisson(rate=4, target=r) for r in ring], entities=ring + sinks).lowered()
+    assert 8 * 10 < g2.log_capacity(10.0) < 8 * 10 + 10 * 9 + 70 + 8
+    sim = hs.Simulation(duration=10, sources=[], entities=[hs.Server("x")], log_capacity=123, bag_capacity=32, msg_capacity=512)
+    assert (sim._log_capacity, sim._bag_capacity, sim._msg_capacity) == (123, 32, 512)
