@@ -269,6 +269,8 @@ def lib():
     L.hs_debug_lb_flags.argtypes = [C.c_void_p, C.c_int]
     L.hs_merge_sink_records.restype = C.c_int
     L.hs_merge_sink_records.argtypes = [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
+    L.hs_sink_latency_stats.restype = C.c_int
+    L.hs_sink_latency_stats.argtypes = [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.hs_debug_radix_sort.restype = C.c_int
     L.hs_debug_radix_sort.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]
@@ -291,5 +293,6 @@ EXPORTED_SYMBOLS = (
     "hs_lb_create", "hs_lb_run", "hs_lb_bench_runs", "hs_lb_get_summary", "hs_lb_get_stats", "hs_lb_read_sink",
     "hs_lb_latency_stats",
     "hs_lb_ring", "hs_lb_select", "hs_lb_last_error", "hs_lb_destroy", "hs_md5", "hs_debug_radix_sort", "hs_merge_sink_records",
+    "hs_sink_latency_stats",
     "hs_debug_lb_flags",
 )

@@ -1606,4 +1606,40 @@ int hs_merge_sink_records(int32_t device, int64_t n, int64_t *t_ns, int64_t *cre
     return HS_OK;
 }
 
+// Sink.latency_stats() (components/common.py:59-76, instrumentation/data.py:197-210) of any Sink's records on the device:
+// latencies = t - created_at, radix-sorted, summed left to right in binary64, interpolated p50 / p99 -- the shared-Sink
+// routine of the load-balancer engine (hs_lb_latency_stats) for the station engines' Sinks.  out = {count, avg, min, max,
+// p50, p99}.  Host buffers in, six doubles out.
+int hs_sink_latency_stats(int32_t device, int64_t n, const int64_t *t_ns, const int64_t *created_ns, double out[6]) {
+    if (n < 0 || !out || (n > 0 && (!t_ns || !created_ns))) return lfail(nullptr, HS_E_INVALID, "hs_sink_latency_stats: bad argument");
+    for (int k = 0; k < 6; ++k) out[k] = 0.0;
+    if (n == 0) return HS_OK;
+    std::vector<uint64_t> lat((size_t)n), zero((size_t)n, 0ull), ko((size_t)n), vo((size_t)n);
+    uint64_t lmax = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (t_ns[i] < created_ns[i]) return lfail(nullptr, HS_E_INVALID, "hs_sink_latency_stats: a record completes before it was created");
+        lat[(size_t)i] = (uint64_t)(t_ns[i] - created_ns[i]);
+        if (lat[(size_t)i] > lmax) lmax = lat[(size_t)i];
+    }
+    int bits = 1;
+    while (bits < 63 && (lmax >> bits) != 0) ++bits;
+    int rc = hs_debug_radix_sort(device, n, bits, lat.data(), zero.data(), ko.data(), vo.data(), nullptr);
+    if (rc != HS_OK) return rc;
+    if (hipSetDevice(device) != hipSuccess) return lfail(nullptr, HS_E_HIP, "hipSetDevice failed");
+    uint64_t *d_sorted = nullptr; int64_t *d_n = nullptr; double *d_out = nullptr;
+    hipError_t e = hipMalloc(&d_sorted, (size_t)n * 8);
+    if (e == hipSuccess) e = hipMalloc(&d_n, 8);
+    if (e == hipSuccess) e = hipMalloc(&d_out, 6 * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(d_sorted, ko.data(), (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_n, &n, 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(hs_lb_latency_stats_kernel, dim3(1), dim3(64), 0, nullptr, d_sorted, d_n, d_out);
+        e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, 6 * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(d_sorted); hipFree(d_n); hipFree(d_out);
+    if (e != hipSuccess) return lfail(nullptr, HS_E_HIP, "hs_sink_latency_stats: %s", hipGetErrorString(e));
+    return HS_OK;
+}
+
 }  // extern "C"

@@ -336,6 +336,9 @@ def _percentile_sorted(sorted_values, p: float) -> float:
     return float(sorted_values[lo] * (1.0 - frac) + sorted_values[hi] * frac)
 
 
+_DEVICE_STATS_MIN = 4096      # Sink.latency_stats(): records from which the device routine is used
+
+
 class _RecordSink(Entity):
     """Shared result holder: the engine hands back (completion ns, created_at ns) arrays; the Python lists the
     reference exposes are materialised lazily (31 M-element lists are the user's choice, not ours)."""
@@ -386,8 +389,21 @@ class Sink(_RecordSink):
         dev = getattr(self, "_device_latency_stats", None)
         if dev is not None:                      # a load balancer's shared Sink: computed by the engine (hs_lb_latency_stats)
             return dict(dev)
+        n = len(self._t_ns)
+        if n >= _DEVICE_STATS_MIN:               # a large record set stays numeric: sort + sum + percentiles on the device
+            from . import _native as N
+
+            if N.lib().hs_device_count() > 0:
+                import ctypes as C
+
+                t = np.ascontiguousarray(self._t_ns, np.int64)
+                cr = np.ascontiguousarray(self._created_ns, np.int64)
+                out = (C.c_double * 6)()
+                rc = N.lib().hs_sink_latency_stats(getattr(self, "_device", 0), n, t.ctypes.data, cr.ctypes.data, out)
+                if rc != N.HS_OK:
+                    raise N.EngineError(rc, (N.lib().hs_lb_last_error(None) or b"").decode())
+                return {"count": int(out[0]), "avg": out[1], "min": out[2], "max": out[3], "p50": out[4], "p99": out[5]}
         lat = self.latencies_s
-        n = len(lat)
         if n == 0:
             return {"count": 0, "avg": 0.0, "min": 0.0, "max": 0.0, "p50": 0.0, "p99": 0.0}
         s = sorted(lat)

@@ -140,15 +140,28 @@ class Simulation:
         return self._summary
 
     def run(self) -> SimulationSummary:
-        if self._end_time == Instant.Infinity:
-            raise UnsupportedTopology("auto-terminating runs (end_time = Infinity) are not lowered; pass end_time/duration")
+        auto = self._end_time == Instant.Infinity
+        if auto:
+            # Auto-termination (core/simulation.py:311-322): the loop ends when no PRIMARY event is pending
+            # (core/event_heap.py:102-104).  A Source's ticks are primary and never stop -- with any Source the reference
+            # itself never returns -- so the lowered case is a Simulation driven by schedule()d Requests only: it ends with
+            # the last completion, nothing beyond it is processed.  (Probe ticks are daemon events: where the run stops
+            # relative to them is decided pop by pop -- not lowered.)
+            if self._sources:
+                raise UnsupportedTopology("end_time = Infinity with Sources never terminates (their ticks are primary events, in "
+                                          "the reference too); pass end_time/duration")
+            if self._probes:
+                raise UnsupportedTopology("auto-terminating runs with probes are not lowered; pass end_time/duration")
         wall0 = _time.monotonic()
         g = self.lowered()
         if isinstance(g, LbGraph):
             if self._scheduled:
                 raise UnsupportedTopology("schedule() is not lowered for load-balancer topologies yet")
             return self._run_lb(g, wall0)
-        end_ns = self._end_time.nanoseconds
+        if auto and g.is_network:
+            raise UnsupportedTopology("auto-terminating runs of station networks are not lowered; pass end_time/duration")
+        # auto-termination: a horizon nothing reaches (the station kernel stops when no event is pending)
+        end_ns = self._end_time.nanoseconds if not auto else (1 << 61)
         net = g.network_arrays(self._bag_capacity or 0) if g.is_network else None
         horizon_s = (end_ns - self._start_time.nanoseconds) / 1e9
         arrays = g.arrays()

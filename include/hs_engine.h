@@ -418,6 +418,11 @@ int hs_debug_radix_sort(int32_t device, int64_t n, int32_t key_bits, const uint6
  * arrays.  Feed it the stations' records concatenated in station order. */
 int hs_merge_sink_records(int32_t device, int64_t n, int64_t *t_ns, int64_t *created_ns);
 
+/* Sink.latency_stats() (components/common.py:59-76; percentiles as instrumentation/data.py:197-210) of a Sink's records on
+ * the device: latency = t - created_at in ns -> seconds, radix sort, left-to-right binary64 sum of the SORTED values (what
+ * `sum(sorted_vals)` does), interpolated percentiles.  out = {count, avg, min, max, p50, p99}.  Host buffers. */
+int hs_sink_latency_stats(int32_t device, int64_t n, const int64_t *t_ns, const int64_t *created_ns, double out[6]);
+
 /* Samples of the LP's Probe in sampling order: (sample time ns, value) -- what the reference appends to the probe's
  * Data container (instrumentation/probe.py:63).  Returns the number copied or a negative hs_status. */
 int64_t hs_engine_read_probe(hs_engine *h, int32_t lp, int64_t *t_ns, int64_t *values, int64_t cap);

@@ -695,3 +695,54 @@ def test_linked_partitions_with_one_sink_fed_from_every_partition():
     assert sink.events_received == sink1.events_received > 200
     assert [t.nanoseconds for t in sink.completion_times] == [t.nanoseconds for t in sink1.completion_times]
     assert sink.latencies_s == sink1.latencies_s
+
+
+def test_auto_terminate_of_a_schedule_driven_simulation():
+    """`Simulation(end_time=None)` = Instant.Infinity = auto-termination (core/simulation.py:311-322, core/event_heap.py:102-104):
+    driven by schedule()d Requests only, the run ends when the heap is empty -- the last completion -- and processes nothing
+    beyond it; with a Source it would never return (refused, as before)."""
+    sinks = [hs.Sink(f"sink{i}") for i in range(3)]
+    servers = [hs.Server(f"srv{i}", concurrency=c, service_time=hs.ExponentialLatency(m), queue_capacity=q, downstream=sinks[i])
+               for i, (c, m, q) in enumerate([(1, 0.2, None), (2, 0.5, 3), (1, 0.05, 0)])]
+    sim = hs.Simulation(sources=[], entities=[e for pair in zip(servers, sinks) for e in pair], seed=5)
+    rng = np.random.default_rng(3)
+    calls = [(int(rng.integers(0, 3)), float(np.round(rng.uniform(0.0, 4.0), 2))) for _ in range(60)] + [(0, 0.0), (0, 0.0), (1, 0.0)]
+    for c, t in calls:
+        sim.schedule(hs.Event(time=Instant.from_seconds(t), event_type="Request", target=servers[c]))
+    summary = sim.run()
+    g = O.Graph()
+    nodes = []
+    for i, (c, m, q) in enumerate([(1, 0.2, -1), (2, 0.5, 3), (1, 0.05, 0)]):
+        sv = g.server(O.LAT_EXP, m, concurrency=c, queue_cap=q, stream_base=i)
+        sk = g.sink()
+        g.target[sv] = sk
+        nodes.append((sv, sk))
+    r = O.run(g, 1 << 61, seed=5, schedule=[(nodes[c][0], H.ns_from_seconds(t)) for c, t in calls])
+    assert summary.total_events_processed == r.events_processed > 300
+    assert int(round(summary.duration_s * 1e9)) == r.final_time_ns
+    assert [s.stats_accepted for s in servers] == [int(r.accepted[n[0]]) for n in nodes]
+    assert [s.stats_dropped for s in servers] == [int(r.dropped[n[0]]) for n in nodes]
+    assert [s.stats.requests_completed for s in servers] == [int(r.completed[n[0]]) for n in nodes]
+    for i, n in enumerate(nodes):
+        assert [t.nanoseconds for t in sinks[i].completion_times] == r.sinks[n[1]][0].tolist()
+    assert all(s.depth == 0 and s.active_requests == 0 for s in servers)              # everything drained
+    src = hs.Source.poisson(rate=1, target=servers[0])
+    with pytest.raises(hs.UnsupportedTopology, match="never terminates"):
+        hs.Simulation(sources=[src], entities=servers).run()
+
+
+def test_sink_latency_stats_on_the_device_equal_the_reference_formula():
+    """Sink.latency_stats() (components/common.py:59-76): above 4 096 records the sort, the left-to-right sum of the sorted
+    values and the interpolated percentiles run on the device (hs_sink_latency_stats) -- bit-identical to the list formula."""
+    from happy_simulator_amd.entities import _percentile_sorted
+
+    sink = hs.Sink("sink")
+    servers = [hs.Server(f"srv{i}", service_time=hs.ExponentialLatency(0.1), downstream=sink) for i in range(40)]
+    sources = [hs.Source.poisson(rate=8, target=s, name=f"src{i}") for i, s in enumerate(servers)]
+    hs.Simulation(duration=30, sources=sources, entities=servers + [sink], seed=12).run()
+    assert sink.events_received > 8000
+    got = sink.latency_stats()
+    lat = sorted(sink.latencies_s)
+    want = {"count": len(lat), "avg": sum(lat) / len(lat), "min": lat[0], "max": lat[-1],
+            "p50": _percentile_sorted(lat, 0.50), "p99": _percentile_sorted(lat, 0.99)}
+    assert got == want
