@@ -81,7 +81,7 @@ __device__ __forceinline__ void load_station(Station<C, PF> &S, const StationPar
             S.sc_i = X.sched_i[lp]; S.sc_end = P.sched_off[lp + 1];
             S.SA = S.sc_i < S.sc_end ? P.sched_t[S.sc_i] : kInfNs;
         }
-        S.prof.kind = P.prof_kind[lp];
+        S.prof.kind = P.prof_kind[lp]; S.prof.owner = lp;
         S.prof.p0 = P.prof_p[lp]; S.prof.p1 = P.prof_p[(size_t)n + lp]; S.prof.p2 = P.prof_p[(size_t)2 * n + lp];
         S.prof.p3 = P.prof_p[(size_t)3 * n + lp];
         S.p_metric = P.probe_metric[lp]; S.p_rate = P.probe_rate[lp];
@@ -193,16 +193,16 @@ __device__ __forceinline__ void overshoot_one(Station<C, PF> &S) {
 // kernels
 // =============================================================================================
 
-__device__ __noinline__ int64_t first_probe_tick(double rate, int64_t start_ns) {
+__device__ __noinline__ int64_t first_probe_tick(double rate, int64_t start_ns, int owner) {
     Profile pp;
-    pp.kind = kProfGeneralConstant; pp.p0 = rate; pp.p1 = pp.p2 = pp.p3 = 0.0;
+    pp.kind = kProfGeneralConstant; pp.p0 = rate; pp.p1 = pp.p2 = pp.p3 = 0.0; pp.owner = owner;
     return prof_next_arrival(pp, start_ns, 1.0);
 }
 __device__ __noinline__ int64_t first_profile_arrival(const StationParams &P, int lp, int n, int64_t start_ns, double area) {
     Profile pf;
     pf.kind = P.prof_kind[lp];
     pf.p0 = P.prof_p[lp]; pf.p1 = P.prof_p[(size_t)n + lp]; pf.p2 = P.prof_p[(size_t)2 * n + lp];
-    pf.p3 = P.prof_p[(size_t)3 * n + lp];
+    pf.p3 = P.prof_p[(size_t)3 * n + lp]; pf.owner = lp;
     return prof_next_arrival(pf, start_ns, area);
 }
 
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
     if (X.PA != nullptr) {   // probes start after the sources (core/simulation.py:156-160): first tick from start_ns
         int64_t PA = kInfNs, p_arr = start_ns;
         if (P.probe_metric[lp] != kProbeNone) {
-            p_arr = first_probe_tick(P.probe_rate[lp], start_ns);
+            p_arr = first_probe_tick(P.probe_rate[lp], start_ns, lp);
             PA = p_arr;
         }
         if (NX.next_time != nullptr && PA < A) NX.next_time[lp] = PA;   // network engine: the LP's first pending event
@@ -1704,6 +1704,10 @@ int run_net_async(hs_engine *h, int64_t end_ns) {
 }
 
 int do_reset_async(hs_engine *h) {
+    if (h->any_profile) {      // the arrival-time inversion's budget flag (hs_profile.hpp): cleared BEFORE the bootstrap draws
+        static const unsigned long long zero = 0ull;
+        HS_HIP(h, hipMemcpyToSymbolAsync(HIP_SYMBOL(hs_prof_budget_hit), &zero, sizeof zero, 0, hipMemcpyHostToDevice, h->stream));
+    }
     hipLaunchKernelGGL(hs_station_reset, dim3(h->n_blocks), dim3(kBlock), 0, h->stream, h->P, h->X, h->tot,
                        h->cfg.n_lp, h->C, h->cfg.start_ns, h->NX, h->is_net ? h->NP.n_links : 0);
     HS_HIP(h, hipGetLastError());
@@ -2566,6 +2570,15 @@ int hs_engine_run_until(hs_engine *h, int64_t end_ns) {
     if (rc) return rc;
     Totals t;
     HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
+    if (h->any_profile) {
+        unsigned long long hit = 0ull;
+        HS_HIP(h, hipMemcpyFromSymbol(&hit, HIP_SYMBOL(hs_prof_budget_hit), sizeof hit, 0, hipMemcpyDeviceToHost));
+        if (hit != 0ull)
+            return fail(h, HS_E_UNSUPPORTED, "LP %lld: one arrival of its time-varying Source needs more than %lld adaptive-Simpson "
+                        "intervals (the reference's own integrator needs minutes for such an arrival: a ramp that starts near zero "
+                        "rate; check with tools/profile_cost.py) -- refused instead of stalling a lane",
+                        (long long)hit - 2, (long long)kProfBudget);
+    }
     if (t.qoverflow) return fail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
     if (t.overflow & 16)
         return fail(h, HS_E_OVERFLOW, "the prologue (csrc/hs_exact.hpp) ran out of heap / payload-pool space");

@@ -251,7 +251,7 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
             int64_t a2;
             if (P.prof_kind[lp] != kProfConstant)
                 a2 = profile_next_tick(P.prof_kind[lp], P.prof_p[lp], P.prof_p[N + lp], P.prof_p[2 * N + lp], P.prof_p[3 * N + lp],
-                                       X.arr_time[lp], area);
+                                       X.arr_time[lp], area, lp);
             else
                 a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(X.arr_time[lp]), __ddiv_rn(area, P.src_rate[lp])));
             X.arr_time[lp] = a2;
@@ -384,7 +384,7 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
             // Source.handle_event with _ProbeEventProvider (instrumentation/probe.py:69-78): the daemon probe_event, then the next tick
             X.ev_probe[lp] += 1;
             const unsigned long long idx_pe = S.G++;
-            const int64_t a2 = probe_next_tick(P.probe_rate[lp], X.p_arr[lp]);
+            const int64_t a2 = probe_next_tick(P.probe_rate[lp], X.p_arr[lp], lp);
             X.p_arr[lp] = a2;
             xpush(S, xev(t, idx_pe, XE_PSAMPLE, lp));
             if (a2 != kInfNs) {

@@ -128,16 +128,16 @@ constexpr int kEnqPay = 8;   // ENQ payload FIFO depth (general path only)
 // _ProbeProfile(interval).  Deliberately NOT inlined: its explicit recursion stack (4 KB of scratch per lane) inside the
 // register-starved network kernels made hs_net_window<2> misbehave; as a callee it has its own frame and is only entered
 // by the rare lane that owns a probe.
-__device__ __noinline__ inline int64_t probe_next_tick(double rate, int64_t from_ns) {
+__device__ __noinline__ inline int64_t probe_next_tick(double rate, int64_t from_ns, int owner = -1) {
     Profile pp;
-    pp.kind = kProfGeneralConstant; pp.p0 = rate; pp.p1 = pp.p2 = pp.p3 = 0.0;
+    pp.kind = kProfGeneralConstant; pp.p0 = rate; pp.p1 = pp.p2 = pp.p3 = 0.0; pp.owner = owner;
     return prof_next_arrival(pp, from_ns, 1.0);
 }
 // Next arrival of a Source with a time-varying rate profile (load/arrival_time_provider.py:84-144), same reasons.
 __device__ __noinline__ inline int64_t profile_next_tick(uint32_t kind, double p0, double p1, double p2, double p3,
-                                                         int64_t from_ns, double area) {
+                                                         int64_t from_ns, double area, int owner = -1) {
     Profile pf;
-    pf.kind = kind; pf.p0 = p0; pf.p1 = p1; pf.p2 = p2; pf.p3 = p3;
+    pf.kind = kind; pf.p0 = p0; pf.p1 = p1; pf.p2 = p2; pf.p3 = p3; pf.owner = owner;
     return prof_next_arrival(pf, from_ns, area);
 }
 
@@ -397,7 +397,7 @@ struct NetStation {
         if constexpr (PF) {
             if (prof_kind != kProfConstant) {      // general path: invert the profile for the target area E (Poisson) or 1.0
                 const double area = src_kind == 1 ? arr_inc() : 1.0;   // (for such a Source the ring / stream value IS E)
-                arr_time = profile_next_tick(prof_kind, prof_p0, prof_p1, prof_p2, prof_p3, arr_time, area);
+                arr_time = profile_next_tick(prof_kind, prof_p0, prof_p1, prof_p2, prof_p3, arr_time, area, lp);
                 return arr_time;
             }
         }
@@ -418,7 +418,7 @@ struct NetStation {
     __device__ __forceinline__ void root_probe(int64_t t) {
         evp[0]++;
         qpush(Q_PSAMPLE);                                                 // the daemon probe_event, created first
-        const int64_t a2 = probe_next_tick(p_rate, p_arr);                // ConstantArrivalTimeProvider over _ProbeProfile
+        const int64_t a2 = probe_next_tick(p_rate, p_arr, lp);            // ConstantArrivalTimeProvider over _ProbeProfile
         p_arr = a2;
         if (a2 <= t) PA = kInfNs;
         else { PA = a2; seqP = seq++; crtP = t; }

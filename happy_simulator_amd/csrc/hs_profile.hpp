@@ -19,7 +19,17 @@ enum : uint32_t { kProfConstant = 0, kProfLinearRamp = 1, kProfSpike = 2,
 struct Profile {
     uint32_t kind;
     double p0, p1, p2, p3;   // ramp: duration_s, start_rate, end_rate;  spike: baseline, spike_rate, warmup_s, spike_duration_s
+    int32_t owner = -1;      // the LP the inversion runs for (named when the evaluation budget is exceeded)
 };
+
+// Evaluation budget of ONE next_arrival_time call.  The reference's adaptive Simpson rule works on a rate that is quantised to
+// whole nanoseconds; on a ramp whose bracket is wide (a first arrival drawn from a near-zero rate) its error test is only met
+// once the intervals are narrower than 1 ns -- 8e7 rate evaluations for a single arrival, minutes in the reference's Python
+//  and an unbounded stall for the one lane that inherits it here.  Typical arrivals need 10-100
+// intervals.  Beyond the budget the LP is reported (HS_E_UNSUPPORTED naming it) instead of spinning: hs_prof_budget_hit =
+// 1 + LP of the first offender.
+constexpr long long kProfBudget = 1ll << 20;       // Simpson intervals per arrival (3 rate evaluations each)
+__device__ unsigned long long hs_prof_budget_hit = 0ull;
 
 // rate_fn(t) = profile.get_rate(Instant.from_seconds(t))
 __device__ __forceinline__ double prof_rate(const Profile &pf, double t_seconds) {
@@ -43,7 +53,7 @@ __device__ __forceinline__ double prof_simpson3(double fa, double fm, double fb,
 constexpr int kSimpsonMaxDepth = 50;
 
 // integrate_adaptive_simpson(rate_fn, a, b, tol) for a <= b
-__device__ inline double prof_integrate(const Profile &pf, double a0, double b0, double tol0) {
+__device__ inline double prof_integrate(const Profile &pf, double a0, double b0, double tol0, long long &budget) {
     if (a0 == b0) return 0.0;
     double A[kSimpsonMaxDepth + 1], B[kSimpsonMaxDepth + 1], FA[kSimpsonMaxDepth + 1], FB[kSimpsonMaxDepth + 1];
     double SW[kSimpsonMaxDepth + 1], TOL[kSimpsonMaxDepth + 1], M[kSimpsonMaxDepth + 1], FM[kSimpsonMaxDepth + 1];
@@ -61,6 +71,7 @@ __device__ inline double prof_integrate(const Profile &pf, double a0, double b0,
     double ret = 0.0;
     for (;;) {
         if (!have) {
+            if (--budget < 0) return 0.0;                    // over budget: the caller gives up on this arrival
             const double a = A[d], b = B[d], fa = FA[d], fb = FB[d];
             const double m = (a + b) / 2.0;
             const double h = (b - a) / 2.0;
@@ -98,9 +109,10 @@ __device__ inline double prof_integrate(const Profile &pf, double a0, double b0,
 
 struct ProfObjective {
     const Profile *pf; double t_start, target;
+    long long *budget;
     __device__ __forceinline__ double operator()(double t) const {
         // (Brent and the bracket search stay at or above t_start; the a > b branch of the integrator is not reachable)
-        return prof_integrate(*pf, t_start, t, 1e-10) - target;
+        return prof_integrate(*pf, t_start, t, 1e-10, *budget) - target;
     }
 };
 
@@ -147,7 +159,8 @@ __device__ inline bool prof_brentq(const ProfObjective &f, double a, double b, d
 // next_arrival_time from t_start_ns; kInfNs when the reference would raise (rate zero for ever, no convergence)
 __device__ inline int64_t prof_next_arrival(const Profile &pf, int64_t t_start_ns, double target_area) {
     const double t_start_sec = seconds_from_ns_ieee(t_start_ns);
-    ProfObjective f{&pf, t_start_sec, target_area};
+    long long budget = kProfBudget;
+    ProfObjective f{&pf, t_start_sec, target_area, &budget};
     const double current_rate = prof_rate(pf, t_start_sec);
     double t_high;
     if (current_rate > 0) {
@@ -159,12 +172,16 @@ __device__ inline int64_t prof_next_arrival(const Profile &pf, int64_t t_start_n
     bool found = false;
     for (int i = 0; i < 50; ++i) {                                           // bracket search, geometric expansion
         if (f(t_high) > 0) { found = true; break; }
+        if (budget < 0) break;
         const double step = py_max(1e-6, t_high - t_low);
         t_high += step * 2.0;
     }
+    if (budget < 0) { atomicMax(&hs_prof_budget_hit, (unsigned long long)(pf.owner + 1) + 1ull); return kInfNs; }
     if (!found) return kInfNs;
     double root;
-    if (!prof_brentq(f, t_low, t_high, root)) return kInfNs;
+    const bool ok = prof_brentq(f, t_low, t_high, root);
+    if (budget < 0) { atomicMax(&hs_prof_budget_hit, (unsigned long long)(pf.owner + 1) + 1ull); return kInfNs; }
+    if (!ok) return kInfNs;
     return ns_from_seconds(root);                                            // Instant.from_seconds(result.root)
 }
 

@@ -427,7 +427,7 @@ struct Station {
     __device__ __forceinline__ void root_probe(int64_t t) {
         evp[0]++;
         Profile pp;
-        pp.kind = kProfGeneralConstant; pp.p0 = p_rate; pp.p1 = pp.p2 = pp.p3 = 0.0;
+        pp.kind = kProfGeneralConstant; pp.p0 = p_rate; pp.p1 = pp.p2 = pp.p3 = 0.0; pp.owner = lp;
         qpush(Q_PSAMPLE);                                                 // the daemon probe_event, created first
         const int64_t a2 = prof_next_arrival(pp, p_arr, 1.0);             // ConstantArrivalTimeProvider over _ProbeProfile
         p_arr = a2;

@@ -307,3 +307,29 @@ def test_nonzero_start_time_matches_oracle():
     with LoadBalancerEngine(src, be, virtual_nodes=100, horizon_ns=end, start_ns=start, seed=11) as eng:
         eng.run(end)
         H.compare_lb_engine_with_oracle(eng, p, rl)
+
+
+def test_profile_inversion_budget_reports_the_lp_instead_of_stalling():
+    """N3: one arrival of LinearRampProfile(3 s, 1 -> 9) on stream base 97, seed 77 needs 8e7 rate evaluations in the
+    reference's own adaptive-Simpson inversion (70 s of the reference's Python).  The device gives up
+    after 2^20 Simpson intervals and the run is refused with the LP's index -- it used to stall a lane for minutes."""
+    from happy_simulator_amd import _native as N
+    from happy_simulator_amd.engine import StationArrays, StationEngine
+
+    n = 130
+    st = StationArrays.uniform(n, rate=8.0, mean=0.1)
+    st.src_profile_kind = np.zeros(n, np.uint8)
+    st.src_profile_params = np.zeros((n, 4), np.float64)
+    st.src_profile_kind[97] = N.PROF_LINEAR_RAMP
+    st.src_profile_params[97, :3] = (3.0, 1.0, 9.0)
+    st.src_rate[97] = 9.0
+    import time
+    t0 = time.perf_counter()
+    with pytest.raises(N.EngineError, match="LP 97.*adaptive-Simpson"):
+        with StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=5_000_000_000, seed=77) as eng:
+            eng.run_until(5_000_000_000)
+    assert time.perf_counter() - t0 < 30.0
+    st.src_profile_params[97, :3] = (5.0, 3.0, 20.0)             # an ordinary ramp on the same stream: runs
+    with StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=5_000_000_000, seed=77) as eng:
+        eng.run_until(5_000_000_000)
+        assert eng.lp_stats()["generated"][97] > 20
