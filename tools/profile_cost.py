@@ -40,6 +40,7 @@ static inline long long __double2ll_rz(double a) { return (long long)a; }
 static inline double __ll2double_rn(long long a) { return (double)a; }
 static inline long long __double_as_longlong(double a) { long long r; memcpy(&r, &a, 8); return r; }
 static inline double __longlong_as_double(long long a) { double r; memcpy(&r, &a, 8); return r; }
+static inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
 """
 
 MAIN = r"""
@@ -64,7 +65,9 @@ int main(int argc, char **argv) {
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         printf("arrival %d: from %.9f s, target area %.6g, rate there %.6g/s, first bracket %.4g s -> %.9f s   host %.4f s%s\n",
                k, t / 1e9, area, rate, rate > 0 ? 2.0 * area / rate : 0.1, t2 == kInfNs ? INFINITY : t2 / 1e9, dt,
-               dt > limit ? "   <-- SLOW: expect a long stall of this LP on the device" : "");
+               hs_prof_budget_hit ? "   <-- OVER THE DEVICE'S EVALUATION BUDGET: the engine refuses this LP (HS_E_UNSUPPORTED)" :
+               dt > limit ? "   <-- slow" : "");
+        if (hs_prof_budget_hit) break;
         if (t2 == kInfNs || t2 <= t) break;
         t = t2;
     }
