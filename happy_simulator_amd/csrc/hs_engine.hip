@@ -39,6 +39,13 @@ __device__ __forceinline__ long long shfl_xor_ll(long long v, int o) {
     return ((long long)hi << 32) | (unsigned)lo;
 }
 
+__device__ __forceinline__ long long shfl_up_ll(long long v, int o) {
+    int lo = (int)(unsigned)(v & 0xffffffffll), hi = (int)(v >> 32);
+    lo = __shfl_up(lo, o, 64);
+    hi = __shfl_up(hi, o, 64);
+    return ((long long)hi << 32) | (unsigned)lo;
+}
+
 __device__ __forceinline__ bool cand_less(const Candidate &a, const Candidate &b) {
     if (a.valid != b.valid) return a.valid > b.valid;
     if (!a.valid) return false;
@@ -214,7 +221,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
     if (NX.next_time != nullptr) {   // network engine: clear routing / link / bag state
         for (int l = lp; l < n_links; l += gridDim.x * kBlock) {
             NX.link_k[l] = 0; NX.link_in[l] = 0; NX.link_sent[l] = 0; NX.link_packets[l] = 0;
-            if (NX.aq_tail != nullptr) { NX.aq_tail[l] = 0; NX.aq_head[l] = 0; NX.aq_ea[l] = start_ns; }
+            if (NX.aq_tail != nullptr) { NX.aq_tail[l] = 0; NX.aq_head[l] = 0; NX.aq_ea[l] = 0; }   // (bound = start, tail = 0)
         }
         if (lp < n) {
             NX.route_k[lp] = 0; NX.routed[lp] = 0; NX.bag_cnt[lp] = 0; NX.in_cnt[lp] = 0; NX.in_cnt[n + lp] = 0;
@@ -641,7 +648,7 @@ __global__ void __launch_bounds__(64) hs_exact_run(StationParams P, NetParams NP
             if (over) atomicOr(&tot->overflow, 2);
             if (NX.aq_tail != nullptr)                    // asynchronous engine: the link queues continue behind them
                 for (int l = 0; l < n_links; ++l) {
-                    NX.aq_tail[l] = (unsigned long long)NX.link_sent[l];
+                    NX.aq_ea[l] = pk_pack(start_ns, (unsigned long long)NX.link_sent[l], NX.pk_base);
                     NX.aq_head[l] = (unsigned long long)NX.link_sent[l];
                 }
         }
@@ -737,14 +744,17 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF> &S, const Stati
     }
     S.ha = S.na = S.hs_ = S.nsv = S.hj = S.nj = S.rn = 0; S.rbits = 0; S.fl_link = -1; S.fi_link = -1; S.fi_packets = 0;
     S.fl_remote = false; S.fi_head = 0; S.pf_s0 = S.pf_s1 = -1; S.pf_v0 = S.pf_v1 = 0;
+    S.bh = 0; S.tail_hint = 0ull;
     S.presend = false; S.early_upto = S.completed; S.D_pre = S.last_time; S.fl_q = 0; S.end_ns = kInfNs;
     S.bag_n = NX.bag_cnt[lp];
     if constexpr (FAST) {
         // (S.fl was set by the caller.)  The bag moves into LDS for the lifetime of the kernel ...
-        if (S.bag_n > kLBag) { S.bagoverflow = 1; S.bag_n = kLBag; }   // (a fresh run starts with empty bags)
-        for (int i = 0; i < S.bag_n; ++i) {
+        int nb = S.bag_n;
+        if (nb > kLBag) { S.bagoverflow = 1; nb = kLBag; }             // (a fresh run starts with empty bags)
+        S.bag_n = 0; S.bh = 0; S.bmin = kInfNs;
+        for (int i = 0; i < nb; ++i) {                                 // ... sorted by arrival time (NetStation::bag_insert)
             const size_t b = (size_t)lp * NX.bag_cap + i;
-            S.bg_set(i, NX.bag_t[b], NX.bag_ts[b], NX.bag_cr[b], NX.bag_link[b]);
+            S.bag_insert(NX.bag_t[b], NX.bag_ts[b], NX.bag_cr[b], NX.bag_link[b]);
         }
         // ... and the LP's outgoing link into registers when there is exactly one
         int32_t l = -1;
@@ -757,7 +767,7 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF> &S, const Stati
             S.fl_lam = __ddiv_rn(1.0, NP.link_jit_mean[l]);
             S.fl_loss = NP.link_loss[l];
             S.fl_in = NX.link_in[l]; S.fl_sent = NX.link_sent[l];
-            S.fl_q = (NX.aq_tail != nullptr && !S.fl_remote) ? (int64_t)NX.aq_tail[l] : S.fl_sent;
+            S.fl_q = (NX.aq_tail != nullptr && !S.fl_remote) ? (int64_t)pk_tail(NX.aq_ea[l], NX.aq_head[l]) : S.fl_sent;
             S.jit.init(S.seed, stream_id(NP.link_base[l], kStreamLink), NX.link_k[l]);
         }
         if (C == 1 && l >= 0 && S.conc == 1 && S.fl_loss == 0.0 && NX.early_upto != nullptr) {
@@ -871,8 +881,8 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
         int bn = NX.bag_cnt[lp];
         for (int q = NP.in_off[lp]; q < NP.in_off[lp + 1]; ++q) {
             const int l = NP.in_links[q];
-            const unsigned long long tail = ag_load(&NX.aq_tail[l]);
             unsigned long long head = NX.aq_head[l];
+            const unsigned long long tail = pk_tail(ag_load(&NX.aq_ea[l]), head);
             for (; head < tail; ++head) {
                 if (bn >= NX.bag_cap) { merge_overflow = 1; break; }
                 const size_t slot = (size_t)l * NX.aq_cap + (size_t)(head & (unsigned long long)(NX.aq_cap - 1));
@@ -1147,20 +1157,27 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         const bool chain = (flags & 64) == 0 && lane > 0 && my_in >= 0 && prev_next == my_in;
         const int64_t next_lat = next_l >= 0 ? NP.link_lat_ns[next_l] : 0;
         auto sat = [](int64_t a, int64_t b) { return (a == kInfNs || b == kInfNs) ? kInfNs : a + b; };
+        int c_kind = -1;                                      // the sender map kept across the iteration boundary (bound_map)
+        int64_t c_A = kInfNs, c_B = kInfNs, c_D = INT64_MIN, c_sdl = 0;
 #ifdef HS_CYCLES   // tools/cycles.py --ring: cycles in receive / bound scan / group processing / publication
         unsigned long long cyc[4] = {0, 0, 0, 0};
 #endif
         for (unsigned iter = 0;; ++iter) {
             n_iter = iter + 1;
-#ifdef HS_JITTER   // scratch build: pseudo-random per-wavefront delays (results must not depend on timing)
-            if ((((iter + 1u) * 2654435761u + (blockIdx.x * 4u + (tid >> 6)) * 40503u) >> 7 & (HS_JITTER)) == 0) __builtin_amdgcn_s_sleep(127);
-#endif
+            // debug flag 1024: pseudo-random per-wavefront delays -- results must not depend on timing (tests/test_gpu_ring.py)
+            if ((flags & 1024) && ((((iter + 1u) * 2654435761u + (blockIdx.x * 4u + (tid >> 6)) * 40503u) >> 7) & 3u) == 0)
+                __builtin_amdgcn_s_sleep(127);
             S.pf_commit();                                            // created_at prefetches of the previous iteration -> LDS
             S.top_up(!done, group_cap < 4 ? group_cap : 4);           // whole wavefront: refill the pre-drawn values
             int64_t H = kInfNs;
 #ifdef HS_CYCLES
             const unsigned long long q0 = __builtin_readcyclecounter();
 #endif
+            {   // (a chain lane's only incoming link is the previous lane's next_l: async_receive_one)
+                const long long q_next = next_l >= 0 ? (long long)S.link_sent_of(next_l) : 0ll;
+                const long long q_prev = shfl_up_ll(q_next, 1);
+                S.tail_hint = chain ? (unsigned long long)q_prev : 0ull;
+            }
             if (!done) H = S.async_receive();                         // messages below H are all in the bag now
 #ifdef HS_CYCLES
             const unsigned long long q1 = __builtin_readcyclecounter();
@@ -1172,7 +1189,14 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             // that backlog has (pre-sending stations, hs_netstation.hpp `early_upto`).  The family is closed under composition:
             //     (A2,B2,D2) o (A1,B1,D1) = (min(A2, max(A1 + B2, D2)), B1 + B2, max(D1 + B2, D2)).
             int64_t mA = kInfNs, mB = kInfNs, mD = INT64_MIN;
-            if (!done && next_l >= 0) S.bound_map(next_l, next_lat, mA, mB, mD);
+            if (!done && next_l >= 0) {
+                if (c_kind >= 0) {         // the map evaluated at the end of the previous iteration; only the receive has happened since
+                    mB = c_B; mD = c_D;
+                    if (c_kind == 0) mA = c_A;
+                    else if (c_kind == 1) { const int64_t a = S.next_admission(); mA = sat(a > S.D_pre ? a : S.D_pre, c_sdl); }
+                    else mA = sat(S.next_time(), c_sdl);
+                } else S.bound_map(next_l, next_lat, mA, mB, mD);
+            }
             auto satd = [](int64_t d, int64_t b) { return d == INT64_MIN ? INT64_MIN : (b == kInfNs ? kInfNs : d + b); };
             if (!chain) {                                             // head of a chain: its input bound is known
                 if (!done && S.undrained < H) H = S.undrained;
@@ -1234,28 +1258,29 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
 #endif
                 const int64_t t2 = S.next_time();
                 const int64_t base = t2 < H ? t2 : H;                 // nothing happens here before `base`
-                if (S.sent_async) {
-                    // payloads complete -> tails -> complete: only then may a bound that no longer covers those messages
-                    // be seen, through memory (aq_ea below) or through the in-wavefront scan of the next iteration
-                    drain_stores();
-#pragma unroll
-                    for (int o = 0; o < 2; ++o)
-                        if (out_l[o] >= 0) ag_store(&NX.aq_tail[out_l[o]], (unsigned long long)S.link_sent_of(out_l[o]));
-                    drain_stores();
-                    S.sent_async = false;
-                }
+                // payloads complete (one drain), THEN the link's word (bound, tail): a consumer that sees the word sees every
+                // message below its tail, and no bound it can read -- from memory or through the in-wavefront scan of the next
+                // iteration (after this drain) -- covers less than the messages that are visible behind it
+                if (S.sent_async) drain_stores();
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {
                     const int32_t l = out_l[o];
                     if (l < 0) continue;
                     // the bound of everything this LP has NOT appended to link l yet: its map evaluated at `base`
-                    int64_t bA, bB, bD;
-                    S.bound_map(l, NP.link_lat_ns[l], bA, bB, bD);
+                    int64_t bA, bB, bD, sdl = 0;
+                    int kind = -1;
+                    S.bound_map(l, NP.link_lat_ns[l], bA, bB, bD, &kind, &sdl);
+                    if (l == next_l) { c_kind = kind; c_A = bA; c_B = bB; c_D = bD; c_sdl = sdl; }
                     int64_t v = sat(base, bB);
                     v = v > bD ? v : bD;
                     v = v < bA ? v : bA;
-                    if (v > out_pub[o]) { ag_store(&NX.aq_ea[l], v); out_pub[o] = v; }
+                    v = v > out_pub[o] ? v : out_pub[o];
+                    if (S.sent_async || v > out_pub[o]) {
+                        ag_store(&NX.aq_ea[l], pk_pack(v, (unsigned long long)S.link_sent_of(l), NX.pk_base));
+                        out_pub[o] = v;
+                    }
                 }
+                S.sent_async = false;
                 done = base > end_ns;                                 // nothing at or before end_ns can happen any more
             }
 #ifdef HS_CYCLES
@@ -1368,10 +1393,10 @@ __global__ void hs_shard_inject(NetState NX, const int64_t *inbox, int64_t *outb
 // between launches instead of by a concurrently running producer.  Exchange rounds therefore follow the boundary LPs'
 // lookahead (tens of ms of simulated time), not the 1 ms link floor of the windowed protocol.
 // What this rank publishes after a round: the bounds of the cross links that START here, and whether it still has work.
-__global__ void hs_shard_bounds_out(const int64_t *aq_ea, const int32_t *cross_local, const uint8_t *cross_role, int n_cross,
+__global__ void hs_shard_bounds_out(const int64_t *aq_ea, int64_t pk_base, const int32_t *cross_local, const uint8_t *cross_role, int n_cross,
                                     int64_t *bounds, const Totals *tot) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_cross) bounds[i] = (cross_role[i] & 1) ? aq_ea[cross_local[i]] : INT64_MIN;
+    if (i < n_cross) bounds[i] = (cross_role[i] & 1) ? pk_ea(aq_ea[cross_local[i]], pk_base) : INT64_MIN;
     if (i == n_cross) bounds[n_cross] = tot->not_done ? 1 : 0;
 }
 // After the exchange: the received messages go to the queues of their links (row r holds what rank r sent here, in send
@@ -1391,16 +1416,20 @@ __global__ void hs_shard_inject_async(NetState NX, const int64_t *inbox, int64_t
             const int64_t dst = (m[3] >> 32) - lp_base, gid = m[3] & 0xffffffffll;
             if (dst < 0 || dst >= n || gid >= n_gid || gid2local[gid] < 0) { atomicOr(&tot->overflow, 4); continue; }
             const int l = gid2local[gid];
-            const unsigned long long tail = NX.aq_tail[l], head = NX.aq_head[l];
+            const unsigned long long head = NX.aq_head[l], tail = pk_tail(NX.aq_ea[l], head);
             if (tail - head >= (unsigned long long)NX.aq_cap) { atomicOr(&tot->overflow, 2); continue; }
             const size_t slot = (size_t)l * NX.aq_cap + (size_t)(tail & (unsigned long long)(NX.aq_cap - 1));
             NX.aq_t[slot] = m[0]; NX.aq_ts[slot] = m[1]; NX.aq_cr[slot] = m[2];
-            NX.aq_tail[l] = tail + 1;
+            NX.aq_ea[l] = pk_pack(pk_ea(NX.aq_ea[l], NX.pk_base), tail + 1, NX.pk_base);
         }
         outbox[(size_t)r * row] = 0;
     }
+    __syncthreads();          // the tails first (one thread per row), then the bounds (one thread per link): the same words
     for (int i = tid; i < n_cross; i += blockDim.x)
-        if (cross_role[i] & 2) NX.aq_ea[cross_local[i]] = bounds[i];
+        if (cross_role[i] & 2) {
+            const int l = cross_local[i];
+            NX.aq_ea[l] = pk_pack(bounds[i], pk_tail(NX.aq_ea[l], NX.aq_head[l]), NX.pk_base);
+        }
     if (tid == 0) tot->not_done = 0;
 }
 
@@ -1630,7 +1659,7 @@ void launch_net_dispatch(hs_engine *h, int64_t wend, int win, int flags) {
 
 template <int C>
 hipError_t launch_async(hs_engine *h, int64_t end_ns, NetState NX) {
-    int n = h->cfg.n_lp, flags = h->flags & (1 | 64 | 128 | 0xff00), lanes = h->async_lanes;
+    int n = h->cfg.n_lp, flags = h->flags & (1 | 64 | 128 | 1024 | 0xff00), lanes = h->async_lanes;
     const int per_block = (kBlock / 64) * lanes;
     int max_iters = h->round_iters;
     void *args[] = {&h->P, &h->NP, &h->X, &NX, &h->L, &h->tot, &n, &end_ns, &flags, &h->SC, &lanes, &max_iters};
@@ -2245,6 +2274,7 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     if (global && aqc < 256) aqc = 256; // a shard's incoming cross links are filled a whole exchange round at a time
     h->NX.aq_cap = aqc;
     h->NX.aq_on = 0;
+    h->NX.pk_base = h->cfg.start_ns;
     if (nl > 0) {
         const size_t NQ = NL * (size_t)aqc;
         ALN(aq_t, NQ); ALN(aq_ts, NQ); ALN(aq_cr, NQ); ALN(aq_tail, NL); ALN(aq_head, NL); ALN(aq_ea, NL);
@@ -2253,7 +2283,9 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
         // or scheduled Requests the PF instantiation of the kernel
         // (time-varying profiles and scheduled Requests stay on the windowed engine; the asynchronous PF instantiation is
         // validated at scale for probes only)
-        h->async_ok = !global && !h->any_timevarying && !h->any_sched;
+        // (the links' packed (bound, tail) words hold 44 bits of nanoseconds: 4.9 hours of simulated time)
+        const bool fits = h->cfg.horizon_ns - h->cfg.start_ns < (int64_t)kPkNever - 2 && aqc < (1 << (kPkTailBits - 2));
+        h->async_ok = !global && !h->any_timevarying && !h->any_sched && fits;
         h->net_pf = h->any_probe || h->any_timevarying || h->any_sched;
     }
 #undef ALN
@@ -2388,6 +2420,8 @@ int hs_engine_shard_async_setup(hs_engine *h, int32_t n_cross, const int64_t *cr
         return fail(h, HS_E_UNSUPPORTED, "time-varying profiles and scheduled Requests run on the window protocol (rounds = False)");
     HS_HIP(h, hipSetDevice(h->cfg.device));
     if (!ensure_async_fit(h)) return fail(h, HS_E_UNSUPPORTED, "the shard's stations are not co-resident on this device (asynchronous rounds need a cooperative launch)");
+    if (h->cfg.horizon_ns - h->cfg.start_ns >= (int64_t)kPkNever - 2)
+        return fail(h, HS_E_UNSUPPORTED, "asynchronous rounds hold 44 bits of nanoseconds per link bound (4.9 h of simulated time); use rounds = False");
     const int64_t lo = (int64_t)h->cfg.lp_base, hi = lo + h->cfg.n_lp;
     std::vector<int32_t> loc((size_t)(n_cross > 0 ? n_cross : 1), -1);
     std::vector<uint8_t> role((size_t)(n_cross > 0 ? n_cross : 1), 0);
@@ -2435,7 +2469,7 @@ int hs_engine_shard_round(hs_engine *h) {
     h->round_iters = 0;
     if (e != hipSuccess) return fail(h, HS_E_HIP, "cooperative launch failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(hs_shard_bounds_out, dim3((unsigned)((h->n_cross + 1 + 255) / 256)), dim3(256), 0, h->stream, h->NX.aq_ea,
-                       h->cross_local, h->cross_role, h->n_cross, h->cross_bounds, h->tot);
+                       h->NX.pk_base, h->cross_local, h->cross_role, h->n_cross, h->cross_bounds, h->tot);
     HS_HIP(h, hipGetLastError());
     h->launches += 2;
     return HS_OK;

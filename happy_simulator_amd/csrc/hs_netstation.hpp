@@ -89,7 +89,10 @@ struct NetState {
     int64_t *aq_t, *aq_ts, *aq_cr;   // [n_links][aq_cap] arrival ns, send ns, created_at ns
     unsigned long long *aq_tail;     // [n_links] messages appended so far (producer)
     unsigned long long *aq_head;     // [n_links] messages taken so far (consumer; the producer reads it for flow control)
-    int64_t *aq_ea;                  // [n_links] every message NOT yet appended arrives at or after this time
+    int64_t *aq_ea;                  // [n_links] ONE word per link = (bound << 20 | messages appended so far mod 2^20):
+                                     //   bound: every message NOT yet appended arrives at or after pk_base + bound ns
+                                     //   (2^44 - 1 = never); a consumer gets a consistent (bound, tail) pair from a single load
+    int64_t pk_base;                 // = start_ns
     // pre-sent departures (hs_net_async, one-worker stations): see NetStation::early_upto
     int64_t *early_upto;             // [n_lp]
     int64_t *d_pre;                  // [n_lp]
@@ -121,6 +124,23 @@ __device__ __forceinline__ unsigned long long ag_load(const unsigned long long *
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// the packed (bound, tail) word of a link queue (NetState::aq_ea)
+constexpr int kPkTailBits = 20;
+constexpr unsigned long long kPkTailMask = (1ull << kPkTailBits) - 1ull;
+constexpr int64_t kPkNever = (1ll << 44) - 1;                   // bound field: nothing will ever be appended again
+__device__ __forceinline__ int64_t pk_pack(int64_t ea, unsigned long long tail, int64_t base) {
+    int64_t rel = ea == kInfNs ? kPkNever : ea - base;
+    rel = rel < 0 ? 0 : (rel > kPkNever - 1 && ea != kInfNs ? kPkNever - 1 : rel);   // clamping DOWN is conservative
+    return (int64_t)(((unsigned long long)rel << kPkTailBits) | (tail & kPkTailMask));
+}
+__device__ __forceinline__ int64_t pk_ea(int64_t w, int64_t base) {
+    const int64_t rel = (int64_t)((unsigned long long)w >> kPkTailBits);
+    return rel == kPkNever ? kInfNs : base + rel;
+}
+__device__ __forceinline__ unsigned long long pk_tail(int64_t w, unsigned long long head) {   // head <= tail < head + 2^20
+    return head + (((unsigned long long)w - head) & kPkTailMask);
+}
 
 constexpr int kEnqPay = 8;   // ENQ payload FIFO depth (general path only)
 
@@ -219,6 +239,8 @@ struct NetStation {
     int send_idx;
     int32_t bag_n;
     int64_t bmin;                 // min over the bag's arrival times (kInfNs: empty)
+    int bh;                       // FAST: the LDS bag is a circular buffer SORTED by arrival time; logical entry i sits in slot
+                                  // (bh + i) & (kLBag - 1), entry 0 is the earliest: taking the next message is O(1), no scans
     // FAST: pre-drawn values (ring head / count per stream), router choices as bits, the one outgoing link in registers
     NetFastLds fl;
     int ha, na, hs_, nsv, hj, nj, rn;
@@ -252,6 +274,7 @@ struct NetStation {
     // a synchronous read at delivery time: 64 % of the wavefront's group trips stalled on one, measured on the full ring.)
     int64_t pf_v0, pf_v1;
     int pf_s0, pf_s1;             // slots the prefetched values belong to (-1: none pending)
+    unsigned long long tail_hint; // asynchronous engine: the in-wavefront sender's appended count (0: none)
     int32_t fi_link;              // the LP's only incoming link (-1: none or several): its packets_sent counter in a register
     int64_t fi_packets;
     unsigned long long fi_head;   // ... and this LP's position in that link's queue (the only writer of aq_head[fi_link])
@@ -301,23 +324,41 @@ struct NetStation {
         if constexpr (FAST) return kLBag < ns->bag_cap ? kLBag : ns->bag_cap;
         else return ns->bag_cap;
     }
-    __device__ __forceinline__ int64_t bg_t(int i) const { if constexpr (FAST) return fl.bag_t[i][tid]; else return ns->bag_t[bidx(i)]; }
-    __device__ __forceinline__ int64_t bg_ts(int i) const { if constexpr (FAST) return fl.bag_ts[i][tid]; else return ns->bag_ts[bidx(i)]; }
-    __device__ __forceinline__ int64_t bg_cr(int i) const { if constexpr (FAST) return fl.bag_cr[i][tid]; else return ns->bag_cr[bidx(i)]; }
-    __device__ __forceinline__ int32_t bg_link(int i) const { if constexpr (FAST) return fl.bag_link[i][tid]; else return ns->bag_link[bidx(i)]; }
+    static_assert((kLBag & (kLBag - 1)) == 0, "the LDS bag is addressed with a mask");
+    __device__ __forceinline__ int bslot(int i) const { return (bh + i) & (kLBag - 1); }
+    __device__ __forceinline__ int64_t bg_t(int i) const { if constexpr (FAST) return fl.bag_t[bslot(i)][tid]; else return ns->bag_t[bidx(i)]; }
+    __device__ __forceinline__ int64_t bg_ts(int i) const { if constexpr (FAST) return fl.bag_ts[bslot(i)][tid]; else return ns->bag_ts[bidx(i)]; }
+    __device__ __forceinline__ int64_t bg_cr(int i) const { if constexpr (FAST) return fl.bag_cr[bslot(i)][tid]; else return ns->bag_cr[bidx(i)]; }
+    __device__ __forceinline__ int32_t bg_link(int i) const { if constexpr (FAST) return fl.bag_link[bslot(i)][tid]; else return ns->bag_link[bidx(i)]; }
     __device__ __forceinline__ void bg_set(int i, int64_t t, int64_t ts, int64_t cr, int32_t l) {
-        if constexpr (FAST) { fl.bag_t[i][tid] = t; fl.bag_ts[i][tid] = ts; fl.bag_cr[i][tid] = cr; fl.bag_link[i][tid] = l; }
+        if constexpr (FAST) { const int k = bslot(i); fl.bag_t[k][tid] = t; fl.bag_ts[k][tid] = ts; fl.bag_cr[k][tid] = cr; fl.bag_link[k][tid] = l; }
         else { const size_t d = bidx(i); ns->bag_t[d] = t; ns->bag_ts[d] = ts; ns->bag_cr[d] = cr; ns->bag_link[d] = l; }
     }
-    // earliest arrival in the bag, kept in a register (`bmin`): next_time() runs several times per step and a scan of the
-    // bag is a chain of global loads; the scan is only redone when a message leaves the bag
+    // FAST: insert in arrival-time order (stable: behind equal times).  Messages of one link arrive almost in send order,
+    // so the new one usually goes last: one comparison.
+    __device__ __forceinline__ void bag_insert(int64_t t, int64_t ts, int64_t cr, int32_t l) {
+        int p = bag_n;
+        while (p > 0 && bg_t(p - 1) > t) { bg_set(p, bg_t(p - 1), bg_ts(p - 1), bg_cr(p - 1), bg_link(p - 1)); --p; }
+        bg_set(p, t, ts, cr, l);
+        ++bag_n;
+        bmin = t < bmin ? t : bmin;
+    }
+    // earliest arrival in the bag, kept in a register (`bmin`): next_time() runs several times per step
     __device__ __forceinline__ int64_t bag_scan_min() const {
+        if constexpr (FAST) return bag_n > 0 ? bg_t(0) : kInfNs;
         int64_t m = kInfNs;
         for (int i = 0; i < bag_n; ++i) { const int64_t t = bg_t(i); m = t < m ? t : m; }
         return m;
     }
     __device__ __forceinline__ int64_t bag_min() const { return bmin; }
     __device__ __forceinline__ void bag_remove(int i) {
+        if constexpr (FAST) {
+            if (i == 0) bh = (bh + 1) & (kLBag - 1);                  // the earliest message: the common case
+            else for (int k = i; k + 1 < bag_n; ++k) bg_set(k, bg_t(k + 1), bg_ts(k + 1), bg_cr(k + 1), bg_link(k + 1));
+            --bag_n;
+            bmin = bag_scan_min();
+            return;
+        }
         const int last = bag_n - 1;
         if (i != last) bg_set(i, bg_t(last), bg_ts(last), bg_cr(last), bg_link(last));
         bag_n = last;
@@ -704,18 +745,21 @@ struct NetStation {
     // state has already sent are only guaranteed to be behind a tail read after the neighbour's drains.)
     __device__ __forceinline__ int64_t async_receive_one() {
         const int l = fi_link;
-        const int64_t ea = ag_load_acquire(&ns->aq_ea[l]);                     // bound BEFORE tail, as in async_receive
-        const unsigned long long tail = ag_load(&ns->aq_tail[l]);
+        const int64_t w = ag_load(&ns->aq_ea[l]);                     // (bound, tail) in one word: a consistent pair; the payload
+        const int64_t ea = pk_ea(w, ns->pk_base);                     // loads below depend on it (loop bounds), so they follow it
         undrained = kInfNs;
         unsigned long long head = fi_head;
+        unsigned long long tail = pk_tail(w, head);
+        // a sender in the same wavefront hands over its tail through a shuffle (the scan's bound is computed from its
+        // CURRENT state: everything that state has appended must be taken, whether or not the word has landed yet; the
+        // payloads are complete -- the sender drained them before the iteration ended)
+        if (tail_hint > tail) tail = tail_hint;
         if (head != tail) {
             const int bcap = bag_capacity();
             for (; head < tail && bag_n < bcap; ++head) {
                 const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
                 const int64_t ta = ag_load(&ns->aq_t[slot]);
-                bmin = ta < bmin ? ta : bmin;
-                bg_set(bag_n, ta, ag_load(&ns->aq_ts[slot]), ag_load(&ns->aq_cr[slot]), l);
-                ++bag_n;
+                bag_insert(ta, ag_load(&ns->aq_ts[slot]), ag_load(&ns->aq_cr[slot]), l);
             }
             fi_head = head;
             ag_store(&ns->aq_head[l], head);
@@ -733,18 +777,17 @@ struct NetStation {
         const int a = np->in_off[lp], b = np->in_off[lp + 1];
         for (int q = a; q < b; ++q) {
             const int l = np->in_links[q];
-            const int64_t ea = ag_load_acquire(&ns->aq_ea[l]);                 // read BEFORE the tail: see the ordering note above
+            const int64_t w = ag_load(&ns->aq_ea[l]);                  // (bound, tail) in one word
+            const int64_t ea = pk_ea(w, ns->pk_base);
             H = ea < H ? ea : H;
-            const unsigned long long tail = ag_load(&ns->aq_tail[l]);
             unsigned long long head = ns->aq_head[l];                  // ours
+            const unsigned long long tail = pk_tail(w, head);
             if (head == tail) continue;
             const int bcap = bag_capacity();
             for (; head < tail && bag_n < bcap; ++head) {
                 const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
                 const int64_t ta = ag_load(&ns->aq_t[slot]);
-                bmin = ta < bmin ? ta : bmin;
-                bg_set(bag_n, ta, ag_load(&ns->aq_ts[slot]), ag_load(&ns->aq_cr[slot]), l);
-                ++bag_n;
+                bag_insert(ta, ag_load(&ns->aq_ts[slot]), ag_load(&ns->aq_cr[slot]), l);
             }
             ag_store(&ns->aq_head[l], head);
             if (head < tail) {
@@ -807,13 +850,24 @@ struct NetStation {
         return sum;
     }
     __device__ __forceinline__ int services_known() const { return svc_kind != 0 ? kNRing : nsv; }
+    // the next admission the LP already knows about: its own Source's tick, a message in the bag, an injected Request
+    __device__ __forceinline__ int64_t next_admission() const {
+        int64_t a = A < bmin ? A : bmin;
+        if (has_sched() && SA < a) a = SA;
+        return a;
+    }
 
     // The map  ea(H) = min(mA, max(H + mB, mD))  of this LP as the sender on link l (transit floor `lat`), from its CURRENT
     // state: a lower bound on the arrival of every message it has not appended to l yet, given that nothing reaches it from
     // upstream before H.  (min D / next own event / the next free workers' service times: every quantity is already determined.)
-    __device__ __forceinline__ void bound_map(int32_t l, int64_t lat, int64_t &mA, int64_t &mB, int64_t &mD) const {
+    // `kind` / `sdl` (optional) say how mA depends on what the next receive can change, so that the caller can keep the map
+    // across the iteration boundary instead of evaluating it twice:  0: not at all;  1: mA = max(next known admission, D_pre)
+    // + sdl;  2: mA = next_time() + sdl;  -1: re-evaluate.
+    __device__ __forceinline__ void bound_map(int32_t l, int64_t lat, int64_t &mA, int64_t &mB, int64_t &mD, int *kind = nullptr,
+                                              int64_t *sdl = nullptr) const {
         auto sat = [](int64_t a, int64_t b) { return (a == kInfNs || b == kInfNs) ? kInfNs : a + b; };
         mA = kInfNs; mB = kInfNs; mD = INT64_MIN;
+        if (kind) *kind = -1;
         if constexpr (C == 1 && FAST) {
             const int known = services_known();
             if (presend && l == fl_link) {
@@ -834,19 +888,20 @@ struct NetStation {
                 if (u < started) {                                   // in service
                     const int e = q < known ? q : known;
                     mA = sat(sat(D[0], sum_services(e)), lat);
+                    if (kind) *kind = 0;
                     return;
                 }
                 const int off = (int)(u - started);
                 int64_t sd = 0;
                 if (svc_kind != 0) sd = (int64_t)(q + 1) * svc_const_ns;
                 else for (int i = 0; i <= q && off + i < known; ++i) sd += ns_from_seconds(fl.ring_s[(hs_ + off + i) & (kNRing - 1)][tid]);
-                if (u < accepted) { mA = sat(sat(D_pre, sd), lat); return; }
-                int64_t arr_next = A < bmin ? A : bmin;              // the next admission the LP already knows about
-                if (has_sched() && SA < arr_next) arr_next = SA;
+                if (u < accepted) { mA = sat(sat(D_pre, sd), lat); if (kind) *kind = 0; return; }
+                const int64_t arr_next = next_admission();
                 const int64_t own = arr_next > D_pre ? arr_next : D_pre;
                 mA = sat(sat(own, sd), lat);
                 mB = sd + lat;
                 mD = sat(sat(D_pre, sd), lat);
+                if (kind) { *kind = 1; *sdl = sd + lat; }
                 return;
             }
             if (kLookMax > 1) {
@@ -856,11 +911,13 @@ struct NetStation {
                 if (active >= conc) {
                     const int e = (m - 1) < known ? (m - 1) : known;
                     mA = sat(sat(D[0], sum_services(e)), lat);
+                    if (kind) *kind = 0;
                 } else {
                     const int e = m < known ? m : known;
                     const int64_t sd = sum_services(e);
                     mA = sat(sat(next_time(), sd), lat);
                     mB = sd + lat;
+                    if (kind) { *kind = 2; *sdl = sd + lat; }
                 }
                 return;
             }
@@ -963,8 +1020,7 @@ struct NetStation {
 #endif
         const bool tick = (A == t), dep = (D[0] == t);
         int cnt = (tick ? 1 : 0) + (dep ? 1 : 0), mi = 0;
-        if (bmin == t)
-            for (int i = 0; i < bag_n; ++i) if (bg_t(i) == t) { ++cnt; mi = i; }
+        if (bmin == t) { ++cnt; if (bag_n > 1 && bg_t(1) == t) ++cnt; }   // the sorted bag: entry 0 is the message (mi = 0)
         const bool msg = !tick && !dep;                               // (cnt == 1 is checked below)
         // speculative draws: peeks, nothing consumed yet
         const bool poisson = src_kind == 1, svc_exp = svc_kind == 0;
