@@ -1640,7 +1640,8 @@ void launch_run_dispatch(hs_engine *h, int64_t end_ns) {
         case 2: launch_run<2>(h, end_ns); break;
         case 4: launch_run<4>(h, end_ns); break;
         case 8: launch_run<8>(h, end_ns); break;
-        default: launch_run<16>(h, end_ns); break;
+        case 16: launch_run<16>(h, end_ns); break;
+        default: launch_run<32>(h, end_ns); break;     // (departure slots beyond 16 live in scratch: correct, not fast)
     }
 }
 
@@ -1835,7 +1836,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         }
         const int c = st->concurrency ? st->concurrency[i] : 1;
         if (c < 1) return fail(h, HS_E_INVALID, "LP %d: max_concurrent must be >= 1, got %d", i, c);
-        if (c > 16) return fail(h, HS_E_UNSUPPORTED, "LP %d: concurrency %d > 16 is not lowered yet", i, c);
+        if (c > 32) return fail(h, HS_E_UNSUPPORTED, "LP %d: concurrency %d > 32 is not lowered yet", i, c);
         if (c > maxc) maxc = c;
         const int vk = st->svc_kind ? st->svc_kind[i] : HS_LAT_CONSTANT;
         if (vk != HS_LAT_EXPONENTIAL && vk != HS_LAT_CONSTANT && vk != HS_LAT_NO_SERVER)
@@ -1907,7 +1908,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         n_sched = st->sched_off[n];
         if (n_sched > 0) { h->any_profile = true; h->any_sched = true; }
     }
-    h->C = maxc <= 1 ? 1 : maxc <= 2 ? 2 : maxc <= 4 ? 4 : maxc <= 8 ? 8 : 16;
+    h->C = maxc <= 1 ? 1 : maxc <= 2 ? 2 : maxc <= 4 ? 4 : maxc <= 8 ? 8 : maxc <= 16 ? 16 : 32;
     int64_t cap = h->cfg.log_capacity;
     if (cap <= 0) {
         const double c = max_mean_records + 10.0 * std::sqrt(max_mean_records + 1.0) + 64.0 + (double)max_sched;

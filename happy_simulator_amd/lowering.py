@@ -210,8 +210,8 @@ def lower(sources: list, entities: list) -> LoweredGraph:
         if not isinstance(sv.service_time, (ExponentialLatency, ConstantLatency)):
             raise UnsupportedTopology(
                 f"server '{sv.name}': service distribution {type(sv.service_time).__name__} is not lowered")
-        if sv.concurrency > 16:
-            raise UnsupportedTopology(f"server '{sv.name}': concurrency {sv.concurrency} > 16 is not lowered yet")
+        if sv.concurrency > 32:
+            raise UnsupportedTopology(f"server '{sv.name}': concurrency {sv.concurrency} > 32 is not lowered yet")
 
     def check_link(lk: NetworkLink, owner: str):
         if id(lk) in used_links:

@@ -659,6 +659,8 @@ CASES = [
          rng="philox", seed=42, mode="replicas", trace=False),
     dict(name="philox_c3_rho08", n_chains=4, arr="poisson", rate=24.0, svc="exp", mean=0.1, concurrency=3,
          end_s=30.0, rng="philox", seed=7, mode="single", trace=True),
+    dict(name="philox_c24_c32", n_chains=3, arr=["poisson", "poisson", "constant"], rate=[200.0, 330.0, 250.0], svc=["exp", "exp", "const"],
+         mean=0.1, concurrency=[24, 32, 20], queue_cap=[None, 5, None], end_s=6.0, rng="philox", seed=23, mode="single", trace=True),
     dict(name="philox_overload_cap4", n_chains=4, arr="poisson", rate=15.0, svc="exp", mean=0.1, queue_cap=4,
          end_s=30.0, rng="philox", seed=11, mode="single", trace=True),
     dict(name="philox_c2_cap1_overload", n_chains=3, arr="poisson", rate=30.0, svc="exp", mean=0.1, concurrency=2,
