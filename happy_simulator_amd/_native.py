@@ -86,6 +86,7 @@ class Network(C.Structure):
         ("link_jitter_mean_s", C.c_void_p), ("link_stream_base", C.c_void_p), ("link_src", C.c_void_p),
         ("bag_capacity", C.c_int32), ("n_global_lp", C.c_int32), ("link_gid", C.c_void_p),
         ("n_global_links", C.c_int64), ("link_loss_rate", C.c_void_p),
+        ("router_n_targets", C.c_void_p), ("router_target2", C.c_void_p), ("router_target3", C.c_void_p),
     ]
 
 

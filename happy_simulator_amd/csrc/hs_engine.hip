@@ -687,7 +687,8 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF> &S, const Stati
     S.lp = lp; S.n = n;
     S.sc = &SC; S.sent_min = kInfNs; S.sent_async = false;
     S.src_kind = P.src_kind[lp]; S.svc_kind = P.svc_kind[lp]; S.egress = NP.egress[lp];
-    S.conc = P.conc[lp]; S.rt0 = NP.rt0[lp]; S.rt1 = NP.rt1[lp]; S.link_of = NP.link_of[lp];
+    S.conc = P.conc[lp]; S.rt0 = NP.rt0[lp]; S.rt1 = NP.rt1[lp]; S.rt2 = NP.rt2[lp]; S.rt3 = NP.rt3[lp]; S.rtk = NP.rt_cnt[lp];
+    S.link_of = NP.link_of[lp];
     S.rate = P.src_rate[lp];
     const double mean = P.svc_mean[lp];
     S.svc_lambda = __ddiv_rn(1.0, mean);
@@ -759,7 +760,11 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF> &S, const Stati
         // ... and the LP's outgoing link into registers when there is exactly one
         int32_t l = -1;
         if (S.egress == EG_LINK) l = S.link_of;
-        else if (S.egress == EG_ROUTER) l = (S.rt0 >= 0 && S.rt1 < 0) ? S.rt0 : (S.rt1 >= 0 && S.rt0 < 0) ? S.rt1 : -1;
+        else if (S.egress == EG_ROUTER) {          // exactly one link among the router's targets
+            int cnt = 0;
+            for (int k = 0; k < S.rtk; ++k) { const int32_t t = S.rt_target(k); if (t >= 0) { l = t; ++cnt; } }
+            if (cnt != 1) l = -1;
+        }
         if (l >= 0) {
             S.fl_link = l; S.fl_dst = NP.link_dst[l]; S.fl_jit = NP.link_jit_kind[l];
             S.fl_remote = SC.wend_slots != nullptr && SC.link_rank[l] != SC.rank;
@@ -1125,7 +1130,10 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         // this LP's outgoing links (router targets in constructor order, or the single link) and what it last published
         int32_t out_l[2] = {-1, -1};
         if (S.egress == EG_LINK) out_l[0] = S.link_of;
-        else if (S.egress == EG_ROUTER) { out_l[0] = S.rt0; out_l[1] = S.rt1; }
+        else if (S.egress == EG_ROUTER) {          // at most two links among the router's targets (hs_engine_set_network)
+            int no = 0;
+            for (int k = 0; k < S.rtk; ++k) { const int32_t t = S.rt_target(k); if (t >= 0 && no < 2) out_l[no++] = t; }
+        }
         int64_t out_pub[2] = {INT64_MIN, INT64_MIN};
         unsigned long long head_seen[2] = {0ull, 0ull};
         const bool force_general = (flags & 1) != 0;
@@ -2148,7 +2156,8 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
         if (jk != HS_LAT_EXPONENTIAL && jk != HS_LAT_CONSTANT)
             return fail(h, HS_E_UNSUPPORTED, "link %d: jitter kind %d is not lowered", l, jk);
     }
-    std::vector<int32_t> rt0((size_t)n, -1), rt1((size_t)n, -1), lof((size_t)n, -1);
+    std::vector<int32_t> rt0((size_t)n, -1), rt1((size_t)n, -1), rt2((size_t)n, -1), rt3((size_t)n, -1), lof((size_t)n, -1);
+    std::vector<uint8_t> rtk((size_t)n, (uint8_t)2);
     std::vector<uint8_t> link_used((size_t)(nl > 0 ? nl : 1), 0);
     auto use_link = [&](int lp, int l) -> int {
         if (l < 0 || l >= nl) return fail(h, HS_E_INVALID, "LP %d: link index %d out of range", lp, l);
@@ -2162,10 +2171,20 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
         int rc2;
         if (ek == HS_EGRESS_ROUTER) {
             if (!net->router_target0 || !net->router_target1) return fail(h, HS_E_INVALID, "router targets are required");
-            rt0[(size_t)i] = net->router_target0[i]; rt1[(size_t)i] = net->router_target1[i];
-            if (rt0[(size_t)i] >= 0 && (rc2 = use_link(i, rt0[(size_t)i]))) return rc2;
-            if (rt1[(size_t)i] >= 0 && (rc2 = use_link(i, rt1[(size_t)i]))) return rc2;
-            if (rt0[(size_t)i] < -1 || rt1[(size_t)i] < -1) return fail(h, HS_E_INVALID, "LP %d: bad router target", i);
+            const int k = net->router_n_targets ? net->router_n_targets[i] : 2;
+            if (k < 1 || k > 4) return fail(h, HS_E_UNSUPPORTED, "LP %d: RandomRouter with %d targets (1..4 are lowered)", i, k);
+            if ((k > 2 && !net->router_target2) || (k > 3 && !net->router_target3))
+                return fail(h, HS_E_INVALID, "router_target2 / router_target3 are required for routers with that many targets");
+            rtk[(size_t)i] = (uint8_t)k;
+            const int32_t tg[4] = {net->router_target0[i], net->router_target1[i], k > 2 ? net->router_target2[i] : -1,
+                                   k > 3 ? net->router_target3[i] : -1};
+            int n_link = 0;
+            for (int q = 0; q < k; ++q) {
+                if (tg[q] < -1) return fail(h, HS_E_INVALID, "LP %d: bad router target", i);
+                if (tg[q] >= 0) { if ((rc2 = use_link(i, tg[q]))) return rc2; ++n_link; }
+            }
+            if (n_link > 2) return fail(h, HS_E_UNSUPPORTED, "LP %d: a router with more than two NetworkLink targets is not lowered", i);
+            rt0[(size_t)i] = tg[0]; rt1[(size_t)i] = tg[1]; rt2[(size_t)i] = tg[2]; rt3[(size_t)i] = tg[3];
         } else if (ek == HS_EGRESS_LINK) {
             if (!net->link_of) return fail(h, HS_E_INVALID, "link_of is required");
             lof[(size_t)i] = net->link_of[i];
@@ -2205,6 +2224,9 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     if ((rc = upload<uint8_t>(h, &h->NP.egress, net->egress_kind, (size_t)n, 0))) return rc;
     if ((rc = upload<int32_t>(h, &h->NP.rt0, rt0.data(), (size_t)n, -1))) return rc;
     if ((rc = upload<int32_t>(h, &h->NP.rt1, rt1.data(), (size_t)n, -1))) return rc;
+    if ((rc = upload<int32_t>(h, &h->NP.rt2, rt2.data(), (size_t)n, -1))) return rc;
+    if ((rc = upload<int32_t>(h, &h->NP.rt3, rt3.data(), (size_t)n, -1))) return rc;
+    if ((rc = upload<uint8_t>(h, &h->NP.rt_cnt, rtk.data(), (size_t)n, 2))) return rc;
     if ((rc = upload<int32_t>(h, &h->NP.link_of, lof.data(), (size_t)n, -1))) return rc;
     if ((rc = upload<uint64_t>(h, &h->NP.route_base, rbase.data(), (size_t)n, 0))) return rc;
     h->NP.n_links = nl;

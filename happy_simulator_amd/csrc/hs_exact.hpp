@@ -351,7 +351,8 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
             const uint64_t k = NX.route_k[lp];
             const double u = xuniform(P.seed[lp], stream_id(NP.route_base[lp], kStreamRoute), k);
             NX.route_k[lp] = k + 1;
-            const int32_t target = ((int)__dmul_rn(u, 2.0)) == 0 ? NP.rt0[lp] : NP.rt1[lp];
+            const int ri = (int)__dmul_rn(u, (double)NP.rt_cnt[lp]);         // targets[int(u * len(targets))]
+            const int32_t target = ri == 0 ? NP.rt0[lp] : ri == 1 ? NP.rt1[lp] : ri == 2 ? NP.rt2[lp] : NP.rt3[lp];
             if (target < 0) xpush(S, xev(t, S.G++, XE_SINK, lp, e.cr));
             else xpush(S, xev(t, S.G++, XE_LINK, lp, e.cr, target));
         } break;

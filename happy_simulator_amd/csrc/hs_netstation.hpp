@@ -32,6 +32,8 @@ enum : uint32_t { EG_NONE = 0, EG_SINK = 1, EG_LINK = 2, EG_ROUTER = 3 };
 struct NetParams {
     const uint8_t *egress;        // [n_lp] EG_*
     const int32_t *rt0, *rt1;     // [n_lp] router targets in RandomRouter(targets=[...]) order: -1 = the LP's Sink, else link
+    const int32_t *rt2, *rt3;     // [n_lp] ... the third and fourth target of routers with more than two
+    const uint8_t *rt_cnt;        // [n_lp] len(targets), 1..4: the route draw picks targets[int(u * len(targets))]
     const int32_t *link_of;       // [n_lp] EG_LINK: the link
     const uint64_t *route_base;   // [n_lp] stream base of the router entity
     int32_t n_links;
@@ -196,7 +198,7 @@ struct NetStation {
     // parameters
     int lp, n;
     uint32_t src_kind, svc_kind, egress;
-    int32_t conc, rt0, rt1, link_of;
+    int32_t conc, rt0, rt1, rt2, rt3, rtk, link_of;   // rtk = len(router.targets)
     double rate, svc_lambda, svc_const_s;
     int64_t stop_ns, qcap, svc_const_ns;
     uint64_t seed, route_base;
@@ -387,8 +389,12 @@ struct NetStation {
             fl.ring_j[(hj + nj) & (kNRing - 1)][tid] = seconds_from_ns(ns_from_seconds(sample)); ++nj;
         }
     }
+    // RandomRouter (components/random_router.py:32-45, Philox-plugged): targets[int(u * len(targets))].  Pre-drawn decisions are
+    // kept two bits each in `rbits` (16 of them), oldest in the low bits.
+    __device__ __forceinline__ int32_t rt_target(int idx) const { return idx == 0 ? rt0 : idx == 1 ? rt1 : idx == 2 ? rt2 : rt3; }
+    __device__ __forceinline__ int route_draw() { return (int)__dmul_rn(rte.next_uniform(), (double)rtk); }
     __device__ __forceinline__ void refill_r(int m) {
-        for (int i = 0; i < m; ++i) { rbits |= (uint32_t)((int)__dmul_rn(rte.next_uniform(), 2.0) & 1) << rn; ++rn; }
+        for (int i = 0; i < m; ++i) { rbits |= (uint32_t)(route_draw() & 3) << (2 * rn); ++rn; }
     }
     __device__ __forceinline__ double arr_inc() {                     // E / rate of the next Poisson arrival
         if constexpr (FAST) {
@@ -412,10 +418,10 @@ struct NetStation {
     __device__ __forceinline__ int route_idx() {
         if constexpr (FAST) {
             if (rn == 0) refill_r(2);
-            const int idx = (int)(rbits & 1u);
-            rbits >>= 1; --rn;
+            const int idx = (int)(rbits & 3u);
+            rbits >>= 2; --rn;
             return idx;
-        } else return (int)__dmul_rn(rte.next_uniform(), 2.0);
+        } else return route_draw();
     }
     __device__ __forceinline__ uint64_t arr_consumed() const { return FAST ? arr.k - (uint64_t)na : arr.k; }
     __device__ __forceinline__ uint64_t svc_consumed() const { return FAST ? svc.k - (uint64_t)nsv : svc.k; }
@@ -430,7 +436,7 @@ struct NetStation {
             if (__any(act && wa && na < need)) { if (act && wa && na <= kNRing - 4) refill_a(4); }
             if (__any(act && ws && nsv < need)) { if (act && ws && nsv <= kNRing - 4) refill_s(4); }
             if (__any(act && wj && nj < need)) { if (act && wj && nj <= kNRing - 4) refill_j(4); }
-            if (__any(act && wr && rn < need)) { if (act && wr && rn <= 24) refill_r(8); }
+            if (__any(act && wr && rn < need)) { if (act && wr && rn <= 8) refill_r(8); }
         }
     }
 
@@ -598,7 +604,7 @@ struct NetStation {
         const bool router = egress == EG_ROUTER;
         if (router && bit_off >= rn) return false;
         const int32_t target = egress == EG_SINK ? -1 : egress == EG_LINK ? link_of
-                             : router ? (((rbits >> bit_off) & 1u) == 0 ? rt0 : rt1) : -2;
+                             : router ? rt_target((int)((rbits >> (2 * bit_off)) & 3u)) : -2;
         if (target >= 0 && D <= end_ns) {
             if (fl_jit == 0 && nj == 0) return false;
             double delay = fl_delay0;
@@ -705,7 +711,7 @@ struct NetStation {
         else if (egress == EG_ROUTER) {  // RandomRouter.handle_event (components/random_router.py:32-45)
             ev[10]++; routed++;
             const int idx = route_idx();
-            target = idx == 0 ? rt0 : rt1;
+            target = rt_target(idx);
         }
         if (target == -1) {              // Sink.handle_event (components/common.py:36-44)
             ev[7]++;
@@ -840,7 +846,7 @@ struct NetStation {
         if (egress != EG_ROUTER) return 0;                            // EG_LINK: every completion enters the link
         int q = 0;
         uint32_t b = rbits;
-        while (q < rn && ((b & 1u) == 0 ? rt0 : rt1) != l) { ++q; b >>= 1; }
+        while (q < rn && rt_target((int)(b & 3u)) != l) { ++q; b >>= 2; }
         return q;                                                     // == rn: none of the known decisions goes to l
     }
     __device__ __forceinline__ int64_t sum_services(int m) const {   // of the next m requests to start, m <= services_known()
@@ -881,9 +887,9 @@ struct NetStation {
                 const int boff = (int)(u - completed);               // its distance from the next completion
                 int q = 0;                                           // requests from u on that go elsewhere first
                 if (egress == EG_ROUTER) {
-                    uint32_t b = boff < 32 ? rbits >> boff : 0u;
+                    uint32_t b = boff < 16 ? rbits >> (2 * boff) : 0u;
                     const int have = rn - boff;
-                    while (q < have && q < kLookMax && ((b & 1u) == 0 ? rt0 : rt1) != l) { ++q; b >>= 1; }
+                    while (q < have && q < kLookMax && rt_target((int)(b & 3u)) != l) { ++q; b >>= 2; }
                 }
                 if (u < started) {                                   // in service
                     const int e = q < known ? q : known;
@@ -1029,8 +1035,8 @@ struct NetStation {
         const double s_new = svc_exp ? fl.ring_s[hs_][tid] : svc_const_s;
         const int64_t dur = svc_exp ? ns_from_seconds(s_new) : svc_const_ns;
         const bool router = egress == EG_ROUTER;
-        const int ridx = (int)(rbits & 1u);
-        const int32_t target = egress == EG_SINK ? -1 : egress == EG_LINK ? link_of : router ? (ridx == 0 ? rt0 : rt1) : -2;
+        const int ridx = (int)(rbits & 3u);
+        const int32_t target = egress == EG_SINK ? -1 : egress == EG_LINK ? link_of : router ? rt_target(ridx) : -2;
         const bool to_sink = dep && target == -1, to_link = dep && target >= 0;
         // which reference events happen
         const bool payload = tick && !(stop_ns >= 0 && t > stop_ns);
@@ -1099,7 +1105,7 @@ struct NetStation {
             created_out = crt[0];
             active = active > 0 ? active - 1 : 0;
             D[0] = kInfNs;
-            if (router) { ev[10]++; routed++; rbits >>= 1; --rn; }
+            if (router) { ev[10]++; routed++; rbits >>= 2; --rn; }
         }
         if (to_sink) {
             ev[7]++;

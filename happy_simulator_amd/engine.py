@@ -68,6 +68,9 @@ class NetworkArrays:
     router_stream_base: np.ndarray | None = None
     link_stream_base: np.ndarray | None = None
     link_loss_rate: np.ndarray | None = None   # [n_links] NetworkLink.packet_loss_rate; None = lossless
+    router_n_targets: np.ndarray | None = None # [n] len(RandomRouter.targets), 1..4; None = 2 everywhere
+    router_target2: np.ndarray | None = None   # [n] third / fourth target of routers with more than two
+    router_target3: np.ndarray | None = None
     bag_capacity: int = 0
     # one shard of a partitioned network (happy_simulator_amd/sharded.py): network-wide endpoints and link ids
     n_global_lp: int = 0
@@ -188,6 +191,9 @@ class StationEngine:
         put("link_jitter_mean_s", net.link_jitter_mean_s, np.float64, nl)
         put("link_stream_base", net.link_stream_base, np.uint64, nl)
         put("link_loss_rate", net.link_loss_rate, np.float64, nl)
+        put("router_n_targets", net.router_n_targets, np.uint8, self.n)
+        put("router_target2", net.router_target2, np.int32, self.n)
+        put("router_target3", net.router_target3, np.int32, self.n)
         nw.bag_capacity = int(net.bag_capacity)
         nw.n_global_lp = int(net.n_global_lp)
         put("link_gid", net.link_gid, np.int64, nl)

@@ -98,15 +98,16 @@ class LoweredGraph:
     def network_arrays(self, bag_capacity: int = 0) -> NetworkArrays:
         n, nl = len(self.stations), len(self.links)
         eg = np.zeros(n, np.uint8)
-        rt0 = np.full(n, -1, np.int32)
-        rt1 = np.full(n, -1, np.int32)
+        rt = np.full((4, n), -1, np.int32)
+        rtk = np.full(n, 2, np.uint8)
         lof = np.full(n, -1, np.int32)
         for i, st in enumerate(self.stations):
             if st.router is not None:
                 eg[i] = N.EGRESS_ROUTER
                 ids = iter(st.link_ids)
                 tg = [(-1 if isinstance(t, _SINKS) else next(ids)) for t in st.router.targets]
-                rt0[i], rt1[i] = tg
+                rtk[i] = len(tg)
+                rt[:len(tg), i] = tg
             elif st.links:
                 eg[i] = N.EGRESS_LINK
                 lof[i] = st.link_ids[0]
@@ -119,7 +120,9 @@ class LoweredGraph:
                 jk[l] = N.LAT_EXPONENTIAL
                 jm[l] = lk.jitter.mean
         return NetworkArrays(
-            egress_kind=eg, router_target0=rt0, router_target1=rt1, link_of=lof,
+            egress_kind=eg, router_target0=rt[0], router_target1=rt[1], link_of=lof,
+            router_n_targets=rtk if (rtk != 2).any() else None,
+            router_target2=rt[2] if (rtk > 2).any() else None, router_target3=rt[3] if (rtk > 3).any() else None,
             link_src=np.array([s for _, s, _ in self.links], np.int32).reshape(nl),
             link_dst=np.array([d for _, _, d in self.links], np.int32).reshape(nl),
             link_lat_min_s=np.array([lk.latency.mean for lk, _, _ in self.links], np.float64).reshape(nl),
@@ -242,13 +245,16 @@ def lower(sources: list, entities: list) -> LoweredGraph:
             if id(obj) in used_routers:
                 raise UnsupportedTopology(f"router '{obj.name}' has several upstreams (not lowered)")
             used_routers[id(obj)] = len(g.stations)
-            if len(obj.targets) != 2:
-                raise UnsupportedTopology(f"router '{obj.name}': exactly two targets are lowered, got {len(obj.targets)}")
+            if not (1 <= len(obj.targets) <= 4):
+                raise UnsupportedTopology(f"router '{obj.name}': 1..4 targets are lowered, got {len(obj.targets)}")
+            if sum(isinstance(t, NetworkLink) for t in obj.targets) > 2:
+                raise UnsupportedTopology(f"router '{obj.name}': at most two NetworkLink targets are lowered")
             st.router = obj
             for t in obj.targets:
                 if isinstance(t, _SINKS):
-                    if st.sink is not None:
-                        raise UnsupportedTopology(f"router '{obj.name}': at most one Sink target")
+                    if st.sink is not None and st.sink is not t:
+                        raise UnsupportedTopology(f"router '{obj.name}': at most one distinct Sink target (it may be listed "
+                                                  "several times)")
                     check_sink(t, f"router '{obj.name}'")
                     st.sink = t
                 elif isinstance(t, NetworkLink):
@@ -367,9 +373,12 @@ def write_back(g: LoweredGraph, stats: dict, counts: np.ndarray, t_ns: np.ndarra
                 st.router.stats_routed = int(net_stats["routed"][i])
                 tc = {}
                 ids = iter(st.link_ids)
+                seen_sink = False
                 for t in st.router.targets:
                     if isinstance(t, _SINKS):
-                        tc[t.name] = tc.get(t.name, 0) + c
+                        if not seen_sink:                  # (listed several times: one counter, by name -- random_router.py:37)
+                            tc[t.name] = tc.get(t.name, 0) + c
+                        seen_sink = True
                     else:
                         tc[t.name] = tc.get(t.name, 0) + int(net_stats["link_entered"][next(ids)])
                 st.router.target_counts = {k: v for k, v in tc.items() if v}

@@ -192,6 +192,9 @@ def shard_arrays(stations: StationArrays, net: NetworkArrays, lo: int, hi: int):
         link_jitter_mean_s=np.asarray(net.link_jitter_mean_s)[gids],
         router_stream_base=np.asarray(rbase, np.uint64)[sl], link_stream_base=np.asarray(lbase, np.uint64)[gids],
         link_loss_rate=None if net.link_loss_rate is None else np.asarray(net.link_loss_rate, np.float64)[gids],
+        router_n_targets=None if net.router_n_targets is None else np.asarray(net.router_n_targets)[sl],
+        router_target2=None if net.router_target2 is None else remap(net.router_target2),
+        router_target3=None if net.router_target3 is None else remap(net.router_target3),
         bag_capacity=net.bag_capacity, n_global_lp=n, link_gid=gids, n_global_links=net.n_links)
     return st, sub
 

@@ -189,6 +189,12 @@ typedef struct hs_network {
      * providers put no payload_size into the metadata, so the transmission time (link.py:209-214) is 0 for any
      * bandwidth and bytes_transmitted stays 0, exactly as in the reference. */
     const double *link_loss_rate;    /* [n_links] */
+    /* RandomRouter(targets=[...]) with other than two targets (components/random_router.py:32-45): the route draw picks
+     * targets[int(u * len(targets))].  1..4 targets, at most two of them NetworkLinks (-1 = the station's Sink, which may
+     * appear several times).  NULL = every router has exactly two targets (router_target0 / router_target1). */
+    const uint8_t *router_n_targets; /* [n_lp] */
+    const int32_t *router_target2;   /* [n_lp] */
+    const int32_t *router_target3;   /* [n_lp] */
 } hs_network;
 
 /* Exchange buffers of a shard: device memory owned by the caller (torch tensors on the host side, so that

@@ -391,7 +391,9 @@ def run_ring_case(spec):
                                  packet_loss_rate=loss[i] if isinstance(loss, list) else loss,
                                  egress=servers[(i + 1) % n]))
         links[i]._loss_stream = hs.Stream(seed, i, hs.STREAM_LOSS)
-        routers.append(PhiloxRandomRouter(f"router{i}", targets=[sinks[i], links[i]],
+        # spec["rt_pattern"][i]: the router's target list, 's' = the station's Sink, 'l' = its link (default "sl")
+        pat = (spec.get("rt_pattern") or ["sl"] * n)[i]
+        routers.append(PhiloxRandomRouter(f"router{i}", targets=[sinks[i] if ch == "s" else links[i] for ch in pat],
                                           stream=hs.Stream(seed, i, hs.STREAM_ROUTE)))
         servers[i].downstream = routers[i]
         rate = spec["ext_rate"][i] if isinstance(spec["ext_rate"], list) else spec["ext_rate"]
@@ -620,6 +622,8 @@ RING_CASES = [
     dict(name="ring_5_loss_mixed", topology="ring", n=5, ext_rate=[6.0, 3.0, 7.0, 2.0, 5.0], mean=0.08, concurrency=2,
          lat_min=0.002, jitter_mean=None, loss=[0.0, 0.5, 1.0, 0.1, 0.03], bandwidth_bps=1e6, end_s=15.0, seed=13,
          trace=True),
+    dict(name="ring_6_router_k", topology="ring", n=6, ext_rate=[5.0, 6.0, 4.0, 7.0, 3.0, 5.0], mean=0.08, lat_min=0.002,
+         jitter_mean=0.006, rt_pattern=["sls", "lss", "ssls", "l", "sl", "ssl"], end_s=12.0, seed=321, trace=True),
     dict(name="ring_8_s42", topology="ring", n=8, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, end_s=20.0,
          seed=42, trace=True),
     dict(name="ring_3_short_hops", topology="ring", n=3, ext_rate=4.0, mean=0.1, lat_min=0.0005, jitter_mean=0.002,

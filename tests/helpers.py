@@ -167,7 +167,8 @@ def oracle_ring_graph(spec):
         nodes[i]["srv"] = g.server(O.LAT_EXP, p["mean"], concurrency=p["conc"], queue_cap=p["qcap"], stream_base=i)
         nodes[i]["snk"] = g.sink()
         nodes[i]["lnk"] = g.link(p["lat_min"], p["jitter_mean"], stream_base=i, loss=p["loss"][i])
-        nodes[i]["rtr"] = g.router([nodes[i]["snk"], nodes[i]["lnk"]], stream_base=i)
+        pat = (spec.get("rt_pattern") or ["sl"] * n)[i]
+        nodes[i]["rtr"] = g.router([nodes[i]["snk"] if ch == "s" else nodes[i]["lnk"] for ch in pat], stream_base=i)
     for i in range(n):
         if nodes[i]["src"] >= 0:
             g.target[nodes[i]["src"]] = nodes[i]["srv"]
@@ -299,6 +300,18 @@ def oracle_per_chain(spec, runs):
     return out, sinks
 
 
+def _router_pattern(spec, n):
+    """spec["rt_pattern"][i] = the router's target list ('s' = the station's Sink, 'l' = its link) -> the hs_network fields."""
+    pats = spec.get("rt_pattern")
+    if not pats:
+        return {}
+    rt = np.full((4, n), -1, np.int32)
+    for i, pat in enumerate(pats):
+        rt[:len(pat), i] = [(-1 if ch == "s" else i) for ch in pat]
+    return dict(router_target0=rt[0], router_target1=rt[1], router_target2=rt[2], router_target3=rt[3],
+                router_n_targets=np.array([len(p) for p in pats], np.uint8))
+
+
 def ring_arrays(spec, bag_capacity=0, log_capacity=0):
     """(StationArrays, NetworkArrays, log capacity, params) of a ring spec -- network-wide description."""
     from happy_simulator_amd import _native as N
@@ -338,8 +351,8 @@ def ring_arrays(spec, bag_capacity=0, log_capacity=0):
     jit = p["jitter_mean"]
     net = NetworkArrays(
         egress_kind=np.full(n, N.EGRESS_ROUTER, np.uint8),
-        router_target0=np.full(n, -1, np.int32),             # targets=[sink_i, link_i]
-        router_target1=np.arange(n, dtype=np.int32),
+        **{**dict(router_target0=np.full(n, -1, np.int32),   # targets=[sink_i, link_i] unless spec["rt_pattern"] says otherwise
+                  router_target1=np.arange(n, dtype=np.int32)), **_router_pattern(spec, n)},
         link_of=np.full(n, -1, np.int32),
         link_src=np.arange(n, dtype=np.int32),
         link_dst=((np.arange(n) + 1) % n).astype(np.int32),

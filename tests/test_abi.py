@@ -34,7 +34,7 @@ def test_abi_version_and_struct_sizes(lib):
     assert C.sizeof(N.Stations) == 19 * 8
     assert C.sizeof(N.LbConfig) == 56 and C.sizeof(N.LbSources) == 40 and C.sizeof(N.LbBackends) == 64
     assert C.sizeof(N.LbStats) == 88
-    assert C.sizeof(N.Network) == 128 and C.sizeof(N.NetStats) == 4 * 8
+    assert C.sizeof(N.Network) == 152 and C.sizeof(N.NetStats) == 4 * 8
 
 
 def test_no_gpu_means_loud_failure(lib):

@@ -139,7 +139,8 @@ def _build_ring(spec):
                                     bandwidth_bps=spec.get("bandwidth_bps"),
                                     packet_loss_rate=loss[i] if isinstance(loss, list) else loss,
                                     egress=servers[(i + 1) % n]))
-        routers.append(hs.RandomRouter(f"router{i}", targets=[sinks[i], links[i]]))
+        pat = (spec.get("rt_pattern") or ["sl"] * n)[i]
+        routers.append(hs.RandomRouter(f"router{i}", targets=[sinks[i] if ch == "s" else links[i] for ch in pat]))
         servers[i].downstream = routers[i]
         rate = spec["ext_rate"][i] if isinstance(spec["ext_rate"], list) else spec["ext_rate"]
         pr = (spec.get("profile") or [None] * n)[i]
@@ -169,7 +170,8 @@ def _check_ring_objects(gold, servers, routers, links, sinks):
     assert lat == gold.sink_latency_s.tolist()
 
 
-@pytest.mark.parametrize("name", ["ring_8_s42", "ring_5_const_link", "ring_6_c2_cap3", "ring_8_loss", "ring_5_loss_mixed"])
+@pytest.mark.parametrize("name", ["ring_8_s42", "ring_5_const_link", "ring_6_c2_cap3", "ring_8_loss", "ring_5_loss_mixed",
+                                  "ring_6_router_k"])
 def test_ring_network_through_the_api_matches_reference_golden(name):
     gold = H.Golden(name)
     spec = gold.spec
