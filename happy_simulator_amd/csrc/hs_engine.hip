@@ -81,7 +81,9 @@ __device__ __forceinline__ void load_station(Station<C, PF> &S, const StationPar
     S.svc_const_ns = ns_from_seconds(S.svc_const_s);
     S.stop_ns = P.src_stop[lp]; S.qcap = P.qcap[lp];
     S.prof.kind = kProfConstant;
-    S.p_metric = kProbeNone; S.PA = kInfNs; S.evp[0] = S.evp[1] = 0;
+    S.n_probes = 0; S.evp[0] = S.evp[1] = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxProbes; ++j) { S.p_metric[j] = kProbeNone; S.PA[j] = kInfNs; S.seqP[j] = 0; S.crtP[j] = 0; S.p_arr[j] = 0; S.p_n[j] = 0; S.p_rate[j] = 1.0; }
     S.SA = kInfNs; S.sc_i = S.sc_end = 0; S.sc_t = P.sched_t; S.sc_idx = P.sched_idx;
     if constexpr (PF) {
         if (P.sched_off != nullptr) {
@@ -91,8 +93,16 @@ __device__ __forceinline__ void load_station(Station<C, PF> &S, const StationPar
         S.prof.kind = P.prof_kind[lp]; S.prof.owner = lp;
         S.prof.p0 = P.prof_p[lp]; S.prof.p1 = P.prof_p[(size_t)n + lp]; S.prof.p2 = P.prof_p[(size_t)2 * n + lp];
         S.prof.p3 = P.prof_p[(size_t)3 * n + lp];
-        S.p_metric = P.probe_metric[lp]; S.p_rate = P.probe_rate[lp];
-        S.PA = X.PA[lp]; S.seqP = X.seqP[lp]; S.crtP = X.crtP[lp]; S.p_arr = X.p_arr[lp]; S.p_n = X.p_n[lp];
+#pragma unroll
+        for (int j = 0; j < kMaxProbes; ++j) {
+            const size_t o = (size_t)j * n + lp;
+            S.p_metric[j] = P.probe_metric[o];
+            if (S.p_metric[j] != kProbeNone) {
+                S.n_probes = j + 1;
+                S.p_rate[j] = P.probe_rate[o];
+                S.PA[j] = X.PA[o]; S.seqP[j] = X.seqP[o]; S.crtP[j] = X.crtP[o]; S.p_arr[j] = X.p_arr[o]; S.p_n[j] = X.p_n[o];
+            }
+        }
         S.probe_t = L.probe_t + lp; S.probe_v = L.probe_v + lp; S.pcap = L.pcap;
     }
     S.A = X.A[lp]; S.seqA = X.seqA[lp]; S.crtA = X.crtA[lp]; S.arr_time = X.arr_time[lp];
@@ -149,7 +159,11 @@ __device__ __forceinline__ void store_station(const Station<C, PF> &Sc, const St
 #pragma unroll
     for (int k = 0; k < 8; ++k) { X.ev_kind[(size_t)k * n + lp] += S.ev[k]; tot += S.ev[k]; }
     if constexpr (PF) {
-        X.PA[lp] = S.PA; X.seqP[lp] = S.seqP; X.crtP[lp] = S.crtP; X.p_arr[lp] = S.p_arr; X.p_n[lp] = S.p_n;
+#pragma unroll
+        for (int j = 0; j < kMaxProbes; ++j) if (j < S.n_probes) {
+            const size_t o = (size_t)j * n + lp;
+            X.PA[o] = S.PA[j]; X.seqP[o] = S.seqP[j]; X.crtP[o] = S.crtP[j]; X.p_arr[o] = S.p_arr[j]; X.p_n[o] = S.p_n[j];
+        }
         X.ev_probe[lp] += S.evp[0]; X.ev_probe[(size_t)n + lp] += S.evp[1];
         tot += S.evp[0] + S.evp[1];
         if (S.sc_t != nullptr) X.sched_i[lp] = S.sc_i;
@@ -171,7 +185,10 @@ __device__ __forceinline__ Candidate make_candidate(const Station<C, PF> &S) {
     const int w = S.pick_root(t);
     c.t = t; c.valid = 1;
     if (w == 0) c.t_created = S.crtA;
-    else if (w == kRootProbe) c.t_created = S.crtP;
+    else if (w >= kRootProbe) {
+#pragma unroll
+        for (int j = 0; j < kMaxProbes; ++j) if (j == w - kRootProbe) c.t_created = S.crtP[j];
+    }
     else if (w == kRootSched) c.t_created = INT64_MIN;   // constructed before run()
     else {
 #pragma unroll
@@ -266,15 +283,19 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
     }
     for (int k = 0; k < 11; ++k) X.ev_kind[(size_t)k * n + lp] = 0;
     if (X.PA != nullptr) {   // probes start after the sources (core/simulation.py:156-160): first tick from start_ns
-        int64_t PA = kInfNs, p_arr = start_ns;
-        if (P.probe_metric[lp] != kProbeNone) {
-            p_arr = first_probe_tick(P.probe_rate[lp], start_ns, lp);
-            PA = p_arr;
+        uint32_t stamp = 1;
+        for (int j = 0; j < kMaxProbes; ++j) {
+            const size_t o = (size_t)j * n + lp;
+            int64_t PA = kInfNs, p_arr = start_ns;
+            if (P.probe_metric[o] != kProbeNone) {
+                p_arr = first_probe_tick(P.probe_rate[o], start_ns, lp);
+                PA = p_arr;
+            }
+            if (NX.next_time != nullptr && PA < NX.next_time[lp]) NX.next_time[lp] = PA;   // network engine: first pending event
+            X.PA[o] = PA; X.seqP[o] = stamp++; X.crtP[o] = start_ns; X.p_arr[o] = p_arr; X.p_n[o] = 0;
         }
-        if (NX.next_time != nullptr && PA < A) NX.next_time[lp] = PA;   // network engine: the LP's first pending event
-        X.PA[lp] = PA; X.seqP[lp] = 1; X.crtP[lp] = start_ns; X.p_arr[lp] = p_arr; X.p_n[lp] = 0;
         X.ev_probe[lp] = 0; X.ev_probe[(size_t)n + lp] = 0;
-        X.seq[lp] = 2;
+        X.seq[lp] = 1 + kMaxProbes;
         if (P.sched_off != nullptr) {
             X.sched_i[lp] = P.sched_off[lp];
             if (NX.next_time != nullptr && P.sched_off[lp] < P.sched_off[lp + 1]) {   // network engine: first pending event
@@ -660,7 +681,10 @@ __global__ void __launch_bounds__(64) hs_exact_run(StationParams P, NetParams NP
             int64_t t = X.A[lp];
             for (int i = 0; i < C; ++i) { const int64_t d = X.D[(size_t)i * n + lp]; t = d < t ? d : t; }
             if (X.PA != nullptr) {
-                if (P.probe_metric[lp] != kProbeNone && X.PA[lp] < t) t = X.PA[lp];
+                for (int j = 0; j < kMaxProbes; ++j) {
+                    const size_t o = (size_t)j * n + lp;
+                    if (P.probe_metric[o] != kProbeNone && X.PA[o] < t) t = X.PA[o];
+                }
                 if (P.sched_off != nullptr && X.sched_i[lp] < P.sched_off[lp + 1]) {
                     const int64_t sa = P.sched_t[X.sched_i[lp]];
                     t = sa < t ? sa : t;
@@ -723,8 +747,9 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF> &S, const Stati
     S.np = &NP; S.ns = &NX; S.send_idx = send_idx;
     S.tid = tid;
     S.inc_const = __ddiv_rn(1.0, S.rate);
-    S.p_metric = kProbeNone; S.PA = kInfNs; S.evp[0] = S.evp[1] = 0; S.p_n = 0; S.pcap = 0; S.seqP = 0; S.crtP = 0; S.p_arr = 0;
-    S.p_rate = 1.0; S.probe_t = nullptr; S.probe_v = nullptr;
+    S.n_probes = 0; S.evp[0] = S.evp[1] = 0; S.pcap = 0; S.probe_t = nullptr; S.probe_v = nullptr;
+#pragma unroll
+    for (int j = 0; j < kMaxProbes; ++j) { S.p_metric[j] = kProbeNone; S.PA[j] = kInfNs; S.seqP[j] = 0; S.crtP[j] = 0; S.p_arr[j] = 0; S.p_n[j] = 0; S.p_rate[j] = 1.0; }
     S.prof_kind = kProfConstant; S.prof_p0 = S.prof_p1 = S.prof_p2 = S.prof_p3 = 0.0;
     S.SA = kInfNs; S.sc_i = S.sc_end = 0; S.sc_t = P.sched_t; S.sc_idx = P.sched_idx;
     if constexpr (PF) {
@@ -738,8 +763,16 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF> &S, const Stati
             S.prof_p3 = P.prof_p[(size_t)3 * n + lp];
         }
         if (X.PA != nullptr) {      // probes on a network: windowed engine only
-            S.p_metric = P.probe_metric[lp]; S.p_rate = P.probe_rate[lp];
-            S.PA = X.PA[lp]; S.seqP = X.seqP[lp]; S.crtP = X.crtP[lp]; S.p_arr = X.p_arr[lp]; S.p_n = X.p_n[lp];
+#pragma unroll
+            for (int j = 0; j < kMaxProbes; ++j) {
+                const size_t o = (size_t)j * n + lp;
+                S.p_metric[j] = P.probe_metric[o];
+                if (S.p_metric[j] != kProbeNone) {
+                    S.n_probes = j + 1;
+                    S.p_rate[j] = P.probe_rate[o];
+                    S.PA[j] = X.PA[o]; S.seqP[j] = X.seqP[o]; S.crtP[j] = X.crtP[o]; S.p_arr[j] = X.p_arr[o]; S.p_n[j] = X.p_n[o];
+                }
+            }
             S.probe_t = L.probe_t + lp; S.probe_v = L.probe_v + lp; S.pcap = L.pcap;
         }
     }
@@ -829,7 +862,11 @@ __device__ __forceinline__ void store_net(NetStation<C, FAST, PF> &S, const Stat
     uint32_t tot = 0;
     if constexpr (PF) {
         if (X.PA != nullptr) {
-            X.PA[lp] = S.PA; X.seqP[lp] = S.seqP; X.crtP[lp] = S.crtP; X.p_arr[lp] = S.p_arr; X.p_n[lp] = S.p_n;
+#pragma unroll
+            for (int j = 0; j < kMaxProbes; ++j) if (j < S.n_probes) {
+                const size_t o = (size_t)j * n + lp;
+                X.PA[o] = S.PA[j]; X.seqP[o] = S.seqP[j]; X.crtP[o] = S.crtP[j]; X.p_arr[o] = S.p_arr[j]; X.p_n[o] = S.p_n[j];
+            }
             X.ev_probe[lp] += S.evp[0]; X.ev_probe[(size_t)n + lp] += S.evp[1];
             tot += S.evp[0] + S.evp[1];
             if (S.sc_t != nullptr && X.sched_i != nullptr) X.sched_i[lp] = S.sc_i;
@@ -953,7 +990,10 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
                 mine.t = t; mine.valid = 1;
                 if (w == 1) mine.t_created = S.crtA;
                 else if (w >= 64) mine.t_created = NX.bag_ts[(size_t)lp * NX.bag_cap + (w - 64)];
-                else if (w == 63) mine.t_created = S.crtP;
+                else if (w >= 56 && w < 56 + kMaxProbes) {
+#pragma unroll
+                    for (int j = 0; j < kMaxProbes; ++j) if (j == w - 56) mine.t_created = S.crtP[j];
+                }
                 else if (w == 62) mine.t_created = INT64_MIN;     // constructed before run()
                 else {
 #pragma unroll
@@ -1049,7 +1089,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
             const int w = W.pick_root(t);
             if (w == 1) (void)W.do_tick(t);
             else if (w >= 64) (void)W.do_msg(w - 64, t);
-            else if (w == 63) W.root_probe(t);                 // the SourceEvent of the Probe; its probe_event stays unprocessed
+            else if (w >= 56 && w < 56 + kMaxProbes) W.root_probe(w - 56, t);   // the SourceEvent of the Probe; its probe_event stays unprocessed
             else if (w == 62) W.root_sched(t);                 // the injected Request@Server; its QUEUE_NOTIFY stays unprocessed
             else (void)W.do_cont_core(w - 2, t);
             W.last_time = t;
@@ -1455,7 +1495,7 @@ __global__ void hs_shard_overshoot(StationParams P, NetParams NP, StationState X
     const int w = W.pick_root(t);
     if (w == 1) (void)W.do_tick(t);
     else if (w >= 64) (void)W.do_msg(w - 64, t);
-    else if (w == 63) W.root_probe(t);
+    else if (w >= 56 && w < 56 + kMaxProbes) W.root_probe(w - 56, t);
     else if (w == 62) W.root_sched(t);
     else (void)W.do_cont_core(w - 2, t);
     W.last_time = t;
@@ -1544,6 +1584,7 @@ struct hs_engine {
     bool any_timevarying = false, any_sched = false;   // (subsets of any_profile: what a network does not lower)
     bool any_profile = false;  // some source has a time-varying rate profile (or a probe: same kernel instantiation)
     bool any_probe = false;
+    int n_probe_slots = 1;     // probe slots in use (max probes on one LP): sizes the probe logs
     NetParams NP{};
     NetState NX{};
     ShardCtl SC{};             // wend_slots == nullptr: the engine holds the whole network
@@ -1878,21 +1919,30 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         h->any_profile = true;
         h->any_timevarying = true;
     }
-    // Probes (instrumentation/probe.py:81-164): at most one per LP; rate = 1.0 / interval as the reference computes it
-    std::vector<uint8_t> pm((size_t)n, (uint8_t)255);
-    std::vector<double> prate((size_t)n, 1.0);
+    // Probes (instrumentation/probe.py:81-164): up to kMaxProbes per LP (slot 0 = probe_metric, slots 1.. = probe_metric_more);
+    // rate = 1.0 / interval as the reference computes it
+    std::vector<uint8_t> pm((size_t)n * kMaxProbes, (uint8_t)255);
+    std::vector<double> prate((size_t)n * kMaxProbes, 1.0);
     double min_interval = 0.0;
-    for (int i = 0; i < n && st->probe_metric; ++i) {
-        const int m = st->probe_metric[i];
-        if (m == 255) continue;
-        if (m < 0 || m > 6) return fail(h, HS_E_UNSUPPORTED, "LP %d: probe metric %d is not lowered", i, m);
-        if (!st->probe_interval_s) return fail(h, HS_E_INVALID, "probe_interval_s is required with probe_metric");
-        const double iv = st->probe_interval_s[i];
-        if (!(iv > 0.0) || !std::isfinite(iv)) return fail(h, HS_E_INVALID, "Probe interval must be positive.");   // probe.py:29-30
-        pm[(size_t)i] = (uint8_t)m;
-        prate[(size_t)i] = 1.0 / iv;
-        if (min_interval == 0.0 || iv < min_interval) min_interval = iv;
-        h->any_probe = true;
+    int64_t n_prb_total = 0;
+    for (int j = 0; j < kMaxProbes; ++j) {
+        const uint8_t *pmj = j == 0 ? st->probe_metric : (st->probe_metric_more ? st->probe_metric_more + (size_t)(j - 1) * n : nullptr);
+        const double *pij = j == 0 ? st->probe_interval_s : (st->probe_interval_more ? st->probe_interval_more + (size_t)(j - 1) * n : nullptr);
+        for (int i = 0; i < n && pmj; ++i) {
+            const int m = pmj[i];
+            if (m == 255) continue;
+            if (m < 0 || m > 6) return fail(h, HS_E_UNSUPPORTED, "LP %d: probe metric %d is not lowered", i, m);
+            if (j > 0 && pm[(size_t)(j - 1) * n + i] == 255) return fail(h, HS_E_INVALID, "LP %d: probe slots must be filled from 0", i);
+            if (!pij) return fail(h, HS_E_INVALID, "probe_interval_s is required with probe_metric");
+            const double iv = pij[i];
+            if (!(iv > 0.0) || !std::isfinite(iv)) return fail(h, HS_E_INVALID, "Probe interval must be positive.");   // probe.py:29-30
+            pm[(size_t)j * n + i] = (uint8_t)m;
+            prate[(size_t)j * n + i] = 1.0 / iv;
+            if (min_interval == 0.0 || iv < min_interval) min_interval = iv;
+            h->any_probe = true;
+            if (j + 1 > h->n_probe_slots) h->n_probe_slots = j + 1;
+            ++n_prb_total;
+        }
     }
     if (h->any_probe) h->any_profile = true;                        // probes run on the general-path instantiation
     // Requests injected with Simulation.schedule(): validated here, run by the general-path instantiation too
@@ -1945,8 +1995,8 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
 #undef UP
     if ((rc = upload<uint8_t>(h, &h->P.prof_kind, pk.data(), (size_t)n, 0))) return rc;
     if ((rc = upload<double>(h, &h->P.prof_p, pp.data(), (size_t)n * 4, 0.0))) return rc;
-    if ((rc = upload<uint8_t>(h, &h->P.probe_metric, pm.data(), (size_t)n, 255))) return rc;
-    if ((rc = upload<double>(h, &h->P.probe_rate, prate.data(), (size_t)n, 1.0))) return rc;
+    if ((rc = upload<uint8_t>(h, &h->P.probe_metric, pm.data(), (size_t)n * kMaxProbes, 255))) return rc;
+    if ((rc = upload<double>(h, &h->P.probe_rate, prate.data(), (size_t)n * kMaxProbes, 1.0))) return rc;
     h->P.sched_off = nullptr; h->P.sched_t = nullptr;
     if (n_sched > 0) {
         if ((rc = upload<int64_t>(h, &h->P.sched_off, st->sched_off, (size_t)n + 1, 0))) return rc;
@@ -1994,7 +2044,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if ((rc = dev_alloc(h, &h->XI.sched_idx, (size_t)n_sched))) return rc;
         HS_HIP(h, hipMemset(h->XI.sched_idx, 0, (size_t)(n_sched > 0 ? n_sched : 1) * sizeof(uint32_t)));
         h->P.sched_idx = h->XI.sched_idx;
-        const int64_t n_init_lp = 2 + span;
+        const int64_t n_init_lp = 1 + kMaxProbes + span;
         h->XI.init_cap_lp = n_init_lp;
         h->XI.heap_cap_lp = n_init_lp + h->C + 32;
         h->XI.pool_cap_lp = 2 * n_init_lp + 64;
@@ -2011,17 +2061,33 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     if (h->cfg.mode == HS_MODE_SINGLE && (n_sched > 0 || h->any_probe)) {
         // The prologue (hs_exact.hpp): the reference's pre-run events in the order it constructs them
         std::vector<int32_t> so, po, sl((size_t)n_sched);
+        std::vector<uint8_t> pslot;
         std::vector<int64_t> se((size_t)n_sched);
         std::vector<uint8_t> seen((size_t)n, (uint8_t)0);
-        size_t n_src = 0, n_prb = 0;
-        for (int i = 0; i < n; ++i) {
+        size_t n_src = 0;
+        for (int i = 0; i < n; ++i)
             if ((st->src_kind ? st->src_kind[i] : HS_SRC_POISSON) != HS_SRC_NONE) ++n_src;
-            if (pm[(size_t)i] != 255) ++n_prb;
+        {   // probes in `probes=[...]` order: (LP, slot) pairs; default = LP-major, slot-minor
+            std::vector<uint8_t> taken((size_t)n * kMaxProbes, (uint8_t)0);
+            for (int64_t k = 0; k < n_prb_total; ++k) {
+                int lp = -1, slot = 0;
+                if (st->probe_order) { lp = st->probe_order[k]; slot = st->probe_slot_order ? st->probe_slot_order[k] : 0; }
+                else {
+                    int64_t seen_k = 0;
+                    for (int i = 0; i < n && lp < 0; ++i)
+                        for (int j = 0; j < kMaxProbes; ++j)
+                            if (pm[(size_t)j * n + i] != 255) { if (seen_k == k) { lp = i; slot = j; break; } ++seen_k; }
+                }
+                if (lp < 0 || lp >= n || slot < 0 || slot >= kMaxProbes || pm[(size_t)slot * n + lp] == 255 || taken[(size_t)slot * n + lp])
+                    return fail(h, HS_E_INVALID, "probe_order / probe_slot_order must list every probe exactly once");
+                taken[(size_t)slot * n + lp] = 1;
+                po.push_back(lp); pslot.push_back((uint8_t)slot);
+            }
         }
-        for (int pass = 0; pass < 2; ++pass) {
+        for (int pass = 0; pass < 1; ++pass) {
             const int32_t *ord = pass == 0 ? st->source_order : st->probe_order;
             std::vector<int32_t> &out = pass == 0 ? so : po;
-            const size_t want = pass == 0 ? n_src : n_prb;
+            const size_t want = n_src;
             std::fill(seen.begin(), seen.end(), (uint8_t)0);
             for (size_t k = 0; k < want; ++k) {
                 int lp = -1;
@@ -2059,6 +2125,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if ((rc = upload<int64_t>(h, &h->XI.sched_rank, sr.data(), sr.size(), 0))) return rc;
         if ((rc = upload<int32_t>(h, &h->XI.src_lp, so.data(), so.size(), 0))) return rc;
         if ((rc = upload<int32_t>(h, &h->XI.probe_lp, po.data(), po.size(), 0))) return rc;
+        if ((rc = upload<uint8_t>(h, &h->XI.probe_slot, pslot.data(), pslot.size(), 0))) return rc;
         if ((rc = upload<int32_t>(h, &h->XI.sched_lp, sl.data(), sl.size(), 0))) return rc;
         if ((rc = upload<int64_t>(h, &h->XI.sched_entry, se.data(), se.size(), 0))) return rc;
         h->XI.n_src = (int32_t)so.size(); h->XI.n_probe = (int32_t)po.size(); h->XI.n_sched = n_sched;
@@ -2090,13 +2157,14 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     AL(received, N); AL(sink_w, N); AL(total_service, N); AL(q, N); AL(grp_time, N); AL(last_time, N);
     AL(events, N); AL(ev_kind, N * 11);
     if (h->any_profile) {      // the general-path instantiation of the run kernel loads / stores the probe state of every LP
-        AL(PA, N); AL(seqP, N); AL(crtP, N); AL(p_arr, N); AL(p_n, N); AL(ev_probe, N * 2); AL(sched_i, N);
+        AL(PA, N * kMaxProbes); AL(seqP, N * kMaxProbes); AL(crtP, N * kMaxProbes); AL(p_arr, N * kMaxProbes);
+        AL(p_n, N * kMaxProbes); AL(ev_probe, N * 2); AL(sched_i, N);
     }
     if (h->any_probe) {
         h->L.pcap = (int64_t)(horizon_s / min_interval) + 8;
         if ((double)h->L.pcap * (double)n * 16.0 > 50e9) return fail(h, HS_E_INVALID, "probe logs would need %.1f GB", (double)h->L.pcap * n * 16.0 / 1e9);
-        if ((rc = dev_alloc(h, &h->L.probe_t, N * (size_t)h->L.pcap))) return rc;
-        if ((rc = dev_alloc(h, &h->L.probe_v, N * (size_t)h->L.pcap))) return rc;
+        if ((rc = dev_alloc(h, &h->L.probe_t, N * (size_t)h->L.pcap * (size_t)h->n_probe_slots))) return rc;
+        if ((rc = dev_alloc(h, &h->L.probe_v, N * (size_t)h->L.pcap * (size_t)h->n_probe_slots))) return rc;
     }
 #undef AL
     if ((rc = dev_alloc(h, &h->L.adm, N * (size_t)cap))) return rc;
@@ -2799,19 +2867,25 @@ int64_t hs_engine_read_sinks(hs_engine *h, int64_t *counts, int64_t *t_ns, int64
 }
 
 int64_t hs_engine_read_probe(hs_engine *h, int32_t lp, int64_t *t_ns, int64_t *values, int64_t cap) {
+    return hs_engine_read_probe_slot(h, lp, 0, t_ns, values, cap);
+}
+
+int64_t hs_engine_read_probe_slot(hs_engine *h, int32_t lp, int32_t slot, int64_t *t_ns, int64_t *values, int64_t cap) {
     if (!h || !h->have_stations) return fail(h, HS_E_STATE, "stations not set");
     if (lp < 0 || lp >= h->cfg.n_lp) return fail(h, HS_E_INVALID, "LP index %d out of range", lp);
-    if (!h->any_probe) return 0;
+    if (slot < 0 || slot >= kMaxProbes) return fail(h, HS_E_INVALID, "probe slot %d out of range", slot);
+    if (!h->any_probe || slot >= h->n_probe_slots) return 0;
     if (hipSetDevice(h->cfg.device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
         return fail(h, HS_E_HIP, "device synchronisation failed");
     int64_t cnt = 0;
-    if (hipMemcpy(&cnt, h->X.p_n + lp, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, HS_E_HIP, "memcpy");
+    if (hipMemcpy(&cnt, h->X.p_n + (size_t)slot * h->cfg.n_lp + lp, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, HS_E_HIP, "memcpy");
     if (cnt > h->L.pcap) cnt = h->L.pcap;
     if (cnt > cap) cnt = cap;
     if (cnt > 0) {
         int64_t *tmp = nullptr;
         if (hipMalloc(&tmp, (size_t)cnt * 8) != hipSuccess) return fail(h, HS_E_HIP, "hipMalloc of the read-back staging buffer failed");
-        const int64_t *cols[2] = {h->L.probe_t, h->L.probe_v};
+        const size_t so = (size_t)slot * (size_t)h->L.pcap * (size_t)h->cfg.n_lp;
+        const int64_t *cols[2] = {h->L.probe_t + so, h->L.probe_v + so};
         int64_t *dsts[2] = {t_ns, values};
         for (int c = 0; c < 2; ++c) {
             if (!dsts[c]) continue;

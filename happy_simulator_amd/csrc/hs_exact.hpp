@@ -74,6 +74,7 @@ constexpr uint16_t kXInitFlag = 0x8000;   // XEvent::slot: constructed before ru
 struct XInit {        // pre-run events in the order the reference constructs them
     const int32_t *src_lp;       // [n_src]   LPs of the Sources in `sources=[...]` order
     const int32_t *probe_lp;     // [n_probe] LPs of the Probes in `probes=[...]` order
+    const uint8_t *probe_slot;   // [n_probe] ... and their slot on that LP
     const int32_t *sched_lp;     // [n_sched] LP of the j-th Event handed to schedule(), in construction order
     const int64_t *sched_entry;  // [n_sched] its position in StationParams::sched_t
     const int64_t *sched_rank;   // [n_sched] its position among all Events the caller constructed (cancelled ones leave gaps)
@@ -158,9 +159,11 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
             X.seqA[lp] = 0; S.init_t[g] = X.A[lp];
             xpush(S, xev(X.A[lp], g++, XE_TICK, lp, 0, 0, kXInitFlag));
         }
-        if (P.probe_metric[lp] != kProbeNone && X.PA[lp] != kInfNs) {
-            X.seqP[lp] = (uint32_t)g; S.init_t[g] = X.PA[lp];
-            xpush(S, xev(X.PA[lp], g++, XE_PTICK, lp, 0, 0, kXInitFlag));
+        for (int j = 0; j < kMaxProbes; ++j) {
+            const size_t o = (size_t)j * (size_t)n + lp;
+            if (P.probe_metric[o] == kProbeNone || X.PA[o] == kInfNs) continue;
+            X.seqP[o] = (uint32_t)g; S.init_t[g] = X.PA[o];
+            xpush(S, xev(X.PA[o], g++, XE_PTICK, lp, 0, 0, (uint16_t)(kXInitFlag | j)));
         }
         const unsigned long long g0 = g;
         if (P.sched_off != nullptr)
@@ -188,11 +191,12 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
         }
         for (int i = 0; i < I.n_probe; ++i) {
             const int lp = I.probe_lp[i];
-            const int64_t a = X.PA[lp];
+            const size_t o = (size_t)I.probe_slot[i] * (size_t)n + lp;
+            const int64_t a = X.PA[o];
             if (a == kInfNs) continue;
-            X.seqP[lp] = (uint32_t)g;
+            X.seqP[o] = (uint32_t)g;
             S.init_t[g] = a;
-            xpush(S, xev(a, g++, XE_PTICK, lp, 0, 0, kXInitFlag));
+            xpush(S, xev(a, g++, XE_PTICK, lp, 0, 0, (uint16_t)(kXInitFlag | I.probe_slot[i])));
         }
         const unsigned long long g0 = g;
         for (int64_t j = 0; j < I.n_sched; ++j) {
@@ -383,21 +387,25 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
             break;
         case XE_PTICK: {
             // Source.handle_event with _ProbeEventProvider (instrumentation/probe.py:69-78): the daemon probe_event, then the next tick
+            const int pj = e.slot & 0xff;
+            const size_t o = (size_t)pj * N + lp;
             X.ev_probe[lp] += 1;
             const unsigned long long idx_pe = S.G++;
-            const int64_t a2 = probe_next_tick(P.probe_rate[lp], X.p_arr[lp], lp);
-            X.p_arr[lp] = a2;
-            xpush(S, xev(t, idx_pe, XE_PSAMPLE, lp));
+            const int64_t a2 = probe_next_tick(P.probe_rate[o], X.p_arr[o], lp);
+            X.p_arr[o] = a2;
+            xpush(S, xev(t, idx_pe, XE_PSAMPLE, lp, 0, 0, (uint16_t)pj));
             if (a2 != kInfNs) {
                 const unsigned long long idx_t = S.G++;
-                xpush(S, xev(a2, idx_t, XE_PTICK, lp));
-                X.PA[lp] = a2 < t ? kInfNs : a2; X.seqP[lp] = (uint32_t)idx_t; X.crtP[lp] = t;
-            } else X.PA[lp] = kInfNs;
+                xpush(S, xev(a2, idx_t, XE_PTICK, lp, 0, 0, (uint16_t)pj));
+                X.PA[o] = a2 < t ? kInfNs : a2; X.seqP[o] = (uint32_t)idx_t; X.crtP[o] = t;
+            } else X.PA[o] = kInfNs;
         } break;
         case XE_PSAMPLE: {                                                   // measure_callback (probe.py:51-66)
+            const int pj = e.slot & 0xff;
+            const size_t o = (size_t)pj * N + lp;
             X.ev_probe[N + lp] += 1;
             int64_t v = 0;
-            switch (P.probe_metric[lp]) {
+            switch (P.probe_metric[o]) {
                 case kProbeDepth: v = X.buf[lp]; break;
                 case kProbeActive: v = X.active[lp]; break;
                 case kProbeAccepted: v = X.accepted[lp]; break;
@@ -407,9 +415,9 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
                 case kProbeGenerated: v = X.generated[lp]; break;
                 default: break;
             }
-            const int64_t pn = X.p_n[lp];
-            if (pn < L.pcap) { L.probe_t[(size_t)pn * N + lp] = t; L.probe_v[(size_t)pn * N + lp] = v; } else overflow |= 1;
-            X.p_n[lp] = pn + 1;
+            const int64_t pn = X.p_n[o];
+            if (pn < L.pcap) { const size_t q = ((size_t)pj * (size_t)L.pcap + (size_t)pn) * N + lp; L.probe_t[q] = t; L.probe_v[q] = v; } else overflow |= 1;
+            X.p_n[o] = pn + 1;
         } break;
         default: break;
         }

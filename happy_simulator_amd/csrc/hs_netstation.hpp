@@ -215,10 +215,11 @@ struct NetStation {
     uint32_t ev[11];
     // Probe attached to this station (instrumentation/probe.py:81-164), as in hs_station.hpp: a daemon Source of its own
     // whose ticks sample one attribute (PF instantiations).
-    uint32_t p_metric, seqP;
-    double p_rate;
-    int64_t PA, crtP, p_arr, p_n, pcap;
-    int64_t *probe_t, *probe_v;
+    uint32_t p_metric[kMaxProbes], seqP[kMaxProbes];
+    double p_rate[kMaxProbes];
+    int64_t PA[kMaxProbes], crtP[kMaxProbes], p_arr[kMaxProbes], p_n[kMaxProbes], pcap;
+    int64_t *probe_t, *probe_v;     // slot j's log starts at probe_t + j * pcap * ls
+    int n_probes;
     uint32_t evp[2];
     // time-varying arrival rate of this station's Source (load/profile.py); 0 = constant.  Windowed engine only, like probes.
     uint32_t prof_kind;
@@ -461,19 +462,38 @@ struct NetStation {
     }
 
     // ---- Probe: Source.handle_event with _ProbeEventProvider, then the measurement callback (hs_station.hpp)
-    __device__ __forceinline__ bool has_probe() const { return PF && p_metric != kProbeNone; }
-    __device__ __forceinline__ void root_probe(int64_t t) {
-        evp[0]++;
-        qpush(Q_PSAMPLE);                                                 // the daemon probe_event, created first
-        const int64_t a2 = probe_next_tick(p_rate, p_arr, lp);            // ConstantArrivalTimeProvider over _ProbeProfile
-        p_arr = a2;
-        if (a2 <= t) PA = kInfNs;
-        else { PA = a2; seqP = seq++; crtP = t; }
+    __device__ __forceinline__ bool has_probe() const { return PF && n_probes > 0; }
+    __device__ __forceinline__ int64_t probe_min() const {
+        int64_t m = kInfNs;
+#pragma unroll
+        for (int j = 0; j < kMaxProbes; ++j) if (j < n_probes && PA[j] < m) m = PA[j];
+        return m;
     }
-    __device__ __forceinline__ void do_probe_sample(int64_t t) {
+    __device__ __forceinline__ bool probe_at(int64_t t) const {
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < kMaxProbes; ++j) any = any || (j < n_probes && PA[j] == t);
+        return any;
+    }
+    __device__ __forceinline__ void root_probe(int j, int64_t t) {
+        evp[0]++;
+        qpush(Q_PSAMPLE | ((uint32_t)j << 3));                            // the daemon probe_event, created first
+#pragma unroll
+        for (int i = 0; i < kMaxProbes; ++i) if (i == j) {
+            const int64_t a2 = probe_next_tick(p_rate[i], p_arr[i], lp);  // ConstantArrivalTimeProvider over _ProbeProfile
+            p_arr[i] = a2;
+            if (a2 <= t) PA[i] = kInfNs;
+            else { PA[i] = a2; seqP[i] = seq++; crtP[i] = t; }
+        }
+    }
+    __device__ __forceinline__ void do_probe_sample(int j, int64_t t) {
         evp[1]++;
+        uint32_t metric = kProbeNone;
+        int64_t pn = 0;
+#pragma unroll
+        for (int i = 0; i < kMaxProbes; ++i) if (i == j) { metric = p_metric[i]; pn = p_n[i]; p_n[i] = pn + 1; }
         int64_t v = 0;
-        switch (p_metric) {
+        switch (metric) {
             case kProbeDepth: v = buf; break;
             case kProbeActive: v = active; break;
             case kProbeAccepted: v = accepted; break;
@@ -483,8 +503,7 @@ struct NetStation {
             case kProbeGenerated: v = generated; break;
             default: break;
         }
-        if (p_n < pcap) { probe_t[p_n * ls] = t; probe_v[p_n * ls] = v; } else overflow = 1;
-        p_n++;
+        if (pn < pcap) { const int64_t o = ((int64_t)j * pcap + pn) * ls; probe_t[o] = t; probe_v[o] = v; } else overflow = 1;
     }
 
     // ---- Simulation.schedule(): the injected Event IS the Request@Server
@@ -961,7 +980,9 @@ struct NetStation {
 #pragma unroll
         for (int i = 0; i < C; ++i)
             if (D[i] == t && (best == 0 || (int32_t)(seqD[i] - bs) < 0)) { best = 2 + i; bc = crtD[i]; bs = seqD[i]; }
-        if (has_probe() && PA == t && (best == 0 || (int32_t)(seqP - bs) < 0)) { best = 63; bc = crtP; bs = seqP; }
+#pragma unroll
+        for (int j = 0; j < kMaxProbes; ++j)     // probe j's pending tick: root code 56 + j
+            if (PF && j < n_probes && PA[j] == t && (best == 0 || (int32_t)(seqP[j] - bs) < 0)) { best = 56 + j; bc = crtP[j]; bs = seqP[j]; }
         for (int i = 0; bmin == t && i < bag_n; ++i) {
             if (bg_t(i) != t) continue;
             const int64_t ts = bg_ts(i);
@@ -977,7 +998,7 @@ struct NetStation {
     __device__ __forceinline__ void run_root(int w, int64_t t) {
         if (w == 1) root_tick(t);
         else if (w >= 64) root_msg(w - 64, t);
-        else if (PF && w == 63) { if constexpr (PF) root_probe(t); }
+        else if (PF && w >= 56 && w < 56 + kMaxProbes) { if constexpr (PF) root_probe(w - 56, t); }
         else if (PF && w == 62) { if constexpr (PF) root_sched(t); }
         else root_cont(w - 2, t);
     }
@@ -991,7 +1012,7 @@ struct NetStation {
                 case Q_DELIVER: { const uint32_t sm = do_deliver_work(t, false, 0); if (sm) qpush(Q_CONT | ((sm - 1) << 3)); } break;
                 case Q_TICK: root_tick(t); break;
                 case Q_CONT: root_cont((int)(code >> 3), t); break;
-                case Q_PSAMPLE: if constexpr (PF) do_probe_sample(t); break;
+                case Q_PSAMPLE: if constexpr (PF) do_probe_sample((int)(code >> 3), t); break;
                 default: break;
             }
         }
@@ -1005,7 +1026,7 @@ struct NetStation {
         int64_t t = A;
 #pragma unroll
         for (int i = 0; i < C; ++i) t = D[i] < t ? D[i] : t;
-        if (has_probe() && PA < t) t = PA;
+        if (has_probe()) { const int64_t pm = probe_min(); if (pm < t) t = pm; }
         if (has_sched() && SA < t) t = SA;
         return t;
     }
@@ -1047,7 +1068,7 @@ struct NetStation {
         const int64_t buf1 = buf + (acc ? 1 : 0);
         const bool deliver = poll && buf1 > 0;
         if constexpr (PF) {
-            if (has_probe() && PA == t) cnt += 2;                     // the rare roots: always the general path
+            if (has_probe() && probe_at(t)) cnt += 2;                 // the rare roots: always the general path
             if (has_sched() && SA == t) cnt += 2;
             if (tick && prof_kind != kProfConstant) cnt += 2;         // (its next arrival is a numerical inversion)
         }
@@ -1152,7 +1173,7 @@ struct NetStation {
         int mi = -1;
         if (bmin == t)                    // (the bag's earliest arrival is in a register: no scan for local-only groups)
             for (int i = 0; i < bag_n; ++i) if (bg_t(i) == t) { ++n_at; mi = i; }
-        if (has_probe() && PA == t) n_at += 2;                           // a probe tick: always the general path
+        if (has_probe() && probe_at(t)) n_at += 2;                       // a probe tick: always the general path
         if (has_sched() && SA == t) n_at += 2;                           // so is a scheduled Request
         if (n_at == 1 && !force_general) {
             bool general = false, want_poll = false, have_created = false;

@@ -29,7 +29,8 @@ namespace hs {
 
 // in-group event codes (low 3 bits) | slot << 3
 enum : uint32_t { Q_PSAMPLE = 0, Q_ENQ = 1, Q_NOTIFY = 2, Q_POLL = 3, Q_DELIVER = 4, Q_TICK = 5, Q_CONT = 6, Q_SINK = 7 };
-constexpr int kRootProbe = 99;  // pick_root: the pending probe tick
+constexpr int kMaxProbes = 4;   // Probes per LP (Probe.on_many: several metrics of one entity, instrumentation/probe.py:119-164)
+constexpr int kRootProbe = 100; // pick_root: the pending tick of probe j is kRootProbe + j
 constexpr int kRootSched = 98;  // pick_root: the next Request injected with Simulation.schedule()
 
 constexpr int kBlock = 256;     // LPs per workgroup (4 wavefronts)
@@ -90,8 +91,8 @@ struct StationParams {          // read-only, [n_lp] each
     const uint64_t *stream_base;
     const uint8_t *prof_kind;       // time-varying arrival rate (hs_profile.hpp): 0 constant, 1 linear ramp, 2 spike
     const double *prof_p;           // [4][n_lp]
-    const uint8_t *probe_metric;    // Probe attached to this LP: kProbe* metric, 255 = none
-    const double *probe_rate;       // 1.0 / interval  (_ProbeProfile.rate, instrumentation/probe.py:27-35)
+    const uint8_t *probe_metric;    // [kMaxProbes][n_lp] Probes attached to this LP: kProbe* metric, 255 = none (slots fill from 0)
+    const double *probe_rate;       // [kMaxProbes][n_lp] 1.0 / interval  (_ProbeProfile.rate, instrumentation/probe.py:27-35)
     // Simulation.schedule() (core/simulation.py:195-206): Requests injected before run(), per LP sorted by time (stable in
     // call order): LP lp owns sched_t[sched_off[lp] .. sched_off[lp + 1]).  null = none.
     const int64_t *sched_off;       // [n_lp + 1]
@@ -131,9 +132,9 @@ struct StationState {           // read-write; [n_lp] each unless noted
     int64_t *events;            // events processed by this LP
     int64_t *ev_kind;           // [11][n_lp] station / network kinds
     // Probe (PF instantiation only)
-    int64_t *PA;                // pending probe tick (kInfNs: none)
-    uint32_t *seqP;
-    int64_t *crtP, *p_arr, *p_n;   // creation time of the pending tick, the probe provider's current_time, samples taken
+    int64_t *PA;                // [kMaxProbes][n_lp] pending probe tick (kInfNs: none)
+    uint32_t *seqP;             // [kMaxProbes][n_lp]
+    int64_t *crtP, *p_arr, *p_n;   // [kMaxProbes][n_lp] creation time of the pending tick, the provider's current_time, samples taken
     int64_t *ev_probe;          // [2][n_lp] SourceEvent@Probe, probe_event
     int64_t *sched_i;           // [n_lp] index into sched_t of the LP's next scheduled Request (PF instantiation only)
 };
@@ -144,7 +145,7 @@ struct RecordLogs {
     int64_t *sink_created;      // [cap][n_lp] created_at of the m-th sink record (C > 1; C == 1 aliases adm)
     int64_t *sink_created_own;  // the separately allocated column (null when the alias is the only option)
     int64_t cap;
-    int64_t *probe_t, *probe_v; // [pcap][n_lp] sample time / sampled value
+    int64_t *probe_t, *probe_v; // [kMaxProbes][pcap][n_lp] sample time / sampled value
     int64_t pcap;
 };
 
@@ -202,10 +203,11 @@ struct Station {
     double inc_const;           // constant source: 1.0 / rate
     Profile prof;               // kind != 0: the ring holds target AREAS (E, not E / rate) and next_arrival() inverts the profile
     // Probe (PF): a daemon Source of its own (instrumentation/probe.py:81-164) whose ticks sample this LP
-    uint32_t p_metric, seqP;
-    double p_rate;
-    int64_t PA, crtP, p_arr, p_n, pcap;
-    int64_t *probe_t, *probe_v;
+    uint32_t p_metric[kMaxProbes], seqP[kMaxProbes];
+    double p_rate[kMaxProbes];
+    int64_t PA[kMaxProbes], crtP[kMaxProbes], p_arr[kMaxProbes], p_n[kMaxProbes], pcap;
+    int64_t *probe_t, *probe_v;     // slot j's log starts at probe_t + j * pcap * ls
+    int n_probes;
     uint32_t evp[2];
     // Simulation.schedule() (PF): the next injected Request; it was constructed before run(), so it precedes every
     // run-time event of the same nanosecond
@@ -423,21 +425,41 @@ struct Station {
     }
 
     // ---- Probe: Source.handle_event with _ProbeEventProvider, then the measurement callback ------------------
-    __device__ __forceinline__ bool has_probe() const { return PF && p_metric != kProbeNone; }
-    __device__ __forceinline__ void root_probe(int64_t t) {
+    __device__ __forceinline__ bool has_probe() const { return PF && n_probes > 0; }
+    __device__ __forceinline__ int64_t probe_min() const {
+        int64_t m = kInfNs;
+#pragma unroll
+        for (int j = 0; j < kMaxProbes; ++j) if (j < n_probes && PA[j] < m) m = PA[j];
+        return m;
+    }
+    __device__ __forceinline__ bool probe_at(int64_t t) const {
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < kMaxProbes; ++j) any = any || (j < n_probes && PA[j] == t);
+        return any;
+    }
+    __device__ __forceinline__ void root_probe(int j, int64_t t) {
         evp[0]++;
         Profile pp;
-        pp.kind = kProfGeneralConstant; pp.p0 = p_rate; pp.p1 = pp.p2 = pp.p3 = 0.0; pp.owner = lp;
-        qpush(Q_PSAMPLE);                                                 // the daemon probe_event, created first
-        const int64_t a2 = prof_next_arrival(pp, p_arr, 1.0);             // ConstantArrivalTimeProvider over _ProbeProfile
-        p_arr = a2;
-        if (a2 <= t) PA = kInfNs;
-        else { PA = a2; seqP = seq++; crtP = t; }
+        pp.kind = kProfGeneralConstant; pp.p1 = pp.p2 = pp.p3 = 0.0; pp.owner = lp;
+        qpush(Q_PSAMPLE | ((uint32_t)j << 3));                            // the daemon probe_event, created first
+#pragma unroll
+        for (int i = 0; i < kMaxProbes; ++i) if (i == j) {
+            pp.p0 = p_rate[i];
+            const int64_t a2 = prof_next_arrival(pp, p_arr[i], 1.0);      // ConstantArrivalTimeProvider over _ProbeProfile
+            p_arr[i] = a2;
+            if (a2 <= t) PA[i] = kInfNs;
+            else { PA[i] = a2; seqP[i] = seq++; crtP[i] = t; }
+        }
     }
-    __device__ __forceinline__ void do_probe_sample(int64_t t) {
+    __device__ __forceinline__ void do_probe_sample(int j, int64_t t) {
         evp[1]++;
+        uint32_t metric = kProbeNone;
+        int64_t pn = 0;
+#pragma unroll
+        for (int i = 0; i < kMaxProbes; ++i) if (i == j) { metric = p_metric[i]; pn = p_n[i]; p_n[i] = pn + 1; }
         int64_t v = 0;
-        switch (p_metric) {
+        switch (metric) {
             case kProbeDepth: v = buf; break;
             case kProbeActive: v = active; break;
             case kProbeAccepted: v = accepted; break;
@@ -447,8 +469,7 @@ struct Station {
             case kProbeGenerated: v = generated; break;
             default: break;
         }
-        if (p_n < pcap) { probe_t[p_n * ls] = t; probe_v[p_n * ls] = v; } else overflow = 1;
-        p_n++;
+        if (pn < pcap) { const int64_t o = ((int64_t)j * pcap + pn) * ls; probe_t[o] = t; probe_v[o] = v; } else overflow = 1;
     }
 
     // ---- Simulation.schedule(): the injected Event IS the Request@Server (QueuedResource.handle_event -> enqueue)
@@ -503,13 +524,15 @@ struct Station {
         for (int i = 0; i < C; ++i)
             if (D[i] == t && (best < 0 || (int32_t)(seqD[i] - bs) < 0)) { best = 1 + i; bs = seqD[i]; }
         if constexpr (PF) {
-            if (has_probe() && PA == t && (best < 0 || (int32_t)(seqP - bs) < 0)) { best = kRootProbe; bs = seqP; }
+#pragma unroll
+            for (int j = 0; j < kMaxProbes; ++j)
+                if (j < n_probes && PA[j] == t && (best < 0 || (int32_t)(seqP[j] - bs) < 0)) { best = kRootProbe + j; bs = seqP[j]; }
         }
         return best;
     }
     __device__ __forceinline__ void run_root(int which, int64_t t) {
         if (which == 0) root_tick(t);
-        else if (PF && which == kRootProbe) root_probe(t);
+        else if (PF && which >= kRootProbe) root_probe(which - kRootProbe, t);
         else if (PF && which == kRootSched) root_sched(t);
         else root_cont(which - 1, t);
     }
@@ -530,7 +553,7 @@ struct Station {
                 case Q_TICK: root_tick(t); break;
                 case Q_CONT: root_cont((int)(code >> 3), t); break;
                 case Q_SINK: do_sink(); break;
-                case Q_PSAMPLE: if constexpr (PF) do_probe_sample(t); break;
+                case Q_PSAMPLE: if constexpr (PF) do_probe_sample((int)(code >> 3), t); break;
                 default: break;
             }
         }
@@ -550,7 +573,7 @@ struct Station {
         int64_t t = A;
 #pragma unroll
         for (int i = 0; i < C; ++i) t = D[i] < t ? D[i] : t;
-        if constexpr (PF) { if (has_probe() && PA < t) t = PA; if (SA < t) t = SA; }
+        if constexpr (PF) { if (has_probe()) { const int64_t pm = probe_min(); if (pm < t) t = pm; } if (SA < t) t = SA; }
         return t;
     }
 
@@ -558,7 +581,7 @@ struct Station {
         int n_at = (A == t) ? 1 : 0;
 #pragma unroll
         for (int i = 0; i < C; ++i) n_at += (D[i] == t) ? 1 : 0;
-        if constexpr (PF) { if (has_probe() && PA == t) n_at += 2; }      // a probe tick: always the general path
+        if constexpr (PF) { if (has_probe() && probe_at(t)) n_at += 2; }  // a probe tick: always the general path
         if constexpr (PF) { if (SA == t) n_at += 2; }                     // so is a scheduled Request
         if (n_at == 1 && !force_general) {
             // Fast path: one event in flight at a time.  Both kinds of root converge on ONE poll/deliver/work

@@ -38,6 +38,9 @@ class StationArrays:
     # construction order of the reference's pre-run events (include/hs_engine.h): None = LP order / array order
     source_order: np.ndarray | None = None          # LP indices of the Sources in `sources=[...]` order
     probe_order: np.ndarray | None = None           # LP indices of the Probes in `probes=[...]` order
+    probe_metric_more: np.ndarray | None = None     # [3, n] further probes of an LP (slots 1..3; N.PROBE_NONE = none)
+    probe_interval_more: np.ndarray | None = None   # [3, n]
+    probe_slot_order: np.ndarray | None = None      # slot of every entry of probe_order (None = 0 everywhere)
     sched_rank: np.ndarray | None = None            # like sched_time_ns: the Event's position among all constructed Events
 
     @staticmethod
@@ -142,18 +145,29 @@ class StationEngine:
                     raise ValueError("sched_rank must hold one position >= 0 per scheduled time")
                 keep.append(co)
                 st.sched_rank = co.ctypes.data if len(co) else None
-        for name, mask in (("source_order", np.asarray(stations.src_kind) != N.SRC_NONE),
-                           ("probe_order", None if stations.probe_metric is None
-                            else np.asarray(stations.probe_metric) != N.PROBE_NONE)):
-            a = getattr(stations, name)
-            if a is None:
-                continue
-            a = np.ascontiguousarray(a, np.int32)
-            want = np.flatnonzero(mask) if mask is not None else np.zeros(0, np.int64)
-            if sorted(a.tolist()) != want.tolist():
-                raise ValueError(f"{name} must list exactly the LPs that carry one, each once")
+        if stations.source_order is not None:
+            a = np.ascontiguousarray(stations.source_order, np.int32)
+            if sorted(a.tolist()) != np.flatnonzero(np.asarray(stations.src_kind) != N.SRC_NONE).tolist():
+                raise ValueError("source_order must list exactly the LPs that carry a Source, each once")
             keep.append(a)
-            setattr(st, name, a.ctypes.data if len(a) else None)
+            st.source_order = a.ctypes.data if len(a) else None
+        if stations.probe_metric_more is not None:
+            pm = np.ascontiguousarray(stations.probe_metric_more, np.uint8)
+            pi = np.ascontiguousarray(stations.probe_interval_more, np.float64)
+            if pm.shape != (3, self.n) or pi.shape != (3, self.n):
+                raise ValueError("probe_metric_more / probe_interval_more must have shape (3, n)")
+            keep += [pm, pi]
+            st.probe_metric_more, st.probe_interval_more = pm.ctypes.data, pi.ctypes.data
+        if stations.probe_order is not None:        # (the engine checks that every (LP, slot) probe is listed exactly once)
+            a = np.ascontiguousarray(stations.probe_order, np.int32)
+            keep.append(a)
+            st.probe_order = a.ctypes.data if len(a) else None
+            if stations.probe_slot_order is not None:
+                b = np.ascontiguousarray(stations.probe_slot_order, np.uint8)
+                if b.shape != a.shape:
+                    raise ValueError("probe_slot_order must have one entry per entry of probe_order")
+                keep.append(b)
+                st.probe_slot_order = b.ctypes.data if len(b) else None
         self.n_links = 0
         try:
             self._check(self._lib.hs_engine_set_stations(self._h, C.byref(st)))
@@ -281,11 +295,11 @@ class StationEngine:
         got = self._check(self._lib.hs_engine_read_sink(self._h, lp, t.ctypes.data, cr.ctypes.data, cap))
         return t[:got], cr[:got]
 
-    def read_probe(self, lp: int, cap: int = 1 << 22):
-        """(sample ns, value) of the LP's Probe in sampling order."""
+    def read_probe(self, lp: int, slot: int = 0, cap: int = 1 << 22):
+        """(sample ns, value) of the Probe in `slot` of the LP, in sampling order."""
         t = np.zeros(cap, np.int64)
         v = np.zeros(cap, np.int64)
-        got = self._check(self._lib.hs_engine_read_probe(self._h, lp, t.ctypes.data, v.ctypes.data, cap))
+        got = self._check(self._lib.hs_engine_read_probe_slot(self._h, lp, slot, t.ctypes.data, v.ctypes.data, cap))
         return t[:got].copy(), v[:got].copy()
 
     def read_sinks(self):

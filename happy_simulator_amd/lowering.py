@@ -31,7 +31,7 @@ class UnsupportedTopology(NotImplementedError):
 
 @dataclass
 class Station:
-    probe: object | None = None                      # the Probe sampling one of this station's entities
+    probes: list = field(default_factory=list)       # the Probes sampling this station's entities (up to 4: engine slots)
     source: Source | None = None
     server: Server | None = None
     sink: _RecordSink | None = None
@@ -85,14 +85,20 @@ class LoweredGraph:
                 a.svc_kind[i] = N.LAT_NO_SERVER
                 a.svc_mean_s[i] = 0.0
             a.egress[i] = N.EGRESS_SINK if st.sink is not None else N.EGRESS_NONE
-            if st.probe is not None:
+            for slot, pr in enumerate(st.probes):
                 if a.probe_metric is None:
                     a.probe_metric = np.full(n, N.PROBE_NONE, np.uint8)
                     a.probe_interval_s = np.ones(n, np.float64)
-                m = st.probe.metric
-                a.probe_metric[i] = N.PROBE_METRICS["active_requests" if m == "utilization" else
-                                                    "generated_count" if m == "_generated_count" else m]
-                a.probe_interval_s[i] = st.probe.interval
+                if slot > 0 and a.probe_metric_more is None:
+                    a.probe_metric_more = np.full((3, n), N.PROBE_NONE, np.uint8)
+                    a.probe_interval_more = np.ones((3, n), np.float64)
+                m = pr.metric
+                code = N.PROBE_METRICS["active_requests" if m == "utilization" else
+                                       "generated_count" if m == "_generated_count" else m]
+                if slot == 0:
+                    a.probe_metric[i], a.probe_interval_s[i] = code, pr.interval
+                else:
+                    a.probe_metric_more[slot - 1, i], a.probe_interval_more[slot - 1, i] = code, pr.interval
         return a
 
     def network_arrays(self, bag_capacity: int = 0) -> NetworkArrays:
@@ -179,20 +185,20 @@ def attach_probes(g: LoweredGraph, probes: list) -> None:
         if id(pr.target) in shared:
             raise UnsupportedTopology(f"probe '{pr.name}': a Sink shared by several stations is not sampled on the engine yet")
         st = g.stations[i]
-        if st.probe is not None:
-            raise UnsupportedTopology(f"station of '{pr.target.name}' already has a probe; one Probe per station is lowered")
+        if len(st.probes) >= 4:
+            raise UnsupportedTopology(f"station of '{pr.target.name}' already has four probes (the engine's slots per station)")
         kinds = {"generated_count": Source, "_generated_count": Source, "events_received": _SINKS}
         want = kinds.get(pr.metric, Server)
         if not isinstance(pr.target, want):
             raise UnsupportedTopology(f"probe '{pr.name}': metric '{pr.metric}' is not an attribute of {type(pr.target).__name__}")
-        st.probe = pr
+        st.probes.append(pr)
 
 
 def write_back_probes(g: LoweredGraph, eng) -> None:
     for i, st in enumerate(g.stations):
-        if st.probe is not None:
-            t, v = eng.read_probe(i)
-            st.probe.data_sink._set(t, v, st.server.concurrency if st.probe.metric == "utilization" else None)
+        for slot, pr in enumerate(st.probes):
+            t, v = eng.read_probe(i, slot)
+            pr.data_sink._set(t, v, st.server.concurrency if pr.metric == "utilization" else None)
 
 
 def lower(sources: list, entities: list) -> LoweredGraph:

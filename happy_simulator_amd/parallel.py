@@ -85,6 +85,11 @@ def _concat(arrs: list[StationArrays]) -> StationArrays:
                                            else np.full(a.n, N.PROBE_NONE, np.uint8) for a in arrs])
         out.probe_interval_s = np.concatenate([a.probe_interval_s if a.probe_interval_s is not None
                                                else np.ones(a.n, np.float64) for a in arrs])
+    if any(a.probe_metric_more is not None for a in arrs):
+        out.probe_metric_more = np.concatenate([a.probe_metric_more if a.probe_metric_more is not None
+                                                else np.full((3, a.n), N.PROBE_NONE, np.uint8) for a in arrs], axis=1)
+        out.probe_interval_more = np.concatenate([a.probe_interval_more if a.probe_interval_more is not None
+                                                  else np.ones((3, a.n), np.float64) for a in arrs], axis=1)
     if any(a.sched_off is not None for a in arrs):
         offs, times, ranks, base = [np.zeros(1, np.int64)], [], [], 0
         for a in arrs:
@@ -105,9 +110,10 @@ def _concat(arrs: list[StationArrays]) -> StationArrays:
 def write_back_probes_sharded(g, sn) -> None:
     """Probe samples of the stations this process's shards own."""
     for i, stn in enumerate(g.stations):
-        if stn.probe is not None and any(s.lo <= i < s.hi for s in sn.shards):
-            t, v = sn.read_probe(i)
-            stn.probe.data_sink._set(t, v, stn.server.concurrency if stn.probe.metric == "utilization" else None)
+        if stn.probes and any(s.lo <= i < s.hi for s in sn.shards):
+            for slot, pr in enumerate(stn.probes):
+                t, v = sn.read_probe(i, slot)
+                pr.data_sink._set(t, v, stn.server.concurrency if pr.metric == "utilization" else None)
 
 
 class _LpOffset:
@@ -116,8 +122,8 @@ class _LpOffset:
     def __init__(self, eng, off):
         self._eng, self._off = eng, off
 
-    def read_probe(self, i):
-        return self._eng.read_probe(self._off + i)
+    def read_probe(self, i, slot=0):
+        return self._eng.read_probe(self._off + i, slot)
 
 
 def _run_independent(sims: list[Simulation], seeds: list[int], device: int = 0,

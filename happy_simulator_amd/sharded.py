@@ -169,6 +169,8 @@ def shard_arrays(stations: StationArrays, net: NetworkArrays, lo: int, hi: int):
         src_profile_params=None if stations.src_profile_params is None else stations.src_profile_params[sl],
         probe_metric=None if stations.probe_metric is None else stations.probe_metric[sl],
         probe_interval_s=None if stations.probe_interval_s is None else stations.probe_interval_s[sl],
+        probe_metric_more=None if stations.probe_metric_more is None else np.asarray(stations.probe_metric_more)[:, sl],
+        probe_interval_more=None if stations.probe_interval_more is None else np.asarray(stations.probe_interval_more)[:, sl],
         sched_off=None if stations.sched_off is None else (np.asarray(stations.sched_off)[lo:hi + 1] - int(stations.sched_off[lo])),
         sched_time_ns=None if stations.sched_off is None else np.asarray(stations.sched_time_ns)[
             int(stations.sched_off[lo]):int(stations.sched_off[hi])])
@@ -469,11 +471,11 @@ class ShardedNetwork:
                 net[k][s.gids] += ns[k]
         return stats, counts, np.concatenate(ts), np.concatenate(crs), net
 
-    def read_probe(self, station: int):
-        """Samples of the Probe on network-wide station `station` (owned by one of this process's shards)."""
+    def read_probe(self, station: int, slot: int = 0):
+        """Samples of the Probe in `slot` of network-wide station `station` (owned by one of this process's shards)."""
         for s in self.shards:
             if s.lo <= station < s.hi:
-                return s.engine.read_probe(station - s.lo)
+                return s.engine.read_probe(station - s.lo, slot)
         raise IndexError(f"station {station} is not on this process's shards")
 
     def close(self):

@@ -166,10 +166,12 @@ class Simulation:
         horizon_s = (end_ns - self._start_time.nanoseconds) / 1e9
         arrays = g.arrays()
         # the order in which Simulation.__init__ constructs the first SourceEvents / probe ticks (core/simulation.py:145-160)
-        st_of = {id(o): i for i, st in enumerate(g.stations) for o in (st.source, st.probe) if o is not None}
+        st_of = {id(st.source): i for i, st in enumerate(g.stations) if st.source is not None}
         arrays.source_order = np.array([st_of[id(s)] for s in self._sources], np.int32)
         if self._probes:
-            arrays.probe_order = np.array([st_of[id(p)] for p in self._probes], np.int32)
+            where = {id(pr): (i, slot) for i, st in enumerate(g.stations) for slot, pr in enumerate(st.probes)}
+            arrays.probe_order = np.array([where[id(p)][0] for p in self._probes], np.int32)
+            arrays.probe_slot_order = np.array([where[id(p)][1] for p in self._probes], np.uint8)
         cancelled_ns = self._schedule_arrays(g, arrays)
         if net is not None and arrays.n > self._resident_stations():
             return self._run_time_shared(g, arrays, net, end_ns, horizon_s, wall0, cancelled_ns)

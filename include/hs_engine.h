@@ -121,7 +121,7 @@ typedef struct hs_stations {
     /* Probe(target, metric, interval) attached to the LP's Source / Server / Sink (instrumentation/probe.py:81-164):
      * a daemon Source of its own that samples getattr(target, metric) every `interval` seconds (tick times follow
      * ConstantArrivalTimeProvider over _ProbeProfile: the general numerical path, like the reference).  Each tick is two
-     * reference events (SourceEvent@Probe, probe_event).  One probe per LP.  NULL = no probes. */
+     * reference events (SourceEvent@Probe, probe_event).  Up to four probes per LP (probe_metric_more).  NULL = no probes. */
     const uint8_t *probe_metric;       /* hs_probe_metric; 255 = none */
     const double *probe_interval_s;    /* > 0 */
     /* Simulation.schedule(Event(time, "Request", target=<the LP's Server>)) before run() (core/simulation.py:195-206):
@@ -140,6 +140,12 @@ typedef struct hs_stations {
      * array order. */
     const int32_t *source_order;       /* [number of LPs with a Source] LP indices in `sources=` order */
     const int32_t *probe_order;        /* [number of LPs with a Probe] LP indices in `probes=` order */
+    /* More than one Probe on an LP (Probe.on_many, instrumentation/probe.py:119-164): slots 1 .. 3 (slot 0 = probe_metric /
+     * probe_interval_s above); slots are filled from 0.  probe_slot_order[k] = slot of the k-th entry of probe_order (an LP
+     * with several probes appears several times there); NULL = every entry is slot 0. */
+    const uint8_t *probe_metric_more;  /* [3][n_lp] hs_probe_metric; 255 = none */
+    const double *probe_interval_more; /* [3][n_lp] */
+    const uint8_t *probe_slot_order;   /* [number of probes] */
     const int64_t *sched_rank;         /* [sched_off[n_lp]], indexed like sched_time_ns: the Event's position among ALL the
                                           Events the caller constructed for schedule(), distinct and >= 0 (an Event that was
                                           cancelled before run() keeps its position -- it consumed a sort index -- but is not
@@ -432,6 +438,8 @@ int hs_sink_latency_stats(int32_t device, int64_t n, const int64_t *t_ns, const 
 /* Samples of the LP's Probe in sampling order: (sample time ns, value) -- what the reference appends to the probe's
  * Data container (instrumentation/probe.py:63).  Returns the number copied or a negative hs_status. */
 int64_t hs_engine_read_probe(hs_engine *h, int32_t lp, int64_t *t_ns, int64_t *values, int64_t cap);
+/* ... of the probe in `slot` (0 .. 3) of the LP */
+int64_t hs_engine_read_probe_slot(hs_engine *h, int32_t lp, int32_t slot, int64_t *t_ns, int64_t *values, int64_t cap);
 
 const char *hs_last_error(const hs_engine *h);
 const char *hs_last_global_error(void);

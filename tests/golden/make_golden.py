@@ -241,21 +241,24 @@ def run_sim(spec, chain_ids, seed, want_trace):
     sources, entities, handles = build_chains(spec, chain_ids, seed)
     probes, probe_data = [], {}
     for local, c in enumerate(chain_ids):
-        pr = (spec.get("probes") or [None] * spec["n_chains"])[c]
-        if pr is None:
+        prs = (spec.get("probes") or [None] * spec["n_chains"])[c]
+        if prs is None:
             continue
-        who, attr = PROBE_METRICS[pr[0]]
-        target = {"source": handles[local][0], "server": handles[local][1], "sink": handles[local][2]}[who]
-        probe, data = Probe.on(target, attr, interval=pr[1])
-        data._ns = []                  # Data keeps seconds; keep the exact nanoseconds beside it
+        if not isinstance(prs[0], (list, tuple)):
+            prs = [prs]                # one probe; a list of [metric, interval] pairs = several probes on one chain
+        for j, pr in enumerate(prs):
+            who, attr = PROBE_METRICS[pr[0]]
+            target = {"source": handles[local][0], "server": handles[local][1], "sink": handles[local][2]}[who]
+            probe, data = Probe.on(target, attr, interval=pr[1])
+            data._ns = []              # Data keeps seconds; keep the exact nanoseconds beside it
 
-        def add_stat(value, time, _orig=data.add_stat, _d=data):
-            _d._ns.append((time.nanoseconds, value))
-            _orig(value, time)
+            def add_stat(value, time, _orig=data.add_stat, _d=data):
+                _d._ns.append((time.nanoseconds, value))
+                _orig(value, time)
 
-        data.add_stat = add_stat
-        probes.append((c, probe))
-        probe_data[c] = data
+            data.add_stat = add_stat
+            probes.append((c, probe))
+            probe_data[(c, j)] = data
     sim = Simulation(start_time=Instant.from_seconds(spec.get("start_s", 0)) if spec.get("start_s") else None,
                      end_time=Instant.from_seconds(spec["end_s"]), sources=sources, entities=entities,
                      probes=[p for _, p in probes])
@@ -347,12 +350,15 @@ def run_case(spec):
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     if spec.get("probes"):
         pt, pv, poff = [], [], [0]
-        for i in range(n):
-            d = probe_all.get(i)
-            if d is not None:
-                pt.extend(t for t, _ in d._ns)
-                pv.extend(int(v) for _, v in d._ns)
-            poff.append(len(pt))
+        slots = max([len(pr) if pr is not None and isinstance(pr[0], (list, tuple)) else 1 for pr in spec["probes"]])
+        for i in range(n):             # offsets indexed chain * slots + slot (slots == 1: one entry per chain)
+            for j in range(slots):
+                d = probe_all.get((i, j))
+                if d is not None:
+                    pt.extend(t for t, _ in d._ns)
+                    pv.extend(int(v) for _, v in d._ns)
+                poff.append(len(pt))
+        out["probe_slots"] = np.asarray([slots], np.int64)
         out["probe_t_ns"] = np.asarray(pt, np.int64)
         out["probe_v"] = np.asarray(pv, np.int64)
         out["probe_off"] = np.asarray(poff, np.int64)
@@ -410,21 +416,24 @@ def run_ring_case(spec):
         else:
             sources.append(None)
     probes, probe_data = [], {}
-    for i, pr in enumerate(spec.get("probes") or []):
-        if pr is None:
+    for i, prs in enumerate(spec.get("probes") or []):
+        if prs is None:
             continue
-        who, attr = PROBE_METRICS[pr[0]]
-        target = {"source": sources[i], "server": servers[i], "sink": sinks[i]}[who]
-        probe, data = Probe.on(target, attr, interval=pr[1])
-        data._ns = []
+        if not isinstance(prs[0], (list, tuple)):
+            prs = [prs]                # one probe; a list of [metric, interval] pairs = several probes on one station
+        for j, pr in enumerate(prs):
+            who, attr = PROBE_METRICS[pr[0]]
+            target = {"source": sources[i], "server": servers[i], "sink": sinks[i]}[who]
+            probe, data = Probe.on(target, attr, interval=pr[1])
+            data._ns = []
 
-        def add_stat(value, time, _orig=data.add_stat, _d=data):
-            _d._ns.append((time.nanoseconds, value))
-            _orig(value, time)
+            def add_stat(value, time, _orig=data.add_stat, _d=data):
+                _d._ns.append((time.nanoseconds, value))
+                _orig(value, time)
 
-        data.add_stat = add_stat
-        probes.append((i, probe))
-        probe_data[i] = data
+            data.add_stat = add_stat
+            probes.append((i, probe))
+            probe_data[(i, j)] = data
     sim = Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=[s for s in sources if s is not None],
                      entities=servers + routers + links + sinks, probes=[p for _, p in probes])
     node_of = {}
@@ -472,12 +481,15 @@ def run_ring_case(spec):
     out["packets_sent"] = np.array([l.packets_sent for l in links], np.int64)
     if probes:
         pt, pv, poff = [], [], [0]
-        for i in range(n):
-            d = probe_data.get(i)
-            if d is not None:
-                pt.extend(t for t, _ in d._ns)
-                pv.extend(int(v) for _, v in d._ns)
-            poff.append(len(pt))
+        slots = max([len(pr) if pr is not None and isinstance(pr[0], (list, tuple)) else 1 for pr in spec["probes"]])
+        for i in range(n):             # offsets indexed station * slots + slot
+            for j in range(slots):
+                d = probe_data.get((i, j))
+                if d is not None:
+                    pt.extend(t for t, _ in d._ns)
+                    pv.extend(int(v) for _, v in d._ns)
+                poff.append(len(pt))
+        out["probe_slots"] = np.asarray([slots], np.int64)
         out["probe_t_ns"] = np.asarray(pt, np.int64)
         out["probe_v"] = np.asarray(pv, np.int64)
         out["probe_off"] = np.asarray(poff, np.int64)
@@ -614,6 +626,11 @@ RING_CASES = [
          probes=[["depth", 0.25], ["active_requests", 0.1], None, ["stats_accepted", 0.5], ["events_received", 0.3],
                  ["requests_completed", 0.4]],
          end_s=12.0, seed=61, trace=True),
+    dict(name="ring_5_multi_probes", topology="ring", n=5, ext_rate=[8.0, 5.0, 0.0, 6.0, 7.0], mean=0.09, concurrency=2,
+         queue_cap=4, lat_min=0.002, jitter_mean=0.006,
+         probes=[[["depth", 0.25], ["active_requests", 0.25], ["stats_dropped", 0.5], ["events_received", 0.2]], None,
+                 [["stats_accepted", 0.5], ["requests_completed", 0.5]], [["depth", 0.3]], None],
+         end_s=10.0, seed=63, trace=True),
     # NetworkLink(packet_loss_rate): lost packets vanish at the link (link.py:131-138)
     dict(name="ring_8_loss", topology="ring", n=8, ext_rate=6.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, loss=0.2,
          end_s=20.0, seed=42, trace=True),
@@ -708,6 +725,13 @@ CASES = [
          concurrency=[1, 1, 2, 1], queue_cap=[None, None, 6, None],
          probes=[["depth", 0.5], ["active_requests", 0.25], ["stats_dropped", 1.0], ["events_received", 0.3]],
          end_s=20.0, rng="philox", seed=31, mode="single", trace=True),
+    # several probes on one station (reference: each Probe.on() is its own daemon Source, numbered in probes=[...] order)
+    dict(name="probe_multi_4chains", n_chains=4, arr=["poisson", "constant", "poisson", "poisson"], rate=[12.0, 4.0, 30.0, 8.0],
+         svc="exp", mean=[0.1, 0.1, 0.05, 0.1], concurrency=[1, 1, 2, 1], queue_cap=[None, None, 6, None],
+         probes=[[["depth", 0.5], ["active_requests", 0.5], ["stats_accepted", 0.2]],
+                 [["events_received", 0.25], ["depth", 0.25], ["generated_count", 1.0], ["requests_completed", 0.5]],
+                 [["stats_dropped", 1.0]], None],
+         end_s=15.0, rng="philox", seed=33, mode="single", trace=True),
     dict(name="probe_const_ties", n_chains=3, arr="constant", rate=[10.0, 20.0, 4.0], svc="const", mean=[0.1, 0.07, 0.2],
          probes=[["depth", 0.1], ["generated_count", 0.05], ["requests_completed", 0.25]],
          end_s=6.0, rng="philox", seed=32, mode="single", trace=True),

@@ -43,6 +43,16 @@ class Golden:
         except KeyError as e:
             raise AttributeError(k) from e
 
+    @property
+    def n_probe_slots(self):
+        return int(self.arrays["probe_slots"][0]) if "probe_slots" in self.arrays else 1
+
+    def probe_samples(self, chain, slot=0):
+        """(times ns, values) the reference's probe number `slot` of the chain appended to its Data (empty: no such probe)."""
+        k = chain * self.n_probe_slots + slot
+        a, b = self.probe_off[k], self.probe_off[k + 1]
+        return self.probe_t_ns[a:b], self.probe_v[a:b]
+
     def sink_records(self, chain):
         a, b = self.sink_off[chain], self.sink_off[chain + 1]
         return self.sink_t_ns[a:b], self.sink_latency_s[a:b]
@@ -59,6 +69,18 @@ def ns_from_seconds(x: float) -> int:
     return int(x * 1_000_000_000)
 
 
+def _probe_lists(spec, n):
+    """spec["probes"][c] is None, one [metric, interval] pair, or a list of pairs (several probes on one chain)."""
+    out = []
+    for pr in (spec.get("probes") or [None] * n):
+        out.append([] if pr is None else [list(q) for q in pr] if isinstance(pr[0], (list, tuple)) else [list(pr)])
+    return out
+
+
+def _first_probes(spec, n):
+    return [prs[0] if prs else None for prs in _probe_lists(spec, n)]
+
+
 def spec_chain_params(spec):
     n = spec["n_chains"]
     return dict(
@@ -73,7 +95,8 @@ def spec_chain_params(spec):
         downstream=spec.get("downstream", True),
         end_ns=ns_from_seconds(spec["end_s"]),
         profile=[None if pr is None else tuple(pr) for pr in (spec.get("profile") or [None] * n)],
-        probes=[None if pr is None else (pr[0], float(pr[1])) for pr in (spec.get("probes") or [None] * n)],
+        probes=[None if pr is None else (pr[0], float(pr[1])) for pr in _first_probes(spec, n)],
+        probe_list=[[(m, float(iv)) for m, iv in prs] for prs in _probe_lists(spec, n)],       # every probe of a chain, in order
         # Simulation.schedule(): (chain, time ns) in the caller's construction order; a chain with rate 0 has no Source
         schedule=[(int(c), ns_from_seconds(float(t))) for c, t in (spec.get("schedule") or [])],
         no_source=[float(r) == 0.0 and pr is None
@@ -85,6 +108,32 @@ def spec_chain_params(spec):
 PROBE_METRICS = {"depth": ("server", 0), "active_requests": ("server", 1), "stats_accepted": ("server", 2),
                  "stats_dropped": ("server", 3), "requests_completed": ("server", 4), "events_received": ("sink", 5),
                  "generated_count": ("source", 6)}
+
+
+def _probe_arrays(st, p, n):
+    """Probes of every chain into StationArrays: slot 0 in probe_metric, slots 1..3 in probe_metric_more, and the construction
+    order (chain-major, slot-minor -- the order make_golden lists them in `probes=[...]`)."""
+    from happy_simulator_amd import _native as N
+    if not any(p["probe_list"]):
+        return
+    st.probe_metric = np.full(n, N.PROBE_NONE, np.uint8)
+    st.probe_interval_s = np.ones(n, np.float64)
+    more = max(len(prs) for prs in p["probe_list"]) > 1
+    if more:
+        st.probe_metric_more = np.full((3, n), N.PROBE_NONE, np.uint8)
+        st.probe_interval_more = np.ones((3, n), np.float64)
+    order, slots = [], []
+    for i, prs in enumerate(p["probe_list"]):
+        for j, pr in enumerate(prs):
+            if j == 0:
+                st.probe_metric[i], st.probe_interval_s[i] = PROBE_METRICS[pr[0]][1], pr[1]
+            else:
+                st.probe_metric_more[j - 1, i], st.probe_interval_more[j - 1, i] = PROBE_METRICS[pr[0]][1], pr[1]
+            order.append(i)
+            slots.append(j)
+    if more:
+        st.probe_order = np.asarray(order, np.int32)
+        st.probe_slot_order = np.asarray(slots, np.uint8)
 
 
 def oracle_graph_for(spec, chain_ids, stream_bases):
@@ -110,13 +159,14 @@ def oracle_graph_for(spec, chain_ids, stream_bases):
             g.target[srcs[k]] = sv
         g.target[sv] = sk
         nodes[c] = (srcs[k], sv, sk if not (spec.get("shared_sink") and k > 0) else -1)
-    g.probe_nodes = {}
+    g.probe_nodes, g.probe_nodes_all = {}, {}
     for c in chain_ids:                                   # probes start after every source, in list order
-        pr = p["probes"][c]
-        if pr is not None:
+        for j, pr in enumerate(p["probe_list"][c]):
             who, mid = PROBE_METRICS[pr[0]]
             tgt = nodes[c][{"source": 0, "server": 1, "sink": 2}[who]]
-            g.probe_nodes[c] = g.probe(tgt, mid, pr[1])
+            g.probe_nodes_all[(c, j)] = g.probe(tgt, mid, pr[1])
+            if j == 0:
+                g.probe_nodes[c] = g.probe_nodes_all[(c, j)]
     return g, nodes
 
 
@@ -136,7 +186,7 @@ def run_oracle_for_spec(spec, trace_cap=0):
         r = O.run(g, p["end_ns"], seed=seed, rng_mode=rng, mt_seed_py=seed & 0xFFFFFFFF,
                   mt_seed_np=seed & 0xFFFFFFFF, trace_cap=trace_cap,
                   schedule=[(nodes[c][1], t) for c, t in p["schedule"] if c in nodes])
-        r.probe_nodes = g.probe_nodes
+        r.probe_nodes, r.probe_nodes_all = g.probe_nodes, g.probe_nodes_all
         runs.append((chain_ids, nodes, r))
     return runs
 
@@ -148,7 +198,8 @@ def ring_params(spec):
         conc=int(spec.get("concurrency", 1)), qcap=-1 if spec.get("queue_cap") is None else int(spec["queue_cap"]),
         lat_min=float(spec["lat_min"]), jitter_mean=spec.get("jitter_mean"), end_ns=ns_from_seconds(spec["end_s"]),
         loss=[float(x) for x in per_chain(spec.get("loss", 0.0), n)], p_targets=2,
-        probes=[None if pr is None else (pr[0], float(pr[1])) for pr in (spec.get("probes") or [None] * n)],
+        probes=[None if pr is None else (pr[0], float(pr[1])) for pr in _first_probes(spec, n)],
+        probe_list=[[(m, float(iv)) for m, iv in prs] for prs in _probe_lists(spec, n)],
         profile=[None if pr is None else tuple(pr) for pr in (spec.get("profile") or [None] * n)],
         schedule=[(int(c), ns_from_seconds(float(t))) for c, t in (spec.get("schedule") or [])])
 
@@ -175,10 +226,10 @@ def oracle_ring_graph(spec):
         g.target[nodes[i]["srv"]] = nodes[i]["rtr"]
         g.target[nodes[i]["lnk"]] = nodes[(i + 1) % n]["srv"]
     for i in range(n):                                    # probes start after every source, in list order
-        pr = p["probes"][i]
-        if pr is not None:
+        for j, pr in enumerate(p["probe_list"][i]):
             who, mid = PROBE_METRICS[pr[0]]
-            nodes[i]["prb"] = g.probe(nodes[i][{"source": "src", "server": "srv", "sink": "snk"}[who]], mid, pr[1])
+            nodes[i]["prb" if j == 0 else f"prb{j}"] = g.probe(nodes[i][{"source": "src", "server": "srv", "sink": "snk"}[who]],
+                                                              mid, pr[1])
     return g, nodes
 
 
@@ -253,13 +304,7 @@ def engine_for_spec(spec, log_capacity=0, horizon_ns=None, flags=0):
             st.src_profile_kind[i] = N.PROF_LINEAR_RAMP if pr[0] == "ramp" else N.PROF_SPIKE
             st.src_profile_params[i, :len(pr) - 1] = pr[1:]
             st.src_rate[i] = max(pr[2], pr[3]) if pr[0] == "ramp" else max(pr[1], pr[2])     # peak: sizes the logs
-    if any(pr is not None for pr in p["probes"]):
-        st.probe_metric = np.full(n, N.PROBE_NONE, np.uint8)
-        st.probe_interval_s = np.ones(n, np.float64)
-        for i, pr in enumerate(p["probes"]):
-            if pr is not None:
-                st.probe_metric[i] = PROBE_METRICS[pr[0]][1]
-                st.probe_interval_s[i] = pr[1]
+    _probe_arrays(st, p, n)
     if p["schedule"]:              # Simulation.schedule(): per station ascending, ties in call order (stable sort)
         st.sched_off, st.sched_time_ns, st.sched_rank = sched_arrays(n, p["schedule"], per_station=spec["mode"] != "single")
     if spec["mode"] == "single":
@@ -331,13 +376,7 @@ def ring_arrays(spec, bag_capacity=0, log_capacity=0):
         queue_cap=np.full(n, p["qcap"], np.int64),
         egress=np.full(n, N.EGRESS_SINK, np.uint8),
     )
-    if any(pr is not None for pr in p["probes"]):
-        st.probe_metric = np.full(n, N.PROBE_NONE, np.uint8)
-        st.probe_interval_s = np.ones(n, np.float64)
-        for i, pr in enumerate(p["probes"]):
-            if pr is not None:
-                st.probe_metric[i] = PROBE_METRICS[pr[0]][1]
-                st.probe_interval_s[i] = pr[1]
+    _probe_arrays(st, p, n)
     if any(pr is not None for pr in p["profile"]):
         st.src_profile_kind = np.zeros(n, np.uint8)
         st.src_profile_params = np.zeros((n, 4), np.float64)

@@ -318,34 +318,40 @@ def test_time_varying_profiles_through_the_api_match_reference_golden():
         assert c[2].latencies_s == glat.tolist()
 
 
-def test_probes_through_the_api_match_reference_golden():
+@pytest.mark.parametrize("name", ["probe_depth_4chains", "probe_multi_4chains"])
+def test_probes_through_the_api_match_reference_golden(name):
     """`Simulation(probes=[Probe.on(server, "depth", 0.5), ...])`: sample times and values equal what the live reference's
-    probes appended to their Data containers (tests/golden/probe_depth_4chains.npz)."""
-    gold = H.Golden("probe_depth_4chains")
+    probes appended to their Data containers (tests/golden/probe_*.npz).  probe_multi_4chains has up to four probes on one
+    chain, two of them on the same interval (equal instants: the reference fires them in `probes=[...]` order) and one on
+    the nanoseconds of a constant-rate Source."""
+    gold = H.Golden(name)
     spec = gold.spec
     p = H.spec_chain_params(spec)
-    chains, probes, datas = [], [], []
+    chains, probes, datas = [], [], {}
     for i in range(p["n"]):
         sink = hs.Sink(f"sink{i}")
         srv = hs.Server(f"srv{i}", concurrency=p["conc"][i], service_time=hs.ExponentialLatency(p["mean"][i]),
                         queue_capacity=None if p["qcap"][i] < 0 else p["qcap"][i], downstream=sink)
-        src = hs.Source.poisson(rate=p["rate"][i], target=srv, name=f"src{i}")
-        metric, interval = p["probes"][i]
-        target = {"server": srv, "sink": sink, "source": src}[H.PROBE_METRICS[metric][0]]
-        pr, d = hs.Probe.on(target, metric, interval=interval)
+        if p["arr"][i] == H.O.ARR_POISSON:
+            src = hs.Source.poisson(rate=p["rate"][i], target=srv, name=f"src{i}")
+        else:
+            src = hs.Source.constant(rate=p["rate"][i], target=srv, name=f"src{i}")
+        for j, (metric, interval) in enumerate(p["probe_list"][i]):
+            target = {"server": srv, "sink": sink, "source": src}[H.PROBE_METRICS[metric][0]]
+            pr, d = hs.Probe.on(target, metric, interval=interval)
+            probes.append(pr)
+            datas[(i, j)] = d
         chains.append((src, srv, sink))
-        probes.append(pr)
-        datas.append(d)
     sim = hs.Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=[c[0] for c in chains],
                         entities=[e for c in chains for e in c[1:]], probes=probes, seed=spec["seed"])
     summary = sim.run()
     assert summary.total_events_processed == gold.meta["total_events"][0]
     assert summary.duration_s == gold.meta["duration_s"][0]
-    for i, d in enumerate(datas):
-        a, b = gold.probe_off[i], gold.probe_off[i + 1]
-        assert d.raw_values() == gold.probe_v[a:b].tolist()
-        assert d.times() == (gold.probe_t_ns[a:b].astype(np.float64) / 1e9).tolist()        # Data stores time.to_seconds()
-        assert d.count() == b - a and d.max() == max(gold.probe_v[a:b].tolist())
+    for (i, j), d in datas.items():
+        gt, gv = gold.probe_samples(i, j)
+        assert d.raw_values() == gv.tolist()
+        assert d.times() == (gt.astype(np.float64) / 1e9).tolist()        # Data stores time.to_seconds()
+        assert d.count() == len(gt) and d.max() == max(gv.tolist())
     assert [c[2].events_received for c in chains] == gold.received.tolist()
 
 
@@ -467,7 +473,7 @@ def test_network_larger_than_one_cooperative_launch_is_time_shared(monkeypatch):
     assert whole[0] > 100_000 and sum(whole[8]) > 0 and all(len(v[0]) >= 11 for v in whole[2])
 
 
-@pytest.mark.parametrize("name", ["ring_6_probes", "ring_5_profiles", "ring_4_schedule"])
+@pytest.mark.parametrize("name", ["ring_6_probes", "ring_5_multi_probes", "ring_5_profiles", "ring_4_schedule"])
 def test_probes_and_profiles_on_networked_stations_match_reference_golden(name):
     """Probe.on(server / sink, metric, interval), Source.with_profile(LinearRamp / Spike) and Simulation.schedule() on the
     stations of a ring (windowed network engine): every object as the live reference left it, probe samples value for
@@ -476,15 +482,12 @@ def test_probes_and_profiles_on_networked_stations_match_reference_golden(name):
     spec = gold.spec
     sources, servers, routers, links, sinks = _build_ring(spec)
     probes, datas = [], {}
-    for i, pr in enumerate(spec.get("probes") or []):
-        if pr is None:
-            continue
-        who, attr = {"depth": ("server", "depth"), "active_requests": ("server", "active_requests"),
-                     "stats_accepted": ("server", "stats_accepted"), "events_received": ("sink", "events_received"),
-                     "requests_completed": ("server", "requests_completed")}[pr[0]]
-        probe, data = hs.Probe.on({"server": servers[i], "sink": sinks[i]}[who], attr, interval=pr[1])
-        probes.append(probe)
-        datas[i] = data
+    for i, prs in enumerate(H.ring_params(spec)["probe_list"]):
+        for j, (metric, interval) in enumerate(prs):         # several probes of a station: engine slots in this order
+            who = H.PROBE_METRICS[metric][0]
+            probe, data = hs.Probe.on({"server": servers[i], "sink": sinks[i]}[who], metric, interval=interval)
+            probes.append(probe)
+            datas[(i, j)] = data
     sim = hs.Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=sources,
                         entities=servers + routers + links + sinks, probes=probes, seed=spec["seed"])
     for i, t_s in spec.get("schedule") or []:
@@ -493,11 +496,11 @@ def test_probes_and_profiles_on_networked_stations_match_reference_golden(name):
     assert summary.total_events_processed == gold.meta["total_events"][0]
     assert summary.duration_s == gold.meta["duration_s"][0]
     _check_ring_objects(gold, servers, routers, links, sinks)
-    for i, data in datas.items():
-        a, b = gold.probe_off[i], gold.probe_off[i + 1]
-        assert data.times() == [x / 1_000_000_000 for x in gold.probe_t_ns[a:b].tolist()]     # Instant.to_seconds()
-        assert [int(v) for v in data.raw_values()] == gold.probe_v[a:b].tolist()
-        assert data.count() == b - a > 0
+    for (i, j), data in datas.items():
+        gt, gv = gold.probe_samples(i, j)
+        assert data.times() == [x / 1_000_000_000 for x in gt.tolist()]     # Instant.to_seconds()
+        assert [int(v) for v in data.raw_values()] == gv.tolist()
+        assert data.count() == len(gt) > 0
 
 
 def test_ring_with_one_shared_sink_matches_oracle():

@@ -104,10 +104,11 @@ def test_engine_matches_reference_golden(name):
             np.testing.assert_array_equal(s.events_by_kind, np.bincount(gold.trace[:, 1], minlength=len(s.events_by_kind)))
         if "probe_t_ns" in gold.arrays:          # Probe samples: what the reference appended to each probe's Data
             for c in range(spec["n_chains"]):
-                a, b = gold.probe_off[c], gold.probe_off[c + 1]
-                pt, pv = eng.read_probe(c)
-                np.testing.assert_array_equal(pt, gold.probe_t_ns[a:b], err_msg=f"probe times chain {c}")
-                np.testing.assert_array_equal(pv, gold.probe_v[a:b], err_msg=f"probe values chain {c}")
+                for j in range(gold.n_probe_slots):
+                    gt, gv = gold.probe_samples(c, j)
+                    pt, pv = eng.read_probe(c, j)
+                    np.testing.assert_array_equal(pt, gt, err_msg=f"probe times chain {c} slot {j}")
+                    np.testing.assert_array_equal(pv, gv, err_msg=f"probe values chain {c} slot {j}")
         shared = bool(spec.get("shared_sink"))
         for k, g in (("generated", "generated"), ("accepted", "accepted"), ("dropped", "dropped"),
                      ("completed", "completed"), ("rejected", "rejected"), ("sink_received", "received"),

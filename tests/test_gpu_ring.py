@@ -74,10 +74,11 @@ def test_ring_engine_matches_reference_golden(name, engine_flags):
         np.testing.assert_array_equal((t - cr).astype(np.float64) / 1e9, gold.sink_latency_s)
         if "probe_t_ns" in gold.arrays:                     # probes on networked stations (both engines)
             for i in range(spec["n"]):
-                a, b = gold.probe_off[i], gold.probe_off[i + 1]
-                pt, pv = eng.read_probe(i)
-                np.testing.assert_array_equal(pt, gold.probe_t_ns[a:b], err_msg=f"probe times station {i}")
-                np.testing.assert_array_equal(pv, gold.probe_v[a:b], err_msg=f"probe values station {i}")
+                for j in range(gold.n_probe_slots):
+                    gt, gv = gold.probe_samples(i, j)
+                    pt, pv = eng.read_probe(i, j)
+                    np.testing.assert_array_equal(pt, gt, err_msg=f"probe times station {i} slot {j}")
+                    np.testing.assert_array_equal(pv, gv, err_msg=f"probe values station {i} slot {j}")
             assert s.events_by_kind[13] > 0 and s.events_by_kind[14] > 0
 
 

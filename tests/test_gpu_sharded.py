@@ -44,7 +44,8 @@ def _sharded(spec, world, sync_every=16, msg_capacity=64, rounds=True, bag_capac
         parts = [s.engine.read_sinks() for s in sn.shards]
         sinks = tuple(np.concatenate([p_[i] for p_ in parts]) for i in range(3))
         if spec.get("probes"):
-            summ.probes = {i: sn.read_probe(i) for i, pr in enumerate(spec["probes"]) if pr is not None}
+            summ.probes = {(i, j): sn.read_probe(i, j) for i, prs in enumerate(H.ring_params(spec)["probe_list"])
+                           for j in range(len(prs))}
         return summ, stats, netst, sinks
 
 
@@ -89,10 +90,10 @@ def test_sharded_matches_reference_golden(name, rounds):
     world = 2 if spec["n"] < 6 else 3
     summ, stats, netst, sinks = _sharded(spec, world, sync_every=8, rounds=rounds)
     if "probe_t_ns" in gold.arrays:          # probes sample on whichever shard owns their station
-        for i, (pt, pv) in summ.probes.items():
-            a, b = gold.probe_off[i], gold.probe_off[i + 1]
-            np.testing.assert_array_equal(pt, gold.probe_t_ns[a:b])
-            np.testing.assert_array_equal(pv, gold.probe_v[a:b])
+        for (i, j), (pt, pv) in summ.probes.items():
+            gt, gv = gold.probe_samples(i, j)
+            np.testing.assert_array_equal(pt, gt)
+            np.testing.assert_array_equal(pv, gv)
     assert summ.events_processed == gold.meta["total_events"][0]
     assert summ.final_time_ns == gold.meta["final_ns"][0]
     for k, g in (("generated", "generated"), ("accepted", "accepted"), ("dropped", "dropped"), ("completed", "completed"),

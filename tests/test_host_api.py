@@ -309,9 +309,16 @@ def test_probes_are_lowered_onto_their_station():
         hs.Probe.on(srv, "depth", interval=0.0)
     with pytest.raises(NotImplementedError, match="arbitrary attribute"):
         hs.Probe.on(srv, "some_custom_attr")
-    p3, _ = hs.Probe.on(srv, "active_requests")
-    with pytest.raises(hs.UnsupportedTopology, match="one Probe per station"):
-        hs.Simulation(duration=1, sources=[src], entities=[srv, sink], probes=[p1, p3]).lowered()
+    # several probes on one station: engine slots 0..3, in `probes=[...]` order
+    more = [hs.Probe.on(t, m, interval=iv)[0] for t, m, iv in ((srv, "active_requests", 1.0), (sink, "events_received", 0.25),
+                                                              (src, "generated_count", 3.0))]
+    b = hs.Simulation(duration=1, sources=[src], entities=[srv, sink], probes=[p1] + more).lowered().arrays()
+    assert list(b.probe_metric) == [N.PROBE_METRICS["depth"]] and list(b.probe_interval_s) == [0.5]
+    assert b.probe_metric_more[:, 0].tolist() == [N.PROBE_METRICS[m] for m in ("active_requests", "events_received", "generated_count")]
+    assert b.probe_interval_more[:, 0].tolist() == [1.0, 0.25, 3.0]
+    p5, _ = hs.Probe.on(srv, "stats_dropped")
+    with pytest.raises(hs.UnsupportedTopology, match="already has four probes"):
+        hs.Simulation(duration=1, sources=[src], entities=[srv, sink], probes=[p1] + more + [p5]).lowered()
     p4, _ = hs.Probe.on(sink, "depth")
     with pytest.raises(hs.UnsupportedTopology, match="not an attribute of Sink"):
         hs.Simulation(duration=1, sources=[src], entities=[srv, sink], probes=[p4]).lowered()

@@ -49,13 +49,14 @@ def check_oracle_against_station_golden(gold):
     if "probe_t_ns" in gold.arrays:          # Probe samples: (time ns, getattr(target, metric)) in sampling order
         for chain_ids, nodes, r in runs:
             for c in chain_ids:
-                a, b = gold.probe_off[c], gold.probe_off[c + 1]
-                if c in r.probe_nodes:
-                    t, v = r.sinks[r.probe_nodes[c]]
-                    np.testing.assert_array_equal(t, gold.probe_t_ns[a:b])
-                    np.testing.assert_array_equal(v, gold.probe_v[a:b])
-                else:
-                    assert a == b
+                for j in range(gold.n_probe_slots):
+                    gt, gv = gold.probe_samples(c, j)
+                    if (c, j) in r.probe_nodes_all:
+                        t, v = r.sinks[r.probe_nodes_all[(c, j)]]
+                        np.testing.assert_array_equal(t, gt)
+                        np.testing.assert_array_equal(v, gv)
+                    else:
+                        assert len(gt) == 0
     if want_trace:
         assert spec["mode"] == "single"
         (chain_ids, nodes, r), = runs
@@ -64,7 +65,7 @@ def check_oracle_against_station_golden(gold):
             for nd in trio:
                 if nd >= 0:
                     node_chain[nd] = c
-        for c, nd in r.probe_nodes.items():
+        for (c, _slot), nd in r.probe_nodes_all.items():
             node_chain[nd] = c
         if spec.get("shared_sink"):          # make_golden's node table labels the one shared Sink with the LAST chain
             node_chain[nodes[chain_ids[0]][2]] = chain_ids[-1]
@@ -117,13 +118,15 @@ def check_oracle_against_ring_golden(gold):
         np.testing.assert_array_equal(t, gt)
         np.testing.assert_array_equal((t - created).astype(np.float64) / 1e9, glat)
         if "probe_t_ns" in gold.arrays:                     # probes on networked stations
-            a, b = gold.probe_off[i], gold.probe_off[i + 1]
-            if "prb" in nd:
-                pt, pv = r.sinks[nd["prb"]]
-                np.testing.assert_array_equal(pt, gold.probe_t_ns[a:b])
-                np.testing.assert_array_equal(pv, gold.probe_v[a:b])
-            else:
-                assert a == b
+            for j in range(gold.n_probe_slots):
+                gt, gv = gold.probe_samples(i, j)
+                key = "prb" if j == 0 else f"prb{j}"
+                if key in nd:
+                    pt, pv = r.sinks[nd[key]]
+                    np.testing.assert_array_equal(pt, gt)
+                    np.testing.assert_array_equal(pv, gv)
+                else:
+                    assert len(gt) == 0
     if want_trace:
         node_station = {v: i for i, d in nodes.items() for v in d.values() if v >= 0}
         t, k, nd, ix = r.trace
