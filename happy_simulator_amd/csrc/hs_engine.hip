@@ -762,7 +762,7 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF> &S, const Stati
             S.prof_p0 = P.prof_p[lp]; S.prof_p1 = P.prof_p[(size_t)n + lp]; S.prof_p2 = P.prof_p[(size_t)2 * n + lp];
             S.prof_p3 = P.prof_p[(size_t)3 * n + lp];
         }
-        if (X.PA != nullptr) {      // probes on a network: windowed engine only
+        if (X.PA != nullptr) {      // probes on a network (PF instantiations of both engines)
 #pragma unroll
             for (int j = 0; j < kMaxProbes; ++j) {
                 const size_t o = (size_t)j * n + lp;
@@ -2371,12 +2371,11 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
         ALN(aq_t, NQ); ALN(aq_ts, NQ); ALN(aq_cr, NQ); ALN(aq_tail, NL); ALN(aq_head, NL); ALN(aq_ea, NL);
         ALN(early_upto, (size_t)n); ALN(d_pre, (size_t)n);
         // the whole network in one cooperative launch (shards: hs_engine_shard_round); with probes, time-varying profiles
-        // or scheduled Requests the PF instantiation of the kernel
-        // (time-varying profiles and scheduled Requests stay on the windowed engine; the asynchronous PF instantiation is
-        // validated at scale for probes only)
+        // or scheduled Requests the PF instantiation of the kernel (a profile's next arrival and the next scheduled Request
+        // are part of next_admission() / next_time(), which is all the bounds are made of)
         // (the links' packed (bound, tail) words hold 44 bits of nanoseconds: 4.9 hours of simulated time)
         const bool fits = h->cfg.horizon_ns - h->cfg.start_ns < (int64_t)kPkNever - 2 && aqc < (1 << (kPkTailBits - 2));
-        h->async_ok = !global && !h->any_timevarying && !h->any_sched && fits;
+        h->async_ok = !global && fits;
         h->net_pf = h->any_probe || h->any_timevarying || h->any_sched;
     }
 #undef ALN
@@ -2507,8 +2506,6 @@ int hs_engine_shard_async_setup(hs_engine *h, int32_t n_cross, const int64_t *cr
     if (n_cross < 0 || (n_cross > 0 && !cross_gid) || !bounds_dev || max_iters < 1)
         return fail(h, HS_E_INVALID, "hs_engine_shard_async_setup: bad argument");
     if (!h->NX.aq_tail) return fail(h, HS_E_STATE, "the network has no links");
-    if (h->any_timevarying || h->any_sched)
-        return fail(h, HS_E_UNSUPPORTED, "time-varying profiles and scheduled Requests run on the window protocol (rounds = False)");
     HS_HIP(h, hipSetDevice(h->cfg.device));
     if (!ensure_async_fit(h)) return fail(h, HS_E_UNSUPPORTED, "the shard's stations are not co-resident on this device (asynchronous rounds need a cooperative launch)");
     if (h->cfg.horizon_ns - h->cfg.start_ns >= (int64_t)kPkNever - 2)

@@ -221,7 +221,7 @@ struct NetStation {
     int64_t *probe_t, *probe_v;     // slot j's log starts at probe_t + j * pcap * ls
     int n_probes;
     uint32_t evp[2];
-    // time-varying arrival rate of this station's Source (load/profile.py); 0 = constant.  Windowed engine only, like probes.
+    // time-varying arrival rate of this station's Source (load/profile.py); 0 = constant..
     uint32_t prof_kind;
     double prof_p0, prof_p1, prof_p2, prof_p3;
     // Simulation.schedule(): Requests injected before run() (hs_station.hpp); they precede every run-time event of their ns

@@ -334,8 +334,6 @@ class ShardedNetwork:
         balanced block partition, e.g. with the user's own SimulationPartition sizes."""
         import torch
 
-        if stations.src_profile_kind is not None or stations.sched_off is not None:
-            rounds = False               # time-varying profiles / scheduled Requests: the window protocol (windowed engine)
         bounds = shard_bounds(stations.n, comm.world) if bounds is None else np.asarray(bounds, np.int64)
         if len(bounds) != comm.world + 1 or bounds[0] != 0 or bounds[-1] != stations.n or (np.diff(bounds) <= 0).any():
             raise ValueError("bounds must be world + 1 increasing station offsets covering every station")

@@ -56,8 +56,8 @@ def test_ring_engine_matches_reference_golden(name, engine_flags):
         assert s.events_processed == gold.meta["total_events"][0]
         assert s.final_time_ns == gold.meta["final_ns"][0]
         assert s.window_ns > 0 and s.launches > 1
-        if engine_flags == 0 and not (spec.get("profile") or spec.get("schedule")):
-            assert s.launches <= 4          # reset + ONE cooperative launch + the election, also with probes
+        if engine_flags == 0:               # reset (+ the start-instant prologue) + ONE cooperative launch + the election,
+            assert s.launches <= 5          # also with probes, time-varying profiles and scheduled Requests
         if "trace" in gold.arrays:
             np.testing.assert_array_equal(s.events_by_kind, np.bincount(gold.trace[:, 1], minlength=len(s.events_by_kind)))
         for k, g in (("generated", "generated"), ("accepted", "accepted"), ("dropped", "dropped"),
@@ -225,6 +225,7 @@ def test_profiles_and_schedule_on_large_rings_match_oracle(n, engine_flags):
         eng.run_until(p["end_ns"])
         _check_against_oracle(spec, eng, r, nodes)
         assert r.events_processed > 30 * n
+        assert (eng.summary().launches <= 5) == (engine_flags == 0)      # the asynchronous engine: one cooperative launch
 
 
 @ENGINES

@@ -106,14 +106,15 @@ def test_sharded_matches_reference_golden(name, rounds):
     np.testing.assert_array_equal(sinks[1], gold.sink_t_ns)
 
 
-def test_sharded_profiles_and_schedule_on_a_large_ring_equal_single_engine():
-    """Time-varying profiles and scheduled Requests on a 130-station ring over 3 shards (window protocol: those two
-    features keep the windowed engine) == the single engine, which tests/test_gpu_ring.py pins against the oracle."""
+@PROTOCOLS
+def test_sharded_profiles_and_schedule_on_a_large_ring_equal_single_engine(rounds):
+    """Time-varying profiles and scheduled Requests on a 130-station ring over 3 shards (asynchronous rounds and the window
+    protocol) == the single engine, which tests/test_gpu_ring.py pins against the oracle."""
     from test_gpu_ring import _big_ring_with_profiles_and_schedule
 
     spec = _big_ring_with_profiles_and_schedule(130, seed=220)
     one = _single(spec)
-    summ, stats, netst, sinks = _sharded(spec, 3)
+    summ, stats, netst, sinks = _sharded(spec, 3, rounds=rounds)
     assert summ.events_processed == one["events"] and summ.final_time_ns == one["final"]
     np.testing.assert_array_equal(summ.events_by_kind, one["by_kind"])
     for k in ("generated", "accepted", "completed", "total_service_s", "sink_received", "queue_depth", "active"):
