@@ -1080,7 +1080,7 @@ struct NetStation {
         if (slow) stat_slow = 1;
         if (deliver && dep && started + kNRing < accepted) stat_gl = 1;   // a prefetch is issued
 #endif
-        if (slow) { run_group(t, force_general); return; }
+        if (__builtin_expect(slow, 0)) { run_group(t, force_general); return; }
         HS_CY2(0)
         // ---- Source.handle_event
         ev[0] += tick; generated += tick;
