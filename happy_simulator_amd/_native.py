@@ -36,7 +36,7 @@ EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuat
 PROBE_METRICS = {"depth": 0, "active_requests": 1, "stats_accepted": 2, "stats_dropped": 3, "requests_completed": 4,
                  "_requests_completed": 4, "events_received": 5, "generated_count": 6}
 PROBE_NONE = 255
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class EngineUnavailable(RuntimeError):
@@ -68,6 +68,8 @@ class Stations(C.Structure):
         ("source_order", C.c_void_p), ("probe_order", C.c_void_p),
         ("probe_metric_more", C.c_void_p), ("probe_interval_more", C.c_void_p), ("probe_slot_order", C.c_void_p),
         ("sched_rank", C.c_void_p),
+        ("src_more_kind", C.c_void_p), ("src_more_rate", C.c_void_p), ("src_more_stop_after_ns", C.c_void_p),
+        ("source_slot_order", C.c_void_p),
     ]
 
 
@@ -230,6 +232,8 @@ def lib():
     L.hs_engine_read_probe.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]
     L.hs_engine_read_probe_slot.restype = C.c_int64
     L.hs_engine_read_probe_slot.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]
+    L.hs_engine_read_source_generated.restype = C.c_int
+    L.hs_engine_read_source_generated.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.hs_engine_read_sinks.restype = C.c_int64
     L.hs_engine_read_sinks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.hs_last_error.restype = C.c_char_p
@@ -293,7 +297,7 @@ EXPORTED_SYMBOLS = (
     "hs_engine_shard_inject_async", "hs_engine_shard_async_done", "hs_engine_reset",
     "hs_engine_run_until", "hs_engine_run_until_async", "hs_engine_synchronize", "hs_engine_bench_runs",
     "hs_engine_get_summary", "hs_engine_get_lp_stats", "hs_engine_read_sink", "hs_engine_read_sinks", "hs_engine_read_probe",
-    "hs_engine_read_probe_slot",
+    "hs_engine_read_probe_slot", "hs_engine_read_source_generated",
     "hs_last_error", "hs_last_global_error", "hs_engine_destroy", "hs_debug_draws", "hs_debug_set_flags",
     "hs_debug_const_div", "hs_debug_async_counters",
     "hs_lb_create", "hs_lb_run", "hs_lb_bench_runs", "hs_lb_get_summary", "hs_lb_get_stats", "hs_lb_read_sink",

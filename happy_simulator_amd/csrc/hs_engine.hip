@@ -85,7 +85,23 @@ __device__ __forceinline__ void load_station(Station<C, PF> &S, const StationPar
 #pragma unroll
     for (int j = 0; j < kMaxProbes; ++j) { S.p_metric[j] = kProbeNone; S.PA[j] = kInfNs; S.seqP[j] = 0; S.crtP[j] = 0; S.p_arr[j] = 0; S.p_n[j] = 0; S.p_rate[j] = 1.0; }
     S.SA = kInfNs; S.sc_i = S.sc_end = 0; S.sc_t = P.sched_t; S.sc_idx = P.sched_idx;
+    S.n_xsrc = 0; S.x_base = P.stream_base[lp];
+#pragma unroll
+    for (int j = 0; j < kMaxXSrc; ++j) { S.x_kind[j] = 0; S.XA[j] = kInfNs; S.seqX[j] = 0; S.crtX[j] = 0; S.x_arr[j] = 0; S.x_n[j] = 0; S.x_k[j] = 0; S.x_rate[j] = 1.0; S.x_stop[j] = -1; }
     if constexpr (PF) {
+        if (P.xsrc_kind != nullptr) {
+#pragma unroll
+            for (int j = 0; j < kMaxXSrc; ++j) {
+                const size_t o = (size_t)j * n + lp;
+                S.x_kind[j] = P.xsrc_kind[o];
+                if (S.x_kind[j] != 0) {
+                    S.n_xsrc = j + 1;
+                    S.x_rate[j] = P.xsrc_rate[o]; S.x_stop[j] = P.xsrc_stop[o];
+                    S.XA[j] = X.XA[o]; S.seqX[j] = X.seqX[o]; S.crtX[j] = X.crtX[o]; S.x_arr[j] = X.x_arr[o]; S.x_n[j] = X.x_n[o];
+                    S.x_k[j] = X.x_k[o];
+                }
+            }
+        }
         if (P.sched_off != nullptr) {
             S.sc_i = X.sched_i[lp]; S.sc_end = P.sched_off[lp + 1];
             S.SA = S.sc_i < S.sc_end ? P.sched_t[S.sc_i] : kInfNs;
@@ -167,6 +183,12 @@ __device__ __forceinline__ void store_station(const Station<C, PF> &Sc, const St
         X.ev_probe[lp] += S.evp[0]; X.ev_probe[(size_t)n + lp] += S.evp[1];
         tot += S.evp[0] + S.evp[1];
         if (S.sc_t != nullptr) X.sched_i[lp] = S.sc_i;
+#pragma unroll
+        for (int j = 0; j < kMaxXSrc; ++j) if (j < S.n_xsrc) {
+            const size_t o = (size_t)j * n + lp;
+            X.XA[o] = S.XA[j]; X.seqX[o] = S.seqX[j]; X.crtX[o] = S.crtX[j]; X.x_arr[o] = S.x_arr[j]; X.x_n[o] = S.x_n[j];
+            X.x_k[o] = S.x_k[j];
+        }
     }
     X.events[lp] += tot;
 }
@@ -185,6 +207,10 @@ __device__ __forceinline__ Candidate make_candidate(const Station<C, PF> &S) {
     const int w = S.pick_root(t);
     c.t = t; c.valid = 1;
     if (w == 0) c.t_created = S.crtA;
+    else if (w >= kRootXSrc) {
+#pragma unroll
+        for (int j = 0; j < kMaxXSrc; ++j) if (j == w - kRootXSrc) c.t_created = S.crtX[j];
+    }
     else if (w >= kRootProbe) {
 #pragma unroll
         for (int j = 0; j < kMaxProbes; ++j) if (j == w - kRootProbe) c.t_created = S.crtP[j];
@@ -282,8 +308,29 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
         X.svc_s[(size_t)i * n + lp] = 0.0; X.crt[(size_t)i * n + lp] = 0;
     }
     for (int k = 0; k < 11; ++k) X.ev_kind[(size_t)k * n + lp] = 0;
+    if (X.XA != nullptr) {   // the LP's further Sources: each draws its first arrival from start_ns like the first one
+        for (int j = 0; j < kMaxXSrc; ++j) {
+            const size_t o = (size_t)j * n + lp;
+            int64_t XA = kInfNs, x_arr = start_ns;
+            uint64_t x_k = 0;
+            const uint32_t xk = P.xsrc_kind[o];
+            if (xk != 0) {
+                double area = 1.0;
+                if (xk == 1) {
+                    Stream s;
+                    s.init(P.seed[lp], xsrc_stream_id(P.stream_base[lp], j), 0);
+                    area = exp1_from_uniform(s.next_uniform());
+                    x_k = 1;
+                }
+                x_arr = ns_from_seconds(__dadd_rn(seconds_from_ns(start_ns), __ddiv_rn(area, P.xsrc_rate[o])));
+                XA = x_arr;
+            }
+            // (default stamps, replaced by the prologue's true sort indices: after the first Source, before the probes)
+            X.XA[o] = XA; X.seqX[o] = 1u + (uint32_t)j; X.crtX[o] = start_ns; X.x_arr[o] = x_arr; X.x_n[o] = 0; X.x_k[o] = x_k;
+        }
+    }
     if (X.PA != nullptr) {   // probes start after the sources (core/simulation.py:156-160): first tick from start_ns
-        uint32_t stamp = 1;
+        uint32_t stamp = 1 + kMaxXSrc;
         for (int j = 0; j < kMaxProbes; ++j) {
             const size_t o = (size_t)j * n + lp;
             int64_t PA = kInfNs, p_arr = start_ns;
@@ -295,7 +342,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
             X.PA[o] = PA; X.seqP[o] = stamp++; X.crtP[o] = start_ns; X.p_arr[o] = p_arr; X.p_n[o] = 0;
         }
         X.ev_probe[lp] = 0; X.ev_probe[(size_t)n + lp] = 0;
-        X.seq[lp] = 1 + kMaxProbes;
+        X.seq[lp] = 1 + kMaxXSrc + kMaxProbes;
         if (P.sched_off != nullptr) {
             X.sched_i[lp] = P.sched_off[lp];
             if (NX.next_time != nullptr && P.sched_off[lp] < P.sched_off[lp + 1]) {   // network engine: first pending event
@@ -1581,6 +1628,7 @@ struct hs_engine {
     Totals *tot = nullptr;
     Candidate *cands = nullptr;
     bool is_net = false;
+    bool any_xsrc = false;     // some LP has more than one Source (general path + prologue)
     bool any_timevarying = false, any_sched = false;   // (subsets of any_profile: what a network does not lower)
     bool any_profile = false;  // some source has a time-varying rate profile (or a probe: same kernel instantiation)
     bool any_probe = false;
@@ -1870,6 +1918,33 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     double max_mean_records = 0.0;
     bool any_source = false;
     const double horizon_s = (double)(h->cfg.horizon_ns - h->cfg.start_ns) / 1e9;
+    // several Sources feeding one Server: slots 1 .. kMaxXSrc of an LP (include/hs_engine.h `src_more_kind`)
+    std::vector<uint8_t> xk((size_t)n * kMaxXSrc, (uint8_t)0);
+    std::vector<double> xr((size_t)n * kMaxXSrc, 1.0), xsum((size_t)n, 0.0);
+    std::vector<int64_t> xstop((size_t)n * kMaxXSrc, (int64_t)-1);
+    int64_t n_xsrc_total = 0;
+    for (int j = 0; j < kMaxXSrc && st->src_more_kind; ++j)
+        for (int i = 0; i < n; ++i) {
+            const size_t o = (size_t)j * n + i;
+            const int k = st->src_more_kind[o];
+            if (k == HS_SRC_NONE) continue;
+            if (k != HS_SRC_POISSON && k != HS_SRC_CONSTANT) return fail(h, HS_E_INVALID, "LP %d: unknown source kind %d in slot %d", i, k, j + 1);
+            const bool prev = j == 0 ? (st->src_kind ? st->src_kind[i] : HS_SRC_POISSON) != HS_SRC_NONE : xk[(size_t)(j - 1) * n + i] != 0;
+            if (!prev) return fail(h, HS_E_INVALID, "LP %d: source slots must be filled from 0", i);
+            if ((st->svc_kind ? st->svc_kind[i] : HS_LAT_CONSTANT) == HS_LAT_NO_SERVER)
+                return fail(h, HS_E_UNSUPPORTED, "LP %d: several Sources need a Server to feed", i);
+            if (st->src_profile_kind && st->src_profile_kind[i] != 0)
+                return fail(h, HS_E_UNSUPPORTED, "LP %d: a time-varying Source next to further Sources is not lowered", i);
+            if (!st->src_more_rate) return fail(h, HS_E_INVALID, "src_more_rate is required with src_more_kind");
+            const double r = st->src_more_rate[o];
+            if (!(r > 0.0) || !std::isfinite(r)) return fail(h, HS_E_INVALID, "LP %d: source rate must be > 0 (got %g)", i, r);
+            if (r > 1e8) return fail(h, HS_E_UNSUPPORTED, "LP %d: source rate %g above 1e8/s is not supported", i, r);
+            xk[o] = (uint8_t)k; xr[o] = r; xsum[(size_t)i] += r;
+            if (st->src_more_stop_after_ns) xstop[o] = st->src_more_stop_after_ns[o];
+            ++n_xsrc_total;
+        }
+    h->any_xsrc = n_xsrc_total > 0;
+    if (h->any_xsrc) h->any_profile = true;                         // such LPs run on the general-path instantiation
     for (int i = 0; i < n; ++i) {
         const int sk = st->src_kind ? st->src_kind[i] : HS_SRC_POISSON;
         if (sk < 0 || sk > 2) return fail(h, HS_E_INVALID, "LP %d: unknown source kind %d", i, sk);
@@ -1880,7 +1955,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
             if (!(r > 0.0) || !std::isfinite(r))
                 return fail(h, HS_E_INVALID, "LP %d: source rate must be > 0 (got %g)", i, r);
             if (r > 1e8) return fail(h, HS_E_UNSUPPORTED, "LP %d: source rate %g above 1e8/s is not supported", i, r);
-            const double m = r * horizon_s;
+            const double m = (r + xsum[(size_t)i]) * horizon_s;
             if (m > max_mean_records) max_mean_records = m;
         }
         const int c = st->concurrency ? st->concurrency[i] : 1;
@@ -1997,27 +2072,56 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     if ((rc = upload<double>(h, &h->P.prof_p, pp.data(), (size_t)n * 4, 0.0))) return rc;
     if ((rc = upload<uint8_t>(h, &h->P.probe_metric, pm.data(), (size_t)n * kMaxProbes, 255))) return rc;
     if ((rc = upload<double>(h, &h->P.probe_rate, prate.data(), (size_t)n * kMaxProbes, 1.0))) return rc;
+    h->P.xsrc_kind = nullptr; h->P.xsrc_rate = nullptr; h->P.xsrc_stop = nullptr;
+    if (h->any_xsrc) {
+        if ((rc = upload<uint8_t>(h, &h->P.xsrc_kind, xk.data(), xk.size(), 0))) return rc;
+        if ((rc = upload<double>(h, &h->P.xsrc_rate, xr.data(), xr.size(), 1.0))) return rc;
+        if ((rc = upload<int64_t>(h, &h->P.xsrc_stop, xstop.data(), xstop.size(), (int64_t)-1))) return rc;
+    }
     h->P.sched_off = nullptr; h->P.sched_t = nullptr;
     if (n_sched > 0) {
         if ((rc = upload<int64_t>(h, &h->P.sched_off, st->sched_off, (size_t)n + 1, 0))) return rc;
         if ((rc = upload<int64_t>(h, &h->P.sched_t, st->sched_time_ns, (size_t)n_sched, 0))) return rc;
     }
     h->P.tie_rank = nullptr;
-    if (st->source_order) {
+    // the Sources in `sources=[...]` order: (LP, slot) pairs; default = LP-major, slot-minor
+    std::vector<int32_t> so;
+    std::vector<uint8_t> sslot;
+    {
+        auto has_src = [&](int lp, int slot) {
+            return slot == 0 ? (st->src_kind ? st->src_kind[lp] : HS_SRC_POISSON) != HS_SRC_NONE : xk[(size_t)(slot - 1) * n + lp] != 0;
+        };
+        int64_t n_src_total = n_xsrc_total;
+        for (int i = 0; i < n; ++i) if (has_src(i, 0)) ++n_src_total;
+        if (st->source_order) {
+            std::vector<uint8_t> taken((size_t)n * (kMaxXSrc + 1), (uint8_t)0);
+            for (int64_t k = 0; k < n_src_total; ++k) {
+                const int lp = st->source_order[k], slot = st->source_slot_order ? st->source_slot_order[k] : 0;
+                if (lp < 0 || lp >= n || slot < 0 || slot > kMaxXSrc || !has_src(lp, slot) || taken[(size_t)slot * n + lp])
+                    return fail(h, HS_E_INVALID, "source_order / source_slot_order must list every Source exactly once");
+                taken[(size_t)slot * n + lp] = 1;
+                so.push_back(lp); sslot.push_back((uint8_t)slot);
+            }
+        } else {
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j <= kMaxXSrc; ++j) if (has_src(i, j)) { so.push_back(i); sslot.push_back((uint8_t)j); }
+        }
+    }
+    if (st->source_order) {   // cross-LP ties go to the LP whose (first) Source the reference constructed first
         std::vector<int32_t> tr((size_t)n, -1);
         int32_t k = 0;
-        for (int i = 0; i < n; ++i)
-            if ((st->src_kind ? st->src_kind[i] : HS_SRC_POISSON) != HS_SRC_NONE) {
-                const int32_t lp = st->source_order[k];
-                if (lp < 0 || lp >= n || tr[(size_t)lp] >= 0 || (st->src_kind ? st->src_kind[lp] : HS_SRC_POISSON) == HS_SRC_NONE)
-                    return fail(h, HS_E_INVALID, "source_order must list every LP that carries a Source exactly once");
-                tr[(size_t)lp] = k++;
-            }
+        for (size_t q = 0; q < so.size(); ++q) if (tr[(size_t)so[q]] < 0) tr[(size_t)so[q]] = k++;
         for (int i = 0; i < n; ++i) if (tr[(size_t)i] < 0) tr[(size_t)i] = k++;
         if ((rc = upload<int32_t>(h, &h->P.tie_rank, tr.data(), (size_t)n, 0))) return rc;
     }
     h->P.sched_idx = nullptr;
-    if (h->cfg.mode == HS_MODE_REPLICAS && (n_sched > 0 || h->any_probe)) {
+    if (h->cfg.mode == HS_MODE_REPLICAS && (n_sched > 0 || h->any_probe || h->any_xsrc)) {
+        {   // every LP's Sources in its own construction order: slots, 255-terminated
+            std::vector<uint8_t> lso((size_t)n * (kMaxXSrc + 1), (uint8_t)255);
+            std::vector<int> cnt((size_t)n, 0);
+            for (size_t q = 0; q < so.size(); ++q) lso[(size_t)cnt[(size_t)so[q]]++ * n + (size_t)so[q]] = sslot[q];
+            if ((rc = upload<uint8_t>(h, &h->XI.lp_src_slots, lso.data(), lso.size(), 255))) return rc;
+        }
         // One prologue per LP (every LP is its own Simulation): its Events sorted by construction rank inside the LP
         std::vector<int64_t> se((size_t)n_sched), sr((size_t)n_sched);
         int64_t span = 0;
@@ -2044,7 +2148,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if ((rc = dev_alloc(h, &h->XI.sched_idx, (size_t)n_sched))) return rc;
         HS_HIP(h, hipMemset(h->XI.sched_idx, 0, (size_t)(n_sched > 0 ? n_sched : 1) * sizeof(uint32_t)));
         h->P.sched_idx = h->XI.sched_idx;
-        const int64_t n_init_lp = 1 + kMaxProbes + span;
+        const int64_t n_init_lp = 1 + kMaxXSrc + kMaxProbes + span;
         h->XI.init_cap_lp = n_init_lp;
         h->XI.heap_cap_lp = n_init_lp + h->C + 32;
         h->XI.pool_cap_lp = 2 * n_init_lp + 64;
@@ -2058,15 +2162,11 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if ((rc = dev_alloc(h, &h->xs, (size_t)n + 1))) return rc;
         h->exact = true;
     }
-    if (h->cfg.mode == HS_MODE_SINGLE && (n_sched > 0 || h->any_probe)) {
+    if (h->cfg.mode == HS_MODE_SINGLE && (n_sched > 0 || h->any_probe || h->any_xsrc)) {
         // The prologue (hs_exact.hpp): the reference's pre-run events in the order it constructs them
-        std::vector<int32_t> so, po, sl((size_t)n_sched);
+        std::vector<int32_t> po, sl((size_t)n_sched);
         std::vector<uint8_t> pslot;
         std::vector<int64_t> se((size_t)n_sched);
-        std::vector<uint8_t> seen((size_t)n, (uint8_t)0);
-        size_t n_src = 0;
-        for (int i = 0; i < n; ++i)
-            if ((st->src_kind ? st->src_kind[i] : HS_SRC_POISSON) != HS_SRC_NONE) ++n_src;
         {   // probes in `probes=[...]` order: (LP, slot) pairs; default = LP-major, slot-minor
             std::vector<uint8_t> taken((size_t)n * kMaxProbes, (uint8_t)0);
             for (int64_t k = 0; k < n_prb_total; ++k) {
@@ -2082,27 +2182,6 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
                     return fail(h, HS_E_INVALID, "probe_order / probe_slot_order must list every probe exactly once");
                 taken[(size_t)slot * n + lp] = 1;
                 po.push_back(lp); pslot.push_back((uint8_t)slot);
-            }
-        }
-        for (int pass = 0; pass < 1; ++pass) {
-            const int32_t *ord = pass == 0 ? st->source_order : st->probe_order;
-            std::vector<int32_t> &out = pass == 0 ? so : po;
-            const size_t want = n_src;
-            std::fill(seen.begin(), seen.end(), (uint8_t)0);
-            for (size_t k = 0; k < want; ++k) {
-                int lp = -1;
-                if (ord) lp = ord[k];
-                else {   // ascending LP order: the next LP that carries one
-                    lp = out.empty() ? 0 : out.back() + 1;
-                    while (lp < n && !(pass == 0 ? (st->src_kind ? st->src_kind[lp] : HS_SRC_POISSON) != HS_SRC_NONE
-                                                 : pm[(size_t)lp] != 255)) ++lp;
-                }
-                const bool has = lp >= 0 && lp < n && (pass == 0 ? (st->src_kind ? st->src_kind[lp] : HS_SRC_POISSON) != HS_SRC_NONE
-                                                                  : pm[(size_t)lp] != 255);
-                if (!has || seen[(size_t)lp])
-                    return fail(h, HS_E_INVALID, "%s must list every LP that carries one exactly once", pass == 0 ? "source_order" : "probe_order");
-                seen[(size_t)lp] = 1;
-                out.push_back(lp);
             }
         }
         std::vector<int32_t> lp_of((size_t)n_sched);
@@ -2124,6 +2203,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         }
         if ((rc = upload<int64_t>(h, &h->XI.sched_rank, sr.data(), sr.size(), 0))) return rc;
         if ((rc = upload<int32_t>(h, &h->XI.src_lp, so.data(), so.size(), 0))) return rc;
+        if ((rc = upload<uint8_t>(h, &h->XI.src_slot, sslot.data(), sslot.size(), 0))) return rc;
         if ((rc = upload<int32_t>(h, &h->XI.probe_lp, po.data(), po.size(), 0))) return rc;
         if ((rc = upload<uint8_t>(h, &h->XI.probe_slot, pslot.data(), pslot.size(), 0))) return rc;
         if ((rc = upload<int32_t>(h, &h->XI.sched_lp, sl.data(), sl.size(), 0))) return rc;
@@ -2160,6 +2240,10 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         AL(PA, N * kMaxProbes); AL(seqP, N * kMaxProbes); AL(crtP, N * kMaxProbes); AL(p_arr, N * kMaxProbes);
         AL(p_n, N * kMaxProbes); AL(ev_probe, N * 2); AL(sched_i, N);
     }
+    if (h->any_xsrc) {
+        AL(XA, N * kMaxXSrc); AL(crtX, N * kMaxXSrc); AL(x_arr, N * kMaxXSrc); AL(x_n, N * kMaxXSrc); AL(seqX, N * kMaxXSrc);
+        AL(x_k, N * kMaxXSrc);
+    }
     if (h->any_probe) {
         h->L.pcap = (int64_t)(horizon_s / min_interval) + 8;
         if ((double)h->L.pcap * (double)n * 16.0 > 50e9) return fail(h, HS_E_INVALID, "probe logs would need %.1f GB", (double)h->L.pcap * n * 16.0 / 1e9);
@@ -2188,6 +2272,7 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     if (h->initialised) return fail(h, HS_E_STATE, "set the network before the first run");
     if (h->cfg.mode != HS_MODE_SINGLE) return fail(h, HS_E_INVALID, "a network of stations is one Simulation: HS_MODE_SINGLE");
     if (h->C > 4) return fail(h, HS_E_UNSUPPORTED, "networked stations support concurrency <= 4 for now");
+    if (h->any_xsrc) return fail(h, HS_E_UNSUPPORTED, "several Sources per Server are lowered for stations without links only");
     HS_HIP(h, hipSetDevice(h->cfg.device));
     const int n = h->cfg.n_lp, nl = net->n_links;
     if (nl < 0) return fail(h, HS_E_INVALID, "n_links < 0");
@@ -2865,6 +2950,18 @@ int64_t hs_engine_read_sinks(hs_engine *h, int64_t *counts, int64_t *t_ns, int64
 
 int64_t hs_engine_read_probe(hs_engine *h, int32_t lp, int64_t *t_ns, int64_t *values, int64_t cap) {
     return hs_engine_read_probe_slot(h, lp, 0, t_ns, values, cap);
+}
+
+int hs_engine_read_source_generated(hs_engine *h, int32_t slot, int64_t *out) {
+    if (!h || !h->have_stations || !out) return fail(h, HS_E_STATE, "stations not set");
+    if (slot < 0 || slot > kMaxXSrc) return fail(h, HS_E_INVALID, "source slot %d out of range", slot);
+    const size_t n = (size_t)h->cfg.n_lp;
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    if (slot == 0) { HS_HIP(h, hipMemcpy(out, h->X.generated, n * 8, hipMemcpyDeviceToHost)); return HS_OK; }
+    if (!h->any_xsrc) { for (size_t i = 0; i < n; ++i) out[i] = 0; return HS_OK; }
+    HS_HIP(h, hipMemcpy(out, h->X.x_n + (size_t)(slot - 1) * n, n * 8, hipMemcpyDeviceToHost));
+    return HS_OK;
 }
 
 int64_t hs_engine_read_probe_slot(hs_engine *h, int32_t lp, int32_t slot, int64_t *t_ns, int64_t *values, int64_t cap) {

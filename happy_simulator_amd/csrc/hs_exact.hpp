@@ -73,6 +73,8 @@ constexpr uint16_t kXInitFlag = 0x8000;   // XEvent::slot: constructed before ru
 
 struct XInit {        // pre-run events in the order the reference constructs them
     const int32_t *src_lp;       // [n_src]   LPs of the Sources in `sources=[...]` order
+    const uint8_t *src_slot;     // [n_src]   ... and their slot on that LP (0 = the LP's first Source, 1.. = further ones)
+    const uint8_t *lp_src_slots; // [kMaxXSrc + 1][n_lp] per_lp: the slots of every LP's Sources in ITS construction order (255 = end)
     const int32_t *probe_lp;     // [n_probe] LPs of the Probes in `probes=[...]` order
     const uint8_t *probe_slot;   // [n_probe] ... and their slot on that LP
     const int32_t *sched_lp;     // [n_sched] LP of the j-th Event handed to schedule(), in construction order
@@ -155,9 +157,19 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
     if (S.phase == 0 && only >= 0) {
         unsigned long long g = 0;
         const int lp = only;
-        if (P.src_kind[lp] != 0 && X.A[lp] != kInfNs) {
-            X.seqA[lp] = 0; S.init_t[g] = X.A[lp];
-            xpush(S, xev(X.A[lp], g++, XE_TICK, lp, 0, 0, kXInitFlag));
+        for (int q = 0; q <= kMaxXSrc; ++q) {                // this Simulation's Sources in `sources=[...]` order
+            const int slot = I.lp_src_slots != nullptr ? I.lp_src_slots[(size_t)q * (size_t)n + lp] : (q == 0 && P.src_kind[lp] != 0 ? 0 : 255);
+            if (slot == 255) break;
+            if (slot == 0) {
+                if (X.A[lp] == kInfNs) continue;
+                X.seqA[lp] = (uint32_t)g; S.init_t[g] = X.A[lp];
+                xpush(S, xev(X.A[lp], g++, XE_TICK, lp, 0, 0, kXInitFlag));
+            } else {
+                const size_t o = (size_t)(slot - 1) * (size_t)n + lp;
+                if (X.XA[o] == kInfNs) continue;
+                X.seqX[o] = (uint32_t)g; S.init_t[g] = X.XA[o];
+                xpush(S, xev(X.XA[o], g++, XE_TICK, lp, 0, 0, (uint16_t)(kXInitFlag | slot)));
+            }
         }
         for (int j = 0; j < kMaxProbes; ++j) {
             const size_t o = (size_t)j * (size_t)n + lp;
@@ -183,11 +195,21 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
         unsigned long long g = 0;
         for (int i = 0; i < I.n_src; ++i) {
             const int lp = I.src_lp[i];
-            const int64_t a = X.A[lp];
-            if (a == kInfNs) continue;                      // "Rate is zero indefinitely. Source will not start." (source.py:137-139)
-            X.seqA[lp] = (uint32_t)g;
-            S.init_t[g] = a;
-            xpush(S, xev(a, g++, XE_TICK, lp, 0, 0, kXInitFlag));
+            const int slot = I.src_slot != nullptr ? I.src_slot[i] : 0;
+            if (slot == 0) {
+                const int64_t a = X.A[lp];
+                if (a == kInfNs) continue;                  // "Rate is zero indefinitely. Source will not start." (source.py:137-139)
+                X.seqA[lp] = (uint32_t)g;
+                S.init_t[g] = a;
+                xpush(S, xev(a, g++, XE_TICK, lp, 0, 0, kXInitFlag));
+            } else {                                        // one of the further Sources of the LP's Server
+                const size_t o = (size_t)(slot - 1) * (size_t)n + lp;
+                const int64_t a = X.XA[o];
+                if (a == kInfNs) continue;
+                X.seqX[o] = (uint32_t)g;
+                S.init_t[g] = a;
+                xpush(S, xev(a, g++, XE_TICK, lp, 0, 0, (uint16_t)(kXInitFlag | slot)));
+            }
         }
         for (int i = 0; i < I.n_probe; ++i) {
             const int lp = I.probe_lp[i];
@@ -238,6 +260,29 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
         switch (e.code) {
         case XE_TICK: {
             // Source.handle_event (load/source.py:142-180): payload first, then the next SourceEvent
+            if ((e.slot & 0xff) != 0) {                              // one of the further Sources of the LP's Server
+                const int j = (int)(e.slot & 0xff) - 1;
+                const size_t o = (size_t)j * N + lp;
+                X.x_n[o] += 1;
+                const int64_t stop = P.xsrc_stop[o];
+                const bool payload = !(stop >= 0 && t > stop);
+                unsigned long long idx_p = 0;
+                if (payload) idx_p = S.G++;
+                double area = 1.0;
+                if (P.xsrc_kind[o] == 1) {
+                    const uint64_t k = X.x_k[o];
+                    area = exp1_from_uniform(xuniform(P.seed[lp], xsrc_stream_id(P.stream_base[lp], j), k));
+                    X.x_k[o] = k + 1;
+                }
+                const int64_t a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(X.x_arr[o]), __ddiv_rn(area, P.xsrc_rate[o])));
+                X.x_arr[o] = a2;
+                if (payload) xpush(S, xev(t, idx_p, XE_ENQ, lp, t));
+                const unsigned long long idx_t = S.G++;
+                xpush(S, xev(a2, idx_t, XE_TICK, lp, 0, 0, (uint16_t)(j + 1)));
+                X.XA[o] = a2 < t ? kInfNs : a2;
+                X.seqX[o] = (uint32_t)idx_t; X.crtX[o] = t;
+                break;
+            }
             X.generated[lp] += 1;
             const int64_t stop = P.src_stop[lp];
             const bool payload = !(stop >= 0 && t > stop);           // SimpleEventProvider.get_events :68

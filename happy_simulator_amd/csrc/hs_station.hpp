@@ -31,6 +31,12 @@ namespace hs {
 enum : uint32_t { Q_PSAMPLE = 0, Q_ENQ = 1, Q_NOTIFY = 2, Q_POLL = 3, Q_DELIVER = 4, Q_TICK = 5, Q_CONT = 6, Q_SINK = 7 };
 constexpr int kMaxProbes = 4;   // Probes per LP (Probe.on_many: several metrics of one entity, instrumentation/probe.py:119-164)
 constexpr int kRootProbe = 100; // pick_root: the pending tick of probe j is kRootProbe + j
+constexpr int kMaxXSrc = 3;     // further Sources feeding the LP's Server (slots 1 .. 3; slot 0 is the LP's first Source)
+constexpr int kRootXSrc = 120;  // pick_root: the pending tick of further Source j is kRootXSrc + j
+// arrival stream of further Source j of an LP: an entity of its own (include/hs_engine.h `src_more_kind`)
+__device__ __forceinline__ uint64_t xsrc_stream_id(uint64_t lp_stream_base, int j) {
+    return stream_id((1ull << 40) | (lp_stream_base << 2) | (uint64_t)j, kStreamArrival);
+}
 constexpr int kRootSched = 98;  // pick_root: the next Request injected with Simulation.schedule()
 
 constexpr int kBlock = 256;     // LPs per workgroup (4 wavefronts)
@@ -103,6 +109,10 @@ struct StationParams {          // read-only, [n_lp] each
     // cross-LP ties the creation times do not decide go to the Source the reference constructed first: the LP's position in
     // `sources=[...]` (sourceless LPs after them); null = LP order
     const int32_t *tie_rank;
+    // further Sources of the LP (PF instantiations, general path): null = none
+    const uint8_t *xsrc_kind;       // [kMaxXSrc][n_lp] 0 none, 1 Poisson, 2 constant
+    const double *xsrc_rate;        // [kMaxXSrc][n_lp]
+    const int64_t *xsrc_stop;       // [kMaxXSrc][n_lp]
 };
 
 // what a Probe samples with getattr(target, metric) (instrumentation/probe.py:51-66)
@@ -137,6 +147,10 @@ struct StationState {           // read-write; [n_lp] each unless noted
     int64_t *crtP, *p_arr, *p_n;   // [kMaxProbes][n_lp] creation time of the pending tick, the provider's current_time, samples taken
     int64_t *ev_probe;          // [2][n_lp] SourceEvent@Probe, probe_event
     int64_t *sched_i;           // [n_lp] index into sched_t of the LP's next scheduled Request (PF instantiation only)
+    // further Sources (PF instantiation only; null = none)
+    int64_t *XA, *crtX, *x_arr, *x_n;   // [kMaxXSrc][n_lp] pending tick, its creation time, provider time, generated_count
+    uint32_t *seqX;             // [kMaxXSrc][n_lp]
+    uint64_t *x_k;              // [kMaxXSrc][n_lp] arrival draws consumed
 };
 
 struct RecordLogs {
@@ -209,6 +223,12 @@ struct Station {
     int64_t *probe_t, *probe_v;     // slot j's log starts at probe_t + j * pcap * ls
     int n_probes;
     uint32_t evp[2];
+    // further Sources feeding this LP's Server (PF): entities of their own, constant or Poisson rate
+    uint32_t x_kind[kMaxXSrc], seqX[kMaxXSrc];
+    double x_rate[kMaxXSrc];
+    int64_t XA[kMaxXSrc], crtX[kMaxXSrc], x_arr[kMaxXSrc], x_n[kMaxXSrc], x_stop[kMaxXSrc];
+    uint64_t x_k[kMaxXSrc], x_base;
+    int n_xsrc;
     // Simulation.schedule() (PF): the next injected Request; it was constructed before run(), so it precedes every
     // run-time event of the same nanosecond
     int64_t SA, sc_i, sc_end;
@@ -480,6 +500,43 @@ struct Station {
         if (do_enqueue(t)) qpush(Q_NOTIFY);
     }
 
+    // ---- further Sources: Source.handle_event (load/source.py:142-180) of an entity of its own; its payload is one more
+    // Request@Server.  Arrival times: ArrivalTimeProvider's constant-rate path, as next_arrival().
+    __device__ __forceinline__ bool has_xsrc() const { return PF && n_xsrc > 0; }
+    __device__ __forceinline__ int64_t xsrc_min() const {
+        int64_t m = kInfNs;
+#pragma unroll
+        for (int j = 0; j < kMaxXSrc; ++j) if (j < n_xsrc && XA[j] < m) m = XA[j];
+        return m;
+    }
+    __device__ __forceinline__ bool xsrc_at(int64_t t) const {
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < kMaxXSrc; ++j) any = any || (j < n_xsrc && XA[j] == t);
+        return any;
+    }
+    __device__ __forceinline__ void root_xsrc(int j, int64_t t) {
+        ev[0]++;
+#pragma unroll
+        for (int i = 0; i < kMaxXSrc; ++i) if (i == j) {
+            x_n[i]++;
+            const bool payload = !(x_stop[i] >= 0 && t > x_stop[i]);     // SimpleEventProvider.get_events :68
+            double area = 1.0;                                            // constant_arrival.py:23
+            if (x_kind[i] == 1) {                                         // poisson_arrival.py:31
+                Stream st;
+                st.init(((uint64_t)key1 << 32) | key0, xsrc_stream_id(x_base, i), x_k[i]);
+                area = exp1_from_uniform(st.next_uniform());
+                x_k[i]++;
+            }
+            const int64_t a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(x_arr[i]), __ddiv_rn(area, x_rate[i])));
+            x_arr[i] = a2;
+            if (payload) qpush(Q_ENQ);
+            if (a2 == t) { XA[i] = kInfNs; qpush(Q_TICK | ((uint32_t)(i + 1) << 3)); }
+            else if (a2 < t) XA[i] = kInfNs;                              // popped later as "time travel" and dropped
+            else { XA[i] = a2; seqX[i] = seq++; crtX[i] = t; }
+        }
+    }
+
     // ---- chains with at most one event in flight (fast path pieces) ---------------------------
     // returns true if the general FIFO must take over (a same-time continuation was created)
     __device__ __forceinline__ bool chain_from_poll(int64_t t) {
@@ -527,11 +584,15 @@ struct Station {
 #pragma unroll
             for (int j = 0; j < kMaxProbes; ++j)
                 if (j < n_probes && PA[j] == t && (best < 0 || (int32_t)(seqP[j] - bs) < 0)) { best = kRootProbe + j; bs = seqP[j]; }
+#pragma unroll
+            for (int j = 0; j < kMaxXSrc; ++j)
+                if (j < n_xsrc && XA[j] == t && (best < 0 || (int32_t)(seqX[j] - bs) < 0)) { best = kRootXSrc + j; bs = seqX[j]; }
         }
         return best;
     }
     __device__ __forceinline__ void run_root(int which, int64_t t) {
         if (which == 0) root_tick(t);
+        else if (PF && which >= kRootXSrc) root_xsrc(which - kRootXSrc, t);
         else if (PF && which >= kRootProbe) root_probe(which - kRootProbe, t);
         else if (PF && which == kRootSched) root_sched(t);
         else root_cont(which - 1, t);
@@ -550,7 +611,10 @@ struct Station {
                     const uint32_t same = do_deliver_work(t);
                     if (same) qpush(Q_CONT | ((same - 1) << 3));
                 } break;
-                case Q_TICK: root_tick(t); break;
+                case Q_TICK:
+                    if (PF && (code >> 3) != 0) { if constexpr (PF) root_xsrc((int)(code >> 3) - 1, t); }
+                    else root_tick(t);
+                    break;
                 case Q_CONT: root_cont((int)(code >> 3), t); break;
                 case Q_SINK: do_sink(); break;
                 case Q_PSAMPLE: if constexpr (PF) do_probe_sample((int)(code >> 3), t); break;
@@ -574,6 +638,7 @@ struct Station {
 #pragma unroll
         for (int i = 0; i < C; ++i) t = D[i] < t ? D[i] : t;
         if constexpr (PF) { if (has_probe()) { const int64_t pm = probe_min(); if (pm < t) t = pm; } if (SA < t) t = SA; }
+        if constexpr (PF) { if (has_xsrc()) { const int64_t xm = xsrc_min(); if (xm < t) t = xm; } }
         return t;
     }
 
@@ -583,6 +648,7 @@ struct Station {
         for (int i = 0; i < C; ++i) n_at += (D[i] == t) ? 1 : 0;
         if constexpr (PF) { if (has_probe() && probe_at(t)) n_at += 2; }  // a probe tick: always the general path
         if constexpr (PF) { if (SA == t) n_at += 2; }                     // so is a scheduled Request
+        if constexpr (PF) { if (has_xsrc() && xsrc_at(t)) n_at += 2; }    // and a tick of one of the LP's further Sources
         if (n_at == 1 && !force_general) {
             // Fast path: one event in flight at a time.  Both kinds of root converge on ONE poll/deliver/work
             // site so that a wavefront whose lanes mix ticks and departures executes the (expensive) service
@@ -638,7 +704,7 @@ struct Station {
         const int64_t buf_enq = buf + (acc ? 1 : 0);
         const bool deliver = poll && buf_enq > 0;                       // queue.py:149-166
         const bool slow = act && (force_general || svc_kind == 2 ||
-                                  (PF && (prof.kind != kProfConstant || has_probe() || has_sched())) ||
+                                  (PF && (prof.kind != kProfConstant || has_probe() || has_sched() || has_xsrc())) ||
                                   (tick && D[0] == t) ||
                                   (tick && ((stop_ns >= 0 && t > stop_ns) || a2 <= t)) || (deliver && dur == 0));
         const bool fast = act && !slow;
@@ -711,7 +777,7 @@ struct Station {
     };
     __device__ __forceinline__ bool req_eligible() const {
         return C == 1 && !force_general && qn == 0 && conc == 1 && qcap < 0 && stop_ns < 0 && svc_kind != 2 &&
-               !(PF && (prof.kind != kProfConstant || has_probe() || has_sched())) &&
+               !(PF && (prof.kind != kProfConstant || has_probe() || has_sched() || has_xsrc())) &&
                (egress == 0 || egress == 1) && !(buf > 0 && active == 0) && active <= 1;
     }
     __device__ __forceinline__ void req_count_departure(ReqCursor &c, bool p, int64_t d, double s) {

@@ -42,6 +42,11 @@ class StationArrays:
     probe_interval_more: np.ndarray | None = None   # [3, n]
     probe_slot_order: np.ndarray | None = None      # slot of every entry of probe_order (None = 0 everywhere)
     sched_rank: np.ndarray | None = None            # like sched_time_ns: the Event's position among all constructed Events
+    # several Sources feeding one Server: slots 1..3 of an LP (slot 0 = src_kind / src_rate / src_stop_after_ns)
+    src_more_kind: np.ndarray | None = None         # [3, n] N.SRC_*; N.SRC_NONE = none
+    src_more_rate: np.ndarray | None = None         # [3, n]
+    src_more_stop_after_ns: np.ndarray | None = None  # [3, n]; None = never
+    source_slot_order: np.ndarray | None = None     # slot of every entry of source_order (None = 0 everywhere)
 
     @staticmethod
     def uniform(n: int, *, src_kind=N.SRC_POISSON, rate=8.0, stop_after_ns=-1, concurrency=1,
@@ -145,12 +150,32 @@ class StationEngine:
                     raise ValueError("sched_rank must hold one position >= 0 per scheduled time")
                 keep.append(co)
                 st.sched_rank = co.ctypes.data if len(co) else None
-        if stations.source_order is not None:
+        if stations.src_more_kind is not None:
+            mk = np.ascontiguousarray(stations.src_more_kind, np.uint8)
+            mr = np.ascontiguousarray(stations.src_more_rate, np.float64)
+            if mk.shape != (3, self.n) or mr.shape != (3, self.n):
+                raise ValueError("src_more_kind / src_more_rate must have shape (3, n)")
+            keep += [mk, mr]
+            st.src_more_kind, st.src_more_rate = mk.ctypes.data, mr.ctypes.data
+            if stations.src_more_stop_after_ns is not None:
+                ms = np.ascontiguousarray(stations.src_more_stop_after_ns, np.int64)
+                if ms.shape != (3, self.n):
+                    raise ValueError("src_more_stop_after_ns must have shape (3, n)")
+                keep.append(ms)
+                st.src_more_stop_after_ns = ms.ctypes.data
+        if stations.source_order is not None:       # (the engine checks that every (LP, slot) Source is listed exactly once)
             a = np.ascontiguousarray(stations.source_order, np.int32)
-            if sorted(a.tolist()) != np.flatnonzero(np.asarray(stations.src_kind) != N.SRC_NONE).tolist():
+            if stations.src_more_kind is None and \
+                    sorted(a.tolist()) != np.flatnonzero(np.asarray(stations.src_kind) != N.SRC_NONE).tolist():
                 raise ValueError("source_order must list exactly the LPs that carry a Source, each once")
             keep.append(a)
             st.source_order = a.ctypes.data if len(a) else None
+            if stations.source_slot_order is not None:
+                b = np.ascontiguousarray(stations.source_slot_order, np.uint8)
+                if b.shape != a.shape:
+                    raise ValueError("source_slot_order must have one entry per entry of source_order")
+                keep.append(b)
+                st.source_slot_order = b.ctypes.data if len(b) else None
         if stations.probe_metric_more is not None:
             pm = np.ascontiguousarray(stations.probe_metric_more, np.uint8)
             pi = np.ascontiguousarray(stations.probe_interval_more, np.float64)
@@ -294,6 +319,12 @@ class StationEngine:
         cr = np.zeros(cap, np.int64)
         got = self._check(self._lib.hs_engine_read_sink(self._h, lp, t.ctypes.data, cr.ctypes.data, cap))
         return t[:got], cr[:got]
+
+    def source_generated(self, slot: int) -> np.ndarray:
+        """Source.generated_count of the Sources in slot 1..3 of every LP (slot 0: lp_stats()["generated"])."""
+        out = np.zeros(self.n, np.int64)
+        self._check(self._lib.hs_engine_read_source_generated(self._h, int(slot), out.ctypes.data))
+        return out
 
     def read_probe(self, lp: int, slot: int = 0, cap: int = 1 << 22):
         """(sample ns, value) of the Probe in `slot` of the LP, in sampling order."""

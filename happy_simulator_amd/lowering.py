@@ -33,6 +33,7 @@ class UnsupportedTopology(NotImplementedError):
 class Station:
     probes: list = field(default_factory=list)       # the Probes sampling this station's entities (up to 4: engine slots)
     source: Source | None = None
+    more_sources: list = field(default_factory=list) # further Sources feeding the same Server (up to 3: engine slots 1..3)
     server: Server | None = None
     sink: _RecordSink | None = None
     router: RandomRouter | None = None
@@ -85,6 +86,16 @@ class LoweredGraph:
                 a.svc_kind[i] = N.LAT_NO_SERVER
                 a.svc_mean_s[i] = 0.0
             a.egress[i] = N.EGRESS_SINK if st.sink is not None else N.EGRESS_NONE
+            for slot, src in enumerate(st.more_sources):
+                if a.src_more_kind is None:
+                    a.src_more_kind = np.full((3, n), N.SRC_NONE, np.uint8)
+                    a.src_more_rate = np.ones((3, n), np.float64)
+                    a.src_more_stop_after_ns = np.full((3, n), -1, np.int64)
+                prov = src._time_provider
+                a.src_more_kind[slot, i] = N.SRC_POISSON if prov.kind == "poisson" else N.SRC_CONSTANT
+                a.src_more_rate[slot, i] = float(prov.profile.peak_rate)
+                stop = src._event_provider._stop_after
+                a.src_more_stop_after_ns[slot, i] = -1 if stop is None else stop.nanoseconds
             for slot, pr in enumerate(st.probes):
                 if a.probe_metric is None:
                     a.probe_metric = np.full(n, N.PROBE_NONE, np.uint8)
@@ -144,7 +155,8 @@ class LoweredGraph:
         of targets behind a RandomRouter) -- also on deep tandems and cycles, where a fixed number of hops undercounts
         (round-1 advisor finding: a 10-station tandem overflowed its logs).  `extra`: injected Requests per station."""
         n = len(self.stations)
-        rate = np.array([st.source.rate if st.source is not None else 0.0 for st in self.stations], np.float64)
+        rate = np.array([(st.source.rate if st.source is not None else 0.0) + sum(x.rate for x in st.more_sources)
+                         for st in self.stations], np.float64)
         mu = np.array([(st.server.concurrency / st.server.service_time.mean) if (st.server is not None and
                        st.server.service_time.mean > 0) else np.inf for st in self.stations], np.float64)
         share = np.array([1.0 / max(len(self.stations[s].router.targets), 1) if self.stations[s].router is not None else 1.0
@@ -181,6 +193,8 @@ def attach_probes(g: LoweredGraph, probes: list) -> None:
             raise UnsupportedTopology(f"probe {type(pr).__name__} is not a lowered Probe")
         i = owner.get(id(pr.target))
         if i is None:
+            if any(pr.target is x for st in g.stations for x in st.more_sources):
+                raise UnsupportedTopology(f"probe '{pr.name}': only the first Source of a Server is sampled on the engine")
             raise UnsupportedTopology(f"probe '{pr.name}': its target is not an entity of this Simulation")
         if id(pr.target) in shared:
             raise UnsupportedTopology(f"probe '{pr.name}': a Sink shared by several stations is not sampled on the engine yet")
@@ -289,8 +303,17 @@ def lower(sources: list, entities: list) -> LoweredGraph:
         tgt = src._event_provider._target
         if isinstance(tgt, Server):
             if id(tgt) in station_of_server:
-                raise UnsupportedTopology(f"server '{tgt.name}' is fed by several sources (not lowered yet)")
-            add_server_station(tgt, src)
+                # several Sources feeding one Server: entities of their own on the same station (engine slots 1..3)
+                st = g.stations[station_of_server[id(tgt)]]
+                if len(st.more_sources) >= 3:
+                    raise UnsupportedTopology(f"server '{tgt.name}' is fed by more than four Sources (the engine's slots per station)")
+                for x in (st.source, src):
+                    if not isinstance(x._time_provider.profile, ConstantRateProfile):
+                        raise UnsupportedTopology(f"source '{x.name}': a time-varying profile next to further Sources of the "
+                                                  "same Server is not lowered")
+                st.more_sources.append(src)
+            else:
+                add_server_station(tgt, src)
         elif isinstance(tgt, _SINKS):
             st = Station(source=src)
             check_sink(tgt, f"source '{src.name}'")
@@ -357,6 +380,11 @@ def write_back(g: LoweredGraph, stats: dict, counts: np.ndarray, t_ns: np.ndarra
             ep = st.source._event_provider
             ep._generated = int(stats["accepted"][i] + stats["dropped"][i]) if st.server is not None else int(
                 counts[i])
+            if st.more_sources:              # the Server's arrivals are the union: per Source, its own tick count
+                ep._generated = st.source._generated_count
+                for slot, x in enumerate(st.more_sources):
+                    x._generated_count = int(stats["generated_more"][slot][i])
+                    x._event_provider._generated = x._generated_count
         if st.server is not None:
             sv = st.server
             sv._queue.stats_accepted = int(stats["accepted"][i])

@@ -90,6 +90,13 @@ def _concat(arrs: list[StationArrays]) -> StationArrays:
                                                 else np.full((3, a.n), N.PROBE_NONE, np.uint8) for a in arrs], axis=1)
         out.probe_interval_more = np.concatenate([a.probe_interval_more if a.probe_interval_more is not None
                                                   else np.ones((3, a.n), np.float64) for a in arrs], axis=1)
+    if any(a.src_more_kind is not None for a in arrs):
+        out.src_more_kind = np.concatenate([a.src_more_kind if a.src_more_kind is not None
+                                            else np.full((3, a.n), N.SRC_NONE, np.uint8) for a in arrs], axis=1)
+        out.src_more_rate = np.concatenate([a.src_more_rate if a.src_more_kind is not None
+                                            else np.ones((3, a.n), np.float64) for a in arrs], axis=1)
+        out.src_more_stop_after_ns = np.concatenate([a.src_more_stop_after_ns if a.src_more_kind is not None
+                                                     else np.full((3, a.n), -1, np.int64) for a in arrs], axis=1)
     if any(a.sched_off is not None for a in arrs):
         offs, times, ranks, base = [np.zeros(1, np.int64)], [], [], 0
         for a in arrs:
@@ -148,12 +155,21 @@ def _run_independent(sims: list[Simulation], seeds: list[int], device: int = 0,
         cancelled.append(s._schedule_arrays(g, a))         # Simulation.schedule() calls of this replica
         per_sim.append(a)
     st = _concat(per_sim)
+    if st.src_more_kind is not None:     # several Sources per Server: every replica's `sources=[...]` order (its own prologue)
+        order, slots = [], []
+        for i, (s, g) in enumerate(zip(sims, graphs)):
+            where = {id(g.stations[0].source): 0, **{id(x): 1 + k for k, x in enumerate(g.stations[0].more_sources)}}
+            for src in s._sources:
+                order.append(i)
+                slots.append(where[id(src)])
+        st.source_order, st.source_slot_order = np.asarray(order, np.int32), np.asarray(slots, np.uint8)
     st.seed = np.asarray(seeds, np.uint64)
     st.stream_base = (np.zeros(st.n, np.uint64) if stream_bases is None else np.asarray(stream_bases, np.uint64))
     wall0 = _time.monotonic()
     with StationEngine(st, mode=N.MODE_REPLICAS, horizon_ns=end_ns, start_ns=start_ns, device=device) as eng:
         eng.run_until(end_ns)
         stats = eng.lp_stats()
+        more = [eng.source_generated(1 + k) for k in range(3)] if st.src_more_kind is not None else None
         counts, t_ns, created_ns = eng.read_sinks()
         for i, (s, g) in enumerate(zip(sims, graphs)):
             if s._probes:
@@ -164,6 +180,8 @@ def _run_independent(sims: list[Simulation], seeds: list[int], device: int = 0,
     for i, (s, g) in enumerate(zip(sims, graphs)):
         c = int(counts[i])
         sl = {k: v[i:i + 1] for k, v in stats.items()}
+        if more is not None:
+            sl["generated_more"] = [m[i:i + 1] for m in more]
         write_back(g, sl, counts[i:i + 1], t_ns[off:off + c], created_ns[off:off + c])
         off += c
         s._events_processed = int(stats["events"][i])

@@ -166,8 +166,13 @@ class Simulation:
         horizon_s = (end_ns - self._start_time.nanoseconds) / 1e9
         arrays = g.arrays()
         # the order in which Simulation.__init__ constructs the first SourceEvents / probe ticks (core/simulation.py:145-160)
-        st_of = {id(st.source): i for i, st in enumerate(g.stations) if st.source is not None}
-        arrays.source_order = np.array([st_of[id(s)] for s in self._sources], np.int32)
+        st_of = {id(st.source): (i, 0) for i, st in enumerate(g.stations) if st.source is not None}
+        st_of.update({id(x): (i, 1 + k) for i, st in enumerate(g.stations) for k, x in enumerate(st.more_sources)})
+        arrays.source_order = np.array([st_of[id(s)][0] for s in self._sources], np.int32)
+        if any(st.more_sources for st in g.stations):
+            if g.is_network:
+                raise UnsupportedTopology("several Sources per Server are lowered for stations without links only")
+            arrays.source_slot_order = np.array([st_of[id(s)][1] for s in self._sources], np.uint8)
         if self._probes:
             where = {id(pr): (i, slot) for i, st in enumerate(g.stations) for slot, pr in enumerate(st.probes)}
             arrays.probe_order = np.array([where[id(p)][0] for p in self._probes], np.int32)
@@ -181,6 +186,8 @@ class Simulation:
             eng.run_until(end_ns)
             es = eng.summary()
             stats = eng.lp_stats()
+            if arrays.src_more_kind is not None:
+                stats["generated_more"] = [eng.source_generated(1 + k) for k in range(3)]
             counts, t_ns, created_ns = eng.read_sinks()
             net_stats = eng.net_stats() if net is not None else None
             if self._probes:

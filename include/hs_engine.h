@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HS_ABI_VERSION 6
+#define HS_ABI_VERSION 7
 
 typedef enum hs_status {
     HS_OK = 0,
@@ -150,6 +150,18 @@ typedef struct hs_stations {
                                           Events the caller constructed for schedule(), distinct and >= 0 (an Event that was
                                           cancelled before run() keeps its position -- it consumed a sort index -- but is not
                                           passed to the engine); NULL = array order */
+    /* Several Sources feeding one Server (`Source.poisson(rate, target=server)` more than once; load/source.py:142-180 runs per
+     * Source): slots 1 .. 3 of the LP (slot 0 = src_kind / src_rate / src_stop_after_ns above); slots are filled from 0.  Each
+     * is an entity of its own with its own arrival stream -- stream base (1 << 40) | (stream_base[lp] << 2) | (slot - 1), kind
+     * ARRIVAL -- constant or Poisson rate (no profile).  An LP with more than one Source runs on the engines' general path, and
+     * the run starts with the prologue (csrc/hs_exact.hpp): the first ticks of an LP's Sources carry consecutive pre-run sort
+     * indices, which run-time events of the same nanosecond can overtake.  source_slot_order[k] = slot of the k-th entry of
+     * source_order (an LP with several Sources appears several times there); NULL = every entry is slot 0.  Station engine
+     * only (hs_engine_set_network refuses such LPs).  NULL = one Source per LP at most. */
+    const uint8_t *src_more_kind;      /* [3][n_lp] hs_source_kind; HS_SRC_NONE = none */
+    const double *src_more_rate;       /* [3][n_lp] */
+    const int64_t *src_more_stop_after_ns; /* [3][n_lp] < 0 = never; NULL = never */
+    const uint8_t *source_slot_order;  /* [number of Sources] */
 } hs_stations;
 typedef enum hs_probe_metric {
     HS_PROBE_DEPTH = 0,        /* QueuedResource.depth */
@@ -440,6 +452,9 @@ int hs_sink_latency_stats(int32_t device, int64_t n, const int64_t *t_ns, const 
 int64_t hs_engine_read_probe(hs_engine *h, int32_t lp, int64_t *t_ns, int64_t *values, int64_t cap);
 /* ... of the probe in `slot` (0 .. 3) of the LP */
 int64_t hs_engine_read_probe_slot(hs_engine *h, int32_t lp, int32_t slot, int64_t *t_ns, int64_t *values, int64_t cap);
+/* Source.generated_count of the Sources in `slot` (1 .. 3: hs_stations.src_more_*; slot 0 = hs_lp_stats.generated) of
+ * every LP -> out[n_lp]. */
+int hs_engine_read_source_generated(hs_engine *h, int32_t slot, int64_t *out);
 
 const char *hs_last_error(const hs_engine *h);
 const char *hs_last_global_error(void);

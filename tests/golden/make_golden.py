@@ -147,6 +147,31 @@ def _per_chain(v, n):
     return list(v) if isinstance(v, (list, tuple)) else [v] * n
 
 
+def source_plan(spec, chain_ids):
+    """`sources=[...]` of a case: the list order as (chain, slot) pairs and, per chain, its Sources in slot order
+    [(arrival kind, rate, is the chain's `rate` / `arr` / `profile` Source)].  A chain's slot = the position among ITS Sources
+    in the list.  sources_order "chain" (default): every chain's first Source followed by its `more_sources`; "extras_first":
+    the `more_sources` (last chain first) before all first Sources."""
+    n = spec["n_chains"]
+    rate, arr = _per_chain(spec["rate"], n), _per_chain(spec["arr"], n)
+    profiles = spec.get("profile") or [None] * n
+    more = spec.get("more_sources") or [None] * n
+    has_first = {c: not (rate[c] == 0 and profiles[c] is None) for c in chain_ids}
+    firsts = [(c, (arr[c], rate[c], True)) for c in chain_ids if has_first[c]]
+    if spec.get("sources_order") == "extras_first":
+        listed = [(c, (xa, xr, False)) for c in reversed(chain_ids) for xa, xr in (more[c] or [])] + firsts
+    else:
+        listed = []
+        for c in chain_ids:
+            listed += [(c, (arr[c], rate[c], True))] * has_first[c] + [(c, (xa, xr, False)) for xa, xr in (more[c] or [])]
+    slot_plan = {c: [] for c in chain_ids}
+    order = []
+    for c, what in listed:
+        order.append((c, len(slot_plan[c])))
+        slot_plan[c].append(what)
+    return order, slot_plan
+
+
 def build_chains(spec, chain_ids, seed):
     """Build reference entities for the given chains; returns (sources, entities, handles)."""
     n = spec["n_chains"]
@@ -167,7 +192,8 @@ def build_chains(spec, chain_ids, seed):
             return LinearRampProfile(duration_s=pr[1], start_rate=pr[2], end_rate=pr[3])
         return SpikeProfile(baseline_rate=pr[1], spike_rate=pr[2], warmup_s=pr[3], spike_duration_s=pr[4])
 
-    sources, entities, handles = [], [], []
+    sources, entities, handles, extras, by_slot = [], [], [], {}, {}
+    order, slot_plan = source_plan(spec, list(chain_ids))
     for local, i in enumerate(chain_ids):
         base = i if spec["mode"] == "single" else 0
         if spec.get("shared_sink"):      # one collector behind every server: its lists are in global processing order
@@ -185,24 +211,32 @@ def build_chains(spec, chain_ids, seed):
         else:
             st = ConstantLatency(mean[i])
         server = Server(f"srv{i}", concurrency=conc[i], service_time=st, queue_capacity=qcap[i], downstream=sink)
-        if rate[i] == 0 and profiles[i] is None:
-            source = None                 # a station fed by Simulation.schedule() only
-        elif spec["rng"] == "philox":
+        # The chain's Sources in slot order (slot = position among the chain's Sources in `sources=[...]`): slot 0 draws from
+        # the chain's ARRIVAL stream, slot j >= 1 from stream base (1 << 40) | (base << 2) | (j - 1)
+        # (include/hs_engine.h `src_more_kind`).  Several Sources feeding one Server are entities of their own.
+        made = []
+        for slot, (sa, sr, is_first) in enumerate(slot_plan[i]):
             stop_instant = None if stop is None else Instant.from_seconds(stop)
-            if arr[i] == "poisson":
-                prov = PhiloxPoissonArrival(make_profile(i), Instant.Epoch, hs.Stream(seed, base, hs.STREAM_ARRIVAL))
+            if spec["rng"] != "philox":
+                factory = Source.poisson if sa == "poisson" else Source.constant
+                made.append(factory(rate=sr, target=server, name=f"src{i}" + ("" if is_first else f"_{slot}"), stop_after=stop))
+                continue
+            prof = make_profile(i) if is_first else ConstantRateProfile(rate=sr)
+            if sa == "poisson":
+                sbase = base if slot == 0 else (1 << 40) | (base << 2) | (slot - 1)
+                prov = PhiloxPoissonArrival(prof, Instant.Epoch, hs.Stream(seed, sbase, hs.STREAM_ARRIVAL))
             else:
-                prov = ConstantArrivalTimeProvider(make_profile(i), start_time=Instant.Epoch)
-            source = Source(f"src{i}", SimpleEventProvider(server, "Request", stop_instant), prov)
-        else:
-            factory = Source.poisson if arr[i] == "poisson" else Source.constant
-            source = factory(rate=rate[i], target=server, name=f"src{i}", stop_after=stop)
-        if source is not None:
-            sources.append(source)
+                prov = ConstantArrivalTimeProvider(prof, start_time=Instant.Epoch)
+            made.append(Source(f"src{i}" + ("" if is_first else f"_{slot}"), SimpleEventProvider(server, "Request", stop_instant), prov))
+        by_slot[i] = made
+        source = made[0] if made else None
+        extras[i] = made[1:]
         entities.append(server)
         if sink is not None and not any(e is sink for e in entities):
             entities.append(sink)
         handles.append((source, server, sink))
+    sources = [by_slot[c][slot] for c, slot in order]
+    build_chains._extras = extras
     return sources, entities, handles
 
 
@@ -269,6 +303,8 @@ def run_sim(spec, chain_ids, seed, want_trace):
         c = chain_ids[local]
         if src is not None:
             node_of[id(src)] = c
+        for x in build_chains._extras.get(c, []):
+            node_of[id(x)] = c
         node_of[id(srv)] = c
         node_of[id(srv._queue)] = c
         node_of[id(srv._driver)] = c
@@ -313,6 +349,7 @@ def run_case(spec):
     stats = {k: np.zeros(n, np.int64) for k in
              ("generated", "accepted", "dropped", "completed", "rejected", "received", "depth", "active")}
     total_service = np.zeros(n, np.float64)
+    gen_more = np.zeros((3, n), np.int64)
     sink_t, sink_lat, sink_off = [], [], [0]
     traces = []
     totals, finals, durations = [], [], []
@@ -331,6 +368,8 @@ def run_case(spec):
         for local, (src, srv, snk) in enumerate(handles):
             i = chain_ids[local]
             stats["generated"][i] = src.generated_count if src is not None else 0
+            for j, x in enumerate(build_chains._extras.get(i, [])):
+                gen_more[j, i] = x.generated_count
             stats["accepted"][i] = srv.stats_accepted
             stats["dropped"][i] = srv.stats_dropped
             stats["completed"][i] = srv._requests_completed
@@ -365,6 +404,8 @@ def run_case(spec):
     for k, v in stats.items():
         out[k] = v
     out["total_service_s"] = total_service
+    if spec.get("more_sources"):
+        out["generated_more"] = gen_more
     out["sink_t_ns"] = np.asarray(sink_t, np.int64)
     out["sink_latency_s"] = np.asarray(sink_lat, np.float64)
     out["sink_off"] = np.asarray(sink_off, np.int64)
@@ -720,6 +761,21 @@ CASES = [
          schedule=[[0, 2.000000001], [1, 3.3000001], [2, 1.0], [2, 1.1], [3, 0.7500003], [0, 2.000000001], [3, 9.1],
                    [1, 0.05], [2, 6.123456789], [0, 11.9999], [3, 12.5]],
          end_s=12.0, rng="philox", seed=42, mode="single", trace=True),
+    # --- several Sources feeding one Server (each an entity of its own; load/source.py:142-180) --------------------------------
+    dict(name="multi_source_4chains", n_chains=4, arr=["poisson", "constant", "poisson", "constant"], rate=[6.0, 4.0, 9.0, 5.0],
+         svc="exp", mean=[0.06, 0.08, 0.05, 0.1], concurrency=[1, 2, 1, 1], queue_cap=[None, 3, None, None],
+         more_sources=[[["poisson", 5.0]], [["constant", 4.0], ["poisson", 3.0], ["constant", 2.0]], None, [["constant", 5.0]]],
+         end_s=12.0, rng="philox", seed=81, mode="single", trace=True),
+    dict(name="multi_source_order", n_chains=3, arr=["constant", "poisson", "constant"], rate=[4.0, 7.0, 2.0],
+         svc=["const", "exp", "exp"], mean=[0.05, 0.07, 0.2], concurrency=[1, 1, 2], queue_cap=[2, None, None],
+         more_sources=[[["constant", 4.0], ["constant", 2.0]], [["poisson", 6.0]], [["constant", 2.0], ["constant", 1.0]]],
+         sources_order="extras_first", probes=[["depth", 0.25], None, [["stats_accepted", 0.5], ["active_requests", 0.5]]],
+         schedule=[[0, 0.25], [2, 0.5], [2, 0.5], [1, 1.0]], stop_after_s=8.0,
+         end_s=10.0, rng="philox", seed=82, mode="single", trace=True),
+    dict(name="multi_source_replicas", n_chains=5, arr=["poisson", "constant", "poisson", "constant", "poisson"], rate=[6.0, 4.0, 9.0, 5.0, 3.0],
+         svc="exp", mean=[0.06, 0.08, 0.05, 0.1, 0.12], concurrency=[1, 2, 1, 1, 1],
+         more_sources=[[["poisson", 5.0]], [["constant", 4.0], ["constant", 2.0]], None, [["constant", 5.0]], [["poisson", 2.0], ["poisson", 2.0]]],
+         sources_order="extras_first", end_s=10.0, rng="philox", seed=83, mode="replicas"),
     # --- probes: Probe.on(target, metric, interval) = a daemon Source sampling an attribute --------
     dict(name="probe_depth_4chains", n_chains=4, arr="poisson", rate=[12.0, 9.0, 30.0, 8.0], svc="exp", mean=[0.1, 0.1, 0.05, 0.1],
          concurrency=[1, 1, 2, 1], queue_cap=[None, None, 6, None],

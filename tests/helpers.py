@@ -101,7 +101,44 @@ def spec_chain_params(spec):
         schedule=[(int(c), ns_from_seconds(float(t))) for c, t in (spec.get("schedule") or [])],
         no_source=[float(r) == 0.0 and pr is None
                    for r, pr in zip(per_chain(spec["rate"], n), spec.get("profile") or [None] * n)],
+        # several Sources feeding one Server: per chain [(arrival kind, rate)] of the further ones
+        more_sources=[[(O.ARR_POISSON if a == "poisson" else O.ARR_CONSTANT, float(r)) for a, r in (xs or [])]
+                      for xs in (spec.get("more_sources") or [None] * n)],
     )
+
+
+def source_plan(spec, chain_ids):
+    """make_golden.source_plan: `sources=[...]` of a case as (chain, slot) pairs in list order and, per chain, its Sources in
+    slot order [(oracle arrival kind, rate, is the chain's `rate` / `arr` / `profile` Source)]; a chain's slot = the position
+    among ITS Sources in the list."""
+    n = spec["n_chains"]
+    rate, arr = per_chain(spec["rate"], n), per_chain(spec["arr"], n)
+    profiles = spec.get("profile") or [None] * n
+    more = spec.get("more_sources") or [None] * n
+    kind = lambda a: O.ARR_POISSON if a == "poisson" else O.ARR_CONSTANT
+    has_first = {c: not (float(rate[c]) == 0.0 and profiles[c] is None) for c in chain_ids}
+    firsts = [(c, (kind(arr[c]), float(rate[c]), True)) for c in chain_ids if has_first[c]]
+    if spec.get("sources_order") == "extras_first":
+        listed = [(c, (kind(xa), float(xr), False)) for c in reversed(chain_ids) for xa, xr in (more[c] or [])] + firsts
+    else:
+        listed = []
+        for c in chain_ids:
+            listed += ([(c, (kind(arr[c]), float(rate[c]), True))] * has_first[c] +
+                       [(c, (kind(xa), float(xr), False)) for xa, xr in (more[c] or [])])
+    slot_plan = {c: [] for c in chain_ids}
+    order = []
+    for c, what in listed:
+        order.append((c, len(slot_plan[c])))
+        slot_plan[c].append(what)
+    return order, slot_plan
+
+
+def source_order_for(spec, chain_ids):
+    return source_plan(spec, list(chain_ids))[0]
+
+
+def xsrc_stream_base(base, j):
+    return (1 << 40) | (base << 2) | j
 
 
 # Probe metric name -> (entity of the chain that carries it, oracle metric id, engine metric id); make_golden.PROBE_METRICS
@@ -142,11 +179,16 @@ def oracle_graph_for(spec, chain_ids, stream_bases):
     p = spec_chain_params(spec)
     g = O.Graph()
     nodes = {}
-    srcs = []
-    for c, base in zip(chain_ids, stream_bases):
-        srcs.append(-1 if p["no_source"][c] else
-                    g.source(p["arr"][c], p["rate"][c], stop_after_ns=p["stop_ns"], stream_base=base,
-                             profile=p["profile"][c]))
+    base_of = dict(zip(chain_ids, stream_bases))
+    made = {}
+    order, slot_plan = source_plan(spec, list(chain_ids))
+    for c, slot in order:                                          # Source nodes in `sources=[...]` order
+        xa, xr, is_first = slot_plan[c][slot]
+        made[(c, slot)] = g.source(xa, xr, stop_after_ns=p["stop_ns"],
+                                   stream_base=base_of[c] if slot == 0 else xsrc_stream_base(base_of[c], slot - 1),
+                                   profile=p["profile"][c] if is_first else None)
+    srcs = [made.get((c, 0), -1) for c in chain_ids]
+    g.xsrc_nodes = {k: v for k, v in made.items() if k[1] > 0}
     for k, (c, base) in enumerate(zip(chain_ids, stream_bases)):
         sv = g.server(p["svc"][c], p["mean"][c], concurrency=p["conc"][c], queue_cap=p["qcap"][c], stream_base=base)
         if spec.get("shared_sink"):        # one Sink node behind every server; its records are reported under the first chain
@@ -157,6 +199,9 @@ def oracle_graph_for(spec, chain_ids, stream_bases):
             sk = g.sink() if p["downstream"] else -1
         if srcs[k] >= 0:
             g.target[srcs[k]] = sv
+        for (cc, slot), nd in g.xsrc_nodes.items():
+            if cc == c:
+                g.target[nd] = sv
         g.target[sv] = sk
         nodes[c] = (srcs[k], sv, sk if not (spec.get("shared_sink") and k > 0) else -1)
     g.probe_nodes, g.probe_nodes_all = {}, {}
@@ -186,7 +231,7 @@ def run_oracle_for_spec(spec, trace_cap=0):
         r = O.run(g, p["end_ns"], seed=seed, rng_mode=rng, mt_seed_py=seed & 0xFFFFFFFF,
                   mt_seed_np=seed & 0xFFFFFFFF, trace_cap=trace_cap,
                   schedule=[(nodes[c][1], t) for c, t in p["schedule"] if c in nodes])
-        r.probe_nodes, r.probe_nodes_all = g.probe_nodes, g.probe_nodes_all
+        r.probe_nodes, r.probe_nodes_all, r.xsrc_nodes = g.probe_nodes, g.probe_nodes_all, g.xsrc_nodes
         runs.append((chain_ids, nodes, r))
     return runs
 
@@ -305,6 +350,20 @@ def engine_for_spec(spec, log_capacity=0, horizon_ns=None, flags=0):
             st.src_profile_params[i, :len(pr) - 1] = pr[1:]
             st.src_rate[i] = max(pr[2], pr[3]) if pr[0] == "ramp" else max(pr[1], pr[2])     # peak: sizes the logs
     _probe_arrays(st, p, n)
+    if any(p["more_sources"]):
+        order, slot_plan = source_plan(spec, list(range(n)))
+        st.src_more_kind = np.full((3, n), N.SRC_NONE, np.uint8)
+        st.src_more_rate = np.ones((3, n), np.float64)
+        st.src_more_stop_after_ns = np.full((3, n), p["stop_ns"], np.int64)
+        for i in range(n):
+            for slot, (xa, xr, _) in enumerate(slot_plan[i]):
+                k = N.SRC_POISSON if xa == O.ARR_POISSON else N.SRC_CONSTANT
+                if slot == 0:
+                    st.src_kind[i], st.src_rate[i] = k, xr
+                else:
+                    st.src_more_kind[slot - 1, i], st.src_more_rate[slot - 1, i] = k, xr
+        st.source_order = np.array([c for c, _ in order], np.int32)
+        st.source_slot_order = np.array([sl for _, sl in order], np.uint8)
     if p["schedule"]:              # Simulation.schedule(): per station ascending, ties in call order (stable sort)
         st.sched_off, st.sched_time_ns, st.sched_rank = sched_arrays(n, p["schedule"], per_station=spec["mode"] != "single")
     if spec["mode"] == "single":

@@ -116,3 +116,30 @@ def tie_spec(k):
     if rng.random() < 0.15 and spec["downstream"] and "probes" not in spec:
         spec["shared_sink"] = True
     return spec
+
+
+def multi_source_spec(k):
+    """Several Sources feeding one Server (entities of their own, lowered onto the station's slots 1..3): a tie storm (even k)
+    or a random station configuration (odd k) with up to three further Sources on some chains, listed after their chain's
+    first Source or all in front (`sources_order`) -- lock-step constant Sources on ONE Server are the tie storm the prologue
+    has to order exactly."""
+    rng = np.random.default_rng(70_000 + k)
+    spec = tie_spec(1000 + k) if k % 2 == 0 else station_spec(1000 + k)
+    spec["name"] = f"multi_source_{k}"
+    spec.pop("profile", None)                                       # (not lowered next to further Sources)
+    spec.pop("shared_sink", None)
+    n = spec["n_chains"]
+    rate = spec["rate"] if isinstance(spec["rate"], list) else [spec["rate"]] * n
+    more = []
+    for i in range(n):
+        cnt = int(rng.choice([0, 1, 1, 2, 3]))
+        more.append([[str(rng.choice(["constant", "poisson"])), float(rate[i]) * float(rng.choice([1.0, 1.0, 0.5, 2.0]))]
+                     for _ in range(cnt)] or None)
+    if not any(more):
+        more[0] = [["constant", float(rate[0])]]
+    spec["more_sources"] = more
+    if rng.random() < 0.5:
+        spec["sources_order"] = "extras_first"
+    if spec.get("probes"):                                          # generated_count is sampled on a chain's first Source only
+        spec["probes"] = [None if pr is None or pr[0] == "generated_count" else pr for pr in spec["probes"]]
+    return spec

@@ -355,6 +355,75 @@ def test_probes_through_the_api_match_reference_golden(name):
     assert [c[2].events_received for c in chains] == gold.received.tolist()
 
 
+@pytest.mark.parametrize("name", ["multi_source_4chains", "multi_source_order", "multi_source_replicas"])
+def test_several_sources_per_server_through_the_api_match_reference_golden(name):
+    """`Source.poisson(rate, target=server)` several times for one Server: every Source is an entity of its
+    own with its own arrival stream; `sources=[...]` lists them in make_golden's order (multi_source_order: the further
+    Sources first, which changes the pre-run sort indices; it also carries probes, schedule() calls and stop_after);
+    multi_source_replicas runs one Simulation per chain through ParallelRunner (one prologue per lane)."""
+    gold = H.Golden(name)
+    spec = gold.spec
+    p = H.spec_chain_params(spec)
+
+    order, slot_plan = H.source_plan(spec, list(range(p["n"])))
+
+    def build(i):
+        sink = hs.Sink(f"sink{i}")
+        lat = hs.ExponentialLatency(p["mean"][i]) if p["svc"][i] == H.O.LAT_EXP else hs.ConstantLatency(p["mean"][i])
+        srv = hs.Server(f"srv{i}", concurrency=p["conc"][i], service_time=lat,
+                        queue_capacity=None if p["qcap"][i] < 0 else p["qcap"][i], downstream=sink)
+        stop = spec.get("stop_after_s")
+        srcs = [(hs.Source.poisson if kind == H.O.ARR_POISSON else hs.Source.constant)(
+                    rate=rate, target=srv, name=f"src{i}_{slot}", stop_after=stop)
+                for slot, (kind, rate, _) in enumerate(slot_plan[i])]       # slot = position among the Server's Sources in `sources=`
+        return srcs, srv, sink
+
+    def check(i, srcs, srv, sink):
+        assert srcs[0].generated_count == gold.generated[i]
+        for j, x in enumerate(srcs[1:]):
+            assert x.generated_count == gold.generated_more[j, i], (i, j)
+        assert (srv.stats_accepted, srv.stats_dropped, srv.depth) == (gold.accepted[i], gold.dropped[i], gold.depth[i])
+        assert srv._total_service_time == gold.total_service_s[i]
+        gt, glat = gold.sink_records(i)
+        assert [t.nanoseconds for t in sink.completion_times] == gt.tolist() and sink.latencies_s == glat.tolist()
+
+    if spec["mode"] == "replicas":
+        built = {}
+
+        def make(i):
+            def fn():
+                srcs, srv, sink = built[i] = build(i)
+                return hs.Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=[srcs[sl] for c, sl in order if c == i],
+                                     entities=[srv, sink])
+            return fn
+        res = hs.ParallelRunner().run_sweep([hs.RunConfig(name=f"r{i}", build_fn=make(i), seed=spec["seed"] + i)
+                                             for i in range(p["n"])])
+        assert [r.summary.total_events_processed for r in res] == gold.meta["total_events"]
+        for i in range(p["n"]):
+            check(i, *built[i])
+        return
+    chains = [build(i) for i in range(p["n"])]
+    listed = [chains[c][0][sl] for c, sl in order]
+    probes, datas = [], {}
+    for i, prs in enumerate(p["probe_list"]):
+        for j, (metric, interval) in enumerate(prs):
+            pr, d = hs.Probe.on(chains[i][1], metric, interval=interval)
+            probes.append(pr)
+            datas[(i, j)] = d
+    sim = hs.Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=listed,
+                        entities=[e for c in chains for e in c[1:]], probes=probes, seed=spec["seed"])
+    for c, t_s in spec.get("schedule") or []:
+        sim.schedule(hs.Event(time=Instant.from_seconds(t_s), event_type="Request", target=chains[c][1]))
+    summary = sim.run()
+    assert summary.total_events_processed == gold.meta["total_events"][0]
+    assert summary.duration_s == gold.meta["duration_s"][0]
+    for i, c in enumerate(chains):
+        check(i, *c)
+    for (i, j), d in datas.items():
+        gt, gv = gold.probe_samples(i, j)
+        assert d.raw_values() == gv.tolist() and d.times() == (gt.astype(np.float64) / 1e9).tolist()
+
+
 def test_schedule_through_the_api_matches_reference_golden():
     """Simulation.schedule(Event(...)) before run() (core/simulation.py:195-206): stations fed only by scheduled Requests,
     and scheduled Requests on top of Sources -- against what the live reference produced for the same calls."""

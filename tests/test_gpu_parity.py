@@ -117,6 +117,9 @@ def test_engine_matches_reference_golden(name):
                 assert stats[k].sum() == gold.arrays[g][0]
                 continue
             np.testing.assert_array_equal(stats[k], gold.arrays[g], err_msg=k)
+        if "generated_more" in gold.arrays:          # several Sources per Server: every Source's own generated_count
+            for j in range(3):
+                np.testing.assert_array_equal(eng.source_generated(1 + j), gold.generated_more[j], err_msg=f"source slot {1 + j}")
         counts, t, cr = eng.read_sinks()
         if shared:                                   # per-station logs -> the shared Sink's lists (device merge by time)
             from happy_simulator_amd import _native as N

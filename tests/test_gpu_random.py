@@ -68,6 +68,22 @@ def test_network_engines_match_oracle_on_random_specs(k, engine_flags):
     check_ring_case(k, engine_flags)
 
 
+@pytest.mark.parametrize("k", range(60))
+def test_several_sources_per_server_match_oracle(k):
+    """Up to four Sources feeding one Server (random_specs.multi_source_spec: tie storms and random configurations, two
+    `sources=[...]` orders, single heap and replicas): engine == oracle, which tests/test_oracle_live_reference.py checks
+    against the live reference on the same 60 cases."""
+    spec = RS.multi_source_spec(k)
+    check_station_case(k, spec)
+    runs = H.run_oracle_for_spec(spec)
+    eng, p = H.engine_for_spec(spec)
+    with eng:
+        eng.run_until(p["end_ns"])
+        for chain_ids, nodes, r in runs:
+            for (c, slot), nd in r.xsrc_nodes.items():
+                assert eng.source_generated(slot)[c] == r.generated[nd], (c, slot)
+
+
 @pytest.mark.parametrize("k", TIE_CASES)
 def test_tie_storms_match_oracle(k):
     check_station_case(k, RS.tie_spec(k))

@@ -326,6 +326,36 @@ def test_probes_are_lowered_onto_their_station():
     assert [p.metric for p in probes] == ["depth", "utilization"] and set(data) == {"depth", "utilization"}
 
 
+def test_several_sources_of_one_server_are_lowered_onto_its_station():
+    """Two or more Sources with the same target Server -> hs_stations.src_more_* (slots 1..3 of the station) and
+    source_order / source_slot_order in `sources=[...]` order."""
+    sink = hs.Sink("k")
+    srv = hs.Server("s", concurrency=1, service_time=hs.ExponentialLatency(0.05), downstream=sink)
+    other = hs.Server("t", downstream=hs.Sink("k2"))
+    a = hs.Source.poisson(rate=6, target=srv, name="a")
+    b = hs.Source.constant(rate=4, target=srv, name="b", stop_after=3.0)
+    c = hs.Source.poisson(rate=2, target=srv, name="c")
+    d = hs.Source.poisson(rate=3, target=other, name="d")
+    sim = hs.Simulation(duration=5, sources=[b, d, a, c], entities=[srv, sink, other, other.downstream])
+    g = sim.lowered()
+    assert g.stations[0].source is b and g.stations[0].more_sources == [a, c] and g.stations[1].more_sources == []
+    arr = g.arrays()
+    assert arr.src_kind.tolist() == [N.SRC_CONSTANT, N.SRC_POISSON] and arr.src_rate.tolist() == [4.0, 3.0]
+    assert arr.src_more_kind[:, 0].tolist() == [N.SRC_POISSON, N.SRC_POISSON, N.SRC_NONE]
+    assert arr.src_more_rate[:2, 0].tolist() == [6.0, 2.0] and arr.src_more_kind[:, 1].tolist() == [N.SRC_NONE] * 3
+    assert arr.src_stop_after_ns.tolist() == [3_000_000_000, -1] and arr.src_more_stop_after_ns[:, 0].tolist() == [-1, -1, -1]
+    assert g.log_capacity(5.0) >= 12 * 5                     # the station admits what all three Sources generate
+    more = [hs.Source.poisson(rate=1, target=srv, name=f"x{k}") for k in range(2)]
+    with pytest.raises(hs.UnsupportedTopology, match="more than four Sources"):
+        hs.Simulation(duration=1, sources=[a, b, c] + more, entities=[srv, sink]).lowered()
+    ramp = hs.Source.with_profile(hs.LinearRampProfile(duration_s=2.0, start_rate=1.0, end_rate=5.0), target=srv)
+    with pytest.raises(hs.UnsupportedTopology, match="time-varying profile next to further Sources"):
+        hs.Simulation(duration=1, sources=[a, ramp], entities=[srv, sink]).lowered()
+    pr, _ = hs.Probe.on(a, "generated_count")
+    with pytest.raises(hs.UnsupportedTopology, match="only the first Source of a Server is sampled"):
+        hs.Simulation(duration=1, sources=[b, a], entities=[srv, sink], probes=[pr]).lowered()
+
+
 def test_schedule_is_lowered_to_per_station_time_lists():
     """Simulation.schedule() (core/simulation.py:195-206) -> hs_stations.sched_off / sched_time_ns: per station, ascending,
     ties in call order; cancelled events are kept out and counted; events before start_time are dropped with the

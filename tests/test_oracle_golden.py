@@ -32,6 +32,9 @@ def check_oracle_against_station_golden(gold):
         for c in chain_ids:
             src, srv, snk = nodes[c]
             assert (r.generated[src] if src >= 0 else 0) == gold.generated[c]
+            for (cc, slot), nd in r.xsrc_nodes.items():               # the Server's further Sources
+                if cc == c:
+                    assert r.generated[nd] == gold.generated_more[slot - 1, c]
             assert r.accepted[srv] == gold.accepted[c]
             assert r.dropped[srv] == gold.dropped[c]
             assert r.completed[srv] == gold.completed[c]
@@ -66,6 +69,8 @@ def check_oracle_against_station_golden(gold):
                 if nd >= 0:
                     node_chain[nd] = c
         for (c, _slot), nd in r.probe_nodes_all.items():
+            node_chain[nd] = c
+        for (c, _slot), nd in r.xsrc_nodes.items():
             node_chain[nd] = c
         if spec.get("shared_sink"):          # make_golden's node table labels the one shared Sink with the LAST chain
             node_chain[nodes[chain_ids[0]][2]] = chain_ids[-1]

@@ -20,7 +20,8 @@ if not os.path.isdir("/root/reference/happysimulator"):
 
 sys.path.insert(0, H.GOLDEN_DIR)
 import make_golden as MG  # noqa: E402  (imports the reference through refshim)
-from random_specs import lb_spec as _lb_spec, ring_spec as _ring_spec, station_spec as _station_spec, tie_spec  # noqa: E402
+from random_specs import (lb_spec as _lb_spec, multi_source_spec, ring_spec as _ring_spec, station_spec as _station_spec,  # noqa: E402
+                          tie_spec)
 
 
 @pytest.mark.parametrize("k", range(40))
@@ -57,4 +58,14 @@ def test_oracle_equals_live_reference_on_tie_storms(k):
     """Same-nanosecond orders (lock-step constant sources, Requests injected at the start instant, c up to 16): the oracle's
     sort-index ledger against the reference's, full traces."""
     out, meta = MG.run_case(tie_spec(k))
+    check_oracle_against_station_golden(H.Golden.from_results(out, meta))
+
+
+@pytest.mark.parametrize("k", range(60))
+def test_oracle_equals_live_reference_with_several_sources_per_server(k):
+    """Up to four Sources feeding one Server, in two `sources=[...]` orders, on tie storms and random configurations."""
+    spec = multi_source_spec(k)
+    if spec["mode"] == "replicas":
+        spec["trace"] = False
+    out, meta = MG.run_case(spec)
     check_oracle_against_station_golden(H.Golden.from_results(out, meta))
