@@ -824,7 +824,7 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF> &S, const Stati
         }
     }
     S.ha = S.na = S.hs_ = S.nsv = S.hj = S.nj = S.rn = 0; S.rbits = 0; S.fl_link = -1; S.fi_link = -1; S.fi_packets = 0;
-    S.fl_remote = false; S.fi_head = 0; S.pf_s0 = S.pf_s1 = -1; S.pf_v0 = S.pf_v1 = 0;
+    S.fl_remote = false; S.fi_head = 0; S.win_hi = S.started;
     S.bh = 0; S.tail_hint = 0ull;
     S.presend = false; S.early_upto = S.completed; S.D_pre = S.last_time; S.fl_q = 0; S.end_ns = kInfNs;
     S.bag_n = NX.bag_cnt[lp];
@@ -868,7 +868,7 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF> &S, const Stati
         // the created_at window: the next kNRing requests to start, as far as they are admitted (read from the log)
         for (int i = 0; i < kNRing; ++i) {
             const int64_t k = S.started + i;
-            if (k < S.accepted && k < S.cap) S.fl.crc[k & (kNRing - 1)][tid] = S.adm[k * S.ls];
+            if (k < S.accepted) { S.fl.crc[k & (kNRing - 1)][tid] = k < S.cap ? S.adm[k * S.ls] : 0; S.win_hi = k + 1; }
         }
     }
     S.bmin = S.bag_scan_min();
@@ -1262,7 +1262,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             // debug flag 1024: pseudo-random per-wavefront delays -- results must not depend on timing (tests/test_gpu_ring.py)
             if ((flags & 1024) && ((((iter + 1u) * 2654435761u + (blockIdx.x * 4u + (tid >> 6)) * 40503u) >> 7) & 3u) == 0)
                 __builtin_amdgcn_s_sleep(127);
-            S.pf_commit();                                            // created_at prefetches of the previous iteration -> LDS
+            S.window_fill(!done);                                     // created_at of what entered the window from a deep queue
             S.top_up(!done, group_cap < 4 ? group_cap : 4);           // whole wavefront: refill the pre-drawn values
             int64_t H = kInfNs;
 #ifdef HS_CYCLES
@@ -1322,24 +1322,39 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             unsigned long long q3 = q2;
 #endif
             blocked = false;
-            if (!done) {
-                const int64_t limit = (H - 1) < end_ns ? (H - 1) : end_ns;
-                blocked = S.undrained != kInfNs;                      // the bag is full and a queue still holds messages
+            {
+                // The group loop is UNIFORM: every lane of the wavefront walks through the same trips and a lane without a ready
+                // group is predicated off (`act`).  (A divergent loop -- lanes breaking out one by one -- made the compiler keep
+                // a dozen exec masks and ~70 loop-carried register copies per trip alive: half of the VALU work of a trip.)
+                const int64_t limit = done ? INT64_MIN : ((H - 1) < end_ns ? (H - 1) : end_ns);
+                if (!done) blocked = S.undrained != kInfNs;           // the bag is full and a queue still holds messages
+                bool stop = done;
                 for (int g = 0; g < group_cap; ++g) {
+#ifdef HS_MARK
+                    asm volatile("; HSMARK loop_top" ::: "memory");
+#endif
                     const int64_t t = S.next_time();
-                    if (t > limit) break;
-                    if (!((out_remote[0] || S.async_can_send(out_l[0], head_seen[0])) &&
-                          (out_remote[1] || S.async_can_send(out_l[1], head_seen[1])))) { blocked = true; break; }   // a consumer is behind: wait
+                    bool act = !stop && t <= limit;
+                    if (act && !((out_remote[0] || S.async_can_send(out_l[0], head_seen[0])) &&
+                                 (out_remote[1] || S.async_can_send(out_l[1], head_seen[1])))) { blocked = true; act = false; }   // a consumer is behind: wait
+                    stop = stop || !act;
+                    if (!__any(act)) break;
 #ifdef HS_RINGSTAT
                     S.stat_gl = 0; S.stat_slow = 0;
 #endif
-                    if constexpr (C == 1) S.step1(t, force_general);
-                    else S.run_group(t, force_general);
-                    ++n_groups;
+#ifdef HS_MARK
+                    asm volatile("; HSMARK before_step1" ::: "memory");
+#endif
+                    if constexpr (C == 1) S.step1(t, act, force_general);
+                    else { if (act) S.run_group(t, force_general); }
+#ifdef HS_MARK
+                    asm volatile("; HSMARK after_step1" ::: "memory");
+#endif
+                    n_groups += act ? 1u : 0u;
 #ifdef HS_RINGSTAT
                     {   // one trip of the wavefront: how many lanes ran it, did any take the general path / a global read
-                        const unsigned long long m = __ballot(1);
-                        const bool leader = (unsigned)lane == (unsigned)__builtin_ctzll(m);
+                        const unsigned long long m = __ballot(act);
+                        const bool leader = (unsigned)lane == (unsigned)__builtin_ctzll(__ballot(1));
                         const int any_gl = __any(S.stat_gl), any_slow = __any(S.stat_slow);
                         if (leader) {
                             atomicAdd(&tot->dbg[0], 1ull); atomicAdd(&tot->dbg[1], (unsigned long long)any_gl);
@@ -1348,6 +1363,8 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                     }
 #endif
                 }
+            }
+            if (!done) {
 #ifdef HS_CYCLES
                 q3 = __builtin_readcyclecounter();
 #endif

@@ -270,13 +270,15 @@ struct NetStation {
     int64_t early_upto, D_pre, fl_q, end_ns;
     bool presend;
     Stream jit;
-    // FAST: the created_at window.  Slot j & 7 of `crc` holds request j for j in [started, started + kNRing); when a start frees
-    // a slot and the request that now enters the window was admitted long ago (a queue deeper than the window), its
-    // created_at comes back from the admission log in HBM -- as a PREFETCH: the load is issued at the start, the value is
-    // committed to LDS at the top of the next iteration (pf_commit), and it is first needed kNRing starts later.  (It used to be
-    // a synchronous read at delivery time: 64 % of the wavefront's group trips stalled on one, measured on the full ring.)
-    int64_t pf_v0, pf_v1;
-    int pf_s0, pf_s1;             // slots the prefetched values belong to (-1: none pending)
+    // FAST: the created_at window.  Slot j & 7 of `crc` holds request j for the ordinals [started, win_hi) -- a contiguous prefix of
+    // the next kNRing requests to start.  An admission inside [started, started + kNRing) writes its slot directly (and extends
+    // the prefix when it is the next ordinal); what a deeper queue admitted comes back from the admission log in HBM at the TOP
+    // of an iteration (window_fill: one round trip per iteration at a point where the wavefront is converged and the previous
+    // iteration's stores have drained).  History: a synchronous read at delivery time stalled 64 % of the group trips; a
+    // "prefetch" issued at the start and committed an iteration later was no better -- the compiler needs the loaded register for
+    // the conditional assignment right away and gfx9 has one counter for loads and stores, so the trip waited for the load AND
+    // for every write-through store before it (measured: ~2 400 of a trip's ~7 600 cycles).
+    int64_t win_hi;
     unsigned long long tail_hint; // asynchronous engine: the in-wavefront sender's appended count (0: none)
     int32_t fi_link;              // the LP's only incoming link (-1: none or several): its packets_sent counter in a register
     int64_t fi_packets;
@@ -291,6 +293,8 @@ struct NetStation {
 #ifdef HS_CYC2       // scratch build: cycles inside step1 (classification / arrival side / departure side / start of service)
     unsigned long long cy2[4];
 #define HS_CY2(k) { const unsigned long long now_ = __builtin_readcyclecounter(); cy2[k] += now_ - cy_t; cy_t = now_; }
+#elif defined(HS_MARK)
+#define HS_CY2(k) asm volatile("; HSMARK step1_" #k ::: "memory");
 #else
 #define HS_CY2(k)
 #endif
@@ -531,7 +535,7 @@ struct NetStation {
         if (qcap >= 0 && buf >= qcap) { dropped++; return false; }
         const bool was_empty = (buf == 0);
         if (accepted < cap) adm[accepted * ls] = created; else overflow = 1;
-        if constexpr (FAST) { if (accepted - started < kNRing) fl.crc[accepted & (kNRing - 1)][tid] = created; }   // inside the window
+        if constexpr (FAST) window_admit(created);
         accepted++; buf++;
         return was_empty;
     }
@@ -542,23 +546,33 @@ struct NetStation {
         buf--;
         return true;
     }
-    // FAST created_at window (see pf_v0): commit pending prefetches; after request k started, request k + kNRing enters
-    __device__ __forceinline__ void pf_commit() {
+    // FAST created_at window (see win_hi): at the top of an iteration, fetch what entered [started, started + kNRing) from the log
+    __device__ __forceinline__ void window_fill(bool act) {
         if constexpr (FAST) {
-            if (pf_s0 >= 0) { fl.crc[pf_s0][tid] = pf_v0; pf_s0 = -1; }
-            if (pf_s1 >= 0) { fl.crc[pf_s1][tid] = pf_v1; pf_s1 = -1; }
+            const int64_t lim = started + kNRing;
+            const int64_t hi = accepted < lim ? accepted : lim;
+            for (int i = 0; i < kNRing; ++i) {
+                const int64_t j = win_hi + i;
+                const bool need = act && j < hi;
+                if (!__any(need)) break;
+                if (need) fl.crc[j & (kNRing - 1)][tid] = (j < cap) ? adm[j * ls] : 0;
+            }
+            if (act && hi > win_hi) win_hi = hi;
         }
     }
-    __device__ __forceinline__ void window_advance(int64_t k) {
-        if constexpr (FAST) {
-            const int64_t j = k + kNRing;
-            if (j < accepted) {                       // admitted while the window was full: its created_at is in the log
-                const int64_t v = (j < cap) ? adm[j * ls] : 0;
-                const int slot = (int)(j & (kNRing - 1));
-                if (pf_s0 < 0) { pf_v0 = v; pf_s0 = slot; }
-                else if (pf_s1 < 0) { pf_v1 = v; pf_s1 = slot; }
-                else fl.crc[slot][tid] = v;           // (more than two starts per iteration: synchronous)
-            }
+    // created_at of request k, which starts now
+    __device__ __forceinline__ int64_t window_take(int64_t k) {
+        int64_t created;
+        if (k < win_hi) created = fl.crc[k & (kNRing - 1)][tid];
+        else created = (k < cap) ? adm[k * ls] : 0;                   // (more than kNRing starts since the last fill: synchronous)
+        if (win_hi <= k) win_hi = k + 1;
+        return created;
+    }
+    // an admission (ordinal `accepted`, before the increment) inside the window
+    __device__ __forceinline__ void window_admit(int64_t created) {
+        if (accepted - started < kNRing) {
+            fl.crc[accepted & (kNRing - 1)][tid] = created;
+            if (win_hi == accepted) win_hi = accepted + 1;
         }
     }
     // `known_created`: created_at of the head request when the caller still has it in a register (the request
@@ -566,15 +580,15 @@ struct NetStation {
     __device__ __forceinline__ uint32_t do_deliver_work(int64_t t, bool have_created, int64_t known_created) {
         ev[4]++; ev[5]++;
         const int64_t k = started++;
-        if (active >= conc) { rejected++; if constexpr (FAST) { pf_commit(); window_advance(k); } return 0; }
+        if (active >= conc) { rejected++; if constexpr (FAST) { if (win_hi <= k) win_hi = k + 1; } return 0; }
         active++;
         double s; int64_t dur;
         sample_service(s, dur);
         int64_t created;
         if (have_created) created = known_created;
-        else if constexpr (FAST) { pf_commit(); created = fl.crc[k & (kNRing - 1)][tid]; }   // no global round trip
+        else if constexpr (FAST) created = window_take(k);             // no global round trip
         else created = (k < cap) ? adm[k * ls] : 0;
-        if constexpr (FAST) window_advance(k);
+        if constexpr (FAST) { if (win_hi <= k) win_hi = k + 1; }
         int j = 0;
 #pragma unroll
         for (int i = C - 1; i >= 0; --i) if (D[i] == kInfNs) j = i;
@@ -1040,15 +1054,18 @@ struct NetStation {
     // speculative peeks at the pre-drawn values, anything unusual is detected before a single word of state changes and is
     // handed to run_group() (ties, a next tick on / before `t`, a zero-length service, an empty ring, a lossy or second
     // link).  Event counts, statistics, creation stamps and draw consumption are exactly run_group()'s.
-    __device__ __forceinline__ void step1(int64_t t, bool force_general) {
+    // `act`: this lane takes part (the caller's loop is UNIFORM: every lane of the wavefront walks through the same trips, a
+    // lane without a ready group is predicated off -- no divergent loop exits, whose exec-mask bookkeeping and loop-carried
+    // copies cost more than the arithmetic).
+    __device__ __forceinline__ void step1(int64_t t, bool act, bool force_general) {
         static_assert(C == 1, "step1 is the single-worker specialisation");
 #ifdef HS_CYC2
         unsigned long long cy_t = __builtin_readcyclecounter();
 #endif
-        const bool tick = (A == t), dep = (D[0] == t);
+        bool tick = act && (A == t), dep = act && (D[0] == t);
         int cnt = (tick ? 1 : 0) + (dep ? 1 : 0), mi = 0;
-        if (bmin == t) { ++cnt; if (bag_n > 1 && bg_t(1) == t) ++cnt; }   // the sorted bag: entry 0 is the message (mi = 0)
-        const bool msg = !tick && !dep;                               // (cnt == 1 is checked below)
+        if (act && bmin == t) { ++cnt; if (bag_n > 1 && bg_t(1) == t) ++cnt; }   // the sorted bag: entry 0 is the message (mi = 0)
+        bool msg = act && !tick && !dep;                              // (cnt == 1 is checked below)
         // speculative draws: peeks, nothing consumed yet
         const bool poisson = src_kind == 1, svc_exp = svc_kind == 0;
         const double inc = poisson ? fl.ring_a[ha][tid] : inc_const;
@@ -1058,29 +1075,34 @@ struct NetStation {
         const bool router = egress == EG_ROUTER;
         const int ridx = (int)(rbits & 3u);
         const int32_t target = egress == EG_SINK ? -1 : egress == EG_LINK ? link_of : router ? rt_target(ridx) : -2;
-        const bool to_sink = dep && target == -1, to_link = dep && target >= 0;
-        // which reference events happen
-        const bool payload = tick && !(stop_ns >= 0 && t > stop_ns);
-        const bool arrv = payload || msg;
-        const bool acc = arrv && !(qcap >= 0 && buf >= qcap);
-        const bool notify = acc && buf == 0;
-        const bool poll = (notify && active < conc) || dep;
-        const int64_t buf1 = buf + (acc ? 1 : 0);
-        const bool deliver = poll && buf1 > 0;
+        bool to_sink, to_link, payload, arrv, acc, notify, poll, deliver, pre_done;
+        int64_t buf1;
+        auto derive = [&]() {                                         // which reference events happen
+            to_sink = dep && target == -1; to_link = dep && target >= 0;
+            payload = tick && !(stop_ns >= 0 && t > stop_ns);
+            arrv = payload || msg;
+            acc = arrv && !(qcap >= 0 && buf >= qcap);
+            notify = acc && buf == 0;
+            poll = (notify && active < conc) || dep;
+            buf1 = buf + (acc ? 1 : 0);
+            deliver = poll && buf1 > 0;
+            pre_done = presend && dep && completed < early_upto;     // the departing request's message went out ahead of time
+        };
+        derive();
         if constexpr (PF) {
-            if (has_probe() && probe_at(t)) cnt += 2;                 // the rare roots: always the general path
-            if (has_sched() && SA == t) cnt += 2;
+            if (act && has_probe() && probe_at(t)) cnt += 2;          // the rare roots: always the general path
+            if (act && has_sched() && SA == t) cnt += 2;
             if (tick && prof_kind != kProfConstant) cnt += 2;         // (its next arrival is a numerical inversion)
         }
-        const bool pre_done = presend && dep && completed < early_upto;   // the departing request's message went out ahead of time
-        const bool slow = force_general || cnt != 1 || (tick && (a2 <= t || (poisson && na == 0))) ||
-                          (deliver && (dur == 0 || (svc_exp && nsv == 0))) || (dep && router && rn == 0) ||
-                          (to_link && (target != fl_link || fl_loss > 0.0 || (!pre_done && fl_jit == 0 && nj == 0)));
+        const bool slow = act && (force_general || cnt != 1 || (tick && (a2 <= t || (poisson && na == 0))) ||
+                          (deliver && (dur == 0 || (svc_exp && nsv == 0) || (dep && started >= win_hi))) || (dep && router && rn == 0) ||
+                          (to_link && (target != fl_link || fl_loss > 0.0 || (!pre_done && fl_jit == 0 && nj == 0))));
 #ifdef HS_RINGSTAT
         if (slow) stat_slow = 1;
-        if (deliver && dep && started + kNRing < accepted) stat_gl = 1;   // a prefetch is issued
 #endif
-        if (__builtin_expect(slow, 0)) { run_group(t, force_general); return; }
+        if (__builtin_expect(slow, 0)) run_group(t, force_general);
+        if (slow) { tick = dep = msg = false; }                       // (handled; the predicated code below does nothing for it)
+        derive();
         HS_CY2(0)
         // ---- Source.handle_event
         ev[0] += tick; generated += tick;
@@ -1103,7 +1125,7 @@ struct NetStation {
         dropped += (arrv && !acc) ? 1 : 0;
         if (acc) {
             if (accepted < cap) adm[accepted * ls] = created_in; else overflow = 1;
-            if (accepted - started < kNRing) fl.crc[accepted & (kNRing - 1)][tid] = created_in;
+            window_admit(created_in);
         }
         if (acc && presend && early_upto == accepted) {
             // pre-send at admission: the request's start and departure are already determined (see `early_upto`)
@@ -1155,14 +1177,14 @@ struct NetStation {
             const int64_t k = started++;
             active++;
             int64_t created = created_in;                             // arrival side: the request that found the buffer empty
-            if (dep) created = fl.crc[k & (kNRing - 1)][tid];        // the window always holds the next request to start
-            window_advance(k);
+            if (dep) created = fl.crc[k & (kNRing - 1)][tid];        // in the window (k < win_hi: checked with `slow`)
+            win_hi = win_hi <= k ? k + 1 : win_hi;
             if (presend && k >= early_upto) (void)pre_send(k, (int)(k - completed), t + dur, created);   // pre-send at the start
             svc_s[0] = s_new; crt[0] = created;
             D[0] = t + dur; seqD[0] = seq++; crtD[0] = t;
             if (svc_exp) { hs_ = (hs_ + 1) & (kNRing - 1); --nsv; }
         }
-        last_time = t;
+        last_time = (tick || dep || msg) ? t : last_time;            // (the general path sets it itself)
         HS_CY2(3)
     }
 
