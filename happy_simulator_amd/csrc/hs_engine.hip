@@ -1222,6 +1222,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             for (int k = 0; k < S.rtk; ++k) { const int32_t t = S.rt_target(k); if (t >= 0 && no < 2) out_l[no++] = t; }
         }
         int64_t out_pub[2] = {INT64_MIN, INT64_MIN};
+        const int64_t out_lat[2] = {out_l[0] >= 0 ? NP.link_lat_ns[out_l[0]] : 0, out_l[1] >= 0 ? NP.link_lat_ns[out_l[1]] : 0};
         unsigned long long head_seen[2] = {0ull, 0ull};
         const bool force_general = (flags & 1) != 0;
         // Groups per LP per iteration.  The loop below is divergent: a lane with a long stretch of ready groups would keep
@@ -1262,6 +1263,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             // debug flag 1024: pseudo-random per-wavefront delays -- results must not depend on timing (tests/test_gpu_ring.py)
             if ((flags & 1024) && ((((iter + 1u) * 2654435761u + (blockIdx.x * 4u + (tid >> 6)) * 40503u) >> 7) & 3u) == 0)
                 __builtin_amdgcn_s_sleep(127);
+            const int64_t w_peek = done ? 0 : S.async_peek();         // the incoming link's word: its latency hides behind the refills
             S.window_fill(!done);                                     // created_at of what entered the window from a deep queue
             S.top_up(!done, group_cap < 4 ? group_cap : 4);           // whole wavefront: refill the pre-drawn values
             int64_t H = kInfNs;
@@ -1273,7 +1275,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                 const long long q_prev = shfl_up_ll(q_next, 1);
                 S.tail_hint = chain ? (unsigned long long)q_prev : 0ull;
             }
-            if (!done) H = S.async_receive();                         // messages below H are all in the bag now
+            if (!done) H = S.async_receive(w_peek);                         // messages below H are all in the bag now
 #ifdef HS_CYCLES
             const unsigned long long q1 = __builtin_readcyclecounter();
 #endif
@@ -1373,7 +1375,8 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                 // payloads complete (one drain), THEN the link's word (bound, tail): a consumer that sees the word sees every
                 // message below its tail, and no bound it can read -- from memory or through the in-wavefront scan of the next
                 // iteration (after this drain) -- covers less than the messages that are visible behind it
-                if (S.sent_async) drain_stores();
+                // (the bounds are computed first -- registers and LDS only -- so that the drain overlaps with that arithmetic)
+                int64_t vo[2] = {INT64_MIN, INT64_MIN};
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {
                     const int32_t l = out_l[o];
@@ -1381,15 +1384,21 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                     // the bound of everything this LP has NOT appended to link l yet: its map evaluated at `base`
                     int64_t bA, bB, bD, sdl = 0;
                     int kind = -1;
-                    S.bound_map(l, NP.link_lat_ns[l], bA, bB, bD, &kind, &sdl);
+                    S.bound_map(l, out_lat[o], bA, bB, bD, &kind, &sdl);
                     if (l == next_l) { c_kind = kind; c_A = bA; c_B = bB; c_D = bD; c_sdl = sdl; }
                     int64_t v = sat(base, bB);
                     v = v > bD ? v : bD;
                     v = v < bA ? v : bA;
-                    v = v > out_pub[o] ? v : out_pub[o];
-                    if (S.sent_async || v > out_pub[o]) {
-                        ag_store(&NX.aq_ea[l], pk_pack(v, (unsigned long long)S.link_sent_of(l), NX.pk_base));
-                        out_pub[o] = v;
+                    vo[o] = v > out_pub[o] ? v : out_pub[o];
+                }
+                if (S.sent_async) drain_stores();
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    const int32_t l = out_l[o];
+                    if (l < 0) continue;
+                    if (S.sent_async || vo[o] > out_pub[o]) {
+                        ag_store(&NX.aq_ea[l], pk_pack(vo[o], (unsigned long long)S.link_sent_of(l), NX.pk_base));
+                        out_pub[o] = vo[o];
                     }
                 }
                 S.sent_async = false;

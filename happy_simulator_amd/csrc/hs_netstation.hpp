@@ -782,9 +782,14 @@ struct NetStation {
     // the (bound, tail) pair.  (Loading that pair ahead of time, before this wavefront's publication drains, is NOT safe:
     // the in-wavefront scan hands a lane its neighbour's bound from the neighbour's CURRENT state, and the messages that
     // state has already sent are only guaranteed to be behind a tail read after the neighbour's drains.)
-    __device__ __forceinline__ int64_t async_receive_one() {
-        const int l = fi_link;
-        const int64_t w = ag_load(&ns->aq_ea[l]);                     // (bound, tail) in one word: a consistent pair; the payload
+    // (It may be loaded at the very top of the iteration, before the stream rings are topped up -- that is after every
+    // publication of the previous iteration: async_peek.)
+    __device__ __forceinline__ int64_t async_peek() const {
+        if constexpr (FAST) { if (fi_link >= 0) return ag_load(&ns->aq_ea[fi_link]); }
+        return 0;
+    }
+    __device__ __forceinline__ int64_t async_receive_one(int64_t w) {
+        const int l = fi_link;                                        // w: (bound, tail) in one word: a consistent pair; the payload
         const int64_t ea = pk_ea(w, ns->pk_base);                     // loads below depend on it (loop bounds), so they follow it
         undrained = kInfNs;
         unsigned long long head = fi_head;
@@ -809,8 +814,8 @@ struct NetStation {
         }
         return ea;
     }
-    __device__ __forceinline__ int64_t async_receive() {
-        if constexpr (FAST) { if (fi_link >= 0) return async_receive_one(); }
+    __device__ __forceinline__ int64_t async_receive(int64_t w_peek) {
+        if constexpr (FAST) { if (fi_link >= 0) return async_receive_one(w_peek); }
         int64_t H = kInfNs;
         undrained = kInfNs;
         const int a = np->in_off[lp], b = np->in_off[lp + 1];
