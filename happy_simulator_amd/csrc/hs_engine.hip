@@ -327,6 +327,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
             }
             // (default stamps, replaced by the prologue's true sort indices: after the first Source, before the probes)
             X.XA[o] = XA; X.seqX[o] = 1u + (uint32_t)j; X.crtX[o] = start_ns; X.x_arr[o] = x_arr; X.x_n[o] = 0; X.x_k[o] = x_k;
+            if (NX.next_time != nullptr && XA < NX.next_time[lp]) NX.next_time[lp] = XA;   // network engine: first pending event
         }
     }
     if (X.PA != nullptr) {   // probes start after the sources (core/simulation.py:156-160): first tick from start_ns
@@ -737,6 +738,8 @@ __global__ void __launch_bounds__(64) hs_exact_run(StationParams P, NetParams NP
                     t = sa < t ? sa : t;
                 }
             }
+            if (X.XA != nullptr)                              // pending ticks of the LP's further Sources
+                for (int j = 0; j < kMaxXSrc; ++j) { const int64_t xa = X.XA[(size_t)j * n + lp]; t = xa < t ? xa : t; }
             const int bn = NX.bag_cnt[lp];
             for (int i = 0; i < bn; ++i) { const int64_t bt = NX.bag_t[(size_t)lp * NX.bag_cap + i]; t = bt < t ? bt : t; }
             NX.next_time[lp] = t;
@@ -799,7 +802,14 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF> &S, const Stati
     for (int j = 0; j < kMaxProbes; ++j) { S.p_metric[j] = kProbeNone; S.PA[j] = kInfNs; S.seqP[j] = 0; S.crtP[j] = 0; S.p_arr[j] = 0; S.p_n[j] = 0; S.p_rate[j] = 1.0; }
     S.prof_kind = kProfConstant; S.prof_p0 = S.prof_p1 = S.prof_p2 = S.prof_p3 = 0.0;
     S.SA = kInfNs; S.sc_i = S.sc_end = 0; S.sc_t = P.sched_t; S.sc_idx = P.sched_idx;
+    S.n_xsrc = 0; S.x_base = P.stream_base[lp]; S.xs_min = kInfNs; S.xp = &P; S.xx = &X; S.x_n_lp = n;
     if constexpr (PF) {
+        if (P.xsrc_kind != nullptr) {      // further Sources of this station's Server (their state stays in X)
+            for (int j = 0; j < kMaxXSrc; ++j) {
+                const size_t o = (size_t)j * n + lp;
+                if (P.xsrc_kind[o] != 0) { S.n_xsrc = j + 1; const int64_t a = X.XA[o]; S.xs_min = a < S.xs_min ? a : S.xs_min; }
+            }
+        }
         if (P.sched_off != nullptr) {
             S.sc_i = X.sched_i[lp]; S.sc_end = P.sched_off[lp + 1];
             S.SA = S.sc_i < S.sc_end ? P.sched_t[S.sc_i] : kInfNs;
@@ -1041,6 +1051,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
 #pragma unroll
                     for (int j = 0; j < kMaxProbes; ++j) if (j == w - 56) mine.t_created = S.crtP[j];
                 }
+                else if (w >= 48 && w < 48 + kMaxXSrc) mine.t_created = X.crtX[(size_t)(w - 48) * n + lp];
                 else if (w == 62) mine.t_created = INT64_MIN;     // constructed before run()
                 else {
 #pragma unroll
@@ -1137,6 +1148,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
             if (w == 1) (void)W.do_tick(t);
             else if (w >= 64) (void)W.do_msg(w - 64, t);
             else if (w >= 56 && w < 56 + kMaxProbes) W.root_probe(w - 56, t);   // the SourceEvent of the Probe; its probe_event stays unprocessed
+            else if (w >= 48 && w < 48 + kMaxXSrc) W.root_xsrc(w - 48, t);      // the SourceEvent of a further Source; its Request stays unprocessed
             else if (w == 62) W.root_sched(t);                 // the injected Request@Server; its QUEUE_NOTIFY stays unprocessed
             else (void)W.do_cont_core(w - 2, t);
             W.last_time = t;
@@ -1569,6 +1581,7 @@ __global__ void hs_shard_overshoot(StationParams P, NetParams NP, StationState X
     if (w == 1) (void)W.do_tick(t);
     else if (w >= 64) (void)W.do_msg(w - 64, t);
     else if (w >= 56 && w < 56 + kMaxProbes) W.root_probe(w - 56, t);
+    else if (w >= 48 && w < 48 + kMaxXSrc) W.root_xsrc(w - 48, t);
     else if (w == 62) W.root_sched(t);
     else (void)W.do_cont_core(w - 2, t);
     W.last_time = t;
@@ -2298,7 +2311,6 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     if (h->initialised) return fail(h, HS_E_STATE, "set the network before the first run");
     if (h->cfg.mode != HS_MODE_SINGLE) return fail(h, HS_E_INVALID, "a network of stations is one Simulation: HS_MODE_SINGLE");
     if (h->C > 4) return fail(h, HS_E_UNSUPPORTED, "networked stations support concurrency <= 4 for now");
-    if (h->any_xsrc) return fail(h, HS_E_UNSUPPORTED, "several Sources per Server are lowered for stations without links only");
     HS_HIP(h, hipSetDevice(h->cfg.device));
     const int n = h->cfg.n_lp, nl = net->n_links;
     if (nl < 0) return fail(h, HS_E_INVALID, "n_links < 0");
@@ -2487,7 +2499,7 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
         // (the links' packed (bound, tail) words hold 44 bits of nanoseconds: 4.9 hours of simulated time)
         const bool fits = h->cfg.horizon_ns - h->cfg.start_ns < (int64_t)kPkNever - 2 && aqc < (1 << (kPkTailBits - 2));
         h->async_ok = !global && fits;
-        h->net_pf = h->any_probe || h->any_timevarying || h->any_sched;
+        h->net_pf = h->any_probe || h->any_timevarying || h->any_sched || h->any_xsrc;
     }
 #undef ALN
     if (!h->L.sink_created_own) {   // not every completion reaches the Sink any more: explicit created_at column

@@ -221,6 +221,14 @@ struct NetStation {
     int64_t *probe_t, *probe_v;     // slot j's log starts at probe_t + j * pcap * ls
     int n_probes;
     uint32_t evp[2];
+    // further Sources feeding this station's Server (PF), as in hs_station.hpp: entities of their own, constant or Poisson rate.
+    // Their state stays in the engine's arrays (a rare root: registers are the scarce resource of these kernels -- with it in
+    // registers hs_net_window<1> went from 451 to 512 VGPRs plus scratch spills); only the earliest pending tick is cached.
+    const StationParams *xp;
+    const StationState *xx;
+    int64_t xs_min;
+    uint64_t x_base;
+    int n_xsrc, x_n_lp;
     // time-varying arrival rate of this station's Source (load/profile.py); 0 = constant..
     uint32_t prof_kind;
     double prof_p0, prof_p1, prof_p2, prof_p3;
@@ -898,6 +906,7 @@ struct NetStation {
     __device__ __forceinline__ int64_t next_admission() const {
         int64_t a = A < bmin ? A : bmin;
         if (has_sched() && SA < a) a = SA;
+        if (has_xsrc()) { const int64_t xm = xsrc_min(); if (xm < a) a = xm; }
         return a;
     }
 
@@ -979,6 +988,35 @@ struct NetStation {
         mA = sat(a, lat);
     }
 
+    // ---- further Sources: Source.handle_event (load/source.py:142-180) of an entity of its own (hs_station.hpp root_xsrc)
+    __device__ __forceinline__ bool has_xsrc() const { return PF && n_xsrc > 0; }
+    __device__ __forceinline__ int64_t xsrc_min() const { return xs_min; }
+    __device__ __forceinline__ bool xsrc_at(int64_t t) const { return xs_min == t; }
+    __device__ __forceinline__ size_t xo(int j) const { return (size_t)j * (size_t)x_n_lp + (size_t)lp; }
+    __device__ __forceinline__ void root_xsrc(int j, int64_t t) {
+        ev[0]++;
+        const size_t o = xo(j);
+        xx->x_n[o] += 1;
+        const int64_t stop = xp->xsrc_stop[o];
+        const bool payload = !(stop >= 0 && t > stop);
+        double area = 1.0;
+        if (xp->xsrc_kind[o] == 1) {
+            Stream st;
+            st.init(seed, xsrc_stream_id(x_base, j), xx->x_k[o]);
+            area = exp1_from_uniform(st.next_uniform());
+            xx->x_k[o] += 1;
+        }
+        const int64_t a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(xx->x_arr[o]), __ddiv_rn(area, xp->xsrc_rate[o])));
+        xx->x_arr[o] = a2;
+        if (payload) push_enq(t);
+        if (a2 == t) { xx->XA[o] = kInfNs; qpush(Q_TICK | ((uint32_t)(j + 1) << 3)); }
+        else if (a2 < t) xx->XA[o] = kInfNs;
+        else { xx->XA[o] = a2; xx->seqX[o] = seq++; xx->crtX[o] = t; }
+        int64_t m = kInfNs;
+        for (int i = 0; i < n_xsrc; ++i) { const int64_t a = xx->XA[xo(i)]; m = a < m ? a : m; }
+        xs_min = m;
+    }
+
     // ---- general path ----------------------------------------------------------------------
     __device__ __forceinline__ void root_tick(int64_t t) {
         const uint32_t r = do_tick(t);
@@ -999,6 +1037,12 @@ struct NetStation {
 #pragma unroll
         for (int i = 0; i < C; ++i)
             if (D[i] == t && (best == 0 || (int32_t)(seqD[i] - bs) < 0)) { best = 2 + i; bc = crtD[i]; bs = seqD[i]; }
+        if (PF && n_xsrc > 0 && xs_min == t)     // further Source j's pending tick: root code 48 + j
+            for (int j = 0; j < n_xsrc; ++j) {
+                const size_t o = xo(j);
+                const uint32_t sq = xx->seqX[o];
+                if (xx->XA[o] == t && (best == 0 || (int32_t)(sq - bs) < 0)) { best = 48 + j; bc = xx->crtX[o]; bs = sq; }
+            }
 #pragma unroll
         for (int j = 0; j < kMaxProbes; ++j)     // probe j's pending tick: root code 56 + j
             if (PF && j < n_probes && PA[j] == t && (best == 0 || (int32_t)(seqP[j] - bs) < 0)) { best = 56 + j; bc = crtP[j]; bs = seqP[j]; }
@@ -1017,6 +1061,7 @@ struct NetStation {
     __device__ __forceinline__ void run_root(int w, int64_t t) {
         if (w == 1) root_tick(t);
         else if (w >= 64) root_msg(w - 64, t);
+        else if (PF && w >= 48 && w < 48 + kMaxXSrc) { if constexpr (PF) root_xsrc(w - 48, t); }
         else if (PF && w >= 56 && w < 56 + kMaxProbes) { if constexpr (PF) root_probe(w - 56, t); }
         else if (PF && w == 62) { if constexpr (PF) root_sched(t); }
         else root_cont(w - 2, t);
@@ -1029,7 +1074,10 @@ struct NetStation {
                 case Q_NOTIFY: if (do_notify()) qpush(Q_POLL); break;
                 case Q_POLL: if (do_poll()) qpush(Q_DELIVER); break;
                 case Q_DELIVER: { const uint32_t sm = do_deliver_work(t, false, 0); if (sm) qpush(Q_CONT | ((sm - 1) << 3)); } break;
-                case Q_TICK: root_tick(t); break;
+                case Q_TICK:
+                    if (PF && (code >> 3) != 0) { if constexpr (PF) root_xsrc((int)(code >> 3) - 1, t); }
+                    else root_tick(t);
+                    break;
                 case Q_CONT: root_cont((int)(code >> 3), t); break;
                 case Q_PSAMPLE: if constexpr (PF) do_probe_sample((int)(code >> 3), t); break;
                 default: break;
@@ -1047,6 +1095,7 @@ struct NetStation {
         for (int i = 0; i < C; ++i) t = D[i] < t ? D[i] : t;
         if (has_probe()) { const int64_t pm = probe_min(); if (pm < t) t = pm; }
         if (has_sched() && SA < t) t = SA;
+        if (has_xsrc()) { const int64_t xm = xsrc_min(); if (xm < t) t = xm; }
         return t;
     }
     __device__ __forceinline__ int64_t next_time() const { const int64_t a = next_local(), b = bag_min(); return a < b ? a : b; }
@@ -1097,6 +1146,7 @@ struct NetStation {
         if constexpr (PF) {
             if (act && has_probe() && probe_at(t)) cnt += 2;          // the rare roots: always the general path
             if (act && has_sched() && SA == t) cnt += 2;
+            if (act && has_xsrc() && xsrc_at(t)) cnt += 2;
             if (tick && prof_kind != kProfConstant) cnt += 2;         // (its next arrival is a numerical inversion)
         }
         const bool slow = act && (force_general || cnt != 1 || (tick && (a2 <= t || (poisson && na == 0))) ||
@@ -1202,6 +1252,7 @@ struct NetStation {
             for (int i = 0; i < bag_n; ++i) if (bg_t(i) == t) { ++n_at; mi = i; }
         if (has_probe() && probe_at(t)) n_at += 2;                       // a probe tick: always the general path
         if (has_sched() && SA == t) n_at += 2;                           // so is a scheduled Request
+        if (has_xsrc() && xsrc_at(t)) n_at += 2;                         // and a tick of a further Source
         if (n_at == 1 && !force_general) {
             bool general = false, want_poll = false, have_created = false;
             int64_t created = 0;

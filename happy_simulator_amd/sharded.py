@@ -169,6 +169,10 @@ def shard_arrays(stations: StationArrays, net: NetworkArrays, lo: int, hi: int):
         src_profile_params=None if stations.src_profile_params is None else stations.src_profile_params[sl],
         probe_metric=None if stations.probe_metric is None else stations.probe_metric[sl],
         probe_interval_s=None if stations.probe_interval_s is None else stations.probe_interval_s[sl],
+        src_more_kind=None if stations.src_more_kind is None else np.asarray(stations.src_more_kind)[:, sl],
+        src_more_rate=None if stations.src_more_kind is None else np.asarray(stations.src_more_rate)[:, sl],
+        src_more_stop_after_ns=(None if stations.src_more_stop_after_ns is None
+                                else np.asarray(stations.src_more_stop_after_ns)[:, sl]),
         probe_metric_more=None if stations.probe_metric_more is None else np.asarray(stations.probe_metric_more)[:, sl],
         probe_interval_more=None if stations.probe_interval_more is None else np.asarray(stations.probe_interval_more)[:, sl],
         sched_off=None if stations.sched_off is None else (np.asarray(stations.sched_off)[lo:hi + 1] - int(stations.sched_off[lo])),

@@ -170,8 +170,6 @@ class Simulation:
         st_of.update({id(x): (i, 1 + k) for i, st in enumerate(g.stations) for k, x in enumerate(st.more_sources)})
         arrays.source_order = np.array([st_of[id(s)][0] for s in self._sources], np.int32)
         if any(st.more_sources for st in g.stations):
-            if g.is_network:
-                raise UnsupportedTopology("several Sources per Server are lowered for stations without links only")
             arrays.source_slot_order = np.array([st_of[id(s)][1] for s in self._sources], np.uint8)
         if self._probes:
             where = {id(pr): (i, slot) for i, st in enumerate(g.stations) for slot, pr in enumerate(st.probes)}

@@ -156,8 +156,8 @@ typedef struct hs_stations {
      * ARRIVAL -- constant or Poisson rate (no profile).  An LP with more than one Source runs on the engines' general path, and
      * the run starts with the prologue (csrc/hs_exact.hpp): the first ticks of an LP's Sources carry consecutive pre-run sort
      * indices, which run-time events of the same nanosecond can overtake.  source_slot_order[k] = slot of the k-th entry of
-     * source_order (an LP with several Sources appears several times there); NULL = every entry is slot 0.  Station engine
-     * only (hs_engine_set_network refuses such LPs).  NULL = one Source per LP at most. */
+     * source_order (an LP with several Sources appears several times there); NULL = every entry is slot 0.  Also on networked
+     * stations (both network engines and shards).  NULL = one Source per LP at most. */
     const uint8_t *src_more_kind;      /* [3][n_lp] hs_source_kind; HS_SRC_NONE = none */
     const double *src_more_rate;       /* [3][n_lp] */
     const int64_t *src_more_stop_after_ns; /* [3][n_lp] < 0 = never; NULL = never */

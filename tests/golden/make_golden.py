@@ -172,6 +172,27 @@ def source_plan(spec, chain_ids):
     return order, slot_plan
 
 
+def ring_source_plan(spec):
+    """source_plan for a ring case: station i's first Source is Poisson(ext_rate[i]) (or its profile), `more_sources[i]` lists
+    [arrival kind, rate] of further Sources feeding the same Server."""
+    n = spec["n"]
+    rate = spec["ext_rate"] if isinstance(spec["ext_rate"], list) else [spec["ext_rate"]] * n
+    more = spec.get("more_sources") or [None] * n
+    firsts = [(i, ("poisson", rate[i], True)) for i in range(n) if rate[i] > 0]
+    if spec.get("sources_order") == "extras_first":
+        listed = [(i, (xa, xr, False)) for i in reversed(range(n)) for xa, xr in (more[i] or [])] + firsts
+    else:
+        listed = []
+        for i in range(n):
+            listed += [(i, ("poisson", rate[i], True))] * (rate[i] > 0) + [(i, (xa, xr, False)) for xa, xr in (more[i] or [])]
+    slot_plan = {i: [] for i in range(n)}
+    order = []
+    for i, what in listed:
+        order.append((i, len(slot_plan[i])))
+        slot_plan[i].append(what)
+    return order, slot_plan
+
+
 def build_chains(spec, chain_ids, seed):
     """Build reference entities for the given chains; returns (sources, entities, handles)."""
     n = spec["n_chains"]
@@ -427,7 +448,7 @@ def run_ring_case(spec):
     servers = [Server(f"srv{i}", concurrency=spec.get("concurrency", 1),
                       service_time=PhiloxExponentialLatency(spec["mean"], hs.Stream(seed, i, hs.STREAM_SERVICE)),
                       queue_capacity=spec.get("queue_cap")) for i in range(n)]
-    links, routers, sources = [], [], []
+    links, routers, sources, first_profile = [], [], [], {}
     for i in range(n):
         jit = None
         if spec.get("jitter_mean") is not None:
@@ -452,10 +473,23 @@ def run_ring_case(spec):
                 profile = LinearRampProfile(duration_s=pr[1], start_rate=pr[2], end_rate=pr[3])
             else:
                 profile = SpikeProfile(baseline_rate=pr[1], spike_rate=pr[2], warmup_s=pr[3], spike_duration_s=pr[4])
-            prov = PhiloxPoissonArrival(profile, Instant.Epoch, hs.Stream(seed, i, hs.STREAM_ARRIVAL))
-            sources.append(Source(f"src{i}", SimpleEventProvider(servers[i], "Request", None), prov))
-        else:
-            sources.append(None)
+            first_profile[i] = profile
+        sources.append(None)
+    # the stations' Sources in `sources=[...]` order; slot = position among the station's Sources (slot 0: the station's ARRIVAL
+    # stream, slot j >= 1: stream base (1 << 40) | (i << 2) | (j - 1)); `more_sources` = further Sources feeding the same Server
+    order, slot_plan = ring_source_plan(spec)
+    by_slot = {i: [] for i in range(n)}
+    for i in range(n):
+        for slot, (sa, sr, is_first) in enumerate(slot_plan[i]):
+            prof = first_profile[i] if is_first else ConstantRateProfile(rate=sr)
+            if sa == "poisson":
+                sbase = i if slot == 0 else (1 << 40) | (i << 2) | (slot - 1)
+                prov = PhiloxPoissonArrival(prof, Instant.Epoch, hs.Stream(seed, sbase, hs.STREAM_ARRIVAL))
+            else:
+                prov = ConstantArrivalTimeProvider(prof, start_time=Instant.Epoch)
+            by_slot[i].append(Source(f"src{i}_{slot}", SimpleEventProvider(servers[i], "Request", None), prov))
+        sources[i] = by_slot[i][0] if by_slot[i] else None
+    listed = [by_slot[i][slot] for i, slot in order]
     probes, probe_data = [], {}
     for i, prs in enumerate(spec.get("probes") or []):
         if prs is None:
@@ -475,11 +509,11 @@ def run_ring_case(spec):
             data.add_stat = add_stat
             probes.append((i, probe))
             probe_data[(i, j)] = data
-    sim = Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=[s for s in sources if s is not None],
+    sim = Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=listed,
                      entities=servers + routers + links + sinks, probes=[p for _, p in probes])
     node_of = {}
     for i in range(n):
-        for obj in (sources[i], servers[i], servers[i]._queue, servers[i]._driver, servers[i]._worker, routers[i],
+        for obj in (*by_slot[i], servers[i], servers[i]._queue, servers[i]._driver, servers[i]._worker, routers[i],
                     links[i], sinks[i]):
             if obj is not None:
                 node_of[id(obj)] = i
@@ -510,6 +544,9 @@ def run_ring_case(spec):
                 duration_s=[summary.duration_s])
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     out["generated"] = np.array([s.generated_count if s is not None else 0 for s in sources], np.int64)
+    if spec.get("more_sources"):
+        out["generated_more"] = np.array([[by_slot[i][j + 1].generated_count if len(by_slot[i]) > j + 1 else 0 for i in range(n)]
+                                          for j in range(3)], np.int64)
     out["accepted"] = np.array([s.stats_accepted for s in servers], np.int64)
     out["dropped"] = np.array([s.stats_dropped for s in servers], np.int64)
     out["completed"] = np.array([s._requests_completed for s in servers], np.int64)
@@ -672,6 +709,15 @@ RING_CASES = [
          probes=[[["depth", 0.25], ["active_requests", 0.25], ["stats_dropped", 0.5], ["events_received", 0.2]], None,
                  [["stats_accepted", 0.5], ["requests_completed", 0.5]], [["depth", 0.3]], None],
          end_s=10.0, seed=63, trace=True),
+    # several Sources feeding one Server of a network (entities of their own), two `sources=[...]` orders
+    dict(name="ring_5_multi_source", topology="ring", n=5, ext_rate=[6.0, 0.0, 5.0, 4.0, 0.0], mean=0.07, concurrency=1,
+         queue_cap=None, lat_min=0.002, jitter_mean=0.006,
+         more_sources=[[["constant", 4.0]], None, [["poisson", 3.0], ["constant", 2.0]], [["constant", 4.0], ["poisson", 2.0], ["constant", 1.0]], None],
+         probes=[["depth", 0.25], None, None, ["stats_accepted", 0.5], None], end_s=10.0, seed=65, trace=True),
+    dict(name="ring_4_multi_source_order", topology="ring", n=4, ext_rate=[5.0, 4.0, 0.0, 6.0], mean=0.08, concurrency=2,
+         queue_cap=3, lat_min=0.001, jitter_mean=None,
+         more_sources=[[["constant", 5.0], ["constant", 5.0]], [["poisson", 4.0]], None, [["constant", 3.0]]],
+         sources_order="extras_first", schedule=[[2, 0.2], [0, 0.2], [0, 0.4]], end_s=8.0, seed=66, trace=True),
     # NetworkLink(packet_loss_rate): lost packets vanish at the link (link.py:131-138)
     dict(name="ring_8_loss", topology="ring", n=8, ext_rate=6.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, loss=0.2,
          end_s=20.0, seed=42, trace=True),

@@ -249,6 +249,29 @@ def ring_params(spec):
         schedule=[(int(c), ns_from_seconds(float(t))) for c, t in (spec.get("schedule") or [])])
 
 
+def ring_source_plan(spec):
+    """make_golden.ring_source_plan with oracle arrival kinds: (station, slot) in `sources=[...]` order and per station its
+    Sources in slot order [(kind, rate, is the station's ext_rate / profile Source)]."""
+    n = spec["n"]
+    rate = [float(r) for r in per_chain(spec["ext_rate"], n)]
+    more = spec.get("more_sources") or [None] * n
+    kind = lambda a: O.ARR_POISSON if a == "poisson" else O.ARR_CONSTANT
+    firsts = [(i, (O.ARR_POISSON, rate[i], True)) for i in range(n) if rate[i] > 0]
+    if spec.get("sources_order") == "extras_first":
+        listed = [(i, (kind(xa), float(xr), False)) for i in reversed(range(n)) for xa, xr in (more[i] or [])] + firsts
+    else:
+        listed = []
+        for i in range(n):
+            listed += ([(i, (O.ARR_POISSON, rate[i], True))] * (rate[i] > 0) +
+                       [(i, (kind(xa), float(xr), False)) for xa, xr in (more[i] or [])])
+    slot_plan = {i: [] for i in range(n)}
+    order = []
+    for i, what in listed:
+        order.append((i, len(slot_plan[i])))
+        slot_plan[i].append(what)
+    return order, slot_plan
+
+
 def oracle_ring_graph(spec):
     """Oracle nodes for a ring golden: sources (list order) first, then per station server, router, sink, link.
     Station i's entities all use stream base i.  Returns (graph, {i: dict(src, srv, rtr, snk, lnk)})."""
@@ -256,9 +279,13 @@ def oracle_ring_graph(spec):
     n = p["n"]
     g = O.Graph()
     nodes = {i: {} for i in range(n)}
+    order, slot_plan = ring_source_plan(spec)
     for i in range(n):
-        nodes[i]["src"] = (g.source(O.ARR_POISSON, p["ext_rate"][i], stream_base=i, profile=p["profile"][i])
-                           if p["ext_rate"][i] > 0 else -1)
+        nodes[i]["src"] = -1
+    for i, slot in order:                                 # Source nodes in `sources=[...]` order
+        xa, xr, is_first = slot_plan[i][slot]
+        nodes[i]["src" if slot == 0 else f"src{slot}"] = g.source(
+            xa, xr, stream_base=i if slot == 0 else xsrc_stream_base(i, slot - 1), profile=p["profile"][i] if is_first else None)
     for i in range(n):
         nodes[i]["srv"] = g.server(O.LAT_EXP, p["mean"], concurrency=p["conc"], queue_cap=p["qcap"], stream_base=i)
         nodes[i]["snk"] = g.sink()
@@ -266,8 +293,9 @@ def oracle_ring_graph(spec):
         pat = (spec.get("rt_pattern") or ["sl"] * n)[i]
         nodes[i]["rtr"] = g.router([nodes[i]["snk"] if ch == "s" else nodes[i]["lnk"] for ch in pat], stream_base=i)
     for i in range(n):
-        if nodes[i]["src"] >= 0:
-            g.target[nodes[i]["src"]] = nodes[i]["srv"]
+        for key, nd in nodes[i].items():
+            if key.startswith("src") and nd >= 0:
+                g.target[nd] = nodes[i]["srv"]
         g.target[nodes[i]["srv"]] = nodes[i]["rtr"]
         g.target[nodes[i]["lnk"]] = nodes[(i + 1) % n]["srv"]
     for i in range(n):                                    # probes start after every source, in list order
@@ -436,6 +464,21 @@ def ring_arrays(spec, bag_capacity=0, log_capacity=0):
         egress=np.full(n, N.EGRESS_SINK, np.uint8),
     )
     _probe_arrays(st, p, n)
+    if spec.get("more_sources"):                         # several Sources per Server: slots in `sources=[...]` order
+        order, slot_plan = ring_source_plan(spec)
+        st.src_more_kind = np.full((3, n), N.SRC_NONE, np.uint8)
+        st.src_more_rate = np.ones((3, n), np.float64)
+        for i in range(n):
+            for slot, (xa, xr, _) in enumerate(slot_plan[i]):
+                k = N.SRC_POISSON if xa == O.ARR_POISSON else N.SRC_CONSTANT
+                if slot == 0:
+                    st.src_kind[i], st.src_rate[i] = k, xr
+                else:
+                    st.src_more_kind[slot - 1, i], st.src_more_rate[slot - 1, i] = k, xr
+        st.source_order = np.array([i for i, _ in order], np.int32)
+        st.source_slot_order = np.array([sl for _, sl in order], np.uint8)
+        rates = rates + np.array([sum(x[1] for x in slot_plan[i][1:]) if len(slot_plan[i]) > 1 else 0.0 for i in range(n)]) \
+            + st.src_rate * (rates <= 0) * (st.src_kind != N.SRC_NONE)
     if any(pr is not None for pr in p["profile"]):
         st.src_profile_kind = np.zeros(n, np.uint8)
         st.src_profile_params = np.zeros((n, 4), np.float64)

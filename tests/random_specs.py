@@ -143,3 +143,25 @@ def multi_source_spec(k):
     if spec.get("probes"):                                          # generated_count is sampled on a chain's first Source only
         spec["probes"] = [None if pr is None or pr[0] == "generated_count" else pr for pr in spec["probes"]]
     return spec
+
+
+def multi_source_ring_spec(k):
+    """A random ring (ring_spec) whose stations carry up to three further Sources on their Servers, in two list orders."""
+    rng = np.random.default_rng(80_000 + k)
+    spec = ring_spec(500 + k)
+    spec["name"] = f"multi_source_ring_{k}"
+    n = spec["n"]
+    prof = spec.get("profile") or [None] * n
+    more = []
+    for i in range(n):
+        cnt = 0 if (spec["ext_rate"][i] == 0.0 or prof[i] is not None) else int(rng.choice([0, 1, 1, 2, 3]))
+        more.append([[str(rng.choice(["constant", "poisson"])), float(rng.choice([2.0, 4.0, 5.0]))] for _ in range(cnt)] or None)
+    if not any(more):
+        i = next(j for j in range(n) if spec["ext_rate"][j] > 0.0)
+        if prof[i] is not None:
+            spec["profile"][i] = None
+        more[i] = [["constant", 4.0]]
+    spec["more_sources"] = more
+    if rng.random() < 0.5:
+        spec["sources_order"] = "extras_first"
+    return spec

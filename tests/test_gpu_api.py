@@ -142,14 +142,21 @@ def _build_ring(spec):
         pat = (spec.get("rt_pattern") or ["sl"] * n)[i]
         routers.append(hs.RandomRouter(f"router{i}", targets=[sinks[i] if ch == "s" else links[i] for ch in pat]))
         servers[i].downstream = routers[i]
-        rate = spec["ext_rate"][i] if isinstance(spec["ext_rate"], list) else spec["ext_rate"]
+    # the Sources in `sources=[...]` order (several per Server: `more_sources`; slot = position among the Server's Sources)
+    order, slot_plan = H.ring_source_plan(spec)
+    by_slot = {i: [] for i in range(n)}
+    for i in range(n):
         pr = (spec.get("profile") or [None] * n)[i]
-        if rate > 0 and pr is not None:
-            profile = (hs.LinearRampProfile(duration_s=pr[1], start_rate=pr[2], end_rate=pr[3]) if pr[0] == "ramp" else
-                       hs.SpikeProfile(baseline_rate=pr[1], spike_rate=pr[2], warmup_s=pr[3], spike_duration_s=pr[4]))
-            sources.append(hs.Source.with_profile(profile, target=servers[i], poisson=True, name=f"src{i}"))
-        elif rate > 0:
-            sources.append(hs.Source.poisson(rate=rate, target=servers[i], name=f"src{i}"))
+        for slot, (kind, rate, is_first) in enumerate(slot_plan[i]):
+            if is_first and pr is not None:
+                profile = (hs.LinearRampProfile(duration_s=pr[1], start_rate=pr[2], end_rate=pr[3]) if pr[0] == "ramp" else
+                           hs.SpikeProfile(baseline_rate=pr[1], spike_rate=pr[2], warmup_s=pr[3], spike_duration_s=pr[4]))
+                by_slot[i].append(hs.Source.with_profile(profile, target=servers[i], poisson=True, name=f"src{i}"))
+            else:
+                make = hs.Source.poisson if kind == H.O.ARR_POISSON else hs.Source.constant
+                by_slot[i].append(make(rate=rate, target=servers[i], name=f"src{i}_{slot}"))
+    sources = [by_slot[i][slot] for i, slot in order]
+    _build_ring.by_slot = by_slot
     return sources, servers, routers, links, sinks
 
 
@@ -171,14 +178,21 @@ def _check_ring_objects(gold, servers, routers, links, sinks):
 
 
 @pytest.mark.parametrize("name", ["ring_8_s42", "ring_5_const_link", "ring_6_c2_cap3", "ring_8_loss", "ring_5_loss_mixed",
-                                  "ring_6_router_k"])
+                                  "ring_6_router_k", "ring_5_multi_source", "ring_4_multi_source_order"])
 def test_ring_network_through_the_api_matches_reference_golden(name):
     gold = H.Golden(name)
     spec = gold.spec
     sources, servers, routers, links, sinks = _build_ring(spec)
+    probes = [hs.Probe.on({"server": servers[i], "sink": sinks[i]}[H.PROBE_METRICS[m][0]], m, interval=iv)
+              for i, prs in enumerate(H.ring_params(spec)["probe_list"]) for m, iv in prs]
     sim = hs.Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=sources,
-                        entities=servers + routers + links + sinks, seed=spec["seed"])
+                        entities=servers + routers + links + sinks, probes=[p for p, _ in probes], seed=spec["seed"])
+    for i, t_s in spec.get("schedule") or []:
+        sim.schedule(hs.Event(time=Instant.from_seconds(t_s), event_type="Request", target=servers[i]))
     summary = sim.run()
+    if "generated_more" in gold.arrays:          # several Sources per Server: each Source's own generated_count
+        for i, srcs in _build_ring.by_slot.items():
+            assert [x.generated_count for x in srcs] == ([gold.generated[i]] + gold.generated_more[:, i].tolist())[:len(srcs)]
     assert summary.total_events_processed == gold.meta["total_events"][0]
     assert summary.duration_s == gold.meta["duration_s"][0]
     _check_ring_objects(gold, servers, routers, links, sinks)

@@ -8,7 +8,7 @@ import helpers as H
 import random_specs as RS
 from oracle import hs_oracle as O
 from test_gpu_parity import _compare_engine_to_oracle
-from test_gpu_ring import _check_against_oracle
+from test_gpu_ring import ENGINES, _check_against_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -82,6 +82,25 @@ def test_several_sources_per_server_match_oracle(k):
         for chain_ids, nodes, r in runs:
             for (c, slot), nd in r.xsrc_nodes.items():
                 assert eng.source_generated(slot)[c] == r.generated[nd], (c, slot)
+
+
+@ENGINES
+@pytest.mark.parametrize("k", range(30))
+def test_several_sources_per_server_on_rings_match_oracle(k, engine_flags):
+    """random_specs.multi_source_ring_spec on both network engines (the live reference agrees with the oracle on the same 30
+    cases: tests/test_oracle_live_reference.py)."""
+    spec = RS.multi_source_ring_spec(k)
+    g, nodes = H.oracle_ring_graph(spec)
+    p = H.ring_params(spec)
+    r = O.run(g, p["end_ns"], seed=spec["seed"], schedule=[(nodes[c]["srv"], t) for c, t in p["schedule"]])
+    eng, p = H.ring_engine_for_spec(spec, flags=engine_flags)
+    with eng:
+        eng.run_until(p["end_ns"])
+        _check_against_oracle(spec, eng, r, nodes)
+        for i in range(spec["n"]):
+            for j in (1, 2, 3):
+                if f"src{j}" in nodes[i]:
+                    assert eng.source_generated(j)[i] == r.generated[nodes[i][f"src{j}"]], (i, j)
 
 
 @pytest.mark.parametrize("k", TIE_CASES)

@@ -72,6 +72,9 @@ def test_ring_engine_matches_reference_golden(name, engine_flags):
         counts, t, cr = eng.read_sinks()
         np.testing.assert_array_equal(t, gold.sink_t_ns)
         np.testing.assert_array_equal((t - cr).astype(np.float64) / 1e9, gold.sink_latency_s)
+        if "generated_more" in gold.arrays:                 # several Sources per Server (both engines)
+            for j in range(3):
+                np.testing.assert_array_equal(eng.source_generated(1 + j), gold.generated_more[j], err_msg=f"source slot {1 + j}")
         if "probe_t_ns" in gold.arrays:                     # probes on networked stations (both engines)
             for i in range(spec["n"]):
                 for j in range(gold.n_probe_slots):
@@ -226,6 +229,36 @@ def test_profiles_and_schedule_on_large_rings_match_oracle(n, engine_flags):
         _check_against_oracle(spec, eng, r, nodes)
         assert r.events_processed > 30 * n
         assert (eng.summary().launches <= 5) == (engine_flags == 0)      # the asynchronous engine: one cooperative launch
+
+
+@ENGINES
+@pytest.mark.parametrize("conc", [3, 4])
+def test_rings_with_three_and_four_workers_per_station_match_oracle(conc, engine_flags):
+    """Server(concurrency = 3 / 4) on networked stations (the C = 4 instantiations of both network kernels -- the ones with the
+    highest register pressure), with probes, several Sources per Server, a profile and scheduled Requests mixed in: oracle
+    parity on a 200-station ring."""
+    n = 200
+    spec = dict(name=f"ring_c{conc}", topology="ring", n=n, ext_rate=[9.0 if i % 3 else 14.0 for i in range(n)], mean=0.22,
+                concurrency=conc, queue_cap=None if conc == 3 else 5, lat_min=0.002, jitter_mean=0.004, end_s=4.0, seed=300 + conc,
+                probes=[["depth", 0.25] if i % 17 == 0 else None for i in range(n)],
+                more_sources=[[["constant", 5.0]] if i % 11 == 3 else None for i in range(n)],
+                schedule=[[i, 0.5 + 0.01 * (i % 5)] for i in range(2, n, 23)])
+    g, nodes = H.oracle_ring_graph(spec)
+    p = H.ring_params(spec)
+    r = O.run(g, p["end_ns"], seed=spec["seed"], schedule=[(nodes[c]["srv"], t) for c, t in p["schedule"]])
+    eng, p = H.ring_engine_for_spec(spec, flags=engine_flags)
+    with eng:
+        eng.run_until(p["end_ns"])
+        _check_against_oracle(spec, eng, r, nodes)
+        for i in range(n):
+            if "prb" in nodes[i]:
+                t, v = r.sinks[nodes[i]["prb"]]
+                pt, pv = eng.read_probe(i)
+                np.testing.assert_array_equal(pt, t)
+                np.testing.assert_array_equal(pv, v)
+            if "src1" in nodes[i]:
+                assert eng.source_generated(1)[i] == r.generated[nodes[i]["src1"]]
+        assert r.events_processed > 40 * n
 
 
 @ENGINES

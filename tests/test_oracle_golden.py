@@ -109,6 +109,9 @@ def check_oracle_against_ring_golden(gold):
         nd = nodes[i]
         if nd["src"] >= 0:
             assert r.generated[nd["src"]] == gold.generated[i]
+        for j in (1, 2, 3):                                  # further Sources of the station's Server
+            if f"src{j}" in nd:
+                assert r.generated[nd[f"src{j}"]] == gold.generated_more[j - 1, i]
         for k, arr in (("accepted", r.accepted), ("dropped", r.dropped), ("completed", r.completed),
                        ("rejected", r.rejected), ("depth", r.depth), ("active", r.active),
                        ("total_service_s", r.total_service_s)):
