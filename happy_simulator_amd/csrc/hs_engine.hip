@@ -258,6 +258,9 @@ __device__ __noinline__ int64_t first_profile_arrival(const StationParams &P, in
 
 // Simulation.__init__ bootstrap (core/simulation.py:145-154, load/source.py:120-140): every Source draws
 // its first arrival from start_ns.  Also zeroes the per-LP state.
+// PF = false: no LP has a time-varying profile, a probe, a scheduled Request or a further Source -- the instantiation every
+// headline workload uses carries none of the numerical inversion's scratch frame (round 1: 4 176 B per lane in the one kernel).
+template <bool PF>
 __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, StationState X, Totals *tot, int n, int C,
                                                            int64_t start_ns, NetState NX, int n_links) {
     const int lp = blockIdx.x * kBlock + threadIdx.x;
@@ -289,8 +292,10 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
             area = exp1_from_uniform(s.next_uniform());
             arr_k = 1;
         }
-        if (P.prof_kind[lp] != kProfConstant) {   // time-varying rate: the general path (hs_profile.hpp)
-            arr_time = first_profile_arrival(P, lp, n, start_ns, area);
+        bool timevarying = false;
+        if constexpr (PF) timevarying = P.prof_kind[lp] != kProfConstant;
+        if (timevarying) {                        // time-varying rate: the general path (hs_profile.hpp)
+            if constexpr (PF) arr_time = first_profile_arrival(P, lp, n, start_ns, area);
         } else {
             const double t_next = __dadd_rn(seconds_from_ns(start_ns), __ddiv_rn(area, P.src_rate[lp]));
             arr_time = ns_from_seconds(t_next);
@@ -308,6 +313,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
         X.svc_s[(size_t)i * n + lp] = 0.0; X.crt[(size_t)i * n + lp] = 0;
     }
     for (int k = 0; k < 11; ++k) X.ev_kind[(size_t)k * n + lp] = 0;
+    if constexpr (!PF) return;
     if (X.XA != nullptr) {   // the LP's further Sources: each draws its first arrival from start_ns like the first one
         for (int j = 0; j < kMaxXSrc; ++j) {
             const size_t o = (size_t)j * n + lp;
@@ -336,7 +342,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
             const size_t o = (size_t)j * n + lp;
             int64_t PA = kInfNs, p_arr = start_ns;
             if (P.probe_metric[o] != kProbeNone) {
-                p_arr = first_probe_tick(P.probe_rate[o], start_ns, lp);
+                if constexpr (PF) p_arr = first_probe_tick(P.probe_rate[o], start_ns, lp);
                 PA = p_arr;
             }
             if (NX.next_time != nullptr && PA < NX.next_time[lp]) NX.next_time[lp] = PA;   // network engine: first pending event
@@ -1874,8 +1880,12 @@ int do_reset_async(hs_engine *h) {
         static const unsigned long long zero = 0ull;
         HS_HIP(h, hipMemcpyToSymbolAsync(HIP_SYMBOL(hs_prof_budget_hit), &zero, sizeof zero, 0, hipMemcpyHostToDevice, h->stream));
     }
-    hipLaunchKernelGGL(hs_station_reset, dim3(h->n_blocks), dim3(kBlock), 0, h->stream, h->P, h->X, h->tot,
-                       h->cfg.n_lp, h->C, h->cfg.start_ns, h->NX, h->is_net ? h->NP.n_links : 0);
+    if (h->any_profile)
+        hipLaunchKernelGGL(hs_station_reset<true>, dim3(h->n_blocks), dim3(kBlock), 0, h->stream, h->P, h->X, h->tot,
+                           h->cfg.n_lp, h->C, h->cfg.start_ns, h->NX, h->is_net ? h->NP.n_links : 0);
+    else
+        hipLaunchKernelGGL(hs_station_reset<false>, dim3(h->n_blocks), dim3(kBlock), 0, h->stream, h->P, h->X, h->tot,
+                           h->cfg.n_lp, h->C, h->cfg.start_ns, h->NX, h->is_net ? h->NP.n_links : 0);
     HS_HIP(h, hipGetLastError());
     if (h->exact) {            // the prologue starts over: empty heap, both counters at 0
         if (h->XI.per_lp) HS_HIP(h, hipMemsetAsync(h->xs, 0, ((size_t)h->cfg.n_lp + 1) * sizeof(XState), h->stream));
