@@ -226,6 +226,8 @@ def ring_main(args, rank, local_rank, world, distributed, dist):
         # bytes that must cross HBM per run: three 8-byte log appends per request (adm, sink_t, sink_created), 64 B per
         # forwarded request (message written once, read once), the per-LP state in and out once
         algo_bytes = requests * 24 + int(events * 0) + (requests // 2) * 64 + args.n_lp * 700
+        async_engine = (args.gpus == 1 and windows <= 5) or (args.gpus > 1 and not args.ring_windows)
+        prof = measured_roofline("ring")
         out = {
             "metric": "committed events/sec (whole node), 65 536-server ring network",
             "value": events / step_s, "unit": "events/s", "n_gpus": args.gpus, "steps": args.steps,
@@ -243,17 +245,25 @@ def ring_main(args, rank, local_rank, world, distributed, dist):
                                 f"{args.gpus} contiguous ring segments; per 1 ms window ({windows} per run): all-to-all of boundary "
                                 "messages + all-reduce(min) GVT over RCCL") if args.gpus > 1 else
                                ("1 engine, asynchronous: the whole run in one cooperative launch (hs_net_async) + the election launch"
-                                if windows <= 4 else "1 engine, one launch per window"),
+                                if windows <= 5 else "1 engine, one launch per window"),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "hs_net_async<1>" if ((args.gpus == 1 and windows <= 4) or
-                                                                 (args.gpus > 1 and not args.ring_windows)) else "hs_net_window<1>",
+                # not an HBM-bound kernel: one wavefront per SIMD walking dependent LDS / 64-bit integer work, waiting for its
+                # neighbours' bounds -- `valu` carries the measured issue and wait fractions next to the HBM figures
+                "bound": "valu", "kernel": "hs_net_async<1>" if async_engine else "hs_net_window<1>",
                 "achieved": algo_bytes / step_s / 1e9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": algo_bytes / step_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "unit": "GB/s", "frac": algo_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                "traffic": prof.get("hbm_bytes_per_launch") if (prof and prof.get("current") and async_engine) else None,
+                "valu": None if not (prof and async_engine and "valu_busy_frac" in prof) else {
+                    "busy_frac": prof["valu_busy_frac"], "wait_frac": prof.get("wait_frac_of_wave_cycles"),
+                    "waves_per_simd": prof.get("waves_per_simd"), "kernel_us_under_rocprof": prof.get("kernel_us_rocprof"),
+                    "profile": prof["file"], "profile_commit": prof.get("commit"),
+                    "profile_is_of_this_code": bool(prof.get("current"))},
                 "algorithmic_bytes_per_launch": algo_bytes,
-                "note": "per RUN; the network engines are bound by chains of dependent memory round trips between neighbouring "
-                        "LPs (asynchronous engine: how fast per-link lower bounds travel; windowed engine: one launch per window), "
-                        "not by HBM",
+                "note": "per RUN; the network engines are bound by chains of dependent work inside one wavefront per SIMD and by how "
+                        "fast per-link lower bounds travel between neighbouring LPs (asynchronous engine) or by one launch per "
+                        "window (windowed engine), not by HBM; traffic / valu come from the committed rocprofv3 passes named in "
+                        "`valu.profile` and are null when the kernel sources changed since",
                 **info,
             },
         }
@@ -263,11 +273,10 @@ def ring_main(args, rank, local_rank, world, distributed, dist):
 
 
 def lb_traffic():
-    """HBM bytes of the sort kernels per step from the committed PMC passes (profiles/r01_lb_pmc_traffic.json), or None."""
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r01_lb_pmc_traffic.json"))).get("hbm_bytes_per_step")
-    except Exception:
-        return None
+    """HBM bytes of the sort kernels per step from the newest committed PMC passes (profiles/derive_lb_traffic.py), or None when
+    there is none or the kernel sources changed since it was taken."""
+    d = measured_roofline("lb")
+    return d.get("hbm_bytes_per_launch") if d and d.get("current") else None
 
 
 def lb_main(args, rank, local_rank, world, distributed, dist):
