@@ -260,6 +260,10 @@ def lib():
     L.hs_lb_get_summary.argtypes = [C.c_void_p, P(Summary)]
     L.hs_lb_get_stats.restype = C.c_int
     L.hs_lb_get_stats.argtypes = [C.c_void_p, P(LbStats)]
+    L.hs_lb_set_probes.restype = C.c_int
+    L.hs_lb_set_probes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hs_lb_read_probe.restype = C.c_int64
+    L.hs_lb_read_probe.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]
     L.hs_lb_read_sink.restype = C.c_int64
     L.hs_lb_read_sink.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]
     L.hs_lb_latency_stats.restype = C.c_int
@@ -301,6 +305,7 @@ EXPORTED_SYMBOLS = (
     "hs_last_error", "hs_last_global_error", "hs_engine_destroy", "hs_debug_draws", "hs_debug_set_flags",
     "hs_debug_const_div", "hs_debug_async_counters",
     "hs_lb_create", "hs_lb_run", "hs_lb_bench_runs", "hs_lb_get_summary", "hs_lb_get_stats", "hs_lb_read_sink",
+    "hs_lb_set_probes", "hs_lb_read_probe",
     "hs_lb_latency_stats",
     "hs_lb_ring", "hs_lb_select", "hs_lb_last_error", "hs_lb_destroy", "hs_md5", "hs_debug_radix_sort", "hs_merge_sink_records",
     "hs_sink_latency_stats",

@@ -1196,6 +1196,10 @@ constexpr unsigned kAsyncBlockedMax = 1u << 17;   // ... while a lane waits for 
 #ifndef HS_LOOK
 #define HS_LOOK 4
 #endif
+#ifndef HS_TOPUP_NEED
+#define HS_TOPUP_NEED 4
+#endif
+constexpr int kTopUpNeed = HS_TOPUP_NEED;
 constexpr int kAsyncGroupCap = HS_GROUP_CAP;   // event groups per LP per iteration of hs_net_async (debug flags bits 8..15 override)
 
 template <int C, bool PF>
@@ -1247,6 +1251,9 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         // the other 63 idle, and their bounds only move at iteration boundaries -- so every lane takes a few groups, then
         // the wavefront exchanges bounds again and (measured) many more lanes are ready in the next trip.
         const int group_cap = ((flags >> 8) & 0xff) ? ((flags >> 8) & 0xff) : kAsyncGroupCap;
+        // a lane with fewer pre-drawn values than this makes the wavefront refill (debug flags bits 16..19 override): refills are
+        // the expensive part (4 values = 2 Philox blocks + logs + divisions per stream), a dry ring costs one general-path group
+        const int topup_need = ((flags >> 16) & 0xf) ? ((flags >> 16) & 0xf) : (group_cap < kTopUpNeed ? group_cap : kTopUpNeed);
         unsigned n_groups = 0, n_iter = 0, groups_before = 0, idle_iters = 0;
         bool aborted = false, blocked = false;
         unsigned blocked_iters = 0;
@@ -1283,7 +1290,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                 __builtin_amdgcn_s_sleep(127);
             const int64_t w_peek = done ? 0 : S.async_peek();         // the incoming link's word: its latency hides behind the refills
             S.window_fill(!done);                                     // created_at of what entered the window from a deep queue
-            S.top_up(!done, group_cap < 4 ? group_cap : 4);           // whole wavefront: refill the pre-drawn values
+            S.top_up(!done, topup_need);                              // whole wavefront: refill the pre-drawn values
             int64_t H = kInfNs;
 #ifdef HS_CYCLES
             const unsigned long long q0 = __builtin_readcyclecounter();

@@ -36,6 +36,7 @@
 
 #include "../../include/hs_engine.h"
 #include "hs_device.hpp"
+#include "hs_profile.hpp"
 #include "hs_radix.hpp"
 
 using namespace hs;
@@ -55,6 +56,7 @@ struct LbTotals {
     long long last_time;          // latest processed event time <= end
     long long final_time;         // Simulation._current_time after the run (the overshoot event's time)
     int qoverflow, bad_client;
+    int probe_tie;                // a probe sample fell on the nanosecond of an event of its target (refused, never guessed)
     long long max_count;          // most Requests emitted by one source (rows of the arrival log in use)
     long long max_be;             // most Requests routed to one backend (rows of the wave-coalesced layout in use)
     int use_t;                    // this run uses the [row][backend] layout for the backend streams (max_be <= rows)
@@ -820,14 +822,141 @@ __global__ void hs_lb_sink_finish(const uint64_t *__restrict__ mkey, const uint6
 // ---------------------------------------------------------------------------------------------
 // 5. The one event beyond end_ns (core/simulation.py:472: the loop tests the PREVIOUS event's time) + totals
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kLbBlock) hs_lb_finalize(LbSrc PS, LbBe PB, int S, int B, int64_t start_ns, LbTotals *tot) {
+// ---------------------------------------------------------------------------------------------
+// 5. Probes on a load-balancer graph (instrumentation/probe.py:81-164): Probe.on(server | sink, metric, interval).
+// A probe is a daemon Source of its own whose ticks do not touch the simulation, so its tick times are a property of
+// (interval, start) alone -- computed once, with the reference's own procedure (ConstantArrivalTimeProvider over
+// _ProbeProfile: the general numerical path, hs_profile.hpp) -- and what it samples is a function of the run's logs:
+//     stats_accepted(T) = #{admissions <= T}     completed(T) = #{completions <= T}     dropped = arrivals - accepted
+//     started(T) = min(accepted, completed + c)  (work-conserving FIFO, c workers)      depth = accepted - started
+//     active = started - completed               Sink.events_received(T) = #{records <= T}
+// A sample on the very nanosecond of one of its target's events would need the reference's sort-index order between the
+// probe's chain and the Request's chain: such a run is refused (probe_tie), never guessed.
+// ---------------------------------------------------------------------------------------------
+struct LbProbes {
+    const int32_t *kind, *idx;    // [n] 0: backend Server idx;  1: Sink idx (shared Sink: 0; per-backend Sinks: backend)
+    const uint8_t *metric;        // [n] hs_probe_metric
+    const double *rate;           // [n] 1.0 / interval
+    int64_t *tick;                // [n][pcap] tick times up to the first one beyond the horizon
+    int64_t *n_tick;              // [n] entries of tick[] (the last one lies beyond the horizon)
+    int64_t *val;                 // [n][pcap] sampled values of the last run
+    int64_t *cnt;                 // [n] samples of the last run (ticks <= end)
+    LbCand *cand;                 // [n] the pending tick beyond end
+    int64_t pcap;
+    int n;
+};
+
+__global__ void hs_lb_probe_ticks(LbProbes Q, int64_t start_ns, int64_t horizon_ns) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Q.n) return;
+    Profile pp;
+    pp.kind = kProfGeneralConstant; pp.p0 = Q.rate[j]; pp.p1 = pp.p2 = pp.p3 = 0.0; pp.owner = j;
+    int64_t t = start_ns, k = 0;
+    for (;;) {                                                    // Source.start(), then one next_arrival_time per tick
+        const int64_t a = prof_next_arrival(pp, t, 1.0);
+        if (k < Q.pcap) Q.tick[(size_t)j * Q.pcap + k] = a;
+        ++k;
+        if (a > horizon_ns || a <= t || k >= Q.pcap) break;
+        t = a;
+    }
+    Q.n_tick[j] = k;
+}
+
+__device__ __forceinline__ int64_t count_le(const int64_t *a, int64_t n, int64_t stride, int64_t T) {   // #{a[i * stride] <= T}, a ascending
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (a[m * stride] <= T) lo = m + 1; else hi = m; }
+    return lo;
+}
+__device__ __forceinline__ int64_t count_lt(const int64_t *a, int64_t n, int64_t stride, int64_t T) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (a[m * stride] < T) lo = m + 1; else hi = m; }
+    return lo;
+}
+
+// per probe: how many of its ticks lie at or before end (= samples of this run) and the pending tick beyond it
+__global__ void hs_lb_probe_cands(LbProbes Q, int S, int B, int64_t end_ns, LbTotals *tot) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Q.n) return;
+    const int64_t *tk = Q.tick + (size_t)j * Q.pcap;
+    const int64_t n = Q.n_tick[j];
+    const int64_t c = count_le(tk, n, 1, end_ns);
+    Q.cnt[j] = c;
+    LbCand cd;
+    cd.valid = c < n ? 1 : 0; cd.t = c < n ? tk[c] : kInfNs; cd.t_created = c > 0 ? tk[c - 1] : INT64_MIN;   // (constructed before run())
+    cd.idx = S + B + j; cd.svc_s = 0.0;
+    Q.cand[j] = cd;
+    if (c > 0) {
+        atomicAdd(&tot->ev[13], (unsigned long long)c);           // SourceEvent@Probe
+        atomicAdd(&tot->ev[14], (unsigned long long)c);           // probe_event
+        atomicMax(&tot->last_time, (long long)tk[c - 1]);
+    }
+}
+
+// one lane per (probe, sample)
+__global__ void hs_lb_probe_sample(LbProbes Q, LbBe PB, int B, int tb, const uint64_t *__restrict__ skey,
+                                   const int64_t *__restrict__ off, const int64_t *__restrict__ adm,
+                                   const int64_t *__restrict__ sink_t, const int64_t *__restrict__ out_t,
+                                   const int64_t *n_done, int shared_sink, int phase, LbTotals *tot) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = (int)(i / Q.pcap);
+    const int64_t k = i - (int64_t)j * Q.pcap;
+    if (j >= Q.n || k >= Q.cnt[j]) return;
+    if ((Q.kind[j] == 1 && shared_sink) != (phase == 1)) return;  // phase 1: probes on the shared Sink (after its merge)
+    const int64_t T = Q.tick[(size_t)j * Q.pcap + k];
+    const uint32_t m = Q.metric[j];
+    int64_t v = 0;
+    bool tie = false;
+    if (Q.kind[j] == 1 && shared_sink) {                          // the shared Sink: the merged completion log
+        const int64_t n = *n_done;
+        v = count_le(out_t, n, 1, T);
+        tie = v != count_lt(out_t, n, 1, T);
+    } else {
+        const int b = Q.idx[j];
+        const int64_t o = off[b], na = off[b + 1] - o;
+        const bool Tl = tot->use_t != 0;                          // [m][backend] completion logs this run?
+        const int64_t *st = sink_t + (Tl ? b : o);
+        const int64_t ss = Tl ? B : 1;
+        const int64_t ndep = PB.received[b];                      // completions at or before end that reached the log
+        const int64_t done = count_le(st, ndep, ss, T);
+        tie = done != count_lt(st, ndep, ss, T);
+        if (Q.kind[j] == 1) v = done;                             // a backend's own Sink
+        else {
+            // arrivals of the backend at or before T: its segment of the sorted (backend << tb | arrival ns) keys
+            const uint64_t tmask = tb >= 64 ? ~0ull : ((1ull << tb) - 1);
+            int64_t lo = 0, hi = na, lt = 0;
+            while (lo < hi) { const int64_t q = (lo + hi) >> 1; if ((int64_t)(skey[o + q] & tmask) <= T) lo = q + 1; else hi = q; }
+            const int64_t arrived = lo;
+            hi = na;
+            while (lt < hi) { const int64_t q = (lt + hi) >> 1; if ((int64_t)(skey[o + q] & tmask) < T) lt = q + 1; else hi = q; }
+            tie = tie || arrived != lt;
+            int64_t accepted = arrived;
+            if (PB.qcap[b] >= 0) {                                // bounded queue: the admission log holds the accepted ones
+                accepted = count_le(adm + o, PB.accepted[b], 1, T);
+            }
+            int64_t started = done + PB.conc[b];
+            started = accepted < started ? accepted : started;
+            switch (m) {
+                case HS_PROBE_DEPTH: v = accepted - started; break;
+                case HS_PROBE_ACTIVE: v = started - done; break;
+                case HS_PROBE_ACCEPTED: v = accepted; break;
+                case HS_PROBE_DROPPED: v = arrived - accepted; break;
+                default: v = done; break;                        // HS_PROBE_COMPLETED
+            }
+        }
+    }
+    Q.val[(size_t)j * Q.pcap + k] = v;
+    if (tie) atomicOr(&tot->probe_tie, 1);
+}
+
+__global__ void __launch_bounds__(kLbBlock) hs_lb_finalize(LbSrc PS, LbBe PB, int S, int B, int64_t start_ns, LbTotals *tot,
+                                                          LbProbes Q) {
     __shared__ LbCand wc[kLbBlock / 64];
     const int tid = threadIdx.x;
     LbCand best;
     best.valid = 0; best.t = kInfNs; best.t_created = 0; best.idx = 0; best.svc_s = 0.0;
     const int nbs = (S + kLbBlock - 1) / kLbBlock, nbb = (B + kLbBlock - 1) / kLbBlock;   // one candidate per workgroup
-    for (int i = tid; i < nbs + nbb; i += kLbBlock) {
-        const LbCand c = i < nbs ? PS.cand[i] : PB.cand[i - nbs];
+    for (int i = tid; i < nbs + nbb + Q.n; i += kLbBlock) {
+        const LbCand c = i < nbs ? PS.cand[i] : i < nbs + nbb ? PB.cand[i - nbs] : Q.cand[i - nbs - nbb];
         if (cand_before(c, best)) best = c;
     }
 #pragma unroll
@@ -841,7 +970,9 @@ __global__ void __launch_bounds__(kLbBlock) hs_lb_finalize(LbSrc PS, LbBe PB, in
     for (int w = 1; w < kLbBlock / 64; ++w) if (cand_before(wc[w], best)) best = wc[w];
     long long fin = tot->last_time == INT64_MIN ? start_ns : tot->last_time;
     if (best.valid) {
-        if (best.idx < S) {                       // SourceEvent: the tick is counted, its Request is not processed
+        if (best.idx >= S + B) {                  // a Probe's SourceEvent: counted, its probe_event is not processed
+            tot->ev[13] += 1;
+        } else if (best.idx < S) {                // SourceEvent: the tick is counted, its Request is not processed
             PS.generated[best.idx] += 1;
             tot->ev[HS_EV_SOURCE] += 1;
         } else {                                  // ProcessContinuation: the Server's statistics move, the Sink's do not
@@ -902,7 +1033,7 @@ __global__ void __launch_bounds__(64) hs_lb_latency_stats_kernel(const uint64_t 
 __global__ void hs_lb_clear(LbTotals *tot) {
     for (int k = 0; k < HS_EV_KINDS; ++k) tot->ev[k] = 0;
     tot->completed = 0; tot->received = 0; tot->last_time = INT64_MIN; tot->final_time = 0;
-    tot->qoverflow = 0; tot->bad_client = 0; tot->max_count = 0; tot->max_be = 0; tot->use_t = 0;
+    tot->qoverflow = 0; tot->bad_client = 0; tot->max_count = 0; tot->max_be = 0; tot->use_t = 0; tot->probe_tie = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -998,6 +1129,8 @@ struct hs_lb {
     int64_t *n_slots_dev = nullptr, *n_arr = nullptr, *n_done = nullptr, *n_tmp = nullptr;
     uint32_t *hist = nullptr, *row_total = nullptr, *digit_base = nullptr;
     int n_tiles = 0;
+    LbProbes Q{};                                     // probes (hs_lb_set_probes); n == 0: none
+    std::vector<int32_t> probe_kind_h;
     bool ran = false;
     int flags = 0;
     double last_run_ms = 0.0, last_sort_ms = 0.0;
@@ -1148,6 +1281,14 @@ int run_async(hs_lb *h, int64_t end_ns) {
         case 8: launch_backends<8>(h, end_ns); break;
         default: launch_backends<16>(h, end_ns); break;
     }
+    if (h->Q.n > 0) {     // probes: the ticks of this run and the pending one beyond end; then the samples of everything but a
+                          // shared Sink, from the backends' logs (the Sink merge below reuses the buffer of the sorted arrivals)
+        hipLaunchKernelGGL(hs_lb_probe_cands, dim3((h->Q.n + 63) / 64), dim3(64), 0, h->stream, h->Q, S, B, end_ns, h->tot);
+        const int64_t lanes = (int64_t)h->Q.n * h->Q.pcap;
+        hipLaunchKernelGGL(hs_lb_probe_sample, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, h->stream, h->Q, h->PB, B, h->tb,
+                           h->skey, h->off, h->adm, h->sink_t, h->out_t, h->n_done, h->cfg.shared_sink ? 1 : 0, 0, h->tot);
+        h->launches += 2;
+    }
     hipEventRecord(h->evs2, h->stream);
     if (h->cfg.shared_sink) {
         // completions by completion ns; the validity functor reads the sorted arrival keys (which slot belongs to which
@@ -1164,7 +1305,13 @@ int run_async(hs_lb *h, int64_t end_ns) {
                            h->mslot, h->n_done, h->sink_created, h->sink_S, h->out_t, h->out_created, h->slot_bits, h->g_sink);
     }
     hipEventRecord(h->evs3, h->stream);
-    hipLaunchKernelGGL(hs_lb_finalize, dim3(1), dim3(kLbBlock), 0, h->stream, h->PS, h->PB, S, B, h->cfg.start_ns, h->tot);
+    if (h->Q.n > 0 && h->cfg.shared_sink) {   // probes on the shared Sink: its merged log exists now
+        const int64_t lanes = (int64_t)h->Q.n * h->Q.pcap;
+        hipLaunchKernelGGL(hs_lb_probe_sample, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, h->stream, h->Q, h->PB, B, h->tb,
+                           h->skey, h->off, h->adm, h->sink_t, h->out_t, h->n_done, 1, 1, h->tot);
+        h->launches += 1;
+    }
+    hipLaunchKernelGGL(hs_lb_finalize, dim3(1), dim3(kLbBlock), 0, h->stream, h->PS, h->PB, S, B, h->cfg.start_ns, h->tot, h->Q);
     h->launches += 6;
     LB_HIP(h, hipGetLastError());
     h->ran = true;
@@ -1177,6 +1324,8 @@ int check_flags(hs_lb *h) {
     if (t.qoverflow) return lfail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
     if (t.bad_client & 1) return lfail(h, HS_E_INVALID, "a client id fell outside the client table");
     if (t.bad_client & 2) return lfail(h, HS_E_OVERFLOW, "a source's tick log overflowed (capacity %lld ticks); raise tick_capacity", (long long)h->cap);
+    if (t.probe_tie) return lfail(h, HS_E_UNSUPPORTED, "a probe sample fell on the nanosecond of an event of its target: on load-balancer "
+                                  "graphs that order (the reference's sort indices) is not lowered");
     return HS_OK;
 }
 
@@ -1432,6 +1581,73 @@ int hs_lb_get_stats(hs_lb *h, const hs_lb_stats *o) {
         if (o->lb) { o->lb[0] = off[B]; o->lb[1] = off[B]; o->lb[2] = 0; o->lb[3] = 0; o->lb[4] = 0; }
     }
     return HS_OK;
+}
+
+int hs_lb_set_probes(hs_lb *h, int32_t n_probes, const int32_t *target_kind, const int32_t *target_index,
+                     const uint8_t *metric, const double *interval_s) {
+    if (!h) return lfail(h, HS_E_INVALID, "hs_lb_set_probes: null handle");
+    if (h->Q.n > 0) return lfail(h, HS_E_STATE, "probes already set");
+    if (n_probes <= 0) return HS_OK;
+    if (!target_kind || !target_index || !metric || !interval_s) return lfail(h, HS_E_INVALID, "hs_lb_set_probes: null argument");
+    LB_HIP(h, hipSetDevice(h->cfg.device));
+    const int B = h->cfg.n_backends;
+    std::vector<double> rate((size_t)n_probes);
+    double min_iv = 0.0;
+    for (int j = 0; j < n_probes; ++j) {
+        const int k = target_kind[j], i = target_index[j], m = metric[j];
+        if (k != 0 && k != 1) return lfail(h, HS_E_UNSUPPORTED, "probe %d: target kind %d (0 = backend Server, 1 = Sink)", j, k);
+        if (k == 0 && (i < 0 || i >= B)) return lfail(h, HS_E_INVALID, "probe %d: backend %d out of range", j, i);
+        if (k == 1 && (i < 0 || i >= (h->cfg.shared_sink ? 1 : B))) return lfail(h, HS_E_INVALID, "probe %d: sink %d out of range", j, i);
+        if (k == 0 && !(m == HS_PROBE_DEPTH || m == HS_PROBE_ACTIVE || m == HS_PROBE_ACCEPTED || m == HS_PROBE_DROPPED ||
+                        m == HS_PROBE_COMPLETED))
+            return lfail(h, HS_E_UNSUPPORTED, "probe %d: metric %d is not an attribute of a Server", j, m);
+        if (k == 1 && m != HS_PROBE_RECEIVED) return lfail(h, HS_E_UNSUPPORTED, "probe %d: metric %d is not an attribute of a Sink", j, m);
+        if (!h->sink_t) return lfail(h, HS_E_UNSUPPORTED, "probes on a load-balancer graph need the backends' completion logs (a Sink downstream)");
+        const double iv = interval_s[j];
+        if (!(iv > 0.0) || !std::isfinite(iv)) return lfail(h, HS_E_INVALID, "Probe interval must be positive.");   // probe.py:29-30
+        rate[(size_t)j] = 1.0 / iv;
+        if (min_iv == 0.0 || iv < min_iv) min_iv = iv;
+    }
+    const double horizon_s = (double)(h->cfg.horizon_ns - h->cfg.start_ns) / 1e9;
+    const int64_t pcap = (int64_t)(horizon_s / min_iv) + 8;
+    if ((double)pcap * n_probes * 16.0 > 8e9) return lfail(h, HS_E_INVALID, "probe logs would need %.1f GB", (double)pcap * n_probes * 16.0 / 1e9);
+    LbProbes Q{};
+    Q.n = n_probes; Q.pcap = pcap;
+    int32_t *dk = nullptr, *di = nullptr; uint8_t *dm = nullptr; double *dr = nullptr;
+    int rc;
+#define PTRY(x) do { if ((rc = (x))) return rc; } while (0)
+    PTRY(lalloc(h, &dk, (size_t)n_probes)); PTRY(lalloc(h, &di, (size_t)n_probes)); PTRY(lalloc(h, &dm, (size_t)n_probes));
+    PTRY(lalloc(h, &dr, (size_t)n_probes));
+    PTRY(lalloc(h, &Q.tick, (size_t)n_probes * (size_t)pcap)); PTRY(lalloc(h, &Q.val, (size_t)n_probes * (size_t)pcap));
+    PTRY(lalloc(h, &Q.n_tick, (size_t)n_probes)); PTRY(lalloc(h, &Q.cnt, (size_t)n_probes)); PTRY(lalloc(h, &Q.cand, (size_t)n_probes));
+#undef PTRY
+    LB_HIP(h, hipMemcpy(dk, target_kind, (size_t)n_probes * 4, hipMemcpyHostToDevice));
+    LB_HIP(h, hipMemcpy(di, target_index, (size_t)n_probes * 4, hipMemcpyHostToDevice));
+    LB_HIP(h, hipMemcpy(dm, metric, (size_t)n_probes, hipMemcpyHostToDevice));
+    LB_HIP(h, hipMemcpy(dr, rate.data(), (size_t)n_probes * 8, hipMemcpyHostToDevice));
+    LB_HIP(h, hipMemset(Q.cnt, 0, (size_t)n_probes * 8));
+    Q.kind = dk; Q.idx = di; Q.metric = dm; Q.rate = dr;
+    // the tick times do not depend on the run: once, up to the first one beyond the horizon
+    hipLaunchKernelGGL(hs_lb_probe_ticks, dim3((n_probes + 63) / 64), dim3(64), 0, h->stream, Q, h->cfg.start_ns, h->cfg.horizon_ns);
+    LB_HIP(h, hipGetLastError());
+    LB_HIP(h, hipStreamSynchronize(h->stream));
+    h->Q = Q;
+    return HS_OK;
+}
+
+int64_t hs_lb_read_probe(hs_lb *h, int32_t probe, int64_t *t_ns, int64_t *values, int64_t cap) {
+    if (!h || !h->ran) return lfail(h, HS_E_STATE, "hs_lb_read_probe before hs_lb_run");
+    if (probe < 0 || probe >= h->Q.n) return lfail(h, HS_E_INVALID, "probe %d out of range", probe);
+    if (hipSetDevice(h->cfg.device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return lfail(h, HS_E_HIP, "device synchronisation failed");
+    int64_t cnt = 0;
+    if (hipMemcpy(&cnt, h->Q.cnt + probe, 8, hipMemcpyDeviceToHost) != hipSuccess) return lfail(h, HS_E_HIP, "memcpy");
+    if (cnt > cap) cnt = cap;
+    if (cnt > 0) {
+        const size_t o = (size_t)probe * (size_t)h->Q.pcap;
+        if (t_ns && hipMemcpy(t_ns, h->Q.tick + o, (size_t)cnt * 8, hipMemcpyDeviceToHost) != hipSuccess) return lfail(h, HS_E_HIP, "memcpy");
+        if (values && hipMemcpy(values, h->Q.val + o, (size_t)cnt * 8, hipMemcpyDeviceToHost) != hipSuccess) return lfail(h, HS_E_HIP, "memcpy");
+    }
+    return cnt;
 }
 
 int64_t hs_lb_read_sink(hs_lb *h, int32_t sink, int64_t *t_ns, int64_t *created_ns, int64_t cap) {

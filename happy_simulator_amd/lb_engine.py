@@ -120,6 +120,25 @@ class LoadBalancerEngine:
         """`Simulation.__init__` + `run()` to end_ns (one-event overshoot included)."""
         self._check(self._lib.hs_lb_run(self._h, int(end_ns)))
 
+    def set_probes(self, target_kind, target_index, metric, interval_s) -> None:
+        """Probe.on(<backend Server> | <Sink>, metric, interval) (include/hs_engine.h `hs_lb_set_probes`): target_kind 0 =
+        backend Server, 1 = Sink; metric = N.PROBE_METRICS id; once, before the first run."""
+        k = np.ascontiguousarray(target_kind, np.int32)
+        i = np.ascontiguousarray(target_index, np.int32)
+        m = np.ascontiguousarray(metric, np.uint8)
+        iv = np.ascontiguousarray(interval_s, np.float64)
+        if not (k.shape == i.shape == m.shape == iv.shape and k.ndim == 1):
+            raise ValueError("one target kind, index, metric and interval per probe")
+        self._check(self._lib.hs_lb_set_probes(self._h, len(k), k.ctypes.data, i.ctypes.data, m.ctypes.data, iv.ctypes.data))
+        self.n_probes = len(k)
+
+    def read_probe(self, probe: int, cap: int = 1 << 22):
+        """(sample times ns, sampled values) of probe `probe` in the last run."""
+        t = np.zeros(cap, np.int64)
+        v = np.zeros(cap, np.int64)
+        n = self._check(self._lib.hs_lb_read_probe(self._h, int(probe), t.ctypes.data, v.ctypes.data, cap))
+        return t[:n].copy(), v[:n].copy()
+
     def bench_runs(self, end_ns: int, repeats: int):
         run_ms = np.zeros(repeats, np.float32)
         sort_ms = np.zeros(repeats, np.float32)

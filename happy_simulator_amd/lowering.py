@@ -437,6 +437,23 @@ class LbGraph:
     backends: list
     sinks: list                    # one shared collector, one per backend, or [] (no downstream anywhere)
     shared_sink: bool
+    probes: list = field(default_factory=list)       # Probes on backend Servers / Sinks, in `probes=[...]` order
+
+    def probe_arrays(self):
+        """(target kind, target index, metric id, interval) per probe for LoadBalancerEngine.set_probes."""
+        kinds, idx, met, iv = [], [], [], []
+        for pr in self.probes:
+            if isinstance(pr.target, Server):
+                kinds.append(0)
+                idx.append(next(j for j, b in enumerate(self.backends) if b is pr.target))
+                m = pr.metric
+                met.append(N.PROBE_METRICS["active_requests" if m == "utilization" else m])
+            else:
+                kinds.append(1)
+                idx.append(next(j for j, k in enumerate(self.sinks) if k is pr.target))
+                met.append(N.PROBE_METRICS["events_received"])
+            iv.append(pr.interval)
+        return kinds, idx, met, iv
 
     def engine_arrays(self):
         from .lb_engine import LbBackendArrays, LbSourceArrays
@@ -524,8 +541,30 @@ def lower_lb(sources: list, entities: list, lb: LoadBalancer) -> LbGraph:
     return LbGraph(sources=sources, lb=lb, backends=backends, sinks=sinks, shared_sink=shared)
 
 
+def attach_lb_probes(g: LbGraph, probes: list) -> None:
+    """Probe.on(<backend Server> | <Sink>, metric, interval) on a load-balancer graph (csrc/hs_lb.hip section 5)."""
+    from .entities import Probe
+
+    for pr in probes or []:
+        if not isinstance(pr, Probe):
+            raise UnsupportedTopology(f"probe {type(pr).__name__} is not a lowered Probe")
+        if any(pr.target is b for b in g.backends):
+            if pr.metric in ("generated_count", "_generated_count", "events_received"):
+                raise UnsupportedTopology(f"probe '{pr.name}': metric '{pr.metric}' is not an attribute of Server")
+        elif any(pr.target is k for k in g.sinks):
+            if pr.metric != "events_received":
+                raise UnsupportedTopology(f"probe '{pr.name}': metric '{pr.metric}' is not an attribute of {type(pr.target).__name__}")
+        else:
+            raise UnsupportedTopology(f"probe '{pr.name}': on a load-balancer graph the backend Servers and the Sinks are sampled "
+                                      f"(not {type(pr.target).__name__} '{getattr(pr.target, 'name', pr.target)}')")
+        g.probes.append(pr)
+
+
 def write_back_lb(g: LbGraph, stats: dict, eng) -> None:
     """Engine results -> the user's objects, under the reference's attribute names."""
+    for j, pr in enumerate(g.probes):
+        t, v = eng.read_probe(j)
+        pr.data_sink._set(t, v, pr.target.concurrency if pr.metric == "utilization" else None)
     for i, s in enumerate(g.sources):
         s._generated_count = int(stats["generated"][i])
     lb = g.lb

@@ -13,7 +13,7 @@ from .core.event import Event
 from .core.temporal import Instant
 from .engine import StationEngine
 from .entities import Entity, Server
-from .lowering import (LbGraph, LoweredGraph, UnsupportedTopology, attach_probes, find_load_balancer, lower, lower_lb,
+from .lowering import (LbGraph, LoweredGraph, UnsupportedTopology, attach_lb_probes, attach_probes, find_load_balancer, lower, lower_lb,
                        write_back, write_back_lb, write_back_probes)
 from .summary import EntitySummary, QueueStats, SimulationSummary
 
@@ -117,8 +117,9 @@ class Simulation:
                                                                                                     self._entities)
             if self._probes:
                 if lb is not None:
-                    raise UnsupportedTopology("probes are not lowered for load-balancer topologies yet")
-                attach_probes(self._graph, self._probes)
+                    attach_lb_probes(self._graph, self._probes)
+                else:
+                    attach_probes(self._graph, self._probes)
         return self._graph
 
     def _run_lb(self, g: LbGraph, wall0: float) -> SimulationSummary:
@@ -130,6 +131,8 @@ class Simulation:
         with LoadBalancerEngine(src, be, virtual_nodes=g.lb.strategy.virtual_nodes, horizon_ns=end_ns,
                                 shared_sink=g.shared_sink, start_ns=self._start_time.nanoseconds, seed=self._seed,
                                 device=self._device) as eng:
+            if g.probes:
+                eng.set_probes(*g.probe_arrays())
             eng.run(end_ns)
             es = eng.summary()
             write_back_lb(g, eng.stats(), eng)

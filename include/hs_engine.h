@@ -415,6 +415,17 @@ int hs_lb_get_stats(hs_lb *h, const hs_lb_stats *out);
 /* Sink records in the Sink's processing order.  shared_sink: sink must be 0 (all completions, global order);
  * otherwise sink = backend index.  Returns the number of records copied or a negative hs_status. */
 int64_t hs_lb_read_sink(hs_lb *h, int32_t sink, int64_t *t_ns, int64_t *created_ns, int64_t cap);
+/* Probe.on(<backend Server> | <Sink>, metric, interval) on a load-balancer graph (instrumentation/probe.py:81-164), set once
+ * after hs_lb_create and before the first run: target_kind 0 = backend Server `target_index` (depth, active_requests,
+ * stats_accepted, stats_dropped, requests_completed), 1 = Sink `target_index` (events_received; the shared Sink is index 0).
+ * Tick times follow the reference's ConstantArrivalTimeProvider over _ProbeProfile; each tick at or before end_ns is two
+ * reference events (kinds 13, 14) and the pending tick takes part in the election of the one event beyond end_ns.  The samples
+ * are read off the run's logs; a sample on the very nanosecond of an event of its target makes hs_lb_run fail with
+ * HS_E_UNSUPPORTED (that order is the reference's sort-index ledger, not lowered for this graph) -- never a guess. */
+int hs_lb_set_probes(hs_lb *h, int32_t n_probes, const int32_t *target_kind, const int32_t *target_index,
+                     const uint8_t *metric, const double *interval_s);
+/* samples of probe `probe` in the last run: times and values -> returns their number (<= cap) */
+int64_t hs_lb_read_probe(hs_lb *h, int32_t probe, int64_t *t_ns, int64_t *values, int64_t cap);
 /* Sink.latency_stats() of the shared Sink, computed on the device (components/common.py:59-76 with
  * instrumentation/data.py:197-210): out = {count, avg, min, max, p50, p99} in seconds.  avg = sum(sorted latencies) / n with
  * the sum taken left to right in binary64 (what CPython's `sum` does before 3.12). */

@@ -609,8 +609,24 @@ def run_lb_case(spec):
         prov = PhiloxPoissonArrival(ConstantRateProfile(rate=rate[i]), Instant.Epoch, hs.Stream(seed, i, hs.STREAM_ARRIVAL))
         ep = PhiloxClientProvider(lb, spec["n_clients"], hs.Stream(seed, i, hs.STREAM_KEY), stop_instant)
         sources.append(Source(f"src{i}", ep, prov))
-    sim = Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=sources, entities=[lb, *servers, *sinks])
+    # probes on backend Servers / Sinks: [["server" | "sink", index, metric, interval], ...] in `probes=[...]` order
+    probes, probe_data = [], []
+    for who, idx, metric, interval in spec.get("probes") or []:
+        probe, data = Probe.on(servers[idx] if who == "server" else sinks[idx], PROBE_METRICS[metric][1], interval=interval)
+        data._ns = []
+
+        def add_stat(value, time, _orig=data.add_stat, _d=data):
+            _d._ns.append((time.nanoseconds, value))
+            _orig(value, time)
+
+        data.add_stat = add_stat
+        probes.append(probe)
+        probe_data.append(data)
+    sim = Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=sources, entities=[lb, *servers, *sinks],
+                     probes=probes)
     node_of = {id(lb): S}
+    for j, probe in enumerate(probes):
+        node_of[id(probe)] = S + 1 + B + len(sinks) + j
     for i, src in enumerate(sources):
         node_of[id(src)] = i
     for j, srv in enumerate(servers):
@@ -623,15 +639,29 @@ def run_lb_case(spec):
         heap = sim._event_heap
         orig_pop = heap.pop
 
+        cb_probe = {id(probe._event_provider.data_sink): S + 1 + B + len(sinks) + j for j, probe in enumerate(probes)}
+
         def pop():
             e = orig_pop()
             k, nd = classify(e, node_of)
+            if k == EV["probe"]:
+                fn = e.target._fn if hasattr(e.target, "_fn") else e.target.fn
+                cells = {id(cell.cell_contents) for cell in (fn.__closure__ or ())}
+                nd = next(c for key, c in cb_probe.items() if key in cells)
             trace.append((e.time.nanoseconds, k, nd, e._sort_index))
             return e
 
         heap.pop = pop
     summary = sim.run()
     out = {}
+    if probes:
+        pt, pv, poff = [], [], [0]
+        for d in probe_data:
+            pt.extend(t for t, _ in d._ns)
+            pv.extend(int(v) for _, v in d._ns)
+            poff.append(len(pt))
+        out["probe_t_ns"], out["probe_v"], out["probe_off"] = (np.asarray(pt, np.int64), np.asarray(pv, np.int64),
+                                                                np.asarray(poff, np.int64))
     meta = dict(spec=spec, total_events=[summary.total_events_processed], final_ns=[sim._current_time.nanoseconds],
                 duration_s=[summary.duration_s])
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
@@ -677,6 +707,15 @@ LB_CASES = [
          vnodes=150, n_clients=200, end_s=20.0, seed=42, trace=True),
     dict(name="lb_4src_8be", topology="lb", n_sources=4, n_backends=8, rate=[12.0, 9.0, 15.0, 6.0], mean=0.1,
          vnodes=150, n_clients=5000, end_s=20.0, seed=7, trace=True),
+    # probes on a load-balancer graph: backend Servers (every Server metric) and the shared Sink
+    dict(name="lb_probes", topology="lb", n_sources=3, n_backends=5, rate=[14.0, 10.0, 8.0], mean=0.12, concurrency=[1, 2, 1, 3, 1],
+         queue_cap=[None, None, 2, None, None], vnodes=40, n_clients=3000, end_s=12.0, seed=19,
+         probes=[["server", 0, "depth", 0.25], ["server", 1, "active_requests", 0.1], ["server", 2, "stats_dropped", 0.5],
+                 ["server", 2, "stats_accepted", 0.5], ["server", 3, "requests_completed", 0.3], ["sink", 0, "events_received", 0.2],
+                 ["server", 4, "depth", 0.7]], trace=True),
+    dict(name="lb_probes_per_backend_sinks", topology="lb", n_sources=2, n_backends=4, rate=[18.0, 9.0], mean=0.1,
+         concurrency=[1, 1, 2, 1], vnodes=30, n_clients=500, end_s=10.0, seed=23, shared_sink=False,
+         probes=[["sink", 2, "events_received", 0.25], ["server", 1, "depth", 0.3], ["sink", 0, "events_received", 1.0]], trace=True),
     dict(name="lb_cap2_overload", topology="lb", n_sources=3, n_backends=4, rate=20.0, mean=0.1, concurrency=1,
          queue_cap=2, vnodes=20, n_clients=1000, end_s=15.0, seed=11, trace=True),
     dict(name="lb_per_backend_sinks", topology="lb", n_sources=6, n_backends=16, rate=16.0, mean=0.1,

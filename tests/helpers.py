@@ -323,6 +323,12 @@ def oracle_lb_graph(spec):
     p = lb_params(spec)
     g = O.lb_topology(p["S"], p["B"], p["rate"], p["mean"], p["vnodes"], p["n_clients"], p["conc"], p["qcap"],
                       p["stop_ns"], p["shared_sink"])
+    # probes on backend Servers / Sinks: [["server" | "sink", index, metric, interval], ...]; nodes after the Sinks
+    g.lb_probe_nodes = []
+    S, B = p["S"], p["B"]
+    for who, idx, metric, interval in spec.get("probes") or []:
+        target = S + 1 + idx if who == "server" else S + 1 + B + idx
+        g.lb_probe_nodes.append(g.probe(target, PROBE_METRICS[metric][1], float(interval)))
     return g, p
 
 
@@ -544,6 +550,9 @@ def lb_engine_for_spec(spec, flags=0, tick_capacity=0):
                              seed=spec["seed"], tick_capacity=tick_capacity)
     if flags:
         eng.set_debug_flags(flags)
+    if spec.get("probes"):
+        eng.set_probes([0 if who == "server" else 1 for who, *_ in spec["probes"]], [i for _, i, *_ in spec["probes"]],
+                       [PROBE_METRICS[m][1] for _, _, m, _ in spec["probes"]], [float(iv) for *_, iv in spec["probes"]])
     return eng, p
 
 

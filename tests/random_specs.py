@@ -165,3 +165,19 @@ def multi_source_ring_spec(k):
     if rng.random() < 0.5:
         spec["sources_order"] = "extras_first"
     return spec
+
+
+def lb_probe_spec(k):
+    """A random load-balancer configuration (lb_spec) with probes on some backend Servers and on its Sink(s)."""
+    rng = np.random.default_rng(90_000 + k)
+    spec = lb_spec(700 + k)
+    spec["name"] = f"lb_probes_{k}"
+    B = spec["n_backends"]
+    metrics = ["depth", "active_requests", "stats_accepted", "stats_dropped", "requests_completed"]
+    pr = [["server", int(rng.integers(0, B)), str(rng.choice(metrics)), float(rng.choice([0.1, 0.25, 0.3, 0.5]))]
+          for _ in range(int(rng.integers(1, 6)))]
+    if rng.random() < 0.7:
+        pr.insert(int(rng.integers(0, len(pr) + 1)),
+                  ["sink", 0 if spec["shared_sink"] else int(rng.integers(0, B)), "events_received", float(rng.choice([0.2, 0.35]))])
+    spec["probes"] = pr
+    return spec

@@ -272,11 +272,17 @@ def test_load_balancer_topology_through_the_api_matches_reference_golden(name):
                               event_provider=hs.ClientKeyEventProvider(lb, n_clients=p["n_clients"],
                                                                        stop_after=spec.get("stop_after_s")))
             for i in range(S)]
+    probes = [hs.Probe.on(nodes[i] if who == "server" else sinks[i], metric, interval=iv)      # (lb_probes*.npz)
+              for who, i, metric, iv in spec.get("probes") or []]
     sim = hs.Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=srcs, entities=[lb, *nodes, *sinks],
-                        seed=spec["seed"])
+                        probes=[p for p, _ in probes], seed=spec["seed"])
     summary = sim.run()
     assert summary.total_events_processed == gold.meta["total_events"][0]
     assert summary.duration_s == gold.meta["duration_s"][0]
+    for j, (_, data) in enumerate(probes):       # what the reference's probes appended to their Data containers
+        a, b = gold.probe_off[j], gold.probe_off[j + 1]
+        assert data.times() == [x / 1_000_000_000 for x in gold.probe_t_ns[a:b].tolist()]
+        assert [int(v) for v in data.raw_values()] == gold.probe_v[a:b].tolist() and data.count() == b - a > 0
     assert [s.generated_count for s in srcs] == gold.generated.tolist()
     st = lb.stats
     assert [st.requests_received, st.requests_forwarded, st.requests_failed, st.no_backend_available] == gold.lb_stats[:4].tolist()

@@ -63,6 +63,11 @@ def test_lb_engine_matches_reference_golden(name):
             cr = np.concatenate([r[1] for r in recs])
         np.testing.assert_array_equal(t, gold.sink_t_ns)
         np.testing.assert_array_equal((t - cr).astype(np.float64) / 1e9, gold.sink_latency_s)   # components/common.py:39-40
+        for j in range(len(spec.get("probes") or [])):            # probes on backend Servers / Sinks: every sample
+            a, b = gold.probe_off[j], gold.probe_off[j + 1]
+            pt, pv = eng.read_probe(j)
+            np.testing.assert_array_equal(pt, gold.probe_t_ns[a:b], err_msg=f"probe {j} times")
+            np.testing.assert_array_equal(pv, gold.probe_v[a:b], err_msg=f"probe {j} values")
         # per-kind histogram: the golden's trace (where recorded), else the oracle's
         if "trace" in gold.arrays:
             hist = np.bincount(gold.trace[:, 1], minlength=len(s.events_by_kind))
@@ -95,6 +100,74 @@ def test_lb_engine_matches_oracle(spec, flags):
         # a second run on the same handle restarts from start_ns: identical result
         eng.run(p["end_ns"])
         H.compare_lb_engine_with_oracle(eng, p, r)
+
+
+def _with_probes(spec):
+    """Probes spread over the backends (every Server metric) and the Sink(s) of a sweep configuration."""
+    B = spec["n_backends"]
+    metrics = ["depth", "active_requests", "stats_accepted", "stats_dropped", "requests_completed"]
+    pr = [["server", (7 * k) % B, metrics[k % 5], [0.1, 0.25, 0.3, 0.5, 0.07][k % 5]] for k in range(min(2 * B, 40))]
+    pr += [["sink", 0, "events_received", 0.05]] + ([] if spec.get("shared_sink", True) else [["sink", B - 1, "events_received", 0.4]])
+    return dict(spec, probes=pr)
+
+
+@pytest.mark.parametrize("spec", SWEEP, ids=[s["name"] for s in SWEEP])
+@pytest.mark.parametrize("flags", [0, 1, 2, 4], ids=["request_order", "general_fifo", "event_order", "dense_layout"])
+def test_lb_probes_match_oracle(spec, flags):
+    """Probe.on(<backend Server> | <Sink>, metric, interval) on load-balancer graphs: every sample, the probes' two event kinds
+    and the election of the event beyond end_time (a pending probe tick takes part) against the oracle, on every backend code
+    path; the live-reference goldens lb_probes*.npz pin the same against the reference itself."""
+    spec = _with_probes(spec)
+    g, p = H.oracle_lb_graph(spec)
+    r = O.run(g, p["end_ns"], seed=spec["seed"])
+    eng, _ = H.lb_engine_for_spec(spec, flags=flags)
+    with eng:
+        for _ in range(2):                                   # (a second run restarts from start_ns: identical)
+            eng.run(p["end_ns"])
+            sinks = dict(r.sinks)
+            for j, nd in enumerate(g.lb_probe_nodes):
+                t, v = sinks.pop(nd)
+                pt, pv = eng.read_probe(j)
+                np.testing.assert_array_equal(pt, t, err_msg=f"probe {j} ({spec['probes'][j]}) times")
+                np.testing.assert_array_equal(pv, v, err_msg=f"probe {j} ({spec['probes'][j]}) values")
+                assert len(t) > 5
+        r.sinks = sinks
+        H.compare_lb_engine_with_oracle(eng, p, r)
+        assert r.events_by_kind[14] > 100 and r.events_by_kind[13] - r.events_by_kind[14] in (0, 1)   # (1: the event beyond end_time is a probe tick)
+
+
+@pytest.mark.parametrize("k", range(20))
+def test_lb_probes_on_random_configurations_match_oracle(k):
+    """random_specs.lb_probe_spec (the live reference agrees with the oracle on the same 20: test_oracle_live_reference.py)."""
+    import random_specs as RS
+
+    spec = RS.lb_probe_spec(k)
+    g, p = H.oracle_lb_graph(spec)
+    r = O.run(g, p["end_ns"], seed=spec["seed"])
+    eng, _ = H.lb_engine_for_spec(spec)
+    with eng:
+        eng.run(p["end_ns"])
+        sinks = dict(r.sinks)
+        for j, nd in enumerate(g.lb_probe_nodes):
+            t, v = sinks.pop(nd)
+            pt, pv = eng.read_probe(j)
+            np.testing.assert_array_equal(pt, t, err_msg=f"probe {j} ({spec['probes'][j]}) times")
+            np.testing.assert_array_equal(pv, v, err_msg=f"probe {j} ({spec['probes'][j]}) values")
+        r.sinks = sinks
+        H.compare_lb_engine_with_oracle(eng, p, r)
+
+
+def test_lb_probe_on_the_nanosecond_of_a_target_event_is_refused():
+    """Constant-rate Sources ticking every 0.1 s and a probe sampling their backend every 0.5 s: the sample falls on arrival
+    nanoseconds, whose order against the probe's chain is the reference's sort-index ledger -- refused, never guessed."""
+    from happy_simulator_amd import _native as N
+
+    spec = dict(n_sources=2, n_backends=1, rate=10.0, mean=0.03, vnodes=3, n_clients=10, end_s=3.0, seed=5, arr="constant",
+                svc="const", probes=[["server", 0, "stats_accepted", 0.5]])
+    eng, p = H.lb_engine_for_spec(spec)
+    with eng:
+        with pytest.raises(N.EngineError, match="nanosecond of an event of its target"):
+            eng.run(p["end_ns"])
 
 
 TIES = [

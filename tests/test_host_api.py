@@ -253,6 +253,24 @@ class TestLoadBalancerLowering:
         with pytest.raises(hs.UnsupportedTopology, match="only Server backends"):
             hs.Simulation(duration=1, sources=[s2], entities=[lb2]).lowered()
 
+    def test_probes_on_backend_servers_and_sinks_are_lowered(self):
+        """Probe.on(<backend Server> | <Sink>, ...) on a load-balancer graph -> hs_lb_set_probes arrays in `probes=[...]` order;
+        other targets are refused explicitly."""
+        srcs, lb, nodes, sinks = self._topology(shared=False, concurrency=2)
+        p1, _ = hs.Probe.on(nodes[2], "depth", interval=0.5)
+        p2, _ = hs.Probe.on(sinks[1], "events_received", interval=0.25)
+        p3, _ = hs.Probe.on(nodes[0], "utilization", interval=1.0)
+        g = hs.Simulation(duration=5.0, sources=srcs, entities=[lb, *nodes, *sinks], probes=[p1, p2, p3]).lowered()
+        kinds, idx, met, iv = g.probe_arrays()
+        assert kinds == [0, 1, 0] and idx == [2, 1, 0] and iv == [0.5, 0.25, 1.0]
+        assert met == [N.PROBE_METRICS["depth"], N.PROBE_METRICS["events_received"], N.PROBE_METRICS["active_requests"]]
+        for target, metric, msg in ((srcs[0], "generated_count", "backend Servers and the Sinks are sampled"),
+                                    (nodes[1], "events_received", "not an attribute of Server"),
+                                    (sinks[0], "depth", "not an attribute of Sink")):
+            pr, _ = hs.Probe.on(target, metric)
+            with pytest.raises(hs.UnsupportedTopology, match=msg):
+                hs.Simulation(duration=1, sources=srcs, entities=[lb, *nodes, *sinks], probes=[pr]).lowered()
+
     def test_product_md5_is_rfc1321(self):
         """The ring's hash function as libhs_hip.so computes it (host code of the library; no GPU involved)."""
         import hashlib

@@ -169,6 +169,11 @@ def check_oracle_against_lb_golden(gold):
     be = slice(S + 1, S + 1 + B)
     for k in ("accepted", "dropped", "completed", "rejected", "depth", "active", "total_service_s"):
         np.testing.assert_array_equal(getattr(r, k)[be], gold.arrays[k], err_msg=k)
+    for j, nd in enumerate(g.lb_probe_nodes):                # Probe samples (time ns, value), then the probe's "sink" goes
+        pt, pv = r.sinks.pop(nd)
+        a, b = gold.probe_off[j], gold.probe_off[j + 1]
+        np.testing.assert_array_equal(pt, gold.probe_t_ns[a:b])
+        np.testing.assert_array_equal(pv, gold.probe_v[a:b])
     sinks = sorted(r.sinks)
     np.testing.assert_array_equal([r.received[i] for i in sinks], gold.received)
     t = np.concatenate([r.sinks[i][0] for i in sinks])
