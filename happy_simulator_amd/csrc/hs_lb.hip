@@ -935,6 +935,7 @@ __global__ void hs_lb_probe_sample(LbProbes Q, LbBe PB, int B, int tb, const uin
             }
             int64_t started = done + PB.conc[b];
             started = accepted < started ? accepted : started;
+            if (PB.rejected[b] > 0) atomicOr(&tot->probe_tie, 2);     // (deliveries that found no free worker: not work-conserving)
             switch (m) {
                 case HS_PROBE_DEPTH: v = accepted - started; break;
                 case HS_PROBE_ACTIVE: v = started - done; break;
@@ -1126,6 +1127,7 @@ struct hs_lb {
     int64_t *n_merge = nullptr;                       // device: slots the Sink merge scans
     double *svdraw = nullptr;                         // [n_slots] service sample per Request slot (single-worker FIFO backends)
     bool any_simple = false;
+    bool any_no_sink = false;                          // some backend has no Sink behind it: no completion log (probes refused)
     int64_t *n_slots_dev = nullptr, *n_arr = nullptr, *n_done = nullptr, *n_tmp = nullptr;
     uint32_t *hist = nullptr, *row_total = nullptr, *digit_base = nullptr;
     int n_tiles = 0;
@@ -1324,8 +1326,10 @@ int check_flags(hs_lb *h) {
     if (t.qoverflow) return lfail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
     if (t.bad_client & 1) return lfail(h, HS_E_INVALID, "a client id fell outside the client table");
     if (t.bad_client & 2) return lfail(h, HS_E_OVERFLOW, "a source's tick log overflowed (capacity %lld ticks); raise tick_capacity", (long long)h->cap);
-    if (t.probe_tie) return lfail(h, HS_E_UNSUPPORTED, "a probe sample fell on the nanosecond of an event of its target: on load-balancer "
-                                  "graphs that order (the reference's sort indices) is not lowered");
+    if (t.probe_tie & 1) return lfail(h, HS_E_UNSUPPORTED, "a probe sample fell on the nanosecond of an event of its target: on load-balancer "
+                                      "graphs that order (the reference's sort indices) is not lowered");
+    if (t.probe_tie & 2) return lfail(h, HS_E_UNSUPPORTED, "a probed backend rejected deliveries (no free worker): its queue is not "
+                                      "work-conserving and the samples cannot be read off the logs");
     return HS_OK;
 }
 
@@ -1371,6 +1375,7 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     }
     if (kmax > (1ll << 26)) return lfail(nullptr, HS_E_UNSUPPORTED, "n_clients above 2^26 is not supported (client -> backend table)");
     int maxc = 1;
+    bool any_no_sink = false;
     for (int j = 0; j < B; ++j) {
         const int c = be->concurrency ? be->concurrency[j] : 1;
         if (c < 1) return lfail(nullptr, HS_E_INVALID, "backend %d: max_concurrent must be >= 1, got %d", j, c);
@@ -1383,6 +1388,7 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
             return lfail(nullptr, HS_E_INVALID, "backend %d: bad service mean %g", j, mean);
         const int eg = be->egress ? be->egress[j] : HS_EGRESS_SINK;
         if (eg != HS_EGRESS_NONE && eg != HS_EGRESS_SINK) return lfail(nullptr, HS_E_UNSUPPORTED, "backend %d: egress kind %d is not lowered", j, eg);
+        if (eg == HS_EGRESS_NONE) any_no_sink = true;
         if (be->name_off[j + 1] < be->name_off[j] || be->name_off[j + 1] - be->name_off[j] > 200)
             return lfail(nullptr, HS_E_INVALID, "backend %d: bad name", j);
     }
@@ -1501,6 +1507,7 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     if (cfg->shared_sink) { TRY(lalloc(h, &h->out_t, NS)); TRY(lalloc(h, &h->out_created, NS)); }
     for (int j = 0; j < B; ++j)
         if ((be->concurrency ? be->concurrency[j] : 1) == 1 && (be->queue_cap ? be->queue_cap[j] : -1) < 0) h->any_simple = true;
+    h->any_no_sink = any_no_sink;
     TRY(lalloc(h, &h->svdraw, (h->C == 1 && h->any_simple) ? NS : (size_t)1));
     TRY(lalloc(h, &h->n_slots_dev, 1)); TRY(lalloc(h, &h->n_arr, 1)); TRY(lalloc(h, &h->n_done, 1)); TRY(lalloc(h, &h->n_tmp, 1));
     TRY(lalloc(h, &h->hist, (size_t)kRadixBins * (size_t)h->n_tiles)); TRY(lalloc(h, &h->row_total, (size_t)kRadixBins));
@@ -1602,7 +1609,7 @@ int hs_lb_set_probes(hs_lb *h, int32_t n_probes, const int32_t *target_kind, con
                         m == HS_PROBE_COMPLETED))
             return lfail(h, HS_E_UNSUPPORTED, "probe %d: metric %d is not an attribute of a Server", j, m);
         if (k == 1 && m != HS_PROBE_RECEIVED) return lfail(h, HS_E_UNSUPPORTED, "probe %d: metric %d is not an attribute of a Sink", j, m);
-        if (!h->sink_t) return lfail(h, HS_E_UNSUPPORTED, "probes on a load-balancer graph need the backends' completion logs (a Sink downstream)");
+        if (h->any_no_sink) return lfail(h, HS_E_UNSUPPORTED, "probes on a load-balancer graph need the backends' completion logs (a Sink downstream)");
         const double iv = interval_s[j];
         if (!(iv > 0.0) || !std::isfinite(iv)) return lfail(h, HS_E_INVALID, "Probe interval must be positive.");   // probe.py:29-30
         rate[(size_t)j] = 1.0 / iv;

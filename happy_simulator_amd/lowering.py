@@ -545,6 +545,8 @@ def attach_lb_probes(g: LbGraph, probes: list) -> None:
     """Probe.on(<backend Server> | <Sink>, metric, interval) on a load-balancer graph (csrc/hs_lb.hip section 5)."""
     from .entities import Probe
 
+    if probes and not g.sinks:
+        raise UnsupportedTopology("probes on a load-balancer graph are read off the backends' completion logs: a Sink downstream is needed")
     for pr in probes or []:
         if not isinstance(pr, Probe):
             raise UnsupportedTopology(f"probe {type(pr).__name__} is not a lowered Probe")
