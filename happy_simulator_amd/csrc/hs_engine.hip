@@ -197,7 +197,7 @@ __device__ __forceinline__ void store_station(const Station<C, PF> &Sc, const St
 template <int C, bool PF>
 __device__ __forceinline__ Candidate make_candidate(const Station<C, PF> &S) {
     Candidate c;
-    c.lp = S.lp; c.rank = S.lp; c.valid = 0; c.t = kInfNs; c.t_created = 0;
+    c.lp = S.lp; c.rank = S.lp; c.valid = 0; c.t = kInfNs; c.t_created = 0; c.pad = 0;
     if (S.qn > 0) {   // a group already in progress keeps the floor
         c.t = S.grp_time; c.t_created = S.grp_time; c.valid = 1;
         return c;
@@ -214,6 +214,7 @@ __device__ __forceinline__ Candidate make_candidate(const Station<C, PF> &S) {
     else if (w >= kRootProbe) {
 #pragma unroll
         for (int j = 0; j < kMaxProbes; ++j) if (j == w - kRootProbe) c.t_created = S.crtP[j];
+        c.pad = 1;              // a Probe's tick: constructed after every Source (core/simulation.py:145-160) -- ranks behind them
     }
     else if (w == kRootSched) c.t_created = INT64_MIN;   // constructed before run()
     else {
@@ -572,7 +573,10 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
     if (live) {
         if (!frozen) {
             if (mode == HS_MODE_REPLICAS) overshoot_one<C, PF>(S);
-            else { mine = make_candidate<C, PF>(S); mine.rank = P.tie_rank != nullptr ? P.tie_rank[lp] : lp; }
+            else {
+                mine = make_candidate<C, PF>(S);
+                mine.rank = (P.tie_rank != nullptr ? P.tie_rank[lp] : lp) + (mine.pad ? n : 0);
+            }
         }
         store_station<C, PF>(S, X, lp, n);
     }
