@@ -834,7 +834,7 @@ __global__ void hs_lb_sink_finish(const uint64_t *__restrict__ mkey, const uint6
 // probe's chain and the Request's chain: such a run is refused (probe_tie), never guessed.
 // ---------------------------------------------------------------------------------------------
 struct LbProbes {
-    const int32_t *kind, *idx;    // [n] 0: backend Server idx;  1: Sink idx (shared Sink: 0; per-backend Sinks: backend)
+    const int32_t *kind, *idx;    // [n] 0: backend Server idx;  1: Sink idx (shared Sink: 0; per-backend Sinks: backend);  2: Source idx
     const uint8_t *metric;        // [n] hs_probe_metric
     const double *rate;           // [n] 1.0 / interval
     int64_t *tick;                // [n][pcap] tick times up to the first one beyond the horizon
@@ -896,7 +896,8 @@ __global__ void hs_lb_probe_cands(LbProbes Q, int S, int B, int64_t end_ns, LbTo
 __global__ void hs_lb_probe_sample(LbProbes Q, LbBe PB, int B, int tb, const uint64_t *__restrict__ skey,
                                    const int64_t *__restrict__ off, const int64_t *__restrict__ adm,
                                    const int64_t *__restrict__ sink_t, const int64_t *__restrict__ out_t,
-                                   const int64_t *n_done, int shared_sink, int phase, LbTotals *tot) {
+                                   const int64_t *n_done, int shared_sink, int phase, LbTotals *tot,
+                                   const uint64_t *__restrict__ keys0, const int64_t *__restrict__ src_count, int S) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int j = (int)(i / Q.pcap);
     const int64_t k = i - (int64_t)j * Q.pcap;
@@ -906,7 +907,17 @@ __global__ void hs_lb_probe_sample(LbProbes Q, LbBe PB, int B, int tb, const uin
     const uint32_t m = Q.metric[j];
     int64_t v = 0;
     bool tie = false;
-    if (Q.kind[j] == 1 && shared_sink) {                          // the shared Sink: the merged completion log
+    if (Q.kind[j] == 2) {                                         // Source.generated_count: its column of the [tick][source] log
+        const int sidx = Q.idx[j];                                // (every tick carries a Request: Sources with stop_after are refused)
+        const uint64_t tmask = tb >= 64 ? ~0ull : ((1ull << tb) - 1);
+        const int64_t n = src_count[sidx];
+        int64_t lo = 0, hi = n, lt = 0;
+        while (lo < hi) { const int64_t q = (lo + hi) >> 1; if ((int64_t)(keys0[(size_t)q * S + sidx] & tmask) <= T) lo = q + 1; else hi = q; }
+        hi = n;
+        while (lt < hi) { const int64_t q = (lt + hi) >> 1; if ((int64_t)(keys0[(size_t)q * S + sidx] & tmask) < T) lt = q + 1; else hi = q; }
+        v = lo;
+        tie = lo != lt;
+    } else if (Q.kind[j] == 1 && shared_sink) {                   // the shared Sink: the merged completion log
         const int64_t n = *n_done;
         v = count_le(out_t, n, 1, T);
         tie = v != count_lt(out_t, n, 1, T);
@@ -1132,7 +1143,7 @@ struct hs_lb {
     uint32_t *hist = nullptr, *row_total = nullptr, *digit_base = nullptr;
     int n_tiles = 0;
     LbProbes Q{};                                     // probes (hs_lb_set_probes); n == 0: none
-    std::vector<int32_t> probe_kind_h;
+    std::vector<int64_t> src_stop_h;                  // stop_after of every Source (host copy: probes on stopping Sources are refused)
     bool ran = false;
     int flags = 0;
     double last_run_ms = 0.0, last_sort_ms = 0.0;
@@ -1288,7 +1299,7 @@ int run_async(hs_lb *h, int64_t end_ns) {
         hipLaunchKernelGGL(hs_lb_probe_cands, dim3((h->Q.n + 63) / 64), dim3(64), 0, h->stream, h->Q, S, B, end_ns, h->tot);
         const int64_t lanes = (int64_t)h->Q.n * h->Q.pcap;
         hipLaunchKernelGGL(hs_lb_probe_sample, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, h->stream, h->Q, h->PB, B, h->tb,
-                           h->skey, h->off, h->adm, h->sink_t, h->out_t, h->n_done, h->cfg.shared_sink ? 1 : 0, 0, h->tot);
+                           h->skey, h->off, h->adm, h->sink_t, h->out_t, h->n_done, h->cfg.shared_sink ? 1 : 0, 0, h->tot, h->keys0, h->PS.count, S);
         h->launches += 2;
     }
     hipEventRecord(h->evs2, h->stream);
@@ -1310,7 +1321,7 @@ int run_async(hs_lb *h, int64_t end_ns) {
     if (h->Q.n > 0 && h->cfg.shared_sink) {   // probes on the shared Sink: its merged log exists now
         const int64_t lanes = (int64_t)h->Q.n * h->Q.pcap;
         hipLaunchKernelGGL(hs_lb_probe_sample, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, h->stream, h->Q, h->PB, B, h->tb,
-                           h->skey, h->off, h->adm, h->sink_t, h->out_t, h->n_done, 1, 1, h->tot);
+                           h->skey, h->off, h->adm, h->sink_t, h->out_t, h->n_done, 1, 1, h->tot, h->keys0, h->PS.count, S);
         h->launches += 1;
     }
     hipLaunchKernelGGL(hs_lb_finalize, dim3(1), dim3(kLbBlock), 0, h->stream, h->PS, h->PB, S, B, h->cfg.start_ns, h->tot, h->Q);
@@ -1476,6 +1487,8 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     TRY(lupload<uint8_t>(h, &h->PS.kind, src->src_kind, (size_t)S, (uint8_t)HS_SRC_POISSON));
     TRY(lupload<double>(h, &h->PS.rate, src->src_rate, (size_t)S, 1.0));
     TRY(lupload<int64_t>(h, &h->PS.stop, src->src_stop_after_ns, (size_t)S, (int64_t)-1));
+    h->src_stop_h.assign((size_t)S, (int64_t)-1);
+    if (src->src_stop_after_ns) h->src_stop_h.assign(src->src_stop_after_ns, src->src_stop_after_ns + S);
     TRY(lupload<int64_t>(h, &h->PS.n_clients, src->n_clients, (size_t)S, (int64_t)1));
     TRY(lupload<uint64_t>(h, &h->PS.base, src->stream_base ? src->stream_base : sbase.data(), (size_t)S, 0));
     TRY(lalloc(h, &h->PS.count, (size_t)S)); TRY(lalloc(h, &h->PS.generated, (size_t)S)); TRY(lalloc(h, &h->PS.cand, (size_t)S));
@@ -1602,7 +1615,13 @@ int hs_lb_set_probes(hs_lb *h, int32_t n_probes, const int32_t *target_kind, con
     double min_iv = 0.0;
     for (int j = 0; j < n_probes; ++j) {
         const int k = target_kind[j], i = target_index[j], m = metric[j];
-        if (k != 0 && k != 1) return lfail(h, HS_E_UNSUPPORTED, "probe %d: target kind %d (0 = backend Server, 1 = Sink)", j, k);
+        if (k < 0 || k > 2) return lfail(h, HS_E_UNSUPPORTED, "probe %d: target kind %d (0 = backend Server, 1 = Sink, 2 = Source)", j, k);
+        if (k == 2) {
+            if (i < 0 || i >= h->cfg.n_sources) return lfail(h, HS_E_INVALID, "probe %d: source %d out of range", j, i);
+            if (m != HS_PROBE_GENERATED) return lfail(h, HS_E_UNSUPPORTED, "probe %d: metric %d is not an attribute of a Source", j, m);
+            if (h->src_stop_h[(size_t)i] >= 0)
+                return lfail(h, HS_E_UNSUPPORTED, "probe %d: a Source with stop_after keeps ticking without Requests, which its log does not hold", j);
+        }
         if (k == 0 && (i < 0 || i >= B)) return lfail(h, HS_E_INVALID, "probe %d: backend %d out of range", j, i);
         if (k == 1 && (i < 0 || i >= (h->cfg.shared_sink ? 1 : B))) return lfail(h, HS_E_INVALID, "probe %d: sink %d out of range", j, i);
         if (k == 0 && !(m == HS_PROBE_DEPTH || m == HS_PROBE_ACTIVE || m == HS_PROBE_ACCEPTED || m == HS_PROBE_DROPPED ||

@@ -448,6 +448,10 @@ class LbGraph:
                 idx.append(next(j for j, b in enumerate(self.backends) if b is pr.target))
                 m = pr.metric
                 met.append(N.PROBE_METRICS["active_requests" if m == "utilization" else m])
+            elif isinstance(pr.target, Source):
+                kinds.append(2)
+                idx.append(next(j for j, x in enumerate(self.sources) if x is pr.target))
+                met.append(N.PROBE_METRICS["generated_count"])
             else:
                 kinds.append(1)
                 idx.append(next(j for j, k in enumerate(self.sinks) if k is pr.target))
@@ -556,9 +560,15 @@ def attach_lb_probes(g: LbGraph, probes: list) -> None:
         elif any(pr.target is k for k in g.sinks):
             if pr.metric != "events_received":
                 raise UnsupportedTopology(f"probe '{pr.name}': metric '{pr.metric}' is not an attribute of {type(pr.target).__name__}")
+        elif any(pr.target is x for x in g.sources):
+            if pr.metric not in ("generated_count", "_generated_count"):
+                raise UnsupportedTopology(f"probe '{pr.name}': metric '{pr.metric}' is not an attribute of Source")
+            if pr.target._event_provider._stop_after is not None:
+                raise UnsupportedTopology(f"probe '{pr.name}': a Source with stop_after keeps ticking without Requests, which the "
+                                          "engine's tick log does not hold (not sampled on load-balancer graphs)")
         else:
-            raise UnsupportedTopology(f"probe '{pr.name}': on a load-balancer graph the backend Servers and the Sinks are sampled "
-                                      f"(not {type(pr.target).__name__} '{getattr(pr.target, 'name', pr.target)}')")
+            raise UnsupportedTopology(f"probe '{pr.name}': on a load-balancer graph the Sources, the backend Servers and the Sinks are "
+                                      f"sampled (not {type(pr.target).__name__} '{getattr(pr.target, 'name', pr.target)}')")
         g.probes.append(pr)
 
 

@@ -417,7 +417,8 @@ int hs_lb_get_stats(hs_lb *h, const hs_lb_stats *out);
 int64_t hs_lb_read_sink(hs_lb *h, int32_t sink, int64_t *t_ns, int64_t *created_ns, int64_t cap);
 /* Probe.on(<backend Server> | <Sink>, metric, interval) on a load-balancer graph (instrumentation/probe.py:81-164), set once
  * after hs_lb_create and before the first run: target_kind 0 = backend Server `target_index` (depth, active_requests,
- * stats_accepted, stats_dropped, requests_completed), 1 = Sink `target_index` (events_received; the shared Sink is index 0).
+ * stats_accepted, stats_dropped, requests_completed), 1 = Sink `target_index` (events_received; the shared Sink is index 0),
+ * 2 = Source `target_index` (generated_count; not for a Source with stop_after).
  * Tick times follow the reference's ConstantArrivalTimeProvider over _ProbeProfile; each tick at or before end_ns is two
  * reference events (kinds 13, 14) and the pending tick takes part in the election of the one event beyond end_ns.  The samples
  * are read off the run's logs; a sample on the very nanosecond of an event of its target makes hs_lb_run fail with

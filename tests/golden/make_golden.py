@@ -612,7 +612,8 @@ def run_lb_case(spec):
     # probes on backend Servers / Sinks: [["server" | "sink", index, metric, interval], ...] in `probes=[...]` order
     probes, probe_data = [], []
     for who, idx, metric, interval in spec.get("probes") or []:
-        probe, data = Probe.on(servers[idx] if who == "server" else sinks[idx], PROBE_METRICS[metric][1], interval=interval)
+        probe, data = Probe.on({"server": servers, "sink": sinks, "source": sources}[who][idx], PROBE_METRICS[metric][1],
+                               interval=interval)
         data._ns = []
 
         def add_stat(value, time, _orig=data.add_stat, _d=data):
@@ -712,7 +713,7 @@ LB_CASES = [
          queue_cap=[None, None, 2, None, None], vnodes=40, n_clients=3000, end_s=12.0, seed=19,
          probes=[["server", 0, "depth", 0.25], ["server", 1, "active_requests", 0.1], ["server", 2, "stats_dropped", 0.5],
                  ["server", 2, "stats_accepted", 0.5], ["server", 3, "requests_completed", 0.3], ["sink", 0, "events_received", 0.2],
-                 ["server", 4, "depth", 0.7]], trace=True),
+                 ["server", 4, "depth", 0.7], ["source", 1, "generated_count", 0.4]], trace=True),
     dict(name="lb_probes_per_backend_sinks", topology="lb", n_sources=2, n_backends=4, rate=[18.0, 9.0], mean=0.1,
          concurrency=[1, 1, 2, 1], vnodes=30, n_clients=500, end_s=10.0, seed=23, shared_sink=False,
          probes=[["sink", 2, "events_received", 0.25], ["server", 1, "depth", 0.3], ["sink", 0, "events_received", 1.0]], trace=True),

@@ -327,7 +327,7 @@ def oracle_lb_graph(spec):
     g.lb_probe_nodes = []
     S, B = p["S"], p["B"]
     for who, idx, metric, interval in spec.get("probes") or []:
-        target = S + 1 + idx if who == "server" else S + 1 + B + idx
+        target = {"server": S + 1 + idx, "sink": S + 1 + B + idx, "source": idx}[who]
         g.lb_probe_nodes.append(g.probe(target, PROBE_METRICS[metric][1], float(interval)))
     return g, p
 
@@ -551,7 +551,7 @@ def lb_engine_for_spec(spec, flags=0, tick_capacity=0):
     if flags:
         eng.set_debug_flags(flags)
     if spec.get("probes"):
-        eng.set_probes([0 if who == "server" else 1 for who, *_ in spec["probes"]], [i for _, i, *_ in spec["probes"]],
+        eng.set_probes([{"server": 0, "sink": 1, "source": 2}[who] for who, *_ in spec["probes"]], [i for _, i, *_ in spec["probes"]],
                        [PROBE_METRICS[m][1] for _, _, m, _ in spec["probes"]], [float(iv) for *_, iv in spec["probes"]])
     return eng, p
 

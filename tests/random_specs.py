@@ -179,5 +179,7 @@ def lb_probe_spec(k):
     if rng.random() < 0.7:
         pr.insert(int(rng.integers(0, len(pr) + 1)),
                   ["sink", 0 if spec["shared_sink"] else int(rng.integers(0, B)), "events_received", float(rng.choice([0.2, 0.35]))])
+    if spec.get("stop_after_s") is None and rng.random() < 0.5:
+        pr.append(["source", int(rng.integers(0, spec["n_sources"])), "generated_count", float(rng.choice([0.15, 0.4]))])
     spec["probes"] = pr
     return spec

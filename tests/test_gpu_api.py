@@ -272,7 +272,7 @@ def test_load_balancer_topology_through_the_api_matches_reference_golden(name):
                               event_provider=hs.ClientKeyEventProvider(lb, n_clients=p["n_clients"],
                                                                        stop_after=spec.get("stop_after_s")))
             for i in range(S)]
-    probes = [hs.Probe.on(nodes[i] if who == "server" else sinks[i], metric, interval=iv)      # (lb_probes*.npz)
+    probes = [hs.Probe.on({"server": nodes, "sink": sinks, "source": srcs}[who][i], metric, interval=iv)      # (lb_probes*.npz)
               for who, i, metric, iv in spec.get("probes") or []]
     sim = hs.Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=srcs, entities=[lb, *nodes, *sinks],
                         probes=[p for p, _ in probes], seed=spec["seed"])

@@ -108,6 +108,8 @@ def _with_probes(spec):
     metrics = ["depth", "active_requests", "stats_accepted", "stats_dropped", "requests_completed"]
     pr = [["server", (7 * k) % B, metrics[k % 5], [0.1, 0.25, 0.3, 0.5, 0.07][k % 5]] for k in range(min(2 * B, 40))]
     pr += [["sink", 0, "events_received", 0.05]] + ([] if spec.get("shared_sink", True) else [["sink", B - 1, "events_received", 0.4]])
+    if spec.get("stop_after_s") is None:
+        pr += [["source", spec["n_sources"] - 1, "generated_count", 0.2], ["source", 0, "generated_count", 0.35]]
     return dict(spec, probes=pr)
 
 

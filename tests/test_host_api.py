@@ -264,7 +264,8 @@ class TestLoadBalancerLowering:
         kinds, idx, met, iv = g.probe_arrays()
         assert kinds == [0, 1, 0] and idx == [2, 1, 0] and iv == [0.5, 0.25, 1.0]
         assert met == [N.PROBE_METRICS["depth"], N.PROBE_METRICS["events_received"], N.PROBE_METRICS["active_requests"]]
-        for target, metric, msg in ((srcs[0], "generated_count", "backend Servers and the Sinks are sampled"),
+        for target, metric, msg in ((srcs[0], "generated_count", "a Source with stop_after keeps ticking"),
+                                    (lb, "depth", "the Sources, the backend Servers and the Sinks are sampled"),
                                     (nodes[1], "events_received", "not an attribute of Server"),
                                     (sinks[0], "depth", "not an attribute of Sink")):
             pr, _ = hs.Probe.on(target, metric)
