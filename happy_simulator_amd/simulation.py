@@ -15,7 +15,7 @@ from .engine import StationEngine
 from .entities import Entity, Server
 from .lowering import (LbGraph, LoweredGraph, UnsupportedTopology, attach_lb_probes, attach_probes, find_load_balancer, lower, lower_lb,
                        write_back, write_back_lb, write_back_probes)
-from .summary import EntitySummary, QueueStats, SimulationSummary
+from .summary import EntitySummary, LazyEntities, QueueStats, SimulationSummary
 
 _DEFAULT_SEED = 42
 
@@ -248,7 +248,11 @@ class Simulation:
         eps = self._events_processed / duration_s if duration_s > 0 else 0.0
         return SimulationSummary(duration_s=duration_s, total_events_processed=self._events_processed,
                                  events_cancelled=self._events_cancelled, events_per_second=eps,
-                                 wall_clock_seconds=wall_elapsed, entities=entity_summaries(self._entities))
+                                 wall_clock_seconds=wall_elapsed,
+                                 # (eager like the reference for ordinary sizes; beyond 4 096 entities the loop is deferred until
+                                 #  somebody reads the dict -- it would cost more than the device run)
+                                 entities=(entity_summaries(self._entities) if len(self._entities) <= 4096 else
+                                           LazyEntities(lambda ents=self._entities: entity_summaries(ents))))
 
 
 def entity_summaries(entities) -> dict[str, EntitySummary]:

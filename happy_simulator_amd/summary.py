@@ -54,6 +54,42 @@ _SCALARS: tuple[tuple[str, str, Callable[[Any], str]], ...] = (
 )
 
 
+class LazyEntities(dict):
+    """`SimulationSummary.entities`, built on first use.  The reference builds the per-entity summaries inside `run()`
+    (core/simulation.py:560-591); for 131 072 entities that loop costs more than the whole device run, so the dict is filled
+    when somebody looks at it -- same keys, same values, same order."""
+
+    def __init__(self, build):
+        super().__init__()
+        self._build = build
+
+    def _fill(self):
+        b, self._build = self._build, None
+        if b is not None:
+            super().update(b())
+
+    def __getitem__(self, k): self._fill(); return super().__getitem__(k)
+    def __iter__(self): self._fill(); return super().__iter__()
+    def __len__(self): self._fill(); return super().__len__()
+    def __contains__(self, k): self._fill(); return super().__contains__(k)
+    def __eq__(self, o): self._fill(); return super().__eq__(o)
+    def __ne__(self, o): self._fill(); return super().__ne__(o)
+    def __repr__(self): self._fill(); return super().__repr__()
+    def __bool__(self): self._fill(); return super().__len__() > 0
+    def keys(self): self._fill(); return super().keys()
+    def values(self): self._fill(); return super().values()
+    def items(self): self._fill(); return super().items()
+    def get(self, k, d=None): self._fill(); return super().get(k, d)
+    def copy(self): self._fill(); return dict(self)
+    def update(self, *a, **kw): self._fill(); return super().update(*a, **kw)
+    def setdefault(self, k, d=None): self._fill(); return super().setdefault(k, d)
+    def pop(self, *a): self._fill(); return super().pop(*a)
+    def __setitem__(self, k, v): self._fill(); return super().__setitem__(k, v)
+    def __delitem__(self, k): self._fill(); return super().__delitem__(k)
+    def __reduce__(self): self._fill(); return (dict, (dict(self),))
+    __hash__ = None
+
+
 @dataclass
 class SimulationSummary:
     duration_s: float

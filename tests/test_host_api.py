@@ -357,7 +357,7 @@ def test_several_sources_of_one_server_are_lowered_onto_its_station():
     d = hs.Source.poisson(rate=3, target=other, name="d")
     sim = hs.Simulation(duration=5, sources=[b, d, a, c], entities=[srv, sink, other, other.downstream])
     g = sim.lowered()
-    assert g.stations[0].source is b and g.stations[0].more_sources == [a, c] and g.stations[1].more_sources == []
+    assert g.stations[0].source is b and list(g.stations[0].more_sources) == [a, c] and not g.stations[1].more_sources
     arr = g.arrays()
     assert arr.src_kind.tolist() == [N.SRC_CONSTANT, N.SRC_POISSON] and arr.src_rate.tolist() == [4.0, 3.0]
     assert arr.src_more_kind[:, 0].tolist() == [N.SRC_POISSON, N.SRC_POISSON, N.SRC_NONE]
