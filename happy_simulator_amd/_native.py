@@ -36,7 +36,7 @@ EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuat
 PROBE_METRICS = {"depth": 0, "active_requests": 1, "stats_accepted": 2, "stats_dropped": 3, "requests_completed": 4,
                  "_requests_completed": 4, "events_received": 5, "generated_count": 6}
 PROBE_NONE = 255
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class EngineUnavailable(RuntimeError):
@@ -122,7 +122,8 @@ class LbConfig(C.Structure):
 
 
 class LbSources(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("src_kind", "src_rate", "src_stop_after_ns", "n_clients", "stream_base")]
+    _fields_ = [(n, C.c_void_p) for n in ("src_kind", "src_rate", "src_stop_after_ns", "n_clients", "stream_base",
+                                          "src_profile_kind", "src_profile_params")]
 
 
 class LbBackends(C.Structure):

@@ -78,6 +78,8 @@ struct LbCand { long long t, t_created; int idx, valid; double svc_s; };
 
 struct LbSrc {                    // [S] each
     const uint8_t *kind; const double *rate; const int64_t *stop; const int64_t *n_clients; const uint64_t *base;
+    const uint8_t *prof_kind;     // time-varying rate (Source.with_profile): 0 constant, 1 linear ramp, 2 spike; null = none anywhere
+    const double *prof_p;         // [4][S]
     int64_t *count;               // Requests emitted (ticks with a payload at t <= end)
     int64_t *generated;           // Source._generated_count
     LbCand *cand;                 // the pending SourceEvent beyond end
@@ -132,6 +134,9 @@ __device__ __forceinline__ void block_min_cand(LbCand c, LbCand *wc, LbCand *out
 // 1. Sources.  Source.handle_event (load/source.py:142-180) with a client-id request factory
 //    (examples/visual/chash_example.py:69-88) and ConsistentHash.select as a table lookup.
 // ---------------------------------------------------------------------------------------------
+// PF: some Source has a time-varying profile -- its next arrival is the reference's numerical inversion (hs_profile.hpp), a
+// separate instantiation so that the common one carries no scratch frame.
+template <bool PF>
 __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint64_t seed, int64_t start_ns, int64_t end_ns,
                                                           const int32_t *__restrict__ client_be, int64_t n_table,
                                                           uint64_t *__restrict__ keys, uint64_t *__restrict__ vals,
@@ -152,6 +157,13 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
         const uint64_t sa = stream_id(P.base[s], kStreamArrival), sk = stream_id(P.base[s], kStreamKey);
         const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
         const double inc_const = __ddiv_rn(1.0, rate);       // constant source: target area 1.0 (providers/constant_arrival.py:23)
+        Profile pf;
+        pf.kind = kProfConstant; pf.p0 = pf.p1 = pf.p2 = pf.p3 = 0.0; pf.owner = s;
+        if constexpr (PF) {
+            pf.kind = P.prof_kind[s];
+            pf.p0 = P.prof_p[s]; pf.p1 = P.prof_p[(size_t)S + s]; pf.p2 = P.prof_p[(size_t)2 * S + s]; pf.p3 = P.prof_p[(size_t)3 * S + s];
+        }
+        const bool timevarying = PF && pf.kind != kProfConstant;     // inc[] then holds the target AREA (E or 1.0), not E / rate
         // Tick d happens at A_d = from_seconds(to_seconds(A_{d-1}) + E_d / rate)  (load/arrival_time_provider.py:72-82;
         // A_{-1} = start: Source.start at Simulation.__init__, load/source.py:120-140) and, while the provider still
         // returns Requests, draws client id number d.  Both streams are therefore indexed by the tick number: the
@@ -171,9 +183,10 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
                 const uint64_t blk = (d0 + j) >> 1;
                 if (kind == HS_SRC_POISSON) {
                     const U4 o = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)sa, (uint32_t)(sa >> 32), k0, k1);
-                    inc[j] = __ddiv_rn(exp1_from_uniform(res53(o.x, o.y)), rate);
-                    inc[j + 1] = __ddiv_rn(exp1_from_uniform(res53(o.z, o.w)), rate);
-                } else { inc[j] = inc_const; inc[j + 1] = inc_const; }
+                    const double e0 = exp1_from_uniform(res53(o.x, o.y)), e1 = exp1_from_uniform(res53(o.z, o.w));
+                    inc[j] = timevarying ? e0 : __ddiv_rn(e0, rate);
+                    inc[j + 1] = timevarying ? e1 : __ddiv_rn(e1, rate);
+                } else { inc[j] = timevarying ? 1.0 : inc_const; inc[j + 1] = inc[j]; }
                 const U4 q = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)sk, (uint32_t)(sk >> 32), k0, k1);
                 const int64_t c0 = __double2ll_rz(__dmul_rn(res53(q.x, q.y), nclients));
                 const int64_t c1 = __double2ll_rz(__dmul_rn(res53(q.z, q.w), nclients));
@@ -185,7 +198,12 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
             for (int j = 0; j < kChunk; ++j) {
                 if (done) continue;
                 const uint64_t d = d0 + j;
-                const int64_t a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc[j]));
+                int64_t a2;
+                if constexpr (PF) {
+                    a2 = timevarying ? prof_next_arrival(pf, arr_time, inc[j])      // load/arrival_time_provider.py:84-144
+                                     : ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc[j]));
+                    if (a2 == kInfNs) { done = true; dead = true; continue; }        // the rate is zero from here on: the Source ends
+                } else a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc[j]));
                 arr_time = a2;
                 if (d > 0) {
                     if (a2 == t_prev) ++depth;                            // next tick on the same nanosecond: a descendant
@@ -1138,6 +1156,7 @@ struct hs_lb {
     int64_t *n_merge = nullptr;                       // device: slots the Sink merge scans
     double *svdraw = nullptr;                         // [n_slots] service sample per Request slot (single-worker FIFO backends)
     bool any_simple = false;
+    bool any_src_profile = false;                      // some Source has a time-varying profile (hs_lbk_sources<true>)
     bool any_no_sink = false;                          // some backend has no Sink behind it: no completion log (probes refused)
     int64_t *n_slots_dev = nullptr, *n_arr = nullptr, *n_done = nullptr, *n_tmp = nullptr;
     uint32_t *hist = nullptr, *row_total = nullptr, *digit_base = nullptr;
@@ -1263,8 +1282,12 @@ int run_async(hs_lb *h, int64_t end_ns) {
     const int S = h->cfg.n_sources, B = h->cfg.n_backends;
     h->launches = 0;
     hipLaunchKernelGGL(hs_lb_clear, dim3(1), dim3(1), 0, h->stream, h->tot);
-    hipLaunchKernelGGL(hs_lbk_sources, dim3((S + kLbBlock - 1) / kLbBlock), dim3(kLbBlock), 0, h->stream, h->PS, S, h->cfg.seed,
-                       h->cfg.start_ns, end_ns, h->client_be, h->n_table, h->keys0, h->vals0, h->cap, h->tb, h->tot);
+    if (h->any_src_profile)
+        hipLaunchKernelGGL(hs_lbk_sources<true>, dim3((S + kLbBlock - 1) / kLbBlock), dim3(kLbBlock), 0, h->stream, h->PS, S, h->cfg.seed,
+                           h->cfg.start_ns, end_ns, h->client_be, h->n_table, h->keys0, h->vals0, h->cap, h->tb, h->tot);
+    else
+        hipLaunchKernelGGL(hs_lbk_sources<false>, dim3((S + kLbBlock - 1) / kLbBlock), dim3(kLbBlock), 0, h->stream, h->PS, S, h->cfg.seed,
+                           h->cfg.start_ns, end_ns, h->client_be, h->n_table, h->keys0, h->vals0, h->cap, h->tb, h->tot);
     hipLaunchKernelGGL(hs_lb_rows, dim3(1), dim3(1), 0, h->stream, h->tot, S, h->n_slots_dev);
     hipEventRecord(h->evs0, h->stream);
     radix_sort_async(h, h->keys0, h->vals0, h->n_slots_dev, h->n_arr, h->tb + h->bb,
@@ -1490,6 +1513,26 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     h->src_stop_h.assign((size_t)S, (int64_t)-1);
     if (src->src_stop_after_ns) h->src_stop_h.assign(src->src_stop_after_ns, src->src_stop_after_ns + S);
     TRY(lupload<int64_t>(h, &h->PS.n_clients, src->n_clients, (size_t)S, (int64_t)1));
+    {   // time-varying profiles (load/profile.py:52-113): src_rate of such a Source is its PEAK rate (it sizes the tick log)
+        std::vector<uint8_t> pk((size_t)S, (uint8_t)0);
+        std::vector<double> pp((size_t)S * 4, 0.0);
+        for (int i = 0; i < S && src->src_profile_kind; ++i) {
+            const int k = src->src_profile_kind[i];
+            if (k == 0) continue;
+            if (k != 1 && k != 2) { rc = lfail(nullptr, HS_E_UNSUPPORTED, "source %d: profile kind %d is not lowered", i, k); hs_lb_destroy(h); return rc; }
+            if (!src->src_profile_params) { rc = lfail(nullptr, HS_E_INVALID, "src_profile_params is required with src_profile_kind"); hs_lb_destroy(h); return rc; }
+            const double *q = src->src_profile_params + 4 * (size_t)i;
+            for (int j = 0; j < 4; ++j) {
+                if (!std::isfinite(q[j]) || q[j] < 0.0) { rc = lfail(nullptr, HS_E_INVALID, "source %d: bad profile parameter %g", i, q[j]); hs_lb_destroy(h); return rc; }
+                pp[(size_t)j * S + i] = q[j];
+            }
+            if (k == 1 && !(q[0] > 0.0)) { rc = lfail(nullptr, HS_E_INVALID, "source %d: LinearRampProfile needs duration_s > 0", i); hs_lb_destroy(h); return rc; }
+            pk[(size_t)i] = (uint8_t)k;
+            h->any_src_profile = true;
+        }
+        TRY(lupload<uint8_t>(h, &h->PS.prof_kind, pk.data(), (size_t)S, (uint8_t)0));
+        TRY(lupload<double>(h, &h->PS.prof_p, pp.data(), (size_t)S * 4, 0.0));
+    }
     TRY(lupload<uint64_t>(h, &h->PS.base, src->stream_base ? src->stream_base : sbase.data(), (size_t)S, 0));
     TRY(lalloc(h, &h->PS.count, (size_t)S)); TRY(lalloc(h, &h->PS.generated, (size_t)S)); TRY(lalloc(h, &h->PS.cand, (size_t)S));
     TRY(lupload<int32_t>(h, &h->PB.conc, be->concurrency, (size_t)B, 1));

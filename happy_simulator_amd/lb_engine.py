@@ -25,6 +25,8 @@ class LbSourceArrays:
     src_kind: np.ndarray | None = None
     src_stop_after_ns: np.ndarray | None = None
     stream_base: np.ndarray | None = None
+    src_profile_kind: np.ndarray | None = None      # N.PROF_*; None = constant rates (src_rate = the peak rate of a profile)
+    src_profile_params: np.ndarray | None = None    # [n, 4]
 
 
 @dataclass
@@ -71,7 +73,13 @@ class LoadBalancerEngine:
 
         src = N.LbSources()
         fill(src, sources, self.S, (("src_kind", np.uint8), ("src_rate", np.float64), ("src_stop_after_ns", np.int64),
-                                   ("n_clients", np.int64), ("stream_base", np.uint64)))
+                                   ("n_clients", np.int64), ("stream_base", np.uint64), ("src_profile_kind", np.uint8)))
+        if sources.src_profile_kind is not None:
+            pp = np.ascontiguousarray(sources.src_profile_params, np.float64)
+            if pp.shape != (self.S, 4):
+                raise ValueError(f"src_profile_params must have shape ({self.S}, 4)")
+            keep.append(pp)
+            src.src_profile_params = pp.ctypes.data
         be = N.LbBackends()
         fill(be, backends, self.B, (("concurrency", np.int32), ("svc_kind", np.uint8), ("svc_mean_s", np.float64),
                                     ("queue_cap", np.int64), ("egress", np.uint8), ("stream_base", np.uint64)))

@@ -474,6 +474,19 @@ class LbGraph:
                                for s in self.sources], np.uint8),
             src_stop_after_ns=np.array([-1 if s._event_provider._stop_after is None
                                         else s._event_provider._stop_after.nanoseconds for s in self.sources], np.int64))
+        for i, s in enumerate(self.sources):           # Source.with_profile in front of the LoadBalancer (src_rate = the peak)
+            pr = s._time_provider.profile
+            if isinstance(pr, ConstantRateProfile):
+                continue
+            if src.src_profile_kind is None:
+                src.src_profile_kind = np.zeros(S, np.uint8)
+                src.src_profile_params = np.zeros((S, 4), np.float64)
+            if isinstance(pr, LinearRampProfile):
+                src.src_profile_kind[i] = N.PROF_LINEAR_RAMP
+                src.src_profile_params[i, :3] = (pr.duration_s, pr.start_rate, pr.end_rate)
+            else:
+                src.src_profile_kind[i] = N.PROF_SPIKE
+                src.src_profile_params[i] = (pr.baseline_rate, pr.spike_rate, pr.warmup_s, pr.spike_duration_s)
         caps = [b._policy.capacity for b in self.backends]
         be = LbBackendArrays(
             n=B, names=[b.name for b in self.backends],

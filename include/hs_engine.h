@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HS_ABI_VERSION 7
+#define HS_ABI_VERSION 8
 
 typedef enum hs_status {
     HS_OK = 0,
@@ -377,6 +377,10 @@ typedef struct hs_lb_sources {     /* [n_sources] each; NULL = documented defaul
     const int64_t *src_stop_after_ns;  /* < 0 = never; the provider returns no Request when time > stop_after */
     const int64_t *n_clients;          /* client ids are drawn uniformly from [0, n_clients); required, >= 1 */
     const uint64_t *stream_base;       /* NULL = i */
+    /* Source.with_profile(LinearRampProfile | SpikeProfile) in front of the LoadBalancer: as hs_stations.src_profile_kind /
+     * src_profile_params (src_rate = the PEAK rate: it sizes the tick log).  NULL = constant rates. */
+    const uint8_t *src_profile_kind;   /* hs_profile_kind */
+    const double *src_profile_params;  /* [n_sources][4] */
 } hs_lb_sources;
 
 typedef struct hs_lb_backends {    /* [n_backends] each */

@@ -605,8 +605,13 @@ def run_lb_case(spec):
     stop = spec.get("stop_after_s")
     stop_instant = None if stop is None else Instant.from_seconds(stop)
     sources = []
+    profiles = spec.get("profile") or [None] * S              # per source: None | ["ramp", d, s, e] | ["spike", b, s, w, d]
     for i in range(S):
-        prov = PhiloxPoissonArrival(ConstantRateProfile(rate=rate[i]), Instant.Epoch, hs.Stream(seed, i, hs.STREAM_ARRIVAL))
+        pr = profiles[i]
+        profile = (ConstantRateProfile(rate=rate[i]) if pr is None else
+                   LinearRampProfile(duration_s=pr[1], start_rate=pr[2], end_rate=pr[3]) if pr[0] == "ramp" else
+                   SpikeProfile(baseline_rate=pr[1], spike_rate=pr[2], warmup_s=pr[3], spike_duration_s=pr[4]))
+        prov = PhiloxPoissonArrival(profile, Instant.Epoch, hs.Stream(seed, i, hs.STREAM_ARRIVAL))
         ep = PhiloxClientProvider(lb, spec["n_clients"], hs.Stream(seed, i, hs.STREAM_KEY), stop_instant)
         sources.append(Source(f"src{i}", ep, prov))
     # probes on backend Servers / Sinks: [["server" | "sink", index, metric, interval], ...] in `probes=[...]` order
@@ -717,6 +722,11 @@ LB_CASES = [
     dict(name="lb_probes_per_backend_sinks", topology="lb", n_sources=2, n_backends=4, rate=[18.0, 9.0], mean=0.1,
          concurrency=[1, 1, 2, 1], vnodes=30, n_clients=500, end_s=10.0, seed=23, shared_sink=False,
          probes=[["sink", 2, "events_received", 0.25], ["server", 1, "depth", 0.3], ["sink", 0, "events_received", 1.0]], trace=True),
+    # Source.with_profile in front of the LoadBalancer: a ramp, a spike and a constant source; a probe on the ramp's Source
+    dict(name="lb_profiles", topology="lb", n_sources=3, n_backends=6, rate=[16.0, 30.0, 9.0], mean=0.1, concurrency=[1, 2, 1, 1, 3, 1],
+         vnodes=60, n_clients=2000, end_s=10.0, seed=29,
+         profile=[["ramp", 6.0, 4.0, 16.0], ["spike", 5.0, 30.0, 3.0, 1.5], None],
+         probes=[["source", 0, "generated_count", 0.5], ["server", 4, "depth", 0.25]], trace=True),
     dict(name="lb_cap2_overload", topology="lb", n_sources=3, n_backends=4, rate=20.0, mean=0.1, concurrency=1,
          queue_cap=2, vnodes=20, n_clients=1000, end_s=15.0, seed=11, trace=True),
     dict(name="lb_per_backend_sinks", topology="lb", n_sources=6, n_backends=16, rate=16.0, mean=0.1,

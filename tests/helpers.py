@@ -323,6 +323,10 @@ def oracle_lb_graph(spec):
     p = lb_params(spec)
     g = O.lb_topology(p["S"], p["B"], p["rate"], p["mean"], p["vnodes"], p["n_clients"], p["conc"], p["qcap"],
                       p["stop_ns"], p["shared_sink"])
+    for i, pr in enumerate(spec.get("profile") or []):    # Source.with_profile in front of the LoadBalancer
+        if pr is not None:
+            g.prof_kind[i] = O.PROF_LINEAR_RAMP if pr[0] == "ramp" else O.PROF_SPIKE
+            g.prof_p[i] = tuple(float(x) for x in pr[1:]) + (0.0,) * (5 - len(pr))
     # probes on backend Servers / Sinks: [["server" | "sink", index, metric, interval], ...]; nodes after the Sinks
     g.lb_probe_nodes = []
     S, B = p["S"], p["B"]
@@ -540,6 +544,14 @@ def lb_engine_for_spec(spec, flags=0, tick_capacity=0):
         n=S, src_rate=np.array(p["rate"], np.float64), n_clients=np.full(S, p["n_clients"], np.int64),
         src_kind=np.array([N.SRC_POISSON if k == "poisson" else N.SRC_CONSTANT for k in per_chain(kinds, S)], np.uint8),
         src_stop_after_ns=np.full(S, p["stop_ns"], np.int64))
+    if spec.get("profile"):
+        src.src_profile_kind = np.zeros(S, np.uint8)
+        src.src_profile_params = np.zeros((S, 4), np.float64)
+        for i, pr in enumerate(spec["profile"]):
+            if pr is not None:
+                src.src_profile_kind[i] = N.PROF_LINEAR_RAMP if pr[0] == "ramp" else N.PROF_SPIKE
+                src.src_profile_params[i, :len(pr) - 1] = pr[1:]
+                src.src_rate[i] = max(pr[2], pr[3]) if pr[0] == "ramp" else max(pr[1], pr[2])     # peak: sizes the tick log
     svc = spec.get("svc", "exp")
     be = LbBackendArrays(
         n=B, names=[f"srv{j}" for j in range(B)], concurrency=np.array(p["conc"], np.int32),

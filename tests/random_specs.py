@@ -183,3 +183,19 @@ def lb_probe_spec(k):
         pr.append(["source", int(rng.integers(0, spec["n_sources"])), "generated_count", float(rng.choice([0.15, 0.4]))])
     spec["probes"] = pr
     return spec
+
+
+def lb_profile_spec(k):
+    """A random load-balancer configuration whose Sources follow ramps / spikes (Source.with_profile), some with probes."""
+    rng = np.random.default_rng(95_000 + k)
+    spec = lb_probe_spec(300 + k) if k % 2 else lb_spec(900 + k)
+    spec["name"] = f"lb_profiles_{k}"
+    spec["stop_after_s"] = None
+    if spec.get("probes"):
+        spec["probes"] = [pr for pr in spec["probes"]]
+    S = spec["n_sources"]
+    prof = [None if rng.random() < 0.35 else profile(rng) for _ in range(S)]
+    if not any(prof):
+        prof[0] = profile(rng)
+    spec["profile"] = prof
+    return spec

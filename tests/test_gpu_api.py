@@ -268,10 +268,15 @@ def test_load_balancer_topology_through_the_api_matches_reference_golden(name):
                        queue_capacity=None if p["qcap"][j] < 0 else p["qcap"][j],
                        downstream=sinks[0] if p["shared_sink"] else sinks[j]) for j in range(B)]
     lb = hs.LoadBalancer("lb", backends=nodes, strategy=hs.ConsistentHash(virtual_nodes=p["vnodes"]))
-    srcs = [hs.Source.poisson(rate=p["rate"][i], name=f"src{i}",
-                              event_provider=hs.ClientKeyEventProvider(lb, n_clients=p["n_clients"],
-                                                                       stop_after=spec.get("stop_after_s")))
-            for i in range(S)]
+    def profile_of(pr):
+        return (hs.LinearRampProfile(duration_s=pr[1], start_rate=pr[2], end_rate=pr[3]) if pr[0] == "ramp" else
+                hs.SpikeProfile(baseline_rate=pr[1], spike_rate=pr[2], warmup_s=pr[3], spike_duration_s=pr[4]))
+
+    profs = spec.get("profile") or [None] * S
+    srcs = [(hs.Source.poisson(rate=p["rate"][i], name=f"src{i}", event_provider=ep) if profs[i] is None else
+             hs.Source.with_profile(profile_of(profs[i]), poisson=True, name=f"src{i}", event_provider=ep))
+            for i in range(S)
+            for ep in [hs.ClientKeyEventProvider(lb, n_clients=p["n_clients"], stop_after=spec.get("stop_after_s"))]]
     probes = [hs.Probe.on({"server": nodes, "sink": sinks, "source": srcs}[who][i], metric, interval=iv)      # (lb_probes*.npz)
               for who, i, metric, iv in spec.get("probes") or []]
     sim = hs.Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=srcs, entities=[lb, *nodes, *sinks],

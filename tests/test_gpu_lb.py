@@ -159,6 +159,28 @@ def test_lb_probes_on_random_configurations_match_oracle(k):
         H.compare_lb_engine_with_oracle(eng, p, r)
 
 
+@pytest.mark.parametrize("k", range(12))
+def test_lb_source_profiles_on_random_configurations_match_oracle(k):
+    """Source.with_profile (ramps, spikes) in front of the LoadBalancer: random_specs.lb_profile_spec, everything against the
+    oracle (the live reference agrees with it on the same 12 and on the golden lb_profiles)."""
+    import random_specs as RS
+
+    spec = RS.lb_profile_spec(k)
+    g, p = H.oracle_lb_graph(spec)
+    r = O.run(g, p["end_ns"], seed=spec["seed"])
+    eng, _ = H.lb_engine_for_spec(spec)
+    with eng:
+        eng.run(p["end_ns"])
+        sinks = dict(r.sinks)
+        for j, nd in enumerate(g.lb_probe_nodes):
+            t, v = sinks.pop(nd)
+            pt, pv = eng.read_probe(j)
+            np.testing.assert_array_equal(pt, t, err_msg=f"probe {j} times")
+            np.testing.assert_array_equal(pv, v, err_msg=f"probe {j} values")
+        r.sinks = sinks
+        H.compare_lb_engine_with_oracle(eng, p, r)
+
+
 def test_lb_probe_on_the_nanosecond_of_a_target_event_is_refused():
     """Constant-rate Sources ticking every 0.1 s and a probe sampling their backend every 0.5 s: the sample falls on arrival
     nanoseconds, whose order against the probe's chain is the reference's sort-index ledger -- refused, never guessed."""

@@ -20,7 +20,7 @@ if not os.path.isdir("/root/reference/happysimulator"):
 
 sys.path.insert(0, H.GOLDEN_DIR)
 import make_golden as MG  # noqa: E402  (imports the reference through refshim)
-from random_specs import (lb_probe_spec, lb_spec as _lb_spec, multi_source_ring_spec, multi_source_spec, ring_spec as _ring_spec, station_spec as _station_spec,  # noqa: E402
+from random_specs import (lb_probe_spec, lb_profile_spec, lb_spec as _lb_spec, multi_source_ring_spec, multi_source_spec, ring_spec as _ring_spec, station_spec as _station_spec,  # noqa: E402
                           tie_spec)
 
 
@@ -80,4 +80,10 @@ def test_oracle_equals_live_reference_with_several_sources_per_server_on_rings(k
 @pytest.mark.parametrize("k", range(20))
 def test_oracle_equals_live_reference_with_probes_on_load_balancer_graphs(k):
     out, meta = MG.run_lb_case(lb_probe_spec(k))
+    check_oracle_against_lb_golden(H.Golden.from_results(out, meta))
+
+
+@pytest.mark.parametrize("k", range(12))
+def test_oracle_equals_live_reference_with_profiles_on_load_balancer_sources(k):
+    out, meta = MG.run_lb_case(lb_profile_spec(k))
     check_oracle_against_lb_golden(H.Golden.from_results(out, meta))
