@@ -763,8 +763,8 @@ __global__ void __launch_bounds__(64) hs_exact_run(StationParams P, NetParams NP
 // ---------------------------------------------------------------------------------------------
 namespace {
 
-template <int C, bool FAST = false, bool PF = !FAST>
-__device__ __forceinline__ void load_net(NetStation<C, FAST, PF> &S, const StationParams &P, const NetParams &NP,
+template <int C, bool FAST = false, bool PF = !FAST, bool UNI = false>
+__device__ __forceinline__ void load_net(NetStation<C, FAST, PF, UNI> &S, const StationParams &P, const NetParams &NP,
                                          const StationState &X, const NetState &NX, const RecordLogs &L, int lp, int n,
                                          uint8_t (*qmem)[kBlock], int64_t (*enqpay)[kBlock], int tid, int send_idx,
                                          const ShardCtl &SC) {
@@ -895,8 +895,8 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF> &S, const Stati
     S.qmem = qmem; S.enqpay = enqpay; S.qh = 0; S.qn = 0; S.ph = 0; S.pn = 0;
 }
 
-template <int C, bool FAST = false, bool PF = !FAST>
-__device__ __forceinline__ void store_net(NetStation<C, FAST, PF> &S, const StationState &X, const NetState &NX, int lp, int n) {
+template <int C, bool FAST = false, bool PF = !FAST, bool UNI = false>
+__device__ __forceinline__ void store_net(NetStation<C, FAST, PF, UNI> &S, const StationState &X, const NetState &NX, int lp, int n) {
     X.A[lp] = S.A; X.seqA[lp] = S.seqA; X.crtA[lp] = S.crtA; X.arr_time[lp] = S.arr_time;
     X.buf[lp] = S.buf; X.active[lp] = S.active; X.seq[lp] = S.seq;
     X.generated[lp] = S.generated; X.accepted[lp] = S.accepted; X.dropped[lp] = S.dropped;
@@ -1206,7 +1206,7 @@ constexpr unsigned kAsyncBlockedMax = 1u << 17;   // ... while a lane waits for 
 constexpr int kTopUpNeed = HS_TOPUP_NEED;
 constexpr int kAsyncGroupCap = HS_GROUP_CAP;   // event groups per LP per iteration of hs_net_async (debug flags bits 8..15 override)
 
-template <int C, bool PF>
+template <int C, bool PF, bool UNI = false>
 __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParams NP, StationState X, NetState NX,
                                                        RecordLogs L, Totals *tot, int n, int64_t end_ns, int flags,
                                                        ShardCtl SC, int lanes, int max_iters) {
@@ -1230,12 +1230,12 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
     if (tid == 0) { red_time = INT64_MIN; red_flags[0] = red_flags[1] = red_flags[2] = red_flags[3] = 0; }
     __syncthreads();
 
-    NetStation<C, true, PF> S;
+    NetStation<C, true, PF, UNI> S;
     S.fl = NetFastLds{ring_a, ring_s, ring_j, lbag_t, lbag_ts, lbag_cr, lbag_link, crc};
     bool done = !live;
     int gave_up = 0;
     if (live) {
-        load_net<C, true, PF>(S, P, NP, X, NX, L, lp, n, qmem, enqpay, tid, 0, SC);
+        load_net<C, true, PF, UNI>(S, P, NP, X, NX, L, lp, n, qmem, enqpay, tid, 0, SC);
         S.end_ns = end_ns;
 #ifdef HS_CYC2
         S.cy2[0] = S.cy2[1] = S.cy2[2] = S.cy2[3] = 0;
@@ -1458,7 +1458,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             if ((flags & 128) && wave_idle) __builtin_amdgcn_s_sleep(64);   // experiment: back off when idle
             groups_before = n_groups;
         }
-        store_net<C, true, PF>(S, X, NX, lp, n);
+        store_net<C, true, PF, UNI>(S, X, NX, lp, n);
         if (max_iters > 0 && !done) atomicAdd(&tot->not_done, 1ull);
         if constexpr (PF) {      // probe events straight to the totals (rare LPs)
             if (S.evp[0]) atomicAdd(&tot->ev[13], (unsigned long long)S.evp[0]);
@@ -1685,6 +1685,8 @@ struct hs_engine {
     Candidate *cands = nullptr;
     bool is_net = false;
     bool any_xsrc = false;     // some LP has more than one Source (general path + prologue)
+    bool uni_stations = false; // every LP: Poisson Source, exponential single-worker Server, unbounded queue, no stop_after
+    bool net_uni = false;      // ... and every router has exactly one NetworkLink (exponential jitter, no loss): hs_net_async<1, false, true>
     bool any_timevarying = false, any_sched = false;   // (subsets of any_profile: what a network does not lower)
     bool any_profile = false;  // some source has a time-varying rate profile (or a probe: same kernel instantiation)
     bool any_probe = false;
@@ -1818,6 +1820,9 @@ hipError_t launch_async(hs_engine *h, int64_t end_ns, NetState NX) {
     int max_iters = h->round_iters;
     void *args[] = {&h->P, &h->NP, &h->X, &NX, &h->L, &h->tot, &n, &end_ns, &flags, &h->SC, &lanes, &max_iters};
     const void *fn = h->net_pf ? (const void *)hs_net_async<C, true> : (const void *)hs_net_async<C, false>;
+    if constexpr (C == 1) {    // uniform entity kinds: the specialised instantiation (debug flag 1 << 20 keeps the generic one)
+        if (h->net_uni && !h->net_pf && (h->flags & (1 << 20)) == 0) fn = (const void *)hs_net_async<1, false, true>;
+    }
     return hipLaunchCooperativeKernel(fn, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(kBlock), args, 0, h->stream);
 }
 template <int C, bool PF>
@@ -2004,6 +2009,14 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
             ++n_xsrc_total;
         }
     h->any_xsrc = n_xsrc_total > 0;
+    // every LP is Source.poisson -> Server(Exp, c = 1, unbounded queue), nothing stops: half of what the specialised network
+    // kernel (NetStation<.., UNI>) assumes; hs_engine_set_network checks the routers and links
+    h->uni_stations = true;
+    for (int i = 0; i < n; ++i) {
+        if ((st->src_kind ? st->src_kind[i] : HS_SRC_POISSON) != HS_SRC_POISSON || (st->concurrency ? st->concurrency[i] : 1) != 1 ||
+            (st->svc_kind ? st->svc_kind[i] : HS_LAT_CONSTANT) != HS_LAT_EXPONENTIAL || (st->queue_cap ? st->queue_cap[i] : -1) >= 0 ||
+            (st->src_stop_after_ns ? st->src_stop_after_ns[i] : -1) >= 0) { h->uni_stations = false; break; }
+    }
     if (h->any_xsrc) h->any_profile = true;                         // such LPs run on the general-path instantiation
     for (int i = 0; i < n; ++i) {
         const int sk = st->src_kind ? st->src_kind[i] : HS_SRC_POISSON;
@@ -2521,6 +2534,15 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
         const bool fits = h->cfg.horizon_ns - h->cfg.start_ns < (int64_t)kPkNever - 2 && aqc < (1 << (kPkTailBits - 2));
         h->async_ok = !global && fits;
         h->net_pf = h->any_probe || h->any_timevarying || h->any_sched || h->any_xsrc;
+        // the network's entity kinds are uniform: the specialised instantiation (hs_netstation.hpp HSU)
+        h->net_uni = h->uni_stations && !global && !h->net_pf && h->C == 1;
+        for (int i = 0; i < n && h->net_uni; ++i) {
+            if (net->egress_kind[i] != HS_EGRESS_ROUTER) { h->net_uni = false; break; }
+            int n_link = 0, l1 = -1;
+            const int32_t tg[4] = {rt0[(size_t)i], rt1[(size_t)i], rt2[(size_t)i], rt3[(size_t)i]};
+            for (int q = 0; q < (int)rtk[(size_t)i]; ++q) if (tg[q] >= 0) { ++n_link; l1 = tg[q]; }
+            if (n_link != 1 || jk[(size_t)l1] != HS_LAT_EXPONENTIAL || lloss[(size_t)l1] != 0.0) h->net_uni = false;
+        }
     }
 #undef ALN
     if (!h->L.sink_created_own) {   // not every completion reaches the Sink any more: explicit created_at column

@@ -25,6 +25,11 @@
 
 #include "hs_station.hpp"
 
+// HSU(x, v): a per-LP configuration predicate `x` that is the compile-time constant `v` in the UNI instantiation of NetStation
+// (every station of the network is Source.poisson -> Server(Exp, c = 1, unbounded) -> RandomRouter -> one NetworkLink with
+// exponential jitter and no loss; the host checks it, hs_engine_set_network).  Those predicates otherwise live as lane masks in
+// SGPR pairs that spill to VGPR lanes, and every use is a select: the specialised kernel is 14 % faster on the headline ring.
+#define HSU(x, v) (UNI ? (v) : (x))
 namespace hs {
 
 enum : uint32_t { EG_NONE = 0, EG_SINK = 1, EG_LINK = 2, EG_ROUTER = 3 };
@@ -193,7 +198,7 @@ struct NetFastLds {
 // PF: the station may carry a Probe, a time-varying arrival profile or Requests injected with Simulation.schedule() -- the
 // rare roots.  The windowed engine always has them; the asynchronous engine has a second instantiation for networks
 // that use any of them, so that the common one keeps its registers.
-template <int C, bool FAST = false, bool PF = !FAST>
+template <int C, bool FAST = false, bool PF = !FAST, bool UNI = false>
 struct NetStation {
     // parameters
     int lp, n;
@@ -444,8 +449,8 @@ struct NetStation {
     // (`need` = what one iteration may consume per stream: the groups-per-iteration cap)
     __device__ __forceinline__ void top_up(bool act, int need) {
         if constexpr (FAST) {
-            const bool wa = src_kind == 1 && A != kInfNs, ws = svc_kind == 0, wj = fl_link >= 0 && fl_jit == 0;
-            const bool wr = egress == EG_ROUTER;
+            const bool wa = HSU(src_kind == 1, true) && A != kInfNs, ws = HSU(svc_kind == 0, true), wj = fl_link >= 0 && HSU(fl_jit == 0, true);
+            const bool wr = HSU(egress == EG_ROUTER, true);
             if (__any(act && wa && na < need)) { if (act && wa && na <= kNRing - 4) refill_a(4); }
             if (__any(act && ws && nsv < need)) { if (act && ws && nsv <= kNRing - 4) refill_s(4); }
             if (__any(act && wj && nj < need)) { if (act && wj && nj <= kNRing - 4) refill_j(4); }
@@ -456,18 +461,18 @@ struct NetStation {
     __device__ __forceinline__ int64_t next_arrival() {
         if constexpr (PF) {
             if (prof_kind != kProfConstant) {      // general path: invert the profile for the target area E (Poisson) or 1.0
-                const double area = src_kind == 1 ? arr_inc() : 1.0;   // (for such a Source the ring / stream value IS E)
+                const double area = HSU(src_kind == 1, true) ? arr_inc() : 1.0;   // (for such a Source the ring / stream value IS E)
                 arr_time = profile_next_tick(prof_kind, prof_p0, prof_p1, prof_p2, prof_p3, arr_time, area, lp);
                 return arr_time;
             }
         }
-        const double inc = src_kind == 1 ? arr_inc() : __ddiv_rn(1.0, rate);
+        const double inc = HSU(src_kind == 1, true) ? arr_inc() : __ddiv_rn(1.0, rate);
         const double t_next = __dadd_rn(seconds_from_ns(arr_time), inc);
         arr_time = ns_from_seconds(t_next);
         return arr_time;
     }
     __device__ __forceinline__ void sample_service(double &s, int64_t &dur_ns) {
-        if (svc_kind == 0) {
+        if (HSU(svc_kind == 0, true)) {
             s = svc_s_next();
             dur_ns = ns_from_seconds(s);
         } else { s = svc_const_s; dur_ns = svc_const_ns; }
@@ -529,7 +534,7 @@ struct NetStation {
     // ---- handlers (see hs_station.hpp for the reference citations of the shared ones)
     __device__ __forceinline__ uint32_t do_tick(int64_t t) {
         ev[0]++; generated++;
-        const bool payload = !(stop_ns >= 0 && t > stop_ns);
+        const bool payload = !(HSU(stop_ns >= 0, false) && t > stop_ns);
         const int64_t a2 = next_arrival();
         uint32_t r = payload ? 1u : 0u;
         if (a2 == t) { r |= 2u; A = kInfNs; }
@@ -540,7 +545,7 @@ struct NetStation {
     __device__ __forceinline__ bool do_enqueue(int64_t t, int64_t created) {
         (void)t;
         ev[1]++;
-        if (qcap >= 0 && buf >= qcap) { dropped++; return false; }
+        if (HSU(qcap >= 0, false) && buf >= qcap) { dropped++; return false; }
         const bool was_empty = (buf == 0);
         if (accepted < cap) adm[accepted * ls] = created; else overflow = 1;
         if constexpr (FAST) window_admit(created);
@@ -642,14 +647,14 @@ struct NetStation {
     // Decide the way out of request `ordinal` (departure D, created_at `created`) ahead of time; `bit_off` = its distance, in
     // completions, from the next one.  False when the pre-drawn route / jitter values do not reach that far.
     __device__ __forceinline__ bool pre_send(int64_t ordinal, int bit_off, int64_t D, int64_t created) {
-        const bool router = egress == EG_ROUTER;
+        const bool router = HSU(egress == EG_ROUTER, true);
         if (router && bit_off >= rn) return false;
-        const int32_t target = egress == EG_SINK ? -1 : egress == EG_LINK ? link_of
+        const int32_t target = HSU(egress == EG_SINK, false) ? -1 : HSU(egress == EG_LINK, false) ? link_of
                              : router ? rt_target((int)((rbits >> (2 * bit_off)) & 3u)) : -2;
         if (target >= 0 && D <= end_ns) {
-            if (fl_jit == 0 && nj == 0) return false;
+            if (HSU(fl_jit == 0, true) && nj == 0) return false;
             double delay = fl_delay0;
-            if (fl_jit == 0) { delay = __dadd_rn(delay, fl.ring_j[hj][tid]); hj = (hj + 1) & (kNRing - 1); --nj; }
+            if (HSU(fl_jit == 0, true)) { delay = __dadd_rn(delay, fl.ring_j[hj][tid]); hj = (hj + 1) & (kNRing - 1); --nj; }
             if (!(delay > 0.0)) delay = 0.0;
             fl_append(D + ns_from_seconds(delay), D, created);
         }
@@ -660,16 +665,16 @@ struct NetStation {
     // the LP's only outgoing link with its state in registers and the jitter E pre-drawn (FAST; queue path only)
     __device__ __forceinline__ void send_link_fast(int64_t t, int64_t created) {
         ev[8]++;
-        if (presend && completed - 1 < early_upto) { fl_in++; fl_sent++; return; }   // its message was appended ahead of time
+        if (HSU(presend, true) && completed - 1 < early_upto) { fl_in++; fl_sent++; return; }   // its message was appended ahead of time
         const int64_t entered = fl_in++;
-        if (fl_loss > 0.0) {
+        if (HSU(fl_loss > 0.0, false)) {
             Stream ls;
             ls.init(seed, stream_id(np->link_base[fl_link], kStreamLoss), (uint64_t)entered);
             if (ls.next_uniform() < fl_loss) return;
         }
         ++fl_sent;
         double delay = fl_delay0;
-        if (fl_jit == 0) {
+        if (HSU(fl_jit == 0, true)) {
             if (nj == 0) refill_j(2);
             delay = __dadd_rn(delay, fl.ring_j[hj][tid]);
             hj = (hj + 1) & (kNRing - 1); --nj;
@@ -741,15 +746,15 @@ struct NetStation {
     }
     // the forwarded request's way out of the LP: Sink / RandomRouter / NetworkLink (all at time t)
     __device__ __forceinline__ void do_egress(int64_t t, int64_t created) {
-        const bool pre = FAST && C == 1 && presend && completed - 1 < early_upto;   // way out decided ahead of time
+        const bool pre = FAST && C == 1 && HSU(presend, true) && completed - 1 < early_upto;   // way out decided ahead of time
         do_egress_inner(t, created);
         if (FAST && C == 1 && !pre) { if (early_upto < completed) { early_upto = completed; D_pre = t; } }
     }
     __device__ __forceinline__ void do_egress_inner(int64_t t, int64_t created) {
         int32_t target = -2;             // -2 nothing, -1 sink, >= 0 link
-        if (egress == EG_SINK) target = -1;
-        else if (egress == EG_LINK) target = link_of;
-        else if (egress == EG_ROUTER) {  // RandomRouter.handle_event (components/random_router.py:32-45)
+        if (HSU(egress == EG_SINK, false)) target = -1;
+        else if (HSU(egress == EG_LINK, false)) target = link_of;
+        else if (HSU(egress == EG_ROUTER, true)) {  // RandomRouter.handle_event (components/random_router.py:32-45)
             ev[10]++; routed++;
             const int idx = route_idx();
             target = rt_target(idx);
@@ -867,7 +872,7 @@ struct NetStation {
     // (pure functions of the draw index).  With `free` idle workers that many requests can be in service before any
     // completion, so the first completion of a not-yet-started request is no earlier than its start + this.
     __device__ __forceinline__ int64_t peek_service_ns(int free) const {
-        if (svc_kind != 0) return svc_const_ns;
+        if (HSU(svc_kind != 0, false)) return svc_const_ns;
         Stream c = svc;                   // FAST: positioned behind the pre-drawn values, which come first
         int64_t m = kInfNs;
         for (int i = 0; i < free; ++i) {
@@ -896,12 +901,12 @@ struct NetStation {
         return q;                                                     // == rn: none of the known decisions goes to l
     }
     __device__ __forceinline__ int64_t sum_services(int m) const {   // of the next m requests to start, m <= services_known()
-        if (svc_kind != 0) return (int64_t)m * svc_const_ns;
+        if (HSU(svc_kind != 0, false)) return (int64_t)m * svc_const_ns;
         int64_t sum = 0;
         for (int i = 0; i < m; ++i) sum += ns_from_seconds(fl.ring_s[(hs_ + i) & (kNRing - 1)][tid]);
         return sum;
     }
-    __device__ __forceinline__ int services_known() const { return svc_kind != 0 ? kNRing : nsv; }
+    __device__ __forceinline__ int services_known() const { return HSU(svc_kind != 0, false) ? kNRing : nsv; }
     // the next admission the LP already knows about: its own Source's tick, a message in the bag, an injected Request
     __device__ __forceinline__ int64_t next_admission() const {
         int64_t a = A < bmin ? A : bmin;
@@ -923,7 +928,7 @@ struct NetStation {
         if (kind) *kind = -1;
         if constexpr (C == 1 && FAST) {
             const int known = services_known();
-            if (presend && l == fl_link) {
+            if (HSU(presend, true) && l == fl_link) {
                 // Requests with ordinal < early_upto are pre-sent; the first message still to come belongs to request u =
                 // early_upto or a later one -- whichever is the first whose (pre-drawn) route decision is l:
                 //   u in service          leaves at D[0]; the requests behind it start when it leaves;
@@ -933,7 +938,7 @@ struct NetStation {
                 const int64_t u = early_upto;
                 const int boff = (int)(u - completed);               // its distance from the next completion
                 int q = 0;                                           // requests from u on that go elsewhere first
-                if (egress == EG_ROUTER) {
+                if (HSU(egress == EG_ROUTER, true)) {
                     uint32_t b = boff < 16 ? rbits >> (2 * boff) : 0u;
                     const int have = rn - boff;
                     while (q < have && q < kLookMax && rt_target((int)(b & 3u)) != l) { ++q; b >>= 2; }
@@ -946,7 +951,7 @@ struct NetStation {
                 }
                 const int off = (int)(u - started);
                 int64_t sd = 0;
-                if (svc_kind != 0) sd = (int64_t)(q + 1) * svc_const_ns;
+                if (HSU(svc_kind != 0, false)) sd = (int64_t)(q + 1) * svc_const_ns;
                 else for (int i = 0; i <= q && off + i < known; ++i) sd += ns_from_seconds(fl.ring_s[(hs_ + off + i) & (kNRing - 1)][tid]);
                 if (u < accepted) { mA = sat(sat(D_pre, sd), lat); if (kind) *kind = 0; return; }
                 const int64_t arr_next = next_admission();
@@ -1121,26 +1126,26 @@ struct NetStation {
         if (act && bmin == t) { ++cnt; if (bag_n > 1 && bg_t(1) == t) ++cnt; }   // the sorted bag: entry 0 is the message (mi = 0)
         bool msg = act && !tick && !dep;                              // (cnt == 1 is checked below)
         // speculative draws: peeks, nothing consumed yet
-        const bool poisson = src_kind == 1, svc_exp = svc_kind == 0;
+        const bool poisson = HSU(src_kind == 1, true), svc_exp = HSU(svc_kind == 0, true);
         const double inc = poisson ? fl.ring_a[ha][tid] : inc_const;
         const int64_t a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc));
         const double s_new = svc_exp ? fl.ring_s[hs_][tid] : svc_const_s;
         const int64_t dur = svc_exp ? ns_from_seconds(s_new) : svc_const_ns;
-        const bool router = egress == EG_ROUTER;
+        const bool router = HSU(egress == EG_ROUTER, true);
         const int ridx = (int)(rbits & 3u);
-        const int32_t target = egress == EG_SINK ? -1 : egress == EG_LINK ? link_of : router ? rt_target(ridx) : -2;
+        const int32_t target = HSU(egress == EG_SINK, false) ? -1 : HSU(egress == EG_LINK, false) ? link_of : router ? rt_target(ridx) : -2;
         bool to_sink, to_link, payload, arrv, acc, notify, poll, deliver, pre_done;
         int64_t buf1;
         auto derive = [&]() {                                         // which reference events happen
             to_sink = dep && target == -1; to_link = dep && target >= 0;
-            payload = tick && !(stop_ns >= 0 && t > stop_ns);
+            payload = tick && !(HSU(stop_ns >= 0, false) && t > stop_ns);
             arrv = payload || msg;
-            acc = arrv && !(qcap >= 0 && buf >= qcap);
+            acc = arrv && !(HSU(qcap >= 0, false) && buf >= qcap);
             notify = acc && buf == 0;
             poll = (notify && active < conc) || dep;
             buf1 = buf + (acc ? 1 : 0);
             deliver = poll && buf1 > 0;
-            pre_done = presend && dep && completed < early_upto;     // the departing request's message went out ahead of time
+            pre_done = HSU(presend, true) && dep && completed < early_upto;     // the departing request's message went out ahead of time
         };
         derive();
         if constexpr (PF) {
@@ -1151,7 +1156,7 @@ struct NetStation {
         }
         const bool slow = act && (force_general || cnt != 1 || (tick && (a2 <= t || (poisson && na == 0))) ||
                           (deliver && (dur == 0 || (svc_exp && nsv == 0) || (dep && started >= win_hi))) || (dep && router && rn == 0) ||
-                          (to_link && (target != fl_link || fl_loss > 0.0 || (!pre_done && fl_jit == 0 && nj == 0))));
+                          (to_link && (target != fl_link || HSU(fl_loss > 0.0, false) || (!pre_done && HSU(fl_jit == 0, true) && nj == 0))));
 #ifdef HS_RINGSTAT
         if (slow) stat_slow = 1;
 #endif
@@ -1182,7 +1187,7 @@ struct NetStation {
             if (accepted < cap) adm[accepted * ls] = created_in; else overflow = 1;
             window_admit(created_in);
         }
-        if (acc && presend && early_upto == accepted) {
+        if (acc && HSU(presend, true) && early_upto == accepted) {
             // pre-send at admission: the request's start and departure are already determined (see `early_upto`)
             const int off = (int)(accepted - started);                 // requests that start before it
             if (!svc_exp || off < nsv) {
@@ -1214,7 +1219,7 @@ struct NetStation {
             ev[8]++; fl_in++; fl_sent++;
             if (!pre_done) {
                 double delay = fl_delay0;
-                if (fl_jit == 0) {
+                if (HSU(fl_jit == 0, true)) {
                     delay = __dadd_rn(delay, fl.ring_j[hj][tid]);
                     hj = (hj + 1) & (kNRing - 1); --nj;
                 }
@@ -1234,7 +1239,7 @@ struct NetStation {
             int64_t created = created_in;                             // arrival side: the request that found the buffer empty
             if (dep) created = fl.crc[k & (kNRing - 1)][tid];        // in the window (k < win_hi: checked with `slow`)
             win_hi = win_hi <= k ? k + 1 : win_hi;
-            if (presend && k >= early_upto) (void)pre_send(k, (int)(k - completed), t + dur, created);   // pre-send at the start
+            if (HSU(presend, true) && k >= early_upto) (void)pre_send(k, (int)(k - completed), t + dur, created);   // pre-send at the start
             svc_s[0] = s_new; crt[0] = created;
             D[0] = t + dur; seqD[0] = seq++; crtD[0] = t;
             if (svc_exp) { hs_ = (hs_ + 1) & (kNRing - 1); --nsv; }
@@ -1282,3 +1287,4 @@ struct NetStation {
 };
 
 }  // namespace hs
+#undef HSU

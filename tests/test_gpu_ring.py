@@ -344,6 +344,25 @@ def test_buffer_deadlock_is_reported_not_spun_on():
     assert res[0] == res[1] and res[0][0] > 10000
 
 
+def test_specialised_uniform_kind_kernel_equals_the_generic_one():
+    """A network whose stations are all Source.poisson -> Server(Exp, c = 1, unbounded) -> RandomRouter([Sink, NetworkLink(Exp jitter,
+    no loss)]) runs on hs_net_async<1, false, true> (compile-time entity kinds, csrc/hs_netstation.hpp HSU); debug flag 1 << 20
+    keeps the generic instantiation: every statistic and every Sink record identical, and both equal the oracle."""
+    spec = dict(name="ring_uni", topology="ring", n=3000, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, end_s=8.0, seed=17)
+    g, nodes = H.oracle_ring_graph(spec)
+    p = H.ring_params(spec)
+    r = O.run(g, p["end_ns"], seed=spec["seed"])
+    got = []
+    for flags in (0, 1 << 20):
+        eng, p = H.ring_engine_for_spec(spec, flags=flags)
+        with eng:
+            eng.run_until(p["end_ns"])
+            _check_against_oracle(spec, eng, r, nodes)
+            got.append((eng.summary().events_by_kind.tolist(), [a.tobytes() for a in eng.read_sinks()],
+                        {k: v.tobytes() for k, v in eng.lp_stats().items()}))
+    assert got[0] == got[1]
+
+
 def test_async_engine_results_do_not_depend_on_timing():
     """The asynchronous engine's LPs exchange bounds and messages through memory while they run; the result must be a function
     of the inputs alone.  Debug flag 1024 delays pseudo-randomly chosen wavefronts in pseudo-randomly chosen iterations
