@@ -552,7 +552,7 @@ def main():
                 # the binding resource is VALU issue (the serial per-LP recursion), not HBM: `achieved` / `frac` are the HBM
                 # figures the contract asks for, `valu` is the measured issue fraction of the same kernel
                 "bound": "valu",
-                "kernel": "hs_station_run<1, false, true> (producer / consumer wavefronts)",
+                "kernel": "hs_station_run<1, false, true, true> (producer / consumer wavefronts, uniform entity kinds)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -68,8 +68,8 @@ __device__ __forceinline__ Candidate wave_min_cand(Candidate c) {
     return c;
 }
 
-template <int C, bool PF>
-__device__ __forceinline__ void load_station(Station<C, PF> &S, const StationParams &P, const StationState &X,
+template <int C, bool PF, bool UNI = false>
+__device__ __forceinline__ void load_station(Station<C, PF, UNI> &S, const StationParams &P, const StationState &X,
                                              const RecordLogs &L, int lp, int n, uint8_t (*qmem)[kBlock],
                                              double (*ring_a)[kBlock], double (*ring_s)[kBlock], int tid) {
     S.lp = lp; S.n = n;
@@ -149,9 +149,9 @@ __device__ __forceinline__ void load_station(Station<C, PF> &S, const StationPar
     for (int i = 0; i < qn; ++i) S.qpush((q >> (8 * i)) & 0xffu);
 }
 
-template <int C, bool PF>
-__device__ __forceinline__ void store_station(const Station<C, PF> &Sc, const StationState &X, int lp, int n) {
-    Station<C, PF> &S = const_cast<Station<C, PF> &>(Sc);
+template <int C, bool PF, bool UNI = false>
+__device__ __forceinline__ void store_station(const Station<C, PF, UNI> &Sc, const StationState &X, int lp, int n) {
+    Station<C, PF, UNI> &S = const_cast<Station<C, PF, UNI> &>(Sc);
     X.A[lp] = S.A; X.seqA[lp] = S.seqA; X.crtA[lp] = S.crtA; X.arr_time[lp] = S.arr_time;
     X.buf[lp] = S.buf; X.active[lp] = S.active; X.seq[lp] = S.seq;
     X.generated[lp] = S.generated; X.accepted[lp] = S.accepted; X.dropped[lp] = S.dropped;
@@ -194,8 +194,8 @@ __device__ __forceinline__ void store_station(const Station<C, PF> &Sc, const St
 }
 
 // first pending event of an LP: time, creation time, which root
-template <int C, bool PF>
-__device__ __forceinline__ Candidate make_candidate(const Station<C, PF> &S) {
+template <int C, bool PF, bool UNI = false>
+__device__ __forceinline__ Candidate make_candidate(const Station<C, PF, UNI> &S) {
     Candidate c;
     c.lp = S.lp; c.rank = S.lp; c.valid = 0; c.t = kInfNs; c.t_created = 0; c.pad = 0;
     if (S.qn > 0) {   // a group already in progress keeps the floor
@@ -225,8 +225,8 @@ __device__ __forceinline__ Candidate make_candidate(const Station<C, PF> &S) {
 }
 
 // process exactly ONE event beyond end_ns: the first micro-event of the LP's next group
-template <int C, bool PF>
-__device__ __forceinline__ void overshoot_one(Station<C, PF> &S) {
+template <int C, bool PF, bool UNI = false>
+__device__ __forceinline__ void overshoot_one(Station<C, PF, UNI> &S) {
     if (S.qn > 0) {   // continue the in-progress group by one event
         // (only reachable when a previous window ended inside this group and the new end is still before it)
         return;
@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
 // consumer -- produce the same LP's stream values into the same LDS rings, and the SIMD interleaves the two instruction
 // streams.  The rings become single-producer / single-consumer queues with 16-bit produced / consumed counters in LDS
 // (release / acquire at workgroup scope); values are pure functions of (stream, index), so who computes them is invisible.
-template <int C, bool PF, bool PC = false>
+template <int C, bool PF, bool PC = false, bool UNI = false>
 __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(StationParams P, StationState X, RecordLogs L, Totals *tot,
                                                          Candidate *cands, int n, int64_t end_ns, int mode, int flags) {
     static_assert(!PC || (C == 1 && !PF), "producer / consumer waves serve the request-order loop of <1, false>");
@@ -402,7 +402,7 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
     const long long cur = tot->cur_time;   // SINGLE: Simulation._current_time (written by the previous launch)
     __syncthreads();
 
-    Station<C, PF> S;
+    Station<C, PF, UNI> S;
     Candidate mine;
     mine.valid = 0; mine.t = kInfNs; mine.t_created = 0; mine.lp = lp; mine.rank = lp;
     if constexpr (PC) {
@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
         }
     }
     if (live) {
-        load_station<C, PF>(S, P, X, L, lp, n, qmem, ring_a, ring_s, tid);
+        load_station<C, PF, UNI>(S, P, X, L, lp, n, qmem, ring_a, ring_s, tid);
         S.force_general = (flags & 1) != 0;
     }
     const bool frozen = (mode == HS_MODE_REPLICAS) ? (live && S.last_time > end_ns) : (cur > end_ns);
@@ -481,7 +481,7 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
             // (1) request-order loop (hs_station.hpp): one whole request per iteration.  Uniform loops: the
             // wavefront iterates until its slowest lane is done, finished lanes are predicated off.
             const bool elig = live && !frozen && !pre_group && S.qn == 0 && S.req_eligible();
-            typename Station<C, PF>::ReqCursor rc;
+            typename Station<C, PF, UNI>::ReqCursor rc;
             rc.bail = false; rc.done = true;
             if (elig) S.req_begin(rc, end_ns);   // (touches the LP's statistics: eligible lanes only)
 #ifdef HS_CYCLES   // tools/cycles.py: where the request-order loop spends its time (never defined in the shipped library)
@@ -546,7 +546,7 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
                 S.ra.head = 0; S.ra.n = 0; S.rs.head = 0; S.rs.n = 0;
             }
             if (bail_reload) {
-                load_station<C, PF>(S, P, X, L, lp, n, qmem, ring_a, ring_s, tid);
+                load_station<C, PF, UNI>(S, P, X, L, lp, n, qmem, ring_a, ring_s, tid);
                 S.force_general = (flags & 1) != 0;
             }
         }
@@ -572,13 +572,13 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
     }
     if (live) {
         if (!frozen) {
-            if (mode == HS_MODE_REPLICAS) overshoot_one<C, PF>(S);
+            if (mode == HS_MODE_REPLICAS) overshoot_one<C, PF, UNI>(S);
             else {
-                mine = make_candidate<C, PF>(S);
+                mine = make_candidate<C, PF, UNI>(S);
                 mine.rank = (P.tie_rank != nullptr ? P.tie_rank[lp] : lp) + (mine.pad ? n : 0);
             }
         }
-        store_station<C, PF>(S, X, lp, n);
+        store_station<C, PF, UNI>(S, X, lp, n);
     }
 
     // ---- workgroup reduction of the per-run deltas -> engine totals
@@ -1686,6 +1686,7 @@ struct hs_engine {
     bool is_net = false;
     bool any_xsrc = false;     // some LP has more than one Source (general path + prologue)
     bool uni_stations = false; // every LP: Poisson Source, exponential single-worker Server, unbounded queue, no stop_after
+    bool uni_grid = false;     // ... and a Sink behind every Server: hs_station_run<1, false, true, true>
     bool net_uni = false;      // ... and every router has exactly one NetworkLink (exponential jitter, no loss): hs_net_async<1, false, true>
     bool any_timevarying = false, any_sched = false;   // (subsets of any_profile: what a network does not lower)
     bool any_profile = false;  // some source has a time-varying rate profile (or a probe: same kernel instantiation)
@@ -1776,8 +1777,12 @@ template <int C>
 void launch_run(hs_engine *h, int64_t end_ns) {
     if constexpr (C == 1) {
         if (!h->any_profile && !(h->flags & 512)) {     // producer / consumer wavefronts (debug flag 512: the one-role kernel)
-            hipLaunchKernelGGL((hs_station_run<1, false, true>), dim3(h->n_blocks), dim3(2 * kBlock), 0, h->stream, h->P, h->X,
-                               h->L, h->tot, h->cands, h->cfg.n_lp, end_ns, h->cfg.mode, h->flags);
+            if (h->uni_grid && (h->flags & (1 << 20)) == 0)   // uniform entity kinds: compile-time predicates (hs_station.hpp HSG)
+                hipLaunchKernelGGL((hs_station_run<1, false, true, true>), dim3(h->n_blocks), dim3(2 * kBlock), 0, h->stream, h->P,
+                                   h->X, h->L, h->tot, h->cands, h->cfg.n_lp, end_ns, h->cfg.mode, h->flags);
+            else
+                hipLaunchKernelGGL((hs_station_run<1, false, true>), dim3(h->n_blocks), dim3(2 * kBlock), 0, h->stream, h->P, h->X,
+                                   h->L, h->tot, h->cands, h->cfg.n_lp, end_ns, h->cfg.mode, h->flags);
             return;
         }
     }
@@ -2017,6 +2022,8 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
             (st->svc_kind ? st->svc_kind[i] : HS_LAT_CONSTANT) != HS_LAT_EXPONENTIAL || (st->queue_cap ? st->queue_cap[i] : -1) >= 0 ||
             (st->src_stop_after_ns ? st->src_stop_after_ns[i] : -1) >= 0) { h->uni_stations = false; break; }
     }
+    h->uni_grid = h->uni_stations;
+    for (int i = 0; i < n && h->uni_grid; ++i) if ((st->egress ? st->egress[i] : HS_EGRESS_SINK) != HS_EGRESS_SINK) h->uni_grid = false;
     if (h->any_xsrc) h->any_profile = true;                         // such LPs run on the general-path instantiation
     for (int i = 0; i < n; ++i) {
         const int sk = st->src_kind ? st->src_kind[i] : HS_SRC_POISSON;

@@ -189,7 +189,11 @@ struct Candidate {              // an LP's first event beyond end_ns (SINGLE-mod
 // ---------------------------------------------------------------------------------------------
 // PF: the LP may have a time-varying arrival profile (hs_profile.hpp).  A separate instantiation, because the numerical
 // inversion needs a 4 KB per-lane stack and would otherwise tax the constant-rate kernel's registers.
-template <int C, bool PF = false>
+// HSG(x, v): a per-LP configuration predicate `x` of the request-order loop that is the compile-time constant `v` in the UNI
+// instantiation (every LP of the engine is Source.poisson -> Server(Exp) -> Sink; the host checks it, hs_engine_set_stations):
+// 4 % of the headline kernel.
+#define HSG(x, v) (UNI ? (v) : (x))
+template <int C, bool PF = false, bool UNI = false>
 struct Station {
     // parameters
     int lp, n;
@@ -782,7 +786,7 @@ struct Station {
     }
     __device__ __forceinline__ void req_count_departure(ReqCursor &c, bool p, int64_t d, double s) {
         total_service = p ? __dadd_rn(total_service, s) : total_service;
-        if (p && egress == 1) {
+        if (p && HSG(egress == 1, true)) {
             const int64_t w = sink_w + (int64_t)c.n_dep;
             if (w < cap) sink_t[w * ls] = d; else overflow = 1;
         }
@@ -807,7 +811,7 @@ struct Station {
         const bool arr = !bk && A <= T;                  // ... or the next arrival
         const bool fin = !bk && !arr;
         // arrival part at a_k = A
-        const double inc = (src_kind == 1) ? ra.peek() : inc_const;
+        const double inc = HSG(src_kind == 1, true) ? ra.peek() : inc_const;
         const int64_t a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc));
         const bool tie_a = arr && (A == c.Sprev || A == c.Dprev || a2 <= A);
         const bool notify = arr && c.Sprev < A;
@@ -815,8 +819,8 @@ struct Station {
         // start part at S_k
         const int64_t Sk = bk ? c.Dprev : (A > c.Dprev ? A : c.Dprev);
         const bool st = (bk || arr) && Sk <= T;
-        const double s_new = (svc_kind == 0) ? rs.peek() : svc_const_s;
-        const int64_t dur = (svc_kind == 0) ? ns_from_seconds(s_new) : svc_const_ns;
+        const double s_new = HSG(svc_kind == 0, true) ? rs.peek() : svc_const_s;
+        const int64_t dur = HSG(svc_kind == 0, true) ? ns_from_seconds(s_new) : svc_const_ns;
         const int64_t Dk = Sk + dur;
         const bool dp = st && Dk <= T;                   // departure part at D_k
         const bool bail = act && (tie_a || (st && dur == 0));
@@ -835,13 +839,13 @@ struct Station {
         c.lt = (arr_g && A > c.lt) ? A : c.lt;
         crtA = arr_g ? A : crtA;
         arr_time = arr_g ? a2 : arr_time;
-        const bool pop_a = arr_g && src_kind == 1;
+        const bool pop_a = arr_g && HSG(src_kind == 1, true);
         ra.advance_if(pop_a);
         arr_k += pop_a ? 1u : 0u;
         // QUEUE_DELIVER + Request@worker: the service sample is drawn at the start of service
         c.n_start += st_g ? 1u : 0u;
         c.lt = (st_g && Sk > c.lt) ? Sk : c.lt;
-        const bool pop_s = st_g && svc_kind == 0;
+        const bool pop_s = st_g && HSG(svc_kind == 0, true);
         rs.advance_if(pop_s);
         svc_k += pop_s ? 1u : 0u;
         // ProcessContinuation + Request@Sink + completion poll
@@ -886,3 +890,4 @@ struct Station {
 };
 
 }  // namespace hs
+#undef HSG

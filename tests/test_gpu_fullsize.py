@@ -134,3 +134,24 @@ def test_baseline_config1_4096_replicas_seed_matched():
         np.testing.assert_array_equal(st[k], want[k], err_msg=k)
     np.testing.assert_array_equal(t, np.concatenate([sinks[c][0] for c in range(4096)]))
     np.testing.assert_array_equal(cr, np.concatenate([sinks[c][1] for c in range(4096)]))
+
+
+def test_specialised_uniform_kind_grid_kernel_equals_the_generic_one():
+    """An engine whose LPs are all Source.poisson -> Server(Exp, c = 1, unbounded) -> Sink runs hs_station_run<1, false, true, true>
+    (compile-time entity kinds in the request-order loop, csrc/hs_station.hpp HSG); debug flag 1 << 20 keeps the generic
+    instantiation: every statistic and every Sink record identical at the headline size."""
+    from happy_simulator_amd import _native as N
+    from happy_simulator_amd.engine import StationArrays, StationEngine
+
+    end_ns = 60_000_000_000
+    got = []
+    for flags in (0, 1 << 20):
+        eng = StationEngine(StationArrays.uniform(65536), mode=N.MODE_SINGLE, horizon_ns=end_ns, seed=42)
+        with eng:
+            if flags:
+                eng.set_debug_flags(flags)
+            eng.run_until(end_ns)
+            s = eng.summary()
+            got.append((s.events_processed, s.final_time_ns, s.events_by_kind.tolist(), [a.tobytes() for a in eng.read_sinks()],
+                        {k: v.tobytes() for k, v in eng.lp_stats().items()}))
+    assert got[0] == got[1] and got[0][0] == 237150263
