@@ -1247,10 +1247,11 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             int no = 0;
             for (int k = 0; k < S.rtk; ++k) { const int32_t t = S.rt_target(k); if (t >= 0 && no < 2) out_l[no++] = t; }
         }
+        constexpr int kOut = UNI ? 1 : 2;                     // (UNI: one NetworkLink per station)
         int64_t out_pub[2] = {INT64_MIN, INT64_MIN};
         const int64_t out_lat[2] = {out_l[0] >= 0 ? NP.link_lat_ns[out_l[0]] : 0, out_l[1] >= 0 ? NP.link_lat_ns[out_l[1]] : 0};
         unsigned long long head_seen[2] = {0ull, 0ull};
-        const bool force_general = (flags & 1) != 0;
+        const bool force_general = !UNI && (flags & 1) != 0;   // (UNI is not launched with debug flag 1)
         // Groups per LP per iteration.  The loop below is divergent: a lane with a long stretch of ready groups would keep
         // the other 63 idle, and their bounds only move at iteration boundaries -- so every lane takes a few groups, then
         // the wavefront exchanges bounds again and (measured) many more lanes are ready in the next trip.
@@ -1271,9 +1272,9 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         int32_t next_l = -1;                                  // my link to the LP in the next lane, if any
         bool out_remote[2] = {false, false};                  // a shard: links that leave it go to an outbox row, no queue
 #pragma unroll
-        for (int o = 0; o < 2; ++o) {
+        for (int o = 0; o < kOut; ++o) {
             if (out_l[o] < 0) continue;
-            out_remote[o] = SC.wend_slots != nullptr && SC.link_rank[out_l[o]] != SC.rank;
+            out_remote[o] = !UNI && SC.wend_slots != nullptr && SC.link_rank[out_l[o]] != SC.rank;
             if (!out_remote[o] && NP.link_dst[out_l[o]] == (int32_t)SC.lp_base + lp + 1) next_l = out_l[o];
         }
         const int in_deg = NP.in_off[lp + 1] - NP.in_off[lp];
@@ -1367,7 +1368,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                     const int64_t t = S.next_time();
                     bool act = !stop && t <= limit;
                     if (act && !((out_remote[0] || S.async_can_send(out_l[0], head_seen[0])) &&
-                                 (out_remote[1] || S.async_can_send(out_l[1], head_seen[1])))) { blocked = true; act = false; }   // a consumer is behind: wait
+                                 (UNI || out_remote[1] || S.async_can_send(out_l[1], head_seen[1])))) { blocked = true; act = false; }   // a consumer is behind: wait
                     stop = stop || !act;
                     if (!__any(act)) break;
 #ifdef HS_RINGSTAT
@@ -1407,7 +1408,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                 // (the bounds are computed first -- registers and LDS only -- so that the drain overlaps with that arithmetic)
                 int64_t vo[2] = {INT64_MIN, INT64_MIN};
 #pragma unroll
-                for (int o = 0; o < 2; ++o) {
+                for (int o = 0; o < kOut; ++o) {
                     const int32_t l = out_l[o];
                     if (l < 0) continue;
                     // the bound of everything this LP has NOT appended to link l yet: its map evaluated at `base`
@@ -1422,7 +1423,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                 }
                 if (S.sent_async) drain_stores();
 #pragma unroll
-                for (int o = 0; o < 2; ++o) {
+                for (int o = 0; o < kOut; ++o) {
                     const int32_t l = out_l[o];
                     if (l < 0) continue;
                     if (S.sent_async || vo[o] > out_pub[o]) {
@@ -1441,7 +1442,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             }
 #endif
             if (__all(done)) break;
-            if (max_iters > 0 && (int)(iter + 1) >= max_iters) break; // a shard's exchange round is over
+            if (!UNI && max_iters > 0 && (int)(iter + 1) >= max_iters) break; // a shard's exchange round is over
             // a fatal condition anywhere ends the launch everywhere: nobody spins on a dead neighbour
             if (__any(aborted) || ((iter & 31u) == 31u && __hip_atomic_load(&tot->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) break;
             // the spin bound counts iterations in which the whole wavefront processed nothing (with at most kAsyncGroupCap
@@ -1459,7 +1460,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             groups_before = n_groups;
         }
         store_net<C, true, PF, UNI>(S, X, NX, lp, n);
-        if (max_iters > 0 && !done) atomicAdd(&tot->not_done, 1ull);
+        if (!UNI && max_iters > 0 && !done) atomicAdd(&tot->not_done, 1ull);
         if constexpr (PF) {      // probe events straight to the totals (rare LPs)
             if (S.evp[0]) atomicAdd(&tot->ev[13], (unsigned long long)S.evp[0]);
             if (S.evp[1]) atomicAdd(&tot->ev[14], (unsigned long long)S.evp[1]);
@@ -1826,7 +1827,8 @@ hipError_t launch_async(hs_engine *h, int64_t end_ns, NetState NX) {
     void *args[] = {&h->P, &h->NP, &h->X, &NX, &h->L, &h->tot, &n, &end_ns, &flags, &h->SC, &lanes, &max_iters};
     const void *fn = h->net_pf ? (const void *)hs_net_async<C, true> : (const void *)hs_net_async<C, false>;
     if constexpr (C == 1) {    // uniform entity kinds: the specialised instantiation (debug flag 1 << 20 keeps the generic one)
-        if (h->net_uni && !h->net_pf && (h->flags & (1 << 20)) == 0) fn = (const void *)hs_net_async<1, false, true>;
+        if (h->net_uni && !h->net_pf && (h->flags & ((1 << 20) | 1 | 32)) == 0 && h->round_iters == 0 && lanes == 64)
+            fn = (const void *)hs_net_async<1, false, true>;
     }
     return hipLaunchCooperativeKernel(fn, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(kBlock), args, 0, h->stream);
 }
@@ -2468,6 +2470,7 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     if ((rc = upload<double>(h, &h->NP.link_jit_mean, jm.data(), NL, 0.0))) return rc;
     if ((rc = upload<uint64_t>(h, &h->NP.link_base, lbase.data(), NL, 0))) return rc;
     if ((rc = upload<double>(h, &h->NP.link_loss, lloss.data(), NL, 0.0))) return rc;
+    std::vector<int32_t> in_deg_h;
     {   // incoming links per LP (CSR) and the transit floor of every link, for the asynchronous engine
         std::vector<int32_t> in_off((size_t)n + 1, 0), in_links(NL, 0);
         std::vector<int64_t> lat_ns(NL, 1);
@@ -2482,6 +2485,8 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
             const double lc = (double)(int64_t)(net->link_lat_min_s[l] * 1e9) / 1e9;   // ConstantLatency.get_latency().to_seconds()
             lat_ns[(size_t)l] = (int64_t)(lc * 1e9);
         }
+        in_deg_h.resize((size_t)n);
+        for (int i = 0; i < n; ++i) in_deg_h[(size_t)i] = in_off[(size_t)i + 1] - in_off[(size_t)i];
         if ((rc = upload<int32_t>(h, &h->NP.in_off, in_off.data(), (size_t)n + 1, 0))) return rc;
         if ((rc = upload<int32_t>(h, &h->NP.in_links, in_links.data(), NL, 0))) return rc;
         if ((rc = upload<int64_t>(h, &h->NP.link_lat_ns, lat_ns.data(), NL, 1))) return rc;
@@ -2549,6 +2554,7 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
             const int32_t tg[4] = {rt0[(size_t)i], rt1[(size_t)i], rt2[(size_t)i], rt3[(size_t)i]};
             for (int q = 0; q < (int)rtk[(size_t)i]; ++q) if (tg[q] >= 0) { ++n_link; l1 = tg[q]; }
             if (n_link != 1 || jk[(size_t)l1] != HS_LAT_EXPONENTIAL || lloss[(size_t)l1] != 0.0) h->net_uni = false;
+            if (h->net_uni && in_deg_h[(size_t)i] != 1) h->net_uni = false;        // exactly one incoming link per station
         }
     }
 #undef ALN

@@ -639,7 +639,7 @@ struct NetStation {
     __device__ __forceinline__ void fl_append(int64_t t_arr, int64_t t_send, int64_t created) {
         sent_min = t_arr < sent_min ? t_arr : sent_min;
         ++fl_q;
-        if (fl_remote) { outbox_append(fl_link, fl_dst, t_arr, t_send, created); return; }
+        if (HSU(fl_remote, false)) { outbox_append(fl_link, fl_dst, t_arr, t_send, created); return; }
         const size_t slot = (size_t)fl_link * ns->aq_cap + (size_t)(((unsigned long long)fl_q - 1) & (unsigned long long)(ns->aq_cap - 1));
         ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t_send); ag_store(&ns->aq_cr[slot], created);
         sent_async = true;
@@ -828,6 +828,7 @@ struct NetStation {
         return ea;
     }
     __device__ __forceinline__ int64_t async_receive(int64_t w_peek) {
+        if constexpr (UNI) return async_receive_one(w_peek);          // (every station has exactly one incoming link)
         if constexpr (FAST) { if (fi_link >= 0) return async_receive_one(w_peek); }
         int64_t H = kInfNs;
         undrained = kInfNs;
@@ -1177,7 +1178,7 @@ struct NetStation {
         if (msg) {
             ev[9]++;
             created_in = bg_cr(mi);
-            if (bg_link(mi) == fi_link) fi_packets++; else ns->link_packets[bg_link(mi)]++;
+            if (UNI || bg_link(mi) == fi_link) fi_packets++; else ns->link_packets[bg_link(mi)]++;
             bag_remove(mi);
         }
         // ---- Queue._handle_enqueue / QueueDriver._handle_notify
