@@ -73,3 +73,36 @@ def test_lb_32768_backends_3s_equals_the_oracle():
         eng.run(p["end_ns"])
         assert eng.summary().events_processed > 5_000_000
         H.compare_lb_engine_with_oracle(eng, p, r)
+
+
+def test_8192_chains_with_several_sources_and_probes_equal_the_single_heap_oracle():
+    """The round-2 station features at a size where every wavefront of the general-path kernel carries them: 8 192 chains, up to
+    four Sources per Server (Poisson and constant, listed extras-first), up to three probes per station, a bounded queue on every
+    third chain, 12 s -- one oracle heap, array equality (the prologue numbers 8 192 x ~2.5 first ticks + the probes)."""
+    from test_gpu_parity import _compare_engine_to_oracle
+
+    n = 8192
+    spec = dict(name="multi_full", n_chains=n, arr=["poisson" if i % 4 else "constant" for i in range(n)],
+                rate=[6.0 + (i % 5) for i in range(n)], svc="exp", mean=[0.04 + 0.01 * (i % 4) for i in range(n)],
+                concurrency=[1 + (i % 7 == 0) for i in range(n)], queue_cap=[3 if i % 3 == 0 else None for i in range(n)],
+                more_sources=[[["poisson", 3.0 + (i % 3)]] * (1 + i % 3) if i % 2 else None for i in range(n)],
+                sources_order="extras_first",
+                probes=[[["depth", 0.5], ["stats_accepted", 1.0], ["active_requests", 0.5]][: 1 + i % 3] if i % 5 == 0 else None
+                        for i in range(n)],
+                end_s=12.0, rng="philox", seed=77, mode="single")
+    runs = H.run_oracle_for_spec(spec)
+    eng, p = H.engine_for_spec(spec)
+    with eng:
+        eng.run_until(p["end_ns"])
+        _compare_engine_to_oracle(spec, eng, p, runs, check_kinds=False)
+        (chain_ids, nodes, r), = runs
+        more = {slot: eng.source_generated(slot) for slot in (1, 2, 3)}
+        for (c, slot), nd in r.xsrc_nodes.items():
+            assert more[slot][c] == r.generated[nd], (c, slot)
+        for (c, j), nd in r.probe_nodes_all.items():
+            if c % 250 == 0:
+                t, v = r.sinks[nd]
+                pt, pv = eng.read_probe(c, j)
+                np.testing.assert_array_equal(pt, t)
+                np.testing.assert_array_equal(pv, v)
+        assert r.events_processed > 5_000_000
