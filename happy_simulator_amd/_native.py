@@ -149,7 +149,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *HIPCC_FLAGS, os.path.join(CSRC, "hs_engine.hip"), os.path.join(CSRC, "hs_lb.hip"), "-o", LIB_PATH]
+    extra = []
+    if os.environ.get("HS_PROF_BUDGET_LOG2"):      # csrc/hs_profile.hpp: 2^N Simpson intervals per arrival before an LP is refused
+        extra.append(f"-DHS_PROF_BUDGET_LOG2={int(os.environ['HS_PROF_BUDGET_LOG2'])}")
+    cmd = [hipcc, *HIPCC_FLAGS, *extra, os.path.join(CSRC, "hs_engine.hip"), os.path.join(CSRC, "hs_lb.hip"), "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

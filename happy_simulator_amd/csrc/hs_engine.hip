@@ -206,10 +206,11 @@ __device__ __forceinline__ Candidate make_candidate(const Station<C, PF, UNI> &S
     if (t == kInfNs) return c;
     const int w = S.pick_root(t);
     c.t = t; c.valid = 1;
-    if (w == 0) c.t_created = S.crtA;
+    if (w == 0) { c.t_created = S.crtA; c.pad = 2; }
     else if (w >= kRootXSrc) {
 #pragma unroll
         for (int j = 0; j < kMaxXSrc; ++j) if (j == w - kRootXSrc) c.t_created = S.crtX[j];
+        c.pad = 3 + (w - kRootXSrc);
     }
     else if (w >= kRootProbe) {
 #pragma unroll
@@ -575,7 +576,7 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
             if (mode == HS_MODE_REPLICAS) overshoot_one<C, PF, UNI>(S);
             else {
                 mine = make_candidate<C, PF, UNI>(S);
-                mine.rank = (P.tie_rank != nullptr ? P.tie_rank[lp] : lp) + (mine.pad ? n : 0);
+                mine.rank = cand_rank(P, lp, n, mine.pad);
             }
         }
         store_station<C, PF, UNI>(S, X, lp, n);
@@ -1040,7 +1041,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
 
     NetStation<C> S;
     Candidate mine;
-    mine.valid = 0; mine.t = kInfNs; mine.t_created = 0; mine.lp = lp; mine.rank = lp;
+    mine.valid = 0; mine.t = kInfNs; mine.t_created = 0; mine.lp = lp; mine.rank = lp; mine.pad = 0;
     if (act) {
         load_net<C>(S, P, NP, X, NX, L, lp, n, qmem, enqpay, tid, send_idx, SC);
         for (;;) {
@@ -1055,18 +1056,20 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
             if (t != kInfNs) {
                 const int w = S.pick_root(t);
                 mine.t = t; mine.valid = 1;
-                if (w == 1) mine.t_created = S.crtA;
+                if (w == 1) { mine.t_created = S.crtA; mine.pad = 2; }
                 else if (w >= 64) mine.t_created = NX.bag_ts[(size_t)lp * NX.bag_cap + (w - 64)];
                 else if (w >= 56 && w < 56 + kMaxProbes) {
 #pragma unroll
                     for (int j = 0; j < kMaxProbes; ++j) if (j == w - 56) mine.t_created = S.crtP[j];
+                    mine.pad = 1;                                 // a Probe's tick ranks behind every Source (as in the station engine)
                 }
-                else if (w >= 48 && w < 48 + kMaxXSrc) mine.t_created = X.crtX[(size_t)(w - 48) * n + lp];
+                else if (w >= 48 && w < 48 + kMaxXSrc) { mine.t_created = X.crtX[(size_t)(w - 48) * n + lp]; mine.pad = 3 + (w - 48); }
                 else if (w == 62) mine.t_created = INT64_MIN;     // constructed before run()
                 else {
 #pragma unroll
                     for (int i = 0; i < C; ++i) if (i == w - 2) mine.t_created = S.crtD[i];
                 }
+                mine.rank = cand_rank(P, lp, n, mine.pad);        // ties on (time, creation time): `sources=[...]` order
             }
         }
         store_net<C>(S, X, NX, lp, n);
@@ -2165,7 +2168,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if ((rc = upload<int64_t>(h, &h->P.sched_off, st->sched_off, (size_t)n + 1, 0))) return rc;
         if ((rc = upload<int64_t>(h, &h->P.sched_t, st->sched_time_ns, (size_t)n_sched, 0))) return rc;
     }
-    h->P.tie_rank = nullptr;
+    h->P.tie_rank = nullptr; h->P.src_rank = nullptr; h->P.probe_rank_off = n;
     // the Sources in `sources=[...]` order: (LP, slot) pairs; default = LP-major, slot-minor
     std::vector<int32_t> so;
     std::vector<uint8_t> sslot;
@@ -2189,12 +2192,16 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
                 for (int j = 0; j <= kMaxXSrc; ++j) if (has_src(i, j)) { so.push_back(i); sslot.push_back((uint8_t)j); }
         }
     }
-    if (st->source_order) {   // cross-LP ties go to the LP whose (first) Source the reference constructed first
-        std::vector<int32_t> tr((size_t)n, -1);
-        int32_t k = 0;
-        for (size_t q = 0; q < so.size(); ++q) if (tr[(size_t)so[q]] < 0) tr[(size_t)so[q]] = k++;
-        for (int i = 0; i < n; ++i) if (tr[(size_t)i] < 0) tr[(size_t)i] = k++;
+    if (st->source_order) {   // cross-LP ties go to the Source the reference constructed first (cand_rank, hs_station.hpp)
+        std::vector<int32_t> tr((size_t)n, -1), sr((size_t)n * (kMaxXSrc + 1), -1);
+        for (size_t q = 0; q < so.size(); ++q) {
+            sr[(size_t)sslot[q] * n + (size_t)so[q]] = (int32_t)q;               // a tick: its own Source's position
+            if (tr[(size_t)so[q]] < 0) tr[(size_t)so[q]] = (int32_t)q;           // anything else: the LP's first-listed Source
+        }
+        for (int i = 0; i < n; ++i) if (tr[(size_t)i] < 0) tr[(size_t)i] = (int32_t)so.size() + i;   // sourceless LPs after them
         if ((rc = upload<int32_t>(h, &h->P.tie_rank, tr.data(), (size_t)n, 0))) return rc;
+        if ((rc = upload<int32_t>(h, &h->P.src_rank, sr.data(), sr.size(), 0))) return rc;
+        h->P.probe_rank_off = (int32_t)so.size() + n;
     }
     h->P.sched_idx = nullptr;
     if (h->cfg.mode == HS_MODE_REPLICAS && (n_sched > 0 || h->any_probe || h->any_xsrc)) {

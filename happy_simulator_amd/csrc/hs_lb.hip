@@ -1282,6 +1282,10 @@ int run_async(hs_lb *h, int64_t end_ns) {
     const int S = h->cfg.n_sources, B = h->cfg.n_backends;
     h->launches = 0;
     hipLaunchKernelGGL(hs_lb_clear, dim3(1), dim3(1), 0, h->stream, h->tot);
+    if (h->any_src_profile) {          // (this translation unit's own instance of the evaluation-budget flag, hs_profile.hpp)
+        const unsigned long long zero = 0ull;
+        LB_HIP(h, hipMemcpyToSymbolAsync(HIP_SYMBOL(hs_prof_budget_hit), &zero, sizeof zero, 0, hipMemcpyHostToDevice, h->stream));
+    }
     if (h->any_src_profile)
         hipLaunchKernelGGL(hs_lbk_sources<true>, dim3((S + kLbBlock - 1) / kLbBlock), dim3(kLbBlock), 0, h->stream, h->PS, S, h->cfg.seed,
                            h->cfg.start_ns, end_ns, h->client_be, h->n_table, h->keys0, h->vals0, h->cap, h->tb, h->tot);
@@ -1359,6 +1363,14 @@ int check_flags(hs_lb *h) {
     LB_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
     if (t.qoverflow) return lfail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
     if (t.bad_client & 1) return lfail(h, HS_E_INVALID, "a client id fell outside the client table");
+    if (h->any_src_profile) {          // a Source whose inversion gave up would simply stop ticking: never silently
+        unsigned long long hit = 0ull;
+        LB_HIP(h, hipMemcpyFromSymbol(&hit, HIP_SYMBOL(hs_prof_budget_hit), sizeof hit, 0, hipMemcpyDeviceToHost));
+        if (hit != 0ull)
+            return lfail(h, HS_E_UNSUPPORTED, "Source %lld: one arrival of its time-varying profile needs more than %lld adaptive-Simpson "
+                         "intervals (csrc/hs_profile.hpp; check with tools/profile_cost.py) -- refused instead of stalling a lane",
+                         (long long)hit - 2, (long long)kProfBudget);
+    }
     if (t.bad_client & 2) return lfail(h, HS_E_OVERFLOW, "a source's tick log overflowed (capacity %lld ticks); raise tick_capacity", (long long)h->cap);
     if (t.probe_tie & 1) return lfail(h, HS_E_UNSUPPORTED, "a probe sample fell on the nanosecond of an event of its target: on load-balancer "
                                       "graphs that order (the reference's sort indices) is not lowered");

@@ -23,12 +23,18 @@ struct Profile {
 };
 
 // Evaluation budget of ONE next_arrival_time call.  The reference's adaptive Simpson rule works on a rate that is quantised to
-// whole nanoseconds; on a ramp whose bracket is wide (a first arrival drawn from a near-zero rate) its error test is only met
-// once the intervals are narrower than 1 ns -- 8e7 rate evaluations for a single arrival, minutes in the reference's Python
-//  and an unbounded stall for the one lane that inherits it here.  Typical arrivals need 10-100
-// intervals.  Beyond the budget the LP is reported (HS_E_UNSUPPORTED naming it) instead of spinning: hs_prof_budget_hit =
-// 1 + LP of the first offender.
-constexpr long long kProfBudget = 1ll << 20;       // Simpson intervals per arrival (3 rate evaluations each)
+// whole nanoseconds; where that quantisation noise exceeds the (halving) tolerance -- a wide bracket on a ramp: a first arrival
+// drawn from a near-zero rate, or an arrival that spans the end of a ramp towards a low rate -- its error test is only met once
+// the intervals are narrower than 1 ns: 10^6 .. 10^8 rate evaluations for a single arrival (seconds to minutes in the reference's
+// Python).  Typical arrivals need 10-100 intervals.  One lane walks the recursion alone (measured on
+// MI355X: 2.9 us per interval -- a dependent fp64 chain plus the explicit stack in scratch), so the budget is a TIME guard: 2^20
+// intervals = 3 s.  Beyond it the LP is reported (HS_E_UNSUPPORTED naming it) instead of stalling its wavefront:
+// hs_prof_budget_hit = 1 + LP of the first offender.  Build with HS_PROF_BUDGET_LOG2=24 (python: the environment variable of
+// that name before build()) to let such arrivals run: tests/random_specs.py station_spec(1011) then takes 22 s and is exact.
+#ifndef HS_PROF_BUDGET_LOG2
+#define HS_PROF_BUDGET_LOG2 20
+#endif
+constexpr long long kProfBudget = 1ll << HS_PROF_BUDGET_LOG2;   // Simpson intervals per arrival (3 rate evaluations each)
 __device__ unsigned long long hs_prof_budget_hit = 0ull;
 
 // rate_fn(t) = profile.get_rate(Instant.from_seconds(t))

@@ -138,7 +138,8 @@ typedef struct hs_stations {
      * runs the first N_init constructions of the run in the reference's exact heap order (csrc/hs_exact.hpp) so that every
      * same-nanosecond meeting of the two counters is decided as the reference decides it.  All three NULL = LP order /
      * array order. */
-    const int32_t *source_order;       /* [number of LPs with a Source] LP indices in `sources=` order */
+    const int32_t *source_order;       /* [number of Sources] LP indices in `sources=` order (also the last key of the election of
+                                        * the one event beyond end_time: a pending tick ranks by its own Source's position here) */
     const int32_t *probe_order;        /* [number of LPs with a Probe] LP indices in `probes=` order */
     /* More than one Probe on an LP (Probe.on_many, instrumentation/probe.py:119-164): slots 1 .. 3 (slot 0 = probe_metric /
      * probe_interval_s above); slots are filled from 0.  probe_slot_order[k] = slot of the k-th entry of probe_order (an LP

@@ -515,7 +515,7 @@ def ring_arrays(spec, bag_capacity=0, log_capacity=0):
     )
     # external rate 4/s + forwarded 4/s per station: size the logs for the total admission rate
     horizon_s = p["end_ns"] / 1e9
-    lam = 2.0 * float(rates.max()) + 1.0
+    lam = 2.0 * float(max(rates.max(), (st.src_rate * (st.src_kind != N.SRC_NONE)).max())) + 1.0   # (src_rate: a profile's peak)
     cap = log_capacity or int(lam * horizon_s + 10 * (lam * horizon_s) ** 0.5 + 64)
     return st, net, cap, p
 

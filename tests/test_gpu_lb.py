@@ -181,6 +181,30 @@ def test_lb_source_profiles_on_random_configurations_match_oracle(k):
         H.compare_lb_engine_with_oracle(eng, p, r)
 
 
+def test_lb_source_whose_inversion_exceeds_the_evaluation_budget_is_refused_not_silently_stopped():
+    """random_specs.lb_profile_spec(1351), found by tools/gpu_random_sweep.py: a Source's ramp ends at 2.25 requests/s and the
+    arrival that spans the end needs ~2^24 adaptive-Simpson intervals (the reference: seconds of Python; one GPU lane: ~50 s).
+    The station engine refused such an LP by name; the load-balancer engine did not look at the flag, the Source simply stopped
+    ticking and the run came back three requests short.  Now HS_E_UNSUPPORTED names the Source (unless the library was built
+    with a larger HS_PROF_BUDGET_LOG2, in which case the run must be exact)."""
+    import random_specs as RS
+    from happy_simulator_amd import _native as N
+
+    spec = RS.lb_profile_spec(1351)
+    g, p = H.oracle_lb_graph(spec)
+    eng, _ = H.lb_engine_for_spec(spec)
+    with eng:
+        try:
+            eng.run(p["end_ns"])
+        except N.EngineError as e:
+            assert "Source 1" in str(e) and "adaptive-Simpson" in str(e)
+            return
+        r = O.run(g, p["end_ns"], seed=spec["seed"])
+        for nd in g.lb_probe_nodes:
+            r.sinks.pop(nd)
+        H.compare_lb_engine_with_oracle(eng, p, r)
+
+
 def test_lb_probe_on_the_nanosecond_of_a_target_event_is_refused():
     """Constant-rate Sources ticking every 0.1 s and a probe sampling their backend every 0.5 s: the sample falls on arrival
     nanoseconds, whose order against the probe's chain is the reference's sort-index ledger -- refused, never guessed."""

@@ -1,0 +1,159 @@
+"""MI355X: a one-off differential sweep, engine == oracle, over MANY more seeded random configurations than the test suite
+keeps (tests/random_specs.py; the build container ran the LIVE reference against the oracle on the same generators:
+tests/test_oracle_live_reference.py).  Every family goes through the checker its `-m gpu` test uses.
+
+    python tools/gpu_random_sweep.py [--first 1000] [--count 400] [--seconds 150] > profiles/rNN_gpu_random_sweep.log
+
+Prints one line per mismatch (family, case, first lines of the assertion) and a summary per family; exit status 1 if anything
+differed.  Case numbers start at --first so that the sweep does not repeat the suite's cases.
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+import helpers as H  # noqa: E402
+import random_specs as RS  # noqa: E402
+import test_gpu_random as TR  # noqa: E402
+from oracle import hs_oracle as O  # noqa: E402
+from test_gpu_ring import _check_against_oracle  # noqa: E402
+
+
+def station(k):
+    TR.check_station_case(k)
+
+
+def tie(k):
+    TR.check_station_case(k, RS.tie_spec(k))
+
+
+def multi_source(k):
+    spec = RS.multi_source_spec(k)
+    TR.check_station_case(k, dict(spec))
+    runs = H.run_oracle_for_spec(spec)
+    eng, p = H.engine_for_spec(spec)
+    with eng:
+        eng.run_until(p["end_ns"])
+        more = {slot: eng.source_generated(slot) for slot in (1, 2, 3)}
+        for _chain_ids, _nodes, r in runs:
+            for (c, slot), nd in r.xsrc_nodes.items():
+                assert more[slot][c] == r.generated[nd], (c, slot)
+
+
+def _ring(spec, flags):
+    g, nodes = H.oracle_ring_graph(spec)
+    p = H.ring_params(spec)
+    r = O.run(g, p["end_ns"], seed=spec["seed"], schedule=[(nodes[c]["srv"], t) for c, t in p["schedule"]])
+    eng, p = H.ring_engine_for_spec(spec, flags=flags)
+    with eng:
+        eng.run_until(p["end_ns"])
+        _check_against_oracle(spec, eng, r, nodes)
+        for i in range(spec["n"]):
+            if "prb" in nodes[i]:
+                t, v = r.sinks[nodes[i]["prb"]]
+                pt, pv = eng.read_probe(i)
+                np.testing.assert_array_equal(pt, t, err_msg=f"probe times station {i}")
+                np.testing.assert_array_equal(pv, v, err_msg=f"probe values station {i}")
+            for j in (1, 2, 3):
+                if f"src{j}" in nodes[i]:
+                    assert eng.source_generated(j)[i] == r.generated[nodes[i][f"src{j}"]], (i, j)
+
+
+def ring_async(k):
+    _ring(RS.ring_spec(k), 0)
+
+
+def ring_windowed(k):
+    _ring(RS.ring_spec(k), 16)
+
+
+def multi_source_ring_async(k):
+    _ring(RS.multi_source_ring_spec(k), 0)
+
+
+def multi_source_ring_windowed(k):
+    _ring(RS.multi_source_ring_spec(k), 16)
+
+
+def _lb(spec, flags=0):
+    g, p = H.oracle_lb_graph(spec)
+    r = O.run(g, p["end_ns"], seed=spec["seed"])
+    eng, _ = H.lb_engine_for_spec(spec, flags=flags)
+    with eng:
+        eng.run(p["end_ns"])
+        sinks = dict(r.sinks)
+        for j, nd in enumerate(g.lb_probe_nodes):
+            t, v = sinks.pop(nd)
+            pt, pv = eng.read_probe(j)
+            np.testing.assert_array_equal(pt, t, err_msg=f"probe {j} times")
+            np.testing.assert_array_equal(pv, v, err_msg=f"probe {j} values")
+        r.sinks = sinks
+        H.compare_lb_engine_with_oracle(eng, p, r)
+
+
+def lb(k):
+    _lb(RS.lb_spec(k), flags=(0, 1, 2, 4)[k % 4])
+
+
+def lb_probes(k):
+    _lb(RS.lb_probe_spec(k))
+
+
+def lb_profiles(k):
+    _lb(RS.lb_profile_spec(k))
+
+
+FAMILIES = [station, tie, multi_source, ring_async, ring_windowed, multi_source_ring_async, multi_source_ring_windowed, lb,
+            lb_probes, lb_profiles]
+# known, documented: the cross-LP election of the one event beyond end_time (deviation (i))
+KNOWN = {("tie", 85), ("tie", 134), ("tie", 279), ("tie", 978)}
+# refused by design (HS_E_UNSUPPORTED), never guessed: a probe on the nanosecond of an event of its target on a load-balancer
+# graph; an arrival whose numerical inversion exceeds the evaluation budget (the reference needs minutes for it)
+REFUSALS = ("nanosecond of an event of its target", "adaptive-Simpson intervals")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--first", type=int, default=1000)
+    ap.add_argument("--count", type=int, default=400)
+    ap.add_argument("--seconds", type=float, default=150.0, help="wall-clock budget for the whole sweep")
+    ap.add_argument("--families", default="")
+    a = ap.parse_args()
+    fams = [f for f in FAMILIES if not a.families or f.__name__ in a.families.split(",")]
+    t_end = time.time() + a.seconds
+    bad = 0
+    tally = {f.__name__: [0, 0, 0, 0] for f in fams}          # run, exact, refused, differed
+    for i in range(a.count):                                   # round-robin: a cut-off sweep still covers every family
+        if time.time() > t_end:
+            break
+        for f in fams:
+            k = a.first + i
+            row = tally[f.__name__]
+            row[0] += 1
+            try:
+                f(k)
+                row[1] += 1
+            except Exception as e:  # noqa: BLE001 -- a sweep reports and goes on
+                text = " | ".join(str(e).strip().splitlines()[:5])[:300]
+                if any(s in text for s in REFUSALS):
+                    row[2] += 1
+                    continue
+                row[3] += 1
+                known = (f.__name__, k) in KNOWN
+                bad += 0 if known else 1
+                print(f"DIFF {f.__name__} {k}{' (known: deviation (i))' if known else ''}: {type(e).__name__}: {text}", flush=True)
+    print(f"{'family':32s} {'run':>6s} {'exact':>6s} {'refused':>8s} {'differ':>7s}")
+    for name, (n, ok, ref, df) in tally.items():
+        print(f"{name:32s} {n:6d} {ok:6d} {ref:8d} {df:7d}")
+    print(f"cases {a.first}..{a.first + max(r[0] for r in tally.values()) - 1}; unexpected differences: {bad}")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--constant-arrivals", action="store_true", help="Source.with_profile(poisson=False): target area 1.0")
     ap.add_argument("--arrivals", type=int, default=8)
     ap.add_argument("--slow-s", type=float, default=0.01, help="host seconds per arrival above which a line is flagged")
+    ap.add_argument("--budget-log2", type=int, default=0, help="compile with another evaluation budget (2^N Simpson intervals per arrival)")
     a = ap.parse_args()
     kind, p = (1, list(a.ramp) + [0.0]) if a.ramp else (2, list(a.spike))
     with tempfile.TemporaryDirectory() as d:
@@ -93,6 +94,7 @@ def main():
         open(os.path.join(d, "main.cpp"), "w").write(MAIN)
         exe = os.path.join(d, "profile_cost")
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I", d, "-I", CSRC,
+                               *([f"-DHS_PROF_BUDGET_LOG2={a.budget_log2}"] if a.budget_log2 else []),
                                os.path.join(d, "main.cpp"), "-o", exe])
         return subprocess.call([exe, str(kind), *[repr(x) for x in p], str(a.seed), str(a.station),
                                 "0" if a.constant_arrivals else "1", str(a.arrivals), repr(a.slow_s)])
