@@ -2168,7 +2168,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if ((rc = upload<int64_t>(h, &h->P.sched_off, st->sched_off, (size_t)n + 1, 0))) return rc;
         if ((rc = upload<int64_t>(h, &h->P.sched_t, st->sched_time_ns, (size_t)n_sched, 0))) return rc;
     }
-    h->P.tie_rank = nullptr; h->P.src_rank = nullptr; h->P.probe_rank_off = n;
+    h->P.tie_rank = nullptr;
     // the Sources in `sources=[...]` order: (LP, slot) pairs; default = LP-major, slot-minor
     std::vector<int32_t> so;
     std::vector<uint8_t> sslot;
@@ -2193,15 +2193,15 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         }
     }
     if (st->source_order) {   // cross-LP ties go to the Source the reference constructed first (cand_rank, hs_station.hpp)
-        std::vector<int32_t> tr((size_t)n, -1), sr((size_t)n * (kMaxXSrc + 1), -1);
+        std::vector<int32_t> tr((size_t)n * (kMaxXSrc + 2) + 1, -1);
+        int32_t *sr = tr.data() + n;
         for (size_t q = 0; q < so.size(); ++q) {
             sr[(size_t)sslot[q] * n + (size_t)so[q]] = (int32_t)q;               // a tick: its own Source's position
             if (tr[(size_t)so[q]] < 0) tr[(size_t)so[q]] = (int32_t)q;           // anything else: the LP's first-listed Source
         }
         for (int i = 0; i < n; ++i) if (tr[(size_t)i] < 0) tr[(size_t)i] = (int32_t)so.size() + i;   // sourceless LPs after them
-        if ((rc = upload<int32_t>(h, &h->P.tie_rank, tr.data(), (size_t)n, 0))) return rc;
-        if ((rc = upload<int32_t>(h, &h->P.src_rank, sr.data(), sr.size(), 0))) return rc;
-        h->P.probe_rank_off = (int32_t)so.size() + n;
+        tr[(size_t)n * (kMaxXSrc + 2)] = (int32_t)so.size() + n;                 // Probes behind all of them
+        if ((rc = upload<int32_t>(h, &h->P.tie_rank, tr.data(), tr.size(), 0))) return rc;
     }
     h->P.sched_idx = nullptr;
     if (h->cfg.mode == HS_MODE_REPLICAS && (n_sched > 0 || h->any_probe || h->any_xsrc)) {

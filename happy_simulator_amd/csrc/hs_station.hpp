@@ -109,11 +109,11 @@ struct StationParams {          // read-only, [n_lp] each
     // cross-LP ties the creation times do not decide go to the Source the reference constructed first: the LP's position in
     // `sources=[...]` (sourceless LPs after them); null = LP order
     const int32_t *tie_rank;
-    // ... and a pending TICK competes with its own Source's position in that list ([kMaxXSrc + 1][n_lp] by slot, null = LP order):
-    // two lock-step Sources of different LPs tie on (time, creation time) at every tick, and the LP whose first-listed Source is
-    // another one need not come first.  A Probe's tick ranks behind every Source and every sourceless LP (`probe_rank_off`).
-    const int32_t *src_rank;
-    int32_t probe_rank_off;
+    // ... [n_lp] those LP ranks, then [kMaxXSrc + 1][n_lp] the position of every SOURCE in that list by slot (a pending TICK
+    // competes with its own Source's position: two lock-step Sources of different LPs tie on (time, creation time) at every
+    // tick, and the LP whose first-listed Source is another one need not come first), then one word: the offset that puts a
+    // Probe's tick behind every Source and every sourceless LP.  One array, so that the run kernels carry no further argument
+    // through their loops (two more kernel arguments cost the headline kernel 2 % -- SGPR pressure, measured); cand_rank().
     // further Sources of the LP (PF instantiations, general path): null = none
     const uint8_t *xsrc_kind;       // [kMaxXSrc][n_lp] 0 none, 1 Poisson, 2 constant
     const double *xsrc_rate;        // [kMaxXSrc][n_lp]
@@ -192,10 +192,11 @@ struct Candidate {              // an LP's first event beyond end_ns (SINGLE-mod
                                 // 2 + slot the tick of the LP's Source in that slot
 };
 
-// the last election key of an LP's candidate (see StationParams::tie_rank / src_rank)
+// the last election key of an LP's candidate (see StationParams::tie_rank)
 __device__ __forceinline__ int cand_rank(const StationParams &P, int lp, int n, int pad) {
-    if (pad >= 2 && P.src_rank != nullptr) return P.src_rank[(size_t)(pad - 2) * (size_t)n + lp];
-    return (P.tie_rank != nullptr ? P.tie_rank[lp] : lp) + (pad == 1 ? P.probe_rank_off : 0);
+    if (P.tie_rank == nullptr) return lp + (pad == 1 ? n : 0);
+    if (pad >= 2) return P.tie_rank[(size_t)(pad - 1) * (size_t)n + lp];
+    return P.tie_rank[lp] + (pad == 1 ? P.tie_rank[(size_t)(kMaxXSrc + 2) * (size_t)n] : 0);
 }
 
 // ---------------------------------------------------------------------------------------------
