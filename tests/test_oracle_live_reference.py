@@ -1,5 +1,5 @@
 """CPU, build container only (needs /root/reference): the oracle against the LIVE reference on randomly drawn
-configurations -- beyond the 52 committed fixtures, which were produced by exactly the same code path
+configurations -- beyond the 55 committed fixtures, which were produced by exactly the same code path
 (tests/golden/make_golden.py: the reference's own event loop, queue protocol, Server generator and sort-index ledger with
 per-entity Philox streams plugged in through its extension points).  Every count, statistic, Sink record and, for the
 small cases, the full processed-event trace incl. `_sort_index`.  Skipped where the reference is absent (the GPU box)."""
