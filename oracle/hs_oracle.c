@@ -21,6 +21,12 @@ typedef struct {
     int32_t node;   /* target node                                            */
     int32_t req;    /* request slot (payload / context), -1 if none           */
     int32_t aux;    /* per-kind scratch (service slot ...)                    */
+#ifdef HSO_LINEAGE  /* analysis build only (tools/election_rules.py): when was it created, and its creator, and that one's */
+    int64_t crt, crt2, crt3;
+    /* ... and its place in the FIFO that the heap is among events of one nanosecond: how many steps after the root of the group
+     * it was created in (cdepth), when that root was created and how deep in ITS group (rcrt, rcdepth), and once more */
+    int64_t cdepth, rcrt, rcdepth, r2crt, r2cdepth;
+#endif
 } hso_event;
 
 /* request = the payload Event's identity + its context dict
@@ -85,6 +91,11 @@ struct hso_sim {
     hsr_mt19937 mt_py, mt_np;
     /* trace */
     int64_t *tr_t; int32_t *tr_kind; int32_t *tr_node; int64_t *tr_idx; int64_t tr_len;
+#ifdef HSO_LINEAGE
+    int cur_valid; int64_t cur_crt, cur_crt2;      /* the event being processed (creator of what is pushed now) */
+    int64_t g_depth, g_rcrt, g_rcdepth, g_r2crt, g_r2cdepth;   /* ... its depth in the current group and the group's root */
+    hso_event *dump; int64_t dump_len;             /* everything pending when the one event beyond end_ns was popped, it first */
+#endif
 };
 
 /* ------------------------------------------------------------------ heap
@@ -96,6 +107,14 @@ static int ev_lt(const hso_event *a, const hso_event *b) {
     return a->idx < b->idx;
 }
 static void heap_push(hso_sim *s, hso_event e) {
+#ifdef HSO_LINEAGE
+    e.crt = s->cur_valid ? s->current_ns : INT64_MIN;          /* INT64_MIN: constructed before run() */
+    e.crt2 = s->cur_valid ? s->cur_crt : INT64_MIN;
+    e.crt3 = s->cur_valid ? s->cur_crt2 : INT64_MIN;
+    e.cdepth = s->cur_valid ? s->g_depth + 1 : 0;
+    e.rcrt = s->cur_valid ? s->g_rcrt : INT64_MIN; e.rcdepth = s->cur_valid ? s->g_rcdepth : 0;
+    e.r2crt = s->cur_valid ? s->g_r2crt : INT64_MIN; e.r2cdepth = s->cur_valid ? s->g_r2cdepth : 0;
+#endif
     if (s->heap_len == s->heap_cap) {
         s->heap_cap = s->heap_cap ? s->heap_cap * 2 : 1024;
         s->heap = (hso_event *)realloc(s->heap, (size_t)s->heap_cap * sizeof(hso_event));
@@ -840,6 +859,20 @@ int hso_run_until(hso_sim *s, int64_t end_ns) {
     while (s->heap_len > 0 && s->current_ns <= end_ns) {            /* :472 tests the PREVIOUS event's time */
         hso_event e = heap_pop(s);
         if (e.time < s->current_ns) continue;                       /* time travel drop, :480-489 */
+#ifdef HSO_LINEAGE
+        if (e.time > end_ns && s->dump == NULL) {
+            s->dump = (hso_event *)malloc((size_t)(s->heap_len + 1) * sizeof(hso_event));
+            s->dump[0] = e;
+            memcpy(s->dump + 1, s->heap, (size_t)s->heap_len * sizeof(hso_event));
+            s->dump_len = s->heap_len + 1;
+        }
+        s->cur_valid = 1; s->cur_crt = e.crt; s->cur_crt2 = e.crt2;
+        if (e.crt < e.time) {          /* created earlier: the root of a chain of this nanosecond's group */
+            s->g_depth = 0; s->g_rcrt = e.crt; s->g_rcdepth = e.cdepth; s->g_r2crt = e.rcrt; s->g_r2cdepth = e.rcdepth;
+        } else {                       /* created in this very nanosecond: it carries its group's context */
+            s->g_depth = e.cdepth; s->g_rcrt = e.rcrt; s->g_rcdepth = e.rcdepth; s->g_r2crt = e.r2crt; s->g_r2cdepth = e.r2cdepth;
+        }
+#endif
         s->current_ns = e.time;
         s->processed++;
         s->by_kind[e.kind]++;
@@ -865,6 +898,21 @@ int hso_run_until(hso_sim *s, int64_t end_ns) {
     }
     return 0;
 }
+
+#ifdef HSO_LINEAGE
+/* rows of (time, sort index, kind, node, created, creator created, its creator created, cdepth, rcrt, rcdepth, r2crt,
+ * r2cdepth); row 0 = the event the reference processed beyond end_ns */
+int64_t hso_read_dump(const hso_sim *s, int64_t *rows, int64_t cap) {
+    const int64_t n = s->dump_len < cap ? s->dump_len : cap;
+    for (int64_t i = 0; i < n; ++i) {
+        const hso_event *e = &s->dump[i];
+        int64_t *r = rows + 12 * i;
+        r[0] = e->time; r[1] = (int64_t)e->idx; r[2] = e->kind; r[3] = e->node; r[4] = e->crt; r[5] = e->crt2; r[6] = e->crt3;
+        r[7] = e->cdepth; r[8] = e->rcrt; r[9] = e->rcdepth; r[10] = e->r2crt; r[11] = e->r2cdepth;
+    }
+    return s->dump_len;
+}
+#endif
 
 void hso_get_summary(const hso_sim *s, hso_summary *out) {
     out->events_processed = s->processed;
@@ -924,6 +972,9 @@ int64_t hso_read_trace(const hso_sim *s, int64_t *t_ns, int32_t *kind, int32_t *
 
 void hso_destroy(hso_sim *s) {
     if (!s) return;
+#ifdef HSO_LINEAGE
+    free(s->dump);
+#endif
     for (int32_t i = 0; i < s->g.n_nodes; ++i) {
         free(s->nodes[i].fifo.buf); free(s->nodes[i].sink_t); free(s->nodes[i].sink_created);
         free(s->nodes[i].ring); free(s->nodes[i].lb_total_requests);

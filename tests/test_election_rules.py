@@ -1,0 +1,39 @@
+"""CPU: the emulation of the engines' election of the one event beyond end_time (tools/election_rules.py, an analysis build of
+the oracle) stays in step with what MI355X measured -- the engine's key fails on exactly the tie storms the GPU fails on
+(tests/test_gpu_random.py leaves out case 85; profiles/r02_gpu_random_sweep*.log) -- and the key that DESIGN.md section 9 names
+as the fix (the heap is a FIFO inside one nanosecond: creation time, steps from the group's root, the root's creation time,
+construction rank; Probes by their own list position) elects the reference's LP on every one of them."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "election_rules.py"), *args], capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = {}
+    for ln in out.stdout.splitlines():
+        if " wrong on " in ln:
+            name, rest = ln.strip().split(" wrong on ")
+            rows[name.strip()] = eval(rest.split(":", 1)[1])          # the list of case numbers
+    return rows
+
+
+def test_election_emulation_matches_the_gpu_and_the_fifo_key_closes_the_deviation():
+    rows = _run("--first", "0", "--count", "1000")
+    assert rows["engine: (created, rank)"] == [85, 134, 279, 978]          # = the GPU's four of 1 000
+    assert rows["(created, depth, root created, rank)"] == []
+    rows = _run("--first", "2000", "--count", "353")
+    assert rows["engine: (created, rank)"] == [2079, 2150]                 # = the second GPU sweep's two
+    assert rows["(created, depth, root created, rank; Probes by their own list position)"] == []
+
+
+def test_a_tick_ranks_by_its_own_source_position():
+    """The rank fix of round 2 (csrc/hs_station.hpp cand_rank), on the several-Sources generator: the key the engine had before
+    the GPU sweep fails on multi_source_spec(1374) -- the case the sweep found -- and the present one does not."""
+    rows = _run("--family", "multi_source", "--first", "1300", "--count", "100")
+    assert 1374 in rows["engine before the GPU sweep: (created, LP's first-listed Source)"]
+    assert rows["engine: (created, rank)"] == []
