@@ -18,7 +18,7 @@ def _run(*args):
     for ln in out.stdout.splitlines():
         if " wrong on " in ln:
             name, rest = ln.strip().split(" wrong on ")
-            rows[name.strip()] = eval(rest.split(":", 1)[1])          # the list of case numbers
+            rows[name.strip()] = eval(rest.split("):", 1)[1])         # the list of case numbers
     return rows
 
 
