@@ -36,7 +36,7 @@ EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuat
 PROBE_METRICS = {"depth": 0, "active_requests": 1, "stats_accepted": 2, "stats_dropped": 3, "requests_completed": 4,
                  "_requests_completed": 4, "events_received": 5, "generated_count": 6}
 PROBE_NONE = 255
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class EngineUnavailable(RuntimeError):
@@ -136,26 +136,77 @@ class LbStats(C.Structure):
                                           "rejected", "total_service_s", "queue_depth", "active", "sink_received")]
 
 
+_TUS = ("hs_engine.hip", "hs_lb.hip", "hs_tables.hip")          # one object each ...
+_INST_TU, _INST_GROUPS = "hs_inst.hip", 13                      # ... plus hs_inst.hip once per instantiation group (csrc/hs_kernels.hpp)
+STAMP_PATH = os.path.join(LIB_DIR, "libhs_hip.stamp")
+
+
 def sources() -> list[str]:
-    return [os.path.join(CSRC, f) for f in ("hs_engine.hip", "hs_lb.hip", "hs_station.hpp", "hs_netstation.hpp",
-                                            "hs_device.hpp", "hs_radix.hpp", "hs_profile.hpp", "hs_exact.hpp")] + [
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))] + [
         os.path.join(INCLUDE, "hs_engine.h")]
 
 
+def _sources_hash() -> str:
+    """Content hash of everything the library is built from (mtimes do not survive the copy to a GPU box)."""
+    import hashlib
+    hh = hashlib.sha256()
+    for src in sources():
+        hh.update(os.path.basename(src).encode())
+        with open(src, "rb") as f:
+            hh.update(f.read())
+    hh.update(" ".join(HIPCC_FLAGS).encode())
+    return hh.hexdigest()
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP_PATH):
+        return True
+    with open(STAMP_PATH) as f:
+        return f.read().strip() != _sources_hash()
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Cross-compile libhs_hip.so for gfx950 with hipcc (works without a GPU)."""
+    """Cross-compile libhs_hip.so for gfx950 with hipcc (works without a GPU): every translation unit -- and every group of
+    kernel instantiations of hs_inst.hip -- is its own object, compiled in parallel (HS_BUILD_JOBS, default = CPU count),
+    then linked.  Objects whose inputs did not change are kept."""
+    import concurrent.futures
+    import hashlib
+
     os.makedirs(LIB_DIR, exist_ok=True)
-    srcs = sources()
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
+    if not force and not is_stale():
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = []
-    if os.environ.get("HS_PROF_BUDGET_LOG2"):      # csrc/hs_profile.hpp: 2^N Simpson intervals per arrival before an LP is refused
-        extra.append(f"-DHS_PROF_BUDGET_LOG2={int(os.environ['HS_PROF_BUDGET_LOG2'])}")
-    cmd = [hipcc, *HIPCC_FLAGS, *extra, os.path.join(CSRC, "hs_engine.hip"), os.path.join(CSRC, "hs_lb.hip"), "-o", LIB_PATH]
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    want = _sources_hash()
+    jobs = [(tu, [], os.path.join(obj_dir, tu.replace(".hip", ".o"))) for tu in _TUS]
+    jobs += [(_INST_TU, [f"-DHS_INST={k}"], os.path.join(obj_dir, f"hs_inst_{k}.o")) for k in range(_INST_GROUPS)]
+
+    def compile_one(job):
+        tu, defs, obj = job
+        tag = obj + ".stamp"
+        if not force and os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == want:
+            return obj
+        cmd = [hipcc, *flags, *defs, "-c", os.path.join(CSRC, tu), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        with open(tag, "w") as f:
+            f.write(want)
+        return obj
+
+    n_jobs = int(os.environ.get("HS_BUILD_JOBS", "0")) or (os.cpu_count() or 4)
+    # the longest compilations first (the asynchronous network kernels)
+    order = sorted(jobs, key=lambda j: 0 if "hs_inst" in j[2] and any(f"_{k}.o" in j[2] for k in (8, 9, 10, 11, 12, 5, 6, 7)) else 1)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=n_jobs) as ex:
+        objs = list(ex.map(compile_one, order))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *sorted(objs), "-o", LIB_PATH]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP_PATH, "w") as f:
+        f.write(want)
     return LIB_PATH
 
 
@@ -168,8 +219,7 @@ def lib():
     if _lib is not None:
         return _lib
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    stale = (not os.path.exists(LIB_PATH)) or any(
-        os.path.getmtime(src) > os.path.getmtime(LIB_PATH) for src in sources() if os.path.exists(src))
+    stale = is_stale()
     if stale and os.path.exists(hipcc) and not os.environ.get("HS_HIP_LIB"):
         build()     # never run a library older than its sources
     if not os.path.exists(LIB_PATH):
@@ -254,6 +304,13 @@ def lib():
                                  C.c_void_p, C.c_void_p, C.c_void_p]
     L.hs_debug_const_div.restype = C.c_int
     L.hs_debug_const_div.argtypes = [C.c_int32, C.c_double, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hs_engine_set_profile_budget.restype = C.c_int
+    L.hs_engine_set_profile_budget.argtypes = [C.c_void_p, C.c_int64]
+    L.hs_lb_set_profile_budget.restype = C.c_int
+    L.hs_lb_set_profile_budget.argtypes = [C.c_void_p, C.c_int64]
+    L.hs_debug_tick_table.restype = C.c_int64
+    L.hs_debug_tick_table.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_int64,
+                                      C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     L.hs_lb_create.restype = C.c_int
     L.hs_lb_create.argtypes = [P(LbConfig), P(LbSources), P(LbBackends), P(C.c_void_p)]
     L.hs_lb_run.restype = C.c_int
@@ -313,5 +370,5 @@ EXPORTED_SYMBOLS = (
     "hs_lb_latency_stats",
     "hs_lb_ring", "hs_lb_select", "hs_lb_last_error", "hs_lb_destroy", "hs_md5", "hs_debug_radix_sort", "hs_merge_sink_records",
     "hs_sink_latency_stats",
-    "hs_debug_lb_flags",
+    "hs_debug_lb_flags", "hs_engine_set_profile_budget", "hs_lb_set_profile_budget", "hs_debug_tick_table",
 )

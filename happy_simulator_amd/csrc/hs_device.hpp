@@ -163,6 +163,6 @@ struct Stream {
     }
 };
 
-__device__ __forceinline__ uint64_t stream_id(uint64_t base, uint32_t kind) { return (base << 3) | kind; }
+__host__ __device__ __forceinline__ uint64_t stream_id(uint64_t base, uint32_t kind) { return (base << 3) | kind; }
 
 }  // namespace hs

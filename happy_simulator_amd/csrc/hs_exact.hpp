@@ -298,9 +298,8 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
                 X.arr_k[lp] = k + 1;
             }
             int64_t a2;
-            if (P.prof_kind[lp] != kProfConstant)
-                a2 = profile_next_tick(P.prof_kind[lp], P.prof_p[lp], P.prof_p[N + lp], P.prof_p[2 * N + lp], P.prof_p[3 * N + lp],
-                                       X.arr_time[lp], area, lp);
+            if (P.prof_kind[lp] != kProfConstant)                    // tick number `generated` of the Source's table (hs_tables.hpp)
+                a2 = tick_lookup(P.tabs->times + (size_t)P.tabs->src_row[lp] * (size_t)P.tabs->cap, P.tabs->cap, X.generated[lp], overflow);
             else
                 a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(X.arr_time[lp]), __ddiv_rn(area, P.src_rate[lp])));
             X.arr_time[lp] = a2;
@@ -436,8 +435,9 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
             const size_t o = (size_t)pj * N + lp;
             X.ev_probe[lp] += 1;
             const unsigned long long idx_pe = S.G++;
-            const int64_t a2 = probe_next_tick(P.probe_rate[o], X.p_arr[o], lp);
-            X.p_arr[o] = a2;
+            const int64_t k2 = X.p_arr[o] + 1;                               // index of the Probe's next tick in its table
+            const int64_t a2 = tick_lookup(P.tabs->times + (size_t)P.tabs->probe_row[o] * (size_t)P.tabs->cap, P.tabs->cap, k2, overflow);
+            X.p_arr[o] = k2;
             xpush(S, xev(t, idx_pe, XE_PSAMPLE, lp, 0, 0, (uint16_t)pj));
             if (a2 != kInfNs) {
                 const unsigned long long idx_t = S.G++;

@@ -36,7 +36,7 @@
 
 #include "../../include/hs_engine.h"
 #include "hs_device.hpp"
-#include "hs_profile.hpp"
+#include "hs_tables_api.hpp"
 #include "hs_radix.hpp"
 
 using namespace hs;
@@ -80,6 +80,9 @@ struct LbSrc {                    // [S] each
     const uint8_t *kind; const double *rate; const int64_t *stop; const int64_t *n_clients; const uint64_t *base;
     const uint8_t *prof_kind;     // time-varying rate (Source.with_profile): 0 constant, 1 linear ramp, 2 spike; null = none anywhere
     const double *prof_p;         // [4][S]
+    const int64_t *tab_times;     // tick tables of the time-varying Sources (hs_tables.hpp): tick d of Source s = tab_times[tab_row[s] * tab_cap + d]
+    const int32_t *tab_row;       // [S] -1: constant rate
+    int64_t tab_cap;
     int64_t *count;               // Requests emitted (ticks with a payload at t <= end)
     int64_t *generated;           // Source._generated_count
     LbCand *cand;                 // the pending SourceEvent beyond end
@@ -157,13 +160,9 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
         const uint64_t sa = stream_id(P.base[s], kStreamArrival), sk = stream_id(P.base[s], kStreamKey);
         const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
         const double inc_const = __ddiv_rn(1.0, rate);       // constant source: target area 1.0 (providers/constant_arrival.py:23)
-        Profile pf;
-        pf.kind = kProfConstant; pf.p0 = pf.p1 = pf.p2 = pf.p3 = 0.0; pf.owner = s;
-        if constexpr (PF) {
-            pf.kind = P.prof_kind[s];
-            pf.p0 = P.prof_p[s]; pf.p1 = P.prof_p[(size_t)S + s]; pf.p2 = P.prof_p[(size_t)2 * S + s]; pf.p3 = P.prof_p[(size_t)3 * S + s];
-        }
-        const bool timevarying = PF && pf.kind != kProfConstant;     // inc[] then holds the target AREA (E or 1.0), not E / rate
+        const int64_t *tab = nullptr;                                 // a time-varying Source: its ticks come from the tick table
+        if constexpr (PF) { if (P.prof_kind[s] != kProfConstant) tab = P.tab_times + (size_t)P.tab_row[s] * (size_t)P.tab_cap; }
+        const bool timevarying = PF && tab != nullptr;
         // Tick d happens at A_d = from_seconds(to_seconds(A_{d-1}) + E_d / rate)  (load/arrival_time_provider.py:72-82;
         // A_{-1} = start: Source.start at Simulation.__init__, load/source.py:120-140) and, while the provider still
         // returns Requests, draws client id number d.  Both streams are therefore indexed by the tick number: the
@@ -184,9 +183,9 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
                 if (kind == HS_SRC_POISSON) {
                     const U4 o = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)sa, (uint32_t)(sa >> 32), k0, k1);
                     const double e0 = exp1_from_uniform(res53(o.x, o.y)), e1 = exp1_from_uniform(res53(o.z, o.w));
-                    inc[j] = timevarying ? e0 : __ddiv_rn(e0, rate);
-                    inc[j + 1] = timevarying ? e1 : __ddiv_rn(e1, rate);
-                } else { inc[j] = timevarying ? 1.0 : inc_const; inc[j + 1] = inc[j]; }
+                    inc[j] = __ddiv_rn(e0, rate);
+                    inc[j + 1] = __ddiv_rn(e1, rate);
+                } else { inc[j] = inc_const; inc[j + 1] = inc[j]; }
                 const U4 q = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)sk, (uint32_t)(sk >> 32), k0, k1);
                 const int64_t c0 = __double2ll_rz(__dmul_rn(res53(q.x, q.y), nclients));
                 const int64_t c1 = __double2ll_rz(__dmul_rn(res53(q.z, q.w), nclients));
@@ -200,7 +199,7 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
                 const uint64_t d = d0 + j;
                 int64_t a2;
                 if constexpr (PF) {
-                    a2 = timevarying ? prof_next_arrival(pf, arr_time, inc[j])      // load/arrival_time_provider.py:84-144
+                    a2 = timevarying ? (d < (uint64_t)P.tab_cap ? tab[d] : (over = 1, kInfNs))   // load/arrival_time_provider.py:84-144
                                      : ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc[j]));
                     if (a2 == kInfNs) { done = true; dead = true; continue; }        // the rate is zero from here on: the Source ends
                 } else a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc[j]));
@@ -864,22 +863,6 @@ struct LbProbes {
     int n;
 };
 
-__global__ void hs_lb_probe_ticks(LbProbes Q, int64_t start_ns, int64_t horizon_ns) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= Q.n) return;
-    Profile pp;
-    pp.kind = kProfGeneralConstant; pp.p0 = Q.rate[j]; pp.p1 = pp.p2 = pp.p3 = 0.0; pp.owner = j;
-    int64_t t = start_ns, k = 0;
-    for (;;) {                                                    // Source.start(), then one next_arrival_time per tick
-        const int64_t a = prof_next_arrival(pp, t, 1.0);
-        if (k < Q.pcap) Q.tick[(size_t)j * Q.pcap + k] = a;
-        ++k;
-        if (a > horizon_ns || a <= t || k >= Q.pcap) break;
-        t = a;
-    }
-    Q.n_tick[j] = k;
-}
-
 __device__ __forceinline__ int64_t count_le(const int64_t *a, int64_t n, int64_t stride, int64_t T) {   // #{a[i * stride] <= T}, a ascending
     int64_t lo = 0, hi = n;
     while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (a[m * stride] <= T) lo = m + 1; else hi = m; }
@@ -1157,6 +1140,10 @@ struct hs_lb {
     double *svdraw = nullptr;                         // [n_slots] service sample per Request slot (single-worker FIFO backends)
     bool any_simple = false;
     bool any_src_profile = false;                      // some Source has a time-varying profile (hs_lbk_sources<true>)
+    // ... their tick tables (hs_tables.hpp), built once on the first run
+    TickRow *tab_rows = nullptr; int n_tab_rows = 0; int64_t *tab_times = nullptr, *tab_count = nullptr;
+    unsigned long long *tab_status = nullptr; bool tables_built = false;
+    long long lane_budget = kDefaultLaneBudget;
     bool any_no_sink = false;                          // some backend has no Sink behind it: no completion log (probes refused)
     int64_t *n_slots_dev = nullptr, *n_arr = nullptr, *n_done = nullptr, *n_tmp = nullptr;
     uint32_t *hist = nullptr, *row_total = nullptr, *digit_base = nullptr;
@@ -1282,9 +1269,10 @@ int run_async(hs_lb *h, int64_t end_ns) {
     const int S = h->cfg.n_sources, B = h->cfg.n_backends;
     h->launches = 0;
     hipLaunchKernelGGL(hs_lb_clear, dim3(1), dim3(1), 0, h->stream, h->tot);
-    if (h->any_src_profile) {          // (this translation unit's own instance of the evaluation-budget flag, hs_profile.hpp)
-        const unsigned long long zero = 0ull;
-        LB_HIP(h, hipMemcpyToSymbolAsync(HIP_SYMBOL(hs_prof_budget_hit), &zero, sizeof zero, 0, hipMemcpyHostToDevice, h->stream));
+    if (h->any_src_profile && !h->tables_built) {      // the time-varying Sources' tick tables: once (hs_tables.hpp)
+        LB_HIP(h, tick_tables_launch(h->stream, h->tab_rows, h->n_tab_rows, h->cfg.start_ns, h->cfg.horizon_ns, h->PS.tab_cap,
+                                     h->tab_times, h->tab_count, h->tab_status, h->lane_budget, false));
+        h->tables_built = true;
     }
     if (h->any_src_profile)
         hipLaunchKernelGGL(hs_lbk_sources<true>, dim3((S + kLbBlock - 1) / kLbBlock), dim3(kLbBlock), 0, h->stream, h->PS, S, h->cfg.seed,
@@ -1364,12 +1352,15 @@ int check_flags(hs_lb *h) {
     if (t.qoverflow) return lfail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
     if (t.bad_client & 1) return lfail(h, HS_E_INVALID, "a client id fell outside the client table");
     if (h->any_src_profile) {          // a Source whose inversion gave up would simply stop ticking: never silently
-        unsigned long long hit = 0ull;
-        LB_HIP(h, hipMemcpyFromSymbol(&hit, HIP_SYMBOL(hs_prof_budget_hit), sizeof hit, 0, hipMemcpyDeviceToHost));
-        if (hit != 0ull)
-            return lfail(h, HS_E_UNSUPPORTED, "Source %lld: one arrival of its time-varying profile needs more than %lld adaptive-Simpson "
-                         "intervals (csrc/hs_profile.hpp; check with tools/profile_cost.py) -- refused instead of stalling a lane",
-                         (long long)hit - 2, (long long)kProfBudget);
+        unsigned long long st[2] = {0ull, 0ull};
+        LB_HIP(h, hipMemcpy(st, h->tab_status, sizeof st, hipMemcpyDeviceToHost));
+        if (st[0] != 0ull)
+            return lfail(h, HS_E_UNSUPPORTED, "Source %lld: one arrival of its time-varying profile needs more than 64 x %lld adaptive-Simpson "
+                         "intervals (csrc/hs_tables.hpp; hs_lb_set_profile_budget raises the limit) -- refused instead of stalling the device",
+                         (long long)st[0] - 2, (long long)h->lane_budget);
+        if (st[1] != 0ull)
+            return lfail(h, HS_E_OVERFLOW, "Source %lld: its tick table overflowed (capacity %lld ticks); raise tick_capacity",
+                         (long long)st[1] - 2, (long long)h->PS.tab_cap);
     }
     if (t.bad_client & 2) return lfail(h, HS_E_OVERFLOW, "a source's tick log overflowed (capacity %lld ticks); raise tick_capacity", (long long)h->cap);
     if (t.probe_tie & 1) return lfail(h, HS_E_UNSUPPORTED, "a probe sample fell on the nanosecond of an event of its target: on load-balancer "
@@ -1544,6 +1535,35 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
         }
         TRY(lupload<uint8_t>(h, &h->PS.prof_kind, pk.data(), (size_t)S, (uint8_t)0));
         TRY(lupload<double>(h, &h->PS.prof_p, pp.data(), (size_t)S * 4, 0.0));
+        if (h->any_src_profile) {
+            // one tick-table row per time-varying Source (hs_tables.hpp); a table holds cap + 2 ticks: everything the tick
+            // log can take plus the two beyond the horizon
+            std::vector<TickRow> rows;
+            std::vector<int32_t> row_of((size_t)S, -1);
+            for (int i = 0; i < S; ++i) {
+                if (pk[(size_t)i] == 0) continue;
+                TickRow r{};
+                r.kind = pk[(size_t)i];
+                r.poisson = (src->src_kind ? src->src_kind[i] : HS_SRC_POISSON) == HS_SRC_POISSON ? 1u : 0u;
+                r.p0 = pp[(size_t)i]; r.p1 = pp[(size_t)S + i]; r.p2 = pp[(size_t)2 * S + i]; r.p3 = pp[(size_t)3 * S + i];
+                r.seed = cfg->seed;
+                r.sid = stream_id(src->stream_base ? src->stream_base[i] : sbase[(size_t)i], kStreamArrival);
+                r.owner = i;
+                row_of[(size_t)i] = (int32_t)rows.size();
+                rows.push_back(r);
+            }
+            h->n_tab_rows = (int)rows.size();
+            h->PS.tab_cap = h->cap + 2;
+            TRY(lalloc(h, &h->tab_rows, rows.size()));
+            if (hipMemcpy(h->tab_rows, rows.data(), rows.size() * sizeof(TickRow), hipMemcpyHostToDevice) != hipSuccess) {
+                rc = lfail(nullptr, HS_E_HIP, "memcpy"); hs_lb_destroy(h); return rc;
+            }
+            TRY(lupload<int32_t>(h, &h->PS.tab_row, row_of.data(), (size_t)S, -1));
+            TRY(lalloc(h, &h->tab_times, rows.size() * (size_t)h->PS.tab_cap));
+            TRY(lalloc(h, &h->tab_count, rows.size()));
+            TRY(lalloc(h, &h->tab_status, 2));
+            h->PS.tab_times = h->tab_times;
+        }
     }
     TRY(lupload<uint64_t>(h, &h->PS.base, src->stream_base ? src->stream_base : sbase.data(), (size_t)S, 0));
     TRY(lalloc(h, &h->PS.count, (size_t)S)); TRY(lalloc(h, &h->PS.generated, (size_t)S)); TRY(lalloc(h, &h->PS.cand, (size_t)S));
@@ -1708,11 +1728,37 @@ int hs_lb_set_probes(hs_lb *h, int32_t n_probes, const int32_t *target_kind, con
     LB_HIP(h, hipMemcpy(dr, rate.data(), (size_t)n_probes * 8, hipMemcpyHostToDevice));
     LB_HIP(h, hipMemset(Q.cnt, 0, (size_t)n_probes * 8));
     Q.kind = dk; Q.idx = di; Q.metric = dm; Q.rate = dr;
-    // the tick times do not depend on the run: once, up to the first one beyond the horizon
-    hipLaunchKernelGGL(hs_lb_probe_ticks, dim3((n_probes + 63) / 64), dim3(64), 0, h->stream, Q, h->cfg.start_ns, h->cfg.horizon_ns);
-    LB_HIP(h, hipGetLastError());
-    LB_HIP(h, hipStreamSynchronize(h->stream));
+    // the tick times do not depend on the run: once, from the tick-table kernel (hs_tables.hpp: _ProbeProfile goes through
+    // the reference's numerical path), Q.tick IS the table (row j, pcap entries), up to the second tick beyond the horizon
+    {
+        std::vector<TickRow> rows((size_t)n_probes);
+        for (int j = 0; j < n_probes; ++j) {
+            TickRow r{};
+            r.kind = kProfGeneralConstant; r.poisson = 0; r.p0 = rate[(size_t)j]; r.owner = j;
+            rows[(size_t)j] = r;
+        }
+        TickRow *drows = nullptr;
+        unsigned long long *dstat = nullptr;
+        if ((rc = lalloc(h, &drows, (size_t)n_probes))) return rc;
+        if ((rc = lalloc(h, &dstat, 2))) return rc;
+        LB_HIP(h, hipMemcpy(drows, rows.data(), rows.size() * sizeof(TickRow), hipMemcpyHostToDevice));
+        LB_HIP(h, tick_tables_launch(h->stream, drows, n_probes, h->cfg.start_ns, h->cfg.horizon_ns, pcap, Q.tick, Q.n_tick, dstat,
+                                     h->lane_budget, false));
+        LB_HIP(h, hipStreamSynchronize(h->stream));
+        unsigned long long st[2] = {0ull, 0ull};
+        LB_HIP(h, hipMemcpy(st, dstat, sizeof st, hipMemcpyDeviceToHost));
+        if (st[0] != 0ull) return lfail(h, HS_E_UNSUPPORTED, "probe %lld: a tick needs more than 64 x %lld adaptive-Simpson intervals", (long long)st[0] - 2, (long long)h->lane_budget);
+        // (a table that ends before `pcap` entries simply has fewer ticks; one that fills it ends on its last entry, as before)
+    }
     h->Q = Q;
+    return HS_OK;
+}
+
+int hs_lb_set_profile_budget(hs_lb *h, int64_t intervals_per_lane) {
+    if (!h) return lfail(h, HS_E_INVALID, "hs_lb_set_profile_budget: null handle");
+    if (intervals_per_lane < 1) return lfail(h, HS_E_INVALID, "hs_lb_set_profile_budget: the budget must be >= 1");
+    h->lane_budget = (long long)intervals_per_lane;
+    h->tables_built = false;
     return HS_OK;
 }
 

@@ -151,23 +151,6 @@ __device__ __forceinline__ unsigned long long pk_tail(int64_t w, unsigned long l
 
 constexpr int kEnqPay = 8;   // ENQ payload FIFO depth (general path only)
 
-// Next tick of a Probe: the general numerical path of ArrivalTimeProvider (adaptive Simpson + Brent, hs_profile.hpp) over
-// _ProbeProfile(interval).  Deliberately NOT inlined: its explicit recursion stack (4 KB of scratch per lane) inside the
-// register-starved network kernels made hs_net_window<2> misbehave; as a callee it has its own frame and is only entered
-// by the rare lane that owns a probe.
-__device__ __noinline__ inline int64_t probe_next_tick(double rate, int64_t from_ns, int owner = -1) {
-    Profile pp;
-    pp.kind = kProfGeneralConstant; pp.p0 = rate; pp.p1 = pp.p2 = pp.p3 = 0.0; pp.owner = owner;
-    return prof_next_arrival(pp, from_ns, 1.0);
-}
-// Next arrival of a Source with a time-varying rate profile (load/arrival_time_provider.py:84-144), same reasons.
-__device__ __noinline__ inline int64_t profile_next_tick(uint32_t kind, double p0, double p1, double p2, double p3,
-                                                         int64_t from_ns, double area, int owner = -1) {
-    Profile pf;
-    pf.kind = kind; pf.p0 = p0; pf.p1 = p1; pf.p2 = p2; pf.p3 = p3; pf.owner = owner;
-    return prof_next_arrival(pf, from_ns, area);
-}
-
 // ---- FAST instantiation (hs_net_async only) ------------------------------------------------------------------------
 // The asynchronous engine runs a wavefront's event groups in a divergent loop with only a few lanes active per trip
 // (measured on the 65 536-station ring: ~3 of 64), so whatever a group costs is paid almost per LANE.  Three things kept
@@ -221,8 +204,8 @@ struct NetStation {
     // Probe attached to this station (instrumentation/probe.py:81-164), as in hs_station.hpp: a daemon Source of its own
     // whose ticks sample one attribute (PF instantiations).
     uint32_t p_metric[kMaxProbes], seqP[kMaxProbes];
-    double p_rate[kMaxProbes];
-    int64_t PA[kMaxProbes], crtP[kMaxProbes], p_arr[kMaxProbes], p_n[kMaxProbes], pcap;
+    int64_t PA[kMaxProbes], crtP[kMaxProbes], p_arr[kMaxProbes], p_n[kMaxProbes], pcap;   // p_arr: index of the pending tick in tab_p
+    const int64_t *tab_p[kMaxProbes];   // the Probes' tick tables (hs_tables.hpp)
     int64_t *probe_t, *probe_v;     // slot j's log starts at probe_t + j * pcap * ls
     int n_probes;
     uint32_t evp[2];
@@ -234,9 +217,11 @@ struct NetStation {
     int64_t xs_min;
     uint64_t x_base;
     int n_xsrc, x_n_lp;
-    // time-varying arrival rate of this station's Source (load/profile.py); 0 = constant..
+    // time-varying arrival rate of this station's Source (load/profile.py); 0 = constant.  Tick k of such a Source is tab_a[k]
+    // (the tick table, hs_tables.hpp); it draws nothing here.
     uint32_t prof_kind;
-    double prof_p0, prof_p1, prof_p2, prof_p3;
+    const int64_t *tab_a;
+    int64_t tab_cap;
     // Simulation.schedule(): Requests injected before run() (hs_station.hpp); they precede every run-time event of their ns
     int64_t SA, sc_i, sc_end;
     const int64_t *sc_t;
@@ -393,7 +378,7 @@ struct NetStation {
     __device__ __forceinline__ void refill_a(int m) {
         for (int i = 0; i < m; ++i) {
             const double e = exp1_from_uniform(arr.next_uniform());
-            fl.ring_a[(ha + na) & (kNRing - 1)][tid] = (PF && prof_kind != kProfConstant) ? e : __ddiv_rn(e, rate); ++na;
+            fl.ring_a[(ha + na) & (kNRing - 1)][tid] = __ddiv_rn(e, rate); ++na;
         }
     }
     __device__ __forceinline__ void refill_s(int m) {
@@ -421,8 +406,7 @@ struct NetStation {
             ha = (ha + 1) & (kNRing - 1); --na;
             return v;
         } else {
-            const double e = exp1_from_uniform(arr.next_uniform());
-            return (PF && prof_kind != kProfConstant) ? e : __ddiv_rn(e, rate);
+            return __ddiv_rn(exp1_from_uniform(arr.next_uniform()), rate);
         }
     }
     __device__ __forceinline__ double svc_s_next() {                  // service time of the next start, seconds
@@ -449,7 +433,7 @@ struct NetStation {
     // (`need` = what one iteration may consume per stream: the groups-per-iteration cap)
     __device__ __forceinline__ void top_up(bool act, int need) {
         if constexpr (FAST) {
-            const bool wa = HSU(src_kind == 1, true) && A != kInfNs, ws = HSU(svc_kind == 0, true), wj = fl_link >= 0 && HSU(fl_jit == 0, true);
+            const bool wa = HSU(src_kind == 1, true) && A != kInfNs && !(PF && prof_kind != kProfConstant), ws = HSU(svc_kind == 0, true), wj = fl_link >= 0 && HSU(fl_jit == 0, true);
             const bool wr = HSU(egress == EG_ROUTER, true);
             if (__any(act && wa && na < need)) { if (act && wa && na <= kNRing - 4) refill_a(4); }
             if (__any(act && ws && nsv < need)) { if (act && ws && nsv <= kNRing - 4) refill_s(4); }
@@ -460,9 +444,8 @@ struct NetStation {
 
     __device__ __forceinline__ int64_t next_arrival() {
         if constexpr (PF) {
-            if (prof_kind != kProfConstant) {      // general path: invert the profile for the target area E (Poisson) or 1.0
-                const double area = HSU(src_kind == 1, true) ? arr_inc() : 1.0;   // (for such a Source the ring / stream value IS E)
-                arr_time = profile_next_tick(prof_kind, prof_p0, prof_p1, prof_p2, prof_p3, arr_time, area, lp);
+            if (prof_kind != kProfConstant) {      // general path: tick number `generated` of the Source's table
+                arr_time = tick_lookup(tab_a, tab_cap, generated, overflow);
                 return arr_time;
             }
         }
@@ -497,8 +480,9 @@ struct NetStation {
         qpush(Q_PSAMPLE | ((uint32_t)j << 3));                            // the daemon probe_event, created first
 #pragma unroll
         for (int i = 0; i < kMaxProbes; ++i) if (i == j) {
-            const int64_t a2 = probe_next_tick(p_rate[i], p_arr[i], lp);  // ConstantArrivalTimeProvider over _ProbeProfile
-            p_arr[i] = a2;
+            const int64_t k2 = p_arr[i] + 1;                              // ConstantArrivalTimeProvider over _ProbeProfile: the table
+            const int64_t a2 = tick_lookup(tab_p[i], tab_cap, k2, overflow);
+            p_arr[i] = k2;
             if (a2 <= t) PA[i] = kInfNs;
             else { PA[i] = a2; seqP[i] = seq++; crtP[i] = t; }
         }

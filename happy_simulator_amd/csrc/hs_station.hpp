@@ -23,7 +23,7 @@
 #pragma once
 
 #include "hs_device.hpp"
-#include "hs_profile.hpp"
+#include "hs_tables.hpp"
 
 namespace hs {
 
@@ -95,8 +95,11 @@ struct StationParams {          // read-only, [n_lp] each
     const uint8_t *egress;
     const uint64_t *seed;
     const uint64_t *stream_base;
-    const uint8_t *prof_kind;       // time-varying arrival rate (hs_profile.hpp): 0 constant, 1 linear ramp, 2 spike
+    const uint8_t *prof_kind;       // time-varying arrival rate (load/profile.py): 0 constant, 1 linear ramp, 2 spike
     const double *prof_p;           // [4][n_lp]
+    // tick times of the streams whose next tick is a numerical inversion -- Sources with such a profile, Probes -- produced before
+    // the run by the tick-table kernel (hs_tables.hpp); null = the engine has none
+    const TickTables *tabs;
     const uint8_t *probe_metric;    // [kMaxProbes][n_lp] Probes attached to this LP: kProbe* metric, 255 = none (slots fill from 0)
     const double *probe_rate;       // [kMaxProbes][n_lp] 1.0 / interval  (_ProbeProfile.rate, instrumentation/probe.py:27-35)
     // Simulation.schedule() (core/simulation.py:195-206): Requests injected before run(), per LP sorted by time (stable in
@@ -149,7 +152,7 @@ struct StationState {           // read-write; [n_lp] each unless noted
     // Probe (PF instantiation only)
     int64_t *PA;                // [kMaxProbes][n_lp] pending probe tick (kInfNs: none)
     uint32_t *seqP;             // [kMaxProbes][n_lp]
-    int64_t *crtP, *p_arr, *p_n;   // [kMaxProbes][n_lp] creation time of the pending tick, the provider's current_time, samples taken
+    int64_t *crtP, *p_arr, *p_n;   // [kMaxProbes][n_lp] creation time of the pending tick, its index in the Probe's tick table, samples taken
     int64_t *ev_probe;          // [2][n_lp] SourceEvent@Probe, probe_event
     int64_t *sched_i;           // [n_lp] index into sched_t of the LP's next scheduled Request (PF instantiation only)
     // further Sources (PF instantiation only; null = none)
@@ -232,10 +235,12 @@ struct Station {
     DrawRing ra, rs;            // ra: E / rate per arrival draw;  rs: service_time_s per service draw
     ConstDiv div_rate, div_lambda;
     double inc_const;           // constant source: 1.0 / rate
-    Profile prof;               // kind != 0: the ring holds target AREAS (E, not E / rate) and next_arrival() inverts the profile
+    uint32_t prof_kind;         // != 0: a time-varying rate; tick k of the Source is tab_a[k] (hs_tables.hpp), no arrival draws here
+    const int64_t *tab_a;
+    const int64_t *tab_p[kMaxProbes];   // tick k of the Probe in slot j is tab_p[j][k]; p_arr[j] = index of its pending tick
+    int64_t tab_cap;
     // Probe (PF): a daemon Source of its own (instrumentation/probe.py:81-164) whose ticks sample this LP
     uint32_t p_metric[kMaxProbes], seqP[kMaxProbes];
-    double p_rate[kMaxProbes];
     int64_t PA[kMaxProbes], crtP[kMaxProbes], p_arr[kMaxProbes], p_n[kMaxProbes], pcap;
     int64_t *probe_t, *probe_v;     // slot j's log starts at probe_t + j * pcap * ls
     int n_probes;
@@ -286,7 +291,7 @@ struct Station {
         ssid0 = (uint32_t)ss; ssid1 = (uint32_t)(ss >> 32);
         arr_k = ak; svc_k = sk;
         ra.reset(ring_a, tid); rs.reset(ring_s, tid);
-        div_rate.init((PF && prof.kind != kProfConstant) ? 1.0 : rate);
+        div_rate.init(rate);
         div_lambda.init(svc_lambda);
         inc_const = __ddiv_rn(1.0, rate);
     }
@@ -329,14 +334,15 @@ struct Station {
             rs.push(v1);
         }
     }
-    __device__ __forceinline__ bool wants_arr() const { return src_kind == 1 && A != kInfNs && ra.n == 0; }
+    __device__ __forceinline__ bool timevarying() const { return PF && prof_kind != kProfConstant; }
+    __device__ __forceinline__ bool wants_arr() const { return src_kind == 1 && A != kInfNs && ra.n == 0 && !timevarying(); }
     __device__ __forceinline__ bool wants_svc() const { return svc_kind == 0 && rs.n == 0; }
     // Wave-level top-up, called at a point where the whole wavefront is converged on the main loop: if any lane
     // has run dry, every lane with room generates kRefill more values (lanes consume at similar rates, so the
     // refills stay in step: ~93 % of the generated lanes-worth of values are used).
     __device__ __forceinline__ void top_up(bool act = true) {
         if (__any(act && wants_arr())) {
-            if (src_kind == 1 && A != kInfNs && ra.n <= kRing - kRefill) refill_arr<kRefill / 2>();
+            if (src_kind == 1 && A != kInfNs && !timevarying() && ra.n <= kRing - kRefill) refill_arr<kRefill / 2>();
         }
         if (__any(act && wants_svc())) {
             if (svc_kind == 0 && rs.n <= kRing - kRefill) refill_svc<kRefill / 2>();
@@ -345,18 +351,18 @@ struct Station {
 
     // ---- ArrivalTimeProvider.next_arrival_time, constant-rate fast path (load/arrival_time_provider.py:72-82)
     __device__ __forceinline__ int64_t next_arrival() {
+        if constexpr (PF) {
+            if (prof_kind != kProfConstant) {      // general path (load/arrival_time_provider.py:84-144): the tick table; this is
+                arr_time = tick_lookup(tab_a, tab_cap, generated, overflow);   // tick number `generated` (do_tick counted the one that runs)
+                return arr_time;
+            }
+        }
         double inc;
         if (src_kind == 1) {                       // Poisson: -log(1-u) / rate
             if (ra.n == 0) refill_arr<1>();        // ran dry inside a group (rare): one block, in place
             inc = ra.pop();
             ++arr_k;
         } else inc = inc_const;                    // constant: 1.0 / rate   (providers/constant_arrival.py:23)
-        if constexpr (PF) {
-            if (prof.kind != kProfConstant) {      // general path (load/arrival_time_provider.py:84-144)
-                arr_time = prof_next_arrival(prof, arr_time, src_kind == 1 ? inc : 1.0);
-                return arr_time;
-            }
-        }
         const double t_next = __dadd_rn(seconds_from_ns(arr_time), inc);
         arr_time = ns_from_seconds(t_next);
         return arr_time;
@@ -477,14 +483,12 @@ struct Station {
     }
     __device__ __forceinline__ void root_probe(int j, int64_t t) {
         evp[0]++;
-        Profile pp;
-        pp.kind = kProfGeneralConstant; pp.p1 = pp.p2 = pp.p3 = 0.0; pp.owner = lp;
         qpush(Q_PSAMPLE | ((uint32_t)j << 3));                            // the daemon probe_event, created first
 #pragma unroll
         for (int i = 0; i < kMaxProbes; ++i) if (i == j) {
-            pp.p0 = p_rate[i];
-            const int64_t a2 = prof_next_arrival(pp, p_arr[i], 1.0);      // ConstantArrivalTimeProvider over _ProbeProfile
-            p_arr[i] = a2;
+            const int64_t k2 = p_arr[i] + 1;                              // ConstantArrivalTimeProvider over _ProbeProfile: the table
+            const int64_t a2 = tick_lookup(tab_p[i], tab_cap, k2, overflow);
+            p_arr[i] = k2;
             if (a2 <= t) PA[i] = kInfNs;
             else { PA[i] = a2; seqP[i] = seq++; crtP[i] = t; }
         }
@@ -721,7 +725,7 @@ struct Station {
         const int64_t buf_enq = buf + (acc ? 1 : 0);
         const bool deliver = poll && buf_enq > 0;                       // queue.py:149-166
         const bool slow = act && (force_general || svc_kind == 2 ||
-                                  (PF && (prof.kind != kProfConstant || has_probe() || has_sched() || has_xsrc())) ||
+                                  (PF && (prof_kind != kProfConstant || has_probe() || has_sched() || has_xsrc())) ||
                                   (tick && D[0] == t) ||
                                   (tick && ((stop_ns >= 0 && t > stop_ns) || a2 <= t)) || (deliver && dur == 0));
         const bool fast = act && !slow;
@@ -794,7 +798,7 @@ struct Station {
     };
     __device__ __forceinline__ bool req_eligible() const {
         return C == 1 && !force_general && qn == 0 && conc == 1 && qcap < 0 && stop_ns < 0 && svc_kind != 2 &&
-               !(PF && (prof.kind != kProfConstant || has_probe() || has_sched() || has_xsrc())) &&
+               !(PF && (prof_kind != kProfConstant || has_probe() || has_sched() || has_xsrc())) &&
                (egress == 0 || egress == 1) && !(buf > 0 && active == 0) && active <= 1;
     }
     __device__ __forceinline__ void req_count_departure(ReqCursor &c, bool p, int64_t d, double s) {

@@ -6,6 +6,7 @@ work happens in libhs_hip.so; nothing here computes event logic.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -196,6 +197,8 @@ class StationEngine:
         self.n_links = 0
         try:
             self._check(self._lib.hs_engine_set_stations(self._h, C.byref(st)))
+            if os.environ.get("HS_PROF_BUDGET_LOG2"):
+                self.set_profile_budget(1 << int(os.environ["HS_PROF_BUDGET_LOG2"]))
             if network is not None:
                 self._set_network(network)
         except Exception:
@@ -292,6 +295,12 @@ class StationEngine:
 
     def set_debug_flags(self, flags: int):
         self._lib.hs_debug_set_flags(self._h, flags)
+
+    def set_profile_budget(self, intervals_per_lane: int):
+        """Evaluation budget of the tick-table kernel (csrc/hs_tables.hpp): adaptive-Simpson intervals one lane may visit for one
+        arrival of a time-varying Source; an arrival beyond it is refused by name.  A run-time setting (default 2**24, or
+        2**HS_PROF_BUDGET_LOG2 from the environment); takes effect at the next reset / run."""
+        self._check(self._lib.hs_engine_set_profile_budget(self._h, int(intervals_per_lane)))
 
     # -- results -------------------------------------------------------------------------------
     def summary(self) -> EngineSummary:

@@ -7,6 +7,7 @@ sources, the sorts and the backends all live in libhs_hip.so.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -99,6 +100,8 @@ class LoadBalancerEngine:
             if rc == N.HS_E_NO_DEVICE:
                 raise N.EngineUnavailable(msg)
             raise N.EngineError(rc, msg)
+        if os.environ.get("HS_PROF_BUDGET_LOG2"):
+            self.set_profile_budget(1 << int(os.environ["HS_PROF_BUDGET_LOG2"]))
 
     # ------------------------------------------------------------------
     def _check(self, rc):
@@ -155,6 +158,10 @@ class LoadBalancerEngine:
 
     def set_debug_flags(self, flags: int) -> None:
         self._check(self._lib.hs_debug_lb_flags(self._h, flags))
+
+    def set_profile_budget(self, intervals_per_lane: int) -> None:
+        """Evaluation budget of the tick-table kernel (StationEngine.set_profile_budget); before the first run."""
+        self._check(self._lib.hs_lb_set_profile_budget(self._h, int(intervals_per_lane)))
 
     def summary(self) -> EngineSummary:
         s = N.Summary()

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HS_ABI_VERSION 8
+#define HS_ABI_VERSION 9
 
 typedef enum hs_status {
     HS_OK = 0,
@@ -490,6 +490,21 @@ int hs_debug_async_counters(hs_engine *h, unsigned long long out[4]);
 
 int hs_debug_draws(int32_t device, uint64_t seed, uint64_t sid, uint64_t k0, int64_t n, double rate,
                    double *u, double *e, int64_t *ns);
+
+/* Evaluation budget of the tick-table kernel (csrc/hs_tables.hpp): adaptive-Simpson intervals ONE lane may visit for ONE
+ * arrival of a time-varying Source (64 lanes share an integral).  Replaces nothing in the reference -- its integrator
+ * (numerics/integration.py:11-90) has no limit and needs minutes for such arrivals; this is the device's time guard, a
+ * RUN-TIME argument (round 2: a build-time constant).  Default 2^24; takes effect at the next reset / run. */
+int hs_engine_set_profile_budget(hs_engine *h, int64_t intervals_per_lane);
+int hs_lb_set_profile_budget(hs_lb *h, int64_t intervals_per_lane);
+
+/* Debug / test hook: the tick table of one stream -- next_arrival_time's general path (load/arrival_time_provider.py:84-144)
+ * iterated from start_ns until two ticks lie beyond horizon_ns.  profile = {kind (1 ramp, 2 spike, 3 constant rate through the
+ * general path), p0..p3}; lone = 0: the cooperative kernel, 1: one lane with the sequential integrator.  Returns the number of
+ * entries (<= cap) or a negative error; out_status[0] != 0: over the evaluation budget, out_status[1] != 0: cap too small. */
+int64_t hs_debug_tick_table(int32_t device, const double *profile, int32_t poisson, uint64_t seed, uint64_t sid,
+                            int64_t start_ns, int64_t horizon_ns, int64_t cap, int64_t lane_budget, int32_t lone,
+                            int64_t *out_times, uint64_t *out_status);
 
 /* Debug: the engine divides by per-LP constants (1e9, rate, lambda) with a multiply + FMA sequence that must be
  * bit-identical to the IEEE quotient.  q_fast[i] = that sequence for a[i] / b, q_ieee[i] = the hardware

@@ -27,7 +27,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_abi_version_and_struct_sizes(lib):
-    assert lib.hs_abi_version() == N.ABI_VERSION == 8
+    assert lib.hs_abi_version() == N.ABI_VERSION == 9
     assert C.sizeof(N.Config) == 56
     assert N.EV_KINDS == 15 and len(N.EV_NAMES) == 15
     assert C.sizeof(N.Summary) == 8 * (1 + 15 + 1 + 1 + 1 + 1) + 8 + 8 + 8 + 8 + 8

@@ -181,12 +181,12 @@ def test_lb_source_profiles_on_random_configurations_match_oracle(k):
         H.compare_lb_engine_with_oracle(eng, p, r)
 
 
-def test_lb_source_whose_inversion_exceeds_the_evaluation_budget_is_refused_not_silently_stopped():
+def test_lb_source_whose_inversion_needs_2_to_24_intervals_is_exact_and_a_small_budget_refuses_it_by_name():
     """random_specs.lb_profile_spec(1351), found by tools/gpu_random_sweep.py: a Source's ramp ends at 2.25 requests/s and the
     arrival that spans the end needs ~2^24 adaptive-Simpson intervals (the reference: seconds of Python; one GPU lane: ~50 s).
-    The station engine refused such an LP by name; the load-balancer engine did not look at the flag, the Source simply stopped
-    ticking and the run came back three requests short.  Now HS_E_UNSUPPORTED names the Source (unless the library was built
-    with a larger HS_PROF_BUDGET_LOG2, in which case the run must be exact)."""
+    Round 2: the load-balancer engine first ignored the budget flag (the Source silently stopped ticking, three requests
+    short), then refused the Source by name.  Now the tick-table kernel (csrc/hs_tables.hpp, 64 lanes per integral) runs it and
+    the result equals the oracle; with a small run-time budget HS_E_UNSUPPORTED still names the Source."""
     import random_specs as RS
     from happy_simulator_amd import _native as N
 
@@ -194,11 +194,12 @@ def test_lb_source_whose_inversion_exceeds_the_evaluation_budget_is_refused_not_
     g, p = H.oracle_lb_graph(spec)
     eng, _ = H.lb_engine_for_spec(spec)
     with eng:
-        try:
+        eng.set_profile_budget(1 << 12)
+        with pytest.raises(N.EngineError, match="Source 1.*adaptive-Simpson"):
             eng.run(p["end_ns"])
-        except N.EngineError as e:
-            assert "Source 1" in str(e) and "adaptive-Simpson" in str(e)
-            return
+    eng, _ = H.lb_engine_for_spec(spec)
+    with eng:
+        eng.run(p["end_ns"])
         r = O.run(g, p["end_ns"], seed=spec["seed"])
         for nd in g.lb_probe_nodes:
             r.sinks.pop(nd)

@@ -315,8 +315,10 @@ def test_nonzero_start_time_matches_oracle():
 
 def test_profile_inversion_budget_reports_the_lp_instead_of_stalling():
     """N3: one arrival of LinearRampProfile(3 s, 1 -> 9) on stream base 97, seed 77 needs 8e7 rate evaluations in the
-    reference's own adaptive-Simpson inversion (70 s of the reference's Python).  The device gives up
-    after 2^20 Simpson intervals and the run is refused with the LP's index -- it used to stall a lane for minutes."""
+    reference's own adaptive-Simpson inversion (70 s of the reference's Python).  Round 2 refused it
+    (a lone lane, 2^20 intervals); the tick-table kernel (csrc/hs_tables.hpp) evaluates the integral with 64 lanes and the run
+    is EXACT (tests/test_gpu_tables.py compares the whole network with the oracle).  The evaluation budget is a run-time
+    argument now: with a small one the run is refused with the LP's index instead of guessed."""
     from happy_simulator_amd import _native as N
     from happy_simulator_amd.engine import StationArrays, StationEngine
 
@@ -331,9 +333,15 @@ def test_profile_inversion_budget_reports_the_lp_instead_of_stalling():
     t0 = time.perf_counter()
     with pytest.raises(N.EngineError, match="LP 97.*adaptive-Simpson"):
         with StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=5_000_000_000, seed=77) as eng:
+            eng.set_profile_budget(1 << 10)
             eng.run_until(5_000_000_000)
     assert time.perf_counter() - t0 < 30.0
-    st.src_profile_params[97, :3] = (5.0, 3.0, 20.0)             # an ordinary ramp on the same stream: runs
+    t0 = time.perf_counter()
+    with StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=5_000_000_000, seed=77) as eng:   # the default budget: it runs
+        eng.run_until(5_000_000_000)
+        assert eng.lp_stats()["generated"][97] > 5
+    assert time.perf_counter() - t0 < 30.0
+    st.src_profile_params[97, :3] = (5.0, 3.0, 20.0)             # an ordinary ramp on the same stream
     with StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=5_000_000_000, seed=77) as eng:
         eng.run_until(5_000_000_000)
         assert eng.lp_stats()["generated"][97] > 20

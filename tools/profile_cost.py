@@ -4,7 +4,7 @@
 The arrival times of `Source.with_profile(...)` are DEFINED by the reference's numerical procedure (adaptive Simpson
 inside a bracket search and Brent's method, load/arrival_time_provider.py:84-144); csrc/hs_profile.hpp restates it for
 the device.  For a few inputs the procedure itself needs ~10^8 rate evaluations for ONE arrival (DESIGN.md section 1.2:
-minutes in the reference, a long stall on a single GPU lane).  This tool compiles the very same header for the host
+minutes in the reference; the tick-table kernel, csrc/hs_tables.hpp, shares such an integral among 64 lanes).  This tool compiles the very same header for the host
 (a 20-line stand-in for <hip/hip_runtime.h>, g++ -ffp-contract=off) and times the arrivals of one stream, so that a
 profile / seed / station combination can be checked before a long run:
 
@@ -49,6 +49,10 @@ MAIN = r"""
 #include <cstdio>
 #include <cstdlib>
 using namespace hs;
+#ifndef HS_TOOL_BUDGET_LOG2
+#define HS_TOOL_BUDGET_LOG2 30       /* 64 lanes x the device's default 2^24 */
+#endif
+static const long long BUDGET = 1ll << HS_TOOL_BUDGET_LOG2;
 int main(int argc, char **argv) {
     Profile pf; pf.kind = (uint32_t)atoi(argv[1]);
     pf.p0 = atof(argv[2]); pf.p1 = atof(argv[3]); pf.p2 = atof(argv[4]); pf.p3 = atof(argv[5]);
@@ -61,13 +65,14 @@ int main(int argc, char **argv) {
         const double area = poisson ? exp1_from_uniform(s.next_uniform()) : 1.0;
         const double rate = prof_rate(pf, seconds_from_ns_ieee(t));
         const auto t0 = std::chrono::steady_clock::now();
-        const int64_t t2 = prof_next_arrival(pf, t, area);
+        bool over = false;
+        const int64_t t2 = prof_next_arrival(pf, t, area, BUDGET, over);
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         printf("arrival %d: from %.9f s, target area %.6g, rate there %.6g/s, first bracket %.4g s -> %.9f s   host %.4f s%s\n",
                k, t / 1e9, area, rate, rate > 0 ? 2.0 * area / rate : 0.1, t2 == kInfNs ? INFINITY : t2 / 1e9, dt,
-               hs_prof_budget_hit ? "   <-- OVER THE DEVICE'S EVALUATION BUDGET: the engine refuses this LP (HS_E_UNSUPPORTED)" :
+               over ? "   <-- over 64 x the device's default evaluation budget per lane (hs_engine_set_profile_budget raises it)" :
                dt > limit ? "   <-- slow" : "");
-        if (hs_prof_budget_hit) break;
+        if (over) break;
         if (t2 == kInfNs || t2 <= t) break;
         t = t2;
     }
@@ -94,7 +99,7 @@ def main():
         open(os.path.join(d, "main.cpp"), "w").write(MAIN)
         exe = os.path.join(d, "profile_cost")
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I", d, "-I", CSRC,
-                               *([f"-DHS_PROF_BUDGET_LOG2={a.budget_log2}"] if a.budget_log2 else []),
+                               *([f"-DHS_TOOL_BUDGET_LOG2={a.budget_log2}"] if a.budget_log2 else []),
                                os.path.join(d, "main.cpp"), "-o", exe])
         return subprocess.call([exe, str(kind), *[repr(x) for x in p], str(a.seed), str(a.station),
                                 "0" if a.constant_arrivals else "1", str(a.arrivals), repr(a.slow_s)])
