@@ -611,15 +611,35 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
                 for (int j = 0; j <= kMaxXSrc; ++j) if (has_src(i, j)) { so.push_back(i); sslot.push_back((uint8_t)j); }
         }
     }
-    if (st->source_order) {   // cross-LP ties go to the Source the reference constructed first (cand_rank, hs_station.hpp)
-        std::vector<int32_t> tr((size_t)n * (kMaxXSrc + 2) + 1, -1);
+    // the Probes in `probes=[...]` order: (LP, slot) pairs; default = LP-major, slot-minor
+    std::vector<int32_t> po;
+    std::vector<uint8_t> pslot;
+    {
+        std::vector<uint8_t> taken((size_t)n * kMaxProbes, (uint8_t)0);
+        if (st->probe_order) {
+            for (int64_t k = 0; k < n_prb_total; ++k) {
+                const int lp = st->probe_order[k], slot = st->probe_slot_order ? st->probe_slot_order[k] : 0;
+                if (lp < 0 || lp >= n || slot < 0 || slot >= kMaxProbes || pm[(size_t)slot * n + lp] == 255 || taken[(size_t)slot * n + lp])
+                    return fail(h, HS_E_INVALID, "probe_order / probe_slot_order must list every probe exactly once");
+                taken[(size_t)slot * n + lp] = 1;
+                po.push_back(lp); pslot.push_back((uint8_t)slot);
+            }
+        } else {
+            for (int i = 0; i < n && n_prb_total > 0; ++i)
+                for (int j = 0; j < kMaxProbes; ++j) if (pm[(size_t)j * n + i] != 255) { po.push_back(i); pslot.push_back((uint8_t)j); }
+        }
+    }
+    if (st->source_order || st->probe_order) {   // cross-LP ties go to the entity the reference constructed first (cand_rank, hs_station.hpp)
+        std::vector<int32_t> tr((size_t)n * (kMaxXSrc + 2) + 1 + (size_t)n * kMaxProbes, -1);
         int32_t *sr = tr.data() + n;
         for (size_t q = 0; q < so.size(); ++q) {
             sr[(size_t)sslot[q] * n + (size_t)so[q]] = (int32_t)q;               // a tick: its own Source's position
             if (tr[(size_t)so[q]] < 0) tr[(size_t)so[q]] = (int32_t)q;           // anything else: the LP's first-listed Source
         }
         for (int i = 0; i < n; ++i) if (tr[(size_t)i] < 0) tr[(size_t)i] = (int32_t)so.size() + i;   // sourceless LPs after them
-        tr[(size_t)n * (kMaxXSrc + 2)] = (int32_t)so.size() + n;                 // Probes behind all of them
+        tr[(size_t)n * (kMaxXSrc + 2)] = (int32_t)so.size() + n;                 // Probes behind all of them ...
+        int32_t *pr = tr.data() + (size_t)n * (kMaxXSrc + 2) + 1;                // ... each by its own position in `probes=[...]`
+        for (size_t q = 0; q < po.size(); ++q) pr[(size_t)pslot[q] * n + (size_t)po[q]] = (int32_t)so.size() + n + (int32_t)q;
         if ((rc = upload<int32_t>(h, &h->P.tie_rank, tr.data(), tr.size(), 0))) return rc;
     }
     h->P.sched_idx = nullptr;
@@ -672,26 +692,8 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     }
     if (h->cfg.mode == HS_MODE_SINGLE && (n_sched > 0 || h->any_probe || h->any_xsrc)) {
         // The prologue (hs_exact.hpp): the reference's pre-run events in the order it constructs them
-        std::vector<int32_t> po, sl((size_t)n_sched);
-        std::vector<uint8_t> pslot;
+        std::vector<int32_t> sl((size_t)n_sched);
         std::vector<int64_t> se((size_t)n_sched);
-        {   // probes in `probes=[...]` order: (LP, slot) pairs; default = LP-major, slot-minor
-            std::vector<uint8_t> taken((size_t)n * kMaxProbes, (uint8_t)0);
-            for (int64_t k = 0; k < n_prb_total; ++k) {
-                int lp = -1, slot = 0;
-                if (st->probe_order) { lp = st->probe_order[k]; slot = st->probe_slot_order ? st->probe_slot_order[k] : 0; }
-                else {
-                    int64_t seen_k = 0;
-                    for (int i = 0; i < n && lp < 0; ++i)
-                        for (int j = 0; j < kMaxProbes; ++j)
-                            if (pm[(size_t)j * n + i] != 255) { if (seen_k == k) { lp = i; slot = j; break; } ++seen_k; }
-                }
-                if (lp < 0 || lp >= n || slot < 0 || slot >= kMaxProbes || pm[(size_t)slot * n + lp] == 255 || taken[(size_t)slot * n + lp])
-                    return fail(h, HS_E_INVALID, "probe_order / probe_slot_order must list every probe exactly once");
-                taken[(size_t)slot * n + lp] = 1;
-                po.push_back(lp); pslot.push_back((uint8_t)slot);
-            }
-        }
         std::vector<int32_t> lp_of((size_t)n_sched);
         for (int i = 0; i < n && n_sched > 0; ++i)
             for (int64_t k = st->sched_off[i]; k < st->sched_off[i + 1]; ++k) lp_of[(size_t)k] = i;
@@ -744,13 +746,14 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     AL(generated, N); AL(accepted, N); AL(dropped, N); AL(completed, N); AL(rejected, N); AL(started, N);
     AL(received, N); AL(sink_w, N); AL(total_service, N); AL(q, N); AL(grp_time, N); AL(last_time, N);
     AL(events, N); AL(ev_kind, N * 11);
+    AL(dpA, N); AL(rcA, N); AL(dpD, NC); AL(rcD, NC); AL(qdep, N * kQCap); AL(qrc, N * kQCap);   // lineage (hs_station.hpp)
     if (h->any_profile) {      // the general-path instantiation of the run kernel loads / stores the probe state of every LP
         AL(PA, N * kMaxProbes); AL(seqP, N * kMaxProbes); AL(crtP, N * kMaxProbes); AL(p_arr, N * kMaxProbes);
-        AL(p_n, N * kMaxProbes); AL(ev_probe, N * 2); AL(sched_i, N);
+        AL(p_n, N * kMaxProbes); AL(ev_probe, N * 2); AL(sched_i, N); AL(rcP, N * kMaxProbes);
     }
     if (h->any_xsrc) {
         AL(XA, N * kMaxXSrc); AL(crtX, N * kMaxXSrc); AL(x_arr, N * kMaxXSrc); AL(x_n, N * kMaxXSrc); AL(seqX, N * kMaxXSrc);
-        AL(x_k, N * kMaxXSrc);
+        AL(x_k, N * kMaxXSrc); AL(dpX, N * kMaxXSrc); AL(rcX, N * kMaxXSrc);
     }
     if (h->any_probe) {
         h->L.pcap = (int64_t)(horizon_s / min_interval) + 8;

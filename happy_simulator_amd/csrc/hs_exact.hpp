@@ -44,6 +44,10 @@ struct XEvent {
     int64_t cr;       // context["created_at"] of the Request it carries; DELIVER / WORK: the request's admission ordinal
     int64_t aux;      // LINK / LINKCONT: link id;  DELIVER: pool entry of the payload;  LINKCONT: see ts
     int64_t ts;       // LINKCONT: send time (the message's creation stamp in the parallel engines)
+    // lineage (hs_station.hpp StationState::dpA ...): when it was created (INT64_MIN: before run()), how many steps after the
+    // root of the group it was created in, and when that root was created -- filled by xpush from XState's context
+    int64_t crt, rcrt;
+    int32_t dep;
     int32_t lp;
     uint16_t code, slot;
 };
@@ -68,6 +72,9 @@ struct XState {       // device memory, one per engine
     // hand-over waits until the clock has passed it
     int64_t *init_t;             // [n_init]
     int64_t tc;
+    // lineage context: the event being processed (ctx_on = 0: none, events are being constructed before run())
+    int64_t ctx_t, ctx_rc;
+    int32_t ctx_dp, ctx_on;
 };
 constexpr uint16_t kXInitFlag = 0x8000;   // XEvent::slot: constructed before run()
 
@@ -96,8 +103,12 @@ __device__ __forceinline__ bool xlt(const XEvent &a, const XEvent &b) {      // 
     return a.idx < b.idx;
 }
 // heapq.heappush: append, then _siftdown(heap, 0, len - 1)
-__device__ inline void xpush(XState &S, const XEvent &e) {
+__device__ inline void xpush(XState &S, const XEvent &e0) {
     if (S.heap_len >= S.heap_cap) { S.err |= 1; return; }
+    XEvent e = e0;
+    e.crt = S.ctx_on ? S.ctx_t : INT64_MIN;
+    e.dep = S.ctx_on ? (S.ctx_dp >= 254 ? 255 : S.ctx_dp + 1) : 0;
+    e.rcrt = S.ctx_on ? S.ctx_rc : INT64_MIN;
     int64_t pos = S.heap_len++;
     while (pos > 0) {
         const int64_t parent = (pos - 1) >> 1;
@@ -136,6 +147,7 @@ __device__ __forceinline__ XEvent xev(int64_t t, uint64_t idx, uint16_t code, in
                                       uint16_t slot = 0, int64_t ts = 0) {
     XEvent e;
     e.t = t; e.idx = idx; e.cr = cr; e.aux = aux; e.ts = ts; e.lp = lp; e.code = code; e.slot = slot;
+    e.crt = INT64_MIN; e.rcrt = INT64_MIN; e.dep = 0;
     return e;
 }
 
@@ -154,6 +166,7 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
                                   const RecordLogs &L, Totals *tot, XState &S, const XInit &I, int n, int C, bool net,
                                   int64_t start_ns, int64_t end_ns, int only = -1) {
     using namespace xdetail;
+    if (S.phase == 0) { S.ctx_on = 0; S.ctx_t = INT64_MIN; S.ctx_rc = INT64_MIN; S.ctx_dp = 0; }
     if (S.phase == 0 && only >= 0) {
         unsigned long long g = 0;
         const int lp = only;
@@ -251,6 +264,11 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
         cur = e.t;
         const int lp = e.lp;
         const int64_t t = e.t;
+        // lineage context of whatever this event constructs: created earlier -> it is the root of a chain of this nanosecond's
+        // group; created in this very nanosecond -> it carries its group's context
+        S.ctx_on = 1; S.ctx_t = t;
+        if (e.crt < t) { S.ctx_dp = 0; S.ctx_rc = e.crt; } else { S.ctx_dp = e.dep; S.ctx_rc = e.rcrt; }
+        const uint8_t lin_dp = (uint8_t)(S.ctx_dp >= 254 ? 255 : S.ctx_dp + 1);   // ... of a pending event it creates
         int kind = e.code == XE_SCHED ? 1 : (int)e.code;
         evk[kind]++;
         S.processed++;
@@ -280,7 +298,7 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
                 const unsigned long long idx_t = S.G++;
                 xpush(S, xev(a2, idx_t, XE_TICK, lp, 0, 0, (uint16_t)(j + 1)));
                 X.XA[o] = a2 < t ? kInfNs : a2;
-                X.seqX[o] = (uint32_t)idx_t; X.crtX[o] = t;
+                X.seqX[o] = (uint32_t)idx_t; X.crtX[o] = t; X.dpX[o] = lin_dp; X.rcX[o] = S.ctx_rc;
                 break;
             }
             X.generated[lp] += 1;
@@ -308,7 +326,7 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
                 const unsigned long long idx_t = S.G++;
                 xpush(S, xev(a2, idx_t, XE_TICK, lp));
                 X.A[lp] = a2 < t ? kInfNs : a2;                      // a tick in the past is popped and dropped
-                X.seqA[lp] = (uint32_t)idx_t; X.crtA[lp] = t;
+                X.seqA[lp] = (uint32_t)idx_t; X.crtA[lp] = t; X.dpA[lp] = lin_dp; X.rcA[lp] = S.ctx_rc;
             } else X.A[lp] = kInfNs;
         } break;
         case XE_SCHED:
@@ -369,7 +387,7 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
             X.svc_s[sj] = s;
             X.crt[sj] = k < L.cap ? L.adm[(size_t)k * N + lp] : 0;
             const unsigned long long idx_c = S.G++;
-            X.D[sj] = t + dur; X.seqD[sj] = (uint32_t)idx_c; X.crtD[sj] = t;
+            X.D[sj] = t + dur; X.seqD[sj] = (uint32_t)idx_c; X.crtD[sj] = t; X.dpD[sj] = lin_dp; X.rcD[sj] = S.ctx_rc;
             xpush(S, xev(t + dur, idx_c, XE_CONT, lp, 0, 0, (uint16_t)j));
         } break;
         case XE_CONT: {
@@ -442,7 +460,7 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
             if (a2 != kInfNs) {
                 const unsigned long long idx_t = S.G++;
                 xpush(S, xev(a2, idx_t, XE_PTICK, lp, 0, 0, (uint16_t)pj));
-                X.PA[o] = a2 < t ? kInfNs : a2; X.seqP[o] = (uint32_t)idx_t; X.crtP[o] = t;
+                X.PA[o] = a2 < t ? kInfNs : a2; X.seqP[o] = (uint32_t)idx_t; X.crtP[o] = t; X.rcP[o] = S.ctx_rc;
             } else X.PA[o] = kInfNs;
         } break;
         case XE_PSAMPLE: {                                                   // measure_callback (probe.py:51-66)

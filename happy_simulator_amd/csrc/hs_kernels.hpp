@@ -45,8 +45,30 @@ __device__ __forceinline__ bool cand_less(const Candidate &a, const Candidate &b
     if (a.valid != b.valid) return a.valid > b.valid;
     if (!a.valid) return false;
     if (a.t != b.t) return a.t < b.t;
+    // the reference's (time, _sort_index): of two events on one nanosecond the one created first; of two created in one
+    // nanosecond the one fewer steps from the root of the group that created it, then the one whose root was created first
+    // (the heap is a FIFO inside a nanosecond: StationState lineage); then the construction order
     if (a.t_created != b.t_created) return a.t_created < b.t_created;
+    if (a.depth != b.depth) return a.depth < b.depth;
+    if (a.rcrt != b.rcrt) return a.rcrt < b.rcrt;
     return a.rank < b.rank;
+}
+__device__ __forceinline__ Candidate cand_load_agent(const Candidate *p) {
+    Candidate c;
+    c.t = __hip_atomic_load(&p->t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    c.t_created = __hip_atomic_load(&p->t_created, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    c.rcrt = __hip_atomic_load(&p->rcrt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    c.depth = __hip_atomic_load(&p->depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    c.lp = __hip_atomic_load(&p->lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    c.rank = __hip_atomic_load(&p->rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    c.valid = __hip_atomic_load(&p->valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    c.pad = 0; c.pad2 = 0;
+    return c;
+}
+__device__ __forceinline__ Candidate cand_none(int lp) {
+    Candidate c;
+    c.valid = 0; c.t = kInfNs; c.t_created = 0; c.rcrt = INT64_MIN; c.depth = 0; c.lp = lp; c.rank = lp; c.pad = 0; c.pad2 = 0;
+    return c;
 }
 
 __device__ __forceinline__ Candidate wave_min_cand(Candidate c) {
@@ -55,6 +77,9 @@ __device__ __forceinline__ Candidate wave_min_cand(Candidate c) {
         Candidate d;
         d.t = shfl_xor_ll(c.t, o);
         d.t_created = shfl_xor_ll(c.t_created, o);
+        d.rcrt = shfl_xor_ll(c.rcrt, o);
+        d.depth = __shfl_xor(c.depth, o, 64);
+        d.pad = 0; d.pad2 = 0;
         d.lp = __shfl_xor(c.lp, o, 64);
         d.rank = __shfl_xor(c.rank, o, 64);
         d.valid = __shfl_xor(c.valid, o, 64);
@@ -82,7 +107,9 @@ __device__ __forceinline__ void load_station(Station<C, PF, UNI> &S, const Stati
     S.SA = kInfNs; S.sc_i = S.sc_end = 0; S.sc_t = P.sched_t; S.sc_idx = P.sched_idx;
     S.n_xsrc = 0; S.x_base = P.stream_base[lp];
 #pragma unroll
-    for (int j = 0; j < kMaxXSrc; ++j) { S.x_kind[j] = 0; S.XA[j] = kInfNs; S.seqX[j] = 0; S.crtX[j] = 0; S.x_arr[j] = 0; S.x_n[j] = 0; S.x_k[j] = 0; S.x_rate[j] = 1.0; S.x_stop[j] = -1; }
+    for (int j = 0; j < kMaxXSrc; ++j) { S.x_kind[j] = 0; S.XA[j] = kInfNs; S.seqX[j] = 0; S.crtX[j] = 0; S.x_arr[j] = 0; S.x_n[j] = 0; S.x_k[j] = 0; S.x_rate[j] = 1.0; S.x_stop[j] = -1; S.dpX[j] = 0; S.rcX[j] = INT64_MIN; }
+#pragma unroll
+    for (int j = 0; j < kMaxProbes; ++j) S.rcP[j] = INT64_MIN;
     if constexpr (PF) {
         if (P.xsrc_kind != nullptr) {
 #pragma unroll
@@ -93,7 +120,7 @@ __device__ __forceinline__ void load_station(Station<C, PF, UNI> &S, const Stati
                     S.n_xsrc = j + 1;
                     S.x_rate[j] = P.xsrc_rate[o]; S.x_stop[j] = P.xsrc_stop[o];
                     S.XA[j] = X.XA[o]; S.seqX[j] = X.seqX[o]; S.crtX[j] = X.crtX[o]; S.x_arr[j] = X.x_arr[o]; S.x_n[j] = X.x_n[o];
-                    S.x_k[j] = X.x_k[o];
+                    S.x_k[j] = X.x_k[o]; S.dpX[j] = X.dpX[o]; S.rcX[j] = X.rcX[o];
                 }
             }
         }
@@ -115,6 +142,7 @@ __device__ __forceinline__ void load_station(Station<C, PF, UNI> &S, const Stati
                 S.n_probes = j + 1;
                 S.tab_p[j] = P.tabs->times + (size_t)P.tabs->probe_row[o] * (size_t)S.tab_cap;
                 S.PA[j] = X.PA[o]; S.seqP[j] = X.seqP[o]; S.crtP[j] = X.crtP[o]; S.p_arr[j] = X.p_arr[o]; S.p_n[j] = X.p_n[o];
+                S.rcP[j] = X.rcP[o];
             }
         }
         S.probe_t = L.probe_t + lp; S.probe_v = L.probe_v + lp; S.pcap = L.pcap;
@@ -126,11 +154,14 @@ __device__ __forceinline__ void load_station(Station<C, PF, UNI> &S, const Stati
     S.received = X.received[lp]; S.sink_w = X.sink_w[lp];
     S.total_service = X.total_service[lp];
     S.last_time = X.last_time[lp]; S.grp_time = X.grp_time[lp];
+    S.dpA = X.dpA[lp]; S.rcA = X.rcA[lp]; S.cd = 0; S.cr = INT64_MIN;
+    S.qdep = X.qdep + lp; S.qrc = X.qrc + lp;
 #pragma unroll
     for (int i = 0; i < C; ++i) {
         S.D[i] = X.D[(size_t)i * n + lp]; S.seqD[i] = X.seqD[(size_t)i * n + lp];
         S.crtD[i] = X.crtD[(size_t)i * n + lp]; S.svc_s[i] = X.svc_s[(size_t)i * n + lp];
         S.crt[i] = (C > 1) ? X.crt[(size_t)i * n + lp] : 0;
+        S.dpD[i] = X.dpD[(size_t)i * n + lp]; S.rcD[i] = X.rcD[(size_t)i * n + lp];
     }
     S.tid = tid;
     S.init_streams(P.seed[lp], P.stream_base[lp], X.arr_k[lp], X.svc_k[lp], ring_a, ring_s);
@@ -144,7 +175,10 @@ __device__ __forceinline__ void load_station(Station<C, PF, UNI> &S, const Stati
     S.qmem = qmem; S.tid = tid; S.qh = 0; S.qn = 0;
     const uint32_t q = X.q[lp];
     const int qn = (int)(q >> 16);
-    for (int i = 0; i < qn; ++i) S.qpush((q >> (8 * i)) & 0xffu);
+    // (a group that an earlier window stopped inside: the lineage of its <= 2 waiting events is already in slots 0, 1 of the
+    // lineage columns -- store_station put it there)
+    for (int i = 0; i < qn; ++i) { S.qmem[i][tid] = (uint8_t)((q >> (8 * i)) & 0xffu); }
+    S.qn = qn;
 }
 
 template <int C, bool PF, bool UNI = false>
@@ -157,15 +191,23 @@ __device__ __forceinline__ void store_station(const Station<C, PF, UNI> &Sc, con
     X.received[lp] = S.received; X.sink_w[lp] = S.sink_w;
     X.total_service[lp] = S.total_service;
     X.last_time[lp] = S.last_time; X.grp_time[lp] = S.grp_time;
+    X.dpA[lp] = (uint8_t)S.dpA; X.rcA[lp] = S.rcA;
 #pragma unroll
     for (int i = 0; i < C; ++i) {
         X.D[(size_t)i * n + lp] = S.D[i]; X.seqD[(size_t)i * n + lp] = S.seqD[i];
         X.crtD[(size_t)i * n + lp] = S.crtD[i]; X.svc_s[(size_t)i * n + lp] = S.svc_s[i];
         if (C > 1) X.crt[(size_t)i * n + lp] = S.crt[i];
+        X.dpD[(size_t)i * n + lp] = (uint8_t)S.dpD[i]; X.rcD[(size_t)i * n + lp] = S.rcD[i];
     }
     X.arr_k[lp] = S.arr_k; X.svc_k[lp] = S.svc_k;   // draws CONSUMED; pre-drawn values still in the rings are dropped
     uint32_t q = 0;
     int qn = S.qn > 2 ? 2 : S.qn;   // an overshoot root leaves at most two in-group events
+    if (qn > 0 && S.qh != 0) {      // ... whose lineage moves to slots 0, 1 (where load_station expects it)
+        uint8_t d0 = S.qdep[(size_t)(S.qh % kQCap) * S.ls], d1 = S.qdep[(size_t)((S.qh + 1) % kQCap) * S.ls];
+        int64_t r0 = S.qrc[(size_t)(S.qh % kQCap) * S.ls], r1 = S.qrc[(size_t)((S.qh + 1) % kQCap) * S.ls];
+        S.qdep[0] = d0; S.qrc[0] = r0;
+        if (qn > 1) { S.qdep[(size_t)S.ls] = d1; S.qrc[(size_t)S.ls] = r1; }
+    }
     for (int i = 0; i < qn; ++i) q |= (uint32_t)S.qmem[(S.qh + i) % kQCap][S.tid] << (8 * i);
     q |= (uint32_t)qn << 16;
     X.q[lp] = q;
@@ -177,6 +219,7 @@ __device__ __forceinline__ void store_station(const Station<C, PF, UNI> &Sc, con
         for (int j = 0; j < kMaxProbes; ++j) if (j < S.n_probes) {
             const size_t o = (size_t)j * n + lp;
             X.PA[o] = S.PA[j]; X.seqP[o] = S.seqP[j]; X.crtP[o] = S.crtP[j]; X.p_arr[o] = S.p_arr[j]; X.p_n[o] = S.p_n[j];
+            X.rcP[o] = S.rcP[j];
         }
         X.ev_probe[lp] += S.evp[0]; X.ev_probe[(size_t)n + lp] += S.evp[1];
         tot += S.evp[0] + S.evp[1];
@@ -185,17 +228,16 @@ __device__ __forceinline__ void store_station(const Station<C, PF, UNI> &Sc, con
         for (int j = 0; j < kMaxXSrc; ++j) if (j < S.n_xsrc) {
             const size_t o = (size_t)j * n + lp;
             X.XA[o] = S.XA[j]; X.seqX[o] = S.seqX[j]; X.crtX[o] = S.crtX[j]; X.x_arr[o] = S.x_arr[j]; X.x_n[o] = S.x_n[j];
-            X.x_k[o] = S.x_k[j];
+            X.x_k[o] = S.x_k[j]; X.dpX[o] = (uint8_t)S.dpX[j]; X.rcX[o] = S.rcX[j];
         }
     }
     X.events[lp] += tot;
 }
 
-// first pending event of an LP: time, creation time, which root
+// first pending event of an LP: time, creation time, lineage, which root
 template <int C, bool PF, bool UNI = false>
 __device__ __forceinline__ Candidate make_candidate(const Station<C, PF, UNI> &S) {
-    Candidate c;
-    c.lp = S.lp; c.rank = S.lp; c.valid = 0; c.t = kInfNs; c.t_created = 0; c.pad = 0;
+    Candidate c = cand_none(S.lp);
     if (S.qn > 0) {   // a group already in progress keeps the floor
         c.t = S.grp_time; c.t_created = S.grp_time; c.valid = 1;
         return c;
@@ -204,21 +246,23 @@ __device__ __forceinline__ Candidate make_candidate(const Station<C, PF, UNI> &S
     if (t == kInfNs) return c;
     const int w = S.pick_root(t);
     c.t = t; c.valid = 1;
-    if (w == 0) { c.t_created = S.crtA; c.pad = 2; }
-    else if (w >= kRootXSrc) {
+    c.t_created = S.root_crt(w);
+    if (w == 0) { c.depth = S.dpA; c.rcrt = S.rcA; c.pad = 2; }
+    else if (PF && w >= kRootXSrc) {
 #pragma unroll
-        for (int j = 0; j < kMaxXSrc; ++j) if (j == w - kRootXSrc) c.t_created = S.crtX[j];
+        for (int j = 0; j < kMaxXSrc; ++j) if (j == w - kRootXSrc) { c.depth = S.dpX[j]; c.rcrt = S.rcX[j]; }
         c.pad = 3 + (w - kRootXSrc);
     }
-    else if (w >= kRootProbe) {
+    else if (PF && w >= kRootProbe) {
 #pragma unroll
-        for (int j = 0; j < kMaxProbes; ++j) if (j == w - kRootProbe) c.t_created = S.crtP[j];
-        c.pad = 1;              // a Probe's tick: constructed after every Source (core/simulation.py:145-160) -- ranks behind them
+        for (int j = 0; j < kMaxProbes; ++j) if (j == w - kRootProbe) c.rcrt = S.rcP[j];
+        c.depth = 1;            // a Probe's next tick is created by its tick, always a root
+        c.pad = 8 + (w - kRootProbe);   // ranked by the Probe's own position in `probes=[...]`, behind every Source (cand_rank)
     }
-    else if (w == kRootSched) c.t_created = INT64_MIN;   // constructed before run()
+    else if (PF && w == kRootSched) { c.depth = 0; c.rcrt = INT64_MIN; }   // constructed before run()
     else {
 #pragma unroll
-        for (int i = 0; i < C; ++i) if (i == w - 1) c.t_created = S.crtD[i];
+        for (int i = 0; i < C; ++i) if (i == w - 1) { c.depth = S.dpD[i]; c.rcrt = S.rcD[i]; }
     }
     return c;
 }
@@ -295,9 +339,11 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
     X.generated[lp] = 0; X.accepted[lp] = 0; X.dropped[lp] = 0; X.completed[lp] = 0; X.rejected[lp] = 0;
     X.started[lp] = 0; X.received[lp] = 0; X.sink_w[lp] = 0; X.total_service[lp] = 0.0;
     X.q[lp] = 0; X.grp_time[lp] = start_ns; X.last_time[lp] = start_ns; X.events[lp] = 0;
+    X.dpA[lp] = 0; X.rcA[lp] = INT64_MIN;     // lineage: the first tick was constructed before run()
     for (int i = 0; i < C; ++i) {
         X.D[(size_t)i * n + lp] = kInfNs; X.seqD[(size_t)i * n + lp] = 0; X.crtD[(size_t)i * n + lp] = start_ns;
         X.svc_s[(size_t)i * n + lp] = 0.0; X.crt[(size_t)i * n + lp] = 0;
+        X.dpD[(size_t)i * n + lp] = 0; X.rcD[(size_t)i * n + lp] = INT64_MIN;
     }
     for (int k = 0; k < 11; ++k) X.ev_kind[(size_t)k * n + lp] = 0;
     if constexpr (!PF) return;
@@ -320,6 +366,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
             }
             // (default stamps, replaced by the prologue's true sort indices: after the first Source, before the probes)
             X.XA[o] = XA; X.seqX[o] = 1u + (uint32_t)j; X.crtX[o] = start_ns; X.x_arr[o] = x_arr; X.x_n[o] = 0; X.x_k[o] = x_k;
+            X.dpX[o] = 0; X.rcX[o] = INT64_MIN;
             if (NX.next_time != nullptr && XA < NX.next_time[lp]) NX.next_time[lp] = XA;   // network engine: first pending event
         }
     }
@@ -333,7 +380,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
                 p_arr = 0;                                                                                     // ... whose index it is
             }
             if (NX.next_time != nullptr && PA < NX.next_time[lp]) NX.next_time[lp] = PA;   // network engine: first pending event
-            X.PA[o] = PA; X.seqP[o] = stamp++; X.crtP[o] = start_ns; X.p_arr[o] = p_arr; X.p_n[o] = 0;
+            X.PA[o] = PA; X.seqP[o] = stamp++; X.crtP[o] = start_ns; X.p_arr[o] = p_arr; X.p_n[o] = 0; X.rcP[o] = INT64_MIN;
         }
         X.ev_probe[lp] = 0; X.ev_probe[(size_t)n + lp] = 0;
         X.seq[lp] = 1 + kMaxXSrc + kMaxProbes;
@@ -390,7 +437,7 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
 
     Station<C, PF, UNI> S;
     Candidate mine;
-    mine.valid = 0; mine.t = kInfNs; mine.t_created = 0; mine.lp = lp; mine.rank = lp;
+    mine = cand_none(lp);
     if constexpr (PC) {
         if (producer) {
             // ---- producer wavefront: stream values for LP `tid`, as long as its consumer is in the request-order loop
@@ -619,15 +666,10 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
     if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     Candidate best;
-    best.valid = 0; best.t = kInfNs; best.t_created = 0; best.lp = 0; best.rank = 0;
+    best = cand_none(0);
     if (!producer) {
         for (int b = tid; b < (int)gridDim.x; b += kBlock) {
-            Candidate c;
-            c.t = __hip_atomic_load(&cands[b].t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            c.t_created = __hip_atomic_load(&cands[b].t_created, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            c.lp = __hip_atomic_load(&cands[b].lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            c.rank = __hip_atomic_load(&cands[b].rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            c.valid = __hip_atomic_load(&cands[b].valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const Candidate c = cand_load_agent(&cands[b]);
             if (cand_less(c, best)) best = c;
         }
         best = wave_min_cand(best);
@@ -1028,7 +1070,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
 
     NetStation<C> S;
     Candidate mine;
-    mine.valid = 0; mine.t = kInfNs; mine.t_created = 0; mine.lp = lp; mine.rank = lp; mine.pad = 0;
+    mine = cand_none(lp);
     if (act) {
         load_net<C>(S, P, NP, X, NX, L, lp, n, qmem, enqpay, tid, send_idx, SC);
         for (;;) {
@@ -1112,14 +1154,9 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
     if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     Candidate best;
-    best.valid = 0; best.t = kInfNs; best.t_created = 0; best.lp = 0; best.rank = 0;
+    best = cand_none(0);
     for (int b = tid; b < (int)gridDim.x; b += kBlock) {
-        Candidate c;
-        c.t = __hip_atomic_load(&cands[b].t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c.t_created = __hip_atomic_load(&cands[b].t_created, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c.lp = __hip_atomic_load(&cands[b].lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c.rank = __hip_atomic_load(&cands[b].rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c.valid = __hip_atomic_load(&cands[b].valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const Candidate c = cand_load_agent(&cands[b]);
         if (cand_less(c, best)) best = c;
     }
     best = wave_min_cand(best);

@@ -117,6 +117,8 @@ struct StationParams {          // read-only, [n_lp] each
     // tick, and the LP whose first-listed Source is another one need not come first), then one word: the offset that puts a
     // Probe's tick behind every Source and every sourceless LP.  One array, so that the run kernels carry no further argument
     // through their loops (two more kernel arguments cost the headline kernel 2 % -- SGPR pressure, measured); cand_rank().
+    // ... then [kMaxProbes][n_lp]: the rank of the PROBE in that slot (its position in `probes=[...]`, behind every Source and
+    // every sourceless LP): a Probe's tick competes with its own list position.
     // further Sources of the LP (PF instantiations, general path): null = none
     const uint8_t *xsrc_kind;       // [kMaxXSrc][n_lp] 0 none, 1 Poisson, 2 constant
     const double *xsrc_rate;        // [kMaxXSrc][n_lp]
@@ -155,6 +157,17 @@ struct StationState {           // read-write; [n_lp] each unless noted
     int64_t *crtP, *p_arr, *p_n;   // [kMaxProbes][n_lp] creation time of the pending tick, its index in the Probe's tick table, samples taken
     int64_t *ev_probe;          // [2][n_lp] SourceEvent@Probe, probe_event
     int64_t *sched_i;           // [n_lp] index into sched_t of the LP's next scheduled Request (PF instantiation only)
+    // LINEAGE of every pending event (the election of the one event beyond end_time, cand_less): the reference's heap is a FIFO
+    // among the events of one nanosecond -- a group runs breadth-first from its roots (the events that were pending from
+    // earlier) -- so of two events CREATED in one nanosecond the one fewer steps from its group's root was created first, then
+    // the one whose root was created first (core/event.py:62-77,337-344; tools/election_rules.py).  Per pending event: how many
+    // steps after the root of the group it was created in (dp*), and when that root was created (rc*).
+    uint8_t *dpA; int64_t *rcA;   // [n_lp] the pending tick
+    uint8_t *dpD; int64_t *rcD;   // [C][n_lp] the pending departures
+    int64_t *rcP;                 // [kMaxProbes][n_lp] the pending probe ticks (always one step from the previous tick)
+    uint8_t *dpX; int64_t *rcX;   // [kMaxXSrc][n_lp] the pending ticks of the further Sources
+    // ... and of the events waiting in the in-group FIFO (general path only; global memory, [kQCap][n_lp])
+    uint8_t *qdep; int64_t *qrc;
     // further Sources (PF instantiation only; null = none)
     int64_t *XA, *crtX, *x_arr, *x_n;   // [kMaxXSrc][n_lp] pending tick, its creation time, provider time, generated_count
     uint32_t *seqX;             // [kMaxXSrc][n_lp]
@@ -187,19 +200,24 @@ struct Totals {                 // engine-wide accumulators (device memory)
 
 struct Candidate {              // an LP's first event beyond end_ns (SINGLE-mode overshoot election)
     long long t;                // event time
-    long long t_created;        // when it was created (proxy for the global sort index)
+    long long t_created;        // when it was created
+    long long rcrt;             // when the root of the group it was created in was created (StationState lineage)
+    int depth;                  // steps from that root
     int lp;
     int valid;
-    int rank;                   // last key: the position in the reference's construction order (`sources=[...]`), cand_rank()
-    int pad;                    // what the candidate is, for cand_rank: 0 departure / message / injected Request, 1 a Probe's tick,
-                                // 2 + slot the tick of the LP's Source in that slot
+    int rank;                   // last key: the position in the reference's construction order (`sources=[...]`, `probes=[...]`), cand_rank()
+    int pad;                    // what the candidate is, for cand_rank: 0 departure / message / injected Request,
+                                // 2 + slot the tick of the LP's Source in that slot, 8 + slot the tick of the Probe in that slot
+    int pad2;
 };
 
 // the last election key of an LP's candidate (see StationParams::tie_rank)
 __device__ __forceinline__ int cand_rank(const StationParams &P, int lp, int n, int pad) {
-    if (P.tie_rank == nullptr) return lp + (pad == 1 ? n : 0);
+    if (P.tie_rank == nullptr)   // construction order = LP order: the LP's Sources by slot, Probes behind everything
+        return pad >= 8 ? n * (kMaxXSrc + 1) + lp * kMaxProbes + (pad - 8) : lp * (kMaxXSrc + 1) + (pad >= 2 ? pad - 2 : 0);
+    if (pad >= 8) return P.tie_rank[(size_t)(kMaxXSrc + 2) * (size_t)n + 1 + (size_t)(pad - 8) * (size_t)n + lp];
     if (pad >= 2) return P.tie_rank[(size_t)(pad - 1) * (size_t)n + lp];
-    return P.tie_rank[lp] + (pad == 1 ? P.tie_rank[(size_t)(kMaxXSrc + 2) * (size_t)n] : 0);
+    return P.tie_rank[lp];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -229,6 +247,14 @@ struct Station {
     int64_t crt[C];
     double total_service;
     int64_t last_time, grp_time;
+    // lineage (StationState::dpA ...): of the pending events, and of the event being processed (cd steps from its group's root,
+    // which was created at cr)
+    int32_t dpA, dpD[C], cd;
+    int64_t rcA, rcD[C], cr;
+    int64_t rcP[kMaxProbes];
+    int32_t dpX[kMaxXSrc];
+    int64_t rcX[kMaxXSrc];
+    uint8_t *qdep; int64_t *qrc;     // the in-group FIFO's lineage columns: entry `slot` of this LP at [slot * ls]
     // entity streams (DESIGN.md "Random streams"): draws consumed so far + the pre-drawn values
     uint32_t key0, key1, asid0, asid1, ssid0, ssid1;
     uint64_t arr_k, svc_k;
@@ -271,17 +297,24 @@ struct Station {
     int qoverflow;
     bool force_general;         // debug: route every group through the general FIFO path
 
+    // an event created by the one being processed: one step further from the group's root
     __device__ __forceinline__ void qpush(uint32_t code) {
         if (qn >= kQCap) { qoverflow = 1; return; }
-        qmem[(qh + qn) % kQCap][tid] = (uint8_t)code;
+        const int slot = (qh + qn) % kQCap;
+        qmem[slot][tid] = (uint8_t)code;
+        qdep[(size_t)slot * ls] = (uint8_t)(cd >= 254 ? 255 : cd + 1);
+        qrc[(size_t)slot * ls] = cr;
         ++qn;
     }
     __device__ __forceinline__ uint32_t qpop() {
         const uint32_t c = qmem[qh][tid];
+        cd = qdep[(size_t)qh * ls];
+        cr = qrc[(size_t)qh * ls];
         qh = (qh + 1) % kQCap;
         --qn;
         return c;
     }
+    __device__ __forceinline__ int32_t dp_next(int steps) const { return cd + steps > 255 ? 255 : cd + steps; }
 
     __device__ __forceinline__ void init_streams(uint64_t seed, uint64_t base, uint64_t ak, uint64_t sk,
                                                  double (*ring_a)[kBlock], double (*ring_s)[kBlock]) {
@@ -391,7 +424,7 @@ struct Station {
         uint32_t r = payload ? 1u : 0u;
         if (a2 == t) { r |= 2u; A = kInfNs; }
         else if (a2 < t) { A = kInfNs; }                                  // popped later as "time travel" and dropped (simulation.py:480-489)
-        else { A = a2; seqA = seq++; crtA = t; }
+        else { A = a2; seqA = seq++; crtA = t; dpA = dp_next(1); rcA = cr; }
         return r;
     }
     // QueuedResource.handle_event -> Queue._handle_enqueue (components/queue.py:122-147).  True: QUEUE_NOTIFY created.
@@ -434,8 +467,9 @@ struct Station {
             svc_s[i] = s;
             if (C > 1) crt[i] = (k < cap) ? adm[k * ls] : 0;
             if (d == t) { D[i] = kInfNs - 1; same = (uint32_t)i + 1; }   // in-group continuation: parked, not pending
-            else { D[i] = d; seqD[i] = seq++; crtD[i] = t; }
+            else { D[i] = d; seqD[i] = seq++; crtD[i] = t; dpD[i] = dp_next(2); rcD[i] = cr; }   // QUEUE_DELIVER -> payload -> continuation
         }
+        if (same) ++cd;                                                   // (the caller pushes the in-group continuation: deliver + 2)
         return same;
     }
     // generator resumes (server/server.py:252-273) + schedule_poll hook (queue_driver.py:79-84).
@@ -490,7 +524,7 @@ struct Station {
             const int64_t a2 = tick_lookup(tab_p[i], tab_cap, k2, overflow);
             p_arr[i] = k2;
             if (a2 <= t) PA[i] = kInfNs;
-            else { PA[i] = a2; seqP[i] = seq++; crtP[i] = t; }
+            else { PA[i] = a2; seqP[i] = seq++; rcP[i] = cr; crtP[i] = t; }
         }
     }
     __device__ __forceinline__ void do_probe_sample(int j, int64_t t) {
@@ -554,21 +588,25 @@ struct Station {
             if (payload) qpush(Q_ENQ);
             if (a2 == t) { XA[i] = kInfNs; qpush(Q_TICK | ((uint32_t)(i + 1) << 3)); }
             else if (a2 < t) XA[i] = kInfNs;                              // popped later as "time travel" and dropped
-            else { XA[i] = a2; seqX[i] = seq++; crtX[i] = t; }
+            else { XA[i] = a2; seqX[i] = seq++; crtX[i] = t; dpX[i] = dp_next(1); rcX[i] = cr; }
         }
     }
 
     // ---- chains with at most one event in flight (fast path pieces) ---------------------------
     // returns true if the general FIFO must take over (a same-time continuation was created)
+    // (cd = the QUEUE_POLL's steps from the group's root)
     __device__ __forceinline__ bool chain_from_poll(int64_t t) {
         if (!do_poll()) return false;
+        ++cd;                                                             // the QUEUE_DELIVER it created
         const uint32_t same = do_deliver_work(t);
         if (same) { qpush(Q_CONT | ((same - 1) << 3)); return true; }
         return false;
     }
-    __device__ __forceinline__ bool chain_from_enqueue(int64_t t) {
+    __device__ __forceinline__ bool chain_from_enqueue(int64_t t) {   // (cd = the Request's steps from the group's root)
         if (!do_enqueue(t)) return false;
+        ++cd;
         if (!do_notify()) return false;
+        ++cd;
         return chain_from_poll(t);
     }
 
@@ -611,7 +649,24 @@ struct Station {
         }
         return best;
     }
+    // creation time of pending root `which` (pick_root's code)
+    __device__ __forceinline__ int64_t root_crt(int which) const {
+        int64_t c = INT64_MIN;                                            // kRootSched: constructed before run()
+        if (which == 0) c = crtA;
+        else if (PF && which >= kRootXSrc) {
+#pragma unroll
+            for (int j = 0; j < kMaxXSrc; ++j) if (j == which - kRootXSrc) c = crtX[j];
+        } else if (PF && which >= kRootProbe) {
+#pragma unroll
+            for (int j = 0; j < kMaxProbes; ++j) if (j == which - kRootProbe) c = crtP[j];
+        } else if (!(PF && which == kRootSched)) {
+#pragma unroll
+            for (int i = 0; i < C; ++i) if (i == which - 1) c = crtD[i];
+        }
+        return c;
+    }
     __device__ __forceinline__ void run_root(int which, int64_t t) {
+        cd = 0; cr = root_crt(which);                                     // a root: pending from an earlier nanosecond
         if (which == 0) root_tick(t);
         else if (PF && which >= kRootXSrc) root_xsrc(which - kRootXSrc, t);
         else if (PF && which >= kRootProbe) root_probe(which - kRootProbe, t);
@@ -675,21 +730,26 @@ struct Station {
             // site so that a wavefront whose lanes mix ticks and departures executes the (expensive) service
             // draw once per iteration, not once per branch.
             bool general = false, want_poll = false;
+            cd = 0;
             if (A == t) {
+                cr = crtA;
                 const uint32_t r = do_tick(t);
                 if (svc_kind == 2) {             // Source -> Sink directly
                     if ((r & 1u) && egress == 1) { stage_direct_sink(t); do_sink(); }
                     if (r & 2u) { qpush(Q_TICK); general = true; }
                 }
                 else if (r & 2u) { if (r & 1u) qpush(Q_ENQ); qpush(Q_TICK); general = true; }
-                else if (r & 1u) want_poll = do_enqueue(t) && do_notify();
+                else if (r & 1u) { want_poll = do_enqueue(t) && do_notify(); cd = 3; }   // tick -> Request -> QUEUE_NOTIFY -> QUEUE_POLL
             } else {
                 int slot = 0;
 #pragma unroll
                 for (int i = 0; i < C; ++i) if (D[i] == t) slot = i;
+#pragma unroll
+                for (int i = 0; i < C; ++i) if (i == slot) cr = crtD[i];
                 const uint32_t r = do_cont(slot, t);
                 if (r & 1u) do_sink();
                 want_poll = (r & 2u) != 0;
+                cd = 1;                                                  // continuation -> QUEUE_POLL
             }
             if (want_poll) general = chain_from_poll(t);
             if (general) drain(t);
@@ -736,6 +796,13 @@ struct Station {
         arr_time = tick_f ? a2 : arr_time;
         A = tick_f ? a2 : A;
         seqA = tick_f ? seq : seqA;
+        // lineage: the next tick is one step from this one; a service that starts is six steps from a tick (Request, QUEUE_NOTIFY,
+        // QUEUE_POLL, QUEUE_DELIVER, the payload, the continuation), four from the departure that freed the worker
+        const int64_t root_c = tick ? crtA : crtD[0];
+        rcA = tick_f ? crtA : rcA;
+        dpA = tick_f ? 1 : dpA;
+        rcD[0] = del_f ? root_c : rcD[0];
+        dpD[0] = del_f ? (tick ? 6 : 4) : dpD[0];
         crtA = tick_f ? t : crtA;
         seq += tick_f ? 1u : 0u;
         const bool pop_a = tick_f && src_kind == 1;
@@ -795,6 +862,7 @@ struct Station {
         int64_t lt;                 // time of the latest processed event
         uint32_t n_tick, n_notify, n_poll, n_start, n_dep;
         bool pend, blocked, bail, done;
+        int64_t crtA0;              // creation time of the tick that was pending when the window began (lineage, req_finish)
     };
     __device__ __forceinline__ bool req_eligible() const {
         return C == 1 && !force_general && qn == 0 && conc == 1 && qcap < 0 && stop_ns < 0 && svc_kind != 2 &&
@@ -811,7 +879,7 @@ struct Station {
         c.lt = (p && d > c.lt) ? d : c.lt;
     }
     __device__ __forceinline__ void req_begin(ReqCursor &c, int64_t T) {
-        c.T = T; c.nb = buf; c.lt = last_time;
+        c.T = T; c.nb = buf; c.lt = last_time; c.crtA0 = crtA;
         c.n_tick = c.n_notify = c.n_poll = c.n_start = c.n_dep = 0;
         c.blocked = c.bail = c.done = false;
         const bool busy = active > 0;
@@ -901,6 +969,30 @@ struct Station {
             seqA = seq + (d_first ? 1u : 0u);
             seqD[0] = seq + (d_first ? 0u : 1u);
             seq += 2u;
+        }
+        // Lineage of what is pending now (only the election beyond end_time reads it, so it is reconstructed HERE, from the
+        // admission log and the service stream, instead of being carried through the loop).  Every tick was a root of its own group
+        // (a tie made the lane bail), and in this regime every tick is admitted: adm[k] is the time of tick k.
+        if (c.n_tick != 0u) {       // the pending tick was created by tick number accepted - 1, itself created at tick accepted - 2
+            dpA = 1;
+            rcA = accepted >= 2 ? adm[(accepted - 2) * ls] : c.crtA0;
+        }
+        if (c.pend && c.n_start != 0u) {      // the request in service is number m = started - 1; it started at pendS
+            const int64_t m = started - 1;
+            const int64_t a_m = m < cap ? adm[m * ls] : 0;
+            if (c.pendS == a_m) {             // ... on arrival: six steps from tick m, which was created at tick m - 1
+                dpD[0] = 6;
+                rcD[0] = m >= 1 ? adm[(m - 1) * ls] : c.crtA0;
+            } else {                          // ... when request m - 1 left: four steps from that continuation, created when IT started
+                double s_prev = svc_const_s;
+                if (HSG(svc_kind == 0, true)) {
+                    Stream st;
+                    st.init(((uint64_t)key1 << 32) | key0, ((uint64_t)ssid1 << 32) | ssid0, (uint64_t)(m - 1));
+                    s_prev = svc_value(st.next_uniform());
+                }
+                dpD[0] = 4;
+                rcD[0] = c.pendS - ns_from_seconds(s_prev);
+            }
         }
         last_time = c.lt;
     }

@@ -16,9 +16,10 @@ STATION_CASES = list(range(40))
 RING_CASES = list(range(30))          # incl. case 24: two Requests injected for one Server at the start instant
 # Tie storms (random_specs.tie_spec): lock-step constant sources, Requests injected at the start instant and on the sources'
 # own tick times, probes on the same nanoseconds, c <= 16 -- every order the reference's TWO sort counters decide, reproduced
-# by the prologue (csrc/hs_exact.hpp).  Case 85 is left out: its one event beyond end_time is a tie between two LPs whose
-# candidates were also CREATED in the same nanosecond (documented cross-LP deviation (i)).
-TIE_CASES = [k for k in range(100) if k != 85]
+# by the prologue (csrc/hs_exact.hpp).  Case 85 -- its one event beyond end_time is a tie between two LPs whose candidates were
+# also CREATED in the same nanosecond -- was left out in round 2; the election's lineage key (csrc/hs_station.hpp StationState::dpA)
+# decides it now.
+TIE_CASES = list(range(100))
 
 
 def check_station_case(k, spec=None):

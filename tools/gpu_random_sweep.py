@@ -111,8 +111,8 @@ def lb_profiles(k):
 
 FAMILIES = [station, tie, multi_source, ring_async, ring_windowed, multi_source_ring_async, multi_source_ring_windowed, lb,
             lb_probes, lb_profiles]
-# known, documented: the cross-LP election of the one event beyond end_time (deviation (i))
-KNOWN = {("tie", k) for k in (85, 134, 279, 978, 1438, 1558, 2079, 2150, 2357, 2443, 2737, 2795, 2884)}   # (tools/election_rules.py predicts them)
+# (round 2 listed 13 tie storms here -- the cross-LP election of the one event beyond end_time, closed by the lineage key)
+KNOWN = set()
 # refused by design (HS_E_UNSUPPORTED), never guessed: a probe on the nanosecond of an event of its target on a load-balancer
 # graph; an arrival whose numerical inversion exceeds the evaluation budget (the reference needs minutes for it)
 REFUSALS = ("nanosecond of an event of its target", "adaptive-Simpson intervals")
