@@ -952,8 +952,9 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     const size_t N = (size_t)n, NB = (size_t)n * (size_t)bag;
 #define ALN(field, count) if ((rc = dev_alloc(h, &h->NX.field, count))) return rc
     ALN(route_k, N); ALN(routed, N); ALN(link_k, NL); ALN(link_in, NL); ALN(link_sent, NL); ALN(link_packets, NL); ALN(next_time, N);
-    ALN(bag_cnt, N); ALN(bag_t, NB); ALN(bag_ts, NB); ALN(bag_cr, NB); ALN(bag_link, NB);
-    ALN(in_cnt, 2 * N); ALN(in_t, 2 * NB); ALN(in_ts, 2 * NB); ALN(in_cr, 2 * NB); ALN(in_link, 2 * NB);
+    ALN(bag_cnt, N); ALN(bag_t, NB); ALN(bag_ts, NB); ALN(bag_cr, NB); ALN(bag_link, NB); ALN(bag_lin, NB);
+    ALN(in_cnt, 2 * N); ALN(in_t, 2 * NB); ALN(in_ts, 2 * NB); ALN(in_cr, 2 * NB); ALN(in_link, 2 * NB); ALN(in_lin, 2 * NB);
+    if ((rc = dev_alloc(h, &h->X.enqpay, N * (size_t)kEnqPay))) return rc;    // hs_net_async's ENQ payloads (general path)
     int aqc = 1;
     while (aqc < bag) aqc <<= 1;      // a power of two: queue slots are addressed with a mask, not a 64-bit modulo
 #ifndef HS_AQ_MIN
@@ -966,7 +967,7 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     h->NX.pk_base = h->cfg.start_ns;
     if (nl > 0) {
         const size_t NQ = NL * (size_t)aqc;
-        ALN(aq_t, NQ); ALN(aq_ts, NQ); ALN(aq_cr, NQ); ALN(aq_tail, NL); ALN(aq_head, NL); ALN(aq_ea, NL);
+        ALN(aq_t, NQ); ALN(aq_ts, NQ); ALN(aq_cr, NQ); ALN(aq_lin, NQ); ALN(aq_tail, NL); ALN(aq_head, NL); ALN(aq_ea, NL);
         ALN(early_upto, (size_t)n); ALN(d_pre, (size_t)n);
         // the whole network in one cooperative launch (shards: hs_engine_shard_round); with probes, time-varying profiles
         // or scheduled Requests the PF instantiation of the kernel (a profile's next arrival and the next scheduled Request
@@ -1035,7 +1036,7 @@ int hs_engine_shard_attach(hs_engine *h, const hs_shard *sh) {
     if ((rc = dev_alloc(h, &h->SC.wend_slots, 2))) return rc;
     h->SC.gvt_in = sh->gvt_dev; h->SC.gvt_out = sh->gvt_dev;     // re-pointed per launch (parity)
     h->SC.outbox = sh->outbox_dev; h->SC.cand_out = sh->cand_dev;
-    h->SC.msg_cap = sh->msg_capacity; h->SC.row = 1 + 4 * sh->msg_capacity;
+    h->SC.msg_cap = sh->msg_capacity; h->SC.row = 1 + kMsgWords * sh->msg_capacity;
     h->SC.rank = sh->rank; h->SC.world = sh->world;
     h->SC.W = sh->window_ns;
     h->SC.lp_base = (int64_t)h->cfg.lp_base;

@@ -751,6 +751,7 @@ __global__ void __launch_bounds__(64) hs_exact_run(StationParams P, NetParams NP
                 if (b >= NX.bag_cap) { over = 1; continue; }
                 const size_t d = (size_t)e.lp * NX.bag_cap + b;
                 NX.bag_t[d] = e.t; NX.bag_ts[d] = e.ts; NX.bag_cr[d] = e.cr; NX.bag_link[d] = (int32_t)e.aux;
+                NX.bag_lin[d] = lin_pack(e.dep, e.rcrt, e.ts);
                 NX.bag_cnt[e.lp] = b + 1;
             }
             if (over) atomicOr(&tot->overflow, 2);
@@ -797,7 +798,7 @@ namespace {
 template <int C, bool FAST = false, bool PF = !FAST, bool UNI = false>
 __device__ __forceinline__ void load_net(NetStation<C, FAST, PF, UNI> &S, const StationParams &P, const NetParams &NP,
                                          const StationState &X, const NetState &NX, const RecordLogs &L, int lp, int n,
-                                         uint8_t (*qmem)[kBlock], int64_t (*enqpay)[kBlock], int tid, int send_idx,
+                                         uint8_t (*qmem)[kBlock], int64_t *enq, size_t enq_stride, int tid, int send_idx,
                                          const ShardCtl &SC) {
     S.lp = lp; S.n = n;
     S.sc = &SC; S.sent_min = kInfNs; S.sent_async = false;
@@ -818,11 +819,14 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF, UNI> &S, const 
     S.received = X.received[lp]; S.routed = NX.routed[lp];
     S.total_service = X.total_service[lp];
     S.last_time = X.last_time[lp];
+    S.dpA = X.dpA[lp]; S.rcA = X.rcA[lp]; S.cd = 0; S.cr = INT64_MIN;
+    S.qdep = X.qdep + lp; S.qrc = X.qrc + lp;
 #pragma unroll
     for (int i = 0; i < C; ++i) {
         S.D[i] = X.D[(size_t)i * n + lp]; S.seqD[i] = X.seqD[(size_t)i * n + lp];
         S.crtD[i] = X.crtD[(size_t)i * n + lp]; S.svc_s[i] = X.svc_s[(size_t)i * n + lp];
         S.crt[i] = X.crt[(size_t)i * n + lp];
+        S.dpD[i] = X.dpD[(size_t)i * n + lp]; S.rcD[i] = X.rcD[(size_t)i * n + lp];
     }
     const uint64_t base = P.stream_base[lp];
     S.arr.init(S.seed, stream_id(base, kStreamArrival), X.arr_k[lp]);
@@ -840,7 +844,7 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF, UNI> &S, const 
     S.inc_const = __ddiv_rn(1.0, S.rate);
     S.n_probes = 0; S.evp[0] = S.evp[1] = 0; S.pcap = 0; S.probe_t = nullptr; S.probe_v = nullptr;
 #pragma unroll
-    for (int j = 0; j < kMaxProbes; ++j) { S.p_metric[j] = kProbeNone; S.PA[j] = kInfNs; S.seqP[j] = 0; S.crtP[j] = 0; S.p_arr[j] = 0; S.p_n[j] = 0; S.tab_p[j] = nullptr; }
+    for (int j = 0; j < kMaxProbes; ++j) { S.p_metric[j] = kProbeNone; S.PA[j] = kInfNs; S.seqP[j] = 0; S.crtP[j] = 0; S.p_arr[j] = 0; S.p_n[j] = 0; S.tab_p[j] = nullptr; S.rcP[j] = INT64_MIN; }
     S.prof_kind = kProfConstant; S.tab_a = nullptr; S.tab_cap = P.tabs != nullptr ? P.tabs->cap : 0;
     S.SA = kInfNs; S.sc_i = S.sc_end = 0; S.sc_t = P.sched_t; S.sc_idx = P.sched_idx;
     S.n_xsrc = 0; S.x_base = P.stream_base[lp]; S.xs_min = kInfNs; S.xp = &P; S.xx = &X; S.x_n_lp = n;
@@ -868,6 +872,7 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF, UNI> &S, const 
                     S.n_probes = j + 1;
                     S.tab_p[j] = P.tabs->times + (size_t)P.tabs->probe_row[o] * (size_t)S.tab_cap;
                     S.PA[j] = X.PA[o]; S.seqP[j] = X.seqP[o]; S.crtP[j] = X.crtP[o]; S.p_arr[j] = X.p_arr[o]; S.p_n[j] = X.p_n[o];
+                    S.rcP[j] = X.rcP[o];
                 }
             }
             S.probe_t = L.probe_t + lp; S.probe_v = L.probe_v + lp; S.pcap = L.pcap;
@@ -885,7 +890,7 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF, UNI> &S, const 
         S.bag_n = 0; S.bh = 0; S.bmin = kInfNs;
         for (int i = 0; i < nb; ++i) {                                 // ... sorted by arrival time (NetStation::bag_insert)
             const size_t b = (size_t)lp * NX.bag_cap + i;
-            S.bag_insert(NX.bag_t[b], NX.bag_ts[b], NX.bag_cr[b], NX.bag_link[b]);
+            S.bag_insert(NX.bag_t[b], NX.bag_ts[b], NX.bag_cr[b], NX.bag_link[b], NX.bag_lin[b]);
         }
         // ... and the LP's outgoing link into registers when there is exactly one
         int32_t l = -1;
@@ -922,7 +927,7 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF, UNI> &S, const 
         }
     }
     S.bmin = S.bag_scan_min();
-    S.qmem = qmem; S.enqpay = enqpay; S.qh = 0; S.qn = 0; S.ph = 0; S.pn = 0;
+    S.qmem = qmem; S.enq = enq; S.enq_stride = enq_stride; S.qh = 0; S.qn = 0; S.ph = 0; S.pn = 0;
 }
 
 template <int C, bool FAST = false, bool PF = !FAST, bool UNI = false>
@@ -934,11 +939,13 @@ __device__ __forceinline__ void store_net(NetStation<C, FAST, PF, UNI> &S, const
     X.received[lp] = S.received; X.sink_w[lp] = S.received; NX.routed[lp] = S.routed;
     X.total_service[lp] = S.total_service;
     X.last_time[lp] = S.last_time;
+    X.dpA[lp] = (uint8_t)S.dpA; X.rcA[lp] = S.rcA;
 #pragma unroll
     for (int i = 0; i < C; ++i) {
         X.D[(size_t)i * n + lp] = S.D[i]; X.seqD[(size_t)i * n + lp] = S.seqD[i];
         X.crtD[(size_t)i * n + lp] = S.crtD[i]; X.svc_s[(size_t)i * n + lp] = S.svc_s[i];
         X.crt[(size_t)i * n + lp] = S.crt[i];
+        X.dpD[(size_t)i * n + lp] = (uint8_t)S.dpD[i]; X.rcD[(size_t)i * n + lp] = S.rcD[i];
     }
     // draws CONSUMED (pre-drawn values still in the FAST rings are dropped: pure functions of the index)
     X.arr_k[lp] = S.arr_consumed(); X.svc_k[lp] = S.svc_consumed(); NX.route_k[lp] = S.rte_consumed();
@@ -946,6 +953,7 @@ __device__ __forceinline__ void store_net(NetStation<C, FAST, PF, UNI> &S, const
         for (int i = 0; i < S.bag_n; ++i) {
             const size_t b = (size_t)lp * NX.bag_cap + i;
             NX.bag_t[b] = S.bg_t(i); NX.bag_ts[b] = S.bg_ts(i); NX.bag_cr[b] = S.bg_cr(i); NX.bag_link[b] = S.bg_link(i);
+            NX.bag_lin[b] = S.bg_lin(i);
         }
         if (S.fl_link >= 0) {
             NX.link_in[S.fl_link] = S.fl_in; NX.link_sent[S.fl_link] = S.fl_sent;
@@ -963,6 +971,7 @@ __device__ __forceinline__ void store_net(NetStation<C, FAST, PF, UNI> &S, const
             for (int j = 0; j < kMaxProbes; ++j) if (j < S.n_probes) {
                 const size_t o = (size_t)j * n + lp;
                 X.PA[o] = S.PA[j]; X.seqP[o] = S.seqP[j]; X.crtP[o] = S.crtP[j]; X.p_arr[o] = S.p_arr[j]; X.p_n[o] = S.p_n[j];
+                X.rcP[o] = S.rcP[j];
             }
             X.ev_probe[lp] += S.evp[0]; X.ev_probe[(size_t)n + lp] += S.evp[1];
             tot += S.evp[0] + S.evp[1];
@@ -1028,6 +1037,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
                 const size_t dst = (size_t)lp * NX.bag_cap + bn;
                 const int64_t t = ag_load(&NX.aq_t[slot]);
                 NX.bag_t[dst] = t; NX.bag_ts[dst] = ag_load(&NX.aq_ts[slot]); NX.bag_cr[dst] = ag_load(&NX.aq_cr[slot]);
+                NX.bag_lin[dst] = ag_load(&NX.aq_lin[slot]);
                 NX.bag_link[dst] = l;
                 nt = t < nt ? t : nt;
                 ++bn;
@@ -1048,7 +1058,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
                 if (bn >= NX.bag_cap) { merge_overflow = 1; break; }
                 const size_t src = cs * NX.bag_cap + i, dst = (size_t)lp * NX.bag_cap + bn;
                 const int64_t t = NX.in_t[src];
-                NX.bag_t[dst] = t; NX.bag_ts[dst] = NX.in_ts[src]; NX.bag_cr[dst] = NX.in_cr[src];
+                NX.bag_t[dst] = t; NX.bag_ts[dst] = NX.in_ts[src]; NX.bag_cr[dst] = NX.in_cr[src]; NX.bag_lin[dst] = NX.in_lin[src];
                 NX.bag_link[dst] = NX.in_link[src];
                 nt = t < nt ? t : nt;
                 ++bn;
@@ -1072,7 +1082,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
     Candidate mine;
     mine = cand_none(lp);
     if (act) {
-        load_net<C>(S, P, NP, X, NX, L, lp, n, qmem, enqpay, tid, send_idx, SC);
+        load_net<C>(S, P, NP, X, NX, L, lp, n, qmem, &enqpay[0][tid], (size_t)kBlock, tid, send_idx, SC);
         for (;;) {
             const int64_t t = S.next_time();
             if (t > wend) break;
@@ -1085,18 +1095,23 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
             if (t != kInfNs) {
                 const int w = S.pick_root(t);
                 mine.t = t; mine.valid = 1;
-                if (w == 1) { mine.t_created = S.crtA; mine.pad = 2; }
-                else if (w >= 64) mine.t_created = NX.bag_ts[(size_t)lp * NX.bag_cap + (w - 64)];
+                mine.t_created = S.root_crt(w);
+                if (w == 1) { mine.depth = S.dpA; mine.rcrt = S.rcA; mine.pad = 2; }
+                else if (w >= 64) { const int64_t lin = S.bg_lin(w - 64); mine.depth = lin_steps(lin); mine.rcrt = lin_root(lin, mine.t_created); }
                 else if (w >= 56 && w < 56 + kMaxProbes) {
 #pragma unroll
-                    for (int j = 0; j < kMaxProbes; ++j) if (j == w - 56) mine.t_created = S.crtP[j];
-                    mine.pad = 1;                                 // a Probe's tick ranks behind every Source (as in the station engine)
+                    for (int j = 0; j < kMaxProbes; ++j) if (j == w - 56) mine.rcrt = S.rcP[j];
+                    mine.depth = 1;
+                    mine.pad = 8 + (w - 56);                      // a Probe's tick: by the Probe's own position in `probes=[...]`
                 }
-                else if (w >= 48 && w < 48 + kMaxXSrc) { mine.t_created = X.crtX[(size_t)(w - 48) * n + lp]; mine.pad = 3 + (w - 48); }
-                else if (w == 62) mine.t_created = INT64_MIN;     // constructed before run()
+                else if (w >= 48 && w < 48 + kMaxXSrc) {
+                    const size_t o = (size_t)(w - 48) * n + lp;
+                    mine.depth = X.dpX[o]; mine.rcrt = X.rcX[o]; mine.pad = 3 + (w - 48);
+                }
+                else if (w == 62) { mine.depth = 0; mine.rcrt = INT64_MIN; }   // constructed before run()
                 else {
 #pragma unroll
-                    for (int i = 0; i < C; ++i) if (i == w - 2) mine.t_created = S.crtD[i];
+                    for (int i = 0; i < C; ++i) if (i == w - 2) { mine.depth = S.dpD[i]; mine.rcrt = S.rcD[i]; }
                 }
                 mine.rank = cand_rank(P, lp, n, mine.pad);        // ties on (time, creation time): `sources=[...]` order
             }
@@ -1170,7 +1185,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
             // sharded network: the election continues across the ranks on the host (hs_engine_shard_overshoot runs
             // the winner); publish this rank's candidate
             SC.cand_out[0] = b.valid; SC.cand_out[1] = b.t; SC.cand_out[2] = b.t_created;
-            SC.cand_out[3] = SC.lp_base + b.lp;
+            SC.cand_out[3] = SC.lp_base + b.lp; SC.cand_out[4] = b.depth; SC.cand_out[5] = b.rcrt; SC.cand_out[6] = b.rank; SC.cand_out[7] = 0;
             tot->cur_time = new_cur;
             tot->done = 0;
             return;
@@ -1179,7 +1194,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
         else if (b.valid) {
             // the one event beyond end_time (core/simulation.py:472): first micro-event of the winner's next group
             NetStation<C> W;
-            load_net<C>(W, P, NP, X, NX, L, b.lp, n, qmem, enqpay, 0, send_idx, SC);
+            load_net<C>(W, P, NP, X, NX, L, b.lp, n, qmem, &enqpay[0][0], (size_t)kBlock, 0, send_idx, SC);
             const int64_t t = W.next_time();
             const int w = W.pick_root(t);
             if (w == 1) (void)W.do_tick(t);
@@ -1238,9 +1253,11 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                                                        RecordLogs L, Totals *tot, int n, int64_t end_ns, int flags,
                                                        ShardCtl SC, int lanes, int max_iters) {
     __shared__ uint8_t qmem[kQCap][kBlock];
-    __shared__ int64_t enqpay[kEnqPay][kBlock];
+    // (the ENQ payloads of the general path live in global memory here -- X.enqpay, [kEnqPay][n_lp]: the LDS they had is the
+    // bags' lineage column)
     __shared__ double ring_a[kNRing][kBlock], ring_s[kNRing][kBlock], ring_j[kNRing][kBlock];   // pre-drawn E values
     __shared__ int64_t lbag_t[kLBag][kBlock], lbag_ts[kLBag][kBlock], lbag_cr[kLBag][kBlock];   // the bags, in LDS
+    __shared__ int64_t lbag_lin[kLBag][kBlock];
     __shared__ int32_t lbag_link[kLBag][kBlock];
     __shared__ int64_t crc[kNRing][kBlock];                                                     // created_at of the FIFO's tail
     __shared__ unsigned long long red[14];
@@ -1258,11 +1275,11 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
     __syncthreads();
 
     NetStation<C, true, PF, UNI> S;
-    S.fl = NetFastLds{ring_a, ring_s, ring_j, lbag_t, lbag_ts, lbag_cr, lbag_link, crc};
+    S.fl = NetFastLds{ring_a, ring_s, ring_j, lbag_t, lbag_ts, lbag_cr, lbag_lin, lbag_link, crc};
     bool done = !live;
     int gave_up = 0;
     if (live) {
-        load_net<C, true, PF, UNI>(S, P, NP, X, NX, L, lp, n, qmem, enqpay, tid, 0, SC);
+        load_net<C, true, PF, UNI>(S, P, NP, X, NX, L, lp, n, qmem, X.enqpay + lp, (size_t)n, tid, 0, SC);
         S.end_ns = end_ns;
 #ifdef HS_CYC2
         S.cy2[0] = S.cy2[1] = S.cy2[2] = S.cy2[3] = 0;
@@ -1554,14 +1571,14 @@ __global__ void hs_shard_inject(NetState NX, const int64_t *inbox, int64_t *outb
     const int64_t cnt = rowp[0];
     if (cnt > msg_cap && i == 0) atomicOr(&tot->overflow, 2);
     if (i >= cnt) return;
-    const int64_t *m = rowp + 1 + 4 * (size_t)i;
+    const int64_t *m = rowp + 1 + kMsgWords * (size_t)i;
     const int64_t dst = (m[3] >> 32) - lp_base, gid = m[3] & 0xffffffffll;
     if (dst < 0 || dst >= n || gid >= n_gid || gid2local[gid] < 0) { atomicOr(&tot->overflow, 4); return; }
     const size_t cslot = (size_t)send_idx * n + (size_t)dst;
     const int pos = atomicAdd(&NX.in_cnt[cslot], 1);
     if (pos < NX.bag_cap) {
         const size_t b = cslot * NX.bag_cap + pos;
-        NX.in_t[b] = m[0]; NX.in_ts[b] = m[1]; NX.in_cr[b] = m[2]; NX.in_link[b] = gid2local[gid];
+        NX.in_t[b] = m[0]; NX.in_ts[b] = m[1]; NX.in_cr[b] = m[2]; NX.in_link[b] = gid2local[gid]; NX.in_lin[b] = m[4];
     } else atomicOr(&tot->overflow, 2);
 }
 
@@ -1591,14 +1608,14 @@ __global__ void hs_shard_inject_async(NetState NX, const int64_t *inbox, int64_t
         int64_t cnt = rowp[0];
         if (cnt > msg_cap) { atomicOr(&tot->overflow, 2); cnt = msg_cap; }
         for (int64_t i = 0; i < cnt; ++i) {
-            const int64_t *m = rowp + 1 + 4 * (size_t)i;
+            const int64_t *m = rowp + 1 + kMsgWords * (size_t)i;
             const int64_t dst = (m[3] >> 32) - lp_base, gid = m[3] & 0xffffffffll;
             if (dst < 0 || dst >= n || gid >= n_gid || gid2local[gid] < 0) { atomicOr(&tot->overflow, 4); continue; }
             const int l = gid2local[gid];
             const unsigned long long head = NX.aq_head[l], tail = pk_tail(NX.aq_ea[l], head);
             if (tail - head >= (unsigned long long)NX.aq_cap) { atomicOr(&tot->overflow, 2); continue; }
             const size_t slot = (size_t)l * NX.aq_cap + (size_t)(tail & (unsigned long long)(NX.aq_cap - 1));
-            NX.aq_t[slot] = m[0]; NX.aq_ts[slot] = m[1]; NX.aq_cr[slot] = m[2];
+            NX.aq_t[slot] = m[0]; NX.aq_ts[slot] = m[1]; NX.aq_cr[slot] = m[2]; NX.aq_lin[slot] = m[4];
             NX.aq_ea[l] = pk_pack(pk_ea(NX.aq_ea[l], NX.pk_base), tail + 1, NX.pk_base);
         }
         outbox[(size_t)r * row] = 0;
@@ -1622,7 +1639,7 @@ __global__ void hs_shard_overshoot(StationParams P, NetParams NP, StationState X
     __shared__ int64_t enqpay[kEnqPay][kBlock];
     if (threadIdx.x != 0) return;
     NetStation<C> W;
-    load_net<C>(W, P, NP, X, NX, L, lp, n, qmem, enqpay, 0, win & 1, SC);
+    load_net<C>(W, P, NP, X, NX, L, lp, n, qmem, &enqpay[0][0], (size_t)kBlock, 0, win & 1, SC);
     const int64_t t = W.next_time();
     if (t == kInfNs) return;
     const int w = W.pick_root(t);

@@ -65,8 +65,9 @@ struct ShardCtl {
     const int64_t *gvt_in;        // GVT after the previous window (all-reduced)
     int64_t *gvt_out;             // this rank's earliest pending work after this window (atomicMin)
     int64_t end_ns, W, lp_base;
-    int64_t *outbox;              // [world][row] : row = {count, 4 x int64 per message ...}
-    int64_t *cand_out;            // [4] {valid, t, t_created, global lp} of the rank's first event beyond end_ns
+    int64_t *outbox;              // [world][row] : row = {count, kMsgWords x int64 per message ...}
+    int64_t *cand_out;            // [8] {valid, t, t_created, global lp, steps from its group's root, that root's creation time,
+                                  //      construction rank, 0} of the rank's first event beyond end_ns (the election's key)
     const int32_t *link_rank;     // [n_links] rank that owns the link's destination station
     int32_t msg_cap, row, rank, world;
 };
@@ -83,10 +84,11 @@ struct NetState {
     // current bag (owner only)
     int32_t *bag_cnt;             // [n_lp]
     int64_t *bag_t, *bag_ts, *bag_cr;   // [n_lp][bag_cap]
+    int64_t *bag_lin;             // [n_lp][bag_cap] the message's lineage (lin_pack)
     int32_t *bag_link;            // [n_lp][bag_cap]
     // incoming bags, double-buffered by window parity: [2][n_lp] / [2][n_lp][bag_cap]
     int32_t *in_cnt;
-    int64_t *in_t, *in_ts, *in_cr;
+    int64_t *in_t, *in_ts, *in_cr, *in_lin;
     int32_t *in_link;
     int32_t bag_cap;
     // asynchronous engine: one single-producer / single-consumer message queue per link.  Every word below is written
@@ -94,6 +96,7 @@ struct NetState {
     // (cdna_hip_programming.md section 6, Guideline 16, recipe R2); the producer drains its stores (vmcnt(0)) between
     // the payload, `aq_tail` and `aq_ea`, so a consumer that sees a value of `aq_ea` also sees every message below it.
     int64_t *aq_t, *aq_ts, *aq_cr;   // [n_links][aq_cap] arrival ns, send ns, created_at ns
+    int64_t *aq_lin;                 // [n_links][aq_cap] lineage (lin_pack)
     unsigned long long *aq_tail;     // [n_links] messages appended so far (producer)
     unsigned long long *aq_head;     // [n_links] messages taken so far (consumer; the producer reads it for flow control)
     int64_t *aq_ea;                  // [n_links] ONE word per link = (bound << 20 | messages appended so far mod 2^20):
@@ -150,6 +153,20 @@ __device__ __forceinline__ unsigned long long pk_tail(int64_t w, unsigned long l
 }
 
 constexpr int kEnqPay = 8;   // ENQ payload FIFO depth (general path only)
+constexpr int kMsgWords = 5; // int64 words per message in an outbox / inbox row: arrival, send time, created_at, dst << 32 | link, lineage
+
+// LINEAGE of a message (the NetworkLink's continuation event, components/network/link.py:114-154): how many steps after the root
+// of the group it was created in, and when that root was created (hs_station.hpp StationState::dpA) -- one word:
+// steps << 56 | "the root was constructed before run()" << 55 | (send time - root's creation time).
+__device__ __forceinline__ int64_t lin_pack(int32_t steps, int64_t root_crt, int64_t t_send) {
+    const uint64_t d = (uint64_t)(steps > 255 ? 255 : steps) << 56;
+    if (root_crt == INT64_MIN) return (int64_t)(d | (1ull << 55));
+    return (int64_t)(d | ((uint64_t)(t_send - root_crt) & ((1ull << 55) - 1ull)));
+}
+__device__ __forceinline__ int32_t lin_steps(int64_t lin) { return (int32_t)((uint64_t)lin >> 56); }
+__device__ __forceinline__ int64_t lin_root(int64_t lin, int64_t t_send) {
+    return (((uint64_t)lin >> 55) & 1ull) ? INT64_MIN : t_send - (int64_t)((uint64_t)lin & ((1ull << 55) - 1ull));
+}
 
 // ---- FAST instantiation (hs_net_async only) ------------------------------------------------------------------------
 // The asynchronous engine runs a wavefront's event groups in a divergent loop with only a few lanes active per trip
@@ -174,6 +191,7 @@ struct NetFastLds {
     int64_t (*bag_t)[kBlock];
     int64_t (*bag_ts)[kBlock];
     int64_t (*bag_cr)[kBlock];
+    int64_t (*bag_lin)[kBlock];
     int32_t (*bag_link)[kBlock];
     int64_t (*crc)[kBlock];       // created_at of the NEXT kNRing requests to start: ordinals [started, started + kNRing), slot = ordinal mod kNRing
 };
@@ -199,6 +217,10 @@ struct NetStation {
     double svc_s[C];
     double total_service;
     int64_t last_time;
+    // lineage of the pending events and of the event being processed (hs_station.hpp)
+    int32_t dpA, dpD[C], cd;
+    int64_t rcA, rcD[C], cr, rcP[kMaxProbes];
+    uint8_t *qdep; int64_t *qrc;  // the in-group FIFO's lineage columns (global memory): entry `slot` of this LP at [slot * ls]
     Stream arr, svc, rte;
     uint32_t ev[11];
     // Probe attached to this station (instrumentation/probe.py:81-164), as in hs_station.hpp: a daemon Source of its own
@@ -281,9 +303,10 @@ struct NetStation {
     int32_t fi_link;              // the LP's only incoming link (-1: none or several): its packets_sent counter in a register
     int64_t fi_packets;
     unsigned long long fi_head;   // ... and this LP's position in that link's queue (the only writer of aq_head[fi_link])
-    // in-group FIFO + ENQ payloads (LDS columns)
+    // in-group FIFO (an LDS column) + ENQ payloads (an LDS column, or global memory in hs_net_async: entry k at enq[k * enq_stride])
     uint8_t (*qmem)[kBlock];
-    int64_t (*enqpay)[kBlock];
+    int64_t *enq;
+    size_t enq_stride;
     int tid, qh, qn, ph, pn;
 #ifdef HS_RINGSTAT   // scratch statistics build (never defined in the shipped library)
     int stat_gl, stat_slow;
@@ -297,25 +320,32 @@ struct NetStation {
 #define HS_CY2(k)
 #endif
 
+    // an event created by the one being processed: one step further from the group's root (hs_station.hpp)
     __device__ __forceinline__ void qpush(uint32_t code) {
         if (qn >= kQCap) { qoverflow = 1; return; }
-        qmem[(qh + qn) % kQCap][tid] = (uint8_t)code;
+        const int slot = (qh + qn) % kQCap;
+        qmem[slot][tid] = (uint8_t)code;
+        qdep[(size_t)slot * ls] = (uint8_t)(cd >= 254 ? 255 : cd + 1);
+        qrc[(size_t)slot * ls] = cr;
         ++qn;
     }
     __device__ __forceinline__ uint32_t qpop() {
         const uint32_t c = qmem[qh][tid];
+        cd = qdep[(size_t)qh * ls];
+        cr = qrc[(size_t)qh * ls];
         qh = (qh + 1) % kQCap;
         --qn;
         return c;
     }
+    __device__ __forceinline__ int32_t dp_next(int steps) const { return cd + steps > 255 ? 255 : cd + steps; }
     __device__ __forceinline__ void push_enq(int64_t created) {
         if (pn >= kEnqPay) { qoverflow = 1; return; }
-        enqpay[(ph + pn) % kEnqPay][tid] = created;
+        enq[(size_t)((ph + pn) % kEnqPay) * enq_stride] = created;
         ++pn;
         qpush(Q_ENQ);
     }
     __device__ __forceinline__ int64_t pop_enq_payload() {
-        const int64_t v = enqpay[ph][tid];
+        const int64_t v = enq[(size_t)ph * enq_stride];
         ph = (ph + 1) % kEnqPay;
         --pn;
         return v;
@@ -335,16 +365,17 @@ struct NetStation {
     __device__ __forceinline__ int64_t bg_ts(int i) const { if constexpr (FAST) return fl.bag_ts[bslot(i)][tid]; else return ns->bag_ts[bidx(i)]; }
     __device__ __forceinline__ int64_t bg_cr(int i) const { if constexpr (FAST) return fl.bag_cr[bslot(i)][tid]; else return ns->bag_cr[bidx(i)]; }
     __device__ __forceinline__ int32_t bg_link(int i) const { if constexpr (FAST) return fl.bag_link[bslot(i)][tid]; else return ns->bag_link[bidx(i)]; }
-    __device__ __forceinline__ void bg_set(int i, int64_t t, int64_t ts, int64_t cr, int32_t l) {
-        if constexpr (FAST) { const int k = bslot(i); fl.bag_t[k][tid] = t; fl.bag_ts[k][tid] = ts; fl.bag_cr[k][tid] = cr; fl.bag_link[k][tid] = l; }
-        else { const size_t d = bidx(i); ns->bag_t[d] = t; ns->bag_ts[d] = ts; ns->bag_cr[d] = cr; ns->bag_link[d] = l; }
+    __device__ __forceinline__ int64_t bg_lin(int i) const { if constexpr (FAST) return fl.bag_lin[bslot(i)][tid]; else return ns->bag_lin[bidx(i)]; }
+    __device__ __forceinline__ void bg_set(int i, int64_t t, int64_t ts, int64_t created, int32_t l, int64_t lin) {
+        if constexpr (FAST) { const int k = bslot(i); fl.bag_t[k][tid] = t; fl.bag_ts[k][tid] = ts; fl.bag_cr[k][tid] = created; fl.bag_link[k][tid] = l; fl.bag_lin[k][tid] = lin; }
+        else { const size_t d = bidx(i); ns->bag_t[d] = t; ns->bag_ts[d] = ts; ns->bag_cr[d] = created; ns->bag_link[d] = l; ns->bag_lin[d] = lin; }
     }
     // FAST: insert in arrival-time order (stable: behind equal times).  Messages of one link arrive almost in send order,
     // so the new one usually goes last: one comparison.
-    __device__ __forceinline__ void bag_insert(int64_t t, int64_t ts, int64_t cr, int32_t l) {
+    __device__ __forceinline__ void bag_insert(int64_t t, int64_t ts, int64_t created, int32_t l, int64_t lin) {
         int p = bag_n;
-        while (p > 0 && bg_t(p - 1) > t) { bg_set(p, bg_t(p - 1), bg_ts(p - 1), bg_cr(p - 1), bg_link(p - 1)); --p; }
-        bg_set(p, t, ts, cr, l);
+        while (p > 0 && bg_t(p - 1) > t) { bg_set(p, bg_t(p - 1), bg_ts(p - 1), bg_cr(p - 1), bg_link(p - 1), bg_lin(p - 1)); --p; }
+        bg_set(p, t, ts, created, l, lin);
         ++bag_n;
         bmin = t < bmin ? t : bmin;
     }
@@ -359,13 +390,13 @@ struct NetStation {
     __device__ __forceinline__ void bag_remove(int i) {
         if constexpr (FAST) {
             if (i == 0) bh = (bh + 1) & (kLBag - 1);                  // the earliest message: the common case
-            else for (int k = i; k + 1 < bag_n; ++k) bg_set(k, bg_t(k + 1), bg_ts(k + 1), bg_cr(k + 1), bg_link(k + 1));
+            else for (int k = i; k + 1 < bag_n; ++k) bg_set(k, bg_t(k + 1), bg_ts(k + 1), bg_cr(k + 1), bg_link(k + 1), bg_lin(k + 1));
             --bag_n;
             bmin = bag_scan_min();
             return;
         }
         const int last = bag_n - 1;
-        if (i != last) bg_set(i, bg_t(last), bg_ts(last), bg_cr(last), bg_link(last));
+        if (i != last) bg_set(i, bg_t(last), bg_ts(last), bg_cr(last), bg_link(last), bg_lin(last));
         bag_n = last;
         bmin = bag_scan_min();
     }
@@ -484,7 +515,7 @@ struct NetStation {
             const int64_t a2 = tick_lookup(tab_p[i], tab_cap, k2, overflow);
             p_arr[i] = k2;
             if (a2 <= t) PA[i] = kInfNs;
-            else { PA[i] = a2; seqP[i] = seq++; crtP[i] = t; }
+            else { PA[i] = a2; seqP[i] = seq++; rcP[i] = cr; crtP[i] = t; }
         }
     }
     __device__ __forceinline__ void do_probe_sample(int j, int64_t t) {
@@ -523,7 +554,7 @@ struct NetStation {
         uint32_t r = payload ? 1u : 0u;
         if (a2 == t) { r |= 2u; A = kInfNs; }
         else if (a2 < t) { A = kInfNs; }
-        else { A = a2; seqA = seq++; crtA = t; }
+        else { A = a2; seqA = seq++; crtA = t; dpA = dp_next(1); rcA = cr; }
         return r;
     }
     __device__ __forceinline__ bool do_enqueue(int64_t t, int64_t created) {
@@ -595,8 +626,9 @@ struct NetStation {
         for (int i = 0; i < C; ++i) if (i == j) {
             svc_s[i] = s; crt[i] = created;
             if (d == t) { D[i] = kInfNs - 1; same = (uint32_t)i + 1; }
-            else { D[i] = d; seqD[i] = seq++; crtD[i] = t; }
+            else { D[i] = d; seqD[i] = seq++; crtD[i] = t; dpD[i] = dp_next(2); rcD[i] = cr; }   // QUEUE_DELIVER -> payload -> continuation
         }
+        if (same) ++cd;                                                   // (the caller pushes the in-group continuation: deliver + 2)
         return same;
     }
 
@@ -606,13 +638,13 @@ struct NetStation {
         return sc->wend_slots != nullptr && sc->link_rank[l] != sc->rank;
     }
     // a message for a station of another shard: append to that rank's outbox row (the host exchanges the rows)
-    __device__ __forceinline__ void outbox_append(int32_t l, int32_t dst, int64_t t_arr, int64_t t, int64_t created) {
+    __device__ __forceinline__ void outbox_append(int32_t l, int32_t dst, int64_t t_arr, int64_t t, int64_t created, int64_t lin) {
         int64_t *row = sc->outbox + (size_t)sc->link_rank[l] * sc->row;
         const unsigned long long pos = atomicAdd((unsigned long long *)row, 1ull);
         if (pos < (unsigned long long)sc->msg_cap) {
-            int64_t *m = row + 1 + 4 * pos;
+            int64_t *m = row + 1 + kMsgWords * pos;
             const int64_t gid = np->link_gid ? np->link_gid[l] : l;
-            m[0] = t_arr; m[1] = t; m[2] = created; m[3] = ((int64_t)dst << 32) | gid;
+            m[0] = t_arr; m[1] = t; m[2] = created; m[3] = ((int64_t)dst << 32) | gid; m[4] = lin;
         } else bagoverflow = 1;
     }
     __device__ __forceinline__ int64_t link_sent_of(int32_t l) const {   // the link queue's sequence number
@@ -620,17 +652,20 @@ struct NetStation {
         return ns->link_sent[l];
     }
     // append {arrival, send time, created_at} to the LP's one outgoing link (queue or, on a shard, the outbox row)
-    __device__ __forceinline__ void fl_append(int64_t t_arr, int64_t t_send, int64_t created) {
+    __device__ __forceinline__ void fl_append(int64_t t_arr, int64_t t_send, int64_t created, int64_t lin) {
         sent_min = t_arr < sent_min ? t_arr : sent_min;
         ++fl_q;
-        if (HSU(fl_remote, false)) { outbox_append(fl_link, fl_dst, t_arr, t_send, created); return; }
+        if (HSU(fl_remote, false)) { outbox_append(fl_link, fl_dst, t_arr, t_send, created, lin); return; }
         const size_t slot = (size_t)fl_link * ns->aq_cap + (size_t)(((unsigned long long)fl_q - 1) & (unsigned long long)(ns->aq_cap - 1));
-        ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t_send); ag_store(&ns->aq_cr[slot], created);
+        ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t_send); ag_store(&ns->aq_cr[slot], created); ag_store(&ns->aq_lin[slot], lin);
         sent_async = true;
     }
+    // steps from a Server's continuation to the NetworkLink's continuation it causes: Request@Link, the link's continuation
+    // (+ Request@RandomRouter in front of them)
+    __device__ __forceinline__ int link_steps() const { return HSU(egress == EG_ROUTER, true) ? 3 : 2; }
     // Decide the way out of request `ordinal` (departure D, created_at `created`) ahead of time; `bit_off` = its distance, in
     // completions, from the next one.  False when the pre-drawn route / jitter values do not reach that far.
-    __device__ __forceinline__ bool pre_send(int64_t ordinal, int bit_off, int64_t D, int64_t created) {
+    __device__ __forceinline__ bool pre_send(int64_t ordinal, int bit_off, int64_t D, int64_t created, int64_t S_start) {
         const bool router = HSU(egress == EG_ROUTER, true);
         if (router && bit_off >= rn) return false;
         const int32_t target = HSU(egress == EG_SINK, false) ? -1 : HSU(egress == EG_LINK, false) ? link_of
@@ -640,7 +675,7 @@ struct NetStation {
             double delay = fl_delay0;
             if (HSU(fl_jit == 0, true)) { delay = __dadd_rn(delay, fl.ring_j[hj][tid]); hj = (hj + 1) & (kNRing - 1); --nj; }
             if (!(delay > 0.0)) delay = 0.0;
-            fl_append(D + ns_from_seconds(delay), D, created);
+            fl_append(D + ns_from_seconds(delay), D, created, lin_pack(link_steps(), S_start, D));   // (the continuation at D: a root, created at S_start)
         }
         early_upto = ordinal + 1;
         D_pre = D;
@@ -664,7 +699,7 @@ struct NetStation {
             hj = (hj + 1) & (kNRing - 1); --nj;
         }
         if (!(delay > 0.0)) delay = 0.0;
-        fl_append(t + ns_from_seconds(delay), t, created);
+        fl_append(t + ns_from_seconds(delay), t, created, lin_pack(dp_next(link_steps()), cr, t));
     }
     __device__ __forceinline__ void send_link(int32_t l, int64_t t, int64_t created) {
         if constexpr (FAST) { if (l == fl_link) { send_link_fast(t, created); return; } }
@@ -692,8 +727,9 @@ struct NetStation {
         const int64_t t_arr = t + ns_from_seconds(delay);
         sent_min = t_arr < sent_min ? t_arr : sent_min;
         const int32_t dst = np->link_dst[l];                 // network-wide station index
+        const int64_t lin = lin_pack(dp_next(link_steps()), cr, t);
         if (link_is_remote(l)) {                             // destination lives on another engine
-            outbox_append(l, dst, t_arr, t, created);
+            outbox_append(l, dst, t_arr, t, created, lin);
             return;
         }
         if (ns->aq_on) {
@@ -702,7 +738,7 @@ struct NetStation {
             // (room for this group's messages was checked before the group started: async_can_send)
             const unsigned long long seq = (unsigned long long)ns->link_sent[l];
             const size_t slot = (size_t)l * ns->aq_cap + (size_t)((seq - 1) & (unsigned long long)(ns->aq_cap - 1));
-            ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t); ag_store(&ns->aq_cr[slot], created);
+            ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t); ag_store(&ns->aq_cr[slot], created); ag_store(&ns->aq_lin[slot], lin);
             sent_async = true;          // the caller publishes aq_tail (= link_sent) after draining these stores
             return;
         }
@@ -711,7 +747,7 @@ struct NetStation {
         const int pos = atomicAdd(&ns->in_cnt[cslot], 1);
         if (pos < ns->bag_cap) {
             const size_t b = cslot * ns->bag_cap + pos;
-            ns->in_t[b] = t_arr; ns->in_ts[b] = t; ns->in_cr[b] = created; ns->in_link[b] = l;
+            ns->in_t[b] = t_arr; ns->in_ts[b] = t; ns->in_cr[b] = created; ns->in_link[b] = l; ns->in_lin[b] = lin;
         } else bagoverflow = 1;
     }
     __device__ __forceinline__ int64_t gid_of(int64_t l) const { return np->link_gid ? np->link_gid[l] : l; }
@@ -720,13 +756,13 @@ struct NetStation {
     __device__ __forceinline__ int64_t do_cont_core(int slot, int64_t t) {
         (void)t;
         ev[6]++;
-        double s = 0.0; int64_t cr = 0;
+        double s = 0.0; int64_t created = 0;
 #pragma unroll
-        for (int i = 0; i < C; ++i) if (i == slot) { s = svc_s[i]; cr = crt[i]; D[i] = kInfNs; }
+        for (int i = 0; i < C; ++i) if (i == slot) { s = svc_s[i]; created = crt[i]; D[i] = kInfNs; }
         active = active > 0 ? active - 1 : 0;
         completed++;
         total_service = __dadd_rn(total_service, s);
-        return cr;
+        return created;
     }
     // the forwarded request's way out of the LP: Sink / RandomRouter / NetworkLink (all at time t)
     __device__ __forceinline__ void do_egress(int64_t t, int64_t created) {
@@ -751,8 +787,8 @@ struct NetStation {
     }
     // full continuation: statistics, egress chain, schedule_poll hook.  Returns true if QUEUE_POLL is created.
     __device__ __forceinline__ bool do_cont(int slot, int64_t t) {
-        const int64_t cr = do_cont_core(slot, t);
-        do_egress(t, cr);
+        const int64_t created = do_cont_core(slot, t);
+        do_egress(t, created);
         return active < conc;
     }
     // NetworkLink continuation at the egress side (link.py:156-189): transit over, a new Request for the Server
@@ -766,8 +802,10 @@ struct NetStation {
         return created;
     }
 
+    // (cd = the QUEUE_POLL's steps from the group's root)
     __device__ __forceinline__ bool chain_from_poll(int64_t t, bool have_created, int64_t created) {
         if (!do_poll()) return false;
+        ++cd;                                                             // the QUEUE_DELIVER it created
         const uint32_t same = do_deliver_work(t, have_created, created);
         if (same) { qpush(Q_CONT | ((same - 1) << 3)); return true; }
         return false;
@@ -800,7 +838,7 @@ struct NetStation {
             for (; head < tail && bag_n < bcap; ++head) {
                 const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
                 const int64_t ta = ag_load(&ns->aq_t[slot]);
-                bag_insert(ta, ag_load(&ns->aq_ts[slot]), ag_load(&ns->aq_cr[slot]), l);
+                bag_insert(ta, ag_load(&ns->aq_ts[slot]), ag_load(&ns->aq_cr[slot]), l, ag_load(&ns->aq_lin[slot]));
             }
             fi_head = head;
             ag_store(&ns->aq_head[l], head);
@@ -829,7 +867,7 @@ struct NetStation {
             for (; head < tail && bag_n < bcap; ++head) {
                 const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
                 const int64_t ta = ag_load(&ns->aq_t[slot]);
-                bag_insert(ta, ag_load(&ns->aq_ts[slot]), ag_load(&ns->aq_cr[slot]), l);
+                bag_insert(ta, ag_load(&ns->aq_ts[slot]), ag_load(&ns->aq_cr[slot]), l, ag_load(&ns->aq_lin[slot]));
             }
             ag_store(&ns->aq_head[l], head);
             if (head < tail) {
@@ -1001,7 +1039,7 @@ struct NetStation {
         if (payload) push_enq(t);
         if (a2 == t) { xx->XA[o] = kInfNs; qpush(Q_TICK | ((uint32_t)(j + 1) << 3)); }
         else if (a2 < t) xx->XA[o] = kInfNs;
-        else { xx->XA[o] = a2; xx->seqX[o] = seq++; xx->crtX[o] = t; }
+        else { xx->XA[o] = a2; xx->seqX[o] = seq++; xx->crtX[o] = t; xx->dpX[o] = (uint8_t)dp_next(1); xx->rcX[o] = cr; }
         int64_t m = kInfNs;
         for (int i = 0; i < n_xsrc; ++i) { const int64_t a = xx->XA[xo(i)]; m = a < m ? a : m; }
         xs_min = m;
@@ -1048,7 +1086,23 @@ struct NetStation {
         }
         return best;
     }
+    // creation time of pending root `w` (pick_root's code); a message's is its send time
+    __device__ __forceinline__ int64_t root_crt(int w) const {
+        int64_t c = INT64_MIN;                                            // 62: constructed before run()
+        if (w == 1) c = crtA;
+        else if (w >= 64) c = bg_ts(w - 64);
+        else if (PF && w >= 48 && w < 48 + kMaxXSrc) c = xx->crtX[xo(w - 48)];
+        else if (PF && w >= 56 && w < 56 + kMaxProbes) {
+#pragma unroll
+            for (int j = 0; j < kMaxProbes; ++j) if (j == w - 56) c = crtP[j];
+        } else if (!(PF && w == 62)) {
+#pragma unroll
+            for (int i = 0; i < C; ++i) if (i == w - 2) c = crtD[i];
+        }
+        return c;
+    }
     __device__ __forceinline__ void run_root(int w, int64_t t) {
+        cd = 0; cr = root_crt(w);                                         // a root: pending from an earlier nanosecond
         if (w == 1) root_tick(t);
         else if (w >= 64) root_msg(w - 64, t);
         else if (PF && w >= 48 && w < 48 + kMaxXSrc) { if constexpr (PF) root_xsrc(w - 48, t); }
@@ -1154,6 +1208,10 @@ struct NetStation {
         arr_time = tick ? a2 : arr_time;
         A = tick ? a2 : A;
         seqA = tick ? seq : seqA;
+        // lineage (hs_station.hpp step_c1): the group's one root is the tick, the message (created at its send time) or the departure
+        const int64_t root_c = tick ? crtA : msg ? bg_ts(mi) : crtD[0];
+        rcA = tick ? crtA : rcA;
+        dpA = tick ? 1 : dpA;
         crtA = tick ? t : crtA;
         seq += tick ? 1u : 0u;
         if (tick && poisson) { ha = (ha + 1) & (kNRing - 1); --na; }
@@ -1179,7 +1237,7 @@ struct NetStation {
                 const double s_k = svc_exp ? fl.ring_s[(hs_ + off) & (kNRing - 1)][tid] : svc_const_s;
                 const int64_t dur_k = svc_exp ? ns_from_seconds(s_k) : svc_const_ns;
                 const int64_t s_at = t > D_pre ? t : D_pre;
-                if (dur_k > 0) (void)pre_send(accepted, (int)(accepted - completed), s_at + dur_k, created_in);
+                if (dur_k > 0) (void)pre_send(accepted, (int)(accepted - completed), s_at + dur_k, created_in, s_at);
             }
         }
         accepted += acc;
@@ -1209,7 +1267,7 @@ struct NetStation {
                     hj = (hj + 1) & (kNRing - 1); --nj;
                 }
                 if (!(delay > 0.0)) delay = 0.0;
-                fl_append(t + ns_from_seconds(delay), t, created_out);
+                fl_append(t + ns_from_seconds(delay), t, created_out, lin_pack(link_steps(), root_c, t));   // (the departure is the root)
             }
         }
         if (dep && early_upto < completed) { early_upto = completed; D_pre = t; }   // (left the ordinary way)
@@ -1224,9 +1282,10 @@ struct NetStation {
             int64_t created = created_in;                             // arrival side: the request that found the buffer empty
             if (dep) created = fl.crc[k & (kNRing - 1)][tid];        // in the window (k < win_hi: checked with `slow`)
             win_hi = win_hi <= k ? k + 1 : win_hi;
-            if (HSU(presend, true) && k >= early_upto) (void)pre_send(k, (int)(k - completed), t + dur, created);   // pre-send at the start
+            if (HSU(presend, true) && k >= early_upto) (void)pre_send(k, (int)(k - completed), t + dur, created, t);   // pre-send at the start
             svc_s[0] = s_new; crt[0] = created;
             D[0] = t + dur; seqD[0] = seq++; crtD[0] = t;
+            dpD[0] = dep ? 4 : 6; rcD[0] = root_c;
             if (svc_exp) { hs_ = (hs_ + 1) & (kNRing - 1); --nsv; }
         }
         last_time = (tick || dep || msg) ? t : last_time;            // (the general path sets it itself)
@@ -1246,19 +1305,26 @@ struct NetStation {
         if (n_at == 1 && !force_general) {
             bool general = false, want_poll = false, have_created = false;
             int64_t created = 0;
+            cd = 0;
             if (A == t) {
+                cr = crtA;
                 const uint32_t r = do_tick(t);
                 if (r & 2u) { if (r & 1u) push_enq(t); qpush(Q_TICK); general = true; }
-                else if (r & 1u) { want_poll = do_enqueue(t, t) && do_notify(); have_created = true; created = t; }
+                else if (r & 1u) { want_poll = do_enqueue(t, t) && do_notify(); have_created = true; created = t; cd = 3; }   // tick -> Request -> QUEUE_NOTIFY -> QUEUE_POLL
             } else if (mi >= 0) {
+                cr = bg_ts(mi);                                          // the link's continuation was created when the message was sent
                 created = do_msg(mi, t);
                 want_poll = do_enqueue(t, created) && do_notify();
                 have_created = true;
+                cd = 3;                                                  // continuation -> Request -> QUEUE_NOTIFY -> QUEUE_POLL
             } else {
                 int slot = 0;
 #pragma unroll
                 for (int i = 0; i < C; ++i) if (D[i] == t) slot = i;
+#pragma unroll
+                for (int i = 0; i < C; ++i) if (i == slot) cr = crtD[i];
                 want_poll = do_cont(slot, t);
+                cd = 1;                                                  // continuation -> QUEUE_POLL
             }
             // `have_created` is only valid when the buffer was empty before this chain's enqueue, which is exactly
             // when do_enqueue returned true (was_empty) -- the only way want_poll is set on the arrival branches.

@@ -168,6 +168,7 @@ struct StationState {           // read-write; [n_lp] each unless noted
     uint8_t *dpX; int64_t *rcX;   // [kMaxXSrc][n_lp] the pending ticks of the further Sources
     // ... and of the events waiting in the in-group FIFO (general path only; global memory, [kQCap][n_lp])
     uint8_t *qdep; int64_t *qrc;
+    int64_t *enqpay;              // [kEnqPay][n_lp] network engines: ENQ payloads of hs_net_async's general path (null: stations only)
     // further Sources (PF instantiation only; null = none)
     int64_t *XA, *crtX, *x_arr, *x_n;   // [kMaxXSrc][n_lp] pending tick, its creation time, provider time, generated_count
     uint32_t *seqX;             // [kMaxXSrc][n_lp]
@@ -476,15 +477,15 @@ struct Station {
     // Returns bit0: Request@Sink created, bit1: QUEUE_POLL created.
     __device__ __forceinline__ uint32_t do_cont(int slot, int64_t t) {
         ev[6]++;
-        double s = 0.0; int64_t cr = 0;
+        double s = 0.0; int64_t created = 0;
 #pragma unroll
-        for (int i = 0; i < C; ++i) if (i == slot) { s = svc_s[i]; cr = crt[i]; D[i] = kInfNs; }
+        for (int i = 0; i < C; ++i) if (i == slot) { s = svc_s[i]; created = crt[i]; D[i] = kInfNs; }
         active = active > 0 ? active - 1 : 0;
         completed++;
         total_service = __dadd_rn(total_service, s);
         uint32_t r = 0;
         if (egress == 1) {
-            if (sink_w < cap) { sink_t[sink_w * ls] = t; if (C > 1) sink_created[sink_w * ls] = cr; }
+            if (sink_w < cap) { sink_t[sink_w * ls] = t; if (C > 1) sink_created[sink_w * ls] = created; }
             else overflow = 1;
             sink_w++;
             r |= 1u;

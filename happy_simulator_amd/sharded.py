@@ -37,6 +37,10 @@ from dataclasses import dataclass
 
 import numpy as np
 
+MSG_WORDS = 5      # int64 words per message in an outbox / inbox row (csrc/hs_netstation.hpp kMsgWords): arrival, send time, created_at,
+                   # destination << 32 | link, lineage
+CAND_WORDS = 8     # a rank's candidate for the one event beyond end_time (ShardCtl::cand_out)
+
 from . import _native as N
 from .engine import NetworkArrays, StationArrays, StationEngine
 
@@ -221,11 +225,11 @@ class GpuShard:
         self.gids = np.asarray(net.link_gid, np.int64)
         self.msg_capacity = msg_capacity
         dev = torch.device("cuda", device)
-        row = 1 + 4 * msg_capacity
+        row = 1 + MSG_WORDS * msg_capacity
         self.outbox = torch.zeros((self.world, row), dtype=torch.int64, device=dev)
         self.inbox = torch.zeros((self.world, row), dtype=torch.int64, device=dev)
         self.gvt = torch.zeros(2, dtype=torch.int64, device=dev)
-        self.cand = torch.zeros(4, dtype=torch.int64, device=dev)
+        self.cand = torch.zeros(CAND_WORDS, dtype=torch.int64, device=dev)
         self.engine = StationEngine(stations, mode=N.MODE_SINGLE, horizon_ns=horizon_ns, start_ns=start_ns, seed=seed,
                                     lp_base=self.lo, device=device, log_capacity=log_capacity, network=net)
         self.engine.set_stream(torch.cuda.current_stream(dev).cuda_stream)
@@ -436,12 +440,14 @@ class ShardedNetwork:
             for s in sh:
                 s.final(k)
         self.windows = k
-        cands = comm.allgather_rows([s.cand for s in sh])              # [world, 4]: valid, t, t_created, station
+        # [world, CAND_WORDS]: valid, t, t_created, station, steps from its group's root, that root's creation time, construction rank
+        cands = comm.allgather_rows([s.cand for s in sh])
         valid = cands[cands[:, 0] != 0]
         winner_t = None
         if len(valid):
-            order = np.lexsort((valid[:, 3], valid[:, 2], valid[:, 1]))  # by (t, t_created, station)
-            _, t, _, station = (int(x) for x in valid[order[0]])
+            # the election's key (csrc/hs_kernels.hpp cand_less): time, creation time, lineage, construction rank
+            order = np.lexsort((valid[:, 3], valid[:, 6], valid[:, 5], valid[:, 4], valid[:, 2], valid[:, 1]))
+            t, station = int(valid[order[0]][1]), int(valid[order[0]][3])
             winner_t = t
             for s in sh:
                 if s.lo <= station < s.hi:

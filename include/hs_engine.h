@@ -217,20 +217,23 @@ typedef struct hs_network {
 } hs_network;
 
 /* Exchange buffers of a shard: device memory owned by the caller (torch tensors on the host side, so that
- * torch.distributed / RCCL can move them).  A row is {count, then 4 x int64 per message}: arrival ns, send ns,
- * created_at ns, (destination station << 32 | link gid).  Replaces the reference's per-partition Python outbox lists
+ * torch.distributed / RCCL can move them).  A row is {count, then 5 x int64 per message}: arrival ns, send ns,
+ * created_at ns, (destination station << 32 | link gid), lineage (csrc/hs_netstation.hpp lin_pack).  Replaces the reference's per-partition Python outbox lists
  * (parallel/simulation.py:107,142-151) and `_exchange_events` (parallel/coordinator.py:182-227). */
 typedef struct hs_shard {
     int32_t rank, world;
     const int64_t *shard_lo;         /* host, [world + 1]: rank r owns stations [shard_lo[r], shard_lo[r+1]) */
-    int64_t *outbox_dev;             /* device int64 [world][1 + 4 * msg_capacity]: row r = messages for rank r */
+    int64_t *outbox_dev;             /* device int64 [world][1 + 5 * msg_capacity]: row r = messages for rank r */
     int64_t *inbox_dev;              /* device, same shape: row r = messages from rank r (after the all-to-all) */
     int32_t msg_capacity;
     int32_t reserved;
     int64_t window_ns;               /* lookahead W = min over ALL shards of hs_summary.window_ns (caller all-reduces) */
     int64_t *gvt_dev;                /* device int64[2]: window k accumulates this rank's earliest pending work into
                                         [k & 1]; the caller all-reduces (min) it before window k + 1 reads it */
-    int64_t *cand_dev;               /* device int64[4]: {valid, t, t_created, station} first event beyond end_ns */
+    int64_t *cand_dev;               /* device int64[8]: {valid, t, t_created, station, steps from its group's root, that root's
+                                        creation time, construction rank, 0}: this rank's first event beyond end_ns; the ranks'
+                                        candidates compare by (t, t_created, steps, root time, rank) = (time, _sort_index),
+                                        core/event.py:337-344 */
 } hs_shard;
 
 typedef struct hs_net_stats {

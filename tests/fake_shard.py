@@ -26,11 +26,11 @@ class FakeShard:
         self.lo, self.hi = int(bounds[rank]), int(bounds[rank + 1])
         self.W = W
         self.cap = msg_capacity
-        row = 1 + 4 * msg_capacity
+        row = 1 + 5 * msg_capacity
         self.outbox = torch.zeros((self.world, row), dtype=torch.int64)
         self.inbox = torch.zeros((self.world, row), dtype=torch.int64)
         self.gvt = torch.zeros(2, dtype=torch.int64)
-        self.cand = torch.zeros(4, dtype=torch.int64)
+        self.cand = torch.zeros(8, dtype=torch.int64)
 
     def begin(self, end_ns):
         self.end = end_ns
@@ -70,7 +70,7 @@ class FakeShard:
             else:
                 c = int(self.outbox[r, 0])
                 assert c < self.cap
-                self.outbox[r, 1 + 4 * c:5 + 4 * c] = torch.tensor([ta, t, 0, (j << 32) | i])
+                self.outbox[r, 1 + 5 * c:6 + 5 * c] = torch.tensor([ta, t, 0, (j << 32) | i, 0])
                 self.outbox[r, 0] = c + 1
         nxt = self.heap[0][0] if self.heap else INF
         self.gvt[k & 1] = min(int(self.gvt[k & 1]), nxt, sent_min)
@@ -79,7 +79,7 @@ class FakeShard:
     def inject(self, k):
         for r in range(self.world):
             for c in range(int(self.inbox[r, 0])):
-                ta, _, _, w3 = (int(x) for x in self.inbox[r, 1 + 4 * c:5 + 4 * c])
+                ta, _, _, w3, _ = (int(x) for x in self.inbox[r, 1 + 5 * c:6 + 5 * c])
                 j = w3 >> 32
                 assert self.lo <= j < self.hi
                 heapq.heappush(self.heap, (ta, j))
@@ -109,7 +109,7 @@ class FakeShard:
             else:
                 c = int(self.outbox[r, 0])
                 assert c < self.cap
-                self.outbox[r, 1 + 4 * c:5 + 4 * c] = torch.tensor([ta, t, 0, (j << 32) | i])
+                self.outbox[r, 1 + 5 * c:6 + 5 * c] = torch.tensor([ta, t, 0, (j << 32) | i, 0])
                 self.outbox[r, 0] = c + 1
         nxt = min(self.heap[0][0] if self.heap else INF, H)          # nothing happens here before `nxt`
         for k, g in enumerate(self.cross):
@@ -121,7 +121,7 @@ class FakeShard:
     def inject_async(self):
         for r in range(self.world):
             for c in range(int(self.inbox[r, 0])):
-                ta, _, _, w3 = (int(x) for x in self.inbox[r, 1 + 4 * c:5 + 4 * c])
+                ta, _, _, w3, _ = (int(x) for x in self.inbox[r, 1 + 5 * c:6 + 5 * c])
                 j = w3 >> 32
                 assert self.lo <= j < self.hi
                 heapq.heappush(self.heap, (ta, j))
@@ -142,9 +142,9 @@ class FakeShard:
     def final(self, k):
         if self.heap:
             t, i = self.heap[0]
-            self.cand[:] = torch.tensor([1, t, 0, i])
+            self.cand[:] = torch.tensor([1, t, 0, i, 0, 0, i, 0])
         else:
-            self.cand[:] = torch.tensor([0, INF, 0, 0])
+            self.cand[:] = torch.tensor([0, INF, 0, 0, 0, 0, 0, 0])
 
     def overshoot(self, lp_local):
         t, i = heapq.heappop(self.heap)

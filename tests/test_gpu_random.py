@@ -136,3 +136,34 @@ def test_prologue_off_reproduces_the_old_deviation():
         eng.run_until(p["end_ns"])
         s = eng.summary()
         assert r.events_processed - s.events_processed == 1
+
+
+def test_2000_tie_storms_and_1000_several_source_rings_match_the_oracle():
+    """The election of the one event beyond end_time at scale: 2 000 tie storms on the station engine
+    and 1 000 rings with several Sources per station on both network engines, engine == oracle on everything the case
+    checkers compare.  (Round 2: 13 of 3 000 tie storms and 11 of 3 000 such rings elected the wrong LP; the key is now the
+    reference's: time, creation time, steps from the group's root, the root's creation time, construction rank.)"""
+    import time
+
+    t0 = time.time()
+    bad = []
+    for k in range(3000, 5000):
+        try:
+            check_station_case(k, RS.tie_spec(k))
+        except AssertionError as e:
+            bad.append(("tie", k, str(e).strip().splitlines()[0][:120]))
+    for k in range(3000, 3500):
+        for flags in (0, 16):
+            spec = RS.multi_source_ring_spec(k)
+            g, nodes = H.oracle_ring_graph(spec)
+            p = H.ring_params(spec)
+            r = O.run(g, p["end_ns"], seed=spec["seed"], schedule=[(nodes[c]["srv"], t) for c, t in p["schedule"]])
+            eng, p = H.ring_engine_for_spec(spec, flags=flags)
+            try:
+                with eng:
+                    eng.run_until(p["end_ns"])
+                    _check_against_oracle(spec, eng, r, nodes)
+            except AssertionError as e:
+                bad.append(("ring", k, flags, str(e).strip().splitlines()[0][:120]))
+    assert not bad, bad[:10]
+    assert time.time() - t0 < 600
