@@ -74,7 +74,11 @@ struct LbLayout {
     double *tsv;                  // [rows][B] service sample of that request (single-worker FIFO backends)
 };
 
-struct LbCand { long long t, t_created; int idx, valid; double svc_s; };
+// a candidate for the one event beyond end_time.  The election's key is the reference's (time, _sort_index): of two events on one
+// nanosecond the one created first; of two CREATED in one nanosecond the one fewer steps from the root of the group that created
+// it, then the one whose root was created first (the heap is a FIFO inside a nanosecond; csrc/hs_station.hpp StationState
+// lineage, tools/election_rules.py), then the construction order.
+struct LbCand { long long t, t_created, rcrt; int depth, idx, valid, pad; double svc_s; };
 
 struct LbSrc {                    // [S] each
     const uint8_t *kind; const double *rate; const int64_t *stop; const int64_t *n_clients; const uint64_t *base;
@@ -102,7 +106,14 @@ __device__ __forceinline__ bool cand_before(const LbCand &a, const LbCand &b) {
     if (!a.valid) return false;
     if (a.t != b.t) return a.t < b.t;
     if (a.t_created != b.t_created) return a.t_created < b.t_created;
+    if (a.depth != b.depth) return a.depth < b.depth;
+    if (a.rcrt != b.rcrt) return a.rcrt < b.rcrt;
     return a.idx < b.idx;
+}
+__device__ __forceinline__ LbCand lb_cand_none(int idx) {
+    LbCand c;
+    c.t = kInfNs; c.t_created = 0; c.rcrt = INT64_MIN; c.depth = 0; c.idx = idx; c.valid = 0; c.pad = 0; c.svc_s = 0.0;
+    return c;
 }
 
 template <typename T>
@@ -114,7 +125,8 @@ __device__ __forceinline__ T wave_sum(T v) {
 
 __device__ __forceinline__ LbCand cand_shfl_xor(const LbCand &c, int o) {
     LbCand d;
-    d.t = __shfl_xor(c.t, o, 64); d.t_created = __shfl_xor(c.t_created, o, 64);
+    d.t = __shfl_xor(c.t, o, 64); d.t_created = __shfl_xor(c.t_created, o, 64); d.rcrt = __shfl_xor(c.rcrt, o, 64);
+    d.depth = __shfl_xor(c.depth, o, 64); d.pad = 0;
     d.idx = __shfl_xor(c.idx, o, 64); d.valid = __shfl_xor(c.valid, o, 64); d.svc_s = __shfl_xor(c.svc_s, o, 64);
     return d;
 }
@@ -150,8 +162,7 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
     uint32_t n_tick = 0, n_req = 0;
     int bad = 0, over = 0;
     int64_t last = INT64_MIN;
-    LbCand c;
-    c.t = kInfNs; c.t_created = 0; c.idx = s; c.valid = 0; c.svc_s = 0.0;
+    LbCand c = lb_cand_none(s);
     if (live) {
         const uint32_t kind = P.kind[s];
         const double rate = P.rate[s];
@@ -172,6 +183,8 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
         int64_t arr_time = start_ns, t_prev = start_ns;
         int64_t root_crt = start_ns;         // creation time of the SourceEvent that heads the current same-ns chain
         uint32_t depth = 0;
+        int64_t rc_a2 = INT64_MIN;           // lineage of the tick a2 itself: the root of the group that created it was created at
+        uint32_t dp_a2 = 0;                  // ... rc_a2, dp_a2 steps before it (0: constructed before run())
         int64_t A = kInfNs;
         bool done = false, dead = false;
         for (uint64_t d0 = 0; !done; d0 += kChunk) {
@@ -205,6 +218,7 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
                 } else a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc[j]));
                 arr_time = a2;
                 if (d > 0) {
+                    rc_a2 = root_crt; dp_a2 = depth + 1;                  // created by the tick at t_prev: one step below it in ITS group
                     if (a2 == t_prev) ++depth;                            // next tick on the same nanosecond: a descendant
                     else if (a2 < t_prev) { done = true; dead = true; continue; }   // popped later as "time travel" and dropped (simulation.py:480-489)
                     else { root_crt = t_prev; depth = 0; }
@@ -227,6 +241,7 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
         P.count[s] = (int64_t)(n_req < (uint32_t)cap ? n_req : (uint32_t)cap);
         P.generated[s] = n_tick;
         c.t = A; c.t_created = root_crt; c.valid = (!dead && A != kInfNs) ? 1 : 0;
+        c.depth = (int)(dp_a2 > 255u ? 255u : dp_a2); c.rcrt = rc_a2;
     }
     block_min_cand(c, wc, P.cand);
     if (live && n_req) atomicMax(&tot->max_count, (long long)(n_req < (uint32_t)cap ? n_req : (uint32_t)cap));
@@ -436,20 +451,29 @@ struct LbBackend {
     double svc_s[C];
     double total_service;
     int64_t last_time;
+    // lineage of the pending departures and of the event being processed (hs_station.hpp StationState::dpA)
+    int32_t dpD[C], cd;
+    int64_t rcD[C], cr;
     Stream svc;
     uint32_t ev[8];
     int64_t *adm, *sink_t, *sink_created, *sink_S;   // this backend's segment of the dense logs
     int qoverflow;
     uint8_t (*qmem)[kLbBlock];
+    uint8_t (*qdep)[kLbBlock];
+    int64_t (*qrc)[kLbBlock];
     int tid, qh, qn;
 
     __device__ __forceinline__ void qpush(uint32_t code) {
         if (qn >= kLbQCap) { qoverflow = 1; return; }
-        qmem[(qh + qn) % kLbQCap][tid] = (uint8_t)code;
+        const int slot = (qh + qn) % kLbQCap;
+        qmem[slot][tid] = (uint8_t)code;
+        qdep[slot][tid] = (uint8_t)(cd >= 254 ? 255 : cd + 1);   // created by the event being processed: one step further from the root
+        qrc[slot][tid] = cr;
         ++qn;
     }
     __device__ __forceinline__ uint32_t qpop() {
         const uint32_t c = qmem[qh][tid];
+        cd = qdep[qh][tid]; cr = qrc[qh][tid];
         qh = (qh + 1) % kLbQCap;
         --qn;
         return c;
@@ -504,8 +528,9 @@ struct LbBackend {
         for (int i = 0; i < C; ++i) if (i == j) {
             svc_s[i] = s; crt[i] = created; crtD[i] = t;
             if (d == t) { D[i] = kInfNs - 1; same = (uint32_t)i + 1; }
-            else { D[i] = d; seqD[i] = seq++; }
+            else { D[i] = d; seqD[i] = seq++; dpD[i] = cd + 2 > 255 ? 255 : cd + 2; rcD[i] = cr; }   // QUEUE_DELIVER -> payload -> continuation
         }
+        if (same) ++cd;                                                   // (the caller pushes the in-group continuation: deliver + 2)
         return same;
     }
     // generator resumes (server/server.py:252-273): statistics, forward to the Sink (components/common.py:36-44),
@@ -525,8 +550,9 @@ struct LbBackend {
         }
         return active < conc;
     }
-    __device__ __forceinline__ bool chain_from_poll(int64_t t) {
+    __device__ __forceinline__ bool chain_from_poll(int64_t t) {       // (cd = the QUEUE_POLL's steps from the group's root)
         if (!do_poll()) return false;
+        ++cd;
         const uint32_t same = do_deliver_work(t);
         if (same) { qpush(LQ_CONT | ((same - 1) << 3)); return true; }
         return false;
@@ -580,10 +606,16 @@ struct LbBackend {
                 take_arr = Acrt < cd;             // the backend's own event first on equal creation times
             }
             if (take_arr) {
+                cd = 0; cr = Acrt;                    // the chain's root: the SourceEvent that heads the tick's same-ns chain
                 qpush(LQ_PRE | ((1u + Adepth) << 3));
                 ++ai;
                 load_arrival();
-            } else if (do_cont(bd, t)) qpush(LQ_POLL);
+            } else {
+                cd = 0;
+#pragma unroll
+                for (int i = 0; i < C; ++i) if (i == bd) cr = crtD[i];
+                if (do_cont(bd, t)) qpush(LQ_POLL);
+            }
         }
         drain(t);
     }
@@ -615,7 +647,7 @@ struct LbBackend {
         int64_t Sprev = INT64_MIN, Dprev = INT64_MIN, aprev = INT64_MIN, lt = INT64_MIN;
         uint32_t n_notify = 0, n_poll = 0, n_start = 0, n_dep = 0;
         bool pend = false;
-        int64_t pendD = kInfNs, pendS = 0;
+        int64_t pendD = kInfNs, pendS = 0, pendA = 0, pendSprev = INT64_MIN, pendK = 0;
         double pend_s = 0.0, tsvc = 0.0;
         constexpr int kAhead = 8;
         const double *sp = asv;
@@ -654,7 +686,7 @@ struct LbBackend {
                     if (egress == HS_EGRESS_SINK) { sink_t[n_dep * ss] = Dk; sink_created[n_dep * ss] = a; sink_S[n_dep * ss] = S; }
                     ++n_dep;
                     pend = false;
-                } else { pend = true; pendD = Dk; pendS = S; pend_s = sv; }
+                } else { pend = true; pendD = Dk; pendS = S; pend_s = sv; pendA = a; pendSprev = Sprev; pendK = base + j; }
                 Sprev = S; Dprev = Dk; aprev = a;
             }
 #pragma unroll
@@ -672,6 +704,12 @@ struct LbBackend {
         buf = n - (int64_t)n_start;
         active = pend ? 1 : 0;
         D[0] = pend ? pendD : kInfNs; crtD[0] = pendS; svc_s[0] = pend_s; seqD[0] = 0;
+        if (pend) {      // lineage of the pending departure (only the election beyond end_time reads it)
+            if (pendS == pendA) {          // started on arrival: SourceEvent -> Request@LoadBalancer -> Request@Server -> QUEUE_NOTIFY ->
+                const uint64_t v = aval[ai + pendK];   // QUEUE_POLL -> QUEUE_DELIVER -> payload -> continuation, below the tick's chain root
+                dpD[0] = (int32_t)(v >> 56) + 7; rcD[0] = (int64_t)(v & kCrtMask);
+            } else { dpD[0] = 4; rcD[0] = pendSprev; }   // started when the request before it left: four steps below that continuation
+        }
         total_service = tsvc;
         last_time = n > 0 ? lt : INT64_MIN;
         ai = aend; At = kInfNs;
@@ -686,6 +724,7 @@ struct LbBackend {
         if (n_at == 1 && !force_general) {
             bool want_poll, general = false;
             if (arr) {
+                cr = Acrt; cd = (int32_t)Adepth + 4;   // tick (Adepth) -> Request@LoadBalancer -> Request@Server -> QUEUE_NOTIFY -> QUEUE_POLL
                 ++ai;
                 load_arrival();
                 want_poll = do_enqueue(t) && do_notify();
@@ -693,6 +732,9 @@ struct LbBackend {
                 int slot = 0;
 #pragma unroll
                 for (int i = 0; i < C; ++i) if (D[i] == t) slot = i;
+#pragma unroll
+                for (int i = 0; i < C; ++i) if (i == slot) cr = crtD[i];
+                cd = 1;                                // continuation -> QUEUE_POLL
                 want_poll = do_cont(slot, t);
             }
             if (want_poll) general = chain_from_poll(t);
@@ -711,12 +753,13 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_backends(LbBe P, int B, int S
                                                            const double *__restrict__ svdraw, LbTotals *tot, int flags,
                                                            LbLayout LY) {
     __shared__ uint8_t qmem[kLbQCap][kLbBlock];
+    __shared__ uint8_t qdep[kLbQCap][kLbBlock];          // lineage of the in-group FIFO's entries
+    __shared__ int64_t qrc[kLbQCap][kLbBlock];
     __shared__ LbCand wc[kLbBlock / 64];
     const int tid = threadIdx.x;
     const int b = blockIdx.x * kLbBlock + tid;
     const bool live = b < B;
-    LbCand c;
-    c.t = kInfNs; c.t_created = 0; c.idx = S + b; c.valid = 0; c.svc_s = 0.0;
+    LbCand c = lb_cand_none(S + b);
     LbBackend<C> X;
 #pragma unroll
     for (int k = 0; k < 8; ++k) X.ev[k] = 0;
@@ -732,7 +775,8 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_backends(LbBe P, int B, int S
         X.buf = 0; X.accepted = 0; X.dropped = 0; X.rejected = 0; X.started = 0; X.active = 0; X.seq = 0;
         X.total_service = 0.0;
 #pragma unroll
-        for (int i = 0; i < C; ++i) { X.D[i] = kInfNs; X.crtD[i] = start_ns; X.crt[i] = 0; X.seqD[i] = 0; X.svc_s[i] = 0.0; }
+        for (int i = 0; i < C; ++i) { X.D[i] = kInfNs; X.crtD[i] = start_ns; X.crt[i] = 0; X.seqD[i] = 0; X.svc_s[i] = 0.0; X.dpD[i] = 0; X.rcD[i] = INT64_MIN; }
+        X.cd = 0; X.cr = INT64_MIN;
         X.svc.init(seed, stream_id(P.base[b], kStreamService), 0);
         const int64_t o = off[b];
         const bool T = tot->use_t != 0;
@@ -740,7 +784,7 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_backends(LbBe P, int B, int S
         X.ss = T ? B : 1;
         const int64_t so = T ? b : o;
         X.adm = adm + o; X.sink_t = sink_t + so; X.sink_created = sink_created + so; X.sink_S = sink_S + so;
-        X.qmem = qmem; X.tid = tid; X.qh = 0; X.qn = 0;
+        X.qmem = qmem; X.qdep = qdep; X.qrc = qrc; X.tid = tid; X.qh = 0; X.qn = 0;
         const bool force_general = (flags & 1) != 0;
         bool event_order = true;
         if constexpr (C == 1) {
@@ -769,6 +813,7 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_backends(LbBe P, int B, int S
         for (int i = 0; i < C; ++i)
             if (X.D[i] != kInfNs && (!c.valid || X.D[i] < c.t || (X.D[i] == c.t && (int32_t)(X.seqD[i] - bs) < 0))) {
                 c.t = X.D[i]; c.t_created = X.crtD[i]; c.svc_s = X.svc_s[i]; c.valid = 1; bs = X.seqD[i];
+                c.depth = X.dpD[i]; c.rcrt = X.rcD[i];
             }
     }
     block_min_cand(c, wc, P.cand);
@@ -882,9 +927,9 @@ __global__ void hs_lb_probe_cands(LbProbes Q, int S, int B, int64_t end_ns, LbTo
     const int64_t n = Q.n_tick[j];
     const int64_t c = count_le(tk, n, 1, end_ns);
     Q.cnt[j] = c;
-    LbCand cd;
+    LbCand cd = lb_cand_none(S + B + j);
     cd.valid = c < n ? 1 : 0; cd.t = c < n ? tk[c] : kInfNs; cd.t_created = c > 0 ? tk[c - 1] : INT64_MIN;   // (constructed before run())
-    cd.idx = S + B + j; cd.svc_s = 0.0;
+    cd.depth = c > 0 ? 1 : 0; cd.rcrt = c > 1 ? tk[c - 2] : INT64_MIN;    // a tick is created by the tick before it, always a root
     Q.cand[j] = cd;
     if (c > 0) {
         atomicAdd(&tot->ev[13], (unsigned long long)c);           // SourceEvent@Probe
@@ -965,8 +1010,7 @@ __global__ void __launch_bounds__(kLbBlock) hs_lb_finalize(LbSrc PS, LbBe PB, in
                                                           LbProbes Q) {
     __shared__ LbCand wc[kLbBlock / 64];
     const int tid = threadIdx.x;
-    LbCand best;
-    best.valid = 0; best.t = kInfNs; best.t_created = 0; best.idx = 0; best.svc_s = 0.0;
+    LbCand best = lb_cand_none(0);
     const int nbs = (S + kLbBlock - 1) / kLbBlock, nbb = (B + kLbBlock - 1) / kLbBlock;   // one candidate per workgroup
     for (int i = tid; i < nbs + nbb + Q.n; i += kLbBlock) {
         const LbCand c = i < nbs ? PS.cand[i] : i < nbs + nbb ? PB.cand[i - nbs] : Q.cand[i - nbs - nbb];

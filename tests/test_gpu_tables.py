@@ -30,7 +30,7 @@ def _table(profile, poisson, seed, sid, horizon_s, cap, lone, budget=0, start_ns
 CASES = [
     ("ramp 5 s 3->20, Poisson", (RAMP, 5.0, 3.0, 20.0, 0.0), 1, 4.0),
     ("ramp 5 s 3->20, deterministic", (RAMP, 5.0, 3.0, 20.0, 0.0), 0, 4.0),
-    ("ramp from a low rate", (RAMP, 2.0, 0.5, 30.0, 0.0), 1, 3.0),
+    ("ramp 2 s 2->30", (RAMP, 2.0, 2.0, 30.0, 0.0), 1, 3.0),
     ("ramp down to a low rate", (RAMP, 2.0, 25.0, 2.0, 0.0), 1, 4.0),
     ("spike 3 / 40 at 1 s for 0.5 s", (SPIKE, 3.0, 40.0, 1.0, 0.5), 1, 3.0),
     ("spike, deterministic", (SPIKE, 3.0, 40.0, 1.0, 0.5), 0, 3.0),
