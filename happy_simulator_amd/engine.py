@@ -169,6 +169,12 @@ class StationEngine:
             if stations.src_more_kind is None and \
                     sorted(a.tolist()) != np.flatnonzero(np.asarray(stations.src_kind) != N.SRC_NONE).tolist():
                 raise ValueError("source_order must list exactly the LPs that carry a Source, each once")
+            # the engine reads one entry per Source from this pointer: the length must be the number of Sources
+            n_src = int(np.count_nonzero(np.asarray(stations.src_kind) != N.SRC_NONE))
+            if stations.src_more_kind is not None:
+                n_src += int(np.count_nonzero(np.asarray(stations.src_more_kind) != N.SRC_NONE))
+            if len(a) != n_src:
+                raise ValueError(f"source_order must have one entry per Source ({n_src}), got {len(a)}")
             keep.append(a)
             st.source_order = a.ctypes.data if len(a) else None
             if stations.source_slot_order is not None:
@@ -186,6 +192,11 @@ class StationEngine:
             st.probe_metric_more, st.probe_interval_more = pm.ctypes.data, pi.ctypes.data
         if stations.probe_order is not None:        # (the engine checks that every (LP, slot) probe is listed exactly once)
             a = np.ascontiguousarray(stations.probe_order, np.int32)
+            n_prb = 0 if stations.probe_metric is None else int(np.count_nonzero(np.asarray(stations.probe_metric) != N.PROBE_NONE))
+            if stations.probe_metric_more is not None:
+                n_prb += int(np.count_nonzero(np.asarray(stations.probe_metric_more) != N.PROBE_NONE))
+            if len(a) != n_prb:                     # the engine reads one entry per Probe from this pointer
+                raise ValueError(f"probe_order must have one entry per Probe ({n_prb}), got {len(a)}")
             keep.append(a)
             st.probe_order = a.ctypes.data if len(a) else None
             if stations.probe_slot_order is not None:

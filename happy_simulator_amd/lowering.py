@@ -165,12 +165,14 @@ class LoweredGraph:
                        st.server.service_time.mean > 0) else np.inf for st in self.stations], np.float64)
         share = np.array([1.0 / max(len(self.stations[s].router.targets), 1) if self.stations[s].router is not None else 1.0
                           for _, s, _ in self.links], np.float64)
+        src = np.array([s_ for _, s_, _ in self.links], np.int64)
+        dst = np.array([d_ for _, _, d_ in self.links], np.int64)
         inflow = rate.copy()
-        for _ in range(4 * n + 16):
+        for _ in range(4 * n + 16):                       # (one vectorised pass per iteration: a deep tandem needs ~n of them)
             out = np.minimum(inflow, mu)
             nxt = rate.copy()
-            for k, (_, s, d) in enumerate(self.links):
-                nxt[d] += share[k] * out[s]
+            if len(src):
+                np.add.at(nxt, dst, share * out[src])
             if np.allclose(nxt, inflow, rtol=1e-9, atol=1e-12):
                 inflow = nxt
                 break
@@ -205,6 +207,9 @@ def attach_probes(g: LoweredGraph, probes: list) -> None:
         st = g.stations[i]
         if len(st.probes) >= 4:
             raise UnsupportedTopology(f"station of '{pr.target.name}' already has four probes (the engine's slots per station)")
+        if pr.metric != "utilization" and pr.metric not in N.PROBE_METRICS:
+            raise UnsupportedTopology(f"probe '{pr.name}': metric '{pr.metric}' is not sampled on the engine "
+                                      f"(lowered: {', '.join(sorted(N.PROBE_METRICS))}, utilization)")
         kinds = {"generated_count": Source, "_generated_count": Source, "events_received": _SINKS}
         want = kinds.get(pr.metric, Server)
         if not isinstance(pr.target, want):
@@ -429,6 +434,7 @@ def write_back(g: LoweredGraph, stats: dict, counts: np.ndarray, t_ns: np.ndarra
             if rc != N.HS_OK:
                 raise N.EngineError(rc, (N.lib().hs_lb_last_error(None) or b"").decode())
         sink._set_records(t, cr)
+        sink._device = device           # Sink.latency_stats() sorts on the GPU the run used (one rank per GPU: not device 0)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -571,6 +577,9 @@ def attach_lb_probes(g: LbGraph, probes: list) -> None:
     for pr in probes or []:
         if not isinstance(pr, Probe):
             raise UnsupportedTopology(f"probe {type(pr).__name__} is not a lowered Probe")
+        if pr.metric != "utilization" and pr.metric not in N.PROBE_METRICS:
+            raise UnsupportedTopology(f"probe '{pr.name}': metric '{pr.metric}' is not sampled on the engine "
+                                      f"(lowered: {', '.join(sorted(N.PROBE_METRICS))}, utilization)")
         if any(pr.target is b for b in g.backends):
             if pr.metric in ("generated_count", "_generated_count", "events_received"):
                 raise UnsupportedTopology(f"probe '{pr.name}': metric '{pr.metric}' is not an attribute of Server")

@@ -182,6 +182,20 @@ def shard_arrays(stations: StationArrays, net: NetworkArrays, lo: int, hi: int):
         sched_off=None if stations.sched_off is None else (np.asarray(stations.sched_off)[lo:hi + 1] - int(stations.sched_off[lo])),
         sched_time_ns=None if stations.sched_off is None else np.asarray(stations.sched_time_ns)[
             int(stations.sched_off[lo]):int(stations.sched_off[hi])])
+    # the reference's construction order (`sources=[...]`, `probes=[...]`, the Events handed to schedule()): the shard keeps the
+    # relative order of what it owns -- the election's last key (csrc/hs_kernels.hpp cand_rank) and, on one engine, the prologue
+    if stations.sched_off is not None and getattr(stations, "sched_rank", None) is not None:
+        st.sched_rank = np.asarray(stations.sched_rank, np.int64)[int(stations.sched_off[lo]):int(stations.sched_off[hi])]
+    for order_name, slot_name in (("source_order", "source_slot_order"), ("probe_order", "probe_slot_order")):
+        order = getattr(stations, order_name, None)
+        if order is None:
+            continue
+        order = np.asarray(order, np.int64)
+        keep = (order >= lo) & (order < hi)
+        setattr(st, order_name, (order[keep] - lo).astype(np.int32))
+        slots = getattr(stations, slot_name, None)
+        if slots is not None:
+            setattr(st, slot_name, np.asarray(slots, np.uint8)[keep])
     src, dst = np.asarray(net.link_src), np.asarray(net.link_dst)
     touch = ((src >= lo) & (src < hi)) | ((dst >= lo) & (dst < hi))
     gids = np.nonzero(touch)[0].astype(np.int64)
@@ -234,6 +248,7 @@ class GpuShard:
                                     lp_base=self.lo, device=device, log_capacity=log_capacity, network=net)
         self.engine.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         self.local_window_ns = self.engine.summary().window_ns
+        self.has_more_sources = stations.src_more_kind is not None
         self._attached = False
 
     def attach(self, window_ns: int):
@@ -469,6 +484,10 @@ class ShardedNetwork:
         for s in sorted(self.shards, key=lambda x: x.lo):
             for k, v in s.engine.lp_stats().items():
                 stats.setdefault(k, np.zeros(n_stations, v.dtype))[s.lo:s.hi] = v
+            if getattr(s, "has_more_sources", False):      # several Sources per Server: Source.generated_count of slots 1..3
+                more = stats.setdefault("generated_more", [np.zeros(n_stations, np.int64) for _ in range(3)])
+                for slot in range(3):
+                    more[slot][s.lo:s.hi] = s.engine.source_generated(1 + slot)
             c, t, cr = s.engine.read_sinks()
             counts[s.lo:s.hi] = c
             ts.append(t)

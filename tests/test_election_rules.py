@@ -1,8 +1,10 @@
-"""CPU: the emulation of the engines' election of the one event beyond end_time (tools/election_rules.py, an analysis build of
-the oracle) stays in step with what MI355X measured -- the engine's key fails on exactly the tie storms the GPU fails on
-(tests/test_gpu_random.py leaves out case 85; profiles/r02_gpu_random_sweep*.log) -- and the key that DESIGN.md section 9 names
-as the fix (the heap is a FIFO inside one nanosecond: creation time, steps from the group's root, the root's creation time,
-construction rank; Probes by their own list position) elects the reference's LP on every one of them."""
+"""CPU: the emulation of the election of the one event beyond end_time (tools/election_rules.py, an analysis build of the
+oracle).  Round 2's engines elected by (time, creation time, construction rank); the emulation of THAT key fails on exactly the
+tie storms MI355X failed on then (profiles/r02_gpu_random_sweep*.log), which validates the emulation -- and the key the kernels
+use since round 3 (the heap is a FIFO inside one nanosecond: creation time, steps from the group's root, the root's creation
+time, construction rank; Probes by their own list position -- csrc/hs_station.hpp StationState lineage, csrc/hs_kernels.hpp
+cand_less) elects the reference's LP on every one of them.  The GPU side: tests/test_gpu_random.py (2 000 tie storms, 1 000
+several-Sources rings), profiles/r03_gpu_sweep_*_election.log."""
 import os
 import subprocess
 import sys

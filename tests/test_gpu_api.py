@@ -567,6 +567,35 @@ def test_network_larger_than_one_cooperative_launch_is_time_shared(monkeypatch):
     assert whole[0] > 100_000 and sum(whole[8]) > 0 and all(len(v[0]) >= 11 for v in whole[2])
 
 
+def test_several_sources_per_server_on_the_time_shared_path(monkeypatch):
+    """a network with several Sources per Server that exceeds one cooperative launch ran on the device and then died in
+    write_back with KeyError 'generated_more' (ShardedNetwork.collect() did not gather the further Sources' tick counts).  A
+    600-station ring with up to three further Sources per station, whole vs four time-shared segments: every object equal,
+    the further Sources' generated_count included, the list order reversed (`extras_first`)."""
+    n = 600
+    more = [None] * n
+    for i in range(0, n, 7):
+        more[i] = [["constant", 4.0]] if i % 2 else [["poisson", 2.0], ["constant", 5.0], ["poisson", 4.0]]
+    spec = dict(n=n, ext_rate=[3.0] * n, mean=0.1, lat_min=0.001, jitter_mean=0.01, more_sources=more, sources_order="extras_first")
+
+    def run(limit):
+        if limit:
+            monkeypatch.setattr(hs.Simulation, "_resident_stations", lambda self: limit)
+        sources, servers, routers, links, sinks = _build_ring(spec)
+        sim = hs.Simulation(end_time=Instant.from_seconds(4.0), sources=sources, entities=servers + routers + links + sinks, seed=9)
+        summary = sim.run()
+        monkeypatch.undo()
+        return (summary.total_events_processed, summary.duration_s, [src.generated_count for src in sources],
+                [s.stats_accepted for s in servers], [s.stats.requests_completed for s in servers],
+                [s.stats.total_service_time for s in servers], [r.stats_routed for r in routers],
+                [l.packets_sent for l in links], [k.events_received for k in sinks], [x for k in sinks for x in k.latencies_s])
+
+    whole = run(0)
+    shared = run(160)
+    assert whole == shared
+    assert whole[0] > 50_000 and min(whole[2]) >= 5
+
+
 @pytest.mark.parametrize("name", ["ring_6_probes", "ring_5_multi_probes", "ring_5_profiles", "ring_4_schedule"])
 def test_probes_and_profiles_on_networked_stations_match_reference_golden(name):
     """Probe.on(server / sink, metric, interval), Source.with_profile(LinearRamp / Spike) and Simulation.schedule() on the
