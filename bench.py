@@ -130,8 +130,11 @@ def parse():
                          "ONE 65 536-station ring network, sharded over the GPUs (strong scaling, RCCL exchange + GVT); "
                          "lb = BASELINE configs[4]: 32 768 Sources -> LoadBalancer(ConsistentHash(150)) -> 32 768 Servers -> "
                          "one Sink (one topology per GPU, replicas only)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="grid: weak = every GPU its own n_lp chains (the default); strong = n_lp chains in total, split over the GPUs")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="grid: strong = n_lp chains IN TOTAL, a contiguous block per GPU (the metric's 65 536-server grid on 1/2/4/8 "
+                         "GPUs, SURVEY 8(d) 2b: the default with --gpus > 1; each GPU then runs the K-lanes-per-LP kernel, "
+                         "csrc/hs_kernels_wide.hpp); weak = every GPU its own n_lp chains.  With --gpus > 1 the other one is "
+                         "timed as well and printed as `other_scaling`.")
     ap.add_argument("--api-run", type=int, default=1,
                     help="grid, 1 GPU: also time the user-visible hs.Simulation(...).run() at this size (config.api_run_s)")
     ap.add_argument("--lb-backends", type=int, default=32768)
@@ -382,6 +385,10 @@ def cpu_baseline(args):
     horizon_all = args.end_s if cores >= 64 else min(args.end_s, args.cpu_sample_s)
     ra = O.run_blocks_parallel(blocks, int(horizon_all * 1e9), seed=args.seed)
     return {
+        # the three CPU figures side by side: the C port on one core, on all cores, the reference's Python
+        "value_1_core": r.events_processed / r.run_seconds,
+        "value_all_cores": ra["events"] / ra["wall_seconds"],
+        "cores_all": ra["threads"],
         "all_cores": {
             "value": ra["events"] / ra["wall_seconds"], "unit": "events/s", "cores": ra["threads"], "kind": "port",
             "sample": f"{args.n_lp} chains in {ra['threads']} blocks (one heap and one thread per block), "
@@ -481,37 +488,46 @@ def main():
         return
     end_ns = int(args.end_s * 1_000_000_000)
     n_total = args.n_lp
-    if args.scaling == "strong":          # the metric's 65 536 servers in total: rank r owns the contiguous block [lo, hi)
-        lo, hi = rank * n_total // world, (rank + 1) * n_total // world
-    else:                                 # every rank its own n_lp chains with disjoint stream ids
-        lo, hi = rank * n_total, (rank + 1) * n_total
-    n_mine = hi - lo
-    st = StationArrays.uniform(n_mine, rate=args.rate, mean=args.mean)
-    eng = StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=end_ns, seed=args.seed, lp_base=lo, device=local_rank)
+    if args.scaling is None:
+        args.scaling = "strong" if world > 1 else "weak"
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.warmup > 0:
-        eng.bench_runs(end_ns, args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    kernel_ms, dev_total_ms = eng.bench_runs(end_ns, args.steps)   # K x (reset + run), engine stream, HIP events
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def timed(scaling):
+        """W warm-up + K timed steps of this rank's share; (engine, elapsed max over ranks, events summed over ranks, ...)."""
+        if scaling == "strong":           # the metric's 65 536 servers in total: rank r owns the contiguous block [lo, hi)
+            lo, hi = rank * n_total // world, (rank + 1) * n_total // world
+        else:                             # every rank its own n_lp chains with disjoint stream ids
+            lo, hi = rank * n_total, (rank + 1) * n_total
+        st = StationArrays.uniform(hi - lo, rate=args.rate, mean=args.mean)
+        eng = StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=end_ns, seed=args.seed, lp_base=lo, device=local_rank)
+        if args.warmup > 0:
+            eng.bench_runs(end_ns, args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        kernel_ms, dev_total_ms = eng.bench_runs(end_ns, args.steps)   # K x (reset + run), engine stream, HIP events
+        barrier()
+        elapsed = time.perf_counter() - t0
+        s = eng.summary()
+        t_elapsed = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t_events = torch.tensor([float(s.events_processed)], dtype=torch.float64, device="cuda")
+        if distributed:
+            dist.all_reduce(t_elapsed, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t_events, op=dist.ReduceOp.SUM)
+        return eng, float(t_elapsed.item()), float(t_events.item()), kernel_ms, dev_total_ms, s, hi - lo
 
-    s = eng.summary()
+    other = None
+    if world > 1:                         # the other reading of "N GPUs", for the record
+        oth = "weak" if args.scaling == "strong" else "strong"
+        e2, el2, ev2, _, _, _, n2 = timed(oth)
+        e2.close()
+        other = {"scaling": oth, "value": ev2 * args.steps / el2, "ms_per_step": el2 / args.steps * 1e3, "n_lp_per_gpu": n2}
+    eng, elapsed, total_events_per_step, kernel_ms, dev_total_ms, s, n_mine = timed(args.scaling)
     events_per_step = s.events_processed
     requests_per_step = s.requests_completed
-    t_elapsed = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    t_events = torch.tensor([float(events_per_step)], dtype=torch.float64, device="cuda")
-    if distributed:
-        dist.all_reduce(t_elapsed, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t_events, op=dist.ReduceOp.SUM)
-    elapsed = float(t_elapsed.item())
-    total_events_per_step = float(t_events.item())
 
     if rank == 0:
         k_avg_ms = float(np.mean(kernel_ms))
@@ -552,7 +568,8 @@ def main():
                 # the binding resource is VALU issue (the serial per-LP recursion), not HBM: `achieved` / `frac` are the HBM
                 # figures the contract asks for, `valu` is the measured issue fraction of the same kernel
                 "bound": "valu",
-                "kernel": "hs_station_run<1, false, true, true> (producer / consumer wavefronts, uniform entity kinds)",
+                "kernel": ("hs_station_run<1, false, true, true> (producer / consumer wavefronts, uniform entity kinds)" if n_mine > 32768
+                           else "hs_station_wide<K> + hs_station_wide_finish (K lanes per LP: fewer LPs than the device has lanes)"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -576,11 +593,16 @@ def main():
                         "and are null when the kernel sources changed since",
             },
         }
+        if other is not None:
+            out["other_scaling"] = other
         if args.cpu_sample_s > 0 and args.gpus == 1:
             out["cpu_baseline"] = cpu_baseline(args)
             ref = reference_python()
             if ref is not None:
                 out["cpu_baseline"]["reference_python"] = ref
+                vals = [v.get("value") for v in ref.values() if isinstance(v, dict) and "value" in v] if isinstance(ref, dict) else []
+                if vals:
+                    out["cpu_baseline"]["value_reference_python_best"] = max(vals)
         if args.api_run and args.gpus == 1:
             out["config"].update(api_run(args, local_rank))
         print(json.dumps(out))

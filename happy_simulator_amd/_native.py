@@ -137,7 +137,7 @@ class LbStats(C.Structure):
 
 
 _TUS = ("hs_engine.hip", "hs_lb.hip", "hs_tables.hip")          # one object each ...
-_INST_TU, _INST_GROUPS = "hs_inst.hip", 13                      # ... plus hs_inst.hip once per instantiation group (csrc/hs_kernels.hpp)
+_INST_TU, _INST_GROUPS = "hs_inst.hip", 15                      # ... plus hs_inst.hip once per instantiation group (csrc/hs_kernels.hpp)
 STAMP_PATH = os.path.join(LIB_DIR, "libhs_hip.stamp")
 
 
@@ -162,24 +162,27 @@ def is_stale() -> bool:
     if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP_PATH):
         return True
     with open(STAMP_PATH) as f:
-        return f.read().strip() != _sources_hash()
+        return f.read().strip() != _sources_hash() + "|"
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, defines: tuple = (), lib_path: str | None = None) -> str:
     """Cross-compile libhs_hip.so for gfx950 with hipcc (works without a GPU): every translation unit -- and every group of
     kernel instantiations of hs_inst.hip -- is its own object, compiled in parallel (HS_BUILD_JOBS, default = CPU count),
-    then linked.  Objects whose inputs did not change are kept."""
+    then linked.  Objects whose inputs did not change are kept.  `defines` / `lib_path`: an instrumented copy of the library
+    (tools/cycles.py: -DHS_CYCLES ...) with its own object directory; load it with HS_HIP_LIB=<lib_path>."""
     import concurrent.futures
-    import hashlib
 
     os.makedirs(LIB_DIR, exist_ok=True)
-    if not force and not is_stale():
-        return LIB_PATH
+    out = lib_path or LIB_PATH
+    stamp = out + ".stamp" if lib_path else STAMP_PATH
+    extra = [f"-D{d}" for d in defines]
+    want = _sources_hash() + "|" + " ".join(extra)
+    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    obj_dir = os.path.join(LIB_DIR, "obj")
+    obj_dir = os.path.join(LIB_DIR, "obj") if not lib_path else out + ".obj"
     os.makedirs(obj_dir, exist_ok=True)
-    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
-    want = _sources_hash()
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + extra
     jobs = [(tu, [], os.path.join(obj_dir, tu.replace(".hip", ".o"))) for tu in _TUS]
     jobs += [(_INST_TU, [f"-DHS_INST={k}"], os.path.join(obj_dir, f"hs_inst_{k}.o")) for k in range(_INST_GROUPS)]
 
@@ -201,13 +204,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     order = sorted(jobs, key=lambda j: 0 if "hs_inst" in j[2] and any(f"_{k}.o" in j[2] for k in (8, 9, 10, 11, 12, 5, 6, 7)) else 1)
     with concurrent.futures.ThreadPoolExecutor(max_workers=n_jobs) as ex:
         objs = list(ex.map(compile_one, order))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *sorted(objs), "-o", LIB_PATH]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *sorted(objs), "-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    with open(STAMP_PATH, "w") as f:
+    with open(stamp, "w") as f:
         f.write(want)
-    return LIB_PATH
+    return out
 
 
 _lib = None

@@ -79,6 +79,10 @@ struct hs_engine {
     XState *xs = nullptr;
     XState xs_host{};          // the device pointers / capacities of *xs (phase etc. are reset from it)
     XInit XI{};
+    // K lanes per LP (hs_kernels_wide.hpp): the uniform grid with fewer LPs than the device has lanes
+    WideCtl *wide_ctl = nullptr; int32_t *wide_bail = nullptr;
+    int wide_K = 0;            // 0: one lane per LP (hs_station_run)
+    bool fresh = false;        // nothing has run since the last reset (the wide kernel starts from empty queues)
     // tick tables (hs_tables.hpp): Sources with a time-varying profile and Probes
     TickRow *tab_rows = nullptr; int n_tab_rows = 0; int64_t tab_cap = 0;
     int64_t *tab_times = nullptr, *tab_count = nullptr;
@@ -153,7 +157,43 @@ void launch_run(hs_engine *h, int64_t end_ns) {
                            h->cands, h->cfg.n_lp, end_ns, h->cfg.mode, h->flags);
 }
 
+// K lanes per LP when the grid is uniform and leaves lanes idle (hs_kernels_wide.hpp); debug flag 1 << 22 keeps the one-lane kernel,
+// bits 24..27 force K = 1 << (value - 1)
+int wide_lanes(const hs_engine *h) {
+    if (h->C != 1 || !h->uni_grid || h->any_profile || h->cfg.mode != HS_MODE_SINGLE || !h->fresh || h->wide_ctl == nullptr) return 0;
+    if (h->flags & ((1 << 22) | 1 | 512 | (1 << 20))) return 0;
+    const int forced = (h->flags >> 24) & 0xf;
+    if (forced) return (1 << (forced - 1)) <= 16 ? 1 << (forced - 1) : 16;
+    // Measured on MI355X (tools/wide_timing.py, 60 s of the headline grid, kernel ms): one lane per LP 0.39 at every size;
+    //   8 192 LPs: K = 4 0.168, K = 8 0.185, K = 16 0.32;   2 048 LPs: K = 4 0.121, K = 8 0.101, K = 16 0.122.
+    // Fewer lanes per LP = less redundant work in the serial arrival chain, more = shorter steps: K = 8 while the device has SIMDs
+    // to spare, K = 4 up to the size at which a lane per LP fills the machine.
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->cfg.device) != hipSuccess) return 0;
+    const long long lanes = (long long)prop.multiProcessorCount * 4 * 64;        // one wavefront per SIMD
+    const long long n = h->cfg.n_lp;
+    if (n * 16 <= lanes) return 8;              // <= 4 096 LPs on 256 CUs
+    if (n * 2 <= lanes) return 4;               // <= 32 768 LPs
+    return 0;
+}
+template <int K>
+void launch_wide(hs_engine *h, int64_t end_ns) {
+    const int n = h->cfg.n_lp, G = 64 / K, nb = (n + G - 1) / G;
+    hipLaunchKernelGGL(hs_station_wide<K>, dim3(nb), dim3(kWideBlock), 0, h->stream, h->P, h->X, h->L, h->tot, h->cands, h->wide_ctl,
+                       h->wide_bail, n, end_ns, h->flags);
+    hipLaunchKernelGGL(hs_station_wide_finish, dim3(1), dim3(kBlock), 0, h->stream, h->P, h->X, h->L, h->tot, h->cands, nb, h->wide_ctl,
+                       h->wide_bail, n, end_ns);
+}
+
 void launch_run_dispatch(hs_engine *h, int64_t end_ns) {
+    const int K = wide_lanes(h);
+    h->fresh = false;
+    switch (K) {
+        case 4: launch_wide<4>(h, end_ns); return;
+        case 8: launch_wide<8>(h, end_ns); return;
+        case 16: launch_wide<16>(h, end_ns); return;
+        default: break;
+    }
     switch (h->C) {
         case 1: launch_run<1>(h, end_ns); break;
         case 2: launch_run<2>(h, end_ns); break;
@@ -277,6 +317,7 @@ int do_reset_async(hs_engine *h) {
     }
     h->initialised = true;
     h->net_ran = false;
+    h->fresh = true;
     return HS_OK;
 }
 
@@ -770,7 +811,12 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     }
     h->L.sink_created = (h->C > 1) ? h->L.sink_created_own : h->L.adm;
     if ((rc = dev_alloc(h, &h->tot, 1))) return rc;
-    if ((rc = dev_alloc(h, &h->cands, (size_t)h->n_blocks))) return rc;
+    if ((rc = dev_alloc(h, &h->cands, std::max<size_t>((size_t)h->n_blocks, (size_t)(n + 1) / 2)))) return rc;   // (the wide kernel: one per >= 2 LPs)
+    if (h->C == 1 && h->uni_grid && !h->any_profile && h->cfg.mode == HS_MODE_SINGLE) {
+        if ((rc = dev_alloc(h, &h->wide_ctl, 1))) return rc;
+        if ((rc = dev_alloc(h, &h->wide_bail, (size_t)n))) return rc;
+        HS_HIP(h, hipMemset(h->wide_ctl, 0, sizeof(WideCtl)));
+    }
     HS_HIP(h, hipMemset(h->tot, 0, sizeof(Totals)));
     h->have_stations = true;
     return HS_OK;

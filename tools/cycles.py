@@ -23,9 +23,7 @@ a = ap.parse_args()
 from happy_simulator_amd import _native as N
 if a.build:
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = ["/opt/rocm/bin/hipcc", *N.HIPCC_FLAGS, "-DHS_CYCLES", *[f"-D{d}" for d in a.define],
-           os.path.join(N.CSRC, "hs_engine.hip"), os.path.join(N.CSRC, "hs_lb.hip"), "-o", OUT]
-    subprocess.check_call(cmd)
+    N.build(defines=("HS_CYCLES", *a.define), lib_path=OUT)
     print("built", OUT)
     sys.exit(0)
 if a.ring:
