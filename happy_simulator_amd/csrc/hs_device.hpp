@@ -96,6 +96,21 @@ __device__ __forceinline__ double seconds_from_ns(int64_t ns) {
     const double r1 = __fma_rn(-1e9, q1, a);
     return __fma_rn(r1, 1e-9, q1);
 }
+// Whole nanoseconds in [0, 2^52) are EXACT in binary64, so the time algebra can stay in fp64 registers where the values allow it
+// (the uniform-grid kernels check it on the host): from_seconds is one v_trunc_f64 instead of the multi-instruction f64 -> i64
+// conversion, to_seconds starts from the value itself instead of an i64 -> f64 conversion, and the int64 a log or a comparison
+// needs is an add and a mask.  Bit-identical to ns_from_seconds / seconds_from_ns on that range.
+__device__ __forceinline__ double ns_from_seconds_d(double x) { return __builtin_trunc(__dmul_rn(x, 1e9)); }
+__device__ __forceinline__ double seconds_from_ns_d(double ns) {
+    const double q0 = __dmul_rn(ns, 1e-9);
+    const double r0 = __fma_rn(-1e9, q0, ns);
+    const double q1 = __fma_rn(r0, 1e-9, q0);
+    const double r1 = __fma_rn(-1e9, q1, ns);
+    return __fma_rn(r1, 1e-9, q1);
+}
+__device__ __forceinline__ int64_t i64_from_whole_d(double d) {   // whole d in [0, 2^52)
+    return (int64_t)((uint64_t)__double_as_longlong(__dadd_rn(d, 4503599627370496.0)) & 0xFFFFFFFFFFFFFull);
+}
 // the plain IEEE division, kept for the device-vs-division test hook
 __device__ __forceinline__ double seconds_from_ns_ieee(int64_t ns) { return __ddiv_rn(__ll2double_rn(ns), 1e9); }
 

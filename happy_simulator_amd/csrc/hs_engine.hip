@@ -164,16 +164,21 @@ int wide_lanes(const hs_engine *h) {
     if (h->flags & ((1 << 22) | 1 | 512 | (1 << 20))) return 0;
     const int forced = (h->flags >> 24) & 0xf;
     if (forced) return (1 << (forced - 1)) <= 16 ? 1 << (forced - 1) : 16;
-    // Measured on MI355X (tools/wide_timing.py, 60 s of the headline grid, kernel ms): one lane per LP 0.39 at every size;
-    //   8 192 LPs: K = 4 0.168, K = 8 0.185, K = 16 0.32;   2 048 LPs: K = 4 0.121, K = 8 0.101, K = 16 0.122.
+    // Measured on MI355X (tools/wide_timing.py, profiles/r03_wide_timing.log; 60 s of the headline grid, kernel ms):
+    //   n_lp      one lane   K = 4    K = 8    K = 16
+    //    1 024     0.372     0.118    0.087    0.093
+    //    4 096     0.378     0.138    0.129    0.177
+    //    8 192     0.385     0.166    0.187    0.315
+    //   16 384     0.388     0.231    0.344    0.579
+    //   32 768     0.403     0.422    0.610    1.059
     // Fewer lanes per LP = less redundant work in the serial arrival chain, more = shorter steps: K = 8 while the device has SIMDs
-    // to spare, K = 4 up to the size at which a lane per LP fills the machine.
+    // to spare, K = 4 up to a quarter of the size at which a lane per LP fills the machine.
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->cfg.device) != hipSuccess) return 0;
     const long long lanes = (long long)prop.multiProcessorCount * 4 * 64;        // one wavefront per SIMD
     const long long n = h->cfg.n_lp;
     if (n * 16 <= lanes) return 8;              // <= 4 096 LPs on 256 CUs
-    if (n * 2 <= lanes) return 4;               // <= 32 768 LPs
+    if (n * 4 <= lanes) return 4;               // <= 16 384 LPs
     return 0;
 }
 template <int K>
@@ -426,6 +431,10 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     }
     h->uni_grid = h->uni_stations;
     for (int i = 0; i < n && h->uni_grid; ++i) if ((st->egress ? st->egress[i] : HS_EGRESS_SINK) != HS_EGRESS_SINK) h->uni_grid = false;
+    // (the uniform-grid kernels keep times as exact binary64 integers: whole ns in [0, 2^51), hs_device.hpp ns_from_seconds_d)
+    if (h->cfg.start_ns < 0 || h->cfg.horizon_ns >= (1ll << 51)) h->uni_grid = false;
+    for (int i = 0; i < n && h->uni_grid; ++i)      // (one draw is at most 36.8 means / inter-arrival times: everything stays below 2^52 ns)
+        if (!((st->svc_mean_s ? st->svc_mean_s[i] : 0.01) < 1e4) || !((st->src_rate ? st->src_rate[i] : 1.0) > 1e-3)) h->uni_grid = false;
     if (h->any_xsrc) h->any_profile = true;                         // such LPs run on the general-path instantiation
     for (int i = 0; i < n; ++i) {
         const int sk = st->src_kind ? st->src_kind[i] : HS_SRC_POISSON;

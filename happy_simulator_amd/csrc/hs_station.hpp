@@ -336,6 +336,7 @@ struct Station {
     //                                         (distributions/exponential.py:43, server/server.py:246-247)
     __device__ __forceinline__ double svc_value(double u) const {
         const double sample = div_lambda.div(exp1_from_uniform(u));
+        if constexpr (UNI) return seconds_from_ns_d(ns_from_seconds_d(sample));   // (times below 2^51 ns: hs_engine uni_grid)
         return seconds_from_ns(ns_from_seconds(sample));      // Duration.from_seconds(sample).to_seconds()
     }
     // Append `blocks` Philox blocks (two draws each) to the ring; a ring that ends on an odd draw index
@@ -864,6 +865,7 @@ struct Station {
         uint32_t n_tick, n_notify, n_poll, n_start, n_dep;
         bool pend, blocked, bail, done;
         int64_t crtA0;              // creation time of the tick that was pending when the window began (lineage, req_finish)
+        double arr_d;               // UNI: ArrivalTimeProvider.current_time as a binary64 (whole ns below 2^52: exact)
     };
     __device__ __forceinline__ bool req_eligible() const {
         return C == 1 && !force_general && qn == 0 && conc == 1 && qcap < 0 && stop_ns < 0 && svc_kind != 2 &&
@@ -880,7 +882,7 @@ struct Station {
         c.lt = (p && d > c.lt) ? d : c.lt;
     }
     __device__ __forceinline__ void req_begin(ReqCursor &c, int64_t T) {
-        c.T = T; c.nb = buf; c.lt = last_time; c.crtA0 = crtA;
+        c.T = T; c.nb = buf; c.lt = last_time; c.crtA0 = crtA; c.arr_d = (double)arr_time;
         c.n_tick = c.n_notify = c.n_poll = c.n_start = c.n_dep = 0;
         c.blocked = c.bail = c.done = false;
         const bool busy = active > 0;
@@ -898,7 +900,8 @@ struct Station {
         const bool fin = !bk && !arr;
         // arrival part at a_k = A
         const double inc = HSG(src_kind == 1, true) ? ra.peek() : inc_const;
-        const int64_t a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc));
+        const double a2d = UNI ? ns_from_seconds_d(__dadd_rn(seconds_from_ns_d(c.arr_d), inc)) : 0.0;
+        const int64_t a2 = UNI ? i64_from_whole_d(a2d) : ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc));
         const bool tie_a = arr && (A == c.Sprev || A == c.Dprev || a2 <= A);
         const bool notify = arr && c.Sprev < A;
         const bool idle = arr && c.Dprev < A;
@@ -906,7 +909,7 @@ struct Station {
         const int64_t Sk = bk ? c.Dprev : (A > c.Dprev ? A : c.Dprev);
         const bool st = (bk || arr) && Sk <= T;
         const double s_new = HSG(svc_kind == 0, true) ? rs.peek() : svc_const_s;
-        const int64_t dur = HSG(svc_kind == 0, true) ? ns_from_seconds(s_new) : svc_const_ns;
+        const int64_t dur = UNI ? i64_from_whole_d(ns_from_seconds_d(s_new)) : (HSG(svc_kind == 0, true) ? ns_from_seconds(s_new) : svc_const_ns);
         const int64_t Dk = Sk + dur;
         const bool dp = st && Dk <= T;                   // departure part at D_k
         const bool bail = act && (tie_a || (st && dur == 0));
@@ -925,6 +928,7 @@ struct Station {
         c.lt = (arr_g && A > c.lt) ? A : c.lt;
         crtA = arr_g ? A : crtA;
         arr_time = arr_g ? a2 : arr_time;
+        if constexpr (UNI) c.arr_d = arr_g ? a2d : c.arr_d;
         const bool pop_a = arr_g && HSG(src_kind == 1, true);
         ra.advance_if(pop_a);
         arr_k += pop_a ? 1u : 0u;
