@@ -132,11 +132,41 @@ class SpikeProfile:
         return max(self.baseline_rate, self.spike_rate)
 
 
+class _Stat:
+    """A result counter of an entity: its own value, or -- after a run on n plain chains (lowering.write_back_plain) -- row
+    `_bound[1]` of the run's per-LP result arrays `_bound[0]`.  Binding an object is ONE attribute store instead of one per
+    counter (196 608 objects at the headline size); assigning a value un-binds the object (the general write-back sets them all)."""
+
+    def __init__(self, key, cast=int, default=0):
+        self.key, self.cast, self.default = key, cast, default
+
+    def __set_name__(self, owner, name):
+        self.own = "_own" + name
+
+    def __get__(self, obj, owner=None):
+        if obj is None:
+            return self
+        b = obj._bound
+        if b is None:
+            return obj.__dict__.get(self.own, self.default)
+        key = self.key
+        return self.cast(b[0][key][b[1]]) if isinstance(key, str) else key(b[0], b[1])
+
+    def __set__(self, obj, value):
+        obj.__dict__[self.own] = value
+        if obj._bound is not None:
+            obj._bound = None
+
+
 class SimpleEventProvider:
+    _bound = None
+    _generated = _Stat(lambda st, i: int(st["accepted"][i] + st["dropped"][i]))     # Requests handed out
+
     def __init__(self, target: Entity, event_type: str = "Request", stop_after: Instant | None = None,
                  context_fn=None):
         if context_fn is not None:
             raise NotImplementedError("context_fn is arbitrary Python and is not lowered to the engine")
+        self._bound = None                  # (set first: _Stat's setter reads it; the same keys in the same order keep the instance dicts shared)
         self._target = target
         self._event_type = event_type
         self._stop_after = stop_after
@@ -163,8 +193,12 @@ class PoissonArrivalTimeProvider(_ArrivalProvider):
 
 
 class Source(Entity):
+    _bound = None
+    _generated_count = _Stat("generated")
+
     def __init__(self, name: str, event_provider: SimpleEventProvider, arrival_time_provider: _ArrivalProvider):
         super().__init__(name)
+        self._bound = None
         self._event_provider = event_provider
         self._time_provider = arrival_time_provider
         self._generated_count = 0
@@ -234,14 +268,25 @@ class ServerStats:
 
 class _QueueView:
     """What users read off `server.queue`: acceptance / drop counters and depth."""
+    _bound = None
+    stats_accepted = _Stat("accepted")
+    stats_dropped = _Stat("dropped")
+    depth = _Stat("queue_depth")
 
     def __init__(self):
+        self._bound = None
         self.stats_accepted = 0
         self.stats_dropped = 0
         self.depth = 0
 
 
 class Server(Entity):
+    _bound = None
+    _requests_completed = _Stat("completed")
+    _requests_rejected = _Stat("rejected")
+    _total_service_time = _Stat("total_service_s", float, 0.0)
+    _active = _Stat("active")
+
     def __init__(self, name: str, concurrency: int = 1, service_time: LatencyDistribution | None = None,
                  queue_policy: FIFOQueue | None = None, queue_capacity: int | None = None,
                  downstream: Entity | None = None):
@@ -254,6 +299,7 @@ class Server(Entity):
             queue_policy = FIFOQueue(capacity=queue_capacity if queue_capacity is not None else float("inf"))
         elif not isinstance(queue_policy, FIFOQueue):
             raise NotImplementedError("only FIFOQueue is lowered to the engine")
+        self._bound = None
         self._policy = queue_policy
         self._concurrency = concurrency
         self._service_time = service_time or ConstantLatency(0.01)
@@ -343,14 +389,42 @@ class _RecordSink(Entity):
     """Shared result holder: the engine hands back (completion ns, created_at ns) arrays; the Python lists the
     reference exposes are materialised lazily (31 M-element lists are the user's choice, not ours)."""
 
+    _EMPTY = np.zeros(0, np.int64)
+
     def __init__(self, name: str):
         super().__init__(name)
-        self._t_ns = np.zeros(0, np.int64)
-        self._created_ns = np.zeros(0, np.int64)
+        self._rec_t = self._EMPTY
+        self._rec_cr = self._EMPTY
+        self._lazy = None                   # (LazyRecords, station): the run's records are still on the device (lowering.py)
+        self._device = 0
 
     def _set_records(self, t_ns: np.ndarray, created_ns: np.ndarray):
-        self._t_ns = t_ns
-        self._created_ns = created_ns
+        self._rec_t = t_ns
+        self._rec_cr = created_ns
+        self._lazy = None
+
+    def _bind_lazy(self, records, station: int, device: int = 0):
+        self._lazy = (records, station)
+        self._device = device
+
+    def _materialise(self):
+        if self._lazy is not None:
+            records, i = self._lazy
+            self._rec_t, self._rec_cr = records.records(i)
+            self._lazy = None
+
+    @property
+    def _t_ns(self) -> np.ndarray:
+        self._materialise()
+        return self._rec_t
+
+    @property
+    def _created_ns(self) -> np.ndarray:
+        self._materialise()
+        return self._rec_cr
+
+    def _n_records(self) -> int:
+        return self._lazy[0].count(self._lazy[1]) if self._lazy is not None else int(len(self._rec_t))
 
     @property
     def completion_ns(self) -> np.ndarray:
@@ -368,7 +442,7 @@ class Sink(_RecordSink):
 
     @property
     def events_received(self) -> int:
-        return int(len(self._t_ns))
+        return self._n_records()
 
     @property
     def completion_times(self) -> list[Instant]:
@@ -418,7 +492,7 @@ class Counter(_RecordSink):
 
     @property
     def total(self) -> int:
-        return int(len(self._t_ns))
+        return self._n_records()
 
     @property
     def by_type(self) -> dict:
@@ -431,7 +505,7 @@ class LatencyTracker(_RecordSink):
 
     @property
     def count(self) -> int:
-        return int(len(self._t_ns))
+        return self._n_records()
 
     def mean_latency(self) -> float:
         lat = self.latencies_array

@@ -45,16 +45,115 @@ class Station:
         self.link_ids = ()          # their indices in LoweredGraph.links
 
 
-@dataclass
+class PlainChains:
+    """The commonest graph -- n independent `Source -> Server -> [Sink]` chains, every Source a constant-rate one with a Server of
+    its own (BASELINE configs[1], the headline grid) -- lowered WITHOUT one Python object per station: the per-object walk of
+    lower() and write_back() was 3 200 x the device run at 65 536 chains.  Holds the entities in station order
+    and the engine's struct-of-arrays, both built with list comprehensions over the homogeneous lists."""
+
+    def __init__(self, sources, servers, sinks, source_station, arrays):
+        self.sources = sources                  # station order
+        self.servers = servers
+        self.sinks = sinks                      # the Server's collector or None
+        self.source_station = source_station    # int32[len(sources)]: the station of every Source in `sources=[...]` order
+        self.arrays = arrays
+
+    def stations(self) -> list:
+        out = []
+        for src, sv, sk in zip(self.sources, self.servers, self.sinks):
+            st = Station(source=src, server=sv, sink=sk)
+            out.append(st)
+        return out
+
+
+def _plain_chains(sources, entities):
+    """PlainChains when `sources` / `entities` are exactly that shape, else None (lower() then walks the graph).  Every check is
+    one C-level pass (map / attrgetter / set) over the homogeneous lists: ~50 ms for 65 536 chains."""
+    from operator import attrgetter as ag
+
+    n = len(sources)
+    if n < 64 or set(map(type, sources)) != {Source}:
+        return None
+    servers = list(map(ag("_event_provider._target"), sources))
+    server_ids = set(map(id, servers))
+    if set(map(type, servers)) != {Server} or len(server_ids) != n:
+        return None
+    ent_types = set(map(type, entities))
+    if not ent_types <= {Server, Sink, Counter, LatencyTracker}:
+        return None
+    ent_servers = [e for e in entities if type(e) is Server]
+    if len(ent_servers) != n or set(map(id, ent_servers)) != server_ids:
+        return None
+    downs = list(map(ag("_downstream"), servers))
+    if not set(map(type, downs)) <= {Sink, Counter, LatencyTracker, type(None)}:
+        return None
+    real = [id(d) for d in downs if d is not None]
+    if len(set(real)) != len(real):                     # a collector shared by several Servers: the general path merges its records
+        return None
+    svcs = list(map(ag("_service_time"), servers))
+    svc_types = set(map(type, svcs))
+    if not svc_types <= {ExponentialLatency, ConstantLatency}:
+        return None
+    conc = np.fromiter(map(ag("_concurrency"), servers), np.int32, n)
+    profiles = list(map(ag("_time_provider.profile"), sources))
+    if set(map(type, profiles)) != {ConstantRateProfile}:
+        return None
+    rate = np.fromiter(map(ag("rate"), profiles), np.float64, n)
+    if conc.max() > 32 or not (rate > 0).all():
+        return None
+    # station order = the Servers' order in `entities` (the entity stream numbering, see lower())
+    pos = dict(zip(map(id, ent_servers), range(n)))
+    station_of_source = np.fromiter(map(pos.__getitem__, map(id, servers)), np.int32, n)
+    in_order = bool((station_of_source == np.arange(n, dtype=np.int32)).all())
+    order = None if in_order else np.argsort(station_of_source, kind="stable")
+
+    def perm(lst):
+        return lst if in_order else [lst[k] for k in order]
+
+    a = StationArrays.uniform(n)
+    kinds = list(map(ag("_time_provider.kind"), sources))
+    kind = np.fromiter((N.SRC_POISSON if k == "poisson" else N.SRC_CONSTANT for k in kinds), np.uint8, n)
+    stops = list(map(ag("_event_provider._stop_after"), sources))
+    stop = (np.full(n, -1, np.int64) if set(stops) == {None} else
+            np.fromiter((-1 if x is None else x.nanoseconds for x in stops), np.int64, n))
+    svk = (np.full(n, N.LAT_EXPONENTIAL if svc_types == {ExponentialLatency} else N.LAT_CONSTANT, np.uint8) if len(svc_types) == 1 else
+           np.fromiter((N.LAT_EXPONENTIAL if type(x) is ExponentialLatency else N.LAT_CONSTANT for x in svcs), np.uint8, n))
+    svm = np.fromiter(map(ag("mean"), svcs), np.float64, n)
+    inf = float("inf")
+    caps = list(map(ag("_policy.capacity"), servers))
+    qcap = np.full(n, -1, np.int64) if set(caps) == {inf} else np.fromiter((-1 if c == inf else int(c) for c in caps), np.int64, n)
+    egr = np.fromiter((N.EGRESS_NONE if d is None else N.EGRESS_SINK for d in downs), np.uint8, n)
+    take = (lambda x: x) if in_order else (lambda x: x[order])
+    a.src_kind[:] = take(kind); a.src_rate[:] = take(rate); a.src_stop_after_ns[:] = take(stop)
+    a.concurrency[:] = take(conc); a.svc_kind[:] = take(svk); a.svc_mean_s[:] = take(svm); a.queue_cap[:] = take(qcap)
+    a.egress[:] = take(egr)
+    return PlainChains(perm(list(sources)), perm(servers), perm(downs), station_of_source, a)
+
+
 class LoweredGraph:
-    stations: list[Station] = field(default_factory=list)
-    links: list = field(default_factory=list)        # (NetworkLink, source station, destination station)
+    """stations: one Station per LP; links: (NetworkLink, source station, destination station).  `plain`: the graph is n plain
+    chains (PlainChains) -- the Station objects are then only built if somebody asks for them (probes, schedule(), partitions)."""
+
+    def __init__(self, plain: "PlainChains | None" = None):
+        self._stations: list[Station] | None = None if plain is not None else []
+        self.links: list = []
+        self.plain = plain
+
+    @property
+    def stations(self) -> list[Station]:
+        if self._stations is None:
+            self._stations = self.plain.stations()
+        return self._stations
 
     @property
     def is_network(self) -> bool:
+        if self.plain is not None and self._stations is None:
+            return False
         return bool(self.links) or any(st.router is not None for st in self.stations)
 
     def arrays(self) -> StationArrays:
+        if self.plain is not None and self._stations is None:
+            return self.plain.arrays
         n = len(self.stations)
         a = StationArrays.uniform(n)
         for i, st in enumerate(self.stations):
@@ -227,6 +326,9 @@ def write_back_probes(g: LoweredGraph, eng) -> None:
 def lower(sources: list, entities: list) -> LoweredGraph:
     sources = list(sources or [])
     entities = list(entities or [])
+    plain = _plain_chains(sources, entities)
+    if plain is not None:
+        return LoweredGraph(plain)
     g = LoweredGraph()
     station_of_server: dict[int, int] = {}
     used_sinks: dict[int, int] = {}
@@ -371,6 +473,58 @@ def lower(sources: list, entities: list) -> LoweredGraph:
             st.link_ids = (*st.link_ids, len(g.links))
             g.links.append((lk, i, dst))
     return g
+
+
+class LazyRecords:
+    """The Sink records of a run, left on the device until a Sink's lists are first read (0.5 GB at the headline size: the download
+    and the per-Sink slicing were most of Simulation.run()'s wall time).  Owns the engine until then."""
+
+    def __init__(self, eng, counts: np.ndarray):
+        self._eng = eng
+        self.off = np.zeros(len(counts) + 1, np.int64)
+        np.cumsum(counts, out=self.off[1:])
+        self._t = self._cr = None
+
+    def fetch(self):
+        if self._t is None:
+            _, self._t, self._cr = self._eng.read_sinks()
+            self._eng.close()
+            self._eng = None
+        return self._t, self._cr
+
+    def count(self, i: int) -> int:
+        return int(self.off[i + 1] - self.off[i])
+
+    def records(self, i: int):
+        t, cr = self.fetch()
+        a, b = int(self.off[i]), int(self.off[i + 1])
+        return t[a:b], cr[a:b]
+
+    def close(self):
+        if self._eng is not None:
+            self._eng.close()
+            self._eng = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def write_back_plain(pc: PlainChains, stats: dict, records: LazyRecords, device: int = 0) -> None:
+    """write_back() for PlainChains: every object is BOUND to its row of the run's result arrays (entities._Stat: one attribute
+    store per object instead of one per counter) and the Sinks to the lazily downloaded records -- the attributes users read
+    (`stats_accepted`, `stats.requests_completed`, `generated_count`, `events_received`, `latencies_s` ...) are unchanged."""
+    for i, (src, sv, sk) in enumerate(zip(pc.sources, pc.servers, pc.sinks)):
+        b = (stats, i)
+        src._bound = b
+        src._event_provider._bound = b
+        sv._bound = b
+        sv._queue._bound = b
+        if sk is not None:
+            sk._lazy = (records, i)
+            sk._device = device
 
 
 def write_back(g: LoweredGraph, stats: dict, counts: np.ndarray, t_ns: np.ndarray, created_ns: np.ndarray,
