@@ -657,7 +657,8 @@ struct NetStation {
         ++fl_q;
         if (HSU(fl_remote, false)) { outbox_append(fl_link, fl_dst, t_arr, t_send, created, lin); return; }
         const size_t slot = (size_t)fl_link * ns->aq_cap + (size_t)(((unsigned long long)fl_q - 1) & (unsigned long long)(ns->aq_cap - 1));
-        ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t_send); ag_store(&ns->aq_cr[slot], created); ag_store(&ns->aq_lin[slot], lin);
+        ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t_send); ag_store(&ns->aq_cr[slot], created);
+        ag_store(&ns->aq_lin[slot], lin);
         sent_async = true;
     }
     // steps from a Server's continuation to the NetworkLink's continuation it causes: Request@Link, the link's continuation
@@ -1208,18 +1209,21 @@ struct NetStation {
         arr_time = tick ? a2 : arr_time;
         A = tick ? a2 : A;
         seqA = tick ? seq : seqA;
-        // lineage (hs_station.hpp step_c1): the group's one root is the tick, the message (created at its send time) or the departure
-        const int64_t root_c = tick ? crtA : msg ? bg_ts(mi) : crtD[0];
+        // lineage (hs_station.hpp step_c1): the group's one root is the tick, the message (created at its send time, read from the bag
+        // together with its created_at below -- as a read of its own up here it sat on the trip's critical path: +0.36 ms on the
+        // headline ring) or the departure
+        const int64_t crtA_root = crtA, crtD_root = crtD[0];
         rcA = tick ? crtA : rcA;
         dpA = tick ? 1 : dpA;
         crtA = tick ? t : crtA;
         seq += tick ? 1u : 0u;
         if (tick && poisson) { ha = (ha + 1) & (kNRing - 1); --na; }
         // ---- NetworkLink continuation at the egress side: the message leaves the bag
-        int64_t created_in = t;
+        int64_t created_in = t, msg_ts = 0;
         if (msg) {
             ev[9]++;
             created_in = bg_cr(mi);
+            msg_ts = bg_ts(mi);
             if (UNI || bg_link(mi) == fi_link) fi_packets++; else ns->link_packets[bg_link(mi)]++;
             bag_remove(mi);
         }
@@ -1267,7 +1271,7 @@ struct NetStation {
                     hj = (hj + 1) & (kNRing - 1); --nj;
                 }
                 if (!(delay > 0.0)) delay = 0.0;
-                fl_append(t + ns_from_seconds(delay), t, created_out, lin_pack(link_steps(), root_c, t));   // (the departure is the root)
+                fl_append(t + ns_from_seconds(delay), t, created_out, lin_pack(link_steps(), crtD_root, t));   // (the departure is the root)
             }
         }
         if (dep && early_upto < completed) { early_upto = completed; D_pre = t; }   // (left the ordinary way)
@@ -1285,7 +1289,7 @@ struct NetStation {
             if (HSU(presend, true) && k >= early_upto) (void)pre_send(k, (int)(k - completed), t + dur, created, t);   // pre-send at the start
             svc_s[0] = s_new; crt[0] = created;
             D[0] = t + dur; seqD[0] = seq++; crtD[0] = t;
-            dpD[0] = dep ? 4 : 6; rcD[0] = root_c;
+            dpD[0] = dep ? 4 : 6; rcD[0] = dep ? crtD_root : tick ? crtA_root : msg_ts;
             if (svc_exp) { hs_ = (hs_ + 1) & (kNRing - 1); --nsv; }
         }
         last_time = (tick || dep || msg) ? t : last_time;            // (the general path sets it itself)
