@@ -40,6 +40,7 @@ struct hs_engine {
     bool any_xsrc = false;     // some LP has more than one Source (general path + prologue)
     bool uni_stations = false; // every LP: Poisson Source, exponential single-worker Server, unbounded queue, no stop_after
     bool uni_grid = false;     // ... and a Sink behind every Server: hs_station_run<1, false, true, true>
+    bool f64_times = false;    // every time of a run is a whole number of ns in [0, 2^52): the UNI kernels' exact binary64 time algebra
     bool net_uni = false;      // ... and every router has exactly one NetworkLink (exponential jitter, no loss): hs_net_async<1, false, true>
     bool any_timevarying = false, any_sched = false;   // (subsets of any_profile: what a network does not lower)
     bool any_profile = false;  // some source has a time-varying rate profile (or a probe: same kernel instantiation)
@@ -431,10 +432,11 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     }
     h->uni_grid = h->uni_stations;
     for (int i = 0; i < n && h->uni_grid; ++i) if ((st->egress ? st->egress[i] : HS_EGRESS_SINK) != HS_EGRESS_SINK) h->uni_grid = false;
-    // (the uniform-grid kernels keep times as exact binary64 integers: whole ns in [0, 2^51), hs_device.hpp ns_from_seconds_d)
-    if (h->cfg.start_ns < 0 || h->cfg.horizon_ns >= (1ll << 51)) h->uni_grid = false;
-    for (int i = 0; i < n && h->uni_grid; ++i)      // (one draw is at most 36.8 means / inter-arrival times: everything stays below 2^52 ns)
-        if (!((st->svc_mean_s ? st->svc_mean_s[i] : 0.01) < 1e4) || !((st->src_rate ? st->src_rate[i] : 1.0) > 1e-3)) h->uni_grid = false;
+    // (the uniform-kind kernels keep times as exact binary64 integers: whole ns in [0, 2^51), hs_device.hpp ns_from_seconds_d)
+    h->f64_times = h->cfg.start_ns >= 0 && h->cfg.horizon_ns < (1ll << 51);
+    for (int i = 0; i < n && h->f64_times; ++i)     // (one draw is at most 36.8 means / inter-arrival times: everything stays below 2^52 ns)
+        if (!((st->svc_mean_s ? st->svc_mean_s[i] : 0.01) < 1e4) || !((st->src_rate ? st->src_rate[i] : 1.0) > 1e-3)) h->f64_times = false;
+    if (!h->f64_times) h->uni_grid = false;
     if (h->any_xsrc) h->any_profile = true;                         // such LPs run on the general-path instantiation
     for (int i = 0; i < n; ++i) {
         const int sk = st->src_kind ? st->src_kind[i] : HS_SRC_POISSON;
@@ -1032,13 +1034,14 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
         h->async_ok = !global && fits;
         h->net_pf = h->any_probe || h->any_timevarying || h->any_sched || h->any_xsrc;
         // the network's entity kinds are uniform: the specialised instantiation (hs_netstation.hpp HSU)
-        h->net_uni = h->uni_stations && !global && !h->net_pf && h->C == 1;
+        h->net_uni = h->uni_stations && h->f64_times && !global && !h->net_pf && h->C == 1;
         for (int i = 0; i < n && h->net_uni; ++i) {
             if (net->egress_kind[i] != HS_EGRESS_ROUTER) { h->net_uni = false; break; }
             int n_link = 0, l1 = -1;
             const int32_t tg[4] = {rt0[(size_t)i], rt1[(size_t)i], rt2[(size_t)i], rt3[(size_t)i]};
             for (int q = 0; q < (int)rtk[(size_t)i]; ++q) if (tg[q] >= 0) { ++n_link; l1 = tg[q]; }
             if (n_link != 1 || jk[(size_t)l1] != HS_LAT_EXPONENTIAL || lloss[(size_t)l1] != 0.0) h->net_uni = false;
+            if (h->net_uni && !(net->link_lat_min_s[l1] < 1e4 && (net->link_jitter_mean_s ? net->link_jitter_mean_s[l1] : 0.0) < 1e4)) h->net_uni = false;
             if (h->net_uni && in_deg_h[(size_t)i] != 1) h->net_uni = false;        // exactly one incoming link per station
         }
     }

@@ -812,7 +812,7 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF, UNI> &S, const 
     S.svc_const_ns = ns_from_seconds(S.svc_const_s);
     S.stop_ns = P.src_stop[lp]; S.qcap = P.qcap[lp];
     S.seed = P.seed[lp]; S.route_base = NP.route_base[lp];
-    S.A = X.A[lp]; S.seqA = X.seqA[lp]; S.crtA = X.crtA[lp]; S.arr_time = X.arr_time[lp];
+    S.A = X.A[lp]; S.seqA = X.seqA[lp]; S.crtA = X.crtA[lp]; S.arr_time = X.arr_time[lp]; S.arr_d = (double)S.arr_time;
     S.buf = X.buf[lp]; S.active = X.active[lp]; S.seq = X.seq[lp];
     S.generated = X.generated[lp]; S.accepted = X.accepted[lp]; S.dropped = X.dropped[lp];
     S.completed = X.completed[lp]; S.rejected = X.rejected[lp]; S.started = X.started[lp];

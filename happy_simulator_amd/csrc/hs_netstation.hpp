@@ -210,6 +210,7 @@ struct NetStation {
     uint64_t seed, route_base;
     // state
     int64_t A, crtA, arr_time, buf, generated, accepted, dropped, completed, rejected, started, received, routed;
+    double arr_d;                 // UNI: arr_time as a binary64 (exact: whole ns below 2^52)
     uint32_t seqA, seq;
     int32_t active;
     int64_t D[C], crtD[C], crt[C];
@@ -405,7 +406,13 @@ struct NetStation {
     // The rings hold the values as the handlers use them: the arrival increment E / rate, the service time
     // to_seconds(from_seconds(E / lambda)), the jitter to_seconds(from_seconds(E / lambda_link)) -- the divisions and ns
     // truncations run here, for 64 lanes at once, not in the divergent group loop.
-    __device__ __forceinline__ double svc_value(double e) const { return seconds_from_ns(ns_from_seconds(__ddiv_rn(e, svc_lambda))); }
+    // UNI (the host checks it, hs_engine_set_network): every time is a whole number of ns in [0, 2^51), exact in binary64 -- the time
+    // algebra stays in fp64 registers (hs_device.hpp ns_from_seconds_d: v_trunc_f64 instead of the f64 <-> i64 conversion sequences)
+    __device__ __forceinline__ int64_t ns_i(double x) const { return UNI ? i64_from_whole_d(ns_from_seconds_d(x)) : ns_from_seconds(x); }
+    __device__ __forceinline__ double sec_rt(double x) const {           // Duration.from_seconds(x).to_seconds()
+        return UNI ? seconds_from_ns_d(ns_from_seconds_d(x)) : seconds_from_ns(ns_from_seconds(x));
+    }
+    __device__ __forceinline__ double svc_value(double e) const { return sec_rt(__ddiv_rn(e, svc_lambda)); }
     __device__ __forceinline__ void refill_a(int m) {
         for (int i = 0; i < m; ++i) {
             const double e = exp1_from_uniform(arr.next_uniform());
@@ -420,7 +427,7 @@ struct NetStation {
     __device__ __forceinline__ void refill_j(int m) {
         for (int i = 0; i < m; ++i) {
             const double sample = __ddiv_rn(exp1_from_uniform(jit.next_uniform()), fl_lam);
-            fl.ring_j[(hj + nj) & (kNRing - 1)][tid] = seconds_from_ns(ns_from_seconds(sample)); ++nj;
+            fl.ring_j[(hj + nj) & (kNRing - 1)][tid] = sec_rt(sample); ++nj;
         }
     }
     // RandomRouter (components/random_router.py:32-45, Philox-plugged): targets[int(u * len(targets))].  Pre-drawn decisions are
@@ -483,6 +490,7 @@ struct NetStation {
         const double inc = HSU(src_kind == 1, true) ? arr_inc() : __ddiv_rn(1.0, rate);
         const double t_next = __dadd_rn(seconds_from_ns(arr_time), inc);
         arr_time = ns_from_seconds(t_next);
+        arr_d = (double)arr_time;
         return arr_time;
     }
     __device__ __forceinline__ void sample_service(double &s, int64_t &dur_ns) {
@@ -676,7 +684,7 @@ struct NetStation {
             double delay = fl_delay0;
             if (HSU(fl_jit == 0, true)) { delay = __dadd_rn(delay, fl.ring_j[hj][tid]); hj = (hj + 1) & (kNRing - 1); --nj; }
             if (!(delay > 0.0)) delay = 0.0;
-            fl_append(D + ns_from_seconds(delay), D, created, lin_pack(link_steps(), S_start, D));   // (the continuation at D: a root, created at S_start)
+            fl_append(D + ns_i(delay), D, created, lin_pack(link_steps(), S_start, D));   // (the continuation at D: a root, created at S_start)
         }
         early_upto = ordinal + 1;
         D_pre = D;
@@ -700,7 +708,7 @@ struct NetStation {
             hj = (hj + 1) & (kNRing - 1); --nj;
         }
         if (!(delay > 0.0)) delay = 0.0;
-        fl_append(t + ns_from_seconds(delay), t, created, lin_pack(dp_next(link_steps()), cr, t));
+        fl_append(t + ns_i(delay), t, created, lin_pack(dp_next(link_steps()), cr, t));
     }
     __device__ __forceinline__ void send_link(int32_t l, int64_t t, int64_t created) {
         if constexpr (FAST) { if (l == fl_link) { send_link_fast(t, created); return; } }
@@ -903,7 +911,7 @@ struct NetStation {
             double sv;
             if (FAST && i < nsv) sv = fl.ring_s[(hs_ + i) & (kNRing - 1)][tid];
             else sv = svc_value(exp1_from_uniform(c.next_uniform()));
-            const int64_t d = ns_from_seconds(sv);
+            const int64_t d = ns_i(sv);
             m = d < m ? d : m;
         }
         return m;
@@ -927,7 +935,7 @@ struct NetStation {
     __device__ __forceinline__ int64_t sum_services(int m) const {   // of the next m requests to start, m <= services_known()
         if (HSU(svc_kind != 0, false)) return (int64_t)m * svc_const_ns;
         int64_t sum = 0;
-        for (int i = 0; i < m; ++i) sum += ns_from_seconds(fl.ring_s[(hs_ + i) & (kNRing - 1)][tid]);
+        for (int i = 0; i < m; ++i) sum += ns_i(fl.ring_s[(hs_ + i) & (kNRing - 1)][tid]);
         return sum;
     }
     __device__ __forceinline__ int services_known() const { return HSU(svc_kind != 0, false) ? kNRing : nsv; }
@@ -976,7 +984,7 @@ struct NetStation {
                 const int off = (int)(u - started);
                 int64_t sd = 0;
                 if (HSU(svc_kind != 0, false)) sd = (int64_t)(q + 1) * svc_const_ns;
-                else for (int i = 0; i <= q && off + i < known; ++i) sd += ns_from_seconds(fl.ring_s[(hs_ + off + i) & (kNRing - 1)][tid]);
+                else for (int i = 0; i <= q && off + i < known; ++i) sd += ns_i(fl.ring_s[(hs_ + off + i) & (kNRing - 1)][tid]);
                 if (u < accepted) { mA = sat(sat(D_pre, sd), lat); if (kind) *kind = 0; return; }
                 const int64_t arr_next = next_admission();
                 const int64_t own = arr_next > D_pre ? arr_next : D_pre;
@@ -1168,9 +1176,9 @@ struct NetStation {
         // speculative draws: peeks, nothing consumed yet
         const bool poisson = HSU(src_kind == 1, true), svc_exp = HSU(svc_kind == 0, true);
         const double inc = poisson ? fl.ring_a[ha][tid] : inc_const;
-        const int64_t a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc));
+        const int64_t a2 = ns_i(__dadd_rn(UNI ? seconds_from_ns_d(arr_d) : seconds_from_ns(arr_time), inc));
         const double s_new = svc_exp ? fl.ring_s[hs_][tid] : svc_const_s;
-        const int64_t dur = svc_exp ? ns_from_seconds(s_new) : svc_const_ns;
+        const int64_t dur = svc_exp ? ns_i(s_new) : svc_const_ns;
         const bool router = HSU(egress == EG_ROUTER, true);
         const int ridx = (int)(rbits & 3u);
         const int32_t target = HSU(egress == EG_SINK, false) ? -1 : HSU(egress == EG_LINK, false) ? link_of : router ? rt_target(ridx) : -2;
@@ -1207,6 +1215,7 @@ struct NetStation {
         // ---- Source.handle_event
         ev[0] += tick; generated += tick;
         arr_time = tick ? a2 : arr_time;
+        if constexpr (UNI) arr_d = tick ? (double)a2 : arr_d;
         A = tick ? a2 : A;
         seqA = tick ? seq : seqA;
         // lineage (hs_station.hpp step_c1): the group's one root is the tick, the message (created at its send time, read from the bag
@@ -1239,7 +1248,7 @@ struct NetStation {
             const int off = (int)(accepted - started);                 // requests that start before it
             if (!svc_exp || off < nsv) {
                 const double s_k = svc_exp ? fl.ring_s[(hs_ + off) & (kNRing - 1)][tid] : svc_const_s;
-                const int64_t dur_k = svc_exp ? ns_from_seconds(s_k) : svc_const_ns;
+                const int64_t dur_k = svc_exp ? ns_i(s_k) : svc_const_ns;
                 const int64_t s_at = t > D_pre ? t : D_pre;
                 if (dur_k > 0) (void)pre_send(accepted, (int)(accepted - completed), s_at + dur_k, created_in, s_at);
             }
@@ -1271,7 +1280,7 @@ struct NetStation {
                     hj = (hj + 1) & (kNRing - 1); --nj;
                 }
                 if (!(delay > 0.0)) delay = 0.0;
-                fl_append(t + ns_from_seconds(delay), t, created_out, lin_pack(link_steps(), crtD_root, t));   // (the departure is the root)
+                fl_append(t + ns_i(delay), t, created_out, lin_pack(link_steps(), crtD_root, t));   // (the departure is the root)
             }
         }
         if (dep && early_upto < completed) { early_upto = completed; D_pre = t; }   // (left the ordinary way)
