@@ -8,10 +8,9 @@ the kernel trace, and the commit + hash of csrc/ the profile was taken at (bench
 """
 import json
 import os
-import subprocess
 import sys
 
-from derive_roofline import HERE, csrc_sha16
+from derive_roofline import HERE, csrc_sha16, head_commit
 
 tag = sys.argv[1]
 runs = 0
@@ -42,8 +41,7 @@ for line in open(os.path.join(HERE, f"{tag}_trace.txt")):
             pass
 out = {
     "kernels": "radix_hist + radix_scan_* + radix_scatter (all passes of both sorts)", "tag": tag, "workload": "lb",
-    "commit": subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True,
-                             cwd=os.path.dirname(HERE)).stdout.strip(),
+    "commit": head_commit(),
     "csrc_sha16": csrc_sha16(), "pipeline_runs_profiled": runs,
     "FETCH_SIZE_KB_per_step": kb["FETCH_SIZE"] / runs, "WRITE_SIZE_KB_per_step": kb["WRITE_SIZE"] / runs,
     "fetch_correction": "x2 (gfx950: rocprofv3 reports half the bytes of coalesced streaming reads)",

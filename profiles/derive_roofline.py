@@ -6,7 +6,8 @@ profiles/<tag>_roofline_<workload>.json, the measured side of bench.py's `roofli
                          dominant kernel, per dispatch (separate --pmc passes)
   valu_busy_frac         SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES summed over the SEs' SIMDs ...) -- see below
   kernel_us_rocprof      average duration of that kernel under `rocprofv3 --kernel-trace --stats`
-  commit                 git HEAD the profile was taken at (bench.py prints traffic = null when the kernel sources changed since)
+  commit                 the commit the profiled tree was built from (head_commit(): env / profiles/HEAD_COMMIT / git);
+                         bench.py prints traffic = null when the kernel sources (`csrc_sha16`) changed since
 
 VALU issue fraction: SQ_ACTIVE_INST_VALU counts, per SIMD, the (quad-)cycles in which the VALU was executing; SQ_WAVE_CYCLES
 counts wave-resident (quad-)cycles summed over the waves.  With ONE wave per SIMD the ratio of the two is the fraction of the
@@ -30,6 +31,20 @@ def csrc_sha16():
     for f in sorted(os.listdir(d)):
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def head_commit():
+    """The commit the profiled tree was built from.  The GPU box has no .git (gpurun snapshots the work tree), so the commit
+    travels with the snapshot: HS_PROFILE_COMMIT, else profiles/HEAD_COMMIT (profiles/collect.sh's caller writes it with
+    `git rev-parse --short=12 HEAD > profiles/HEAD_COMMIT` before the gpurun call), else git here.  The identity bench.py
+    checks is `csrc_sha16`, the hash of the kernel sources themselves."""
+    c = os.environ.get("HS_PROFILE_COMMIT", "").strip()
+    f = os.path.join(HERE, "HEAD_COMMIT")
+    if not c and os.path.exists(f):
+        c = open(f).read().strip()
+    if not c:
+        c = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, cwd=HERE).stdout.strip()
+    return c or None
 
 
 def rows(path, kernel):
@@ -67,8 +82,7 @@ def main(tag, workload, kernel, waves_per_simd):
     sq = rows(os.path.join(HERE, f"{tag}_sq.txt"), kernel)
     avg_us, calls = kernel_time(os.path.join(HERE, f"{tag}_trace.txt"), kernel)
     out = {"kernel": kernel, "tag": tag, "workload": workload,
-           "commit": subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True,
-                                    cwd=HERE).stdout.strip(),
+           "commit": head_commit(),
            "kernel_us_rocprof": avg_us, "dispatches": calls, "csrc_sha16": csrc_sha16()}
     if "FETCH_SIZE" in f and "WRITE_SIZE" in w:
         out["FETCH_SIZE_KB_per_launch"] = f["FETCH_SIZE"][2]
