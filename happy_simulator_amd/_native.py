@@ -29,14 +29,14 @@ MODE_SINGLE, MODE_REPLICAS = 0, 1
 SRC_NONE, SRC_POISSON, SRC_CONSTANT = 0, 1, 2
 PROF_CONSTANT, PROF_LINEAR_RAMP, PROF_SPIKE = 0, 1, 2
 LAT_EXPONENTIAL, LAT_CONSTANT, LAT_NO_SERVER = 0, 1, 2
-EGRESS_NONE, EGRESS_SINK, EGRESS_LINK, EGRESS_ROUTER = 0, 1, 2, 3
+EGRESS_NONE, EGRESS_SINK, EGRESS_LINK, EGRESS_ROUTER, EGRESS_SERVER = 0, 1, 2, 3, 4
 EV_KINDS = 15
 EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuation", "sink", "link", "link_cont",
             "route", "lb", "lb_resp", "probe_tick", "probe")
 PROBE_METRICS = {"depth": 0, "active_requests": 1, "stats_accepted": 2, "stats_dropped": 3, "requests_completed": 4,
                  "_requests_completed": 4, "events_received": 5, "generated_count": 6}
 PROBE_NONE = 255
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class EngineUnavailable(RuntimeError):
@@ -70,6 +70,7 @@ class Stations(C.Structure):
         ("sched_rank", C.c_void_p),
         ("src_more_kind", C.c_void_p), ("src_more_rate", C.c_void_p), ("src_more_stop_after_ns", C.c_void_p),
         ("source_slot_order", C.c_void_p),
+        ("downstream_lp", C.c_void_p),
     ]
 
 

@@ -38,6 +38,7 @@ struct hs_engine {
     Candidate *cands = nullptr;
     bool is_net = false;
     bool any_xsrc = false;     // some LP has more than one Source (general path + prologue)
+    int n_pass = 0;            // tandem queues (Server -> Server): passes of the station kernel, 0 = none
     bool uni_stations = false; // every LP: Poisson Source, exponential single-worker Server, unbounded queue, no stop_after
     bool uni_grid = false;     // ... and a Sink behind every Server: hs_station_run<1, false, true, true>
     bool f64_times = false;    // every time of a run is a whole number of ns in [0, 2^52): the UNI kernels' exact binary64 time algebra
@@ -138,24 +139,29 @@ int upload(hs_engine *h, const T **dst, const T *src, size_t n, T dflt) {
 }
 
 template <int C>
-void launch_run(hs_engine *h, int64_t end_ns) {
+void launch_run(hs_engine *h, int64_t end_ns, int mode, int flags) {
+    if (h->n_pass > 0) {      // tandem queues: the general-path instantiation, one pass (hs_station.hpp `trk`)
+        hipLaunchKernelGGL((hs_station_run<C, true>), dim3(h->n_blocks), dim3(kBlock), 0, h->stream, h->P, h->X, h->L, h->tot,
+                           h->cands, h->cfg.n_lp, end_ns, mode, flags);
+        return;
+    }
     if constexpr (C == 1) {
-        if (!h->any_profile && !(h->flags & 512)) {     // producer / consumer wavefronts (debug flag 512: the one-role kernel)
-            if (h->uni_grid && (h->flags & (1 << 20)) == 0)   // uniform entity kinds: compile-time predicates (hs_station.hpp HSG)
+        if (!h->any_profile && !(flags & 512)) {     // producer / consumer wavefronts (debug flag 512: the one-role kernel)
+            if (h->uni_grid && (flags & (1 << 20)) == 0)   // uniform entity kinds: compile-time predicates (hs_station.hpp HSG)
                 hipLaunchKernelGGL((hs_station_run<1, false, true, true>), dim3(h->n_blocks), dim3(2 * kBlock), 0, h->stream, h->P,
-                                   h->X, h->L, h->tot, h->cands, h->cfg.n_lp, end_ns, h->cfg.mode, h->flags);
+                                   h->X, h->L, h->tot, h->cands, h->cfg.n_lp, end_ns, mode, flags);
             else
                 hipLaunchKernelGGL((hs_station_run<1, false, true>), dim3(h->n_blocks), dim3(2 * kBlock), 0, h->stream, h->P, h->X,
-                                   h->L, h->tot, h->cands, h->cfg.n_lp, end_ns, h->cfg.mode, h->flags);
+                                   h->L, h->tot, h->cands, h->cfg.n_lp, end_ns, mode, flags);
             return;
         }
     }
     if (h->any_profile)
         hipLaunchKernelGGL((hs_station_run<C, true>), dim3(h->n_blocks), dim3(kBlock), 0, h->stream, h->P, h->X, h->L, h->tot,
-                           h->cands, h->cfg.n_lp, end_ns, h->cfg.mode, h->flags);
+                           h->cands, h->cfg.n_lp, end_ns, mode, flags);
     else
         hipLaunchKernelGGL((hs_station_run<C, false>), dim3(h->n_blocks), dim3(kBlock), 0, h->stream, h->P, h->X, h->L, h->tot,
-                           h->cands, h->cfg.n_lp, end_ns, h->cfg.mode, h->flags);
+                           h->cands, h->cfg.n_lp, end_ns, mode, flags);
 }
 
 // K lanes per LP when the grid is uniform and leaves lanes idle (hs_kernels_wide.hpp); debug flag 1 << 22 keeps the one-lane kernel,
@@ -200,13 +206,20 @@ void launch_run_dispatch(hs_engine *h, int64_t end_ns) {
         case 16: launch_wide<16>(h, end_ns); return;
         default: break;
     }
-    switch (h->C) {
-        case 1: launch_run<1>(h, end_ns); break;
-        case 2: launch_run<2>(h, end_ns); break;
-        case 4: launch_run<4>(h, end_ns); break;
-        case 8: launch_run<8>(h, end_ns); break;
-        case 16: launch_run<16>(h, end_ns); break;
-        default: launch_run<32>(h, end_ns); break;     // (departure slots beyond 16 live in scratch: correct, not fast)
+    // Tandem queues: one launch per pass, upstream Servers first; the last one elects the event beyond end_ns among ALL LPs
+    // (an internal mode 2 = "no election" for the others).  Everything else: one launch.
+    const int passes = h->n_pass > 0 ? h->n_pass : 1;
+    for (int p = 0; p < passes; ++p) {
+        const int mode = (p == passes - 1) ? h->cfg.mode : 2;
+        const int flags = h->n_pass > 0 ? (h->flags | ((p + 1) << 28)) : h->flags;
+        switch (h->C) {
+            case 1: launch_run<1>(h, end_ns, mode, flags); break;
+            case 2: launch_run<2>(h, end_ns, mode, flags); break;
+            case 4: launch_run<4>(h, end_ns, mode, flags); break;
+            case 8: launch_run<8>(h, end_ns, mode, flags); break;
+            case 16: launch_run<16>(h, end_ns, mode, flags); break;
+            default: launch_run<32>(h, end_ns, mode, flags); break;     // (departure slots beyond 16 live in scratch: correct, not fast)
+        }
     }
 }
 
@@ -465,8 +478,37 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if (vk == HS_LAT_EXPONENTIAL && !(mean > 0.0))
             return fail(h, HS_E_INVALID, "LP %d: exponential service needs mean > 0", i);
         const int eg = st->egress ? st->egress[i] : HS_EGRESS_SINK;
-        if (eg != HS_EGRESS_NONE && eg != HS_EGRESS_SINK)
+        if (eg != HS_EGRESS_NONE && eg != HS_EGRESS_SINK && eg != HS_EGRESS_SERVER)
             return fail(h, HS_E_UNSUPPORTED, "LP %d: egress kind %d is not lowered", i, eg);
+    }
+    // Tandem queues: Server(downstream=<Server>) (components/server/server.py:271-272).  up[d] = the LP that forwards to LP d;
+    // an LP's pass = its distance from the head of its chain (hs_station.hpp `trk`).
+    std::vector<int32_t> tandem;
+    for (int i = 0; i < n; ++i) {
+        if ((st->egress ? st->egress[i] : HS_EGRESS_SINK) != HS_EGRESS_SERVER) continue;
+        if (tandem.empty()) { tandem.assign((size_t)2 * n, -1); for (int k = 0; k < n; ++k) tandem[(size_t)n + k] = 0; }
+        if (!st->downstream_lp) return fail(h, HS_E_INVALID, "downstream_lp is required with HS_EGRESS_SERVER");
+        const int d = st->downstream_lp[i];
+        if (d < 0 || d >= n || d == i) return fail(h, HS_E_INVALID, "LP %d: downstream_lp %d is not another LP of this engine", i, d);
+        if ((st->svc_kind ? st->svc_kind[i] : HS_LAT_CONSTANT) == HS_LAT_NO_SERVER || (st->svc_kind ? st->svc_kind[d] : HS_LAT_CONSTANT) == HS_LAT_NO_SERVER)
+            return fail(h, HS_E_INVALID, "LP %d: HS_EGRESS_SERVER connects two Servers", i);
+        if (tandem[(size_t)d] >= 0)
+            return fail(h, HS_E_UNSUPPORTED, "LP %d: two Servers (LPs %d and %d) forward to it; one upstream Server per Server is lowered", d, tandem[(size_t)d], i);
+        tandem[(size_t)d] = i;
+    }
+    if (!tandem.empty()) {
+        if (h->cfg.mode != HS_MODE_SINGLE) return fail(h, HS_E_UNSUPPORTED, "tandem queues (HS_EGRESS_SERVER) need HS_MODE_SINGLE: the LPs of a chain are one Simulation");
+        int max_pass = 0;
+        for (int i = 0; i < n; ++i) {
+            int p = 0;
+            for (int u = tandem[(size_t)i]; u >= 0; u = tandem[(size_t)u]) if (++p > 6) break;
+            if (p > 6) return fail(h, HS_E_UNSUPPORTED, "LP %d: more than 7 Servers in a row (or a cycle of Servers) is not lowered", i);
+            tandem[(size_t)n + i] = p;
+            if (p > max_pass) max_pass = p;
+        }
+        h->n_pass = max_pass + 1;
+        h->any_profile = true;                                       // the general-path instantiation
+        h->uni_grid = false;
     }
     (void)any_source;
     // time-varying profiles (load/profile.py:52-113); src_rate of such a source is its PEAK rate (it sizes the logs)
@@ -566,7 +608,10 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     if ((rc = upload<uint8_t>(h, &h->P.probe_metric, pm.data(), (size_t)n * kMaxProbes, 255))) return rc;
     if ((rc = upload<double>(h, &h->P.probe_rate, prate.data(), (size_t)n * kMaxProbes, 1.0))) return rc;
     h->P.tabs = nullptr;
-    if (h->any_timevarying || h->any_probe) {
+    if (!tandem.empty() && (h->any_probe || n_sched > 0 || h->any_xsrc))
+        return fail(h, HS_E_UNSUPPORTED, "tandem queues (HS_EGRESS_SERVER) together with Probes, scheduled Requests or several Sources per "
+                                         "Server are not lowered yet (the prologue, csrc/hs_exact.hpp, does not forward between LPs)");
+    if (h->any_timevarying || h->any_probe || !tandem.empty()) {
         // Tick tables (hs_tables.hpp): one row per time-varying Source (Poisson ones draw from their own arrival stream;
         // deterministic ones with equal parameters share a row) and one per distinct Probe interval (a Probe's tick times are a
         // property of (interval, start) alone).
@@ -616,14 +661,25 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         h->n_tab_rows = (int)rows.size();
         if ((double)rows.size() * (double)tcap * 8.0 > 100e9)
             return fail(h, HS_E_INVALID, "tick tables would need %.1f GB", (double)rows.size() * (double)tcap * 8.0 / 1e9);
-        if ((rc = dev_alloc(h, &h->tab_rows, rows.size()))) return rc;
-        HS_HIP(h, hipMemcpy(h->tab_rows, rows.data(), rows.size() * sizeof(TickRow), hipMemcpyHostToDevice));
-        if ((rc = dev_alloc(h, &h->tab_times, rows.size() * (size_t)tcap))) return rc;
-        if ((rc = dev_alloc(h, &h->tab_count, rows.size()))) return rc;
-        if ((rc = dev_alloc(h, &h->tab_status, 2))) return rc;
-        HS_HIP(h, hipMemset(h->tab_status, 0, 2 * sizeof(unsigned long long)));
+        if (!rows.empty()) {
+            if ((rc = dev_alloc(h, &h->tab_rows, rows.size()))) return rc;
+            HS_HIP(h, hipMemcpy(h->tab_rows, rows.data(), rows.size() * sizeof(TickRow), hipMemcpyHostToDevice));
+            if ((rc = dev_alloc(h, &h->tab_times, rows.size() * (size_t)tcap))) return rc;
+            if ((rc = dev_alloc(h, &h->tab_count, rows.size()))) return rc;
+            if ((rc = dev_alloc(h, &h->tab_status, 2))) return rc;
+            HS_HIP(h, hipMemset(h->tab_status, 0, 2 * sizeof(unsigned long long)));
+        }
         TickTables tt{};
         tt.times = h->tab_times; tt.cap = tcap;
+        if (!tandem.empty()) {                                      // tandem queues: hs_tables.hpp TickTables::tandem
+            if ((double)n * (double)cap * 32.0 > 100e9)
+                return fail(h, HS_E_INVALID, "the forward logs of the tandem queues would need %.1f GB", (double)n * (double)cap * 32.0 / 1e9);
+            if ((rc = upload<int32_t>(h, &tt.tandem, tandem.data(), tandem.size(), -1))) return rc;
+            if ((rc = dev_alloc(h, &tt.inj_i, (size_t)n))) return rc;
+            HS_HIP(h, hipMemset(tt.inj_i, 0, (size_t)n * sizeof(int64_t)));
+            for (int64_t **col : {&tt.fw_rc, &tt.fw_rrc, &tt.fw_rdr, &tt.fw_dep}) if ((rc = dev_alloc(h, col, (size_t)n * (size_t)cap))) return rc;
+            for (int64_t **col : {&tt.q_rrc, &tt.q_rdr, &tt.q_pay}) if ((rc = dev_alloc(h, col, (size_t)n * (size_t)kQCap))) return rc;
+        }
         if ((rc = upload<int32_t>(h, &tt.src_row, srow.data(), srow.size(), -1))) return rc;
         if ((rc = upload<int32_t>(h, &tt.probe_row, prow.data(), prow.size(), -1))) return rc;
         if ((rc = upload<TickTables>(h, &h->P.tabs, &tt, 1, TickTables{}))) return rc;
@@ -681,17 +737,29 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
                 for (int j = 0; j < kMaxProbes; ++j) if (pm[(size_t)j * n + i] != 255) { po.push_back(i); pslot.push_back((uint8_t)j); }
         }
     }
-    if (st->source_order || st->probe_order) {   // cross-LP ties go to the entity the reference constructed first (cand_rank, hs_station.hpp)
+    if (st->source_order || st->probe_order || !tandem.empty()) {   // cross-LP ties go to the entity the reference constructed first (cand_rank, hs_station.hpp)
         std::vector<int32_t> tr((size_t)n * (kMaxXSrc + 2) + 1 + (size_t)n * kMaxProbes, -1);
         int32_t *sr = tr.data() + n;
         for (size_t q = 0; q < so.size(); ++q) {
             sr[(size_t)sslot[q] * n + (size_t)so[q]] = (int32_t)q;               // a tick: its own Source's position
             if (tr[(size_t)so[q]] < 0) tr[(size_t)so[q]] = (int32_t)q;           // anything else: the LP's first-listed Source
         }
+        if (!tandem.empty())                                                     // a Server behind a Server: what reaches it descends
+            for (int i = 0; i < n; ++i) {                                        // from the Sources of its chain's head
+                int head = i;
+                while (tandem[(size_t)head] >= 0) head = tandem[(size_t)head];
+                if (head != i && tr[(size_t)i] < 0 && tr[(size_t)head] >= 0) tr[(size_t)i] = tr[(size_t)head];
+            }
         for (int i = 0; i < n; ++i) if (tr[(size_t)i] < 0) tr[(size_t)i] = (int32_t)so.size() + i;   // sourceless LPs after them
         tr[(size_t)n * (kMaxXSrc + 2)] = (int32_t)so.size() + n;                 // Probes behind all of them ...
         int32_t *pr = tr.data() + (size_t)n * (kMaxXSrc + 2) + 1;                // ... each by its own position in `probes=[...]`
         for (size_t q = 0; q < po.size(); ++q) pr[(size_t)pslot[q] * n + (size_t)po[q]] = (int32_t)so.size() + n + (int32_t)q;
+        if (!tandem.empty())     // ... and where every other key ties between two Servers of a chain, the upstream one's event was created first
+            for (size_t q = 0; q < tr.size(); ++q) {                             // (ranks only compare: room for the pass below them)
+                const size_t lp = q < (size_t)n * (kMaxXSrc + 2) ? q % (size_t)n : (q - (size_t)n * (kMaxXSrc + 2) - 1) % (size_t)n;
+                if (q == (size_t)n * (kMaxXSrc + 2)) { tr[q] = tr[q] * 8; continue; }
+                tr[q] = tr[q] * 8 + tandem[(size_t)n + lp];
+            }
         if ((rc = upload<int32_t>(h, &h->P.tie_rank, tr.data(), tr.size(), 0))) return rc;
     }
     h->P.sched_idx = nullptr;

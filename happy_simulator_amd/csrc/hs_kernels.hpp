@@ -147,6 +147,26 @@ __device__ __forceinline__ void load_station(Station<C, PF, UNI> &S, const Stati
         }
         S.probe_t = L.probe_t + lp; S.probe_v = L.probe_v + lp; S.pcap = L.pcap;
     }
+    S.trk = false; S.up = -1; S.inj_i = 0; S.inj_n = 0; S.IA = kInfNs; S.imask = 0; S.cur_pay = 0;
+    S.rk_dp = 0; S.rk_rank = 0; S.rk_rc = INT64_MIN; S.tie_rank_p = P.tie_rank; S.n_rank = n;
+    if constexpr (PF) {
+        if (P.tabs != nullptr && P.tabs->tandem != nullptr) {            // tandem queues (hs_station.hpp `trk`)
+            const TickTables &T = *P.tabs;
+            S.trk = true;
+            S.fw_rc = T.fw_rc + lp; S.fw_rrc = T.fw_rrc + lp; S.fw_rdr = T.fw_rdr + lp; S.fw_dep = T.fw_dep + lp;
+            S.q_rrc = T.q_rrc + lp; S.q_rdr = T.q_rdr + lp; S.q_pay = T.q_pay + lp;
+            S.up = T.tandem[lp];
+            if (S.up >= 0) {
+                const int up = S.up;
+                S.inj_i_p = T.inj_i + lp; S.inj_i = *S.inj_i_p;
+                S.inj_n = X.received[up];                               // forwards it has published (its pass is over)
+                S.inj_n = S.inj_n < L.cap ? S.inj_n : L.cap;
+                S.up_t = L.sink_t + up; S.up_created = ((C > 1) ? L.sink_created : L.adm) + up;
+                S.up_rc = T.fw_rc + up; S.up_rrc = T.fw_rrc + up; S.up_rdr = T.fw_rdr + up; S.up_dep = T.fw_dep + up;
+                S.IA = S.inj_i < S.inj_n ? S.up_t[(size_t)S.inj_i * (size_t)n] : kInfNs;
+            }
+        }
+    }
     S.A = X.A[lp]; S.seqA = X.seqA[lp]; S.crtA = X.crtA[lp]; S.arr_time = X.arr_time[lp];
     S.buf = X.buf[lp]; S.active = X.active[lp]; S.seq = X.seq[lp];
     S.generated = X.generated[lp]; S.accepted = X.accepted[lp]; S.dropped = X.dropped[lp];
@@ -207,6 +227,16 @@ __device__ __forceinline__ void store_station(const Station<C, PF, UNI> &Sc, con
         int64_t r0 = S.qrc[(size_t)(S.qh % kQCap) * S.ls], r1 = S.qrc[(size_t)((S.qh + 1) % kQCap) * S.ls];
         S.qdep[0] = d0; S.qrc[0] = r0;
         if (qn > 1) { S.qdep[(size_t)S.ls] = d1; S.qrc[(size_t)S.ls] = r1; }
+        if constexpr (PF) {
+            if (S.trk) {
+                int64_t *cols[3] = {S.q_rrc, S.q_rdr, S.q_pay};
+                for (int c = 0; c < 3; ++c) {
+                    const int64_t v0 = cols[c][(size_t)(S.qh % kQCap) * S.ls], v1 = cols[c][(size_t)((S.qh + 1) % kQCap) * S.ls];
+                    cols[c][0] = v0;
+                    if (qn > 1) cols[c][(size_t)S.ls] = v1;
+                }
+            }
+        }
     }
     for (int i = 0; i < qn; ++i) q |= (uint32_t)S.qmem[(S.qh + i) % kQCap][S.tid] << (8 * i);
     q |= (uint32_t)qn << 16;
@@ -224,6 +254,7 @@ __device__ __forceinline__ void store_station(const Station<C, PF, UNI> &Sc, con
         X.ev_probe[lp] += S.evp[0]; X.ev_probe[(size_t)n + lp] += S.evp[1];
         tot += S.evp[0] + S.evp[1];
         if (S.sc_t != nullptr) X.sched_i[lp] = S.sc_i;
+        if (S.trk && S.up >= 0) *S.inj_i_p = S.inj_i;      // (imask == 0 between groups: a run of forwards is consumed whole)
 #pragma unroll
         for (int j = 0; j < kMaxXSrc; ++j) if (j < S.n_xsrc) {
             const size_t o = (size_t)j * n + lp;
@@ -347,6 +378,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
     }
     for (int k = 0; k < 11; ++k) X.ev_kind[(size_t)k * n + lp] = 0;
     if constexpr (!PF) return;
+    if constexpr (PF) { if (P.tabs != nullptr && P.tabs->tandem != nullptr) P.tabs->inj_i[lp] = 0; }   // tandem: no forward consumed yet
     if (X.XA != nullptr) {   // the LP's further Sources: each draws its first arrival from start_ns like the first one
         for (int j = 0; j < kMaxXSrc; ++j) {
             const size_t o = (size_t)j * n + lp;
@@ -498,9 +530,17 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
     }
     if (live) {
         load_station<C, PF, UNI>(S, P, X, L, lp, n, qmem, ring_a, ring_s, tid);
-        S.force_general = (flags & 1) != 0;
+        S.force_general = (flags & 1) != 0 || (PF && S.trk && (S.up >= 0 || S.egress == kEgressServer));   // (tandem LPs: event order)
     }
-    const bool frozen = (mode == HS_MODE_REPLICAS) ? (live && S.last_time > end_ns) : (cur > end_ns);
+    const bool ended = (mode == HS_MODE_REPLICAS) ? (live && S.last_time > end_ns) : (cur > end_ns);
+    // tandem queues run in passes, upstream Servers first (hs_station.hpp `trk`): flags bits 28..30 = pass + 1; an LP of another
+    // pass keeps its state in this launch, and still names its first event beyond end_ns in the launch that elects
+    bool other_pass = false;
+    if constexpr (PF) {
+        const int pass1 = (flags >> 28) & 7;
+        if (pass1 != 0 && live && P.tabs != nullptr && P.tabs->tandem != nullptr) other_pass = P.tabs->tandem[(size_t)n + lp] != pass1 - 1;
+    }
+    const bool frozen = ended || other_pass;
     bool pre_group = false;
     bool event_order = true;
     if (live && !frozen && S.qn > 0 && S.grp_time <= end_ns) {   // finish a group a previous window stopped inside
@@ -580,7 +620,7 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
             }
             if (bail_reload) {
                 load_station<C, PF, UNI>(S, P, X, L, lp, n, qmem, ring_a, ring_s, tid);
-                S.force_general = (flags & 1) != 0;
+                S.force_general = (flags & 1) != 0 || (PF && S.trk && (S.up >= 0 || S.egress == kEgressServer));   // (tandem LPs: event order)
             }
         }
         // (2) event-order loop for whatever (1) does not cover
@@ -604,7 +644,7 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
         }
     }
     if (live) {
-        if (!frozen) {
+        if (!ended) {
             if (mode == HS_MODE_REPLICAS) overshoot_one<C, PF, UNI>(S);
             else {
                 mine = make_candidate<C, PF, UNI>(S);

@@ -38,6 +38,9 @@ __device__ __forceinline__ uint64_t xsrc_stream_id(uint64_t lp_stream_base, int 
     return stream_id((1ull << 40) | (lp_stream_base << 2) | (uint64_t)j, kStreamArrival);
 }
 constexpr int kRootSched = 98;  // pick_root: the next Request injected with Simulation.schedule()
+constexpr int kRootInj = 40;    // pick_root: forward j of the run of forwards that arrive from the upstream Server at this nanosecond
+constexpr int kMaxInjRun = 32;  // ... such runs are one long (two upstream workers finishing on one nanosecond: two)
+constexpr uint32_t kEgressServer = 4;   // HS_EGRESS_SERVER: the Server forwards to another Server (tandem queues)
 
 constexpr int kBlock = 256;     // LPs per workgroup (4 wavefronts)
 constexpr int kQCap = 48;       // in-group FIFO capacity per LP (LDS)
@@ -297,24 +300,56 @@ struct Station {
     int qh, qn;
     int qoverflow;
     bool force_general;         // debug: route every group through the general FIFO path
+    // ---- tandem queues: Server(downstream=<Server>) (components/server/server.py:271-272, core/entity.py:83-105) ----------------
+    // A completion forwards the Request to the downstream Server's LP at the same instant.  The engine runs the LPs of a tandem in
+    // PASSES, upstream first: pass p's LPs run to end_time while every forward they create goes to a log (time and created_at in the
+    // LP's sink_t / sink_created columns, where a Sink's records would go); pass p + 1's LPs read their upstream LP's log as a list
+    // of arrivals.  What the downstream LP cannot see from the list alone is where, inside a shared nanosecond, the reference's heap
+    // puts the forwarded Request among the LP's own events.  The heap is a FIFO inside a nanosecond (StationState lineage): a group
+    // runs breadth-first from its roots -- the events pending from earlier nanoseconds, in the order they were created -- so the
+    // forwarded Request, `dep` steps below ITS root (the upstream continuation, if that was pending from earlier), runs after
+    // everything fewer steps below any root and, among equals, in root order.  The log therefore carries the root's key -- creation
+    // time, its own lineage, construction rank (cand_less) -- and `dep`; the downstream LP enters the root among its own roots by
+    // that key (pick_root) as a root that does nothing but create a chain of `dep` placeholders ending in the Request@Server.
+    bool trk;                   // the engine has tandem queues: every in-group event knows its root's key (rk_*, with cr)
+    int32_t rk_dp, rk_rank;     // key of the root of the chain being processed: its steps from ITS group's root, construction rank,
+    int64_t rk_rc;              // ... and that group's root's creation time (its own creation time is cr)
+    int64_t cur_pay;            // created_at carried by the FIFO entry just popped (a forward on its way to the enqueue)
+    const int32_t *tie_rank_p; int n_rank;   // cand_rank()'s table
+    int64_t *fw_rc, *fw_rrc, *fw_rdr, *fw_dep;   // this LP's forward-log lineage columns, record m at [m * ls]
+    int64_t *q_rrc, *q_rdr, *q_pay;              // this LP's FIFO root-key / payload columns, entry `slot` at [slot * ls]
+    // forwards arriving from the upstream LP `up`: records inj_i .. inj_n - 1 of ITS log (complete: its pass is over)
+    int up;
+    int64_t inj_i, inj_n, IA;   // IA: time of record inj_i (kInfNs: none left)
+    int64_t *inj_i_p;
+    uint32_t imask;             // forwards of the current nanosecond's run already taken as roots (bit j: record inj_i + j)
+    const int64_t *up_t, *up_created, *up_rc, *up_rrc, *up_rdr, *up_dep;
 
     // an event created by the one being processed: one step further from the group's root
-    __device__ __forceinline__ void qpush(uint32_t code) {
+    __device__ __forceinline__ void qpush(uint32_t code, int64_t pay = 0) {
         if (qn >= kQCap) { qoverflow = 1; return; }
         const int slot = (qh + qn) % kQCap;
         qmem[slot][tid] = (uint8_t)code;
         qdep[(size_t)slot * ls] = (uint8_t)(cd >= 254 ? 255 : cd + 1);
         qrc[(size_t)slot * ls] = cr;
+        if constexpr (PF) {
+            if (trk) { q_rrc[(size_t)slot * ls] = rk_rc; q_rdr[(size_t)slot * ls] = rk_pack(); q_pay[(size_t)slot * ls] = pay; }
+        }
         ++qn;
     }
     __device__ __forceinline__ uint32_t qpop() {
         const uint32_t c = qmem[qh][tid];
         cd = qdep[(size_t)qh * ls];
         cr = qrc[(size_t)qh * ls];
+        if constexpr (PF) {
+            if (trk) { rk_rc = q_rrc[(size_t)qh * ls]; rk_unpack(q_rdr[(size_t)qh * ls]); cur_pay = q_pay[(size_t)qh * ls]; }
+        }
         qh = (qh + 1) % kQCap;
         --qn;
         return c;
     }
+    __device__ __forceinline__ int64_t rk_pack() const { return (int64_t)(uint32_t)(rk_dp & 0xff) | ((int64_t)rk_rank << 8); }
+    __device__ __forceinline__ void rk_unpack(int64_t w) { rk_dp = (int32_t)(w & 0xff); rk_rank = (int32_t)(w >> 8); }
     __device__ __forceinline__ int32_t dp_next(int steps) const { return cd + steps > 255 ? 255 : cd + steps; }
 
     __device__ __forceinline__ void init_streams(uint64_t seed, uint64_t base, uint64_t ak, uint64_t sk,
@@ -430,11 +465,12 @@ struct Station {
         return r;
     }
     // QueuedResource.handle_event -> Queue._handle_enqueue (components/queue.py:122-147).  True: QUEUE_NOTIFY created.
-    __device__ __forceinline__ bool do_enqueue(int64_t t) {
+    __device__ __forceinline__ bool do_enqueue(int64_t t) { return do_enqueue(t, t); }   // context["created_at"] = tick time
+    __device__ __forceinline__ bool do_enqueue(int64_t t, int64_t created) {   // (a forwarded Request keeps its context: entity.py:100-105)
         ev[1]++;
         if (qcap >= 0 && buf >= qcap) { dropped++; return false; }        // FIFOQueue.push refuses (queue_policy.py:94-98)
         const bool was_empty = (buf == 0);
-        if (accepted < cap) adm[accepted * ls] = t; else overflow = 1;   // context["created_at"] = tick time
+        if (accepted < cap) adm[accepted * ls] = created; else overflow = 1;
         accepted++;
         buf++;
         return was_empty;
@@ -485,7 +521,7 @@ struct Station {
         completed++;
         total_service = __dadd_rn(total_service, s);
         uint32_t r = 0;
-        if (egress == 1) {
+        if (egress == 1 || (PF && egress == kEgressServer)) {             // (forward(event, downstream): the same record, see do_sink)
             if (sink_w < cap) { sink_t[sink_w * ls] = t; if (C > 1) sink_created[sink_w * ls] = created; }
             else overflow = 1;
             sink_w++;
@@ -495,7 +531,21 @@ struct Station {
         return r;
     }
     // Sink.handle_event (components/common.py:36-44); the record itself was staged by do_cont.
-    __device__ __forceinline__ void do_sink() { ev[7]++; received++; }
+    // A Server downstream instead (tandem): this is the moment the forwarded Request runs -- at the downstream LP, which reads
+    // the record in its own pass; here its place in the nanosecond (root key, steps) joins the record and the record becomes
+    // visible (`received` = forwards published; no event is counted on this LP).
+    __device__ __forceinline__ void do_sink() {
+        if constexpr (PF) {
+            if (egress == kEgressServer) {
+                if (received < cap) {
+                    fw_rc[received * ls] = cr; fw_rrc[received * ls] = rk_rc; fw_rdr[received * ls] = rk_pack(); fw_dep[received * ls] = cd;
+                }
+                received++;
+                return;
+            }
+        }
+        ev[7]++; received++;
+    }
     // A Source wired straight to a Sink/Counter (no Server in this LP): the payload IS the Sink's event.
     __device__ __forceinline__ void stage_direct_sink(int64_t t) {
         if (sink_w < cap) { sink_t[sink_w * ls] = t; if (C > 1) sink_created[sink_w * ls] = t; else adm[sink_w * ls] = t; }
@@ -555,6 +605,79 @@ struct Station {
         ++sc_i;
         SA = sc_i < sc_end ? sc_t[sc_i] : kInfNs;
         if (do_enqueue(t)) qpush(Q_NOTIFY);
+    }
+
+    // ---- tandem: the forwards of the upstream Server (see `trk` above)
+    __device__ __forceinline__ bool has_inj() const { return PF && IA != kInfNs; }
+    __device__ __forceinline__ int64_t inj_time(int64_t k) const { return k < inj_n ? up_t[k * ls] : kInfNs; }
+    // forward j of the run at time t (records inj_i + j, all at t) whose root comes first, among those not taken yet: -1 none
+    __device__ __forceinline__ int inj_pick(int64_t t) const {
+        int best = -1;
+        for (int j = 0; j < kMaxInjRun && inj_time(inj_i + j) == t; ++j) {
+            if (imask & (1u << j)) continue;
+            if (best < 0 || inj_key_less(inj_i + j, inj_i + best)) best = j;
+        }
+        return best;
+    }
+    __device__ __forceinline__ bool inj_key_less(int64_t a, int64_t b) const {    // cand_less on the roots of two forwards
+        const int64_t ca = up_rc[a * ls], cb = up_rc[b * ls];
+        if (ca != cb) return ca < cb;
+        const int64_t da = up_rdr[a * ls], db = up_rdr[b * ls];
+        if ((da & 0xff) != (db & 0xff)) return (da & 0xff) < (db & 0xff);
+        const int64_t ra = up_rrc[a * ls], rb = up_rrc[b * ls];
+        if (ra != rb) return ra < rb;
+        return (da >> 8) < (db >> 8);                                              // (equal: list order -- the `best < 0 ||` above)
+    }
+    // ... against one of this LP's own pending roots `w` (pick_root's code): true = the forward's root was created first
+    __device__ __forceinline__ bool inj_before_own(int64_t k, int w) const {
+        int32_t dp; int64_t rc; int pad;
+        own_root_key(w, dp, rc, pad);
+        const int64_t ca = up_rc[k * ls], cb = root_crt(w);
+        if (ca != cb) return ca < cb;
+        const int64_t da = up_rdr[k * ls];
+        if ((int32_t)(da & 0xff) != dp) return (int32_t)(da & 0xff) < dp;
+        const int64_t ra = up_rrc[k * ls];
+        if (ra != rc) return ra < rc;
+        return (int32_t)(da >> 8) < rank_of(pad);
+    }
+    // lineage of the LP's own pending root `w` as the election sees it (make_candidate)
+    __device__ __forceinline__ void own_root_key(int w, int32_t &dp, int64_t &rc, int &pad) const {
+        dp = 0; rc = INT64_MIN; pad = 0;
+        if (w == 0) { dp = dpA; rc = rcA; pad = 2; }
+        else if (PF && w >= kRootXSrc) {
+#pragma unroll
+            for (int j = 0; j < kMaxXSrc; ++j) if (j == w - kRootXSrc) { dp = dpX[j]; rc = rcX[j]; }
+            pad = 3 + (w - kRootXSrc);
+        } else if (PF && w >= kRootProbe) {
+#pragma unroll
+            for (int j = 0; j < kMaxProbes; ++j) if (j == w - kRootProbe) rc = rcP[j];
+            dp = 1; pad = 8 + (w - kRootProbe);
+        } else if (PF && w == kRootSched) { dp = 0; rc = INT64_MIN; }
+        else {
+#pragma unroll
+            for (int i = 0; i < C; ++i) if (i == w - 1) { dp = dpD[i]; rc = rcD[i]; }
+        }
+    }
+    __device__ __forceinline__ int rank_of(int pad) const {                        // cand_rank()
+        if (tie_rank_p == nullptr)
+            return pad >= 8 ? n_rank * (kMaxXSrc + 1) + lp * kMaxProbes + (pad - 8) : lp * (kMaxXSrc + 1) + (pad >= 2 ? pad - 2 : 0);
+        if (pad >= 8) return tie_rank_p[(size_t)(kMaxXSrc + 2) * (size_t)n_rank + 1 + (size_t)(pad - 8) * (size_t)n_rank + lp];
+        if (pad >= 2) return tie_rank_p[(size_t)(pad - 1) * (size_t)n_rank + lp];
+        return tie_rank_p[lp];
+    }
+    // the forward's root, entered among this LP's roots: it does nothing here but head the chain that ends in the Request@Server
+    __device__ __forceinline__ void root_inj(int j, int64_t t) {
+        const int64_t k = inj_i + j;
+        const int64_t dep = up_dep[k * ls];
+        cr = up_rc[k * ls]; rk_rc = up_rrc[k * ls]; rk_unpack(up_rdr[k * ls]);     // (cd = 0: run_root)
+        if (dep < 1 || dep > 31) { qoverflow = 1; }                               // (a same-nanosecond chain deeper than the FIFO codes hold)
+        else qpush(Q_ENQ | ((uint32_t)dep << 3), up_created[k * ls]);
+        imask |= 1u << j;
+        // the run is consumed once every forward of it has been taken
+        int len = 0;
+        while (len < kMaxInjRun && inj_time(inj_i + len) == t) ++len;
+        if (inj_time(inj_i + len) == t && len == kMaxInjRun) qoverflow = 1;        // (a longer run than the mask holds)
+        if (imask == (len >= 32 ? 0xffffffffu : ((1u << len) - 1u))) { inj_i += len; imask = 0; IA = inj_time(inj_i); }
     }
 
     // ---- further Sources: Source.handle_event (load/source.py:142-180) of an entity of its own; its payload is one more
@@ -648,12 +771,17 @@ struct Station {
 #pragma unroll
             for (int j = 0; j < kMaxXSrc; ++j)
                 if (j < n_xsrc && XA[j] == t && (best < 0 || (int32_t)(seqX[j] - bs) < 0)) { best = kRootXSrc + j; bs = seqX[j]; }
+            if (IA == t) {      // tandem: the roots of the forwards arriving now compete by the election key
+                const int j = inj_pick(t);
+                if (j >= 0 && (best < 0 || inj_before_own(inj_i + j, best))) best = kRootInj + j;
+            }
         }
         return best;
     }
     // creation time of pending root `which` (pick_root's code)
     __device__ __forceinline__ int64_t root_crt(int which) const {
         int64_t c = INT64_MIN;                                            // kRootSched: constructed before run()
+        if (PF && which >= kRootInj && which < kRootInj + kMaxInjRun) return up_rc[(inj_i + (which - kRootInj)) * ls];
         if (which == 0) c = crtA;
         else if (PF && which >= kRootXSrc) {
 #pragma unroll
@@ -669,6 +797,14 @@ struct Station {
     }
     __device__ __forceinline__ void run_root(int which, int64_t t) {
         cd = 0; cr = root_crt(which);                                     // a root: pending from an earlier nanosecond
+        if constexpr (PF) {
+            if (trk) {
+                if (which >= kRootInj && which < kRootInj + kMaxInjRun) { root_inj(which - kRootInj, t); return; }
+                int pad;
+                own_root_key(which, rk_dp, rk_rc, pad);
+                rk_rank = rank_of(pad);
+            }
+        }
         if (which == 0) root_tick(t);
         else if (PF && which >= kRootXSrc) root_xsrc(which - kRootXSrc, t);
         else if (PF && which >= kRootProbe) root_probe(which - kRootProbe, t);
@@ -681,7 +817,11 @@ struct Station {
         while (qn > 0) {
             const uint32_t code = qpop();
             switch (code & 7u) {
-                case Q_ENQ: if (do_enqueue(t)) qpush(Q_NOTIFY); break;
+                case Q_ENQ: {
+                    const uint32_t hop = PF ? (code >> 3) : 0u;          // tandem: a forward `hop` steps above its Request@Server
+                    if (hop > 1) qpush(Q_ENQ | ((hop - 1) << 3), cur_pay);
+                    else if (do_enqueue(t, hop == 1 ? cur_pay : t)) qpush(Q_NOTIFY);
+                } break;
                 case Q_NOTIFY: if (do_notify()) qpush(Q_POLL); break;
                 case Q_POLL: if (do_poll()) qpush(Q_DELIVER); break;
                 case Q_DELIVER: {
@@ -717,6 +857,7 @@ struct Station {
         for (int i = 0; i < C; ++i) t = D[i] < t ? D[i] : t;
         if constexpr (PF) { if (has_probe()) { const int64_t pm = probe_min(); if (pm < t) t = pm; } if (SA < t) t = SA; }
         if constexpr (PF) { if (has_xsrc()) { const int64_t xm = xsrc_min(); if (xm < t) t = xm; } }
+        if constexpr (PF) { if (IA < t) t = IA; }
         return t;
     }
 

@@ -37,6 +37,17 @@ struct TickTables {
     int64_t cap;
     const int32_t *src_row;    // [n_lp] row of the LP's time-varying Source, -1: none
     const int32_t *probe_row;  // [kMaxProbes][n_lp] row of the Probe in that slot, -1: none
+    // ---- tandem queues (Server(downstream=<Server>), hs_station.hpp "tandem"): further per-engine arrays that only the PF
+    // instantiations read live behind this pointer as well, so that the headline kernels' argument list stays what it was.
+    // null = the engine has no Server that forwards to a Server.
+    const int32_t *tandem;     // [2][n_lp]: [0][lp] the LP whose forwarded Requests arrive here (-1: none); [1][lp] the LP's pass
+    int64_t *inj_i;            // [n_lp] forwards of the upstream LP consumed so far
+    // lineage of forward record m of an LP (its time / created_at are record m of the LP's sink_t / sink_created logs): when the
+    // root of the nanosecond group the forward was created in was created, that root's own lineage (its root's creation time;
+    // steps | construction rank << 8), and how many steps below the root the forwarded Request is.  [cap][n_lp]
+    int64_t *fw_rc, *fw_rrc, *fw_rdr, *fw_dep;
+    // ... and the same root key for every entry of the in-group FIFO, plus the created_at an arriving forward carries.  [kQCap][n_lp]
+    int64_t *q_rrc, *q_rdr, *q_pay;
 };
 __device__ __forceinline__ int64_t tick_lookup(const int64_t *row, int64_t cap, int64_t k, int &overflow) {
     if (k < cap) return row[k];

@@ -48,6 +48,9 @@ class StationArrays:
     src_more_rate: np.ndarray | None = None         # [3, n]
     src_more_stop_after_ns: np.ndarray | None = None  # [3, n]; None = never
     source_slot_order: np.ndarray | None = None     # slot of every entry of source_order (None = 0 everywhere)
+    # tandem queues, Server(downstream=<Server>): egress[i] == N.EGRESS_SERVER forwards station i's completions to the Server of
+    # station downstream_lp[i] (include/hs_engine.h)
+    downstream_lp: np.ndarray | None = None         # [n] int32
 
     @staticmethod
     def uniform(n: int, *, src_kind=N.SRC_POISSON, rate=8.0, stop_after_ns=-1, concurrency=1,
@@ -205,6 +208,13 @@ class StationEngine:
                     raise ValueError("probe_slot_order must have one entry per entry of probe_order")
                 keep.append(b)
                 st.probe_slot_order = b.ctypes.data if len(b) else None
+        self._tandem = stations.downstream_lp is not None
+        if stations.downstream_lp is not None:
+            a = np.ascontiguousarray(stations.downstream_lp, np.int32)
+            if a.shape != (self.n,):
+                raise ValueError(f"downstream_lp has the wrong shape for {self.n} stations")
+            keep.append(a)
+            st.downstream_lp = a.ctypes.data
         self.n_links = 0
         try:
             self._check(self._lib.hs_engine_set_stations(self._h, C.byref(st)))
@@ -356,6 +366,8 @@ class StationEngine:
     def read_sinks(self):
         """All sink records: (counts[n], t_ns[total], created_ns[total]) concatenated in LP order."""
         total = self.summary().sink_records
+        if self._tandem:            # a Server that forwards to a Server logs its forwards where a Sink's records would go
+            total = int(self.lp_stats()["sink_received"].sum())
         counts = np.zeros(self.n, np.int64)
         t = np.zeros(max(total, 1), np.int64)
         cr = np.zeros(max(total, 1), np.int64)

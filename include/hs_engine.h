@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HS_ABI_VERSION 9
+#define HS_ABI_VERSION 10
 
 typedef enum hs_status {
     HS_OK = 0,
@@ -59,7 +59,8 @@ typedef enum hs_egress_kind {
     HS_EGRESS_NONE = 0,
     HS_EGRESS_SINK = 1,
     HS_EGRESS_LINK = 2,
-    HS_EGRESS_ROUTER = 3
+    HS_EGRESS_ROUTER = 3,
+    HS_EGRESS_SERVER = 4   /* hs_stations.egress only: another Server (hs_stations.downstream_lp), tandem queues */
 } hs_egress_kind;
 
 /* reference-equivalent event kinds counted by the engine */
@@ -163,6 +164,13 @@ typedef struct hs_stations {
     const double *src_more_rate;       /* [3][n_lp] */
     const int64_t *src_more_stop_after_ns; /* [3][n_lp] < 0 = never; NULL = never */
     const uint8_t *source_slot_order;  /* [number of Sources] */
+    /* Tandem queues: `Server(..., downstream=<another Server>)` (components/server/server.py:64-122,271-272; the forwarded Event
+     * keeps its context, core/entity.py:83-105).  egress[i] == HS_EGRESS_SERVER: every completion of LP i arrives at the Server of
+     * LP downstream_lp[i] at the same instant, created_at unchanged.  At most one upstream Server per Server, at most 7 Servers in a
+     * row, HS_MODE_SINGLE, no hs_engine_set_network; Probes / scheduled Requests / several Sources per Server in the same engine
+     * are refused for now.  The engine runs the chain in passes, upstream first (csrc/hs_station.hpp "tandem queues"); results
+     * equal the reference's single heap event for event, ties inside a nanosecond included.  NULL = no such Server. */
+    const int32_t *downstream_lp;      /* [n_lp] read where egress == HS_EGRESS_SERVER */
 } hs_stations;
 typedef enum hs_probe_metric {
     HS_PROBE_DEPTH = 0,        /* QueuedResource.depth */
