@@ -39,6 +39,11 @@ struct hs_engine {
     bool is_net = false;
     bool any_xsrc = false;     // some LP has more than one Source (general path + prologue)
     int n_pass = 0;            // tandem queues (Server -> Server): passes of the station kernel, 0 = none
+    // ... whose nanosecond ties the passes' lineage key does not decide (Totals::undecided), or which stand next to Probes / scheduled
+    // Requests / several Sources per Server, run on the single-heap loop (hs_exact.hpp) from start to end instead
+    bool exact_only = false;
+    bool exact_prologue = false;   // the prologue takes part in ordinary runs (pre-run events whose indices run-time events can pass)
+    std::vector<int64_t> window_ends;   // tandem queues: the end times of the run_until calls since the last reset (replayed on the single heap)
     bool uni_stations = false; // every LP: Poisson Source, exponential single-worker Server, unbounded queue, no stop_after
     bool uni_grid = false;     // ... and a Sink behind every Server: hs_station_run<1, false, true, true>
     bool f64_times = false;    // every time of a run is a whole number of ns in [0, 2^52): the UNI kernels' exact binary64 time algebra
@@ -198,6 +203,7 @@ void launch_wide(hs_engine *h, int64_t end_ns) {
 }
 
 void launch_run_dispatch(hs_engine *h, int64_t end_ns) {
+    if (h->exact_only) return;     // (the single-heap loop has run the whole window: launch_prologue)
     const int K = wide_lanes(h);
     h->fresh = false;
     switch (K) {
@@ -337,12 +343,15 @@ int do_reset_async(hs_engine *h) {
     h->initialised = true;
     h->net_ran = false;
     h->fresh = true;
+    h->window_ends.clear();
     return HS_OK;
 }
 
 // the prologue of a run (hs_exact.hpp); a no-op launch once it has handed over
 int launch_prologue(hs_engine *h, int64_t end_ns) {
     if (!h->exact || (h->flags & 256)) return HS_OK;
+    if (!h->exact_prologue && !h->exact_only) return HS_OK;
+    h->XI.no_handover = h->exact_only ? 1 : 0;
     hipLaunchKernelGGL(hs_exact_run, dim3(h->XI.per_lp ? (unsigned)((h->cfg.n_lp + 63) / 64) : 1u), dim3(64), 0, h->stream, h->P, h->NP, h->X, h->NX, h->L, h->tot, h->xs, h->XI,
                        h->cfg.n_lp, h->C, h->is_net ? 1 : 0, h->is_net ? h->NP.n_links : 0, h->cfg.start_ns, end_ns);
     HS_HIP(h, hipGetLastError());
@@ -486,7 +495,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     std::vector<int32_t> tandem;
     for (int i = 0; i < n; ++i) {
         if ((st->egress ? st->egress[i] : HS_EGRESS_SINK) != HS_EGRESS_SERVER) continue;
-        if (tandem.empty()) { tandem.assign((size_t)2 * n, -1); for (int k = 0; k < n; ++k) tandem[(size_t)n + k] = 0; }
+        if (tandem.empty()) { tandem.assign((size_t)3 * n, -1); for (int k = 0; k < n; ++k) tandem[(size_t)n + k] = 0; }
         if (!st->downstream_lp) return fail(h, HS_E_INVALID, "downstream_lp is required with HS_EGRESS_SERVER");
         const int d = st->downstream_lp[i];
         if (d < 0 || d >= n || d == i) return fail(h, HS_E_INVALID, "LP %d: downstream_lp %d is not another LP of this engine", i, d);
@@ -495,6 +504,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if (tandem[(size_t)d] >= 0)
             return fail(h, HS_E_UNSUPPORTED, "LP %d: two Servers (LPs %d and %d) forward to it; one upstream Server per Server is lowered", d, tandem[(size_t)d], i);
         tandem[(size_t)d] = i;
+        tandem[(size_t)2 * n + i] = d;
     }
     if (!tandem.empty()) {
         if (h->cfg.mode != HS_MODE_SINGLE) return fail(h, HS_E_UNSUPPORTED, "tandem queues (HS_EGRESS_SERVER) need HS_MODE_SINGLE: the LPs of a chain are one Simulation");
@@ -608,9 +618,6 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     if ((rc = upload<uint8_t>(h, &h->P.probe_metric, pm.data(), (size_t)n * kMaxProbes, 255))) return rc;
     if ((rc = upload<double>(h, &h->P.probe_rate, prate.data(), (size_t)n * kMaxProbes, 1.0))) return rc;
     h->P.tabs = nullptr;
-    if (!tandem.empty() && (h->any_probe || n_sched > 0 || h->any_xsrc))
-        return fail(h, HS_E_UNSUPPORTED, "tandem queues (HS_EGRESS_SERVER) together with Probes, scheduled Requests or several Sources per "
-                                         "Server are not lowered yet (the prologue, csrc/hs_exact.hpp, does not forward between LPs)");
     if (h->any_timevarying || h->any_probe || !tandem.empty()) {
         // Tick tables (hs_tables.hpp): one row per time-varying Source (Poisson ones draw from their own arrival stream;
         // deterministic ones with equal parameters share a row) and one per distinct Probe interval (a Probe's tick times are a
@@ -679,6 +686,8 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
             HS_HIP(h, hipMemset(tt.inj_i, 0, (size_t)n * sizeof(int64_t)));
             for (int64_t **col : {&tt.fw_rc, &tt.fw_rrc, &tt.fw_rdr, &tt.fw_dep}) if ((rc = dev_alloc(h, col, (size_t)n * (size_t)cap))) return rc;
             for (int64_t **col : {&tt.q_rrc, &tt.q_rdr, &tt.q_pay}) if ((rc = dev_alloc(h, col, (size_t)n * (size_t)kQCap))) return rc;
+            if ((rc = dev_alloc(h, &tt.cand_key, (size_t)n * 4))) return rc;
+            HS_HIP(h, hipMemset(tt.cand_key, 0, (size_t)n * 4 * sizeof(int64_t)));
         }
         if ((rc = upload<int32_t>(h, &tt.src_row, srow.data(), srow.size(), -1))) return rc;
         if ((rc = upload<int32_t>(h, &tt.probe_row, prow.data(), prow.size(), -1))) return rc;
@@ -810,8 +819,11 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if ((rc = dev_alloc(h, &h->xs, (size_t)n + 1))) return rc;
         h->exact = true;
     }
-    if (h->cfg.mode == HS_MODE_SINGLE && (n_sched > 0 || h->any_probe || h->any_xsrc)) {
-        // The prologue (hs_exact.hpp): the reference's pre-run events in the order it constructs them
+    if (h->cfg.mode == HS_MODE_SINGLE && (n_sched > 0 || h->any_probe || h->any_xsrc || !tandem.empty())) {
+        // The prologue (hs_exact.hpp): the reference's pre-run events in the order it constructs them.  (Tandem queues: the same
+        // loop as the engine's exact path for whole runs -- `exact_only`.)
+        h->exact_prologue = n_sched > 0 || h->any_probe || h->any_xsrc;
+        h->exact_only = !tandem.empty() && h->exact_prologue;
         std::vector<int32_t> sl((size_t)n_sched);
         std::vector<int64_t> se((size_t)n_sched);
         std::vector<int32_t> lp_of((size_t)n_sched);
@@ -849,6 +861,8 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         h->xs_host = XState{};
         h->xs_host.heap_cap = n_init + (int64_t)n * (h->C + 16) + 1024;
         h->xs_host.pool_cap = 2 * n_init + 16 * (int64_t)n + 1024;
+        if (!tandem.empty())       // a whole run: one list cell per admitted Request
+            h->xs_host.pool_cap = std::min<int64_t>(h->xs_host.pool_cap + (int64_t)n * cap, (int64_t)1 << 30);
         if ((rc = dev_alloc(h, &h->xs_host.heap, (size_t)h->xs_host.heap_cap))) return rc;
         if ((rc = dev_alloc(h, &h->xs_host.qhead, (size_t)n))) return rc;
         if ((rc = dev_alloc(h, &h->xs_host.qtail, (size_t)n))) return rc;
@@ -1399,6 +1413,8 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
         rc = run_net_async(h, end_ns);
         if (rc) return rc;
     } else {
+        if (h->n_pass > 0 && (h->flags & (1 << 17)) && h->exact && h->window_ends.empty()) h->exact_only = true;   // debug: single heap from the start
+        if (h->n_pass > 0) h->window_ends.push_back(end_ns);
         int rc = launch_prologue(h, end_ns);
         if (rc) return rc;
         launch_run_dispatch(h, end_ns);
@@ -1410,10 +1426,35 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
     return HS_OK;
 }
 
+// Tandem queues: the passes met an order between two LPs' events that their lineage key does not decide (Totals::undecided).
+// The run since the last reset is repeated, window by window, on the single-heap loop -- the reference's own algorithm.
+int tandem_fallback(hs_engine *h) {
+    if (h->n_pass == 0 || h->exact_only || !h->exact) return HS_OK;
+    int und = 0;
+    HS_HIP(h, hipMemcpy(&und, &h->tot->undecided, sizeof und, hipMemcpyDeviceToHost));
+    if (!und) return HS_OK;
+    const std::vector<int64_t> ends = h->window_ends;
+    h->exact_only = true;
+    int rc = do_reset_async(h);
+    if (rc) return rc;
+    h->window_ends = ends;
+    for (int64_t e : ends) {
+        rc = launch_prologue(h, e);
+        if (rc) return rc;
+    }
+    HS_HIP(h, hipEventRecord(h->ev_k1, h->stream));
+    HS_HIP(h, hipEventRecord(h->ev_b, h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    return HS_OK;
+}
+
+int hs_engine_tandem_path(const hs_engine *h) { return !h || h->n_pass == 0 ? 0 : h->exact_only ? 2 : 1; }
+
 int hs_engine_synchronize(hs_engine *h) {
     if (!h) return fail(h, HS_E_INVALID, "null handle");
     HS_HIP(h, hipSetDevice(h->cfg.device));
     HS_HIP(h, hipStreamSynchronize(h->stream));
+    { int rc = tandem_fallback(h); if (rc) return rc; }
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, h->ev_a, h->ev_b) == hipSuccess) h->last_run_ms = ms;
     if (hipEventElapsedTime(&ms, h->ev_k0, h->ev_k1) == hipSuccess) h->last_kernel_ms = ms;
@@ -1486,6 +1527,9 @@ int hs_engine_bench_runs(hs_engine *h, int64_t end_ns, int32_t repeats, float *k
     for (auto &e : ev) hipEventDestroy(e);
     Totals t;                                                       // a timed run that overflowed is not a result
     HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
+    if (h->n_pass > 0 && !h->exact_only && t.undecided)
+        return fail(h, HS_E_UNSUPPORTED, "tandem queues: this configuration needs the single-heap path (lock-step ties); hs_engine_run_until "
+                                         "switches to it, hs_engine_bench_runs does not");
     if (t.qoverflow) return fail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
     if (t.overflow & 8) return fail(h, HS_E_HIP, "the asynchronous network engine gave up waiting for a neighbour (bounded spin)");
     if (t.overflow & 2) return fail(h, HS_E_OVERFLOW, "a station's in-flight message bag overflowed (capacity %d); raise bag_capacity", (int)h->NX.bag_cap);

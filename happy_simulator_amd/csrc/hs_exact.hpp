@@ -94,6 +94,9 @@ struct XInit {        // pre-run events in the order the reference constructs th
     // positions [sched_off[i], sched_off[i + 1]); the buffers of XState[0] are cut into per-LP slices of these sizes
     int32_t per_lp;
     int64_t heap_cap_lp, pool_cap_lp, init_cap_lp;
+    // 1: never hand over -- the whole run on this loop.  Tandem queues (Server -> Server) whose nanosecond ties the parallel
+    // engine's lineage key does not decide (Totals::undecided), and tandem queues next to Probes / scheduled Requests
+    int32_t no_handover;
 };
 
 namespace xdetail {
@@ -405,6 +408,8 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
             if (eg == EG_SINK) xpush(S, xev(t, S.G++, XE_SINK, lp, cr));
             else if (eg == EG_LINK) xpush(S, xev(t, S.G++, XE_LINK, lp, cr, NP.link_of[lp]));
             else if (eg == EG_ROUTER) xpush(S, xev(t, S.G++, XE_ROUTE, lp, cr));
+            else if (eg == kEgressServer)                                    // forward(event, downstream) to another Server: its Request,
+                xpush(S, xev(t, S.G++, XE_ENQ, P.tabs->tandem[2 * N + lp], cr));   // context preserved (core/entity.py:83-105)
             if (active < P.conc[lp]) xpush(S, xev(t, S.G++, XE_POLL, lp));
         } break;
         case XE_SINK: {                                                      // Sink.handle_event (components/common.py:36-44)
@@ -484,7 +489,7 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
         } break;
         default: break;
         }
-        if (S.G >= S.n_init) {
+        if (S.G >= S.n_init && !I.no_handover) {
             if (S.tc == INT64_MAX) {                                         // once: run-time events that share a pre-run event's key
                 int64_t tc = INT64_MIN;
                 for (int64_t i = 0; i < S.heap_len; ++i) {

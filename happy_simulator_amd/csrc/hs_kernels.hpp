@@ -147,7 +147,7 @@ __device__ __forceinline__ void load_station(Station<C, PF, UNI> &S, const Stati
         }
         S.probe_t = L.probe_t + lp; S.probe_v = L.probe_v + lp; S.pcap = L.pcap;
     }
-    S.trk = false; S.up = -1; S.inj_i = 0; S.inj_n = 0; S.IA = kInfNs; S.imask = 0; S.cur_pay = 0;
+    S.trk = false; S.up = -1; S.inj_i = 0; S.inj_n = 0; S.IA = kInfNs; S.imask = 0; S.cur_pay = 0; S.undecided = 0;
     S.rk_dp = 0; S.rk_rank = 0; S.rk_rc = INT64_MIN; S.tie_rank_p = P.tie_rank; S.n_rank = n;
     if constexpr (PF) {
         if (P.tabs != nullptr && P.tabs->tandem != nullptr) {            // tandem queues (hs_station.hpp `trk`)
@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
     if (lp == 0) {
         for (int k = 0; k < 15; ++k) tot->ev[k] = 0;
         tot->completed = 0; tot->received = 0; tot->final_time = start_ns; tot->cur_time = start_ns;
-        tot->overflow = 0; tot->qoverflow = 0; tot->done = 0;
+        tot->overflow = 0; tot->qoverflow = 0; tot->done = 0; tot->undecided = 0;
         tot->dbg[0] = tot->dbg[1] = tot->dbg[2] = tot->dbg[3] = 0; tot->not_done = 0;
     }
     if (lp >= n) return;
@@ -652,6 +652,14 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
             }
         }
         store_station<C, PF, UNI>(S, X, lp, n);
+        if constexpr (PF) {
+            if (S.trk) {     // tandem queues: what the election's tie check reads (TickTables::cand_key), and this LP's undecided orders
+                int64_t *ck = P.tabs->cand_key + (size_t)lp * 4;
+                ck[0] = mine.t; ck[1] = mine.t_created; ck[2] = mine.rcrt;
+                ck[3] = (int64_t)(uint32_t)mine.depth | ((int64_t)(mine.valid ? 1 : 0) << 32);
+                if (S.undecided) atomicOr(&tot->undecided, 1);
+            }
+        }
     }
 
     // ---- workgroup reduction of the per-run deltas -> engine totals
@@ -739,6 +747,26 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
         }
         if (cur <= end_ns) tot->cur_time = new_cur;
         tot->done = 0;   // self-resetting ticket
+        wave_c[0] = b;   // (for the tie check below)
+    }
+    if constexpr (PF) {
+        // Tandem queues: did the election rest on the construction rank?  Then another LP's candidate shares the winner's whole
+        // lineage key, and only the two events' ancestry decides which the reference pops first (Totals::undecided).
+        if (P.tabs != nullptr && P.tabs->tandem != nullptr && cur <= end_ns) {
+            __syncthreads();
+            const Candidate b = wave_c[0];
+            bool tie = false;
+            if (b.valid)
+                for (int q = tid; q < n; q += kBlock) {
+                    const int64_t *ck = P.tabs->cand_key + (size_t)q * 4;
+                    const int64_t t = __hip_atomic_load(&ck[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int64_t cr = __hip_atomic_load(&ck[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int64_t rc = __hip_atomic_load(&ck[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int64_t dv = __hip_atomic_load(&ck[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (q != b.lp && (dv >> 32) != 0 && t == b.t && cr == b.t_created && rc == b.rcrt && (int)(uint32_t)dv == b.depth) tie = true;
+                }
+            if (tie) atomicOr(&tot->undecided, 2);
+        }
     }
 }
 

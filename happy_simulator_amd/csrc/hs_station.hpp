@@ -197,7 +197,12 @@ struct Totals {                 // engine-wide accumulators (device memory)
     int overflow;
     int qoverflow;
     unsigned int done;          // last-block ticket
-    int pad;
+    // tandem queues: an order between events of DIFFERENT LPs was needed that the lineage key does not decide (the two were created
+    // in one nanosecond, equally many steps below roots that were created in one nanosecond as well -- lock-step constant
+    // arrivals and services).  The reference decides it by comparing those roots' ancestry, arbitrarily far back; the engine
+    // then repeats the run on the single-heap loop (hs_exact.hpp), which is the reference's algorithm.  bit 0: a forwarded Request
+    // against an event of the downstream Server, bit 1: the election of the event beyond end_ns.
+    int undecided;
     unsigned long long dbg[4];  // asynchronous engine telemetry: sum of wave iterations, max, groups run, waves
     unsigned long long not_done; // shard rounds of hs_net_async: LPs that still have work at or before end_ns
 };
@@ -323,6 +328,7 @@ struct Station {
     int64_t inj_i, inj_n, IA;   // IA: time of record inj_i (kInfNs: none left)
     int64_t *inj_i_p;
     uint32_t imask;             // forwards of the current nanosecond's run already taken as roots (bit j: record inj_i + j)
+    int undecided;              // Totals::undecided bit 0, this LP
     const int64_t *up_t, *up_created, *up_rc, *up_rrc, *up_rdr, *up_dep;
 
     // an event created by the one being processed: one step further from the group's root
@@ -638,6 +644,7 @@ struct Station {
         if ((int32_t)(da & 0xff) != dp) return (int32_t)(da & 0xff) < dp;
         const int64_t ra = up_rrc[k * ls];
         if (ra != rc) return ra < rc;
+        const_cast<Station *>(this)->undecided = 1;                                // (the roots' own ancestry would decide: Totals::undecided)
         return (int32_t)(da >> 8) < rank_of(pad);
     }
     // lineage of the LP's own pending root `w` as the election sees it (make_candidate)

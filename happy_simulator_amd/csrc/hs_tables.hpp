@@ -40,7 +40,8 @@ struct TickTables {
     // ---- tandem queues (Server(downstream=<Server>), hs_station.hpp "tandem"): further per-engine arrays that only the PF
     // instantiations read live behind this pointer as well, so that the headline kernels' argument list stays what it was.
     // null = the engine has no Server that forwards to a Server.
-    const int32_t *tandem;     // [2][n_lp]: [0][lp] the LP whose forwarded Requests arrive here (-1: none); [1][lp] the LP's pass
+    const int32_t *tandem;     // [3][n_lp]: [0][lp] the LP whose forwarded Requests arrive here (-1: none); [1][lp] the LP's pass;
+                               // [2][lp] the LP this LP's Server forwards to (-1: none)
     int64_t *inj_i;            // [n_lp] forwards of the upstream LP consumed so far
     // lineage of forward record m of an LP (its time / created_at are record m of the LP's sink_t / sink_created logs): when the
     // root of the nanosecond group the forward was created in was created, that root's own lineage (its root's creation time;
@@ -48,6 +49,9 @@ struct TickTables {
     int64_t *fw_rc, *fw_rrc, *fw_rdr, *fw_dep;
     // ... and the same root key for every entry of the in-group FIFO, plus the created_at an arriving forward carries.  [kQCap][n_lp]
     int64_t *q_rrc, *q_rdr, *q_pay;
+    // every LP's first event beyond end_ns as the electing launch saw it: the election's check for ties that the lineage key does
+    // not decide (hs_kernels.hpp hs_station_run, Totals::undecided).  [n_lp] {t, t_created, rcrt, depth | valid << 32}
+    int64_t *cand_key;
 };
 __device__ __forceinline__ int64_t tick_lookup(const int64_t *row, int64_t cap, int64_t k, int &overflow) {
     if (k < cap) return row[k];

@@ -303,6 +303,10 @@ class StationEngine:
     def run_until_async(self, end_ns: int):
         self._check(self._lib.hs_engine_run_until_async(self._h, int(end_ns)))
 
+    def tandem_path(self) -> int:
+        """0: no Server forwards to a Server; 1: passes of the station kernel; 2: the single-heap loop (include/hs_engine.h)."""
+        return int(self._lib.hs_engine_tandem_path(self._h))
+
     def synchronize(self):
         self._check(self._lib.hs_engine_synchronize(self._h))
 

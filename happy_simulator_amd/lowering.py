@@ -32,7 +32,7 @@ class UnsupportedTopology(NotImplementedError):
 class Station:
     """One station LP.  (A slotted class with shared empty tuples as defaults: lowering 65 536 chains builds 65 536 of these, and
     a dataclass with four list factories was a third of that time.)"""
-    __slots__ = ("probes", "source", "more_sources", "server", "sink", "router", "links", "link_ids")
+    __slots__ = ("probes", "source", "more_sources", "server", "sink", "router", "links", "link_ids", "next_server", "next_station")
 
     def __init__(self, source=None, server=None, sink=None):
         self.probes = ()            # the Probes sampling this station's entities (up to 4: engine slots)
@@ -43,6 +43,8 @@ class Station:
         self.router = None
         self.links = ()             # NetworkLink objects leaving this station (router order)
         self.link_ids = ()          # their indices in LoweredGraph.links
+        self.next_server = None     # tandem queues: Server(downstream=<Server>) -- that Server, and its station
+        self.next_station = -1
 
 
 class PlainChains:
@@ -189,6 +191,11 @@ class LoweredGraph:
                 a.svc_kind[i] = N.LAT_NO_SERVER
                 a.svc_mean_s[i] = 0.0
             a.egress[i] = N.EGRESS_SINK if st.sink is not None else N.EGRESS_NONE
+            if st.next_server is not None:                        # tandem queues (include/hs_engine.h downstream_lp)
+                if a.downstream_lp is None:
+                    a.downstream_lp = np.full(n, -1, np.int32)
+                a.egress[i] = N.EGRESS_SERVER
+                a.downstream_lp[i] = st.next_station
             for slot, src in enumerate(st.more_sources):
                 if a.src_more_kind is None:
                     a.src_more_kind = np.full((3, n), N.SRC_NONE, np.uint8)
@@ -334,6 +341,7 @@ def lower(sources: list, entities: list) -> LoweredGraph:
     used_sinks: dict[int, int] = {}
     used_links: dict[int, int] = {}
     used_routers: dict[int, int] = {}
+    fed_by: dict[int, str] = {}
 
     def check_sink(obj, owner):
         # one collector may hang behind several stations (`[Server(..., downstream=sink) for ...]`): every station logs its
@@ -372,6 +380,13 @@ def lower(sources: list, entities: list) -> LoweredGraph:
         elif isinstance(obj, NetworkLink):
             check_link(obj, owner)
             st.links = (*st.links, obj)
+        elif isinstance(obj, Server):
+            # tandem queues (components/server/server.py:271-272): the completion is the next Server's arrival, at the same instant
+            if id(obj) in fed_by:
+                raise UnsupportedTopology(f"server '{obj.name}' is the downstream of several Servers ('{fed_by[id(obj)]}' and "
+                                          f"{owner}): one upstream Server per Server is lowered")
+            fed_by[id(obj)] = owner
+            st.next_server = obj
         elif isinstance(obj, RandomRouter):
             if id(obj) in used_routers:
                 raise UnsupportedTopology(f"router '{obj.name}' has several upstreams (not lowered)")
@@ -463,6 +478,15 @@ def lower(sources: list, entities: list) -> LoweredGraph:
     g.stations.sort(key=order_key)
     station_of_server = {id(st.server): i for i, st in enumerate(g.stations) if st.server is not None}
 
+    for i, st in enumerate(g.stations):                     # tandem queues: the downstream Servers' stations
+        if st.next_server is None:
+            continue
+        st.next_station = station_of_server.get(id(st.next_server), -1)
+        if st.next_station < 0:
+            raise UnsupportedTopology(f"server '{st.server.name}' forwards to server '{st.next_server.name}', which is not listed in "
+                                      "`entities` of this Simulation")
+    if any(st.next_server is not None for st in g.stations) and (any(st.links or st.router is not None for st in g.stations)):
+        raise UnsupportedTopology("Server(downstream=<Server>) inside a network of NetworkLinks / RandomRouters is not lowered yet")
     # resolve link destinations (every Server is a station by now) in station order, router-target order
     for i, st in enumerate(g.stations):
         for lk in st.links:

@@ -289,6 +289,12 @@ int hs_abi_version(void);
 /* Number of visible HIP devices (0 when there is no GPU). */
 int hs_device_count(void);
 
+/* Tandem queues (hs_stations.downstream_lp): which path the engine is on -- 0 no tandem queues, 1 passes of the station kernel
+ * (upstream Servers first), 2 the single-heap loop (csrc/hs_exact.hpp): hs_engine_run_until repeats a run there when the passes
+ * met a same-nanosecond order between two Servers' events that their lineage key does not decide (lock-step constant arrivals
+ * and services), and tandem queues next to Probes / scheduled Requests / several Sources per Server start there. */
+int hs_engine_tandem_path(const hs_engine *h);
+
 int hs_engine_create(const hs_config *cfg, hs_engine **out);
 int hs_engine_set_stations(hs_engine *h, const hs_stations *st);
 /* Optional, after hs_engine_set_stations and before the first run: connect stations with links / routers.

@@ -436,6 +436,85 @@ def run_case(spec):
     return out, meta
 
 
+def run_tandem_case(spec):
+    """Tandem queues with reference components only: per chain `Source -> Server -> Server -> ... [-> Sink]`, every Server built
+    with `downstream=<the next Server>` (components/server/server.py:64-122,271-272).  Spec format, station numbering and stream
+    bases: tests/tandem_specs.py (one station per Server, chain-major; station i's entities draw from stream base i; the chain's
+    Source belongs to its first station).  Trace nodes: the station index (a Source: its chain's first station, a Sink: its
+    chain's last)."""
+    for d in (os.path.dirname(HERE), os.path.dirname(os.path.dirname(HERE))):
+        if d not in sys.path:
+            sys.path.insert(0, d)
+    import tandem_specs as TS
+
+    order, first = TS.station_index(spec)
+    seed = spec["seed"]
+    sources, entities, servers, sinks, node_of = [], [], {}, [], {}
+    for c, ch in enumerate(spec["chains"]):
+        n_st = len(ch["stages"])
+        sink = Sink(f"sink{c}") if ch["sink"] else None
+        nxt = sink
+        for st in reversed(range(n_st)):
+            sg = ch["stages"][st]
+            lat = (PhiloxExponentialLatency(sg["mean"], hs.Stream(seed, first[c] + st, hs.STREAM_SERVICE)) if sg["svc"] == "exp"
+                   else ConstantLatency(sg["mean"]))
+            nxt = servers[(c, st)] = Server(f"srv{c}_{st}", concurrency=sg["conc"], service_time=lat, queue_capacity=sg["qcap"],
+                                            downstream=nxt)
+        prof = ConstantRateProfile(rate=ch["rate"])
+        prov = (PhiloxPoissonArrival(prof, Instant.Epoch, hs.Stream(seed, first[c], hs.STREAM_ARRIVAL)) if ch["arr"] == "poisson"
+                else ConstantArrivalTimeProvider(prof, start_time=Instant.Epoch))
+        stop = None if ch["stop_after_s"] is None else Instant.from_seconds(ch["stop_after_s"])
+        src = Source(f"src{c}", SimpleEventProvider(servers[(c, 0)], "Request", stop), prov)
+        sources.append(src)
+        node_of[id(src)] = first[c]
+        for st in range(n_st):
+            sv = servers[(c, st)]
+            entities.append(sv)
+            for x in (sv, sv._queue, sv._driver, sv._worker):
+                node_of[id(x)] = first[c] + st
+        sinks.append(sink)
+        if sink is not None:
+            entities.append(sink)
+            node_of[id(sink)] = first[c] + n_st - 1
+    sim = Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=sources, entities=entities)
+    trace = []
+    heap = sim._event_heap
+    orig_pop = heap.pop
+
+    def pop():
+        e = orig_pop()
+        k, nd = classify(e, node_of)
+        trace.append((e.time.nanoseconds, k, nd, e._sort_index))
+        return e
+
+    heap.pop = pop
+    summary = sim.run()
+    n = len(order)
+    out = {k: np.zeros(n, np.int64) for k in ("accepted", "dropped", "completed", "rejected", "depth", "active")}
+    out["total_service_s"] = np.zeros(n, np.float64)
+    for i, (c, st) in enumerate(order):
+        sv = servers[(c, st)]
+        out["accepted"][i], out["dropped"][i] = sv.stats_accepted, sv.stats_dropped
+        out["completed"][i], out["rejected"][i] = sv._requests_completed, sv._requests_rejected
+        out["depth"][i], out["active"][i] = sv.depth, sv.active_requests
+        out["total_service_s"][i] = sv._total_service_time
+    out["generated"] = np.asarray([s.generated_count for s in sources], np.int64)
+    sink_t, sink_lat, sink_off = [], [], [0]
+    for sk in sinks:
+        if sk is not None:
+            sink_t.extend(t.nanoseconds for t in sk.completion_times)
+            sink_lat.extend(sk.latencies_s)
+        sink_off.append(len(sink_t))
+    out["sink_t_ns"] = np.asarray(sink_t, np.int64)
+    out["sink_latency_s"] = np.asarray(sink_lat, np.float64)
+    out["sink_off"] = np.asarray(sink_off, np.int64)
+    out["trace"] = np.asarray(trace, np.int64).reshape(-1, 4)
+    meta = dict(spec=spec, total_events=[summary.total_events_processed], final_ns=[sim._current_time.nanoseconds],
+                duration_s=[summary.duration_s])
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    return out, meta
+
+
 def run_ring_case(spec):
     """N stations on a ring, reference components only:
     Source.poisson(ext_rate) -> Server_i(Exp mean) -> RandomRouter_i([Sink_i, Link_i]);
@@ -707,6 +786,28 @@ def run_lb_case(spec):
     return out, meta
 
 
+def _stage(svc, mean, conc=1, qcap=None):
+    return dict(svc=svc, mean=mean, conc=conc, qcap=qcap)
+
+
+# Tandem queues (tests/tandem_specs.py): Philox streams, full traces.
+TANDEM_CASES = [
+    dict(name="tandem_2stage_philox", topology="tandem", end_s=20.0, seed=42, chains=[
+        dict(arr="poisson", rate=8.0, stop_after_s=None, sink=True, stages=[_stage("exp", 0.1), _stage("exp", 0.08)])]),
+    dict(name="tandem_lock_step_consts", topology="tandem", end_s=3.0, seed=7, chains=[
+        dict(arr="constant", rate=10.0, stop_after_s=None, sink=True, stages=[_stage("const", 0.1)] * 4),
+        dict(arr="constant", rate=10.0, stop_after_s=None, sink=True, stages=[_stage("const", 0.1), _stage("const", 0.0), _stage("const", 0.05, 2)]),
+        dict(arr="constant", rate=50.0, stop_after_s=None, sink=True,
+             stages=[_stage("const", 0.1, 3), _stage("const", 0.1, 1, 1), _stage("const", 0.0, 4), _stage("const", 0.05, 4)]),
+        dict(arr="constant", rate=10.0, stop_after_s=1.0, sink=False, stages=[_stage("const", 0.2, 2, 1), _stage("const", 0.1, 2, 1)])]),
+    dict(name="tandem_4stage_mixed", topology="tandem", end_s=10.0, seed=2026, chains=[
+        dict(arr="poisson", rate=12.0, stop_after_s=None, sink=True,
+             stages=[_stage("exp", 0.05, 2), _stage("const", 0.06), _stage("exp", 0.1, 3, 4), _stage("exp", 0.02)]),
+        dict(arr="constant", rate=16.0, stop_after_s=6.0, sink=True, stages=[_stage("exp", 0.05), _stage("exp", 0.05, 1, 2)]),
+        dict(arr="poisson", rate=8.0, stop_after_s=None, sink=True, stages=[_stage("exp", 0.1)]),
+        dict(arr="poisson", rate=20.0, stop_after_s=None, sink=False, stages=[_stage("exp", 0.03), _stage("exp", 0.04), _stage("const", 0.01)])]),
+]
+
 LB_CASES = [
     # the chash_example wiring: 1 source, 3 backends with concurrency 3, 150 vnodes, 200 clients
     dict(name="lb_chash_example", topology="lb", n_sources=1, n_backends=3, rate=30.0, mean=0.1, concurrency=3,
@@ -904,6 +1005,14 @@ def main(argv):
         np.savez_compressed(path, **out)
         print(f"{spec['name']}: events={sum(meta['total_events'])} final={meta['final_ns'][-1]} "
               f"sink_records={len(out['sink_t_ns'])} lb={out['lb_stats'].tolist()} -> {os.path.getsize(path)} B")
+    for spec in TANDEM_CASES:
+        if only and spec["name"] not in only:
+            continue
+        out, meta = run_tandem_case(dict(spec))
+        path = os.path.join(HERE, spec["name"] + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{spec['name']}: events={sum(meta['total_events'])} final={meta['final_ns'][-1]} "
+              f"sink_records={len(out['sink_t_ns'])} -> {os.path.getsize(path)} B")
     for spec in RING_CASES:
         if only and spec["name"] not in only:
             continue

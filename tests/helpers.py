@@ -16,7 +16,7 @@ def golden_names(topology="chains"):
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
 
     def topo(n):
-        return "ring" if n.startswith("ring_") else "lb" if n.startswith("lb_") else "chains"
+        return "ring" if n.startswith("ring_") else "lb" if n.startswith("lb_") else "tandem" if n.startswith("tandem_") else "chains"
 
     return [n for n in names if topo(n) == topology]
 

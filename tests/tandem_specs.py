@@ -38,6 +38,10 @@ def tandem_spec(k: int) -> dict:
     return dict(chains=chains, end_s=float(rng.choice([1.0, 2.0, 3.0, 5.0])), seed=int(rng.integers(1, 1 << 30)))
 
 
+def has_tandem(spec) -> bool:
+    return any(len(ch["stages"]) > 1 for ch in spec["chains"])
+
+
 def station_index(spec):
     """[(chain, stage)] in station order and chain -> first station."""
     order, first = [], []

@@ -27,11 +27,11 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_abi_version_and_struct_sizes(lib):
-    assert lib.hs_abi_version() == N.ABI_VERSION == 9
+    assert lib.hs_abi_version() == N.ABI_VERSION == 10
     assert C.sizeof(N.Config) == 56
     assert N.EV_KINDS == 15 and len(N.EV_NAMES) == 15
     assert C.sizeof(N.Summary) == 8 * (1 + 15 + 1 + 1 + 1 + 1) + 8 + 8 + 8 + 8 + 8
-    assert C.sizeof(N.Stations) == 26 * 8
+    assert C.sizeof(N.Stations) == 27 * 8
     assert C.sizeof(N.LbConfig) == 56 and C.sizeof(N.LbSources) == 56 and C.sizeof(N.LbBackends) == 64
     assert C.sizeof(N.LbStats) == 88
     assert C.sizeof(N.Network) == 152 and C.sizeof(N.NetStats) == 4 * 8

@@ -27,7 +27,11 @@ def _run_case(spec, windows=(), flags=0):
             eng.run_until(int(w * 1e9))
         eng.run_until(end)
         TS.compare(spec, eng, r, srcs, servers, sinks)
+        r.engine_path = eng.tandem_path()
     return r
+
+
+SINGLE_HEAP = 1 << 17      # debug flag: the whole run on the single-heap loop (csrc/hs_exact.hpp), as after an undecided tie
 
 
 def test_two_servers_in_a_row():
@@ -54,21 +58,35 @@ def test_lock_step_constants_share_every_nanosecond():
 
 @pytest.mark.parametrize("first", range(0, 200, 50))
 def test_random_tandems_match_the_oracle(first):
-    bad = []
+    bad, paths = [], {0: 0, 1: 0, 2: 0}
     for k in range(first, first + 50):
         try:
-            _run_case(TS.tandem_spec(k))
+            paths[_run_case(TS.tandem_spec(k)).engine_path] += 1
+            if k % 5 == 0:
+                assert _run_case(TS.tandem_spec(k), flags=SINGLE_HEAP).engine_path == (2 if TS.has_tandem(TS.tandem_spec(k)) else 0)
         except AssertionError as e:
             bad.append((k, str(e).strip().splitlines()[:3]))
     assert not bad, bad
+    print("paths (none / passes / single heap):", paths)
+    assert paths[1] > paths[2]            # the single heap is the exception: lock-step ties
 
 
 def test_several_windows_continue_the_chain():
     """run_until twice: the event the first window elected beyond its end (a completion whose forward is still pending, a
     forward's enqueue, ...) is part of the state the second window starts from."""
-    for k in (1, 4, 8, 12, 17, 20, 33):
+    for k in (1, 4, 8, 12, 17, 20, 33, 1196, 1756, 3892):
         spec = TS.tandem_spec(k)
         _run_case(spec, windows=(0.37 * spec["end_s"], 0.81 * spec["end_s"]))
+        _run_case(spec, windows=(0.37 * spec["end_s"], 0.81 * spec["end_s"]), flags=SINGLE_HEAP)
+
+
+def test_ties_the_lineage_key_does_not_decide_go_to_the_single_heap():
+    """The three cases of 3 000 (profiles/r03_gpu_sweep_tandem.log, first sweep) on which the passes alone differed from the
+    reference: lock-step constant chains whose Servers' events tie on (time, creation time, steps from the root, the root's creation
+    time) -- the reference decides by the roots' ancestry, arbitrarily far back (tools/election_rules.py --family tandem)."""
+    for k in (1196, 1756, 3892):
+        r = _run_case(TS.tandem_spec(k))
+        assert r.engine_path == 2
 
 
 def test_what_is_not_lowered_is_refused_by_name():
@@ -84,9 +102,115 @@ def test_what_is_not_lowered_is_refused_by_name():
     st = TS.engine_arrays(spec)
     with pytest.raises(N.EngineError, match="HS_MODE_SINGLE"):
         StationEngine(st, mode=N.MODE_REPLICAS, horizon_ns=10**9)
+
+
+# ---- through the reference-shaped API, against the live-reference goldens (tests/golden/tandem_*.npz) -----------------------------
+def _build_api(spec):
+    import happy_simulator_amd as hs
+
+    sources, entities, servers, sinks = [], [], {}, []
+    for c, ch in enumerate(spec["chains"]):
+        sink = hs.Sink(f"sink{c}") if ch["sink"] else None
+        nxt = sink
+        for st in reversed(range(len(ch["stages"]))):
+            sg = ch["stages"][st]
+            lat = hs.ExponentialLatency(sg["mean"]) if sg["svc"] == "exp" else hs.ConstantLatency(sg["mean"])
+            nxt = servers[(c, st)] = hs.Server(f"srv{c}_{st}", concurrency=sg["conc"], service_time=lat, queue_capacity=sg["qcap"],
+                                               downstream=nxt)
+        make = hs.Source.poisson if ch["arr"] == "poisson" else hs.Source.constant
+        sources.append(make(rate=ch["rate"], target=servers[(c, 0)], name=f"src{c}", stop_after=ch["stop_after_s"]))
+        entities += [servers[(c, st)] for st in range(len(ch["stages"]))]
+        if sink is not None:
+            entities.append(sink)
+        sinks.append(sink)
+    return sources, entities, servers, sinks
+
+
+@pytest.mark.parametrize("name", ["tandem_2stage_philox", "tandem_lock_step_consts", "tandem_4stage_mixed"])
+def test_tandem_queues_through_the_api_match_the_reference_golden(name):
+    import happy_simulator_amd as hs
+    import helpers as H
+
+    gold = H.Golden(name)
+    spec = gold.spec
+    sources, entities, servers, sinks = _build_api(spec)
+    summary = hs.Simulation(duration=spec["end_s"], sources=sources, entities=entities, seed=spec["seed"]).run()
+    assert summary.total_events_processed == gold.meta["total_events"][0]
+    assert summary.duration_s == gold.meta["duration_s"][0]
+    order, first = TS.station_index(spec)
+    for i, (c, st) in enumerate(order):
+        sv = servers[(c, st)]
+        assert sv.stats_accepted == gold.accepted[i] and sv.stats_dropped == gold.dropped[i], (c, st)
+        assert sv.stats.requests_completed == gold.completed[i] and sv.depth == gold.depth[i], (c, st)
+        assert sv.stats.total_service_time == gold.total_service_s[i], (c, st)
+        assert sv.active_requests == gold.active[i], (c, st)
+    for c, src in enumerate(sources):
+        assert src.generated_count == gold.generated[c]
+        t, lat = gold.sink_records(c)
+        if sinks[c] is None:
+            continue
+        assert sinks[c].events_received == len(t)
+        np.testing.assert_array_equal(sinks[c].completion_ns, t)
+        assert sinks[c].latencies_s == lat.tolist()
+
+
+def test_api_refusals_name_what_is_missing():
+    import happy_simulator_amd as hs
+
+    sink = hs.Sink()
+    b = hs.Server("b", service_time=hs.ExponentialLatency(0.05), downstream=sink)
+    a1 = hs.Server("a1", service_time=hs.ExponentialLatency(0.05), downstream=b)
+    a2 = hs.Server("a2", service_time=hs.ExponentialLatency(0.05), downstream=b)
+    s1, s2 = hs.Source.poisson(rate=5, target=a1, name="s1"), hs.Source.poisson(rate=5, target=a2, name="s2")
+    with pytest.raises(hs.UnsupportedTopology, match="one upstream Server per Server"):
+        hs.Simulation(duration=1.0, sources=[s1, s2], entities=[a1, a2, b, sink]).run()
+    b = hs.Server("b", service_time=hs.ExponentialLatency(0.05), downstream=hs.Sink())
+    a = hs.Server("a", service_time=hs.ExponentialLatency(0.05), downstream=b)
+    with pytest.raises(hs.UnsupportedTopology, match="not listed in `entities`"):
+        hs.Simulation(duration=1.0, sources=[hs.Source.poisson(rate=5, target=a)], entities=[a]).run()
+
+
+def test_probes_and_scheduled_requests_next_to_tandem_queues():
+    """Probes on Servers of a chain and Requests injected with Simulation.schedule() into its second Server: pre-run events whose
+    sort indices run-time events can overtake (csrc/hs_exact.hpp) -- such engines run on the single heap from the start."""
+    from happy_simulator_amd import _native as N
+    from happy_simulator_amd.engine import StationEngine
+
+    spec = dict(chains=[dict(arr="poisson", rate=12.0, stop_after_s=None, sink=True,
+                             stages=[dict(svc="exp", mean=0.05, conc=1, qcap=None), dict(svc="exp", mean=0.07, conc=2, qcap=3),
+                                     dict(svc="const", mean=0.02, conc=1, qcap=None)]),
+                        dict(arr="constant", rate=10.0, stop_after_s=None, sink=True,
+                             stages=[dict(svc="const", mean=0.1, conc=1, qcap=None), dict(svc="const", mean=0.1, conc=1, qcap=None)])],
+                end_s=6.0, seed=11)
+    g, srcs, servers, sinks = TS.oracle_graph(spec)
+    probes = [((0, 1), "depth", 0.25), ((0, 0), "completed", 0.5), ((1, 1), "active", 0.1)]
+    metric_id = {"depth": N.PROBE_METRICS["depth"], "completed": N.PROBE_METRICS["requests_completed"], "active": N.PROBE_METRICS["active_requests"]}
+    pnodes = [g.probe(servers[cs], metric_id[m], iv) for cs, m, iv in probes]
+    sched = [((0, 1), 1.0), ((0, 1), 1.0), ((1, 1), 2.5), ((0, 2), 0.0)]
+    end = int(spec["end_s"] * 1e9)
+    r = O.run(g, end, seed=spec["seed"], schedule=[(servers[cs], int(t * 1e9)) for cs, t in sched])
     st = TS.engine_arrays(spec)
+    order, first = TS.station_index(spec)
+    lp_of = {cs: i for i, cs in enumerate(order)}
     st.probe_metric = np.full(st.n, N.PROBE_NONE, np.uint8)
-    st.probe_metric[1] = 0
-    st.probe_interval_s = np.full(st.n, 0.1)
-    with pytest.raises(N.EngineError, match="not lowered yet"):
-        StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=10**9)
+    st.probe_interval_s = np.ones(st.n)
+    for cs, m, iv in probes:
+        st.probe_metric[lp_of[cs]], st.probe_interval_s[lp_of[cs]] = metric_id[m], iv
+    st.probe_order = np.array([lp_of[cs] for cs, _, _ in probes], np.int32)
+    per = [[] for _ in range(st.n)]
+    for rank, (cs, t) in enumerate(sched):
+        per[lp_of[cs]].append((int(t * 1e9), rank))
+    for lst in per:
+        lst.sort(key=lambda x: x[0])
+    st.sched_off = np.concatenate([[0], np.cumsum([len(x) for x in per])]).astype(np.int64)
+    st.sched_time_ns = np.array([t for lst in per for t, _ in lst], np.int64)
+    st.sched_rank = np.array([rk for lst in per for _, rk in lst], np.int64)
+    with StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=end, seed=spec["seed"]) as eng:
+        eng.run_until(end)
+        assert eng.tandem_path() == 2
+        TS.compare(spec, eng, r, srcs, servers, sinks)
+        for (cs, _m, _iv), nd in zip(probes, pnodes):
+            t, v = r.sinks[nd]
+            pt, pv = eng.read_probe(lp_of[cs])
+            np.testing.assert_array_equal(pt, t)
+            np.testing.assert_array_equal(pv, v)

@@ -186,6 +186,44 @@ def check_oracle_against_lb_golden(gold):
         np.testing.assert_array_equal(got, gold.trace)
 
 
+@pytest.mark.parametrize("name", H.golden_names("tandem"))
+def test_oracle_matches_reference_tandem_golden(name):
+    check_oracle_against_tandem_golden(H.Golden(name))
+
+
+def check_oracle_against_tandem_golden(gold):
+    """Tandem queues, `Server(downstream=<Server>)` (tests/tandem_specs.py; make_golden.run_tandem_case): the oracle against the
+    reference on every Server's statistics, every Sink record and the whole processed-event trace with sort indices."""
+    import tandem_specs as TS
+
+    spec = gold.spec
+    order, first = TS.station_index(spec)
+    g, srcs, servers, sinks = TS.oracle_graph(spec)
+    r = O.run(g, int(spec["end_s"] * 1e9), seed=spec["seed"], trace_cap=len(gold.trace) + 16)
+    assert [r.events_processed] == gold.meta["total_events"]
+    assert [r.final_time_ns] == gold.meta["final_ns"]
+    for i, (c, st) in enumerate(order):
+        nd = servers[(c, st)]
+        for k in ("accepted", "dropped", "completed", "rejected", "depth", "active"):
+            assert getattr(r, k)[nd] == gold.arrays[k][i], (k, c, st)
+        assert r.total_service_s[nd] == gold.total_service_s[i], ("total_service_s", c, st)
+    np.testing.assert_array_equal([r.generated[s] for s in srcs], gold.generated)
+    for c, ch in enumerate(spec["chains"]):
+        gt, glat = gold.sink_records(c)
+        if sinks[c] < 0:
+            assert len(gt) == 0
+            continue
+        t, cr = r.sinks[sinks[c]]
+        np.testing.assert_array_equal(t, gt)
+        np.testing.assert_array_equal((t - cr) / 1e9, glat)            # latency_s = (t - created_at).to_seconds()
+    node_station = {srcs[c]: first[c] for c in range(len(srcs))}
+    node_station.update({nd: first[c] + st for (c, st), nd in servers.items()})
+    node_station.update({sinks[c]: first[c] + len(ch["stages"]) - 1 for c, ch in enumerate(spec["chains"]) if sinks[c] >= 0})
+    t, k, nd, ix = r.trace
+    got = np.stack([t, k.astype(np.int64), np.array([node_station[x] for x in nd], np.int64), ix], axis=1)
+    np.testing.assert_array_equal(got, gold.trace)
+
+
 def test_oracle_md5_known_answers():
     """RFC 1321 appendix A.5 test suite + lengths around the 56/64-byte padding boundary."""
     import hashlib

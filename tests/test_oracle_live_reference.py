@@ -11,7 +11,7 @@ import pytest
 
 import helpers as H
 from test_oracle_golden import (check_oracle_against_lb_golden, check_oracle_against_ring_golden,
-                                check_oracle_against_station_golden)
+                                check_oracle_against_station_golden, check_oracle_against_tandem_golden)
 
 pytestmark = pytest.mark.live_reference
 
@@ -87,3 +87,13 @@ def test_oracle_equals_live_reference_with_probes_on_load_balancer_graphs(k):
 def test_oracle_equals_live_reference_with_profiles_on_load_balancer_sources(k):
     out, meta = MG.run_lb_case(lb_profile_spec(k))
     check_oracle_against_lb_golden(H.Golden.from_results(out, meta))
+
+
+@pytest.mark.parametrize("k", range(60))
+def test_oracle_equals_live_reference_on_random_tandem_queues(k):
+    """Server(downstream=<Server>), up to four in a row (tests/tandem_specs.py; every fourth case a lock-step tie storm): the
+    cases tests/test_gpu_tandem.py runs engine == oracle on MI355X."""
+    import tandem_specs as TS
+
+    out, meta = MG.run_tandem_case(TS.tandem_spec(k))
+    check_oracle_against_tandem_golden(H.Golden.from_results(out, meta))

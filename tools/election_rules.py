@@ -173,12 +173,48 @@ def ring_candidates(spec, rows, nodes):
     return ref_lp, list(best.values())
 
 
+def run_tandem(spec):
+    import tandem_specs as TS
+
+    g, srcs, servers, sinks = TS.oracle_graph(spec)
+    O.run(g, int(spec["end_s"] * 1e9), seed=spec["seed"])
+    return srcs, servers
+
+
+def tandem_candidates(spec, rows, nodes):
+    """Tandem queues (tests/tandem_specs.py): one LP per Server, the chain's Source on its first Server's LP; the rank of an LP
+    = its chain's position in `sources=[...]`, upstream Servers first (csrc/hs_engine.hip tie_rank of a tandem engine)."""
+    import tandem_specs as TS
+
+    srcs, servers = nodes
+    order, first = TS.station_index(spec)
+    where, rank = {}, {}
+    for c, nd in enumerate(srcs):
+        where[nd] = first[c]
+        rank[nd] = c * 8
+    for (c, st), nd in servers.items():
+        where[nd] = first[c] + st
+        rank[nd] = c * 8 + st
+    t_star = rows[0, 0]
+    best = {}
+    for t, idx, kind, node, crt, crt2, crt3, cdepth, rcrt, rcdepth, r2crt, r2cdepth in rows:
+        if t != t_star or node not in where:
+            continue
+        lp = where[node]
+        if lp not in best or idx < best[lp]["idx"]:
+            best[lp] = dict(lp=lp, idx=int(idx), kind=int(kind), crt=int(crt), crt2=int(crt2), crt3=int(crt3), cdepth=int(cdepth),
+                            rcrt=int(rcrt), rcdepth=int(rcdepth), r2crt=int(r2crt), r2cdepth=int(r2cdepth), rank=rank[node],
+                            old_rank=lp, rank2=rank[node])
+    ref_lp = where.get(rows[0, 3])
+    return ref_lp, list(best.values())
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--count", type=int, default=1000)
     ap.add_argument("--verbose", action="store_true", help="print the candidates of every case a key gets wrong")
-    ap.add_argument("--family", choices=("tie", "multi_source", "multi_source_ring"), default="tie",
+    ap.add_argument("--family", choices=("tie", "multi_source", "multi_source_ring", "tandem"), default="tie",
                     help="tests/random_specs.py tie_spec, multi_source_spec (several Sources per Server, two list orders) or "
                          "multi_source_ring_spec (the same on rings: the network engines' election)")
     a = ap.parse_args()
@@ -195,6 +231,11 @@ def main():
             if a.family == "multi_source_ring":
                 spec = RS.multi_source_ring_spec(k)
                 rows, nodes = pending_at_overshoot(spec, run_ring)
+            elif a.family == "tandem":
+                import tandem_specs as TS
+
+                spec = TS.tandem_spec(k)
+                rows, nodes = pending_at_overshoot(spec, run_tandem)
             else:
                 spec = RS.tie_spec(k) if a.family == "tie" else RS.multi_source_spec(k)
                 if spec["mode"] != "single":
@@ -206,7 +247,8 @@ def main():
             if rows is None or len(rows) == 0:
                 skipped += 1                         # nothing beyond end_time
                 continue
-            ref_lp, cands = ring_candidates(spec, rows, nodes) if a.family == "multi_source_ring" else candidates(spec, rows, runs)
+            ref_lp, cands = (ring_candidates(spec, rows, nodes) if a.family == "multi_source_ring" else
+                             tandem_candidates(spec, rows, nodes) if a.family == "tandem" else candidates(spec, rows, runs))
             if ref_lp is None:
                 skipped += 1
                 continue

@@ -109,8 +109,16 @@ def lb_profiles(k):
     _lb(RS.lb_profile_spec(k))
 
 
+def tandem(k):
+    import tandem_specs as TS
+    from test_gpu_tandem import _run_case
+
+    spec = TS.tandem_spec(k)
+    _run_case(spec, windows=() if k % 3 else (0.37 * spec["end_s"], 0.81 * spec["end_s"]))
+
+
 FAMILIES = [station, tie, multi_source, ring_async, ring_windowed, multi_source_ring_async, multi_source_ring_windowed, lb,
-            lb_probes, lb_profiles]
+            lb_probes, lb_profiles, tandem]
 # (round 2 listed 13 tie storms here -- the cross-LP election of the one event beyond end_time, closed by the lineage key)
 KNOWN = set()
 # refused by design (HS_E_UNSUPPORTED), never guessed: a probe on the nanosecond of an event of its target on a load-balancer

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 sys.path.insert(0, ROOT)
 
-FAMILIES = ("station", "tie", "multi_source", "ring", "multi_source_ring", "lb", "lb_probes", "lb_profiles")
+FAMILIES = ("station", "tie", "multi_source", "ring", "multi_source_ring", "lb", "lb_probes", "lb_profiles", "tandem")
 
 
 def one(job):
@@ -25,8 +25,14 @@ def one(job):
     import make_golden as MG
     import random_specs as RS
     from test_oracle_golden import (check_oracle_against_lb_golden, check_oracle_against_ring_golden,
-                                    check_oracle_against_station_golden)
+                                    check_oracle_against_station_golden, check_oracle_against_tandem_golden)
     try:
+        if fam == "tandem":
+            import tandem_specs as TS
+
+            out, meta = MG.run_tandem_case(TS.tandem_spec(k))
+            check_oracle_against_tandem_golden(H.Golden.from_results(out, meta))
+            return fam, k, ""
         if fam in ("station", "tie", "multi_source"):
             spec = {"station": RS.station_spec, "tie": RS.tie_spec, "multi_source": RS.multi_source_spec}[fam](k)
             if spec["mode"] == "replicas":
