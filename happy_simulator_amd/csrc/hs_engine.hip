@@ -818,6 +818,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if ((rc = dev_alloc(h, &h->xs_host.init_t, (size_t)n * (size_t)n_init_lp))) return rc;
         if ((rc = dev_alloc(h, &h->xs, (size_t)n + 1))) return rc;
         h->exact = true;
+        h->exact_prologue = true;
     }
     if (h->cfg.mode == HS_MODE_SINGLE && (n_sched > 0 || h->any_probe || h->any_xsrc || !tandem.empty())) {
         // The prologue (hs_exact.hpp): the reference's pre-run events in the order it constructs them.  (Tandem queues: the same
