@@ -126,9 +126,18 @@ class TestLowering:
             hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=Custom("x"))]).lowered()
         with pytest.raises(hs.UnsupportedTopology, match="not lowered"):
             hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=hs.Sink())], entities=[Custom("x")]).lowered()
-        tandem = hs.Server("t1", downstream=hs.Server("t2"))
-        with pytest.raises(hs.UnsupportedTopology, match="forwards to Server"):
+        t2 = hs.Server("t2")
+        tandem = hs.Server("t1", downstream=t2)
+        with pytest.raises(hs.UnsupportedTopology, match="not listed in `entities`"):        # (the reference would leave t2 without a clock)
             hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=tandem)]).lowered()
+        # tandem queues ARE lowered: one station per Server, the upstream one's egress is the downstream one's station
+        a = hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=tandem)], entities=[tandem, t2]).lowered().arrays()
+        assert a.egress.tolist() == [N.EGRESS_SERVER, N.EGRESS_NONE] and a.downstream_lp.tolist() == [1, -1]
+        assert a.src_kind.tolist() == [N.SRC_POISSON, N.SRC_NONE]
+        t3 = hs.Server("t3", downstream=t2)
+        with pytest.raises(hs.UnsupportedTopology, match="one upstream Server per Server"):
+            hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=tandem), hs.Source.poisson(1, target=t3)],
+                          entities=[tandem, t3, t2]).lowered()
         with pytest.raises(hs.UnsupportedTopology, match="not a lowered Probe"):
             hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=hs.Sink())], probes=[object()]).lowered()
 
