@@ -51,7 +51,11 @@ __device__ __forceinline__ int64_t shfl_i64(int64_t v, int src) {
 
 }  // namespace
 
-constexpr int kWideBlock = 192;    // three wavefronts per workgroup, one per role (values / arrival chain / the rest), one barrier per step
+#ifndef HS_WIDE_T_ROLE
+#define HS_WIDE_T_ROLE 1          // which wavefront sums the service times: 1 the chain's, 0 the values', 3 one of its own
+#endif
+constexpr int kWideTRole = HS_WIDE_T_ROLE;
+constexpr int kWideBlock = kWideTRole == 3 ? 256 : 192;    // one wavefront per role (values / arrival chain / the rest [/ service-time sum]), one barrier per step
 
 struct WideCtl {                   // device memory: what hs_station_wide leaves for hs_station_wide_finish
     unsigned int n_bail;           // LPs that bailed (same-nanosecond hazards), listed in bail[]
@@ -67,8 +71,14 @@ __device__ __forceinline__ double dpp_shr(double v) {   // lane i <- lane i - N 
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
-template <int K, int Q = 2>
-__global__ void __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(3))) hs_station_wide(StationParams P, StationState X, RecordLogs L, Totals *tot,
+#ifndef HS_WIDE_Q
+#define HS_WIDE_Q 2
+#endif
+#ifndef HS_WIDE_WPE
+#define HS_WIDE_WPE (kWideBlock / 64)
+#endif
+template <int K, int Q = HS_WIDE_Q>
+__global__ void __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(HS_WIDE_WPE))) hs_station_wide(StationParams P, StationState X, RecordLogs L, Totals *tot,
                                                               Candidate *cands, WideCtl *ctl, int32_t *bail, int n,
                                                               int64_t end_ns, int flags) {
     static_assert(K == 4 || K == 8 || K == 16, "a group of lanes lives inside one DPP row of 16 lanes");
@@ -219,10 +229,20 @@ __global__ void __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu
     while (__syncthreads_or(role == 2 && !fin)) {
         const int cb = it & 1;
         HS_WCYC_BEGIN
-        if (role == 0) { produce_step(); r0 += R; ++it; HS_WCYC_END continue; }   // V of step it + 3
+        if (role == 0) {                                                         // V of step it + 3
+            produce_step();
+            if (kWideTRole == 0 && it > 0) service_sum(s_ndp[cb ^ 1][g], r0 - R);
+            r0 += R; ++it; HS_WCYC_END continue;
+        }
         if (role == 1) {
             chain(cb ^ 1, r0 + R);                                               // C of step it + 1 (speculative beyond the LP's last arrival: harmless)
-            if (it > 0) service_sum(s_ndp[cb ^ 1][g], r0 - R);                   // T of step it - 1
+            if (kWideTRole == 1 && it > 0) service_sum(s_ndp[cb ^ 1][g], r0 - R);   // T of step it - 1
+            r0 += R; ++it;
+            HS_WCYC_END
+            continue;
+        }
+        if (role == 3) {
+            if (it > 0) service_sum(s_ndp[cb ^ 1][g], r0 - R);
             r0 += R; ++it;
             HS_WCYC_END
             continue;
@@ -309,7 +329,7 @@ __global__ void __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu
         if (role == 2) atomicAdd(&tot->dbg[3], __builtin_readcyclecounter() - cyc_t0);
     }
 #endif
-    if (role == 1) {                                     // T of the last step, then hand the sum over
+    if (role == kWideTRole) {                            // T of the last step, then hand the sum over
         if (it > 0) service_sum(s_ndp[(it & 1) ^ 1][g], r0 - R);
         if (j == 0) s_ts[g] = total_service;
     }

@@ -149,13 +149,45 @@ __device__ __forceinline__ void block_min_cand(LbCand c, LbCand *wc, LbCand *out
 // 1. Sources.  Source.handle_event (load/source.py:142-180) with a client-id request factory
 //    (examples/visual/chash_example.py:69-88) and ConsistentHash.select as a table lookup.
 // ---------------------------------------------------------------------------------------------
+// The stream values of the Sources' ticks, produced by a kernel of their own (round 3): the inter-arrival increment E_d / rate and
+// the backend of client-id draw d are pure functions of (seed, Source, d), so one thread per (pair of ticks, Source) computes them
+// with the whole device -- hs_lbk_sources, one lane per Source and therefore half the SIMDs idle, keeps only the serial ns
+// recursion and the log appends.  [tick][source] layout: the consumers' reads are coalesced.  `n_pre` ticks per Source are
+// produced (mean + 5 sigma of the busiest Source); a Source that needs more computes them itself.
+__global__ void __launch_bounds__(256) hs_lb_source_draws(LbSrc P, int S, uint64_t seed, const int32_t *__restrict__ client_be,
+                                                          int64_t n_table, int64_t n_pre, double *__restrict__ dinc,
+                                                          int32_t *__restrict__ dbe) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t pair = i / S;
+    const int s = (int)(i - pair * S);
+    if (2 * pair >= n_pre) return;
+    const uint32_t kind = P.kind[s];
+    const double rate = P.rate[s];
+    const double nclients = (double)P.n_clients[s];
+    const uint64_t sa = stream_id(P.base[s], kStreamArrival), sk = stream_id(P.base[s], kStreamKey);
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    double inc0, inc1;
+    if (kind == HS_SRC_POISSON) {
+        const U4 o = philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), (uint32_t)sa, (uint32_t)(sa >> 32), k0, k1);
+        inc0 = __ddiv_rn(exp1_from_uniform(res53(o.x, o.y)), rate);
+        inc1 = __ddiv_rn(exp1_from_uniform(res53(o.z, o.w)), rate);
+    } else { inc0 = __ddiv_rn(1.0, rate); inc1 = inc0; }
+    const U4 q = philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), (uint32_t)sk, (uint32_t)(sk >> 32), k0, k1);
+    const int64_t c0 = __double2ll_rz(__dmul_rn(res53(q.x, q.y), nclients));
+    const int64_t c1 = __double2ll_rz(__dmul_rn(res53(q.z, q.w), nclients));
+    const size_t o0 = (size_t)(2 * pair) * (size_t)S + (size_t)s, o1 = o0 + (size_t)S;
+    dinc[o0] = inc0; dbe[o0] = (c0 >= 0 && c0 < n_table) ? client_be[c0] : -1;
+    if (2 * pair + 1 < n_pre) { dinc[o1] = inc1; dbe[o1] = (c1 >= 0 && c1 < n_table) ? client_be[c1] : -1; }
+}
+
 // PF: some Source has a time-varying profile -- its next arrival is the reference's numerical inversion (hs_profile.hpp), a
 // separate instantiation so that the common one carries no scratch frame.
 template <bool PF>
 __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint64_t seed, int64_t start_ns, int64_t end_ns,
                                                           const int32_t *__restrict__ client_be, int64_t n_table,
                                                           uint64_t *__restrict__ keys, uint64_t *__restrict__ vals,
-                                                          int64_t cap, int tb, LbTotals *tot) {
+                                                          int64_t cap, int tb, LbTotals *tot, const double *__restrict__ dinc,
+                                                          const int32_t *__restrict__ dbe, int64_t n_pre, int f64_times) {
     __shared__ LbCand wc[kLbBlock / 64];
     const int s = blockIdx.x * kLbBlock + threadIdx.x;
     const bool live = s < S;
@@ -179,7 +211,11 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
         // returns Requests, draws client id number d.  Both streams are therefore indexed by the tick number: the
         // expensive part (Philox, hs_log, the division, the client -> backend lookup) is produced eight ticks at a time
         // in straight-line code -- independent chains the SIMD can overlap -- and only the ns recursion is serial.
-        constexpr int kChunk = 8;
+        constexpr int kChunk = 16;
+        // (f64_times: every time of the run is a whole number of ns below 2^51, so the recursion runs on binary64 integers --
+        //  hs_device.hpp ns_from_seconds_d: 8 dependent fp64 instructions per tick instead of ~60 with the i64 <-> f64 conversion
+        //  sequences; the int64 the logs need is converted off the chain.  Round 3: the chain was 0.67 us per tick per wavefront.)
+        double arr_d = (double)start_ns;
         int64_t arr_time = start_ns, t_prev = start_ns;
         int64_t root_crt = start_ns;         // creation time of the SourceEvent that heads the current same-ns chain
         uint32_t depth = 0;
@@ -187,9 +223,27 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
         uint32_t dp_a2 = 0;                  // ... rc_a2, dp_a2 steps before it (0: constructed before run())
         int64_t A = kInfNs;
         bool done = false, dead = false;
+        // (the produced values of chunk c + 1 are in flight while chunk c runs: with one wavefront per two SIMDs nothing else
+        //  hides a load's latency, and a chunk's eight loads issued when the chunk begins cost one round trip per eight ticks)
+        double inc_n[kChunk];
+        int32_t be_n[kChunk];
+        auto fetch = [&](uint64_t d0) {
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j) {
+                const bool in = (int64_t)(d0 + kChunk) <= n_pre;
+                const size_t o = in ? (size_t)(d0 + j) * (size_t)S + (size_t)s : (size_t)s;
+                inc_n[j] = in ? dinc[o] : 0.0; be_n[j] = in ? dbe[o] : -1;
+            }
+        };
+        if (n_pre >= kChunk) fetch(0);
         for (uint64_t d0 = 0; !done; d0 += kChunk) {
             double inc[kChunk];
             int32_t be[kChunk];
+            if ((int64_t)(d0 + kChunk) <= n_pre) {                       // the values hs_lb_source_draws produced
+#pragma unroll
+                for (int j = 0; j < kChunk; ++j) { inc[j] = inc_n[j]; be[j] = be_n[j]; }
+                fetch(d0 + kChunk);
+            } else
 #pragma unroll
             for (int j = 0; j < kChunk; j += 2) {
                 const uint64_t blk = (d0 + j) >> 1;
@@ -215,6 +269,9 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
                     a2 = timevarying ? (d < (uint64_t)P.tab_cap ? tab[d] : (over = 1, kInfNs))   // load/arrival_time_provider.py:84-144
                                      : ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc[j]));
                     if (a2 == kInfNs) { done = true; dead = true; continue; }        // the rate is zero from here on: the Source ends
+                } else if (f64_times) {
+                    arr_d = ns_from_seconds_d(__dadd_rn(seconds_from_ns_d(arr_d), inc[j]));
+                    a2 = i64_from_whole_d(arr_d);
                 } else a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc[j]));
                 arr_time = a2;
                 if (d > 0) {
@@ -1173,6 +1230,8 @@ struct hs_lb {
     int32_t *client_be = nullptr;
     int64_t n_table = 0, cap = 0, n_slots = 0;
     uint64_t *keys0 = nullptr, *vals0 = nullptr;      // [cap][S] arrival logs
+    int64_t n_pre = 0;                                 // ticks per Source whose stream values hs_lb_source_draws produces
+    bool f64_times = false;                            // every time of a run is a whole ns in [0, 2^51): exact in binary64
     uint64_t *kA = nullptr, *vA = nullptr, *kB = nullptr, *vB = nullptr;   // dense ping-pong buffers [n_slots]
     uint64_t *skey = nullptr, *sval = nullptr;        // where the sorted arrivals ended up
     uint64_t *mkey = nullptr, *mslot = nullptr;       // where the merged Sink order ended up
@@ -1191,6 +1250,8 @@ struct hs_lb {
     bool any_no_sink = false;                          // some backend has no Sink behind it: no completion log (probes refused)
     int64_t *n_slots_dev = nullptr, *n_arr = nullptr, *n_done = nullptr, *n_tmp = nullptr;
     uint32_t *hist = nullptr, *row_total = nullptr, *digit_base = nullptr;
+    uint32_t *ghist = nullptr, *tickets = nullptr;     // hs_radix.hpp round 3: digit histograms of all passes, tile tickets per pass
+    int *radix_err = nullptr;                          // a look-back gave up (bounded spin)
     int n_tiles = 0;
     LbProbes Q{};                                     // probes (hs_lb_set_probes); n == 0: none
     std::vector<int64_t> src_stop_h;                  // stop_after of every Source (host copy: probes on stopping Sources are refused)
@@ -1273,6 +1334,40 @@ void radix_sort_async(hs_lb *h, const uint64_t *k_in, const uint64_t *v_in, cons
     const bool startB = keep_through_pass0 == h->kA;
     uint64_t *ko = startB ? h->kB : h->kA, *vo = startB ? h->vB : h->vA;
     const uint64_t *ki = k_in, *vi = v_in;
+    if (h->ghist == nullptr) {       // (the one-off sorts of hs_debug_radix_sort / hs_merge_sink_records / the latency statistics)
+        if (lalloc(h, &h->ghist, (size_t)kRadixMaxPasses * kRadixBins) || lalloc(h, &h->tickets, (size_t)kRadixMaxPasses) ||
+            lalloc(h, &h->radix_err, (size_t)1)) h->ghist = nullptr;
+        else { hipMemset(h->tickets, 0, kRadixMaxPasses * sizeof(uint32_t)); hipMemset(h->radix_err, 0, sizeof(int)); }
+    }
+    if ((h->flags & 16) != 0 && passes <= kRadixMaxPasses && h->ghist != nullptr) {
+        // debug flag 16 (hs_radix.hpp, round 3): one histogram read for all passes, then one look-back scatter per pass.  Measured on
+        // MI355X at the configs[4] size: a dense pass 162 us instead of 101 + 35 (histogram) + 23 (scans) -- the tiles of a launch
+        // start together, so a tile's look-back walks hundreds of aggregates, and every descriptor load is a device-scope access
+        // that leaves its XCD's L2 (8 XCDs, one L2 each): ~1 us per window of 16.  The three-kernels-per-pass sort stays the default.
+        hipMemsetAsync(h->ghist, 0, (size_t)kRadixMaxPasses * kRadixBins * sizeof(uint32_t), h->stream);
+        const int hist_blocks = tiles0 < 1024 ? tiles0 : 1024;
+        hipLaunchKernelGGL((radix_hist_all<Valid>), dim3((unsigned)hist_blocks), blk, 0, h->stream, ki, n_in_dev, shift0, passes, h->ghist, valid);
+        hipLaunchKernelGGL(radix_digit_bases, dim3(1), blk, 0, h->stream, h->ghist, passes, n_out_dev, h->tickets);
+        h->launches += 2;
+        for (int p = 0; p < passes; ++p) {
+            const int shift = shift0 + p * kRadixBits;
+            const int64_t *n_dev = p == 0 ? n_in_dev : n_out_dev;
+            const int nt = p == 0 ? tiles0 : (tiles_rest < h->n_tiles ? tiles_rest : h->n_tiles);
+            hipMemsetAsync(h->hist, 0, (size_t)nt * kRadixBins * sizeof(uint32_t), h->stream);     // the pass's tile descriptors
+            if (p == 0)
+                hipLaunchKernelGGL((radix_scatter_lb<Valid, MakeVal>), dim3((unsigned)nt), blk, 0, h->stream, ki, vi, ko, vo, n_dev, shift,
+                                   h->ghist + p * kRadixBins, h->hist, h->tickets + p, h->radix_err, valid, mk);
+            else
+                hipLaunchKernelGGL((radix_scatter_lb<RadixAll, NoVal>), dim3((unsigned)nt), blk, 0, h->stream, ki, vi, ko, vo, n_dev, shift,
+                                   h->ghist + p * kRadixBins, h->hist, h->tickets + p, h->radix_err, RadixAll{}, NoVal{});
+            h->launches += 2;
+            ki = ko; vi = vo;
+            if (ko == h->kA) { ko = h->kB; vo = h->vB; } else { ko = h->kA; vo = h->vA; }
+        }
+        *k_res = const_cast<uint64_t *>(ki);
+        *v_res = const_cast<uint64_t *>(vi);
+        return;
+    }
     for (int p = 0; p < passes; ++p) {
         const int shift = shift0 + p * kRadixBits;
         const int64_t *n_dev = p == 0 ? n_in_dev : n_out_dev;
@@ -1318,12 +1413,23 @@ int run_async(hs_lb *h, int64_t end_ns) {
                                      h->tab_times, h->tab_count, h->tab_status, h->lane_budget, false));
         h->tables_built = true;
     }
+    // the Sources' stream values first, with every SIMD (hs_lb_source_draws; the sort's ping-pong buffers are free until the sort);
+    // debug flag 8: the Sources draw their own
+    const int64_t n_pre = (h->flags & 8) ? 0 : h->n_pre;
+    double *dinc = (double *)h->kA;
+    int32_t *dbe = (int32_t *)h->vA;
+    if (n_pre > 0) {
+        const int64_t threads = ((n_pre + 1) / 2) * (int64_t)S;
+        hipLaunchKernelGGL(hs_lb_source_draws, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, h->stream, h->PS, S, h->cfg.seed,
+                           h->client_be, h->n_table, n_pre, dinc, dbe);
+        h->launches += 1;
+    }
     if (h->any_src_profile)
         hipLaunchKernelGGL(hs_lbk_sources<true>, dim3((S + kLbBlock - 1) / kLbBlock), dim3(kLbBlock), 0, h->stream, h->PS, S, h->cfg.seed,
-                           h->cfg.start_ns, end_ns, h->client_be, h->n_table, h->keys0, h->vals0, h->cap, h->tb, h->tot);
+                           h->cfg.start_ns, end_ns, h->client_be, h->n_table, h->keys0, h->vals0, h->cap, h->tb, h->tot, dinc, dbe, n_pre, h->f64_times ? 1 : 0);
     else
         hipLaunchKernelGGL(hs_lbk_sources<false>, dim3((S + kLbBlock - 1) / kLbBlock), dim3(kLbBlock), 0, h->stream, h->PS, S, h->cfg.seed,
-                           h->cfg.start_ns, end_ns, h->client_be, h->n_table, h->keys0, h->vals0, h->cap, h->tb, h->tot);
+                           h->cfg.start_ns, end_ns, h->client_be, h->n_table, h->keys0, h->vals0, h->cap, h->tb, h->tot, dinc, dbe, n_pre, h->f64_times ? 1 : 0);
     hipLaunchKernelGGL(hs_lb_rows, dim3(1), dim3(1), 0, h->stream, h->tot, S, h->n_slots_dev);
     hipEventRecord(h->evs0, h->stream);
     radix_sort_async(h, h->keys0, h->vals0, h->n_slots_dev, h->n_arr, h->tb + h->bb,
@@ -1394,6 +1500,11 @@ int check_flags(hs_lb *h) {
     LbTotals t;
     LB_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
     if (t.qoverflow) return lfail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
+    if (h->radix_err != nullptr) {
+        int re = 0;
+        LB_HIP(h, hipMemcpy(&re, h->radix_err, sizeof re, hipMemcpyDeviceToHost));
+        if (re) return lfail(h, HS_E_HIP, "the radix sort's look-back (debug flag 16) gave up waiting for an earlier tile (bounded spin)");
+    }
     if (t.bad_client & 1) return lfail(h, HS_E_INVALID, "a client id fell outside the client table");
     if (h->any_src_profile) {          // a Source whose inversion gave up would simply stop ticking: never silently
         unsigned long long st[2] = {0ull, 0ull};
@@ -1441,7 +1552,7 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     if (cfg->device < 0 || cfg->device >= ndev) return lfail(nullptr, HS_E_INVALID, "device ordinal %d out of range (%d devices)", cfg->device, ndev);
     // ---- validation + sizing
     const double horizon_s = (double)(cfg->horizon_ns - cfg->start_ns) / 1e9;
-    double max_ticks = 0.0, total_rate = 0.0;
+    double max_ticks = 0.0, total_rate = 0.0, min_rate = 1e300;
     int64_t kmax = 0;
     for (int i = 0; i < S; ++i) {
         const int sk = src->src_kind ? src->src_kind[i] : HS_SRC_POISSON;
@@ -1450,6 +1561,7 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
         if (!(r > 0.0) || !std::isfinite(r)) return lfail(nullptr, HS_E_INVALID, "source %d: rate must be > 0 (got %g)", i, r);
         if (r > 1e8) return lfail(nullptr, HS_E_UNSUPPORTED, "source %d: rate %g above 1e8/s is not supported", i, r);
         max_ticks = std::max(max_ticks, r * horizon_s);
+        min_rate = std::min(min_rate, r);
         total_rate += r;
         if (src->n_clients[i] < 1) return lfail(nullptr, HS_E_INVALID, "source %d: n_clients must be >= 1", i);
         kmax = std::max(kmax, src->n_clients[i]);
@@ -1483,7 +1595,9 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     int64_t cap = cfg->tick_capacity;
     if (cap <= 0) cap = ((int64_t)(max_ticks + 10.0 * std::sqrt(max_ticks + 1.0) + 64.0) + 15) & ~(int64_t)15;
     h->cap = cap;
+    h->n_pre = std::min<int64_t>(cap, ((int64_t)(max_ticks + 5.0 * std::sqrt(max_ticks + 1.0) + 16.0) + 15) & ~(int64_t)15);   // hs_lb_source_draws (whole chunks of 16)
     h->n_slots = cap * (int64_t)S;
+    h->f64_times = cfg->start_ns >= 0 && cfg->horizon_ns < (1ll << 50) && min_rate > 1e-3;   // (one increment <= 36.8 / rate seconds)
     if ((double)h->n_slots * 88.0 > 200e9) { delete h; return lfail(nullptr, HS_E_INVALID, "buffers would need %.1f GB", (double)h->n_slots * 88.0 / 1e9); }
     {   // rows of the [k][backend] layout: three times the mean load of a backend (consistent hashing with >= 100 virtual
         // nodes keeps the busiest backend below ~2x); capped so that the five transposed arrays stay within ~4x n_slots
@@ -1644,6 +1758,10 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     TRY(lalloc(h, &h->n_slots_dev, 1)); TRY(lalloc(h, &h->n_arr, 1)); TRY(lalloc(h, &h->n_done, 1)); TRY(lalloc(h, &h->n_tmp, 1));
     TRY(lalloc(h, &h->hist, (size_t)kRadixBins * (size_t)h->n_tiles)); TRY(lalloc(h, &h->row_total, (size_t)kRadixBins));
     TRY(lalloc(h, &h->digit_base, (size_t)kRadixBins));
+    TRY(lalloc(h, &h->ghist, (size_t)kRadixMaxPasses * kRadixBins)); TRY(lalloc(h, &h->tickets, (size_t)kRadixMaxPasses));
+    TRY(lalloc(h, &h->radix_err, (size_t)1));
+    LB_HIP(h, hipMemset(h->tickets, 0, kRadixMaxPasses * sizeof(uint32_t)));
+    LB_HIP(h, hipMemset(h->radix_err, 0, sizeof(int)));
     TRY(lalloc(h, &h->tot, 1));
 #undef TRY
     if (hipMemcpy(h->n_slots_dev, &h->n_slots, 8, hipMemcpyHostToDevice) != hipSuccess) {

@@ -39,6 +39,9 @@ class Entity:
 
 # ---- distributions -------------------------------------------------------------------------------
 class LatencyDistribution:
+    __slots__ = ("_mean_latency",)      # (slotted like the other leaf objects of a chain: lowering 65 536 chains is a walk over
+                                        #  ~600 000 Python objects, bound by the cache lines each visit touches)
+
     def __init__(self, mean_latency):
         if isinstance(mean_latency, Duration):
             self._mean_latency = mean_latency.to_seconds()
@@ -52,6 +55,7 @@ class LatencyDistribution:
 
 class ExponentialLatency(LatencyDistribution):
     """Exponentially distributed latency; on the engine: sample = -hs_log(1-u) / (1/mean)."""
+    __slots__ = ("_lambda",)
 
     def __init__(self, mean_latency):
         super().__init__(mean_latency)
@@ -59,12 +63,13 @@ class ExponentialLatency(LatencyDistribution):
 
 
 class ConstantLatency(LatencyDistribution):
-    pass
+    __slots__ = ()
 
 
 # ---- queue policy --------------------------------------------------------------------------------
 class FIFOQueue:
     """components/queue_policy.py:75-114 -- the only policy lowered to the engine."""
+    __slots__ = ("_capacity",)
 
     def __init__(self, capacity: float = float("inf")):
         self._capacity = capacity
@@ -75,7 +80,7 @@ class FIFOQueue:
 
 
 # ---- load ----------------------------------------------------------------------------------------
-@dataclass(frozen=True)
+@dataclass(frozen=True, slots=True)
 class ConstantRateProfile:
     rate: float
 
@@ -132,6 +137,27 @@ class SpikeProfile:
         return max(self.baseline_rate, self.spike_rate)
 
 
+# Results of a run on n plain chains whose objects have not been bound to them yet (lowering.write_back_plain): binding 4 x 65 536
+# objects costs more than the run, so it happens when somebody first reads or writes a result attribute of ANY lowered entity
+# (or starts another run) -- the same laziness as the Sink records that stay on the device until they are read.
+_PENDING: list = []
+
+
+def _flush_pending() -> None:
+    if not _PENDING:
+        return
+    import gc
+
+    was = gc.isenabled()
+    gc.disable()                   # (65 536 new tuples would otherwise trigger full collections over ~600 000 live objects)
+    try:
+        while _PENDING:
+            _PENDING.pop(0)()
+    finally:
+        if was:
+            gc.enable()
+
+
 class _Stat:
     """A result counter of an entity: its own value, or -- after a run on n plain chains (lowering.write_back_plain) -- row
     `_bound[1]` of the run's per-LP result arrays `_bound[0]`.  Binding an object is ONE attribute store instead of one per
@@ -146,6 +172,8 @@ class _Stat:
     def __get__(self, obj, owner=None):
         if obj is None:
             return self
+        if _PENDING:
+            _flush_pending()
         b = obj._bound
         if b is None:
             return obj.__dict__.get(self.own, self.default)
@@ -153,13 +181,17 @@ class _Stat:
         return self.cast(b[0][key][b[1]]) if isinstance(key, str) else key(b[0], b[1])
 
     def __set__(self, obj, value):
+        if _PENDING:
+            _flush_pending()
         obj.__dict__[self.own] = value
         if obj._bound is not None:
             obj._bound = None
 
 
 class SimpleEventProvider:
-    _bound = None
+    # (the attributes the lowering reads live in slots -- inline in the object, no dictionary to chase; everything else, the
+    #  _Stat values included, goes to the instance __dict__ as before)
+    __slots__ = ("_bound", "_target", "_event_type", "_stop_after", "__dict__")
     _generated = _Stat(lambda st, i: int(st["accepted"][i] + st["dropped"][i]))     # Requests handed out
 
     def __init__(self, target: Entity, event_type: str = "Request", stop_after: Instant | None = None,
@@ -175,6 +207,7 @@ class SimpleEventProvider:
 
 class _ArrivalProvider:
     kind = "constant"
+    __slots__ = ("profile",)
 
     def __init__(self, profile, start_time: Instant = None):
         if not isinstance(profile, (ConstantRateProfile, LinearRampProfile, SpikeProfile)):
@@ -186,14 +219,16 @@ class _ArrivalProvider:
 
 class ConstantArrivalTimeProvider(_ArrivalProvider):
     kind = "constant"
+    __slots__ = ()
 
 
 class PoissonArrivalTimeProvider(_ArrivalProvider):
     kind = "poisson"
+    __slots__ = ()
 
 
 class Source(Entity):
-    _bound = None
+    __slots__ = ("_bound", "_event_provider", "_time_provider")
     _generated_count = _Stat("generated")
 
     def __init__(self, name: str, event_provider: SimpleEventProvider, arrival_time_provider: _ArrivalProvider):
@@ -281,7 +316,7 @@ class _QueueView:
 
 
 class Server(Entity):
-    _bound = None
+    __slots__ = ("_bound", "_policy", "_concurrency", "_service_time", "_downstream", "_queue")
     _requests_completed = _Stat("completed")
     _requests_rejected = _Stat("rejected")
     _total_service_time = _Stat("total_service_s", float, 0.0)
@@ -399,6 +434,8 @@ class _RecordSink(Entity):
         self._device = 0
 
     def _set_records(self, t_ns: np.ndarray, created_ns: np.ndarray):
+        if _PENDING:
+            _flush_pending()
         self._rec_t = t_ns
         self._rec_cr = created_ns
         self._lazy = None
@@ -408,6 +445,8 @@ class _RecordSink(Entity):
         self._device = device
 
     def _materialise(self):
+        if _PENDING:
+            _flush_pending()
         if self._lazy is not None:
             records, i = self._lazy
             self._rec_t, self._rec_cr = records.records(i)
@@ -424,6 +463,8 @@ class _RecordSink(Entity):
         return self._rec_cr
 
     def _n_records(self) -> int:
+        if _PENDING:
+            _flush_pending()
         return self._lazy[0].count(self._lazy[1]) if self._lazy is not None else int(len(self._rec_t))
 
     @property

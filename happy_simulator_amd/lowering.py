@@ -70,61 +70,71 @@ class PlainChains:
 
 def _plain_chains(sources, entities):
     """PlainChains when `sources` / `entities` are exactly that shape, else None (lower() then walks the graph).  Every check is
-    one C-level pass (map / attrgetter / set) over the homogeneous lists: ~50 ms for 65 536 chains."""
-    from operator import attrgetter as ag
+    a C-level pass (map / attrgetter / set) over the homogeneous lists, and every object is visited ONCE per pass that needs it
+    (one multi-attribute getter per class: at 65 536 chains the passes are bound by the cache misses of walking 200 000 Python
+    objects, ~0.2 us per object and visit): ~0.1 s for 65 536 chains."""
+    from operator import attrgetter as ag, is_
 
     n = len(sources)
     if n < 64 or set(map(type, sources)) != {Source}:
         return None
-    servers = list(map(ag("_event_provider._target"), sources))
-    server_ids = set(map(id, servers))
-    if set(map(type, servers)) != {Server} or len(server_ids) != n:
+    cols = list(zip(*map(ag("_event_provider._target", "_event_provider._stop_after", "_time_provider.kind", "_time_provider.profile"),
+                         sources)))
+    servers, stops, kinds, profiles = (list(c) for c in cols)
+    if set(map(type, servers)) != {Server}:
         return None
     ent_types = set(map(type, entities))
     if not ent_types <= {Server, Sink, Counter, LatencyTracker}:
         return None
     ent_servers = [e for e in entities if type(e) is Server]
-    if len(ent_servers) != n or set(map(id, ent_servers)) != server_ids:
+    if len(ent_servers) != n:
         return None
-    downs = list(map(ag("_downstream"), servers))
+    # station order = the Servers' order in `entities` (the entity stream numbering, see lower()); the usual case: the same order
+    in_order = all(map(is_, ent_servers, servers))
+    order = None
+    if in_order:
+        station_of_source = np.arange(n, dtype=np.int32)
+    else:
+        server_ids = set(map(id, servers))
+        if len(server_ids) != n or set(map(id, ent_servers)) != server_ids:
+            return None
+        pos = dict(zip(map(id, ent_servers), range(n)))
+        station_of_source = np.fromiter(map(pos.__getitem__, map(id, servers)), np.int32, n)
+        order = np.argsort(station_of_source, kind="stable")
+    downs, svcs, concs, caps = (list(c) for c in zip(*map(ag("_downstream", "_service_time", "_concurrency", "_policy._capacity"), servers)))
     if not set(map(type, downs)) <= {Sink, Counter, LatencyTracker, type(None)}:
         return None
-    real = [id(d) for d in downs if d is not None]
-    if len(set(real)) != len(real):                     # a collector shared by several Servers: the general path merges its records
+    real = [d for d in downs if d is not None]
+    if len(set(map(id, real))) != len(real):            # a collector shared by several Servers: the general path merges its records
         return None
-    svcs = list(map(ag("_service_time"), servers))
+    if in_order and len(set(map(id, servers))) != n:    # (one Server behind several Sources: the general path)
+        return None
     svc_types = set(map(type, svcs))
     if not svc_types <= {ExponentialLatency, ConstantLatency}:
         return None
-    conc = np.fromiter(map(ag("_concurrency"), servers), np.int32, n)
-    profiles = list(map(ag("_time_provider.profile"), sources))
+    conc = np.fromiter(concs, np.int32, n)
     if set(map(type, profiles)) != {ConstantRateProfile}:
         return None
     rate = np.fromiter(map(ag("rate"), profiles), np.float64, n)
     if conc.max() > 32 or not (rate > 0).all():
         return None
-    # station order = the Servers' order in `entities` (the entity stream numbering, see lower())
-    pos = dict(zip(map(id, ent_servers), range(n)))
-    station_of_source = np.fromiter(map(pos.__getitem__, map(id, servers)), np.int32, n)
-    in_order = bool((station_of_source == np.arange(n, dtype=np.int32)).all())
-    order = None if in_order else np.argsort(station_of_source, kind="stable")
 
     def perm(lst):
         return lst if in_order else [lst[k] for k in order]
 
     a = StationArrays.uniform(n)
-    kinds = list(map(ag("_time_provider.kind"), sources))
-    kind = np.fromiter((N.SRC_POISSON if k == "poisson" else N.SRC_CONSTANT for k in kinds), np.uint8, n)
-    stops = list(map(ag("_event_provider._stop_after"), sources))
+    kind_set = set(kinds)
+    kind = (np.full(n, N.SRC_POISSON if kind_set == {"poisson"} else N.SRC_CONSTANT, np.uint8) if len(kind_set) == 1 else
+            np.fromiter((N.SRC_POISSON if k == "poisson" else N.SRC_CONSTANT for k in kinds), np.uint8, n))
     stop = (np.full(n, -1, np.int64) if set(stops) == {None} else
             np.fromiter((-1 if x is None else x.nanoseconds for x in stops), np.int64, n))
     svk = (np.full(n, N.LAT_EXPONENTIAL if svc_types == {ExponentialLatency} else N.LAT_CONSTANT, np.uint8) if len(svc_types) == 1 else
            np.fromiter((N.LAT_EXPONENTIAL if type(x) is ExponentialLatency else N.LAT_CONSTANT for x in svcs), np.uint8, n))
-    svm = np.fromiter(map(ag("mean"), svcs), np.float64, n)
+    svm = np.fromiter(map(ag("_mean_latency"), svcs), np.float64, n)
     inf = float("inf")
-    caps = list(map(ag("_policy.capacity"), servers))
     qcap = np.full(n, -1, np.int64) if set(caps) == {inf} else np.fromiter((-1 if c == inf else int(c) for c in caps), np.int64, n)
-    egr = np.fromiter((N.EGRESS_NONE if d is None else N.EGRESS_SINK for d in downs), np.uint8, n)
+    egr = (np.full(n, N.EGRESS_SINK, np.uint8) if len(real) == n else
+           np.fromiter((N.EGRESS_NONE if d is None else N.EGRESS_SINK for d in downs), np.uint8, n))
     take = (lambda x: x) if in_order else (lambda x: x[order])
     a.src_kind[:] = take(kind); a.src_rate[:] = take(rate); a.src_stop_after_ns[:] = take(stop)
     a.concurrency[:] = take(conc); a.svc_kind[:] = take(svk); a.svc_mean_s[:] = take(svm); a.queue_cap[:] = take(qcap)
@@ -539,16 +549,24 @@ class LazyRecords:
 def write_back_plain(pc: PlainChains, stats: dict, records: LazyRecords, device: int = 0) -> None:
     """write_back() for PlainChains: every object is BOUND to its row of the run's result arrays (entities._Stat: one attribute
     store per object instead of one per counter) and the Sinks to the lazily downloaded records -- the attributes users read
-    (`stats_accepted`, `stats.requests_completed`, `generated_count`, `events_received`, `latencies_s` ...) are unchanged."""
-    for i, (src, sv, sk) in enumerate(zip(pc.sources, pc.servers, pc.sinks)):
-        b = (stats, i)
-        src._bound = b
-        src._event_provider._bound = b
-        sv._bound = b
-        sv._queue._bound = b
-        if sk is not None:
-            sk._lazy = (records, i)
-            sk._device = device
+    (`stats_accepted`, `stats.requests_completed`, `generated_count`, `events_received`, `latencies_s` ...) are unchanged.
+    The binding itself (4 x n attribute stores) is deferred until a result attribute of any lowered entity is first touched
+    (entities._PENDING): at 65 536 chains it costs 100 x the device run."""
+    from . import entities as E
+
+    def bind():
+        for i, (src, sv, sk) in enumerate(zip(pc.sources, pc.servers, pc.sinks)):
+            b = (stats, i)
+            src._bound = b
+            src._event_provider._bound = b
+            sv._bound = b
+            sv._queue._bound = b
+            if sk is not None:
+                sk._lazy = (records, i)
+                sk._device = device
+
+    E._flush_pending()             # (an earlier run's results first: bindings apply in run order)
+    E._PENDING.append(bind)
 
 
 def write_back(g: LoweredGraph, stats: dict, counts: np.ndarray, t_ns: np.ndarray, created_ns: np.ndarray,
@@ -685,11 +703,18 @@ class LbGraph:
 
 def find_load_balancer(sources: list, entities: list):
     """The LoadBalancer of a load-balancer topology, or None when the graph has none."""
-    lbs = [e for e in (entities or []) if isinstance(e, LoadBalancer)]
-    for s in sources or []:
-        t = getattr(getattr(s, "_event_provider", None), "_target", None)
-        if isinstance(t, LoadBalancer) and all(t is not x for x in lbs):
-            lbs.append(t)
+    from operator import attrgetter as ag
+
+    lbs = [e for e in (entities or []) if isinstance(e, LoadBalancer)] if any(
+        issubclass(t, LoadBalancer) for t in set(map(type, entities or []))) else []
+    try:                                           # (one C-level pass; an object without the attributes is no lowered Source)
+        targets = list(map(ag("_event_provider._target"), sources or []))
+    except AttributeError:
+        targets = [getattr(getattr(s, "_event_provider", None), "_target", None) for s in sources or []]
+    if any(issubclass(t, LoadBalancer) for t in set(map(type, targets))):
+        for t in targets:
+            if isinstance(t, LoadBalancer) and all(t is not x for x in lbs):
+                lbs.append(t)
     if not lbs:
         return None
     if len(lbs) > 1:

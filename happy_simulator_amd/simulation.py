@@ -15,6 +15,7 @@ from .engine import StationEngine
 from .entities import Entity, Server
 from .lowering import (LazyRecords, LbGraph, LoweredGraph, UnsupportedTopology, attach_lb_probes, attach_probes, find_load_balancer, lower,
                        lower_lb, write_back, write_back_lb, write_back_plain, write_back_probes)
+from .lowering import _plain_chains as plain_chains
 from .summary import EntitySummary, LazyEntities, QueueStats, SimulationSummary
 
 _DEFAULT_SEED = 42
@@ -112,9 +113,14 @@ class Simulation:
 
     def lowered(self) -> "LoweredGraph | LbGraph":
         if self._graph is None:
-            lb = find_load_balancer(self._sources, self._entities)
-            self._graph = lower_lb(self._sources, self._entities, lb) if lb is not None else lower(self._sources,
-                                                                                                    self._entities)
+            plain = plain_chains(self._sources, self._entities)      # (n plain chains: no LoadBalancer among them, one pass less)
+            if plain is not None:
+                self._graph = LoweredGraph(plain)
+                lb = None
+            else:
+                lb = find_load_balancer(self._sources, self._entities)
+                self._graph = lower_lb(self._sources, self._entities, lb) if lb is not None else lower(self._sources,
+                                                                                                        self._entities)
             if self._probes:
                 if lb is not None:
                     attach_lb_probes(self._graph, self._probes)
@@ -141,6 +147,13 @@ class Simulation:
         self._current_time = Instant(es.final_time_ns)
         self._summary = self._build_summary(_time.monotonic() - wall0)
         return self._summary
+
+    def __del__(self):
+        try:                       # results this run has not bound to its entities yet (entities._PENDING) outlive the Simulation
+            from .entities import _flush_pending
+            _flush_pending()
+        except Exception:          # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def run(self) -> SimulationSummary:
         auto = self._end_time == Instant.Infinity

@@ -89,7 +89,8 @@ SWEEP = [
 
 
 @pytest.mark.parametrize("spec", SWEEP, ids=[s["name"] for s in SWEEP])
-@pytest.mark.parametrize("flags", [0, 1, 2, 4], ids=["request_order", "general_fifo", "event_order", "dense_layout"])
+@pytest.mark.parametrize("flags", [0, 1, 2, 4, 8, 16], ids=["request_order", "general_fifo", "event_order", "dense_layout",
+                                                             "sources_draw_their_own_values", "look_back_radix_passes"])
 def test_lb_engine_matches_oracle(spec, flags):
     g, p = H.oracle_lb_graph(spec)
     r = O.run(g, p["end_ns"], seed=spec["seed"])
