@@ -187,10 +187,10 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
                                                           const int32_t *__restrict__ client_be, int64_t n_table,
                                                           uint64_t *__restrict__ keys, uint64_t *__restrict__ vals,
                                                           int64_t cap, int tb, LbTotals *tot, const double *__restrict__ dinc,
-                                                          const int32_t *__restrict__ dbe, int64_t n_pre, int f64_times) {
+                                                          const int32_t *__restrict__ dbe, int64_t n_pre, int f64_times, int lanes) {
     __shared__ LbCand wc[kLbBlock / 64];
-    const int s = blockIdx.x * kLbBlock + threadIdx.x;
-    const bool live = s < S;
+    const int s = ((blockIdx.x * kLbBlock + threadIdx.x) >> 6) * lanes + (threadIdx.x & 63);     // `lanes` Sources per wavefront (lb_lanes())
+    const bool live = (threadIdx.x & 63) < lanes && s < S;
     uint32_t n_tick = 0, n_req = 0;
     int bad = 0, over = 0;
     int64_t last = INT64_MIN;
@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
         // returns Requests, draws client id number d.  Both streams are therefore indexed by the tick number: the
         // expensive part (Philox, hs_log, the division, the client -> backend lookup) is produced eight ticks at a time
         // in straight-line code -- independent chains the SIMD can overlap -- and only the ns recursion is serial.
-        constexpr int kChunk = 16;
+        constexpr int kChunk = 32;
         // (f64_times: every time of the run is a whole number of ns below 2^51, so the recursion runs on binary64 integers --
         //  hs_device.hpp ns_from_seconds_d: 8 dependent fp64 instructions per tick instead of ~60 with the i64 <-> f64 conversion
         //  sequences; the int64 the logs need is converted off the chain.  Round 3: the chain was 0.67 us per tick per wavefront.)
@@ -223,26 +223,17 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
         uint32_t dp_a2 = 0;                  // ... rc_a2, dp_a2 steps before it (0: constructed before run())
         int64_t A = kInfNs;
         bool done = false, dead = false;
-        // (the produced values of chunk c + 1 are in flight while chunk c runs: with one wavefront per two SIMDs nothing else
-        //  hides a load's latency, and a chunk's eight loads issued when the chunk begins cost one round trip per eight ticks)
-        double inc_n[kChunk];
-        int32_t be_n[kChunk];
-        auto fetch = [&](uint64_t d0) {
-#pragma unroll
-            for (int j = 0; j < kChunk; ++j) {
-                const bool in = (int64_t)(d0 + kChunk) <= n_pre;
-                const size_t o = in ? (size_t)(d0 + j) * (size_t)S + (size_t)s : (size_t)s;
-                inc_n[j] = in ? dinc[o] : 0.0; be_n[j] = in ? dbe[o] : -1;
-            }
-        };
-        if (n_pre >= kChunk) fetch(0);
+        // (a chunk's values are loaded when nothing else is in flight, with one explicit vmcnt(0): see run_request_order)
         for (uint64_t d0 = 0; !done; d0 += kChunk) {
             double inc[kChunk];
             int32_t be[kChunk];
             if ((int64_t)(d0 + kChunk) <= n_pre) {                       // the values hs_lb_source_draws produced
 #pragma unroll
-                for (int j = 0; j < kChunk; ++j) { inc[j] = inc_n[j]; be[j] = be_n[j]; }
-                fetch(d0 + kChunk);
+                for (int j = 0; j < kChunk; ++j) {
+                    const size_t o = (size_t)(d0 + j) * (size_t)S + (size_t)s;
+                    inc[j] = dinc[o]; be[j] = dbe[o];
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) here, on every path: the chunk's values have arrived
             } else
 #pragma unroll
             for (int j = 0; j < kChunk; j += 2) {
@@ -706,20 +697,26 @@ struct LbBackend {
         bool pend = false;
         int64_t pendD = kInfNs, pendS = 0, pendA = 0, pendSprev = INT64_MIN, pendK = 0;
         double pend_s = 0.0, tsvc = 0.0;
-        constexpr int kAhead = 8;
+        // A block of requests is LOADED, then processed, with ONE explicit vmcnt(0) in between: gfx9 counts loads and stores with one
+        // counter, and inside this control flow the compiler's wait before the first use of a prefetched register was vmcnt(0) at every
+        // request (the disassembly of round 2's double-buffered version), i.e. every request also waited for the record stores of
+        // the request before it.  Measured (scratch micro-kernels, round 3): a lone wavefront pays ~0.11 us per step for batched
+        // loads, ~0.06 us more per 512-byte store it issues, ~0.7 us per step when a load's round trip is exposed; this loop is
+        // ~0.95 us per request -- three record stores, ~125 instructions with five divergent branches -- so the stores and the
+        // dependent instruction chain, not the loads, are what is left.
+        constexpr int kAhead = 16;
         const double *sp = asv;
-        uint64_t cur[kAhead], nxt[kAhead];
-        double scur[kAhead], snxt[kAhead];
-#pragma unroll
-        for (int j = 0; j < kAhead; ++j) { cur[j] = j < n ? kp[j * rs] : 0ull; scur[j] = j < n ? sp[j * rs] : 0.0; }
+        uint64_t cur[kAhead];
+        double scur[kAhead];
         bool blocked = false;
         for (int64_t base = 0; base < n && !blocked; base += kAhead) {
 #pragma unroll
-            for (int j = 0; j < kAhead; ++j) {                          // in flight while cur is processed
-                const bool in = (base + kAhead + j) < n;
-                nxt[j] = in ? kp[(base + kAhead + j) * rs] : 0ull;
-                snxt[j] = in ? sp[(base + kAhead + j) * rs] : 0.0;
+            for (int j = 0; j < kAhead; ++j) {
+                const bool in = (base + j) < n;
+                cur[j] = in ? kp[(base + j) * rs] : 0ull;
+                scur[j] = in ? sp[(base + j) * rs] : 0.0;
             }
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) HERE, on every path (see above): the block's values have arrived
 #pragma unroll
             for (int j = 0; j < kAhead; ++j) {
                 if (base + j >= n || blocked) continue;
@@ -746,8 +743,6 @@ struct LbBackend {
                 } else { pend = true; pendD = Dk; pendS = S; pend_s = sv; pendA = a; pendSprev = Sprev; pendK = base + j; }
                 Sprev = S; Dprev = Dk; aprev = a;
             }
-#pragma unroll
-            for (int j = 0; j < kAhead; ++j) { cur[j] = nxt[j]; scur[j] = snxt[j]; }
         }
         if (n > 0) {                                                  // arrivals behind a blocked head were not iterated
             const int64_t a_last = (int64_t)(kp[(n - 1) * rs] & tmask);
@@ -808,15 +803,17 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_backends(LbBe P, int B, int S
                                                            int tb, int64_t *__restrict__ adm, int64_t *__restrict__ sink_t,
                                                            int64_t *__restrict__ sink_created, int64_t *__restrict__ sink_S,
                                                            const double *__restrict__ svdraw, LbTotals *tot, int flags,
-                                                           LbLayout LY) {
+                                                           LbLayout LY, int lanes) {
     __shared__ uint8_t qmem[kLbQCap][kLbBlock];
     __shared__ uint8_t qdep[kLbQCap][kLbBlock];          // lineage of the in-group FIFO's entries
     __shared__ int64_t qrc[kLbQCap][kLbBlock];
     __shared__ LbCand wc[kLbBlock / 64];
     const int tid = threadIdx.x;
-    const int b = blockIdx.x * kLbBlock + tid;
-    const bool live = b < B;
-    LbCand c = lb_cand_none(S + b);
+    // `lanes` backends per wavefront (lb_lanes()): one backend per lane would leave half the SIMDs without a wavefront at the
+    // configs[4] size, and a lone wavefront per SIMD waits out every dependent instruction
+    const int b = ((blockIdx.x * kLbBlock + tid) >> 6) * lanes + (tid & 63);
+    const bool live = (tid & 63) < lanes && b < B;
+    LbCand c = lb_cand_none(S + (live ? b : 0));
     LbBackend<C> X;
 #pragma unroll
     for (int k = 0; k < 8; ++k) X.ev[k] = 0;
@@ -1064,11 +1061,11 @@ __global__ void hs_lb_probe_sample(LbProbes Q, LbBe PB, int B, int tb, const uin
 }
 
 __global__ void __launch_bounds__(kLbBlock) hs_lb_finalize(LbSrc PS, LbBe PB, int S, int B, int64_t start_ns, LbTotals *tot,
-                                                          LbProbes Q) {
+                                                          LbProbes Q, int nbs, int nbb) {
     __shared__ LbCand wc[kLbBlock / 64];
     const int tid = threadIdx.x;
     LbCand best = lb_cand_none(0);
-    const int nbs = (S + kLbBlock - 1) / kLbBlock, nbb = (B + kLbBlock - 1) / kLbBlock;   // one candidate per workgroup
+    // (nbs, nbb: the workgroups of hs_lbk_sources / hs_lbk_backends -- one candidate each)
     for (int i = tid; i < nbs + nbb + Q.n; i += kLbBlock) {
         const LbCand c = i < nbs ? PS.cand[i] : i < nbs + nbb ? PB.cand[i - nbs] : Q.cand[i - nbs - nbb];
         if (cand_before(c, best)) best = c;
@@ -1231,6 +1228,7 @@ struct hs_lb {
     int64_t n_table = 0, cap = 0, n_slots = 0;
     uint64_t *keys0 = nullptr, *vals0 = nullptr;      // [cap][S] arrival logs
     int64_t n_pre = 0;                                 // ticks per Source whose stream values hs_lb_source_draws produces
+    int n_simd = 1024;                                 // SIMDs of the device (4 per CU): lb_lanes()
     bool f64_times = false;                            // every time of a run is a whole ns in [0, 2^51): exact in binary64
     uint64_t *kA = nullptr, *vA = nullptr, *kB = nullptr, *vB = nullptr;   // dense ping-pong buffers [n_slots]
     uint64_t *skey = nullptr, *sval = nullptr;        // where the sorted arrivals ended up
@@ -1396,12 +1394,20 @@ void radix_sort_async(hs_lb *h, const uint64_t *k_in, const uint64_t *v_in, cons
     *v_res = const_cast<uint64_t *>(vi);
 }
 
+// LPs (Sources, backends) per wavefront of the one-LP-per-lane kernels.
+int lb_lanes(const hs_lb *h, int n) {
+    (void)n;
+    return (h->flags & 32) ? 32 : 64;     // (measured: a per-LP serial chain does not get shorter on more SIMDs; debug flag 32 keeps the mapping tested)
+}
+
 template <int C>
 void launch_backends(hs_lb *h, int64_t end_ns) {
     const int B = h->cfg.n_backends;
-    hipLaunchKernelGGL(hs_lbk_backends<C>, dim3((B + kLbBlock - 1) / kLbBlock), dim3(kLbBlock), 0, h->stream, h->PB, B,
+    const int lanes = lb_lanes(h, B);
+    const int per_block = lanes * (kLbBlock / 64);
+    hipLaunchKernelGGL(hs_lbk_backends<C>, dim3((B + per_block - 1) / per_block), dim3(kLbBlock), 0, h->stream, h->PB, B,
                        h->cfg.n_sources, h->cfg.seed, h->cfg.start_ns, end_ns, h->skey, h->sval, h->off, h->tb, h->adm,
-                       h->sink_t, h->sink_created, h->sink_S, h->svdraw, h->tot, h->flags, h->LY);
+                       h->sink_t, h->sink_created, h->sink_S, h->svdraw, h->tot, h->flags, h->LY, lanes);
 }
 
 int run_async(hs_lb *h, int64_t end_ns) {
@@ -1424,12 +1430,13 @@ int run_async(hs_lb *h, int64_t end_ns) {
                            h->client_be, h->n_table, n_pre, dinc, dbe);
         h->launches += 1;
     }
+    const int src_lanes = lb_lanes(h, S), src_per_block = src_lanes * (kLbBlock / 64);
     if (h->any_src_profile)
-        hipLaunchKernelGGL(hs_lbk_sources<true>, dim3((S + kLbBlock - 1) / kLbBlock), dim3(kLbBlock), 0, h->stream, h->PS, S, h->cfg.seed,
-                           h->cfg.start_ns, end_ns, h->client_be, h->n_table, h->keys0, h->vals0, h->cap, h->tb, h->tot, dinc, dbe, n_pre, h->f64_times ? 1 : 0);
+        hipLaunchKernelGGL(hs_lbk_sources<true>, dim3((S + src_per_block - 1) / src_per_block), dim3(kLbBlock), 0, h->stream, h->PS, S, h->cfg.seed,
+                           h->cfg.start_ns, end_ns, h->client_be, h->n_table, h->keys0, h->vals0, h->cap, h->tb, h->tot, dinc, dbe, n_pre, h->f64_times ? 1 : 0, src_lanes);
     else
-        hipLaunchKernelGGL(hs_lbk_sources<false>, dim3((S + kLbBlock - 1) / kLbBlock), dim3(kLbBlock), 0, h->stream, h->PS, S, h->cfg.seed,
-                           h->cfg.start_ns, end_ns, h->client_be, h->n_table, h->keys0, h->vals0, h->cap, h->tb, h->tot, dinc, dbe, n_pre, h->f64_times ? 1 : 0);
+        hipLaunchKernelGGL(hs_lbk_sources<false>, dim3((S + src_per_block - 1) / src_per_block), dim3(kLbBlock), 0, h->stream, h->PS, S, h->cfg.seed,
+                           h->cfg.start_ns, end_ns, h->client_be, h->n_table, h->keys0, h->vals0, h->cap, h->tb, h->tot, dinc, dbe, n_pre, h->f64_times ? 1 : 0, src_lanes);
     hipLaunchKernelGGL(hs_lb_rows, dim3(1), dim3(1), 0, h->stream, h->tot, S, h->n_slots_dev);
     hipEventRecord(h->evs0, h->stream);
     radix_sort_async(h, h->keys0, h->vals0, h->n_slots_dev, h->n_arr, h->tb + h->bb,
@@ -1489,7 +1496,11 @@ int run_async(hs_lb *h, int64_t end_ns) {
                            h->skey, h->off, h->adm, h->sink_t, h->out_t, h->n_done, 1, 1, h->tot, h->keys0, h->PS.count, S);
         h->launches += 1;
     }
-    hipLaunchKernelGGL(hs_lb_finalize, dim3(1), dim3(kLbBlock), 0, h->stream, h->PS, h->PB, S, B, h->cfg.start_ns, h->tot, h->Q);
+    {
+        const int sl = lb_lanes(h, S) * (kLbBlock / 64), bl = lb_lanes(h, B) * (kLbBlock / 64);
+        hipLaunchKernelGGL(hs_lb_finalize, dim3(1), dim3(kLbBlock), 0, h->stream, h->PS, h->PB, S, B, h->cfg.start_ns, h->tot, h->Q,
+                           (S + sl - 1) / sl, (B + bl - 1) / bl);
+    }
     h->launches += 6;
     LB_HIP(h, hipGetLastError());
     h->ran = true;
@@ -1660,6 +1671,7 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     h->n_table = kmax;
     hipError_t e = hipSetDevice(cfg->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) h->n_simd = 4 * cus; }
     hipEvent_t *evs[6] = {&h->ev0, &h->ev1, &h->evs0, &h->evs1, &h->evs2, &h->evs3};
     for (auto pe : evs) if (e == hipSuccess) e = hipEventCreate(pe);
     if (e != hipSuccess) { int rc = lfail(nullptr, HS_E_HIP, "device setup: %s", hipGetErrorString(e)); hs_lb_destroy(h); return rc; }
