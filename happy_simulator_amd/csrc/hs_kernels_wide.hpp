@@ -91,6 +91,11 @@ __global__ void __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu
     __shared__ double s_carry[G][2];       // D and S of the last request of the step before
     __shared__ int s_ndp[2][G];            // completions of a step (for the service-time sum, one iteration later)
     __shared__ double s_ts[G];             // _total_service_time, handed from the summing wavefront to the storing one
+    // (Round 3 experiments, all bit-identical, none faster at 8 192 LPs: the service-time sum on the values' wavefront 0.171 ms or on
+    //  a fourth wavefront 0.198 (HS_WIDE_T_ROLE); four requests per lane and step 0.228 (HS_WIDE_Q); two wavefronts per EU instead of
+    //  three 0.168; the roles decoupled by progress counters in LDS instead of the barrier per step 0.162 -- the roles take about the
+    //  same time per step (s_memtime: values 2 200, chain + sum 1 800, Lindley 2 700 per step at K = 4), each is a chain of dependent
+    //  instructions on a wavefront of its own, and VALU busy is 51 % per SIMD: the step is latency-bound three ways at once.)
     // Three ROLES, one wavefront each, on the same 64 / K LPs, a step apart (one workgroup barrier per iteration).  In iteration i:
     //   wavefront 0  V: the stream values of step i + 3;
     //   wavefront 1  C: the arrival chain of step i + 1, and T: the service-time sum of step i - 1;
