@@ -4,7 +4,7 @@
     gpurun -- 'python tools/wide_timing.py'                      # kernel ms (median of 10 reset + run steps), sizes x K
     gpurun -- 'HS_HIP_LIB=happy_simulator_amd/lib/instr/libhs_widecyc.so python tools/wide_timing.py --cycles'
 
---cycles needs a library built with -DHS_WIDE_CYC (a scratch build of round 3; the instrumentation has been removed from the kernel again).
+--cycles needs a library built with -DHS_WIDE_CYC (python -c "from happy_simulator_amd import _native as N;
 N.build(defines=('HS_WIDE_CYC',), lib_path='happy_simulator_amd/lib/instr/libhs_widecyc.so')"): s_memtime cycles each of the three
 role wavefronts of workgroup 0 spends working, next to the loop's total (what is left is barrier wait).
 Debug flags: bits 24..27 force K = 1 << (value - 1); 1 << 22 keeps hs_station_run; 1 << 19 / 1 << 18 switch the log appends /
