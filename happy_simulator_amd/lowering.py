@@ -319,7 +319,12 @@ def attach_probes(g: LoweredGraph, probes: list) -> None:
                 raise UnsupportedTopology(f"probe '{pr.name}': only the first Source of a Server is sampled on the engine")
             raise UnsupportedTopology(f"probe '{pr.name}': its target is not an entity of this Simulation")
         if id(pr.target) in shared:
-            raise UnsupportedTopology(f"probe '{pr.name}': a Sink shared by several stations is not sampled on the engine yet")
+            # A Sink behind several Servers (`events_received` is the sum over its stations): the probe ticks on the FIRST station
+            # that feeds the Sink -- its tick chain, its two events per tick and its place in the election of the event beyond
+            # end_time are those of any probe -- and the values are read off the Sink's merged records after the run
+            # (write_back_shared_sink_probes).  A tick on the very nanosecond of one of the Sink's records is refused there.
+            i = min(k for k, st_k in enumerate(g.stations) if st_k.sink is pr.target)
+            g.shared_sink_probes = (*getattr(g, "shared_sink_probes", ()), pr)
         st = g.stations[i]
         if len(st.probes) >= 4:
             raise UnsupportedTopology(f"station of '{pr.target.name}' already has four probes (the engine's slots per station)")
@@ -338,6 +343,22 @@ def write_back_probes(g: LoweredGraph, eng) -> None:
         for slot, pr in enumerate(st.probes):
             t, v = eng.read_probe(i, slot)
             pr.data_sink._set(t, v, st.server.concurrency if pr.metric == "utilization" else None)
+
+
+def write_back_shared_sink_probes(g: LoweredGraph) -> None:
+    """After write_back(): a probe on a Sink that several stations feed (attach_probes) samples `events_received` = the number of
+    the Sink's merged records before the tick.  When a tick shares its nanosecond with one of those records the reference's heap
+    order decides whether the record counts -- not reconstructed here: refused by name, never guessed."""
+    for pr in getattr(g, "shared_sink_probes", ()):
+        t = np.asarray(pr.data_sink._t_ns, np.int64)
+        rec = np.asarray(pr.target.completion_ns, np.int64)          # in processing order = ascending
+        before, upto = np.searchsorted(rec, t, side="left"), np.searchsorted(rec, t, side="right")
+        if (before != upto).any():
+            k = int(np.flatnonzero(before != upto)[0])
+            raise UnsupportedTopology(f"probe '{pr.name}': its tick at {int(t[k])} ns falls on the nanosecond of a record of the shared "
+                                      f"Sink '{pr.target.name}'; the order inside that nanosecond is not reconstructed for a Sink behind "
+                                      "several Servers")
+        pr.data_sink._set(t, before.astype(np.int64), None)
 
 
 def lower(sources: list, entities: list) -> LoweredGraph:

@@ -14,7 +14,7 @@ from .core.temporal import Instant
 from .engine import StationEngine
 from .entities import Entity, Server
 from .lowering import (LazyRecords, LbGraph, LoweredGraph, UnsupportedTopology, attach_lb_probes, attach_probes, find_load_balancer, lower,
-                       lower_lb, write_back, write_back_lb, write_back_plain, write_back_probes)
+                       lower_lb, write_back, write_back_lb, write_back_plain, write_back_probes, write_back_shared_sink_probes)
 from .lowering import _plain_chains as plain_chains
 from .summary import EntitySummary, LazyEntities, QueueStats, SimulationSummary
 
@@ -220,6 +220,7 @@ class Simulation:
             if self._probes:
                 write_back_probes(g, eng)
         write_back(g, stats, counts, t_ns, created_ns, net_stats, device=self._device)
+        write_back_shared_sink_probes(g)
         # a cancelled event is counted when the loop pops it: everything up to the last processed event, or the whole
         # heap when the run ended with nothing left beyond end_time (core/simulation.py:472-477)
         drained = es.final_time_ns <= end_ns
@@ -284,6 +285,7 @@ class Simulation:
             if self._probes:
                 write_back_probes(g, sn)
         write_back(g, stats, counts, t_ns, created_ns, net_stats, device=self._device)
+        write_back_shared_sink_probes(g)
         drained = es.final_time_ns <= end_ns
         self._events_cancelled = sum(1 for t in cancelled_ns if drained or t <= es.final_time_ns)
         self._engine_summary = es

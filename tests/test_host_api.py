@@ -118,10 +118,10 @@ class TestLowering:
         g = hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=s1), hs.Source.poisson(1, target=s2)],
                           entities=[s1, s2, sink]).lowered()
         assert [st.sink for st in g.stations] == [sink, sink]
-        pr, _ = hs.Probe.on(sink, "events_received")
-        with pytest.raises(hs.UnsupportedTopology, match="shared by several stations"):
-            hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=s1), hs.Source.poisson(1, target=s2)],
+        pr, _ = hs.Probe.on(sink, "events_received")       # a probe on such a Sink ticks on the first station that feeds it
+        g = hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=s1), hs.Source.poisson(1, target=s2)],
                           entities=[s1, s2, sink], probes=[pr]).lowered()
+        assert g.stations[0].probes == (pr,) and g.stations[1].probes == () and g.shared_sink_probes == (pr,)
         with pytest.raises(hs.UnsupportedTopology, match="only Server / Sink"):
             hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=Custom("x"))]).lowered()
         with pytest.raises(hs.UnsupportedTopology, match="not lowered"):
