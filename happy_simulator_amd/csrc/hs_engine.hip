@@ -1107,7 +1107,7 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     h->NX.pk_base = h->cfg.start_ns;
     if (nl > 0) {
         const size_t NQ = NL * (size_t)aqc;
-        ALN(aq_t, NQ); ALN(aq_ts, NQ); ALN(aq_cr, NQ); ALN(aq_lin, NQ); ALN(aq_tail, NL); ALN(aq_head, NL); ALN(aq_ea, NL);
+        ALN(aq_rec, NQ * 4); ALN(aq_tail, NL); ALN(aq_head, NL); ALN(aq_ea, NL);
         ALN(early_upto, (size_t)n); ALN(d_pre, (size_t)n);
         // the whole network in one cooperative launch (shards: hs_engine_shard_round); with probes, time-varying profiles
         // or scheduled Requests the PF instantiation of the kernel (a profile's next arrival and the next scheduled Request

@@ -1103,9 +1103,9 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
                 if (bn >= NX.bag_cap) { merge_overflow = 1; break; }
                 const size_t slot = (size_t)l * NX.aq_cap + (size_t)(head & (unsigned long long)(NX.aq_cap - 1));
                 const size_t dst = (size_t)lp * NX.bag_cap + bn;
-                const int64_t t = ag_load(&NX.aq_t[slot]);
-                NX.bag_t[dst] = t; NX.bag_ts[dst] = ag_load(&NX.aq_ts[slot]); NX.bag_cr[dst] = ag_load(&NX.aq_cr[slot]);
-                NX.bag_lin[dst] = ag_load(&NX.aq_lin[slot]);
+                const int64_t t = ag_load(&NX.aq_rec[4 * slot]);
+                NX.bag_t[dst] = t; NX.bag_ts[dst] = ag_load(&NX.aq_rec[4 * slot + 1]); NX.bag_cr[dst] = ag_load(&NX.aq_rec[4 * slot + 2]);
+                NX.bag_lin[dst] = ag_load(&NX.aq_rec[4 * slot + 3]);
                 NX.bag_link[dst] = l;
                 nt = t < nt ? t : nt;
                 ++bn;
@@ -1683,7 +1683,7 @@ __global__ void hs_shard_inject_async(NetState NX, const int64_t *inbox, int64_t
             const unsigned long long head = NX.aq_head[l], tail = pk_tail(NX.aq_ea[l], head);
             if (tail - head >= (unsigned long long)NX.aq_cap) { atomicOr(&tot->overflow, 2); continue; }
             const size_t slot = (size_t)l * NX.aq_cap + (size_t)(tail & (unsigned long long)(NX.aq_cap - 1));
-            NX.aq_t[slot] = m[0]; NX.aq_ts[slot] = m[1]; NX.aq_cr[slot] = m[2]; NX.aq_lin[slot] = m[4];
+            NX.aq_rec[4 * slot] = m[0]; NX.aq_rec[4 * slot + 1] = m[1]; NX.aq_rec[4 * slot + 2] = m[2]; NX.aq_rec[4 * slot + 3] = m[4];
             NX.aq_ea[l] = pk_pack(pk_ea(NX.aq_ea[l], NX.pk_base), tail + 1, NX.pk_base);
         }
         outbox[(size_t)r * row] = 0;

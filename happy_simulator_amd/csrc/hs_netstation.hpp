@@ -95,8 +95,10 @@ struct NetState {
     // with write-through (sc1) agent-scope stores and read with agent-scope loads -- the data is its own flag
     // (cdna_hip_programming.md section 6, Guideline 16, recipe R2); the producer drains its stores (vmcnt(0)) between
     // the payload, `aq_tail` and `aq_ea`, so a consumer that sees a value of `aq_ea` also sees every message below it.
-    int64_t *aq_t, *aq_ts, *aq_cr;   // [n_links][aq_cap] arrival ns, send ns, created_at ns
-    int64_t *aq_lin;                 // [n_links][aq_cap] lineage (lin_pack)
+    // [n_links][aq_cap] records of four words {arrival ns, send ns, created_at ns, lineage (lin_pack)}: one message = one 32-byte
+    // sector (round 3; rounds 1-2 kept four arrays, i.e. four write-through stores to four different lines per message and four
+    // lines read per message: 3.7-5.2 x the algorithmic HBM traffic)
+    int64_t *aq_rec;
     unsigned long long *aq_tail;     // [n_links] messages appended so far (producer)
     unsigned long long *aq_head;     // [n_links] messages taken so far (consumer; the producer reads it for flow control)
     int64_t *aq_ea;                  // [n_links] ONE word per link = (bound << 20 | messages appended so far mod 2^20):
@@ -116,6 +118,16 @@ __device__ __forceinline__ void ag_store(int64_t *p, int64_t v) {
 }
 __device__ __forceinline__ void ag_store(unsigned long long *p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one link-queue record = four words = two 16-byte agent-scope stores into one 32-byte sector (NetState::aq_rec)
+__device__ __forceinline__ void ag_store_rec(int64_t *rec, int64_t w0, int64_t w1, int64_t w2, int64_t w3) {
+#ifdef HS_REC_WORDS
+    ag_store(rec, w0); ag_store(rec + 1, w1); ag_store(rec + 2, w2); ag_store(rec + 3, w3);
+#else
+    typedef long long v2i64 __attribute__((ext_vector_type(2)));
+    const v2i64 lo = {w0, w1}, hi = {w2, w3};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(rec), "v"(lo), "v"(hi) : "memory");
+#endif
 }
 __device__ __forceinline__ int64_t ag_load(const int64_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -665,8 +677,7 @@ struct NetStation {
         ++fl_q;
         if (HSU(fl_remote, false)) { outbox_append(fl_link, fl_dst, t_arr, t_send, created, lin); return; }
         const size_t slot = (size_t)fl_link * ns->aq_cap + (size_t)(((unsigned long long)fl_q - 1) & (unsigned long long)(ns->aq_cap - 1));
-        ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t_send); ag_store(&ns->aq_cr[slot], created);
-        ag_store(&ns->aq_lin[slot], lin);
+        ag_store_rec(&ns->aq_rec[4 * slot], t_arr, t_send, created, lin);
         sent_async = true;
     }
     // steps from a Server's continuation to the NetworkLink's continuation it causes: Request@Link, the link's continuation
@@ -747,7 +758,7 @@ struct NetStation {
             // (room for this group's messages was checked before the group started: async_can_send)
             const unsigned long long seq = (unsigned long long)ns->link_sent[l];
             const size_t slot = (size_t)l * ns->aq_cap + (size_t)((seq - 1) & (unsigned long long)(ns->aq_cap - 1));
-            ag_store(&ns->aq_t[slot], t_arr); ag_store(&ns->aq_ts[slot], t); ag_store(&ns->aq_cr[slot], created); ag_store(&ns->aq_lin[slot], lin);
+            ag_store_rec(&ns->aq_rec[4 * slot], t_arr, t, created, lin);
             sent_async = true;          // the caller publishes aq_tail (= link_sent) after draining these stores
             return;
         }
@@ -846,14 +857,14 @@ struct NetStation {
             const int bcap = bag_capacity();
             for (; head < tail && bag_n < bcap; ++head) {
                 const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
-                const int64_t ta = ag_load(&ns->aq_t[slot]);
-                bag_insert(ta, ag_load(&ns->aq_ts[slot]), ag_load(&ns->aq_cr[slot]), l, ag_load(&ns->aq_lin[slot]));
+                const int64_t ta = ag_load(&ns->aq_rec[4 * slot]);
+                bag_insert(ta, ag_load(&ns->aq_rec[4 * slot + 1]), ag_load(&ns->aq_rec[4 * slot + 2]), l, ag_load(&ns->aq_rec[4 * slot + 3]));
             }
             fi_head = head;
             ag_store(&ns->aq_head[l], head);
             if (head < tail) {
                 const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
-                undrained = ag_load(&ns->aq_ts[slot]) + np->link_lat_ns[l];
+                undrained = ag_load(&ns->aq_rec[4 * slot + 1]) + np->link_lat_ns[l];
             }
         }
         return ea;
@@ -875,15 +886,15 @@ struct NetStation {
             const int bcap = bag_capacity();
             for (; head < tail && bag_n < bcap; ++head) {
                 const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
-                const int64_t ta = ag_load(&ns->aq_t[slot]);
-                bag_insert(ta, ag_load(&ns->aq_ts[slot]), ag_load(&ns->aq_cr[slot]), l, ag_load(&ns->aq_lin[slot]));
+                const int64_t ta = ag_load(&ns->aq_rec[4 * slot]);
+                bag_insert(ta, ag_load(&ns->aq_rec[4 * slot + 1]), ag_load(&ns->aq_rec[4 * slot + 2]), l, ag_load(&ns->aq_rec[4 * slot + 3]));
             }
             ag_store(&ns->aq_head[l], head);
             if (head < tail) {
                 // the bag is full: what stays in the queue was sent no earlier than its first entry (send times do not
                 // decrease along a queue), so it arrives no earlier than that + the link's transit floor
                 const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
-                const int64_t lb = ag_load(&ns->aq_ts[slot]) + np->link_lat_ns[l];
+                const int64_t lb = ag_load(&ns->aq_rec[4 * slot + 1]) + np->link_lat_ns[l];
                 undrained = lb < undrained ? lb : undrained;
             }
         }
