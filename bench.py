@@ -234,9 +234,10 @@ def ring_main(args, rank, local_rank, world, distributed, dist):
     if rank == 0:
         step_s = elapsed / args.steps
         # bytes that must cross HBM per run ("the ring's byte model"): three 8-byte log appends per request
-        # (adm, sink_t, sink_created), 80 B per forwarded request (a 5-word message written once by the sender and read once by the
-        # receiver; the RandomRouter forwards every second completion), the per-LP state in and out once (700 B)
-        algo_bytes = requests * 24 + (requests // 2) * 80 + args.n_lp * 700
+        # (adm, sink_t, sink_created), 64 B per forwarded request (a 4-word record {arrival, send, created_at, lineage} written once by
+        # the sender and read once by the receiver; the RandomRouter forwards every second completion), the per-LP state in and out
+        # once (700 B)
+        algo_bytes = requests * 24 + (requests // 2) * 64 + args.n_lp * 700
         async_engine = (args.gpus == 1 and windows <= 5) or (args.gpus > 1 and not args.ring_windows)
         prof = measured_roofline("ring")
         out = {
