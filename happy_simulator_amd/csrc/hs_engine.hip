@@ -42,6 +42,7 @@ struct hs_engine {
     // ... whose nanosecond ties the passes' lineage key does not decide (Totals::undecided), or which stand next to Probes / scheduled
     // Requests / several Sources per Server, run on the single-heap loop (hs_exact.hpp) from start to end instead
     bool exact_only = false;
+    bool tandem_fan_in = false;   // some Server is the downstream of several Servers: no passes, the single heap from the start
     bool exact_prologue = false;   // the prologue takes part in ordinary runs (pre-run events whose indices run-time events can pass)
     std::vector<int64_t> window_ends;   // tandem queues: the end times of the run_until calls since the last reset (replayed on the single heap)
     bool uni_stations = false; // every LP: Poisson Source, exponential single-worker Server, unbounded queue, no stop_after
@@ -493,6 +494,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     // Tandem queues: Server(downstream=<Server>) (components/server/server.py:271-272).  up[d] = the LP that forwards to LP d;
     // an LP's pass = its distance from the head of its chain (hs_station.hpp `trk`).
     std::vector<int32_t> tandem;
+    bool fan_in = false;
     for (int i = 0; i < n; ++i) {
         if ((st->egress ? st->egress[i] : HS_EGRESS_SINK) != HS_EGRESS_SERVER) continue;
         if (tandem.empty()) { tandem.assign((size_t)3 * n, -1); for (int k = 0; k < n; ++k) tandem[(size_t)n + k] = 0; }
@@ -501,22 +503,42 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if (d < 0 || d >= n || d == i) return fail(h, HS_E_INVALID, "LP %d: downstream_lp %d is not another LP of this engine", i, d);
         if ((st->svc_kind ? st->svc_kind[i] : HS_LAT_CONSTANT) == HS_LAT_NO_SERVER || (st->svc_kind ? st->svc_kind[d] : HS_LAT_CONSTANT) == HS_LAT_NO_SERVER)
             return fail(h, HS_E_INVALID, "LP %d: HS_EGRESS_SERVER connects two Servers", i);
-        if (tandem[(size_t)d] >= 0)
-            return fail(h, HS_E_UNSUPPORTED, "LP %d: two Servers (LPs %d and %d) forward to it; one upstream Server per Server is lowered", d, tandem[(size_t)d], i);
-        tandem[(size_t)d] = i;
+        if (tandem[(size_t)d] >= 0) fan_in = true;      // several Servers forward to LP d: no passes, the single-heap loop (below)
+        else tandem[(size_t)d] = i;
         tandem[(size_t)2 * n + i] = d;
     }
     if (!tandem.empty()) {
         if (h->cfg.mode != HS_MODE_SINGLE) return fail(h, HS_E_UNSUPPORTED, "tandem queues (HS_EGRESS_SERVER) need HS_MODE_SINGLE: the LPs of a chain are one Simulation");
+        for (int i = 0; i < n; ++i) {                                   // no cycles of Servers (zero-length services would never end)
+            int steps = 0;
+            for (int d = tandem[(size_t)2 * n + i]; d >= 0; d = tandem[(size_t)2 * n + d])
+                if (++steps > n) return fail(h, HS_E_UNSUPPORTED, "LP %d: a cycle of Servers (downstream of downstream ... of itself) is not lowered", i);
+        }
         int max_pass = 0;
-        for (int i = 0; i < n; ++i) {
+        for (int i = 0; i < n && !fan_in; ++i) {
             int p = 0;
             for (int u = tandem[(size_t)i]; u >= 0; u = tandem[(size_t)u]) if (++p > 6) break;
-            if (p > 6) return fail(h, HS_E_UNSUPPORTED, "LP %d: more than 7 Servers in a row (or a cycle of Servers) is not lowered", i);
+            if (p > 6) return fail(h, HS_E_UNSUPPORTED, "LP %d: more than 7 Servers in a row is not lowered", i);
             tandem[(size_t)n + i] = p;
             if (p > max_pass) max_pass = p;
         }
         h->n_pass = max_pass + 1;
+        h->tandem_fan_in = fan_in;
+        // what a Server behind Servers can admit: its own Sources' ticks plus everything upstream (sizes the record logs)
+        std::vector<double> flow((size_t)n, 0.0);
+        for (int i = 0; i < n; ++i)
+            flow[(size_t)i] = ((st->src_kind ? st->src_kind[i] : HS_SRC_POISSON) != HS_SRC_NONE ? st->src_rate[i] : 0.0) + xsum[(size_t)i];
+        for (int round = 0; round < n; ++round) {                       // (acyclic: settles after as many rounds as the longest chain)
+            std::vector<double> in((size_t)n, 0.0);
+            for (int i = 0; i < n; ++i) { const int d = tandem[(size_t)2 * n + i]; if (d >= 0) in[(size_t)d] += flow[(size_t)i]; }
+            bool changed = false;
+            for (int i = 0; i < n; ++i) {
+                const double f = ((st->src_kind ? st->src_kind[i] : HS_SRC_POISSON) != HS_SRC_NONE ? st->src_rate[i] : 0.0) + xsum[(size_t)i] + in[(size_t)i];
+                if (f != flow[(size_t)i]) { flow[(size_t)i] = f; changed = true; }
+            }
+            if (!changed) break;
+        }
+        for (int i = 0; i < n; ++i) if (flow[(size_t)i] * horizon_s > max_mean_records) max_mean_records = flow[(size_t)i] * horizon_s;
         h->any_profile = true;                                       // the general-path instantiation
         h->uni_grid = false;
     }
@@ -824,7 +846,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         // The prologue (hs_exact.hpp): the reference's pre-run events in the order it constructs them.  (Tandem queues: the same
         // loop as the engine's exact path for whole runs -- `exact_only`.)
         h->exact_prologue = n_sched > 0 || h->any_probe || h->any_xsrc;
-        h->exact_only = !tandem.empty() && h->exact_prologue;
+        h->exact_only = !tandem.empty() && (h->exact_prologue || h->tandem_fan_in);   // (several upstream Servers per Server: one heap)
         std::vector<int32_t> sl((size_t)n_sched);
         std::vector<int64_t> se((size_t)n_sched);
         std::vector<int32_t> lp_of((size_t)n_sched);

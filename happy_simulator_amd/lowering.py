@@ -413,10 +413,7 @@ def lower(sources: list, entities: list) -> LoweredGraph:
             st.links = (*st.links, obj)
         elif isinstance(obj, Server):
             # tandem queues (components/server/server.py:271-272): the completion is the next Server's arrival, at the same instant
-            if id(obj) in fed_by:
-                raise UnsupportedTopology(f"server '{obj.name}' is the downstream of several Servers ('{fed_by[id(obj)]}' and "
-                                          f"{owner}): one upstream Server per Server is lowered")
-            fed_by[id(obj)] = owner
+            fed_by[id(obj)] = owner            # (several upstream Servers per Server: the engine's single-heap path, hs_engine.h)
             st.next_server = obj
         elif isinstance(obj, RandomRouter):
             if id(obj) in used_routers:

@@ -166,9 +166,9 @@ typedef struct hs_stations {
     const uint8_t *source_slot_order;  /* [number of Sources] */
     /* Tandem queues: `Server(..., downstream=<another Server>)` (components/server/server.py:64-122,271-272; the forwarded Event
      * keeps its context, core/entity.py:83-105).  egress[i] == HS_EGRESS_SERVER: every completion of LP i arrives at the Server of
-     * LP downstream_lp[i] at the same instant, created_at unchanged.  At most one upstream Server per Server, at most 7 Servers in a
-     * row, HS_MODE_SINGLE, no hs_engine_set_network; Probes / scheduled Requests / several Sources per Server in the same engine
-     * are refused for now.  The engine runs the chain in passes, upstream first (csrc/hs_station.hpp "tandem queues"); results
+     * LP downstream_lp[i] at the same instant, created_at unchanged.  At most 7 Servers in a row, no cycles, HS_MODE_SINGLE, no
+     * hs_engine_set_network.  A Server with SEVERAL upstream Servers, and tandem queues next to Probes / scheduled Requests / several
+     * Sources per Server, run on the single-heap loop from the start (hs_engine_tandem_path() == 2).  The engine runs the chain in passes, upstream first (csrc/hs_station.hpp "tandem queues"); results
      * equal the reference's single heap event for event, ties inside a nanosecond included.  NULL = no such Server. */
     const int32_t *downstream_lp;      /* [n_lp] read where egress == HS_EGRESS_SERVER */
 } hs_stations;

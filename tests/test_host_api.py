@@ -134,10 +134,10 @@ class TestLowering:
         a = hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=tandem)], entities=[tandem, t2]).lowered().arrays()
         assert a.egress.tolist() == [N.EGRESS_SERVER, N.EGRESS_NONE] and a.downstream_lp.tolist() == [1, -1]
         assert a.src_kind.tolist() == [N.SRC_POISSON, N.SRC_NONE]
-        t3 = hs.Server("t3", downstream=t2)
-        with pytest.raises(hs.UnsupportedTopology, match="one upstream Server per Server"):
-            hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=tandem), hs.Source.poisson(1, target=t3)],
-                          entities=[tandem, t3, t2]).lowered()
+        t3 = hs.Server("t3", downstream=t2)                  # several upstream Servers per Server: lowered too (the engine's single heap)
+        a = hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=tandem), hs.Source.poisson(1, target=t3)],
+                          entities=[tandem, t3, t2]).lowered().arrays()
+        assert a.downstream_lp.tolist() == [2, 2, -1]
         with pytest.raises(hs.UnsupportedTopology, match="not a lowered Probe"):
             hs.Simulation(duration=1, sources=[hs.Source.poisson(1, target=hs.Sink())], probes=[object()]).lowered()
 
