@@ -493,34 +493,44 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     }
     // Tandem queues: Server(downstream=<Server>) (components/server/server.py:271-272).  up[d] = the LP that forwards to LP d;
     // an LP's pass = its distance from the head of its chain (hs_station.hpp `trk`).
-    std::vector<int32_t> tandem;
-    bool fan_in = false;
+    std::vector<int32_t> tandem;                     // hs_tables.hpp TickTables::tandem: kMaxUp upstream rows, the pass, the downstream LP
+    const size_t rowP = (size_t)kMaxUp * n, rowD = (size_t)(kMaxUp + 1) * n;
+    bool fan_in = false;                             // more than kMaxUp Servers forward to one: no passes, the single-heap loop
     for (int i = 0; i < n; ++i) {
         if ((st->egress ? st->egress[i] : HS_EGRESS_SINK) != HS_EGRESS_SERVER) continue;
-        if (tandem.empty()) { tandem.assign((size_t)3 * n, -1); for (int k = 0; k < n; ++k) tandem[(size_t)n + k] = 0; }
+        if (tandem.empty()) { tandem.assign((size_t)(kMaxUp + 2) * n, -1); for (int k = 0; k < n; ++k) tandem[rowP + k] = 0; }
         if (!st->downstream_lp) return fail(h, HS_E_INVALID, "downstream_lp is required with HS_EGRESS_SERVER");
         const int d = st->downstream_lp[i];
         if (d < 0 || d >= n || d == i) return fail(h, HS_E_INVALID, "LP %d: downstream_lp %d is not another LP of this engine", i, d);
         if ((st->svc_kind ? st->svc_kind[i] : HS_LAT_CONSTANT) == HS_LAT_NO_SERVER || (st->svc_kind ? st->svc_kind[d] : HS_LAT_CONSTANT) == HS_LAT_NO_SERVER)
             return fail(h, HS_E_INVALID, "LP %d: HS_EGRESS_SERVER connects two Servers", i);
-        if (tandem[(size_t)d] >= 0) fan_in = true;      // several Servers forward to LP d: no passes, the single-heap loop (below)
-        else tandem[(size_t)d] = i;
-        tandem[(size_t)2 * n + i] = d;
+        int u = 0;
+        while (u < kMaxUp && tandem[(size_t)u * n + d] >= 0) ++u;
+        if (u == kMaxUp) fan_in = true;
+        else tandem[(size_t)u * n + d] = i;
+        tandem[rowD + i] = d;
     }
     if (!tandem.empty()) {
         if (h->cfg.mode != HS_MODE_SINGLE) return fail(h, HS_E_UNSUPPORTED, "tandem queues (HS_EGRESS_SERVER) need HS_MODE_SINGLE: the LPs of a chain are one Simulation");
         for (int i = 0; i < n; ++i) {                                   // no cycles of Servers (zero-length services would never end)
             int steps = 0;
-            for (int d = tandem[(size_t)2 * n + i]; d >= 0; d = tandem[(size_t)2 * n + d])
+            for (int d = tandem[rowD + i]; d >= 0; d = tandem[rowD + d])
                 if (++steps > n) return fail(h, HS_E_UNSUPPORTED, "LP %d: a cycle of Servers (downstream of downstream ... of itself) is not lowered", i);
         }
+        // an LP's pass = the longest chain of Servers above it (acyclic: relax until nothing moves)
         int max_pass = 0;
-        for (int i = 0; i < n && !fan_in; ++i) {
-            int p = 0;
-            for (int u = tandem[(size_t)i]; u >= 0; u = tandem[(size_t)u]) if (++p > 6) break;
-            if (p > 6) return fail(h, HS_E_UNSUPPORTED, "LP %d: more than 7 Servers in a row is not lowered", i);
-            tandem[(size_t)n + i] = p;
-            if (p > max_pass) max_pass = p;
+        for (int round = 0; round < n; ++round) {
+            bool changed = false;
+            for (int i = 0; i < n; ++i) {
+                const int d = tandem[rowD + i];
+                if (d >= 0 && tandem[rowP + d] < tandem[rowP + i] + 1) { tandem[rowP + d] = tandem[rowP + i] + 1; changed = true; }
+            }
+            if (!changed) break;
+        }
+        for (int i = 0; i < n; ++i) max_pass = std::max(max_pass, (int)tandem[rowP + i]);
+        if (max_pass > 6) {
+            if (!fan_in) return fail(h, HS_E_UNSUPPORTED, "more than 7 Servers in a row are not lowered");
+            max_pass = 6;                                                // (fan-in beyond kMaxUp runs on the single heap anyway)
         }
         h->n_pass = max_pass + 1;
         h->tandem_fan_in = fan_in;
@@ -530,7 +540,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
             flow[(size_t)i] = ((st->src_kind ? st->src_kind[i] : HS_SRC_POISSON) != HS_SRC_NONE ? st->src_rate[i] : 0.0) + xsum[(size_t)i];
         for (int round = 0; round < n; ++round) {                       // (acyclic: settles after as many rounds as the longest chain)
             std::vector<double> in((size_t)n, 0.0);
-            for (int i = 0; i < n; ++i) { const int d = tandem[(size_t)2 * n + i]; if (d >= 0) in[(size_t)d] += flow[(size_t)i]; }
+            for (int i = 0; i < n; ++i) { const int d = tandem[rowD + i]; if (d >= 0) in[(size_t)d] += flow[(size_t)i]; }
             bool changed = false;
             for (int i = 0; i < n; ++i) {
                 const double f = ((st->src_kind ? st->src_kind[i] : HS_SRC_POISSON) != HS_SRC_NONE ? st->src_rate[i] : 0.0) + xsum[(size_t)i] + in[(size_t)i];
@@ -704,8 +714,8 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
             if ((double)n * (double)cap * 32.0 > 100e9)
                 return fail(h, HS_E_INVALID, "the forward logs of the tandem queues would need %.1f GB", (double)n * (double)cap * 32.0 / 1e9);
             if ((rc = upload<int32_t>(h, &tt.tandem, tandem.data(), tandem.size(), -1))) return rc;
-            if ((rc = dev_alloc(h, &tt.inj_i, (size_t)n))) return rc;
-            HS_HIP(h, hipMemset(tt.inj_i, 0, (size_t)n * sizeof(int64_t)));
+            if ((rc = dev_alloc(h, &tt.inj_i, (size_t)kMaxUp * (size_t)n))) return rc;
+            HS_HIP(h, hipMemset(tt.inj_i, 0, (size_t)kMaxUp * (size_t)n * sizeof(int64_t)));
             for (int64_t **col : {&tt.fw_rc, &tt.fw_rrc, &tt.fw_rdr, &tt.fw_dep}) if ((rc = dev_alloc(h, col, (size_t)n * (size_t)cap))) return rc;
             for (int64_t **col : {&tt.q_rrc, &tt.q_rdr, &tt.q_pay}) if ((rc = dev_alloc(h, col, (size_t)n * (size_t)kQCap))) return rc;
             if ((rc = dev_alloc(h, &tt.cand_key, (size_t)n * 4))) return rc;
@@ -777,7 +787,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         }
         if (!tandem.empty())                                                     // a Server behind a Server: what reaches it descends
             for (int i = 0; i < n; ++i) {                                        // from the Sources of its chain's head
-                int head = i;
+                int head = i;                                                    // (its first-listed upstream, all the way up)
                 while (tandem[(size_t)head] >= 0) head = tandem[(size_t)head];
                 if (head != i && tr[(size_t)i] < 0 && tr[(size_t)head] >= 0) tr[(size_t)i] = tr[(size_t)head];
             }
@@ -789,7 +799,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
             for (size_t q = 0; q < tr.size(); ++q) {                             // (ranks only compare: room for the pass below them)
                 const size_t lp = q < (size_t)n * (kMaxXSrc + 2) ? q % (size_t)n : (q - (size_t)n * (kMaxXSrc + 2) - 1) % (size_t)n;
                 if (q == (size_t)n * (kMaxXSrc + 2)) { tr[q] = tr[q] * 8; continue; }
-                tr[q] = tr[q] * 8 + tandem[(size_t)n + lp];
+                tr[q] = tr[q] * 8 + tandem[(size_t)kMaxUp * n + lp];
             }
         if ((rc = upload<int32_t>(h, &h->P.tie_rank, tr.data(), tr.size(), 0))) return rc;
     }

@@ -409,7 +409,7 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
             else if (eg == EG_LINK) xpush(S, xev(t, S.G++, XE_LINK, lp, cr, NP.link_of[lp]));
             else if (eg == EG_ROUTER) xpush(S, xev(t, S.G++, XE_ROUTE, lp, cr));
             else if (eg == kEgressServer)                                    // forward(event, downstream) to another Server: its Request,
-                xpush(S, xev(t, S.G++, XE_ENQ, P.tabs->tandem[2 * N + lp], cr));   // context preserved (core/entity.py:83-105)
+                xpush(S, xev(t, S.G++, XE_ENQ, P.tabs->tandem[(size_t)(kMaxUp + 1) * N + lp], cr));   // context preserved (core/entity.py:83-105)
             if (active < P.conc[lp]) xpush(S, xev(t, S.G++, XE_POLL, lp));
         } break;
         case XE_SINK: {                                                      // Sink.handle_event (components/common.py:36-44)

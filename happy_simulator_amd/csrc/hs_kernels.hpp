@@ -147,7 +147,9 @@ __device__ __forceinline__ void load_station(Station<C, PF, UNI> &S, const Stati
         }
         S.probe_t = L.probe_t + lp; S.probe_v = L.probe_v + lp; S.pcap = L.pcap;
     }
-    S.trk = false; S.up = -1; S.inj_i = 0; S.inj_n = 0; S.IA = kInfNs; S.imask = 0; S.cur_pay = 0; S.undecided = 0;
+    S.trk = false; S.n_up = 0; S.cur_pay = 0; S.undecided = 0; S.wk = 0;
+#pragma unroll
+    for (int u = 0; u < kMaxUp; ++u) { S.U[u].up = -1; S.U[u].i = 0; S.U[u].n = 0; S.U[u].IA = kInfNs; S.U[u].mask = 0; }
     S.rk_dp = 0; S.rk_rank = 0; S.rk_rc = INT64_MIN; S.tie_rank_p = P.tie_rank; S.n_rank = n;
     if constexpr (PF) {
         if (P.tabs != nullptr && P.tabs->tandem != nullptr) {            // tandem queues (hs_station.hpp `trk`)
@@ -155,15 +157,19 @@ __device__ __forceinline__ void load_station(Station<C, PF, UNI> &S, const Stati
             S.trk = true;
             S.fw_rc = T.fw_rc + lp; S.fw_rrc = T.fw_rrc + lp; S.fw_rdr = T.fw_rdr + lp; S.fw_dep = T.fw_dep + lp;
             S.q_rrc = T.q_rrc + lp; S.q_rdr = T.q_rdr + lp; S.q_pay = T.q_pay + lp;
-            S.up = T.tandem[lp];
-            if (S.up >= 0) {
-                const int up = S.up;
-                S.inj_i_p = T.inj_i + lp; S.inj_i = *S.inj_i_p;
-                S.inj_n = X.received[up];                               // forwards it has published (its pass is over)
-                S.inj_n = S.inj_n < L.cap ? S.inj_n : L.cap;
-                S.up_t = L.sink_t + up; S.up_created = ((C > 1) ? L.sink_created : L.adm) + up;
-                S.up_rc = T.fw_rc + up; S.up_rrc = T.fw_rrc + up; S.up_rdr = T.fw_rdr + up; S.up_dep = T.fw_dep + up;
-                S.IA = S.inj_i < S.inj_n ? S.up_t[(size_t)S.inj_i * (size_t)n] : kInfNs;
+#pragma unroll
+            for (int u = 0; u < kMaxUp; ++u) {
+                const int up = T.tandem[(size_t)u * n + lp];
+                if (up < 0) continue;
+                S.n_up = u + 1;                                          // (the lists are filled from 0)
+                auto &Lu = S.U[u];
+                Lu.up = up;
+                Lu.i_p = T.inj_i + (size_t)u * n + lp; Lu.i = *Lu.i_p;
+                Lu.n = X.received[up];                                   // forwards it has published (its pass is over)
+                Lu.n = Lu.n < L.cap ? Lu.n : L.cap;
+                Lu.t = L.sink_t + up; Lu.created = ((C > 1) ? L.sink_created : L.adm) + up;
+                Lu.rc = T.fw_rc + up; Lu.rrc = T.fw_rrc + up; Lu.rdr = T.fw_rdr + up; Lu.dep = T.fw_dep + up;
+                Lu.IA = Lu.i < Lu.n ? Lu.t[(size_t)Lu.i * (size_t)n] : kInfNs;
             }
         }
     }
@@ -254,7 +260,10 @@ __device__ __forceinline__ void store_station(const Station<C, PF, UNI> &Sc, con
         X.ev_probe[lp] += S.evp[0]; X.ev_probe[(size_t)n + lp] += S.evp[1];
         tot += S.evp[0] + S.evp[1];
         if (S.sc_t != nullptr) X.sched_i[lp] = S.sc_i;
-        if (S.trk && S.up >= 0) *S.inj_i_p = S.inj_i;      // (imask == 0 between groups: a run of forwards is consumed whole)
+        if (S.trk) {                                       // (mask == 0 between groups: a run of forwards is consumed whole)
+#pragma unroll
+            for (int u = 0; u < kMaxUp; ++u) if (u < S.n_up) *S.U[u].i_p = S.U[u].i;
+        }
 #pragma unroll
         for (int j = 0; j < kMaxXSrc; ++j) if (j < S.n_xsrc) {
             const size_t o = (size_t)j * n + lp;
@@ -279,12 +288,12 @@ __device__ __forceinline__ Candidate make_candidate(const Station<C, PF, UNI> &S
     c.t = t; c.valid = 1;
     c.t_created = S.root_crt(w);
     if (w == 0) { c.depth = S.dpA; c.rcrt = S.rcA; c.pad = 2; }
-    else if (PF && w >= kRootXSrc) {
+    else if (PF && w >= kRootXSrc && w < kRootInj) {
 #pragma unroll
         for (int j = 0; j < kMaxXSrc; ++j) if (j == w - kRootXSrc) { c.depth = S.dpX[j]; c.rcrt = S.rcX[j]; }
         c.pad = 3 + (w - kRootXSrc);
     }
-    else if (PF && w >= kRootProbe) {
+    else if (PF && w >= kRootProbe && w < kRootInj) {
 #pragma unroll
         for (int j = 0; j < kMaxProbes; ++j) if (j == w - kRootProbe) c.rcrt = S.rcP[j];
         c.depth = 1;            // a Probe's next tick is created by its tick, always a root
@@ -378,7 +387,9 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
     }
     for (int k = 0; k < 11; ++k) X.ev_kind[(size_t)k * n + lp] = 0;
     if constexpr (!PF) return;
-    if constexpr (PF) { if (P.tabs != nullptr && P.tabs->tandem != nullptr) P.tabs->inj_i[lp] = 0; }   // tandem: no forward consumed yet
+    if constexpr (PF) {                                    // tandem: no forward consumed yet
+        if (P.tabs != nullptr && P.tabs->tandem != nullptr) for (int u = 0; u < kMaxUp; ++u) P.tabs->inj_i[(size_t)u * n + lp] = 0;
+    }
     if (X.XA != nullptr) {   // the LP's further Sources: each draws its first arrival from start_ns like the first one
         for (int j = 0; j < kMaxXSrc; ++j) {
             const size_t o = (size_t)j * n + lp;
@@ -530,7 +541,7 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
     }
     if (live) {
         load_station<C, PF, UNI>(S, P, X, L, lp, n, qmem, ring_a, ring_s, tid);
-        S.force_general = (flags & 1) != 0 || (PF && S.trk && (S.up >= 0 || S.egress == kEgressServer));   // (tandem LPs: event order)
+        S.force_general = (flags & 1) != 0 || (PF && S.trk && (S.n_up > 0 || S.egress == kEgressServer));   // (tandem LPs: event order)
     }
     const bool ended = (mode == HS_MODE_REPLICAS) ? (live && S.last_time > end_ns) : (cur > end_ns);
     // tandem queues run in passes, upstream Servers first (hs_station.hpp `trk`): flags bits 28..30 = pass + 1; an LP of another
@@ -538,7 +549,7 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
     bool other_pass = false;
     if constexpr (PF) {
         const int pass1 = (flags >> 28) & 7;
-        if (pass1 != 0 && live && P.tabs != nullptr && P.tabs->tandem != nullptr) other_pass = P.tabs->tandem[(size_t)n + lp] != pass1 - 1;
+        if (pass1 != 0 && live && P.tabs != nullptr && P.tabs->tandem != nullptr) other_pass = P.tabs->tandem[(size_t)kMaxUp * n + lp] != pass1 - 1;
     }
     const bool frozen = ended || other_pass;
     bool pre_group = false;
@@ -620,7 +631,7 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
             }
             if (bail_reload) {
                 load_station<C, PF, UNI>(S, P, X, L, lp, n, qmem, ring_a, ring_s, tid);
-                S.force_general = (flags & 1) != 0 || (PF && S.trk && (S.up >= 0 || S.egress == kEgressServer));   // (tandem LPs: event order)
+                S.force_general = (flags & 1) != 0 || (PF && S.trk && (S.n_up > 0 || S.egress == kEgressServer));   // (tandem LPs: event order)
             }
         }
         // (2) event-order loop for whatever (1) does not cover

@@ -38,7 +38,8 @@ __device__ __forceinline__ uint64_t xsrc_stream_id(uint64_t lp_stream_base, int 
     return stream_id((1ull << 40) | (lp_stream_base << 2) | (uint64_t)j, kStreamArrival);
 }
 constexpr int kRootSched = 98;  // pick_root: the next Request injected with Simulation.schedule()
-constexpr int kRootInj = 40;    // pick_root: forward j of the run of forwards that arrive from the upstream Server at this nanosecond
+constexpr int kRootInj = 200;   // pick_root: kRootInj + 32 u + j = forward j of the run of forwards that arrive from upstream Server u at this nanosecond
+constexpr int kMaxUp = 4;       // upstream Servers of one Server on the passes (more: the single-heap loop)
 constexpr int kMaxInjRun = 32;  // ... such runs are one long (two upstream workers finishing on one nanosecond: two)
 constexpr uint32_t kEgressServer = 4;   // HS_EGRESS_SERVER: the Server forwards to another Server (tandem queues)
 
@@ -320,16 +321,25 @@ struct Station {
     int32_t rk_dp, rk_rank;     // key of the root of the chain being processed: its steps from ITS group's root, construction rank,
     int64_t rk_rc;              // ... and that group's root's creation time (its own creation time is cr)
     int64_t cur_pay;            // created_at carried by the FIFO entry just popped (a forward on its way to the enqueue)
+    // The steps `cd` count the retargeted payload (Request@worker) as a step of its own -- the convention of the election key --
+    // but in the heap that payload keeps its OLD sort index and runs at once, inside its QUEUE_DELIVER's turn: it does not take a
+    // place in the nanosecond's breadth-first order.  Where a forwarded Request lands among the downstream Server's events is a
+    // matter of that order, so the payloads on the way are counted (`wk`) and taken off again (fw_dep: cd - wk places it)
+    int32_t wk;
     const int32_t *tie_rank_p; int n_rank;   // cand_rank()'s table
     int64_t *fw_rc, *fw_rrc, *fw_rdr, *fw_dep;   // this LP's forward-log lineage columns, record m at [m * ls]
     int64_t *q_rrc, *q_rdr, *q_pay;              // this LP's FIFO root-key / payload columns, entry `slot` at [slot * ls]
-    // forwards arriving from the upstream LP `up`: records inj_i .. inj_n - 1 of ITS log (complete: its pass is over)
-    int up;
-    int64_t inj_i, inj_n, IA;   // IA: time of record inj_i (kInfNs: none left)
-    int64_t *inj_i_p;
-    uint32_t imask;             // forwards of the current nanosecond's run already taken as roots (bit j: record inj_i + j)
+    // forwards arriving from the upstream LPs U[u].up: records i .. n - 1 of THEIR logs (complete: their passes are over)
+    struct UpList {
+        int up;                 // the upstream LP (-1: none)
+        int64_t i, n, IA;       // records consumed / published; IA: time of record i (kInfNs: none left)
+        uint32_t mask;          // forwards of the current nanosecond's run already taken as roots (bit j: record i + j)
+        int64_t *i_p;
+        const int64_t *t, *created, *rc, *rrc, *rdr, *dep;
+    };
+    UpList U[kMaxUp];
+    int n_up;
     int undecided;              // Totals::undecided bit 0, this LP
-    const int64_t *up_t, *up_created, *up_rc, *up_rrc, *up_rdr, *up_dep;
 
     // an event created by the one being processed: one step further from the group's root
     __device__ __forceinline__ void qpush(uint32_t code, int64_t pay = 0) {
@@ -339,7 +349,7 @@ struct Station {
         qdep[(size_t)slot * ls] = (uint8_t)(cd >= 254 ? 255 : cd + 1);
         qrc[(size_t)slot * ls] = cr;
         if constexpr (PF) {
-            if (trk) { q_rrc[(size_t)slot * ls] = rk_rc; q_rdr[(size_t)slot * ls] = rk_pack(); q_pay[(size_t)slot * ls] = pay; }
+            if (trk) { q_rrc[(size_t)slot * ls] = rk_rc; q_rdr[(size_t)slot * ls] = rk_pack() | ((int64_t)(wk & 0x7f) << 56); q_pay[(size_t)slot * ls] = pay; }
         }
         ++qn;
     }
@@ -348,14 +358,14 @@ struct Station {
         cd = qdep[(size_t)qh * ls];
         cr = qrc[(size_t)qh * ls];
         if constexpr (PF) {
-            if (trk) { rk_rc = q_rrc[(size_t)qh * ls]; rk_unpack(q_rdr[(size_t)qh * ls]); cur_pay = q_pay[(size_t)qh * ls]; }
+            if (trk) { rk_rc = q_rrc[(size_t)qh * ls]; rk_unpack(q_rdr[(size_t)qh * ls]); wk = (int32_t)(q_rdr[(size_t)qh * ls] >> 56); cur_pay = q_pay[(size_t)qh * ls]; }
         }
         qh = (qh + 1) % kQCap;
         --qn;
         return c;
     }
     __device__ __forceinline__ int64_t rk_pack() const { return (int64_t)(uint32_t)(rk_dp & 0xff) | ((int64_t)rk_rank << 8); }
-    __device__ __forceinline__ void rk_unpack(int64_t w) { rk_dp = (int32_t)(w & 0xff); rk_rank = (int32_t)(w >> 8); }
+    __device__ __forceinline__ void rk_unpack(int64_t w) { rk_dp = (int32_t)(w & 0xff); rk_rank = (int32_t)((w >> 8) & 0xffffffffll); }
     __device__ __forceinline__ int32_t dp_next(int steps) const { return cd + steps > 255 ? 255 : cd + steps; }
 
     __device__ __forceinline__ void init_streams(uint64_t seed, uint64_t base, uint64_t ak, uint64_t sk,
@@ -513,7 +523,7 @@ struct Station {
             if (d == t) { D[i] = kInfNs - 1; same = (uint32_t)i + 1; }   // in-group continuation: parked, not pending
             else { D[i] = d; seqD[i] = seq++; crtD[i] = t; dpD[i] = dp_next(2); rcD[i] = cr; }   // QUEUE_DELIVER -> payload -> continuation
         }
-        if (same) ++cd;                                                   // (the caller pushes the in-group continuation: deliver + 2)
+        if (same) { ++cd; if constexpr (PF) ++wk; }                        // (the caller pushes the in-group continuation: deliver + 2)
         return same;
     }
     // generator resumes (server/server.py:252-273) + schedule_poll hook (queue_driver.py:79-84).
@@ -544,7 +554,8 @@ struct Station {
         if constexpr (PF) {
             if (egress == kEgressServer) {
                 if (received < cap) {
-                    fw_rc[received * ls] = cr; fw_rrc[received * ls] = rk_rc; fw_rdr[received * ls] = rk_pack(); fw_dep[received * ls] = cd;
+                    fw_rc[received * ls] = cr; fw_rrc[received * ls] = rk_rc; fw_rdr[received * ls] = rk_pack();
+                    fw_dep[received * ls] = ((int64_t)cd << 8) | (int64_t)(cd - wk);          // steps by the key's count | places in the order
                 }
                 received++;
                 return;
@@ -613,36 +624,58 @@ struct Station {
         if (do_enqueue(t)) qpush(Q_NOTIFY);
     }
 
-    // ---- tandem: the forwards of the upstream Server (see `trk` above)
-    __device__ __forceinline__ bool has_inj() const { return PF && IA != kInfNs; }
-    __device__ __forceinline__ int64_t inj_time(int64_t k) const { return k < inj_n ? up_t[k * ls] : kInfNs; }
-    // forward j of the run at time t (records inj_i + j, all at t) whose root comes first, among those not taken yet: -1 none
-    __device__ __forceinline__ int inj_pick(int64_t t) const {
-        int best = -1;
-        for (int j = 0; j < kMaxInjRun && inj_time(inj_i + j) == t; ++j) {
-            if (imask & (1u << j)) continue;
-            if (best < 0 || inj_key_less(inj_i + j, inj_i + best)) best = j;
-        }
-        return best;
+    // ---- tandem: the forwards of the upstream Servers (see `trk` above)
+    __device__ __forceinline__ int64_t inj_next() const {                          // earliest forward still to arrive
+        int64_t m = kInfNs;
+#pragma unroll
+        for (int u = 0; u < kMaxUp; ++u) if (u < n_up && U[u].IA < m) m = U[u].IA;
+        return m;
     }
-    __device__ __forceinline__ bool inj_key_less(int64_t a, int64_t b) const {    // cand_less on the roots of two forwards
-        const int64_t ca = up_rc[a * ls], cb = up_rc[b * ls];
+    __device__ __forceinline__ bool has_inj() const { return PF && inj_next() != kInfNs; }
+    __device__ __forceinline__ int64_t inj_time(const UpList &L, int64_t k) const { return k < L.n ? L.t[k * ls] : kInfNs; }
+    // cand_less on the roots of two forwards; `tie`: the whole key agrees (the roots' own ancestry would decide)
+    __device__ __forceinline__ bool inj_key_less(const UpList &A, int64_t a, const UpList &B, int64_t b, bool &tie) const {
+        tie = false;
+        const int64_t ca = A.rc[a * ls], cb = B.rc[b * ls];
         if (ca != cb) return ca < cb;
-        const int64_t da = up_rdr[a * ls], db = up_rdr[b * ls];
+        const int64_t da = A.rdr[a * ls], db = B.rdr[b * ls];
         if ((da & 0xff) != (db & 0xff)) return (da & 0xff) < (db & 0xff);
-        const int64_t ra = up_rrc[a * ls], rb = up_rrc[b * ls];
+        const int64_t ra = A.rrc[a * ls], rb = B.rrc[b * ls];
         if (ra != rb) return ra < rb;
-        return (da >> 8) < (db >> 8);                                              // (equal: list order -- the `best < 0 ||` above)
+        tie = true;
+        return (da >> 8) < (db >> 8);
+    }
+    // the forward at time t whose root comes first, among those of every upstream list not taken yet: u_best < 0 none.  Inside one
+    // list equal keys keep the list's order (= the upstream LP's processing order: exact); between lists a full tie is undecided.
+    __device__ __forceinline__ void inj_pick(int64_t t, int &u_best, int &j_best) const {
+        u_best = -1; j_best = -1;
+#pragma unroll
+        for (int u = 0; u < kMaxUp; ++u) {
+            if (u >= n_up || U[u].IA != t) continue;
+            int best = -1;
+            for (int j = 0; j < kMaxInjRun && inj_time(U[u], U[u].i + j) == t; ++j) {
+                if (U[u].mask & (1u << j)) continue;
+                bool tie;
+                if (best < 0 || (inj_key_less(U[u], U[u].i + j, U[u], U[u].i + best, tie) && !tie)) best = j;
+            }
+            if (best < 0) continue;
+            if (u_best < 0) { u_best = u; j_best = best; continue; }
+            bool tie = false, less = false;
+#pragma unroll
+            for (int v = 0; v < kMaxUp; ++v) if (v == u_best) less = inj_key_less(U[u], U[u].i + best, U[v], U[v].i + j_best, tie);
+            if (tie) const_cast<Station *>(this)->undecided = 1;
+            if (less) { u_best = u; j_best = best; }
+        }
     }
     // ... against one of this LP's own pending roots `w` (pick_root's code): true = the forward's root was created first
-    __device__ __forceinline__ bool inj_before_own(int64_t k, int w) const {
+    __device__ __forceinline__ bool inj_before_own(const UpList &L, int64_t k, int w) const {
         int32_t dp; int64_t rc; int pad;
         own_root_key(w, dp, rc, pad);
-        const int64_t ca = up_rc[k * ls], cb = root_crt(w);
+        const int64_t ca = L.rc[k * ls], cb = root_crt(w);
         if (ca != cb) return ca < cb;
-        const int64_t da = up_rdr[k * ls];
+        const int64_t da = L.rdr[k * ls];
         if ((int32_t)(da & 0xff) != dp) return (int32_t)(da & 0xff) < dp;
-        const int64_t ra = up_rrc[k * ls];
+        const int64_t ra = L.rrc[k * ls];
         if (ra != rc) return ra < rc;
         const_cast<Station *>(this)->undecided = 1;                                // (the roots' own ancestry would decide: Totals::undecided)
         return (int32_t)(da >> 8) < rank_of(pad);
@@ -651,11 +684,11 @@ struct Station {
     __device__ __forceinline__ void own_root_key(int w, int32_t &dp, int64_t &rc, int &pad) const {
         dp = 0; rc = INT64_MIN; pad = 0;
         if (w == 0) { dp = dpA; rc = rcA; pad = 2; }
-        else if (PF && w >= kRootXSrc) {
+        else if (PF && w >= kRootXSrc && w < kRootInj) {
 #pragma unroll
             for (int j = 0; j < kMaxXSrc; ++j) if (j == w - kRootXSrc) { dp = dpX[j]; rc = rcX[j]; }
             pad = 3 + (w - kRootXSrc);
-        } else if (PF && w >= kRootProbe) {
+        } else if (PF && w >= kRootProbe && w < kRootInj) {
 #pragma unroll
             for (int j = 0; j < kMaxProbes; ++j) if (j == w - kRootProbe) rc = rcP[j];
             dp = 1; pad = 8 + (w - kRootProbe);
@@ -673,18 +706,25 @@ struct Station {
         return tie_rank_p[lp];
     }
     // the forward's root, entered among this LP's roots: it does nothing here but head the chain that ends in the Request@Server
-    __device__ __forceinline__ void root_inj(int j, int64_t t) {
-        const int64_t k = inj_i + j;
-        const int64_t dep = up_dep[k * ls];
-        cr = up_rc[k * ls]; rk_rc = up_rrc[k * ls]; rk_unpack(up_rdr[k * ls]);     // (cd = 0: run_root)
-        if (dep < 1 || dep > 31) { qoverflow = 1; }                               // (a same-nanosecond chain deeper than the FIFO codes hold)
-        else qpush(Q_ENQ | ((uint32_t)dep << 3), up_created[k * ls]);
-        imask |= 1u << j;
-        // the run is consumed once every forward of it has been taken
-        int len = 0;
-        while (len < kMaxInjRun && inj_time(inj_i + len) == t) ++len;
-        if (inj_time(inj_i + len) == t && len == kMaxInjRun) qoverflow = 1;        // (a longer run than the mask holds)
-        if (imask == (len >= 32 ? 0xffffffffu : ((1u << len) - 1u))) { inj_i += len; imask = 0; IA = inj_time(inj_i); }
+    __device__ __forceinline__ void root_inj(int uu, int j, int64_t t) {
+#pragma unroll
+        for (int u = 0; u < kMaxUp; ++u) {
+            if (u != uu) continue;
+            UpList &L = U[u];
+            const int64_t k = L.i + j;
+            const int64_t dv = L.dep[k * ls];
+            const int32_t dep = (int32_t)(dv & 0xff), label = (int32_t)(dv >> 8);  // places in the breadth-first order | the key's steps
+            cr = L.rc[k * ls]; rk_rc = L.rrc[k * ls]; rk_unpack(L.rdr[k * ls]);
+            wk = label - dep; cd = wk;                                            // (the placeholders add `dep` steps: the Request arrives with `label`)
+            if (dep < 1 || dep > 31) { qoverflow = 1; }                           // (a same-nanosecond chain deeper than the FIFO codes hold)
+            else qpush(Q_ENQ | ((uint32_t)dep << 3), L.created[k * ls]);
+            L.mask |= 1u << j;
+            // the run is consumed once every forward of it has been taken
+            int len = 0;
+            while (len < kMaxInjRun && inj_time(L, L.i + len) == t) ++len;
+            if (inj_time(L, L.i + len) == t && len == kMaxInjRun) qoverflow = 1;   // (a longer run than the mask holds)
+            if (L.mask == (len >= 32 ? 0xffffffffu : ((1u << len) - 1u))) { L.i += len; L.mask = 0; L.IA = inj_time(L, L.i); }
+        }
     }
 
     // ---- further Sources: Source.handle_event (load/source.py:142-180) of an entity of its own; its payload is one more
@@ -778,9 +818,15 @@ struct Station {
 #pragma unroll
             for (int j = 0; j < kMaxXSrc; ++j)
                 if (j < n_xsrc && XA[j] == t && (best < 0 || (int32_t)(seqX[j] - bs) < 0)) { best = kRootXSrc + j; bs = seqX[j]; }
-            if (IA == t) {      // tandem: the roots of the forwards arriving now compete by the election key
-                const int j = inj_pick(t);
-                if (j >= 0 && (best < 0 || inj_before_own(inj_i + j, best))) best = kRootInj + j;
+            if (n_up > 0 && inj_next() == t) {      // tandem: the roots of the forwards arriving now compete by the election key
+                int u, j;
+                inj_pick(t, u, j);
+                if (u >= 0) {
+                    bool first = best < 0;
+#pragma unroll
+                    for (int v = 0; v < kMaxUp; ++v) if (v == u && !first) first = inj_before_own(U[v], U[v].i + j, best);
+                    if (first) best = kRootInj + 32 * u + j;
+                }
             }
         }
         return best;
@@ -788,12 +834,18 @@ struct Station {
     // creation time of pending root `which` (pick_root's code)
     __device__ __forceinline__ int64_t root_crt(int which) const {
         int64_t c = INT64_MIN;                                            // kRootSched: constructed before run()
-        if (PF && which >= kRootInj && which < kRootInj + kMaxInjRun) return up_rc[(inj_i + (which - kRootInj)) * ls];
+        if (PF && which >= kRootInj) {
+            const int u = (which - kRootInj) >> 5, j = (which - kRootInj) & 31;
+            int64_t c = INT64_MIN;
+#pragma unroll
+            for (int v = 0; v < kMaxUp; ++v) if (v == u) c = U[v].rc[(U[v].i + j) * ls];
+            return c;
+        }
         if (which == 0) c = crtA;
-        else if (PF && which >= kRootXSrc) {
+        else if (PF && which >= kRootXSrc && which < kRootInj) {
 #pragma unroll
             for (int j = 0; j < kMaxXSrc; ++j) if (j == which - kRootXSrc) c = crtX[j];
-        } else if (PF && which >= kRootProbe) {
+        } else if (PF && which >= kRootProbe && which < kRootInj) {
 #pragma unroll
             for (int j = 0; j < kMaxProbes; ++j) if (j == which - kRootProbe) c = crtP[j];
         } else if (!(PF && which == kRootSched)) {
@@ -806,10 +858,11 @@ struct Station {
         cd = 0; cr = root_crt(which);                                     // a root: pending from an earlier nanosecond
         if constexpr (PF) {
             if (trk) {
-                if (which >= kRootInj && which < kRootInj + kMaxInjRun) { root_inj(which - kRootInj, t); return; }
+                if (which >= kRootInj) { root_inj((which - kRootInj) >> 5, (which - kRootInj) & 31, t); return; }
                 int pad;
                 own_root_key(which, rk_dp, rk_rc, pad);
                 rk_rank = rank_of(pad);
+                wk = 0;
             }
         }
         if (which == 0) root_tick(t);
@@ -864,7 +917,7 @@ struct Station {
         for (int i = 0; i < C; ++i) t = D[i] < t ? D[i] : t;
         if constexpr (PF) { if (has_probe()) { const int64_t pm = probe_min(); if (pm < t) t = pm; } if (SA < t) t = SA; }
         if constexpr (PF) { if (has_xsrc()) { const int64_t xm = xsrc_min(); if (xm < t) t = xm; } }
-        if constexpr (PF) { if (IA < t) t = IA; }
+        if constexpr (PF) { if (n_up > 0) { const int64_t ia = inj_next(); if (ia < t) t = ia; } }
         return t;
     }
 

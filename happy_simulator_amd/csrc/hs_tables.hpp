@@ -40,9 +40,9 @@ struct TickTables {
     // ---- tandem queues (Server(downstream=<Server>), hs_station.hpp "tandem"): further per-engine arrays that only the PF
     // instantiations read live behind this pointer as well, so that the headline kernels' argument list stays what it was.
     // null = the engine has no Server that forwards to a Server.
-    const int32_t *tandem;     // [3][n_lp]: [0][lp] the LP whose forwarded Requests arrive here (-1: none); [1][lp] the LP's pass;
-                               // [2][lp] the LP this LP's Server forwards to (-1: none)
-    int64_t *inj_i;            // [n_lp] forwards of the upstream LP consumed so far
+    const int32_t *tandem;     // [kMaxUp + 2][n_lp]: rows 0 .. kMaxUp-1 the LPs whose forwarded Requests arrive here (-1: none,
+                               // filled from 0); row kMaxUp the LP's pass; row kMaxUp + 1 the LP this LP's Server forwards to (-1: none)
+    int64_t *inj_i;            // [kMaxUp][n_lp] forwards of each upstream LP consumed so far
     // lineage of forward record m of an LP (its time / created_at are record m of the LP's sink_t / sink_created logs): when the
     // root of the nanosecond group the forward was created in was created, that root's own lineage (its root's creation time;
     // steps | construction rank << 8), and how many steps below the root the forwarded Request is.  [cap][n_lp]

@@ -290,14 +290,23 @@ def _run_fan_in(case):
 
 
 def test_several_upstream_servers_per_server_match_the_oracle():
-    """Fan-in (`Server(downstream=s)` for several Servers with the same `s`): the single-heap loop from the start."""
-    seen = {True: 0, False: 0}
-    for k in range(120):
+    """Fan-in (`Server(downstream=s)` for several Servers with the same `s`): up to four upstream Servers per Server on the passes
+    (the downstream LP merges their forward logs by the roots' keys), more -- or an undecided tie -- on the single-heap loop."""
+    seen, paths = {True: 0, False: 0}, {1: 0, 2: 0}
+    for k in range(300):
         try:
             fan_in, path = _run_fan_in(_fan_in_case(k))
         except AssertionError as e:
             raise AssertionError(f"_fan_in_case({k}): {e}") from e
         seen[fan_in] += 1
         if fan_in:
-            assert path == 2
-    assert seen[True] >= 40
+            paths[path] += 1
+    print("fan-in cases on the passes / on the single heap:", paths)
+    assert seen[True] >= 100 and paths[1] > paths[2]
+
+
+def test_more_upstream_servers_than_the_passes_merge_run_on_the_single_heap():
+    sv = [dict(svc="exp", mean=0.05, conc=1, qcap=None, src=("poisson", 6.0), sink=False) for _ in range(6)]
+    sv.append(dict(svc="exp", mean=0.01, conc=2, qcap=None, src=None, sink=True))
+    fan_in, path = _run_fan_in(dict(servers=sv, down=[6] * 6 + [-1], end_s=3.0, seed=5))
+    assert fan_in and path == 2

@@ -117,8 +117,14 @@ def tandem(k):
     _run_case(spec, windows=() if k % 3 else (0.37 * spec["end_s"], 0.81 * spec["end_s"]))
 
 
+def tandem_fan_in(k):
+    from test_gpu_tandem import _fan_in_case, _run_fan_in
+
+    _run_fan_in(_fan_in_case(k))
+
+
 FAMILIES = [station, tie, multi_source, ring_async, ring_windowed, multi_source_ring_async, multi_source_ring_windowed, lb,
-            lb_probes, lb_profiles, tandem]
+            lb_probes, lb_profiles, tandem, tandem_fan_in]
 # (round 2 listed 13 tie storms here -- the cross-LP election of the one event beyond end_time, closed by the lineage key)
 KNOWN = set()
 # refused by design (HS_E_UNSUPPORTED), never guessed: a probe on the nanosecond of an event of its target on a load-balancer
