@@ -619,6 +619,10 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if (n_sched > 0) { h->any_profile = true; h->any_sched = true; }
     }
     h->C = maxc <= 1 ? 1 : maxc <= 2 ? 2 : maxc <= 4 ? 4 : maxc <= 8 ? 8 : maxc <= 16 ? 16 : 32;
+    // (C == 1 reads a sink record's created_at from the admission log: the m-th completion is the m-th admission.  A tandem Server
+    // can take two enqueues and a poll in one nanosecond -- a forward beside its own Source's Request -- deliver both and REJECT
+    // the second at the worker (server.py:223-234), after which that shortcut is off by one: explicit column, C >= 2.)
+    if (!tandem.empty() && h->C == 1) h->C = 2;
     int64_t cap = h->cfg.log_capacity;
     if (cap <= 0) {
         const double c = max_mean_records + 10.0 * std::sqrt(max_mean_records + 1.0) + 64.0 + (double)max_sched;
@@ -913,7 +917,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     AL(generated, N); AL(accepted, N); AL(dropped, N); AL(completed, N); AL(rejected, N); AL(started, N);
     AL(received, N); AL(sink_w, N); AL(total_service, N); AL(q, N); AL(grp_time, N); AL(last_time, N);
     AL(events, N); AL(ev_kind, N * 11);
-    AL(dpA, N); AL(rcA, N); AL(dpD, NC); AL(rcD, NC); AL(qdep, N * kQCap); AL(qrc, N * kQCap);   // lineage (hs_station.hpp)
+    AL(dpA, N); AL(rcA, N); AL(dpD, NC); AL(rcD, NC); AL(wkD, NC); AL(qdep, N * kQCap); AL(qrc, N * kQCap);   // lineage (hs_station.hpp)
     if (h->any_profile) {      // the general-path instantiation of the run kernel loads / stores the probe state of every LP
         AL(PA, N * kMaxProbes); AL(seqP, N * kMaxProbes); AL(crtP, N * kMaxProbes); AL(p_arr, N * kMaxProbes);
         AL(p_n, N * kMaxProbes); AL(ev_probe, N * 2); AL(sched_i, N); AL(rcP, N * kMaxProbes);

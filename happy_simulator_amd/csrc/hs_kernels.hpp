@@ -147,7 +147,9 @@ __device__ __forceinline__ void load_station(Station<C, PF, UNI> &S, const Stati
         }
         S.probe_t = L.probe_t + lp; S.probe_v = L.probe_v + lp; S.pcap = L.pcap;
     }
-    S.trk = false; S.n_up = 0; S.cur_pay = 0; S.undecided = 0; S.wk = 0;
+    S.trk = false; S.n_up = 0; S.cur_pay = 0; S.undecided = 0; S.wk = 0; S.rk_wk = 0;
+#pragma unroll
+    for (int i = 0; i < C; ++i) S.wkD[i] = PF ? (int32_t)X.wkD[(size_t)i * n + lp] : 1;
 #pragma unroll
     for (int u = 0; u < kMaxUp; ++u) { S.U[u].up = -1; S.U[u].i = 0; S.U[u].n = 0; S.U[u].IA = kInfNs; S.U[u].mask = 0; }
     S.rk_dp = 0; S.rk_rank = 0; S.rk_rc = INT64_MIN; S.tie_rank_p = P.tie_rank; S.n_rank = n;
@@ -260,6 +262,8 @@ __device__ __forceinline__ void store_station(const Station<C, PF, UNI> &Sc, con
         X.ev_probe[lp] += S.evp[0]; X.ev_probe[(size_t)n + lp] += S.evp[1];
         tot += S.evp[0] + S.evp[1];
         if (S.sc_t != nullptr) X.sched_i[lp] = S.sc_i;
+#pragma unroll
+        for (int i = 0; i < C; ++i) X.wkD[(size_t)i * n + lp] = (uint8_t)S.wkD[i];
         if (S.trk) {                                       // (mask == 0 between groups: a run of forwards is consumed whole)
 #pragma unroll
             for (int u = 0; u < kMaxUp; ++u) if (u < S.n_up) *S.U[u].i_p = S.U[u].i;
@@ -383,7 +387,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
     for (int i = 0; i < C; ++i) {
         X.D[(size_t)i * n + lp] = kInfNs; X.seqD[(size_t)i * n + lp] = 0; X.crtD[(size_t)i * n + lp] = start_ns;
         X.svc_s[(size_t)i * n + lp] = 0.0; X.crt[(size_t)i * n + lp] = 0;
-        X.dpD[(size_t)i * n + lp] = 0; X.rcD[(size_t)i * n + lp] = INT64_MIN;
+        X.dpD[(size_t)i * n + lp] = 0; X.rcD[(size_t)i * n + lp] = INT64_MIN; X.wkD[(size_t)i * n + lp] = 1;
     }
     for (int k = 0; k < 11; ++k) X.ev_kind[(size_t)k * n + lp] = 0;
     if constexpr (!PF) return;

@@ -168,6 +168,7 @@ struct StationState {           // read-write; [n_lp] each unless noted
     // steps after the root of the group it was created in (dp*), and when that root was created (rc*).
     uint8_t *dpA; int64_t *rcA;   // [n_lp] the pending tick
     uint8_t *dpD; int64_t *rcD;   // [C][n_lp] the pending departures
+    uint8_t *wkD;                 // [C][n_lp] ... and how many of their steps were retargeted payloads (Station::wk; tandem engines)
     int64_t *rcP;                 // [kMaxProbes][n_lp] the pending probe ticks (always one step from the previous tick)
     uint8_t *dpX; int64_t *rcX;   // [kMaxXSrc][n_lp] the pending ticks of the further Sources
     // ... and of the events waiting in the in-group FIFO (general path only; global memory, [kQCap][n_lp])
@@ -326,6 +327,7 @@ struct Station {
     // place in the nanosecond's breadth-first order.  Where a forwarded Request lands among the downstream Server's events is a
     // matter of that order, so the payloads on the way are counted (`wk`) and taken off again (fw_dep: cd - wk places it)
     int32_t wk;
+    int32_t wkD[C], rk_wk;      // ... on the way to each pending departure; of the root of the chain being processed
     const int32_t *tie_rank_p; int n_rank;   // cand_rank()'s table
     int64_t *fw_rc, *fw_rrc, *fw_rdr, *fw_dep;   // this LP's forward-log lineage columns, record m at [m * ls]
     int64_t *q_rrc, *q_rdr, *q_pay;              // this LP's FIFO root-key / payload columns, entry `slot` at [slot * ls]
@@ -364,8 +366,15 @@ struct Station {
         --qn;
         return c;
     }
-    __device__ __forceinline__ int64_t rk_pack() const { return (int64_t)(uint32_t)(rk_dp & 0xff) | ((int64_t)rk_rank << 8); }
-    __device__ __forceinline__ void rk_unpack(int64_t w) { rk_dp = (int32_t)(w & 0xff); rk_rank = (int32_t)((w >> 8) & 0xffffffffll); }
+    // a root's own lineage in one word: steps (bits 0-7), construction rank (8-39), retargeted payloads among the steps (40-47)
+    __device__ __forceinline__ int64_t rk_pack() const {
+        return (int64_t)(uint32_t)(rk_dp & 0xff) | ((int64_t)(uint32_t)rk_rank << 8) | ((int64_t)(rk_wk & 0xff) << 40);
+    }
+    __device__ __forceinline__ void rk_unpack(int64_t w) {
+        rk_dp = (int32_t)(w & 0xff); rk_rank = (int32_t)((w >> 8) & 0xffffffffll); rk_wk = (int32_t)((w >> 40) & 0xff);
+    }
+    // where the root stood in the breadth-first order of the nanosecond it was created in (Station::wk)
+    static __device__ __forceinline__ int32_t rk_place(int64_t w) { return (int32_t)(w & 0xff) - (int32_t)((w >> 40) & 0xff); }
     __device__ __forceinline__ int32_t dp_next(int steps) const { return cd + steps > 255 ? 255 : cd + steps; }
 
     __device__ __forceinline__ void init_streams(uint64_t seed, uint64_t base, uint64_t ak, uint64_t sk,
@@ -521,7 +530,7 @@ struct Station {
             svc_s[i] = s;
             if (C > 1) crt[i] = (k < cap) ? adm[k * ls] : 0;
             if (d == t) { D[i] = kInfNs - 1; same = (uint32_t)i + 1; }   // in-group continuation: parked, not pending
-            else { D[i] = d; seqD[i] = seq++; crtD[i] = t; dpD[i] = dp_next(2); rcD[i] = cr; }   // QUEUE_DELIVER -> payload -> continuation
+            else { D[i] = d; seqD[i] = seq++; crtD[i] = t; dpD[i] = dp_next(2); rcD[i] = cr; if constexpr (PF) wkD[i] = wk + 1; }   // QUEUE_DELIVER -> payload -> continuation
         }
         if (same) { ++cd; if constexpr (PF) ++wk; }                        // (the caller pushes the in-group continuation: deliver + 2)
         return same;
@@ -639,11 +648,11 @@ struct Station {
         const int64_t ca = A.rc[a * ls], cb = B.rc[b * ls];
         if (ca != cb) return ca < cb;
         const int64_t da = A.rdr[a * ls], db = B.rdr[b * ls];
-        if ((da & 0xff) != (db & 0xff)) return (da & 0xff) < (db & 0xff);
+        if (rk_place(da) != rk_place(db)) return rk_place(da) < rk_place(db);
         const int64_t ra = A.rrc[a * ls], rb = B.rrc[b * ls];
         if (ra != rb) return ra < rb;
         tie = true;
-        return (da >> 8) < (db >> 8);
+        return ((da >> 8) & 0xffffffffll) < ((db >> 8) & 0xffffffffll);
     }
     // the forward at time t whose root comes first, among those of every upstream list not taken yet: u_best < 0 none.  Inside one
     // list equal keys keep the list's order (= the upstream LP's processing order: exact); between lists a full tie is undecided.
@@ -669,20 +678,20 @@ struct Station {
     }
     // ... against one of this LP's own pending roots `w` (pick_root's code): true = the forward's root was created first
     __device__ __forceinline__ bool inj_before_own(const UpList &L, int64_t k, int w) const {
-        int32_t dp; int64_t rc; int pad;
-        own_root_key(w, dp, rc, pad);
+        int32_t dp, wkr; int64_t rc; int pad;
+        own_root_key(w, dp, rc, pad, wkr);
         const int64_t ca = L.rc[k * ls], cb = root_crt(w);
         if (ca != cb) return ca < cb;
         const int64_t da = L.rdr[k * ls];
-        if ((int32_t)(da & 0xff) != dp) return (int32_t)(da & 0xff) < dp;
+        if (rk_place(da) != dp - wkr) return rk_place(da) < dp - wkr;
         const int64_t ra = L.rrc[k * ls];
         if (ra != rc) return ra < rc;
         const_cast<Station *>(this)->undecided = 1;                                // (the roots' own ancestry would decide: Totals::undecided)
-        return (int32_t)(da >> 8) < rank_of(pad);
+        return (int32_t)((da >> 8) & 0xffffffffll) < rank_of(pad);
     }
     // lineage of the LP's own pending root `w` as the election sees it (make_candidate)
-    __device__ __forceinline__ void own_root_key(int w, int32_t &dp, int64_t &rc, int &pad) const {
-        dp = 0; rc = INT64_MIN; pad = 0;
+    __device__ __forceinline__ void own_root_key(int w, int32_t &dp, int64_t &rc, int &pad, int32_t &wkr) const {
+        dp = 0; rc = INT64_MIN; pad = 0; wkr = 0;
         if (w == 0) { dp = dpA; rc = rcA; pad = 2; }
         else if (PF && w >= kRootXSrc && w < kRootInj) {
 #pragma unroll
@@ -695,7 +704,7 @@ struct Station {
         } else if (PF && w == kRootSched) { dp = 0; rc = INT64_MIN; }
         else {
 #pragma unroll
-            for (int i = 0; i < C; ++i) if (i == w - 1) { dp = dpD[i]; rc = rcD[i]; }
+            for (int i = 0; i < C; ++i) if (i == w - 1) { dp = dpD[i]; rc = rcD[i]; wkr = wkD[i]; }
         }
     }
     __device__ __forceinline__ int rank_of(int pad) const {                        // cand_rank()
@@ -860,7 +869,7 @@ struct Station {
             if (trk) {
                 if (which >= kRootInj) { root_inj((which - kRootInj) >> 5, (which - kRootInj) & 31, t); return; }
                 int pad;
-                own_root_key(which, rk_dp, rk_rc, pad);
+                own_root_key(which, rk_dp, rk_rc, pad, rk_wk);
                 rk_rank = rank_of(pad);
                 wk = 0;
             }
