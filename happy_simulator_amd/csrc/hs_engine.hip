@@ -713,7 +713,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
             HS_HIP(h, hipMemset(h->tab_status, 0, 2 * sizeof(unsigned long long)));
         }
         TickTables tt{};
-        tt.times = h->tab_times; tt.cap = tcap;
+        tt.times = h->tab_times; tt.cap = tcap; tt.t_start = h->cfg.start_ns;
         if (!tandem.empty()) {                                      // tandem queues: hs_tables.hpp TickTables::tandem
             if ((double)n * (double)cap * 32.0 > 100e9)
                 return fail(h, HS_E_INVALID, "the forward logs of the tandem queues would need %.1f GB", (double)n * (double)cap * 32.0 / 1e9);

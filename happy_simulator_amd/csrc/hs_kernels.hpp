@@ -147,7 +147,7 @@ __device__ __forceinline__ void load_station(Station<C, PF, UNI> &S, const Stati
         }
         S.probe_t = L.probe_t + lp; S.probe_v = L.probe_v + lp; S.pcap = L.pcap;
     }
-    S.trk = false; S.n_up = 0; S.cur_pay = 0; S.undecided = 0; S.wk = 0; S.rk_wk = 0;
+    S.trk = false; S.t_start = INT64_MIN; S.n_up = 0; S.cur_pay = 0; S.undecided = 0; S.wk = 0; S.rk_wk = 0;
 #pragma unroll
     for (int i = 0; i < C; ++i) S.wkD[i] = PF ? (int32_t)X.wkD[(size_t)i * n + lp] : 1;
 #pragma unroll
@@ -156,7 +156,7 @@ __device__ __forceinline__ void load_station(Station<C, PF, UNI> &S, const Stati
     if constexpr (PF) {
         if (P.tabs != nullptr && P.tabs->tandem != nullptr) {            // tandem queues (hs_station.hpp `trk`)
             const TickTables &T = *P.tabs;
-            S.trk = true;
+            S.trk = true; S.t_start = T.t_start;
             S.fw_rc = T.fw_rc + lp; S.fw_rrc = T.fw_rrc + lp; S.fw_rdr = T.fw_rdr + lp; S.fw_dep = T.fw_dep + lp;
             S.q_rrc = T.q_rrc + lp; S.q_rdr = T.q_rdr + lp; S.q_pay = T.q_pay + lp;
 #pragma unroll

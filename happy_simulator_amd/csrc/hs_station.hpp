@@ -322,6 +322,7 @@ struct Station {
     int32_t rk_dp, rk_rank;     // key of the root of the chain being processed: its steps from ITS group's root, construction rank,
     int64_t rk_rc;              // ... and that group's root's creation time (its own creation time is cr)
     int64_t cur_pay;            // created_at carried by the FIFO entry just popped (a forward on its way to the enqueue)
+    int64_t t_start;            // TickTables::t_start
     // The steps `cd` count the retargeted payload (Request@worker) as a step of its own -- the convention of the election key --
     // but in the heap that payload keeps its OLD sort index and runs at once, inside its QUEUE_DELIVER's turn: it does not take a
     // place in the nanosecond's breadth-first order.  Where a forwarded Request lands among the downstream Server's events is a
@@ -641,15 +642,22 @@ struct Station {
         return m;
     }
     __device__ __forceinline__ bool has_inj() const { return PF && inj_next() != kInfNs; }
+    // Two events of different origin, created at ca / cb in groups whose roots were created at ra / rb: is a pre-run event (a
+    // Source's first tick, stamped t_start) involved in a way that leaves their order to sort indices no key here knows?  Either
+    // one IS a first tick, or both were created in one nanosecond and one of them in a first tick's group (TickTables::t_start).
+    __device__ __forceinline__ bool pre_run_tie(int64_t ca, int64_t cb, int64_t ra, int64_t rb) const {
+        return ca == t_start || cb == t_start || (ca == cb && (ra == t_start || rb == t_start));
+    }
     __device__ __forceinline__ int64_t inj_time(const UpList &L, int64_t k) const { return k < L.n ? L.t[k * ls] : kInfNs; }
     // cand_less on the roots of two forwards; `tie`: the whole key agrees (the roots' own ancestry would decide)
     __device__ __forceinline__ bool inj_key_less(const UpList &A, int64_t a, const UpList &B, int64_t b, bool &tie) const {
         tie = false;
         const int64_t ca = A.rc[a * ls], cb = B.rc[b * ls];
+        const int64_t ra = A.rrc[a * ls], rb = B.rrc[b * ls];
+        if (&A != &B && pre_run_tie(ca, cb, ra, rb)) tie = true;                   // (inside one list the list's order stands)
         if (ca != cb) return ca < cb;
         const int64_t da = A.rdr[a * ls], db = B.rdr[b * ls];
         if (rk_place(da) != rk_place(db)) return rk_place(da) < rk_place(db);
-        const int64_t ra = A.rrc[a * ls], rb = B.rrc[b * ls];
         if (ra != rb) return ra < rb;
         tie = true;
         return ((da >> 8) & 0xffffffffll) < ((db >> 8) & 0xffffffffll);
@@ -681,10 +689,11 @@ struct Station {
         int32_t dp, wkr; int64_t rc; int pad;
         own_root_key(w, dp, rc, pad, wkr);
         const int64_t ca = L.rc[k * ls], cb = root_crt(w);
+        const int64_t ra = L.rrc[k * ls];
+        if (pre_run_tie(ca, cb, ra, rc)) const_cast<Station *>(this)->undecided = 1;
         if (ca != cb) return ca < cb;
         const int64_t da = L.rdr[k * ls];
         if (rk_place(da) != dp - wkr) return rk_place(da) < dp - wkr;
-        const int64_t ra = L.rrc[k * ls];
         if (ra != rc) return ra < rc;
         const_cast<Station *>(this)->undecided = 1;                                // (the roots' own ancestry would decide: Totals::undecided)
         return (int32_t)((da >> 8) & 0xffffffffll) < rank_of(pad);
@@ -827,6 +836,8 @@ struct Station {
 #pragma unroll
             for (int j = 0; j < kMaxXSrc; ++j)
                 if (j < n_xsrc && XA[j] == t && (best < 0 || (int32_t)(seqX[j] - bs) < 0)) { best = kRootXSrc + j; bs = seqX[j]; }
+            if (n_up > 0 && best > 0 && A == t && crtA == t_start) const_cast<Station *>(this)->undecided = 1;   // (a first tick beside a
+                                                                                                                // departure: pre_run_tie)
             if (n_up > 0 && inj_next() == t) {      // tandem: the roots of the forwards arriving now compete by the election key
                 int u, j;
                 inj_pick(t, u, j);

@@ -52,6 +52,11 @@ struct TickTables {
     // every LP's first event beyond end_ns as the electing launch saw it: the election's check for ties that the lineage key does
     // not decide (hs_kernels.hpp hs_station_run, Totals::undecided).  [n_lp] {t, t_created, rcrt, depth | valid << 32}
     int64_t *cand_key;
+    // start of the run: the creation stamp of the events constructed before it (the Sources' first ticks).  The reference numbers
+    // those first, then restarts the count for the run's own events -- so until the run has created as many events as there are
+    // Sources, a new event can sort BEFORE a first tick of its nanosecond, and the breadth-first order the lineage key stands for
+    // does not hold around first ticks (Station::pre_run_tie).
+    int64_t t_start;
 };
 __device__ __forceinline__ int64_t tick_lookup(const int64_t *row, int64_t cap, int64_t k, int &overflow) {
     if (k < cap) return row[k];
