@@ -672,8 +672,8 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
                 int64_t *ck = P.tabs->cand_key + (size_t)lp * 4;
                 ck[0] = mine.t; ck[1] = mine.t_created; ck[2] = mine.rcrt;
                 ck[3] = (int64_t)(uint32_t)mine.depth | ((int64_t)(mine.valid ? 1 : 0) << 32);
-                if (S.undecided) atomicOr(&tot->undecided, 1);
             }
+            if (S.undecided) atomicOr(&tot->undecided, S.undecided);
         }
     }
 
@@ -1420,6 +1420,9 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             // debug flag 1024: pseudo-random per-wavefront delays -- results must not depend on timing (tests/test_gpu_ring.py)
             if ((flags & 1024) && ((((iter + 1u) * 2654435761u + (blockIdx.x * 4u + (tid >> 6)) * 40503u) >> 7) & 3u) == 0)
                 __builtin_amdgcn_s_sleep(127);
+#ifdef HS_CYCLES
+            const unsigned long long qs = __builtin_readcyclecounter();
+#endif
             const int64_t w_peek = done ? 0 : S.async_peek();         // the incoming link's word: its latency hides behind the refills
             S.window_fill(!done);                                     // created_at of what entered the window from a deep queue
             S.top_up(!done, topup_need);                              // whole wavefront: refill the pre-drawn values
@@ -1564,7 +1567,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
 #ifdef HS_CYCLES
             {
                 const unsigned long long q4 = __builtin_readcyclecounter();
-                cyc[0] += q1 - q0; cyc[1] += q2 - q1; cyc[2] += q3 - q2;
+                cyc[0] += q0 - qs; cyc[1] += q2 - q0; cyc[2] += q3 - q2;   // refills | receive + bound scan | groups | publication
                 cyc[3] += q4 - q3;
             }
 #endif

@@ -204,6 +204,10 @@ struct Totals {                 // engine-wide accumulators (device memory)
     // arrivals and services).  The reference decides it by comparing those roots' ancestry, arbitrarily far back; the engine
     // then repeats the run on the single-heap loop (hs_exact.hpp), which is the reference's algorithm.  bit 0: a forwarded Request
     // against an event of the downstream Server, bit 1: the election of the event beyond end_ns.
+    // bit 2 (every general-path engine): a PRE-RUN event -- a first tick of a Source or Probe, a Request injected with
+    // Simulation.schedule() -- shared its nanosecond with another pending event of its LP.  Only there can the reference's second
+    // sort counter (run-time events are numbered from 0 again, core/simulation.py:77) put a run-time event BEFORE a pre-run one;
+    // an engine that skipped the prologue (hs_engine.hip `lazy_prologue`) repeats the run with it.
     int undecided;
     unsigned long long dbg[4];  // asynchronous engine telemetry: sum of wave iterations, max, groups run, waves
     unsigned long long not_done; // shard rounds of hs_net_async: LPs that still have work at or before end_ns
@@ -342,7 +346,7 @@ struct Station {
     };
     UpList U[kMaxUp];
     int n_up;
-    int undecided;              // Totals::undecided bit 0, this LP
+    int undecided;              // Totals::undecided bits 0 and 2, this LP
 
     // an event created by the one being processed: one step further from the group's root
     __device__ __forceinline__ void qpush(uint32_t code, int64_t pay = 0) {
@@ -680,7 +684,7 @@ struct Station {
             bool tie = false, less = false;
 #pragma unroll
             for (int v = 0; v < kMaxUp; ++v) if (v == u_best) less = inj_key_less(U[u], U[u].i + best, U[v], U[v].i + j_best, tie);
-            if (tie) const_cast<Station *>(this)->undecided = 1;
+            if (tie) const_cast<Station *>(this)->undecided |= 1;
             if (less) { u_best = u; j_best = best; }
         }
     }
@@ -690,12 +694,12 @@ struct Station {
         own_root_key(w, dp, rc, pad, wkr);
         const int64_t ca = L.rc[k * ls], cb = root_crt(w);
         const int64_t ra = L.rrc[k * ls];
-        if (pre_run_tie(ca, cb, ra, rc)) const_cast<Station *>(this)->undecided = 1;
+        if (pre_run_tie(ca, cb, ra, rc)) const_cast<Station *>(this)->undecided |= 1;
         if (ca != cb) return ca < cb;
         const int64_t da = L.rdr[k * ls];
         if (rk_place(da) != dp - wkr) return rk_place(da) < dp - wkr;
         if (ra != rc) return ra < rc;
-        const_cast<Station *>(this)->undecided = 1;                                // (the roots' own ancestry would decide: Totals::undecided)
+        const_cast<Station *>(this)->undecided |= 1;                               // (the roots' own ancestry would decide: Totals::undecided)
         return (int32_t)((da >> 8) & 0xffffffffll) < rank_of(pad);
     }
     // lineage of the LP's own pending root `w` as the election sees it (make_candidate)
@@ -820,6 +824,20 @@ struct Station {
         int best = -1;
         uint32_t bs = 0xffffffffu;
         if constexpr (PF) {
+            // Totals::undecided bit 2: a pre-run root (its group's root stamp is "before the run") beside any other root of t
+            int cnt = 0;
+            bool pre = false;
+            if (SA == t) { ++cnt; pre = true; if (sc_i + 1 < sc_end && sc_t[sc_i + 1] == t) ++cnt; }
+            if (A == t) { ++cnt; pre = pre || rcA == INT64_MIN; }
+#pragma unroll
+            for (int i = 0; i < C; ++i) cnt += D[i] == t ? 1 : 0;
+#pragma unroll
+            for (int j = 0; j < kMaxProbes; ++j) if (j < n_probes && PA[j] == t) { ++cnt; pre = pre || rcP[j] == INT64_MIN; }
+#pragma unroll
+            for (int j = 0; j < kMaxXSrc; ++j) if (j < n_xsrc && XA[j] == t) { ++cnt; pre = pre || rcX[j] == INT64_MIN; }
+            if (pre && (cnt >= 2 || (n_up > 0 && inj_next() == t))) const_cast<Station *>(this)->undecided |= 4;
+        }
+        if constexpr (PF) {
             if (SA == t) {
                 if (sc_idx == nullptr) return kRootSched;
                 best = kRootSched; bs = sc_idx[sc_i];            // its true sort index (after the prologue: hs_exact.hpp)
@@ -836,7 +854,7 @@ struct Station {
 #pragma unroll
             for (int j = 0; j < kMaxXSrc; ++j)
                 if (j < n_xsrc && XA[j] == t && (best < 0 || (int32_t)(seqX[j] - bs) < 0)) { best = kRootXSrc + j; bs = seqX[j]; }
-            if (n_up > 0 && best > 0 && A == t && crtA == t_start) const_cast<Station *>(this)->undecided = 1;   // (a first tick beside a
+            if (n_up > 0 && best > 0 && A == t && crtA == t_start) const_cast<Station *>(this)->undecided |= 1;   // (a first tick beside a
                                                                                                                 // departure: pre_run_tie)
             if (n_up > 0 && inj_next() == t) {      // tandem: the roots of the forwards arriving now compete by the election key
                 int u, j;

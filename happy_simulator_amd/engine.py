@@ -307,6 +307,11 @@ class StationEngine:
         """0: no Server forwards to a Server; 1: passes of the station kernel; 2: the single-heap loop (include/hs_engine.h)."""
         return int(self._lib.hs_engine_tandem_path(self._h))
 
+    def prologue_path(self) -> int:
+        """0: no pre-run events that need the prologue; 1: the prologue was skipped (no pre-run event shared its nanosecond with
+        another event of its LP); 2: the run went through the single-heap prologue (include/hs_engine.h)."""
+        return int(self._lib.hs_engine_prologue_path(self._h))
+
     def synchronize(self):
         self._check(self._lib.hs_engine_synchronize(self._h))
 

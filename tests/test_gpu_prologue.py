@@ -1,0 +1,174 @@
+"""The prologue is skipped where it cannot matter (include/hs_engine.h hs_engine_prologue_path, csrc/hs_engine.hip `lazy_prologue`).
+
+The reference numbers the events constructed before run() first and restarts the count for run-time events
+(core/simulation.py:77,145-160; core/event.py:62-77): only a pre-run event that shares its nanosecond with another event of its
+LP can be overtaken by a run-time event.  The single-heap prologue (csrc/hs_exact.hpp) replays that -- on ONE lane for the whole
+engine.  A station engine runs without it, lets the kernels report such coincidences, and repeats the run behind the prologue
+only then.  These tests pin: the skipped path gives what the prologue path gives, coincidences and too-short runs are detected,
+and the speed difference is what the skipping is for."""
+import time
+
+import numpy as np
+import pytest
+
+from happy_simulator_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+
+FORCE_PROLOGUE = 1 << 16
+
+
+def _grid(n, *, constant=False, probe_interval=1.0, rate=8.0):
+    from happy_simulator_amd.engine import StationArrays
+
+    st = StationArrays.uniform(n, src_kind=N.SRC_CONSTANT if constant else N.SRC_POISSON, rate=rate, mean=0.1)
+    st.probe_metric = np.zeros(n, np.uint8)                       # depth
+    st.probe_interval_s = np.full(n, probe_interval)
+    return st
+
+
+def _everything(eng, n_probe_lps):
+    s = eng.summary()
+    stats = eng.lp_stats()
+    counts, t, cr = eng.read_sinks()
+    probes = [eng.read_probe(lp) for lp in range(n_probe_lps)]
+    return s, stats, counts, t, cr, probes
+
+
+def _assert_same(a, b):
+    sa, sta, ca, ta, cra, pa = a
+    sb, stb, cb, tb, crb, pb = b
+    assert sa.events_processed == sb.events_processed
+    np.testing.assert_array_equal(sa.events_by_kind, sb.events_by_kind)
+    assert sa.final_time_ns == sb.final_time_ns
+    for k in sta:
+        np.testing.assert_array_equal(sta[k], stb[k], err_msg=k)
+    np.testing.assert_array_equal(ca, cb)
+    np.testing.assert_array_equal(ta, tb)
+    np.testing.assert_array_equal(cra, crb)
+    for (t1, v1), (t2, v2) in zip(pa, pb):
+        np.testing.assert_array_equal(t1, t2)
+        np.testing.assert_array_equal(v1, v2)
+
+
+def test_poisson_chains_with_probes_skip_the_prologue_and_match_it():
+    from happy_simulator_amd.engine import StationEngine
+
+    n, end = 2048, 20_000_000_000
+    with StationEngine(_grid(n), mode=N.MODE_SINGLE, horizon_ns=end, seed=7) as eng:
+        eng.run_until(end)
+        assert eng.prologue_path() == 1
+        lazy = _everything(eng, 64)
+    with StationEngine(_grid(n), mode=N.MODE_SINGLE, horizon_ns=end, seed=7) as eng:
+        eng.set_debug_flags(FORCE_PROLOGUE)
+        eng.run_until(end)
+        assert eng.prologue_path() == 2
+        eager = _everything(eng, 64)
+    _assert_same(lazy, eager)
+
+
+def test_windows_skip_the_prologue_too():
+    from happy_simulator_amd.engine import StationEngine
+
+    n, end = 512, 6_000_000_000
+    with StationEngine(_grid(n), mode=N.MODE_SINGLE, horizon_ns=end, seed=11) as eng:
+        for e in (2_000_000_000, 2_000_000_001, 4_500_000_000, end):
+            eng.run_until(e)
+        assert eng.prologue_path() == 1
+        lazy = _everything(eng, 32)
+    with StationEngine(_grid(n), mode=N.MODE_SINGLE, horizon_ns=end, seed=11) as eng:
+        eng.set_debug_flags(FORCE_PROLOGUE)
+        eng.run_until(end)
+        eager = _everything(eng, 32)
+    _assert_same(lazy, eager)
+
+
+def test_constant_arrivals_with_aligned_probes_match_the_prologue_whichever_path_they_take():
+    from happy_simulator_amd.engine import StationEngine
+
+    n, end = 256, 5_000_000_000
+    with StationEngine(_grid(n, constant=True, rate=10.0), mode=N.MODE_SINGLE, horizon_ns=end, seed=3) as eng:
+        eng.run_until(end)
+        print("constant 10/s + 1 s Probe: prologue path", eng.prologue_path())
+        lazy = _everything(eng, 16)
+    with StationEngine(_grid(n, constant=True, rate=10.0), mode=N.MODE_SINGLE, horizon_ns=end, seed=3) as eng:
+        eng.set_debug_flags(FORCE_PROLOGUE)
+        eng.run_until(end)
+        eager = _everything(eng, 16)
+    _assert_same(lazy, eager)
+
+
+def _sched_grid(n, times_ns):
+    from happy_simulator_amd.engine import StationArrays
+
+    st = StationArrays.uniform(n, src_kind=N.SRC_CONSTANT, rate=10.0, mean=0.03)
+    k = len(times_ns)
+    st.sched_off = np.arange(n + 1, dtype=np.int64) * k
+    st.sched_time_ns = np.tile(np.asarray(times_ns, np.int64), n)
+    return st
+
+
+@pytest.mark.parametrize("times", [(300_000_000,), (450_000_000, 450_000_000)])
+def test_an_injected_request_on_the_nanosecond_of_another_event_goes_through_the_prologue(times):
+    """Constant 10/s arrivals and a Request injected at 0.3 s (the third arrival's nanosecond) / two Requests injected at one instant."""
+    from happy_simulator_amd.engine import StationEngine
+
+    n, end = 64, 3_000_000_000
+    with StationEngine(_sched_grid(n, times), mode=N.MODE_SINGLE, horizon_ns=end, seed=3) as eng:
+        eng.run_until(end)
+        assert eng.prologue_path() == 2
+        s, stats, counts, t, cr, _ = _everything(eng, 0)
+    with StationEngine(_sched_grid(n, times), mode=N.MODE_SINGLE, horizon_ns=end, seed=3) as eng:
+        eng.set_debug_flags(FORCE_PROLOGUE)
+        eng.run_until(end)
+        s2, stats2, counts2, t2, cr2, _ = _everything(eng, 0)
+    _assert_same((s, stats, counts, t, cr, []), (s2, stats2, counts2, t2, cr2, []))
+
+
+def test_injected_requests_away_from_other_events_skip_the_prologue():
+    from happy_simulator_amd.engine import StationEngine
+
+    n, end = 64, 3_000_000_000
+    with StationEngine(_sched_grid(n, (1_234_567_891, 2_000_000_007)), mode=N.MODE_SINGLE, horizon_ns=end, seed=3) as eng:
+        eng.run_until(end)
+        assert eng.prologue_path() == 1
+        a = _everything(eng, 0)
+    with StationEngine(_sched_grid(n, (1_234_567_891, 2_000_000_007)), mode=N.MODE_SINGLE, horizon_ns=end, seed=3) as eng:
+        eng.set_debug_flags(FORCE_PROLOGUE)
+        eng.run_until(end)
+        b = _everything(eng, 0)
+    _assert_same(a, b)
+
+
+def test_a_run_shorter_than_the_pre_run_events_are_many_goes_through_the_prologue():
+    from happy_simulator_amd.engine import StationEngine
+
+    n, end = 4096, 50_000_000           # 50 ms: ~0.4 arrivals per chain, 8 192 pre-run events
+    with StationEngine(_grid(n), mode=N.MODE_SINGLE, horizon_ns=10_000_000_000, seed=5) as eng:
+        eng.run_until(end)
+        assert eng.prologue_path() == 2
+        lazy = _everything(eng, 16)
+    with StationEngine(_grid(n), mode=N.MODE_SINGLE, horizon_ns=10_000_000_000, seed=5) as eng:
+        eng.set_debug_flags(FORCE_PROLOGUE)
+        eng.run_until(end)
+        eager = _everything(eng, 16)
+    _assert_same(lazy, eager)
+
+
+def test_65536_chains_with_a_probe_each_run_in_milliseconds():
+    from happy_simulator_amd.engine import StationEngine
+
+    n, end = 65536, 60_000_000_000
+    with StationEngine(_grid(n), mode=N.MODE_SINGLE, horizon_ns=end, seed=42) as eng:
+        eng.run_until(end)
+        eng.reset()
+        t0 = time.perf_counter()
+        eng.run_until(end)
+        wall = time.perf_counter() - t0
+        s = eng.summary()
+        assert eng.prologue_path() == 1
+        print(f"65 536 chains x 60 s with a Probe each: {wall * 1e3:.2f} ms wall, kernel {s.kernel_ms:.3f} ms, {s.events_processed} events")
+        assert wall < 0.25                      # (behind the prologue: 2.2 s)
+        stats = eng.lp_stats()
+        assert s.events_by_kind[13] >= n * 59 and s.events_by_kind[14] >= n * 59   # every Probe ticked and sampled
+        assert int(stats["generated"].sum()) == s.events_by_kind[0]

@@ -39,7 +39,7 @@ if a.ring:
         N.lib().hs_debug_async_counters(eng._h, out)
         waves = (a.n_lp + 63) // 64
         print(json.dumps(dict(events=s.events_processed, kernel_ms=float(s.kernel_ms), waves=waves,
-                              cycles_per_wave=dict(receive=out[0] / waves, bound_scan=out[1] / waves,
+                              cycles_per_wave=dict(refills=out[0] / waves, receive_and_bound_scan=out[1] / waves,
                                                    groups=out[2] / waves, publish=out[3] / waves))))
     sys.exit(0)
 from happy_simulator_amd.engine import StationArrays, StationEngine
