@@ -1026,7 +1026,8 @@ struct Station {
         const int64_t buf_enq = buf + (acc ? 1 : 0);
         const bool deliver = poll && buf_enq > 0;                       // queue.py:149-166
         const bool slow = act && (force_general || svc_kind == 2 ||
-                                  (PF && (prof_kind != kProfConstant || has_probe() || has_sched() || has_xsrc())) ||
+                                  (PF && (prof_kind != kProfConstant || (has_probe() && probe_at(t)) || (has_sched() && SA == t) ||
+                                          (has_xsrc() && xsrc_at(t)) || n_up > 0)) ||     // (a rare root at t, forwards: run_group)
                                   (tick && D[0] == t) ||
                                   (tick && ((stop_ns >= 0 && t > stop_ns) || a2 <= t)) || (deliver && dur == 0));
         const bool fast = act && !slow;
