@@ -873,7 +873,9 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         // The prologue (hs_exact.hpp): the reference's pre-run events in the order it constructs them.  (Tandem queues: the same
         // loop as the engine's exact path for whole runs -- `exact_only`.)
         h->exact_prologue = n_sched > 0 || h->any_probe || h->any_xsrc;
-        h->exact_only = !tandem.empty() && (h->exact_prologue || h->tandem_fan_in);   // (several upstream Servers per Server: one heap)
+        // (more upstream Servers than the passes merge: one heap from the start.  Tandem queues next to pre-run events start on the
+        // passes like any lazy_prologue engine and move to the single heap -- which IS the prologue's loop -- on the first hazard)
+        h->exact_only = !tandem.empty() && h->tandem_fan_in;
         std::vector<int32_t> sl((size_t)n_sched);
         std::vector<int64_t> se((size_t)n_sched);
         std::vector<int32_t> lp_of((size_t)n_sched);
@@ -909,7 +911,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if (rank_span > n_sched + (1 << 20)) return fail(h, HS_E_INVALID, "sched_rank positions are implausibly sparse");
         const int64_t n_init = (int64_t)so.size() + (int64_t)po.size() + rank_span;
         h->n_init = n_init;
-        h->lazy_prologue = h->exact_prologue && tandem.empty();
+        h->lazy_prologue = h->exact_prologue;
         h->xs_host = XState{};
         h->xs_host.heap_cap = n_init + (int64_t)n * (h->C + 16) + 1024;
         h->xs_host.pool_cap = 2 * n_init + 16 * (int64_t)n + 1024;
@@ -1465,7 +1467,8 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
         rc = run_net_async(h, end_ns);
         if (rc) return rc;
     } else {
-        if (h->n_pass > 0 && (h->flags & (1 << 17)) && h->exact && h->window_ends.empty()) h->exact_only = true;   // debug: single heap from the start
+        if (h->n_pass > 0 && ((h->flags & (1 << 17)) || ((h->flags & (1 << 16)) && h->exact_prologue)) && h->exact && h->window_ends.empty())
+            h->exact_only = true;   // debug: single heap from the start (1 << 16: wherever a prologue exists -- with tandem queues that is this loop)
         if (h->n_pass > 0 || lazy_active(h)) h->window_ends.push_back(end_ns);
         int rc = launch_prologue(h, end_ns);
         if (rc) return rc;
@@ -1478,12 +1481,27 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
     return HS_OK;
 }
 
+// A station engine that skipped the prologue (lazy_prologue): did the run meet what only the prologue orders exactly?
+static bool lazy_hazard(hs_engine *h, bool &hazard) {
+    Totals t;
+    if (hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    unsigned long long total = 0;
+    for (int k = 0; k < HS_EV_KINDS; ++k) total += t.ev[k];
+    // (the election of the event beyond end_ns ranks a pre-run event first: true once the run has created n_init events)
+    hazard = (t.undecided & 4) != 0 || total < 2ull * (unsigned long long)h->n_init;
+    return true;
+}
 // Tandem queues: the passes met an order between two LPs' events that their lineage key does not decide (Totals::undecided).
 // The run since the last reset is repeated, window by window, on the single-heap loop -- the reference's own algorithm.
 int tandem_fallback(hs_engine *h) {
     if (h->n_pass == 0 || h->exact_only || !h->exact) return HS_OK;
     int und = 0;
     HS_HIP(h, hipMemcpy(&und, &h->tot->undecided, sizeof und, hipMemcpyDeviceToHost));
+    if (!und && lazy_active(h)) {             // (pre-run events next to tandem queues: lazy_prologue's short-run rule)
+        bool hazard = false;
+        if (!lazy_hazard(h, hazard)) return fail(h, HS_E_HIP, "reading the totals failed");
+        und = hazard ? 4 : 0;
+    }
     if (!und) return HS_OK;
     const std::vector<int64_t> ends = h->window_ends;
     h->exact_only = true;
@@ -1500,16 +1518,6 @@ int tandem_fallback(hs_engine *h) {
     return HS_OK;
 }
 
-// A station engine that skipped the prologue (lazy_prologue): did the run meet what only the prologue orders exactly?
-static bool lazy_hazard(hs_engine *h, bool &hazard) {
-    Totals t;
-    if (hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost) != hipSuccess) return false;
-    unsigned long long total = 0;
-    for (int k = 0; k < HS_EV_KINDS; ++k) total += t.ev[k];
-    // (the election of the event beyond end_ns ranks a pre-run event first: true once the run has created n_init events)
-    hazard = (t.undecided & 4) != 0 || total < 2ull * (unsigned long long)h->n_init;
-    return true;
-}
 int prologue_fallback(hs_engine *h) {
     if (!lazy_active(h) || h->window_ends.empty()) return HS_OK;
     bool hazard = false;

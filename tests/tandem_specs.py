@@ -130,3 +130,64 @@ def compare(spec, eng, r, srcs, servers, sinks):
             assert counts[last] == len(ot), ("sink count", c, counts[last], len(ot))
             np.testing.assert_array_equal(t[off[last]:off[last + 1]], ot, err_msg=f"sink t chain {c}")
             np.testing.assert_array_equal(cr[off[last]:off[last + 1]], ocr, err_msg=f"sink created chain {c}")
+
+
+def tandem_probe_case(k: int) -> dict:
+    """tandem_spec(k) with Probes on some of its Servers and Requests injected with Simulation.schedule(): pre-run events next to
+    tandem queues.  Returns the spec plus {"probes": [((chain, stage), metric name, interval_s)], "sched": [((chain, stage), t_s)]}."""
+    rng = np.random.default_rng(4_400_000 + k)
+    spec = tandem_spec(k)
+    order, _first = station_index(spec)
+    probes, seen = [], set()
+    for _ in range(int(rng.integers(0, 4))):
+        cs = order[int(rng.integers(0, len(order)))]
+        if cs in seen:
+            continue                                     # (one Probe per Server here: slot 0)
+        seen.add(cs)
+        probes.append((cs, str(rng.choice(["depth", "active_requests", "stats_accepted", "stats_dropped", "requests_completed"])),
+                       float(rng.choice([0.05, 0.1, 0.25, 0.3, 0.5, 1.0]))))
+    sched = []
+    for _ in range(int(rng.integers(0, 4)) if rng.random() < 0.6 else 0):
+        cs = order[int(rng.integers(0, len(order)))]
+        sched.append((cs, float(rng.choice([0.0, 0.1, 0.25, 0.5, 0.7, 1.0, round(float(rng.random()) * spec["end_s"], 6)]))))
+    spec["probes"], spec["sched"] = probes, sched
+    return spec
+
+
+def run_tandem_probe_case(spec):
+    """Oracle and engine on a tandem_probe_case: everything compare() checks plus every Probe's samples.  Returns the engine's
+    (tandem path, prologue path)."""
+    from happy_simulator_amd import _native as N
+    from happy_simulator_amd.engine import StationEngine
+
+    g, srcs, servers, sinks = oracle_graph(spec)
+    pnodes = [g.probe(servers[cs], N.PROBE_METRICS[m], iv) for cs, m, iv in spec["probes"]]
+    end = _ns(spec["end_s"])
+    r = O.run(g, end, seed=spec["seed"], schedule=[(servers[cs], _ns(t)) for cs, t in spec["sched"]])
+    st = engine_arrays(spec)
+    order, _first = station_index(spec)
+    lp_of = {cs: i for i, cs in enumerate(order)}
+    if spec["probes"]:
+        st.probe_metric = np.full(st.n, N.PROBE_NONE, np.uint8)
+        st.probe_interval_s = np.ones(st.n)
+        for cs, m, iv in spec["probes"]:
+            st.probe_metric[lp_of[cs]], st.probe_interval_s[lp_of[cs]] = N.PROBE_METRICS[m], iv
+        st.probe_order = np.array([lp_of[cs] for cs, _, _ in spec["probes"]], np.int32)
+    if spec["sched"]:
+        per = [[] for _ in range(st.n)]
+        for rank, (cs, t) in enumerate(spec["sched"]):
+            per[lp_of[cs]].append((_ns(t), rank))
+        for lst in per:
+            lst.sort(key=lambda x: x[0])
+        st.sched_off = np.concatenate([[0], np.cumsum([len(x) for x in per])]).astype(np.int64)
+        st.sched_time_ns = np.array([t for lst in per for t, _ in lst], np.int64)
+        st.sched_rank = np.array([rk for lst in per for _, rk in lst], np.int64)
+    with StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=end, seed=spec["seed"]) as eng:
+        eng.run_until(end)
+        compare(spec, eng, r, srcs, servers, sinks)
+        for (cs, _m, _iv), nd in zip(spec["probes"], pnodes):
+            t, v = r.sinks[nd]
+            pt, pv = eng.read_probe(lp_of[cs])
+            np.testing.assert_array_equal(pt, t, err_msg=f"probe times {cs}")
+            np.testing.assert_array_equal(pv, v, err_msg=f"probe values {cs}")
+        return eng.tandem_path(), eng.prologue_path()

@@ -173,7 +173,8 @@ def test_api_refusals_name_what_is_missing():
 
 def test_probes_and_scheduled_requests_next_to_tandem_queues():
     """Probes on Servers of a chain and Requests injected with Simulation.schedule() into its second Server: pre-run events whose
-    sort indices run-time events can overtake (csrc/hs_exact.hpp) -- such engines run on the single heap from the start."""
+    sort indices run-time events can overtake (csrc/hs_exact.hpp).  Two of the Requests are injected at one instant: the passes
+    report that and the run is repeated on the single heap."""
     from happy_simulator_amd import _native as N
     from happy_simulator_amd.engine import StationEngine
 
@@ -215,6 +216,22 @@ def test_probes_and_scheduled_requests_next_to_tandem_queues():
             pt, pv = eng.read_probe(lp_of[cs])
             np.testing.assert_array_equal(pt, t)
             np.testing.assert_array_equal(pv, v)
+
+
+def test_random_tandem_queues_with_probes_and_injected_requests_equal_the_oracle():
+    """300 tandem_probe_case configurations: on the passes without the prologue where no pre-run event shares its nanosecond with
+    another event of its LP (hs_engine_prologue_path() == 1), on the single heap otherwise -- exact either way."""
+    from collections import Counter
+
+    paths = Counter()
+    for k in range(300):
+        spec = TS.tandem_probe_case(k)
+        try:
+            paths[TS.run_tandem_probe_case(spec)] += 1
+        except AssertionError as e:
+            raise AssertionError(f"tandem_probe_case({k}): {e}") from e
+    print("(tandem path, prologue path):", dict(paths))
+    assert paths[(1, 1)] > paths[(2, 2)] > 0
 
 
 def _fan_in_case(k):

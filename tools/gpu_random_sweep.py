@@ -123,8 +123,14 @@ def tandem_fan_in(k):
     _run_fan_in(_fan_in_case(k))
 
 
+def tandem_probes(k):
+    import tandem_specs as TS
+
+    TS.run_tandem_probe_case(TS.tandem_probe_case(k))
+
+
 FAMILIES = [station, tie, multi_source, ring_async, ring_windowed, multi_source_ring_async, multi_source_ring_windowed, lb,
-            lb_probes, lb_profiles, tandem, tandem_fan_in]
+            lb_probes, lb_profiles, tandem, tandem_fan_in, tandem_probes]
 # (round 2 listed 13 tie storms here -- the cross-LP election of the one event beyond end_time, closed by the lineage key)
 KNOWN = set()
 # refused by design (HS_E_UNSUPPORTED), never guessed: a probe on the nanosecond of an event of its target on a load-balancer
