@@ -167,8 +167,10 @@ typedef struct hs_stations {
     /* Tandem queues: `Server(..., downstream=<another Server>)` (components/server/server.py:64-122,271-272; the forwarded Event
      * keeps its context, core/entity.py:83-105).  egress[i] == HS_EGRESS_SERVER: every completion of LP i arrives at the Server of
      * LP downstream_lp[i] at the same instant, created_at unchanged.  At most 7 Servers in a row, no cycles, HS_MODE_SINGLE, no
-     * hs_engine_set_network.  A Server with SEVERAL upstream Servers, and tandem queues next to Probes / scheduled Requests / several
-     * Sources per Server, run on the single-heap loop from the start (hs_engine_tandem_path() == 2).  The engine runs the chain in passes, upstream first (csrc/hs_station.hpp "tandem queues"); results
+     * hs_engine_set_network.  A Server may have several upstream Servers: up to four merge on the passes, more run on the single-heap
+     * loop from the start (hs_engine_tandem_path() == 2).  Tandem queues next to Probes / scheduled Requests / several Sources per
+     * Server start on the passes and move to the single heap when a pre-run event shares its nanosecond with another event of its LP
+     * (hs_engine_prologue_path).  The engine runs the chain in passes, upstream first (csrc/hs_station.hpp "tandem queues"); results
      * equal the reference's single heap event for event, ties inside a nanosecond included.  NULL = no such Server. */
     const int32_t *downstream_lp;      /* [n_lp] read where egress == HS_EGRESS_SERVER */
 } hs_stations;
@@ -292,7 +294,7 @@ int hs_device_count(void);
 /* Tandem queues (hs_stations.downstream_lp): which path the engine is on -- 0 no tandem queues, 1 passes of the station kernel
  * (upstream Servers first), 2 the single-heap loop (csrc/hs_exact.hpp): hs_engine_run_until repeats a run there when the passes
  * met a same-nanosecond order between two Servers' events that their lineage key does not decide (lock-step constant arrivals
- * and services), and tandem queues next to Probes / scheduled Requests / several Sources per Server start there. */
+ * and services, comparisons around the Sources' first ticks), and a Server with more than four upstream Servers starts there. */
 int hs_engine_tandem_path(const hs_engine *h);
 
 /* The prologue (csrc/hs_exact.hpp): the reference numbers the events constructed before run() -- the Sources' and Probes' first
