@@ -1106,11 +1106,79 @@ struct Station {
         bool pend, blocked, bail, done;
         int64_t crtA0;              // creation time of the tick that was pending when the window began (lineage, req_finish)
         double arr_d;               // UNI: ArrivalTimeProvider.current_time as a binary64 (whole ns below 2^52: exact)
+        // PF, an LP with ONE Probe (slot 0): its ticks inside the window, sampled from the request sequence (req_probe_*).  A sample
+        // needs generated(T) -- known once an arrival beyond T is seen -- and completed(T) -- known once a departure beyond T is
+        // seen; the two become known in either order, so each has its own pointer into the tick table and a third one finalises.
+        int64_t pTa, pTd;           // time of the next tick of the arrival / the departure pointer (kInfNs: none inside the window)
+        uint32_t ma, md, mf;        // ticks passed by the arrival pointer, the departure pointer, finalised
+        int64_t p_prev;             // time of the last tick the arrival pointer passed (a tick that does not advance ends the Probe)
     };
     __device__ __forceinline__ bool req_eligible() const {
         return C == 1 && !force_general && qn == 0 && conc == 1 && qcap < 0 && stop_ns < 0 && svc_kind != 2 &&
-               !(PF && (prof_kind != kProfConstant || has_probe() || has_sched() || has_xsrc())) &&
+               !(PF && (prof_kind != kProfConstant || n_probes > 1 || has_sched() || has_xsrc() || n_up > 0)) &&
                (egress == 0 || egress == 1) && !(buf > 0 && active == 0) && active <= 1;
+    }
+    // ---- a Probe in request order (one per LP).  Between two events of its LP a sample is a function of two counts:
+    //     generated(T) = accepted(T) = #{a_k <= T},  completed(T) = #{D_k <= T},  started(T) = min(generated, completed + 1)
+    // (one worker, FIFO, unbounded: request k starts at max(a_k, D_{k-1})), depth = generated - started, active = started -
+    // completed.  A tick ON the nanosecond of an arrival or a departure is decided by sort indices: the lane bails to the
+    // event-order loop, which is also where the pre-run first tick's coincidences are reported (Totals::undecided bit 2).
+    __device__ __forceinline__ int64_t req_probe_time(uint32_t m) {                 // tick number p_arr[0] + m of the table
+        return tick_lookup(tab_p[0], tab_cap, p_arr[0] + (int64_t)m, overflow);
+    }
+    __device__ __forceinline__ void req_probe_begin(ReqCursor &c) {
+        c.ma = c.md = c.mf = 0;
+        c.pTa = c.pTd = n_probes == 1 ? PA[0] : kInfNs;
+        c.p_prev = INT64_MIN;
+        if (c.pTa > c.T) c.pTa = c.pTd = kInfNs;
+    }
+    // the arrival pointer passes every tick before `limit` (the arrival being processed, or T + 1 at the end of the window)
+    __device__ __forceinline__ void req_probe_arrivals(ReqCursor &c, bool on, int64_t limit, int64_t gen_now) {
+        while (on && c.pTa < limit) {
+            const int64_t o = ((int64_t)p_n[0] + (int64_t)c.ma) * ls;
+            if (p_n[0] + (int64_t)c.ma < pcap) probe_v[o] = gen_now; else overflow = 1;
+            c.p_prev = c.pTa;
+            ++c.ma;
+            int64_t nx = req_probe_time(c.ma);
+            if (nx <= c.p_prev) { c.bail = true; nx = kInfNs; }          // (a tick that does not advance ends the Probe: event order)
+            c.pTa = nx <= c.T ? nx : kInfNs;
+        }
+    }
+    __device__ __forceinline__ void req_probe_departures(ReqCursor &c, bool on, int64_t limit, int64_t comp_now) {
+        while (on && c.pTd < limit) {
+            const int64_t o = ((int64_t)p_n[0] + (int64_t)c.md) * ls;
+            if (p_n[0] + (int64_t)c.md < pcap) probe_t[o] = comp_now;
+            ++c.md;
+            const int64_t nx = req_probe_time(c.md);
+            c.pTd = nx <= c.T ? nx : kInfNs;
+        }
+    }
+    __device__ __forceinline__ void req_probe_finalise(ReqCursor &c, bool on) {
+        while (on && c.mf < (c.ma < c.md ? c.ma : c.md)) {
+            const int64_t pn = p_n[0] + (int64_t)c.mf;
+            if (pn < pcap) {
+                const int64_t o = pn * ls;
+                __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the two halves were stored by this lane ...
+                const int64_t g_rel = __hip_atomic_load(&probe_v[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (... past its L1)
+                const int64_t c_rel = __hip_atomic_load(&probe_t[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int64_t acc = accepted + g_rel, cn = completed + c_rel;
+                const int64_t stt = acc < cn + 1 ? acc : cn + 1;
+                int64_t v = 0;
+                switch (p_metric[0]) {
+                    case kProbeDepth: v = acc - stt; break;
+                    case kProbeActive: v = stt - cn; break;
+                    case kProbeAccepted: v = acc; break;
+                    case kProbeDropped: v = dropped; break;
+                    case kProbeCompleted: v = cn; break;
+                    case kProbeReceived: v = egress == 1 ? received + c_rel : received; break;
+                    case kProbeGenerated: v = generated + g_rel; break;
+                    default: break;
+                }
+                probe_t[o] = req_probe_time(c.mf);
+                probe_v[o] = v;
+            }
+            ++c.mf;
+        }
     }
     __device__ __forceinline__ void req_count_departure(ReqCursor &c, bool p, int64_t d, double s) {
         total_service = p ? __dadd_rn(total_service, s) : total_service;
@@ -1132,6 +1200,13 @@ struct Station {
         req_count_departure(c, dep0, D[0], svc_s[0]);
         c.pend = busy && !dep0;
         c.pendD = D[0]; c.pendS = crtD[0]; c.pend_s = svc_s[0];
+        if constexpr (PF) {
+            req_probe_begin(c);
+            if (n_probes == 1 && busy) {                  // ticks before the departure that was pending: nothing has completed yet
+                req_probe_departures(c, true, D[0], 0);
+                c.bail = c.bail || c.pTd == D[0];         // (a tick on its nanosecond: event order)
+            }
+        }
     }
     __device__ __forceinline__ void req_step(ReqCursor &c, bool act) {
         const int64_t T = c.T;
@@ -1152,7 +1227,16 @@ struct Station {
         const int64_t dur = UNI ? i64_from_whole_d(ns_from_seconds_d(s_new)) : (HSG(svc_kind == 0, true) ? ns_from_seconds(s_new) : svc_const_ns);
         const int64_t Dk = Sk + dur;
         const bool dp = st && Dk <= T;                   // departure part at D_k
-        const bool bail = act && (tie_a || (st && dur == 0));
+        bool tie_p = false;
+        if constexpr (PF) {
+            const bool pon = act && n_probes == 1;
+            if (__any(pon)) {                            // the LP's Probe: ticks before this arrival / this departure (req_probe_*)
+                req_probe_arrivals(c, pon && (arr || fin), arr ? A : T + 1, (int64_t)c.n_tick);
+                req_probe_departures(c, pon && (st || fin), st ? Dk : T + 1, (int64_t)c.n_dep);
+                tie_p = pon && ((arr && c.pTa == A) || (st && c.pTd == Dk));
+            }
+        }
+        const bool bail = act && (tie_a || tie_p || (st && dur == 0));
         const bool go = act && !bail && !fin;
         c.bail = c.bail || bail;
         c.done = c.done || (act && fin);
@@ -1193,9 +1277,13 @@ struct Station {
         c.blocked = c.blocked || (go && bk && !st);
         c.nb -= (go && bk && st) ? 1 : 0;
         A = arr_g ? a2 : A;                              // last: `A` is read above
+        if constexpr (PF) {
+            const bool pon = act && !bail && n_probes == 1;
+            if (__any(pon && c.mf < (c.ma < c.md ? c.ma : c.md))) req_probe_finalise(c, pon);
+        }
     }
     // fold the window's deltas into the LP state exactly as the event-order loop would have left it
-    __device__ __forceinline__ void req_finish(const ReqCursor &c) {
+    __device__ __forceinline__ void req_finish(const ReqCursor &c) {   // (not const: the Probe's table look-ups can flag an overflow)
         ev[0] += c.n_tick; ev[1] += c.n_tick; ev[2] += c.n_notify; ev[3] += c.n_poll + c.n_dep;
         ev[4] += c.n_start; ev[5] += c.n_start; ev[6] += c.n_dep;
         generated += c.n_tick; accepted += c.n_tick; started += c.n_start; completed += c.n_dep;
@@ -1205,15 +1293,44 @@ struct Station {
         D[0] = c.pend ? c.pendD : kInfNs;
         crtD[0] = c.pend ? c.pendS : crtD[0];
         svc_s[0] = c.pend ? c.pend_s : svc_s[0];
+        // the Probe's ticks of the window (req_probe_*): two events each; the pending tick was created by the last of them, whose
+        // own creation time (the tick before it) is the pending tick's group root
+        uint32_t n_pt = 0;
+        int64_t last_probe = INT64_MIN;
+        if constexpr (PF) {
+            n_pt = n_probes == 1 ? c.ma : 0u;
+            if (n_pt != 0u) {
+                evp[0] += n_pt; evp[1] += n_pt;
+                const int64_t t_last = req_probe_time(n_pt - 1);
+                last_probe = t_last;
+                rcP[0] = n_pt >= 2u ? req_probe_time(n_pt - 2) : crtP[0];
+                crtP[0] = t_last;
+                const int64_t nx = req_probe_time(n_pt);
+                PA[0] = nx > t_last ? nx : kInfNs;
+                p_arr[0] += (int64_t)n_pt;
+                p_n[0] += (int64_t)n_pt;
+            }
+        }
         // creation stamps: only their order matters (pick_root).  The pending departure was created at pendS, the
         // pending tick at crtA; a tick that also started the service created the next tick first.
         // (No two of this window's events shared a timestamp -- the lane would have bailed -- so times decide; stamps
         // that were not re-created in this window keep their order.)
-        if ((c.n_tick | c.n_start) != 0u) {
+        if ((c.n_tick | c.n_start | n_pt) != 0u) {
             const bool d_first = c.pend && c.pendS < crtA;
-            seqA = seq + (d_first ? 1u : 0u);
-            seqD[0] = seq + (d_first ? 0u : 1u);
-            seq += 2u;
+            uint32_t sA = d_first ? 1u : 0u, sD = d_first ? 0u : 1u, sP = 2u;
+            if constexpr (PF) {
+                if (n_probes == 1) {                      // the pending probe tick among them, by creation time (ties: it was there first
+                    const int64_t tP = crtP[0];           // only if neither of the others was re-created after it)
+                    const bool p_before_a = tP < crtA, p_before_d = !c.pend || tP < c.pendS;
+                    sP = (p_before_a ? 0u : 1u) + ((c.pend && !p_before_d) ? 1u : 0u);
+                    sA += p_before_a ? 1u : 0u;
+                    sD += p_before_d ? 1u : 0u;
+                    seqP[0] = seq + sP;
+                }
+            }
+            seqA = seq + sA;
+            seqD[0] = seq + sD;
+            seq += 3u;
         }
         // Lineage of what is pending now (only the election beyond end_time reads it, so it is reconstructed HERE, from the
         // admission log and the service stream, instead of being carried through the loop).  Every tick was a root of its own group
@@ -1239,7 +1356,7 @@ struct Station {
                 rcD[0] = c.pendS - ns_from_seconds(s_prev);
             }
         }
-        last_time = c.lt;
+        last_time = c.lt > last_probe ? c.lt : last_probe;
     }
 };
 

@@ -172,3 +172,21 @@ def test_65536_chains_with_a_probe_each_run_in_milliseconds():
         stats = eng.lp_stats()
         assert s.events_by_kind[13] >= n * 59 and s.events_by_kind[14] >= n * 59   # every Probe ticked and sampled
         assert int(stats["generated"].sum()) == s.events_by_kind[0]
+
+
+def test_probes_sampled_in_request_order_equal_the_oracle():
+    """Chains that stay on the request-order loop with a Probe (one worker, unbounded FIFO, Poisson arrivals, one Probe per Server):
+    every metric, intervals from 20 ms to 1 s, with and without a Sink -- everything the ABI reports and every sample against
+    the oracle's single heap (csrc/hs_station.hpp req_probe_*)."""
+    import tandem_specs as TS
+
+    metrics = ["depth", "active_requests", "stats_accepted", "stats_dropped", "requests_completed"]
+    for seed in range(6):
+        rng = np.random.default_rng(31_000 + seed)
+        chains, probes = [], []
+        for c in range(16):
+            chains.append(dict(arr="poisson", rate=float(rng.choice([4.0, 8.0, 12.0, 30.0])), stop_after_s=None, sink=bool(c % 4 != 3),
+                               stages=[dict(svc="exp" if c % 5 else "const", mean=float(rng.choice([0.02, 0.05, 0.1])), conc=1, qcap=None)]))
+            probes.append(((c, 0), metrics[(c + seed) % len(metrics)], float(rng.choice([0.02, 0.05, 0.1, 0.25, 0.3, 1.0]))))
+        spec = dict(chains=chains, end_s=float(rng.choice([2.0, 5.0, 8.0])), seed=int(rng.integers(1, 1 << 30)), probes=probes, sched=[])
+        assert TS.run_tandem_probe_case(spec) == (0, 1)
