@@ -632,10 +632,12 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if (n_sched > 0) { h->any_profile = true; h->any_sched = true; }
     }
     h->C = maxc <= 1 ? 1 : maxc <= 2 ? 2 : maxc <= 4 ? 4 : maxc <= 8 ? 8 : maxc <= 16 ? 16 : 32;
-    // (C == 1 reads a sink record's created_at from the admission log: the m-th completion is the m-th admission.  A tandem Server
-    // can take two enqueues and a poll in one nanosecond -- a forward beside its own Source's Request -- deliver both and REJECT
-    // the second at the worker (server.py:223-234), after which that shortcut is off by one: explicit column, C >= 2.)
-    if (!tandem.empty() && h->C == 1) h->C = 2;
+    // (C == 1 reads a sink record's created_at from the admission log: the m-th completion is the m-th admission.  A Server that can
+    // receive TWO Requests in one nanosecond while idle -- a forward beside its own Source's Request, two injected Requests, two
+    // Sources in lock step -- delivers both and REJECTS the second at the worker (server.py:223-234), after which that shortcut is
+    // off by one: explicit column, C >= 2.  Found by the tandem + probes sweep on a chain WITHOUT tandem queues: two Requests
+    // injected at one instant into an idle Server.)
+    if ((!tandem.empty() || n_sched > 0 || h->any_xsrc) && h->C == 1) h->C = 2;
     int64_t cap = h->cfg.log_capacity;
     if (cap <= 0) {
         const double c = max_mean_records + 10.0 * std::sqrt(max_mean_records + 1.0) + 64.0 + (double)max_sched;

@@ -190,3 +190,14 @@ def test_probes_sampled_in_request_order_equal_the_oracle():
             probes.append(((c, 0), metrics[(c + seed) % len(metrics)], float(rng.choice([0.02, 0.05, 0.1, 0.25, 0.3, 1.0]))))
         spec = dict(chains=chains, end_s=float(rng.choice([2.0, 5.0, 8.0])), seed=int(rng.integers(1, 1 << 30)), probes=probes, sched=[])
         assert TS.run_tandem_probe_case(spec) == (0, 1)
+
+
+@pytest.mark.parametrize("k", [7932, 8264])
+def test_two_requests_in_one_nanosecond_at_an_idle_single_worker_server(k):
+    """tandem_probe_case(7932 / 8264), found by the sweep on chains WITHOUT tandem queues: an injected Request on the nanosecond of
+    an arrival / two Requests injected at one instant reach an idle one-worker Server together; the reference delivers both and
+    rejects the second at the worker (server.py:223-234).  The engine's single-slot shortcut "the m-th completion is the m-th
+    admission" then named the wrong created_at for every later Sink record; such engines now carry the explicit column."""
+    import tandem_specs as TS
+
+    TS.run_tandem_probe_case(TS.tandem_probe_case(k))
