@@ -476,7 +476,25 @@ def run_tandem_case(spec):
         if sink is not None:
             entities.append(sink)
             node_of[id(sink)] = first[c] + n_st - 1
-    sim = Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=sources, entities=entities)
+    # spec["probes"] = [((chain, stage), metric, interval_s)]: Probes on Servers of the chains, in `probes=[...]` order;
+    # spec["sched"] = [((chain, stage), t_s)]: Simulation.schedule(Event(t, "Request", target=that Server)) calls, in call order
+    # (tests/tandem_specs.py tandem_probe_case)
+    probes, probe_data = [], []
+    for cs, metric, iv in spec.get("probes") or []:
+        _who, attr = PROBE_METRICS[metric]
+        probe, data = Probe.on(servers[tuple(cs)], attr, interval=iv)
+        data._ns = []
+
+        def add_stat(value, time, _orig=data.add_stat, _d=data):
+            _d._ns.append((time.nanoseconds, value))
+            _orig(value, time)
+
+        data.add_stat = add_stat
+        probes.append(probe)
+        probe_data.append(data)
+        node_of[id(probe)] = first[cs[0]] + cs[1]
+    sim = Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=sources, entities=entities, probes=probes)
+    cb_station = {id(p._event_provider.data_sink): node_of[id(p)] for p in probes}
     trace = []
     heap = sim._event_heap
     orig_pop = heap.pop
@@ -484,10 +502,16 @@ def run_tandem_case(spec):
     def pop():
         e = orig_pop()
         k, nd = classify(e, node_of)
+        if k == EV["probe"]:
+            fn = e.target._fn if hasattr(e.target, "_fn") else e.target.fn
+            cells = {id(cell.cell_contents) for cell in (fn.__closure__ or ())}
+            nd = next(c for key, c in cb_station.items() if key in cells)
         trace.append((e.time.nanoseconds, k, nd, e._sort_index))
         return e
 
     heap.pop = pop
+    for cs, t_s in spec.get("sched") or []:
+        sim.schedule(Event(time=Instant.from_seconds(t_s), event_type="Request", target=servers[tuple(cs)]))
     summary = sim.run()
     n = len(order)
     out = {k: np.zeros(n, np.int64) for k in ("accepted", "dropped", "completed", "rejected", "depth", "active")}
@@ -509,10 +533,86 @@ def run_tandem_case(spec):
     out["sink_latency_s"] = np.asarray(sink_lat, np.float64)
     out["sink_off"] = np.asarray(sink_off, np.int64)
     out["trace"] = np.asarray(trace, np.int64).reshape(-1, 4)
+    if probes:
+        pt, pv, poff = [], [], [0]
+        for d in probe_data:
+            pt.extend(t for t, _ in d._ns)
+            pv.extend(int(v) for _, v in d._ns)
+            poff.append(len(pt))
+        out["probe_t_ns"] = np.asarray(pt, np.int64)
+        out["probe_v"] = np.asarray(pv, np.int64)
+        out["probe_off"] = np.asarray(poff, np.int64)
     meta = dict(spec=spec, total_events=[summary.total_events_processed], final_ns=[sim._current_time.nanoseconds],
                 duration_s=[summary.duration_s])
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     return out, meta
+
+
+def run_fan_in_case(case):
+    """A forest of Servers with reference components only (tests/tandem_specs.py fan_in_case): Server i forwards to Server
+    case["down"][i] (`downstream=`; several Servers may forward to one), Sources on some of them, a Sink behind some roots.
+    Station i = Server i; its entities draw from stream base i.  Returns per-Server statistics, the Sinks' records and the full
+    processed-event trace (node = the Server's index; a Source / Sink: its Server's)."""
+    sv, down, seed = case["servers"], case["down"], case["seed"]
+    n = len(sv)
+    servers, sinks, node_of = [None] * n, {}, {}
+    for i in reversed(range(n)):                     # forwards go to later Servers: build from the back
+        s = sv[i]
+        if down[i] >= 0:
+            nxt = servers[down[i]]
+        elif s["sink"]:
+            nxt = sinks[i] = Sink(f"sink{i}")
+        else:
+            nxt = None
+        lat = (PhiloxExponentialLatency(s["mean"], hs.Stream(seed, i, hs.STREAM_SERVICE)) if s["svc"] == "exp" else ConstantLatency(s["mean"]))
+        servers[i] = Server(f"srv{i}", concurrency=s["conc"], service_time=lat, queue_capacity=s["qcap"], downstream=nxt)
+    sources, src_of = [], {}
+    for i, s in enumerate(sv):
+        if s["src"] is None:
+            continue
+        prof = ConstantRateProfile(rate=s["src"][1])
+        prov = (PhiloxPoissonArrival(prof, Instant.Epoch, hs.Stream(seed, i, hs.STREAM_ARRIVAL)) if s["src"][0] == "poisson"
+                else ConstantArrivalTimeProvider(prof, start_time=Instant.Epoch))
+        src = Source(f"src{i}", SimpleEventProvider(servers[i], "Request", None), prov)
+        sources.append(src)
+        src_of[i] = src
+        node_of[id(src)] = i
+    entities = []
+    for i in range(n):
+        entities.append(servers[i])
+        for x in (servers[i], servers[i]._queue, servers[i]._driver, servers[i]._worker):
+            node_of[id(x)] = i
+        if i in sinks:
+            entities.append(sinks[i])
+            node_of[id(sinks[i])] = i
+    sim = Simulation(end_time=Instant.from_seconds(case["end_s"]), sources=sources, entities=entities)
+    trace = []
+    heap = sim._event_heap
+    orig_pop = heap.pop
+
+    def pop():
+        e = orig_pop()
+        k, nd = classify(e, node_of)
+        trace.append((e.time.nanoseconds, k, nd, e._sort_index))
+        return e
+
+    heap.pop = pop
+    summary = sim.run()
+    out = {k: np.zeros(n, np.int64) for k in ("accepted", "dropped", "completed", "rejected", "depth", "active", "generated")}
+    out["total_service_s"] = np.zeros(n, np.float64)
+    for i in range(n):
+        x = servers[i]
+        out["accepted"][i], out["dropped"][i] = x.stats_accepted, x.stats_dropped
+        out["completed"][i], out["rejected"][i] = x._requests_completed, x._requests_rejected
+        out["depth"][i], out["active"][i] = x.depth, x.active_requests
+        out["total_service_s"][i] = x._total_service_time
+        out["generated"][i] = src_of[i].generated_count if i in src_of else 0
+    out["sinks"] = {i: (np.asarray([t.nanoseconds for t in sk.completion_times], np.int64), np.asarray(sk.latencies_s, np.float64))
+                    for i, sk in sinks.items()}
+    out["trace"] = np.asarray(trace, np.int64).reshape(-1, 4)
+    out["total_events"] = summary.total_events_processed
+    out["final_ns"] = sim._current_time.nanoseconds
+    return out
 
 
 def run_ring_case(spec):

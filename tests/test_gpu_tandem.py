@@ -234,27 +234,7 @@ def test_random_tandem_queues_with_probes_and_injected_requests_equal_the_oracle
     assert paths[(1, 1)] > paths[(2, 2)] > 0
 
 
-def _fan_in_case(k):
-    """Several chains' heads merging into shared Servers: a random forest of Servers (every Server has at most one downstream,
-    any number of upstreams), Sources on some of them."""
-    rng = np.random.default_rng(70_000 + k)
-    n = int(rng.integers(3, 9))
-    storm = k % 3 == 0
-    down = [-1] * n
-    for i in range(n - 1):
-        if rng.random() < 0.8:
-            down[i] = int(rng.integers(i + 1, n))            # forwards to a later Server: acyclic
-    servers = []
-    for i in range(n):
-        if storm:
-            svc, mean = "const", float(rng.choice([0.0, 0.01, 0.05, 0.1, 0.1]))
-        else:
-            svc, mean = ("exp", float(rng.choice([0.02, 0.05, 0.1]))) if rng.random() < 0.7 else ("const", 0.05)
-        servers.append(dict(svc=svc, mean=mean, conc=int(rng.choice([1, 1, 2, 3])), qcap=None if rng.random() < 0.7 else int(rng.integers(0, 4)),
-                            src=None if (rng.random() < 0.35 and any(d == i for d in down)) else
-                            (("constant", float(rng.choice([5.0, 10.0, 20.0]))) if storm else ("poisson", float(rng.choice([4.0, 8.0, 12.0])))),
-                            sink=down[i] < 0 and rng.random() < 0.85))
-    return dict(servers=servers, down=down, end_s=float(rng.choice([1.0, 2.0, 3.0])), seed=int(rng.integers(1, 1 << 30)))
+_fan_in_case = TS.fan_in_case
 
 
 def _run_fan_in(case):

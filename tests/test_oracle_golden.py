@@ -199,7 +199,18 @@ def check_oracle_against_tandem_golden(gold):
     spec = gold.spec
     order, first = TS.station_index(spec)
     g, srcs, servers, sinks = TS.oracle_graph(spec)
-    r = O.run(g, int(spec["end_s"] * 1e9), seed=spec["seed"], trace_cap=len(gold.trace) + 16)
+    # (tandem_probe_case: Probes on Servers and injected Requests next to the tandem queues; JSON turned the keys into lists)
+    from happy_simulator_amd import _native as N
+    probes = [(tuple(cs), m, iv) for cs, m, iv in spec.get("probes") or []]
+    sched = [(tuple(cs), t) for cs, t in spec.get("sched") or []]
+    pnodes = [g.probe(servers[cs], N.PROBE_METRICS[m], iv) for cs, m, iv in probes]
+    r = O.run(g, int(spec["end_s"] * 1e9), seed=spec["seed"], trace_cap=len(gold.trace) + 16,
+              schedule=[(servers[cs], int(t * 1e9)) for cs, t in sched])
+    for j, nd in enumerate(pnodes):
+        off = gold.arrays["probe_off"]
+        pt, pv = r.sinks[nd]
+        np.testing.assert_array_equal(pt, gold.arrays["probe_t_ns"][off[j]:off[j + 1]], err_msg=f"probe {j} times")
+        np.testing.assert_array_equal(pv, gold.arrays["probe_v"][off[j]:off[j + 1]], err_msg=f"probe {j} values")
     assert [r.events_processed] == gold.meta["total_events"]
     assert [r.final_time_ns] == gold.meta["final_ns"]
     for i, (c, st) in enumerate(order):
@@ -219,9 +230,49 @@ def check_oracle_against_tandem_golden(gold):
     node_station = {srcs[c]: first[c] for c in range(len(srcs))}
     node_station.update({nd: first[c] + st for (c, st), nd in servers.items()})
     node_station.update({sinks[c]: first[c] + len(ch["stages"]) - 1 for c, ch in enumerate(spec["chains"]) if sinks[c] >= 0})
+    node_station.update({nd: first[cs[0]] + cs[1] for nd, (cs, _m, _iv) in zip(pnodes, probes)})
     t, k, nd, ix = r.trace
     got = np.stack([t, k.astype(np.int64), np.array([node_station[x] for x in nd], np.int64), ix], axis=1)
     np.testing.assert_array_equal(got, gold.trace)
+
+
+def check_oracle_against_fan_in_reference(case, ref):
+    """fan_in_case forests (make_golden.run_fan_in_case): the oracle against the live reference on every Server's statistics,
+    every Sink record and the whole processed-event trace with sort indices."""
+    sv, down = case["servers"], case["down"]
+    n = len(sv)
+    g = O.Graph()
+    srcs = {i: g.source(O.ARR_POISSON if s["src"][0] == "poisson" else O.ARR_CONSTANT, s["src"][1], stream_base=i)
+            for i, s in enumerate(sv) if s["src"] is not None}
+    nodes = [g.server(O.LAT_EXP if s["svc"] == "exp" else O.LAT_CONST, s["mean"], concurrency=s["conc"],
+                      queue_cap=-1 if s["qcap"] is None else s["qcap"], stream_base=i) for i, s in enumerate(sv)]
+    sinks = {i: g.sink() for i, s in enumerate(sv) if s["sink"]}
+    for i, nd in srcs.items():
+        g.target[nd] = nodes[i]
+    for i in range(n):
+        g.target[nodes[i]] = nodes[down[i]] if down[i] >= 0 else sinks.get(i, -1)
+    r = O.run(g, int(case["end_s"] * 1e9), seed=case["seed"], trace_cap=len(ref["trace"]) + 16)
+    assert r.events_processed == ref["total_events"]
+    assert r.final_time_ns == ref["final_ns"]
+    for i in range(n):
+        for k, ok in (("accepted", "accepted"), ("dropped", "dropped"), ("completed", "completed"), ("rejected", "rejected"),
+                      ("depth", "depth"), ("active", "active")):
+            assert getattr(r, ok)[nodes[i]] == ref[k][i], (k, i)
+        assert r.total_service_s[nodes[i]] == ref["total_service_s"][i], ("total_service_s", i)
+        if i in srcs:
+            assert r.generated[srcs[i]] == ref["generated"][i], ("generated", i)
+    for i, (gt, glat) in ref["sinks"].items():
+        if down[i] >= 0:
+            continue                                # (a Sink flag on a Server that forwards: no Sink was built)
+        t, cr = r.sinks[sinks[i]]
+        np.testing.assert_array_equal(t, gt)
+        np.testing.assert_array_equal((t - cr) / 1e9, glat)
+    station = {nd: i for i, nd in srcs.items()}
+    station.update({nd: i for i, nd in enumerate(nodes)})
+    station.update({nd: i for i, nd in sinks.items()})
+    t, k, nd, ix = r.trace
+    got = np.stack([t, k.astype(np.int64), np.array([station[x] for x in nd], np.int64), ix], axis=1)
+    np.testing.assert_array_equal(got, ref["trace"])
 
 
 def test_oracle_md5_known_answers():

@@ -97,3 +97,26 @@ def test_oracle_equals_live_reference_on_random_tandem_queues(k):
 
     out, meta = MG.run_tandem_case(TS.tandem_spec(k))
     check_oracle_against_tandem_golden(H.Golden.from_results(out, meta))
+
+
+@pytest.mark.parametrize("k", list(range(40)) + [7932, 8264])
+def test_oracle_equals_live_reference_on_tandem_queues_with_probes_and_injected_requests(k):
+    """tests/tandem_specs.py tandem_probe_case: Probes on Servers of the chains and Simulation.schedule() Requests next to tandem
+    queues -- statistics, Sink records, every Probe sample and the full trace with sort indices.  7932 / 8264: two Requests reach
+    an idle one-worker Server in one nanosecond and the reference rejects the second at the worker (server.py:223-234)."""
+    import tandem_specs as TS
+
+    out, meta = MG.run_tandem_case(TS.tandem_probe_case(k))
+    check_oracle_against_tandem_golden(H.Golden.from_results(out, meta))
+
+
+@pytest.mark.parametrize("k", list(range(0, 60)) + [1788, 4095, 4329, 4857, 6237])
+def test_oracle_equals_live_reference_on_forests_of_servers(k):
+    """tests/tandem_specs.py fan_in_case: several Servers forwarding to one, Sources of their own on downstream Servers; every third
+    case lock-step constants.  The five extra cases are the ones the GPU sweep differed on while fan-in was being built (the worker's
+    rejection of a second same-nanosecond Request; the Sources' first ticks and the restarted sort counter)."""
+    import tandem_specs as TS
+    from test_oracle_golden import check_oracle_against_fan_in_reference
+
+    case = TS.fan_in_case(k)
+    check_oracle_against_fan_in_reference(case, MG.run_fan_in_case(case))

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 sys.path.insert(0, ROOT)
 
-FAMILIES = ("station", "tie", "multi_source", "ring", "multi_source_ring", "lb", "lb_probes", "lb_profiles", "tandem")
+FAMILIES = ("station", "tie", "multi_source", "ring", "multi_source_ring", "lb", "lb_probes", "lb_profiles", "tandem", "tandem_probes", "tandem_fan_in")
 
 
 def one(job):
@@ -27,10 +27,17 @@ def one(job):
     from test_oracle_golden import (check_oracle_against_lb_golden, check_oracle_against_ring_golden,
                                     check_oracle_against_station_golden, check_oracle_against_tandem_golden)
     try:
-        if fam == "tandem":
+        if fam == "tandem_fan_in":
+            import tandem_specs as TS
+            from test_oracle_golden import check_oracle_against_fan_in_reference
+
+            case = TS.fan_in_case(k)
+            check_oracle_against_fan_in_reference(case, MG.run_fan_in_case(case))
+            return fam, k, ""
+        if fam in ("tandem", "tandem_probes"):
             import tandem_specs as TS
 
-            out, meta = MG.run_tandem_case(TS.tandem_spec(k))
+            out, meta = MG.run_tandem_case(TS.tandem_spec(k) if fam == "tandem" else TS.tandem_probe_case(k))
             check_oracle_against_tandem_golden(H.Golden.from_results(out, meta))
             return fam, k, ""
         if fam in ("station", "tie", "multi_source"):
