@@ -5,7 +5,9 @@ work happens in libhs_hip.so; nothing here computes event logic.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import weakref
 import os
 from dataclasses import dataclass
 
@@ -92,6 +94,23 @@ class NetworkArrays:
     @property
     def n_links(self) -> int:
         return int(len(self.link_dst))
+
+
+# Engines that are still open when the interpreter exits (a Simulation keeps its engine while Sink records / Probe samples are on
+# the device: lowering.LazyRecords) are closed BEFORE Python tears its modules down -- destroying one from a late __del__, after
+# the HIP runtime has started to unload, aborts the process in free().
+_LIVE: "weakref.WeakSet" = weakref.WeakSet()
+
+
+def _close_live_engines():
+    for e in list(_LIVE):
+        try:
+            e.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_live_engines)
 
 
 class EngineSummary:
@@ -225,6 +244,7 @@ class StationEngine:
         except Exception:
             self.close()
             raise
+        _LIVE.add(self)
 
     def _set_network(self, net: "NetworkArrays"):
         nw = N.Network()
@@ -388,6 +408,7 @@ class StationEngine:
         if self._h:
             self._lib.hs_engine_destroy(self._h)
             self._h = C.c_void_p()
+        _LIVE.discard(self)
 
     def __del__(self):
         try:

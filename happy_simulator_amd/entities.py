@@ -754,12 +754,31 @@ class Data:
     """Time-series container of a Probe (instrumentation/data.py:20-110): `values` = [(time_s, value), ...]."""
 
     def __init__(self) -> None:
-        self._t_ns = np.zeros(0, np.int64)
-        self._v = np.zeros(0, np.int64)
+        self._tt = np.zeros(0, np.int64)
+        self._vv = np.zeros(0, np.int64)
         self._scale = None           # utilisation: value / concurrency
+        self._lazy = None            # () -> (t_ns, v): the samples are still on the device (lowering.write_back_plain_probes)
 
     def _set(self, t_ns: np.ndarray, v: np.ndarray, scale=None) -> None:
-        self._t_ns, self._v, self._scale = t_ns, v, scale
+        self._tt, self._vv, self._scale, self._lazy = t_ns, v, scale, None
+
+    def _set_lazy(self, fetch, scale=None) -> None:
+        self._lazy, self._scale = fetch, scale
+
+    def _load(self) -> None:
+        if self._lazy is not None:
+            fetch, self._lazy = self._lazy, None
+            self._tt, self._vv = fetch()
+
+    @property
+    def _t_ns(self) -> np.ndarray:
+        self._load()
+        return self._tt
+
+    @property
+    def _v(self) -> np.ndarray:
+        self._load()
+        return self._vv
 
     def _val(self, v):
         return int(v) if self._scale is None else int(v) / self._scale

@@ -338,6 +338,57 @@ def attach_probes(g: LoweredGraph, probes: list) -> None:
         st.probes = (*st.probes, pr)
 
 
+def plain_probe_arrays(pc: "PlainChains", probes: list, arrays):
+    """attach_probes() for PlainChains without a Station object per chain: fills the engine's probe arrays (slot 0 and the three
+    further slots, in the order the probes are listed per station) and returns [(station, slot, scale)] per probe in `probes=[...]`
+    order, or None when a probe needs the general lowering (a Sink shared by several Servers, a target outside the chains)."""
+    from .entities import Probe
+
+    n = len(pc.servers)
+    owner = dict(zip(map(id, pc.servers), range(n)))
+    owner.update(zip(map(id, pc.sources), range(n)))
+    sink_ids = [id(sk) for sk in pc.sinks if sk is not None]
+    if len(set(sink_ids)) != len(sink_ids):
+        return None                                   # (a collector behind several Servers: write_back_shared_sink_probes)
+    owner.update((id(sk), i) for i, sk in enumerate(pc.sinks) if sk is not None)
+    metric = np.full((4, n), N.PROBE_NONE, np.uint8)
+    interval = np.ones((4, n))
+    used = np.zeros(n, np.int8)
+    kinds = {"generated_count": Source, "_generated_count": Source, "events_received": _SINKS}
+    where = []
+    for pr in probes:
+        if not isinstance(pr, Probe):
+            raise UnsupportedTopology(f"probe {type(pr).__name__} is not a lowered Probe")
+        i = owner.get(id(pr.target))
+        if i is None:
+            return None                               # (attach_probes words the refusal)
+        slot = int(used[i])
+        if slot >= 4:
+            raise UnsupportedTopology(f"station of '{pr.target.name}' already has four probes (the engine's slots per station)")
+        if pr.metric != "utilization" and pr.metric not in N.PROBE_METRICS:
+            raise UnsupportedTopology(f"probe '{pr.name}': metric '{pr.metric}' is not sampled on the engine "
+                                      f"(lowered: {', '.join(sorted(N.PROBE_METRICS))}, utilization)")
+        if not isinstance(pr.target, kinds.get(pr.metric, Server)):
+            raise UnsupportedTopology(f"probe '{pr.name}': metric '{pr.metric}' is not an attribute of {type(pr.target).__name__}")
+        used[i] = slot + 1
+        metric[slot, i] = N.PROBE_METRICS["active_requests" if pr.metric == "utilization" else pr.metric]
+        interval[slot, i] = pr.interval
+        where.append((i, slot, pc.servers[i].concurrency if pr.metric == "utilization" else None))
+    arrays.probe_metric, arrays.probe_interval_s = metric[0].copy(), interval[0].copy()
+    if (used > 1).any():
+        arrays.probe_metric_more, arrays.probe_interval_more = metric[1:].copy(), interval[1:].copy()
+    arrays.probe_order = np.array([w[0] for w in where], np.int32)
+    arrays.probe_slot_order = np.array([w[1] for w in where], np.uint8)
+    return where
+
+
+def write_back_plain_probes(probes: list, where: list, eng) -> None:
+    """The samples stay on the device until a probe's Data is first read (65 536 read-backs of a few hundred bytes each are
+    seconds of host time); `eng` must outlive them (LazyRecords keeps it)."""
+    for pr, (i, slot, scale) in zip(probes, where):
+        pr.data_sink._set_lazy(lambda i=i, slot=slot: eng.read_probe(i, slot), scale)
+
+
 def write_back_probes(g: LoweredGraph, eng) -> None:
     for i, st in enumerate(g.stations):
         for slot, pr in enumerate(st.probes):
@@ -531,8 +582,9 @@ class LazyRecords:
     """The Sink records of a run, left on the device until a Sink's lists are first read (0.5 GB at the headline size: the download
     and the per-Sink slicing were most of Simulation.run()'s wall time).  Owns the engine until then."""
 
-    def __init__(self, eng, counts: np.ndarray):
+    def __init__(self, eng, counts: np.ndarray, keep_engine: bool = False):
         self._eng = eng
+        self._keep = keep_engine               # probes read their samples from the engine later (write_back_plain_probes)
         self.off = np.zeros(len(counts) + 1, np.int64)
         np.cumsum(counts, out=self.off[1:])
         self._t = self._cr = None
@@ -540,8 +592,9 @@ class LazyRecords:
     def fetch(self):
         if self._t is None:
             _, self._t, self._cr = self._eng.read_sinks()
-            self._eng.close()
-            self._eng = None
+            if not self._keep:
+                self._eng.close()
+                self._eng = None
         return self._t, self._cr
 
     def count(self, i: int) -> int:

@@ -14,6 +14,7 @@ from .core.temporal import Instant
 from .engine import StationEngine
 from .entities import Entity, Server
 from .lowering import (LazyRecords, LbGraph, LoweredGraph, UnsupportedTopology, attach_lb_probes, attach_probes, find_load_balancer, lower,
+                       plain_probe_arrays, write_back_plain_probes,
                        lower_lb, write_back, write_back_lb, write_back_plain, write_back_probes, write_back_shared_sink_probes)
 from .lowering import _plain_chains as plain_chains
 from .summary import EntitySummary, LazyEntities, QueueStats, SimulationSummary
@@ -124,6 +125,8 @@ class Simulation:
             if self._probes:
                 if lb is not None:
                     attach_lb_probes(self._graph, self._probes)
+                elif plain is not None and not self._scheduled:
+                    self._plain_probes_pending = True     # (_run puts them into the arrays without a Station per chain)
                 else:
                     attach_probes(self._graph, self._probes)
         return self._graph
@@ -192,7 +195,15 @@ class Simulation:
         net = g.network_arrays(self._bag_capacity or 0) if g.is_network else None
         horizon_s = (end_ns - self._start_time.nanoseconds) / 1e9
         arrays = g.arrays()
-        if g.plain is not None and not self._probes and not self._scheduled:
+        if getattr(self, "_plain_probes_pending", False):
+            self._plain_probes_pending = False
+            fast = not self._scheduled and g.plain is not None and g._stations is None      # (`arrays` is PlainChains.arrays)
+            where = plain_probe_arrays(g.plain, self._probes, arrays) if fast else None
+            if where is not None:
+                return self._run_plain(g, arrays, end_ns, wall0, where)
+            attach_probes(g, self._probes)                # (a probe the fast path does not cover: Station objects after all)
+            arrays = g.arrays()
+        elif g.plain is not None and not self._probes and not self._scheduled:
             return self._run_plain(g, arrays, end_ns, wall0)
         # the order in which Simulation.__init__ constructs the first SourceEvents / probe ticks (core/simulation.py:145-160)
         st_of = {id(st.source): (i, 0) for i, st in enumerate(g.stations) if st.source is not None}
@@ -231,7 +242,7 @@ class Simulation:
         self._summary = self._build_summary(_time.monotonic() - wall0)
         return self._summary
 
-    def _run_plain(self, g: LoweredGraph, arrays, end_ns: int, wall0: float) -> SimulationSummary:
+    def _run_plain(self, g: LoweredGraph, arrays, end_ns: int, wall0: float, probe_where=None) -> SimulationSummary:
         """n plain Source -> Server -> [Sink] chains (lowering.PlainChains): no per-station Python objects on the way in, Python
         lists instead of numpy scalars on the way out, and the Sink records stay on the device until a Sink's lists are first read
         (LazyRecords keeps the engine until then) -- at 65 536 chains run() used to spend 0.7 s around a 0.45 ms device run."""
@@ -245,9 +256,11 @@ class Simulation:
         except Exception:
             eng.close()
             raise
-        records = LazyRecords(eng, stats["sink_received"])
+        records = LazyRecords(eng, stats["sink_received"], keep_engine=bool(probe_where))
         self._records = records                 # (keeps the device buffers alive as long as the Simulation, or until fetched)
         write_back_plain(g.plain, stats, records, device=self._device)
+        if probe_where:
+            write_back_plain_probes(self._probes, probe_where, eng)    # samples stay on the device until a Data is read
         self._events_cancelled = 0
         self._engine_summary = es
         self._events_processed = es.events_processed

@@ -898,3 +898,43 @@ def test_probe_on_a_sink_shared_by_several_servers_matches_the_oracle():
     np.testing.assert_array_equal(np.asarray(data._t_ns), t)
     np.testing.assert_array_equal(np.asarray(data._v), v)
     assert sink.events_received == len(r.sinks[nodes[0][2]][0])
+
+
+def test_probes_on_plain_chains_take_the_object_free_path_and_equal_the_general_lowering(monkeypatch):
+    """>= 64 plain Source -> Server -> Sink chains with Probes: the probes go into the engine's arrays without a Station object
+    per chain (lowering.plain_probe_arrays) and their samples stay on the device until a Data is first read.  Same configuration
+    through the general lowering (plain detection switched off): every sample, statistic and Sink record equal."""
+    import happy_simulator_amd.simulation as SIM
+
+    def build():
+        sinks = [hs.Sink(f"k{i}") for i in range(96)]
+        servers = [hs.Server(f"s{i}", concurrency=1 + (i % 3 == 0), service_time=hs.ExponentialLatency(0.05 + 0.01 * (i % 5)), downstream=sinks[i])
+                   for i in range(96)]
+        sources = [hs.Source.poisson(rate=6 + i % 7, target=servers[i], name=f"src{i}") for i in range(96)]
+        probes, data = [], []
+        for i in range(96):
+            tgt, metric = [(servers[i], "depth"), (servers[i], "utilization"), (sinks[i], "events_received"), (sources[i], "generated_count"),
+                           (servers[i], "stats_accepted"), (servers[i], "requests_completed")][i % 6]
+            p, d = hs.Probe.on(tgt, metric, interval=[0.1, 0.25, 0.5, 1.0][i % 4])
+            probes.append(p); data.append(d)
+            if i % 8 == 0:                                   # a second and third probe on the same Server
+                ps, ds = hs.Probe.on_many(servers[i], ["active_requests", "stats_dropped"], interval=0.2)
+                probes += ps; data += [ds["active_requests"], ds["stats_dropped"]]
+        probes = probes[::-1]; data = data[::-1]            # `probes=[...]` in another order than the stations
+        sim = hs.Simulation(duration=4.0, sources=sources, entities=servers + sinks, probes=probes)
+        return sim, servers, sinks, sources, data
+
+    sim, servers, sinks, sources, data = build()
+    summary = sim.run()
+    assert sim.lowered().plain is not None and sim.lowered()._stations is None           # no Station objects were built
+    assert all(d._lazy is not None for d in data)                                        # nothing downloaded yet
+    fast = ([d.values for d in data], [(s.stats_accepted, s.stats.requests_completed) for s in servers],
+            [list(k.completion_times) for k in sinks], [s.generated_count for s in sources], summary.total_events_processed)
+    monkeypatch.setattr(SIM, "plain_chains", lambda *a: None)
+    sim2, servers2, sinks2, sources2, data2 = build()
+    summary2 = sim2.run()
+    assert sim2.lowered()._stations is not None                  # Station objects, attach_probes, write_back_probes
+    general = ([d.values for d in data2], [(s.stats_accepted, s.stats.requests_completed) for s in servers2],
+               [list(k.completion_times) for k in sinks2], [s.generated_count for s in sources2], summary2.total_events_processed)
+    assert fast == general
+    assert sum(len(v) for v in fast[0]) > 1000

@@ -534,3 +534,22 @@ def test_log_capacity_follows_deep_tandems_and_cycles():
     assert 8 * 10 < g2.log_capacity(10.0) < 8 * 10 + 10 * 9 + 70 + 8
     sim = hs.Simulation(duration=10, sources=[], entities=[hs.Server("x")], log_capacity=123, bag_capacity=32, msg_capacity=512)
     assert (sim._log_capacity, sim._bag_capacity, sim._msg_capacity) == (123, 32, 512)
+
+
+def test_probe_data_can_stay_on_the_device_until_first_read():
+    """Data._set_lazy (lowering.write_back_plain_probes): one download on the first access, whichever accessor it is."""
+    import numpy as np
+
+    calls = []
+
+    def fetch():
+        calls.append(1)
+        return np.array([1_000_000_000, 2_000_000_000], np.int64), np.array([3, 4], np.int64)
+
+    d = hs.Data()
+    d._set_lazy(fetch, scale=2)
+    assert not calls
+    assert d.count() == 2 and d.values == [(1.0, 1.5), (2.0, 2.0)] and d.max() == 2.0 and len(d) == 2
+    assert calls == [1]
+    d._set(np.array([5], np.int64), np.array([7], np.int64))
+    assert d.values == [(5e-9, 7)]
