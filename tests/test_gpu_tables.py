@@ -2,6 +2,8 @@
 produced before the run by 64 lanes per integral -- against (a) the same chain walked by ONE lane with the sequential
 integrator of csrc/hs_profile.hpp (the restatement of load/arrival_time_provider.py:84-144 that rounds 1 - 2 pinned with
 live-reference goldens), bit for bit, and (b) the oracle, on the two configurations round 2 had to refuse."""
+import os
+
 import numpy as np
 import pytest
 
@@ -40,7 +42,15 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("name,profile,poisson,horizon_s", CASES, ids=[c[0] for c in CASES])
+# Two comparisons let ONE lane finish an integral of 10^7 Simpson intervals (that is what they are for): 223 s and 91 s of a
+# 9-minute suite.  They run with HS_SLOW_TESTS=1 (last: profiles/r03_gpu_tests_part2.log, both passed); the other eight profile
+# cases and the budget / overflow tests always run.
+SLOW = bool(os.environ.get("HS_SLOW_TESTS"))
+needs_minutes = pytest.mark.skipif(not SLOW, reason="minutes of one lane by design; HS_SLOW_TESTS=1 runs it (passed in profiles/r03_gpu_tests_part2.log)")
+
+
+@pytest.mark.parametrize("name,profile,poisson,horizon_s",
+                         [pytest.param(*c, marks=needs_minutes) if c[0] == "ramp 2 s 2->30" else c for c in CASES], ids=[c[0] for c in CASES])
 def test_cooperative_tables_equal_the_lone_lane_chain(name, profile, poisson, horizon_s):
     for seed, sid in ((42, 8 * 3), (77, 8 * 97), (5, 8 * 1234567)):
         coop, st_c = _table(profile, poisson, seed, sid, horizon_s, 4096, lone=0)
@@ -52,6 +62,7 @@ def test_cooperative_tables_equal_the_lone_lane_chain(name, profile, poisson, ho
             break
 
 
+@needs_minutes
 def test_an_explosive_integral_is_split_over_the_lanes_bit_for_bit():
     """LinearRampProfile(3 s, 1 -> 9), stream base 97, seed 77 -- the first arrival's bracket search
     integrates over [0, 9.12 s] and needs 2.65e7 Simpson intervals (7.95e7 rate evaluations).  The lone lane is allowed to
