@@ -553,3 +553,49 @@ def test_probe_data_can_stay_on_the_device_until_first_read():
     assert calls == [1]
     d._set(np.array([5], np.int64), np.array([7], np.int64))
     assert d.values == [(5e-9, 7)]
+
+
+def test_plain_probe_arrays_equal_the_per_station_lowering():
+    """lowering.plain_probe_arrays (no Station object per chain) fills the same probe arrays, slots and `probes=[...]` order as
+    attach_probes + LoweredGraph.arrays() do through Station objects."""
+    import numpy as np
+
+    from happy_simulator_amd import lowering as L
+
+    def build():
+        sinks = [hs.Sink(f"k{i}") for i in range(80)]
+        servers = [hs.Server(f"s{i}", concurrency=1 + i % 3, service_time=hs.ExponentialLatency(0.05), downstream=sinks[i]) for i in range(80)]
+        sources = [hs.Source.poisson(rate=5 + i % 4, target=servers[i], name=f"src{i}") for i in range(80)]
+        probes = []
+        for i in range(0, 80, 3):
+            tgt, metric = [(servers[i], "depth"), (servers[i], "utilization"), (sinks[i], "events_received"),
+                           (sources[i], "generated_count")][(i // 3) % 4]
+            probes.append(hs.Probe.on(tgt, metric, interval=0.1 * (1 + i % 5))[0])
+            if i % 2 == 0:
+                probes += hs.Probe.on_many(servers[i], ["stats_accepted", "stats_dropped", "requests_completed"], interval=0.5)[0]
+        return sources, servers + sinks, probes[::-1]
+
+    sources, entities, probes = build()
+    pc = L._plain_chains(sources, entities)
+    assert pc is not None
+    where = L.plain_probe_arrays(pc, probes, pc.arrays)
+    fast = pc.arrays
+    g = L.LoweredGraph(L._plain_chains(sources, entities))
+    L.attach_probes(g, probes)
+    slow = g.arrays()
+    np.testing.assert_array_equal(fast.probe_metric, slow.probe_metric)
+    np.testing.assert_array_equal(fast.probe_interval_s, slow.probe_interval_s)
+    np.testing.assert_array_equal(fast.probe_metric_more, slow.probe_metric_more)
+    np.testing.assert_array_equal(fast.probe_interval_more, slow.probe_interval_more)
+    at = {id(pr): (i, slot) for i, st in enumerate(g.stations) for slot, pr in enumerate(st.probes)}
+    assert [(w[0], w[1]) for w in where] == [at[id(p)] for p in probes]
+    np.testing.assert_array_equal(fast.probe_order, [at[id(p)][0] for p in probes])
+    np.testing.assert_array_equal(fast.probe_slot_order, [at[id(p)][1] for p in probes])
+    assert [w[2] for w in where] == [p.target.concurrency if p.metric == "utilization" else None for p in probes]
+    # what the fast path leaves to the general lowering / refuses like it
+    other = hs.Server("elsewhere", service_time=hs.ExponentialLatency(0.1))
+    assert L.plain_probe_arrays(pc, [hs.Probe.on(other, "depth")[0]], L.StationArrays.uniform(80)) is None
+    with pytest.raises(hs.UnsupportedTopology, match="four probes"):
+        L.plain_probe_arrays(pc, [hs.Probe.on(entities[0], "depth")[0] for _ in range(5)], L.StationArrays.uniform(80))
+    with pytest.raises(hs.UnsupportedTopology, match="not an attribute"):
+        L.plain_probe_arrays(pc, [hs.Probe.on(entities[0], "events_received")[0]], L.StationArrays.uniform(80))
