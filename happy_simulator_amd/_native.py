@@ -36,7 +36,7 @@ EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuat
 PROBE_METRICS = {"depth": 0, "active_requests": 1, "stats_accepted": 2, "stats_dropped": 3, "requests_completed": 4,
                  "_requests_completed": 4, "events_received": 5, "generated_count": 6}
 PROBE_NONE = 255
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class EngineUnavailable(RuntimeError):
@@ -139,7 +139,8 @@ class LbStats(C.Structure):
 
 _TUS = ("hs_engine.hip", "hs_lb.hip", "hs_tables.hip")          # one object each ...
 _INST_TU, _INST_GROUPS = "hs_inst.hip", 15                      # ... plus hs_inst.hip once per instantiation group (csrc/hs_kernels.hpp)
-STAMP_PATH = os.path.join(LIB_DIR, "libhs_hip.stamp")
+_STAMP_TU = "hs_stamp.hip"                                      # ... plus the build identity (the sources' hash, inside the .so)
+_MARK, _MARK_END = b"HS_SRC_HASH=", b"=HS_SRC_HASH_END"
 
 
 def sources() -> list[str]:
@@ -159,11 +160,25 @@ def _sources_hash() -> str:
     return hh.hexdigest()
 
 
+def built_from(path: str) -> str | None:
+    """The sources' hash (+ "|" + extra defines) the library at `path` was built from: it is compiled into the library
+    (csrc/hs_stamp.hip), so a checkout that changes csrc/ cannot leave a stale binary looking current (no side file to trust)."""
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    i = blob.find(_MARK)
+    while i >= 0:                                   # (the marker's own pieces also occur as separate literals: take the full form)
+        j = blob.find(_MARK_END, i)
+        if 0 <= j - i - len(_MARK) <= 4096 and b"\0" not in blob[i:j]:
+            return blob[i + len(_MARK):j].decode(errors="replace")
+        i = blob.find(_MARK, i + 1)
+    return None
+
+
 def is_stale() -> bool:
-    if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP_PATH):
-        return True
-    with open(STAMP_PATH) as f:
-        return f.read().strip() != _sources_hash() + "|"
+    return built_from(LIB_PATH) != _sources_hash() + "|"
 
 
 def build(force: bool = False, verbose: bool = False, defines: tuple = (), lib_path: str | None = None) -> str:
@@ -175,10 +190,9 @@ def build(force: bool = False, verbose: bool = False, defines: tuple = (), lib_p
 
     os.makedirs(LIB_DIR, exist_ok=True)
     out = lib_path or LIB_PATH
-    stamp = out + ".stamp" if lib_path else STAMP_PATH
     extra = [f"-D{d}" for d in defines]
     want = _sources_hash() + "|" + " ".join(extra)
-    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+    if not force and built_from(out) == want:
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     obj_dir = os.path.join(LIB_DIR, "obj") if not lib_path else out + ".obj"
@@ -186,6 +200,7 @@ def build(force: bool = False, verbose: bool = False, defines: tuple = (), lib_p
     flags = [f for f in HIPCC_FLAGS if f != "-shared"] + extra
     jobs = [(tu, [], os.path.join(obj_dir, tu.replace(".hip", ".o"))) for tu in _TUS]
     jobs += [(_INST_TU, [f"-DHS_INST={k}"], os.path.join(obj_dir, f"hs_inst_{k}.o")) for k in range(_INST_GROUPS)]
+    jobs += [(_STAMP_TU, [f'-DHS_SOURCES_HASH="{want}"'], os.path.join(obj_dir, "hs_stamp.o"))]
 
     def compile_one(job):
         tu, defs, obj = job
@@ -209,8 +224,7 @@ def build(force: bool = False, verbose: bool = False, defines: tuple = (), lib_p
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    with open(stamp, "w") as f:
-        f.write(want)
+    assert built_from(out) == want, "the build identity did not make it into the library"
     return out
 
 
@@ -242,6 +256,7 @@ def lib():
     L = C.CDLL(os.environ.get("HS_HIP_LIB") or LIB_PATH)   # HS_HIP_LIB: an instrumented build (tools/cycles.py)
     P = C.POINTER
     L.hs_abi_version.restype = C.c_int
+    L.hs_build_sources_hash.restype = C.c_char_p
     L.hs_device_count.restype = C.c_int
     L.hs_engine_create.restype = C.c_int
     L.hs_engine_create.argtypes = [P(Config), P(C.c_void_p)]
@@ -363,7 +378,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = (
-    "hs_abi_version", "hs_device_count", "hs_engine_create", "hs_engine_set_stations", "hs_engine_set_network",
+    "hs_abi_version", "hs_build_sources_hash", "hs_device_count", "hs_engine_create", "hs_engine_set_stations", "hs_engine_set_network",
     "hs_engine_get_net_stats", "hs_engine_set_stream", "hs_engine_shard_attach", "hs_engine_shard_begin",
     "hs_engine_shard_window", "hs_engine_shard_inject", "hs_engine_shard_progress", "hs_engine_shard_final",
     "hs_engine_shard_overshoot", "hs_engine_shard_async_setup", "hs_engine_shard_round",

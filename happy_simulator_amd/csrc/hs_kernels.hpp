@@ -1268,7 +1268,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
             // sharded network: the election continues across the ranks on the host (hs_engine_shard_overshoot runs
             // the winner); publish this rank's candidate
             SC.cand_out[0] = b.valid; SC.cand_out[1] = b.t; SC.cand_out[2] = b.t_created;
-            SC.cand_out[3] = SC.lp_base + b.lp; SC.cand_out[4] = b.depth; SC.cand_out[5] = b.rcrt; SC.cand_out[6] = b.rank; SC.cand_out[7] = 0;
+            SC.cand_out[3] = SC.lp_base + b.lp; SC.cand_out[4] = b.depth; SC.cand_out[5] = b.rcrt; SC.cand_out[6] = b.rank; SC.cand_out[7] = b.pad;   // [6] is shard-LOCAL: the host re-ranks by (station, [7]) network-wide
             tot->cur_time = new_cur;
             tot->done = 0;
             return;

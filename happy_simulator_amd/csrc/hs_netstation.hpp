@@ -67,7 +67,8 @@ struct ShardCtl {
     int64_t end_ns, W, lp_base;
     int64_t *outbox;              // [world][row] : row = {count, kMsgWords x int64 per message ...}
     int64_t *cand_out;            // [8] {valid, t, t_created, global lp, steps from its group's root, that root's creation time,
-                                  //      construction rank, 0} of the rank's first event beyond end_ns (the election's key)
+                                  //      construction rank among THIS shard's entities, what the candidate is (Candidate::pad)}
+                                  //      of the rank's first event beyond end_ns (the election's key)
     const int32_t *link_rank;     // [n_links] rank that owns the link's destination station
     int32_t msg_cap, row, rank, world;
 };

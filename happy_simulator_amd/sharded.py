@@ -95,7 +95,13 @@ class LocalComm:
 
 
 class DistComm:
-    """One shard per process: torch.distributed (backend "nccl" is RCCL on ROCm; "gloo" on CPU tensors for tests)."""
+    """One shard per process: torch.distributed (backend "nccl" is RCCL on ROCm; "gloo" for tests).
+
+    RCCL moves device tensors directly.  gloo has no all-to-all on device tensors (and RCCL refuses two ranks on one GPU), so under
+    gloo every device tensor is staged through host memory: copy out (which waits for the engine launches enqueued on torch's current
+    stream), collective on the host copy, copy back.  That is the mode in which two REAL shards run as two processes on ONE GPU
+    (`tests/test_gpu_dist.py`, `bench.py --fake-ranks`): the protocol, the slicing and the collectives' semantics are the multi-GPU
+    run's, only the transport differs."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
@@ -105,28 +111,42 @@ class DistComm:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.local_ranks = [self.rank]
+        self.stage_host = dist.get_backend(group) != "nccl"
+
+    def _staged(self, t):
+        return t.cpu() if (self.stage_host and t.is_cuda) else t
 
     def exchange(self, outboxes, inboxes):
-        self._dist.all_to_all_single(inboxes[0], outboxes[0], group=self._group)
+        src, dst = self._staged(outboxes[0]), self._staged(inboxes[0])
+        self._dist.all_to_all_single(dst, src, group=self._group)
+        if dst is not inboxes[0]:
+            inboxes[0].copy_(dst)
+
+    def _all_reduce(self, t, op):
+        h = self._staged(t)
+        self._dist.all_reduce(h, op=op, group=self._group)
+        if h is not t:
+            t.copy_(h)
 
     def allreduce_min(self, scalars):
-        self._dist.all_reduce(scalars[0], op=self._dist.ReduceOp.MIN, group=self._group)
+        self._all_reduce(scalars[0], self._dist.ReduceOp.MIN)
 
     def allreduce_max(self, vectors):
-        self._dist.all_reduce(vectors[0], op=self._dist.ReduceOp.MAX, group=self._group)
+        self._all_reduce(vectors[0], self._dist.ReduceOp.MAX)
 
     def allgather_rows(self, rows):
         import torch
 
-        out = [torch.empty_like(rows[0]) for _ in range(self.world)]
-        self._dist.all_gather(out, rows[0], group=self._group)
+        row = self._staged(rows[0])
+        out = [torch.empty_like(row) for _ in range(self.world)]
+        self._dist.all_gather(out, row, group=self._group)
         return torch.stack(out).cpu().numpy()
 
     def reduce_host(self, dicts):
         import torch
 
         local = _combine(dicts)
-        dev = "cuda" if self._dist.get_backend(self._group) == "nccl" else "cpu"
+        dev = "cpu" if self.stage_host else "cuda"
         out = {}
         for k in sorted(local):
             v = local[k]
@@ -221,6 +241,67 @@ def shard_arrays(stations: StationArrays, net: NetworkArrays, lo: int, hi: int):
         router_target3=None if net.router_target3 is None else remap(net.router_target3),
         bag_capacity=net.bag_capacity, n_global_lp=n, link_gid=gids, n_global_links=net.n_links)
     return st, sub
+
+
+MAX_XSRC, MAX_PROBES = 3, 4     # csrc/hs_station.hpp kMaxXSrc / kMaxProbes
+
+
+class ElectionRanks:
+    """The last key of the election of the one event beyond `end_time`, NETWORK-WIDE: the position of the candidate's entity in the
+    reference's construction order (`sources=[...]`, then sourceless stations, then `probes=[...]`) -- the table
+    `hs_engine_set_stations` builds for one engine (csrc/hs_engine.hip, `tie_rank`; csrc/hs_station.hpp `cand_rank`), built here
+    from the unsharded description.  A shard's engine only knows the relative order of its OWN entities (its `source_order` /
+    `probe_order` are filtered and re-based, `shard_arrays`), so a rank it reports cannot be compared with another shard's: the
+    host looks the winner's rank up by (station, kind) instead (`hs_shard.cand_dev` words 3 and 7)."""
+
+    def __init__(self, stations: StationArrays):
+        n = self.n = int(stations.n)
+        # no order given: the engine ranks by LP position (cand_rank's closed form, `tie_rank == nullptr`)
+        self.lp_order = stations.source_order is None and stations.probe_order is None
+        kinds = np.zeros((1 + MAX_XSRC, n), np.uint8)
+        kinds[0] = np.asarray(stations.src_kind)
+        if stations.src_more_kind is not None:
+            kinds[1:] = np.asarray(stations.src_more_kind)
+        has = kinds != N.SRC_NONE
+        if stations.source_order is not None:
+            so = np.asarray(stations.source_order, np.int64)
+            ss = (np.zeros(len(so), np.int64) if stations.source_slot_order is None
+                  else np.asarray(stations.source_slot_order, np.int64))
+        else:                                                  # LP-major, slot-minor
+            lp, slot = np.nonzero(has.T)
+            so, ss = lp.astype(np.int64), slot.astype(np.int64)
+        self.tick = np.full((1 + MAX_XSRC, n), -1, np.int64)   # a tick: its own Source's position
+        self.tick[ss, so] = np.arange(len(so))
+        self.first = np.full(n, -1, np.int64)                  # anything else of the station: its first-listed Source
+        for q in range(len(so) - 1, -1, -1):
+            self.first[so[q]] = q
+        none = self.first < 0
+        self.first[none] = len(so) + np.nonzero(none)[0]       # sourceless stations after every Source
+        pm = np.full((MAX_PROBES, n), N.PROBE_NONE, np.uint8)
+        if stations.probe_metric is not None:
+            pm[0] = np.asarray(stations.probe_metric)
+        if stations.probe_metric_more is not None:
+            pm[1:] = np.asarray(stations.probe_metric_more)
+        if stations.probe_order is not None:
+            po = np.asarray(stations.probe_order, np.int64)
+            ps = (np.zeros(len(po), np.int64) if stations.probe_slot_order is None
+                  else np.asarray(stations.probe_slot_order, np.int64))
+        else:
+            lp, slot = np.nonzero((pm != N.PROBE_NONE).T)
+            po, ps = lp.astype(np.int64), slot.astype(np.int64)
+        self.probe = np.full((MAX_PROBES, n), -1, np.int64)    # Probes behind all of them, each by its own position
+        self.probe[ps, po] = len(so) + n + np.arange(len(po))
+
+    def rank(self, station: int, kind: int) -> int:
+        if self.lp_order:
+            if kind >= 8:
+                return self.n * (MAX_XSRC + 1) + station * MAX_PROBES + (kind - 8)
+            return station * (MAX_XSRC + 1) + (kind - 2 if kind >= 2 else 0)
+        if kind >= 8:
+            return int(self.probe[kind - 8, station])
+        if kind >= 2:
+            return int(self.tick[kind - 2, station])
+        return int(self.first[station])
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -339,8 +420,10 @@ class ShardedNetwork:
     """Drives the shards this process owns through the window protocol.  `shards` are the local shard objects
     (GpuShard, or any object with the same methods), `comm` moves rows and scalars between all shards."""
 
-    def __init__(self, shards: list, comm, *, window_ns: int, sync_every: int = 64, rounds: bool = False):
+    def __init__(self, shards: list, comm, *, window_ns: int, sync_every: int = 64, rounds: bool = False,
+                 ranks: "ElectionRanks | None" = None):
         self.shards = shards
+        self.ranks = ranks               # network-wide construction ranks for the election across shards (None: trust word 6)
         self.comm = comm
         self.window_ns = int(window_ns)
         self.sync_every = max(1, int(sync_every))
@@ -381,7 +464,7 @@ class ShardedNetwork:
                 s.async_setup(cross, round_iters)
         if sync_every is None:           # exchanges between host synchronisations: a run is ~25 rounds or ~60 000 windows
             sync_every = 4 if rounds else 64
-        return cls(shards, comm, window_ns=window_ns, sync_every=sync_every, rounds=rounds)
+        return cls(shards, comm, window_ns=window_ns, sync_every=sync_every, rounds=rounds, ranks=ElectionRanks(stations))
 
     def _run_rounds(self, end_ns: int) -> int:
         """Asynchronous rounds: every shard runs the asynchronous engine for a few iterations, then messages (all-to-all)
@@ -455,13 +538,17 @@ class ShardedNetwork:
             for s in sh:
                 s.final(k)
         self.windows = k
-        # [world, CAND_WORDS]: valid, t, t_created, station, steps from its group's root, that root's creation time, construction rank
+        # [world, CAND_WORDS]: valid, t, t_created, station, steps from its group's root, that root's creation time, the construction
+        # rank among the shard's own entities, what the candidate is
         cands = comm.allgather_rows([s.cand for s in sh])
         valid = cands[cands[:, 0] != 0]
         winner_t = None
         if len(valid):
-            # the election's key (csrc/hs_kernels.hpp cand_less): time, creation time, lineage, construction rank
-            order = np.lexsort((valid[:, 3], valid[:, 6], valid[:, 5], valid[:, 4], valid[:, 2], valid[:, 1]))
+            # the election's key (csrc/hs_kernels.hpp cand_less): time, creation time, lineage, construction rank -- the last one
+            # network-wide: a shard's word 6 only orders that shard's entities (ElectionRanks)
+            rank = valid[:, 6] if self.ranks is None else np.array(
+                [self.ranks.rank(int(c[3]), int(c[7])) for c in valid], np.int64)
+            order = np.lexsort((valid[:, 3], rank, valid[:, 5], valid[:, 4], valid[:, 2], valid[:, 1]))
             t, station = int(valid[order[0]][1]), int(valid[order[0]][3])
             winner_t = t
             for s in sh:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HS_ABI_VERSION 10
+#define HS_ABI_VERSION 11
 
 typedef enum hs_status {
     HS_OK = 0,
@@ -241,9 +241,13 @@ typedef struct hs_shard {
     int64_t *gvt_dev;                /* device int64[2]: window k accumulates this rank's earliest pending work into
                                         [k & 1]; the caller all-reduces (min) it before window k + 1 reads it */
     int64_t *cand_dev;               /* device int64[8]: {valid, t, t_created, station, steps from its group's root, that root's
-                                        creation time, construction rank, 0}: this rank's first event beyond end_ns; the ranks'
-                                        candidates compare by (t, t_created, steps, root time, rank) = (time, _sort_index),
-                                        core/event.py:337-344 */
+                                        creation time, construction rank among this shard's entities, kind}: this rank's first
+                                        event beyond end_ns; the ranks' candidates compare by (t, t_created, steps, root time,
+                                        construction rank) = (time, _sort_index), core/event.py:337-344.  The rank in [6] only
+                                        orders entities of ONE shard; across shards the caller derives the network-wide rank from
+                                        (station, kind): kind 0 = a departure / message / injected Request (ranks like the
+                                        station's first-listed Source), 2 + s = the tick of the station's Source in slot s,
+                                        8 + s = the tick of its Probe in slot s (happy_simulator_amd/sharded.py election_rank) */
 } hs_shard;
 
 typedef struct hs_net_stats {
@@ -288,6 +292,9 @@ typedef struct hs_lp_stats {
 typedef struct hs_engine hs_engine;
 
 int hs_abi_version(void);
+/* Build identity: the hash of the sources (csrc/, this header, the compiler flags) the library was built from, compiled into the
+ * library itself; the host side rebuilds when it differs from the sources next to it (happy_simulator_amd/_native.py). */
+const char *hs_build_sources_hash(void);
 /* Number of visible HIP devices (0 when there is no GPU). */
 int hs_device_count(void);
 

@@ -27,7 +27,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_abi_version_and_struct_sizes(lib):
-    assert lib.hs_abi_version() == N.ABI_VERSION == 10
+    assert lib.hs_abi_version() == N.ABI_VERSION == 11
     assert C.sizeof(N.Config) == 56
     assert N.EV_KINDS == 15 and len(N.EV_NAMES) == 15
     assert C.sizeof(N.Summary) == 8 * (1 + 15 + 1 + 1 + 1 + 1) + 8 + 8 + 8 + 8 + 8
@@ -99,3 +99,17 @@ def test_library_is_loaded_after_torch():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+def test_library_carries_the_hash_of_its_sources():
+    """The "is the binary older than its sources" check reads the hash compiled INTO libhs_hip.so (csrc/hs_stamp.hip), never a side
+    file: a checkout that changes csrc/ cannot make an old binary look current, and no stamp file is tracked."""
+    import subprocess
+
+    lib = N.lib()
+    want = N._sources_hash() + "|"
+    assert lib.hs_build_sources_hash().decode() == want == N.built_from(N.LIB_PATH)
+    assert not N.is_stale()
+    tracked = subprocess.run(["git", "ls-files", "happy_simulator_amd/lib"], capture_output=True, text=True, cwd=ROOT)
+    if tracked.returncode == 0:                      # (the GPU box's copy has no .git)
+        assert tracked.stdout.strip() == "", tracked.stdout

@@ -24,7 +24,7 @@ def _run(*args):
 
 
 @pytest.mark.parametrize("args", [
-    ("--n-lp", "4096", "--end-s", "20", "--cpu-sample-s", "2"),
+    ("--n-lp", "4096", "--end-s", "20", "--cpu-sample-s", "2", "--extras", "0"),
     ("--workload", "ring", "--n-lp", "2048", "--end-s", "5", "--cpu-sample-s", "2"),
     ("--workload", "lb", "--lb-sources", "512", "--lb-backends", "512", "--end-s", "10", "--cpu-sample-s", "2"),
 ], ids=["grid", "ring", "lb"])
@@ -41,8 +41,12 @@ def test_bench_prints_one_contract_line(args):
         assert "valu" in r and (r["valu"] is None or 0.0 < r["valu"]["busy_frac"] <= 1.0)
     if "--workload" not in args:             # the grid line also carries the API run and the reference's own Python path
         assert "api_run_s" in d["config"] and d["config"]["api_events"] == d["config"]["events_per_step_per_gpu"]
-        ref = c_ref = d["cpu_baseline"].get("reference_python")
-        assert ref is None or (ref["single_process_65536_chains"]["value"] > 1e3 and "cpu" in c_ref)
+        # the reference's own Python loop was timed on ANOTHER host (the GPU box has no /root/reference): labelled as such
+        assert "reference_python" not in d["cpu_baseline"]
+        ref = d["cpu_baseline"].get("reference_python_other_host")
+        assert ref is None or (ref["single_process_65536_chains"]["value"] > 1e3 and
+                               d["cpu_baseline"]["reference_python_host"]["cpu"] == ref["cpu"])
+        assert d["cpu_baseline"]["same_box_host"]["cores_available"] >= 1
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 1e4 and c["unit"] == "events/s" and c["sample"]
@@ -52,8 +56,42 @@ def test_bench_prints_one_contract_line(args):
 def test_bench_strong_scaling_and_self_launch_flags():
     """`--scaling strong` keeps the metric's total station count (here on one GPU: the same numbers as weak), and a plain
     `python bench.py --gpus N` without a launcher starts its own ranks (checked with N = 1: no torch.distributed.run child)."""
-    weak = _run("--steps", "2", "--warmup", "1", "--n-lp", "2048", "--end-s", "5", "--cpu-sample-s", "0", "--api-run", "0")
+    weak = _run("--steps", "2", "--warmup", "1", "--n-lp", "2048", "--end-s", "5", "--cpu-sample-s", "0", "--api-run", "0", "--extras", "0")
     strong = _run("--steps", "2", "--warmup", "1", "--n-lp", "2048", "--end-s", "5", "--cpu-sample-s", "0", "--api-run", "0",
-                  "--scaling", "strong")
+                  "--scaling", "strong", "--extras", "0")
     assert strong["scaling"] == "strong" and weak["scaling"] == "weak"
     assert strong["config"]["events_per_step_per_gpu"] == weak["config"]["events_per_step_per_gpu"]
+
+
+def test_default_line_carries_ring_lb_and_the_strong_shard():
+    """The default invocation (grid, one GPU) times the ring, the load balancer and the 8-GPU strong shard with the same
+    --steps / --warmup and prints them inside the ONE line -- each workload with its own roofline and CPU-port baseline."""
+    d = _run("--steps", "3", "--warmup", "1", "--n-lp", "4096", "--end-s", "10", "--cpu-sample-s", "2", "--lb-sources", "512",
+             "--lb-backends", "512", "--api-run", "0")
+    for name, metric in (("ring", "ring network"), ("lb", "load balancer")):
+        w = d["workloads"][name]
+        assert metric in w["metric"] and w["value"] > 1e6 and w["ms_per_step"] > 0 and w["steps"] == 3 and w["warmup"] == 1
+        assert w["roofline"]["achieved"] > 0 and w["roofline"]["peak"] == 8000.0
+        assert w["cpu_baseline"]["kind"] == "port" and w["cpu_baseline"]["value"] > 1e4
+    sh = d["strong_shard"]
+    assert sh["n_lp"] == 512 and 0 < sh["kernel_ms_avg"] <= sh["ms_per_step"]
+    assert sh["events_per_step"] < d["config"]["events_per_step_per_gpu"]
+
+
+def test_fake_ranks_run_the_multi_rank_bench_paths_on_one_gpu():
+    """`--fake-ranks 2`: two processes on one GPU over gloo run what `--gpus 2` runs on two GPUs -- the self-launch, the strong
+    split of the grid, `other_scaling`, the MAX / SUM reductions, and the sharded ring's exchange rounds on real shards."""
+    one = _run("--steps", "2", "--warmup", "1", "--n-lp", "4096", "--end-s", "5", "--cpu-sample-s", "0", "--api-run", "0", "--extras", "0")
+    two = _run("--steps", "2", "--warmup", "1", "--n-lp", "4096", "--end-s", "5", "--cpu-sample-s", "0", "--fake-ranks", "2")
+    assert two["fake_ranks"] == 2 and two["n_gpus"] == 1 and two["scaling"] == "strong"
+    assert two["config"]["n_lp_per_gpu"] == 2048 and two["other_scaling"]["scaling"] == "weak"
+    # the strong split's ranks hold the same 4 096 chains (disjoint stream ids by lp_base): the same events in total
+    # (every rank is a Simulation of its own here, so each processes its own one event beyond end_time)
+    assert abs(round(two["value"] * two["ms_per_step"] * 1e-3) - one["config"]["events_per_step_per_gpu"]) <= 2
+    assert two["other_scaling"]["n_lp_per_gpu"] == 4096
+    ring1 = _run("--workload", "ring", "--steps", "2", "--warmup", "1", "--n-lp", "2048", "--end-s", "3", "--cpu-sample-s", "0")
+    ring2 = _run("--workload", "ring", "--steps", "2", "--warmup", "1", "--n-lp", "2048", "--end-s", "3", "--cpu-sample-s", "0",
+                 "--fake-ranks", "2")
+    assert ring2["fake_ranks"] == 2 and "gloo" in ring2["config"]["parallelism"]
+    assert ring2["config"]["events_per_step"] == ring1["config"]["events_per_step"]       # two shards == one engine
+    assert ring2["config"]["launches_per_step"] >= 1

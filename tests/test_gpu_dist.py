@@ -1,7 +1,13 @@
-"""GPU: the multi-GPU path through torch.distributed with backend "nccl" (= RCCL on ROCm) on REAL shards -- the
-all_to_all_single of the outbox rows, the all_reduce (MAX of the cross links' bounds / MIN of the GVT), the all_gather of the
-overshoot candidates and the totals' reductions all run on device tensors.  With one GPU the process group has world size 1
-(every collective still goes through RCCL); with two or more visible GPUs the same worker runs as two ranks."""
+"""GPU: the multi-rank path through torch.distributed on REAL shards (`GpuShard` + `DistComm`, happy_simulator_amd/sharded.py) --
+the reference's execute / exchange / advance loop (parallel/coordinator.py:87-124) with one partition per process.
+
+* backend "nccl" (= RCCL on ROCm): the all_to_all_single of the outbox rows, the all_reduce (MAX of the cross links' bounds / MIN
+  of the GVT), the all_gather of the overshoot candidates and the totals' reductions run on device tensors; world size 1 on a
+  one-GPU box, two ranks when two GPUs are visible;
+* backend "gloo", both ranks on device 0 (`--same-device`): RCCL refuses two ranks on one GPU, so DistComm stages the exchange
+  tensors through host memory -- everything else (two processes, two engines, `shard_arrays`' slicing and re-basing, both exchange
+  protocols, the cross-rank election with network-wide construction ranks) is the multi-GPU run.  This is the N > 1 evidence a
+  one-GPU box can give."""
 import json
 import os
 import socket
@@ -21,33 +27,67 @@ def _port():
         return sk.getsockname()[1]
 
 
-def _check(out, world):
+def _check(out, world, fewer_rounds=True):
     one = out["single"]
     for proto in ("rounds", "windows"):
         r = out[proto]
         assert r["world"] == world
         assert r["events"] == one["events"] and r["final"] == one["final"], (proto, r, one)
+        assert r["by_kind"] == one["by_kind"], (proto, r, one)
+        assert r["stats_equal"] and r["sinks_equal"] and r["probes_equal"], (proto, r)
         assert r["exchanges"] >= 1
-    assert out["rounds"]["exchanges"] < out["windows"]["exchanges"]       # bounds travel further than the 1 ms link floor
-    assert out["rounds"]["completed_local"] == out["windows"]["completed_local"] == one["completed_local"]
+    if fewer_rounds:
+        assert out["rounds"]["exchanges"] < out["windows"]["exchanges"]   # bounds travel further than the 1 ms link floor
+
+
+def _launch(world, worker_args, timeout=600):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), WORKER, *worker_args]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
 
 
 def test_distcomm_over_nccl_world_1_on_a_real_shard():
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port()))
-    p = subprocess.run([sys.executable, WORKER, "4096", "3.0"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    p = subprocess.run([sys.executable, WORKER, "ring", "4096", "3.0"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     _check(out, 1)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_as_processes_on_one_gpu_ring_equals_the_single_engine(world):
+    """`world` processes, one real shard each, all on device 0 over gloo: rounds == windows == the single engine."""
+    out = _launch(world, ["ring", "8192", "3.0", "--backend", "gloo", "--same-device"])
+    assert out["backend"] == "gloo" and out["same_device"]
+    _check(out, world)
+
+
+def test_two_processes_on_one_gpu_sources_probes_schedule_profiles():
+    """Several Sources per Server listed extras-first, probes, a ramp profile and schedule()d Requests on a 260-station ring cut
+    into two processes: the order arrays, slot orders and schedule ranks `shard_arrays` filters and re-bases (ADVICE r2's bug
+    site) on real engines; every per-station statistic, Sink record digest and probe sample equals the single engine."""
+    out = _launch(2, ["mixed", "260", "4.0", "--backend", "gloo", "--same-device"])
+    _check(out, 2)
+    assert out["rounds"]["n_probes"] >= 20
+
+
+def test_two_processes_lock_step_tie_across_shards_goes_to_the_network_wide_rank():
+    """The one event beyond end_time is a lock-step tie between the ticks of two constant Sources in DIFFERENT shards, listed in
+    reverse station order (`sources=[...]` extras first): time, creation time and lineage all tie, so the reference's answer is
+    the construction order of the two Sources -- a NETWORK-WIDE rank no shard knows (the shard-local rank let the
+    lower station win).  The winner's `generated` count shows who ran."""
+    out = _launch(2, ["lockstep", "8", "2.1", "--backend", "gloo", "--same-device"])
+    _check(out, 2, fewer_rounds=False)
+    gen = out["single"]["generated"]
+    assert gen[6] == gen[1] + 1, gen            # station 6's Source (listed first) ticked once more: the event beyond end_time
 
 
 def test_two_ranks_over_rccl_equal_the_single_engine():
     import torch
 
     if torch.cuda.device_count() < 2:
-        pytest.skip("needs two GPUs (the driver's multi-GPU tier); world size 1 is covered above")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_port()), WORKER, "8192", "3.0"]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert p.returncode == 0, p.stderr[-3000:]
-    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        pytest.skip("needs two GPUs (the driver's multi-GPU tier); two ranks on one GPU run over gloo above")
+    out = _launch(2, ["ring", "8192", "3.0"])
     _check(out, 2)

@@ -126,3 +126,37 @@ def test_two_process_gloo_run_matches_single_heap(rounds):
     assert got[0][3] == got[1][3]                        # same number of windows on every rank
     np.testing.assert_array_equal(np.array(got[0][4] + got[1][4]), counts)
     assert got[0][5] + got[1][5] == ev                   # and owns only its share of the events
+
+
+def test_election_ranks_are_network_wide_construction_positions():
+    """The last key of the cross-shard election (sharded.ElectionRanks): a candidate's rank is its entity's position in the WHOLE
+    network's construction order -- `sources=[...]` as listed, sourceless stations behind every Source, Probes behind all of them
+    in `probes=[...]` order -- the table hs_engine_set_stations builds for one engine; a shard's own rank (its filtered, re-based
+    order) cannot be compared across shards."""
+    from happy_simulator_amd import _native as N
+    from happy_simulator_amd.engine import StationArrays
+    from happy_simulator_amd.sharded import ElectionRanks
+
+    n = 8
+    st = StationArrays.uniform(n, rate=4.0)
+    st.src_kind[3] = N.SRC_NONE                                     # a sourceless station
+    r = ElectionRanks(st)                                           # no order arrays: the engine's closed form (LP order)
+    assert [r.rank(i, 2) for i in range(n)] == [4 * i for i in range(n)]
+    assert r.rank(5, 0) == 20 and r.rank(5, 3) == 21 and r.rank(2, 9) == 4 * n + 2 * 4 + 1
+    # Sources listed in reverse station order, station 6 with a second Source (slot 1) listed first of all
+    st.src_more_kind = np.full((3, n), N.SRC_NONE, np.uint8)
+    st.src_more_rate = np.ones((3, n))
+    st.src_more_kind[0, 6] = N.SRC_CONSTANT
+    st.source_order = np.array([6, 7, 6, 5, 4, 2, 1, 0], np.int32)
+    st.source_slot_order = np.array([1, 0, 0, 0, 0, 0, 0, 0], np.uint8)
+    st.probe_metric = np.full(n, N.PROBE_NONE, np.uint8)
+    st.probe_metric[[1, 6]] = 0
+    st.probe_interval_s = np.full(n, 0.5)
+    st.probe_order = np.array([6, 1], np.int32)
+    r = ElectionRanks(st)
+    assert r.rank(6, 3) == 0 and r.rank(7, 2) == 1 and r.rank(6, 2) == 2 and r.rank(0, 2) == 7
+    assert r.rank(6, 0) == 0                                        # a departure of station 6: its first-listed Source
+    assert r.rank(3, 0) == 8 + 3                                    # sourceless: behind the 8 Sources, by station
+    assert r.rank(6, 8) == 8 + n and r.rank(1, 8) == 8 + n + 1      # Probes last, in probes=[...] order
+    # the lock-step tie of ADVICE r3: station 1 (shard 0) against station 6 (shard 1) -- both shards call their Source "rank 0"
+    assert r.rank(6, 2) < r.rank(1, 2)

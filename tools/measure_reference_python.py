@@ -50,8 +50,16 @@ def main(tag):
     import random
 
     import numpy as np
+    import subprocess
+    try:
+        head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        head = None
     out = {"python": platform.python_version(), "cpu": cpu_model(), "cores_available": os.cpu_count(),
-           "where": "build container (the GPU box has no /root/reference)", "reference": "adamfilli/happy-simulator v0.2.5"}
+           "where": "build container, NOT the GPU box (the GPU box has no /root/reference and the reference must not be copied "
+                    "into the repo, so a same-box figure is not obtainable)",
+           "host": platform.node(), "date": time.strftime("%Y-%m-%d"), "repo_head": head,
+           "reference": "adamfilli/happy-simulator v0.2.5"}
     # (i) one Simulation, one core
     for n, end_s in ((4096, 2.0), (65536, 0.25)):
         random.seed(42); np.random.seed(42)
