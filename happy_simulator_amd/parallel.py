@@ -259,6 +259,7 @@ class ParallelSimulationSummary:
     window_size_s: float = 0.0
     barrier_overhead_seconds: float = 0.0
     coordination_efficiency: float = 1.0
+    engine_exchanges: int = 0       # (not a reference field, not in to_dict()) exchange rounds the engine's shards actually ran
 
     def to_dict(self) -> dict:
         return {"duration_s": self.duration_s, "total_events_processed": self.total_events_processed,
@@ -287,6 +288,22 @@ class ParallelSimulationSummary:
                       f"  Barrier overhead: {self.barrier_overhead_seconds:.3f}s",
                       f"  Coordination efficiency: {self.coordination_efficiency:.1%}"]
         return "\n".join(lines)
+
+
+def reference_window_count(start: Instant, end: Instant, window_s: float) -> int:
+    """`total_windows` as the reference's coordinator counts them (parallel/coordinator.py:87-114): from the start, the window end is
+    `Instant.from_seconds(current.to_seconds() + W)` clamped to the end, until the clock reaches the end -- binary64 accumulation
+    included (12 s of 0.05 s windows are 241, not 240).  The engine's own exchange cadence follows the lookahead of the boundary
+    stations instead (a few dozen rounds, `engine_exchanges`); the reference's early exit when every heap is empty does not arise
+    while a Source ticks."""
+    n, cur, end_s = 0, start, end.to_seconds()
+    while cur < end:
+        w = cur.to_seconds() + window_s
+        nxt = Instant.from_seconds(min(w, end_s))
+        if not (cur < nxt):          # a window too small to move the nanosecond clock: the reference would spin
+            raise ValueError(f"window_size {window_s}s does not advance the clock at {cur.to_seconds()}s")
+        cur, n = nxt, n + 1
+    return n
 
 
 def _parallel_summary(part_summaries: dict, part_wall: dict, wall: float, *, duration_s: float, total_events: int,
@@ -326,6 +343,7 @@ class ParallelSimulation:
         if duration is not None and end_time is not None:
             raise ValueError("Cannot specify both 'duration' and 'end_time'")
         self._links = list(links or [])
+        self._window_size = window_size
         self._validate(partitions, self._links, window_size)
         self._partitions = partitions
         self._seed = seed
@@ -371,7 +389,15 @@ class ParallelSimulation:
             if lk.dest_partition not in seen:
                 raise ValueError(f"PartitionLink references unknown dest partition '{lk.dest_partition}'")
             if lk.latency is not None or lk.packet_loss != 0.0:
-                raise UnsupportedTopology("PartitionLink latency overrides / packet loss are not lowered")
+                # parallel/coordinator.py:200-210.  `latency`: the coordinator calls `link.latency.sample()`, a method none of the
+                # reference's LatencyDistributions has (AttributeError there: tests/test_oracle_live_reference.py), so there is no
+                # library behaviour to mirror.  `packet_loss`: ONE `random.Random(seed)` per coordinator, drawn once per cross event
+                # in exchange order (partition dict order inside a window, window by window) -- a sequential MT19937 stream whose
+                # order is a property of the windowing, with no extension point to plug a per-link counter-based stream into
+                # (the Philox-plugged parity definition).  Loss on the hop itself is lowered:
+                # NetworkLink(packet_loss_rate=...).
+                raise UnsupportedTopology("PartitionLink(latency=...) / PartitionLink(packet_loss=...) are not lowered: put the loss "
+                                          "on the hop (NetworkLink(packet_loss_rate=...)); see happy_simulator_amd/parallel.py")
         if window_size is not None and links:
             m = min(lk.min_latency for lk in links)
             if window_size > m:
@@ -499,7 +525,12 @@ class ParallelSimulation:
         dur = (summ.final_time_ns - start_ns) / 1e9
         # this process's shards take turns on its GPU: they split the time run_until spent outside the exchanges
         busy = max(summ.run_seconds - summ.exchange_seconds, 0.0) / max(len(part_summaries), 1)
-        return _parallel_summary(part_summaries, {name: busy for name in part_summaries}, _time.monotonic() - wall0,
-                                 duration_s=dur, total_events=summ.events_processed, n_partitions=world,
-                                 windows=summ.windows, cross=int(cross), window_s=summ.window_ns / 1e9,
-                                 barrier_s=summ.exchange_seconds)
+        # total_windows / window_size_s read as the reference's (parallel/simulation.py:82-87, coordinator.py:87-114): W = the
+        # caller's window_size or the smallest PartitionLink.min_latency; the engine's exchange rounds are reported beside them
+        window_s = self._window_size if self._window_size is not None else min(lk.min_latency for lk in self._links)
+        out = _parallel_summary(part_summaries, {name: busy for name in part_summaries}, _time.monotonic() - wall0,
+                                duration_s=dur, total_events=summ.events_processed, n_partitions=world,
+                                windows=reference_window_count(self._start, self._end, window_s), cross=int(cross),
+                                window_s=window_s, barrier_s=summ.exchange_seconds)
+        out.engine_exchanges = int(summ.windows)
+        return out

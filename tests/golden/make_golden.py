@@ -216,7 +216,7 @@ def build_chains(spec, chain_ids, seed):
     sources, entities, handles, extras, by_slot = [], [], [], {}, {}
     order, slot_plan = source_plan(spec, list(chain_ids))
     for local, i in enumerate(chain_ids):
-        base = i if spec["mode"] == "single" else 0
+        base = 0 if spec["mode"] == "replicas" else i     # "single" / "partitions": entities numbered across the whole model
         if spec.get("shared_sink"):      # one collector behind every server: its lists are in global processing order
             shared = getattr(build_chains, "_shared", None)
             if local == 0 or shared is None:
@@ -991,6 +991,275 @@ RING_CASES = [
          seed=2026, trace=False),
 ]
 
+# =====================================================================================================================
+# The reference's OWN `ParallelSimulation(...).run()` (parallel/simulation.py:164-223, parallel/coordinator.py:75-227)
+# =====================================================================================================================
+# SURVEY 8(a) row X2.  What the live class accepts, probed here (tests/test_oracle_live_reference.py pins each fact):
+#   * a LINKED run refuses a library `Server` unless the partition also lists the Server's private queue / driver / worker
+#     entities (`routing.py:52-60`: their events count as "not in this partition");
+#   * a library `NetworkLink` cannot carry a request across partitions: it forwards at `self.now`, so the coordinator raises
+#     "violates min_latency: delay=0" (`coordinator.py:213-219`); `PartitionLink(latency=<library distribution>)` raises
+#     AttributeError (`coordinator.py:209` calls `.sample()`, which no LatencyDistribution has);
+#   * what DOES run across a link is the pattern of the reference's own tests (`tests/integration/test_parallel_simulation.py:
+#     21-38`, SURVEY 8(d) workload 3): an entity that returns `Event(time=self.now + delay, target=<entity over there>)`.
+# `FutureForward` below is that pattern with NetworkLink's delay arithmetic (link.py:190-216): one event per hop where a
+# NetworkLink has two (Request@Link and its continuation) -- so per-ENTITY statistics and Sink records of such a run are those of
+# the same topology with NetworkLinks, and the totals differ by the continuations (`packets_sent`).
+from happysimulator.components.common import Counter  # noqa: E402
+from happysimulator.core.entity import Entity  # noqa: E402
+from happysimulator.parallel import ParallelSimulation, PartitionLink, SimulationPartition  # noqa: E402
+
+
+class FutureForward(Entity):
+    """A hop that delivers in the future: `Event(time=now + delay)` with delay = ConstantLatency + optional (Philox-plugged)
+    exponential jitter, each through `get_latency(now).to_seconds()` like NetworkLink._calculate_delay (link.py:190-216)."""
+
+    def __init__(self, name, egress, latency, jitter=None):
+        super().__init__(name)
+        self.egress, self.latency, self.jitter = egress, latency, jitter
+        self.entered = 0
+
+    def handle_event(self, event):
+        self.entered += 1
+        delay = self.latency.get_latency(self.now).to_seconds()
+        if self.jitter is not None:
+            delay += self.jitter.get_latency(self.now).to_seconds()
+        return [Event(time=self.now + max(0.0, delay), event_type=event.event_type, target=self.egress,
+                      context=event.context.copy())]
+
+
+def _server_parts(srv):
+    """What a linked partition must list next to a library Server (see above)."""
+    return [srv, srv._queue, srv._driver, srv._worker]
+
+
+def _count_time_travel(sims):
+    """Wrap every partition's heap pop: an event popped with time < the clock is what `_execute_until` drops as time travel
+    (core/simulation.py:480-489)."""
+    dropped = {name: 0 for name in sims}
+    for name, sim in sims.items():
+        heap, orig = sim._event_heap, sim._event_heap.pop
+
+        def pop(_orig=orig, _sim=sim, _name=name):
+            e = _orig()
+            if e.time < _sim._current_time:
+                dropped[_name] += 1
+            return e
+
+        heap.pop = pop
+    return dropped
+
+
+def _pipeline(spec, hop_kind):
+    """stages[k] = list of per-lane Server descriptions of partition k; lane j flows stage 0 -> 1 -> ... over hops.
+    Stream bases = station index in (stage-major, lane-minor) order; a hop draws its jitter from its SENDER's LINK stream."""
+    seed, lanes, stages = spec["seed"], spec["lanes"], spec["stages"]
+    servers, sinks, hops, sources = [], [], [], []
+    for k, stage in enumerate(stages):
+        row = []
+        for j in range(lanes):
+            base = k * lanes + j
+            svc, mean = stage["svc"], stage["mean"][j] if isinstance(stage["mean"], list) else stage["mean"]
+            st = (PhiloxExponentialLatency(mean, hs.Stream(seed, base, hs.STREAM_SERVICE)) if svc == "exp" else ConstantLatency(mean))
+            row.append(Server(f"srv{k}_{j}", concurrency=stage.get("concurrency", 1), service_time=st,
+                              queue_capacity=stage.get("queue_cap")))
+        servers.append(row)
+    for j in range(lanes):
+        sinks.append(Sink(f"sink{j}"))
+        servers[-1][j].downstream = sinks[j]
+    for k in range(len(stages) - 1):
+        row = []
+        for j in range(lanes):
+            base = k * lanes + j
+            lat = ConstantLatency(spec["hop_latency"])
+            jit = (PhiloxExponentialLatency(spec["hop_jitter"], hs.Stream(seed, base, hs.STREAM_LINK))
+                   if spec.get("hop_jitter") else None)
+            if hop_kind == "network":
+                hop = NetworkLink(f"hop{k}_{j}", latency=lat, jitter=jit, egress=servers[k + 1][j])
+            else:
+                hop = FutureForward(f"hop{k}_{j}", servers[k + 1][j], lat, jit)
+            servers[k][j].downstream = hop
+            row.append(hop)
+        hops.append(row)
+    for j in range(lanes):
+        rate = spec["rate"][j] if isinstance(spec["rate"], list) else spec["rate"]
+        prov = PhiloxPoissonArrival(ConstantRateProfile(rate=rate), Instant.Epoch, hs.Stream(seed, j, hs.STREAM_ARRIVAL))
+        sources.append(Source(f"src{j}", SimpleEventProvider(servers[0][j], "Request", None), prov))
+    return sources, servers, hops, sinks
+
+
+def _pipeline_results(servers, hops, sinks, sources):
+    flat = [s for row in servers for s in row]
+    out = {
+        "generated": np.array([s.generated_count for s in sources], np.int64),
+        "accepted": np.array([s.stats_accepted for s in flat], np.int64),
+        "dropped": np.array([s.stats_dropped for s in flat], np.int64),
+        "completed": np.array([s._requests_completed for s in flat], np.int64),
+        "depth": np.array([s.depth for s in flat], np.int64),
+        "active": np.array([s.active_requests for s in flat], np.int64),
+        "total_service_s": np.array([s._total_service_time for s in flat], np.float64),
+        "received": np.array([k.events_received for k in sinks], np.int64),
+        "hop_entered": np.array([(h.entered if isinstance(h, FutureForward) else h.packets_sent + h.packets_dropped)
+                                 for row in hops for h in row], np.int64),
+    }
+    t, lat, off = [], [], [0]
+    for k in sinks:
+        t.extend(x.nanoseconds for x in k.completion_times)
+        lat.extend(k.latencies_s)
+        off.append(len(t))
+    out["sink_t_ns"], out["sink_latency_s"], out["sink_off"] = np.asarray(t, np.int64), np.asarray(lat, np.float64), np.asarray(off, np.int64)
+    return out
+
+
+def run_parallel_linked_case(spec):
+    """A pipeline of partitions (one stage per partition) three ways:
+    `windowed`   -- the reference's own ParallelSimulation(partitions, links=[PartitionLink ...]).run(), FutureForward hops;
+    `seq_future` -- the same entities in ONE reference Simulation (what the windowed run claims to equal);
+    `seq_network`-- the topology with library NetworkLinks in ONE reference Simulation: what the engine's linked partitions compute
+                    (hs.ParallelSimulation == the single heap)."""
+    end = Instant.from_seconds(spec["end_s"])
+    out = {}
+    meta = dict(spec=spec)
+    # --- seq_network
+    sources, servers, hops, sinks = _pipeline(spec, "network")
+    sim = Simulation(end_time=end, sources=sources, entities=[s for r in servers for s in r] + [h for r in hops for h in r] + sinks)
+    summ = sim.run()
+    for k, v in _pipeline_results(servers, hops, sinks, sources).items():
+        out["seqnet_" + k] = v
+    meta["seq_network"] = dict(total_events=summ.total_events_processed, final_ns=sim._current_time.nanoseconds, duration_s=summ.duration_s,
+                               packets_sent=[h.packets_sent for r in hops for h in r])
+    # --- seq_future
+    sources, servers, hops, sinks = _pipeline(spec, "future")
+    sim = Simulation(end_time=end, sources=sources, entities=[s for r in servers for s in r] + [h for r in hops for h in r] + sinks)
+    summ = sim.run()
+    for k, v in _pipeline_results(servers, hops, sinks, sources).items():
+        out["seqfut_" + k] = v
+    meta["seq_future"] = dict(total_events=summ.total_events_processed, final_ns=sim._current_time.nanoseconds, duration_s=summ.duration_s)
+    # --- windowed: the reference's coordinator
+    sources, servers, hops, sinks = _pipeline(spec, "future")
+    parts = []
+    for k, row in enumerate(servers):
+        ents = [x for s in row for x in _server_parts(s)] + (hops[k] if k < len(hops) else []) + (sinks if k == len(servers) - 1 else [])
+        parts.append(SimulationPartition(name=f"P{k}", entities=ents, sources=sources if k == 0 else []))
+    links = [PartitionLink(f"P{k}", f"P{k + 1}", min_latency=spec["hop_latency"]) for k in range(len(servers) - 1)]
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                      # the GIL warning
+        ps = ParallelSimulation(parts, end_time=end, links=links)
+    dropped = _count_time_travel(ps.simulations)
+    summ = ps.run()
+    for k, v in _pipeline_results(servers, hops, sinks, sources).items():
+        out["win_" + k] = v
+    meta["windowed"] = dict(
+        total_events=summ.total_events_processed, duration_s=summ.duration_s, total_windows=summ.total_windows,
+        total_cross_partition_events=summ.total_cross_partition_events, window_size_s=summ.window_size_s,
+        partition_events={k: v.total_events_processed for k, v in summ.partitions.items()},
+        partition_duration_s={k: v.duration_s for k, v in summ.partitions.items()},
+        time_travel_drops=dropped)
+    same = all(np.array_equal(out["win_" + k], out["seqfut_" + k]) for k in ("accepted", "completed", "received", "sink_t_ns"))
+    meta["windowed_equals_sequential"] = bool(same)
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    return out, meta
+
+
+def run_parallel_independent_case(spec):
+    """`ParallelSimulation(partitions).run()` WITHOUT links (parallel/simulation.py:170-195): one partition per chain of the spec
+    (build_chains: stream base = chain id, the run's seed for all -- how hs.ParallelSimulation numbers its partitions), every
+    partition a Simulation of its own on the reference's thread pool.  Also each sub-case of the reference's own tests
+    (tests/integration/test_parallel_simulation.py:75-109,239-289): constant Sources feeding Counters."""
+    out, meta = {}, dict(spec=spec)
+    if spec.get("counters"):
+        res = []
+        for sub in spec["counters"]:
+            counters = [Counter(f"counter{i}") for i in range(len(sub["rates"]))]
+            srcs = [Source.constant(rate=r, target=c, event_type="Ping") for r, c in zip(sub["rates"], counters)]
+            parts = [SimulationPartition(name=f"P{i}", entities=[c], sources=[s_]) for i, (c, s_) in enumerate(zip(counters, srcs))]
+            kw = dict(links=[]) if sub.get("empty_links") else {}
+            import warnings
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                summ = ParallelSimulation(parts, duration=sub["duration"], **kw).run()
+            # the sequential twin (test_deterministic_equivalence): separate Simulations
+            seq = []
+            for r in sub["rates"]:
+                c = Counter("c")
+                Simulation(duration=sub["duration"], sources=[Source.constant(rate=r, target=c, event_type="Ping")], entities=[c]).run()
+                seq.append(c.total)
+            res.append(dict(totals=[c.total for c in counters], sequential_totals=seq, generated=[s_.generated_count for s_ in srcs],
+                            total_events=summ.total_events_processed, duration_s=summ.duration_s,
+                            partition_events=[summ.partitions[f"P{i}"].total_events_processed for i in range(len(parts))],
+                            partition_duration_s=[summ.partitions[f"P{i}"].duration_s for i in range(len(parts))],
+                            total_windows=summ.total_windows, total_cross_partition_events=summ.total_cross_partition_events,
+                            events_per_second=summ.events_per_second,
+                            entity_events_handled={k: v.events_handled for k, v in summ.entities.items()}))
+        meta["counters"] = res
+        out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        return out, meta
+    n = spec["n_chains"]
+    sources, entities, handles = build_chains(spec, list(range(n)), spec["seed"])
+    parts = []
+    for i, (src, srv, snk) in enumerate(handles):
+        parts.append(SimulationPartition(name=f"P{i}", entities=[srv] + ([snk] if snk is not None else []),
+                                         sources=[s_ for s_ in sources if s_._event_provider._target is srv]))
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ps = ParallelSimulation(parts, end_time=Instant.from_seconds(spec["end_s"]))
+    summ = ps.run()
+    meta.update(total_events=[summ.partitions[f"P{i}"].total_events_processed for i in range(n)],
+                duration_s=[summ.partitions[f"P{i}"].duration_s for i in range(n)],
+                final_ns=[ps.simulations[f"P{i}"]._current_time.nanoseconds for i in range(n)],
+                parallel=dict(total_events=summ.total_events_processed, duration_s=summ.duration_s,
+                              events_per_second=summ.events_per_second, total_windows=summ.total_windows,
+                              total_cross_partition_events=summ.total_cross_partition_events, window_size_s=summ.window_size_s,
+                              entity_events_handled={k: v.events_handled for k, v in summ.entities.items()}))
+    out["generated"] = np.array([h[0].generated_count for h in handles], np.int64)
+    for key, attr in (("accepted", "stats_accepted"), ("dropped", "stats_dropped"), ("completed", "_requests_completed"),
+                      ("rejected", "_requests_rejected"), ("depth", "depth"), ("active", "active_requests")):
+        out[key] = np.array([getattr(h[1], attr) for h in handles], np.int64)
+    out["total_service_s"] = np.array([h[1]._total_service_time for h in handles], np.float64)
+    out["received"] = np.array([h[2].events_received if h[2] is not None else 0 for h in handles], np.int64)
+    t, lat, off = [], [], [0]
+    for h in handles:
+        if h[2] is not None:
+            t.extend(x.nanoseconds for x in h[2].completion_times)
+            lat.extend(h[2].latencies_s)
+        off.append(len(t))
+    out["sink_t_ns"], out["sink_latency_s"], out["sink_off"] = np.asarray(t, np.int64), np.asarray(lat, np.float64), np.asarray(off, np.int64)
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    return out, meta
+
+
+PARALLEL_CASES = [
+    # the reference's own known-answer tests of ParallelSimulation, verbatim configurations
+    dict(name="parallel_ref_counters", kind="independent", counters=[
+        dict(rates=[10, 10], duration=10.0),                    # test_two_independent_partitions: 100 / 100
+        dict(rates=[5], duration=20.0),                         # test_single_partition_matches_simulation: 100
+        dict(rates=[10], duration=5.0, empty_links=True),       # test_empty_links_independent: 50, no windows
+        dict(rates=[10, 10], duration=10.0),                    # test_deterministic_equivalence (sequential twins recorded)
+        dict(rates=[3, 7, 11], duration=7.3)]),
+    # Philox-plugged M/M/c partitions, one chain each, through the reference's ParallelSimulation (threads)
+    dict(name="parallel_philox_independent_6", kind="independent", n_chains=6, arr=["poisson", "constant", "poisson", "poisson", "constant", "poisson"],
+         rate=[8.0, 10.0, 30.0, 12.0, 4.0, 9.0], svc=["exp", "exp", "exp", "const", "exp", "exp"], mean=[0.1, 0.08, 0.05, 0.06, 0.3, 0.1],
+         concurrency=[1, 1, 2, 1, 2, 1], queue_cap=[None, None, 4, None, None, 2], end_s=15.0, rng="philox", seed=61, mode="partitions"),
+    # linked partitions where the windowed run IS its sequential twin: downstream partitions never hold an event of their own
+    # beyond the clock (zero service time), hops deliver in send order (no jitter) -- no overshoot can run ahead of an arrival
+    dict(name="parallel_linked_pipeline", kind="linked", lanes=4, rate=[8.0, 5.0, 12.0, 3.0], seed=71, end_s=12.0, hop_latency=0.05,
+         stages=[dict(svc="exp", mean=[0.1, 0.15, 0.06, 0.2]), dict(svc="const", mean=0.0)]),
+    dict(name="parallel_linked_three_stages", kind="linked", lanes=3, rate=[6.0, 9.0, 4.0], seed=72, end_s=10.0, hop_latency=0.02,
+         stages=[dict(svc="exp", mean=[0.1, 0.08, 0.2], concurrency=2, queue_cap=3), dict(svc="const", mean=0.0), dict(svc="const", mean=0.0)]),
+    # failing by design: an ACTIVE downstream partition (its own service completions lie beyond the window end) and jittered hops
+    # -- every window's one-event overshoot (core/simulation.py:472) runs a completion early, and the arrivals injected at the next
+    # barrier lie behind the partition's clock: dropped as time travel (core/simulation.py:480-489).  The reference's windowed run
+    # departs from its own sequential run; the engine's linked partitions equal the SEQUENTIAL one (DESIGN section 7).
+    dict(name="parallel_linked_hazard", kind="linked", lanes=3, rate=[9.0, 7.0, 11.0], seed=73, end_s=15.0, hop_latency=0.02,
+         hop_jitter=0.01, stages=[dict(svc="exp", mean=[0.08, 0.1, 0.06]), dict(svc="exp", mean=[0.07, 0.09, 0.05])]),
+]
+
+
 CASES = [
     # --- Oracle-A: stock MT19937 streams -------------------------------------------------
     dict(name="quickstart_mt42", n_chains=1, arr="poisson", rate=8.0, svc="exp", mean=0.1, end_s=60.0,
@@ -1097,6 +1366,15 @@ CASES = [
 
 def main(argv):
     only = set(argv[1:])
+    for spec in PARALLEL_CASES:
+        if only and spec["name"] not in only:
+            continue
+        fn = run_parallel_linked_case if spec["kind"] == "linked" else run_parallel_independent_case
+        out, meta = fn(dict(spec))
+        path = os.path.join(HERE, spec["name"] + ".npz")
+        np.savez_compressed(path, **out)
+        brief = {k: meta[k] for k in ("windowed", "seq_future", "seq_network", "windowed_equals_sequential", "parallel") if k in meta}
+        print(f"{spec['name']}: {brief} -> {os.path.getsize(path)} B")
     for spec in LB_CASES:
         if only and spec["name"] not in only:
             continue

@@ -16,7 +16,8 @@ def golden_names(topology="chains"):
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
 
     def topo(n):
-        return "ring" if n.startswith("ring_") else "lb" if n.startswith("lb_") else "tandem" if n.startswith("tandem_") else "chains"
+        return ("ring" if n.startswith("ring_") else "lb" if n.startswith("lb_") else "tandem" if n.startswith("tandem_")
+                else "parallel" if n.startswith("parallel_") else "chains")
 
     return [n for n in names if topo(n) == topology]
 
@@ -224,6 +225,8 @@ def run_oracle_for_spec(spec, trace_cap=0):
     runs = []
     if spec["mode"] == "single":
         groups = [(list(range(n)), spec["seed"], list(range(n)))]
+    elif spec["mode"] == "partitions":   # ParallelSimulation without links: a Simulation per chain, ONE seed, stream base = partition
+        groups = [([i], spec["seed"], [i]) for i in range(n)]
     else:
         groups = [([i], spec["seed"] + i, [0]) for i in range(n)]
     for chain_ids, seed, bases in groups:
@@ -614,3 +617,30 @@ def compare_lb_engine_with_oracle(eng, p, r, check_sink_order=True):
             t, cr = eng.read_sink(j)
             np.testing.assert_array_equal(t, r.sinks[i][0])
             np.testing.assert_array_equal(cr, r.sinks[i][1])
+
+
+# ---- pipelines of partitions (tests/golden/make_golden.py run_parallel_linked_case) -----------------------------------------------
+def pipeline_oracle_graph(spec):
+    """Oracle nodes of the `seq_network` form of a parallel_linked_* golden: lane j flows Server(stage 0) -> NetworkLink -> Server
+    (stage 1) -> ... -> Sink_j.  Stream base = station index (stage-major, lane-minor); a link draws from its sender's LINK stream.
+    Returns (graph, srv[stage][lane], lnk[stage][lane], snk[lane], src[lane])."""
+    lanes, stages = spec["lanes"], spec["stages"]
+    g = O.Graph()
+    rate = per_chain(spec["rate"], lanes)
+    src = [g.source(O.ARR_POISSON, float(rate[j]), stream_base=j) for j in range(lanes)]
+    srv, lnk = [], []
+    for k, stg in enumerate(stages):
+        mean = per_chain(stg["mean"], lanes)
+        srv.append([g.server(O.LAT_EXP if stg["svc"] == "exp" else O.LAT_CONST, float(mean[j]), concurrency=stg.get("concurrency", 1),
+                             queue_cap=-1 if stg.get("queue_cap") is None else int(stg["queue_cap"]), stream_base=k * lanes + j)
+                    for j in range(lanes)])
+    snk = [g.sink() for _ in range(lanes)]
+    for k in range(len(stages) - 1):
+        lnk.append([g.link(spec["hop_latency"], spec.get("hop_jitter"), stream_base=k * lanes + j) for j in range(lanes)])
+    for j in range(lanes):
+        g.target[src[j]] = srv[0][j]
+        for k in range(len(stages)):
+            g.target[srv[k][j]] = lnk[k][j] if k < len(stages) - 1 else snk[j]
+            if k < len(stages) - 1:
+                g.target[lnk[k][j]] = srv[k + 1][j]
+    return g, srv, lnk, snk, src

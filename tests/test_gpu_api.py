@@ -217,7 +217,10 @@ def test_linked_partitions_equal_the_single_heap_run():
     summary = ps.run()
     assert summary.total_events_processed == gold.meta["total_events"][0]
     assert summary.duration_s == gold.meta["duration_s"][0]
-    assert summary.total_windows > 0 and summary.window_size_s == 0.001
+    # total_windows / window_size_s as the reference's coordinator counts them: W = the smallest PartitionLink.min_latency
+    from happy_simulator_amd.parallel import reference_window_count
+    assert summary.window_size_s == 0.0005 and summary.engine_exchanges > 0
+    assert summary.total_windows == reference_window_count(Instant.Epoch, Instant.from_seconds(spec["end_s"]), 0.0005) > summary.engine_exchanges
     assert summary.total_cross_partition_events == sum(links[i]._entered for i in (2, 4, 7))
     assert set(summary.partitions) == {"p0", "p1", "p2"}
     assert sum(p.total_events_processed for p in summary.partitions.values()) == summary.total_events_processed
@@ -938,3 +941,135 @@ def test_probes_on_plain_chains_take_the_object_free_path_and_equal_the_general_
                [list(k.completion_times) for k in sinks2], [s.generated_count for s in sources2], summary2.total_events_processed)
     assert fast == general
     assert sum(len(v) for v in fast[0]) > 1000
+
+
+# ---- X2 pinned to the reference's OWN ParallelSimulation(...).run() (fixtures: tests/golden/make_golden.py PARALLEL_CASES) --------------
+def test_parallel_simulation_equals_the_reference_known_answer_tests():
+    """The configurations of the reference's own tests (tests/integration/test_parallel_simulation.py:75-109,239-289) -- constant
+    Sources feeding Counters, 1-3 partitions, with and without `links=[]` -- against what the live reference's ParallelSimulation
+    computed for them: every Counter total (100 / 100, 100, 50), per-partition and total event counts, durations, no windows."""
+    gold = H.Golden("parallel_ref_counters")
+    for sub, want in zip(gold.spec["counters"], gold.meta["counters"]):
+        counters = [hs.Counter(f"counter{i}") for i in range(len(sub["rates"]))]
+        srcs = [hs.Source.constant(rate=r, target=c, event_type="Ping") for r, c in zip(sub["rates"], counters)]
+        parts = [hs.SimulationPartition(name=f"P{i}", entities=[c], sources=[s_]) for i, (c, s_) in enumerate(zip(counters, srcs))]
+        summ = hs.ParallelSimulation(parts, duration=sub["duration"], **(dict(links=[]) if sub.get("empty_links") else {})).run()
+        assert [c.total for c in counters] == want["totals"] == want["sequential_totals"]
+        assert [s_.generated_count for s_ in srcs] == want["generated"]
+        assert summ.total_events_processed == want["total_events"] and summ.duration_s == want["duration_s"]
+        assert [summ.partitions[f"P{i}"].total_events_processed for i in range(len(parts))] == want["partition_events"]
+        assert [summ.partitions[f"P{i}"].duration_s for i in range(len(parts))] == want["partition_duration_s"]
+        assert summ.total_windows == want["total_windows"] == 0 and summ.total_cross_partition_events == 0
+        assert summ.events_per_second == want["events_per_second"]
+        assert {k: v.events_handled for k, v in summ.entities.items()} == want["entity_events_handled"]
+
+
+def test_parallel_simulation_without_links_equals_the_reference_fixture():
+    """Six Philox-plugged M/M/c partitions through the reference's ParallelSimulation (one Simulation per partition on its thread
+    pool, model-wide entity numbering, one seed) == hs.ParallelSimulation: totals per partition, every statistic and Sink record."""
+    gold = H.Golden("parallel_philox_independent_6")
+    spec, p = gold.spec, H.spec_chain_params(gold.spec)
+    parts, servers, sinks, sources = [], [], [], []
+    for i in range(spec["n_chains"]):
+        sink = hs.Sink(f"sink{i}")
+        svc = hs.ExponentialLatency(p["mean"][i]) if spec["svc"][i] == "exp" else hs.ConstantLatency(p["mean"][i])
+        srv = hs.Server(f"srv{i}", concurrency=p["conc"][i], service_time=svc,
+                        queue_capacity=None if p["qcap"][i] < 0 else p["qcap"][i], downstream=sink)
+        factory = hs.Source.poisson if spec["arr"][i] == "poisson" else hs.Source.constant
+        src = factory(rate=spec["rate"][i], target=srv, name=f"src{i}")
+        parts.append(hs.SimulationPartition(name=f"P{i}", entities=[srv, sink], sources=[src]))
+        servers.append(srv); sinks.append(sink); sources.append(src)
+    summ = hs.ParallelSimulation(parts, end_time=Instant.from_seconds(spec["end_s"]), seed=spec["seed"]).run()
+    par = gold.meta["parallel"]
+    assert [summ.partitions[f"P{i}"].total_events_processed for i in range(len(parts))] == gold.meta["total_events"]
+    assert [summ.partitions[f"P{i}"].duration_s for i in range(len(parts))] == gold.meta["duration_s"]
+    assert summ.total_events_processed == par["total_events"] and summ.duration_s == par["duration_s"]
+    assert summ.events_per_second == par["events_per_second"] and summ.total_windows == 0 == summ.total_cross_partition_events
+    assert {k: v.events_handled for k, v in summ.entities.items()} == par["entity_events_handled"]
+    assert [s_.generated_count for s_ in sources] == gold.generated.tolist()
+    for key, attr in (("accepted", "stats_accepted"), ("dropped", "stats_dropped"), ("depth", "depth"), ("active", "active_requests")):
+        assert [getattr(sv, attr) for sv in servers] == gold.arrays[key].tolist(), key
+    assert [sv.stats.requests_completed for sv in servers] == gold.completed.tolist()
+    assert [sv.stats.total_service_time for sv in servers] == gold.total_service_s.tolist()
+    for i, sk in enumerate(sinks):
+        t, lat = gold.sink_records(i)
+        np.testing.assert_array_equal(sk.completion_ns, t)
+        np.testing.assert_array_equal(sk.latencies_array, lat)
+
+
+def _build_pipeline(spec):
+    """make_golden._pipeline(spec, "network") with this package's classes: lane j flows stage 0 -> NetworkLink -> stage 1 -> ... ->
+    Sink_j; one partition per stage."""
+    lanes, stages = spec["lanes"], spec["stages"]
+    servers = []
+    for k, stg in enumerate(stages):
+        mean = H.per_chain(stg["mean"], lanes)
+        servers.append([hs.Server(f"srv{k}_{j}", concurrency=stg.get("concurrency", 1), queue_capacity=stg.get("queue_cap"),
+                                  service_time=(hs.ExponentialLatency(mean[j]) if stg["svc"] == "exp" else hs.ConstantLatency(mean[j])))
+                        for j in range(lanes)])
+    sinks = [hs.Sink(f"sink{j}") for j in range(lanes)]
+    hops = []
+    for j in range(lanes):
+        servers[-1][j].downstream = sinks[j]
+    for k in range(len(stages) - 1):
+        row = []
+        for j in range(lanes):
+            jit = hs.ExponentialLatency(spec["hop_jitter"]) if spec.get("hop_jitter") else None
+            row.append(hs.NetworkLink(f"hop{k}_{j}", latency=hs.ConstantLatency(spec["hop_latency"]), jitter=jit, egress=servers[k + 1][j]))
+            servers[k][j].downstream = row[-1]
+        hops.append(row)
+    rate = H.per_chain(spec["rate"], lanes)
+    sources = [hs.Source.poisson(rate=rate[j], target=servers[0][j], name=f"src{j}") for j in range(lanes)]
+    parts = [hs.SimulationPartition(name=f"P{k}", entities=row + (hops[k] if k < len(hops) else []) + (sinks if k == len(stages) - 1 else []),
+                                    sources=sources if k == 0 else []) for k, row in enumerate(servers)]
+    links = [hs.PartitionLink(f"P{k}", f"P{k + 1}", min_latency=spec["hop_latency"]) for k in range(len(stages) - 1)]
+    return parts, links, sources, servers, hops, sinks
+
+
+@pytest.mark.parametrize("name", ["parallel_linked_pipeline", "parallel_linked_three_stages", "parallel_linked_hazard"])
+def test_linked_partitions_against_the_reference_parallel_simulation(name):
+    """hs.ParallelSimulation(partitions, links=[PartitionLink ...]) -- one shard of the network engine per partition -- against the
+    three runs of the LIVE reference the fixture holds (tests/golden/make_golden.py run_parallel_linked_case):
+
+    * `seqnet_*`: the same library topology (NetworkLinks) in ONE reference Simulation -- equal to the bit: totals, final time,
+      every statistic and Sink record.  This is the semantics the engine follows.
+    * `win_*`: the reference's own windowed ParallelSimulation (whose hops must be future-delivering entities: its coordinator
+      refuses NetworkLinks, tests/test_oracle_live_reference.py).  Where that run is self-consistent (no time-travel drops) every
+      Sink record and completion count agrees, `total_windows` / `window_size_s` / `total_cross_partition_events` are the
+      reference's numbers, and the event totals differ only by what is written below.
+    * `parallel_linked_hazard` -- failing by design: the reference's windowed run drops more than half of the downstream
+      partition's traffic as time travel (one-event overshoot per window, SURVEY section 5); the engine equals the reference's
+      SEQUENTIAL run instead."""
+    gold = H.Golden(name)
+    spec = gold.spec
+    parts, links, sources, servers, hops, sinks = _build_pipeline(spec)
+    summ = hs.ParallelSimulation(parts, end_time=Instant.from_seconds(spec["end_s"]), links=links, seed=spec["seed"]).run()
+    sn, win = gold.meta["seq_network"], gold.meta["windowed"]
+    flat = [sv for row in servers for sv in row]
+    # == the reference's sequential run of the same library entities
+    assert summ.total_events_processed == sn["total_events"] and summ.duration_s == sn["duration_s"]
+    assert [s_.generated_count for s_ in sources] == gold.seqnet_generated.tolist()
+    for key, attr in (("accepted", "stats_accepted"), ("dropped", "stats_dropped"), ("depth", "depth"), ("active", "active_requests")):
+        assert [getattr(sv, attr) for sv in flat] == gold.arrays["seqnet_" + key].tolist(), key
+    assert [sv.stats.requests_completed for sv in flat] == gold.seqnet_completed.tolist()
+    assert [sv.stats.total_service_time for sv in flat] == gold.seqnet_total_service_s.tolist()
+    assert [h.packets_sent for row in hops for h in row] == sn["packets_sent"]
+    np.testing.assert_array_equal(np.concatenate([k.completion_ns for k in sinks]), gold.seqnet_sink_t_ns)
+    np.testing.assert_array_equal(np.concatenate([k.latencies_array for k in sinks]), gold.seqnet_sink_latency_s)
+    # the reference's windowed bookkeeping: W = min(PartitionLink.min_latency), its binary64 window count
+    assert summ.window_size_s == win["window_size_s"] and summ.total_windows == win["total_windows"]
+    assert set(summ.partitions) == set(win["partition_events"])
+    if name == "parallel_linked_hazard":
+        assert not gold.meta["windowed_equals_sequential"] and sum(win["time_travel_drops"].values()) > 100
+        assert sum(k.events_received for k in sinks) == int(gold.seqfut_received.sum()) > 1.6 * int(gold.win_received.sum())
+        return
+    # ... and where the windowed run loses nothing, it saw what the engine saw
+    np.testing.assert_array_equal(np.concatenate([k.completion_ns for k in sinks]), gold.win_sink_t_ns)
+    assert [sv.stats.requests_completed for sv in flat] == gold.win_completed.tolist()
+    # a cross-partition event = a request that entered a hop; the windowed run counts the ones its partitions SENT, incl. those of
+    # its per-partition events beyond end_time (at most one per upstream partition)
+    assert 0 <= win["total_cross_partition_events"] - summ.total_cross_partition_events <= len(spec["stages"]) - 1
+    # event totals: a NetworkLink is two events per hop where the future-delivering entity is one (its continuation = packets_sent),
+    # and every PARTITION of the windowed run processes its own one event beyond end_time, the engine (one heap) a single one
+    diff = summ.total_events_processed - sum(sn["packets_sent"]) - win["total_events"]
+    assert -len(spec["stages"]) <= diff <= 1

@@ -59,7 +59,7 @@ def test_distcomm_over_nccl_world_1_on_a_real_shard():
 @pytest.mark.parametrize("world", [2, 3])
 def test_ranks_as_processes_on_one_gpu_ring_equals_the_single_engine(world):
     """`world` processes, one real shard each, all on device 0 over gloo: rounds == windows == the single engine."""
-    out = _launch(world, ["ring", "8192", "3.0", "--backend", "gloo", "--same-device"])
+    out = _launch(world, ["ring", "4096", "2.0", "--backend", "gloo", "--same-device"])
     assert out["backend"] == "gloo" and out["same_device"]
     _check(out, world)
 
@@ -68,7 +68,7 @@ def test_two_processes_on_one_gpu_sources_probes_schedule_profiles():
     """Several Sources per Server listed extras-first, probes, a ramp profile and schedule()d Requests on a 260-station ring cut
     into two processes: the order arrays, slot orders and schedule ranks `shard_arrays` filters and re-bases (ADVICE r2's bug
     site) on real engines; every per-station statistic, Sink record digest and probe sample equals the single engine."""
-    out = _launch(2, ["mixed", "260", "4.0", "--backend", "gloo", "--same-device"])
+    out = _launch(2, ["mixed", "260", "3.0", "--backend", "gloo", "--same-device"])
     _check(out, 2)
     assert out["rounds"]["n_probes"] >= 20
 

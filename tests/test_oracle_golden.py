@@ -287,3 +287,82 @@ def test_oracle_md5_known_answers():
     for n in (55, 56, 57, 63, 64, 65, 119, 120, 200):
         msg = bytes((i * 7 + 3) & 0xFF for i in range(n))
         assert O.md5(msg) == hashlib.md5(msg).digest()
+
+
+# ---- the reference's own ParallelSimulation (fixtures: make_golden.PARALLEL_CASES) -----------------------------
+def test_oracle_matches_reference_parallel_simulation_without_links():
+    """`ParallelSimulation(partitions).run()` of the live reference, one Philox-plugged M/M/c chain per partition: every partition
+    is a Simulation of its own (own heap, own one event beyond end_time) with the model-wide entity numbering."""
+    gold = H.Golden("parallel_philox_independent_6")
+    assert gold.spec["mode"] == "partitions"
+    check_oracle_against_station_golden(gold)
+    par = gold.meta["parallel"]
+    assert par["total_events"] == sum(gold.meta["total_events"]) and par["duration_s"] == max(gold.meta["duration_s"])
+    assert par["total_windows"] == 0 and par["total_cross_partition_events"] == 0
+
+
+def test_reference_parallel_simulation_known_answers():
+    """The reference's own known-answer tests (tests/integration/test_parallel_simulation.py:75-109,239-289), as its
+    ParallelSimulation computed them when the fixture was made: 100 / 100, 100, 50 with no windows, parallel == sequential."""
+    subs = H.Golden("parallel_ref_counters").meta["counters"]
+    assert subs[0]["totals"] == [100, 100] and subs[1]["totals"] == [100] and subs[2]["totals"] == [50]
+    assert subs[2]["total_windows"] == 0 and subs[2]["total_cross_partition_events"] == 0
+    for sub in subs:
+        assert sub["totals"] == sub["sequential_totals"]
+        assert sub["total_events"] == sum(sub["partition_events"]) and sub["duration_s"] == max(sub["partition_duration_s"])
+    # the C oracle on the same partitions: a constant Source straight into a collector, one heap per partition
+    spec = H.Golden("parallel_ref_counters").spec
+    for sub, want in zip(spec["counters"], subs):
+        for i, rate in enumerate(sub["rates"]):
+            g = O.Graph()
+            src, snk = g.source(O.ARR_CONSTANT, float(rate)), g.sink()
+            g.target[src] = snk
+            r = O.run(g, H.ns_from_seconds(sub["duration"]))
+            assert r.received[snk] == want["totals"][i] and r.generated[src] == want["generated"][i]
+            assert r.events_processed == want["partition_events"][i]
+            assert float(r.final_time_ns) / 1e9 == want["partition_duration_s"][i]
+
+
+@pytest.mark.parametrize("name", ["parallel_linked_pipeline", "parallel_linked_three_stages", "parallel_linked_hazard"])
+def test_oracle_matches_linked_partition_pipelines(name):
+    """Linked partitions.  The fixture holds three runs of the live reference: its own windowed ParallelSimulation (hops = entities
+    that deliver in the future, the only thing its coordinator accepts), the same entities in ONE Simulation, and the topology with
+    library NetworkLinks in ONE Simulation (`seqnet_*`) -- the last is what the engine's linked partitions compute, and the
+    oracle's single heap must equal it to the bit.  Where the reference's windowed run is self-consistent it agrees with that on
+    every Sink record; `parallel_linked_hazard` is the failing-by-design case where it is not."""
+    gold = H.Golden(name)
+    spec = gold.spec
+    g, srv, lnk, snk, src = H.pipeline_oracle_graph(spec)
+    r = O.run(g, H.ns_from_seconds(spec["end_s"]), seed=spec["seed"])
+    sn = gold.meta["seq_network"]
+    assert r.events_processed == sn["total_events"] and r.final_time_ns == sn["final_ns"]
+    flat = [x for row in srv for x in row]
+    np.testing.assert_array_equal(r.generated[src], gold.seqnet_generated)
+    for key in ("accepted", "dropped", "completed", "depth", "active", "total_service_s"):
+        np.testing.assert_array_equal(getattr(r, key)[flat], gold.arrays["seqnet_" + key], err_msg=key)
+    np.testing.assert_array_equal(r.received[snk], gold.seqnet_received)
+    np.testing.assert_array_equal(r.packets_sent[[x for row in lnk for x in row]], np.asarray(sn["packets_sent"]))
+    np.testing.assert_array_equal(np.concatenate([r.sinks[k][0] for k in snk]), gold.seqnet_sink_t_ns)
+    lat = np.concatenate([(r.sinks[k][0] - r.sinks[k][1]).astype(np.float64) / 1e9 for k in snk])
+    np.testing.assert_array_equal(lat, gold.seqnet_sink_latency_s)
+    # the reference against itself
+    win = gold.meta["windowed"]
+    drops = sum(win["time_travel_drops"].values())
+    if name == "parallel_linked_hazard":
+        # failing by design: the windowed coordinator loses requests its own sequential run delivers
+        assert not gold.meta["windowed_equals_sequential"] and drops > 100
+        assert gold.win_received.sum() < 0.6 * gold.seqfut_received.sum()
+        lanes = spec["lanes"]                  # what the downstream partition accepted + what it dropped as time travel = what was sent to it
+        assert abs(int(gold.win_accepted[lanes:].sum()) + drops - int(gold.win_hop_entered.sum())) <= lanes
+    else:
+        assert drops == 0
+        np.testing.assert_array_equal(gold.win_sink_t_ns, gold.seqnet_sink_t_ns)          # every Sink record, to the nanosecond
+        np.testing.assert_array_equal(gold.win_sink_latency_s, gold.seqnet_sink_latency_s)
+        np.testing.assert_array_equal(gold.win_completed, gold.seqnet_completed)
+        # what differs is bounded by the events beyond end_time: every PARTITION runs one of its own in the windowed run
+        assert 0 <= (gold.win_accepted - gold.seqfut_accepted).sum() <= len(spec["stages"])
+        assert 0 <= (gold.win_generated - gold.seqfut_generated).sum() <= 1
+        assert 0 <= win["total_events"] - gold.meta["seq_future"]["total_events"] <= len(spec["stages"]) - 1
+    # a NetworkLink is two events per hop (Request@Link + its continuation), the future-delivering entity one
+    # (+- 1: the one event beyond end_time is of a different kind in the two runs)
+    assert abs(sn["total_events"] - gold.meta["seq_future"]["total_events"] - sum(sn["packets_sent"])) <= 1

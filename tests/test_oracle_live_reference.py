@@ -120,3 +120,63 @@ def test_oracle_equals_live_reference_on_forests_of_servers(k):
 
     case = TS.fan_in_case(k)
     check_oracle_against_fan_in_reference(case, MG.run_fan_in_case(case))
+
+
+# ---- the reference's own ParallelSimulation ---------------------------------------------------------------
+def test_live_parallel_simulation_fixtures_are_current():
+    """The committed parallel_* fixtures are what the live `ParallelSimulation(...).run()` computes now (threads and all)."""
+    for spec in MG.PARALLEL_CASES:
+        fn = MG.run_parallel_linked_case if spec["kind"] == "linked" else MG.run_parallel_independent_case
+        out, meta = fn(dict(spec))
+        gold = H.Golden(spec["name"])
+        fresh = H.Golden.from_results(out, meta)
+        drop = lambda m: {k: v for k, v in m.items() if k != "spec"}                                    # noqa: E731
+        assert drop(fresh.meta) == drop(gold.meta), spec["name"]
+        for k, v in gold.arrays.items():
+            np.testing.assert_array_equal(fresh.arrays[k], v, err_msg=f"{spec['name']}: {k}")
+
+
+def _two_partition_chain(hop):
+    """Source -> Server_a -> <hop> -> Server_b -> Sink with library components; `hop(srv_b)` builds the hop."""
+    from happysimulator import ConstantLatency, Server, Sink, Source
+
+    sink = Sink("sink_b")
+    srv_b = Server("srv_b", service_time=ConstantLatency(0.02), downstream=sink)
+    h = hop(srv_b)
+    srv_a = Server("srv_a", service_time=ConstantLatency(0.03), downstream=h if h is not None else srv_b)
+    return Source.constant(rate=7, target=srv_a, event_type="Request"), srv_a, h, srv_b, sink
+
+
+def test_what_the_live_linked_parallel_simulation_refuses():
+    """Failing by design -- three facts about the reference's LINKED mode that shape what `hs.ParallelSimulation(links=...)` mirrors
+    (DESIGN section 7): (1) a library Server inside a linked partition needs its private queue / driver / worker listed as entities
+    (parallel/routing.py:52-60); (2) a library NetworkLink cannot cross partitions, whichever side owns it: it forwards at its own
+    `now`, the coordinator demands `delay >= min_latency` (parallel/coordinator.py:213-219); (3) `PartitionLink(latency=<library
+    distribution>)` is unusable: the coordinator calls `.sample()` (`coordinator.py:209`), which no LatencyDistribution has.  What
+    does cross is an entity that returns `Event(time=self.now + delay)` -- the pattern of the reference's own tests, which the
+    parallel_linked_* fixtures use."""
+    import warnings
+
+    from happysimulator import ConstantLatency
+    from happysimulator.components.network.link import NetworkLink
+    from happysimulator.parallel import ParallelSimulation, PartitionLink, SimulationPartition
+
+    warnings.simplefilter("ignore")
+    link = lambda srv_b: NetworkLink("hop", latency=ConstantLatency(0.05), egress=srv_b)           # noqa: E731
+    src, a, hop, b, sink = _two_partition_chain(link)
+    ps = ParallelSimulation([SimulationPartition(name="A", entities=[a, hop], sources=[src]),
+                             SimulationPartition(name="B", entities=[b, sink])], duration=2.0,
+                            links=[PartitionLink("A", "B", min_latency=0.05)])
+    with pytest.raises(RuntimeError, match="srv_a.driver.*not in this partition"):
+        ps.run()
+    for owner in ("A", "B"):
+        src, a, hop, b, sink = _two_partition_chain(link)
+        pa = SimulationPartition(name="A", entities=MG._server_parts(a) + ([hop] if owner == "A" else []), sources=[src])
+        pb = SimulationPartition(name="B", entities=([hop] if owner == "B" else []) + MG._server_parts(b) + [sink])
+        with pytest.raises(RuntimeError, match="violates min_latency: delay=0.000000s"):
+            ParallelSimulation([pa, pb], duration=2.0, links=[PartitionLink("A", "B", min_latency=0.05)]).run()
+    src, a, hop, b, sink = _two_partition_chain(lambda srv_b: None)
+    with pytest.raises(AttributeError, match="no attribute 'sample'"):
+        ParallelSimulation([SimulationPartition(name="A", entities=MG._server_parts(a), sources=[src]),
+                            SimulationPartition(name="B", entities=MG._server_parts(b) + [sink])], duration=2.0,
+                           links=[PartitionLink("A", "B", min_latency=0.05, latency=ConstantLatency(0.05))]).run()
