@@ -803,7 +803,7 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_backends(LbBe P, int B, int S
                                                            int tb, int64_t *__restrict__ adm, int64_t *__restrict__ sink_t,
                                                            int64_t *__restrict__ sink_created, int64_t *__restrict__ sink_S,
                                                            const double *__restrict__ svdraw, LbTotals *tot, int flags,
-                                                           LbLayout LY, int lanes) {
+                                                           LbLayout LY, int lanes, const uint8_t *__restrict__ only) {
     __shared__ uint8_t qmem[kLbQCap][kLbBlock];
     __shared__ uint8_t qdep[kLbQCap][kLbBlock];          // lineage of the in-group FIFO's entries
     __shared__ int64_t qrc[kLbQCap][kLbBlock];
@@ -812,7 +812,8 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_backends(LbBe P, int B, int S
     // `lanes` backends per wavefront (lb_lanes()): one backend per lane would leave half the SIMDs without a wavefront at the
     // configs[4] size, and a lone wavefront per SIMD waits out every dependent instruction
     const int b = ((blockIdx.x * kLbBlock + tid) >> 6) * lanes + (tid & 63);
-    const bool live = (tid & 63) < lanes && b < B;
+    // `only` != nullptr: the backends hs_lbk_scan handed back (bounded queues, a zero-nanosecond service), nobody else
+    const bool live = (tid & 63) < lanes && b < B && (only == nullptr || only[b] != 0);
     LbCand c = lb_cand_none(S + (live ? b : 0));
     LbBackend<C> X;
 #pragma unroll
@@ -884,6 +885,202 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_backends(LbBe P, int B, int S
     if (live && X.last_time != INT64_MIN) atomicMax(&tot->last_time, (long long)X.last_time);
     if (live && X.qoverflow) atomicOr(&tot->qoverflow, 1);
 }
+
+// ---------------------------------------------------------------------------------------------
+// 3b. One-worker unbounded FIFO backends as a SEGMENTED (max, +) SCAN (round 4): one WAVEFRONT per backend over its dense
+//     segment of the sorted arrival list, two requests per lane, 128 per step.
+//
+// run_request_order above is a serial recursion per backend lane -- D_k = max(a_k, D_{k-1}) + dur_k -- on 512 wavefronts (half the
+// SIMDs idle, ~1 us per request: 354 us at the configs[4] size, behind a 108 us transpose into the [k][backend] layout it needs
+// for coalescing and a 129 us kernel that draws the service times).  But request k's step is the map x -> max(x + dur_k, a_k + dur_k),
+// such maps compose associatively (x -> max(x + p, q) then x -> max(x + p', q') is x -> max(x + p + p', max(q + p', q'))), exactly,
+// in int64 ns: the departures of a backend are a prefix scan.  Everything else the request-order loop derives is a function of
+// (a_k, a_{k-1}, S_{k-1}, D_{k-1}, S_k, D_k) -- the same formulas, evaluated by every lane for its own requests:
+//     notify_k = S_{k-1} < a_k || (S_{k-1} == a_k && a_{k-1} < a_k)         idle_k = notify_k && D_{k-1} <= a_k
+//     started_k = S_k <= T (S is monotone: the requests behind a blocked head never start)      departed_k = D_k <= T
+// and the counts are ballots.  The service draw of request k is a pure function of (seed, backend, k) and is computed right here
+// (one Philox block serves the lane's two requests).  What stays serial is the binary64 `_total_service_time` -- the reference
+// adds the service times in completion order, and fp addition does not re-associate -- so the wavefront adds the step's
+// samples one after the other (128 dependent v_add_f64 per step, issue-bound, hidden behind the other wavefronts of the SIMD).
+// Completion records go to the DENSE segment (slot = position in the sorted arrival list) with coalesced stores; a request that
+// does not complete by T leaves an invalid marker, so the Sink merge scans a dense input.  Backends this formulation does not
+// cover (bounded queue, a zero-nanosecond service among the started requests) are handed to hs_lbk_backends<1> (`redo`).
+// Bit-identical to run_request_order (tests/test_gpu_lb.py compares both against the oracle and each other, debug flag 64).
+// ---------------------------------------------------------------------------------------------
+constexpr int64_t kNegInfNs = INT64_MIN / 4;      // "-infinity" of the (max, +) maps: sums of durations stay far from overflow
+constexpr int64_t kSinkInvalid = INT64_MAX;       // sink_t marker: this slot of the dense completion log holds no record
+
+struct MaxPlus { int64_t p, q; };                 // x -> max(x + p, q)
+__device__ __forceinline__ MaxPlus mp_then(const MaxPlus &f, const MaxPlus &g) {   // first f, then g
+    const int64_t a = f.q + g.p;
+    return MaxPlus{f.p + g.p, a > g.q ? a : g.q};
+}
+
+__global__ void __launch_bounds__(kLbBlock) hs_lbk_scan(LbBe P, int B, int S, uint64_t seed, int64_t T,
+                                                       const uint64_t *__restrict__ skey, const uint64_t *__restrict__ sval,
+                                                       const int64_t *__restrict__ off, int tb, int64_t *__restrict__ sink_t,
+                                                       int64_t *__restrict__ sink_created, int64_t *__restrict__ sink_S,
+                                                       uint32_t *__restrict__ bev, int64_t *__restrict__ blast,
+                                                       uint8_t *__restrict__ redo, LbCand *__restrict__ cand_out) {
+    __shared__ LbCand wc[kLbBlock / 64];
+    const int lane = threadIdx.x & 63;
+    const int b = (int)(((size_t)blockIdx.x * kLbBlock + threadIdx.x) >> 6);
+    LbCand c = lb_cand_none(S + (b < B ? b : 0));
+    if (b < B) {
+        const int64_t o = off[b], n = off[b + 1] - o;
+        const uint64_t tmask = tb >= 64 ? ~0ull : ((1ull << tb) - 1);
+        const bool eligible = P.conc[b] == 1 && P.qcap[b] < 0;
+        const uint32_t svc_kind = P.svc_kind[b];
+        const bool sink = P.egress[b] == HS_EGRESS_SINK;
+        const double mean = P.svc_mean[b];
+        const double lambda = __ddiv_rn(1.0, mean);                        // ExponentialLatency._lambda = 1 / mean
+        const double const_s = seconds_from_ns(ns_from_seconds(mean));     // ConstantLatency
+        const uint64_t sid = stream_id(P.base[b], kStreamService);
+        int64_t carryD = kNegInfNs, carryS = INT64_MIN, carryA = INT64_MIN;
+        uint32_t n_notify = 0, n_poll = 0, n_start = 0, n_dep = 0;
+        double tsvc = 0.0;
+        bool bail = !eligible;
+        int64_t lastS = INT64_MIN, lastD = INT64_MIN;
+        bool pend = false;
+        int64_t pendD = 0, pendS = 0, pendA = 0, pendSprev = 0, pendK = 0;
+        double pend_s = 0.0;
+        for (int64_t base = 0; base < n && !bail; base += 128) {
+            const int64_t k0 = base + 2 * lane, k1 = k0 + 1;
+            const bool in0 = k0 < n, in1 = k1 < n;
+            const int64_t a0 = in0 ? (int64_t)(skey[o + k0] & tmask) : 0, a1 = in1 ? (int64_t)(skey[o + k1] & tmask) : 0;
+            double sv0 = const_s, sv1 = const_s;
+            if (svc_kind == HS_LAT_EXPONENTIAL) {   // random.expovariate(lambda) -> Duration.from_seconds -> to_seconds (server.py:246-247)
+                const uint64_t blk = (uint64_t)k0 >> 1;                      // draws k0 (even) and k0 + 1 share a block
+                const U4 q = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)sid, (uint32_t)(sid >> 32), (uint32_t)seed,
+                                           (uint32_t)(seed >> 32));
+                sv0 = seconds_from_ns(ns_from_seconds(__ddiv_rn(exp1_from_uniform(res53(q.x, q.y)), lambda)));
+                sv1 = seconds_from_ns(ns_from_seconds(__ddiv_rn(exp1_from_uniform(res53(q.z, q.w)), lambda)));
+            }
+            const int64_t dur0 = ns_from_seconds(sv0), dur1 = ns_from_seconds(sv1);   // `yield s`: now + int(s * 1e9) (core/event.py:499)
+            const MaxPlus m0 = in0 ? MaxPlus{dur0, a0 + dur0} : MaxPlus{0, kNegInfNs};
+            const MaxPlus m1 = in1 ? MaxPlus{dur1, a1 + dur1} : MaxPlus{0, kNegInfNs};
+            MaxPlus inc = mp_then(m0, m1);                                   // inclusive scan over the lanes' pairs
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                MaxPlus up;
+                up.p = __shfl_up(inc.p, d, 64); up.q = __shfl_up(inc.q, d, 64);
+                if (lane >= d) inc = mp_then(up, inc);
+            }
+            MaxPlus exc;                                                     // everything of this step before the lane's pair
+            exc.p = __shfl_up(inc.p, 1, 64); exc.q = __shfl_up(inc.q, 1, 64);
+            if (lane == 0) exc = MaxPlus{0, kNegInfNs};
+            const int64_t x0 = carryD + exc.p;
+            const int64_t Dp0 = x0 > exc.q ? x0 : exc.q;                     // D of request k0 - 1 (-infinity before the first)
+            const int64_t S0 = Dp0 > a0 ? Dp0 : a0, D0 = S0 + dur0;
+            const int64_t S1 = D0 > a1 ? D0 : a1, D1 = S1 + dur1;
+            int64_t Sp0 = __shfl_up(in1 ? S1 : S0, 1, 64), Ap0 = __shfl_up(in1 ? a1 : a0, 1, 64);
+            if (lane == 0) { Sp0 = carryS; Ap0 = carryA; }
+            const bool notify0 = in0 && (Sp0 < a0 || (Sp0 == a0 && Ap0 < a0));
+            const bool notify1 = in1 && (S0 < a1 || (S0 == a1 && a0 < a1));
+            const bool st0 = in0 && S0 <= T, st1 = in1 && S1 <= T;
+            const bool idle0 = notify0 && Dp0 <= a0 && st0, idle1 = notify1 && D0 <= a1 && st1;
+            const bool dp0 = st0 && D0 <= T, dp1 = st1 && D1 <= T;
+            if (__ballot((st0 && dur0 == 0) || (st1 && dur1 == 0))) { bail = true; break; }   // a zero-nanosecond service: event order
+            const uint64_t bs0 = __ballot(st0), bs1 = __ballot(st1), bd0 = __ballot(dp0), bd1 = __ballot(dp1);
+            n_notify += (uint32_t)(__popcll(__ballot(notify0)) + __popcll(__ballot(notify1)));
+            n_poll += (uint32_t)(__popcll(__ballot(idle0)) + __popcll(__ballot(idle1)));
+            n_start += (uint32_t)(__popcll(bs0) + __popcll(bs1));
+            n_dep += (uint32_t)(__popcll(bd0) + __popcll(bd1));
+            if (in0) { sink_t[o + k0] = dp0 && sink ? D0 : kSinkInvalid; if (dp0 && sink) { sink_created[o + k0] = a0; sink_S[o + k0] = S0; } }
+            if (in1) { sink_t[o + k1] = dp1 && sink ? D1 : kSinkInvalid; if (dp1 && sink) { sink_created[o + k1] = a1; sink_S[o + k1] = S1; } }
+            if (bd0) {                                                       // _total_service_time: left to right, in completion order
+                const double x0s = dp0 ? sv0 : 0.0, x1s = dp1 ? sv1 : 0.0;  // (+ 0.0 is exact: departures are a prefix)
+                const int pairs = 64 - (int)__builtin_clzll(bd0);
+                for (int j = 0; j < pairs; ++j) {
+                    tsvc = __dadd_rn(tsvc, __shfl(x0s, j, 64));
+                    tsvc = __dadd_rn(tsvc, __shfl(x1s, j, 64));
+                }
+            }
+            if (bs0) {                                                       // the last request that started so far: pending iff not departed
+                const int hl = 63 - (int)__builtin_clzll(bs0);
+                const bool second = ((bs1 >> hl) & 1ull) != 0;
+                const int64_t Sl = __shfl(second ? S1 : S0, hl, 64), Dl = __shfl(second ? D1 : D0, hl, 64);
+                lastS = Sl;
+                pend = Dl > T;
+                if (pend) {
+                    pendD = Dl; pendS = Sl; pend_s = __shfl(second ? sv1 : sv0, hl, 64); pendA = __shfl(second ? a1 : a0, hl, 64);
+                    pendSprev = __shfl(second ? S0 : Sp0, hl, 64); pendK = base + 2 * hl + (second ? 1 : 0);
+                }
+            }
+            if (bd0) {
+                const int hl = 63 - (int)__builtin_clzll(bd0);
+                const bool second = ((bd1 >> hl) & 1ull) != 0;
+                lastD = __shfl(second ? D1 : D0, hl, 64);
+            }
+            // carries: the step's last valid request
+            const int64_t left = n - base;
+            const int ll = left >= 128 ? 63 : (int)((left - 1) >> 1);
+            const bool two = left >= 128 || ((left & 1) == 0);
+            carryD = __shfl(two ? D1 : D0, ll, 64); carryS = __shfl(two ? S1 : S0, ll, 64); carryA = __shfl(two ? a1 : a0, ll, 64);
+            if (!bs0) {                                                      // S is monotone: nobody behind this step starts either
+                for (int64_t r = base + 128 + lane; r < n; r += 64) sink_t[o + r] = kSinkInvalid;
+                carryA = n > 0 ? (int64_t)(skey[o + n - 1] & tmask) : carryA;
+                break;
+            }
+        }
+        if (bail) {                                                          // hs_lbk_backends<1> runs this backend; its log starts empty
+            for (int64_t r = lane; r < n; r += 64) sink_t[o + r] = kSinkInvalid;
+            if (lane == 0) redo[b] = 1;
+        } else if (lane == 0) {
+            redo[b] = 0;
+            P.accepted[b] = n; P.dropped[b] = 0; P.completed[b] = n_dep; P.rejected[b] = 0;
+            P.received[b] = sink ? n_dep : 0; P.depth[b] = n - (int64_t)n_start; P.active[b] = pend ? 1 : 0;
+            P.total_service[b] = tsvc;
+            bev[b] = n_notify; bev[(size_t)B + b] = n_poll; bev[(size_t)2 * B + b] = n_start;
+            int64_t lt = n > 0 ? carryA : INT64_MIN;                         // the last arrival (arrivals are sorted), last start, last departure
+            lt = lastS > lt ? lastS : lt; lt = lastD > lt ? lastD : lt;
+            blast[b] = lt;
+            if (pend) {          // the one pending departure: this backend's candidate for the event beyond end_time, with its lineage
+                c.t = pendD; c.t_created = pendS; c.svc_s = pend_s; c.valid = 1;
+                if (pendS == pendA) {          // started on arrival: SourceEvent -> Request@LoadBalancer -> Request@Server -> QUEUE_NOTIFY ->
+                    const uint64_t v = sval[o + pendK];   // QUEUE_POLL -> QUEUE_DELIVER -> payload -> continuation, below the tick's chain root
+                    c.depth = (int)(v >> 56) + 7; c.rcrt = (int64_t)(v & kCrtMask);
+                } else { c.depth = 4; c.rcrt = pendSprev; }   // started when the request before it left: four steps below that continuation
+            }
+        }
+    }
+    block_min_cand(c, wc, cand_out);
+}
+
+// totals of the backends hs_lbk_scan ran (the ones it handed back add theirs in hs_lbk_backends)
+__global__ void __launch_bounds__(256) hs_lb_scan_totals(LbBe P, int B, const uint32_t *__restrict__ bev, const int64_t *__restrict__ blast,
+                                                        const uint8_t *__restrict__ redo, LbTotals *tot) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    const bool live = b < B && redo[b] == 0;
+    unsigned long long v[7];
+    const unsigned long long n = live ? (unsigned long long)P.accepted[b] : 0ull, dep = live ? (unsigned long long)P.completed[b] : 0ull;
+    v[0] = n;                                                        // Request@Server
+    v[1] = live ? bev[b] : 0u;                                       // QUEUE_NOTIFY
+    v[2] = (live ? bev[(size_t)B + b] : 0u) + dep;                   // QUEUE_POLL: idle arrivals + one per completion
+    v[3] = live ? bev[(size_t)2 * B + b] : 0u;                       // QUEUE_DELIVER = Request@worker
+    v[4] = dep;                                                      // ProcessContinuation
+    v[5] = live ? (unsigned long long)P.received[b] : 0ull;          // Request@Sink
+    long long lt = live ? (long long)blast[b] : INT64_MIN;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = wave_sum<unsigned long long>(v[k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const long long d = __shfl_xor(lt, o, 64); lt = d > lt ? d : lt; }
+    if ((threadIdx.x & 63) == 0) {
+        if (v[0]) atomicAdd(&tot->ev[HS_EV_ENQUEUE], v[0]);
+        if (v[1]) atomicAdd(&tot->ev[HS_EV_NOTIFY], v[1]);
+        if (v[2]) atomicAdd(&tot->ev[HS_EV_POLL], v[2]);
+        if (v[3]) { atomicAdd(&tot->ev[HS_EV_DELIVER], v[3]); atomicAdd(&tot->ev[HS_EV_WORK], v[3]); }
+        if (v[4]) { atomicAdd(&tot->ev[HS_EV_CONTINUATION], v[4]); atomicAdd(&tot->completed, v[4]); }
+        if (v[5]) { atomicAdd(&tot->ev[HS_EV_SINK], v[5]); atomicAdd(&tot->received, v[5]); }
+        if (lt != INT64_MIN) atomicMax(&tot->last_time, lt);
+    }
+}
+// the dense completion log after hs_lbk_scan (+ hs_lbk_backends for the backends it handed back): a slot holds a record iff it
+// is not the marker
+struct SinkMark {
+    const int64_t *sink_t;
+    __device__ __forceinline__ bool operator()(int64_t i) const { return sink_t[i] != kSinkInvalid; }
+};
 
 // ---------------------------------------------------------------------------------------------
 // 4. Shared Sink: slot i of the dense completion log is valid iff it lies in the used part of its backend's segment
@@ -1061,13 +1258,14 @@ __global__ void hs_lb_probe_sample(LbProbes Q, LbBe PB, int B, int tb, const uin
 }
 
 __global__ void __launch_bounds__(kLbBlock) hs_lb_finalize(LbSrc PS, LbBe PB, int S, int B, int64_t start_ns, LbTotals *tot,
-                                                          LbProbes Q, int nbs, int nbb) {
+                                                          LbProbes Q, int nbs, int nbb, const LbCand *__restrict__ scan_cand, int nsc) {
     __shared__ LbCand wc[kLbBlock / 64];
     const int tid = threadIdx.x;
     LbCand best = lb_cand_none(0);
-    // (nbs, nbb: the workgroups of hs_lbk_sources / hs_lbk_backends -- one candidate each)
-    for (int i = tid; i < nbs + nbb + Q.n; i += kLbBlock) {
-        const LbCand c = i < nbs ? PS.cand[i] : i < nbs + nbb ? PB.cand[i - nbs] : Q.cand[i - nbs - nbb];
+    // (nbs, nbb, nsc: the workgroups of hs_lbk_sources / hs_lbk_backends / hs_lbk_scan -- one candidate each)
+    for (int i = tid; i < nbs + nbb + Q.n + nsc; i += kLbBlock) {
+        const LbCand c = i < nbs ? PS.cand[i] : i < nbs + nbb ? PB.cand[i - nbs] : i < nbs + nbb + Q.n ? Q.cand[i - nbs - nbb]
+                                                                                 : scan_cand[i - nbs - nbb - Q.n];
         if (cand_before(c, best)) best = c;
     }
 #pragma unroll
@@ -1239,6 +1437,8 @@ struct hs_lb {
     int64_t n_layout = 0;                             // max(n_slots, rows * B): slots of the completion logs / draw grid
     int64_t *n_merge = nullptr;                       // device: slots the Sink merge scans
     double *svdraw = nullptr;                         // [n_slots] service sample per Request slot (single-worker FIFO backends)
+    // hs_lbk_scan (round 4): per-backend event counts [3][B], last event time [B], "run me in event order" [B], one candidate per workgroup
+    uint32_t *bev = nullptr; int64_t *blast = nullptr; uint8_t *redo = nullptr; LbCand *scan_cand = nullptr;
     bool any_simple = false;
     bool any_src_profile = false;                      // some Source has a time-varying profile (hs_lbk_sources<true>)
     // ... their tick tables (hs_tables.hpp), built once on the first run
@@ -1401,14 +1601,17 @@ int lb_lanes(const hs_lb *h, int n) {
 }
 
 template <int C>
-void launch_backends(hs_lb *h, int64_t end_ns) {
+void launch_backends(hs_lb *h, int64_t end_ns, int flags, const uint8_t *only = nullptr) {
     const int B = h->cfg.n_backends;
     const int lanes = lb_lanes(h, B);
     const int per_block = lanes * (kLbBlock / 64);
     hipLaunchKernelGGL(hs_lbk_backends<C>, dim3((B + per_block - 1) / per_block), dim3(kLbBlock), 0, h->stream, h->PB, B,
                        h->cfg.n_sources, h->cfg.seed, h->cfg.start_ns, end_ns, h->skey, h->sval, h->off, h->tb, h->adm,
-                       h->sink_t, h->sink_created, h->sink_S, h->svdraw, h->tot, h->flags, h->LY, lanes);
+                       h->sink_t, h->sink_created, h->sink_S, h->svdraw, h->tot, flags, h->LY, lanes, only);
 }
+// Every backend has one worker and no debug flag asks for a particular legacy path: the backends run as segmented (max, +) scans over
+// the dense sorted arrival list (hs_lbk_scan), no [k][backend] layout, no separate service draws; debug flag 64 keeps round 3's pipeline.
+bool scan_path(const hs_lb *h) { return h->C == 1 && (h->flags & (1 | 2 | 4 | 64)) == 0; }
 
 int run_async(hs_lb *h, int64_t end_ns) {
     const int S = h->cfg.n_sources, B = h->cfg.n_backends;
@@ -1449,22 +1652,34 @@ int run_async(hs_lb *h, int64_t end_ns) {
                            h->sval, fk, fv, h->n_arr, h->tb, h->g_arr, B, h->off);
         h->skey = fk; h->sval = fv;
     }
-    // layout of the backend streams for this run: [k][backend] when the busiest backend fits the allocated rows
-    hipLaunchKernelGGL(hs_lb_maxcount, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->off, B, h->tot);
-    hipLaunchKernelGGL(hs_lb_layout, dim3(1), dim3(1), 0, h->stream, h->tot, h->LY, B, h->n_arr, h->n_merge,
-                       (h->flags & 4) ? 1 : 0);
-    if (h->LY.rows > 0 && (h->flags & 4) == 0)
-        hipLaunchKernelGGL(hs_lb_transpose, dim3((B + 63) / 64), dim3(256), 0, h->stream, h->skey, h->off, B, h->LY, h->tot);
-    if (h->C == 1 && h->any_simple && (h->flags & 3) == 0)
-        hipLaunchKernelGGL(hs_lb_service_draws, dim3((unsigned)((h->n_layout + 255) / 256)), dim3(256), 0, h->stream, h->skey,
-                           h->n_arr, h->off, h->tb, h->PB, h->cfg.seed, h->svdraw, h->LY, B, h->tot);
-    h->launches += 4;
-    switch (h->C) {
-        case 1: launch_backends<1>(h, end_ns); break;
-        case 2: launch_backends<2>(h, end_ns); break;
-        case 4: launch_backends<4>(h, end_ns); break;
-        case 8: launch_backends<8>(h, end_ns); break;
-        default: launch_backends<16>(h, end_ns); break;
+    const bool scan = scan_path(h);
+    const int n_scan_blocks = (B + kLbBlock / 64 - 1) / (kLbBlock / 64);
+    if (scan) {
+        // one wavefront per backend over its dense segment: service draws, the (max, +) scan, counts, completion records (section 3b);
+        // what it hands back (bounded queues, a zero-nanosecond service) runs in event order on the dense layout
+        hipLaunchKernelGGL(hs_lbk_scan, dim3((unsigned)n_scan_blocks), dim3(kLbBlock), 0, h->stream, h->PB, B, S, h->cfg.seed, end_ns, h->skey,
+                           h->sval, h->off, h->tb, h->sink_t, h->sink_created, h->sink_S, h->bev, h->blast, h->redo, h->scan_cand);
+        hipLaunchKernelGGL(hs_lb_scan_totals, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->PB, B, h->bev, h->blast, h->redo, h->tot);
+        launch_backends<1>(h, end_ns, h->flags | 2, h->redo);
+        h->launches += 3;
+    } else {
+        // layout of the backend streams for this run: [k][backend] when the busiest backend fits the allocated rows
+        hipLaunchKernelGGL(hs_lb_maxcount, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->off, B, h->tot);
+        hipLaunchKernelGGL(hs_lb_layout, dim3(1), dim3(1), 0, h->stream, h->tot, h->LY, B, h->n_arr, h->n_merge,
+                           (h->flags & 4) ? 1 : 0);
+        if (h->LY.rows > 0 && (h->flags & 4) == 0)
+            hipLaunchKernelGGL(hs_lb_transpose, dim3((B + 63) / 64), dim3(256), 0, h->stream, h->skey, h->off, B, h->LY, h->tot);
+        if (h->C == 1 && h->any_simple && (h->flags & 3) == 0)
+            hipLaunchKernelGGL(hs_lb_service_draws, dim3((unsigned)((h->n_layout + 255) / 256)), dim3(256), 0, h->stream, h->skey,
+                               h->n_arr, h->off, h->tb, h->PB, h->cfg.seed, h->svdraw, h->LY, B, h->tot);
+        h->launches += 4;
+        switch (h->C) {
+            case 1: launch_backends<1>(h, end_ns, h->flags); break;
+            case 2: launch_backends<2>(h, end_ns, h->flags); break;
+            case 4: launch_backends<4>(h, end_ns, h->flags); break;
+            case 8: launch_backends<8>(h, end_ns, h->flags); break;
+            default: launch_backends<16>(h, end_ns, h->flags); break;
+        }
     }
     if (h->Q.n > 0) {     // probes: the ticks of this run and the pending one beyond end; then the samples of everything but a
                           // shared Sink, from the backends' logs (the Sink merge below reuses the buffer of the sorted arrivals)
@@ -1478,7 +1693,13 @@ int run_async(hs_lb *h, int64_t end_ns) {
     if (h->cfg.shared_sink) {
         // completions by completion ns; the validity functor reads the sorted arrival keys (which slot belongs to which
         // backend), so pass 0 must not overwrite them
-        if (h->slot_bits)
+        if (scan && h->slot_bits)        // the dense completion log of hs_lbk_scan: a slot holds a record iff it is not the marker
+            radix_sort_async(h, (const uint64_t *)h->sink_t, (const uint64_t *)nullptr, h->n_arr, h->n_done, h->tb, SinkMark{h->sink_t},
+                             PackCreatedSlot{h->sink_created, h->slot_bits}, &h->mkey, &h->mslot, h->skey, h->g_sink, h->n_slots);
+        else if (scan)
+            radix_sort_async(h, (const uint64_t *)h->sink_t, (const uint64_t *)nullptr, h->n_arr, h->n_done, h->tb, SinkMark{h->sink_t},
+                             SlotVal{}, &h->mkey, &h->mslot, h->skey, h->g_sink, h->n_slots);
+        else if (h->slot_bits)
             radix_sort_async(h, (const uint64_t *)h->sink_t, (const uint64_t *)nullptr, h->n_merge, h->n_done, h->tb,
                              SinkValid{h->skey, h->off, h->PB.received, h->tb, h->tot, B},
                              PackCreatedSlot{h->sink_created, h->slot_bits}, &h->mkey, &h->mslot, h->skey, h->g_sink, h->n_layout);
@@ -1499,7 +1720,7 @@ int run_async(hs_lb *h, int64_t end_ns) {
     {
         const int sl = lb_lanes(h, S) * (kLbBlock / 64), bl = lb_lanes(h, B) * (kLbBlock / 64);
         hipLaunchKernelGGL(hs_lb_finalize, dim3(1), dim3(kLbBlock), 0, h->stream, h->PS, h->PB, S, B, h->cfg.start_ns, h->tot, h->Q,
-                           (S + sl - 1) / sl, (B + bl - 1) / bl);
+                           (S + sl - 1) / sl, (B + bl - 1) / bl, h->scan_cand, scan ? n_scan_blocks : 0);
     }
     h->launches += 6;
     LB_HIP(h, hipGetLastError());
@@ -1762,6 +1983,8 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
         TRY(lalloc(h, &h->LY.tsv, (size_t)h->LY.rows * (size_t)B));
     }
     TRY(lalloc(h, &h->n_merge, 1));
+    TRY(lalloc(h, &h->bev, (size_t)3 * (size_t)B)); TRY(lalloc(h, &h->blast, (size_t)B)); TRY(lalloc(h, &h->redo, (size_t)B));
+    TRY(lalloc(h, &h->scan_cand, (size_t)(B + kLbBlock / 64 - 1) / (kLbBlock / 64)));
     if (cfg->shared_sink) { TRY(lalloc(h, &h->out_t, NS)); TRY(lalloc(h, &h->out_created, NS)); }
     for (int j = 0; j < B; ++j)
         if ((be->concurrency ? be->concurrency[j] : 1) == 1 && (be->queue_cap ? be->queue_cap[j] : -1) < 0) h->any_simple = true;
@@ -1802,13 +2025,33 @@ int hs_lb_run(hs_lb *h, int64_t end_ns) {
 
 int hs_lb_bench_runs(hs_lb *h, int64_t end_ns, int32_t repeats, float *run_ms_out, float *sort_ms_out) {
     if (!h || repeats <= 0) return lfail(h, HS_E_INVALID, "hs_lb_bench_runs: bad argument");
-    for (int r = 0; r < repeats; ++r) {
-        int rc = hs_lb_run(h, end_ns);
-        if (rc) return rc;
-        if (run_ms_out) run_ms_out[r] = (float)h->last_run_ms;
-        if (sort_ms_out) sort_ms_out[r] = (float)h->last_sort_ms;
+    if (end_ns < h->cfg.start_ns || end_ns > h->cfg.horizon_ns) return lfail(h, HS_E_INVALID, "end_ns outside [start_ns, horizon_ns]");
+    LB_HIP(h, hipSetDevice(h->cfg.device));
+    // `repeats` complete runs enqueued back to back (every count lives in device memory: a run needs no host synchronisation), each
+    // bracketed by its own HIP events on the engine's stream; ONE synchronisation at the end, as hs_engine_bench_runs does
+    std::vector<hipEvent_t> ev((size_t)repeats * 6);
+    for (auto &e : ev) LB_HIP(h, hipEventCreate(&e));
+    hipEvent_t keep[4] = {h->evs0, h->evs1, h->evs2, h->evs3};
+    int rc = HS_OK;
+    for (int r = 0; r < repeats && rc == HS_OK; ++r) {
+        hipEvent_t *e = &ev[(size_t)r * 6];
+        h->evs0 = e[2]; h->evs1 = e[3]; h->evs2 = e[4]; h->evs3 = e[5];
+        if (hipEventRecord(e[0], h->stream) != hipSuccess) rc = lfail(h, HS_E_HIP, "hipEventRecord failed");
+        if (rc == HS_OK) rc = run_async(h, end_ns);
+        if (rc == HS_OK && hipEventRecord(e[1], h->stream) != hipSuccess) rc = lfail(h, HS_E_HIP, "hipEventRecord failed");
     }
-    return HS_OK;
+    h->evs0 = keep[0]; h->evs1 = keep[1]; h->evs2 = keep[2]; h->evs3 = keep[3];
+    if (rc == HS_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = lfail(h, HS_E_HIP, "hipStreamSynchronize failed");
+    for (int r = 0; r < repeats && rc == HS_OK; ++r) {
+        hipEvent_t *e = &ev[(size_t)r * 6];
+        float ms = 0, s1 = 0, s2 = 0;
+        hipEventElapsedTime(&ms, e[0], e[1]); hipEventElapsedTime(&s1, e[2], e[3]); hipEventElapsedTime(&s2, e[4], e[5]);
+        h->last_run_ms = ms; h->last_sort_ms = s1 + s2;
+        if (run_ms_out) run_ms_out[r] = ms;
+        if (sort_ms_out) sort_ms_out[r] = s1 + s2;
+    }
+    for (auto &e : ev) hipEventDestroy(e);
+    return rc == HS_OK ? check_flags(h) : rc;
 }
 
 int hs_lb_get_summary(hs_lb *h, hs_summary *out) {

@@ -34,14 +34,15 @@ def case_spec(case, n, end_s):
     if case == "mixed":
         prof = [None] * n
         for i in range(5, n, 31):
-            prof[i] = ["ramp", 2.0 + (i % 5), 3.0 + (i % 4), 6.0 + (i % 17)]
+            prof[i] = ["ramp", end_s * (0.5 + 0.1 * (i % 5)), 3.0 + (i % 4), 6.0 + (i % 17)]
         more = [None if prof[i] is not None else ([["constant", 5.0]] if i % 11 == 3 else
                                                    [["poisson", 2.0], ["constant", 4.0]] if i % 29 == 7 else None) for i in range(n)]
         return dict(name="dist_mixed", topology="ring", n=n, ext_rate=[0.0 if i % 13 == 12 else 4.0 for i in range(n)], mean=0.1,
                     lat_min=0.001, jitter_mean=0.006, end_s=end_s, seed=17, profile=prof, more_sources=more,
                     sources_order="extras_first",
-                    probes=[["depth", 0.25] if i % 17 == 0 else ["requests_completed", 0.4] if i % 23 == 5 else None for i in range(n)],
-                    schedule=[[i, 0.25 + 0.37 * k + 1e-9 * (i % 7)] for i in range(3, n, 19) for k in range(3)] + [[n - 1, 1.5], [n - 1, 1.5]])
+                    probes=[["depth", end_s / 12.0] if i % 17 == 0 else ["requests_completed", end_s / 7.5] if i % 23 == 5 else None for i in range(n)],
+                    schedule=[[i, end_s * (0.08 + 0.12 * k) + 1e-9 * (i % 7)] for i in range(3, n, 19) for k in range(3)] +
+                             [[n - 1, 0.5 * end_s], [n - 1, 0.5 * end_s]])
     if case == "lockstep":
         # stations 1 (first shard) and n - 2 (last shard) tick in lock-step; "extras_first" lists station n - 2's Source first
         more = [[["constant", 4.0]] if i in (1, n - 2) else None for i in range(n)]
@@ -57,6 +58,9 @@ def main():
     ap.add_argument("end_s", type=float)
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--same-device", action="store_true")
+    ap.add_argument("--windows-end-s", type=float, default=None,
+                    help="horizon of the WINDOW protocol's run (default END_S): one exchange per smallest link latency, and with several "
+                         "processes on one GPU every exchange costs process switches on the device")
     args = ap.parse_args()
 
     import torch
@@ -74,11 +78,13 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     else:
         dist.init_process_group(args.backend, rank=rank, world_size=world)
-    spec = case_spec(args.case, args.n, args.end_s)
-    n = spec["n"]
+    specs = {True: case_spec(args.case, args.n, args.end_s),
+             False: case_spec(args.case, args.n, args.windows_end_s if args.windows_end_s is not None else args.end_s)}
+    n = specs[True]["n"]
     out = {"backend": args.backend, "same_device": bool(args.same_device), "case": args.case}
     mine = {}
     for rounds in (True, False):
+        spec = specs[rounds]
         st, net, cap, p = H.ring_arrays(spec)
         with ShardedNetwork.on_gpu(st, net, DistComm(), horizon_ns=p["end_ns"], seed=spec["seed"], device=local,
                                    log_capacity=cap, rounds=rounds) as sn:
@@ -108,22 +114,24 @@ def main():
     gathered = [None] * world
     dist.all_gather_object(gathered, {k: v[1] for k, v in mine.items()})
     if rank == 0:
-        eng, p = H.ring_engine_for_spec(spec)            # the same network on one engine
-        with eng:
-            eng.run_until(p["end_ns"])
-            s1 = eng.summary()
-            stats = eng.lp_stats()
-            counts, t, cr = eng.read_sinks()
-            rows = np.stack([stats[k].astype(np.int64) for k in STAT_KEYS] + [counts, eng.net_stats()["routed"]])
-            want = np.concatenate([rows.ravel(), [int(t.sum() % (1 << 61)) , int(cr.sum() % (1 << 61))]])
-            want_probes = {}
-            for i, prs in enumerate(p["probe_list"]):
-                for j in range(len(prs)):
-                    pt, pv = eng.read_probe(i, j)
-                    want_probes[f"{i}.{j}"] = [int(pt.sum()), int(pv.sum()), len(pt)]
-            out["single"] = dict(events=int(s1.events_processed), final=int(s1.final_time_ns),
-                                 by_kind=[int(x) for x in s1.events_by_kind], generated=[int(x) for x in stats["generated"]][:64])
         for name in ("rounds", "windows"):
+            spec = specs[name == "rounds"]
+            eng, p = H.ring_engine_for_spec(spec)            # the same network on one engine
+            with eng:
+                eng.run_until(p["end_ns"])
+                s1 = eng.summary()
+                stats = eng.lp_stats()
+                counts, t, cr = eng.read_sinks()
+                rows = np.stack([stats[k].astype(np.int64) for k in STAT_KEYS] + [counts, eng.net_stats()["routed"]])
+                want = np.concatenate([rows.ravel(), [int(t.sum() % (1 << 61)) , int(cr.sum() % (1 << 61))]])
+                want_probes = {}
+                for i, prs in enumerate(p["probe_list"]):
+                    for j in range(len(prs)):
+                        pt, pv = eng.read_probe(i, j)
+                        want_probes[f"{i}.{j}"] = [int(pt.sum()), int(pv.sum()), len(pt)]
+                out["single" if name == "rounds" else "single_windows"] = dict(
+                    events=int(s1.events_processed), final=int(s1.final_time_ns), by_kind=[int(x) for x in s1.events_by_kind],
+                    generated=[int(x) for x in stats["generated"]][:64])
             got = mine[name][0]
             # the sink digests are sums of per-rank sums mod 2^61: compare mod 2^61
             ok_rows = bool(np.array_equal(got[:-2], want[:-2]))

@@ -85,14 +85,22 @@ SWEEP = [
     dict(name="stop", n_sources=20, n_backends=50, rate=25.0, mean=0.08, vnodes=150, n_clients=4096, stop_after_s=2.5,
          end_s=5.0, seed=5),
     dict(name="one_backend", n_sources=8, n_backends=1, rate=1.0, mean=0.1, vnodes=3, n_clients=10, end_s=20.0, seed=6),
+    # one worker everywhere, but every third backend has a bounded queue and every fifth a ZERO service time: the segmented-scan
+    # kernel (hs_lbk_scan) hands those back to the event-order loop, next to backends it runs itself; some backends overloaded
+    # (requests that never start before end_time), some idle, one backend with hundreds of requests per step of 128
+    dict(name="c1_scan_and_handed_back", n_sources=40, n_backends=37, rate=45.0, mean=[0.0 if j % 5 == 4 else 0.04 * (1 + j % 4) for j in range(37)],
+         svc=["const" if j % 5 == 4 or j % 7 == 3 else "exp" for j in range(37)], queue_cap=[3 if j % 3 == 1 else None for j in range(37)],
+         vnodes=9, n_clients=3000, end_s=6.0, seed=7),
+    dict(name="c1_scan_heavy_backend", n_sources=24, n_backends=3, rate=40.0, mean=[0.002, 0.004, 0.5], vnodes=5, n_clients=77,
+         end_s=8.0, seed=8),
 ]
 
 
 @pytest.mark.parametrize("spec", SWEEP, ids=[s["name"] for s in SWEEP])
-@pytest.mark.parametrize("flags", [0, 1, 2, 4, 8, 16], ids=["request_order", "general_fifo", "event_order", "dense_layout",
-                                                             "sources_draw_their_own_values", "look_back_radix_passes"])
+@pytest.mark.parametrize("flags", [0, 64, 1, 2, 4, 8, 16], ids=["segmented_scan", "request_order", "general_fifo", "event_order", "dense_layout",
+                                                                 "sources_draw_their_own_values", "look_back_radix_passes"])
 def test_lb_engine_matches_oracle(spec, flags):
-    g, p = H.oracle_lb_graph(spec)
+    g, p = H.oracle_lb_graph_ext(spec)
     r = O.run(g, p["end_ns"], seed=spec["seed"])
     eng, _ = H.lb_engine_for_spec(spec, flags=flags)
     with eng:
@@ -115,13 +123,13 @@ def _with_probes(spec):
 
 
 @pytest.mark.parametrize("spec", SWEEP, ids=[s["name"] for s in SWEEP])
-@pytest.mark.parametrize("flags", [0, 1, 2, 4], ids=["request_order", "general_fifo", "event_order", "dense_layout"])
+@pytest.mark.parametrize("flags", [0, 64, 1, 2, 4], ids=["segmented_scan", "request_order", "general_fifo", "event_order", "dense_layout"])
 def test_lb_probes_match_oracle(spec, flags):
     """Probe.on(<backend Server> | <Sink>, metric, interval) on load-balancer graphs: every sample, the probes' two event kinds
     and the election of the event beyond end_time (a pending probe tick takes part) against the oracle, on every backend code
     path; the live-reference goldens lb_probes*.npz pin the same against the reference itself."""
     spec = _with_probes(spec)
-    g, p = H.oracle_lb_graph(spec)
+    g, p = H.oracle_lb_graph_ext(spec)
     r = O.run(g, p["end_ns"], seed=spec["seed"])
     eng, _ = H.lb_engine_for_spec(spec, flags=flags)
     with eng:
@@ -236,11 +244,12 @@ TIES = [
 ]
 
 
+@pytest.mark.parametrize("flags", [0, 64], ids=["segmented_scan", "request_order"])
 @pytest.mark.parametrize("spec", TIES, ids=[s["name"] for s in TIES])
-def test_lb_engine_tie_storms_match_oracle(spec):
+def test_lb_engine_tie_storms_match_oracle(spec, flags):
     g, p = H.oracle_lb_graph_ext(spec)
     r = O.run(g, p["end_ns"], seed=spec["seed"])
-    eng, _ = H.lb_engine_for_spec(spec)
+    eng, _ = H.lb_engine_for_spec(spec, flags=flags)
     with eng:
         eng.run(p["end_ns"])
         # everything exact (counts, statistics, every record); only the ORDER of same-ns Sink records of different backends
