@@ -202,17 +202,32 @@ def build(force: bool = False, verbose: bool = False, defines: tuple = (), lib_p
     jobs += [(_INST_TU, [f"-DHS_INST={k}"], os.path.join(obj_dir, f"hs_inst_{k}.o")) for k in range(_INST_GROUPS)]
     jobs += [(_STAMP_TU, [f'-DHS_SOURCES_HASH="{want}"'], os.path.join(obj_dir, "hs_stamp.o"))]
 
+    def inputs_hash(tu, defs):
+        """What one object is built from: its translation unit, every header, the flags and its own defines (another .hip file
+        changing does not touch it)."""
+        import hashlib
+        hh = hashlib.sha256()
+        for src in sources():
+            if src.endswith(".hip") and os.path.basename(src) != tu:
+                continue
+            hh.update(os.path.basename(src).encode())
+            with open(src, "rb") as f:
+                hh.update(f.read())
+        hh.update(" ".join(flags + list(defs)).encode())
+        return hh.hexdigest()
+
     def compile_one(job):
         tu, defs, obj = job
         tag = obj + ".stamp"
-        if not force and os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == want:
+        mine = inputs_hash(tu, defs)
+        if not force and os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == mine:
             return obj
         cmd = [hipcc, *flags, *defs, "-c", os.path.join(CSRC, tu), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         with open(tag, "w") as f:
-            f.write(want)
+            f.write(mine)
         return obj
 
     n_jobs = int(os.environ.get("HS_BUILD_JOBS", "0")) or (os.cpu_count() or 4)

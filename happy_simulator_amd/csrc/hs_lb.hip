@@ -333,37 +333,54 @@ struct SlotVal { __device__ __forceinline__ uint64_t operator()(int64_t i) const
 // input order.  Such runs are short (the host picks g so that a bucket holds <= 1 element on average); every element
 // finds its place inside its run by counting the run's smaller (key, position) pairs -- stable -- and the list is
 // written out in full-key order to the other ping-pong buffer.  g <= tb, so a run never spans two backends.
-__global__ void hs_lb_segments(const uint64_t *__restrict__ skey, const uint64_t *__restrict__ sval,
-                               uint64_t *__restrict__ fkey, uint64_t *__restrict__ fval, const int64_t *n_ptr, int tb,
-                               int g, int B, int64_t *__restrict__ off) {
+// (round 4: a workgroup stages its 1 024 keys + a halo in LDS, so the walk along a run reads LDS instead of one dependent global
+//  load per step: 163 us -> see profiles/; a run that reaches past the halo continues in global memory)
+constexpr int kSegTile = 1024, kSegHalo = 32;
+__global__ void __launch_bounds__(256) hs_lb_segments(const uint64_t *__restrict__ skey, const uint64_t *__restrict__ sval,
+                                                     uint64_t *__restrict__ fkey, uint64_t *__restrict__ fval, const int64_t *n_ptr, int tb,
+                                                     int g, int B, int64_t *__restrict__ off) {
+    __shared__ uint64_t lk[kSegTile + 2 * kSegHalo];
     const int64_t n = *n_ptr;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n) return;
-    const uint64_t k_prev = i == 0 ? 0ull : skey[i - 1];
-    const uint64_t k_here = i == n ? 0ull : skey[i];
-    const int64_t b_prev = i == 0 ? -1 : (int64_t)(k_prev >> tb);
-    const int64_t b_here = i == n ? (int64_t)B : (int64_t)(k_here >> tb);
-    for (int64_t b = b_prev + 1; b <= b_here; ++b) off[b] = i;
-    if (i == n) return;
-    int64_t pos = i;
-    if (g > 0) {
-        const uint64_t hi = k_here >> g;
-        int64_t lo = i, rank = 0;
-        while (lo > 0) {                                     // elements of the run before this one
-            const uint64_t k = skey[lo - 1];
-            if ((k >> g) != hi) break;
-            rank += (k <= k_here) ? 1 : 0;                   // equal keys keep their input order
-            --lo;
-        }
-        for (int64_t j = i + 1; j < n; ++j) {                // ... and after it
-            const uint64_t k = skey[j];
-            if ((k >> g) != hi) break;
-            rank += (k < k_here) ? 1 : 0;
-        }
-        pos = lo + rank;
+    const int64_t base = (int64_t)blockIdx.x * kSegTile;
+    if (base > n) return;
+    const int tid = threadIdx.x;
+    for (int q = tid; q < kSegTile + 2 * kSegHalo; q += 256) {
+        const int64_t i = base - kSegHalo + q;
+        lk[q] = (i >= 0 && i < n) ? skey[i] : 0ull;
     }
-    fkey[pos] = k_here;
-    fval[pos] = sval[i];
+    __syncthreads();
+    const int64_t lds_lo = base - kSegHalo, lds_hi = base + kSegTile + kSegHalo;      // global indices [lds_lo, lds_hi) are in LDS
+    auto key_at = [&](int64_t i) -> uint64_t { return (i >= lds_lo && i < lds_hi) ? lk[i - lds_lo] : skey[i]; };
+#pragma unroll
+    for (int r = 0; r < kSegTile / 256; ++r) {
+        const int64_t i = base + tid + 256 * r;
+        if (i > n) continue;
+        const uint64_t k_prev = i == 0 ? 0ull : key_at(i - 1);
+        const uint64_t k_here = i == n ? 0ull : key_at(i);
+        const int64_t b_prev = i == 0 ? -1 : (int64_t)(k_prev >> tb);
+        const int64_t b_here = i == n ? (int64_t)B : (int64_t)(k_here >> tb);
+        for (int64_t b = b_prev + 1; b <= b_here; ++b) off[b] = i;
+        if (i == n) continue;
+        int64_t pos = i;
+        if (g > 0) {
+            const uint64_t hi = k_here >> g;
+            int64_t lo = i, rank = 0;
+            while (lo > 0) {                                     // elements of the run before this one
+                const uint64_t k = key_at(lo - 1);
+                if ((k >> g) != hi) break;
+                rank += (k <= k_here) ? 1 : 0;                   // equal keys keep their input order
+                --lo;
+            }
+            for (int64_t j = i + 1; j < n; ++j) {                // ... and after it
+                const uint64_t k = key_at(j);
+                if ((k >> g) != hi) break;
+                rank += (k < k_here) ? 1 : 0;
+            }
+            pos = lo + rank;
+        }
+        fkey[pos] = k_here;
+        fval[pos] = sval[i];
+    }
 }
 
 __global__ void hs_lb_maxcount(const int64_t *__restrict__ off, int B, LbTotals *tot) {
@@ -505,6 +522,7 @@ struct LbBackend {
     Stream svc;
     uint32_t ev[8];
     int64_t *adm, *sink_t, *sink_created, *sink_S;   // this backend's segment of the dense logs
+    int pack_bits; int64_t slot0;                     // pack_bits > 0: sink_created holds (created_at << pack_bits) | slot (hs_lbk_scan)
     int qoverflow;
     uint8_t (*qmem)[kLbBlock];
     uint8_t (*qdep)[kLbBlock];
@@ -593,7 +611,8 @@ struct LbBackend {
         total_service = __dadd_rn(total_service, s);
         if (egress == HS_EGRESS_SINK) {
             ev[HS_EV_SINK]++;
-            sink_t[received * ss] = t; sink_created[received * ss] = cr; sink_S[received * ss] = st;
+            sink_t[received * ss] = t; sink_S[received * ss] = st;
+            sink_created[received * ss] = pack_bits ? (int64_t)(((uint64_t)cr << pack_bits) | (uint64_t)(slot0 + received * ss)) : cr;
             received++;
         }
         return active < conc;
@@ -803,7 +822,7 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_backends(LbBe P, int B, int S
                                                            int tb, int64_t *__restrict__ adm, int64_t *__restrict__ sink_t,
                                                            int64_t *__restrict__ sink_created, int64_t *__restrict__ sink_S,
                                                            const double *__restrict__ svdraw, LbTotals *tot, int flags,
-                                                           LbLayout LY, int lanes, const uint8_t *__restrict__ only) {
+                                                           LbLayout LY, int lanes, const uint8_t *__restrict__ only, int pack_bits) {
     __shared__ uint8_t qmem[kLbQCap][kLbBlock];
     __shared__ uint8_t qdep[kLbQCap][kLbBlock];          // lineage of the in-group FIFO's entries
     __shared__ int64_t qrc[kLbQCap][kLbBlock];
@@ -839,6 +858,7 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_backends(LbBe P, int B, int S
         X.ss = T ? B : 1;
         const int64_t so = T ? b : o;
         X.adm = adm + o; X.sink_t = sink_t + so; X.sink_created = sink_created + so; X.sink_S = sink_S + so;
+        X.pack_bits = only != nullptr ? pack_bits : 0; X.slot0 = so;
         X.qmem = qmem; X.qdep = qdep; X.qrc = qrc; X.tid = tid; X.qh = 0; X.qn = 0;
         const bool force_general = (flags & 1) != 0;
         bool event_order = true;
@@ -916,16 +936,42 @@ __device__ __forceinline__ MaxPlus mp_then(const MaxPlus &f, const MaxPlus &g) {
     return MaxPlus{f.p + g.p, a > g.q ? a : g.q};
 }
 
-__global__ void __launch_bounds__(kLbBlock) hs_lbk_scan(LbBe P, int B, int S, uint64_t seed, int64_t T,
-                                                       const uint64_t *__restrict__ skey, const uint64_t *__restrict__ sval,
-                                                       const int64_t *__restrict__ off, int tb, int64_t *__restrict__ sink_t,
-                                                       int64_t *__restrict__ sink_created, int64_t *__restrict__ sink_S,
-                                                       uint32_t *__restrict__ bev, int64_t *__restrict__ blast,
-                                                       uint8_t *__restrict__ redo, LbCand *__restrict__ cand_out) {
+// F64: every time of the run is a whole number of nanoseconds below 2^50 (hs_lb::f64_times), so the (max, +) maps, the service
+// durations and the comparisons run on binary64 values -- exact there -- and lose the 64-bit integer pairs and the i64 <-> f64
+// conversion sequences (hs_device.hpp ns_from_seconds_d); bit-identical to the int64 instantiation.
+// the value of lane `l` (wave-uniform) as a wave-uniform value: two v_readlane into SGPRs, so that what the whole wavefront shares
+// (carries, the pending request) does not occupy vector registers
+template <typename T>
+__device__ __forceinline__ T bcast64(T v, int l) {
+    static_assert(sizeof(T) == 8, "64-bit values");
+    uint64_t u;
+    __builtin_memcpy(&u, &v, 8);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l);
+    u = ((uint64_t)hi << 32) | lo;
+    T r;
+    __builtin_memcpy(&r, &u, 8);
+    return r;
+}
+template <bool F64> struct ScanT { using T = int64_t; };
+template <> struct ScanT<true> { using T = double; };
+
+template <bool F64>
+__global__ void __launch_bounds__(kLbBlock) hs_lbk_scan(LbBe P, int B, int S, uint64_t seed, int64_t T_ns,
+                                                          const uint64_t *__restrict__ skey, const uint64_t *__restrict__ sval,
+                                                          const int64_t *__restrict__ off, int tb, int64_t *__restrict__ sink_t,
+                                                          int64_t *__restrict__ sink_created, int64_t *__restrict__ sink_S,
+                                                          uint32_t *__restrict__ bev, int64_t *__restrict__ blast,
+                                                          uint8_t *__restrict__ redo, LbCand *__restrict__ cand_out, int pack_bits) {
+    // pack_bits > 0 (one Sink shared by all backends): sink_created holds (created_at << pack_bits) | slot, the value the Sink merge
+    // carries -- its first pass then reads a ready-made (key, value) pair like every later pass
+    using TT = typename ScanT<F64>::T;
     __shared__ LbCand wc[kLbBlock / 64];
-    const int lane = threadIdx.x & 63;
+    __shared__ double ssum[kLbBlock / 64][128];                             // the step's service samples, in completion order
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int b = (int)(((size_t)blockIdx.x * kLbBlock + threadIdx.x) >> 6);
     LbCand c = lb_cand_none(S + (b < B ? b : 0));
+    const TT neg_inf = F64 ? (TT)(-__builtin_huge_val()) : (TT)kNegInfNs;
+    auto to_i64 = [](TT v) -> int64_t { if constexpr (F64) return i64_from_whole_d((double)v); else return (int64_t)v; };
     if (b < B) {
         const int64_t o = off[b], n = off[b + 1] - o;
         const uint64_t tmask = tb >= 64 ? ~0ull : ((1ull << tb) - 1);
@@ -933,93 +979,115 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_scan(LbBe P, int B, int S, ui
         const uint32_t svc_kind = P.svc_kind[b];
         const bool sink = P.egress[b] == HS_EGRESS_SINK;
         const double mean = P.svc_mean[b];
-        const double lambda = __ddiv_rn(1.0, mean);                        // ExponentialLatency._lambda = 1 / mean
+        ConstDiv by_lambda;
+        by_lambda.init(__ddiv_rn(1.0, mean));                              // ExponentialLatency._lambda = 1 / mean
         const double const_s = seconds_from_ns(ns_from_seconds(mean));     // ConstantLatency
         const uint64_t sid = stream_id(P.base[b], kStreamService);
-        int64_t carryD = kNegInfNs, carryS = INT64_MIN, carryA = INT64_MIN;
+        const TT T = (TT)T_ns;
+        TT carryD = neg_inf, carryS = neg_inf, carryA = neg_inf;
         uint32_t n_notify = 0, n_poll = 0, n_start = 0, n_dep = 0;
         double tsvc = 0.0;
         bool bail = !eligible;
-        int64_t lastS = INT64_MIN, lastD = INT64_MIN;
+        TT lastS = neg_inf, lastD = neg_inf;
         bool pend = false;
-        int64_t pendD = 0, pendS = 0, pendA = 0, pendSprev = 0, pendK = 0;
+        TT pendD = 0, pendS = 0, pendA = 0, pendSprev = 0;
+        int64_t pendK = 0;
         double pend_s = 0.0;
+        // the keys of a step are loaded while the step before it is computed
+        uint64_t nk0 = (2 * lane < n) ? skey[o + 2 * lane] : 0ull, nk1 = (2 * lane + 1 < n) ? skey[o + 2 * lane + 1] : 0ull;
         for (int64_t base = 0; base < n && !bail; base += 128) {
             const int64_t k0 = base + 2 * lane, k1 = k0 + 1;
             const bool in0 = k0 < n, in1 = k1 < n;
-            const int64_t a0 = in0 ? (int64_t)(skey[o + k0] & tmask) : 0, a1 = in1 ? (int64_t)(skey[o + k1] & tmask) : 0;
+            const uint64_t key0 = nk0, key1 = nk1;
+            nk0 = (k0 + 128 < n) ? skey[o + k0 + 128] : 0ull;
+            nk1 = (k1 + 128 < n) ? skey[o + k1 + 128] : 0ull;
+            TT a0, a1;
+            if constexpr (F64) {       // whole ns < 2^52: the bits under an exponent of 2^52, minus 2^52
+                a0 = __longlong_as_double((long long)((key0 & tmask) | 0x4330000000000000ull)) - 4503599627370496.0;
+                a1 = __longlong_as_double((long long)((key1 & tmask) | 0x4330000000000000ull)) - 4503599627370496.0;
+            } else { a0 = (TT)(key0 & tmask); a1 = (TT)(key1 & tmask); }
             double sv0 = const_s, sv1 = const_s;
             if (svc_kind == HS_LAT_EXPONENTIAL) {   // random.expovariate(lambda) -> Duration.from_seconds -> to_seconds (server.py:246-247)
                 const uint64_t blk = (uint64_t)k0 >> 1;                      // draws k0 (even) and k0 + 1 share a block
                 const U4 q = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)sid, (uint32_t)(sid >> 32), (uint32_t)seed,
                                            (uint32_t)(seed >> 32));
-                sv0 = seconds_from_ns(ns_from_seconds(__ddiv_rn(exp1_from_uniform(res53(q.x, q.y)), lambda)));
-                sv1 = seconds_from_ns(ns_from_seconds(__ddiv_rn(exp1_from_uniform(res53(q.z, q.w)), lambda)));
+                const double e0 = by_lambda.div(exp1_from_uniform(res53(q.x, q.y))), e1 = by_lambda.div(exp1_from_uniform(res53(q.z, q.w)));
+                if constexpr (F64) { sv0 = seconds_from_ns_d(ns_from_seconds_d(e0)); sv1 = seconds_from_ns_d(ns_from_seconds_d(e1)); }
+                else { sv0 = seconds_from_ns(ns_from_seconds(e0)); sv1 = seconds_from_ns(ns_from_seconds(e1)); }
             }
-            const int64_t dur0 = ns_from_seconds(sv0), dur1 = ns_from_seconds(sv1);   // `yield s`: now + int(s * 1e9) (core/event.py:499)
-            const MaxPlus m0 = in0 ? MaxPlus{dur0, a0 + dur0} : MaxPlus{0, kNegInfNs};
-            const MaxPlus m1 = in1 ? MaxPlus{dur1, a1 + dur1} : MaxPlus{0, kNegInfNs};
-            MaxPlus inc = mp_then(m0, m1);                                   // inclusive scan over the lanes' pairs
+            TT dur0, dur1;                                                   // `yield s`: now + int(s * 1e9) (core/event.py:499)
+            if constexpr (F64) { dur0 = ns_from_seconds_d(sv0); dur1 = ns_from_seconds_d(sv1); }
+            else { dur0 = ns_from_seconds(sv0); dur1 = ns_from_seconds(sv1); }
+            // inclusive scan over the lanes' pairs of the maps x -> max(x + p, q)
+            TT ip = (in0 ? dur0 : (TT)0) + (in1 ? dur1 : (TT)0);
+            TT iq;
+            {
+                const TT q0 = in0 ? a0 + dur0 : neg_inf, q1 = in1 ? a1 + dur1 : neg_inf;
+                const TT x = q0 + (in1 ? dur1 : (TT)0);
+                iq = x > q1 ? x : q1;
+            }
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
-                MaxPlus up;
-                up.p = __shfl_up(inc.p, d, 64); up.q = __shfl_up(inc.q, d, 64);
-                if (lane >= d) inc = mp_then(up, inc);
+                const TT up_p = __shfl_up(ip, d, 64), up_q = __shfl_up(iq, d, 64);
+                if (lane >= d) { const TT x = up_q + ip; iq = x > iq ? x : iq; ip = up_p + ip; }
             }
-            MaxPlus exc;                                                     // everything of this step before the lane's pair
-            exc.p = __shfl_up(inc.p, 1, 64); exc.q = __shfl_up(inc.q, 1, 64);
-            if (lane == 0) exc = MaxPlus{0, kNegInfNs};
-            const int64_t x0 = carryD + exc.p;
-            const int64_t Dp0 = x0 > exc.q ? x0 : exc.q;                     // D of request k0 - 1 (-infinity before the first)
-            const int64_t S0 = Dp0 > a0 ? Dp0 : a0, D0 = S0 + dur0;
-            const int64_t S1 = D0 > a1 ? D0 : a1, D1 = S1 + dur1;
-            int64_t Sp0 = __shfl_up(in1 ? S1 : S0, 1, 64), Ap0 = __shfl_up(in1 ? a1 : a0, 1, 64);
+            TT ep = __shfl_up(ip, 1, 64), eq = __shfl_up(iq, 1, 64);          // everything of this step before the lane's pair
+            if (lane == 0) { ep = (TT)0; eq = neg_inf; }
+            const TT x0 = carryD + ep;
+            const TT Dp0 = x0 > eq ? x0 : eq;                                // D of request k0 - 1 (-infinity before the first)
+            const TT S0 = Dp0 > a0 ? Dp0 : a0, D0 = S0 + dur0;
+            const TT S1 = D0 > a1 ? D0 : a1, D1 = S1 + dur1;
+            TT Sp0 = __shfl_up(in1 ? S1 : S0, 1, 64), Ap0 = __shfl_up(in1 ? a1 : a0, 1, 64);
             if (lane == 0) { Sp0 = carryS; Ap0 = carryA; }
             const bool notify0 = in0 && (Sp0 < a0 || (Sp0 == a0 && Ap0 < a0));
             const bool notify1 = in1 && (S0 < a1 || (S0 == a1 && a0 < a1));
             const bool st0 = in0 && S0 <= T, st1 = in1 && S1 <= T;
             const bool idle0 = notify0 && Dp0 <= a0 && st0, idle1 = notify1 && D0 <= a1 && st1;
             const bool dp0 = st0 && D0 <= T, dp1 = st1 && D1 <= T;
-            if (__ballot((st0 && dur0 == 0) || (st1 && dur1 == 0))) { bail = true; break; }   // a zero-nanosecond service: event order
+            if (__ballot((st0 && dur0 == (TT)0) || (st1 && dur1 == (TT)0))) { bail = true; break; }   // a zero-nanosecond service: event order
             const uint64_t bs0 = __ballot(st0), bs1 = __ballot(st1), bd0 = __ballot(dp0), bd1 = __ballot(dp1);
             n_notify += (uint32_t)(__popcll(__ballot(notify0)) + __popcll(__ballot(notify1)));
             n_poll += (uint32_t)(__popcll(__ballot(idle0)) + __popcll(__ballot(idle1)));
             n_start += (uint32_t)(__popcll(bs0) + __popcll(bs1));
             n_dep += (uint32_t)(__popcll(bd0) + __popcll(bd1));
-            if (in0) { sink_t[o + k0] = dp0 && sink ? D0 : kSinkInvalid; if (dp0 && sink) { sink_created[o + k0] = a0; sink_S[o + k0] = S0; } }
-            if (in1) { sink_t[o + k1] = dp1 && sink ? D1 : kSinkInvalid; if (dp1 && sink) { sink_created[o + k1] = a1; sink_S[o + k1] = S1; } }
-            if (bd0) {                                                       // _total_service_time: left to right, in completion order
-                const double x0s = dp0 ? sv0 : 0.0, x1s = dp1 ? sv1 : 0.0;  // (+ 0.0 is exact: departures are a prefix)
-                const int pairs = 64 - (int)__builtin_clzll(bd0);
-                for (int j = 0; j < pairs; ++j) {
-                    tsvc = __dadd_rn(tsvc, __shfl(x0s, j, 64));
-                    tsvc = __dadd_rn(tsvc, __shfl(x1s, j, 64));
+            if (in0) { sink_t[o + k0] = dp0 && sink ? to_i64(D0) : kSinkInvalid; if (dp0 && sink) { sink_created[o + k0] = pack_bits ? (int64_t)(((uint64_t)to_i64(a0) << pack_bits) | (uint64_t)(o + k0)) : to_i64(a0); sink_S[o + k0] = to_i64(S0); } }
+            if (in1) { sink_t[o + k1] = dp1 && sink ? to_i64(D1) : kSinkInvalid; if (dp1 && sink) { sink_created[o + k1] = pack_bits ? (int64_t)(((uint64_t)to_i64(a1) << pack_bits) | (uint64_t)(o + k1)) : to_i64(a1); sink_S[o + k1] = to_i64(S1); } }
+            if (bd0) {       // _total_service_time: left to right, in completion order -- through LDS: broadcast reads off the VALU
+                ssum[w][2 * lane] = dp0 ? sv0 : 0.0;                        // (+ 0.0 is exact; departures are a prefix)
+                ssum[w][2 * lane + 1] = dp1 ? sv1 : 0.0;
+                const int cnt = 2 * (64 - (int)__builtin_clzll(bd0));
+                for (int j = 0; j < cnt; j += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = ssum[w][j + q];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) tsvc = __dadd_rn(tsvc, v[q]);   // (slots past cnt of the last 8 hold this step's 0.0 / samples not yet departed: 0.0)
                 }
             }
             if (bs0) {                                                       // the last request that started so far: pending iff not departed
                 const int hl = 63 - (int)__builtin_clzll(bs0);
                 const bool second = ((bs1 >> hl) & 1ull) != 0;
-                const int64_t Sl = __shfl(second ? S1 : S0, hl, 64), Dl = __shfl(second ? D1 : D0, hl, 64);
+                const TT Sl = bcast64(second ? S1 : S0, hl), Dl = bcast64(second ? D1 : D0, hl);
                 lastS = Sl;
                 pend = Dl > T;
                 if (pend) {
-                    pendD = Dl; pendS = Sl; pend_s = __shfl(second ? sv1 : sv0, hl, 64); pendA = __shfl(second ? a1 : a0, hl, 64);
-                    pendSprev = __shfl(second ? S0 : Sp0, hl, 64); pendK = base + 2 * hl + (second ? 1 : 0);
+                    pendD = Dl; pendS = Sl; pend_s = bcast64(second ? sv1 : sv0, hl); pendA = bcast64(second ? a1 : a0, hl);
+                    pendSprev = bcast64(second ? S0 : Sp0, hl); pendK = base + 2 * hl + (second ? 1 : 0);
                 }
             }
             if (bd0) {
                 const int hl = 63 - (int)__builtin_clzll(bd0);
                 const bool second = ((bd1 >> hl) & 1ull) != 0;
-                lastD = __shfl(second ? D1 : D0, hl, 64);
+                lastD = bcast64(second ? D1 : D0, hl);
             }
             // carries: the step's last valid request
             const int64_t left = n - base;
             const int ll = left >= 128 ? 63 : (int)((left - 1) >> 1);
             const bool two = left >= 128 || ((left & 1) == 0);
-            carryD = __shfl(two ? D1 : D0, ll, 64); carryS = __shfl(two ? S1 : S0, ll, 64); carryA = __shfl(two ? a1 : a0, ll, 64);
+            carryD = bcast64(two ? D1 : D0, ll); carryS = bcast64(two ? S1 : S0, ll); carryA = bcast64(two ? a1 : a0, ll);
             if (!bs0) {                                                      // S is monotone: nobody behind this step starts either
                 for (int64_t r = base + 128 + lane; r < n; r += 64) sink_t[o + r] = kSinkInvalid;
-                carryA = n > 0 ? (int64_t)(skey[o + n - 1] & tmask) : carryA;
+                if (n > 0) carryA = (TT)(int64_t)(skey[o + n - 1] & tmask);
                 break;
             }
         }
@@ -1032,48 +1100,112 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_scan(LbBe P, int B, int S, ui
             P.received[b] = sink ? n_dep : 0; P.depth[b] = n - (int64_t)n_start; P.active[b] = pend ? 1 : 0;
             P.total_service[b] = tsvc;
             bev[b] = n_notify; bev[(size_t)B + b] = n_poll; bev[(size_t)2 * B + b] = n_start;
-            int64_t lt = n > 0 ? carryA : INT64_MIN;                         // the last arrival (arrivals are sorted), last start, last departure
+            TT lt = n > 0 ? carryA : neg_inf;                                // the last arrival (arrivals are sorted), last start, last departure
             lt = lastS > lt ? lastS : lt; lt = lastD > lt ? lastD : lt;
-            blast[b] = lt;
+            blast[b] = n > 0 ? to_i64(lt) : INT64_MIN;
             if (pend) {          // the one pending departure: this backend's candidate for the event beyond end_time, with its lineage
-                c.t = pendD; c.t_created = pendS; c.svc_s = pend_s; c.valid = 1;
+                c.t = to_i64(pendD); c.t_created = to_i64(pendS); c.svc_s = pend_s; c.valid = 1;
                 if (pendS == pendA) {          // started on arrival: SourceEvent -> Request@LoadBalancer -> Request@Server -> QUEUE_NOTIFY ->
                     const uint64_t v = sval[o + pendK];   // QUEUE_POLL -> QUEUE_DELIVER -> payload -> continuation, below the tick's chain root
                     c.depth = (int)(v >> 56) + 7; c.rcrt = (int64_t)(v & kCrtMask);
-                } else { c.depth = 4; c.rcrt = pendSprev; }   // started when the request before it left: four steps below that continuation
+                } else { c.depth = 4; c.rcrt = to_i64(pendSprev); }   // started when the request before it left: four steps below that continuation
             }
         }
     }
     block_min_cand(c, wc, cand_out);
 }
 
-// totals of the backends hs_lbk_scan ran (the ones it handed back add theirs in hs_lbk_backends)
+// totals of the backends hs_lbk_scan ran (the ones it handed back add theirs in hs_lbk_backends) and the earliest of its workgroups'
+// candidates -> scan_cand[0].  kScanParts workgroups reduce their share to one partial each; the last one to finish (a ticket) adds
+// the partials up -- no same-address atomics (512 wavefronts adding to the same eight words took 49 us; one workgroup walking
+// all 32 768 backends 151 us).
+constexpr int kScanParts = 64;
+struct ScanPartial { unsigned long long v[6]; long long lt; LbCand c; };
+static_assert(sizeof(ScanPartial) % 8 == 0, "whole words");
+
 __global__ void __launch_bounds__(256) hs_lb_scan_totals(LbBe P, int B, const uint32_t *__restrict__ bev, const int64_t *__restrict__ blast,
-                                                        const uint8_t *__restrict__ redo, LbTotals *tot) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    const bool live = b < B && redo[b] == 0;
-    unsigned long long v[7];
-    const unsigned long long n = live ? (unsigned long long)P.accepted[b] : 0ull, dep = live ? (unsigned long long)P.completed[b] : 0ull;
-    v[0] = n;                                                        // Request@Server
-    v[1] = live ? bev[b] : 0u;                                       // QUEUE_NOTIFY
-    v[2] = (live ? bev[(size_t)B + b] : 0u) + dep;                   // QUEUE_POLL: idle arrivals + one per completion
-    v[3] = live ? bev[(size_t)2 * B + b] : 0u;                       // QUEUE_DELIVER = Request@worker
-    v[4] = dep;                                                      // ProcessContinuation
-    v[5] = live ? (unsigned long long)P.received[b] : 0ull;          // Request@Sink
-    long long lt = live ? (long long)blast[b] : INT64_MIN;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) v[k] = wave_sum<unsigned long long>(v[k]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const long long d = __shfl_xor(lt, o, 64); lt = d > lt ? d : lt; }
-    if ((threadIdx.x & 63) == 0) {
-        if (v[0]) atomicAdd(&tot->ev[HS_EV_ENQUEUE], v[0]);
-        if (v[1]) atomicAdd(&tot->ev[HS_EV_NOTIFY], v[1]);
-        if (v[2]) atomicAdd(&tot->ev[HS_EV_POLL], v[2]);
-        if (v[3]) { atomicAdd(&tot->ev[HS_EV_DELIVER], v[3]); atomicAdd(&tot->ev[HS_EV_WORK], v[3]); }
-        if (v[4]) { atomicAdd(&tot->ev[HS_EV_CONTINUATION], v[4]); atomicAdd(&tot->completed, v[4]); }
-        if (v[5]) { atomicAdd(&tot->ev[HS_EV_SINK], v[5]); atomicAdd(&tot->received, v[5]); }
-        if (lt != INT64_MIN) atomicMax(&tot->last_time, lt);
+                                                        const uint8_t *__restrict__ redo, LbTotals *tot, LbCand *__restrict__ scan_cand,
+                                                        int n_cand, ScanPartial *__restrict__ part, unsigned *__restrict__ ticket) {
+    __shared__ unsigned long long sv[4][6];
+    __shared__ long long slt[4];
+    __shared__ LbCand wc[4];
+    __shared__ bool is_last;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    unsigned long long v[6] = {0, 0, 0, 0, 0, 0};
+    long long lt = INT64_MIN;
+    for (int b = blockIdx.x * 256 + tid; b < B; b += kScanParts * 256) {
+        if (redo[b] != 0) continue;
+        const unsigned long long n = (unsigned long long)P.accepted[b], dep = (unsigned long long)P.completed[b];
+        v[0] += n;                                                   // Request@Server
+        v[1] += bev[b];                                              // QUEUE_NOTIFY
+        v[2] += bev[(size_t)B + b] + dep;                            // QUEUE_POLL: idle arrivals + one per completion
+        v[3] += bev[(size_t)2 * B + b];                              // QUEUE_DELIVER = Request@worker
+        v[4] += dep;                                                 // ProcessContinuation
+        v[5] += (unsigned long long)P.received[b];                   // Request@Sink
+        const long long l = (long long)blast[b];
+        lt = l > lt ? l : lt;
     }
+    LbCand best = lb_cand_none(0);
+    for (int i = blockIdx.x * 256 + tid; i < n_cand; i += kScanParts * 256) { const LbCand c = scan_cand[i]; if (cand_before(c, best)) best = c; }
+    auto reduce_block = [&]() {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = wave_sum<unsigned long long>(v[k]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long d = __shfl_xor(lt, o, 64); lt = d > lt ? d : lt;
+            const LbCand cd = cand_shfl_xor(best, o);
+            if (cand_before(cd, best)) best = cd;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sv[w][k] = v[k];
+            slt[w] = lt; wc[w] = best;
+        }
+        __syncthreads();
+        if (tid == 0)
+            for (int q = 1; q < 4; ++q) {
+                for (int k = 0; k < 6; ++k) v[k] += sv[q][k];
+                lt = slt[q] > lt ? slt[q] : lt;
+                if (cand_before(wc[q], best)) best = wc[q];
+            }
+    };
+    reduce_block();
+    if (tid == 0) {
+        ScanPartial pp;
+        for (int k = 0; k < 6; ++k) pp.v[k] = v[k];
+        pp.lt = lt; pp.c = best;
+        unsigned long long raw[sizeof(ScanPartial) / 8];
+        __builtin_memcpy(raw, &pp, sizeof pp);
+        unsigned long long *q = (unsigned long long *)&part[blockIdx.x];
+        for (int k = 0; k < (int)(sizeof(ScanPartial) / 8); ++k) __hip_atomic_store(q + k, raw[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        is_last = atomicAdd(ticket, 1u) == (unsigned)(gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    for (int k = 0; k < 6; ++k) v[k] = 0;
+    lt = INT64_MIN; best = lb_cand_none(0);
+    if (tid < (int)gridDim.x) {
+        // (agent-scope loads: the partials were written by other workgroups, possibly on another XCD's L2)
+        const unsigned long long *q = (const unsigned long long *)&part[tid];
+        unsigned long long raw[sizeof(ScanPartial) / 8];
+        for (int k = 0; k < (int)(sizeof(ScanPartial) / 8); ++k) raw[k] = __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ScanPartial pp;
+        __builtin_memcpy(&pp, raw, sizeof pp);
+        for (int k = 0; k < 6; ++k) v[k] = pp.v[k];
+        lt = pp.lt; best = pp.c;
+    }
+    __syncthreads();
+    reduce_block();
+    if (tid != 0) return;
+    tot->ev[HS_EV_ENQUEUE] += v[0]; tot->ev[HS_EV_NOTIFY] += v[1]; tot->ev[HS_EV_POLL] += v[2];
+    tot->ev[HS_EV_DELIVER] += v[3]; tot->ev[HS_EV_WORK] += v[3];
+    tot->ev[HS_EV_CONTINUATION] += v[4]; tot->completed += v[4];
+    tot->ev[HS_EV_SINK] += v[5]; tot->received += v[5];
+    if (lt > tot->last_time) tot->last_time = lt;
+    scan_cand[n_cand] = best;     // (one slot behind the workgroups' candidates)
+    *ticket = 0;
 }
 // the dense completion log after hs_lbk_scan (+ hs_lbk_backends for the backends it handed back): a slot holds a record iff it
 // is not the marker
@@ -1105,31 +1237,45 @@ struct SinkValid {
 // is gathered from the completion log.  The merge sorted on key bits [g, tb) only: a run of completions within the same
 // 2^g ns is still in slot order; every element finds its place in its run by counting the run's elements that precede it
 // in (completion ns, service start, slot) order.
-__global__ void hs_lb_sink_finish(const uint64_t *__restrict__ mkey, const uint64_t *__restrict__ mval, const int64_t *n_ptr,
-                                  const int64_t *__restrict__ sink_created, const int64_t *__restrict__ sink_S,
-                                  int64_t *__restrict__ out_t, int64_t *__restrict__ out_created, int slot_bits, int g) {
+__global__ void __launch_bounds__(256) hs_lb_sink_finish(const uint64_t *__restrict__ mkey, const uint64_t *__restrict__ mval, const int64_t *n_ptr,
+                                                        const int64_t *__restrict__ sink_created, const int64_t *__restrict__ sink_S,
+                                                        int64_t *__restrict__ out_t, int64_t *__restrict__ out_created, int slot_bits, int g) {
+    __shared__ uint64_t lk[kSegTile + 2 * kSegHalo];         // the tile's keys + a halo (round 4: the walk along a run reads LDS)
     const int64_t n = *n_ptr;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int64_t base = (int64_t)blockIdx.x * kSegTile;
+    if (base >= n) return;
+    const int tid = threadIdx.x;
+    for (int q = tid; q < kSegTile + 2 * kSegHalo; q += 256) {
+        const int64_t i = base - kSegHalo + q;
+        lk[q] = (i >= 0 && i < n) ? mkey[i] : 0ull;
+    }
+    __syncthreads();
+    const int64_t lds_lo = base - kSegHalo, lds_hi = base + kSegTile + kSegHalo;
+    auto key_at = [&](int64_t i) -> uint64_t { return (i >= lds_lo && i < lds_hi) ? lk[i - lds_lo] : mkey[i]; };
     const uint64_t smask = slot_bits ? ((1ull << slot_bits) - 1) : ~0ull;
-    const uint64_t k = mkey[i], v = mval[i], slot = v & smask;
-    const uint64_t hi = k >> g;
-    int64_t lo = i, rank = 0, S_me = 0;
-    bool haveS = false;
-    // before(c): element c precedes this one: smaller time, or equal time and (earlier service start, then lower slot)
-    auto before = [&](int64_t c) {
-        const uint64_t kc = mkey[c];
-        if (kc != k) return kc < k;
-        if (!haveS) { S_me = sink_S[slot]; haveS = true; }
-        const uint64_t sc = mval[c] & smask;
-        const int64_t Sc = sink_S[sc];
-        return Sc < S_me || (Sc == S_me && sc < slot);
-    };
-    while (lo > 0 && (mkey[lo - 1] >> g) == hi) { rank += before(lo - 1) ? 1 : 0; --lo; }
-    for (int64_t j = i + 1; j < n && (mkey[j] >> g) == hi; ++j) rank += before(j) ? 1 : 0;
-    const int64_t pos = lo + rank;
-    out_t[pos] = (int64_t)k;
-    out_created[pos] = slot_bits ? (int64_t)(v >> slot_bits) : sink_created[slot];
+#pragma unroll
+    for (int r = 0; r < kSegTile / 256; ++r) {
+        const int64_t i = base + tid + 256 * r;
+        if (i >= n) continue;
+        const uint64_t k = key_at(i), v = mval[i], slot = v & smask;
+        const uint64_t hi = k >> g;
+        int64_t lo = i, rank = 0, S_me = 0;
+        bool haveS = false;
+        // before(c): element c precedes this one: smaller time, or equal time and (earlier service start, then lower slot)
+        auto before = [&](int64_t c) {
+            const uint64_t kc = key_at(c);
+            if (kc != k) return kc < k;
+            if (!haveS) { S_me = sink_S[slot]; haveS = true; }
+            const uint64_t sc = mval[c] & smask;
+            const int64_t Sc = sink_S[sc];
+            return Sc < S_me || (Sc == S_me && sc < slot);
+        };
+        while (lo > 0 && (key_at(lo - 1) >> g) == hi) { rank += before(lo - 1) ? 1 : 0; --lo; }
+        for (int64_t j = i + 1; j < n && (key_at(j) >> g) == hi; ++j) rank += before(j) ? 1 : 0;
+        const int64_t pos = lo + rank;
+        out_t[pos] = (int64_t)k;
+        out_created[pos] = slot_bits ? (int64_t)(v >> slot_bits) : sink_created[slot];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1439,6 +1585,7 @@ struct hs_lb {
     double *svdraw = nullptr;                         // [n_slots] service sample per Request slot (single-worker FIFO backends)
     // hs_lbk_scan (round 4): per-backend event counts [3][B], last event time [B], "run me in event order" [B], one candidate per workgroup
     uint32_t *bev = nullptr; int64_t *blast = nullptr; uint8_t *redo = nullptr; LbCand *scan_cand = nullptr;
+    ScanPartial *scan_part = nullptr; unsigned *scan_ticket = nullptr;
     bool any_simple = false;
     bool any_src_profile = false;                      // some Source has a time-varying profile (hs_lbk_sources<true>)
     // ... their tick tables (hs_tables.hpp), built once on the first run
@@ -1533,9 +1680,9 @@ void radix_sort_async(hs_lb *h, const uint64_t *k_in, const uint64_t *v_in, cons
     uint64_t *ko = startB ? h->kB : h->kA, *vo = startB ? h->vB : h->vA;
     const uint64_t *ki = k_in, *vi = v_in;
     if (h->ghist == nullptr) {       // (the one-off sorts of hs_debug_radix_sort / hs_merge_sink_records / the latency statistics)
-        if (lalloc(h, &h->ghist, (size_t)kRadixMaxPasses * kRadixBins) || lalloc(h, &h->tickets, (size_t)kRadixMaxPasses) ||
+        if (lalloc(h, &h->ghist, (size_t)kRadixMaxPasses * kRadixBins) || lalloc(h, &h->tickets, (size_t)kRadixMaxPasses + 1) ||
             lalloc(h, &h->radix_err, (size_t)1)) h->ghist = nullptr;
-        else { hipMemset(h->tickets, 0, kRadixMaxPasses * sizeof(uint32_t)); hipMemset(h->radix_err, 0, sizeof(int)); }
+        else { hipMemset(h->tickets, 0, (kRadixMaxPasses + 1) * sizeof(uint32_t)); hipMemset(h->radix_err, 0, sizeof(int)); }
     }
     if ((h->flags & 16) != 0 && passes <= kRadixMaxPasses && h->ghist != nullptr) {
         // debug flag 16 (hs_radix.hpp, round 3): one histogram read for all passes, then one look-back scatter per pass.  Measured on
@@ -1576,9 +1723,8 @@ void radix_sort_async(hs_lb *h, const uint64_t *k_in, const uint64_t *v_in, cons
         } else {
             hipLaunchKernelGGL((radix_hist<RadixAll>), grid, blk, 0, h->stream, ki, n_dev, shift, h->hist, nt, RadixAll{});
         }
-        hipLaunchKernelGGL(radix_scan_rows, dim3(kRadixBins), blk, 0, h->stream, h->hist, nt, h->row_total);
-        hipLaunchKernelGGL(radix_scan_digits, dim3(1), blk, 0, h->stream, h->row_total, h->digit_base,
-                           p == 0 ? n_out_dev : (int64_t *)nullptr);
+        hipLaunchKernelGGL(radix_scan_rows, dim3(kRadixBins), blk, 0, h->stream, h->hist, nt, h->row_total, h->digit_base,
+                           p == 0 ? n_out_dev : (int64_t *)nullptr, h->tickets + kRadixMaxPasses);
         if (p == 0) {
             hipLaunchKernelGGL((radix_scatter<Valid, MakeVal>), grid, blk, 0, h->stream, ki, vi, ko, vo, n_dev, shift, h->hist,
                                h->digit_base, nt, valid, mk);
@@ -1586,7 +1732,7 @@ void radix_sort_async(hs_lb *h, const uint64_t *k_in, const uint64_t *v_in, cons
             hipLaunchKernelGGL((radix_scatter<RadixAll, NoVal>), grid, blk, 0, h->stream, ki, vi, ko, vo, n_dev, shift, h->hist,
                                h->digit_base, nt, RadixAll{}, NoVal{});
         }
-        h->launches += 4;
+        h->launches += 3;
         ki = ko; vi = vo;
         if (ko == h->kA) { ko = h->kB; vo = h->vB; } else { ko = h->kA; vo = h->vA; }
     }
@@ -1601,13 +1747,13 @@ int lb_lanes(const hs_lb *h, int n) {
 }
 
 template <int C>
-void launch_backends(hs_lb *h, int64_t end_ns, int flags, const uint8_t *only = nullptr) {
+void launch_backends(hs_lb *h, int64_t end_ns, int flags, const uint8_t *only = nullptr, int pack_bits = 0) {
     const int B = h->cfg.n_backends;
     const int lanes = lb_lanes(h, B);
     const int per_block = lanes * (kLbBlock / 64);
     hipLaunchKernelGGL(hs_lbk_backends<C>, dim3((B + per_block - 1) / per_block), dim3(kLbBlock), 0, h->stream, h->PB, B,
                        h->cfg.n_sources, h->cfg.seed, h->cfg.start_ns, end_ns, h->skey, h->sval, h->off, h->tb, h->adm,
-                       h->sink_t, h->sink_created, h->sink_S, h->svdraw, h->tot, flags, h->LY, lanes, only);
+                       h->sink_t, h->sink_created, h->sink_S, h->svdraw, h->tot, flags, h->LY, lanes, only, pack_bits);
 }
 // Every backend has one worker and no debug flag asks for a particular legacy path: the backends run as segmented (max, +) scans over
 // the dense sorted arrival list (hs_lbk_scan), no [k][backend] layout, no separate service draws; debug flag 64 keeps round 3's pipeline.
@@ -1648,19 +1794,26 @@ int run_async(hs_lb *h, int64_t end_ns) {
     hipEventRecord(h->evs1, h->stream);
     {   // segment offsets + full-key order inside the runs the sort left, written to the other ping-pong buffer
         uint64_t *fk = h->skey == h->kA ? h->kB : h->kA, *fv = h->skey == h->kA ? h->vB : h->vA;
-        hipLaunchKernelGGL(hs_lb_segments, dim3((unsigned)((h->n_slots + 1 + 255) / 256)), dim3(256), 0, h->stream, h->skey,
+        hipLaunchKernelGGL(hs_lb_segments, dim3((unsigned)((h->n_slots + 1 + kSegTile - 1) / kSegTile)), dim3(256), 0, h->stream, h->skey,
                            h->sval, fk, fv, h->n_arr, h->tb, h->g_arr, B, h->off);
         h->skey = fk; h->sval = fv;
     }
     const bool scan = scan_path(h);
     const int n_scan_blocks = (B + kLbBlock / 64 - 1) / (kLbBlock / 64);
+    const int pack_bits = (scan && h->cfg.shared_sink) ? h->slot_bits : 0;
     if (scan) {
         // one wavefront per backend over its dense segment: service draws, the (max, +) scan, counts, completion records (section 3b);
         // what it hands back (bounded queues, a zero-nanosecond service) runs in event order on the dense layout
-        hipLaunchKernelGGL(hs_lbk_scan, dim3((unsigned)n_scan_blocks), dim3(kLbBlock), 0, h->stream, h->PB, B, S, h->cfg.seed, end_ns, h->skey,
-                           h->sval, h->off, h->tb, h->sink_t, h->sink_created, h->sink_S, h->bev, h->blast, h->redo, h->scan_cand);
-        hipLaunchKernelGGL(hs_lb_scan_totals, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->PB, B, h->bev, h->blast, h->redo, h->tot);
-        launch_backends<1>(h, end_ns, h->flags | 2, h->redo);
+        if (h->f64_times && (h->flags & 128) == 0)      // (debug flag 128: the int64 instantiation)
+            hipLaunchKernelGGL(hs_lbk_scan<true>, dim3((unsigned)n_scan_blocks), dim3(kLbBlock), 0, h->stream, h->PB, B, S, h->cfg.seed, end_ns, h->skey,
+                               h->sval, h->off, h->tb, h->sink_t, h->sink_created, h->sink_S, h->bev, h->blast, h->redo, h->scan_cand, pack_bits);
+        else
+            hipLaunchKernelGGL(hs_lbk_scan<false>, dim3((unsigned)n_scan_blocks), dim3(kLbBlock), 0, h->stream, h->PB, B, S, h->cfg.seed, end_ns, h->skey,
+                               h->sval, h->off, h->tb, h->sink_t, h->sink_created, h->sink_S, h->bev, h->blast, h->redo, h->scan_cand, pack_bits);
+        // (the totals kernel runs in the stream BEFORE the handed-back backends add theirs with atomics: plain read-modify-writes are safe)
+        hipLaunchKernelGGL(hs_lb_scan_totals, dim3(kScanParts), dim3(256), 0, h->stream, h->PB, B, h->bev, h->blast, h->redo, h->tot, h->scan_cand,
+                           n_scan_blocks, h->scan_part, h->scan_ticket);
+        launch_backends<1>(h, end_ns, h->flags | 2, h->redo, pack_bits);
         h->launches += 3;
     } else {
         // layout of the backend streams for this run: [k][backend] when the busiest backend fits the allocated rows
@@ -1693,9 +1846,10 @@ int run_async(hs_lb *h, int64_t end_ns) {
     if (h->cfg.shared_sink) {
         // completions by completion ns; the validity functor reads the sorted arrival keys (which slot belongs to which
         // backend), so pass 0 must not overwrite them
-        if (scan && h->slot_bits)        // the dense completion log of hs_lbk_scan: a slot holds a record iff it is not the marker
-            radix_sort_async(h, (const uint64_t *)h->sink_t, (const uint64_t *)nullptr, h->n_arr, h->n_done, h->tb, SinkMark{h->sink_t},
-                             PackCreatedSlot{h->sink_created, h->slot_bits}, &h->mkey, &h->mslot, h->skey, h->g_sink, h->n_slots);
+        if (scan && h->slot_bits)        // the dense completion log of hs_lbk_scan: a slot holds a record iff it is not the marker;
+                                         // sink_created already holds the merge's value (created_at << slot_bits | slot)
+            radix_sort_async(h, (const uint64_t *)h->sink_t, (const uint64_t *)h->sink_created, h->n_arr, h->n_done, h->tb, SinkMark{h->sink_t},
+                             NoVal{}, &h->mkey, &h->mslot, h->skey, h->g_sink, h->n_slots);
         else if (scan)
             radix_sort_async(h, (const uint64_t *)h->sink_t, (const uint64_t *)nullptr, h->n_arr, h->n_done, h->tb, SinkMark{h->sink_t},
                              SlotVal{}, &h->mkey, &h->mslot, h->skey, h->g_sink, h->n_slots);
@@ -1707,7 +1861,7 @@ int run_async(hs_lb *h, int64_t end_ns) {
             radix_sort_async(h, (const uint64_t *)h->sink_t, (const uint64_t *)nullptr, h->n_merge, h->n_done, h->tb,
                              SinkValid{h->skey, h->off, h->PB.received, h->tb, h->tot, B}, SlotVal{}, &h->mkey, &h->mslot,
                              h->skey, h->g_sink, h->n_layout);
-        hipLaunchKernelGGL(hs_lb_sink_finish, dim3((unsigned)((h->n_slots + 255) / 256)), dim3(256), 0, h->stream, h->mkey,
+        hipLaunchKernelGGL(hs_lb_sink_finish, dim3((unsigned)((h->n_slots + kSegTile - 1) / kSegTile)), dim3(256), 0, h->stream, h->mkey,
                            h->mslot, h->n_done, h->sink_created, h->sink_S, h->out_t, h->out_created, h->slot_bits, h->g_sink);
     }
     hipEventRecord(h->evs3, h->stream);
@@ -1720,7 +1874,7 @@ int run_async(hs_lb *h, int64_t end_ns) {
     {
         const int sl = lb_lanes(h, S) * (kLbBlock / 64), bl = lb_lanes(h, B) * (kLbBlock / 64);
         hipLaunchKernelGGL(hs_lb_finalize, dim3(1), dim3(kLbBlock), 0, h->stream, h->PS, h->PB, S, B, h->cfg.start_ns, h->tot, h->Q,
-                           (S + sl - 1) / sl, (B + bl - 1) / bl, h->scan_cand, scan ? n_scan_blocks : 0);
+                           (S + sl - 1) / sl, (B + bl - 1) / bl, h->scan_cand + n_scan_blocks, scan ? 1 : 0);
     }
     h->launches += 6;
     LB_HIP(h, hipGetLastError());
@@ -1984,7 +2138,9 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     }
     TRY(lalloc(h, &h->n_merge, 1));
     TRY(lalloc(h, &h->bev, (size_t)3 * (size_t)B)); TRY(lalloc(h, &h->blast, (size_t)B)); TRY(lalloc(h, &h->redo, (size_t)B));
-    TRY(lalloc(h, &h->scan_cand, (size_t)(B + kLbBlock / 64 - 1) / (kLbBlock / 64)));
+    TRY(lalloc(h, &h->scan_cand, (size_t)(B + kLbBlock / 64 - 1) / (kLbBlock / 64) + 1));
+    TRY(lalloc(h, &h->scan_part, (size_t)kScanParts)); TRY(lalloc(h, &h->scan_ticket, (size_t)1));
+    LB_HIP(h, hipMemset(h->scan_ticket, 0, sizeof(unsigned)));
     if (cfg->shared_sink) { TRY(lalloc(h, &h->out_t, NS)); TRY(lalloc(h, &h->out_created, NS)); }
     for (int j = 0; j < B; ++j)
         if ((be->concurrency ? be->concurrency[j] : 1) == 1 && (be->queue_cap ? be->queue_cap[j] : -1) < 0) h->any_simple = true;
@@ -1993,9 +2149,9 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     TRY(lalloc(h, &h->n_slots_dev, 1)); TRY(lalloc(h, &h->n_arr, 1)); TRY(lalloc(h, &h->n_done, 1)); TRY(lalloc(h, &h->n_tmp, 1));
     TRY(lalloc(h, &h->hist, (size_t)kRadixBins * (size_t)h->n_tiles)); TRY(lalloc(h, &h->row_total, (size_t)kRadixBins));
     TRY(lalloc(h, &h->digit_base, (size_t)kRadixBins));
-    TRY(lalloc(h, &h->ghist, (size_t)kRadixMaxPasses * kRadixBins)); TRY(lalloc(h, &h->tickets, (size_t)kRadixMaxPasses));
+    TRY(lalloc(h, &h->ghist, (size_t)kRadixMaxPasses * kRadixBins)); TRY(lalloc(h, &h->tickets, (size_t)kRadixMaxPasses + 1));
     TRY(lalloc(h, &h->radix_err, (size_t)1));
-    LB_HIP(h, hipMemset(h->tickets, 0, kRadixMaxPasses * sizeof(uint32_t)));
+    LB_HIP(h, hipMemset(h->tickets, 0, (kRadixMaxPasses + 1) * sizeof(uint32_t)));
     LB_HIP(h, hipMemset(h->radix_err, 0, sizeof(int)));
     TRY(lalloc(h, &h->tot, 1));
 #undef TRY

@@ -89,11 +89,15 @@ __global__ void __launch_bounds__(kRadixThreads) radix_hist(const uint64_t *__re
     hist[(size_t)tid * n_tiles + blockIdx.x] = h[tid];
 }
 
-// exclusive scan of every digit row (one block per digit), row totals out
+// exclusive scan of every digit row (one block per digit), row totals out; the LAST block to finish (a ticket) scans the 256 row
+// totals into the digit bases and writes the element count of the pass -- what radix_scan_digits did in a launch of its own
+// (round 4: six launches fewer per run)
 __global__ void __launch_bounds__(kRadixThreads) radix_scan_rows(uint32_t *__restrict__ hist, int n_tiles,
-                                                                 uint32_t *__restrict__ row_total) {
+                                                                 uint32_t *__restrict__ row_total, uint32_t *__restrict__ digit_base,
+                                                                 int64_t *n_out, uint32_t *__restrict__ ticket) {
     __shared__ uint32_t wsum[kRadixWaves];
     __shared__ uint32_t carry;
+    __shared__ bool is_last;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     uint32_t *row = hist + (size_t)blockIdx.x * n_tiles;
     if (tid == 0) carry = 0;
@@ -117,7 +121,28 @@ __global__ void __launch_bounds__(kRadixThreads) radix_scan_rows(uint32_t *__res
         if (tid == kRadixThreads - 1) carry = c + wbase + s;
         __syncthreads();
     }
-    if (tid == 0) row_total[blockIdx.x] = carry;
+    if (tid == 0) {
+        __hip_atomic_store(&row_total[blockIdx.x], carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    const uint32_t v = __hip_atomic_load(&row_total[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // kRadixBins == kRadixThreads
+    uint32_t s = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(s, o, 64);
+        if (lane >= o) s += t;
+    }
+    if (lane == 63) wsum[w] = s;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int k = 0; k < w; ++k) wbase += wsum[k];
+    digit_base[tid] = wbase + s - v;
+    if (tid == kRadixThreads - 1 && n_out) *n_out = (int64_t)(wbase + s);
+    if (tid == 0) *ticket = 0;
 }
 
 // exclusive scan of the 256 row totals -> digit bases; also the element count of the pass (all digits)
