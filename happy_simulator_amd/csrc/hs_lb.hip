@@ -154,9 +154,37 @@ __device__ __forceinline__ void block_min_cand(LbCand c, LbCand *wc, LbCand *out
 // with the whole device -- hs_lbk_sources, one lane per Source and therefore half the SIMDs idle, keeps only the serial ns
 // recursion and the log appends.  [tick][source] layout: the consumers' reads are coalesced.  `n_pre` ticks per Source are
 // produced (mean + 5 sigma of the busiest Source); a Source that needs more computes them itself.
+// Speculated arrival steps (round 4).  A tick is A' = trunc((A / 1e9 + inc) * 1e9) with three binary64 roundings: ten DEPENDENT fp64
+// instructions, the serial chain of hs_lbk_sources.  With F = inc * 1e9:  the rounded product z the truncation sees satisfies
+// |z - (A + F)| <= 3u (A + F) + O(u^2), u = 2^-53 (A / 1e9 is correctly rounded -- hs_device.hpp seconds_from_ns_d --, then one
+// rounded sum and one rounded product), and F itself is known to u F from the rounded product RN(inc * 1e9).  So for horizons below
+// 2^40 ns (18 minutes) every error is below 4e-4 ns, and whenever frac(RN(inc * 1e9)) lies in [2^-10, 1 - 2^-10] the tick is EXACTLY
+// A' = A + floor(RN(inc * 1e9)): one dependent add.  The draws kernel stores that whole-nanosecond step; the (one in 500) increments
+// too close to a whole number keep `inc` itself, marked by the sign bit, and take the ten-instruction step.  margin == 0: no
+// speculation (time-varying Sources, horizons of 2^40 ns and more): the value is `inc`.
+// Where the stream values of (tick d, Source s) live in hs_lb_source_draws' output: tiled so that what ONE wavefront of
+// hs_lbk_sources loads for a chunk of 16 ticks (16 x 64 values) is contiguous -- with a plain [tick][source] array those 32 loads
+// went to 32 rows 256 KB apart (a page each), and the chunk's load latency, not the ticks, set the kernel's time.
+__device__ __forceinline__ size_t lb_draw_index(uint64_t d, int s, int S) {
+    const size_t waves = ((size_t)S + 63) >> 6;
+    return ((((size_t)(d >> 4) * waves + ((size_t)s >> 6)) << 4) + (size_t)(d & 15)) * 64 + ((size_t)s & 63);
+}
+__device__ __forceinline__ double lb_step_encode(double inc, double margin) {
+    if (!(margin > 0.0)) return inc;
+    const double F = __dmul_rn(inc, 1e9), fl = __builtin_floor(F), frac = __dsub_rn(F, fl);
+    const bool safe = frac >= margin && frac <= __dsub_rn(1.0, margin) && F < 4.0e15;
+    return safe ? fl : __longlong_as_double((long long)((uint64_t)__double_as_longlong(inc) | 0x8000000000000000ull));
+}
+// the next tick after the one at `arr_d` (whole ns as a double) for an encoded step
+__device__ __forceinline__ double lb_step_apply(double arr_d, double v) {
+    if (__double_as_longlong(v) >= 0) return __dadd_rn(arr_d, v);                                  // a whole-nanosecond step: exact
+    const double inc = __longlong_as_double((long long)((uint64_t)__double_as_longlong(v) & 0x7fffffffffffffffull));
+    return ns_from_seconds_d(__dadd_rn(seconds_from_ns_d(arr_d), inc));
+}
+
 __global__ void __launch_bounds__(256) hs_lb_source_draws(LbSrc P, int S, uint64_t seed, const int32_t *__restrict__ client_be,
                                                           int64_t n_table, int64_t n_pre, double *__restrict__ dinc,
-                                                          int32_t *__restrict__ dbe) {
+                                                          int32_t *__restrict__ dbe, double margin) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t pair = i / S;
     const int s = (int)(i - pair * S);
@@ -175,20 +203,32 @@ __global__ void __launch_bounds__(256) hs_lb_source_draws(LbSrc P, int S, uint64
     const U4 q = philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), (uint32_t)sk, (uint32_t)(sk >> 32), k0, k1);
     const int64_t c0 = __double2ll_rz(__dmul_rn(res53(q.x, q.y), nclients));
     const int64_t c1 = __double2ll_rz(__dmul_rn(res53(q.z, q.w), nclients));
-    const size_t o0 = (size_t)(2 * pair) * (size_t)S + (size_t)s, o1 = o0 + (size_t)S;
-    dinc[o0] = inc0; dbe[o0] = (c0 >= 0 && c0 < n_table) ? client_be[c0] : -1;
-    if (2 * pair + 1 < n_pre) { dinc[o1] = inc1; dbe[o1] = (c1 >= 0 && c1 < n_table) ? client_be[c1] : -1; }
+    const size_t o0 = lb_draw_index((uint64_t)(2 * pair), s, S), o1 = lb_draw_index((uint64_t)(2 * pair + 1), s, S);
+    dinc[o0] = lb_step_encode(inc0, margin); dbe[o0] = (c0 >= 0 && c0 < n_table) ? client_be[c0] : -1;
+    if (2 * pair + 1 < n_pre) { dinc[o1] = lb_step_encode(inc1, margin); dbe[o1] = (c1 >= 0 && c1 < n_table) ? client_be[c1] : -1; }
 }
 
 // PF: some Source has a time-varying profile -- its next arrival is the reference's numerical inversion (hs_profile.hpp), a
 // separate instantiation so that the common one carries no scratch frame.
-template <bool PF>
+// F64: every time of the run is a whole number of ns below 2^51 (hs_lb::f64_times): the recursion runs on binary64 integers.
+// Round 4: a chunk's stream values go through LDS (gfx9 counts loads and stores with ONE counter, and with the chunk in registers the
+// compiler put an `s_waitcnt vmcnt(0)` in front of every tick's first use of a loaded value, i.e. behind the log stores of the tick
+// before it; LDS reads have their own counter), the next chunk is in flight meanwhile, the common tick is straight-line code on a
+// speculated whole-nanosecond step (lb_step_encode) and the totals take one atomic per wavefront.  Measured honestly: the kernel
+// stayed at 170-180 us through all of it -- SQ counters say ~110 instructions per tick at ~8.4 cycles each on a LONE wavefront per
+// SIMD (512 wavefronts of 64 Sources; the chain of a Source is serial, so more wavefronts do not shorten it).  What would: K lanes
+// per Source on the whole-ns steps (an exact integer prefix sum, the marked increments resolved one by one) -- not built.
+template <bool PF, bool F64>
 __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint64_t seed, int64_t start_ns, int64_t end_ns,
                                                           const int32_t *__restrict__ client_be, int64_t n_table,
                                                           uint64_t *__restrict__ keys, uint64_t *__restrict__ vals,
                                                           int64_t cap, int tb, LbTotals *tot, const double *__restrict__ dinc,
-                                                          const int32_t *__restrict__ dbe, int64_t n_pre, int f64_times, int lanes) {
+                                                          const int32_t *__restrict__ dbe, int64_t n_pre, int lanes, double margin) {
+    constexpr int kChunk = 16;
     __shared__ LbCand wc[kLbBlock / 64];
+    __shared__ double s_inc[kChunk][kLbBlock];
+    __shared__ int32_t s_be[kChunk][kLbBlock];
+    const int f64_times = F64 ? 1 : 0;
     const int s = ((blockIdx.x * kLbBlock + threadIdx.x) >> 6) * lanes + (threadIdx.x & 63);     // `lanes` Sources per wavefront (lb_lanes())
     const bool live = (threadIdx.x & 63) < lanes && s < S;
     uint32_t n_tick = 0, n_req = 0;
@@ -211,7 +251,6 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
         // returns Requests, draws client id number d.  Both streams are therefore indexed by the tick number: the
         // expensive part (Philox, hs_log, the division, the client -> backend lookup) is produced eight ticks at a time
         // in straight-line code -- independent chains the SIMD can overlap -- and only the ns recursion is serial.
-        constexpr int kChunk = 32;
         // (f64_times: every time of the run is a whole number of ns below 2^51, so the recursion runs on binary64 integers --
         //  hs_device.hpp ns_from_seconds_d: 8 dependent fp64 instructions per tick instead of ~60 with the i64 <-> f64 conversion
         //  sequences; the int64 the logs need is converted off the chain.  Round 3: the chain was 0.67 us per tick per wavefront.)
@@ -222,19 +261,30 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
         int64_t rc_a2 = INT64_MIN;           // lineage of the tick a2 itself: the root of the group that created it was created at
         uint32_t dp_a2 = 0;                  // ... rc_a2, dp_a2 steps before it (0: constructed before run())
         int64_t A = kInfNs;
+        size_t kpos = (size_t)s;             // slot of the next Request in the [tick][source] logs: n_req * S + s
         bool done = false, dead = false;
         // (a chunk's values are loaded when nothing else is in flight, with one explicit vmcnt(0): see run_request_order)
+        // the chunk after the one being processed is in flight (registers) while the ticks of this one run out of LDS: a chunk's
+        // loads take 2-3 us, as long as its sixteen ticks
+        double pinc[kChunk];
+        int32_t pbe[kChunk];
+        auto prefetch = [&](uint64_t d0) {
+            if ((int64_t)(d0 + kChunk) > n_pre) return;
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j) {
+                const size_t o = lb_draw_index(d0 + j, s, S);
+                pinc[j] = dinc[o]; pbe[j] = dbe[o];
+            }
+        };
+        prefetch(0);
         for (uint64_t d0 = 0; !done; d0 += kChunk) {
-            double inc[kChunk];
-            int32_t be[kChunk];
             if ((int64_t)(d0 + kChunk) <= n_pre) {                       // the values hs_lb_source_draws produced
 #pragma unroll
-                for (int j = 0; j < kChunk; ++j) {
-                    const size_t o = (size_t)(d0 + j) * (size_t)S + (size_t)s;
-                    inc[j] = dinc[o]; be[j] = dbe[o];
-                }
-                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) here, on every path: the chunk's values have arrived
-            } else
+                for (int j = 0; j < kChunk; ++j) { s_inc[j][threadIdx.x] = pinc[j]; s_be[j][threadIdx.x] = pbe[j]; }
+                prefetch(d0 + kChunk);
+            } else {
+            double inc[kChunk];
+            int32_t be[kChunk];
 #pragma unroll
             for (int j = 0; j < kChunk; j += 2) {
                 const uint64_t blk = (d0 + j) >> 1;
@@ -244,6 +294,7 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
                     inc[j] = __ddiv_rn(e0, rate);
                     inc[j + 1] = __ddiv_rn(e1, rate);
                 } else { inc[j] = inc_const; inc[j + 1] = inc[j]; }
+                if constexpr (!PF && F64) { inc[j] = lb_step_encode(inc[j], margin); inc[j + 1] = lb_step_encode(inc[j + 1], margin); }
                 const U4 q = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)sk, (uint32_t)(sk >> 32), k0, k1);
                 const int64_t c0 = __double2ll_rz(__dmul_rn(res53(q.x, q.y), nclients));
                 const int64_t c1 = __double2ll_rz(__dmul_rn(res53(q.z, q.w), nclients));
@@ -252,18 +303,43 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
                 be[j + 1] = ok1 ? client_be[c1] : -1;
             }
 #pragma unroll
+            for (int j = 0; j < kChunk; ++j) { s_inc[j][threadIdx.x] = inc[j]; s_be[j][threadIdx.x] = be[j]; }
+            }
+            // (each lane reads back only what it wrote itself: no barrier)
+#pragma unroll 4
             for (int j = 0; j < kChunk; ++j) {
                 if (done) continue;
                 const uint64_t d = d0 + j;
+                const double inc_j = s_inc[j][threadIdx.x];
+                const int32_t be_j = s_be[j][threadIdx.x];
+                if constexpr (!PF && F64) {
+                    // The common tick as straight-line code: later than the tick before it, not beyond end_ns, a Request with a valid
+                    // backend and room in the log.  When every lane of the wavefront that still ticks is there (a ballot), the tick is
+                    // the ns recursion, two packed stores and four counters -- no branches; anything else (the first tick, two ticks on
+                    // one nanosecond, time travel, the tick beyond end_ns, stop_after) takes the general code below, unchanged.
+                    const double arr_n = __dadd_rn(arr_d, inc_j);                  // (a whole-ns step: exact; a marked increment fails `plain`)
+                    const int64_t a2f = i64_from_whole_d(arr_n);
+                    const bool plain = __double_as_longlong(inc_j) >= 0 && margin > 0.0 && d > 0 && a2f > t_prev && a2f <= end_ns && !(stop >= 0 && a2f > stop) && be_j >= 0 && (int64_t)n_req < cap;
+                    if (__ballot(!plain) == 0ull) {
+                        arr_d = arr_n; arr_time = a2f;
+                        rc_a2 = root_crt; dp_a2 = depth + 1;
+                        root_crt = t_prev; depth = 0;
+                        t_prev = a2f; ++n_tick; last = a2f;
+                        keys[kpos] = ((uint64_t)be_j << tb) | (uint64_t)a2f;
+                        vals[kpos] = (uint64_t)root_crt & kCrtMask;
+                        ++n_req; kpos += (size_t)S;
+                        continue;
+                    }
+                }
                 int64_t a2;
                 if constexpr (PF) {
                     a2 = timevarying ? (d < (uint64_t)P.tab_cap ? tab[d] : (over = 1, kInfNs))   // load/arrival_time_provider.py:84-144
-                                     : ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc[j]));
+                                     : ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc_j));
                     if (a2 == kInfNs) { done = true; dead = true; continue; }        // the rate is zero from here on: the Source ends
                 } else if (f64_times) {
-                    arr_d = ns_from_seconds_d(__dadd_rn(seconds_from_ns_d(arr_d), inc[j]));
+                    arr_d = margin > 0.0 ? lb_step_apply(arr_d, inc_j) : ns_from_seconds_d(__dadd_rn(seconds_from_ns_d(arr_d), inc_j));
                     a2 = i64_from_whole_d(arr_d);
-                } else a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc[j]));
+                } else a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(arr_time), inc_j));
                 arr_time = a2;
                 if (d > 0) {
                     rc_a2 = root_crt; dp_a2 = depth + 1;                  // created by the tick at t_prev: one step below it in ITS group
@@ -277,12 +353,12 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
                 ++n_tick;
                 last = t;
                 if (!(stop >= 0 && t > stop)) {                           // the provider returns one Request
-                    if (be[j] < 0) bad = 1;
+                    if (be_j < 0) bad = 1;
                     if ((int64_t)n_req < cap) {
-                        keys[(size_t)n_req * S + s] = ((uint64_t)(be[j] < 0 ? 0 : be[j]) << tb) | (uint64_t)t;
-                        vals[(size_t)n_req * S + s] = ((uint64_t)(depth > 30 ? 30 : depth) << 56) | ((uint64_t)root_crt & kCrtMask);
+                        keys[kpos] = ((uint64_t)(be_j < 0 ? 0 : be_j) << tb) | (uint64_t)t;
+                        vals[kpos] = ((uint64_t)(depth > 30 ? 30 : depth) << 56) | ((uint64_t)root_crt & kCrtMask);
                     } else over = 1;
-                    ++n_req;
+                    ++n_req; kpos += (size_t)S;
                 }
             }
         }
@@ -292,13 +368,20 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_sources(LbSrc P, int S, uint6
         c.depth = (int)(dp_a2 > 255u ? 255u : dp_a2); c.rcrt = rc_a2;
     }
     block_min_cand(c, wc, P.cand);
-    if (live && n_req) atomicMax(&tot->max_count, (long long)(n_req < (uint32_t)cap ? n_req : (uint32_t)cap));
+    // (one atomic per WAVEFRONT instead of two per lane on the same two words)
+    long long mc = (live && n_req) ? (long long)(n_req < (uint32_t)cap ? n_req : (uint32_t)cap) : 0ll, ml = live ? (long long)last : INT64_MIN;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long a = __shfl_xor(mc, o, 64), b2 = __shfl_xor(ml, o, 64);
+        mc = a > mc ? a : mc; ml = b2 > ml ? b2 : ml;
+    }
     const uint32_t st = wave_sum<uint32_t>(n_tick), sr = wave_sum<uint32_t>(n_req);
     if ((threadIdx.x & 63) == 0) {
+        if (mc) atomicMax(&tot->max_count, mc);
         if (st) atomicAdd(&tot->ev[HS_EV_SOURCE], (unsigned long long)st);
         if (sr) { atomicAdd(&tot->ev[HS_EV_LB], (unsigned long long)sr); atomicAdd(&tot->ev[HS_EV_LB_RESP], (unsigned long long)sr); }
+        if (ml != INT64_MIN) atomicMax(&tot->last_time, ml);
     }
-    if (live && last != INT64_MIN) atomicMax(&tot->last_time, (long long)last);
     if (bad) atomicOr(&tot->bad_client, 1);
     if (over) atomicOr(&tot->bad_client, 2);
 }
@@ -902,7 +985,12 @@ __global__ void __launch_bounds__(kLbBlock) hs_lbk_backends(LbBe P, int B, int S
         if (sc) atomicAdd(&tot->completed, (unsigned long long)sc);
         if (sr) atomicAdd(&tot->received, (unsigned long long)sr);
     }
-    if (live && X.last_time != INT64_MIN) atomicMax(&tot->last_time, (long long)X.last_time);
+    {   // (one atomic per wavefront, not per lane: same-address atomics serialise in the L2)
+        long long ml = live ? (long long)X.last_time : INT64_MIN;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const long long d = __shfl_xor(ml, o, 64); ml = d > ml ? d : ml; }
+        if ((tid & 63) == 0 && ml != INT64_MIN) atomicMax(&tot->last_time, ml);
+    }
     if (live && X.qoverflow) atomicOr(&tot->qoverflow, 1);
 }
 
@@ -1771,21 +1859,23 @@ int run_async(hs_lb *h, int64_t end_ns) {
     // the Sources' stream values first, with every SIMD (hs_lb_source_draws; the sort's ping-pong buffers are free until the sort);
     // debug flag 8: the Sources draw their own
     const int64_t n_pre = (h->flags & 8) ? 0 : h->n_pre;
+    // speculated arrival steps (lb_step_encode): constant-rate Sources on the exact-binary64 path, horizons below 2^40 ns; debug flag 256 off
+    const double margin = (h->f64_times && !h->any_src_profile && h->cfg.horizon_ns < (1ll << 40) && (h->flags & 256) == 0) ? 1.0 / 1024.0 : 0.0;
     double *dinc = (double *)h->kA;
     int32_t *dbe = (int32_t *)h->vA;
     if (n_pre > 0) {
         const int64_t threads = ((n_pre + 1) / 2) * (int64_t)S;
         hipLaunchKernelGGL(hs_lb_source_draws, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, h->stream, h->PS, S, h->cfg.seed,
-                           h->client_be, h->n_table, n_pre, dinc, dbe);
+                           h->client_be, h->n_table, n_pre, dinc, dbe, margin);
         h->launches += 1;
     }
     const int src_lanes = lb_lanes(h, S), src_per_block = src_lanes * (kLbBlock / 64);
-    if (h->any_src_profile)
-        hipLaunchKernelGGL(hs_lbk_sources<true>, dim3((S + src_per_block - 1) / src_per_block), dim3(kLbBlock), 0, h->stream, h->PS, S, h->cfg.seed,
-                           h->cfg.start_ns, end_ns, h->client_be, h->n_table, h->keys0, h->vals0, h->cap, h->tb, h->tot, dinc, dbe, n_pre, h->f64_times ? 1 : 0, src_lanes);
-    else
-        hipLaunchKernelGGL(hs_lbk_sources<false>, dim3((S + src_per_block - 1) / src_per_block), dim3(kLbBlock), 0, h->stream, h->PS, S, h->cfg.seed,
-                           h->cfg.start_ns, end_ns, h->client_be, h->n_table, h->keys0, h->vals0, h->cap, h->tb, h->tot, dinc, dbe, n_pre, h->f64_times ? 1 : 0, src_lanes);
+#define HS_LAUNCH_SOURCES(PFV, F64V) hipLaunchKernelGGL((hs_lbk_sources<PFV, F64V>), dim3((S + src_per_block - 1) / src_per_block), dim3(kLbBlock), 0, h->stream, \
+        h->PS, S, h->cfg.seed, h->cfg.start_ns, end_ns, h->client_be, h->n_table, h->keys0, h->vals0, h->cap, h->tb, h->tot, dinc, dbe, n_pre, src_lanes, margin)
+    if (h->any_src_profile) HS_LAUNCH_SOURCES(true, false);
+    else if (h->f64_times) HS_LAUNCH_SOURCES(false, true);
+    else HS_LAUNCH_SOURCES(false, false);
+#undef HS_LAUNCH_SOURCES
     hipLaunchKernelGGL(hs_lb_rows, dim3(1), dim3(1), 0, h->stream, h->tot, S, h->n_slots_dev);
     hipEventRecord(h->evs0, h->stream);
     radix_sort_async(h, h->keys0, h->vals0, h->n_slots_dev, h->n_arr, h->tb + h->bb,
@@ -2128,7 +2218,9 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     }
     const size_t NS = (size_t)h->n_slots;
     TRY(lalloc(h, &h->keys0, NS)); TRY(lalloc(h, &h->vals0, NS));
-    TRY(lalloc(h, &h->kA, NS)); TRY(lalloc(h, &h->vA, NS)); TRY(lalloc(h, &h->kB, NS)); TRY(lalloc(h, &h->vB, NS));
+    // (kA / vA also hold hs_lb_source_draws' tiled output before the first sort: whole wavefronts of Sources, lb_draw_index)
+    const size_t NSP = (size_t)h->cap * (((size_t)S + 63) & ~(size_t)63);
+    TRY(lalloc(h, &h->kA, NSP)); TRY(lalloc(h, &h->vA, NSP)); TRY(lalloc(h, &h->kB, NS)); TRY(lalloc(h, &h->vB, NS));
     TRY(lalloc(h, &h->off, (size_t)B + 1));
     const size_t NL = (size_t)h->n_layout;
     TRY(lalloc(h, &h->adm, NS)); TRY(lalloc(h, &h->sink_t, NL)); TRY(lalloc(h, &h->sink_created, NL)); TRY(lalloc(h, &h->sink_S, NL));

@@ -97,8 +97,9 @@ SWEEP = [
 
 
 @pytest.mark.parametrize("spec", SWEEP, ids=[s["name"] for s in SWEEP])
-@pytest.mark.parametrize("flags", [0, 64, 1, 2, 4, 8, 16], ids=["segmented_scan", "request_order", "general_fifo", "event_order", "dense_layout",
-                                                                 "sources_draw_their_own_values", "look_back_radix_passes"])
+@pytest.mark.parametrize("flags", [0, 64, 1, 2, 4, 8, 16, 128, 256],
+                         ids=["segmented_scan", "request_order", "general_fifo", "event_order", "dense_layout", "sources_draw_their_own_values",
+                              "look_back_radix_passes", "int64_scan", "no_speculated_arrival_steps"])
 def test_lb_engine_matches_oracle(spec, flags):
     g, p = H.oracle_lb_graph_ext(spec)
     r = O.run(g, p["end_ns"], seed=spec["seed"])
