@@ -17,7 +17,7 @@ from .core.temporal import Duration, Instant  # noqa: F401
 from .entities import (BackendInfo, ClientKeyEventProvider, ConsistentHash, ConstantArrivalTimeProvider, Data, Probe,  # noqa: F401
                        ConstantLatency, ConstantRateProfile, Counter, Entity, ExponentialLatency, FIFOQueue,
                        LatencyTracker, LinearRampProfile, LoadBalancer, LoadBalancerStats, NetworkLink, NetworkLinkStats,
-                       PoissonArrivalTimeProvider, RandomRouter, Server, ServerStats, SimpleEventProvider, Sink, Source,
+                       PoissonArrivalTimeProvider, Random, RandomRouter, RoundRobin, Server, ServerStats, SimpleEventProvider, Sink, Source,
                        SpikeProfile)
 from .lowering import UnsupportedTopology  # noqa: F401
 from .parallel import (ParallelResult, ParallelRunner, ParallelSimulation, ParallelSimulationSummary,  # noqa: F401

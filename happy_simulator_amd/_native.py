@@ -30,13 +30,14 @@ SRC_NONE, SRC_POISSON, SRC_CONSTANT = 0, 1, 2
 PROF_CONSTANT, PROF_LINEAR_RAMP, PROF_SPIKE = 0, 1, 2
 LAT_EXPONENTIAL, LAT_CONSTANT, LAT_NO_SERVER = 0, 1, 2
 EGRESS_NONE, EGRESS_SINK, EGRESS_LINK, EGRESS_ROUTER, EGRESS_SERVER = 0, 1, 2, 3, 4
+LB_CONSISTENT_HASH, LB_ROUND_ROBIN, LB_RANDOM = 0, 1, 2
 EV_KINDS = 15
 EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuation", "sink", "link", "link_cont",
             "route", "lb", "lb_resp", "probe_tick", "probe")
 PROBE_METRICS = {"depth": 0, "active_requests": 1, "stats_accepted": 2, "stats_dropped": 3, "requests_completed": 4,
                  "_requests_completed": 4, "events_received": 5, "generated_count": 6}
 PROBE_NONE = 255
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class EngineUnavailable(RuntimeError):
@@ -118,7 +119,7 @@ class LbConfig(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("device", C.c_int32), ("n_sources", C.c_int32), ("n_backends", C.c_int32),
         ("start_ns", C.c_int64), ("horizon_ns", C.c_int64), ("seed", C.c_uint64), ("virtual_nodes", C.c_int32),
-        ("shared_sink", C.c_int32), ("tick_capacity", C.c_int64),
+        ("shared_sink", C.c_int32), ("tick_capacity", C.c_int64), ("strategy", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

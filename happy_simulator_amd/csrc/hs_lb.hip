@@ -466,6 +466,48 @@ __global__ void __launch_bounds__(256) hs_lb_segments(const uint64_t *__restrict
     }
 }
 
+// RoundRobin (strategies.py:50-73): the k-th Request the LoadBalancer processes goes to backend k mod B.  Input: ALL Requests sorted
+// by arrival ns on key bits [g, tb) (backend column 0); inside a run of equal high bits every Request finds its place by counting
+// the run's Requests that the LoadBalancer processes before it -- earlier ns; on one ns the one whose SourceEvent chain was created
+// first (the stamp the per-backend order uses as well, LbBackend::order_arrival_run), then input order = (tick, Source) --, and
+// that place IS the RoundRobin index: the Request leaves with key (place mod B) << tb | ns for the usual (backend, ns) sort.
+__global__ void __launch_bounds__(256) hs_lb_rr_assign(const uint64_t *__restrict__ skey, const uint64_t *__restrict__ sval,
+                                                      uint64_t *__restrict__ fkey, uint64_t *__restrict__ fval, const int64_t *n_ptr, int tb,
+                                                      int g, int B) {
+    __shared__ uint64_t lk[kSegTile + 2 * kSegHalo];
+    const int64_t n = *n_ptr;
+    const int64_t base = (int64_t)blockIdx.x * kSegTile;
+    if (base >= n) return;
+    const int tid = threadIdx.x;
+    for (int q = tid; q < kSegTile + 2 * kSegHalo; q += 256) {
+        const int64_t i = base - kSegHalo + q;
+        lk[q] = (i >= 0 && i < n) ? skey[i] : 0ull;
+    }
+    __syncthreads();
+    const int64_t lds_lo = base - kSegHalo, lds_hi = base + kSegTile + kSegHalo;
+    auto key_at = [&](int64_t i) -> uint64_t { return (i >= lds_lo && i < lds_hi) ? lk[i - lds_lo] : skey[i]; };
+#pragma unroll
+    for (int r = 0; r < kSegTile / 256; ++r) {
+        const int64_t i = base + tid + 256 * r;
+        if (i >= n) continue;
+        const uint64_t k = key_at(i), v = sval[i], c_me = v & kCrtMask;
+        const uint64_t hi = k >> g;
+        int64_t lo = i, rank = 0;
+        auto before = [&](int64_t j) {
+            const uint64_t kj = key_at(j);
+            if (kj != k) return kj < k;
+            const uint64_t cj = sval[j] & kCrtMask;
+            return cj < c_me || (cj == c_me && j < i);
+        };
+        while (lo > 0 && (key_at(lo - 1) >> g) == hi) { rank += before(lo - 1) ? 1 : 0; --lo; }
+        for (int64_t j = i + 1; j < n && (key_at(j) >> g) == hi; ++j) rank += before(j) ? 1 : 0;
+        const int64_t pos = lo + rank;
+        const uint64_t tmask = tb >= 64 ? ~0ull : ((1ull << tb) - 1);
+        fkey[pos] = ((uint64_t)(pos % B) << tb) | (k & tmask);
+        fval[pos] = v;
+    }
+}
+
 __global__ void hs_lb_maxcount(const int64_t *__restrict__ off, int B, LbTotals *tot) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     long long c = b < B ? (long long)(off[b + 1] - off[b]) : 0;
@@ -1878,9 +1920,21 @@ int run_async(hs_lb *h, int64_t end_ns) {
 #undef HS_LAUNCH_SOURCES
     hipLaunchKernelGGL(hs_lb_rows, dim3(1), dim3(1), 0, h->stream, h->tot, S, h->n_slots_dev);
     hipEventRecord(h->evs0, h->stream);
-    radix_sort_async(h, h->keys0, h->vals0, h->n_slots_dev, h->n_arr, h->tb + h->bb,
-                     TickValid{h->PS.count, S, h->n_slots < (1ll << 31)}, NoVal{}, &h->skey, &h->sval, nullptr, h->g_arr,
-                     h->n_slots);
+    if (h->cfg.strategy == HS_LB_ROUND_ROBIN) {
+        // the LoadBalancer's processing order first: all Requests by arrival ns (backend column 0), every Request's place in that
+        // order, backend = place mod B (hs_lb_rr_assign); then the (backend, ns) sort of any other strategy over the dense result
+        uint64_t *tk = nullptr, *tv = nullptr;
+        radix_sort_async(h, h->keys0, h->vals0, h->n_slots_dev, h->n_arr, h->tb, TickValid{h->PS.count, S, h->n_slots < (1ll << 31)},
+                         NoVal{}, &tk, &tv, nullptr, h->g_sink, h->n_slots);
+        uint64_t *fk = tk == h->kA ? h->kB : h->kA, *fv = tk == h->kA ? h->vB : h->vA;
+        hipLaunchKernelGGL(hs_lb_rr_assign, dim3((unsigned)((h->n_slots + kSegTile - 1) / kSegTile)), dim3(256), 0, h->stream, tk, tv, fk, fv,
+                           h->n_arr, h->tb, h->g_sink, B);
+        h->launches += 1;
+        radix_sort_async(h, fk, fv, h->n_arr, h->n_arr, h->tb + h->bb, RadixAll{}, NoVal{}, &h->skey, &h->sval, fk, h->g_arr, h->n_slots);
+    } else
+        radix_sort_async(h, h->keys0, h->vals0, h->n_slots_dev, h->n_arr, h->tb + h->bb,
+                         TickValid{h->PS.count, S, h->n_slots < (1ll << 31)}, NoVal{}, &h->skey, &h->sval, nullptr, h->g_arr,
+                         h->n_slots);
     hipEventRecord(h->evs1, h->stream);
     {   // segment offsets + full-key order inside the runs the sort left, written to the other ping-pong buffer
         uint64_t *fk = h->skey == h->kA ? h->kB : h->kA, *fv = h->skey == h->kA ? h->vB : h->vA;
@@ -2018,9 +2072,11 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     const int S = cfg->n_sources, B = cfg->n_backends;
     if (S <= 0) return lfail(nullptr, HS_E_INVALID, "hs_lb_create: n_sources must be > 0");
     if (B <= 0) return lfail(nullptr, HS_E_INVALID, "hs_lb_create: n_backends must be > 0 (the reference rejects every request otherwise)");
-    if (cfg->virtual_nodes < 1) return lfail(nullptr, HS_E_INVALID, "virtual_nodes must be >= 1, got %d", cfg->virtual_nodes);
+    if (cfg->strategy < HS_LB_CONSISTENT_HASH || cfg->strategy > HS_LB_RANDOM) return lfail(nullptr, HS_E_UNSUPPORTED, "load-balancing strategy %d is not lowered", cfg->strategy);
+    const bool chash = cfg->strategy == HS_LB_CONSISTENT_HASH;
+    if (chash && cfg->virtual_nodes < 1) return lfail(nullptr, HS_E_INVALID, "virtual_nodes must be >= 1, got %d", cfg->virtual_nodes);
     if (cfg->horizon_ns < cfg->start_ns || cfg->start_ns < 0) return lfail(nullptr, HS_E_INVALID, "hs_lb_create: bad start / horizon");
-    if (!src->src_rate || !src->n_clients) return lfail(nullptr, HS_E_INVALID, "src_rate and n_clients are required");
+    if (!src->src_rate || (chash && !src->n_clients)) return lfail(nullptr, HS_E_INVALID, "src_rate and n_clients are required");
     if (!be->names || !be->name_off) return lfail(nullptr, HS_E_INVALID, "backend names are required (the ring hashes them)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -2039,9 +2095,15 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
         max_ticks = std::max(max_ticks, r * horizon_s);
         min_rate = std::min(min_rate, r);
         total_rate += r;
-        if (src->n_clients[i] < 1) return lfail(nullptr, HS_E_INVALID, "source %d: n_clients must be >= 1", i);
-        kmax = std::max(kmax, src->n_clients[i]);
+        if (chash) {
+            if (src->n_clients[i] < 1) return lfail(nullptr, HS_E_INVALID, "source %d: n_clients must be >= 1", i);
+            kmax = std::max(kmax, src->n_clients[i]);
+        }
     }
+    // RANDOM: the key draw IS the backend index -- int(u * B) through an identity table; ROUND_ROBIN: the Sources' backend column is
+    // a placeholder (0), the assignment follows the global arrival order (hs_lb_rr_assign)
+    if (cfg->strategy == HS_LB_RANDOM) kmax = B;
+    if (cfg->strategy == HS_LB_ROUND_ROBIN) kmax = 1;
     if (kmax > (1ll << 26)) return lfail(nullptr, HS_E_UNSUPPORTED, "n_clients above 2^26 is not supported (client -> backend table)");
     int maxc = 1;
     bool any_no_sink = false;
@@ -2104,9 +2166,9 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
         h->slot_bits = (h->tb + sb <= 64) ? sb : 0;                     // created_at (tb bits) and the slot share one word
     }
     // ---- the ring: ConsistentHash.add_backend for every backend in order (strategies.py:381-391)
-    const int V = cfg->virtual_nodes;
+    const int V = chash ? cfg->virtual_nodes : 0;
     h->ring.resize((size_t)B * V);
-    {
+    if (chash) {
         char key[256];
         size_t k = 0;
         for (int j = 0; j < B; ++j) {
@@ -2126,13 +2188,13 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     }
     // ---- client id -> backend (ConsistentHash.select for key str(id)); a pure function of the id
     std::vector<int32_t> table((size_t)kmax);
-    {
+    if (chash) {
         char key[32];
         for (int64_t c = 0; c < kmax; ++c) {
             const int m = snprintf(key, sizeof key, "%lld", (long long)c);
             table[(size_t)c] = ring_select(h->ring, key, (size_t)m);
         }
-    }
+    } else for (int64_t c = 0; c < kmax; ++c) table[(size_t)c] = (int32_t)c;
     h->n_table = kmax;
     hipError_t e = hipSetDevice(cfg->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -2150,7 +2212,8 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     TRY(lupload<int64_t>(h, &h->PS.stop, src->src_stop_after_ns, (size_t)S, (int64_t)-1));
     h->src_stop_h.assign((size_t)S, (int64_t)-1);
     if (src->src_stop_after_ns) h->src_stop_h.assign(src->src_stop_after_ns, src->src_stop_after_ns + S);
-    TRY(lupload<int64_t>(h, &h->PS.n_clients, src->n_clients, (size_t)S, (int64_t)1));
+    if (chash) TRY(lupload<int64_t>(h, &h->PS.n_clients, src->n_clients, (size_t)S, (int64_t)1));
+    else TRY(lupload<int64_t>(h, &h->PS.n_clients, (const int64_t *)nullptr, (size_t)S, (int64_t)kmax));
     {   // time-varying profiles (load/profile.py:52-113): src_rate of such a Source is its PEAK rate (it sizes the tick log)
         std::vector<uint8_t> pk((size_t)S, (uint8_t)0);
         std::vector<double> pp((size_t)S * 4, 0.0);
@@ -2519,12 +2582,14 @@ int hs_lb_latency_stats(hs_lb *h, double out[6]) {
 
 int hs_lb_ring(hs_lb *h, int32_t *ring_backend) {
     if (!h || !ring_backend) return lfail(h, HS_E_INVALID, "hs_lb_ring: null argument");
+    if (h->cfg.strategy != HS_LB_CONSISTENT_HASH) return lfail(h, HS_E_STATE, "hs_lb_ring: this LoadBalancer has no ConsistentHash ring");
     for (size_t i = 0; i < h->ring.size(); ++i) ring_backend[i] = h->ring[i].backend;
     return HS_OK;
 }
 
 int32_t hs_lb_select(hs_lb *h, const char *key) {
     if (!h || !key) return lfail(h, HS_E_INVALID, "hs_lb_select: null argument");
+    if (h->cfg.strategy != HS_LB_CONSISTENT_HASH) return lfail(h, HS_E_STATE, "hs_lb_select: this LoadBalancer has no ConsistentHash ring");
     return ring_select(h->ring, key, strlen(key));
 }
 

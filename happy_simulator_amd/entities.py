@@ -653,6 +653,25 @@ class ConsistentHash:
         return self._virtual_nodes
 
 
+class RoundRobin:
+    """Cycles through the backends (components/load_balancer/strategies.py:50-73), the LoadBalancer's default strategy: the k-th
+    Request the LoadBalancer processes goes to backends[k % len(backends)].  On the engine the Requests of all Sources are ranked
+    by arrival on the device (csrc/hs_lb.hip hs_lb_rr_assign); `_index` holds the number of selections after a run."""
+
+    def __init__(self):
+        self._index = 0
+
+    def reset(self) -> None:
+        self._index = 0
+
+
+class Random:
+    """Random backend selection (strategies.py:137-150: `random.choice(backends)`).  On the engine the choice is
+    backends[int(u * len(backends))] with u the Request's draw from its Source's own Philox KEY stream -- the seed-matched form
+    of the process-wide `random`, pinned against the reference with that plug (tests/golden/make_golden.py
+    `_PerRequestChoice`)."""
+
+
 @dataclass(frozen=True)
 class LoadBalancerStats:
     """components/load_balancer/load_balancer.py:40-58."""
@@ -679,17 +698,18 @@ class BackendInfo:
 
 
 class LoadBalancer(Entity):
-    """Distributes requests over backends (components/load_balancer/load_balancer.py:83-473).  Lowered: the
-    ConsistentHash strategy over Server backends that all stay healthy for the whole run."""
+    """Distributes requests over backends (components/load_balancer/load_balancer.py:83-473).  Lowered: the ConsistentHash,
+    RoundRobin (the default) and Random strategies over Server backends that all stay healthy for the whole run."""
 
     def __init__(self, name: str, backends: list[Entity] | None = None, strategy=None, on_no_backend: str = "reject"):
         super().__init__(name)
         if on_no_backend not in ("reject", "queue"):
             raise ValueError(f"on_no_backend must be 'reject' or 'queue', got {on_no_backend}")   # load_balancer.py:120-121
         if strategy is None:
-            raise NotImplementedError("the default RoundRobin strategy is not lowered; pass strategy=ConsistentHash(...)")
-        if not isinstance(strategy, ConsistentHash):
-            raise NotImplementedError(f"strategy {type(strategy).__name__} is not lowered to the engine (only ConsistentHash)")
+            strategy = RoundRobin()                                                       # load_balancer.py:112
+        if not isinstance(strategy, (ConsistentHash, RoundRobin, Random)):
+            raise NotImplementedError(f"strategy {type(strategy).__name__} is not lowered to the engine (ConsistentHash, "
+                                      "RoundRobin and Random are)")
         self._strategy = strategy
         self._on_no_backend = on_no_backend
         self._backends: dict[str, BackendInfo] = {}

@@ -48,7 +48,8 @@ class LoadBalancerEngine:
     """S Sources -> LoadBalancer(ConsistentHash(virtual_nodes)) -> B Servers -> Sink(s) on one device."""
 
     def __init__(self, sources: LbSourceArrays, backends: LbBackendArrays, *, virtual_nodes: int, horizon_ns: int,
-                 shared_sink: bool = True, start_ns: int = 0, seed: int = 42, device: int = 0, tick_capacity: int = 0):
+                 shared_sink: bool = True, start_ns: int = 0, seed: int = 42, device: int = 0, tick_capacity: int = 0,
+                 strategy: int = N.LB_CONSISTENT_HASH):
         self._lib = N.lib()
         if self._lib.hs_device_count() <= 0:
             raise N.EngineUnavailable("no HIP device visible: the engine has no CPU fallback")
@@ -57,7 +58,8 @@ class LoadBalancerEngine:
         self.shared_sink = bool(shared_sink)
         self._h = C.c_void_p()
         cfg = N.LbConfig(C.sizeof(N.LbConfig), device, self.S, self.B, start_ns, horizon_ns, seed, self.virtual_nodes,
-                         1 if shared_sink else 0, tick_capacity)
+                         1 if shared_sink else 0, tick_capacity, int(strategy), 0)
+        self.strategy = int(strategy)
         keep = []
 
         def fill(struct, obj, n, fields):

@@ -19,8 +19,8 @@ import numpy as np
 from . import _native as N
 from .engine import NetworkArrays, StationArrays
 from .entities import (ClientKeyEventProvider, ConsistentHash, ConstantLatency, ConstantRateProfile, Counter, Entity,
-                       ExponentialLatency, LatencyTracker, LinearRampProfile, LoadBalancer, NetworkLink, RandomRouter, Server,
-                       Sink, Source, _RecordSink)
+                       ExponentialLatency, LatencyTracker, LinearRampProfile, LoadBalancer, NetworkLink, Random, RandomRouter,
+                       RoundRobin, Server, SimpleEventProvider, Sink, Source, _RecordSink)
 
 _SINKS = (Sink, Counter, LatencyTracker)
 
@@ -742,7 +742,7 @@ class LbGraph:
         S, B = len(self.sources), len(self.backends)
         src = LbSourceArrays(
             n=S, src_rate=np.array([s.rate for s in self.sources], np.float64),
-            n_clients=np.array([s._event_provider._n_clients for s in self.sources], np.int64),
+            n_clients=np.array([getattr(s._event_provider, "_n_clients", 1) for s in self.sources], np.int64),
             src_kind=np.array([N.SRC_POISSON if s._time_provider.kind == "poisson" else N.SRC_CONSTANT
                                for s in self.sources], np.uint8),
             src_stop_after_ns=np.array([-1 if s._event_provider._stop_after is None
@@ -802,15 +802,17 @@ def lower_lb(sources: list, entities: list, lb: LoadBalancer) -> LbGraph:
         if not isinstance(s, Source):
             raise UnsupportedTopology(f"source {type(s).__name__} is not a lowered Source")
         ep = s._event_provider
-        if not isinstance(ep, ClientKeyEventProvider):
+        if isinstance(lb.strategy, ConsistentHash) and not isinstance(ep, ClientKeyEventProvider):
             raise UnsupportedTopology(
                 f"source '{s.name}': requests for a key-based LoadBalancer must come from a ClientKeyEventProvider "
-                "(ConsistentHash falls back to RoundRobin for key-less requests, which is not lowered)")
+                "(ConsistentHash falls back to RoundRobin for key-less requests: use strategy=RoundRobin() for those)")
+        if not isinstance(ep, (ClientKeyEventProvider, SimpleEventProvider)):
+            raise UnsupportedTopology(f"source '{s.name}': event provider {type(ep).__name__} is not lowered")
         if ep._target is not lb:
             raise UnsupportedTopology(f"source '{s.name}' does not target the LoadBalancer '{lb.name}'")
         if not (s.rate > 0):
             raise UnsupportedTopology(f"source '{s.name}': rate must be > 0")
-    if not isinstance(lb.strategy, ConsistentHash):
+    if not isinstance(lb.strategy, (ConsistentHash, RoundRobin, Random)):
         raise UnsupportedTopology(f"strategy {type(lb.strategy).__name__} is not lowered")
     backends = lb.all_backends
     if not backends:
@@ -882,6 +884,8 @@ def write_back_lb(g: LbGraph, stats: dict, eng) -> None:
     lb = g.lb
     lb._requests_received, lb._requests_forwarded, lb._requests_failed, lb._no_backend_available, lb._in_flight_count = (
         int(v) for v in stats["lb"])
+    if isinstance(lb.strategy, RoundRobin):
+        lb.strategy._index += lb._requests_forwarded              # one select per forwarded Request (strategies.py:66-67)
     for j, b in enumerate(g.backends):
         b._queue.stats_accepted = int(stats["accepted"][j])
         b._queue.stats_dropped = int(stats["dropped"][j])

@@ -137,9 +137,13 @@ class Simulation:
 
         end_ns = self._end_time.nanoseconds
         src, be = g.engine_arrays()
-        with LoadBalancerEngine(src, be, virtual_nodes=g.lb.strategy.virtual_nodes, horizon_ns=end_ns,
+        from .entities import ConsistentHash, RoundRobin
+
+        strat = g.lb.strategy
+        code = N.LB_CONSISTENT_HASH if isinstance(strat, ConsistentHash) else N.LB_ROUND_ROBIN if isinstance(strat, RoundRobin) else N.LB_RANDOM
+        with LoadBalancerEngine(src, be, virtual_nodes=getattr(strat, "virtual_nodes", 1), horizon_ns=end_ns,
                                 shared_sink=g.shared_sink, start_ns=self._start_time.nanoseconds, seed=self._seed,
-                                device=self._device) as eng:
+                                device=self._device, strategy=code) as eng:
             if g.probes:
                 eng.set_probes(*g.probe_arrays())
             eng.run(end_ns)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HS_ABI_VERSION 11
+#define HS_ABI_VERSION 12
 
 typedef enum hs_status {
     HS_OK = 0,
@@ -405,7 +405,19 @@ typedef struct hs_lb_config {
     int32_t virtual_nodes;     /* ConsistentHash(virtual_nodes=...), >= 1 */
     int32_t shared_sink;       /* 1: every backend's downstream is ONE Sink; 0: one Sink per backend (or none, see egress) */
     int64_t tick_capacity;     /* ticks per source in the arrival log; 0 = derive from rate * horizon */
+    int32_t strategy;          /* hs_lb_strategy: how LoadBalancer._forward_request picks the backend (load_balancer.py:368) */
+    int32_t reserved;
 } hs_lb_config;
+/* LoadBalancingStrategy.select (components/load_balancer/strategies.py), all backends healthy:
+ *   CONSISTENT_HASH  strategies.py:336-433: the md5 ring over `virtual_nodes` points per backend, key = metadata["client_id"];
+ *   ROUND_ROBIN      strategies.py:50-73, the LoadBalancer's DEFAULT: backends[_index % len(backends)], _index += 1 per select --
+ *                    i.e. the k-th Request the LoadBalancer processes (global (time, _sort_index) order over all Sources) goes
+ *                    to backend k mod B.  The engine ranks all Requests by arrival first (one more device sort), then proceeds
+ *                    as for any other assignment;  hs_lb_sources.n_clients and virtual_nodes are ignored;
+ *   RANDOM           strategies.py:137-150: random.choice(backends) with the choice plugged like every draw of the seed-matched
+ *                    definition: backends[int(u * len(backends))], u = the Request's draw from its Source's
+ *                    KEY stream (the stream the client ids come from otherwise);  n_clients and virtual_nodes are ignored. */
+typedef enum hs_lb_strategy { HS_LB_CONSISTENT_HASH = 0, HS_LB_ROUND_ROBIN = 1, HS_LB_RANDOM = 2 } hs_lb_strategy;
 
 typedef struct hs_lb_sources {     /* [n_sources] each; NULL = documented default */
     const uint8_t *src_kind;           /* hs_source_kind (POISSON / CONSTANT); NULL = POISSON */

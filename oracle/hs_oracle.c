@@ -678,7 +678,7 @@ static int ring_cmp(const void *pa, const void *pb) {
 /* ConsistentHash.add_backend for every backend in LoadBalancer.__init__ order (strategies.py:381-391) */
 static void lb_build_ring(hso_sim *s, int32_t n) {
     hso_node *nd = &s->nodes[n];
-    int32_t cnt = s->g.rt_cnt[n], v = s->g.vnodes[n];
+    int32_t cnt = s->g.rt_cnt[n], v = s->g.vnodes[n] > 0 ? s->g.vnodes[n] : 0;    /* (<= 0: RoundRobin / Random -- no ring) */
     nd->ring_len = (int64_t)cnt * v;
     nd->ring = (hso_ring_pt *)malloc((size_t)(nd->ring_len > 0 ? nd->ring_len : 1) * sizeof(hso_ring_pt));
     nd->lb_total_requests = (int64_t *)calloc((size_t)(cnt > 0 ? cnt : 1), sizeof(int64_t));
@@ -714,7 +714,10 @@ static int32_t lb_select_key(const hso_sim *s, int32_t n, const char *key, int64
 }
 int32_t hso_lb_select(const hso_sim *s, int32_t node, const char *key) { return lb_select_key(s, node, key, (int64_t)strlen(key)); }
 
-/* LoadBalancer._forward_request, load_balancer.py:347-433 (all backends healthy, ConsistentHash strategy) */
+/* LoadBalancer._forward_request, load_balancer.py:347-433 (all backends healthy).  Strategy by `vnodes`: > 0 ConsistentHash
+ * (strategies.py:336-433); 0 RoundRobin (strategies.py:50-73: backends[_index % len], _index += 1 per select -- the LB's processing
+ * order); -1 Random (strategies.py:137-150: random.choice(backends)) with the choice plugged like every other draw of the
+ * seed-matched oracle: backends[int(u * len)], u the Request's draw from its Source's KEY stream (client_id holds the index). */
 static void on_lb(hso_sim *s, const hso_event *e) {
     int32_t n = e->node;
     hso_node *nd = &s->nodes[n];
@@ -724,9 +727,18 @@ static void on_lb(hso_sim *s, const hso_event *e) {
         req_release(s, e->req);
         return;
     }
-    char key[32];
-    int len = snprintf(key, sizeof key, "%lld", (long long)s->reqs[e->req].client_id);   /* str(metadata["client_id"]) */
-    int32_t be = lb_select_key(s, n, key, len);
+    int32_t be;
+    if (s->g.vnodes[n] > 0) {
+        char key[32];
+        int len = snprintf(key, sizeof key, "%lld", (long long)s->reqs[e->req].client_id);   /* str(metadata["client_id"]) */
+        be = lb_select_key(s, n, key, len);
+    } else if (s->g.vnodes[n] == 0) {
+        be = s->g.rt_targets[s->g.rt_off[n] + (int32_t)(nd->lb_next_id % s->g.rt_cnt[n])];  /* RoundRobin._index == selects so far */
+    } else {
+        int64_t c = s->reqs[e->req].client_id;
+        if (c < 0 || c >= s->g.rt_cnt[n]) c = 0;
+        be = s->g.rt_targets[s->g.rt_off[n] + (int32_t)c];
+    }
     nd->lb_next_id++;                                               /* :375-376 */
     nd->lb_in_flight++;                                             /* :378-382 */
     for (int32_t b = 0; b < s->g.rt_cnt[n]; ++b)

@@ -388,7 +388,7 @@ def run_blocks_parallel(graphs: list, end_ns: int, seed: int = 42) -> dict:
 
 
 def lb_topology(n_sources, n_backends, rate, mean, vnodes, n_clients, concurrency=1, queue_cap=-1,
-                stop_after_ns=-1, shared_sink=True) -> Graph:
+                stop_after_ns=-1, shared_sink=True, strategy="chash") -> Graph:
     """S sources (Poisson, client ids from their KEY stream) -> LoadBalancer(ConsistentHash(vnodes)) -> B Server backends
     -> one shared Sink or one per backend (tests/golden/make_golden.py run_lb_case).  Node order: sources 0..S-1,
     LB = S, backends S+1..S+B, sinks after; stream bases: source i -> i, backend j -> S + j; names "srv<j>"."""
@@ -397,6 +397,12 @@ def lb_topology(n_sources, n_backends, rate, mean, vnodes, n_clients, concurrenc
     S, B = n_sources, n_backends
     g = Graph()
     rate, mean, conc, qcap = per(rate, S), per(mean, B), per(concurrency, B), per(queue_cap, B)
+    # strategy (hs_oracle.c on_lb): "chash" ConsistentHash(vnodes); "round_robin": vnodes field 0; "random": -1, and every Request
+    # draws its backend index int(u * B) from its Source's KEY stream
+    if strategy == "round_robin":
+        vnodes = 0
+    elif strategy == "random":
+        vnodes, n_clients = -1, B
     for i in range(S):
         g.source(ARR_POISSON, rate[i], target=S, stop_after_ns=stop_after_ns, stream_base=i, n_clients=n_clients)
     lb = g._add(kind=LB)          # placeholder, filled in below once the backend nodes exist

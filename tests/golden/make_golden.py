@@ -124,6 +124,18 @@ class _PerLinkRandom:
         return link._loss_stream.next_uniform()
 
 
+class _PerRequestChoice:
+    """Stands in for the `random` module inside components/load_balancer/strategies.py so that the reference's own
+    `Random.select` (`random.choice(backends)`, strategies.py:146-150) picks backends[client_id] -- the index the Request's Source
+    drew from its KEY stream, int(u * len(backends)) (PhiloxClientProvider with n_clients = number of backends) -- instead of asking
+    the process-wide MT19937; the strategy's body that runs is the reference's, untouched."""
+
+    @staticmethod
+    def choice(seq):
+        request = sys._getframe(1).f_locals["request"]
+        return seq[int(request.context["metadata"]["client_id"])]
+
+
 class PhiloxClientProvider(EventProvider):
     """The request factory of examples/visual/chash_example.py:69-88 (`ClientRequestProvider`): one Request per
     tick whose metadata carries a random client_id for the ConsistentHash strategy -- with the id drawn from the
@@ -779,7 +791,17 @@ def run_lb_case(spec):
     servers = [Server(f"srv{j}", concurrency=conc[j],
                       service_time=PhiloxExponentialLatency(mean[j], hs.Stream(seed, S + j, hs.STREAM_SERVICE)),
                       queue_capacity=qcap[j], downstream=sinks[0] if shared else sinks[j]) for j in range(B)]
-    lb = LoadBalancer("lb", backends=servers, strategy=ConsistentHash(virtual_nodes=spec["vnodes"]))
+    strategy = spec.get("strategy", "chash")
+    if strategy == "round_robin":              # the LoadBalancer's DEFAULT strategy (load_balancer.py:112, strategies.py:50-73)
+        from happysimulator.components.load_balancer.strategies import RoundRobin
+        lb = LoadBalancer("lb", backends=servers, strategy=RoundRobin())
+    elif strategy == "random":                 # strategies.py:137-150, its random.choice plugged per Request (_PerRequestChoice)
+        import happysimulator.components.load_balancer.strategies as strat_mod
+        strat_mod.random = _PerRequestChoice
+        lb = LoadBalancer("lb", backends=servers, strategy=strat_mod.Random())
+        spec["n_clients"] = B
+    else:
+        lb = LoadBalancer("lb", backends=servers, strategy=ConsistentHash(virtual_nodes=spec["vnodes"]))
     rate = _per_chain(spec["rate"], S)
     stop = spec.get("stop_after_s")
     stop_instant = None if stop is None else Instant.from_seconds(stop)
@@ -863,16 +885,19 @@ def run_lb_case(spec):
     out["lb_stats"] = np.array([st.requests_received, st.requests_forwarded, st.requests_failed,
                                 st.no_backend_available, len(lb._in_flight)], np.int64)
     out["backend_total_requests"] = np.array([lb.get_backend_info(s).total_requests for s in servers], np.int64)
-    # the ring itself (hash is a 128-bit int: split) and the client -> backend map the strategy implements
-    ring = lb.strategy._ring
-    out["ring_hash_hi"] = np.array([h >> 64 for h, _ in ring], np.uint64)
-    out["ring_hash_lo"] = np.array([h & ((1 << 64) - 1) for h, _ in ring], np.uint64)
-    out["ring_backend"] = np.array([int(nm[3:]) for _, nm in ring], np.int32)
-    probe = []
-    for cid in range(min(spec["n_clients"], 4096)):
-        ev = Event(time=Instant.Epoch, event_type="Request", target=lb, context={"metadata": {"client_id": str(cid)}})
-        probe.append(int(lb.strategy.select(servers, ev).name[3:]))
-    out["client_backend"] = np.array(probe, np.int32)
+    if strategy == "chash":
+        # the ring itself (hash is a 128-bit int: split) and the client -> backend map the strategy implements
+        ring = lb.strategy._ring
+        out["ring_hash_hi"] = np.array([h >> 64 for h, _ in ring], np.uint64)
+        out["ring_hash_lo"] = np.array([h & ((1 << 64) - 1) for h, _ in ring], np.uint64)
+        out["ring_backend"] = np.array([int(nm[3:]) for _, nm in ring], np.int32)
+        probe = []
+        for cid in range(min(spec["n_clients"], 4096)):
+            ev = Event(time=Instant.Epoch, event_type="Request", target=lb, context={"metadata": {"client_id": str(cid)}})
+            probe.append(int(lb.strategy.select(servers, ev).name[3:]))
+        out["client_backend"] = np.array(probe, np.int32)
+    elif strategy == "round_robin":
+        out["rr_index"] = np.array([lb.strategy._index], np.int64)
     sink_t, sink_lat, off = [], [], [0]
     for k in sinks:
         sink_t.extend(t.nanoseconds for t in k.completion_times)
@@ -936,6 +961,18 @@ LB_CASES = [
          n_clients=777, stop_after_s=6.0, end_s=12.0, seed=5, trace=True),
     dict(name="lb_64src_256be", topology="lb", n_sources=64, n_backends=256, rate=24.0, mean=0.1, vnodes=150,
          n_clients=65536, end_s=8.0, seed=2026, trace=False),
+    # the LoadBalancer's DEFAULT strategy, RoundRobin (backends[_index % len] in the LB's processing order), and Random
+    dict(name="lb_rr_3src_5be", topology="lb", strategy="round_robin", n_sources=3, n_backends=5, rate=[14.0, 9.0, 11.0], mean=0.12,
+         concurrency=[1, 2, 1, 1, 3], queue_cap=[None, None, 2, None, None], vnodes=1, n_clients=1, end_s=12.0, seed=31, trace=True),
+    dict(name="lb_rr_per_backend_sinks", topology="lb", strategy="round_robin", n_sources=5, n_backends=7, rate=12.0, mean=0.1,
+         vnodes=1, n_clients=1, end_s=10.0, seed=32, shared_sink=False, stop_after_s=7.0,
+         probes=[["server", 2, "depth", 0.25], ["sink", 6, "events_received", 0.5]], trace=True),
+    dict(name="lb_rr_64src_96be", topology="lb", strategy="round_robin", n_sources=64, n_backends=96, rate=20.0, mean=0.06,
+         vnodes=1, n_clients=1, end_s=6.0, seed=33, trace=False),
+    dict(name="lb_random_4src_6be", topology="lb", strategy="random", n_sources=4, n_backends=6, rate=[10.0, 16.0, 8.0, 12.0], mean=0.1,
+         concurrency=[1, 1, 2, 1, 1, 1], vnodes=1, n_clients=6, end_s=12.0, seed=34, trace=True),
+    dict(name="lb_random_32src_64be", topology="lb", strategy="random", n_sources=32, n_backends=64, rate=25.0, mean=0.07,
+         vnodes=1, n_clients=64, end_s=6.0, seed=35, trace=False),
 ]
 
 RING_CASES = [

@@ -317,7 +317,8 @@ def lb_params(spec):
         qcap=[-1 if q is None else int(q) for q in per_chain(spec.get("queue_cap"), B)],
         vnodes=int(spec["vnodes"]), n_clients=int(spec["n_clients"]),
         stop_ns=-1 if spec.get("stop_after_s") is None else ns_from_seconds(spec["stop_after_s"]),
-        shared_sink=bool(spec.get("shared_sink", True)), end_ns=ns_from_seconds(spec["end_s"]))
+        shared_sink=bool(spec.get("shared_sink", True)), end_ns=ns_from_seconds(spec["end_s"]),
+        strategy=spec.get("strategy", "chash"))
 
 
 def oracle_lb_graph(spec):
@@ -325,7 +326,7 @@ def oracle_lb_graph(spec):
     then the Sink(s).  Returns (graph, params)."""
     p = lb_params(spec)
     g = O.lb_topology(p["S"], p["B"], p["rate"], p["mean"], p["vnodes"], p["n_clients"], p["conc"], p["qcap"],
-                      p["stop_ns"], p["shared_sink"])
+                      p["stop_ns"], p["shared_sink"], strategy=p["strategy"])
     for i, pr in enumerate(spec.get("profile") or []):    # Source.with_profile in front of the LoadBalancer
         if pr is not None:
             g.prof_kind[i] = O.PROF_LINEAR_RAMP if pr[0] == "ramp" else O.PROF_SPIKE
@@ -562,7 +563,8 @@ def lb_engine_for_spec(spec, flags=0, tick_capacity=0):
         svc_mean_s=np.array(p["mean"], np.float64), queue_cap=np.array(p["qcap"], np.int64),
         egress=np.full(B, N.EGRESS_SINK, np.uint8))
     eng = LoadBalancerEngine(src, be, virtual_nodes=p["vnodes"], horizon_ns=p["end_ns"], shared_sink=p["shared_sink"],
-                             seed=spec["seed"], tick_capacity=tick_capacity)
+                             seed=spec["seed"], tick_capacity=tick_capacity,
+                             strategy={"chash": N.LB_CONSISTENT_HASH, "round_robin": N.LB_ROUND_ROBIN, "random": N.LB_RANDOM}[p["strategy"]])
     if flags:
         eng.set_debug_flags(flags)
     if spec.get("probes"):

@@ -27,12 +27,12 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_abi_version_and_struct_sizes(lib):
-    assert lib.hs_abi_version() == N.ABI_VERSION == 11
+    assert lib.hs_abi_version() == N.ABI_VERSION == 12
     assert C.sizeof(N.Config) == 56
     assert N.EV_KINDS == 15 and len(N.EV_NAMES) == 15
     assert C.sizeof(N.Summary) == 8 * (1 + 15 + 1 + 1 + 1 + 1) + 8 + 8 + 8 + 8 + 8
     assert C.sizeof(N.Stations) == 27 * 8
-    assert C.sizeof(N.LbConfig) == 56 and C.sizeof(N.LbSources) == 56 and C.sizeof(N.LbBackends) == 64
+    assert C.sizeof(N.LbConfig) == 64 and C.sizeof(N.LbSources) == 56 and C.sizeof(N.LbBackends) == 64
     assert C.sizeof(N.LbStats) == 88
     assert C.sizeof(N.Network) == 152 and C.sizeof(N.NetStats) == 4 * 8
 
@@ -54,7 +54,7 @@ def test_no_gpu_means_loud_failure(lib):
 
     from happy_simulator_amd.lb_engine import LbBackendArrays, LbSourceArrays, LoadBalancerEngine
 
-    lcfg = N.LbConfig(C.sizeof(N.LbConfig), 0, 1, 1, 0, 10**9, 42, 10, 1, 0)
+    lcfg = N.LbConfig(C.sizeof(N.LbConfig), 0, 1, 1, 0, 10**9, 42, 10, 1, 0, 0, 0)
     rate, ncl, off = np.array([1.0]), np.array([4], np.int64), np.array([0, 1], np.int32)
     src = N.LbSources(None, rate.ctypes.data, None, ncl.ctypes.data, None)
     names = C.create_string_buffer(b"s")

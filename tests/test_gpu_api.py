@@ -270,16 +270,20 @@ def test_load_balancer_topology_through_the_api_matches_reference_golden(name):
     nodes = [hs.Server(f"srv{j}", concurrency=p["conc"][j], service_time=hs.ExponentialLatency(p["mean"][j]),
                        queue_capacity=None if p["qcap"][j] < 0 else p["qcap"][j],
                        downstream=sinks[0] if p["shared_sink"] else sinks[j]) for j in range(B)]
-    lb = hs.LoadBalancer("lb", backends=nodes, strategy=hs.ConsistentHash(virtual_nodes=p["vnodes"]))
+    strat = p["strategy"]       # ConsistentHash; RoundRobin = the reference's default (no strategy argument); Random
+    lb = (hs.LoadBalancer("lb", backends=nodes, strategy=hs.ConsistentHash(virtual_nodes=p["vnodes"])) if strat == "chash" else
+          hs.LoadBalancer("lb", backends=nodes) if strat == "round_robin" else hs.LoadBalancer("lb", backends=nodes, strategy=hs.Random()))
     def profile_of(pr):
         return (hs.LinearRampProfile(duration_s=pr[1], start_rate=pr[2], end_rate=pr[3]) if pr[0] == "ramp" else
                 hs.SpikeProfile(baseline_rate=pr[1], spike_rate=pr[2], warmup_s=pr[3], spike_duration_s=pr[4]))
 
     profs = spec.get("profile") or [None] * S
+    # (RoundRobin / Random need no client key: the plain request factory of Source.poisson(rate, target=lb) -- stop_after included)
     srcs = [(hs.Source.poisson(rate=p["rate"][i], name=f"src{i}", event_provider=ep) if profs[i] is None else
              hs.Source.with_profile(profile_of(profs[i]), poisson=True, name=f"src{i}", event_provider=ep))
             for i in range(S)
-            for ep in [hs.ClientKeyEventProvider(lb, n_clients=p["n_clients"], stop_after=spec.get("stop_after_s"))]]
+            for ep in [hs.ClientKeyEventProvider(lb, n_clients=p["n_clients"], stop_after=spec.get("stop_after_s")) if strat == "chash" else
+                       hs.SimpleEventProvider(lb, "Request", hs.Source._resolve_stop_after(spec.get("stop_after_s")))]]
     probes = [hs.Probe.on({"server": nodes, "sink": sinks, "source": srcs}[who][i], metric, interval=iv)      # (lb_probes*.npz)
               for who, i, metric, iv in spec.get("probes") or []]
     sim = hs.Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=srcs, entities=[lb, *nodes, *sinks],
@@ -295,6 +299,8 @@ def test_load_balancer_topology_through_the_api_matches_reference_golden(name):
     st = lb.stats
     assert [st.requests_received, st.requests_forwarded, st.requests_failed, st.no_backend_available] == gold.lb_stats[:4].tolist()
     assert [lb.get_backend_info(n).total_requests for n in nodes] == gold.backend_total_requests.tolist()
+    if strat == "round_robin":
+        assert lb.strategy._index == int(gold.rr_index[0]) == st.requests_forwarded
     assert [n.stats_accepted for n in nodes] == gold.accepted.tolist()
     assert [n.stats_dropped for n in nodes] == gold.dropped.tolist()
     assert [n.stats.requests_completed for n in nodes] == gold.completed.tolist()

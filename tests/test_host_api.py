@@ -225,8 +225,9 @@ class TestLoadBalancerLowering:
             lb.add_backend(hs.Server("s"), weight=0)
         with pytest.raises(ValueError, match="n_clients must be >= 1"):
             hs.ClientKeyEventProvider(lb, n_clients=0)
-        with pytest.raises(NotImplementedError, match="RoundRobin"):
-            hs.LoadBalancer("lb")
+        assert isinstance(hs.LoadBalancer("lb").strategy, hs.RoundRobin)          # the reference's default (load_balancer.py:112)
+        with pytest.raises(NotImplementedError, match="is not lowered"):
+            hs.LoadBalancer("lb", strategy=object())
         lb.add_backend(hs.Server("s"))
         lb.add_backend(hs.Server("t"), weight=3)
         assert lb.backend_count == lb.healthy_count == 2 and [b.name for b in lb.all_backends] == ["s", "t"]

@@ -156,15 +156,19 @@ def check_oracle_against_lb_golden(gold):
     want_trace = "trace" in gold.arrays
     g, p = H.oracle_lb_graph(spec)
     S, B = p["S"], p["B"]
+    chash = spec.get("strategy", "chash") == "chash"          # (RoundRobin / Random: no ring to compare)
     r = O.run(g, p["end_ns"], seed=spec["seed"], trace_cap=(len(gold.trace) + 16) if want_trace else 0,
-              lb_probe=len(gold.client_backend))
+              lb_probe=len(gold.client_backend) if chash else 0)
     assert [r.events_processed] == gold.meta["total_events"]
     assert [r.final_time_ns] == gold.meta["final_ns"]
     lb = r.lbs[S]
     np.testing.assert_array_equal(lb["stats"], gold.lb_stats)
     np.testing.assert_array_equal(lb["total_requests"], gold.backend_total_requests)
-    np.testing.assert_array_equal(lb["ring_backend"] - (S + 1), gold.ring_backend)       # the sorted md5 ring
-    np.testing.assert_array_equal(np.array(lb["select"]) - (S + 1), gold.client_backend)  # ConsistentHash.select
+    if chash:
+        np.testing.assert_array_equal(lb["ring_backend"] - (S + 1), gold.ring_backend)       # the sorted md5 ring
+        np.testing.assert_array_equal(np.array(lb["select"]) - (S + 1), gold.client_backend)  # ConsistentHash.select
+    elif "rr_index" in gold.arrays:
+        assert int(gold.rr_index[0]) == lb["stats"][1]                                        # RoundRobin._index = selects made
     np.testing.assert_array_equal(r.generated[:S], gold.generated)
     be = slice(S + 1, S + 1 + B)
     for k in ("accepted", "dropped", "completed", "rejected", "depth", "active", "total_service_s"):
