@@ -24,6 +24,8 @@
 static thread_local std::string g_global_error;
 
 struct hs_engine {
+    bool pending_async = false;   // hs_engine_run_until_async enqueued a run whose results hs_engine_synchronize has not finalised yet
+
     hs_config cfg{};
     int C = 1;                 // departure slots compiled for (>= max concurrency)
     bool have_stations = false;
@@ -797,6 +799,8 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
                 for (int j = 0; j < kMaxProbes; ++j) if (pm[(size_t)j * n + i] != 255) { po.push_back(i); pslot.push_back((uint8_t)j); }
         }
     }
+    if (((double)so.size() + (double)n + (double)po.size() + 1.0) * 8.0 >= 2147483647.0)
+        return fail(h, HS_E_UNSUPPORTED, "too many Sources / stations / Probes for the 32-bit construction ranks of the election key");
     if (st->source_order || st->probe_order || !tandem.empty()) {   // cross-LP ties go to the entity the reference constructed first (cand_rank, hs_station.hpp)
         std::vector<int32_t> tr((size_t)n * (kMaxXSrc + 2) + 1 + (size_t)n * kMaxProbes, -1);
         int32_t *sr = tr.data() + n;
@@ -817,8 +821,11 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         if (!tandem.empty())     // ... and where every other key ties between two Servers of a chain, the upstream one's event was created first
             for (size_t q = 0; q < tr.size(); ++q) {                             // (ranks only compare: room for the pass below them)
                 const size_t lp = q < (size_t)n * (kMaxXSrc + 2) ? q % (size_t)n : (q - (size_t)n * (kMaxXSrc + 2) - 1) % (size_t)n;
+                // (3 bits for the pass: clamped -- a chain deeper than 7 behind a fan-in beyond kMaxUp runs on the single heap, which
+                //  does not read this key; unclamped, a pass >= 8 spilled into the construction rank above it: ADVICE r3)
                 if (q == (size_t)n * (kMaxXSrc + 2)) { tr[q] = tr[q] * 8; continue; }
-                tr[q] = tr[q] * 8 + tandem[(size_t)kMaxUp * n + lp];
+                const int32_t ps = tandem[(size_t)kMaxUp * n + lp];
+                tr[q] = tr[q] * 8 + (ps > 7 ? 7 : ps < 0 ? 0 : ps);
             }
         if ((rc = upload<int32_t>(h, &h->P.tie_rank, tr.data(), tr.size(), 0))) return rc;
     }
@@ -1424,9 +1431,11 @@ int hs_engine_shard_overshoot(hs_engine *h, int32_t lp) {
     return HS_OK;
 }
 
+static int results_final(hs_engine *h);
 int hs_engine_get_net_stats(hs_engine *h, const hs_net_stats *o) {
     if (!h || !o) return fail(h, HS_E_INVALID, "hs_engine_get_net_stats: null argument");
     if (!h->is_net) return fail(h, HS_E_STATE, "no network set");
+    if (h) { const int rcf = results_final(h); if (rcf) return rcf; }
     HS_HIP(h, hipSetDevice(h->cfg.device));
     HS_HIP(h, hipStreamSynchronize(h->stream));
     const size_t n = (size_t)h->cfg.n_lp, nl = (size_t)h->NP.n_links;
@@ -1480,6 +1489,7 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
     }
     HS_HIP(h, hipEventRecord(h->ev_k1, h->stream));
     HS_HIP(h, hipEventRecord(h->ev_b, h->stream));
+    h->pending_async = true;
     return HS_OK;
 }
 
@@ -1554,9 +1564,19 @@ int hs_engine_synchronize(hs_engine *h) {
     HS_HIP(h, hipStreamSynchronize(h->stream));
     { int rc = tandem_fallback(h); if (rc) return rc; }
     { int rc = prologue_fallback(h); if (rc) return rc; }
+    h->pending_async = false;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, h->ev_a, h->ev_b) == hipSuccess) h->last_run_ms = ms;
     if (hipEventElapsedTime(&ms, h->ev_k0, h->ev_k1) == hipSuccess) h->last_kernel_ms = ms;
+    return HS_OK;
+}
+
+// Every getter goes through here: a run enqueued with hs_engine_run_until_async is FINAL only behind hs_engine_synchronize -- that is
+// where a run that skipped the prologue, or tandem passes that met an undecided tie, are repeated on the single heap (ADVICE r3:
+// a getter that merely waited for the stream returned the results of the skipped path).
+static int results_final(hs_engine *h) {
+    if (h->pending_async) return hs_engine_synchronize(h);
+    if (hipSetDevice(h->cfg.device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return fail(h, HS_E_HIP, "device synchronisation failed");
     return HS_OK;
 }
 
@@ -1654,6 +1674,7 @@ int hs_engine_set_profile_budget(hs_engine *h, int64_t intervals_per_lane) {
 int hs_engine_get_summary(hs_engine *h, hs_summary *out) {
     if (!h || !out) return fail(h, HS_E_INVALID, "hs_engine_get_summary: null argument");
     if (!h->have_stations) return fail(h, HS_E_STATE, "stations not set");
+    if (h) { const int rcf = results_final(h); if (rcf) return rcf; }
     HS_HIP(h, hipSetDevice(h->cfg.device));
     HS_HIP(h, hipStreamSynchronize(h->stream));
     Totals t;
@@ -1677,6 +1698,7 @@ int hs_engine_get_summary(hs_engine *h, hs_summary *out) {
 int hs_engine_get_lp_stats(hs_engine *h, const hs_lp_stats *o) {
     if (!h || !o) return fail(h, HS_E_INVALID, "hs_engine_get_lp_stats: null argument");
     if (!h->have_stations) return fail(h, HS_E_STATE, "stations not set");
+    if (h) { const int rcf = results_final(h); if (rcf) return rcf; }
     HS_HIP(h, hipSetDevice(h->cfg.device));
     HS_HIP(h, hipStreamSynchronize(h->stream));
     const size_t n = (size_t)h->cfg.n_lp;
@@ -1692,6 +1714,7 @@ int hs_engine_get_lp_stats(hs_engine *h, const hs_lp_stats *o) {
 int64_t hs_engine_read_sink(hs_engine *h, int32_t lp, int64_t *t_ns, int64_t *created_ns, int64_t cap) {
     if (!h || !h->have_stations) return fail(h, HS_E_STATE, "stations not set");
     if (lp < 0 || lp >= h->cfg.n_lp) return fail(h, HS_E_INVALID, "LP index %d out of range", lp);
+    if (h) { const int rcf = results_final(h); if (rcf) return rcf; }
     if (hipSetDevice(h->cfg.device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
         return fail(h, HS_E_HIP, "device synchronisation failed");
     int64_t cnt = 0;
@@ -1721,6 +1744,7 @@ int64_t hs_engine_read_sink(hs_engine *h, int32_t lp, int64_t *t_ns, int64_t *cr
 int64_t hs_engine_read_sinks(hs_engine *h, int64_t *counts, int64_t *t_ns, int64_t *created_ns, int64_t cap_total) {
     if (!h || !h->have_stations) return fail(h, HS_E_STATE, "stations not set");
     if (!counts) return fail(h, HS_E_INVALID, "counts is required");
+    if (h) { const int rcf = results_final(h); if (rcf) return rcf; }
     if (hipSetDevice(h->cfg.device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
         return fail(h, HS_E_HIP, "device synchronisation failed");
     const size_t n = (size_t)h->cfg.n_lp;
@@ -1767,6 +1791,7 @@ int hs_engine_read_source_generated(hs_engine *h, int32_t slot, int64_t *out) {
     if (!h || !h->have_stations || !out) return fail(h, HS_E_STATE, "stations not set");
     if (slot < 0 || slot > kMaxXSrc) return fail(h, HS_E_INVALID, "source slot %d out of range", slot);
     const size_t n = (size_t)h->cfg.n_lp;
+    if (h) { const int rcf = results_final(h); if (rcf) return rcf; }
     HS_HIP(h, hipSetDevice(h->cfg.device));
     HS_HIP(h, hipStreamSynchronize(h->stream));
     if (slot == 0) { HS_HIP(h, hipMemcpy(out, h->X.generated, n * 8, hipMemcpyDeviceToHost)); return HS_OK; }
@@ -1780,6 +1805,7 @@ int64_t hs_engine_read_probe_slot(hs_engine *h, int32_t lp, int32_t slot, int64_
     if (lp < 0 || lp >= h->cfg.n_lp) return fail(h, HS_E_INVALID, "LP index %d out of range", lp);
     if (slot < 0 || slot >= kMaxProbes) return fail(h, HS_E_INVALID, "probe slot %d out of range", slot);
     if (!h->any_probe || slot >= h->n_probe_slots) return 0;
+    if (h) { const int rcf = results_final(h); if (rcf) return rcf; }
     if (hipSetDevice(h->cfg.device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
         return fail(h, HS_E_HIP, "device synchronisation failed");
     int64_t cnt = 0;

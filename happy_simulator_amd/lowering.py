@@ -382,11 +382,16 @@ def plain_probe_arrays(pc: "PlainChains", probes: list, arrays):
     return where
 
 
-def write_back_plain_probes(probes: list, where: list, eng) -> None:
-    """The samples stay on the device until a probe's Data is first read (65 536 read-backs of a few hundred bytes each are
-    seconds of host time); `eng` must outlive them (LazyRecords keeps it)."""
+def write_back_plain_probes(probes: list, where: list, records: "LazyRecords", lazy: bool = True) -> None:
+    """lazy: the samples stay on the device until a probe's Data is first read (65 536 read-backs of a few hundred bytes each are
+    seconds of host time); every such Data holds `records` -- the owner of the engine -- so the engine lives as long as any unread
+    Data does, whatever happens to the Simulation.  Not lazy: the samples are read now."""
     for pr, (i, slot, scale) in zip(probes, where):
-        pr.data_sink._set_lazy(lambda i=i, slot=slot: eng.read_probe(i, slot), scale)
+        if lazy:
+            pr.data_sink._set_lazy(lambda i=i, slot=slot, records=records: records.engine().read_probe(i, slot), scale)
+        else:
+            t, v = records.engine().read_probe(i, slot)
+            pr.data_sink._set(t, v, scale)
 
 
 def write_back_probes(g: LoweredGraph, eng) -> None:
@@ -596,6 +601,11 @@ class LazyRecords:
                 self._eng.close()
                 self._eng = None
         return self._t, self._cr
+
+    def engine(self):
+        if self._eng is None:
+            raise RuntimeError("the engine of this run has been closed")
+        return self._eng
 
     def count(self, i: int) -> int:
         return int(self.off[i + 1] - self.off[i])

@@ -260,11 +260,15 @@ class Simulation:
         except Exception:
             eng.close()
             raise
-        records = LazyRecords(eng, stats["sink_received"], keep_engine=bool(probe_where))
+        # a few probes: their samples come down now (microseconds each) and nothing pins the engine beyond the Sink records; many
+        # (a Probe on every one of 65 536 Servers): they stay on the device until a Data is read, and every unread Data keeps the
+        # engine alive through the LazyRecords it holds (a Data read after the Simulation was dropped found a closed engine)
+        lazy_probes = len(probe_where) > 256
+        records = LazyRecords(eng, stats["sink_received"], keep_engine=lazy_probes)
         self._records = records                 # (keeps the device buffers alive as long as the Simulation, or until fetched)
         write_back_plain(g.plain, stats, records, device=self._device)
         if probe_where:
-            write_back_plain_probes(self._probes, probe_where, eng)    # samples stay on the device until a Data is read
+            write_back_plain_probes(self._probes, probe_where, records, lazy=lazy_probes)
         self._events_cancelled = 0
         self._engine_summary = es
         self._events_processed = es.events_processed

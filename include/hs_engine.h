@@ -359,7 +359,10 @@ int hs_engine_reset(hs_engine *h);
  * end_ns (one-event overshoot included).  Re-entrant with non-decreasing end_ns (windows).  Blocks until
  * the device work is complete. */
 int hs_engine_run_until(hs_engine *h, int64_t end_ns);
-/* Same, but only enqueues the work on the engine's stream. */
+/* Same, but only enqueues the work on the engine's stream.  The results are FINAL behind hs_engine_synchronize: that is where a run
+ * that skipped the prologue (hs_engine_prologue_path) or tandem passes that met an undecided tie (hs_engine_tandem_path) are
+ * repeated on the single heap.  Every getter below (get_summary, get_lp_stats, get_net_stats, read_sink(s), read_probe(_slot),
+ * read_source_generated) finalises a pending asynchronous run first, so results read without an explicit synchronize are final too. */
 int hs_engine_run_until_async(hs_engine *h, int64_t end_ns);
 int hs_engine_synchronize(hs_engine *h);
 /* hs_engine_reset + hs_engine_run_until_async, `repeats` times back to back on the engine stream, timing

@@ -199,3 +199,15 @@ def lb_profile_spec(k):
         prof[0] = profile(rng)
     spec["profile"] = prof
     return spec
+
+
+def lb_strategy_spec(k):
+    """A random load-balancer configuration (lb_spec) under the LoadBalancer's default RoundRobin strategy (even k) or Random (odd k);
+    every fourth with probes on backend Servers / Sinks."""
+    spec = lb_probe_spec(500 + k) if k % 4 == 3 else lb_spec(1500 + k)
+    spec["name"] = f"lb_strategy_{k}"
+    spec["strategy"] = "round_robin" if k % 2 == 0 else "random"
+    spec["vnodes"], spec["n_clients"] = 1, (1 if k % 2 == 0 else spec["n_backends"])
+    if spec.get("probes"):                        # (a Source with stop_after is not probed: its ticks without Requests are not logged)
+        spec["probes"] = [pr for pr in spec["probes"] if not (pr[0] == "source" and spec.get("stop_after_s") is not None)]
+    return spec

@@ -1079,3 +1079,33 @@ def test_linked_partitions_against_the_reference_parallel_simulation(name):
     # and every PARTITION of the windowed run processes its own one event beyond end_time, the engine (one heap) a single one
     diff = summ.total_events_processed - sum(sn["packets_sent"]) - win["total_events"]
     assert -len(spec["stages"]) <= diff <= 1
+
+
+def test_probe_data_outlives_the_simulation_that_produced_it():
+    """Probe samples of a large plain-chain run stay on the device until a Data is first read; a Data read after the Simulation
+    (and its Sinks) are gone still finds the engine -- every unread Data keeps it alive -- and reads what an eager
+    read would have."""
+    import gc
+
+    def build(n):
+        sinks = [hs.Sink(f"k{i}") for i in range(n)]
+        servers = [hs.Server(f"s{i}", service_time=hs.ExponentialLatency(0.05), downstream=sinks[i]) for i in range(n)]
+        sources = [hs.Source.poisson(rate=9, target=servers[i], name=f"src{i}") for i in range(n)]
+        probes = [hs.Probe.on(servers[i], "depth", interval=0.25) for i in range(n)]
+        sim = hs.Simulation(duration=5.0, sources=sources, entities=[e for p in zip(servers, sinks) for e in p],
+                            probes=[p for p, _ in probes], seed=13)
+        return sim, [d for _, d in probes]
+
+    sim, data = build(320)                       # more than 256 probes: lazy
+    sim.run()
+    want7, want300 = list(data[7].raw_values()), list(data[300].raw_values())
+    assert len(want7) == 20
+    sim2, data2 = build(320)
+    sim2.run()
+    keep = [data2[7], data2[300]]
+    del sim2, data2
+    gc.collect()
+    assert list(keep[0].raw_values()) == want7 and list(keep[1].raw_values()) == want300
+    small, dsmall = build(8)                     # a few probes: read at once, nothing pins the engine
+    small.run()
+    assert small._records._keep is False and dsmall[3].count() == 20

@@ -380,3 +380,26 @@ def test_device_latency_stats_at_scale():
         t, cr = eng.read_sink(0)
     want = _python_latency_stats(((t - cr).astype(np.float64) / 1e9).tolist())
     assert len(t) > 400_000 and got == want
+
+
+@pytest.mark.parametrize("k", range(40))
+def test_lb_round_robin_and_random_on_random_configurations_match_oracle(k):
+    """random_specs.lb_strategy_spec: RoundRobin (the LoadBalancer's default) / Random on random topologies -- c <= 3, bounded queues,
+    stop_after, shared / per-backend Sinks, probes -- engine == oracle (the live reference agrees with the oracle on the first 24:
+    tests/test_oracle_live_reference.py)."""
+    import random_specs as RS
+
+    spec = RS.lb_strategy_spec(k)
+    g, p = H.oracle_lb_graph_ext(spec)
+    r = O.run(g, p["end_ns"], seed=spec["seed"])
+    eng, _ = H.lb_engine_for_spec(spec)
+    with eng:
+        eng.run(p["end_ns"])
+        sinks = dict(r.sinks)
+        for j, nd in enumerate(g.lb_probe_nodes):
+            t, v = sinks.pop(nd)
+            pt, pv = eng.read_probe(j)
+            np.testing.assert_array_equal(pt, t)
+            np.testing.assert_array_equal(pv, v)
+        r.sinks = sinks
+        H.compare_lb_engine_with_oracle(eng, p, r)

@@ -201,3 +201,23 @@ def test_two_requests_in_one_nanosecond_at_an_idle_single_worker_server(k):
     import tandem_specs as TS
 
     TS.run_tandem_probe_case(TS.tandem_probe_case(k))
+
+
+@pytest.mark.parametrize("first", ["summary", "lp_stats", "read_sinks"])
+def test_getters_after_an_asynchronous_run_return_the_final_results(first):
+    """hs_engine_run_until_async + a getter, with no hs_engine_synchronize in between: the getter itself finalises the run,
+    i.e. repeats it behind the prologue when a pre-run event met another event of its LP -- the same results as the blocking call,
+    whichever getter comes first."""
+    from happy_simulator_amd.engine import StationEngine
+
+    n, end, times = 64, 3_000_000_000, (300_000_000,)
+    with StationEngine(_sched_grid(n, times), mode=N.MODE_SINGLE, horizon_ns=end, seed=3) as eng:
+        eng.run_until(end)
+        want = _everything(eng, 0)
+    with StationEngine(_sched_grid(n, times), mode=N.MODE_SINGLE, horizon_ns=end, seed=3) as eng:
+        eng.run_until_async(end)
+        assert eng.prologue_path() == 1                       # nothing has looked at the results yet
+        getattr(eng, first)()
+        assert eng.prologue_path() == 2                       # ... the first look repeated the run behind the prologue
+        got = _everything(eng, 0)
+    _assert_same(want, got)

@@ -20,7 +20,7 @@ if not os.path.isdir("/root/reference/happysimulator"):
 
 sys.path.insert(0, H.GOLDEN_DIR)
 import make_golden as MG  # noqa: E402  (imports the reference through refshim)
-from random_specs import (lb_probe_spec, lb_profile_spec, lb_spec as _lb_spec, multi_source_ring_spec, multi_source_spec, ring_spec as _ring_spec, station_spec as _station_spec,  # noqa: E402
+from random_specs import (lb_probe_spec, lb_profile_spec, lb_spec as _lb_spec, lb_strategy_spec, multi_source_ring_spec, multi_source_spec, ring_spec as _ring_spec, station_spec as _station_spec,  # noqa: E402
                           tie_spec)
 
 
@@ -180,3 +180,13 @@ def test_what_the_live_linked_parallel_simulation_refuses():
         ParallelSimulation([SimulationPartition(name="A", entities=MG._server_parts(a), sources=[src]),
                             SimulationPartition(name="B", entities=MG._server_parts(b) + [sink])], duration=2.0,
                            links=[PartitionLink("A", "B", min_latency=0.05, latency=ConstantLatency(0.05))]).run()
+
+
+@pytest.mark.parametrize("k", range(24))
+def test_oracle_equals_live_reference_on_random_round_robin_and_random_load_balancers(k):
+    """The LoadBalancer's default RoundRobin strategy and Random (its `random.choice` plugged per Request) on random topologies: the
+    live reference against the oracle -- totals, per-backend statistics, every Sink record, probes, the full trace."""
+    out, meta = MG.run_lb_case(lb_strategy_spec(k))
+    gold = H.Golden.from_results(out, meta)
+    assert gold.meta["total_events"][0] > 50
+    check_oracle_against_lb_golden(gold)
