@@ -933,6 +933,7 @@ def test_probes_on_plain_chains_take_the_object_free_path_and_equal_the_general_
         sim = hs.Simulation(duration=4.0, sources=sources, entities=servers + sinks, probes=probes)
         return sim, servers, sinks, sources, data
 
+    monkeypatch.setattr(SIM, "LAZY_PROBES_MIN", 0)           # (the lazy read-back is for runs with hundreds of Probes: force it here)
     sim, servers, sinks, sources, data = build()
     summary = sim.run()
     assert sim.lowered().plain is not None and sim.lowered()._stations is None           # no Station objects were built
