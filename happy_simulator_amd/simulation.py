@@ -266,7 +266,7 @@ class Simulation:
         # a few probes: their samples come down now (microseconds each) and nothing pins the engine beyond the Sink records; many
         # (a Probe on every one of 65 536 Servers): they stay on the device until a Data is read, and every unread Data keeps the
         # engine alive through the LazyRecords it holds (a Data read after the Simulation was dropped found a closed engine)
-        lazy_probes = len(probe_where) > LAZY_PROBES_MIN
+        lazy_probes = bool(probe_where) and len(probe_where) > LAZY_PROBES_MIN
         records = LazyRecords(eng, stats["sink_received"], keep_engine=lazy_probes)
         self._records = records                 # (keeps the device buffers alive as long as the Simulation, or until fetched)
         write_back_plain(g.plain, stats, records, device=self._device)

@@ -1107,6 +1107,6 @@ def test_probe_data_outlives_the_simulation_that_produced_it():
     del sim2, data2
     gc.collect()
     assert list(keep[0].raw_values()) == want7 and list(keep[1].raw_values()) == want300
-    small, dsmall = build(8)                     # a few probes: read at once, nothing pins the engine
+    small, dsmall = build(80)                    # a few probes: read at once, nothing pins the engine
     small.run()
-    assert small._records._keep is False and dsmall[3].count() == 20
+    assert small._records._keep is False and dsmall[3].count() == 20 and dsmall[3]._lazy is None
