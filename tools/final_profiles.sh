@@ -1,0 +1,36 @@
+#!/bin/bash
+# ON THE GPU BOX (gpurun): the round's committed evidence -- rocprofv3 kernel trace + the separate PMC passes (FETCH_SIZE, WRITE_SIZE,
+# SQ_*) for the three workloads, the derived roofline JSONs bench.py quotes, and the bench lines themselves.
+#   usage: bash tools/final_profiles.sh r04        (profiles/HEAD_COMMIT must name the commit of the tree)
+R=${1:-r04}
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+T0=$(date +%s)
+mkdir -p gpurun_out/final
+export HS_PROFILE_COMMIT=$(cat profiles/HEAD_COMMIT)
+STEPS=6 bash profiles/collect.sh $R > gpurun_out/collect_$R.log 2>&1
+for k in trace fetch write sq; do cp gpurun_out/prof_$R/${R}_$k.txt profiles/; done
+cp gpurun_out/prof_$R/${R}_bench_line.json profiles/${R}_bench_line_under_rocprof.json 2>/dev/null
+python profiles/derive_roofline.py $R grid "hs_station_run<1, false, true, true>" 2 > gpurun_out/final/derive.log 2>&1
+echo "grid profile done $(( $(date +%s) - T0 )) s"
+STEPS=3 BENCH_ARGS="--workload ring" bash profiles/collect.sh ${R}ring > gpurun_out/collect_${R}ring.log 2>&1
+for k in trace fetch write sq; do cp gpurun_out/prof_${R}ring/${R}ring_$k.txt profiles/; done
+cp gpurun_out/prof_${R}ring/${R}ring_bench_line.json profiles/${R}ring_bench_line_under_rocprof.json 2>/dev/null
+python profiles/derive_roofline.py ${R}ring ring "hs_net_async<1, false, true>" 1 >> gpurun_out/final/derive.log 2>&1
+echo "ring profile done $(( $(date +%s) - T0 )) s"
+STEPS=3 BENCH_ARGS="--workload lb" bash profiles/collect.sh ${R}lb > gpurun_out/collect_${R}lb.log 2>&1
+for k in trace fetch write sq; do cp gpurun_out/prof_${R}lb/${R}lb_$k.txt profiles/; done
+cp gpurun_out/prof_${R}lb/${R}lb_bench_line.json profiles/${R}lb_bench_line_under_rocprof.json 2>/dev/null
+(cd profiles && python derive_lb_traffic.py ${R}lb) >> gpurun_out/final/derive.log 2>&1
+echo "lb profile done $(( $(date +%s) - T0 )) s"
+cp profiles/${R}*_roofline_*.json gpurun_out/final/ 2>/dev/null
+for k in trace fetch write sq; do cp profiles/${R}_$k.txt profiles/${R}ring_$k.txt profiles/${R}lb_$k.txt gpurun_out/final/ 2>/dev/null; done
+cp profiles/${R}*_bench_line_under_rocprof.json gpurun_out/final/ 2>/dev/null
+python bench.py --steps 20 --warmup 5 2> gpurun_out/final/bench_default.err | tail -1 > gpurun_out/final/${R}_bench_default.json
+python bench.py --workload ring --cpu-sample-s 6 2> gpurun_out/final/bench_ring.err | tail -1 > gpurun_out/final/${R}_bench_ring.json
+python bench.py --workload lb --cpu-sample-s 6 2> gpurun_out/final/bench_lb.err | tail -1 > gpurun_out/final/${R}_bench_lb.json
+python bench.py --n-lp 8192 --cpu-sample-s 0 --extras 0 --api-run 0 2> gpurun_out/final/bench_8192.err | tail -1 > gpurun_out/final/${R}_bench_8192.json
+python bench.py --fake-ranks 2 --cpu-sample-s 0 --steps 5 --warmup 2 2> gpurun_out/final/bench_fake2.err | tail -1 > gpurun_out/final/${R}_bench_fake_ranks_2.json
+python bench.py --workload ring --fake-ranks 2 --cpu-sample-s 0 --steps 3 --warmup 1 2> gpurun_out/final/bench_ring_fake2.err | tail -1 > gpurun_out/final/${R}_bench_ring_fake_ranks_2.json
+echo "bench done $(( $(date +%s) - T0 )) s"
+cut -c1-400 gpurun_out/final/${R}_bench_default.json
+tail -3 gpurun_out/final/derive.log
