@@ -843,8 +843,6 @@ class Probe(Entity):
     def __init__(self, target: Entity, metric: str, data: Data, interval: float = 1.0, start_time: Instant | None = None):
         if interval <= 0:
             raise ValueError("Probe interval must be positive.")                  # probe.py:29-30
-        if start_time is not None and start_time != Instant.Epoch:
-            raise NotImplementedError("a probe start_time other than the Simulation's is not lowered")
         if metric not in self._LOWERED:
             raise NotImplementedError(f"probe metric '{metric}' is an arbitrary attribute; lowered: {sorted(self._LOWERED)}")
         super().__init__(f"Probe_{target.name}_{metric}")
@@ -852,6 +850,10 @@ class Probe(Entity):
         self.metric = metric
         self.data_sink = data
         self.interval = float(interval)
+        # `start_time` only seeds the arrival-time provider, and Source.start() overwrites that with the Simulation's start time
+        # before the first tick is drawn (load/source.py:120-127): the reference samples at start + k * interval whatever it is
+        # (tests/test_oracle_live_reference.py::test_live_reference_ignores_a_probe_start_time)
+        self.start_time = start_time if start_time is not None else Instant.Epoch
 
     @classmethod
     def on(cls, target: Entity, metric: str, interval: float = 1.0):

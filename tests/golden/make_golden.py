@@ -316,7 +316,12 @@ def run_sim(spec, chain_ids, seed, want_trace):
         for j, pr in enumerate(prs):
             who, attr = PROBE_METRICS[pr[0]]
             target = {"source": handles[local][0], "server": handles[local][1], "sink": handles[local][2]}[who]
-            probe, data = Probe.on(target, attr, interval=pr[1])
+            if spec.get("probe_start_s") is not None:      # Probe(start_time=...): Source.start() overwrites it (load/source.py:127)
+                from happysimulator.instrumentation.data import Data as _Data
+                data = _Data()
+                probe = Probe(target, attr, data, interval=pr[1], start_time=Instant.from_seconds(spec["probe_start_s"]))
+            else:
+                probe, data = Probe.on(target, attr, interval=pr[1])
             data._ns = []              # Data keeps seconds; keep the exact nanoseconds beside it
 
             def add_stat(value, time, _orig=data.add_stat, _d=data):

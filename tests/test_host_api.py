@@ -338,6 +338,12 @@ def test_probes_are_lowered_onto_their_station():
         hs.Probe.on(srv, "depth", interval=0.0)
     with pytest.raises(NotImplementedError, match="arbitrary attribute"):
         hs.Probe.on(srv, "some_custom_attr")
+    # Probe(start_time=...) is accepted and changes nothing, as in the reference (Source.start() overwrites the provider's clock,
+    # load/source.py:127; tests/test_oracle_live_reference.py::test_live_reference_ignores_a_probe_start_time)
+    late = hs.Probe(srv, "depth", hs.Data(), interval=0.5, start_time=hs.Instant.from_seconds(4.0))
+    c = hs.Simulation(duration=10, sources=[src, src2], entities=[srv, sink, other, other.downstream], probes=[late, p2]).lowered().arrays()
+    assert list(c.probe_metric) == list(a.probe_metric) and list(c.probe_interval_s) == list(a.probe_interval_s)
+    assert late.start_time == hs.Instant.from_seconds(4.0)
     # several probes on one station: engine slots 0..3, in `probes=[...]` order
     more = [hs.Probe.on(t, m, interval=iv)[0] for t, m, iv in ((srv, "active_requests", 1.0), (sink, "events_received", 0.25),
                                                               (src, "generated_count", 3.0))]

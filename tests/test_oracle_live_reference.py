@@ -190,3 +190,19 @@ def test_oracle_equals_live_reference_on_random_round_robin_and_random_load_bala
     gold = H.Golden.from_results(out, meta)
     assert gold.meta["total_events"][0] > 50
     check_oracle_against_lb_golden(gold)
+
+
+@pytest.mark.parametrize("k", range(6))
+def test_live_reference_ignores_a_probe_start_time(k):
+    """`Probe(start_time=...)` seeds the probe's ConstantArrivalTimeProvider, but `Source.start()` overwrites the provider's
+    clock with the Simulation's start time before it draws the first tick (load/source.py:120-127): the live reference samples
+    at start + k * interval whatever `start_time` says.  The mirror accepts the argument and does the same."""
+    spec = next(s for s in (_station_spec(j) for j in range(7 * k, 400)) if s.get("probes") and s["mode"] != "replicas")
+    spec["trace"] = False
+    plain, meta = MG.run_case(dict(spec))
+    shifted, meta2 = MG.run_case(dict(spec, probe_start_s=0.37 * spec["end_s"]))
+    assert len(plain["probe_t_ns"]) > 0
+    for key in plain:
+        if key != "meta":                         # (the spec itself, with the extra field)
+            assert np.array_equal(plain[key], shifted[key]), key
+    check_oracle_against_station_golden(H.Golden.from_results(shifted, meta2))
