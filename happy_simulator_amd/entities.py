@@ -801,7 +801,9 @@ class Data:
         return self._vv
 
     def _val(self, v):
-        return int(v) if self._scale is None else int(v) / self._scale
+        if self._scale is None:
+            return int(v)
+        return self._scale(int(v)) if callable(self._scale) else int(v) / self._scale
 
     @property
     def values(self) -> list:
@@ -834,11 +836,31 @@ class Data:
 
 class Probe(Entity):
     """Periodic metric sampler (instrumentation/probe.py:81-164): a daemon Source that reads `getattr(target, metric)`
-    every `interval` seconds into a Data container.  Lowered metrics: Server.depth / active_requests / utilization /
+    every `interval` seconds into a Data container.  Lowered metrics: Server.depth / active_requests / utilization / available_capacity / has_capacity /
     stats_accepted / stats_dropped / requests completed, Sink.events_received, Source.generated_count."""
 
-    _LOWERED = {"depth", "active_requests", "utilization", "stats_accepted", "stats_dropped", "requests_completed",
-                "_requests_completed", "events_received", "generated_count", "_generated_count"}
+    _LOWERED = {"depth", "active_requests", "utilization", "available_capacity", "has_capacity", "stats_accepted", "stats_dropped",
+                "requests_completed", "_requests_completed", "events_received", "generated_count", "_generated_count"}
+    # Server attributes that are functions of `active_requests` and the (fixed) concurrency: the engine samples the integer,
+    # the Data container applies the reference's expression (components/server/server.py:153-173,191-200, concurrency.py:117-131)
+    _ON_ACTIVE = ("utilization", "available_capacity", "has_capacity")
+
+    @classmethod
+    def engine_metric(cls, metric: str) -> str:
+        """The counter the engine samples for `metric`."""
+        return "active_requests" if metric in cls._ON_ACTIVE else "generated_count" if metric == "_generated_count" else metric
+
+    @classmethod
+    def value_map(cls, metric: str, server):
+        """What `Data` does with a sampled integer: None = keep, a number = divide by it, a callable = apply it."""
+        if metric not in cls._ON_ACTIVE:
+            return None
+        c = int(server.concurrency)
+        if metric == "utilization":
+            return c                                        # active / limit
+        if metric == "available_capacity":
+            return lambda active: c - active                # FixedConcurrency.available
+        return lambda active: active < c                    # has_capacity(): a callable attribute, the probe calls it (probe.py:52-55)
 
     def __init__(self, target: Entity, metric: str, data: Data, interval: float = 1.0, start_time: Instant | None = None):
         if interval <= 0:

@@ -19,7 +19,7 @@ import numpy as np
 from . import _native as N
 from .engine import NetworkArrays, StationArrays
 from .entities import (ClientKeyEventProvider, ConsistentHash, ConstantLatency, ConstantRateProfile, Counter, Entity,
-                       ExponentialLatency, LatencyTracker, LinearRampProfile, LoadBalancer, NetworkLink, Random, RandomRouter,
+                       ExponentialLatency, LatencyTracker, LinearRampProfile, LoadBalancer, NetworkLink, Probe, Random, RandomRouter,
                        RoundRobin, Server, SimpleEventProvider, Sink, Source, _RecordSink)
 
 _SINKS = (Sink, Counter, LatencyTracker)
@@ -224,8 +224,7 @@ class LoweredGraph:
                     a.probe_metric_more = np.full((3, n), N.PROBE_NONE, np.uint8)
                     a.probe_interval_more = np.ones((3, n), np.float64)
                 m = pr.metric
-                code = N.PROBE_METRICS["active_requests" if m == "utilization" else
-                                       "generated_count" if m == "_generated_count" else m]
+                code = N.PROBE_METRICS[Probe.engine_metric(m)]
                 if slot == 0:
                     a.probe_metric[i], a.probe_interval_s[i] = code, pr.interval
                 else:
@@ -328,9 +327,9 @@ def attach_probes(g: LoweredGraph, probes: list) -> None:
         st = g.stations[i]
         if len(st.probes) >= 4:
             raise UnsupportedTopology(f"station of '{pr.target.name}' already has four probes (the engine's slots per station)")
-        if pr.metric != "utilization" and pr.metric not in N.PROBE_METRICS:
+        if Probe.engine_metric(pr.metric) not in N.PROBE_METRICS:
             raise UnsupportedTopology(f"probe '{pr.name}': metric '{pr.metric}' is not sampled on the engine "
-                                      f"(lowered: {', '.join(sorted(N.PROBE_METRICS))}, utilization)")
+                                      f"(lowered: {', '.join(sorted(Probe._LOWERED))})")
         kinds = {"generated_count": Source, "_generated_count": Source, "events_received": _SINKS}
         want = kinds.get(pr.metric, Server)
         if not isinstance(pr.target, want):
@@ -365,15 +364,15 @@ def plain_probe_arrays(pc: "PlainChains", probes: list, arrays):
         slot = int(used[i])
         if slot >= 4:
             raise UnsupportedTopology(f"station of '{pr.target.name}' already has four probes (the engine's slots per station)")
-        if pr.metric != "utilization" and pr.metric not in N.PROBE_METRICS:
+        if Probe.engine_metric(pr.metric) not in N.PROBE_METRICS:
             raise UnsupportedTopology(f"probe '{pr.name}': metric '{pr.metric}' is not sampled on the engine "
-                                      f"(lowered: {', '.join(sorted(N.PROBE_METRICS))}, utilization)")
+                                      f"(lowered: {', '.join(sorted(Probe._LOWERED))})")
         if not isinstance(pr.target, kinds.get(pr.metric, Server)):
             raise UnsupportedTopology(f"probe '{pr.name}': metric '{pr.metric}' is not an attribute of {type(pr.target).__name__}")
         used[i] = slot + 1
-        metric[slot, i] = N.PROBE_METRICS["active_requests" if pr.metric == "utilization" else pr.metric]
+        metric[slot, i] = N.PROBE_METRICS[Probe.engine_metric(pr.metric)]
         interval[slot, i] = pr.interval
-        where.append((i, slot, pc.servers[i].concurrency if pr.metric == "utilization" else None))
+        where.append((i, slot, Probe.value_map(pr.metric, pc.servers[i])))
     arrays.probe_metric, arrays.probe_interval_s = metric[0].copy(), interval[0].copy()
     if (used > 1).any():
         arrays.probe_metric_more, arrays.probe_interval_more = metric[1:].copy(), interval[1:].copy()
@@ -398,7 +397,7 @@ def write_back_probes(g: LoweredGraph, eng) -> None:
     for i, st in enumerate(g.stations):
         for slot, pr in enumerate(st.probes):
             t, v = eng.read_probe(i, slot)
-            pr.data_sink._set(t, v, st.server.concurrency if pr.metric == "utilization" else None)
+            pr.data_sink._set(t, v, Probe.value_map(pr.metric, st.server))
 
 
 def write_back_shared_sink_probes(g: LoweredGraph) -> None:
@@ -734,7 +733,7 @@ class LbGraph:
                 kinds.append(0)
                 idx.append(next(j for j, b in enumerate(self.backends) if b is pr.target))
                 m = pr.metric
-                met.append(N.PROBE_METRICS["active_requests" if m == "utilization" else m])
+                met.append(N.PROBE_METRICS[Probe.engine_metric(m)])
             elif isinstance(pr.target, Source):
                 kinds.append(2)
                 idx.append(next(j for j, x in enumerate(self.sources) if x is pr.target))
@@ -863,9 +862,9 @@ def attach_lb_probes(g: LbGraph, probes: list) -> None:
     for pr in probes or []:
         if not isinstance(pr, Probe):
             raise UnsupportedTopology(f"probe {type(pr).__name__} is not a lowered Probe")
-        if pr.metric != "utilization" and pr.metric not in N.PROBE_METRICS:
+        if Probe.engine_metric(pr.metric) not in N.PROBE_METRICS:
             raise UnsupportedTopology(f"probe '{pr.name}': metric '{pr.metric}' is not sampled on the engine "
-                                      f"(lowered: {', '.join(sorted(N.PROBE_METRICS))}, utilization)")
+                                      f"(lowered: {', '.join(sorted(Probe._LOWERED))})")
         if any(pr.target is b for b in g.backends):
             if pr.metric in ("generated_count", "_generated_count", "events_received"):
                 raise UnsupportedTopology(f"probe '{pr.name}': metric '{pr.metric}' is not an attribute of Server")
@@ -888,7 +887,7 @@ def write_back_lb(g: LbGraph, stats: dict, eng) -> None:
     """Engine results -> the user's objects, under the reference's attribute names."""
     for j, pr in enumerate(g.probes):
         t, v = eng.read_probe(j)
-        pr.data_sink._set(t, v, pr.target.concurrency if pr.metric == "utilization" else None)
+        pr.data_sink._set(t, v, Probe.value_map(pr.metric, pr.target))
     for i, s in enumerate(g.sources):
         s._generated_count = int(stats["generated"][i])
     lb = g.lb

@@ -21,6 +21,7 @@ import numpy as np
 from . import _native as N
 from .core.temporal import Instant
 from .engine import StationArrays, StationEngine
+from .entities import Probe
 from .lowering import UnsupportedTopology, write_back, write_back_probes
 from .simulation import Simulation, entity_summaries
 from .summary import SimulationSummary
@@ -120,7 +121,7 @@ def write_back_probes_sharded(g, sn) -> None:
         if stn.probes and any(s.lo <= i < s.hi for s in sn.shards):
             for slot, pr in enumerate(stn.probes):
                 t, v = sn.read_probe(i, slot)
-                pr.data_sink._set(t, v, stn.server.concurrency if pr.metric == "utilization" else None)
+                pr.data_sink._set(t, v, Probe.value_map(pr.metric, stn.server))
 
 
 class _LpOffset:

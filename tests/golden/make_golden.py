@@ -68,7 +68,9 @@ EV = {"source": 0, "enqueue": 1, "notify": 2, "poll": 3, "deliver": 4, "work": 5
 PROBE_METRICS = {"depth": ("server", "depth"), "active_requests": ("server", "active_requests"),
                  "stats_accepted": ("server", "stats_accepted"), "stats_dropped": ("server", "stats_dropped"),
                  "requests_completed": ("server", "_requests_completed"), "events_received": ("sink", "events_received"),
-                 "generated_count": ("source", "generated_count")}
+                 "generated_count": ("source", "generated_count"),
+                 # functions of active_requests and the concurrency (live tests only: the engine samples active_requests)
+                 "available_capacity": ("server", "available_capacity"), "has_capacity": ("server", "has_capacity")}
 
 
 # ---- Seam-3 plug-ins (ours; they only choose the random numbers) ------------------------

@@ -950,6 +950,30 @@ def test_probes_on_plain_chains_take_the_object_free_path_and_equal_the_general_
     assert sum(len(v) for v in fast[0]) > 1000
 
 
+def test_capacity_probes_are_the_references_functions_of_active_requests():
+    """`available_capacity`, the callable `has_capacity` and `utilization` are sampled as `active_requests` on the engine and
+    mapped by the Data container with the reference's expressions (server.py:153-173,191-200; the live relation is pinned by
+    tests/test_oracle_live_reference.py::test_live_reference_capacity_probes_are_functions_of_active_requests)."""
+    sinks = [hs.Sink(f"k{i}") for i in range(12)]
+    servers = [hs.Server(f"s{i}", concurrency=1 + i % 3, service_time=hs.ExponentialLatency(0.12), downstream=sinks[i]) for i in range(12)]
+    sources = [hs.Source.poisson(rate=9 + i, target=servers[i], name=f"src{i}") for i in range(12)]
+    probes, data = [], []
+    for sv in servers:
+        ps, ds = hs.Probe.on_many(sv, ["active_requests", "available_capacity", "has_capacity", "utilization"], interval=0.05)
+        probes += ps; data.append(ds)
+    hs.Simulation(duration=5.0, sources=sources, entities=servers + sinks, probes=probes).run()
+    seen_full = 0
+    for sv, ds in zip(servers, data):
+        c = sv.concurrency
+        act = ds["active_requests"].raw_values()
+        assert len(act) == 100 and ds["available_capacity"].times() == ds["active_requests"].times()
+        assert ds["available_capacity"].raw_values() == [c - a for a in act]
+        assert ds["has_capacity"].raw_values() == [a < c for a in act]
+        assert ds["utilization"].raw_values() == [a / c for a in act]
+        seen_full += sum(a == c for a in act)
+    assert seen_full > 50
+
+
 # ---- X2 pinned to the reference's OWN ParallelSimulation(...).run() (fixtures: tests/golden/make_golden.py PARALLEL_CASES) --------------
 def test_parallel_simulation_equals_the_reference_known_answer_tests():
     """The configurations of the reference's own tests (tests/integration/test_parallel_simulation.py:75-109,239-289) -- constant

@@ -599,6 +599,12 @@ def test_plain_probe_arrays_equal_the_per_station_lowering():
     np.testing.assert_array_equal(fast.probe_order, [at[id(p)][0] for p in probes])
     np.testing.assert_array_equal(fast.probe_slot_order, [at[id(p)][1] for p in probes])
     assert [w[2] for w in where] == [p.target.concurrency if p.metric == "utilization" else None for p in probes]
+    # Server attributes that are functions of active_requests: one engine counter, three value maps
+    caps = hs.Probe.on_many(entities[0], ["available_capacity", "has_capacity", "utilization"], interval=0.5)[0]
+    assert {hs.Probe.engine_metric(p.metric) for p in caps} == {"active_requests"}
+    f = [hs.Probe.value_map(p.metric, hs.Server("c3", concurrency=3)) for p in caps]
+    assert [f[0](a) for a in range(4)] == [3, 2, 1, 0] and [f[1](a) for a in range(4)] == [True, True, True, False] and f[2] == 3
+    assert hs.Probe.value_map("depth", entities[0]) is None
     # what the fast path leaves to the general lowering / refuses like it
     other = hs.Server("elsewhere", service_time=hs.ExponentialLatency(0.1))
     assert L.plain_probe_arrays(pc, [hs.Probe.on(other, "depth")[0]], L.StationArrays.uniform(80)) is None

@@ -206,3 +206,27 @@ def test_live_reference_ignores_a_probe_start_time(k):
         if key != "meta":                         # (the spec itself, with the extra field)
             assert np.array_equal(plain[key], shifted[key]), key
     check_oracle_against_station_golden(H.Golden.from_results(shifted, meta2))
+
+
+@pytest.mark.parametrize("k", range(6))
+def test_live_reference_capacity_probes_are_functions_of_active_requests(k):
+    """`Server.available_capacity` (= limit - active, concurrency.py:129-131) and the callable `Server.has_capacity` (the probe
+    calls it: probe.py:52-55; active < limit, concurrency.py:117-127) sampled by the live reference == the mirror's value maps
+    applied to the live `active_requests` samples of the same run (probes draw no random numbers: same trajectory)."""
+    import happy_simulator_amd as hs
+
+    spec = next(s for s in (_station_spec(j) for j in range(5 * k, 400)) if s["mode"] != "replicas" and s["downstream"])
+    spec["trace"] = False
+    n = spec["n_chains"]
+    conc = spec["concurrency"] if isinstance(spec["concurrency"], (list, tuple)) else [spec["concurrency"]] * n
+    spec["probes"] = [["active_requests", 0.05 * spec["end_s"]]] * n
+    base, _ = MG.run_case(dict(spec))
+    for metric in ("available_capacity", "has_capacity"):
+        out, _ = MG.run_case(dict(spec, probes=[[metric, 0.05 * spec["end_s"]]] * n))
+        assert np.array_equal(out["probe_t_ns"], base["probe_t_ns"]) and np.array_equal(out["probe_off"], base["probe_off"])
+        for c in range(n):
+            lo, hi = int(base["probe_off"][c]), int(base["probe_off"][c + 1])
+            srv = hs.Server(f"s{c}", concurrency=int(conc[c]))
+            f = hs.Probe.value_map(metric, srv)
+            assert [int(f(int(a))) for a in base["probe_v"][lo:hi]] == [int(v) for v in out["probe_v"][lo:hi]], (metric, c)
+            assert hi > lo
