@@ -1975,7 +1975,8 @@ int run_async(hs_lb *h, int64_t end_ns) {
             case 2: launch_backends<2>(h, end_ns, h->flags); break;
             case 4: launch_backends<4>(h, end_ns, h->flags); break;
             case 8: launch_backends<8>(h, end_ns, h->flags); break;
-            default: launch_backends<16>(h, end_ns, h->flags); break;
+            case 16: launch_backends<16>(h, end_ns, h->flags); break;
+            default: launch_backends<32>(h, end_ns, h->flags); break;    // (the 32 slots' departure times do not fit the register file: they live in scratch)
         }
     }
     if (h->Q.n > 0) {     // probes: the ticks of this run and the pending one beyond end; then the samples of everything but a
@@ -2110,7 +2111,7 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     for (int j = 0; j < B; ++j) {
         const int c = be->concurrency ? be->concurrency[j] : 1;
         if (c < 1) return lfail(nullptr, HS_E_INVALID, "backend %d: max_concurrent must be >= 1, got %d", j, c);
-        if (c > 16) return lfail(nullptr, HS_E_UNSUPPORTED, "backend %d: concurrency %d > 16 is not lowered yet", j, c);
+        if (c > 32) return lfail(nullptr, HS_E_UNSUPPORTED, "backend %d: concurrency %d > 32 is not lowered yet", j, c);
         maxc = std::max(maxc, c);
         const int vk = be->svc_kind ? be->svc_kind[j] : HS_LAT_CONSTANT;
         if (vk != HS_LAT_EXPONENTIAL && vk != HS_LAT_CONSTANT) return lfail(nullptr, HS_E_UNSUPPORTED, "backend %d: service distribution kind %d is not lowered", j, vk);
@@ -2126,7 +2127,7 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     hs_lb *h = new (std::nothrow) hs_lb();
     if (!h) return lfail(nullptr, HS_E_INVALID, "out of host memory");
     h->cfg = *cfg;
-    h->C = maxc <= 1 ? 1 : maxc <= 2 ? 2 : maxc <= 4 ? 4 : maxc <= 8 ? 8 : 16;
+    h->C = maxc <= 1 ? 1 : maxc <= 2 ? 2 : maxc <= 4 ? 4 : maxc <= 8 ? 8 : maxc <= 16 ? 16 : 32;
     h->tb = bit_length((uint64_t)cfg->horizon_ns);
     h->bb = bit_length((uint64_t)(B - 1));
     if (h->tb + h->bb > 64 || h->tb > 56) { delete h; return lfail(nullptr, HS_E_UNSUPPORTED, "horizon x backends do not fit the 64-bit sort key"); }

@@ -832,8 +832,8 @@ def lower_lb(sources: list, entities: list, lb: LoadBalancer) -> LbGraph:
             raise UnsupportedTopology(f"backend '{b.name}' is a {type(b).__name__}: only Server backends are lowered")
         if not isinstance(b.service_time, (ExponentialLatency, ConstantLatency)):
             raise UnsupportedTopology(f"backend '{b.name}': service distribution {type(b.service_time).__name__} is not lowered")
-        if b.concurrency > 16:
-            raise UnsupportedTopology(f"backend '{b.name}': concurrency {b.concurrency} > 16 is not lowered yet")
+        if b.concurrency > 32:
+            raise UnsupportedTopology(f"backend '{b.name}': concurrency {b.concurrency} > 32 is not lowered yet")
         d = b.downstream
         if d is not None and not isinstance(d, _SINKS):
             raise UnsupportedTopology(f"backend '{b.name}' forwards to {type(d).__name__}: only Sink-like collectors")

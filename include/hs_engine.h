@@ -105,7 +105,7 @@ typedef struct hs_stations {
     const uint8_t *src_kind;           /* hs_source_kind; NULL = HS_SRC_POISSON */
     const double *src_rate;            /* events/s; required when any source exists */
     const int64_t *src_stop_after_ns;  /* < 0 = never; NULL = never */
-    const int32_t *concurrency;        /* NULL = 1 */
+    const int32_t *concurrency;        /* 1..32; NULL = 1 */
     const uint8_t *svc_kind;           /* hs_latency_kind; NULL = HS_LAT_CONSTANT */
     const double *svc_mean_s;          /* NULL = 0.01 */
     const int64_t *queue_cap;          /* < 0 = unbounded; NULL = unbounded */
@@ -435,7 +435,7 @@ typedef struct hs_lb_sources {     /* [n_sources] each; NULL = documented defaul
 } hs_lb_sources;
 
 typedef struct hs_lb_backends {    /* [n_backends] each */
-    const int32_t *concurrency;        /* NULL = 1 */
+    const int32_t *concurrency;        /* 1..32; NULL = 1 */
     const uint8_t *svc_kind;           /* hs_latency_kind; NULL = HS_LAT_CONSTANT */
     const double *svc_mean_s;          /* NULL = 0.01 */
     const int64_t *queue_cap;          /* < 0 = unbounded */

@@ -89,6 +89,20 @@ def lb_spec(k):
         seed=int(rng.integers(1, 10_000)), trace=True)
 
 
+def lb_workers_spec(k):
+    """A load-balancer configuration whose backends have up to 32 workers, loaded so that most of them are busy."""
+    rng = np.random.default_rng(8800 + k)
+    S, B = int(rng.integers(2, 6)), int(rng.integers(1, 5))
+    conc = [int(rng.choice([1, 7, 16, 17, 24, 32])) for _ in range(B)]
+    mean = float(rng.choice([0.4, 0.8]))
+    load = float(rng.uniform(0.7, 1.3)) * sum(conc) / mean
+    return dict(
+        name=f"live_lb_workers_{k}", topology="lb", n_sources=S, n_backends=B, rate=[float(np.round(load / S, 2))] * S, mean=mean,
+        concurrency=conc, queue_cap=None if rng.random() < 0.5 else int(rng.integers(0, 5)),
+        vnodes=int(rng.choice([3, 40])), n_clients=int(rng.choice([50, 5000])), shared_sink=bool(rng.random() < 0.5),
+        end_s=float(np.round(rng.uniform(3.0, 5.0), 3)), seed=int(rng.integers(1, 10_000)), trace=True)
+
+
 def tie_spec(k):
     """Tie storms: lock-step constant-rate sources, constant service times that are multiples of one another, Requests
     scheduled at the start instant and at the sources' own tick times, c up to 16, zero-capacity queues -- every same-nanosecond

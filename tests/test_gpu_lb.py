@@ -101,6 +101,11 @@ SWEEP = [
     dict(name="round_robin_c2_cap", strategy="round_robin", n_sources=12, n_backends=5, rate=30.0, mean=0.02, concurrency=[1, 2, 1, 3, 1],
          queue_cap=[None, 2, None, None, 1], vnodes=1, n_clients=1, end_s=5.0, seed=10, shared_sink=False),
     dict(name="random", strategy="random", n_sources=30, n_backends=17, rate=30.0, mean=0.02, vnodes=1, n_clients=17, end_s=6.0, seed=11),
+    # many workers per backend, loaded so that most slots are busy: hs_lbk_backends<16> and <32> (the 32 slots' state lives in scratch)
+    dict(name="c16_workers", n_sources=10, n_backends=6, rate=22.0, mean=0.5, concurrency=[16, 9, 12, 1, 16, 5], queue_cap=[None, 2, None, 0, 4, None],
+         vnodes=20, n_clients=400, end_s=6.0, seed=12, shared_sink=False),
+    dict(name="c32_workers", n_sources=12, n_backends=7, rate=30.0, mean=0.6, concurrency=[32, 17, 24, 1, 32, 20, 3], queue_cap=[None, 2, None, 0, 6, None, 1],
+         vnodes=20, n_clients=400, end_s=6.0, seed=13),
 ]
 
 

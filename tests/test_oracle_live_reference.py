@@ -20,7 +20,7 @@ if not os.path.isdir("/root/reference/happysimulator"):
 
 sys.path.insert(0, H.GOLDEN_DIR)
 import make_golden as MG  # noqa: E402  (imports the reference through refshim)
-from random_specs import (lb_probe_spec, lb_profile_spec, lb_spec as _lb_spec, lb_strategy_spec, multi_source_ring_spec, multi_source_spec, ring_spec as _ring_spec, station_spec as _station_spec,  # noqa: E402
+from random_specs import (lb_probe_spec, lb_profile_spec, lb_spec as _lb_spec, lb_strategy_spec, lb_workers_spec, multi_source_ring_spec, multi_source_spec, ring_spec as _ring_spec, station_spec as _station_spec,  # noqa: E402
                           tie_spec)
 
 
@@ -230,3 +230,11 @@ def test_live_reference_capacity_probes_are_functions_of_active_requests(k):
             f = hs.Probe.value_map(metric, srv)
             assert [int(f(int(a))) for a in base["probe_v"][lo:hi]] == [int(v) for v in out["probe_v"][lo:hi]], (metric, c)
             assert hi > lo
+
+
+@pytest.mark.parametrize("k", range(8))
+def test_oracle_equals_live_reference_on_load_balancers_with_up_to_32_workers_per_backend(k):
+    out, meta = MG.run_lb_case(lb_workers_spec(k))
+    gold = H.Golden.from_results(out, meta)
+    assert gold.meta["total_events"][0] > 500
+    check_oracle_against_lb_golden(gold)
