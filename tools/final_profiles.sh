@@ -7,10 +7,17 @@ cd ${GRAFT_REPO_ROOT:-$(pwd)}
 T0=$(date +%s)
 mkdir -p gpurun_out/final
 export HS_PROFILE_COMMIT=$(cat profiles/HEAD_COMMIT)
-STEPS=6 bash profiles/collect.sh $R > gpurun_out/collect_$R.log 2>&1
+STEPS=6 BENCH_ARGS="--extras 0" bash profiles/collect.sh $R > gpurun_out/collect_$R.log 2>&1
 for k in trace fetch write sq; do cp gpurun_out/prof_$R/${R}_$k.txt profiles/; done
 cp gpurun_out/prof_$R/${R}_bench_line.json profiles/${R}_bench_line_under_rocprof.json 2>/dev/null
 python profiles/derive_roofline.py $R grid "hs_station_run<1, false, true, true>" 2 > gpurun_out/final/derive.log 2>&1
+# the driver's own command (default flags: grid + ring + LB + strong shard in one line), kernel trace only
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_${R}default -o ${R}default -- python $GRAFT_REPO_ROOT/bench.py > $GRAFT_REPO_ROOT/gpurun_out/prof_${R}default.log 2>&1)
+f=$(ls gpurun_out/prof_${R}default/*_results.db 2>/dev/null | head -1)
+[ -n "$f" ] && python profiles/summarize_rocprof.py $f > profiles/${R}default_trace.txt 2>&1
+grep -h '"metric"' gpurun_out/prof_${R}default.log | tail -1 > profiles/${R}default_bench_line_under_rocprof.json
+cp profiles/${R}default_trace.txt profiles/${R}default_bench_line_under_rocprof.json gpurun_out/final/ 2>/dev/null
+rm -rf gpurun_out/prof_${R}default
 echo "grid profile done $(( $(date +%s) - T0 )) s"
 STEPS=3 BENCH_ARGS="--workload ring" bash profiles/collect.sh ${R}ring > gpurun_out/collect_${R}ring.log 2>&1
 for k in trace fetch write sq; do cp gpurun_out/prof_${R}ring/${R}ring_$k.txt profiles/; done
