@@ -302,7 +302,7 @@ def ring_main(args, ctx):
                 "bound": "valu", "kernel": "hs_net_async<1>" if async_engine else "hs_net_window<1>",
                 "achieved": algo_bytes / step_s / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": algo_bytes / step_s / 1e9 / HBM_PEAK_GBS,
-                "traffic": prof.get("hbm_bytes_per_launch") if (prof and prof.get("current") and async_engine) else None,
+                "traffic": prof.get("hbm_bytes_per_launch") if (prof and prof.get("current") and async_engine and n_ranks == 1 and args.n_lp == 65536) else None,   # (the profile is of the one-engine 65 536-station run)
                 "valu": None if not (prof and async_engine and "valu_busy_frac" in prof) else {
                     "busy_frac": prof["valu_busy_frac"], "wait_frac": prof.get("wait_frac_of_wave_cycles"),
                     "waves_per_simd": prof.get("waves_per_simd"), "kernel_us_under_rocprof": prof.get("kernel_us_rocprof"),

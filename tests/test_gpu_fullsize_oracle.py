@@ -62,10 +62,15 @@ def test_ring_65536_stations_10s_equals_the_oracle(engine_flags, ring_oracle):
         _check_against_oracle(RING_SPEC, eng, r, nodes)
 
 
-def test_lb_32768_backends_3s_equals_the_oracle():
+@pytest.mark.parametrize("strategy", ["chash", "round_robin", "random"])
+def test_lb_32768_backends_3s_equals_the_oracle(strategy):
     """BASELINE configs[4] at its size (32 768 sources -> LoadBalancer(ConsistentHash(150)) -> 32 768 servers -> one Sink),
-    3 s: the md5 ring, every routing decision, every backend's statistics and the shared Sink's record order."""
+    3 s: the md5 ring, every routing decision, every backend's statistics and the shared Sink's record order -- and the same
+    graph behind the LoadBalancer's default RoundRobin (the device sort of all ~590 000 Requests into the LoadBalancer's
+    processing order) and behind Random."""
     spec = dict(n_sources=32768, n_backends=32768, rate=6.0, mean=0.1, vnodes=150, n_clients=1 << 20, end_s=3.0, seed=42)
+    if strategy != "chash":
+        spec.update(strategy=strategy, vnodes=1, n_clients=1)
     g, p = H.oracle_lb_graph(spec)
     r = O.run(g, p["end_ns"], seed=spec["seed"])
     eng, p = H.lb_engine_for_spec(spec)
