@@ -50,7 +50,9 @@ struct hs_engine {
     // events than there are pre-run events, can the second counter change an order -- and the prologue is one lane for the whole
     // engine (65 536 chains with a Probe each: 2.2 s before a 3 ms run).  A station engine therefore runs WITHOUT it first; the
     // kernels report the coincidences (Totals::undecided bit 2), and only then is the run repeated, window by window, behind the
-    // prologue (prologue_fallback).  Debug flag 1 << 16 keeps the prologue in every run.
+    // prologue (prologue_fallback).  Debug flag 1 << 16 keeps the prologue in every run.  Round 4: network engines driven with
+    // hs_engine_run_until do the same (NetStation::run_group reports the coincidences, messages included) -- a 16 384-station ring with
+    // a Probe per station spent 0.5 s on the single lane before a run of milliseconds; shards of a partitioned network keep it.
     bool lazy_prologue = false, lazy_failed = false;
     int64_t n_init = 0;            // pre-run events of the engine
     std::vector<int64_t> window_ends;   // tandem queues: the end times of the run_until calls since the last reset (replayed on the single heap)
@@ -358,7 +360,8 @@ int do_reset_async(hs_engine *h) {
 }
 
 bool lazy_active(const hs_engine *h) {
-    return h->lazy_prologue && !h->lazy_failed && !h->is_net && !h->exact_only && (h->flags & (1 << 16)) == 0;
+    // (a shard of a partitioned network is driven window by window / round by round from outside: it keeps the eager prologue)
+    return h->lazy_prologue && !h->lazy_failed && !(h->is_net && h->net_global) && !h->exact_only && (h->flags & (1 << 16)) == 0;
 }
 
 // the prologue of a run (hs_exact.hpp); a no-op launch once it has handed over
@@ -1473,6 +1476,7 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
     if (h->is_net) {
         if (h->net_global) return fail(h, HS_E_STATE, "a shard of a partitioned network is driven with hs_engine_shard_*");
         if (h->net_ran) return fail(h, HS_E_STATE, "network engine: one hs_engine_run_until per hs_engine_reset");
+        if (lazy_active(h)) h->window_ends.push_back(end_ns);
         int rc = launch_prologue(h, end_ns);
         if (rc) return rc;
         rc = run_net_async(h, end_ns);
@@ -1542,9 +1546,9 @@ int prologue_fallback(hs_engine *h) {
     for (int64_t e : ends) {
         rc = launch_prologue(h, e);
         if (rc) return rc;
-        launch_run_dispatch(h, e);
+        if (h->is_net) { rc = run_net_async(h, e); if (rc) return rc; }
+        else { launch_run_dispatch(h, e); h->launches++; }
         HS_HIP(h, hipGetLastError());
-        h->launches++;
     }
     HS_HIP(h, hipEventRecord(h->ev_k1, h->stream));
     HS_HIP(h, hipEventRecord(h->ev_b, h->stream));

@@ -929,6 +929,7 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF, UNI> &S, const 
 #pragma unroll
     for (int j = 0; j < kMaxProbes; ++j) { S.p_metric[j] = kProbeNone; S.PA[j] = kInfNs; S.seqP[j] = 0; S.crtP[j] = 0; S.p_arr[j] = 0; S.p_n[j] = 0; S.tab_p[j] = nullptr; S.rcP[j] = INT64_MIN; }
     S.prof_kind = kProfConstant; S.tab_a = nullptr; S.tab_cap = P.tabs != nullptr ? P.tabs->cap : 0;
+    S.undecided = 0;
     S.SA = kInfNs; S.sc_i = S.sc_end = 0; S.sc_t = P.sched_t; S.sc_idx = P.sched_idx;
     S.n_xsrc = 0; S.x_base = P.stream_base[lp]; S.xs_min = kInfNs; S.xp = &P; S.xx = &X; S.x_n_lp = n;
     if constexpr (PF) {
@@ -1200,6 +1201,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
             }
         }
         store_net<C>(S, X, NX, lp, n);
+        if (S.undecided) atomicOr(&tot->undecided, S.undecided);
     }
 
     unsigned vals[13];
@@ -1590,6 +1592,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             groups_before = n_groups;
         }
         store_net<C, true, PF, UNI>(S, X, NX, lp, n);
+        if constexpr (PF) { if (S.undecided) atomicOr(&tot->undecided, S.undecided); }
         if (!UNI && max_iters > 0 && !done) atomicAdd(&tot->not_done, 1ull);
         if constexpr (PF) {      // probe events straight to the totals (rare LPs)
             if (S.evp[0]) atomicAdd(&tot->ev[13], (unsigned long long)S.evp[0]);

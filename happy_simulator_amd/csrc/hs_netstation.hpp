@@ -260,6 +260,7 @@ struct NetStation {
     int64_t tab_cap;
     // Simulation.schedule(): Requests injected before run() (hs_station.hpp); they precede every run-time event of their ns
     int64_t SA, sc_i, sc_end;
+    int undecided;                // Totals::undecided bit 2, this LP (run_group)
     const int64_t *sc_t;
     const uint32_t *sc_idx;       // true sort indices of the injected Requests (after the prologue, hs_exact.hpp), or null
     // logs
@@ -1327,6 +1328,24 @@ struct NetStation {
         if (has_probe() && probe_at(t)) n_at += 2;                       // a probe tick: always the general path
         if (has_sched() && SA == t) n_at += 2;                           // so is a scheduled Request
         if (has_xsrc() && xsrc_at(t)) n_at += 2;                         // and a tick of a further Source
+        if constexpr (PF) {
+            // Totals::undecided bit 2 (as Station::pick_root, hs_station.hpp): a root constructed BEFORE run() -- a first tick, a
+            // Probe's first tick, a scheduled Request -- beside any other root of this nanosecond (a message counts).  Their order
+            // is what the prologue's true sort indices decide; an engine that skipped the prologue repeats the run behind it
+            // (hs_engine.hip lazy_prologue).  Lone roots cannot tie, and every group with two roots comes through here.
+            int cnt = 0;                                                     // (n_at above is a path selector, not a count)
+            bool pre = false;
+            if (A == t) { ++cnt; pre = rcA == INT64_MIN; }
+#pragma unroll
+            for (int i = 0; i < C; ++i) cnt += (D[i] == t) ? 1 : 0;
+            if (bmin == t) for (int i = 0; i < bag_n; ++i) cnt += bg_t(i) == t ? 1 : 0;
+#pragma unroll
+            for (int j = 0; j < kMaxProbes; ++j) if (j < n_probes && PA[j] == t) { ++cnt; pre = pre || rcP[j] == INT64_MIN; }
+            if (has_sched() && SA == t) { ++cnt; pre = true; if (sc_i + 1 < sc_end && sc_t[sc_i + 1] == t) ++cnt; }
+            if (has_xsrc() && xsrc_at(t))
+                for (int j = 0; j < n_xsrc; ++j) if (xx->XA[xo(j)] == t) { ++cnt; pre = pre || xx->rcX[xo(j)] == INT64_MIN; }
+            if (pre && cnt >= 2) undecided |= 4;
+        }
         if (n_at == 1 && !force_general) {
             bool general = false, want_poll = false, have_created = false;
             int64_t created = 0;

@@ -307,10 +307,11 @@ int hs_engine_tandem_path(const hs_engine *h);
 /* The prologue (csrc/hs_exact.hpp): the reference numbers the events constructed before run() -- the Sources' and Probes' first
  * ticks, Requests injected with Simulation.schedule() -- first and restarts the count for the run's own events
  * (core/simulation.py:77,145-160), so a run-time event can sort BEFORE a pre-run event of its nanosecond.  Engines with Probes,
- * scheduled Requests or several Sources per Server replay that on a single-heap loop.  A station engine (HS_MODE_SINGLE, no
- * network) skips it at first and repeats the run behind it only if a pre-run event shared its nanosecond with another event of
- * its LP, or the run was shorter than the pre-run events are many.  0: the engine has no prologue, 1: skipped so far,
- * 2: it runs (debug flag 1 << 16 makes it run always). */
+ * scheduled Requests or several Sources per Server replay that on a single-heap loop -- one lane for the whole engine.  A station
+ * engine and (since ABI 12's round) a network engine driven with hs_engine_run_until skip it at first and repeat the run behind it
+ * only if a pre-run event shared its nanosecond with another event of its LP (an arriving message counts), or the run was shorter
+ * than the pre-run events are many; shards of a partitioned network (hs_engine_shard_*) keep it.  0: the engine has no prologue,
+ * 1: skipped so far, 2: it runs (debug flag 1 << 16 makes it run always). */
 int hs_engine_prologue_path(const hs_engine *h);
 
 int hs_engine_create(const hs_config *cfg, hs_engine **out);

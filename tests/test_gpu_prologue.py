@@ -221,3 +221,118 @@ def test_getters_after_an_asynchronous_run_return_the_final_results(first):
         assert eng.prologue_path() == 2                       # ... the first look repeated the run behind the prologue
         got = _everything(eng, 0)
     _assert_same(want, got)
+
+
+# ---- networks (round 4): the asynchronous / windowed network engines skip the prologue too ---------------------------------------
+def _probed_ring(n, end_s, *, lockstep=False, schedule=True):
+    """A ring with a Probe on most stations (some with three), Requests injected with schedule() and a few extra constant Sources;
+    `lockstep`: station 1 gets a constant 4 /s Source whose FIRST tick (0.25 s) falls on its Probe's first tick -- two pre-run
+    events on one nanosecond of one LP."""
+    probes = [None if i % 7 == 6 else [["depth", 0.25], ["active_requests", 0.1], ["stats_accepted", 0.35]] if i % 5 == 0
+              else ["depth", 0.25] for i in range(n)]
+    more = [[["constant", 4.0]] if (lockstep and i == 1) else [["constant", 3.0]] if i % 11 == 4 else None for i in range(n)]
+    if lockstep:
+        probes[1] = ["depth", 0.25]
+    spec = dict(name=f"probed_ring_{n}", topology="ring", n=n, ext_rate=[0.0 if i % 13 == 12 else 5.0 for i in range(n)], mean=0.1,
+                lat_min=0.001, jitter_mean=0.006, end_s=end_s, seed=29, probes=probes, more_sources=more)
+    if schedule:
+        spec["schedule"] = [[i, end_s * (0.11 + 0.2 * k) + 1e-9 * (i % 5)] for i in range(2, n, 17) for k in range(3)]
+    return spec
+
+
+def _ring_everything(eng, spec):
+    s, st, ns = eng.summary(), eng.lp_stats(), eng.net_stats()
+    counts, t, cr = eng.read_sinks()
+    probes = []
+    for i, pr in enumerate(spec["probes"]):
+        for j in range(0 if pr is None else len(pr) if isinstance(pr[0], list) else 1):
+            probes.append(eng.read_probe(i, j))
+    return s, st, ns, counts, t, cr, probes
+
+
+def _assert_same_ring(a, b):
+    sa, sta, nsa, ca, ta, cra, pa = a
+    sb, stb, nsb, cb, tb, crb, pb = b
+    assert sa.events_processed == sb.events_processed and sa.final_time_ns == sb.final_time_ns
+    np.testing.assert_array_equal(sa.events_by_kind, sb.events_by_kind)
+    for k in sta:
+        np.testing.assert_array_equal(sta[k], stb[k], err_msg=k)
+    for k in nsa:
+        np.testing.assert_array_equal(nsa[k], nsb[k], err_msg=k)
+    np.testing.assert_array_equal(ca, cb)
+    np.testing.assert_array_equal(ta, tb)
+    np.testing.assert_array_equal(cra, crb)
+    assert len(pa) == len(pb) and len(pa) > 0
+    for (t1, v1), (t2, v2) in zip(pa, pb):
+        np.testing.assert_array_equal(t1, t2)
+        np.testing.assert_array_equal(v1, v2)
+
+
+@pytest.mark.parametrize("engine_flags", [0, 16], ids=["async", "windowed"])
+def test_probed_rings_skip_the_prologue_and_match_it(engine_flags):
+    """Probes, scheduled Requests and further Sources on a 300-station ring: no pre-run event shares its nanosecond with another
+    event of its station, so the network engine runs without the single-lane prologue (path 1) -- and gives exactly what the run
+    behind the prologue gives (debug flag 1 << 16), sample for sample."""
+    import helpers as H
+
+    spec = _probed_ring(300, 4.0)
+    eng, p = H.ring_engine_for_spec(spec, flags=engine_flags)
+    with eng:
+        eng.run_until(p["end_ns"])
+        assert eng.prologue_path() == 1
+        lazy = _ring_everything(eng, spec)
+    eng, p = H.ring_engine_for_spec(spec, flags=engine_flags | FORCE_PROLOGUE)
+    with eng:
+        eng.run_until(p["end_ns"])
+        assert eng.prologue_path() == 2
+        eager = _ring_everything(eng, spec)
+    _assert_same_ring(lazy, eager)
+    assert lazy[0].events_processed > 50_000
+
+
+@pytest.mark.parametrize("engine_flags", [0, 16], ids=["async", "windowed"])
+def test_a_ring_station_whose_probe_meets_a_pre_run_tick_repeats_the_run_behind_the_prologue(engine_flags):
+    """A constant Source's first tick on the nanosecond of its station's first Probe tick: the run reports the coincidence
+    (Totals::undecided bit 2, NetStation::run_group) and is repeated behind the prologue (path 2) -- the results are those of an
+    engine that never skipped it, and the oracle's."""
+    import helpers as H
+    from oracle import hs_oracle as O
+
+    spec = _probed_ring(40, 3.0, lockstep=True, schedule=False)
+    eng, p = H.ring_engine_for_spec(spec, flags=engine_flags)
+    with eng:
+        eng.run_until(p["end_ns"])
+        assert eng.prologue_path() == 2
+        got = _ring_everything(eng, spec)
+    eng, p = H.ring_engine_for_spec(spec, flags=engine_flags | FORCE_PROLOGUE)
+    with eng:
+        eng.run_until(p["end_ns"])
+        eager = _ring_everything(eng, spec)
+    _assert_same_ring(got, eager)
+    g, nodes = H.oracle_ring_graph(spec)
+    r = O.run(g, p["end_ns"], seed=spec["seed"])
+    assert got[0].events_processed == r.events_processed and got[0].final_time_ns == r.final_time_ns
+    np.testing.assert_array_equal(got[0].events_by_kind, r.events_by_kind)
+
+
+def test_a_probe_on_every_station_of_a_large_ring_no_longer_costs_the_single_lane_prologue():
+    """VERDICT r3 'one-lane cliffs': 16 384 stations with a Probe each = 32 768 pre-run events, ~17 us each on the prologue's single
+    lane (0.5 s) before a run of a few milliseconds.  The skipped path must be at least 20x faster than the forced prologue, and equal."""
+    import helpers as H
+
+    n = 16384
+    spec = dict(name="probed_ring_16k", topology="ring", n=n, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, end_s=2.0,
+                seed=31, probes=[["depth", 0.5]] * n)
+    out = {}
+    for name, flags in (("lazy", 0), ("eager", FORCE_PROLOGUE)):
+        eng, p = H.ring_engine_for_spec(spec, flags=flags)
+        with eng:
+            eng.run_until(p["end_ns"])                       # (warm-up: code objects, first touch)
+            eng.reset()
+            t0 = time.perf_counter()
+            eng.run_until(p["end_ns"])
+            out[name] = (time.perf_counter() - t0, eng.prologue_path(), _ring_everything(eng, spec))
+    assert out["lazy"][1] == 1 and out["eager"][1] == 2
+    _assert_same_ring(out["lazy"][2], out["eager"][2])
+    print(f"probed ring, {n} stations: {out['lazy'][0] * 1e3:.1f} ms without the prologue, {out['eager'][0] * 1e3:.1f} ms behind it")
+    assert out["lazy"][0] * 20 < out["eager"][0]

@@ -57,7 +57,9 @@ def test_ring_engine_matches_reference_golden(name, engine_flags):
         assert s.final_time_ns == gold.meta["final_ns"][0]
         assert s.window_ns > 0 and s.launches > 1
         if engine_flags == 0:               # reset (+ the start-instant prologue) + ONE cooperative launch + the election,
-            assert s.launches <= 5          # also with probes, time-varying profiles and scheduled Requests
+            # also with probes, time-varying profiles and scheduled Requests; a run that met a pre-run event on the nanosecond of
+            # another event of its station was repeated behind the prologue (round 4: networks skip it first, path 2 = repeated)
+            assert s.launches <= (5 if eng.prologue_path() != 2 else 9)
         if "trace" in gold.arrays:
             np.testing.assert_array_equal(s.events_by_kind, np.bincount(gold.trace[:, 1], minlength=len(s.events_by_kind)))
         for k, g in (("generated", "generated"), ("accepted", "accepted"), ("dropped", "dropped"),
@@ -228,7 +230,7 @@ def test_profiles_and_schedule_on_large_rings_match_oracle(n, engine_flags):
         eng.run_until(p["end_ns"])
         _check_against_oracle(spec, eng, r, nodes)
         assert r.events_processed > 30 * n
-        assert (eng.summary().launches <= 5) == (engine_flags == 0)      # the asynchronous engine: one cooperative launch
+        assert (eng.summary().launches <= (5 if eng.prologue_path() != 2 else 9)) == (engine_flags == 0)      # the asynchronous engine: one cooperative launch
 
 
 @ENGINES
