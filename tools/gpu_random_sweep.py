@@ -82,7 +82,7 @@ def multi_source_ring_windowed(k):
 
 
 def _lb(spec, flags=0):
-    g, p = H.oracle_lb_graph(spec)
+    g, p = H.oracle_lb_graph_ext(spec)
     r = O.run(g, p["end_ns"], seed=spec["seed"])
     eng, _ = H.lb_engine_for_spec(spec, flags=flags)
     with eng:
@@ -98,7 +98,15 @@ def _lb(spec, flags=0):
 
 
 def lb(k):
-    _lb(RS.lb_spec(k), flags=(0, 1, 2, 4)[k % 4])
+    _lb(RS.lb_spec(k), flags=(0, 1, 2, 4, 64, 128, 256, 8)[k % 8])
+
+
+def lb_strategies(k):          # RoundRobin (the default) / Random (round 4)
+    _lb(RS.lb_strategy_spec(k), flags=(0, 64, 2)[k % 3])
+
+
+def lb_workers(k):             # backends with up to 32 workers (round 4)
+    _lb(RS.lb_workers_spec(k))
 
 
 def lb_probes(k):
@@ -130,7 +138,7 @@ def tandem_probes(k):
 
 
 FAMILIES = [station, tie, multi_source, ring_async, ring_windowed, multi_source_ring_async, multi_source_ring_windowed, lb,
-            lb_probes, lb_profiles, tandem, tandem_fan_in, tandem_probes]
+            lb_probes, lb_profiles, lb_strategies, lb_workers, tandem, tandem_fan_in, tandem_probes]
 # (round 2 listed 13 tie storms here -- the cross-LP election of the one event beyond end_time, closed by the lineage key)
 KNOWN = set()
 # refused by design (HS_E_UNSUPPORTED), never guessed: a probe on the nanosecond of an event of its target on a load-balancer
