@@ -674,7 +674,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     if ((rc = upload<uint8_t>(h, &h->P.probe_metric, pm.data(), (size_t)n * kMaxProbes, 255))) return rc;
     if ((rc = upload<double>(h, &h->P.probe_rate, prate.data(), (size_t)n * kMaxProbes, 1.0))) return rc;
     h->P.tabs = nullptr;
-    if (h->any_timevarying || h->any_probe || !tandem.empty()) {
+    if (h->any_timevarying || h->any_probe || !tandem.empty() || h->any_xsrc) {
         // Tick tables (hs_tables.hpp): one row per time-varying Source (Poisson ones draw from their own arrival stream;
         // deterministic ones with equal parameters share a row) and one per distinct Probe interval (a Probe's tick times are a
         // property of (interval, start) alone).
@@ -742,6 +742,16 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
             HS_HIP(h, hipMemset(tt.inj_i, 0, (size_t)kMaxUp * (size_t)n * sizeof(int64_t)));
             for (int64_t **col : {&tt.fw_rc, &tt.fw_rrc, &tt.fw_rdr, &tt.fw_dep}) if ((rc = dev_alloc(h, col, (size_t)n * (size_t)cap))) return rc;
             for (int64_t **col : {&tt.q_rrc, &tt.q_rdr, &tt.q_pay}) if ((rc = dev_alloc(h, col, (size_t)n * (size_t)kQCap))) return rc;
+            if ((rc = dev_alloc(h, &tt.cand_key, (size_t)n * 4))) return rc;
+            HS_HIP(h, hipMemset(tt.cand_key, 0, (size_t)n * 4 * sizeof(int64_t)));
+        }
+        if (tandem.empty() && h->any_xsrc && h->cfg.mode == HS_MODE_SINGLE) {
+            // several Sources per Server: a pending DEPARTURE's last election key is the construction rank of the Source its lineage
+            // goes back to, which the engine does not carry -- cand_rank() uses the LP's first-listed Source.  When the election of
+            // the event beyond end_ns comes down to that key for such a candidate (every other key ties with another LP's), the run
+            // is repeated on the single heap (Totals::undecided bit 1, tandem_fallback) instead of guessing.  Found by
+            // tools/gpu_random_sweep.py, multi_source case 22522: two lock-step constant Sources in different LPs, the other LP's
+            // first-listed Source a Poisson one constructed earlier.
             if ((rc = dev_alloc(h, &tt.cand_key, (size_t)n * 4))) return rc;
             HS_HIP(h, hipMemset(tt.cand_key, 0, (size_t)n * 4 * sizeof(int64_t)));
         }
@@ -927,7 +937,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         h->xs_host = XState{};
         h->xs_host.heap_cap = n_init + (int64_t)n * (h->C + 16) + 1024;
         h->xs_host.pool_cap = 2 * n_init + 16 * (int64_t)n + 1024;
-        if (!tandem.empty())       // a whole run: one list cell per admitted Request
+        if (!tandem.empty() || h->any_xsrc)       // a whole run (tandem queues; several Sources per Server after an undecided election): one list cell per admitted Request
             h->xs_host.pool_cap = std::min<int64_t>(h->xs_host.pool_cap + (int64_t)n * cap, (int64_t)1 << 30);
         if ((rc = dev_alloc(h, &h->xs_host.heap, (size_t)h->xs_host.heap_cap))) return rc;
         if ((rc = dev_alloc(h, &h->xs_host.qhead, (size_t)n))) return rc;
@@ -1484,7 +1494,7 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
     } else {
         if (h->n_pass > 0 && ((h->flags & (1 << 17)) || ((h->flags & (1 << 16)) && h->exact_prologue)) && h->exact && h->window_ends.empty())
             h->exact_only = true;   // debug: single heap from the start (1 << 16: wherever a prologue exists -- with tandem queues that is this loop)
-        if (h->n_pass > 0 || lazy_active(h)) h->window_ends.push_back(end_ns);
+        if (h->n_pass > 0 || lazy_active(h) || (h->any_xsrc && h->exact)) h->window_ends.push_back(end_ns);
         int rc = launch_prologue(h, end_ns);
         if (rc) return rc;
         launch_run_dispatch(h, end_ns);
@@ -1510,7 +1520,8 @@ static bool lazy_hazard(hs_engine *h, bool &hazard) {
 // Tandem queues: the passes met an order between two LPs' events that their lineage key does not decide (Totals::undecided).
 // The run since the last reset is repeated, window by window, on the single-heap loop -- the reference's own algorithm.
 int tandem_fallback(hs_engine *h) {
-    if (h->n_pass == 0 || h->exact_only || !h->exact) return HS_OK;
+    // (also engines with several Sources per Server whose election rested on a departure's construction rank: set_stations)
+    if ((h->n_pass == 0 && !(h->any_xsrc && !h->is_net && h->cfg.mode == HS_MODE_SINGLE)) || h->exact_only || !h->exact) return HS_OK;
     int und = 0;
     HS_HIP(h, hipMemcpy(&und, &h->tot->undecided, sizeof und, hipMemcpyDeviceToHost));
     if (!und && lazy_active(h)) {             // (pre-run events next to tandem queues: lazy_prologue's short-run rule)
@@ -1657,8 +1668,8 @@ int hs_engine_bench_runs(hs_engine *h, int64_t end_ns, int32_t repeats, float *k
     for (auto &e : ev) hipEventDestroy(e);
     Totals t;                                                       // a timed run that overflowed is not a result
     HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
-    if (h->n_pass > 0 && !h->exact_only && t.undecided)
-        return fail(h, HS_E_UNSUPPORTED, "tandem queues: this configuration needs the single-heap path (lock-step ties); hs_engine_run_until "
+    if ((h->n_pass > 0 || h->any_xsrc) && !h->is_net && !h->exact_only && (t.undecided & 3))
+        return fail(h, HS_E_UNSUPPORTED, "tandem queues / several Sources per Server: this configuration needs the single-heap path (lock-step ties); hs_engine_run_until "
                                          "switches to it, hs_engine_bench_runs does not");
     if (t.qoverflow) return fail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
     if (t.overflow & 8) return fail(h, HS_E_HIP, "the asynchronous network engine gave up waiting for a neighbour (bounded spin)");

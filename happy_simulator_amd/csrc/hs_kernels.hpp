@@ -668,10 +668,13 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
         }
         store_station<C, PF, UNI>(S, X, lp, n);
         if constexpr (PF) {
-            if (S.trk) {     // tandem queues: what the election's tie check reads (TickTables::cand_key), and this LP's undecided orders
+            if (P.tabs != nullptr && P.tabs->cand_key != nullptr) {
+                // tandem queues / several Sources per Server: what the election's tie check reads (TickTables::cand_key); bit 33: the
+                // candidate's construction rank is a stand-in (a departure or injected Request of an LP with several Sources)
                 int64_t *ck = P.tabs->cand_key + (size_t)lp * 4;
                 ck[0] = mine.t; ck[1] = mine.t_created; ck[2] = mine.rcrt;
-                ck[3] = (int64_t)(uint32_t)mine.depth | ((int64_t)(mine.valid ? 1 : 0) << 32);
+                ck[3] = (int64_t)(uint32_t)mine.depth | ((int64_t)(mine.valid ? 1 : 0) << 32) |
+                        ((int64_t)((mine.valid && mine.pad < 2 && S.n_xsrc > 0) ? 1 : 0) << 33);
             }
             if (S.undecided) atomicOr(&tot->undecided, S.undecided);
         }
@@ -767,19 +770,25 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
     if constexpr (PF) {
         // Tandem queues: did the election rest on the construction rank?  Then another LP's candidate shares the winner's whole
         // lineage key, and only the two events' ancestry decides which the reference pops first (Totals::undecided).
-        if (P.tabs != nullptr && P.tabs->tandem != nullptr && cur <= end_ns) {
+        // Several Sources per Server (no tandem queues): the same, but only where one of the two tying candidates ranks with a stand-in
+        // (bit 33 of its key word: hs_engine_set_stations).
+        if (P.tabs != nullptr && P.tabs->cand_key != nullptr && cur <= end_ns) {
             __syncthreads();
             const Candidate b = wave_c[0];
+            const bool any_tie = P.tabs->tandem != nullptr;
             bool tie = false;
-            if (b.valid)
+            if (b.valid) {
+                const int64_t bv = __hip_atomic_load(&P.tabs->cand_key[(size_t)b.lp * 4 + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 for (int q = tid; q < n; q += kBlock) {
                     const int64_t *ck = P.tabs->cand_key + (size_t)q * 4;
                     const int64_t t = __hip_atomic_load(&ck[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const int64_t cr = __hip_atomic_load(&ck[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const int64_t rc = __hip_atomic_load(&ck[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const int64_t dv = __hip_atomic_load(&ck[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (q != b.lp && (dv >> 32) != 0 && t == b.t && cr == b.t_created && rc == b.rcrt && (int)(uint32_t)dv == b.depth) tie = true;
+                    if (q != b.lp && ((dv >> 32) & 1) != 0 && t == b.t && cr == b.t_created && rc == b.rcrt && (int)(uint32_t)dv == b.depth &&
+                        (any_tie || (((dv | bv) >> 33) & 1) != 0)) tie = true;
                 }
+            }
             if (tie) atomicOr(&tot->undecided, 2);
         }
     }

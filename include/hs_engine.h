@@ -159,7 +159,11 @@ typedef struct hs_stations {
      * the run starts with the prologue (csrc/hs_exact.hpp): the first ticks of an LP's Sources carry consecutive pre-run sort
      * indices, which run-time events of the same nanosecond can overtake.  source_slot_order[k] = slot of the k-th entry of
      * source_order (an LP with several Sources appears several times there); NULL = every entry is slot 0.  Also on networked
-     * stations (both network engines and shards).  NULL = one Source per LP at most. */
+     * stations (both network engines and shards).  NULL = one Source per LP at most.
+     * The election of the one event beyond end_ns: a pending DEPARTURE of a Server with several Sources ranks by its LP's
+     * first-listed Source -- a stand-in for the Source its lineage goes back to.  A station engine (HS_MODE_SINGLE) notices when the
+     * election comes down to that key and repeats the run on the single-heap loop (exact, one lane: hs_engine_prologue_path() == 2
+     * afterwards); the network engines and shards use the stand-in as it is (no case found in 6 000 random several-Source rings). */
     const uint8_t *src_more_kind;      /* [3][n_lp] hs_source_kind; HS_SRC_NONE = none */
     const double *src_more_rate;       /* [3][n_lp] */
     const int64_t *src_more_stop_after_ns; /* [3][n_lp] < 0 = never; NULL = never */

@@ -39,3 +39,15 @@ def test_a_tick_ranks_by_its_own_source_position():
     rows = _run("--family", "multi_source", "--first", "1300", "--count", "100")
     assert 1374 in rows["engine before the GPU sweep: (created, LP's first-listed Source)"]
     assert rows["engine: (created, rank)"] == []
+
+
+def test_a_departure_of_a_server_with_several_sources_ranks_with_a_stand_in_and_such_ties_go_to_the_single_heap():
+    """Round 4, found by the GPU sweep (multi_source_spec(22522)): two lock-step constant Sources of different Servers, the winner a
+    DEPARTURE whose Server's first-listed Source is another (earlier constructed) one -- the construction rank of a non-tick is a
+    stand-in once a Server has several Sources.  The engine now repeats such a run on the single heap when the election comes down to
+    that key (csrc/hs_engine.hip set_stations, csrc/hs_kernels.hpp tie check): the rule catches the case, and no case slips past it."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "election_rules.py"), "--family", "multi_source", "--first", "22500",
+                          "--count", "60"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = [ln for ln in out.stdout.splitlines() if "round-4 rule" in ln][0]
+    assert "would have been wrong [22522]" in line and "wrong and NOT caught: 0 []" in line, line

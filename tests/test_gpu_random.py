@@ -73,7 +73,10 @@ def test_network_engines_match_oracle_on_random_specs(k, engine_flags):
 # (time, creation time) at the one event beyond end_time; the election's last key must be the position of the ticking Source
 # itself in `sources=[...]` (csrc/hs_station.hpp cand_rank), not of its LP's first-listed Source -- and a Probe's tick ranks
 # behind every Source on the network engines too.
-ELECTION_REGRESSIONS_STATION = [1374]
+# 22522 (round 4): the winner is a DEPARTURE of a Server with several Sources, whose construction rank is a stand-in (its LP's
+# first-listed Source, here a Poisson one constructed before the other LP's lock-step constant Source): the election reports the tie
+# and the run is repeated on the single heap (csrc/hs_engine.hip set_stations; tests/test_election_rules.py)
+ELECTION_REGRESSIONS_STATION = [1374, 22522]
 ELECTION_REGRESSIONS_RING = [1068, 1084, 1282]
 
 

@@ -33,6 +33,7 @@ from oracle import hs_oracle as O  # noqa: E402
 
 EV_SOURCE, EV_ENQUEUE, EV_CONTINUATION, EV_PROBE_TICK = 0, 1, 6, 13
 
+ENGINE_KEY = "(created, depth, root created, rank; Probes by their own list position)"
 KEYS = {
     "engine before the GPU sweep: (created, LP's first-listed Source)": lambda c: (c["crt"], c["old_rank"]),
     "engine: (created, rank)": lambda c: (c["crt"], c["rank"]),
@@ -120,6 +121,9 @@ def candidates(spec, rows, runs):
                             old_rank=lp_first[lp] + (n if what == "probe" else 0))
             # next: a Probe's tick by the Probe's own position in `probes=[...]` (behind every Source and sourceless LP)
             best[lp]["rank2"] = best[lp]["rank"] if what != "probe" else 2 * len(order) + 2 * n + probe_pos[node]
+            # round 4: the rank of anything but a tick stands in for the rank of the Source its lineage goes back to -- exact with
+            # one Source per Server, a guess with several (csrc/hs_engine.hip set_stations: such ties go to the single heap)
+            best[lp]["amb"] = (not isinstance(what, tuple)) and what != "probe" and sum(1 for (c2, _s) in order if c2 == lp) > 1
     ref_lp = where[rows[0, 3]][0] if rows[0, 3] in where else None
     return ref_lp, list(best.values())
 
@@ -227,6 +231,7 @@ def main():
         wrong = {name: [] for name in KEYS}
         silent = {name: 0 for name in KEYS}     # ... of which between two Probes' ticks: the tick beyond end_time records nothing
         ties = skipped = 0
+        fb = {"fallbacks": 0, "missed": [], "saved": []}
         for k in range(a.first, a.first + a.count):
             if a.family == "multi_source_ring":
                 spec = RS.multi_source_ring_spec(k)
@@ -254,6 +259,15 @@ def main():
                 continue
             if len({(c["crt"]) for c in cands}) < len(cands):
                 ties += 1                            # at least two LPs' candidates were created on one nanosecond
+            if a.family in ("tie", "multi_source"):      # the engine's key + its fallback (round 4)
+                ek = lambda c: (c["crt"], c["cdepth"], c["rcrt"])
+                w = min(cands, key=KEYS[ENGINE_KEY])
+                fell_back = any(c is not w and ek(c) == ek(w) and (c.get("amb") or w.get("amb")) for c in cands)
+                fb["fallbacks"] += fell_back
+                if w["lp"] != ref_lp and not fell_back:
+                    fb["missed"].append(k)
+                if w["lp"] != ref_lp and fell_back:
+                    fb["saved"].append(k)
             for name, key in KEYS.items():
                 win = min(cands, key=key)["lp"]
                 if win != ref_lp:
@@ -268,6 +282,10 @@ def main():
               f"{ties} where two LPs' candidates share their creation nanosecond")
         for name, ks in wrong.items():
             print(f"  {name:82s} wrong on {len(ks):3d} ({silent[name]} between two Probes' ticks: nothing recorded differs): {ks[:20]}")
+        if a.family in ("tie", "multi_source"):
+            print(f"  engine key + the round-4 rule (a tie on every key but the rank, one of the two a non-tick of an LP with several Sources -> "
+                  f"single heap): {fb['fallbacks']} runs fall back, {len(fb['saved'])} of them would have been wrong {fb['saved'][:10]}, "
+                  f"wrong and NOT caught: {len(fb['missed'])} {fb['missed'][:20]}")
     return 0
 
 
