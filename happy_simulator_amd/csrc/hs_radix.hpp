@@ -95,6 +95,10 @@ __global__ void __launch_bounds__(kRadixThreads) radix_hist(const uint64_t *__re
 __global__ void __launch_bounds__(kRadixThreads) radix_scan_rows(uint32_t *__restrict__ hist, int n_tiles,
                                                                  uint32_t *__restrict__ row_total, uint32_t *__restrict__ digit_base,
                                                                  int64_t *n_out, uint32_t *__restrict__ ticket) {
+    // (round 4: 16 consecutive entries per thread through LDS -- one block-wide scan per 4 096 entries instead of one per 256: the row of
+    //  the configs[4] load balancer, 2 880 tiles, took twelve barrier-separated rounds = 22 us per launch, six launches per run)
+    constexpr int kPer = 16, kChunk = kRadixThreads * kPer;
+    __shared__ uint32_t buf[kChunk + kChunk / kPer];               // entry e at e + e / 16: a thread's 16 entries hit 16 different banks
     __shared__ uint32_t wsum[kRadixWaves];
     __shared__ uint32_t carry;
     __shared__ bool is_last;
@@ -102,10 +106,17 @@ __global__ void __launch_bounds__(kRadixThreads) radix_scan_rows(uint32_t *__res
     uint32_t *row = hist + (size_t)blockIdx.x * n_tiles;
     if (tid == 0) carry = 0;
     __syncthreads();
-    for (int c0 = 0; c0 < n_tiles; c0 += kRadixThreads) {
-        const int i = c0 + tid;
-        const uint32_t v = i < n_tiles ? row[i] : 0u;
-        uint32_t s = v;                                            // inclusive scan inside the wavefront
+    for (int c0 = 0; c0 < n_tiles; c0 += kChunk) {
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {                             // coalesced in
+            const int e = k * kRadixThreads + tid, i = c0 + e;
+            buf[e + e / kPer] = i < n_tiles ? row[i] : 0u;
+        }
+        __syncthreads();
+        uint32_t loc[kPer], v = 0;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) { loc[j] = v; v += buf[tid * (kPer + 1) + j]; }   // exclusive inside the thread, v = its total
+        uint32_t s = v;                                              // inclusive scan of the thread totals inside the wavefront
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t t = __shfl_up(s, o, 64);
@@ -115,10 +126,16 @@ __global__ void __launch_bounds__(kRadixThreads) radix_scan_rows(uint32_t *__res
         __syncthreads();
         uint32_t wbase = 0;
         for (int k = 0; k < w; ++k) wbase += wsum[k];
-        const uint32_t c = carry;
-        if (i < n_tiles) row[i] = c + wbase + s - v;
+        const uint32_t c = carry, base = c + wbase + s - v;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) buf[tid * (kPer + 1) + j] = base + loc[j];
         __syncthreads();
         if (tid == kRadixThreads - 1) carry = c + wbase + s;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {                             // coalesced out
+            const int e = k * kRadixThreads + tid, i = c0 + e;
+            if (i < n_tiles) row[i] = buf[e + e / kPer];
+        }
         __syncthreads();
     }
     if (tid == 0) {
