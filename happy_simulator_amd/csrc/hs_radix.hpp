@@ -68,6 +68,10 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
 }
 
 // hist[digit * n_tiles + tile] = number of valid elements of the tile with that digit
+// (Round 4 measured two alternatives at the configs[4] size, both bit-identical, both rejected: a TILE-major histogram -- this kernel
+//  33.6 -> 26.8 us with coalesced stores, but the scan down the columns needs two dependent phases of ~100 serial device-scope
+//  loads: 115 us against radix_scan_rows' 18; and four tiles per block with one 16-byte store per digit row: 47.6 us, a quarter of
+//  the workgroups keeps fewer loads in flight than the stores save.)
 template <typename Valid>
 __global__ void __launch_bounds__(kRadixThreads) radix_hist(const uint64_t *__restrict__ keys, const int64_t *n_ptr,
                                                             int shift, uint32_t *__restrict__ hist, int n_tiles,
