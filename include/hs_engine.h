@@ -502,7 +502,11 @@ void hs_md5(const char *msg, int64_t len, uint8_t out[16]);
 
 /* Debug: bit 0 routes every timestamp group of every backend through the general in-group FIFO path; bit 1 disables the
  * request-order loop of single-worker unbounded backends (event-order loop with its single-event fast path instead);
- * bit 2 keeps the backend streams in dense per-backend segments instead of the wave-coalesced [k][backend] layout. */
+ * bit 2 keeps the backend streams in dense per-backend segments instead of the wave-coalesced [k][backend] layout;
+ * 8: the Sources draw their own stream values; 16: look-back radix passes; 32: 32 LPs per wavefront; 64: round 3's backend pipeline
+ * instead of the segmented scan; 128: the int64 instantiation of the scan; 256: no speculated whole-ns arrival steps;
+ * 512: hs_lbk_sources instead of hs_lbk_sources_lean; 1024: the lean Source kernel gives up, so that the run repeats with
+ * hs_lbk_sources.  Every combination gives bit-identical results (tests/test_gpu_lb.py). */
 int hs_debug_lb_flags(hs_lb *h, int flags);
 
 /* Debug / tests: stable LSD radix sort of n (key, value) pairs on `device` over key bits [0, key_bits) --

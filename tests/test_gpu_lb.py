@@ -110,9 +110,10 @@ SWEEP = [
 
 
 @pytest.mark.parametrize("spec", SWEEP, ids=[s["name"] for s in SWEEP])
-@pytest.mark.parametrize("flags", [0, 64, 1, 2, 4, 8, 16, 128, 256],
+@pytest.mark.parametrize("flags", [0, 64, 1, 2, 4, 8, 16, 128, 256, 512, 1024],
                          ids=["segmented_scan", "request_order", "general_fifo", "event_order", "dense_layout", "sources_draw_their_own_values",
-                              "look_back_radix_passes", "int64_scan", "no_speculated_arrival_steps"])
+                              "look_back_radix_passes", "int64_scan", "no_speculated_arrival_steps", "full_sources_kernel",
+                              "lean_sources_kernel_gives_up_and_the_run_repeats"])
 def test_lb_engine_matches_oracle(spec, flags):
     g, p = H.oracle_lb_graph_ext(spec)
     r = O.run(g, p["end_ns"], seed=spec["seed"])
