@@ -1524,6 +1524,10 @@ int tandem_fallback(hs_engine *h) {
     if ((h->n_pass == 0 && !(h->any_xsrc && !h->is_net && h->cfg.mode == HS_MODE_SINGLE)) || h->exact_only || !h->exact) return HS_OK;
     int und = 0;
     HS_HIP(h, hipMemcpy(&und, &h->tot->undecided, sizeof und, hipMemcpyDeviceToHost));
+    if (h->n_pass == 0) {                     // several Sources per Server, no tandem queues: only the election's tie (value 2) moves the
+        und &= 2;                             // run to the single heap; a skipped prologue's hazards (value 4) are prologue_fallback's
+        if (!und) return HS_OK;
+    }
     if (!und && lazy_active(h)) {             // (pre-run events next to tandem queues: lazy_prologue's short-run rule)
         bool hazard = false;
         if (!lazy_hazard(h, hazard)) return fail(h, HS_E_HIP, "reading the totals failed");
