@@ -19,6 +19,8 @@ from .entities import (BackendInfo, ClientKeyEventProvider, ConsistentHash, Cons
                        LatencyTracker, LinearRampProfile, LoadBalancer, LoadBalancerStats, NetworkLink, NetworkLinkStats,
                        PoissonArrivalTimeProvider, Random, RandomRouter, RoundRobin, Server, ServerStats, SimpleEventProvider, Sink, Source,
                        SpikeProfile)
+from .entities import (cross_region_network, datacenter_network, internet_network, local_network, lossy_network,  # noqa: F401
+                       mobile_3g_network, mobile_4g_network, satellite_network, slow_network)
 from .lowering import UnsupportedTopology  # noqa: F401
 from .parallel import (ParallelResult, ParallelRunner, ParallelSimulation, ParallelSimulationSummary,  # noqa: F401
                        PartitionLink, RunConfig, SimulationPartition, reduce_summaries, shard_range)

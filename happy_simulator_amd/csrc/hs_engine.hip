@@ -1033,6 +1033,8 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
             return fail(h, HS_E_INVALID, "link %d: exponential jitter needs mean > 0", l);
         if (jk != HS_LAT_EXPONENTIAL && jk != HS_LAT_CONSTANT)
             return fail(h, HS_E_UNSUPPORTED, "link %d: jitter kind %d is not lowered", l, jk);
+        if (jk == HS_LAT_CONSTANT && net->link_jitter_mean_s && !(net->link_jitter_mean_s[l] >= 0.0 && net->link_jitter_mean_s[l] < 1e6))
+            return fail(h, HS_E_INVALID, "link %d: constant jitter %g s", l, net->link_jitter_mean_s[l]);
     }
     std::vector<int32_t> rt0((size_t)n, -1), rt1((size_t)n, -1), rt2((size_t)n, -1), rt3((size_t)n, -1), lof((size_t)n, -1);
     std::vector<uint8_t> rtk((size_t)n, (uint8_t)2);

@@ -444,7 +444,7 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
                 NX.link_k[l] = k + 1;
                 const double sample = __ddiv_rn(exp1_from_uniform(u), __ddiv_rn(1.0, NP.link_jit_mean[l]));
                 delay = __dadd_rn(delay, seconds_from_ns(ns_from_seconds(sample)));
-            }
+            } else delay = __dadd_rn(delay, seconds_from_ns(ns_from_seconds(NP.link_jit_mean[l])));   // ConstantLatency jitter (0: none)
             if (!(delay > 0.0)) delay = 0.0;
             xpush(S, xev(t + ns_from_seconds(delay), S.G++, XE_LINKCONT, NP.link_dst[l], e.cr, l, 0, t));
         } break;

@@ -997,6 +997,8 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF, UNI> &S, const 
             S.fl_link = l; S.fl_dst = NP.link_dst[l]; S.fl_jit = NP.link_jit_kind[l];
             S.fl_remote = SC.wend_slots != nullptr && SC.link_rank[l] != SC.rank;
             S.fl_delay0 = seconds_from_ns(ns_from_seconds(NP.link_lat_min[l]));
+            // jitter = ConstantLatency(m): + Duration.from_seconds(m).to_seconds(), no draw (link.py:195-200); m == 0: none
+            if (S.fl_jit != 0) S.fl_delay0 = __dadd_rn(S.fl_delay0, seconds_from_ns(ns_from_seconds(NP.link_jit_mean[l])));
             S.fl_lam = __ddiv_rn(1.0, NP.link_jit_mean[l]);
             S.fl_loss = NP.link_loss[l];
             S.fl_in = NX.link_in[l]; S.fl_sent = NX.link_sent[l];

@@ -44,7 +44,7 @@ struct NetParams {
     int32_t n_links;
     const int32_t *link_dst;      // [n_links] destination LP
     const double *link_lat_min;   // [n_links] ConstantLatency(latency) seconds
-    const uint8_t *link_jit_kind; // [n_links] 0 = ExponentialLatency jitter, 1 = no jitter
+    const uint8_t *link_jit_kind; // [n_links] 0 = ExponentialLatency(link_jit_mean) jitter, 1 = ConstantLatency(link_jit_mean) jitter (0: none)
     const double *link_jit_mean;  // [n_links]
     const uint64_t *link_base;    // [n_links] stream base of the link entity
     const double *link_loss;      // [n_links] NetworkLink.packet_loss_rate (0 = lossless)
@@ -744,7 +744,7 @@ struct NetStation {
             const double lam = __ddiv_rn(1.0, np->link_jit_mean[l]);
             const double sample = __ddiv_rn(exp1_from_uniform(js.next_uniform()), lam);
             delay = __dadd_rn(delay, seconds_from_ns(ns_from_seconds(sample)));        // + jitter
-        }
+        } else delay = __dadd_rn(delay, seconds_from_ns(ns_from_seconds(np->link_jit_mean[l])));   // ConstantLatency jitter (0: none)
         if (!(delay > 0.0)) delay = 0.0;                                               // max(0.0, delay)
         const int64_t t_arr = t + ns_from_seconds(delay);
         sent_min = t_arr < sent_min ? t_arr : sent_min;

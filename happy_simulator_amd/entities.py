@@ -572,7 +572,8 @@ class NetworkLinkStats:
 
 class NetworkLink(Entity):
     """Point-to-point link (components/network/link.py:36-234).  Lowered: a constant base latency > 0 (it is the
-    lookahead of the conservative windows) plus optional exponential jitter, towards a Server.  `packet_loss_rate` is
+    lookahead of the conservative windows) plus optional jitter -- ExponentialLatency (one draw per packet) or ConstantLatency (a
+    constant on top, as the reference's datacenter_network preset has it) --, towards a Server.  `packet_loss_rate` is
     lowered with the link's own Philox LOSS stream in place of the process-wide `random.random()` (link.py:131).
     `bandwidth_bps` is accepted: requests of the lowered event providers carry no payload_size, so their transmission
     time is 0 s and `bytes_transmitted` stays 0, as in the reference (link.py:209-234)."""
@@ -602,6 +603,47 @@ class NetworkLink(Entity):
     @property
     def current_utilization(self) -> float:
         return 0.0          # bandwidth is infinite on the lowered path (link.py:93-95)
+
+
+# ---- network condition presets (components/network/conditions.py:13-258): the same nine links, from one table ----------------
+_NETWORK_PRESETS = {
+    # name of the function: (default link name, base latency s, bandwidth bit/s, packet loss, jitter kind, jitter mean s)
+    "local_network": ("local", 0.0001, 1_000_000_000, 0.0, None, 0.0),
+    "datacenter_network": ("datacenter", 0.0005, 10_000_000_000, 0.0, "const", 0.0001),
+    "cross_region_network": ("cross_region", 0.050, 1_000_000_000, 0.0001, "exp", 0.005),
+    "internet_network": ("internet", 0.100, 100_000_000, 0.001, "exp", 0.020),
+    "satellite_network": ("satellite", 0.600, 10_000_000, 0.005, "exp", 0.050),
+    "mobile_3g_network": ("mobile_3g", 0.100, 2_000_000, 0.005, "exp", 0.030),
+    "mobile_4g_network": ("mobile_4g", 0.050, 20_000_000, 0.001, "exp", 0.015),
+}
+
+
+def _preset_link(key: str, name: str | None = None) -> "NetworkLink":
+    dflt, lat, bw, loss, jk, jm = _NETWORK_PRESETS[key]
+    jitter = None if jk is None else ConstantLatency(jm) if jk == "const" else ExponentialLatency(jm)
+    return NetworkLink(name=dflt if name is None else name, latency=ConstantLatency(lat), bandwidth_bps=bw, packet_loss_rate=loss,
+                       jitter=jitter)
+
+
+def local_network(name: str = "local"): return _preset_link("local_network", name)
+def datacenter_network(name: str = "datacenter"): return _preset_link("datacenter_network", name)
+def cross_region_network(name: str = "cross_region"): return _preset_link("cross_region_network", name)
+def internet_network(name: str = "internet"): return _preset_link("internet_network", name)
+def satellite_network(name: str = "satellite"): return _preset_link("satellite_network", name)
+def mobile_3g_network(name: str = "mobile_3g"): return _preset_link("mobile_3g_network", name)
+def mobile_4g_network(name: str = "mobile_4g"): return _preset_link("mobile_4g_network", name)
+
+
+def lossy_network(loss_rate: float, name: str = "lossy", base_latency: float = 0.010):
+    """conditions.py:148-178: a 100 Mbit/s link that drops `loss_rate` of its packets."""
+    if loss_rate < 0.0 or loss_rate > 1.0:
+        raise ValueError(f"loss_rate must be in [0, 1], got {loss_rate}")
+    return NetworkLink(name=name, latency=ConstantLatency(base_latency), bandwidth_bps=100_000_000, packet_loss_rate=loss_rate, jitter=None)
+
+
+def slow_network(latency_seconds: float, name: str = "slow", bandwidth_bps: float = 1_000_000):
+    """conditions.py:181-204."""
+    return NetworkLink(name=name, latency=ConstantLatency(latency_seconds), bandwidth_bps=bandwidth_bps, packet_loss_rate=0.0, jitter=None)
 
 
 class RandomRouter(Entity):

@@ -252,8 +252,8 @@ class LoweredGraph:
         jk = np.full(nl, N.LAT_CONSTANT, np.uint8)
         jm = np.zeros(nl, np.float64)
         for l, (lk, _, _) in enumerate(self.links):
-            if lk.jitter is not None:
-                jk[l] = N.LAT_EXPONENTIAL
+            if lk.jitter is not None:      # ExponentialLatency: one draw per packet; ConstantLatency: a constant on top (link.py:195-200)
+                jk[l] = N.LAT_EXPONENTIAL if isinstance(lk.jitter, ExponentialLatency) else N.LAT_CONSTANT
                 jm[l] = lk.jitter.mean
         return NetworkArrays(
             egress_kind=eg, router_target0=rt[0], router_target1=rt[1], link_of=lof,
@@ -448,7 +448,7 @@ def lower(sources: list, entities: list) -> LoweredGraph:
             raise UnsupportedTopology(
                 f"link '{lk.name}': the base latency must be a ConstantLatency > 0 -- it is the lookahead of the "
                 "conservative time windows (the reference enforces min_latency > 0 the same way, parallel/link.py:41-45)")
-        if lk.jitter is not None and not isinstance(lk.jitter, ExponentialLatency):
+        if lk.jitter is not None and not isinstance(lk.jitter, (ExponentialLatency, ConstantLatency)):
             raise UnsupportedTopology(f"link '{lk.name}': jitter {type(lk.jitter).__name__} is not lowered")
         # packet_loss_rate is lowered (the link's own LOSS stream).  bandwidth_bps is accepted as it is: requests built by
         # the lowered event providers carry no payload_size, so the transmission time (link.py:209-214) is 0 s and

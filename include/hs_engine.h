@@ -203,7 +203,8 @@ typedef struct hs_network {
     int32_t n_links;
     const int32_t *link_dst;         /* [n_links] destination station (its Server) */
     const double *link_lat_min_s;    /* [n_links] ConstantLatency seconds, > 0 */
-    const uint8_t *link_jitter_kind; /* [n_links] HS_LAT_EXPONENTIAL = exponential jitter, HS_LAT_CONSTANT = none */
+    const uint8_t *link_jitter_kind; /* [n_links] HS_LAT_EXPONENTIAL: jitter = ExponentialLatency(mean), one draw of the link's stream per
+                                      * packet; HS_LAT_CONSTANT: jitter = ConstantLatency(mean), no draw (link.py:195-200); mean 0 = jitter=None */
     const double *link_jitter_mean_s;/* [n_links] */
     const uint64_t *link_stream_base;/* [n_links] NULL = stream base of the source station */
     const int32_t *link_src;         /* [n_links] source station (for the default stream base and validation) */

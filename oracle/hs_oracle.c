@@ -586,7 +586,8 @@ static void on_route(hso_sim *s, const hso_event *e) {
  * metadata, so the transmission time (:209-214) is 0 * 8 / bandwidth = 0.0 whatever the bandwidth.
  * delay = latency.get_latency(now).to_seconds() [+ jitter.get_latency(now).to_seconds()], max(0, .)
  * (_calculate_delay :190-216).  Modelled link: latency = ConstantLatency(lat_min),
- * jitter = ExponentialLatency(lat_mean) when lat_kind == EXP, no jitter otherwise. */
+ * jitter = ExponentialLatency(lat_mean) when lat_kind == EXP, ConstantLatency(lat_mean) when lat_kind == CONST and
+ * lat_mean > 0 (the reference's datacenter_network preset, components/network/conditions.py:60-63), none otherwise. */
 static void on_link(hso_sim *s, const hso_event *e) {
     int32_t n = e->node;
     hso_node *nd = &s->nodes[n];
@@ -601,6 +602,8 @@ static void on_link(hso_sim *s, const hso_event *e) {
         double lambda = 1.0 / s->g.lat_mean[n];
         double sample = exp1(s, draw_uniform(s, n, HS_STREAM_LINK, &nd->link_draws)) / lambda;
         delay = delay + hsr_seconds_from_ns(hsr_ns_from_seconds(sample));           /* jitter */
+    } else if (s->g.lat_mean[n] > 0.0) {
+        delay = delay + hsr_seconds_from_ns(hsr_ns_from_seconds(s->g.lat_mean[n])); /* jitter = ConstantLatency(lat_mean): no draw */
     }
     if (!(delay > 0.0)) delay = 0.0;                                /* max(0.0, delay) */
     hso_event ct = {e->time + hsr_ns_from_seconds(delay), next_index(s), HSO_EV_LINK_CONT, n, e->req, 0};

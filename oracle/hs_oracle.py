@@ -197,11 +197,11 @@ class Graph:
         return self._add(kind=PROBE, target=target, arr_kind=ARR_CONSTANT, probe_metric=metric,
                          prof_kind=PROF_GENERAL_CONSTANT, prof_p=(1.0 / interval, 0.0, 0.0, 0.0))
 
-    def link(self, lat_min, jitter_mean=None, target=-1, stream_base=None, loss=0.0) -> int:
-        """NetworkLink(latency=ConstantLatency(lat_min), jitter=ExponentialLatency(jitter_mean) | None, egress=target,
-        packet_loss_rate=loss)."""
+    def link(self, lat_min, jitter_mean=None, target=-1, stream_base=None, loss=0.0, jitter_kind="exp") -> int:
+        """NetworkLink(latency=ConstantLatency(lat_min), jitter=ExponentialLatency(jitter_mean) | ConstantLatency(jitter_mean)
+        (jitter_kind="const") | None, egress=target, packet_loss_rate=loss)."""
         kw = dict(kind=LINK, lat_min=float(lat_min), target=target, loss=float(loss),
-                  lat_kind=LAT_CONST if jitter_mean is None else LAT_EXP,
+                  lat_kind=LAT_CONST if (jitter_mean is None or jitter_kind == "const") else LAT_EXP,
                   lat_mean=0.0 if jitter_mean is None else float(jitter_mean))
         if stream_base is not None:
             kw["stream_base"] = stream_base

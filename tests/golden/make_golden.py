@@ -649,8 +649,14 @@ def run_ring_case(spec):
     links, routers, sources, first_profile = [], [], [], {}
     for i in range(n):
         jit = None
-        if spec.get("jitter_mean") is not None:
-            jit = PhiloxExponentialLatency(spec["jitter_mean"], hs.Stream(seed, i, hs.STREAM_LINK))
+        jk = spec.get("jitter_kind", "exp")
+        jk = jk[i] if isinstance(jk, list) else jk
+        jm = spec.get("jitter_mean")
+        jm = jm[i] if isinstance(jm, list) else jm
+        if jm is not None and jk == "exp":
+            jit = PhiloxExponentialLatency(jm, hs.Stream(seed, i, hs.STREAM_LINK))
+        elif jm is not None and jk == "const":       # the reference's own class: no random numbers (conditions.py:60-63 uses it)
+            jit = ConstantLatency(jm)
         loss = spec.get("loss", 0.0)
         links.append(NetworkLink(f"link{i}", latency=ConstantLatency(spec["lat_min"]), jitter=jit,
                                  bandwidth_bps=spec.get("bandwidth_bps"),
@@ -1013,6 +1019,14 @@ RING_CASES = [
          queue_cap=3, lat_min=0.001, jitter_mean=None,
          more_sources=[[["constant", 5.0], ["constant", 5.0]], [["poisson", 4.0]], None, [["constant", 3.0]]],
          sources_order="extras_first", schedule=[[2, 0.2], [0, 0.2], [0, 0.4]], end_s=8.0, seed=66, trace=True),
+    # jitter = ConstantLatency (the reference's datacenter_network preset: 0.5 ms + 0.1 ms, components/network/conditions.py:60-63):
+    # a constant on top of the base latency, no random numbers; and a ring mixing the three kinds of jitter with loss
+    dict(name="ring_5_const_jitter", topology="ring", n=5, ext_rate=[9.0, 6.0, 8.0, 0.0, 7.0], mean=0.07, lat_min=0.0005,
+         jitter_mean=0.0001, jitter_kind="const", end_s=10.0, seed=91, trace=True),
+    dict(name="ring_6_mixed_jitter", topology="ring", n=6, ext_rate=[7.0, 5.0, 8.0, 6.0, 0.0, 9.0], mean=0.08, concurrency=2,
+         queue_cap=5, lat_min=0.002, jitter_mean=[0.004, 0.0013, None, 0.00025, 0.006, 0.0000007],
+         jitter_kind=["exp", "const", None, "const", "exp", "const"], loss=[0.0, 0.1, 0.0, 0.3, 0.05, 0.0],
+         probes=[["depth", 0.25], None, ["active_requests", 0.3], None, None, ["stats_accepted", 0.5]], end_s=12.0, seed=93, trace=True),
     # NetworkLink(packet_loss_rate): lost packets vanish at the link (link.py:131-138)
     dict(name="ring_8_loss", topology="ring", n=8, ext_rate=6.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, loss=0.2,
          end_s=20.0, seed=42, trace=True),

@@ -245,6 +245,9 @@ def ring_params(spec):
         n=n, ext_rate=[float(r) for r in per_chain(spec["ext_rate"], n)], mean=float(spec["mean"]),
         conc=int(spec.get("concurrency", 1)), qcap=-1 if spec.get("queue_cap") is None else int(spec["queue_cap"]),
         lat_min=float(spec["lat_min"]), jitter_mean=spec.get("jitter_mean"), end_ns=ns_from_seconds(spec["end_s"]),
+        # per link: (kind, mean) with kind "exp" | "const" | None -- spec["jitter_kind"] (default "exp") and spec["jitter_mean"] may be lists
+        jitter=[(None, 0.0) if (m is None or k is None) else (k, float(m))
+                for k, m in zip(per_chain(spec.get("jitter_kind", "exp"), n), per_chain(spec.get("jitter_mean"), n))],
         loss=[float(x) for x in per_chain(spec.get("loss", 0.0), n)], p_targets=2,
         probes=[None if pr is None else (pr[0], float(pr[1])) for pr in _first_probes(spec, n)],
         probe_list=[[(m, float(iv)) for m, iv in prs] for prs in _probe_lists(spec, n)],
@@ -292,7 +295,8 @@ def oracle_ring_graph(spec):
     for i in range(n):
         nodes[i]["srv"] = g.server(O.LAT_EXP, p["mean"], concurrency=p["conc"], queue_cap=p["qcap"], stream_base=i)
         nodes[i]["snk"] = g.sink()
-        nodes[i]["lnk"] = g.link(p["lat_min"], p["jitter_mean"], stream_base=i, loss=p["loss"][i])
+        jk, jm = p["jitter"][i]
+        nodes[i]["lnk"] = g.link(p["lat_min"], None if jk is None else jm, stream_base=i, loss=p["loss"][i], jitter_kind=jk or "exp")
         pat = (spec.get("rt_pattern") or ["sl"] * n)[i]
         nodes[i]["rtr"] = g.router([nodes[i]["snk"] if ch == "s" else nodes[i]["lnk"] for ch in pat], stream_base=i)
     for i in range(n):
@@ -503,7 +507,6 @@ def ring_arrays(spec, bag_capacity=0, log_capacity=0):
                 st.src_rate[i] = max(pr[2], pr[3]) if pr[0] == "ramp" else max(pr[1], pr[2])   # peak: sizes the logs
     if p["schedule"]:
         st.sched_off, st.sched_time_ns, st.sched_rank = sched_arrays(n, p["schedule"])
-    jit = p["jitter_mean"]
     net = NetworkArrays(
         egress_kind=np.full(n, N.EGRESS_ROUTER, np.uint8),
         **{**dict(router_target0=np.full(n, -1, np.int32),   # targets=[sink_i, link_i] unless spec["rt_pattern"] says otherwise
@@ -512,8 +515,8 @@ def ring_arrays(spec, bag_capacity=0, log_capacity=0):
         link_src=np.arange(n, dtype=np.int32),
         link_dst=((np.arange(n) + 1) % n).astype(np.int32),
         link_lat_min_s=np.full(n, p["lat_min"], np.float64),
-        link_jitter_kind=np.full(n, N.LAT_CONSTANT if jit is None else N.LAT_EXPONENTIAL, np.uint8),
-        link_jitter_mean_s=np.full(n, 0.0 if jit is None else jit, np.float64),
+        link_jitter_kind=np.array([N.LAT_EXPONENTIAL if k == "exp" else N.LAT_CONSTANT for k, _ in p["jitter"]], np.uint8),
+        link_jitter_mean_s=np.array([m for _, m in p["jitter"]], np.float64),
         link_loss_rate=np.array(p["loss"], np.float64) if any(p["loss"]) else None,
         bag_capacity=bag_capacity,
     )

@@ -103,6 +103,20 @@ def lb_workers_spec(k):
         end_s=float(np.round(rng.uniform(3.0, 5.0), 3)), seed=int(rng.integers(1, 10_000)), trace=True)
 
 
+def jitter_ring_spec(k):
+    """ring_spec(k) with every NetworkLink's jitter drawn among ExponentialLatency / ConstantLatency (incl. sub-nanosecond and
+    zero constants) / None -- the reference's presets use all three (components/network/conditions.py)."""
+    spec = ring_spec(k)
+    rng = np.random.default_rng(91_000 + k)
+    n = spec["n"]
+    kinds = [str(rng.choice(["exp", "const", "const", "none"])) for _ in range(n)]
+    spec["jitter_kind"] = [None if q == "none" else q for q in kinds]
+    spec["jitter_mean"] = [None if q == "none" else float(rng.choice([0.0001, 0.0013, 0.006, 0.0000004, 0.0])) if q == "const"
+                           else float(rng.choice([0.002, 0.006, 0.01])) for q in kinds]
+    spec["name"] = f"jitter_ring_{k}"
+    return spec
+
+
 def tie_spec(k):
     """Tie storms: lock-step constant-rate sources, constant service times that are multiples of one another, Requests
     scheduled at the start instant and at the sources' own tick times, c up to 16, zero-capacity queues -- every same-nanosecond

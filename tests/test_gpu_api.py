@@ -133,12 +133,18 @@ def _build_ring(spec):
                for i in range(n)]
     links, routers, sources = [], [], []
     for i in range(n):
-        jit = None if spec.get("jitter_mean") is None else hs.ExponentialLatency(spec["jitter_mean"])
+        jk, jm = H.per_chain(spec.get("jitter_kind", "exp"), n)[i], H.per_chain(spec.get("jitter_mean"), n)[i]
+        jit = None if (jk is None or jm is None) else hs.ExponentialLatency(jm) if jk == "exp" else hs.ConstantLatency(jm)
         loss = spec.get("loss", 0.0)
-        links.append(hs.NetworkLink(f"link{i}", latency=hs.ConstantLatency(spec["lat_min"]), jitter=jit,
-                                    bandwidth_bps=spec.get("bandwidth_bps"),
-                                    packet_loss_rate=loss[i] if isinstance(loss, list) else loss,
-                                    egress=servers[(i + 1) % n]))
+        if spec.get("name") == "ring_5_const_jitter":        # 0.5 ms + ConstantLatency(0.1 ms): the reference's datacenter preset itself
+            links.append(hs.datacenter_network(f"link{i}"))
+            links[-1].egress = servers[(i + 1) % n]
+            assert (links[-1].latency.mean, links[-1].jitter.mean) == (spec["lat_min"], jm) and isinstance(links[-1].jitter, hs.ConstantLatency)
+        else:
+            links.append(hs.NetworkLink(f"link{i}", latency=hs.ConstantLatency(spec["lat_min"]), jitter=jit,
+                                        bandwidth_bps=spec.get("bandwidth_bps"),
+                                        packet_loss_rate=loss[i] if isinstance(loss, list) else loss,
+                                        egress=servers[(i + 1) % n]))
         pat = (spec.get("rt_pattern") or ["sl"] * n)[i]
         routers.append(hs.RandomRouter(f"router{i}", targets=[sinks[i] if ch == "s" else links[i] for ch in pat]))
         servers[i].downstream = routers[i]
@@ -178,7 +184,8 @@ def _check_ring_objects(gold, servers, routers, links, sinks):
 
 
 @pytest.mark.parametrize("name", ["ring_8_s42", "ring_5_const_link", "ring_6_c2_cap3", "ring_8_loss", "ring_5_loss_mixed",
-                                  "ring_6_router_k", "ring_5_multi_source", "ring_4_multi_source_order"])
+                                  "ring_6_router_k", "ring_5_multi_source", "ring_4_multi_source_order", "ring_5_const_jitter",
+                                  "ring_6_mixed_jitter"])
 def test_ring_network_through_the_api_matches_reference_golden(name):
     gold = H.Golden(name)
     spec = gold.spec

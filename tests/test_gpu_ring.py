@@ -393,3 +393,22 @@ def test_async_engine_results_do_not_depend_on_timing():
     for _ in range(2):
         assert digest(1024)[0] == base
     assert digest(16)[0] == base                      # and the windowed engine agrees
+
+
+@ENGINES
+@pytest.mark.parametrize("k", range(24))
+def test_rings_with_constant_exponential_and_no_jitter_match_oracle(k, engine_flags):
+    """random_specs.jitter_ring_spec: every link's jitter ExponentialLatency / ConstantLatency (the reference's datacenter_network
+    preset; incl. sub-nanosecond and zero constants) / None; the live reference agrees with the oracle on the same 24 cases
+    (tests/test_oracle_live_reference.py)."""
+    import random_specs as RS
+
+    spec = RS.jitter_ring_spec(k)
+    g, nodes = H.oracle_ring_graph(spec)
+    p = H.ring_params(spec)
+    r = O.run(g, p["end_ns"], seed=spec["seed"], schedule=[(nodes[c]["srv"], t) for c, t in p["schedule"]])
+    eng, p = H.ring_engine_for_spec(spec, flags=engine_flags)
+    with eng:
+        eng.run_until(p["end_ns"])
+        _check_against_oracle(spec, eng, r, nodes)
+

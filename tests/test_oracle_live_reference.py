@@ -20,7 +20,7 @@ if not os.path.isdir("/root/reference/happysimulator"):
 
 sys.path.insert(0, H.GOLDEN_DIR)
 import make_golden as MG  # noqa: E402  (imports the reference through refshim)
-from random_specs import (lb_probe_spec, lb_profile_spec, lb_spec as _lb_spec, lb_strategy_spec, lb_workers_spec, multi_source_ring_spec, multi_source_spec, ring_spec as _ring_spec, station_spec as _station_spec,  # noqa: E402
+from random_specs import (jitter_ring_spec, lb_probe_spec, lb_profile_spec, lb_spec as _lb_spec, lb_strategy_spec, lb_workers_spec, multi_source_ring_spec, multi_source_spec, ring_spec as _ring_spec, station_spec as _station_spec,  # noqa: E402
                           tie_spec)
 
 
@@ -238,3 +238,42 @@ def test_oracle_equals_live_reference_on_load_balancers_with_up_to_32_workers_pe
     gold = H.Golden.from_results(out, meta)
     assert gold.meta["total_events"][0] > 500
     check_oracle_against_lb_golden(gold)
+
+
+@pytest.mark.parametrize("k", range(24))
+def test_oracle_equals_live_reference_on_rings_with_constant_exponential_and_no_jitter(k):
+    """NetworkLink(jitter=ConstantLatency(x)) -- the reference's datacenter_network preset (components/network/conditions.py:60-63) --
+    next to exponential jitter and none, per link: a constant on top of the base latency, no random number (link.py:195-200)."""
+    out, meta = MG.run_ring_case(jitter_ring_spec(k))
+    gold = H.Golden.from_results(out, meta)
+    assert gold.meta["total_events"][0] > 100
+    check_oracle_against_ring_golden(gold)
+
+
+def test_network_condition_presets_equal_the_live_references():
+    """components/network/conditions.py:13-258 -- nine NetworkLink presets -- against the mirror's table: every parameter."""
+    import happy_simulator_amd as hs
+    from happysimulator.components.network import conditions as RC
+
+    def params(link):
+        jit = link.jitter
+        jm = None if jit is None else getattr(jit, "mean", None)
+        if jm is None and jit is not None:
+            jm = jit._mean_latency
+        lat = getattr(link.latency, "mean", None)
+        if lat is None:
+            lat = link.latency._mean_latency
+        return (link.name, float(lat), link.bandwidth_bps, link.packet_loss_rate, None if jit is None else type(jit).__name__, None if jm is None else float(jm))
+
+    for fn in ("local_network", "datacenter_network", "cross_region_network", "internet_network", "satellite_network",
+               "mobile_3g_network", "mobile_4g_network"):
+        assert params(getattr(hs, fn)()) == params(getattr(RC, fn)()), fn
+        assert params(getattr(hs, fn)("x")) == params(getattr(RC, fn)("x")), fn
+    assert params(hs.lossy_network(0.07)) == params(RC.lossy_network(0.07))
+    assert params(hs.lossy_network(0.5, "l2", 0.2)) == params(RC.lossy_network(0.5, "l2", 0.2))
+    assert params(hs.slow_network(0.3)) == params(RC.slow_network(0.3))
+    assert params(hs.slow_network(0.3, "s2", 5e5)) == params(RC.slow_network(0.3, "s2", 5e5))
+    with pytest.raises(ValueError):
+        hs.lossy_network(1.5)
+    with pytest.raises(ValueError):
+        RC.lossy_network(1.5)

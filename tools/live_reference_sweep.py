@@ -16,7 +16,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 sys.path.insert(0, ROOT)
 
-FAMILIES = ("station", "tie", "multi_source", "ring", "multi_source_ring", "lb", "lb_probes", "lb_profiles", "tandem", "tandem_probes", "tandem_fan_in")
+FAMILIES = ("station", "tie", "multi_source", "ring", "multi_source_ring", "lb", "lb_probes", "lb_profiles", "lb_strategies", "lb_workers",
+            "tandem", "tandem_probes", "tandem_fan_in")
 
 
 def one(job):
@@ -51,7 +52,8 @@ def one(job):
             out, meta = MG.run_ring_case(spec)
             check_oracle_against_ring_golden(H.Golden.from_results(out, meta))
         else:
-            spec = {"lb": RS.lb_spec, "lb_probes": RS.lb_probe_spec, "lb_profiles": RS.lb_profile_spec}[fam](k)
+            spec = {"lb": RS.lb_spec, "lb_probes": RS.lb_probe_spec, "lb_profiles": RS.lb_profile_spec, "lb_strategies": RS.lb_strategy_spec,
+                    "lb_workers": RS.lb_workers_spec}[fam](k)
             out, meta = MG.run_lb_case(spec)
             check_oracle_against_lb_golden(H.Golden.from_results(out, meta))
         return fam, k, ""
