@@ -73,6 +73,14 @@ def ring_windowed(k):
     _ring(RS.ring_spec(k), 16)
 
 
+def jitter_ring_async(k):       # every link's jitter Exponential / Constant / None (round 4)
+    _ring(RS.jitter_ring_spec(k), 0)
+
+
+def jitter_ring_windowed(k):
+    _ring(RS.jitter_ring_spec(k), 16)
+
+
 def multi_source_ring_async(k):
     _ring(RS.multi_source_ring_spec(k), 0)
 
@@ -137,7 +145,8 @@ def tandem_probes(k):
     TS.run_tandem_probe_case(TS.tandem_probe_case(k))
 
 
-FAMILIES = [station, tie, multi_source, ring_async, ring_windowed, multi_source_ring_async, multi_source_ring_windowed, lb,
+FAMILIES = [station, tie, multi_source, ring_async, ring_windowed, jitter_ring_async, jitter_ring_windowed, multi_source_ring_async,
+            multi_source_ring_windowed, lb,
             lb_probes, lb_profiles, lb_strategies, lb_workers, tandem, tandem_fan_in, tandem_probes]
 # (round 2 listed 13 tie storms here -- the cross-LP election of the one event beyond end_time, closed by the lineage key)
 KNOWN = set()
