@@ -26,6 +26,7 @@ typedef struct {
     /* ... and its place in the FIFO that the heap is among events of one nanosecond: how many steps after the root of the group
      * it was created in (cdepth), when that root was created and how deep in ITS group (rcrt, rcdepth), and once more */
     int64_t cdepth, rcrt, rcdepth, r2crt, r2cdepth;
+    int64_t rsrc;      /* the Source / Probe node whose tick is the most recent one in the event's ancestry (its own node for a tick); -1 none */
 #endif
 } hso_event;
 
@@ -93,6 +94,7 @@ struct hso_sim {
     int64_t *tr_t; int32_t *tr_kind; int32_t *tr_node; int64_t *tr_idx; int64_t tr_len;
 #ifdef HSO_LINEAGE
     int cur_valid; int64_t cur_crt, cur_crt2;      /* the event being processed (creator of what is pushed now) */
+    int64_t cur_rsrc;                              /* ... and the tick its children descend from (hso_event::rsrc) */
     int64_t g_depth, g_rcrt, g_rcdepth, g_r2crt, g_r2cdepth;   /* ... its depth in the current group and the group's root */
     hso_event *dump; int64_t dump_len;             /* everything pending when the one event beyond end_ns was popped, it first */
 #endif
@@ -114,6 +116,7 @@ static void heap_push(hso_sim *s, hso_event e) {
     e.cdepth = s->cur_valid ? s->g_depth + 1 : 0;
     e.rcrt = s->cur_valid ? s->g_rcrt : INT64_MIN; e.rcdepth = s->cur_valid ? s->g_rcdepth : 0;
     e.r2crt = s->cur_valid ? s->g_r2crt : INT64_MIN; e.r2cdepth = s->cur_valid ? s->g_r2cdepth : 0;
+    e.rsrc = (e.kind == HSO_EV_SOURCE || e.kind == HSO_EV_PROBE_TICK) ? (int64_t)e.node : s->cur_valid ? s->cur_rsrc : -1;
 #endif
     if (s->heap_len == s->heap_cap) {
         s->heap_cap = s->heap_cap ? s->heap_cap * 2 : 1024;
@@ -881,7 +884,7 @@ int hso_run_until(hso_sim *s, int64_t end_ns) {
             memcpy(s->dump + 1, s->heap, (size_t)s->heap_len * sizeof(hso_event));
             s->dump_len = s->heap_len + 1;
         }
-        s->cur_valid = 1; s->cur_crt = e.crt; s->cur_crt2 = e.crt2;
+        s->cur_valid = 1; s->cur_crt = e.crt; s->cur_crt2 = e.crt2; s->cur_rsrc = e.rsrc;
         if (e.crt < e.time) {          /* created earlier: the root of a chain of this nanosecond's group */
             s->g_depth = 0; s->g_rcrt = e.crt; s->g_rcdepth = e.cdepth; s->g_r2crt = e.rcrt; s->g_r2cdepth = e.rcdepth;
         } else {                       /* created in this very nanosecond: it carries its group's context */
@@ -916,14 +919,14 @@ int hso_run_until(hso_sim *s, int64_t end_ns) {
 
 #ifdef HSO_LINEAGE
 /* rows of (time, sort index, kind, node, created, creator created, its creator created, cdepth, rcrt, rcdepth, r2crt,
- * r2cdepth); row 0 = the event the reference processed beyond end_ns */
+ * r2cdepth, rsrc); row 0 = the event the reference processed beyond end_ns */
 int64_t hso_read_dump(const hso_sim *s, int64_t *rows, int64_t cap) {
     const int64_t n = s->dump_len < cap ? s->dump_len : cap;
     for (int64_t i = 0; i < n; ++i) {
         const hso_event *e = &s->dump[i];
-        int64_t *r = rows + 12 * i;
+        int64_t *r = rows + 13 * i;
         r[0] = e->time; r[1] = (int64_t)e->idx; r[2] = e->kind; r[3] = e->node; r[4] = e->crt; r[5] = e->crt2; r[6] = e->crt3;
-        r[7] = e->cdepth; r[8] = e->rcrt; r[9] = e->rcdepth; r[10] = e->r2crt; r[11] = e->r2cdepth;
+        r[7] = e->cdepth; r[8] = e->rcrt; r[9] = e->rcdepth; r[10] = e->r2crt; r[11] = e->r2cdepth; r[12] = e->rsrc;
     }
     return s->dump_len;
 }

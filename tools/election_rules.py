@@ -47,6 +47,7 @@ KEYS = {
     "(created, depth, rank)": lambda c: (c["crt"], c["cdepth"], c["rank"]),
     "(created, depth, root created, rank)": lambda c: (c["crt"], c["cdepth"], c["rcrt"], c["rank"]),
     "(created, depth, root created, rank; Probes by their own list position)": lambda c: (c["crt"], c["cdepth"], c["rcrt"], c["rank2"]),
+    "(created, depth, root created, rank of the lineage's Source)": lambda c: (c["crt"], c["cdepth"], c["rcrt"], c.get("rank3", c.get("rank2", c["rank"]))),
     "(created, depth, root created, root depth, rank)": lambda c: (c["crt"], c["cdepth"], c["rcrt"], c["rcdepth"], c["rank"]),
     "(created, depth, root created, root depth, its root created, its depth, rank)":
         lambda c: (c["crt"], c["cdepth"], c["rcrt"], c["rcdepth"], c["r2crt"], c["r2cdepth"], c["rank"]),
@@ -68,7 +69,7 @@ def pending_at_overshoot(spec, run=None):
     real_destroy = L.hso_destroy
 
     def destroy(h):                                 # O.run destroys its handle: read the dump first
-        buf = np.zeros((4096, 12), np.int64)
+        buf = np.zeros((4096, 13), np.int64)
         n = L.hso_read_dump(h, buf.ctypes.data, 4096)
         got["rows"] = buf[:min(n, 4096)].copy()
         real_destroy(h)
@@ -109,7 +110,7 @@ def candidates(spec, rows, runs):
         lp_first.setdefault(c, len(lp_first))
     t_star = rows[0, 0]
     best = {}
-    for t, idx, kind, node, crt, crt2, crt3, cdepth, rcrt, rcdepth, r2crt, r2cdepth in rows:
+    for t, idx, kind, node, crt, crt2, crt3, cdepth, rcrt, rcdepth, r2crt, r2cdepth, rsrc in rows:
         if t != t_star or node not in where:
             continue
         lp, what = where[node]
@@ -124,6 +125,11 @@ def candidates(spec, rows, runs):
             # round 4: the rank of anything but a tick stands in for the rank of the Source its lineage goes back to -- exact with
             # one Source per Server, a guess with several (csrc/hs_engine.hip set_stations: such ties go to the single heap)
             best[lp]["amb"] = (not isinstance(what, tuple)) and what != "probe" and sum(1 for (c2, _s) in order if c2 == lp) > 1
+            # candidate for round 5: anything but a tick ranks by the Source whose tick is the most recent one in its ancestry
+            # (hso_event::rsrc, analysis build) -- what a device-side `root source` carried with every pending departure would give
+            rs = where.get(int(rsrc))
+            best[lp]["rank3"] = (best[lp]["rank2"] if (isinstance(what, tuple) or what == "probe" or rs is None or not isinstance(rs[1], tuple))
+                                 else src_rank[(rs[0], rs[1][1])])
     ref_lp = where[rows[0, 3]][0] if rows[0, 3] in where else None
     return ref_lp, list(best.values())
 
@@ -163,7 +169,7 @@ def ring_candidates(spec, rows, nodes):
         lp_rank.setdefault(i, len(order) + i)
     t_star = rows[0, 0]
     best = {}
-    for t, idx, kind, node, crt, crt2, crt3, cdepth, rcrt, rcdepth, r2crt, r2cdepth in rows:
+    for t, idx, kind, node, crt, crt2, crt3, cdepth, rcrt, rcdepth, r2crt, r2cdepth, rsrc in rows:
         if t != t_star or node not in where:
             continue
         lp, what = where[node]
@@ -201,7 +207,7 @@ def tandem_candidates(spec, rows, nodes):
         rank[nd] = c * 8 + st
     t_star = rows[0, 0]
     best = {}
-    for t, idx, kind, node, crt, crt2, crt3, cdepth, rcrt, rcdepth, r2crt, r2cdepth in rows:
+    for t, idx, kind, node, crt, crt2, crt3, cdepth, rcrt, rcdepth, r2crt, r2cdepth, rsrc in rows:
         if t != t_star or node not in where:
             continue
         lp = where[node]
