@@ -19,6 +19,6 @@ for flags in (0, 1 << 16, 1):
         print("  by kind", list(s.events_by_kind))
 for chain_ids, nodes, r in runs:
     print("oracle events", r.events_processed, "final", r.final_time_ns, "by kind", list(r.events_by_kind))
-    srv = [nodes[c]["srv"] for c in chain_ids]
+    srv = [nodes[c][1] for c in chain_ids]          # nodes[c] = (source, server, sink)
     for key, arr in (("accepted", r.accepted), ("dropped", r.dropped), ("completed", r.completed), ("rejected", r.rejected), ("depth", r.depth), ("active", r.active)):
         print("  orc", key, list(arr[srv]))
