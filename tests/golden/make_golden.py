@@ -790,6 +790,86 @@ def run_ring_case(spec):
     return out, meta
 
 
+def run_graph_case(spec):
+    """An arbitrary graph of the lowered entity set, reference components only (round 4: the oracle's ground for what the engines
+    still refuse -- routers with more than four targets or several upstreams, a NetworkLink with several senders, a Server behind a
+    Server inside a link network, more than four Sources per Server).  spec:
+        n_sinks; servers = [{mean, c, cap, out}], links = [{lat, jk, jm, loss, to}], routers = [{targets}], sources = [{kind, rate, to}]
+    with `out` / a router target = ["sink", j] | ["link", l] | ["router", r] | ["server", s] (`out` may be None), `to` a Server index.
+    Streams: Source k ARRIVAL base k, Server s SERVICE base s, link l LINK / LOSS base l, router r ROUTE base r."""
+    seed = spec["seed"]
+    import happysimulator.components.network.link as link_mod
+
+    link_mod.random = _PerLinkRandom
+    sinks = [Sink(f"sink{j}") for j in range(spec["n_sinks"])]
+    servers = [Server(f"srv{i}", concurrency=sv.get("c", 1),
+                      service_time=PhiloxExponentialLatency(sv["mean"], hs.Stream(seed, i, hs.STREAM_SERVICE)),
+                      queue_capacity=sv.get("cap")) for i, sv in enumerate(spec["servers"])]
+    links = []
+    for l, lk in enumerate(spec["links"]):
+        jit = None
+        if lk.get("jm") is not None and lk.get("jk") == "exp":
+            jit = PhiloxExponentialLatency(lk["jm"], hs.Stream(seed, l, hs.STREAM_LINK))
+        elif lk.get("jm") is not None and lk.get("jk") == "const":
+            jit = ConstantLatency(lk["jm"])
+        links.append(NetworkLink(f"link{l}", latency=ConstantLatency(lk["lat"]), jitter=jit, packet_loss_rate=lk.get("loss", 0.0),
+                                 egress=servers[lk["to"]]))
+        links[l]._loss_stream = hs.Stream(seed, l, hs.STREAM_LOSS)
+    routers = [None] * len(spec["routers"])
+
+    def entity(ref):
+        kind, idx = ref
+        return {"sink": sinks, "link": links, "router": routers, "server": servers}[kind][idx]
+
+    # routers may target routers: build them in an order in which every router's router-targets exist (the generator keeps them acyclic)
+    pending = list(range(len(routers)))
+    while pending:
+        progressed = False
+        for r in list(pending):
+            tg = spec["routers"][r]["targets"]
+            if all(k != "router" or routers[i] is not None for k, i in tg):
+                routers[r] = PhiloxRandomRouter(f"router{r}", targets=[entity(t) for t in tg], stream=hs.Stream(seed, r, hs.STREAM_ROUTE))
+                pending.remove(r)
+                progressed = True
+        assert progressed, "router targets form a cycle of routers"
+    for i, sv in enumerate(spec["servers"]):
+        if sv.get("out") is not None:
+            servers[i].downstream = entity(sv["out"])
+    sources = []
+    for k, sc in enumerate(spec["sources"]):
+        prof = ConstantRateProfile(rate=sc["rate"])
+        prov = (PhiloxPoissonArrival(prof, Instant.Epoch, hs.Stream(seed, k, hs.STREAM_ARRIVAL)) if sc["kind"] == "poisson"
+                else ConstantArrivalTimeProvider(prof, start_time=Instant.Epoch))
+        sources.append(Source(f"src{k}", SimpleEventProvider(servers[sc["to"]], "Request", None), prov))
+    sim = Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=sources, entities=servers + routers + links + sinks)
+    summary = sim.run()
+    out = {}
+    meta = dict(spec=spec, total_events=[summary.total_events_processed], final_ns=[sim._current_time.nanoseconds],
+                duration_s=[summary.duration_s])
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    out["generated"] = np.array([s.generated_count for s in sources], np.int64)
+    out["accepted"] = np.array([s.stats_accepted for s in servers], np.int64)
+    out["dropped"] = np.array([s.stats_dropped for s in servers], np.int64)
+    out["completed"] = np.array([s._requests_completed for s in servers], np.int64)
+    out["rejected"] = np.array([s._requests_rejected for s in servers], np.int64)
+    out["depth"] = np.array([s.depth for s in servers], np.int64)
+    out["active"] = np.array([s.active_requests for s in servers], np.int64)
+    out["total_service_s"] = np.array([s._total_service_time for s in servers], np.float64)
+    out["received"] = np.array([k.events_received for k in sinks], np.int64)
+    out["routed"] = np.array([r.stats_routed for r in routers], np.int64)
+    out["packets_sent"] = np.array([l.packets_sent for l in links], np.int64)
+    out["packets_dropped"] = np.array([l.packets_dropped for l in links], np.int64)
+    sink_t, sink_lat, off = [], [], [0]
+    for k in sinks:
+        sink_t.extend(t.nanoseconds for t in k.completion_times)
+        sink_lat.extend(k.latencies_s)
+        off.append(len(sink_t))
+    out["sink_t_ns"] = np.asarray(sink_t, np.int64)
+    out["sink_latency_s"] = np.asarray(sink_lat, np.float64)
+    out["sink_off"] = np.asarray(off, np.int64)
+    return out, meta
+
+
 def run_lb_case(spec):
     """BASELINE configs[4] in miniature, reference components only (examples/visual/chash_example.py wiring):
     S x Source(Poisson rate_i, PhiloxClientProvider) -> LoadBalancer(ConsistentHash(vnodes)) -> B x Server(c, Exp mean,
@@ -986,6 +1066,27 @@ LB_CASES = [
          concurrency=[1, 1, 2, 1, 1, 1], vnodes=1, n_clients=6, end_s=12.0, seed=34, trace=True),
     dict(name="lb_random_32src_64be", topology="lb", strategy="random", n_sources=32, n_backends=64, rate=25.0, mean=0.07,
          vnodes=1, n_clients=64, end_s=6.0, seed=35, trace=False),
+]
+
+# arbitrary graphs (run_graph_case): what the engines still refuse, pinned for the oracle -- a router with eight targets among Sinks,
+# links, Servers; links with several senders; Servers behind Servers next to links; six Sources on one Server
+GRAPH_CASES = [
+    dict(name="graph_fanout_8", topology="graph", n_sinks=2, end_s=8.0, seed=171,
+         servers=[dict(mean=0.05, c=1, cap=None, out=["router", 0]), dict(mean=0.08, c=2, cap=3, out=["router", 0]),
+                  dict(mean=0.04, c=1, cap=None, out=["link", 1]), dict(mean=0.1, c=4, cap=None, out=["sink", 1])],
+         links=[dict(lat=0.001, jk="exp", jm=0.004, loss=0.0, to=2), dict(lat=0.002, jk="const", jm=0.0005, loss=0.1, to=3),
+                dict(lat=0.0005, jk=None, jm=None, loss=0.0, to=0)],
+         routers=[dict(targets=[["sink", 0], ["link", 0], ["server", 2], ["link", 1], ["sink", 1], ["link", 0], ["server", 3], ["link", 2]])],
+         sources=[dict(kind="poisson", rate=7.0, to=0), dict(kind="poisson", rate=5.0, to=1), dict(kind="constant", rate=4.0, to=0)]),
+    dict(name="graph_shared_links_tandem", topology="graph", n_sinks=3, end_s=10.0, seed=173,
+         servers=[dict(mean=0.03, c=1, cap=None, out=["server", 1]), dict(mean=0.05, c=2, cap=4, out=["link", 0]),
+                  dict(mean=0.06, c=1, cap=None, out=["link", 0]), dict(mean=0.04, c=1, cap=2, out=["router", 1]),
+                  dict(mean=0.07, c=3, cap=None, out=["router", 0])],
+         links=[dict(lat=0.002, jk="exp", jm=0.003, loss=0.05, to=3), dict(lat=0.001, jk=None, jm=None, loss=0.0, to=4)],
+         routers=[dict(targets=[["sink", 0], ["link", 1], ["sink", 2]]), dict(targets=[["link", 1], ["sink", 1], ["server", 4], ["link", 0]])],
+         sources=[dict(kind="poisson", rate=6.0, to=0), dict(kind="poisson", rate=4.0, to=2), dict(kind="constant", rate=2.0, to=0),
+                  dict(kind="poisson", rate=3.0, to=0), dict(kind="constant", rate=2.0, to=0), dict(kind="poisson", rate=2.0, to=0),
+                  dict(kind="poisson", rate=1.0, to=0)]),
 ]
 
 RING_CASES = [
@@ -1445,6 +1546,14 @@ def main(argv):
         if only and spec["name"] not in only:
             continue
         out, meta = run_tandem_case(dict(spec))
+        path = os.path.join(HERE, spec["name"] + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{spec['name']}: events={sum(meta['total_events'])} final={meta['final_ns'][-1]} "
+              f"sink_records={len(out['sink_t_ns'])} -> {os.path.getsize(path)} B")
+    for spec in GRAPH_CASES:
+        if only and spec["name"] not in only:
+            continue
+        out, meta = run_graph_case(dict(spec))
         path = os.path.join(HERE, spec["name"] + ".npz")
         np.savez_compressed(path, **out)
         print(f"{spec['name']}: events={sum(meta['total_events'])} final={meta['final_ns'][-1]} "

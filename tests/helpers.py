@@ -17,7 +17,7 @@ def golden_names(topology="chains"):
 
     def topo(n):
         return ("ring" if n.startswith("ring_") else "lb" if n.startswith("lb_") else "tandem" if n.startswith("tandem_")
-                else "parallel" if n.startswith("parallel_") else "chains")
+                else "parallel" if n.startswith("parallel_") else "graph" if n.startswith("graph_") else "chains")
 
     return [n for n in names if topo(n) == topology]
 
@@ -310,6 +310,39 @@ def oracle_ring_graph(spec):
             who, mid = PROBE_METRICS[pr[0]]
             nodes[i]["prb" if j == 0 else f"prb{j}"] = g.probe(nodes[i][{"source": "src", "server": "srv", "sink": "snk"}[who]],
                                                               mid, pr[1])
+    return g, nodes
+
+
+def oracle_graph(spec):
+    """Oracle nodes of a graph golden (tests/golden/make_golden.py run_graph_case): sources in list order first, then sinks, servers,
+    links, routers.  Returns (graph, {"source": [...], "sink": [...], "server": [...], "link": [...], "router": [...]})."""
+    g = O.Graph()
+    nodes = {"source": [], "sink": [], "server": [], "link": [], "router": [None] * len(spec["routers"])}
+    for k, sc in enumerate(spec["sources"]):
+        nodes["source"].append(g.source(O.ARR_POISSON if sc["kind"] == "poisson" else O.ARR_CONSTANT, sc["rate"], stream_base=k))
+    for _ in range(spec["n_sinks"]):
+        nodes["sink"].append(g.sink())
+    for i, sv in enumerate(spec["servers"]):
+        nodes["server"].append(g.server(O.LAT_EXP, sv["mean"], concurrency=sv.get("c", 1),
+                                        queue_cap=-1 if sv.get("cap") is None else sv["cap"], stream_base=i))
+    for l, lk in enumerate(spec["links"]):
+        jk = lk.get("jk") if lk.get("jm") is not None else None
+        nodes["link"].append(g.link(lk["lat"], None if jk is None else lk["jm"], stream_base=l, loss=lk.get("loss", 0.0),
+                                    jitter_kind=jk or "exp"))
+    pending = list(range(len(spec["routers"])))
+    while pending:
+        for r in list(pending):
+            tg = spec["routers"][r]["targets"]
+            if all(k != "router" or nodes["router"][i] is not None for k, i in tg):
+                nodes["router"][r] = g.router([nodes[k][i] for k, i in tg], stream_base=r)
+                pending.remove(r)
+    for k, sc in enumerate(spec["sources"]):
+        g.target[nodes["source"][k]] = nodes["server"][sc["to"]]
+    for i, sv in enumerate(spec["servers"]):
+        if sv.get("out") is not None:
+            g.target[nodes["server"][i]] = nodes[sv["out"][0]][sv["out"][1]]
+    for l, lk in enumerate(spec["links"]):
+        g.target[nodes["link"][l]] = nodes["server"][lk["to"]]
     return g, nodes
 
 

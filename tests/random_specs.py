@@ -117,6 +117,52 @@ def jitter_ring_spec(k):
     return spec
 
 
+def graph_spec(k):
+    """A random graph of the lowered entity set beyond what the engines take today: routers with up to 8 targets (Sinks, links,
+    Servers, other routers) and several upstreams, links shared by several senders, Servers behind Servers next to links, up to six
+    Sources per Server -- the oracle's ground (live reference: tests/test_oracle_live_reference.py)."""
+    rng = np.random.default_rng(77_000 + k)
+    n_srv, n_snk = int(rng.integers(2, 8)), int(rng.integers(1, 4))
+    n_lnk, n_rtr = int(rng.integers(1, 6)), int(rng.integers(1, 5))
+    links = [dict(lat=float(rng.choice([0.0005, 0.001, 0.004])), jk=[None, "exp", "const"][int(rng.integers(0, 3))],
+                  jm=float(rng.choice([0.0002, 0.003, 0.008])), loss=float(rng.choice([0.0, 0.0, 0.1, 0.4])),
+                  to=int(rng.integers(0, n_srv))) for _ in range(n_lnk)]
+    for lk in links:
+        if lk["jk"] is None:
+            lk["jm"] = None
+    routers = []
+    for r in range(n_rtr):                                   # router r may target routers < r only (no router cycles)
+        tg = [["sink", int(rng.integers(0, n_snk))]]         # every router can end a Request
+        for _ in range(int(rng.integers(0, 8))):
+            kind = str(rng.choice(["sink", "link", "link", "server"] + (["router"] if r > 0 else [])))
+            tg.append([kind, int(rng.integers(0, {"sink": n_snk, "link": n_lnk, "server": n_srv, "router": max(r, 1)}[kind]))])
+        order = rng.permutation(len(tg))
+        routers.append(dict(targets=[tg[i] for i in order]))
+    servers = []
+    for i in range(n_srv):
+        kind = str(rng.choice(["router", "router", "link", "sink", "server", "none"]))
+        out = (None if kind == "none" else ["router", int(rng.integers(0, n_rtr))] if kind == "router" else
+               ["link", int(rng.integers(0, n_lnk))] if kind == "link" else ["sink", int(rng.integers(0, n_snk))] if kind == "sink" else
+               ["server", int(rng.integers(i + 1, n_srv))] if i + 1 < n_srv else ["sink", 0])   # Server -> later Server: no zero-delay cycles
+        servers.append(dict(mean=float(rng.choice([0.02, 0.05, 0.1])), c=int(rng.choice([1, 1, 2, 4])),
+                            cap=None if rng.random() < 0.6 else int(rng.integers(0, 5)), out=out))
+    # a zero-delay cycle Server -> router -> Server would never end a nanosecond: routers may target Servers only with a larger index
+    # than every Server that feeds them directly
+    for r, rt in enumerate(routers):
+        feeders = [i for i, sv in enumerate(servers) if sv["out"] == ["router", r]]
+        lo = (max(feeders) + 1) if feeders else 0
+        for t in rt["targets"]:
+            if t[0] == "server" and t[1] < lo:
+                t[0], t[1] = ("sink", int(rng.integers(0, n_snk))) if lo >= n_srv else ("server", int(rng.integers(lo, n_srv)))
+            if t[0] == "router":                             # ... and a router reached through a router inherits the constraint: keep it simple
+                t[0], t[1] = "sink", int(rng.integers(0, n_snk))
+    n_src = int(rng.integers(1, 2 * n_srv + 1))
+    sources = [dict(kind=str(rng.choice(["poisson", "poisson", "constant"])), rate=float(rng.choice([2.0, 4.0, 6.0, 9.0])),
+                    to=int(rng.integers(0, n_srv)) if rng.random() < 0.7 else 0) for _ in range(n_src)]
+    return dict(name=f"graph_{k}", topology="graph", n_sinks=n_snk, servers=servers, links=links, routers=routers, sources=sources,
+                end_s=float(np.round(rng.uniform(3.0, 8.0), 3)), seed=int(rng.integers(1, 10_000)))
+
+
 def tie_spec(k):
     """Tie storms: lock-step constant-rate sources, constant service times that are multiples of one another, Requests
     scheduled at the start instant and at the sources' own tick times, c up to 16, zero-capacity queues -- every same-nanosecond

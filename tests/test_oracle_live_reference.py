@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import helpers as H
-from test_oracle_golden import (check_oracle_against_lb_golden, check_oracle_against_ring_golden,
+from test_oracle_golden import (check_oracle_against_graph_golden, check_oracle_against_lb_golden, check_oracle_against_ring_golden,
                                 check_oracle_against_station_golden, check_oracle_against_tandem_golden)
 
 pytestmark = pytest.mark.live_reference
@@ -20,7 +20,7 @@ if not os.path.isdir("/root/reference/happysimulator"):
 
 sys.path.insert(0, H.GOLDEN_DIR)
 import make_golden as MG  # noqa: E402  (imports the reference through refshim)
-from random_specs import (jitter_ring_spec, lb_probe_spec, lb_profile_spec, lb_spec as _lb_spec, lb_strategy_spec, lb_workers_spec, multi_source_ring_spec, multi_source_spec, ring_spec as _ring_spec, station_spec as _station_spec,  # noqa: E402
+from random_specs import (graph_spec, jitter_ring_spec, lb_probe_spec, lb_profile_spec, lb_spec as _lb_spec, lb_strategy_spec, lb_workers_spec, multi_source_ring_spec, multi_source_spec, ring_spec as _ring_spec, station_spec as _station_spec,  # noqa: E402
                           tie_spec)
 
 
@@ -277,3 +277,11 @@ def test_network_condition_presets_equal_the_live_references():
         hs.lossy_network(1.5)
     with pytest.raises(ValueError):
         RC.lossy_network(1.5)
+
+
+@pytest.mark.parametrize("k", range(40))
+def test_oracle_equals_live_reference_on_random_graphs_beyond_the_engines(k):
+    """random_specs.graph_spec: routers with up to 8 targets incl. Servers and several upstreams, links with several senders, Servers
+    behind Servers inside link networks, more than four Sources per Server -- live reference == oracle."""
+    out, meta = MG.run_graph_case(graph_spec(k))
+    check_oracle_against_graph_golden(H.Golden.from_results(out, meta))

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 sys.path.insert(0, ROOT)
 
-FAMILIES = ("station", "tie", "multi_source", "ring", "multi_source_ring", "jitter_ring", "lb", "lb_probes", "lb_profiles", "lb_strategies", "lb_workers",
+FAMILIES = ("station", "tie", "multi_source", "ring", "multi_source_ring", "jitter_ring", "graph", "lb", "lb_probes", "lb_profiles", "lb_strategies", "lb_workers",
             "tandem", "tandem_probes", "tandem_fan_in")
 
 
@@ -47,6 +47,11 @@ def one(job):
                 spec["trace"] = False
             out, meta = MG.run_case(spec)
             check_oracle_against_station_golden(H.Golden.from_results(out, meta))
+        elif fam == "graph":
+            from test_oracle_golden import check_oracle_against_graph_golden
+
+            out, meta = MG.run_graph_case(RS.graph_spec(k))
+            check_oracle_against_graph_golden(H.Golden.from_results(out, meta))
         elif fam in ("ring", "multi_source_ring", "jitter_ring"):
             spec = {"ring": RS.ring_spec, "multi_source_ring": RS.multi_source_ring_spec, "jitter_ring": RS.jitter_ring_spec}[fam](k)
             out, meta = MG.run_ring_case(spec)
