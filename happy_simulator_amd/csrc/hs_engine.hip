@@ -754,6 +754,12 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
             // first-listed Source a Poisson one constructed earlier.
             if ((rc = dev_alloc(h, &tt.cand_key, (size_t)n * 4))) return rc;
             HS_HIP(h, hipMemset(tt.cand_key, 0, (size_t)n * 4 * sizeof(int64_t)));
+            // ... and the engine carries the lineage's Source with every pending departure (TickTables::rs_dep): the stand-in is then
+            // only used for departures whose lineage starts at an injected Request
+            if ((rc = dev_alloc(h, &tt.rs_dep, (size_t)n * (size_t)h->C))) return rc;
+            if ((rc = dev_alloc(h, &tt.rs_q, (size_t)n * (size_t)kQCap))) return rc;
+            HS_HIP(h, hipMemset(tt.rs_dep, 0xff, (size_t)n * (size_t)h->C));
+            HS_HIP(h, hipMemset(tt.rs_q, 0xff, (size_t)n * (size_t)kQCap));
         }
         if ((rc = upload<int32_t>(h, &tt.src_row, srow.data(), srow.size(), -1))) return rc;
         if ((rc = upload<int32_t>(h, &tt.probe_row, prow.data(), prow.size(), -1))) return rc;

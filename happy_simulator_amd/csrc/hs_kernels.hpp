@@ -153,7 +153,15 @@ __device__ __forceinline__ void load_station(Station<C, PF, UNI> &S, const Stati
 #pragma unroll
     for (int u = 0; u < kMaxUp; ++u) { S.U[u].up = -1; S.U[u].i = 0; S.U[u].n = 0; S.U[u].IA = kInfNs; S.U[u].mask = 0; }
     S.rk_dp = 0; S.rk_rank = 0; S.rk_rc = INT64_MIN; S.tie_rank_p = P.tie_rank; S.n_rank = n;
+    S.lsrc = 255u; S.rs_qp = nullptr; S.rs_dp = nullptr;
+#pragma unroll
+    for (int i = 0; i < C; ++i) S.lsrcD[i] = 255u;
     if constexpr (PF) {
+        if (P.tabs != nullptr && P.tabs->rs_dep != nullptr) {            // several Sources per Server: the lineage's Source (TickTables::rs_dep)
+            S.rs_qp = P.tabs->rs_q + lp; S.rs_dp = P.tabs->rs_dep + lp;
+#pragma unroll
+            for (int i = 0; i < C; ++i) S.lsrcD[i] = P.tabs->rs_dep[(size_t)i * n + lp];
+        }
         if (P.tabs != nullptr && P.tabs->tandem != nullptr) {            // tandem queues (hs_station.hpp `trk`)
             const TickTables &T = *P.tabs;
             S.trk = true; S.t_start = T.t_start;
@@ -226,6 +234,12 @@ __device__ __forceinline__ void store_station(const Station<C, PF, UNI> &Sc, con
         X.crtD[(size_t)i * n + lp] = S.crtD[i]; X.svc_s[(size_t)i * n + lp] = S.svc_s[i];
         if (C > 1) X.crt[(size_t)i * n + lp] = S.crt[i];
         X.dpD[(size_t)i * n + lp] = (uint8_t)S.dpD[i]; X.rcD[(size_t)i * n + lp] = S.rcD[i];
+    }
+    if constexpr (PF) {
+        if (S.rs_dp != nullptr) {
+#pragma unroll
+            for (int i = 0; i < C; ++i) S.rs_dp[(size_t)i * n] = (uint8_t)S.lsrcD[i];
+        }
     }
     X.arr_k[lp] = S.arr_k; X.svc_k[lp] = S.svc_k;   // draws CONSUMED; pre-drawn values still in the rings are dropped
     uint32_t q = 0;
@@ -306,7 +320,7 @@ __device__ __forceinline__ Candidate make_candidate(const Station<C, PF, UNI> &S
     else if (PF && w == kRootSched) { c.depth = 0; c.rcrt = INT64_MIN; }   // constructed before run()
     else {
 #pragma unroll
-        for (int i = 0; i < C; ++i) if (i == w - 1) { c.depth = S.dpD[i]; c.rcrt = S.rcD[i]; }
+        for (int i = 0; i < C; ++i) if (i == w - 1) { c.depth = S.dpD[i]; c.rcrt = S.rcD[i]; if (PF && S.rs_dp != nullptr && S.lsrcD[i] != 255u) c.pad = 2 + (int)S.lsrcD[i]; }
     }
     return c;
 }
@@ -388,6 +402,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
         X.D[(size_t)i * n + lp] = kInfNs; X.seqD[(size_t)i * n + lp] = 0; X.crtD[(size_t)i * n + lp] = start_ns;
         X.svc_s[(size_t)i * n + lp] = 0.0; X.crt[(size_t)i * n + lp] = 0;
         X.dpD[(size_t)i * n + lp] = 0; X.rcD[(size_t)i * n + lp] = INT64_MIN; X.wkD[(size_t)i * n + lp] = 1;
+        if constexpr (PF) { if (P.tabs != nullptr && P.tabs->rs_dep != nullptr) P.tabs->rs_dep[(size_t)i * n + lp] = 255; }
     }
     for (int k = 0; k < 11; ++k) X.ev_kind[(size_t)k * n + lp] = 0;
     if constexpr (!PF) return;

@@ -347,6 +347,9 @@ struct Station {
     UpList U[kMaxUp];
     int n_up;
     int undecided;              // Totals::undecided bits 0 and 2, this LP
+    // the Source slot the event being processed descends from, of the pending departures, and the FIFO's column (TickTables::rs_dep / rs_q)
+    uint32_t lsrc, lsrcD[C];
+    uint8_t *rs_qp, *rs_dp;     // null: not tracked (this LP's columns of TickTables::rs_q / rs_dep)
 
     // an event created by the one being processed: one step further from the group's root
     __device__ __forceinline__ void qpush(uint32_t code, int64_t pay = 0) {
@@ -356,6 +359,7 @@ struct Station {
         qdep[(size_t)slot * ls] = (uint8_t)(cd >= 254 ? 255 : cd + 1);
         qrc[(size_t)slot * ls] = cr;
         if constexpr (PF) {
+            if (rs_qp != nullptr) rs_qp[(size_t)slot * ls] = (uint8_t)lsrc;
             if (trk) { q_rrc[(size_t)slot * ls] = rk_rc; q_rdr[(size_t)slot * ls] = rk_pack() | ((int64_t)(wk & 0x7f) << 56); q_pay[(size_t)slot * ls] = pay; }
         }
         ++qn;
@@ -365,6 +369,7 @@ struct Station {
         cd = qdep[(size_t)qh * ls];
         cr = qrc[(size_t)qh * ls];
         if constexpr (PF) {
+            if (rs_qp != nullptr) lsrc = rs_qp[(size_t)qh * ls];
             if (trk) { rk_rc = q_rrc[(size_t)qh * ls]; rk_unpack(q_rdr[(size_t)qh * ls]); wk = (int32_t)(q_rdr[(size_t)qh * ls] >> 56); cur_pay = q_pay[(size_t)qh * ls]; }
         }
         qh = (qh + 1) % kQCap;
@@ -535,7 +540,7 @@ struct Station {
             svc_s[i] = s;
             if (C > 1) crt[i] = (k < cap) ? adm[k * ls] : 0;
             if (d == t) { D[i] = kInfNs - 1; same = (uint32_t)i + 1; }   // in-group continuation: parked, not pending
-            else { D[i] = d; seqD[i] = seq++; crtD[i] = t; dpD[i] = dp_next(2); rcD[i] = cr; if constexpr (PF) wkD[i] = wk + 1; }   // QUEUE_DELIVER -> payload -> continuation
+            else { D[i] = d; seqD[i] = seq++; crtD[i] = t; dpD[i] = dp_next(2); rcD[i] = cr; if constexpr (PF) { wkD[i] = wk + 1; lsrcD[i] = lsrc; } }   // QUEUE_DELIVER -> payload -> continuation
         }
         if (same) { ++cd; if constexpr (PF) ++wk; }                        // (the caller pushes the in-group continuation: deliver + 2)
         return same;
@@ -895,6 +900,13 @@ struct Station {
     __device__ __forceinline__ void run_root(int which, int64_t t) {
         cd = 0; cr = root_crt(which);                                     // a root: pending from an earlier nanosecond
         if constexpr (PF) {
+            lsrc = 255u;                                                  // a tick descends from its own Source, a departure inherits
+            if (which == 0) lsrc = 0u;
+            else if (which >= kRootXSrc && which < kRootXSrc + kMaxXSrc) lsrc = 1u + (uint32_t)(which - kRootXSrc);
+            else if (which >= 1 && which <= C) {
+#pragma unroll
+                for (int i = 0; i < C; ++i) if (i == which - 1) lsrc = lsrcD[i];
+            }
             if (trk) {
                 if (which >= kRootInj) { root_inj((which - kRootInj) >> 5, (which - kRootInj) & 31, t); return; }
                 int pad;
@@ -974,6 +986,7 @@ struct Station {
             cd = 0;
             if (A == t) {
                 cr = crtA;
+                if constexpr (PF) lsrc = 0u;
                 const uint32_t r = do_tick(t);
                 if (svc_kind == 2) {             // Source -> Sink directly
                     if ((r & 1u) && egress == 1) { stage_direct_sink(t); do_sink(); }
@@ -986,7 +999,7 @@ struct Station {
 #pragma unroll
                 for (int i = 0; i < C; ++i) if (D[i] == t) slot = i;
 #pragma unroll
-                for (int i = 0; i < C; ++i) if (i == slot) cr = crtD[i];
+                for (int i = 0; i < C; ++i) if (i == slot) { cr = crtD[i]; if constexpr (PF) lsrc = lsrcD[i]; }
                 const uint32_t r = do_cont(slot, t);
                 if (r & 1u) do_sink();
                 want_poll = (r & 2u) != 0;

@@ -52,6 +52,12 @@ struct TickTables {
     // every LP's first event beyond end_ns as the electing launch saw it: the election's check for ties that the lineage key does
     // not decide (hs_kernels.hpp hs_station_run, Totals::undecided).  [n_lp] {t, t_created, rcrt, depth | valid << 32}
     int64_t *cand_key;
+    // several Sources per Server (no tandem queues): which of the LP's Sources the lineage of a pending departure / an in-group FIFO
+    // entry goes back to -- the slot of the Source whose tick is the most recent one in its ancestry (255: none: an injected Request,
+    // a Probe) -- so that the election ranks a departure by THAT Source's construction position (cand_rank pad 2 + slot) instead of
+    // the LP's first-listed Source.  tools/election_rules.py (`rsrc`): right on 9 100 several-Source cases incl. the three the
+    // stand-in gets wrong.  [C][n_lp] and [kQCap][n_lp]; null = the engine has no LP with several Sources.
+    uint8_t *rs_dep, *rs_q;
     // start of the run: the creation stamp of the events constructed before it (the Sources' first ticks).  The reference numbers
     // those first, then restarts the count for the run's own events -- so until the run has created as many events as there are
     // Sources, a new event can sort BEFORE a first tick of its nanosecond, and the breadth-first order the lineage key stands for
