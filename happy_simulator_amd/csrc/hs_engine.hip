@@ -100,6 +100,7 @@ struct hs_engine {
     XInit XI{};
     // K lanes per LP (hs_kernels_wide.hpp): the uniform grid with fewer LPs than the device has lanes
     WideCtl *wide_ctl = nullptr; int32_t *wide_bail = nullptr;
+    WavePart *wave_parts = nullptr;   // one wavefront per LP (hs_kernels_wave.hpp): the workgroups' partial totals
     int wide_K = 0;            // 0: one lane per LP (hs_station_run)
     bool fresh = false;        // nothing has run since the last reset (the wide kernel starts from empty queues)
     // tick tables (hs_tables.hpp): Sources with a time-varying profile and Probes
@@ -187,7 +188,8 @@ int wide_lanes(const hs_engine *h) {
     if (h->C != 1 || !h->uni_grid || h->any_profile || h->cfg.mode != HS_MODE_SINGLE || !h->fresh || h->wide_ctl == nullptr) return 0;
     if (h->flags & ((1 << 22) | 1 | 512 | (1 << 20))) return 0;
     const int forced = (h->flags >> 24) & 0xf;
-    if (forced) return (1 << (forced - 1)) <= 16 ? 1 << (forced - 1) : 16;
+    if (forced) return forced == 7 ? 64 : forced == 8 ? 65 : (1 << (forced - 1)) <= 16 ? 1 << (forced - 1) : 16;   // 7 / 8: a wavefront per LP, 16 / 8 LPs per workgroup
+    const bool wave_ok = h->cfg.horizon_ns < (1ll << 39);      // (the speculated whole-ns arrival steps: hs_kernels_wave.hpp)
     // Measured on MI355X (tools/wide_timing.py, profiles/r03_wide_timing.log; 60 s of the headline grid, kernel ms):
     //   n_lp      one lane   K = 4    K = 8    K = 16
     //    1 024     0.372     0.118    0.087    0.093
@@ -201,6 +203,7 @@ int wide_lanes(const hs_engine *h) {
     if (hipGetDeviceProperties(&prop, h->cfg.device) != hipSuccess) return 0;
     const long long lanes = (long long)prop.multiProcessorCount * 4 * 64;        // one wavefront per SIMD
     const long long n = h->cfg.n_lp;
+    if (wave_ok && n * 4 <= lanes) return 64;   // <= 16 384 LPs: one wavefront per LP (round 5; see DESIGN section 6 for the measured crossover)
     if (n * 16 <= lanes) return 8;              // <= 4 096 LPs on 256 CUs
     if (n * 4 <= lanes) return 4;               // <= 16 384 LPs
     return 0;
@@ -211,7 +214,15 @@ void launch_wide(hs_engine *h, int64_t end_ns) {
     hipLaunchKernelGGL(hs_station_wide<K>, dim3(nb), dim3(kWideBlock), 0, h->stream, h->P, h->X, h->L, h->tot, h->cands, h->wide_ctl,
                        h->wide_bail, n, end_ns, h->flags);
     hipLaunchKernelGGL(hs_station_wide_finish, dim3(1), dim3(kBlock), 0, h->stream, h->P, h->X, h->L, h->tot, h->cands, nb, h->wide_ctl,
-                       h->wide_bail, n, end_ns);
+                       h->wide_bail, n, end_ns, (const WavePart *)nullptr);
+}
+template <int NW>
+void launch_wave(hs_engine *h, int64_t end_ns) {
+    const int n = h->cfg.n_lp, nb = (n + NW - 1) / NW;
+    hipLaunchKernelGGL(hs_station_wave<NW>, dim3(nb), dim3(NW * 64), 0, h->stream, h->P, h->X, h->L, h->tot, h->cands, h->wide_ctl,
+                       h->wide_bail, h->wave_parts, n, end_ns, h->flags);
+    hipLaunchKernelGGL(hs_station_wide_finish, dim3(1), dim3(kBlock), 0, h->stream, h->P, h->X, h->L, h->tot, h->cands, nb, h->wide_ctl,
+                       h->wide_bail, n, end_ns, (const WavePart *)h->wave_parts);
 }
 
 void launch_run_dispatch(hs_engine *h, int64_t end_ns) {
@@ -222,6 +233,8 @@ void launch_run_dispatch(hs_engine *h, int64_t end_ns) {
         case 4: launch_wide<4>(h, end_ns); return;
         case 8: launch_wide<8>(h, end_ns); return;
         case 16: launch_wide<16>(h, end_ns); return;
+        case 64: launch_wave<16>(h, end_ns); return;
+        case 65: launch_wave<8>(h, end_ns); return;
         default: break;
     }
     // Tandem queues: one launch per pass, upstream Servers first; the last one elects the event beyond end_ns among ALL LPs
@@ -990,6 +1003,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     if (h->C == 1 && h->uni_grid && !h->any_profile && h->cfg.mode == HS_MODE_SINGLE) {
         if ((rc = dev_alloc(h, &h->wide_ctl, 1))) return rc;
         if ((rc = dev_alloc(h, &h->wide_bail, (size_t)n))) return rc;
+        if ((rc = dev_alloc(h, &h->wave_parts, ((size_t)n + 7) / 8))) return rc;
         HS_HIP(h, hipMemset(h->wide_ctl, 0, sizeof(WideCtl)));
     }
     HS_HIP(h, hipMemset(h->tot, 0, sizeof(Totals)));

@@ -62,7 +62,8 @@ __device__ __forceinline__ Candidate cand_load_agent(const Candidate *p) {
     c.lp = __hip_atomic_load(&p->lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     c.rank = __hip_atomic_load(&p->rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     c.valid = __hip_atomic_load(&p->valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    c.pad = 0; c.pad2 = 0;
+    c.pad = __hip_atomic_load(&p->pad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (what the candidate is: the shards' network-wide re-ranking reads it, ShardCtl::cand_out[7])
+    c.pad2 = 0;
     return c;
 }
 __device__ __forceinline__ Candidate cand_none(int lp) {
@@ -79,7 +80,7 @@ __device__ __forceinline__ Candidate wave_min_cand(Candidate c) {
         d.t_created = shfl_xor_ll(c.t_created, o);
         d.rcrt = shfl_xor_ll(c.rcrt, o);
         d.depth = __shfl_xor(c.depth, o, 64);
-        d.pad = 0; d.pad2 = 0;
+        d.pad = __shfl_xor(c.pad, o, 64); d.pad2 = 0;
         d.lp = __shfl_xor(c.lp, o, 64);
         d.rank = __shfl_xor(c.rank, o, 64);
         d.valid = __shfl_xor(c.valid, o, 64);
@@ -1831,6 +1832,7 @@ __global__ void hs_debug_const_div_kernel(double b, int64_t n, const double *a, 
 #endif  // HS_KERNELS_MAIN
 
 #include "hs_kernels_wide.hpp"
+#include "hs_kernels_wave.hpp"
 
 // ---------------------------------------------------------------------------------------------
 // The template instantiations the host launches, in build groups (hs_inst.hip -DHS_INST=k defines group k).
@@ -1857,10 +1859,12 @@ __global__ void hs_debug_const_div_kernel(double b, int64_t n, const double *a, 
 #define HS_ARGS_WIDE (StationParams, StationState, RecordLogs, Totals *, Candidate *, WideCtl *, int32_t *, int, int64_t, int)
 #define HS_INST_GROUP_13(X) X(hs_station_wide<4> HS_ARGS_WIDE) X(hs_station_wide<8> HS_ARGS_WIDE)
 #define HS_INST_GROUP_14(X) X(hs_station_wide<16> HS_ARGS_WIDE)
-#define HS_INST_GROUPS 15
+#define HS_ARGS_WAVE (StationParams, StationState, RecordLogs, Totals *, Candidate *, WideCtl *, int32_t *, WavePart *, int, int64_t, int)
+#define HS_INST_GROUP_15(X) X(hs_station_wave<16> HS_ARGS_WAVE) X(hs_station_wave<8> HS_ARGS_WAVE)
+#define HS_INST_GROUPS 16
 #define HS_INST_ALL(X) HS_INST_GROUP_0(X) HS_INST_GROUP_1(X) HS_INST_GROUP_2(X) HS_INST_GROUP_3(X) HS_INST_GROUP_4(X) HS_INST_GROUP_5(X) \
     HS_INST_GROUP_6(X) HS_INST_GROUP_7(X) HS_INST_GROUP_8(X) HS_INST_GROUP_9(X) HS_INST_GROUP_10(X) HS_INST_GROUP_11(X) HS_INST_GROUP_12(X) \
-    HS_INST_GROUP_13(X) HS_INST_GROUP_14(X)
+    HS_INST_GROUP_13(X) HS_INST_GROUP_14(X) HS_INST_GROUP_15(X)
 #define HS_DECLARE_INST(...) extern template __global__ void __VA_ARGS__;
 #define HS_DEFINE_INST(...) template __global__ void __VA_ARGS__;
 #ifdef HS_KERNELS_MAIN

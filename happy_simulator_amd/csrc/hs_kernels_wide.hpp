@@ -62,6 +62,12 @@ struct WideCtl {                   // device memory: what hs_station_wide leaves
     unsigned int pad;
 };
 
+struct WavePart {                  // what one workgroup of hs_station_wave (hs_kernels_wave.hpp) adds to the engine's totals
+    unsigned long long ev[8];
+    long long lt;                  // latest processed event (INT64_MIN: none)
+    int ovf, pad;
+};
+
 template <int N>
 __device__ __forceinline__ double dpp_shr(double v) {   // lane i <- lane i - N inside its row of 16 lanes (v_mov_b32_dpp row_shr: ~10 cycles;
     const long long b = __double_as_longlong(v);        // a ds_bpermute round trip is ~150); lanes without a source keep their value
@@ -459,13 +465,38 @@ __global__ void __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu
 // beyond end_ns is elected among all candidates and processed -- the last-block part of hs_station_run (SINGLE mode).
 __global__ void __launch_bounds__(kBlock) hs_station_wide_finish(StationParams P, StationState X, RecordLogs L, Totals *tot,
                                                                  Candidate *cands, int n_cands, WideCtl *ctl, const int32_t *bail,
-                                                                 int n, int64_t end_ns) {
+                                                                 int n, int64_t end_ns, const WavePart *parts) {
     __shared__ uint8_t qmem[kQCap][kBlock];
     __shared__ double ring_a[kRing][kBlock], ring_s[kRing][kBlock];
     __shared__ Candidate wave_c[kBlock / 64];
     const int tid = threadIdx.x;
     const long long cur = tot->cur_time;
     const unsigned nb = ctl->n_bail;
+    if (parts != nullptr) {                                  // hs_station_wave: the workgroups' partial totals (one per candidate)
+        unsigned long long s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        long long mx = INT64_MIN;
+        int ov = 0;
+        for (int b = tid; b < n_cands; b += kBlock) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += parts[b].ev[k];
+            mx = parts[b].lt > mx ? parts[b].lt : mx;
+            ov |= parts[b].ovf;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned long long v = wave_sum<unsigned long long>(s[k]);
+            if ((tid & 63) == 0 && v) {
+                atomicAdd(&tot->ev[k], v);
+                if (k == 6) atomicAdd(&tot->completed, v);
+                if (k == 7) atomicAdd(&tot->received, v);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const long long d = shfl_xor_ll(mx, o); mx = d > mx ? d : mx; }
+        if ((tid & 63) == 0 && mx != INT64_MIN) atomicMax(&tot->final_time, mx);
+        if (__any(ov) && (tid & 63) == 0) atomicOr(&tot->overflow, 1);
+        __syncthreads();                                     // (thread 0 reads final_time below)
+    }
     Candidate best = cand_none(0);
     for (unsigned b0 = 0; b0 < nb; b0 += kBlock) {
         const unsigned b = b0 + (unsigned)tid;

@@ -2255,7 +2255,9 @@ int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_
     int64_t cap = cfg->tick_capacity;
     if (cap <= 0) cap = ((int64_t)(max_ticks + 10.0 * std::sqrt(max_ticks + 1.0) + 64.0) + 15) & ~(int64_t)15;
     h->cap = cap;
-    h->n_pre = std::min<int64_t>(cap, ((int64_t)(max_ticks + 5.0 * std::sqrt(max_ticks + 1.0) + 16.0) + 15) & ~(int64_t)15);   // hs_lb_source_draws (whole chunks of 16)
+    // hs_lb_source_draws produces whole chunks of 16 ticks (lb_draw_index tiles kA / vA by 16-tick chunks: a partial last chunk would
+    // reach past cap * roundup64(S) slots when S > 64), so a tick_capacity that is no multiple of 16 rounds DOWN; the rest is self-drawn
+    h->n_pre = std::min<int64_t>(cap & ~(int64_t)15, ((int64_t)(max_ticks + 5.0 * std::sqrt(max_ticks + 1.0) + 16.0) + 15) & ~(int64_t)15);
     h->n_slots = cap * (int64_t)S;
     h->f64_times = cfg->start_ns >= 0 && cfg->horizon_ns < (1ll << 50) && min_rate > 1e-3;   // (one increment <= 36.8 / rate seconds)
     if ((double)h->n_slots * 88.0 > 200e9) { delete h; return lfail(nullptr, HS_E_INVALID, "buffers would need %.1f GB", (double)h->n_slots * 88.0 / 1e9); }

@@ -294,6 +294,20 @@ def test_lb_medium_scale_matches_oracle():
         H.compare_lb_engine_with_oracle(eng, p, r)
 
 
+@pytest.mark.parametrize("tick_capacity", [100, 129, 255])
+def test_lb_tick_capacity_that_is_no_multiple_of_16_with_more_than_64_sources(tick_capacity):
+    """the tiled draw layout (lb_draw_index) needs whole 16-tick chunks; a caller's tick_capacity that is no multiple of
+    16 used to let hs_lb_source_draws write past kA / vA when S > 64.  Pre-drawn ticks now round down to whole chunks."""
+    spec = dict(n_sources=130, n_backends=9, rate=9.0, mean=0.05, vnodes=20, n_clients=999, end_s=6.0, seed=31)
+    g, p = H.oracle_lb_graph(spec)
+    r = O.run(g, p["end_ns"], seed=spec["seed"])
+    for flags in (0, 512):
+        eng, _ = H.lb_engine_for_spec(spec, flags=flags, tick_capacity=tick_capacity)
+        with eng:
+            eng.run(p["end_ns"])
+            H.compare_lb_engine_with_oracle(eng, p, r)
+
+
 def test_lb_full_size_properties():
     """BASELINE configs[4] at full size (32 768 sources -> ConsistentHash(150) -> 32 768 servers -> one Sink, 60 s,
     ~11.8 M requests): size-independent properties of the reference's semantics."""

@@ -17,7 +17,8 @@ ONE_LANE = 1 << 22
 
 
 def _force(k):
-    return ({4: 3, 8: 4, 16: 5}[k]) << 24
+    """4 / 8 / 16 lanes per LP (hs_station_wide); 64 / 65: a wavefront per LP with 16 / 8 LPs per workgroup (hs_station_wave)"""
+    return ({4: 3, 8: 4, 16: 5, 64: 7, 65: 8}[k]) << 24
 
 
 def _run(n, end_ns, flags, seed=42, rate=8.0, mean=0.1, second_end=None):
@@ -50,7 +51,7 @@ def test_wide_kernel_equals_the_one_lane_kernel(n, end_s):
     end = int(end_s * 1e9)
     ref = _run(n, end, ONE_LANE)
     assert ref["tot_events"] > 20 * n * end_s
-    for k in (4, 8, 16):
+    for k in (4, 8, 16, 64, 65):
         _same(_run(n, end, _force(k)), ref, f"K = {k}")
     _same(_run(n, end, 0), ref, "automatic K")
 
@@ -61,12 +62,15 @@ def test_wide_kernel_other_rates_and_seeds():
         ref = _run(500, end, ONE_LANE, seed=seed, rate=rate, mean=mean)
         _same(_run(500, end, _force(8), seed=seed, rate=rate, mean=mean), ref, f"seed {seed}")
         _same(_run(500, end, _force(16), seed=seed, rate=rate, mean=mean), ref, f"seed {seed}")
+        _same(_run(500, end, _force(64), seed=seed, rate=rate, mean=mean), ref, f"seed {seed}, a wavefront per LP")
+        _same(_run(500, end, _force(65), seed=seed, rate=rate, mean=mean), ref, f"seed {seed}, a wavefront per LP, 8 per workgroup")
 
 
 def test_bailed_lps_rerun_in_event_order():
     end = 6_000_000_000
     ref = _run(2000, end, ONE_LANE)
     _same(_run(2000, end, _force(8) | (1 << 21)), ref, "every 97th LP bails")
+    _same(_run(2000, end, _force(64) | (1 << 21)), ref, "every 97th LP bails, a wavefront per LP")
 
 
 def test_the_state_the_wide_kernel_leaves_continues_identically():
@@ -76,6 +80,9 @@ def test_the_state_the_wide_kernel_leaves_continues_identically():
     _same(_run(1000, 3_000_000_000, _force(16), second_end=7_500_000_000), ref, "two windows")
     ref = _run(1000, 100_000_000, ONE_LANE, second_end=2_000_000_000)                 # a window in which most LPs see no tick
     _same(_run(1000, 100_000_000, _force(4), second_end=2_000_000_000), ref, "short first window")
+    _same(_run(1000, 100_000_000, _force(64), second_end=2_000_000_000), ref, "short first window, a wavefront per LP")
+    ref = _run(1000, 3_000_000_000, ONE_LANE, second_end=7_500_000_000)
+    _same(_run(1000, 3_000_000_000, _force(64), second_end=7_500_000_000), ref, "two windows, a wavefront per LP")
 
 
 def test_wide_kernel_against_the_oracle():
@@ -86,7 +93,7 @@ def test_wide_kernel_against_the_oracle():
     spec = dict(name="wide_200", n_chains=n, arr="poisson", rate=8.0, svc="exp", mean=0.1, concurrency=1, queue_cap=None,
                 stop_after_s=None, downstream=True, end_s=12.0, rng="philox", seed=4242, mode="single", trace=False)
     runs = H.run_oracle_for_spec(spec)
-    for flags in (_force(8), _force(16)):
+    for flags in (_force(8), _force(16), _force(64), _force(65)):
         eng, p = H.engine_for_spec(spec)
         with eng:
             eng.set_debug_flags(flags)
@@ -109,4 +116,4 @@ def test_8192_lps_run_at_least_twice_as_fast_as_one_lane_each():
             k, _ = eng.bench_runs(end, 10)
             times[name] = float(np.median(k))
     print(times)
-    assert times["wide"] < 0.5 * times["one lane per LP"], times      # (measured: 0.168 vs 0.39 ms)
+    assert times["wide"] < 0.3 * times["one lane per LP"], times      # (measured r4: 0.168 vs 0.39 ms; r5, a wavefront per LP: see DESIGN section 6)

@@ -21,7 +21,7 @@ from happy_simulator_amd import _native as N  # noqa: E402
 from happy_simulator_amd.engine import StationArrays, StationEngine  # noqa: E402
 
 END = 60_000_000_000
-FORCE = {4: 3 << 24, 8: 4 << 24, 16: 5 << 24}
+FORCE = {4: 3 << 24, 8: 4 << 24, 16: 5 << 24, 64: 7 << 24, 65: 8 << 24}   # 64 / 65: a wavefront per LP, 16 / 8 LPs per workgroup
 
 
 def step_ms(n, flags, reps=10):
@@ -35,7 +35,7 @@ def step_ms(n, flags, reps=10):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--sizes", default="1024,2048,4096,8192,16384,32768")
+    ap.add_argument("--sizes", default="1024,4096,8192,16384,32768,65536")
     ap.add_argument("--cycles", action="store_true")
     a = ap.parse_args()
     for n in (int(x) for x in a.sizes.split(",")):
@@ -50,8 +50,10 @@ def main():
                     print(f"n_lp {n} K {K}: work cycles of workgroup 0 [values, chain + sum, Lindley]: {list(out)[:3]}, loop total {out[3]}")
             continue
         row = {"one lane per LP": round(step_ms(n, 1 << 22), 4), "automatic": round(step_ms(n, 0), 4)}
-        for K in (4, 8, 16):
+        for K in (4, 8, 16, 64, 65):
             row[f"K={K}"] = round(step_ms(n, FORCE[K]), 4)
+        row["K=64 no logs"] = round(step_ms(n, FORCE[64] | (1 << 19)), 4)
+        row["K=64 no logs, no sum"] = round(step_ms(n, FORCE[64] | (1 << 19) | (1 << 18)), 4)
         print(f"n_lp {n}: kernel ms {row}", flush=True)
 
 
