@@ -14,7 +14,7 @@
 //   L  the Lindley recursion  D_k = max(a_k, D_{k-1}) + s_k  as a wave-wide scan in the (max, +) semiring (hs_kernels_wide.hpp), the
 //      reference's events of request k counted with ballots exactly as Station::req_step does (hs_station.hpp);
 //   T  `_total_service_time += s` in completion order (server/server.py:252-273): one dependent binary64 addition per completed
-//      request, samples broadcast from LDS -- the only serial part left.
+//      request -- the only serial part left; ONE wavefront of the workgroup sums for all its LPs, a lane each, out of LDS.
 // A workgroup is NW wavefronts = NW neighbouring LPs.  The record logs are [record][LP] (a lane-per-LP wavefront appends 512
 // contiguous bytes); a wavefront that owns ONE LP would write 128 words 8 n_lp bytes apart, each a partial line shared with 15
 // other LPs -- so a step's records are staged in LDS and the workgroup writes them out transposed: 16 neighbouring LPs' k-th
@@ -37,6 +37,41 @@ __device__ __forceinline__ double wave_shr1(double v) {
     hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
+// v_mov_b32_dpp with an identity for the lanes that have no source (and for the rows outside the row mask RM): the scans below
+// combine unconditionally instead of selecting per lane.  CTRL: 0x110 + N row_shr:N, 0x138 wave_shr:1, 0x142 row_bcast:15 (lane
+// 15 of every row to the next row), 0x143 row_bcast:31 (lane 31 to rows 2 and 3).
+template <int CTRL, int RM>
+__device__ __forceinline__ double dpp_or0(double v) {                 // identity 0.0 (bound_ctrl: no source = zero)
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(unsigned)(b & 0xffffffffll), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, RM, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, RM, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <int CTRL, int RM>
+__device__ __forceinline__ double dpp_orneg(double v) {               // identity -infinity
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(unsigned)(b & 0xffffffffll), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, RM, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp((int)0xfff00000u, hi, CTRL, RM, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <int CTRL, int RM>
+__device__ __forceinline__ double dpp_orv(double v, double other) {   // identity: a given value
+    const long long b = __double_as_longlong(v), o = __double_as_longlong(other);
+    int lo = (int)(unsigned)(b & 0xffffffffll), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp((int)(unsigned)(o & 0xffffffffll), lo, CTRL, RM, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp((int)(o >> 32), hi, CTRL, RM, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// f(x) = max(p, x + q) after g: hs_kernels_wide.hpp mp_compose with v_max_f64 (the values are never NaN)
+__device__ __forceinline__ MaxPlus mp_after(const MaxPlus &f2, const MaxPlus &f1) {
+    return MaxPlus{__builtin_fmax(f2.p, f1.p + f2.q), f1.q + f2.q};
+}
+template <int CTRL, int RM>
+__device__ __forceinline__ MaxPlus mp_scan_step(const MaxPlus &F) {   // F after the map of the lane CTRL names (identity where there is none)
+    return mp_after(F, MaxPlus{dpp_orneg<CTRL, RM>(F.p), dpp_or0<CTRL, RM>(F.q)});
+}
 // the value of lane `l` (wave-uniform index) as a wave-uniform value (two v_readlane)
 __device__ __forceinline__ double rl64(double v, int l) {
     const long long b = __double_as_longlong(v);
@@ -54,22 +89,33 @@ __device__ __forceinline__ double rfl64(double v) {     // ... of the first acti
 }  // namespace
 
 #ifndef HS_WAVE_WPE
-#define HS_WAVE_WPE 4
+#define HS_WAVE_WPE 8                  // wavefronts per SIMD the register allocation aims at (<= 64 VGPRs: two workgroups of 16 per CU)
 #endif
-
 template <int NW>
-__global__ void __launch_bounds__(NW * 64) hs_station_wave(StationParams P, StationState X, RecordLogs L, Totals *tot, Candidate *cands,
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HS_WAVE_WPE, HS_WAVE_WPE))) hs_station_wave(StationParams P, StationState X, RecordLogs L, Totals *tot, Candidate *cands,
                                                            WideCtl *ctl, int32_t *bail, WavePart *parts, int n, int64_t end_ns, int flags) {
     static_assert(NW == 4 || NW == 8 || NW == 16, "a 128-byte line of a record log holds 16 LPs");
     constexpr int R = kWaveR;
     __shared__ int64_t st_a[NW][kWaveRowPad], st_d[NW][kWaveRowPad];   // the step's admission / completion records, INT64_MIN = none
-    __shared__ double s_sv[NW][R];                                     // the step's service samples in completion order (0.0: not completed)
+    // the step's service samples in completion order and how many of them count: double-buffered, wavefront 0 adds up step s - 1
+    // while step s is computed (T)
+    __shared__ double s_sv[2][NW][R + 1];
+    __shared__ int s_cnt[2][NW];
+    __shared__ double s_ts[NW];                                        // _total_service_time of the workgroup's LPs
     __shared__ int64_t s_base[NW][2];                                  // index of slot 0's record in adm / sink_t
+    // what only the fold at the end reads (kept out of the loop's registers): the request still in service {D, S, arrival, arrival
+    // before it, index, service time}, the last two ticks and the pending one, arrivals
+    __shared__ double s_pend[NW][7];
+    __shared__ double s_tick[NW][3];
     __shared__ Candidate wave_c[NW];
     __shared__ unsigned s_ev[NW][8];
     __shared__ long long s_lt[NW];
     __shared__ int s_ovf[NW];
 
+#ifdef HS_WAVE_CYC   // scratch build (tools/wide_timing.py --wave-cycles): where a wavefront of workgroup 0 spends its cycles
+    const unsigned long long cyc_k0 = __builtin_readcyclecounter();
+    unsigned long long cyc_compute = 0, cyc_phase2 = 0, cyc_loop0 = 0, cyc_bar = 0;
+#endif
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lp0 = blockIdx.x * NW;
@@ -85,24 +131,36 @@ __global__ void __launch_bounds__(NW * 64) hs_station_wave(StationParams P, Stat
     uint64_t ak0 = 0, sk0 = 0;
     double total_service = 0.0, svc_s0 = 0.0;
     bool busy = false, elig = false;
+    uint32_t seq_in = 0, seqA_in = 0, seqD_in = 0;
+    int32_t dpA_in = 0, dpD_in = 0;
+    int64_t rcA_in = 0, rcD_in = 0;
     ConstDiv div_rate, div_lambda;
     uint32_t key0 = 0, key1 = 0, asid0 = 0, asid1 = 0, ssid0 = 0, ssid1 = 0;
     div_rate.init(1.0); div_lambda.init(1.0);
     if (live) {
+        // every load first, unconditionally (a short-circuited `&&` chain loads one value per memory round trip: 40 of them were
+        // 16 000 cycles before the first step), then the predicates
         A = X.A[lp]; crtA = X.crtA[lp]; ak0 = X.arr_k[lp]; sk0 = X.svc_k[lp];
         accepted = X.accepted[lp]; started = X.started[lp]; sink_w = X.sink_w[lp]; last_time = X.last_time[lp];
         total_service = X.total_service[lp];
-        busy = X.active[lp] > 0;
-        if (busy) { Dprev = X.D[lp]; Sprev = X.crtD[lp]; svc_s0 = X.svc_s[lp]; }
-        elig = !frozen && X.q[lp] == 0 && X.buf[lp] == 0 && X.active[lp] <= 1 && X.arr_time[lp] == A && ak0 >= 1 &&
-               A >= 0 && crtA >= 0 && last_time >= 0 && end_ns < (1ll << 51) && (A == kInfNs || A < (1ll << 51)) &&   // (exact in binary64)
-               (X.active[lp] == 0 || (X.D[lp] < (1ll << 51) && X.crtD[lp] >= 0));
+        const int32_t active_in = X.active[lp];
+        const int64_t D_in = X.D[lp], crtD_in = X.crtD[lp], buf_in = X.buf[lp], arr_time_in = X.arr_time[lp];
+        const double svc_s_in = X.svc_s[lp];
+        const uint32_t q_in = X.q[lp];
+        seq_in = X.seq[lp]; seqA_in = X.seqA[lp]; seqD_in = X.seqD[lp];              // (only the fold reads these)
+        dpA_in = X.dpA[lp]; dpD_in = X.dpD[lp]; rcA_in = X.rcA[lp]; rcD_in = X.rcD[lp];
         const uint64_t seed = P.seed[lp], base = P.stream_base[lp];
+        const double rate_in = P.src_rate[lp], mean_in = P.svc_mean[lp];
+        busy = active_in > 0;
+        if (busy) { Dprev = D_in; Sprev = crtD_in; svc_s0 = svc_s_in; }
+        elig = (int)!frozen & (int)(q_in == 0) & (int)(buf_in == 0) & (int)(active_in <= 1) & (int)(arr_time_in == A) &
+               (int)(A >= 0) & (int)(crtA >= 0) & (int)(last_time >= 0) & (int)(end_ns < (1ll << 51)) & (int)(A == kInfNs || A < (1ll << 51)) &   // (exact in binary64)
+               (int)(active_in == 0 || (D_in < (1ll << 51) && crtD_in >= 0));
         key0 = (uint32_t)seed; key1 = (uint32_t)(seed >> 32);
         const uint64_t sa = stream_id(base, kStreamArrival), ss = stream_id(base, kStreamService);
         asid0 = (uint32_t)sa; asid1 = (uint32_t)(sa >> 32); ssid0 = (uint32_t)ss; ssid1 = (uint32_t)(ss >> 32);
-        div_rate.init(P.src_rate[lp]);
-        div_lambda.init(__ddiv_rn(1.0, P.svc_mean[lp]));
+        div_rate.init(rate_in);
+        div_lambda.init(__ddiv_rn(1.0, mean_in));
     }
     if ((flags & (1 << 21)) && live && (lp % 97) == 5) elig = false;     // debug: force some LPs through the bail path
     const int64_t crtA0 = crtA;
@@ -119,11 +177,7 @@ __global__ void __launch_bounds__(NW * 64) hs_station_wave(StationParams P, Stat
     }
     const uint32_t dep0 = n_dep;
     bool pend = run && busy && dep0 == 0;               // a request in service beyond the window: nobody else starts
-    int64_t pendD = Dprev, pendS = Sprev;
-    double pend_s = svc_s0;
-    bool pend_new = false;                              // ... one that started in this window:
-    double pendA_d = 0.0, pendAp_d = 0.0;               //     its arrival and the arrival before it (lineage, Station::req_finish)
-    int64_t pend_i = 0;                                 //     its index among the window's requests
+    bool pend_new = false;                              // ... one that started in this window (s_pend)
 
     auto sec_d = [](double ns) {                        // to_seconds: float(ns) / 1e9, correctly rounded (hs_device.hpp seconds_from_ns_d)
         const double q0 = __dmul_rn(ns, 1e-9);
@@ -137,18 +191,21 @@ __global__ void __launch_bounds__(NW * 64) hs_station_wave(StationParams P, Stat
         return (int64_t)((uint64_t)__double_as_longlong(__dadd_rn(d, 4503599627370496.0)) & 0xFFFFFFFFFFFFFull);
     };
 
-    // ---- how the window's requests map onto Philox blocks.  Slot p = 2 lane + q of step s holds arrival draw pa + 128 s + p, whose
-    // increment leads from request i = 128 s + p - da to request i + 1 (da = 1: draw pa made the pending tick A, slot 0 of step 0
-    // is dead).  Request i takes service draw sk0 + i = sg + 128 s + p with sg = sk0 - da: an even sg aligns the service blocks with
-    // the lanes, an odd one puts a block's first half into its lane's slot 1 and its second half into the NEXT lane's slot 0.
-    const uint32_t da = (uint32_t)(ak0 & 1ull);
-    const uint64_t pa = ak0 - da;
-    const int64_t sg = (int64_t)sk0 - (int64_t)da;       // (-1 when nothing has been served yet and draw pa is consumed)
-    const bool ds = (sg & 1ll) != 0;
-    uint64_t blk_a = (pa >> 1) + (uint64_t)lane;
-    uint64_t blk_s = (uint64_t)((sg + (ds ? 1 : 0)) >> 1) + (uint64_t)lane;
-    double carry_sv = 0.0;                               // odd sg: the second half of the block before lane 0's
-    if (run && ds && da == 0) {                          // (resuming in the middle of a service block)
+    // ---- how the window's requests map onto Philox blocks.  Slot p = 2 lane + q of step s is request i = 128 s + p of the window; it
+    // takes arrival draw ak0 + i (the increment from its own arrival to the next one) and service draw sk0 + i.  A stream whose
+    // first draw k0 is even aligns its blocks with the lanes (block k0 / 2 + 64 s + lane = the lane's two slots); an odd k0 puts the
+    // FIRST half of block (k0 + 1) / 2 + 64 s + lane into the lane's slot 1 and its second half into the NEXT lane's slot 0 (lane
+    // 0: the second half of the block before it, carried from the step before -- at the start, the rest of the block draw k0 - 1
+    // was taken from).
+    const bool da = (ak0 & 1ull) != 0, ds = (sk0 & 1ull) != 0;
+    uint64_t blk_a = ((ak0 + 1) >> 1) + (uint64_t)lane, blk_s = ((sk0 + 1) >> 1) + (uint64_t)lane;
+    double carry_inc = 0.0, carry_sv = 0.0;
+    if (run && da) {
+        const uint64_t b = ak0 >> 1;
+        const U4 o = philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), asid0, asid1, key0, key1);
+        carry_inc = div_rate.div(exp1_from_uniform(res53(o.z, o.w)));
+    }
+    if (run && ds) {
         const uint64_t b = sk0 >> 1;
         const U4 o = philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), ssid0, ssid1, key0, key1);
         carry_sv = sec_d(nsd(div_lambda.div(exp1_from_uniform(res53(o.z, o.w)))));
@@ -157,191 +214,216 @@ __global__ void __launch_bounds__(NW * 64) hs_station_wave(StationParams P, Stat
     const double Td = (double)T;
     double base_a = (double)A;                           // arrival time of the step's slot 0
     double carryD = busy ? (double)Dprev : NEG, carryS = busy ? (double)Sprev : NEG;   // D and S of the request before the step's first
-    double carryA = NEG;                                 // arrival of the last request of the step before (NEG: none in this window)
+    double carryA = NEG;                                 // its arrival (NEG: none in this window)
     double lt_d = (double)lt;
     bool fin = !run || A > T;
-    int64_t n_arr_total = 0;
-    double A_next = (double)A, a_last = (double)crtA, a_last2 = (double)crtA;   // pending tick and the two ticks before it
-    int64_t r0 = -(int64_t)da;                           // request index of the step's slot 0
-    bool first = true;
+    int64_t r0 = 0;                                      // request index of the step's slot 0 = arrivals so far
     int64_t steps_left = L.cap / R + 2;                  // (more steps than the record log has room for: an overflow, never a hang)
+    if (lane == 0) {
+        s_ts[w] = total_service;
+        s_tick[w][0] = (double)A; s_tick[w][1] = (double)crtA; s_tick[w][2] = (double)crtA;   // pending tick and the two ticks before it
+    }
+    __syncthreads();
+    double ts_mine = (w == 0 && lane < NW) ? s_ts[lane] : 0.0;   // wavefront 0, lane l: _total_service_time of LP lp0 + l
+    bool rows_clear = false;                             // this wavefront's staging rows hold no record
 
-    while (__syncthreads_or(!fin)) {
-        const bool act = !fin;
-        if (act && --steps_left < 0) { overflow = 1; fin = true; }
-        // ---- V: the step's stream values
-        const U4 oa = philox4x32_10((uint32_t)blk_a, (uint32_t)(blk_a >> 32), asid0, asid1, key0, key1);
-        const U4 os = philox4x32_10((uint32_t)blk_s, (uint32_t)(blk_s >> 32), ssid0, ssid1, key0, key1);
-        blk_a += 64; blk_s += 64;
-        const double inc0 = div_rate.div(exp1_from_uniform(res53(oa.x, oa.y))), inc1 = div_rate.div(exp1_from_uniform(res53(oa.z, oa.w)));
-        const double e0 = div_lambda.div(exp1_from_uniform(res53(os.x, os.y))), e1 = div_lambda.div(exp1_from_uniform(res53(os.z, os.w)));
-        const double v0 = sec_d(nsd(e0)), v1 = sec_d(nsd(e1));                     // Duration.from_seconds(sample).to_seconds()
-        double sv0 = v0, sv1 = v1;
-        if (ds) {
-            double up = wave_shr1(v1);
-            if (lane == 0) up = carry_sv;
-            carry_sv = rl64(v1, 63);
-            sv0 = up; sv1 = v0;
-        }
-        const double du0 = nsd(sv0), du1 = nsd(sv1);
-        const bool dead0 = first && da != 0 && lane == 0;                         // slot 0 of step 0: no request
-        // ---- C: arrival times.  a0 / a1 = arrival of slots 2 lane / 2 lane + 1, an = the tick after slot 2 lane + 1
-        double a0, a1, an;
-        {
-            const double F0 = __dmul_rn(inc0, 1e9), F1 = __dmul_rn(inc1, 1e9);
-            const double fl0 = __builtin_floor(F0), fl1 = __builtin_floor(F1);
-            const double fr0 = __dsub_rn(F0, fl0), fr1 = __dsub_rn(F1, fl1);
-            constexpr double m = 1.0 / 1024.0;
-            bool safe0 = spec && fr0 >= m && fr0 <= 1.0 - m && F0 < 549755813888.0;
-            const bool safe1 = spec && fr1 >= m && fr1 <= 1.0 - m && F1 < 549755813888.0;
-            double f0 = safe0 ? fl0 : 0.0;
-            const double f1 = safe1 ? fl1 : 0.0;
-            if (dead0) { f0 = 0.0; safe0 = true; }
-            const double ps = f0 + f1;
-            double I = ps;                                                       // inclusive scan over the lanes (whole numbers: exact)
-            { const double u = dpp_shr<1>(I); if ((lane & 15) >= 1) I += u; }
-            { const double u = dpp_shr<2>(I); if ((lane & 15) >= 2) I += u; }
-            { const double u = dpp_shr<4>(I); if ((lane & 15) >= 4) I += u; }
-            { const double u = dpp_shr<8>(I); if ((lane & 15) >= 8) I += u; }
-            { const double t15 = rl64(I, 15), t47 = rl64(I, 47); if (lane & 16) I += (lane & 32) ? t47 : t15; }
-            { const double t31 = rl64(I, 31); if (lane & 32) I += t31; }
-            a0 = base_a + (I - ps); a1 = a0 + f0; an = base_a + I;
-            unsigned long long ub0 = __ballot(!safe0), ub1 = __ballot(!safe1);
-            while ((ub0 | ub1) != 0ull) {                                        // the increments too close to a whole number, in order
-                const int l0 = ub0 ? (int)__builtin_ctzll(ub0) : 64, l1 = ub1 ? (int)__builtin_ctzll(ub1) : 64;
-                const bool at0 = l0 <= l1;                                       // position 2 l0 before position 2 l1 + 1
-                const int lu = at0 ? l0 : l1;
-                const double au = at0 ? rl64(a0, lu) : rl64(a1, lu), iu = at0 ? rl64(inc0, lu) : rl64(inc1, lu);
-                const double dl = nsd(__dadd_rn(sec_d(au), iu)) - au;            // the reference's step, exactly
-                if (at0) { if (lane >= lu) { a1 += dl; an += dl; } if (lane > lu) a0 += dl; ub0 &= ub0 - 1; }
-                else { if (lane >= lu) an += dl; if (lane > lu) { a0 += dl; a1 += dl; } ub1 &= ub1 - 1; }
-            }
-        }
-        const double base_next = rl64(an, 63);
-        // ---- L: Lindley recursion as a (max, +) scan (hs_kernels_wide.hpp MaxPlus), two requests per lane
-        MaxPlus F{dead0 ? NEG : a0 + du0, dead0 ? 0.0 : du0};
-        F = mp_compose(MaxPlus{a1 + du1, du1}, F);
-        { MaxPlus Pm{dpp_shr<1>(F.p), dpp_shr<1>(F.q)}; if ((lane & 15) >= 1) F = mp_compose(F, Pm); }
-        { MaxPlus Pm{dpp_shr<2>(F.p), dpp_shr<2>(F.q)}; if ((lane & 15) >= 2) F = mp_compose(F, Pm); }
-        { MaxPlus Pm{dpp_shr<4>(F.p), dpp_shr<4>(F.q)}; if ((lane & 15) >= 4) F = mp_compose(F, Pm); }
-        { MaxPlus Pm{dpp_shr<8>(F.p), dpp_shr<8>(F.q)}; if ((lane & 15) >= 8) F = mp_compose(F, Pm); }
-        {   // rows 1 and 3 take the row before them, then rows 2 and 3 take rows 0-1
-            const MaxPlus t15{rl64(F.p, 15), rl64(F.q, 15)}, t47{rl64(F.p, 47), rl64(F.q, 47)};
-            if (lane & 16) F = mp_compose(F, (lane & 32) ? t47 : t15);
-            const MaxPlus t31{rl64(F.p, 31), rl64(F.q, 31)};
-            if (lane & 32) F = mp_compose(F, t31);
-        }
-        const MaxPlus E{wave_shr1(F.p), wave_shr1(F.q)};                         // composition of the lanes before this one
-        const double xq = carryD + E.q;                                          // (-inf + q = -inf: nothing before the first request)
-        const double Dp_in = lane == 0 ? carryD : (E.p > xq ? E.p : xq);         // D of the request before this lane's first
-        double S0 = a0 > Dp_in ? a0 : Dp_in, D0 = S0 + du0;
-        if (dead0) { S0 = carryS; D0 = Dp_in; }                                  // (no request in the slot: S and D pass through)
-        const double S1 = a1 > D0 ? a1 : D0, D1 = S1 + du1;
-        double Sp_in = wave_shr1(S1);                                            // S of the request before this lane's first
-        if (lane == 0) Sp_in = carryS;
-        double Ap_in = wave_shr1(a1);                                            // arrival of the request before this lane's first
-        if (lane == 0) Ap_in = carryA;
-        // which reference events happen (Station::req_step), request by request
-        const bool live0 = !dead0;
-        const bool arr0 = act && live0 && a0 <= Td, arr1 = act && a1 <= Td;
-        const bool st0 = arr0 && S0 <= Td, st1 = arr1 && S1 <= Td;
-        const bool dp0 = st0 && D0 <= Td, dp1 = st1 && D1 <= Td;
-        const bool hz0 = (arr0 && (a0 == Sp_in || a0 == Dp_in || a1 <= a0)) || (st0 && du0 == 0.0);
-        const bool hz1 = (arr1 && (a1 == S0 || a1 == D0 || an <= a1)) || (st1 && du1 == 0.0);
-        const unsigned long long b_arr0 = __ballot(arr0), b_arr1 = __ballot(arr1);
-        const unsigned long long b_st0 = __ballot(st0), b_st1 = __ballot(st1), b_dp0 = __ballot(dp0), b_dp1 = __ballot(dp1);
-        const bool hz = __ballot(hz0 || hz1) != 0ull;
-        if (act && hz) { bailed = true; fin = true; }
-        const bool ok = act && !bailed;
-        const int n_arr_l = ok ? __popcll(b_arr0) + __popcll(b_arr1) : 0;
-        const int n_dp_l = ok ? __popcll(b_dp0) + __popcll(b_dp1) : 0;
-        if (ok) {
-            n_tick += (uint32_t)n_arr_l;
-            n_notify += (uint32_t)(__popcll(__ballot(arr0 && Sp_in < a0)) + __popcll(__ballot(arr1 && S0 < a1)));
-            n_poll += (uint32_t)(__popcll(__ballot(arr0 && Dp_in < a0)) + __popcll(__ballot(arr1 && D0 < a1)));
-            n_start += (uint32_t)(__popcll(b_st0) + __popcll(b_st1));
-            n_dep += (uint32_t)n_dp_l;
-            // the latest processed event of each request (a <= S < D); a later request may have arrived before an earlier one left
-            const double e0_ = dp0 ? D0 : st0 ? S0 : arr0 ? a0 : NEG, e1_ = dp1 ? D1 : st1 ? S1 : arr1 ? a1 : NEG;
-            const double em = e0_ > e1_ ? e0_ : e1_;
-            lt_d = em > lt_d ? em : lt_d;
-            // the one request (at most) that started and is still in service at the end of the window
-            const unsigned long long bp0 = __ballot(st0 && !dp0), bp1 = __ballot(st1 && !dp1);
-            if ((bp0 | bp1) != 0ull) {
-                const bool at1 = bp0 == 0ull;
-                const int lh = (int)__builtin_ctzll(at1 ? bp1 : bp0);
-                pend_new = true;
-                pendD = to_i64(at1 ? rl64(D1, lh) : rl64(D0, lh)); pendS = to_i64(at1 ? rl64(S1, lh) : rl64(S0, lh));
-                pend_s = at1 ? rl64(sv1, lh) : rl64(sv0, lh);
-                pendA_d = at1 ? rl64(a1, lh) : rl64(a0, lh);
-                pendAp_d = at1 ? rl64(a0, lh) : rl64(Ap_in, lh);
-                pend_i = r0 + 2 * lh + (at1 ? 1 : 0);
-                // (slot 1 of lane 0 in step 0 with a dead slot 0 is request 0: pend_i == 0, pendAp_d unused)
-            }
-        }
-        // ---- the step's records -> LDS (coalesced transposed write below), service samples for T
-        if (!(flags & (1 << 19))) {
-            st_a[w][2 * lane] = (ok && arr0) ? to_i64(a0) : INT64_MIN; st_a[w][2 * lane + 1] = (ok && arr1) ? to_i64(a1) : INT64_MIN;
-            st_d[w][2 * lane] = (ok && dp0) ? to_i64(D0) : INT64_MIN; st_d[w][2 * lane + 1] = (ok && dp1) ? to_i64(D1) : INT64_MIN;
-            if (lane == 0) { s_base[w][0] = accepted + r0; s_base[w][1] = sink_w + (int64_t)dep0 + r0; }
-        }
-        // ---- T: _total_service_time in completion order (departures are a prefix of the step's requests)
-        if (n_dp_l > 0 && !(flags & (1 << 18))) {
-            s_sv[w][2 * lane] = dp0 ? sv0 : 0.0; s_sv[w][2 * lane + 1] = dp1 ? sv1 : 0.0;
-            const int hi0 = b_dp0 ? 2 * (63 - (int)__builtin_clzll(b_dp0)) : -1, hi1 = b_dp1 ? 2 * (63 - (int)__builtin_clzll(b_dp1)) + 1 : -1;
-            const int cnt = (hi0 > hi1 ? hi0 : hi1) + 1;
-            for (int c = 0; c < cnt; c += 8) {
+#ifdef HS_WAVE_CYC
+    cyc_loop0 = __builtin_readcyclecounter();
+#endif
+    auto service_sum = [&](int b) {                      // T of the step whose samples are in buffer b: wavefront 0, a lane per LP
+        if (w == 0 && lane < NW) {
+            const int c = s_cnt[b][lane];
+            for (int k = 0; k < R && __any(k < c); k += 8) {
                 double v[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = s_sv[w][c + q];              // (past cnt: this step's 0.0 / not yet departed: 0.0; + 0.0 is exact)
+                for (int q = 0; q < 8; ++q) v[q] = s_sv[b][lane][k + q];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) total_service = __dadd_rn(total_service, v[q]);
+                for (int q = 0; q < 8; ++q) v[q] = (k + q) < c ? v[q] : 0.0;         // (+ 0.0 is exact: the chain is the additions alone)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ts_mine = __dadd_rn(ts_mine, v[q]);
             }
         }
-        if (ok) {
-            // the pending tick and the two ticks before it (lineage, Station::req_finish); position of the first arrival beyond T
-            const int dead = (first && da != 0) ? 1 : 0;
-            const int pf = n_arr_l + dead;                                       // slot of the first request that did not arrive
-            auto slot_a = [&](int p) { return (p & 1) ? rl64(a1, p >> 1) : rl64(a0, p >> 1); };
-            if (n_arr_l > 0) {
-                const double last = slot_a(pf - 1);
-                a_last2 = n_arr_l >= 2 ? slot_a(pf - 2) : a_last;
-                a_last = last;
+    };
+    int step = 0;
+    for (; __syncthreads_or(!fin); ++step) {
+        int cnt_sv = 0;
+        bool did = false;
+        const int sb = step & 1;
+        if (step > 0) service_sum(sb ^ 1);
+#ifdef HS_WAVE_CYC
+        const unsigned long long c0_ = __builtin_readcyclecounter();
+#endif
+        if (!fin) {
+            if (--steps_left < 0) { overflow = 1; fin = true; }
+            // ---- V: the step's stream values.  (The empty asm keeps the ten round keys from being hoisted out of the loop: twenty more
+            // live SGPRs spill to VGPR lanes and every round then pays a v_readlane; twenty s_add per step are free next to the VALU.)
+            asm volatile("" : "+s"(key0), "+s"(key1));
+            const U4 oa = philox4x32_10((uint32_t)blk_a, (uint32_t)(blk_a >> 32), asid0, asid1, key0, key1);
+            const U4 os = philox4x32_10((uint32_t)blk_s, (uint32_t)(blk_s >> 32), ssid0, ssid1, key0, key1);
+            blk_a += 64; blk_s += 64;
+            double inc0 = div_rate.div(exp1_from_uniform(res53(oa.x, oa.y))), inc1 = div_rate.div(exp1_from_uniform(res53(oa.z, oa.w)));
+            if (da) {
+                const double up = dpp_orv<0x138, 0xf>(inc1, carry_inc);
+                carry_inc = rl64(inc1, 63);
+                inc1 = inc0; inc0 = up;
             }
-            n_arr_total += n_arr_l;
-            A_next = pf < R ? slot_a(pf) : base_next;
-            if (pf < R) fin = true;
+            const double e0 = div_lambda.div(exp1_from_uniform(res53(os.x, os.y))), e1 = div_lambda.div(exp1_from_uniform(res53(os.z, os.w)));
+            double sv0 = sec_d(nsd(e0)), sv1 = sec_d(nsd(e1));                     // Duration.from_seconds(sample).to_seconds()
+            if (ds) {
+                const double up = dpp_orv<0x138, 0xf>(sv1, carry_sv);
+                carry_sv = rl64(sv1, 63);
+                sv1 = sv0; sv0 = up;
+            }
+            const double du0 = nsd(sv0), du1 = nsd(sv1);
+            // ---- C: arrival times.  a0 / a1 = arrival of slots 2 lane / 2 lane + 1, an = the tick after slot 2 lane + 1
+            double a0, a1, an;
+            {
+                const double F0 = __dmul_rn(inc0, 1e9), F1 = __dmul_rn(inc1, 1e9);
+                const double fl0 = __builtin_floor(F0), fl1 = __builtin_floor(F1);
+                const double fr0 = __dsub_rn(F0, fl0), fr1 = __dsub_rn(F1, fl1);
+                constexpr double m = 1.0 / 1024.0;
+                const bool safe0 = spec && fr0 >= m && fr0 <= 1.0 - m && F0 < 549755813888.0;
+                const bool safe1 = spec && fr1 >= m && fr1 <= 1.0 - m && F1 < 549755813888.0;
+                const double f0 = safe0 ? fl0 : 0.0, f1 = safe1 ? fl1 : 0.0;
+                const double ps = f0 + f1;
+                double I = ps;                                                   // inclusive scan over the lanes (whole numbers: exact)
+                I += dpp_or0<0x111, 0xf>(I); I += dpp_or0<0x112, 0xf>(I); I += dpp_or0<0x114, 0xf>(I); I += dpp_or0<0x118, 0xf>(I);
+                I += dpp_or0<0x142, 0xa>(I);                                     // rows 1 and 3 take the row before them
+                I += dpp_or0<0x143, 0xc>(I);                                     // rows 2 and 3 take rows 0-1
+                a0 = base_a + (I - ps); a1 = a0 + f0; an = base_a + I;
+                unsigned long long ub0 = __ballot(!safe0), ub1 = __ballot(!safe1);
+                while ((ub0 | ub1) != 0ull) {                                    // the increments too close to a whole number, in order
+                    const int l0 = ub0 ? (int)__builtin_ctzll(ub0) : 64, l1 = ub1 ? (int)__builtin_ctzll(ub1) : 64;
+                    const bool at0 = l0 <= l1;                                   // position 2 l0 before position 2 l1 + 1
+                    const int lu = at0 ? l0 : l1;
+                    const double au = at0 ? rl64(a0, lu) : rl64(a1, lu), iu = at0 ? rl64(inc0, lu) : rl64(inc1, lu);
+                    const double dl = nsd(__dadd_rn(sec_d(au), iu)) - au;        // the reference's step, exactly
+                    if (at0) { if (lane >= lu) { a1 += dl; an += dl; } if (lane > lu) a0 += dl; ub0 &= ub0 - 1; }
+                    else { if (lane >= lu) an += dl; if (lane > lu) { a0 += dl; a1 += dl; } ub1 &= ub1 - 1; }
+                }
+            }
+            const double base_next = rl64(an, 63);
+            // ---- L: Lindley recursion as a (max, +) scan (hs_kernels_wide.hpp MaxPlus), two requests per lane
+            MaxPlus F = mp_after(MaxPlus{a1 + du1, du1}, MaxPlus{a0 + du0, du0});
+            F = mp_scan_step<0x111, 0xf>(F); F = mp_scan_step<0x112, 0xf>(F); F = mp_scan_step<0x114, 0xf>(F); F = mp_scan_step<0x118, 0xf>(F);
+            F = mp_scan_step<0x142, 0xa>(F);                                     // rows 1 and 3 take the row before them
+            F = mp_scan_step<0x143, 0xc>(F);                                     // rows 2 and 3 take rows 0-1
+            const MaxPlus E{dpp_orneg<0x138, 0xf>(F.p), dpp_or0<0x138, 0xf>(F.q)};   // composition of the lanes before this one (lane 0: the identity)
+            const double Dp_in = __builtin_fmax(E.p, carryD + E.q);              // D of the request before this lane's first (-inf + q = -inf)
+            const double S0 = __builtin_fmax(a0, Dp_in), D0 = S0 + du0;
+            const double S1 = __builtin_fmax(a1, D0), D1 = S1 + du1;
+            const double Sp_in = dpp_orv<0x138, 0xf>(S1, carryS);                // S of the request before this lane's first
+            // which reference events happen (Station::req_step), request by request
+            const bool arr0 = a0 <= Td, arr1 = a1 <= Td;
+            const bool st0 = arr0 && S0 <= Td, st1 = arr1 && S1 <= Td;
+            const bool dp0 = st0 && D0 <= Td, dp1 = st1 && D1 <= Td;
+            const bool hz0 = (arr0 && (a0 == Sp_in || a0 == Dp_in || a1 <= a0)) || (st0 && du0 == 0.0);
+            const bool hz1 = (arr1 && (a1 == S0 || a1 == D0 || an <= a1)) || (st1 && du1 == 0.0);
+            if (__ballot(hz0 || hz1) != 0ull) { bailed = true; fin = true; }
+            if (!bailed) {
+                const unsigned long long b_arr0 = __ballot(arr0), b_arr1 = __ballot(arr1);
+                const unsigned long long b_st0 = __ballot(st0), b_st1 = __ballot(st1), b_dp0 = __ballot(dp0), b_dp1 = __ballot(dp1);
+                const int n_arr_l = __popcll(b_arr0) + __popcll(b_arr1);
+                n_tick += (uint32_t)n_arr_l;
+                n_notify += (uint32_t)(__popcll(__ballot(arr0 && Sp_in < a0)) + __popcll(__ballot(arr1 && S0 < a1)));
+                n_poll += (uint32_t)(__popcll(__ballot(arr0 && Dp_in < a0)) + __popcll(__ballot(arr1 && D0 < a1)));
+                n_start += (uint32_t)(__popcll(b_st0) + __popcll(b_st1));
+                n_dep += (uint32_t)(__popcll(b_dp0) + __popcll(b_dp1));
+                auto slot_of = [&](const double &x0, const double &x1, int p) { return (p & 1) ? rl64(x1, p >> 1) : rl64(x0, p >> 1); };
+                // the latest processed event: arrivals, starts and departures are each in request order, and each a prefix of the step
+                if (n_arr_l > 0) { const double v = slot_of(a0, a1, n_arr_l - 1); lt_d = v > lt_d ? v : lt_d; }
+                const int n_st_l = __popcll(b_st0) + __popcll(b_st1), n_dp_l = __popcll(b_dp0) + __popcll(b_dp1);
+                if (n_st_l > 0) { const double v = slot_of(S0, S1, n_st_l - 1); lt_d = v > lt_d ? v : lt_d; }
+                if (n_dp_l > 0) { const double v = slot_of(D0, D1, n_dp_l - 1); lt_d = v > lt_d ? v : lt_d; }
+                // the one request (at most) that started and is still in service at the end of the window: the last one that started
+                if (n_st_l > n_dp_l) {
+                    const int pp = n_st_l - 1;
+                    pend_new = true;
+                    if (lane == 0) {
+                        s_pend[w][0] = slot_of(D0, D1, pp); s_pend[w][1] = slot_of(S0, S1, pp); s_pend[w][2] = slot_of(a0, a1, pp);
+                        s_pend[w][3] = pp >= 1 ? slot_of(a0, a1, pp - 1) : carryA;
+                        s_pend[w][4] = (double)(r0 + pp); s_pend[w][5] = slot_of(sv0, sv1, pp);
+                        s_pend[w][6] = pp >= 1 ? slot_of(S0, S1, pp - 1) : carryS;  // S of the request before it
+                    }
+                }
+                // ---- the step's records -> LDS (coalesced transposed write below); service samples for T
+                st_a[w][2 * lane] = arr0 ? to_i64(a0) : INT64_MIN; st_a[w][2 * lane + 1] = arr1 ? to_i64(a1) : INT64_MIN;
+                st_d[w][2 * lane] = dp0 ? to_i64(D0) : INT64_MIN; st_d[w][2 * lane + 1] = dp1 ? to_i64(D1) : INT64_MIN;
+                if (n_dp_l > 0) { s_sv[sb][w][2 * lane] = sv0; s_sv[sb][w][2 * lane + 1] = sv1; }
+                cnt_sv = n_dp_l;
+                did = true; rows_clear = false;
+                if (lane == 0) {
+                    s_base[w][0] = accepted + r0; s_base[w][1] = sink_w + (int64_t)dep0 + r0;
+                    // the pending tick and the two ticks before it (lineage, Station::req_finish)
+                    if (n_arr_l > 0) {
+                        const double last = slot_of(a0, a1, n_arr_l - 1);
+                        s_tick[w][2] = n_arr_l >= 2 ? slot_of(a0, a1, n_arr_l - 2) : s_tick[w][1];
+                        s_tick[w][1] = last;
+                    }
+                    s_tick[w][0] = n_arr_l < R ? slot_of(a0, a1, n_arr_l) : base_next;
+                }
+                if (n_arr_l < R) fin = true;
+                r0 += n_arr_l;
+                carryD = rl64(D1, 63); carryS = rl64(S1, 63); carryA = rl64(a1, 63);
+                base_a = base_next;
+            }
         }
-        // carries into the next step
-        carryD = rl64(D1, 63); carryS = rl64(S1, 63); carryA = rl64(a1, 63);
-        base_a = base_next;
-        r0 += R;
-        first = false;
+        if (!did && !rows_clear) {                        // nothing to write for this LP in this step (done, or bailed): clear its rows once
+            st_a[w][2 * lane] = INT64_MIN; st_a[w][2 * lane + 1] = INT64_MIN; st_d[w][2 * lane] = INT64_MIN; st_d[w][2 * lane + 1] = INT64_MIN;
+            rows_clear = true;
+        }
+        if (lane == 0) s_cnt[sb][w] = (flags & (1 << 18)) ? 0 : cnt_sv;
+#ifdef HS_WAVE_CYC
+        const unsigned long long c1_ = __builtin_readcyclecounter();
+        cyc_compute += c1_ - c0_;
+#endif
         // ---- the workgroup writes the step's records: 16 neighbouring LPs' k-th records are one line
         __syncthreads();
+#ifdef HS_WAVE_CYC
+        const unsigned long long c2_ = __builtin_readcyclecounter();
+        cyc_bar += c2_ - c1_;
+#endif
         if (!(flags & (1 << 19))) {
+            // (the thread's slot / LP / addresses are recomputed every step: hoisted out of the loop they spill to scratch under the
+            //  64-VGPR budget, and every reload waits for vmcnt(0), i.e. for the stores before it -- 5 000 cycles per step, measured)
+            int tx = (int)threadIdx.x;
+            asm volatile("" : "+v"(tx));
+            const int ww = tx % NW, s0 = tx / NW;
+            const int64_t ba = s_base[ww][0], bd = s_base[ww][1];
+            int64_t *const pa = L.adm + (lp0 + ww), *const pd = L.sink_t + (lp0 + ww);
 #pragma unroll
             for (int it = 0; it < R / 64; ++it) {
-                const int idx = it * (NW * 64) + (int)threadIdx.x;
-                const int slot = idx / NW, ww = idx % NW;
+                const int slot = s0 + it * 64;
                 const int64_t va = st_a[ww][slot], vd = st_d[ww][slot];
-                const int64_t ka = s_base[ww][0] + slot, kd = s_base[ww][1] + slot;
-                if (va != INT64_MIN) { if (ka < L.cap) L.adm[(size_t)ka * n + lp0 + ww] = va; else overflow = 1; }
-                if (vd != INT64_MIN) { if (kd < L.cap) L.sink_t[(size_t)kd * n + lp0 + ww] = vd; else overflow = 1; }
+                const int64_t ka = ba + slot, kd = bd + slot;
+                if (va != INT64_MIN) { if (ka < L.cap) pa[(size_t)ka * n] = va; else overflow = 1; }
+                if (vd != INT64_MIN) { if (kd < L.cap) pd[(size_t)kd * n] = vd; else overflow = 1; }
             }
         }
+#ifdef HS_WAVE_CYC
+        cyc_phase2 += __builtin_readcyclecounter() - c2_;
+#endif
     }
+#ifdef HS_WAVE_CYC
+    const unsigned long long cyc_loop1 = __builtin_readcyclecounter();
+#endif
+    if (step > 0) service_sum((step - 1) & 1);           // T of the last step
+    if (w == 0 && lane < NW) s_ts[lane] = ts_mine;
+    __syncthreads();
+    total_service = s_ts[w];
     lt = (int64_t)lt_d;
-    {   // the lanes' latest event: maximum over the wavefront
-        long long mx = (long long)lt;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const long long d = shfl_xor_ll(mx, o); mx = d > mx ? d : mx; }
-        lt = mx;
-    }
     const int ovf_w = __any(overflow) ? 1 : 0;
 
     // ---- fold the window into the LP's state (Station::req_finish): wave-uniform values, lane 0 stores
-    if (pend_new) pend = true;
+    int64_t pendD = Dprev, pendS = Sprev, pend_i = 0;
+    double pend_s = svc_s0, pendA_d = 0.0, pendAp_d = 0.0, pendSp_d = 0.0;
+    if (pend_new) {
+        pend = true;
+        pendD = to_i64(s_pend[w][0]); pendS = to_i64(s_pend[w][1]); pendA_d = s_pend[w][2]; pendAp_d = s_pend[w][3];
+        pend_i = (int64_t)s_pend[w][4]; pend_s = s_pend[w][5]; pendSp_d = s_pend[w][6];
+    }
+    const double A_next = s_tick[w][0], a_last = s_tick[w][1], a_last2 = s_tick[w][2];
+    const int64_t n_arr_total = r0;
     Candidate mine = cand_none(live ? lp : 0);
     unsigned ev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool count = run && !bailed;
@@ -351,15 +433,14 @@ __global__ void __launch_bounds__(NW * 64) hs_station_wave(StationParams P, Stat
         const int64_t acc2 = accepted + c_tick, st2 = started + c_start;
         const int64_t A_next_i = A != kInfNs ? (int64_t)A_next : A;
         const int64_t crtA2 = c_tick ? (int64_t)a_last : crtA0;
-        uint32_t seq = X.seq[lp];
-        uint32_t seqA = X.seqA[lp], seqD = X.seqD[lp];
+        uint32_t seq = seq_in, seqA = seqA_in, seqD = seqD_in;
         if ((c_tick | c_start) != 0u) {                  // creation stamps: only their order matters (Station::req_finish)
             const bool d_first = pend && pendS < crtA2;
             seqA = seq + (d_first ? 1u : 0u); seqD = seq + (d_first ? 0u : 1u); seq += 2u;
         }
         // lineage of what is pending now (Station::req_finish)
-        int32_t dpA = X.dpA[lp], dpD = X.dpD[lp];
-        int64_t rcA = X.rcA[lp], rcD = X.rcD[lp];
+        int32_t dpA = dpA_in, dpD = dpD_in;
+        int64_t rcA = rcA_in, rcD = rcD_in;
         if (c_tick) { dpA = 1; rcA = acc2 >= 2 ? (c_tick >= 2 ? (int64_t)a_last2 : L.adm[(size_t)(acc2 - 2) * n + lp]) : crtA0; }
         if (pend && pend_new) {
             const int64_t m = st2 - 1;                   // the request in service: it started at pendS
@@ -367,15 +448,18 @@ __global__ void __launch_bounds__(NW * 64) hs_station_wave(StationParams P, Stat
                 dpD = 6;
                 rcD = m >= 1 ? (pend_i >= 1 ? (int64_t)pendAp_d : (m - 1 < L.cap ? L.adm[(size_t)(m - 1) * n + lp] : 0)) : crtA0;
             } else {                                     // ... when request m - 1 left: four steps from that continuation, created when IT started
-                Stream st;
-                st.init(((uint64_t)key1 << 32) | key0, ((uint64_t)ssid1 << 32) | ssid0, (uint64_t)(m - 1));
-                const double s_prev = seconds_from_ns(ns_from_seconds(div_lambda.div(exp1_from_uniform(st.next_uniform()))));
-                dpD = 4; rcD = pendS - ns_from_seconds(s_prev);
+                dpD = 4; rcD = (int64_t)pendSp_d;        // (= pendS - its service time: Station::req_finish draws that again)
             }
         }
+        // (the read-modify-write counters: every load before the first store -- the pointers may alias as far as the compiler knows, and
+        //  a load behind each store is a memory round trip each)
+        const int64_t o_gen = X.generated[lp], o_comp = X.completed[lp], o_recv = X.received[lp], o_events = X.events[lp];
+        int64_t o_ev[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o_ev[k] = X.ev_kind[(size_t)k * n + lp];
         if (lane == 0) {
-            X.generated[lp] += c_tick; X.accepted[lp] = acc2; X.started[lp] = st2; X.completed[lp] += c_dep;
-            X.received[lp] += c_dep; X.sink_w[lp] = sink_w + c_dep;
+            X.generated[lp] = o_gen + c_tick; X.accepted[lp] = acc2; X.started[lp] = st2; X.completed[lp] = o_comp + c_dep;
+            X.received[lp] = o_recv + c_dep; X.sink_w[lp] = sink_w + c_dep;
             X.buf[lp] = (int64_t)c_tick - (int64_t)c_start;
             X.active[lp] = pend ? 1 : 0;
             X.D[lp] = pend ? pendD : kInfNs;
@@ -389,8 +473,8 @@ __global__ void __launch_bounds__(NW * 64) hs_station_wave(StationParams P, Stat
             if (pend && pend_new) { X.dpD[lp] = (uint8_t)dpD; X.rcD[lp] = rcD; }
             uint32_t tot_ev = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { X.ev_kind[(size_t)k * n + lp] += ev[k]; tot_ev += ev[k]; }
-            X.events[lp] += tot_ev;
+            for (int k = 0; k < 8; ++k) { X.ev_kind[(size_t)k * n + lp] = o_ev[k] + ev[k]; tot_ev += ev[k]; }
+            X.events[lp] = o_events + tot_ev;
         }
         // this LP's candidate for the one event beyond end_ns (make_candidate / pick_root: creation stamps decide a tie)
         const int64_t Dn = pend ? pendD : kInfNs;
@@ -434,4 +518,10 @@ __global__ void __launch_bounds__(NW * 64) hs_station_wave(StationParams P, Stat
         for (int q = 1; q < NW; ++q) if (cand_less(wave_c[q], b)) b = wave_c[q];
         cands[blockIdx.x] = b;
     }
+#ifdef HS_WAVE_CYC
+    if (blockIdx.x == 0 && lane == 0 && (w == 0 || w == 1)) {     // dbg[0..3]: wavefront 1 {compute, barrier wait, T + writes, before + after the loop}
+        const unsigned long long end_ = __builtin_readcyclecounter();
+        if (w == 1) { tot->dbg[0] = cyc_compute; tot->dbg[1] = cyc_bar; tot->dbg[2] = cyc_phase2; tot->dbg[3] = (cyc_loop0 - cyc_k0) * 1000000ull + (end_ - cyc_loop1); }
+    }
+#endif
 }

@@ -116,4 +116,4 @@ def test_8192_lps_run_at_least_twice_as_fast_as_one_lane_each():
             k, _ = eng.bench_runs(end, 10)
             times[name] = float(np.median(k))
     print(times)
-    assert times["wide"] < 0.3 * times["one lane per LP"], times      # (measured r4: 0.168 vs 0.39 ms; r5, a wavefront per LP: see DESIGN section 6)
+    assert times["wide"] < 0.35 * times["one lane per LP"], times      # (measured r4: 0.168 vs 0.39 ms; r5, a wavefront per LP: see DESIGN section 6)

@@ -37,8 +37,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", default="1024,4096,8192,16384,32768,65536")
     ap.add_argument("--cycles", action="store_true")
+    ap.add_argument("--wave-cycles", action="store_true", help="library built with -DHS_WAVE_CYC: cycles of wavefront 1 of workgroup 0 of hs_station_wave")
     a = ap.parse_args()
     for n in (int(x) for x in a.sizes.split(",")):
+        if a.wave_cycles:
+            for K in (64, 65):
+                st = StationArrays.uniform(n, rate=8.0, mean=0.1)
+                with StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=END, seed=42) as eng:
+                    eng.set_debug_flags(FORCE[K])
+                    eng.run_until(END)
+                    out = (C.c_ulonglong * 4)()
+                    eng._lib.hs_debug_async_counters(eng._h, out)
+                    print(f"n_lp {n} K {K}: cycles of wavefront 1 of workgroup 0: compute {out[0]}, barrier wait {out[1]}, T + writes {out[2]}, "
+                          f"before the loop {out[3] // 1000000}, after it {out[3] % 1000000}", flush=True)
+            continue
         if a.cycles:
             for K in (4, 8):
                 st = StationArrays.uniform(n, rate=8.0, mean=0.1)
