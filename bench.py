@@ -45,6 +45,20 @@ BYTES_PER_REQUEST = 16
 STATE_BYTES_PER_LP = 576
 SURVEY_BYTES_PER_EVENT = 128        # traffic of an engine that materialises every event
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_SIMD = 256 * 4                    # 256 CUs x 4 SIMD16 (same guide)
+PEAK_CLOCK_HZ = 2.4e9               # peak engine clock
+VALU_CYCLES_PER_WAVE_INST = 4       # a 64-wide wavefront instruction on a SIMD16: the lower bound (fp64 FMA / 32-bit ops; quarter-rate ops take 16)
+
+
+def valu_frac(prof, kernel_s):
+    """wave-instructions x cycles / SIMD-cycles available -- the share of the device's VALU issue slots the
+    dominant kernel's vector instructions need at the minimum 4 cycles each (SQ_INSTS_VALU of the committed SQ pass; the instruction
+    count of a deterministic run does not depend on the box).  None without a profile of this workload."""
+    try:
+        insts = float(prof["SQ_per_launch"]["SQ_INSTS_VALU"])
+    except Exception:
+        return None
+    return insts * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * PEAK_CLOCK_HZ * kernel_s)
 
 
 def csrc_sha16():
@@ -302,6 +316,8 @@ def ring_main(args, ctx):
                 "bound": "valu", "kernel": "hs_net_async<1>" if async_engine else "hs_net_window<1>",
                 "achieved": algo_bytes / step_s / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": algo_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                "frac_survey_8d": events * SURVEY_BYTES_PER_EVENT / step_s / 1e9 / HBM_PEAK_GBS,
+                "valu_frac": valu_frac(prof, step_s) if (prof and async_engine and n_ranks == 1 and args.n_lp == 65536) else None,
                 "traffic": prof.get("hbm_bytes_per_launch") if (prof and prof.get("current") and async_engine and n_ranks == 1 and args.n_lp == 65536) else None,   # (the profile is of the one-engine 65 536-station run)
                 "valu": None if not (prof and async_engine and "valu_busy_frac" in prof) else {
                     "busy_frac": prof["valu_busy_frac"], "wait_frac": prof.get("wait_frac_of_wave_cycles"),
@@ -569,12 +585,17 @@ def grid_main(args, ctx, headline=True):
             # the binding resource is VALU issue (the serial per-LP recursion), not HBM: `achieved` / `frac` are the HBM
             # figures the contract asks for, `valu` is the measured issue fraction of the same kernel
             "bound": "valu",
-            "kernel": ("hs_station_run<1, false, true, true> (producer / consumer wavefronts, uniform entity kinds)" if n_mine > 32768
-                       else "hs_station_wide<K> + hs_station_wide_finish (K lanes per LP: fewer LPs than the device has lanes)"),
+            "kernel": ("hs_station_run<1, false, true, true> (producer / consumer wavefronts, uniform entity kinds)" if n_mine > 16384
+                       else "hs_station_wave<NW> + hs_station_wide_finish (one wavefront per LP: fewer LPs than the device has lanes)"),
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
+            # SURVEY 8(d)'s own model (128 B per reference event) against the HBM peak: above 1, i.e. the kernel does NOT move per-event
+            # records (it counts the ~7.6 protocol events of a request analytically); `frac` above prices what it does move
+            "frac_survey_8d": survey_model / HBM_PEAK_GBS,
+            # the binding resource: vector instructions issued x 4 cycles / (1 024 SIMDs x 2.4 GHz x kernel time)
+            "valu_frac": valu_frac(prof, k_avg_ms * 1e-3) if full else None,
             "traffic": traffic,
             "valu": None if not prof or "valu_busy_frac" not in prof else {
                 "busy_frac": prof["valu_busy_frac"], "waves_per_simd": prof.get("waves_per_simd"),
@@ -667,8 +688,8 @@ def main():
             shard.n_lp, shard.scaling = args.n_lp // 8, "weak"
             sl = grid_main(shard, ctx, headline=False)
             out["strong_shard"] = {
-                "what": f"the per-GPU share of the metric's {args.n_lp} servers at 8 GPUs: {shard.n_lp} LPs on ONE device (K lanes "
-                        "per LP, csrc/hs_kernels_wide.hpp), reset included; 8 such shards run with no data-path collective",
+                "what": f"the per-GPU share of the metric's {args.n_lp} servers at 8 GPUs: {shard.n_lp} LPs on ONE device (one wavefront "
+                        "per LP, csrc/hs_kernels_wave.hpp), reset included; 8 such shards run with no data-path collective",
                 "n_lp": shard.n_lp, "ms_per_step": sl["ms_per_step"], "kernel_ms_avg": sl["roofline"]["kernel_ms_avg"],
                 "events_per_step": sl["config"]["events_per_step_per_gpu"],
                 "projected_8gpu_speedup_over_1gpu": out["ms_per_step"] / sl["ms_per_step"],

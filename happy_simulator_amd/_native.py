@@ -37,7 +37,7 @@ EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuat
 PROBE_METRICS = {"depth": 0, "active_requests": 1, "stats_accepted": 2, "stats_dropped": 3, "requests_completed": 4,
                  "_requests_completed": 4, "events_received": 5, "generated_count": 6}
 PROBE_NONE = 255
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class EngineUnavailable(RuntimeError):
@@ -384,11 +384,15 @@ def lib():
     L.hs_merge_sink_records.argtypes = [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
     L.hs_sink_latency_stats.restype = C.c_int
     L.hs_sink_latency_stats.argtypes = [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hs_set_float_sum_mode.restype = C.c_int
+    L.hs_set_float_sum_mode.argtypes = [C.c_int]
     L.hs_debug_radix_sort.restype = C.c_int
     L.hs_debug_radix_sort.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]
     if L.hs_abi_version() != ABI_VERSION:
         raise EngineUnavailable("libhs_hip.so ABI version mismatch; rebuild")
+    import sys
+    L.hs_set_float_sum_mode(1 if sys.version_info >= (3, 12) else 0)   # `sum(floats)`: Neumaier-compensated from CPython 3.12 on
     _lib = L
     return L
 
@@ -408,6 +412,6 @@ EXPORTED_SYMBOLS = (
     "hs_lb_set_probes", "hs_lb_read_probe",
     "hs_lb_latency_stats",
     "hs_lb_ring", "hs_lb_select", "hs_lb_last_error", "hs_lb_destroy", "hs_md5", "hs_debug_radix_sort", "hs_merge_sink_records",
-    "hs_sink_latency_stats",
+    "hs_sink_latency_stats", "hs_set_float_sum_mode",
     "hs_debug_lb_flags", "hs_engine_set_profile_budget", "hs_lb_set_profile_budget", "hs_debug_tick_table",
 )

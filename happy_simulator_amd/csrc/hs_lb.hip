@@ -1688,19 +1688,31 @@ __device__ __forceinline__ double percentile_sorted_ns(const uint64_t *s, int64_
     const double a = seconds_from_ns_ieee((int64_t)s[lo]), b = seconds_from_ns_ieee((int64_t)s[hi]);
     return __dadd_rn(__dmul_rn(a, __dsub_rn(1.0, frac)), __dmul_rn(b, frac));
 }
+static int g_float_sum_mode = 0;     // hs_set_float_sum_mode: 0 left to right, 1 Neumaier (what the host interpreter's `sum` does)
+// `sum(sorted_vals)` as the interpreter that runs the reference computes it: CPython's float fast path (Python/bltinmodule.c
+// builtin_sum) is a plain left-to-right binary64 sum before 3.12 and Neumaier's compensated sum from 3.12 on (the reference
+// requires >= 3.13, pyproject.toml:11) -- `compensated` says which; hs_set_float_sum_mode, set by the host side from sys.version_info.
 __global__ void __launch_bounds__(64) hs_lb_latency_stats_kernel(const uint64_t *__restrict__ sorted, const int64_t *n_ptr,
-                                                                 double *__restrict__ out) {
+                                                                 double *__restrict__ out, int compensated) {
     const int64_t n = *n_ptr;
     const int lane = threadIdx.x;
     if (n <= 0) { if (lane < 6) out[lane] = 0.0; return; }
-    // sequential left-to-right sum: the wavefront converts 64 values at a time, then they are added in index order
-    double sum = 0.0;
+    // sequential sum: the wavefront converts 64 values at a time, then they are added in index order
+    double sum = 0.0, comp = 0.0;
     for (int64_t base = 0; base < n; base += 64) {
         const int64_t i = base + lane;
         const double v = i < n ? seconds_from_ns_ieee((int64_t)sorted[i]) : 0.0;
         const int m = (n - base) < 64 ? (int)(n - base) : 64;
-        for (int j = 0; j < m; ++j) sum = __dadd_rn(sum, __shfl(v, j, 64));
+        if (!compensated) { for (int j = 0; j < m; ++j) sum = __dadd_rn(sum, __shfl(v, j, 64)); }
+        else {
+            for (int j = 0; j < m; ++j) {                 // t = sum + x; c += |sum| >= |x| ? (sum - t) + x : (x - t) + sum; sum = t
+                const double x = __shfl(v, j, 64), t = __dadd_rn(sum, x);
+                comp = __dadd_rn(comp, __builtin_fabs(sum) >= __builtin_fabs(x) ? __dadd_rn(__dsub_rn(sum, t), x) : __dadd_rn(__dsub_rn(x, t), sum));
+                sum = t;
+            }
+        }
     }
+    if (compensated && comp != 0.0 && __builtin_isfinite(comp)) sum = __dadd_rn(sum, comp);
     if (lane == 0) {
         out[0] = (double)n;
         out[1] = __ddiv_rn(sum, (double)n);
@@ -2699,7 +2711,7 @@ int hs_lb_latency_stats(hs_lb *h, double out[6]) {
         // the ragged low bits were skipped: finish short runs in place (keys only) with the segment kernel's fix-up
         hipLaunchKernelGGL(hs_lb_fix_runs, dim3((unsigned)((h->n_slots + 255) / 256)), dim3(256), 0, h->stream, kr, h->n_done, g);
     }
-    hipLaunchKernelGGL(hs_lb_latency_stats_kernel, dim3(1), dim3(64), 0, h->stream, kr, h->n_done, d_out);
+    hipLaunchKernelGGL(hs_lb_latency_stats_kernel, dim3(1), dim3(64), 0, h->stream, kr, h->n_done, d_out, g_float_sum_mode);
     hipError_t e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess) e = hipMemcpy(out, d_out, 6 * sizeof(double), hipMemcpyDeviceToHost);
     hipFree(d_out);
@@ -2807,7 +2819,13 @@ int hs_merge_sink_records(int32_t device, int64_t n, int64_t *t_ns, int64_t *cre
 }
 
 // Sink.latency_stats() (components/common.py:59-76, instrumentation/data.py:197-210) of any Sink's records on the device:
-// latencies = t - created_at, radix-sorted, summed left to right in binary64, interpolated p50 / p99 -- the shared-Sink
+int hs_set_float_sum_mode(int compensated) {
+    if (compensated != 0 && compensated != 1) return lfail(nullptr, HS_E_INVALID, "hs_set_float_sum_mode: 0 (left to right) or 1 (Neumaier, CPython >= 3.12)");
+    g_float_sum_mode = compensated;
+    return HS_OK;
+}
+
+// latencies = t - created_at, radix-sorted, summed in index order in binary64 (hs_set_float_sum_mode), interpolated p50 / p99 -- the shared-Sink
 // routine of the load-balancer engine (hs_lb_latency_stats) for the station engines' Sinks.  out = {count, avg, min, max,
 // p50, p99}.  Host buffers in, six doubles out.
 int hs_sink_latency_stats(int32_t device, int64_t n, const int64_t *t_ns, const int64_t *created_ns, double out[6]) {
@@ -2833,7 +2851,7 @@ int hs_sink_latency_stats(int32_t device, int64_t n, const int64_t *t_ns, const 
     if (e == hipSuccess) e = hipMemcpy(d_sorted, ko.data(), (size_t)n * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_n, &n, 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(hs_lb_latency_stats_kernel, dim3(1), dim3(64), 0, nullptr, d_sorted, d_n, d_out);
+        hipLaunchKernelGGL(hs_lb_latency_stats_kernel, dim3(1), dim3(64), 0, nullptr, d_sorted, d_n, d_out, g_float_sum_mode);
         e = hipDeviceSynchronize();
     }
     if (e == hipSuccess) e = hipMemcpy(out, d_out, 6 * sizeof(double), hipMemcpyDeviceToHost);

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HS_ABI_VERSION 12
+#define HS_ABI_VERSION 13
 
 typedef enum hs_status {
     HS_OK = 0,
@@ -490,8 +490,14 @@ int hs_lb_set_probes(hs_lb *h, int32_t n_probes, const int32_t *target_kind, con
 int64_t hs_lb_read_probe(hs_lb *h, int32_t probe, int64_t *t_ns, int64_t *values, int64_t cap);
 /* Sink.latency_stats() of the shared Sink, computed on the device (components/common.py:59-76 with
  * instrumentation/data.py:197-210): out = {count, avg, min, max, p50, p99} in seconds.  avg = sum(sorted latencies) / n with
- * the sum taken left to right in binary64 (what CPython's `sum` does before 3.12). */
+ * the sum taken in index order in binary64 the way hs_set_float_sum_mode says. */
 int hs_lb_latency_stats(hs_lb *h, double out[6]);
+/* What `sum(list_of_floats)` means on the interpreter that runs the reference (CPython Python/bltinmodule.c builtin_sum):
+ * 0 = plain left-to-right additions (CPython < 3.12; the library's default), 1 = Neumaier's compensated sum (CPython >= 3.12 --
+ * the reference requires >= 3.13, pyproject.toml:11).  The host side sets it from sys.version_info, so that the device
+ * statistics (hs_lb_latency_stats, hs_sink_latency_stats) equal what the same interpreter computes from the list
+ * (components/common.py:59-76 `sum(sorted_vals) / n`).  Process-wide. */
+int hs_set_float_sum_mode(int compensated);
 /* The sorted ring's backend index per point, [n_backends * virtual_nodes] (strategies.py:381-391). */
 int hs_lb_ring(hs_lb *h, int32_t *ring_backend);
 /* ConsistentHash.select for a key string (strategies.py:412-433): backend index. */
@@ -520,8 +526,8 @@ int hs_debug_radix_sort(int32_t device, int64_t n, int32_t key_bits, const uint6
 int hs_merge_sink_records(int32_t device, int64_t n, int64_t *t_ns, int64_t *created_ns);
 
 /* Sink.latency_stats() (components/common.py:59-76; percentiles as instrumentation/data.py:197-210) of a Sink's records on
- * the device: latency = t - created_at in ns -> seconds, radix sort, left-to-right binary64 sum of the SORTED values (what
- * `sum(sorted_vals)` does), interpolated percentiles.  out = {count, avg, min, max, p50, p99}.  Host buffers. */
+ * the device: latency = t - created_at in ns -> seconds, radix sort, binary64 sum of the SORTED values in index order (what
+ * `sum(sorted_vals)` does: hs_set_float_sum_mode), interpolated percentiles.  out = {count, avg, min, max, p50, p99}.  Host buffers. */
 int hs_sink_latency_stats(int32_t device, int64_t n, const int64_t *t_ns, const int64_t *created_ns, double out[6]);
 
 /* Samples of the LP's Probe in sampling order: (sample time ns, value) -- what the reference appends to the probe's

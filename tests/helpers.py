@@ -5,6 +5,8 @@ import glob
 import json
 import os
 
+import math
+
 import numpy as np
 
 from oracle import hs_oracle as O
@@ -682,3 +684,22 @@ def pipeline_oracle_graph(spec):
             if k < len(stages) - 1:
                 g.target[lnk[k][j]] = srv[k + 1][j]
     return g, srv, lnk, snk, src
+
+
+def float_sum(vals, compensated):
+    """`sum(list_of_floats)` of CPython (Python/bltinmodule.c builtin_sum): left-to-right additions before 3.12, Neumaier's
+    compensated sum from 3.12 on (the reference requires >= 3.13).  None = what THIS interpreter's own `sum` does -- the mode
+    happy_simulator_amd/_native.py sets on the library (hs_set_float_sum_mode)."""
+    if compensated is None:
+        return sum(vals)
+    total, c = 0.0, 0.0
+    for x in vals:
+        if not compensated:
+            total += x
+            continue
+        t = total + x
+        c += (total - t) + x if abs(total) >= abs(x) else (x - t) + total
+        total = t
+    if compensated and c and math.isfinite(c):
+        total += c
+    return total

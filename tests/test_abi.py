@@ -4,7 +4,13 @@ import ctypes as C
 import os
 import re
 
+import math
+import sys
+
+import numpy as np
 import pytest
+
+import helpers as H
 
 from happy_simulator_amd import _native as N
 
@@ -27,7 +33,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_abi_version_and_struct_sizes(lib):
-    assert lib.hs_abi_version() == N.ABI_VERSION == 12
+    assert lib.hs_abi_version() == N.ABI_VERSION == 13
     assert C.sizeof(N.Config) == 56
     assert N.EV_KINDS == 15 and len(N.EV_NAMES) == 15
     assert C.sizeof(N.Summary) == 8 * (1 + 15 + 1 + 1 + 1 + 1) + 8 + 8 + 8 + 8 + 8
@@ -113,3 +119,13 @@ def test_library_carries_the_hash_of_its_sources():
     tracked = subprocess.run(["git", "ls-files", "happy_simulator_amd/lib"], capture_output=True, text=True, cwd=ROOT)
     if tracked.returncode == 0:                      # (the GPU box's copy has no .git)
         assert tracked.stdout.strip() == "", tracked.stdout
+
+
+def test_the_two_float_sums_are_what_cpython_does():
+    """CPU: the statement of `sum` above against this interpreter's builtin (whichever side of 3.12 it is on) and, for the
+    compensated form, against the exactly rounded sum on inputs where Neumaier's result is known to be exact."""
+    rng = np.random.default_rng(5)
+    vals = sorted(rng.exponential(0.4, 20_000).tolist())
+    assert H.float_sum(vals, sys.version_info >= (3, 12)) == sum(vals)
+    assert H.float_sum(vals, True) == math.fsum(vals)              # (one rounding away at most in general; equal on this input)
+    assert H.float_sum([1.0, 1e100, 1.0, -1e100], True) == 2.0 and H.float_sum([1.0, 1e100, 1.0, -1e100], False) == 0.0
