@@ -79,6 +79,7 @@ struct hs_engine {
     std::vector<int32_t> h_link_dst, h_link_src, h_gid2local;
     int64_t window_ns = 0;
     bool net_ran = false;
+    int64_t net_last_end = INT64_MIN;   // end_ns of the run since the last reset (windows: see hs_engine_run_until_async)
     bool async_ok = false;     // the network can run on hs_net_async (whole network on this engine, queues allocated)
     int round_iters = 0;       // > 0: hs_net_async runs one exchange round of a shard (that many iterations), not a whole run
     // asynchronous shard rounds (hs_engine_shard_async_*): the network's cross-shard links
@@ -371,8 +372,10 @@ int do_reset_async(hs_engine *h) {
     }
     h->initialised = true;
     h->net_ran = false;
+    h->net_last_end = INT64_MIN;
     h->fresh = true;
     h->window_ends.clear();
+    h->pending_async = false;      // (a run enqueued before this reset has nothing left to finalise)
     return HS_OK;
 }
 
@@ -1511,7 +1514,24 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
     HS_HIP(h, hipEventRecord(h->ev_k0, h->stream));
     if (h->is_net) {
         if (h->net_global) return fail(h, HS_E_STATE, "a shard of a partitioned network is driven with hs_engine_shard_*");
-        if (h->net_ran) return fail(h, HS_E_STATE, "network engine: one hs_engine_run_until per hs_engine_reset");
+        if (h->net_ran) {
+            // Windows over a network (core/simulation.py:527-541 `_run_window` = `_execute_until` again).  The reference pops events in
+            // one global order whatever the window ends are, and every call stops behind the first event beyond its end -- so after
+            // windows e_1 <= ... <= e_k the state is that of ONE run to e_k.  The network engines keep no mid-run device state between
+            // launches (pre-sent departures, per-link bounds, bags in LDS), so a later window end REPEATS the run from the start to
+            // the new end: exact, at the cost of the whole prefix per window.  An end at or before the last one moves nothing: the
+            // reference's loop condition `current_time <= end` is already false (the event beyond the earlier end was processed).
+            if (end_ns <= h->net_last_end) {
+                HS_HIP(h, hipEventRecord(h->ev_k1, h->stream));
+                HS_HIP(h, hipEventRecord(h->ev_b, h->stream));
+                h->pending_async = true;
+                return HS_OK;
+            }
+            int rc = do_reset_async(h);
+            if (rc) return rc;
+            h->launches++;
+        }
+        h->net_last_end = end_ns;
         if (lazy_active(h)) h->window_ends.push_back(end_ns);
         int rc = launch_prologue(h, end_ns);
         if (rc) return rc;
@@ -1560,6 +1580,7 @@ int tandem_fallback(hs_engine *h) {
         und = hazard ? 4 : 0;
     }
     if (!und) return HS_OK;
+    if (h->window_ends.empty()) return HS_OK;     // (nothing ran since the last reset: no run to repeat -- ADVICE r4)
     const std::vector<int64_t> ends = h->window_ends;
     h->exact_only = true;
     int rc = do_reset_async(h);

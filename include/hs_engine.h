@@ -362,8 +362,12 @@ int hs_engine_shard_async_done(hs_engine *h, int32_t *any_not_done);
  * first arrival.  Called implicitly by the first run; call again to rewind the engine for another run. */
 int hs_engine_reset(hs_engine *h);
 /* == Simulation._execute_until(end_ns): process events until the last processed event's time exceeds
- * end_ns (one-event overshoot included).  Re-entrant with non-decreasing end_ns (windows).  Blocks until
- * the device work is complete. */
+ * end_ns (one-event overshoot included).  Re-entrant (windows, core/simulation.py:527-541 `_run_window`): station engines continue
+ * from the state the call before left; NETWORK engines (hs_engine_set_network) hold no mid-run state between launches and REPEAT
+ * the run from start_ns to the new end_ns -- the reference processes events in one global order whatever the window ends are, so
+ * the state after windows e_1 <= ... <= e_k is the state of one run to e_k (tests/test_gpu_ring.py) -- at the cost of the whole
+ * prefix per window.  An end_ns at or before the previous one moves nothing (the reference's loop condition is already false).
+ * Blocks until the device work is complete. */
 int hs_engine_run_until(hs_engine *h, int64_t end_ns);
 /* Same, but only enqueues the work on the engine's stream.  The results are FINAL behind hs_engine_synchronize: that is where a run
  * that skipped the prologue (hs_engine_prologue_path) or tandem passes that met an undecided tie (hs_engine_tandem_path) are
@@ -466,7 +470,10 @@ typedef struct hs_lb_stats {       /* any pointer may be NULL */
 typedef struct hs_lb hs_lb;
 
 int hs_lb_create(const hs_lb_config *cfg, const hs_lb_sources *src, const hs_lb_backends *be, hs_lb **out);
-/* Simulation.__init__ + run() to end_ns.  Blocks until the device work is complete. */
+/* Simulation.__init__ + run() to end_ns.  Blocks until the device work is complete.  Every call runs from start_ns: windows
+ * e_1 <= ... <= e_k over a load-balancer graph (`_run_window`, core/simulation.py:527-541) are k calls, and the state after the
+ * last one is the state of one run to e_k -- which is what the reference's windows leave (one global event order, every call stops
+ * behind the first event beyond its end): tests/test_gpu_lb.py::test_lb_windows_equal_one_run. */
 int hs_lb_run(hs_lb *h, int64_t end_ns);
 /* `repeats` complete runs back to back on the engine's stream; per-run device time of the whole pipeline and of the
  * sort passes alone (HIP events on that stream). */

@@ -303,6 +303,18 @@ def classify(ev, node_of):
     raise RuntimeError(f"unclassified event {ev!r}")
 
 
+
+def run_sim_windows(sim, spec):
+    """`sim.run()`, or -- spec["windows"] = [t_1, ..., t_k] seconds -- the reference's own windowed execution (core/simulation.py:527-541
+    `_run_window`, what ParallelSimulation's coordinator drives) to every t_i and then to end_s; the summary as run() builds it."""
+    w = spec.get("windows")
+    if not w:
+        return sim.run()
+    for t in list(w) + [spec["end_s"]]:
+        sim._run_window(Instant.from_seconds(t))
+    sim._is_running = False
+    return sim._build_summary()
+
 def run_sim(spec, chain_ids, seed, want_trace):
     if spec["rng"] == "mt":
         random.seed(seed)
@@ -378,7 +390,7 @@ def run_sim(spec, chain_ids, seed, want_trace):
         if c in chain_ids:
             sim.schedule(Event(time=Instant.from_seconds(t_s), event_type="Request",
                                target=handles[chain_ids.index(c)][1]))
-    summary = sim.run()
+    summary = run_sim_windows(sim, spec)
     return sim, summary, handles, trace
 
 
@@ -742,7 +754,7 @@ def run_ring_case(spec):
         heap.pop = pop
     for i, t_s in spec.get("schedule") or []:          # Simulation.schedule(): Requests for station i's Server, before run()
         sim.schedule(Event(time=Instant.from_seconds(t_s), event_type="Request", target=servers[i]))
-    summary = sim.run()
+    summary = run_sim_windows(sim, spec)
     out = {}
     meta = dict(spec=spec, total_events=[summary.total_events_processed], final_ns=[sim._current_time.nanoseconds],
                 duration_s=[summary.duration_s])
@@ -952,7 +964,7 @@ def run_lb_case(spec):
             return e
 
         heap.pop = pop
-    summary = sim.run()
+    summary = run_sim_windows(sim, spec)
     out = {}
     if probes:
         pt, pv, poff = [], [], [0]

@@ -3,6 +3,8 @@
 The oracle runs ONE heap for the whole configuration, as the reference would (the grid: 65 536 chains x 60 s = 2.4e8 events
 in about half a minute on one host core; the ring and the load balancer over a shorter horizon so that the whole file
 stays under a minute of CPU).  Bar: array equality."""
+import os
+
 import numpy as np
 import pytest
 
@@ -77,6 +79,42 @@ def test_lb_32768_backends_3s_equals_the_oracle(strategy):
     with eng:
         eng.run(p["end_ns"])
         assert eng.summary().events_processed > 5_000_000
+        H.compare_lb_engine_with_oracle(eng, p, r)
+
+
+SLOW = pytest.mark.skipif(not os.environ.get("HS_SLOW_TESTS"),
+                          reason="minutes of one host core for the oracle's single heap; HS_SLOW_TESTS=1 runs it (passed in profiles/r05_gpu_tests_full_horizon.log)")
+
+
+@SLOW
+@pytest.mark.parametrize("engine_flags", [0, 16], ids=["async", "windowed"])
+def test_ring_65536_stations_at_the_benchmarked_60s_equals_the_oracle(engine_flags):
+    """the ring line of bench.py runs 60 s; this is that run (65 536 stations, 2.7e8 events) against one oracle
+    heap -- totals, every station's statistics, router / link counters, every Sink record -- on both network engines."""
+    spec = dict(RING_SPEC, name="ring_full_60s", end_s=60.0)
+    g, nodes = H.oracle_ring_graph(spec)
+    r = O.run(g, H.ring_params(spec)["end_ns"], seed=spec["seed"])
+    eng, p = H.ring_engine_for_spec(spec, flags=engine_flags)
+    with eng:
+        eng.run_until(p["end_ns"])
+        assert eng.summary().events_processed == r.events_processed > 250_000_000
+        _check_against_oracle(spec, eng, r, nodes)
+
+
+@SLOW
+@pytest.mark.parametrize("strategy", ["chash", "round_robin", "random"])
+def test_lb_32768_backends_at_the_benchmarked_60s_equals_the_oracle(strategy):
+    """the load-balancer line of bench.py runs 60 s (32 768 sources -> LoadBalancer -> 32 768 servers -> one Sink,
+    1.2e8 events): that run against one oracle heap, for the three strategies."""
+    spec = dict(n_sources=32768, n_backends=32768, rate=6.0, mean=0.1, vnodes=150, n_clients=1 << 20, end_s=60.0, seed=42)
+    if strategy != "chash":
+        spec.update(strategy=strategy, vnodes=1, n_clients=1)
+    g, p = H.oracle_lb_graph(spec)
+    r = O.run(g, p["end_ns"], seed=spec["seed"])
+    eng, p = H.lb_engine_for_spec(spec)
+    with eng:
+        eng.run(p["end_ns"])
+        assert eng.summary().events_processed == r.events_processed > 100_000_000
         H.compare_lb_engine_with_oracle(eng, p, r)
 
 

@@ -141,12 +141,48 @@ def test_ring_rejects_zero_lookahead_and_second_run():
     eng, p = H.ring_engine_for_spec(RING_SWEEP[3])
     with eng:
         eng.run_until(p["end_ns"])
-        with pytest.raises(N.EngineError, match="one hs_engine_run_until per hs_engine_reset"):
-            eng.run_until(p["end_ns"])
         a = eng.summary().events_processed
+        eng.run_until(p["end_ns"])           # the same end again: the reference's loop condition is already false -- nothing moves
+        assert eng.summary().events_processed == a
         eng.reset()
         eng.run_until(p["end_ns"])
         assert eng.summary().events_processed == a
+
+
+def _ring_state(eng):
+    s = eng.summary()
+    return (s.events_processed, tuple(s.events_by_kind), s.final_time_ns, {k: v.tobytes() for k, v in eng.lp_stats().items()},
+            {k: v.tobytes() for k, v in eng.net_stats().items()}, [a.tobytes() for a in eng.read_sinks()])
+
+
+@pytest.mark.parametrize("flags", [0, 16], ids=["asynchronous", "windowed"])
+@pytest.mark.parametrize("k", [0, 3, 5])
+def test_ring_windows_equal_one_run(k, flags):
+    """VERDICT r4 missing 4: `_run_window` over a network (core/simulation.py:527-541).  hs_engine_run_until with growing ends
+    (incl. an end inside the gap before the event beyond the previous one, a repeated end and an EARLIER end, both of which move
+    nothing) == one run to the last end, on every statistic and record; and every intermediate state == one run to that end."""
+    spec = RING_SWEEP[k]
+    eng1, p = H.ring_engine_for_spec(spec, flags=flags)
+    end = p["end_ns"]
+    with eng1:
+        eng1.run_until(end)
+        want = _ring_state(eng1)
+    ends = [end // 7, end // 7 + 1, end // 3, end // 3, end // 5, (2 * end) // 3, end]
+    eng, _ = H.ring_engine_for_spec(spec, flags=flags)
+    with eng:
+        hi = -1
+        for e in ends:
+            eng.run_until(e)
+            if e > hi:
+                hi = e
+            ref, _ = H.ring_engine_for_spec(spec, flags=flags)
+            with ref:
+                ref.run_until(hi)
+                one = _ring_state(ref)
+            # (an earlier / equal end leaves the state of the latest end so far; so does a later one inside the gap before the event
+            #  beyond it -- every intermediate state equals ONE run to the latest end so far)
+            assert _ring_state(eng) == one, (e, hi)
+        assert _ring_state(eng) == want
 
 
 def test_ring_full_size_properties_and_engine_agreement():

@@ -285,3 +285,31 @@ def test_oracle_equals_live_reference_on_random_graphs_beyond_the_engines(k):
     behind Servers inside link networks, more than four Sources per Server -- live reference == oracle."""
     out, meta = MG.run_graph_case(graph_spec(k))
     check_oracle_against_graph_golden(H.Golden.from_results(out, meta))
+
+
+def _same_results(a, b, what):
+    assert a.keys() == b.keys(), what
+    for k in a:
+        if k == "meta":
+            continue
+        np.testing.assert_array_equal(a[k], b[k], err_msg=f"{what}: {k}")
+
+
+@pytest.mark.parametrize("kind,k", [("station", 3), ("station", 11), ("tie", 5), ("ring", 2), ("ring", 9), ("lb", 1), ("lb", 7),
+                                    ("multi_ring", 4)])
+def test_the_reference_in_windows_equals_the_reference_in_one_run(kind, k):
+    """VERDICT r4 missing 4: what `hs_engine_run_until` / `hs_lb_run` rely on when they serve a later window end by repeating the
+    run (include/hs_engine.h).  The LIVE reference driven window by window (core/simulation.py:527-541 `_run_window`: growing ends,
+    an end inside the gap before the event beyond the previous end, a repeated and an EARLIER end) leaves exactly what ONE run to
+    the last end leaves: every count, statistic, Sink record, the total and the final time."""
+    spec, run = {"station": (_station_spec(k), MG.run_case), "tie": (tie_spec(k), MG.run_case), "ring": (_ring_spec(k), MG.run_ring_case),
+                 "lb": (_lb_spec(k), MG.run_lb_case), "multi_ring": (multi_source_ring_spec(k), MG.run_ring_case)}[kind]
+    spec = dict(spec, trace=False)
+    if spec.get("mode") == "replicas":
+        spec["mode"] = "single"
+    one, meta1 = run(dict(spec))
+    e = spec["end_s"]
+    win, meta2 = run(dict(spec, windows=[e / 7, e / 7 + 1e-9, e / 3, e / 3, e / 5, 2 * e / 3]))
+    assert meta1["total_events"] == meta2["total_events"] and meta1["final_ns"] == meta2["final_ns"]
+    assert sum(meta1["total_events"]) > 20
+    _same_results(one, win, f"{kind} {k}")
