@@ -269,7 +269,8 @@ def ring_main(args, ctx):
         rounds = not args.ring_windows
         sn = ShardedNetwork.on_gpu(st, net, DistComm(), horizon_ns=end_ns, seed=args.seed, device=local_rank,
                                    log_capacity=cap, sync_every=args.sync_every or (4 if rounds else 256), rounds=rounds)
-        info["exchange_protocol"] = "asynchronous rounds" if rounds else "windows"
+        info["exchange_protocol"] = ("asynchronous rounds, device-side exchange (peers' buffers mapped over IPC, one word all-reduced per round)"
+                                     if sn.device_exchange else "asynchronous rounds over collectives" if rounds else "windows")
         for _ in range(args.warmup):
             sn.run_until(end_ns)
         barrier()
@@ -303,8 +304,9 @@ def ring_main(args, ctx):
                 "n_stations": args.n_lp, "events_per_step": events, "requests_per_step": requests,
                 "launches_per_step": windows, "lookahead_ns": window_ns,
                 "parallelism": (f"{n_ranks} contiguous ring segments, each on the asynchronous engine; per exchange round "
-                                f"({windows} per run): all-to-all of boundary messages + all-reduce(max) of the cross links' "
-                                f"lower bounds over {'gloo, host-staged' if ctx.fake else 'RCCL'}" if not args.ring_windows else
+                                f"({windows} per run): every rank writes its boundary messages and link bounds into its peers' "
+                                f"buffers (hipIpcOpenMemHandle; xGMI peer-to-peer between GPUs), then all-reduce(max) of ONE word "
+                                f"(still working?) over {'gloo' if ctx.fake else 'RCCL'} -- the only collective" if not args.ring_windows else
                                 f"{n_ranks} contiguous ring segments; per 1 ms window ({windows} per run): all-to-all of boundary "
                                 f"messages + all-reduce(min) GVT over {'gloo, host-staged' if ctx.fake else 'RCCL'}") if n_ranks > 1 else
                                ("1 engine, asynchronous: the whole run in one cooperative launch (hs_net_async) + the election launch"

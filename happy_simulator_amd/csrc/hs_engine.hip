@@ -88,6 +88,12 @@ struct hs_engine {
     const uint8_t *cross_role = nullptr;    // [n_cross] bit 0: the source station is here, bit 1: the destination is
     int64_t *cross_bounds = nullptr;        // device int64[n_cross + 1], owned by the caller (all-reduced with MAX)
     bool shard_async = false;
+    // device-side exchange (hs_engine_shard_ipc_*): this rank's exchange buffers, written by the peers, and the peers' buffers
+    int64_t *ipc_inbox = nullptr, *ipc_bounds = nullptr;      // [2][world][row] / [2][world][n_cross + 1], uncached device memory
+    int64_t **peer_inbox_dev = nullptr, **peer_bounds_dev = nullptr;   // device arrays [world] of the ranks' buffers as mapped here
+    std::vector<void *> ipc_opened;                           // peer mappings to close
+    bool ipc_ready = false;
+    int ipc_parity = 0;
     bool net_pf = false;       // the network has probes / profiles / scheduled Requests: the PF instantiation of hs_net_async
     int round_iters_cfg = 0;
     int async_fit = -1;        // -1 unknown, 0 the grid is not co-resident (windowed engine), 1 it is
@@ -395,6 +401,19 @@ int launch_prologue(hs_engine *h, int64_t end_ns) {
                        h->cfg.n_lp, h->C, h->is_net ? 1 : 0, h->is_net ? h->NP.n_links : 0, h->cfg.start_ns, end_ns);
     HS_HIP(h, hipGetLastError());
     h->launches++;
+    return HS_OK;
+}
+
+// the ranks' exchange buffers as this process addresses them -> device arrays for hs_shard_push
+int ipc_set_peers(hs_engine *h, const std::vector<int64_t *> &pin, const std::vector<int64_t *> &pbd) {
+    const int world = h->SC.world;
+    int rc;
+    if ((rc = dev_alloc(h, &h->peer_inbox_dev, (size_t)world))) return rc;
+    if ((rc = dev_alloc(h, &h->peer_bounds_dev, (size_t)world))) return rc;
+    HS_HIP(h, hipMemcpy(h->peer_inbox_dev, pin.data(), (size_t)world * sizeof(int64_t *), hipMemcpyHostToDevice));
+    HS_HIP(h, hipMemcpy(h->peer_bounds_dev, pbd.data(), (size_t)world * sizeof(int64_t *), hipMemcpyHostToDevice));
+    h->ipc_ready = true;
+    h->ipc_parity = 0;
     return HS_OK;
 }
 
@@ -1310,6 +1329,7 @@ int hs_engine_shard_begin(hs_engine *h, int64_t end_ns) {
     HS_HIP(h, hipStreamSynchronize(h->stream));                   // the host arrays above are stack memory
     h->launches = 1;
     h->net_ran = true;
+    h->ipc_parity = 0;            // (every rank starts a run on the same half of the double-buffered exchange buffers)
     return HS_OK;
 }
 
@@ -1398,6 +1418,92 @@ int hs_engine_shard_async_setup(hs_engine *h, int32_t n_cross, const int64_t *cr
     h->round_iters_cfg = max_iters;
     h->shard_async = true;
     return HS_OK;
+}
+
+// ---- device-side exchange between asynchronous rounds (csrc/hs_kernels.hpp hs_shard_push) -----------------------------------
+int hs_engine_shard_ipc_export(hs_engine *h, void *handles_out) {
+    if (!h || !h->shard_async || !handles_out) return fail(h, HS_E_STATE, "hs_engine_shard_ipc_export: call hs_engine_shard_async_setup first");
+    static_assert(sizeof(hipIpcMemHandle_t) == HS_IPC_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    if (!h->ipc_inbox) {
+        const size_t nin = (size_t)2 * h->SC.world * h->SC.row, nb = (size_t)2 * h->SC.world * ((size_t)h->n_cross + 1);
+        void *a = nullptr, *b = nullptr;
+        // uncached: a peer's stores arrive in HBM past this device's L2, the readers use system-scope loads
+        HS_HIP(h, hipExtMallocWithFlags(&a, nin * 8, hipDeviceMallocUncached));
+        h->allocs.push_back(a);
+        HS_HIP(h, hipExtMallocWithFlags(&b, nb * 8, hipDeviceMallocUncached));
+        h->allocs.push_back(b);
+        HS_HIP(h, hipMemset(a, 0, nin * 8));
+        {   // bounds start at "nothing known" (INT64_MIN), like the vector they replace
+            std::vector<int64_t> init(nb, INT64_MIN);
+            HS_HIP(h, hipMemcpy(b, init.data(), nb * 8, hipMemcpyHostToDevice));
+        }
+        h->ipc_inbox = (int64_t *)a; h->ipc_bounds = (int64_t *)b;
+    }
+    hipIpcMemHandle_t hh[2];
+    HS_HIP(h, hipIpcGetMemHandle(&hh[0], h->ipc_inbox));
+    HS_HIP(h, hipIpcGetMemHandle(&hh[1], h->ipc_bounds));
+    memcpy(handles_out, hh, sizeof hh);
+    return HS_OK;
+}
+
+int hs_engine_shard_ipc_attach(hs_engine *h, const void *all_handles) {
+    if (!h || !h->ipc_inbox || !all_handles) return fail(h, HS_E_STATE, "hs_engine_shard_ipc_attach: call hs_engine_shard_ipc_export first");
+    if (h->ipc_ready) return fail(h, HS_E_STATE, "hs_engine_shard_ipc_attach: already attached");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    const int world = h->SC.world;
+    const hipIpcMemHandle_t *hh = (const hipIpcMemHandle_t *)all_handles;
+    std::vector<int64_t *> pin((size_t)world), pbd((size_t)world);
+    for (int r = 0; r < world; ++r) {
+        if (r == h->SC.rank) { pin[(size_t)r] = h->ipc_inbox; pbd[(size_t)r] = h->ipc_bounds; continue; }
+        void *a = nullptr, *b = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&a, hh[2 * r], hipIpcMemLazyEnablePeerAccess);
+        if (e == hipSuccess) { h->ipc_opened.push_back(a); e = hipIpcOpenMemHandle(&b, hh[2 * r + 1], hipIpcMemLazyEnablePeerAccess); }
+        if (e != hipSuccess) return fail(h, HS_E_HIP, "hipIpcOpenMemHandle (rank %d's exchange buffers): %s", r, hipGetErrorString(e));
+        h->ipc_opened.push_back(b);
+        pin[(size_t)r] = (int64_t *)a; pbd[(size_t)r] = (int64_t *)b;
+    }
+    return ipc_set_peers(h, pin, pbd);
+}
+
+int hs_engine_shard_peers_local(hs_engine *h, int64_t *const *inbox_ptrs, int64_t *const *bounds_ptrs) {
+    if (!h || !h->ipc_inbox || !inbox_ptrs || !bounds_ptrs) return fail(h, HS_E_STATE, "hs_engine_shard_peers_local: call hs_engine_shard_ipc_export first");
+    if (h->ipc_ready) return fail(h, HS_E_STATE, "hs_engine_shard_peers_local: already attached");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    const int world = h->SC.world;
+    std::vector<int64_t *> pin(inbox_ptrs, inbox_ptrs + world), pbd(bounds_ptrs, bounds_ptrs + world);
+    if (pin[(size_t)h->SC.rank] != h->ipc_inbox || pbd[(size_t)h->SC.rank] != h->ipc_bounds)
+        return fail(h, HS_E_INVALID, "hs_engine_shard_peers_local: entry [rank] must be this engine's own buffers (hs_engine_shard_ipc_buffers)");
+    return ipc_set_peers(h, pin, pbd);
+}
+
+int hs_engine_shard_ipc_buffers(hs_engine *h, int64_t **inbox_out, int64_t **bounds_out) {
+    if (!h || !h->ipc_inbox || !inbox_out || !bounds_out) return fail(h, HS_E_STATE, "hs_engine_shard_ipc_buffers: call hs_engine_shard_ipc_export first");
+    *inbox_out = h->ipc_inbox; *bounds_out = h->ipc_bounds;
+    return HS_OK;
+}
+
+int hs_engine_shard_push(hs_engine *h) {
+    if (!h || !h->ipc_ready) return fail(h, HS_E_STATE, "hs_engine_shard_push: call hs_engine_shard_ipc_attach first");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(hs_shard_push, dim3((unsigned)h->SC.world), dim3(256), 0, h->stream, h->SC.outbox, h->SC.row, h->SC.msg_cap,
+                       h->SC.world, h->SC.rank, h->ipc_parity, h->peer_inbox_dev, h->peer_bounds_dev, h->cross_bounds, h->n_cross, h->tot);
+    HS_HIP(h, hipGetLastError());
+    h->launches++;
+    return HS_OK;
+}
+
+int hs_engine_shard_inject_ipc(hs_engine *h) {
+    if (!h || !h->ipc_ready) return fail(h, HS_E_STATE, "hs_engine_shard_inject_ipc: call hs_engine_shard_ipc_attach first");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(hs_shard_combine_bounds, dim3((unsigned)((h->n_cross + 1 + 255) / 256)), dim3(256), 0, h->stream, h->ipc_bounds,
+                       h->SC.world, h->ipc_parity, h->n_cross, h->cross_bounds);
+    hipLaunchKernelGGL(hs_shard_fetch_inbox, dim3((unsigned)h->SC.world), dim3(256), 0, h->stream, h->ipc_inbox, h->SC.world, h->ipc_parity,
+                       h->SC.row, h->SC.msg_cap, const_cast<int64_t *>(h->inbox));
+    HS_HIP(h, hipGetLastError());
+    h->ipc_parity ^= 1;
+    h->launches += 2;
+    return hs_engine_shard_inject_async(h);
 }
 
 int hs_engine_shard_round(hs_engine *h) {
@@ -1903,6 +2009,7 @@ void hs_engine_destroy(hs_engine *h) {
     if (!h) return;
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    for (void *p : h->ipc_opened) hipIpcCloseMemHandle(p);      // the peers' exchange buffers as mapped here
     for (void *p : h->allocs) hipFree(p);
     if (h->ev_a) hipEventDestroy(h->ev_a);
     if (h->ev_b) hipEventDestroy(h->ev_b);

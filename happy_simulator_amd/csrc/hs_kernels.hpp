@@ -1745,6 +1745,61 @@ __global__ void hs_shard_inject_async(NetState NX, const int64_t *inbox, int64_t
     if (tid == 0) tot->not_done = 0;
 }
 
+// ---- device-side exchange between the rounds (round 5): peers' buffers mapped with hipIpcOpenMemHandle ---------------------
+// Instead of an all-to-all of whole outbox rows and an all-reduce of the bounds (staged through the host when the transport
+// cannot move device tensors), every rank WRITES what it has for rank d straight into rank d's memory -- its row of d's inbox
+// (only the messages that exist) and its row of d's bound table -- over xGMI peer-to-peer stores (the same device when the
+// ranks share one).  The buffers are double-buffered by round parity, so ONE barrier per round orders everything: the
+// stream-ordered all-reduce of the one "still working" word (RCCL), the only collective left on the path.  Peer memory is
+// written with system-scope stores and read with system-scope loads (remote writes reach HBM past the reader's L2).
+// One workgroup per destination rank.
+__global__ void __launch_bounds__(256) hs_shard_push(const int64_t *outbox, int row, int msg_cap, int world, int rank, int parity,
+                                                     int64_t *const *peer_inbox, int64_t *const *peer_bounds,
+                                                     const int64_t *bounds, int n_cross, Totals *tot) {
+    const int d = blockIdx.x;
+    if (d >= world) return;
+    const int64_t *src = outbox + (size_t)d * row;
+    int64_t cnt = src[0];
+    if (cnt > msg_cap) { if (threadIdx.x == 0) atomicOr(&tot->overflow, 2); cnt = msg_cap; }
+    int64_t *dst = peer_inbox[d] + ((size_t)parity * world + (size_t)rank) * (size_t)row;
+    const int64_t words = 1 + (int64_t)kMsgWords * cnt;
+    for (int64_t i = threadIdx.x; i < words; i += blockDim.x)
+        __hip_atomic_store(&dst[i], i == 0 ? cnt : src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    int64_t *bd = peer_bounds[d] + ((size_t)parity * world + (size_t)rank) * (size_t)(n_cross + 1);
+    for (int i = threadIdx.x; i <= n_cross; i += blockDim.x)
+        __hip_atomic_store(&bd[i], bounds[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+}
+// After the barrier: the element-wise maximum of what the ranks pushed (= the all-reduce(MAX) of the collective path) into the
+// engine's own bound vector, which hs_shard_inject_async and hs_engine_shard_async_done read as before.
+__global__ void __launch_bounds__(256) hs_shard_combine_bounds(const int64_t *ipc_bounds, int world, int parity, int n_cross, int64_t *bounds) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= n_cross; i += gridDim.x * blockDim.x) {
+        int64_t m = INT64_MIN;
+        for (int r = 0; r < world; ++r) {
+            const int64_t v = __hip_atomic_load(&ipc_bounds[((size_t)parity * world + (size_t)r) * (size_t)(n_cross + 1) + i],
+                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            m = v > m ? v : m;
+        }
+        bounds[i] = m;
+    }
+}
+// ... and the pushed rows copied out of the uncached exchange buffer (system-scope loads) into the engine's own inbox
+__global__ void __launch_bounds__(256) hs_shard_fetch_inbox(const int64_t *ipc_inbox, int world, int parity, int row, int msg_cap, int64_t *inbox) {
+    const int r = blockIdx.x;
+    if (r >= world) return;
+    const int64_t *src = ipc_inbox + ((size_t)parity * world + (size_t)r) * (size_t)row;
+    __shared__ int64_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = __hip_atomic_load(&src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    int64_t cnt = s_cnt;
+    if (cnt > msg_cap) cnt = msg_cap;
+    if (cnt < 0) cnt = 0;
+    int64_t *dst = inbox + (size_t)r * row;
+    const int64_t words = 1 + (int64_t)kMsgWords * cnt;
+    for (int64_t i = threadIdx.x; i < words; i += blockDim.x)
+        dst[i] = i == 0 ? s_cnt : __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 #endif  // HS_KERNELS_MAIN
 
 // Sharded network: this rank owns the globally first event beyond end_ns -- process it (core/simulation.py:472).

@@ -28,6 +28,14 @@ boundary messages (the same all-to-all) and all-reduce (MAX) one vector: the low
 queue refilled and a bound raised between launches -- and exchange rounds follow the boundary stations' lookahead (their
 next possible completion + the link floor: tens of ms) instead of the link floor alone: 24 exchanges (rounds of 64 iterations) instead of
 59 968 for the 65 536-station ring on 4 shards, the same bits.  `rounds=False` keeps the window protocol.
+
+**Device-side exchange (round 5, the default of the rounds).**  Instead of the all-to-all and the all-reduce of the bounds, every
+rank maps its peers' exchange buffers (`hipIpcGetMemHandle` / `hipIpcOpenMemHandle`; handles all-gathered once) and, after a
+round, WRITES its outbox rows and link bounds straight into them (`hs_engine_shard_push`: xGMI peer-to-peer stores across GPUs,
+plain device memory when ranks share one).  One barrier per round -- the all-reduce of the one "still working" word, which is all
+RCCL is left with on this path, as `north_star` asks -- then `hs_engine_shard_inject_ipc` takes what the peers pushed.  No
+whole rows, no host staging under gloo, nothing to ranks that are not neighbours beyond an empty row header.
+`exchange="collective"` keeps the all-to-all path (and is what ranks that are virtual shards of ONE process may also use).
 """
 from __future__ import annotations
 
@@ -93,6 +101,17 @@ class LocalComm:
     def reduce_host(self, dicts):
         return _combine(dicts)
 
+    def connect_peers(self, shards):
+        """Device-side exchange between virtual shards of one process: the buffers' addresses instead of IPC handles."""
+        for s in shards:
+            s.ipc_export()
+        ptrs = [s.ipc_buffers() for s in sorted(shards, key=lambda x: x.rank)]
+        for s in shards:
+            s.peers_local([p[0] for p in ptrs], [p[1] for p in ptrs])
+
+    def flag_barrier(self, flags):
+        self.allreduce_max(flags)
+
 
 class DistComm:
     """One shard per process: torch.distributed (backend "nccl" is RCCL on ROCm; "gloo" for tests).
@@ -133,6 +152,20 @@ class DistComm:
 
     def allreduce_max(self, vectors):
         self._all_reduce(vectors[0], self._dist.ReduceOp.MAX)
+
+    def connect_peers(self, shards):
+        """Device-side exchange: all-gather the IPC handles of every rank's exchange buffers, map the peers' (once)."""
+        (s,) = shards
+        mine = s.ipc_export()
+        every = [None] * self.world
+        self._dist.all_gather_object(every, mine, group=self._group)
+        s.ipc_attach(b"".join(every))
+
+    def flag_barrier(self, flags):
+        """The one collective of a round on the device-side exchange path: all-reduce(MAX) of the "still working" word.  It is also the
+        barrier between the ranks' pushes and their injects: stream-ordered under RCCL (every rank's push precedes its share of the
+        all-reduce on its stream); under gloo the staging copy waits for the stream first."""
+        self._all_reduce(flags[0], self._dist.ReduceOp.MAX)
 
     def allgather_rows(self, rows):
         import torch
@@ -383,6 +416,42 @@ class GpuShard:
         e = self.engine
         e._check(e._lib.hs_engine_shard_inject_async(e._h))
 
+    # -- device-side exchange (hs_engine_shard_ipc_*) ----------------------------------------------------------
+    def ipc_export(self) -> bytes:
+        e = self.engine
+        buf = (C.c_char * (2 * N.IPC_HANDLE_BYTES))()
+        e._check(e._lib.hs_engine_shard_ipc_export(e._h, buf))
+        return bytes(buf)
+
+    def ipc_attach(self, all_handles: bytes):
+        e = self.engine
+        if len(all_handles) != 2 * N.IPC_HANDLE_BYTES * self.world:
+            raise ValueError("expected two handles per rank")
+        e._check(e._lib.hs_engine_shard_ipc_attach(e._h, all_handles))
+
+    def ipc_buffers(self):
+        e = self.engine
+        a, b = C.c_void_p(), C.c_void_p()
+        e._check(e._lib.hs_engine_shard_ipc_buffers(e._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def peers_local(self, inbox_ptrs, bounds_ptrs):
+        e = self.engine
+        pi = (C.c_void_p * self.world)(*inbox_ptrs)
+        pb = (C.c_void_p * self.world)(*bounds_ptrs)
+        e._check(e._lib.hs_engine_shard_peers_local(e._h, pi, pb))
+
+    def push(self):
+        e = self.engine
+        e._check(e._lib.hs_engine_shard_push(e._h))
+
+    def inject_ipc(self):
+        e = self.engine
+        e._check(e._lib.hs_engine_shard_inject_ipc(e._h))
+
+    def flag_word(self):
+        return self.xbounds[-1:]
+
     def round_done(self) -> bool:
         e = self.engine
         flag = C.c_int32(0)
@@ -421,7 +490,7 @@ class ShardedNetwork:
     (GpuShard, or any object with the same methods), `comm` moves rows and scalars between all shards."""
 
     def __init__(self, shards: list, comm, *, window_ns: int, sync_every: int = 64, rounds: bool = False,
-                 ranks: "ElectionRanks | None" = None):
+                 ranks: "ElectionRanks | None" = None, device_exchange: bool = False):
         self.shards = shards
         self.ranks = ranks               # network-wide construction ranks for the election across shards (None: trust word 6)
         self.comm = comm
@@ -429,12 +498,13 @@ class ShardedNetwork:
         self.sync_every = max(1, int(sync_every))
         self.windows = 0
         self.rounds = bool(rounds)       # asynchronous exchange rounds instead of windows (GpuShard.async_setup done)
+        self.device_exchange = bool(device_exchange)   # ... with the ranks pushing into each other's buffers (comm.connect_peers done)
 
     @classmethod
     def on_gpu(cls, stations: StationArrays, net: NetworkArrays, comm, *, horizon_ns: int, start_ns: int = 0,
                seed: int = 42, device: int = 0, msg_capacity: int = 256, log_capacity: int = 0,
                sync_every: int | None = None, bounds: np.ndarray | None = None, rounds: bool = True,
-               round_iters: int = 64):
+               round_iters: int = 64, exchange: str = "device"):
         """Partition `stations` / `net` (network-wide descriptions, identical on every rank) over comm.world shards
         and build the shards this process owns on `device`.  `bounds` (world + 1 station offsets) overrides the
         balanced block partition, e.g. with the user's own SimulationPartition sizes."""
@@ -462,9 +532,15 @@ class ShardedNetwork:
             cross = np.nonzero(rank_of(src) != rank_of(dst))[0].astype(np.int64)
             for s in shards:
                 s.async_setup(cross, round_iters)
+        if exchange not in ("device", "collective"):
+            raise ValueError("exchange must be 'device' or 'collective'")
+        device_exchange = rounds and exchange == "device" and hasattr(comm, "connect_peers")
+        if device_exchange:
+            comm.connect_peers(shards)
         if sync_every is None:           # exchanges between host synchronisations: a run is ~25 rounds or ~60 000 windows
             sync_every = 4 if rounds else 64
-        return cls(shards, comm, window_ns=window_ns, sync_every=sync_every, rounds=rounds, ranks=ElectionRanks(stations))
+        return cls(shards, comm, window_ns=window_ns, sync_every=sync_every, rounds=rounds, ranks=ElectionRanks(stations),
+                   device_exchange=device_exchange)
 
     def _run_rounds(self, end_ns: int) -> int:
         """Asynchronous rounds: every shard runs the asynchronous engine for a few iterations, then messages (all-to-all)
@@ -476,10 +552,17 @@ class ShardedNetwork:
                 for s in sh:
                     s.round()                                          # EXECUTE (one cooperative launch per shard)
                 t0 = _time.perf_counter()
-                comm.exchange([s.outbox for s in sh], [s.inbox for s in sh])   # EXCHANGE messages ...
-                comm.allreduce_max([s.xbounds for s in sh])             # ... and bounds (+ the "still working" flag)
-                for s in sh:
-                    s.inject_async()
+                if self.device_exchange:
+                    for s in sh:
+                        s.push()                                       # EXCHANGE: straight into the peers' buffers ...
+                    comm.flag_barrier([s.flag_word() for s in sh])     # ... one word all-reduced = the round's barrier
+                    for s in sh:
+                        s.inject_ipc()
+                else:
+                    comm.exchange([s.outbox for s in sh], [s.inbox for s in sh])   # EXCHANGE messages ...
+                    comm.allreduce_max([s.xbounds for s in sh])         # ... and bounds (+ the "still working" flag)
+                    for s in sh:
+                        s.inject_async()
                 self._exchange_s += _time.perf_counter() - t0
                 r += 1
             done = self._all_ranks([lambda s=s: s.round_done() for s in sh])   # the only host synchronisation

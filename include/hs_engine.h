@@ -358,6 +358,25 @@ int hs_engine_shard_async_setup(hs_engine *h, int32_t n_cross, const int64_t *cr
 int hs_engine_shard_round(hs_engine *h);
 int hs_engine_shard_inject_async(hs_engine *h);
 int hs_engine_shard_async_done(hs_engine *h, int32_t *any_not_done);
+/* DEVICE-SIDE exchange between the rounds, replacing the all-to-all and the all-reduce of the bounds (the reference's exchange
+ * step: parallel/coordinator.py:182-227 drains Python outboxes on the main thread).  Every rank exports the handles of its two
+ * exchange buffers (hipIpcGetMemHandle; HS_IPC_HANDLE_BYTES each: inbox, bounds), the ranks all-gather them (2 x world handles in
+ * rank order) and attach (hipIpcOpenMemHandle: the peers' buffers mapped into this process -- xGMI peer-to-peer across GPUs, plain
+ * device memory when ranks share a GPU).  After a round, `push` writes this rank's outbox rows and link bounds straight into the
+ * peers' buffers (system-scope stores, only the messages that exist); then ONE barrier -- the stream-ordered all-reduce of the
+ * "still working" word, the only collective left on the path -- and `inject_ipc` takes what the peers pushed (system-scope loads,
+ * element-wise max of the bounds) and injects it as inject_async does.  The buffers are double-buffered by round parity, which is
+ * what makes one barrier per round enough.
+ *   export; <all-gather handles>; attach; begin; do { round; push; <all-reduce MAX of 1 word>; inject_ipc; } while (any_not_done); final(0) */
+#define HS_IPC_HANDLE_BYTES 64
+int hs_engine_shard_ipc_export(hs_engine *h, void *handles_out /* 2 x HS_IPC_HANDLE_BYTES */);
+int hs_engine_shard_ipc_attach(hs_engine *h, const void *all_handles /* world x 2 x HS_IPC_HANDLE_BYTES, rank order */);
+/* ... ranks that live in ONE process (virtual shards on one device: tests, tools) hand each other the buffers' addresses instead:
+ * ipc_buffers returns this engine's two buffers (after ipc_export), peers_local takes the [world] addresses of every rank's. */
+int hs_engine_shard_ipc_buffers(hs_engine *h, int64_t **inbox_out, int64_t **bounds_out);
+int hs_engine_shard_peers_local(hs_engine *h, int64_t *const *inbox_ptrs, int64_t *const *bounds_ptrs);
+int hs_engine_shard_push(hs_engine *h);
+int hs_engine_shard_inject_ipc(hs_engine *h);
 /* Simulation.__init__ bootstrap (core/simulation.py:145-154): clock to start_ns, every Source draws its
  * first arrival.  Called implicitly by the first run; call again to rewind the engine for another run. */
 int hs_engine_reset(hs_engine *h);

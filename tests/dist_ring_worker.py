@@ -51,6 +51,9 @@ def case_spec(case, n, end_s):
     raise SystemExit(f"unknown case {case}")
 
 
+PROTOCOLS = (("rounds", True, "device"), ("rounds_collective", True, "collective"), ("windows", False, "collective"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("case")
@@ -83,11 +86,14 @@ def main():
     n = specs[True]["n"]
     out = {"backend": args.backend, "same_device": bool(args.same_device), "case": args.case}
     mine = {}
-    for rounds in (True, False):
+    # the three exchange paths: asynchronous rounds with the DEVICE-SIDE exchange (peers' buffers mapped over IPC, one word
+    # all-reduced per round: the default), the same rounds over collectives (all-to-all + all-reduce), the window protocol
+    for name, rounds, exchange in PROTOCOLS:
         spec = specs[rounds]
         st, net, cap, p = H.ring_arrays(spec)
         with ShardedNetwork.on_gpu(st, net, DistComm(), horizon_ns=p["end_ns"], seed=spec["seed"], device=local,
-                                   log_capacity=cap, rounds=rounds) as sn:
+                                   log_capacity=cap, rounds=rounds, exchange=exchange) as sn:
+            assert sn.device_exchange == (rounds and exchange == "device")
             s = sn.run_until(p["end_ns"])
             stats, counts, t, cr, ns = sn.collect(n, net.n_links)
             lo, hi = sn.shards[0].lo, sn.shards[0].hi
@@ -107,15 +113,14 @@ def main():
                     for j in range(len(prs)):
                         pt, pv = sn.read_probe(i, j)
                         probes[f"{i}.{j}"] = [int(pt.sum()), int(pv.sum()), len(pt)]
-            name = "rounds" if rounds else "windows"
             out[name] = dict(events=int(s.events_processed), final=int(s.final_time_ns), exchanges=int(s.windows),
                              world=int(s.world), by_kind=[int(x) for x in s.events_by_kind], owns=[lo, hi])
             mine[name] = (tt.numpy().copy(), probes)
     gathered = [None] * world
     dist.all_gather_object(gathered, {k: v[1] for k, v in mine.items()})
     if rank == 0:
-        for name in ("rounds", "windows"):
-            spec = specs[name == "rounds"]
+        for name, rounds, _ in PROTOCOLS:
+            spec = specs[rounds]
             eng, p = H.ring_engine_for_spec(spec)            # the same network on one engine
             with eng:
                 eng.run_until(p["end_ns"])
@@ -129,7 +134,7 @@ def main():
                     for j in range(len(prs)):
                         pt, pv = eng.read_probe(i, j)
                         want_probes[f"{i}.{j}"] = [int(pt.sum()), int(pv.sum()), len(pt)]
-                out["single" if name == "rounds" else "single_windows"] = dict(
+                out["single" if rounds else "single_windows"] = dict(
                     events=int(s1.events_processed), final=int(s1.final_time_ns), by_kind=[int(x) for x in s1.events_by_kind],
                     generated=[int(x) for x in stats["generated"]][:64])
             got = mine[name][0]

@@ -4,8 +4,9 @@ the reference's execute / exchange / advance loop (parallel/coordinator.py:87-12
 * backend "nccl" (= RCCL on ROCm): the all_to_all_single of the outbox rows, the all_reduce (MAX of the cross links' bounds / MIN
   of the GVT), the all_gather of the overshoot candidates and the totals' reductions run on device tensors; world size 1 on a
   one-GPU box, two ranks when two GPUs are visible;
-* backend "gloo", both ranks on device 0 (`--same-device`): RCCL refuses two ranks on one GPU, so DistComm stages the exchange
-  tensors through host memory -- everything else (two processes, two engines, `shard_arrays`' slicing and re-basing, both exchange
+* backend "gloo", both ranks on device 0 (`--same-device`): RCCL refuses two ranks on one GPU, so DistComm stages the collectives'
+  tensors through host memory; the DEVICE-SIDE exchange of the rounds (round 5: `hs_engine_shard_push` into the peers' buffers
+  mapped with hipIpcOpenMemHandle, one word all-reduced per round) runs exactly as between GPUs -- everything else (two processes, two engines, `shard_arrays`' slicing and re-basing, both exchange
   protocols, the cross-rank election with network-wide construction ranks) is the multi-GPU run.  This is the N > 1 evidence a
   one-GPU box can give."""
 import json
@@ -28,8 +29,8 @@ def _port():
 
 
 def _check(out, world, fewer_rounds=True):
-    for proto in ("rounds", "windows"):
-        one = out["single" if proto == "rounds" else "single_windows"]
+    for proto in ("rounds", "rounds_collective", "windows"):        # device-side exchange over IPC / collectives / windows
+        one = out["single" if proto != "windows" else "single_windows"]
         r = out[proto]
         assert r["world"] == world
         assert r["events"] == one["events"] and r["final"] == one["final"], (proto, r, one)
@@ -38,6 +39,7 @@ def _check(out, world, fewer_rounds=True):
         assert r["exchanges"] >= 1
     if fewer_rounds:    # bounds travel further than the 1 ms link floor: fewer exchanges per simulated second
         assert out["rounds"]["exchanges"] / out["single"]["final"] < out["windows"]["exchanges"] / out["single_windows"]["final"]
+    assert out["rounds"]["exchanges"] == out["rounds_collective"]["exchanges"]        # the same rounds, another transport
 
 
 def _launch(world, worker_args, timeout=600):

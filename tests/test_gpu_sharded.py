@@ -20,11 +20,15 @@ def _single(spec):
 
 
 def _sharded(spec, world, sync_every=16, msg_capacity=64, rounds=True, bag_capacity=0):
+    exchange = "device"
+    if rounds == "collective":               # asynchronous rounds over the all-to-all + all-reduce instead of the device-side exchange
+        rounds, exchange = True, "collective"
     from happy_simulator_amd.sharded import LocalComm, ShardedNetwork
 
     st, net, cap, p = H.ring_arrays(spec, bag_capacity=bag_capacity)
     sn = ShardedNetwork.on_gpu(st, net, LocalComm(world), horizon_ns=p["end_ns"], seed=spec["seed"], log_capacity=cap,
-                               sync_every=sync_every, msg_capacity=msg_capacity, rounds=rounds)
+                               sync_every=sync_every, msg_capacity=msg_capacity, rounds=rounds, exchange=exchange)
+    assert sn.device_exchange == (rounds is True and exchange == "device")
     with sn:
         summ = sn.run_until(p["end_ns"])
         stats = {}
@@ -59,7 +63,7 @@ SPECS = [
 ]
 
 
-PROTOCOLS = pytest.mark.parametrize("rounds", [True, False], ids=["async_rounds", "windows"])
+PROTOCOLS = pytest.mark.parametrize("rounds", [True, "collective", False], ids=["async_rounds_device_exchange", "async_rounds_collectives", "windows"])
 
 
 @PROTOCOLS
@@ -215,7 +219,7 @@ def test_sharded_mesh_with_two_links_per_station(world, rounds):
         one = (s.events_processed, s.final_time_ns, tuple(s.events_by_kind), {k: v.tobytes() for k, v in eng.lp_stats().items()},
                {k: v.tobytes() for k, v in eng.net_stats().items()})
     sn = ShardedNetwork.on_gpu(st, net, LocalComm(world), horizon_ns=end_ns, seed=seed, log_capacity=1024, msg_capacity=2048,
-                               rounds=rounds)
+                               rounds=rounds is not False, exchange="collective" if rounds == "collective" else "device")
     with sn:
         summ = sn.run_until(end_ns)
         stats, counts, t, cr, netst = sn.collect(n, 2 * n)
