@@ -1025,6 +1025,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     }
     h->L.sink_created = (h->C > 1) ? h->L.sink_created_own : h->L.adm;
     if ((rc = dev_alloc(h, &h->tot, 1))) return rc;
+    HS_HIP(h, hipMemset(h->tot, 0, sizeof(Totals)));          // (Totals::net_cand_key stays null unless hs_engine_set_network sets it)
     if ((rc = dev_alloc(h, &h->cands, std::max<size_t>((size_t)h->n_blocks, (size_t)(n + 1) / 2)))) return rc;   // (the wide kernel: one per >= 2 LPs)
     if (h->C == 1 && h->uni_grid && !h->any_profile && h->cfg.mode == HS_MODE_SINGLE) {
         if ((rc = dev_alloc(h, &h->wide_ctl, 1))) return rc;
@@ -1256,6 +1257,12 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
         if ((rc = dev_alloc(h, &h->L.sink_created_own, N * (size_t)h->L.cap))) return rc;
     }
     h->L.sink_created = h->L.sink_created_own;
+    {   // the election's tie check of the network engines (hs_net_window: Totals::net_cand_key)
+        long long *ck = nullptr;
+        if ((rc = dev_alloc(h, &ck, N * 4))) return rc;
+        HS_HIP(h, hipMemset(ck, 0, N * 4 * sizeof(long long)));
+        HS_HIP(h, hipMemcpy(&h->tot->net_cand_key, &ck, sizeof ck, hipMemcpyHostToDevice));
+    }
     h->is_net = true;
     return HS_OK;
 }
@@ -1772,6 +1779,11 @@ int hs_engine_run_until(hs_engine *h, int64_t end_ns) {
                         (long long)st[1] - 2, (long long)h->tab_cap);
     }
     if (t.qoverflow) return fail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
+    if (h->is_net && (t.undecided & 2))
+        return fail(h, HS_E_UNSUPPORTED, "the one event beyond end_time is a lock-step tie between two stations (same time, creation time and "
+                    "lineage) that only the reference's sort-index ledger decides, and one of the two is a departure, a message or an injected "
+                    "Request, whose construction rank the network engines do not carry: refused instead of guessing (constant arrivals, "
+                    "services and link latencies in lock step; a different end_time or seed-free jitter avoids it)");
     if (t.overflow & 16)
         return fail(h, HS_E_OVERFLOW, "the prologue (csrc/hs_exact.hpp) ran out of heap / payload-pool space");
     if (t.overflow & 8)

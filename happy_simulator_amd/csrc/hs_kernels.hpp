@@ -1226,6 +1226,16 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
                 }
                 mine.rank = cand_rank(P, lp, n, mine.pad);        // ties on (time, creation time): `sources=[...]` order
             }
+            // What the election's tie check reads (below).  A tick ranks with its own Source's construction position, a Probe's tick
+            // with the Probe's; everything else of a station -- a departure, a message, an injected Request -- ranks with the
+            // station's first-listed Source, a STAND-IN for the Source (or schedule() call) its lineage goes back to, which on a
+            // network may be another station's.
+            long long *ck = tot->net_cand_key;
+            if (ck != nullptr) {
+                ck += (size_t)lp * 4;
+                ck[0] = mine.t; ck[1] = mine.t_created; ck[2] = mine.rcrt;
+                ck[3] = (long long)(unsigned)mine.depth | ((long long)(mine.valid ? 1 : 0) << 32) | ((long long)((mine.valid && mine.pad < 2) ? 1 : 0) << 33);
+            }
         }
         store_net<C>(S, X, NX, lp, n);
         if (S.undecided) atomicOr(&tot->undecided, S.undecided);
@@ -1289,14 +1299,38 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
     best = wave_min_cand(best);
     if ((tid & 63) == 0) wave_c[tid >> 6] = best;
     __syncthreads();
+    Candidate b = wave_c[0];
+    for (int w = 1; w < kBlock / 64; ++w) if (cand_less(wave_c[w], b)) b = wave_c[w];
+    // Did the election rest on the construction rank of a STAND-IN (round 5)?  Another station's candidate shares
+    // the winner's (time, creation time, steps from the root, root's creation time), and one of the two ranks with its station's
+    // first-listed Source instead of the Source its lineage goes back to (a departure, a message, an injected Request): only the
+    // two events' ancestry decides which the reference pops first.  Totals::undecided bit 1 -- hs_engine_run_until refuses the
+    // result by name (lock-step constant arrivals, services and link latencies; never seen on a random workload) instead of
+    // guessing; a shard reports it in bit 1 of its candidate's first word.
+    bool tie = false;
+    {
+        const long long *ck = tot->net_cand_key;
+        if (ck != nullptr && b.valid && cur0 <= wend) {
+            const long long bv = __hip_atomic_load(&ck[(size_t)b.lp * 4 + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int q = tid; q < n; q += kBlock) {
+                const long long *c4 = ck + (size_t)q * 4;
+                const long long t = __hip_atomic_load(&c4[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const long long cr = __hip_atomic_load(&c4[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const long long rc = __hip_atomic_load(&c4[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const long long dv = __hip_atomic_load(&c4[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (q != b.lp && ((dv >> 32) & 1) != 0 && t == b.t && cr == b.t_created && rc == b.rcrt && (int)(unsigned)dv == b.depth &&
+                    (((dv | bv) >> 33) & 1) != 0) tie = true;
+            }
+        }
+    }
+    const int any_tie = __syncthreads_or((int)tie);
     if (tid == 0) {
-        Candidate b = wave_c[0];
-        for (int w = 1; w < kBlock / 64; ++w) if (cand_less(wave_c[w], b)) b = wave_c[w];
+        if (any_tie) atomicOr(&tot->undecided, 2);
         long long new_cur = __hip_atomic_load(&tot->final_time, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (flags & 4) {
             // sharded network: the election continues across the ranks on the host (hs_engine_shard_overshoot runs
             // the winner); publish this rank's candidate
-            SC.cand_out[0] = b.valid; SC.cand_out[1] = b.t; SC.cand_out[2] = b.t_created;
+            SC.cand_out[0] = (b.valid ? 1 : 0) | (any_tie ? 2 : 0); SC.cand_out[1] = b.t; SC.cand_out[2] = b.t_created;
             SC.cand_out[3] = SC.lp_base + b.lp; SC.cand_out[4] = b.depth; SC.cand_out[5] = b.rcrt; SC.cand_out[6] = b.rank; SC.cand_out[7] = b.pad;   // [6] is shard-LOCAL: the host re-ranks by (station, [7]) network-wide
             tot->cur_time = new_cur;
             tot->done = 0;

@@ -632,7 +632,18 @@ class ShardedNetwork:
             rank = valid[:, 6] if self.ranks is None else np.array(
                 [self.ranks.rank(int(c[3]), int(c[7])) for c in valid], np.int64)
             order = np.lexsort((valid[:, 3], rank, valid[:, 5], valid[:, 4], valid[:, 2], valid[:, 1]))
-            t, station = int(valid[order[0]][1]), int(valid[order[0]][3])
+            win = valid[order[0]]
+            # Did the election rest on the construction rank of a stand-in (csrc/hs_kernels.hpp hs_net_window, round 5)?  Inside the
+            # winner's shard: bit 1 of its first word.  Across shards: another rank's candidate shares the winner's whole lineage key
+            # and one of the two is a departure / a message / an injected Request (word 7 < 2), which ranks with its station's
+            # first-listed Source instead of the Source its lineage goes back to.  Every rank sees the same rows: all raise together.
+            same = [c for c in valid[order[1:]] if (c[1], c[2], c[4], c[5]) == (win[1], win[2], win[4], win[5])]
+            if (int(win[0]) & 2) or any(int(c[7]) < 2 or int(win[7]) < 2 for c in same):
+                raise N.EngineError(N.HS_E_UNSUPPORTED,
+                                    "the one event beyond end_time is a lock-step tie between two stations that only the reference's "
+                                    "sort-index ledger decides (one of them a departure, a message or an injected Request): refused "
+                                    "instead of guessing")
+            t, station = int(win[1]), int(win[3])
             winner_t = t
             for s in sh:
                 if s.lo <= station < s.hi:
