@@ -609,7 +609,16 @@ class LazyRecords:
     def count(self, i: int) -> int:
         return int(self.off[i + 1] - self.off[i])
 
+    SINGLE_READS = 64        # Sinks read one by one (a device-side gather of that Sink's column each) before everything comes down
+
     def records(self, i: int):
+        # one Sink's records: its column of the device logs, gathered on the device (hs_engine_read_sink: microseconds) -- the
+        # first `latencies_s` of a 65 536-chain run used to wait for the download of all 0.5 GB.  A caller that walks the Sinks
+        # gets the bulk download after a few of them.
+        if self._t is None and self._eng is not None:
+            self._singles = getattr(self, "_singles", 0) + 1
+            if self._singles <= self.SINGLE_READS:
+                return self._eng.read_sink(i, cap=max(self.count(i), 1))
         t, cr = self.fetch()
         a, b = int(self.off[i]), int(self.off[i + 1])
         return t[a:b], cr[a:b]

@@ -448,3 +448,39 @@ def test_rings_with_constant_exponential_and_no_jitter_match_oracle(k, engine_fl
         eng.run_until(p["end_ns"])
         _check_against_oracle(spec, eng, r, nodes)
 
+
+
+def _stand_in_tie_spec():
+    """Two Requests injected with Simulation.schedule() for ONE instant at two sourceless stations, station 3's first; the run ends a
+    nanosecond before that instant, so the one event beyond end_time is whichever of the two the reference constructed first
+    (core/simulation.py:195-206: schedule() call order).  The network engines rank an injected Request with its station's
+    construction rank -- a stand-in that would elect station 1."""
+    return dict(name="stand_in_tie", topology="ring", n=4, ext_rate=[6.0, 0.0, 6.0, 0.0], mean=0.05, lat_min=0.002, jitter_mean=0.004,
+                end_s=2.999999998, seed=5, schedule=[[3, 3.0], [1, 3.0]])
+
+
+@pytest.mark.parametrize("engine_flags", [0, 16], ids=["async", "windowed"])
+def test_an_election_that_rests_on_a_stand_in_rank_is_refused_not_guessed(engine_flags):
+    """the regression that fails on the stand-in.  The oracle (= the reference's sort-index ledger) processes
+    station 3's Request as the event beyond end_time; the engines either reproduce that (the single-heap prologue decided it) or
+    refuse the run by name -- never station 1."""
+    from happy_simulator_amd import _native as N
+
+    spec = _stand_in_tie_spec()
+    g, nodes = H.oracle_ring_graph(spec)
+    p = H.ring_params(spec)
+    assert p["end_ns"] < 3_000_000_000
+    r = O.run(g, p["end_ns"], seed=spec["seed"], schedule=[(nodes[c]["srv"], t) for c, t in p["schedule"]])
+    assert r.final_time_ns == 3_000_000_000 and r.events_processed > 200
+    spec_rev = dict(spec, schedule=list(reversed(spec["schedule"])))              # the other call order: the other station's Request runs
+    g2, nodes2 = H.oracle_ring_graph(spec_rev)
+    r2 = O.run(g2, p["end_ns"], seed=spec["seed"], schedule=[(nodes2[c]["srv"], t) for c, t in H.ring_params(spec_rev)["schedule"]])
+    assert r.accepted[nodes[3]["srv"]] == r2.accepted[nodes2[3]["srv"]] + 1 and r.accepted[nodes[1]["srv"]] == r2.accepted[nodes2[1]["srv"]] - 1
+    eng, _ = H.ring_engine_for_spec(spec, flags=engine_flags)
+    with eng:
+        try:
+            eng.run_until(p["end_ns"])
+        except N.EngineError as e:
+            assert e.code == N.HS_E_UNSUPPORTED and "lock-step tie" in str(e)
+            return
+        _check_against_oracle(spec, eng, r, nodes)          # (decided on the single heap: then it must be the reference's answer)

@@ -227,3 +227,15 @@ def test_sharded_mesh_with_two_links_per_station(world, rounds):
     assert {k: v.tobytes() for k, v in stats.items()} == one[3]
     assert {k: v.tobytes() for k, v in netst.items()} == one[4]
     assert summ.events_processed > 5000
+
+
+def test_a_cross_shard_election_that_rests_on_a_stand_in_rank_is_refused():
+    """The stand-in tie of tests/test_gpu_ring.py with its two stations in DIFFERENT shards: every shard reports its candidate, the
+    host finds two that share the whole lineage key and rank with a stand-in, and refuses (sharded.py run_until)."""
+    from happy_simulator_amd import _native as N
+    from test_gpu_ring import _stand_in_tie_spec
+
+    spec = _stand_in_tie_spec()
+    for rounds in (True, "collective", False):
+        with pytest.raises(N.EngineError, match="lock-step tie"):
+            _sharded(spec, 2, rounds=rounds)
