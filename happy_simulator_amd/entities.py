@@ -158,6 +158,23 @@ def _flush_pending() -> None:
             gc.enable()
 
 
+_LAZY_LOOKUPS = 32                 # objects bound one by one (an identity search in the run's object lists) before everything is
+
+
+def _resolve(obj) -> None:
+    """A result attribute of `obj` is being touched while a run's results are not bound yet.  Round 5: bind THIS object alone --
+    the pending run (lowering.write_back_plain) finds its row by an identity search, ~1 ms at 65 536 chains -- instead of all
+    4 x n objects (16-33 ms there: the first counter read after run() cost 70 x the device run); whoever walks many objects gets
+    the bulk binding after a few lookups.  Several pending runs, or an object the run does not know: bind everything, in run order."""
+    if len(_PENDING) == 1:
+        ent = _PENDING[0]
+        find = getattr(ent, "find_and_bind", None)
+        if find is not None and ent.lookups < _LAZY_LOOKUPS and find(obj):
+            ent.lookups += 1
+            return
+    _flush_pending()
+
+
 class _Stat:
     """A result counter of an entity: its own value, or -- after a run on n plain chains (lowering.write_back_plain) -- row
     `_bound[1]` of the run's per-LP result arrays `_bound[0]`.  Binding an object is ONE attribute store instead of one per
@@ -173,7 +190,7 @@ class _Stat:
         if obj is None:
             return self
         if _PENDING:
-            _flush_pending()
+            _resolve(obj)
         b = obj._bound
         if b is None:
             return obj.__dict__.get(self.own, self.default)
@@ -446,7 +463,7 @@ class _RecordSink(Entity):
 
     def _materialise(self):
         if _PENDING:
-            _flush_pending()
+            _resolve(self)
         if self._lazy is not None:
             records, i = self._lazy
             self._rec_t, self._rec_cr = records.records(i)
@@ -464,7 +481,7 @@ class _RecordSink(Entity):
 
     def _n_records(self) -> int:
         if _PENDING:
-            _flush_pending()
+            _resolve(self)
         return self._lazy[0].count(self._lazy[1]) if self._lazy is not None else int(len(self._rec_t))
 
     @property

@@ -643,19 +643,44 @@ def write_back_plain(pc: PlainChains, stats: dict, records: LazyRecords, device:
     (entities._PENDING): at 65 536 chains it costs 100 x the device run."""
     from . import entities as E
 
-    def bind():
-        for i, (src, sv, sk) in enumerate(zip(pc.sources, pc.servers, pc.sinks)):
-            b = (stats, i)
-            src._bound = b
-            src._event_provider._bound = b
-            sv._bound = b
-            sv._queue._bound = b
-            if sk is not None:
-                sk._lazy = (records, i)
-                sk._device = device
+    def bind_row(i):
+        src, sv, sk = pc.sources[i], pc.servers[i], pc.sinks[i]
+        b = (stats, i)
+        src._bound = b
+        src._event_provider._bound = b
+        sv._bound = b
+        sv._queue._bound = b
+        if sk is not None:
+            sk._lazy = (records, i)
+            sk._device = device
+
+    class _Bind:
+        """The deferred binding of one run: everything at once (call), or the chain of ONE object (find_and_bind: entities._resolve)."""
+
+        lookups = 0
+
+        def __call__(self):
+            for i in range(len(pc.sources)):
+                bind_row(i)
+
+        def find_and_bind(self, obj) -> bool:
+            t = type(obj)
+            try:                                           # (list.index: an identity search at C speed, ~1 ms per 65 536 objects)
+                if t is Source:
+                    i = pc.sources.index(obj)
+                elif t is Server:
+                    i = pc.servers.index(obj)
+                elif t in (Sink, Counter, LatencyTracker):
+                    i = pc.sinks.index(obj)
+                else:
+                    return False                           # a provider / queue object: the bulk binding
+            except ValueError:
+                return False                               # not an object of this run
+            bind_row(i)
+            return True
 
     E._flush_pending()             # (an earlier run's results first: bindings apply in run order)
-    E._PENDING.append(bind)
+    E._PENDING.append(_Bind())
 
 
 def write_back(g: LoweredGraph, stats: dict, counts: np.ndarray, t_ns: np.ndarray, created_ns: np.ndarray,

@@ -1141,3 +1141,39 @@ def test_probe_data_outlives_the_simulation_that_produced_it():
     small, dsmall = build(80)                    # a few probes: read at once, nothing pins the engine
     small.run()
     assert small._records._keep is False and dsmall[3].count() == 20 and dsmall[3]._lazy is None
+
+
+def test_results_bind_one_object_at_a_time_until_somebody_walks_them():
+    """Round 5: after `run()` on n plain chains nothing is bound; the first read of ONE Server's / Sink's result
+    binds that chain alone (an identity search in the run's lists, entities._resolve) and gathers that Sink's column on the device
+    (LazyRecords.records) -- not 4 x n attribute stores and a download of every record; a caller that walks the objects gets the bulk
+    binding after a few lookups.  The values are the ones the bulk path gives."""
+    from happy_simulator_amd import entities as E
+
+    def build(n=200):
+        sinks = [hs.Sink(f"sink{i}") for i in range(n)]
+        servers = [hs.Server(f"srv{i}", service_time=hs.ExponentialLatency(0.1), downstream=sinks[i]) for i in range(n)]
+        sources = [hs.Source.poisson(rate=8.0, target=servers[i], name=f"src{i}") for i in range(n)]
+        sim = hs.Simulation(duration=20, sources=sources, entities=[e for pr in zip(servers, sinks) for e in pr], seed=9)
+        return sinks, servers, sources, sim
+
+    sinks, servers, sources, sim = build()
+    sim.run()
+    assert len(E._PENDING) == 1 and all(s._bound is None for s in servers)
+    done = servers[117].stats.requests_completed                       # one Server: its chain alone
+    assert servers[117]._bound is not None and sources[117]._bound is not None and servers[3]._bound is None and len(E._PENDING) == 1
+    lat = sinks[60].latencies_s                                        # one Sink: its column, gathered on the device
+    assert sim._records._t is None and len(lat) == sinks[60].events_received > 50
+    assert servers[60]._bound is not None and servers[61]._bound is None
+    assert sources[5].generated_count > 100 and sources[5]._bound is not None
+    ref_sinks, ref_servers, ref_sources, ref_sim = build()             # the same run, everything bound at once
+    ref_sim.run()
+    E._flush_pending()
+    assert len(E._PENDING) == 1                                        # (that was the second run's binding; the first is still lazy)
+    assert done == ref_servers[117].stats.requests_completed and lat == ref_sinks[60].latencies_s
+    assert sources[5].generated_count == ref_sources[5].generated_count
+    total = sum(s.stats_accepted for s in servers)                     # walking the objects: the bulk binding after a few lookups
+    assert not E._PENDING and all(s._bound is not None for s in servers)
+    assert total == sum(s.stats_accepted for s in ref_servers)
+    assert [k.events_received for k in sinks] == [k.events_received for k in ref_sinks]
+    assert sinks[7].latencies_s == ref_sinks[7].latencies_s
