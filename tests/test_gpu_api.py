@@ -1157,6 +1157,10 @@ def test_results_bind_one_object_at_a_time_until_somebody_walks_them():
         sim = hs.Simulation(duration=20, sources=sources, entities=[e for pr in zip(servers, sinks) for e in pr], seed=9)
         return sinks, servers, sources, sim
 
+    ref_sinks, ref_servers, ref_sources, ref_sim = build()             # the reference: the same run, everything bound at once
+    ref_sim.run()
+    E._flush_pending()
+    assert not E._PENDING and all(s._bound is not None for s in ref_servers)
     sinks, servers, sources, sim = build()
     sim.run()
     assert len(E._PENDING) == 1 and all(s._bound is None for s in servers)
@@ -1166,10 +1170,6 @@ def test_results_bind_one_object_at_a_time_until_somebody_walks_them():
     assert sim._records._t is None and len(lat) == sinks[60].events_received > 50
     assert servers[60]._bound is not None and servers[61]._bound is None
     assert sources[5].generated_count > 100 and sources[5]._bound is not None
-    ref_sinks, ref_servers, ref_sources, ref_sim = build()             # the same run, everything bound at once
-    ref_sim.run()
-    E._flush_pending()
-    assert len(E._PENDING) == 1                                        # (that was the second run's binding; the first is still lazy)
     assert done == ref_servers[117].stats.requests_completed and lat == ref_sinks[60].latencies_s
     assert sources[5].generated_count == ref_sources[5].generated_count
     total = sum(s.stats_accepted for s in servers)                     # walking the objects: the bulk binding after a few lookups
