@@ -1414,7 +1414,11 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
     // ring: 16 LPs per wavefront (4 wavefronts per SIMD, 128 VGPRs with spills) is 2.4x SLOWER than 64 -- progress is bound
     // by how fast bounds travel from LP to LP, and neighbours inside one wavefront exchange them once per iteration
     const int lane = tid & 63;
-    const int lp = (blockIdx.x * (kBlock / 64) + (tid >> 6)) * lanes + lane;
+    // (generic instantiations: bits 8.. of `lanes` = the first station of this launch in workgroups -- a network with more
+    //  stations than one cooperative launch holds runs in SEGMENTS that take turns, hs_engine.hip run_net_segments)
+    int lp0 = 0;
+    if constexpr (!UNI) { lp0 = (lanes >> 8) * kBlock; lanes &= 0xff; }
+    const int lp = lp0 + (blockIdx.x * (kBlock / 64) + (tid >> 6)) * lanes + lane;
     const bool live = lane < lanes && lp < n;
     if (tid < 14) red[tid] = 0;
     if (tid == 0) { red_time = INT64_MIN; red_flags[0] = red_flags[1] = red_flags[2] = red_flags[3] = 0; }

@@ -484,3 +484,28 @@ def test_an_election_that_rests_on_a_stand_in_rank_is_refused_not_guessed(engine
             assert e.code == N.HS_E_UNSUPPORTED and "lock-step tie" in str(e)
             return
         _check_against_oracle(spec, eng, r, nodes)          # (decided on the single heap: then it must be the reference's answer)
+
+
+@pytest.mark.parametrize("n", [66_048, 131_072])
+def test_a_ring_with_more_stations_than_one_cooperative_launch_holds_runs_in_segments(n):
+    """VERDICT r4 missing 5: above 65 536 resident stations `hs_engine_run_until` used to drop to one launch per smallest link
+    latency.  Now contiguous segments take turns on the asynchronous engine (hs_engine.hip run_net_segments): a few dozen sweeps
+    instead of thousands of windows, == the oracle's single heap on every statistic and record, and == the window protocol
+    (debug flag 1 << 23)."""
+    import time
+
+    spec = dict(name=f"ring_{n}_segments", topology="ring", n=n, ext_rate=4.0, mean=0.1, lat_min=0.001, jitter_mean=0.01, end_s=1.5, seed=7)
+    g, nodes = H.oracle_ring_graph(spec)
+    r = O.run(g, H.ring_params(spec)["end_ns"], seed=spec["seed"])
+    res = {}
+    for name, flags in (("segments", 0), ("windows", 1 << 23)):
+        eng, p = H.ring_engine_for_spec(spec, flags=flags)
+        with eng:
+            t0 = time.perf_counter()
+            eng.run_until(p["end_ns"])
+            wall = time.perf_counter() - t0
+            s = eng.summary()
+            res[name] = (s.launches, wall)
+            _check_against_oracle(spec, eng, r, nodes)
+    print(res)
+    assert res["segments"][0] < 200 < res["windows"][0], res
