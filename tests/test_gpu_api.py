@@ -1150,12 +1150,13 @@ def test_results_bind_one_object_at_a_time_until_somebody_walks_them():
     binding after a few lookups.  The values are the ones the bulk path gives."""
     from happy_simulator_amd import entities as E
 
-    def build(n=200):
+    def build(n=2200):                                             # (> 4 096 entities: run() builds its entity summaries lazily too)
         sinks = [hs.Sink(f"sink{i}") for i in range(n)]
         servers = [hs.Server(f"srv{i}", service_time=hs.ExponentialLatency(0.1), downstream=sinks[i]) for i in range(n)]
         sources = [hs.Source.poisson(rate=8.0, target=servers[i], name=f"src{i}") for i in range(n)]
         sim = hs.Simulation(duration=20, sources=sources, entities=[e for pr in zip(servers, sinks) for e in pr], seed=9)
         return sinks, servers, sources, sim
+
 
     ref_sinks, ref_servers, ref_sources, ref_sim = build()             # the reference: the same run, everything bound at once
     ref_sim.run()
