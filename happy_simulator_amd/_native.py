@@ -140,7 +140,7 @@ class LbStats(C.Structure):
 
 
 _TUS = ("hs_engine.hip", "hs_lb.hip", "hs_tables.hip")          # one object each ...
-_INST_TU, _INST_GROUPS = "hs_inst.hip", 16                      # ... plus hs_inst.hip once per instantiation group (csrc/hs_kernels.hpp)
+_INST_TU, _INST_GROUPS = "hs_inst.hip", 17                      # ... plus hs_inst.hip once per instantiation group (csrc/hs_kernels.hpp)
 _STAMP_TU = "hs_stamp.hip"                                      # ... plus the build identity (the sources' hash, inside the .so)
 _MARK, _MARK_END = b"HS_SRC_HASH=", b"=HS_SRC_HASH_END"
 

@@ -111,6 +111,10 @@ struct hs_engine {
     WavePart *wave_parts = nullptr;   // one wavefront per LP (hs_kernels_wave.hpp): the workgroups' partial totals
     int wide_K = 0;            // 0: one lane per LP (hs_station_run)
     bool fresh = false;        // nothing has run since the last reset (the wide kernel starts from empty queues)
+    // hs_engine_reset on an engine whose next run is one wavefront per LP: the bootstrap is DEFERRED into that run's kernel
+    // (hs_station_wave<NW, true>); anything else that touches the state first launches the reset kernel after all (ensure_reset)
+    bool reset_pending = false;
+    mutable long long device_lanes = 0;   // CUs x 4 SIMDs x 64 lanes of the engine's device (wide_lanes)
     // tick tables (hs_tables.hpp): Sources with a time-varying profile and Probes
     TickRow *tab_rows = nullptr; int n_tab_rows = 0; int64_t tab_cap = 0;
     int64_t *tab_times = nullptr, *tab_count = nullptr;
@@ -207,9 +211,12 @@ int wide_lanes(const hs_engine *h) {
     //   32 768     0.403     0.422    0.610    1.059
     // Fewer lanes per LP = less redundant work in the serial arrival chain, more = shorter steps: K = 8 while the device has SIMDs
     // to spare, K = 4 up to a quarter of the size at which a lane per LP fills the machine.
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, h->cfg.device) != hipSuccess) return 0;
-    const long long lanes = (long long)prop.multiProcessorCount * 4 * 64;        // one wavefront per SIMD
+    if (h->device_lanes == 0) {                                                  // (asked once: it is a ~10 us host call, twice per step)
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->cfg.device) != hipSuccess) return 0;
+        h->device_lanes = (long long)prop.multiProcessorCount * 4 * 64;          // one wavefront per SIMD
+    }
+    const long long lanes = h->device_lanes;
     const long long n = h->cfg.n_lp;
     // Round 5: one wavefront per LP (hs_kernels_wave.hpp).  Measured (tools/wide_timing.py, profiles/r05_wide_timing.log; kernel ms incl.
     // hs_station_wide_finish): 1 024 LPs 0.056 (8 LPs per workgroup) / 0.068 (16) against K = 8: 0.087; 8 192: 0.106 against K = 4: 0.168;
@@ -226,20 +233,28 @@ void launch_wide(hs_engine *h, int64_t end_ns) {
     hipLaunchKernelGGL(hs_station_wide<K>, dim3(nb), dim3(kWideBlock), 0, h->stream, h->P, h->X, h->L, h->tot, h->cands, h->wide_ctl,
                        h->wide_bail, n, end_ns, h->flags);
     hipLaunchKernelGGL(hs_station_wide_finish, dim3(1), dim3(kBlock), 0, h->stream, h->P, h->X, h->L, h->tot, h->cands, nb, h->wide_ctl,
-                       h->wide_bail, n, end_ns, (const WavePart *)nullptr);
+                       h->wide_bail, n, end_ns, (const WavePart *)nullptr, (long long)INT64_MIN);
 }
 template <int NW>
 void launch_wave(hs_engine *h, int64_t end_ns) {
     const int n = h->cfg.n_lp, nb = (n + NW - 1) / NW;
-    hipLaunchKernelGGL(hs_station_wave<NW>, dim3(nb), dim3(NW * 64), 0, h->stream, h->P, h->X, h->L, h->tot, h->cands, h->wide_ctl,
-                       h->wide_bail, h->wave_parts, n, end_ns, h->flags);
+    const bool fresh = h->reset_pending;                      // the bootstrap inside the kernel, no hs_station_reset launch
+    h->reset_pending = false;
+    if (fresh)
+        hipLaunchKernelGGL((hs_station_wave<NW, true>), dim3(nb), dim3(NW * 64), 0, h->stream, h->P, h->X, h->L, h->tot, h->cands, h->wide_ctl,
+                           h->wide_bail, h->wave_parts, n, end_ns, h->flags, h->cfg.start_ns);
+    else
+        hipLaunchKernelGGL((hs_station_wave<NW, false>), dim3(nb), dim3(NW * 64), 0, h->stream, h->P, h->X, h->L, h->tot, h->cands, h->wide_ctl,
+                           h->wide_bail, h->wave_parts, n, end_ns, h->flags, h->cfg.start_ns);
     hipLaunchKernelGGL(hs_station_wide_finish, dim3(1), dim3(kBlock), 0, h->stream, h->P, h->X, h->L, h->tot, h->cands, nb, h->wide_ctl,
-                       h->wide_bail, n, end_ns, (const WavePart *)h->wave_parts);
+                       h->wide_bail, n, end_ns, (const WavePart *)h->wave_parts, fresh ? (long long)h->cfg.start_ns : (long long)INT64_MIN);
 }
 
+int ensure_reset(hs_engine *h);
 void launch_run_dispatch(hs_engine *h, int64_t end_ns) {
     if (h->exact_only) return;     // (the single-heap loop has run the whole window: launch_prologue)
     const int K = wide_lanes(h);
+    if (K != 64 && K != 65) (void)ensure_reset(h);            // (only hs_station_wave performs a deferred bootstrap itself)
     h->fresh = false;
     switch (K) {
         case 4: launch_wide<4>(h, end_ns); return;
@@ -417,7 +432,37 @@ int run_net_async(hs_engine *h, int64_t end_ns) {
     return HS_OK;
 }
 
+// the reset kernel itself (the Simulation.__init__ bootstrap on the device)
+int launch_reset(hs_engine *h);
+int ensure_reset(hs_engine *h) {
+    if (!h->reset_pending) return HS_OK;
+    h->reset_pending = false;
+    return launch_reset(h);
+}
 int do_reset_async(hs_engine *h) {
+    // An engine whose next run is hs_station_wave (wide_lanes() == 64 / 65 once `fresh`): that kernel performs the bootstrap itself
+    // (FRESH instantiation) and hs_station_wide_finish starts the totals -- no reset launch, no state round trip through HBM.
+    // Debug flag 1 << 29 keeps the reset kernel.
+    {
+        const bool was_fresh = h->fresh;
+        h->fresh = true;
+        const int K = (h->flags & (1 << 29)) ? 0 : wide_lanes(h);
+        h->fresh = was_fresh;
+        if ((K == 64 || K == 65) && !h->exact) {
+            h->reset_pending = true;
+            h->initialised = true;
+            h->net_ran = false;
+            h->net_last_end = INT64_MIN;
+            h->fresh = true;
+            h->window_ends.clear();
+            h->pending_async = false;
+            return HS_OK;
+        }
+    }
+    h->reset_pending = false;
+    return launch_reset(h);
+}
+int launch_reset(hs_engine *h) {
     if (h->n_tab_rows > 0 && !h->tables_built) {      // the tick tables (hs_tables.hpp): once, BEFORE the bootstrap reads tick 0
         HS_HIP(h, tick_tables_launch(h->stream, h->tab_rows, h->n_tab_rows, h->cfg.start_ns, h->cfg.horizon_ns, h->tab_cap,
                                      h->tab_times, h->tab_count, h->tab_status, h->lane_budget, false));
@@ -1814,6 +1859,7 @@ int hs_engine_synchronize(hs_engine *h) {
 // where a run that skipped the prologue, or tandem passes that met an undecided tie, are repeated on the single heap (ADVICE r3:
 // a getter that merely waited for the stream returned the results of the skipped path).
 static int results_final(hs_engine *h) {
+    { const int rcr = ensure_reset(h); if (rcr) return rcr; }      // (a reset whose bootstrap was deferred into a run that never came)
     if (h->pending_async) return hs_engine_synchronize(h);
     if (hipSetDevice(h->cfg.device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return fail(h, HS_E_HIP, "device synchronisation failed");
     return HS_OK;

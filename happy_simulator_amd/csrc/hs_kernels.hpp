@@ -1952,12 +1952,13 @@ __global__ void hs_debug_const_div_kernel(double b, int64_t n, const double *a, 
 #define HS_ARGS_WIDE (StationParams, StationState, RecordLogs, Totals *, Candidate *, WideCtl *, int32_t *, int, int64_t, int)
 #define HS_INST_GROUP_13(X) X(hs_station_wide<4> HS_ARGS_WIDE) X(hs_station_wide<8> HS_ARGS_WIDE)
 #define HS_INST_GROUP_14(X) X(hs_station_wide<16> HS_ARGS_WIDE)
-#define HS_ARGS_WAVE (StationParams, StationState, RecordLogs, Totals *, Candidate *, WideCtl *, int32_t *, WavePart *, int, int64_t, int)
-#define HS_INST_GROUP_15(X) X(hs_station_wave<16> HS_ARGS_WAVE) X(hs_station_wave<8> HS_ARGS_WAVE)
-#define HS_INST_GROUPS 16
+#define HS_ARGS_WAVE (StationParams, StationState, RecordLogs, Totals *, Candidate *, WideCtl *, int32_t *, WavePart *, int, int64_t, int, int64_t)
+#define HS_INST_GROUP_15(X) X(hs_station_wave<16, false> HS_ARGS_WAVE) X(hs_station_wave<8, false> HS_ARGS_WAVE)
+#define HS_INST_GROUP_16(X) X(hs_station_wave<16, true> HS_ARGS_WAVE) X(hs_station_wave<8, true> HS_ARGS_WAVE)
+#define HS_INST_GROUPS 17
 #define HS_INST_ALL(X) HS_INST_GROUP_0(X) HS_INST_GROUP_1(X) HS_INST_GROUP_2(X) HS_INST_GROUP_3(X) HS_INST_GROUP_4(X) HS_INST_GROUP_5(X) \
     HS_INST_GROUP_6(X) HS_INST_GROUP_7(X) HS_INST_GROUP_8(X) HS_INST_GROUP_9(X) HS_INST_GROUP_10(X) HS_INST_GROUP_11(X) HS_INST_GROUP_12(X) \
-    HS_INST_GROUP_13(X) HS_INST_GROUP_14(X) HS_INST_GROUP_15(X)
+    HS_INST_GROUP_13(X) HS_INST_GROUP_14(X) HS_INST_GROUP_15(X) HS_INST_GROUP_16(X)
 #define HS_DECLARE_INST(...) extern template __global__ void __VA_ARGS__;
 #define HS_DEFINE_INST(...) template __global__ void __VA_ARGS__;
 #ifdef HS_KERNELS_MAIN

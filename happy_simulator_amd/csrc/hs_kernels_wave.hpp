@@ -91,9 +91,14 @@ __device__ __forceinline__ double rfl64(double v) {     // ... of the first acti
 #ifndef HS_WAVE_WPE
 #define HS_WAVE_WPE 8                  // wavefronts per SIMD the register allocation aims at (<= 64 VGPRs: two workgroups of 16 per CU)
 #endif
-template <int NW>
+// FRESH: the engine was reset and nothing has run since -- the kernel performs the bootstrap itself (hs_station_reset: the first
+// arrival of every Source from start_ns) instead of loading the state a reset kernel would have written, and STORES the whole
+// per-LP state instead of folding deltas into it; hs_station_wide_finish sets the engine totals (round 5: one launch, ~45 scalar
+// loads and ~12 read-modify-writes per LP less on the strong shard's step).
+template <int NW, bool FRESH = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HS_WAVE_WPE, HS_WAVE_WPE))) hs_station_wave(StationParams P, StationState X, RecordLogs L, Totals *tot, Candidate *cands,
-                                                           WideCtl *ctl, int32_t *bail, WavePart *parts, int n, int64_t end_ns, int flags) {
+                                                           WideCtl *ctl, int32_t *bail, WavePart *parts, int n, int64_t end_ns, int flags,
+                                                           int64_t start_ns) {
     static_assert(NW == 4 || NW == 8 || NW == 16, "a 128-byte line of a record log holds 16 LPs");
     constexpr int R = kWaveR;
     __shared__ int64_t st_a[NW][kWaveRowPad], st_d[NW][kWaveRowPad];   // the step's admission / completion records, INT64_MIN = none
@@ -121,7 +126,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HS
     const int lp0 = blockIdx.x * NW;
     const int lp = lp0 + w;
     const bool live = lp < n;
-    const long long cur = tot->cur_time;
+    const long long cur = FRESH ? (long long)start_ns : tot->cur_time;
     const int64_t T = end_ns;
     const bool frozen = cur > end_ns;
     const double NEG = -__builtin_huge_val();
@@ -137,7 +142,25 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HS
     ConstDiv div_rate, div_lambda;
     uint32_t key0 = 0, key1 = 0, asid0 = 0, asid1 = 0, ssid0 = 0, ssid1 = 0;
     div_rate.init(1.0); div_lambda.init(1.0);
-    if (live) {
+    double carry_fresh = 0.0;
+    if constexpr (FRESH) {
+        if (live) {      // Simulation.__init__ bootstrap (core/simulation.py:145-154, hs_station_reset): the first arrival from start_ns
+            const uint64_t seed = P.seed[lp], base = P.stream_base[lp];
+            const double rate_in = P.src_rate[lp], mean_in = P.svc_mean[lp];
+            key0 = (uint32_t)seed; key1 = (uint32_t)(seed >> 32);
+            const uint64_t sa = stream_id(base, kStreamArrival), ss = stream_id(base, kStreamService);
+            asid0 = (uint32_t)sa; asid1 = (uint32_t)(sa >> 32); ssid0 = (uint32_t)ss; ssid1 = (uint32_t)(ss >> 32);
+            div_rate.init(rate_in);
+            div_lambda.init(__ddiv_rn(1.0, mean_in));
+            const U4 o = philox4x32_10(0u, 0u, asid0, asid1, key0, key1);
+            A = ns_from_seconds(__dadd_rn(seconds_from_ns(start_ns), __ddiv_rn(exp1_from_uniform(res53(o.x, o.y)), rate_in)));
+            carry_fresh = div_rate.div(exp1_from_uniform(res53(o.z, o.w)));      // draw 1: the increment behind the first arrival
+            crtA = start_ns; ak0 = 1; sk0 = 0; last_time = start_ns;
+            seq_in = 1; rcA_in = INT64_MIN; rcD_in = INT64_MIN;
+            elig = (int)!frozen & (int)(A >= 0) & (int)(start_ns >= 0) & (int)(end_ns < (1ll << 51)) & (int)(A < (1ll << 51));
+        }
+    }
+    if (!FRESH && live) {
         // every load first, unconditionally (a short-circuited `&&` chain loads one value per memory round trip: 40 of them were
         // 16 000 cycles before the first step), then the predicates
         A = X.A[lp]; crtA = X.crtA[lp]; ak0 = X.arr_k[lp]; sk0 = X.svc_k[lp];
@@ -200,7 +223,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HS
     const bool da = (ak0 & 1ull) != 0, ds = (sk0 & 1ull) != 0;
     uint64_t blk_a = ((ak0 + 1) >> 1) + (uint64_t)lane, blk_s = ((sk0 + 1) >> 1) + (uint64_t)lane;
     double carry_inc = 0.0, carry_sv = 0.0;
-    if (run && da) {
+    if constexpr (FRESH) carry_inc = carry_fresh;
+    if (!FRESH && run && da) {
         const uint64_t b = ak0 >> 1;
         const U4 o = philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), asid0, asid1, key0, key1);
         carry_inc = div_rate.div(exp1_from_uniform(res53(o.z, o.w)));
@@ -411,7 +435,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HS
     if (w == 0 && lane < NW) s_ts[lane] = ts_mine;
     __syncthreads();
     total_service = s_ts[w];
-    lt = (int64_t)lt_d;
+    lt = to_i64(lt_d);
     const int ovf_w = __any(overflow) ? 1 : 0;
 
     // ---- fold the window into the LP's state (Station::req_finish): wave-uniform values, lane 0 stores
@@ -420,37 +444,73 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HS
     if (pend_new) {
         pend = true;
         pendD = to_i64(s_pend[w][0]); pendS = to_i64(s_pend[w][1]); pendA_d = s_pend[w][2]; pendAp_d = s_pend[w][3];
-        pend_i = (int64_t)s_pend[w][4]; pend_s = s_pend[w][5]; pendSp_d = s_pend[w][6];
+        pend_i = to_i64(s_pend[w][4]); pend_s = s_pend[w][5]; pendSp_d = s_pend[w][6];
     }
     const double A_next = s_tick[w][0], a_last = s_tick[w][1], a_last2 = s_tick[w][2];
     const int64_t n_arr_total = r0;
     Candidate mine = cand_none(live ? lp : 0);
     unsigned ev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool count = run && !bailed;
+    // what the LP's state becomes (FRESH: for an LP that did not run, or bailed, what the reset leaves)
+    uint32_t c_tick = 0, c_start = 0, c_dep = 0, seq = seq_in, seqA = seqA_in, seqD = seqD_in;
+    int64_t acc2 = accepted, st2 = started, A_next_i = A, crtA2 = crtA0, rcA = rcA_in, rcD = rcD_in;
+    int32_t dpA = dpA_in, dpD = dpD_in;
     if (count) {
-        const uint32_t c_tick = n_tick, c_notify = n_notify, c_poll = n_poll, c_start = n_start, c_dep = n_dep;
+        c_tick = n_tick; c_start = n_start; c_dep = n_dep;
+        const uint32_t c_notify = n_notify, c_poll = n_poll;
         ev[0] = c_tick; ev[1] = c_tick; ev[2] = c_notify; ev[3] = c_poll + c_dep; ev[4] = c_start; ev[5] = c_start; ev[6] = c_dep; ev[7] = c_dep;
-        const int64_t acc2 = accepted + c_tick, st2 = started + c_start;
-        const int64_t A_next_i = A != kInfNs ? (int64_t)A_next : A;
-        const int64_t crtA2 = c_tick ? (int64_t)a_last : crtA0;
-        uint32_t seq = seq_in, seqA = seqA_in, seqD = seqD_in;
+        acc2 = accepted + c_tick; st2 = started + c_start;
+        A_next_i = A != kInfNs ? to_i64(A_next) : A;
+        crtA2 = c_tick ? to_i64(a_last) : crtA0;
         if ((c_tick | c_start) != 0u) {                  // creation stamps: only their order matters (Station::req_finish)
             const bool d_first = pend && pendS < crtA2;
             seqA = seq + (d_first ? 1u : 0u); seqD = seq + (d_first ? 0u : 1u); seq += 2u;
         }
         // lineage of what is pending now (Station::req_finish)
-        int32_t dpA = dpA_in, dpD = dpD_in;
-        int64_t rcA = rcA_in, rcD = rcD_in;
-        if (c_tick) { dpA = 1; rcA = acc2 >= 2 ? (c_tick >= 2 ? (int64_t)a_last2 : L.adm[(size_t)(acc2 - 2) * n + lp]) : crtA0; }
+        if (c_tick) { dpA = 1; rcA = acc2 >= 2 ? (c_tick >= 2 ? to_i64(a_last2) : L.adm[(size_t)(acc2 - 2) * n + lp]) : crtA0; }
         if (pend && pend_new) {
             const int64_t m = st2 - 1;                   // the request in service: it started at pendS
-            if (pendS == (int64_t)pendA_d) {             // ... on arrival: six steps from its tick, which was created at the tick before
+            if (pendS == to_i64(pendA_d)) {              // ... on arrival: six steps from its tick, which was created at the tick before
                 dpD = 6;
-                rcD = m >= 1 ? (pend_i >= 1 ? (int64_t)pendAp_d : (m - 1 < L.cap ? L.adm[(size_t)(m - 1) * n + lp] : 0)) : crtA0;
+                rcD = m >= 1 ? (pend_i >= 1 ? to_i64(pendAp_d) : (m - 1 < L.cap ? L.adm[(size_t)(m - 1) * n + lp] : 0)) : crtA0;
             } else {                                     // ... when request m - 1 left: four steps from that continuation, created when IT started
-                dpD = 4; rcD = (int64_t)pendSp_d;        // (= pendS - its service time: Station::req_finish draws that again)
+                dpD = 4; rcD = to_i64(pendSp_d);         // (= pendS - its service time: Station::req_finish draws that again)
             }
         }
+        // this LP's candidate for the one event beyond end_ns (make_candidate / pick_root: creation stamps decide a tie)
+        const int64_t Dn = pend ? pendD : kInfNs;
+        const int64_t tmin = A_next_i < Dn ? A_next_i : Dn;
+        if (tmin != kInfNs) {
+            const bool tick_first = A_next_i < Dn || (A_next_i == Dn && (int32_t)(seqA - seqD) < 0);
+            mine.t = tmin; mine.valid = 1;
+            if (tick_first) { mine.t_created = crtA2; mine.depth = dpA; mine.rcrt = rcA; mine.pad = 2; }
+            else { mine.t_created = pend ? pendS : 0; mine.depth = dpD; mine.rcrt = rcD; mine.pad = 0; }
+            mine.rank = cand_rank(P, lp, n, mine.pad);
+        }
+    }
+    if constexpr (FRESH) {
+        if (live && lane == 0) {                         // the WHOLE state, as hs_station_reset + the fold would have left it
+            const bool pd = count && pend;
+            uint32_t tot_ev = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { X.ev_kind[(size_t)k * n + lp] = ev[k]; tot_ev += ev[k]; }
+#pragma unroll
+            for (int k = 8; k < 11; ++k) X.ev_kind[(size_t)k * n + lp] = 0;
+            X.events[lp] = tot_ev;
+            X.generated[lp] = c_tick; X.accepted[lp] = acc2; X.dropped[lp] = 0; X.completed[lp] = c_dep; X.rejected[lp] = 0;
+            X.started[lp] = st2; X.received[lp] = c_dep; X.sink_w[lp] = c_dep;
+            X.buf[lp] = (int64_t)c_tick - (int64_t)c_start;
+            X.active[lp] = pd ? 1 : 0;
+            X.D[lp] = pd ? pendD : kInfNs; X.crtD[lp] = pd ? pendS : start_ns; X.svc_s[lp] = pd ? pend_s : 0.0; X.crt[lp] = 0;
+            X.total_service[lp] = count ? total_service : 0.0;
+            X.A[lp] = A_next_i; X.arr_time[lp] = A_next_i; X.arr_k[lp] = 1u + (uint64_t)(count ? n_arr_total : 0); X.svc_k[lp] = (uint64_t)c_start;
+            X.crtA[lp] = crtA2;
+            X.seqA[lp] = seqA; X.seqD[lp] = seqD; X.seq[lp] = seq;
+            X.q[lp] = 0; X.grp_time[lp] = start_ns;
+            X.last_time[lp] = count ? lt : start_ns;
+            X.dpA[lp] = (uint8_t)dpA; X.rcA[lp] = rcA; X.dpD[lp] = (uint8_t)dpD; X.rcD[lp] = rcD; X.wkD[lp] = 1;
+        }
+    } else if (count) {
         // (the read-modify-write counters: every load before the first store -- the pointers may alias as far as the compiler knows, and
         //  a load behind each store is a memory round trip each)
         const int64_t o_gen = X.generated[lp], o_comp = X.completed[lp], o_recv = X.received[lp], o_events = X.events[lp];
@@ -475,16 +535,6 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HS
 #pragma unroll
             for (int k = 0; k < 8; ++k) { X.ev_kind[(size_t)k * n + lp] = o_ev[k] + ev[k]; tot_ev += ev[k]; }
             X.events[lp] = o_events + tot_ev;
-        }
-        // this LP's candidate for the one event beyond end_ns (make_candidate / pick_root: creation stamps decide a tie)
-        const int64_t Dn = pend ? pendD : kInfNs;
-        const int64_t tmin = A_next_i < Dn ? A_next_i : Dn;
-        if (tmin != kInfNs) {
-            const bool tick_first = A_next_i < Dn || (A_next_i == Dn && (int32_t)(seqA - seqD) < 0);
-            mine.t = tmin; mine.valid = 1;
-            if (tick_first) { mine.t_created = crtA2; mine.depth = dpA; mine.rcrt = rcA; mine.pad = 2; }
-            else { mine.t_created = pend ? pendS : 0; mine.depth = dpD; mine.rcrt = rcD; mine.pad = 0; }
-            mine.rank = cand_rank(P, lp, n, mine.pad);
         }
     }
     if (bailed && lane == 0) {

@@ -465,12 +465,24 @@ __global__ void __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu
 // beyond end_ns is elected among all candidates and processed -- the last-block part of hs_station_run (SINGLE mode).
 __global__ void __launch_bounds__(kBlock) hs_station_wide_finish(StationParams P, StationState X, RecordLogs L, Totals *tot,
                                                                  Candidate *cands, int n_cands, WideCtl *ctl, const int32_t *bail,
-                                                                 int n, int64_t end_ns, const WavePart *parts) {
+                                                                 int n, int64_t end_ns, const WavePart *parts, long long fresh_start) {
     __shared__ uint8_t qmem[kQCap][kBlock];
     __shared__ double ring_a[kRing][kBlock], ring_s[kRing][kBlock];
     __shared__ Candidate wave_c[kBlock / 64];
     const int tid = threadIdx.x;
-    const long long cur = tot->cur_time;
+    // fresh_start != INT64_MIN: hs_station_wave<NW, true> ran the bootstrap itself (no hs_station_reset launch before it) -- the
+    // engine totals start here, as the reset kernel leaves them
+    const bool fresh = fresh_start != INT64_MIN;
+    if (fresh) {
+        if (tid == 0) {
+            for (int k = 0; k < 15; ++k) tot->ev[k] = 0;
+            tot->completed = 0; tot->received = 0; tot->final_time = fresh_start; tot->cur_time = fresh_start;
+            tot->overflow = 0; tot->qoverflow = 0; tot->done = 0; tot->undecided = 0;
+            tot->dbg[0] = tot->dbg[1] = tot->dbg[2] = tot->dbg[3] = 0; tot->not_done = 0;
+        }
+        __syncthreads();
+    }
+    const long long cur = fresh ? fresh_start : tot->cur_time;
     const unsigned nb = ctl->n_bail;
     if (parts != nullptr) {                                  // hs_station_wave: the workgroups' partial totals (one per candidate)
         unsigned long long s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
