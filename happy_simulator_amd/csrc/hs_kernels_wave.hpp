@@ -281,6 +281,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HS
             if (--steps_left < 0) { overflow = 1; fin = true; }
             // ---- V: the step's stream values.  (The empty asm keeps the ten round keys from being hoisted out of the loop: twenty more
             // live SGPRs spill to VGPR lanes and every round then pays a v_readlane; twenty s_add per step are free next to the VALU.)
+            key0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)key0); key1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)key1);   // (wave-uniform by construction: say so)
             asm volatile("" : "+s"(key0), "+s"(key1));
             const U4 oa = philox4x32_10((uint32_t)blk_a, (uint32_t)(blk_a >> 32), asid0, asid1, key0, key1);
             const U4 os = philox4x32_10((uint32_t)blk_s, (uint32_t)(blk_s >> 32), ssid0, ssid1, key0, key1);
