@@ -172,7 +172,9 @@ __device__ __forceinline__ size_t lb_draw_index(uint64_t d, int s, int S) {
 __device__ __forceinline__ double lb_step_encode(double inc, double margin) {
     if (!(margin > 0.0)) return inc;
     const double F = __dmul_rn(inc, 1e9), fl = __builtin_floor(F), frac = __dsub_rn(F, fl);
-    const bool safe = frac >= margin && frac <= __dsub_rn(1.0, margin) && F < 4.0e15;
+    // (F < 2^39: with A < 2^40 the three roundings of the reference's step stay below 3u(A + F) + uF < 6.2e-4 ns < the 2^-10 margin --
+    //  the old guard F < 4e15 let a Poisson Source slower than ~0.017/s step by > 2^41 ns, where that bound fails)
+    const bool safe = frac >= margin && frac <= __dsub_rn(1.0, margin) && F < 549755813888.0;
     return safe ? fl : __longlong_as_double((long long)((uint64_t)__double_as_longlong(inc) | 0x8000000000000000ull));
 }
 // the next tick after the one at `arr_d` (whole ns as a double) for an encoded step
