@@ -696,6 +696,20 @@ def main():
                 "events_per_step": sl["config"]["events_per_step_per_gpu"],
                 "projected_8gpu_speedup_over_1gpu": out["ms_per_step"] / sl["ms_per_step"],
                 "note": "a projection from one device, not a measurement on eight"}
+        if rank == 0 and ("workloads" in out or "strong_shard" in out):
+            # the same figures in a place every consumer of the line keeps (`config` travels whole; top-level keys beyond the contract's
+            # are listed as extras by the driver's parser and dropped -- VERDICT r4 next 9)
+            brief = {}
+            for name, sub in (out.get("workloads") or {}).items():
+                if sub:
+                    r = sub.get("roofline", {})
+                    brief[name] = {"ms_per_step": sub["ms_per_step"], "events_per_s": sub["value"], "kernel": r.get("kernel"),
+                                   "hbm_frac_algorithmic": r.get("frac"), "valu_frac": r.get("valu_frac"),
+                                   "hbm_bytes_counters": r.get("traffic"), "algorithmic_bytes": r.get("algorithmic_bytes_per_launch")}
+            if "strong_shard" in out:
+                ss = out["strong_shard"]
+                brief["strong_shard_8192"] = {k: ss[k] for k in ("n_lp", "ms_per_step", "kernel_ms_avg", "projected_8gpu_speedup_over_1gpu")}
+            out["config"]["other_workloads"] = brief
         if args.api_run and world == 1 and rank == 0:
             out["config"].update(api_run(args, local_rank))
     if rank == 0:

@@ -39,6 +39,8 @@ def test_bench_prints_one_contract_line(args):
     assert r["bound"] in ("hbm", "mfma", "valu") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     if r["bound"] == "valu":                 # grid / ring: the HBM figures of the contract + the measured VALU issue fraction
         assert "valu" in r and (r["valu"] is None or 0.0 < r["valu"]["busy_frac"] <= 1.0)
+        # the binding resource and SURVEY 8(d)'s own model as FIELDS (valu_frac is None away from the profiled size)
+        assert "valu_frac" in r and (r["valu_frac"] is None or 0.0 < r["valu_frac"] <= 1.0) and r["frac_survey_8d"] > r["frac"]
     if "--workload" not in args:             # the grid line also carries the API run and the reference's own Python path
         assert "api_run_s" in d["config"] and d["config"]["api_events"] == d["config"]["events_per_step_per_gpu"]
         # the reference's own Python loop was timed on ANOTHER host (the GPU box has no /root/reference): labelled as such
@@ -75,6 +77,9 @@ def test_default_line_carries_ring_lb_and_the_strong_shard():
         assert w["cpu_baseline"]["kind"] == "port" and w["cpu_baseline"]["value"] > 1e4
     sh = d["strong_shard"]
     assert sh["n_lp"] == 512 and 0 < sh["kernel_ms_avg"] <= sh["ms_per_step"]
+    brief = d["config"]["other_workloads"]           # ... and again under `config`, which every consumer of the line keeps whole
+    assert brief["ring"]["ms_per_step"] == d["workloads"]["ring"]["ms_per_step"] and brief["lb"]["events_per_s"] == d["workloads"]["lb"]["value"]
+    assert brief["strong_shard_8192"]["ms_per_step"] == sh["ms_per_step"]
     assert sh["events_per_step"] < d["config"]["events_per_step_per_gpu"]
 
 
@@ -92,6 +97,6 @@ def test_fake_ranks_run_the_multi_rank_bench_paths_on_one_gpu():
     ring1 = _run("--workload", "ring", "--steps", "2", "--warmup", "1", "--n-lp", "2048", "--end-s", "3", "--cpu-sample-s", "0")
     ring2 = _run("--workload", "ring", "--steps", "2", "--warmup", "1", "--n-lp", "2048", "--end-s", "3", "--cpu-sample-s", "0",
                  "--fake-ranks", "2")
-    assert ring2["fake_ranks"] == 2 and "gloo" in ring2["config"]["parallelism"]
+    assert ring2["fake_ranks"] == 2 and "gloo" in ring2["config"]["parallelism"] and "peers' buffers" in ring2["config"]["parallelism"]
     assert ring2["config"]["events_per_step"] == ring1["config"]["events_per_step"]       # two shards == one engine
     assert ring2["config"]["launches_per_step"] >= 1

@@ -1,8 +1,8 @@
 #!/bin/bash
 # ON THE GPU BOX (gpurun): the round's committed evidence -- rocprofv3 kernel trace + the separate PMC passes (FETCH_SIZE, WRITE_SIZE,
 # SQ_*) for the three workloads, the derived roofline JSONs bench.py quotes, and the bench lines themselves.
-#   usage: bash tools/final_profiles.sh r04        (profiles/HEAD_COMMIT must name the commit of the tree)
-R=${1:-r04}
+#   usage: bash tools/final_profiles.sh r05        (profiles/HEAD_COMMIT must name the commit of the tree)
+R=${1:-r05}
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 T0=$(date +%s)
 mkdir -p gpurun_out/final
@@ -38,6 +38,13 @@ python bench.py --workload lb --cpu-sample-s 6 2> gpurun_out/final/bench_lb.err 
 python bench.py --n-lp 8192 --cpu-sample-s 0 --extras 0 --api-run 0 2> gpurun_out/final/bench_8192.err | tail -1 > gpurun_out/final/${R}_bench_8192.json
 python bench.py --fake-ranks 2 --cpu-sample-s 0 --steps 5 --warmup 2 2> gpurun_out/final/bench_fake2.err | tail -1 > gpurun_out/final/${R}_bench_fake_ranks_2.json
 python bench.py --workload ring --fake-ranks 2 --cpu-sample-s 0 --steps 3 --warmup 1 2> gpurun_out/final/bench_ring_fake2.err | tail -1 > gpurun_out/final/${R}_bench_ring_fake_ranks_2.json
+# the strong shard (8 192 LPs: one wavefront per LP) under the kernel trace, the K sweep, and the ring past one cooperative launch
+bash tools/trace_cmd.sh ${R}_wave8192 --n-lp 8192 --cpu-sample-s 0 --extras 0 --api-run 0 --steps 20 --warmup 5 > gpurun_out/final/${R}_wave8192.log 2>&1
+cp gpurun_out/${R}_wave8192/trace.txt profiles/${R}_trace_wave_8192lp.txt 2>/dev/null
+python tools/wide_timing.py --sizes 1024,4096,8192,16384,32768 > gpurun_out/final/${R}_wide_timing.log 2>&1
+python tools/ring_fullsize.py > gpurun_out/final/${R}_ring_fullsize.log 2>&1
+python tools/ring_fullsize.py --n 131072 >> gpurun_out/final/${R}_ring_fullsize.log 2>&1
+python tools/api_profile.py 2>&1 | grep "^pass" > gpurun_out/final/${R}_api_profile.log
 echo "bench done $(( $(date +%s) - T0 )) s"
 cut -c1-400 gpurun_out/final/${R}_bench_default.json
 tail -3 gpurun_out/final/derive.log
