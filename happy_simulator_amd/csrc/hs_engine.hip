@@ -197,6 +197,7 @@ void launch_run(hs_engine *h, int64_t end_ns, int mode, int flags) {
 // K lanes per LP when the grid is uniform and leaves lanes idle (hs_kernels_wide.hpp); debug flag 1 << 22 keeps the one-lane kernel,
 // bits 24..27 force K = 1 << (value - 1)
 int wide_lanes(const hs_engine *h) {
+    if (h->is_net) return 0;      // (a network's stations run on the network engines, whatever their egress arrays said before hs_engine_set_network)
     if (h->C != 1 || !h->uni_grid || h->any_profile || h->cfg.mode != HS_MODE_SINGLE || !h->fresh || h->wide_ctl == nullptr) return 0;
     if (h->flags & ((1 << 22) | 1 | 512 | (1 << 20))) return 0;
     const int forced = (h->flags >> 24) & 0xf;

@@ -1417,7 +1417,9 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
     // (generic instantiations: bits 8.. of `lanes` = the first station of this launch in workgroups -- a network with more
     //  stations than one cooperative launch holds runs in SEGMENTS that take turns, hs_engine.hip run_net_segments)
     int lp0 = 0;
+#ifndef HS_NO_SEG
     if constexpr (!UNI) { lp0 = (lanes >> 8) * kBlock; lanes &= 0xff; }
+#endif
     const int lp = lp0 + (blockIdx.x * (kBlock / 64) + (tid >> 6)) * lanes + lane;
     const bool live = lane < lanes && lp < n;
     if (tid < 14) red[tid] = 0;
