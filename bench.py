@@ -127,8 +127,14 @@ def api_run(args, device):
     t3 = time.perf_counter()
     lat = sinks[n // 2].latencies_s
     t4 = time.perf_counter()
-    return {"api_construct_s": t1 - t0, "api_run_s": t2 - t1, "api_events": summary.total_events_processed,
-            "api_first_counter_read_s": t3 - t2, "api_first_sink_read_s": t4 - t3, "api_checked": [int(done), len(lat)]}
+    out = {"api_construct_s": t1 - t0, "api_run_s": t2 - t1, "api_events": summary.total_events_processed,
+           "api_first_counter_read_s": t3 - t2, "api_first_sink_read_s": t4 - t3, "api_checked": [int(done), len(lat)]}
+    # the run's records stay on the device behind the Sinks that were not read (LazyRecords owns the engine): release it here, not in an
+    # exit handler (under rocprofv3 the profiler's own finalisation runs first, and an engine torn down behind it takes the tool with it)
+    rec = getattr(sim, "_records", None)
+    if rec is not None:
+        rec.close()
+    return out
 
 
 def self_launch(args):
@@ -587,7 +593,7 @@ def grid_main(args, ctx, headline=True):
             # the binding resource is VALU issue (the serial per-LP recursion), not HBM: `achieved` / `frac` are the HBM
             # figures the contract asks for, `valu` is the measured issue fraction of the same kernel
             "bound": "valu",
-            "kernel": ("hs_station_run<1, false, true, true> (producer / consumer wavefronts, uniform entity kinds)" if n_mine > 16384
+            "kernel": ("hs_station_run<1, false, true, true> (producer / consumer wavefronts, uniform entity kinds)" if n_mine > 32768
                        else "hs_station_wave<NW> + hs_station_wide_finish (one wavefront per LP: fewer LPs than the device has lanes)"),
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
