@@ -117,3 +117,26 @@ def test_8192_lps_run_at_least_twice_as_fast_as_one_lane_each():
             times[name] = float(np.median(k))
     print(times)
     assert times["wide"] < 0.35 * times["one lane per LP"], times      # (measured r4: 0.168 vs 0.39 ms; r5, a wavefront per LP: see DESIGN section 6)
+
+
+def test_wave_kernel_on_random_uniform_grids():
+    """Round 5: one wavefront per LP (hs_station_wave, both workgroup shapes, the FRESH and the loading instantiation) against one lane
+    per LP on 160 random uniform grids -- sizes 1 .. 3 000, rates 0.002 .. 60 per second (the slowest step by more than 2^39 ns: every
+    arrival takes the reference's own step, no speculation), services 1 ms .. 0.8 s (over- and underloaded), horizons 0.02 .. 40 s, and
+    a second window on top of half of them (the state the kernel leaves must continue identically)."""
+    rng = np.random.default_rng(2026)
+    for case in range(160):
+        n = int(rng.choice([1, 2, 5, 17, 63, 64, 65, 200, 513, 1500, 3000]))
+        rate = float(rng.choice([0.002, 0.05, 0.7, 3.0, 8.0, 8.0, 20.0, 60.0]))
+        mean = float(rng.choice([0.001, 0.02, 0.1, 0.1, 0.3, 0.8]))
+        end = int(float(rng.choice([0.02, 0.3, 2.0, 7.0, 40.0])) * 1e9)
+        if rate * (end / 1e9) * n > 3.0e6:          # keep a case below a few million requests
+            end = int(3.0e6 / (rate * n) * 1e9)
+        seed = int(rng.integers(1, 1 << 30))
+        second = int(end * float(rng.choice([1.3, 2.0]))) if case % 2 else None
+        ref = _run(n, end, ONE_LANE, seed=seed, rate=rate, mean=mean, second_end=second)
+        for k in (64, 65):
+            got = _run(n, end, _force(k), seed=seed, rate=rate, mean=mean, second_end=second)
+            _same(got, ref, f"case {case}: n {n} rate {rate} mean {mean} end {end} seed {seed} second {second} K {k}")
+        got = _run(n, end, _force(64) | (1 << 29), seed=seed, rate=rate, mean=mean, second_end=second)     # the reset kernel + the loading instantiation
+        _same(got, ref, f"case {case} (reset kernel): n {n} rate {rate} mean {mean} end {end} seed {seed}")
