@@ -378,7 +378,10 @@ int hs_engine_shard_peers_local(hs_engine *h, int64_t *const *inbox_ptrs, int64_
 int hs_engine_shard_push(hs_engine *h);
 int hs_engine_shard_inject_ipc(hs_engine *h);
 /* Simulation.__init__ bootstrap (core/simulation.py:145-154): clock to start_ns, every Source draws its
- * first arrival.  Called implicitly by the first run; call again to rewind the engine for another run. */
+ * first arrival.  Called implicitly by the first run; call again to rewind the engine for another run.
+ * (On a uniform grid small enough for one wavefront per LP -- csrc/hs_kernels_wave.hpp -- the bootstrap is performed by the next
+ * run's kernel itself instead of a launch of its own; any getter or other run path in between performs it first: no observable
+ * difference, one launch and one round trip of the state through HBM less.) */
 int hs_engine_reset(hs_engine *h);
 /* == Simulation._execute_until(end_ns): process events until the last processed event's time exceeds
  * end_ns (one-event overshoot included).  Re-entrant (windows, core/simulation.py:527-541 `_run_window`): station engines continue
