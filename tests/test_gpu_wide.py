@@ -21,12 +21,12 @@ def _force(k):
     return ({4: 3, 8: 4, 16: 5, 64: 7, 65: 8}[k]) << 24
 
 
-def _run(n, end_ns, flags, seed=42, rate=8.0, mean=0.1, second_end=None):
+def _run(n, end_ns, flags, seed=42, rate=8.0, mean=0.1, second_end=None, start_ns=0):
     from happy_simulator_amd import _native as N
     from happy_simulator_amd.engine import StationArrays, StationEngine
 
     st = StationArrays.uniform(n, rate=rate, mean=mean)
-    with StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=second_end or end_ns, seed=seed) as eng:
+    with StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=second_end or end_ns, seed=seed, start_ns=start_ns) as eng:
         eng.set_debug_flags(flags)
         eng.run_until(end_ns)
         if second_end:
@@ -133,10 +133,11 @@ def test_wave_kernel_on_random_uniform_grids():
         if rate * (end / 1e9) * n > 3.0e6:          # keep a case below a few million requests
             end = int(3.0e6 / (rate * n) * 1e9)
         seed = int(rng.integers(1, 1 << 30))
-        second = int(end * float(rng.choice([1.3, 2.0]))) if case % 2 else None
-        ref = _run(n, end, ONE_LANE, seed=seed, rate=rate, mean=mean, second_end=second)
+        start = int(rng.choice([0, 0, 17, 1_500_000_000]))                   # Simulation(start_time=...): the bootstrap draws from there
+        end += start
+        second = start + int((end - start) * float(rng.choice([1.3, 2.0]))) if case % 2 else None
+        kw = dict(seed=seed, rate=rate, mean=mean, second_end=second, start_ns=start)
+        ref = _run(n, end, ONE_LANE, **kw)
         for k in (64, 65):
-            got = _run(n, end, _force(k), seed=seed, rate=rate, mean=mean, second_end=second)
-            _same(got, ref, f"case {case}: n {n} rate {rate} mean {mean} end {end} seed {seed} second {second} K {k}")
-        got = _run(n, end, _force(64) | (1 << 29), seed=seed, rate=rate, mean=mean, second_end=second)     # the reset kernel + the loading instantiation
-        _same(got, ref, f"case {case} (reset kernel): n {n} rate {rate} mean {mean} end {end} seed {seed}")
+            _same(_run(n, end, _force(k), **kw), ref, f"case {case}: n {n} end {end} K {k} {kw}")
+        _same(_run(n, end, _force(64) | (1 << 29), **kw), ref, f"case {case} (reset kernel + the loading instantiation): n {n} end {end} {kw}")
