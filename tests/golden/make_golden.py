@@ -1039,6 +1039,9 @@ TANDEM_CASES = [
 ]
 
 LB_CASES = [
+    # round 5: the load-balancer graph driven window by window on the reference (see ring_6_windows)
+    dict(name="lb_windows", topology="lb", n_sources=3, n_backends=5, rate=[12.0, 9.0, 7.0], mean=0.1, concurrency=[1, 2, 1, 1, 3],
+         vnodes=60, n_clients=900, windows=[0.5, 2.0, 2.0, 1.0, 6.5], end_s=10.0, seed=321, trace=False),
     # the chash_example wiring: 1 source, 3 backends with concurrency 3, 150 vnodes, 200 clients
     dict(name="lb_chash_example", topology="lb", n_sources=1, n_backends=3, rate=30.0, mean=0.1, concurrency=3,
          vnodes=150, n_clients=200, end_s=20.0, seed=42, trace=True),
@@ -1102,6 +1105,10 @@ GRAPH_CASES = [
 ]
 
 RING_CASES = [
+    # round 5: the reference driven WINDOW BY WINDOW (`_run_window`, core/simulation.py:527-541: growing ends, a repeated end, an
+    # earlier end, an end a nanosecond behind the previous one) -- what it leaves is what ONE run to end_s leaves (run_sim_windows)
+    dict(name="ring_6_windows", topology="ring", n=6, ext_rate=[6.0, 4.0, 0.0, 7.0, 5.0, 3.0], mean=0.08, lat_min=0.002, jitter_mean=0.005,
+         windows=[1.0, 1.000000001, 3.5, 3.5, 2.0, 7.25], end_s=9.0, seed=123, trace=False),
     # Simulation.schedule() on networked stations: bursts at one timestamp, a station without a Source, one beyond the end
     dict(name="ring_4_schedule", topology="ring", n=4, ext_rate=[5.0, 0.0, 7.0, 4.0], mean=0.08, lat_min=0.002,
          jitter_mean=0.004,
@@ -1432,6 +1439,10 @@ PARALLEL_CASES = [
 
 
 CASES = [
+    # round 5: station chains driven window by window on the reference (see ring_6_windows)
+    dict(name="philox_windows_8", n_chains=8, arr="poisson", rate=8.0, svc="exp", mean=0.1, concurrency=[1, 2, 1, 1, 3, 1, 1, 2],
+         queue_cap=[None, None, 3, None, None, 1, None, None], windows=[0.7, 2.2, 2.2, 1.5, 2.200000001, 9.0], end_s=12.0,
+         rng="philox", seed=77, mode="single", trace=False),
     # --- Oracle-A: stock MT19937 streams -------------------------------------------------
     dict(name="quickstart_mt42", n_chains=1, arr="poisson", rate=8.0, svc="exp", mean=0.1, end_s=60.0,
          rng="mt", seed=42, mode="single", trace=True),

@@ -47,6 +47,8 @@ def test_lb_engine_matches_reference_golden(name):
         if p["strategy"] == "chash":
             np.testing.assert_array_equal(eng.ring(), gold.ring_backend)
             np.testing.assert_array_equal([eng.select(str(c)) for c in range(len(gold.client_backend))], gold.client_backend)
+        for w in spec.get("windows", ()):           # a golden of the reference driven window by window: so is the engine
+            eng.run(H.ns_from_seconds(w))
         eng.run(p["end_ns"])
         s = eng.summary()
         st = eng.stats()

@@ -91,6 +91,8 @@ def test_engine_matches_reference_golden(name):
         pytest.skip("stock MT19937 streams are sequential by construction (oracle-only golden)")
     eng, p = H.engine_for_spec(spec)
     with eng:
+        for w in spec.get("windows", ()):           # a golden of the reference driven window by window: so is the engine
+            eng.run_until(H.ns_from_seconds(w))
         eng.run_until(p["end_ns"])
         s = eng.summary()
         stats = eng.lp_stats()
