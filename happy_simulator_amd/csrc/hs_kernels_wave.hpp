@@ -120,6 +120,9 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HS
 #ifdef HS_WAVE_CYC   // scratch build (tools/wide_timing.py --wave-cycles): where a wavefront of workgroup 0 spends its cycles
     const unsigned long long cyc_k0 = __builtin_readcyclecounter();
     unsigned long long cyc_compute = 0, cyc_phase2 = 0, cyc_loop0 = 0, cyc_bar = 0;
+#ifdef HS_WAVE_SPAN
+    const unsigned long long span_k0 = wall_clock64();
+#endif
 #endif
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -258,13 +261,13 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HS
         if (w == 0 && lane < NW) {
             const int c = s_cnt[b][lane];
             for (int k = 0; k < R && __any(k < c); k += 8) {
-                double v[8];
+                if (k < c) {                             // (the writer zeroed the slots behind the last departure: + 0.0 is exact, the
+                    double v[8];                         // chain is the additions alone -- no per-sample select)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = s_sv[b][lane][k + q];
+                    for (int q = 0; q < 8; ++q) v[q] = s_sv[b][lane][k + q];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = (k + q) < c ? v[q] : 0.0;         // (+ 0.0 is exact: the chain is the additions alone)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) ts_mine = __dadd_rn(ts_mine, v[q]);
+                    for (int q = 0; q < 8; ++q) ts_mine = __dadd_rn(ts_mine, v[q]);
+                }
             }
         }
     };
@@ -374,7 +377,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HS
                 // ---- the step's records -> LDS (coalesced transposed write below); service samples for T
                 st_a[w][2 * lane] = arr0 ? to_i64(a0) : INT64_MIN; st_a[w][2 * lane + 1] = arr1 ? to_i64(a1) : INT64_MIN;
                 st_d[w][2 * lane] = dp0 ? to_i64(D0) : INT64_MIN; st_d[w][2 * lane + 1] = dp1 ? to_i64(D1) : INT64_MIN;
-                if (n_dp_l > 0) { s_sv[sb][w][2 * lane] = sv0; s_sv[sb][w][2 * lane + 1] = sv1; }
+                if (n_dp_l > 0) { s_sv[sb][w][2 * lane] = dp0 ? sv0 : 0.0; s_sv[sb][w][2 * lane + 1] = dp1 ? sv1 : 0.0; }
                 cnt_sv = n_dp_l;
                 did = true; rows_clear = false;
                 if (lane == 0) {
@@ -572,7 +575,15 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HS
 #ifdef HS_WAVE_CYC
     if (blockIdx.x == 0 && lane == 0 && (w == 0 || w == 1)) {     // dbg[0..3]: wavefront 1 {compute, barrier wait, T + writes, before + after the loop}
         const unsigned long long end_ = __builtin_readcyclecounter();
+#ifndef HS_WAVE_SPAN
         if (w == 1) { tot->dbg[0] = cyc_compute; tot->dbg[1] = cyc_bar; tot->dbg[2] = cyc_phase2; tot->dbg[3] = (cyc_loop0 - cyc_k0) * 1000000ull + (end_ - cyc_loop1); }
+#endif
     }
+#ifdef HS_WAVE_SPAN   // (with HS_WAVE_CYC) dbg = {~earliest start, latest start, ~earliest end, latest end} over the workgroups (s_memtime)
+    if (lane == 0 && w == 0) {                               // (s_memrealtime, 100 MHz: s_memtime is not synchronised between XCDs)
+        const unsigned long long end_ = wall_clock64();
+        atomicMax(&tot->dbg[0], ~span_k0); atomicMax(&tot->dbg[1], span_k0); atomicMax(&tot->dbg[2], ~end_); atomicMax(&tot->dbg[3], end_);
+    }
+#endif
 #endif
 }

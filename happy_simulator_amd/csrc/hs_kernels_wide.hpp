@@ -478,7 +478,10 @@ __global__ void __launch_bounds__(kBlock) hs_station_wide_finish(StationParams P
             for (int k = 0; k < 15; ++k) tot->ev[k] = 0;
             tot->completed = 0; tot->received = 0; tot->final_time = fresh_start; tot->cur_time = fresh_start;
             tot->overflow = 0; tot->qoverflow = 0; tot->done = 0; tot->undecided = 0;
-            tot->dbg[0] = tot->dbg[1] = tot->dbg[2] = tot->dbg[3] = 0; tot->not_done = 0;
+#ifndef HS_WAVE_CYC           // (the instrumented build keeps hs_station_wave's counters)
+            tot->dbg[0] = tot->dbg[1] = tot->dbg[2] = tot->dbg[3] = 0;
+#endif
+            tot->not_done = 0;
         }
         __syncthreads();
     }

@@ -37,9 +37,22 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", default="1024,4096,8192,16384,32768,65536")
     ap.add_argument("--cycles", action="store_true")
+    ap.add_argument("--wave-span", action="store_true", help="library built with -DHS_WAVE_CYC -DHS_WAVE_SPAN: first / last start and end of the workgroups")
     ap.add_argument("--wave-cycles", action="store_true", help="library built with -DHS_WAVE_CYC: cycles of wavefront 1 of workgroup 0 of hs_station_wave")
     a = ap.parse_args()
     for n in (int(x) for x in a.sizes.split(",")):
+        if a.wave_span:
+            for K in (64, 65):
+                st = StationArrays.uniform(n, rate=8.0, mean=0.1)
+                with StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=END, seed=42) as eng:
+                    eng.set_debug_flags(FORCE[K])
+                    eng.run_until(END)
+                    out = (C.c_ulonglong * 4)()
+                    eng._lib.hs_debug_async_counters(eng._h, out)
+                    m = (1 << 64) - 1
+                    s0, s1, e0, e1 = m - out[0], out[1], m - out[2], out[3]
+                    print(f"n_lp {n} K {K}: workgroup starts span {s1 - s0} ticks, first end {e0 - s0}, last end {e1 - s0} (ticks after the first start)", flush=True)
+            continue
         if a.wave_cycles:
             for K in (64, 65):
                 st = StationArrays.uniform(n, rate=8.0, mean=0.1)
