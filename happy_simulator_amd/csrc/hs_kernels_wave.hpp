@@ -86,6 +86,149 @@ __device__ __forceinline__ double rfl64(double v) {     // ... of the first acti
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// wave-uniform copies of a value every lane read from one LDS address (v_readfirstlane: the value lives in SGPRs afterwards)
+__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni(uint64_t v) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+__device__ __forceinline__ int64_t uni(int64_t v) { return (int64_t)uni((uint64_t)v); }
+__device__ __forceinline__ double uni(double v) { return rfl64(v); }
+
+// What an LP's wavefront starts from (WaveIn) and what it hands to the fold (WaveOut).  Both cross the workgroup through LDS, a lane
+// per LP on wavefront 0 at the other end: the bootstrap / the state loads before the first step and the fold + state stores behind
+// the last are wave-uniform work -- run by every wavefront for its own LP they cost 64 lanes' issue slots for one lane's worth of
+// values (~850 of the ~5 500 VALU instructions of a 60 s window), and sixteen wavefronts' single-lane stores of one field are
+// sixteen partial lines where a lane per LP writes one.
+struct WaveIn {
+    int64_t A, crtA, Dprev, Sprev, accepted, started, sink_w, last_time, rcA, rcD;
+    uint64_t ak0, sk0;
+    double total_service, svc_s0, carry_fresh, rate_b, rate_y, lam_b, lam_y;
+    uint32_t key0, key1, asid0, asid1, ssid0, ssid1, seq, seqA, seqD;
+    int32_t dpA, dpD;
+    int32_t bits;                       // 1 busy, 2 eligible, 4 div_rate.fast, 8 div_lambda.fast
+};
+struct WaveOut {
+    int64_t r0, lt;                     // arrivals of the window; the latest processed event
+    uint32_t n_tick, n_start, n_dep, n_notify, n_poll;
+    int32_t bits;                       // 1 pend, 2 pend_new, 4 count (ran, did not bail), 8 bailed, 16 overflow, 32 live
+};
+
+// Station::req_finish for one LP (lane `l` of wavefront 0): folds the window into the LP's state and stores it, lists a bailed LP,
+// and returns the LP's event counts, latest time and candidate for the one event beyond end_ns.
+template <bool FRESH>
+__device__ __forceinline__ void wave_fold(const StationParams &P, StationState &X, const RecordLogs &L, WideCtl *ctl, int32_t *bail, int n, int lp,
+                                          int64_t start_ns, const WaveIn &I, const double *pendv, const double *tick, const WaveOut &O,
+                                          double total_service, unsigned (&ev)[8], long long &lt_out, Candidate &mine) {
+    auto to_i64 = [](double d) {                        // exact for whole d in [0, 2^52)
+        return (int64_t)((uint64_t)__double_as_longlong(__dadd_rn(d, 4503599627370496.0)) & 0xFFFFFFFFFFFFFull);
+    };
+    const bool live = (O.bits & 32) != 0, count = (O.bits & 4) != 0, bailed = (O.bits & 8) != 0, pend_new = (O.bits & 2) != 0;
+    bool pend = (O.bits & 1) != 0;
+    const int64_t A = I.A, crtA0 = I.crtA, accepted = I.accepted, started = I.started, lt = O.lt;
+    int64_t pendD = I.Dprev, pendS = I.Sprev, pend_i = 0;
+    double pend_s = I.svc_s0, pendA_d = 0.0, pendAp_d = 0.0, pendSp_d = 0.0;
+    if (pend_new) {
+        pend = true;
+        pendD = to_i64(pendv[0]); pendS = to_i64(pendv[1]); pendA_d = pendv[2]; pendAp_d = pendv[3];
+        pend_i = to_i64(pendv[4]); pend_s = pendv[5]; pendSp_d = pendv[6];
+    }
+    const double A_next = tick[0], a_last = tick[1], a_last2 = tick[2];
+    const int64_t n_arr_total = O.r0;
+    mine = cand_none(live ? lp : 0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ev[k] = 0;
+    // what the LP's state becomes (FRESH: for an LP that did not run, or bailed, what the reset leaves)
+    uint32_t c_tick = 0, c_start = 0, c_dep = 0, seq = I.seq, seqA = I.seqA, seqD = I.seqD;
+    int64_t acc2 = accepted, st2 = started, A_next_i = A, crtA2 = crtA0, rcA = I.rcA, rcD = I.rcD;
+    int32_t dpA = I.dpA, dpD = I.dpD;
+    if (count) {
+        c_tick = O.n_tick; c_start = O.n_start; c_dep = O.n_dep;
+        const uint32_t c_notify = O.n_notify, c_poll = O.n_poll;
+        ev[0] = c_tick; ev[1] = c_tick; ev[2] = c_notify; ev[3] = c_poll + c_dep; ev[4] = c_start; ev[5] = c_start; ev[6] = c_dep; ev[7] = c_dep;
+        acc2 = accepted + c_tick; st2 = started + c_start;
+        A_next_i = A != kInfNs ? to_i64(A_next) : A;
+        crtA2 = c_tick ? to_i64(a_last) : crtA0;
+        if ((c_tick | c_start) != 0u) {                  // creation stamps: only their order matters (Station::req_finish)
+            const bool d_first = pend && pendS < crtA2;
+            seqA = seq + (d_first ? 1u : 0u); seqD = seq + (d_first ? 0u : 1u); seq += 2u;
+        }
+        // lineage of what is pending now (Station::req_finish)
+        if (c_tick) { dpA = 1; rcA = acc2 >= 2 ? (c_tick >= 2 ? to_i64(a_last2) : L.adm[(size_t)(acc2 - 2) * n + lp]) : crtA0; }
+        if (pend && pend_new) {
+            const int64_t m = st2 - 1;                   // the request in service: it started at pendS
+            if (pendS == to_i64(pendA_d)) {              // ... on arrival: six steps from its tick, which was created at the tick before
+                dpD = 6;
+                rcD = m >= 1 ? (pend_i >= 1 ? to_i64(pendAp_d) : (m - 1 < L.cap ? L.adm[(size_t)(m - 1) * n + lp] : 0)) : crtA0;
+            } else {                                     // ... when request m - 1 left: four steps from that continuation, created when IT started
+                dpD = 4; rcD = to_i64(pendSp_d);         // (= pendS - its service time: Station::req_finish draws that again)
+            }
+        }
+        // this LP's candidate for the one event beyond end_ns (make_candidate / pick_root: creation stamps decide a tie)
+        const int64_t Dn = pend ? pendD : kInfNs;
+        const int64_t tmin = A_next_i < Dn ? A_next_i : Dn;
+        if (tmin != kInfNs) {
+            const bool tick_first = A_next_i < Dn || (A_next_i == Dn && (int32_t)(seqA - seqD) < 0);
+            mine.t = tmin; mine.valid = 1;
+            if (tick_first) { mine.t_created = crtA2; mine.depth = dpA; mine.rcrt = rcA; mine.pad = 2; }
+            else { mine.t_created = pend ? pendS : 0; mine.depth = dpD; mine.rcrt = rcD; mine.pad = 0; }
+            mine.rank = cand_rank(P, lp, n, mine.pad);
+        }
+    }
+    if constexpr (FRESH) {
+        if (live) {                                      // the WHOLE state, as hs_station_reset + the fold would have left it
+            const bool pd = count && pend;
+            uint32_t tot_ev = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { X.ev_kind[(size_t)k * n + lp] = ev[k]; tot_ev += ev[k]; }
+#pragma unroll
+            for (int k = 8; k < 11; ++k) X.ev_kind[(size_t)k * n + lp] = 0;
+            X.events[lp] = tot_ev;
+            X.generated[lp] = c_tick; X.accepted[lp] = acc2; X.dropped[lp] = 0; X.completed[lp] = c_dep; X.rejected[lp] = 0;
+            X.started[lp] = st2; X.received[lp] = c_dep; X.sink_w[lp] = c_dep;
+            X.buf[lp] = (int64_t)c_tick - (int64_t)c_start;
+            X.active[lp] = pd ? 1 : 0;
+            X.D[lp] = pd ? pendD : kInfNs; X.crtD[lp] = pd ? pendS : start_ns; X.svc_s[lp] = pd ? pend_s : 0.0; X.crt[lp] = 0;
+            X.total_service[lp] = count ? total_service : 0.0;
+            X.A[lp] = A_next_i; X.arr_time[lp] = A_next_i; X.arr_k[lp] = 1u + (uint64_t)(count ? n_arr_total : 0); X.svc_k[lp] = (uint64_t)c_start;
+            X.crtA[lp] = crtA2;
+            X.seqA[lp] = seqA; X.seqD[lp] = seqD; X.seq[lp] = seq;
+            X.q[lp] = 0; X.grp_time[lp] = start_ns;
+            X.last_time[lp] = count ? lt : start_ns;
+            X.dpA[lp] = (uint8_t)dpA; X.rcA[lp] = rcA; X.dpD[lp] = (uint8_t)dpD; X.rcD[lp] = rcD; X.wkD[lp] = 1;
+        }
+    } else if (count) {
+        // (the read-modify-write counters: every load before the first store -- the pointers may alias as far as the compiler knows, and
+        //  a load behind each store is a memory round trip each)
+        const int64_t o_gen = X.generated[lp], o_comp = X.completed[lp], o_recv = X.received[lp], o_events = X.events[lp];
+        int64_t o_ev[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o_ev[k] = X.ev_kind[(size_t)k * n + lp];
+        X.generated[lp] = o_gen + c_tick; X.accepted[lp] = acc2; X.started[lp] = st2; X.completed[lp] = o_comp + c_dep;
+        X.received[lp] = o_recv + c_dep; X.sink_w[lp] = I.sink_w + c_dep;
+        X.buf[lp] = (int64_t)c_tick - (int64_t)c_start;
+        X.active[lp] = pend ? 1 : 0;
+        X.D[lp] = pend ? pendD : kInfNs;
+        if (pend) { X.crtD[lp] = pendS; X.svc_s[lp] = pend_s; }
+        X.total_service[lp] = total_service;
+        X.A[lp] = A_next_i; X.arr_time[lp] = A_next_i; X.arr_k[lp] = I.ak0 + (uint64_t)n_arr_total; X.svc_k[lp] = I.sk0 + (uint64_t)c_start;
+        X.crtA[lp] = crtA2;
+        if ((c_tick | c_start) != 0u) { X.seqA[lp] = seqA; X.seqD[lp] = seqD; X.seq[lp] = seq; }
+        X.last_time[lp] = lt;
+        if (c_tick) { X.dpA[lp] = (uint8_t)dpA; X.rcA[lp] = rcA; }
+        if (pend && pend_new) { X.dpD[lp] = (uint8_t)dpD; X.rcD[lp] = rcD; }
+        uint32_t tot_ev = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { X.ev_kind[(size_t)k * n + lp] = o_ev[k] + ev[k]; tot_ev += ev[k]; }
+        X.events[lp] = o_events + tot_ev;
+    }
+    if (bailed) {
+        const unsigned pos = atomicAdd(&ctl->n_bail, 1u);
+        bail[pos] = lp;
+    }
+    lt_out = count ? (long long)lt : INT64_MIN;
+}
+
 }  // namespace
 
 #ifndef HS_WAVE_WPE
@@ -116,6 +259,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HS
     __shared__ unsigned s_ev[NW][8];
     __shared__ long long s_lt[NW];
     __shared__ int s_ovf[NW];
+    __shared__ WaveIn s_in[NW];
+    __shared__ WaveOut s_out[NW];
 
 #ifdef HS_WAVE_CYC   // scratch build (tools/wide_timing.py --wave-cycles): where a wavefront of workgroup 0 spends its cycles
     const unsigned long long cyc_k0 = __builtin_readcyclecounter();
@@ -134,62 +279,71 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HS
     const bool frozen = cur > end_ns;
     const double NEG = -__builtin_huge_val();
 
-    // ---- the LP's state: wave-uniform (scalar loads)
-    int64_t A = kInfNs, crtA = 0, Dprev = INT64_MIN, Sprev = INT64_MIN, accepted = 0, started = 0, sink_w = 0, last_time = 0;
-    uint64_t ak0 = 0, sk0 = 0;
-    double total_service = 0.0, svc_s0 = 0.0;
-    bool busy = false, elig = false;
-    uint32_t seq_in = 0, seqA_in = 0, seqD_in = 0;
-    int32_t dpA_in = 0, dpD_in = 0;
-    int64_t rcA_in = 0, rcD_in = 0;
-    ConstDiv div_rate, div_lambda;
-    uint32_t key0 = 0, key1 = 0, asid0 = 0, asid1 = 0, ssid0 = 0, ssid1 = 0;
-    div_rate.init(1.0); div_lambda.init(1.0);
-    double carry_fresh = 0.0;
-    if constexpr (FRESH) {
-        if (live) {      // Simulation.__init__ bootstrap (core/simulation.py:145-154, hs_station_reset): the first arrival from start_ns
-            const uint64_t seed = P.seed[lp], base = P.stream_base[lp];
-            const double rate_in = P.src_rate[lp], mean_in = P.svc_mean[lp];
-            key0 = (uint32_t)seed; key1 = (uint32_t)(seed >> 32);
+    // ---- the LPs' state: wavefront 0, a lane per LP (coalesced loads, ONE bootstrap per LP), handed over in LDS (WaveIn)
+    if (w == 0 && lane < NW) {
+        const int lpl = lp0 + lane;
+        WaveIn I;
+        I.A = kInfNs; I.crtA = 0; I.Dprev = INT64_MIN; I.Sprev = INT64_MIN; I.accepted = 0; I.started = 0; I.sink_w = 0; I.last_time = 0;
+        I.rcA = 0; I.rcD = 0; I.ak0 = 0; I.sk0 = 0; I.total_service = 0.0; I.svc_s0 = 0.0; I.carry_fresh = 0.0;
+        I.key0 = I.key1 = I.asid0 = I.asid1 = I.ssid0 = I.ssid1 = 0; I.seq = I.seqA = I.seqD = 0; I.dpA = I.dpD = 0;
+        ConstDiv dr, dl;
+        dr.init(1.0); dl.init(1.0);
+        bool busy_l = false, elig_l = false;
+        if (lpl < n) {
+            const uint64_t seed = P.seed[lpl], base = P.stream_base[lpl];
+            const double rate_in = P.src_rate[lpl], mean_in = P.svc_mean[lpl];
+            I.key0 = (uint32_t)seed; I.key1 = (uint32_t)(seed >> 32);
             const uint64_t sa = stream_id(base, kStreamArrival), ss = stream_id(base, kStreamService);
-            asid0 = (uint32_t)sa; asid1 = (uint32_t)(sa >> 32); ssid0 = (uint32_t)ss; ssid1 = (uint32_t)(ss >> 32);
-            div_rate.init(rate_in);
-            div_lambda.init(__ddiv_rn(1.0, mean_in));
-            const U4 o = philox4x32_10(0u, 0u, asid0, asid1, key0, key1);
-            A = ns_from_seconds(__dadd_rn(seconds_from_ns(start_ns), __ddiv_rn(exp1_from_uniform(res53(o.x, o.y)), rate_in)));
-            carry_fresh = div_rate.div(exp1_from_uniform(res53(o.z, o.w)));      // draw 1: the increment behind the first arrival
-            crtA = start_ns; ak0 = 1; sk0 = 0; last_time = start_ns;
-            seq_in = 1; rcA_in = INT64_MIN; rcD_in = INT64_MIN;
-            elig = (int)!frozen & (int)(A >= 0) & (int)(start_ns >= 0) & (int)(end_ns < (1ll << 51)) & (int)(A < (1ll << 51));
+            I.asid0 = (uint32_t)sa; I.asid1 = (uint32_t)(sa >> 32); I.ssid0 = (uint32_t)ss; I.ssid1 = (uint32_t)(ss >> 32);
+            dr.init(rate_in);
+            dl.init(__ddiv_rn(1.0, mean_in));
+            if constexpr (FRESH) {   // Simulation.__init__ bootstrap (core/simulation.py:145-154, hs_station_reset): the first arrival from start_ns
+                const U4 o = philox4x32_10(0u, 0u, I.asid0, I.asid1, I.key0, I.key1);
+                I.A = ns_from_seconds(__dadd_rn(seconds_from_ns(start_ns), __ddiv_rn(exp1_from_uniform(res53(o.x, o.y)), rate_in)));
+                I.carry_fresh = dr.div(exp1_from_uniform(res53(o.z, o.w)));      // draw 1: the increment behind the first arrival
+                I.crtA = start_ns; I.ak0 = 1; I.sk0 = 0; I.last_time = start_ns;
+                I.seq = 1; I.rcA = INT64_MIN; I.rcD = INT64_MIN;
+                elig_l = (int)!frozen & (int)(I.A >= 0) & (int)(start_ns >= 0) & (int)(end_ns < (1ll << 51)) & (int)(I.A < (1ll << 51));
+            } else {
+                // every load first, unconditionally (a short-circuited `&&` chain loads one value per memory round trip), then the predicates
+                I.A = X.A[lpl]; I.crtA = X.crtA[lpl]; I.ak0 = X.arr_k[lpl]; I.sk0 = X.svc_k[lpl];
+                I.accepted = X.accepted[lpl]; I.started = X.started[lpl]; I.sink_w = X.sink_w[lpl]; I.last_time = X.last_time[lpl];
+                I.total_service = X.total_service[lpl];
+                const int32_t active_in = X.active[lpl];
+                const int64_t D_in = X.D[lpl], crtD_in = X.crtD[lpl], buf_in = X.buf[lpl], arr_time_in = X.arr_time[lpl];
+                const double svc_s_in = X.svc_s[lpl];
+                const uint32_t q_in = X.q[lpl];
+                I.seq = X.seq[lpl]; I.seqA = X.seqA[lpl]; I.seqD = X.seqD[lpl];              // (only the fold reads these)
+                I.dpA = X.dpA[lpl]; I.dpD = X.dpD[lpl]; I.rcA = X.rcA[lpl]; I.rcD = X.rcD[lpl];
+                busy_l = active_in > 0;
+                if (busy_l) { I.Dprev = D_in; I.Sprev = crtD_in; I.svc_s0 = svc_s_in; }
+                elig_l = (int)!frozen & (int)(q_in == 0) & (int)(buf_in == 0) & (int)(active_in <= 1) & (int)(arr_time_in == I.A) &
+                         (int)(I.A >= 0) & (int)(I.crtA >= 0) & (int)(I.last_time >= 0) & (int)(end_ns < (1ll << 51)) &
+                         (int)(I.A == kInfNs || I.A < (1ll << 51)) &                        // (exact in binary64)
+                         (int)(active_in == 0 || (D_in < (1ll << 51) && crtD_in >= 0));
+            }
+            if ((flags & (1 << 21)) && (lpl % 97) == 5) elig_l = false;     // debug: force some LPs through the bail path
         }
+        I.rate_b = dr.b; I.rate_y = dr.y; I.lam_b = dl.b; I.lam_y = dl.y;
+        I.bits = (busy_l ? 1 : 0) | (elig_l ? 2 : 0) | (dr.fast ? 4 : 0) | (dl.fast ? 8 : 0);
+        s_in[lane] = I;
     }
-    if (!FRESH && live) {
-        // every load first, unconditionally (a short-circuited `&&` chain loads one value per memory round trip: 40 of them were
-        // 16 000 cycles before the first step), then the predicates
-        A = X.A[lp]; crtA = X.crtA[lp]; ak0 = X.arr_k[lp]; sk0 = X.svc_k[lp];
-        accepted = X.accepted[lp]; started = X.started[lp]; sink_w = X.sink_w[lp]; last_time = X.last_time[lp];
-        total_service = X.total_service[lp];
-        const int32_t active_in = X.active[lp];
-        const int64_t D_in = X.D[lp], crtD_in = X.crtD[lp], buf_in = X.buf[lp], arr_time_in = X.arr_time[lp];
-        const double svc_s_in = X.svc_s[lp];
-        const uint32_t q_in = X.q[lp];
-        seq_in = X.seq[lp]; seqA_in = X.seqA[lp]; seqD_in = X.seqD[lp];              // (only the fold reads these)
-        dpA_in = X.dpA[lp]; dpD_in = X.dpD[lp]; rcA_in = X.rcA[lp]; rcD_in = X.rcD[lp];
-        const uint64_t seed = P.seed[lp], base = P.stream_base[lp];
-        const double rate_in = P.src_rate[lp], mean_in = P.svc_mean[lp];
-        busy = active_in > 0;
-        if (busy) { Dprev = D_in; Sprev = crtD_in; svc_s0 = svc_s_in; }
-        elig = (int)!frozen & (int)(q_in == 0) & (int)(buf_in == 0) & (int)(active_in <= 1) & (int)(arr_time_in == A) &
-               (int)(A >= 0) & (int)(crtA >= 0) & (int)(last_time >= 0) & (int)(end_ns < (1ll << 51)) & (int)(A == kInfNs || A < (1ll << 51)) &   // (exact in binary64)
-               (int)(active_in == 0 || (D_in < (1ll << 51) && crtD_in >= 0));
-        key0 = (uint32_t)seed; key1 = (uint32_t)(seed >> 32);
-        const uint64_t sa = stream_id(base, kStreamArrival), ss = stream_id(base, kStreamService);
-        asid0 = (uint32_t)sa; asid1 = (uint32_t)(sa >> 32); ssid0 = (uint32_t)ss; ssid1 = (uint32_t)(ss >> 32);
-        div_rate.init(rate_in);
-        div_lambda.init(__ddiv_rn(1.0, mean_in));
-    }
-    if ((flags & (1 << 21)) && live && (lp % 97) == 5) elig = false;     // debug: force some LPs through the bail path
-    const int64_t crtA0 = crtA;
+    __syncthreads();
+    // the LP's wavefront: everything wave-uniform (SGPRs)
+    const int32_t in_bits = uni(s_in[w].bits);
+    const int64_t A = uni(s_in[w].A), crtA = uni(s_in[w].crtA), accepted = uni(s_in[w].accepted), sink_w = uni(s_in[w].sink_w);
+    const int64_t last_time = uni(s_in[w].last_time);
+    const uint64_t ak0 = uni(s_in[w].ak0), sk0 = uni(s_in[w].sk0);
+    const bool busy = (in_bits & 1) != 0, elig = (in_bits & 2) != 0;
+    const int64_t Dprev = uni(s_in[w].Dprev), Sprev = uni(s_in[w].Sprev);
+    double total_service = uni(s_in[w].total_service);
+    const double svc_s0 = uni(s_in[w].svc_s0);
+    uint32_t key0 = uni(s_in[w].key0), key1 = uni(s_in[w].key1);
+    const uint32_t asid0 = uni(s_in[w].asid0), asid1 = uni(s_in[w].asid1), ssid0 = uni(s_in[w].ssid0), ssid1 = uni(s_in[w].ssid1);
+    ConstDiv div_rate, div_lambda;
+    div_rate.b = uni(s_in[w].rate_b); div_rate.y = uni(s_in[w].rate_y); div_rate.fast = (in_bits & 4) != 0;
+    div_lambda.b = uni(s_in[w].lam_b); div_lambda.y = uni(s_in[w].lam_y); div_lambda.fast = (in_bits & 8) != 0;
+    const double carry_fresh = FRESH ? uni(s_in[w].carry_fresh) : 0.0;
     uint32_t n_dep = 0, n_tick = 0, n_notify = 0, n_poll = 0, n_start = 0;   // wave-uniform counts (ballots)
     int64_t lt = last_time;
     int overflow = 0;
@@ -435,123 +589,29 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HS
 #ifdef HS_WAVE_CYC
     const unsigned long long cyc_loop1 = __builtin_readcyclecounter();
 #endif
-    if (step > 0) service_sum((step - 1) & 1);           // T of the last step
-    if (w == 0 && lane < NW) s_ts[lane] = ts_mine;
-    __syncthreads();
-    total_service = s_ts[w];
-    lt = to_i64(lt_d);
-    const int ovf_w = __any(overflow) ? 1 : 0;
-
-    // ---- fold the window into the LP's state (Station::req_finish): wave-uniform values, lane 0 stores
-    int64_t pendD = Dprev, pendS = Sprev, pend_i = 0;
-    double pend_s = svc_s0, pendA_d = 0.0, pendAp_d = 0.0, pendSp_d = 0.0;
-    if (pend_new) {
-        pend = true;
-        pendD = to_i64(s_pend[w][0]); pendS = to_i64(s_pend[w][1]); pendA_d = s_pend[w][2]; pendAp_d = s_pend[w][3];
-        pend_i = to_i64(s_pend[w][4]); pend_s = s_pend[w][5]; pendSp_d = s_pend[w][6];
-    }
-    const double A_next = s_tick[w][0], a_last = s_tick[w][1], a_last2 = s_tick[w][2];
-    const int64_t n_arr_total = r0;
-    Candidate mine = cand_none(live ? lp : 0);
-    unsigned ev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool count = run && !bailed;
-    // what the LP's state becomes (FRESH: for an LP that did not run, or bailed, what the reset leaves)
-    uint32_t c_tick = 0, c_start = 0, c_dep = 0, seq = seq_in, seqA = seqA_in, seqD = seqD_in;
-    int64_t acc2 = accepted, st2 = started, A_next_i = A, crtA2 = crtA0, rcA = rcA_in, rcD = rcD_in;
-    int32_t dpA = dpA_in, dpD = dpD_in;
-    if (count) {
-        c_tick = n_tick; c_start = n_start; c_dep = n_dep;
-        const uint32_t c_notify = n_notify, c_poll = n_poll;
-        ev[0] = c_tick; ev[1] = c_tick; ev[2] = c_notify; ev[3] = c_poll + c_dep; ev[4] = c_start; ev[5] = c_start; ev[6] = c_dep; ev[7] = c_dep;
-        acc2 = accepted + c_tick; st2 = started + c_start;
-        A_next_i = A != kInfNs ? to_i64(A_next) : A;
-        crtA2 = c_tick ? to_i64(a_last) : crtA0;
-        if ((c_tick | c_start) != 0u) {                  // creation stamps: only their order matters (Station::req_finish)
-            const bool d_first = pend && pendS < crtA2;
-            seqA = seq + (d_first ? 1u : 0u); seqD = seq + (d_first ? 0u : 1u); seq += 2u;
-        }
-        // lineage of what is pending now (Station::req_finish)
-        if (c_tick) { dpA = 1; rcA = acc2 >= 2 ? (c_tick >= 2 ? to_i64(a_last2) : L.adm[(size_t)(acc2 - 2) * n + lp]) : crtA0; }
-        if (pend && pend_new) {
-            const int64_t m = st2 - 1;                   // the request in service: it started at pendS
-            if (pendS == to_i64(pendA_d)) {              // ... on arrival: six steps from its tick, which was created at the tick before
-                dpD = 6;
-                rcD = m >= 1 ? (pend_i >= 1 ? to_i64(pendAp_d) : (m - 1 < L.cap ? L.adm[(size_t)(m - 1) * n + lp] : 0)) : crtA0;
-            } else {                                     // ... when request m - 1 left: four steps from that continuation, created when IT started
-                dpD = 4; rcD = to_i64(pendSp_d);         // (= pendS - its service time: Station::req_finish draws that again)
-            }
-        }
-        // this LP's candidate for the one event beyond end_ns (make_candidate / pick_root: creation stamps decide a tie)
-        const int64_t Dn = pend ? pendD : kInfNs;
-        const int64_t tmin = A_next_i < Dn ? A_next_i : Dn;
-        if (tmin != kInfNs) {
-            const bool tick_first = A_next_i < Dn || (A_next_i == Dn && (int32_t)(seqA - seqD) < 0);
-            mine.t = tmin; mine.valid = 1;
-            if (tick_first) { mine.t_created = crtA2; mine.depth = dpA; mine.rcrt = rcA; mine.pad = 2; }
-            else { mine.t_created = pend ? pendS : 0; mine.depth = dpD; mine.rcrt = rcD; mine.pad = 0; }
-            mine.rank = cand_rank(P, lp, n, mine.pad);
-        }
-    }
-    if constexpr (FRESH) {
-        if (live && lane == 0) {                         // the WHOLE state, as hs_station_reset + the fold would have left it
-            const bool pd = count && pend;
-            uint32_t tot_ev = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { X.ev_kind[(size_t)k * n + lp] = ev[k]; tot_ev += ev[k]; }
-#pragma unroll
-            for (int k = 8; k < 11; ++k) X.ev_kind[(size_t)k * n + lp] = 0;
-            X.events[lp] = tot_ev;
-            X.generated[lp] = c_tick; X.accepted[lp] = acc2; X.dropped[lp] = 0; X.completed[lp] = c_dep; X.rejected[lp] = 0;
-            X.started[lp] = st2; X.received[lp] = c_dep; X.sink_w[lp] = c_dep;
-            X.buf[lp] = (int64_t)c_tick - (int64_t)c_start;
-            X.active[lp] = pd ? 1 : 0;
-            X.D[lp] = pd ? pendD : kInfNs; X.crtD[lp] = pd ? pendS : start_ns; X.svc_s[lp] = pd ? pend_s : 0.0; X.crt[lp] = 0;
-            X.total_service[lp] = count ? total_service : 0.0;
-            X.A[lp] = A_next_i; X.arr_time[lp] = A_next_i; X.arr_k[lp] = 1u + (uint64_t)(count ? n_arr_total : 0); X.svc_k[lp] = (uint64_t)c_start;
-            X.crtA[lp] = crtA2;
-            X.seqA[lp] = seqA; X.seqD[lp] = seqD; X.seq[lp] = seq;
-            X.q[lp] = 0; X.grp_time[lp] = start_ns;
-            X.last_time[lp] = count ? lt : start_ns;
-            X.dpA[lp] = (uint8_t)dpA; X.rcA[lp] = rcA; X.dpD[lp] = (uint8_t)dpD; X.rcD[lp] = rcD; X.wkD[lp] = 1;
-        }
-    } else if (count) {
-        // (the read-modify-write counters: every load before the first store -- the pointers may alias as far as the compiler knows, and
-        //  a load behind each store is a memory round trip each)
-        const int64_t o_gen = X.generated[lp], o_comp = X.completed[lp], o_recv = X.received[lp], o_events = X.events[lp];
-        int64_t o_ev[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) o_ev[k] = X.ev_kind[(size_t)k * n + lp];
+    if (step > 0) service_sum((step - 1) & 1);           // T of the last step (wavefront 0 holds its LPs' sums in its lanes)
+    // ---- fold the window into the LPs' state (Station::req_finish): wavefront 0 again, a lane per LP (wave_fold)
+    {
+        const int ovf_w = __any(overflow) ? 1 : 0;
         if (lane == 0) {
-            X.generated[lp] = o_gen + c_tick; X.accepted[lp] = acc2; X.started[lp] = st2; X.completed[lp] = o_comp + c_dep;
-            X.received[lp] = o_recv + c_dep; X.sink_w[lp] = sink_w + c_dep;
-            X.buf[lp] = (int64_t)c_tick - (int64_t)c_start;
-            X.active[lp] = pend ? 1 : 0;
-            X.D[lp] = pend ? pendD : kInfNs;
-            if (pend) { X.crtD[lp] = pendS; X.svc_s[lp] = pend_s; }
-            X.total_service[lp] = total_service;
-            X.A[lp] = A_next_i; X.arr_time[lp] = A_next_i; X.arr_k[lp] = ak0 + (uint64_t)n_arr_total; X.svc_k[lp] = sk0 + (uint64_t)c_start;
-            X.crtA[lp] = crtA2;
-            if ((c_tick | c_start) != 0u) { X.seqA[lp] = seqA; X.seqD[lp] = seqD; X.seq[lp] = seq; }
-            X.last_time[lp] = lt;
-            if (c_tick) { X.dpA[lp] = (uint8_t)dpA; X.rcA[lp] = rcA; }
-            if (pend && pend_new) { X.dpD[lp] = (uint8_t)dpD; X.rcD[lp] = rcD; }
-            uint32_t tot_ev = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { X.ev_kind[(size_t)k * n + lp] = o_ev[k] + ev[k]; tot_ev += ev[k]; }
-            X.events[lp] = o_events + tot_ev;
+            WaveOut O;
+            O.r0 = r0; O.lt = to_i64(lt_d);
+            O.n_tick = n_tick; O.n_start = n_start; O.n_dep = n_dep; O.n_notify = n_notify; O.n_poll = n_poll;
+            O.bits = (pend ? 1 : 0) | (pend_new ? 2 : 0) | (run && !bailed ? 4 : 0) | (bailed ? 8 : 0) | (ovf_w ? 16 : 0) | (live ? 32 : 0);
+            s_out[w] = O;
         }
     }
-    if (bailed && lane == 0) {
-        const unsigned pos = atomicAdd(&ctl->n_bail, 1u);
-        bail[pos] = lp;
-    }
-    // ---- the workgroup's partial totals and candidate
-    if (lane == 0) {
+    __syncthreads();
+    if (w == 0 && lane < NW) {
+        unsigned ev[8];
+        long long lt_l;
+        Candidate mine;
+        wave_fold<FRESH>(P, X, L, ctl, bail, n, lp0 + lane, start_ns, s_in[lane], s_pend[lane], s_tick[lane], s_out[lane], ts_mine, ev, lt_l, mine);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s_ev[w][k] = count ? ev[k] : 0u;
-        s_lt[w] = count ? (long long)lt : INT64_MIN;
-        s_ovf[w] = ovf_w;
-        wave_c[w] = mine;
+        for (int k = 0; k < 8; ++k) s_ev[lane][k] = ev[k];
+        s_lt[lane] = lt_l;
+        s_ovf[lane] = (s_out[lane].bits & 16) ? 1 : 0;
+        wave_c[lane] = mine;
     }
     __syncthreads();
     if (threadIdx.x < 8) {
