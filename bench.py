@@ -593,7 +593,7 @@ def grid_main(args, ctx, headline=True):
             # the binding resource is VALU issue (the serial per-LP recursion), not HBM: `achieved` / `frac` are the HBM
             # figures the contract asks for, `valu` is the measured issue fraction of the same kernel
             "bound": "valu",
-            "kernel": ("hs_station_run<1, false, true, true> (producer / consumer wavefronts, uniform entity kinds)" if n_mine > 32768
+            "kernel": ("hs_station_run<1, false, true, true> (producer / consumer wavefronts, uniform entity kinds)" if n_mine * 3 > 65536 * 2
                        else "hs_station_wave<NW> + hs_station_wide_finish (one wavefront per LP: fewer LPs than the device has lanes)"),
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

@@ -222,8 +222,10 @@ int wide_lanes(const hs_engine *h) {
     // Round 5: one wavefront per LP (hs_kernels_wave.hpp).  Measured (tools/wide_timing.py, profiles/r05_wide_timing.log; kernel ms incl.
     // hs_station_wide_finish): 1 024 LPs 0.056 (8 LPs per workgroup) / 0.068 (16) against K = 8: 0.087; 8 192: 0.106 against K = 4: 0.168;
     // 16 384: 0.17 against K = 4: 0.23; 32 768: 0.31 against one lane per LP: 0.40; 65 536: ~0.6 against 0.42 -- one lane per LP from there.
+    // Later in round 5 (T without selects, bootstrap and fold once per LP on wavefront 0): 8 192: 0.089; 32 768: 0.27; 40 960: 0.34 against
+    // 0.40; 45 056: 0.37 against 0.41; 49 152: 0.405 against 0.410 (the crossover); 65 536: 0.53 against 0.43.
     if (wave_ok && n * 16 <= lanes) return 65;  // <= 4 096 LPs: 8 LPs per workgroup (more workgroups than CUs)
-    if (wave_ok && n * 2 <= lanes) return 64;   // <= 32 768 LPs: 16 LPs per workgroup (a whole line of every record row)
+    if (wave_ok && n * 3 <= lanes * 2) return 64;   // <= 43 690 LPs: 16 LPs per workgroup (a whole line of every record row)
     if (n * 16 <= lanes) return 8;              // <= 4 096 LPs on 256 CUs
     if (n * 4 <= lanes) return 4;               // <= 16 384 LPs
     return 0;

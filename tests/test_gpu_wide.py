@@ -46,7 +46,7 @@ def _same(a, b, what):
         np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]), err_msg=f"{what}: {k}")
 
 
-@pytest.mark.parametrize("n,end_s", [(1, 5.0), (7, 3.0), (64, 10.0), (300, 2.5), (4096, 6.0), (8192, 60.0), (32768, 12.0)])
+@pytest.mark.parametrize("n,end_s", [(1, 5.0), (7, 3.0), (64, 10.0), (300, 2.5), (4096, 6.0), (8192, 60.0), (32768, 12.0), (43000, 5.0)])
 def test_wide_kernel_equals_the_one_lane_kernel(n, end_s):
     end = int(end_s * 1e9)
     ref = _run(n, end, ONE_LANE)
