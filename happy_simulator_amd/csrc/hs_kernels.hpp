@@ -1493,8 +1493,10 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             const unsigned long long qs = __builtin_readcyclecounter();
 #endif
             const int64_t w_peek = done ? 0 : S.async_peek();         // the incoming link's word: its latency hides behind the refills
-            S.window_fill(!done);                                     // created_at of what entered the window from a deep queue
+            int64_t wf0, wf1;                                         // created_at of what entered the window from a deep queue:
+            const int wf_n = S.window_issue(!done, wf0, wf1);         // loaded before, stored behind the refill
             S.top_up(!done, topup_need);                              // whole wavefront: refill the pre-drawn values
+            S.window_commit(!done, wf_n, wf0, wf1);
             int64_t H = kInfNs;
 #ifdef HS_CYCLES
             const unsigned long long q0 = __builtin_readcyclecounter();

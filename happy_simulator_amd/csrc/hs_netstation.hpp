@@ -610,6 +610,29 @@ struct NetStation {
             if (act && hi > win_hi) win_hi = hi;
         }
     }
+    // window_fill in two halves around the wave-level refill of the stream rings (hs_net_async): the first two entries a lane needs are
+    // LOADED here and stored there, so that their memory round trip runs behind the refill's arithmetic instead of in front of it
+    // (the LP's own admission log: nothing between the two halves touches it, `accepted`, `started` or `win_hi`); a lane that needs
+    // more than two (rare) takes the rest in window_fill as before.
+    __device__ __forceinline__ int window_issue(bool act, int64_t &v0, int64_t &v1) const {
+        int cnt = 0;
+        v0 = 0; v1 = 0;
+        if constexpr (FAST) {
+            const int64_t lim = started + kNRing;
+            const int64_t hi = accepted < lim ? accepted : lim;
+            if (act && win_hi < hi) { v0 = (win_hi < cap) ? adm[win_hi * ls] : 0; cnt = 1; }
+            if (act && win_hi + 1 < hi) { v1 = (win_hi + 1 < cap) ? adm[(win_hi + 1) * ls] : 0; cnt = 2; }
+        }
+        return cnt;
+    }
+    __device__ __forceinline__ void window_commit(bool act, int cnt, int64_t v0, int64_t v1) {
+        if constexpr (FAST) {
+            if (cnt >= 1) fl.crc[win_hi & (kNRing - 1)][tid] = v0;
+            if (cnt >= 2) fl.crc[(win_hi + 1) & (kNRing - 1)][tid] = v1;
+            win_hi += cnt;
+            window_fill(act);
+        }
+    }
     // created_at of request k, which starts now
     __device__ __forceinline__ int64_t window_take(int64_t k) {
         int64_t created;
