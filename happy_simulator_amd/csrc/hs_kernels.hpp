@@ -1493,20 +1493,29 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             const unsigned long long qs = __builtin_readcyclecounter();
 #endif
             const int64_t w_peek = done ? 0 : S.async_peek();         // the incoming link's word: its latency hides behind the refills
+            // Three memory round trips of an iteration run behind the wave-level refill of the pre-drawn stream values instead of in
+            // front of it: the word of the incoming link (above) and the created_at window's entries behind its first half, the first
+            // two waiting messages' payloads behind its second half (round 5: 7.39 -> 6.x ms on the 65 536-station ring).
             int64_t wf0, wf1;                                         // created_at of what entered the window from a deep queue:
             const int wf_n = S.window_issue(!done, wf0, wf1);         // loaded before, stored behind the refill
-            S.top_up(!done, topup_need);                              // whole wavefront: refill the pre-drawn values
-            S.window_commit(!done, wf_n, wf0, wf1);
-            int64_t H = kInfNs;
-#ifdef HS_CYCLES
-            const unsigned long long q0 = __builtin_readcyclecounter();
-#endif
             {   // (a chain lane's only incoming link is the previous lane's next_l: async_receive_one)
                 const long long q_next = next_l >= 0 ? (long long)S.link_sent_of(next_l) : 0ll;
                 const long long q_prev = shfl_up_ll(q_next, 1);
                 S.tail_hint = chain ? (unsigned long long)q_prev : 0ull;
             }
-            if (!done) H = S.async_receive(w_peek);                         // messages below H are all in the bag now
+            S.top_up(!done, topup_need, 1);                           // whole wavefront: refill the pre-drawn values (arrivals, services)
+            const bool split_rx = !done && S.fi_link >= 0;            // one incoming link, held in registers (FAST)
+            int64_t rx[8];
+            unsigned long long rx_tail = 0ull;
+            const int rx_n = split_rx ? S.async_receive_issue(w_peek, rx, rx_tail) : 0;
+            S.top_up(!done, topup_need, 2);                           // ... jitter, routing decisions
+            S.window_commit(!done, wf_n, wf0, wf1);
+            int64_t H = kInfNs;
+#ifdef HS_CYCLES
+            const unsigned long long q0 = __builtin_readcyclecounter();
+#endif
+            if (split_rx) H = S.async_receive_commit(w_peek, rx_n, rx, rx_tail);
+            else if (!done) H = S.async_receive(w_peek);                    // messages below H are all in the bag now
 #ifdef HS_CYCLES
             const unsigned long long q1 = __builtin_readcyclecounter();
 #endif

@@ -483,14 +483,20 @@ struct NetStation {
     // Wave-level top-up at a converged point: when some lane has run dry, every lane with room draws 4 more values
     // (2 Philox blocks) -- 64 lanes at the price the divergent loop would pay for one
     // (`need` = what one iteration may consume per stream: the groups-per-iteration cap)
-    __device__ __forceinline__ void top_up(bool act, int need) {
+    // (`parts`: 1 = the arrival and service streams, 2 = the jitter stream and the router's decisions -- hs_net_async runs the two
+    //  halves around the point at which the incoming link's word has arrived, each hiding one memory round trip)
+    __device__ __forceinline__ void top_up(bool act, int need, int parts = 3) {
         if constexpr (FAST) {
             const bool wa = HSU(src_kind == 1, true) && A != kInfNs && !(PF && prof_kind != kProfConstant), ws = HSU(svc_kind == 0, true), wj = fl_link >= 0 && HSU(fl_jit == 0, true);
             const bool wr = HSU(egress == EG_ROUTER, true);
-            if (__any(act && wa && na < need)) { if (act && wa && na <= kNRing - 4) refill_a(4); }
-            if (__any(act && ws && nsv < need)) { if (act && ws && nsv <= kNRing - 4) refill_s(4); }
-            if (__any(act && wj && nj < need)) { if (act && wj && nj <= kNRing - 4) refill_j(4); }
-            if (__any(act && wr && rn < need)) { if (act && wr && rn <= 8) refill_r(8); }
+            if (parts & 1) {
+                if (__any(act && wa && na < need)) { if (act && wa && na <= kNRing - 4) refill_a(4); }
+                if (__any(act && ws && nsv < need)) { if (act && ws && nsv <= kNRing - 4) refill_s(4); }
+            }
+            if (parts & 2) {
+                if (__any(act && wj && nj < need)) { if (act && wj && nj <= kNRing - 4) refill_j(4); }
+                if (__any(act && wr && rn < need)) { if (act && wr && rn <= 8) refill_r(8); }
+            }
         }
     }
 
@@ -879,6 +885,51 @@ struct NetStation {
         // payloads are complete -- the sender drained them before the iteration ended)
         if (tail_hint > tail) tail = tail_hint;
         if (head != tail) {
+            const int bcap = bag_capacity();
+            for (; head < tail && bag_n < bcap; ++head) {
+                const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
+                const int64_t ta = ag_load(&ns->aq_rec[4 * slot]);
+                bag_insert(ta, ag_load(&ns->aq_rec[4 * slot + 1]), ag_load(&ns->aq_rec[4 * slot + 2]), l, ag_load(&ns->aq_rec[4 * slot + 3]));
+            }
+            fi_head = head;
+            ag_store(&ns->aq_head[l], head);
+            if (head < tail) {
+                const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
+                undrained = ag_load(&ns->aq_rec[4 * slot + 1]) + np->link_lat_ns[l];
+            }
+        }
+        return ea;
+    }
+    // async_receive_one in two halves (one incoming link, its word `w` has arrived): the first two messages of [head, tail) that fit
+    // into the bag are LOADED here and inserted there; the second half of the stream refill runs between the two.
+    __device__ __forceinline__ int async_receive_issue(int64_t w, int64_t (&r)[8], unsigned long long &tail_out) const {
+        const int l = fi_link;
+        const unsigned long long head = fi_head;
+        unsigned long long tail = pk_tail(w, head);
+        if (tail_hint > tail) tail = tail_hint;
+        tail_out = tail;
+        const int room = bag_capacity() - bag_n;
+        int cnt = 0;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            r[4 * m] = r[4 * m + 1] = r[4 * m + 2] = r[4 * m + 3] = 0;
+            if (head + (unsigned long long)m < tail && m < room) {
+                const size_t slot = (size_t)l * ns->aq_cap + (size_t)((head + (unsigned long long)m) & (unsigned long long)(ns->aq_cap - 1));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r[4 * m + q] = ag_load(&ns->aq_rec[4 * slot + q]);
+                cnt = m + 1;
+            }
+        }
+        return cnt;
+    }
+    __device__ __forceinline__ int64_t async_receive_commit(int64_t w, int cnt, const int64_t (&r)[8], unsigned long long tail) {
+        const int l = fi_link;
+        const int64_t ea = pk_ea(w, ns->pk_base);
+        undrained = kInfNs;
+        unsigned long long head = fi_head;
+        if (head != tail) {
+            if (cnt >= 1) { bag_insert(r[0], r[1], r[2], l, r[3]); ++head; }
+            if (cnt >= 2) { bag_insert(r[4], r[5], r[6], l, r[7]); ++head; }
             const int bcap = bag_capacity();
             for (; head < tail && bag_n < bcap; ++head) {
                 const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
