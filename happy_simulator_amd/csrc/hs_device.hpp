@@ -176,6 +176,21 @@ struct Stream {
         ++k;
         return u;
     }
+    // Four consecutive draws at once: whatever the parity of k they need exactly the two blocks (k + 1) / 2 and (k + 1) / 2 + 1, so
+    // both are computed in straight-line code (two independent chains the scheduler interleaves) and the parity only selects which
+    // halves are which -- the same values and the same cached half as four calls of next_uniform().
+    __device__ __forceinline__ void next4(double (&u)[4]) {
+        const bool odd = (k & 1ull) != 0;
+        const uint64_t b = (k + 1) >> 1;
+        const U4 f = philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), sid0, sid1, key0, key1);
+        const U4 s = philox4x32_10((uint32_t)(b + 1), (uint32_t)((b + 1) >> 32), sid0, sid1, key0, key1);
+        u[0] = res53(odd ? c2 : f.x, odd ? c3 : f.y);
+        u[1] = res53(odd ? f.x : f.z, odd ? f.y : f.w);
+        u[2] = res53(odd ? f.z : s.x, odd ? f.w : s.y);
+        u[3] = res53(odd ? s.x : s.z, odd ? s.y : s.w);
+        c2 = s.z; c3 = s.w;
+        k += 4;
+    }
 };
 
 __host__ __device__ __forceinline__ uint64_t stream_id(uint64_t base, uint32_t kind) { return (base << 3) | kind; }

@@ -444,6 +444,35 @@ struct NetStation {
             fl.ring_j[(hj + nj) & (kNRing - 1)][tid] = sec_rt(sample); ++nj;
         }
     }
+    // the wave-level refills of top_up: four values in straight-line code (Stream::next4) -- on one wavefront per SIMD the four
+    // logarithms and quotients overlap instead of waiting for one another
+    __device__ __forceinline__ void refill_a4() {
+        double u[4];
+        arr.next4(u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = __ddiv_rn(exp1_from_uniform(u[i]), rate);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fl.ring_a[(ha + na + i) & (kNRing - 1)][tid] = u[i];
+        na += 4;
+    }
+    __device__ __forceinline__ void refill_s4() {
+        double u[4];
+        svc.next4(u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = svc_value(exp1_from_uniform(u[i]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fl.ring_s[(hs_ + nsv + i) & (kNRing - 1)][tid] = u[i];
+        nsv += 4;
+    }
+    __device__ __forceinline__ void refill_j4() {
+        double u[4];
+        jit.next4(u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = sec_rt(__ddiv_rn(exp1_from_uniform(u[i]), fl_lam));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fl.ring_j[(hj + nj + i) & (kNRing - 1)][tid] = u[i];
+        nj += 4;
+    }
     // RandomRouter (components/random_router.py:32-45, Philox-plugged): targets[int(u * len(targets))].  Pre-drawn decisions are
     // kept two bits each in `rbits` (16 of them), oldest in the low bits.
     __device__ __forceinline__ int32_t rt_target(int idx) const { return idx == 0 ? rt0 : idx == 1 ? rt1 : idx == 2 ? rt2 : rt3; }
@@ -490,11 +519,11 @@ struct NetStation {
             const bool wa = HSU(src_kind == 1, true) && A != kInfNs && !(PF && prof_kind != kProfConstant), ws = HSU(svc_kind == 0, true), wj = fl_link >= 0 && HSU(fl_jit == 0, true);
             const bool wr = HSU(egress == EG_ROUTER, true);
             if (parts & 1) {
-                if (__any(act && wa && na < need)) { if (act && wa && na <= kNRing - 4) refill_a(4); }
-                if (__any(act && ws && nsv < need)) { if (act && ws && nsv <= kNRing - 4) refill_s(4); }
+                if (__any(act && wa && na < need)) { if (act && wa && na <= kNRing - 4) refill_a4(); }
+                if (__any(act && ws && nsv < need)) { if (act && ws && nsv <= kNRing - 4) refill_s4(); }
             }
             if (parts & 2) {
-                if (__any(act && wj && nj < need)) { if (act && wj && nj <= kNRing - 4) refill_j(4); }
+                if (__any(act && wj && nj < need)) { if (act && wj && nj <= kNRing - 4) refill_j4(); }
                 if (__any(act && wr && rn < need)) { if (act && wr && rn <= 8) refill_r(8); }
             }
         }
