@@ -191,6 +191,16 @@ struct Stream {
         c2 = s.z; c3 = s.w;
         k += 4;
     }
+    // ... and two: exactly the block (k + 1) / 2 whatever the parity
+    __device__ __forceinline__ void next2(double (&u)[2]) {
+        const bool odd = (k & 1ull) != 0;
+        const uint64_t b = (k + 1) >> 1;
+        const U4 o = philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), sid0, sid1, key0, key1);
+        u[0] = res53(odd ? c2 : o.x, odd ? c3 : o.y);
+        u[1] = res53(odd ? o.x : o.z, odd ? o.y : o.w);
+        c2 = o.z; c3 = o.w;
+        k += 2;
+    }
 };
 
 __host__ __device__ __forceinline__ uint64_t stream_id(uint64_t base, uint32_t kind) { return (base << 3) | kind; }

@@ -455,6 +455,33 @@ struct NetStation {
         for (int i = 0; i < 4; ++i) fl.ring_a[(ha + na + i) & (kNRing - 1)][tid] = u[i];
         na += 4;
     }
+    __device__ __forceinline__ void refill_a2() {
+        double u[2];
+        arr.next2(u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) u[i] = __ddiv_rn(exp1_from_uniform(u[i]), rate);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fl.ring_a[(ha + na + i) & (kNRing - 1)][tid] = u[i];
+        na += 2;
+    }
+    __device__ __forceinline__ void refill_s2() {
+        double u[2];
+        svc.next2(u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) u[i] = svc_value(exp1_from_uniform(u[i]));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fl.ring_s[(hs_ + nsv + i) & (kNRing - 1)][tid] = u[i];
+        nsv += 2;
+    }
+    __device__ __forceinline__ void refill_j2() {
+        double u[2];
+        jit.next2(u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) u[i] = sec_rt(__ddiv_rn(exp1_from_uniform(u[i]), fl_lam));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fl.ring_j[(hj + nj + i) & (kNRing - 1)][tid] = u[i];
+        nj += 2;
+    }
     __device__ __forceinline__ void refill_s4() {
         double u[4];
         svc.next4(u);
@@ -518,12 +545,36 @@ struct NetStation {
         if constexpr (FAST) {
             const bool wa = HSU(src_kind == 1, true) && A != kInfNs && !(PF && prof_kind != kProfConstant), ws = HSU(svc_kind == 0, true), wj = fl_link >= 0 && HSU(fl_jit == 0, true);
             const bool wr = HSU(egress == EG_ROUTER, true);
+            // A top-up costs the wavefront what its NEEDIEST lane draws, and one is due in almost every iteration (some lane of 64 is
+            // always below the mark): so it is one Philox block = two values for every lane with room, and a second block only when a
+            // lane is down to fewer than two values (HS_TOPUP4: four values at a time, as until round 5).
+#ifdef HS_TOPUP4
             if (parts & 1) {
                 if (__any(act && wa && na < need)) { if (act && wa && na <= kNRing - 4) refill_a4(); }
                 if (__any(act && ws && nsv < need)) { if (act && ws && nsv <= kNRing - 4) refill_s4(); }
             }
             if (parts & 2) {
                 if (__any(act && wj && nj < need)) { if (act && wj && nj <= kNRing - 4) refill_j4(); }
+#else
+            if (parts & 1) {
+                if (__any(act && wa && na < need)) {
+                    const bool low = act && wa && na < 2;
+                    if (act && wa && na <= kNRing - 2) refill_a2();
+                    if (__any(low)) { if (low) refill_a2(); }
+                }
+                if (__any(act && ws && nsv < need)) {
+                    const bool low = act && ws && nsv < 2;
+                    if (act && ws && nsv <= kNRing - 2) refill_s2();
+                    if (__any(low)) { if (low) refill_s2(); }
+                }
+            }
+            if (parts & 2) {
+                if (__any(act && wj && nj < need)) {
+                    const bool low = act && wj && nj < 2;
+                    if (act && wj && nj <= kNRing - 2) refill_j2();
+                    if (__any(low)) { if (low) refill_j2(); }
+                }
+#endif
                 if (__any(act && wr && rn < need)) { if (act && wr && rn <= 8) refill_r(8); }
             }
         }
