@@ -1495,7 +1495,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             const int64_t w_peek = done ? 0 : S.async_peek();         // the incoming link's word: its latency hides behind the refills
             // Three memory round trips of an iteration run behind the wave-level refill of the pre-drawn stream values instead of in
             // front of it: the word of the incoming link (above) and the created_at window's entries behind its first half, the first
-            // two waiting messages' payloads behind its second half (round 5: 7.39 -> 6.x ms on the 65 536-station ring).
+            // two waiting messages' payloads behind its second half (round 5, with the two-value top-ups of hs_netstation.hpp: 7.39 -> 6.25 ms on the 65 536-station ring).
             int64_t wf0, wf1;                                         // created_at of what entered the window from a deep queue:
             const int wf_n = S.window_issue(!done, wf0, wf1);         // loaded before, stored behind the refill
             {   // (a chain lane's only incoming link is the previous lane's next_l: async_receive_one)
