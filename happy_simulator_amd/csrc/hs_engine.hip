@@ -254,17 +254,18 @@ void launch_wave(hs_engine *h, int64_t end_ns) {
 }
 
 int ensure_reset(hs_engine *h);
-void launch_run_dispatch(hs_engine *h, int64_t end_ns) {
-    if (h->exact_only) return;     // (the single-heap loop has run the whole window: launch_prologue)
+int launch_run_dispatch(hs_engine *h, int64_t end_ns) {
+    if (h->exact_only) return HS_OK;     // (the single-heap loop has run the whole window: launch_prologue)
     const int K = wide_lanes(h);
-    if (K != 64 && K != 65) (void)ensure_reset(h);            // (only hs_station_wave performs a deferred bootstrap itself)
+    // (only hs_station_wave performs a deferred bootstrap itself; ADVICE r5: a reset launch that fails is the run's failure)
+    if (K != 64 && K != 65) { const int rcr = ensure_reset(h); if (rcr) return rcr; }
     h->fresh = false;
     switch (K) {
-        case 4: launch_wide<4>(h, end_ns); return;
-        case 8: launch_wide<8>(h, end_ns); return;
-        case 16: launch_wide<16>(h, end_ns); return;
-        case 64: launch_wave<16>(h, end_ns); return;
-        case 65: launch_wave<8>(h, end_ns); return;
+        case 4: launch_wide<4>(h, end_ns); return HS_OK;
+        case 8: launch_wide<8>(h, end_ns); return HS_OK;
+        case 16: launch_wide<16>(h, end_ns); return HS_OK;
+        case 64: launch_wave<16>(h, end_ns); return HS_OK;
+        case 65: launch_wave<8>(h, end_ns); return HS_OK;
         default: break;
     }
     // Tandem queues: one launch per pass, upstream Servers first; the last one elects the event beyond end_ns among ALL LPs
@@ -282,6 +283,7 @@ void launch_run_dispatch(hs_engine *h, int64_t end_ns) {
             default: launch_run<32>(h, end_ns, mode, flags); break;     // (departure slots beyond 16 live in scratch: correct, not fast)
         }
     }
+    return HS_OK;
 }
 
 template <int C>
@@ -299,7 +301,7 @@ void launch_net_dispatch(hs_engine *h, int64_t wend, int win, int flags) {
 
 template <int C>
 hipError_t launch_async(hs_engine *h, int64_t end_ns, NetState NX) {
-    int n = h->cfg.n_lp, flags = h->flags & (1 | 64 | 128 | 1024 | 0xff00), lanes = h->async_lanes;
+    int n = h->cfg.n_lp, flags = h->flags & (1 | 64 | 128 | 1024 | 0xff00 | (1 << 21)), lanes = h->async_lanes;
     const int per_block = (kBlock / 64) * lanes;
     int max_iters = h->round_iters;
     void *args[] = {&h->P, &h->NP, &h->X, &NX, &h->L, &h->tot, &n, &end_ns, &flags, &h->SC, &lanes, &max_iters};
@@ -314,7 +316,7 @@ hipError_t launch_async(hs_engine *h, int64_t end_ns, NetState NX) {
 // the generic asynchronous kernel (the segment's first station travels in bits 8.. of `lanes`)
 template <int C>
 hipError_t launch_async_segment(hs_engine *h, int64_t end_ns, NetState NX, int lp0, int blocks, int iters) {
-    int n = h->cfg.n_lp, flags = h->flags & (1 | 64 | 128 | 1024 | 0xff00), lanes = 64 | ((lp0 / kBlock) << 8), max_iters = iters;
+    int n = h->cfg.n_lp, flags = h->flags & (1 | 64 | 128 | 1024 | 0xff00 | (1 << 21)), lanes = 64 | ((lp0 / kBlock) << 8), max_iters = iters;
     void *args[] = {&h->P, &h->NP, &h->X, &NX, &h->L, &h->tot, &n, &end_ns, &flags, &h->SC, &lanes, &max_iters};
     const void *fn = h->net_pf ? (const void *)hs_net_async<C, true> : (const void *)hs_net_async<C, false>;
     return hipLaunchCooperativeKernel(fn, dim3((unsigned)blocks), dim3(kBlock), args, 0, h->stream);
@@ -413,6 +415,7 @@ int try_run_net_whole(hs_engine *h, int64_t end_ns) {
 
 // EXECUTE / EXCHANGE / ADVANCE (parallel/coordinator.py:87-124) as a stream of window launches
 int run_net_async(hs_engine *h, int64_t end_ns) {
+    { const int rcr = ensure_reset(h); if (rcr) return rcr; }     // (never a network run on a deferred bootstrap)
     {
         const int whole = try_run_net_whole(h, end_ns);
         if (whole != 0) return whole < 0 ? whole : HS_OK;
@@ -1154,6 +1157,7 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     if (h->cfg.mode != HS_MODE_SINGLE) return fail(h, HS_E_INVALID, "a network of stations is one Simulation: HS_MODE_SINGLE");
     if (h->C > 4) return fail(h, HS_E_UNSUPPORTED, "networked stations support concurrency <= 4 for now");
     HS_HIP(h, hipSetDevice(h->cfg.device));
+    { const int rcr = ensure_reset(h); if (rcr) return rcr; }     // (a bootstrap deferred for a station engine this no longer is)
     const int n = h->cfg.n_lp, nl = net->n_links;
     if (nl < 0) return fail(h, HS_E_INVALID, "n_links < 0");
     // A shard of a larger network: link endpoints are network-wide station indices, this engine owns
@@ -1434,6 +1438,8 @@ int hs_engine_shard_begin(hs_engine *h, int64_t end_ns) {
     if (end_ns > h->cfg.horizon_ns) return fail(h, HS_E_INVALID, "end_ns beyond the configured horizon");
     HS_HIP(h, hipSetDevice(h->cfg.device));
     int rc = do_reset_async(h);
+    if (rc) return rc;
+    rc = ensure_reset(h);
     if (rc) return rc;
     h->SC.end_ns = end_ns;
     const int64_t init_slots[2] = {h->cfg.start_ns - 1, h->cfg.start_ns - 1};
@@ -1764,7 +1770,8 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
         if (h->n_pass > 0 || lazy_active(h) || (h->any_xsrc && h->exact)) h->window_ends.push_back(end_ns);
         int rc = launch_prologue(h, end_ns);
         if (rc) return rc;
-        launch_run_dispatch(h, end_ns);
+        rc = launch_run_dispatch(h, end_ns);
+        if (rc) return rc;
         HS_HIP(h, hipGetLastError());
         h->launches++;
     }
@@ -1830,9 +1837,11 @@ int prologue_fallback(hs_engine *h) {
         rc = launch_prologue(h, e);
         if (rc) return rc;
         if (h->is_net) { rc = run_net_async(h, e); if (rc) return rc; }
-        else { launch_run_dispatch(h, e); h->launches++; }
+        else { rc = launch_run_dispatch(h, e); if (rc) return rc; h->launches++; }
         HS_HIP(h, hipGetLastError());
     }
+    // the reset above forgot the network's last window end; an earlier or equal end after this moves nothing
+    if (h->is_net) h->net_last_end = ends.back();
     HS_HIP(h, hipEventRecord(h->ev_k1, h->stream));
     HS_HIP(h, hipEventRecord(h->ev_b, h->stream));
     HS_HIP(h, hipStreamSynchronize(h->stream));
@@ -1920,7 +1929,7 @@ int hs_engine_bench_runs(hs_engine *h, int64_t end_ns, int32_t repeats, float *k
             HS_HIP(h, hipEventRecord(ev[(size_t)2 * r], h->stream));
             { int rc1 = launch_prologue(h, end_ns); if (rc1) return rc1; }
             if (h->is_net) { h->launches = 0; int rc2 = run_net_async(h, end_ns); if (rc2) return rc2; }
-            else launch_run_dispatch(h, end_ns);
+            else { const int rc2 = launch_run_dispatch(h, end_ns); if (rc2) return rc2; }
             HS_HIP(h, hipGetLastError());
             HS_HIP(h, hipEventRecord(ev[(size_t)2 * r + 1], h->stream));
         }

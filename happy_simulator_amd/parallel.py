@@ -296,14 +296,20 @@ def reference_window_count(start: Instant, end: Instant, window_s: float) -> int
     `Instant.from_seconds(current.to_seconds() + W)` clamped to the end, until the clock reaches the end -- binary64 accumulation
     included (12 s of 0.05 s windows are 241, not 240).  The engine's own exchange cadence follows the lookahead of the boundary
     stations instead (a few dozen rounds, `engine_exchanges`); the reference's early exit when every heap is empty does not arise
-    while a Source ticks."""
+    while a Source ticks.  Beyond 5 million windows the count is the quotient without the walk's drift (approximate, reported only)."""
     # (the same arithmetic on plain ints / floats: Instant.to_seconds() is ns / 1e9, Instant.from_seconds(x) is int(x * 1e9) --
     #  ADVICE r4: one Instant per window made a 60 s run with 1 us windows spend tens of seconds here, for a number that is only reported)
     cur, end_ns, end_s = start.nanoseconds, end.nanoseconds, end.to_seconds()
     if (end_ns - cur) / 1e9 / window_s > 5_000_000:
         # beyond a few million windows the walk itself would dominate the run: the count without the binary64 drift of the walk
         # (the reference's own loop would take minutes of pure Python per partition there)
+        # (approximate there: the reference's walk accumulates binary64 drift window by window).  ADVICE r5: a window too small to move
+        # the nanosecond clock still raises as the walk would -- one step at the start and one just before the end.
         import math
+        for c in (cur, end_ns - 1):
+            w = c / 1e9 + window_s
+            if not (c < int((w if w < end_s else end_s) * 1e9)):
+                raise ValueError(f"window_size {window_s}s does not advance the clock at {c / 1e9}s")
         return math.ceil((end_ns - cur) / 1e9 / window_s)
     n = 0
     while cur < end_ns:

@@ -156,10 +156,28 @@ class DistComm:
     def connect_peers(self, shards):
         """Device-side exchange: all-gather the IPC handles of every rank's exchange buffers, map the peers' (once)."""
         (s,) = shards
-        mine = s.ipc_export()
+        # ADVICE r5: every step that can fail on ONE rank (export: uncached allocation / IPC unsupported; attach: ranks on different
+        # nodes, peer access disabled) is followed by an agreement of all ranks, so that either every rank uses the device-side
+        # exchange or every rank falls back to the collective path -- never one rank raising while its peers wait in a collective.
+        try:
+            mine, err = s.ipc_export(), None
+        except Exception as e:                     # noqa: BLE001 -- whatever it is, the peers must hear about it
+            mine, err = None, f"rank {self.rank}: export: {e}"
         every = [None] * self.world
-        self._dist.all_gather_object(every, mine, group=self._group)
-        s.ipc_attach(b"".join(every))
+        self._dist.all_gather_object(every, (mine, err), group=self._group)
+        errs = [e for _, e in every if e]
+        if not errs:
+            try:
+                s.ipc_attach(b"".join(h for h, _ in every))
+            except Exception as e:                 # noqa: BLE001
+                err = f"rank {self.rank}: attach: {e}"
+            oks = [None] * self.world
+            self._dist.all_gather_object(oks, err, group=self._group)
+            errs = [e for e in oks if e]
+        if errs:
+            self.peer_errors = errs
+            return False
+        return True
 
     def flag_barrier(self, flags):
         """The one collective of a round on the device-side exchange path: all-reduce(MAX) of the "still working" word.  It is also the
@@ -535,8 +553,8 @@ class ShardedNetwork:
         if exchange not in ("device", "collective"):
             raise ValueError("exchange must be 'device' or 'collective'")
         device_exchange = rounds and exchange == "device" and hasattr(comm, "connect_peers")
-        if device_exchange:
-            comm.connect_peers(shards)
+        if device_exchange and comm.connect_peers(shards) is False:
+            device_exchange = False          # (agreed by all ranks: the collective exchange path, comm.peer_errors says why)
         if sync_every is None:           # exchanges between host synchronisations: a run is ~25 rounds or ~60 000 windows
             sync_every = 4 if rounds else 64
         return cls(shards, comm, window_ns=window_ns, sync_every=sync_every, rounds=rounds, ranks=ElectionRanks(stations),
@@ -638,7 +656,9 @@ class ShardedNetwork:
             # and one of the two is a departure / a message / an injected Request (word 7 < 2), which ranks with its station's
             # first-listed Source instead of the Source its lineage goes back to.  Every rank sees the same rows: all raise together.
             same = [c for c in valid[order[1:]] if (c[1], c[2], c[4], c[5]) == (win[1], win[2], win[4], win[5])]
-            if (int(win[0]) & 2) or any(int(c[7]) < 2 or int(win[7]) < 2 for c in same):
+            # (a LOSING shard's best candidate that tied in-shard with a stand-in -- its bit 1 -- and shares the winner's key
+            #  means that stand-in ties the winner too)
+            if (int(win[0]) & 2) or any(int(c[7]) < 2 or int(win[7]) < 2 or (int(c[0]) & 2) for c in same):
                 raise N.EngineError(N.HS_E_UNSUPPORTED,
                                     "the one event beyond end_time is a lock-step tie between two stations that only the reference's "
                                     "sort-index ledger decides (one of them a departure, a message or an injected Request): refused "

@@ -315,6 +315,37 @@ def test_a_ring_station_whose_probe_meets_a_pre_run_tick_repeats_the_run_behind_
     np.testing.assert_array_equal(got[0].events_by_kind, r.events_by_kind)
 
 
+@pytest.mark.parametrize("engine_flags", [0, 16], ids=["async", "windowed"])
+def test_an_earlier_window_end_after_a_repeated_network_run_moves_nothing(engine_flags):
+    """a network whose lazy prologue met a hazard is repeated behind the prologue (path 2); that repeat reset the
+    engine and used to forget the last window end, so a REPEATED or EARLIER `run_until` ran again to the earlier end and the state
+    regressed.  The reference's loop condition is already false there (core/simulation.py:527-541): nothing moves."""
+    import helpers as H
+
+    spec = _probed_ring(40, 4.5, lockstep=True, schedule=False)
+    one, p = H.ring_engine_for_spec(spec, flags=engine_flags)
+    end, mid = p["end_ns"], (2 * p["end_ns"]) // 3
+    with one:
+        one.run_until(mid)
+        want_mid = _ring_everything(one, spec)
+    one, _ = H.ring_engine_for_spec(spec, flags=engine_flags)
+    with one:
+        one.run_until(end)
+        want_end = _ring_everything(one, spec)
+    eng, _ = H.ring_engine_for_spec(spec, flags=engine_flags)
+    with eng:
+        eng.run_until(mid)
+        assert eng.prologue_path() == 2
+        _assert_same_ring(_ring_everything(eng, spec), want_mid)
+        for e in (mid, mid // 2, mid - 1):             # repeated, earlier, just before: nothing moves
+            eng.run_until(e)
+            _assert_same_ring(_ring_everything(eng, spec), want_mid)
+        eng.run_until(end)                             # a later end continues to what one run gives
+        _assert_same_ring(_ring_everything(eng, spec), want_end)
+        eng.run_until(mid)
+        _assert_same_ring(_ring_everything(eng, spec), want_end)
+
+
 def test_a_probe_on_every_station_of_a_large_ring_no_longer_costs_the_single_lane_prologue():
     """VERDICT r3 'one-lane cliffs': 16 384 stations with a Probe each = 32 768 pre-run events, ~17 us each on the prologue's single
     lane (0.5 s) before a run of a few milliseconds.  The skipped path must be at least 20x faster than the forced prologue, and equal."""
