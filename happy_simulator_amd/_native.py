@@ -37,7 +37,7 @@ EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuat
 PROBE_METRICS = {"depth": 0, "active_requests": 1, "stats_accepted": 2, "stats_dropped": 3, "requests_completed": 4,
                  "_requests_completed": 4, "events_received": 5, "generated_count": 6}
 PROBE_NONE = 255
-ABI_VERSION = 13
+ABI_VERSION = 14
 IPC_HANDLE_BYTES = 64
 
 
@@ -94,6 +94,7 @@ class Network(C.Structure):
         ("bag_capacity", C.c_int32), ("n_global_lp", C.c_int32), ("link_gid", C.c_void_p),
         ("n_global_links", C.c_int64), ("link_loss_rate", C.c_void_p),
         ("router_n_targets", C.c_void_p), ("router_target2", C.c_void_p), ("router_target3", C.c_void_p),
+        ("link_drop_capacity", C.c_void_p),
     ]
 
 
@@ -314,6 +315,10 @@ def lib():
         getattr(L, name).argtypes = [C.c_void_p]
     L.hs_engine_shard_async_done.restype = C.c_int
     L.hs_engine_shard_async_done.argtypes = [C.c_void_p, P(C.c_int32)]
+    L.hs_engine_set_link_drops.restype = C.c_int
+    L.hs_engine_set_link_drops.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+    L.hs_engine_read_send_log.restype = C.c_int64
+    L.hs_engine_read_send_log.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.hs_engine_reset.restype = C.c_int
     L.hs_engine_reset.argtypes = [C.c_void_p]
     for name in ("hs_engine_run_until", "hs_engine_run_until_async"):
@@ -411,7 +416,7 @@ def lib():
 
 EXPORTED_SYMBOLS = (
     "hs_abi_version", "hs_build_sources_hash", "hs_device_count", "hs_engine_create", "hs_engine_set_stations", "hs_engine_set_network",
-    "hs_engine_get_net_stats", "hs_engine_set_stream", "hs_engine_shard_attach", "hs_engine_shard_begin",
+    "hs_engine_get_net_stats", "hs_engine_set_link_drops", "hs_engine_read_send_log", "hs_engine_set_stream", "hs_engine_shard_attach", "hs_engine_shard_begin",
     "hs_engine_shard_window", "hs_engine_shard_inject", "hs_engine_shard_progress", "hs_engine_shard_final",
     "hs_engine_shard_overshoot", "hs_engine_shard_async_setup", "hs_engine_shard_round",
     "hs_engine_shard_inject_async", "hs_engine_shard_async_done", "hs_engine_shard_ipc_export", "hs_engine_shard_ipc_attach",

@@ -80,6 +80,9 @@ struct hs_engine {
     int64_t window_ns = 0;
     bool net_ran = false;
     int64_t net_last_end = INT64_MIN;   // end_ns of the run since the last reset (windows: see hs_engine_run_until_async)
+    std::vector<int64_t> drop_off_host;  // table-decided link losses (hs_network.link_drop_capacity): bit offsets per link
+    uint32_t *drop_bits_dev = nullptr;
+    LossTables loss_host{};              // (host copy of the device object: the send log's pointers)
     bool async_ok = false;     // the network can run on hs_net_async (whole network on this engine, queues allocated)
     int round_iters = 0;       // > 0: hs_net_async runs one exchange round of a shard (that many iterations), not a whole run
     // asynchronous shard rounds (hs_engine_shard_async_*): the network's cross-shard links
@@ -487,6 +490,7 @@ int launch_reset(hs_engine *h) {
         HS_HIP(h, hipMemsetAsync(h->xs_host.qhead, 0xff, (size_t)h->cfg.n_lp * sizeof(int32_t), h->stream));
         HS_HIP(h, hipMemsetAsync(h->xs_host.qtail, 0xff, (size_t)h->cfg.n_lp * sizeof(int32_t), h->stream));
     }
+    if (h->is_net && h->loss_host.send_log_n) HS_HIP(h, hipMemsetAsync(h->loss_host.send_log_n, 0, sizeof(unsigned long long), h->stream));
     h->initialised = true;
     h->net_ran = false;
     h->net_last_end = INT64_MIN;
@@ -1274,6 +1278,41 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     if ((rc = upload<uint8_t>(h, &h->NP.link_jit_kind, jk.data(), NL, 1))) return rc;
     if ((rc = upload<double>(h, &h->NP.link_jit_mean, jm.data(), NL, 0.0))) return rc;
     if ((rc = upload<uint64_t>(h, &h->NP.link_base, lbase.data(), NL, 0))) return rc;
+    {   // table-decided losses (hs_network.link_drop_capacity): the bit tables, all clear, and the send log
+        std::vector<int64_t> doff(NL + 1, 0);
+        int64_t total = 0;
+        for (int l = 0; l < nl; ++l) {
+            const int64_t c = net->link_drop_capacity ? net->link_drop_capacity[l] : 0;
+            if (c < 0) return fail(h, HS_E_INVALID, "link %d: link_drop_capacity < 0", l);
+            if (c > 0 && lloss[(size_t)l] != 0.0)
+                return fail(h, HS_E_INVALID, "link %d: a link with a loss table must have link_loss_rate 0", l);
+            doff[(size_t)l] = total;
+            if (c > 0) { lloss[(size_t)l] = kLossTable; total += (c + 31) / 32 * 32; }
+        }
+        for (size_t l = (size_t)(nl > 0 ? nl : 0); l <= NL; ++l) doff[l] = total;
+        h->drop_off_host = doff;
+#ifdef HS_NO_LOSS_TABLES
+        if (total > 0) return fail(h, HS_E_UNSUPPORTED, "built without loss tables");
+#else
+        h->NP.loss_tables = nullptr;
+        if (total > 0) {
+            LossTables lt{};
+            uint32_t *bits = nullptr;
+            if ((rc = upload<int64_t>(h, &lt.drop_off, doff.data(), NL + 1, 0))) return rc;
+            if ((rc = dev_alloc(h, &bits, (size_t)(total / 32)))) return rc;
+            HS_HIP(h, hipMemset(bits, 0, (size_t)(total / 32) * sizeof(uint32_t)));
+            lt.drop_bits = bits;
+            h->drop_bits_dev = bits;
+            if ((rc = dev_alloc(h, &lt.send_log, (size_t)total * 3))) return rc;
+            if ((rc = dev_alloc(h, &lt.send_log_n, 1))) return rc;
+            HS_HIP(h, hipMemset(lt.send_log_n, 0, sizeof(unsigned long long)));
+            lt.send_log_cap = total;
+            lt.overflow_word = &h->tot->overflow;
+            h->loss_host = lt;
+            if ((rc = upload<LossTables>(h, &h->NP.loss_tables, &lt, 1, lt))) return rc;
+        }
+#endif
+    }
     if ((rc = upload<double>(h, &h->NP.link_loss, lloss.data(), NL, 0.0))) return rc;
     std::vector<int32_t> in_deg_h;
     {   // incoming links per LP (CSR) and the transit floor of every link, for the asynchronous engine
@@ -1487,6 +1526,7 @@ int hs_engine_shard_progress(hs_engine *h, int64_t k_last, int64_t *wend_out) {
     HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
     if (t.qoverflow) return fail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
     if (t.overflow & 4) return fail(h, HS_E_INVALID, "a message arrived for a station or link this shard does not own");
+    if (t.overflow & 32) return fail(h, HS_E_OVERFLOW, "a link's loss table (hs_network.link_drop_capacity) is shorter than the packets that entered the link");
     if (t.overflow & 2) return fail(h, HS_E_OVERFLOW, "a message bag or an exchange row overflowed; raise bag_capacity / msg_capacity");
     if (t.overflow) return fail(h, HS_E_OVERFLOW, "a per-LP record log overflowed (capacity %lld records)", (long long)h->L.cap);
     return HS_OK;
@@ -1668,6 +1708,7 @@ int hs_engine_shard_async_done(hs_engine *h, int32_t *any_not_done) {
     if (t.qoverflow) return fail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
     if (t.overflow & 4) return fail(h, HS_E_INVALID, "a message arrived for a station or link this shard does not own");
     if (t.overflow & 8) return fail(h, HS_E_HIP, "the asynchronous engine gave up waiting for a neighbour (bounded spin exhausted)");
+    if (t.overflow & 32) return fail(h, HS_E_OVERFLOW, "a link's loss table (hs_network.link_drop_capacity) is shorter than the packets that entered the link");
     if (t.overflow & 2) return fail(h, HS_E_OVERFLOW, "a message bag, a link queue or an exchange row overflowed; raise bag_capacity / msg_capacity");
     if (t.overflow) return fail(h, HS_E_OVERFLOW, "a per-LP record log overflowed (capacity %lld records)", (long long)h->L.cap);
     return HS_OK;
@@ -1718,6 +1759,31 @@ int hs_engine_get_net_stats(hs_engine *h, const hs_net_stats *o) {
         for (size_t l = 0; l < nl; ++l) o->link_packets_dropped[l] = in[l] - sent[l];
     }
     return HS_OK;
+}
+
+int hs_engine_set_link_drops(hs_engine *h, int32_t link, const uint32_t *bits, int64_t n_bits) {
+    if (!h || !h->is_net) return fail(h, HS_E_STATE, "hs_engine_set_link_drops: no network set");
+    if (link < 0 || link >= h->NP.n_links || !h->drop_bits_dev) return fail(h, HS_E_INVALID, "link %d has no loss table", (int)link);
+    const int64_t b0 = h->drop_off_host[(size_t)link], cap = h->drop_off_host[(size_t)link + 1] - b0;
+    if (cap <= 0) return fail(h, HS_E_INVALID, "link %d has no loss table", (int)link);
+    if (n_bits < 0 || n_bits > cap || (n_bits > 0 && !bits)) return fail(h, HS_E_INVALID, "link %d: %lld bits for a table of %lld", (int)link, (long long)n_bits, (long long)cap);
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    HS_HIP(h, hipMemset(h->drop_bits_dev + b0 / 32, 0, (size_t)(cap / 32) * sizeof(uint32_t)));
+    if (n_bits > 0) HS_HIP(h, hipMemcpy(h->drop_bits_dev + b0 / 32, bits, (size_t)((n_bits + 31) / 32) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return HS_OK;
+}
+
+int64_t hs_engine_read_send_log(hs_engine *h, int64_t *out_triples, int64_t capacity) {
+    if (!h || !h->is_net) return fail(h, HS_E_STATE, "hs_engine_read_send_log: no network set");
+    if (!h->loss_host.send_log_n) return 0;
+    { const int rcf = results_final(h); if (rcf) return rcf; }
+    unsigned long long n = 0;
+    HS_HIP(h, hipMemcpy(&n, h->loss_host.send_log_n, sizeof n, hipMemcpyDeviceToHost));
+    const int64_t have = (int64_t)(n < (unsigned long long)h->loss_host.send_log_cap ? n : (unsigned long long)h->loss_host.send_log_cap);
+    const int64_t take = have < capacity ? have : capacity;
+    if (take > 0 && out_triples) HS_HIP(h, hipMemcpy(out_triples, h->loss_host.send_log, (size_t)take * 3 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return (int64_t)n;
 }
 
 int hs_engine_reset(hs_engine *h) {
@@ -1907,6 +1973,7 @@ int hs_engine_run_until(hs_engine *h, int64_t end_ns) {
     if (t.overflow & 8)
         return fail(h, HS_E_HIP, "the asynchronous network engine gave up waiting for a neighbour (bounded spin); "
                                  "set debug flag 16 to use the windowed engine");
+    if (t.overflow & 32) return fail(h, HS_E_OVERFLOW, "a link's loss table (hs_network.link_drop_capacity) is shorter than the packets that entered the link");
     if (t.overflow & 2)
         return fail(h, HS_E_OVERFLOW, "a station's in-flight message bag overflowed (capacity %d); raise bag_capacity",
                     (int)h->NX.bag_cap);
@@ -1960,6 +2027,7 @@ int hs_engine_bench_runs(hs_engine *h, int64_t end_ns, int32_t repeats, float *k
                                          "switches to it, hs_engine_bench_runs does not");
     if (t.qoverflow) return fail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
     if (t.overflow & 8) return fail(h, HS_E_HIP, "the asynchronous network engine gave up waiting for a neighbour (bounded spin)");
+    if (t.overflow & 32) return fail(h, HS_E_OVERFLOW, "a link's loss table (hs_network.link_drop_capacity) is shorter than the packets that entered the link");
     if (t.overflow & 2) return fail(h, HS_E_OVERFLOW, "a station's in-flight message bag overflowed (capacity %d); raise bag_capacity", (int)h->NX.bag_cap);
     if (t.overflow) return fail(h, HS_E_OVERFLOW, "a per-LP record log overflowed (capacity %lld records)", (long long)h->L.cap);
     return HS_OK;

@@ -434,7 +434,8 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
             const int64_t entered = NX.link_in[l];
             NX.link_in[l] = entered + 1;
             const double loss = NP.link_loss[l];
-            if (loss > 0.0 &&
+            if (loss > 1.0) { if (link_loses(NP, P.seed[lp], l, entered, t)) break; }    // (a table decides: PartitionLink.packet_loss)
+            else if (loss > 0.0 &&
                 xuniform(P.seed[lp], stream_id(NP.link_base[l], kStreamLoss), (uint64_t)entered) < loss) break;   // link.py:131-138
             NX.link_sent[l] += 1;
             double delay = seconds_from_ns(ns_from_seconds(NP.link_lat_min[l]));

@@ -988,7 +988,7 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF, UNI> &S, const 
         }
     }
     S.ha = S.na = S.hs_ = S.nsv = S.hj = S.nj = S.rn = 0; S.rbits = 0; S.fl_link = -1; S.fi_link = -1; S.fi_packets = 0;
-    S.fl_remote = false; S.fi_head = 0; S.win_hi = S.started;
+    S.fl_remote = false; S.fi_head = 0; S.fi_unpub = 0; S.win_hi = S.started;
     S.bh = 0; S.tail_hint = 0ull;
     S.presend = false; S.early_upto = S.completed; S.D_pre = S.last_time; S.fl_q = 0; S.end_ns = kInfNs;
     S.bag_n = NX.bag_cnt[lp];
@@ -1070,7 +1070,7 @@ __device__ __forceinline__ void store_net(NetStation<C, FAST, PF, UNI> &S, const
             NX.link_in[S.fl_link] = S.fl_in; NX.link_sent[S.fl_link] = S.fl_sent;
             NX.link_k[S.fl_link] = S.jit.k - (uint64_t)S.nj;
         }
-        if (S.fi_link >= 0) NX.link_packets[S.fi_link] = S.fi_packets;
+        if (S.fi_link >= 0) { NX.link_packets[S.fi_link] = S.fi_packets; NX.aq_head[S.fi_link] = S.fi_head; }   // (head_taken publishes lazily)
         if (S.presend) { NX.early_upto[lp] = S.early_upto; NX.d_pre[lp] = S.D_pre; }
     }
     NX.bag_cnt[lp] = S.bag_n;
@@ -1477,6 +1477,15 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         const int32_t my_in = in_deg == 1 ? NP.in_links[NP.in_off[lp]] : -1;
         const int32_t prev_next = __shfl_up(next_l, 1, 64);
         const bool chain = (flags & 64) == 0 && lane > 0 && my_in >= 0 && prev_next == my_in;
+        // Round 6: the words of a link INSIDE a wavefront stay out of memory while the launch runs.  A chain lane's input bound is
+        // the scan's (from the sender's current state: never below what that sender last published) and its tail is the sender's
+        // appended count, handed over by a shuffle (tail_hint) -- so it does not load the link's (bound, tail) word, and its sender
+        // does not store it until the launch ends (the final launch, the next round / segment and load_net read the tail from
+        // memory).  On the 65 536-station ring 63 of 64 links are such links: ~365 polls and publications per link and run were
+        // 2.5 GB of the kernel's 5.9 GB of HBM traffic (1.78 GB algorithmic).  Debug flag 1 << 21 keeps every word in memory.
+        const bool quiet = (flags & (1 << 21)) == 0;
+        const bool next_chain = quiet && next_l >= 0 && lane + 1 < lanes && __shfl_down(chain ? 1 : 0, 1, 64) != 0;
+        bool pub_skipped = false;
         const int64_t next_lat = next_l >= 0 ? NP.link_lat_ns[next_l] : 0;
         auto sat = [](int64_t a, int64_t b) { return (a == kInfNs || b == kInfNs) ? kInfNs : a + b; };
         int c_kind = -1;                                      // the sender map kept across the iteration boundary (bound_map)
@@ -1492,7 +1501,8 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
 #ifdef HS_CYCLES
             const unsigned long long qs = __builtin_readcyclecounter();
 #endif
-            const int64_t w_peek = done ? 0 : S.async_peek();         // the incoming link's word: its latency hides behind the refills
+            // the incoming link's word: its latency hides behind the refills (a chain lane: "nothing new" -- bound 0, tail = head)
+            const int64_t w_peek = done ? 0 : (chain && quiet) ? (int64_t)(S.fi_head & kPkTailMask) : S.async_peek();
             // Three memory round trips of an iteration run behind the wave-level refill of the pre-drawn stream values instead of in
             // front of it: the word of the incoming link (above) and the created_at window's entries behind its first half, the first
             // two waiting messages' payloads behind its second half (round 5, with the two-value top-ups of hs_netstation.hpp: 7.39 -> 6.25 ms on the 65 536-station ring).
@@ -1500,7 +1510,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             const int wf_n = S.window_issue(!done, wf0, wf1);         // loaded before, stored behind the refill
             {   // (a chain lane's only incoming link is the previous lane's next_l: async_receive_one)
                 const long long q_next = next_l >= 0 ? (long long)S.link_sent_of(next_l) : 0ll;
-                const long long q_prev = shfl_up_ll(q_next, 1);
+                const long long q_prev = __double_as_longlong(dpp_or0<0x138, 0xf>(__longlong_as_double(q_next)));   // wave_shr:1
                 S.tail_hint = chain ? (unsigned long long)q_prev : 0ull;
             }
             S.top_up(!done, topup_need, 1);                           // whole wavefront: refill the pre-drawn values (arrivals, services)
@@ -1534,7 +1544,6 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                     else mA = sat(S.next_time(), c_sdl);
                 } else S.bound_map(next_l, next_lat, mA, mB, mD);
             }
-            auto satd = [](int64_t d, int64_t b) { return d == INT64_MIN ? INT64_MIN : (b == kInfNs ? kInfNs : d + b); };
             if (!chain) {                                             // head of a chain: its input bound is known
                 if (!done && S.undrained < H) H = S.undrained;
                 int64_t v = sat(H, mB);
@@ -1542,6 +1551,8 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                 mA = v < mA ? v : mA;
                 mB = kInfNs; mD = INT64_MIN;
             }
+#ifdef HS_SCAN_I64   // (scratch build: the scan on int64 through ds_bpermute shuffles, as until round 5)
+            auto satd = [](int64_t d, int64_t b) { return d == INT64_MIN ? INT64_MIN : (b == kInfNs ? kInfNs : d + b); };
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {                        // prefix composition m_i o m_{i-1} o ... (Kogge-Stone)
                 const int64_t pA = __shfl_up(mA, o, 64), pB = __shfl_up(mB, o, 64), pD = __shfl_up(mD, o, 64);
@@ -1559,6 +1570,44 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                 if (chain && hp > H) H = hp;
                 if (!done && S.undrained < H) H = S.undrained;        // ... never beyond what is still sitting in a queue
             }
+#else
+            // Round 6: the prefix composition in whole-ns binary64 on the VALU's own lane movement (DPP row shifts / row broadcasts
+            // with the identity map (+inf, 0, -inf) where a lane has no source: no per-lane selects).  Times travel as offsets from
+            // pk_base -- whole numbers below 2^51, exact in binary64, +-infinity for "never" / "no floor" -- so a saturating 64-bit
+            // add is ONE v_add_f64 and a 64-bit min / max one instruction instead of a compare and two selects; the six steps were
+            // 36 ds_bpermute round trips and ~200 integer instructions per iteration on a wavefront that is alone on its SIMD.
+            {
+                constexpr double kTwo51 = 2251799813685248.0, kTwo52 = 4503599627370496.0;
+                const double kPosInf = __longlong_as_double(0x7ff0000000000000ll), kNegInf = __longlong_as_double((long long)0xfff0000000000000ull);
+                // (clamping a time up to pk_base and a finite value down to 2^51 - 1 is conservative: nothing happens before the start)
+                auto whole_d = [&](int64_t r) {
+                    r = r < 0 ? 0 : (r > (int64_t)kTwo51 - 1 ? (int64_t)kTwo51 - 1 : r);
+                    return __longlong_as_double(r | 0x4330000000000000ll) - kTwo52;
+                };
+                double fA = mA == kInfNs ? kPosInf : whole_d(mA - NX.pk_base);
+                double fB = mB == kInfNs ? kPosInf : whole_d(mB);
+                double fD = mD == INT64_MIN ? kNegInf : mD == kInfNs ? kPosInf : whole_d(mD - NX.pk_base);
+                auto after = [&](double pA, double pB, double pD) {      // (fA, fB, fD) o (pA, pB, pD)
+                    const double v = __builtin_fmax(pA + fB, fD);
+                    fA = __builtin_fmin(v, fA);
+                    const double d2 = pD == kNegInf ? kNegInf : pD + fB;   // (-inf + inf: the floor that does not exist stays none)
+                    fD = __builtin_fmax(d2, fD);
+                    fB = pB + fB;
+                };
+                after(dpp_orpos<0x111, 0xf>(fA), dpp_or0<0x111, 0xf>(fB), dpp_orneg<0x111, 0xf>(fD));   // row_shr:1, 2, 4, 8
+                after(dpp_orpos<0x112, 0xf>(fA), dpp_or0<0x112, 0xf>(fB), dpp_orneg<0x112, 0xf>(fD));
+                after(dpp_orpos<0x114, 0xf>(fA), dpp_or0<0x114, 0xf>(fB), dpp_orneg<0x114, 0xf>(fD));
+                after(dpp_orpos<0x118, 0xf>(fA), dpp_or0<0x118, 0xf>(fB), dpp_orneg<0x118, 0xf>(fD));
+                after(dpp_orpos<0x142, 0xa>(fA), dpp_or0<0x142, 0xa>(fB), dpp_orneg<0x142, 0xa>(fD));   // rows 1, 3 <- the row before
+                after(dpp_orpos<0x143, 0xc>(fA), dpp_or0<0x143, 0xc>(fB), dpp_orneg<0x143, 0xc>(fD));   // rows 2, 3 <- rows 0-1
+                const double hp_d = dpp_orpos<0x138, 0xf>(fA);        // wave_shr:1: the previous lane's bound towards me
+                if (chain) {
+                    const int64_t hp = hp_d == kPosInf ? kInfNs : NX.pk_base + i64_from_whole_d(__builtin_fmin(hp_d, kTwo51));
+                    if (hp > H) H = hp;
+                }
+                if (!done && S.undrained < H) H = S.undrained;        // ... never beyond what is still sitting in a queue
+            }
+#endif
 #ifdef HS_CYCLES
             const unsigned long long q2 = __builtin_readcyclecounter();
             unsigned long long q3 = q2;
@@ -1637,7 +1686,8 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                     const int32_t l = out_l[o];
                     if (l < 0) continue;
                     if (S.sent_async || vo[o] > out_pub[o]) {
-                        ag_store(&NX.aq_ea[l], pk_pack(vo[o], (unsigned long long)S.link_sent_of(l), NX.pk_base));
+                        if (l == next_l && next_chain) pub_skipped = true;      // (its reader is the next lane: the scan and tail_hint)
+                        else ag_store(&NX.aq_ea[l], pk_pack(vo[o], (unsigned long long)S.link_sent_of(l), NX.pk_base));
                         out_pub[o] = vo[o];
                     }
                 }
@@ -1668,6 +1718,12 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             } else blocked_iters = 0;
             if ((flags & 128) && wave_idle) __builtin_amdgcn_s_sleep(64);   // experiment: back off when idle
             groups_before = n_groups;
+        }
+        if (pub_skipped) {                                    // the in-wavefront link's word, once (payloads: drained in the loop)
+#pragma unroll
+            for (int o = 0; o < kOut; ++o)
+                if (out_l[o] >= 0 && out_l[o] == next_l)
+                    ag_store(&NX.aq_ea[next_l], pk_pack(out_pub[o], (unsigned long long)S.link_sent_of(next_l), NX.pk_base));
         }
         store_net<C, true, PF, UNI>(S, X, NX, lp, n);
         if constexpr (PF) { if (S.undecided) atomicOr(&tot->undecided, S.undecided); }

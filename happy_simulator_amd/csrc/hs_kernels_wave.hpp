@@ -37,33 +37,7 @@ __device__ __forceinline__ double wave_shr1(double v) {
     hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
-// v_mov_b32_dpp with an identity for the lanes that have no source (and for the rows outside the row mask RM): the scans below
-// combine unconditionally instead of selecting per lane.  CTRL: 0x110 + N row_shr:N, 0x138 wave_shr:1, 0x142 row_bcast:15 (lane
-// 15 of every row to the next row), 0x143 row_bcast:31 (lane 31 to rows 2 and 3).
-template <int CTRL, int RM>
-__device__ __forceinline__ double dpp_or0(double v) {                 // identity 0.0 (bound_ctrl: no source = zero)
-    const long long b = __double_as_longlong(v);
-    int lo = (int)(unsigned)(b & 0xffffffffll), hi = (int)(b >> 32);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, RM, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, RM, 0xf, true);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-template <int CTRL, int RM>
-__device__ __forceinline__ double dpp_orneg(double v) {               // identity -infinity
-    const long long b = __double_as_longlong(v);
-    int lo = (int)(unsigned)(b & 0xffffffffll), hi = (int)(b >> 32);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, RM, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp((int)0xfff00000u, hi, CTRL, RM, 0xf, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-template <int CTRL, int RM>
-__device__ __forceinline__ double dpp_orv(double v, double other) {   // identity: a given value
-    const long long b = __double_as_longlong(v), o = __double_as_longlong(other);
-    int lo = (int)(unsigned)(b & 0xffffffffll), hi = (int)(b >> 32);
-    lo = __builtin_amdgcn_update_dpp((int)(unsigned)(o & 0xffffffffll), lo, CTRL, RM, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp((int)(o >> 32), hi, CTRL, RM, 0xf, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
+// (dpp_or0 / dpp_orneg / dpp_orv: hs_device.hpp)
 // f(x) = max(p, x + q) after g: hs_kernels_wide.hpp mp_compose with v_max_f64 (the values are never NaN)
 __device__ __forceinline__ MaxPlus mp_after(const MaxPlus &f2, const MaxPlus &f1) {
     return MaxPlus{__builtin_fmax(f2.p, f1.p + f2.q), f1.q + f2.q};

@@ -34,6 +34,22 @@ namespace hs {
 
 enum : uint32_t { EG_NONE = 0, EG_SINK = 1, EG_LINK = 2, EG_ROUTER = 3 };
 
+// Losses decided by a TABLE (round 6: PartitionLink.packet_loss, parallel/coordinator.py:203-205 -- the coordinator's ONE
+// `random.Random(seed)` drawn in exchange order, which the host replays over the run's cross-partition sends,
+// happy_simulator_amd/parallel.py): packet number e of link l is lost iff bit drop_off[l] + e of drop_bits is set; every packet
+// that enters such a link is logged so that the host can order the sends of a run.  One object in device memory behind ONE
+// pointer of NetParams: the asynchronous kernels keep every kernel argument they touch in scalar registers, and the six words
+// this would add to the argument structs cost hs_net_async<1, false, true> 5 % on the headline ring (spills), for a path it
+// never takes.
+struct LossTables {
+    const int64_t *drop_off;      // [n_links + 1] bit offsets
+    const uint32_t *drop_bits;
+    int64_t *send_log;            // {send time ns, network-wide link id, packet number} of every packet that entered such a link
+    unsigned long long *send_log_n;   // ... since the last reset, in no particular order
+    int64_t send_log_cap;
+    int *overflow_word;           // Totals::overflow (bit 32: a loss table or the send log is too short)
+};
+
 struct NetParams {
     const uint8_t *egress;        // [n_lp] EG_*
     const int32_t *rt0, *rt1;     // [n_lp] router targets in RandomRouter(targets=[...]) order: -1 = the LP's Sink, else link
@@ -47,8 +63,12 @@ struct NetParams {
     const uint8_t *link_jit_kind; // [n_links] 0 = ExponentialLatency(link_jit_mean) jitter, 1 = ConstantLatency(link_jit_mean) jitter (0: none)
     const double *link_jit_mean;  // [n_links]
     const uint64_t *link_base;    // [n_links] stream base of the link entity
-    const double *link_loss;      // [n_links] NetworkLink.packet_loss_rate (0 = lossless)
+    const double *link_loss;      // [n_links] NetworkLink.packet_loss_rate (0 = lossless); kLossTable: decided by the table below
     const int32_t *link_gid;      // [n_links] network-wide link id (tie-break key); null = the index itself
+    // Losses decided by a TABLE (round 6: PartitionLink.packet_loss): one pointer, see LossTables (null: no link has one)
+#ifndef HS_NO_LOSS_TABLES   // (scratch build: what the argument costs the asynchronous kernels)
+    const struct LossTables *loss_tables;
+#endif
     // asynchronous engine (hs_net_async): incoming links of every LP (CSR) and each link's transit floor in ns
     const int32_t *in_off;        // [n_lp + 1]
     const int32_t *in_links;      // [n_links] link ids grouped by destination LP
@@ -163,6 +183,32 @@ __device__ __forceinline__ int64_t pk_ea(int64_t w, int64_t base) {
 }
 __device__ __forceinline__ unsigned long long pk_tail(int64_t w, unsigned long long head) {   // head <= tail < head + 2^20
     return head + (((unsigned long long)w - head) & kPkTailMask);
+}
+
+// Is packet number `entered` of link l lost?  NetworkLink.packet_loss_rate (components/network/link.py:131-138): u of the link's
+// LOSS stream, one draw per packet that enters.  kLossTable: the table of NetParams::drop_off (PartitionLink.packet_loss).
+constexpr double kLossTable = 2.0;
+__device__ __forceinline__ bool link_loses(const NetParams &np, uint64_t seed, int32_t l, int64_t entered, int64_t t_send) {
+    const double loss = np.link_loss[l];
+    if (loss <= 1.0) {
+        Stream ls;
+        ls.init(seed, stream_id(np.link_base[l], kStreamLoss), (uint64_t)entered);
+        return ls.next_uniform() < loss;
+    }
+#ifdef HS_NO_LOSS_TABLES
+    (void)t_send;
+    return false;
+#else
+    const LossTables lt = *np.loss_tables;
+    const unsigned long long pos = atomicAdd(lt.send_log_n, 1ull);
+    if (pos < (unsigned long long)lt.send_log_cap) {
+        lt.send_log[3 * pos] = t_send; lt.send_log[3 * pos + 1] = np.link_gid ? np.link_gid[l] : (int64_t)l; lt.send_log[3 * pos + 2] = entered;
+    } else atomicOr(lt.overflow_word, 32);
+    const int64_t b0 = lt.drop_off[l], nb = lt.drop_off[l + 1] - b0;
+    if (entered >= nb) { atomicOr(lt.overflow_word, 32); return false; }
+    const int64_t b = b0 + entered;
+    return ((lt.drop_bits[b >> 5] >> (b & 31)) & 1u) != 0u;
+#endif
 }
 
 constexpr int kEnqPay = 8;   // ENQ payload FIFO depth (general path only)
@@ -318,6 +364,7 @@ struct NetStation {
     int32_t fi_link;              // the LP's only incoming link (-1: none or several): its packets_sent counter in a register
     int64_t fi_packets;
     unsigned long long fi_head;   // ... and this LP's position in that link's queue (the only writer of aq_head[fi_link])
+    int32_t fi_unpub;             // ... messages taken since aq_head[fi_link] was last written (head_taken)
     // in-group FIFO (an LDS column) + ENQ payloads (an LDS column, or global memory in hs_net_async: entry k at enq[k * enq_stride])
     uint8_t (*qmem)[kBlock];
     int64_t *enq;
@@ -817,11 +864,7 @@ struct NetStation {
         ev[8]++;
         if (HSU(presend, true) && completed - 1 < early_upto) { fl_in++; fl_sent++; return; }   // its message was appended ahead of time
         const int64_t entered = fl_in++;
-        if (HSU(fl_loss > 0.0, false)) {
-            Stream ls;
-            ls.init(seed, stream_id(np->link_base[fl_link], kStreamLoss), (uint64_t)entered);
-            if (ls.next_uniform() < fl_loss) return;
-        }
+        if (HSU(fl_loss > 0.0, false)) { if (link_loses(*np, seed, fl_link, entered, t)) return; }
         ++fl_sent;
         double delay = fl_delay0;
         if (HSU(fl_jit == 0, true)) {
@@ -840,9 +883,7 @@ struct NetStation {
         if (loss > 0.0) {
             // packet loss is decided before anything else (link.py:131-138: `random.random() < packet_loss_rate`, here u
             // of the link's LOSS stream, one draw per packet that enters); the generator ends without yielding
-            Stream ls;
-            ls.init(seed, stream_id(np->link_base[l], kStreamLoss), (uint64_t)entered);
-            if (ls.next_uniform() < loss) return;
+            if (link_loses(*np, seed, l, entered, t)) return;
         }
         ns->link_sent[l]++;
         double delay = seconds_from_ns(ns_from_seconds(np->link_lat_min[l]));          // ConstantLatency
@@ -950,6 +991,17 @@ struct NetStation {
     // state has already sent are only guaranteed to be behind a tail read after the neighbour's drains.)
     // (It may be loaded at the very top of the iteration, before the stream rings are topped up -- that is after every
     // publication of the previous iteration: async_peek.)
+    // This LP has taken the messages below `head` of its one incoming link (FAST: the position lives in a register).  The
+    // producer reads the published position only when its queue LOOKS full (async_can_send), so the word is written when that
+    // can be the case -- the queue, measured from the last published position, is at least half full -- and when the launch
+    // ends (store_net); a producer that blocks on a stale position therefore gets the exact one at this LP's next receive.
+    // (Round 6: one write-through store per receive -- ~10 M partial-line writes on the headline ring -- was a tenth of the
+    // kernel's HBM traffic for a word that was read a few hundred times.)
+    __device__ __forceinline__ void head_taken(int l, unsigned long long head, unsigned long long tail) {
+        fi_unpub += (int32_t)(head - fi_head);
+        fi_head = head;
+        if ((long long)(tail - head) + fi_unpub >= (long long)(ns->aq_cap >> 1)) { ag_store(&ns->aq_head[l], head); fi_unpub = 0; }
+    }
     __device__ __forceinline__ int64_t async_peek() const {
         if constexpr (FAST) { if (fi_link >= 0) return ag_load(&ns->aq_ea[fi_link]); }
         return 0;
@@ -971,8 +1023,7 @@ struct NetStation {
                 const int64_t ta = ag_load(&ns->aq_rec[4 * slot]);
                 bag_insert(ta, ag_load(&ns->aq_rec[4 * slot + 1]), ag_load(&ns->aq_rec[4 * slot + 2]), l, ag_load(&ns->aq_rec[4 * slot + 3]));
             }
-            fi_head = head;
-            ag_store(&ns->aq_head[l], head);
+            head_taken(l, head, tail);
             if (head < tail) {
                 const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
                 undrained = ag_load(&ns->aq_rec[4 * slot + 1]) + np->link_lat_ns[l];
@@ -1016,8 +1067,7 @@ struct NetStation {
                 const int64_t ta = ag_load(&ns->aq_rec[4 * slot]);
                 bag_insert(ta, ag_load(&ns->aq_rec[4 * slot + 1]), ag_load(&ns->aq_rec[4 * slot + 2]), l, ag_load(&ns->aq_rec[4 * slot + 3]));
             }
-            fi_head = head;
-            ag_store(&ns->aq_head[l], head);
+            head_taken(l, head, tail);
             if (head < tail) {
                 const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
                 undrained = ag_load(&ns->aq_rec[4 * slot + 1]) + np->link_lat_ns[l];

@@ -85,6 +85,7 @@ class NetworkArrays:
     router_n_targets: np.ndarray | None = None # [n] len(RandomRouter.targets), 1..4; None = 2 everywhere
     router_target2: np.ndarray | None = None   # [n] third / fourth target of routers with more than two
     router_target3: np.ndarray | None = None
+    link_drop_capacity: np.ndarray | None = None  # [n_links] packets of a table-decided loss (PartitionLink.packet_loss); None / 0 = none
     bag_capacity: int = 0
     # one shard of a partitioned network (happy_simulator_amd/sharded.py): network-wide endpoints and link ids
     n_global_lp: int = 0
@@ -277,12 +278,30 @@ class StationEngine:
         put("router_n_targets", net.router_n_targets, np.uint8, self.n)
         put("router_target2", net.router_target2, np.int32, self.n)
         put("router_target3", net.router_target3, np.int32, self.n)
+        put("link_drop_capacity", net.link_drop_capacity, np.int64, nl)
         nw.bag_capacity = int(net.bag_capacity)
         nw.n_global_lp = int(net.n_global_lp)
         put("link_gid", net.link_gid, np.int64, nl)
         nw.n_global_links = int(net.n_global_links)
         self._check(self._lib.hs_engine_set_network(self._h, C.byref(nw)))
         self.n_links = nl
+
+    def set_link_drops(self, link: int, drops: np.ndarray):
+        """Packet number e of `link` (a local link index with a loss table, NetworkArrays.link_drop_capacity) is lost iff drops[e]."""
+        bits = np.packbits(np.asarray(drops, bool), bitorder="little")
+        words = np.zeros((len(bits) + 3) // 4 * 4, np.uint8)
+        words[:len(bits)] = bits
+        w = np.ascontiguousarray(words.view(np.uint32))
+        self._check(self._lib.hs_engine_set_link_drops(self._h, int(link), w.ctypes.data if len(w) else None, int(len(drops))))
+
+    def send_log(self) -> np.ndarray:
+        """[k, 3] int64 {send time ns, network-wide link id, packet number} of every packet that entered a table-decided link since
+        the last reset (no particular order)."""
+        n = int(self._check(self._lib.hs_engine_read_send_log(self._h, None, 0)))
+        out = np.zeros((max(n, 1), 3), np.int64)
+        if n:
+            self._check(self._lib.hs_engine_read_send_log(self._h, out.ctypes.data, n))
+        return out[:n]
 
     def net_stats(self) -> dict:
         out = {"routed": np.zeros(self.n, np.int64), "link_entered": np.zeros(max(self.n_links, 1), np.int64),

@@ -231,6 +231,17 @@ class PartitionLink:
     def __post_init__(self):
         if self.min_latency <= 0:
             raise ValueError(f"PartitionLink min_latency must be > 0, got {self.min_latency}")  # parallel/link.py:41-45
+        if not (0.0 <= self.packet_loss < 1.0):                                                  # parallel/link.py:46-49
+            raise ValueError(f"PartitionLink packet_loss must be in [0, 1), got {self.packet_loss}")
+        if self.source_partition == self.dest_partition:                                         # parallel/link.py:50-53
+            raise ValueError(f"PartitionLink source and dest must differ, got '{self.source_partition}'")
+
+    @staticmethod
+    def bidirectional(partition_a: str, partition_b: str, min_latency: float, latency: Any = None,
+                      packet_loss: float = 0.0) -> "tuple[PartitionLink, PartitionLink]":
+        """A pair of links (A -> B and B -> A) with identical parameters (parallel/link.py:55-79)."""
+        return (PartitionLink(partition_a, partition_b, min_latency, latency, packet_loss),
+                PartitionLink(partition_b, partition_a, min_latency, latency, packet_loss))
 
 
 @dataclass
@@ -289,6 +300,12 @@ class ParallelSimulationSummary:
                       f"  Barrier overhead: {self.barrier_overhead_seconds:.3f}s",
                       f"  Coordination efficiency: {self.coordination_efficiency:.1%}"]
         return "\n".join(lines)
+
+
+def _trim(a: np.ndarray) -> np.ndarray:
+    """A loss table without its trailing zeros (a kept packet needs no bit)."""
+    nz = np.nonzero(a)[0]
+    return a[:int(nz[-1]) + 1] if len(nz) else a[:0]
 
 
 def reference_window_count(start: Instant, end: Instant, window_s: float) -> int:
@@ -403,16 +420,25 @@ class ParallelSimulation:
                 raise ValueError(f"PartitionLink references unknown source partition '{lk.source_partition}'")
             if lk.dest_partition not in seen:
                 raise ValueError(f"PartitionLink references unknown dest partition '{lk.dest_partition}'")
-            if lk.latency is not None or lk.packet_loss != 0.0:
-                # parallel/coordinator.py:200-210.  `latency`: the coordinator calls `link.latency.sample()`, a method none of the
-                # reference's LatencyDistributions has (AttributeError there: tests/test_oracle_live_reference.py), so there is no
-                # library behaviour to mirror.  `packet_loss`: ONE `random.Random(seed)` per coordinator, drawn once per cross event
-                # in exchange order (partition dict order inside a window, window by window) -- a sequential MT19937 stream whose
-                # order is a property of the windowing, with no extension point to plug a per-link counter-based stream into
-                # (the Philox-plugged parity definition).  Loss on the hop itself is lowered:
-                # NetworkLink(packet_loss_rate=...).
-                raise UnsupportedTopology("PartitionLink(latency=...) / PartitionLink(packet_loss=...) are not lowered: put the loss "
-                                          "on the hop (NetworkLink(packet_loss_rate=...)); see happy_simulator_amd/parallel.py")
+            if lk.latency is not None:
+                # parallel/coordinator.py:207-210: the coordinator calls `link.latency.sample()`, a method none of the reference's
+                # LatencyDistributions has (AttributeError there: tests/test_oracle_live_reference.py) -- no library behaviour to mirror.
+                raise UnsupportedTopology("PartitionLink(latency=...) is not lowered: the reference's coordinator calls `.sample()` on it, "
+                                          "which its own LatencyDistributions do not have; put the latency on the hop "
+                                          "(NetworkLink(latency=..., jitter=...))")
+        # PartitionLink(packet_loss=p) (parallel/coordinator.py:68,203-205): ONE `random.Random(seed)` per coordinator, drawn once per
+        # cross-partition event of a lossy link, in exchange order = (window, source partition in dict order, outbox order).  While
+        # every lossy PartitionLink leaves the SAME partition that order is the partition's own processing order of the sending
+        # events (pinned on the live class: tests/golden parallel_linked_loss*), which the host replays over the run's sends
+        # (`_replay_partition_losses`).  With several lossy source partitions the order depends on which window the reference's
+        # coordinator processed each sending event in -- its one-event overshoot per window included (core/simulation.py:472) -- a
+        # property of its window walk over EVERY event of the partition, not of the model: refused by name.
+        lossy_from = {lk.source_partition for lk in links if lk.packet_loss > 0.0}
+        if len(lossy_from) > 1:
+            raise UnsupportedTopology("PartitionLink(packet_loss=...) on links out of several partitions (" + ", ".join(sorted(lossy_from)) +
+                                      "): the reference's one loss stream then interleaves by its windows' event-by-event overshoot, "
+                                      "which is not lowered; keep the lossy links to one source partition or put the loss on the hops "
+                                      "(NetworkLink(packet_loss_rate=...))")
         if window_size is not None and links:
             m = min(lk.min_latency for lk in links)
             if window_size > m:
@@ -438,7 +464,9 @@ class ParallelSimulation:
         if (sizes == 0).any():
             raise UnsupportedTopology("a partition without a Server / Source station cannot be a shard")
         declared = {(lk.source_partition, lk.dest_partition): lk.min_latency for lk in self._links}
+        loss_of = {(lk.source_partition, lk.dest_partition): lk.packet_loss for lk in self._links}
         self._cross_links = []
+        self._lossy_links: dict[int, float] = {}          # graph link -> PartitionLink.packet_loss of the pair it crosses
         for l, (lk, s, d) in enumerate(g.links):
             ps, pd = part_of[s], part_of[d]
             if ps == pd:
@@ -451,6 +479,12 @@ class ParallelSimulation:
                 raise ValueError(f"link '{lk.name}' can deliver after {lk.latency.mean}s, less than the PartitionLink "
                                  f"min_latency {declared[key]}s")
             self._cross_links.append(l)
+            p_loss = loss_of.get(key, 0.0)
+            if p_loss > 0.0:
+                if lk.packet_loss_rate > 0.0:
+                    raise UnsupportedTopology(f"link '{lk.name}' has a packet_loss_rate of its own and crosses a PartitionLink with "
+                                              "packet_loss: two loss decisions per packet are not lowered")
+                self._lossy_links[l] = p_loss
         if any(p.probes for p in parts):
             from .lowering import attach_probes
 
@@ -481,6 +515,42 @@ class ParallelSimulation:
                                  {p.name: launch for p in self._partitions}, _time.monotonic() - wall0,
                                  duration_s=dur, total_events=tot, n_partitions=n)
 
+    def _replay_partition_losses(self, sn, comm, summ, end_ns):
+        """`PartitionLink.packet_loss` by host replay (parallel/coordinator.py:68,203-205).  The k-th cross-partition event of a lossy
+        link, in the sending partition's processing order, is lost iff the k-th `random.Random(seed).random()` is below the link's
+        `packet_loss`.  Which send is the k-th depends on the run, so: run, read every shard's send log (hs_engine_read_send_log),
+        order it by send time, draw, hand the decisions back as one bit per packet of each link (hs_engine_set_link_drops), run
+        again -- until a run's sends reproduce the decisions it ran with.  A pipeline settles after the second run (nothing upstream
+        of the lossy link depends on what it loses); a cycle back into the sending partition settles decision by decision."""
+        import random
+
+        p_of = self._lossy_links
+        used: dict[int, np.ndarray] = {l: np.zeros(0, bool) for l in p_of}
+        for _attempt in range(64):
+            logs = comm.gather_rows([s.engine.send_log() for s in sn.shards])          # [k, 3]: send ns, link, packet number
+            order = np.lexsort((logs[:, 2], logs[:, 1], logs[:, 0]))
+            logs = logs[order]
+            # two sends of DIFFERENT links on one nanosecond: their order is the reference's sort-index order of two events of
+            # different stations, which the send log does not carry (lock-step constants only) -- refused by name
+            same_ns = (logs[1:, 0] == logs[:-1, 0]) & (logs[1:, 1] != logs[:-1, 1])
+            if same_ns.any():
+                raise UnsupportedTopology("two hops of a lossy PartitionLink sent on the same nanosecond: the order of their loss draws "
+                                          "is the reference's sort-index order, which is not lowered (lock-step constant services)")
+            rng = random.Random(self._seed)                                # the coordinator's generator (ParallelSimulation(seed=))
+            want = {l: np.zeros(int((logs[:, 1] == l).sum()), bool) for l in p_of}
+            for _t, l, e in logs.tolist():
+                want[l][e] = rng.random() < p_of[l]
+            # (trailing survivors need no bits: packets beyond the table's written part are kept)
+            if all(np.array_equal(_trim(want[l]), _trim(used[l])) for l in p_of):
+                return summ
+            for s in sn.shards:
+                for l in p_of:
+                    if s.lo <= self._graph.links[l][1] < s.hi:
+                        s.engine.set_link_drops(int(np.nonzero(s.gids == l)[0][0]), want[l])
+            used = want
+            summ = sn.run_until(end_ns)
+        raise N.EngineError(N.HS_E_UNSUPPORTED, "PartitionLink.packet_loss: the loss decisions did not settle in 64 runs")
+
     def _run_linked(self) -> ParallelSimulationSummary:
         import torch.distributed as dist
 
@@ -500,10 +570,15 @@ class ParallelSimulation:
         end_ns, start_ns = self._end.nanoseconds, self._start.nanoseconds
         st, net = g.arrays(), g.network_arrays(self._bag_capacity or 0)
         cap = self._log_capacity or g.log_capacity((end_ns - start_ns) / 1e9)
+        if self._lossy_links:            # a loss table per lossy cross link, as long as a record log (no station forwards more)
+            net.link_drop_capacity = np.zeros(net.n_links, np.int64)
+            net.link_drop_capacity[list(self._lossy_links)] = cap
         with ShardedNetwork.on_gpu(st, net, comm, horizon_ns=end_ns, start_ns=start_ns, seed=self._seed,
                                    device=self._device, log_capacity=cap, bounds=self._bounds,
                                    **({"msg_capacity": self._msg_capacity} if self._msg_capacity else {})) as sn:
             summ = sn.run_until(end_ns)
+            if self._lossy_links:
+                summ = self._replay_partition_losses(sn, comm, summ, end_ns)
             part_summaries = {}
             cross_local = 0
             # ONE write-back over all of this process's shards: a collector fed by stations of several shards gets its
@@ -523,7 +598,8 @@ class ParallelSimulation:
                         lk.packets_sent = int(fnet["link_packets_sent"][l])
                     if s.lo <= src < s.hi:
                         lk._entered = int(fnet["link_entered"][l])
-                        lk.packets_dropped = int(fnet["link_packets_dropped"][l])
+                        # (what a lossy PartitionLink took is the coordinator's doing, not the hop's: NetworkLink.packets_dropped stays 0)
+                        lk.packets_dropped = 0 if l in self._lossy_links else int(fnet["link_packets_dropped"][l])
                 for i in range(s.lo, s.hi):
                     if g.stations[i].router is not None:
                         g.stations[i].router.stats_routed = int(fnet["routed"][i])

@@ -98,6 +98,10 @@ class LocalComm:
 
         return torch.stack(rows).cpu().numpy()
 
+    def gather_rows(self, arrays):
+        """Host arrays of every shard (different lengths), concatenated -- the same on every rank."""
+        return np.concatenate([np.asarray(a) for a in arrays], axis=0)
+
     def reduce_host(self, dicts):
         return _combine(dicts)
 
@@ -192,6 +196,11 @@ class DistComm:
         out = [torch.empty_like(row) for _ in range(self.world)]
         self._dist.all_gather(out, row, group=self._group)
         return torch.stack(out).cpu().numpy()
+
+    def gather_rows(self, arrays):
+        every = [None] * self.world
+        self._dist.all_gather_object(every, np.concatenate([np.asarray(a) for a in arrays], axis=0), group=self._group)
+        return np.concatenate(every, axis=0)
 
     def reduce_host(self, dicts):
         import torch
@@ -290,6 +299,9 @@ def shard_arrays(stations: StationArrays, net: NetworkArrays, lo: int, hi: int):
         router_n_targets=None if net.router_n_targets is None else np.asarray(net.router_n_targets)[sl],
         router_target2=None if net.router_target2 is None else remap(net.router_target2),
         router_target3=None if net.router_target3 is None else remap(net.router_target3),
+        # (a loss table belongs to the shard that owns the link's SOURCE station: that is where packets enter the link)
+        link_drop_capacity=None if net.link_drop_capacity is None else np.where(
+            (src[gids] >= lo) & (src[gids] < hi), np.asarray(net.link_drop_capacity, np.int64)[gids], 0),
         bag_capacity=net.bag_capacity, n_global_lp=n, link_gid=gids, n_global_links=net.n_links)
     return st, sub
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HS_ABI_VERSION 13
+#define HS_ABI_VERSION 14
 
 typedef enum hs_status {
     HS_OK = 0,
@@ -229,6 +229,14 @@ typedef struct hs_network {
     const uint8_t *router_n_targets; /* [n_lp] */
     const int32_t *router_target2;   /* [n_lp] */
     const int32_t *router_target3;   /* [n_lp] */
+    /* Links whose losses are decided by a TABLE instead of a stream (ABI 14): `PartitionLink(packet_loss=p)`
+     * (parallel/link.py:31-39) is applied by the reference's coordinator at the exchange with ONE `random.Random(seed)`
+     * for the whole run, drawn in exchange order (parallel/coordinator.py:68,203-205) -- a sequence the caller replays
+     * over the cross-partition sends of a run (hs_engine_read_send_log) and hands back as one bit per packet
+     * (hs_engine_set_link_drops).  link_drop_capacity[l] > 0: link l has a table of that many packets (all zero = nothing
+     * is lost until the caller says so); a packet beyond it is HS_E_OVERFLOW.  Such a link must have link_loss_rate 0.
+     * NULL = no link has one. */
+    const int64_t *link_drop_capacity; /* [n_links] */
 } hs_network;
 
 /* Exchange buffers of a shard: device memory owned by the caller (torch tensors on the host side, so that
@@ -326,6 +334,14 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st);
  * hs_engine_run_until per hs_engine_reset (windows are internal, the call is not re-entrant). */
 int hs_engine_set_network(hs_engine *h, const hs_network *net);
 int hs_engine_get_net_stats(hs_engine *h, const hs_net_stats *out);
+/* Table-decided link losses (hs_network.link_drop_capacity; replaces the `self._rng.random() < link.packet_loss` of
+ * parallel/coordinator.py:203-205).  hs_engine_set_link_drops: packet number e of `link` (a local link index) is lost iff
+ * bit e of `bits` is set (n_bits <= the link's capacity; the rest stays 0); takes effect at the next reset / run.
+ * hs_engine_read_send_log: every packet that entered a table-decided link since the last reset, as int64 triples
+ * {send time ns, network-wide link id, packet number}, in no particular order; returns their number (the first
+ * `capacity` are written) or a negative hs_status. */
+int hs_engine_set_link_drops(hs_engine *h, int32_t link, const uint32_t *bits, int64_t n_bits);
+int64_t hs_engine_read_send_log(hs_engine *h, int64_t *out_triples, int64_t capacity);
 /* external != 0: run on the caller's HIP stream (e.g. torch's current stream, so that collectives and engine
  * launches are ordered by the stream; a NULL handle is the device's default stream).  external == 0: back to the
  * engine's own stream. */

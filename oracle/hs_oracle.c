@@ -90,6 +90,7 @@ struct hso_sim {
     int64_t current_ns;
     int64_t processed, by_kind[HSO_EV_KINDS];
     hsr_mt19937 mt_py, mt_np;
+    hsr_mt19937 mt_coord;                 /* the coordinator's random.Random(seed) (hso_graph.ploss) */
     /* trace */
     int64_t *tr_t; int32_t *tr_kind; int32_t *tr_node; int64_t *tr_idx; int64_t tr_len;
 #ifdef HSO_LINEAGE
@@ -600,6 +601,13 @@ static void on_link(hso_sim *s, const hso_event *e) {
         req_release(s, e->req);
         return;
     }
+    /* PartitionLink.packet_loss: the coordinator drops the cross-partition event at the exchange (parallel/coordinator.py:203-205:
+     * `if link.packet_loss > 0 and self._rng.random() < link.packet_loss: continue`) -- it never reaches the destination */
+    if (s->g.ploss[n] > 0.0 && hsr_mt_res53(&s->mt_coord) < s->g.ploss[n]) {
+        nd->dropped++;
+        req_release(s, e->req);
+        return;
+    }
     double delay = hsr_seconds_from_ns(hsr_ns_from_seconds(s->g.lat_min[n]));      /* ConstantLatency */
     if (s->g.lat_kind[n] == HSO_LAT_EXP) {
         double lambda = 1.0 / s->g.lat_mean[n];
@@ -786,7 +794,7 @@ hso_sim *hso_create(const hso_graph *g, const hso_params *p) {
     DUP(arr_kind, int32_t); DUP(rate, double); DUP(stop_after_ns, int64_t);
     DUP(concurrency, int32_t); DUP(lat_kind, int32_t); DUP(lat_mean, double); DUP(lat_min, double);
     DUP(queue_cap, int64_t); DUP(rt_off, int32_t); DUP(rt_cnt, int32_t);
-    DUP(n_clients, int64_t); DUP(vnodes, int32_t); DUP(prof_kind, int32_t); DUP(probe_metric, int32_t); DUP(loss, double);
+    DUP(n_clients, int64_t); DUP(vnodes, int32_t); DUP(prof_kind, int32_t); DUP(probe_metric, int32_t); DUP(loss, double); DUP(ploss, double);
     {
         double *pp = (double *)calloc((size_t)n * 4 + 1, sizeof(double));
         if (g->prof_p) memcpy(pp, g->prof_p, (size_t)n * 4 * sizeof(double));
@@ -817,6 +825,7 @@ hso_sim *hso_create(const hso_graph *g, const hso_params *p) {
         s->tr_node = (int32_t *)malloc((size_t)p->trace_cap * 4);
         s->tr_idx = (int64_t *)malloc((size_t)p->trace_cap * 8);
     }
+    { uint32_t ck = p->coord_seed; hsr_mt_init_by_array(&s->mt_coord, &ck, 1); }   /* random.Random(seed), parallel/coordinator.py:68 */
     if (p->rng_mode == HSO_RNG_MT19937) {
         uint32_t key = p->mt_seed_py;
         hsr_mt_init_by_array(&s->mt_py, &key, 1);   /* random.seed(int) */
@@ -1000,7 +1009,7 @@ void hso_destroy(hso_sim *s) {
     free((void *)s->g.kind); free((void *)s->g.target); free((void *)s->g.stream_base);
     free((void *)s->g.arr_kind); free((void *)s->g.rate); free((void *)s->g.stop_after_ns);
     free((void *)s->g.concurrency); free((void *)s->g.lat_kind); free((void *)s->g.lat_mean);
-    free((void *)s->g.prof_kind); free((void *)s->g.prof_p); free((void *)s->g.probe_metric); free((void *)s->g.loss);
+    free((void *)s->g.prof_kind); free((void *)s->g.prof_p); free((void *)s->g.probe_metric); free((void *)s->g.loss); free((void *)s->g.ploss);
     free((void *)s->g.n_clients); free((void *)s->g.vnodes); free((void *)s->g.names); free((void *)s->g.name_off);
     free((void *)s->g.lat_min); free((void *)s->g.queue_cap); free((void *)s->g.rt_off); free((void *)s->g.rt_cnt); free((void *)s->g.rt_targets);
     free(s->nodes); free(s->heap); free(s->reqs);

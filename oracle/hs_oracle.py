@@ -65,6 +65,7 @@ class _Graph(C.Structure):
         ("prof_p", C.POINTER(C.c_double)),
         ("probe_metric", C.POINTER(C.c_int32)),
         ("loss", C.POINTER(C.c_double)),
+        ("ploss", C.POINTER(C.c_double)),
     ]
 
 
@@ -77,6 +78,7 @@ class _Params(C.Structure):
         ("mt_seed_py", C.c_uint32),
         ("mt_seed_np", C.c_uint32),
         ("trace_cap", C.c_int64),
+        ("coord_seed", C.c_uint32),
     ]
 
 
@@ -158,12 +160,14 @@ class Graph:
     prof_p: list = field(default_factory=list)       # 4 parameters per node
     probe_metric: list = field(default_factory=list)
     loss: list = field(default_factory=list)
+    ploss: list = field(default_factory=list)        # PartitionLink.packet_loss of the partition pair a link crosses (coord_seed)
 
     def _add(self, **kw) -> int:
         defaults = dict(
             kind=0, target=-1, stream_base=len(self.kind), arr_kind=0, rate=0.0, stop_after_ns=-1,
             concurrency=1, lat_kind=LAT_CONST, lat_mean=0.0, lat_min=0.0, queue_cap=-1, rt_off=0, rt_cnt=0,
             n_clients=0, vnodes=0, names="", prof_kind=PROF_CONSTANT, prof_p=(0.0, 0.0, 0.0, 0.0), probe_metric=0, loss=0.0,
+            ploss=0.0,
         )
         defaults.update(kw)
         for k, v in defaults.items():
@@ -197,10 +201,11 @@ class Graph:
         return self._add(kind=PROBE, target=target, arr_kind=ARR_CONSTANT, probe_metric=metric,
                          prof_kind=PROF_GENERAL_CONSTANT, prof_p=(1.0 / interval, 0.0, 0.0, 0.0))
 
-    def link(self, lat_min, jitter_mean=None, target=-1, stream_base=None, loss=0.0, jitter_kind="exp") -> int:
+    def link(self, lat_min, jitter_mean=None, target=-1, stream_base=None, loss=0.0, jitter_kind="exp", ploss=0.0) -> int:
         """NetworkLink(latency=ConstantLatency(lat_min), jitter=ExponentialLatency(jitter_mean) | ConstantLatency(jitter_mean)
-        (jitter_kind="const") | None, egress=target, packet_loss_rate=loss)."""
-        kw = dict(kind=LINK, lat_min=float(lat_min), target=target, loss=float(loss),
+        (jitter_kind="const") | None, egress=target, packet_loss_rate=loss); ploss: the PartitionLink.packet_loss of the partition
+        pair the link crosses (drawn from the coordinator's generator, `run(coord_seed=)`)."""
+        kw = dict(kind=LINK, lat_min=float(lat_min), target=target, loss=float(loss), ploss=float(ploss),
                   lat_kind=LAT_CONST if (jitter_mean is None or jitter_kind == "const") else LAT_EXP,
                   lat_mean=0.0 if jitter_mean is None else float(jitter_mean))
         if stream_base is not None:
@@ -248,7 +253,7 @@ class Result:
 
 
 def _create(g: Graph, end_ns: int, start_ns: int, seed: int, rng_mode: int, mt_seed_py: int, mt_seed_np: int,
-            trace_cap: int):
+            trace_cap: int, coord_seed: int = 42):
     """hso_create for a Graph; returns the handle (the C side copies every array)."""
     L = lib()
     n = len(g)
@@ -266,6 +271,7 @@ def _create(g: Graph, end_ns: int, start_ns: int, seed: int, rng_mode: int, mt_s
         "prof_p": np.asarray(g.prof_p, np.float64).reshape(-1),
         "probe_metric": np.asarray(g.probe_metric, np.int32),
         "loss": np.asarray(g.loss, np.float64),
+        "ploss": np.asarray(g.ploss, np.float64),
     }
     enc = [nm.encode() for nm in g.names]
     names_blob = b"".join(enc) + b"\0"
@@ -279,20 +285,20 @@ def _create(g: Graph, end_ns: int, start_ns: int, seed: int, rng_mode: int, mt_s
         setattr(G, name, a.ctypes.data_as(ftype))
     G.names = names_blob
     G.name_off = name_off.ctypes.data_as(C.POINTER(C.c_int32))
-    P = _Params(start_ns, end_ns, seed, rng_mode, mt_seed_py, mt_seed_np, trace_cap)
+    P = _Params(start_ns, end_ns, seed, rng_mode, mt_seed_py, mt_seed_np, trace_cap, coord_seed)
     return L.hso_create(C.byref(G), C.byref(P))
 
 
 def run(g: Graph, end_ns: int, start_ns: int = 0, seed: int = 42, rng_mode: int = RNG_PHILOX,
         mt_seed_py: int = 42, mt_seed_np: int = 42, trace_cap: int = 0, windows: list | None = None,
-        lb_probe: int = 0, schedule: list | None = None) -> Result:
+        lb_probe: int = 0, schedule: list | None = None, coord_seed: int = 42) -> Result:
     """Run the oracle once; returns a Result with summary, per-node stats, sink records, trace.
     schedule: [(node, time_ns), ...] = Simulation.schedule(Event(time, "Request", target=node)) calls before run()."""
     L = lib()
     n = len(g)
     import time as _time
 
-    h = _create(g, end_ns, start_ns, seed, rng_mode, mt_seed_py, mt_seed_np, trace_cap)
+    h = _create(g, end_ns, start_ns, seed, rng_mode, mt_seed_py, mt_seed_np, trace_cap, coord_seed)
     try:
         for node, t_ns in (schedule or []):
             if L.hso_schedule(h, int(node), int(t_ns)) != 0:

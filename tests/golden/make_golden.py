@@ -1319,12 +1319,16 @@ def run_parallel_linked_case(spec):
     for k, row in enumerate(servers):
         ents = [x for s in row for x in _server_parts(s)] + (hops[k] if k < len(hops) else []) + (sinks if k == len(servers) - 1 else [])
         parts.append(SimulationPartition(name=f"P{k}", entities=ents, sources=sources if k == 0 else []))
-    links = [PartitionLink(f"P{k}", f"P{k + 1}", min_latency=spec["hop_latency"]) for k in range(len(servers) - 1)]
+    # `packet_loss` (round 6): PartitionLink(packet_loss=p_k) on the link out of partition k -- the coordinator drops the cross-partition
+    # event at the exchange with ONE random.Random(coord_seed) (parallel/coordinator.py:68,204); the sequential twins above have no
+    # coordinator and lose nothing
+    ploss = spec.get("packet_loss") or [0.0] * (len(servers) - 1)
+    links = [PartitionLink(f"P{k}", f"P{k + 1}", min_latency=spec["hop_latency"], packet_loss=ploss[k]) for k in range(len(servers) - 1)]
     import warnings
 
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")                      # the GIL warning
-        ps = ParallelSimulation(parts, end_time=end, links=links)
+        ps = ParallelSimulation(parts, end_time=end, links=links, **({"seed": spec["coord_seed"]} if "coord_seed" in spec else {}))
     dropped = _count_time_travel(ps.simulations)
     summ = ps.run()
     for k, v in _pipeline_results(servers, hops, sinks, sources).items():
@@ -1435,6 +1439,14 @@ PARALLEL_CASES = [
     # departs from its own sequential run; the engine's linked partitions equal the SEQUENTIAL one.
     dict(name="parallel_linked_hazard", kind="linked", lanes=3, rate=[9.0, 7.0, 11.0], seed=73, end_s=15.0, hop_latency=0.02,
          hop_jitter=0.01, stages=[dict(svc="exp", mean=[0.08, 0.1, 0.06]), dict(svc="exp", mean=[0.07, 0.09, 0.05])]),
+    # round 6: PartitionLink(packet_loss=...) -- the coordinator's own random.Random(seed) decides at the exchange; four hops share
+    # the lossy PartitionLink, so the draws interleave over them in the sending partition's processing order
+    dict(name="parallel_linked_loss", kind="linked", lanes=4, rate=[8.0, 5.0, 12.0, 3.0], seed=74, end_s=12.0, hop_latency=0.05,
+         packet_loss=[0.25], coord_seed=74, stages=[dict(svc="exp", mean=[0.1, 0.15, 0.06, 0.2]), dict(svc="const", mean=0.0)]),
+    # ... three stages, the FIRST PartitionLink lossy: what the second partition forwards depends on what survived
+    dict(name="parallel_linked_loss_three", kind="linked", lanes=3, rate=[6.0, 9.0, 4.0], seed=75, end_s=10.0, hop_latency=0.02,
+         packet_loss=[0.4, 0.0], coord_seed=75,
+         stages=[dict(svc="exp", mean=[0.1, 0.08, 0.2], concurrency=2, queue_cap=3), dict(svc="const", mean=0.0), dict(svc="const", mean=0.0)]),
 ]
 
 

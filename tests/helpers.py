@@ -675,8 +675,9 @@ def pipeline_oracle_graph(spec):
                              queue_cap=-1 if stg.get("queue_cap") is None else int(stg["queue_cap"]), stream_base=k * lanes + j)
                     for j in range(lanes)])
     snk = [g.sink() for _ in range(lanes)]
+    ploss = spec.get("packet_loss") or [0.0] * (len(stages) - 1)       # PartitionLink.packet_loss of the pair the hop crosses
     for k in range(len(stages) - 1):
-        lnk.append([g.link(spec["hop_latency"], spec.get("hop_jitter"), stream_base=k * lanes + j) for j in range(lanes)])
+        lnk.append([g.link(spec["hop_latency"], spec.get("hop_jitter"), stream_base=k * lanes + j, ploss=ploss[k]) for j in range(lanes)])
     for j in range(lanes):
         g.target[src[j]] = srv[0][j]
         for k in range(len(stages)):

@@ -612,3 +612,79 @@ def test_plain_probe_arrays_equal_the_per_station_lowering():
         L.plain_probe_arrays(pc, [hs.Probe.on(entities[0], "depth")[0] for _ in range(5)], L.StationArrays.uniform(80))
     with pytest.raises(hs.UnsupportedTopology, match="not an attribute"):
         L.plain_probe_arrays(pc, [hs.Probe.on(entities[0], "events_received")[0]], L.StationArrays.uniform(80))
+
+
+def test_partition_link_is_the_reference_value_type():
+    """parallel/link.py:18-79 and the reference's tests/unit/test_partition_link.py: defaults, the three ValueErrors, bidirectional()."""
+    lk = hs.PartitionLink("A", "B", min_latency=0.01)
+    assert lk.packet_loss == 0.0 and lk.latency is None
+    with pytest.raises(ValueError, match="min_latency must be > 0"):
+        hs.PartitionLink("A", "B", min_latency=0.0)
+    with pytest.raises(ValueError, match="packet_loss must be in"):
+        hs.PartitionLink("A", "B", min_latency=0.01, packet_loss=1.0)
+    with pytest.raises(ValueError, match="packet_loss must be in"):
+        hs.PartitionLink("A", "B", min_latency=0.01, packet_loss=-0.1)
+    with pytest.raises(ValueError, match="source and dest must differ"):
+        hs.PartitionLink("A", "A", min_latency=0.01)
+    a_to_b, b_to_a = hs.PartitionLink.bidirectional("X", "Y", min_latency=0.1, packet_loss=0.05)
+    assert (a_to_b.source_partition, a_to_b.dest_partition, b_to_a.source_partition, b_to_a.dest_partition) == ("X", "Y", "Y", "X")
+    assert a_to_b.packet_loss == b_to_a.packet_loss == 0.05 and a_to_b.min_latency == b_to_a.min_latency == 0.1
+
+
+def test_partition_link_losses_are_replayed_until_a_run_reproduces_them():
+    """Host logic of `PartitionLink.packet_loss` without a GPU (happy_simulator_amd/parallel.py `_replay_partition_losses`): stand-in
+    shards whose sends FOLLOW the loss decisions (a cycle back into the sending partition: what link 1 loses never comes back as a
+    send of link 0) -- the loop must settle on the decisions of ONE `random.Random(seed)` drawn in send-time order, and the run it
+    returns must be the one that ran with exactly those decisions."""
+    import random
+    import types
+
+    from happy_simulator_amd.parallel import ParallelSimulation
+
+    base = {0: [10 * k + 3 for k in range(40)], 1: [10 * k + 7 for k in range(40)]}     # link -> send times without any loss
+    p_of = {0: 0.3, 1: 0.5}
+
+    class Eng:
+        def __init__(self, links):
+            self.links, self.drops = links, {l: np.zeros(0, bool) for l in links}
+
+        def set_link_drops(self, local, drops):
+            self.drops[self.links[local]] = np.asarray(drops, bool).copy()
+
+        def sends(self):
+            d1 = self.drops.get(1, np.zeros(0, bool))
+            out = {1: list(base[1])}
+            # a packet of link 1 that survives comes back 4 ns later as an extra send of link 0
+            extra = [t + 4 for e, t in enumerate(base[1]) if not (e < len(d1) and d1[e])]
+            out[0] = sorted(base[0] + extra)
+            return out
+
+        def send_log(self):
+            rows = [(t, l, e) for l, ts in self.sends().items() if l in self.links for e, t in enumerate(ts)]
+            return np.array(rows, np.int64).reshape(-1, 3)
+
+    class Comm:
+        def gather_rows(self, arrays):
+            return np.concatenate(arrays, axis=0)
+
+    eng = Eng([0, 1])
+    shard = types.SimpleNamespace(engine=eng, lo=0, hi=1, gids=np.array([0, 1]))
+    runs = []
+    sn = types.SimpleNamespace(shards=[shard], run_until=lambda end: runs.append({l: d.copy() for l, d in eng.drops.items()}) or len(runs))
+    me = types.SimpleNamespace(_lossy_links=p_of, _seed=11, _graph=types.SimpleNamespace(links=[(None, 0, 5), (None, 0, 6)]))
+    got = ParallelSimulation._replay_partition_losses(me, sn, Comm(), 0, 10**9)
+    assert 2 <= got == len(runs) <= 45                       # the summary of the LAST run, which ran with the settled decisions
+    # the fixed point: draw in send-time order over the sends of the settled run
+    rng = random.Random(11)
+    rows = sorted((t, l, e) for l, ts in eng.sends().items() for e, t in enumerate(ts))
+    want = {0: [], 1: []}
+    for t, l, e in rows:
+        want[l].append(rng.random() < p_of[l])
+    for l in (0, 1):
+        d = np.zeros(len(want[l]), bool)
+        d[:len(eng.drops[l])] = eng.drops[l][:len(want[l])]
+        assert d.tolist() == want[l], l
+    # two hops sending on one nanosecond: refused by name
+    base[1][5] = base[0][5]
+    with pytest.raises(hs.UnsupportedTopology, match="same nanosecond"):
+        ParallelSimulation._replay_partition_losses(me, sn, Comm(), 0, 10**9)

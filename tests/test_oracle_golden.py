@@ -397,6 +397,56 @@ def test_oracle_matches_linked_partition_pipelines(name):
     assert abs(sn["total_events"] - gold.meta["seq_future"]["total_events"] - sum(sn["packets_sent"])) <= 1
 
 
+@pytest.mark.parametrize("name", ["parallel_linked_loss", "parallel_linked_loss_three"])
+def test_oracle_matches_partition_links_that_lose_packets(name):
+    """`PartitionLink(packet_loss=p)` (parallel/link.py:31-39): the reference's coordinator drops a cross-partition event at the
+    exchange when `self._rng.random() < link.packet_loss` -- ONE `random.Random(seed)` for the whole run
+    (parallel/coordinator.py:68,203-205), drawn in (window, source partition, outbox) order.  While every lossy PartitionLink leaves
+    one partition that is the partition's own processing order of the sending events, i.e. the order of ONE heap -- the oracle draws
+    CPython's MT19937 `random()` there (hso_graph.ploss, hso_params.coord_seed).  Against the LIVE windowed run of the fixture
+    (tests/golden/make_golden.py run_parallel_linked_case): every Server statistic, every Sink record, what each hop took in."""
+    gold = H.Golden(name)
+    spec = gold.spec
+    assert sum(1 for p in spec["packet_loss"] if p > 0) == 1
+    g, srv, lnk, snk, src = H.pipeline_oracle_graph(spec)
+    r = O.run(g, H.ns_from_seconds(spec["end_s"]), seed=spec["seed"], coord_seed=spec["coord_seed"])
+    win = gold.meta["windowed"]
+    assert sum(win["time_travel_drops"].values()) == 0                 # the windowed run is self-consistent: it lost nothing else
+    flat = [x for row in srv for x in row]
+    links = [x for row in lnk for x in row]
+    np.testing.assert_array_equal(np.concatenate([r.sinks[k][0] for k in snk]), gold.win_sink_t_ns)
+    lat = np.concatenate([(r.sinks[k][0] - r.sinks[k][1]).astype(np.float64) / 1e9 for k in snk])
+    np.testing.assert_array_equal(lat, gold.win_sink_latency_s)
+    np.testing.assert_array_equal(r.received[snk], gold.win_received)
+    np.testing.assert_array_equal(r.completed[flat], gold.win_completed)
+    np.testing.assert_array_equal(r.total_service_s[flat], gold.win_total_service_s)
+    # the partitions of the windowed run each process ONE event of their own beyond end_time (the single heap: one in all), so an
+    # upstream Server may have taken in one more request there, and a hop one more packet
+    lanes = spec["lanes"]
+    d_acc = gold.win_accepted - r.accepted[flat]
+    assert (d_acc >= 0).all() and d_acc.sum() <= len(spec["stages"])
+    d_hop = gold.win_hop_entered - (r.packets_sent[links] + r.dropped[links] + _in_flight(r, links, g))
+    assert (d_hop >= 0).all() and d_hop.sum() <= len(spec["stages"]) - 1
+    # what was lost: the lossy hops dropped a share of what entered them close to p, the others nothing
+    for k, p in enumerate(spec["packet_loss"]):
+        dropped = int(r.dropped[lnk[k]].sum())
+        entered = int((r.packets_sent[lnk[k]] + r.dropped[lnk[k]]).sum())
+        assert (dropped == 0) if p == 0 else abs(dropped / entered - p) < 0.08
+    # delivered cross-partition events: the coordinator counts what it injected (incl. events beyond end_time)
+    delivered = int(r.packets_sent[links].sum())
+    assert 0 <= win["total_cross_partition_events"] - delivered <= len(links)
+
+
+def _in_flight(r, links, g):
+    """Packets that entered a link before end_time and arrive behind it (neither sent-through nor dropped in the oracle's counters):
+    the difference between what the link's source Server forwarded and what the link counted."""
+    out = np.zeros(len(links), np.int64)
+    for i, l in enumerate(links):
+        up = [n for n in range(len(g)) if g.target[n] == l]
+        out[i] = int(r.completed[up].sum()) - int(r.packets_sent[l] + r.dropped[l])
+    return out
+
+
 @pytest.mark.parametrize("name", H.golden_names("graph"))
 def test_oracle_matches_reference_on_arbitrary_graphs(name):
     """Graphs the engines still refuse -- a RandomRouter with eight targets (Sinks, links, Servers), NetworkLinks with several senders,
