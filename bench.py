@@ -45,20 +45,46 @@ BYTES_PER_REQUEST = 16
 STATE_BYTES_PER_LP = 576
 SURVEY_BYTES_PER_EVENT = 128        # traffic of an engine that materialises every event
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-N_SIMD = 256 * 4                    # 256 CUs x 4 SIMD16 (same guide)
+HBM_STREAM_GBS = 6290.0             # same guide: 6.29 TB/s measured (float4 copy, 79 % of the spec) -- SURVEY 8(d)'s second denominator
+N_SIMD = 256 * 4                    # 256 CUs x 4 SIMD-32 (same guide, "Wave scheduling": a wave64 32-bit VALU op issues over 2 cycles)
 PEAK_CLOCK_HZ = 2.4e9               # peak engine clock
-VALU_CYCLES_PER_WAVE_INST = 4       # a 64-wide wavefront instruction on a SIMD16: the lower bound (fp64 FMA / 32-bit ops; quarter-rate ops take 16)
+VALU_MIN_CYCLES_PER_WAVE_INST = 2   # the cheapest class (32-bit): the flat lower bound; binary64 / 64-bit integer ops take 4, v_rcp_f64 16
+                                    # (measured per class: tools/valu_rates.hip -> profiles/r06_valu_rates.json)
 
 
 def valu_frac(prof, kernel_s):
-    """wave-instructions x cycles / SIMD-cycles available -- the share of the device's VALU issue slots the
-    dominant kernel's vector instructions need at the minimum 4 cycles each (SQ_INSTS_VALU of the committed SQ pass; the instruction
-    count of a deterministic run does not depend on the box).  None without a profile of this workload."""
+    """Wave-instructions x the CHEAPEST class's 2 cycles / SIMD-cycles available: the flat lower bound on the share of the device's
+    VALU issue slots the dominant kernel's vector instructions need (SQ_INSTS_VALU of the committed SQ pass; the instruction count of
+    a deterministic run does not depend on the box).  Rounds 4-5 priced every instruction at 4 cycles "on a SIMD16" -- wrong on both
+    counts; the class-weighted figure is `valu_floor_frac`.  None without a profile of this workload."""
     try:
         insts = float(prof["SQ_per_launch"]["SQ_INSTS_VALU"])
     except Exception:
         return None
-    return insts * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * PEAK_CLOCK_HZ * kernel_s)
+    return insts * VALU_MIN_CYCLES_PER_WAVE_INST / (N_SIMD * PEAK_CLOCK_HZ * kernel_s)
+
+
+def valu_floor(workload, kernel_s):
+    """the class-weighted issue floor.  profiles/r*_valu_floor_<workload>.json (profiles/derive_valu_floor.py) holds
+    the kernel's DYNAMIC instruction counts by class (rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 / _INT32 / _INT64 / _CVT) times
+    the issue cost of each class measured on an MI355X at the kernel's occupancy (tools/valu_rates.hip), summed per SIMD: the time the
+    vector instructions alone need when every issue slot is used.  Returns (fraction of the measured kernel time, details)."""
+    import glob
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_valu_floor_{workload}.json")))
+    if not paths:
+        return None, None
+    try:
+        d = json.load(open(paths[-1]))
+        floor_s = float(d["floor_simd_ns_per_launch"]) * 1e-9
+    except Exception:
+        return None, None
+    det = {"floor_us_per_launch": floor_s * 1e6, "waves_per_simd": d.get("waves_per_simd"),
+           "classes": [{"class": c["class"], "wave_insts": c["wave_insts_per_launch"], "priced_as": c["priced_as"],
+                        "cycles_at_2p4GHz": round(c["cycles_at_2p4GHz"], 2)} for c in d.get("classes", [])],
+           "profile": os.path.relpath(paths[-1], ROOT), "rates": d.get("rates_file"),
+           "profile_is_of_this_code": d.get("csrc_sha16") == csrc_sha16()}
+    return floor_s / kernel_s, det
 
 
 def csrc_sha16():
@@ -325,6 +351,10 @@ def ring_main(args, ctx):
                 "achieved": algo_bytes / step_s / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": algo_bytes / step_s / 1e9 / HBM_PEAK_GBS,
                 "frac_survey_8d": events * SURVEY_BYTES_PER_EVENT / step_s / 1e9 / HBM_PEAK_GBS,
+                "frac_of_measured_stream": algo_bytes / step_s / 1e9 / HBM_STREAM_GBS,
+                # class-weighted issue floor at ONE wavefront per SIMD (a lone in-order instruction stream issues one vector instruction
+                # per ~5 cycles whatever its class: profiles/r06_valu_rates.json, W = 1) and the flat 2-cycle bound
+                "valu_floor_frac": valu_floor("ring", step_s)[0] if (async_engine and n_ranks == 1 and args.n_lp == 65536) else None,
                 "valu_frac": valu_frac(prof, step_s) if (prof and async_engine and n_ranks == 1 and args.n_lp == 65536) else None,
                 "traffic": prof.get("hbm_bytes_per_launch") if (prof and prof.get("current") and async_engine and n_ranks == 1 and args.n_lp == 65536) else None,   # (the profile is of the one-engine 65 536-station run)
                 "valu": None if not (prof and async_engine and "valu_busy_frac" in prof) else {
@@ -562,6 +592,7 @@ def grid_main(args, ctx, headline=True):
     prof = measured_roofline("grid")
     full = n_mine == 65536 and args.end_s == 60.0      # the configuration the profile was taken on
     traffic = prof["hbm_bytes_per_launch"] if (prof and prof.get("current") and full and "hbm_bytes_per_launch" in prof) else None
+    vf_frac, vf_det = valu_floor("grid", k_avg_ms * 1e-3)
     out = {
         "metric": "committed events/sec (whole node), 65 536-server M/M/1 grid",
         "value": total_events_per_step * args.steps / elapsed,
@@ -602,7 +633,13 @@ def grid_main(args, ctx, headline=True):
             # SURVEY 8(d)'s own model (128 B per reference event) against the HBM peak: above 1, i.e. the kernel does NOT move per-event
             # records (it counts the ~7.6 protocol events of a request analytically); `frac` above prices what it does move
             "frac_survey_8d": survey_model / HBM_PEAK_GBS,
-            # the binding resource: vector instructions issued x 4 cycles / (1 024 SIMDs x 2.4 GHz x kernel time)
+            # SURVEY 8(d) also asks for the fraction of the MEASURED stream bandwidth (6.29 TB/s)
+            "frac_of_measured_stream": achieved / HBM_STREAM_GBS,
+            # the binding resource.  valu_floor_frac: the kernel's dynamic instruction counts by class x the issue cost of each class
+            # measured on this device type at the kernel's two wavefronts per SIMD, / kernel time (what is left is dependency stalls of
+            # two in-order instruction streams per SIMD + LDS hand-over waits); valu_frac: the flat bound, every instruction at 2 cycles
+            "valu_floor_frac": vf_frac if full else None,
+            "valu_floor": vf_det if full else None,
             "valu_frac": valu_frac(prof, k_avg_ms * 1e-3) if full else None,
             "traffic": traffic,
             "valu": None if not prof or "valu_busy_frac" not in prof else {

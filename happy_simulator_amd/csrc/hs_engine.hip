@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <new>
@@ -1414,6 +1415,9 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
         HS_HIP(h, hipMemset(ck, 0, N * 4 * sizeof(long long)));
         HS_HIP(h, hipMemcpy(&h->tot->net_cand_key, &ck, sizeof ck, hipMemcpyHostToDevice));
     }
+#ifndef HS_LOGS_ROW_MAJOR   // (scratch build: the [cap][n_lp] logs the network engines had until round 5)
+    h->L.lp_major = 1;          // an LP's records contiguous (hs_station.hpp RecordLogs::lp_major); nothing has been logged yet
+#endif
     h->is_net = true;
     return HS_OK;
 }
@@ -1988,17 +1992,23 @@ int hs_engine_bench_runs(hs_engine *h, int64_t end_ns, int32_t repeats, float *k
     HS_HIP(h, hipSetDevice(h->cfg.device));
     std::vector<hipEvent_t> ev((size_t)repeats * 2 + 2);
     for (auto &e : ev) HS_HIP(h, hipEventCreate(&e));
+    // Round 6: the kernel duration is SAMPLED on every eighth repeat instead of bracketed on every one.  An event pair is two barrier
+    // packets on the stream; around a 90 us step (the strong shard) they were 13.7 us of every step the caller's clock saw (measured:
+    // 0.1078 against 0.0941 ms per step).  A repeat without a pair reports the latest sample.  HS_BENCH_STEP_EVENTS=1 brackets every
+    // repeat as before, =0 none (every repeat then reports the batch average).
+    static const int step_events_mode = []() { const char *e = getenv("HS_BENCH_STEP_EVENTS"); return e ? (e[0] == '0' ? 0 : 1) : 2; }();
+    auto step_events_at = [&](int r) { return step_events_mode == 1 || (step_events_mode == 2 && (r & 7) == 0); };
     for (int attempt = 0; attempt < 2; ++attempt) {
         HS_HIP(h, hipEventRecord(ev[(size_t)repeats * 2], h->stream));
         for (int r = 0; r < repeats; ++r) {
             int rc = do_reset_async(h);
             if (rc) return rc;
-            HS_HIP(h, hipEventRecord(ev[(size_t)2 * r], h->stream));
+            if (step_events_at(r)) HS_HIP(h, hipEventRecord(ev[(size_t)2 * r], h->stream));
             { int rc1 = launch_prologue(h, end_ns); if (rc1) return rc1; }
             if (h->is_net) { h->launches = 0; int rc2 = run_net_async(h, end_ns); if (rc2) return rc2; }
             else { const int rc2 = launch_run_dispatch(h, end_ns); if (rc2) return rc2; }
             HS_HIP(h, hipGetLastError());
-            HS_HIP(h, hipEventRecord(ev[(size_t)2 * r + 1], h->stream));
+            if (step_events_at(r)) HS_HIP(h, hipEventRecord(ev[(size_t)2 * r + 1], h->stream));
         }
         HS_HIP(h, hipEventRecord(ev[(size_t)repeats * 2 + 1], h->stream));
         HS_HIP(h, hipStreamSynchronize(h->stream));
@@ -2008,14 +2018,14 @@ int hs_engine_bench_runs(hs_engine *h, int64_t end_ns, int32_t repeats, float *k
         if (!hazard) break;
         h->lazy_failed = true;
     }
-    for (int r = 0; r < repeats; ++r) {
-        float ms = 0.f;
-        HS_HIP(h, hipEventElapsedTime(&ms, ev[(size_t)2 * r], ev[(size_t)2 * r + 1]));
-        if (kernel_ms_out) kernel_ms_out[r] = ms;
-        h->last_kernel_ms = ms;
-    }
     float tot_ms = 0.f;
     HS_HIP(h, hipEventElapsedTime(&tot_ms, ev[(size_t)repeats * 2], ev[(size_t)repeats * 2 + 1]));
+    float sample_ms = tot_ms / (float)repeats;
+    for (int r = 0; r < repeats; ++r) {
+        if (step_events_at(r)) HS_HIP(h, hipEventElapsedTime(&sample_ms, ev[(size_t)2 * r], ev[(size_t)2 * r + 1]));
+        if (kernel_ms_out) kernel_ms_out[r] = sample_ms;
+        h->last_kernel_ms = sample_ms;
+    }
     if (total_ms_out) *total_ms_out = tot_ms;
     h->last_run_ms = tot_ms / (float)repeats;
     if (!h->is_net) h->launches = 2;
@@ -2099,7 +2109,7 @@ int64_t hs_engine_read_sink(hs_engine *h, int32_t lp, int64_t *t_ns, int64_t *cr
         for (int c = 0; c < 2; ++c) {
             if (!dsts[c]) continue;
             hipLaunchKernelGGL(hs_gather_one, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, cols[c], tmp,
-                               h->cfg.n_lp, lp, cnt);
+                               h->cfg.n_lp, lp, cnt, h->L.lp_major ? h->L.cap : (int64_t)0);
             if (hipStreamSynchronize(h->stream) != hipSuccess ||
                 hipMemcpy(dsts[c], tmp, (size_t)cnt * 8, hipMemcpyDeviceToHost) != hipSuccess) {
                 hipFree(tmp);
@@ -2143,7 +2153,7 @@ int64_t hs_engine_read_sinks(hs_engine *h, int64_t *counts, int64_t *t_ns, int64
     for (int c = 0; c < 2 && ok; ++c) {
         if (!dsts[c]) continue;
         const dim3 grid((unsigned)((n + 63) / 64), (unsigned)((maxc + 63) / 64));
-        hipLaunchKernelGGL(hs_gather_logs, grid, dim3(256), 0, h->stream, cols[c], h->X.received, d_off, d_out, (int)n, cap);
+        hipLaunchKernelGGL(hs_gather_logs, grid, dim3(256), 0, h->stream, cols[c], h->X.received, d_off, d_out, (int)n, cap, (int)h->L.lp_major);
         ok = hipStreamSynchronize(h->stream) == hipSuccess &&
              hipMemcpy(dsts[c], d_out, (size_t)total * 8, hipMemcpyDeviceToHost) == hipSuccess;
     }
@@ -2191,7 +2201,7 @@ int64_t hs_engine_read_probe_slot(hs_engine *h, int32_t lp, int32_t slot, int64_
         for (int c = 0; c < 2; ++c) {
             if (!dsts[c]) continue;
             hipLaunchKernelGGL(hs_gather_one, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, cols[c], tmp,
-                               h->cfg.n_lp, lp, cnt);
+                               h->cfg.n_lp, lp, cnt, (int64_t)0);
             if (hipStreamSynchronize(h->stream) != hipSuccess ||
                 hipMemcpy(dsts[c], tmp, (size_t)cnt * 8, hipMemcpyDeviceToHost) != hipSuccess) {
                 hipFree(tmp);

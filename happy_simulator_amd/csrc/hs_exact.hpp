@@ -340,7 +340,7 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
             const int64_t qcap = P.qcap[lp], buf = X.buf[lp];
             if (qcap >= 0 && buf >= qcap) { X.dropped[lp] += 1; break; }     // FIFOQueue.push refuses (queue_policy.py:94-98)
             const int64_t acc = X.accepted[lp];
-            if (acc < L.cap) L.adm[(size_t)acc * N + lp] = e.cr; else overflow |= 1;
+            if (acc < L.cap) L.adm[log_at(L, acc, lp, N)] = e.cr; else overflow |= 1;
             if (S.pool_n >= S.pool_cap) { S.err |= 2; break; }
             const int32_t pe = (int32_t)S.pool_n++;
             S.pidx[pe] = e.idx; S.pnext[pe] = -1;
@@ -388,7 +388,7 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
             const size_t sj = (size_t)j * N + lp;
             const int64_t k = e.cr;
             X.svc_s[sj] = s;
-            X.crt[sj] = k < L.cap ? L.adm[(size_t)k * N + lp] : 0;
+            X.crt[sj] = k < L.cap ? L.adm[log_at(L, k, lp, N)] : 0;
             const unsigned long long idx_c = S.G++;
             X.D[sj] = t + dur; X.seqD[sj] = (uint32_t)idx_c; X.crtD[sj] = t; X.dpD[sj] = lin_dp; X.rcD[sj] = S.ctx_rc;
             xpush(S, xev(t + dur, idx_c, XE_CONT, lp, 0, 0, (uint16_t)j));
@@ -414,7 +414,7 @@ __device__ inline bool exact_loop(const StationParams &P, const NetParams &NP, c
         } break;
         case XE_SINK: {                                                      // Sink.handle_event (components/common.py:36-44)
             const int64_t r = X.received[lp];
-            if (r < L.cap) { L.sink_t[(size_t)r * N + lp] = t; L.sink_created[(size_t)r * N + lp] = e.cr; } else overflow |= 1;
+            if (r < L.cap) { L.sink_t[log_at(L, r, lp, N)] = t; L.sink_created[log_at(L, r, lp, N)] = e.cr; } else overflow |= 1;
             X.received[lp] = r + 1; X.sink_w[lp] = r + 1; n_received++;
         } break;
         case XE_ROUTE: {                                                     // RandomRouter.handle_event (random_router.py:32-45)

@@ -942,10 +942,12 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF, UNI> &S, const 
     S.rte.init(S.seed, stream_id(S.route_base, kStreamRoute), NX.route_k[lp]);
 #pragma unroll
     for (int k = 0; k < 11; ++k) S.ev[k] = 0;
-    S.adm = L.adm + lp;
-    S.sink_t = L.sink_t + lp;
-    S.sink_created = L.sink_created + lp;
-    S.cap = L.cap; S.ls = n;
+    // (network engines keep their record logs LP-major, RecordLogs::lp_major: record k of this LP at [lp * cap + k])
+    const size_t log0 = L.lp_major ? (size_t)lp * (size_t)L.cap : (size_t)lp;
+    S.adm = L.adm + log0;
+    S.sink_t = L.sink_t + log0;
+    S.sink_created = L.sink_created + log0;
+    S.cap = L.cap; S.ls = n; S.lgs = L.lp_major ? 1 : n;
     S.overflow = 0; S.qoverflow = 0; S.bagoverflow = 0;
     S.np = &NP; S.ns = &NX; S.send_idx = send_idx;
     S.tid = tid;
@@ -988,7 +990,7 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF, UNI> &S, const 
         }
     }
     S.ha = S.na = S.hs_ = S.nsv = S.hj = S.nj = S.rn = 0; S.rbits = 0; S.fl_link = -1; S.fi_link = -1; S.fi_packets = 0;
-    S.fl_remote = false; S.fi_head = 0; S.fi_unpub = 0; S.win_hi = S.started;
+    S.fl_remote = false; S.fi_head = 0; S.fi_unpub = 0; S.fl_local = false; S.fi_local = false; S.win_hi = S.started;
     S.bh = 0; S.tail_hint = 0ull;
     S.presend = false; S.early_upto = S.completed; S.D_pre = S.last_time; S.fl_q = 0; S.end_ns = kInfNs;
     S.bag_n = NX.bag_cnt[lp];
@@ -1034,7 +1036,7 @@ __device__ __forceinline__ void load_net(NetStation<C, FAST, PF, UNI> &S, const 
         // the created_at window: the next kNRing requests to start, as far as they are admitted (read from the log)
         for (int i = 0; i < kNRing; ++i) {
             const int64_t k = S.started + i;
-            if (k < S.accepted) { S.fl.crc[k & (kNRing - 1)][tid] = k < S.cap ? S.adm[k * S.ls] : 0; S.win_hi = k + 1; }
+            if (k < S.accepted) { S.fl.crc[k & (kNRing - 1)][tid] = k < S.cap ? S.adm[k * S.lgs] : 0; S.win_hi = k + 1; }
         }
     }
     S.bmin = S.bag_scan_min();
@@ -1467,6 +1469,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         // state covers everything that state can still send).  Chains are cut where the previous lane is not the sender.
         int32_t next_l = -1;                                  // my link to the LP in the next lane, if any
         bool out_remote[2] = {false, false};                  // a shard: links that leave it go to an outbox row, no queue
+        const bool live = !UNI && SC.live != 0;               // ... LIVE exchange: to the queue in the destination rank's memory
 #pragma unroll
         for (int o = 0; o < kOut; ++o) {
             if (out_l[o] < 0) continue;
@@ -1486,6 +1489,11 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
         const bool quiet = (flags & (1 << 21)) == 0;
         const bool next_chain = quiet && next_l >= 0 && lane + 1 < lanes && __shfl_down(chain ? 1 : 0, 1, 64) != 0;
         bool pub_skipped = false;
+        // ... and such a link's records move at workgroup scope (hs_netstation.hpp wg_store_rec): both ends are lanes of this wavefront
+#ifndef HS_NO_WG_SCOPE   // (scratch build: every record at device scope, as until round 5)
+        S.fl_local = next_chain && next_l == S.fl_link;
+        S.fi_local = chain && quiet && my_in == S.fi_link;
+#endif
         const int64_t next_lat = next_l >= 0 ? NP.link_lat_ns[next_l] : 0;
         auto sat = [](int64_t a, int64_t b) { return (a == kInfNs || b == kInfNs) ? kInfNs : a + b; };
         int c_kind = -1;                                      // the sender map kept across the iteration boundary (bound_map)
@@ -1626,8 +1634,9 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
 #endif
                     const int64_t t = S.next_time();
                     bool act = !stop && t <= limit;
-                    if (act && !((out_remote[0] || S.async_can_send(out_l[0], head_seen[0])) &&
-                                 (UNI || out_remote[1] || S.async_can_send(out_l[1], head_seen[1])))) { blocked = true; act = false; }   // a consumer is behind: wait
+                    // (a link that leaves the shard: an outbox row takes what a round sends -- LIVE exchange: the queue in the peer's memory)
+                    if (act && !(((out_remote[0] && !live) || S.async_can_send(out_l[0], head_seen[0], out_remote[0])) &&
+                                 (UNI || (out_remote[1] && !live) || S.async_can_send(out_l[1], head_seen[1], out_remote[1])))) { blocked = true; act = false; }   // a consumer is behind: wait
                     stop = stop || !act;
                     if (!__any(act)) break;
 #ifdef HS_RINGSTAT
@@ -1687,6 +1696,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                     if (l < 0) continue;
                     if (S.sent_async || vo[o] > out_pub[o]) {
                         if (l == next_l && next_chain) pub_skipped = true;      // (its reader is the next lane: the scan and tail_hint)
+                        else if (live && out_remote[o]) S.live_publish(l, pk_pack(vo[o], (unsigned long long)S.link_sent_of(l), NX.pk_base));
                         else ag_store(&NX.aq_ea[l], pk_pack(vo[o], (unsigned long long)S.link_sent_of(l), NX.pk_base));
                         out_pub[o] = vo[o];
                     }
@@ -1942,11 +1952,22 @@ __global__ void hs_shard_overshoot(StationParams P, NetParams NP, StationState X
 // reads along lp, coalesced writes along k.
 __global__ void __launch_bounds__(256) hs_gather_logs(const int64_t *__restrict__ log, const int64_t *__restrict__ cnt,
                                                       const int64_t *__restrict__ off, int64_t *__restrict__ out, int n,
-                                                      int64_t cap) {
+                                                      int64_t cap, int lp_major) {
     __shared__ int64_t tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int lp0 = blockIdx.x * 64;
     const int64_t k0 = (int64_t)blockIdx.y * 64;
+    if (lp_major) {                 // network engines: every LP's records are contiguous already -- a copy of 64 LPs x 64 records
+        for (int l = ty; l < 64; l += 4) {
+            const int lp = lp0 + l;
+            if (lp >= n) continue;
+            int64_t c = cnt[lp];
+            c = c > cap ? cap : c;
+            const int64_t k = k0 + tx;
+            if (k < c) out[off[lp] + k] = log[(size_t)lp * cap + k];
+        }
+        return;
+    }
     for (int kk = ty; kk < 64; kk += 4) {
         const int64_t k = k0 + kk;
         const int lp = lp0 + tx;
@@ -1963,9 +1984,9 @@ __global__ void __launch_bounds__(256) hs_gather_logs(const int64_t *__restrict_
     }
 }
 // one LP's records (hs_engine_read_sink)
-__global__ void hs_gather_one(const int64_t *__restrict__ log, int64_t *__restrict__ out, int n, int lp, int64_t cnt) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < cnt) out[k] = log[(size_t)k * n + lp];
+__global__ void hs_gather_one(const int64_t *__restrict__ log, int64_t *__restrict__ out, int n, int lp, int64_t cnt, int64_t lp_major_cap) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // lp_major_cap > 0: an LP-major log of that capacity
+    if (k < cnt) out[k] = lp_major_cap > 0 ? log[(size_t)lp * lp_major_cap + k] : log[(size_t)k * n + lp];
 }
 
 __global__ void hs_debug_draws_kernel(uint64_t seed, uint64_t sid, uint64_t k0, int64_t n, double rate, double *u,

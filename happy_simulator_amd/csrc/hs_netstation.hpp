@@ -91,6 +91,16 @@ struct ShardCtl {
                                   //      of the rank's first event beyond end_ns (the election's key)
     const int32_t *link_rank;     // [n_links] rank that owns the link's destination station
     int32_t msg_cap, row, rank, world;
+    // LIVE exchange (round 6): no launch boundary per round -- a station whose link leaves the shard appends to the link's queue in
+    // the DESTINATION rank's memory (peer-mapped: hipIpcOpenMemHandle / xGMI peer access) and publishes the link's (bound, tail)
+    // word there, with system-scope stores, while both ranks' hs_net_async kernels run; the receiver polls its own memory and
+    // writes the positions it has taken where the sender reads them.  `live` != 0: per rank r the base of its link-queue records,
+    // words and positions, and per link the index it has in its destination rank's link table.
+    int32_t live;
+    int64_t *const *peer_rec;     // [world] NetState::aq_rec of rank r
+    int64_t *const *peer_ea;      // [world] NetState::aq_ea
+    unsigned long long *const *peer_head;   // [world] NetState::aq_head
+    const int32_t *peer_link;     // [n_links] the link's index at its destination rank (-1: the destination is here)
 };
 
 struct NetState {
@@ -152,6 +162,25 @@ __device__ __forceinline__ void ag_store_rec(int64_t *rec, int64_t w0, int64_t w
 }
 __device__ __forceinline__ int64_t ag_load(const int64_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// ... and into ANOTHER rank's memory (ShardCtl::live): system scope
+__device__ __forceinline__ void sys_store_rec(int64_t *rec, int64_t w0, int64_t w1, int64_t w2, int64_t w3) {
+    typedef long long v2i64 __attribute__((ext_vector_type(2)));
+    const v2i64 lo = {w0, w1}, hi = {w2, w3};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1" ::"v"(rec), "v"(lo), "v"(hi) : "memory");
+}
+// Round 6: a link whose two ends are lanes of ONE wavefront (63 of 64 links of the ring) moves its records at WORKGROUP scope: the
+// CU's own L1 / L2 path is coherent for them, so the record is a plain write-back line -- two records fill one 64-byte line, written
+// to HBM once when the L2 evicts it -- instead of two 16-byte write-through transactions per record and a fetch past the L2 per
+// read (measured on the headline ring: WRITE_SIZE 2.8 GB against 1.05 GB of records and log appends).  The order between the
+// sender's stores and the receiver's loads is the iteration boundary's vmcnt(0) drain, as for the device-scope path.
+__device__ __forceinline__ void wg_store_rec(int64_t *rec, int64_t w0, int64_t w1, int64_t w2, int64_t w3) {
+    typedef long long v2i64 __attribute__((ext_vector_type(2)));
+    const v2i64 lo = {w0, w1}, hi = {w2, w3};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0" ::"v"(rec), "v"(lo), "v"(hi) : "memory");
+}
+__device__ __forceinline__ int64_t wg_load(const int64_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // the bound word of a link: everything the producer made visible before it published this value must be seen by the
 // loads that FOLLOW this one (the tail, the payload) -- an acquire, not just program order: two relaxed loads of different
@@ -310,8 +339,8 @@ struct NetStation {
     const int64_t *sc_t;
     const uint32_t *sc_idx;       // true sort indices of the injected Requests (after the prologue, hs_exact.hpp), or null
     // logs
-    int64_t *adm, *sink_t, *sink_created;   // record k at [k * ls] (hs_station.hpp)
-    int64_t cap, ls;
+    int64_t *adm, *sink_t, *sink_created;   // record k at [k * lgs] (RecordLogs::lp_major: 1 for network engines, else n_lp)
+    int64_t cap, ls, lgs;                   // ls: stride of the other per-LP columns ([slot][n_lp]: in-group FIFO lineage, probe logs)
     int overflow, qoverflow, bagoverflow;
     // network
     const NetParams *np;
@@ -365,6 +394,7 @@ struct NetStation {
     int64_t fi_packets;
     unsigned long long fi_head;   // ... and this LP's position in that link's queue (the only writer of aq_head[fi_link])
     int32_t fi_unpub;             // ... messages taken since aq_head[fi_link] was last written (head_taken)
+    bool fl_local, fi_local;      // hs_net_async: the outgoing / the incoming link's other end is a lane of this wavefront (wg_store_rec)
     // in-group FIFO (an LDS column) + ENQ payloads (an LDS column, or global memory in hs_net_async: entry k at enq[k * enq_stride])
     uint8_t (*qmem)[kBlock];
     int64_t *enq;
@@ -717,7 +747,7 @@ struct NetStation {
         ev[1]++;
         if (HSU(qcap >= 0, false) && buf >= qcap) { dropped++; return false; }
         const bool was_empty = (buf == 0);
-        if (accepted < cap) adm[accepted * ls] = created; else overflow = 1;
+        if (accepted < cap) adm[accepted * lgs] = created; else overflow = 1;
         if constexpr (FAST) window_admit(created);
         accepted++; buf++;
         return was_empty;
@@ -738,7 +768,7 @@ struct NetStation {
                 const int64_t j = win_hi + i;
                 const bool need = act && j < hi;
                 if (!__any(need)) break;
-                if (need) fl.crc[j & (kNRing - 1)][tid] = (j < cap) ? adm[j * ls] : 0;
+                if (need) fl.crc[j & (kNRing - 1)][tid] = (j < cap) ? adm[j * lgs] : 0;
             }
             if (act && hi > win_hi) win_hi = hi;
         }
@@ -753,8 +783,8 @@ struct NetStation {
         if constexpr (FAST) {
             const int64_t lim = started + kNRing;
             const int64_t hi = accepted < lim ? accepted : lim;
-            if (act && win_hi < hi) { v0 = (win_hi < cap) ? adm[win_hi * ls] : 0; cnt = 1; }
-            if (act && win_hi + 1 < hi) { v1 = (win_hi + 1 < cap) ? adm[(win_hi + 1) * ls] : 0; cnt = 2; }
+            if (act && win_hi < hi) { v0 = (win_hi < cap) ? adm[win_hi * lgs] : 0; cnt = 1; }
+            if (act && win_hi + 1 < hi) { v1 = (win_hi + 1 < cap) ? adm[(win_hi + 1) * lgs] : 0; cnt = 2; }
         }
         return cnt;
     }
@@ -770,7 +800,7 @@ struct NetStation {
     __device__ __forceinline__ int64_t window_take(int64_t k) {
         int64_t created;
         if (k < win_hi) created = fl.crc[k & (kNRing - 1)][tid];
-        else created = (k < cap) ? adm[k * ls] : 0;                   // (more than kNRing starts since the last fill: synchronous)
+        else created = (k < cap) ? adm[k * lgs] : 0;                   // (more than kNRing starts since the last fill: synchronous)
         if (win_hi <= k) win_hi = k + 1;
         return created;
     }
@@ -793,7 +823,7 @@ struct NetStation {
         int64_t created;
         if (have_created) created = known_created;
         else if constexpr (FAST) created = window_take(k);             // no global round trip
-        else created = (k < cap) ? adm[k * ls] : 0;
+        else created = (k < cap) ? adm[k * lgs] : 0;
         if constexpr (FAST) { if (win_hi <= k) win_hi = k + 1; }
         int j = 0;
 #pragma unroll
@@ -825,6 +855,23 @@ struct NetStation {
             m[0] = t_arr; m[1] = t; m[2] = created; m[3] = ((int64_t)dst << 32) | gid; m[4] = lin;
         } else bagoverflow = 1;
     }
+    // LIVE exchange: message number `seq` of a link that leaves the shard goes straight into the link's queue in the destination
+    // rank's memory (the caller publishes the link's word behind a drain of these stores, as for a local queue)
+    __device__ __forceinline__ int64_t *live_rec(int32_t l, unsigned long long seq) const {
+        const int r = sc->link_rank[l];
+        const size_t slot = (size_t)sc->peer_link[l] * ns->aq_cap + (size_t)(seq & (unsigned long long)(ns->aq_cap - 1));
+        return sc->peer_rec[r] + 4 * slot;
+    }
+    __device__ __forceinline__ void live_append(int32_t l, unsigned long long seq, int64_t t_arr, int64_t t_send, int64_t created, int64_t lin) {
+        sys_store_rec(live_rec(l, seq), t_arr, t_send, created, lin);
+        sent_async = true;
+    }
+    __device__ __forceinline__ void live_publish(int32_t l, int64_t word) const {
+        __hip_atomic_store(sc->peer_ea[sc->link_rank[l]] + sc->peer_link[l], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __device__ __forceinline__ unsigned long long live_head(int32_t l) const {
+        return __hip_atomic_load(sc->peer_head[sc->link_rank[l]] + sc->peer_link[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __device__ __forceinline__ int64_t link_sent_of(int32_t l) const {   // the link queue's sequence number
         if constexpr (FAST) { if (l == fl_link) return fl_q; }
         return ns->link_sent[l];
@@ -833,9 +880,17 @@ struct NetStation {
     __device__ __forceinline__ void fl_append(int64_t t_arr, int64_t t_send, int64_t created, int64_t lin) {
         sent_min = t_arr < sent_min ? t_arr : sent_min;
         ++fl_q;
-        if (HSU(fl_remote, false)) { outbox_append(fl_link, fl_dst, t_arr, t_send, created, lin); return; }
+        if (HSU(fl_remote, false)) {
+            if (sc->live) { live_append(fl_link, (unsigned long long)fl_q - 1ull, t_arr, t_send, created, lin); return; }
+            outbox_append(fl_link, fl_dst, t_arr, t_send, created, lin);
+            return;
+        }
         const size_t slot = (size_t)fl_link * ns->aq_cap + (size_t)(((unsigned long long)fl_q - 1) & (unsigned long long)(ns->aq_cap - 1));
-        ag_store_rec(&ns->aq_rec[4 * slot], t_arr, t_send, created, lin);
+#ifndef HS_NO_WG_SCOPE
+        if (fl_local) wg_store_rec(&ns->aq_rec[4 * slot], t_arr, t_send, created, lin);
+        else
+#endif
+            ag_store_rec(&ns->aq_rec[4 * slot], t_arr, t_send, created, lin);
         sent_async = true;
     }
     // steps from a Server's continuation to the NetworkLink's continuation it causes: Request@Link, the link's continuation
@@ -901,7 +956,8 @@ struct NetStation {
         const int32_t dst = np->link_dst[l];                 // network-wide station index
         const int64_t lin = lin_pack(dp_next(link_steps()), cr, t);
         if (link_is_remote(l)) {                             // destination lives on another engine
-            outbox_append(l, dst, t_arr, t, created, lin);
+            if (sc->live) live_append(l, (unsigned long long)ns->link_sent[l] - 1ull, t_arr, t, created, lin);
+            else outbox_append(l, dst, t_arr, t, created, lin);
             return;
         }
         if (ns->aq_on) {
@@ -953,7 +1009,7 @@ struct NetStation {
         }
         if (target == -1) {              // Sink.handle_event (components/common.py:36-44)
             ev[7]++;
-            if (received < cap) { sink_t[received * ls] = t; sink_created[received * ls] = created; } else overflow = 1;
+            if (received < cap) { sink_t[received * lgs] = t; sink_created[received * lgs] = created; } else overflow = 1;
             received++;
         } else if (target >= 0) send_link(target, t, created);
     }
@@ -1002,6 +1058,11 @@ struct NetStation {
         fi_head = head;
         if ((long long)(tail - head) + fi_unpub >= (long long)(ns->aq_cap >> 1)) { ag_store(&ns->aq_head[l], head); fi_unpub = 0; }
     }
+#ifndef HS_NO_WG_SCOPE
+    __device__ __forceinline__ int64_t rec_load(const int64_t *p) const { return fi_local ? wg_load(p) : ag_load(p); }
+#else
+    __device__ __forceinline__ int64_t rec_load(const int64_t *p) const { return ag_load(p); }
+#endif
     __device__ __forceinline__ int64_t async_peek() const {
         if constexpr (FAST) { if (fi_link >= 0) return ag_load(&ns->aq_ea[fi_link]); }
         return 0;
@@ -1020,13 +1081,13 @@ struct NetStation {
             const int bcap = bag_capacity();
             for (; head < tail && bag_n < bcap; ++head) {
                 const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
-                const int64_t ta = ag_load(&ns->aq_rec[4 * slot]);
-                bag_insert(ta, ag_load(&ns->aq_rec[4 * slot + 1]), ag_load(&ns->aq_rec[4 * slot + 2]), l, ag_load(&ns->aq_rec[4 * slot + 3]));
+                const int64_t ta = rec_load(&ns->aq_rec[4 * slot]);
+                bag_insert(ta, rec_load(&ns->aq_rec[4 * slot + 1]), rec_load(&ns->aq_rec[4 * slot + 2]), l, rec_load(&ns->aq_rec[4 * slot + 3]));
             }
             head_taken(l, head, tail);
             if (head < tail) {
                 const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
-                undrained = ag_load(&ns->aq_rec[4 * slot + 1]) + np->link_lat_ns[l];
+                undrained = rec_load(&ns->aq_rec[4 * slot + 1]) + np->link_lat_ns[l];
             }
         }
         return ea;
@@ -1047,7 +1108,7 @@ struct NetStation {
             if (head + (unsigned long long)m < tail && m < room) {
                 const size_t slot = (size_t)l * ns->aq_cap + (size_t)((head + (unsigned long long)m) & (unsigned long long)(ns->aq_cap - 1));
 #pragma unroll
-                for (int q = 0; q < 4; ++q) r[4 * m + q] = ag_load(&ns->aq_rec[4 * slot + q]);
+                for (int q = 0; q < 4; ++q) r[4 * m + q] = rec_load(&ns->aq_rec[4 * slot + q]);
                 cnt = m + 1;
             }
         }
@@ -1064,13 +1125,13 @@ struct NetStation {
             const int bcap = bag_capacity();
             for (; head < tail && bag_n < bcap; ++head) {
                 const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
-                const int64_t ta = ag_load(&ns->aq_rec[4 * slot]);
-                bag_insert(ta, ag_load(&ns->aq_rec[4 * slot + 1]), ag_load(&ns->aq_rec[4 * slot + 2]), l, ag_load(&ns->aq_rec[4 * slot + 3]));
+                const int64_t ta = rec_load(&ns->aq_rec[4 * slot]);
+                bag_insert(ta, rec_load(&ns->aq_rec[4 * slot + 1]), rec_load(&ns->aq_rec[4 * slot + 2]), l, rec_load(&ns->aq_rec[4 * slot + 3]));
             }
             head_taken(l, head, tail);
             if (head < tail) {
                 const size_t slot = (size_t)l * ns->aq_cap + (size_t)(head & (unsigned long long)(ns->aq_cap - 1));
-                undrained = ag_load(&ns->aq_rec[4 * slot + 1]) + np->link_lat_ns[l];
+                undrained = rec_load(&ns->aq_rec[4 * slot + 1]) + np->link_lat_ns[l];
             }
         }
         return ea;
@@ -1110,11 +1171,11 @@ struct NetStation {
     // may send (one message per completion, at most C completions per group; a pre-sending station up to two per group)
     // `head_seen` caches the consumer's published position: it only moves forward, so a stale value errs on the safe
     // side and the (cache-bypassing) reload is needed only when the queue looks full
-    __device__ __forceinline__ bool async_can_send(int32_t l, unsigned long long &head_seen) const {
+    __device__ __forceinline__ bool async_can_send(int32_t l, unsigned long long &head_seen, bool remote = false) const {
         if (l < 0) return true;
         const unsigned long long sent = (unsigned long long)link_sent_of(l);
         if (sent - head_seen + 2ull * C <= (unsigned long long)ns->aq_cap) return true;
-        head_seen = ag_load(&ns->aq_head[l]);
+        head_seen = remote ? live_head(l) : ag_load(&ns->aq_head[l]);      // (LIVE exchange: the consumer is on another rank)
         return sent - head_seen + 2ull * C <= (unsigned long long)ns->aq_cap;
     }
     // Shortest duration among the next `free` services to start: service draws svc.k .. svc.k + free - 1, not consumed
@@ -1457,7 +1518,7 @@ struct NetStation {
         ev[1] += arrv;
         dropped += (arrv && !acc) ? 1 : 0;
         if (acc) {
-            if (accepted < cap) adm[accepted * ls] = created_in; else overflow = 1;
+            if (accepted < cap) adm[accepted * lgs] = created_in; else overflow = 1;
             window_admit(created_in);
         }
         if (acc && HSU(presend, true) && early_upto == accepted) {
@@ -1485,7 +1546,7 @@ struct NetStation {
         }
         if (to_sink) {
             ev[7]++;
-            if (received < cap) { sink_t[received * ls] = t; sink_created[received * ls] = created_out; } else overflow = 1;
+            if (received < cap) { sink_t[received * lgs] = t; sink_created[received * lgs] = created_out; } else overflow = 1;
             received++;
         }
         if (to_link) {                                                // send_link_fast without the loss branch

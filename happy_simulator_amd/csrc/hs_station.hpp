@@ -188,7 +188,16 @@ struct RecordLogs {
     int64_t cap;
     int64_t *probe_t, *probe_v; // [kMaxProbes][pcap][n_lp] sample time / sampled value
     int64_t pcap;
+    // Network engines (round 6): the three record logs are [n_lp][cap] instead -- an LP's records are contiguous.  The station
+    // kernels advance their lanes request by request in lock step, so a [cap][n_lp] row receives whole 128-byte lines; the LPs of
+    // the asynchronous network engine are at different records at any time, a row's line was written 8 bytes at a time over a
+    // stretch of the run longer than it survives in the L2 and went to HBM several times as partial sectors (WRITE_SIZE 3.3 GB
+    // against 1.05 GB of records on the headline ring).  LP-major, the line an LP appends to stays in the L2 until it is full.
+    int32_t lp_major;
 };
+__device__ __forceinline__ size_t log_at(const RecordLogs &L, int64_t k, int lp, int n) {
+    return L.lp_major ? (size_t)lp * (size_t)L.cap + (size_t)k : (size_t)k * (size_t)n + (size_t)lp;
+}
 
 struct Totals {                 // engine-wide accumulators (device memory)
     unsigned long long ev[15];  // HS_EV_KINDS; the station / network engines fill 0..10 and 13..14 (probes)

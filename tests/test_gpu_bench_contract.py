@@ -41,6 +41,9 @@ def test_bench_prints_one_contract_line(args):
         assert "valu" in r and (r["valu"] is None or 0.0 < r["valu"]["busy_frac"] <= 1.0)
         # the binding resource and SURVEY 8(d)'s own model as FIELDS (valu_frac is None away from the profiled size)
         assert "valu_frac" in r and (r["valu_frac"] is None or 0.0 < r["valu_frac"] <= 1.0) and r["frac_survey_8d"] > r["frac"]
+        # the class-weighted issue floor (None away from the profiled size) and SURVEY 8(d)'s second denominator
+        assert "valu_floor_frac" in r and (r["valu_floor_frac"] is None or 0.0 < r["valu_floor_frac"] <= 1.0)
+        assert abs(r["frac_of_measured_stream"] - r["achieved"] / 6290.0) < 1e-12
     if "--workload" not in args:             # the grid line also carries the API run and the reference's own Python path
         assert "api_run_s" in d["config"] and d["config"]["api_events"] == d["config"]["events_per_step_per_gpu"]
         # the reference's own Python loop was timed on ANOTHER host (the GPU box has no /root/reference): labelled as such
