@@ -214,6 +214,9 @@ def parse():
     ap.add_argument("--extras", type=int, default=1,
                     help="grid, 1 GPU: also time the ring, the load balancer and the 8 192-LP strong shard and print them inside the "
                          "line (workloads / strong_shard)")
+    ap.add_argument("--ring-exchange", choices=("live", "device", "collective"), default="live",
+                    help="--workload ring on several ranks: how the shards exchange (live: one launch per rank and run; device / collective: "
+                         "asynchronous rounds)")
     ap.add_argument("--ring-windows", action="store_true",
                     help="ring, N > 1: the windowed protocol (one exchange per 1 ms window) instead of asynchronous rounds")
     return ap.parse_args()
@@ -299,9 +302,14 @@ def ring_main(args, ctx):
         eng.close()
     else:
         rounds = not args.ring_windows
+        if ctx.fake:
+            os.environ["HS_RANKS_PER_DEVICE"] = str(n_ranks)       # (the LIVE exchange: every rank's launch resident on the ONE device)
         sn = ShardedNetwork.on_gpu(st, net, DistComm(), horizon_ns=end_ns, seed=args.seed, device=local_rank,
-                                   log_capacity=cap, sync_every=args.sync_every or (4 if rounds else 256), rounds=rounds)
-        info["exchange_protocol"] = ("asynchronous rounds, device-side exchange (peers' buffers mapped over IPC, one word all-reduced per round)"
+                                   log_capacity=cap, sync_every=args.sync_every or (4 if rounds else 256), rounds=rounds,
+                                   exchange=args.ring_exchange)
+        info["exchange_protocol"] = ("LIVE: one launch per rank and run, the kernels append to each other's link queues (peer-mapped memory: "
+                                     "IPC / xGMI) while they run; no collective inside the run" if sn.live else
+                                     "asynchronous rounds, device-side exchange (peers' buffers mapped over IPC, one word all-reduced per round)"
                                      if sn.device_exchange else "asynchronous rounds over collectives" if rounds else "windows")
         for _ in range(args.warmup):
             sn.run_until(end_ns)
@@ -335,7 +343,10 @@ def ring_main(args, ctx):
                             f"{args.end_s:g} s simulated, seed {args.seed} (BASELINE configs[2]/[3])",
                 "n_stations": args.n_lp, "events_per_step": events, "requests_per_step": requests,
                 "launches_per_step": windows, "lookahead_ns": window_ns,
-                "parallelism": (f"{n_ranks} contiguous ring segments, each on the asynchronous engine; per exchange round "
+                "parallelism": (info.get("exchange_protocol", "") and f"{n_ranks} contiguous ring segments; {info['exchange_protocol']}; the one event beyond "
+                                f"end_time elected across ranks afterwards (all-gather of one candidate per rank)"
+                                if info.get("exchange_protocol", "").startswith("LIVE") else
+                                f"{n_ranks} contiguous ring segments, each on the asynchronous engine; per exchange round "
                                 f"({windows} per run): every rank writes its boundary messages and link bounds into its peers' "
                                 f"buffers (hipIpcOpenMemHandle; xGMI peer-to-peer between GPUs), then all-reduce(max) of ONE word "
                                 f"(still working?) over {'gloo' if ctx.fake else 'RCCL'} -- the only collective" if not args.ring_windows else

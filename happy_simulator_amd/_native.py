@@ -313,6 +313,13 @@ def lib():
     for name in ("hs_engine_shard_push", "hs_engine_shard_inject_ipc"):
         getattr(L, name).restype = C.c_int
         getattr(L, name).argtypes = [C.c_void_p]
+    L.hs_engine_shard_live_export.restype = C.c_int
+    L.hs_engine_shard_live_export.argtypes = [C.c_void_p, C.c_void_p]
+    L.hs_engine_shard_live_attach.restype = C.c_int
+    L.hs_engine_shard_live_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    for name in ("hs_engine_shard_live_run", "hs_engine_shard_live_wait"):
+        getattr(L, name).restype = C.c_int
+        getattr(L, name).argtypes = [C.c_void_p]
     L.hs_engine_shard_async_done.restype = C.c_int
     L.hs_engine_shard_async_done.argtypes = [C.c_void_p, P(C.c_int32)]
     L.hs_engine_set_link_drops.restype = C.c_int
@@ -420,7 +427,9 @@ EXPORTED_SYMBOLS = (
     "hs_engine_shard_window", "hs_engine_shard_inject", "hs_engine_shard_progress", "hs_engine_shard_final",
     "hs_engine_shard_overshoot", "hs_engine_shard_async_setup", "hs_engine_shard_round",
     "hs_engine_shard_inject_async", "hs_engine_shard_async_done", "hs_engine_shard_ipc_export", "hs_engine_shard_ipc_attach",
-    "hs_engine_shard_ipc_buffers", "hs_engine_shard_peers_local", "hs_engine_shard_push", "hs_engine_shard_inject_ipc", "hs_engine_reset",
+    "hs_engine_shard_ipc_buffers", "hs_engine_shard_peers_local", "hs_engine_shard_push", "hs_engine_shard_inject_ipc",
+    "hs_engine_shard_live_export", "hs_engine_shard_live_attach",
+    "hs_engine_shard_live_run", "hs_engine_shard_live_wait", "hs_engine_reset",
     "hs_engine_run_until", "hs_engine_run_until_async", "hs_engine_synchronize", "hs_engine_tandem_path", "hs_engine_prologue_path", "hs_engine_bench_runs",
     "hs_engine_get_summary", "hs_engine_get_lp_stats", "hs_engine_read_sink", "hs_engine_read_sinks", "hs_engine_read_probe",
     "hs_engine_read_probe_slot", "hs_engine_read_source_generated",

@@ -96,6 +96,13 @@ struct hs_engine {
     int64_t *ipc_inbox = nullptr, *ipc_bounds = nullptr;      // [2][world][row] / [2][world][n_cross + 1], uncached device memory
     int64_t **peer_inbox_dev = nullptr, **peer_bounds_dev = nullptr;   // device arrays [world] of the ranks' buffers as mapped here
     std::vector<void *> ipc_opened;                           // peer mappings to close
+    // LIVE exchange (ShardCtl::live): the ranks' link-queue arrays as mapped here, the links' indices at their destination ranks
+    bool live_ready = false;
+    int64_t **live_rec_dev = nullptr, **live_ea_dev = nullptr;
+    unsigned long long **live_head_dev = nullptr;
+    int32_t *live_link_dev = nullptr;
+    hipStream_t live_stream = nullptr;   // the live launch's own stream: it waits for the peers' launches, nothing may queue behind it
+    hipEvent_t live_ev = nullptr;
     bool ipc_ready = false;
     int ipc_parity = 0;
     bool net_pf = false;       // the network has probes / profiles / scheduled Requests: the PF instantiation of hs_net_async
@@ -311,9 +318,13 @@ hipError_t launch_async(hs_engine *h, int64_t end_ns, NetState NX) {
     void *args[] = {&h->P, &h->NP, &h->X, &NX, &h->L, &h->tot, &n, &end_ns, &flags, &h->SC, &lanes, &max_iters};
     const void *fn = h->net_pf ? (const void *)hs_net_async<C, true> : (const void *)hs_net_async<C, false>;
     if constexpr (C == 1) {    // uniform entity kinds: the specialised instantiation (debug flag 1 << 20 keeps the generic one)
-        if (h->net_uni && !h->net_pf && (h->flags & ((1 << 20) | 1 | 32)) == 0 && h->round_iters == 0 && lanes == 64)
+        if (h->net_uni && !h->net_pf && !h->net_global && (h->flags & ((1 << 20) | 1 | 32)) == 0 && h->round_iters == 0 && lanes == 64)
             fn = (const void *)hs_net_async<1, false, true>;
     }
+    // LIVE exchange: the ranks' kernels wait for one another, and several of them may share this device (shards of one process, or
+    // of several processes) -- a plain launch each: what makes them co-resident is that together they have no more workgroups than
+    // the device has CUs (hs_engine_shard_live_run checks its own share)
+    if (h->SC.live) return hipLaunchKernel(fn, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(kBlock), args, 0, h->stream);
     return hipLaunchCooperativeKernel(fn, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(kBlock), args, 0, h->stream);
 }
 // one SEGMENT of a network that does not fit one cooperative launch: stations [lp0, lp0 + blocks x 256) for `iters` iterations of
@@ -1383,7 +1394,21 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     h->NX.pk_base = h->cfg.start_ns;
     if (nl > 0) {
         const size_t NQ = NL * (size_t)aqc;
-        ALN(aq_rec, NQ * 4); ALN(aq_tail, NL); ALN(aq_head, NL); ALN(aq_ea, NL);
+        if (global) {
+            // a shard: the link queues other ranks may write into while this rank's kernel runs (LIVE exchange) -- uncached device
+            // memory, exportable with hipIpcGetMemHandle: a peer's stores arrive in HBM past this device's L2
+            void *a = nullptr, *b = nullptr, *c = nullptr;
+            HS_HIP(h, hipExtMallocWithFlags(&a, NQ * 4 * sizeof(int64_t), hipDeviceMallocUncached)); h->allocs.push_back(a);
+            HS_HIP(h, hipExtMallocWithFlags(&b, NL * sizeof(unsigned long long), hipDeviceMallocUncached)); h->allocs.push_back(b);
+            HS_HIP(h, hipExtMallocWithFlags(&c, NL * sizeof(int64_t), hipDeviceMallocUncached)); h->allocs.push_back(c);
+            h->NX.aq_rec = (int64_t *)a; h->NX.aq_head = (unsigned long long *)b; h->NX.aq_ea = (int64_t *)c;
+            HS_HIP(h, hipMemset(a, 0, NQ * 4 * sizeof(int64_t)));
+            HS_HIP(h, hipMemset(b, 0, NL * sizeof(unsigned long long)));
+            HS_HIP(h, hipMemset(c, 0, NL * sizeof(int64_t)));
+            ALN(aq_tail, NL);
+        } else {
+            ALN(aq_rec, NQ * 4); ALN(aq_tail, NL); ALN(aq_head, NL); ALN(aq_ea, NL);
+        }
         ALN(early_upto, (size_t)n); ALN(d_pre, (size_t)n);
         // the whole network in one cooperative launch (shards: hs_engine_shard_round); with probes, time-varying profiles
         // or scheduled Requests the PF instantiation of the kernel (a profile's next arrival and the next scheduled Request
@@ -1671,6 +1696,113 @@ int hs_engine_shard_inject_ipc(hs_engine *h) {
     return hs_engine_shard_inject_async(h);
 }
 
+// ---- LIVE exchange (ShardCtl::live): no launch boundary per round ----------------------------------------------------------------
+static int live_set_peers(hs_engine *h, const std::vector<int64_t *> &rec, const std::vector<int64_t *> &ea,
+                          const std::vector<unsigned long long *> &head, const int32_t *peer_link) {
+    const int world = h->SC.world;
+    int rc;
+    if ((rc = dev_alloc(h, &h->live_rec_dev, (size_t)world))) return rc;
+    if ((rc = dev_alloc(h, &h->live_ea_dev, (size_t)world))) return rc;
+    if ((rc = dev_alloc(h, &h->live_head_dev, (size_t)world))) return rc;
+    HS_HIP(h, hipMemcpy(h->live_rec_dev, rec.data(), (size_t)world * sizeof(void *), hipMemcpyHostToDevice));
+    HS_HIP(h, hipMemcpy(h->live_ea_dev, ea.data(), (size_t)world * sizeof(void *), hipMemcpyHostToDevice));
+    HS_HIP(h, hipMemcpy(h->live_head_dev, head.data(), (size_t)world * sizeof(void *), hipMemcpyHostToDevice));
+    const size_t NL = (size_t)(h->NP.n_links > 0 ? h->NP.n_links : 1);
+    {
+        const int32_t *pl = nullptr;
+        if ((rc = upload<int32_t>(h, &pl, peer_link, NL, -1))) return rc;
+        h->live_link_dev = const_cast<int32_t *>(pl);
+    }
+    // every link that leaves the shard needs a place in its destination's table
+    const int64_t lo = (int64_t)h->cfg.lp_base, hi = lo + h->cfg.n_lp;
+    for (int l = 0; l < h->NP.n_links; ++l) {
+        const bool s_here = h->h_link_src[(size_t)l] >= lo && h->h_link_src[(size_t)l] < hi;
+        const bool d_here = h->h_link_dst[(size_t)l] >= lo && h->h_link_dst[(size_t)l] < hi;
+        if (s_here && !d_here && peer_link[l] < 0) return fail(h, HS_E_INVALID, "link %d leaves the shard but has no index at its destination rank", l);
+    }
+    if (!ensure_async_fit(h)) return fail(h, HS_E_UNSUPPORTED, "the shard's stations are not co-resident on this device");
+    h->SC.peer_rec = h->live_rec_dev; h->SC.peer_ea = h->live_ea_dev; h->SC.peer_head = h->live_head_dev; h->SC.peer_link = h->live_link_dev;
+    h->SC.live = 0;                       // (set for the duration of a live launch only: rounds and windows keep their outbox rows)
+    h->live_ready = true;
+    return HS_OK;
+}
+
+int hs_engine_shard_live_export(hs_engine *h, void *handles_out) {
+    if (!h || !h->SC.wend_slots || !h->NX.aq_rec || !handles_out) return fail(h, HS_E_STATE, "hs_engine_shard_live_export: attach the shard first");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    hipIpcMemHandle_t hh[3];
+    HS_HIP(h, hipIpcGetMemHandle(&hh[0], h->NX.aq_rec));
+    HS_HIP(h, hipIpcGetMemHandle(&hh[1], h->NX.aq_ea));
+    HS_HIP(h, hipIpcGetMemHandle(&hh[2], h->NX.aq_head));
+    memcpy(handles_out, hh, sizeof hh);
+    return HS_OK;
+}
+
+int hs_engine_shard_live_attach(hs_engine *h, const void *all_handles, const int32_t *peer_link) {
+    if (!h || !h->SC.wend_slots || !h->NX.aq_rec || !all_handles || !peer_link) return fail(h, HS_E_STATE, "hs_engine_shard_live_attach: attach the shard first");
+    if (h->live_ready) return fail(h, HS_E_STATE, "hs_engine_shard_live_attach: already attached");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    const int world = h->SC.world;
+    const hipIpcMemHandle_t *hh = (const hipIpcMemHandle_t *)all_handles;
+    std::vector<int64_t *> rec((size_t)world), ea((size_t)world);
+    std::vector<unsigned long long *> head((size_t)world);
+    for (int r = 0; r < world; ++r) {
+        if (r == h->SC.rank) { rec[(size_t)r] = h->NX.aq_rec; ea[(size_t)r] = h->NX.aq_ea; head[(size_t)r] = h->NX.aq_head; continue; }
+        void *p[3] = {nullptr, nullptr, nullptr};
+        for (int k = 0; k < 3; ++k) {
+            const hipError_t e = hipIpcOpenMemHandle(&p[k], hh[3 * r + k], hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) return fail(h, HS_E_HIP, "hipIpcOpenMemHandle (rank %d's link queues): %s", r, hipGetErrorString(e));
+            h->ipc_opened.push_back(p[k]);
+        }
+        rec[(size_t)r] = (int64_t *)p[0]; ea[(size_t)r] = (int64_t *)p[1]; head[(size_t)r] = (unsigned long long *)p[2];
+    }
+    return live_set_peers(h, rec, ea, head, peer_link);
+}
+
+// enqueue the whole run of this rank (hs_engine_shard_begin set its end): ONE launch of the asynchronous engine, which exchanges
+// messages and bounds with the other ranks' launches while it runs.  Every rank must have passed hs_engine_shard_begin (a barrier
+// of the caller's) before any rank gets here.
+int hs_engine_shard_live_run(hs_engine *h) {
+    if (!h || !h->live_ready) return fail(h, HS_E_STATE, "hs_engine_shard_live_run: call hs_engine_shard_live_attach first");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    if (!h->live_stream) {
+        HS_HIP(h, hipStreamCreateWithFlags(&h->live_stream, hipStreamNonBlocking));
+        HS_HIP(h, hipEventCreateWithFlags(&h->live_ev, hipEventDisableTiming));
+    }
+    // behind everything enqueued on the engine's stream so far (the reset), on a stream of its own: the launch waits for the peers'
+    // launches, which -- shards of one process -- may sit on the very stream this engine shares with them
+    HS_HIP(h, hipEventRecord(h->live_ev, h->stream));
+    HS_HIP(h, hipStreamWaitEvent(h->live_stream, h->live_ev, 0));
+    NetState NX = h->NX;
+    NX.aq_on = 1;
+    h->round_iters = 0;
+    h->SC.live = 1;
+    const int64_t end_ns = h->SC.end_ns;
+    const hipStream_t keep = h->stream;
+    h->stream = h->live_stream;
+    const hipError_t e = h->C == 1 ? launch_async<1>(h, end_ns, NX) : h->C == 2 ? launch_async<2>(h, end_ns, NX) : launch_async<4>(h, end_ns, NX);
+    h->stream = keep;
+    h->SC.live = 0;
+    if (e != hipSuccess) return fail(h, HS_E_HIP, "launch of the live asynchronous engine failed: %s", hipGetErrorString(e));
+    h->launches += 1;
+    return HS_OK;
+}
+
+int hs_engine_shard_live_wait(hs_engine *h) {
+    if (!h || !h->live_ready) return fail(h, HS_E_STATE, "hs_engine_shard_live_wait: not attached");
+    HS_HIP(h, hipSetDevice(h->cfg.device));
+    if (h->live_stream) HS_HIP(h, hipStreamSynchronize(h->live_stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    Totals t;
+    HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
+    if (t.qoverflow) return fail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");
+    if (t.overflow & 8) return fail(h, HS_E_HIP, "the asynchronous engine gave up waiting for a neighbour (bounded spin exhausted): did every rank launch?");
+    if (t.overflow & 32) return fail(h, HS_E_OVERFLOW, "a link's loss table (hs_network.link_drop_capacity) is shorter than the packets that entered the link");
+    if (t.overflow & 2) return fail(h, HS_E_OVERFLOW, "a message bag or a link queue overflowed; raise bag_capacity");
+    if (t.overflow) return fail(h, HS_E_OVERFLOW, "a per-LP record log overflowed (capacity %lld records)", (long long)h->L.cap);
+    return HS_OK;
+}
+
 int hs_engine_shard_round(hs_engine *h) {
     if (!h || !h->shard_async) return fail(h, HS_E_STATE, "hs_engine_shard_round: call hs_engine_shard_async_setup first");
     HS_HIP(h, hipSetDevice(h->cfg.device));
@@ -1723,7 +1855,7 @@ int hs_engine_shard_final(hs_engine *h, int64_t k) {
     HS_HIP(h, hipSetDevice(h->cfg.device));
     h->SC.gvt_in = h->shard_gvt + ((k + 1) & 1);
     h->SC.gvt_out = h->shard_gvt + (k & 1);
-    launch_net_dispatch(h, h->SC.end_ns, (int)(k & 0x3fffffff), (h->flags & 1) | 2 | 4 | (h->shard_async ? 8 : 0));
+    launch_net_dispatch(h, h->SC.end_ns, (int)(k & 0x3fffffff), (h->flags & 1) | 2 | 4 | ((h->shard_async || h->live_ready) ? 8 : 0));
     HS_HIP(h, hipGetLastError());
     h->launches++;
     h->final_win = k;
@@ -2218,6 +2350,7 @@ void hs_engine_destroy(hs_engine *h) {
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (void *p : h->ipc_opened) hipIpcCloseMemHandle(p);      // the peers' exchange buffers as mapped here
+    if (h->live_stream) { hipStreamDestroy(h->live_stream); hipEventDestroy(h->live_ev); }
     for (void *p : h->allocs) hipFree(p);
     if (h->ev_a) hipEventDestroy(h->ev_a);
     if (h->ev_b) hipEventDestroy(h->ev_b);

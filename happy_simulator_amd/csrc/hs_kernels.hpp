@@ -1719,7 +1719,8 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             // groups per LP per iteration, the number of WORKING iterations grows with the run and is not a sign of a hang)
             const bool wave_idle = !__any(n_groups != groups_before);
             idle_iters = wave_idle ? idle_iters + 1 : 0;
-            if (idle_iters >= kAsyncMaxIter) { gave_up = 1; atomicOr(&tot->overflow, 8); break; }
+            // (LIVE exchange: the neighbour may be another process's launch that never came -- give up after ~a second of idling)
+            if (idle_iters >= (live ? (1u << 19) : kAsyncMaxIter)) { gave_up = 1; atomicOr(&tot->overflow, 8); break; }
             // Bounded buffers + time-ordered processing can deadlock on a cycle: every LP waits for room in its outgoing
             // queue while its own bag is full of messages it may not process yet.  A wavefront that makes no progress for
             // a long time while one of its lanes waits for buffer space reports that (raise bag_capacity) instead of spinning.

@@ -116,6 +116,12 @@ class LocalComm:
     def flag_barrier(self, flags):
         self.allreduce_max(flags)
 
+    # (no connect_live: the LIVE exchange needs every shard's launch RUNNING at the same time; launches of one process on several
+    #  streams may share a hardware queue and then run one after the other -- measured: the second never started, the first gave up
+    #  waiting.  Virtual shards of one process keep the asynchronous rounds; one shard per process (DistComm) goes live.)
+    def barrier(self):
+        pass
+
 
 class DistComm:
     """One shard per process: torch.distributed (backend "nccl" is RCCL on ROCm; "gloo" for tests).
@@ -135,6 +141,10 @@ class DistComm:
         self.rank = dist.get_rank(group)
         self.local_ranks = [self.rank]
         self.stage_host = dist.get_backend(group) != "nccl"
+        # how many ranks share ONE device (1 on a real multi-GPU node; `bench.py --fake-ranks R` / tests/test_gpu_dist.py: R) -- the
+        # LIVE exchange needs every rank's launch resident at the same time
+        import os as _os
+        self.ranks_per_device = int(_os.environ.get("HS_RANKS_PER_DEVICE", "1"))
 
     def _staged(self, t):
         return t.cpu() if (self.stage_host and t.is_cuda) else t
@@ -182,6 +192,33 @@ class DistComm:
             self.peer_errors = errs
             return False
         return True
+
+    def connect_live(self, shards, peer_links):
+        """LIVE exchange: all-gather the IPC handles of every rank's link queues, map the peers' (once).  Like connect_peers, every step
+        that can fail on one rank is followed by an agreement of all ranks."""
+        (s,) = shards
+        try:
+            mine, err = s.live_export(), None
+        except Exception as e:                     # noqa: BLE001
+            mine, err = None, f"rank {self.rank}: export: {e}"
+        every = [None] * self.world
+        self._dist.all_gather_object(every, (mine, err), group=self._group)
+        errs = [e for _, e in every if e]
+        if not errs:
+            try:
+                s.live_attach(b"".join(h for h, _ in every), peer_links[s.rank])
+            except Exception as e:                 # noqa: BLE001
+                err = f"rank {self.rank}: attach: {e}"
+            oks = [None] * self.world
+            self._dist.all_gather_object(oks, err, group=self._group)
+            errs = [e for e in oks if e]
+        if errs:
+            self.peer_errors = errs
+            return False
+        return True
+
+    def barrier(self):
+        self._dist.barrier(group=self._group)
 
     def flag_barrier(self, flags):
         """The one collective of a round on the device-side exchange path: all-reduce(MAX) of the "still working" word.  It is also the
@@ -447,6 +484,28 @@ class GpuShard:
         e._check(e._lib.hs_engine_shard_inject_async(e._h))
 
     # -- device-side exchange (hs_engine_shard_ipc_*) ----------------------------------------------------------
+    # -- LIVE exchange: one launch per run, the ranks' kernels talk through each other's link queues (hs_engine_shard_live_*) -----
+    def live_export(self) -> bytes:
+        e = self.engine
+        buf = (C.c_char * (3 * N.IPC_HANDLE_BYTES))()
+        e._check(e._lib.hs_engine_shard_live_export(e._h, buf))
+        return bytes(buf)
+
+    def live_attach(self, all_handles: bytes, peer_link: np.ndarray):
+        e = self.engine
+        if len(all_handles) != 3 * N.IPC_HANDLE_BYTES * self.world:
+            raise ValueError("expected three handles per rank")
+        pl = np.ascontiguousarray(peer_link, np.int32)
+        e._check(e._lib.hs_engine_shard_live_attach(e._h, all_handles, pl.ctypes.data))
+
+    def live_run(self):
+        e = self.engine
+        e._check(e._lib.hs_engine_shard_live_run(e._h))
+
+    def live_wait(self):
+        e = self.engine
+        e._check(e._lib.hs_engine_shard_live_wait(e._h))
+
     def ipc_export(self) -> bytes:
         e = self.engine
         buf = (C.c_char * (2 * N.IPC_HANDLE_BYTES))()
@@ -520,7 +579,7 @@ class ShardedNetwork:
     (GpuShard, or any object with the same methods), `comm` moves rows and scalars between all shards."""
 
     def __init__(self, shards: list, comm, *, window_ns: int, sync_every: int = 64, rounds: bool = False,
-                 ranks: "ElectionRanks | None" = None, device_exchange: bool = False):
+                 ranks: "ElectionRanks | None" = None, device_exchange: bool = False, live: bool = False):
         self.shards = shards
         self.ranks = ranks               # network-wide construction ranks for the election across shards (None: trust word 6)
         self.comm = comm
@@ -529,12 +588,13 @@ class ShardedNetwork:
         self.windows = 0
         self.rounds = bool(rounds)       # asynchronous exchange rounds instead of windows (GpuShard.async_setup done)
         self.device_exchange = bool(device_exchange)   # ... with the ranks pushing into each other's buffers (comm.connect_peers done)
+        self.live = bool(live)           # ONE launch per rank and run, the kernels exchange while they run (comm.connect_live done)
 
     @classmethod
     def on_gpu(cls, stations: StationArrays, net: NetworkArrays, comm, *, horizon_ns: int, start_ns: int = 0,
                seed: int = 42, device: int = 0, msg_capacity: int = 256, log_capacity: int = 0,
                sync_every: int | None = None, bounds: np.ndarray | None = None, rounds: bool = True,
-               round_iters: int = 64, exchange: str = "device"):
+               round_iters: int = 64, exchange: str = "live"):
         """Partition `stations` / `net` (network-wide descriptions, identical on every rank) over comm.world shards
         and build the shards this process owns on `device`.  `bounds` (world + 1 station offsets) overrides the
         balanced block partition, e.g. with the user's own SimulationPartition sizes."""
@@ -562,15 +622,39 @@ class ShardedNetwork:
             cross = np.nonzero(rank_of(src) != rank_of(dst))[0].astype(np.int64)
             for s in shards:
                 s.async_setup(cross, round_iters)
-        if exchange not in ("device", "collective"):
-            raise ValueError("exchange must be 'device' or 'collective'")
-        device_exchange = rounds and exchange == "device" and hasattr(comm, "connect_peers")
+        if exchange not in ("device", "collective", "live"):
+            raise ValueError("exchange must be 'live', 'device' or 'collective'")
+        live = False
+        if rounds and exchange == "live" and hasattr(comm, "connect_live"):
+            # LIVE exchange (round 6): ONE launch per rank and run; the kernels exchange messages and bounds through each other's link
+            # queues while they run.  Every link that leaves a shard needs its index in the destination rank's link table (the table
+            # of a shard = the links that touch it, in network order: shard_arrays).  The launches wait for one another, so what this
+            # process puts on its device must be resident together: one workgroup of 256 stations per CU.
+            src, dst = np.asarray(net.link_src, np.int64), np.asarray(net.link_dst, np.int64)
+            rank_of = lambda x: np.searchsorted(bounds, x, side="right") - 1          # noqa: E731
+            rs, rd = rank_of(src), rank_of(dst)
+            tables = {}
+            for r in range(comm.world):
+                lo, hi = int(bounds[r]), int(bounds[r + 1])
+                tables[r] = np.nonzero(((src >= lo) & (src < hi)) | ((dst >= lo) & (dst < hi)))[0]
+            peer_links = {}
+            for s in shards:
+                pl = np.full(len(s.gids), -1, np.int32)
+                for l, g in enumerate(s.gids):
+                    if rs[g] == s.rank and rd[g] != s.rank:
+                        pl[l] = int(np.searchsorted(tables[int(rd[g])], g))
+                peer_links[s.rank] = pl
+            blocks = sum(-(-(s.hi - s.lo) // 256) for s in shards)
+            cus = torch.cuda.get_device_properties(device).multi_processor_count
+            fits = blocks <= cus // max(1, getattr(comm, "ranks_per_device", 1))
+            live = fits and comm.connect_live(shards, peer_links) is not False
+        device_exchange = rounds and not live and exchange in ("device", "live") and hasattr(comm, "connect_peers")
         if device_exchange and comm.connect_peers(shards) is False:
             device_exchange = False          # (agreed by all ranks: the collective exchange path, comm.peer_errors says why)
         if sync_every is None:           # exchanges between host synchronisations: a run is ~25 rounds or ~60 000 windows
             sync_every = 4 if rounds else 64
         return cls(shards, comm, window_ns=window_ns, sync_every=sync_every, rounds=rounds, ranks=ElectionRanks(stations),
-                   device_exchange=device_exchange)
+                   device_exchange=device_exchange, live=live)
 
     def _run_rounds(self, end_ns: int) -> int:
         """Asynchronous rounds: every shard runs the asynchronous engine for a few iterations, then messages (all-to-all)
@@ -629,7 +713,16 @@ class ShardedNetwork:
         for s in sh:
             s.begin(end_ns)
         k = 0
-        if self.rounds:
+        if self.live:
+            comm.barrier()                                             # every rank has reset its queues: now the peers may write
+            for s in sh:
+                s.live_run()                                           # EXECUTE + EXCHANGE: one launch per rank, they talk while they run
+            self._all_ranks([lambda s=s: s.live_wait() for s in sh])
+            comm.barrier()                                             # (nobody resets while a peer still writes)
+            k = 1
+            for s in sh:
+                s.final(0)
+        elif self.rounds:
             k = self._run_rounds(end_ns)
             for s in sh:
                 s.final(0)

@@ -357,6 +357,22 @@ int hs_engine_set_stream(hs_engine *h, void *hip_stream, int external);
  *   shard_final(k+1); all-gather cand_dev; shard_overshoot(station - lp_base) on the rank that owns the minimum.
  * All calls except shard_progress only enqueue work on the engine's stream. */
 int hs_engine_shard_attach(hs_engine *h, const hs_shard *sh);
+/* LIVE exchange (ABI 14): the EXCHANGE step of parallel/coordinator.py:182-227 without a launch boundary.  Every rank runs ONE
+ * launch of the asynchronous engine for the whole run; a station whose link leaves the shard appends to the link's queue in the
+ * DESTINATION rank's memory and publishes the link's lower bound there (system-scope stores over hipIpcOpenMemHandle mappings:
+ * peer-to-peer over xGMI between GPUs, plain device memory when ranks share a device), the receiver polls its own memory.  A shard
+ * engine's link queues are uncached, exportable device memory for this.  Per process:
+ *   live_export -> all-gather the 3 handles per rank -> live_attach(all handles, peer_link)        (once)
+ *   per run: shard_begin(end); <barrier of the caller's: every rank has reset>; live_run(); live_wait();
+ *            shard_final(0); all-gather cand_dev; shard_overshoot on the winner           (as for the other exchange paths)
+ * peer_link[l] (local link index l): the link's index in the link table of the rank that owns its destination station (-1 when
+ * that is this rank).  The launches wait for one another: together they must be resident on the device(s) -- no more workgroups
+ * of 256 stations than CUs per device; every wait is bounded (HS_E_HIP instead of a hang).  One shard per PROCESS: launches of one
+ * process on several streams may share a hardware queue and then run one after the other. */
+int hs_engine_shard_live_export(hs_engine *h, void *handles_out);               /* 3 x HS_IPC_HANDLE_BYTES: records, words, positions */
+int hs_engine_shard_live_attach(hs_engine *h, const void *all_handles, const int32_t *peer_link);
+int hs_engine_shard_live_run(hs_engine *h);
+int hs_engine_shard_live_wait(hs_engine *h);
 int hs_engine_shard_begin(hs_engine *h, int64_t end_ns);
 int hs_engine_shard_window(hs_engine *h, int64_t k);
 int hs_engine_shard_inject(hs_engine *h, int64_t k);

@@ -51,7 +51,7 @@ def case_spec(case, n, end_s):
     raise SystemExit(f"unknown case {case}")
 
 
-PROTOCOLS = (("rounds", True, "device"), ("rounds_collective", True, "collective"), ("windows", False, "collective"))
+PROTOCOLS = (("live", True, "live"), ("rounds", True, "device"), ("rounds_collective", True, "collective"), ("windows", False, "collective"))
 
 
 def main():
@@ -74,6 +74,8 @@ def main():
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.same_device:
+        os.environ["HS_RANKS_PER_DEVICE"] = str(world)         # (the LIVE exchange: every rank's launch must be resident on the ONE device)
     torch.cuda.set_device(local)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
@@ -93,7 +95,7 @@ def main():
         st, net, cap, p = H.ring_arrays(spec)
         with ShardedNetwork.on_gpu(st, net, DistComm(), horizon_ns=p["end_ns"], seed=spec["seed"], device=local,
                                    log_capacity=cap, rounds=rounds, exchange=exchange) as sn:
-            assert sn.device_exchange == (rounds and exchange == "device")
+            assert sn.device_exchange == (rounds and exchange == "device") and sn.live == (exchange == "live"), getattr(sn.comm, "peer_errors", None)
             s = sn.run_until(p["end_ns"])
             stats, counts, t, cr, ns = sn.collect(n, net.n_links)
             lo, hi = sn.shards[0].lo, sn.shards[0].hi

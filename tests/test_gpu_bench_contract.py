@@ -100,6 +100,12 @@ def test_fake_ranks_run_the_multi_rank_bench_paths_on_one_gpu():
     ring1 = _run("--workload", "ring", "--steps", "2", "--warmup", "1", "--n-lp", "2048", "--end-s", "3", "--cpu-sample-s", "0")
     ring2 = _run("--workload", "ring", "--steps", "2", "--warmup", "1", "--n-lp", "2048", "--end-s", "3", "--cpu-sample-s", "0",
                  "--fake-ranks", "2")
-    assert ring2["fake_ranks"] == 2 and "gloo" in ring2["config"]["parallelism"] and "peers' buffers" in ring2["config"]["parallelism"]
+    # round 6: the LIVE exchange by default -- one launch per rank and run, the two kernels talk through each other's link queues
+    assert ring2["fake_ranks"] == 2 and ring2["config"]["parallelism"].count("LIVE") == 1
     assert ring2["config"]["events_per_step"] == ring1["config"]["events_per_step"]       # two shards == one engine
-    assert ring2["config"]["launches_per_step"] >= 1
+    assert ring2["config"]["launches_per_step"] == 1
+    # ... and the asynchronous rounds with the device-side exchange (round 5) on request
+    ring3 = _run("--workload", "ring", "--steps", "2", "--warmup", "1", "--n-lp", "2048", "--end-s", "3", "--cpu-sample-s", "0",
+                 "--fake-ranks", "2", "--ring-exchange", "device")
+    assert "gloo" in ring3["config"]["parallelism"] and "peers' buffers" in ring3["config"]["parallelism"]
+    assert ring3["config"]["events_per_step"] == ring1["config"]["events_per_step"] and ring3["config"]["launches_per_step"] >= 1

@@ -29,7 +29,7 @@ def _port():
 
 
 def _check(out, world, fewer_rounds=True):
-    for proto in ("rounds", "rounds_collective", "windows"):        # device-side exchange over IPC / collectives / windows
+    for proto in ("live", "rounds", "rounds_collective", "windows"):        # live exchange / device-side exchange over IPC / collectives / windows
         one = out["single" if proto != "windows" else "single_windows"]
         r = out[proto]
         assert r["world"] == world

@@ -28,7 +28,7 @@ def _sharded(spec, world, sync_every=16, msg_capacity=64, rounds=True, bag_capac
     st, net, cap, p = H.ring_arrays(spec, bag_capacity=bag_capacity)
     sn = ShardedNetwork.on_gpu(st, net, LocalComm(world), horizon_ns=p["end_ns"], seed=spec["seed"], log_capacity=cap,
                                sync_every=sync_every, msg_capacity=msg_capacity, rounds=rounds, exchange=exchange)
-    assert sn.device_exchange == (rounds is True and exchange == "device")
+    assert sn.device_exchange == (rounds is True and exchange == "device") and not sn.live
     with sn:
         summ = sn.run_until(p["end_ns"])
         stats = {}
@@ -63,6 +63,7 @@ SPECS = [
 ]
 
 
+# (the LIVE exchange -- one launch per rank and run -- needs one shard per PROCESS: tests/test_gpu_dist.py)
 PROTOCOLS = pytest.mark.parametrize("rounds", [True, "collective", False], ids=["async_rounds_device_exchange", "async_rounds_collectives", "windows"])
 
 
@@ -239,3 +240,18 @@ def test_a_cross_shard_election_that_rests_on_a_stand_in_rank_is_refused():
     for rounds in (True, "collective", False):
         with pytest.raises(N.EngineError, match="lock-step tie"):
             _sharded(spec, 2, rounds=rounds)
+
+
+def test_the_live_exchange_is_for_one_shard_per_process():
+    """Round 6: `exchange="live"` (one launch per rank and run, hs_engine_shard_live_*) needs every shard's launch running at the
+    same time; virtual shards of ONE process keep the asynchronous rounds (their launches may share a hardware queue) -- asked for
+    live, they say so and still equal the single engine.  The live path itself: tests/test_gpu_dist.py (2 and 3 processes)."""
+    from happy_simulator_amd.sharded import LocalComm, ShardedNetwork
+
+    spec = SPECS[0]
+    one = _single(spec)
+    st, net, cap, p = H.ring_arrays(spec)
+    with ShardedNetwork.on_gpu(st, net, LocalComm(2), horizon_ns=p["end_ns"], seed=spec["seed"], log_capacity=cap, exchange="live") as sn:
+        assert not sn.live and sn.device_exchange
+        summ = sn.run_until(p["end_ns"])
+    assert summ.events_processed == one["events"] and summ.final_time_ns == one["final"]
