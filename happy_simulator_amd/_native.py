@@ -335,6 +335,8 @@ def lib():
     L.hs_engine_tandem_path.argtypes = [C.c_void_p]
     L.hs_engine_prologue_path.restype = C.c_int
     L.hs_engine_prologue_path.argtypes = [C.c_void_p]
+    L.hs_engine_window_path.restype = C.c_int
+    L.hs_engine_window_path.argtypes = [C.c_void_p]
     L.hs_engine_synchronize.restype = C.c_int
     L.hs_engine_synchronize.argtypes = [C.c_void_p]
     L.hs_engine_bench_runs.restype = C.c_int
@@ -430,7 +432,7 @@ EXPORTED_SYMBOLS = (
     "hs_engine_shard_ipc_buffers", "hs_engine_shard_peers_local", "hs_engine_shard_push", "hs_engine_shard_inject_ipc",
     "hs_engine_shard_live_export", "hs_engine_shard_live_attach",
     "hs_engine_shard_live_run", "hs_engine_shard_live_wait", "hs_engine_reset",
-    "hs_engine_run_until", "hs_engine_run_until_async", "hs_engine_synchronize", "hs_engine_tandem_path", "hs_engine_prologue_path", "hs_engine_bench_runs",
+    "hs_engine_run_until", "hs_engine_run_until_async", "hs_engine_synchronize", "hs_engine_tandem_path", "hs_engine_prologue_path", "hs_engine_window_path", "hs_engine_bench_runs",
     "hs_engine_get_summary", "hs_engine_get_lp_stats", "hs_engine_read_sink", "hs_engine_read_sinks", "hs_engine_read_probe",
     "hs_engine_read_probe_slot", "hs_engine_read_source_generated",
     "hs_last_error", "hs_last_global_error", "hs_engine_destroy", "hs_debug_draws", "hs_debug_set_flags",

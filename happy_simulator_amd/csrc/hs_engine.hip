@@ -81,6 +81,9 @@ struct hs_engine {
     int64_t window_ns = 0;
     bool net_ran = false;
     int64_t net_last_end = INT64_MIN;   // end_ns of the run since the last reset (windows: see hs_engine_run_until_async)
+    bool net_resume = false;            // ... and this run_until continues from the state that run left (hs_net_resume first)
+    int64_t net_resume_from = 0;        // ... whose end_ns this was
+    int net_window_path = 0;            // hs_engine_window_path
     std::vector<int64_t> drop_off_host;  // table-decided link losses (hs_network.link_drop_capacity): bit offsets per link
     uint32_t *drop_bits_dev = nullptr;
     LossTables loss_host{};              // (host copy of the device object: the send log's pointers)
@@ -310,6 +313,16 @@ void launch_net_dispatch(hs_engine *h, int64_t wend, int win, int flags) {
     }
 }
 
+// windows: finish the timestamp group the last run_until's election stopped inside (hs_kernels.hpp hs_net_resume)
+void launch_net_resume(hs_engine *h, const NetState &NX, int send_idx) {
+    switch (h->C) {
+        case 1: hipLaunchKernelGGL(hs_net_resume<1>, dim3(1), dim3(64), 0, h->stream, h->P, h->NP, h->X, NX, h->L, h->tot, h->cfg.n_lp, send_idx, h->SC); break;
+        case 2: hipLaunchKernelGGL(hs_net_resume<2>, dim3(1), dim3(64), 0, h->stream, h->P, h->NP, h->X, NX, h->L, h->tot, h->cfg.n_lp, send_idx, h->SC); break;
+        default: hipLaunchKernelGGL(hs_net_resume<4>, dim3(1), dim3(64), 0, h->stream, h->P, h->NP, h->X, NX, h->L, h->tot, h->cfg.n_lp, send_idx, h->SC); break;
+    }
+    h->launches++;
+}
+
 template <int C>
 hipError_t launch_async(hs_engine *h, int64_t end_ns, NetState NX) {
     int n = h->cfg.n_lp, flags = h->flags & (1 | 64 | 128 | 1024 | 0xff00 | (1 << 21)), lanes = h->async_lanes;
@@ -403,6 +416,7 @@ int try_run_net_whole(hs_engine *h, int64_t end_ns) {
         if ((h->flags & (1 << 23)) || h->async_resident_blocks < 1) return 0;
         NetState NXs = h->NX;
         NXs.aq_on = 1;
+        if (h->net_resume) launch_net_resume(h, NXs, 0);
         const int rc = run_net_segments(h, end_ns, NXs, h->async_resident_blocks);
         if (rc) return rc;
         const NetState keep = h->NX;
@@ -416,8 +430,14 @@ int try_run_net_whole(hs_engine *h, int64_t end_ns) {
     }
     NetState NX = h->NX;
     NX.aq_on = 1;
+    if (h->net_resume) launch_net_resume(h, NX, 0);
     hipError_t e = h->C == 1 ? launch_async<1>(h, end_ns, NX) : h->C == 2 ? launch_async<2>(h, end_ns, NX) : launch_async<4>(h, end_ns, NX);
-    if (e != hipSuccess) { (void)hipGetLastError(); h->async_fit = 0; return 0; }   // not co-resident after all: windows
+    if (e != hipSuccess) {      // not co-resident after all
+        (void)hipGetLastError();
+        h->async_fit = 0;
+        if (h->net_resume) return fail(h, HS_E_HIP, "the cooperative launch of a resumed window failed: %s", hipGetErrorString(e));
+        return 0;               // ... windows
+    }
     const NetState keep = h->NX;
     h->NX = NX;
     launch_net_dispatch(h, end_ns, 1, (h->flags & 1) | 2 | 8);       // FINAL: leftover queue entries, overshoot
@@ -438,6 +458,12 @@ int run_net_async(hs_engine *h, int64_t end_ns) {
     const int64_t W = h->window_ns;
     int64_t t0 = h->cfg.start_ns;
     int win = 0;
+    if (h->net_resume) {
+        // windows: the conservative windows continue behind the last end (everything at or before it has happened); what the
+        // finished group sends waits in the incoming bags the first window merges (parity 1)
+        launch_net_resume(h, h->NX, 1);
+        t0 = h->net_resume_from + 1;
+    }
     for (;;) {
         int64_t wend = t0 + W - 1;
         if (wend >= end_ns || wend < t0) wend = end_ns;
@@ -1379,6 +1405,7 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
     const size_t N = (size_t)n, NB = (size_t)n * (size_t)bag;
 #define ALN(field, count) if ((rc = dev_alloc(h, &h->NX.field, count))) return rc
     ALN(route_k, N); ALN(routed, N); ALN(link_k, NL); ALN(link_in, NL); ALN(link_sent, NL); ALN(link_packets, NL); ALN(next_time, N);
+    ALN(pend_pay, N);
     ALN(bag_cnt, N); ALN(bag_t, NB); ALN(bag_ts, NB); ALN(bag_cr, NB); ALN(bag_link, NB); ALN(bag_lin, NB);
     ALN(in_cnt, 2 * N); ALN(in_t, 2 * NB); ALN(in_ts, 2 * NB); ALN(in_cr, 2 * NB); ALN(in_link, 2 * NB); ALN(in_lin, 2 * NB);
     if ((rc = dev_alloc(h, &h->X.enqpay, N * (size_t)kEnqPay))) return rc;    // hs_net_async's ENQ payloads (general path)
@@ -1931,6 +1958,19 @@ int hs_engine_reset(hs_engine *h) {
     return HS_OK;
 }
 
+// Windows over a network: what a run_until with a later end does.  0: repeat the run from the start; 1: continue from the state the
+// last run left; 2: nothing moves.
+static int net_window_state(hs_engine *h, int64_t end_ns, int &state) {
+    state = 0;
+    if (h->exact || h->net_global || (h->flags & (1 << 24)) || h->NX.pend_pay == nullptr) return HS_OK;
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    Totals t;
+    HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
+    if (t.overflow != 0 || t.qoverflow != 0 || t.undecided != 0 || t.no_resume != 0) return HS_OK;
+    state = t.cur_time > end_ns ? 2 : 1;
+    return HS_OK;
+}
+
 int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
     if (!h || !h->have_stations) return fail(h, HS_E_STATE, "hs_engine_run_until: stations not set");
     if (end_ns > h->cfg.horizon_ns)
@@ -1943,28 +1983,47 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
     HS_HIP(h, hipEventRecord(h->ev_k0, h->stream));
     if (h->is_net) {
         if (h->net_global) return fail(h, HS_E_STATE, "a shard of a partitioned network is driven with hs_engine_shard_*");
+        h->net_window_path = 0;
         if (h->net_ran) {
             // Windows over a network (core/simulation.py:527-541 `_run_window` = `_execute_until` again).  The reference pops events in
             // one global order whatever the window ends are, and every call stops behind the first event beyond its end -- so after
-            // windows e_1 <= ... <= e_k the state is that of ONE run to e_k.  The network engines keep no mid-run device state between
-            // launches (pre-sent departures, per-link bounds, bags in LDS), so a later window end REPEATS the run from the start to
-            // the new end: exact, at the cost of the whole prefix per window.  An end at or before the last one moves nothing: the
+            // windows e_1 <= ... <= e_k the state is that of ONE run to e_k.  An end at or before the last one moves nothing: the
             // reference's loop condition `current_time <= end` is already false (the event beyond the earlier end was processed).
             if (end_ns <= h->net_last_end) {
+                h->net_window_path = 2;
                 HS_HIP(h, hipEventRecord(h->ev_k1, h->stream));
                 HS_HIP(h, hipEventRecord(h->ev_b, h->stream));
                 h->pending_async = true;
                 return HS_OK;
             }
-            int rc = do_reset_async(h);
-            if (rc) return rc;
-            h->launches++;
+            // Round 6: a later end CONTINUES from the state the last run left -- every station's rows, the bags (the final launch took
+            // the link queues' leftovers into them), the links' bounds (lower bounds whatever the end was: NetStation::pre_send) and
+            // the group the election stopped inside (hs_net_resume) -- O(window) as the reference's `_run_window`, not O(prefix).
+            // Plain networks only (no prologue, no shard); a state the asynchronous kernel cannot take back (a bag larger than its
+            // LDS column, an overflow) and debug flag 1 << 24 repeat the run from the start as rounds 4-5 did.
+            int state = 0;
+            { const int rc = net_window_state(h, end_ns, state); if (rc) return rc; }
+            h->net_window_path = state == 0 ? 3 : state;
+            if (state == 2) {            // the event beyond the last end lies beyond this one too: `current_time <= end` is false
+                h->net_last_end = end_ns;
+                HS_HIP(h, hipEventRecord(h->ev_k1, h->stream));
+                HS_HIP(h, hipEventRecord(h->ev_b, h->stream));
+                h->pending_async = true;
+                return HS_OK;
+            }
+            if (state == 1) { h->net_resume = true; h->net_resume_from = h->net_last_end; }
+            else {
+                int rc = do_reset_async(h);
+                if (rc) return rc;
+                h->launches++;
+            }
         }
         h->net_last_end = end_ns;
         if (lazy_active(h)) h->window_ends.push_back(end_ns);
         int rc = launch_prologue(h, end_ns);
         if (rc) return rc;
         rc = run_net_async(h, end_ns);
+        h->net_resume = false;
         if (rc) return rc;
     } else {
         if (h->n_pass > 0 && ((h->flags & (1 << 17)) || ((h->flags & (1 << 16)) && h->exact_prologue)) && h->exact && h->window_ends.empty())
@@ -2054,6 +2113,7 @@ int hs_engine_prologue_path(const hs_engine *h) {
     if (!h || !h->exact || (!h->exact_prologue && !h->exact_only)) return 0;
     return lazy_active(h) ? 1 : 2;
 }
+int hs_engine_window_path(const hs_engine *h) { return h ? h->net_window_path : 0; }
 int hs_engine_tandem_path(const hs_engine *h) { return !h || h->n_pass == 0 ? 0 : h->exact_only ? 2 : 1; }
 
 int hs_engine_synchronize(hs_engine *h) {

@@ -369,6 +369,7 @@ __global__ void __launch_bounds__(kBlock) hs_station_reset(StationParams P, Stat
         tot->completed = 0; tot->received = 0; tot->final_time = start_ns; tot->cur_time = start_ns;
         tot->overflow = 0; tot->qoverflow = 0; tot->done = 0; tot->undecided = 0;
         tot->dbg[0] = tot->dbg[1] = tot->dbg[2] = tot->dbg[3] = 0; tot->not_done = 0;
+        tot->pend_lp = -1; tot->no_resume = 0;
     }
     if (lp >= n) return;
     int64_t A = kInfNs, arr_time = start_ns;
@@ -1159,6 +1160,8 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
         }
         NX.bag_cnt[lp] = bn;
         NX.next_time[lp] = nt;
+        // (windows: the next run_until continues from this state when hs_net_async can take every bag back into LDS)
+        if (bn > kLBag) __hip_atomic_fetch_or(&tot->no_resume, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (live) {
         nt = NX.next_time[lp];
         const size_t cs = (size_t)merge_idx * n + lp;
@@ -1343,15 +1346,18 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
             // the one event beyond end_time (core/simulation.py:472): first micro-event of the winner's next group
             NetStation<C> W;
             load_net<C>(W, P, NP, X, NX, L, b.lp, n, qmem, &enqpay[0][0], (size_t)kBlock, 0, send_idx, SC);
+            // (NetStation::root_first: what the event created stays in the in-group FIFO, unprocessed -- and is kept for the next
+            //  run_until, which finishes the group before anything else: StationState::q / grp_time, NetState::pend_pay, hs_net_resume)
             const int64_t t = W.next_time();
             const int w = W.pick_root(t);
-            if (w == 1) (void)W.do_tick(t);
-            else if (w >= 64) (void)W.do_msg(w - 64, t);
-            else if (w >= 56 && w < 56 + kMaxProbes) W.root_probe(w - 56, t);   // the SourceEvent of the Probe; its probe_event stays unprocessed
-            else if (w >= 48 && w < 48 + kMaxXSrc) W.root_xsrc(w - 48, t);      // the SourceEvent of a further Source; its Request stays unprocessed
-            else if (w == 62) W.root_sched(t);                 // the injected Request@Server; its QUEUE_NOTIFY stays unprocessed
-            else (void)W.do_cont_core(w - 2, t);
+            const bool egress = W.root_first(w, t);
             W.last_time = t;
+            bool fits = true;
+            const uint32_t pend = W.pending_pack(egress, egress ? w - 2 : 0, fits);
+            X.q[b.lp] = pend; X.grp_time[b.lp] = t;
+            if (NX.pend_pay != nullptr) NX.pend_pay[b.lp] = W.pending_payload();
+            tot->pend_lp = pend != 0u ? b.lp : -1;
+            if (!fits || NX.pend_pay == nullptr) tot->no_resume |= 2;
             store_net<C>(W, X, NX, b.lp, n);
             for (int k = 0; k < 11; ++k) if (W.ev[k]) atomicAdd(&tot->ev[k], (unsigned long long)W.ev[k]);
             if (W.evp[0]) atomicAdd(&tot->ev[13], (unsigned long long)W.evp[0]);
@@ -1361,6 +1367,50 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
         }
         tot->cur_time = new_cur;
         tot->done = 0;
+    }
+}
+
+// Windows over a network (core/simulation.py:527-541): the previous run_until's election stopped inside a timestamp group -- the one
+// event beyond its end_time was the group's first micro-event.  This launch (one lane) finishes that group from what the election
+// kept (NetStation::resume_pending); it is the network's earliest pending work, so nothing else can come before it.  Messages it
+// sends go where the engine that runs next looks for them: the links' queues (NX.aq_on) or the incoming bags of parity `send_idx`.
+template <int C>
+__global__ void __launch_bounds__(64) hs_net_resume(StationParams P, NetParams NP, StationState X, NetState NX, RecordLogs L,
+                                                    Totals *tot, int n, int send_idx, ShardCtl SC) {
+    __shared__ uint8_t qmem[kQCap][kBlock];
+    __shared__ int64_t enqpay[kEnqPay][kBlock];
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int lp = tot->pend_lp;
+    tot->pend_lp = -1;
+    if (lp < 0 || lp >= n) return;
+    const uint32_t pend = X.q[lp];
+    X.q[lp] = 0;
+    if (pend == 0u) return;
+    NetStation<C> W;
+    load_net<C>(W, P, NP, X, NX, L, lp, n, qmem, &enqpay[0][0], (size_t)kBlock, 0, send_idx, SC);
+    const int64_t t = X.grp_time[lp];
+    W.resume_pending(pend, t, NX.pend_pay[lp]);
+    store_net<C>(W, X, NX, lp, n);
+    for (int k = 0; k < 11; ++k) if (W.ev[k]) atomicAdd(&tot->ev[k], (unsigned long long)W.ev[k]);
+    if (W.evp[0]) atomicAdd(&tot->ev[13], (unsigned long long)W.evp[0]);
+    if (W.evp[1]) atomicAdd(&tot->ev[14], (unsigned long long)W.evp[1]);
+    if (W.ev[6]) atomicAdd(&tot->completed, (unsigned long long)W.ev[6]);
+    if (W.ev[7]) atomicAdd(&tot->received, (unsigned long long)W.ev[7]);
+    atomicMax(&tot->final_time, (long long)t);
+    if (W.overflow) atomicOr(&tot->overflow, 1);
+    if (W.qoverflow) atomicOr(&tot->qoverflow, 1);
+    if (W.bagoverflow) atomicOr(&tot->overflow, 2);
+    if (W.undecided) atomicOr(&tot->undecided, W.undecided);
+    if (NX.aq_on && W.sent_async) {
+        // the links' (bound, tail) words: the bound stays (it covered this message), the tail is the link's sequence number
+        drain_stores();
+        const int nt = W.egress == EG_LINK ? 1 : W.egress == EG_ROUTER ? W.rtk : 0;
+        for (int k = 0; k < nt; ++k) {
+            const int32_t l = W.egress == EG_LINK ? W.link_of : W.rt_target(k);
+            if (l < 0) continue;
+            const int64_t w = ag_load(&NX.aq_ea[l]);
+            ag_store(&NX.aq_ea[l], (int64_t)(((unsigned long long)w & ~kPkTailMask) | ((unsigned long long)NX.link_sent[l] & kPkTailMask)));
+        }
     }
 }
 
@@ -1552,6 +1602,10 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                     else mA = sat(S.next_time(), c_sdl);
                 } else S.bound_map(next_l, next_lat, mA, mB, mD);
             }
+            // (a lane that is done still sends -- in the NEXT run_until: everything at or before end_ns has happened, so whatever it sends
+            //  leaves after end_ns.  "Never" would do for this launch, but the bounds its neighbours derive from it stay in the links'
+            //  words, and a later window end continues from them: round 6)
+            else if (done && next_l >= 0) mA = sat(end_ns + 1, next_lat);
             if (!chain) {                                             // head of a chain: its input bound is known
                 if (!done && S.undrained < H) H = S.undrained;
                 int64_t v = sat(H, mB);
@@ -2025,6 +2079,7 @@ __global__ void hs_debug_const_div_kernel(double b, int64_t n, const double *a, 
 #define HS_ARGS_NET_WINDOW (StationParams, NetParams, StationState, NetState, RecordLogs, Totals *, Candidate *, int, int64_t, int, int, ShardCtl)
 #define HS_ARGS_NET_ASYNC (StationParams, NetParams, StationState, NetState, RecordLogs, Totals *, int, int64_t, int, ShardCtl, int, int)
 #define HS_ARGS_SHARD_OVERSHOOT (StationParams, NetParams, StationState, NetState, RecordLogs, Totals *, int, int, int, ShardCtl)
+#define HS_ARGS_NET_RESUME (StationParams, NetParams, StationState, NetState, RecordLogs, Totals *, int, int, ShardCtl)
 #define HS_INST_GROUP_0(X) X(hs_station_run<1, false, true, true> HS_ARGS_STATION_RUN) X(hs_station_run<1, false, true> HS_ARGS_STATION_RUN)
 #define HS_INST_GROUP_1(X) X(hs_station_run<1, true> HS_ARGS_STATION_RUN) X(hs_station_run<1, false> HS_ARGS_STATION_RUN) \
                            X(hs_station_run<2, true> HS_ARGS_STATION_RUN) X(hs_station_run<2, false> HS_ARGS_STATION_RUN)
@@ -2032,9 +2087,9 @@ __global__ void hs_debug_const_div_kernel(double b, int64_t n, const double *a, 
                            X(hs_station_run<8, true> HS_ARGS_STATION_RUN) X(hs_station_run<8, false> HS_ARGS_STATION_RUN)
 #define HS_INST_GROUP_3(X) X(hs_station_run<16, true> HS_ARGS_STATION_RUN) X(hs_station_run<16, false> HS_ARGS_STATION_RUN)
 #define HS_INST_GROUP_4(X) X(hs_station_run<32, true> HS_ARGS_STATION_RUN) X(hs_station_run<32, false> HS_ARGS_STATION_RUN)
-#define HS_INST_GROUP_5(X) X(hs_net_window<1> HS_ARGS_NET_WINDOW) X(hs_shard_overshoot<1> HS_ARGS_SHARD_OVERSHOOT)
-#define HS_INST_GROUP_6(X) X(hs_net_window<2> HS_ARGS_NET_WINDOW) X(hs_shard_overshoot<2> HS_ARGS_SHARD_OVERSHOOT)
-#define HS_INST_GROUP_7(X) X(hs_net_window<4> HS_ARGS_NET_WINDOW) X(hs_shard_overshoot<4> HS_ARGS_SHARD_OVERSHOOT)
+#define HS_INST_GROUP_5(X) X(hs_net_window<1> HS_ARGS_NET_WINDOW) X(hs_shard_overshoot<1> HS_ARGS_SHARD_OVERSHOOT) X(hs_net_resume<1> HS_ARGS_NET_RESUME)
+#define HS_INST_GROUP_6(X) X(hs_net_window<2> HS_ARGS_NET_WINDOW) X(hs_shard_overshoot<2> HS_ARGS_SHARD_OVERSHOOT) X(hs_net_resume<2> HS_ARGS_NET_RESUME)
+#define HS_INST_GROUP_7(X) X(hs_net_window<4> HS_ARGS_NET_WINDOW) X(hs_shard_overshoot<4> HS_ARGS_SHARD_OVERSHOOT) X(hs_net_resume<4> HS_ARGS_NET_RESUME)
 #define HS_INST_GROUP_8(X) X(hs_net_async<1, false, true> HS_ARGS_NET_ASYNC)
 #define HS_INST_GROUP_9(X) X(hs_net_async<1, false> HS_ARGS_NET_ASYNC)
 #define HS_INST_GROUP_10(X) X(hs_net_async<1, true> HS_ARGS_NET_ASYNC)

@@ -139,6 +139,7 @@ struct NetState {
     // pre-sent departures (hs_net_async, one-worker stations): see NetStation::early_upto
     int64_t *early_upto;             // [n_lp]
     int64_t *d_pre;                  // [n_lp]
+    int64_t *pend_pay;               // [n_lp] windows: the ENQ payload of the group the last election stopped inside (NetStation::pending_pack)
     int32_t aq_cap;               // entries per link queue, a power of two (slot = sequence number & (aq_cap - 1))
     int32_t aq_on;                   // 1 inside hs_net_async / its final launch: send_link uses the queues
 };
@@ -903,7 +904,10 @@ struct NetStation {
         if (router && bit_off >= rn) return false;
         const int32_t target = HSU(egress == EG_SINK, false) ? -1 : HSU(egress == EG_LINK, false) ? link_of
                              : router ? rt_target((int)((rbits >> (2 * bit_off)) & 3u)) : -2;
-        if (target >= 0 && D <= end_ns) {
+        // (a message that leaves beyond end_ns is NOT decided ahead of time: what this launch leaves behind -- early_upto, the bounds that
+        //  skip pre-sent requests -- must not depend on where it stops, so that the next run_until continues from it; round 6)
+        if (target >= 0 && D > end_ns) return false;
+        if (target >= 0) {
             if (HSU(fl_jit == 0, true) && nj == 0) return false;
             double delay = fl_delay0;
             if (HSU(fl_jit == 0, true)) { delay = __dadd_rn(delay, fl.ring_j[hj][tid]); hj = (hj + 1) & (kNRing - 1); --nj; }
@@ -1396,6 +1400,54 @@ struct NetStation {
         else if (PF && w >= 56 && w < 56 + kMaxProbes) { if constexpr (PF) root_probe(w - 56, t); }
         else if (PF && w == 62) { if constexpr (PF) root_sched(t); }
         else root_cont(w - 2, t);
+    }
+    // ---- windows (core/simulation.py:527-541 `_run_window`: `_execute_until` again) ------------------------------------------
+    // The one event beyond end_time is the FIRST micro-event of its timestamp group.  The election (hs_net_window) runs it with
+    // root_first(), which leaves what that event created in the in-group FIFO exactly as run_root() would; pending_pack() /
+    // resume_pending() carry the FIFO over to the next run_until, where the group finishes before anything else happens (it is
+    // the network's earliest pending work).  Returns true for a departure: its continuation has run (statistics), the forwarded
+    // request's way out (Sink / RandomRouter / NetworkLink -- reference events of their own) has not.
+    __device__ __forceinline__ bool root_first(int w, int64_t t) {
+        cd = 0; cr = root_crt(w);
+        if (w == 1) root_tick(t);                                         // the SourceEvent; its Request / a same-ns next tick wait in the FIFO
+        else if (w >= 64) root_msg(w - 64, t);                            // the link's continuation; its Request@Server waits
+        else if (PF && w >= 48 && w < 48 + kMaxXSrc) { if constexpr (PF) root_xsrc(w - 48, t); }
+        else if (PF && w >= 56 && w < 56 + kMaxProbes) { if constexpr (PF) root_probe(w - 56, t); }   // its probe_event waits
+        else if (PF && w == 62) { if constexpr (PF) root_sched(t); }      // the injected Request@Server; its QUEUE_NOTIFY waits
+        else { (void)do_cont_core(w - 2, t); return true; }
+        return false;
+    }
+    // the FIFO behind root_first() as one word: codes 0..2 (8 bits each) | count << 24 | way-out-pending << 26 | worker slot << 27
+    __device__ __forceinline__ uint32_t pending_pack(bool egress, int slot, bool &fits) const {
+        fits = qn <= 3 && pn <= 1 && qh == 0 && ph == 0 && slot < 32;
+        uint32_t p = (uint32_t)(qn & 3) << 24;
+        for (int k = 0; k < qn && k < 3; ++k) p |= (uint32_t)qmem[k][tid] << (8 * k);
+        if (egress) p |= (1u << 26) | ((uint32_t)slot << 27);
+        return p;
+    }
+    __device__ __forceinline__ int64_t pending_payload() const { return pn > 0 ? enq[(size_t)ph * enq_stride] : 0; }
+    // ... and the rest of that group, on a freshly loaded LP (the FIFO's lineage columns qdep / qrc are global memory: slots
+    // 0 .. count - 1 still hold what the election's qpush wrote)
+    __device__ __forceinline__ void resume_pending(uint32_t p, int64_t t, int64_t payload) {
+        const int cnt = (int)((p >> 24) & 3u);
+        qh = 0; qn = 0; ph = 0; pn = 0;
+        for (int k = 0; k < cnt; ++k) {
+            const uint32_t code = (p >> (8 * k)) & 0xffu;
+            qmem[k][tid] = (uint8_t)code;
+            if ((code & 7u) == Q_ENQ && pn == 0) { enq[0] = payload; pn = 1; }
+        }
+        qn = cnt;
+        if (p & (1u << 26)) {                                             // root_cont() behind its do_cont_core()
+            const int slot = (int)(p >> 27);
+            int64_t created = 0;
+            cd = 0;
+#pragma unroll
+            for (int i = 0; i < C; ++i) if (i == slot) { cr = crtD[i]; created = crt[i]; }
+            do_egress(t, created);
+            if (active < conc) qpush(Q_POLL);
+        }
+        run_group_general(t);             // the roots of this nanosecond that are still pending, then the FIFO
+        last_time = t;
     }
     __device__ __forceinline__ void drain(int64_t t) {
         while (qn > 0) {

@@ -220,6 +220,9 @@ struct Totals {                 // engine-wide accumulators (device memory)
     int undecided;
     unsigned long long dbg[4];  // asynchronous engine telemetry: sum of wave iterations, max, groups run, waves
     unsigned long long not_done; // shard rounds of hs_net_async: LPs that still have work at or before end_ns
+    // Network engines, windows: the station whose timestamp group the election stopped inside (-1: none; StationState::q holds what is
+    // left of the group, hs_net_resume finishes it), and why the next run_until cannot continue from this state (0: it can)
+    int pend_lp, no_resume;
     // Network engines (set once by hs_engine_set_network, never reset): [n_lp][4] every station's first event beyond end_ns as the
     // electing launch saw it {t, t_created, rcrt, depth | valid << 32 | stand-in << 33} -- the election's tie check (hs_net_window).
     long long *net_cand_key;

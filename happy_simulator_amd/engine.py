@@ -351,6 +351,11 @@ class StationEngine:
         another event of its LP); 2: the run went through the single-heap prologue (include/hs_engine.h)."""
         return int(self._lib.hs_engine_prologue_path(self._h))
 
+    def window_path(self) -> int:
+        """Network engines, what the last run_until did: 0 first run since the reset; 1 continued from the state the run before it
+        left; 2 nothing moved; 3 repeated from the start (include/hs_engine.h hs_engine_window_path)."""
+        return int(self._lib.hs_engine_window_path(self._h))
+
     def synchronize(self):
         self._check(self._lib.hs_engine_synchronize(self._h))
 

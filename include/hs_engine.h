@@ -327,6 +327,16 @@ int hs_engine_tandem_path(const hs_engine *h);
  * 1: skipped so far, 2: it runs (debug flag 1 << 16 makes it run always). */
 int hs_engine_prologue_path(const hs_engine *h);
 
+/* Windows over a station NETWORK (ABI 14): `Simulation.control.run_until / _run_window` (core/simulation.py:527-541) call
+ * `_execute_until` again with a later end, and the reference continues from its heap -- O(window).  What the last hs_engine_run_until on a
+ * network engine did: 0 the first run since the reset, 1 it CONTINUED from the state the run before it left (every station's rows, the
+ * messages in flight, the links' lower bounds, and the timestamp group the election of the one event beyond the earlier end stopped
+ * inside -- finished first, csrc/hs_kernels.hpp hs_net_resume), 2 nothing moved (the end is not beyond the event the earlier run
+ * already processed: the reference's loop condition `current_time <= end` is false), 3 the run was REPEATED from the start to the
+ * new end (engines with a prologue -- Probes, scheduled Requests, several Sources per Server --, a state the asynchronous kernel
+ * cannot take back, debug flag 1 << 24): exact as well, at the cost of the prefix.  Diagnostics only; results are identical. */
+int hs_engine_window_path(const hs_engine *h);
+
 int hs_engine_create(const hs_config *cfg, hs_engine **out);
 int hs_engine_set_stations(hs_engine *h, const hs_stations *st);
 /* Optional, after hs_engine_set_stations and before the first run: connect stations with links / routers.
