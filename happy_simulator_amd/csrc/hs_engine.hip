@@ -14,6 +14,9 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #define HS_KERNELS_MAIN
 #include "hs_kernels.hpp"
@@ -34,6 +37,7 @@ struct hs_engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
     std::vector<void *> allocs;
+    std::vector<std::pair<void *, size_t>> uncached;   // buffers of the process-wide uncached pool this engine holds (uncached_alloc)
     StationParams P{};
     StationState X{};
     RecordLogs L{};
@@ -84,6 +88,8 @@ struct hs_engine {
     bool net_resume = false;            // ... and this run_until continues from the state that run left (hs_net_resume first)
     int64_t net_resume_from = 0;        // ... whose end_ns this was
     int net_window_path = 0;            // hs_engine_window_path
+    Totals tot_seen{};                  // the totals hs_engine_run_until read behind the last run (valid until the next launch):
+    bool tot_seen_valid = false;        //   the next window's decision without another round trip to the device
     std::vector<int64_t> drop_off_host;  // table-decided link losses (hs_network.link_drop_capacity): bit offsets per link
     uint32_t *drop_bits_dev = nullptr;
     LossTables loss_host{};              // (host copy of the device object: the send log's pointers)
@@ -166,7 +172,48 @@ int dev_alloc(hs_engine *h, T **p, size_t count) {
     if (e != hipSuccess) return fail(h, HS_E_HIP, "hipMalloc(%zu B): %s", count * sizeof(T), hipGetErrorString(e));
     h->allocs.push_back(q);
     *p = (T *)q;
+    // debug: HS_POISON_ALLOC=<byte> fills every device allocation with that byte -- nothing may depend on what hipMalloc hands out
+    // (memory of an engine destroyed earlier in the process), tests/test_gpu_sharded.py runs a case under it
+    static const char *poison = getenv("HS_POISON_ALLOC");
+    if (poison && *poison) (void)hipMemset(q, (int)strtol(poison, nullptr, 0) & 0xff, count * sizeof(T) ? count * sizeof(T) : sizeof(T));
     return HS_OK;
+}
+
+// Uncached device memory (hipExtMallocWithFlags(hipDeviceMallocUncached): the buffers other ranks' kernels write into while this
+// rank's kernel runs) comes from a process-wide pool and is never handed back to the runtime while the process lives.  Measured
+// (round 6, tests/test_gpu_sharded.py in one process): after ~50 engines that each freed five such buffers, ordinary hipMalloc'ed
+// arrays of a LATER engine read back as zeros although its kernels had written them -- an address range that changes its memory
+// type between allocations is not safe here; with the pool (or without uncached memory) the same sequence is clean.
+struct UncachedPool {
+    std::mutex m;
+    std::multimap<size_t, void *> idle;      // capacity in bytes -> buffer
+};
+UncachedPool &uncached_pool() { static UncachedPool *p = new UncachedPool; return *p; }
+int uncached_alloc(hs_engine *h, void **out, size_t bytes) {
+    const size_t want = ((bytes ? bytes : 1) + 65535) & ~(size_t)65535;
+    {
+        UncachedPool &P = uncached_pool();
+        std::lock_guard<std::mutex> g(P.m);
+        auto it = P.idle.lower_bound(want);
+        if (it != P.idle.end() && it->first <= 2 * want) {
+            *out = it->second;
+            h->uncached.emplace_back(it->second, it->first);
+            P.idle.erase(it);
+            return HS_OK;
+        }
+    }
+    void *q = nullptr;
+    const hipError_t e = hipExtMallocWithFlags(&q, want, hipDeviceMallocUncached);
+    if (e != hipSuccess) return fail(h, HS_E_HIP, "hipExtMallocWithFlags(%zu B, uncached): %s", want, hipGetErrorString(e));
+    h->uncached.emplace_back(q, want);
+    *out = q;
+    return HS_OK;
+}
+void uncached_release(hs_engine *h) {
+    UncachedPool &P = uncached_pool();
+    std::lock_guard<std::mutex> g(P.m);
+    for (auto &b : h->uncached) P.idle.emplace(b.second, b.first);
+    h->uncached.clear();
 }
 
 template <typename T>
@@ -500,6 +547,7 @@ int do_reset_async(hs_engine *h) {
             h->initialised = true;
             h->net_ran = false;
             h->net_last_end = INT64_MIN;
+            h->tot_seen_valid = false;
             h->fresh = true;
             h->window_ends.clear();
             h->pending_async = false;
@@ -532,6 +580,7 @@ int launch_reset(hs_engine *h) {
     h->initialised = true;
     h->net_ran = false;
     h->net_last_end = INT64_MIN;
+    h->tot_seen_valid = false;
     h->fresh = true;
     h->window_ends.clear();
     h->pending_async = false;      // (a run enqueued before this reset has nothing left to finalise)
@@ -1178,7 +1227,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     }
     h->L.sink_created = (h->C > 1) ? h->L.sink_created_own : h->L.adm;
     if ((rc = dev_alloc(h, &h->tot, 1))) return rc;
-    HS_HIP(h, hipMemset(h->tot, 0, sizeof(Totals)));          // (Totals::net_cand_key stays null unless hs_engine_set_network sets it)
+    HS_HIP(h, hipMemset(h->tot, 0, sizeof(Totals)));
     if ((rc = dev_alloc(h, &h->cands, std::max<size_t>((size_t)h->n_blocks, (size_t)(n + 1) / 2)))) return rc;   // (the wide kernel: one per >= 2 LPs)
     if (h->C == 1 && h->uni_grid && !h->any_profile && h->cfg.mode == HS_MODE_SINGLE) {
         if ((rc = dev_alloc(h, &h->wide_ctl, 1))) return rc;
@@ -1187,6 +1236,9 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         HS_HIP(h, hipMemset(h->wide_ctl, 0, sizeof(WideCtl)));
     }
     HS_HIP(h, hipMemset(h->tot, 0, sizeof(Totals)));
+    // (the uploads and fills above went through the NULL stream; the engine's launches use a non-blocking stream, which does not
+    //  wait for it: everything is in place before the caller can enqueue a run)
+    HS_HIP(h, hipDeviceSynchronize());
     h->have_stations = true;
     return HS_OK;
 }
@@ -1425,9 +1477,9 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
             // a shard: the link queues other ranks may write into while this rank's kernel runs (LIVE exchange) -- uncached device
             // memory, exportable with hipIpcGetMemHandle: a peer's stores arrive in HBM past this device's L2
             void *a = nullptr, *b = nullptr, *c = nullptr;
-            HS_HIP(h, hipExtMallocWithFlags(&a, NQ * 4 * sizeof(int64_t), hipDeviceMallocUncached)); h->allocs.push_back(a);
-            HS_HIP(h, hipExtMallocWithFlags(&b, NL * sizeof(unsigned long long), hipDeviceMallocUncached)); h->allocs.push_back(b);
-            HS_HIP(h, hipExtMallocWithFlags(&c, NL * sizeof(int64_t), hipDeviceMallocUncached)); h->allocs.push_back(c);
+            if ((rc = uncached_alloc(h, &a, NQ * 4 * sizeof(int64_t)))) return rc;
+            if ((rc = uncached_alloc(h, &b, NL * sizeof(unsigned long long)))) return rc;
+            if ((rc = uncached_alloc(h, &c, NL * sizeof(int64_t)))) return rc;
             h->NX.aq_rec = (int64_t *)a; h->NX.aq_head = (unsigned long long *)b; h->NX.aq_ea = (int64_t *)c;
             HS_HIP(h, hipMemset(a, 0, NQ * 4 * sizeof(int64_t)));
             HS_HIP(h, hipMemset(b, 0, NL * sizeof(unsigned long long)));
@@ -1461,15 +1513,10 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
         if ((rc = dev_alloc(h, &h->L.sink_created_own, N * (size_t)h->L.cap))) return rc;
     }
     h->L.sink_created = h->L.sink_created_own;
-    {   // the election's tie check of the network engines (hs_net_window: Totals::net_cand_key)
-        long long *ck = nullptr;
-        if ((rc = dev_alloc(h, &ck, N * 4))) return rc;
-        HS_HIP(h, hipMemset(ck, 0, N * 4 * sizeof(long long)));
-        HS_HIP(h, hipMemcpy(&h->tot->net_cand_key, &ck, sizeof ck, hipMemcpyHostToDevice));
-    }
 #ifndef HS_LOGS_ROW_MAJOR   // (scratch build: the [cap][n_lp] logs the network engines had until round 5)
     h->L.lp_major = 1;          // an LP's records contiguous (hs_station.hpp RecordLogs::lp_major); nothing has been logged yet
 #endif
+    HS_HIP(h, hipDeviceSynchronize());      // (null-stream uploads and fills, as in hs_engine_set_stations)
     h->is_net = true;
     return HS_OK;
 }
@@ -1646,15 +1693,14 @@ int hs_engine_shard_ipc_export(hs_engine *h, void *handles_out) {
         const size_t nin = (size_t)2 * h->SC.world * h->SC.row, nb = (size_t)2 * h->SC.world * ((size_t)h->n_cross + 1);
         void *a = nullptr, *b = nullptr;
         // uncached: a peer's stores arrive in HBM past this device's L2, the readers use system-scope loads
-        HS_HIP(h, hipExtMallocWithFlags(&a, nin * 8, hipDeviceMallocUncached));
-        h->allocs.push_back(a);
-        HS_HIP(h, hipExtMallocWithFlags(&b, nb * 8, hipDeviceMallocUncached));
-        h->allocs.push_back(b);
+        { const int rca = uncached_alloc(h, &a, nin * 8); if (rca) return rca; }
+        { const int rcb = uncached_alloc(h, &b, nb * 8); if (rcb) return rcb; }
         HS_HIP(h, hipMemset(a, 0, nin * 8));
         {   // bounds start at "nothing known" (INT64_MIN), like the vector they replace
             std::vector<int64_t> init(nb, INT64_MIN);
             HS_HIP(h, hipMemcpy(b, init.data(), nb * 8, hipMemcpyHostToDevice));
         }
+        HS_HIP(h, hipDeviceSynchronize());  // (the peers write into these from their own streams)
         h->ipc_inbox = (int64_t *)a; h->ipc_bounds = (int64_t *)b;
     }
     hipIpcMemHandle_t hh[2];
@@ -1934,6 +1980,7 @@ int hs_engine_set_link_drops(hs_engine *h, int32_t link, const uint32_t *bits, i
     HS_HIP(h, hipStreamSynchronize(h->stream));
     HS_HIP(h, hipMemset(h->drop_bits_dev + b0 / 32, 0, (size_t)(cap / 32) * sizeof(uint32_t)));
     if (n_bits > 0) HS_HIP(h, hipMemcpy(h->drop_bits_dev + b0 / 32, bits, (size_t)((n_bits + 31) / 32) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HS_HIP(h, hipDeviceSynchronize());
     return HS_OK;
 }
 
@@ -1960,12 +2007,15 @@ int hs_engine_reset(hs_engine *h) {
 
 // Windows over a network: what a run_until with a later end does.  0: repeat the run from the start; 1: continue from the state the
 // last run left; 2: nothing moves.
-static int net_window_state(hs_engine *h, int64_t end_ns, int &state) {
+static int net_window_state(hs_engine *h, int64_t end_ns, int &state, const Totals *seen) {
     state = 0;
     if (h->exact || h->net_global || (h->flags & (1 << 24)) || h->NX.pend_pay == nullptr) return HS_OK;
-    HS_HIP(h, hipStreamSynchronize(h->stream));
     Totals t;
-    HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
+    if (seen) t = *seen;
+    else {
+        HS_HIP(h, hipStreamSynchronize(h->stream));
+        HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
+    }
     if (t.overflow != 0 || t.qoverflow != 0 || t.undecided != 0 || t.no_resume != 0) return HS_OK;
     state = t.cur_time > end_ns ? 2 : 1;
     return HS_OK;
@@ -1978,6 +2028,8 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
                     (long long)h->cfg.horizon_ns);
     HS_HIP(h, hipSetDevice(h->cfg.device));
     h->launches = 0;
+    const bool seen_valid = h->tot_seen_valid && !h->pending_async;
+    h->tot_seen_valid = false;
     HS_HIP(h, hipEventRecord(h->ev_a, h->stream));
     if (!h->initialised) { int rc = do_reset_async(h); if (rc) return rc; h->launches++; }
     HS_HIP(h, hipEventRecord(h->ev_k0, h->stream));
@@ -2002,7 +2054,7 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
             // Plain networks only (no prologue, no shard); a state the asynchronous kernel cannot take back (a bag larger than its
             // LDS column, an overflow) and debug flag 1 << 24 repeat the run from the start as rounds 4-5 did.
             int state = 0;
-            { const int rc = net_window_state(h, end_ns, state); if (rc) return rc; }
+            { const int rc = net_window_state(h, end_ns, state, seen_valid ? &h->tot_seen : nullptr); if (rc) return rc; }
             h->net_window_path = state == 0 ? 3 : state;
             if (state == 2) {            // the event beyond the last end lies beyond this one too: `current_time <= end` is false
                 h->net_last_end = end_ns;
@@ -2146,6 +2198,7 @@ int hs_engine_run_until(hs_engine *h, int64_t end_ns) {
     if (rc) return rc;
     Totals t;
     HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
+    h->tot_seen = t; h->tot_seen_valid = h->is_net;
     if (h->n_tab_rows > 0) {
         unsigned long long st[2] = {0ull, 0ull};
         HS_HIP(h, hipMemcpy(st, h->tab_status, sizeof st, hipMemcpyDeviceToHost));
@@ -2412,6 +2465,7 @@ void hs_engine_destroy(hs_engine *h) {
     for (void *p : h->ipc_opened) hipIpcCloseMemHandle(p);      // the peers' exchange buffers as mapped here
     if (h->live_stream) { hipStreamDestroy(h->live_stream); hipEventDestroy(h->live_ev); }
     for (void *p : h->allocs) hipFree(p);
+    uncached_release(h);                       // (back to the process-wide pool, never to the runtime)
     if (h->ev_a) hipEventDestroy(h->ev_a);
     if (h->ev_b) hipEventDestroy(h->ev_b);
     if (h->ev_k0) hipEventDestroy(h->ev_k0);

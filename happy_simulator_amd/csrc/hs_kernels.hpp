@@ -63,7 +63,7 @@ __device__ __forceinline__ Candidate cand_load_agent(const Candidate *p) {
     c.rank = __hip_atomic_load(&p->rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     c.valid = __hip_atomic_load(&p->valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     c.pad = __hip_atomic_load(&p->pad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (what the candidate is: the shards' network-wide re-ranking reads it, ShardCtl::cand_out[7])
-    c.pad2 = 0;
+    c.pad2 = __hip_atomic_load(&p->pad2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (hs_net_window: the workgroup's equal-key peers of its best candidate)
     return c;
 }
 __device__ __forceinline__ Candidate cand_none(int lp) {
@@ -1231,16 +1231,6 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
                 }
                 mine.rank = cand_rank(P, lp, n, mine.pad);        // ties on (time, creation time): `sources=[...]` order
             }
-            // What the election's tie check reads (below).  A tick ranks with its own Source's construction position, a Probe's tick
-            // with the Probe's; everything else of a station -- a departure, a message, an injected Request -- ranks with the
-            // station's first-listed Source, a STAND-IN for the Source (or schedule() call) its lineage goes back to, which on a
-            // network may be another station's.
-            long long *ck = tot->net_cand_key;
-            if (ck != nullptr) {
-                ck += (size_t)lp * 4;
-                ck[0] = mine.t; ck[1] = mine.t_created; ck[2] = mine.rcrt;
-                ck[3] = (long long)(unsigned)mine.depth | ((long long)(mine.valid ? 1 : 0) << 32) | ((long long)((mine.valid && mine.pad < 2) ? 1 : 0) << 33);
-            }
         }
         store_net<C>(S, X, NX, lp, n);
         if (S.undecided) atomicOr(&tot->undecided, S.undecided);
@@ -1282,10 +1272,19 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
     }
     if (!final_launch) return;
 
+    // The workgroup's best candidate, and (for the election's tie check below) whether ANOTHER station of this workgroup has a
+    // candidate with the same (time, creation time, steps from the root, root's creation time): Candidate::pad2 bit 0 -- any such
+    // peer, bit 1 -- one that ranks with a stand-in (pad < 2: a departure, a message, an injected Request).
+    Candidate bb = wave_c[0];
+    for (int w = 1; w < kBlock / 64; ++w) if (cand_less(wave_c[w], bb)) bb = wave_c[w];
+    {
+        const bool peer = bb.valid && mine.valid && mine.lp != bb.lp && mine.t == bb.t && mine.t_created == bb.t_created &&
+                          mine.rcrt == bb.rcrt && mine.depth == bb.depth;
+        const int peer_any = __syncthreads_or((int)peer), peer_standin = __syncthreads_or((int)(peer && mine.pad < 2));
+        bb.pad2 = (peer_any ? 1 : 0) | (peer_standin ? 2 : 0);
+    }
     if (tid == 0) {
-        Candidate b = wave_c[0];
-        for (int w = 1; w < kBlock / 64; ++w) if (cand_less(wave_c[w], b)) b = wave_c[w];
-        cands[blockIdx.x] = b;
+        cands[blockIdx.x] = bb;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned ticket = atomicAdd(&tot->done, 1u);
@@ -1312,20 +1311,16 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
     // two events' ancestry decides which the reference pops first.  Totals::undecided bit 1 -- hs_engine_run_until refuses the
     // result by name (lock-step constant arrivals, services and link latencies; never seen on a random workload) instead of
     // guessing; a shard reports it in bit 1 of its candidate's first word.
+    // (round 6: from the workgroups' summaries -- a station with the winner's key is its workgroup's best candidate or one of that
+    //  candidate's peers; until then the last workgroup read every station's key, 65 536 x 32 bytes through 256 lanes: most of this launch)
     bool tie = false;
-    {
-        const long long *ck = tot->net_cand_key;
-        if (ck != nullptr && b.valid && cur0 <= wend) {
-            const long long bv = __hip_atomic_load(&ck[(size_t)b.lp * 4 + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int q = tid; q < n; q += kBlock) {
-                const long long *c4 = ck + (size_t)q * 4;
-                const long long t = __hip_atomic_load(&c4[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const long long cr = __hip_atomic_load(&c4[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const long long rc = __hip_atomic_load(&c4[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const long long dv = __hip_atomic_load(&c4[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (q != b.lp && ((dv >> 32) & 1) != 0 && t == b.t && cr == b.t_created && rc == b.rcrt && (int)(unsigned)dv == b.depth &&
-                    (((dv | bv) >> 33) & 1) != 0) tie = true;
-            }
+    if (b.valid && cur0 <= wend) {
+        const bool b_standin = b.pad < 2;
+        for (int k = tid; k < (int)gridDim.x; k += kBlock) {
+            const Candidate c = cand_load_agent(&cands[k]);
+            if (!c.valid || c.t != b.t || c.t_created != b.t_created || c.rcrt != b.rcrt || c.depth != b.depth) continue;
+            if (c.lp != b.lp && (b_standin || c.pad < 2)) tie = true;            // another workgroup's best is a peer
+            if ((c.pad2 & 2) || (b_standin && (c.pad2 & 1))) tie = true;         // ... or one of that best's own peers is
         }
     }
     const int any_tie = __syncthreads_or((int)tie);

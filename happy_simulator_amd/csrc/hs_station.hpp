@@ -223,9 +223,6 @@ struct Totals {                 // engine-wide accumulators (device memory)
     // Network engines, windows: the station whose timestamp group the election stopped inside (-1: none; StationState::q holds what is
     // left of the group, hs_net_resume finishes it), and why the next run_until cannot continue from this state (0: it can)
     int pend_lp, no_resume;
-    // Network engines (set once by hs_engine_set_network, never reset): [n_lp][4] every station's first event beyond end_ns as the
-    // electing launch saw it {t, t_created, rcrt, depth | valid << 32 | stand-in << 33} -- the election's tie check (hs_net_window).
-    long long *net_cand_key;
 };
 
 struct Candidate {              // an LP's first event beyond end_ns (SINGLE-mode overshoot election)
@@ -238,7 +235,7 @@ struct Candidate {              // an LP's first event beyond end_ns (SINGLE-mod
     int rank;                   // last key: the position in the reference's construction order (`sources=[...]`, `probes=[...]`), cand_rank()
     int pad;                    // what the candidate is, for cand_rank: 0 departure / message / injected Request,
                                 // 2 + slot the tick of the LP's Source in that slot, 8 + slot the tick of the Probe in that slot
-    int pad2;
+    int pad2;                   // hs_net_window: the workgroup's other candidates with this one's key (bit 0: any, bit 1: a stand-in)
 };
 
 // the last election key of an LP's candidate (see StationParams::tie_rank)

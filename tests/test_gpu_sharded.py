@@ -255,3 +255,20 @@ def test_the_live_exchange_is_for_one_shard_per_process():
         assert not sn.live and sn.device_exchange
         summ = sn.run_until(p["end_ns"])
     assert summ.events_processed == one["events"] and summ.final_time_ns == one["final"]
+
+
+def test_fifty_engines_in_one_process_do_not_disturb_the_next_one():
+    """Round 6: a FRESH process that creates and destroys ~57 engines (ring_64 in every protocol and world, then two worlds of
+    ring_300_c2_cap) and then runs ring_300_c2_cap on three shards.  With the shards' uncached link queues handed back to the runtime
+    (hipFree) at every destroy, the last engine's ordinary arrays (routed, link counters) read back as ZEROS although its kernels had
+    written them; the process-wide pool of csrc/hs_engine.hip (uncached_alloc: never back to the runtime) keeps the sequence clean."""
+    import os, subprocess, sys
+
+    def block(name, worlds):
+        return [f"{name}:{w}:{p}" for w in worlds for p in "dcw"]
+
+    seq = block("ring_64", (1, 2, 3, 4)) + block("ring_300_c2_cap", (1, 2)) + ["ring_300_c2_cap:3:d"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "sharded_seq.py"), ",".join(seq)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert f"n = {len(seq)} bad = 0" in r.stdout, r.stdout[-2000:]

@@ -46,12 +46,16 @@ def multi_source(k):
                 assert more[slot][c] == r.generated[nd], (c, slot)
 
 
-def _ring(spec, flags):
+def _ring(spec, flags, windows=0):
     g, nodes = H.oracle_ring_graph(spec)
     p = H.ring_params(spec)
     r = O.run(g, p["end_ns"], seed=spec["seed"], schedule=[(nodes[c]["srv"], t) for c, t in p["schedule"]])
     eng, p = H.ring_engine_for_spec(spec, flags=flags)
     with eng:
+        if windows:         # driven window by window (round 6: every later end continues from the state the last run left)
+            rng = np.random.default_rng(spec["seed"] + 977)
+            for e in np.unique(rng.integers(1, p["end_ns"], windows)):
+                eng.run_until(int(e))
         eng.run_until(p["end_ns"])
         _check_against_oracle(spec, eng, r, nodes)
         for i in range(spec["n"]):
@@ -71,6 +75,22 @@ def ring_async(k):
 
 def ring_windowed(k):
     _ring(RS.ring_spec(k), 16)
+
+
+def ring_windows_async(k):      # 12 random window ends, then the end: == ONE run of the oracle's heap
+    _ring(RS.ring_spec(k), 0, windows=12)
+
+
+def ring_windows_windowed(k):
+    _ring(RS.ring_spec(k), 16, windows=12)
+
+
+def jitter_ring_windows_async(k):
+    _ring(RS.jitter_ring_spec(k), 0, windows=12)
+
+
+def multi_source_ring_windows_async(k):    # (engines with a prologue repeat the run per window: the same bits)
+    _ring(RS.multi_source_ring_spec(k), 0, windows=5)
 
 
 def jitter_ring_async(k):       # every link's jitter Exponential / Constant / None (round 4)
@@ -146,13 +166,16 @@ def tandem_probes(k):
 
 
 FAMILIES = [station, tie, multi_source, ring_async, ring_windowed, jitter_ring_async, jitter_ring_windowed, multi_source_ring_async,
-            multi_source_ring_windowed, lb,
+            multi_source_ring_windowed, ring_windows_async, ring_windows_windowed, jitter_ring_windows_async,
+            multi_source_ring_windows_async, lb,
             lb_probes, lb_profiles, lb_strategies, lb_workers, tandem, tandem_fan_in, tandem_probes]
 # (round 2 listed 13 tie storms here -- the cross-LP election of the one event beyond end_time, closed by the lineage key)
 KNOWN = set()
 # refused by design (HS_E_UNSUPPORTED), never guessed: a probe on the nanosecond of an event of its target on a load-balancer
 # graph; an arrival whose numerical inversion exceeds the evaluation budget (the reference needs minutes for it)
-REFUSALS = ("nanosecond of an event of its target", "adaptive-Simpson intervals")
+# ... and (windows families: 13 elections per case instead of one) an election of the event beyond a window end that is a lock-step
+# tie between two stations' injected Requests / departures / messages (hs_engine.h, DESIGN 1.1: network engines refuse it by name)
+REFUSALS = ("nanosecond of an event of its target", "adaptive-Simpson intervals", "lock-step tie between two stations")
 
 
 def main():
