@@ -67,3 +67,14 @@ python tools/api_profile.py 2>&1 | grep "^pass" > gpurun_out/final/${R}_api_prof
 echo "bench done $(( $(date +%s) - T0 )) s"
 cut -c1-400 gpurun_out/final/${R}_bench_default.json
 tail -3 gpurun_out/final/derive.log
+# round 6: windows over the ring -- continued from the last state against repeated from the start against one run
+python - <<'PY' > profiles/${R}_ring_windows.json 2> gpurun_out/final/ring_windows.err
+import json, subprocess, sys
+out = {}
+for tag, args in (("1000_windows_of_1ms", ["--end-s", "1", "--windows", "1000", "--repeat-windows", "100"]), ("60_windows_of_1s", ["--end-s", "60", "--windows", "60", "--repeat-windows", "60"])):
+    r = subprocess.run([sys.executable, "tools/ring_windows.py"] + args, capture_output=True, text=True, timeout=900)
+    out[tag] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else dict(error=r.stderr[-500:])
+json.dump(dict(what="65 536-station ring (the bench's), run_until with growing ends: wall ms of one run, of W windows continued from the last state, of windows repeated from the start (debug flag 1 << 24)", **out), sys.stdout, indent=1)
+PY
+cp profiles/${R}_ring_windows.json gpurun_out/final/ 2>/dev/null
+echo "windows done $(( $(date +%s) - T0 )) s"
