@@ -49,6 +49,9 @@ struct hs_engine {
     // ... whose nanosecond ties the passes' lineage key does not decide (Totals::undecided), or which stand next to Probes / scheduled
     // Requests / several Sources per Server, run on the single-heap loop (hs_exact.hpp) from start to end instead
     bool exact_only = false;
+    bool net_on_heap = false;     // ... a network that moved there behind an undecided election (tandem_fallback); hs_engine_reset moves it back
+    std::vector<int32_t> h_src_lp;     // the Sources in `sources=[...]` order (hs_engine_set_stations), kept for setup_exact_plain
+    std::vector<uint8_t> h_src_slot;
     bool tandem_fan_in = false;   // some Server is the downstream of several Servers: no passes, the single heap from the start
     bool exact_prologue = false;   // the prologue takes part in ordinary runs (pre-run events whose indices run-time events can pass)
     // ... but only where a pre-run event shares its nanosecond with another event of its LP, or while the run has created fewer
@@ -1041,6 +1044,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
                 for (int j = 0; j <= kMaxXSrc; ++j) if (has_src(i, j)) { so.push_back(i); sslot.push_back((uint8_t)j); }
         }
     }
+    h->h_src_lp = so; h->h_src_slot = sslot;      // (setup_exact_plain: the single-heap machinery built on demand)
     // the Probes in `probes=[...]` order: (LP, slot) pairs; default = LP-major, slot-minor
     std::vector<int32_t> po;
     std::vector<uint8_t> pslot;
@@ -1516,6 +1520,16 @@ int hs_engine_set_network(hs_engine *h, const hs_network *net) {
 #ifndef HS_LOGS_ROW_MAJOR   // (scratch build: the [cap][n_lp] logs the network engines had until round 5)
     h->L.lp_major = 1;          // an LP's records contiguous (hs_station.hpp RecordLogs::lp_major); nothing has been logged yet
 #endif
+    if (h->exact && h->cfg.mode == HS_MODE_SINGLE && !global) {
+        // a whole run on the single heap (an election the lineage key does not decide: tandem_fallback) takes one list cell per
+        // admitted Request, like tandem queues
+        const int64_t want = std::min<int64_t>(h->xs_host.pool_cap + (int64_t)n * h->L.cap, (int64_t)1 << 28);
+        if (want > h->xs_host.pool_cap) {
+            if ((rc = dev_alloc(h, &h->xs_host.pnext, (size_t)want))) return rc;
+            if ((rc = dev_alloc(h, &h->xs_host.pidx, (size_t)want))) return rc;
+            h->xs_host.pool_cap = want;
+        }
+    }
     HS_HIP(h, hipDeviceSynchronize());      // (null-stream uploads and fills, as in hs_engine_set_stations)
     h->is_net = true;
     return HS_OK;
@@ -1999,6 +2013,7 @@ int64_t hs_engine_read_send_log(hs_engine *h, int64_t *out_triples, int64_t capa
 int hs_engine_reset(hs_engine *h) {
     if (!h || !h->have_stations) return fail(h, HS_E_STATE, "hs_engine_reset: stations not set");
     HS_HIP(h, hipSetDevice(h->cfg.device));
+    if (h->net_on_heap) { h->exact_only = false; h->net_on_heap = false; }      // (the next run starts on the parallel engines again)
     int rc = do_reset_async(h);
     if (rc) return rc;
     HS_HIP(h, hipStreamSynchronize(h->stream));
@@ -2036,6 +2051,20 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
     if (h->is_net) {
         if (h->net_global) return fail(h, HS_E_STATE, "a shard of a partitioned network is driven with hs_engine_shard_*");
         h->net_window_path = 0;
+        if (h->exact_only) {
+            // the single-heap loop (hs_exact.hpp, no hand-over) holds the whole network since an election its lineage key did not
+            // decide (tandem_fallback): `_execute_until` again is that loop again -- the heap keeps every pending event
+            h->window_ends.push_back(end_ns);
+            if (end_ns > h->net_last_end) h->net_last_end = end_ns;
+            h->net_window_path = 1;
+            int rc = launch_prologue(h, end_ns);
+            if (rc) return rc;
+            h->net_ran = true;
+            HS_HIP(h, hipEventRecord(h->ev_k1, h->stream));
+            HS_HIP(h, hipEventRecord(h->ev_b, h->stream));
+            h->pending_async = true;
+            return HS_OK;
+        }
         if (h->net_ran) {
             // Windows over a network (core/simulation.py:527-541 `_run_window` = `_execute_until` again).  The reference pops events in
             // one global order whatever the window ends are, and every call stops behind the first event beyond its end -- so after
@@ -2071,7 +2100,7 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
             }
         }
         h->net_last_end = end_ns;
-        if (lazy_active(h)) h->window_ends.push_back(end_ns);
+        if (h->exact) h->window_ends.push_back(end_ns);       // (a skipped prologue's hazards and an undecided election repeat the run)
         int rc = launch_prologue(h, end_ns);
         if (rc) return rc;
         rc = run_net_async(h, end_ns);
@@ -2104,16 +2133,70 @@ static bool lazy_hazard(hs_engine *h, bool &hazard) {
     hazard = (t.undecided & 4) != 0 || total < 2ull * (unsigned long long)h->n_init;
     return true;
 }
+// The single-heap machinery (hs_exact.hpp) for an engine whose model has no pre-run events beyond its Sources' first ticks -- built
+// on demand, the first time an election needs the reference's sort-index ledger (tandem_fallback).  Mirrors the HS_MODE_SINGLE block
+// of hs_engine_set_stations with no Probes and no scheduled Requests.
+int setup_exact_plain(hs_engine *h) {
+    const int n = h->cfg.n_lp;
+    int rc;
+    const int32_t zero32 = 0; const uint8_t zero8 = 0; const int64_t zero64 = 0;
+    if ((rc = upload<int32_t>(h, &h->XI.src_lp, h->h_src_lp.data(), h->h_src_lp.size(), 0))) return rc;
+    if ((rc = upload<uint8_t>(h, &h->XI.src_slot, h->h_src_slot.data(), h->h_src_slot.size(), 0))) return rc;
+    if ((rc = upload<int32_t>(h, &h->XI.probe_lp, &zero32, 0, 0))) return rc;
+    if ((rc = upload<uint8_t>(h, &h->XI.probe_slot, &zero8, 0, 0))) return rc;
+    if ((rc = upload<int32_t>(h, &h->XI.sched_lp, &zero32, 0, 0))) return rc;
+    if ((rc = upload<int64_t>(h, &h->XI.sched_entry, &zero64, 0, 0))) return rc;
+    if ((rc = upload<int64_t>(h, &h->XI.sched_rank, &zero64, 0, 0))) return rc;
+    h->XI.n_src = (int32_t)h->h_src_lp.size(); h->XI.n_probe = 0; h->XI.n_sched = 0; h->XI.per_lp = 0;
+    if ((rc = dev_alloc(h, &h->XI.sched_idx, (size_t)1))) return rc;
+    HS_HIP(h, hipMemset(h->XI.sched_idx, 0, sizeof(uint32_t)));
+    const int64_t n_init = (int64_t)h->h_src_lp.size();
+    h->n_init = n_init;
+    h->xs_host = XState{};
+    h->xs_host.heap_cap = n_init + (int64_t)n * (h->C + 16) + 1024;
+    h->xs_host.pool_cap = std::min<int64_t>(2 * n_init + 16 * (int64_t)n + 1024 + (int64_t)n * h->L.cap, (int64_t)1 << 28);
+    if ((rc = dev_alloc(h, &h->xs_host.heap, (size_t)h->xs_host.heap_cap))) return rc;
+    if ((rc = dev_alloc(h, &h->xs_host.qhead, (size_t)n))) return rc;
+    if ((rc = dev_alloc(h, &h->xs_host.qtail, (size_t)n))) return rc;
+    if ((rc = dev_alloc(h, &h->xs_host.pnext, (size_t)h->xs_host.pool_cap))) return rc;
+    if ((rc = dev_alloc(h, &h->xs_host.pidx, (size_t)h->xs_host.pool_cap))) return rc;
+    if ((rc = dev_alloc(h, &h->xs_host.init_t, (size_t)std::max<int64_t>(n_init, 1)))) return rc;
+    if ((rc = dev_alloc(h, &h->xs, 1))) return rc;
+    HS_HIP(h, hipDeviceSynchronize());
+    h->exact = true;
+    return HS_OK;
+}
+
+constexpr unsigned long long kSingleHeapReplayMax = 4000000ull;   // events a network's undecided election may cost on the single lane (~2 us each)
 // Tandem queues: the passes met an order between two LPs' events that their lineage key does not decide (Totals::undecided).
 // The run since the last reset is repeated, window by window, on the single-heap loop -- the reference's own algorithm.
 int tandem_fallback(hs_engine *h) {
     // (also engines with several Sources per Server whose election rested on a departure's construction rank: set_stations)
-    if ((h->n_pass == 0 && !(h->any_xsrc && !h->is_net && h->cfg.mode == HS_MODE_SINGLE)) || h->exact_only || !h->exact) return HS_OK;
+    // (round 6: and station NETWORKS held by one engine whose election of the one event beyond end_time rested on a stand-in rank --
+    //  hs_net_window's tie check: until now refused by name; the single heap IS the reference's sort-index ledger)
+    const bool net_election = h->is_net && !h->net_global && h->cfg.mode == HS_MODE_SINGLE;
+    if ((h->n_pass == 0 && !(h->any_xsrc && !h->is_net && h->cfg.mode == HS_MODE_SINGLE) && !net_election) || h->exact_only) return HS_OK;
+    if (!h->exact && !net_election) return HS_OK;
     int und = 0;
     HS_HIP(h, hipMemcpy(&und, &h->tot->undecided, sizeof und, hipMemcpyDeviceToHost));
     if (h->n_pass == 0) {                     // several Sources per Server, no tandem queues: only the election's tie (value 2) moves the
         und &= 2;                             // run to the single heap; a skipped prologue's hazards (value 4) are prologue_fallback's
         if (!und) return HS_OK;
+    }
+    if (net_election && und) {
+        // one lane replays the whole run: only while that is seconds (lock-step constants live in small models); beyond it the run
+        // stays refused by name (hs_engine_run_until)
+        Totals t;
+        HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
+        unsigned long long total = 0;
+        for (int k = 0; k < HS_EV_KINDS; ++k) total += t.ev[k];
+        if (total > kSingleHeapReplayMax) return HS_OK;
+        if (!h->exact) {                       // a model without Probes / scheduled Requests / further Sources: no machinery yet
+            if (h->net_last_end == INT64_MIN) return HS_OK;
+            h->window_ends.assign(1, h->net_last_end);      // (plain networks keep no list of ends: the state is that of ONE run to the last one)
+            const int rcx = setup_exact_plain(h);
+            if (rcx) return rcx;
+        }
     }
     if (!und && lazy_active(h)) {             // (pre-run events next to tandem queues: lazy_prologue's short-run rule)
         bool hazard = false;
@@ -2124,6 +2207,7 @@ int tandem_fallback(hs_engine *h) {
     if (h->window_ends.empty()) return HS_OK;     // (nothing ran since the last reset: no run to repeat -- ADVICE r4)
     const std::vector<int64_t> ends = h->window_ends;
     h->exact_only = true;
+    h->net_on_heap = net_election;
     int rc = do_reset_async(h);
     if (rc) return rc;
     h->window_ends = ends;
@@ -2216,7 +2300,8 @@ int hs_engine_run_until(hs_engine *h, int64_t end_ns) {
         return fail(h, HS_E_UNSUPPORTED, "the one event beyond end_time is a lock-step tie between two stations (same time, creation time and "
                     "lineage) that only the reference's sort-index ledger decides, and one of the two is a departure, a message or an injected "
                     "Request, whose construction rank the network engines do not carry: refused instead of guessing (constant arrivals, "
-                    "services and link latencies in lock step; a different end_time or seed-free jitter avoids it)");
+                    "services and link latencies in lock step; a different end_time or seed-free jitter avoids it; runs of up to "
+                    "4 000 000 events are repeated on the single-heap loop and answered instead)");
     if (t.overflow & 16)
         return fail(h, HS_E_OVERFLOW, "the prologue (csrc/hs_exact.hpp) ran out of heap / payload-pool space");
     if (t.overflow & 8)

@@ -163,7 +163,9 @@ typedef struct hs_stations {
      * The election of the one event beyond end_ns: a pending DEPARTURE of a Server with several Sources ranks by its LP's
      * first-listed Source -- a stand-in for the Source its lineage goes back to.  A station engine (HS_MODE_SINGLE) notices when the
      * election comes down to that key and repeats the run on the single-heap loop (exact, one lane: hs_engine_prologue_path() == 2
-     * afterwards); the network engines and shards use the stand-in as it is (no case found in 6 000 random several-Source rings). */
+     * afterwards).  So does a station NETWORK held by one engine (since the round of ABI 14: runs of up to 4 000 000 events; the
+     * single-heap machinery is built on demand for models without pre-run events, and hs_engine_reset returns to the parallel
+     * engines); longer runs and shards of a partitioned network detect such an election and refuse it by name (HS_E_UNSUPPORTED). */
     const uint8_t *src_more_kind;      /* [3][n_lp] hs_source_kind; HS_SRC_NONE = none */
     const double *src_more_rate;       /* [3][n_lp] */
     const int64_t *src_more_stop_after_ns; /* [3][n_lp] < 0 = never; NULL = never */

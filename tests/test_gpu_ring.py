@@ -466,30 +466,44 @@ def _stand_in_tie_spec():
 
 
 @pytest.mark.parametrize("engine_flags", [0, 16], ids=["async", "windowed"])
-def test_an_election_that_rests_on_a_stand_in_rank_is_refused_not_guessed(engine_flags):
-    """the regression that fails on the stand-in.  The oracle (= the reference's sort-index ledger) processes
-    station 3's Request as the event beyond end_time; the engines either reproduce that (the single-heap prologue decided it) or
-    refuse the run by name -- never station 1."""
-    from happy_simulator_amd import _native as N
-
+def test_an_election_that_rests_on_a_stand_in_rank_is_decided_on_the_single_heap(engine_flags):
+    """the regression that fails on the stand-in.  The oracle (= the reference's sort-index ledger)
+    processes station 3's Request as the event beyond end_time; rounds 4-5 REFUSED the run by name, round 6 repeats it on the
+    single-heap loop (csrc/hs_exact.hpp -- the reference's own algorithm, one lane; hs_engine.hip tandem_fallback) and answers:
+    the oracle's station, never station 1 -- and a later window end continues on that heap."""
     spec = _stand_in_tie_spec()
     g, nodes = H.oracle_ring_graph(spec)
     p = H.ring_params(spec)
     assert p["end_ns"] < 3_000_000_000
-    r = O.run(g, p["end_ns"], seed=spec["seed"], schedule=[(nodes[c]["srv"], t) for c, t in p["schedule"]])
+    sched = [(nodes[c]["srv"], t) for c, t in p["schedule"]]
+    r = O.run(g, p["end_ns"], seed=spec["seed"], schedule=sched)
     assert r.final_time_ns == 3_000_000_000 and r.events_processed > 200
     spec_rev = dict(spec, schedule=list(reversed(spec["schedule"])))              # the other call order: the other station's Request runs
     g2, nodes2 = H.oracle_ring_graph(spec_rev)
     r2 = O.run(g2, p["end_ns"], seed=spec["seed"], schedule=[(nodes2[c]["srv"], t) for c, t in H.ring_params(spec_rev)["schedule"]])
     assert r.accepted[nodes[3]["srv"]] == r2.accepted[nodes2[3]["srv"]] + 1 and r.accepted[nodes[1]["srv"]] == r2.accepted[nodes2[1]["srv"]] - 1
-    eng, _ = H.ring_engine_for_spec(spec, flags=engine_flags)
-    with eng:
-        try:
+    for sp, rr, nn in ((spec, r, nodes), (spec_rev, r2, nodes2)):
+        eng, _ = H.ring_engine_for_spec(sp, flags=engine_flags)
+        with eng:
             eng.run_until(p["end_ns"])
-        except N.EngineError as e:
-            assert e.code == N.HS_E_UNSUPPORTED and "lock-step tie" in str(e)
-            return
-        _check_against_oracle(spec, eng, r, nodes)          # (decided on the single heap: then it must be the reference's answer)
+            _check_against_oracle(sp, eng, rr, nn)
+            assert eng.prologue_path() == 2                 # on the single heap
+            eng.reset()                                     # ... until the next reset: the parallel engines again, the same tie, the same answer
+            eng.run_until(p["end_ns"] - 1_000_000)
+            eng.run_until(p["end_ns"])
+            _check_against_oracle(sp, eng, rr, nn)
+    # a longer horizon: the run to the tie, then a later end ON the heap == one oracle run to that end
+    later = dict(spec, end_s=3.4)
+    g3, nodes3 = H.oracle_ring_graph(later)
+    p3 = H.ring_params(later)
+    r3 = O.run(g3, p3["end_ns"], seed=later["seed"], schedule=[(nodes3[c]["srv"], t) for c, t in p3["schedule"]])
+    eng, _ = H.ring_engine_for_spec(later, flags=engine_flags)
+    with eng:
+        eng.run_until(p["end_ns"])
+        assert eng.prologue_path() == 2
+        eng.run_until((p["end_ns"] + p3["end_ns"]) // 2)
+        eng.run_until(p3["end_ns"])
+        _check_against_oracle(later, eng, r3, nodes3)
 
 
 @pytest.mark.parametrize("n", [66_048, 131_072])
@@ -567,3 +581,63 @@ def test_a_later_window_end_continues_from_the_state_the_last_run_left(spec, fla
             else:
                 assert paths[0] == 0 and set(paths[1:]) <= {2, 3} and 3 in paths, paths
     assert states[0] == states[1 << 24]          # ... and an intermediate state is the same either way
+
+
+@ENGINES
+def test_a_lock_step_network_without_pre_run_events_is_decided_on_the_single_heap_too(engine_flags):
+    """Round 6: five identical stations -- Source.constant(10) -> Server(Constant 0.05 s, queue capacity 2) ->
+    NetworkLink(20 ms, no jitter) -> the next Server -- run in lock step: at every end_time just before a common departure instant the
+    election's candidates are five departures with one lineage key, which only the reference's sort-index ledger orders.  The model has no
+    Probe, scheduled Request or further Source (no prologue machinery); the engine builds it on demand, repeats the run on the
+    single-heap loop and returns the oracle's answer -- rounds 4-5 refused such runs by name.  Later ends continue on the heap; a
+    reset returns to the parallel engines (where this model ties again at whatever end)."""
+    from happy_simulator_amd import _native as N
+    from happy_simulator_amd.engine import NetworkArrays, StationArrays, StationEngine
+
+    n, seed = 5, 31
+    g = O.Graph()
+    src = [g.source(O.ARR_CONSTANT, 10.0, stream_base=i) for i in range(n)]
+    srv = [g.server(O.LAT_CONST, 0.05, concurrency=1, queue_cap=2, stream_base=i) for i in range(n)]
+    lnk = [g.link(0.02, None, stream_base=i) for i in range(n)]
+    for i in range(n):
+        g.target[src[i]] = srv[i]
+        g.target[srv[i]] = lnk[i]
+        g.target[lnk[i]] = srv[(i + 1) % n]
+    st = StationArrays(
+        n=n, src_kind=np.full(n, N.SRC_CONSTANT, np.uint8), src_rate=np.full(n, 10.0), src_stop_after_ns=np.full(n, -1, np.int64),
+        concurrency=np.ones(n, np.int32), svc_kind=np.full(n, N.LAT_CONSTANT, np.uint8), svc_mean_s=np.full(n, 0.05),
+        queue_cap=np.full(n, 2, np.int64), egress=np.full(n, N.EGRESS_NONE, np.uint8))
+    net = NetworkArrays(
+        egress_kind=np.full(n, N.EGRESS_LINK, np.uint8), router_target0=np.full(n, -1, np.int32),
+        router_target1=np.full(n, -1, np.int32), link_of=np.arange(n, dtype=np.int32),
+        link_src=np.arange(n, dtype=np.int32), link_dst=((np.arange(n) + 1) % n).astype(np.int32),
+        link_lat_min_s=np.full(n, 0.02), link_jitter_kind=np.full(n, N.LAT_CONSTANT, np.uint8), link_jitter_mean_s=np.zeros(n),
+        link_stream_base=np.arange(n, dtype=np.uint64), link_loss_rate=np.zeros(n))
+    ends = [1_149_999_999, 1_150_000_000, 1_500_000_000, 2_349_999_990]
+    horizon = ends[-1]
+
+    def check(eng, r):
+        s = eng.summary()
+        stt, ns = eng.lp_stats(), eng.net_stats()
+        assert s.events_processed == r.events_processed and s.final_time_ns == r.final_time_ns
+        np.testing.assert_array_equal(s.events_by_kind, r.events_by_kind)
+        for k, arr in (("accepted", r.accepted), ("dropped", r.dropped), ("completed", r.completed), ("queue_depth", r.depth),
+                       ("active", r.active), ("total_service_s", r.total_service_s)):
+            np.testing.assert_array_equal(stt[k], arr[srv], err_msg=k)
+        np.testing.assert_array_equal(ns["link_packets_sent"], r.packets_sent[lnk])
+        assert r.dropped[srv].sum() > 0 or r.final_time_ns < 600_000_000
+
+    with StationEngine(st, mode=N.MODE_SINGLE, horizon_ns=horizon, seed=seed, log_capacity=256, network=net) as eng:
+        if engine_flags:
+            eng.set_debug_flags(engine_flags)
+        assert eng.prologue_path() == 0                  # no prologue machinery
+        for e in ends:                                   # the first end is a five-way tie of departures
+            eng.run_until(e)
+            check(eng, O.run(g, e, seed=seed))
+            assert eng.prologue_path() == 2              # ... decided on the single heap, where the later ends continue
+        eng.reset()                                      # back on the parallel engines: one run to the last end (another tie)
+        eng.run_until(ends[-1])
+        check(eng, O.run(g, ends[-1], seed=seed))
+        assert eng.prologue_path() == 2
+        eng.reset()
+        assert eng.prologue_path() == 0                  # (a reset returns to the parallel engines -- until the next tie)
