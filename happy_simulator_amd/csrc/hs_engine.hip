@@ -176,7 +176,7 @@ int dev_alloc(hs_engine *h, T **p, size_t count) {
     h->allocs.push_back(q);
     *p = (T *)q;
     // debug: HS_POISON_ALLOC=<byte> fills every device allocation with that byte -- nothing may depend on what hipMalloc hands out
-    // (memory of an engine destroyed earlier in the process), tests/test_gpu_sharded.py runs a case under it
+    // (memory of an engine destroyed earlier in the process): tests/test_gpu_sharded.py::test_nothing_depends_on_what_the_allocator_hands_out
     static const char *poison = getenv("HS_POISON_ALLOC");
     if (poison && *poison) (void)hipMemset(q, (int)strtol(poison, nullptr, 0) & 0xff, count * sizeof(T) ? count * sizeof(T) : sizeof(T));
     return HS_OK;

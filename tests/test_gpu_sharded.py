@@ -272,3 +272,16 @@ def test_fifty_engines_in_one_process_do_not_disturb_the_next_one():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "sharded_seq.py"), ",".join(seq)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert f"n = {len(seq)} bad = 0" in r.stdout, r.stdout[-2000:]
+
+
+def test_nothing_depends_on_what_the_allocator_hands_out():
+    """HS_POISON_ALLOC (csrc/hs_engine.hip dev_alloc): every device allocation filled with 0xAB before use -- single engines and shards
+    in every protocol still equal each other (a fresh process, so that the poison is what the engines see)."""
+    import os, subprocess, sys
+
+    seq = ["ring_64:2:d", "ring_7_dense:3:c", "ring_300_c2_cap:2:w", "ring_33_fixed_latency:4:d", "ring_300_c2_cap:3:d"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "sharded_seq.py"), ",".join(seq)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HS_POISON_ALLOC="0xAB"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert f"n = {len(seq)} bad = 0" in r.stdout, r.stdout[-2000:]
