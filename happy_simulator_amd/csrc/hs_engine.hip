@@ -91,6 +91,7 @@ struct hs_engine {
     bool net_resume = false;            // ... and this run_until continues from the state that run left (hs_net_resume first)
     int64_t net_resume_from = 0;        // ... whose end_ns this was
     int net_window_path = 0;            // hs_engine_window_path
+    int xs_phase_seen = 0;              // ... and the prologue's phase (XState::phase)
     Totals tot_seen{};                  // the totals hs_engine_run_until read behind the last run (valid until the next launch):
     bool tot_seen_valid = false;        //   the next window's decision without another round trip to the device
     std::vector<int64_t> drop_off_host;  // table-decided link losses (hs_network.link_drop_capacity): bit offsets per link
@@ -2024,13 +2025,19 @@ int hs_engine_reset(hs_engine *h) {
 // last run left; 2: nothing moves.
 static int net_window_state(hs_engine *h, int64_t end_ns, int &state, const Totals *seen) {
     state = 0;
-    if (h->exact || h->net_global || (h->flags & (1 << 24)) || h->NX.pend_pay == nullptr) return HS_OK;
+    if (h->net_global || (h->flags & (1 << 24)) || h->NX.pend_pay == nullptr) return HS_OK;
     Totals t;
+    int phase = h->xs_phase_seen;
     if (seen) t = *seen;
     else {
         HS_HIP(h, hipStreamSynchronize(h->stream));
         HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
+        if (h->exact && h->xs && !h->XI.per_lp) HS_HIP(h, hipMemcpy(&phase, &h->xs->phase, sizeof phase, hipMemcpyDeviceToHost));
     }
+    // An engine with a prologue (hs_exact.hpp) continues while the prologue is skipped (lazy_prologue: a hazard repeats ALL windows
+    // behind it, prologue_fallback) or once it has handed over to the parallel engines (phase 2: its launches are no-ops from then on);
+    // in between -- the single lane still holds the heap at a window end -- the run is repeated
+    if (h->exact && !lazy_active(h) && phase != 2) return HS_OK;
     if (t.overflow != 0 || t.qoverflow != 0 || t.undecided != 0 || t.no_resume != 0) return HS_OK;
     state = t.cur_time > end_ns ? 2 : 1;
     return HS_OK;
@@ -2230,12 +2237,20 @@ int prologue_fallback(hs_engine *h) {
     h->lazy_failed = true;
     int rc = do_reset_async(h);
     if (rc) return rc;
+    int64_t prev = INT64_MIN;
     for (int64_t e : ends) {
         rc = launch_prologue(h, e);
         if (rc) return rc;
-        if (h->is_net) { rc = run_net_async(h, e); if (rc) return rc; }
+        if (h->is_net) {
+            // (round 6: the windows of a network continue from one another -- hs_engine_run_until_async -- so does their repetition)
+            if (prev != INT64_MIN) { h->net_resume = true; h->net_resume_from = prev; }
+            rc = run_net_async(h, e);
+            h->net_resume = false;
+            if (rc) return rc;
+        }
         else { rc = launch_run_dispatch(h, e); if (rc) return rc; h->launches++; }
         HS_HIP(h, hipGetLastError());
+        prev = e;
     }
     // the reset above forgot the network's last window end; an earlier or equal end after this moves nothing
     if (h->is_net) h->net_last_end = ends.back();
@@ -2283,6 +2298,7 @@ int hs_engine_run_until(hs_engine *h, int64_t end_ns) {
     Totals t;
     HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
     h->tot_seen = t; h->tot_seen_valid = h->is_net;
+    if (h->is_net && h->exact && h->xs && !h->XI.per_lp) HS_HIP(h, hipMemcpy(&h->xs_phase_seen, &h->xs->phase, sizeof(int), hipMemcpyDeviceToHost));
     if (h->n_tab_rows > 0) {
         unsigned long long st[2] = {0ull, 0ull};
         HS_HIP(h, hipMemcpy(st, h->tab_status, sizeof st, hipMemcpyDeviceToHost));

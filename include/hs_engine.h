@@ -335,8 +335,9 @@ int hs_engine_prologue_path(const hs_engine *h);
  * messages in flight, the links' lower bounds, and the timestamp group the election of the one event beyond the earlier end stopped
  * inside -- finished first, csrc/hs_kernels.hpp hs_net_resume), 2 nothing moved (the end is not beyond the event the earlier run
  * already processed: the reference's loop condition `current_time <= end` is false), 3 the run was REPEATED from the start to the
- * new end (engines with a prologue -- Probes, scheduled Requests, several Sources per Server --, a state the asynchronous kernel
- * cannot take back, debug flag 1 << 24): exact as well, at the cost of the prefix.  Diagnostics only; results are identical. */
+ * new end (an engine whose prologue -- Probes, scheduled Requests, several Sources per Server -- still holds the single-lane heap at
+ * the window end, a state the asynchronous kernel cannot take back, debug flag 1 << 24): exact as well, at the cost of the prefix.
+ * Diagnostics only; results are identical. */
 int hs_engine_window_path(const hs_engine *h);
 
 int hs_engine_create(const hs_config *cfg, hs_engine **out);
