@@ -1597,10 +1597,6 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
                     else mA = sat(S.next_time(), c_sdl);
                 } else S.bound_map(next_l, next_lat, mA, mB, mD);
             }
-            // (a lane that is done still sends -- in the NEXT run_until: everything at or before end_ns has happened, so whatever it sends
-            //  leaves after end_ns.  "Never" would do for this launch, but the bounds its neighbours derive from it stay in the links'
-            //  words, and a later window end continues from them: round 6)
-            else if (done && next_l >= 0) mA = sat(end_ns + 1, next_lat);
             if (!chain) {                                             // head of a chain: its input bound is known
                 if (!done && S.undrained < H) H = S.undrained;
                 int64_t v = sat(H, mB);
@@ -1779,11 +1775,18 @@ __global__ void __launch_bounds__(kBlock) hs_net_async(StationParams P, NetParam
             if ((flags & 128) && wave_idle) __builtin_amdgcn_s_sleep(64);   // experiment: back off when idle
             groups_before = n_groups;
         }
-        if (pub_skipped) {                                    // the in-wavefront link's word, once (payloads: drained in the loop)
+        // The links' words as the launch leaves them.  (i) an in-wavefront link's word, once (payloads: drained in the loop).  (ii) A
+        // later window end continues from these words (hs_engine_run_until_async), and a bound may rest on neighbours that were DONE:
+        // in the scan a lane that is done contributes "never" -- right for this launch, not for the next.  What is certain is that
+        // nothing has been sent at or before end_ns: every word is capped at end_ns + 1 + the link's transit floor (round 6; found on
+        // the full-size ring only: 3 - 16 of 65 536 stations, all at wavefront / DPP-row boundaries, differed in the second window).
 #pragma unroll
-            for (int o = 0; o < kOut; ++o)
-                if (out_l[o] >= 0 && out_l[o] == next_l)
-                    ag_store(&NX.aq_ea[next_l], pk_pack(out_pub[o], (unsigned long long)S.link_sent_of(next_l), NX.pk_base));
+        for (int o = 0; o < kOut; ++o) {
+            const int32_t l = out_l[o];
+            if (l < 0 || out_remote[o]) continue;
+            const int64_t cap = sat(end_ns + 1, out_lat[o]);
+            if (out_pub[o] > cap || (pub_skipped && l == next_l))
+                ag_store(&NX.aq_ea[l], pk_pack(out_pub[o] < cap ? out_pub[o] : cap, (unsigned long long)S.link_sent_of(l), NX.pk_base));
         }
         store_net<C, true, PF, UNI>(S, X, NX, lp, n);
         if constexpr (PF) { if (S.undecided) atomicOr(&tot->undecided, S.undecided); }
