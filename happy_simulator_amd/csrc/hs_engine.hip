@@ -2052,6 +2052,7 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
     h->launches = 0;
     const bool seen_valid = h->tot_seen_valid && !h->pending_async;
     h->tot_seen_valid = false;
+    h->net_resume = false;
     HS_HIP(h, hipEventRecord(h->ev_a, h->stream));
     if (!h->initialised) { int rc = do_reset_async(h); if (rc) return rc; h->launches++; }
     HS_HIP(h, hipEventRecord(h->ev_k0, h->stream));
@@ -2087,8 +2088,9 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
             // Round 6: a later end CONTINUES from the state the last run left -- every station's rows, the bags (the final launch took
             // the link queues' leftovers into them), the links' bounds (lower bounds whatever the end was: NetStation::pre_send) and
             // the group the election stopped inside (hs_net_resume) -- O(window) as the reference's `_run_window`, not O(prefix).
-            // Plain networks only (no prologue, no shard); a state the asynchronous kernel cannot take back (a bag larger than its
-            // LDS column, an overflow) and debug flag 1 << 24 repeat the run from the start as rounds 4-5 did.
+            // Not for shards; a prologue that still holds the single-lane heap (net_window_state), a state the asynchronous kernel
+            // cannot take back (a bag larger than its LDS column, an overflow) and debug flag 1 << 24 repeat the run from the start
+            // as rounds 4-5 did.
             int state = 0;
             { const int rc = net_window_state(h, end_ns, state, seen_valid ? &h->tot_seen : nullptr); if (rc) return rc; }
             h->net_window_path = state == 0 ? 3 : state;
