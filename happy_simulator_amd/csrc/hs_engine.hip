@@ -919,7 +919,8 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
     if ((rc = upload<uint8_t>(h, &h->P.probe_metric, pm.data(), (size_t)n * kMaxProbes, 255))) return rc;
     if ((rc = upload<double>(h, &h->P.probe_rate, prate.data(), (size_t)n * kMaxProbes, 1.0))) return rc;
     h->P.tabs = nullptr;
-    if (h->any_timevarying || h->any_probe || !tandem.empty() || h->any_xsrc) {
+    const bool sched_single = h->any_sched && h->cfg.mode == HS_MODE_SINGLE;      // (the election's tie check: TickTables::standin_sched)
+    if (h->any_timevarying || h->any_probe || !tandem.empty() || h->any_xsrc || sched_single) {
         // Tick tables (hs_tables.hpp): one row per time-varying Source (Poisson ones draw from their own arrival stream;
         // deterministic ones with equal parameters share a row) and one per distinct Probe interval (a Probe's tick times are a
         // property of (interval, start) alone).
@@ -990,6 +991,12 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
             if ((rc = dev_alloc(h, &tt.cand_key, (size_t)n * 4))) return rc;
             HS_HIP(h, hipMemset(tt.cand_key, 0, (size_t)n * 4 * sizeof(int64_t)));
         }
+        if (tandem.empty() && !h->any_xsrc && sched_single) {
+            // injected Requests only: the same tie check, every departure / injected Request a stand-in (TickTables::standin_sched)
+            if ((rc = dev_alloc(h, &tt.cand_key, (size_t)n * 4))) return rc;
+            HS_HIP(h, hipMemset(tt.cand_key, 0, (size_t)n * 4 * sizeof(int64_t)));
+        }
+        tt.standin_sched = sched_single ? 1 : 0;
         if (tandem.empty() && h->any_xsrc && h->cfg.mode == HS_MODE_SINGLE) {
             // several Sources per Server: a pending DEPARTURE's last election key is the construction rank of the Source its lineage
             // goes back to, which the engine does not carry -- cand_rank() uses the LP's first-listed Source.  When the election of
@@ -1189,7 +1196,7 @@ int hs_engine_set_stations(hs_engine *h, const hs_stations *st) {
         h->xs_host = XState{};
         h->xs_host.heap_cap = n_init + (int64_t)n * (h->C + 16) + 1024;
         h->xs_host.pool_cap = 2 * n_init + 16 * (int64_t)n + 1024;
-        if (!tandem.empty() || h->any_xsrc)       // a whole run (tandem queues; several Sources per Server after an undecided election): one list cell per admitted Request
+        if (!tandem.empty() || h->any_xsrc || h->any_sched)       // a whole run (tandem queues; several Sources per Server after an undecided election): one list cell per admitted Request
             h->xs_host.pool_cap = std::min<int64_t>(h->xs_host.pool_cap + (int64_t)n * cap, (int64_t)1 << 30);
         if ((rc = dev_alloc(h, &h->xs_host.heap, (size_t)h->xs_host.heap_cap))) return rc;
         if ((rc = dev_alloc(h, &h->xs_host.qhead, (size_t)n))) return rc;
@@ -2118,7 +2125,7 @@ int hs_engine_run_until_async(hs_engine *h, int64_t end_ns) {
     } else {
         if (h->n_pass > 0 && ((h->flags & (1 << 17)) || ((h->flags & (1 << 16)) && h->exact_prologue)) && h->exact && h->window_ends.empty())
             h->exact_only = true;   // debug: single heap from the start (1 << 16: wherever a prologue exists -- with tandem queues that is this loop)
-        if (h->n_pass > 0 || lazy_active(h) || (h->any_xsrc && h->exact)) h->window_ends.push_back(end_ns);
+        if (h->n_pass > 0 || lazy_active(h) || ((h->any_xsrc || h->any_sched) && h->exact)) h->window_ends.push_back(end_ns);
         int rc = launch_prologue(h, end_ns);
         if (rc) return rc;
         rc = launch_run_dispatch(h, end_ns);
@@ -2184,7 +2191,8 @@ int tandem_fallback(hs_engine *h) {
     // (round 6: and station NETWORKS held by one engine whose election of the one event beyond end_time rested on a stand-in rank --
     //  hs_net_window's tie check: until now refused by name; the single heap IS the reference's sort-index ledger)
     const bool net_election = h->is_net && !h->net_global && h->cfg.mode == HS_MODE_SINGLE;
-    if ((h->n_pass == 0 && !(h->any_xsrc && !h->is_net && h->cfg.mode == HS_MODE_SINGLE) && !net_election) || h->exact_only) return HS_OK;
+    const bool station_election = (h->any_xsrc || h->any_sched) && !h->is_net && h->cfg.mode == HS_MODE_SINGLE;
+    if ((h->n_pass == 0 && !station_election && !net_election) || h->exact_only) return HS_OK;
     if (!h->exact && !net_election) return HS_OK;
     int und = 0;
     HS_HIP(h, hipMemcpy(&und, &h->tot->undecided, sizeof und, hipMemcpyDeviceToHost));
@@ -2380,7 +2388,7 @@ int hs_engine_bench_runs(hs_engine *h, int64_t end_ns, int32_t repeats, float *k
     for (auto &e : ev) hipEventDestroy(e);
     Totals t;                                                       // a timed run that overflowed is not a result
     HS_HIP(h, hipMemcpy(&t, h->tot, sizeof t, hipMemcpyDeviceToHost));
-    if ((h->n_pass > 0 || h->any_xsrc) && !h->is_net && !h->exact_only && (t.undecided & 3))
+    if ((h->n_pass > 0 || h->any_xsrc || h->any_sched) && !h->is_net && !h->exact_only && (t.undecided & 3))
         return fail(h, HS_E_UNSUPPORTED, "tandem queues / several Sources per Server: this configuration needs the single-heap path (lock-step ties); hs_engine_run_until "
                                          "switches to it, hs_engine_bench_runs does not");
     if (t.qoverflow) return fail(h, HS_E_UNSUPPORTED, "a same-timestamp event cascade exceeded the in-group queue");

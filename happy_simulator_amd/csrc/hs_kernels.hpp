@@ -691,7 +691,7 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
                 int64_t *ck = P.tabs->cand_key + (size_t)lp * 4;
                 ck[0] = mine.t; ck[1] = mine.t_created; ck[2] = mine.rcrt;
                 ck[3] = (int64_t)(uint32_t)mine.depth | ((int64_t)(mine.valid ? 1 : 0) << 32) |
-                        ((int64_t)((mine.valid && mine.pad < 2 && S.n_xsrc > 0) ? 1 : 0) << 33);
+                        ((int64_t)((mine.valid && mine.pad < 2 && (S.n_xsrc > 0 || P.tabs->standin_sched != 0)) ? 1 : 0) << 33);
             }
             if (S.undecided) atomicOr(&tot->undecided, S.undecided);
         }

@@ -58,6 +58,11 @@ struct TickTables {
     // the LP's first-listed Source.  tools/election_rules.py (`rsrc`): right on 9 100 several-Source cases incl. the three the
     // stand-in gets wrong.  [C][n_lp] and [kQCap][n_lp]; null = the engine has no LP with several Sources.
     uint8_t *rs_dep, *rs_q;
+    // the engine has Requests injected with Simulation.schedule(): a departure's lineage may go back to one of them, whose construction
+    // rank (the order of the schedule() calls, across LPs) the engine does not carry -- every departure / injected Request candidate
+    // ranks with a stand-in in the election's tie check (round 6: tools/gpu_random_sweep.py, tie case 120013 -- two Requests
+    // scheduled for the end instant on two lock-step Servers; until then only LPs with several Sources were checked)
+    int32_t standin_sched;
     // start of the run: the creation stamp of the events constructed before it (the Sources' first ticks).  The reference numbers
     // those first, then restarts the count for the run's own events -- so until the run has created as many events as there are
     // Sources, a new event can sort BEFORE a first tick of its nanosecond, and the breadth-first order the lineage key stands for
