@@ -2045,7 +2045,9 @@ static int net_window_state(hs_engine *h, int64_t end_ns, int &state, const Tota
     // behind it, prologue_fallback) or once it has handed over to the parallel engines (phase 2: its launches are no-ops from then on);
     // in between -- the single lane still holds the heap at a window end -- the run is repeated
     if (h->exact && !lazy_active(h) && phase != 2) return HS_OK;
-    if (t.overflow != 0 || t.qoverflow != 0 || t.undecided != 0 || t.no_resume != 0) return HS_OK;
+    // (undecided bit 2 -- a pre-run root beside another root of its nanosecond -- only matters while the prologue is skipped)
+    const int und = lazy_active(h) ? t.undecided : (t.undecided & ~4);
+    if (t.overflow != 0 || t.qoverflow != 0 || und != 0 || t.no_resume != 0) return HS_OK;
     state = t.cur_time > end_ns ? 2 : 1;
     return HS_OK;
 }

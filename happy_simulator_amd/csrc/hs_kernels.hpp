@@ -322,6 +322,9 @@ __device__ __forceinline__ Candidate make_candidate(const Station<C, PF, UNI> &S
     else {
 #pragma unroll
         for (int i = 0; i < C; ++i) if (i == w - 1) { c.depth = S.dpD[i]; c.rcrt = S.rcD[i]; if (PF && S.rs_dp != nullptr && S.lsrcD[i] != 255u) c.pad = 2 + (int)S.lsrcD[i]; }
+        c.pad2 = 1;     // a DEPARTURE: whatever Source its rank borrows (the lineage's: a rule of thumb, tools/election_rules.py), a tie of
+                        // the whole lineage key with another LP's candidate goes to the single heap (hs_station_run's tie check; round 6:
+                        // multi_source case 130100 of tools/gpu_random_sweep.py is a counter-example to the rule)
     }
     return c;
 }
@@ -691,7 +694,7 @@ __global__ void __launch_bounds__(PC ? 2 * kBlock : kBlock) hs_station_run(Stati
                 int64_t *ck = P.tabs->cand_key + (size_t)lp * 4;
                 ck[0] = mine.t; ck[1] = mine.t_created; ck[2] = mine.rcrt;
                 ck[3] = (int64_t)(uint32_t)mine.depth | ((int64_t)(mine.valid ? 1 : 0) << 32) |
-                        ((int64_t)((mine.valid && mine.pad < 2 && (S.n_xsrc > 0 || P.tabs->standin_sched != 0)) ? 1 : 0) << 33);
+                        ((int64_t)((mine.valid && (mine.pad < 2 || mine.pad2 != 0) && (S.n_xsrc > 0 || P.tabs->standin_sched != 0)) ? 1 : 0) << 33);
             }
             if (S.undecided) atomicOr(&tot->undecided, S.undecided);
         }
@@ -1354,6 +1357,7 @@ __global__ void __launch_bounds__(kBlock) hs_net_window(StationParams P, NetPara
             tot->pend_lp = pend != 0u ? b.lp : -1;
             if (!fits || NX.pend_pay == nullptr) tot->no_resume |= 2;
             store_net<C>(W, X, NX, b.lp, n);
+            if (W.undecided) atomicOr(&tot->undecided, W.undecided);           // (a pre-run root beside another root of the nanosecond)
             for (int k = 0; k < 11; ++k) if (W.ev[k]) atomicAdd(&tot->ev[k], (unsigned long long)W.ev[k]);
             if (W.evp[0]) atomicAdd(&tot->ev[13], (unsigned long long)W.evp[0]);
             if (W.ev[6]) atomicAdd(&tot->completed, (unsigned long long)W.ev[6]);

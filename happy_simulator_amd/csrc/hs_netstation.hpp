@@ -1408,6 +1408,7 @@ struct NetStation {
     // the network's earliest pending work).  Returns true for a departure: its continuation has run (statistics), the forwarded
     // request's way out (Sink / RandomRouter / NetworkLink -- reference events of their own) has not.
     __device__ __forceinline__ bool root_first(int w, int64_t t) {
+        pre_run_hazard(t);
         cd = 0; cr = root_crt(w);
         if (w == 1) root_tick(t);                                         // the SourceEvent; its Request / a same-ns next tick wait in the FIFO
         else if (w >= 64) root_msg(w - 64, t);                            // the link's continuation; its Request@Server waits
@@ -1635,22 +1636,16 @@ struct NetStation {
         HS_CY2(3)
     }
 
-    __device__ __forceinline__ void run_group(int64_t t, bool force_general) {
-        int n_at = (A == t) ? 1 : 0;
-#pragma unroll
-        for (int i = 0; i < C; ++i) n_at += (D[i] == t) ? 1 : 0;
-        int mi = -1;
-        if (bmin == t)                    // (the bag's earliest arrival is in a register: no scan for local-only groups)
-            for (int i = 0; i < bag_n; ++i) if (bg_t(i) == t) { ++n_at; mi = i; }
-        if (has_probe() && probe_at(t)) n_at += 2;                       // a probe tick: always the general path
-        if (has_sched() && SA == t) n_at += 2;                           // so is a scheduled Request
-        if (has_xsrc() && xsrc_at(t)) n_at += 2;                         // and a tick of a further Source
+    // Totals::undecided bit 2 (as Station::pick_root, hs_station.hpp): a root constructed BEFORE run() -- a first tick, a
+    // Probe's first tick, a scheduled Request -- beside any other root of this nanosecond (a message counts).  Their order
+    // is what the prologue's true sort indices decide; an engine that skipped the prologue repeats the run behind it
+    // (hs_engine.hip lazy_prologue).  Lone roots cannot tie; every group with two roots comes through run_group() -- or is the
+    // group of the one event beyond end_time, which the election enters through root_first() (round 6: the election did not
+    // look, tools/gpu_random_sweep.py multi_source_ring_windows_async 132469: a Probe's first tick on the nanosecond of a
+    // constant Source's tick, first event beyond a window end).
+    __device__ __forceinline__ void pre_run_hazard(int64_t t) {
         if constexpr (PF) {
-            // Totals::undecided bit 2 (as Station::pick_root, hs_station.hpp): a root constructed BEFORE run() -- a first tick, a
-            // Probe's first tick, a scheduled Request -- beside any other root of this nanosecond (a message counts).  Their order
-            // is what the prologue's true sort indices decide; an engine that skipped the prologue repeats the run behind it
-            // (hs_engine.hip lazy_prologue).  Lone roots cannot tie, and every group with two roots comes through here.
-            int cnt = 0;                                                     // (n_at above is a path selector, not a count)
+            int cnt = 0;
             bool pre = false;
             if (A == t) { ++cnt; pre = rcA == INT64_MIN; }
 #pragma unroll
@@ -1663,6 +1658,18 @@ struct NetStation {
                 for (int j = 0; j < n_xsrc; ++j) if (xx->XA[xo(j)] == t) { ++cnt; pre = pre || xx->rcX[xo(j)] == INT64_MIN; }
             if (pre && cnt >= 2) undecided |= 4;
         }
+    }
+    __device__ __forceinline__ void run_group(int64_t t, bool force_general) {
+        int n_at = (A == t) ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < C; ++i) n_at += (D[i] == t) ? 1 : 0;
+        int mi = -1;
+        if (bmin == t)                    // (the bag's earliest arrival is in a register: no scan for local-only groups)
+            for (int i = 0; i < bag_n; ++i) if (bg_t(i) == t) { ++n_at; mi = i; }
+        if (has_probe() && probe_at(t)) n_at += 2;                       // a probe tick: always the general path
+        if (has_sched() && SA == t) n_at += 2;                           // so is a scheduled Request
+        if (has_xsrc() && xsrc_at(t)) n_at += 2;                         // and a tick of a further Source
+        pre_run_hazard(t);
         if (n_at == 1 && !force_general) {
             bool general = false, want_poll = false, have_created = false;
             int64_t created = 0;

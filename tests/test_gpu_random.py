@@ -80,7 +80,10 @@ def test_network_engines_match_oracle_on_random_specs(k, engine_flags):
 # 22522 (round 4): the winner is a DEPARTURE of a Server with several Sources, whose construction rank is a stand-in (its LP's
 # first-listed Source, here a Poisson one constructed before the other LP's lock-step constant Source): the election reports the tie
 # and the run is repeated on the single heap (csrc/hs_engine.hip set_stations; tests/test_election_rules.py)
-ELECTION_REGRESSIONS_STATION = [1374, 22522, 45638, 45990]      # (the last two: found by the CPU emulation, tools/election_rules.py)
+# 130100 (round 6): a counter-example to the rule of thumb by which a departure borrows the rank of the Source its lineage goes back
+# to (two lock-step Servers with constant Sources and services): a tie of the whole lineage key that involves a DEPARTURE now goes to
+# the single heap whatever rank it borrowed (csrc/hs_kernels.hpp make_candidate `pad2`)
+ELECTION_REGRESSIONS_STATION = [1374, 22522, 45638, 45990, 130100]      # (45638, 45990: found by the CPU emulation, tools/election_rules.py)
 ELECTION_REGRESSIONS_RING = [1068, 1084, 1282]
 
 

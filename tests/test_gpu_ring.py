@@ -654,3 +654,34 @@ def test_a_lock_step_network_without_pre_run_events_is_decided_on_the_single_hea
         assert eng.prologue_path() == 2
         eng.reset()
         assert eng.prologue_path() == 0                  # (a reset returns to the parallel engines -- until the next tie)
+
+
+@ENGINES
+def test_the_election_sees_a_pre_run_tick_on_the_nanosecond_of_another_root(engine_flags):
+    """Round 6, tools/gpu_random_sweep.py multi_source_ring_windows_async 132469: a Probe's FIRST tick (a pre-run event) falls on
+    the nanosecond of a constant Source's tick, and that group is the first one beyond a window end.  A run that skipped the prologue
+    orders the two roots by their stand-in stamps; inside a run NetStation::run_group reports the coincidence (Totals::undecided bit 2)
+    and the run is repeated behind the prologue -- the election of the event beyond end_time entered the group without looking.  Now it
+    looks (NetStation::root_first): the windowed drive gives the oracle's probe samples."""
+    import random_specs as RS
+
+    spec = RS.multi_source_ring_spec(132469)
+    g, nodes = H.oracle_ring_graph(spec)
+    p = H.ring_params(spec)
+    r = O.run(g, p["end_ns"], seed=spec["seed"], schedule=[(nodes[c]["srv"], t) for c, t in p["schedule"]])
+    rng = np.random.default_rng(spec["seed"] + 977)
+    ends = [int(e) for e in np.unique(rng.integers(1, p["end_ns"], 5))]
+    assert ends[0] < 500_000_000 < ends[1]                      # the probe's first tick (0.5 s) is the first event beyond the first end
+    eng, _ = H.ring_engine_for_spec(spec, flags=engine_flags)
+    with eng:
+        for e in ends:
+            eng.run_until(e)
+        eng.run_until(p["end_ns"])
+        assert eng.prologue_path() == 2
+        _check_against_oracle(spec, eng, r, nodes)
+        for i in range(spec["n"]):
+            if "prb" in nodes[i]:
+                t, v = r.sinks[nodes[i]["prb"]]
+                pt, pv = eng.read_probe(i)
+                np.testing.assert_array_equal(pt, t)
+                np.testing.assert_array_equal(pv, v)
