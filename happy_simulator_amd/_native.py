@@ -31,13 +31,14 @@ PROF_CONSTANT, PROF_LINEAR_RAMP, PROF_SPIKE = 0, 1, 2
 LAT_EXPONENTIAL, LAT_CONSTANT, LAT_NO_SERVER = 0, 1, 2
 EGRESS_NONE, EGRESS_SINK, EGRESS_LINK, EGRESS_ROUTER, EGRESS_SERVER = 0, 1, 2, 3, 4
 LB_CONSISTENT_HASH, LB_ROUND_ROBIN, LB_RANDOM = 0, 1, 2
+NODE_SOURCE, NODE_SERVER, NODE_SINK, NODE_LINK, NODE_ROUTER = 0, 1, 2, 3, 4
 EV_KINDS = 15
 EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuation", "sink", "link", "link_cont",
             "route", "lb", "lb_resp", "probe_tick", "probe")
 PROBE_METRICS = {"depth": 0, "active_requests": 1, "stats_accepted": 2, "stats_dropped": 3, "requests_completed": 4,
                  "_requests_completed": 4, "events_received": 5, "generated_count": 6}
 PROBE_NONE = 255
-ABI_VERSION = 14
+ABI_VERSION = 15
 IPC_HANDLE_BYTES = 64
 
 
@@ -117,6 +118,27 @@ class LpStats(C.Structure):
         "queue_depth", "active", "events", "final_time_ns")]
 
 
+class GraphConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("device", C.c_int32), ("start_ns", C.c_int64), ("seed", C.c_uint64),
+        ("heap_capacity", C.c_int64), ("request_capacity", C.c_int64), ("record_capacity", C.c_int64), ("max_events", C.c_int64),
+    ]
+
+
+class GraphNodes(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32)] + [(n, C.c_void_p) for n in (
+        "kind", "target", "stream_base", "src_kind", "src_rate", "src_stop_after_ns", "concurrency", "lat_kind", "lat_mean_s",
+        "link_lat_min_s", "link_loss_rate", "queue_cap", "rt_off", "rt_cnt", "rt_targets")] + [("n_rt", C.c_int32)]
+
+
+GRAPH_STATS = ("generated", "payloads", "accepted", "dropped", "completed", "rejected", "total_service_s", "queue_depth", "active",
+               "received", "entered", "packets_sent", "packets_dropped", "routed", "rt_taken")
+
+
+class GraphStats(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in GRAPH_STATS]
+
+
 class LbConfig(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("device", C.c_int32), ("n_sources", C.c_int32), ("n_backends", C.c_int32),
@@ -140,7 +162,7 @@ class LbStats(C.Structure):
                                           "rejected", "total_service_s", "queue_depth", "active", "sink_received")]
 
 
-_TUS = ("hs_engine.hip", "hs_lb.hip", "hs_tables.hip")          # one object each ...
+_TUS = ("hs_engine.hip", "hs_lb.hip", "hs_tables.hip", "hs_graph.hip")          # one object each ...
 _INST_TU, _INST_GROUPS = "hs_inst.hip", 17                      # ... plus hs_inst.hip once per instantiation group (csrc/hs_kernels.hpp)
 _STAMP_TU = "hs_stamp.hip"                                      # ... plus the build identity (the sources' hash, inside the .so)
 _MARK, _MARK_END = b"HS_SRC_HASH=", b"=HS_SRC_HASH_END"
@@ -415,6 +437,22 @@ def lib():
     L.hs_debug_radix_sort.restype = C.c_int
     L.hs_debug_radix_sort.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]
+    L.hs_graph_create.restype = C.c_int
+    L.hs_graph_create.argtypes = [P(GraphConfig), P(GraphNodes), P(C.c_void_p)]
+    L.hs_graph_schedule.restype = C.c_int
+    L.hs_graph_schedule.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
+    L.hs_graph_run_until.restype = C.c_int
+    L.hs_graph_run_until.argtypes = [C.c_void_p, C.c_int64]
+    L.hs_graph_get_summary.restype = C.c_int
+    L.hs_graph_get_summary.argtypes = [C.c_void_p, P(Summary)]
+    L.hs_graph_get_stats.restype = C.c_int
+    L.hs_graph_get_stats.argtypes = [C.c_void_p, P(GraphStats)]
+    L.hs_graph_read_records.restype = C.c_int64
+    L.hs_graph_read_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.hs_graph_last_error.restype = C.c_char_p
+    L.hs_graph_last_error.argtypes = [C.c_void_p]
+    L.hs_graph_destroy.restype = None
+    L.hs_graph_destroy.argtypes = [C.c_void_p]
     if L.hs_abi_version() != ABI_VERSION:
         raise EngineUnavailable("libhs_hip.so ABI version mismatch; rebuild")
     import sys
@@ -443,4 +481,6 @@ EXPORTED_SYMBOLS = (
     "hs_lb_ring", "hs_lb_select", "hs_lb_last_error", "hs_lb_destroy", "hs_md5", "hs_debug_radix_sort", "hs_merge_sink_records",
     "hs_sink_latency_stats", "hs_set_float_sum_mode",
     "hs_debug_lb_flags", "hs_engine_set_profile_budget", "hs_lb_set_profile_budget", "hs_debug_tick_table",
+    "hs_graph_create", "hs_graph_schedule", "hs_graph_run_until", "hs_graph_get_summary", "hs_graph_get_stats", "hs_graph_read_records",
+    "hs_graph_last_error", "hs_graph_destroy",
 )

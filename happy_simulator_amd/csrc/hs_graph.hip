@@ -1,0 +1,721 @@
+// hs_graph.hip -- general entity graphs on ONE heap (include/hs_engine.h "General entity graphs", ABI 15).
+//
+// The station engines (hs_station.hpp / hs_netstation.hpp) get their speed from a fixed LP shape; what the same entity classes
+// can be wired into beyond that shape -- links with several senders, routers with any fan-out that also target Servers and
+// routers, Servers behind Servers next to links, any number of Sources per Server -- has no LP decomposition that the lineage
+// key orders, and the reference's own definition of the order is the heap: (time, _sort_index) with the index taken from two
+// global creation counters (core/event.py:53-77, core/event_heap.py:48).  So this file IS that loop, on the device:
+//   * one lane of one wavefront pops and invokes events exactly like `Simulation._execute_until` (core/simulation.py:449-505);
+//   * the binary heap follows CPython's heapq sift procedures step for step, so equal (time, index) keys -- possible between
+//     the pre-run counter and the run-time counter -- pop in heapq's layout order;
+//   * the first kLdsHeap entries of the heap (every level a sift touches first) live in LDS, the rest in HBM; node parameters
+//     and state are two 64-byte rows per node (L2-resident for the models this path is for);
+//   * heap, Request pool and the Sink record log grow on demand: the kernel stops in front of the event that would not fit,
+//     the host enlarges the buffer and launches again (a launch also ends after kBudget events, so no launch runs for minutes).
+// Handlers restate the reference handler by handler (citations at each); arithmetic through hs_device.hpp (the same fixed IEEE
+// operation sequences as every other engine), streams through the Philox streams of DESIGN.md section 3.
+//
+// Cost: ~1 us per event (dependent loads on one lane).  An exactness path for the graphs the parallel engines refuse.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hs_engine.h"
+#include "hs_device.hpp"
+
+namespace hs {
+namespace graph {
+
+constexpr int kLdsHeap = 4096;                 // heap entries in LDS: 4 096 x 32 B = 128 KB of the CU's 160
+constexpr long long kBudget = 1ll << 21;       // events per launch (~2 s)
+
+struct GEvent {                                // 32 bytes
+    int64_t t;                                 // Event.time
+    uint64_t idx;                              // Event._sort_index
+    int32_t node;                              // target entity
+    int32_t req;                               // the Request it carries (-1: none)
+    uint32_t kind;                             // HS_EV_*
+    uint32_t pad;
+};
+
+struct GParam {                                // 64 bytes, read-only
+    uint64_t stream_base;
+    double mean;                               // Source: rate; Server: mean service; link: mean jitter
+    double lat_min;                            // link: ConstantLatency base
+    double loss;                               // link: packet_loss_rate
+    int64_t lim;                               // Source: stop_after ns (< 0 never); Server: queue capacity (< 0 unbounded)
+    int32_t target;
+    int32_t conc;
+    int32_t rt_off, rt_cnt;
+    uint8_t kind, sub;                         // sub: Source arrival kind (hs_source_kind); Server / link latency kind
+    uint8_t pad[6];
+};
+
+struct GState {                                // 64 bytes
+    // Source: a = ArrivalTimeProvider.current_time, b = arrival draws, c = generated_count, d = payload Requests built
+    // Server: a = stats_accepted, b = stats_dropped, c = completed, d = rejected
+    // link:   a = entered, b = packets_sent, c = packets_dropped, d = jitter draws
+    // router: a = stats_routed (= route draws);  Sink: a = events_received
+    int64_t a, b, c, d;
+    double total_service;                      // Server._total_service_time
+    uint64_t svc_draws;
+    int32_t qhead, qtail;                      // FIFOQueue (components/queue_policy.py:75-114) as a list through Request::next
+    int32_t qlen, active;
+};
+
+struct GRequest {                              // 32 bytes: the payload Event's identity + its context
+    int64_t created;                           // context["created_at"] (load/source.py:76-79; forwarded unchanged, core/entity.py:100-105)
+    uint64_t idx;                              // sort index of the queued payload Event (kept on retarget, queue_driver.py:86-90)
+    double service_s;                          // service_time_s of the generator frame (server/server.py:246-247)
+    int32_t next;                              // FIFO / free list
+    int32_t pad;
+};
+
+enum : int { kRunning = 0, kDone = 1, kGrowHeap = 2, kGrowReq = 4, kGrowRec = 8, kBadKind = 16 };
+
+struct GVars {                                 // device scalars
+    long long heap_len;
+    unsigned long long counter;                // the heap's own counter (run-time sort indices, core/event_heap.py:48)
+    unsigned long long global_counter;         // the process-wide counter (pre-run events and schedule()d Events)
+    long long cur;                             // Simulation._current_time
+    long long processed;
+    long long by_kind[HS_EV_KINDS];
+    long long completed, received;
+    long long rec_n;
+    int req_len, req_free;
+    int booted;
+    int status;
+    long long sched_done;                      // scheduled entries already pushed
+    long long heap_peak;
+};
+
+struct GCtl {                                  // kernel argument
+    GEvent *heap; long long heap_cap;
+    GRequest *reqs; int req_cap;
+    int32_t *rec_node; int64_t *rec_t, *rec_cr; long long rec_cap;
+    const GParam *P; GState *S; int n;
+    const int32_t *rt_targets; long long *rt_taken;
+    const int32_t *sched_node; const int64_t *sched_t; long long n_sched;
+    GVars *V;
+    uint64_t seed;
+    int64_t start_ns, end_ns;
+    long long budget;
+};
+
+__device__ __forceinline__ bool ev_lt(const GEvent &a, const GEvent &b) {   // Event.__lt__, core/event.py:337-344
+    if (a.t != b.t) return a.t < b.t;
+    return a.idx < b.idx;
+}
+
+struct Heap {
+    GEvent *lds; GEvent *glob; long long len;
+    __device__ __forceinline__ GEvent get(long long i) const { return i < kLdsHeap ? lds[i] : glob[i]; }
+    __device__ __forceinline__ void set(long long i, const GEvent &e) { if (i < kLdsHeap) lds[i] = e; else glob[i] = e; }
+    // heapq.heappush: append, then _siftdown(heap, 0, len - 1)
+    __device__ inline void push(const GEvent &e) {
+        long long pos = len++;
+        while (pos > 0) {
+            const long long parent = (pos - 1) >> 1;
+            const GEvent p = get(parent);
+            if (!ev_lt(e, p)) break;
+            set(pos, p);
+            pos = parent;
+        }
+        set(pos, e);
+    }
+    // heapq.heappop: the last leaf replaces the root; _siftup walks the hole down to a leaf along the smaller child (the right
+    // one unless left < right), then _siftdown bubbles the moved item back up
+    __device__ inline GEvent pop() {
+        const GEvent top = get(0);
+        const GEvent last = get(--len);
+        const long long n = len;
+        if (n == 0) return top;
+        long long pos = 0, child = 1;
+        while (child < n) {
+            GEvent c = get(child);
+            const long long right = child + 1;
+            if (right < n) {
+                const GEvent r = get(right);
+                if (!ev_lt(c, r)) { child = right; c = r; }
+            }
+            set(pos, c);
+            pos = child;
+            child = 2 * pos + 1;
+        }
+        while (pos > 0) {
+            const long long parent = (pos - 1) >> 1;
+            const GEvent p = get(parent);
+            if (!ev_lt(last, p)) break;
+            set(pos, p);
+            pos = parent;
+        }
+        set(pos, last);
+        return top;
+    }
+};
+
+__device__ __forceinline__ double uniform_at(uint64_t seed, uint64_t sid, uint64_t k) {
+    Stream s;
+    s.init(seed, sid, k);
+    return s.next_uniform();
+}
+
+// a Request-carrying Event aimed at `node`: which handler it lands in (Entity.handle_event of that class)
+__device__ __forceinline__ uint32_t arrival_kind(const GParam *P, int node) {
+    switch (P[node].kind) {
+        case HS_NODE_SERVER: return HS_EV_ENQUEUE;
+        case HS_NODE_SINK: return HS_EV_SINK;
+        case HS_NODE_LINK: return HS_EV_LINK;
+        case HS_NODE_ROUTER: return HS_EV_ROUTE;
+        default: return 0xffffffffu;
+    }
+}
+
+__device__ __forceinline__ GEvent mk(int64_t t, uint64_t idx, uint32_t kind, int node, int req) {
+    GEvent e;
+    e.t = t; e.idx = idx; e.node = node; e.req = req; e.kind = kind; e.pad = 0;
+    return e;
+}
+
+// ArrivalTimeProvider.next_arrival_time, constant-rate fast path (load/arrival_time_provider.py:72-82) with the target area of
+// poisson_arrival.py:31 / constant_arrival.py:23
+__device__ inline int64_t next_arrival(const GCtl &c, int n) {
+    const GParam &p = c.P[n];
+    GState &s = c.S[n];
+    double area = 1.0;
+    if (p.sub == HS_SRC_POISSON) {
+        area = exp1_from_uniform(uniform_at(c.seed, stream_id(p.stream_base, kStreamArrival), (uint64_t)s.b));
+        s.b += 1;
+    }
+    const int64_t a2 = ns_from_seconds(__dadd_rn(seconds_from_ns(s.a), __ddiv_rn(area, p.mean)));
+    s.a = a2;
+    return a2;
+}
+
+__global__ void __launch_bounds__(64) hs_graph_run(GCtl c) {
+    __shared__ GEvent lheap[kLdsHeap];
+    GVars &V = *c.V;
+    const int lane = threadIdx.x;
+    {   // the heap's head comes into LDS (all 64 lanes copy; 8 bytes per lane and step)
+        const long long n8 = (V.heap_len < kLdsHeap ? V.heap_len : (long long)kLdsHeap) * (long long)(sizeof(GEvent) / 8);
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(c.heap);
+        uint64_t *dst = reinterpret_cast<uint64_t *>(lheap);
+        for (long long i = lane; i < n8; i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (lane == 0) {
+        Heap H{lheap, c.heap, V.heap_len};
+        unsigned long long G = V.counter;
+        int status = kRunning;
+        if (!V.booted) {
+            // Simulation.__init__ (core/simulation.py:145-154) + Source.start (load/source.py:120-140): the Sources in list order,
+            // their first SourceEvents numbered by the process-wide counter
+            unsigned long long g = 0;
+            for (int i = 0; i < c.n; ++i) {
+                if (c.P[i].kind != HS_NODE_SOURCE) continue;
+                c.S[i].a = c.start_ns;                          // provider.current_time = start_time
+                const int64_t t = next_arrival(c, i);
+                H.push(mk(t, g++, HS_EV_SOURCE, i, -1));        // (heap_cap >= 4 n: hs_graph_create)
+            }
+            V.global_counter = g; V.booted = 1; G = 0; V.cur = c.start_ns;
+        }
+        // Simulation.schedule (core/simulation.py:195-206): Events constructed outside the run
+        while (status == kRunning && V.sched_done < c.n_sched) {
+            if (H.len + 1 > c.heap_cap) { status |= kGrowHeap; break; }
+            int r = V.req_free;
+            if (r >= 0) V.req_free = c.reqs[r].next;
+            else if (V.req_len < c.req_cap) r = V.req_len++;
+            else { status |= kGrowReq; break; }
+            const int node = c.sched_node[V.sched_done];
+            const int64_t t = c.sched_t[V.sched_done];
+            GRequest q; q.created = t; q.idx = V.global_counter; q.service_s = 0.0; q.next = -1; q.pad = 0;
+            c.reqs[r] = q;
+            H.push(mk(t, V.global_counter++, arrival_kind(c.P, node), node, r));
+            V.sched_done++;
+        }
+        long long cur = V.cur, processed = 0, n_completed = 0, n_received = 0, rec_n = V.rec_n;
+        long long by_kind[HS_EV_KINDS];
+        for (int k = 0; k < HS_EV_KINDS; ++k) by_kind[k] = 0;
+        long long peak = V.heap_peak;
+        while (status == kRunning) {
+            if (!(H.len > 0 && cur <= c.end_ns)) { status = kDone; break; }       // core/simulation.py:472 tests the PREVIOUS event's time
+            if (processed >= c.budget) break;
+            // room for whatever this event constructs (at most two pushes, one Request, one record)
+            if (H.len + 2 > c.heap_cap) { status |= kGrowHeap; break; }
+            if (V.req_free < 0 && V.req_len >= c.req_cap) { status |= kGrowReq; break; }
+            if (rec_n >= c.rec_cap) { status |= kGrowRec; break; }
+            if (H.len > peak) peak = H.len;
+            const GEvent e = H.pop();
+            if (e.t < cur) continue;                                               // time-travel drop, core/simulation.py:480-489
+            cur = e.t;
+            processed++;
+            const int n = e.node;
+            const int64_t t = e.t;
+            if (e.kind >= (uint32_t)HS_EV_KINDS) { status |= kBadKind; break; }
+            by_kind[e.kind]++;
+            const GParam p = c.P[n];
+            GState &s = c.S[n];
+            switch (e.kind) {
+            case HS_EV_SOURCE: {
+                // Source.handle_event (load/source.py:142-180): the payload is constructed first, then the next SourceEvent;
+                // `return [*payload_events, next_tick]`
+                const bool payload = !(p.lim >= 0 && t > p.lim);                    // SimpleEventProvider.get_events :68
+                int r = -1;
+                unsigned long long idx_p = 0;
+                if (payload) {
+                    r = V.req_free;
+                    if (r >= 0) V.req_free = c.reqs[r].next; else r = V.req_len++;
+                    idx_p = G++;
+                    GRequest q; q.created = t; q.idx = idx_p; q.service_s = 0.0; q.next = -1; q.pad = 0;
+                    c.reqs[r] = q;
+                    s.d += 1;
+                }
+                s.c += 1;                                                           // _generated_count (:159)
+                const int64_t a2 = next_arrival(c, n);
+                const unsigned long long idx_t = G++;
+                if (payload) H.push(mk(t, idx_p, arrival_kind(c.P, p.target), p.target, r));
+                H.push(mk(a2, idx_t, HS_EV_SOURCE, n, -1));
+            } break;
+            case HS_EV_ENQUEUE: {
+                // QueuedResource.handle_event -> Queue._handle_enqueue (components/queue.py:122-147)
+                if (p.lim >= 0 && s.qlen >= p.lim) {                               // FIFOQueue.push refuses (queue_policy.py:94-98)
+                    s.b += 1;
+                    c.reqs[e.req].next = V.req_free; V.req_free = e.req;
+                    break;
+                }
+                c.reqs[e.req].idx = e.idx;                  // the queued payload IS this Event object
+                c.reqs[e.req].next = -1;
+                if (s.qtail >= 0) c.reqs[s.qtail].next = e.req; else s.qhead = e.req;
+                s.qtail = e.req;
+                s.a += 1;
+                const bool was_empty = s.qlen == 0;
+                s.qlen += 1;
+                if (was_empty) H.push(mk(t, G++, HS_EV_NOTIFY, n, -1));            // queue.py:144-146
+            } break;
+            case HS_EV_NOTIFY:                                                      // QueueDriver._handle_notify (queue_driver.py:92-99)
+                if (s.active < p.conc) H.push(mk(t, G++, HS_EV_POLL, n, -1));
+                break;
+            case HS_EV_POLL: {                                                      // Queue._handle_poll (queue.py:149-166)
+                if (s.qlen == 0) break;
+                const int r = s.qhead;
+                s.qhead = c.reqs[r].next;
+                if (s.qhead < 0) s.qtail = -1;
+                s.qlen -= 1;
+                H.push(mk(t, G++, HS_EV_DELIVER, n, r));
+            } break;
+            case HS_EV_DELIVER:                                                     // queue_driver.py:66-90: same payload, ORIGINAL index
+                H.push(mk(t, c.reqs[e.req].idx, HS_EV_WORK, n, e.req));
+                break;
+            case HS_EV_WORK: {
+                // Server.handle_queued_event up to its yield (server/server.py:202-250) via Event._start_process
+                // (core/event.py:313-325): one continuation is built and invoked at once, the pushed one is the second
+                (void)G++;
+                if (!(s.active < p.conc)) {                                         // acquire() failed (server.py:223-234)
+                    s.d += 1;
+                    c.reqs[e.req].next = V.req_free; V.req_free = e.req;
+                    break;
+                }
+                s.active += 1;
+                double sv;
+                if (p.sub == HS_LAT_EXPONENTIAL) {
+                    const double u = uniform_at(c.seed, stream_id(p.stream_base, kStreamService), s.svc_draws);
+                    s.svc_draws += 1;
+                    const double sample = __ddiv_rn(exp1_from_uniform(u), __ddiv_rn(1.0, p.mean));   // expovariate(1 / mean)
+                    sv = seconds_from_ns(ns_from_seconds(sample));
+                } else sv = seconds_from_ns(ns_from_seconds(p.mean));
+                c.reqs[e.req].service_s = sv;
+                H.push(mk(t + ns_from_seconds(sv), G++, HS_EV_CONTINUATION, n, e.req));   // Instant + float seconds (temporal.py:222)
+            } break;
+            case HS_EV_CONTINUATION: {
+                // the generator resumes (server/server.py:252-273): statistics, forward(event, downstream), then the
+                // schedule_poll completion hook (queue_driver.py:79-84)
+                s.active = s.active > 0 ? s.active - 1 : 0;
+                s.c += 1; n_completed++;
+                s.total_service = __dadd_rn(s.total_service, c.reqs[e.req].service_s);
+                if (p.target >= 0) H.push(mk(t, G++, arrival_kind(c.P, p.target), p.target, e.req));
+                else { c.reqs[e.req].next = V.req_free; V.req_free = e.req; }
+                if (s.active < p.conc) H.push(mk(t, G++, HS_EV_POLL, n, -1));
+            } break;
+            case HS_EV_SINK: {                                                      // Sink.handle_event (components/common.py:36-44)
+                c.rec_node[rec_n] = n; c.rec_t[rec_n] = t; c.rec_cr[rec_n] = c.reqs[e.req].created;
+                rec_n++;
+                s.a += 1; n_received++;
+                c.reqs[e.req].next = V.req_free; V.req_free = e.req;
+            } break;
+            case HS_EV_ROUTE: {                                                     // RandomRouter.handle_event (random_router.py:32-45)
+                const double u = uniform_at(c.seed, stream_id(p.stream_base, kStreamRoute), (uint64_t)s.a);
+                s.a += 1;
+                const int ri = (int)__dmul_rn(u, (double)p.rt_cnt);                 // targets[int(u * len(targets))]
+                const int tg = c.rt_targets[p.rt_off + ri];
+                c.rt_taken[p.rt_off + ri] += 1;
+                H.push(mk(t, G++, arrival_kind(c.P, tg), tg, e.req));
+            } break;
+            case HS_EV_LINK: {
+                // NetworkLink.handle_event up to its yield (components/network/link.py:114-154, _calculate_delay :190-216)
+                (void)G++;                                                          // the continuation built by _start_process
+                const int64_t entered = s.a;
+                s.a = entered + 1;
+                if (p.loss > 0.0 && uniform_at(c.seed, stream_id(p.stream_base, kStreamLoss), (uint64_t)entered) < p.loss) {   // link.py:131-138
+                    s.c += 1;
+                    c.reqs[e.req].next = V.req_free; V.req_free = e.req;
+                    break;
+                }
+                double delay = seconds_from_ns(ns_from_seconds(p.lat_min));
+                if (p.sub == HS_LAT_EXPONENTIAL) {
+                    const double u = uniform_at(c.seed, stream_id(p.stream_base, kStreamLink), (uint64_t)s.d);
+                    s.d += 1;
+                    const double sample = __ddiv_rn(exp1_from_uniform(u), __ddiv_rn(1.0, p.mean));
+                    delay = __dadd_rn(delay, seconds_from_ns(ns_from_seconds(sample)));
+                } else if (p.mean > 0.0) delay = __dadd_rn(delay, seconds_from_ns(ns_from_seconds(p.mean)));   // ConstantLatency jitter: no draw
+                if (!(delay > 0.0)) delay = 0.0;                                    // max(0.0, delay)
+                H.push(mk(t + ns_from_seconds(delay), G++, HS_EV_LINK_CONT, n, e.req));
+            } break;
+            case HS_EV_LINK_CONT:                                                   // transit over (link.py:156-189): a NEW Event for the egress
+                s.b += 1;
+                if (p.target >= 0) H.push(mk(t, G++, arrival_kind(c.P, p.target), p.target, e.req));
+                else { c.reqs[e.req].next = V.req_free; V.req_free = e.req; }
+                break;
+            default: status |= kBadKind; break;
+            }
+        }
+        V.heap_len = H.len; V.counter = G; V.cur = cur; V.processed += processed; V.rec_n = rec_n;
+        for (int k = 0; k < HS_EV_KINDS; ++k) V.by_kind[k] += by_kind[k];
+        V.completed += n_completed; V.received += n_received;
+        V.heap_peak = peak;
+        V.status = status;
+    }
+    __syncthreads();
+    {   // ... and back
+        const long long n8 = (V.heap_len < kLdsHeap ? V.heap_len : (long long)kLdsHeap) * (long long)(sizeof(GEvent) / 8);
+        uint64_t *dst = reinterpret_cast<uint64_t *>(c.heap);
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(lheap);
+        for (long long i = lane; i < n8; i += 64) dst[i] = src[i];
+    }
+}
+
+}  // namespace graph
+}  // namespace hs
+
+using namespace hs::graph;
+
+struct hs_graph {
+    hs_graph_config cfg{};
+    int n = 0, n_rt = 0;
+    GCtl ctl{};
+    std::vector<GParam> params;
+    std::vector<int32_t> sched_node; std::vector<int64_t> sched_t;
+    int32_t *d_sched_node = nullptr; int64_t *d_sched_t = nullptr; long long d_sched_cap = 0;
+    int32_t *d_rt_targets = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    double last_run_ms = 0.0;
+    long long launches = 0;
+    bool ran = false;
+    std::string error;
+};
+
+static thread_local std::string g_graph_error;
+
+static int gfail(hs_graph *g, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (g) g->error = buf;
+    g_graph_error = buf;
+    return code;
+}
+
+#define HSG_HIP(g, expr)                                                                               \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return gfail(g, HS_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));       \
+    } while (0)
+
+template <typename T>
+static int grow(hs_graph *g, T **buf, long long old_n, long long new_n) {
+    T *nb = nullptr;
+    HSG_HIP(g, hipMalloc(&nb, (size_t)new_n * sizeof(T)));
+    if (*buf && old_n > 0) HSG_HIP(g, hipMemcpy(nb, *buf, (size_t)old_n * sizeof(T), hipMemcpyDeviceToDevice));
+    if (*buf) HSG_HIP(g, hipFree(*buf));
+    *buf = nb;
+    return HS_OK;
+}
+
+extern "C" {
+
+const char *hs_graph_last_error(const hs_graph *g) { return g ? g->error.c_str() : g_graph_error.c_str(); }
+
+void hs_graph_destroy(hs_graph *g) {
+    if (!g) return;
+    (void)hipSetDevice(g->cfg.device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    void *bufs[] = {g->ctl.heap, g->ctl.reqs, g->ctl.rec_node, g->ctl.rec_t, g->ctl.rec_cr, (void *)g->ctl.P, g->ctl.S,
+                    g->d_rt_targets, g->ctl.rt_taken, g->d_sched_node, g->d_sched_t, g->ctl.V};
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    if (g->ev_a) (void)hipEventDestroy(g->ev_a);
+    if (g->ev_b) (void)hipEventDestroy(g->ev_b);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+}
+
+int hs_graph_create(const hs_graph_config *cfg, const hs_graph_nodes *nd, hs_graph **out) {
+    if (!cfg || !nd || !out) return gfail(nullptr, HS_E_INVALID, "hs_graph_create: null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(hs_graph_config)) return gfail(nullptr, HS_E_INVALID, "hs_graph_config.struct_size mismatch (ABI)");
+    const int n = nd->n_nodes;
+    if (n < 1) return gfail(nullptr, HS_E_INVALID, "n_nodes must be >= 1");
+    if (!nd->kind || !nd->target) return gfail(nullptr, HS_E_INVALID, "kind and target are required");
+    if (nd->n_rt < 0 || (nd->n_rt > 0 && !nd->rt_targets)) return gfail(nullptr, HS_E_INVALID, "rt_targets is required with n_rt > 0");
+    int dev_count = 0;
+    if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count < 1)
+        return gfail(nullptr, HS_E_NO_DEVICE, "no HIP device is visible (the engine has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= dev_count) return gfail(nullptr, HS_E_INVALID, "device %d out of range", cfg->device);
+    auto takes_requests = [&](int t) { const int k = nd->kind[t]; return k == HS_NODE_SERVER || k == HS_NODE_SINK || k == HS_NODE_LINK || k == HS_NODE_ROUTER; };
+    std::vector<GParam> P((size_t)n);
+    double rate_sum = 0.0;
+    int n_src = 0;
+    for (int i = 0; i < n; ++i) {
+        GParam p{};
+        p.kind = nd->kind[i];
+        p.target = nd->target[i];
+        p.stream_base = nd->stream_base ? nd->stream_base[i] : (uint64_t)i;
+        p.conc = 1; p.lim = -1; p.rt_off = 0; p.rt_cnt = 0; p.mean = 0.0; p.lat_min = 0.0; p.loss = 0.0;
+        if (p.target < -1 || p.target >= n) return gfail(nullptr, HS_E_INVALID, "node %d: target %d out of range", i, p.target);
+        if (p.target >= 0 && !takes_requests(p.target))
+            return gfail(nullptr, HS_E_INVALID, "node %d: its target %d takes no Requests (a Source)", i, p.target);
+        switch (p.kind) {
+        case HS_NODE_SOURCE: {
+            if (!nd->src_rate) return gfail(nullptr, HS_E_INVALID, "src_rate is required");
+            p.sub = nd->src_kind ? nd->src_kind[i] : (uint8_t)HS_SRC_POISSON;
+            if (p.sub != HS_SRC_POISSON && p.sub != HS_SRC_CONSTANT) return gfail(nullptr, HS_E_UNSUPPORTED, "node %d: source kind %d is not lowered", i, (int)p.sub);
+            p.mean = nd->src_rate[i];
+            if (!(p.mean > 0.0) || !std::isfinite(p.mean)) return gfail(nullptr, HS_E_INVALID, "node %d: source rate must be > 0, got %g", i, p.mean);
+            p.lim = nd->src_stop_after_ns ? nd->src_stop_after_ns[i] : -1;
+            if (p.target < 0) return gfail(nullptr, HS_E_INVALID, "node %d: a Source needs a target", i);
+            rate_sum += p.mean;
+            ++n_src;
+        } break;
+        case HS_NODE_SERVER: {
+            p.conc = nd->concurrency ? nd->concurrency[i] : 1;
+            if (p.conc < 1) return gfail(nullptr, HS_E_INVALID, "node %d: max_concurrent must be >= 1, got %d", i, p.conc);
+            p.sub = nd->lat_kind ? nd->lat_kind[i] : (uint8_t)HS_LAT_CONSTANT;
+            if (p.sub != HS_LAT_EXPONENTIAL && p.sub != HS_LAT_CONSTANT) return gfail(nullptr, HS_E_UNSUPPORTED, "node %d: service distribution kind %d is not lowered", i, (int)p.sub);
+            p.mean = nd->lat_mean_s ? nd->lat_mean_s[i] : 0.0;
+            if (!(p.mean >= 0.0) || !std::isfinite(p.mean)) return gfail(nullptr, HS_E_INVALID, "node %d: bad service mean %g", i, p.mean);
+            if (p.sub == HS_LAT_EXPONENTIAL && !(p.mean > 0.0)) return gfail(nullptr, HS_E_INVALID, "node %d: exponential service needs mean > 0", i);
+            p.lim = nd->queue_cap ? nd->queue_cap[i] : -1;
+        } break;
+        case HS_NODE_SINK: break;
+        case HS_NODE_LINK: {
+            p.sub = nd->lat_kind ? nd->lat_kind[i] : (uint8_t)HS_LAT_CONSTANT;
+            if (p.sub != HS_LAT_EXPONENTIAL && p.sub != HS_LAT_CONSTANT) return gfail(nullptr, HS_E_UNSUPPORTED, "node %d: jitter kind %d is not lowered", i, (int)p.sub);
+            p.mean = nd->lat_mean_s ? nd->lat_mean_s[i] : 0.0;
+            if (p.sub == HS_LAT_EXPONENTIAL && !(p.mean > 0.0)) return gfail(nullptr, HS_E_INVALID, "node %d: exponential jitter needs mean > 0", i);
+            if (!(p.mean >= 0.0) || !std::isfinite(p.mean)) return gfail(nullptr, HS_E_INVALID, "node %d: bad jitter mean %g", i, p.mean);
+            p.lat_min = nd->link_lat_min_s ? nd->link_lat_min_s[i] : 0.0;
+            if (!(p.lat_min >= 0.0) || !std::isfinite(p.lat_min)) return gfail(nullptr, HS_E_INVALID, "node %d: bad link latency %g", i, p.lat_min);
+            p.loss = nd->link_loss_rate ? nd->link_loss_rate[i] : 0.0;
+            if (!(p.loss >= 0.0 && p.loss <= 1.0)) return gfail(nullptr, HS_E_INVALID, "node %d: packet_loss_rate must be in [0, 1], got %g", i, p.loss);   // link.py:71-72
+        } break;
+        case HS_NODE_ROUTER: {
+            if (!nd->rt_off || !nd->rt_cnt) return gfail(nullptr, HS_E_INVALID, "rt_off and rt_cnt are required for routers");
+            p.rt_off = nd->rt_off[i]; p.rt_cnt = nd->rt_cnt[i];
+            if (p.rt_cnt < 1) return gfail(nullptr, HS_E_INVALID, "node %d: a RandomRouter needs at least one target", i);
+            if (p.rt_off < 0 || (long long)p.rt_off + p.rt_cnt > nd->n_rt) return gfail(nullptr, HS_E_INVALID, "node %d: router targets out of range", i);
+            for (int q = 0; q < p.rt_cnt; ++q) {
+                const int t = nd->rt_targets[p.rt_off + q];
+                if (t < 0 || t >= n || !takes_requests(t)) return gfail(nullptr, HS_E_INVALID, "node %d: router target %d takes no Requests", i, t);
+            }
+        } break;
+        default: return gfail(nullptr, HS_E_UNSUPPORTED, "node %d: kind %d is not lowered", i, (int)p.kind);
+        }
+        P[(size_t)i] = p;
+    }
+    hs_graph *g = new hs_graph();
+    g->cfg = *cfg; g->n = n; g->n_rt = nd->n_rt; g->params = P;
+#define HSG_TRY(expr) do { int rc_ = (expr); if (rc_) { g_graph_error = g->error; hs_graph_destroy(g); return rc_; } } while (0)
+#define HSG_HIPD(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { gfail(g, HS_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); g_graph_error = g->error; hs_graph_destroy(g); return HS_E_HIP; } } while (0)
+    HSG_HIPD(hipSetDevice(cfg->device));
+    HSG_HIPD(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    HSG_HIPD(hipEventCreate(&g->ev_a));
+    HSG_HIPD(hipEventCreate(&g->ev_b));
+    GCtl &c = g->ctl;
+    c.n = n; c.seed = cfg->seed; c.start_ns = cfg->start_ns; c.budget = kBudget;
+    c.heap_cap = std::max<long long>(cfg->heap_capacity > 0 ? cfg->heap_capacity : 0, (long long)n * 4 + 1024);
+    c.req_cap = (int)std::min<long long>(std::max<long long>(cfg->request_capacity > 0 ? cfg->request_capacity : 0, (long long)n * 4 + 1024), 1ll << 30);
+    c.rec_cap = cfg->record_capacity > 0 ? cfg->record_capacity : 65536;
+    (void)rate_sum;
+    HSG_TRY(grow(g, &c.heap, 0, c.heap_cap));
+    HSG_TRY(grow(g, &c.reqs, 0, c.req_cap));
+    HSG_TRY(grow(g, &c.rec_node, 0, c.rec_cap));
+    HSG_TRY(grow(g, &c.rec_t, 0, c.rec_cap));
+    HSG_TRY(grow(g, &c.rec_cr, 0, c.rec_cap));
+    GParam *dP = nullptr;
+    HSG_HIPD(hipMalloc(&dP, (size_t)n * sizeof(GParam)));
+    c.P = dP;
+    HSG_HIPD(hipMemcpy(dP, P.data(), (size_t)n * sizeof(GParam), hipMemcpyHostToDevice));
+    HSG_HIPD(hipMalloc(&c.S, (size_t)n * sizeof(GState)));
+    {
+        std::vector<GState> S0((size_t)n);
+        for (auto &s : S0) { std::memset(&s, 0, sizeof s); s.qhead = -1; s.qtail = -1; }
+        HSG_HIPD(hipMemcpy(c.S, S0.data(), (size_t)n * sizeof(GState), hipMemcpyHostToDevice));
+    }
+    const size_t nrt = (size_t)(nd->n_rt > 0 ? nd->n_rt : 1);
+    HSG_HIPD(hipMalloc(&g->d_rt_targets, nrt * sizeof(int32_t)));
+    if (nd->n_rt > 0) HSG_HIPD(hipMemcpy(g->d_rt_targets, nd->rt_targets, (size_t)nd->n_rt * sizeof(int32_t), hipMemcpyHostToDevice));
+    c.rt_targets = g->d_rt_targets;
+    HSG_HIPD(hipMalloc(&c.rt_taken, nrt * sizeof(long long)));
+    HSG_HIPD(hipMemset(c.rt_taken, 0, nrt * sizeof(long long)));
+    HSG_HIPD(hipMalloc(&c.V, sizeof(GVars)));
+    {
+        GVars v{};
+        v.req_free = -1; v.cur = cfg->start_ns;
+        HSG_HIPD(hipMemcpy(c.V, &v, sizeof v, hipMemcpyHostToDevice));
+    }
+    HSG_HIPD(hipDeviceSynchronize());
+#undef HSG_TRY
+#undef HSG_HIPD
+    *out = g;
+    return HS_OK;
+}
+
+int hs_graph_schedule(hs_graph *g, int32_t node, int64_t time_ns) {
+    if (!g) return gfail(g, HS_E_INVALID, "null handle");
+    if (node < 0 || node >= g->n) return gfail(g, HS_E_INVALID, "schedule: node %d out of range", node);
+    if (g->params[(size_t)node].kind == HS_NODE_SOURCE)
+        return gfail(g, HS_E_UNSUPPORTED, "schedule: node %d is a Source (only Requests for a Server, Sink, link or router are lowered)", node);
+    g->sched_node.push_back(node);
+    g->sched_t.push_back(time_ns);
+    return HS_OK;
+}
+
+int hs_graph_run_until(hs_graph *g, int64_t end_ns) {
+    if (!g) return gfail(g, HS_E_INVALID, "null handle");
+    HSG_HIP(g, hipSetDevice(g->cfg.device));
+    GCtl &c = g->ctl;
+    const long long ns = (long long)g->sched_node.size();
+    if (ns > g->d_sched_cap) {
+        if (g->d_sched_node) HSG_HIP(g, hipFree(g->d_sched_node));
+        if (g->d_sched_t) HSG_HIP(g, hipFree(g->d_sched_t));
+        g->d_sched_node = nullptr; g->d_sched_t = nullptr;
+        g->d_sched_cap = ns + ns / 2 + 16;
+        HSG_HIP(g, hipMalloc(&g->d_sched_node, (size_t)g->d_sched_cap * sizeof(int32_t)));
+        HSG_HIP(g, hipMalloc(&g->d_sched_t, (size_t)g->d_sched_cap * sizeof(int64_t)));
+    }
+    if (ns > 0) {
+        HSG_HIP(g, hipMemcpy(g->d_sched_node, g->sched_node.data(), (size_t)ns * sizeof(int32_t), hipMemcpyHostToDevice));
+        HSG_HIP(g, hipMemcpy(g->d_sched_t, g->sched_t.data(), (size_t)ns * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    c.sched_node = g->d_sched_node; c.sched_t = g->d_sched_t; c.n_sched = ns;
+    c.end_ns = end_ns;
+    g->launches = 0;
+    HSG_HIP(g, hipEventRecord(g->ev_a, g->stream));
+    for (;;) {
+        hipLaunchKernelGGL(hs_graph_run, dim3(1), dim3(64), 0, g->stream, c);
+        HSG_HIP(g, hipGetLastError());
+        g->launches++;
+        HSG_HIP(g, hipStreamSynchronize(g->stream));
+        GVars v;
+        HSG_HIP(g, hipMemcpy(&v, c.V, sizeof v, hipMemcpyDeviceToHost));
+        if (v.status & kBadKind) return gfail(g, HS_E_INVALID, "an event of unknown kind reached the loop (internal error)");
+        if (g->cfg.max_events > 0 && v.processed > g->cfg.max_events)
+            return gfail(g, HS_E_UNSUPPORTED, "the run exceeds max_events = %lld events on the single-heap path (one lane, ~1 us per event); "
+                         "raise max_events, or bring the graph into the shape the station engines take", (long long)g->cfg.max_events);
+        if (v.status & kGrowHeap) {
+            const long long nc = c.heap_cap * 2;
+            int rc = grow(g, &c.heap, c.heap_cap, nc); if (rc) return rc;
+            c.heap_cap = nc;
+        }
+        if (v.status & kGrowReq) {
+            if (c.req_cap >= (1 << 30)) return gfail(g, HS_E_OVERFLOW, "more than 2^30 Requests alive at once");
+            const int nc = c.req_cap * 2;
+            int rc = grow(g, &c.reqs, c.req_cap, nc); if (rc) return rc;
+            c.req_cap = nc;
+        }
+        if (v.status & kGrowRec) {
+            const long long nc = c.rec_cap * 2;
+            int rc;
+            if ((rc = grow(g, &c.rec_node, c.rec_cap, nc))) return rc;
+            if ((rc = grow(g, &c.rec_t, c.rec_cap, nc))) return rc;
+            if ((rc = grow(g, &c.rec_cr, c.rec_cap, nc))) return rc;
+            c.rec_cap = nc;
+        }
+        if (v.status == kDone) break;
+    }
+    HSG_HIP(g, hipEventRecord(g->ev_b, g->stream));
+    HSG_HIP(g, hipStreamSynchronize(g->stream));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g->ev_a, g->ev_b) == hipSuccess) g->last_run_ms = ms;
+    g->ran = true;
+    return HS_OK;
+}
+
+int hs_graph_get_summary(hs_graph *g, hs_summary *out) {
+    if (!g || !out) return gfail(g, HS_E_INVALID, "null argument");
+    HSG_HIP(g, hipSetDevice(g->cfg.device));
+    GVars v;
+    HSG_HIP(g, hipMemcpy(&v, g->ctl.V, sizeof v, hipMemcpyDeviceToHost));
+    std::memset(out, 0, sizeof *out);
+    out->events_processed = v.processed;
+    for (int k = 0; k < HS_EV_KINDS; ++k) out->events_by_kind[k] = v.by_kind[k];
+    out->final_time_ns = v.cur;
+    out->requests_completed = v.completed;
+    out->sink_records = v.received;
+    out->last_run_ms = g->last_run_ms;
+    out->kernel_ms = g->last_run_ms;
+    out->launches = g->launches;
+    return HS_OK;
+}
+
+int hs_graph_get_stats(hs_graph *g, hs_graph_stats *o) {
+    if (!g || !o) return gfail(g, HS_E_INVALID, "null argument");
+    HSG_HIP(g, hipSetDevice(g->cfg.device));
+    std::vector<GState> S((size_t)g->n);
+    HSG_HIP(g, hipMemcpy(S.data(), g->ctl.S, (size_t)g->n * sizeof(GState), hipMemcpyDeviceToHost));
+    for (int i = 0; i < g->n; ++i) {
+        const GState &s = S[(size_t)i];
+        const int k = g->params[(size_t)i].kind;
+        const bool src = k == HS_NODE_SOURCE, srv = k == HS_NODE_SERVER, lnk = k == HS_NODE_LINK;
+        if (o->generated) o->generated[i] = src ? s.c : 0;
+        if (o->payloads) o->payloads[i] = src ? s.d : 0;
+        if (o->accepted) o->accepted[i] = srv ? s.a : 0;
+        if (o->dropped) o->dropped[i] = srv ? s.b : 0;
+        if (o->completed) o->completed[i] = srv ? s.c : 0;
+        if (o->rejected) o->rejected[i] = srv ? s.d : 0;
+        if (o->total_service_s) o->total_service_s[i] = srv ? s.total_service : 0.0;
+        if (o->queue_depth) o->queue_depth[i] = srv ? s.qlen : 0;
+        if (o->active) o->active[i] = srv ? s.active : 0;
+        if (o->received) o->received[i] = k == HS_NODE_SINK ? s.a : 0;
+        if (o->entered) o->entered[i] = lnk ? s.a : 0;
+        if (o->packets_sent) o->packets_sent[i] = lnk ? s.b : 0;
+        if (o->packets_dropped) o->packets_dropped[i] = lnk ? s.c : 0;
+        if (o->routed) o->routed[i] = k == HS_NODE_ROUTER ? s.a : 0;
+    }
+    if (o->rt_taken && g->n_rt > 0)
+        HSG_HIP(g, hipMemcpy(o->rt_taken, g->ctl.rt_taken, (size_t)g->n_rt * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return HS_OK;
+}
+
+int64_t hs_graph_read_records(hs_graph *g, int32_t *node, int64_t *t_ns, int64_t *created_ns, int64_t cap) {
+    if (!g) return gfail(g, HS_E_INVALID, "null handle");
+    if (hipSetDevice(g->cfg.device) != hipSuccess) return gfail(g, HS_E_HIP, "hipSetDevice failed");
+    GVars v;
+    if (hipMemcpy(&v, g->ctl.V, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return gfail(g, HS_E_HIP, "reading the run's scalars failed");
+    const long long m = std::min<long long>(v.rec_n, cap > 0 ? cap : 0);
+    if (m > 0) {
+        if (node && hipMemcpy(node, g->ctl.rec_node, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return gfail(g, HS_E_HIP, "record copy failed");
+        if (t_ns && hipMemcpy(t_ns, g->ctl.rec_t, (size_t)m * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return gfail(g, HS_E_HIP, "record copy failed");
+        if (created_ns && hipMemcpy(created_ns, g->ctl.rec_cr, (size_t)m * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return gfail(g, HS_E_HIP, "record copy failed");
+    }
+    return v.rec_n;
+}
+
+}  // extern "C"

@@ -1,0 +1,300 @@
+"""General entity graphs: what the lowered entity classes can be wired into beyond the station shape of lowering.lower().
+
+The station engines take `[Sources] -> Server -> {Sink | NetworkLink | RandomRouter}` with one sender per link, at most four
+Sources per Server, four router targets ...; lowering.lower() refuses the rest by name.  `lower_general()` takes exactly those
+graphs -- a NetworkLink with several senders (components/network/link.py:114-189), a RandomRouter with any number of targets,
+Servers and routers among them, and with several upstreams (components/random_router.py:32-45), Server(downstream=<Server>)
+next to links (components/server/server.py:64-122), any number of Sources per Server (load/source.py:93-180), any
+FixedConcurrency (server/concurrency.py:67-141) -- and runs them on the device's single-heap loop (csrc/hs_graph.hip,
+include/hs_engine.h "General entity graphs"): the reference's own (time, _sort_index) order event by event, ~1 us per event on
+one lane.  Exact, not fast: Simulation only comes here with a graph lower() refused.
+
+Entity streams (DESIGN.md section 3 -- the one definition that is the engine's own): the k-th Source of `sources=[...]` draws
+ARRIVAL from stream base k; the s-th Server / l-th NetworkLink / r-th RandomRouter in node order (entities in `entities=[...]`
+order, then whatever is only reachable downstream, in discovery order) draws SERVICE / LINK + LOSS / ROUTE from base s / l / r.
+For a graph built station by station this is the numbering of the station engines.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .entities import (ConstantLatency, ConstantRateProfile, Counter, Entity, ExponentialLatency, LatencyTracker, LoadBalancer,
+                       NetworkLink, RandomRouter, Server, SimpleEventProvider, Sink, Source)
+
+_SINKS = (Sink, Counter, LatencyTracker)
+DEFAULT_MAX_EVENTS = 200_000_000          # ~ minutes on the one lane; Simulation(max_graph_events=) raises it
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class GraphArrays:
+    """Struct-of-arrays form of hs_graph_nodes (include/hs_engine.h)."""
+
+    def __init__(self, n: int):
+        self.n = n
+        self.kind = np.zeros(n, np.uint8)
+        self.target = np.full(n, -1, np.int32)
+        self.stream_base = np.zeros(n, np.uint64)
+        self.src_kind = np.full(n, N.SRC_POISSON, np.uint8)
+        self.src_rate = np.ones(n, np.float64)
+        self.src_stop_after_ns = np.full(n, -1, np.int64)
+        self.concurrency = np.ones(n, np.int32)
+        self.lat_kind = np.full(n, N.LAT_CONSTANT, np.uint8)
+        self.lat_mean_s = np.zeros(n, np.float64)
+        self.link_lat_min_s = np.zeros(n, np.float64)
+        self.link_loss_rate = np.zeros(n, np.float64)
+        self.queue_cap = np.full(n, -1, np.int64)
+        self.rt_off = np.zeros(n, np.int32)
+        self.rt_cnt = np.zeros(n, np.int32)
+        self.rt_targets = np.zeros(0, np.int32)
+
+    def struct(self) -> N.GraphNodes:
+        s = N.GraphNodes()
+        s.n_nodes = self.n
+        for name in ("kind", "target", "stream_base", "src_kind", "src_rate", "src_stop_after_ns", "concurrency", "lat_kind",
+                     "lat_mean_s", "link_lat_min_s", "link_loss_rate", "queue_cap", "rt_off", "rt_cnt"):
+            setattr(s, name, _ptr(getattr(self, name)))
+        self.rt_targets = np.ascontiguousarray(self.rt_targets, np.int32)
+        s.rt_targets = _ptr(self.rt_targets) if len(self.rt_targets) else None
+        s.n_rt = len(self.rt_targets)
+        return s
+
+
+class GraphEngine:
+    """ctypes handle of one hs_graph.  No CPU fallback: without the library or a GPU the constructor raises."""
+
+    def __init__(self, arrays: GraphArrays, *, seed: int = 42, start_ns: int = 0, device: int = 0, max_events: int = 0,
+                 heap_capacity: int = 0, request_capacity: int = 0, record_capacity: int = 0):
+        self._lib = N.lib()
+        self.arrays = arrays
+        cfg = N.GraphConfig(struct_size=C.sizeof(N.GraphConfig), device=device, start_ns=start_ns, seed=seed,
+                            heap_capacity=heap_capacity, request_capacity=request_capacity, record_capacity=record_capacity,
+                            max_events=max_events)
+        h = C.c_void_p()
+        nodes = arrays.struct()
+        rc = self._lib.hs_graph_create(C.byref(cfg), C.byref(nodes), C.byref(h))
+        if rc != N.HS_OK:
+            msg = (self._lib.hs_graph_last_error(None) or b"").decode()
+            if rc == N.HS_E_NO_DEVICE:
+                raise N.EngineUnavailable(msg)
+            raise N.EngineError(rc, msg)
+        self._h = h
+
+    def _check(self, rc: int):
+        if rc < 0:
+            raise N.EngineError(rc, (self._lib.hs_graph_last_error(self._h) or b"").decode())
+        return rc
+
+    def schedule(self, node: int, time_ns: int) -> None:
+        self._check(self._lib.hs_graph_schedule(self._h, int(node), int(time_ns)))
+
+    def run_until(self, end_ns: int) -> None:
+        self._check(self._lib.hs_graph_run_until(self._h, int(end_ns)))
+
+    def summary(self) -> N.Summary:
+        s = N.Summary()
+        self._check(self._lib.hs_graph_get_summary(self._h, C.byref(s)))
+        return s
+
+    def stats(self) -> dict:
+        n, nrt = self.arrays.n, max(len(self.arrays.rt_targets), 1)
+        out = {k: np.zeros(nrt if k == "rt_taken" else n, np.float64 if k == "total_service_s" else np.int64) for k in N.GRAPH_STATS}
+        st = N.GraphStats()
+        for k, a in out.items():
+            setattr(st, k, _ptr(a))
+        self._check(self._lib.hs_graph_get_stats(self._h, C.byref(st)))
+        out["rt_taken"] = out["rt_taken"][:len(self.arrays.rt_targets)]
+        return out
+
+    def records(self):
+        """(Sink node, completion ns, created_at ns) of every Sink record, in processing order."""
+        n = self._check(self._lib.hs_graph_read_records(self._h, None, None, None, 0))
+        node, t, cr = np.zeros(n, np.int32), np.zeros(n, np.int64), np.zeros(n, np.int64)
+        if n:
+            self._check(self._lib.hs_graph_read_records(self._h, _ptr(node), _ptr(t), _ptr(cr), n))
+        return node, t, cr
+
+    def close(self):
+        if self._h:
+            self._lib.hs_graph_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+class GeneralGraph:
+    """The node list of one Simulation: Sources in `sources=[...]` order, then the other entities."""
+
+    def __init__(self, nodes: list, arrays: GraphArrays, node_of: dict):
+        self.nodes = nodes              # entity objects by node id
+        self.arrays = arrays
+        self.node_of = node_of          # id(entity) -> node id
+
+
+def lower_general(sources: list, entities: list, probes=None) -> GeneralGraph:
+    """`sources` / `entities` of a Simulation -> the node arrays of the single-heap engine.  Refuses by name what that engine
+    does not run either (lowering.UnsupportedTopology)."""
+    from .lowering import UnsupportedTopology
+
+    if probes:
+        raise UnsupportedTopology("probes on a graph outside the station shape are not lowered (the single-heap path samples nothing yet)")
+    nodes: list = []
+    node_of: dict[int, int] = {}
+
+    def add(ent):
+        if id(ent) not in node_of:
+            node_of[id(ent)] = len(nodes)
+            nodes.append(ent)
+        return node_of[id(ent)]
+
+    for src in sources or []:
+        if not isinstance(src, Source):
+            raise UnsupportedTopology(f"source {type(src).__name__} is not a lowered Source")
+        if id(src) in node_of:
+            raise UnsupportedTopology(f"source '{src.name}' is listed twice")
+        add(src)
+    n_src = len(nodes)
+    lowered = (Server, NetworkLink, RandomRouter) + _SINKS
+
+    def check(ent, where):
+        if isinstance(ent, LoadBalancer):
+            raise UnsupportedTopology(f"{where}: a LoadBalancer inside a general graph is not lowered")
+        if isinstance(ent, Source):
+            raise UnsupportedTopology(f"{where}: a Source takes no Requests")
+        if not isinstance(ent, lowered):
+            raise UnsupportedTopology(f"{where}: {type(ent).__name__} '{getattr(ent, 'name', ent)}' is not lowered to the engine")
+
+    for ent in entities or []:
+        if isinstance(ent, Source):
+            if id(ent) not in node_of:
+                raise UnsupportedTopology(f"source '{ent.name}' is listed in entities but not in sources: it would never start")
+            continue
+        if not isinstance(ent, Entity):
+            raise UnsupportedTopology(f"object {ent!r} is not an Entity")
+        check(ent, "entities")
+        add(ent)
+    # whatever is only reachable downstream (the reference never needs it listed: events carry their target), in discovery order
+    k = 0
+    while k < len(nodes):
+        ent = nodes[k]
+        k += 1
+        for d in ent.downstream_entities():
+            if d is None:
+                continue
+            check(d, f"'{ent.name}' forwards to it")
+            add(d)
+    n = len(nodes)
+    a = GraphArrays(n)
+    counters = {Server: 0, NetworkLink: 0, RandomRouter: 0}
+    rt: list[int] = []
+    for i, ent in enumerate(nodes):
+        if isinstance(ent, Source):
+            ep, prov = ent._event_provider, ent._time_provider
+            if not isinstance(ep, SimpleEventProvider):
+                raise UnsupportedTopology(f"source '{ent.name}': event provider {type(ep).__name__} is not lowered on a general graph")
+            if not isinstance(prov.profile, ConstantRateProfile):
+                raise UnsupportedTopology(f"source '{ent.name}': a time-varying profile on a graph outside the station shape is not lowered")
+            if not (ent.rate > 0):
+                raise UnsupportedTopology(f"source '{ent.name}': rate must be > 0")
+            if not isinstance(ep._target, Entity) or id(ep._target) not in node_of:
+                raise UnsupportedTopology(f"source '{ent.name}' has no lowered target")
+            a.kind[i] = N.NODE_SOURCE
+            a.target[i] = node_of[id(ep._target)]
+            a.stream_base[i] = i                              # (Sources are nodes 0 .. n_src - 1, in `sources` order)
+            a.src_kind[i] = N.SRC_POISSON if prov.kind == "poisson" else N.SRC_CONSTANT
+            a.src_rate[i] = float(prov.profile.peak_rate)
+            a.src_stop_after_ns[i] = -1 if ep._stop_after is None else ep._stop_after.nanoseconds
+        elif isinstance(ent, Server):
+            svc = ent.service_time
+            if not isinstance(svc, (ExponentialLatency, ConstantLatency)):
+                raise UnsupportedTopology(f"server '{ent.name}': service distribution {type(svc).__name__} is not lowered")
+            a.kind[i] = N.NODE_SERVER
+            a.stream_base[i] = counters[Server]
+            counters[Server] += 1
+            a.concurrency[i] = ent.concurrency
+            a.lat_kind[i] = N.LAT_EXPONENTIAL if isinstance(svc, ExponentialLatency) else N.LAT_CONSTANT
+            a.lat_mean_s[i] = svc.mean
+            cap = ent._policy.capacity
+            a.queue_cap[i] = -1 if cap == float("inf") else int(cap)
+            d = ent.downstream
+            a.target[i] = -1 if d is None else node_of[id(d)]
+        elif isinstance(ent, NetworkLink):
+            if not isinstance(ent.latency, ConstantLatency) or not (ent.latency.mean >= 0):
+                raise UnsupportedTopology(f"link '{ent.name}': the base latency must be a ConstantLatency >= 0")
+            if ent.jitter is not None and not isinstance(ent.jitter, (ExponentialLatency, ConstantLatency)):
+                raise UnsupportedTopology(f"link '{ent.name}': jitter {type(ent.jitter).__name__} is not lowered")
+            a.kind[i] = N.NODE_LINK
+            a.stream_base[i] = counters[NetworkLink]
+            counters[NetworkLink] += 1
+            a.link_lat_min_s[i] = ent.latency.mean
+            if ent.jitter is not None:
+                a.lat_kind[i] = N.LAT_EXPONENTIAL if isinstance(ent.jitter, ExponentialLatency) else N.LAT_CONSTANT
+                a.lat_mean_s[i] = ent.jitter.mean
+            a.link_loss_rate[i] = ent.packet_loss_rate
+            a.target[i] = -1 if ent.egress is None else node_of[id(ent.egress)]
+        elif isinstance(ent, RandomRouter):
+            if not ent.targets:
+                raise UnsupportedTopology(f"router '{ent.name}' has no targets")
+            a.kind[i] = N.NODE_ROUTER
+            a.stream_base[i] = counters[RandomRouter]
+            counters[RandomRouter] += 1
+            a.rt_off[i] = len(rt)
+            a.rt_cnt[i] = len(ent.targets)
+            rt.extend(node_of[id(t)] for t in ent.targets)
+        else:
+            a.kind[i] = N.NODE_SINK
+    a.rt_targets = np.array(rt, np.int32)
+    assert all(a.kind[i] == N.NODE_SOURCE for i in range(n_src))
+    return GeneralGraph(nodes, a, node_of)
+
+
+def write_back_general(g: GeneralGraph, stats: dict, rec_node: np.ndarray, rec_t: np.ndarray, rec_cr: np.ndarray, device: int = 0) -> None:
+    """The run's per-node results onto the user's objects, under the attribute names the reference uses (lowering.write_back's
+    counterpart)."""
+    a = g.arrays
+    order = np.argsort(rec_node, kind="stable")              # per Sink, still in processing order
+    bounds = np.searchsorted(rec_node[order], np.arange(a.n + 1))
+    for i, ent in enumerate(g.nodes):
+        if isinstance(ent, Source):
+            ent._generated_count = int(stats["generated"][i])
+            ent._event_provider._generated = int(stats["payloads"][i])
+        elif isinstance(ent, Server):
+            ent._queue.stats_accepted = int(stats["accepted"][i])
+            ent._queue.stats_dropped = int(stats["dropped"][i])
+            ent._queue.depth = int(stats["queue_depth"][i])
+            ent._requests_completed = int(stats["completed"][i])
+            ent._requests_rejected = int(stats["rejected"][i])
+            ent._total_service_time = float(stats["total_service_s"][i])
+            ent._active = int(stats["active"][i])
+        elif isinstance(ent, NetworkLink):
+            ent.packets_sent = int(stats["packets_sent"][i])
+            ent.packets_dropped = int(stats["packets_dropped"][i])
+            ent._entered = int(stats["entered"][i])
+        elif isinstance(ent, RandomRouter):
+            ent.stats_routed = int(stats["routed"][i])
+            tc: dict[str, int] = {}
+            off = int(a.rt_off[i])
+            for q, t in enumerate(ent.targets):               # target_counts[target.name] += 1 (random_router.py:37)
+                c = int(stats["rt_taken"][off + q])
+                if c:
+                    tc[t.name] = tc.get(t.name, 0) + c
+            ent.target_counts = tc
+        else:
+            sel = order[bounds[i]:bounds[i + 1]]
+            ent._set_records(rec_t[sel].copy(), rec_cr[sel].copy())
+            ent._device = device

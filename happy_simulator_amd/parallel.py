@@ -140,7 +140,7 @@ def _run_independent(sims: list[Simulation], seeds: list[int], device: int = 0,
     `stream_bases`: entity stream numbering per Simulation (default 0: every replica numbers its entities from 0)."""
     graphs = [s.lowered() for s in sims]
     for s, g in zip(sims, graphs):
-        if len(g.stations) != 1:
+        if not hasattr(g, "stations") or len(g.stations) != 1:        # (graph_engine.GeneralGraph: no stations at all)
             raise UnsupportedTopology(
                 "batched replicas need one station per Simulation; run multi-station Simulations with .run()")
     ends = {s._end_time.nanoseconds for s in sims}

@@ -12,6 +12,7 @@ from . import _native as N
 from .core.event import Event
 from .core.temporal import Instant
 from .engine import StationEngine
+from .graph_engine import DEFAULT_MAX_EVENTS, GeneralGraph, GraphEngine, lower_general, write_back_general
 from .entities import Entity, Server
 from .lowering import (LazyRecords, LbGraph, LoweredGraph, UnsupportedTopology, attach_lb_probes, attach_probes, find_load_balancer, lower,
                        plain_probe_arrays, write_back_plain_probes,
@@ -35,7 +36,7 @@ class Simulation:
     def __init__(self, start_time: Instant | None = None, end_time: Instant | None = None, sources=None,
                  entities=None, probes=None, trace_recorder=None, fault_schedule=None, duration: float | None = None,
                  *, seed: int | None = None, device: int = 0, log_capacity: int | None = None,
-                 bag_capacity: int | None = None, msg_capacity: int | None = None):
+                 bag_capacity: int | None = None, msg_capacity: int | None = None, max_graph_events: int | None = None):
         if duration is not None and end_time is not None:
             raise ValueError("Cannot specify both 'duration' and 'end_time'")        # core/simulation.py:79-80
         self._start_time = start_time if start_time is not None else Instant.Epoch
@@ -57,6 +58,8 @@ class Simulation:
         # engine capacities (records per station log / in-flight messages per station / messages per exchange row); None =
         # derived from the rates.  An HS_E_OVERFLOW names the one to raise.
         self._log_capacity, self._bag_capacity, self._msg_capacity = log_capacity, bag_capacity, msg_capacity
+        # a graph outside the station shape runs on the single-heap loop (graph_engine.py): events it may cost before it is refused
+        self._max_graph_events = DEFAULT_MAX_EVENTS if max_graph_events is None else int(max_graph_events)
         self._summary: SimulationSummary | None = None
         self._graph: LoweredGraph | None = None
         self._events_processed = 0
@@ -115,7 +118,7 @@ class Simulation:
     def summary(self) -> SimulationSummary | None:
         return self._summary
 
-    def lowered(self) -> "LoweredGraph | LbGraph":
+    def lowered(self) -> "LoweredGraph | LbGraph | GeneralGraph":
         if self._graph is None:
             plain = plain_chains(self._sources, self._entities)      # (n plain chains: no LoadBalancer among them, one pass less)
             if plain is not None:
@@ -123,8 +126,20 @@ class Simulation:
                 lb = None
             else:
                 lb = find_load_balancer(self._sources, self._entities)
-                self._graph = lower_lb(self._sources, self._entities, lb) if lb is not None else lower(self._sources,
-                                                                                                        self._entities)
+                try:
+                    self._graph = lower_lb(self._sources, self._entities, lb) if lb is not None else lower(self._sources,
+                                                                                                            self._entities)
+                except UnsupportedTopology as station_shape:
+                    # not the shape the station engines take: the single-heap loop (csrc/hs_graph.hip) runs what the same entity
+                    # classes can be wired into otherwise -- exactly, at ~1 us per event
+                    if lb is not None:
+                        raise
+                    try:
+                        self._graph = lower_general(self._sources, self._entities, self._probes)
+                    except UnsupportedTopology as general:
+                        raise UnsupportedTopology(f"{station_shape}; and not on the single-heap path either: {general}") from None
+                    self._station_refusal = str(station_shape)
+                    return self._graph
             if self._probes:
                 if lb is not None:
                     attach_lb_probes(self._graph, self._probes)
@@ -191,6 +206,8 @@ class Simulation:
 
     def _run(self, auto: bool, wall0: float) -> SimulationSummary:
         g = self.lowered()
+        if isinstance(g, GeneralGraph):
+            return self._run_general(g, auto, wall0)
         if isinstance(g, LbGraph):
             if self._scheduled:
                 raise UnsupportedTopology("schedule() is not lowered for load-balancer topologies yet")
@@ -241,6 +258,55 @@ class Simulation:
         write_back_shared_sink_probes(g)
         # a cancelled event is counted when the loop pops it: everything up to the last processed event, or the whole
         # heap when the run ended with nothing left beyond end_time (core/simulation.py:472-477)
+        drained = es.final_time_ns <= end_ns
+        self._events_cancelled = sum(1 for t in cancelled_ns if drained or t <= es.final_time_ns)
+        self._engine_summary = es
+        self._events_processed = es.events_processed
+        self._current_time = Instant(es.final_time_ns)
+        self._summary = self._build_summary(_time.monotonic() - wall0)
+        return self._summary
+
+    def _run_general(self, g: GeneralGraph, auto: bool, wall0: float) -> SimulationSummary:
+        """A graph outside the station shape (graph_engine.lower_general) on the device's single-heap loop."""
+        end_ns = self._end_time.nanoseconds if not auto else (1 << 61)
+        start_ns = self._start_time.nanoseconds
+        a = g.arrays
+        # ~8 reference events per Request that is served and ~2 per hop: refuse up front what would take the one lane minutes
+        horizon_s = 0.0 if auto else (end_ns - start_ns) / 1e9
+        est = 12.0 * float(a.src_rate[a.kind == N.NODE_SOURCE].sum()) * horizon_s
+        if self._max_graph_events > 0 and est > 4.0 * self._max_graph_events:
+            raise UnsupportedTopology(
+                f"{self._station_refusal}; the single-heap path (one lane, ~1 us per event) would need ~{est:.2g} events for this run "
+                f"(limit {self._max_graph_events}: Simulation(max_graph_events=...))")
+        cancelled_ns: list[int] = []
+        sched: list[tuple[int, int]] = []
+        for ev in self._scheduled:
+            if ev.cancelled:                       # lazy deletion: skipped when popped, counted (simulation.py:475-477)
+                cancelled_ns.append(ev.time.nanoseconds)
+                continue
+            i = g.node_of.get(id(ev.target))
+            if i is None or a.kind[i] == N.NODE_SOURCE:
+                raise UnsupportedTopology(f"scheduled event {ev!r}: only Requests for a Server / Sink / NetworkLink / RandomRouter of "
+                                          "this Simulation are lowered")
+            if ev.on_complete:
+                raise UnsupportedTopology(f"scheduled event {ev!r}: completion hooks are host Python (not lowered)")
+            if ev.context.get("created_at") != ev.time:
+                raise UnsupportedTopology(f"scheduled event {ev!r}: a custom created_at is not lowered")
+            if cancelled_ns:
+                # a cancelled Event keeps its place in the process-wide counter: the ones behind it would need the gap
+                raise UnsupportedTopology("cancelled Events in front of live ones are not lowered on the single-heap path")
+            if ev.time.nanoseconds < start_ns:     # "time travel": the loop skips it without counting (simulation.py:480-489)
+                warnings.warn(f"Time travel detected: {ev!r} lies before the simulation start; skipping event", stacklevel=3)
+                continue
+            sched.append((i, ev.time.nanoseconds))
+        with GraphEngine(a, seed=self._seed, start_ns=start_ns, device=self._device, max_events=self._max_graph_events) as eng:
+            for node, t in sched:
+                eng.schedule(node, t)
+            eng.run_until(end_ns)
+            es = eng.summary()
+            stats = eng.stats()
+            rec = eng.records()
+        write_back_general(g, stats, *rec, device=self._device)
         drained = es.final_time_ns <= end_ns
         self._events_cancelled = sum(1 for t in cancelled_ns if drained or t <= es.final_time_ns)
         self._engine_summary = es

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HS_ABI_VERSION 14
+#define HS_ABI_VERSION 15
 
 typedef enum hs_status {
     HS_OK = 0,
@@ -651,6 +651,95 @@ int64_t hs_debug_tick_table(int32_t device, const double *profile, int32_t poiss
  * division, q_ns[i] = seconds_from_ns((int64)a[i]) (compare with a[i] / 1e9). */
 int hs_debug_const_div(int32_t device, double b, int64_t n, const double *a, double *q_fast, double *q_ieee,
                        double *q_ns);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * General entity graphs (ABI 15).
+ *
+ * The station engines take graphs of the shape [Sources] -> Server -> {Sink | NetworkLink | RandomRouter} with one sender
+ * per link, <= 4 Sources per Server, <= 4 router targets ... (hs_engine_set_stations / hs_engine_set_network).  Everything
+ * else the same entity classes can be wired into -- a NetworkLink with several senders (components/network/link.py:114-189),
+ * a RandomRouter with any number of targets, among them Servers and other routers, and with several upstreams
+ * (components/random_router.py:32-45), Server(downstream=<Server>) next to links (components/server/server.py:64-122,271-272),
+ * any number of Sources per Server (load/source.py:93-180), any concurrency (server/concurrency.py:67-141) -- runs here:
+ * ONE heap ordered by (time, _sort_index), popped event by event like `Simulation._execute_until`
+ * (core/simulation.py:449-505), every reference Event materialised with the sort index the reference gives it (the two
+ * counters of core/event.py:53-77 and core/event_heap.py:48), push / pop in CPython's heapq sift order.  One lane of one
+ * wavefront walks the loop; the first 4 096 heap entries live in LDS (128 KB of the CU's 160), the rest and all node state
+ * in HBM.  An exactness path for small models (~1 us per event), not a throughput path: the station engines stay the
+ * product's hot path, and the host (happy_simulator_amd/graph_engine.py) only comes here with a graph they refuse.
+ * Replaces: Simulation.__init__'s bootstrap (core/simulation.py:145-160), Simulation.schedule (:195-206), _execute_until
+ * (:449-505) and the handlers of load/source.py:142-180, components/queue.py:122-166, components/queue_driver.py:66-99,
+ * components/server/server.py:202-273, components/common.py:36-44, components/random_router.py:32-45,
+ * components/network/link.py:114-216 for such a graph.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct hs_graph hs_graph;
+
+typedef enum hs_node_kind { HS_NODE_SOURCE = 0, HS_NODE_SERVER = 1, HS_NODE_SINK = 2, HS_NODE_LINK = 3, HS_NODE_ROUTER = 4 } hs_node_kind;
+
+typedef struct hs_graph_config {
+    uint32_t struct_size;            /* sizeof(hs_graph_config) */
+    int32_t device;
+    int64_t start_ns;                /* Simulation(start_time=) */
+    uint64_t seed;                   /* Philox key of every entity stream */
+    int64_t heap_capacity;           /* pending events; 0 = sized from the graph.  All three capacities GROW on demand: */
+    int64_t request_capacity;        /* Requests alive (queued, in service, in transit); 0 = sized from the graph */
+    int64_t record_capacity;         /* Sink records of the whole run; 0 = 65 536 */
+    int64_t max_events;              /* a run that would process more is refused (HS_E_UNSUPPORTED); 0 = no limit */
+} hs_graph_config;
+
+/* Nodes in the caller's order.  SOURCE nodes must come in `sources=[...]` order (their first SourceEvents take the pre-run
+ * sort indices 0, 1, ... in that order, core/simulation.py:145-154).  Entity streams: sid = stream_base << 3 | kind
+ * (DESIGN.md section 3): a Source draws ARRIVAL, a Server SERVICE, a link LINK (jitter) and LOSS, a router ROUTE. */
+typedef struct hs_graph_nodes {
+    int32_t n_nodes;
+    const uint8_t *kind;             /* [n] hs_node_kind */
+    const int32_t *target;           /* [n] Source: the node its Requests are aimed at; Server: downstream; link: egress; -1 = none */
+    const uint64_t *stream_base;     /* [n] */
+    const uint8_t *src_kind;         /* [n] Sources: HS_SRC_POISSON / HS_SRC_CONSTANT (constant-rate profile) */
+    const double *src_rate;          /* [n] Sources: events / s, > 0 */
+    const int64_t *src_stop_after_ns;/* [n] Sources: SimpleEventProvider(stop_after); < 0 = never */
+    const int32_t *concurrency;      /* [n] Servers: FixedConcurrency(max_concurrent) >= 1 */
+    const uint8_t *lat_kind;         /* [n] Servers: service distribution; links: jitter (HS_LAT_EXPONENTIAL / HS_LAT_CONSTANT) */
+    const double *lat_mean_s;        /* [n] ... its mean (a link with HS_LAT_CONSTANT and mean 0: jitter=None) */
+    const double *link_lat_min_s;    /* [n] links: ConstantLatency base latency, >= 0 */
+    const double *link_loss_rate;    /* [n] links: packet_loss_rate in [0, 1]; NULL = lossless */
+    const int64_t *queue_cap;        /* [n] Servers: FIFOQueue capacity; < 0 = unbounded */
+    const int32_t *rt_off;           /* [n] routers: targets rt_targets[rt_off .. rt_off + rt_cnt) in constructor order */
+    const int32_t *rt_cnt;           /* [n] */
+    const int32_t *rt_targets;       /* [n_rt] node ids (Sink / link / Server / router) */
+    int32_t n_rt;
+} hs_graph_nodes;
+
+typedef struct hs_graph_stats {      /* host arrays [n_nodes] (rt_taken: [n_rt]); any pointer may be NULL */
+    int64_t *generated;              /* Source._generated_count                         load/source.py:159 */
+    int64_t *payloads;               /* Requests the Source's event provider built      load/source.py:67-86 */
+    int64_t *accepted, *dropped;     /* Queue.stats_accepted / stats_dropped            components/queue.py:127-139 */
+    int64_t *completed, *rejected;   /* Server._requests_completed / _rejected          server/server.py:112-114 */
+    double *total_service_s;         /* Server._total_service_time */
+    int64_t *queue_depth, *active;   /* QueuedResource.depth, Server.active_requests */
+    int64_t *received;               /* Sink.events_received */
+    int64_t *entered;                /* Requests that entered the link */
+    int64_t *packets_sent;           /* NetworkLink.packets_sent                        components/network/link.py:162 */
+    int64_t *packets_dropped;        /* NetworkLink.packets_dropped                     components/network/link.py:132 */
+    int64_t *routed;                 /* RandomRouter.stats_routed                       components/random_router.py:36 */
+    int64_t *rt_taken;               /* [n_rt] how often each target slot was drawn     (target_counts, random_router.py:37) */
+} hs_graph_stats;
+
+int hs_graph_create(const hs_graph_config *cfg, const hs_graph_nodes *nodes, hs_graph **out);
+/* Simulation.schedule(Event(time, "Request", target=<node>)) (core/simulation.py:195-206): the Event was constructed outside
+ * the run, so it takes the next index of the process-wide counter behind the Sources' first ticks; context["created_at"] =
+ * its own time.  Calls in the order the caller constructed the Events.  `node`: a Server, Sink, link or router. */
+int hs_graph_schedule(hs_graph *g, int32_t node, int64_t time_ns);
+/* `_execute_until(end)`: pops while the PREVIOUS event's time <= end_ns (so exactly one event beyond the end is processed,
+ * core/simulation.py:472); may be called again with a later end (windows, :527-541). */
+int hs_graph_run_until(hs_graph *g, int64_t end_ns);
+int hs_graph_get_summary(hs_graph *g, hs_summary *out);
+int hs_graph_get_stats(hs_graph *g, hs_graph_stats *out);
+/* Every Sink record of the run in processing order: (Sink node, completion ns, created_at ns).  Returns the number of
+ * records (copies min(that, cap)) or a negative hs_status. */
+int64_t hs_graph_read_records(hs_graph *g, int32_t *node, int64_t *t_ns, int64_t *created_ns, int64_t cap);
+const char *hs_graph_last_error(const hs_graph *g);
+void hs_graph_destroy(hs_graph *g);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_abi_version_and_struct_sizes(lib):
-    assert lib.hs_abi_version() == N.ABI_VERSION == 14
+    assert lib.hs_abi_version() == N.ABI_VERSION == 15
     assert C.sizeof(N.Config) == 56
     assert N.EV_KINDS == 15 and len(N.EV_NAMES) == 15
     assert C.sizeof(N.Summary) == 8 * (1 + 15 + 1 + 1 + 1 + 1) + 8 + 8 + 8 + 8 + 8
@@ -41,6 +41,7 @@ def test_abi_version_and_struct_sizes(lib):
     assert C.sizeof(N.LbConfig) == 64 and C.sizeof(N.LbSources) == 56 and C.sizeof(N.LbBackends) == 64
     assert C.sizeof(N.LbStats) == 88
     assert C.sizeof(N.Network) == 160 and C.sizeof(N.NetStats) == 4 * 8
+    assert C.sizeof(N.GraphConfig) == 56 and C.sizeof(N.GraphNodes) == 136 and C.sizeof(N.GraphStats) == 120
 
 
 def test_no_gpu_means_loud_failure(lib):
@@ -65,6 +66,14 @@ def test_no_gpu_means_loud_failure(lib):
     src = N.LbSources(None, rate.ctypes.data, None, ncl.ctypes.data, None)
     names = C.create_string_buffer(b"s")
     be = N.LbBackends(None, None, None, None, None, None, C.cast(names, C.c_void_p).value, off.ctypes.data)
+    # the general-graph engine: same rule
+    from happy_simulator_amd.graph_engine import GraphArrays, GraphEngine
+
+    ga = GraphArrays(2)
+    ga.kind[:] = (N.NODE_SOURCE, N.NODE_SINK)
+    ga.target[0] = 1
+    with pytest.raises(N.EngineUnavailable, match="no CPU fallback"):
+        GraphEngine(ga)
     assert lib.hs_lb_create(C.byref(lcfg), C.byref(src), C.byref(be), C.byref(h)) == N.HS_E_NO_DEVICE
     assert b"no CPU fallback" in lib.hs_lb_last_error(None)
     with pytest.raises(N.EngineUnavailable):

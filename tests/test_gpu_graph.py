@@ -1,0 +1,156 @@
+"""GPU: graphs outside the station shape on the device's single-heap loop (csrc/hs_graph.hip, happy_simulator_amd/graph_engine.py)
+-- a RandomRouter with eight targets among Sinks, links and Servers, links with several senders, Servers behind Servers next to
+links, seven Sources on one Server, routers with several upstreams -- through `hs.Simulation(...).run()`, against the LIVE-REFERENCE
+goldens (tests/golden/graph_*.npz, make_golden.run_graph_case) and the C oracle on random graphs (random_specs.graph_spec, which
+tests/test_oracle_live_reference.py pins on the live reference).  Bit-exact: totals, final time, every Source / Server / link /
+router / Sink statistic, every Sink record."""
+import numpy as np
+import pytest
+
+import graph_specs as GS
+import happy_simulator_amd as hs
+import helpers as H
+from happy_simulator_amd import _native as N
+from happy_simulator_amd.graph_engine import GeneralGraph, GraphEngine
+from oracle import hs_oracle as O
+from random_specs import graph_spec
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare_with_oracle(spec, sim, ents, r, nodes):
+    assert sim.summary.total_events_processed == r.events_processed
+    assert sim._current_time.nanoseconds == r.final_time_ns
+    np.testing.assert_array_equal(list(sim._engine_summary.events_by_kind), r.events_by_kind)
+    got = GS.results(ents)
+    np.testing.assert_array_equal(got["generated"], r.generated[nodes["source"]])
+    srv = nodes["server"]
+    for k, arr in (("accepted", r.accepted), ("dropped", r.dropped), ("completed", r.completed), ("rejected", r.rejected),
+                   ("depth", r.depth), ("active", r.active), ("total_service_s", r.total_service_s)):
+        np.testing.assert_array_equal(got[k], arr[srv], err_msg=k)
+    if nodes["router"]:
+        np.testing.assert_array_equal(got["routed"], r.routed[nodes["router"]])
+    if nodes["link"]:
+        np.testing.assert_array_equal(got["packets_sent"], r.packets_sent[nodes["link"]])
+        np.testing.assert_array_equal(got["packets_dropped"], r.dropped[nodes["link"]])
+    for j, nd in enumerate(nodes["sink"]):
+        t, created = r.sinks[nd]
+        np.testing.assert_array_equal(ents["sinks"][j].completion_ns, t, err_msg=f"sink {j}")
+        np.testing.assert_array_equal(ents["sinks"][j]._created_ns, created, err_msg=f"sink {j} created_at")
+    for rt in ents["routers"]:                                   # target_counts (random_router.py:37): consistent with what was routed
+        assert sum(rt.target_counts.values()) == rt.stats_routed
+
+
+@pytest.mark.parametrize("name", H.golden_names("graph"))
+def test_general_graphs_match_the_live_reference_goldens(name):
+    gold = H.Golden(name)
+    spec = gold.spec
+    sim, ents = GS.build(spec)
+    assert isinstance(sim.lowered(), GeneralGraph)               # (the station engines refuse these by name)
+    summary = sim.run()
+    assert [summary.total_events_processed] == gold.meta["total_events"]
+    assert [sim._current_time.nanoseconds] == gold.meta["final_ns"]
+    assert [summary.duration_s] == gold.meta["duration_s"]
+    got = GS.results(ents)
+    for k in ("generated", "accepted", "dropped", "completed", "rejected", "depth", "active", "total_service_s", "received", "routed",
+              "packets_sent", "packets_dropped"):
+        np.testing.assert_array_equal(got[k], gold.arrays[k], err_msg=k)
+    for j, sk in enumerate(ents["sinks"]):
+        gt, glat = gold.sink_records(j)
+        np.testing.assert_array_equal(sk.completion_ns, gt, err_msg=f"sink {j}")
+        np.testing.assert_array_equal(sk.latencies_array, glat, err_msg=f"sink {j} latencies")
+        assert sk.latencies_s == list(glat)
+
+
+@pytest.mark.parametrize("block", range(8))
+def test_random_general_graphs_match_the_oracle(block):
+    """40 graphs per block: up to 7 Servers, 5 shared links, 4 routers with up to 8 targets and several upstreams, up to 14 Sources."""
+    ran = 0
+    for k in range(block * 40, block * 40 + 40):
+        spec = graph_spec(k)
+        sim, ents = GS.build(spec)
+        g = sim.lowered()
+        if not isinstance(g, GeneralGraph):                      # (a draw the station engines take: theirs to test)
+            continue
+        g_o, nodes = H.oracle_graph(spec)
+        r = O.run(g_o, H.ns_from_seconds(spec["end_s"]), seed=spec["seed"])
+        sim.run()
+        _compare_with_oracle(spec, sim, ents, r, nodes)
+        ran += 1
+    assert ran >= 30
+
+
+def test_scheduled_requests_on_a_general_graph_take_the_pre_run_indices():
+    """Simulation.schedule() (core/simulation.py:195-206) on a general graph: Requests for a Server, a router, a link and a Sink, some
+    on the nanosecond of a Source's constant tick and of each other, one beyond the end -- the oracle's hso_schedule in call order."""
+    spec = dict(H.Golden("graph_shared_links_tandem").spec)
+    sched = [("server", 0, 0.5), ("server", 0, 0.5), ("router", 1, 0.5), ("link", 0, 1.0), ("sink", 2, 1.0), ("server", 3, 0.0),
+             ("server", 0, 2.0), ("server", 4, 9.999999999), ("server", 1, 10.5), ("router", 0, 0.0)]
+    sim, ents = GS.build(spec, extra_schedule=sched)
+    g_o, nodes = H.oracle_graph(spec)
+    r = O.run(g_o, H.ns_from_seconds(spec["end_s"]), seed=spec["seed"],
+              schedule=[(nodes[k][i], H.ns_from_seconds(t)) for k, i, t in sched])
+    sim.run()
+    _compare_with_oracle(spec, sim, ents, r, nodes)
+
+
+def test_windows_over_a_general_graph_equal_one_run():
+    """`_run_window` = `_execute_until` again (core/simulation.py:527-541): growing, repeated and earlier ends on the engine handle."""
+    spec = H.Golden("graph_fanout_8").spec
+    sim, _ = GS.build(spec)
+    g = sim.lowered()
+    end_ns = H.ns_from_seconds(spec["end_s"])
+    with GraphEngine(g.arrays, seed=spec["seed"]) as one:
+        one.run_until(end_ns)
+        s1, st1, rec1 = one.summary(), one.stats(), one.records()
+    with GraphEngine(g.arrays, seed=spec["seed"], heap_capacity=1, request_capacity=1, record_capacity=16) as eng:   # (and every buffer grows)
+        for w in (0.5, 0.5, 0.500000001, 3.25, 2.0, 7.75):
+            eng.run_until(H.ns_from_seconds(w))
+        eng.run_until(end_ns)
+        s2, st2, rec2 = eng.summary(), eng.stats(), eng.records()
+    assert s1.events_processed == s2.events_processed and s1.final_time_ns == s2.final_time_ns
+    for k in st1:
+        np.testing.assert_array_equal(st1[k], st2[k], err_msg=k)
+    for a, b in zip(rec1, rec2):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_a_heap_beyond_the_lds_window_and_a_large_concurrency():
+    """6 000 Sources on one Server with concurrency 5 000 (the station engines stop at four Sources and c = 32): the heap holds more
+    pending events than its 4 096 LDS entries, so sifts cross from LDS into HBM; == the oracle."""
+    n_src = 6000
+    g = O.Graph()
+    src = [g.source(O.ARR_POISSON if k % 3 else O.ARR_CONSTANT, 2.0 + (k % 7), stream_base=k) for k in range(n_src)]
+    snk = g.sink()
+    srv = g.server(O.LAT_EXP, 0.4, concurrency=5000, queue_cap=-1, stream_base=0)
+    for s in src:
+        g.target[s] = srv
+    g.target[srv] = snk
+    end_ns = 1_000_000_000
+    r = O.run(g, end_ns, seed=99)
+    assert r.heap_peak > 4096 + 2000
+    sink = hs.Sink("k")
+    server = hs.Server("s", concurrency=5000, service_time=hs.ExponentialLatency(0.4), downstream=sink)
+    sources = [(hs.Source.poisson if k % 3 else hs.Source.constant)(rate=2.0 + (k % 7), target=server, name=f"src{k}") for k in range(n_src)]
+    sim = hs.Simulation(end_time=hs.Instant.from_seconds(1.0), sources=sources, entities=[server, sink], seed=99)
+    summary = sim.run()
+    assert summary.total_events_processed == r.events_processed
+    assert sim._current_time.nanoseconds == r.final_time_ns
+    np.testing.assert_array_equal([s.generated_count for s in sources], r.generated[src])
+    assert server._requests_completed == r.completed[srv] and server._total_service_time == r.total_service_s[srv]
+    assert server.active_requests == r.active[srv] and server.stats_accepted == r.accepted[srv]
+    np.testing.assert_array_equal(sink.completion_ns, r.sinks[snk][0])
+    np.testing.assert_array_equal(sink._created_ns, r.sinks[snk][1])
+
+
+def test_a_run_beyond_max_graph_events_is_refused_by_name():
+    spec = H.Golden("graph_fanout_8").spec
+    sim, _ = GS.build(spec)
+    sim._max_graph_events = 10
+    with pytest.raises(hs.UnsupportedTopology, match="single-heap path"):
+        sim.run()
+    sim2, _ = GS.build(spec)
+    g = sim2.lowered()
+    with GraphEngine(g.arrays, seed=spec["seed"], max_events=500) as eng:
+        with pytest.raises(N.EngineError, match="max_events"):
+            eng.run_until(H.ns_from_seconds(spec["end_s"]))

@@ -1,0 +1,134 @@
+"""Host side of the general-graph path (happy_simulator_amd/graph_engine.py), no GPU: which graphs go there, the node arrays and
+stream numbering lower_general() builds, the refusals it keeps, the write-back, and the ABI structs of include/hs_engine.h."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import graph_specs as GS
+import happy_simulator_amd as hs
+import helpers as H
+from happy_simulator_amd import _native as N
+from happy_simulator_amd.graph_engine import GeneralGraph, lower_general, write_back_general
+from happy_simulator_amd.lowering import LoweredGraph
+from random_specs import graph_spec
+
+
+def test_graphs_the_station_engines_refuse_lower_to_the_single_heap_path():
+    for name in H.golden_names("graph"):
+        sim, _ = GS.build(H.Golden(name).spec)
+        assert isinstance(sim.lowered(), GeneralGraph)
+        assert sim._station_refusal                            # (what lowering.lower() said: kept for the messages)
+
+
+def test_station_shaped_graphs_stay_on_the_station_engines():
+    sink = hs.Sink("k")
+    servers = [hs.Server(f"s{i}", service_time=hs.ExponentialLatency(0.05)) for i in range(3)]
+    for i, sv in enumerate(servers):
+        link = hs.NetworkLink(f"l{i}", latency=hs.ConstantLatency(0.001), jitter=hs.ExponentialLatency(0.002), egress=servers[(i + 1) % 3])
+        sv.downstream = hs.RandomRouter(f"r{i}", targets=[sink, link])
+    sources = [hs.Source.poisson(rate=5.0, target=sv, name=f"src{i}") for i, sv in enumerate(servers)]
+    sim = hs.Simulation(duration=1.0, sources=sources, entities=servers + [sink])
+    assert isinstance(sim.lowered(), LoweredGraph)
+
+
+def test_node_arrays_and_stream_numbering_of_a_golden_graph():
+    spec = H.Golden("graph_shared_links_tandem").spec
+    sim, ents = GS.build(spec)
+    g = sim.lowered()
+    a = g.arrays
+    S, V, R, L, K = (len(spec[k]) if k != "n_sinks" else spec[k] for k in ("sources", "servers", "routers", "links", "n_sinks"))
+    assert a.n == S + V + R + L + K
+    np.testing.assert_array_equal(a.kind, [N.NODE_SOURCE] * S + [N.NODE_SERVER] * V + [N.NODE_ROUTER] * R + [N.NODE_LINK] * L + [N.NODE_SINK] * K)
+    # Source k / Server s / router r / link l draw from stream base k / s / r / l (the fixtures' numbering)
+    np.testing.assert_array_equal(a.stream_base[:S + V + R + L], list(range(S)) + list(range(V)) + list(range(R)) + list(range(L)))
+    node = lambda kind, i: {"server": S, "router": S + V, "link": S + V + R, "sink": S + V + R + L}[kind] + i   # noqa: E731
+    np.testing.assert_array_equal(a.target[:S], [node("server", sc["to"]) for sc in spec["sources"]])
+    np.testing.assert_array_equal(a.target[S:S + V], [node(*sv["out"]) for sv in spec["servers"]])
+    np.testing.assert_array_equal(a.target[S + V + R:S + V + R + L], [node("server", lk["to"]) for lk in spec["links"]])
+    flat = [node(k, i) for rt in spec["routers"] for k, i in rt["targets"]]
+    np.testing.assert_array_equal(a.rt_targets, flat)
+    np.testing.assert_array_equal(a.rt_cnt[S + V:S + V + R], [len(rt["targets"]) for rt in spec["routers"]])
+    np.testing.assert_array_equal(a.link_loss_rate[S + V + R:S + V + R + L], [lk["loss"] for lk in spec["links"]])
+    np.testing.assert_array_equal(a.queue_cap[S:S + V], [-1 if sv["cap"] is None else sv["cap"] for sv in spec["servers"]])
+    np.testing.assert_array_equal(a.src_kind[:S], [N.SRC_POISSON if sc["kind"] == "poisson" else N.SRC_CONSTANT for sc in spec["sources"]])
+    st = a.struct()
+    assert st.n_nodes == a.n and st.n_rt == len(flat)
+
+
+def test_entities_only_reachable_downstream_become_nodes_in_discovery_order():
+    sink = hs.Sink("k")
+    b = hs.Server("b", service_time=hs.ConstantLatency(0.01), downstream=sink)
+    link = hs.NetworkLink("l", latency=hs.ConstantLatency(0.001), egress=b)
+    a = hs.Server("a", service_time=hs.ConstantLatency(0.01), downstream=link)
+    c = hs.Server("c", service_time=hs.ConstantLatency(0.01), downstream=link)        # the link's second sender
+    src = [hs.Source.constant(rate=3.0, target=a, name="s0"), hs.Source.constant(rate=2.0, target=c, name="s1")]
+    g = lower_general(src, [a, c])                 # link, b and the Sink are not listed
+    assert [getattr(x, "name") for x in g.nodes] == ["s0", "s1", "a", "c", "l", "b", "k"]
+    np.testing.assert_array_equal(g.arrays.stream_base, [0, 1, 0, 1, 0, 2, 0])
+
+
+@pytest.mark.parametrize("k", range(40))
+def test_random_graph_specs_lower(k):
+    sim, ents = GS.build(graph_spec(k))
+    g = sim.lowered()
+    if isinstance(g, GeneralGraph):
+        a = g.arrays
+        assert (a.target[a.kind == N.NODE_SOURCE] >= 0).all()
+        assert all(0 <= t < a.n and a.kind[t] != N.NODE_SOURCE for t in a.rt_targets)
+
+
+def test_what_the_single_heap_path_refuses_too():
+    sink = hs.Sink("k")
+    sv = hs.Server("s", concurrency=64, service_time=hs.ExponentialLatency(0.05), downstream=sink)      # c > 32: not a station
+    src = hs.Source.poisson(rate=5.0, target=sv, name="src")
+    probe, _ = hs.Probe.on(sv, "depth", interval=0.5)
+    with pytest.raises(hs.UnsupportedTopology, match="probes on a graph outside the station shape"):
+        hs.Simulation(duration=1.0, sources=[src], entities=[sv, sink], probes=[probe]).lowered()
+    ramp = hs.Source.with_profile(hs.LinearRampProfile(duration_s=2.0, start_rate=1.0, end_rate=9.0), target=sv, name="ramp")
+    with pytest.raises(hs.UnsupportedTopology, match="time-varying profile"):
+        hs.Simulation(duration=1.0, sources=[ramp], entities=[sv, sink]).lowered()
+    assert isinstance(hs.Simulation(duration=1.0, sources=[src], entities=[sv, sink]).lowered(), GeneralGraph)
+    with pytest.raises(hs.UnsupportedTopology, match="would need"):       # 65 536 such chains for a minute: refused before anything runs
+        sinks = [hs.Sink(f"k{i}") for i in range(64)]
+        svs = [hs.Server(f"s{i}", concurrency=64, service_time=hs.ExponentialLatency(0.05), downstream=sinks[i]) for i in range(64)]
+        srcs = [hs.Source.poisson(rate=1e6, target=x, name=f"src{i}") for i, x in enumerate(svs)]
+        hs.Simulation(duration=60.0, sources=srcs, entities=svs + sinks).run()
+
+
+def test_write_back_puts_the_node_results_on_the_objects():
+    spec = H.Golden("graph_fanout_8").spec
+    sim, ents = GS.build(spec)
+    g = sim.lowered()
+    a = g.arrays
+    stats = {k: (np.arange(a.n, dtype=np.float64) * 0.5 if k == "total_service_s" else
+                 np.arange(len(a.rt_targets), dtype=np.int64) + 1 if k == "rt_taken" else np.arange(a.n, dtype=np.int64) * 10 + j)
+             for j, k in enumerate(N.GRAPH_STATS)}
+    sink_nodes = [g.node_of[id(x)] for x in ents["sinks"]]
+    rec_node = np.array([sink_nodes[1], sink_nodes[0], sink_nodes[1], sink_nodes[1]], np.int32)
+    rec_t, rec_cr = np.array([5, 6, 7, 9], np.int64), np.array([1, 2, 3, 4], np.int64)
+    write_back_general(g, stats, rec_node, rec_t, rec_cr)
+    i = g.node_of[id(ents["servers"][2])]
+    sv = ents["servers"][2]
+    assert (sv.stats_accepted, sv.stats_dropped, sv._requests_completed, sv._requests_rejected) == (
+        i * 10 + 2, i * 10 + 3, i * 10 + 4, i * 10 + 5)
+    assert sv._total_service_time == i * 0.5 and sv.depth == i * 10 + 7 and sv.active_requests == i * 10 + 8
+    s0 = ents["sources"][0]
+    assert s0.generated_count == 0 and s0._event_provider._generated == 1
+    np.testing.assert_array_equal(ents["sinks"][1].completion_ns, [5, 7, 9])
+    np.testing.assert_array_equal(ents["sinks"][0]._created_ns, [2])
+    rt = ents["routers"][0]
+    assert rt.stats_routed == g.node_of[id(rt)] * 10 + 13
+    # eight targets, two of them listed twice (link0, sink1 ...): counts add up per target NAME (random_router.py:37)
+    assert sum(rt.target_counts.values()) == sum(range(1, 9))
+    assert rt.target_counts["link0"] == 2 + 6
+
+
+def test_abi_structs_of_the_graph_entry_points():
+    assert C.sizeof(N.GraphConfig) == 56
+    assert C.sizeof(N.GraphNodes) == 8 + 15 * 8 + 8
+    assert C.sizeof(N.GraphStats) == 15 * 8
+    L = N.lib()
+    for sym in ("hs_graph_create", "hs_graph_schedule", "hs_graph_run_until", "hs_graph_get_summary", "hs_graph_get_stats",
+                "hs_graph_read_records", "hs_graph_last_error", "hs_graph_destroy"):
+        assert sym in N.EXPORTED_SYMBOLS and getattr(L, sym)
