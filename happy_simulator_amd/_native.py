@@ -31,7 +31,7 @@ PROF_CONSTANT, PROF_LINEAR_RAMP, PROF_SPIKE = 0, 1, 2
 LAT_EXPONENTIAL, LAT_CONSTANT, LAT_NO_SERVER = 0, 1, 2
 EGRESS_NONE, EGRESS_SINK, EGRESS_LINK, EGRESS_ROUTER, EGRESS_SERVER = 0, 1, 2, 3, 4
 LB_CONSISTENT_HASH, LB_ROUND_ROBIN, LB_RANDOM = 0, 1, 2
-NODE_SOURCE, NODE_SERVER, NODE_SINK, NODE_LINK, NODE_ROUTER = 0, 1, 2, 3, 4
+NODE_SOURCE, NODE_SERVER, NODE_SINK, NODE_LINK, NODE_ROUTER, NODE_PROBE = 0, 1, 2, 3, 4, 5
 EV_KINDS = 15
 EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuation", "sink", "link", "link_cont",
             "route", "lb", "lb_resp", "probe_tick", "probe")
@@ -122,13 +122,15 @@ class GraphConfig(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("device", C.c_int32), ("start_ns", C.c_int64), ("seed", C.c_uint64),
         ("heap_capacity", C.c_int64), ("request_capacity", C.c_int64), ("record_capacity", C.c_int64), ("max_events", C.c_int64),
+        ("profile_budget", C.c_int64),
     ]
 
 
 class GraphNodes(C.Structure):
     _fields_ = [("n_nodes", C.c_int32)] + [(n, C.c_void_p) for n in (
         "kind", "target", "stream_base", "src_kind", "src_rate", "src_stop_after_ns", "concurrency", "lat_kind", "lat_mean_s",
-        "link_lat_min_s", "link_loss_rate", "queue_cap", "rt_off", "rt_cnt", "rt_targets")] + [("n_rt", C.c_int32)]
+        "link_lat_min_s", "link_loss_rate", "queue_cap", "rt_off", "rt_cnt", "rt_targets")] + [("n_rt", C.c_int32)] + [
+        (n, C.c_void_p) for n in ("src_profile_kind", "src_profile_params", "probe_metric", "probe_interval_s")]
 
 
 GRAPH_STATS = ("generated", "payloads", "accepted", "dropped", "completed", "rejected", "total_service_s", "queue_depth", "active",

@@ -28,6 +28,7 @@
 
 #include "../../include/hs_engine.h"
 #include "hs_device.hpp"
+#include "hs_tables_api.hpp"
 
 namespace hs {
 namespace graph {
@@ -52,8 +53,8 @@ struct GParam {                                // 64 bytes, read-only
     int64_t lim;                               // Source: stop_after ns (< 0 never); Server: queue capacity (< 0 unbounded)
     int32_t target;
     int32_t conc;
-    int32_t rt_off, rt_cnt;
-    uint8_t kind, sub;                         // sub: Source arrival kind (hs_source_kind); Server / link latency kind
+    int32_t rt_off, rt_cnt;                    // router: its targets; Source / Probe: rt_off = row of its tick table (-1: none)
+    uint8_t kind, sub;                         // sub: Source arrival kind (hs_source_kind); Server / link latency kind; Probe metric
     uint8_t pad[6];
 };
 
@@ -62,6 +63,7 @@ struct GState {                                // 64 bytes
     // Server: a = stats_accepted, b = stats_dropped, c = completed, d = rejected
     // link:   a = entered, b = packets_sent, c = packets_dropped, d = jitter draws
     // router: a = stats_routed (= route draws);  Sink: a = events_received
+    // Probe:  a = ticks taken from its table, c = samples
     int64_t a, b, c, d;
     double total_service;                      // Server._total_service_time
     uint64_t svc_draws;
@@ -77,7 +79,7 @@ struct GRequest {                              // 32 bytes: the payload Event's 
     int32_t pad;
 };
 
-enum : int { kRunning = 0, kDone = 1, kGrowHeap = 2, kGrowReq = 4, kGrowRec = 8, kBadKind = 16 };
+enum : int { kRunning = 0, kDone = 1, kGrowHeap = 2, kGrowReq = 4, kGrowRec = 8, kBadKind = 16, kGrowTicks = 32 };
 
 struct GVars {                                 // device scalars
     long long heap_len;
@@ -102,6 +104,9 @@ struct GCtl {                                  // kernel argument
     const GParam *P; GState *S; int n;
     const int32_t *rt_targets; long long *rt_taken;
     const int32_t *sched_node; const int64_t *sched_t; long long n_sched;
+    // tick tables (hs_tables.hpp) of the time-varying Sources and the Probes: tick k of row r at ticks[r * tick_cap + k]; a row
+    // holds tick_count[r] ticks -- up to two beyond the horizon it was computed for, or up to the stream's end (kInfNs)
+    const int64_t *ticks; long long tick_cap; const int64_t *tick_count;
     GVars *V;
     uint64_t seed;
     int64_t start_ns, end_ns;
@@ -188,6 +193,11 @@ __device__ __forceinline__ GEvent mk(int64_t t, uint64_t idx, uint32_t kind, int
 __device__ inline int64_t next_arrival(const GCtl &c, int n) {
     const GParam &p = c.P[n];
     GState &s = c.S[n];
+    if (p.rt_off >= 0) {                       // a time-varying profile: tick number `generated` of the Source's table
+        const int64_t a2 = c.ticks[(size_t)p.rt_off * (size_t)c.tick_cap + (size_t)s.c];
+        s.a = a2;
+        return a2;
+    }
     double area = 1.0;
     if (p.sub == HS_SRC_POISSON) {
         area = exp1_from_uniform(uniform_at(c.seed, stream_id(p.stream_base, kStreamArrival), (uint64_t)s.b));
@@ -221,7 +231,14 @@ __global__ void __launch_bounds__(64) hs_graph_run(GCtl c) {
                 if (c.P[i].kind != HS_NODE_SOURCE) continue;
                 c.S[i].a = c.start_ns;                          // provider.current_time = start_time
                 const int64_t t = next_arrival(c, i);
+                if (t == kInfNs) continue;                      // "Rate is zero indefinitely. Source will not start." (source.py:137-139)
                 H.push(mk(t, g++, HS_EV_SOURCE, i, -1));        // (heap_cap >= 4 n: hs_graph_create)
+            }
+            for (int i = 0; i < c.n; ++i) {                     // then the probes, in list order (core/simulation.py:156-160)
+                if (c.P[i].kind != HS_NODE_PROBE) continue;
+                const int64_t t = c.ticks[(size_t)c.P[i].rt_off * (size_t)c.tick_cap];
+                if (t == kInfNs) continue;
+                H.push(mk(t, g++, HS_EV_PROBE_TICK, i, -1));
             }
             V.global_counter = g; V.booted = 1; G = 0; V.cur = c.start_ns;
         }
@@ -250,6 +267,19 @@ __global__ void __launch_bounds__(64) hs_graph_run(GCtl c) {
             if (H.len + 2 > c.heap_cap) { status |= kGrowHeap; break; }
             if (V.req_free < 0 && V.req_len >= c.req_cap) { status |= kGrowReq; break; }
             if (rec_n >= c.rec_cap) { status |= kGrowRec; break; }
+            if (c.ticks != nullptr) {                                              // the next tick of a table-driven stream must be in its table
+                const GEvent top = H.get(0);
+                if (top.kind == HS_EV_SOURCE || top.kind == HS_EV_PROBE_TICK) {
+                    const GParam &tp = c.P[top.node];
+                    if (tp.rt_off >= 0) {
+                        const int64_t need = (top.kind == HS_EV_SOURCE ? c.S[top.node].c : c.S[top.node].a) + 1;
+                        const int64_t cnt = c.tick_count[tp.rt_off];
+                        if (need >= cnt && c.ticks[(size_t)tp.rt_off * (size_t)c.tick_cap + (size_t)(cnt - 1)] != kInfNs && top.t >= cur) {
+                            status |= kGrowTicks; break;
+                        }
+                    }
+                }
+            }
             if (H.len > peak) peak = H.len;
             const GEvent e = H.pop();
             if (e.t < cur) continue;                                               // time-travel drop, core/simulation.py:480-489
@@ -278,9 +308,8 @@ __global__ void __launch_bounds__(64) hs_graph_run(GCtl c) {
                 }
                 s.c += 1;                                                           // _generated_count (:159)
                 const int64_t a2 = next_arrival(c, n);
-                const unsigned long long idx_t = G++;
                 if (payload) H.push(mk(t, idx_p, arrival_kind(c.P, p.target), p.target, r));
-                H.push(mk(a2, idx_t, HS_EV_SOURCE, n, -1));
+                if (a2 != kInfNs) H.push(mk(a2, G++, HS_EV_SOURCE, n, -1));       // RuntimeError: the source is exhausted (:176-180)
             } break;
             case HS_EV_ENQUEUE: {
                 // QueuedResource.handle_event -> Queue._handle_enqueue (components/queue.py:122-147)
@@ -381,6 +410,32 @@ __global__ void __launch_bounds__(64) hs_graph_run(GCtl c) {
                 if (p.target >= 0) H.push(mk(t, G++, arrival_kind(c.P, p.target), p.target, e.req));
                 else { c.reqs[e.req].next = V.req_free; V.req_free = e.req; }
                 break;
+            case HS_EV_PROBE_TICK: {
+                // Source.handle_event with _ProbeEventProvider (instrumentation/probe.py:69-78): the daemon probe_event, then the next tick
+                const unsigned long long idx_pe = G++;
+                const int64_t k2 = s.a + 1;
+                const int64_t a2 = c.ticks[(size_t)p.rt_off * (size_t)c.tick_cap + (size_t)k2];
+                s.a = k2;
+                H.push(mk(t, idx_pe, HS_EV_PROBE, n, -1));
+                if (a2 != kInfNs) H.push(mk(a2, G++, HS_EV_PROBE_TICK, n, -1));
+            } break;
+            case HS_EV_PROBE: {                                                     // measure_callback (probe.py:51-66)
+                const GState &tg = c.S[p.target];
+                int64_t v = 0;
+                switch (p.sub) {
+                    case HS_PROBE_DEPTH: v = tg.qlen; break;
+                    case HS_PROBE_ACTIVE: v = tg.active; break;
+                    case HS_PROBE_ACCEPTED: v = tg.a; break;
+                    case HS_PROBE_DROPPED: v = tg.b; break;
+                    case HS_PROBE_COMPLETED: v = tg.c; break;
+                    case HS_PROBE_RECEIVED: v = tg.a; break;                        // Sink.events_received
+                    case HS_PROBE_GENERATED: v = tg.c; break;                       // Source.generated_count
+                    default: break;
+                }
+                c.rec_node[rec_n] = n; c.rec_t[rec_n] = t; c.rec_cr[rec_n] = v;
+                rec_n++;
+                s.c += 1;
+            } break;
             default: status |= kBadKind; break;
             }
         }
@@ -412,6 +467,11 @@ struct hs_graph {
     std::vector<int32_t> sched_node; std::vector<int64_t> sched_t;
     int32_t *d_sched_node = nullptr; int64_t *d_sched_t = nullptr; long long d_sched_cap = 0;
     int32_t *d_rt_targets = nullptr;
+    // tick tables: one row per time-varying Source and per distinct Probe interval, computed up to `tick_horizon`
+    std::vector<hs::TickRow> rows;
+    std::vector<double> row_rate;              // ticks per second a row may reach (sizes the table)
+    hs::TickRow *d_rows = nullptr; int64_t *d_ticks = nullptr, *d_tick_count = nullptr; unsigned long long *d_tick_status = nullptr;
+    int64_t tick_horizon = INT64_MIN, tick_cap = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     double last_run_ms = 0.0;
@@ -458,7 +518,8 @@ void hs_graph_destroy(hs_graph *g) {
     (void)hipSetDevice(g->cfg.device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     void *bufs[] = {g->ctl.heap, g->ctl.reqs, g->ctl.rec_node, g->ctl.rec_t, g->ctl.rec_cr, (void *)g->ctl.P, g->ctl.S,
-                    g->d_rt_targets, g->ctl.rt_taken, g->d_sched_node, g->d_sched_t, g->ctl.V};
+                    g->d_rt_targets, g->ctl.rt_taken, g->d_sched_node, g->d_sched_t, g->ctl.V, g->d_rows, g->d_ticks, g->d_tick_count,
+                    g->d_tick_status};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (g->ev_a) (void)hipEventDestroy(g->ev_a);
     if (g->ev_b) (void)hipEventDestroy(g->ev_b);
@@ -480,17 +541,27 @@ int hs_graph_create(const hs_graph_config *cfg, const hs_graph_nodes *nd, hs_gra
     if (cfg->device < 0 || cfg->device >= dev_count) return gfail(nullptr, HS_E_INVALID, "device %d out of range", cfg->device);
     auto takes_requests = [&](int t) { const int k = nd->kind[t]; return k == HS_NODE_SERVER || k == HS_NODE_SINK || k == HS_NODE_LINK || k == HS_NODE_ROUTER; };
     std::vector<GParam> P((size_t)n);
+    std::vector<hs::TickRow> rows;
+    std::vector<double> row_rate;
     double rate_sum = 0.0;
     int n_src = 0;
+    bool seen_other = false, seen_probe = false;      // node order: Sources, then Probes (the pre-run sort indices), then the rest
     for (int i = 0; i < n; ++i) {
         GParam p{};
         p.kind = nd->kind[i];
         p.target = nd->target[i];
         p.stream_base = nd->stream_base ? nd->stream_base[i] : (uint64_t)i;
         p.conc = 1; p.lim = -1; p.rt_off = 0; p.rt_cnt = 0; p.mean = 0.0; p.lat_min = 0.0; p.loss = 0.0;
+        p.rt_off = -1;
         if (p.target < -1 || p.target >= n) return gfail(nullptr, HS_E_INVALID, "node %d: target %d out of range", i, p.target);
-        if (p.target >= 0 && !takes_requests(p.target))
-            return gfail(nullptr, HS_E_INVALID, "node %d: its target %d takes no Requests (a Source)", i, p.target);
+        if (p.kind != HS_NODE_PROBE && p.target >= 0 && !takes_requests(p.target))
+            return gfail(nullptr, HS_E_INVALID, "node %d: its target %d takes no Requests (a Source or a Probe)", i, p.target);
+        if (p.kind == HS_NODE_SOURCE && (seen_other || seen_probe))
+            return gfail(nullptr, HS_E_INVALID, "node %d: SOURCE nodes come first, in sources=[...] order", i);
+        if (p.kind == HS_NODE_PROBE && seen_other)
+            return gfail(nullptr, HS_E_INVALID, "node %d: PROBE nodes come behind the SOURCE nodes, in probes=[...] order", i);
+        if (p.kind == HS_NODE_PROBE) seen_probe = true;
+        else if (p.kind != HS_NODE_SOURCE) seen_other = true;
         switch (p.kind) {
         case HS_NODE_SOURCE: {
             if (!nd->src_rate) return gfail(nullptr, HS_E_INVALID, "src_rate is required");
@@ -502,6 +573,43 @@ int hs_graph_create(const hs_graph_config *cfg, const hs_graph_nodes *nd, hs_gra
             if (p.target < 0) return gfail(nullptr, HS_E_INVALID, "node %d: a Source needs a target", i);
             rate_sum += p.mean;
             ++n_src;
+            const int pk = nd->src_profile_kind ? nd->src_profile_kind[i] : 0;
+            if (pk != HS_PROF_CONSTANT) {
+                if (pk != HS_PROF_LINEAR_RAMP && pk != HS_PROF_SPIKE) return gfail(nullptr, HS_E_UNSUPPORTED, "node %d: profile kind %d is not lowered", i, pk);
+                if (!nd->src_profile_params) return gfail(nullptr, HS_E_INVALID, "src_profile_params is required with src_profile_kind");
+                const double *q = nd->src_profile_params + 4 * (size_t)i;
+                for (int j = 0; j < 4; ++j) if (!std::isfinite(q[j]) || q[j] < 0.0) return gfail(nullptr, HS_E_INVALID, "node %d: bad profile parameter %g", i, q[j]);
+                hs::TickRow r{};
+                r.kind = (uint32_t)pk; r.poisson = p.sub == HS_SRC_POISSON ? 1u : 0u;
+                r.p0 = q[0]; r.p1 = q[1]; r.p2 = q[2]; r.p3 = q[3];
+                r.seed = cfg->seed; r.sid = hs::stream_id(p.stream_base, hs::kStreamArrival); r.owner = i;
+                p.rt_off = (int32_t)rows.size();
+                rows.push_back(r);
+                row_rate.push_back(p.mean);
+            }
+        } break;
+        case HS_NODE_PROBE: {
+            if (!nd->probe_metric || !nd->probe_interval_s) return gfail(nullptr, HS_E_INVALID, "probe_metric and probe_interval_s are required for probes");
+            p.sub = nd->probe_metric[i];
+            const double iv = nd->probe_interval_s[i];
+            if (!(iv > 0.0) || !std::isfinite(iv)) return gfail(nullptr, HS_E_INVALID, "node %d: Probe interval must be positive", i);   // probe.py:29-30
+            if (p.target < 0) return gfail(nullptr, HS_E_INVALID, "node %d: a Probe needs a target", i);
+            const int tk = nd->kind[p.target];
+            const bool ok = p.sub == HS_PROBE_GENERATED ? tk == HS_NODE_SOURCE : p.sub == HS_PROBE_RECEIVED ? tk == HS_NODE_SINK
+                            : (p.sub <= HS_PROBE_COMPLETED && tk == HS_NODE_SERVER);
+            if (!ok) return gfail(nullptr, HS_E_UNSUPPORTED, "node %d: metric %d is not an attribute of its target (node kind %d)", i, (int)p.sub, tk);
+            const double rate = 1.0 / iv;                           // _ProbeProfile.rate (probe.py:31)
+            int found = -1;
+            for (size_t q = 0; q < rows.size() && found < 0; ++q)
+                if (rows[q].kind == hs::kProfGeneralConstant && rows[q].p0 == rate) found = (int)q;
+            if (found < 0) {
+                hs::TickRow r{};
+                r.kind = hs::kProfGeneralConstant; r.poisson = 0; r.p0 = rate; r.owner = i;
+                found = (int)rows.size();
+                rows.push_back(r);
+                row_rate.push_back(rate);
+            }
+            p.rt_off = found;
         } break;
         case HS_NODE_SERVER: {
             p.conc = nd->concurrency ? nd->concurrency[i] : 1;
@@ -540,7 +648,7 @@ int hs_graph_create(const hs_graph_config *cfg, const hs_graph_nodes *nd, hs_gra
         P[(size_t)i] = p;
     }
     hs_graph *g = new hs_graph();
-    g->cfg = *cfg; g->n = n; g->n_rt = nd->n_rt; g->params = P;
+    g->cfg = *cfg; g->n = n; g->n_rt = nd->n_rt; g->params = P; g->rows = rows; g->row_rate = row_rate;
 #define HSG_TRY(expr) do { int rc_ = (expr); if (rc_) { g_graph_error = g->error; hs_graph_destroy(g); return rc_; } } while (0)
 #define HSG_HIPD(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { gfail(g, HS_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); g_graph_error = g->error; hs_graph_destroy(g); return HS_E_HIP; } } while (0)
     HSG_HIPD(hipSetDevice(cfg->device));
@@ -574,6 +682,12 @@ int hs_graph_create(const hs_graph_config *cfg, const hs_graph_nodes *nd, hs_gra
     c.rt_targets = g->d_rt_targets;
     HSG_HIPD(hipMalloc(&c.rt_taken, nrt * sizeof(long long)));
     HSG_HIPD(hipMemset(c.rt_taken, 0, nrt * sizeof(long long)));
+    if (!rows.empty()) {
+        HSG_HIPD(hipMalloc(&g->d_rows, rows.size() * sizeof(hs::TickRow)));
+        HSG_HIPD(hipMemcpy(g->d_rows, rows.data(), rows.size() * sizeof(hs::TickRow), hipMemcpyHostToDevice));
+        HSG_HIPD(hipMalloc(&g->d_tick_count, rows.size() * sizeof(int64_t)));
+        HSG_HIPD(hipMalloc(&g->d_tick_status, 2 * sizeof(unsigned long long)));
+    }
     HSG_HIPD(hipMalloc(&c.V, sizeof(GVars)));
     {
         GVars v{};
@@ -597,10 +711,62 @@ int hs_graph_schedule(hs_graph *g, int32_t node, int64_t time_ns) {
     return HS_OK;
 }
 
+}  // extern "C"
+
+// Tick tables up to `horizon` (two ticks beyond it, hs_tables.hip); the same prefix whatever the horizon, so a later, longer table
+// continues the run that used the shorter one.
+static int build_tables(hs_graph *g, int64_t horizon) {
+    if (g->rows.empty() || horizon <= g->tick_horizon) return HS_OK;
+    const double span_s = (double)(horizon - g->cfg.start_ns) / 1e9;
+    int64_t cap = g->tick_cap > 0 ? g->tick_cap : 0;
+    for (double r : g->row_rate) {
+        const double mean = r * (span_s > 0 ? span_s : 0.0);
+        const double want = mean + 10.0 * std::sqrt(mean + 1.0) + 72.0;
+        if (want > 4e9) return gfail(g, HS_E_INVALID, "a tick table up to %lld ns would need %.3g ticks", (long long)horizon, want);
+        if ((int64_t)want > cap) cap = (int64_t)want;
+    }
+    const long long budget = g->cfg.profile_budget > 0 ? g->cfg.profile_budget : hs::kDefaultLaneBudget;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        if ((double)g->rows.size() * (double)cap * 8.0 > 64e9) return gfail(g, HS_E_INVALID, "tick tables would need %.1f GB", (double)g->rows.size() * (double)cap * 8.0 / 1e9);
+        if (cap != g->tick_cap || !g->d_ticks) {
+            if (g->d_ticks) HSG_HIP(g, hipFree(g->d_ticks));
+            g->d_ticks = nullptr;
+            HSG_HIP(g, hipMalloc(&g->d_ticks, g->rows.size() * (size_t)cap * sizeof(int64_t)));
+            g->tick_cap = cap;
+        }
+        HSG_HIP(g, hs::tick_tables_launch(g->stream, g->d_rows, (int)g->rows.size(), g->cfg.start_ns, horizon, cap, g->d_ticks, g->d_tick_count,
+                                          g->d_tick_status, budget, false));
+        HSG_HIP(g, hipStreamSynchronize(g->stream));
+        unsigned long long st[2] = {0ull, 0ull};
+        HSG_HIP(g, hipMemcpy(st, g->d_tick_status, sizeof st, hipMemcpyDeviceToHost));
+        if (st[0] != 0ull)
+            return gfail(g, HS_E_UNSUPPORTED, "node %lld: one tick of its time-varying Source / Probe needs more than 64 x %lld adaptive-Simpson "
+                         "intervals (hs_graph_config.profile_budget raises the limit) -- refused instead of stalling the device",
+                         (long long)st[0] - 2, budget);
+        if (st[1] == 0ull) {
+            g->tick_horizon = horizon;
+            g->ctl.ticks = g->d_ticks; g->ctl.tick_cap = cap; g->ctl.tick_count = g->d_tick_count;
+            return HS_OK;
+        }
+        cap *= 2;                                           // (a Poisson stream that ran ahead of its mean: a longer table)
+    }
+    return gfail(g, HS_E_OVERFLOW, "a tick table overflowed after eight doublings");
+}
+
+extern "C" {
+
 int hs_graph_run_until(hs_graph *g, int64_t end_ns) {
     if (!g) return gfail(g, HS_E_INVALID, "null handle");
     HSG_HIP(g, hipSetDevice(g->cfg.device));
     GCtl &c = g->ctl;
+    // table-driven streams: up to this end when it is a real horizon, else (an auto-terminating run) a minute at a time
+    int64_t table_h = end_ns;
+    if (!g->rows.empty()) {
+        const int64_t minute = 60ll * 1000000000ll;
+        if (end_ns - g->cfg.start_ns > 64 * minute) table_h = std::max<int64_t>(g->tick_horizon, g->cfg.start_ns + minute);
+        const int rc = build_tables(g, table_h);
+        if (rc) return rc;
+    }
     const long long ns = (long long)g->sched_node.size();
     if (ns > g->d_sched_cap) {
         if (g->d_sched_node) HSG_HIP(g, hipFree(g->d_sched_node));
@@ -639,6 +805,15 @@ int hs_graph_run_until(hs_graph *g, int64_t end_ns) {
             const int nc = c.req_cap * 2;
             int rc = grow(g, &c.reqs, c.req_cap, nc); if (rc) return rc;
             c.req_cap = nc;
+        }
+        if (v.status & kGrowTicks) {
+            // a table-driven stream reached the end of its table: twice the span (never beyond the end the caller asked for + the two
+            // ticks every table holds beyond its horizon)
+            const int64_t span = g->tick_horizon - g->cfg.start_ns;
+            int64_t nh = g->cfg.start_ns + (span > 0 ? 2 * span : 1000000000ll);
+            if (nh <= g->tick_horizon) return gfail(g, HS_E_OVERFLOW, "the tick tables cannot grow any further");
+            const int rc = build_tables(g, nh);
+            if (rc) return rc;
         }
         if (v.status & kGrowRec) {
             const long long nc = c.rec_cap * 2;

@@ -21,8 +21,8 @@ import ctypes as C
 import numpy as np
 
 from . import _native as N
-from .entities import (ConstantLatency, ConstantRateProfile, Counter, Entity, ExponentialLatency, LatencyTracker, LoadBalancer,
-                       NetworkLink, RandomRouter, Server, SimpleEventProvider, Sink, Source)
+from .entities import (ConstantLatency, ConstantRateProfile, Counter, Entity, ExponentialLatency, LatencyTracker, LinearRampProfile,
+                       LoadBalancer, NetworkLink, Probe, RandomRouter, Server, SimpleEventProvider, Sink, Source)
 
 _SINKS = (Sink, Counter, LatencyTracker)
 DEFAULT_MAX_EVENTS = 200_000_000          # ~ minutes on the one lane; Simulation(max_graph_events=) raises it
@@ -52,6 +52,10 @@ class GraphArrays:
         self.rt_off = np.zeros(n, np.int32)
         self.rt_cnt = np.zeros(n, np.int32)
         self.rt_targets = np.zeros(0, np.int32)
+        self.src_profile_kind = None         # [n] uint8 / [n, 4] float64: Sources with a time-varying profile
+        self.src_profile_params = None
+        self.probe_metric = None             # [n] uint8 / [n] float64: PROBE nodes
+        self.probe_interval_s = None
 
     def struct(self) -> N.GraphNodes:
         s = N.GraphNodes()
@@ -62,6 +66,8 @@ class GraphArrays:
         self.rt_targets = np.ascontiguousarray(self.rt_targets, np.int32)
         s.rt_targets = _ptr(self.rt_targets) if len(self.rt_targets) else None
         s.n_rt = len(self.rt_targets)
+        for name in ("src_profile_kind", "src_profile_params", "probe_metric", "probe_interval_s"):
+            setattr(s, name, _ptr(getattr(self, name)))
         return s
 
 
@@ -69,12 +75,12 @@ class GraphEngine:
     """ctypes handle of one hs_graph.  No CPU fallback: without the library or a GPU the constructor raises."""
 
     def __init__(self, arrays: GraphArrays, *, seed: int = 42, start_ns: int = 0, device: int = 0, max_events: int = 0,
-                 heap_capacity: int = 0, request_capacity: int = 0, record_capacity: int = 0):
+                 heap_capacity: int = 0, request_capacity: int = 0, record_capacity: int = 0, profile_budget: int = 0):
         self._lib = N.lib()
         self.arrays = arrays
         cfg = N.GraphConfig(struct_size=C.sizeof(N.GraphConfig), device=device, start_ns=start_ns, seed=seed,
                             heap_capacity=heap_capacity, request_capacity=request_capacity, record_capacity=record_capacity,
-                            max_events=max_events)
+                            max_events=max_events, profile_budget=profile_budget)
         h = C.c_void_p()
         nodes = arrays.struct()
         rc = self._lib.hs_graph_create(C.byref(cfg), C.byref(nodes), C.byref(h))
@@ -151,8 +157,6 @@ def lower_general(sources: list, entities: list, probes=None) -> GeneralGraph:
     does not run either (lowering.UnsupportedTopology)."""
     from .lowering import UnsupportedTopology
 
-    if probes:
-        raise UnsupportedTopology("probes on a graph outside the station shape are not lowered (the single-heap path samples nothing yet)")
     nodes: list = []
     node_of: dict[int, int] = {}
 
@@ -169,6 +173,13 @@ def lower_general(sources: list, entities: list, probes=None) -> GeneralGraph:
             raise UnsupportedTopology(f"source '{src.name}' is listed twice")
         add(src)
     n_src = len(nodes)
+    for pr in probes or []:                                   # PROBE nodes behind the Sources, in `probes=[...]` order
+        if not isinstance(pr, Probe):
+            raise UnsupportedTopology(f"probe {type(pr).__name__} is not a lowered Probe")
+        if id(pr) in node_of:
+            raise UnsupportedTopology(f"probe '{pr.name}' is listed twice")
+        add(pr)
+    n_front = len(nodes)
     lowered = (Server, NetworkLink, RandomRouter) + _SINKS
 
     def check(ent, where):
@@ -193,10 +204,16 @@ def lower_general(sources: list, entities: list, probes=None) -> GeneralGraph:
     while k < len(nodes):
         ent = nodes[k]
         k += 1
+        if isinstance(ent, Probe):
+            continue
         for d in ent.downstream_entities():
             if d is None:
                 continue
             check(d, f"'{ent.name}' forwards to it")
+            if isinstance(d, Server) and id(d) not in node_of:
+                # (the reference hands a clock to what `entities` lists: an unlisted Server would fail on its first event)
+                raise UnsupportedTopology(f"'{ent.name}' forwards to server '{d.name}', which is not listed in `entities` of this "
+                                          "Simulation (not part of this Simulation)")
             add(d)
     n = len(nodes)
     a = GraphArrays(n)
@@ -207,8 +224,6 @@ def lower_general(sources: list, entities: list, probes=None) -> GeneralGraph:
             ep, prov = ent._event_provider, ent._time_provider
             if not isinstance(ep, SimpleEventProvider):
                 raise UnsupportedTopology(f"source '{ent.name}': event provider {type(ep).__name__} is not lowered on a general graph")
-            if not isinstance(prov.profile, ConstantRateProfile):
-                raise UnsupportedTopology(f"source '{ent.name}': a time-varying profile on a graph outside the station shape is not lowered")
             if not (ent.rate > 0):
                 raise UnsupportedTopology(f"source '{ent.name}': rate must be > 0")
             if not isinstance(ep._target, Entity) or id(ep._target) not in node_of:
@@ -219,6 +234,34 @@ def lower_general(sources: list, entities: list, probes=None) -> GeneralGraph:
             a.src_kind[i] = N.SRC_POISSON if prov.kind == "poisson" else N.SRC_CONSTANT
             a.src_rate[i] = float(prov.profile.peak_rate)
             a.src_stop_after_ns[i] = -1 if ep._stop_after is None else ep._stop_after.nanoseconds
+            pr = prov.profile
+            if not isinstance(pr, ConstantRateProfile):        # its ticks come from the tick-table kernel, like the station engines'
+                if a.src_profile_kind is None:
+                    a.src_profile_kind = np.zeros(n, np.uint8)
+                    a.src_profile_params = np.zeros((n, 4), np.float64)
+                if isinstance(pr, LinearRampProfile):
+                    a.src_profile_kind[i] = N.PROF_LINEAR_RAMP
+                    a.src_profile_params[i, :3] = (pr.duration_s, pr.start_rate, pr.end_rate)
+                else:
+                    a.src_profile_kind[i] = N.PROF_SPIKE
+                    a.src_profile_params[i] = (pr.baseline_rate, pr.spike_rate, pr.warmup_s, pr.spike_duration_s)
+        elif isinstance(ent, Probe):
+            m = Probe.engine_metric(ent.metric)
+            if m not in N.PROBE_METRICS:
+                raise UnsupportedTopology(f"probe '{ent.name}': metric '{ent.metric}' is not sampled on the engine")
+            tgt = ent.target
+            if id(tgt) not in node_of:
+                raise UnsupportedTopology(f"probe '{ent.name}': its target is not an entity of this Simulation")
+            want = Source if m == "generated_count" else _SINKS if m == "events_received" else Server
+            if not isinstance(tgt, want):
+                raise UnsupportedTopology(f"probe '{ent.name}': metric '{ent.metric}' is not an attribute of {type(tgt).__name__}")
+            if a.probe_metric is None:
+                a.probe_metric = np.full(n, N.PROBE_NONE, np.uint8)
+                a.probe_interval_s = np.ones(n, np.float64)
+            a.kind[i] = N.NODE_PROBE
+            a.target[i] = node_of[id(tgt)]
+            a.probe_metric[i] = N.PROBE_METRICS[m]
+            a.probe_interval_s[i] = ent.interval
         elif isinstance(ent, Server):
             svc = ent.service_time
             if not isinstance(svc, (ExponentialLatency, ConstantLatency)):
@@ -259,7 +302,7 @@ def lower_general(sources: list, entities: list, probes=None) -> GeneralGraph:
         else:
             a.kind[i] = N.NODE_SINK
     a.rt_targets = np.array(rt, np.int32)
-    assert all(a.kind[i] == N.NODE_SOURCE for i in range(n_src))
+    assert all(a.kind[i] == N.NODE_SOURCE for i in range(n_src)) and all(a.kind[i] == N.NODE_PROBE for i in range(n_src, n_front))
     return GeneralGraph(nodes, a, node_of)
 
 
@@ -285,6 +328,9 @@ def write_back_general(g: GeneralGraph, stats: dict, rec_node: np.ndarray, rec_t
             ent.packets_sent = int(stats["packets_sent"][i])
             ent.packets_dropped = int(stats["packets_dropped"][i])
             ent._entered = int(stats["entered"][i])
+        elif isinstance(ent, Probe):
+            sel = order[bounds[i]:bounds[i + 1]]                 # its samples: (time, sampled integer)
+            ent.data_sink._set(rec_t[sel].copy(), rec_cr[sel].copy(), Probe.value_map(ent.metric, ent.target))
         elif isinstance(ent, RandomRouter):
             ent.stats_routed = int(stats["routed"][i])
             tc: dict[str, int] = {}

@@ -146,7 +146,15 @@ class Simulation:
                 elif plain is not None and not self._scheduled:
                     self._plain_probes_pending = True     # (_run puts them into the arrays without a Station per chain)
                 else:
-                    attach_probes(self._graph, self._probes)
+                    try:
+                        attach_probes(self._graph, self._probes)
+                    except UnsupportedTopology as station_shape:
+                        # (more than four probes on a station, a further Source of a Server sampled ...: the single heap samples anything)
+                        try:
+                            self._graph = lower_general(self._sources, self._entities, self._probes)
+                        except UnsupportedTopology:
+                            raise station_shape from None
+                        self._station_refusal = str(station_shape)
         return self._graph
 
     def _run_lb(self, g: LbGraph, wall0: float) -> SimulationSummary:
@@ -192,7 +200,11 @@ class Simulation:
                 raise UnsupportedTopology("end_time = Infinity with Sources never terminates (their ticks are primary events, in "
                                           "the reference too); pass end_time/duration")
             if self._probes:
-                raise UnsupportedTopology("auto-terminating runs with probes are not lowered; pass end_time/duration")
+                # a Probe IS a Source (instrumentation/probe.py:81): its ticks are SourceEvents built with daemon=False
+                # (load/source.py:136,171; load/source_event.py:27) -- only the probe_event samples are daemons -- so they keep
+                # the primary count above zero for ever, exactly like a Source's
+                raise UnsupportedTopology("end_time = Infinity with Probes never terminates either (a Probe's ticks are primary events: "
+                                          "only its probe_event samples are daemons, load/source_event.py:27); pass end_time/duration")
         wall0 = _time.monotonic()
         import gc
 
@@ -206,14 +218,34 @@ class Simulation:
 
     def _run(self, auto: bool, wall0: float) -> SimulationSummary:
         g = self.lowered()
-        if isinstance(g, GeneralGraph):
+        if not isinstance(g, GeneralGraph):
+            try:
+                return self._run_station(g, auto, wall0)
+            except UnsupportedTopology as station_shape:
+                # refused on the way (a probe the station slots do not hold, a tick on the nanosecond of a shared Sink's record ...):
+                # the single-heap loop takes it if the graph is its kind; otherwise the station engines' refusal stands
+                if isinstance(g, LbGraph):
+                    raise
+                try:
+                    g = lower_general(self._sources, self._entities, self._probes)
+                except UnsupportedTopology:
+                    raise station_shape from None
+                self._station_refusal = str(station_shape)
+                self._graph = g
+        try:
             return self._run_general(g, auto, wall0)
+        except UnsupportedTopology as general:
+            raise UnsupportedTopology(f"{self._station_refusal}; and not on the single-heap path either: {general}") from None
+
+    def _run_station(self, g, auto: bool, wall0: float) -> SimulationSummary:
         if isinstance(g, LbGraph):
             if self._scheduled:
                 raise UnsupportedTopology("schedule() is not lowered for load-balancer topologies yet")
             return self._run_lb(g, wall0)
         if auto and g.is_network:
-            raise UnsupportedTopology("auto-terminating runs of station networks are not lowered; pass end_time/duration")
+            # the network engines run to a horizon; the single-heap loop ends with its heap, as the reference's does
+            # (core/simulation.py:304-322: no Sources here, so every pending event is primary and the run drains)
+            raise UnsupportedTopology("auto-terminating runs of station networks are not lowered on the network engines")
         # auto-termination: a horizon nothing reaches (the station kernel stops when no event is pending)
         end_ns = self._end_time.nanoseconds if not auto else (1 << 61)
         net = g.network_arrays(self._bag_capacity or 0) if g.is_network else None
@@ -276,7 +308,7 @@ class Simulation:
         est = 12.0 * float(a.src_rate[a.kind == N.NODE_SOURCE].sum()) * horizon_s
         if self._max_graph_events > 0 and est > 4.0 * self._max_graph_events:
             raise UnsupportedTopology(
-                f"{self._station_refusal}; the single-heap path (one lane, ~1 us per event) would need ~{est:.2g} events for this run "
+                f"the single-heap path (one lane, ~1 us per event) would need ~{est:.2g} events for this run "
                 f"(limit {self._max_graph_events}: Simulation(max_graph_events=...))")
         cancelled_ns: list[int] = []
         sched: list[tuple[int, int]] = []

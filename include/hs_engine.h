@@ -674,7 +674,7 @@ int hs_debug_const_div(int32_t device, double b, int64_t n, const double *a, dou
  * ------------------------------------------------------------------------------------------------------------------ */
 typedef struct hs_graph hs_graph;
 
-typedef enum hs_node_kind { HS_NODE_SOURCE = 0, HS_NODE_SERVER = 1, HS_NODE_SINK = 2, HS_NODE_LINK = 3, HS_NODE_ROUTER = 4 } hs_node_kind;
+typedef enum hs_node_kind { HS_NODE_SOURCE = 0, HS_NODE_SERVER = 1, HS_NODE_SINK = 2, HS_NODE_LINK = 3, HS_NODE_ROUTER = 4, HS_NODE_PROBE = 5 } hs_node_kind;
 
 typedef struct hs_graph_config {
     uint32_t struct_size;            /* sizeof(hs_graph_config) */
@@ -685,6 +685,8 @@ typedef struct hs_graph_config {
     int64_t request_capacity;        /* Requests alive (queued, in service, in transit); 0 = sized from the graph */
     int64_t record_capacity;         /* Sink records of the whole run; 0 = 65 536 */
     int64_t max_events;              /* a run that would process more is refused (HS_E_UNSUPPORTED); 0 = no limit */
+    int64_t profile_budget;          /* adaptive-Simpson intervals one lane may visit for one tick of a time-varying Source or a
+                                      * Probe (hs_engine_set_profile_budget); 0 = the default 2^24 */
 } hs_graph_config;
 
 /* Nodes in the caller's order.  SOURCE nodes must come in `sources=[...]` order (their first SourceEvents take the pre-run
@@ -708,6 +710,18 @@ typedef struct hs_graph_nodes {
     const int32_t *rt_cnt;           /* [n] */
     const int32_t *rt_targets;       /* [n_rt] node ids (Sink / link / Server / router) */
     int32_t n_rt;
+    /* Sources with a time-varying profile (load/profile.py:52-113; Source.with_profile): hs_profile_kind and its four parameters as
+     * in hs_stations.src_profile_*; src_rate is then the peak rate.  Their ticks -- next_arrival_time's general path,
+     * load/arrival_time_provider.py:84-144 -- come from the tick-table kernel (csrc/hs_tables.hpp), like the station engines'.  NULL = none. */
+    const uint8_t *src_profile_kind; /* [n] */
+    const double *src_profile_params;/* [n][4] */
+    /* HS_NODE_PROBE: Probe(target, metric, interval) (instrumentation/probe.py:81-164) -- a Source whose provider is a constant
+     * tick chain over _ProbeProfile(interval) (the general path too) and whose payload is the daemon probe_event that samples
+     * getattr(target, metric).  `target` = the sampled node; PROBE nodes come behind the SOURCE nodes in `probes=[...]` order (their
+     * first ticks take the pre-run indices behind the Sources', core/simulation.py:156-160).  Samples: hs_graph_read_records
+     * (node = the probe, t = sample time, created = the value). */
+    const uint8_t *probe_metric;     /* [n] hs_probe_metric */
+    const double *probe_interval_s;  /* [n] > 0 */
 } hs_graph_nodes;
 
 typedef struct hs_graph_stats {      /* host arrays [n_nodes] (rt_taken: [n_rt]); any pointer may be NULL */

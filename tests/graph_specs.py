@@ -37,8 +37,8 @@ def build(spec, extra_schedule=None):
     for k, sc in enumerate(spec["sources"]):
         make = hs.Source.poisson if sc["kind"] == "poisson" else hs.Source.constant
         sources.append(make(rate=sc["rate"], target=servers[sc["to"]], name=f"src{k}"))
-    sim = hs.Simulation(end_time=hs.Instant.from_seconds(spec["end_s"]), sources=sources, entities=servers + routers + links + sinks,
-                        seed=spec["seed"])
+    end = None if spec.get("end_s") is None else hs.Instant.from_seconds(spec["end_s"])      # None: auto-termination
+    sim = hs.Simulation(end_time=end, sources=sources, entities=servers + routers + links + sinks, seed=spec["seed"])
     for kind, idx, t_s in (extra_schedule or []):
         sim.schedule(hs.Event(time=hs.Instant.from_seconds(t_s), event_type="Request", target=pools[kind][idx]))
     return sim, dict(sources=sources, servers=servers, links=links, routers=routers, sinks=sinks)

@@ -41,7 +41,7 @@ def test_abi_version_and_struct_sizes(lib):
     assert C.sizeof(N.LbConfig) == 64 and C.sizeof(N.LbSources) == 56 and C.sizeof(N.LbBackends) == 64
     assert C.sizeof(N.LbStats) == 88
     assert C.sizeof(N.Network) == 160 and C.sizeof(N.NetStats) == 4 * 8
-    assert C.sizeof(N.GraphConfig) == 56 and C.sizeof(N.GraphNodes) == 136 and C.sizeof(N.GraphStats) == 120
+    assert C.sizeof(N.GraphConfig) == 64 and C.sizeof(N.GraphNodes) == 168 and C.sizeof(N.GraphStats) == 120
 
 
 def test_no_gpu_means_loud_failure(lib):

@@ -154,3 +154,91 @@ def test_a_run_beyond_max_graph_events_is_refused_by_name():
     with GraphEngine(g.arrays, seed=spec["seed"], max_events=500) as eng:
         with pytest.raises(N.EngineError, match="max_events"):
             eng.run_until(H.ns_from_seconds(spec["end_s"]))
+
+
+def test_an_auto_terminating_station_network_runs_on_the_single_heap():
+    """`Simulation(end_time=None)` over a ring of stations driven by schedule()d Requests only (core/simulation.py:304-322): the
+    network engines run to a horizon and refuse it; the single-heap loop drains its heap like the reference's -- every Request
+    circles until its router draws the Sink.  The graph itself is station-shaped (lower() takes it)."""
+    n = 5
+    spec = dict(n_sinks=n, end_s=None, seed=321,
+                servers=[dict(mean=0.02 * (1 + i % 3), c=1 + i % 2, cap=None if i % 2 else 6, out=["router", i]) for i in range(n)],
+                links=[dict(lat=0.001, jk="exp", jm=0.002, loss=0.05 if i == 2 else 0.0, to=(i + 1) % n) for i in range(n)],
+                routers=[dict(targets=[["sink", i], ["link", i]]) for i in range(n)], sources=[])
+    rng = np.random.default_rng(8)
+    sched = [("server", int(rng.integers(0, n)), float(np.round(rng.uniform(0.0, 2.0), 3))) for _ in range(200)]
+    sim, ents = GS.build(spec, extra_schedule=sched)
+    from happy_simulator_amd.lowering import LoweredGraph
+    assert isinstance(sim.lowered(), LoweredGraph) and sim.lowered().is_network
+    g_o, nodes = H.oracle_graph(spec)
+    r = O.run(g_o, 1 << 61, seed=spec["seed"], schedule=[(nodes[k][i], H.ns_from_seconds(t)) for k, i, t in sched])
+    summary = sim.run()
+    assert summary.total_events_processed == r.events_processed > 2000
+    _compare_with_oracle(spec, sim, ents, r, nodes)
+    assert all(s.depth == 0 and s.active_requests == 0 for s in ents["servers"])          # everything drained
+    assert sum(k.events_received for k in ents["sinks"]) + sum(l.packets_dropped for l in ents["links"]) + sum(
+        s.stats_dropped for s in ents["servers"]) == len(sched)
+
+
+def _with_probes_and_profiles(k):
+    """graph_spec(k) + Probes on its Servers / Sinks / Sources (several per target, shared and distinct intervals) and, on odd k,
+    time-varying profiles on some Sources.  Returns (sim, ents, probes, oracle graph, oracle nodes, oracle probe nodes)."""
+    spec = graph_spec(k)
+    rng = np.random.default_rng(88_000 + k)
+    profiles = {}
+    if k % 2:
+        for j in range(len(spec["sources"])):
+            if rng.random() < 0.5:
+                profiles[j] = (("ramp", float(rng.choice([1.0, 2.5])), float(rng.choice([0.0, 2.0])), float(rng.choice([6.0, 12.0])))
+                               if rng.random() < 0.5 else
+                               ("spike", float(rng.choice([1.0, 3.0])), float(rng.choice([10.0, 25.0])), float(rng.choice([0.5, 1.25])),
+                                float(rng.choice([0.25, 0.5]))))
+    sim, ents = GS.build(spec)
+    for j, pf in profiles.items():                              # swap the Source for one with the profile (same name, target, kind)
+        old = ents["sources"][j]
+        prof = (hs.LinearRampProfile(duration_s=pf[1], start_rate=pf[2], end_rate=pf[3]) if pf[0] == "ramp" else
+                hs.SpikeProfile(baseline_rate=pf[1], spike_rate=pf[2], warmup_s=pf[3], spike_duration_s=pf[4]))
+        new = hs.Source.with_profile(prof, target=old._event_provider._target, poisson=spec["sources"][j]["kind"] == "poisson", name=old.name)
+        ents["sources"][j] = new
+    plan = []
+    for _ in range(int(rng.integers(1, 7))):
+        kind = str(rng.choice(["server", "server", "sink", "source"]))
+        idx = int(rng.integers(0, len(ents[kind + "s"])))
+        metric = (str(rng.choice(["depth", "active_requests", "stats_accepted", "stats_dropped", "requests_completed"])) if kind == "server"
+                  else "events_received" if kind == "sink" else "generated_count")
+        plan.append((kind, idx, metric, float(rng.choice([0.1, 0.25, 0.25, 0.5, 1.0]))))
+    probes = [hs.Probe.on(ents[kind + "s"][idx], metric, interval=iv) for kind, idx, metric, iv in plan]
+    sim = hs.Simulation(end_time=hs.Instant.from_seconds(spec["end_s"]), sources=ents["sources"],
+                        entities=ents["servers"] + ents["routers"] + ents["links"] + ents["sinks"], probes=[p for p, _ in probes],
+                        seed=spec["seed"])
+    g_o, nodes = H.oracle_graph(spec)
+    for j, pf in profiles.items():
+        nd = nodes["source"][j]
+        g_o.prof_kind[nd] = O.PROF_LINEAR_RAMP if pf[0] == "ramp" else O.PROF_SPIKE
+        g_o.prof_p[nd] = tuple(pf[1:]) + (0.0,) * (5 - len(pf))
+    codes = {"depth": 0, "active_requests": 1, "stats_accepted": 2, "stats_dropped": 3, "requests_completed": 4, "events_received": 5,
+             "generated_count": 6}
+    o_probes = [g_o.probe(nodes[kind][idx], codes[metric], iv) for kind, idx, metric, iv in plan]
+    return spec, sim, ents, probes, g_o, nodes, o_probes
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_probes_and_time_varying_sources_on_general_graphs_match_the_oracle(block):
+    """Probes (instrumentation/probe.py:81-164: a tick chain through next_arrival_time's general path + daemon samples) and
+    Source.with_profile ramps / spikes (load/profile.py:52-113) on graphs outside the station shape: tick tables from the
+    cooperative kernel, events and samples on the single heap -- every sample (time, value), statistic and Sink record."""
+    ran = 0
+    for k in range(block * 20, block * 20 + 20):
+        spec, sim, ents, probes, g_o, nodes, o_probes = _with_probes_and_profiles(k)
+        if not isinstance(sim.lowered(), GeneralGraph):
+            continue
+        r = O.run(g_o, H.ns_from_seconds(spec["end_s"]), seed=spec["seed"])
+        sim.run()
+        _compare_with_oracle(spec, sim, ents, r, nodes)
+        for (pr, data), nd in zip(probes, o_probes):
+            t, v = r.sinks[nd]
+            np.testing.assert_array_equal(data._t_ns, t, err_msg=pr.name)
+            np.testing.assert_array_equal(data._v, v, err_msg=pr.name)
+            assert len(t) > 0
+        ran += 1
+    assert ran >= 15

@@ -63,9 +63,11 @@ def test_entities_only_reachable_downstream_become_nodes_in_discovery_order():
     a = hs.Server("a", service_time=hs.ConstantLatency(0.01), downstream=link)
     c = hs.Server("c", service_time=hs.ConstantLatency(0.01), downstream=link)        # the link's second sender
     src = [hs.Source.constant(rate=3.0, target=a, name="s0"), hs.Source.constant(rate=2.0, target=c, name="s1")]
-    g = lower_general(src, [a, c])                 # link, b and the Sink are not listed
-    assert [getattr(x, "name") for x in g.nodes] == ["s0", "s1", "a", "c", "l", "b", "k"]
-    np.testing.assert_array_equal(g.arrays.stream_base, [0, 1, 0, 1, 0, 2, 0])
+    g = lower_general(src, [a, c, b])              # the link and the Sink are not listed
+    assert [getattr(x, "name") for x in g.nodes] == ["s0", "s1", "a", "c", "b", "l", "k"]
+    np.testing.assert_array_equal(g.arrays.stream_base, [0, 1, 0, 1, 2, 0, 0])
+    with pytest.raises(hs.UnsupportedTopology, match="not listed in `entities`"):     # (a Server needs the clock `entities` hands out)
+        lower_general(src, [a, c])
 
 
 @pytest.mark.parametrize("k", range(40))
@@ -78,18 +80,47 @@ def test_random_graph_specs_lower(k):
         assert all(0 <= t < a.n and a.kind[t] != N.NODE_SOURCE for t in a.rt_targets)
 
 
+def test_probes_and_profiles_on_a_general_graph_become_nodes_behind_the_sources():
+    sink = hs.Sink("k")
+    sv = hs.Server("s", concurrency=64, service_time=hs.ExponentialLatency(0.05), downstream=sink)      # c > 32: not a station
+    src = hs.Source.poisson(rate=5.0, target=sv, name="src")
+    ramp = hs.Source.with_profile(hs.LinearRampProfile(duration_s=2.0, start_rate=1.0, end_rate=9.0), target=sv, name="ramp")
+    spike = hs.Source.with_profile(hs.SpikeProfile(baseline_rate=2.0, spike_rate=20.0, warmup_s=0.5, spike_duration_s=0.25), target=sv,
+                                   poisson=False, name="spike")
+    p_depth, _ = hs.Probe.on(sv, "depth", interval=0.5)
+    p_util, _ = hs.Probe.on(sv, "utilization", interval=0.25)
+    p_recv, _ = hs.Probe.on(sink, "events_received", interval=0.5)
+    p_gen, _ = hs.Probe.on(ramp, "generated_count", interval=1.0)
+    g = hs.Simulation(duration=1.0, sources=[src, ramp, spike], entities=[sv, sink], probes=[p_depth, p_util, p_recv, p_gen]).lowered()
+    assert isinstance(g, GeneralGraph)
+    a = g.arrays
+    np.testing.assert_array_equal(a.kind, [N.NODE_SOURCE] * 3 + [N.NODE_PROBE] * 4 + [N.NODE_SERVER, N.NODE_SINK])
+    np.testing.assert_array_equal(a.target[3:7], [7, 7, 8, 1])
+    np.testing.assert_array_equal(a.probe_metric[3:7], [N.PROBE_METRICS["depth"], N.PROBE_METRICS["active_requests"],
+                                                        N.PROBE_METRICS["events_received"], N.PROBE_METRICS["generated_count"]])
+    np.testing.assert_array_equal(a.probe_interval_s[3:7], [0.5, 0.25, 0.5, 1.0])
+    np.testing.assert_array_equal(a.src_profile_kind[:3], [N.PROF_CONSTANT, N.PROF_LINEAR_RAMP, N.PROF_SPIKE])
+    np.testing.assert_array_equal(a.src_profile_params[1], [2.0, 1.0, 9.0, 0.0])
+    np.testing.assert_array_equal(a.src_profile_params[2], [2.0, 20.0, 0.5, 0.25])
+    np.testing.assert_array_equal(a.src_rate[:3], [5.0, 9.0, 20.0])                      # (a profile's peak)
+    np.testing.assert_array_equal(a.src_kind[:3], [N.SRC_POISSON, N.SRC_POISSON, N.SRC_CONSTANT])
+
+
 def test_what_the_single_heap_path_refuses_too():
     sink = hs.Sink("k")
     sv = hs.Server("s", concurrency=64, service_time=hs.ExponentialLatency(0.05), downstream=sink)      # c > 32: not a station
     src = hs.Source.poisson(rate=5.0, target=sv, name="src")
-    probe, _ = hs.Probe.on(sv, "depth", interval=0.5)
-    with pytest.raises(hs.UnsupportedTopology, match="probes on a graph outside the station shape"):
+    other = hs.Server("elsewhere", service_time=hs.ExponentialLatency(0.05))
+    probe, _ = hs.Probe.on(other, "depth", interval=0.5)
+    with pytest.raises(hs.UnsupportedTopology, match="not an entity of this Simulation"):
         hs.Simulation(duration=1.0, sources=[src], entities=[sv, sink], probes=[probe]).lowered()
-    ramp = hs.Source.with_profile(hs.LinearRampProfile(duration_s=2.0, start_rate=1.0, end_rate=9.0), target=sv, name="ramp")
-    with pytest.raises(hs.UnsupportedTopology, match="time-varying profile"):
-        hs.Simulation(duration=1.0, sources=[ramp], entities=[sv, sink]).lowered()
+    probe, _ = hs.Probe.on(sink, "events_received", interval=0.5)
+    with pytest.raises(hs.UnsupportedTopology, match="never terminates either"):         # (a Probe's ticks are primary events)
+        sim = hs.Simulation(sources=[], entities=[sv, sink], probes=[probe])
+        sim.schedule(hs.Event(time=hs.Instant.from_seconds(0.5), event_type="Request", target=sv))
+        sim.run()
     assert isinstance(hs.Simulation(duration=1.0, sources=[src], entities=[sv, sink]).lowered(), GeneralGraph)
-    with pytest.raises(hs.UnsupportedTopology, match="would need"):       # 65 536 such chains for a minute: refused before anything runs
+    with pytest.raises(hs.UnsupportedTopology, match="would need"):       # 64 such chains at 10^6 / s for a minute: refused before anything runs
         sinks = [hs.Sink(f"k{i}") for i in range(64)]
         svs = [hs.Server(f"s{i}", concurrency=64, service_time=hs.ExponentialLatency(0.05), downstream=sinks[i]) for i in range(64)]
         srcs = [hs.Source.poisson(rate=1e6, target=x, name=f"src{i}") for i, x in enumerate(svs)]
@@ -125,8 +156,8 @@ def test_write_back_puts_the_node_results_on_the_objects():
 
 
 def test_abi_structs_of_the_graph_entry_points():
-    assert C.sizeof(N.GraphConfig) == 56
-    assert C.sizeof(N.GraphNodes) == 8 + 15 * 8 + 8
+    assert C.sizeof(N.GraphConfig) == 64
+    assert C.sizeof(N.GraphNodes) == 8 + 15 * 8 + 8 + 4 * 8
     assert C.sizeof(N.GraphStats) == 15 * 8
     L = N.lib()
     for sym in ("hs_graph_create", "hs_graph_schedule", "hs_graph_run_until", "hs_graph_get_summary", "hs_graph_get_stats",

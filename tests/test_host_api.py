@@ -8,6 +8,7 @@ import pytest
 
 import happy_simulator_amd as hs
 from happy_simulator_amd import _native as N
+from happy_simulator_amd import lowering as L
 from happy_simulator_amd.core.temporal import Duration, Instant
 
 
@@ -352,8 +353,12 @@ def test_probes_are_lowered_onto_their_station():
     assert b.probe_metric_more[:, 0].tolist() == [N.PROBE_METRICS[m] for m in ("active_requests", "events_received", "generated_count")]
     assert b.probe_interval_more[:, 0].tolist() == [1.0, 0.25, 3.0]
     p5, _ = hs.Probe.on(srv, "stats_dropped")
+    # a fifth probe on the station: beyond the station engines' four slots -- the single-heap path takes it (round 6: refused until then)
+    from happy_simulator_amd.graph_engine import GeneralGraph
+    five = hs.Simulation(duration=1, sources=[src], entities=[srv, sink], probes=[p1] + more + [p5])
+    assert isinstance(five.lowered(), GeneralGraph) and "already has four probes" in five._station_refusal
     with pytest.raises(hs.UnsupportedTopology, match="already has four probes"):
-        hs.Simulation(duration=1, sources=[src], entities=[srv, sink], probes=[p1] + more + [p5]).lowered()
+        L.attach_probes(hs.Simulation(duration=1, sources=[src], entities=[srv, sink]).lowered(), [p1] + more + [p5])
     p4, _ = hs.Probe.on(sink, "depth")
     with pytest.raises(hs.UnsupportedTopology, match="not an attribute of Sink"):
         hs.Simulation(duration=1, sources=[src], entities=[srv, sink], probes=[p4]).lowered()
@@ -381,14 +386,19 @@ def test_several_sources_of_one_server_are_lowered_onto_its_station():
     assert arr.src_stop_after_ns.tolist() == [3_000_000_000, -1] and arr.src_more_stop_after_ns[:, 0].tolist() == [-1, -1, -1]
     assert g.log_capacity(5.0) >= 12 * 5                     # the station admits what all three Sources generate
     more = [hs.Source.poisson(rate=1, target=srv, name=f"x{k}") for k in range(2)]
+    # beyond the station's slots: lower() refuses by name, Simulation takes the graph to the single-heap path (round 6)
+    from happy_simulator_amd.graph_engine import GeneralGraph
     with pytest.raises(hs.UnsupportedTopology, match="more than four Sources"):
-        hs.Simulation(duration=1, sources=[a, b, c] + more, entities=[srv, sink]).lowered()
+        L.lower([a, b, c] + more, [srv, sink])
+    five = hs.Simulation(duration=1, sources=[a, b, c] + more, entities=[srv, sink])
+    assert isinstance(five.lowered(), GeneralGraph) and "more than four Sources" in five._station_refusal
     ramp = hs.Source.with_profile(hs.LinearRampProfile(duration_s=2.0, start_rate=1.0, end_rate=5.0), target=srv)
     with pytest.raises(hs.UnsupportedTopology, match="time-varying profile next to further Sources"):
-        hs.Simulation(duration=1, sources=[a, ramp], entities=[srv, sink]).lowered()
+        L.lower([a, ramp], [srv, sink])
+    assert isinstance(hs.Simulation(duration=1, sources=[a, ramp], entities=[srv, sink]).lowered(), GeneralGraph)
     pr, _ = hs.Probe.on(a, "generated_count")
-    with pytest.raises(hs.UnsupportedTopology, match="only the first Source of a Server is sampled"):
-        hs.Simulation(duration=1, sources=[b, a], entities=[srv, sink], probes=[pr]).lowered()
+    sampled = hs.Simulation(duration=1, sources=[b, a], entities=[srv, sink], probes=[pr])
+    assert isinstance(sampled.lowered(), GeneralGraph) and "only the first Source of a Server is sampled" in sampled._station_refusal
 
 
 def test_schedule_is_lowered_to_per_station_time_lists():
