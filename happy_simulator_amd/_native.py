@@ -31,14 +31,14 @@ PROF_CONSTANT, PROF_LINEAR_RAMP, PROF_SPIKE = 0, 1, 2
 LAT_EXPONENTIAL, LAT_CONSTANT, LAT_NO_SERVER = 0, 1, 2
 EGRESS_NONE, EGRESS_SINK, EGRESS_LINK, EGRESS_ROUTER, EGRESS_SERVER = 0, 1, 2, 3, 4
 LB_CONSISTENT_HASH, LB_ROUND_ROBIN, LB_RANDOM = 0, 1, 2
-NODE_SOURCE, NODE_SERVER, NODE_SINK, NODE_LINK, NODE_ROUTER, NODE_PROBE = 0, 1, 2, 3, 4, 5
+NODE_SOURCE, NODE_SERVER, NODE_SINK, NODE_LINK, NODE_ROUTER, NODE_PROBE, NODE_LB = 0, 1, 2, 3, 4, 5, 6
 EV_KINDS = 15
 EV_NAMES = ("source", "enqueue", "notify", "poll", "deliver", "work", "continuation", "sink", "link", "link_cont",
             "route", "lb", "lb_resp", "probe_tick", "probe")
 PROBE_METRICS = {"depth": 0, "active_requests": 1, "stats_accepted": 2, "stats_dropped": 3, "requests_completed": 4,
                  "_requests_completed": 4, "events_received": 5, "generated_count": 6}
 PROBE_NONE = 255
-ABI_VERSION = 15
+ABI_VERSION = 16
 IPC_HANDLE_BYTES = 64
 
 
@@ -130,11 +130,12 @@ class GraphNodes(C.Structure):
     _fields_ = [("n_nodes", C.c_int32)] + [(n, C.c_void_p) for n in (
         "kind", "target", "stream_base", "src_kind", "src_rate", "src_stop_after_ns", "concurrency", "lat_kind", "lat_mean_s",
         "link_lat_min_s", "link_loss_rate", "queue_cap", "rt_off", "rt_cnt", "rt_targets")] + [("n_rt", C.c_int32)] + [
-        (n, C.c_void_p) for n in ("src_profile_kind", "src_profile_params", "probe_metric", "probe_interval_s")]
+        (n, C.c_void_p) for n in ("src_profile_kind", "src_profile_params", "probe_metric", "probe_interval_s", "lb_strategy", "lb_vnodes",
+                                  "names", "name_off", "src_n_clients")]
 
 
 GRAPH_STATS = ("generated", "payloads", "accepted", "dropped", "completed", "rejected", "total_service_s", "queue_depth", "active",
-               "received", "entered", "packets_sent", "packets_dropped", "routed", "rt_taken")
+               "received", "entered", "packets_sent", "packets_dropped", "routed", "rt_taken", "lb")
 
 
 class GraphStats(C.Structure):

@@ -1,4 +1,4 @@
-// hs_graph.hip -- general entity graphs on ONE heap (include/hs_engine.h "General entity graphs", ABI 15).
+// hs_graph.hip -- general entity graphs on ONE heap (include/hs_engine.h "General entity graphs", ABI 15, LoadBalancer nodes ABI 16).
 //
 // The station engines (hs_station.hpp / hs_netstation.hpp) get their speed from a fixed LP shape; what the same entity classes
 // can be wired into beyond that shape -- links with several senders, routers with any fan-out that also target Servers and
@@ -29,6 +29,7 @@
 #include "../../include/hs_engine.h"
 #include "hs_device.hpp"
 #include "hs_tables_api.hpp"
+#include "hs_ring.hpp"
 
 namespace hs {
 namespace graph {
@@ -52,9 +53,10 @@ struct GParam {                                // 64 bytes, read-only
     double loss;                               // link: packet_loss_rate
     int64_t lim;                               // Source: stop_after ns (< 0 never); Server: queue capacity (< 0 unbounded)
     int32_t target;
-    int32_t conc;
-    int32_t rt_off, rt_cnt;                    // router: its targets; Source / Probe: rt_off = row of its tick table (-1: none)
-    uint8_t kind, sub;                         // sub: Source arrival kind (hs_source_kind); Server / link latency kind; Probe metric
+    int32_t conc;                              // Server: max_concurrent; Source: n_clients of its ClientKeyEventProvider (0: none);
+                                               // LoadBalancer: entries of its client -> backend-slot table (lim = its offset)
+    int32_t rt_off, rt_cnt;                    // router / LoadBalancer: its targets; Source / Probe: rt_off = row of its tick table (-1: none)
+    uint8_t kind, sub;                         // sub: Source arrival kind (hs_source_kind); Server / link latency kind; Probe metric; LB strategy
     uint8_t pad[6];
 };
 
@@ -64,6 +66,8 @@ struct GState {                                // 64 bytes
     // link:   a = entered, b = packets_sent, c = packets_dropped, d = jitter draws
     // router: a = stats_routed (= route draws);  Sink: a = events_received
     // Probe:  a = ticks taken from its table, c = samples
+    // LoadBalancer: a = requests_received, b = requests_forwarded, c = requests_failed (= no_backend_available), d = in flight,
+    //               svc_draws = RoundRobin._index;  Source: svc_draws = KEY draws
     int64_t a, b, c, d;
     double total_service;                      // Server._total_service_time
     uint64_t svc_draws;
@@ -75,8 +79,9 @@ struct GRequest {                              // 32 bytes: the payload Event's 
     int64_t created;                           // context["created_at"] (load/source.py:76-79; forwarded unchanged, core/entity.py:100-105)
     uint64_t idx;                              // sort index of the queued payload Event (kept on retarget, queue_driver.py:86-90)
     double service_s;                          // service_time_s of the generator frame (server/server.py:246-247)
+    int64_t client;                            // context["metadata"]["client_id"] (-1: none)
     int32_t next;                              // FIFO / free list
-    int32_t pad;
+    int32_t hook;                              // LoadBalancer whose `_lb_response` hook rides on the Event (-1: none)
 };
 
 enum : int { kRunning = 0, kDone = 1, kGrowHeap = 2, kGrowReq = 4, kGrowRec = 8, kBadKind = 16, kGrowTicks = 32 };
@@ -107,6 +112,7 @@ struct GCtl {                                  // kernel argument
     // tick tables (hs_tables.hpp) of the time-varying Sources and the Probes: tick k of row r at ticks[r * tick_cap + k]; a row
     // holds tick_count[r] ticks -- up to two beyond the horizon it was computed for, or up to the stream's end (kInfNs)
     const int64_t *ticks; long long tick_cap; const int64_t *tick_count;
+    const int32_t *key_table;                  // ConsistentHash.select(str(client id)) as a backend slot, per LoadBalancer (GParam::lim)
     GVars *V;
     uint64_t seed;
     int64_t start_ns, end_ns;
@@ -178,6 +184,7 @@ __device__ __forceinline__ uint32_t arrival_kind(const GParam *P, int node) {
         case HS_NODE_SINK: return HS_EV_SINK;
         case HS_NODE_LINK: return HS_EV_LINK;
         case HS_NODE_ROUTER: return HS_EV_ROUTE;
+        case HS_NODE_LB: return HS_EV_LB;
         default: return 0xffffffffu;
     }
 }
@@ -251,7 +258,7 @@ __global__ void __launch_bounds__(64) hs_graph_run(GCtl c) {
             else { status |= kGrowReq; break; }
             const int node = c.sched_node[V.sched_done];
             const int64_t t = c.sched_t[V.sched_done];
-            GRequest q; q.created = t; q.idx = V.global_counter; q.service_s = 0.0; q.next = -1; q.pad = 0;
+            GRequest q; q.created = t; q.idx = V.global_counter; q.service_s = 0.0; q.client = -1; q.next = -1; q.hook = -1;
             c.reqs[r] = q;
             H.push(mk(t, V.global_counter++, arrival_kind(c.P, node), node, r));
             V.sched_done++;
@@ -302,7 +309,12 @@ __global__ void __launch_bounds__(64) hs_graph_run(GCtl c) {
                     r = V.req_free;
                     if (r >= 0) V.req_free = c.reqs[r].next; else r = V.req_len++;
                     idx_p = G++;
-                    GRequest q; q.created = t; q.idx = idx_p; q.service_s = 0.0; q.next = -1; q.pad = 0;
+                    GRequest q; q.created = t; q.idx = idx_p; q.service_s = 0.0; q.client = -1; q.next = -1; q.hook = -1;
+                    if (p.conc > 0) {                                               // chash_example.py:83: one client id per Request
+                        const double u = uniform_at(c.seed, stream_id(p.stream_base, kStreamKey), s.svc_draws);
+                        s.svc_draws += 1;
+                        q.client = (int64_t)__dmul_rn(u, (double)p.conc);
+                    }
                     c.reqs[r] = q;
                     s.d += 1;
                 }
@@ -313,19 +325,24 @@ __global__ void __launch_bounds__(64) hs_graph_run(GCtl c) {
             } break;
             case HS_EV_ENQUEUE: {
                 // QueuedResource.handle_event -> Queue._handle_enqueue (components/queue.py:122-147)
+                const int hook = c.reqs[e.req].hook;                               // Event.on_complete of THIS Event: one-shot (core/event.py:290-311)
+                c.reqs[e.req].hook = -1;
                 if (p.lim >= 0 && s.qlen >= p.lim) {                               // FIFOQueue.push refuses (queue_policy.py:94-98)
                     s.b += 1;
                     c.reqs[e.req].next = V.req_free; V.req_free = e.req;
-                    break;
+                } else {
+                    c.reqs[e.req].idx = e.idx;              // the queued payload IS this Event object
+                    c.reqs[e.req].next = -1;
+                    if (s.qtail >= 0) c.reqs[s.qtail].next = e.req; else s.qhead = e.req;
+                    s.qtail = e.req;
+                    s.a += 1;
+                    const bool was_empty = s.qlen == 0;
+                    s.qlen += 1;
+                    if (was_empty) H.push(mk(t, G++, HS_EV_NOTIFY, n, -1));        // queue.py:144-146
                 }
-                c.reqs[e.req].idx = e.idx;                  // the queued payload IS this Event object
-                c.reqs[e.req].next = -1;
-                if (s.qtail >= 0) c.reqs[s.qtail].next = e.req; else s.qhead = e.req;
-                s.qtail = e.req;
-                s.a += 1;
-                const bool was_empty = s.qlen == 0;
-                s.qlen += 1;
-                if (was_empty) H.push(mk(t, G++, HS_EV_NOTIFY, n, -1));            // queue.py:144-146
+                // Event.invoke (core/event.py:277-283): the handler returned a plain list, so the completion hooks run now, behind
+                // the handler's own events: the LoadBalancer's `_lb_response`
+                if (hook >= 0) H.push(mk(t, G++, HS_EV_LB_RESP, hook, -1));
             } break;
             case HS_EV_NOTIFY:                                                      // QueueDriver._handle_notify (queue_driver.py:92-99)
                 if (s.active < p.conc) H.push(mk(t, G++, HS_EV_POLL, n, -1));
@@ -410,6 +427,33 @@ __global__ void __launch_bounds__(64) hs_graph_run(GCtl c) {
                 if (p.target >= 0) H.push(mk(t, G++, arrival_kind(c.P, p.target), p.target, e.req));
                 else { c.reqs[e.req].next = V.req_free; V.req_free = e.req; }
                 break;
+            case HS_EV_LB: {
+                // LoadBalancer._forward_request (load_balancer.py:347-433), every backend healthy
+                s.a += 1;                                                           // :349
+                if (p.rt_cnt == 0) {                                                // no healthy backends, :352-366
+                    s.c += 1;
+                    c.reqs[e.req].next = V.req_free; V.req_free = e.req;
+                    break;
+                }
+                const int64_t client = c.reqs[e.req].client;
+                int slot = 0;
+                if (p.sub == HS_LB_CONSISTENT_HASH) {
+                    if (client >= 0 && client < (int64_t)p.conc) slot = c.key_table[p.lim + client];   // ConsistentHash.select(str(client_id))
+                } else if (p.sub == HS_LB_ROUND_ROBIN) {
+                    slot = (int)(s.svc_draws % (uint64_t)p.rt_cnt);                 // backends[_index % len], _index += 1 (strategies.py:66-67)
+                    s.svc_draws += 1;
+                } else if (client >= 0 && client < (int64_t)p.rt_cnt) slot = (int)client;            // Random: the plugged random.choice
+                s.d += 1;                                                           // _in_flight, :378-382
+                c.rt_taken[p.rt_off + slot] += 1;                                   // BackendInfo.total_requests, :385-386
+                s.b += 1;                                                           // :388
+                // a NEW Event for the backend with the same context (created_at survives) + the response hook (:398-431)
+                const int be = c.rt_targets[p.rt_off + slot];
+                c.reqs[e.req].hook = n;
+                H.push(mk(t, G++, arrival_kind(c.P, be), be, e.req));
+            } break;
+            case HS_EV_LB_RESP:                                                     // LoadBalancer._handle_response (load_balancer.py:435-473)
+                if (s.d > 0) s.d -= 1;
+                break;
             case HS_EV_PROBE_TICK: {
                 // Source.handle_event with _ProbeEventProvider (instrumentation/probe.py:69-78): the daemon probe_event, then the next tick
                 const unsigned long long idx_pe = G++;
@@ -467,6 +511,7 @@ struct hs_graph {
     std::vector<int32_t> sched_node; std::vector<int64_t> sched_t;
     int32_t *d_sched_node = nullptr; int64_t *d_sched_t = nullptr; long long d_sched_cap = 0;
     int32_t *d_rt_targets = nullptr;
+    int32_t *d_key_table = nullptr;
     // tick tables: one row per time-varying Source and per distinct Probe interval, computed up to `tick_horizon`
     std::vector<hs::TickRow> rows;
     std::vector<double> row_rate;              // ticks per second a row may reach (sizes the table)
@@ -518,7 +563,7 @@ void hs_graph_destroy(hs_graph *g) {
     (void)hipSetDevice(g->cfg.device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     void *bufs[] = {g->ctl.heap, g->ctl.reqs, g->ctl.rec_node, g->ctl.rec_t, g->ctl.rec_cr, (void *)g->ctl.P, g->ctl.S,
-                    g->d_rt_targets, g->ctl.rt_taken, g->d_sched_node, g->d_sched_t, g->ctl.V, g->d_rows, g->d_ticks, g->d_tick_count,
+                    g->d_rt_targets, g->d_key_table, g->ctl.rt_taken, g->d_sched_node, g->d_sched_t, g->ctl.V, g->d_rows, g->d_ticks, g->d_tick_count,
                     g->d_tick_status};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (g->ev_a) (void)hipEventDestroy(g->ev_a);
@@ -539,7 +584,12 @@ int hs_graph_create(const hs_graph_config *cfg, const hs_graph_nodes *nd, hs_gra
     if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count < 1)
         return gfail(nullptr, HS_E_NO_DEVICE, "no HIP device is visible (the engine has no CPU fallback)");
     if (cfg->device < 0 || cfg->device >= dev_count) return gfail(nullptr, HS_E_INVALID, "device %d out of range", cfg->device);
-    auto takes_requests = [&](int t) { const int k = nd->kind[t]; return k == HS_NODE_SERVER || k == HS_NODE_SINK || k == HS_NODE_LINK || k == HS_NODE_ROUTER; };
+    auto takes_requests = [&](int t) { const int k = nd->kind[t]; return k == HS_NODE_SERVER || k == HS_NODE_SINK || k == HS_NODE_LINK || k == HS_NODE_ROUTER || k == HS_NODE_LB; };
+    int64_t kmax = 0;                                  // client ids any Source hands out: [0, kmax)
+    for (int i = 0; i < n; ++i)
+        if (nd->kind[i] == HS_NODE_SOURCE && nd->src_n_clients && nd->src_n_clients[i] > kmax) kmax = nd->src_n_clients[i];
+    if (kmax > (1ll << 26)) return gfail(nullptr, HS_E_UNSUPPORTED, "n_clients above 2^26 is not supported (client -> backend table)");
+    std::vector<int32_t> key_table;
     std::vector<GParam> P((size_t)n);
     std::vector<hs::TickRow> rows;
     std::vector<double> row_rate;
@@ -571,6 +621,11 @@ int hs_graph_create(const hs_graph_config *cfg, const hs_graph_nodes *nd, hs_gra
             if (!(p.mean > 0.0) || !std::isfinite(p.mean)) return gfail(nullptr, HS_E_INVALID, "node %d: source rate must be > 0, got %g", i, p.mean);
             p.lim = nd->src_stop_after_ns ? nd->src_stop_after_ns[i] : -1;
             if (p.target < 0) return gfail(nullptr, HS_E_INVALID, "node %d: a Source needs a target", i);
+            {
+                const int64_t nc = nd->src_n_clients ? nd->src_n_clients[i] : 0;
+                if (nc < 0) return gfail(nullptr, HS_E_INVALID, "node %d: src_n_clients < 0", i);
+                p.conc = (int32_t)nc;
+            }
             rate_sum += p.mean;
             ++n_src;
             const int pk = nd->src_profile_kind ? nd->src_profile_kind[i] : 0;
@@ -643,6 +698,39 @@ int hs_graph_create(const hs_graph_config *cfg, const hs_graph_nodes *nd, hs_gra
                 if (t < 0 || t >= n || !takes_requests(t)) return gfail(nullptr, HS_E_INVALID, "node %d: router target %d takes no Requests", i, t);
             }
         } break;
+        case HS_NODE_LB: {
+            if (!nd->rt_off || !nd->rt_cnt) return gfail(nullptr, HS_E_INVALID, "rt_off and rt_cnt are required for LoadBalancers");
+            p.rt_off = nd->rt_off[i]; p.rt_cnt = nd->rt_cnt[i];
+            if (p.rt_cnt < 0 || p.rt_off < 0 || (long long)p.rt_off + p.rt_cnt > nd->n_rt) return gfail(nullptr, HS_E_INVALID, "node %d: backends out of range", i);
+            p.sub = nd->lb_strategy ? nd->lb_strategy[i] : (uint8_t)HS_LB_ROUND_ROBIN;                  // load_balancer.py:112: the default
+            if (p.sub > HS_LB_RANDOM) return gfail(nullptr, HS_E_UNSUPPORTED, "node %d: load-balancing strategy %d is not lowered", i, (int)p.sub);
+            for (int q = 0; q < p.rt_cnt; ++q) {
+                const int t = nd->rt_targets[p.rt_off + q];
+                if (t < 0 || t >= n || nd->kind[t] != HS_NODE_SERVER) return gfail(nullptr, HS_E_UNSUPPORTED, "node %d: backend %d is not a Server (only Server backends are lowered)", i, t);
+            }
+            p.lim = -1; p.conc = 0;
+            if (p.sub == HS_LB_CONSISTENT_HASH && p.rt_cnt > 0) {
+                const int V = nd->lb_vnodes ? nd->lb_vnodes[i] : 100;
+                if (V < 1) return gfail(nullptr, HS_E_INVALID, "node %d: virtual_nodes must be >= 1, got %d", i, V);   // strategies.py:355-356
+                if (!nd->names || !nd->name_off) return gfail(nullptr, HS_E_INVALID, "names / name_off are required for a ConsistentHash LoadBalancer");
+                std::string names;
+                std::vector<int32_t> off(1, 0);
+                for (int q = 0; q < p.rt_cnt; ++q) {
+                    const int t = nd->rt_targets[p.rt_off + q];
+                    const int nl = nd->name_off[t + 1] - nd->name_off[t];
+                    if (nl < 1 || nl > 200) return gfail(nullptr, HS_E_INVALID, "node %d: backend %d needs a name (1 .. 200 bytes)", i, t);
+                    names.append(nd->names + nd->name_off[t], (size_t)nl);
+                    off.push_back((int32_t)names.size());
+                }
+                const std::vector<hs::ring::RingPoint> ring = hs::ring::build_ring(names.data(), off.data(), p.rt_cnt, V);
+                p.lim = (int64_t)key_table.size(); p.conc = (int32_t)kmax;
+                char key[32];
+                for (int64_t cid = 0; cid < kmax; ++cid) {                          // ConsistentHash.select for key str(id): a pure function of the id
+                    const int len = snprintf(key, sizeof key, "%lld", (long long)cid);
+                    key_table.push_back(hs::ring::ring_select(ring, key, (size_t)len));
+                }
+            }
+        } break;
         default: return gfail(nullptr, HS_E_UNSUPPORTED, "node %d: kind %d is not lowered", i, (int)p.kind);
         }
         P[(size_t)i] = p;
@@ -680,6 +768,11 @@ int hs_graph_create(const hs_graph_config *cfg, const hs_graph_nodes *nd, hs_gra
     HSG_HIPD(hipMalloc(&g->d_rt_targets, nrt * sizeof(int32_t)));
     if (nd->n_rt > 0) HSG_HIPD(hipMemcpy(g->d_rt_targets, nd->rt_targets, (size_t)nd->n_rt * sizeof(int32_t), hipMemcpyHostToDevice));
     c.rt_targets = g->d_rt_targets;
+    if (!key_table.empty()) {
+        HSG_HIPD(hipMalloc(&g->d_key_table, key_table.size() * sizeof(int32_t)));
+        HSG_HIPD(hipMemcpy(g->d_key_table, key_table.data(), key_table.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    c.key_table = g->d_key_table;
     HSG_HIPD(hipMalloc(&c.rt_taken, nrt * sizeof(long long)));
     HSG_HIPD(hipMemset(c.rt_taken, 0, nrt * sizeof(long long)));
     if (!rows.empty()) {
@@ -873,6 +966,11 @@ int hs_graph_get_stats(hs_graph *g, hs_graph_stats *o) {
         if (o->packets_sent) o->packets_sent[i] = lnk ? s.b : 0;
         if (o->packets_dropped) o->packets_dropped[i] = lnk ? s.c : 0;
         if (o->routed) o->routed[i] = k == HS_NODE_ROUTER ? s.a : 0;
+        if (o->lb) {
+            const bool lb = k == HS_NODE_LB;
+            int64_t *r = o->lb + 5 * (size_t)i;
+            r[0] = lb ? s.a : 0; r[1] = lb ? s.b : 0; r[2] = lb ? s.c : 0; r[3] = lb ? s.c : 0; r[4] = lb ? s.d : 0;
+        }
     }
     if (o->rt_taken && g->n_rt > 0)
         HSG_HIP(g, hipMemcpy(o->rt_taken, g->ctl.rt_taken, (size_t)g->n_rt * sizeof(int64_t), hipMemcpyDeviceToHost));

@@ -21,8 +21,9 @@ import ctypes as C
 import numpy as np
 
 from . import _native as N
-from .entities import (ConstantLatency, ConstantRateProfile, Counter, Entity, ExponentialLatency, LatencyTracker, LinearRampProfile,
-                       LoadBalancer, NetworkLink, Probe, RandomRouter, Server, SimpleEventProvider, Sink, Source)
+from .entities import (ClientKeyEventProvider, ConsistentHash, ConstantLatency, ConstantRateProfile, Counter, Entity, ExponentialLatency,
+                       LatencyTracker, LinearRampProfile, LoadBalancer, NetworkLink, Probe, Random, RandomRouter, RoundRobin, Server,
+                       SimpleEventProvider, Sink, Source)
 
 _SINKS = (Sink, Counter, LatencyTracker)
 DEFAULT_MAX_EVENTS = 200_000_000          # ~ minutes on the one lane; Simulation(max_graph_events=) raises it
@@ -56,6 +57,11 @@ class GraphArrays:
         self.src_profile_params = None
         self.probe_metric = None             # [n] uint8 / [n] float64: PROBE nodes
         self.probe_interval_s = None
+        self.lb_strategy = None              # [n] uint8 / [n] int32: LB nodes; names (bytes) / name_off [n + 1] int32: their backends' names
+        self.lb_vnodes = None
+        self.names = None
+        self.name_off = None
+        self.src_n_clients = None            # [n] int64: Sources with a ClientKeyEventProvider
 
     def struct(self) -> N.GraphNodes:
         s = N.GraphNodes()
@@ -66,8 +72,12 @@ class GraphArrays:
         self.rt_targets = np.ascontiguousarray(self.rt_targets, np.int32)
         s.rt_targets = _ptr(self.rt_targets) if len(self.rt_targets) else None
         s.n_rt = len(self.rt_targets)
-        for name in ("src_profile_kind", "src_profile_params", "probe_metric", "probe_interval_s"):
+        for name in ("src_profile_kind", "src_profile_params", "probe_metric", "probe_interval_s", "lb_strategy", "lb_vnodes", "name_off",
+                     "src_n_clients"):
             setattr(s, name, _ptr(getattr(self, name)))
+        if self.names is not None:
+            self._names_buf = C.create_string_buffer(self.names, max(len(self.names), 1))
+            s.names = C.cast(self._names_buf, C.c_void_p)
         return s
 
 
@@ -109,7 +119,8 @@ class GraphEngine:
 
     def stats(self) -> dict:
         n, nrt = self.arrays.n, max(len(self.arrays.rt_targets), 1)
-        out = {k: np.zeros(nrt if k == "rt_taken" else n, np.float64 if k == "total_service_s" else np.int64) for k in N.GRAPH_STATS}
+        out = {k: np.zeros(nrt if k == "rt_taken" else (n, 5) if k == "lb" else n, np.float64 if k == "total_service_s" else np.int64)
+               for k in N.GRAPH_STATS}
         st = N.GraphStats()
         for k, a in out.items():
             setattr(st, k, _ptr(a))
@@ -180,11 +191,9 @@ def lower_general(sources: list, entities: list, probes=None) -> GeneralGraph:
             raise UnsupportedTopology(f"probe '{pr.name}' is listed twice")
         add(pr)
     n_front = len(nodes)
-    lowered = (Server, NetworkLink, RandomRouter) + _SINKS
+    lowered = (Server, NetworkLink, RandomRouter, LoadBalancer) + _SINKS
 
     def check(ent, where):
-        if isinstance(ent, LoadBalancer):
-            raise UnsupportedTopology(f"{where}: a LoadBalancer inside a general graph is not lowered")
         if isinstance(ent, Source):
             raise UnsupportedTopology(f"{where}: a Source takes no Requests")
         if not isinstance(ent, lowered):
@@ -222,8 +231,16 @@ def lower_general(sources: list, entities: list, probes=None) -> GeneralGraph:
     for i, ent in enumerate(nodes):
         if isinstance(ent, Source):
             ep, prov = ent._event_provider, ent._time_provider
-            if not isinstance(ep, SimpleEventProvider):
+            if not isinstance(ep, (SimpleEventProvider, ClientKeyEventProvider)):
                 raise UnsupportedTopology(f"source '{ent.name}': event provider {type(ep).__name__} is not lowered on a general graph")
+            tgt = ep._target
+            n_clients = getattr(ep, "_n_clients", 0)
+            if isinstance(tgt, LoadBalancer) and isinstance(tgt.strategy, Random):
+                n_clients = len(tgt.all_backends)             # the Request's draw IS the choice: backends[int(u * len)] (entities.Random)
+            if n_clients:
+                if a.src_n_clients is None:
+                    a.src_n_clients = np.zeros(n, np.int64)
+                a.src_n_clients[i] = n_clients
             if not (ent.rate > 0):
                 raise UnsupportedTopology(f"source '{ent.name}': rate must be > 0")
             if not isinstance(ep._target, Entity) or id(ep._target) not in node_of:
@@ -290,6 +307,22 @@ def lower_general(sources: list, entities: list, probes=None) -> GeneralGraph:
                 a.lat_mean_s[i] = ent.jitter.mean
             a.link_loss_rate[i] = ent.packet_loss_rate
             a.target[i] = -1 if ent.egress is None else node_of[id(ent.egress)]
+        elif isinstance(ent, LoadBalancer):
+            backends = ent.all_backends
+            for b in backends:
+                if not isinstance(b, Server):
+                    raise UnsupportedTopology(f"backend '{b.name}' of '{ent.name}' is a {type(b).__name__}: only Server backends are lowered")
+            if a.lb_strategy is None:
+                a.lb_strategy = np.full(n, N.LB_ROUND_ROBIN, np.uint8)
+                a.lb_vnodes = np.zeros(n, np.int32)
+            st = ent.strategy
+            a.kind[i] = N.NODE_LB
+            a.lb_strategy[i] = (N.LB_CONSISTENT_HASH if isinstance(st, ConsistentHash) else N.LB_ROUND_ROBIN if isinstance(st, RoundRobin)
+                                else N.LB_RANDOM)
+            a.lb_vnodes[i] = getattr(st, "virtual_nodes", 0)
+            a.rt_off[i] = len(rt)
+            a.rt_cnt[i] = len(backends)
+            rt.extend(node_of[id(b)] for b in backends)
         elif isinstance(ent, RandomRouter):
             if not ent.targets:
                 raise UnsupportedTopology(f"router '{ent.name}' has no targets")
@@ -302,8 +335,62 @@ def lower_general(sources: list, entities: list, probes=None) -> GeneralGraph:
         else:
             a.kind[i] = N.NODE_SINK
     a.rt_targets = np.array(rt, np.int32)
+    if a.lb_strategy is not None:
+        _check_keys(nodes, node_of, a)
+        blobs = [(x.name.encode() if isinstance(x, Server) else b"") for x in nodes]     # (only an LB's backends need their name)
+        a.names = b"".join(blobs)
+        a.name_off = np.zeros(n + 1, np.int32)
+        a.name_off[1:] = np.cumsum([len(b) for b in blobs])
     assert all(a.kind[i] == N.NODE_SOURCE for i in range(n_src)) and all(a.kind[i] == N.NODE_PROBE for i in range(n_src, n_front))
     return GeneralGraph(nodes, a, node_of)
+
+
+def _reaches(nodes, node_of, start) -> set:
+    """Node ids a Request that enters `start` can visit."""
+    seen, todo = set(), [node_of[id(start)]]
+    while todo:
+        i = todo.pop()
+        if i in seen:
+            continue
+        seen.add(i)
+        todo.extend(node_of[id(d)] for d in nodes[i].downstream_entities() if d is not None)
+    return seen
+
+
+def _check_keys(nodes, node_of, a) -> None:
+    """A Request without a client id must not reach a ConsistentHash or Random LoadBalancer (there the reference falls back to a
+    RoundRobin of the strategy's own / asks the process-wide `random`, which the engine's streams do not define for it); a Random
+    LoadBalancer takes its Requests from Sources that aim at it directly (their draw is the choice)."""
+    from .lowering import UnsupportedTopology
+
+    keyed = [i for i, x in enumerate(nodes) if isinstance(x, LoadBalancer) and not isinstance(x.strategy, RoundRobin)]
+    if not keyed:
+        return
+    for i, src in enumerate(nodes):
+        if not isinstance(src, Source):
+            continue
+        tgt = src._event_provider._target
+        reach = _reaches(nodes, node_of, tgt)
+        for j in keyed:
+            if j not in reach:
+                continue
+            lb = nodes[j]
+            if isinstance(lb.strategy, Random) and tgt is not lb:
+                raise UnsupportedTopology(f"source '{src.name}' reaches the Random LoadBalancer '{lb.name}' through other entities: only "
+                                          "Sources that aim at it directly carry the draw it chooses by")
+            if isinstance(lb.strategy, ConsistentHash) and not isinstance(src._event_provider, ClientKeyEventProvider):
+                raise UnsupportedTopology(f"source '{src.name}': requests for the key-based LoadBalancer '{lb.name}' must come from a "
+                                          "ClientKeyEventProvider (ConsistentHash falls back to a RoundRobin of its own for key-less "
+                                          "requests: use strategy=RoundRobin() for those)")
+
+
+def keyless_hazard(g: "GeneralGraph", target) -> str | None:
+    """Simulation.schedule(): a scheduled Request carries no client id -- the name of a key-based LoadBalancer it could reach."""
+    for j in _reaches(g.nodes, g.node_of, target):
+        x = g.nodes[j]
+        if isinstance(x, LoadBalancer) and not isinstance(x.strategy, RoundRobin):
+            return x.name
+    return None
 
 
 def write_back_general(g: GeneralGraph, stats: dict, rec_node: np.ndarray, rec_t: np.ndarray, rec_cr: np.ndarray, device: int = 0) -> None:
@@ -328,6 +415,14 @@ def write_back_general(g: GeneralGraph, stats: dict, rec_node: np.ndarray, rec_t
             ent.packets_sent = int(stats["packets_sent"][i])
             ent.packets_dropped = int(stats["packets_dropped"][i])
             ent._entered = int(stats["entered"][i])
+        elif isinstance(ent, LoadBalancer):
+            (ent._requests_received, ent._requests_forwarded, ent._requests_failed, ent._no_backend_available,
+             ent._in_flight_count) = (int(v) for v in stats["lb"][i])
+            if isinstance(ent.strategy, RoundRobin):
+                ent.strategy._index += ent._requests_forwarded     # one select per forwarded Request (strategies.py:66-67)
+            off = int(a.rt_off[i])
+            for q, b in enumerate(ent.all_backends):
+                ent._backends[b.name].total_requests = int(stats["rt_taken"][off + q])
         elif isinstance(ent, Probe):
             sel = order[bounds[i]:bounds[i + 1]]                 # its samples: (time, sampled integer)
             ent.data_sink._set(rec_t[sel].copy(), rec_cr[sel].copy(), Probe.value_map(ent.metric, ent.target))

@@ -12,7 +12,7 @@ from . import _native as N
 from .core.event import Event
 from .core.temporal import Instant
 from .engine import StationEngine
-from .graph_engine import DEFAULT_MAX_EVENTS, GeneralGraph, GraphEngine, lower_general, write_back_general
+from .graph_engine import DEFAULT_MAX_EVENTS, GeneralGraph, GraphEngine, keyless_hazard, lower_general, write_back_general
 from .entities import Entity, Server
 from .lowering import (LazyRecords, LbGraph, LoweredGraph, UnsupportedTopology, attach_lb_probes, attach_probes, find_load_balancer, lower,
                        plain_probe_arrays, write_back_plain_probes,
@@ -125,15 +125,15 @@ class Simulation:
                 self._graph = LoweredGraph(plain)
                 lb = None
             else:
-                lb = find_load_balancer(self._sources, self._entities)
+                lb = None
                 try:
+                    lb = find_load_balancer(self._sources, self._entities)
                     self._graph = lower_lb(self._sources, self._entities, lb) if lb is not None else lower(self._sources,
                                                                                                             self._entities)
                 except UnsupportedTopology as station_shape:
                     # not the shape the station engines take: the single-heap loop (csrc/hs_graph.hip) runs what the same entity
-                    # classes can be wired into otherwise -- exactly, at ~1 us per event
-                    if lb is not None:
-                        raise
+                    # classes can be wired into otherwise -- exactly, at ~1 us per event (several LoadBalancers, a LoadBalancer
+                    # behind Servers ... included)
                     try:
                         self._graph = lower_general(self._sources, self._entities, self._probes)
                     except UnsupportedTopology as general:
@@ -141,20 +141,21 @@ class Simulation:
                     self._station_refusal = str(station_shape)
                     return self._graph
             if self._probes:
-                if lb is not None:
-                    attach_lb_probes(self._graph, self._probes)
-                elif plain is not None and not self._scheduled:
-                    self._plain_probes_pending = True     # (_run puts them into the arrays without a Station per chain)
-                else:
-                    try:
+                try:
+                    if lb is not None:
+                        attach_lb_probes(self._graph, self._probes)
+                    elif plain is not None and not self._scheduled:
+                        self._plain_probes_pending = True     # (_run puts them into the arrays without a Station per chain)
+                    else:
                         attach_probes(self._graph, self._probes)
-                    except UnsupportedTopology as station_shape:
-                        # (more than four probes on a station, a further Source of a Server sampled ...: the single heap samples anything)
-                        try:
-                            self._graph = lower_general(self._sources, self._entities, self._probes)
-                        except UnsupportedTopology:
-                            raise station_shape from None
-                        self._station_refusal = str(station_shape)
+                except UnsupportedTopology as station_shape:
+                    # (more than four probes on a station, a further Source of a Server sampled, a probe on the LoadBalancer's
+                    # Source with stop_after ...: the single heap samples anything)
+                    try:
+                        self._graph = lower_general(self._sources, self._entities, self._probes)
+                    except UnsupportedTopology:
+                        raise station_shape from None
+                    self._station_refusal = str(station_shape)
         return self._graph
 
     def _run_lb(self, g: LbGraph, wall0: float) -> SimulationSummary:
@@ -224,8 +225,6 @@ class Simulation:
             except UnsupportedTopology as station_shape:
                 # refused on the way (a probe the station slots do not hold, a tick on the nanosecond of a shared Sink's record ...):
                 # the single-heap loop takes it if the graph is its kind; otherwise the station engines' refusal stands
-                if isinstance(g, LbGraph):
-                    raise
                 try:
                     g = lower_general(self._sources, self._entities, self._probes)
                 except UnsupportedTopology:
@@ -324,6 +323,11 @@ class Simulation:
                 raise UnsupportedTopology(f"scheduled event {ev!r}: completion hooks are host Python (not lowered)")
             if ev.context.get("created_at") != ev.time:
                 raise UnsupportedTopology(f"scheduled event {ev!r}: a custom created_at is not lowered")
+            lb_name = keyless_hazard(g, ev.target)
+            if lb_name is not None:
+                raise UnsupportedTopology(f"scheduled event {ev!r} carries no client id and can reach the key-based LoadBalancer "
+                                          f"'{lb_name}' (the reference would fall back to a RoundRobin of the strategy's own / the "
+                                          "process-wide random generator): not lowered")
             if cancelled_ns:
                 # a cancelled Event keeps its place in the process-wide counter: the ones behind it would need the gap
                 raise UnsupportedTopology("cancelled Events in front of live ones are not lowered on the single-heap path")

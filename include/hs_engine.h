@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HS_ABI_VERSION 15
+#define HS_ABI_VERSION 16
 
 typedef enum hs_status {
     HS_OK = 0,
@@ -653,7 +653,7 @@ int hs_debug_const_div(int32_t device, double b, int64_t n, const double *a, dou
                        double *q_ns);
 
 /* ------------------------------------------------------------------------------------------------------------------
- * General entity graphs (ABI 15).
+ * General entity graphs (ABI 15; LoadBalancer nodes: ABI 16).
  *
  * The station engines take graphs of the shape [Sources] -> Server -> {Sink | NetworkLink | RandomRouter} with one sender
  * per link, <= 4 Sources per Server, <= 4 router targets ... (hs_engine_set_stations / hs_engine_set_network).  Everything
@@ -674,7 +674,7 @@ int hs_debug_const_div(int32_t device, double b, int64_t n, const double *a, dou
  * ------------------------------------------------------------------------------------------------------------------ */
 typedef struct hs_graph hs_graph;
 
-typedef enum hs_node_kind { HS_NODE_SOURCE = 0, HS_NODE_SERVER = 1, HS_NODE_SINK = 2, HS_NODE_LINK = 3, HS_NODE_ROUTER = 4, HS_NODE_PROBE = 5 } hs_node_kind;
+typedef enum hs_node_kind { HS_NODE_SOURCE = 0, HS_NODE_SERVER = 1, HS_NODE_SINK = 2, HS_NODE_LINK = 3, HS_NODE_ROUTER = 4, HS_NODE_PROBE = 5, HS_NODE_LB = 6 } hs_node_kind;
 
 typedef struct hs_graph_config {
     uint32_t struct_size;            /* sizeof(hs_graph_config) */
@@ -722,6 +722,21 @@ typedef struct hs_graph_nodes {
      * (node = the probe, t = sample time, created = the value). */
     const uint8_t *probe_metric;     /* [n] hs_probe_metric */
     const double *probe_interval_s;  /* [n] > 0 */
+    /* HS_NODE_LB: LoadBalancer(backends=[...], strategy) (components/load_balancer/load_balancer.py:347-473) -- any number of them,
+     * anywhere a Request can go.  Backends = rt_targets[rt_off .. rt_off + rt_cnt) in add_backend order, SERVER nodes, all healthy.
+     * ConsistentHash (strategies.py:336-433): lb_vnodes ring points md5("<backend name>:<i>") per backend (names / name_off), the key
+     * of a Request is str(client_id); RoundRobin (strategies.py:50-73); Random (strategies.py:137-150) with random.choice plugged by
+     * the Request's key draw: backends[client_id].  A Source with src_n_clients > 0 builds its Requests like a
+     * ClientKeyEventProvider (examples/visual/chash_example.py:69-88): client_id = int(u * n_clients), u from its KEY stream.  A
+     * Request WITHOUT a client_id (a scheduled one, one of a plain Source) must not reach a ConsistentHash or Random LoadBalancer
+     * (the reference falls back to a RoundRobin of its own / draws from the process-wide generator): the caller refuses such
+     * graphs; the device sends it to backend 0.  Every forwarded Request carries the `_lb_response` completion hook
+     * (load_balancer.py:413-431): one more event behind the backend's enqueue.  NULL = no LoadBalancer. */
+    const uint8_t *lb_strategy;      /* [n] hs_lb_strategy */
+    const int32_t *lb_vnodes;        /* [n] ConsistentHash(virtual_nodes) */
+    const char *names;               /* concatenated entity names (only an LB's backends need one) */
+    const int32_t *name_off;         /* [n + 1] */
+    const int64_t *src_n_clients;    /* [n] Sources; 0 = a plain SimpleEventProvider */
 } hs_graph_nodes;
 
 typedef struct hs_graph_stats {      /* host arrays [n_nodes] (rt_taken: [n_rt]); any pointer may be NULL */
@@ -736,7 +751,10 @@ typedef struct hs_graph_stats {      /* host arrays [n_nodes] (rt_taken: [n_rt])
     int64_t *packets_sent;           /* NetworkLink.packets_sent                        components/network/link.py:162 */
     int64_t *packets_dropped;        /* NetworkLink.packets_dropped                     components/network/link.py:132 */
     int64_t *routed;                 /* RandomRouter.stats_routed                       components/random_router.py:36 */
-    int64_t *rt_taken;               /* [n_rt] how often each target slot was drawn     (target_counts, random_router.py:37) */
+    int64_t *rt_taken;               /* [n_rt] how often each target slot was drawn     (target_counts, random_router.py:37);
+                                      * a LoadBalancer's slots: BackendInfo.total_requests       load_balancer.py:385-386 */
+    int64_t *lb;                     /* [n][5] LoadBalancer: requests_received, requests_forwarded, requests_failed,
+                                      * no_backend_available, len(_in_flight)                    load_balancer.py:349-388 */
 } hs_graph_stats;
 
 int hs_graph_create(const hs_graph_config *cfg, const hs_graph_nodes *nodes, hs_graph **out);

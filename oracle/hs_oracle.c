@@ -868,7 +868,9 @@ hso_sim *hso_create(const hso_graph *g, const hso_params *p) {
  * Calls must come in the order the caller constructed the Events.  Returns 0, or -1 for a node that takes no Request. */
 int hso_schedule(hso_sim *s, int32_t node, int64_t time_ns) {
     int32_t k = arrival_kind_for(s, node);
-    if (k < 0 || k == HSO_EV_LB) return -1;
+    /* (a scheduled Request carries no metadata: a ConsistentHash / Random LoadBalancer would fall back to a RoundRobin of its own /
+     * ask the process-wide generator -- not modelled; a RoundRobin LoadBalancer takes it like any other) */
+    if (k < 0 || (k == HSO_EV_LB && s->g.vnodes[node] != 0)) return -1;
     int32_t r = req_alloc(s);
     s->reqs[r].created_ns = time_ns;
     s->reqs[r].hops = 0;

@@ -828,10 +828,24 @@ def run_graph_case(spec):
                                  egress=servers[lk["to"]]))
         links[l]._loss_stream = hs.Stream(seed, l, hs.STREAM_LOSS)
     routers = [None] * len(spec["routers"])
+    # LoadBalancers anywhere a Request can go (round 6): [{strategy: "chash" | "round_robin" | "random", vnodes, backends: [server ...]}]
+    lbs = []
+    for j, lb in enumerate(spec.get("lbs") or []):
+        backends = [servers[b] for b in lb["backends"]]
+        if lb["strategy"] == "round_robin":
+            from happysimulator.components.load_balancer.strategies import RoundRobin
+            strat = RoundRobin()
+        elif lb["strategy"] == "random":
+            import happysimulator.components.load_balancer.strategies as strat_mod
+            strat_mod.random = _PerRequestChoice
+            strat = strat_mod.Random()
+        else:
+            strat = ConsistentHash(virtual_nodes=lb["vnodes"])
+        lbs.append(LoadBalancer(f"lb{j}", backends=backends, strategy=strat))
 
     def entity(ref):
         kind, idx = ref
-        return {"sink": sinks, "link": links, "router": routers, "server": servers}[kind][idx]
+        return {"sink": sinks, "link": links, "router": routers, "server": servers, "lb": lbs}[kind][idx]
 
     # routers may target routers: build them in an order in which every router's router-targets exist (the generator keeps them acyclic)
     pending = list(range(len(routers)))
@@ -852,8 +866,15 @@ def run_graph_case(spec):
         prof = ConstantRateProfile(rate=sc["rate"])
         prov = (PhiloxPoissonArrival(prof, Instant.Epoch, hs.Stream(seed, k, hs.STREAM_ARRIVAL)) if sc["kind"] == "poisson"
                 else ConstantArrivalTimeProvider(prof, start_time=Instant.Epoch))
-        sources.append(Source(f"src{k}", SimpleEventProvider(servers[sc["to"]], "Request", None), prov))
-    sim = Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=sources, entities=servers + routers + links + sinks)
+        to = servers[sc["to"]] if isinstance(sc["to"], int) else entity(sc["to"])
+        if sc.get("n_clients"):                     # a Request with a client id (ConsistentHash's key / the Random strategy's draw)
+            ep = PhiloxClientProvider(to, sc["n_clients"], hs.Stream(seed, k, hs.STREAM_KEY))
+        else:
+            ep = SimpleEventProvider(to, "Request", None)
+        sources.append(Source(f"src{k}", ep, prov))
+    sim = Simulation(end_time=Instant.from_seconds(spec["end_s"]), sources=sources, entities=servers + lbs + routers + links + sinks)
+    for ref, t_s in spec.get("schedule") or []:      # Simulation.schedule() before run(), in this order (core/simulation.py:195-206)
+        sim.schedule(Event(time=Instant.from_seconds(t_s), event_type="Request", target=entity(ref)))
     summary = sim.run()
     out = {}
     meta = dict(spec=spec, total_events=[summary.total_events_processed], final_ns=[sim._current_time.nanoseconds],
@@ -871,6 +892,16 @@ def run_graph_case(spec):
     out["routed"] = np.array([r.stats_routed for r in routers], np.int64)
     out["packets_sent"] = np.array([l.packets_sent for l in links], np.int64)
     out["packets_dropped"] = np.array([l.packets_dropped for l in links], np.int64)
+    if lbs:
+        out["lb_stats"] = np.array([[lb.stats.requests_received, lb.stats.requests_forwarded, lb.stats.requests_failed,
+                                     lb.stats.no_backend_available, len(lb._in_flight)] for lb in lbs], np.int64)
+        tot, toff = [], [0]
+        for j, lb in enumerate(lbs):
+            tot.extend(lb.get_backend_info(servers[b]).total_requests for b in spec["lbs"][j]["backends"])
+            toff.append(len(tot))
+        out["lb_backend_total_requests"] = np.asarray(tot, np.int64)
+        out["lb_backend_off"] = np.asarray(toff, np.int64)
+        out["lb_rr_index"] = np.array([getattr(lb.strategy, "_index", -1) for lb in lbs], np.int64)
     sink_t, sink_lat, off = [], [], [0]
     for k in sinks:
         sink_t.extend(t.nanoseconds for t in k.completion_times)
@@ -1102,6 +1133,30 @@ GRAPH_CASES = [
          sources=[dict(kind="poisson", rate=6.0, to=0), dict(kind="poisson", rate=4.0, to=2), dict(kind="constant", rate=2.0, to=0),
                   dict(kind="poisson", rate=3.0, to=0), dict(kind="constant", rate=2.0, to=0), dict(kind="poisson", rate=2.0, to=0),
                   dict(kind="poisson", rate=1.0, to=0)]),
+    # round 6: LoadBalancers INSIDE a general graph -- three of them (ConsistentHash behind a Server and a router, RoundRobin behind a
+    # router and a Source, Random behind its own Source), every Source handing out client ids
+    dict(name="graph_three_load_balancers", topology="graph", n_sinks=2, end_s=8.0, seed=181,
+         servers=[dict(mean=0.03, c=1, cap=None, out=["lb", 0]), dict(mean=0.05, c=2, cap=None, out=["router", 0]),
+                  dict(mean=0.06, c=1, cap=3, out=["sink", 0]), dict(mean=0.04, c=1, cap=None, out=["link", 0]),
+                  dict(mean=0.08, c=3, cap=None, out=["sink", 1]), dict(mean=0.05, c=1, cap=2, out=["sink", 0])],
+         links=[dict(lat=0.002, jk="exp", jm=0.003, loss=0.05, to=4)],
+         routers=[dict(targets=[["sink", 1], ["lb", 0], ["lb", 1], ["link", 0]])],
+         lbs=[dict(strategy="chash", vnodes=17, backends=[2, 3, 5]), dict(strategy="round_robin", vnodes=0, backends=[4, 2]),
+              dict(strategy="random", vnodes=0, backends=[0, 1, 3])],
+         sources=[dict(kind="poisson", rate=8.0, to=0, n_clients=50), dict(kind="poisson", rate=6.0, to=1, n_clients=5),
+                  dict(kind="constant", rate=4.0, to=["lb", 1], n_clients=1000), dict(kind="poisson", rate=9.0, to=["lb", 2], n_clients=3),
+                  dict(kind="poisson", rate=5.0, to=["lb", 0], n_clients=1000)]),
+    # ... and key-less: two RoundRobin LoadBalancers sharing a backend, Requests `schedule()`d for Servers, a router, a link and the
+    # LoadBalancers themselves (bursts on one nanosecond, on a Source's constant tick, at and beyond the end)
+    dict(name="graph_round_robin_schedule", topology="graph", n_sinks=2, end_s=6.0, seed=183,
+         servers=[dict(mean=0.04, c=1, cap=None, out=["lb", 1]), dict(mean=0.05, c=1, cap=2, out=["router", 0]),
+                  dict(mean=0.03, c=2, cap=None, out=["sink", 0]), dict(mean=0.07, c=1, cap=None, out=["sink", 1])],
+         links=[dict(lat=0.001, jk="const", jm=0.0005, loss=0.0, to=3)],
+         routers=[dict(targets=[["sink", 0], ["link", 0], ["lb", 1]])],
+         lbs=[dict(strategy="round_robin", vnodes=0, backends=[0, 1, 2]), dict(strategy="round_robin", vnodes=0, backends=[3, 2])],
+         sources=[dict(kind="poisson", rate=9.0, to=["lb", 0]), dict(kind="constant", rate=2.0, to=["lb", 0]), dict(kind="poisson", rate=3.0, to=1)],
+         schedule=[[["lb", 0], 0.5], [["lb", 0], 0.5], [["server", 1], 0.5], [["lb", 1], 1.0], [["router", 0], 1.0], [["link", 0], 0.0],
+                   [["lb", 0], 0.0], [["lb", 1], 6.0], [["server", 0], 6.0], [["lb", 0], 6.5], [["lb", 1], 2.25]]),
 ]
 
 RING_CASES = [

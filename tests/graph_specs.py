@@ -22,7 +22,11 @@ def build(spec, extra_schedule=None):
         links.append(hs.NetworkLink(f"link{l}", latency=hs.ConstantLatency(lk["lat"]), jitter=jit,
                                     packet_loss_rate=lk.get("loss", 0.0), egress=servers[lk["to"]]))
     routers = [None] * len(spec["routers"])
-    pools = {"sink": sinks, "link": links, "router": routers, "server": servers}
+    lbs = [hs.LoadBalancer(f"lb{j}", backends=[servers[b] for b in lb["backends"]],
+                           strategy=(hs.ConsistentHash(virtual_nodes=lb["vnodes"]) if lb["strategy"] == "chash" else
+                                     hs.RoundRobin() if lb["strategy"] == "round_robin" else hs.Random()))
+           for j, lb in enumerate(spec.get("lbs") or [])]
+    pools = {"sink": sinks, "link": links, "router": routers, "server": servers, "lb": lbs}
     pending = list(range(len(routers)))
     while pending:
         for r in list(pending):
@@ -36,12 +40,18 @@ def build(spec, extra_schedule=None):
     sources = []
     for k, sc in enumerate(spec["sources"]):
         make = hs.Source.poisson if sc["kind"] == "poisson" else hs.Source.constant
-        sources.append(make(rate=sc["rate"], target=servers[sc["to"]], name=f"src{k}"))
+        to = servers[sc["to"]] if isinstance(sc["to"], int) else pools[sc["to"][0]][sc["to"][1]]
+        if sc.get("n_clients"):
+            sources.append(make(rate=sc["rate"], event_provider=hs.ClientKeyEventProvider(to, n_clients=sc["n_clients"]), name=f"src{k}"))
+        else:
+            sources.append(make(rate=sc["rate"], target=to, name=f"src{k}"))
     end = None if spec.get("end_s") is None else hs.Instant.from_seconds(spec["end_s"])      # None: auto-termination
-    sim = hs.Simulation(end_time=end, sources=sources, entities=servers + routers + links + sinks, seed=spec["seed"])
+    sim = hs.Simulation(end_time=end, sources=sources, entities=servers + lbs + routers + links + sinks, seed=spec["seed"])
+    for (kind, idx), t_s in spec.get("schedule") or []:
+        sim.schedule(hs.Event(time=hs.Instant.from_seconds(t_s), event_type="Request", target=pools[kind][idx]))
     for kind, idx, t_s in (extra_schedule or []):
         sim.schedule(hs.Event(time=hs.Instant.from_seconds(t_s), event_type="Request", target=pools[kind][idx]))
-    return sim, dict(sources=sources, servers=servers, links=links, routers=routers, sinks=sinks)
+    return sim, dict(sources=sources, servers=servers, links=links, routers=routers, sinks=sinks, lbs=lbs)
 
 
 def results(ents):

@@ -319,14 +319,18 @@ def oracle_graph(spec):
     """Oracle nodes of a graph golden (tests/golden/make_golden.py run_graph_case): sources in list order first, then sinks, servers,
     links, routers.  Returns (graph, {"source": [...], "sink": [...], "server": [...], "link": [...], "router": [...]})."""
     g = O.Graph()
-    nodes = {"source": [], "sink": [], "server": [], "link": [], "router": [None] * len(spec["routers"])}
+    nodes = {"source": [], "sink": [], "server": [], "link": [], "router": [None] * len(spec["routers"]), "lb": []}
     for k, sc in enumerate(spec["sources"]):
-        nodes["source"].append(g.source(O.ARR_POISSON if sc["kind"] == "poisson" else O.ARR_CONSTANT, sc["rate"], stream_base=k))
+        nodes["source"].append(g.source(O.ARR_POISSON if sc["kind"] == "poisson" else O.ARR_CONSTANT, sc["rate"], stream_base=k,
+                                        n_clients=sc.get("n_clients", 0)))
     for _ in range(spec["n_sinks"]):
         nodes["sink"].append(g.sink())
     for i, sv in enumerate(spec["servers"]):
         nodes["server"].append(g.server(O.LAT_EXP, sv["mean"], concurrency=sv.get("c", 1),
-                                        queue_cap=-1 if sv.get("cap") is None else sv["cap"], stream_base=i))
+                                        queue_cap=-1 if sv.get("cap") is None else sv["cap"], stream_base=i, name=f"srv{i}"))
+    for lb in spec.get("lbs") or []:                # strategy by the vnodes field (hs_oracle.c on_lb): > 0 ConsistentHash, 0 RoundRobin, -1 Random
+        vn = {"chash": lb.get("vnodes", 100), "round_robin": 0, "random": -1}[lb["strategy"]]
+        nodes["lb"].append(g.load_balancer([nodes["server"][b] for b in lb["backends"]], vn))
     for l, lk in enumerate(spec["links"]):
         jk = lk.get("jk") if lk.get("jm") is not None else None
         nodes["link"].append(g.link(lk["lat"], None if jk is None else lk["jm"], stream_base=l, loss=lk.get("loss", 0.0),
@@ -339,13 +343,18 @@ def oracle_graph(spec):
                 nodes["router"][r] = g.router([nodes[k][i] for k, i in tg], stream_base=r)
                 pending.remove(r)
     for k, sc in enumerate(spec["sources"]):
-        g.target[nodes["source"][k]] = nodes["server"][sc["to"]]
+        g.target[nodes["source"][k]] = nodes["server"][sc["to"]] if isinstance(sc["to"], int) else nodes[sc["to"][0]][sc["to"][1]]
     for i, sv in enumerate(spec["servers"]):
         if sv.get("out") is not None:
             g.target[nodes["server"][i]] = nodes[sv["out"][0]][sv["out"][1]]
     for l, lk in enumerate(spec["links"]):
         g.target[nodes["link"][l]] = nodes["server"][lk["to"]]
     return g, nodes
+
+
+def oracle_graph_schedule(spec, nodes):
+    """spec["schedule"] = [[[kind, index], seconds], ...] -> hso_schedule's (node, ns) list, in call order."""
+    return [(nodes[ref[0]][ref[1]], ns_from_seconds(t)) for ref, t in spec.get("schedule") or []]
 
 
 def lb_params(spec):

@@ -163,6 +163,63 @@ def graph_spec(k):
                 end_s=float(np.round(rng.uniform(3.0, 8.0), 3)), seed=int(rng.integers(1, 10_000)))
 
 
+def lb_graph_spec(k):
+    """graph_spec(k) with one to three LoadBalancers wired INTO it (round 6: several LoadBalancers, a LoadBalancer behind Servers and
+    routers, `schedule()` on such graphs).  k % 3 != 0: every Source hands out client ids (ClientKeyEventProvider), the LoadBalancers
+    are ConsistentHash / RoundRobin anywhere and Random right behind Sources (a Random LoadBalancer chooses by the draw of a Source
+    that aims at it).  k % 3 == 0: plain Sources, RoundRobin LoadBalancers only, plus Requests `schedule()`d for Servers, routers,
+    links and the LoadBalancers themselves.  Backends of a LoadBalancer that a Server or router feeds have larger indices than the
+    feeders (no zero-delay cycles, as in graph_spec)."""
+    spec = graph_spec(k)
+    rng = np.random.default_rng(79_000 + k)
+    keyed = k % 3 != 0
+    n_srv, n_rtr = len(spec["servers"]), len(spec["routers"])
+    lbs = []
+    for j in range(int(rng.integers(1, 4))):
+        strategy = str(rng.choice(["chash", "round_robin", "random"] if keyed else ["round_robin"]))
+        nb = int(rng.integers(1, min(4, n_srv) + 1))
+        lo = int(rng.integers(0, n_srv - nb + 1))
+        backends = sorted(int(b) for b in rng.choice(np.arange(lo, n_srv), size=nb, replace=False))
+        rng.shuffle(backends)
+        lbs.append(dict(strategy=strategy, vnodes=int(rng.choice([3, 17, 100])), backends=[int(b) for b in backends]))
+    inner = [j for j, lb in enumerate(lbs) if lb["strategy"] != "random"]        # LoadBalancers that entities may forward to
+    for i, sv in enumerate(spec["servers"]):
+        ok = [j for j in inner if min(lbs[j]["backends"]) > i]
+        if ok and rng.random() < 0.35:
+            sv["out"] = ["lb", int(rng.choice(ok))]
+    for r, rt in enumerate(spec["routers"]):
+        feeders = [i for i, sv in enumerate(spec["servers"]) if sv["out"] == ["router", r]]
+        lo = (max(feeders) + 1) if feeders else 0
+        ok = [j for j in inner if min(lbs[j]["backends"]) >= lo]
+        for t in rt["targets"]:
+            if ok and rng.random() < 0.25:
+                t[0], t[1] = "lb", int(rng.choice(ok))
+    for sc in spec["sources"]:
+        if keyed:
+            sc["n_clients"] = int(rng.choice([5, 50, 1000]))
+        if rng.random() < 0.6:
+            j = int(rng.integers(0, len(lbs)))
+            sc["to"] = ["lb", j]
+            if lbs[j]["strategy"] == "random":
+                sc["n_clients"] = len(lbs[j]["backends"])
+    for j, lb in enumerate(lbs):                                  # every LoadBalancer sees traffic
+        if not any(sc["to"] == ["lb", j] for sc in spec["sources"]):
+            nc = len(lb["backends"]) if lb["strategy"] == "random" else int(rng.choice([5, 50, 1000])) if keyed else 0
+            spec["sources"].append(dict(kind="poisson", rate=float(rng.choice([2.0, 6.0])), to=["lb", j], **({"n_clients": nc} if nc else {})))
+    spec["lbs"] = lbs
+    if not keyed:
+        end = spec["end_s"]
+        pools = [["server", n_srv], ["router", n_rtr], ["link", len(spec["links"])], ["lb", len(lbs)], ["lb", len(lbs)]]
+        sched = []
+        for _ in range(int(rng.integers(2, 9))):
+            kind, cnt = pools[int(rng.integers(0, len(pools)))]
+            t = float(rng.choice([0.0, 0.5, 0.5, 1.0, float(np.round(rng.uniform(0.0, end), 3)), end, end + 0.5]))
+            sched.append([[kind, int(rng.integers(0, cnt))], t])
+        spec["schedule"] = sched
+    spec["name"] = f"lb_graph_{k}"
+    return spec
+
+
 def tie_spec(k):
     """Tie storms: lock-step constant-rate sources, constant service times that are multiples of one another, Requests
     scheduled at the start instant and at the sources' own tick times, c up to 16, zero-capacity queues -- every same-nanosecond

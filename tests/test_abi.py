@@ -33,7 +33,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_abi_version_and_struct_sizes(lib):
-    assert lib.hs_abi_version() == N.ABI_VERSION == 15
+    assert lib.hs_abi_version() == N.ABI_VERSION == 16
     assert C.sizeof(N.Config) == 56
     assert N.EV_KINDS == 15 and len(N.EV_NAMES) == 15
     assert C.sizeof(N.Summary) == 8 * (1 + 15 + 1 + 1 + 1 + 1) + 8 + 8 + 8 + 8 + 8
@@ -41,7 +41,7 @@ def test_abi_version_and_struct_sizes(lib):
     assert C.sizeof(N.LbConfig) == 64 and C.sizeof(N.LbSources) == 56 and C.sizeof(N.LbBackends) == 64
     assert C.sizeof(N.LbStats) == 88
     assert C.sizeof(N.Network) == 160 and C.sizeof(N.NetStats) == 4 * 8
-    assert C.sizeof(N.GraphConfig) == 64 and C.sizeof(N.GraphNodes) == 168 and C.sizeof(N.GraphStats) == 120
+    assert C.sizeof(N.GraphConfig) == 64 and C.sizeof(N.GraphNodes) == 208 and C.sizeof(N.GraphStats) == 128
 
 
 def test_no_gpu_means_loud_failure(lib):

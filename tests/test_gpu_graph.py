@@ -13,7 +13,7 @@ import helpers as H
 from happy_simulator_amd import _native as N
 from happy_simulator_amd.graph_engine import GeneralGraph, GraphEngine
 from oracle import hs_oracle as O
-from random_specs import graph_spec
+from random_specs import graph_spec, lb_graph_spec
 
 pytestmark = pytest.mark.gpu
 
@@ -39,6 +39,14 @@ def _compare_with_oracle(spec, sim, ents, r, nodes):
         np.testing.assert_array_equal(ents["sinks"][j]._created_ns, created, err_msg=f"sink {j} created_at")
     for rt in ents["routers"]:                                   # target_counts (random_router.py:37): consistent with what was routed
         assert sum(rt.target_counts.values()) == rt.stats_routed
+    for j, nd in enumerate(nodes.get("lb", [])):                 # LoadBalancer.stats / BackendInfo.total_requests / RoundRobin._index
+        lb, st = ents["lbs"][j], ents["lbs"][j].stats
+        np.testing.assert_array_equal([st.requests_received, st.requests_forwarded, st.requests_failed, st.no_backend_available,
+                                       lb._in_flight_count], r.lbs[nd]["stats"], err_msg=f"lb {j}")
+        np.testing.assert_array_equal([lb.get_backend_info(b).total_requests for b in lb.all_backends], r.lbs[nd]["total_requests"],
+                                      err_msg=f"lb {j} backends")
+        if spec["lbs"][j]["strategy"] == "round_robin":
+            assert lb.strategy._index == st.requests_forwarded
 
 
 @pytest.mark.parametrize("name", H.golden_names("graph"))
@@ -60,6 +68,14 @@ def test_general_graphs_match_the_live_reference_goldens(name):
         np.testing.assert_array_equal(sk.completion_ns, gt, err_msg=f"sink {j}")
         np.testing.assert_array_equal(sk.latencies_array, glat, err_msg=f"sink {j} latencies")
         assert sk.latencies_s == list(glat)
+    for j, lb in enumerate(ents["lbs"]):                          # (graph_three_load_balancers, graph_round_robin_schedule)
+        st = lb.stats
+        np.testing.assert_array_equal([st.requests_received, st.requests_forwarded, st.requests_failed, st.no_backend_available,
+                                       lb._in_flight_count], gold.lb_stats[j], err_msg=f"lb {j}")
+        lo, hi = gold.lb_backend_off[j], gold.lb_backend_off[j + 1]
+        np.testing.assert_array_equal([lb.get_backend_info(b).total_requests for b in lb.all_backends],
+                                      gold.lb_backend_total_requests[lo:hi], err_msg=f"lb {j} backends")
+        assert getattr(lb.strategy, "_index", -1) == gold.lb_rr_index[j]
 
 
 @pytest.mark.parametrize("block", range(8))
@@ -78,6 +94,43 @@ def test_random_general_graphs_match_the_oracle(block):
         _compare_with_oracle(spec, sim, ents, r, nodes)
         ran += 1
     assert ran >= 30
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_graphs_with_several_load_balancers_match_the_oracle(block):
+    """random_specs.lb_graph_spec (pinned on the live reference by tests/test_oracle_live_reference.py): one to three LoadBalancers --
+    ConsistentHash, RoundRobin, Random -- behind Sources, Servers and routers, Requests `schedule()`d on key-less graphs incl. for
+    the LoadBalancers themselves (components/load_balancer/load_balancer.py:347-473, core/simulation.py:195-206)."""
+    for k in range(block * 30, block * 30 + 30):
+        spec = lb_graph_spec(k)
+        sim, ents = GS.build(spec)
+        assert isinstance(sim.lowered(), GeneralGraph)           # (lower_lb takes ONE LoadBalancer right behind every Source)
+        g_o, nodes = H.oracle_graph(spec)
+        r = O.run(g_o, H.ns_from_seconds(spec["end_s"]), seed=spec["seed"], schedule=H.oracle_graph_schedule(spec, nodes))
+        sim.run()
+        _compare_with_oracle(spec, sim, ents, r, nodes)
+        assert sum(lb.stats.requests_forwarded for lb in ents["lbs"]) > 0
+
+
+def test_key_less_requests_for_a_key_based_load_balancer_are_refused_by_name():
+    """A Request without a client id at a ConsistentHash / Random LoadBalancer: the reference falls back to a RoundRobin of the
+    strategy's own / the process-wide generator -- refused by name, for plain Sources and for `schedule()`d Requests."""
+    sink = hs.Sink("k")
+    servers = [hs.Server(f"srv{i}", service_time=hs.ExponentialLatency(0.01), downstream=sink) for i in range(3)]
+    lb = hs.LoadBalancer("lb", backends=servers[1:], strategy=hs.ConsistentHash(virtual_nodes=5))
+    servers[0].downstream = lb
+    keyed = hs.Source.poisson(rate=5, event_provider=hs.ClientKeyEventProvider(servers[0], n_clients=7), name="a")
+    plain = hs.Source.poisson(rate=5, target=servers[0], name="b")
+    with pytest.raises(hs.UnsupportedTopology, match="must come from a ClientKeyEventProvider"):
+        hs.Simulation(duration=1, sources=[keyed, plain], entities=[*servers, lb, sink]).lowered()
+    sim = hs.Simulation(duration=1, sources=[keyed], entities=[*servers, lb, sink])
+    sim.schedule(hs.Event(time=hs.Instant.from_seconds(0.5), event_type="Request", target=servers[0]))
+    with pytest.raises(hs.UnsupportedTopology, match="carries no client id"):
+        sim.run()
+    sim = hs.Simulation(duration=1, sources=[keyed], entities=[*servers, lb, sink])
+    sim.schedule(hs.Event(time=hs.Instant.from_seconds(0.5), event_type="Request", target=servers[2]))     # (cannot reach the LoadBalancer)
+    sim.run()
+    assert lb.stats.requests_received == servers[0]._requests_completed > 0
 
 
 def test_scheduled_requests_on_a_general_graph_take_the_pre_run_indices():

@@ -157,8 +157,8 @@ def test_write_back_puts_the_node_results_on_the_objects():
 
 def test_abi_structs_of_the_graph_entry_points():
     assert C.sizeof(N.GraphConfig) == 64
-    assert C.sizeof(N.GraphNodes) == 8 + 15 * 8 + 8 + 4 * 8
-    assert C.sizeof(N.GraphStats) == 15 * 8
+    assert C.sizeof(N.GraphNodes) == 8 + 15 * 8 + 8 + 9 * 8
+    assert C.sizeof(N.GraphStats) == 16 * 8
     L = N.lib()
     for sym in ("hs_graph_create", "hs_graph_schedule", "hs_graph_run_until", "hs_graph_get_summary", "hs_graph_get_stats",
                 "hs_graph_read_records", "hs_graph_last_error", "hs_graph_destroy"):

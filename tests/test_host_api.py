@@ -253,12 +253,17 @@ class TestLoadBalancerLowering:
         plain = hs.Source.poisson(rate=5, target=lb)
         with pytest.raises(hs.UnsupportedTopology, match="ClientKeyEventProvider"):
             hs.Simulation(duration=1, sources=[plain], entities=[lb, *nodes, sinks[0]]).lowered()
+        # outside the pipeline's shape: lower_lb refuses by name, Simulation takes the graph to the single-heap path (round 6)
+        from happy_simulator_amd.graph_engine import GeneralGraph
         nodes[1].downstream = hs.Sink("other")
         with pytest.raises(hs.UnsupportedTopology, match="share ONE Sink"):
-            hs.Simulation(duration=1, sources=srcs, entities=[lb, *nodes]).lowered()
+            L.lower_lb(srcs, [lb, *nodes], lb)
+        sim = hs.Simulation(duration=1, sources=srcs, entities=[lb, *nodes])
+        assert isinstance(sim.lowered(), GeneralGraph) and "share ONE Sink" in sim._station_refusal
         srcs, lb, nodes, sinks = self._topology()
         with pytest.raises(hs.UnsupportedTopology, match="not part of the load-balancer topology"):
-            hs.Simulation(duration=1, sources=srcs, entities=[lb, *nodes, sinks[0], hs.Server("stray")]).lowered()
+            L.lower_lb(srcs, [lb, *nodes, sinks[0], hs.Server("stray")], lb)
+        assert isinstance(hs.Simulation(duration=1, sources=srcs, entities=[lb, *nodes, sinks[0], hs.Server("stray")]).lowered(), GeneralGraph)
         lb2 = hs.LoadBalancer("lb2", backends=[hs.Sink("k")], strategy=hs.ConsistentHash())
         s2 = hs.Source.poisson(rate=1, event_provider=hs.ClientKeyEventProvider(lb2, n_clients=5))
         with pytest.raises(hs.UnsupportedTopology, match="only Server backends"):
@@ -275,8 +280,11 @@ class TestLoadBalancerLowering:
         kinds, idx, met, iv = g.probe_arrays()
         assert kinds == [0, 1, 0] and idx == [2, 1, 0] and iv == [0.5, 0.25, 1.0]
         assert met == [N.PROBE_METRICS["depth"], N.PROBE_METRICS["events_received"], N.PROBE_METRICS["active_requests"]]
-        for target, metric, msg in ((srcs[0], "generated_count", "a Source with stop_after keeps ticking"),
-                                    (lb, "depth", "the Sources, the backend Servers and the Sinks are sampled"),
+        from happy_simulator_amd.graph_engine import GeneralGraph
+        pr, _ = hs.Probe.on(srcs[0], "generated_count")        # (a Source with stop_after keeps ticking: the pipeline's tick log does not
+        sim = hs.Simulation(duration=1, sources=srcs, entities=[lb, *nodes, *sinks], probes=[pr])      # hold that; the single heap does)
+        assert isinstance(sim.lowered(), GeneralGraph) and "a Source with stop_after keeps ticking" in sim._station_refusal
+        for target, metric, msg in ((lb, "depth", "the Sources, the backend Servers and the Sinks are sampled"),
                                     (nodes[1], "events_received", "not an attribute of Server"),
                                     (sinks[0], "depth", "not an attribute of Sink")):
             pr, _ = hs.Probe.on(target, metric)

@@ -101,10 +101,16 @@ def check_oracle_against_graph_golden(gold):
     Sink record (time and latency), bit for bit."""
     spec = gold.spec
     g, nodes = H.oracle_graph(spec)
-    r = O.run(g, H.ns_from_seconds(spec["end_s"]), seed=spec["seed"])
+    r = O.run(g, H.ns_from_seconds(spec["end_s"]), seed=spec["seed"], schedule=H.oracle_graph_schedule(spec, nodes))
     assert [r.events_processed] == gold.meta["total_events"]
     assert [r.final_time_ns] == gold.meta["final_ns"]
     np.testing.assert_array_equal(r.generated[nodes["source"]], gold.generated)
+    for j, nd in enumerate(nodes["lb"]):                     # LoadBalancer.stats, BackendInfo.total_requests, RoundRobin._index
+        np.testing.assert_array_equal(r.lbs[nd]["stats"], gold.lb_stats[j], err_msg=f"lb {j}")
+        lo, hi = gold.lb_backend_off[j], gold.lb_backend_off[j + 1]
+        np.testing.assert_array_equal(r.lbs[nd]["total_requests"], gold.lb_backend_total_requests[lo:hi], err_msg=f"lb {j} backends")
+        if spec["lbs"][j]["strategy"] == "round_robin":
+            assert r.lbs[nd]["stats"][1] == gold.lb_rr_index[j]
     srv = nodes["server"]
     for k, arr in (("accepted", r.accepted), ("dropped", r.dropped), ("completed", r.completed), ("rejected", r.rejected),
                    ("depth", r.depth), ("active", r.active), ("total_service_s", r.total_service_s)):

@@ -20,7 +20,7 @@ if not os.path.isdir("/root/reference/happysimulator"):
 
 sys.path.insert(0, H.GOLDEN_DIR)
 import make_golden as MG  # noqa: E402  (imports the reference through refshim)
-from random_specs import (graph_spec, jitter_ring_spec, lb_probe_spec, lb_profile_spec, lb_spec as _lb_spec, lb_strategy_spec, lb_workers_spec, multi_source_ring_spec, multi_source_spec, ring_spec as _ring_spec, station_spec as _station_spec,  # noqa: E402
+from random_specs import (graph_spec, jitter_ring_spec, lb_graph_spec, lb_probe_spec, lb_profile_spec, lb_spec as _lb_spec, lb_strategy_spec, lb_workers_spec, multi_source_ring_spec, multi_source_spec, ring_spec as _ring_spec, station_spec as _station_spec,  # noqa: E402
                           tie_spec)
 
 
@@ -284,6 +284,15 @@ def test_oracle_equals_live_reference_on_random_graphs_beyond_the_engines(k):
     """random_specs.graph_spec: routers with up to 8 targets incl. Servers and several upstreams, links with several senders, Servers
     behind Servers inside link networks, more than four Sources per Server -- live reference == oracle."""
     out, meta = MG.run_graph_case(graph_spec(k))
+    check_oracle_against_graph_golden(H.Golden.from_results(out, meta))
+
+
+@pytest.mark.parametrize("k", range(60))
+def test_oracle_equals_live_reference_on_graphs_with_several_load_balancers(k):
+    """random_specs.lb_graph_spec: one to three LoadBalancers (ConsistentHash / RoundRobin / Random) behind Sources, Servers and
+    routers of a general graph, `schedule()`d Requests on the key-less ones -- LoadBalancer.stats, BackendInfo.total_requests,
+    RoundRobin._index and everything test_..._on_random_graphs_beyond_the_engines compares: live reference == oracle."""
+    out, meta = MG.run_graph_case(lb_graph_spec(k))
     check_oracle_against_graph_golden(H.Golden.from_results(out, meta))
 
 
