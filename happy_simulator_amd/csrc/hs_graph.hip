@@ -215,8 +215,7 @@ __device__ inline int64_t next_arrival(const GCtl &c, int n) {
     return a2;
 }
 
-__global__ void __launch_bounds__(64) hs_graph_run(GCtl c) {
-    __shared__ GEvent lheap[kLdsHeap];
+__device__ __forceinline__ void graph_loop(const GCtl &c, GEvent *lheap) {
     GVars &V = *c.V;
     const int lane = threadIdx.x;
     {   // the heap's head comes into LDS (all 64 lanes copy; 8 bytes per lane and step)
@@ -496,6 +495,19 @@ __global__ void __launch_bounds__(64) hs_graph_run(GCtl c) {
         const uint64_t *src = reinterpret_cast<const uint64_t *>(lheap);
         for (long long i = lane; i < n8; i += 64) dst[i] = src[i];
     }
+}
+
+__global__ void __launch_bounds__(64) hs_graph_run(GCtl c) {
+    __shared__ GEvent lheap[kLdsHeap];
+    graph_loop(c, lheap);
+}
+
+// Independent graphs -- the replicas / sweep points of parallel/runner.py:82-142 -- side by side: one workgroup (one heap) each, one
+// per CU at a time (the heap's LDS window), as many as the device has CUs at once.
+__global__ void __launch_bounds__(64) hs_graph_run_batch(const GCtl *cs) {
+    __shared__ GEvent lheap[kLdsHeap];
+    const GCtl c = cs[blockIdx.x];
+    graph_loop(c, lheap);
 }
 
 }  // namespace graph
@@ -846,11 +858,8 @@ static int build_tables(hs_graph *g, int64_t horizon) {
     return gfail(g, HS_E_OVERFLOW, "a tick table overflowed after eight doublings");
 }
 
-extern "C" {
-
-int hs_graph_run_until(hs_graph *g, int64_t end_ns) {
-    if (!g) return gfail(g, HS_E_INVALID, "null handle");
-    HSG_HIP(g, hipSetDevice(g->cfg.device));
+// What a run needs before its first launch: tick tables up to the end, the schedule()d entries on the device.
+static int prepare_run(hs_graph *g, int64_t end_ns) {
     GCtl &c = g->ctl;
     // table-driven streams: up to this end when it is a real horizon, else (an auto-terminating run) a minute at a time
     int64_t table_h = end_ns;
@@ -876,53 +885,122 @@ int hs_graph_run_until(hs_graph *g, int64_t end_ns) {
     c.sched_node = g->d_sched_node; c.sched_t = g->d_sched_t; c.n_sched = ns;
     c.end_ns = end_ns;
     g->launches = 0;
+    return HS_OK;
+}
+
+// What a launch left (the device is idle): enlarge what it ran out of; *done = the run reached its end.
+static int after_launch(hs_graph *g, bool *done) {
+    GCtl &c = g->ctl;
+    g->launches++;
+    GVars v;
+    HSG_HIP(g, hipMemcpy(&v, c.V, sizeof v, hipMemcpyDeviceToHost));
+    if (v.status & kBadKind) return gfail(g, HS_E_INVALID, "an event of unknown kind reached the loop (internal error)");
+    if (g->cfg.max_events > 0 && v.processed > g->cfg.max_events)
+        return gfail(g, HS_E_UNSUPPORTED, "the run exceeds max_events = %lld events on the single-heap path (one lane, ~1 us per event); "
+                     "raise max_events, or bring the graph into the shape the station engines take", (long long)g->cfg.max_events);
+    if (v.status & kGrowHeap) {
+        const long long nc = c.heap_cap * 2;
+        int rc = grow(g, &c.heap, c.heap_cap, nc); if (rc) return rc;
+        c.heap_cap = nc;
+    }
+    if (v.status & kGrowReq) {
+        if (c.req_cap >= (1 << 30)) return gfail(g, HS_E_OVERFLOW, "more than 2^30 Requests alive at once");
+        const int nc = c.req_cap * 2;
+        int rc = grow(g, &c.reqs, c.req_cap, nc); if (rc) return rc;
+        c.req_cap = nc;
+    }
+    if (v.status & kGrowTicks) {
+        // a table-driven stream reached the end of its table: twice the span (never beyond the end the caller asked for + the two
+        // ticks every table holds beyond its horizon)
+        const int64_t span = g->tick_horizon - g->cfg.start_ns;
+        int64_t nh = g->cfg.start_ns + (span > 0 ? 2 * span : 1000000000ll);
+        if (nh <= g->tick_horizon) return gfail(g, HS_E_OVERFLOW, "the tick tables cannot grow any further");
+        const int rc = build_tables(g, nh);
+        if (rc) return rc;
+    }
+    if (v.status & kGrowRec) {
+        const long long nc = c.rec_cap * 2;
+        int rc;
+        if ((rc = grow(g, &c.rec_node, c.rec_cap, nc))) return rc;
+        if ((rc = grow(g, &c.rec_t, c.rec_cap, nc))) return rc;
+        if ((rc = grow(g, &c.rec_cr, c.rec_cap, nc))) return rc;
+        c.rec_cap = nc;
+    }
+    *done = v.status == kDone;
+    return HS_OK;
+}
+
+extern "C" {
+
+int hs_graph_run_until(hs_graph *g, int64_t end_ns) {
+    if (!g) return gfail(g, HS_E_INVALID, "null handle");
+    HSG_HIP(g, hipSetDevice(g->cfg.device));
+    {
+        const int rc = prepare_run(g, end_ns);
+        if (rc) return rc;
+    }
     HSG_HIP(g, hipEventRecord(g->ev_a, g->stream));
-    for (;;) {
-        hipLaunchKernelGGL(hs_graph_run, dim3(1), dim3(64), 0, g->stream, c);
+    for (bool done = false; !done;) {
+        hipLaunchKernelGGL(hs_graph_run, dim3(1), dim3(64), 0, g->stream, g->ctl);
         HSG_HIP(g, hipGetLastError());
-        g->launches++;
         HSG_HIP(g, hipStreamSynchronize(g->stream));
-        GVars v;
-        HSG_HIP(g, hipMemcpy(&v, c.V, sizeof v, hipMemcpyDeviceToHost));
-        if (v.status & kBadKind) return gfail(g, HS_E_INVALID, "an event of unknown kind reached the loop (internal error)");
-        if (g->cfg.max_events > 0 && v.processed > g->cfg.max_events)
-            return gfail(g, HS_E_UNSUPPORTED, "the run exceeds max_events = %lld events on the single-heap path (one lane, ~1 us per event); "
-                         "raise max_events, or bring the graph into the shape the station engines take", (long long)g->cfg.max_events);
-        if (v.status & kGrowHeap) {
-            const long long nc = c.heap_cap * 2;
-            int rc = grow(g, &c.heap, c.heap_cap, nc); if (rc) return rc;
-            c.heap_cap = nc;
-        }
-        if (v.status & kGrowReq) {
-            if (c.req_cap >= (1 << 30)) return gfail(g, HS_E_OVERFLOW, "more than 2^30 Requests alive at once");
-            const int nc = c.req_cap * 2;
-            int rc = grow(g, &c.reqs, c.req_cap, nc); if (rc) return rc;
-            c.req_cap = nc;
-        }
-        if (v.status & kGrowTicks) {
-            // a table-driven stream reached the end of its table: twice the span (never beyond the end the caller asked for + the two
-            // ticks every table holds beyond its horizon)
-            const int64_t span = g->tick_horizon - g->cfg.start_ns;
-            int64_t nh = g->cfg.start_ns + (span > 0 ? 2 * span : 1000000000ll);
-            if (nh <= g->tick_horizon) return gfail(g, HS_E_OVERFLOW, "the tick tables cannot grow any further");
-            const int rc = build_tables(g, nh);
-            if (rc) return rc;
-        }
-        if (v.status & kGrowRec) {
-            const long long nc = c.rec_cap * 2;
-            int rc;
-            if ((rc = grow(g, &c.rec_node, c.rec_cap, nc))) return rc;
-            if ((rc = grow(g, &c.rec_t, c.rec_cap, nc))) return rc;
-            if ((rc = grow(g, &c.rec_cr, c.rec_cap, nc))) return rc;
-            c.rec_cap = nc;
-        }
-        if (v.status == kDone) break;
+        const int rc = after_launch(g, &done);
+        if (rc) return rc;
     }
     HSG_HIP(g, hipEventRecord(g->ev_b, g->stream));
     HSG_HIP(g, hipStreamSynchronize(g->stream));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, g->ev_a, g->ev_b) == hipSuccess) g->last_run_ms = ms;
     g->ran = true;
+    return HS_OK;
+}
+
+int hs_graph_run_many(hs_graph *const *gs, int32_t n, int64_t end_ns) {
+    if (!gs || n < 1) return gfail(nullptr, HS_E_INVALID, "hs_graph_run_many: no handles");
+    for (int i = 0; i < n; ++i) {
+        if (!gs[i]) return gfail(nullptr, HS_E_INVALID, "hs_graph_run_many: handle %d is null", i);
+        if (gs[i]->cfg.device != gs[0]->cfg.device) return gfail(gs[i], HS_E_INVALID, "hs_graph_run_many: handle %d lives on another device", i);
+        for (int j = 0; j < i; ++j) if (gs[j] == gs[i]) return gfail(gs[i], HS_E_INVALID, "hs_graph_run_many: handle %d is listed twice", i);
+    }
+    hs_graph *g0 = gs[0];
+    HSG_HIP(g0, hipSetDevice(g0->cfg.device));
+    for (int i = 0; i < n; ++i) {
+        const int rc = prepare_run(gs[i], end_ns);
+        if (rc) { if (gs[i] != g0) gfail(g0, rc, "graph %d: %s", i, gs[i]->error.c_str()); return rc; }
+    }
+    GCtl *d_ctl = nullptr;
+    HSG_HIP(g0, hipMalloc(&d_ctl, (size_t)n * sizeof(GCtl)));
+    std::vector<int> pending((size_t)n);
+    for (int i = 0; i < n; ++i) pending[(size_t)i] = i;
+    std::vector<GCtl> h_ctl;
+    int rc = HS_OK;
+    hipError_t he = hipEventRecord(g0->ev_a, g0->stream);
+    while (he == hipSuccess && rc == HS_OK && !pending.empty()) {
+        h_ctl.clear();
+        for (int i : pending) h_ctl.push_back(gs[i]->ctl);
+        if ((he = hipMemcpy(d_ctl, h_ctl.data(), h_ctl.size() * sizeof(GCtl), hipMemcpyHostToDevice)) != hipSuccess) break;
+        hipLaunchKernelGGL(hs_graph_run_batch, dim3((unsigned)pending.size()), dim3(64), 0, g0->stream, (const GCtl *)d_ctl);
+        if ((he = hipGetLastError()) != hipSuccess) break;
+        if ((he = hipStreamSynchronize(g0->stream)) != hipSuccess) break;
+        std::vector<int> left;
+        for (int i : pending) {
+            bool done = false;
+            rc = after_launch(gs[i], &done);
+            if (rc) { if (gs[i] != g0) gfail(g0, rc, "graph %d: %s", i, gs[i]->error.c_str()); break; }
+            if (done) gs[i]->ran = true; else left.push_back(i);
+        }
+        pending.swap(left);
+    }
+    if (he == hipSuccess && rc == HS_OK) {
+        he = hipEventRecord(g0->ev_b, g0->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(g0->stream);
+        float ms = 0.f;
+        if (he == hipSuccess && hipEventElapsedTime(&ms, g0->ev_a, g0->ev_b) == hipSuccess)
+            for (int i = 0; i < n; ++i) gs[i]->last_run_ms = ms;          // (the batch's wall time: the replicas ran side by side)
+    }
+    (void)hipFree(d_ctl);
+    if (rc) return rc;
+    if (he != hipSuccess) return gfail(g0, HS_E_HIP, "hs_graph_run_many: %s", hipGetErrorString(he));
     return HS_OK;
 }
 

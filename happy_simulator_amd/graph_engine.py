@@ -112,6 +112,15 @@ class GraphEngine:
     def run_until(self, end_ns: int) -> None:
         self._check(self._lib.hs_graph_run_until(self._h, int(end_ns)))
 
+    @staticmethod
+    def run_many(engines: list, end_ns: int) -> None:
+        """hs_graph_run_many: independent graphs (replicas, sweep points) to `end_ns` side by side, one workgroup each."""
+        if not engines:
+            return
+        hs_ = (C.c_void_p * len(engines))(*[e._h for e in engines])
+        rc = engines[0]._lib.hs_graph_run_many(hs_, len(engines), int(end_ns))
+        engines[0]._check(rc)
+
     def summary(self) -> N.Summary:
         s = N.Summary()
         self._check(self._lib.hs_graph_get_summary(self._h, C.byref(s)))

@@ -22,6 +22,7 @@ from . import _native as N
 from .core.temporal import Instant
 from .engine import StationArrays, StationEngine
 from .entities import Probe
+from .graph_engine import GeneralGraph, GraphEngine
 from .lowering import UnsupportedTopology, write_back, write_back_probes
 from .simulation import Simulation, entity_summaries
 from .summary import SimulationSummary
@@ -139,10 +140,26 @@ def _run_independent(sims: list[Simulation], seeds: list[int], device: int = 0,
     """Run independent Simulations as one engine launch (each Simulation must lower to a single station).
     `stream_bases`: entity stream numbering per Simulation (default 0: every replica numbers its entities from 0)."""
     graphs = [s.lowered() for s in sims]
-    for s, g in zip(sims, graphs):
-        if not hasattr(g, "stations") or len(g.stations) != 1:        # (graph_engine.GeneralGraph: no stations at all)
-            raise UnsupportedTopology(
-                "batched replicas need one station per Simulation; run multi-station Simulations with .run()")
+    one_station = [i for i, g in enumerate(graphs) if hasattr(g, "stations") and len(g.stations) == 1]
+    if len(one_station) != len(sims):
+        # Simulations that are more than one station -- what parallel/runner.py:82-142 hands to a worker process each.  General
+        # graphs (graph_engine.GeneralGraph) run SIDE BY SIDE on the device, one workgroup and one heap each
+        # (hs_graph_run_many); a station network or a load-balancer pipeline fills the device on its own and takes its turn.
+        if stream_bases is not None:
+            raise UnsupportedTopology("stream_bases number the entities of one-station replicas only")
+        out: list = [None] * len(sims)
+        for i, s in enumerate(sims):
+            s._seed, s._device = int(seeds[i]), device
+        if one_station:
+            for i, summ in zip(one_station, _run_independent([sims[i] for i in one_station], [seeds[i] for i in one_station], device)):
+                out[i] = summ
+        general = [i for i, g in enumerate(graphs) if isinstance(g, GeneralGraph)]
+        for i, summ in zip(general, _run_general_batch([sims[i] for i in general], [graphs[i] for i in general])):
+            out[i] = summ
+        for i, s in enumerate(sims):
+            if out[i] is None:
+                out[i] = s.run()
+        return out
     ends = {s._end_time.nanoseconds for s in sims}
     starts = {s._start_time.nanoseconds for s in sims}
     if len(ends) != 1 or len(starts) != 1:
@@ -192,6 +209,31 @@ def _run_independent(sims: list[Simulation], seeds: list[int], device: int = 0,
         s._summary = s._build_summary(wall / len(sims))
         out.append(s._summary)
     return out
+
+
+def _run_general_batch(sims: list[Simulation], graphs: list) -> list[SimulationSummary]:
+    """Independent general graphs with one end each: engines created one by one, run to their ends in ONE batch per distinct end
+    (hs_graph_run_many), results bound like Simulation._run_general binds them."""
+    if not sims:
+        return []
+    wall0 = _time.monotonic()
+    engines, plans = [], []
+    try:
+        for s, g in zip(sims, graphs):
+            auto = s._end_time == Instant.Infinity
+            if auto and (s._sources or s._probes):
+                raise UnsupportedTopology("end_time = Infinity with Sources or Probes never terminates (their ticks are primary events, "
+                                          "in the reference too); pass end_time/duration")
+            end_ns, start_ns, sched, cancelled_ns = s._general_prepare(g, auto)
+            engines.append(s._general_engine(g, start_ns, sched))
+            plans.append((end_ns, cancelled_ns))
+        for end_ns in sorted({p[0] for p in plans}):
+            GraphEngine.run_many([e for e, p in zip(engines, plans) if p[0] == end_ns], end_ns)
+        wall = (_time.monotonic() - wall0) / len(sims)
+        return [s._general_finish(g, e, p[0], p[1], wall) for s, g, e, p in zip(sims, graphs, engines, plans)]
+    finally:
+        for e in engines:
+            e.close()
 
 
 class ParallelRunner:

@@ -299,6 +299,14 @@ class Simulation:
 
     def _run_general(self, g: GeneralGraph, auto: bool, wall0: float) -> SimulationSummary:
         """A graph outside the station shape (graph_engine.lower_general) on the device's single-heap loop."""
+        end_ns, start_ns, sched, cancelled_ns = self._general_prepare(g, auto)
+        with self._general_engine(g, start_ns, sched) as eng:
+            eng.run_until(end_ns)
+            return self._general_finish(g, eng, end_ns, cancelled_ns, _time.monotonic() - wall0)
+
+    def _general_prepare(self, g: GeneralGraph, auto: bool):
+        """What the single-heap engine is created with: (end ns, start ns, the schedule()d Requests as (node, ns), the cancelled
+        Events' times) -- or the refusal of a run it does not take."""
         end_ns = self._end_time.nanoseconds if not auto else (1 << 61)
         start_ns = self._start_time.nanoseconds
         a = g.arrays
@@ -335,20 +343,30 @@ class Simulation:
                 warnings.warn(f"Time travel detected: {ev!r} lies before the simulation start; skipping event", stacklevel=3)
                 continue
             sched.append((i, ev.time.nanoseconds))
-        with GraphEngine(a, seed=self._seed, start_ns=start_ns, device=self._device, max_events=self._max_graph_events) as eng:
+        return end_ns, start_ns, sched, cancelled_ns
+
+    def _general_engine(self, g: GeneralGraph, start_ns: int, sched) -> GraphEngine:
+        eng = GraphEngine(g.arrays, seed=self._seed, start_ns=start_ns, device=self._device, max_events=self._max_graph_events)
+        try:
             for node, t in sched:
                 eng.schedule(node, t)
-            eng.run_until(end_ns)
-            es = eng.summary()
-            stats = eng.stats()
-            rec = eng.records()
+        except BaseException:
+            eng.close()
+            raise
+        return eng
+
+    def _general_finish(self, g: GeneralGraph, eng: GraphEngine, end_ns: int, cancelled_ns, wall_s: float) -> SimulationSummary:
+        """The run's results off the engine onto the user's objects (the engine may have run alone or in a batch)."""
+        es = eng.summary()
+        stats = eng.stats()
+        rec = eng.records()
         write_back_general(g, stats, *rec, device=self._device)
         drained = es.final_time_ns <= end_ns
         self._events_cancelled = sum(1 for t in cancelled_ns if drained or t <= es.final_time_ns)
         self._engine_summary = es
         self._events_processed = es.events_processed
         self._current_time = Instant(es.final_time_ns)
-        self._summary = self._build_summary(_time.monotonic() - wall0)
+        self._summary = self._build_summary(wall_s)
         return self._summary
 
     def _run_plain(self, g: LoweredGraph, arrays, end_ns: int, wall0: float, probe_where=None) -> SimulationSummary:

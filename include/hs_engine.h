@@ -760,11 +760,18 @@ typedef struct hs_graph_stats {      /* host arrays [n_nodes] (rt_taken: [n_rt])
 int hs_graph_create(const hs_graph_config *cfg, const hs_graph_nodes *nodes, hs_graph **out);
 /* Simulation.schedule(Event(time, "Request", target=<node>)) (core/simulation.py:195-206): the Event was constructed outside
  * the run, so it takes the next index of the process-wide counter behind the Sources' first ticks; context["created_at"] =
- * its own time.  Calls in the order the caller constructed the Events.  `node`: a Server, Sink, link or router. */
+ * its own time.  Calls in the order the caller constructed the Events.  `node`: a Server, Sink, link, router or
+ * LoadBalancer. */
 int hs_graph_schedule(hs_graph *g, int32_t node, int64_t time_ns);
 /* `_execute_until(end)`: pops while the PREVIOUS event's time <= end_ns (so exactly one event beyond the end is processed,
  * core/simulation.py:472); may be called again with a later end (windows, :527-541). */
 int hs_graph_run_until(hs_graph *g, int64_t end_ns);
+/* ParallelRunner.run_sweep / run_replicas (parallel/runner.py:82-142: one worker process per independent Simulation) for graphs of
+ * this path: `n` handles on one device run to `end_ns` SIDE BY SIDE -- one workgroup and one heap each, one launch for all of them
+ * (256 at a time, the heap's LDS window keeps one per CU), relaunched for the ones that have to grow a buffer.  Every handle ends in
+ * exactly the state hs_graph_run_until(handle, end_ns) would leave; the run's wall time (hs_summary.device_ms) is the batch's.  On
+ * an error the first handle's hs_graph_last_error names the graph. */
+int hs_graph_run_many(hs_graph *const *graphs, int32_t n, int64_t end_ns);
 int hs_graph_get_summary(hs_graph *g, hs_summary *out);
 int hs_graph_get_stats(hs_graph *g, hs_graph_stats *out);
 /* Every Sink record of the run in processing order: (Sink node, completion ns, created_at ns).  Returns the number of

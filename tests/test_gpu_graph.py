@@ -168,6 +168,105 @@ def test_windows_over_a_general_graph_equal_one_run():
         np.testing.assert_array_equal(a, b)
 
 
+def test_replicas_of_a_general_graph_run_side_by_side():
+    """ParallelRunner.run_replicas (parallel/runner.py:82-142: one worker process per replica, seeds base_seed + i) over a graph
+    outside the station shape: 300 replicas in one launch of one workgroup each (hs_graph_run_many; more than the 256 the device
+    holds at once) -- replica i == the oracle with seed base_seed + i, every statistic and Sink record."""
+    spec = lb_graph_spec(7)
+    built = []
+
+    def build_fn():
+        sim, ents = GS.build(spec)
+        built.append((sim, ents))
+        return sim
+
+    results = hs.ParallelRunner().run_replicas(build_fn, 300, base_seed=1000)
+    assert len(results) == len(built) == 300 and isinstance(built[0][0].lowered(), GeneralGraph)
+    g_o, nodes = H.oracle_graph(spec)
+    for i, ((sim, ents), res) in enumerate(zip(built, results)):
+        r = O.run(g_o, H.ns_from_seconds(spec["end_s"]), seed=1000 + i, schedule=H.oracle_graph_schedule(spec, nodes))
+        assert res.name == f"replica_{i}" and res.summary.total_events_processed == r.events_processed
+        _compare_with_oracle(spec, sim, ents, r, nodes)
+    assert len({res.summary.total_events_processed for res in results}) > 100        # (the seeds differ)
+
+
+def test_a_sweep_over_different_kinds_of_simulations():
+    """ParallelRunner.run_sweep over Simulations of every kind at once -- general graphs with different ends, a ring of stations (a
+    network engine), a load-balancer pipeline, plain chains: each result == the same Simulation's own run() with that seed."""
+    from random_specs import ring_spec
+    from test_gpu_api import _build_ring
+
+    def ring():
+        spec = ring_spec(3)
+        sources, servers, routers, links, sinks = _build_ring(spec)
+        return hs.Simulation(end_time=hs.Instant.from_seconds(spec["end_s"]), sources=sources, entities=servers + routers + links + sinks)
+
+    def general(k):
+        return lambda: GS.build(lb_graph_spec(k) if k % 2 else graph_spec(k))[0]
+
+    def chain(rate):
+        def fn():
+            sink = hs.Sink("k")
+            srv = hs.Server("s", service_time=hs.ExponentialLatency(0.05), downstream=sink)
+            return hs.Simulation(duration=5, sources=[hs.Source.poisson(rate=rate, target=srv)], entities=[srv, sink])
+        return fn
+
+    def lb_pipeline():
+        sink = hs.Sink("k")
+        servers = [hs.Server(f"srv{j}", service_time=hs.ExponentialLatency(0.05), downstream=sink) for j in range(4)]
+        lb = hs.LoadBalancer("lb", backends=servers, strategy=hs.ConsistentHash(virtual_nodes=20))
+        srcs = [hs.Source.poisson(rate=9, event_provider=hs.ClientKeyEventProvider(lb, n_clients=40), name=f"c{i}") for i in range(3)]
+        return hs.Simulation(duration=4, sources=srcs, entities=[lb, *servers, sink])
+
+    makers = [general(1), chain(7.0), general(4), ring, general(9), lb_pipeline, chain(3.0),
+              general(12), general(1)]
+    configs = [hs.RunConfig(name=f"c{i}", build_fn=fn, seed=500 + 3 * i) for i, fn in enumerate(makers)]
+    results = hs.ParallelRunner().run_sweep(configs)
+    assert [r.name for r in results] == [c.name for c in configs]
+    for cfg, res in zip(configs, results):
+        alone = cfg.build_fn()
+        alone._seed = cfg.seed
+        want = alone.run()
+        assert res.summary.total_events_processed == want.total_events_processed > 0, cfg.name
+        assert res.summary.duration_s == want.duration_s
+        assert ({k: (e.entity_type, e.events_handled, e.queue_stats) for k, e in res.summary.entities.items()} ==
+                {k: (e.entity_type, e.events_handled, e.queue_stats) for k, e in want.entities.items()}), cfg.name
+
+
+def test_engines_run_in_a_batch_grow_their_buffers_and_continue():
+    """hs_graph_run_many on handles created with the smallest capacities (every buffer grows, replicas finish in different launches),
+    then again to a later end: each handle == the same graph run alone."""
+    specs = [graph_spec(k) for k in (2, 3, 5)] + [lb_graph_spec(k) for k in (1, 2)]
+    lowered = [GS.build(sp)[0].lowered() for sp in specs]
+    assert all(isinstance(g, GeneralGraph) for g in lowered)
+    ends = [1_500_000_000, 3_000_000_000]
+    alone = []
+    for sp, g in zip(specs, lowered):
+        with GraphEngine(g.arrays, seed=sp["seed"]) as e:
+            per_end = []
+            for end in ends:
+                e.run_until(end)
+                per_end.append((e.summary().events_processed, e.summary().final_time_ns, e.stats(), e.records()))
+            alone.append(per_end)
+    engines = [GraphEngine(g.arrays, seed=sp["seed"], heap_capacity=1, request_capacity=1, record_capacity=16) for sp, g in zip(specs, lowered)]
+    try:
+        for w, end in enumerate(ends):
+            GraphEngine.run_many(engines, end)
+            for e, per_end in zip(engines, alone):
+                ev, fin, st, rec = per_end[w]
+                assert (e.summary().events_processed, e.summary().final_time_ns) == (ev, fin)
+                got = e.stats()
+                for k in st:
+                    np.testing.assert_array_equal(got[k], st[k], err_msg=k)
+                for a, b in zip(e.records(), rec):
+                    np.testing.assert_array_equal(a, b)
+        with pytest.raises(N.EngineError, match="listed twice"):
+            GraphEngine.run_many([engines[0], engines[1], engines[0]], ends[-1])
+    finally:
+        for e in engines:
+            e.close()
+
+
 def test_a_heap_beyond_the_lds_window_and_a_large_concurrency():
     """6 000 Sources on one Server with concurrency 5 000 (the station engines stop at four Sources and c = 32): the heap holds more
     pending events than its 4 096 LDS entries, so sifts cross from LDS into HBM; == the oracle."""

@@ -160,6 +160,6 @@ def test_abi_structs_of_the_graph_entry_points():
     assert C.sizeof(N.GraphNodes) == 8 + 15 * 8 + 8 + 9 * 8
     assert C.sizeof(N.GraphStats) == 16 * 8
     L = N.lib()
-    for sym in ("hs_graph_create", "hs_graph_schedule", "hs_graph_run_until", "hs_graph_get_summary", "hs_graph_get_stats",
+    for sym in ("hs_graph_create", "hs_graph_schedule", "hs_graph_run_until", "hs_graph_run_many", "hs_graph_get_summary", "hs_graph_get_stats",
                 "hs_graph_read_records", "hs_graph_last_error", "hs_graph_destroy"):
         assert sym in N.EXPORTED_SYMBOLS and getattr(L, sym)
