@@ -34,6 +34,7 @@
 namespace hs {
 namespace graph {
 
+constexpr int kLdsHeapBatch = 1024;            // ... of each of the heaps hs_graph_run_many runs side by side
 constexpr int kLdsHeap = 4096;                 // heap entries in LDS: 4 096 x 32 B = 128 KB of the CU's 160
 constexpr long long kBudget = 1ll << 21;       // events per launch (~2 s)
 
@@ -124,10 +125,11 @@ __device__ __forceinline__ bool ev_lt(const GEvent &a, const GEvent &b) {   // E
     return a.idx < b.idx;
 }
 
+template <int W>
 struct Heap {
     GEvent *lds; GEvent *glob; long long len;
-    __device__ __forceinline__ GEvent get(long long i) const { return i < kLdsHeap ? lds[i] : glob[i]; }
-    __device__ __forceinline__ void set(long long i, const GEvent &e) { if (i < kLdsHeap) lds[i] = e; else glob[i] = e; }
+    __device__ __forceinline__ GEvent get(long long i) const { return i < W ? lds[i] : glob[i]; }
+    __device__ __forceinline__ void set(long long i, const GEvent &e) { if (i < W) lds[i] = e; else glob[i] = e; }
     // heapq.heappush: append, then _siftdown(heap, 0, len - 1)
     __device__ inline void push(const GEvent &e) {
         long long pos = len++;
@@ -215,18 +217,19 @@ __device__ inline int64_t next_arrival(const GCtl &c, int n) {
     return a2;
 }
 
+template <int W>
 __device__ __forceinline__ void graph_loop(const GCtl &c, GEvent *lheap) {
     GVars &V = *c.V;
     const int lane = threadIdx.x;
     {   // the heap's head comes into LDS (all 64 lanes copy; 8 bytes per lane and step)
-        const long long n8 = (V.heap_len < kLdsHeap ? V.heap_len : (long long)kLdsHeap) * (long long)(sizeof(GEvent) / 8);
+        const long long n8 = (V.heap_len < W ? V.heap_len : (long long)W) * (long long)(sizeof(GEvent) / 8);
         const uint64_t *src = reinterpret_cast<const uint64_t *>(c.heap);
         uint64_t *dst = reinterpret_cast<uint64_t *>(lheap);
         for (long long i = lane; i < n8; i += 64) dst[i] = src[i];
     }
     __syncthreads();
     if (lane == 0) {
-        Heap H{lheap, c.heap, V.heap_len};
+        Heap<W> H{lheap, c.heap, V.heap_len};
         unsigned long long G = V.counter;
         int status = kRunning;
         if (!V.booted) {
@@ -490,7 +493,7 @@ __device__ __forceinline__ void graph_loop(const GCtl &c, GEvent *lheap) {
     }
     __syncthreads();
     {   // ... and back
-        const long long n8 = (V.heap_len < kLdsHeap ? V.heap_len : (long long)kLdsHeap) * (long long)(sizeof(GEvent) / 8);
+        const long long n8 = (V.heap_len < W ? V.heap_len : (long long)W) * (long long)(sizeof(GEvent) / 8);
         uint64_t *dst = reinterpret_cast<uint64_t *>(c.heap);
         const uint64_t *src = reinterpret_cast<const uint64_t *>(lheap);
         for (long long i = lane; i < n8; i += 64) dst[i] = src[i];
@@ -499,15 +502,16 @@ __device__ __forceinline__ void graph_loop(const GCtl &c, GEvent *lheap) {
 
 __global__ void __launch_bounds__(64) hs_graph_run(GCtl c) {
     __shared__ GEvent lheap[kLdsHeap];
-    graph_loop(c, lheap);
+    graph_loop<kLdsHeap>(c, lheap);
 }
 
 // Independent graphs -- the replicas / sweep points of parallel/runner.py:82-142 -- side by side: one workgroup (one heap) each, one
-// per CU at a time (the heap's LDS window), as many as the device has CUs at once.
+// with a quarter of the lone run's LDS window (32 KB: five workgroups per CU, 1 280 heaps on the device at once; a heap that outgrows
+// the window continues in HBM as it does behind the large one -- the window's size changes nothing the loop computes).
 __global__ void __launch_bounds__(64) hs_graph_run_batch(const GCtl *cs) {
-    __shared__ GEvent lheap[kLdsHeap];
+    __shared__ GEvent lheap[kLdsHeapBatch];
     const GCtl c = cs[blockIdx.x];
-    graph_loop(c, lheap);
+    graph_loop<kLdsHeapBatch>(c, lheap);
 }
 
 }  // namespace graph
@@ -529,8 +533,9 @@ struct hs_graph {
     std::vector<double> row_rate;              // ticks per second a row may reach (sizes the table)
     hs::TickRow *d_rows = nullptr; int64_t *d_ticks = nullptr, *d_tick_count = nullptr; unsigned long long *d_tick_status = nullptr;
     int64_t tick_horizon = INT64_MIN, tick_cap = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;              // created with the first launch that needs one (a replica run in a batch never does)
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    char *slab = nullptr; size_t slab_bytes = 0;   // every buffer of hs_graph_create in ONE allocation (a replica costs one hipMalloc / hipFree)
     double last_run_ms = 0.0;
     long long launches = 0;
     bool ran = false;
@@ -556,13 +561,25 @@ static int gfail(hs_graph *g, int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return gfail(g, HS_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));       \
     } while (0)
 
+static bool in_slab(const hs_graph *g, const void *p) {
+    return g->slab && (const char *)p >= g->slab && (const char *)p < g->slab + g->slab_bytes;
+}
+
 template <typename T>
 static int grow(hs_graph *g, T **buf, long long old_n, long long new_n) {
     T *nb = nullptr;
     HSG_HIP(g, hipMalloc(&nb, (size_t)new_n * sizeof(T)));
     if (*buf && old_n > 0) HSG_HIP(g, hipMemcpy(nb, *buf, (size_t)old_n * sizeof(T), hipMemcpyDeviceToDevice));
-    if (*buf) HSG_HIP(g, hipFree(*buf));
+    if (*buf && !in_slab(g, *buf)) HSG_HIP(g, hipFree(*buf));
     *buf = nb;
+    return HS_OK;
+}
+
+static int ensure_stream(hs_graph *g) {
+    if (g->stream) return HS_OK;
+    HSG_HIP(g, hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    HSG_HIP(g, hipEventCreate(&g->ev_a));
+    HSG_HIP(g, hipEventCreate(&g->ev_b));
     return HS_OK;
 }
 
@@ -577,7 +594,8 @@ void hs_graph_destroy(hs_graph *g) {
     void *bufs[] = {g->ctl.heap, g->ctl.reqs, g->ctl.rec_node, g->ctl.rec_t, g->ctl.rec_cr, (void *)g->ctl.P, g->ctl.S,
                     g->d_rt_targets, g->d_key_table, g->ctl.rt_taken, g->d_sched_node, g->d_sched_t, g->ctl.V, g->d_rows, g->d_ticks, g->d_tick_count,
                     g->d_tick_status};
-    for (void *b : bufs) if (b) (void)hipFree(b);
+    for (void *b : bufs) if (b && !in_slab(g, b)) (void)hipFree(b);
+    if (g->slab) (void)hipFree(g->slab);
     if (g->ev_a) (void)hipEventDestroy(g->ev_a);
     if (g->ev_b) (void)hipEventDestroy(g->ev_b);
     if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -752,53 +770,58 @@ int hs_graph_create(const hs_graph_config *cfg, const hs_graph_nodes *nd, hs_gra
 #define HSG_TRY(expr) do { int rc_ = (expr); if (rc_) { g_graph_error = g->error; hs_graph_destroy(g); return rc_; } } while (0)
 #define HSG_HIPD(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { gfail(g, HS_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); g_graph_error = g->error; hs_graph_destroy(g); return HS_E_HIP; } } while (0)
     HSG_HIPD(hipSetDevice(cfg->device));
-    HSG_HIPD(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
-    HSG_HIPD(hipEventCreate(&g->ev_a));
-    HSG_HIPD(hipEventCreate(&g->ev_b));
     GCtl &c = g->ctl;
     c.n = n; c.seed = cfg->seed; c.start_ns = cfg->start_ns; c.budget = kBudget;
     c.heap_cap = std::max<long long>(cfg->heap_capacity > 0 ? cfg->heap_capacity : 0, (long long)n * 4 + 1024);
     c.req_cap = (int)std::min<long long>(std::max<long long>(cfg->request_capacity > 0 ? cfg->request_capacity : 0, (long long)n * 4 + 1024), 1ll << 30);
     c.rec_cap = cfg->record_capacity > 0 ? cfg->record_capacity : 65536;
     (void)rate_sum;
-    HSG_TRY(grow(g, &c.heap, 0, c.heap_cap));
-    HSG_TRY(grow(g, &c.reqs, 0, c.req_cap));
-    HSG_TRY(grow(g, &c.rec_node, 0, c.rec_cap));
-    HSG_TRY(grow(g, &c.rec_t, 0, c.rec_cap));
-    HSG_TRY(grow(g, &c.rec_cr, 0, c.rec_cap));
-    GParam *dP = nullptr;
-    HSG_HIPD(hipMalloc(&dP, (size_t)n * sizeof(GParam)));
-    c.P = dP;
-    HSG_HIPD(hipMemcpy(dP, P.data(), (size_t)n * sizeof(GParam), hipMemcpyHostToDevice));
-    HSG_HIPD(hipMalloc(&c.S, (size_t)n * sizeof(GState)));
-    {
-        std::vector<GState> S0((size_t)n);
-        for (auto &s : S0) { std::memset(&s, 0, sizeof s); s.qhead = -1; s.qtail = -1; }
-        HSG_HIPD(hipMemcpy(c.S, S0.data(), (size_t)n * sizeof(GState), hipMemcpyHostToDevice));
-    }
+    // one allocation: the initialised arrays first (one copy from a host image), behind them the ones the run fills (a buffer that
+    // has to grow later moves into an allocation of its own, grow())
     const size_t nrt = (size_t)(nd->n_rt > 0 ? nd->n_rt : 1);
-    HSG_HIPD(hipMalloc(&g->d_rt_targets, nrt * sizeof(int32_t)));
-    if (nd->n_rt > 0) HSG_HIPD(hipMemcpy(g->d_rt_targets, nd->rt_targets, (size_t)nd->n_rt * sizeof(int32_t), hipMemcpyHostToDevice));
-    c.rt_targets = g->d_rt_targets;
-    if (!key_table.empty()) {
-        HSG_HIPD(hipMalloc(&g->d_key_table, key_table.size() * sizeof(int32_t)));
-        HSG_HIPD(hipMemcpy(g->d_key_table, key_table.data(), key_table.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    }
-    c.key_table = g->d_key_table;
-    HSG_HIPD(hipMalloc(&c.rt_taken, nrt * sizeof(long long)));
-    HSG_HIPD(hipMemset(c.rt_taken, 0, nrt * sizeof(long long)));
-    if (!rows.empty()) {
-        HSG_HIPD(hipMalloc(&g->d_rows, rows.size() * sizeof(hs::TickRow)));
-        HSG_HIPD(hipMemcpy(g->d_rows, rows.data(), rows.size() * sizeof(hs::TickRow), hipMemcpyHostToDevice));
-        HSG_HIPD(hipMalloc(&g->d_tick_count, rows.size() * sizeof(int64_t)));
-        HSG_HIPD(hipMalloc(&g->d_tick_status, 2 * sizeof(unsigned long long)));
-    }
-    HSG_HIPD(hipMalloc(&c.V, sizeof(GVars)));
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t o_P = take((size_t)n * sizeof(GParam)), o_S = take((size_t)n * sizeof(GState)), o_rt = take(nrt * sizeof(int32_t)),
+                 o_key = take(key_table.size() * sizeof(int32_t)), o_taken = take(nrt * sizeof(long long)),
+                 o_rows = take(rows.size() * sizeof(hs::TickRow)), o_V = take(sizeof(GVars));
+    const size_t image_bytes = off;
+    const size_t o_tcount = take(rows.size() * sizeof(int64_t)), o_tstatus = take(rows.empty() ? 0 : 2 * sizeof(unsigned long long)),
+                 o_heap = take((size_t)c.heap_cap * sizeof(GEvent)), o_reqs = take((size_t)c.req_cap * sizeof(GRequest)),
+                 o_rnode = take((size_t)c.rec_cap * sizeof(int32_t)), o_rt_ns = take((size_t)c.rec_cap * sizeof(int64_t)),
+                 o_rcr = take((size_t)c.rec_cap * sizeof(int64_t));
+    g->slab_bytes = off;
+    HSG_HIPD(hipMalloc((void **)&g->slab, g->slab_bytes));
     {
+        std::vector<char> image(image_bytes, 0);
+        std::memcpy(image.data() + o_P, P.data(), (size_t)n * sizeof(GParam));
+        GState *S0 = reinterpret_cast<GState *>(image.data() + o_S);
+        for (int i = 0; i < n; ++i) { S0[i].qhead = -1; S0[i].qtail = -1; }
+        if (nd->n_rt > 0) std::memcpy(image.data() + o_rt, nd->rt_targets, (size_t)nd->n_rt * sizeof(int32_t));
+        if (!key_table.empty()) std::memcpy(image.data() + o_key, key_table.data(), key_table.size() * sizeof(int32_t));
+        if (!rows.empty()) std::memcpy(image.data() + o_rows, rows.data(), rows.size() * sizeof(hs::TickRow));
         GVars v{};
         v.req_free = -1; v.cur = cfg->start_ns;
-        HSG_HIPD(hipMemcpy(c.V, &v, sizeof v, hipMemcpyHostToDevice));
+        std::memcpy(image.data() + o_V, &v, sizeof v);
+        HSG_HIPD(hipMemcpy(g->slab, image.data(), image_bytes, hipMemcpyHostToDevice));
     }
+    c.P = reinterpret_cast<const GParam *>(g->slab + o_P);
+    c.S = reinterpret_cast<GState *>(g->slab + o_S);
+    g->d_rt_targets = reinterpret_cast<int32_t *>(g->slab + o_rt);
+    c.rt_targets = g->d_rt_targets;
+    g->d_key_table = key_table.empty() ? nullptr : reinterpret_cast<int32_t *>(g->slab + o_key);
+    c.key_table = g->d_key_table;
+    c.rt_taken = reinterpret_cast<long long *>(g->slab + o_taken);
+    c.V = reinterpret_cast<GVars *>(g->slab + o_V);
+    if (!rows.empty()) {
+        g->d_rows = reinterpret_cast<hs::TickRow *>(g->slab + o_rows);
+        g->d_tick_count = reinterpret_cast<int64_t *>(g->slab + o_tcount);
+        g->d_tick_status = reinterpret_cast<unsigned long long *>(g->slab + o_tstatus);
+    }
+    c.heap = reinterpret_cast<GEvent *>(g->slab + o_heap);
+    c.reqs = reinterpret_cast<GRequest *>(g->slab + o_reqs);
+    c.rec_node = reinterpret_cast<int32_t *>(g->slab + o_rnode);
+    c.rec_t = reinterpret_cast<int64_t *>(g->slab + o_rt_ns);
+    c.rec_cr = reinterpret_cast<int64_t *>(g->slab + o_rcr);
     HSG_HIPD(hipDeviceSynchronize());
 #undef HSG_TRY
 #undef HSG_HIPD
@@ -839,6 +862,7 @@ static int build_tables(hs_graph *g, int64_t horizon) {
             HSG_HIP(g, hipMalloc(&g->d_ticks, g->rows.size() * (size_t)cap * sizeof(int64_t)));
             g->tick_cap = cap;
         }
+        { const int rc = ensure_stream(g); if (rc) return rc; }
         HSG_HIP(g, hs::tick_tables_launch(g->stream, g->d_rows, (int)g->rows.size(), g->cfg.start_ns, horizon, cap, g->d_ticks, g->d_tick_count,
                                           g->d_tick_status, budget, false));
         HSG_HIP(g, hipStreamSynchronize(g->stream));
@@ -939,6 +963,7 @@ int hs_graph_run_until(hs_graph *g, int64_t end_ns) {
         const int rc = prepare_run(g, end_ns);
         if (rc) return rc;
     }
+    { const int rc = ensure_stream(g); if (rc) return rc; }
     HSG_HIP(g, hipEventRecord(g->ev_a, g->stream));
     for (bool done = false; !done;) {
         hipLaunchKernelGGL(hs_graph_run, dim3(1), dim3(64), 0, g->stream, g->ctl);
@@ -964,6 +989,7 @@ int hs_graph_run_many(hs_graph *const *gs, int32_t n, int64_t end_ns) {
     }
     hs_graph *g0 = gs[0];
     HSG_HIP(g0, hipSetDevice(g0->cfg.device));
+    { const int rc = ensure_stream(g0); if (rc) return rc; }
     for (int i = 0; i < n; ++i) {
         const int rc = prepare_run(gs[i], end_ns);
         if (rc) { if (gs[i] != g0) gfail(g0, rc, "graph %d: %s", i, gs[i]->error.c_str()); return rc; }

@@ -30,7 +30,7 @@ DEFAULT_MAX_EVENTS = 200_000_000          # ~ minutes on the one lane; Simulatio
 
 
 def _ptr(a):
-    return None if a is None else a.ctypes.data_as(C.c_void_p)
+    return None if a is None else a.__array_interface__["data"][0]      # (the address; `.ctypes.data_as` costs 3 us per array)
 
 
 class GraphArrays:
