@@ -62,6 +62,52 @@ def test_cooperative_tables_equal_the_lone_lane_chain(name, profile, poisson, ho
             break
 
 
+def _oracle_ticks(profile, poisson, seed, sid, horizon_s):
+    """The same stream on the ORACLE's event loop (hs_oracle.c: ArrivalTimeProvider.next_arrival_time's general path, adaptive
+    Simpson + bracket search + Brent, load/arrival_time_provider.py:84-144): a Source with the profile in front of a Sink -- the
+    Sink's record times are the arrival times; a Probe's sample times are its ticks."""
+    g = O.Graph()
+    if profile[0] == GENERAL_CONSTANT:
+        snk = g.sink()
+        node = g.probe(snk, 5, 1.0 / profile[1])
+        assert g.prof_p[node][0] == profile[1]
+    else:
+        prof = ("ramp",) + tuple(profile[1:4]) if profile[0] == RAMP else ("spike",) + tuple(profile[1:5])
+        src = g.source(O.ARR_POISSON if poisson else O.ARR_CONSTANT, 1.0, stream_base=sid >> 3, profile=prof)
+        node = g.sink()
+        g.target[src] = node
+    r = O.run(g, int(horizon_s * 1e9), seed=seed)
+    return r.sinks[node][0]
+
+
+@pytest.mark.parametrize("name,profile,poisson,horizon_s", CASES, ids=[c[0] for c in CASES])
+def test_cooperative_tables_equal_the_oracle(name, profile, poisson, horizon_s):
+    """... and against the ORACLE (the CPU restatement the live reference pins: profile_* / probe goldens, live random cases), not
+    only against the device's own lone-lane chain: every tick up to the horizon and the one beyond it, bit for bit -- incl. the
+    `ramp 2 s 2->30` case whose lone-lane comparison takes minutes."""
+    for seed, sid in ((42, 8 * 3), (77, 8 * 97), (5, 8 * 1234567)):
+        coop, st = _table(profile, poisson, seed, sid, horizon_s, 4096, lone=0)
+        assert st[0] == 0 and st[1] == 0, (name, seed, st)
+        want = _oracle_ticks(profile, poisson, seed, sid, horizon_s)
+        # (the oracle's run ends with the first event beyond the end -- the tick's SourceEvent --, so the Sink holds every tick up
+        #  to the end; the table goes on: its next entry is that tick beyond the end)
+        assert len(want) >= 2 and len(coop) > len(want) and coop[len(want)] > horizon_s * 1e9 >= want[-1]
+        np.testing.assert_array_equal(coop[:len(want)], want, err_msg=f"{name} seed {seed}")
+        if not poisson:
+            break
+
+
+def test_the_explosive_integral_equals_the_oracle():
+    """LinearRampProfile(3 s, 1 -> 9), stream base 97, seed 77 (2.65e7 Simpson intervals for the first arrival): the cooperative
+    table == the oracle's chain (the lone-lane comparison below needs minutes of one lane)."""
+    prof = (RAMP, 3.0, 1.0, 9.0, 0.0)
+    coop, st = _table(prof, 1, 77, 8 * 97, 2.0, 64, lone=0)
+    assert st[0] == 0
+    want = _oracle_ticks(prof, 1, 77, 8 * 97, 2.0)
+    assert len(want) >= 1 and len(coop) >= len(want)
+    np.testing.assert_array_equal(coop[:len(want)], want)
+
+
 @needs_minutes
 def test_an_explosive_integral_is_split_over_the_lanes_bit_for_bit():
     """LinearRampProfile(3 s, 1 -> 9), stream base 97, seed 77 -- the first arrival's bracket search
