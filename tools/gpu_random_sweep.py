@@ -165,7 +165,46 @@ def tandem_probes(k):
     TS.run_tandem_probe_case(TS.tandem_probe_case(k))
 
 
-FAMILIES = [station, tie, multi_source, ring_async, ring_windowed, jitter_ring_async, jitter_ring_windowed, multi_source_ring_async,
+def _general(spec):
+    """Graphs outside the station shape through hs.Simulation on the single-heap loop (tests/test_gpu_graph.py)."""
+    import graph_specs as GS
+    from happy_simulator_amd.graph_engine import GeneralGraph
+    from test_gpu_graph import _compare_with_oracle
+
+    sim, ents = GS.build(spec)
+    if not isinstance(sim.lowered(), GeneralGraph):          # (a draw the station engines take: their families' ground)
+        return
+    g_o, nodes = H.oracle_graph(spec)
+    r = O.run(g_o, H.ns_from_seconds(spec["end_s"]), seed=spec["seed"], schedule=H.oracle_graph_schedule(spec, nodes))
+    sim.run()
+    _compare_with_oracle(spec, sim, ents, r, nodes)
+
+
+def graph(k):                  # round 6: several senders per link, any fan-out, Server -> Server next to links, many Sources per Server
+    _general(RS.graph_spec(k))
+
+
+def lb_graph(k):               # round 6: one to three LoadBalancers inside such graphs, schedule()d Requests
+    _general(RS.lb_graph_spec(k))
+
+
+def graph_probes(k):           # round 6: Probes and time-varying Sources on them
+    from happy_simulator_amd.graph_engine import GeneralGraph
+    from test_gpu_graph import _compare_with_oracle, _with_probes_and_profiles
+
+    spec, sim, ents, probes, g_o, nodes, o_probes = _with_probes_and_profiles(k)
+    if not isinstance(sim.lowered(), GeneralGraph):
+        return
+    r = O.run(g_o, H.ns_from_seconds(spec["end_s"]), seed=spec["seed"])
+    sim.run()
+    _compare_with_oracle(spec, sim, ents, r, nodes)
+    for (pr, data), nd in zip(probes, o_probes):
+        t, v = r.sinks[nd]
+        np.testing.assert_array_equal(data._t_ns, t, err_msg=pr.name)
+        np.testing.assert_array_equal(data._v, v, err_msg=pr.name)
+
+
+FAMILIES = [graph, lb_graph, graph_probes, station, tie, multi_source, ring_async, ring_windowed, jitter_ring_async, jitter_ring_windowed, multi_source_ring_async,
             multi_source_ring_windowed, ring_windows_async, ring_windows_windowed, jitter_ring_windows_async,
             multi_source_ring_windows_async, lb,
             lb_probes, lb_profiles, lb_strategies, lb_workers, tandem, tandem_fan_in, tandem_probes]
