@@ -68,7 +68,7 @@ struct GState {                                // 64 bytes
     // router: a = stats_routed (= route draws);  Sink: a = events_received
     // Probe:  a = ticks taken from its table, c = samples
     // LoadBalancer: a = requests_received, b = requests_forwarded, c = requests_failed (= no_backend_available), d = in flight,
-    //               svc_draws = RoundRobin._index;  Source: svc_draws = KEY draws
+    //               svc_draws = RoundRobin._index (ConsistentHash: its fallback's, the key-less Requests);  Source: svc_draws = KEY draws
     int64_t a, b, c, d;
     double total_service;                      // Server._total_service_time
     uint64_t svc_draws;
@@ -441,6 +441,10 @@ __device__ __forceinline__ void graph_loop(const GCtl &c, GEvent *lheap) {
                 int slot = 0;
                 if (p.sub == HS_LB_CONSISTENT_HASH) {
                     if (client >= 0 && client < (int64_t)p.conc) slot = c.key_table[p.lim + client];   // ConsistentHash.select(str(client_id))
+                    else {                                                          // no key: `self._fallback.select(...)`, a RoundRobin of
+                        slot = (int)(s.svc_draws % (uint64_t)p.rt_cnt);             // the strategy's own (strategies.py:362,420-421)
+                        s.svc_draws += 1;
+                    }
                 } else if (p.sub == HS_LB_ROUND_ROBIN) {
                     slot = (int)(s.svc_draws % (uint64_t)p.rt_cnt);                 // backends[_index % len], _index += 1 (strategies.py:66-67)
                     s.svc_draws += 1;
@@ -1072,8 +1076,9 @@ int hs_graph_get_stats(hs_graph *g, hs_graph_stats *o) {
         if (o->routed) o->routed[i] = k == HS_NODE_ROUTER ? s.a : 0;
         if (o->lb) {
             const bool lb = k == HS_NODE_LB;
-            int64_t *r = o->lb + 5 * (size_t)i;
+            int64_t *r = o->lb + 6 * (size_t)i;
             r[0] = lb ? s.a : 0; r[1] = lb ? s.b : 0; r[2] = lb ? s.c : 0; r[3] = lb ? s.c : 0; r[4] = lb ? s.d : 0;
+            r[5] = lb ? (int64_t)s.svc_draws : 0;
         }
     }
     if (o->rt_taken && g->n_rt > 0)

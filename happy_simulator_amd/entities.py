@@ -706,6 +706,7 @@ class ConsistentHash:
         if get_key is not None:
             raise NotImplementedError("a custom get_key is arbitrary Python; the engine hashes metadata['client_id']")
         self._virtual_nodes = int(virtual_nodes)
+        self._fallback = RoundRobin()       # what a Request without a key gets (strategies.py:362,420-421): only the single-heap path runs those
 
     @property
     def virtual_nodes(self) -> int:

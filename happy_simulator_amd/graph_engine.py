@@ -128,7 +128,7 @@ class GraphEngine:
 
     def stats(self) -> dict:
         n, nrt = self.arrays.n, max(len(self.arrays.rt_targets), 1)
-        out = {k: np.zeros(nrt if k == "rt_taken" else (n, 5) if k == "lb" else n, np.float64 if k == "total_service_s" else np.int64)
+        out = {k: np.zeros(nrt if k == "rt_taken" else (n, 6) if k == "lb" else n, np.float64 if k == "total_service_s" else np.int64)
                for k in N.GRAPH_STATS}
         st = N.GraphStats()
         for k, a in out.items():
@@ -367,37 +367,30 @@ def _reaches(nodes, node_of, start) -> set:
 
 
 def _check_keys(nodes, node_of, a) -> None:
-    """A Request without a client id must not reach a ConsistentHash or Random LoadBalancer (there the reference falls back to a
-    RoundRobin of the strategy's own / asks the process-wide `random`, which the engine's streams do not define for it); a Random
-    LoadBalancer takes its Requests from Sources that aim at it directly (their draw is the choice)."""
+    """A Random LoadBalancer takes its Requests from Sources that aim at it directly (their KEY draw is the choice; a Request
+    without one would ask the process-wide `random`, which the engine's streams do not define).  A key-less Request at a
+    ConsistentHash LoadBalancer is the reference's own case: the strategy's fallback RoundRobin (strategies.py:362,420-421)."""
     from .lowering import UnsupportedTopology
 
-    keyed = [i for i, x in enumerate(nodes) if isinstance(x, LoadBalancer) and not isinstance(x.strategy, RoundRobin)]
-    if not keyed:
+    rnd = [i for i, x in enumerate(nodes) if isinstance(x, LoadBalancer) and isinstance(x.strategy, Random)]
+    if not rnd:
         return
-    for i, src in enumerate(nodes):
+    for src in nodes:
         if not isinstance(src, Source):
             continue
         tgt = src._event_provider._target
         reach = _reaches(nodes, node_of, tgt)
-        for j in keyed:
-            if j not in reach:
-                continue
-            lb = nodes[j]
-            if isinstance(lb.strategy, Random) and tgt is not lb:
-                raise UnsupportedTopology(f"source '{src.name}' reaches the Random LoadBalancer '{lb.name}' through other entities: only "
-                                          "Sources that aim at it directly carry the draw it chooses by")
-            if isinstance(lb.strategy, ConsistentHash) and not isinstance(src._event_provider, ClientKeyEventProvider):
-                raise UnsupportedTopology(f"source '{src.name}': requests for the key-based LoadBalancer '{lb.name}' must come from a "
-                                          "ClientKeyEventProvider (ConsistentHash falls back to a RoundRobin of its own for key-less "
-                                          "requests: use strategy=RoundRobin() for those)")
+        for j in rnd:
+            if j in reach and tgt is not nodes[j]:
+                raise UnsupportedTopology(f"source '{src.name}' reaches the Random LoadBalancer '{nodes[j].name}' through other entities: "
+                                          "only Sources that aim at it directly carry the draw it chooses by")
 
 
 def keyless_hazard(g: "GeneralGraph", target) -> str | None:
-    """Simulation.schedule(): a scheduled Request carries no client id -- the name of a key-based LoadBalancer it could reach."""
+    """Simulation.schedule(): a scheduled Request carries no client id -- the name of a Random LoadBalancer it could reach."""
     for j in _reaches(g.nodes, g.node_of, target):
         x = g.nodes[j]
-        if isinstance(x, LoadBalancer) and not isinstance(x.strategy, RoundRobin):
+        if isinstance(x, LoadBalancer) and isinstance(x.strategy, Random):
             return x.name
     return None
 
@@ -426,9 +419,11 @@ def write_back_general(g: GeneralGraph, stats: dict, rec_node: np.ndarray, rec_t
             ent._entered = int(stats["entered"][i])
         elif isinstance(ent, LoadBalancer):
             (ent._requests_received, ent._requests_forwarded, ent._requests_failed, ent._no_backend_available,
-             ent._in_flight_count) = (int(v) for v in stats["lb"][i])
+             ent._in_flight_count, selections) = (int(v) for v in stats["lb"][i])
             if isinstance(ent.strategy, RoundRobin):
-                ent.strategy._index += ent._requests_forwarded     # one select per forwarded Request (strategies.py:66-67)
+                ent.strategy._index += selections                  # one select per forwarded Request (strategies.py:66-67)
+            elif isinstance(ent.strategy, ConsistentHash):
+                ent.strategy._fallback._index += selections        # ... per KEY-LESS Request (strategies.py:362,420-421)
             off = int(a.rt_off[i])
             for q, b in enumerate(ent.all_backends):
                 ent._backends[b.name].total_requests = int(stats["rt_taken"][off + q])

@@ -333,9 +333,8 @@ class Simulation:
                 raise UnsupportedTopology(f"scheduled event {ev!r}: a custom created_at is not lowered")
             lb_name = keyless_hazard(g, ev.target)
             if lb_name is not None:
-                raise UnsupportedTopology(f"scheduled event {ev!r} carries no client id and can reach the key-based LoadBalancer "
-                                          f"'{lb_name}' (the reference would fall back to a RoundRobin of the strategy's own / the "
-                                          "process-wide random generator): not lowered")
+                raise UnsupportedTopology(f"scheduled event {ev!r} carries no client id and can reach the Random LoadBalancer "
+                                          f"'{lb_name}' (the reference would ask the process-wide random generator): not lowered")
             if cancelled_ns:
                 # a cancelled Event keeps its place in the process-wide counter: the ones behind it would need the gap
                 raise UnsupportedTopology("cancelled Events in front of live ones are not lowered on the single-heap path")

@@ -728,9 +728,9 @@ typedef struct hs_graph_nodes {
      * of a Request is str(client_id); RoundRobin (strategies.py:50-73); Random (strategies.py:137-150) with random.choice plugged by
      * the Request's key draw: backends[client_id].  A Source with src_n_clients > 0 builds its Requests like a
      * ClientKeyEventProvider (examples/visual/chash_example.py:69-88): client_id = int(u * n_clients), u from its KEY stream.  A
-     * Request WITHOUT a client_id (a scheduled one, one of a plain Source) must not reach a ConsistentHash or Random LoadBalancer
-     * (the reference falls back to a RoundRobin of its own / draws from the process-wide generator): the caller refuses such
-     * graphs; the device sends it to backend 0.  Every forwarded Request carries the `_lb_response` completion hook
+     * Request WITHOUT a client_id (a scheduled one, one of a plain Source) at a ConsistentHash LoadBalancer takes the strategy's own
+     * fallback RoundRobin, which only such Requests advance (strategies.py:362,420-421); it must not reach a Random LoadBalancer
+     * (the reference draws from the process-wide generator): the caller refuses such graphs; the device sends it to backend 0.  Every forwarded Request carries the `_lb_response` completion hook
      * (load_balancer.py:413-431): one more event behind the backend's enqueue.  NULL = no LoadBalancer. */
     const uint8_t *lb_strategy;      /* [n] hs_lb_strategy */
     const int32_t *lb_vnodes;        /* [n] ConsistentHash(virtual_nodes) */
@@ -753,8 +753,10 @@ typedef struct hs_graph_stats {      /* host arrays [n_nodes] (rt_taken: [n_rt])
     int64_t *routed;                 /* RandomRouter.stats_routed                       components/random_router.py:36 */
     int64_t *rt_taken;               /* [n_rt] how often each target slot was drawn     (target_counts, random_router.py:37);
                                       * a LoadBalancer's slots: BackendInfo.total_requests       load_balancer.py:385-386 */
-    int64_t *lb;                     /* [n][5] LoadBalancer: requests_received, requests_forwarded, requests_failed,
-                                      * no_backend_available, len(_in_flight)                    load_balancer.py:349-388 */
+    int64_t *lb;                     /* [n][6] LoadBalancer: requests_received, requests_forwarded, requests_failed,
+                                      * no_backend_available, len(_in_flight)                    load_balancer.py:349-388
+                                      * and the selections of the strategy's RoundRobin: RoundRobin._index, or the index of
+                                      * ConsistentHash's key-less fallback                         strategies.py:66-67,362 */
 } hs_graph_stats;
 
 int hs_graph_create(const hs_graph_config *cfg, const hs_graph_nodes *nodes, hs_graph **out);

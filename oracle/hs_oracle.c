@@ -69,7 +69,7 @@ typedef struct {
     int64_t routed;                       /* RandomRouter.stats_routed, components/random_router.py:36 */
     uint64_t route_draws;
     /* LoadBalancer */
-    int64_t lb_received, lb_forwarded, lb_failed, lb_no_backend, lb_in_flight, lb_next_id;
+    int64_t lb_received, lb_forwarded, lb_failed, lb_no_backend, lb_in_flight, lb_next_id, lb_fallback_idx;
     int64_t *lb_total_requests;           /* [rt_cnt] BackendInfo.total_requests */
     hso_ring_pt *ring; int64_t ring_len;
     uint64_t key_draws;
@@ -742,7 +742,12 @@ static void on_lb(hso_sim *s, const hso_event *e) {
         return;
     }
     int32_t be;
-    if (s->g.vnodes[n] > 0) {
+    if (s->g.vnodes[n] > 0 && s->reqs[e->req].client_id < 0) {
+        /* no metadata, so _default_get_key returns None: `return self._fallback.select(backends, request)` (strategies.py:362,420-421),
+         * a RoundRobin of the strategy's own that only the key-less Requests advance */
+        be = s->g.rt_targets[s->g.rt_off[n] + (int32_t)(nd->lb_fallback_idx % s->g.rt_cnt[n])];
+        nd->lb_fallback_idx++;
+    } else if (s->g.vnodes[n] > 0) {
         char key[32];
         int len = snprintf(key, sizeof key, "%lld", (long long)s->reqs[e->req].client_id);   /* str(metadata["client_id"]) */
         be = lb_select_key(s, n, key, len);
@@ -769,10 +774,11 @@ static void on_lb_resp(hso_sim *s, const hso_event *e) {
     if (nd->lb_in_flight > 0) nd->lb_in_flight--;
 }
 
-void hso_get_lb_stats(const hso_sim *s, int32_t node, int64_t out[5], int64_t *total_requests, int32_t *ring_backend) {
+void hso_get_lb_stats(const hso_sim *s, int32_t node, int64_t out[6], int64_t *total_requests, int32_t *ring_backend) {
     const hso_node *nd = &s->nodes[node];
     out[0] = nd->lb_received; out[1] = nd->lb_forwarded; out[2] = nd->lb_failed; out[3] = nd->lb_no_backend;
     out[4] = nd->lb_in_flight;
+    out[5] = s->g.vnodes[node] > 0 ? nd->lb_fallback_idx : s->g.vnodes[node] == 0 ? nd->lb_next_id : -1;   /* the strategy's RoundRobin._index */
     if (total_requests) memcpy(total_requests, nd->lb_total_requests, (size_t)s->g.rt_cnt[node] * 8);
     if (ring_backend) for (int64_t i = 0; i < nd->ring_len; ++i) ring_backend[i] = nd->ring[i].backend;
 }
@@ -868,9 +874,9 @@ hso_sim *hso_create(const hso_graph *g, const hso_params *p) {
  * Calls must come in the order the caller constructed the Events.  Returns 0, or -1 for a node that takes no Request. */
 int hso_schedule(hso_sim *s, int32_t node, int64_t time_ns) {
     int32_t k = arrival_kind_for(s, node);
-    /* (a scheduled Request carries no metadata: a ConsistentHash / Random LoadBalancer would fall back to a RoundRobin of its own /
-     * ask the process-wide generator -- not modelled; a RoundRobin LoadBalancer takes it like any other) */
-    if (k < 0 || (k == HSO_EV_LB && s->g.vnodes[node] != 0)) return -1;
+    /* (a scheduled Request carries no metadata: a ConsistentHash LoadBalancer falls back to a RoundRobin of its own (on_lb), a Random
+     * one would ask the process-wide generator -- not modelled) */
+    if (k < 0 || (k == HSO_EV_LB && s->g.vnodes[node] < 0)) return -1;
     int32_t r = req_alloc(s);
     s->reqs[r].created_ns = time_ns;
     s->reqs[r].hops = 0;

@@ -330,11 +330,11 @@ def run(g: Graph, end_ns: int, start_ns: int = 0, seed: int = 42, rng_mode: int 
         r.lbs = {}
         for i in range(n):
             if g.kind[i] == LB:
-                st = np.zeros(5, np.int64)
+                st = np.zeros(6, np.int64)
                 tot = np.zeros(max(g.rt_cnt[i], 1), np.int64)
                 ring = np.zeros(max(g.rt_cnt[i] * g.vnodes[i], 1), np.int32)
                 L.hso_get_lb_stats(h, i, st.ctypes.data, tot.ctypes.data, ring.ctypes.data)
-                r.lbs[i] = dict(stats=st, total_requests=tot[:g.rt_cnt[i]], ring_backend=ring[:g.rt_cnt[i] * g.vnodes[i]],
+                r.lbs[i] = dict(stats=st[:5], strategy_index=int(st[5]), total_requests=tot[:g.rt_cnt[i]], ring_backend=ring[:g.rt_cnt[i] * g.vnodes[i]],
                                 select=[L.hso_lb_select(h, i, str(c).encode()) for c in range(lb_probe)])
         r.sinks = {}
         for i in range(n):

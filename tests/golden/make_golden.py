@@ -901,7 +901,9 @@ def run_graph_case(spec):
             toff.append(len(tot))
         out["lb_backend_total_requests"] = np.asarray(tot, np.int64)
         out["lb_backend_off"] = np.asarray(toff, np.int64)
-        out["lb_rr_index"] = np.array([getattr(lb.strategy, "_index", -1) for lb in lbs], np.int64)
+        # the selections of the strategy's RoundRobin: RoundRobin._index; ConsistentHash: its key-less fallback's; Random: -1
+        out["lb_rr_index"] = np.array([lb.strategy._fallback._index if isinstance(lb.strategy, ConsistentHash) else
+                                       getattr(lb.strategy, "_index", -1) for lb in lbs], np.int64)
     sink_t, sink_lat, off = [], [], [0]
     for k in sinks:
         sink_t.extend(t.nanoseconds for t in k.completion_times)
@@ -1157,6 +1159,20 @@ GRAPH_CASES = [
          sources=[dict(kind="poisson", rate=9.0, to=["lb", 0]), dict(kind="constant", rate=2.0, to=["lb", 0]), dict(kind="poisson", rate=3.0, to=1)],
          schedule=[[["lb", 0], 0.5], [["lb", 0], 0.5], [["server", 1], 0.5], [["lb", 1], 1.0], [["router", 0], 1.0], [["link", 0], 0.0],
                    [["lb", 0], 0.0], [["lb", 1], 6.0], [["server", 0], 6.0], [["lb", 0], 6.5], [["lb", 1], 2.25]]),
+    # ... and Requests WITHOUT a key at ConsistentHash LoadBalancers -- plain Sources next to client-keyed ones, `schedule()`d Requests:
+    # the strategy's own fallback RoundRobin (strategies.py:362,420-421), advanced by the key-less Requests only
+    dict(name="graph_keyless_consistent_hash", topology="graph", n_sinks=2, end_s=6.0, seed=185,
+         servers=[dict(mean=0.04, c=1, cap=None, out=["lb", 1]), dict(mean=0.05, c=2, cap=None, out=["sink", 0]),
+                  dict(mean=0.03, c=1, cap=4, out=["sink", 0]), dict(mean=0.06, c=1, cap=None, out=["sink", 1]),
+                  dict(mean=0.05, c=1, cap=None, out=["router", 0])],
+         links=[dict(lat=0.001, jk="exp", jm=0.002, loss=0.0, to=3)],
+         routers=[dict(targets=[["sink", 1], ["lb", 1], ["link", 0]])],
+         lbs=[dict(strategy="chash", vnodes=7, backends=[0, 1, 4]), dict(strategy="chash", vnodes=100, backends=[2, 3, 1])],
+         sources=[dict(kind="poisson", rate=7.0, to=["lb", 0], n_clients=40), dict(kind="poisson", rate=6.0, to=["lb", 0]),
+                  dict(kind="constant", rate=3.0, to=["lb", 1]), dict(kind="poisson", rate=4.0, to=0, n_clients=9),
+                  dict(kind="poisson", rate=3.0, to=4)],
+         schedule=[[["lb", 0], 0.5], [["lb", 1], 0.5], [["lb", 0], 0.5], [["server", 0], 1.0], [["router", 0], 2.0], [["lb", 1], 6.0],
+                   [["lb", 0], 6.25]]),
 ]
 
 RING_CASES = [

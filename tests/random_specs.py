@@ -165,18 +165,19 @@ def graph_spec(k):
 
 def lb_graph_spec(k):
     """graph_spec(k) with one to three LoadBalancers wired INTO it (round 6: several LoadBalancers, a LoadBalancer behind Servers and
-    routers, `schedule()` on such graphs).  k % 3 != 0: every Source hands out client ids (ClientKeyEventProvider), the LoadBalancers
-    are ConsistentHash / RoundRobin anywhere and Random right behind Sources (a Random LoadBalancer chooses by the draw of a Source
-    that aims at it).  k % 3 == 0: plain Sources, RoundRobin LoadBalancers only, plus Requests `schedule()`d for Servers, routers,
-    links and the LoadBalancers themselves.  Backends of a LoadBalancer that a Server or router feeds have larger indices than the
-    feeders (no zero-delay cycles, as in graph_spec)."""
+    routers, `schedule()` on such graphs).  k % 3 != 0: most Sources hand out client ids (ClientKeyEventProvider), the rest are plain
+    -- their Requests and the `schedule()`d ones take ConsistentHash's key-less fallback (a RoundRobin of the strategy's own); the
+    LoadBalancers are ConsistentHash / RoundRobin anywhere and Random right behind Sources (a Random LoadBalancer chooses by the
+    draw of a Source that aims at it).  k % 3 == 0: plain Sources, RoundRobin LoadBalancers only.  Both: Requests `schedule()`d for
+    Servers, routers, links and the LoadBalancers themselves (never a Random one).  Backends of a LoadBalancer that a Server or
+    router feeds have larger indices than the feeders (no zero-delay cycles, as in graph_spec)."""
     spec = graph_spec(k)
     rng = np.random.default_rng(79_000 + k)
     keyed = k % 3 != 0
     n_srv, n_rtr = len(spec["servers"]), len(spec["routers"])
     lbs = []
     for j in range(int(rng.integers(1, 4))):
-        strategy = str(rng.choice(["chash", "round_robin", "random"] if keyed else ["round_robin"]))
+        strategy = str(rng.choice(["chash", "chash", "round_robin", "random"] if keyed else ["round_robin"]))
         nb = int(rng.integers(1, min(4, n_srv) + 1))
         lo = int(rng.integers(0, n_srv - nb + 1))
         backends = sorted(int(b) for b in rng.choice(np.arange(lo, n_srv), size=nb, replace=False))
@@ -195,7 +196,7 @@ def lb_graph_spec(k):
             if ok and rng.random() < 0.25:
                 t[0], t[1] = "lb", int(rng.choice(ok))
     for sc in spec["sources"]:
-        if keyed:
+        if keyed and rng.random() < 0.7:
             sc["n_clients"] = int(rng.choice([5, 50, 1000]))
         if rng.random() < 0.6:
             j = int(rng.integers(0, len(lbs)))
@@ -204,17 +205,17 @@ def lb_graph_spec(k):
                 sc["n_clients"] = len(lbs[j]["backends"])
     for j, lb in enumerate(lbs):                                  # every LoadBalancer sees traffic
         if not any(sc["to"] == ["lb", j] for sc in spec["sources"]):
-            nc = len(lb["backends"]) if lb["strategy"] == "random" else int(rng.choice([5, 50, 1000])) if keyed else 0
+            nc = len(lb["backends"]) if lb["strategy"] == "random" else int(rng.choice([0, 5, 50, 1000])) if keyed else 0
             spec["sources"].append(dict(kind="poisson", rate=float(rng.choice([2.0, 6.0])), to=["lb", j], **({"n_clients": nc} if nc else {})))
     spec["lbs"] = lbs
-    if not keyed:
-        end = spec["end_s"]
-        pools = [["server", n_srv], ["router", n_rtr], ["link", len(spec["links"])], ["lb", len(lbs)], ["lb", len(lbs)]]
-        sched = []
-        for _ in range(int(rng.integers(2, 9))):
-            kind, cnt = pools[int(rng.integers(0, len(pools)))]
-            t = float(rng.choice([0.0, 0.5, 0.5, 1.0, float(np.round(rng.uniform(0.0, end), 3)), end, end + 0.5]))
-            sched.append([[kind, int(rng.integers(0, cnt))], t])
+    end = spec["end_s"]
+    pools = [["server", n_srv], ["router", n_rtr], ["link", len(spec["links"])]] + [["lb", j] for j in inner] * 2
+    sched = []
+    for _ in range(int(rng.integers(2, 9)) if (not keyed or k % 2) else 0):
+        kind, cnt = pools[int(rng.integers(0, len(pools)))]
+        t = float(rng.choice([0.0, 0.5, 0.5, 1.0, float(np.round(rng.uniform(0.0, end), 3)), end, end + 0.5]))
+        sched.append([[kind, cnt if kind == "lb" else int(rng.integers(0, cnt))], t])
+    if sched:
         spec["schedule"] = sched
     spec["name"] = f"lb_graph_{k}"
     return spec

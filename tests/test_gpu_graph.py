@@ -45,8 +45,9 @@ def _compare_with_oracle(spec, sim, ents, r, nodes):
                                        lb._in_flight_count], r.lbs[nd]["stats"], err_msg=f"lb {j}")
         np.testing.assert_array_equal([lb.get_backend_info(b).total_requests for b in lb.all_backends], r.lbs[nd]["total_requests"],
                                       err_msg=f"lb {j} backends")
-        if spec["lbs"][j]["strategy"] == "round_robin":
-            assert lb.strategy._index == st.requests_forwarded
+        kind = spec["lbs"][j]["strategy"]
+        got_index = lb.strategy._index if kind == "round_robin" else lb.strategy._fallback._index if kind == "chash" else -1
+        assert got_index == r.lbs[nd]["strategy_index"]
 
 
 @pytest.mark.parametrize("name", H.golden_names("graph"))
@@ -75,7 +76,7 @@ def test_general_graphs_match_the_live_reference_goldens(name):
         lo, hi = gold.lb_backend_off[j], gold.lb_backend_off[j + 1]
         np.testing.assert_array_equal([lb.get_backend_info(b).total_requests for b in lb.all_backends],
                                       gold.lb_backend_total_requests[lo:hi], err_msg=f"lb {j} backends")
-        assert getattr(lb.strategy, "_index", -1) == gold.lb_rr_index[j]
+        assert (lb.strategy._fallback._index if isinstance(lb.strategy, hs.ConsistentHash) else getattr(lb.strategy, "_index", -1)) == gold.lb_rr_index[j]
 
 
 @pytest.mark.parametrize("block", range(8))
@@ -112,25 +113,27 @@ def test_graphs_with_several_load_balancers_match_the_oracle(block):
         assert sum(lb.stats.requests_forwarded for lb in ents["lbs"]) > 0
 
 
-def test_key_less_requests_for_a_key_based_load_balancer_are_refused_by_name():
-    """A Request without a client id at a ConsistentHash / Random LoadBalancer: the reference falls back to a RoundRobin of the
-    strategy's own / the process-wide generator -- refused by name, for plain Sources and for `schedule()`d Requests."""
+def test_key_less_requests_for_a_random_load_balancer_are_refused_by_name():
+    """A Request without a client id at a Random LoadBalancer would ask the process-wide generator -- refused by name, for Sources
+    that reach it through other entities and for `schedule()`d Requests.  (At a ConsistentHash LoadBalancer a key-less Request is
+    the reference's own case -- the strategy's fallback RoundRobin: lb_graph_spec, the graph_keyless_consistent_hash fixture.)"""
     sink = hs.Sink("k")
     servers = [hs.Server(f"srv{i}", service_time=hs.ExponentialLatency(0.01), downstream=sink) for i in range(3)]
-    lb = hs.LoadBalancer("lb", backends=servers[1:], strategy=hs.ConsistentHash(virtual_nodes=5))
+    lb = hs.LoadBalancer("lb", backends=servers[1:], strategy=hs.Random())
+    direct = hs.Source.poisson(rate=5, event_provider=hs.ClientKeyEventProvider(lb, n_clients=2), name="a")
     servers[0].downstream = lb
-    keyed = hs.Source.poisson(rate=5, event_provider=hs.ClientKeyEventProvider(servers[0], n_clients=7), name="a")
-    plain = hs.Source.poisson(rate=5, target=servers[0], name="b")
-    with pytest.raises(hs.UnsupportedTopology, match="must come from a ClientKeyEventProvider"):
-        hs.Simulation(duration=1, sources=[keyed, plain], entities=[*servers, lb, sink]).lowered()
-    sim = hs.Simulation(duration=1, sources=[keyed], entities=[*servers, lb, sink])
-    sim.schedule(hs.Event(time=hs.Instant.from_seconds(0.5), event_type="Request", target=servers[0]))
+    around = hs.Source.poisson(rate=5, target=servers[0], name="b")
+    with pytest.raises(hs.UnsupportedTopology, match="only Sources that aim at it directly"):
+        hs.Simulation(duration=1, sources=[direct, around], entities=[*servers, lb, sink]).lowered()
+    servers[0].downstream = sink
+    sim = hs.Simulation(duration=1, sources=[direct, around], entities=[*servers, lb, sink])
+    sim.schedule(hs.Event(time=hs.Instant.from_seconds(0.5), event_type="Request", target=lb))
     with pytest.raises(hs.UnsupportedTopology, match="carries no client id"):
         sim.run()
-    sim = hs.Simulation(duration=1, sources=[keyed], entities=[*servers, lb, sink])
+    sim = hs.Simulation(duration=1, sources=[direct, around], entities=[*servers, lb, sink])
     sim.schedule(hs.Event(time=hs.Instant.from_seconds(0.5), event_type="Request", target=servers[2]))     # (cannot reach the LoadBalancer)
     sim.run()
-    assert lb.stats.requests_received == servers[0]._requests_completed > 0
+    assert 0 < lb.stats.requests_received <= direct.generated_count
 
 
 def test_scheduled_requests_on_a_general_graph_take_the_pre_run_indices():

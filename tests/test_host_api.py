@@ -251,10 +251,13 @@ class TestLoadBalancerLowering:
     def test_unsupported_lb_graphs_are_refused_explicitly(self):
         srcs, lb, nodes, sinks = self._topology()
         plain = hs.Source.poisson(rate=5, target=lb)
-        with pytest.raises(hs.UnsupportedTopology, match="ClientKeyEventProvider"):
-            hs.Simulation(duration=1, sources=[plain], entities=[lb, *nodes, sinks[0]]).lowered()
-        # outside the pipeline's shape: lower_lb refuses by name, Simulation takes the graph to the single-heap path (round 6)
         from happy_simulator_amd.graph_engine import GeneralGraph
+        with pytest.raises(hs.UnsupportedTopology, match="ClientKeyEventProvider"):
+            L.lower_lb([plain], [lb, *nodes, sinks[0]], lb)
+        # (key-less Requests at a ConsistentHash LoadBalancer take the strategy's fallback RoundRobin: the single-heap path runs them)
+        sim = hs.Simulation(duration=1, sources=[plain], entities=[lb, *nodes, sinks[0]])
+        assert isinstance(sim.lowered(), GeneralGraph) and "ClientKeyEventProvider" in sim._station_refusal
+        # outside the pipeline's shape: lower_lb refuses by name, Simulation takes the graph to the single-heap path (round 6)
         nodes[1].downstream = hs.Sink("other")
         with pytest.raises(hs.UnsupportedTopology, match="share ONE Sink"):
             L.lower_lb(srcs, [lb, *nodes], lb)

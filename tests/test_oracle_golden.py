@@ -109,8 +109,7 @@ def check_oracle_against_graph_golden(gold):
         np.testing.assert_array_equal(r.lbs[nd]["stats"], gold.lb_stats[j], err_msg=f"lb {j}")
         lo, hi = gold.lb_backend_off[j], gold.lb_backend_off[j + 1]
         np.testing.assert_array_equal(r.lbs[nd]["total_requests"], gold.lb_backend_total_requests[lo:hi], err_msg=f"lb {j} backends")
-        if spec["lbs"][j]["strategy"] == "round_robin":
-            assert r.lbs[nd]["stats"][1] == gold.lb_rr_index[j]
+        assert r.lbs[nd]["strategy_index"] == gold.lb_rr_index[j]          # RoundRobin._index / ConsistentHash's key-less fallback's / -1
     srv = nodes["server"]
     for k, arr in (("accepted", r.accepted), ("dropped", r.dropped), ("completed", r.completed), ("rejected", r.rejected),
                    ("depth", r.depth), ("active", r.active), ("total_service_s", r.total_service_s)):
