@@ -34,8 +34,9 @@
 namespace hs {
 namespace graph {
 
+constexpr int kLdsNodes = 192, kLdsNodesBatch = 48;   // nodes whose parameters and state stay in LDS for a launch (24 KB / 6 KB)
 constexpr int kLdsHeapBatch = 1024;            // ... of each of the heaps hs_graph_run_many runs side by side
-constexpr int kLdsHeap = 4096;                 // heap entries in LDS: 4 096 x 32 B = 128 KB of the CU's 160
+constexpr int kLdsHeap = 4096;                 // heap entries in LDS: 4 096 x 32 B = 128 KB of the CU's 160 (+ 24 KB of nodes)
 constexpr long long kBudget = 1ll << 21;       // events per launch (~2 s)
 
 struct GEvent {                                // 32 bytes
@@ -217,10 +218,25 @@ __device__ inline int64_t next_arrival(const GCtl &c, int n) {
     return a2;
 }
 
-template <int W>
-__device__ __forceinline__ void graph_loop(const GCtl &c, GEvent *lheap) {
+// NL: graphs of up to NL nodes keep their nodes' parameters and state in LDS for the launch (the loop's dependent chain goes
+// through them several times per event: 64-cycle LDS round trips instead of L2's) -- `lnodes`: NL x (GParam + GState).
+template <int W, int NL>
+__device__ __forceinline__ void graph_loop(const GCtl &c0, GEvent *lheap, char *lnodes) {
+    __shared__ unsigned long long s_by_kind[HS_EV_KINDS];
+    GCtl c = c0;
     GVars &V = *c.V;
     const int lane = threadIdx.x;
+    const bool nodes_in_lds = c.n <= NL;
+    if (nodes_in_lds) {
+        const long long n8 = (long long)c.n * (long long)(sizeof(GParam) / 8);
+        static_assert(sizeof(GParam) == sizeof(GState), "one copy loop for both");
+        const uint64_t *sp = reinterpret_cast<const uint64_t *>(c0.P), *ss = reinterpret_cast<const uint64_t *>(c0.S);
+        uint64_t *dp = reinterpret_cast<uint64_t *>(lnodes), *ds = reinterpret_cast<uint64_t *>(lnodes + (size_t)NL * sizeof(GParam));
+        for (long long i = lane; i < n8; i += 64) { dp[i] = sp[i]; ds[i] = ss[i]; }
+        c.P = reinterpret_cast<const GParam *>(lnodes);
+        c.S = reinterpret_cast<GState *>(lnodes + (size_t)NL * sizeof(GParam));
+    }
+    if (lane < HS_EV_KINDS) s_by_kind[lane] = 0ull;
     {   // the heap's head comes into LDS (all 64 lanes copy; 8 bytes per lane and step)
         const long long n8 = (V.heap_len < W ? V.heap_len : (long long)W) * (long long)(sizeof(GEvent) / 8);
         const uint64_t *src = reinterpret_cast<const uint64_t *>(c.heap);
@@ -229,6 +245,7 @@ __device__ __forceinline__ void graph_loop(const GCtl &c, GEvent *lheap) {
     }
     __syncthreads();
     if (lane == 0) {
+        int req_free = V.req_free, req_len = V.req_len;                     // (registers for the launch)
         Heap<W> H{lheap, c.heap, V.heap_len};
         unsigned long long G = V.counter;
         int status = kRunning;
@@ -254,9 +271,9 @@ __device__ __forceinline__ void graph_loop(const GCtl &c, GEvent *lheap) {
         // Simulation.schedule (core/simulation.py:195-206): Events constructed outside the run
         while (status == kRunning && V.sched_done < c.n_sched) {
             if (H.len + 1 > c.heap_cap) { status |= kGrowHeap; break; }
-            int r = V.req_free;
-            if (r >= 0) V.req_free = c.reqs[r].next;
-            else if (V.req_len < c.req_cap) r = V.req_len++;
+            int r = req_free;
+            if (r >= 0) req_free = c.reqs[r].next;
+            else if (req_len < c.req_cap) r = req_len++;
             else { status |= kGrowReq; break; }
             const int node = c.sched_node[V.sched_done];
             const int64_t t = c.sched_t[V.sched_done];
@@ -266,15 +283,13 @@ __device__ __forceinline__ void graph_loop(const GCtl &c, GEvent *lheap) {
             V.sched_done++;
         }
         long long cur = V.cur, processed = 0, n_completed = 0, n_received = 0, rec_n = V.rec_n;
-        long long by_kind[HS_EV_KINDS];
-        for (int k = 0; k < HS_EV_KINDS; ++k) by_kind[k] = 0;
         long long peak = V.heap_peak;
         while (status == kRunning) {
             if (!(H.len > 0 && cur <= c.end_ns)) { status = kDone; break; }       // core/simulation.py:472 tests the PREVIOUS event's time
             if (processed >= c.budget) break;
             // room for whatever this event constructs (at most two pushes, one Request, one record)
             if (H.len + 2 > c.heap_cap) { status |= kGrowHeap; break; }
-            if (V.req_free < 0 && V.req_len >= c.req_cap) { status |= kGrowReq; break; }
+            if (req_free < 0 && req_len >= c.req_cap) { status |= kGrowReq; break; }
             if (rec_n >= c.rec_cap) { status |= kGrowRec; break; }
             if (c.ticks != nullptr) {                                              // the next tick of a table-driven stream must be in its table
                 const GEvent top = H.get(0);
@@ -297,7 +312,7 @@ __device__ __forceinline__ void graph_loop(const GCtl &c, GEvent *lheap) {
             const int n = e.node;
             const int64_t t = e.t;
             if (e.kind >= (uint32_t)HS_EV_KINDS) { status |= kBadKind; break; }
-            by_kind[e.kind]++;
+            s_by_kind[e.kind] += 1ull;
             const GParam p = c.P[n];
             GState &s = c.S[n];
             switch (e.kind) {
@@ -308,8 +323,8 @@ __device__ __forceinline__ void graph_loop(const GCtl &c, GEvent *lheap) {
                 int r = -1;
                 unsigned long long idx_p = 0;
                 if (payload) {
-                    r = V.req_free;
-                    if (r >= 0) V.req_free = c.reqs[r].next; else r = V.req_len++;
+                    r = req_free;
+                    if (r >= 0) req_free = c.reqs[r].next; else r = req_len++;
                     idx_p = G++;
                     GRequest q; q.created = t; q.idx = idx_p; q.service_s = 0.0; q.client = -1; q.next = -1; q.hook = -1;
                     if (p.conc > 0) {                                               // chash_example.py:83: one client id per Request
@@ -331,7 +346,7 @@ __device__ __forceinline__ void graph_loop(const GCtl &c, GEvent *lheap) {
                 c.reqs[e.req].hook = -1;
                 if (p.lim >= 0 && s.qlen >= p.lim) {                               // FIFOQueue.push refuses (queue_policy.py:94-98)
                     s.b += 1;
-                    c.reqs[e.req].next = V.req_free; V.req_free = e.req;
+                    c.reqs[e.req].next = req_free; req_free = e.req;
                 } else {
                     c.reqs[e.req].idx = e.idx;              // the queued payload IS this Event object
                     c.reqs[e.req].next = -1;
@@ -366,7 +381,7 @@ __device__ __forceinline__ void graph_loop(const GCtl &c, GEvent *lheap) {
                 (void)G++;
                 if (!(s.active < p.conc)) {                                         // acquire() failed (server.py:223-234)
                     s.d += 1;
-                    c.reqs[e.req].next = V.req_free; V.req_free = e.req;
+                    c.reqs[e.req].next = req_free; req_free = e.req;
                     break;
                 }
                 s.active += 1;
@@ -387,14 +402,14 @@ __device__ __forceinline__ void graph_loop(const GCtl &c, GEvent *lheap) {
                 s.c += 1; n_completed++;
                 s.total_service = __dadd_rn(s.total_service, c.reqs[e.req].service_s);
                 if (p.target >= 0) H.push(mk(t, G++, arrival_kind(c.P, p.target), p.target, e.req));
-                else { c.reqs[e.req].next = V.req_free; V.req_free = e.req; }
+                else { c.reqs[e.req].next = req_free; req_free = e.req; }
                 if (s.active < p.conc) H.push(mk(t, G++, HS_EV_POLL, n, -1));
             } break;
             case HS_EV_SINK: {                                                      // Sink.handle_event (components/common.py:36-44)
                 c.rec_node[rec_n] = n; c.rec_t[rec_n] = t; c.rec_cr[rec_n] = c.reqs[e.req].created;
                 rec_n++;
                 s.a += 1; n_received++;
-                c.reqs[e.req].next = V.req_free; V.req_free = e.req;
+                c.reqs[e.req].next = req_free; req_free = e.req;
             } break;
             case HS_EV_ROUTE: {                                                     // RandomRouter.handle_event (random_router.py:32-45)
                 const double u = uniform_at(c.seed, stream_id(p.stream_base, kStreamRoute), (uint64_t)s.a);
@@ -411,7 +426,7 @@ __device__ __forceinline__ void graph_loop(const GCtl &c, GEvent *lheap) {
                 s.a = entered + 1;
                 if (p.loss > 0.0 && uniform_at(c.seed, stream_id(p.stream_base, kStreamLoss), (uint64_t)entered) < p.loss) {   // link.py:131-138
                     s.c += 1;
-                    c.reqs[e.req].next = V.req_free; V.req_free = e.req;
+                    c.reqs[e.req].next = req_free; req_free = e.req;
                     break;
                 }
                 double delay = seconds_from_ns(ns_from_seconds(p.lat_min));
@@ -427,14 +442,14 @@ __device__ __forceinline__ void graph_loop(const GCtl &c, GEvent *lheap) {
             case HS_EV_LINK_CONT:                                                   // transit over (link.py:156-189): a NEW Event for the egress
                 s.b += 1;
                 if (p.target >= 0) H.push(mk(t, G++, arrival_kind(c.P, p.target), p.target, e.req));
-                else { c.reqs[e.req].next = V.req_free; V.req_free = e.req; }
+                else { c.reqs[e.req].next = req_free; req_free = e.req; }
                 break;
             case HS_EV_LB: {
                 // LoadBalancer._forward_request (load_balancer.py:347-433), every backend healthy
                 s.a += 1;                                                           // :349
                 if (p.rt_cnt == 0) {                                                // no healthy backends, :352-366
                     s.c += 1;
-                    c.reqs[e.req].next = V.req_free; V.req_free = e.req;
+                    c.reqs[e.req].next = req_free; req_free = e.req;
                     break;
                 }
                 const int64_t client = c.reqs[e.req].client;
@@ -490,7 +505,8 @@ __device__ __forceinline__ void graph_loop(const GCtl &c, GEvent *lheap) {
             }
         }
         V.heap_len = H.len; V.counter = G; V.cur = cur; V.processed += processed; V.rec_n = rec_n;
-        for (int k = 0; k < HS_EV_KINDS; ++k) V.by_kind[k] += by_kind[k];
+        for (int k = 0; k < HS_EV_KINDS; ++k) V.by_kind[k] += (long long)s_by_kind[k];
+        V.req_free = req_free; V.req_len = req_len;
         V.completed += n_completed; V.received += n_received;
         V.heap_peak = peak;
         V.status = status;
@@ -502,20 +518,28 @@ __device__ __forceinline__ void graph_loop(const GCtl &c, GEvent *lheap) {
         const uint64_t *src = reinterpret_cast<const uint64_t *>(lheap);
         for (long long i = lane; i < n8; i += 64) dst[i] = src[i];
     }
+    if (nodes_in_lds) {   // the nodes' state returns to its place
+        const long long n8 = (long long)c.n * (long long)(sizeof(GState) / 8);
+        const uint64_t *ss = reinterpret_cast<const uint64_t *>(lnodes + (size_t)NL * sizeof(GParam));
+        uint64_t *ds = reinterpret_cast<uint64_t *>(c0.S);
+        for (long long i = lane; i < n8; i += 64) ds[i] = ss[i];
+    }
 }
 
 __global__ void __launch_bounds__(64) hs_graph_run(GCtl c) {
     __shared__ GEvent lheap[kLdsHeap];
-    graph_loop<kLdsHeap>(c, lheap);
+    __shared__ __attribute__((aligned(16))) char lnodes[kLdsNodes * (sizeof(GParam) + sizeof(GState))];
+    graph_loop<kLdsHeap, kLdsNodes>(c, lheap, lnodes);
 }
 
 // Independent graphs -- the replicas / sweep points of parallel/runner.py:82-142 -- side by side: one workgroup (one heap) each, one
-// with a quarter of the lone run's LDS window (32 KB: five workgroups per CU, 1 280 heaps on the device at once; a heap that outgrows
+// with a quarter of the lone run's LDS window (32 KB + 6 KB of nodes: four workgroups per CU, 1 024 heaps on the device at once; a heap that outgrows
 // the window continues in HBM as it does behind the large one -- the window's size changes nothing the loop computes).
 __global__ void __launch_bounds__(64) hs_graph_run_batch(const GCtl *cs) {
     __shared__ GEvent lheap[kLdsHeapBatch];
+    __shared__ __attribute__((aligned(16))) char lnodes[kLdsNodesBatch * (sizeof(GParam) + sizeof(GState))];
     const GCtl c = cs[blockIdx.x];
-    graph_loop<kLdsHeapBatch>(c, lheap);
+    graph_loop<kLdsHeapBatch, kLdsNodesBatch>(c, lheap, lnodes);
 }
 
 }  // namespace graph

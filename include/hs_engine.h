@@ -770,7 +770,7 @@ int hs_graph_schedule(hs_graph *g, int32_t node, int64_t time_ns);
 int hs_graph_run_until(hs_graph *g, int64_t end_ns);
 /* ParallelRunner.run_sweep / run_replicas (parallel/runner.py:82-142: one worker process per independent Simulation) for graphs of
  * this path: `n` handles on one device run to `end_ns` SIDE BY SIDE -- one workgroup and one heap each, one launch for all of them
- * (up to 1 280 resident at once: five per CU with a 32 KB window of the heap in LDS), relaunched for the ones that have to grow a buffer.  Every handle ends in
+ * (up to 1 024 resident at once: four per CU with a 32 KB window of the heap in LDS), relaunched for the ones that have to grow a buffer.  Every handle ends in
  * exactly the state hs_graph_run_until(handle, end_ns) would leave; the device time a handle reports (hs_summary.last_run_ms) is the batch's.  On
  * an error the first handle's hs_graph_last_error names the graph. */
 int hs_graph_run_many(hs_graph *const *graphs, int32_t n, int64_t end_ns);
