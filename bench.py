@@ -163,6 +163,45 @@ def api_run(args, device):
     return out
 
 
+def graph_replicas_run(args, device, n_replicas=1024):
+    """ParallelRunner.run_replicas over a graph OUTSIDE the station shape (three LoadBalancers -- ConsistentHash behind a Server and a
+    router, RoundRobin, Random --, six Servers, a router, a lossy link, five Sources: the `graph_three_load_balancers` fixture's
+    topology): `n_replicas` independent heaps side by side, one workgroup each (csrc/hs_graph.hip hs_graph_run_many).  Device time of
+    the batch, wall time through the Python API."""
+    import happy_simulator_amd as hs
+
+    sims = []
+
+    def build():
+        sinks = [hs.Sink(f"sink{j}") for j in range(2)]
+        mean, conc, cap = (0.03, 0.05, 0.06, 0.04, 0.08, 0.05), (1, 2, 1, 1, 3, 1), (None, None, 3, None, None, 2)
+        sv = [hs.Server(f"srv{i}", concurrency=conc[i], service_time=hs.ExponentialLatency(mean[i]), queue_capacity=cap[i]) for i in range(6)]
+        link = hs.NetworkLink("link0", latency=hs.ConstantLatency(0.002), jitter=hs.ExponentialLatency(0.003), packet_loss_rate=0.05, egress=sv[4])
+        lbs = [hs.LoadBalancer("lb0", backends=[sv[2], sv[3], sv[5]], strategy=hs.ConsistentHash(virtual_nodes=17)),
+               hs.LoadBalancer("lb1", backends=[sv[4], sv[2]], strategy=hs.RoundRobin()),
+               hs.LoadBalancer("lb2", backends=[sv[0], sv[1], sv[3]], strategy=hs.Random())]
+        router = hs.RandomRouter("router0", targets=[sinks[1], lbs[0], lbs[1], link])
+        for i, d in enumerate((lbs[0], router, sinks[0], link, sinks[1], sinks[0])):
+            sv[i].downstream = d
+        plan = (("poisson", 8.0, sv[0], 50), ("poisson", 6.0, sv[1], 5), ("constant", 4.0, lbs[1], 1000), ("poisson", 9.0, lbs[2], 3),
+                ("poisson", 5.0, lbs[0], 1000))
+        sources = [(hs.Source.poisson if k == "poisson" else hs.Source.constant)(
+            rate=r, event_provider=hs.ClientKeyEventProvider(to, n_clients=nc), name=f"src{j}") for j, (k, r, to, nc) in enumerate(plan)]
+        sims.append(hs.Simulation(end_time=hs.Instant.from_seconds(args.end_s), sources=sources, entities=sv + lbs + [router, link] + sinks,
+                                  device=device))
+        return sims[-1]
+
+    t0 = time.perf_counter()
+    res = hs.ParallelRunner(device=device).run_replicas(build, n_replicas, base_seed=args.seed)
+    wall = time.perf_counter() - t0
+    events = sum(r.summary.total_events_processed for r in res)
+    dev_ms = float(sims[0]._engine_summary.last_run_ms)
+    return {"graph_replicas": {"what": f"{n_replicas} replicas of a 17-entity graph with three LoadBalancers x {args.end_s:g} s on the single-heap "
+                                       "path, one workgroup per replica (hs_graph_run_many)",
+                               "replicas": n_replicas, "events": events, "device_ms": dev_ms, "events_per_s_device": events / (dev_ms / 1e3),
+                               "wall_s_python_api": wall, "events_per_s_python_api": events / wall}}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start one rank per GPU (torch.distributed.run, 127.0.0.1)."""
     import socket
@@ -766,6 +805,8 @@ def main():
             out["config"]["other_workloads"] = brief
         if args.api_run and world == 1 and rank == 0:
             out["config"].update(api_run(args, local_rank))
+        if args.extras and world == 1 and rank == 0:
+            out["config"].setdefault("other_workloads", {}).update(graph_replicas_run(args, local_rank))
     if rank == 0:
         if fake:
             out["fake_ranks"] = world

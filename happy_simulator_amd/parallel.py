@@ -225,7 +225,15 @@ def _run_general_batch(sims: list[Simulation], graphs: list) -> list[SimulationS
                 raise UnsupportedTopology("end_time = Infinity with Sources or Probes never terminates (their ticks are primary events, "
                                           "in the reference too); pass end_time/duration")
             end_ns, start_ns, sched, cancelled_ns = s._general_prepare(g, auto)
-            engines.append(s._general_engine(g, start_ns, sched))
+            # the record log of a replica starts near what its Sources can produce (it grows on demand): thousands of replicas
+            # should not hold 1.3 MB of log each
+            a = g.arrays
+            horizon_s = 0.0 if auto else max(end_ns - start_ns, 0) / 1e9
+            want = 2.0 * float(a.src_rate[a.kind == N.NODE_SOURCE].sum()) * horizon_s + 2.0 * len(sched) + 256.0
+            n_probe = int((a.kind == N.NODE_PROBE).sum())
+            if n_probe:
+                want += float((horizon_s / a.probe_interval_s[a.kind == N.NODE_PROBE]).sum()) + 2.0 * n_probe
+            engines.append(s._general_engine(g, start_ns, sched, record_capacity=int(min(max(want, 1024.0), 65536.0))))
             plans.append((end_ns, cancelled_ns))
         for end_ns in sorted({p[0] for p in plans}):
             GraphEngine.run_many([e for e, p in zip(engines, plans) if p[0] == end_ns], end_ns)

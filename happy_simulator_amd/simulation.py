@@ -344,8 +344,9 @@ class Simulation:
             sched.append((i, ev.time.nanoseconds))
         return end_ns, start_ns, sched, cancelled_ns
 
-    def _general_engine(self, g: GeneralGraph, start_ns: int, sched) -> GraphEngine:
-        eng = GraphEngine(g.arrays, seed=self._seed, start_ns=start_ns, device=self._device, max_events=self._max_graph_events)
+    def _general_engine(self, g: GeneralGraph, start_ns: int, sched, record_capacity: int = 0) -> GraphEngine:
+        eng = GraphEngine(g.arrays, seed=self._seed, start_ns=start_ns, device=self._device, max_events=self._max_graph_events,
+                          record_capacity=record_capacity)
         try:
             for node, t in sched:
                 eng.schedule(node, t)

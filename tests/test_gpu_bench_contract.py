@@ -84,6 +84,9 @@ def test_default_line_carries_ring_lb_and_the_strong_shard():
     assert brief["ring"]["ms_per_step"] == d["workloads"]["ring"]["ms_per_step"] and brief["lb"]["events_per_s"] == d["workloads"]["lb"]["value"]
     assert brief["strong_shard_8192"]["ms_per_step"] == sh["ms_per_step"]
     assert sh["events_per_step"] < d["config"]["events_per_step_per_gpu"]
+    gr = brief["graph_replicas"]                     # round 6: replicas of a graph outside the station shape, one workgroup each
+    assert gr["replicas"] == 1024 and gr["events"] > 1024 * 1000 and 0 < gr["device_ms"] < 1e3 * gr["wall_s_python_api"]
+    assert gr["events_per_s_device"] > gr["events_per_s_python_api"] > 1e6
 
 
 def test_fake_ranks_run_the_multi_rank_bench_paths_on_one_gpu():
