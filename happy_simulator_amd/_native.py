@@ -448,6 +448,8 @@ def lib():
     L.hs_graph_run_until.argtypes = [C.c_void_p, C.c_int64]
     L.hs_graph_run_many.restype = C.c_int
     L.hs_graph_run_many.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int64]
+    L.hs_graph_run_parts.restype = C.c_int
+    L.hs_graph_run_parts.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int64]
     L.hs_graph_get_summary.restype = C.c_int
     L.hs_graph_get_summary.argtypes = [C.c_void_p, P(Summary)]
     L.hs_graph_get_stats.restype = C.c_int
@@ -486,6 +488,6 @@ EXPORTED_SYMBOLS = (
     "hs_lb_ring", "hs_lb_select", "hs_lb_last_error", "hs_lb_destroy", "hs_md5", "hs_debug_radix_sort", "hs_merge_sink_records",
     "hs_sink_latency_stats", "hs_set_float_sum_mode",
     "hs_debug_lb_flags", "hs_engine_set_profile_budget", "hs_lb_set_profile_budget", "hs_debug_tick_table",
-    "hs_graph_create", "hs_graph_schedule", "hs_graph_run_until", "hs_graph_run_many", "hs_graph_get_summary", "hs_graph_get_stats", "hs_graph_read_records",
+    "hs_graph_create", "hs_graph_schedule", "hs_graph_run_until", "hs_graph_run_many", "hs_graph_run_parts", "hs_graph_get_summary", "hs_graph_get_stats", "hs_graph_read_records",
     "hs_graph_last_error", "hs_graph_destroy",
 )

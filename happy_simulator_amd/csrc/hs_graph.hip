@@ -86,7 +86,7 @@ struct GRequest {                              // 32 bytes: the payload Event's 
     int32_t hook;                              // LoadBalancer whose `_lb_response` hook rides on the Event (-1: none)
 };
 
-enum : int { kRunning = 0, kDone = 1, kGrowHeap = 2, kGrowReq = 4, kGrowRec = 8, kBadKind = 16, kGrowTicks = 32 };
+enum : int { kRunning = 0, kDone = 1, kGrowHeap = 2, kGrowReq = 4, kGrowRec = 8, kBadKind = 16, kGrowTicks = 32, kUndecided = 64 };
 
 struct GVars {                                 // device scalars
     long long heap_len;
@@ -119,6 +119,7 @@ struct GCtl {                                  // kernel argument
     uint64_t seed;
     int64_t start_ns, end_ns;
     long long budget;
+    int part;                                  // 1: this heap holds PART of a Simulation (hs_graph_run_parts)
 };
 
 __device__ __forceinline__ bool ev_lt(const GEvent &a, const GEvent &b) {   // Event.__lt__, core/event.py:337-344
@@ -197,6 +198,14 @@ __device__ __forceinline__ GEvent mk(int64_t t, uint64_t idx, uint32_t kind, int
     e.t = t; e.idx = idx; e.node = node; e.req = req; e.kind = kind; e.pad = 0;
     return e;
 }
+// ... one constructed BEFORE the run: its index comes from the process-wide counter (core/event.py:53-67), the run's own events count
+// from zero again -- GEvent::pad tells the two apart (part runs: a timestamp group that mixes them is order-sensitive to ALL of a
+// Simulation's events, hs_graph_run_parts)
+__device__ __forceinline__ GEvent mk_pre(int64_t t, uint64_t idx, uint32_t kind, int node, int req) {
+    GEvent e = mk(t, idx, kind, node, req);
+    e.pad = 1;
+    return e;
+}
 
 // ArrivalTimeProvider.next_arrival_time, constant-rate fast path (load/arrival_time_provider.py:72-82) with the target area of
 // poisson_arrival.py:31 / constant_arrival.py:23
@@ -258,13 +267,13 @@ __device__ __forceinline__ void graph_loop(const GCtl &c0, GEvent *lheap, char *
                 c.S[i].a = c.start_ns;                          // provider.current_time = start_time
                 const int64_t t = next_arrival(c, i);
                 if (t == kInfNs) continue;                      // "Rate is zero indefinitely. Source will not start." (source.py:137-139)
-                H.push(mk(t, g++, HS_EV_SOURCE, i, -1));        // (heap_cap >= 4 n: hs_graph_create)
+                H.push(mk_pre(t, g++, HS_EV_SOURCE, i, -1));    // (heap_cap >= 4 n: hs_graph_create)
             }
             for (int i = 0; i < c.n; ++i) {                     // then the probes, in list order (core/simulation.py:156-160)
                 if (c.P[i].kind != HS_NODE_PROBE) continue;
                 const int64_t t = c.ticks[(size_t)c.P[i].rt_off * (size_t)c.tick_cap];
                 if (t == kInfNs) continue;
-                H.push(mk(t, g++, HS_EV_PROBE_TICK, i, -1));
+                H.push(mk_pre(t, g++, HS_EV_PROBE_TICK, i, -1));
             }
             V.global_counter = g; V.booted = 1; G = 0; V.cur = c.start_ns;
         }
@@ -279,13 +288,15 @@ __device__ __forceinline__ void graph_loop(const GCtl &c0, GEvent *lheap, char *
             const int64_t t = c.sched_t[V.sched_done];
             GRequest q; q.created = t; q.idx = V.global_counter; q.service_s = 0.0; q.client = -1; q.next = -1; q.hook = -1;
             c.reqs[r] = q;
-            H.push(mk(t, V.global_counter++, arrival_kind(c.P, node), node, r));
+            H.push(mk_pre(t, V.global_counter++, arrival_kind(c.P, node), node, r));
             V.sched_done++;
         }
         long long cur = V.cur, processed = 0, n_completed = 0, n_received = 0, rec_n = V.rec_n;
         long long peak = V.heap_peak;
         while (status == kRunning) {
-            if (!(H.len > 0 && cur <= c.end_ns)) { status = kDone; break; }       // core/simulation.py:472 tests the PREVIOUS event's time
+            // core/simulation.py:472 tests the PREVIOUS event's time; a PART of a Simulation stops in front of the first event beyond
+            // the end (which of the parts' first events the reference still processes is decided across all of them)
+            if (!(H.len > 0 && (c.part ? H.get(0).t <= c.end_ns : cur <= c.end_ns))) { status = kDone; break; }
             if (processed >= c.budget) break;
             // room for whatever this event constructs (at most two pushes, one Request, one record)
             if (H.len + 2 > c.heap_cap) { status |= kGrowHeap; break; }
@@ -306,6 +317,13 @@ __device__ __forceinline__ void graph_loop(const GCtl &c0, GEvent *lheap, char *
             }
             if (H.len > peak) peak = H.len;
             const GEvent e = H.pop();
+            if (c.part && H.len > 0) {
+                // two PENDING events of one nanosecond, one numbered before the run and one by the run: which comes first depends on how
+                // many events the WHOLE Simulation had created by then, not only this part -- undecided here.  (Every such pair meets as
+                // (popped, next) at some pop: a timestamp group is popped back to back.)
+                const GEvent nx = H.get(0);
+                if (nx.t == e.t && ((nx.pad ^ e.pad) & 1u)) { status |= kUndecided; break; }
+            }
             if (e.t < cur) continue;                                               // time-travel drop, core/simulation.py:480-489
             cur = e.t;
             processed++;
@@ -567,6 +585,7 @@ struct hs_graph {
     double last_run_ms = 0.0;
     long long launches = 0;
     bool ran = false;
+    bool undecided = false;                    // a part run met a timestamp group only the whole Simulation orders (hs_graph_run_parts)
     std::string error;
 };
 
@@ -978,6 +997,7 @@ static int after_launch(hs_graph *g, bool *done) {
         if ((rc = grow(g, &c.rec_cr, c.rec_cap, nc))) return rc;
         c.rec_cap = nc;
     }
+    if (v.status & kUndecided) { g->undecided = true; *done = true; return HS_OK; }
     *done = v.status == kDone;
     return HS_OK;
 }
@@ -1008,17 +1028,22 @@ int hs_graph_run_until(hs_graph *g, int64_t end_ns) {
     return HS_OK;
 }
 
-int hs_graph_run_many(hs_graph *const *gs, int32_t n, int64_t end_ns) {
-    if (!gs || n < 1) return gfail(nullptr, HS_E_INVALID, "hs_graph_run_many: no handles");
+static int run_batch(hs_graph *const *gs, int32_t n, int64_t end_ns, int part) {
+    if (!gs || n < 1) return gfail(nullptr, HS_E_INVALID, "no handles");
     for (int i = 0; i < n; ++i) {
-        if (!gs[i]) return gfail(nullptr, HS_E_INVALID, "hs_graph_run_many: handle %d is null", i);
-        if (gs[i]->cfg.device != gs[0]->cfg.device) return gfail(gs[i], HS_E_INVALID, "hs_graph_run_many: handle %d lives on another device", i);
-        for (int j = 0; j < i; ++j) if (gs[j] == gs[i]) return gfail(gs[i], HS_E_INVALID, "hs_graph_run_many: handle %d is listed twice", i);
+        if (!gs[i]) return gfail(nullptr, HS_E_INVALID, "handle %d is null", i);
+        if (gs[i]->cfg.device != gs[0]->cfg.device) return gfail(gs[i], HS_E_INVALID, "handle %d lives on another device", i);
+    }
+    {   // (a handle listed twice would run on one heap from two workgroups)
+        std::vector<hs_graph *> sorted(gs, gs + n);
+        std::sort(sorted.begin(), sorted.end());
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return gfail(gs[0], HS_E_INVALID, "a handle is listed twice");
     }
     hs_graph *g0 = gs[0];
     HSG_HIP(g0, hipSetDevice(g0->cfg.device));
     { const int rc = ensure_stream(g0); if (rc) return rc; }
     for (int i = 0; i < n; ++i) {
+        gs[i]->ctl.part = part;
         const int rc = prepare_run(gs[i], end_ns);
         if (rc) { if (gs[i] != g0) gfail(g0, rc, "graph %d: %s", i, gs[i]->error.c_str()); return rc; }
     }
@@ -1050,12 +1075,64 @@ int hs_graph_run_many(hs_graph *const *gs, int32_t n, int64_t end_ns) {
         if (he == hipSuccess) he = hipStreamSynchronize(g0->stream);
         float ms = 0.f;
         if (he == hipSuccess && hipEventElapsedTime(&ms, g0->ev_a, g0->ev_b) == hipSuccess)
-            for (int i = 0; i < n; ++i) gs[i]->last_run_ms = ms;          // (the batch's wall time: the replicas ran side by side)
+            for (int i = 0; i < n; ++i) gs[i]->last_run_ms = ms;          // (the batch's wall time: the heaps ran side by side)
     }
     (void)hipFree(d_ctl);
+    for (int i = 0; i < n; ++i) gs[i]->ctl.part = 0;
     if (rc) return rc;
-    if (he != hipSuccess) return gfail(g0, HS_E_HIP, "hs_graph_run_many: %s", hipGetErrorString(he));
+    if (he != hipSuccess) return gfail(g0, HS_E_HIP, "batch launch: %s", hipGetErrorString(he));
     return HS_OK;
+}
+
+int hs_graph_run_many(hs_graph *const *gs, int32_t n, int64_t end_ns) { return run_batch(gs, n, end_ns, 0); }
+
+int hs_graph_run_parts(hs_graph *const *gs, int32_t n, int64_t end_ns) {
+    {
+        const int rc = run_batch(gs, n, end_ns, 1);
+        if (rc) return rc;
+    }
+    hs_graph *g0 = gs[0];
+    for (int i = 0; i < n; ++i) if (gs[i]->undecided) return 1;
+    // every part stands in front of its first event beyond end_ns: the reference processes the earliest of them (its loop tests the
+    // PREVIOUS event's time, core/simulation.py:472) and nothing else
+    int best = -1; int64_t best_t = 0; bool tie = false;
+    for (int i = 0; i < n; ++i) {
+        GVars v;
+        HSG_HIP(g0, hipMemcpy(&v, gs[i]->ctl.V, sizeof v, hipMemcpyDeviceToHost));
+        if (v.heap_len <= 0) continue;
+        GEvent top;
+        HSG_HIP(g0, hipMemcpy(&top, gs[i]->ctl.heap, sizeof top, hipMemcpyDeviceToHost));
+        if (best < 0 || top.t < best_t) { best = i; best_t = top.t; tie = false; }
+        else if (top.t == best_t) tie = true;          // (two parts' events on one nanosecond: their order is the whole Simulation's)
+    }
+    if (tie) return 1;
+    if (best < 0) return HS_OK;
+    hs_graph *g = gs[best];
+    {
+        const int rc = ensure_stream(g);
+        if (rc) { gfail(g0, rc, "%s", g->error.c_str()); return rc; }
+    }
+    GCtl one = g->ctl;
+    one.part = 1; one.budget = 1; one.end_ns = INT64_MAX;
+    GVars before;
+    HSG_HIP(g0, hipMemcpy(&before, g->ctl.V, sizeof before, hipMemcpyDeviceToHost));
+    for (int attempt = 0; attempt < 64; ++attempt) {
+        one.heap = g->ctl.heap; one.heap_cap = g->ctl.heap_cap; one.reqs = g->ctl.reqs; one.req_cap = g->ctl.req_cap;
+        one.rec_node = g->ctl.rec_node; one.rec_t = g->ctl.rec_t; one.rec_cr = g->ctl.rec_cr; one.rec_cap = g->ctl.rec_cap;
+        one.ticks = g->ctl.ticks; one.tick_cap = g->ctl.tick_cap; one.tick_count = g->ctl.tick_count;
+        hipLaunchKernelGGL(hs_graph_run, dim3(1), dim3(64), 0, g->stream, one);
+        HSG_HIP(g0, hipGetLastError());
+        HSG_HIP(g0, hipStreamSynchronize(g->stream));
+        bool done = false;
+        const int rc = after_launch(g, &done);       // (enlarges what the one event needed)
+        if (rc) { if (g != g0) gfail(g0, rc, "%s", g->error.c_str()); return rc; }
+        GVars now;
+        HSG_HIP(g0, hipMemcpy(&now, g->ctl.V, sizeof now, hipMemcpyDeviceToHost));
+        if (now.processed > before.processed || now.heap_len <= 0) {
+            return g->undecided ? 1 : HS_OK;      // (a neighbour of the other origin on the event's own nanosecond: the device's check)
+        }
+    }
+    return gfail(g0, HS_E_OVERFLOW, "the event beyond the end could not be processed");
 }
 
 int hs_graph_get_summary(hs_graph *g, hs_summary *out) {

@@ -354,6 +354,132 @@ def lower_general(sources: list, entities: list, probes=None) -> GeneralGraph:
     return GeneralGraph(nodes, a, node_of)
 
 
+MAX_PARTS = 2048          # heaps one Simulation is spread over (hs_graph_run_parts): components beyond that share heaps
+
+
+def split_parts(a: GraphArrays, max_parts: int = MAX_PARTS):
+    """The graph's parts no Request can cross -- its connected components, packed into at most `max_parts` groups of neighbouring
+    components -- as [(node ids ascending, rt positions, GraphArrays of the part)], or None when the graph is one component.
+    Node order inside a part is the Simulation's (Sources first, then Probes: hs_graph_nodes' contract)."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+
+    n = a.n
+    rt = np.asarray(a.rt_targets, np.int64)
+    has_t = np.nonzero(a.target >= 0)[0]
+    rt_owner = np.repeat(np.arange(n, dtype=np.int64), a.rt_cnt.astype(np.int64))
+    if len(rt_owner) != len(rt):                       # (rt_off / rt_cnt do not tile rt_targets: leave it to the one heap)
+        return None
+    src = np.concatenate([has_t, rt_owner])
+    dst = np.concatenate([a.target[has_t].astype(np.int64), rt])
+    n_comp, label = connected_components(coo_matrix((np.ones(len(src), np.int8), (src, dst)), shape=(n, n)), directed=False)
+    if n_comp < 2:
+        return None
+    # components in the order of their first node; neighbours share a heap when there are more components than heaps
+    first = np.full(n_comp, n, np.int64)
+    np.minimum.at(first, label, np.arange(n))
+    rank = np.empty(n_comp, np.int64)
+    rank[np.argsort(first, kind="stable")] = np.arange(n_comp)
+    k = min(n_comp, max_parts)
+    part_of_node = rank[label] * k // n_comp
+    order = np.argsort(part_of_node, kind="stable")                    # node ids grouped by part, ascending inside a part
+    bounds = np.searchsorted(part_of_node[order], np.arange(k + 1))
+    rt_off = np.asarray(a.rt_off, np.int64)
+    new_index = np.empty(n, np.int64)
+    per_node = [nm for nm in ("kind", "stream_base", "src_kind", "src_rate", "src_stop_after_ns", "concurrency", "lat_kind", "lat_mean_s",
+                              "link_lat_min_s", "link_loss_rate", "queue_cap", "src_profile_kind", "src_profile_params", "probe_metric",
+                              "probe_interval_s", "lb_strategy", "lb_vnodes", "src_n_clients") if getattr(a, nm) is not None]
+    names = None if a.names is None else [a.names[a.name_off[i]:a.name_off[i + 1]] for i in range(n)]
+    parts = []
+    for p in range(k):
+        ids = order[bounds[p]:bounds[p + 1]]
+        m = len(ids)
+        new_index[ids] = np.arange(m)
+        b = GraphArrays(m)
+        for nm in per_node:
+            setattr(b, nm, np.ascontiguousarray(getattr(a, nm)[ids]))
+        t = a.target[ids].astype(np.int64)
+        b.target = np.where(t >= 0, new_index[np.maximum(t, 0)], -1).astype(np.int32)
+        cnt = a.rt_cnt[ids].astype(np.int64)
+        b.rt_cnt = cnt.astype(np.int32)
+        b.rt_off = (np.cumsum(cnt) - cnt).astype(np.int32)
+        total = int(cnt.sum())
+        if total:
+            pos = np.repeat(rt_off[ids] - (np.cumsum(cnt) - cnt), cnt) + np.arange(total)
+            b.rt_targets = new_index[rt[pos]].astype(np.int32)
+        else:
+            pos = np.zeros(0, np.int64)
+            b.rt_targets = np.zeros(0, np.int32)
+        if names is not None:
+            blobs = [names[i] for i in ids]
+            b.names = b"".join(blobs)
+            b.name_off = np.zeros(m + 1, np.int32)
+            b.name_off[1:] = np.cumsum([len(x) for x in blobs])
+        parts.append((ids, pos, b))
+    return parts
+
+
+class PartRun:
+    """The engines of one Simulation's parts behind GraphEngine's reading interface (summary / stats / records), merged back into the
+    Simulation's node numbering."""
+
+    def __init__(self, arrays: GraphArrays, parts, engines):
+        self.arrays, self.parts, self.engines = arrays, parts, engines
+
+    def run(self, end_ns: int) -> bool:
+        """hs_graph_run_parts: True when the parts' results are the Simulation's, False when the run is undecided (one heap decides)."""
+        hs_ = (C.c_void_p * len(self.engines))(*[e._h for e in self.engines])
+        rc = self.engines[0]._lib.hs_graph_run_parts(hs_, len(self.engines), int(end_ns))
+        self.engines[0]._check(rc)
+        return rc == 0
+
+    def summary(self) -> N.Summary:
+        subs = [e.summary() for e in self.engines]
+        out = N.Summary()
+        out.events_processed = sum(s.events_processed for s in subs)
+        out.final_time_ns = max(s.final_time_ns for s in subs)           # (the one event beyond the end, or the last event of a drained run)
+        for k in range(N.EV_KINDS):
+            out.events_by_kind[k] = sum(s.events_by_kind[k] for s in subs)
+        out.requests_completed = sum(s.requests_completed for s in subs)
+        out.sink_records = sum(s.sink_records for s in subs)
+        out.launches = sum(s.launches for s in subs)
+        out.last_run_ms = max(s.last_run_ms for s in subs)
+        out.kernel_ms = out.last_run_ms
+        return out
+
+    def stats(self) -> dict:
+        n, nrt = self.arrays.n, len(self.arrays.rt_targets)
+        out = {k: np.zeros(nrt if k == "rt_taken" else (n, 6) if k == "lb" else n, np.float64 if k == "total_service_s" else np.int64)
+               for k in N.GRAPH_STATS}
+        for (ids, pos, _b), e in zip(self.parts, self.engines):
+            st = e.stats()
+            for k, v in st.items():
+                if k == "rt_taken":
+                    out[k][pos] = v
+                else:
+                    out[k][ids] = v
+        return out
+
+    def records(self):
+        node, t, cr = [], [], []
+        for (ids, _pos, _b), e in zip(self.parts, self.engines):
+            nd, tt, cc = e.records()
+            node.append(ids[nd].astype(np.int32))
+            t.append(tt)
+            cr.append(cc)
+        return np.concatenate(node), np.concatenate(t), np.concatenate(cr)
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def _reaches(nodes, node_of, start) -> set:
     """Node ids a Request that enters `start` can visit."""
     seen, todo = set(), [node_of[id(start)]]

@@ -225,6 +225,7 @@ def _run_general_batch(sims: list[Simulation], graphs: list) -> list[SimulationS
                 raise UnsupportedTopology("end_time = Infinity with Sources or Probes never terminates (their ticks are primary events, "
                                           "in the reference too); pass end_time/duration")
             end_ns, start_ns, sched, cancelled_ns = s._general_prepare(g, auto)
+            s._refuse_long_run(1)
             # the record log of a replica starts near what its Sources can produce (it grows on demand): thousands of replicas
             # should not hold 1.3 MB of log each
             a = g.arrays

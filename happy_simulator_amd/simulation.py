@@ -12,7 +12,8 @@ from . import _native as N
 from .core.event import Event
 from .core.temporal import Instant
 from .engine import StationEngine
-from .graph_engine import DEFAULT_MAX_EVENTS, GeneralGraph, GraphEngine, keyless_hazard, lower_general, write_back_general
+from .graph_engine import (DEFAULT_MAX_EVENTS, GeneralGraph, GraphEngine, PartRun, keyless_hazard, lower_general, split_parts,
+                           write_back_general)
 from .entities import Entity, Server
 from .lowering import (LazyRecords, LbGraph, LoweredGraph, UnsupportedTopology, attach_lb_probes, attach_probes, find_load_balancer, lower,
                        plain_probe_arrays, write_back_plain_probes,
@@ -300,9 +301,49 @@ class Simulation:
     def _run_general(self, g: GeneralGraph, auto: bool, wall0: float) -> SimulationSummary:
         """A graph outside the station shape (graph_engine.lower_general) on the device's single-heap loop."""
         end_ns, start_ns, sched, cancelled_ns = self._general_prepare(g, auto)
+        parts = None if cancelled_ns else split_parts(g.arrays)
+        try:
+            self._refuse_long_run(1 if parts is None else len(parts))
+        except UnsupportedTopology:
+            if parts is None:
+                raise
+            parts = None                                           # (uneven parts: the one heap's own estimate decides)
+            self._refuse_long_run(1)
+        if parts is not None:
+            # the graph falls into parts no Request can cross: one heap each, side by side (hs_graph_run_parts) -- exact unless a
+            # timestamp group turns out to be ordered by ALL of the Simulation's events; then the one heap below decides
+            part_of = np.empty(g.arrays.n, np.int64)
+            local = np.empty(g.arrays.n, np.int64)
+            for p, (ids, _pos, _b) in enumerate(parts):
+                part_of[ids] = p
+                local[ids] = np.arange(len(ids))
+            engines = []
+            try:
+                for p, (ids, _pos, b) in enumerate(parts):
+                    engines.append(GraphEngine(b, seed=self._seed, start_ns=start_ns, device=self._device, max_events=self._max_graph_events,
+                                               record_capacity=4096))
+                for node, t in sched:                              # (call order: each part keeps the order of its own)
+                    engines[int(part_of[node])].schedule(int(local[node]), t)
+                run = PartRun(g.arrays, parts, engines)
+                if run.run(end_ns):
+                    self._graph_parts = len(parts)
+                    return self._general_finish(g, run, end_ns, cancelled_ns, _time.monotonic() - wall0)
+            finally:
+                for e in engines:
+                    e.close()
+        self._graph_parts = 1
+        self._refuse_long_run(1)
         with self._general_engine(g, start_ns, sched) as eng:
             eng.run_until(end_ns)
             return self._general_finish(g, eng, end_ns, cancelled_ns, _time.monotonic() - wall0)
+
+    def _refuse_long_run(self, heaps: int = 1) -> None:
+        """(after _general_prepare) refuse up front what would keep one lane busy for minutes; `heaps`: the heaps the run is spread over."""
+        est = self._general_est / max(heaps, 1)
+        if self._max_graph_events > 0 and est > 4.0 * self._max_graph_events:
+            raise UnsupportedTopology(
+                f"the single-heap path (one lane, ~2 us per event) would need ~{est:.2g} events per heap for this run "
+                f"(limit {self._max_graph_events}: Simulation(max_graph_events=...))")
 
     def _general_prepare(self, g: GeneralGraph, auto: bool):
         """What the single-heap engine is created with: (end ns, start ns, the schedule()d Requests as (node, ns), the cancelled
@@ -312,11 +353,7 @@ class Simulation:
         a = g.arrays
         # ~8 reference events per Request that is served and ~2 per hop: refuse up front what would take the one lane minutes
         horizon_s = 0.0 if auto else (end_ns - start_ns) / 1e9
-        est = 12.0 * float(a.src_rate[a.kind == N.NODE_SOURCE].sum()) * horizon_s
-        if self._max_graph_events > 0 and est > 4.0 * self._max_graph_events:
-            raise UnsupportedTopology(
-                f"the single-heap path (one lane, ~1 us per event) would need ~{est:.2g} events for this run "
-                f"(limit {self._max_graph_events}: Simulation(max_graph_events=...))")
+        self._general_est = 12.0 * float(a.src_rate[a.kind == N.NODE_SOURCE].sum()) * horizon_s
         cancelled_ns: list[int] = []
         sched: list[tuple[int, int]] = []
         for ev in self._scheduled:

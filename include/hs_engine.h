@@ -774,6 +774,17 @@ int hs_graph_run_until(hs_graph *g, int64_t end_ns);
  * exactly the state hs_graph_run_until(handle, end_ns) would leave; the device time a handle reports (hs_summary.last_run_ms) is the batch's.  On
  * an error the first handle's hs_graph_last_error names the graph. */
 int hs_graph_run_many(hs_graph *const *graphs, int32_t n, int64_t end_ns);
+/* ONE Simulation whose entity graph falls into parts that no Request can cross (connected components, or unions of them), every
+ * handle one part with its nodes in the Simulation's order: the parts run side by side like hs_graph_run_many's replicas and
+ * together leave what ONE heap over all of them leaves (core/simulation.py:449-505).  Why that is exact: an event's place among
+ * its part's events never depends on the other parts -- except (i) inside a timestamp group that holds both an event numbered
+ * BEFORE the run (a Source's / Probe's first tick, a schedule()d Request: the process-wide counter, core/event.py:53-67) and one
+ * numbered BY the run (the heap's own counter, which counts every part's events), and (ii) for the single event beyond `end_ns`,
+ * which is the earliest over all parts (the loop tests the previous event's time, core/simulation.py:472).  The parts stop in front
+ * of their first event beyond `end_ns`; the one part that holds the earliest then processes it.  Returns HS_OK; or 1 = UNDECIDED
+ * -- case (i) occurred, or two parts hold the earliest time: the caller repeats the run on one heap (the handles' state is then
+ * meaningless); or a negative hs_status.  Call once per handle set (no later end). */
+int hs_graph_run_parts(hs_graph *const *parts, int32_t n, int64_t end_ns);
 int hs_graph_get_summary(hs_graph *g, hs_summary *out);
 int hs_graph_get_stats(hs_graph *g, hs_graph_stats *out);
 /* Every Sink record of the run in processing order: (Sink node, completion ns, created_at ns).  Returns the number of

@@ -221,6 +221,40 @@ def lb_graph_spec(k):
     return spec
 
 
+def union_spec(specs, name="union"):
+    """Several graph specs (graph_spec / lb_graph_spec) side by side in ONE Simulation: disjoint entity sets, indices shifted, the
+    Sources of all of them in one list (spec by spec), one end and one seed (the first spec's)."""
+    import copy
+
+    out = dict(name=name, topology="graph", n_sinks=0, servers=[], links=[], routers=[], lbs=[], sources=[], schedule=[],
+               end_s=specs[0]["end_s"], seed=specs[0]["seed"])
+    for sp in specs:
+        sp = copy.deepcopy(sp)
+        off = {"sink": out["n_sinks"], "server": len(out["servers"]), "link": len(out["links"]), "router": len(out["routers"]),
+               "lb": len(out["lbs"])}
+
+        def sh(ref):
+            return None if ref is None else [ref[0], ref[1] + off[ref[0]]]
+
+        for sv in sp["servers"]:
+            sv["out"] = sh(sv.get("out"))
+        for lk in sp["links"]:
+            lk["to"] += off["server"]
+        for rt in sp["routers"]:
+            rt["targets"] = [sh(t) for t in rt["targets"]]
+        for lb in sp.get("lbs") or []:
+            lb["backends"] = [b + off["server"] for b in lb["backends"]]
+        for sc in sp["sources"]:
+            sc["to"] = sc["to"] + off["server"] if isinstance(sc["to"], int) else sh(sc["to"])
+        for ref, t in sp.get("schedule") or []:
+            out["schedule"].append([sh(ref), min(t, out["end_s"] + 0.5)])
+        out["n_sinks"] += sp["n_sinks"]
+        for k in ("servers", "links", "routers", "sources"):
+            out[k].extend(sp[k])
+        out["lbs"].extend(sp.get("lbs") or [])
+    return out
+
+
 def tie_spec(k):
     """Tie storms: lock-step constant-rate sources, constant service times that are multiples of one another, Requests
     scheduled at the start instant and at the sources' own tick times, c up to 16, zero-capacity queues -- every same-nanosecond

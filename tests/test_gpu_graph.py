@@ -270,6 +270,81 @@ def test_engines_run_in_a_batch_grow_their_buffers_and_continue():
             e.close()
 
 
+@pytest.mark.parametrize("block", range(4))
+def test_a_simulation_of_several_disconnected_graphs_runs_as_parts(block):
+    """Two to six graphs that share nothing in ONE Simulation: no Request crosses between them, so each part runs on a heap of its
+    own, side by side (hs_graph_run_parts) -- and together they leave what the reference's ONE heap leaves (the oracle on the union):
+    every statistic and record, the total, the single event beyond end_time.  A run whose order the parts cannot decide (a first tick
+    or a schedule()d Request on the nanosecond of an event the run created) is repeated on one heap: same answer either way."""
+    from random_specs import union_spec
+
+    split = 0
+    for k in range(block * 12, block * 12 + 12):
+        rng = np.random.default_rng(91_000 + k)
+        members = [(lb_graph_spec if rng.random() < 0.5 else graph_spec)(int(rng.integers(0, 5000))) for _ in range(int(rng.integers(2, 7)))]
+        spec = union_spec(members, name=f"union_{k}")
+        if k % 2 == 0:                                           # Poisson Sources only, nothing schedule()d: no tick shares a nanosecond
+            spec["schedule"] = []
+            for sc in spec["sources"]:
+                sc["kind"] = "poisson"
+        sim, ents = GS.build(spec)
+        assert isinstance(sim.lowered(), GeneralGraph)
+        g_o, nodes = H.oracle_graph(spec)
+        r = O.run(g_o, H.ns_from_seconds(spec["end_s"]), seed=spec["seed"], schedule=H.oracle_graph_schedule(spec, nodes))
+        sim.run()
+        _compare_with_oracle(spec, sim, ents, r, nodes)
+        split += sim._graph_parts >= 2
+        assert k % 2 or sim._graph_parts >= 2
+    assert split >= 6
+
+
+def test_many_chains_beyond_the_station_shape_run_on_many_heaps():
+    """6 000 independent chains of FIVE Poisson Sources -> Server(c = 40) -> Sink (the station engines stop at four Sources and
+    c = 32): one Simulation, 2 048 heaps side by side, == the oracle's one heap."""
+    n, per = 6000, 5
+    g = O.Graph()
+    src = [g.source(O.ARR_POISSON, 1.0 + (k % 5), stream_base=k) for k in range(n * per)]
+    snk, srv = [], []
+    for i in range(n):
+        snk.append(g.sink())
+    for i in range(n):
+        srv.append(g.server(O.LAT_EXP, 0.3, concurrency=40, queue_cap=-1, stream_base=i))
+        g.target[srv[i]] = snk[i]
+    for k, s_ in enumerate(src):
+        g.target[s_] = srv[k // per]
+    end_ns = 2_000_000_000
+    r = O.run(g, end_ns, seed=11)
+    sinks = [hs.Sink(f"k{i}") for i in range(n)]
+    servers = [hs.Server(f"s{i}", concurrency=40, service_time=hs.ExponentialLatency(0.3), downstream=sinks[i]) for i in range(n)]
+    sources = [hs.Source.poisson(rate=1.0 + (k % 5), target=servers[k // per], name=f"src{k}") for k in range(n * per)]
+    sim = hs.Simulation(end_time=hs.Instant.from_seconds(2.0), sources=sources, entities=servers + sinks, seed=11)
+    summary = sim.run()
+    assert sim._graph_parts == 2048
+    assert summary.total_events_processed == r.events_processed and sim._current_time.nanoseconds == r.final_time_ns
+    np.testing.assert_array_equal([s.generated_count for s in sources], r.generated[src])
+    np.testing.assert_array_equal([s._requests_completed for s in servers], r.completed[srv])
+    np.testing.assert_array_equal([s._total_service_time for s in servers], r.total_service_s[srv])
+    for i in (0, 1, n // 2, n - 1):
+        np.testing.assert_array_equal(sinks[i].completion_ns, r.sinks[snk[i]][0])
+        np.testing.assert_array_equal(sinks[i]._created_ns, r.sinks[snk[i]][1])
+
+
+def test_parts_that_cannot_decide_an_order_hand_the_run_to_one_heap():
+    """Two constant Sources of one rate on one Server: the second one's first tick (numbered before the run) shares its nanosecond
+    with the payload of the first (numbered by the run) -- which comes first depends on every event the Simulation created so far,
+    other parts' included.  The part run reports it undecided; the one heap answers; == the oracle."""
+    spec = dict(name="undecided", topology="graph", n_sinks=2, end_s=4.0, seed=5, links=[], routers=[],
+                servers=[dict(mean=0.05, c=40, cap=None, out=["sink", 0]), dict(mean=0.05, c=40, cap=None, out=["sink", 1])],     # (c > 32: no station)
+                sources=[dict(kind="poisson", rate=7.0, to=1), dict(kind="constant", rate=4.0, to=0), dict(kind="constant", rate=4.0, to=0)])
+    sim, ents = GS.build(spec)
+    assert isinstance(sim.lowered(), GeneralGraph)
+    g_o, nodes = H.oracle_graph(spec)
+    r = O.run(g_o, H.ns_from_seconds(spec["end_s"]), seed=spec["seed"])
+    sim.run()
+    assert sim._graph_parts == 1
+    _compare_with_oracle(spec, sim, ents, r, nodes)
+
+
 def test_a_heap_beyond_the_lds_window_and_a_large_concurrency():
     """6 000 Sources on one Server with concurrency 5 000 (the station engines stop at four Sources and c = 32): the heap holds more
     pending events than its 4 096 LDS entries, so sifts cross from LDS into HBM; == the oracle."""

@@ -120,10 +120,10 @@ def test_what_the_single_heap_path_refuses_too():
         sim.schedule(hs.Event(time=hs.Instant.from_seconds(0.5), event_type="Request", target=sv))
         sim.run()
     assert isinstance(hs.Simulation(duration=1.0, sources=[src], entities=[sv, sink]).lowered(), GeneralGraph)
-    with pytest.raises(hs.UnsupportedTopology, match="would need"):       # 64 such chains at 10^6 / s for a minute: refused before anything runs
+    with pytest.raises(hs.UnsupportedTopology, match="would need"):       # 64 such chains (64 heaps) at 10^7 / s for a minute: refused before anything runs
         sinks = [hs.Sink(f"k{i}") for i in range(64)]
         svs = [hs.Server(f"s{i}", concurrency=64, service_time=hs.ExponentialLatency(0.05), downstream=sinks[i]) for i in range(64)]
-        srcs = [hs.Source.poisson(rate=1e6, target=x, name=f"src{i}") for i, x in enumerate(svs)]
+        srcs = [hs.Source.poisson(rate=1e7, target=x, name=f"src{i}") for i, x in enumerate(svs)]
         hs.Simulation(duration=60.0, sources=srcs, entities=svs + sinks).run()
 
 
@@ -160,6 +160,6 @@ def test_abi_structs_of_the_graph_entry_points():
     assert C.sizeof(N.GraphNodes) == 8 + 15 * 8 + 8 + 9 * 8
     assert C.sizeof(N.GraphStats) == 16 * 8
     L = N.lib()
-    for sym in ("hs_graph_create", "hs_graph_schedule", "hs_graph_run_until", "hs_graph_run_many", "hs_graph_get_summary", "hs_graph_get_stats",
+    for sym in ("hs_graph_create", "hs_graph_schedule", "hs_graph_run_until", "hs_graph_run_many", "hs_graph_run_parts", "hs_graph_get_summary", "hs_graph_get_stats",
                 "hs_graph_read_records", "hs_graph_last_error", "hs_graph_destroy"):
         assert sym in N.EXPORTED_SYMBOLS and getattr(L, sym)
