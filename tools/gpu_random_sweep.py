@@ -204,7 +204,18 @@ def graph_probes(k):           # round 6: Probes and time-varying Sources on the
         np.testing.assert_array_equal(data._v, v, err_msg=pr.name)
 
 
-FAMILIES = [graph, lb_graph, graph_probes, station, tie, multi_source, ring_async, ring_windowed, jitter_ring_async, jitter_ring_windowed, multi_source_ring_async,
+def graph_union(k):             # round 6: several disconnected graphs in ONE Simulation -> parts side by side (or the one heap when undecided)
+    rng = np.random.default_rng(93_000 + k)
+    members = [(RS.lb_graph_spec if rng.random() < 0.5 else RS.graph_spec)(int(rng.integers(0, 100000))) for _ in range(int(rng.integers(2, 9)))]
+    spec = RS.union_spec(members, name=f"union_{k}")
+    if k % 4:                                                # three of four: Poisson only (decidable by the parts)
+        spec["schedule"] = [] if k % 4 == 1 else [x for x in spec["schedule"] if x[1] not in (0.0, 0.5, 1.0)]
+        for sc in spec["sources"]:
+            sc["kind"] = "poisson"
+    _general(spec)
+
+
+FAMILIES = [graph, lb_graph, graph_probes, graph_union, station, tie, multi_source, ring_async, ring_windowed, jitter_ring_async, jitter_ring_windowed, multi_source_ring_async,
             multi_source_ring_windowed, ring_windows_async, ring_windows_windowed, jitter_ring_windows_async,
             multi_source_ring_windows_async, lb,
             lb_probes, lb_profiles, lb_strategies, lb_workers, tandem, tandem_fan_in, tandem_probes]
