@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -34,6 +35,7 @@
 namespace hs {
 namespace graph {
 
+constexpr int kBatchStat = 4;                  // int64 per heap a batch launch reports: status, processed, pending events, the earliest's time
 constexpr int kLdsNodes = 192, kLdsNodesBatch = 48;   // nodes whose parameters and state stay in LDS for a launch (24 KB / 6 KB)
 constexpr int kLdsHeapBatch = 1024;            // ... of each of the heaps hs_graph_run_many runs side by side
 constexpr int kLdsHeap = 4096;                 // heap entries in LDS: 4 096 x 32 B = 128 KB of the CU's 160 (+ 24 KB of nodes)
@@ -553,11 +555,17 @@ __global__ void __launch_bounds__(64) hs_graph_run(GCtl c) {
 // Independent graphs -- the replicas / sweep points of parallel/runner.py:82-142 -- side by side: one workgroup (one heap) each, one
 // with a quarter of the lone run's LDS window (32 KB + 6 KB of nodes: four workgroups per CU, 1 024 heaps on the device at once; a heap that outgrows
 // the window continues in HBM as it does behind the large one -- the window's size changes nothing the loop computes).
-__global__ void __launch_bounds__(64) hs_graph_run_batch(const GCtl *cs) {
+__global__ void __launch_bounds__(64) hs_graph_run_batch(const GCtl *cs, long long *stat) {
     __shared__ GEvent lheap[kLdsHeapBatch];
     __shared__ __attribute__((aligned(16))) char lnodes[kLdsNodesBatch * (sizeof(GParam) + sizeof(GState))];
     const GCtl c = cs[blockIdx.x];
     graph_loop<kLdsHeapBatch, kLdsNodesBatch>(c, lheap, lnodes);
+    __syncthreads();
+    if (threadIdx.x == 0) {                    // what the host decides on, in ONE array for the whole batch
+        long long *o = stat + kBatchStat * blockIdx.x;
+        o[0] = c.V->status; o[1] = c.V->processed; o[2] = c.V->heap_len;
+        o[3] = c.V->heap_len > 0 ? c.heap[0].t : 0;                // (the earliest pending event: hs_graph_run_parts elects across parts)
+    }
 }
 
 }  // namespace graph
@@ -581,10 +589,11 @@ struct hs_graph {
     int64_t tick_horizon = INT64_MIN, tick_cap = 0;
     hipStream_t stream = nullptr;              // created with the first launch that needs one (a replica run in a batch never does)
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    char *slab = nullptr; size_t slab_bytes = 0;   // every buffer of hs_graph_create in ONE allocation (a replica costs one hipMalloc / hipFree)
+    char *slab = nullptr; size_t slab_bytes = 0, slab_alloc = 0;   // every buffer of hs_graph_create in ONE allocation (a replica costs one hipMalloc / hipFree)
     double last_run_ms = 0.0;
     long long launches = 0;
     bool ran = false;
+    long long pending_events = 0; int64_t earliest_ns = 0;   // after a batch launch: the heap's length and its top's time
     bool undecided = false;                    // a part run met a timestamp group only the whole Simulation orders (hs_graph_run_parts)
     std::string error;
 };
@@ -607,6 +616,36 @@ static int gfail(hs_graph *g, int code, const char *fmt, ...) {
         hipError_t e_ = (expr);                                                                        \
         if (e_ != hipSuccess) return gfail(g, HS_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));       \
     } while (0)
+
+// Slabs of destroyed handles wait here for the next handle of about their size: a Simulation spread over thousands of parts, or a sweep of
+// thousands of replicas, creates and frees as many handles back to back, and hipFree synchronises the device every time (0.2 ms).
+// Bounded: 4 096 slabs / 4 GB; the rest goes back to the runtime.
+struct SlabPool {
+    std::mutex mu;
+    std::vector<std::pair<size_t, char *>> free;          // (bytes, pointer) of ONE device (the pool serves the device of its first slab)
+    size_t bytes = 0; int device = -1;
+    char *take(int dev, size_t want, size_t *have) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev != device) return nullptr;
+        for (size_t i = free.size(); i-- > 0;) {
+            if (free[i].first >= want && free[i].first <= want + want / 2 + 4096) {
+                char *p = free[i].second; *have = free[i].first; bytes -= free[i].first;
+                free[i] = free.back(); free.pop_back();
+                return p;
+            }
+            if (free.size() - i > 64) break;              // (the newest 64: a sweep's handles are all of one size)
+        }
+        return nullptr;
+    }
+    bool give(int dev, size_t have, char *p) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (device < 0) device = dev;
+        if (dev != device || free.size() >= 4096 || bytes + have > (4ull << 30)) return false;
+        free.emplace_back(have, p); bytes += have;
+        return true;
+    }
+};
+static SlabPool g_slabs;
 
 static bool in_slab(const hs_graph *g, const void *p) {
     return g->slab && (const char *)p >= g->slab && (const char *)p < g->slab + g->slab_bytes;
@@ -642,7 +681,7 @@ void hs_graph_destroy(hs_graph *g) {
                     g->d_rt_targets, g->d_key_table, g->ctl.rt_taken, g->d_sched_node, g->d_sched_t, g->ctl.V, g->d_rows, g->d_ticks, g->d_tick_count,
                     g->d_tick_status};
     for (void *b : bufs) if (b && !in_slab(g, b)) (void)hipFree(b);
-    if (g->slab) (void)hipFree(g->slab);
+    if (g->slab && !g_slabs.give(g->cfg.device, g->slab_alloc, g->slab)) (void)hipFree(g->slab);
     if (g->ev_a) (void)hipEventDestroy(g->ev_a);
     if (g->ev_b) (void)hipEventDestroy(g->ev_b);
     if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -837,7 +876,8 @@ int hs_graph_create(const hs_graph_config *cfg, const hs_graph_nodes *nd, hs_gra
                  o_rnode = take((size_t)c.rec_cap * sizeof(int32_t)), o_rt_ns = take((size_t)c.rec_cap * sizeof(int64_t)),
                  o_rcr = take((size_t)c.rec_cap * sizeof(int64_t));
     g->slab_bytes = off;
-    HSG_HIPD(hipMalloc((void **)&g->slab, g->slab_bytes));
+    g->slab = g_slabs.take(cfg->device, off, &g->slab_alloc);   // (a destroyed handle's slab of about this size, else a new one)
+    if (!g->slab) { HSG_HIPD(hipMalloc((void **)&g->slab, g->slab_bytes)); g->slab_alloc = g->slab_bytes; }
     {
         std::vector<char> image(image_bytes, 0);
         std::memcpy(image.data() + o_P, P.data(), (size_t)n * sizeof(GParam));
@@ -960,11 +1000,16 @@ static int prepare_run(hs_graph *g, int64_t end_ns) {
 }
 
 // What a launch left (the device is idle): enlarge what it ran out of; *done = the run reached its end.
+static int after_launch_with(hs_graph *g, int status, long long processed, bool *done);
 static int after_launch(hs_graph *g, bool *done) {
+    GVars v;
+    HSG_HIP(g, hipMemcpy(&v, g->ctl.V, sizeof v, hipMemcpyDeviceToHost));
+    return after_launch_with(g, v.status, v.processed, done);
+}
+static int after_launch_with(hs_graph *g, int status, long long processed, bool *done) {
     GCtl &c = g->ctl;
     g->launches++;
-    GVars v;
-    HSG_HIP(g, hipMemcpy(&v, c.V, sizeof v, hipMemcpyDeviceToHost));
+    struct { int status; long long processed; } v{status, processed};
     if (v.status & kBadKind) return gfail(g, HS_E_INVALID, "an event of unknown kind reached the loop (internal error)");
     if (g->cfg.max_events > 0 && v.processed > g->cfg.max_events)
         return gfail(g, HS_E_UNSUPPORTED, "the run exceeds max_events = %lld events on the single-heap path (one lane, ~1 us per event); "
@@ -1048,7 +1093,9 @@ static int run_batch(hs_graph *const *gs, int32_t n, int64_t end_ns, int part) {
         if (rc) { if (gs[i] != g0) gfail(g0, rc, "graph %d: %s", i, gs[i]->error.c_str()); return rc; }
     }
     GCtl *d_ctl = nullptr;
-    HSG_HIP(g0, hipMalloc(&d_ctl, (size_t)n * sizeof(GCtl)));
+    HSG_HIP(g0, hipMalloc(&d_ctl, (size_t)n * (sizeof(GCtl) + kBatchStat * sizeof(long long))));
+    long long *d_stat = reinterpret_cast<long long *>(d_ctl + n);
+    std::vector<long long> h_stat;
     std::vector<int> pending((size_t)n);
     for (int i = 0; i < n; ++i) pending[(size_t)i] = i;
     std::vector<GCtl> h_ctl;
@@ -1058,13 +1105,18 @@ static int run_batch(hs_graph *const *gs, int32_t n, int64_t end_ns, int part) {
         h_ctl.clear();
         for (int i : pending) h_ctl.push_back(gs[i]->ctl);
         if ((he = hipMemcpy(d_ctl, h_ctl.data(), h_ctl.size() * sizeof(GCtl), hipMemcpyHostToDevice)) != hipSuccess) break;
-        hipLaunchKernelGGL(hs_graph_run_batch, dim3((unsigned)pending.size()), dim3(64), 0, g0->stream, (const GCtl *)d_ctl);
+        hipLaunchKernelGGL(hs_graph_run_batch, dim3((unsigned)pending.size()), dim3(64), 0, g0->stream, (const GCtl *)d_ctl, d_stat);
         if ((he = hipGetLastError()) != hipSuccess) break;
         if ((he = hipStreamSynchronize(g0->stream)) != hipSuccess) break;
+        h_stat.resize((size_t)kBatchStat * pending.size());
+        if ((he = hipMemcpy(h_stat.data(), d_stat, h_stat.size() * sizeof(long long), hipMemcpyDeviceToHost)) != hipSuccess) break;
         std::vector<int> left;
+        size_t slot = 0;
         for (int i : pending) {
             bool done = false;
-            rc = after_launch(gs[i], &done);
+            const long long *st = &h_stat[(size_t)kBatchStat * slot++];
+            rc = after_launch_with(gs[i], (int)st[0], st[1], &done);
+            gs[i]->pending_events = st[2]; gs[i]->earliest_ns = st[3];
             if (rc) { if (gs[i] != g0) gfail(g0, rc, "graph %d: %s", i, gs[i]->error.c_str()); break; }
             if (done) gs[i]->ran = true; else left.push_back(i);
         }
@@ -1097,13 +1149,10 @@ int hs_graph_run_parts(hs_graph *const *gs, int32_t n, int64_t end_ns) {
     // PREVIOUS event's time, core/simulation.py:472) and nothing else
     int best = -1; int64_t best_t = 0; bool tie = false;
     for (int i = 0; i < n; ++i) {
-        GVars v;
-        HSG_HIP(g0, hipMemcpy(&v, gs[i]->ctl.V, sizeof v, hipMemcpyDeviceToHost));
-        if (v.heap_len <= 0) continue;
-        GEvent top;
-        HSG_HIP(g0, hipMemcpy(&top, gs[i]->ctl.heap, sizeof top, hipMemcpyDeviceToHost));
-        if (best < 0 || top.t < best_t) { best = i; best_t = top.t; tie = false; }
-        else if (top.t == best_t) tie = true;          // (two parts' events on one nanosecond: their order is the whole Simulation's)
+        if (gs[i]->pending_events <= 0) continue;
+        const int64_t t = gs[i]->earliest_ns;
+        if (best < 0 || t < best_t) { best = i; best_t = t; tie = false; }
+        else if (t == best_t) tie = true;              // (two parts' events on one nanosecond: their order is the whole Simulation's)
     }
     if (tie) return 1;
     if (best < 0) return HS_OK;

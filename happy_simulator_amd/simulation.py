@@ -12,7 +12,7 @@ from . import _native as N
 from .core.event import Event
 from .core.temporal import Instant
 from .engine import StationEngine
-from .graph_engine import (DEFAULT_MAX_EVENTS, GeneralGraph, GraphEngine, PartRun, keyless_hazard, lower_general, split_parts,
+from .graph_engine import (DEFAULT_MAX_EVENTS, MAX_PARTS, GeneralGraph, GraphEngine, PartRun, keyless_hazard, lower_general, split_parts,
                            write_back_general)
 from .entities import Entity, Server
 from .lowering import (LazyRecords, LbGraph, LoweredGraph, UnsupportedTopology, attach_lb_probes, attach_probes, find_load_balancer, lower,
@@ -301,7 +301,8 @@ class Simulation:
     def _run_general(self, g: GeneralGraph, auto: bool, wall0: float) -> SimulationSummary:
         """A graph outside the station shape (graph_engine.lower_general) on the device's single-heap loop."""
         end_ns, start_ns, sched, cancelled_ns = self._general_prepare(g, auto)
-        parts = None if cancelled_ns else split_parts(g.arrays)
+        # (a heap is worth its handle from ~16 000 events on: creating, reading and freeing one costs the host ~0.5 ms)
+        parts = None if cancelled_ns else split_parts(g.arrays, max(2, min(MAX_PARTS, int(self._general_est / 16384.0))) if not auto else MAX_PARTS)
         try:
             self._refuse_long_run(1 if parts is None else len(parts))
         except UnsupportedTopology:

@@ -300,7 +300,7 @@ def test_a_simulation_of_several_disconnected_graphs_runs_as_parts(block):
 
 def test_many_chains_beyond_the_station_shape_run_on_many_heaps():
     """6 000 independent chains of FIVE Poisson Sources -> Server(c = 40) -> Sink (the station engines stop at four Sources and
-    c = 32): one Simulation, 2 048 heaps side by side, == the oracle's one heap."""
+    c = 32): one Simulation, its 6 000 components on ~130 heaps side by side, == the oracle's one heap."""
     n, per = 6000, 5
     g = O.Graph()
     src = [g.source(O.ARR_POISSON, 1.0 + (k % 5), stream_base=k) for k in range(n * per)]
@@ -319,7 +319,7 @@ def test_many_chains_beyond_the_station_shape_run_on_many_heaps():
     sources = [hs.Source.poisson(rate=1.0 + (k % 5), target=servers[k // per], name=f"src{k}") for k in range(n * per)]
     sim = hs.Simulation(end_time=hs.Instant.from_seconds(2.0), sources=sources, entities=servers + sinks, seed=11)
     summary = sim.run()
-    assert sim._graph_parts == 2048
+    assert 64 <= sim._graph_parts <= 2048                     # (a heap per ~16 000 estimated events)
     assert summary.total_events_processed == r.events_processed and sim._current_time.nanoseconds == r.final_time_ns
     np.testing.assert_array_equal([s.generated_count for s in sources], r.generated[src])
     np.testing.assert_array_equal([s._requests_completed for s in servers], r.completed[srv])
