@@ -196,7 +196,22 @@ def graph_replicas_run(args, device, n_replicas=1024):
     wall = time.perf_counter() - t0
     events = sum(r.summary.total_events_processed for r in res)
     dev_ms = float(sims[0]._engine_summary.last_run_ms)
-    return {"graph_replicas": {"what": f"{n_replicas} replicas of a 17-entity graph with three LoadBalancers x {args.end_s:g} s on the single-heap "
+    # ONE Simulation whose graph falls into parts no Request can cross: chains the station engines refuse (five Sources per Server, c = 40)
+    n, per = 16384, 5
+    sinks = [hs.Sink(f"k{i}") for i in range(n)]
+    servers = [hs.Server(f"s{i}", concurrency=40, service_time=hs.ExponentialLatency(args.mean), downstream=sinks[i]) for i in range(n)]
+    sources = [hs.Source.poisson(rate=args.rate / per, target=servers[k // per], name=f"src{k}") for k in range(n * per)]
+    psim = hs.Simulation(end_time=hs.Instant.from_seconds(10.0), sources=sources, entities=servers + sinks, seed=args.seed, device=device)
+    t0 = time.perf_counter()
+    psum = psim.run()
+    pwall = time.perf_counter() - t0
+    pdev = float(psim._engine_summary.last_run_ms)
+    parts = {"what": f"{n} chains of five Poisson Sources -> Server(c=40) -> Sink x 10 s in ONE Simulation (outside the station shape): the "
+                     "graph's disconnected parts on heaps of their own, side by side (hs_graph_run_parts)",
+             "chains": n, "heaps": int(psim._graph_parts), "events": psum.total_events_processed, "device_ms": pdev,
+             "events_per_s_device": psum.total_events_processed / (pdev / 1e3), "run_s_python_api": pwall,
+             "events_per_s_python_api": psum.total_events_processed / pwall}
+    return {"graph_parts": parts, "graph_replicas": {"what": f"{n_replicas} replicas of a 17-entity graph with three LoadBalancers x {args.end_s:g} s on the single-heap "
                                        "path, one workgroup per replica (hs_graph_run_many)",
                                "replicas": n_replicas, "events": events, "device_ms": dev_ms, "events_per_s_device": events / (dev_ms / 1e3),
                                "wall_s_python_api": wall, "events_per_s_python_api": events / wall}}

@@ -87,6 +87,9 @@ def test_default_line_carries_ring_lb_and_the_strong_shard():
     gr = brief["graph_replicas"]                     # round 6: replicas of a graph outside the station shape, one workgroup each
     assert gr["replicas"] == 1024 and gr["events"] > 1024 * 1000 and 0 < gr["device_ms"] < 1e3 * gr["wall_s_python_api"]
     assert gr["events_per_s_device"] > gr["events_per_s_python_api"] > 1e6
+    gp = brief["graph_parts"]                        # ... and ONE Simulation's disconnected parts on heaps of their own
+    assert gp["chains"] == 16384 and 64 <= gp["heaps"] <= 2048 and gp["events"] > 16384 * 100
+    assert gp["events_per_s_device"] > gp["events_per_s_python_api"] > 1e6
 
 
 def test_fake_ranks_run_the_multi_rank_bench_paths_on_one_gpu():
