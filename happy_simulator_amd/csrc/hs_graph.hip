@@ -129,11 +129,31 @@ __device__ __forceinline__ bool ev_lt(const GEvent &a, const GEvent &b) {   // E
     return a.idx < b.idx;
 }
 
+// The window's entries are addressed as LDS (address space 3), two 16-byte words each: a pointer that may be LDS or HBM compiles to FLAT
+// loads and stores, which wait on both memory counters (113 + 118 of them in the loop before: every level of a sift).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 template <int W>
 struct Heap {
-    GEvent *lds; GEvent *glob; long long len;
-    __device__ __forceinline__ GEvent get(long long i) const { return i < W ? lds[i] : glob[i]; }
-    __device__ __forceinline__ void set(long long i, const GEvent &e) { if (i < W) lds[i] = e; else glob[i] = e; }
+    lds_u32x4 *lds; GEvent *glob; long long len;
+    __device__ __forceinline__ GEvent get(long long i) const {
+        if (i < W) {
+            const u32x4 a = lds[2 * i], b = lds[2 * i + 1];
+            GEvent e;
+            e.t = (int64_t)(((uint64_t)a.y << 32) | (uint64_t)a.x); e.idx = ((uint64_t)a.w << 32) | (uint64_t)a.z;
+            e.node = (int32_t)b.x; e.req = (int32_t)b.y; e.kind = b.z; e.pad = b.w;
+            return e;
+        }
+        return glob[i];
+    }
+    __device__ __forceinline__ void set(long long i, const GEvent &e) {
+        if (i < W) {
+            u32x4 a, b;
+            a.x = (uint32_t)(uint64_t)e.t; a.y = (uint32_t)((uint64_t)e.t >> 32); a.z = (uint32_t)e.idx; a.w = (uint32_t)(e.idx >> 32);
+            b.x = (uint32_t)e.node; b.y = (uint32_t)e.req; b.z = e.kind; b.w = e.pad;
+            lds[2 * i] = a; lds[2 * i + 1] = b;
+        } else glob[i] = e;
+    }
     // heapq.heappush: append, then _siftdown(heap, 0, len - 1)
     __device__ inline void push(const GEvent &e) {
         long long pos = len++;
@@ -257,7 +277,7 @@ __device__ __forceinline__ void graph_loop(const GCtl &c0, GEvent *lheap, char *
     __syncthreads();
     if (lane == 0) {
         int req_free = V.req_free, req_len = V.req_len;                     // (registers for the launch)
-        Heap<W> H{lheap, c.heap, V.heap_len};
+        Heap<W> H{(lds_u32x4 *)lheap, c.heap, V.heap_len};
         unsigned long long G = V.counter;
         int status = kRunning;
         if (!V.booted) {
