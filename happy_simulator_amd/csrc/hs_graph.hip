@@ -15,7 +15,9 @@
 // Handlers restate the reference handler by handler (citations at each); arithmetic through hs_device.hpp (the same fixed IEEE
 // operation sequences as every other engine), streams through the Philox streams of DESIGN.md section 3.
 //
-// Cost: ~1 us per event (dependent loads on one lane).  An exactness path for the graphs the parallel engines refuse.
+// Cost: ~2.4 us per event (~1 000 vector instructions of ONE lane; measured: not memory).  An exactness path for the graphs the parallel
+// engines refuse; its throughput comes from heaps side by side: replicas (hs_graph_run_many) and a Simulation's disconnected parts
+// (hs_graph_run_parts).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -1032,7 +1034,7 @@ static int after_launch_with(hs_graph *g, int status, long long processed, bool 
     struct { int status; long long processed; } v{status, processed};
     if (v.status & kBadKind) return gfail(g, HS_E_INVALID, "an event of unknown kind reached the loop (internal error)");
     if (g->cfg.max_events > 0 && v.processed > g->cfg.max_events)
-        return gfail(g, HS_E_UNSUPPORTED, "the run exceeds max_events = %lld events on the single-heap path (one lane, ~1 us per event); "
+        return gfail(g, HS_E_UNSUPPORTED, "the run exceeds max_events = %lld events on the single-heap path (one lane, ~2.4 us per event); "
                      "raise max_events, or bring the graph into the shape the station engines take", (long long)g->cfg.max_events);
     if (v.status & kGrowHeap) {
         const long long nc = c.heap_cap * 2;

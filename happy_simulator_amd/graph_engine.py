@@ -6,7 +6,7 @@ graphs -- a NetworkLink with several senders (components/network/link.py:114-189
 Servers and routers among them, and with several upstreams (components/random_router.py:32-45), Server(downstream=<Server>)
 next to links (components/server/server.py:64-122), any number of Sources per Server (load/source.py:93-180), any
 FixedConcurrency (server/concurrency.py:67-141) -- and runs them on the device's single-heap loop (csrc/hs_graph.hip,
-include/hs_engine.h "General entity graphs"): the reference's own (time, _sort_index) order event by event, ~1 us per event on
+include/hs_engine.h "General entity graphs"): the reference's own (time, _sort_index) order event by event, ~2.4 us per event on
 one lane.  Exact, not fast: Simulation only comes here with a graph lower() refused.
 
 Entity streams (DESIGN.md section 3 -- the one definition that is the engine's own): the k-th Source of `sources=[...]` draws

@@ -133,7 +133,7 @@ class Simulation:
                                                                                                             self._entities)
                 except UnsupportedTopology as station_shape:
                     # not the shape the station engines take: the single-heap loop (csrc/hs_graph.hip) runs what the same entity
-                    # classes can be wired into otherwise -- exactly, at ~1 us per event (several LoadBalancers, a LoadBalancer
+                    # classes can be wired into otherwise -- exactly, at ~2.4 us per event and heap (several LoadBalancers, a LoadBalancer
                     # behind Servers ... included)
                     try:
                         self._graph = lower_general(self._sources, self._entities, self._probes)

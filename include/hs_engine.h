@@ -665,7 +665,7 @@ int hs_debug_const_div(int32_t device, double b, int64_t n, const double *a, dou
  * (core/simulation.py:449-505), every reference Event materialised with the sort index the reference gives it (the two
  * counters of core/event.py:53-77 and core/event_heap.py:48), push / pop in CPython's heapq sift order.  One lane of one
  * wavefront walks the loop; the first 4 096 heap entries live in LDS (128 KB of the CU's 160), the rest and all node state
- * in HBM.  An exactness path for small models (~1 us per event), not a throughput path: the station engines stay the
+ * in HBM.  An exactness path for small models (~2.4 us per event and heap; heaps side by side: hs_graph_run_many / _parts), not a throughput path: the station engines stay the
  * product's hot path, and the host (happy_simulator_amd/graph_engine.py) only comes here with a graph they refuse.
  * Replaces: Simulation.__init__'s bootstrap (core/simulation.py:145-160), Simulation.schedule (:195-206), _execute_until
  * (:449-505) and the handlers of load/source.py:142-180, components/queue.py:122-166, components/queue_driver.py:66-99,
