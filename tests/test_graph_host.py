@@ -163,3 +163,51 @@ def test_abi_structs_of_the_graph_entry_points():
     for sym in ("hs_graph_create", "hs_graph_schedule", "hs_graph_run_until", "hs_graph_run_many", "hs_graph_run_parts", "hs_graph_get_summary", "hs_graph_get_stats",
                 "hs_graph_read_records", "hs_graph_last_error", "hs_graph_destroy"):
         assert sym in N.EXPORTED_SYMBOLS and getattr(L, sym)
+
+
+@pytest.mark.parametrize("k", range(12))
+def test_split_parts_partitions_the_graph_without_cutting_an_edge(k):
+    """graph_engine.split_parts (hs_graph_run_parts' host side): unions of random graphs fall into parts that (i) partition the
+    nodes, ascending inside a part (Sources first: hs_graph_nodes' contract), (ii) keep every edge -- target, router targets,
+    LoadBalancer backends -- inside one part under the part's own numbering, (iii) carry every per-node array and the backends'
+    names unchanged, (iv) never exceed `max_parts`; a connected graph is not split."""
+    from happy_simulator_amd.graph_engine import split_parts
+    from random_specs import lb_graph_spec, union_spec
+
+    rng = np.random.default_rng(95_000 + k)
+    members = [(lb_graph_spec if rng.random() < 0.5 else graph_spec)(int(rng.integers(0, 5000))) for _ in range(int(rng.integers(2, 7)))]
+    sim, _ = GS.build(union_spec(members))
+    g = sim.lowered()
+    assert isinstance(g, GeneralGraph)
+    a = g.arrays
+    for max_parts in (2048, 3):
+        parts = split_parts(a, max_parts)
+        assert parts is not None and 2 <= len(parts) <= max_parts and len(parts) >= min(len(members), max_parts)
+        seen = np.concatenate([ids for ids, _pos, _b in parts])
+        np.testing.assert_array_equal(np.sort(seen), np.arange(a.n))                  # (i) a partition
+        rt_seen = np.concatenate([pos for _ids, pos, _b in parts])
+        np.testing.assert_array_equal(np.sort(rt_seen), np.arange(len(a.rt_targets)))
+        for ids, pos, b in parts:
+            assert (np.diff(ids) > 0).all() and b.n == len(ids)
+            kinds = a.kind[ids]
+            first_other = int(np.argmax(kinds != N.NODE_SOURCE)) if (kinds != N.NODE_SOURCE).any() else len(kinds)
+            assert (kinds[first_other:] != N.NODE_SOURCE).all()                       # Sources first
+            for nm in ("kind", "stream_base", "src_kind", "src_rate", "concurrency", "lat_kind", "lat_mean_s", "link_loss_rate", "queue_cap"):
+                np.testing.assert_array_equal(getattr(b, nm), getattr(a, nm)[ids], err_msg=nm)
+            has = a.target[ids] >= 0                                                  # (ii) edges stay inside, renumbered
+            np.testing.assert_array_equal(ids[b.target[has]], a.target[ids][has])
+            assert (b.target[~has] == -1).all()
+            np.testing.assert_array_equal(b.rt_cnt, a.rt_cnt[ids])
+            np.testing.assert_array_equal(ids[b.rt_targets], a.rt_targets[pos])
+            off = 0
+            for j, i in enumerate(ids):
+                assert b.rt_off[j] == off or b.rt_cnt[j] == 0
+                np.testing.assert_array_equal(pos[off:off + b.rt_cnt[j]], np.arange(a.rt_off[i], a.rt_off[i] + a.rt_cnt[i]))
+                off += int(b.rt_cnt[j])
+            if a.names is not None:                                                   # (iii) names travel with their nodes
+                for j, i in enumerate(ids):
+                    assert b.names[b.name_off[j]:b.name_off[j + 1]] == a.names[a.name_off[i]:a.name_off[i + 1]]
+            b.struct()
+    chain = hs.Simulation(duration=1.0, sources=[hs.Source.poisson(rate=5.0, target=(sv := hs.Server("s", concurrency=64, downstream=hs.Sink("k"))))],
+                          entities=[sv, sv.downstream])
+    assert split_parts(chain.lowered().arrays) is None                                # one component: the one heap
