@@ -301,8 +301,9 @@ class Simulation:
     def _run_general(self, g: GeneralGraph, auto: bool, wall0: float) -> SimulationSummary:
         """A graph outside the station shape (graph_engine.lower_general) on the device's single-heap loop."""
         end_ns, start_ns, sched, cancelled_ns = self._general_prepare(g, auto)
-        # (a heap is worth its handle from ~16 000 events on: creating, reading and freeing one costs the host ~0.5 ms)
-        parts = None if cancelled_ns else split_parts(g.arrays, max(2, min(MAX_PARTS, int(self._general_est / 16384.0))) if not auto else MAX_PARTS)
+        # (one component per heap while there are at most MAX_PARTS: components that SHARE a heap are checked as one -- two Probes of one
+        #  interval, two constant Sources of one rate in different components then look like a mixed timestamp group: undecided)
+        parts = None if cancelled_ns else split_parts(g.arrays, MAX_PARTS)
         try:
             self._refuse_long_run(1 if parts is None else len(parts))
         except UnsupportedTopology:

@@ -300,7 +300,7 @@ def test_a_simulation_of_several_disconnected_graphs_runs_as_parts(block):
 
 def test_many_chains_beyond_the_station_shape_run_on_many_heaps():
     """6 000 independent chains of FIVE Poisson Sources -> Server(c = 40) -> Sink (the station engines stop at four Sources and
-    c = 32): one Simulation, its 6 000 components on ~130 heaps side by side, == the oracle's one heap."""
+    c = 32): one Simulation, its 6 000 components on 2 048 heaps side by side, == the oracle's one heap."""
     n, per = 6000, 5
     g = O.Graph()
     src = [g.source(O.ARR_POISSON, 1.0 + (k % 5), stream_base=k) for k in range(n * per)]
@@ -319,7 +319,7 @@ def test_many_chains_beyond_the_station_shape_run_on_many_heaps():
     sources = [hs.Source.poisson(rate=1.0 + (k % 5), target=servers[k // per], name=f"src{k}") for k in range(n * per)]
     sim = hs.Simulation(end_time=hs.Instant.from_seconds(2.0), sources=sources, entities=servers + sinks, seed=11)
     summary = sim.run()
-    assert 64 <= sim._graph_parts <= 2048                     # (a heap per ~16 000 estimated events)
+    assert sim._graph_parts == 2048                          # (6 000 components share 2 048 heaps)
     assert summary.total_events_processed == r.events_processed and sim._current_time.nanoseconds == r.final_time_ns
     np.testing.assert_array_equal([s.generated_count for s in sources], r.generated[src])
     np.testing.assert_array_equal([s._requests_completed for s in servers], r.completed[srv])
@@ -327,6 +327,66 @@ def test_many_chains_beyond_the_station_shape_run_on_many_heaps():
     for i in (0, 1, n // 2, n - 1):
         np.testing.assert_array_equal(sinks[i].completion_ns, r.sinks[snk[i]][0])
         np.testing.assert_array_equal(sinks[i]._created_ns, r.sinks[snk[i]][1])
+
+
+def test_parts_with_probes_and_time_varying_sources_match_the_oracle():
+    """300 chains of five Sources -> Server(c = 40) -> Sink in ONE Simulation, a Probe on the Server or the Sink of two chains in three, a ramp instead of
+    one Poisson Source in every tenth chain: every part builds its own tick tables (hs_tables.hip) and runs on a heap of its own --
+    every sample, statistic and record == the oracle's one heap."""
+    n, per = 300, 5
+    g = O.Graph()
+    src = []
+    for k in range(n * per):
+        ramp = (k % per == 0) and ((k // per) % 10 == 0)
+        src.append(g.source(O.ARR_POISSON, 1.0 + (k % 4), stream_base=k, profile=("ramp", 2.0, 1.0, 6.0) if ramp else None))
+    # (ONE Probe per chain: two Probes of one interval in a part put the second one's first tick -- numbered before the run -- on the
+    #  nanosecond of the first one's sample -- numbered by the run: undecided, the one heap's case)
+    probe_plan = [(i, "server" if i % 3 == 0 else "sink") for i in range(n) if i % 3 != 2]
+    o_probes = [None] * len(probe_plan)
+    snk = [None] * n
+    srv = [None] * n
+    # oracle node order = the product's: Sources, Probes, then entities (servers + sinks)
+    placeholders = [g.probe(0, 0, 0.25) for _ in probe_plan]
+    for i in range(n):
+        srv[i] = g.server(O.LAT_EXP, 0.2, concurrency=40, queue_cap=-1, stream_base=i)
+    for i in range(n):
+        snk[i] = g.sink()
+        g.target[srv[i]] = snk[i]
+    for k, s_ in enumerate(src):
+        g.target[s_] = srv[k // per]
+    for j, (i, which) in enumerate(probe_plan):
+        nd = placeholders[j]
+        g.target[nd] = srv[i] if which == "server" else snk[i]
+        g.probe_metric[nd] = 0 if which == "server" else 5                    # depth / events_received
+        o_probes[j] = nd
+    end_ns = 3_000_000_000
+    r = O.run(g, end_ns, seed=23)
+    sinks = [hs.Sink(f"k{i}") for i in range(n)]
+    servers = [hs.Server(f"s{i}", concurrency=40, service_time=hs.ExponentialLatency(0.2), downstream=sinks[i]) for i in range(n)]
+    sources = []
+    for k in range(n * per):
+        if (k % per == 0) and ((k // per) % 10 == 0):
+            sources.append(hs.Source.with_profile(hs.LinearRampProfile(duration_s=2.0, start_rate=1.0, end_rate=6.0), target=servers[k // per],
+                                                  name=f"src{k}"))
+        else:
+            sources.append(hs.Source.poisson(rate=1.0 + (k % 4), target=servers[k // per], name=f"src{k}"))
+    probes = [hs.Probe.on(servers[i] if which == "server" else sinks[i], "depth" if which == "server" else "events_received", interval=0.25)
+              for i, which in probe_plan]
+    sim = hs.Simulation(end_time=hs.Instant.from_seconds(3.0), sources=sources, entities=servers + sinks, probes=[p for p, _ in probes], seed=23)
+    assert isinstance(sim.lowered(), GeneralGraph)
+    summary = sim.run()
+    assert sim._graph_parts >= 2
+    assert summary.total_events_processed == r.events_processed and sim._current_time.nanoseconds == r.final_time_ns
+    np.testing.assert_array_equal([s.generated_count for s in sources], r.generated[src])
+    np.testing.assert_array_equal([s._requests_completed for s in servers], r.completed[srv])
+    np.testing.assert_array_equal([s._total_service_time for s in servers], r.total_service_s[srv])
+    for i in range(0, n, 7):
+        np.testing.assert_array_equal(sinks[i].completion_ns, r.sinks[snk[i]][0])
+    for (pr, data), nd in zip(probes, o_probes):
+        t, v = r.sinks[nd]
+        np.testing.assert_array_equal(data._t_ns, t, err_msg=pr.name)
+        np.testing.assert_array_equal(data._v, v, err_msg=pr.name)
+        assert len(t) >= 11
 
 
 def test_parts_that_cannot_decide_an_order_hand_the_run_to_one_heap():
